@@ -1,0 +1,123 @@
+/*
+ * omx.h -- C ABI of libomx_hip.so: the MI355X (gfx950) implementation of the
+ * mlx-rs-core inference hot path of OminiX-MLX.
+ *
+ * This is the drop-in boundary.  The reference's Rust
+ * crates reach their arithmetic through the mlx-c C shim (mlx-sys bindgen,
+ * mlx-rs/mlx-sys/build.rs:390-399).  Two layers are exported:
+ *
+ *   1. omx_*  (this file): eager, raw-pointer kernels.  Plain device pointers,
+ *      sizes and a hipStream_t (passed as void*; NULL = the null stream).  Each
+ *      entry cites the mlx-c function (header:line under
+ *      mlx-rs/mlx-sys/src/mlx-c/mlx/c/) and the Rust call site it replaces.
+ *   2. mlx_*  (omx_mlx_c.h): the handle-based subset of the mlx-c ABI with the
+ *      reference's ownership / status / error-handler conventions, implemented
+ *      on top of layer 1, so `mlx-sys` can link against libomx_hip.so.
+ *
+ * Conventions (same as mlx-c, error.cpp:37-54, fast.cpp:614-632):
+ *   - every function returns int: 0 = ok, 1 = error;
+ *   - on error the registered handler (omx_set_error_handler == mlx_set_error_handler)
+ *     is invoked on the calling thread with a NUL-terminated message; the default
+ *     handler stores it in a thread-local slot readable with omx_last_error();
+ *   - all tensor arguments are DEVICE pointers, row-major contiguous unless a
+ *     stride argument says otherwise; dtype codes are the mlx_dtype values
+ *     (array.h:37-52);
+ *   - no function allocates, frees or synchronises unless its name says so:
+ *     everything is enqueued on `stream` and is hipGraph-capturable.
+ */
+#ifndef OMX_H
+#define OMX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* mlx_dtype numbering (mlx/c/array.h:37-52) */
+typedef enum omx_dtype_ {
+    OMX_BOOL = 0, OMX_UINT8 = 1, OMX_UINT16 = 2, OMX_UINT32 = 3, OMX_UINT64 = 4,
+    OMX_INT8 = 5, OMX_INT16 = 6, OMX_INT32 = 7, OMX_INT64 = 8,
+    OMX_FLOAT16 = 9, OMX_FLOAT32 = 10, OMX_FLOAT64 = 11, OMX_BFLOAT16 = 12, OMX_COMPLEX64 = 13
+} omx_dtype;
+
+typedef void* omx_stream; /* hipStream_t */
+
+/* ---- library / error plumbing (mlx/c/error.h:15-23, stream.h:63, memory.h:30) ---- */
+const char* omx_version(void);
+typedef void (*omx_error_handler_func)(const char* msg, void* data);
+void omx_set_error_handler(omx_error_handler_func handler, void* data, void (*dtor)(void*));
+const char* omx_last_error(void);          /* thread-local; "" when none */
+void omx_clear_error(void);
+int omx_device_count(int* count);
+int omx_device_name(char* buf, size_t buflen);
+int omx_synchronize(omx_stream stream);    /* mlx_synchronize */
+
+/* device memory (what mlx_array_new_data / mlx_array_data_* do underneath) */
+int omx_malloc(void** ptr, size_t bytes);
+int omx_free(void* ptr);
+int omx_memcpy_h2d(void* dst, const void* src, size_t bytes, omx_stream stream);
+int omx_memcpy_d2h(void* dst, const void* src, size_t bytes, omx_stream stream);
+int omx_memcpy_d2d(void* dst, const void* src, size_t bytes, omx_stream stream);
+int omx_memset(void* dst, int value, size_t bytes, omx_stream stream);
+
+/* synthetic tensors: value(i) = offset + amp*(2*u24(hash(seed,i))-1), RNE to dtype */
+int omx_fill_uniform(void* dst, size_t n, uint32_t seed, float amp, float offset, omx_dtype dtype, omx_stream stream);
+
+/* ---- a4: norms.  mlx_fast_rms_norm fast.h:163-168 (mlx-rs/src/fast.rs:165-180),
+ *           mlx_fast_layer_norm fast.h:93-99 (fast.rs:204-218).  weight/bias may be NULL.
+ *      x, out: [rows, dim] contiguous.                                                      */
+int omx_rms_norm(void* out, const void* x, const void* weight, int64_t rows, int dim, float eps,
+                 omx_dtype dtype, omx_stream stream);
+int omx_layer_norm(void* out, const void* x, const void* weight, const void* bias, int64_t rows, int dim,
+                   float eps, omx_dtype dtype, omx_stream stream);
+
+/* ---- a3: RoPE.  mlx_fast_rope fast.h:169-178 (fast.rs:15-46; nn/positional_encoding.rs:112-137).
+ *      x,out: [batch(=B*H), T, D] contiguous, position = axis -2, positions offset..offset+T-1.
+ *      traditional=0: pairs (i, i+dims/2); =1: pairs (2i, 2i+1).  theta_i = base^(-2i/dims).  */
+int omx_rope(void* out, const void* x, int64_t batch, int T, int D, int dims, int traditional, float base,
+             float scale, int offset, omx_dtype dtype, omx_stream stream);
+
+/* ---- a8/a9: the two mlx-rs-core fused kernels (metal_kernels.rs:188-236, 260-339), which the
+ *      reference JIT-compiles from Metal source through mlx_fast_metal_kernel_apply (fast.h:156).
+ *      omx_fused_swiglu(out, x=up, gate): silu(gate)*x.   omx_fused_modulate: (1+scale)*LN(x)+shift,
+ *      x [B,S,H], shift/scale [B,H].                                                           */
+int omx_fused_swiglu(void* out, const void* x, const void* gate, int64_t n, omx_dtype dtype, omx_stream stream);
+int omx_fused_modulate(void* out, const void* x, const void* shift, const void* scale, int B, int S, int H,
+                       float eps, omx_dtype dtype, omx_stream stream);
+
+/* ---- a5: Linear.  mlx_matmul ops.h:598-602 / mlx_addmm ops.h:36-43 as used by nn::Linear
+ *      (mlx-rs/src/nn/linear.rs:87-92): out[M,N] = x[M,K] . W[N,K]^T (+ bias[N]).
+ *      M <= 8 takes the HBM-streaming GEMV path, larger M the MFMA GEMM path.                  */
+int omx_linear(void* out, const void* x, const void* w, const void* bias, int M, int N, int K,
+               omx_dtype dtype, omx_stream stream);
+
+/* ---- a1: SDPA.  mlx_fast_scaled_dot_product_attention fast.h:189-198 (fast.rs:121-151;
+ *      mlx-rs-core/src/utils.rs:191-209).  q [B,H,Tq,D]; k,v [B,Hkv,Tk,D] with explicit element
+ *      strides so that the [..,:offset,:] views of the step-256 KV buffer (cache.rs:190-193) are
+ *      passed without a copy: kv_batch_stride, kv_head_stride (row stride is D).
+ *      mask_mode: 0 none, 1 "causal" (bottom-right aligned), 2 bool array [Tq,Tk] (keep-true),
+ *      3 additive array [Tq,Tk] of `dtype`.  out [B,H,Tq,D].                                   */
+enum { OMX_MASK_NONE = 0, OMX_MASK_CAUSAL = 1, OMX_MASK_BOOL = 2, OMX_MASK_ADDITIVE = 3 };
+int omx_sdpa(void* out, const void* q, const void* k, const void* v, int B, int H, int Hkv, int Tq, int Tk,
+             int D, int64_t kv_batch_stride, int64_t kv_head_stride, float scale, int mask_mode,
+             const void* mask, omx_dtype dtype, omx_stream stream);
+/* bytes of scratch omx_sdpa needs for the split-KV decode path (0 for prefill) */
+size_t omx_sdpa_workspace_bytes(int B, int H, int Tq, int D);
+int omx_set_workspace(void* ws, size_t bytes);   /* caller-provided scratch used by split kernels */
+
+/* ---- a10: greedy sampler.  mlx_argmax_axis ops.h:106-111 (mlx-rs-core/src/sampler.rs:9-12):
+ *      out[r] = first index of the maximum of logits[r, :]  (u32).                              */
+int omx_argmax(uint32_t* out, const void* logits, int64_t rows, int n, omx_dtype dtype, omx_stream stream);
+
+/* embedding gather (mlx_take_axis ops.h:1109, nn/embedding.rs): out[r,:] = table[ids[r],:] */
+int omx_take_rows(void* out, const void* table, const uint32_t* ids, int64_t n_ids, int dim, omx_dtype dtype,
+                  omx_stream stream);
+/* elementwise add (mlx_add): residual connections */
+int omx_add(void* out, const void* a, const void* b, int64_t n, omx_dtype dtype, omx_stream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OMX_H */

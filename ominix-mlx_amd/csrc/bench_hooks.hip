@@ -1,0 +1,64 @@
+// Measurement hooks (not part of the drop-in surface): time one kernel family with HIP events on
+// the stream it is launched on.  Weight buffers are rotated through `n_copies` distinct
+// allocations so that the 256 MiB Infinity Cache cannot serve re-reads (MI355X_MICROARCH.md).
+#include <vector>
+
+#include "gemv.hpp"
+
+extern "C" int omx_bench_gemv(int N, int K, int pro, int epi, int rows_per_wave, int n_copies, int iters,
+                              float* avg_ms) {
+    using namespace omx;
+    OMX_REQUIRE(avg_ms && n_copies > 0 && iters > 0, "omx_bench_gemv: bad arguments");
+    const int mats = (epi == EPI_SWIGLU) ? 2 : 1;
+    const size_t wbytes = (size_t)N * K * 2 * mats;
+    std::vector<void*> w(n_copies, nullptr);
+    void *x = nullptr, *nw = nullptr, *out = nullptr, *resid = nullptr, *slot = nullptr;
+    for (auto& p : w) {
+        OMX_HIP_CHECK(hipMalloc(&p, wbytes));
+        if (omx_fill_uniform(p, wbytes / 2, 17u + (uint32_t)(&p - &w[0]), 0.03f, 0.f, OMX_BFLOAT16, nullptr)) return 1;
+    }
+    OMX_HIP_CHECK(hipMalloc(&x, (size_t)K * 2));
+    OMX_HIP_CHECK(hipMalloc(&nw, (size_t)K * 2));
+    OMX_HIP_CHECK(hipMalloc(&out, (size_t)N * 4));
+    OMX_HIP_CHECK(hipMalloc(&resid, (size_t)N * 2));
+    OMX_HIP_CHECK(hipMalloc(&slot, 8));
+    omx_fill_uniform(x, K, 3, 1.0f, 0.f, OMX_BFLOAT16, nullptr);
+    omx_fill_uniform(nw, K, 4, 0.1f, 1.f, OMX_BFLOAT16, nullptr);
+    omx_fill_uniform(resid, N, 5, 1.0f, 0.f, OMX_BFLOAT16, nullptr);
+    OMX_HIP_CHECK(hipMemset(slot, 0, 8));
+    hipStream_t s;
+    OMX_HIP_CHECK(hipStreamCreate(&s));
+    hipEvent_t e0, e1;
+    OMX_HIP_CHECK(hipEventCreate(&e0));
+    OMX_HIP_CHECK(hipEventCreate(&e1));
+    auto run = [&](int i) {
+        GemvArgs a = {};
+        const bf16_t* base = (const bf16_t*)w[i % n_copies];
+        a.w0 = base;
+        a.w1 = base + (size_t)N * K;
+        a.n0 = N; a.N = N; a.K = K;
+        a.x = (const bf16_t*)x;
+        a.norm_w = (const bf16_t*)nw;
+        a.eps = 1e-6f;
+        a.resid = (const bf16_t*)resid;
+        a.out = out;
+        a.argmax_slot = (unsigned long long*)slot;
+        a.rows_per_wave = rows_per_wave;
+        return launch_gemv(a, pro, epi, s);
+    };
+    for (int i = 0; i < n_copies + 2; ++i)
+        if (run(i)) return 1;
+    OMX_HIP_CHECK(hipStreamSynchronize(s));
+    OMX_HIP_CHECK(hipEventRecord(e0, s));
+    for (int i = 0; i < iters; ++i)
+        if (run(i)) return 1;
+    OMX_HIP_CHECK(hipEventRecord(e1, s));
+    OMX_HIP_CHECK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    OMX_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+    *avg_ms = ms / iters;
+    for (auto p : w) hipFree(p);
+    hipFree(x); hipFree(nw); hipFree(out); hipFree(resid); hipFree(slot);
+    hipEventDestroy(e0); hipEventDestroy(e1); hipStreamDestroy(s);
+    return 0;
+}

@@ -1,0 +1,107 @@
+// Shared device/host helpers for the gfx950 (MI355X, CDNA4) kernels.
+// Wavefront = 64 lanes; every reduction below is written for that width.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/omx.h"
+
+namespace omx {
+
+typedef uint16_t bf16_t;   // raw bfloat16 bits
+typedef _Float16 f16_t;
+
+using u32x4 = __attribute__((ext_vector_type(4))) uint32_t;
+using u32x2 = __attribute__((ext_vector_type(2))) uint32_t;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+constexpr int kWave = 64;
+
+// ---- bf16 <-> f32 ---------------------------------------------------------
+__device__ __host__ __forceinline__ float bf16_to_f32(bf16_t b) {
+    union { uint32_t u; float f; } c;
+    c.u = (uint32_t)b << 16;
+    return c.f;
+}
+// round-to-nearest-even, NaN kept quiet
+__device__ __host__ __forceinline__ bf16_t f32_to_bf16(float f) {
+    union { uint32_t u; float f; } c;
+    c.f = f;
+    uint32_t u = c.u;
+    if ((u & 0x7FFFFFFFu) > 0x7F800000u) return (bf16_t)((u >> 16) | 0x0040u);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ float round_bf16(float f) { return bf16_to_f32(f32_to_bf16(f)); }
+
+// low / high bf16 of a packed dword as f32
+__device__ __forceinline__ float bf16lo(uint32_t p) { return __uint_as_float(p << 16); }
+__device__ __forceinline__ float bf16hi(uint32_t p) { return __uint_as_float(p & 0xFFFF0000u); }
+__device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {
+    return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+}
+
+// ---- dtype traits: element load/store as f32 --------------------------------
+template <int DT> struct Elem;
+template <> struct Elem<OMX_BFLOAT16> {
+    typedef bf16_t T;
+    static __device__ __forceinline__ float ld(const T* p) { return bf16_to_f32(*p); }
+    static __device__ __forceinline__ void st(T* p, float v) { *p = f32_to_bf16(v); }
+    static __device__ __forceinline__ float rnd(float v) { return round_bf16(v); }
+};
+template <> struct Elem<OMX_FLOAT16> {
+    typedef f16_t T;
+    static __device__ __forceinline__ float ld(const T* p) { return (float)*p; }
+    static __device__ __forceinline__ void st(T* p, float v) { *p = (f16_t)v; }
+    static __device__ __forceinline__ float rnd(float v) { return (float)(f16_t)v; }
+};
+template <> struct Elem<OMX_FLOAT32> {
+    typedef float T;
+    static __device__ __forceinline__ float ld(const T* p) { return *p; }
+    static __device__ __forceinline__ void st(T* p, float v) { *p = v; }
+    static __device__ __forceinline__ float rnd(float v) { return v; }
+};
+
+// ---- wave64 reductions -------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// block reductions over NW waves through a small LDS scratch (NW floats)
+template <int NW>
+__device__ __forceinline__ float block_sum(float v, float* scratch) {
+    v = wave_sum(v);
+    if (NW == 1) return v;
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    __syncthreads();
+    if (l == 0) scratch[w] = v;
+    __syncthreads();
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) s += scratch[i];
+    return s;
+}
+
+}  // namespace omx
+
+// ---- host-side error plumbing (capi.cpp) ------------------------------------
+namespace omx {
+int set_error(const char* fmt, ...);   // formats into TLS slot, calls handler, returns 1
+}
+#define OMX_HIP_CHECK(expr)                                                                   \
+    do {                                                                                      \
+        hipError_t _e = (expr);                                                               \
+        if (_e != hipSuccess) return omx::set_error("%s failed: %s", #expr, hipGetErrorString(_e)); \
+    } while (0)
+#define OMX_REQUIRE(cond, ...)                        \
+    do {                                              \
+        if (!(cond)) return omx::set_error(__VA_ARGS__); \
+    } while (0)
+#define OMX_LAUNCH_CHECK() OMX_HIP_CHECK(hipGetLastError())

@@ -1,0 +1,277 @@
+// See gemv.hpp for the design notes.
+#include "gemv.hpp"
+
+#include <stdlib.h>
+
+namespace omx {
+
+namespace {
+
+constexpr int kBlock = 256;   // 4 waves
+constexpr int kWaves = 4;
+
+__device__ __forceinline__ u32x4 ld_nt(const u32x4* p) { return __builtin_nontemporal_load(p); }
+
+__device__ __forceinline__ const bf16_t* row_ptr(const GemvArgs& a, int row) {
+    // wave-uniform: which of the stacked matrices owns this row
+    if (row < a.n0) return a.w0 + (size_t)row * a.K;
+    row -= a.n0;
+    if (row < a.n1) return a.w1 + (size_t)row * a.K;
+    row -= a.n1;
+    return a.w2 + (size_t)row * a.K;
+}
+
+__device__ __forceinline__ float dot8(const u32x4 w, const float (&xf)[8], float acc) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        acc = fmaf(bf16lo(w[i]), xf[2 * i], acc);
+        acc = fmaf(bf16hi(w[i]), xf[2 * i + 1], acc);
+    }
+    return acc;
+}
+
+__device__ __forceinline__ uint64_t argmax_key(float v, uint32_t idx) {
+    uint32_t u = __float_as_uint(v);
+    u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+    if (v != v) u = 0;
+    return ((uint64_t)u << 32) | (uint32_t)(~idx);
+}
+
+template <int EPI>
+__device__ __forceinline__ void epilogue(const GemvArgs& a, int row, float v0, float v1) {
+    if (EPI == EPI_STORE) {
+        reinterpret_cast<bf16_t*>(a.out)[row] = f32_to_bf16(v0);
+    } else if (EPI == EPI_F32) {
+        reinterpret_cast<float*>(a.out)[row] = v0;
+    } else if (EPI == EPI_RESIDUAL) {
+        reinterpret_cast<bf16_t*>(a.out)[row] = f32_to_bf16(bf16_to_f32(a.resid[row]) + round_bf16(v0));
+    } else if (EPI == EPI_SWIGLU) {
+        // nn::silu(gate) * up, every primitive's result held in bf16
+        // (qwen3-mlx/src/model.rs:264-265; mlx-rs/src/nn/activation.rs:876-880)
+        const float g = round_bf16(v0);
+        const float u = round_bf16(v1);
+        const float sg = round_bf16(1.0f / (1.0f + expf(-g)));
+        reinterpret_cast<bf16_t*>(a.out)[row] = f32_to_bf16(round_bf16(g * sg) * u);
+    } else if (EPI == EPI_ARGMAX) {
+        const bf16_t lb = f32_to_bf16(v0);
+        reinterpret_cast<bf16_t*>(a.out)[row] = lb;
+        atomicMax(a.argmax_slot, argmax_key(bf16_to_f32(lb), (uint32_t)(row + a.row_offset)));
+    }
+}
+
+// NVW    = 16-byte vectors per lane per row per wave (compile-time, fully unrolled)
+// KSPLIT = waves sharing one row (1: a wave owns whole rows; 4: each wave owns a K quarter)
+// RB     = logical rows per register batch; LR physical rows per logical row (2 for SwiGLU)
+template <int NVW, int KSPLIT, int RB, int PRO, int EPI>
+__global__ __launch_bounds__(kBlock) void gemv_kernel(const GemvArgs a) {
+    constexpr int LR = (EPI == EPI_SWIGLU) ? 2 : 1;
+    constexpr int NV = NVW * KSPLIT;            // vectors per lane for the whole row
+    constexpr int NR = RB * LR;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    u32x4* xs = reinterpret_cast<u32x4*>(smem);                            // [NV*64] packed bf16 activation
+    float* red = reinterpret_cast<float*>(smem + (size_t)NV * 64 * 16);    // [4] block-reduce scratch
+    float* part = red + 4;                                                 // KSPLIT>1: [rows][LR][KSPLIT]
+
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int K = a.K;
+    const int rpw = a.rows_per_wave;
+    // KSPLIT==1: every wave has its own rows.  KSPLIT==4: the block's waves share the rows.
+    const int row_begin = (KSPLIT == 1 ? (blockIdx.x * kWaves + wave) : blockIdx.x) * rpw;
+    const int row_end = min(row_begin + rpw, a.N);
+    const bool active = row_begin < a.N;
+    const int koff = (KSPLIT == 1) ? 0 : wave * NVW * 64;   // first vector of this wave's K slice
+
+    u32x4 wA[NR][NVW], wB[NR][NVW];
+
+#define OMX_ISSUE(WB, R0)                                                                          \
+    {                                                                                              \
+        _Pragma("unroll") for (int r = 0; r < RB; ++r) {                                           \
+            const int row = min((R0) + r, a.N - 1); /* clamp: tail re-reads a valid row */         \
+            if (EPI == EPI_SWIGLU) {                                                               \
+                const u32x4* g = reinterpret_cast<const u32x4*>(a.w0 + (size_t)row * K) + koff;    \
+                const u32x4* u = reinterpret_cast<const u32x4*>(a.w1 + (size_t)row * K) + koff;    \
+                _Pragma("unroll") for (int j = 0; j < NVW; ++j) {                                  \
+                    WB[LR * r][j] = ld_nt(g + j * 64 + lane);                                      \
+                    WB[LR * r + (LR - 1)][j] = ld_nt(u + j * 64 + lane);                           \
+                }                                                                                  \
+            } else {                                                                               \
+                const u32x4* p = reinterpret_cast<const u32x4*>(row_ptr(a, row)) + koff;           \
+                _Pragma("unroll") for (int j = 0; j < NVW; ++j) WB[r][j] = ld_nt(p + j * 64 + lane); \
+            }                                                                                      \
+        }                                                                                          \
+    }
+
+#define OMX_COMPUTE(WB, R0)                                                                        \
+    {                                                                                              \
+        float acc[NR];                                                                             \
+        _Pragma("unroll") for (int r = 0; r < NR; ++r) acc[r] = 0.f;                               \
+        _Pragma("unroll") for (int j = 0; j < NVW; ++j) {                                          \
+            const u32x4 xp = xs[koff + j * 64 + lane];                                             \
+            float xf[8];                                                                           \
+            _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                        \
+                xf[2 * q] = bf16lo(xp[q]);                                                         \
+                xf[2 * q + 1] = bf16hi(xp[q]);                                                     \
+            }                                                                                      \
+            _Pragma("unroll") for (int r = 0; r < NR; ++r) acc[r] = dot8(WB[r][j], xf, acc[r]);    \
+        }                                                                                          \
+        _Pragma("unroll") for (int r = 0; r < NR; ++r) acc[r] = wave_sum(acc[r]);                  \
+        if (lane == 0) {                                                                           \
+            _Pragma("unroll") for (int r = 0; r < RB; ++r) {                                       \
+                const int row = (R0) + r;                                                          \
+                if (row < row_end) {                                                               \
+                    if (KSPLIT == 1) {                                                             \
+                        epilogue<EPI>(a, row, acc[LR * r], acc[LR * r + (LR - 1)]);                \
+                    } else {                                                                       \
+                        const int lr = row - row_begin;                                            \
+                        part[(lr * LR) * KSPLIT + wave] = acc[LR * r];                             \
+                        if (LR == 2) part[(lr * LR + 1) * KSPLIT + wave] = acc[LR * r + (LR - 1)]; \
+                    }                                                                              \
+                }                                                                                  \
+            }                                                                                      \
+        }                                                                                          \
+    }
+
+    // ---- first weight batch goes out before the activation is even loaded ----
+    if (active) OMX_ISSUE(wA, row_begin);
+
+    // ---- prologue: stage x (bf16) in LDS; optionally x := bf16(x + bf16(partial)); RMS-normalise ----
+    {
+        const bf16_t* xg = a.x + (a.x_row ? (size_t)a.x_row[0] * K : 0);
+        float ss = 0.f;
+        constexpr int PV = (NV * 64 + kBlock - 1) / kBlock;   // vectors per thread
+        u32x4 xv[PV];
+#pragma unroll
+        for (int i = 0; i < PV; ++i) {
+            const int v = threadIdx.x + i * kBlock;
+            if (v < NV * 64) {
+                u32x4 raw = *(reinterpret_cast<const u32x4*>(xg) + v);
+                if (a.x_partial) {
+                    const f32x4 p0 = *(reinterpret_cast<const f32x4*>(a.x_partial) + 2 * v);
+                    const f32x4 p1 = *(reinterpret_cast<const f32x4*>(a.x_partial) + 2 * v + 1);
+                    const float pp[8] = {p0[0], p0[1], p0[2], p0[3], p1[0], p1[1], p1[2], p1[3]};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        raw[q] = pack_bf16(bf16lo(raw[q]) + round_bf16(pp[2 * q]),
+                                           bf16hi(raw[q]) + round_bf16(pp[2 * q + 1]));
+                    if (a.x_out && blockIdx.x == 0) *(reinterpret_cast<u32x4*>(a.x_out) + v) = raw;
+                }
+                xv[i] = raw;
+                if (PRO == PRO_RMSNORM) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float lo = bf16lo(raw[q]), hi = bf16hi(raw[q]);
+                        ss = fmaf(lo, lo, ss);
+                        ss = fmaf(hi, hi, ss);
+                    }
+                }
+            }
+        }
+        if (PRO == PRO_RMSNORM) {
+            ss = block_sum<kWaves>(ss, red);
+            const float rstd = 1.0f / sqrtf(ss / (float)K + a.eps);
+#pragma unroll
+            for (int i = 0; i < PV; ++i) {
+                const int v = threadIdx.x + i * kBlock;
+                if (v < NV * 64) {
+                    const u32x4 nw = *(reinterpret_cast<const u32x4*>(a.norm_w) + v);
+                    u32x4 o;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        o[q] = pack_bf16(bf16lo(xv[i][q]) * rstd * bf16lo(nw[q]),
+                                         bf16hi(xv[i][q]) * rstd * bf16hi(nw[q]));
+                    xs[v] = o;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < PV; ++i) {
+                const int v = threadIdx.x + i * kBlock;
+                if (v < NV * 64) xs[v] = xv[i];
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- stream rows: batch b is reduced from one register set while batch b+1 is in flight ----
+    if (active) {
+        for (int r0 = row_begin; r0 < row_end; r0 += 2 * RB) {
+            if (r0 + RB < row_end) OMX_ISSUE(wB, r0 + RB);
+            OMX_COMPUTE(wA, r0);
+            if (r0 + RB >= row_end) break;
+            if (r0 + 2 * RB < row_end) OMX_ISSUE(wA, r0 + 2 * RB);
+            OMX_COMPUTE(wB, r0 + RB);
+        }
+    }
+    if (KSPLIT > 1) {
+        __syncthreads();
+        const int lr = threadIdx.x;
+        if (lr < row_end - row_begin) {
+            float v0 = 0.f, v1 = 0.f;
+#pragma unroll
+            for (int w = 0; w < KSPLIT; ++w) {
+                v0 += part[(lr * LR) * KSPLIT + w];
+                if (LR == 2) v1 += part[(lr * LR + 1) * KSPLIT + w];
+            }
+            epilogue<EPI>(a, row_begin + lr, v0, v1);
+        }
+    }
+#undef OMX_ISSUE
+#undef OMX_COMPUTE
+}
+
+template <int NVW, int KSPLIT, int RB>
+int launch_nv(const GemvArgs& a, int pro, int epi, hipStream_t s) {
+    const int groups = (a.N + a.rows_per_wave - 1) / a.rows_per_wave;   // row groups (waves or blocks)
+    const dim3 grid(KSPLIT == 1 ? (groups + kWaves - 1) / kWaves : groups), block(kBlock);
+    const size_t shmem = (size_t)NVW * KSPLIT * 64 * 16 + 16 + (KSPLIT > 1 ? (size_t)a.rows_per_wave * 2 * KSPLIT * 4 : 0);
+#define OMX_GEMV_CASE(P, E)                                                                          \
+    if (pro == P && epi == E) {                                                                      \
+        gemv_kernel<NVW, KSPLIT, (E == EPI_SWIGLU ? (RB > 1 ? RB / 2 : 1) : RB), P, E><<<grid, block, shmem, s>>>(a); \
+        OMX_LAUNCH_CHECK();                                                                          \
+        return 0;                                                                                    \
+    }
+    OMX_GEMV_CASE(PRO_NONE, EPI_STORE)
+    OMX_GEMV_CASE(PRO_RMSNORM, EPI_STORE)
+    OMX_GEMV_CASE(PRO_NONE, EPI_RESIDUAL)
+    OMX_GEMV_CASE(PRO_RMSNORM, EPI_SWIGLU)
+    OMX_GEMV_CASE(PRO_NONE, EPI_SWIGLU)
+    OMX_GEMV_CASE(PRO_RMSNORM, EPI_ARGMAX)
+    OMX_GEMV_CASE(PRO_NONE, EPI_F32)
+#undef OMX_GEMV_CASE
+    return set_error("gemv: unsupported prologue/epilogue combination %d/%d", pro, epi);
+}
+
+}  // namespace
+
+int launch_gemv(const GemvArgs& a_in, int pro, int epi, hipStream_t s) {
+    GemvArgs a = a_in;
+    OMX_REQUIRE(a.K > 0 && a.K % 512 == 0, "gemv: K=%d must be a positive multiple of 512", a.K);
+    OMX_REQUIRE(a.N > 0, "gemv: N must be positive");
+    const int nv = a.K / 512;
+    const bool split = nv > 8;
+    if (a.rows_per_wave <= 0) {
+        // ~3072 row groups: ~12 waves per CU on 256 CUs when a wave owns its rows
+        int rpw = (a.N + 3071) / 3072;
+        if (split) rpw = (a.N + 1023) / 1024;   // 4 waves share a group
+        if (rpw < 2) rpw = 2;
+        a.rows_per_wave = rpw;
+    }
+    if (split && a.rows_per_wave > 256) a.rows_per_wave = 256;
+    switch (nv) {
+        // RB*NVW ~ 16 x 1-KiB loads in flight per wave per register set
+        case 1: return launch_nv<1, 1, 8>(a, pro, epi, s);
+        case 2: return launch_nv<2, 1, 8>(a, pro, epi, s);
+        case 3: return launch_nv<3, 1, 4>(a, pro, epi, s);
+        case 4: return launch_nv<4, 1, 4>(a, pro, epi, s);
+        case 6: return launch_nv<6, 1, 2>(a, pro, epi, s);
+        case 8: return launch_nv<8, 1, 2>(a, pro, epi, s);
+        case 12: return launch_nv<3, 4, 4>(a, pro, epi, s);
+        case 16: return launch_nv<4, 4, 4>(a, pro, epi, s);
+        case 24: return launch_nv<6, 4, 2>(a, pro, epi, s);
+        case 28: return launch_nv<7, 4, 2>(a, pro, epi, s);
+        default: return set_error("gemv: K=%d (K/512=%d) has no instantiated kernel", a.K, nv);
+    }
+}
+
+}  // namespace omx

@@ -1,0 +1,49 @@
+// Decode-time (M == 1) weight-streaming GEMV family for gfx950 -- the HBM-bound kernel that
+// decides decode tokens/s.  Reference op: nn::Linear::forward = x . W^T
+// (mlx-rs/src/nn/linear.rs:87-92 -> mlx_matmul, mlx-c ops.h:598-602) at M == 1, i.e. > 97 % of
+// the bytes of a decode step.
+//
+// Design (MI355X_MICROARCH.md / cdna_hip_programming.md "GEMV / M <= 16 decode weights"):
+//   * weights go HBM -> VGPR directly with global_load_dwordx4 (nt), never through LDS: each
+//     weight byte is used once by one wave;
+//   * one wave64 owns whole rows: lane l reads 16 B at (j*64 + l)*16 of the row, so every
+//     wave-instruction is one fully coalesced 1 KiB burst;
+//   * the activation vector is staged ONCE per block in LDS as bf16 (optionally RMS-normalised
+//     on the way in: the fused prologue removes the separate norm launch and its round trip);
+//   * a register double buffer keeps the next batch of rows in flight while the current one is
+//     reduced, and the first batch is issued BEFORE the prologue so its latency hides the
+//     x load + norm reduction;
+//   * fused epilogues: bf16 store, residual add, SwiGLU (gate/up row pairs), f32 partial
+//     (tensor-parallel row split), logits + greedy argmax.
+#pragma once
+#include "common.hpp"
+
+namespace omx {
+
+enum { PRO_NONE = 0, PRO_RMSNORM = 1 };
+enum { EPI_STORE = 0, EPI_RESIDUAL = 1, EPI_SWIGLU = 2, EPI_ARGMAX = 3, EPI_F32 = 4 };
+
+struct GemvArgs {
+    // up to three row-stacked weight matrices sharing K (q/k/v) -- or gate (w0) / up (w1) for SwiGLU
+    const bf16_t* w0;
+    const bf16_t* w1;
+    const bf16_t* w2;
+    int n0, n1, n2;
+    int N;                      // logical output rows
+    int K;
+    const bf16_t* x;            // [K] activation (bf16)
+    const uint32_t* x_row;      // optional device scalar: x += x_row[0] * K (embedding gather)
+    const float* x_partial;     // optional [K] f32 added to x before use (TP: all-reduced partial sums)
+    const bf16_t* norm_w;       // [K] RMSNorm weight (PRO_RMSNORM)
+    float eps;
+    const bf16_t* resid;        // [N] (EPI_RESIDUAL)
+    void* out;                  // [N] bf16 (f32 for EPI_F32)
+    bf16_t* x_out;              // optional [K]: block 0 writes the (x + x_partial) it consumed (residual stream)
+    unsigned long long* argmax_slot;   // EPI_ARGMAX: atomicMax of (orderable(logit)<<32 | ~row)
+    int row_offset;             // EPI_ARGMAX: global row index offset (vocab shard)
+    int rows_per_wave;
+};
+
+int launch_gemv(const GemvArgs& a, int pro, int epi, hipStream_t s);
+
+}  // namespace omx

@@ -1,0 +1,232 @@
+"""Host mirror of the mlx-rs / mlx-rs-core operator surface over the omx_* C ABI.
+
+Names, argument meaning and error behaviour follow the reference so the parity tests read
+like its own: mlx_rs::fast::{rms_norm, layer_norm, rope, scaled_dot_product_attention}
+(mlx-rs/src/fast.rs), mlx_rs_core::{fused_swiglu, fused_modulate} (metal_kernels.rs),
+nn::Linear::forward (nn/linear.rs:87-92), DefaultSampler (sampler.rs).  `Tensor` is the
+stand-in for mlx_rs::Array: device memory + shape + dtype, owned by the library allocator.
+Everything executes eagerly on the null stream (eval == stream sync).
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional, Sequence
+
+import numpy as np
+
+from . import (BFLOAT16, BOOL, FLOAT16, FLOAT32, MASK_ADDITIVE, MASK_BOOL, MASK_CAUSAL, MASK_NONE, UINT32, UINT8,
+               OmxError, check, lib, require_device)
+
+_ITEMSIZE = {BFLOAT16: 2, FLOAT16: 2, FLOAT32: 4, UINT32: 4, UINT8: 1, BOOL: 1}
+_NAMES = {"bf16": BFLOAT16, "f16": FLOAT16, "f32": FLOAT32, "u32": UINT32, "u8": UINT8, "bool": BOOL}
+
+
+def dtype_code(dt) -> int:
+    return _NAMES[dt] if isinstance(dt, str) else int(dt)
+
+
+def _f32_to_bf16_bits(x: np.ndarray) -> np.ndarray:
+    u = np.ascontiguousarray(x, dtype=np.float32).view(np.uint32).astype(np.uint64)
+    r = ((u >> np.uint64(16)) & np.uint64(1)) + np.uint64(0x7FFF)
+    return ((u + r) >> np.uint64(16)).astype(np.uint16)
+
+
+class Tensor:
+    """Device array (stand-in for mlx_rs::Array)."""
+
+    def __init__(self, shape: Sequence[int], dtype, ptr: Optional[int] = None, owner=None):
+        self.shape = tuple(int(s) for s in shape)
+        self.dtype = dtype_code(dtype)
+        self.nbytes = int(np.prod(self.shape, dtype=np.int64)) * _ITEMSIZE[self.dtype]
+        self._owner = owner
+        if ptr is None:
+            require_device()
+            p = ctypes.c_void_p()
+            check(lib.omx_malloc(ctypes.byref(p), self.nbytes))
+            self.ptr = p.value
+            self._owned = True
+        else:
+            self.ptr = int(ptr)
+            self._owned = False
+
+    def __del__(self):
+        if getattr(self, "_owned", False) and self.ptr:
+            lib.omx_free(self.ptr)
+            self.ptr = None
+
+    @property
+    def size(self) -> int:
+        return int(np.prod(self.shape, dtype=np.int64))
+
+    @staticmethod
+    def from_numpy(a: np.ndarray, dtype="bf16") -> "Tensor":
+        code = dtype_code(dtype)
+        a = np.asarray(a)
+        if code == BFLOAT16:
+            host = _f32_to_bf16_bits(a.astype(np.float32))
+        elif code == FLOAT16:
+            host = np.ascontiguousarray(a, dtype=np.float16)
+        elif code == FLOAT32:
+            host = np.ascontiguousarray(a, dtype=np.float32)
+        elif code == UINT32:
+            host = np.ascontiguousarray(a, dtype=np.uint32)
+        elif code in (UINT8, BOOL):
+            host = np.ascontiguousarray(a, dtype=np.uint8)
+        else:
+            raise OmxError(f"unsupported dtype {dtype}")
+        t = Tensor(a.shape, code)
+        if t.nbytes:
+            check(lib.omx_memcpy_h2d(t.ptr, host.ctypes.data, t.nbytes, None))
+            check(lib.omx_synchronize(None))
+        return t
+
+    def numpy(self) -> np.ndarray:
+        """Copy back; bf16/f16 are widened to float32."""
+        code = self.dtype
+        raw = {BFLOAT16: np.uint16, FLOAT16: np.float16, FLOAT32: np.float32, UINT32: np.uint32,
+               UINT8: np.uint8, BOOL: np.uint8}[code]
+        host = np.empty(self.shape, dtype=raw)
+        if self.nbytes:
+            check(lib.omx_memcpy_d2h(host.ctypes.data, self.ptr, self.nbytes, None))
+        if code == BFLOAT16:
+            return (host.astype(np.uint32) << np.uint32(16)).view(np.float32).reshape(self.shape)
+        if code == FLOAT16:
+            return host.astype(np.float32)
+        if code == BOOL:
+            return host.astype(bool)
+        return host
+
+    def view(self, shape) -> "Tensor":
+        t = Tensor(shape, self.dtype, ptr=self.ptr, owner=self)
+        assert t.nbytes == self.nbytes
+        return t
+
+    def slice_rows(self, start_elem: int, shape) -> "Tensor":
+        """Contiguous sub-view starting `start_elem` elements in (no copy)."""
+        return Tensor(shape, self.dtype, ptr=self.ptr + start_elem * _ITEMSIZE[self.dtype], owner=self)
+
+
+def empty_like(x: Tensor, shape=None) -> Tensor:
+    return Tensor(x.shape if shape is None else shape, x.dtype)
+
+
+def synchronize() -> None:
+    check(lib.omx_synchronize(None))
+
+
+def _p(t: Optional[Tensor]):
+    return None if t is None else t.ptr
+
+
+def fill_uniform(shape, seed: int, amp: float, offset: float = 0.0, dtype="bf16") -> Tensor:
+    t = Tensor(shape, dtype)
+    check(lib.omx_fill_uniform(t.ptr, t.size, seed & 0xFFFFFFFF, amp, offset, t.dtype, None))
+    return t
+
+
+# ---- mlx_rs::fast -----------------------------------------------------------------------
+
+def rms_norm(x: Tensor, weight: Optional[Tensor], eps: float) -> Tensor:
+    """fast::rms_norm(x, weight, eps) -- mlx-rs/src/fast.rs:165-180."""
+    dim = x.shape[-1]
+    if weight is not None and weight.shape != (dim,):
+        raise OmxError(f"rms_norm: weight shape {weight.shape} does not match last axis {dim}")
+    out = empty_like(x)
+    check(lib.omx_rms_norm(out.ptr, x.ptr, _p(weight), x.size // max(dim, 1), dim, eps, x.dtype, None))
+    return out
+
+
+def layer_norm(x: Tensor, weight: Optional[Tensor], bias: Optional[Tensor], eps: float) -> Tensor:
+    """fast::layer_norm -- mlx-rs/src/fast.rs:204-218."""
+    dim = x.shape[-1]
+    out = empty_like(x)
+    check(lib.omx_layer_norm(out.ptr, x.ptr, _p(weight), _p(bias), x.size // max(dim, 1), dim, eps, x.dtype, None))
+    return out
+
+
+def rope(x: Tensor, dims: int, traditional: bool, base: float, scale: float, offset: int) -> Tensor:
+    """fast::rope(a, dims, traditional, base, scale, offset, freqs=None) -- fast.rs:15-46.
+    Position axis is -2."""
+    if len(x.shape) < 2:
+        raise OmxError("rope: input must have at least 2 dimensions")
+    T, D = x.shape[-2], x.shape[-1]
+    out = empty_like(x)
+    check(lib.omx_rope(out.ptr, x.ptr, x.size // max(T * D, 1), T, D, dims, int(traditional), base, scale, offset,
+                       x.dtype, None))
+    return out
+
+
+def scaled_dot_product_attention(q: Tensor, k: Tensor, v: Tensor, scale: float, mask=None,
+                                 kv_strides=None) -> Tensor:
+    """mlx_rs_core::scaled_dot_product_attention (utils.rs:191-209) ->
+    fast::scaled_dot_product_attention (fast.rs:121-151).  q [B,H,Tq,D]; k,v [B,Hkv,Tk,D].
+    mask: None | "causal" | Tensor(bool/u8 [Tq,Tk]) | Tensor(float [Tq,Tk])."""
+    B, H, Tq, D = q.shape
+    Hkv, Tk = k.shape[1], k.shape[2]
+    if isinstance(mask, str):
+        if mask not in ("", "causal"):
+            raise OmxError(f"Invalid mask mode {mask!r}")
+        mode, mptr = (MASK_CAUSAL if mask == "causal" else MASK_NONE), None
+    elif mask is None:
+        mode, mptr = MASK_NONE, None
+    else:
+        mode = MASK_BOOL if mask.dtype in (BOOL, UINT8) else MASK_ADDITIVE
+        mptr = mask.ptr
+    bs, hs = kv_strides if kv_strides is not None else (Hkv * Tk * D, Tk * D)
+    out = Tensor((B, H, Tq, D), q.dtype)
+    check(lib.omx_sdpa(out.ptr, q.ptr, k.ptr, v.ptr, B, H, Hkv, Tq, Tk, D, bs, hs, scale, mode, mptr, q.dtype, None))
+    return out
+
+
+# ---- mlx_rs_core::metal_kernels -----------------------------------------------------------
+
+def fused_swiglu(x: Tensor, gate: Tensor) -> Tensor:
+    """fused_swiglu(x, gate) = silu(gate) * x -- mlx-rs-core/src/metal_kernels.rs:188-236."""
+    if x.shape != gate.shape:
+        raise OmxError(f"fused_swiglu: shape mismatch {x.shape} vs {gate.shape}")
+    out = empty_like(x)
+    check(lib.omx_fused_swiglu(out.ptr, x.ptr, gate.ptr, x.size, x.dtype, None))
+    return out
+
+
+def fused_modulate(x: Tensor, shift: Tensor, scale: Tensor, eps: float = 1e-6) -> Tensor:
+    """fused_modulate(x[B,S,H], shift[B,H], scale[B,H]) -- metal_kernels.rs:260-339."""
+    B, S, H = x.shape
+    out = empty_like(x)
+    check(lib.omx_fused_modulate(out.ptr, x.ptr, shift.ptr, scale.ptr, B, S, H, eps, x.dtype, None))
+    return out
+
+
+# ---- nn::Linear / Embedding / sampler -------------------------------------------------------
+
+def linear(x: Tensor, w: Tensor, bias: Optional[Tensor] = None) -> Tensor:
+    """nn::Linear::forward: x @ W^T (+ b), W [out,in] -- mlx-rs/src/nn/linear.rs:87-92."""
+    N, K = w.shape
+    if x.shape[-1] != K:
+        raise OmxError(f"linear: input features {x.shape[-1]} != weight in-features {K}")
+    M = x.size // K
+    out = Tensor(tuple(x.shape[:-1]) + (N,), x.dtype)
+    check(lib.omx_linear(out.ptr, x.ptr, w.ptr, _p(bias), M, N, K, x.dtype, None))
+    return out
+
+
+def take_rows(table: Tensor, ids: Tensor) -> Tensor:
+    """nn::Embedding::forward (gather rows)."""
+    dim = table.shape[-1]
+    out = Tensor(tuple(ids.shape) + (dim,), table.dtype)
+    check(lib.omx_take_rows(out.ptr, table.ptr, ids.ptr, ids.size, dim, table.dtype, None))
+    return out
+
+
+def add(a: Tensor, b: Tensor) -> Tensor:
+    out = empty_like(a)
+    check(lib.omx_add(out.ptr, a.ptr, b.ptr, a.size, a.dtype, None))
+    return out
+
+
+def argmax(logits: Tensor) -> Tensor:
+    """DefaultSampler temp == 0: argmax over the last axis, u32 (sampler.rs:9-12)."""
+    n = logits.shape[-1]
+    out = Tensor(logits.shape[:-1], UINT32)
+    check(lib.omx_argmax(out.ptr, logits.ptr, logits.size // n, n, logits.dtype, None))
+    return out

@@ -1,0 +1,101 @@
+"""TEST INFRASTRUCTURE ONLY -- CPU restatement of the MLX random generator.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
+anything under oracle/.  The shipped product path never does.
+
+The reference's seeded unit tests (mlx-rs/src/fast.rs:231-298,
+mlx-rs/src/nn/{positional_encoding.rs:432-462, normalization.rs:666-733,
+activation.rs:1156-1180,1291-1320, linear.rs:224-252}) draw their inputs from
+MLX's global RNG.  MLX core (ml-explore/mlx v0.30.1, fetched at build time by
+mlx-rs/mlx-sys/src/mlx-c/CMakeLists.txt:35-39) is NOT vendored in the reference
+tree, so this file restates the published algorithm (Threefry-2x32, 20 rounds,
+JAX-compatible key splitting) and is pinned by reproducing the *input*
+statistics those reference tests assert (tests/test_oracle_kats.py).
+
+Entry points mirror mlx-rs/src/random.rs:
+    seed(s)                  random.rs:88-91
+    key(s)                   random.rs:98-100
+    uniform(lo, hi, shape)   random.rs (uniform::<_, f32>)
+"""
+from __future__ import annotations
+
+import numpy as np
+
+_M32 = np.uint64(0xFFFFFFFF)
+_ROT = ((13, 15, 26, 6), (17, 29, 16, 24))
+
+
+def _rotl(x: np.ndarray, r: int) -> np.ndarray:
+    return ((x << np.uint64(r)) | (x >> np.uint64(32 - r))) & _M32
+
+
+def threefry2x32(key, c0: np.ndarray, c1: np.ndarray):
+    """Threefry-2x32, 20 rounds; all arithmetic mod 2^32 (held in uint64 lanes)."""
+    k0 = np.uint64(key[0])
+    k1 = np.uint64(key[1])
+    ks = (k0, k1, np.uint64(0x1BD11BDA) ^ k0 ^ k1)
+    x0 = (c0.astype(np.uint64) + ks[0]) & _M32
+    x1 = (c1.astype(np.uint64) + ks[1]) & _M32
+    for g in range(5):
+        for r in _ROT[g % 2]:
+            x0 = (x0 + x1) & _M32
+            x1 = _rotl(x1, r)
+            x1 = x1 ^ x0
+        x0 = (x0 + ks[(g + 1) % 3]) & _M32
+        x1 = (x1 + ks[(g + 2) % 3] + np.uint64(g + 1)) & _M32
+    return x0.astype(np.uint32), x1.astype(np.uint32)
+
+
+def bits(key, n: int) -> np.ndarray:
+    """n uint32 words. Layout per SURVEY Appendix C (odd n puts the unpaired word in the middle)."""
+    out = np.empty(n, dtype=np.uint32)
+    h = n // 2
+    if n % 2 == 0:
+        i = np.arange(h, dtype=np.uint64)
+        a, b = threefry2x32(key, i, i + np.uint64(h))
+        out[:h] = a
+        out[h:] = b
+    else:
+        i = np.arange(h, dtype=np.uint64)
+        a, b = threefry2x32(key, i, i + np.uint64(h + 1))
+        out[:h] = a
+        out[h + 1:] = b
+        m, _ = threefry2x32(key, np.array([h], dtype=np.uint64), np.array([0], dtype=np.uint64))
+        out[h] = m[0]
+    return out
+
+
+def key(seed_value: int):
+    s = int(seed_value) & 0xFFFFFFFFFFFFFFFF
+    return (np.uint32(s >> 32), np.uint32(s & 0xFFFFFFFF))
+
+
+def split2(k):
+    b = bits(k, 4)
+    return (b[0], b[1]), (b[2], b[3])
+
+
+class _State:
+    state = key(0)
+
+
+def seed(s: int) -> None:
+    _State.state = key(s)
+
+
+def _next_key():
+    k0, k1 = split2(_State.state)
+    _State.state = k0
+    return k1
+
+
+def uniform(lo: float, hi: float, shape, k=None) -> np.ndarray:
+    """float32 uniform in [lo, hi), row-major fill."""
+    if k is None:
+        k = _next_key()
+    n = int(np.prod(shape))
+    b = bits(k, n)
+    u = b.astype(np.float32) / np.float32(4294967295.0)
+    u = np.minimum(u, np.nextafter(np.float32(1.0), np.float32(0.0)))
+    lo32, hi32 = np.float32(lo), np.float32(hi)
+    return (lo32 + (hi32 - lo32) * u).astype(np.float32).reshape(shape)

@@ -1,0 +1,176 @@
+"""TEST INFRASTRUCTURE ONLY -- CPU (numpy) restatement of the qwen3-mlx dense decoder
+forward and greedy generation loop, i.e. the *caller* that drives the mlx-rs-core hot
+path.  Never imported by the product path.
+
+Follows, op by op (each op's output rounded to the activation dtype, as MLX does):
+  Attention::forward        qwen3-mlx/src/model.rs:161-215
+  Mlp::forward              qwen3-mlx/src/model.rs:263-267
+  TransformerBlock::forward qwen3-mlx/src/model.rs:321-332
+  Qwen3Model::forward       qwen3-mlx/src/model.rs:394-424
+  Model::forward            qwen3-mlx/src/model.rs:480-490   (lm_head or tied embedding)
+  sample / Generate         qwen3-mlx/src/model.rs:733-741, 804-843
+PARITY UNPINNED at model level: the reference holds no golden token ids / logits
+(qwen3-mlx has 0 tests); the primitives used here are pinned
+individually in tests/test_oracle_kats.py.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional
+
+import numpy as np
+
+from . import ref_core as rc
+from . import synth
+
+
+@dataclass
+class Qwen3Config:
+    """Fields of ModelArgs (qwen3-mlx/src/model.rs:47-64)."""
+    hidden_size: int = 256
+    num_hidden_layers: int = 2
+    intermediate_size: int = 768
+    num_attention_heads: int = 4
+    num_key_value_heads: int = 2
+    head_dim: int = 64
+    vocab_size: int = 1024
+    rms_norm_eps: float = 1e-6
+    rope_theta: float = 1e6
+    tie_word_embeddings: bool = False
+    rope_scaling: Optional[dict] = None
+    max_position_embeddings: int = 40960
+
+    @staticmethod
+    def qwen3_8b():
+        return Qwen3Config(4096, 36, 12288, 32, 8, 128, 151936, 1e-6, 1e6, False)
+
+    @staticmethod
+    def qwen3_0_6b():
+        return Qwen3Config(1024, 28, 3072, 16, 8, 128, 151936, 1e-6, 1e6, True)
+
+
+def weight_shapes(cfg: Qwen3Config) -> Dict[str, tuple]:
+    """HF key names the loader expects (qwen3-mlx/src/model.rs:631-716)."""
+    h, I, H, Hkv, D, V = (cfg.hidden_size, cfg.intermediate_size, cfg.num_attention_heads,
+                          cfg.num_key_value_heads, cfg.head_dim, cfg.vocab_size)
+    s = {"model.embed_tokens.weight": (V, h), "model.norm.weight": (h,)}
+    for i in range(cfg.num_hidden_layers):
+        p = f"model.layers.{i}."
+        s[p + "self_attn.q_proj.weight"] = (H * D, h)
+        s[p + "self_attn.k_proj.weight"] = (Hkv * D, h)
+        s[p + "self_attn.v_proj.weight"] = (Hkv * D, h)
+        s[p + "self_attn.o_proj.weight"] = (h, H * D)
+        s[p + "self_attn.q_norm.weight"] = (D,)
+        s[p + "self_attn.k_norm.weight"] = (D,)
+        s[p + "mlp.gate_proj.weight"] = (I, h)
+        s[p + "mlp.up_proj.weight"] = (I, h)
+        s[p + "mlp.down_proj.weight"] = (h, I)
+        s[p + "input_layernorm.weight"] = (h,)
+        s[p + "post_attention_layernorm.weight"] = (h,)
+    if not cfg.tie_word_embeddings:
+        s["lm_head.weight"] = (V, h)
+    return s
+
+
+def weight_spec(name: str):
+    """(std, offset) of the synthetic generator per tensor class:
+    matrices N(0,0.02^2)-like, norm weights 1 + small noise."""
+    if name.endswith("norm.weight") or name.endswith("layernorm.weight"):
+        return 0.01, 1.0
+    return 0.02, 0.0
+
+
+def synth_weights(cfg: Qwen3Config, dt: str = "bf16") -> Dict[str, np.ndarray]:
+    out = {}
+    for name, shape in weight_shapes(cfg).items():
+        std, off = weight_spec(name)
+        out[name] = synth.tensor(name, shape, std, off, dt)
+    return out
+
+
+class Qwen3Oracle:
+    def __init__(self, cfg: Qwen3Config, weights: Dict[str, np.ndarray], dt: str = "bf16"):
+        self.cfg, self.w, self.dt = cfg, weights, dt
+        self.rope = rc.initialize_rope(cfg.head_dim, cfg.rope_theta, False, cfg.rope_scaling)
+        self.scale = float(np.float32(1.0) / np.sqrt(np.float32(cfg.head_dim)))
+
+    # model.rs:161-215
+    def attention(self, i: int, x, mask, cache):
+        cfg, dt = self.cfg, self.dt
+        p = f"model.layers.{i}.self_attn."
+        B, L, _ = x.shape
+        q = rc.linear(x, self.w[p + "q_proj.weight"], None, dt)
+        k = rc.linear(x, self.w[p + "k_proj.weight"], None, dt)
+        v = rc.linear(x, self.w[p + "v_proj.weight"], None, dt)
+        q = q.reshape(B, L, cfg.num_attention_heads, -1).transpose(0, 2, 1, 3)
+        k = k.reshape(B, L, cfg.num_key_value_heads, -1).transpose(0, 2, 1, 3)
+        v = v.reshape(B, L, cfg.num_key_value_heads, -1).transpose(0, 2, 1, 3)
+        q = rc.rms_norm(q, self.w[p + "q_norm.weight"], cfg.rms_norm_eps, dt)
+        k = rc.rms_norm(k, self.w[p + "k_norm.weight"], cfg.rms_norm_eps, dt)
+        off = cache.offset()
+        r = self.rope
+        q = rc.rope(q, r["dims"], r["traditional"], r["base"], r["scale"], off, dt)
+        k = rc.rope(k, r["dims"], r["traditional"], r["base"], r["scale"], off, dt)
+        k, v = cache.update_and_fetch(k, v)
+        if mask is not None:
+            m = mask
+        elif L > 1:
+            m = "causal"
+        else:
+            m = None
+        o = rc.scaled_dot_product_attention(q, k, v, self.scale, m, dt)
+        o = o.transpose(0, 2, 1, 3).reshape(B, L, -1)
+        return rc.linear(o, self.w[p + "o_proj.weight"], None, dt)
+
+    # model.rs:263-267
+    def mlp(self, i: int, x):
+        p = f"model.layers.{i}.mlp."
+        dt = self.dt
+        g = rc.linear(x, self.w[p + "gate_proj.weight"], None, dt)
+        u = rc.linear(x, self.w[p + "up_proj.weight"], None, dt)
+        act = rc.multiply(rc.silu(g, dt), u, dt)
+        return rc.linear(act, self.w[p + "down_proj.weight"], None, dt)
+
+    # model.rs:321-332
+    def block(self, i: int, x, mask, cache):
+        cfg, dt = self.cfg, self.dt
+        p = f"model.layers.{i}."
+        xn = rc.rms_norm(x, self.w[p + "input_layernorm.weight"], cfg.rms_norm_eps, dt)
+        h = rc.add(x, self.attention(i, xn, mask, cache), dt)
+        hn = rc.rms_norm(h, self.w[p + "post_attention_layernorm.weight"], cfg.rms_norm_eps, dt)
+        return rc.add(h, self.mlp(i, hn), dt)
+
+    # model.rs:394-424 + 480-490
+    def forward(self, tokens: np.ndarray, caches: List):
+        """tokens [B, L] -> logits [B, L, V] (lm_head applied to ALL positions, as the reference does)."""
+        cfg = self.cfg
+        tokens = np.asarray(tokens)
+        h = self.w["model.embed_tokens.weight"][tokens]          # Embedding gather
+        T = h.shape[1]
+        off = caches[0].offset() if caches else None
+        m = rc.create_attention_mask(T, off, None, True)        # every caller passes Some(true) (model.rs:401)
+        mask = m if isinstance(m, np.ndarray) else None
+        if not caches:
+            caches.extend(rc.KVCache() for _ in range(cfg.num_hidden_layers))
+        for i in range(cfg.num_hidden_layers):
+            h = self.block(i, h, mask, caches[i])
+        h = rc.rms_norm(h, self.w["model.norm.weight"], cfg.rms_norm_eps, self.dt)
+        head = self.w["model.embed_tokens.weight"] if cfg.tie_word_embeddings else self.w["lm_head.weight"]
+        return rc.linear(h, head, None, self.dt)
+
+    # model.rs:804-843 (yield order == plain sequential greedy decoding)
+    def generate(self, prompt: np.ndarray, n_new: int, caches: Optional[List] = None, return_logits: bool = False):
+        caches = [] if caches is None else caches
+        logits = self.forward(np.asarray(prompt)[None, :], caches)
+        last = logits[:, -1, :]
+        y = rc.sample_greedy(last)
+        toks, all_logits = [int(y[0])], [last[0]]
+        for _ in range(n_new - 1):
+            logits = self.forward(y[:, None].astype(np.int64), caches)
+            last = logits[:, -1, :]
+            y = rc.sample_greedy(last)
+            toks.append(int(y[0]))
+            all_logits.append(last[0])
+        if return_logits:
+            return np.array(toks, dtype=np.uint32), np.stack(all_logits)
+        return np.array(toks, dtype=np.uint32)

@@ -1,0 +1,330 @@
+"""GPU parity tests (through the C ABI) for the hot-path primitives, SURVEY.md section 8a rows
+a1, a3, a4, a5, a8, a9, a10.  The first block replays the reference's own seeded tests on the
+MI355X; the rest compares against the CPU oracle on seeded inputs, including the edge cases the
+reference's layouts imply (ragged dims, offsets, GQA groups, strided KV views, masks).
+
+Tolerances (stated per SURVEY.md 8c "Consequence"):
+  f32 kernels ........ |d| <= 2e-5 * max(1,|ref|)   (fp32 accumulation order only)
+  bf16 kernels ....... <= 1 bf16 ulp of the oracle value for single-rounding ops
+                       (<= 2 ulp where the op holds an intermediate in bf16)
+"""
+import numpy as np
+import pytest
+
+from oracle import mlx_rng as rng
+from oracle import ref_core as rc
+
+pytestmark = pytest.mark.gpu
+
+
+def ulp_bf16(ref):
+    ref = np.abs(np.asarray(ref, dtype=np.float64))
+    e = np.floor(np.log2(np.maximum(ref, 2.0 ** -126)))
+    return 2.0 ** (e - 7)
+
+
+def assert_bf16_close(got, ref, ulps=1.0, atol=0.0):
+    got = np.asarray(got, dtype=np.float64)
+    ref = np.asarray(ref, dtype=np.float64)
+    err = np.abs(got - ref)
+    tol = ulps * ulp_bf16(ref) + atol
+    bad = err > tol
+    assert not bad.any(), f"{bad.sum()} of {bad.size} elements off by > {ulps} bf16 ulp; worst err {err.max():.3e} (ref {ref.ravel()[err.argmax()]:.5g})"
+
+
+def assert_f32_close(got, ref, rtol=2e-5):
+    got = np.asarray(got, dtype=np.float64)
+    ref = np.asarray(ref, dtype=np.float64)
+    err = np.abs(got - ref)
+    assert (err <= rtol * np.maximum(1.0, np.abs(ref))).all(), f"worst err {err.max():.3e}"
+
+
+def rand(shape, seed, lo=-1.0, hi=1.0):
+    g = np.random.default_rng(seed)
+    return g.uniform(lo, hi, size=shape).astype(np.float32)
+
+
+# ----------------------------------------------------------------------------------------
+# the reference's own seeded tests, run on the GPU path
+# ----------------------------------------------------------------------------------------
+
+def _draw(seed):
+    rng.seed(seed)
+    return rng.uniform(0.0, 1.0, (2, 8, 16))
+
+
+def test_ref_test_rope_on_gpu(omx):
+    """mlx-rs/src/fast.rs:232-250."""
+    T = omx.ops.Tensor
+    a = _draw(71)
+    out = omx.ops.rope(T.from_numpy(a, "f32"), 8, False, 10000.0, 1.0, 0).numpy()
+    assert out.shape == (2, 8, 16) and out.dtype == np.float32
+    assert out.mean(dtype=np.float64) == pytest.approx(0.45625377, abs=1e-6)
+    assert out.sum(dtype=np.float64) == pytest.approx(116.800964, abs=3e-4)
+
+
+def test_ref_test_rms_norm_on_gpu(omx):
+    """mlx-rs/src/fast.rs:254-273."""
+    T = omx.ops.Tensor
+    out = omx.ops.rms_norm(T.from_numpy(_draw(103), "f32"), T.from_numpy(np.ones(16), "f32"), 1e-5).numpy()
+    assert out.mean(dtype=np.float64) == pytest.approx(0.87293875, abs=1e-6)
+    assert out.sum(dtype=np.float64) == pytest.approx(223.47232, abs=3e-4)
+
+
+def test_ref_test_layer_norm_affine_on_gpu(omx):
+    """mlx-rs/src/fast.rs:277-298."""
+    T = omx.ops.Tensor
+    out = omx.ops.layer_norm(T.from_numpy(_draw(635), "f32"), T.from_numpy(np.ones(16), "f32"),
+                             T.from_numpy(np.zeros(16), "f32"), 1e-5).numpy()[..., 0]
+    assert out.mean(dtype=np.float64) == pytest.approx(0.29099038, abs=2e-6)
+    assert out.sum(dtype=np.float64) == pytest.approx(4.655846, abs=3e-5)
+
+
+# ----------------------------------------------------------------------------------------
+# a4 norms
+# ----------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("rows,dim", [(1, 4096), (7, 128), (33, 1000), (5, 3), (4, 3072), (0, 64)])
+@pytest.mark.parametrize("dt", ["bf16", "f32", "f16"])
+def test_rms_norm_parity(omx, rows, dim, dt):
+    T = omx.ops.Tensor
+    x = rc.rnd(rand((rows, dim), 1) * 3, dt)
+    w = rc.rnd(1 + 0.1 * rand((dim,), 2), dt)
+    got = omx.ops.rms_norm(T.from_numpy(x, dt), T.from_numpy(w, dt), 1e-6).numpy()
+    ref = rc.rms_norm(x, w, 1e-6, dt)
+    if dt == "f32":
+        assert_f32_close(got, ref)
+    elif dt == "bf16":
+        assert_bf16_close(got, ref, 1)
+    else:
+        np.testing.assert_allclose(got, ref, rtol=2e-3, atol=1e-6)
+    # weight == None is legal at the boundary (fast.h:166 "may be null")
+    if rows:
+        got = omx.ops.rms_norm(T.from_numpy(x, dt), None, 1e-6).numpy()
+        ref = rc.rms_norm(x, None, 1e-6, dt)
+        (assert_f32_close if dt == "f32" else (lambda g, r: np.testing.assert_allclose(g, r, rtol=8e-3, atol=1e-6)))(got, ref)
+
+
+@pytest.mark.parametrize("rows,dim", [(3, 3072), (9, 512), (2, 37)])
+@pytest.mark.parametrize("dt", ["bf16", "f32"])
+def test_layer_norm_parity(omx, rows, dim, dt):
+    T = omx.ops.Tensor
+    x = rc.rnd(rand((rows, dim), 3) * 2 + 0.5, dt)
+    w = rc.rnd(1 + 0.1 * rand((dim,), 4), dt)
+    b = rc.rnd(0.1 * rand((dim,), 5), dt)
+    for ww, bb in ((w, b), (None, None), (w, None)):
+        got = omx.ops.layer_norm(T.from_numpy(x, dt), None if ww is None else T.from_numpy(ww, dt),
+                                 None if bb is None else T.from_numpy(bb, dt), 1e-5).numpy()
+        ref = rc.layer_norm(x, ww, bb, 1e-5, dt)
+        if dt == "f32":
+            assert_f32_close(got, ref, 5e-5)
+        else:
+            assert_bf16_close(got, ref, 1, atol=1e-3)   # near-zero outputs: absolute floor from (x-mu) cancellation
+
+
+@pytest.mark.parametrize("dt", ["bf16", "f32"])
+def test_fused_modulate_parity(omx, dt):
+    """mlx-rs-core/src/metal_kernels.rs:260-339."""
+    T = omx.ops.Tensor
+    B, S, H = 2, 37, 3072
+    x = rc.rnd(rand((B, S, H), 6) * 2, dt)
+    shift = rc.rnd(0.2 * rand((B, H), 7), dt)
+    scale = rc.rnd(0.2 * rand((B, H), 8), dt)
+    got = omx.ops.fused_modulate(T.from_numpy(x, dt), T.from_numpy(shift, dt), T.from_numpy(scale, dt), 1e-6).numpy()
+    ref = rc.fused_modulate(x, shift, scale, 1e-6, dt)
+    if dt == "f32":
+        assert_f32_close(got, ref, 5e-5)
+    else:
+        assert_bf16_close(got, ref, 1, atol=2e-3)
+
+
+# ----------------------------------------------------------------------------------------
+# a3 RoPE
+# ----------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("shape,dims,trad,base,scale,offset", [
+    ((1, 32, 1, 128), 128, False, 1e6, 1.0, 2047),      # Qwen3-8B decode q at ctx 2047
+    ((1, 8, 17, 128), 128, False, 1e6, 1.0, 5),         # prefill chunk with offset
+    ((2, 4, 9, 64), 32, False, 1e4, 0.25, 100),         # partial rotary + linear scaling (utils.rs:70-85)
+    ((1, 2, 6, 64), 64, True, 1e4, 1.0, 0),             # traditional (interleaved) pairing
+    ((3, 5, 16), 8, False, 1e4, 1.0, 3),                # 3-D input as in the reference test
+])
+@pytest.mark.parametrize("dt", ["bf16", "f32"])
+def test_rope_parity(omx, shape, dims, trad, base, scale, offset, dt):
+    T = omx.ops.Tensor
+    x = rc.rnd(rand(shape, 9), dt)
+    got = omx.ops.rope(T.from_numpy(x, dt), dims, trad, base, scale, offset).numpy()
+    ref = rc.rope(x, dims, trad, base, scale, offset, dt)
+    if dt == "f32":
+        assert_f32_close(got, ref, 1e-5)
+    else:
+        assert_bf16_close(got, ref, 1, atol=1e-6)
+
+
+def test_rope_rejects_bad_dims(omx):
+    T = omx.ops.Tensor
+    with pytest.raises(omx.OmxError):
+        omx.ops.rope(T.from_numpy(np.zeros((1, 2, 8)), "f32"), 16, False, 1e4, 1.0, 0)
+
+
+# ----------------------------------------------------------------------------------------
+# a8 fused_swiglu, add, gather, argmax
+# ----------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("n", [14336, 9216 * 3, 1001, 1])
+@pytest.mark.parametrize("dt", ["bf16", "f32"])
+def test_fused_swiglu_parity(omx, n, dt):
+    T = omx.ops.Tensor
+    up = rc.rnd(rand((n,), 10) * 4, dt)
+    gate = rc.rnd(rand((n,), 11) * 6, dt)
+    got = omx.ops.fused_swiglu(T.from_numpy(up, dt), T.from_numpy(gate, dt)).numpy()
+    ref = rc.fused_swiglu(up, gate, dt)
+    if dt == "f32":
+        assert_f32_close(got, ref, 1e-5)
+    else:
+        assert_bf16_close(got, ref, 1)
+
+
+def test_add_and_take_rows(omx):
+    T = omx.ops.Tensor
+    a = rc.bf16_round(rand((5, 300), 12))
+    b = rc.bf16_round(rand((5, 300), 13))
+    np.testing.assert_array_equal(omx.ops.add(T.from_numpy(a), T.from_numpy(b)).numpy(), rc.add(a, b, "bf16"))
+    table = rc.bf16_round(rand((50, 256), 14))
+    ids = np.array([[3, 49, 0], [7, 7, 21]], dtype=np.uint32)
+    got = omx.ops.take_rows(T.from_numpy(table), T.from_numpy(ids, "u32")).numpy()
+    np.testing.assert_array_equal(got, table[ids])
+
+
+@pytest.mark.parametrize("n", [151936, 1000, 5])
+def test_argmax_first_index_on_ties(omx, n):
+    """sampler.rs:9-12; tie-break = first index."""
+    T = omx.ops.Tensor
+    x = rc.bf16_round(rand((3, n), 15))
+    x[0, n // 2] = 9.0
+    x[1, [1, n - 1]] = 7.0          # tie -> index 1
+    x[2, :] = -3.0                  # all equal -> index 0
+    got = omx.ops.argmax(T.from_numpy(x)).numpy()
+    np.testing.assert_array_equal(got, rc.sample_greedy(x))
+    assert got.tolist() == [n // 2, 1, 0]
+
+
+def test_fill_uniform_matches_numpy_twin(omx):
+    from oracle import synth
+    for dt in ("bf16", "f32"):
+        got = omx.ops.fill_uniform((3, 1000), 1234, 0.05, 1.0, dt).numpy()
+        ref = synth.uniform_pm((3, 1000), 1234, 0.05, 1.0, dt)
+        np.testing.assert_array_equal(got, ref)
+
+
+# ----------------------------------------------------------------------------------------
+# a5 Linear at decode (M small): GEMV family
+# ----------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("N,K", [(4096, 4096), (1024, 4096), (4096, 12288), (3072, 1024), (1000, 512),
+                                 (257, 2048), (96, 1536), (64, 3072), (40, 6144), (8, 8192), (16, 14336)])
+def test_linear_decode_parity(omx, N, K):
+    T = omx.ops.Tensor
+    x = rc.bf16_round(rand((1, K), 16))
+    w = rc.bf16_round(rand((N, K), 17) * 0.05)
+    got = omx.ops.linear(T.from_numpy(x), T.from_numpy(w)).numpy()
+    ref = rc.linear(x, w, None, "bf16")
+    assert got.shape == (1, N)
+    assert_bf16_close(got, ref, 1, atol=1e-30)
+
+
+def test_linear_small_batch(omx):
+    T = omx.ops.Tensor
+    x = rc.bf16_round(rand((3, 1024), 18))
+    w = rc.bf16_round(rand((512, 1024), 19) * 0.05)
+    got = omx.ops.linear(T.from_numpy(x), T.from_numpy(w)).numpy()
+    assert_bf16_close(got, rc.linear(x, w, None, "bf16"), 1)
+
+
+def test_linear_shape_error(omx):
+    T = omx.ops.Tensor
+    with pytest.raises(omx.OmxError):
+        omx.ops.linear(T.from_numpy(np.zeros((1, 100))), T.from_numpy(np.zeros((8, 512))))
+
+
+# ----------------------------------------------------------------------------------------
+# a1 SDPA, decode shape (Tq == 1)
+# ----------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("B,H,Hkv,Tk,D", [
+    (1, 32, 8, 2304, 128),     # Qwen3-8B decode at the end of the bench window
+    (1, 32, 8, 1, 128),        # first token
+    (1, 16, 8, 129, 128),      # Qwen3-0.6B, ragged length
+    (2, 4, 4, 77, 64),         # MHA, D=64, batch 2
+    (1, 28, 4, 300, 128),      # Qwen2.5-7B grouping (7 q heads per kv head)
+    (1, 14, 2, 63, 64),        # Qwen2-0.5B
+])
+def test_sdpa_decode_parity(omx, B, H, Hkv, Tk, D):
+    T = omx.ops.Tensor
+    q = rc.bf16_round(rand((B, H, 1, D), 20) * 2)
+    k = rc.bf16_round(rand((B, Hkv, Tk, D), 21) * 2)
+    v = rc.bf16_round(rand((B, Hkv, Tk, D), 22))
+    scale = 1.0 / np.sqrt(D)
+    got = omx.ops.scaled_dot_product_attention(T.from_numpy(q), T.from_numpy(k), T.from_numpy(v), scale).numpy()
+    ref = rc.scaled_dot_product_attention(q, k, v, scale, None, "bf16")
+    assert_bf16_close(got, ref, 1, atol=2e-3 * np.abs(ref).max())
+
+
+def test_sdpa_decode_strided_kv_view_and_masks(omx):
+    """K/V handed over as the [..,:offset,:] view of the step-256 buffer (cache.rs:190-193)."""
+    T = omx.ops.Tensor
+    B, H, Hkv, cap, off, D = 1, 8, 2, 512, 300, 128
+    q = rc.bf16_round(rand((B, H, 1, D), 23))
+    kbuf = rc.bf16_round(rand((B, Hkv, cap, D), 24))
+    vbuf = rc.bf16_round(rand((B, Hkv, cap, D), 25))
+    scale = D ** -0.5
+    tk, tv = T.from_numpy(kbuf), T.from_numpy(vbuf)
+    for mask_np, mask_t in [
+        (None, None),
+        ("causal", "causal"),
+    ]:
+        got = omx.ops.scaled_dot_product_attention(T.from_numpy(q), T.from_numpy(kbuf[:, :, :off]).view((B, Hkv, off, D)),
+                                                   T.from_numpy(vbuf[:, :, :off]).view((B, Hkv, off, D)), scale, mask_t).numpy()
+        ref = rc.scaled_dot_product_attention(q, kbuf[:, :, :off], vbuf[:, :, :off], scale, mask_np, "bf16")
+        assert_bf16_close(got, ref, 1, atol=2e-3 * np.abs(ref).max())
+    # strided view: same buffers, Tk = off, strides of the full-capacity buffer
+    kview = T((B, Hkv, off, D), "bf16", ptr=tk.ptr, owner=tk)
+    vview = T((B, Hkv, off, D), "bf16", ptr=tv.ptr, owner=tv)
+    got = omx.ops.scaled_dot_product_attention(T.from_numpy(q), kview, vview, scale, None,
+                                               kv_strides=(Hkv * cap * D, cap * D)).numpy()
+    ref = rc.scaled_dot_product_attention(q, kbuf[:, :, :off], vbuf[:, :, :off], scale, None, "bf16")
+    assert_bf16_close(got, ref, 1, atol=2e-3 * np.abs(ref).max())
+    # bool mask (keep-where-true) and additive mask of shape [1, Tk]
+    keep = (np.arange(off) % 3 != 0)[None, :]
+    got = omx.ops.scaled_dot_product_attention(T.from_numpy(q), kview, vview, scale, T.from_numpy(keep, "bool"),
+                                               kv_strides=(Hkv * cap * D, cap * D)).numpy()
+    ref = rc.scaled_dot_product_attention(q, kbuf[:, :, :off], vbuf[:, :, :off], scale, keep, "bf16")
+    assert_bf16_close(got, ref, 1, atol=2e-3 * np.abs(ref).max())
+    addm = rc.bf16_round(rand((1, off), 26) * 3)
+    got = omx.ops.scaled_dot_product_attention(T.from_numpy(q), kview, vview, scale, T.from_numpy(addm, "bf16"),
+                                               kv_strides=(Hkv * cap * D, cap * D)).numpy()
+    ref = rc.scaled_dot_product_attention(q, kbuf[:, :, :off], vbuf[:, :, :off], scale, addm, "bf16")
+    assert_bf16_close(got, ref, 1, atol=2e-3 * np.abs(ref).max())
+
+
+def test_sdpa_softmax_spike_forces_rescale(omx):
+    """One key far above the rest in a late tile: exercises the running-max rescale branch of the
+    online softmax (cdna_hip_programming.md rule 26)."""
+    T = omx.ops.Tensor
+    B, H, Hkv, Tk, D = 1, 4, 1, 700, 128
+    q = rc.bf16_round(rand((B, H, 1, D), 27))
+    k = rc.bf16_round(rand((B, Hkv, Tk, D), 28) * 0.1)
+    v = rc.bf16_round(rand((B, Hkv, Tk, D), 29))
+    k[0, 0, 555] = rc.bf16_round(q[0, 1, 0] * 8)     # huge score for head 1 at token 555
+    scale = D ** -0.5
+    got = omx.ops.scaled_dot_product_attention(T.from_numpy(q), T.from_numpy(k), T.from_numpy(v), scale).numpy()
+    ref = rc.scaled_dot_product_attention(q, k, v, scale, None, "bf16")
+    assert_bf16_close(got, ref, 1, atol=2e-3 * np.abs(ref).max())
+
+
+def test_sdpa_rejects_bad_group(omx):
+    T = omx.ops.Tensor
+    z = np.zeros((1, 6, 1, 64))
+    with pytest.raises(omx.OmxError):
+        omx.ops.scaled_dot_product_attention(T.from_numpy(z), T.from_numpy(np.zeros((1, 4, 8, 64))),
+                                             T.from_numpy(np.zeros((1, 4, 8, 64))), 1.0)

@@ -1,0 +1,237 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json headline metric on MI355X: greedy decode tokens/s of the
+Qwen3-8B-shaped bf16 model ("qwen3-mlx 7B bf16 TP=1 on one MI355X, 2k prefill + 256 decode",
+BASELINE.json configs[1]; Qwen3-8B is the in-family size the reference pins).
+
+A "step" is ONE decode token through the whole hot path (36 layers + lm_head + greedy sample)
+at a context that starts at --prompt (2048) tokens.  Synthetic weights / prompt (no network).
+One process per GPU; for N > 1 the model is tensor-parallel (column-split q/k/v/gate/up/lm_head,
+row-split o/down, KV heads sharded) with RCCL all-reduce over xGMI -- strong scaling (one token
+stream, fixed total work).
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` for the dominant
+kernel (gate/up GEMV + SwiGLU) and `cpu_baseline` (plain-C port of the same decode step timed on
+the host cores; oracle/c/omx_oracle.c).
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
+
+QWEN3_8B = dict(hidden_size=4096, num_hidden_layers=36, intermediate_size=12288, num_attention_heads=32,
+                num_key_value_heads=8, head_dim=128, vocab_size=151936, rms_norm_eps=1e-6, rope_theta=1e6,
+                tie_word_embeddings=False)
+QWEN3_0_6B = dict(hidden_size=1024, num_hidden_layers=28, intermediate_size=3072, num_attention_heads=16,
+                  num_key_value_heads=8, head_dim=128, vocab_size=151936, rms_norm_eps=1e-6, rope_theta=1e6,
+                  tie_word_embeddings=True)
+MODELS = {"qwen3-8b": QWEN3_8B, "qwen3-0.6b": QWEN3_0_6B}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=128)
+    ap.add_argument("--warmup", type=int, default=16)
+    ap.add_argument("--prompt", type=int, default=2048)
+    ap.add_argument("--model", default="qwen3-8b", choices=list(MODELS))
+    ap.add_argument("--layers", type=int, default=0, help="debug: override layer count (invalidates the metric)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def init_dist(n_gpus):
+    """One process per GPU (torchrun env).  Returns (rank, world, local_rank, dist or None)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if n_gpus != world:
+        if world == 1 and n_gpus > 1:
+            raise SystemExit(f"--gpus {n_gpus} needs torch.distributed.run with --nproc-per-node {n_gpus}")
+    import torch
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist_mod.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+        dist = dist_mod
+    return rank, world, local, dist
+
+
+def rccl_comm(dist, rank, world):
+    """Create an RCCL communicator for the C++ engine, bootstrapped through torch.distributed.
+    torch ships librccl.so; the engine only needs the comm handle and ncclAllReduce's address."""
+    import torch
+    lib = ctypes.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so"), mode=ctypes.RTLD_GLOBAL)
+
+    class UniqueId(ctypes.Structure):
+        _fields_ = [("internal", ctypes.c_byte * 128)]
+
+    uid = UniqueId()
+    if rank == 0:
+        lib.ncclGetUniqueId.argtypes = [ctypes.POINTER(UniqueId)]
+        assert lib.ncclGetUniqueId(ctypes.byref(uid)) == 0
+    t = torch.frombuffer(bytearray(bytes(uid)), dtype=torch.uint8).cuda()
+    if dist is not None:
+        dist.broadcast(t, 0)
+    ctypes.memmove(ctypes.byref(uid), bytes(t.cpu().numpy().tobytes()), 128)
+    comm = ctypes.c_void_p()
+    lib.ncclCommInitRank.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, UniqueId, ctypes.c_int]
+    rc = lib.ncclCommInitRank(ctypes.byref(comm), world, uid, rank)
+    if rc != 0:
+        raise RuntimeError(f"ncclCommInitRank failed with {rc}")
+    fn = ctypes.cast(lib.ncclAllReduce, ctypes.c_void_p).value
+    return lib, comm.value, fn
+
+
+def time_dominant_kernel(omx, cfg, world, iters=3):
+    """roofline.achieved: average duration of the dominant kernel (RMSNorm + gate/up GEMV + SwiGLU,
+    52 % of a step's bytes) over distinct per-layer weight buffers (no Infinity-Cache reuse), HIP
+    events on the launch stream (omx_bench_gemv)."""
+    lib = omx.lib
+    lib.omx_bench_gemv.restype = ctypes.c_int
+    lib.omx_bench_gemv.argtypes = [ctypes.c_int] * 7 + [ctypes.POINTER(ctypes.c_float)]
+    N, K = cfg["intermediate_size"] // world, cfg["hidden_size"]
+    nbytes = 2 * N * K * 2
+    copies = max(2, int(1.2e9 // nbytes))
+    ms = ctypes.c_float()
+    omx.check(lib.omx_bench_gemv(N, K, 1, 2, 0, copies, copies * iters, ctypes.byref(ms)))
+    return nbytes, ms.value * 1e-3
+
+
+def cpu_baseline(cfg, ctx, n_layers_sample=2, reps=2):
+    """Plain-C port (oracle/c/omx_oracle.c, OpenMP over the host cores) of the same decode step,
+    timed on a bounded sample: `n_layers_sample` of the model's layers at context `ctx` plus the
+    lm_head, scaled to the full layer count."""
+    import numpy as np
+    from oracle import c_oracle
+    lib = c_oracle.load()
+    hd, I, H, Hkv, D, V = (cfg["hidden_size"], cfg["intermediate_size"], cfg["num_attention_heads"],
+                           cfg["num_key_value_heads"], cfg["head_dim"], cfg["vocab_size"])
+    cap = ctx + 8
+    rngs = iter(range(1, 10000))
+
+    def filled(n, amp=0.0346, off=0.0):
+        a = np.empty(n, np.uint16)
+        lib.oracle_fill_uniform_bf16(c_oracle.ptr(a), n, next(rngs), np.float32(amp), np.float32(off))
+        return a
+
+    layers = []
+    for _ in range(n_layers_sample):
+        arrs = [filled(H * D * hd), filled(Hkv * D * hd), filled(Hkv * D * hd), filled(hd * H * D), filled(I * hd),
+                filled(I * hd), filled(hd * I), filled(D, 0.017, 1.0), filled(D, 0.017, 1.0), filled(hd, 0.017, 1.0),
+                filled(hd, 0.017, 1.0), filled(Hkv * cap * D, 1.0), filled(Hkv * cap * D, 1.0)]
+        layers.append((arrs, c_oracle.Layer(*[c_oracle.ptr(a) for a in arrs])))
+    lc = c_oracle.LayerCfg(hd, I, H, Hkv, D, cap, cfg["rms_norm_eps"], cfg["rope_theta"], 1.0)
+    scratch = np.zeros(lib.oracle_qwen3_scratch_elems(ctypes.byref(lc)), np.uint16)
+    h = filled(hd, 1.0)
+    head, norm_w, logits = filled(V * hd), filled(hd, 0.017, 1.0), np.empty(V, np.uint16)
+    t_layers = t_head = 1e30
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        for _, L in layers:
+            lib.oracle_qwen3_layer_decode(ctypes.byref(lc), ctypes.byref(L), c_oracle.ptr(h), ctx, c_oracle.ptr(scratch))
+        t1 = time.perf_counter()
+        lib.oracle_qwen3_head(c_oracle.ptr(h), c_oracle.ptr(norm_w), c_oracle.ptr(head), hd, V, cfg["rms_norm_eps"],
+                              c_oracle.ptr(logits), c_oracle.ptr(scratch))
+        t2 = time.perf_counter()
+        t_layers, t_head = min(t_layers, t1 - t0), min(t_head, t2 - t1)
+    step_s = t_layers / n_layers_sample * cfg["num_hidden_layers"] + t_head
+    return {"value": round(1.0 / step_s, 4), "unit": "tokens/s", "cores": os.cpu_count(), "kind": "port",
+            "sample": f"{n_layers_sample} of {cfg['num_hidden_layers']} decoder layers at ctx {ctx} + lm_head, "
+                      f"best of {reps}, scaled to the full model; C port with OpenMP on all host cores"}
+
+
+def main():
+    args = parse()
+    rank, world, local, dist = init_dist(args.gpus)
+    import torch
+    import omx_import
+    omx = omx_import.load_package()
+    from ominix_mlx_amd import engine
+    from oracle import synth   # prompt id generator only (no oracle compute on the timed path)
+
+    cfg = dict(MODELS[args.model])
+    if args.layers:
+        cfg["num_hidden_layers"] = args.layers
+    max_ctx = args.prompt + args.warmup + args.steps + 8
+    model = engine.Model(max_context=max_ctx, tp_rank=rank, tp_size=world, **cfg)
+    keep = None
+    if world > 1:
+        keep = rccl_comm(dist, rank, world)
+        model.set_comm(keep[1], keep[2])
+    model.synth_weights()
+
+    prompt = synth.prompt_ids(args.prompt, cfg["vocab_size"])
+    t0 = time.perf_counter()
+    first = model.prefill(prompt)
+    torch.cuda.synchronize()
+    prefill_s = time.perf_counter() - t0
+    if args.warmup:
+        model.decode(args.warmup)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        omx.check(omx.lib.omx_synchronize(model.stream()))
+
+    barrier()
+    t0 = time.perf_counter()
+    toks = model.decode(args.steps)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    dev_ms = model.last_decode_ms()
+
+    if rank != 0:
+        return
+    ctx_mid = args.prompt + args.warmup + args.steps // 2
+    step_bytes = model.step_bytes(ctx_mid) * world       # whole-job algorithmic bytes per token
+    ms_per_step = elapsed * 1e3 / args.steps
+    tok_s = args.steps / elapsed
+    k_bytes, k_s = time_dominant_kernel(omx, cfg, world)
+    achieved = k_bytes / k_s / 1e9
+    out = {
+        "metric": "decode_tokens_per_sec", "value": round(tok_s, 2), "unit": "tokens/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+        "scaling": "strong", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": f"{args.model} (Qwen3-8B shapes for BASELINE 'Qwen3-7B') bf16 greedy decode, batch 1, "
+                               f"{args.prompt}-token prompt then {args.warmup}+{args.steps} decode tokens",
+                   "parallelism": f"tp{world}", "context_at_timing": ctx_mid,
+                   "layers": cfg["num_hidden_layers"]},
+        "roofline": {"bound": "hbm", "kernel": "gemv_kernel<rmsnorm, gate/up, swiglu>", "achieved": round(achieved, 1),
+                     "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                     "algorithmic_bytes_per_launch": k_bytes, "avg_launch_us": round(k_s * 1e6, 2)},
+        "step_roofline": {"algorithmic_bytes_per_token": int(step_bytes),
+                          "achieved_GBps": round(step_bytes / (ms_per_step * 1e-3) / 1e9, 1),
+                          "frac_of_hbm_peak": round(step_bytes / (ms_per_step * 1e-3) / 1e9 / (HBM_PEAK_GBPS * world), 4),
+                          "roofline_tokens_per_sec": round(HBM_PEAK_GBPS * 1e9 * world / step_bytes, 1),
+                          "device_ms_per_step_hip_events": round(dev_ms / args.steps, 4)},
+        "prefill": {"tokens": args.prompt, "seconds": round(prefill_s, 3), "mode": "token-serial (decode kernels)"},
+        "first_tokens": [int(first)] + [int(t) for t in toks[:4]],
+    }
+    if not args.no_cpu_baseline:
+        try:
+            out["cpu_baseline"] = cpu_baseline(cfg, ctx_mid)
+        except Exception as e:   # the baseline is a report, never a reason to lose the measured line
+            out["cpu_baseline"] = {"value": None, "unit": "tokens/s", "cores": os.cpu_count(), "kind": "port",
+                                   "sample": f"failed: {e}"}
+    print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -117,6 +117,53 @@ int omx_take_rows(void* out, const void* table, const uint32_t* ids, int64_t n_i
 /* elementwise add (mlx_add): residual connections */
 int omx_add(void* out, const void* a, const void* b, int64_t n, omx_dtype dtype, omx_stream stream);
 
+/* 2-D synthetic fill of a shard of a logical [*, ld_full] tensor: element (r,c) of dst[rows,cols]
+ * takes the value of logical index (row0+r)*ld_full + (col0+c) -- tensor-parallel shards of the
+ * same logical weight are bit-identical to slices of the single-GPU tensor.                        */
+int omx_fill_uniform_2d(void* dst, int64_t rows, int64_t cols, int64_t ld_full, int64_t row0, int64_t col0,
+                        uint32_t seed, float amp, float offset, omx_dtype dtype, omx_stream stream);
+
+/* =====================================================================================
+ * Fused decode engine: the qwen3-mlx dense decoder + greedy Generate loop as ONE captured
+ * hipGraph per token (qwen3-mlx/src/model.rs:161-215, 263-267, 321-332,
+ * 394-424, 480-490, 733-741, 804-843).  Per layer: [RMSNorm+QKV GEMV] [q/k-norm+RoPE+cache
+ * write+split-KV attention] [combine] [O GEMV+residual] [RMSNorm+gate/up GEMV+SwiGLU]
+ * [down GEMV+residual]; then [RMSNorm+lm_head GEMV+argmax].  Weights are borrowed device
+ * pointers registered under their HF checkpoint key names (model.rs:631-716).
+ * ===================================================================================== */
+typedef struct omx_qwen3_config_ {
+    int hidden_size, num_hidden_layers, intermediate_size, num_attention_heads, num_key_value_heads, head_dim,
+        vocab_size;
+    float rms_norm_eps, rope_theta, rope_scale;   /* rope_scale = 1/factor for "linear" (utils.rs:70-85) */
+    int tie_word_embeddings;
+    int max_context;                              /* KV slab capacity (rounded up to the 256 step of cache.rs) */
+    int tp_rank, tp_size;                         /* tensor parallel shard of this process (1 process per GPU) */
+} omx_qwen3_config;
+typedef struct omx_qwen3_* omx_qwen3;
+
+int omx_qwen3_create(omx_qwen3* out, const omx_qwen3_config* cfg);
+int omx_qwen3_destroy(omx_qwen3 m);
+/* register a weight by HF key name; `ptr` is this rank's shard (column-split q/k/v/gate/up/lm_head rows,
+ * row-split o/down columns), bf16, contiguous.                                                      */
+int omx_qwen3_set_weight(omx_qwen3 m, const char* name, const void* ptr);
+/* allocate + fill every weight with the seeded synthetic generator (seed = base ^ crc32(name))      */
+int omx_qwen3_synth_weights(omx_qwen3 m, uint32_t base_seed);
+/* tensor-parallel hook: `allreduce` has the ncclAllReduce signature, `comm` is the ncclComm_t.      */
+int omx_qwen3_set_comm(omx_qwen3 m, void* comm, void* allreduce_fn);
+int omx_qwen3_reset(omx_qwen3 m);                                  /* KVCache::reset (cache.rs:130-132) */
+int omx_qwen3_offset(omx_qwen3 m, int* offset);                    /* KeyValueCache::offset           */
+/* Generate: prefill the prompt, return the first sampled token (model.rs:808-827)                   */
+int omx_qwen3_prefill(omx_qwen3 m, const uint32_t* prompt, int n_prompt, uint32_t* first_token);
+/* Generate: n further greedy tokens (model.rs:828-841); tokens_out is a HOST buffer of n entries    */
+int omx_qwen3_decode(omx_qwen3 m, int n, uint32_t* tokens_out);
+/* copy the logits of the last executed step ([vocab_local] bf16) to a host buffer                  */
+int omx_qwen3_last_logits(omx_qwen3 m, void* host_bf16, int n);
+/* timing of the last omx_qwen3_decode call measured with HIP events on the engine stream (ms)       */
+int omx_qwen3_last_decode_ms(omx_qwen3 m, float* ms);
+int omx_qwen3_stream(omx_qwen3 m, omx_stream* s);
+/* algorithmic HBM bytes of ONE decode step at context length ctx (SURVEY.md 8d formula)             */
+int omx_qwen3_step_bytes(omx_qwen3 m, int ctx, double* bytes);
+
 #ifdef __cplusplus
 }
 #endif

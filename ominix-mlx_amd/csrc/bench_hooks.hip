@@ -21,11 +21,11 @@ extern "C" int omx_bench_gemv(int N, int K, int pro, int epi, int rows_per_wave,
     OMX_HIP_CHECK(hipMalloc(&nw, (size_t)K * 2));
     OMX_HIP_CHECK(hipMalloc(&out, (size_t)N * 4));
     OMX_HIP_CHECK(hipMalloc(&resid, (size_t)N * 2));
-    OMX_HIP_CHECK(hipMalloc(&slot, 8));
+    OMX_HIP_CHECK(hipMalloc(&slot, 8 * 65536));
     omx_fill_uniform(x, K, 3, 1.0f, 0.f, OMX_BFLOAT16, nullptr);
     omx_fill_uniform(nw, K, 4, 0.1f, 1.f, OMX_BFLOAT16, nullptr);
     omx_fill_uniform(resid, N, 5, 1.0f, 0.f, OMX_BFLOAT16, nullptr);
-    OMX_HIP_CHECK(hipMemset(slot, 0, 8));
+    OMX_HIP_CHECK(hipMemset(slot, 0, 8 * 65536));
     hipStream_t s;
     OMX_HIP_CHECK(hipStreamCreate(&s));
     hipEvent_t e0, e1;

@@ -1,0 +1,590 @@
+// Fused Qwen3 decode engine (see include/omx.h "Fused decode engine").
+//
+// Host-side mirror, in C++, of the caller of the hot path: qwen3-mlx's Model/Generate
+// (qwen3-mlx/src/model.rs:387-433, 473-498, 743-844) driving mlx-rs-core's KVCache
+// (mlx-rs-core/src/cache.rs:91-194).  The reference records ~1000 lazy graph nodes per token and
+// lets MLX schedule them; here one decode step is 6 launches per layer captured once in a
+// hipGraph and replayed per token, with the step state (position, current token, token ring)
+// kept in device memory so that replay needs no host patching.
+//
+// HBM layout (288 GB part: everything resident, nothing paged):
+//   weights      borrowed pointers, bf16 [out,in] row-major (checkpoint layout, nn/linear.rs)
+//   KV cache     per layer K and V slabs [Hkv_local, cap, D] bf16, cap = max_context rounded up
+//                to the 256-token step of cache.rs:110-117 (same API-visible growth semantics,
+//                no reallocation + concatenate on growth)
+//   rope tables  cos/sin [cap, D/2] f32, built once in fp64
+//   step state   pos, cur_token, out ring, argmax partials
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "attn.hpp"
+#include "gemv.hpp"
+
+namespace omx {
+namespace {
+
+typedef int (*nccl_allreduce_fn)(const void*, void*, size_t, int, int, void*, hipStream_t);
+constexpr int kNcclFloat32 = 7, kNcclUint64 = 5, kNcclSum = 0, kNcclMax = 2;
+
+struct LayerW {
+    const bf16_t *q, *k, *v, *o, *gate, *up, *down, *q_norm, *k_norm, *in_ln, *post_ln;
+};
+
+uint32_t crc32_str(const char* s) {
+    uint32_t crc = 0xFFFFFFFFu;
+    for (; *s; ++s) {
+        crc ^= (uint8_t)*s;
+        for (int k = 0; k < 8; ++k) crc = (crc >> 1) ^ (0xEDB88320u & (0u - (crc & 1u)));
+    }
+    return ~crc;
+}
+
+__global__ void rope_table_kernel(float* cos_t, float* sin_t, int cap, int half, double neg_log_base_over_half,
+                                  double scale) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= cap * half) return;
+    const int t = idx / half, i = idx % half;
+    const double ang = ((double)t * scale) * exp((double)i * neg_log_base_over_half);
+    double s, c;
+    sincos(ang, &s, &c);
+    cos_t[idx] = (float)c;
+    sin_t[idx] = (float)s;
+}
+
+// step state updates (single thread; a few dozen ns of work, they only order the graph)
+struct StepState {
+    int pos;               // tokens in the cache == RoPE offset of the token being processed
+    uint32_t cur_token;    // token fed to the embedding this step
+    int out_count;         // tokens sampled so far
+    int prompt_idx;        // next prompt token to feed during prefill
+};
+
+__global__ void feed_prompt_kernel(StepState* st, const uint32_t* prompt) {
+    // after a no-head prefill step: advance and feed the next prompt token
+    st->pos += 1;
+    st->prompt_idx += 1;
+    st->cur_token = prompt[st->prompt_idx];
+}
+
+__global__ __launch_bounds__(256) void sample_finalize_kernel(StepState* st, const unsigned long long* partials,
+                                                               int n_partials, uint32_t* out_ring, int ring_cap,
+                                                               unsigned long long* key_out) {
+    __shared__ unsigned long long red[4];
+    unsigned long long best = 0;
+    for (int i = threadIdx.x; i < n_partials; i += 256) best = partials[i] > best ? partials[i] : best;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long other = __shfl_xor(best, o, 64);
+        best = other > best ? other : best;
+    }
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = best;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w) best = red[w] > best ? red[w] : best;
+        if (key_out) {
+            *key_out = best;   // TP: all-reduced (max) across ranks before apply_token_kernel
+        } else {
+            const uint32_t tok = ~(uint32_t)(best & 0xFFFFFFFFull);
+            out_ring[st->out_count % ring_cap] = tok;
+            st->out_count += 1;
+            st->cur_token = tok;
+            st->pos += 1;
+        }
+    }
+}
+
+__global__ void apply_token_kernel(StepState* st, const unsigned long long* key, uint32_t* out_ring, int ring_cap) {
+    const uint32_t tok = ~(uint32_t)(*key & 0xFFFFFFFFull);
+    out_ring[st->out_count % ring_cap] = tok;
+    st->out_count += 1;
+    st->cur_token = tok;
+    st->pos += 1;
+}
+
+__global__ __launch_bounds__(256) void embed_kernel(bf16_t* __restrict__ h, const bf16_t* __restrict__ table,
+                                                    const StepState* st, int hidden) {
+    const u32x4* src = reinterpret_cast<const u32x4*>(table + (size_t)st->cur_token * hidden);
+    u32x4* dst = reinterpret_cast<u32x4*>(h);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < hidden / 8; i += gridDim.x * blockDim.x) dst[i] = src[i];
+}
+
+}  // namespace
+}  // namespace omx
+
+using namespace omx;
+
+struct omx_qwen3_ {
+    omx_qwen3_config cfg;
+    int H, Hkv, I, V;            // local (per-rank) heads / intermediate / vocab
+    int cap;                     // KV slab capacity in tokens
+    std::map<std::string, const void*> named;
+    std::vector<void*> owned;    // allocations made by synth_weights
+    std::vector<LayerW> layers;
+    const bf16_t *embed = nullptr, *final_norm = nullptr, *lm_head = nullptr;
+    bool weights_resolved = false;
+
+    hipStream_t stream = nullptr;
+    std::vector<bf16_t*> kcache, vcache;
+    float *rope_cos = nullptr, *rope_sin = nullptr;
+    StepState* st = nullptr;
+    uint32_t *out_ring = nullptr, *prompt_dev = nullptr;
+    int ring_cap = 4096, prompt_cap = 0;
+    bf16_t *h = nullptr, *h2 = nullptr, *qkv = nullptr, *attn_out = nullptr, *act = nullptr, *logits = nullptr;
+    float *partial_a = nullptr, *partial_b = nullptr;   // TP: f32 partial sums awaiting all-reduce
+    unsigned long long *argmax_partials = nullptr, *argmax_key = nullptr;
+    int n_argmax_partials = 0;
+    float *ws_o = nullptr, *ws_ml = nullptr;
+    int nsplit = 1;
+
+    void* comm = nullptr;
+    nccl_allreduce_fn allreduce = nullptr;
+
+    hipGraphExec_t g_full = nullptr, g_nohead = nullptr;
+    bool eager = false;          // fallback when stream capture is unavailable (e.g. a collective refuses capture)
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    float last_decode_ms = 0.f;
+};
+
+namespace {
+
+int resolve_weights(omx_qwen3 m) {
+    if (m->weights_resolved) return 0;
+    auto get = [&](const std::string& n, const bf16_t** out) -> int {
+        auto it = m->named.find(n);
+        if (it == m->named.end()) return set_error("WeightNotFound: %s", n.c_str());   // error.rs:6-32
+        *out = (const bf16_t*)it->second;
+        return 0;
+    };
+    m->layers.resize(m->cfg.num_hidden_layers);
+    for (int i = 0; i < m->cfg.num_hidden_layers; ++i) {
+        const std::string p = "model.layers." + std::to_string(i) + ".";
+        LayerW& L = m->layers[i];
+        if (get(p + "self_attn.q_proj.weight", &L.q) || get(p + "self_attn.k_proj.weight", &L.k) ||
+            get(p + "self_attn.v_proj.weight", &L.v) || get(p + "self_attn.o_proj.weight", &L.o) ||
+            get(p + "self_attn.q_norm.weight", &L.q_norm) || get(p + "self_attn.k_norm.weight", &L.k_norm) ||
+            get(p + "mlp.gate_proj.weight", &L.gate) || get(p + "mlp.up_proj.weight", &L.up) ||
+            get(p + "mlp.down_proj.weight", &L.down) || get(p + "input_layernorm.weight", &L.in_ln) ||
+            get(p + "post_attention_layernorm.weight", &L.post_ln))
+            return 1;
+    }
+    if (get("model.embed_tokens.weight", &m->embed) || get("model.norm.weight", &m->final_norm)) return 1;
+    if (m->cfg.tie_word_embeddings) {
+        // tied head = Embedding::as_linear (model.rs:485-488); under TP the caller registers the vocab shard
+        auto it = m->named.find("lm_head.weight");
+        m->lm_head = it != m->named.end() ? (const bf16_t*)it->second : m->embed;
+        OMX_REQUIRE(m->cfg.tp_size == 1 || it != m->named.end(), "tied lm_head under TP needs a vocab shard registered as lm_head.weight");
+    } else if (get("lm_head.weight", &m->lm_head)) {
+        return 1;
+    }
+    m->weights_resolved = true;
+    return 0;
+}
+
+// enqueue one decode step on m->stream.  with_head=false: prompt token whose logits nobody reads.
+int enqueue_step(omx_qwen3 m, bool with_head) {
+    const omx_qwen3_config& c = m->cfg;
+    hipStream_t s = m->stream;
+    const int hd = c.hidden_size, D = c.head_dim;
+    const bool tp = c.tp_size > 1 || m->allreduce != nullptr;   // a 1-rank communicator exercises the TP path
+    embed_kernel<<<2, 256, 0, s>>>(m->h, m->embed, m->st, hd);
+    OMX_LAUNCH_CHECK();
+    bf16_t* h = m->h;      // residual stream entering the layer
+    bf16_t* hn = m->h2;    // ping-pong partner
+    const float* pending = nullptr;   // TP: all-reduced f32 partial not yet folded into h
+    for (int l = 0; l < c.num_hidden_layers; ++l) {
+        const LayerW& L = m->layers[l];
+        {   // [RMSNorm + QKV GEMV]  model.rs:168-170,324
+            GemvArgs a = {};
+            a.w0 = L.q; a.n0 = m->H * D;
+            a.w1 = L.k; a.n1 = m->Hkv * D;
+            a.w2 = L.v; a.n2 = m->Hkv * D;
+            a.N = (m->H + 2 * m->Hkv) * D;
+            a.K = hd;
+            a.x = h; a.x_partial = pending; a.x_out = pending ? hn : nullptr;
+            a.norm_w = L.in_ln; a.eps = c.rms_norm_eps;
+            a.out = m->qkv;
+            if (launch_gemv(a, PRO_RMSNORM, EPI_STORE, s)) return 1;
+            if (pending) { bf16_t* t = h; h = hn; hn = t; pending = nullptr; }
+        }
+        {   // [q/k RMSNorm + RoPE + cache append + split-KV SDPA] + [combine]  model.rs:172-210
+            AttnDecodeArgs a = {};
+            a.qkv = m->qkv;
+            a.k = m->kcache[l]; a.v = m->vcache[l];
+            a.kv_batch_stride = 0; a.kv_head_stride = (int64_t)m->cap * D;
+            a.B = 1; a.H = m->H; a.Hkv = m->Hkv;
+            a.scale = 1.0f / sqrtf((float)D);
+            a.mask_mode = OMX_MASK_NONE;
+            a.nsplit = m->nsplit;
+            a.ws_o = m->ws_o; a.ws_ml = m->ws_ml;
+            a.out = m->attn_out;
+            a.pos_ptr = &m->st->pos;
+            a.q_norm_w = L.q_norm; a.k_norm_w = L.k_norm;
+            a.rope_cos = m->rope_cos; a.rope_sin = m->rope_sin;
+            a.eps = c.rms_norm_eps;
+            if (launch_attn_decode(a, D, true, s)) return 1;
+        }
+        {   // [O GEMV + residual]  model.rs:214,325
+            GemvArgs a = {};
+            a.w0 = L.o; a.n0 = hd; a.N = hd; a.K = m->H * D;
+            a.x = m->attn_out;
+            if (!tp) {
+                a.resid = h; a.out = hn;
+                if (launch_gemv(a, PRO_NONE, EPI_RESIDUAL, s)) return 1;
+                bf16_t* t = h; h = hn; hn = t;
+            } else {
+                a.out = m->partial_a;
+                if (launch_gemv(a, PRO_NONE, EPI_F32, s)) return 1;
+                OMX_REQUIRE(m->allreduce != nullptr, "tp_size > 1 but no communicator set (omx_qwen3_set_comm)");
+                OMX_REQUIRE(m->allreduce(m->partial_a, m->partial_a, hd, kNcclFloat32, kNcclSum, m->comm, s) == 0, "ncclAllReduce failed");
+                pending = m->partial_a;
+            }
+        }
+        {   // [RMSNorm + gate/up GEMV + SwiGLU]  model.rs:263-265,326
+            GemvArgs a = {};
+            a.w0 = L.gate; a.w1 = L.up; a.n0 = m->I; a.N = m->I; a.K = hd;
+            a.x = h; a.x_partial = pending; a.x_out = pending ? hn : nullptr;
+            a.norm_w = L.post_ln; a.eps = c.rms_norm_eps;
+            a.out = m->act;
+            if (launch_gemv(a, PRO_RMSNORM, EPI_SWIGLU, s)) return 1;
+            if (pending) { bf16_t* t = h; h = hn; hn = t; pending = nullptr; }
+        }
+        {   // [down GEMV + residual]  model.rs:266,327
+            GemvArgs a = {};
+            a.w0 = L.down; a.n0 = hd; a.N = hd; a.K = m->I;
+            a.x = m->act;
+            if (!tp) {
+                a.resid = h; a.out = hn;
+                if (launch_gemv(a, PRO_NONE, EPI_RESIDUAL, s)) return 1;
+                bf16_t* t = h; h = hn; hn = t;
+            } else {
+                a.out = m->partial_b;
+                if (launch_gemv(a, PRO_NONE, EPI_F32, s)) return 1;
+                OMX_REQUIRE(m->allreduce(m->partial_b, m->partial_b, hd, kNcclFloat32, kNcclSum, m->comm, s) == 0, "ncclAllReduce failed");
+                pending = m->partial_b;
+            }
+        }
+    }
+    if (with_head) {   // [final RMSNorm + lm_head GEMV + argmax]  model.rs:423,480-489,733-735
+        GemvArgs a = {};
+        a.w0 = m->lm_head; a.n0 = m->V; a.N = m->V; a.K = hd;
+        a.x = h; a.x_partial = pending; a.x_out = nullptr;
+        a.norm_w = m->final_norm; a.eps = c.rms_norm_eps;
+        a.out = m->logits;
+        a.argmax_slot = m->argmax_partials;
+        a.row_offset = c.tp_rank * m->V;
+        if (launch_gemv(a, PRO_RMSNORM, EPI_ARGMAX, s)) return 1;
+        if (!tp) {
+            sample_finalize_kernel<<<1, 256, 0, s>>>(m->st, m->argmax_partials, m->n_argmax_partials, m->out_ring,
+                                                     m->ring_cap, nullptr);
+            OMX_LAUNCH_CHECK();
+        } else {
+            sample_finalize_kernel<<<1, 256, 0, s>>>(m->st, m->argmax_partials, m->n_argmax_partials, m->out_ring,
+                                                     m->ring_cap, m->argmax_key);
+            OMX_LAUNCH_CHECK();
+            OMX_REQUIRE(m->allreduce(m->argmax_key, m->argmax_key, 1, kNcclUint64, kNcclMax, m->comm, s) == 0, "ncclAllReduce failed");
+            apply_token_kernel<<<1, 1, 0, s>>>(m->st, m->argmax_key, m->out_ring, m->ring_cap);
+            OMX_LAUNCH_CHECK();
+        }
+    } else {
+        feed_prompt_kernel<<<1, 1, 0, s>>>(m->st, m->prompt_dev);
+        OMX_LAUNCH_CHECK();
+    }
+    // the step must leave the residual stream roles as it found them for graph replay: h is
+    // rewritten by embed_kernel at the start of every step, so no copy is needed.
+    return 0;
+}
+
+int build_graphs(omx_qwen3 m) {
+    if (m->g_full || m->eager) return 0;
+    if (resolve_weights(m)) return 1;
+    const char* no_graph = getenv("OMX_NO_GRAPH");
+    if (no_graph && no_graph[0] == '1') {
+        m->eager = true;
+        return 0;
+    }
+    for (int which = 0; which < 2; ++which) {
+        hipGraph_t g = nullptr;
+        OMX_HIP_CHECK(hipStreamBeginCapture(m->stream, hipStreamCaptureModeThreadLocal));
+        const int rc = enqueue_step(m, which == 0);
+        hipError_t e = hipStreamEndCapture(m->stream, &g);
+        hipGraphExec_t ge = nullptr;
+        if (!rc && e == hipSuccess) e = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+        if (g) (void)hipGraphDestroy(g);
+        if (rc || e != hipSuccess) {
+            (void)hipGetLastError();
+            if (m->allreduce != nullptr) {
+                // a captured collective was refused: run the same launches eagerly instead
+                if (m->g_full) { (void)hipGraphExecDestroy(m->g_full); m->g_full = nullptr; }
+                m->eager = true;
+                omx_clear_error();
+                return 0;
+            }
+            return rc ? 1 : set_error("step graph capture failed: %s", hipGetErrorString(e));
+        }
+        (which == 0 ? m->g_full : m->g_nohead) = ge;
+    }
+    return 0;
+}
+
+int run_step(omx_qwen3 m, bool with_head) {
+    if (m->eager) return enqueue_step(m, with_head);
+    OMX_HIP_CHECK(hipGraphLaunch(with_head ? m->g_full : m->g_nohead, m->stream));
+    return 0;
+}
+
+template <class T>
+int dev_alloc(omx_qwen3 m, T** p, size_t n) {
+    void* q = nullptr;
+    OMX_HIP_CHECK(hipMalloc(&q, n * sizeof(T) + 64));
+    OMX_HIP_CHECK(hipMemset(q, 0, n * sizeof(T) + 64));
+    *p = (T*)q;
+    m->owned.push_back(q);
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int omx_fill_uniform_2d(void* dst, int64_t rows, int64_t cols, int64_t ld_full, int64_t row0, int64_t col0,
+                        uint32_t seed, float amp, float offset, omx_dtype dtype, omx_stream stream);
+
+int omx_qwen3_create(omx_qwen3* out, const omx_qwen3_config* cfg) {
+    OMX_REQUIRE(out && cfg, "omx_qwen3_create: null argument");
+    const omx_qwen3_config& c = *cfg;
+    OMX_REQUIRE(c.tp_size >= 1 && c.tp_rank >= 0 && c.tp_rank < c.tp_size, "InvalidConfig: tp rank %d of %d", c.tp_rank, c.tp_size);
+    OMX_REQUIRE(c.hidden_size > 0 && c.hidden_size % 512 == 0, "InvalidConfig: hidden_size %d must be a multiple of 512", c.hidden_size);
+    OMX_REQUIRE(c.head_dim == 64 || c.head_dim == 128, "InvalidConfig: head_dim %d (64 or 128 supported)", c.head_dim);
+    OMX_REQUIRE(c.num_attention_heads % c.num_key_value_heads == 0, "InvalidConfig: heads %d not a multiple of kv heads %d", c.num_attention_heads, c.num_key_value_heads);
+    OMX_REQUIRE(c.num_key_value_heads % c.tp_size == 0 && c.intermediate_size % c.tp_size == 0 && c.vocab_size % c.tp_size == 0,
+                "InvalidConfig: kv heads %d / intermediate %d / vocab %d must divide by tp_size %d", c.num_key_value_heads, c.intermediate_size, c.vocab_size, c.tp_size);
+    omx_qwen3 m = new omx_qwen3_();
+    m->cfg = c;
+    if (m->cfg.rope_scale == 0.f) m->cfg.rope_scale = 1.f;
+    m->H = c.num_attention_heads / c.tp_size;
+    m->Hkv = c.num_key_value_heads / c.tp_size;
+    m->I = c.intermediate_size / c.tp_size;
+    m->V = c.vocab_size / c.tp_size;
+    OMX_REQUIRE((m->H * c.head_dim) % 512 == 0 && m->I % 512 == 0, "InvalidConfig: per-rank attention width %d and intermediate %d must be multiples of 512", m->H * c.head_dim, m->I);
+    const int step = 256;   // cache.rs:110-117
+    m->cap = ((c.max_context > 0 ? c.max_context : 4096) + step - 1) / step * step;
+    OMX_HIP_CHECK(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking));
+    OMX_HIP_CHECK(hipEventCreate(&m->ev0));
+    OMX_HIP_CHECK(hipEventCreate(&m->ev1));
+    const int D = c.head_dim, L = c.num_hidden_layers;
+    m->kcache.resize(L);
+    m->vcache.resize(L);
+    for (int l = 0; l < L; ++l) {
+        if (dev_alloc(m, &m->kcache[l], (size_t)m->Hkv * m->cap * D)) return 1;
+        if (dev_alloc(m, &m->vcache[l], (size_t)m->Hkv * m->cap * D)) return 1;
+    }
+    if (dev_alloc(m, &m->rope_cos, (size_t)m->cap * D / 2) || dev_alloc(m, &m->rope_sin, (size_t)m->cap * D / 2)) return 1;
+    {
+        const int n = m->cap * D / 2;
+        rope_table_kernel<<<(n + 255) / 256, 256, 0, m->stream>>>(m->rope_cos, m->rope_sin, m->cap, D / 2,
+                                                                  -log((double)m->cfg.rope_theta) / (double)(D / 2),
+                                                                  (double)m->cfg.rope_scale);
+        OMX_LAUNCH_CHECK();
+    }
+    m->nsplit = (m->cap + 63) / 64;
+    const int cap_splits = (512 + m->Hkv - 1) / m->Hkv;
+    if (m->nsplit > cap_splits) m->nsplit = cap_splits;
+    if (dev_alloc(m, &m->st, 1) || dev_alloc(m, &m->out_ring, (size_t)m->ring_cap) ||
+        dev_alloc(m, &m->h, (size_t)c.hidden_size) || dev_alloc(m, &m->h2, (size_t)c.hidden_size) ||
+        dev_alloc(m, &m->qkv, (size_t)(m->H + 2 * m->Hkv) * D) || dev_alloc(m, &m->attn_out, (size_t)m->H * D) ||
+        dev_alloc(m, &m->act, (size_t)m->I) || dev_alloc(m, &m->logits, (size_t)m->V) ||
+        dev_alloc(m, &m->partial_a, (size_t)c.hidden_size) || dev_alloc(m, &m->partial_b, (size_t)c.hidden_size) ||
+        dev_alloc(m, &m->argmax_key, 1) || dev_alloc(m, &m->ws_o, (size_t)m->H * m->nsplit * D) ||
+        dev_alloc(m, &m->ws_ml, (size_t)m->H * m->nsplit * 2))
+        return 1;
+    m->prompt_cap = m->cap;
+    if (dev_alloc(m, &m->prompt_dev, (size_t)m->prompt_cap + 1)) return 1;
+    m->n_argmax_partials = gemv_grid(m->V, c.hidden_size, 0);
+    if (dev_alloc(m, &m->argmax_partials, (size_t)m->n_argmax_partials)) return 1;
+    OMX_HIP_CHECK(hipStreamSynchronize(m->stream));
+    *out = m;
+    return 0;
+}
+
+int omx_qwen3_destroy(omx_qwen3 m) {
+    if (!m) return 0;
+    if (m->stream) (void)hipStreamSynchronize(m->stream);
+    if (m->g_full) (void)hipGraphExecDestroy(m->g_full);
+    if (m->g_nohead) (void)hipGraphExecDestroy(m->g_nohead);
+    for (void* p : m->owned) (void)hipFree(p);
+    if (m->ev0) (void)hipEventDestroy(m->ev0);
+    if (m->ev1) (void)hipEventDestroy(m->ev1);
+    if (m->stream) (void)hipStreamDestroy(m->stream);
+    delete m;
+    return 0;
+}
+
+int omx_qwen3_set_weight(omx_qwen3 m, const char* name, const void* ptr) {
+    OMX_REQUIRE(m && name && ptr, "omx_qwen3_set_weight: null argument");
+    OMX_REQUIRE(((uintptr_t)ptr & 15u) == 0, "omx_qwen3_set_weight: %s is not 16-byte aligned", name);
+    OMX_REQUIRE(m->g_full == nullptr, "omx_qwen3_set_weight: weights are frozen once the step graph is built");
+    m->named[name] = ptr;
+    m->weights_resolved = false;
+    return 0;
+}
+
+int omx_qwen3_synth_weights(omx_qwen3 m, uint32_t base_seed) {
+    OMX_REQUIRE(m, "omx_qwen3_synth_weights: null model");
+    const omx_qwen3_config& c = m->cfg;
+    const int D = c.head_dim, hd = c.hidden_size, r = c.tp_rank;
+    const float amp_w = (float)(0.02 * sqrt(3.0)), amp_n = (float)(0.01 * sqrt(3.0));   // == oracle/synth.py
+    // logical tensor [rows_full, cols_full]; this rank holds rows [row0, row0+rows) x cols [col0, col0+cols)
+    auto make = [&](const std::string& name, int64_t rows, int64_t cols, int64_t ld_full, int64_t row0, int64_t col0,
+                    bool is_norm) -> int {
+        bf16_t* p = nullptr;
+        if (dev_alloc(m, &p, (size_t)rows * cols)) return 1;
+        const uint32_t seed = base_seed ^ crc32_str(name.c_str());
+        if (omx_fill_uniform_2d(p, rows, cols, ld_full, row0, col0, seed, is_norm ? amp_n : amp_w, is_norm ? 1.0f : 0.0f,
+                                OMX_BFLOAT16, m->stream))
+            return 1;
+        m->named[name] = p;
+        return 0;
+    };
+    const int Hq = m->H * D, Hk = m->Hkv * D;
+    for (int i = 0; i < c.num_hidden_layers; ++i) {
+        const std::string p = "model.layers." + std::to_string(i) + ".";
+        if (make(p + "self_attn.q_proj.weight", Hq, hd, hd, (int64_t)r * Hq, 0, false) ||
+            make(p + "self_attn.k_proj.weight", Hk, hd, hd, (int64_t)r * Hk, 0, false) ||
+            make(p + "self_attn.v_proj.weight", Hk, hd, hd, (int64_t)r * Hk, 0, false) ||
+            make(p + "self_attn.o_proj.weight", hd, Hq, (int64_t)c.num_attention_heads * D, 0, (int64_t)r * Hq, false) ||
+            make(p + "self_attn.q_norm.weight", 1, D, D, 0, 0, true) ||
+            make(p + "self_attn.k_norm.weight", 1, D, D, 0, 0, true) ||
+            make(p + "mlp.gate_proj.weight", m->I, hd, hd, (int64_t)r * m->I, 0, false) ||
+            make(p + "mlp.up_proj.weight", m->I, hd, hd, (int64_t)r * m->I, 0, false) ||
+            make(p + "mlp.down_proj.weight", hd, m->I, c.intermediate_size, 0, (int64_t)r * m->I, false) ||
+            make(p + "input_layernorm.weight", 1, hd, hd, 0, 0, true) ||
+            make(p + "post_attention_layernorm.weight", 1, hd, hd, 0, 0, true))
+            return 1;
+    }
+    if (make("model.embed_tokens.weight", c.vocab_size, hd, hd, 0, 0, false) || make("model.norm.weight", 1, hd, hd, 0, 0, true))
+        return 1;
+    if (!c.tie_word_embeddings) {
+        if (make("lm_head.weight", m->V, hd, hd, (int64_t)r * m->V, 0, false)) return 1;
+    } else if (c.tp_size > 1) {
+        // vocab shard of the tied table, same logical values as model.embed_tokens.weight
+        bf16_t* p = nullptr;
+        if (dev_alloc(m, &p, (size_t)m->V * hd)) return 1;
+        const uint32_t seed = base_seed ^ crc32_str("model.embed_tokens.weight");
+        if (omx_fill_uniform_2d(p, m->V, hd, hd, (int64_t)r * m->V, 0, seed, amp_w, 0.f, OMX_BFLOAT16, m->stream)) return 1;
+        m->named["lm_head.weight"] = p;
+    }
+    OMX_HIP_CHECK(hipStreamSynchronize(m->stream));
+    m->weights_resolved = false;
+    return 0;
+}
+
+int omx_qwen3_set_comm(omx_qwen3 m, void* comm, void* allreduce_fn) {
+    OMX_REQUIRE(m, "omx_qwen3_set_comm: null model");
+    OMX_REQUIRE(m->g_full == nullptr && !m->eager, "omx_qwen3_set_comm: communicator must be set before the first step");
+    m->comm = comm;
+    m->allreduce = (nccl_allreduce_fn)allreduce_fn;
+    return 0;
+}
+
+int omx_qwen3_reset(omx_qwen3 m) {
+    OMX_REQUIRE(m, "omx_qwen3_reset: null model");
+    OMX_HIP_CHECK(hipMemsetAsync(m->st, 0, sizeof(StepState), m->stream));
+    OMX_HIP_CHECK(hipStreamSynchronize(m->stream));
+    return 0;
+}
+
+int omx_qwen3_offset(omx_qwen3 m, int* offset) {
+    OMX_REQUIRE(m && offset, "omx_qwen3_offset: null argument");
+    StepState st;
+    OMX_HIP_CHECK(hipMemcpyAsync(&st, m->st, sizeof(st), hipMemcpyDeviceToHost, m->stream));
+    OMX_HIP_CHECK(hipStreamSynchronize(m->stream));
+    *offset = st.pos;
+    return 0;
+}
+
+int omx_qwen3_prefill(omx_qwen3 m, const uint32_t* prompt, int n_prompt, uint32_t* first_token) {
+    OMX_REQUIRE(m && prompt && first_token, "omx_qwen3_prefill: null argument");
+    OMX_REQUIRE(n_prompt >= 1, "omx_qwen3_prefill: empty prompt");
+    int off = 0;
+    if (omx_qwen3_offset(m, &off)) return 1;
+    OMX_REQUIRE(off + n_prompt + 1 <= m->cap, "omx_qwen3_prefill: %d cached + %d prompt tokens exceed max_context %d", off, n_prompt, m->cap);
+    for (int i = 0; i < n_prompt; ++i) OMX_REQUIRE(prompt[i] < (uint32_t)m->cfg.vocab_size, "omx_qwen3_prefill: token id %u out of range (vocab %d)", prompt[i], m->cfg.vocab_size);
+    OMX_REQUIRE(n_prompt <= m->prompt_cap, "omx_qwen3_prefill: prompt of %d tokens exceeds max_context %d", n_prompt, m->prompt_cap);
+    if (build_graphs(m)) return 1;
+    OMX_HIP_CHECK(hipMemcpyAsync(m->prompt_dev, prompt, (size_t)n_prompt * 4, hipMemcpyHostToDevice, m->stream));
+    StepState st;
+    OMX_HIP_CHECK(hipMemcpyAsync(&st, m->st, sizeof(st), hipMemcpyDeviceToHost, m->stream));
+    OMX_HIP_CHECK(hipStreamSynchronize(m->stream));
+    st.cur_token = prompt[0];
+    st.prompt_idx = 0;
+    const int count_before = st.out_count;
+    OMX_HIP_CHECK(hipMemcpyAsync(m->st, &st, sizeof(st), hipMemcpyHostToDevice, m->stream));
+    // token-serial prefill: identical arithmetic to n_prompt decode steps (the lm_head is skipped for
+    // all but the last prompt position; the reference computes and discards those logits, model.rs:815)
+    for (int i = 0; i < n_prompt - 1; ++i)
+        if (run_step(m, false)) return 1;
+    if (run_step(m, true)) return 1;
+    OMX_HIP_CHECK(hipMemcpyAsync(first_token, m->out_ring + (count_before % m->ring_cap), 4, hipMemcpyDeviceToHost, m->stream));
+    OMX_HIP_CHECK(hipStreamSynchronize(m->stream));
+    return 0;
+}
+
+int omx_qwen3_decode(omx_qwen3 m, int n, uint32_t* tokens_out) {
+    OMX_REQUIRE(m && tokens_out, "omx_qwen3_decode: null argument");
+    OMX_REQUIRE(n >= 0 && n <= m->ring_cap, "omx_qwen3_decode: n=%d out of range (1..%d per call)", n, m->ring_cap);
+    if (n == 0) return 0;
+    if (build_graphs(m)) return 1;
+    StepState st;
+    OMX_HIP_CHECK(hipMemcpyAsync(&st, m->st, sizeof(st), hipMemcpyDeviceToHost, m->stream));
+    OMX_HIP_CHECK(hipStreamSynchronize(m->stream));
+    OMX_REQUIRE(st.pos + n <= m->cap, "omx_qwen3_decode: %d cached + %d new tokens exceed max_context %d", st.pos, n, m->cap);
+    OMX_HIP_CHECK(hipEventRecord(m->ev0, m->stream));
+    for (int i = 0; i < n; ++i)
+        if (run_step(m, true)) return 1;
+    OMX_HIP_CHECK(hipEventRecord(m->ev1, m->stream));
+    OMX_HIP_CHECK(hipStreamSynchronize(m->stream));
+    OMX_HIP_CHECK(hipEventElapsedTime(&m->last_decode_ms, m->ev0, m->ev1));
+    std::vector<uint32_t> ring(m->ring_cap);
+    OMX_HIP_CHECK(hipMemcpy(ring.data(), m->out_ring, (size_t)m->ring_cap * 4, hipMemcpyDeviceToHost));
+    for (int i = 0; i < n; ++i) tokens_out[i] = ring[(st.out_count + i) % m->ring_cap];
+    return 0;
+}
+
+int omx_qwen3_last_logits(omx_qwen3 m, void* host_bf16, int n) {
+    OMX_REQUIRE(m && host_bf16, "omx_qwen3_last_logits: null argument");
+    OMX_REQUIRE(n == m->V, "omx_qwen3_last_logits: expected %d entries, got %d", m->V, n);
+    OMX_HIP_CHECK(hipMemcpyAsync(host_bf16, m->logits, (size_t)n * 2, hipMemcpyDeviceToHost, m->stream));
+    OMX_HIP_CHECK(hipStreamSynchronize(m->stream));
+    return 0;
+}
+
+int omx_qwen3_last_decode_ms(omx_qwen3 m, float* ms) {
+    OMX_REQUIRE(m && ms, "omx_qwen3_last_decode_ms: null argument");
+    *ms = m->last_decode_ms;
+    return 0;
+}
+
+int omx_qwen3_stream(omx_qwen3 m, omx_stream* s) {
+    OMX_REQUIRE(m && s, "omx_qwen3_stream: null argument");
+    *s = (omx_stream)m->stream;
+    return 0;
+}
+
+int omx_qwen3_step_bytes(omx_qwen3 m, int ctx, double* bytes) {
+    OMX_REQUIRE(m && bytes, "omx_qwen3_step_bytes: null argument");
+    const omx_qwen3_config& c = m->cfg;
+    const double D = c.head_dim, hd = c.hidden_size;
+    // 2 B x [L (h H D + 2 h Hkv D + H D h + 3 h I) + V h] + ctx (2 L Hkv D 2 B) + KV write
+    const double per_layer = hd * m->H * D + 2.0 * hd * m->Hkv * D + m->H * D * hd + 3.0 * hd * m->I;
+    const double w = 2.0 * (c.num_hidden_layers * per_layer + (double)m->V * hd);
+    const double kv = (double)ctx * (2.0 * c.num_hidden_layers * m->Hkv * D * 2.0) + 2.0 * c.num_hidden_layers * m->Hkv * D * 2.0;
+    *bytes = w + kv;
+    return 0;
+}
+
+}  // extern "C"

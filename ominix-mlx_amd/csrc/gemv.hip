@@ -38,7 +38,7 @@ __device__ __forceinline__ uint64_t argmax_key(float v, uint32_t idx) {
 }
 
 template <int EPI>
-__device__ __forceinline__ void epilogue(const GemvArgs& a, int row, float v0, float v1) {
+__device__ __forceinline__ void epilogue(const GemvArgs& a, int row, float v0, float v1, uint64_t& best) {
     if (EPI == EPI_STORE) {
         reinterpret_cast<bf16_t*>(a.out)[row] = f32_to_bf16(v0);
     } else if (EPI == EPI_F32) {
@@ -55,7 +55,8 @@ __device__ __forceinline__ void epilogue(const GemvArgs& a, int row, float v0, f
     } else if (EPI == EPI_ARGMAX) {
         const bf16_t lb = f32_to_bf16(v0);
         reinterpret_cast<bf16_t*>(a.out)[row] = lb;
-        atomicMax(a.argmax_slot, argmax_key(bf16_to_f32(lb), (uint32_t)(row + a.row_offset)));
+        const uint64_t key = argmax_key(bf16_to_f32(lb), (uint32_t)(row + a.row_offset));
+        best = key > best ? key : best;
     }
 }
 
@@ -70,7 +71,7 @@ __global__ __launch_bounds__(kBlock) void gemv_kernel(const GemvArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     u32x4* xs = reinterpret_cast<u32x4*>(smem);                            // [NV*64] packed bf16 activation
     float* red = reinterpret_cast<float*>(smem + (size_t)NV * 64 * 16);    // [4] block-reduce scratch
-    float* part = red + 4;                                                 // KSPLIT>1: [rows][LR][KSPLIT]
+    float* part = red + 8;                                                 // KSPLIT>1: [rows][LR][KSPLIT]
 
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -83,6 +84,7 @@ __global__ __launch_bounds__(kBlock) void gemv_kernel(const GemvArgs a) {
     const int koff = (KSPLIT == 1) ? 0 : wave * NVW * 64;   // first vector of this wave's K slice
 
     u32x4 wA[NR][NVW], wB[NR][NVW];
+    uint64_t best = 0;   // EPI_ARGMAX: running (orderable logit << 32 | ~row) of this thread
 
 #define OMX_ISSUE(WB, R0)                                                                          \
     {                                                                                              \
@@ -121,7 +123,7 @@ __global__ __launch_bounds__(kBlock) void gemv_kernel(const GemvArgs a) {
                 const int row = (R0) + r;                                                          \
                 if (row < row_end) {                                                               \
                     if (KSPLIT == 1) {                                                             \
-                        epilogue<EPI>(a, row, acc[LR * r], acc[LR * r + (LR - 1)]);                \
+                        epilogue<EPI>(a, row, acc[LR * r], acc[LR * r + (LR - 1)], best);          \
                     } else {                                                                       \
                         const int lr = row - row_begin;                                            \
                         part[(lr * LR) * KSPLIT + wave] = acc[LR * r];                             \
@@ -213,7 +215,26 @@ __global__ __launch_bounds__(kBlock) void gemv_kernel(const GemvArgs a) {
                 v0 += part[(lr * LR) * KSPLIT + w];
                 if (LR == 2) v1 += part[(lr * LR + 1) * KSPLIT + w];
             }
-            epilogue<EPI>(a, row_begin + lr, v0, v1);
+            epilogue<EPI>(a, row_begin + lr, v0, v1, best);
+        }
+    }
+    if (EPI == EPI_ARGMAX) {
+        // one partial per block (no same-address atomics: 150k of them serialise at ~12 ns each);
+        // argmax_finalize in engine.hip reduces the partials
+        uint64_t* bred = reinterpret_cast<uint64_t*>(red);   // 4 x u64 = first 32 B of the scratch
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const uint64_t other = __shfl_xor(best, o, 64);
+            best = other > best ? other : best;
+        }
+        __syncthreads();
+        if (lane == 0) bred[wave] = best;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint64_t b = bred[0];
+#pragma unroll
+            for (int w = 1; w < kWaves; ++w) b = bred[w] > b ? bred[w] : b;
+            a.argmax_slot[blockIdx.x] = b;
         }
     }
 #undef OMX_ISSUE
@@ -224,7 +245,7 @@ template <int NVW, int KSPLIT, int RB>
 int launch_nv(const GemvArgs& a, int pro, int epi, hipStream_t s) {
     const int groups = (a.N + a.rows_per_wave - 1) / a.rows_per_wave;   // row groups (waves or blocks)
     const dim3 grid(KSPLIT == 1 ? (groups + kWaves - 1) / kWaves : groups), block(kBlock);
-    const size_t shmem = (size_t)NVW * KSPLIT * 64 * 16 + 16 + (KSPLIT > 1 ? (size_t)a.rows_per_wave * 2 * KSPLIT * 4 : 0);
+    const size_t shmem = (size_t)NVW * KSPLIT * 64 * 16 + 32 + (KSPLIT > 1 ? (size_t)a.rows_per_wave * 2 * KSPLIT * 4 : 0);
 #define OMX_GEMV_CASE(P, E)                                                                          \
     if (pro == P && epi == E) {                                                                      \
         gemv_kernel<NVW, KSPLIT, (E == EPI_SWIGLU ? (RB > 1 ? RB / 2 : 1) : RB), P, E><<<grid, block, shmem, s>>>(a); \
@@ -244,20 +265,31 @@ int launch_nv(const GemvArgs& a, int pro, int epi, hipStream_t s) {
 
 }  // namespace
 
+static int resolve_rpw(int N, int K, int rpw) {
+    const bool split = (K / 512) > 8;
+    if (rpw <= 0) {
+        // ~3072 row groups: ~12 waves per CU on 256 CUs when a wave owns its rows
+        rpw = (N + 3071) / 3072;
+        if (split) rpw = (N + 1023) / 1024;   // 4 waves share a group
+        if (rpw < 2) rpw = 2;
+        if (!split && N >= 65536) rpw = 16;    // long streams (lm_head): amortise the prologue
+    }
+    if (split && rpw > 256) rpw = 256;
+    return rpw;
+}
+
+int gemv_grid(int N, int K, int rows_per_wave) {
+    const int rpw = resolve_rpw(N, K, rows_per_wave);
+    const int groups = (N + rpw - 1) / rpw;
+    return (K / 512) > 8 ? groups : (groups + kWaves - 1) / kWaves;
+}
+
 int launch_gemv(const GemvArgs& a_in, int pro, int epi, hipStream_t s) {
     GemvArgs a = a_in;
     OMX_REQUIRE(a.K > 0 && a.K % 512 == 0, "gemv: K=%d must be a positive multiple of 512", a.K);
     OMX_REQUIRE(a.N > 0, "gemv: N must be positive");
     const int nv = a.K / 512;
-    const bool split = nv > 8;
-    if (a.rows_per_wave <= 0) {
-        // ~3072 row groups: ~12 waves per CU on 256 CUs when a wave owns its rows
-        int rpw = (a.N + 3071) / 3072;
-        if (split) rpw = (a.N + 1023) / 1024;   // 4 waves share a group
-        if (rpw < 2) rpw = 2;
-        a.rows_per_wave = rpw;
-    }
-    if (split && a.rows_per_wave > 256) a.rows_per_wave = 256;
+    a.rows_per_wave = resolve_rpw(a.N, a.K, a.rows_per_wave);
     switch (nv) {
         // RB*NVW ~ 16 x 1-KiB loads in flight per wave per register set
         case 1: return launch_nv<1, 1, 8>(a, pro, epi, s);

@@ -39,11 +39,13 @@ struct GemvArgs {
     const bf16_t* resid;        // [N] (EPI_RESIDUAL)
     void* out;                  // [N] bf16 (f32 for EPI_F32)
     bf16_t* x_out;              // optional [K]: block 0 writes the (x + x_partial) it consumed (residual stream)
-    unsigned long long* argmax_slot;   // EPI_ARGMAX: atomicMax of (orderable(logit)<<32 | ~row)
+    unsigned long long* argmax_slot;   // EPI_ARGMAX: [gridDim.x] per-block max of (orderable(logit)<<32 | ~row)
     int row_offset;             // EPI_ARGMAX: global row index offset (vocab shard)
     int rows_per_wave;
 };
 
 int launch_gemv(const GemvArgs& a, int pro, int epi, hipStream_t s);
+// number of blocks launch_gemv will use (== entries written to argmax_slot); resolves rows_per_wave
+int gemv_grid(int N, int K, int rows_per_wave);
 
 }  // namespace omx

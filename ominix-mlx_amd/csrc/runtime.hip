@@ -122,7 +122,43 @@ __global__ void fill_uniform_kernel(typename omx::Elem<DT>::T* dst, size_t n, ui
         omx::Elem<DT>::st(dst + i, __fadd_rn(offset, __fmul_rn(amp, t)));
     }
 }
+template <int DT>
+__global__ void fill_uniform_2d_kernel(typename omx::Elem<DT>::T* dst, int64_t rows, int64_t cols, int64_t ld_full,
+                                       int64_t row0, int64_t col0, uint32_t seed, float amp, float offset) {
+    const int64_t n = rows * cols;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        const int64_t r = i / cols, c = i % cols;
+        const uint64_t logical = (uint64_t)((row0 + r) * ld_full + col0 + c);
+        const float u = (float)(hash_u32(logical, seed) >> 8) * (1.0f / 16777216.0f);
+        const float t = __fsub_rn(__fmul_rn(2.0f, u), 1.0f);
+        omx::Elem<DT>::st(dst + i, __fadd_rn(offset, __fmul_rn(amp, t)));
+    }
+}
 }  // namespace
+
+extern "C" int omx_fill_uniform_2d(void* dst, int64_t rows, int64_t cols, int64_t ld_full, int64_t row0, int64_t col0,
+                                   uint32_t seed, float amp, float offset, omx_dtype dtype, omx_stream stream) {
+    OMX_REQUIRE(dst && rows >= 0 && cols >= 0 && ld_full >= cols, "omx_fill_uniform_2d: bad arguments");
+    const int64_t n = rows * cols;
+    if (n == 0) return 0;
+    int64_t want = (n + 255) / 256;
+    const int blocks = (int)(want < 8192 ? want : 8192);
+    hipStream_t s = (hipStream_t)stream;
+    switch (dtype) {
+        case OMX_BFLOAT16:
+            fill_uniform_2d_kernel<OMX_BFLOAT16><<<blocks, 256, 0, s>>>((omx::bf16_t*)dst, rows, cols, ld_full, row0, col0, seed, amp, offset);
+            break;
+        case OMX_FLOAT32:
+            fill_uniform_2d_kernel<OMX_FLOAT32><<<blocks, 256, 0, s>>>((float*)dst, rows, cols, ld_full, row0, col0, seed, amp, offset);
+            break;
+        default:
+            return omx::set_error("omx_fill_uniform_2d: unsupported dtype %d", (int)dtype);
+    }
+    OMX_LAUNCH_CHECK();
+    return 0;
+}
 
 extern "C" int omx_fill_uniform(void* dst, size_t n, uint32_t seed, float amp, float offset, omx_dtype dtype,
                                 omx_stream stream) {

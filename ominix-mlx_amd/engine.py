@@ -1,0 +1,161 @@
+"""Host mirror of qwen3-mlx's `Model` + `Generate` (qwen3-mlx/src/model.rs:473-498, 743-844)
+over the fused decode engine of libomx_hip.so (include/omx.h, omx_qwen3_*)."""
+from __future__ import annotations
+
+import ctypes
+from typing import Dict, Iterator, Optional
+
+import numpy as np
+
+from . import OmxError, check, lib, require_device
+from .ops import Tensor
+
+c_int, c_float, c_void_p, c_uint32 = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_uint32
+
+
+class Qwen3Config(ctypes.Structure):
+    """omx_qwen3_config == the ModelArgs fields the forward uses (model.rs:47-64)."""
+    _fields_ = [("hidden_size", c_int), ("num_hidden_layers", c_int), ("intermediate_size", c_int),
+                ("num_attention_heads", c_int), ("num_key_value_heads", c_int), ("head_dim", c_int),
+                ("vocab_size", c_int), ("rms_norm_eps", c_float), ("rope_theta", c_float), ("rope_scale", c_float),
+                ("tie_word_embeddings", c_int), ("max_context", c_int), ("tp_rank", c_int), ("tp_size", c_int)]
+
+
+ENGINE_SIGNATURES = {
+    "omx_fill_uniform_2d": (c_int, [c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
+                                    ctypes.c_int64, c_uint32, c_float, c_float, c_int, c_void_p]),
+    "omx_qwen3_create": (c_int, [ctypes.POINTER(c_void_p), ctypes.POINTER(Qwen3Config)]),
+    "omx_qwen3_destroy": (c_int, [c_void_p]),
+    "omx_qwen3_set_weight": (c_int, [c_void_p, ctypes.c_char_p, c_void_p]),
+    "omx_qwen3_synth_weights": (c_int, [c_void_p, c_uint32]),
+    "omx_qwen3_set_comm": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "omx_qwen3_reset": (c_int, [c_void_p]),
+    "omx_qwen3_offset": (c_int, [c_void_p, ctypes.POINTER(c_int)]),
+    "omx_qwen3_prefill": (c_int, [c_void_p, ctypes.POINTER(c_uint32), c_int, ctypes.POINTER(c_uint32)]),
+    "omx_qwen3_decode": (c_int, [c_void_p, c_int, ctypes.POINTER(c_uint32)]),
+    "omx_qwen3_last_logits": (c_int, [c_void_p, c_void_p, c_int]),
+    "omx_qwen3_last_decode_ms": (c_int, [c_void_p, ctypes.POINTER(c_float)]),
+    "omx_qwen3_stream": (c_int, [c_void_p, ctypes.POINTER(c_void_p)]),
+    "omx_qwen3_step_bytes": (c_int, [c_void_p, c_int, ctypes.POINTER(ctypes.c_double)]),
+}
+for _n, (_r, _a) in ENGINE_SIGNATURES.items():
+    _f = getattr(lib, _n)
+    _f.restype, _f.argtypes = _r, _a
+
+
+def rope_scale_from_config(rope_scaling: Optional[dict]) -> float:
+    """mlx_rs_core::initialize_rope (utils.rs:52-97): only default / linear are accepted."""
+    rope_type = "default"
+    if rope_scaling is not None:
+        rope_type = rope_scaling.get("type", rope_scaling.get("rope_type", "default"))
+    if rope_type == "default":
+        return 1.0
+    if rope_type == "linear":
+        if "factor" not in rope_scaling:
+            raise OmxError('key "factor" is not found in scaling config')
+        try:
+            return 1.0 / float(rope_scaling["factor"])
+        except (TypeError, ValueError):
+            raise OmxError('key "factor" is not a valid float')
+    raise OmxError(f"Unsupported RoPE type {rope_type!r}")
+
+
+class Model:
+    """qwen3_mlx::Model (dense Qwen3) resident on one MI355X (or one TP shard of it)."""
+
+    def __init__(self, *, hidden_size, num_hidden_layers, intermediate_size, num_attention_heads,
+                 num_key_value_heads, head_dim, vocab_size, rms_norm_eps=1e-6, rope_theta=1e6,
+                 tie_word_embeddings=False, rope_scaling=None, max_context=4096, tp_rank=0, tp_size=1, **_ignored):
+        require_device()
+        self.cfg = Qwen3Config(hidden_size, num_hidden_layers, intermediate_size, num_attention_heads,
+                               num_key_value_heads, head_dim, vocab_size, rms_norm_eps, rope_theta,
+                               rope_scale_from_config(rope_scaling), int(bool(tie_word_embeddings)), max_context,
+                               tp_rank, tp_size)
+        self._h = c_void_p()
+        check(lib.omx_qwen3_create(ctypes.byref(self._h), ctypes.byref(self.cfg)))
+        self._keep = []
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h is not None and h.value:
+            lib.omx_qwen3_destroy(h)
+            self._h = c_void_p()
+
+    @property
+    def vocab_local(self) -> int:
+        return self.cfg.vocab_size // self.cfg.tp_size
+
+    def load_weights(self, weights: Dict[str, np.ndarray]) -> None:
+        """ModuleParametersExt::load_safetensors equivalent for in-memory arrays keyed by HF name."""
+        for name, arr in weights.items():
+            t = Tensor.from_numpy(arr, "bf16")
+            self._keep.append(t)
+            check(lib.omx_qwen3_set_weight(self._h, name.encode(), t.ptr))
+
+    def synth_weights(self, base_seed: int = 0x0C0FFEE5) -> None:
+        check(lib.omx_qwen3_synth_weights(self._h, base_seed & 0xFFFFFFFF))
+
+    def set_comm(self, comm_ptr: int, allreduce_fn_ptr: int) -> None:
+        check(lib.omx_qwen3_set_comm(self._h, comm_ptr, allreduce_fn_ptr))
+
+    def reset(self) -> None:
+        check(lib.omx_qwen3_reset(self._h))
+
+    def offset(self) -> int:
+        v = c_int()
+        check(lib.omx_qwen3_offset(self._h, ctypes.byref(v)))
+        return v.value
+
+    def prefill(self, prompt) -> int:
+        p = np.ascontiguousarray(prompt, dtype=np.uint32)
+        first = c_uint32()
+        check(lib.omx_qwen3_prefill(self._h, p.ctypes.data_as(ctypes.POINTER(c_uint32)), p.size, ctypes.byref(first)))
+        return first.value
+
+    def decode(self, n: int) -> np.ndarray:
+        out = np.empty(n, dtype=np.uint32)
+        check(lib.omx_qwen3_decode(self._h, n, out.ctypes.data_as(ctypes.POINTER(c_uint32))))
+        return out
+
+    def last_decode_ms(self) -> float:
+        v = c_float()
+        check(lib.omx_qwen3_last_decode_ms(self._h, ctypes.byref(v)))
+        return v.value
+
+    def last_logits(self) -> np.ndarray:
+        raw = np.empty(self.vocab_local, dtype=np.uint16)
+        check(lib.omx_qwen3_last_logits(self._h, raw.ctypes.data, raw.size))
+        return (raw.astype(np.uint32) << np.uint32(16)).view(np.float32)
+
+    def stream(self) -> int:
+        s = c_void_p()
+        check(lib.omx_qwen3_stream(self._h, ctypes.byref(s)))
+        return s.value or 0
+
+    def step_bytes(self, ctx: int) -> float:
+        v = ctypes.c_double()
+        check(lib.omx_qwen3_step_bytes(self._h, ctx, ctypes.byref(v)))
+        return v.value
+
+
+class Generate:
+    """qwen3_mlx::Generate (model.rs:743-844): iterator yielding greedy tokens; the first `next`
+    prefills the prompt.  temp must be 0 (the greedy path of sample(), model.rs:733-735)."""
+
+    def __init__(self, model: Model, temp: float, prompt_token, chunk: int = 16):
+        if temp != 0.0:
+            raise OmxError("Generate: only temp == 0 (greedy) is implemented on the fused engine")
+        self.model, self.prompt, self.chunk = model, np.asarray(prompt_token, dtype=np.uint32).ravel(), chunk
+        self._prefilled = False
+        self._buf = []
+
+    def __iter__(self) -> Iterator[int]:
+        return self
+
+    def __next__(self) -> int:
+        if not self._prefilled:
+            self._prefilled = True
+            return self.model.prefill(self.prompt)
+        if not self._buf:
+            self._buf = list(self.model.decode(self.chunk))
+        return int(self._buf.pop(0))

@@ -230,7 +230,7 @@ def test_linear_decode_parity(omx, N, K):
     got = omx.ops.linear(T.from_numpy(x), T.from_numpy(w)).numpy()
     ref = rc.linear(x, w, None, "bf16")
     assert got.shape == (1, N)
-    assert_bf16_close(got, ref, 1, atol=1e-30)
+    assert_bf16_close(got, ref, 1, atol=1e-5)   # near-zero dot products: fp32 accumulation-order noise
 
 
 def test_linear_small_batch(omx):

@@ -1,0 +1,113 @@
+"""GPU parity of the fused decode engine against the CPU restatement of qwen3-mlx
+(oracle/ref_qwen3.py): greedy token ids and last-step logits on tiny Qwen3-shaped models
+(SURVEY.md section 7 step 0 fixture protocol: 128-token synthetic prompt, greedy).
+
+Tolerance: logits max-abs-diff <= 2^-7 * max|logit| (bf16 kernels vs order-free restatement);
+token ids must be EQUAL wherever the oracle's top-1/top-2 margin exceeds twice that bound
+(fp32 summation order differs, SURVEY.md section 7 "hard parts" (i))."""
+import numpy as np
+import pytest
+
+from oracle import ref_core as rc
+from oracle import ref_qwen3 as rq
+from oracle import synth
+
+pytestmark = pytest.mark.gpu
+
+CONFIGS = {
+    # hidden, layers, inter, heads, kv_heads, head_dim, vocab, tied
+    "gqa2_d64": rq.Qwen3Config(512, 2, 1536, 8, 4, 64, 2048, 1e-6, 1e6, False),
+    "gqa4_d128": rq.Qwen3Config(1024, 3, 3072, 8, 2, 128, 4096, 1e-6, 1e6, True),
+    "mha_d128_linear_rope": rq.Qwen3Config(512, 2, 1024, 4, 4, 128, 1000 // 8 * 8, 1e-5, 1e4, False,
+                                           {"type": "linear", "factor": 2.0}),
+}
+
+
+def _engine(omx, cfg, weights=None, max_context=512):
+    from ominix_mlx_amd import engine
+    m = engine.Model(hidden_size=cfg.hidden_size, num_hidden_layers=cfg.num_hidden_layers,
+                     intermediate_size=cfg.intermediate_size, num_attention_heads=cfg.num_attention_heads,
+                     num_key_value_heads=cfg.num_key_value_heads, head_dim=cfg.head_dim, vocab_size=cfg.vocab_size,
+                     rms_norm_eps=cfg.rms_norm_eps, rope_theta=cfg.rope_theta,
+                     tie_word_embeddings=cfg.tie_word_embeddings, rope_scaling=cfg.rope_scaling,
+                     max_context=max_context)
+    if weights is None:
+        m.synth_weights()
+    else:
+        m.load_weights(weights)
+    return m
+
+
+@pytest.mark.parametrize("name", list(CONFIGS))
+def test_greedy_decode_matches_oracle(omx, name):
+    cfg = CONFIGS[name]
+    weights = rq.synth_weights(cfg)
+    oracle = rq.Qwen3Oracle(cfg, weights)
+    n_prompt, n_new = 128, 12
+    prompt = synth.prompt_ids(n_prompt, cfg.vocab_size)
+    ref_tokens, ref_logits = oracle.generate(prompt, n_new, return_logits=True)
+
+    m = _engine(omx, cfg)                      # device-side synthetic weights (bit-identical generator)
+    first = m.prefill(prompt)
+    logits0 = m.last_logits()
+    rest = m.decode(n_new - 1)
+    got = np.concatenate([[first], rest]).astype(np.uint32)
+    assert m.offset() == n_prompt + n_new - 1   # KeyValueCache::offset after the loop
+
+    bound = 2.0 ** -7 * np.abs(ref_logits).max()
+    assert np.abs(logits0 - ref_logits[0]).max() <= bound
+    margins = rc.argmax_margin(ref_logits)
+    for i in range(n_new):
+        if got[i] != ref_tokens[i]:
+            assert margins[i] <= 2 * bound, f"token {i}: got {got[i]} want {ref_tokens[i]} with margin {margins[i]:.4f} > {2*bound:.4f}"
+            break                                # sequences legitimately diverge after a near-tie
+    else:
+        np.testing.assert_array_equal(got, ref_tokens)
+    # last-step logits, when no divergence happened
+    if np.array_equal(got, ref_tokens):
+        assert np.abs(m.last_logits() - ref_logits[-1]).max() <= bound
+
+
+def test_uploaded_weights_equal_synth_weights(omx):
+    """load_weights (host arrays by HF key) and synth_weights (device generator) give the same model."""
+    cfg = CONFIGS["gqa2_d64"]
+    prompt = synth.prompt_ids(40, cfg.vocab_size)
+    a = _engine(omx, cfg)
+    b = _engine(omx, cfg, rq.synth_weights(cfg))
+    ta = np.concatenate([[a.prefill(prompt)], a.decode(8)])
+    tb = np.concatenate([[b.prefill(prompt)], b.decode(8)])
+    np.testing.assert_array_equal(ta, tb)
+    np.testing.assert_array_equal(a.last_logits(), b.last_logits())
+
+
+def test_reset_and_generate_iterator(omx):
+    """KVCache::reset (cache.rs:130-132) + Generate iterator protocol (model.rs:804-843)."""
+    from ominix_mlx_amd import engine
+    cfg = CONFIGS["gqa2_d64"]
+    prompt = synth.prompt_ids(33, cfg.vocab_size)
+    m = _engine(omx, cfg)
+    it = engine.Generate(m, 0.0, prompt, chunk=4)
+    first_run = [next(it) for _ in range(9)]
+    m.reset()
+    assert m.offset() == 0
+    it = engine.Generate(m, 0.0, prompt, chunk=3)
+    second_run = [next(it) for _ in range(9)]
+    assert first_run == second_run
+    with pytest.raises(omx.OmxError):
+        engine.Generate(m, 0.7, prompt)
+
+
+def test_missing_weight_and_context_overflow_are_errors(omx):
+    from ominix_mlx_amd import engine
+    cfg = CONFIGS["gqa2_d64"]
+    m = engine.Model(hidden_size=cfg.hidden_size, num_hidden_layers=cfg.num_hidden_layers,
+                     intermediate_size=cfg.intermediate_size, num_attention_heads=cfg.num_attention_heads,
+                     num_key_value_heads=cfg.num_key_value_heads, head_dim=cfg.head_dim, vocab_size=cfg.vocab_size,
+                     max_context=256)
+    with pytest.raises(omx.OmxError, match="WeightNotFound"):
+        m.prefill([1, 2, 3])
+    m2 = _engine(omx, cfg, max_context=256)
+    with pytest.raises(omx.OmxError, match="exceed"):
+        m2.prefill(synth.prompt_ids(300, cfg.vocab_size))
+    with pytest.raises(omx.OmxError, match="out of range"):
+        m2.prefill([cfg.vocab_size + 5])

@@ -341,7 +341,9 @@ template <class T>
 int dev_alloc(omx_qwen3 m, T** p, size_t n) {
     void* q = nullptr;
     OMX_HIP_CHECK(hipMalloc(&q, n * sizeof(T) + 64));
-    OMX_HIP_CHECK(hipMemset(q, 0, n * sizeof(T) + 64));
+    // same stream as every later writer: a null-stream hipMemset is not ordered against the
+    // engine's non-blocking stream and could zero a buffer after it was filled
+    OMX_HIP_CHECK(hipMemsetAsync(q, 0, n * sizeof(T) + 64, m->stream));
     *p = (T*)q;
     m->owned.push_back(q);
     return 0;
@@ -559,6 +561,27 @@ int omx_qwen3_last_logits(omx_qwen3 m, void* host_bf16, int n) {
     OMX_REQUIRE(m && host_bf16, "omx_qwen3_last_logits: null argument");
     OMX_REQUIRE(n == m->V, "omx_qwen3_last_logits: expected %d entries, got %d", m->V, n);
     OMX_HIP_CHECK(hipMemcpyAsync(host_bf16, m->logits, (size_t)n * 2, hipMemcpyDeviceToHost, m->stream));
+    OMX_HIP_CHECK(hipStreamSynchronize(m->stream));
+    return 0;
+}
+
+/* test/debug hook: copy an internal bf16 buffer to the host ("h","h2","qkv","attn_out","act","k<l>","v<l>") */
+int omx_qwen3_debug_read(omx_qwen3 m, const char* name, void* host, size_t n_elems) {
+    OMX_REQUIRE(m && name && host, "omx_qwen3_debug_read: null argument");
+    const void* src = nullptr;
+    const std::string s(name);
+    if (s == "h") src = m->h;
+    else if (s == "h2") src = m->h2;
+    else if (s == "qkv") src = m->qkv;
+    else if (s == "attn_out") src = m->attn_out;
+    else if (s == "act") src = m->act;
+    else if (s.size() > 1 && (s[0] == 'k' || s[0] == 'v')) {
+        const int l = atoi(s.c_str() + 1);
+        OMX_REQUIRE(l >= 0 && l < (int)m->kcache.size(), "omx_qwen3_debug_read: bad layer in %s", name);
+        src = s[0] == 'k' ? m->kcache[l] : m->vcache[l];
+    }
+    OMX_REQUIRE(src != nullptr, "omx_qwen3_debug_read: unknown buffer %s", name);
+    OMX_HIP_CHECK(hipMemcpyAsync(host, src, n_elems * 2, hipMemcpyDeviceToHost, m->stream));
     OMX_HIP_CHECK(hipStreamSynchronize(m->stream));
     return 0;
 }

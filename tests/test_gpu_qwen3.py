@@ -2,9 +2,11 @@
 (oracle/ref_qwen3.py): greedy token ids and last-step logits on tiny Qwen3-shaped models
 (SURVEY.md section 7 step 0 fixture protocol: 128-token synthetic prompt, greedy).
 
-Tolerance: logits max-abs-diff <= 2^-7 * max|logit| (bf16 kernels vs order-free restatement);
-token ids must be EQUAL wherever the oracle's top-1/top-2 margin exceeds twice that bound
-(fp32 summation order differs, SURVEY.md section 7 "hard parts" (i))."""
+Tolerance: logits max-abs-diff <= 2^-7 * max|logit| * sqrt(n_layers) (one bf16 ulp of the
+largest logit per layer, accumulating as a random walk: bf16 kernels vs the order-free
+restatement round the same op outputs differently at ties); token ids must be EQUAL wherever
+the oracle's top-1/top-2 margin exceeds twice that bound (fp32 summation order differs,
+SURVEY.md section 7 "hard parts" (i))."""
 import numpy as np
 import pytest
 
@@ -54,7 +56,7 @@ def test_greedy_decode_matches_oracle(omx, name):
     got = np.concatenate([[first], rest]).astype(np.uint32)
     assert m.offset() == n_prompt + n_new - 1   # KeyValueCache::offset after the loop
 
-    bound = 2.0 ** -7 * np.abs(ref_logits).max()
+    bound = 2.0 ** -7 * np.abs(ref_logits).max() * np.sqrt(cfg.num_hidden_layers)
     assert np.abs(logits0 - ref_logits[0]).max() <= bound
     margins = rc.argmax_margin(ref_logits)
     for i in range(n_new):

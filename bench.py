@@ -198,6 +198,7 @@ def main():
     dev_ms = model.last_decode_ms()
 
     if rank != 0:
+        model.close()
         return
     ctx_mid = args.prompt + args.warmup + args.steps // 2
     step_bytes = model.step_bytes(ctx_mid) * world       # whole-job algorithmic bytes per token
@@ -230,6 +231,7 @@ def main():
         except Exception as e:   # the baseline is a report, never a reason to lose the measured line
             out["cpu_baseline"] = {"value": None, "unit": "tokens/s", "cores": os.cpu_count(), "kind": "port",
                                    "sample": f"failed: {e}"}
+    model.close()
     print(json.dumps(out), flush=True)
 
 

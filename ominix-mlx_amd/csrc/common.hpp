@@ -63,15 +63,42 @@ template <> struct Elem<OMX_FLOAT32> {
 };
 
 // ---- wave64 reductions -------------------------------------------------------
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+// Cross-lane traffic stays in the VALU: DPP inside a 16-lane row (quad_perm xor1 / xor2,
+// row_half_mirror, row_mirror), v_readlane across the four rows.  The LDS-crossbar route
+// (__shfl_xor -> ds_bpermute_b32) costs ~100+ cycles per dependent step and hipcc serialises
+// every step behind an s_waitcnt: 144 of them were 8 us of a 9 us decode-attention kernel.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+constexpr int kDppXor1 = 0xB1, kDppXor2 = 0x4E, kDppHalfMirror = 0x141, kDppRowMirror = 0x140;
+__device__ __forceinline__ float readlane_f(float v, int lane) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+// sum over aligned groups of N lanes (N = 4, 8, 16); every lane of the group gets the result
+template <int N>
+__device__ __forceinline__ float group_sum(float v) {
+    v += dpp_f<kDppXor1>(v);
+    v += dpp_f<kDppXor2>(v);
+    if (N >= 8) v += dpp_f<kDppHalfMirror>(v);
+    if (N >= 16) v += dpp_f<kDppRowMirror>(v);
     return v;
 }
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+template <int N>
+__device__ __forceinline__ float group_max(float v) {
+    v = fmaxf(v, dpp_f<kDppXor1>(v));
+    v = fmaxf(v, dpp_f<kDppXor2>(v));
+    if (N >= 8) v = fmaxf(v, dpp_f<kDppHalfMirror>(v));
+    if (N >= 16) v = fmaxf(v, dpp_f<kDppRowMirror>(v));
     return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+    v = group_sum<16>(v);
+    return (readlane_f(v, 0) + readlane_f(v, 16)) + (readlane_f(v, 32) + readlane_f(v, 48));
+}
+__device__ __forceinline__ float wave_max(float v) {
+    v = group_max<16>(v);
+    return fmaxf(fmaxf(readlane_f(v, 0), readlane_f(v, 16)), fmaxf(readlane_f(v, 32), readlane_f(v, 48)));
 }
 
 // block reductions over NW waves through a small LDS scratch (NW floats)

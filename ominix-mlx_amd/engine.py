@@ -3,6 +3,7 @@ over the fused decode engine of libomx_hip.so (include/omx.h, omx_qwen3_*)."""
 from __future__ import annotations
 
 import ctypes
+import sys
 from typing import Dict, Iterator, Optional
 
 import numpy as np
@@ -75,11 +76,17 @@ class Model:
         check(lib.omx_qwen3_create(ctypes.byref(self._h), ctypes.byref(self.cfg)))
         self._keep = []
 
-    def __del__(self):
+    def close(self) -> None:
         h = getattr(self, "_h", None)
         if h is not None and h.value:
             lib.omx_qwen3_destroy(h)
             self._h = c_void_p()
+
+    def __del__(self):
+        # never call into HIP while the interpreter (and possibly the HIP runtime / a profiler
+        # layered on it) is being torn down
+        if not sys.is_finalizing():
+            self.close()
 
     @property
     def vocab_local(self) -> int:

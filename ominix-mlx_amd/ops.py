@@ -10,6 +10,7 @@ Everything executes eagerly on the null stream (eval == stream sync).
 from __future__ import annotations
 
 import ctypes
+import sys
 from typing import Optional, Sequence
 
 import numpy as np
@@ -50,6 +51,8 @@ class Tensor:
             self._owned = False
 
     def __del__(self):
+        if sys.is_finalizing():
+            return
         if getattr(self, "_owned", False) and self.ptr:
             lib.omx_free(self.ptr)
             self.ptr = None

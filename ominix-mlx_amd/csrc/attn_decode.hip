@@ -291,18 +291,29 @@ __global__ __launch_bounds__(D) void attn_combine_kernel(bf16_t* __restrict__ ou
     }
     __syncthreads();
     const float* src = ws_o + head * nsplit * D + d;
-    float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
+    float acc0 = 0.f, acc1 = 0.f;
     int i = 0;
+    for (; i + 16 <= nsplit; i += 16) {   // 16 independent loads in flight, then the FMAs
+        float v[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v[j] = src[(size_t)(i + j) * D];
+#pragma unroll
+        for (int j = 0; j < 16; j += 2) {
+            acc0 = fmaf(sm_f[i + j], v[j], acc0);
+            acc1 = fmaf(sm_f[i + j + 1], v[j + 1], acc1);
+        }
+    }
     for (; i + 4 <= nsplit; i += 4) {
-        const float v0 = src[(size_t)i * D], v1 = src[(size_t)(i + 1) * D], v2 = src[(size_t)(i + 2) * D],
-                    v3 = src[(size_t)(i + 3) * D];
-        acc0 = fmaf(sm_f[i], v0, acc0);
-        acc1 = fmaf(sm_f[i + 1], v1, acc1);
-        acc2 = fmaf(sm_f[i + 2], v2, acc2);
-        acc3 = fmaf(sm_f[i + 3], v3, acc3);
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = src[(size_t)(i + j) * D];
+        acc0 = fmaf(sm_f[i], v[0], acc0);
+        acc1 = fmaf(sm_f[i + 1], v[1], acc1);
+        acc0 = fmaf(sm_f[i + 2], v[2], acc0);
+        acc1 = fmaf(sm_f[i + 3], v[3], acc1);
     }
     for (; i < nsplit; ++i) acc0 = fmaf(sm_f[i], src[(size_t)i * D], acc0);
-    out[head * D + d] = f32_to_bf16(((acc0 + acc1) + (acc2 + acc3)) / sm_L);
+    out[head * D + d] = f32_to_bf16((acc0 + acc1) / sm_L);
 }
 
 }  // namespace

@@ -406,7 +406,7 @@ int omx_qwen3_create(omx_qwen3* out, const omx_qwen3_config* cfg) {
         return 1;
     m->prompt_cap = m->cap;
     if (dev_alloc(m, &m->prompt_dev, (size_t)m->prompt_cap + 1)) return 1;
-    m->n_argmax_partials = gemv_grid(m->V, c.hidden_size, 0);
+    m->n_argmax_partials = gemv_grid(m->V, c.hidden_size, EPI_ARGMAX, 0);
     if (dev_alloc(m, &m->argmax_partials, (size_t)m->n_argmax_partials)) return 1;
     OMX_HIP_CHECK(hipStreamSynchronize(m->stream));
     *out = m;

@@ -265,21 +265,25 @@ int launch_nv(const GemvArgs& a, int pro, int epi, hipStream_t s) {
 
 }  // namespace
 
-static int resolve_rpw(int N, int K, int rpw) {
+// Row groups are sized so that the WHOLE grid is co-resident in one round: these kernels are
+// register-heavy (two in-flight register sets), 2 waves/SIMD for the 8-vector variants (1 for the
+// SwiGLU pair kernel), and a second round of blocks pays the cold-start latency again.
+static int resolve_rpw(int N, int K, int epi, int rpw) {
     const bool split = (K / 512) > 8;
     if (rpw <= 0) {
-        // ~3072 row groups: ~12 waves per CU on 256 CUs when a wave owns its rows
-        rpw = (N + 3071) / 3072;
-        if (split) rpw = (N + 1023) / 1024;   // 4 waves share a group
-        if (rpw < 2) rpw = 2;
-        if (!split && N >= 65536) rpw = 16;    // long streams (lm_head): amortise the prologue
+        // measured on MI355X (tools/gemv_sweep.py): short row groups in whole double-buffer rounds win;
+        // small matrices want every CU busy (>= ~1500 waves), the vocabulary-sized one longer streams
+        if (split) rpw = 8;
+        else if (N >= 65536) rpw = 8;
+        else rpw = (N / 4 >= 1536) ? 4 : 2;
+        (void)epi;
     }
     if (split && rpw > 256) rpw = 256;
     return rpw;
 }
 
-int gemv_grid(int N, int K, int rows_per_wave) {
-    const int rpw = resolve_rpw(N, K, rows_per_wave);
+int gemv_grid(int N, int K, int epi, int rows_per_wave) {
+    const int rpw = resolve_rpw(N, K, epi, rows_per_wave);
     const int groups = (N + rpw - 1) / rpw;
     return (K / 512) > 8 ? groups : (groups + kWaves - 1) / kWaves;
 }
@@ -289,7 +293,7 @@ int launch_gemv(const GemvArgs& a_in, int pro, int epi, hipStream_t s) {
     OMX_REQUIRE(a.K > 0 && a.K % 512 == 0, "gemv: K=%d must be a positive multiple of 512", a.K);
     OMX_REQUIRE(a.N > 0, "gemv: N must be positive");
     const int nv = a.K / 512;
-    a.rows_per_wave = resolve_rpw(a.N, a.K, a.rows_per_wave);
+    a.rows_per_wave = resolve_rpw(a.N, a.K, epi, a.rows_per_wave);
     switch (nv) {
         // RB*NVW ~ 16 x 1-KiB loads in flight per wave per register set
         case 1: return launch_nv<1, 1, 8>(a, pro, epi, s);

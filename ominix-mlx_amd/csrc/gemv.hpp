@@ -46,6 +46,6 @@ struct GemvArgs {
 
 int launch_gemv(const GemvArgs& a, int pro, int epi, hipStream_t s);
 // number of blocks launch_gemv will use (== entries written to argmax_slot); resolves rows_per_wave
-int gemv_grid(int N, int K, int rows_per_wave);
+int gemv_grid(int N, int K, int epi, int rows_per_wave);
 
 }  // namespace omx

@@ -1,10 +1,207 @@
+// bf16 GEMM on the gfx950 matrix cores for the compute-bound side of the path:
+//   out[M,N] = x[M,K] . W[N,K]^T (+ bias[N]) (+ residual[M,N])      -- nn::Linear at M > 4
+//   (mlx-rs/src/nn/linear.rs:87-92 -> mlx_matmul / mlx_addmm, mlx-c ops.h:598-602, 36-43):
+//   prefill projections (M = 2048), FLUX.2-klein DiT GEMMs (M = 4608), Paraformer encoder (M = 501).
+// Both operands are K-contiguous ("NT"), which is exactly the MFMA A/B fragment shape: a lane
+// reads 8 consecutive k of one row (16 B) for either operand.
+//
+// Fast path (K % 64 == 0, 16-B aligned):
+//   * 128x128x64 tile, 256 threads = 4 waves as 2(M) x 2(N), each wave 64x64 = 2x2 MFMA 32x32x16 tiles
+//     (v_mfma_f32_32x32x16_bf16, fp32 accumulate: 64 accumulator registers per lane);
+//   * HBM -> LDS with global_load_lds_dwordx4 (no VGPR round trip), two LDS buffers: tile t+1 is in
+//     flight while tile t feeds the MFMAs (cdna_hip_programming.md T3+T4 "minimum 2-phase" form);
+//   * LDS image is lane-linear per wave-instruction, so the bank-conflict swizzle (16-B chunk index
+//     ^= row & 7) is applied to the per-lane SOURCE address and again on the ds_read (rule 21);
+//   * XCD-aware block order (T1): consecutive blocks of one XCD share an x row panel in its L2.
+// Fallback (any K, any alignment): register-staged 64x64x32 tiles with zero fill.
 #include "gemm.hpp"
+
 namespace omx {
-int launch_gemm_bf16(bf16_t*, const bf16_t*, const bf16_t*, const bf16_t*, int M, int N, int K, hipStream_t) {
-    return set_error("gemm: M=%d N=%d K=%d MFMA path not built yet", M, N, K);
+namespace {
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+constexpr int BM = 128, BN = 128, BK = 64, NTHREADS = 256;
+constexpr int TILE_BYTES = BM * BK * 2;   // 16 KiB per operand tile
+
+struct GemmArgs {
+    const bf16_t* x;      // [M, K]
+    const bf16_t* w;      // [N, K]
+    const bf16_t* bias;   // [N] or null
+    const bf16_t* resid;  // [M, N] or null : out = bf16(resid + bf16(acc (+bias)))
+    bf16_t* out;          // [M, N]
+    int M, N, K;
+    int grid_m, grid_n;
+};
+
+// stage one 128 x 64 operand tile: 1024 16-B chunks, 4 wave-instructions per wave
+__device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ src, int row0, int rows_valid, int K, int k0,
+                                           unsigned char* lds_tile) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int chunk = p * 256 + wave * 64 + lane;   // LDS chunk index (lane-linear inside the wave)
+        const int row = chunk >> 3;
+        const int kc = (chunk & 7) ^ (row & 7);          // logical k-chunk stored at this LDS slot
+        const int grow = min(row0 + row, rows_valid - 1);
+        const bf16_t* g = src + (size_t)grow * K + k0 + kc * 8;
+        __builtin_amdgcn_global_load_lds((glb_ptr_t)g, (lds_ptr_t)(lds_tile + (p * 256 + wave * 64) * 16), 16, 0, 0);
+    }
 }
-int launch_attn_prefill(bf16_t*, const bf16_t*, const bf16_t*, const bf16_t*, int, int, int, int Tq, int, int,
-                        int64_t, int64_t, float, int, const void*, hipStream_t) {
-    return set_error("sdpa: Tq=%d MFMA prefill path not built yet", Tq);
+
+__device__ __forceinline__ bf16x8 lds_frag(const unsigned char* lds_tile, int row, int kc) {
+    return *reinterpret_cast<const bf16x8*>(lds_tile + ((row << 3) + (kc ^ (row & 7))) * 16);
 }
+
+__global__ __launch_bounds__(NTHREADS) void gemm_bf16_nt_kernel(const GemmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [2 buffers][A tile | B tile]
+    // XCD-aware remap: block b runs on XCD b % 8; give each XCD a contiguous run of tiles
+    const int nblk = a.grid_m * a.grid_n;
+    int bid = blockIdx.x;
+    {
+        const int q = nblk / 8, r = nblk % 8, xcd = bid % 8, idx = bid / 8;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int bm = bid / a.grid_n, bn = bid % a.grid_n;
+    const int m0 = bm * BM, n0 = bn * BN;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int nt = a.K / BK;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    stage_tile(a.x, m0, a.M, a.K, 0, smem);
+    stage_tile(a.w, n0, a.N, a.K, 0, smem + TILE_BYTES);
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+
+    int cur = 0;
+    for (int t = 0; t < nt; ++t) {
+        unsigned char* bufA = smem + cur * 2 * TILE_BYTES;
+        unsigned char* bufB = bufA + TILE_BYTES;
+        if (t + 1 < nt) {
+            unsigned char* nA = smem + (cur ^ 1) * 2 * TILE_BYTES;
+            stage_tile(a.x, m0, a.M, a.K, (t + 1) * BK, nA);
+            stage_tile(a.w, n0, a.N, a.K, (t + 1) * BK, nA + TILE_BYTES);
+        }
+#pragma unroll
+        for (int ks = 0; ks < BK / 16; ++ks) {
+            const int kc = ks * 2 + (lane >> 5);
+            bf16x8 fa[2], fb[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) fa[i] = lds_frag(bufA, wm * 64 + i * 32 + (lane & 31), kc);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) fb[j] = lds_frag(bufB, wn * 64 + j * 32 + (lane & 31), kc);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
+        __builtin_amdgcn_s_waitcnt(0);   // next tile landed (vmcnt) and our ds_reads retired (lgkmcnt)
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // epilogue: C/D layout of 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + wn * 64 + j * 32 + (lane & 31);
+            if (col >= a.N) continue;
+            const float bv = a.bias ? bf16_to_f32(a.bias[col]) : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (row < a.M) {
+                    float v = acc[i][j][r] + bv;
+                    if (a.resid) v = bf16_to_f32(a.resid[(size_t)row * a.N + col]) + round_bf16(v);
+                    a.out[(size_t)row * a.N + col] = f32_to_bf16(v);
+                }
+            }
+        }
+}
+
+// ---- fallback: any K / alignment.  64x64 tile, BK = 32, register staging with zero fill ----
+__global__ __launch_bounds__(NTHREADS) void gemm_bf16_nt_generic_kernel(const GemmArgs a) {
+    __shared__ __attribute__((aligned(16))) bf16_t sA[64][40];   // +8 pad: conflict-free 16-B fragment reads
+    __shared__ __attribute__((aligned(16))) bf16_t sB[64][40];
+    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave >> 1, wn = wave & 1;   // each wave: 32 x 32 output = one MFMA tile
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int k0 = 0; k0 < a.K; k0 += 32) {
+        // 64 rows x 32 k per operand = 2048 elements; 256 threads x 8
+        {
+            const int row = threadIdx.x >> 2, kk = (threadIdx.x & 3) * 8;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int k = k0 + kk + e;
+                const int gm = m0 + row, gn = n0 + row;
+                sA[row][kk + e] = (gm < a.M && k < a.K) ? a.x[(size_t)gm * a.K + k] : (bf16_t)0;
+                sB[row][kk + e] = (gn < a.N && k < a.K) ? a.w[(size_t)gn * a.K + k] : (bf16_t)0;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const bf16x8 fa = *reinterpret_cast<const bf16x8*>(&sA[wm * 32 + (lane & 31)][ks * 16 + (lane >> 5) * 8]);
+            const bf16x8 fb = *reinterpret_cast<const bf16x8*>(&sB[wn * 32 + (lane & 31)][ks * 16 + (lane >> 5) * 8]);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc, 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    const int col = n0 + wn * 32 + (lane & 31);
+    if (col >= a.N) return;
+    const float bv = a.bias ? bf16_to_f32(a.bias[col]) : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (row < a.M) {
+            float v = acc[r] + bv;
+            if (a.resid) v = bf16_to_f32(a.resid[(size_t)row * a.N + col]) + round_bf16(v);
+            a.out[(size_t)row * a.N + col] = f32_to_bf16(v);
+        }
+    }
+}
+
+}  // namespace
+
+int launch_gemm_bf16_ex(bf16_t* out, const bf16_t* x, const bf16_t* w, const bf16_t* bias, const bf16_t* resid, int M,
+                        int N, int K, hipStream_t s) {
+    OMX_REQUIRE(M > 0 && N > 0 && K > 0, "gemm: bad shape M=%d N=%d K=%d", M, N, K);
+    GemmArgs a = {x, w, bias, resid, out, M, N, K, (M + BM - 1) / BM, (N + BN - 1) / BN};
+    const bool fast = (K % BK == 0) && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w)) & 15u) == 0;
+    if (fast) {
+        static bool attr_set = false;
+        const int shmem = 4 * TILE_BYTES;
+        if (!attr_set) {
+            OMX_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_bf16_nt_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, shmem));
+            attr_set = true;
+        }
+        gemm_bf16_nt_kernel<<<a.grid_m * a.grid_n, NTHREADS, shmem, s>>>(a);
+    } else {
+        gemm_bf16_nt_generic_kernel<<<dim3((N + 63) / 64, (M + 63) / 64), NTHREADS, 0, s>>>(a);
+    }
+    OMX_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_gemm_bf16(bf16_t* out, const bf16_t* x, const bf16_t* w, const bf16_t* bias, int M, int N, int K,
+                     hipStream_t s) {
+    return launch_gemm_bf16_ex(out, x, w, bias, nullptr, M, N, K, s);
+}
+
 }  // namespace omx

@@ -1,0 +1,113 @@
+"""GPU parity for the matrix-core side of the path: nn::Linear at M > 4 (a5 prefill / DiT) and
+SDPA with Tq > 1 (a1 prefill: explicit bool mask as every on-path caller passes it, "causal",
+additive, none = FLUX joint attention).  Oracle: oracle/ref_core.py.
+
+Tolerances: GEMM -- <= 1 bf16 ulp of the oracle value + fp32-accumulation noise floor.
+SDPA -- P is rounded to bf16 before the second product (flash attention), so
+|d| <= 2 bf16 ulp + 4e-3 * max|ref| is allowed."""
+import numpy as np
+import pytest
+
+from oracle import ref_core as rc
+from test_gpu_primitives import assert_bf16_close, rand
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("M,N,K", [
+    (2048, 4096, 4096),      # Qwen3-8B prefill q_proj
+    (128, 1024, 4096),       # k_proj for a 128-token prompt
+    (77, 200, 512),          # ragged M and N tails
+    (5, 128, 64),            # smallest GEMM-path M
+    (501, 512, 560),         # Paraformer first layer: K not a multiple of 64 -> generic kernel
+    (64, 72, 2048),
+    (300, 3072, 9216),       # Klein MLP-out shape class
+])
+def test_linear_gemm_parity(omx, M, N, K):
+    T = omx.ops.Tensor
+    x = rc.bf16_round(rand((M, K), 31))
+    w = rc.bf16_round(rand((N, K), 32) * 0.05)
+    got = omx.ops.linear(T.from_numpy(x), T.from_numpy(w)).numpy()
+    ref = rc.linear(x, w, None, "bf16")
+    assert got.shape == (M, N)
+    assert_bf16_close(got, ref, 1, atol=2e-5 * np.sqrt(K))
+
+
+def test_linear_gemm_bias_is_fused_addmm(omx):
+    """nn/linear.rs:88-90: addmm rounds once."""
+    T = omx.ops.Tensor
+    M, N, K = 65, 256, 512
+    x = rc.bf16_round(rand((M, K), 33))
+    w = rc.bf16_round(rand((N, K), 34) * 0.05)
+    b = rc.bf16_round(rand((N,), 35))
+    got = omx.ops.linear(T.from_numpy(x), T.from_numpy(w), T.from_numpy(b)).numpy()
+    assert_bf16_close(got, rc.linear(x, w, b, "bf16"), 1, atol=1e-4)
+
+
+def test_linear_gemm_transpose_detecting(omx):
+    """A = I against an asymmetric W catches swapped C/D row/col mappings (cdna guide rule 16)."""
+    T = omx.ops.Tensor
+    K = 128
+    x = np.eye(K, dtype=np.float32)
+    w = rc.bf16_round((np.arange(K * K).reshape(K, K) % 251 - 125).astype(np.float32) / 64)
+    got = omx.ops.linear(T.from_numpy(x), T.from_numpy(w)).numpy()
+    np.testing.assert_array_equal(got, w.T)
+
+
+def _sdpa(omx, q, k, v, scale, mask_np):
+    T = omx.ops.Tensor
+    if mask_np is None or isinstance(mask_np, str):
+        m = mask_np
+    elif mask_np.dtype == np.bool_:
+        m = T.from_numpy(mask_np, "bool")
+    else:
+        m = T.from_numpy(mask_np, "bf16")
+    return omx.ops.scaled_dot_product_attention(T.from_numpy(q), T.from_numpy(k), T.from_numpy(v), scale, m).numpy()
+
+
+def _check(got, ref):
+    assert_bf16_close(got, ref, 2, atol=4e-3 * np.abs(ref).max())
+
+
+@pytest.mark.parametrize("B,H,Hkv,Tq,Tk,D", [
+    (1, 8, 2, 128, 128, 128),     # GQA prefill
+    (1, 4, 4, 200, 200, 64),      # ragged, D = 64
+    (2, 2, 1, 65, 65, 128),       # batch 2, one-past-a-tile
+    (1, 4, 2, 33, 161, 128),      # chunked prefill: Tq < Tk (offset 128)
+])
+def test_sdpa_prefill_bool_mask_as_reference_callers_pass_it(omx, B, H, Hkv, Tq, Tk, D):
+    """create_attention_mask(.., Some(true)) -> bool [Tq, offset+Tq] (utils.rs:134-153)."""
+    q = rc.bf16_round(rand((B, H, Tq, D), 41))
+    k = rc.bf16_round(rand((B, Hkv, Tk, D), 42))
+    v = rc.bf16_round(rand((B, Hkv, Tk, D), 43))
+    mask = rc.create_causal_mask(Tq, Tk - Tq)
+    scale = D ** -0.5
+    _check(_sdpa(omx, q, k, v, scale, mask), rc.scaled_dot_product_attention(q, k, v, scale, mask, "bf16"))
+    # "causal" mode (bottom-right aligned) must agree with the explicit mask
+    _check(_sdpa(omx, q, k, v, scale, "causal"), rc.scaled_dot_product_attention(q, k, v, scale, "causal", "bf16"))
+
+
+def test_sdpa_prefill_sliding_window_mask(omx):
+    """window_size branch of create_causal_mask (utils.rs:147-150)."""
+    B, H, Hkv, T, D = 1, 2, 2, 150, 64
+    q = rc.bf16_round(rand((B, H, T, D), 44)); k = rc.bf16_round(rand((B, Hkv, T, D), 45)); v = rc.bf16_round(rand((B, Hkv, T, D), 46))
+    mask = rc.create_causal_mask(T, 0, 32)
+    _check(_sdpa(omx, q, k, v, 0.125, mask), rc.scaled_dot_product_attention(q, k, v, 0.125, mask, "bf16"))
+
+
+def test_sdpa_joint_attention_no_mask_and_additive(omx):
+    """FLUX.2-klein joint attention shape class: non-causal, Sq != Sk (img queries over [txt,img] keys)."""
+    B, H, Sq, Sk, D = 1, 3, 192, 256, 128
+    q = rc.bf16_round(rand((B, H, Sq, D), 47)); k = rc.bf16_round(rand((B, H, Sk, D), 48)); v = rc.bf16_round(rand((B, H, Sk, D), 49))
+    scale = D ** -0.5
+    _check(_sdpa(omx, q, k, v, scale, None), rc.scaled_dot_product_attention(q, k, v, scale, None, "bf16"))
+    addm = rc.bf16_round(rand((Sq, Sk), 50) * 2)
+    _check(_sdpa(omx, q, k, v, scale, addm), rc.scaled_dot_product_attention(q, k, v, scale, addm, "bf16"))
+
+
+def test_sdpa_prefill_spike_forces_rescale(omx):
+    B, H, T, D = 1, 2, 256, 128
+    q = rc.bf16_round(rand((B, H, T, D), 51)); k = rc.bf16_round(rand((B, H, T, D), 52) * 0.1); v = rc.bf16_round(rand((B, H, T, D), 53))
+    k[0, 1, 200] = rc.bf16_round(q[0, 1, 230] * 6)   # late-tile spike for query 230 of head 1
+    scale = D ** -0.5
+    _check(_sdpa(omx, q, k, v, scale, "causal"), rc.scaled_dot_product_attention(q, k, v, scale, "causal", "bf16"))

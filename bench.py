@@ -222,7 +222,10 @@ def main():
                           "frac_of_hbm_peak": round(step_bytes / (ms_per_step * 1e-3) / 1e9 / (HBM_PEAK_GBPS * world), 4),
                           "roofline_tokens_per_sec": round(HBM_PEAK_GBPS * 1e9 * world / step_bytes, 1),
                           "device_ms_per_step_hip_events": round(dev_ms / args.steps, 4)},
-        "prefill": {"tokens": args.prompt, "seconds": round(prefill_s, 3), "mode": "token-serial (decode kernels)"},
+        "prefill": {"tokens": args.prompt, "seconds": round(prefill_s, 4), "device_ms": round(model.last_prefill_ms(), 3),
+                    "tokens_per_sec": round(args.prompt / max(model.last_prefill_ms(), 1e-6) * 1e3, 1),
+                    "mode": "token-serial decode steps (TP)" if world > 1 else
+                            "batched: MFMA GEMM + flash attention for n-1 tokens, decode step for the last"},
         "first_tokens": [int(first)] + [int(t) for t in toks[:4]],
     }
     if not args.no_cpu_baseline:
@@ -231,8 +234,8 @@ def main():
         except Exception as e:   # the baseline is a report, never a reason to lose the measured line
             out["cpu_baseline"] = {"value": None, "unit": "tokens/s", "cores": os.cpu_count(), "kind": "port",
                                    "sample": f"failed: {e}"}
-    model.close()
     print(json.dumps(out), flush=True)
+    model.close()
 
 
 if __name__ == "__main__":

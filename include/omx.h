@@ -160,6 +160,9 @@ int omx_qwen3_decode(omx_qwen3 m, int n, uint32_t* tokens_out);
 int omx_qwen3_last_logits(omx_qwen3 m, void* host_bf16, int n);
 /* timing of the last omx_qwen3_decode call measured with HIP events on the engine stream (ms)       */
 int omx_qwen3_last_decode_ms(omx_qwen3 m, float* ms);
+int omx_qwen3_last_prefill_ms(omx_qwen3 m, float* ms);   /* same for the last omx_qwen3_prefill call */
+/* test hook: copy an internal bf16 buffer ("h","h2","qkv","attn_out","act","k<l>","v<l>") to the host */
+int omx_qwen3_debug_read(omx_qwen3 m, const char* name, void* host, size_t n_elems);
 int omx_qwen3_stream(omx_qwen3 m, omx_stream* s);
 /* algorithmic HBM bytes of ONE decode step at context length ctx (SURVEY.md 8d formula)             */
 int omx_qwen3_step_bytes(omx_qwen3 m, int ctx, double* bytes);

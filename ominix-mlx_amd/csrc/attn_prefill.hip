@@ -37,6 +37,8 @@ struct PrefillArgs {
     float scale;
     int mask_mode;
     const void* mask;
+    // element strides of q and out: [B,H,Tq,D] by default; the engine writes out as [Tq, H*D]
+    int64_t q_bs, q_hs, q_ts, o_bs, o_hs, o_ts;
 };
 
 // max / sum over the 4 lanes {l, l^16, l^32, l^48} that hold the same query column
@@ -70,7 +72,7 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(const PrefillArgs a) 
     const int qrow_c = min(qrow, a.Tq - 1);
     const int shift = a.Tk - a.Tq;                       // causal: query i sees keys <= i + shift
 
-    const bf16_t* Qp = a.q + (((size_t)b * a.H + h) * a.Tq + qrow_c) * D;
+    const bf16_t* Qp = a.q + (size_t)b * a.q_bs + (size_t)h * a.q_hs + (size_t)qrow_c * a.q_ts;
     const bf16_t* Kb = a.k + (size_t)b * a.kv_batch_stride + (size_t)kvh * a.kv_head_stride;
     const bf16_t* Vb = a.v + (size_t)b * a.kv_batch_stride + (size_t)kvh * a.kv_head_stride;
 
@@ -170,7 +172,7 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(const PrefillArgs a) 
     const float l_tot = quad_rows_sum(l_run);
     const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
     if (qrow < a.Tq) {
-        bf16_t* op = a.out + (((size_t)b * a.H + h) * a.Tq + qrow) * D;
+        bf16_t* op = a.out + (size_t)b * a.o_bs + (size_t)h * a.o_hs + (size_t)qrow * a.o_ts;
 #pragma unroll
         for (int t = 0; t < NDT; ++t) {
             u32x2v w = {pack_bf16(o[t][0] * inv, o[t][1] * inv), pack_bf16(o[t][2] * inv, o[t][3] * inv)};
@@ -183,9 +185,14 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(const PrefillArgs a) 
 
 int launch_attn_prefill(bf16_t* out, const bf16_t* q, const bf16_t* k, const bf16_t* v, int B, int H, int Hkv, int Tq,
                         int Tk, int D, int64_t kv_batch_stride, int64_t kv_head_stride, float scale, int mask_mode,
-                        const void* mask, hipStream_t s) {
+                        const void* mask, hipStream_t s, bool out_token_major) {
     OMX_REQUIRE(D == 64 || D == 128, "sdpa prefill: head_dim %d unsupported (64 or 128)", D);
-    PrefillArgs a = {q, k, v, out, B, H, Hkv, Tq, Tk, kv_batch_stride, kv_head_stride, scale, mask_mode, mask};
+    PrefillArgs a = {q, k, v, out, B, H, Hkv, Tq, Tk, kv_batch_stride, kv_head_stride, scale, mask_mode, mask,
+                     (int64_t)H * Tq * D, (int64_t)Tq * D, D, (int64_t)H * Tq * D, (int64_t)Tq * D, D};
+    if (out_token_major) {   // out[b][t][h][d]: what o_proj consumes after the reference's transpose+reshape (model.rs:211-213)
+        a.o_hs = D;
+        a.o_ts = (int64_t)H * D;
+    }
     const dim3 grid((Tq + QB - 1) / QB, H, B), block(256);
     if (D == 128) attn_prefill_kernel<128><<<grid, block, 0, s>>>(a);
     else attn_prefill_kernel<64><<<grid, block, 0, s>>>(a);

@@ -23,7 +23,9 @@
 #include <vector>
 
 #include "attn.hpp"
+#include "gemm.hpp"
 #include "gemv.hpp"
+#include "prefill.hpp"
 
 namespace omx {
 namespace {
@@ -143,6 +145,12 @@ struct omx_qwen3_ {
 
     void* comm = nullptr;
     nccl_allreduce_fn allreduce = nullptr;
+
+    // batched-prefill activations (allocated on first use, sized for pf_cap tokens)
+    int pf_cap = 0;
+    bf16_t *pf_h = nullptr, *pf_h2 = nullptr, *pf_xn = nullptr, *pf_q = nullptr, *pf_k = nullptr, *pf_v = nullptr,
+           *pf_qt = nullptr, *pf_attn = nullptr, *pf_g = nullptr, *pf_u = nullptr;
+    float last_prefill_ms = 0.f;
 
     hipGraphExec_t g_full = nullptr, g_nohead = nullptr;
     bool eager = false;          // fallback when stream capture is unavailable (e.g. a collective refuses capture)
@@ -349,6 +357,54 @@ int dev_alloc(omx_qwen3 m, T** p, size_t n) {
     return 0;
 }
 
+// Batched prefill of T prompt tokens (all but the last one, which goes through the decode step so
+// that sampling stays in one place): fills the KV slabs of every layer.  Matrix-core path:
+//   RMSNorm rows -> q/k/v GEMM -> [per-head norm + RoPE + cache scatter] -> flash attention
+//   (causal, bottom-right aligned == the bool mask of utils.rs:134-153) -> o GEMM + residual ->
+//   RMSNorm -> gate/up GEMM -> silu*up -> down GEMM + residual.        (model.rs:161-215,263-267,321-332)
+// The last layer stops after its cache scatter: nothing downstream of it is consumed for these tokens.
+int prefill_prefix_batched(omx_qwen3 m, int T, int off) {
+    const omx_qwen3_config& c = m->cfg;
+    hipStream_t s = m->stream;
+    const int hd = c.hidden_size, D = c.head_dim, H = m->H, Hkv = m->Hkv, I = m->I;
+    if (T > m->pf_cap) {
+        OMX_HIP_CHECK(hipStreamSynchronize(s));
+        bf16_t** bufs[] = {&m->pf_h, &m->pf_h2, &m->pf_xn, &m->pf_q, &m->pf_k, &m->pf_v, &m->pf_qt, &m->pf_attn, &m->pf_g, &m->pf_u};
+        const size_t sizes[] = {(size_t)hd, (size_t)hd, (size_t)hd, (size_t)H * D, (size_t)Hkv * D, (size_t)Hkv * D,
+                                (size_t)H * D, (size_t)H * D, (size_t)I, (size_t)I};
+        for (int i = 0; i < 10; ++i) {
+            if (*bufs[i]) OMX_HIP_CHECK(hipFree(*bufs[i]));
+            OMX_HIP_CHECK(hipMalloc((void**)bufs[i], sizes[i] * (size_t)T * 2));
+        }
+        m->pf_cap = T;
+    }
+    if (omx_take_rows(m->pf_h, m->embed, m->prompt_dev, T, hd, OMX_BFLOAT16, s)) return 1;
+    bf16_t* h = m->pf_h;
+    bf16_t* h2 = m->pf_h2;
+    const float scale = 1.0f / sqrtf((float)D);
+    for (int l = 0; l < c.num_hidden_layers; ++l) {
+        const LayerW& L = m->layers[l];
+        if (omx_rms_norm(m->pf_xn, h, L.in_ln, T, hd, c.rms_norm_eps, OMX_BFLOAT16, s)) return 1;
+        if (launch_gemm_bf16(m->pf_q, m->pf_xn, L.q, nullptr, T, H * D, hd, s)) return 1;
+        if (launch_gemm_bf16(m->pf_k, m->pf_xn, L.k, nullptr, T, Hkv * D, hd, s)) return 1;
+        if (launch_gemm_bf16(m->pf_v, m->pf_xn, L.v, nullptr, T, Hkv * D, hd, s)) return 1;
+        if (launch_qk_norm_rope_scatter(m->pf_q, m->pf_k, m->pf_v, L.q_norm, L.k_norm, m->rope_cos, m->rope_sin, m->pf_qt,
+                                        m->kcache[l], m->vcache[l], T, H, Hkv, D, m->cap, off, c.rms_norm_eps, s))
+            return 1;
+        if (l == c.num_hidden_layers - 1) break;
+        if (launch_attn_prefill(m->pf_attn, m->pf_qt, m->kcache[l], m->vcache[l], 1, H, Hkv, T, off + T, D, 0,
+                                (int64_t)m->cap * D, scale, OMX_MASK_CAUSAL, nullptr, s, /*out_token_major=*/true))
+            return 1;
+        if (launch_gemm_bf16_ex(h2, m->pf_attn, L.o, nullptr, h, T, hd, H * D, s)) return 1;
+        if (omx_rms_norm(m->pf_xn, h2, L.post_ln, T, hd, c.rms_norm_eps, OMX_BFLOAT16, s)) return 1;
+        if (launch_gemm_bf16(m->pf_g, m->pf_xn, L.gate, nullptr, T, I, hd, s)) return 1;
+        if (launch_gemm_bf16(m->pf_u, m->pf_xn, L.up, nullptr, T, I, hd, s)) return 1;
+        if (launch_silu_mul(m->pf_g, m->pf_g, m->pf_u, (int64_t)T * I, s)) return 1;
+        if (launch_gemm_bf16_ex(h, m->pf_g, L.down, nullptr, h2, T, hd, I, s)) return 1;
+    }
+    return 0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -419,6 +475,8 @@ int omx_qwen3_destroy(omx_qwen3 m) {
     if (m->g_full) (void)hipGraphExecDestroy(m->g_full);
     if (m->g_nohead) (void)hipGraphExecDestroy(m->g_nohead);
     for (void* p : m->owned) (void)hipFree(p);
+    for (bf16_t* p : {m->pf_h, m->pf_h2, m->pf_xn, m->pf_q, m->pf_k, m->pf_v, m->pf_qt, m->pf_attn, m->pf_g, m->pf_u})
+        if (p) (void)hipFree(p);
     if (m->ev0) (void)hipEventDestroy(m->ev0);
     if (m->ev1) (void)hipEventDestroy(m->ev1);
     if (m->stream) (void)hipStreamDestroy(m->stream);
@@ -525,14 +583,34 @@ int omx_qwen3_prefill(omx_qwen3 m, const uint32_t* prompt, int n_prompt, uint32_
     st.cur_token = prompt[0];
     st.prompt_idx = 0;
     const int count_before = st.out_count;
-    OMX_HIP_CHECK(hipMemcpyAsync(m->st, &st, sizeof(st), hipMemcpyHostToDevice, m->stream));
-    // token-serial prefill: identical arithmetic to n_prompt decode steps (the lm_head is skipped for
-    // all but the last prompt position; the reference computes and discards those logits, model.rs:815)
-    for (int i = 0; i < n_prompt - 1; ++i)
-        if (run_step(m, false)) return 1;
+    const char* serial_env = getenv("OMX_PREFILL_SERIAL");
+    const bool serial = (serial_env && serial_env[0] == '1') || m->allreduce != nullptr || n_prompt < 2;
+    OMX_HIP_CHECK(hipEventRecord(m->ev0, m->stream));
+    if (serial) {
+        // token-serial prefill: identical arithmetic to n_prompt decode steps (the lm_head is skipped for
+        // all but the last prompt position; the reference computes and discards those logits, model.rs:815)
+        OMX_HIP_CHECK(hipMemcpyAsync(m->st, &st, sizeof(st), hipMemcpyHostToDevice, m->stream));
+        for (int i = 0; i < n_prompt - 1; ++i)
+            if (run_step(m, false)) return 1;
+    } else {
+        // matrix-core prefill of the first n-1 tokens, then the decode step for the last one
+        if (prefill_prefix_batched(m, n_prompt - 1, st.pos)) return 1;
+        st.pos += n_prompt - 1;
+        st.prompt_idx = n_prompt - 1;
+        st.cur_token = prompt[n_prompt - 1];
+        OMX_HIP_CHECK(hipMemcpyAsync(m->st, &st, sizeof(st), hipMemcpyHostToDevice, m->stream));
+    }
     if (run_step(m, true)) return 1;
+    OMX_HIP_CHECK(hipEventRecord(m->ev1, m->stream));
     OMX_HIP_CHECK(hipMemcpyAsync(first_token, m->out_ring + (count_before % m->ring_cap), 4, hipMemcpyDeviceToHost, m->stream));
     OMX_HIP_CHECK(hipStreamSynchronize(m->stream));
+    OMX_HIP_CHECK(hipEventElapsedTime(&m->last_prefill_ms, m->ev0, m->ev1));
+    return 0;
+}
+
+int omx_qwen3_last_prefill_ms(omx_qwen3 m, float* ms) {
+    OMX_REQUIRE(m && ms, "omx_qwen3_last_prefill_ms: null argument");
+    *ms = m->last_prefill_ms;
     return 0;
 }
 

@@ -16,6 +16,6 @@ int launch_gemm_bf16_ex(bf16_t* out, const bf16_t* x, const bf16_t* w, const bf1
 // SDPA with Tq > 1 (prefill / DiT joint attention): flash-attention forward on MFMA.
 int launch_attn_prefill(bf16_t* out, const bf16_t* q, const bf16_t* k, const bf16_t* v, int B, int H, int Hkv, int Tq,
                         int Tk, int D, int64_t kv_batch_stride, int64_t kv_head_stride, float scale, int mask_mode,
-                        const void* mask, hipStream_t s);
+                        const void* mask, hipStream_t s, bool out_token_major = false);
 
 }  // namespace omx

@@ -36,6 +36,8 @@ ENGINE_SIGNATURES = {
     "omx_qwen3_decode": (c_int, [c_void_p, c_int, ctypes.POINTER(c_uint32)]),
     "omx_qwen3_last_logits": (c_int, [c_void_p, c_void_p, c_int]),
     "omx_qwen3_last_decode_ms": (c_int, [c_void_p, ctypes.POINTER(c_float)]),
+    "omx_qwen3_last_prefill_ms": (c_int, [c_void_p, ctypes.POINTER(c_float)]),
+    "omx_qwen3_debug_read": (c_int, [c_void_p, ctypes.c_char_p, c_void_p, ctypes.c_size_t]),
     "omx_qwen3_stream": (c_int, [c_void_p, ctypes.POINTER(c_void_p)]),
     "omx_qwen3_step_bytes": (c_int, [c_void_p, c_int, ctypes.POINTER(ctypes.c_double)]),
 }
@@ -127,6 +129,11 @@ class Model:
     def last_decode_ms(self) -> float:
         v = c_float()
         check(lib.omx_qwen3_last_decode_ms(self._h, ctypes.byref(v)))
+        return v.value
+
+    def last_prefill_ms(self) -> float:
+        v = c_float()
+        check(lib.omx_qwen3_last_prefill_ms(self._h, ctypes.byref(v)))
         return v.value
 
     def last_logits(self) -> np.ndarray:

@@ -113,3 +113,27 @@ def test_missing_weight_and_context_overflow_are_errors(omx):
         m2.prefill(synth.prompt_ids(300, cfg.vocab_size))
     with pytest.raises(omx.OmxError, match="out of range"):
         m2.prefill([cfg.vocab_size + 5])
+
+
+def test_batched_prefill_equals_token_serial_prefill(omx, monkeypatch):
+    """The matrix-core prefill (GEMM + flash attention) and the token-serial prefill (decode
+    kernels) are two implementations of the same arithmetic: KV caches and next-token logits
+    must agree to bf16 rounding, and both must agree with the oracle."""
+    import ctypes
+    cfg = CONFIGS["gqa4_d128"]
+    prompt = synth.prompt_ids(97, cfg.vocab_size)
+    outs = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("OMX_PREFILL_SERIAL", mode)
+        m = _engine(omx, cfg)
+        first = m.prefill(prompt)
+        n = cfg.num_key_value_heads * 512 * cfg.head_dim
+        raw = np.empty(n, np.uint16)
+        omx.check(omx.lib.omx_qwen3_debug_read(m._h, b"k1", raw.ctypes.data, n))
+        k1 = rc.from_bf16_bits(raw).reshape(cfg.num_key_value_heads, 512, cfg.head_dim)[:, :97]
+        outs[mode] = (first, m.last_logits(), k1)
+    (_, ls, ks), (_, lb, kb) = outs["1"], outs["0"]
+    scale = np.abs(ls).max()
+    assert np.abs(ls - lb).max() <= 2.0 ** -7 * scale * np.sqrt(cfg.num_hidden_layers)
+    # layer-1 keys depend on layer 0's full block output: agreement here checks GEMM + attention + MLP
+    assert np.abs(ks - kb).max() <= 2.0 ** -6 * np.abs(ks).max()

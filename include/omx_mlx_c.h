@@ -1,0 +1,153 @@
+/*
+ * omx_mlx_c.h -- the hot-path subset of the mlx-c C ABI, exported by libomx_hip.so with the
+ * reference's exact symbol names, argument order, ownership and status conventions, so that
+ * `mlx-sys` (bindgen over mlx/c/mlx.h, mlx-rs/mlx-sys/build.rs:390-399) can link the MI355X
+ * library in place of libmlxc.a + libmlx.a for this path.
+ *
+ * Every declaration cites the header:line it mirrors under
+ *   /root/reference/mlx-rs/mlx-sys/src/mlx-c/mlx/c/
+ * and, where the hot path calls it, the Rust call site.
+ *
+ * Conventions kept:
+ *   - handles are by-value structs { void* ctx }, ctx == NULL is "empty" (array.h:28-30);
+ *   - ops take `mlx_array* res` and ASSIGN into it (free the old value if non-empty,
+ *     private/array.h:24-41); inputs are borrowed; the caller frees with mlx_array_free;
+ *   - "may be null" optional inputs are empty handles (fast.h:96-97,166,177,196-197);
+ *   - every op returns int, 0 = ok, 1 = error after invoking the registered error handler on the
+ *     calling thread (error.cpp:37-54); mlx_set_error_handler == omx_set_error_handler.
+ * Deliberate differences (documented in INTEGRATION.md):
+ *   - execution is EAGER on a HIP stream: ops enqueue kernels immediately; mlx_eval /
+ *     mlx_async_eval / mlx_array_eval are ordering points (stream sync / no-op / sync);
+ *   - mlx_array_data_* return a pointer to a HOST mirror refreshed at that call (device memory is
+ *     not CPU-addressable on a discrete GPU); it stays valid until the array is freed or re-read;
+ *   - there is no CPU backend: mlx_default_cpu_stream_new reports an error;
+ *   - float matmul is implemented for bfloat16 (the path's dtype); other dtypes report an error.
+ */
+#ifndef OMX_MLX_C_H
+#define OMX_MLX_C_H
+
+#include <stdbool.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* array.h:28-30, 37-52 */
+typedef struct mlx_array_ { void* ctx; } mlx_array;
+typedef enum mlx_dtype_ {
+    MLX_BOOL, MLX_UINT8, MLX_UINT16, MLX_UINT32, MLX_UINT64, MLX_INT8, MLX_INT16, MLX_INT32, MLX_INT64,
+    MLX_FLOAT16, MLX_FLOAT32, MLX_FLOAT64, MLX_BFLOAT16, MLX_COMPLEX64
+} mlx_dtype;
+/* stream.h:23-25, device.h, vector.h:25-27, optional.h:24-43 */
+typedef struct mlx_stream_ { void* ctx; } mlx_stream;
+typedef struct mlx_vector_array_ { void* ctx; } mlx_vector_array;
+typedef struct mlx_optional_int_ { int value; bool has_value; } mlx_optional_int;
+typedef struct mlx_optional_float_ { float value; bool has_value; } mlx_optional_float;
+typedef struct mlx_optional_dtype_ { mlx_dtype value; bool has_value; } mlx_optional_dtype;
+
+/* error.h:15-23 (mlx-rs installs its handler per thread: utils/guard.rs:28-29, error.rs:241-259) */
+typedef void (*mlx_error_handler_func)(const char* msg, void* data);
+void mlx_set_error_handler(mlx_error_handler_func handler, void* data, void (*dtor)(void*));
+
+/* ---- array lifecycle: array.h:57-340 ---- */
+size_t mlx_dtype_size(mlx_dtype dtype);                                   /* :57  */
+mlx_array mlx_array_new(void);                                            /* :67  */
+int mlx_array_free(mlx_array arr);                                        /* :72  */
+mlx_array mlx_array_new_bool(bool val);                                   /* :77  */
+mlx_array mlx_array_new_int(int val);                                     /* :81  */
+mlx_array mlx_array_new_float32(float val);                               /* :85  */
+mlx_array mlx_array_new_float(float val);                                 /* :90  */
+mlx_array mlx_array_new_data(const void* data, const int* shape, int dim, mlx_dtype dtype);   /* :111 copies */
+int mlx_array_set(mlx_array* arr, const mlx_array src);                   /* :119 */
+size_t mlx_array_itemsize(const mlx_array arr);                           /* :166 */
+size_t mlx_array_size(const mlx_array arr);                               /* :170 */
+size_t mlx_array_nbytes(const mlx_array arr);                             /* :174 */
+size_t mlx_array_ndim(const mlx_array arr);                               /* :178 */
+const int* mlx_array_shape(const mlx_array arr);                          /* :183 */
+const size_t* mlx_array_strides(const mlx_array arr);                     /* :188 */
+int mlx_array_dim(const mlx_array arr, int dim);                          /* :192 */
+mlx_dtype mlx_array_dtype(const mlx_array arr);                           /* :196 */
+int mlx_array_eval(mlx_array arr);                                        /* :201 */
+int mlx_array_item_bool(bool* res, const mlx_array arr);                  /* :206 */
+int mlx_array_item_uint32(uint32_t* res, const mlx_array arr);            /* :218 (sampler: token id) */
+int mlx_array_item_int32(int32_t* res, const mlx_array arr);              /* :234 */
+int mlx_array_item_float32(float* res, const mlx_array arr);              /* :242 */
+const uint8_t* mlx_array_data_uint8(const mlx_array arr);                 /* :275 */
+const uint16_t* mlx_array_data_uint16(const mlx_array arr);               /* :280 */
+const uint32_t* mlx_array_data_uint32(const mlx_array arr);               /* :285 */
+const int32_t* mlx_array_data_int32(const mlx_array arr);                 /* :305 */
+const float* mlx_array_data_float32(const mlx_array arr);                 /* :315 */
+const uint16_t* mlx_array_data_bfloat16(const mlx_array arr);             /* :335 (bfloat16_t == 16-bit storage) */
+
+/* ---- vector.h:28-47 ---- */
+mlx_vector_array mlx_vector_array_new(void);
+int mlx_vector_array_free(mlx_vector_array vec);
+int mlx_vector_array_append_value(mlx_vector_array vec, const mlx_array val);
+size_t mlx_vector_array_size(mlx_vector_array vec);
+int mlx_vector_array_get(mlx_array* res, const mlx_vector_array vec, size_t idx);
+
+/* ---- stream.h:30-80, transforms.h:30,42, memory.h:30-34 ---- */
+mlx_stream mlx_stream_new(void);
+int mlx_stream_free(mlx_stream stream);
+bool mlx_stream_equal(mlx_stream lhs, mlx_stream rhs);
+int mlx_synchronize(mlx_stream stream);                                   /* stream.h:63 */
+mlx_stream mlx_default_cpu_stream_new(void);                              /* stream.h:75: no CPU backend -> error */
+mlx_stream mlx_default_gpu_stream_new(void);                              /* stream.h:80 (metal_kernels.rs:196,286) */
+int mlx_async_eval(const mlx_vector_array outputs);                       /* transforms.h:30 (model.rs:817-833) */
+int mlx_eval(const mlx_vector_array outputs);                             /* transforms.h:42 */
+int mlx_clear_cache(void);                                                /* memory.h:30 (model.rs:836-838) */
+int mlx_get_active_memory(size_t* res);                                   /* memory.h:31 */
+int mlx_get_peak_memory(size_t* res);                                     /* memory.h:34 */
+
+/* ---- fast.h:93-99, 163-198 : the fused hot-path ops ---- */
+int mlx_fast_layer_norm(mlx_array* res, const mlx_array x, const mlx_array weight /* may be null */,
+                        const mlx_array bias /* may be null */, float eps, const mlx_stream s);
+int mlx_fast_rms_norm(mlx_array* res, const mlx_array x, const mlx_array weight /* may be null */, float eps,
+                      const mlx_stream s);
+int mlx_fast_rope(mlx_array* res, const mlx_array x, int dims, bool traditional, mlx_optional_float base, float scale,
+                  int offset, const mlx_array freqs /* may be null */, const mlx_stream s);
+int mlx_fast_scaled_dot_product_attention(mlx_array* res, const mlx_array queries, const mlx_array keys,
+                                          const mlx_array values, float scale, const char* mask_mode,
+                                          const mlx_array mask_arr /* may be null */,
+                                          const mlx_array sinks /* may be null */, const mlx_stream s);
+
+/* ---- ops.h: GEMM + glue used by the four callers (line numbers per declaration) ---- */
+int mlx_matmul(mlx_array* res, const mlx_array a, const mlx_array b, const mlx_stream s);                     /* :598 */
+int mlx_addmm(mlx_array* res, const mlx_array c, const mlx_array a, const mlx_array b, float alpha, float beta,
+              const mlx_stream s);                                                                             /* :36  */
+int mlx_add(mlx_array* res, const mlx_array a, const mlx_array b, const mlx_stream s);                        /* :31  */
+int mlx_subtract(mlx_array* res, const mlx_array a, const mlx_array b, const mlx_stream s);                   /* :1080 */
+int mlx_multiply(mlx_array* res, const mlx_array a, const mlx_array b, const mlx_stream s);                   /* :686 */
+int mlx_divide(mlx_array* res, const mlx_array a, const mlx_array b, const mlx_stream s);                     /* :374 */
+int mlx_sigmoid(mlx_array* res, const mlx_array a, const mlx_stream s);                                       /* :956 */
+int mlx_exp(mlx_array* res, const mlx_array a, const mlx_stream s);                                           /* :396 */
+int mlx_negative(mlx_array* res, const mlx_array a, const mlx_stream s);                                      /* :698 */
+int mlx_astype(mlx_array* res, const mlx_array a, mlx_dtype dtype, const mlx_stream s);                       /* :160 */
+int mlx_reshape(mlx_array* res, const mlx_array a, const int* shape, size_t shape_num, const mlx_stream s);   /* :830 */
+int mlx_transpose_axes(mlx_array* res, const mlx_array a, const int* axes, size_t axes_num, const mlx_stream s); /* :1165 */
+int mlx_transpose(mlx_array* res, const mlx_array a, const mlx_stream s);                                     /* :1171 */
+int mlx_expand_dims(mlx_array* res, const mlx_array a, int axis, const mlx_stream s);                         /* :403 */
+int mlx_contiguous(mlx_array* res, const mlx_array a, bool allow_col_major, const mlx_stream s);              /* :220 */
+int mlx_slice(mlx_array* res, const mlx_array a, const int* start, size_t start_num, const int* stop,
+              size_t stop_num, const int* strides, size_t strides_num, const mlx_stream s);                   /* :960 */
+int mlx_slice_update(mlx_array* res, const mlx_array src, const mlx_array update, const int* start,
+                     size_t start_num, const int* stop, size_t stop_num, const int* strides, size_t strides_num,
+                     const mlx_stream s);                                                                      /* :979 (cache.rs:183-188) */
+int mlx_concatenate_axis(mlx_array* res, const mlx_vector_array arrays, int axis, const mlx_stream s);        /* :210 (cache.rs:66-84,152-176) */
+int mlx_zeros(mlx_array* res, const int* shape, size_t shape_num, mlx_dtype dtype, const mlx_stream s);       /* :1220 */
+int mlx_take_axis(mlx_array* res, const mlx_array a, const mlx_array indices, int axis, const mlx_stream s);  /* :1109 (Embedding) */
+int mlx_argmax_axis(mlx_array* res, const mlx_array a, int axis, bool keepdims, const mlx_stream s);          /* :106 (sampler.rs:9-12) */
+int mlx_softmax_axis(mlx_array* res, const mlx_array a, int axis, bool precise, const mlx_stream s);          /* :1005 */
+
+/* ---- native replacements for the two JIT Metal kernels (mlx_fast_metal_kernel_apply, fast.h:156;
+ *      mlx-rs-core/src/metal_kernels.rs:188-236, 260-339): the two Rust call sites switch to these ---- */
+int omx_mlx_fused_swiglu(mlx_array* res, const mlx_array x, const mlx_array gate, const mlx_stream s);
+int omx_mlx_fused_modulate(mlx_array* res, const mlx_array x, const mlx_array shift, const mlx_array scale,
+                           const mlx_stream s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OMX_MLX_C_H */

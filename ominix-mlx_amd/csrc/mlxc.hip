@@ -1,0 +1,863 @@
+// mlx-c compatible handle layer (include/omx_mlx_c.h) over the omx_* kernels.
+//
+// Mirrors the vendored shim mlx-rs/mlx-sys/src/mlx-c/mlx/c/{array,vector,stream,transforms,memory,
+// fast,ops}.cpp in ownership and error behaviour (private/array.h:12-53, error.cpp:12-54), but is
+// EAGER: there is no lazy graph, an op enqueues its kernels on the device stream when called.
+// Arrays are ref-counted device buffers + (shape, strides, offset): reshape / transpose / slice are
+// views, ops that need contiguous data materialise them with a strided-copy kernel.
+#include <string.h>
+
+#include <algorithm>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <vector>
+
+#include "../../include/omx_mlx_c.h"
+#include "common.hpp"
+#include "gemm.hpp"
+
+namespace {
+
+using omx::bf16_t;
+using omx::set_error;
+
+constexpr int kMaxDim = 8;
+hipStream_t g_stream = nullptr;   // one in-order device stream for the whole handle layer
+
+// ---- caching allocator (mlx_clear_cache / mlx_get_{active,peak}_memory) ----
+struct Pool {
+    std::mutex mu;
+    std::multimap<size_t, void*> free_list;
+    size_t active = 0, peak = 0, cached = 0;
+    void* get(size_t bytes) {
+        bytes = (bytes + 511) & ~(size_t)511;
+        if (bytes == 0) bytes = 512;
+        std::lock_guard<std::mutex> lk(mu);
+        auto it = free_list.find(bytes);
+        void* p = nullptr;
+        if (it != free_list.end()) {
+            p = it->second;
+            free_list.erase(it);
+            cached -= bytes;
+        } else if (hipMalloc(&p, bytes) != hipSuccess) {
+            return nullptr;
+        }
+        active += bytes;
+        if (active > peak) peak = active;
+        return p;
+    }
+    void put(void* p, size_t bytes) {
+        bytes = (bytes + 511) & ~(size_t)511;
+        if (bytes == 0) bytes = 512;
+        std::lock_guard<std::mutex> lk(mu);
+        free_list.emplace(bytes, p);
+        active -= bytes;
+        cached += bytes;
+    }
+    void clear() {
+        std::lock_guard<std::mutex> lk(mu);
+        (void)hipStreamSynchronize(g_stream);
+        for (auto& kv : free_list) (void)hipFree(kv.second);
+        free_list.clear();
+        cached = 0;
+    }
+} g_pool;
+
+struct Buf {
+    void* p;
+    size_t bytes;
+    Buf(void* p_, size_t b) : p(p_), bytes(b) {}
+    ~Buf() { if (p) g_pool.put(p, bytes); }
+};
+
+struct Arr {
+    std::shared_ptr<Buf> buf;
+    size_t off = 0;                 // byte offset of element 0
+    std::vector<int> shape;
+    std::vector<size_t> strides;    // in elements
+    mlx_dtype dt = MLX_FLOAT32;
+    std::vector<uint8_t> host;      // mirror handed out by mlx_array_data_*
+    size_t size() const { size_t n = 1; for (int d : shape) n *= (size_t)d; return n; }
+    char* ptr() const { return (char*)buf->p + off; }
+};
+
+size_t dsize(mlx_dtype d) {
+    switch (d) {
+        case MLX_BOOL: case MLX_UINT8: case MLX_INT8: return 1;
+        case MLX_UINT16: case MLX_INT16: case MLX_FLOAT16: case MLX_BFLOAT16: return 2;
+        case MLX_UINT32: case MLX_INT32: case MLX_FLOAT32: return 4;
+        default: return 8;
+    }
+}
+bool is_float(mlx_dtype d) { return d == MLX_FLOAT16 || d == MLX_FLOAT32 || d == MLX_BFLOAT16; }
+
+std::vector<size_t> row_major(const std::vector<int>& shape) {
+    std::vector<size_t> st(shape.size());
+    size_t s = 1;
+    for (int i = (int)shape.size() - 1; i >= 0; --i) { st[i] = s; s *= (size_t)shape[i]; }
+    return st;
+}
+bool is_contig(const Arr& a) {
+    size_t s = 1;
+    for (int i = (int)a.shape.size() - 1; i >= 0; --i) {
+        if (a.shape[i] != 1 && a.strides[i] != s) return false;
+        s *= (size_t)a.shape[i];
+    }
+    return true;
+}
+
+Arr* A(const mlx_array h) { return reinterpret_cast<Arr*>(h.ctx); }
+
+Arr* new_arr(const std::vector<int>& shape, mlx_dtype dt) {
+    Arr* a = new Arr();
+    a->shape = shape;
+    a->strides = row_major(shape);
+    a->dt = dt;
+    const size_t bytes = a->size() * dsize(dt);
+    void* p = g_pool.get(bytes);
+    if (!p) { delete a; return nullptr; }
+    a->buf = std::make_shared<Buf>(p, bytes);
+    return a;
+}
+int assign(mlx_array* res, Arr* n) {
+    if (!res) { delete n; return set_error("null result pointer"); }
+    if (res->ctx) delete A(*res);
+    res->ctx = n;
+    return 0;
+}
+#define NEW_OR_FAIL(var, shape, dt) Arr* var = new_arr(shape, dt); if (!var) return set_error("out of device memory allocating %zu-element array", (size_t)0)
+#define REQ_ARR(h, name) OMX_REQUIRE((h).ctx != nullptr, "%s: empty array handle", name)
+
+// ---- generic strided kernels ----
+struct Idx {
+    int nd;
+    int shape[kMaxDim];
+    long long sa[kMaxDim], sb[kMaxDim];   // element strides of up to two operands (0 = broadcast)
+};
+
+template <int ES>
+__global__ void strided_copy_kernel(char* __restrict__ dst, const char* __restrict__ src, Idx ix, size_t n, bool dst_strided) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        size_t r = i;
+        long long o = 0;
+        for (int d = ix.nd - 1; d >= 0; --d) {
+            const int c = (int)(r % ix.shape[d]);
+            r /= ix.shape[d];
+            o += c * ix.sa[d];
+        }
+        const char* s = dst_strided ? src + i * ES : src + o * ES;
+        char* t = dst_strided ? dst + o * ES : dst + i * ES;
+        if (ES == 1) *t = *s;
+        else if (ES == 2) *(uint16_t*)t = *(const uint16_t*)s;
+        else if (ES == 4) *(uint32_t*)t = *(const uint32_t*)s;
+        else *(uint64_t*)t = *(const uint64_t*)s;
+    }
+}
+
+__device__ __forceinline__ float ld_f(const char* p, int dt, size_t i) {
+    switch (dt) {
+        case MLX_BFLOAT16: return omx::bf16_to_f32(((const bf16_t*)p)[i]);
+        case MLX_FLOAT16: return (float)((const _Float16*)p)[i];
+        case MLX_FLOAT32: return ((const float*)p)[i];
+        case MLX_INT32: return (float)((const int32_t*)p)[i];
+        case MLX_UINT32: return (float)((const uint32_t*)p)[i];
+        case MLX_BOOL: case MLX_UINT8: return (float)((const uint8_t*)p)[i];
+        default: return 0.f;
+    }
+}
+__device__ __forceinline__ void st_f(char* p, int dt, size_t i, float v) {
+    switch (dt) {
+        case MLX_BFLOAT16: ((bf16_t*)p)[i] = omx::f32_to_bf16(v); break;
+        case MLX_FLOAT16: ((_Float16*)p)[i] = (_Float16)v; break;
+        case MLX_FLOAT32: ((float*)p)[i] = v; break;
+        case MLX_INT32: ((int32_t*)p)[i] = (int32_t)v; break;
+        case MLX_UINT32: ((uint32_t*)p)[i] = (uint32_t)v; break;
+        case MLX_BOOL: ((uint8_t*)p)[i] = v != 0.f; break;
+        case MLX_UINT8: ((uint8_t*)p)[i] = (uint8_t)v; break;
+        default: break;
+    }
+}
+
+enum { OP_ADD, OP_SUB, OP_MUL, OP_DIV, OP_SIGMOID, OP_EXP, OP_NEG, OP_CAST };
+
+__global__ void binary_kernel(char* out, int odt, const char* a, int adt, const char* b, int bdt, Idx ix, size_t n, int op) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        size_t r = i;
+        long long oa = 0, ob = 0;
+        for (int d = ix.nd - 1; d >= 0; --d) {
+            const int c = (int)(r % ix.shape[d]);
+            r /= ix.shape[d];
+            oa += c * ix.sa[d];
+            ob += c * ix.sb[d];
+        }
+        const float x = ld_f(a, adt, oa), y = ld_f(b, bdt, ob);
+        float v;
+        switch (op) {
+            case OP_ADD: v = x + y; break;
+            case OP_SUB: v = x - y; break;
+            case OP_MUL: v = x * y; break;
+            default: v = x / y; break;
+        }
+        st_f(out, odt, i, v);
+    }
+}
+__global__ void unary_kernel(char* out, int odt, const char* a, int adt, Idx ix, size_t n, int op) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        size_t r = i;
+        long long oa = 0;
+        for (int d = ix.nd - 1; d >= 0; --d) {
+            const int c = (int)(r % ix.shape[d]);
+            r /= ix.shape[d];
+            oa += c * ix.sa[d];
+        }
+        const float x = ld_f(a, adt, oa);
+        float v;
+        switch (op) {
+            case OP_SIGMOID: v = 1.0f / (1.0f + expf(-x)); break;
+            case OP_EXP: v = expf(x); break;
+            case OP_NEG: v = -x; break;
+            default: v = x; break;
+        }
+        st_f(out, odt, i, v);
+    }
+}
+// softmax over the last axis of a contiguous [rows, n]; one wave per row, fp32 inside (precise)
+__global__ __launch_bounds__(256) void softmax_kernel(char* out, const char* in, int dt, size_t rows, int n) {
+    const size_t row = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    float mx = -INFINITY;
+    for (int i = lane; i < n; i += 64) mx = fmaxf(mx, ld_f(in, dt, row * n + i));
+    mx = omx::wave_max(mx);
+    float s = 0.f;
+    for (int i = lane; i < n; i += 64) s += expf(ld_f(in, dt, row * n + i) - mx);
+    s = omx::wave_sum(s);
+    for (int i = lane; i < n; i += 64) st_f(out, dt, row * n + i, expf(ld_f(in, dt, row * n + i) - mx) / s);
+}
+
+unsigned grid_for(size_t n) { size_t b = (n + 255) / 256; return (unsigned)(b < 1 ? 1 : (b > 8192 ? 8192 : b)); }
+
+int fill_idx(Idx& ix, const std::vector<int>& shape) {
+    OMX_REQUIRE(shape.size() <= (size_t)kMaxDim, "arrays of more than %d dimensions are not supported", kMaxDim);
+    ix.nd = (int)shape.size();
+    for (int i = 0; i < ix.nd; ++i) { ix.shape[i] = shape[i]; ix.sa[i] = ix.sb[i] = 0; }
+    return 0;
+}
+
+// materialise a view as a fresh row-major array
+int contiguous(const Arr& a, Arr** out) {
+    NEW_OR_FAIL(r, a.shape, a.dt);
+    const size_t n = a.size();
+    if (n) {
+        if (is_contig(a)) {
+            OMX_HIP_CHECK(hipMemcpyAsync(r->ptr(), a.ptr(), n * dsize(a.dt), hipMemcpyDeviceToDevice, g_stream));
+        } else {
+            Idx ix;
+            if (fill_idx(ix, a.shape)) { delete r; return 1; }
+            for (int i = 0; i < ix.nd; ++i) ix.sa[i] = (long long)a.strides[i];
+            switch (dsize(a.dt)) {
+                case 1: strided_copy_kernel<1><<<grid_for(n), 256, 0, g_stream>>>(r->ptr(), a.ptr(), ix, n, false); break;
+                case 2: strided_copy_kernel<2><<<grid_for(n), 256, 0, g_stream>>>(r->ptr(), a.ptr(), ix, n, false); break;
+                case 4: strided_copy_kernel<4><<<grid_for(n), 256, 0, g_stream>>>(r->ptr(), a.ptr(), ix, n, false); break;
+                default: strided_copy_kernel<8><<<grid_for(n), 256, 0, g_stream>>>(r->ptr(), a.ptr(), ix, n, false); break;
+            }
+            OMX_LAUNCH_CHECK();
+        }
+    }
+    *out = r;
+    return 0;
+}
+// contiguous view holder: either aliases `a` or owns a materialised copy
+struct Contig {
+    const Arr* a = nullptr;
+    Arr* owned = nullptr;
+    ~Contig() { delete owned; }
+    int init(const Arr& src) {
+        if (is_contig(src)) { a = &src; return 0; }
+        if (contiguous(src, &owned)) return 1;
+        a = owned;
+        return 0;
+    }
+};
+// scatter a contiguous array into a strided region of dst (slice_update / concatenate)
+int scatter_into(char* dst_base, const std::vector<size_t>& dst_strides, const Arr& src_contig, mlx_dtype dt) {
+    const size_t n = src_contig.size();
+    if (!n) return 0;
+    Idx ix;
+    if (fill_idx(ix, src_contig.shape)) return 1;
+    for (int i = 0; i < ix.nd; ++i) ix.sa[i] = (long long)dst_strides[i];
+    switch (dsize(dt)) {
+        case 1: strided_copy_kernel<1><<<grid_for(n), 256, 0, g_stream>>>(dst_base, src_contig.ptr(), ix, n, true); break;
+        case 2: strided_copy_kernel<2><<<grid_for(n), 256, 0, g_stream>>>(dst_base, src_contig.ptr(), ix, n, true); break;
+        case 4: strided_copy_kernel<4><<<grid_for(n), 256, 0, g_stream>>>(dst_base, src_contig.ptr(), ix, n, true); break;
+        default: strided_copy_kernel<8><<<grid_for(n), 256, 0, g_stream>>>(dst_base, src_contig.ptr(), ix, n, true); break;
+    }
+    OMX_LAUNCH_CHECK();
+    return 0;
+}
+
+mlx_dtype promote(mlx_dtype a, mlx_dtype b) {
+    if (a == b) return a;
+    if (is_float(a) && !is_float(b)) return a;
+    if (is_float(b) && !is_float(a)) return b;
+    if (is_float(a) && is_float(b)) return MLX_FLOAT32;   // bf16 x f16, half x f32
+    return dsize(a) >= dsize(b) ? a : b;
+}
+
+int binary(mlx_array* res, const mlx_array ha, const mlx_array hb, int op, const char* name) {
+    REQ_ARR(ha, name); REQ_ARR(hb, name);
+    const Arr &a = *A(ha), &b = *A(hb);
+    const int nd = (int)std::max(a.shape.size(), b.shape.size());
+    std::vector<int> shape(nd);
+    Idx ix;
+    if (fill_idx(ix, shape)) return 1;
+    for (int i = 0; i < nd; ++i) {
+        const int ia = i - (nd - (int)a.shape.size()), ib = i - (nd - (int)b.shape.size());
+        const int da = ia >= 0 ? a.shape[ia] : 1, db = ib >= 0 ? b.shape[ib] : 1;
+        OMX_REQUIRE(da == db || da == 1 || db == 1, "%s: shapes are not broadcastable (dim %d: %d vs %d)", name, i, da, db);
+        shape[i] = da == 1 ? db : da;
+        ix.shape[i] = shape[i];
+        ix.sa[i] = (ia >= 0 && da != 1) ? (long long)a.strides[ia] : 0;
+        ix.sb[i] = (ib >= 0 && db != 1) ? (long long)b.strides[ib] : 0;
+    }
+    const mlx_dtype odt = promote(a.dt, b.dt);
+    NEW_OR_FAIL(r, shape, odt);
+    const size_t n = r->size();
+    if (n) {
+        binary_kernel<<<grid_for(n), 256, 0, g_stream>>>(r->ptr(), odt, a.ptr(), a.dt, b.ptr(), b.dt, ix, n, op);
+        OMX_LAUNCH_CHECK();
+    }
+    return assign(res, r);
+}
+int unary(mlx_array* res, const mlx_array ha, int op, mlx_dtype odt, const char* name) {
+    REQ_ARR(ha, name);
+    const Arr& a = *A(ha);
+    NEW_OR_FAIL(r, a.shape, odt);
+    Idx ix;
+    if (fill_idx(ix, a.shape)) { delete r; return 1; }
+    for (int i = 0; i < ix.nd; ++i) ix.sa[i] = (long long)a.strides[i];
+    const size_t n = r->size();
+    if (n) {
+        unary_kernel<<<grid_for(n), 256, 0, g_stream>>>(r->ptr(), odt, a.ptr(), a.dt, ix, n, op);
+        OMX_LAUNCH_CHECK();
+    }
+    return assign(res, r);
+}
+int norm_axis(int axis, int nd, const char* name, int* out) {
+    const int ax = axis < 0 ? axis + nd : axis;
+    OMX_REQUIRE(ax >= 0 && ax < nd, "%s: axis %d out of range for %d dimensions", name, axis, nd);
+    *out = ax;
+    return 0;
+}
+omx_dtype to_omx(mlx_dtype d) { return (omx_dtype)(int)d; }
+
+int item_host(const mlx_array h, void* dst, mlx_dtype want, const char* name) {
+    REQ_ARR(h, name);
+    const Arr& a = *A(h);
+    OMX_REQUIRE(a.size() == 1, "%s: item() needs a size-1 array (size %zu)", name, a.size());
+    OMX_REQUIRE(a.dt == want || dsize(a.dt) == dsize(want), "%s: dtype mismatch", name);
+    OMX_HIP_CHECK(hipMemcpyAsync(dst, a.ptr(), dsize(a.dt), hipMemcpyDeviceToHost, g_stream));
+    OMX_HIP_CHECK(hipStreamSynchronize(g_stream));
+    return 0;
+}
+const void* data_host(const mlx_array h) {
+    if (!h.ctx) return nullptr;
+    Arr* a = A(h);
+    Contig c;
+    if (c.init(*a)) return nullptr;
+    const size_t bytes = a->size() * dsize(a->dt);
+    a->host.resize(bytes ? bytes : 1);
+    if (bytes) {
+        if (hipMemcpyAsync(a->host.data(), c.a->ptr(), bytes, hipMemcpyDeviceToHost, g_stream) != hipSuccess) return nullptr;
+    }
+    if (hipStreamSynchronize(g_stream) != hipSuccess) return nullptr;
+    return a->host.data();
+}
+
+struct Vec { std::vector<Arr*> v; ~Vec() { for (Arr* a : v) delete a; } };
+struct Str { bool cpu; };
+
+}  // namespace
+
+extern "C" {
+
+void mlx_set_error_handler(mlx_error_handler_func handler, void* data, void (*dtor)(void*)) {
+    omx_set_error_handler(handler, data, dtor);
+}
+
+size_t mlx_dtype_size(mlx_dtype dtype) { return dsize(dtype); }
+mlx_array mlx_array_new(void) { return mlx_array{nullptr}; }
+int mlx_array_free(mlx_array arr) { delete A(arr); return 0; }
+
+static mlx_array scalar(const void* v, mlx_dtype dt) {
+    int shape0 = 0;
+    return mlx_array_new_data(v, &shape0, 0, dt);
+}
+mlx_array mlx_array_new_bool(bool val) { uint8_t v = val; return scalar(&v, MLX_BOOL); }
+mlx_array mlx_array_new_int(int val) { int32_t v = val; return scalar(&v, MLX_INT32); }
+mlx_array mlx_array_new_float32(float val) { return scalar(&val, MLX_FLOAT32); }
+mlx_array mlx_array_new_float(float val) { return scalar(&val, MLX_FLOAT32); }
+
+mlx_array mlx_array_new_data(const void* data, const int* shape, int dim, mlx_dtype dtype) {
+    std::vector<int> sh(shape, shape + (dim > 0 ? dim : 0));
+    Arr* a = new_arr(sh, dtype);
+    if (!a) { set_error("mlx_array_new_data: out of device memory"); return mlx_array{nullptr}; }
+    const size_t bytes = a->size() * dsize(dtype);
+    if (bytes && data) {
+        // pageable host memory: hipMemcpyAsync stages it before returning, so `data` may be released
+        if (hipMemcpyAsync(a->ptr(), data, bytes, hipMemcpyHostToDevice, g_stream) != hipSuccess ||
+            hipStreamSynchronize(g_stream) != hipSuccess) {
+            delete a;
+            set_error("mlx_array_new_data: host to device copy failed");
+            return mlx_array{nullptr};
+        }
+    }
+    return mlx_array{a};
+}
+int mlx_array_set(mlx_array* arr, const mlx_array src) {
+    OMX_REQUIRE(arr != nullptr, "mlx_array_set: null destination");
+    Arr* n = src.ctx ? new Arr(*A(src)) : nullptr;   // shares the buffer (ref-counted), like mlx::core::array copy
+    if (n) n->host.clear();
+    if (arr->ctx) delete A(*arr);
+    arr->ctx = n;
+    return 0;
+}
+size_t mlx_array_itemsize(const mlx_array arr) { return arr.ctx ? dsize(A(arr)->dt) : 0; }
+size_t mlx_array_size(const mlx_array arr) { return arr.ctx ? A(arr)->size() : 0; }
+size_t mlx_array_nbytes(const mlx_array arr) { return arr.ctx ? A(arr)->size() * dsize(A(arr)->dt) : 0; }
+size_t mlx_array_ndim(const mlx_array arr) { return arr.ctx ? A(arr)->shape.size() : 0; }
+const int* mlx_array_shape(const mlx_array arr) { return arr.ctx ? A(arr)->shape.data() : nullptr; }
+const size_t* mlx_array_strides(const mlx_array arr) { return arr.ctx ? A(arr)->strides.data() : nullptr; }
+int mlx_array_dim(const mlx_array arr, int dim) {
+    if (!arr.ctx) return 0;
+    const int nd = (int)A(arr)->shape.size();
+    const int d = dim < 0 ? dim + nd : dim;
+    return (d >= 0 && d < nd) ? A(arr)->shape[d] : 0;
+}
+mlx_dtype mlx_array_dtype(const mlx_array arr) { return arr.ctx ? A(arr)->dt : MLX_FLOAT32; }
+int mlx_array_eval(mlx_array arr) {
+    REQ_ARR(arr, "mlx_array_eval");
+    OMX_HIP_CHECK(hipStreamSynchronize(g_stream));
+    return 0;
+}
+int mlx_array_item_bool(bool* res, const mlx_array arr) { uint8_t v = 0; if (item_host(arr, &v, MLX_BOOL, "mlx_array_item_bool")) return 1; *res = v != 0; return 0; }
+int mlx_array_item_uint32(uint32_t* res, const mlx_array arr) { return item_host(arr, res, MLX_UINT32, "mlx_array_item_uint32"); }
+int mlx_array_item_int32(int32_t* res, const mlx_array arr) { return item_host(arr, res, MLX_INT32, "mlx_array_item_int32"); }
+int mlx_array_item_float32(float* res, const mlx_array arr) { return item_host(arr, res, MLX_FLOAT32, "mlx_array_item_float32"); }
+const uint8_t* mlx_array_data_uint8(const mlx_array arr) { return (const uint8_t*)data_host(arr); }
+const uint16_t* mlx_array_data_uint16(const mlx_array arr) { return (const uint16_t*)data_host(arr); }
+const uint32_t* mlx_array_data_uint32(const mlx_array arr) { return (const uint32_t*)data_host(arr); }
+const int32_t* mlx_array_data_int32(const mlx_array arr) { return (const int32_t*)data_host(arr); }
+const float* mlx_array_data_float32(const mlx_array arr) { return (const float*)data_host(arr); }
+const uint16_t* mlx_array_data_bfloat16(const mlx_array arr) { return (const uint16_t*)data_host(arr); }
+
+mlx_vector_array mlx_vector_array_new(void) { return mlx_vector_array{new Vec()}; }
+int mlx_vector_array_free(mlx_vector_array vec) { delete reinterpret_cast<Vec*>(vec.ctx); return 0; }
+int mlx_vector_array_append_value(mlx_vector_array vec, const mlx_array val) {
+    OMX_REQUIRE(vec.ctx && val.ctx, "mlx_vector_array_append_value: empty handle");
+    Arr* c = new Arr(*A(val));
+    c->host.clear();
+    reinterpret_cast<Vec*>(vec.ctx)->v.push_back(c);
+    return 0;
+}
+size_t mlx_vector_array_size(mlx_vector_array vec) { return vec.ctx ? reinterpret_cast<Vec*>(vec.ctx)->v.size() : 0; }
+int mlx_vector_array_get(mlx_array* res, const mlx_vector_array vec, size_t idx) {
+    OMX_REQUIRE(vec.ctx, "mlx_vector_array_get: empty vector");
+    Vec* v = reinterpret_cast<Vec*>(vec.ctx);
+    OMX_REQUIRE(idx < v->v.size(), "mlx_vector_array_get: index %zu out of range (size %zu)", idx, v->v.size());
+    return mlx_array_set(res, mlx_array{v->v[idx]});
+}
+
+mlx_stream mlx_stream_new(void) { return mlx_stream{new Str{false}}; }
+int mlx_stream_free(mlx_stream stream) { delete reinterpret_cast<Str*>(stream.ctx); return 0; }
+bool mlx_stream_equal(mlx_stream lhs, mlx_stream rhs) {
+    if (!lhs.ctx || !rhs.ctx) return lhs.ctx == rhs.ctx;
+    return reinterpret_cast<Str*>(lhs.ctx)->cpu == reinterpret_cast<Str*>(rhs.ctx)->cpu;
+}
+int mlx_synchronize(mlx_stream) { OMX_HIP_CHECK(hipStreamSynchronize(g_stream)); return 0; }
+mlx_stream mlx_default_cpu_stream_new(void) {
+    set_error("mlx_default_cpu_stream_new: libomx_hip has no CPU backend (MI355X only)");
+    return mlx_stream{nullptr};
+}
+mlx_stream mlx_default_gpu_stream_new(void) { return mlx_stream{new Str{false}}; }
+int mlx_async_eval(const mlx_vector_array) { return 0; }   // eager: the work is already enqueued
+int mlx_eval(const mlx_vector_array) { OMX_HIP_CHECK(hipStreamSynchronize(g_stream)); return 0; }
+int mlx_clear_cache(void) { g_pool.clear(); return 0; }
+int mlx_get_active_memory(size_t* res) { OMX_REQUIRE(res, "null result"); *res = g_pool.active; return 0; }
+int mlx_get_peak_memory(size_t* res) { OMX_REQUIRE(res, "null result"); *res = g_pool.peak; return 0; }
+
+// ---- fused hot-path ops ----
+int mlx_fast_rms_norm(mlx_array* res, const mlx_array x, const mlx_array weight, float eps, const mlx_stream) {
+    REQ_ARR(x, "mlx_fast_rms_norm");
+    Contig cx, cw;
+    if (cx.init(*A(x))) return 1;
+    OMX_REQUIRE(!cx.a->shape.empty(), "mlx_fast_rms_norm: input must have at least 1 dimension");
+    const int dim = cx.a->shape.back();
+    if (weight.ctx) {
+        if (cw.init(*A(weight))) return 1;
+        OMX_REQUIRE(cw.a->shape.size() == 1 && cw.a->shape[0] == dim && cw.a->dt == cx.a->dt,
+                    "mlx_fast_rms_norm: weight must be 1-D of size %d and of the input dtype", dim);
+    }
+    NEW_OR_FAIL(r, cx.a->shape, cx.a->dt);
+    if (omx_rms_norm(r->ptr(), cx.a->ptr(), weight.ctx ? cw.a->ptr() : nullptr, dim ? (int64_t)(r->size() / dim) : 0, dim,
+                     eps, to_omx(r->dt), g_stream)) { delete r; return 1; }
+    return assign(res, r);
+}
+int mlx_fast_layer_norm(mlx_array* res, const mlx_array x, const mlx_array weight, const mlx_array bias, float eps,
+                        const mlx_stream) {
+    REQ_ARR(x, "mlx_fast_layer_norm");
+    Contig cx, cw, cb;
+    if (cx.init(*A(x))) return 1;
+    OMX_REQUIRE(!cx.a->shape.empty(), "mlx_fast_layer_norm: input must have at least 1 dimension");
+    const int dim = cx.a->shape.back();
+    if (weight.ctx && cw.init(*A(weight))) return 1;
+    if (bias.ctx && cb.init(*A(bias))) return 1;
+    NEW_OR_FAIL(r, cx.a->shape, cx.a->dt);
+    if (omx_layer_norm(r->ptr(), cx.a->ptr(), weight.ctx ? cw.a->ptr() : nullptr, bias.ctx ? cb.a->ptr() : nullptr,
+                       dim ? (int64_t)(r->size() / dim) : 0, dim, eps, to_omx(r->dt), g_stream)) { delete r; return 1; }
+    return assign(res, r);
+}
+int mlx_fast_rope(mlx_array* res, const mlx_array x, int dims, bool traditional, mlx_optional_float base, float scale,
+                  int offset, const mlx_array freqs, const mlx_stream) {
+    REQ_ARR(x, "mlx_fast_rope");
+    OMX_REQUIRE(!freqs.ctx, "mlx_fast_rope: custom `freqs` are not supported (the hot path passes none, fast.rs:40-42)");
+    OMX_REQUIRE(base.has_value, "mlx_fast_rope: `base` is required when `freqs` is absent");
+    Contig cx;
+    if (cx.init(*A(x))) return 1;
+    const int nd = (int)cx.a->shape.size();
+    OMX_REQUIRE(nd >= 2, "mlx_fast_rope: input must have at least 2 dimensions");   // same check as MLX core
+    const int T = cx.a->shape[nd - 2], D = cx.a->shape[nd - 1];
+    NEW_OR_FAIL(r, cx.a->shape, cx.a->dt);
+    const int64_t batch = (T && D) ? (int64_t)(r->size() / ((size_t)T * D)) : 0;
+    if (omx_rope(r->ptr(), cx.a->ptr(), batch, T, D, dims, traditional, base.value, scale, offset, to_omx(r->dt), g_stream)) {
+        delete r;
+        return 1;
+    }
+    return assign(res, r);
+}
+int mlx_fast_scaled_dot_product_attention(mlx_array* res, const mlx_array queries, const mlx_array keys,
+                                          const mlx_array values, float scale, const char* mask_mode,
+                                          const mlx_array mask_arr, const mlx_array sinks, const mlx_stream) {
+    REQ_ARR(queries, "mlx_fast_scaled_dot_product_attention");
+    REQ_ARR(keys, "mlx_fast_scaled_dot_product_attention");
+    REQ_ARR(values, "mlx_fast_scaled_dot_product_attention");
+    OMX_REQUIRE(!sinks.ctx, "mlx_fast_scaled_dot_product_attention: attention sinks are not supported");
+    const Arr &q0 = *A(queries), &k0 = *A(keys), &v0 = *A(values);
+    OMX_REQUIRE(q0.shape.size() == 4 && k0.shape.size() == 4 && v0.shape.size() == 4,
+                "mlx_fast_scaled_dot_product_attention: queries, keys, values must be 4-D [B, H, T, D]");
+    OMX_REQUIRE(k0.shape == v0.shape && q0.shape[0] == k0.shape[0] && q0.shape[3] == k0.shape[3],
+                "mlx_fast_scaled_dot_product_attention: incompatible shapes");
+    OMX_REQUIRE(q0.dt == k0.dt && q0.dt == v0.dt, "mlx_fast_scaled_dot_product_attention: dtype mismatch");
+    const int B = q0.shape[0], H = q0.shape[1], Tq = q0.shape[2], D = q0.shape[3], Hkv = k0.shape[1], Tk = k0.shape[2];
+    Contig cq, ck, cv, cm;
+    if (cq.init(q0)) return 1;
+    // K/V: the [.., :offset, :] views of the step-256 cache buffers are consumed in place (cache.rs:190-193)
+    const Arr *k = &k0, *v = &v0;
+    auto kv_ok = [&](const Arr& t) { return t.strides[3] == 1 && (t.strides[2] == (size_t)D || Tk == 1); };
+    if (!kv_ok(k0) || !kv_ok(v0) || k0.strides[0] != v0.strides[0] || k0.strides[1] != v0.strides[1]) {
+        if (ck.init(k0) || cv.init(v0)) return 1;   // row-major copies (or aliases when already contiguous)
+        k = ck.a;
+        v = cv.a;
+    }
+    int mode = OMX_MASK_NONE;
+    const void* mptr = nullptr;
+    const bool causal = mask_mode && strcmp(mask_mode, "causal") == 0;
+    OMX_REQUIRE(!mask_mode || mask_mode[0] == 0 || causal || strcmp(mask_mode, "array") == 0,
+                "mlx_fast_scaled_dot_product_attention: Invalid mask mode '%s'", mask_mode);
+    if (causal) {
+        mode = OMX_MASK_CAUSAL;
+    } else if (mask_arr.ctx) {
+        if (cm.init(*A(mask_arr))) return 1;
+        OMX_REQUIRE(cm.a->size() == (size_t)Tq * Tk, "mlx_fast_scaled_dot_product_attention: mask must broadcast from [Tq=%d, Tk=%d]", Tq, Tk);
+        if (cm.a->dt == MLX_BOOL) mode = OMX_MASK_BOOL;
+        else {
+            OMX_REQUIRE(cm.a->dt == q0.dt, "mlx_fast_scaled_dot_product_attention: additive mask must have the query dtype");
+            mode = OMX_MASK_ADDITIVE;
+        }
+        mptr = cm.a->ptr();
+    }
+    NEW_OR_FAIL(r, q0.shape, q0.dt);
+    if (omx_sdpa(r->ptr(), cq.a->ptr(), k->ptr(), v->ptr(), B, H, Hkv, Tq, Tk, D, (int64_t)k->strides[0], (int64_t)k->strides[1],
+                 scale, mode, mptr, to_omx(q0.dt), g_stream)) { delete r; return 1; }
+    return assign(res, r);
+}
+
+// ---- GEMM ----
+static int matmul_impl(mlx_array* res, const mlx_array ha, const mlx_array hb, const Arr* bias, const char* name) {
+    REQ_ARR(ha, name); REQ_ARR(hb, name);
+    const Arr &a0 = *A(ha), &b0 = *A(hb);
+    OMX_REQUIRE(a0.shape.size() >= 1 && b0.shape.size() == 2, "%s: supported form is a[..., K] @ b[K, N] (b 2-D)", name);
+    const int K = a0.shape.back(), N = b0.shape[1];
+    OMX_REQUIRE(b0.shape[0] == K, "%s: inner dimensions differ (%d vs %d)", name, K, b0.shape[0]);
+    OMX_REQUIRE(a0.dt == b0.dt, "%s: dtype mismatch", name);
+    Contig ca;
+    if (ca.init(a0)) return 1;
+    // nn::Linear passes w.t(): a [N,K] row-major weight seen as [K,N] with strides (1, K) -- the NT operand
+    const Arr* w = nullptr;
+    Arr* wt = nullptr;
+    Arr view;
+    if (b0.strides[0] == 1 && b0.strides[1] == (size_t)K) {
+        w = &b0;
+    } else {   // materialise b^T as [N, K]
+        view = b0;
+        view.shape = {N, K};
+        view.strides = {b0.strides[1], b0.strides[0]};
+        if (contiguous(view, &wt)) return 1;
+        w = wt;
+    }
+    std::vector<int> oshape(a0.shape.begin(), a0.shape.end() - 1);
+    oshape.push_back(N);
+    Arr* r = new_arr(oshape, a0.dt);
+    if (!r) { delete wt; return set_error("%s: out of device memory", name); }
+    const int M = K ? (int)(ca.a->size() / K) : 0;
+    const int rc = omx_linear(r->ptr(), ca.a->ptr(), w->ptr(), bias ? bias->ptr() : nullptr, M, N, K, to_omx(a0.dt), g_stream);
+    delete wt;
+    if (rc) { delete r; return 1; }
+    return assign(res, r);
+}
+int mlx_matmul(mlx_array* res, const mlx_array a, const mlx_array b, const mlx_stream) {
+    return matmul_impl(res, a, b, nullptr, "mlx_matmul");
+}
+int mlx_addmm(mlx_array* res, const mlx_array c, const mlx_array a, const mlx_array b, float alpha, float beta,
+              const mlx_stream) {
+    REQ_ARR(c, "mlx_addmm");
+    OMX_REQUIRE(alpha == 1.0f && beta == 1.0f, "mlx_addmm: only alpha = beta = 1 (nn::Linear, linear.rs:88-90) is supported");
+    Contig cc;
+    if (cc.init(*A(c))) return 1;
+    OMX_REQUIRE(b.ctx && A(b)->shape.size() == 2 && cc.a->size() == (size_t)A(b)->shape[1],
+                "mlx_addmm: c must be a bias of size N");
+    return matmul_impl(res, a, b, cc.a, "mlx_addmm");
+}
+
+// ---- elementwise ----
+int mlx_add(mlx_array* res, const mlx_array a, const mlx_array b, const mlx_stream) { return binary(res, a, b, OP_ADD, "mlx_add"); }
+int mlx_subtract(mlx_array* res, const mlx_array a, const mlx_array b, const mlx_stream) { return binary(res, a, b, OP_SUB, "mlx_subtract"); }
+int mlx_multiply(mlx_array* res, const mlx_array a, const mlx_array b, const mlx_stream) { return binary(res, a, b, OP_MUL, "mlx_multiply"); }
+int mlx_divide(mlx_array* res, const mlx_array a, const mlx_array b, const mlx_stream) { return binary(res, a, b, OP_DIV, "mlx_divide"); }
+int mlx_sigmoid(mlx_array* res, const mlx_array a, const mlx_stream) { return unary(res, a, OP_SIGMOID, a.ctx ? A(a)->dt : MLX_FLOAT32, "mlx_sigmoid"); }
+int mlx_exp(mlx_array* res, const mlx_array a, const mlx_stream) { return unary(res, a, OP_EXP, a.ctx ? A(a)->dt : MLX_FLOAT32, "mlx_exp"); }
+int mlx_negative(mlx_array* res, const mlx_array a, const mlx_stream) { return unary(res, a, OP_NEG, a.ctx ? A(a)->dt : MLX_FLOAT32, "mlx_negative"); }
+int mlx_astype(mlx_array* res, const mlx_array a, mlx_dtype dtype, const mlx_stream) { return unary(res, a, OP_CAST, dtype, "mlx_astype"); }
+
+// ---- shape ops (views where possible) ----
+int mlx_reshape(mlx_array* res, const mlx_array a, const int* shape, size_t shape_num, const mlx_stream) {
+    REQ_ARR(a, "mlx_reshape");
+    const Arr& s = *A(a);
+    std::vector<int> sh(shape, shape + shape_num);
+    size_t known = 1;
+    int infer = -1;
+    for (size_t i = 0; i < sh.size(); ++i) {
+        if (sh[i] == -1) { OMX_REQUIRE(infer < 0, "mlx_reshape: can only infer one dimension"); infer = (int)i; }
+        else known *= (size_t)sh[i];
+    }
+    if (infer >= 0) {
+        OMX_REQUIRE(known != 0 && s.size() % known == 0, "mlx_reshape: cannot infer the missing dimension");
+        sh[infer] = (int)(s.size() / known);
+        known *= (size_t)sh[infer];
+    }
+    OMX_REQUIRE(known == s.size(), "mlx_reshape: cannot reshape array of size %zu into the requested shape", s.size());
+    Arr* r = nullptr;
+    if (is_contig(s)) r = new Arr(s); else if (contiguous(s, &r)) return 1;
+    r->host.clear();
+    r->shape = sh;
+    r->strides = row_major(sh);
+    return assign(res, r);
+}
+int mlx_transpose_axes(mlx_array* res, const mlx_array a, const int* axes, size_t axes_num, const mlx_stream) {
+    REQ_ARR(a, "mlx_transpose_axes");
+    const Arr& s = *A(a);
+    OMX_REQUIRE(axes_num == s.shape.size(), "mlx_transpose_axes: expected %zu axes, got %zu", s.shape.size(), axes_num);
+    Arr* r = new Arr(s);
+    r->host.clear();
+    std::vector<bool> seen(axes_num, false);
+    for (size_t i = 0; i < axes_num; ++i) {
+        int ax;
+        if (norm_axis(axes[i], (int)axes_num, "mlx_transpose_axes", &ax)) { delete r; return 1; }
+        if (seen[ax]) { delete r; return set_error("mlx_transpose_axes: repeated axis %d", ax); }
+        seen[ax] = true;
+        r->shape[i] = s.shape[ax];
+        r->strides[i] = s.strides[ax];
+    }
+    return assign(res, r);
+}
+int mlx_transpose(mlx_array* res, const mlx_array a, const mlx_stream s) {
+    REQ_ARR(a, "mlx_transpose");
+    const int nd = (int)A(a)->shape.size();
+    std::vector<int> axes(nd);
+    for (int i = 0; i < nd; ++i) axes[i] = nd - 1 - i;
+    return mlx_transpose_axes(res, a, axes.data(), axes.size(), s);
+}
+int mlx_expand_dims(mlx_array* res, const mlx_array a, int axis, const mlx_stream) {
+    REQ_ARR(a, "mlx_expand_dims");
+    const Arr& s = *A(a);
+    int ax;
+    if (norm_axis(axis, (int)s.shape.size() + 1, "mlx_expand_dims", &ax)) return 1;
+    Arr* r = new Arr(s);
+    r->host.clear();
+    r->shape.insert(r->shape.begin() + ax, 1);
+    r->strides.insert(r->strides.begin() + ax, ax < (int)s.shape.size() ? s.strides[ax] * (size_t)s.shape[ax] : 1);
+    return assign(res, r);
+}
+int mlx_contiguous(mlx_array* res, const mlx_array a, bool, const mlx_stream) {
+    REQ_ARR(a, "mlx_contiguous");
+    Arr* r = nullptr;
+    if (is_contig(*A(a))) { r = new Arr(*A(a)); r->host.clear(); }
+    else if (contiguous(*A(a), &r)) return 1;
+    return assign(res, r);
+}
+static int slice_view(const Arr& s, const int* start, size_t ns, const int* stop, size_t ne, const int* strides, size_t nst,
+                      const char* name, Arr* view) {
+    const size_t nd = s.shape.size();
+    OMX_REQUIRE(ns == nd && ne == nd && (nst == nd || nst == 0), "%s: start/stop/strides must have one entry per dimension (%zu)", name, nd);
+    *view = s;
+    view->host.clear();
+    for (size_t i = 0; i < nd; ++i) {
+        const int st = nst ? strides[i] : 1;
+        OMX_REQUIRE(st >= 1, "%s: only positive strides are supported", name);
+        int b = start[i] < 0 ? start[i] + s.shape[i] : start[i];
+        int e = stop[i] < 0 ? stop[i] + s.shape[i] : stop[i];
+        b = b < 0 ? 0 : (b > s.shape[i] ? s.shape[i] : b);
+        e = e < b ? b : (e > s.shape[i] ? s.shape[i] : e);
+        view->off += (size_t)b * s.strides[i] * dsize(s.dt);
+        view->shape[i] = (e - b + st - 1) / st;
+        view->strides[i] = s.strides[i] * (size_t)st;
+    }
+    return 0;
+}
+int mlx_slice(mlx_array* res, const mlx_array a, const int* start, size_t start_num, const int* stop, size_t stop_num,
+              const int* strides, size_t strides_num, const mlx_stream) {
+    REQ_ARR(a, "mlx_slice");
+    Arr* r = new Arr();
+    if (slice_view(*A(a), start, start_num, stop, stop_num, strides, strides_num, "mlx_slice", r)) { delete r; return 1; }
+    return assign(res, r);
+}
+int mlx_slice_update(mlx_array* res, const mlx_array src, const mlx_array update, const int* start, size_t start_num,
+                     const int* stop, size_t stop_num, const int* strides, size_t strides_num, const mlx_stream) {
+    REQ_ARR(src, "mlx_slice_update"); REQ_ARR(update, "mlx_slice_update");
+    const Arr& s = *A(src);
+    OMX_REQUIRE(s.dt == A(update)->dt, "mlx_slice_update: dtype mismatch");
+    // Functional semantics: the result is a new array.  When `src` is the only owner of a contiguous
+    // buffer (the KVCache pattern `k = k.slice_update(..)`, cache.rs:183-188) the update is done in place
+    // and the buffer is shared with the result, which is what MLX's buffer donation achieves.
+    Arr* r = nullptr;
+    if (is_contig(s) && s.buf.use_count() == 1 && (!res || res->ctx != src.ctx || true)) {
+        r = new Arr(s);
+        r->host.clear();
+    } else if (contiguous(s, &r)) {
+        return 1;
+    }
+    Arr region;
+    if (slice_view(*r, start, start_num, stop, stop_num, strides, strides_num, "mlx_slice_update", &region)) { delete r; return 1; }
+    Contig cu;
+    if (cu.init(*A(update))) { delete r; return 1; }
+    // broadcast-free form: update must have the region's element count (leading 1s allowed)
+    if (cu.a->size() != region.size()) { delete r; return set_error("mlx_slice_update: update has %zu elements, the slice has %zu", cu.a->size(), region.size()); }
+    Arr upd = *cu.a;
+    upd.shape = region.shape;
+    upd.strides = row_major(region.shape);
+    if (scatter_into(region.ptr(), region.strides, upd, s.dt)) { delete r; return 1; }
+    return assign(res, r);
+}
+int mlx_concatenate_axis(mlx_array* res, const mlx_vector_array arrays, int axis, const mlx_stream) {
+    OMX_REQUIRE(arrays.ctx, "mlx_concatenate_axis: empty vector");
+    Vec* v = reinterpret_cast<Vec*>(arrays.ctx);
+    OMX_REQUIRE(!v->v.empty(), "mlx_concatenate_axis: no arrays to concatenate");
+    const Arr& f = *v->v[0];
+    int ax;
+    if (norm_axis(axis, (int)f.shape.size(), "mlx_concatenate_axis", &ax)) return 1;
+    std::vector<int> shape = f.shape;
+    shape[ax] = 0;
+    for (Arr* a : v->v) {
+        OMX_REQUIRE(a->shape.size() == f.shape.size() && a->dt == f.dt, "mlx_concatenate_axis: rank or dtype mismatch");
+        for (size_t i = 0; i < f.shape.size(); ++i)
+            OMX_REQUIRE((int)i == ax || a->shape[i] == f.shape[i], "mlx_concatenate_axis: shapes differ outside the concatenation axis");
+        shape[ax] += a->shape[ax];
+    }
+    NEW_OR_FAIL(r, shape, f.dt);
+    size_t at = 0;
+    for (Arr* a : v->v) {
+        Contig c;
+        if (c.init(*a)) { delete r; return 1; }
+        char* base = r->ptr() + at * r->strides[ax] * dsize(f.dt);
+        if (scatter_into(base, r->strides, *c.a, f.dt)) { delete r; return 1; }
+        at += (size_t)a->shape[ax];
+    }
+    return assign(res, r);
+}
+int mlx_zeros(mlx_array* res, const int* shape, size_t shape_num, mlx_dtype dtype, const mlx_stream) {
+    std::vector<int> sh(shape, shape + shape_num);
+    NEW_OR_FAIL(r, sh, dtype);
+    if (r->size()) OMX_HIP_CHECK(hipMemsetAsync(r->ptr(), 0, r->size() * dsize(dtype), g_stream));
+    return assign(res, r);
+}
+int mlx_take_axis(mlx_array* res, const mlx_array a, const mlx_array indices, int axis, const mlx_stream) {
+    REQ_ARR(a, "mlx_take_axis"); REQ_ARR(indices, "mlx_take_axis");
+    int ax;
+    if (norm_axis(axis, (int)A(a)->shape.size(), "mlx_take_axis", &ax)) return 1;
+    OMX_REQUIRE(ax == 0 && A(a)->shape.size() == 2, "mlx_take_axis: only row gather from a 2-D table (Embedding) is supported");
+    OMX_REQUIRE(A(indices)->dt == MLX_UINT32 || A(indices)->dt == MLX_INT32, "mlx_take_axis: indices must be (u)int32");
+    Contig ct, ci;
+    if (ct.init(*A(a)) || ci.init(*A(indices))) return 1;
+    std::vector<int> shape = ci.a->shape;
+    shape.push_back(ct.a->shape[1]);
+    NEW_OR_FAIL(r, shape, ct.a->dt);
+    if (omx_take_rows(r->ptr(), ct.a->ptr(), (const uint32_t*)ci.a->ptr(), (int64_t)ci.a->size(), ct.a->shape[1],
+                      to_omx(ct.a->dt), g_stream)) { delete r; return 1; }
+    return assign(res, r);
+}
+int mlx_argmax_axis(mlx_array* res, const mlx_array a, int axis, bool keepdims, const mlx_stream) {
+    REQ_ARR(a, "mlx_argmax_axis");
+    const Arr& s = *A(a);
+    int ax;
+    if (norm_axis(axis, (int)s.shape.size(), "mlx_argmax_axis", &ax)) return 1;
+    OMX_REQUIRE(ax == (int)s.shape.size() - 1, "mlx_argmax_axis: only the last axis is supported (sampler.rs:11)");
+    Contig c;
+    if (c.init(s)) return 1;
+    std::vector<int> shape(s.shape.begin(), s.shape.end() - 1);
+    if (keepdims) shape.push_back(1);
+    NEW_OR_FAIL(r, shape, MLX_UINT32);
+    const int n = s.shape.back();
+    if (omx_argmax((uint32_t*)r->ptr(), c.a->ptr(), n ? (int64_t)(s.size() / n) : 0, n, to_omx(s.dt), g_stream)) { delete r; return 1; }
+    return assign(res, r);
+}
+int mlx_softmax_axis(mlx_array* res, const mlx_array a, int axis, bool, const mlx_stream) {
+    REQ_ARR(a, "mlx_softmax_axis");
+    const Arr& s = *A(a);
+    int ax;
+    if (norm_axis(axis, (int)s.shape.size(), "mlx_softmax_axis", &ax)) return 1;
+    OMX_REQUIRE(ax == (int)s.shape.size() - 1 && is_float(s.dt), "mlx_softmax_axis: last axis of a floating array only");
+    Contig c;
+    if (c.init(s)) return 1;
+    NEW_OR_FAIL(r, s.shape, s.dt);
+    const int n = s.shape.back();
+    const size_t rows = n ? s.size() / n : 0;
+    if (rows) {
+        softmax_kernel<<<(unsigned)((rows + 3) / 4), 256, 0, g_stream>>>(r->ptr(), c.a->ptr(), s.dt, rows, n);
+        OMX_LAUNCH_CHECK();
+    }
+    return assign(res, r);
+}
+
+int omx_mlx_fused_swiglu(mlx_array* res, const mlx_array x, const mlx_array gate, const mlx_stream) {
+    REQ_ARR(x, "fused_swiglu"); REQ_ARR(gate, "fused_swiglu");
+    OMX_REQUIRE(A(x)->shape == A(gate)->shape && A(x)->dt == A(gate)->dt, "fused_swiglu: x and gate must match in shape and dtype");
+    Contig cx, cg;
+    if (cx.init(*A(x)) || cg.init(*A(gate))) return 1;
+    NEW_OR_FAIL(r, cx.a->shape, cx.a->dt);
+    if (omx_fused_swiglu(r->ptr(), cx.a->ptr(), cg.a->ptr(), (int64_t)r->size(), to_omx(r->dt), g_stream)) { delete r; return 1; }
+    return assign(res, r);
+}
+int omx_mlx_fused_modulate(mlx_array* res, const mlx_array x, const mlx_array shift, const mlx_array scale, const mlx_stream) {
+    REQ_ARR(x, "fused_modulate"); REQ_ARR(shift, "fused_modulate"); REQ_ARR(scale, "fused_modulate");
+    OMX_REQUIRE(A(x)->shape.size() == 3, "fused_modulate: x must be [B, S, H]");
+    Contig cx, csh, csc;
+    if (cx.init(*A(x)) || csh.init(*A(shift)) || csc.init(*A(scale))) return 1;
+    const int B = cx.a->shape[0], S = cx.a->shape[1], H = cx.a->shape[2];
+    OMX_REQUIRE(csh.a->size() == (size_t)B * H && csc.a->size() == (size_t)B * H, "fused_modulate: shift/scale must be [B, H]");
+    NEW_OR_FAIL(r, cx.a->shape, cx.a->dt);
+    if (omx_fused_modulate(r->ptr(), cx.a->ptr(), csh.a->ptr(), csc.a->ptr(), B, S, H, 1e-6f, to_omx(r->dt), g_stream)) { delete r; return 1; }
+    return assign(res, r);
+}
+
+}  // extern "C"

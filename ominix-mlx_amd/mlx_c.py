@@ -1,0 +1,332 @@
+"""ctypes binding of the mlx-c compatible surface of libomx_hip.so (include/omx_mlx_c.h) plus a
+thin `Array` wrapper that plays the role of mlx_rs::Array (mlx-rs/src/array/mod.rs): an owned
+handle freed on drop, ops through `Guarded::try_from_op`-style status checks
+(mlx-rs/src/utils/guard.rs:24-48)."""
+from __future__ import annotations
+
+import ctypes
+import sys
+from typing import Optional, Sequence
+
+import numpy as np
+
+from . import OmxError, lib, require_device
+
+c_int, c_float, c_bool, c_size_t, c_void_p, c_char_p = (ctypes.c_int, ctypes.c_float, ctypes.c_bool, ctypes.c_size_t,
+                                                         ctypes.c_void_p, ctypes.c_char_p)
+
+
+class mlx_array(ctypes.Structure):
+    _fields_ = [("ctx", c_void_p)]
+
+
+class mlx_stream(ctypes.Structure):
+    _fields_ = [("ctx", c_void_p)]
+
+
+class mlx_vector_array(ctypes.Structure):
+    _fields_ = [("ctx", c_void_p)]
+
+
+class mlx_optional_float(ctypes.Structure):
+    _fields_ = [("value", c_float), ("has_value", c_bool)]
+
+
+BOOL, UINT8, UINT16, UINT32, UINT64, INT8, INT16, INT32, INT64, FLOAT16, FLOAT32, FLOAT64, BFLOAT16, COMPLEX64 = range(14)
+P_ARR, P_INT = ctypes.POINTER(mlx_array), ctypes.POINTER(c_int)
+
+# name -> (restype, argtypes): must list every symbol include/omx_mlx_c.h declares (tests/test_abi.py)
+SIGNATURES = {
+    "mlx_set_error_handler": (None, [c_void_p, c_void_p, c_void_p]),
+    "mlx_dtype_size": (c_size_t, [c_int]),
+    "mlx_array_new": (mlx_array, []),
+    "mlx_array_free": (c_int, [mlx_array]),
+    "mlx_array_new_bool": (mlx_array, [c_bool]),
+    "mlx_array_new_int": (mlx_array, [c_int]),
+    "mlx_array_new_float32": (mlx_array, [c_float]),
+    "mlx_array_new_float": (mlx_array, [c_float]),
+    "mlx_array_new_data": (mlx_array, [c_void_p, P_INT, c_int, c_int]),
+    "mlx_array_set": (c_int, [P_ARR, mlx_array]),
+    "mlx_array_itemsize": (c_size_t, [mlx_array]),
+    "mlx_array_size": (c_size_t, [mlx_array]),
+    "mlx_array_nbytes": (c_size_t, [mlx_array]),
+    "mlx_array_ndim": (c_size_t, [mlx_array]),
+    "mlx_array_shape": (P_INT, [mlx_array]),
+    "mlx_array_strides": (ctypes.POINTER(c_size_t), [mlx_array]),
+    "mlx_array_dim": (c_int, [mlx_array, c_int]),
+    "mlx_array_dtype": (c_int, [mlx_array]),
+    "mlx_array_eval": (c_int, [mlx_array]),
+    "mlx_array_item_bool": (c_int, [ctypes.POINTER(c_bool), mlx_array]),
+    "mlx_array_item_uint32": (c_int, [ctypes.POINTER(ctypes.c_uint32), mlx_array]),
+    "mlx_array_item_int32": (c_int, [ctypes.POINTER(ctypes.c_int32), mlx_array]),
+    "mlx_array_item_float32": (c_int, [ctypes.POINTER(c_float), mlx_array]),
+    "mlx_array_data_uint8": (c_void_p, [mlx_array]),
+    "mlx_array_data_uint16": (c_void_p, [mlx_array]),
+    "mlx_array_data_uint32": (c_void_p, [mlx_array]),
+    "mlx_array_data_int32": (c_void_p, [mlx_array]),
+    "mlx_array_data_float32": (c_void_p, [mlx_array]),
+    "mlx_array_data_bfloat16": (c_void_p, [mlx_array]),
+    "mlx_vector_array_new": (mlx_vector_array, []),
+    "mlx_vector_array_free": (c_int, [mlx_vector_array]),
+    "mlx_vector_array_append_value": (c_int, [mlx_vector_array, mlx_array]),
+    "mlx_vector_array_size": (c_size_t, [mlx_vector_array]),
+    "mlx_vector_array_get": (c_int, [P_ARR, mlx_vector_array, c_size_t]),
+    "mlx_stream_new": (mlx_stream, []),
+    "mlx_stream_free": (c_int, [mlx_stream]),
+    "mlx_stream_equal": (c_bool, [mlx_stream, mlx_stream]),
+    "mlx_synchronize": (c_int, [mlx_stream]),
+    "mlx_default_cpu_stream_new": (mlx_stream, []),
+    "mlx_default_gpu_stream_new": (mlx_stream, []),
+    "mlx_async_eval": (c_int, [mlx_vector_array]),
+    "mlx_eval": (c_int, [mlx_vector_array]),
+    "mlx_clear_cache": (c_int, []),
+    "mlx_get_active_memory": (c_int, [ctypes.POINTER(c_size_t)]),
+    "mlx_get_peak_memory": (c_int, [ctypes.POINTER(c_size_t)]),
+    "mlx_fast_layer_norm": (c_int, [P_ARR, mlx_array, mlx_array, mlx_array, c_float, mlx_stream]),
+    "mlx_fast_rms_norm": (c_int, [P_ARR, mlx_array, mlx_array, c_float, mlx_stream]),
+    "mlx_fast_rope": (c_int, [P_ARR, mlx_array, c_int, c_bool, mlx_optional_float, c_float, c_int, mlx_array, mlx_stream]),
+    "mlx_fast_scaled_dot_product_attention": (c_int, [P_ARR, mlx_array, mlx_array, mlx_array, c_float, c_char_p,
+                                                      mlx_array, mlx_array, mlx_stream]),
+    "mlx_matmul": (c_int, [P_ARR, mlx_array, mlx_array, mlx_stream]),
+    "mlx_addmm": (c_int, [P_ARR, mlx_array, mlx_array, mlx_array, c_float, c_float, mlx_stream]),
+    "mlx_add": (c_int, [P_ARR, mlx_array, mlx_array, mlx_stream]),
+    "mlx_subtract": (c_int, [P_ARR, mlx_array, mlx_array, mlx_stream]),
+    "mlx_multiply": (c_int, [P_ARR, mlx_array, mlx_array, mlx_stream]),
+    "mlx_divide": (c_int, [P_ARR, mlx_array, mlx_array, mlx_stream]),
+    "mlx_sigmoid": (c_int, [P_ARR, mlx_array, mlx_stream]),
+    "mlx_exp": (c_int, [P_ARR, mlx_array, mlx_stream]),
+    "mlx_negative": (c_int, [P_ARR, mlx_array, mlx_stream]),
+    "mlx_astype": (c_int, [P_ARR, mlx_array, c_int, mlx_stream]),
+    "mlx_reshape": (c_int, [P_ARR, mlx_array, P_INT, c_size_t, mlx_stream]),
+    "mlx_transpose_axes": (c_int, [P_ARR, mlx_array, P_INT, c_size_t, mlx_stream]),
+    "mlx_transpose": (c_int, [P_ARR, mlx_array, mlx_stream]),
+    "mlx_expand_dims": (c_int, [P_ARR, mlx_array, c_int, mlx_stream]),
+    "mlx_contiguous": (c_int, [P_ARR, mlx_array, c_bool, mlx_stream]),
+    "mlx_slice": (c_int, [P_ARR, mlx_array, P_INT, c_size_t, P_INT, c_size_t, P_INT, c_size_t, mlx_stream]),
+    "mlx_slice_update": (c_int, [P_ARR, mlx_array, mlx_array, P_INT, c_size_t, P_INT, c_size_t, P_INT, c_size_t, mlx_stream]),
+    "mlx_concatenate_axis": (c_int, [P_ARR, mlx_vector_array, c_int, mlx_stream]),
+    "mlx_zeros": (c_int, [P_ARR, P_INT, c_size_t, c_int, mlx_stream]),
+    "mlx_take_axis": (c_int, [P_ARR, mlx_array, mlx_array, c_int, mlx_stream]),
+    "mlx_argmax_axis": (c_int, [P_ARR, mlx_array, c_int, c_bool, mlx_stream]),
+    "mlx_softmax_axis": (c_int, [P_ARR, mlx_array, c_int, c_bool, mlx_stream]),
+    "omx_mlx_fused_swiglu": (c_int, [P_ARR, mlx_array, mlx_array, mlx_stream]),
+    "omx_mlx_fused_modulate": (c_int, [P_ARR, mlx_array, mlx_array, mlx_array, mlx_stream]),
+}
+for _n, (_r, _a) in SIGNATURES.items():
+    _f = getattr(lib, _n)
+    _f.restype, _f.argtypes = _r, _a
+
+
+def _check(status: int) -> None:
+    if status != 0:
+        msg = lib.omx_last_error().decode("utf-8", "replace")
+        lib.omx_clear_error()
+        raise OmxError(msg or "unknown mlx_* error")
+
+
+_NP = {FLOAT32: np.float32, UINT32: np.uint32, INT32: np.int32, BOOL: np.bool_, UINT8: np.uint8, FLOAT16: np.float16}
+_STREAM = None
+
+
+def default_stream() -> mlx_stream:
+    global _STREAM
+    if _STREAM is None:
+        require_device()
+        _STREAM = lib.mlx_default_gpu_stream_new()
+    return _STREAM
+
+
+def _ints(seq):
+    arr = (c_int * len(seq))(*[int(v) for v in seq])
+    return arr, len(seq)
+
+
+class Array:
+    """Owned mlx_array handle (mlx_rs::Array)."""
+
+    def __init__(self, handle: mlx_array):
+        self.h = handle
+
+    def __del__(self):
+        if not sys.is_finalizing() and getattr(self, "h", None) is not None and self.h.ctx:
+            lib.mlx_array_free(self.h)
+            self.h = mlx_array(None)
+
+    # -- construction --
+    @staticmethod
+    def from_numpy(a, dtype=BFLOAT16) -> "Array":
+        require_device()
+        a = np.asarray(a)
+        if dtype == BFLOAT16:
+            u = np.ascontiguousarray(a, np.float32).view(np.uint32).astype(np.uint64)
+            host = ((u + ((u >> np.uint64(16)) & np.uint64(1)) + np.uint64(0x7FFF)) >> np.uint64(16)).astype(np.uint16)
+        else:
+            host = np.ascontiguousarray(a, _NP[dtype])
+        shape, n = _ints(a.shape)
+        h = lib.mlx_array_new_data(host.ctypes.data, shape, n, dtype)
+        if not h.ctx:
+            _check(1)
+        return Array(h)
+
+    @staticmethod
+    def op(fn, *args) -> "Array":
+        """Guarded::try_from_op: fresh empty out-handle, adopt on status 0, free + raise otherwise."""
+        res = lib.mlx_array_new()
+        status = fn(ctypes.byref(res), *args)
+        if status != 0:
+            lib.mlx_array_free(res)
+            _check(status)
+        return Array(res)
+
+    # -- inspection --
+    @property
+    def shape(self):
+        n = lib.mlx_array_ndim(self.h)
+        p = lib.mlx_array_shape(self.h)
+        return tuple(p[i] for i in range(n))
+
+    @property
+    def strides(self):
+        n = lib.mlx_array_ndim(self.h)
+        p = lib.mlx_array_strides(self.h)
+        return tuple(p[i] for i in range(n))
+
+    @property
+    def dtype(self) -> int:
+        return lib.mlx_array_dtype(self.h)
+
+    def eval(self) -> None:
+        _check(lib.mlx_array_eval(self.h))
+
+    def item(self):
+        dt = self.dtype
+        if dt == UINT32:
+            v = ctypes.c_uint32(); _check(lib.mlx_array_item_uint32(ctypes.byref(v), self.h)); return v.value
+        if dt == INT32:
+            v = ctypes.c_int32(); _check(lib.mlx_array_item_int32(ctypes.byref(v), self.h)); return v.value
+        if dt == FLOAT32:
+            v = c_float(); _check(lib.mlx_array_item_float32(ctypes.byref(v), self.h)); return v.value
+        raise OmxError(f"item(): unsupported dtype {dt}")
+
+    def numpy(self) -> np.ndarray:
+        """as_slice(): goes through mlx_array_data_* (host mirror); bf16 widened to float32."""
+        dt, shape = self.dtype, self.shape
+        n = int(np.prod(shape, dtype=np.int64))
+        if dt == BFLOAT16:
+            p = lib.mlx_array_data_bfloat16(self.h)
+            raw = np.ctypeslib.as_array(ctypes.cast(p, ctypes.POINTER(ctypes.c_uint16)), (max(n, 1),))[:n].copy()
+            return (raw.astype(np.uint32) << np.uint32(16)).view(np.float32).reshape(shape)
+        fn = {FLOAT32: lib.mlx_array_data_float32, UINT32: lib.mlx_array_data_uint32, INT32: lib.mlx_array_data_int32,
+              BOOL: lib.mlx_array_data_uint8, UINT8: lib.mlx_array_data_uint8}[dt]
+        ct = {FLOAT32: c_float, UINT32: ctypes.c_uint32, INT32: ctypes.c_int32, BOOL: ctypes.c_uint8, UINT8: ctypes.c_uint8}[dt]
+        p = fn(self.h)
+        if not p:
+            _check(1)
+        out = np.ctypeslib.as_array(ctypes.cast(p, ctypes.POINTER(ct)), (max(n, 1),))[:n].copy().reshape(shape)
+        return out.astype(bool) if dt == BOOL else out
+
+
+_EMPTY = mlx_array(None)
+
+
+def _h(a: Optional[Array]) -> mlx_array:
+    return _EMPTY if a is None else a.h
+
+
+# ---- mlx_rs::ops / mlx_rs::fast, one function per C entry point ----
+def rms_norm(x, weight, eps):
+    return Array.op(lib.mlx_fast_rms_norm, x.h, _h(weight), eps, default_stream())
+
+
+def layer_norm(x, weight, bias, eps):
+    return Array.op(lib.mlx_fast_layer_norm, x.h, _h(weight), _h(bias), eps, default_stream())
+
+
+def rope(x, dims, traditional, base, scale, offset, freqs=None):
+    return Array.op(lib.mlx_fast_rope, x.h, dims, traditional, mlx_optional_float(base if base is not None else 0.0,
+                    base is not None), scale, offset, _h(freqs), default_stream())
+
+
+def scaled_dot_product_attention(q, k, v, scale, mask=None):
+    """mask: None | "causal" | Array (bool or additive) -- fast.rs:88-108 (mode "" + array, or "causal")."""
+    mode, arr = b"", None
+    if isinstance(mask, str):
+        mode = mask.encode()
+    elif mask is not None:
+        arr = mask
+    return Array.op(lib.mlx_fast_scaled_dot_product_attention, q.h, k.h, v.h, scale, mode, _h(arr), _EMPTY, default_stream())
+
+
+def matmul(a, b):
+    return Array.op(lib.mlx_matmul, a.h, b.h, default_stream())
+
+
+def addmm(c, a, b, alpha=1.0, beta=1.0):
+    return Array.op(lib.mlx_addmm, c.h, a.h, b.h, alpha, beta, default_stream())
+
+
+def add(a, b): return Array.op(lib.mlx_add, a.h, b.h, default_stream())
+def subtract(a, b): return Array.op(lib.mlx_subtract, a.h, b.h, default_stream())
+def multiply(a, b): return Array.op(lib.mlx_multiply, a.h, b.h, default_stream())
+def divide(a, b): return Array.op(lib.mlx_divide, a.h, b.h, default_stream())
+def sigmoid(a): return Array.op(lib.mlx_sigmoid, a.h, default_stream())
+def exp(a): return Array.op(lib.mlx_exp, a.h, default_stream())
+def negative(a): return Array.op(lib.mlx_negative, a.h, default_stream())
+def astype(a, dtype): return Array.op(lib.mlx_astype, a.h, dtype, default_stream())
+def transpose(a): return Array.op(lib.mlx_transpose, a.h, default_stream())
+def expand_dims(a, axis): return Array.op(lib.mlx_expand_dims, a.h, axis, default_stream())
+def contiguous(a): return Array.op(lib.mlx_contiguous, a.h, False, default_stream())
+def take_axis(a, indices, axis): return Array.op(lib.mlx_take_axis, a.h, indices.h, axis, default_stream())
+def argmax_axis(a, axis, keepdims=False): return Array.op(lib.mlx_argmax_axis, a.h, axis, keepdims, default_stream())
+def softmax_axis(a, axis, precise=True): return Array.op(lib.mlx_softmax_axis, a.h, axis, precise, default_stream())
+def fused_swiglu(x, gate): return Array.op(lib.omx_mlx_fused_swiglu, x.h, gate.h, default_stream())
+def fused_modulate(x, shift, scale): return Array.op(lib.omx_mlx_fused_modulate, x.h, shift.h, scale.h, default_stream())
+
+
+def reshape(a, shape):
+    s, n = _ints(shape)
+    return Array.op(lib.mlx_reshape, a.h, s, n, default_stream())
+
+
+def transpose_axes(a, axes):
+    s, n = _ints(axes)
+    return Array.op(lib.mlx_transpose_axes, a.h, s, n, default_stream())
+
+
+def zeros(shape, dtype):
+    s, n = _ints(shape)
+    return Array.op(lib.mlx_zeros, s, n, dtype, default_stream())
+
+
+def slice(a, start, stop, strides=None):
+    st, n = _ints(start)
+    sp, _ = _ints(stop)
+    sd, _ = _ints(strides if strides is not None else [1] * n)
+    return Array.op(lib.mlx_slice, a.h, st, n, sp, n, sd, n, default_stream())
+
+
+def slice_update(src, update, start, stop, strides=None):
+    st, n = _ints(start)
+    sp, _ = _ints(stop)
+    sd, _ = _ints(strides if strides is not None else [1] * n)
+    return Array.op(lib.mlx_slice_update, src.h, update.h, st, n, sp, n, sd, n, default_stream())
+
+
+def concatenate_axis(arrays: Sequence[Array], axis: int):
+    vec = lib.mlx_vector_array_new()
+    try:
+        for a in arrays:
+            _check(lib.mlx_vector_array_append_value(vec, a.h))
+        return Array.op(lib.mlx_concatenate_axis, vec, axis, default_stream())
+    finally:
+        lib.mlx_vector_array_free(vec)
+
+
+def eval(*arrays) -> None:
+    vec = lib.mlx_vector_array_new()
+    try:
+        for a in arrays:
+            _check(lib.mlx_vector_array_append_value(vec, a.h))
+        _check(lib.mlx_eval(vec))
+    finally:
+        lib.mlx_vector_array_free(vec)

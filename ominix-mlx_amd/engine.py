@@ -96,6 +96,9 @@ class Model:
 
     def load_weights(self, weights: Dict[str, np.ndarray]) -> None:
         """ModuleParametersExt::load_safetensors equivalent for in-memory arrays keyed by HF name."""
+        if self.cfg.tp_size > 1:   # slice the logical checkpoint with the shared shard plan (tp.py)
+            from . import tp
+            weights = tp.shard_state_dict(weights, self.cfg.tp_rank, self.cfg.tp_size, bool(self.cfg.tie_word_embeddings))
         for name, arr in weights.items():
             t = Tensor.from_numpy(arr, "bf16")
             self._keep.append(t)

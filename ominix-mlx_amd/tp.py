@@ -1,0 +1,60 @@
+"""Tensor-parallel shard plan of the dense decoder.
+
+Host logic shared by every consumer of the TP path: `engine.Model.load_weights` slices host
+checkpoints with it, the C++ engine's synthetic generator follows the same plan
+(`omx_qwen3_synth_weights`: row0/col0 of `omx_fill_uniform_2d`), and the world-size-2 gloo test
+(tests/test_tp_plan.py) checks it against the single-device oracle.
+
+    row split  (output features): q_proj, k_proj, v_proj, gate_proj, up_proj, lm_head
+    col split  (input features):  o_proj, down_proj   -> partial sums, one all-reduce(sum) each
+    replicated:                   norms, embedding table (the tied head uses a row shard of it)
+Heads are contiguous per rank: rank r owns q heads [r*H/n, (r+1)*H/n) and KV heads [r*Hkv/n, ...).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+ROW_SPLIT = ("self_attn.q_proj.weight", "self_attn.k_proj.weight", "self_attn.v_proj.weight",
+             "mlp.gate_proj.weight", "mlp.up_proj.weight", "lm_head.weight")
+COL_SPLIT = ("self_attn.o_proj.weight", "mlp.down_proj.weight")
+
+
+def check_divisible(*, num_attention_heads, num_key_value_heads, intermediate_size, vocab_size, world, **_):
+    for what, n in (("num_key_value_heads", num_key_value_heads), ("num_attention_heads", num_attention_heads),
+                    ("intermediate_size", intermediate_size), ("vocab_size", vocab_size)):
+        if n % world:
+            raise ValueError(f"InvalidConfig: {what}={n} is not divisible by tp_size={world}")
+
+
+def shard(name: str, arr: np.ndarray, rank: int, world: int) -> np.ndarray:
+    """This rank's slice of a logical weight (contiguous copy)."""
+    if world == 1:
+        return arr
+    if name.endswith(ROW_SPLIT):
+        n = arr.shape[0] // world
+        return np.ascontiguousarray(arr[rank * n:(rank + 1) * n])
+    if name.endswith(COL_SPLIT):
+        n = arr.shape[1] // world
+        return np.ascontiguousarray(arr[:, rank * n:(rank + 1) * n])
+    return arr
+
+
+def shard_state_dict(weights: dict, rank: int, world: int, tie_word_embeddings: bool = False) -> dict:
+    out = {k: shard(k, v, rank, world) for k, v in weights.items()}
+    if tie_word_embeddings and world > 1:
+        out["lm_head.weight"] = shard("lm_head.weight", weights["model.embed_tokens.weight"], rank, world)
+    return out
+
+
+def argmax_key(value: float, index: int) -> int:
+    """Packed (orderable float32 bits << 32) | ~index: a plain unsigned max over ranks picks the largest
+    logit and, on ties, the smallest vocabulary index -- the single-device argmax (sampler.rs:9-12)."""
+    u = int(np.float32(value).view(np.uint32))
+    u = (~u & 0xFFFFFFFF) if (u & 0x80000000) else (u | 0x80000000)
+    if value != value:
+        u = 0
+    return (u << 32) | (~index & 0xFFFFFFFF)
+
+
+def key_to_index(key: int) -> int:
+    return ~key & 0xFFFFFFFF

@@ -137,3 +137,21 @@ def test_batched_prefill_equals_token_serial_prefill(omx, monkeypatch):
     assert np.abs(ls - lb).max() <= 2.0 ** -7 * scale * np.sqrt(cfg.num_hidden_layers)
     # layer-1 keys depend on layer 0's full block output: agreement here checks GEMM + attention + MLP
     assert np.abs(ks - kb).max() <= 2.0 ** -6 * np.abs(ks).max()
+
+
+def test_tensor_parallel_code_path_with_one_rank_communicator(omx, monkeypatch):
+    """The TP step (f32 partial GEMVs, RCCL all-reduce captured in the step graph, partial folded into
+    the next prologue, packed-key argmax all-reduce) run with a 1-rank communicator must reproduce the
+    non-TP engine token for token: with one rank the arithmetic is identical."""
+    import bench
+    cfg = CONFIGS["gqa4_d128"]
+    prompt = synth.prompt_ids(48, cfg.vocab_size)
+    monkeypatch.setenv("OMX_PREFILL_SERIAL", "1")     # the TP engine prefills token-serially; compare like with like
+    plain = _engine(omx, cfg)
+    want = np.concatenate([[plain.prefill(prompt)], plain.decode(10)])
+    keep = bench.rccl_comm(None, 0, 1)
+    m = _engine(omx, cfg)
+    m.set_comm(keep[1], keep[2])
+    got = np.concatenate([[m.prefill(prompt)], m.decode(10)])
+    np.testing.assert_array_equal(got, want)
+    np.testing.assert_array_equal(m.last_logits(), plain.last_logits())

@@ -1,0 +1,117 @@
+"""World-size-2 gloo test (CPU) of the tensor-parallel shard plan: every rank
+runs its shard of a decode step of the oracle model, partial sums are all-reduced where the engine
+all-reduces them, and the result must equal the single-device oracle (same logits up to the bf16
+rounding of the all-reduced partial, same greedy token)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import ref_core as rc, ref_qwen3 as rq, synth
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _rank_main(rank, world, port, ret):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import omx_import
+    omx_import.load_package()
+    from ominix_mlx_amd import tp
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    cfg = rq.Qwen3Config(256, 2, 768, 4, 2, 64, 512, 1e-6, 1e6, False)
+    full = rq.synth_weights(cfg)
+    tp.check_divisible(world=world, **cfg.__dict__)
+    w = tp.shard_state_dict(full, rank, world)
+    H, Hkv, D = cfg.num_attention_heads // world, cfg.num_key_value_heads // world, cfg.head_dim
+    rope = rc.initialize_rope(D, cfg.rope_theta, False, None)
+
+    def allreduce(x):
+        t = torch.from_numpy(np.ascontiguousarray(x, np.float32))
+        dist.all_reduce(t)
+        return t.numpy()
+
+    prompt = synth.prompt_ids(6, cfg.vocab_size)
+    caches = [rc.KVCache() for _ in range(cfg.num_hidden_layers)]
+    tok = None
+    for t, token in enumerate(prompt):
+        h = full["model.embed_tokens.weight"][[token]][None]                     # replicated embedding
+        for l in range(cfg.num_hidden_layers):
+            p = f"model.layers.{l}."
+            xn = rc.rms_norm(h, w[p + "input_layernorm.weight"], cfg.rms_norm_eps, "bf16")
+            q = rc.linear(xn, w[p + "self_attn.q_proj.weight"], None, "bf16").reshape(1, 1, H, D).transpose(0, 2, 1, 3)
+            k = rc.linear(xn, w[p + "self_attn.k_proj.weight"], None, "bf16").reshape(1, 1, Hkv, D).transpose(0, 2, 1, 3)
+            v = rc.linear(xn, w[p + "self_attn.v_proj.weight"], None, "bf16").reshape(1, 1, Hkv, D).transpose(0, 2, 1, 3)
+            q = rc.rms_norm(q, w[p + "self_attn.q_norm.weight"], cfg.rms_norm_eps, "bf16")
+            k = rc.rms_norm(k, w[p + "self_attn.k_norm.weight"], cfg.rms_norm_eps, "bf16")
+            q = rc.rope(q, D, False, rope["base"], 1.0, t, "bf16"); k = rc.rope(k, D, False, rope["base"], 1.0, t, "bf16")
+            kk, vv = caches[l].update_and_fetch(k, v)                            # KV cache sharded by KV head
+            o = rc.scaled_dot_product_attention(q, kk, vv, D ** -0.5, None, "bf16").transpose(0, 2, 1, 3).reshape(1, 1, -1)
+            part = rc.linear(o, w[p + "self_attn.o_proj.weight"], None, "f32")    # f32 partial (EPI_F32)
+            h = rc.add(h, rc.bf16_round(allreduce(part)), "bf16")                # all-reduce #1, folded into the residual
+            hn = rc.rms_norm(h, w[p + "post_attention_layernorm.weight"], cfg.rms_norm_eps, "bf16")
+            g = rc.linear(hn, w[p + "mlp.gate_proj.weight"], None, "bf16"); u = rc.linear(hn, w[p + "mlp.up_proj.weight"], None, "bf16")
+            act = rc.multiply(rc.silu(g, "bf16"), u, "bf16")
+            part = rc.linear(act, w[p + "mlp.down_proj.weight"], None, "f32")
+            h = rc.add(h, rc.bf16_round(allreduce(part)), "bf16")                # all-reduce #2
+        hn = rc.rms_norm(h, full["model.norm.weight"], cfg.rms_norm_eps, "bf16")
+        logits = rc.linear(hn, w["lm_head.weight"], None, "bf16")[0, 0]           # vocab shard
+        i = int(np.argmax(logits))
+        key = tp.argmax_key(float(logits[i]), i + rank * logits.size)
+        kt = torch.tensor([key >> 32, key & 0xFFFFFFFF], dtype=torch.int64)      # gloo has no u64 max: order by (hi, lo)
+        gathered = [torch.zeros_like(kt) for _ in range(world)]
+        dist.all_gather(gathered, kt)
+        best = max((int(g_[0]) << 32) | int(g_[1]) for g_ in gathered)
+        tok = tp.key_to_index(best)
+        all_logits = [torch.zeros(logits.size) for _ in range(world)]
+        dist.all_gather(all_logits, torch.from_numpy(logits.copy()))
+    if rank == 0:
+        ret["token"] = tok
+        ret["logits"] = torch.cat(all_logits).numpy()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_tp2_shard_plan_matches_single_device_oracle():
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_rank_main, args=(world, _free_port(), ret), nprocs=world, join=True)
+    cfg = rq.Qwen3Config(256, 2, 768, 4, 2, 64, 512, 1e-6, 1e6, False)
+    oracle = rq.Qwen3Oracle(cfg, rq.synth_weights(cfg))
+    prompt = synth.prompt_ids(6, cfg.vocab_size)
+    ref_tok, ref_logits = oracle.generate(prompt, 1, return_logits=True)
+    got = ret["logits"]
+    assert np.abs(got - ref_logits[0]).max() <= 2.0 ** -7 * np.abs(ref_logits).max() * np.sqrt(cfg.num_hidden_layers)
+    if rc.argmax_margin(ref_logits)[0] > 2.0 ** -5 * np.abs(ref_logits).max():
+        assert ret["token"] == int(ref_tok[0])
+    assert ret["token"] == int(np.argmax(got))          # the packed-key reduction is the global first-index argmax
+
+
+def test_argmax_key_orders_like_argmax():
+    import omx_import
+    omx_import.load_package()
+    from ominix_mlx_amd import tp
+    vals = np.array([-3.0, 0.0, -0.0, 2.5, 2.5, -np.inf, 1e-30], np.float32)
+    keys = [tp.argmax_key(float(v), i) for i, v in enumerate(vals)]
+    assert tp.key_to_index(max(keys)) == 3               # first of the tied maxima
+    assert tp.argmax_key(float("nan"), 0) < tp.argmax_key(-1e30, 5)
+
+
+def test_shard_shapes():
+    import omx_import
+    omx_import.load_package()
+    from ominix_mlx_amd import tp
+    w = np.arange(32 * 16, dtype=np.float32).reshape(32, 16)
+    assert tp.shard("model.layers.0.self_attn.q_proj.weight", w, 1, 4).shape == (8, 16)
+    np.testing.assert_array_equal(tp.shard("model.layers.0.mlp.down_proj.weight", w, 3, 4), w[:, 12:16])
+    assert tp.shard("model.norm.weight", w, 1, 4) is w
+    with pytest.raises(ValueError):
+        tp.check_divisible(num_attention_heads=28, num_key_value_heads=4, intermediate_size=18944, vocab_size=152064, world=8)

@@ -167,6 +167,27 @@ int omx_qwen3_stream(omx_qwen3 m, omx_stream* s);
 /* algorithmic HBM bytes of ONE decode step at context length ctx (SURVEY.md 8d formula)             */
 int omx_qwen3_step_bytes(omx_qwen3 m, int ctx, double* bytes);
 
+/* =====================================================================================
+ * a12: Paraformer mel/STFT frontend (funasr-mlx/src/paraformer.rs:195-412), all on device:
+ * x*32768 -> pre-emphasis 0.97 -> frames (n-400)/160+1 -> Hamming -> 400-pt DFT power -> 80 HTK
+ * mel filters -> ln(max(.,1e-10)) -> LFR(7,6) -> CMVN.  Replaces MelFrontend::{new,set_cmvn,forward}.
+ * ===================================================================================== */
+typedef struct omx_mel_config_ {   /* ParaformerConfig frontend fields, paraformer.rs:110-145 */
+    int sample_rate, n_mels, n_fft, hop_length, lfr_m, lfr_n;
+} omx_mel_config;
+typedef struct omx_mel_frontend_* omx_mel_frontend;
+int omx_mel_frontend_create(omx_mel_frontend* out, const omx_mel_config* cfg);          /* MelFrontend::new  :195-222 */
+int omx_mel_frontend_destroy(omx_mel_frontend f);
+/* MelFrontend::set_cmvn :225-228; host vectors of lfr_m*n_mels floats (am.mvn <AddShift>/<Rescale>) */
+int omx_mel_frontend_set_cmvn(omx_mel_frontend f, const float* addshift_host, const float* rescale_host, int dim);
+/* frame counts for n_samples: STFT frames (1 when shorter than n_fft, :386-388) and LFR frames */
+int omx_mel_frontend_frames(omx_mel_frontend f, int64_t n_samples, int* n_frames, int* n_lfr);
+/* MelFrontend::forward :278-367.  audio: device f32 [n_samples]; feats: device f32 [n_lfr, lfr_m*n_mels];
+ * logmel_out ([n_frames, n_mels]) and power_out ([n_frames, n_fft/2+1]) are optional device outputs.
+ * Non-finite samples are an error ("Audio contains NaN or Inf values", :284-286).                     */
+int omx_mel_frontend_forward(omx_mel_frontend f, const float* audio, int64_t n_samples, float* feats, float* logmel_out,
+                             float* power_out, omx_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,174 @@
+"""TEST INFRASTRUCTURE ONLY -- CPU (numpy) restatement of the Paraformer mel/STFT frontend
+(SURVEY.md 8a row a12).  Never imported by the product path.
+
+Follows funasr-mlx/src/paraformer.rs line by line (this arithmetic is fully in-tree):
+    MelFrontend::new (Hamming window)         :195-222
+    hz_to_mel / mel_to_hz / create_mel_filterbank   :231-275
+    MelFrontend::forward                      :278-367  (x32768, pre-emphasis 0.97, STFT power,
+                                                         mel + ln(max(.,1e-10)), LFR(7,6), CMVN)
+    compute_stft                              :374-411  (400-pt FFT per frame, no padding)
+The reference's FFT is rustfft 6.2 in f32; this restatement evaluates the DFT with numpy's rfft in
+float64 on the SAME f32 windowed frames, i.e. it is the exact value the reference's own validation
+(funasr-mlx/examples/validate_correctness.rs:19-59, 284-287: FFT vs direct DFT, relative-L2 < 1e-5)
+accepts both implementations against.  PINNED by that criterion and by the reference's generator
+signals (validate_correctness.rs:441-487), reproduced in `signals()` below.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+F32 = np.float32
+
+
+class ParaformerFrontendConfig:
+    """ParaformerConfig::default() frontend fields (paraformer.rs:110-145)."""
+    sample_rate = 16000
+    n_mels = 80
+    n_fft = 400
+    hop_length = 160
+    lfr_m = 7
+    lfr_n = 6
+
+
+def hamming_window(n_fft: int) -> np.ndarray:
+    i = np.arange(n_fft, dtype=F32)
+    t = i / F32(n_fft - 1)
+    return (F32(0.54) - F32(0.46) * np.cos(F32(2.0) * F32(np.pi) * t).astype(F32)).astype(F32)
+
+
+def hz_to_mel(hz):
+    return F32(2595.0) * np.log10(F32(1.0) + np.asarray(hz, F32) / F32(700.0)).astype(F32)
+
+
+def mel_to_hz(mel):
+    return F32(700.0) * (np.power(F32(10.0), np.asarray(mel, F32) / F32(2595.0)).astype(F32) - F32(1.0))
+
+
+def create_mel_filterbank(n_fft: int, n_mels: int, sample_rate: float) -> np.ndarray:
+    """paraformer.rs:239-275: triangular HTK filters, edges inclusive, no area normalisation. [n_mels, n_freqs]"""
+    n_freqs = n_fft // 2 + 1
+    mel_min, mel_max = hz_to_mel(0.0), hz_to_mel(sample_rate / 2.0)
+    i = np.arange(n_mels + 2, dtype=F32)
+    mel_points = mel_to_hz(mel_min + (mel_max - mel_min) * i / F32(n_mels + 1))
+    fft_freqs = np.arange(n_freqs, dtype=F32) * F32(sample_rate) / F32(n_fft)
+    fb = np.zeros((n_mels, n_freqs), F32)
+    for m in range(n_mels):
+        fl, fc, fr = mel_points[m], mel_points[m + 1], mel_points[m + 2]
+        up = (fft_freqs >= fl) & (fft_freqs <= fc)
+        dn = (fft_freqs > fc) & (fft_freqs <= fr)
+        fb[m, up] = (fft_freqs[up] - fl) / (fc - fl)
+        fb[m, dn] = (fr - fft_freqs[dn]) / (fr - fc)
+    return fb
+
+
+def preemphasis_scaled(audio: np.ndarray) -> np.ndarray:
+    """x*32768 then y[0]=x[0], y[i]=x[i]-0.97*x[i-1] in f32 (paraformer.rs:289-300)."""
+    x = (np.asarray(audio, F32) * F32(32768.0)).astype(F32)
+    y = x.copy()
+    y[1:] = (x[1:] - (F32(0.97) * x[:-1]).astype(F32)).astype(F32)
+    return y
+
+
+def stft_power(samples: np.ndarray, window: np.ndarray, n_fft: int, hop: int) -> np.ndarray:
+    """compute_stft (:374-411): frames (n - n_fft)/hop + 1, no centre padding; |X_k|^2 for k <= n_fft/2.
+    Too-short input yields ONE all-zero frame (the `vec![0; n_freqs]` early return, :386-388)."""
+    n_freqs = n_fft // 2 + 1
+    n = len(samples)
+    n_frames = (n - n_fft) // hop + 1 if n >= n_fft else 0
+    if n_frames == 0:
+        return np.zeros((1, n_freqs), np.float64)
+    idx = np.arange(n_frames)[:, None] * hop + np.arange(n_fft)[None, :]
+    frames = (samples[idx] * window[None, :]).astype(F32)          # f32 product, as buffer[i] = s*w
+    spec = np.fft.rfft(frames.astype(np.float64), axis=1)
+    return spec.real ** 2 + spec.imag ** 2
+
+
+def lfr_indices(n_frames: int, lfr_m: int, lfr_n: int) -> np.ndarray:
+    """:326-351: left-pad (m-1)/2 copies of frame 0, tail clamps to the last frame. [T', m]"""
+    left = (lfr_m - 1) // 2
+    t_out = (n_frames + left + lfr_n - 1) // lfr_n
+    padded = np.arange(t_out)[:, None] * lfr_n + np.arange(lfr_m)[None, :]
+    return np.clip(padded - left, 0, n_frames - 1)
+
+
+def mel_frontend(audio: np.ndarray, addshift=None, rescale=None, cfg=ParaformerFrontendConfig):
+    """MelFrontend::forward -> dict(power [T,201] f64, logmel [T,80] f32, feats [T', 560] f32)."""
+    audio = np.asarray(audio, F32)
+    if not np.all(np.isfinite(audio)):
+        raise ValueError("Audio contains NaN or Inf values")          # :284-286
+    window = hamming_window(cfg.n_fft)
+    fb = create_mel_filterbank(cfg.n_fft, cfg.n_mels, float(cfg.sample_rate))
+    power = stft_power(preemphasis_scaled(audio), window, cfg.n_fft, cfg.hop_length)
+    mel = power @ fb.astype(np.float64).T
+    logmel = np.log(np.maximum(mel, 1e-10)).astype(F32)
+    idx = lfr_indices(logmel.shape[0], cfg.lfr_m, cfg.lfr_n)
+    feats = logmel[idx].reshape(idx.shape[0], cfg.lfr_m * cfg.n_mels)
+    if addshift is not None and rescale is not None:
+        feats = ((feats + np.asarray(addshift, F32)[None, :]) * np.asarray(rescale, F32)[None, :]).astype(F32)
+    return {"power": power, "logmel": logmel, "feats": feats.astype(F32)}
+
+
+# ---- the reference's deterministic test signals (validate_correctness.rs:441-487) ----
+def _t(n, sr):
+    return np.arange(n, dtype=F32) / F32(sr)
+
+
+def generate_sine(sr, duration, freq):
+    n = int(duration * sr)
+    return np.sin(F32(2.0) * F32(np.pi) * F32(freq) * np.arange(n, dtype=F32) / F32(sr)).astype(F32)
+
+
+def generate_noise(sr, duration):
+    n = int(duration * sr)
+    out = np.empty(n, F32)
+    seed = 12345
+    for i in range(n):
+        seed = (seed * 1103515245 + 12345) & 0xFFFFFFFFFFFFFFFF
+        out[i] = F32(F32(seed >> 16) / F32(32768.0)) - F32(1.0)
+    return out
+
+
+def generate_mixed(sr, duration):
+    t = _t(int(duration * sr), sr)
+    tw = F32(2.0) * F32(np.pi)
+    return (F32(0.5) * np.sin(tw * F32(200.0) * t) + F32(0.3) * np.sin(tw * F32(500.0) * t)
+            + F32(0.2) * np.sin(tw * F32(1000.0) * t)).astype(F32)
+
+
+def generate_speech_like(sr, duration):
+    t = _t(int(duration * sr), sr)
+    tw = F32(2.0) * F32(np.pi)
+    f0 = F32(150.0)
+    env = np.abs(np.sin(tw * F32(3.0) * t))
+    return (env * (F32(0.4) * np.sin(tw * f0 * t) + F32(0.3) * np.sin(tw * F32(2.0) * f0 * t)
+                   + F32(0.2) * np.sin(tw * F32(3.0) * f0 * t) + F32(0.1) * np.sin(tw * F32(4.0) * f0 * t))).astype(F32)
+
+
+def signals(sr=16000, duration=1.0):
+    """The four STFT validation cases of the reference plus its LCG noise generator."""
+    return {
+        "sine_440": generate_sine(sr, duration, 440.0),
+        "mixed": generate_mixed(sr, duration),
+        "speech_like": generate_speech_like(sr, duration),
+        "noise_lcg": generate_noise(sr, min(duration, 1.0)),
+    }
+
+
+def stft_power_direct_dft_f32(samples, window, n_fft, hop):
+    """The reference's OWN oracle: compute_stft_reference (validate_correctness.rs:19-59), O(N^2) DFT
+    with f32 angles and f32 accumulation.  Used to pin this module by the reference's criterion."""
+    n_freqs = n_fft // 2 + 1
+    n_frames = (len(samples) - n_fft) // hop + 1 if len(samples) >= n_fft else 0
+    if n_frames == 0:
+        return np.zeros((1, n_freqs), F32)
+    k = np.arange(n_freqs, dtype=F32)[:, None]
+    n = np.arange(n_fft, dtype=F32)[None, :]
+    ang = (F32(2.0) * F32(np.pi) * k * n / F32(n_fft)).astype(F32)
+    c, s = np.cos(ang).astype(F32), np.sin(ang).astype(F32)
+    out = np.empty((n_frames, n_freqs), F32)
+    for f in range(n_frames):
+        w = (samples[f * hop:f * hop + n_fft] * window).astype(F32)
+        re = (c * w[None, :]).sum(axis=1, dtype=F32)
+        im = -(s * w[None, :]).sum(axis=1, dtype=F32)
+        out[f] = re * re + im * im
+    return out

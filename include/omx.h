@@ -168,6 +168,24 @@ int omx_qwen3_stream(omx_qwen3 m, omx_stream* s);
 int omx_qwen3_step_bytes(omx_qwen3 m, int ctx, double* bytes);
 
 /* =====================================================================================
+ * a6 + a7: sparse-MoE block = router + top-k + SwitchGLU + weighted sum.
+ *   mode 0  MixtralSparseMoeBlock::forward (mixtral-mlx/src/model.rs:296-308): top-k of the gate logits,
+ *           softmax (precise) over the SELECTED logits;
+ *   mode 1  MoeBlock::forward of Qwen3-MoE (qwen3-mlx/src/qwen3_moe.rs:475-503): softmax over all experts,
+ *           top-k, scores renormalised when norm_topk_prob.
+ *   experts SwitchGLU::forward_experts (model.rs:243-274) = mlx_gather_qmm x3 (ops.h:471-484) + fused_swiglu;
+ *           here with dense bf16 stacked weights w_gate/w_up [E, inter, hidden], w_down [E, hidden, inter]
+ *           (mlx_gather_mm form, ops.h:463-470).
+ * x [n_tokens, hidden] -> out [n_tokens, hidden]; inds_out [n_tokens, top_k] u32 and scores_out
+ * [n_tokens, top_k] bf16 are optional device outputs (descending score order).  Scratch comes from the
+ * library workspace (omx_moe_workspace_bytes tells how much; omx_set_workspace to provide it).
+ * ===================================================================================== */
+int omx_moe_workspace_bytes(int n_tokens, int hidden, int inter, int n_experts, int top_k, size_t* bytes);
+int omx_moe_forward(void* out, const void* x, const void* gate_w, const void* w_gate, const void* w_up,
+                    const void* w_down, int n_tokens, int hidden, int inter, int n_experts, int top_k, int mode,
+                    int norm_topk_prob, uint32_t* inds_out, void* scores_out, omx_stream stream);
+
+/* =====================================================================================
  * a12: Paraformer mel/STFT frontend (funasr-mlx/src/paraformer.rs:195-412), all on device:
  * x*32768 -> pre-emphasis 0.97 -> frames (n-400)/160+1 -> Hamming -> 400-pt DFT power -> 80 HTK
  * mel filters -> ln(max(.,1e-10)) -> LFR(7,6) -> CMVN.  Replaces MelFrontend::{new,set_cmvn,forward}.

@@ -1,7 +1,10 @@
 // bf16 GEMM on the gfx950 matrix cores for the compute-bound side of the path:
 //   out[M,N] = x[M,K] . W[N,K]^T (+ bias[N]) (+ residual[M,N])      -- nn::Linear at M > 4
 //   (mlx-rs/src/nn/linear.rs:87-92 -> mlx_matmul / mlx_addmm, mlx-c ops.h:598-602, 36-43):
-//   prefill projections (M = 2048), FLUX.2-klein DiT GEMMs (M = 4608), Paraformer encoder (M = 501).
+//   prefill projections (M = 2048), FLUX.2-klein DiT GEMMs (M = 4608), Paraformer encoder (M = 501);
+//   and the GROUPED form used by the sparse-MoE block (gather_mm / gather_qmm semantics,
+//   mlx-rs/src/ops/quantization.rs:169-279; mixtral-mlx/src/model.rs:194-275): rows sorted by expert,
+//   one weight matrix per expert segment, activation rows gathered through an index array.
 // Both operands are K-contiguous ("NT"), which is exactly the MFMA A/B fragment shape: a lane
 // reads 8 consecutive k of one row (16 B) for either operand.
 //
@@ -29,47 +32,77 @@ constexpr int TILE_BYTES = BM * BK * 2;   // 16 KiB per operand tile
 
 struct GemmArgs {
     const bf16_t* x;      // [M, K]
-    const bf16_t* w;      // [N, K]
+    const bf16_t* w;      // [N, K]   (grouped: [E, N, K])
     const bf16_t* bias;   // [N] or null
     const bf16_t* resid;  // [M, N] or null : out = bf16(resid + bf16(acc (+bias)))
     bf16_t* out;          // [M, N]
     int M, N, K;
     int grid_m, grid_n;
+    GroupedDesc g;        // grouped mode when g.tile_expert != nullptr
 };
 
-// stage one 128 x 64 operand tile: 1024 16-B chunks, 4 wave-instructions per wave
-__device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ src, int row0, int rows_valid, int K, int k0,
-                                           unsigned char* lds_tile) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+// one 16-B chunk per lane per wave-instruction, 4 instructions per operand tile: row pointers of the 4
+// rows this thread stages are fixed for the whole K loop
+struct StageRows {
+    const bf16_t* p[4];   // row base + logical k-chunk offset (the source-side swizzle)
+};
+
+__device__ __forceinline__ void stage_tile(const StageRows& r, int k0, unsigned char* lds_tile) {
+    const int wave = threadIdx.x >> 6;
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        const int chunk = p * 256 + wave * 64 + lane;   // LDS chunk index (lane-linear inside the wave)
-        const int row = chunk >> 3;
-        const int kc = (chunk & 7) ^ (row & 7);          // logical k-chunk stored at this LDS slot
-        const int grow = min(row0 + row, rows_valid - 1);
-        const bf16_t* g = src + (size_t)grow * K + k0 + kc * 8;
-        __builtin_amdgcn_global_load_lds((glb_ptr_t)g, (lds_ptr_t)(lds_tile + (p * 256 + wave * 64) * 16), 16, 0, 0);
-    }
+    for (int p = 0; p < 4; ++p)
+        __builtin_amdgcn_global_load_lds((glb_ptr_t)(r.p[p] + k0), (lds_ptr_t)(lds_tile + (p * 256 + wave * 64) * 16), 16, 0, 0);
 }
 
 __device__ __forceinline__ bf16x8 lds_frag(const unsigned char* lds_tile, int row, int kc) {
     return *reinterpret_cast<const bf16x8*>(lds_tile + ((row << 3) + (kc ^ (row & 7))) * 16);
 }
 
+template <bool GROUPED>
 __global__ __launch_bounds__(NTHREADS) void gemm_bf16_nt_kernel(const GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [2 buffers][A tile | B tile]
-    // XCD-aware remap: block b runs on XCD b % 8; give each XCD a contiguous run of tiles
-    const int nblk = a.grid_m * a.grid_n;
-    int bid = blockIdx.x;
-    {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int m0, n0, rows_valid, out_row0;
+    const bf16_t* w = a.w;
+    if (GROUPED) {
+        // tile table built on the device by moe_plan_kernel: tile -> (expert, first row inside its segment)
+        const int tile = blockIdx.x / a.grid_n;
+        if (tile >= *a.g.n_tiles) return;
+        const int e = a.g.tile_expert[tile];
+        const int seg = a.g.seg_start[e];
+        m0 = a.g.tile_m0[tile];
+        rows_valid = a.g.seg_start[e + 1] - seg;   // rows of this expert
+        out_row0 = seg;                            // rows are produced in expert-sorted order
+        n0 = (blockIdx.x % a.grid_n) * BN;
+        w = a.w + (size_t)e * a.g.w_estride;
+    } else {
+        // XCD-aware remap: block b runs on XCD b % 8; give each XCD a contiguous run of tiles
+        const int nblk = a.grid_m * a.grid_n;
+        int bid = blockIdx.x;
         const int q = nblk / 8, r = nblk % 8, xcd = bid % 8, idx = bid / 8;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+        m0 = (bid / a.grid_n) * BM;
+        n0 = (bid % a.grid_n) * BN;
+        rows_valid = a.M;
+        out_row0 = 0;
     }
-    const int bm = bid / a.grid_n, bn = bid % a.grid_n;
-    const int m0 = bm * BM, n0 = bn * BN;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int nt = a.K / BK;
+
+    StageRows ra, rb;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int chunk = p * 256 + wave * 64 + lane;   // LDS chunk index (lane-linear inside the wave)
+        const int row = chunk >> 3;
+        const int kc = (chunk & 7) ^ (row & 7);          // logical k-chunk stored at this LDS slot
+        int arow = min(m0 + row, rows_valid - 1);
+        if (GROUPED) {
+            arow += out_row0;                            // position in expert-sorted order
+            if (a.g.row_src) arow = (int)a.g.row_src[arow];   // gather: sorted position -> source activation row
+        }
+        ra.p[p] = a.x + (size_t)arow * a.K + kc * 8;
+        rb.p[p] = w + (size_t)min(n0 + row, a.N - 1) * a.K + kc * 8;
+    }
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -79,8 +112,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_nt_kernel(const GemmArgs a
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    stage_tile(a.x, m0, a.M, a.K, 0, smem);
-    stage_tile(a.w, n0, a.N, a.K, 0, smem + TILE_BYTES);
+    stage_tile(ra, 0, smem);
+    stage_tile(rb, 0, smem + TILE_BYTES);
     __builtin_amdgcn_s_waitcnt(0);
     __syncthreads();
 
@@ -90,8 +123,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_nt_kernel(const GemmArgs a
         unsigned char* bufB = bufA + TILE_BYTES;
         if (t + 1 < nt) {
             unsigned char* nA = smem + (cur ^ 1) * 2 * TILE_BYTES;
-            stage_tile(a.x, m0, a.M, a.K, (t + 1) * BK, nA);
-            stage_tile(a.w, n0, a.N, a.K, (t + 1) * BK, nA + TILE_BYTES);
+            stage_tile(ra, (t + 1) * BK, nA);
+            stage_tile(rb, (t + 1) * BK, nA + TILE_BYTES);
         }
 #pragma unroll
         for (int ks = 0; ks < BK / 16; ++ks) {
@@ -123,10 +156,11 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_nt_kernel(const GemmArgs a
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (row < a.M) {
+                if (row < rows_valid) {
+                    const size_t o = (size_t)(out_row0 + row) * a.N + col;
                     float v = acc[i][j][r] + bv;
-                    if (a.resid) v = bf16_to_f32(a.resid[(size_t)row * a.N + col]) + round_bf16(v);
-                    a.out[(size_t)row * a.N + col] = f32_to_bf16(v);
+                    if (a.resid) v = bf16_to_f32(a.resid[o]) + round_bf16(v);
+                    a.out[o] = f32_to_bf16(v);
                 }
             }
         }
@@ -177,21 +211,27 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_nt_generic_kernel(const Ge
     }
 }
 
+int ensure_attr() {
+    static bool attr_set = false;
+    if (!attr_set) {
+        const int shmem = 4 * TILE_BYTES;
+        OMX_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_bf16_nt_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, shmem));
+        OMX_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_bf16_nt_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, shmem));
+        attr_set = true;
+    }
+    return 0;
+}
+
 }  // namespace
 
 int launch_gemm_bf16_ex(bf16_t* out, const bf16_t* x, const bf16_t* w, const bf16_t* bias, const bf16_t* resid, int M,
                         int N, int K, hipStream_t s) {
     OMX_REQUIRE(M > 0 && N > 0 && K > 0, "gemm: bad shape M=%d N=%d K=%d", M, N, K);
-    GemmArgs a = {x, w, bias, resid, out, M, N, K, (M + BM - 1) / BM, (N + BN - 1) / BN};
+    GemmArgs a = {x, w, bias, resid, out, M, N, K, (M + BM - 1) / BM, (N + BN - 1) / BN, {}};
     const bool fast = (K % BK == 0) && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w)) & 15u) == 0;
     if (fast) {
-        static bool attr_set = false;
-        const int shmem = 4 * TILE_BYTES;
-        if (!attr_set) {
-            OMX_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_bf16_nt_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, shmem));
-            attr_set = true;
-        }
-        gemm_bf16_nt_kernel<<<a.grid_m * a.grid_n, NTHREADS, shmem, s>>>(a);
+        if (ensure_attr()) return 1;
+        gemm_bf16_nt_kernel<false><<<a.grid_m * a.grid_n, NTHREADS, 4 * TILE_BYTES, s>>>(a);
     } else {
         gemm_bf16_nt_generic_kernel<<<dim3((N + 63) / 64, (M + 63) / 64), NTHREADS, 0, s>>>(a);
     }
@@ -202,6 +242,18 @@ int launch_gemm_bf16_ex(bf16_t* out, const bf16_t* x, const bf16_t* w, const bf1
 int launch_gemm_bf16(bf16_t* out, const bf16_t* x, const bf16_t* w, const bf16_t* bias, int M, int N, int K,
                      hipStream_t s) {
     return launch_gemm_bf16_ex(out, x, w, bias, nullptr, M, N, K, s);
+}
+
+int launch_gemm_bf16_grouped(bf16_t* out, const bf16_t* x, const bf16_t* w, int max_rows, int N, int K,
+                             const GroupedDesc& g, int max_tiles, hipStream_t s) {
+    OMX_REQUIRE(max_rows > 0 && N > 0 && K > 0 && max_tiles > 0, "grouped gemm: bad shape");
+    OMX_REQUIRE(K % BK == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w)) & 15u) == 0,
+                "grouped gemm: K=%d must be a multiple of %d and operands 16-byte aligned", K, BK);
+    GemmArgs a = {x, w, nullptr, nullptr, out, max_rows, N, K, max_tiles, (N + BN - 1) / BN, g};
+    if (ensure_attr()) return 1;
+    gemm_bf16_nt_kernel<true><<<max_tiles * a.grid_n, NTHREADS, 4 * TILE_BYTES, s>>>(a);
+    OMX_LAUNCH_CHECK();
+    return 0;
 }
 
 }  // namespace omx

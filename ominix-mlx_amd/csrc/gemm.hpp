@@ -5,6 +5,16 @@
 
 namespace omx {
 
+// Grouped (expert-segmented) GEMM descriptor; every pointer is DEVICE memory written by moe_plan_kernel.
+struct GroupedDesc {
+    const int* tile_expert = nullptr;   // [max_tiles] expert of each 128-row tile
+    const int* tile_m0 = nullptr;       // [max_tiles] first row of the tile inside its expert segment
+    const int* seg_start = nullptr;     // [E + 1] exclusive prefix sums of rows per expert
+    const int* n_tiles = nullptr;       // [1] tiles actually in use
+    const uint32_t* row_src = nullptr;  // optional [rows]: source activation row of each sorted position (gather)
+    size_t w_estride = 0;               // elements between consecutive experts' [N, K] matrices
+};
+
 // out[M,N] = x[M,K] . W[N,K]^T (+ bias[N]); bf16 in/out, fp32 accumulate (nn::Linear, linear.rs:87-92)
 int launch_gemm_bf16(bf16_t* out, const bf16_t* x, const bf16_t* w, const bf16_t* bias, int M, int N, int K,
                      hipStream_t s);
@@ -12,6 +22,10 @@ int launch_gemm_bf16(bf16_t* out, const bf16_t* x, const bf16_t* w, const bf16_t
 // same with an optional fused residual: out = bf16(resid + bf16(x.W^T (+bias)))
 int launch_gemm_bf16_ex(bf16_t* out, const bf16_t* x, const bf16_t* w, const bf16_t* bias, const bf16_t* resid, int M,
                         int N, int K, hipStream_t s);
+
+// rows sorted by expert: out[p, :] = x[row_src ? row_src[p] : p, :] . W[e(p)]^T, p in expert-sorted order
+int launch_gemm_bf16_grouped(bf16_t* out, const bf16_t* x, const bf16_t* w, int max_rows, int N, int K,
+                             const GroupedDesc& g, int max_tiles, hipStream_t s);
 
 // SDPA with Tq > 1 (prefill / DiT joint attention): flash-attention forward on MFMA.
 int launch_attn_prefill(bf16_t* out, const bf16_t* q, const bf16_t* k, const bf16_t* v, int B, int H, int Hkv, int Tq,

@@ -50,8 +50,13 @@ __device__ __forceinline__ void epilogue(const GemvArgs& a, int row, float v0, f
         // (qwen3-mlx/src/model.rs:264-265; mlx-rs/src/nn/activation.rs:876-880)
         const float g = round_bf16(v0);
         const float u = round_bf16(v1);
-        const float sg = round_bf16(1.0f / (1.0f + expf(-g)));
-        reinterpret_cast<bf16_t*>(a.out)[row] = f32_to_bf16(round_bf16(g * sg) * u);
+        if (a.swiglu_single_round) {
+            // mlx_rs_core::fused_swiglu(up, gate) (metal_kernels.rs:11-18): one kernel, one rounding
+            reinterpret_cast<bf16_t*>(a.out)[row] = f32_to_bf16(g / (1.0f + expf(-g)) * u);
+        } else {
+            const float sg = round_bf16(1.0f / (1.0f + expf(-g)));
+            reinterpret_cast<bf16_t*>(a.out)[row] = f32_to_bf16(round_bf16(g * sg) * u);
+        }
     } else if (EPI == EPI_ARGMAX) {
         const bf16_t lb = f32_to_bf16(v0);
         reinterpret_cast<bf16_t*>(a.out)[row] = lb;
@@ -64,7 +69,20 @@ __device__ __forceinline__ void epilogue(const GemvArgs& a, int row, float v0, f
 // KSPLIT = waves sharing one row (1: a wave owns whole rows; 4: each wave owns a K quarter)
 // RB     = logical rows per register batch; LR physical rows per logical row (2 for SwiGLU)
 template <int NVW, int KSPLIT, int RB, int PRO, int EPI>
-__global__ __launch_bounds__(kBlock) void gemv_kernel(const GemvArgs a) {
+__global__ __launch_bounds__(kBlock) void gemv_kernel(const GemvArgs a_in) {
+    // batched / expert-selected form (MoE decode): blockIdx.y picks the activation row, the output row
+    // block and, through a device index array, the expert whose weights are streamed
+    GemvArgs a = a_in;
+    if (a_in.n_batch > 1 || a_in.w_sel) {
+        const int by = blockIdx.y;
+        a.x = a_in.x + (size_t)(by / a_in.x_div) * a_in.x_bstride;
+        a.out = reinterpret_cast<char*>(a_in.out) + (size_t)by * a_in.out_bstride_bytes;
+        if (a_in.w_sel) {
+            const size_t e = a_in.w_sel[by];
+            a.w0 = a_in.w0 + e * a_in.w_estride;
+            if (a_in.w1) a.w1 = a_in.w1 + e * a_in.w_estride;
+        }
+    }
     constexpr int LR = (EPI == EPI_SWIGLU) ? 2 : 1;
     constexpr int NV = NVW * KSPLIT;            // vectors per lane for the whole row
     constexpr int NR = RB * LR;
@@ -244,7 +262,7 @@ __global__ __launch_bounds__(kBlock) void gemv_kernel(const GemvArgs a) {
 template <int NVW, int KSPLIT, int RB>
 int launch_nv(const GemvArgs& a, int pro, int epi, hipStream_t s) {
     const int groups = (a.N + a.rows_per_wave - 1) / a.rows_per_wave;   // row groups (waves or blocks)
-    const dim3 grid(KSPLIT == 1 ? (groups + kWaves - 1) / kWaves : groups), block(kBlock);
+    const dim3 grid(KSPLIT == 1 ? (groups + kWaves - 1) / kWaves : groups, a.n_batch > 1 ? a.n_batch : 1), block(kBlock);
     const size_t shmem = (size_t)NVW * KSPLIT * 64 * 16 + 32 + (KSPLIT > 1 ? (size_t)a.rows_per_wave * 2 * KSPLIT * 4 : 0);
 #define OMX_GEMV_CASE(P, E)                                                                          \
     if (pro == P && epi == E) {                                                                      \

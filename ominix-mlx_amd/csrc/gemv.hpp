@@ -42,6 +42,14 @@ struct GemvArgs {
     unsigned long long* argmax_slot;   // EPI_ARGMAX: [gridDim.x] per-block max of (orderable(logit)<<32 | ~row)
     int row_offset;             // EPI_ARGMAX: global row index offset (vocab shard)
     int rows_per_wave;
+    // batched / expert-selected launch (MoE decode, gather_mm semantics): grid.y = n_batch
+    int n_batch;                // 0 or 1: plain launch
+    int x_div;                  // activation row of batch entry j is j / x_div (top-k slots share a token)
+    size_t x_bstride;           // elements between activation rows
+    size_t out_bstride_bytes;   // bytes between the output vectors of consecutive batch entries
+    const uint32_t* w_sel;      // optional [n_batch] device array: expert id per batch entry
+    size_t w_estride;           // elements between consecutive experts' matrices
+    int swiglu_single_round;    // EPI_SWIGLU: fused_swiglu (one rounding) instead of nn::silu(g)*u (three)
 };
 
 int launch_gemv(const GemvArgs& a, int pro, int epi, hipStream_t s);

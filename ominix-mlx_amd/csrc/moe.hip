@@ -1,0 +1,227 @@
+// Sparse mixture-of-experts block: router + top-k + SwitchGLU + weighted sum.
+//   reference: MixtralSparseMoeBlock::forward  mixtral-mlx/src/model.rs:296-308
+//              MoeBlock::forward (Qwen3-MoE)   qwen3-mlx/src/qwen3_moe.rs:475-503
+//              SwitchGLU::forward_experts      mixtral-mlx/src/model.rs:243-274  (gather_qmm x3 + fused_swiglu,
+//                                              rows sorted by expert when B*L*k >= 64)
+// The reference issues ~12 lazy ops per block (argpartition, take_along_axis, softmax, argsort x2,
+// floor_divide, take x3, gather_qmm x3, fused_swiglu, multiply, sum).  Here:
+//   moe_router_kernel    gate GEMV + top-k + softmax per token in one block (logits in bf16, softmax fp32)
+//   decode  (N*k <= 32)  two expert-selected batched GEMV launches (gate/up + fused_swiglu epilogue, down)
+//   prefill              counting sort by expert on the device (moe_plan_kernel) -> grouped MFMA GEMM with row
+//                        gather (no materialised x_sorted) -> fused_swiglu -> grouped GEMM
+//   moe_combine_kernel   y * score summed over k, un-sorting through the inverse permutation
+// Expert weights are dense bf16 [E, out, in] (the bf16 build of BASELINE config 3; the reference's 4-bit
+// gather_qmm is a SURVEY 8f "next" row).
+#include "gemm.hpp"
+#include "gemv.hpp"
+#include "workspace.hpp"
+
+namespace omx {
+namespace {
+
+constexpr int kMaxExperts = 256;
+constexpr int kMaxTopK = 8;
+
+// one block per token: logits[e] = bf16(x . Wg[e]) ; mode 0: top-k of logits, softmax over the selected
+// (precise) ; mode 1: softmax over all (precise, rounded to bf16), top-k, optional renormalisation
+__global__ __launch_bounds__(256) void moe_router_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ gate_w,
+                                                         int h, int E, int k, int mode, int renorm,
+                                                         uint32_t* __restrict__ inds, bf16_t* __restrict__ scores) {
+    __shared__ float s_logit[kMaxExperts];
+    const int t = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bf16_t* xr = x + (size_t)t * h;
+    for (int e = wave; e < E; e += 4) {
+        const bf16_t* wr = gate_w + (size_t)e * h;
+        float acc = 0.f;
+        for (int i = lane * 8; i < h; i += 64 * 8) {
+            const u32x4 a = *reinterpret_cast<const u32x4*>(xr + i);
+            const u32x4 b = *reinterpret_cast<const u32x4*>(wr + i);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                acc = fmaf(bf16lo(a[q]), bf16lo(b[q]), acc);
+                acc = fmaf(bf16hi(a[q]), bf16hi(b[q]), acc);
+            }
+        }
+        acc = wave_sum(acc);
+        if (lane == 0) s_logit[e] = round_bf16(acc);   // the gate Linear's output is a bf16 array
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    float v[kMaxExperts];
+    if (mode == 1) {   // softmax over all experts first (qwen3_moe.rs:479)
+        float mx = -INFINITY, sum = 0.f;
+        for (int e = 0; e < E; ++e) mx = fmaxf(mx, s_logit[e]);
+        for (int e = 0; e < E; ++e) sum += expf(s_logit[e] - mx);
+        for (int e = 0; e < E; ++e) s_logit[e] = round_bf16(expf(s_logit[e] - mx) / sum);
+    }
+    uint32_t sel[kMaxTopK];
+    float selv[kMaxTopK];
+    unsigned long long taken[kMaxExperts / 64] = {0, 0, 0, 0};
+    for (int j = 0; j < k; ++j) {   // descending, ties to the lower index
+        int best = -1;
+        float bv = -INFINITY;
+        for (int e = 0; e < E; ++e)
+            if (!((taken[e >> 6] >> (e & 63)) & 1ull) && (best < 0 || s_logit[e] > bv)) { best = e; bv = s_logit[e]; }
+        taken[best >> 6] |= 1ull << (best & 63);
+        sel[j] = (uint32_t)best;
+        selv[j] = bv;
+    }
+    (void)v;
+    if (mode == 0) {   // softmax over the selected logits (model.rs:301-302)
+        float mx = selv[0], sum = 0.f;
+        for (int j = 1; j < k; ++j) mx = fmaxf(mx, selv[j]);
+        for (int j = 0; j < k; ++j) sum += expf(selv[j] - mx);
+        for (int j = 0; j < k; ++j) selv[j] = round_bf16(expf(selv[j] - mx) / sum);
+    } else if (renorm && k > 1) {
+        float sum = 0.f;
+        for (int j = 0; j < k; ++j) sum += selv[j];
+        sum = round_bf16(sum);
+        for (int j = 0; j < k; ++j) selv[j] = round_bf16(selv[j] / sum);
+    }
+    for (int j = 0; j < k; ++j) {
+        inds[(size_t)t * k + j] = sel[j];
+        scores[(size_t)t * k + j] = f32_to_bf16(selv[j]);
+    }
+}
+
+// counting sort of the N*k (token, slot) pairs by expert + tile table of the grouped GEMM (single block)
+__global__ __launch_bounds__(1024) void moe_plan_kernel(const uint32_t* __restrict__ inds, int n_slots, int E, int k,
+                                                        int* __restrict__ seg_start, uint32_t* __restrict__ row_src,
+                                                        uint32_t* __restrict__ pos_of_slot, int* __restrict__ tile_expert,
+                                                        int* __restrict__ tile_m0, int* __restrict__ n_tiles) {
+    __shared__ int s_cnt[kMaxExperts], s_start[kMaxExperts + 1], s_fill[kMaxExperts];
+    for (int e = threadIdx.x; e < E; e += blockDim.x) { s_cnt[e] = 0; s_fill[e] = 0; }
+    __syncthreads();
+    for (int i = threadIdx.x; i < n_slots; i += blockDim.x) atomicAdd(&s_cnt[inds[i]], 1);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int acc = 0, tiles = 0;
+        for (int e = 0; e < E; ++e) {
+            s_start[e] = acc;
+            for (int m0 = 0; m0 < s_cnt[e]; m0 += 128) { tile_expert[tiles] = e; tile_m0[tiles] = m0; ++tiles; }
+            acc += s_cnt[e];
+        }
+        s_start[E] = acc;
+        *n_tiles = tiles;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e <= E; e += blockDim.x) seg_start[e] = s_start[e];
+    // order inside an expert segment is arbitrary (atomics): every row is computed independently and
+    // un-sorted again through pos_of_slot, so the result does not depend on it
+    for (int i = threadIdx.x; i < n_slots; i += blockDim.x) {
+        const int e = (int)inds[i];
+        const int p = s_start[e] + atomicAdd(&s_fill[e], 1);
+        row_src[p] = (uint32_t)(i / k);      // x_sorted = x_flat[order // k]  (model.rs:214-216)
+        pos_of_slot[i] = (uint32_t)p;
+    }
+}
+
+// out[t] = bf16( sum_j bf16( y[pos(t,j)] * score[t,j] ) )     (model.rs:304-307)
+__global__ __launch_bounds__(256) void moe_combine_kernel(bf16_t* __restrict__ out, const bf16_t* __restrict__ y,
+                                                          const bf16_t* __restrict__ scores,
+                                                          const uint32_t* __restrict__ pos_of_slot, int h, int k) {
+    const int t = blockIdx.x;
+    for (int i = threadIdx.x * 8; i < h; i += 256 * 8) {
+        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int j = 0; j < k; ++j) {
+            const size_t slot = (size_t)t * k + j;
+            const size_t p = pos_of_slot ? pos_of_slot[slot] : slot;
+            const float sc = bf16_to_f32(scores[slot]);
+            const u32x4 v = *reinterpret_cast<const u32x4*>(y + p * h + i);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                acc[2 * q] += round_bf16(bf16lo(v[q]) * sc);
+                acc[2 * q + 1] += round_bf16(bf16hi(v[q]) * sc);
+            }
+        }
+        u32x4 o;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) o[q] = pack_bf16(acc[2 * q], acc[2 * q + 1]);
+        *reinterpret_cast<u32x4*>(out + (size_t)t * h + i) = o;
+    }
+}
+
+}  // namespace
+}  // namespace omx
+
+extern "C" int omx_moe_workspace_bytes(int n_tokens, int hidden, int inter, int n_experts, int top_k, size_t* bytes) {
+    OMX_REQUIRE(bytes, "omx_moe_workspace_bytes: null argument");
+    const size_t slots = (size_t)n_tokens * top_k;
+    const size_t tiles = slots / 128 + n_experts + 1;
+    *bytes = slots * 4 * 3 + slots * 2 + (size_t)(n_experts + 2) * 4 + tiles * 8 + 4096 +   // plan
+             slots * (size_t)inter * 2 * 2 + slots * (size_t)hidden * 2;                     // gate/up (act in place), y
+    return 0;
+}
+
+extern "C" int omx_moe_forward(void* out, const void* x, const void* gate_w, const void* w_gate, const void* w_up,
+                               const void* w_down, int n_tokens, int hidden, int inter, int n_experts, int top_k,
+                               int mode, int norm_topk_prob, uint32_t* inds_out, void* scores_out, omx_stream stream) {
+    using namespace omx;
+    OMX_REQUIRE(out && x && gate_w && w_gate && w_up && w_down, "omx_moe_forward: null tensor");
+    OMX_REQUIRE(n_tokens >= 0 && hidden > 0 && inter > 0, "omx_moe_forward: bad shape");
+    OMX_REQUIRE(n_experts >= 1 && n_experts <= kMaxExperts && top_k >= 1 && top_k <= kMaxTopK && top_k <= n_experts,
+                "omx_moe_forward: n_experts=%d (max %d), top_k=%d (max %d)", n_experts, kMaxExperts, top_k, kMaxTopK);
+    OMX_REQUIRE(hidden % 64 == 0 && inter % 64 == 0, "omx_moe_forward: hidden=%d and intermediate=%d must be multiples of 64", hidden, inter);
+    OMX_REQUIRE(mode == 0 || mode == 1, "omx_moe_forward: mode must be 0 (Mixtral) or 1 (Qwen3-MoE)");
+    if (n_tokens == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    const int slots = n_tokens * top_k;
+    const int max_tiles = slots / 128 + n_experts + 1;
+    size_t need = 0;
+    omx_moe_workspace_bytes(n_tokens, hidden, inter, n_experts, top_k, &need);
+    void* ws = nullptr;
+    if (get_workspace(&ws, need)) return 1;
+    char* p = (char*)ws;
+    auto take = [&](size_t bytes) { char* r = p; p += (bytes + 255) & ~(size_t)255; return r; };
+    uint32_t* inds = (uint32_t*)take((size_t)slots * 4);
+    uint32_t* row_src = (uint32_t*)take((size_t)slots * 4);
+    uint32_t* pos_of_slot = (uint32_t*)take((size_t)slots * 4);
+    bf16_t* scores = (bf16_t*)take((size_t)slots * 2);
+    int* seg_start = (int*)take((size_t)(n_experts + 2) * 4);
+    int* tile_expert = (int*)take((size_t)max_tiles * 4);
+    int* tile_m0 = (int*)take((size_t)max_tiles * 4);
+    int* n_tiles = (int*)take(256);
+    bf16_t* gbuf = (bf16_t*)take((size_t)slots * inter * 2);
+    bf16_t* ubuf = (bf16_t*)take((size_t)slots * inter * 2);
+    bf16_t* ybuf = (bf16_t*)take((size_t)slots * hidden * 2);
+
+    moe_router_kernel<<<n_tokens, 256, 0, s>>>((const bf16_t*)x, (const bf16_t*)gate_w, hidden, n_experts, top_k, mode,
+                                               norm_topk_prob, inds, scores);
+    OMX_LAUNCH_CHECK();
+    const bool decode = slots <= 32 && hidden % 512 == 0 && inter % 512 == 0;
+    if (decode) {
+        // SwitchGLU without the sort (model.rs:262-272): expert-selected batched GEMVs
+        GemvArgs a = {};
+        a.w0 = (const bf16_t*)w_gate; a.w1 = (const bf16_t*)w_up; a.n0 = inter; a.N = inter; a.K = hidden;
+        a.x = (const bf16_t*)x; a.out = gbuf;
+        a.n_batch = slots; a.x_div = top_k; a.x_bstride = hidden; a.out_bstride_bytes = (size_t)inter * 2;
+        a.w_sel = inds; a.w_estride = (size_t)inter * hidden; a.swiglu_single_round = 1;
+        if (launch_gemv(a, PRO_NONE, EPI_SWIGLU, s)) return 1;
+        GemvArgs d = {};
+        d.w0 = (const bf16_t*)w_down; d.n0 = hidden; d.N = hidden; d.K = inter;
+        d.x = gbuf; d.out = ybuf;
+        d.n_batch = slots; d.x_div = 1; d.x_bstride = inter; d.out_bstride_bytes = (size_t)hidden * 2;
+        d.w_sel = inds; d.w_estride = (size_t)hidden * inter;
+        if (launch_gemv(d, PRO_NONE, EPI_STORE, s)) return 1;
+        moe_combine_kernel<<<n_tokens, 256, 0, s>>>((bf16_t*)out, ybuf, scores, nullptr, hidden, top_k);
+        OMX_LAUNCH_CHECK();
+    } else {
+        moe_plan_kernel<<<1, 1024, 0, s>>>(inds, slots, n_experts, top_k, seg_start, row_src, pos_of_slot, tile_expert,
+                                           tile_m0, n_tiles);
+        OMX_LAUNCH_CHECK();
+        GroupedDesc g;
+        g.tile_expert = tile_expert; g.tile_m0 = tile_m0; g.seg_start = seg_start; g.n_tiles = n_tiles;
+        g.row_src = row_src; g.w_estride = (size_t)inter * hidden;
+        if (launch_gemm_bf16_grouped(gbuf, (const bf16_t*)x, (const bf16_t*)w_gate, slots, inter, hidden, g, max_tiles, s)) return 1;
+        if (launch_gemm_bf16_grouped(ubuf, (const bf16_t*)x, (const bf16_t*)w_up, slots, inter, hidden, g, max_tiles, s)) return 1;
+        if (omx_fused_swiglu(gbuf, ubuf, gbuf, (int64_t)slots * inter, OMX_BFLOAT16, stream)) return 1;   // fused_swiglu(up, gate)
+        g.row_src = nullptr;   // activations are already in expert-sorted order
+        g.w_estride = (size_t)hidden * inter;
+        if (launch_gemm_bf16_grouped(ybuf, gbuf, (const bf16_t*)w_down, slots, hidden, inter, g, max_tiles, s)) return 1;
+        moe_combine_kernel<<<n_tokens, 256, 0, s>>>((bf16_t*)out, ybuf, scores, pos_of_slot, hidden, top_k);
+        OMX_LAUNCH_CHECK();
+    }
+    if (inds_out) OMX_HIP_CHECK(hipMemcpyAsync(inds_out, inds, (size_t)slots * 4, hipMemcpyDeviceToDevice, s));
+    if (scores_out) OMX_HIP_CHECK(hipMemcpyAsync(scores_out, scores, (size_t)slots * 2, hipMemcpyDeviceToDevice, s));
+    return 0;
+}

@@ -1,0 +1,41 @@
+"""Host mirror of the sparse-MoE block (mixtral-mlx/src/model.rs:280-313 `MixtralSparseMoeBlock`,
+qwen3-mlx/src/qwen3_moe.rs:440-508 `MoeBlock`) over omx_moe_forward."""
+from __future__ import annotations
+
+import ctypes
+
+from . import UINT32, check, lib
+from .ops import Tensor
+
+c_int, c_void_p, c_size_t = ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t
+MOE_SIGNATURES = {
+    "omx_moe_workspace_bytes": (c_int, [c_int, c_int, c_int, c_int, c_int, ctypes.POINTER(c_size_t)]),
+    "omx_moe_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                                c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+}
+for _n, (_r, _a) in MOE_SIGNATURES.items():
+    _f = getattr(lib, _n)
+    _f.restype, _f.argtypes = _r, _a
+
+
+class SparseMoeBlock:
+    """gate: Linear [E, hidden]; switch_mlp.{gate,up,down}_proj stacked [E, ...] (model.rs:478-506)."""
+
+    def __init__(self, gate_w: Tensor, w_gate: Tensor, w_up: Tensor, w_down: Tensor, num_experts_per_tok: int,
+                 mode: str = "mixtral", norm_topk_prob: bool = True):
+        self.gate_w, self.w_gate, self.w_up, self.w_down = gate_w, w_gate, w_up, w_down
+        self.E, self.hidden = gate_w.shape
+        self.inter = w_gate.shape[1]
+        self.k = num_experts_per_tok
+        self.mode = {"mixtral": 0, "qwen3_moe": 1}[mode]
+        self.norm = int(norm_topk_prob)
+
+    def forward(self, x: Tensor, return_routing: bool = False):
+        n = x.size // self.hidden
+        out = Tensor(x.shape, x.dtype)
+        inds = Tensor((n, self.k), UINT32) if return_routing else None
+        scores = Tensor((n, self.k), x.dtype) if return_routing else None
+        check(lib.omx_moe_forward(out.ptr, x.ptr, self.gate_w.ptr, self.w_gate.ptr, self.w_up.ptr, self.w_down.ptr, n,
+                                  self.hidden, self.inter, self.E, self.k, self.mode, self.norm,
+                                  inds.ptr if inds else None, scores.ptr if scores else None, None))
+        return (out, inds, scores) if return_routing else out

@@ -1,0 +1,89 @@
+"""GPU parity of the sparse-MoE block (a6 router, a7 SwitchGLU / grouped GEMM) against
+oracle/ref_moe.py: Mixtral routing and Qwen3-MoE routing, the decode path (expert-selected GEMVs,
+no sort) and the sorted grouped-GEMM path (B*L*k >= 64, model.rs:250-251), ragged expert loads,
+an expert that receives no token, forced-uniform routing.
+
+Tolerance: expert outputs go through three bf16 GEMMs; |d| <= 2 bf16 ulp + 2^-7 * max|ref|.
+Routing (indices) must be identical whenever the oracle's k-th / (k+1)-th score gap exceeds one bf16 ulp."""
+import numpy as np
+import pytest
+
+from oracle import ref_core as rc, ref_moe as rm
+from test_gpu_primitives import assert_bf16_close, rand
+
+pytestmark = pytest.mark.gpu
+
+
+def _weights(E, h, I, seed):
+    return (rc.bf16_round(rand((E, h), seed) * 0.5), rc.bf16_round(rand((E, I, h), seed + 1) * 0.05),
+            rc.bf16_round(rand((E, I, h), seed + 2) * 0.05), rc.bf16_round(rand((E, h, I), seed + 3) * 0.05))
+
+
+def _run(omx, x, gw, wg, wu, wd, k, mode, norm=True):
+    from ominix_mlx_amd import moe
+    T = omx.ops.Tensor
+    blk = moe.SparseMoeBlock(T.from_numpy(gw), T.from_numpy(wg), T.from_numpy(wu), T.from_numpy(wd), k, mode, norm)
+    out, inds, scores = blk.forward(T.from_numpy(x), return_routing=True)
+    return out.numpy(), inds.numpy(), scores.numpy()
+
+
+def _compare(got, ref):
+    out, inds, scores = got
+    rout, rinds, rscores = ref
+    same = np.sort(inds, axis=1) == np.sort(rinds, axis=1)
+    assert same.all(), f"routing differs on {(~same.all(axis=1)).sum()} tokens"
+    np.testing.assert_array_equal(inds, rinds)                       # same (descending) order too
+    assert_bf16_close(scores, rscores, 1, atol=1e-6)
+    assert_bf16_close(out, rout, 2, atol=2.0 ** -7 * np.abs(rout).max())
+
+
+@pytest.mark.parametrize("mode", ["mixtral", "qwen3_moe"])
+@pytest.mark.parametrize("n_tokens", [1, 3, 70])        # decode, small batch, sorted grouped-GEMM path
+def test_moe_block_parity(omx, mode, n_tokens):
+    E, h, I, k = 8, 512, 1024, 2
+    gw, wg, wu, wd = _weights(E, h, I, 60)
+    x = rc.bf16_round(rand((n_tokens, h), 70 + n_tokens))
+    _compare(_run(omx, x, gw, wg, wu, wd, k, mode), rm.moe_block(x, gw, wg, wu, wd, k, mode))
+
+
+def test_moe_many_experts_top8_renorm_and_empty_experts(omx):
+    """Qwen3-30B-A3B-like routing shape (128 experts, top-8) on a small width; with 40 tokens most
+    experts receive no row at all (zero-length segments in the plan)."""
+    E, h, I, k = 128, 512, 512, 8
+    gw, wg, wu, wd = _weights(E, h, I, 80)
+    x = rc.bf16_round(rand((40, h), 81))
+    for norm in (True, False):
+        _compare(_run(omx, x, gw, wg, wu, wd, k, "qwen3_moe", norm), rm.moe_block(x, gw, wg, wu, wd, k, "qwen3_moe", norm))
+
+
+def test_moe_forced_uniform_and_single_expert_load(omx):
+    """forced-uniform routing (token t -> experts (2t, 2t+1) mod 8) separates kernel behaviour from
+    imbalance; the opposite extreme sends every token to the same two experts (one 300-row segment)."""
+    E, h, I, k, N = 8, 512, 1024, 2, 150
+    _, wg, wu, wd = _weights(E, h, I, 90)
+    x = np.abs(rc.bf16_round(rand((N, h), 91))) + 0.25                  # positive activations: the gate row picks the expert
+    gw = np.zeros((E, h), np.float32)
+    for e in range(E):                                                   # uniform: expert score depends on a token-specific dim
+        gw[e, e] = 1.0
+    xu = x.copy()
+    for t in range(N):
+        xu[t, :E] = 0.0
+        xu[t, (2 * t) % E] = 8.0
+        xu[t, (2 * t + 1) % E] = 4.0
+    xu = rc.bf16_round(xu); gw = rc.bf16_round(gw)
+    got = _run(omx, xu, gw, wg, wu, wd, k, "mixtral")
+    assert (got[1][:, 0] == (2 * np.arange(N)) % E).all() and (got[1][:, 1] == (2 * np.arange(N) + 1) % E).all()
+    _compare(got, rm.moe_block(xu, gw, wg, wu, wd, k, "mixtral"))
+    xs = x.copy(); xs[:, :E] = 0.0; xs[:, 3] = 8.0; xs[:, 5] = 4.0      # everyone -> experts 3 and 5
+    xs = rc.bf16_round(xs)
+    got = _run(omx, xs, gw, wg, wu, wd, k, "mixtral")
+    assert (got[1] == np.array([3, 5])).all()
+    _compare(got, rm.moe_block(xs, gw, wg, wu, wd, k, "mixtral"))
+
+
+def test_moe_rejects_bad_config(omx):
+    from ominix_mlx_amd import moe
+    T = omx.ops.Tensor
+    z = lambda *s: T.from_numpy(np.zeros(s, np.float32))
+    with pytest.raises(omx.OmxError, match="top_k"):
+        moe.SparseMoeBlock(z(4, 512), z(4, 512, 512), z(4, 512, 512), z(4, 512, 512), 9).forward(z(1, 512))

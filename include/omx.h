@@ -186,6 +186,29 @@ int omx_moe_forward(void* out, const void* x, const void* gate_w, const void* w_
                     int norm_topk_prob, uint32_t* inds_out, void* scores_out, omx_stream stream);
 
 /* =====================================================================================
+ * a14 (+ a9): FLUX.2-klein DiT / MMDiT forward -- FluxKlein::forward_with_rope
+ * (flux-klein-mlx/src/klein_model.rs:799-854) with KleinDoubleBlock::forward (:399-522) and
+ * KleinSingleBlock::forward (:603-674) as fused launch sequences.  Weights are registered under the
+ * reference's internal names (double_blocks.{i}.img_to_q.weight, single_blocks.{i}.to_qkv_mlp.weight,
+ * x_embedder.weight, ...; flux-klein-mlx/src/weights.rs:479-596), bf16, [out, in].
+ * ===================================================================================== */
+typedef struct omx_klein_config_ {   /* FluxKleinParams, klein_model.rs:166-196 */
+    int in_channels, hidden_size, txt_embed_dim, num_heads, depth, depth_single, head_dim, mlp_hidden;
+} omx_klein_config;
+typedef struct omx_klein_* omx_klein;
+int omx_klein_create(omx_klein* out, const omx_klein_config* cfg);
+int omx_klein_destroy(omx_klein m);
+int omx_klein_set_weight(omx_klein m, const char* name, const void* ptr);
+int omx_klein_synth_weights(omx_klein m, uint32_t base_seed);
+/* latent [s_img, in_channels], txt_embed [s_txt, txt_embed_dim] (device bf16); timestep = t * 1000
+ * (generate_klein.rs:434); rope_cos/rope_sin [s_txt + s_img, 128] device f32 with duplicated pair entries,
+ * text rows first (compute_rope_freqs, klein_model.rs:53-110); out [s_img, in_channels] device bf16.      */
+int omx_klein_forward_with_rope(omx_klein m, void* out, const void* latent, const void* txt_embed, int s_img, int s_txt,
+                                float timestep, const float* rope_cos, const float* rope_sin);
+int omx_klein_last_ms(omx_klein m, float* ms);          /* HIP-event time of the last forward */
+int omx_klein_debug_read(omx_klein m, const char* name, void* host, size_t n_elems);   /* test hook */
+
+/* =====================================================================================
  * a12: Paraformer mel/STFT frontend (funasr-mlx/src/paraformer.rs:195-412), all on device:
  * x*32768 -> pre-emphasis 0.97 -> frames (n-400)/160+1 -> Hamming -> 400-pt DFT power -> 80 HTK
  * mel filters -> ln(max(.,1e-10)) -> LFR(7,6) -> CMVN.  Replaces MelFrontend::{new,set_cmvn,forward}.

@@ -39,6 +39,7 @@ struct PrefillArgs {
     const void* mask;
     // element strides of q and out: [B,H,Tq,D] by default; the engine writes out as [Tq, H*D]
     int64_t q_bs, q_hs, q_ts, o_bs, o_hs, o_ts;
+    int64_t kv_ts;   // elements between consecutive key rows (D when K/V are [.., T, D] contiguous)
 };
 
 // max / sum over the 4 lanes {l, l^16, l^32, l^48} that hold the same query column
@@ -94,9 +95,9 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(const PrefillArgs a) 
         for (int ci = threadIdx.x; ci < KB * DC; ci += 256) {
             const int row = ci / DC, ch = ci % DC;
             const int key = min(k0 + row, a.Tk - 1);
-            const u32x4 kv = *reinterpret_cast<const u32x4*>(Kb + (size_t)key * D + ch * 8);
+            const u32x4 kv = *reinterpret_cast<const u32x4*>(Kb + (size_t)key * a.kv_ts + ch * 8);
             *reinterpret_cast<u32x4*>(&sK[(row * DC + (ch ^ (row & (DC - 1)))) * 8]) = kv;
-            const u32x4 vv = *reinterpret_cast<const u32x4*>(Vb + (size_t)key * D + ch * 8);
+            const u32x4 vv = *reinterpret_cast<const u32x4*>(Vb + (size_t)key * a.kv_ts + ch * 8);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 sVt[(ch * 8 + 2 * e) * VT_STRIDE + row] = (bf16_t)(vv[e] & 0xFFFFu);
@@ -185,13 +186,18 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(const PrefillArgs a) 
 
 int launch_attn_prefill(bf16_t* out, const bf16_t* q, const bf16_t* k, const bf16_t* v, int B, int H, int Hkv, int Tq,
                         int Tk, int D, int64_t kv_batch_stride, int64_t kv_head_stride, float scale, int mask_mode,
-                        const void* mask, hipStream_t s, bool out_token_major) {
+                        const void* mask, hipStream_t s, bool out_token_major, const AttnLayout* layout) {
     OMX_REQUIRE(D == 64 || D == 128, "sdpa prefill: head_dim %d unsupported (64 or 128)", D);
     PrefillArgs a = {q, k, v, out, B, H, Hkv, Tq, Tk, kv_batch_stride, kv_head_stride, scale, mask_mode, mask,
-                     (int64_t)H * Tq * D, (int64_t)Tq * D, D, (int64_t)H * Tq * D, (int64_t)Tq * D, D};
+                     (int64_t)H * Tq * D, (int64_t)Tq * D, D, (int64_t)H * Tq * D, (int64_t)Tq * D, D, D};
     if (out_token_major) {   // out[b][t][h][d]: what o_proj consumes after the reference's transpose+reshape (model.rs:211-213)
         a.o_hs = D;
         a.o_ts = (int64_t)H * D;
+    }
+    if (layout) {            // fully strided operands (DiT blocks read q/k/v straight out of a fused projection)
+        a.q_bs = layout->q_bs; a.q_hs = layout->q_hs; a.q_ts = layout->q_ts;
+        a.o_bs = layout->o_bs; a.o_hs = layout->o_hs; a.o_ts = layout->o_ts;
+        a.kv_ts = layout->kv_ts;
     }
     const dim3 grid((Tq + QB - 1) / QB, H, B), block(256);
     if (D == 128) attn_prefill_kernel<128><<<grid, block, 0, s>>>(a);

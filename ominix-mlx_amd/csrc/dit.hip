@@ -1,0 +1,371 @@
+// FLUX.2-klein DiT / MMDiT forward (BASELINE config 5) on the matrix cores.
+//   reference: flux-klein-mlx/src/klein_model.rs -- FluxKlein::forward_with_rope :799-854,
+//   KleinDoubleBlock::forward :399-522, KleinSingleBlock::forward :603-674, SharedModulation :248-254,
+//   apply_rope :124-162, modulate/gate :909-925; layers.rs:256-283 timestep_embedding.
+// The reference issues every LayerNorm / modulate / Linear / reshape / RoPE / matmul / softmax / concat as a
+// separate lazy op and materialises the [24, S, S] score tensor twice per double block.  Here a block is:
+//   [LN + modulate] -> GEMM(s) -> [per-head RMSNorm + interleaved RoPE, in place on the projection] ->
+//   ONE joint flash attention over the [txt, img] sequence (the txt/img projections are written to adjacent
+//   row ranges of one buffer, so the reference's concatenations cost nothing) -> GEMM with the gated
+//   residual in its epilogue -> [LN + modulate] -> GEMM -> fused_swiglu on the two halves -> GEMM + gated
+//   residual.  Single blocks read q/k/v/gate/up straight out of the fused 27648-wide projection through
+//   strides and write attention and MLP outputs side by side into the [S, 12288] operand of to_out.
+// Activations are bf16 (fp32 accumulate / fp32 softmax and norms); see DESIGN.md for the parity tolerance
+// against the reference's f32 path.
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "gemm.hpp"
+
+namespace omx {
+namespace {
+
+// per-head RMSNorm (weight [128]) then RoPE on interleaved pairs (2i, 2i+1), in place.
+// x: rows of `heads` x 128 starting every `ld` elements; cos/sin [S, 128] f32 with duplicated pairs.
+__global__ __launch_bounds__(256) void klein_qk_norm_rope_kernel(bf16_t* __restrict__ x, int64_t ld, int S, int heads,
+                                                                 const bf16_t* __restrict__ w, const float* __restrict__ cosr,
+                                                                 const float* __restrict__ sinr, int rope_row0, float eps) {
+    constexpr int D = 128, LPR = 16;
+    const int lane = threadIdx.x & 63, c = lane % LPR;
+    const int64_t row = (int64_t)blockIdx.x * 16 + threadIdx.x / LPR;   // (token, head)
+    if (row >= (int64_t)S * heads) return;
+    const int t = (int)(row / heads), h = (int)(row % heads);
+    bf16_t* p = x + (size_t)t * ld + (size_t)h * D + c * 8;
+    const u32x4 r = *reinterpret_cast<const u32x4*>(p);
+    const u32x4 wr = *reinterpret_cast<const u32x4*>(w + c * 8);
+    float v[8], wv[8];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        v[2 * e] = bf16lo(r[e]); v[2 * e + 1] = bf16hi(r[e]);
+        wv[2 * e] = bf16lo(wr[e]); wv[2 * e + 1] = bf16hi(wr[e]);
+    }
+    float ss = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ss = fmaf(v[e], v[e], ss);
+    ss = group_sum<LPR>(ss);
+    const float rstd = 1.0f / sqrtf(ss / (float)D + eps);
+    const float* cp = cosr + (size_t)(rope_row0 + t) * D + c * 8;
+    const float* sp = sinr + (size_t)(rope_row0 + t) * D + c * 8;
+    u32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float x0 = v[2 * e] * rstd * wv[2 * e], x1 = v[2 * e + 1] * rstd * wv[2 * e + 1];
+        const float cs = cp[2 * e], sn = sp[2 * e];   // duplicated pair entries
+        o[e] = pack_bf16(x0 * cs - x1 * sn, x1 * cs + x0 * sn);
+    }
+    *reinterpret_cast<u32x4*>(p) = o;
+}
+
+// mlx_rs_core::fused_swiglu(up, gate) on strided column blocks: out[s, j] = silu(g[s, j]) * u[s, j]
+__global__ __launch_bounds__(256) void swiglu_strided_kernel(bf16_t* __restrict__ out, int64_t ldo, const bf16_t* __restrict__ g,
+                                                             const bf16_t* __restrict__ u, int64_t ldi, int S, int n) {
+    const int nv = n / 8;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < (int64_t)S * nv; i += (int64_t)gridDim.x * 256) {
+        const int s = (int)(i / nv), j = (int)(i % nv) * 8;
+        const u32x4 gv = *reinterpret_cast<const u32x4*>(g + (size_t)s * ldi + j);
+        const u32x4 uv = *reinterpret_cast<const u32x4*>(u + (size_t)s * ldi + j);
+        u32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float g0 = bf16lo(gv[e]), g1 = bf16hi(gv[e]);
+            o[e] = pack_bf16(g0 / (1.0f + expf(-g0)) * bf16lo(uv[e]), g1 / (1.0f + expf(-g1)) * bf16hi(uv[e]));
+        }
+        *reinterpret_cast<u32x4*>(out + (size_t)s * ldo + j) = o;
+    }
+}
+
+// elementwise helpers on small vectors: mode 0 silu(x); mode 1 (1 + scale) * x + shift broadcast over rows
+__global__ __launch_bounds__(256) void small_ew_kernel(bf16_t* __restrict__ out, const bf16_t* __restrict__ x,
+                                                       const bf16_t* __restrict__ shift, const bf16_t* __restrict__ scale,
+                                                       int64_t n, int cols, int mode) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float v = bf16_to_f32(x[i]);
+        float r;
+        if (mode == 0) r = v / (1.0f + expf(-v));
+        else r = (1.0f + bf16_to_f32(scale[i % cols])) * v + bf16_to_f32(shift[i % cols]);
+        out[i] = f32_to_bf16(r);
+    }
+}
+
+uint32_t crc32_name(const char* s) {
+    uint32_t crc = 0xFFFFFFFFu;
+    for (; *s; ++s) {
+        crc ^= (uint8_t)*s;
+        for (int k = 0; k < 8; ++k) crc = (crc >> 1) ^ (0xEDB88320u & (0u - (crc & 1u)));
+    }
+    return ~crc;
+}
+
+}  // namespace
+}  // namespace omx
+
+using namespace omx;
+
+struct omx_klein_ {
+    omx_klein_config cfg;
+    std::map<std::string, const bf16_t*> w;
+    std::vector<void*> owned;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    float last_ms = 0.f;
+    // activations, sized for (s_txt, s_img)
+    int s_txt = 0, s_img = 0;
+    bf16_t *x = nullptr, *x2 = nullptr, *xm = nullptr, *q = nullptr, *k = nullptr, *v = nullptr, *att = nullptr,
+           *proj = nullptr, *comb = nullptr, *act = nullptr, *vec = nullptr, *svec = nullptr, *temb = nullptr,
+           *tmid = nullptr, *mod_img = nullptr, *mod_txt = nullptr, *mod_single = nullptr, *ada = nullptr,
+           *lat_in = nullptr;
+};
+
+namespace {
+
+int kget(omx_klein m, const std::string& name, const bf16_t** out) {
+    auto it = m->w.find(name);
+    if (it == m->w.end()) return set_error("WeightNotFound: %s", name.c_str());
+    *out = it->second;
+    return 0;
+}
+
+template <class T>
+int kalloc(omx_klein m, T** p, size_t n) {
+    void* q = nullptr;
+    OMX_HIP_CHECK(hipMalloc(&q, n * sizeof(T) + 64));
+    *p = (T*)q;
+    m->owned.push_back(q);
+    return 0;
+}
+
+int linear(omx_klein m, bf16_t* out, const bf16_t* x, const char* wname, int M, int N, int K) {
+    const bf16_t* w = nullptr;
+    if (kget(m, wname, &w)) return 1;
+    return omx_linear(out, x, w, nullptr, M, N, K, OMX_BFLOAT16, m->stream);
+}
+
+int ensure_buffers(omx_klein m, int s_txt, int s_img) {
+    if (m->s_txt == s_txt && m->s_img == s_img) return 0;
+    OMX_REQUIRE(m->s_txt == 0, "omx_klein: sequence lengths are fixed by the first forward (%d txt, %d img)", m->s_txt, m->s_img);
+    const omx_klein_config& c = m->cfg;
+    const size_t S = (size_t)s_txt + s_img, h = c.hidden_size, mh = c.mlp_hidden;
+    if (kalloc(m, &m->x, S * h) || kalloc(m, &m->x2, S * h) || kalloc(m, &m->xm, S * h) || kalloc(m, &m->q, S * h) ||
+        kalloc(m, &m->k, S * h) || kalloc(m, &m->v, S * h) || kalloc(m, &m->att, S * h) ||
+        kalloc(m, &m->proj, S * (3 * h + 2 * mh)) || kalloc(m, &m->comb, S * (h + mh)) || kalloc(m, &m->act, S * mh) ||
+        kalloc(m, &m->vec, h) || kalloc(m, &m->svec, h) || kalloc(m, &m->temb, (size_t)256) || kalloc(m, &m->tmid, h) ||
+        kalloc(m, &m->mod_img, 6 * h) || kalloc(m, &m->mod_txt, 6 * h) || kalloc(m, &m->mod_single, 3 * h) ||
+        kalloc(m, &m->ada, 2 * h) || kalloc(m, &m->lat_in, (size_t)s_img * c.in_channels))
+        return 1;
+    m->s_txt = s_txt;
+    m->s_img = s_img;
+    return 0;
+}
+
+int attention(omx_klein m, bf16_t* out, int64_t o_ts, const bf16_t* q, const bf16_t* k, const bf16_t* v, int64_t ld, int S) {
+    const omx_klein_config& c = m->cfg;
+    AttnLayout L = {0, c.head_dim, ld, ld, 0, c.head_dim, o_ts};
+    return launch_attn_prefill(out, q, k, v, 1, c.num_heads, c.num_heads, S, S, c.head_dim, 0, c.head_dim,
+                               1.0f / sqrtf((float)c.head_dim), OMX_MASK_NONE, nullptr, m->stream, false, &L);
+}
+
+}  // namespace
+
+extern "C" {
+
+int omx_klein_create(omx_klein* out, const omx_klein_config* cfg) {
+    OMX_REQUIRE(out && cfg, "omx_klein_create: null argument");
+    OMX_REQUIRE(cfg->head_dim == 128 && cfg->hidden_size == cfg->num_heads * cfg->head_dim,
+                "InvalidConfig: klein needs head_dim 128 and hidden_size = heads * head_dim");
+    OMX_REQUIRE(cfg->hidden_size % 64 == 0 && cfg->mlp_hidden % 64 == 0 && cfg->in_channels % 64 == 0 && cfg->txt_embed_dim % 64 == 0,
+                "InvalidConfig: klein widths must be multiples of 64");
+    omx_klein m = new omx_klein_();
+    m->cfg = *cfg;
+    OMX_HIP_CHECK(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking));
+    OMX_HIP_CHECK(hipEventCreate(&m->ev0));
+    OMX_HIP_CHECK(hipEventCreate(&m->ev1));
+    *out = m;
+    return 0;
+}
+
+int omx_klein_destroy(omx_klein m) {
+    if (!m) return 0;
+    (void)hipStreamSynchronize(m->stream);
+    for (void* p : m->owned) (void)hipFree(p);
+    (void)hipEventDestroy(m->ev0);
+    (void)hipEventDestroy(m->ev1);
+    (void)hipStreamDestroy(m->stream);
+    delete m;
+    return 0;
+}
+
+int omx_klein_set_weight(omx_klein m, const char* name, const void* ptr) {
+    OMX_REQUIRE(m && name && ptr, "omx_klein_set_weight: null argument");
+    m->w[name] = (const bf16_t*)ptr;
+    return 0;
+}
+
+int omx_klein_synth_weights(omx_klein m, uint32_t base_seed) {
+    OMX_REQUIRE(m, "omx_klein_synth_weights: null model");
+    const omx_klein_config& c = m->cfg;
+    const int h = c.hidden_size, mh = c.mlp_hidden, D = c.head_dim;
+    auto make = [&](const std::string& name, size_t rows, size_t cols, bool norm) -> int {
+        bf16_t* p = nullptr;
+        if (kalloc(m, &p, rows * cols)) return 1;
+        const uint32_t seed = base_seed ^ crc32_name(("klein." + name).c_str());
+        if (omx_fill_uniform(p, rows * cols, seed, (float)((norm ? 0.01 : 0.02) * sqrt(3.0)), norm ? 1.0f : 0.0f, OMX_BFLOAT16,
+                             m->stream))
+            return 1;
+        m->w[name] = p;
+        return 0;
+    };
+    if (make("x_embedder.weight", h, c.in_channels, false) || make("context_embedder.weight", h, c.txt_embed_dim, false) ||
+        make("time_embed_1.weight", h, 256, false) || make("time_embed_2.weight", h, h, false) ||
+        make("double_mod_img.linear.weight", 6 * (size_t)h, h, false) || make("double_mod_txt.linear.weight", 6 * (size_t)h, h, false) ||
+        make("single_mod.linear.weight", 3 * (size_t)h, h, false) || make("norm_out.weight", 2 * (size_t)h, h, false) ||
+        make("proj_out.weight", c.in_channels, h, false))
+        return 1;
+    for (int i = 0; i < c.depth; ++i) {
+        const std::string b = "double_blocks." + std::to_string(i) + ".";
+        for (const char* st : {"img", "txt"}) {
+            const std::string s = b + st + "_";
+            if (make(s + "to_q.weight", h, h, false) || make(s + "to_k.weight", h, h, false) || make(s + "to_v.weight", h, h, false) ||
+                make(s + "to_out.weight", h, h, false) || make(s + "norm_q.weight", 1, D, true) || make(s + "norm_k.weight", 1, D, true) ||
+                make(s + "mlp_in.weight", 2 * (size_t)mh, h, false) || make(s + "mlp_out.weight", h, mh, false))
+                return 1;
+        }
+    }
+    for (int i = 0; i < c.depth_single; ++i) {
+        const std::string b = "single_blocks." + std::to_string(i) + ".";
+        if (make(b + "to_qkv_mlp.weight", 3 * (size_t)h + 2 * (size_t)mh, h, false) || make(b + "to_out.weight", h, (size_t)h + mh, false) ||
+            make(b + "norm_q.weight", 1, D, true) || make(b + "norm_k.weight", 1, D, true))
+            return 1;
+    }
+    OMX_HIP_CHECK(hipStreamSynchronize(m->stream));
+    return 0;
+}
+
+/* FluxKlein::forward_with_rope: latent [s_img, in_channels], txt [s_txt, txt_embed_dim] (bf16, device),
+ * timestep = t * 1000, rope cos/sin [s_txt + s_img, 128] f32 (device; txt rows first) -> out [s_img, in_channels] */
+int omx_klein_forward_with_rope(omx_klein m, void* out, const void* latent, const void* txt_embed, int s_img, int s_txt,
+                                float timestep, const float* rope_cos, const float* rope_sin) {
+    OMX_REQUIRE(m && out && latent && txt_embed && rope_cos && rope_sin, "omx_klein_forward_with_rope: null argument");
+    OMX_REQUIRE(s_img > 0 && s_txt > 0, "omx_klein_forward_with_rope: empty sequence");
+    const omx_klein_config& c = m->cfg;
+    if (ensure_buffers(m, s_txt, s_img)) return 1;
+    hipStream_t s = m->stream;
+    const int h = c.hidden_size, mh = c.mlp_hidden, S = s_txt + s_img, D = c.head_dim, H = c.num_heads;
+    const float rms_eps = 1e-5f;   // RmsNorm::DEFAULT_EPS
+    OMX_HIP_CHECK(hipEventRecord(m->ev0, s));
+    bf16_t* x = m->x;     // [S, h]: rows [0, s_txt) = txt stream, [s_txt, S) = img stream
+    bf16_t* x2 = m->x2;
+    // input projections (klein_model.rs:810-811)
+    if (linear(m, x + (size_t)s_txt * h, (const bf16_t*)latent, "x_embedder.weight", s_img, h, c.in_channels)) return 1;
+    if (linear(m, x, (const bf16_t*)txt_embed, "context_embedder.weight", s_txt, h, c.txt_embed_dim)) return 1;
+    {   // timestep_embedding(t, 256) = [cos | sin], layers.rs:256-283 (256 values: host)
+        std::vector<bf16_t> te(256);
+        for (int i = 0; i < 128; ++i) {
+            const float freq = expf(-logf(10000.0f) * (float)i / 128.0f);
+            const float arg = timestep * freq;
+            te[i] = f32_to_bf16((float)cos((double)arg));
+            te[128 + i] = f32_to_bf16((float)sin((double)arg));
+        }
+        OMX_HIP_CHECK(hipMemcpyAsync(m->temb, te.data(), 512, hipMemcpyHostToDevice, s));
+        OMX_HIP_CHECK(hipStreamSynchronize(s));   // te is a stack buffer
+    }
+    if (linear(m, m->tmid, m->temb, "time_embed_1.weight", 1, h, 256)) return 1;
+    small_ew_kernel<<<8, 256, 0, s>>>(m->tmid, m->tmid, nullptr, nullptr, h, h, 0);
+    if (linear(m, m->vec, m->tmid, "time_embed_2.weight", 1, h, h)) return 1;
+    small_ew_kernel<<<8, 256, 0, s>>>(m->svec, m->vec, nullptr, nullptr, h, h, 0);        // silu(vec), shared by all modulations
+    if (linear(m, m->mod_img, m->svec, "double_mod_img.linear.weight", 1, 6 * h, h)) return 1;
+    if (linear(m, m->mod_txt, m->svec, "double_mod_txt.linear.weight", 1, 6 * h, h)) return 1;
+    if (linear(m, m->mod_single, m->svec, "single_mod.linear.weight", 1, 3 * h, h)) return 1;
+    OMX_LAUNCH_CHECK();
+
+    const bf16_t* w = nullptr;
+    for (int i = 0; i < c.depth; ++i) {
+        const std::string b = "double_blocks." + std::to_string(i) + ".";
+        // ---- attention half: per-stream LN+modulate and q/k/v projections into adjacent row ranges ----
+        for (int st = 0; st < 2; ++st) {
+            const char* sn = st ? "img_" : "txt_";
+            const bf16_t* mod = st ? m->mod_img : m->mod_txt;
+            const int rows = st ? s_img : s_txt;
+            const size_t r0 = st ? (size_t)s_txt : 0;
+            if (omx_fused_modulate(m->xm + r0 * h, x + r0 * h, mod /*shift1*/, mod + h /*scale1*/, 1, rows, h, 1e-6f, OMX_BFLOAT16, s)) return 1;
+            if (linear(m, m->q + r0 * h, m->xm + r0 * h, (b + sn + "to_q.weight").c_str(), rows, h, h)) return 1;
+            if (linear(m, m->k + r0 * h, m->xm + r0 * h, (b + sn + "to_k.weight").c_str(), rows, h, h)) return 1;
+            if (linear(m, m->v + r0 * h, m->xm + r0 * h, (b + sn + "to_v.weight").c_str(), rows, h, h)) return 1;
+            const unsigned blocks = (unsigned)(((size_t)rows * H + 15) / 16);
+            if (kget(m, b + sn + "norm_q.weight", &w)) return 1;
+            klein_qk_norm_rope_kernel<<<blocks, 256, 0, s>>>(m->q + r0 * h, h, rows, H, w, rope_cos, rope_sin, (int)r0, rms_eps);
+            if (kget(m, b + sn + "norm_k.weight", &w)) return 1;
+            klein_qk_norm_rope_kernel<<<blocks, 256, 0, s>>>(m->k + r0 * h, h, rows, H, w, rope_cos, rope_sin, (int)r0, rms_eps);
+            OMX_LAUNCH_CHECK();
+        }
+        // ONE joint attention over [txt, img]: img and txt queries both see all keys (klein_model.rs:461-483)
+        if (attention(m, m->att, h, m->q, m->k, m->v, h, S)) return 1;
+        for (int st = 0; st < 2; ++st) {
+            const char* sn = st ? "img_" : "txt_";
+            const bf16_t* mod = st ? m->mod_img : m->mod_txt;
+            const int rows = st ? s_img : s_txt;
+            const size_t r0 = st ? (size_t)s_txt : 0;
+            if (kget(m, b + sn + "to_out.weight", &w)) return 1;
+            if (launch_gemm_bf16_gated(x2 + r0 * h, m->att + r0 * h, w, x + r0 * h, mod + 2 * h /*gate1*/, rows, h, h, s)) return 1;
+            // ---- MLP half ----
+            if (omx_fused_modulate(m->xm + r0 * h, x2 + r0 * h, mod + 3 * h, mod + 4 * h, 1, rows, h, 1e-6f, OMX_BFLOAT16, s)) return 1;
+            if (linear(m, m->proj, m->xm + r0 * h, (b + sn + "mlp_in.weight").c_str(), rows, 2 * mh, h)) return 1;
+            swiglu_strided_kernel<<<2048, 256, 0, s>>>(m->act, mh, m->proj /*gate = first half*/, m->proj + mh /*up*/, 2 * mh, rows, mh);
+            OMX_LAUNCH_CHECK();
+            if (kget(m, b + sn + "mlp_out.weight", &w)) return 1;
+            if (launch_gemm_bf16_gated(x + r0 * h, m->act, w, x2 + r0 * h, mod + 5 * h /*gate2*/, rows, h, mh, s)) return 1;
+        }
+    }
+    // x already holds [txt, img] (klein_model.rs:833)
+    const int64_t ldp = 3 * (int64_t)h + 2 * mh, ldc = (int64_t)h + mh;
+    for (int i = 0; i < c.depth_single; ++i) {
+        const std::string b = "single_blocks." + std::to_string(i) + ".";
+        const bf16_t* mod = m->mod_single;
+        if (omx_fused_modulate(m->xm, x, mod, mod + h, 1, S, h, 1e-6f, OMX_BFLOAT16, s)) return 1;
+        if (linear(m, m->proj, m->xm, (b + "to_qkv_mlp.weight").c_str(), S, (int)ldp, h)) return 1;
+        const unsigned blocks = (unsigned)(((size_t)S * H + 15) / 16);
+        if (kget(m, b + "norm_q.weight", &w)) return 1;
+        klein_qk_norm_rope_kernel<<<blocks, 256, 0, s>>>(m->proj, ldp, S, H, w, rope_cos, rope_sin, 0, rms_eps);
+        if (kget(m, b + "norm_k.weight", &w)) return 1;
+        klein_qk_norm_rope_kernel<<<blocks, 256, 0, s>>>(m->proj + h, ldp, S, H, w, rope_cos, rope_sin, 0, rms_eps);
+        OMX_LAUNCH_CHECK();
+        if (attention(m, m->comb, ldc, m->proj, m->proj + h, m->proj + 2 * h, ldp, S)) return 1;          // cols [0, h)
+        swiglu_strided_kernel<<<2048, 256, 0, s>>>(m->comb + h, ldc, m->proj + 3 * h, m->proj + 3 * h + mh, ldp, S, mh);   // cols [h, h+mh)
+        OMX_LAUNCH_CHECK();
+        if (kget(m, b + "to_out.weight", &w)) return 1;
+        if (launch_gemm_bf16_gated(x2, m->comb, w, x, mod + 2 * h, S, h, (int)ldc, s)) return 1;
+        bf16_t* t = x; x = x2; x2 = t;
+    }
+    // final layer: RmsNorm (weight = ones), AdaLN chunks [scale, shift], proj_out (klein_model.rs:845-853)
+    if (linear(m, m->ada, m->svec, "norm_out.weight", 1, 2 * h, h)) return 1;
+    bf16_t* img_out = x + (size_t)s_txt * h;
+    if (omx_rms_norm(m->xm, img_out, nullptr, s_img, h, rms_eps, OMX_BFLOAT16, s)) return 1;
+    small_ew_kernel<<<2048, 256, 0, s>>>(m->xm, m->xm, m->ada + h /*shift*/, m->ada /*scale*/, (int64_t)s_img * h, h, 1);
+    OMX_LAUNCH_CHECK();
+    if (linear(m, (bf16_t*)out, m->xm, "proj_out.weight", s_img, c.in_channels, h)) return 1;
+    OMX_HIP_CHECK(hipEventRecord(m->ev1, s));
+    OMX_HIP_CHECK(hipStreamSynchronize(s));
+    OMX_HIP_CHECK(hipEventElapsedTime(&m->last_ms, m->ev0, m->ev1));
+    return 0;
+}
+
+int omx_klein_last_ms(omx_klein m, float* ms) {
+    OMX_REQUIRE(m && ms, "omx_klein_last_ms: null argument");
+    *ms = m->last_ms;
+    return 0;
+}
+
+int omx_klein_debug_read(omx_klein m, const char* name, void* host, size_t n_elems) {
+    OMX_REQUIRE(m && name && host, "omx_klein_debug_read: null argument");
+    const std::string s(name);
+    const void* src = s == "x" ? m->x : s == "x2" ? m->x2 : s == "vec" ? m->vec : s == "mod_img" ? m->mod_img : nullptr;
+    OMX_REQUIRE(src != nullptr, "omx_klein_debug_read: unknown buffer %s", name);
+    OMX_HIP_CHECK(hipMemcpy(host, src, n_elems * 2, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+}  // extern "C"

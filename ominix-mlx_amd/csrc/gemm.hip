@@ -35,6 +35,7 @@ struct GemmArgs {
     const bf16_t* w;      // [N, K]   (grouped: [E, N, K])
     const bf16_t* bias;   // [N] or null
     const bf16_t* resid;  // [M, N] or null : out = bf16(resid + bf16(acc (+bias)))
+    const bf16_t* gate;   // [N] or null  : out = bf16(resid + acc * gate[col])  (DiT gated residual)
     bf16_t* out;          // [M, N]
     int M, N, K;
     int grid_m, grid_n;
@@ -159,7 +160,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_nt_kernel(const GemmArgs a
                 if (row < rows_valid) {
                     const size_t o = (size_t)(out_row0 + row) * a.N + col;
                     float v = acc[i][j][r] + bv;
-                    if (a.resid) v = bf16_to_f32(a.resid[o]) + round_bf16(v);
+                    if (a.gate) v = bf16_to_f32(a.resid[o]) + v * bf16_to_f32(a.gate[col]);
+                    else if (a.resid) v = bf16_to_f32(a.resid[o]) + round_bf16(v);
                     a.out[o] = f32_to_bf16(v);
                 }
             }
@@ -205,7 +207,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_nt_generic_kernel(const Ge
         const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         if (row < a.M) {
             float v = acc[r] + bv;
-            if (a.resid) v = bf16_to_f32(a.resid[(size_t)row * a.N + col]) + round_bf16(v);
+            if (a.gate) v = bf16_to_f32(a.resid[(size_t)row * a.N + col]) + v * bf16_to_f32(a.gate[col]);
+            else if (a.resid) v = bf16_to_f32(a.resid[(size_t)row * a.N + col]) + round_bf16(v);
             a.out[(size_t)row * a.N + col] = f32_to_bf16(v);
         }
     }
@@ -224,10 +227,10 @@ int ensure_attr() {
 
 }  // namespace
 
-int launch_gemm_bf16_ex(bf16_t* out, const bf16_t* x, const bf16_t* w, const bf16_t* bias, const bf16_t* resid, int M,
-                        int N, int K, hipStream_t s) {
+static int launch_gemm_impl(bf16_t* out, const bf16_t* x, const bf16_t* w, const bf16_t* bias, const bf16_t* resid,
+                            const bf16_t* gate, int M, int N, int K, hipStream_t s) {
     OMX_REQUIRE(M > 0 && N > 0 && K > 0, "gemm: bad shape M=%d N=%d K=%d", M, N, K);
-    GemmArgs a = {x, w, bias, resid, out, M, N, K, (M + BM - 1) / BM, (N + BN - 1) / BN, {}};
+    GemmArgs a = {x, w, bias, resid, gate, out, M, N, K, (M + BM - 1) / BM, (N + BN - 1) / BN, {}};
     const bool fast = (K % BK == 0) && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w)) & 15u) == 0;
     if (fast) {
         if (ensure_attr()) return 1;
@@ -237,6 +240,17 @@ int launch_gemm_bf16_ex(bf16_t* out, const bf16_t* x, const bf16_t* w, const bf1
     }
     OMX_LAUNCH_CHECK();
     return 0;
+}
+
+int launch_gemm_bf16_ex(bf16_t* out, const bf16_t* x, const bf16_t* w, const bf16_t* bias, const bf16_t* resid, int M,
+                        int N, int K, hipStream_t s) {
+    return launch_gemm_impl(out, x, w, bias, resid, nullptr, M, N, K, s);
+}
+
+int launch_gemm_bf16_gated(bf16_t* out, const bf16_t* x, const bf16_t* w, const bf16_t* resid, const bf16_t* gate, int M,
+                           int N, int K, hipStream_t s) {
+    OMX_REQUIRE(resid && gate, "gated gemm: residual and gate are required");
+    return launch_gemm_impl(out, x, w, nullptr, resid, gate, M, N, K, s);
 }
 
 int launch_gemm_bf16(bf16_t* out, const bf16_t* x, const bf16_t* w, const bf16_t* bias, int M, int N, int K,
@@ -249,7 +263,7 @@ int launch_gemm_bf16_grouped(bf16_t* out, const bf16_t* x, const bf16_t* w, int 
     OMX_REQUIRE(max_rows > 0 && N > 0 && K > 0 && max_tiles > 0, "grouped gemm: bad shape");
     OMX_REQUIRE(K % BK == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w)) & 15u) == 0,
                 "grouped gemm: K=%d must be a multiple of %d and operands 16-byte aligned", K, BK);
-    GemmArgs a = {x, w, nullptr, nullptr, out, max_rows, N, K, max_tiles, (N + BN - 1) / BN, g};
+    GemmArgs a = {x, w, nullptr, nullptr, nullptr, out, max_rows, N, K, max_tiles, (N + BN - 1) / BN, g};
     if (ensure_attr()) return 1;
     gemm_bf16_nt_kernel<true><<<max_tiles * a.grid_n, NTHREADS, 4 * TILE_BYTES, s>>>(a);
     OMX_LAUNCH_CHECK();

@@ -22,14 +22,25 @@ int launch_gemm_bf16(bf16_t* out, const bf16_t* x, const bf16_t* w, const bf16_t
 // same with an optional fused residual: out = bf16(resid + bf16(x.W^T (+bias)))
 int launch_gemm_bf16_ex(bf16_t* out, const bf16_t* x, const bf16_t* w, const bf16_t* bias, const bf16_t* resid, int M,
                         int N, int K, hipStream_t s);
+// gated residual epilogue of the DiT blocks: out = bf16(resid + (x.W^T) * gate[col])   (klein_model.rs:496-497, 922-925)
+int launch_gemm_bf16_gated(bf16_t* out, const bf16_t* x, const bf16_t* w, const bf16_t* resid, const bf16_t* gate, int M,
+                           int N, int K, hipStream_t s);
 
 // rows sorted by expert: out[p, :] = x[row_src ? row_src[p] : p, :] . W[e(p)]^T, p in expert-sorted order
 int launch_gemm_bf16_grouped(bf16_t* out, const bf16_t* x, const bf16_t* w, int max_rows, int N, int K,
                              const GroupedDesc& g, int max_tiles, hipStream_t s);
 
+// element strides for SDPA operands that are not [B,H,T,D]-contiguous
+struct AttnLayout {
+    int64_t q_bs, q_hs, q_ts;   // queries: batch, head, token
+    int64_t kv_ts;              // keys/values: token (head stride = kv_head_stride argument)
+    int64_t o_bs, o_hs, o_ts;   // output
+};
+
 // SDPA with Tq > 1 (prefill / DiT joint attention): flash-attention forward on MFMA.
 int launch_attn_prefill(bf16_t* out, const bf16_t* q, const bf16_t* k, const bf16_t* v, int B, int H, int Hkv, int Tq,
                         int Tk, int D, int64_t kv_batch_stride, int64_t kv_head_stride, float scale, int mask_mode,
-                        const void* mask, hipStream_t s, bool out_token_major = false);
+                        const void* mask, hipStream_t s, bool out_token_major = false,
+                        const AttnLayout* layout = nullptr);
 
 }  // namespace omx

@@ -25,7 +25,6 @@ using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 using f32x4v = __attribute__((ext_vector_type(4))) float;
 using u32x2v = __attribute__((ext_vector_type(2))) uint32_t;
 
-constexpr int QB = 64;    // query rows per block
 constexpr int KB = 64;    // keys per LDS tile
 constexpr int VT_STRIDE = KB + 8;   // bf16 elements per V^T row (144 B): conflict-free 8-B fragment reads
 
@@ -56,11 +55,17 @@ __device__ __forceinline__ float quad_rows_sum(float v) {
     return __uint_as_float(b[0]) + __uint_as_float(b[1]);
 }
 
-template <int D>
+// QW = 16-row query sub-tiles per wave (2: a wave owns 32 query rows and every K / V^T fragment read from
+// LDS feeds two MFMAs).  Next tile's K/V are fetched into registers while the current tile is multiplied
+// (issue-early / write-late staging, cdna_hip_programming.md T14).
+template <int D, int QW, int MASK>
 __global__ __launch_bounds__(256) void attn_prefill_kernel(const PrefillArgs a) {
     constexpr int DC = D / 8;       // 16-B chunks per K row
     constexpr int NI = D / 32;      // MFMA k-steps over the head dim
     constexpr int NDT = D / 16;     // 16-wide output tiles over the head dim
+    constexpr int QBLK = 64 * QW;   // query rows per block
+    constexpr int KCH = KB * DC / 256;          // K chunks staged per thread
+    constexpr int VCH = (KB / 2) * DC / 256;    // V key-pair chunks staged per thread
     __shared__ __attribute__((aligned(16))) bf16_t sK[KB * D];
     __shared__ __attribute__((aligned(16))) bf16_t sVt[D * VT_STRIDE];
 
@@ -68,93 +73,141 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(const PrefillArgs a) 
     const int qcol = lane & 15, rg = lane >> 4;
     const int b = blockIdx.z, h = blockIdx.y;
     const int kvh = h / (a.H / a.Hkv);
-    const int q0 = blockIdx.x * QB;
-    const int qrow = q0 + wave * 16 + qcol;              // this lane's query row
-    const int qrow_c = min(qrow, a.Tq - 1);
+    const int q0 = blockIdx.x * QBLK;
     const int shift = a.Tk - a.Tq;                       // causal: query i sees keys <= i + shift
 
-    const bf16_t* Qp = a.q + (size_t)b * a.q_bs + (size_t)h * a.q_hs + (size_t)qrow_c * a.q_ts;
     const bf16_t* Kb = a.k + (size_t)b * a.kv_batch_stride + (size_t)kvh * a.kv_head_stride;
     const bf16_t* Vb = a.v + (size_t)b * a.kv_batch_stride + (size_t)kvh * a.kv_head_stride;
 
-    bf16x8 qf[NI];
+    int qrow[QW], qrow_c[QW];
+    bf16x8 qf[QW][NI];
 #pragma unroll
-    for (int i = 0; i < NI; ++i) qf[i] = *reinterpret_cast<const bf16x8*>(Qp + i * 32 + rg * 8);
+    for (int w = 0; w < QW; ++w) {
+        qrow[w] = q0 + (wave * QW + w) * 16 + qcol;      // this lane's query row in sub-tile w
+        qrow_c[w] = min(qrow[w], a.Tq - 1);
+        const bf16_t* Qp = a.q + (size_t)b * a.q_bs + (size_t)h * a.q_hs + (size_t)qrow_c[w] * a.q_ts;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) qf[w][i] = *reinterpret_cast<const bf16x8*>(Qp + i * 32 + rg * 8);
+    }
 
-    f32x4v o[NDT];
+    f32x4v o[QW][NDT];
+    float m_run[QW], l_run[QW];   // l_run: this lane's PARTIAL sum (reduced at the end)
 #pragma unroll
-    for (int t = 0; t < NDT; ++t) o[t] = f32x4v{0.f, 0.f, 0.f, 0.f};
-    float m_run = -INFINITY, l_run = 0.f;   // l_run is this lane's PARTIAL sum (reduced at the end)
+    for (int w = 0; w < QW; ++w) {
+        m_run[w] = -INFINITY;
+        l_run[w] = 0.f;
+#pragma unroll
+        for (int t = 0; t < NDT; ++t) o[w][t] = f32x4v{0.f, 0.f, 0.f, 0.f};
+    }
 
     int kv_end = a.Tk;
-    if (a.mask_mode == OMX_MASK_CAUSAL) kv_end = max(0, min(a.Tk, q0 + QB + shift));
+    if (MASK == OMX_MASK_CAUSAL) kv_end = max(0, min(a.Tk, q0 + QBLK + shift));
 
-    for (int k0 = 0; k0 < kv_end; k0 += KB) {
-        __syncthreads();   // previous tile fully consumed
-        // ---- stage K (swizzled rows) and V^T ----
-        for (int ci = threadIdx.x; ci < KB * DC; ci += 256) {
+    // ---- staging registers: K rows as 16-B chunks, V as (key 2p, key 2p+1) chunk pairs ----
+    u32x4 kreg[KCH], vreg[VCH][2];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int it = 0; it < KCH; ++it) {
+            const int ci = threadIdx.x + it * 256;
+            const int key = min(k0 + ci / DC, a.Tk - 1);
+            kreg[it] = *reinterpret_cast<const u32x4*>(Kb + (size_t)key * a.kv_ts + (ci % DC) * 8);
+        }
+#pragma unroll
+        for (int it = 0; it < VCH; ++it) {
+            const int idx = threadIdx.x + it * 256;
+            const int c = (idx % 4) + 4 * (idx / 128), pr = (idx / 4) % 32;
+            const int k_even = min(k0 + 2 * pr, a.Tk - 1), k_odd = min(k0 + 2 * pr + 1, a.Tk - 1);
+            vreg[it][0] = *reinterpret_cast<const u32x4*>(Vb + (size_t)k_even * a.kv_ts + c * 8);
+            vreg[it][1] = *reinterpret_cast<const u32x4*>(Vb + (size_t)k_odd * a.kv_ts + c * 8);
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int it = 0; it < KCH; ++it) {
+            const int ci = threadIdx.x + it * 256;
             const int row = ci / DC, ch = ci % DC;
-            const int key = min(k0 + row, a.Tk - 1);
-            const u32x4 kv = *reinterpret_cast<const u32x4*>(Kb + (size_t)key * a.kv_ts + ch * 8);
-            *reinterpret_cast<u32x4*>(&sK[(row * DC + (ch ^ (row & (DC - 1)))) * 8]) = kv;
-            const u32x4 vv = *reinterpret_cast<const u32x4*>(Vb + (size_t)key * a.kv_ts + ch * 8);
+            *reinterpret_cast<u32x4*>(&sK[(row * DC + (ch ^ (row & (DC - 1)))) * 8]) = kreg[it];
+        }
+        uint32_t* vt32 = reinterpret_cast<uint32_t*>(sVt);
+#pragma unroll
+        for (int it = 0; it < VCH; ++it) {
+            const int idx = threadIdx.x + it * 256;
+            const int c = (idx % 4) + 4 * (idx / 128), pr = (idx / 4) % 32;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                sVt[(ch * 8 + 2 * e) * VT_STRIDE + row] = (bf16_t)(vv[e] & 0xFFFFu);
-                sVt[(ch * 8 + 2 * e + 1) * VT_STRIDE + row] = (bf16_t)(vv[e] >> 16);
+                const uint32_t ev = vreg[it][0][e], od = vreg[it][1][e];
+                // V^T[d][2p], V^T[d][2p+1] packed: one 4-byte store per output row
+                vt32[(c * 8 + 2 * e) * (VT_STRIDE / 2) + pr] = (ev & 0xFFFFu) | (od << 16);
+                vt32[(c * 8 + 2 * e + 1) * (VT_STRIDE / 2) + pr] = (ev >> 16) | (od & 0xFFFF0000u);
             }
         }
-        __syncthreads();
+    };
 
-        // ---- S^T = K Q^T for 4 key tiles of 16 ----
-        f32x4v s[4];
+    if (kv_end > 0) fetch(0);
+    for (int k0 = 0; k0 < kv_end; k0 += KB) {
+        __syncthreads();   // previous tile fully consumed
+        commit();
+        __syncthreads();
+        if (k0 + KB < kv_end) fetch(k0 + KB);   // in flight during the MFMAs below
+
+        // ---- S^T = K Q^T for 4 key tiles of 16, both query sub-tiles share each K fragment ----
+        f32x4v s[QW][4];
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) {
-            s[kt] = f32x4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int w = 0; w < QW; ++w) s[w][kt] = f32x4v{0.f, 0.f, 0.f, 0.f};
             const int row = kt * 16 + qcol;   // A operand: lane & 15 indexes the key row
 #pragma unroll
             for (int i = 0; i < NI; ++i) {
                 const int ch = i * 4 + rg;
                 const bf16x8 kf = *reinterpret_cast<const bf16x8*>(&sK[(row * DC + (ch ^ (row & (DC - 1)))) * 8]);
-                s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[i], s[kt], 0, 0, 0);
+#pragma unroll
+                for (int w = 0; w < QW; ++w) s[w][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[w][i], s[w][kt], 0, 0, 0);
             }
         }
-        // ---- scale, mask, online softmax (lane: query qcol, keys kt*16 + rg*4 + r) ----
-        float mx = -INFINITY;
+        // ---- scale, mask, online softmax (lane: query qcol of each sub-tile, keys kt*16 + rg*4 + r) ----
+        bf16x8 pf[QW][2];
 #pragma unroll
-        for (int kt = 0; kt < 4; ++kt)
+        for (int w = 0; w < QW; ++w) {
+            float mx = -INFINITY;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int key = k0 + kt * 16 + rg * 4 + r;
-                float v = s[kt][r] * a.scale;
-                bool keep = key < a.Tk;
-                if (a.mask_mode == OMX_MASK_CAUSAL) keep = keep && (key <= qrow + shift);
-                else if (a.mask_mode == OMX_MASK_BOOL)
-                    keep = keep && reinterpret_cast<const uint8_t*>(a.mask)[(size_t)qrow_c * a.Tk + min(key, a.Tk - 1)];
-                else if (a.mask_mode == OMX_MASK_ADDITIVE)
-                    v += bf16_to_f32(reinterpret_cast<const bf16_t*>(a.mask)[(size_t)qrow_c * a.Tk + min(key, a.Tk - 1)]);
-                v = keep ? v : -INFINITY;
-                s[kt][r] = v;
-                mx = fmaxf(mx, v);
-            }
-        mx = quad_rows_max(mx);
-        const float m_new = fmaxf(m_run, mx);
-        const float alpha = (m_new == -INFINITY) ? 1.f : __expf(m_run - m_new);
-        m_run = m_new;
-        l_run *= alpha;
+            for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-        for (int t = 0; t < NDT; ++t) o[t] *= alpha;
-        bf16x8 pf[2];
+                for (int r = 0; r < 4; ++r) {
+                    const int key = k0 + kt * 16 + rg * 4 + r;
+                    float v = s[w][kt][r] * a.scale;
+                    bool keep = key < a.Tk;
+                    // MASK is a compile-time mode: the hot loop carries no mode branches, and the mask bytes are
+                    // loaded unconditionally from a clamped address (no per-lane control flow)
+                    if (MASK == OMX_MASK_CAUSAL) keep = keep && (key <= qrow[w] + shift);
+                    if (MASK == OMX_MASK_BOOL) {
+                        const uint8_t mb = reinterpret_cast<const uint8_t*>(a.mask)[(size_t)qrow_c[w] * a.Tk + min(key, a.Tk - 1)];
+                        keep = keep & (mb != 0);
+                    }
+                    if (MASK == OMX_MASK_ADDITIVE)
+                        v += bf16_to_f32(reinterpret_cast<const bf16_t*>(a.mask)[(size_t)qrow_c[w] * a.Tk + min(key, a.Tk - 1)]);
+                    v = keep ? v : -INFINITY;
+                    s[w][kt][r] = v;
+                    mx = fmaxf(mx, v);
+                }
+            mx = quad_rows_max(mx);
+            const float m_new = fmaxf(m_run[w], mx);
+            const float alpha = (m_new == -INFINITY) ? 1.f : __expf(m_run[w] - m_new);
+            m_run[w] = m_new;
+            l_run[w] *= alpha;
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+            for (int t = 0; t < NDT; ++t) o[w][t] *= alpha;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float sv = s[2 * j + (e >> 2)][e & 3];
-                const float p = (m_new == -INFINITY) ? 0.f : __expf(sv - m_new);
-                const bf16_t pb = f32_to_bf16(p);
-                l_run += bf16_to_f32(pb);   // normaliser of the bf16 probabilities actually multiplied
-                pf[j][e] = __builtin_bit_cast(__bf16, pb);
-            }
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float sv = s[w][2 * j + (e >> 2)][e & 3];
+                    const float p = (m_new == -INFINITY) ? 0.f : __expf(sv - m_new);
+                    const bf16_t pb = f32_to_bf16(p);
+                    l_run[w] += bf16_to_f32(pb);   // normaliser of the bf16 probabilities actually multiplied
+                    pf[w][j][e] = __builtin_bit_cast(__bf16, pb);
+                }
+        }
         // ---- O^T += V^T P^T : k-slot (rg*8 + e) <-> key (2j + (e>>2))*16 + rg*4 + (e&3) on BOTH operands ----
 #pragma unroll
         for (int t = 0; t < NDT; ++t) {
@@ -164,20 +217,25 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(const PrefillArgs a) 
                 const u32x2v lo = *reinterpret_cast<const u32x2v*>(vrow + (2 * j) * 16 + rg * 4);
                 const u32x2v hi = *reinterpret_cast<const u32x2v*>(vrow + (2 * j + 1) * 16 + rg * 4);
                 const u32x4 packed = {lo[0], lo[1], hi[0], hi[1]};
-                o[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, packed), pf[j], o[t], 0, 0, 0);
+#pragma unroll
+                for (int w = 0; w < QW; ++w)
+                    o[w][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, packed), pf[w][j], o[w][t], 0, 0, 0);
             }
         }
     }
 
     // ---- normalise and store: lane holds out[qrow][t*16 + rg*4 + 0..3] ----
-    const float l_tot = quad_rows_sum(l_run);
-    const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
-    if (qrow < a.Tq) {
-        bf16_t* op = a.out + (size_t)b * a.o_bs + (size_t)h * a.o_hs + (size_t)qrow * a.o_ts;
 #pragma unroll
-        for (int t = 0; t < NDT; ++t) {
-            u32x2v w = {pack_bf16(o[t][0] * inv, o[t][1] * inv), pack_bf16(o[t][2] * inv, o[t][3] * inv)};
-            *reinterpret_cast<u32x2v*>(op + t * 16 + rg * 4) = w;
+    for (int w = 0; w < QW; ++w) {
+        const float l_tot = quad_rows_sum(l_run[w]);
+        const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+        if (qrow[w] < a.Tq) {
+            bf16_t* op = a.out + (size_t)b * a.o_bs + (size_t)h * a.o_hs + (size_t)qrow[w] * a.o_ts;
+#pragma unroll
+            for (int t = 0; t < NDT; ++t) {
+                u32x2v wv = {pack_bf16(o[w][t][0] * inv, o[w][t][1] * inv), pack_bf16(o[w][t][2] * inv, o[w][t][3] * inv)};
+                *reinterpret_cast<u32x2v*>(op + t * 16 + rg * 4) = wv;
+            }
         }
     }
 }
@@ -199,11 +257,23 @@ int launch_attn_prefill(bf16_t* out, const bf16_t* q, const bf16_t* k, const bf1
         a.o_bs = layout->o_bs; a.o_hs = layout->o_hs; a.o_ts = layout->o_ts;
         a.kv_ts = layout->kv_ts;
     }
-    const dim3 grid((Tq + QB - 1) / QB, H, B), block(256);
-    if (D == 128) attn_prefill_kernel<128><<<grid, block, 0, s>>>(a);
-    else attn_prefill_kernel<64><<<grid, block, 0, s>>>(a);
-    OMX_LAUNCH_CHECK();
-    return 0;
+    // long sequences: 128 query rows per block (each LDS fragment feeds two MFMAs); short ones keep 64-row
+    // blocks so that the grid still covers the chip
+    const bool wide = Tq >= 512;
+    const int qblk = wide ? 128 : 64;
+    const dim3 grid((Tq + qblk - 1) / qblk, H, B), block(256);
+#define OMX_PF_CASE(DD, QQ, MM)                                                      \
+    if (D == DD && (wide ? 2 : 1) == QQ && mask_mode == MM) {                        \
+        attn_prefill_kernel<DD, QQ, MM><<<grid, block, 0, s>>>(a);                   \
+        OMX_LAUNCH_CHECK();                                                          \
+        return 0;                                                                    \
+    }
+#define OMX_PF_MASKS(DD, QQ) OMX_PF_CASE(DD, QQ, OMX_MASK_NONE) OMX_PF_CASE(DD, QQ, OMX_MASK_CAUSAL) \
+    OMX_PF_CASE(DD, QQ, OMX_MASK_BOOL) OMX_PF_CASE(DD, QQ, OMX_MASK_ADDITIVE)
+    OMX_PF_MASKS(128, 1) OMX_PF_MASKS(128, 2) OMX_PF_MASKS(64, 1) OMX_PF_MASKS(64, 2)
+#undef OMX_PF_MASKS
+#undef OMX_PF_CASE
+    return set_error("sdpa prefill: unsupported mask mode %d", mask_mode);
 }
 
 }  // namespace omx

@@ -3,6 +3,7 @@
 // allocations so that the 256 MiB Infinity Cache cannot serve re-reads (MI355X_MICROARCH.md).
 #include <vector>
 
+#include "gemm.hpp"
 #include "gemv.hpp"
 
 extern "C" int omx_bench_gemv(int N, int K, int pro, int epi, int rows_per_wave, int n_copies, int iters,
@@ -60,5 +61,40 @@ extern "C" int omx_bench_gemv(int N, int K, int pro, int epi, int rows_per_wave,
     for (auto p : w) hipFree(p);
     hipFree(x); hipFree(nw); hipFree(out); hipFree(resid); hipFree(slot);
     hipEventDestroy(e0); hipEventDestroy(e1); hipStreamDestroy(s);
+    return 0;
+}
+
+// time the bf16 MFMA GEMM out[M,N] = x[M,K] . W[N,K]^T with HIP events (operands rotated over n_copies buffers)
+extern "C" int omx_bench_gemm(int M, int N, int K, int n_copies, int iters, float* avg_ms) {
+    using namespace omx;
+    OMX_REQUIRE(avg_ms && n_copies > 0 && iters > 0, "omx_bench_gemm: bad arguments");
+    std::vector<void*> w(n_copies, nullptr), x(n_copies, nullptr);
+    void* out = nullptr;
+    for (int i = 0; i < n_copies; ++i) {
+        OMX_HIP_CHECK(hipMalloc(&w[i], (size_t)N * K * 2));
+        OMX_HIP_CHECK(hipMalloc(&x[i], (size_t)M * K * 2));
+        if (omx_fill_uniform(w[i], (size_t)N * K, 100 + i, 0.05f, 0.f, OMX_BFLOAT16, nullptr)) return 1;
+        if (omx_fill_uniform(x[i], (size_t)M * K, 200 + i, 1.0f, 0.f, OMX_BFLOAT16, nullptr)) return 1;
+    }
+    OMX_HIP_CHECK(hipMalloc(&out, (size_t)M * N * 2));
+    hipStream_t s;
+    OMX_HIP_CHECK(hipStreamCreate(&s));
+    hipEvent_t e0, e1;
+    OMX_HIP_CHECK(hipEventCreate(&e0));
+    OMX_HIP_CHECK(hipEventCreate(&e1));
+    OMX_HIP_CHECK(hipDeviceSynchronize());
+    for (int i = 0; i < 3; ++i)
+        if (launch_gemm_bf16((bf16_t*)out, (const bf16_t*)x[i % n_copies], (const bf16_t*)w[i % n_copies], nullptr, M, N, K, s)) return 1;
+    OMX_HIP_CHECK(hipEventRecord(e0, s));
+    for (int i = 0; i < iters; ++i)
+        if (launch_gemm_bf16((bf16_t*)out, (const bf16_t*)x[i % n_copies], (const bf16_t*)w[i % n_copies], nullptr, M, N, K, s)) return 1;
+    OMX_HIP_CHECK(hipEventRecord(e1, s));
+    OMX_HIP_CHECK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    OMX_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+    *avg_ms = ms / iters;
+    for (int i = 0; i < n_copies; ++i) { (void)hipFree(w[i]); (void)hipFree(x[i]); }
+    (void)hipFree(out);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipStreamDestroy(s);
     return 0;
 }

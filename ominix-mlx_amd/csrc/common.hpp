@@ -25,12 +25,18 @@ __device__ __host__ __forceinline__ float bf16_to_f32(bf16_t b) {
 }
 // round-to-nearest-even, NaN kept quiet
 __device__ __host__ __forceinline__ bf16_t f32_to_bf16(float f) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    // gfx950 converts in hardware (v_cvt_pk_bf16_f32, RNE); the software form below costs a compare and a
+    // per-lane branch per element, which dominated the flash-attention softmax (64 conversions per tile)
+    return __builtin_bit_cast(bf16_t, (__bf16)f);
+#else
     union { uint32_t u; float f; } c;
     c.f = f;
-    uint32_t u = c.u;
-    if ((u & 0x7FFFFFFFu) > 0x7F800000u) return (bf16_t)((u >> 16) | 0x0040u);
-    u += 0x7FFFu + ((u >> 16) & 1u);
-    return (bf16_t)(u >> 16);
+    const uint32_t u = c.u;
+    const uint32_t rne = (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+    const uint32_t nan = (u >> 16) | 0x0040u;
+    return (bf16_t)(((u & 0x7FFFFFFFu) > 0x7F800000u) ? nan : rne);
+#endif
 }
 __device__ __forceinline__ float round_bf16(float f) { return bf16_to_f32(f32_to_bf16(f)); }
 

@@ -449,7 +449,9 @@ int omx_qwen3_create(omx_qwen3* out, const omx_qwen3_config* cfg) {
                                                                   (double)m->cfg.rope_scale);
         OMX_LAUNCH_CHECK();
     }
-    m->nsplit = (m->cap + 63) / 64;
+    int tok_per_split = 64;
+    if (const char* v = getenv("OMX_ATTN_SPLIT_TOKENS")) tok_per_split = atoi(v) > 0 ? atoi(v) : 64;
+    m->nsplit = (m->cap + tok_per_split - 1) / tok_per_split;
     const int cap_splits = (512 + m->Hkv - 1) / m->Hkv;
     if (m->nsplit > cap_splits) m->nsplit = cap_splits;
     if (dev_alloc(m, &m->st, 1) || dev_alloc(m, &m->out_ring, (size_t)m->ring_cap) ||

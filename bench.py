@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--model", default="qwen3-8b", choices=list(MODELS))
     ap.add_argument("--layers", type=int, default=0, help="debug: override layer count (invalidates the metric)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-flux", action="store_true", help="skip the secondary FLUX.2-klein sec/step measurement")
     return ap.parse_args()
 
 
@@ -107,6 +108,37 @@ def time_dominant_kernel(omx, cfg, world, iters=3):
     ms = ctypes.c_float()
     omx.check(lib.omx_bench_gemv(N, K, 1, 2, 0, copies, copies * iters, ctypes.byref(ms)))
     return nbytes, ms.value * 1e-3
+
+
+# HBM bytes per launch of the dominant kernel from the PMC pass committed under profiles/
+# (rocprofv3 --pmc FETCH_SIZE, x2 gfx950 correction; profiles/r01_pmc_fetch_size_gemv.md)
+PMC_TRAFFIC_GATE_UP_TP1 = 201641984
+
+
+def flux_secondary(omx, steps=3):
+    """Second half of BASELINE.json's metric string: FLUX.2-klein 1024x1024 sec/step (one MI355X, bf16,
+    synthetic weights/latents; full 5 double + 20 single block model, S = 512 txt + 4096 img tokens)."""
+    import numpy as np
+    from ominix_mlx_amd import klein
+    g = 1024 // 16
+    s_img, s_txt = g * g, 512
+    m = klein.FluxKlein()
+    m.synth_weights()
+    lat = omx.ops.fill_uniform((s_img, 128), 1, 1.7)
+    txt = omx.ops.fill_uniform((s_txt, 7680), 2, 1.7)
+    rcos, rsin = klein.compute_rope(klein.create_txt_ids(s_txt), klein.create_img_ids(g, g))
+    m.forward_with_rope(lat, txt, 1000.0, rcos, rsin)
+    ts = []
+    for i in range(steps):
+        m.forward_with_rope(lat, txt, (1.0 - i / 28.0) * 1000.0, rcos, rsin)
+        ts.append(m.last_ms())
+    m.close()
+    ms = float(np.median(ts))
+    flop = 34.79e12   # SURVEY.md 8d: 28.27 TFLOP linear + 6.52 TFLOP attention at S = 4608
+    return {"metric": "flux_klein_1024_sec_per_step", "value": round(ms / 1e3, 5), "unit": "s/step", "higher_is_better": False,
+            "n_gpus": 1, "steps": steps, "dtype": "bf16", "data": "synthetic",
+            "roofline": {"bound": "mfma", "achieved": round(flop / ms / 1e9, 1), "peak": 2500.0, "unit": "TFLOP/s",
+                         "frac": round(flop / ms / 1e9 / 2500.0, 4)}}
 
 
 def cpu_baseline(cfg, ctx, n_layers_sample=2, reps=2):
@@ -215,7 +247,9 @@ def main():
                    "parallelism": f"tp{world}", "context_at_timing": ctx_mid,
                    "layers": cfg["num_hidden_layers"]},
         "roofline": {"bound": "hbm", "kernel": "gemv_kernel<rmsnorm, gate/up, swiglu>", "achieved": round(achieved, 1),
-                     "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                     "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
+                     "traffic": PMC_TRAFFIC_GATE_UP_TP1 if world == 1 and args.model == "qwen3-8b" else None,
+                     "traffic_source": "profiles/r01_pmc_fetch_size_gemv.md (rocprofv3 --pmc FETCH_SIZE, separate pass, x2 gfx950 correction)",
                      "algorithmic_bytes_per_launch": k_bytes, "avg_launch_us": round(k_s * 1e6, 2)},
         "step_roofline": {"algorithmic_bytes_per_token": int(step_bytes),
                           "achieved_GBps": round(step_bytes / (ms_per_step * 1e-3) / 1e9, 1),
@@ -228,6 +262,12 @@ def main():
                             "batched: MFMA GEMM + flash attention for n-1 tokens, decode step for the last"},
         "first_tokens": [int(first)] + [int(t) for t in toks[:4]],
     }
+    model.close()
+    if world == 1 and not args.no_flux:
+        try:
+            out["secondary"] = flux_secondary(omx)
+        except Exception as e:
+            out["secondary"] = {"metric": "flux_klein_1024_sec_per_step", "value": None, "error": str(e)}
     if not args.no_cpu_baseline:
         try:
             out["cpu_baseline"] = cpu_baseline(cfg, ctx_mid)
@@ -235,7 +275,6 @@ def main():
             out["cpu_baseline"] = {"value": None, "unit": "tokens/s", "cores": os.cpu_count(), "kind": "port",
                                    "sample": f"failed: {e}"}
     print(json.dumps(out), flush=True)
-    model.close()
 
 
 if __name__ == "__main__":

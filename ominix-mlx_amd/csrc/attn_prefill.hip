@@ -16,6 +16,8 @@
 //   * P goes from the S^T accumulator straight into the B operand of the second product: the MFMA
 //     contraction index is permuted identically on the V^T side, so no transpose of P is needed;
 //   * softmax in fp32 (fast.rs:116); P is rounded to bf16 for the second product.
+#include <stdlib.h>
+
 #include "gemm.hpp"
 
 namespace omx {
@@ -259,7 +261,8 @@ int launch_attn_prefill(bf16_t* out, const bf16_t* q, const bf16_t* k, const bf1
     }
     // long sequences: 128 query rows per block (each LDS fragment feeds two MFMAs); short ones keep 64-row
     // blocks so that the grid still covers the chip
-    const bool wide = Tq >= 512;
+    const char* wenv = getenv("OMX_ATTN_WIDE");
+    const bool wide = wenv ? atoi(wenv) != 0 : Tq >= 512;
     const int qblk = wide ? 128 : 64;
     const dim3 grid((Tq + qblk - 1) / qblk, H, B), block(256);
 #define OMX_PF_CASE(DD, QQ, MM)                                                      \

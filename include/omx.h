@@ -229,6 +229,25 @@ int omx_mel_frontend_frames(omx_mel_frontend f, int64_t n_samples, int* n_frames
 int omx_mel_frontend_forward(omx_mel_frontend f, const float* audio, int64_t n_samples, float* feats, float* logmel_out,
                              float* power_out, omx_stream stream);
 
+/* =====================================================================================
+ * a13: Paraformer body pieces (funasr-mlx/src/paraformer.rs).
+ *   omx_sanm_encoder_layer  SanmEncoderLayer::forward :618-634 = LayerNorm(1e-5) -> SanmAttention (:496-532:
+ *       fused qkv Linear, softmax(q k^T d^-1/2) v with heads x 128, FSMN depthwise Conv1d(k=11, pad 5) over v
+ *       plus v, out_proj) -> residual (skipped when in_dim != dim, :625-629) -> LayerNorm -> Linear/ReLU/Linear
+ *       (:560-570) -> residual.  x [T, in_dim] -> out [T, dim], bf16 device tensors; weights bf16:
+ *       Linear [out, in] + bias [out]; fsmn_w [dim, kernel_size] (MLX Conv1d weight [C, k, 1], :1293-1298).
+ *   omx_cif_fire            CIFPredictor::cif_fire :779-879 (threshold 1.0, tail 0.45): hidden [B, T, H] f32,
+ *       alphas [B, T] f32 -> frames [B, max_frames, H] f32 (zero padded) and counts [B]; all device pointers.
+ * ===================================================================================== */
+typedef struct omx_sanm_layer_weights_ {
+    const void *norm1_w, *norm1_b, *qkv_w, *qkv_b, *out_w, *out_b, *fsmn_w, *norm2_w, *norm2_b, *ffn_up_w, *ffn_up_b,
+        *ffn_down_w, *ffn_down_b;
+} omx_sanm_layer_weights;
+int omx_sanm_encoder_layer(void* out, const void* x, const omx_sanm_layer_weights* w, int T, int in_dim, int dim,
+                           int heads, int ffn_dim, int kernel_size, omx_stream stream);
+int omx_cif_fire(float* frames, int* counts, const float* hidden, const float* alphas, int batch, int T, int H,
+                 float threshold, float tail_threshold, int max_frames, omx_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

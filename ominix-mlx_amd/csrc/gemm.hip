@@ -40,6 +40,7 @@ struct GemmArgs {
     int M, N, K;
     int grid_m, grid_n;
     GroupedDesc g;        // grouped mode when g.tile_expert != nullptr
+    int relu;             // out = max(0, acc + bias)  (Paraformer FFN, paraformer.rs:565-569)
 };
 
 // one 16-B chunk per lane per wave-instruction, 4 instructions per operand tile: row pointers of the 4
@@ -160,6 +161,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_nt_kernel(const GemmArgs a
                 if (row < rows_valid) {
                     const size_t o = (size_t)(out_row0 + row) * a.N + col;
                     float v = acc[i][j][r] + bv;
+                    if (a.relu) v = fmaxf(v, 0.f);
                     if (a.gate) v = bf16_to_f32(a.resid[o]) + v * bf16_to_f32(a.gate[col]);
                     else if (a.resid) v = bf16_to_f32(a.resid[o]) + round_bf16(v);
                     a.out[o] = f32_to_bf16(v);
@@ -207,6 +209,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_nt_generic_kernel(const Ge
         const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         if (row < a.M) {
             float v = acc[r] + bv;
+            if (a.relu) v = fmaxf(v, 0.f);
             if (a.gate) v = bf16_to_f32(a.resid[(size_t)row * a.N + col]) + v * bf16_to_f32(a.gate[col]);
             else if (a.resid) v = bf16_to_f32(a.resid[(size_t)row * a.N + col]) + round_bf16(v);
             a.out[(size_t)row * a.N + col] = f32_to_bf16(v);
@@ -228,9 +231,9 @@ int ensure_attr() {
 }  // namespace
 
 static int launch_gemm_impl(bf16_t* out, const bf16_t* x, const bf16_t* w, const bf16_t* bias, const bf16_t* resid,
-                            const bf16_t* gate, int M, int N, int K, hipStream_t s) {
+                            const bf16_t* gate, int M, int N, int K, hipStream_t s, int relu = 0) {
     OMX_REQUIRE(M > 0 && N > 0 && K > 0, "gemm: bad shape M=%d N=%d K=%d", M, N, K);
-    GemmArgs a = {x, w, bias, resid, gate, out, M, N, K, (M + BM - 1) / BM, (N + BN - 1) / BN, {}};
+    GemmArgs a = {x, w, bias, resid, gate, out, M, N, K, (M + BM - 1) / BM, (N + BN - 1) / BN, {}, relu};
     const bool fast = (K % BK == 0) && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w)) & 15u) == 0;
     if (fast) {
         if (ensure_attr()) return 1;
@@ -245,6 +248,11 @@ static int launch_gemm_impl(bf16_t* out, const bf16_t* x, const bf16_t* w, const
 int launch_gemm_bf16_ex(bf16_t* out, const bf16_t* x, const bf16_t* w, const bf16_t* bias, const bf16_t* resid, int M,
                         int N, int K, hipStream_t s) {
     return launch_gemm_impl(out, x, w, bias, resid, nullptr, M, N, K, s);
+}
+
+int launch_gemm_bf16_bias_relu(bf16_t* out, const bf16_t* x, const bf16_t* w, const bf16_t* bias, int M, int N, int K,
+                               hipStream_t s) {
+    return launch_gemm_impl(out, x, w, bias, nullptr, nullptr, M, N, K, s, 1);
 }
 
 int launch_gemm_bf16_gated(bf16_t* out, const bf16_t* x, const bf16_t* w, const bf16_t* resid, const bf16_t* gate, int M,
@@ -263,7 +271,7 @@ int launch_gemm_bf16_grouped(bf16_t* out, const bf16_t* x, const bf16_t* w, int 
     OMX_REQUIRE(max_rows > 0 && N > 0 && K > 0 && max_tiles > 0, "grouped gemm: bad shape");
     OMX_REQUIRE(K % BK == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w)) & 15u) == 0,
                 "grouped gemm: K=%d must be a multiple of %d and operands 16-byte aligned", K, BK);
-    GemmArgs a = {x, w, nullptr, nullptr, nullptr, out, max_rows, N, K, max_tiles, (N + BN - 1) / BN, g};
+    GemmArgs a = {x, w, nullptr, nullptr, nullptr, out, max_rows, N, K, max_tiles, (N + BN - 1) / BN, g, 0};
     if (ensure_attr()) return 1;
     gemm_bf16_nt_kernel<true><<<max_tiles * a.grid_n, NTHREADS, 4 * TILE_BYTES, s>>>(a);
     OMX_LAUNCH_CHECK();

@@ -22,6 +22,9 @@ int launch_gemm_bf16(bf16_t* out, const bf16_t* x, const bf16_t* w, const bf16_t
 // same with an optional fused residual: out = bf16(resid + bf16(x.W^T (+bias)))
 int launch_gemm_bf16_ex(bf16_t* out, const bf16_t* x, const bf16_t* w, const bf16_t* bias, const bf16_t* resid, int M,
                         int N, int K, hipStream_t s);
+// out = bf16(max(0, x.W^T + bias))   (Paraformer FFN: Linear + ReLU, paraformer.rs:565-569)
+int launch_gemm_bf16_bias_relu(bf16_t* out, const bf16_t* x, const bf16_t* w, const bf16_t* bias, int M, int N, int K,
+                               hipStream_t s);
 // gated residual epilogue of the DiT blocks: out = bf16(resid + (x.W^T) * gate[col])   (klein_model.rs:496-497, 922-925)
 int launch_gemm_bf16_gated(bf16_t* out, const bf16_t* x, const bf16_t* w, const bf16_t* resid, const bf16_t* gate, int M,
                            int N, int K, hipStream_t s);

@@ -166,6 +166,10 @@ int omx_qwen3_debug_read(omx_qwen3 m, const char* name, void* host, size_t n_ele
 int omx_qwen3_stream(omx_qwen3 m, omx_stream* s);
 /* algorithmic HBM bytes of ONE decode step at context length ctx (SURVEY.md 8d formula)             */
 int omx_qwen3_step_bytes(omx_qwen3 m, int ctx, double* bytes);
+/* how the decode step is executed once built: 0 = not built yet, 1 = step graph (one launch per phase,
+ * replayed as a hipGraph), 2 = the same launches issued eagerly, 3 = one persistent kernel per token
+ * (csrc/decode_mega.hip; default when the shape has an instantiation, OMX_DECODE_MEGA=0 disables it)    */
+int omx_qwen3_decode_path(omx_qwen3 m, int* path);
 
 /* =====================================================================================
  * a6 + a7: sparse-MoE block = router + top-k + SwitchGLU + weighted sum.

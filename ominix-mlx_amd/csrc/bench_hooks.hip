@@ -98,3 +98,71 @@ extern "C" int omx_bench_gemm(int M, int N, int K, int n_copies, int iters, floa
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipStreamDestroy(s);
     return 0;
 }
+
+// ---- device-wide barrier probe (gridsync.hpp): average cost of one exchange + barrier over `iters` ----
+#include "gridsync.hpp"
+namespace {
+// variant 0: gridsync.hpp as shipped (flags + coherent accessors, no fences)
+// variant 1: the textbook form it replaced: one atomic counter, agent-scope release/acquire fences
+template <int VAR>
+__global__ __launch_bounds__(256) void grid_barrier_probe_kernel(unsigned* words, unsigned* counter, unsigned* mismatches,
+                                                                 int iters, float* sink) {
+    omx::GridSync g{words, 1u, gridDim.x, false};
+    const unsigned nb = gridDim.x;
+    for (int i = 0; i < iters; ++i) {
+        // double-buffered exchange: read what the neighbour wrote LAST round, write this round's value
+        float* src = sink + ((size_t)((i + 1) & 1) * nb + (blockIdx.x + 1) % nb) * 256 + threadIdx.x;
+        float* dst = sink + ((size_t)(i & 1) * nb + blockIdx.x) * 256 + threadIdx.x;
+        if (VAR == 0) {
+            if (omx::ld_coh_f32(src) != (float)i) atomicAdd(mismatches, 1u);
+            omx::st_coh_f32(dst, (float)(i + 1));
+            omx::grid_sync(g);
+        } else {
+            if (*src != (float)i) atomicAdd(mismatches, 1u);
+            *dst = (float)(i + 1);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)(i + 1) * nb)
+                    __builtin_amdgcn_s_sleep(2);
+            }
+            __syncthreads();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+    }
+}
+}  // namespace
+
+extern "C" int omx_bench_grid_barrier(int nblocks, int iters, int variant, float* us_per_barrier, int* failed) {
+    using namespace omx;
+    OMX_REQUIRE(nblocks > 0 && iters > 0 && us_per_barrier && failed, "omx_bench_grid_barrier: bad arguments");
+    unsigned* words = nullptr;
+    float* sink = nullptr;
+    const size_t wbytes = (grid_sync_words(nblocks) + 32) * 4;   // + counter, mismatch count
+    OMX_HIP_CHECK(hipMalloc(&words, wbytes));
+    OMX_HIP_CHECK(hipMalloc(&sink, (size_t)nblocks * 512 * 4));
+    OMX_HIP_CHECK(hipMemset(words, 0, wbytes));
+    OMX_HIP_CHECK(hipMemset(sink, 0, (size_t)nblocks * 512 * 4));
+    unsigned* extra = words + grid_sync_words(nblocks);
+    hipEvent_t e0, e1;
+    OMX_HIP_CHECK(hipEventCreate(&e0));
+    OMX_HIP_CHECK(hipEventCreate(&e1));
+    OMX_HIP_CHECK(hipDeviceSynchronize());
+    OMX_HIP_CHECK(hipEventRecord(e0, nullptr));
+    if (variant == 0) grid_barrier_probe_kernel<0><<<nblocks, 256>>>(words, extra, extra + 16, iters, sink);
+    else grid_barrier_probe_kernel<1><<<nblocks, 256>>>(words, extra, extra + 16, iters, sink);
+    OMX_LAUNCH_CHECK();
+    OMX_HIP_CHECK(hipEventRecord(e1, nullptr));
+    OMX_HIP_CHECK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    OMX_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+    unsigned abort_word = 0, mism = 0;
+    OMX_HIP_CHECK(hipMemcpy(&abort_word, words + 16, 4, hipMemcpyDeviceToHost));
+    OMX_HIP_CHECK(hipMemcpy(&mism, extra + 16, 4, hipMemcpyDeviceToHost));
+    *us_per_barrier = ms * 1000.f / iters;
+    *failed = (abort_word ? 1 : 0) | (mism ? 2 : 0);   // 1: a waiter timed out; 2: an exchange read a stale value
+    (void)hipFree(words); (void)hipFree(sink);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    return 0;
+}

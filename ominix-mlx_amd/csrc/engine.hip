@@ -23,8 +23,10 @@
 #include <vector>
 
 #include "attn.hpp"
+#include "decode_mega.hpp"
 #include "gemm.hpp"
 #include "gemv.hpp"
+#include "gridsync.hpp"
 #include "prefill.hpp"
 
 namespace omx {
@@ -58,13 +60,7 @@ __global__ void rope_table_kernel(float* cos_t, float* sin_t, int cap, int half,
     sin_t[idx] = (float)s;
 }
 
-// step state updates (single thread; a few dozen ns of work, they only order the graph)
-struct StepState {
-    int pos;               // tokens in the cache == RoPE offset of the token being processed
-    uint32_t cur_token;    // token fed to the embedding this step
-    int out_count;         // tokens sampled so far
-    int prompt_idx;        // next prompt token to feed during prefill
-};
+// step state updates (single thread; a few dozen ns of work, they only order the graph); StepState: decode_mega.hpp
 
 __global__ void feed_prompt_kernel(StepState* st, const uint32_t* prompt) {
     // after a no-head prefill step: advance and feed the next prompt token
@@ -151,6 +147,15 @@ struct omx_qwen3_ {
     bf16_t *pf_h = nullptr, *pf_h2 = nullptr, *pf_xn = nullptr, *pf_q = nullptr, *pf_k = nullptr, *pf_v = nullptr,
            *pf_qt = nullptr, *pf_attn = nullptr, *pf_g = nullptr, *pf_u = nullptr;
     float last_prefill_ms = 0.f;
+
+    // persistent one-kernel-per-token path (decode_mega.hip); the step graph below is the fallback
+    bool mega = false;
+    int mega_blocks = 0, mega_attn_blocks = 0;
+    MegaLayer* mega_layers = nullptr;
+    unsigned *mega_sync = nullptr, *mega_kv_count = nullptr;
+    unsigned long long* mega_partials = nullptr;
+    unsigned mega_epoch = 1;
+    unsigned long long* mega_trace = nullptr;   // set for one step by omx_qwen3_debug_trace_step
 
     hipGraphExec_t g_full = nullptr, g_nohead = nullptr;
     bool eager = false;          // fallback when stream capture is unavailable (e.g. a collective refuses capture)
@@ -307,9 +312,55 @@ int enqueue_step(omx_qwen3 m, bool with_head) {
     return 0;
 }
 
+template <class T>
+int dev_alloc(omx_qwen3 m, T** p, size_t n) {
+    void* q = nullptr;
+    OMX_HIP_CHECK(hipMalloc(&q, n * sizeof(T) + 64));
+    // same stream as every later writer: a null-stream hipMemset is not ordered against the
+    // engine's non-blocking stream and could zero a buffer after it was filled
+    OMX_HIP_CHECK(hipMemsetAsync(q, 0, n * sizeof(T) + 64, m->stream));
+    *p = (T*)q;
+    m->owned.push_back(q);
+    return 0;
+}
+
+// The persistent one-kernel-per-token path: eligible for the single-GPU dense decoder when decode_mega.hip has an
+// instantiation for the shape.  OMX_DECODE_MEGA=0 forces the step graph (the two must agree bit for bit).
+int setup_mega(omx_qwen3 m) {
+    const omx_qwen3_config& c = m->cfg;
+    const char* env = getenv("OMX_DECODE_MEGA");
+    if (!env || env[0] != '1') return 0;   // opt-in until it beats the step graph
+    if (c.tp_size > 1 || m->allreduce != nullptr || c.num_hidden_layers < 1) return 0;
+    if (!mega_supported(c.hidden_size, m->H * c.head_dim, m->I, c.head_dim, m->H / m->Hkv)) return 0;
+    int capacity = 0;
+    if (mega_capacity(c.hidden_size, m->H * c.head_dim, m->I, &capacity)) return 1;
+    int blocks = capacity < 512 ? capacity : 512;
+    if (const char* v = getenv("OMX_MEGA_BLOCKS")) blocks = atoi(v) > 0 && atoi(v) < blocks ? atoi(v) : blocks;
+    if (blocks < 16 || (c.hidden_size + blocks - 1) / blocks > 64) return 0;   // not enough co-resident blocks: step graph
+    m->mega_blocks = blocks;
+    m->mega_attn_blocks = blocks / 2;
+    if (const char* v = getenv("OMX_MEGA_ATTN_BLOCKS")) m->mega_attn_blocks = atoi(v) >= 1 && atoi(v) < blocks ? atoi(v) : blocks / 2;
+    std::vector<MegaLayer> host(c.num_hidden_layers);
+    for (int l = 0; l < c.num_hidden_layers; ++l) {
+        const LayerW& L = m->layers[l];
+        host[l] = MegaLayer{L.q, L.k, L.v, L.o, L.gate, L.up, L.down, L.q_norm, L.k_norm, L.in_ln, L.post_ln,
+                            m->kcache[l], m->vcache[l]};
+    }
+    if (dev_alloc(m, &m->mega_layers, host.size()) || dev_alloc(m, &m->mega_sync, grid_sync_words(blocks)) ||
+        dev_alloc(m, &m->mega_kv_count, (size_t)m->Hkv * 16) || dev_alloc(m, &m->mega_partials, (size_t)blocks))
+        return 1;
+    OMX_HIP_CHECK(hipMemcpyAsync(m->mega_layers, host.data(), host.size() * sizeof(MegaLayer), hipMemcpyHostToDevice, m->stream));
+    OMX_HIP_CHECK(hipStreamSynchronize(m->stream));   // `host` goes out of scope
+    m->mega_epoch = 1;
+    m->mega = true;
+    return 0;
+}
+
 int build_graphs(omx_qwen3 m) {
-    if (m->g_full || m->eager) return 0;
+    if (m->mega || m->g_full || m->eager) return 0;
     if (resolve_weights(m)) return 1;
+    if (setup_mega(m)) return 1;
+    if (m->mega) return 0;
     const char* no_graph = getenv("OMX_NO_GRAPH");
     if (no_graph && no_graph[0] == '1') {
         m->eager = true;
@@ -340,20 +391,31 @@ int build_graphs(omx_qwen3 m) {
 }
 
 int run_step(omx_qwen3 m, bool with_head) {
+    if (m->mega) {
+        const omx_qwen3_config& c = m->cfg;
+        MegaArgs a = {};
+        a.layers = m->mega_layers;
+        a.n_layers = c.num_hidden_layers; a.hidden = c.hidden_size; a.H = m->H; a.Hkv = m->Hkv; a.I = m->I; a.V = m->V;
+        a.cap = m->cap;
+        a.eps = c.rms_norm_eps; a.scale = 1.0f / sqrtf((float)c.head_dim);
+        a.embed = m->embed; a.final_norm = m->final_norm; a.lm_head = m->lm_head;
+        a.rope_cos = m->rope_cos; a.rope_sin = m->rope_sin;
+        a.st = m->st;
+        a.h0 = m->h; a.h1 = m->h2; a.qkv = m->qkv; a.attn_out = m->attn_out; a.act = m->act; a.logits = m->logits;
+        a.ws_o = m->ws_o; a.ws_ml = m->ws_ml; a.nsplit = m->nsplit;
+        a.attn_blocks = m->mega_attn_blocks;
+        a.sync_words = m->mega_sync; a.epoch0 = m->mega_epoch;
+        a.kv_count = m->mega_kv_count;
+        a.argmax_partials = m->mega_partials;
+        a.out_ring = m->out_ring; a.ring_cap = m->ring_cap; a.prompt = m->prompt_dev;
+        a.with_head = with_head ? 1 : 0;
+        a.trace = m->mega_trace;
+        if (launch_decode_mega(a, m->mega_blocks, m->stream)) return 1;
+        m->mega_epoch += mega_barriers(a.n_layers, a.with_head);
+        return 0;
+    }
     if (m->eager) return enqueue_step(m, with_head);
     OMX_HIP_CHECK(hipGraphLaunch(with_head ? m->g_full : m->g_nohead, m->stream));
-    return 0;
-}
-
-template <class T>
-int dev_alloc(omx_qwen3 m, T** p, size_t n) {
-    void* q = nullptr;
-    OMX_HIP_CHECK(hipMalloc(&q, n * sizeof(T) + 64));
-    // same stream as every later writer: a null-stream hipMemset is not ordered against the
-    // engine's non-blocking stream and could zero a buffer after it was filled
-    OMX_HIP_CHECK(hipMemsetAsync(q, 0, n * sizeof(T) + 64, m->stream));
-    *p = (T*)q;
-    m->owned.push_back(q);
     return 0;
 }
 
@@ -363,6 +425,15 @@ int dev_alloc(omx_qwen3 m, T** p, size_t n) {
 //   (causal, bottom-right aligned == the bool mask of utils.rs:134-153) -> o GEMM + residual ->
 //   RMSNorm -> gate/up GEMM -> silu*up -> down GEMM + residual.        (model.rs:161-215,263-267,321-332)
 // The last layer stops after its cache scatter: nothing downstream of it is consumed for these tokens.
+// a device-wide barrier of the persistent kernel gave up (a block never arrived): the step's results are void
+int mega_health(omx_qwen3 m) {
+    if (!m->mega) return 0;
+    unsigned abort_word = 0;
+    OMX_HIP_CHECK(hipMemcpy(&abort_word, m->mega_sync + 16, 4, hipMemcpyDeviceToHost));
+    OMX_REQUIRE(abort_word == 0, "decode megakernel: a device-wide barrier timed out (blocks not co-resident?); set OMX_DECODE_MEGA=0");
+    return 0;
+}
+
 int prefill_prefix_batched(omx_qwen3 m, int T, int off) {
     const omx_qwen3_config& c = m->cfg;
     hipStream_t s = m->stream;
@@ -489,7 +560,7 @@ int omx_qwen3_destroy(omx_qwen3 m) {
 int omx_qwen3_set_weight(omx_qwen3 m, const char* name, const void* ptr) {
     OMX_REQUIRE(m && name && ptr, "omx_qwen3_set_weight: null argument");
     OMX_REQUIRE(((uintptr_t)ptr & 15u) == 0, "omx_qwen3_set_weight: %s is not 16-byte aligned", name);
-    OMX_REQUIRE(m->g_full == nullptr, "omx_qwen3_set_weight: weights are frozen once the step graph is built");
+    OMX_REQUIRE(m->g_full == nullptr && !m->mega, "omx_qwen3_set_weight: weights are frozen once the decode step is built");
     m->named[name] = ptr;
     m->weights_resolved = false;
     return 0;
@@ -547,7 +618,7 @@ int omx_qwen3_synth_weights(omx_qwen3 m, uint32_t base_seed) {
 
 int omx_qwen3_set_comm(omx_qwen3 m, void* comm, void* allreduce_fn) {
     OMX_REQUIRE(m, "omx_qwen3_set_comm: null model");
-    OMX_REQUIRE(m->g_full == nullptr && !m->eager, "omx_qwen3_set_comm: communicator must be set before the first step");
+    OMX_REQUIRE(m->g_full == nullptr && !m->eager && !m->mega, "omx_qwen3_set_comm: communicator must be set before the first step");
     m->comm = comm;
     m->allreduce = (nccl_allreduce_fn)allreduce_fn;
     return 0;
@@ -607,7 +678,7 @@ int omx_qwen3_prefill(omx_qwen3 m, const uint32_t* prompt, int n_prompt, uint32_
     OMX_HIP_CHECK(hipMemcpyAsync(first_token, m->out_ring + (count_before % m->ring_cap), 4, hipMemcpyDeviceToHost, m->stream));
     OMX_HIP_CHECK(hipStreamSynchronize(m->stream));
     OMX_HIP_CHECK(hipEventElapsedTime(&m->last_prefill_ms, m->ev0, m->ev1));
-    return 0;
+    return mega_health(m);
 }
 
 int omx_qwen3_last_prefill_ms(omx_qwen3 m, float* ms) {
@@ -631,6 +702,7 @@ int omx_qwen3_decode(omx_qwen3 m, int n, uint32_t* tokens_out) {
     OMX_HIP_CHECK(hipEventRecord(m->ev1, m->stream));
     OMX_HIP_CHECK(hipStreamSynchronize(m->stream));
     OMX_HIP_CHECK(hipEventElapsedTime(&m->last_decode_ms, m->ev0, m->ev1));
+    if (mega_health(m)) return 1;
     std::vector<uint32_t> ring(m->ring_cap);
     OMX_HIP_CHECK(hipMemcpy(ring.data(), m->out_ring, (size_t)m->ring_cap * 4, hipMemcpyDeviceToHost));
     for (int i = 0; i < n; ++i) tokens_out[i] = ring[(st.out_count + i) % m->ring_cap];
@@ -675,6 +747,35 @@ int omx_qwen3_last_decode_ms(omx_qwen3 m, float* ms) {
 int omx_qwen3_stream(omx_qwen3 m, omx_stream* s) {
     OMX_REQUIRE(m && s, "omx_qwen3_stream: null argument");
     *s = (omx_stream)m->stream;
+    return 0;
+}
+
+/* debug hook (tools/mega_trace.py): run ONE decode step of the persistent kernel with the phase timeline
+ * enabled; host receives [layers][kTraceEvents][blocks] 100 MHz wall-clock stamps */
+int omx_qwen3_debug_trace_step(omx_qwen3 m, unsigned long long* host, size_t n_words, int* blocks) {
+    OMX_REQUIRE(m && host && blocks, "omx_qwen3_debug_trace_step: null argument");
+    if (build_graphs(m)) return 1;
+    OMX_REQUIRE(m->mega, "omx_qwen3_debug_trace_step: the persistent step kernel is not in use");
+    const size_t need = (size_t)m->cfg.num_hidden_layers * kTraceEvents * m->mega_blocks;
+    OMX_REQUIRE(n_words >= need, "omx_qwen3_debug_trace_step: buffer of %zu words, need %zu", n_words, need);
+    unsigned long long* dev = nullptr;
+    OMX_HIP_CHECK(hipMalloc(&dev, need * 8));
+    OMX_HIP_CHECK(hipMemsetAsync(dev, 0, need * 8, m->stream));
+    m->mega_trace = dev;
+    const int rc = run_step(m, true);
+    m->mega_trace = nullptr;
+    if (!rc) {
+        OMX_HIP_CHECK(hipStreamSynchronize(m->stream));
+        OMX_HIP_CHECK(hipMemcpy(host, dev, need * 8, hipMemcpyDeviceToHost));
+    }
+    (void)hipFree(dev);
+    *blocks = m->mega_blocks;
+    return rc ? 1 : mega_health(m);
+}
+
+int omx_qwen3_decode_path(omx_qwen3 m, int* path) {
+    OMX_REQUIRE(m && path, "omx_qwen3_decode_path: null argument");
+    *path = m->mega ? 3 : m->eager ? 2 : m->g_full ? 1 : 0;
     return 0;
 }
 

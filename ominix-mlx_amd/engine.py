@@ -40,6 +40,7 @@ ENGINE_SIGNATURES = {
     "omx_qwen3_debug_read": (c_int, [c_void_p, ctypes.c_char_p, c_void_p, ctypes.c_size_t]),
     "omx_qwen3_stream": (c_int, [c_void_p, ctypes.POINTER(c_void_p)]),
     "omx_qwen3_step_bytes": (c_int, [c_void_p, c_int, ctypes.POINTER(ctypes.c_double)]),
+    "omx_qwen3_decode_path": (c_int, [c_void_p, ctypes.POINTER(c_int)]),
 }
 for _n, (_r, _a) in ENGINE_SIGNATURES.items():
     _f = getattr(lib, _n)
@@ -148,6 +149,12 @@ class Model:
         s = c_void_p()
         check(lib.omx_qwen3_stream(self._h, ctypes.byref(s)))
         return s.value or 0
+
+    def decode_path(self) -> str:
+        """'graph' | 'eager' | 'persistent' once the first step ran ('unbuilt' before)."""
+        v = c_int()
+        check(lib.omx_qwen3_decode_path(self._h, ctypes.byref(v)))
+        return ("unbuilt", "graph", "eager", "persistent")[v.value]
 
     def step_bytes(self, ctx: int) -> float:
         v = ctypes.c_double()

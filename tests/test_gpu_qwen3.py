@@ -155,3 +155,52 @@ def test_tensor_parallel_code_path_with_one_rank_communicator(omx, monkeypatch):
     got = np.concatenate([[m.prefill(prompt)], m.decode(10)])
     np.testing.assert_array_equal(got, want)
     np.testing.assert_array_equal(m.last_logits(), plain.last_logits())
+
+
+MEGA_CONFIGS = {
+    # shapes decode_mega.hip instantiates; "ksplit" exercises the down projection split over the block's waves
+    "gqa4_d128": CONFIGS["gqa4_d128"],
+    "ksplit_gqa4": rq.Qwen3Config(1024, 2, 6144, 8, 2, 128, 3000, 1e-6, 1e6, False),
+    "qwen3_0p6b_shape": rq.Qwen3Config(1024, 2, 3072, 16, 8, 128, 2048, 1e-6, 1e6, True),
+}
+
+
+@pytest.mark.parametrize("name", list(MEGA_CONFIGS))
+@pytest.mark.parametrize("serial_prefill", ["0", "1"])
+def test_persistent_step_kernel_is_bit_identical_to_step_graph(omx, monkeypatch, name, serial_prefill):
+    """One persistent kernel per token (csrc/decode_mega.hip: device-wide barriers, weight prefetch across
+    them, attention/O-projection block specialisation) computes every row and head with the arithmetic of
+    the per-phase kernels: token ids, logits and the residual stream must be EQUAL to the step-graph path,
+    over enough steps to cross split boundaries of the KV cache (64 tokens) and with a token-serial prefill
+    (the no-head variant of the step)."""
+    cfg = MEGA_CONFIGS[name]
+    prompt = synth.prompt_ids(70, cfg.vocab_size)
+    monkeypatch.setenv("OMX_PREFILL_SERIAL", serial_prefill)
+    outs = {}
+    for mega in ("1", "0"):
+        monkeypatch.setenv("OMX_DECODE_MEGA", mega)
+        m = _engine(omx, cfg)
+        toks = np.concatenate([[m.prefill(prompt)], m.decode(70)])
+        assert m.decode_path() == ("persistent" if mega == "1" else "graph")
+        n = cfg.hidden_size
+        raw = np.empty(n, np.uint16)
+        omx.check(omx.lib.omx_qwen3_debug_read(m._h, b"h", raw.ctypes.data, n))
+        outs[mega] = (toks, m.last_logits(), raw.copy(), m.offset())
+        m.close()
+    np.testing.assert_array_equal(outs["1"][0], outs["0"][0])
+    np.testing.assert_array_equal(outs["1"][1], outs["0"][1])
+    np.testing.assert_array_equal(outs["1"][2], outs["0"][2])
+    assert outs["1"][3] == outs["0"][3] == 70 + 70
+
+
+def test_persistent_step_kernel_reset_and_long_run(omx, monkeypatch):
+    """Barrier epochs carry over launches; reset() + a second generation must reproduce the first."""
+    cfg = MEGA_CONFIGS["gqa4_d128"]
+    prompt = synth.prompt_ids(19, cfg.vocab_size)
+    monkeypatch.setenv("OMX_DECODE_MEGA", "1")
+    m = _engine(omx, cfg, max_context=1024)
+    a = np.concatenate([[m.prefill(prompt)], m.decode(300)])
+    assert m.decode_path() == "persistent"
+    m.reset()
+    b = np.concatenate([[m.prefill(prompt)], m.decode(300)])
+    np.testing.assert_array_equal(a, b)

@@ -338,8 +338,8 @@ int setup_mega(omx_qwen3 m) {
     if (const char* v = getenv("OMX_MEGA_BLOCKS")) blocks = atoi(v) > 0 && atoi(v) < blocks ? atoi(v) : blocks;
     if (blocks < 16 || (c.hidden_size + blocks - 1) / blocks > 64) return 0;   // not enough co-resident blocks: step graph
     m->mega_blocks = blocks;
-    m->mega_attn_blocks = blocks / 2;
-    if (const char* v = getenv("OMX_MEGA_ATTN_BLOCKS")) m->mega_attn_blocks = atoi(v) >= 1 && atoi(v) < blocks ? atoi(v) : blocks / 2;
+    m->mega_attn_blocks = blocks - blocks / 4;   // at least a quarter of the blocks keep the O-projection rows
+    if (const char* v = getenv("OMX_MEGA_ATTN_BLOCKS")) m->mega_attn_blocks = atoi(v) >= 1 && atoi(v) < blocks ? atoi(v) : m->mega_attn_blocks;
     std::vector<MegaLayer> host(c.num_hidden_layers);
     for (int l = 0; l < c.num_hidden_layers; ++l) {
         const LayerW& L = m->layers[l];

@@ -44,7 +44,7 @@ constexpr int kTPW = 64 / kLPR;  // tokens per wave-instruction
 constexpr int kUnroll = 4;
 constexpr int kStep = kTPW * kUnroll;   // tokens per wave per step
 constexpr int kMaxSplit = 512;
-constexpr int kCombChunk = 16;   // split partials a combine thread keeps in flight per head
+constexpr int kCombChunk = 40;   // split partials a combine thread keeps in flight per head
 constexpr int kPartRows = 64;    // down projection, K split over four waves: rows per block
 
 __device__ __forceinline__ u32x4 ld_nt(const u32x4* p) { return __builtin_nontemporal_load(p); }
@@ -323,19 +323,13 @@ __global__ __launch_bounds__(kBlock) void decode_mega_kernel(const MegaArgs a) {
 
     u32x4 wA[kSet], wB[kSet];
 
-    // A wave's loads return in order, so the wave that polls the barrier (wave 0, gridsync.hpp) must not have
-    // a weight prefetch in flight ahead of its poll: it issues its share AFTER the barrier, every other wave
-    // before.  Both arms define the registers exactly once, which is what keeps them dead across the other
-    // phases for the register allocator.
-    const bool polls = wave == 0;
+    // Loads for the next phase are issued just before the block waits at a barrier.  (Measured variant: the
+    // polling wave issuing its share AFTER the barrier, because a wave's loads return in order and its poll
+    // sits behind its own prefetch -- the release is seen ~4 us earlier by that wave but the late issue costs
+    // as much)
     auto around_barrier = [&](auto&& issue, auto&& barrier) {
-        if (!polls) {
-            issue();
-            barrier();
-        } else {
-            barrier();
-            issue();
-        }
+        issue();
+        barrier();
     };
 
     // attention roles: 4-wave group, wave inside the group, chunk ownership inside a K/V row

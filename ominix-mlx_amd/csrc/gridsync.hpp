@@ -83,17 +83,13 @@ __device__ __forceinline__ void grid_arrive(GridSync& g, bool drain = true) {
     __syncthreads();
     if (threadIdx.x == 0) st_coh32(g.words + 64 + 16 * blockIdx.x, g.epoch);
 }
-// Only WAVE 0 of a block polls: a wave's loads return in order (vmcnt), so a poll issued behind that wave's
-// weight prefetch is not seen until the prefetch has landed (measured: +4 us on the release).  Callers keep
-// wave 0 free of loads in flight across the barrier (it issues its share after grid_wait).
 __device__ __forceinline__ void grid_wait(GridSync& g) {
-    if (threadIdx.x < 64) {
-        if (blockIdx.x == 0) {
-            for (unsigned b = threadIdx.x; b < g.nblocks; b += 64) grid_spin<1>(g, g.words + 64 + 16 * b);
-            if (threadIdx.x == 0) st_coh32(g.words, g.epoch);   // lanes of one wave: all polls above are done
-        } else if (threadIdx.x == 0) {
-            grid_spin<2>(g, g.words);
-        }
+    if (blockIdx.x == 0) {
+        for (unsigned b = threadIdx.x; b < g.nblocks; b += blockDim.x) grid_spin<1>(g, g.words + 64 + 16 * b);
+        asm volatile("s_barrier" ::: "memory");
+        if (threadIdx.x == 0) st_coh32(g.words, g.epoch);
+    } else if (threadIdx.x == 0) {
+        grid_spin<2>(g, g.words);
     }
     // raw s_barrier: no LDS data crosses it, and __syncthreads()'s waitcnt would stall on the prefetch
     asm volatile("s_barrier" ::: "memory");

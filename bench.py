@@ -70,29 +70,9 @@ def init_dist(n_gpus):
 
 
 def rccl_comm(dist, rank, world):
-    """Create an RCCL communicator for the C++ engine, bootstrapped through torch.distributed.
-    torch ships librccl.so; the engine only needs the comm handle and ncclAllReduce's address."""
-    import torch
-    lib = ctypes.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so"), mode=ctypes.RTLD_GLOBAL)
-
-    class UniqueId(ctypes.Structure):
-        _fields_ = [("internal", ctypes.c_byte * 128)]
-
-    uid = UniqueId()
-    if rank == 0:
-        lib.ncclGetUniqueId.argtypes = [ctypes.POINTER(UniqueId)]
-        assert lib.ncclGetUniqueId(ctypes.byref(uid)) == 0
-    t = torch.frombuffer(bytearray(bytes(uid)), dtype=torch.uint8).cuda()
-    if dist is not None:
-        dist.broadcast(t, 0)
-    ctypes.memmove(ctypes.byref(uid), bytes(t.cpu().numpy().tobytes()), 128)
-    comm = ctypes.c_void_p()
-    lib.ncclCommInitRank.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, UniqueId, ctypes.c_int]
-    rc = lib.ncclCommInitRank(ctypes.byref(comm), world, uid, rank)
-    if rc != 0:
-        raise RuntimeError(f"ncclCommInitRank failed with {rc}")
-    fn = ctypes.cast(lib.ncclAllReduce, ctypes.c_void_p).value
-    return lib, comm.value, fn
+    """RCCL communicator for the C++ engine, bootstrapped through torch.distributed (ominix-mlx_amd/comm.py)."""
+    from ominix_mlx_amd import comm
+    return comm.rccl_comm(dist, rank, world)
 
 
 def time_dominant_kernel(omx, cfg, world, iters=3):

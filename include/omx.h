@@ -170,6 +170,9 @@ int omx_qwen3_step_bytes(omx_qwen3 m, int ctx, double* bytes);
  * replayed as a hipGraph), 2 = the same launches issued eagerly, 3 = one persistent kernel per token
  * (csrc/decode_mega.hip; default when the shape has an instantiation, OMX_DECODE_MEGA=0 disables it)    */
 int omx_qwen3_decode_path(omx_qwen3 m, int* path);
+/* debug hook (tools/mega_trace.py): run ONE decode step of the persistent kernel with its phase timeline on;
+ * host receives [layers][16][blocks] 100 MHz wall-clock stamps, *blocks = grid size                        */
+int omx_qwen3_debug_trace_step(omx_qwen3 m, unsigned long long* host, size_t n_words, int* blocks);
 
 /* =====================================================================================
  * a6 + a7: sparse-MoE block = router + top-k + SwitchGLU + weighted sum.
@@ -188,6 +191,18 @@ int omx_moe_workspace_bytes(int n_tokens, int hidden, int inter, int n_experts, 
 int omx_moe_forward(void* out, const void* x, const void* gate_w, const void* w_gate, const void* w_up,
                     const void* w_down, int n_tokens, int hidden, int inter, int n_experts, int top_k, int mode,
                     int norm_topk_prob, uint32_t* inds_out, void* scores_out, omx_stream stream);
+/* The same block as three stages, for an expert-parallel host that exchanges token rows between them
+ * (all-to-all dispatch + combine; ominix-mlx_amd/ep.py):
+ *   route    x [n, hidden] -> inds [n, k] u32, scores [n, k] (dtype of x)            (model.rs:296-302)
+ *   experts  rows [m, hidden] that already carry their (local) expert id -> y [m, hidden]
+ *            = down_e(fused_swiglu(up_e x, gate_e x))                                 (model.rs:243-274)
+ *   combine  y [n, k, hidden], scores [n, k] -> out [n, hidden]                      (model.rs:304-307) */
+int omx_moe_route(uint32_t* inds_out, void* scores_out, const void* x, const void* gate_w, int n_tokens, int hidden,
+                  int n_experts, int top_k, int mode, int norm_topk_prob, omx_stream stream);
+int omx_moe_experts(void* y, const void* x_rows, const uint32_t* expert_ids, int n_rows, const void* w_gate,
+                    const void* w_up, const void* w_down, int hidden, int inter, int n_experts, omx_stream stream);
+int omx_moe_combine(void* out, const void* y_slots, const void* scores, int n_tokens, int hidden, int top_k,
+                    omx_stream stream);
 
 /* =====================================================================================
  * a14 (+ a9): FLUX.2-klein DiT / MMDiT forward -- FluxKlein::forward_with_rope

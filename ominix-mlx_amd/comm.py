@@ -1,0 +1,92 @@
+"""RCCL plumbing for the multi-GPU paths (one process per GPU).
+
+torch ships librccl.so and `torch.distributed` (backend "nccl" == RCCL) is only used to bootstrap:
+rank 0's ncclUniqueId is broadcast through it, every rank then creates a raw communicator that the
+C++ engines (`omx_qwen3_set_comm`, `omx_klein_set_comm`) and the expert-parallel exchange below drive
+on their own HIP streams.  Nothing here touches the data path of a single-GPU run."""
+from __future__ import annotations
+
+import ctypes
+import os
+
+NCCL_UINT8, NCCL_INT32, NCCL_UINT32, NCCL_FLOAT32, NCCL_BFLOAT16 = 1, 2, 3, 7, 9
+
+
+class UniqueId(ctypes.Structure):
+    _fields_ = [("internal", ctypes.c_byte * 128)]
+
+
+def load_rccl():
+    import torch
+    return ctypes.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so"), mode=ctypes.RTLD_GLOBAL)
+
+
+def rccl_comm(dist, rank: int, world: int):
+    """-> (librccl handle, ncclComm_t as int, address of ncclAllReduce).  `dist` is an initialised
+    torch.distributed module (or None for a 1-rank communicator)."""
+    import torch
+    lib = load_rccl()
+    uid = UniqueId()
+    if rank == 0:
+        lib.ncclGetUniqueId.argtypes = [ctypes.POINTER(UniqueId)]
+        assert lib.ncclGetUniqueId(ctypes.byref(uid)) == 0
+    t = torch.frombuffer(bytearray(bytes(uid)), dtype=torch.uint8).cuda()
+    if dist is not None:
+        dist.broadcast(t, 0)
+    ctypes.memmove(ctypes.byref(uid), bytes(t.cpu().numpy().tobytes()), 128)
+    comm = ctypes.c_void_p()
+    lib.ncclCommInitRank.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, UniqueId, ctypes.c_int]
+    rc = lib.ncclCommInitRank(ctypes.byref(comm), world, uid, rank)
+    if rc != 0:
+        raise RuntimeError(f"ncclCommInitRank failed with {rc}")
+    fn = ctypes.cast(lib.ncclAllReduce, ctypes.c_void_p).value
+    return lib, comm.value, fn
+
+
+class RcclExchange:
+    """all-to-all(v) of device rows as one ncclGroup of point-to-point sends/receives: xGMI is a
+    point-to-point fabric, so the exchange is exactly one transfer per peer pair and direction."""
+
+    def __init__(self, lib, comm: int, rank: int, world: int, stream: int = 0):
+        self.lib, self.comm, self.rank, self.world, self.stream = lib, ctypes.c_void_p(comm), rank, world, ctypes.c_void_p(stream)
+        for f in (lib.ncclSend, lib.ncclRecv):
+            f.restype = ctypes.c_int
+            f.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+        lib.ncclGroupStart.restype = lib.ncclGroupEnd.restype = ctypes.c_int
+
+    def counts(self, send_counts):
+        """all-to-all of one int32 per peer (host lists in, host list out)."""
+        import numpy as np
+        from .ops import Tensor, synchronize
+        s = Tensor.from_numpy(np.asarray(send_counts, np.uint32), "u32")
+        r = Tensor((self.world,), "u32")
+        self._group([(s.ptr + 4 * p, 1, p) for p in range(self.world)], [(r.ptr + 4 * p, 1, p) for p in range(self.world)], NCCL_UINT32)
+        synchronize()
+        return [int(v) for v in r.numpy()]
+
+    def rows(self, send, send_counts, recv_counts, row_bytes: int):
+        """send: device Tensor whose rows are grouped by destination rank -> device Tensor of received rows."""
+        from .ops import Tensor
+        recv = Tensor((max(1, sum(recv_counts)) * row_bytes,), "u8")
+        so = ro = 0
+        sends, recvs = [], []
+        for p in range(self.world):
+            if send_counts[p]:
+                sends.append((send.ptr + so * row_bytes, send_counts[p] * row_bytes, p))
+            if recv_counts[p]:
+                recvs.append((recv.ptr + ro * row_bytes, recv_counts[p] * row_bytes, p))
+            so += send_counts[p]
+            ro += recv_counts[p]
+        self._group(sends, recvs, NCCL_UINT8)
+        return recv
+
+    def _group(self, sends, recvs, dtype):
+        lib = self.lib
+        assert lib.ncclGroupStart() == 0
+        for ptr, n, peer in sends:
+            rc = lib.ncclSend(ctypes.c_void_p(ptr), n, dtype, peer, self.comm, self.stream)
+            assert rc == 0, f"ncclSend -> {rc}"
+        for ptr, n, peer in recvs:
+            rc = lib.ncclRecv(ctypes.c_void_p(ptr), n, dtype, peer, self.comm, self.stream)
+            assert rc == 0, f"ncclRecv -> {rc}"
+        assert lib.ncclGroupEnd() == 0

@@ -141,6 +141,14 @@ __global__ __launch_bounds__(256) void moe_combine_kernel(bf16_t* __restrict__ o
     }
 }
 
+// y_rows[i] = y_sorted[pos_of_slot[i]]  (scatter_unsort, model.rs:226-233)
+__global__ __launch_bounds__(256) void moe_unsort_kernel(bf16_t* __restrict__ out, const bf16_t* __restrict__ y,
+                                                         const uint32_t* __restrict__ pos_of_slot, int h) {
+    const size_t src = pos_of_slot[blockIdx.x];
+    for (int i = threadIdx.x * 8; i < h; i += 256 * 8)
+        *reinterpret_cast<u32x4*>(out + (size_t)blockIdx.x * h + i) = *reinterpret_cast<const u32x4*>(y + src * h + i);
+}
+
 }  // namespace
 }  // namespace omx
 
@@ -223,5 +231,95 @@ extern "C" int omx_moe_forward(void* out, const void* x, const void* gate_w, con
     }
     if (inds_out) OMX_HIP_CHECK(hipMemcpyAsync(inds_out, inds, (size_t)slots * 4, hipMemcpyDeviceToDevice, s));
     if (scores_out) OMX_HIP_CHECK(hipMemcpyAsync(scores_out, scores, (size_t)slots * 2, hipMemcpyDeviceToDevice, s));
+    return 0;
+}
+
+/* ---- the three stages of the block as separate entry points: what an expert-parallel host needs between its
+ * all-to-all exchanges (ominix-mlx_amd/ep.py) ---- */
+extern "C" int omx_moe_route(uint32_t* inds_out, void* scores_out, const void* x, const void* gate_w, int n_tokens,
+                             int hidden, int n_experts, int top_k, int mode, int norm_topk_prob, omx_stream stream) {
+    using namespace omx;
+    OMX_REQUIRE(inds_out && scores_out && x && gate_w, "omx_moe_route: null tensor");
+    OMX_REQUIRE(n_experts >= 1 && n_experts <= kMaxExperts && top_k >= 1 && top_k <= kMaxTopK && top_k <= n_experts,
+                "omx_moe_route: n_experts=%d (max %d), top_k=%d (max %d)", n_experts, kMaxExperts, top_k, kMaxTopK);
+    OMX_REQUIRE(hidden > 0 && hidden % 64 == 0, "omx_moe_route: hidden=%d must be a multiple of 64", hidden);
+    OMX_REQUIRE(mode == 0 || mode == 1, "omx_moe_route: mode must be 0 (Mixtral) or 1 (Qwen3-MoE)");
+    if (n_tokens <= 0) return 0;
+    moe_router_kernel<<<n_tokens, 256, 0, (hipStream_t)stream>>>((const bf16_t*)x, (const bf16_t*)gate_w, hidden, n_experts,
+                                                                 top_k, mode, norm_topk_prob, inds_out, (bf16_t*)scores_out);
+    OMX_LAUNCH_CHECK();
+    return 0;
+}
+
+/* y[i] = down_e( fused_swiglu(up_e x[i], gate_e x[i]) ), e = expert_ids[i]: SwitchGLU::forward_experts on rows that
+ * already carry their expert (mixtral-mlx/src/model.rs:243-274); expert_ids index the n_experts matrices passed in */
+extern "C" int omx_moe_experts(void* y, const void* x_rows, const uint32_t* expert_ids, int n_rows, const void* w_gate,
+                               const void* w_up, const void* w_down, int hidden, int inter, int n_experts,
+                               omx_stream stream) {
+    using namespace omx;
+    OMX_REQUIRE(y && x_rows && expert_ids && w_gate && w_up && w_down, "omx_moe_experts: null tensor");
+    OMX_REQUIRE(n_experts >= 1 && n_experts <= kMaxExperts, "omx_moe_experts: n_experts=%d (max %d)", n_experts, kMaxExperts);
+    OMX_REQUIRE(hidden % 64 == 0 && inter % 64 == 0, "omx_moe_experts: hidden=%d and intermediate=%d must be multiples of 64", hidden, inter);
+    if (n_rows <= 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    const int max_tiles = n_rows / 128 + n_experts + 1;
+    size_t need = 0;
+    omx_moe_workspace_bytes(n_rows, hidden, inter, n_experts, 1, &need);
+    void* ws = nullptr;
+    if (get_workspace(&ws, need)) return 1;
+    char* p = (char*)ws;
+    auto take = [&](size_t bytes) { char* r = p; p += (bytes + 255) & ~(size_t)255; return r; };
+    (void)take((size_t)n_rows * 4);
+    uint32_t* row_src = (uint32_t*)take((size_t)n_rows * 4);
+    uint32_t* pos_of_slot = (uint32_t*)take((size_t)n_rows * 4);
+    (void)take((size_t)n_rows * 2);
+    int* seg_start = (int*)take((size_t)(n_experts + 2) * 4);
+    int* tile_expert = (int*)take((size_t)max_tiles * 4);
+    int* tile_m0 = (int*)take((size_t)max_tiles * 4);
+    int* n_tiles = (int*)take(256);
+    bf16_t* gbuf = (bf16_t*)take((size_t)n_rows * inter * 2);
+    bf16_t* ubuf = (bf16_t*)take((size_t)n_rows * inter * 2);
+    bf16_t* ybuf = (bf16_t*)take((size_t)n_rows * hidden * 2);
+    if (n_rows <= 32 && hidden % 512 == 0 && inter % 512 == 0) {
+        GemvArgs a = {};
+        a.w0 = (const bf16_t*)w_gate; a.w1 = (const bf16_t*)w_up; a.n0 = inter; a.N = inter; a.K = hidden;
+        a.x = (const bf16_t*)x_rows; a.out = gbuf;
+        a.n_batch = n_rows; a.x_div = 1; a.x_bstride = hidden; a.out_bstride_bytes = (size_t)inter * 2;
+        a.w_sel = expert_ids; a.w_estride = (size_t)inter * hidden; a.swiglu_single_round = 1;
+        if (launch_gemv(a, PRO_NONE, EPI_SWIGLU, s)) return 1;
+        GemvArgs d = {};
+        d.w0 = (const bf16_t*)w_down; d.n0 = hidden; d.N = hidden; d.K = inter;
+        d.x = gbuf; d.out = y;
+        d.n_batch = n_rows; d.x_div = 1; d.x_bstride = inter; d.out_bstride_bytes = (size_t)hidden * 2;
+        d.w_sel = expert_ids; d.w_estride = (size_t)hidden * inter;
+        return launch_gemv(d, PRO_NONE, EPI_STORE, s);
+    }
+    moe_plan_kernel<<<1, 1024, 0, s>>>(expert_ids, n_rows, n_experts, 1, seg_start, row_src, pos_of_slot, tile_expert, tile_m0,
+                                       n_tiles);
+    OMX_LAUNCH_CHECK();
+    GroupedDesc g;
+    g.tile_expert = tile_expert; g.tile_m0 = tile_m0; g.seg_start = seg_start; g.n_tiles = n_tiles;
+    g.row_src = row_src; g.w_estride = (size_t)inter * hidden;
+    if (launch_gemm_bf16_grouped(gbuf, (const bf16_t*)x_rows, (const bf16_t*)w_gate, n_rows, inter, hidden, g, max_tiles, s)) return 1;
+    if (launch_gemm_bf16_grouped(ubuf, (const bf16_t*)x_rows, (const bf16_t*)w_up, n_rows, inter, hidden, g, max_tiles, s)) return 1;
+    if (omx_fused_swiglu(gbuf, ubuf, gbuf, (int64_t)n_rows * inter, OMX_BFLOAT16, stream)) return 1;
+    g.row_src = nullptr;
+    g.w_estride = (size_t)hidden * inter;
+    if (launch_gemm_bf16_grouped(ybuf, gbuf, (const bf16_t*)w_down, n_rows, hidden, inter, g, max_tiles, s)) return 1;
+    moe_unsort_kernel<<<n_rows, 256, 0, s>>>((bf16_t*)y, ybuf, pos_of_slot, hidden);
+    OMX_LAUNCH_CHECK();
+    return 0;
+}
+
+/* out[t] = bf16( sum_j bf16( y[t, j] * scores[t, j] ) ): the weighted sum of model.rs:304-307 on slot-ordered rows */
+extern "C" int omx_moe_combine(void* out, const void* y_slots, const void* scores, int n_tokens, int hidden, int top_k,
+                               omx_stream stream) {
+    using namespace omx;
+    OMX_REQUIRE(out && y_slots && scores, "omx_moe_combine: null tensor");
+    OMX_REQUIRE(hidden > 0 && hidden % 8 == 0 && top_k >= 1, "omx_moe_combine: bad shape");
+    if (n_tokens <= 0) return 0;
+    moe_combine_kernel<<<n_tokens, 256, 0, (hipStream_t)stream>>>((bf16_t*)out, (const bf16_t*)y_slots, (const bf16_t*)scores,
+                                                                 nullptr, hidden, top_k);
+    OMX_LAUNCH_CHECK();
     return 0;
 }

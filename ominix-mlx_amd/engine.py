@@ -41,6 +41,7 @@ ENGINE_SIGNATURES = {
     "omx_qwen3_stream": (c_int, [c_void_p, ctypes.POINTER(c_void_p)]),
     "omx_qwen3_step_bytes": (c_int, [c_void_p, c_int, ctypes.POINTER(ctypes.c_double)]),
     "omx_qwen3_decode_path": (c_int, [c_void_p, ctypes.POINTER(c_int)]),
+    "omx_qwen3_debug_trace_step": (c_int, [c_void_p, c_void_p, ctypes.c_size_t, ctypes.POINTER(c_int)]),
 }
 for _n, (_r, _a) in ENGINE_SIGNATURES.items():
     _f = getattr(lib, _n)

@@ -87,3 +87,68 @@ def test_moe_rejects_bad_config(omx):
     z = lambda *s: T.from_numpy(np.zeros(s, np.float32))
     with pytest.raises(omx.OmxError, match="top_k"):
         moe.SparseMoeBlock(z(4, 512), z(4, 512, 512), z(4, 512, 512), z(4, 512, 512), 9).forward(z(1, 512))
+
+
+def _ep_loopback(omx, xs, gw, wg, wu, wd, k, mode):
+    """Drive `world` expert-parallel ranks from this process on one GPU: the device stages of ep.py
+    (route / gather / local experts / un-permute / combine) with the fabric replaced by host copies."""
+    from ominix_mlx_amd import ep
+    T = omx.ops.Tensor
+    world, E, h = len(xs), gw.shape[0], gw.shape[1]
+    ex = ep.LoopbackExchange(world)
+    blocks = [ep.ExpertParallelMoe(T.from_numpy(gw), *(T.from_numpy(ep.shard_experts(w, r, world)) for w in (wg, wu, wd)),
+                                   E, k, r, world, ex, mode) for r in range(world)]
+    eid_rows = [None] * world
+    for r, b in enumerate(blocks):                       # route + dispatch
+        rows, eids = b.dispatch(T.from_numpy(xs[r]))
+        ex.put_counts(r, b._send_counts)
+        ex.put_rows(r, rows.numpy(), b._send_counts)
+        eid_rows[r] = eids.numpy()
+    got_rows = [ex.get_rows(r) for r in range(world)]
+    for r, b in enumerate(blocks):
+        ex.put_rows(r, eid_rows[r], b._send_counts)
+    got_eids = [ex.get_rows(r) for r in range(world)]
+    recv_counts = [ex.get_counts(r) for r in range(world)]
+    ys = []
+    for r, b in enumerate(blocks):                       # local experts
+        m = sum(recv_counts[r])
+        y = b.experts(T.from_numpy(got_rows[r].reshape(max(m, 1) if m == 0 else m, h) if m else np.zeros((1, h), np.float32)),
+                      T.from_numpy(got_eids[r].astype(np.uint32) if m else np.zeros(1, np.uint32), "u32"), m)
+        ys.append(y.numpy()[:m])
+    for r in range(world):                               # the way back: roles of the counts swap
+        ex.put_rows(r, ys[r], recv_counts[r])
+    outs = []
+    for r, b in enumerate(blocks):
+        back = ex.get_rows(r)
+        n_back = sum(b._send_counts)
+        outs.append(b.combine(T.from_numpy(back if n_back else np.zeros((1, h), np.float32))).numpy())
+    return np.concatenate(outs, axis=0)
+
+
+@pytest.mark.parametrize("mode", ["mixtral", "qwen3_moe"])
+@pytest.mark.parametrize("tokens", [(1, 1), (5, 3), (90, 70)])     # decode-sized, ragged, grouped-GEMM sized
+def test_expert_parallel_stages_match_single_device_block(omx, mode, tokens):
+    """experts sharded over 2 ranks, tokens sharded too; each rank's device stages with the
+    all-to-all replaced by a loopback must reproduce the single-device block (same kernels per row up to the
+    GEMV-vs-grouped-GEMM choice, which depends on the number of rows a rank receives) and the oracle."""
+    E, h, I, k = 8, 512, 1024, 2
+    gw, wg, wu, wd = _weights(E, h, I, 90)
+    x = rc.bf16_round(rand((sum(tokens), h), 91))
+    xs = [x[:tokens[0]], x[tokens[0]:]]
+    got = _ep_loopback(omx, xs, gw, wg, wu, wd, k, mode)
+    ref, _, _ = rm.moe_block(x, gw, wg, wu, wd, k, mode)
+    assert_bf16_close(got, ref, 2, atol=2.0 ** -7 * np.abs(ref).max())
+    single, _, _ = _run(omx, x, gw, wg, wu, wd, k, mode)
+    assert_bf16_close(got, single, 2, atol=2.0 ** -7 * np.abs(ref).max())
+
+
+def test_expert_parallel_world1_equals_fused_block(omx):
+    """With one rank the staged path is the fused omx_moe_forward split at its seams: identical output."""
+    from ominix_mlx_amd import ep
+    E, h, I, k = 8, 512, 1024, 2
+    gw, wg, wu, wd = _weights(E, h, I, 95)
+    for n in (2, 80):
+        x = rc.bf16_round(rand((n, h), 96 + n))
+        got = _ep_loopback(omx, [x], gw, wg, wu, wd, k, "mixtral")
+        single, _, _ = _run(omx, x, gw, wg, wu, wd, k, "mixtral")
+        np.testing.assert_array_equal(got, single)

@@ -213,12 +213,16 @@ int omx_moe_combine(void* out, const void* y_slots, const void* scores, int n_to
  * ===================================================================================== */
 typedef struct omx_klein_config_ {   /* FluxKleinParams, klein_model.rs:166-196 */
     int in_channels, hidden_size, txt_embed_dim, num_heads, depth, depth_single, head_dim, mlp_hidden;
+    int tp_rank, tp_size;   /* tensor parallel over one node (0/0 or 0/1 = single GPU): heads and MLP width sharded */
 } omx_klein_config;
 typedef struct omx_klein_* omx_klein;
 int omx_klein_create(omx_klein* out, const omx_klein_config* cfg);
 int omx_klein_destroy(omx_klein m);
 int omx_klein_set_weight(omx_klein m, const char* name, const void* ptr);
-int omx_klein_synth_weights(omx_klein m, uint32_t base_seed);
+int omx_klein_synth_weights(omx_klein m, uint32_t base_seed);   /* under TP: this rank's shards of the same logical tensors */
+/* comm: ncclComm_t, allreduce_fn: address of ncclAllReduce (RCCL); one bf16 all-reduce after every row-split
+ * projection (2 per double-block stream, 1 per single block) */
+int omx_klein_set_comm(omx_klein m, void* comm, void* allreduce_fn);
 /* latent [s_img, in_channels], txt_embed [s_txt, txt_embed_dim] (device bf16); timestep = t * 1000
  * (generate_klein.rs:434); rope_cos/rope_sin [s_txt + s_img, 128] device f32 with duplicated pair entries,
  * text rows first (compute_rope_freqs, klein_model.rs:53-110); out [s_img, in_channels] device bf16.      */
@@ -226,6 +230,15 @@ int omx_klein_forward_with_rope(omx_klein m, void* out, const void* latent, cons
                                 float timestep, const float* rope_cos, const float* rope_sin);
 int omx_klein_last_ms(omx_klein m, float* ms);          /* HIP-event time of the last forward */
 int omx_klein_debug_read(omx_klein m, const char* name, void* host, size_t n_elems);   /* test hook */
+
+/* In-process stand-in for an RCCL communicator (csrc/loopback_comm.hip): `world` engine instances driven by
+ * `world` host threads of one process exchange through it, so the tensor-parallel paths run with real shards
+ * on a single-GPU box.  omx_loopback_allreduce has ncclAllReduce's signature.                             */
+typedef struct omx_loopback_* omx_loopback;
+int omx_loopback_create(omx_loopback* out, int world, size_t max_bytes);
+int omx_loopback_destroy(omx_loopback g);
+void* omx_loopback_rank_comm(omx_loopback g, int rank);
+int omx_loopback_abort(omx_loopback g);
 
 /* =====================================================================================
  * a12: Paraformer mel/STFT frontend (funasr-mlx/src/paraformer.rs:195-412), all on device:

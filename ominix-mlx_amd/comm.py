@@ -90,3 +90,62 @@ class RcclExchange:
             rc = lib.ncclRecv(ctypes.c_void_p(ptr), n, dtype, peer, self.comm, self.stream)
             assert rc == 0, f"ncclRecv -> {rc}"
         assert lib.ncclGroupEnd() == 0
+
+
+LOOPBACK_SIGNATURES = {
+    "omx_loopback_create": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_size_t]),
+    "omx_loopback_destroy": (ctypes.c_int, [ctypes.c_void_p]),
+    "omx_loopback_rank_comm": (ctypes.c_void_p, [ctypes.c_void_p, ctypes.c_int]),
+    "omx_loopback_abort": (ctypes.c_int, [ctypes.c_void_p]),
+}
+
+
+class LoopbackGroup:
+    """In-process stand-in for a communicator (csrc/loopback_comm.hip): `world` engines driven by `world` host
+    threads of this process all-reduce through it -- tensor parallelism with real shards on one GPU (tests)."""
+
+    def __init__(self, world: int, max_bytes: int):
+        from . import check, lib
+        for name, (res, args) in LOOPBACK_SIGNATURES.items():
+            f = getattr(lib, name)
+            f.restype, f.argtypes = res, args
+        self._lib, self.world = lib, world
+        self._h = ctypes.c_void_p()
+        check(lib.omx_loopback_create(ctypes.byref(self._h), world, max_bytes))
+        self.allreduce_fn = ctypes.cast(lib.omx_loopback_allreduce, ctypes.c_void_p).value
+
+    def rank_comm(self, rank: int) -> int:
+        return self._lib.omx_loopback_rank_comm(self._h, rank)
+
+    def abort(self) -> None:
+        self._lib.omx_loopback_abort(self._h)
+
+    def close(self) -> None:
+        if self._h.value:
+            self._lib.omx_loopback_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+
+def run_ranks(world: int, fn, group: "LoopbackGroup" = None):
+    """fn(rank) on `world` host threads (ctypes releases the GIL inside library calls); re-raises the first error
+    after releasing the peers of a failed rank."""
+    import threading
+    results, errors = [None] * world, [None] * world
+
+    def body(r):
+        try:
+            results[r] = fn(r)
+        except BaseException as e:   # noqa: BLE001
+            errors[r] = e
+            if group is not None:
+                group.abort()
+
+    threads = [threading.Thread(target=body, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for e in errors:
+        if e is not None:
+            raise e
+    return results

@@ -58,9 +58,9 @@ extern "C" int omx_bench_gemv(int N, int K, int pro, int epi, int rows_per_wave,
     float ms = 0.f;
     OMX_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
     *avg_ms = ms / iters;
-    for (auto p : w) hipFree(p);
-    hipFree(x); hipFree(nw); hipFree(out); hipFree(resid); hipFree(slot);
-    hipEventDestroy(e0); hipEventDestroy(e1); hipStreamDestroy(s);
+    for (auto p : w) (void)hipFree(p);
+    (void)hipFree(x); (void)hipFree(nw); (void)hipFree(out); (void)hipFree(resid); (void)hipFree(slot);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipStreamDestroy(s);
     return 0;
 }
 

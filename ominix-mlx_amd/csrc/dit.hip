@@ -102,9 +102,28 @@ uint32_t crc32_name(const char* s) {
 }
 
 }  // namespace
+// tensor-parallel tail of a row-split projection: out = bf16(resid + sum * gate[col]) on the all-reduced partial
+__global__ __launch_bounds__(256) void gated_residual_kernel(bf16_t* __restrict__ out, const bf16_t* __restrict__ resid,
+                                                             const bf16_t* __restrict__ gate, const bf16_t* __restrict__ sum,
+                                                             int64_t n, int h) {
+    for (int64_t i = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) * 8; i < n; i += (int64_t)gridDim.x * blockDim.x * 8) {
+        const u32x4 r = *reinterpret_cast<const u32x4*>(resid + i);
+        const u32x4 v = *reinterpret_cast<const u32x4*>(sum + i);
+        const u32x4 g = *reinterpret_cast<const u32x4*>(gate + (i % h));
+        u32x4 o;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            o[q] = pack_bf16(bf16lo(r[q]) + bf16lo(v[q]) * bf16lo(g[q]), bf16hi(r[q]) + bf16hi(v[q]) * bf16hi(g[q]));
+        *reinterpret_cast<u32x4*>(out + i) = o;
+    }
+}
+
 }  // namespace omx
 
 using namespace omx;
+
+typedef int (*nccl_allreduce_fn)(const void*, void*, size_t, int, int, void*, hipStream_t);
+constexpr int kNcclBfloat16 = 9, kNcclSum = 0;
 
 struct omx_klein_ {
     omx_klein_config cfg;
@@ -113,6 +132,11 @@ struct omx_klein_ {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     float last_ms = 0.f;
+    // tensor parallel: heads and the MLP width are sharded, the residual stream is replicated
+    int H_l = 0, h_l = 0, mh_l = 0;
+    void* comm = nullptr;
+    nccl_allreduce_fn allreduce = nullptr;
+    bf16_t* partial = nullptr;
     // activations, sized for (s_txt, s_img)
     int s_txt = 0, s_img = 0;
     bf16_t *x = nullptr, *x2 = nullptr, *xm = nullptr, *q = nullptr, *k = nullptr, *v = nullptr, *att = nullptr,
@@ -155,7 +179,7 @@ int ensure_buffers(omx_klein m, int s_txt, int s_img) {
         kalloc(m, &m->proj, S * (3 * h + 2 * mh)) || kalloc(m, &m->comb, S * (h + mh)) || kalloc(m, &m->act, S * mh) ||
         kalloc(m, &m->vec, h) || kalloc(m, &m->svec, h) || kalloc(m, &m->temb, (size_t)256) || kalloc(m, &m->tmid, h) ||
         kalloc(m, &m->mod_img, 6 * h) || kalloc(m, &m->mod_txt, 6 * h) || kalloc(m, &m->mod_single, 3 * h) ||
-        kalloc(m, &m->ada, 2 * h) || kalloc(m, &m->lat_in, (size_t)s_img * c.in_channels))
+        kalloc(m, &m->ada, 2 * h) || kalloc(m, &m->lat_in, (size_t)s_img * c.in_channels) || kalloc(m, &m->partial, S * h))
         return 1;
     m->s_txt = s_txt;
     m->s_img = s_img;
@@ -165,8 +189,22 @@ int ensure_buffers(omx_klein m, int s_txt, int s_img) {
 int attention(omx_klein m, bf16_t* out, int64_t o_ts, const bf16_t* q, const bf16_t* k, const bf16_t* v, int64_t ld, int S) {
     const omx_klein_config& c = m->cfg;
     AttnLayout L = {0, c.head_dim, ld, ld, 0, c.head_dim, o_ts};
-    return launch_attn_prefill(out, q, k, v, 1, c.num_heads, c.num_heads, S, S, c.head_dim, 0, c.head_dim,
+    return launch_attn_prefill(out, q, k, v, 1, m->H_l, m->H_l, S, S, c.head_dim, 0, c.head_dim,
                                1.0f / sqrtf((float)c.head_dim), OMX_MASK_NONE, nullptr, m->stream, false, &L);
+}
+
+// out = resid + gate * (x . W^T): one fused GEMM on a single GPU; under tensor parallelism W holds this rank's
+// input columns, the bf16 partial is all-reduced (RCCL sum) and the gated residual is applied afterwards
+int gated_projection(omx_klein m, bf16_t* out, const bf16_t* x, const bf16_t* w, const bf16_t* resid, const bf16_t* gate,
+                     int M, int N, int K) {
+    hipStream_t s = m->stream;
+    if (m->cfg.tp_size == 1 && m->allreduce == nullptr) return launch_gemm_bf16_gated(out, x, w, resid, gate, M, N, K, s);
+    OMX_REQUIRE(m->allreduce != nullptr, "tp_size > 1 but no communicator set (omx_klein_set_comm)");
+    if (launch_gemm_bf16(m->partial, x, w, nullptr, M, N, K, s)) return 1;
+    OMX_REQUIRE(m->allreduce(m->partial, m->partial, (size_t)M * N, kNcclBfloat16, kNcclSum, m->comm, s) == 0, "ncclAllReduce failed");
+    gated_residual_kernel<<<1024, 256, 0, s>>>(out, resid, gate, m->partial, (int64_t)M * N, N);
+    OMX_LAUNCH_CHECK();
+    return 0;
 }
 
 }  // namespace
@@ -179,8 +217,17 @@ int omx_klein_create(omx_klein* out, const omx_klein_config* cfg) {
                 "InvalidConfig: klein needs head_dim 128 and hidden_size = heads * head_dim");
     OMX_REQUIRE(cfg->hidden_size % 64 == 0 && cfg->mlp_hidden % 64 == 0 && cfg->in_channels % 64 == 0 && cfg->txt_embed_dim % 64 == 0,
                 "InvalidConfig: klein widths must be multiples of 64");
+    OMX_REQUIRE(cfg->tp_size >= 0 && cfg->tp_rank >= 0 && cfg->tp_rank < (cfg->tp_size > 0 ? cfg->tp_size : 1),
+                "InvalidConfig: tp rank %d of %d", cfg->tp_rank, cfg->tp_size);
     omx_klein m = new omx_klein_();
     m->cfg = *cfg;
+    if (m->cfg.tp_size == 0) m->cfg.tp_size = 1;
+    const int n = m->cfg.tp_size;
+    OMX_REQUIRE(cfg->num_heads % n == 0 && (cfg->mlp_hidden / n) % 64 == 0 && cfg->mlp_hidden % n == 0,
+                "InvalidConfig: heads %d / mlp width %d must divide by tp_size %d (mlp shard a multiple of 64)", cfg->num_heads, cfg->mlp_hidden, n);
+    m->H_l = cfg->num_heads / n;
+    m->h_l = m->H_l * cfg->head_dim;
+    m->mh_l = cfg->mlp_hidden / n;
     OMX_HIP_CHECK(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking));
     OMX_HIP_CHECK(hipEventCreate(&m->ev0));
     OMX_HIP_CHECK(hipEventCreate(&m->ev1));
@@ -205,17 +252,59 @@ int omx_klein_set_weight(omx_klein m, const char* name, const void* ptr) {
     return 0;
 }
 
+int omx_klein_set_comm(omx_klein m, void* comm, void* allreduce_fn) {
+    OMX_REQUIRE(m, "omx_klein_set_comm: null model");
+    m->comm = comm;
+    m->allreduce = (nccl_allreduce_fn)allreduce_fn;
+    return 0;
+}
+
 int omx_klein_synth_weights(omx_klein m, uint32_t base_seed) {
     OMX_REQUIRE(m, "omx_klein_synth_weights: null model");
     const omx_klein_config& c = m->cfg;
     const int h = c.hidden_size, mh = c.mlp_hidden, D = c.head_dim;
+    const int r = c.tp_rank, hl = m->h_l, ml = m->mh_l;
+    struct Seg { int64_t start, len; };
+    const float amp_w = (float)(0.02 * sqrt(3.0)), amp_n = (float)(0.01 * sqrt(3.0));
+    auto seed_of = [&](const std::string& name) { return base_seed ^ crc32_name(("klein." + name).c_str()); };
+    // replicated tensor (or a single GPU): the whole logical [rows, cols]
     auto make = [&](const std::string& name, size_t rows, size_t cols, bool norm) -> int {
         bf16_t* p = nullptr;
         if (kalloc(m, &p, rows * cols)) return 1;
-        const uint32_t seed = base_seed ^ crc32_name(("klein." + name).c_str());
-        if (omx_fill_uniform(p, rows * cols, seed, (float)((norm ? 0.01 : 0.02) * sqrt(3.0)), norm ? 1.0f : 0.0f, OMX_BFLOAT16,
-                             m->stream))
-            return 1;
+        if (omx_fill_uniform(p, rows * cols, seed_of(name), norm ? amp_n : amp_w, norm ? 1.0f : 0.0f, OMX_BFLOAT16, m->stream)) return 1;
+        m->w[name] = p;
+        return 0;
+    };
+    // this rank's ROWS of a logical [*, cols] tensor: the listed row ranges stacked
+    auto make_rows = [&](const std::string& name, std::initializer_list<Seg> segs, int64_t cols) -> int {
+        int64_t total = 0;
+        for (const Seg& g : segs) total += g.len;
+        bf16_t* p = nullptr;
+        if (kalloc(m, &p, (size_t)(total * cols))) return 1;
+        int64_t off = 0;
+        for (const Seg& g : segs) {
+            if (omx_fill_uniform_2d(p + off * cols, g.len, cols, cols, g.start, 0, seed_of(name), amp_w, 0.f, OMX_BFLOAT16, m->stream)) return 1;
+            off += g.len;
+        }
+        m->w[name] = p;
+        return 0;
+    };
+    // this rank's COLUMNS of a logical [rows, cols_full] tensor: the listed column ranges side by side
+    auto make_cols = [&](const std::string& name, int64_t rows, std::initializer_list<Seg> segs, int64_t cols_full) -> int {
+        int64_t total = 0, widest = 0;
+        for (const Seg& g : segs) { total += g.len; widest = g.len > widest ? g.len : widest; }
+        bf16_t *p = nullptr, *tmp = nullptr;
+        if (kalloc(m, &p, (size_t)(rows * total))) return 1;
+        OMX_HIP_CHECK(hipMalloc((void**)&tmp, (size_t)(rows * widest) * 2));
+        int64_t off = 0;
+        for (const Seg& g : segs) {
+            if (omx_fill_uniform_2d(tmp, rows, g.len, cols_full, 0, g.start, seed_of(name), amp_w, 0.f, OMX_BFLOAT16, m->stream)) return 1;
+            OMX_HIP_CHECK(hipMemcpy2DAsync(p + off, (size_t)total * 2, tmp, (size_t)g.len * 2, (size_t)g.len * 2, (size_t)rows,
+                                           hipMemcpyDeviceToDevice, m->stream));
+            OMX_HIP_CHECK(hipStreamSynchronize(m->stream));   // tmp is reused by the next segment
+            off += g.len;
+        }
+        OMX_HIP_CHECK(hipFree(tmp));
         m->w[name] = p;
         return 0;
     };
@@ -225,19 +314,25 @@ int omx_klein_synth_weights(omx_klein m, uint32_t base_seed) {
         make("single_mod.linear.weight", 3 * (size_t)h, h, false) || make("norm_out.weight", 2 * (size_t)h, h, false) ||
         make("proj_out.weight", c.in_channels, h, false))
         return 1;
+    // shard plan == klein.shard_state_dict (ominix-mlx_amd/klein.py): heads and MLP columns are contiguous per rank
     for (int i = 0; i < c.depth; ++i) {
         const std::string b = "double_blocks." + std::to_string(i) + ".";
         for (const char* st : {"img", "txt"}) {
-            const std::string s = b + st + "_";
-            if (make(s + "to_q.weight", h, h, false) || make(s + "to_k.weight", h, h, false) || make(s + "to_v.weight", h, h, false) ||
-                make(s + "to_out.weight", h, h, false) || make(s + "norm_q.weight", 1, D, true) || make(s + "norm_k.weight", 1, D, true) ||
-                make(s + "mlp_in.weight", 2 * (size_t)mh, h, false) || make(s + "mlp_out.weight", h, mh, false))
+            const std::string sname = b + st + "_";
+            if (make_rows(sname + "to_q.weight", {{(int64_t)r * hl, hl}}, h) || make_rows(sname + "to_k.weight", {{(int64_t)r * hl, hl}}, h) ||
+                make_rows(sname + "to_v.weight", {{(int64_t)r * hl, hl}}, h) || make_cols(sname + "to_out.weight", h, {{(int64_t)r * hl, hl}}, h) ||
+                make(sname + "norm_q.weight", 1, D, true) || make(sname + "norm_k.weight", 1, D, true) ||
+                make_rows(sname + "mlp_in.weight", {{(int64_t)r * ml, ml}, {(int64_t)mh + (int64_t)r * ml, ml}}, h) ||
+                make_cols(sname + "mlp_out.weight", h, {{(int64_t)r * ml, ml}}, mh))
                 return 1;
         }
     }
     for (int i = 0; i < c.depth_single; ++i) {
         const std::string b = "single_blocks." + std::to_string(i) + ".";
-        if (make(b + "to_qkv_mlp.weight", 3 * (size_t)h + 2 * (size_t)mh, h, false) || make(b + "to_out.weight", h, (size_t)h + mh, false) ||
+        if (make_rows(b + "to_qkv_mlp.weight",
+                      {{(int64_t)r * hl, hl}, {(int64_t)h + (int64_t)r * hl, hl}, {2 * (int64_t)h + (int64_t)r * hl, hl},
+                       {3 * (int64_t)h + (int64_t)r * ml, ml}, {3 * (int64_t)h + mh + (int64_t)r * ml, ml}}, h) ||
+            make_cols(b + "to_out.weight", h, {{(int64_t)r * hl, hl}, {(int64_t)h + (int64_t)r * ml, ml}}, (int64_t)h + mh) ||
             make(b + "norm_q.weight", 1, D, true) || make(b + "norm_k.weight", 1, D, true))
             return 1;
     }
@@ -254,7 +349,8 @@ int omx_klein_forward_with_rope(omx_klein m, void* out, const void* latent, cons
     const omx_klein_config& c = m->cfg;
     if (ensure_buffers(m, s_txt, s_img)) return 1;
     hipStream_t s = m->stream;
-    const int h = c.hidden_size, mh = c.mlp_hidden, S = s_txt + s_img, D = c.head_dim, H = c.num_heads;
+    const int h = c.hidden_size, S = s_txt + s_img, D = c.head_dim;
+    const int H = m->H_l, hl = m->h_l, mh = m->mh_l;   // this rank's heads / attention width / MLP width
     const float rms_eps = 1e-5f;   // RmsNorm::DEFAULT_EPS
     OMX_HIP_CHECK(hipEventRecord(m->ev0, s));
     bf16_t* x = m->x;     // [S, h]: rows [0, s_txt) = txt stream, [s_txt, S) = img stream
@@ -292,36 +388,36 @@ int omx_klein_forward_with_rope(omx_klein m, void* out, const void* latent, cons
             const int rows = st ? s_img : s_txt;
             const size_t r0 = st ? (size_t)s_txt : 0;
             if (omx_fused_modulate(m->xm + r0 * h, x + r0 * h, mod /*shift1*/, mod + h /*scale1*/, 1, rows, h, 1e-6f, OMX_BFLOAT16, s)) return 1;
-            if (linear(m, m->q + r0 * h, m->xm + r0 * h, (b + sn + "to_q.weight").c_str(), rows, h, h)) return 1;
-            if (linear(m, m->k + r0 * h, m->xm + r0 * h, (b + sn + "to_k.weight").c_str(), rows, h, h)) return 1;
-            if (linear(m, m->v + r0 * h, m->xm + r0 * h, (b + sn + "to_v.weight").c_str(), rows, h, h)) return 1;
+            if (linear(m, m->q + r0 * hl, m->xm + r0 * h, (b + sn + "to_q.weight").c_str(), rows, hl, h)) return 1;
+            if (linear(m, m->k + r0 * hl, m->xm + r0 * h, (b + sn + "to_k.weight").c_str(), rows, hl, h)) return 1;
+            if (linear(m, m->v + r0 * hl, m->xm + r0 * h, (b + sn + "to_v.weight").c_str(), rows, hl, h)) return 1;
             const unsigned blocks = (unsigned)(((size_t)rows * H + 15) / 16);
             if (kget(m, b + sn + "norm_q.weight", &w)) return 1;
-            klein_qk_norm_rope_kernel<<<blocks, 256, 0, s>>>(m->q + r0 * h, h, rows, H, w, rope_cos, rope_sin, (int)r0, rms_eps);
+            klein_qk_norm_rope_kernel<<<blocks, 256, 0, s>>>(m->q + r0 * hl, hl, rows, H, w, rope_cos, rope_sin, (int)r0, rms_eps);
             if (kget(m, b + sn + "norm_k.weight", &w)) return 1;
-            klein_qk_norm_rope_kernel<<<blocks, 256, 0, s>>>(m->k + r0 * h, h, rows, H, w, rope_cos, rope_sin, (int)r0, rms_eps);
+            klein_qk_norm_rope_kernel<<<blocks, 256, 0, s>>>(m->k + r0 * hl, hl, rows, H, w, rope_cos, rope_sin, (int)r0, rms_eps);
             OMX_LAUNCH_CHECK();
         }
         // ONE joint attention over [txt, img]: img and txt queries both see all keys (klein_model.rs:461-483)
-        if (attention(m, m->att, h, m->q, m->k, m->v, h, S)) return 1;
+        if (attention(m, m->att, hl, m->q, m->k, m->v, hl, S)) return 1;
         for (int st = 0; st < 2; ++st) {
             const char* sn = st ? "img_" : "txt_";
             const bf16_t* mod = st ? m->mod_img : m->mod_txt;
             const int rows = st ? s_img : s_txt;
             const size_t r0 = st ? (size_t)s_txt : 0;
             if (kget(m, b + sn + "to_out.weight", &w)) return 1;
-            if (launch_gemm_bf16_gated(x2 + r0 * h, m->att + r0 * h, w, x + r0 * h, mod + 2 * h /*gate1*/, rows, h, h, s)) return 1;
+            if (gated_projection(m, x2 + r0 * h, m->att + r0 * hl, w, x + r0 * h, mod + 2 * h /*gate1*/, rows, h, hl)) return 1;
             // ---- MLP half ----
             if (omx_fused_modulate(m->xm + r0 * h, x2 + r0 * h, mod + 3 * h, mod + 4 * h, 1, rows, h, 1e-6f, OMX_BFLOAT16, s)) return 1;
             if (linear(m, m->proj, m->xm + r0 * h, (b + sn + "mlp_in.weight").c_str(), rows, 2 * mh, h)) return 1;
             swiglu_strided_kernel<<<2048, 256, 0, s>>>(m->act, mh, m->proj /*gate = first half*/, m->proj + mh /*up*/, 2 * mh, rows, mh);
             OMX_LAUNCH_CHECK();
             if (kget(m, b + sn + "mlp_out.weight", &w)) return 1;
-            if (launch_gemm_bf16_gated(x + r0 * h, m->act, w, x2 + r0 * h, mod + 5 * h /*gate2*/, rows, h, mh, s)) return 1;
+            if (gated_projection(m, x + r0 * h, m->act, w, x2 + r0 * h, mod + 5 * h /*gate2*/, rows, h, mh)) return 1;
         }
     }
     // x already holds [txt, img] (klein_model.rs:833)
-    const int64_t ldp = 3 * (int64_t)h + 2 * mh, ldc = (int64_t)h + mh;
+    const int64_t ldp = 3 * (int64_t)hl + 2 * mh, ldc = (int64_t)hl + mh;
     for (int i = 0; i < c.depth_single; ++i) {
         const std::string b = "single_blocks." + std::to_string(i) + ".";
         const bf16_t* mod = m->mod_single;
@@ -331,13 +427,13 @@ int omx_klein_forward_with_rope(omx_klein m, void* out, const void* latent, cons
         if (kget(m, b + "norm_q.weight", &w)) return 1;
         klein_qk_norm_rope_kernel<<<blocks, 256, 0, s>>>(m->proj, ldp, S, H, w, rope_cos, rope_sin, 0, rms_eps);
         if (kget(m, b + "norm_k.weight", &w)) return 1;
-        klein_qk_norm_rope_kernel<<<blocks, 256, 0, s>>>(m->proj + h, ldp, S, H, w, rope_cos, rope_sin, 0, rms_eps);
+        klein_qk_norm_rope_kernel<<<blocks, 256, 0, s>>>(m->proj + hl, ldp, S, H, w, rope_cos, rope_sin, 0, rms_eps);
         OMX_LAUNCH_CHECK();
-        if (attention(m, m->comb, ldc, m->proj, m->proj + h, m->proj + 2 * h, ldp, S)) return 1;          // cols [0, h)
-        swiglu_strided_kernel<<<2048, 256, 0, s>>>(m->comb + h, ldc, m->proj + 3 * h, m->proj + 3 * h + mh, ldp, S, mh);   // cols [h, h+mh)
+        if (attention(m, m->comb, ldc, m->proj, m->proj + hl, m->proj + 2 * hl, ldp, S)) return 1;          // cols [0, hl)
+        swiglu_strided_kernel<<<2048, 256, 0, s>>>(m->comb + hl, ldc, m->proj + 3 * hl, m->proj + 3 * hl + mh, ldp, S, mh);   // cols [hl, hl+mh)
         OMX_LAUNCH_CHECK();
         if (kget(m, b + "to_out.weight", &w)) return 1;
-        if (launch_gemm_bf16_gated(x2, m->comb, w, x, mod + 2 * h, S, h, (int)ldc, s)) return 1;
+        if (gated_projection(m, x2, m->comb, w, x, mod + 2 * h, S, h, (int)ldc)) return 1;
         bf16_t* t = x; x = x2; x2 = t;
     }
     // final layer: RmsNorm (weight = ones), AdaLN chunks [scale, shift], proj_out (klein_model.rs:845-853)

@@ -15,7 +15,7 @@ c_int, c_float, c_void_p, c_uint32, c_size_t = ctypes.c_int, ctypes.c_float, cty
 
 class KleinConfig(ctypes.Structure):
     _fields_ = [(n, c_int) for n in ("in_channels", "hidden_size", "txt_embed_dim", "num_heads", "depth", "depth_single",
-                                     "head_dim", "mlp_hidden")]
+                                     "head_dim", "mlp_hidden", "tp_rank", "tp_size")]
 
 
 KLEIN_SIGNATURES = {
@@ -23,6 +23,7 @@ KLEIN_SIGNATURES = {
     "omx_klein_destroy": (c_int, [c_void_p]),
     "omx_klein_set_weight": (c_int, [c_void_p, ctypes.c_char_p, c_void_p]),
     "omx_klein_synth_weights": (c_int, [c_void_p, c_uint32]),
+    "omx_klein_set_comm": (c_int, [c_void_p, c_void_p, c_void_p]),
     "omx_klein_forward_with_rope": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p]),
     "omx_klein_last_ms": (c_int, [c_void_p, ctypes.POINTER(c_float)]),
     "omx_klein_debug_read": (c_int, [c_void_p, ctypes.c_char_p, c_void_p, c_size_t]),
@@ -65,11 +66,47 @@ def compute_rope(txt_ids: np.ndarray, img_ids: np.ndarray):
             Tensor.from_numpy(np.concatenate(sn, 1).astype(np.float32), "f32"))
 
 
+def shard_state_dict(weights: dict, hidden_size: int, mlp_hidden: int, rank: int, world: int) -> dict:
+    """Tensor-parallel shard plan of the DiT, shared by `FluxKlein.load_weights`,
+    the device generator (`omx_klein_synth_weights`) and the world-size-2 gloo test (tests/test_klein_tp.py).
+    Heads are contiguous per rank (width hl = hidden/world), MLP columns too (ml = mlp_hidden/world):
+        row split   to_q / to_k / to_v                      rows  [r*hl, +hl)
+                    mlp_in  = [gate; up]                    rows  [r*ml, +ml) of each half
+                    to_qkv_mlp = [q; k; v; gate; up]        the rank's rows of each of the five parts
+        col split   to_out (double), mlp_out                cols  [r*hl, +hl) / [r*ml, +ml)   -> partial sums
+                    to_out (single) over [attn | mlp]       cols  [r*hl, +hl) and h + [r*ml, +ml)
+        replicated  embedders, time/modulation MLPs, q/k norms, norm_out, proj_out"""
+    if world == 1:
+        return dict(weights)
+    h, mh, r = hidden_size, mlp_hidden, rank
+    if h % world or mh % world:
+        raise ValueError(f"InvalidConfig: hidden_size={h} / mlp_hidden={mh} not divisible by tp_size={world}")
+    hl, ml = h // world, mh // world
+    rows = lambda a, segs: np.ascontiguousarray(np.concatenate([a[s:s + n] for s, n in segs], 0))
+    cols = lambda a, segs: np.ascontiguousarray(np.concatenate([a[:, s:s + n] for s, n in segs], 1))
+    out = {}
+    for name, a in weights.items():
+        leaf = name.rsplit(".", 2)[-2] if name.endswith(".weight") else name
+        if leaf.endswith(("to_q", "to_k", "to_v")):
+            a = rows(a, [(r * hl, hl)])
+        elif leaf.endswith("mlp_in"):
+            a = rows(a, [(r * ml, ml), (mh + r * ml, ml)])
+        elif leaf.endswith("mlp_out"):
+            a = cols(a, [(r * ml, ml)])
+        elif leaf == "to_qkv_mlp":
+            a = rows(a, [(r * hl, hl), (h + r * hl, hl), (2 * h + r * hl, hl), (3 * h + r * ml, ml), (3 * h + mh + r * ml, ml)])
+        elif leaf.endswith("to_out"):
+            a = cols(a, [(r * hl, hl), (h + r * ml, ml)] if name.startswith("single_blocks.") else [(r * hl, hl)])
+        out[name] = a
+    return out
+
+
 class FluxKlein:
     def __init__(self, in_channels=128, hidden_size=3072, txt_embed_dim=7680, num_heads=24, depth=5, depth_single=20,
-                 head_dim=128, mlp_hidden=9216):
+                 head_dim=128, mlp_hidden=9216, tp_rank=0, tp_size=1):
         require_device()
-        self.cfg = KleinConfig(in_channels, hidden_size, txt_embed_dim, num_heads, depth, depth_single, head_dim, mlp_hidden)
+        self.cfg = KleinConfig(in_channels, hidden_size, txt_embed_dim, num_heads, depth, depth_single, head_dim, mlp_hidden,
+                               tp_rank, tp_size)
         self._h = c_void_p()
         check(lib.omx_klein_create(ctypes.byref(self._h), ctypes.byref(self.cfg)))
         self._keep = []
@@ -83,7 +120,13 @@ class FluxKlein:
         if not sys.is_finalizing():
             self.close()
 
+    def set_comm(self, comm_ptr: int, allreduce_fn_ptr: int) -> None:
+        """RCCL communicator + address of ncclAllReduce (comm.rccl_comm), before the first forward."""
+        check(lib.omx_klein_set_comm(self._h, comm_ptr, allreduce_fn_ptr))
+
     def load_weights(self, weights: dict) -> None:
+        """Logical (unsharded) tensors by the reference's internal names; sliced here under tensor parallelism."""
+        weights = shard_state_dict(weights, self.cfg.hidden_size, self.cfg.mlp_hidden, self.cfg.tp_rank, self.cfg.tp_size)
         for name, arr in weights.items():
             t = Tensor.from_numpy(arr, "bf16")
             self._keep.append(t)

@@ -150,9 +150,17 @@ def _attn(q, k, v, D):
 
 
 class KleinOracle:
-    def __init__(self, p: KleinParams, weights: Dict[str, np.ndarray]):
+    """`tp = (world, allreduce)`: this instance is ONE tensor-parallel rank -- `weights` are its shards
+    (klein.shard_state_dict), heads and MLP width are the per-rank ones, and `allreduce` sums the partial
+    outputs of the row-split projections where the device engine calls RCCL (tests/test_klein_tp.py)."""
+
+    def __init__(self, p: KleinParams, weights: Dict[str, np.ndarray], tp=None):
         self.p = p
         self.w = {k: np.asarray(v, np.float64) for k, v in weights.items()}
+        world, self.reduce = tp if tp is not None else (1, lambda x: x)
+        self.H = p.num_heads // world              # local heads
+        self.hq = self.H * p.head_dim              # local attention width
+        self.m = p.mlp_hidden // world             # local MLP width
 
     def lin(self, x, name):
         return x @ self.w[name].T
@@ -162,7 +170,7 @@ class KleinOracle:
 
     def double_block(self, i, img, txt, img_mod, txt_mod, cos, sin):
         p, b = self.p, f"double_blocks.{i}."
-        H, D, St = p.num_heads, p.head_dim, txt.shape[0]
+        H, D, St = self.H, p.head_dim, txt.shape[0]
         xs = {"img": img, "txt": txt}
         mods = {"img": img_mod, "txt": txt_mod}
         q, k, v = {}, {}, {}
@@ -178,24 +186,24 @@ class KleinOracle:
         out = {}
         for st in ("img", "txt"):
             g1, sh2, sc2, g2 = mods[st][2], mods[st][3], mods[st][4], mods[st][5]
-            a = self.lin(_attn(q[st], kk, vv, D), b + f"{st}_to_out.weight")
+            a = self.reduce(self.lin(_attn(q[st], kk, vv, D), b + f"{st}_to_out.weight"))
             x = xs[st] + a * g1
             xm = (1.0 + sc2) * _ln(x) + sh2
             proj = self.lin(xm, b + f"{st}_mlp_in.weight")
-            gate_, up_ = proj[:, :p.mlp_hidden], proj[:, p.mlp_hidden:]
-            out[st] = x + self.lin(_silu(gate_) * up_, b + f"{st}_mlp_out.weight") * g2
+            gate_, up_ = proj[:, :self.m], proj[:, self.m:]
+            out[st] = x + self.reduce(self.lin(_silu(gate_) * up_, b + f"{st}_mlp_out.weight")) * g2
         return out["img"], out["txt"]
 
     def single_block(self, i, x, mod, cos, sin):
         p, b = self.p, f"single_blocks.{i}."
-        H, D, h, m = p.num_heads, p.head_dim, p.hidden_size, p.mlp_hidden
+        H, D, h, m = self.H, p.head_dim, self.hq, self.m
         shift, scale, g = mod
         proj = self.lin((1.0 + scale) * _ln(x) + shift, b + "to_qkv_mlp.weight")
         q, k, v, mg, mu = np.split(proj, [h, 2 * h, 3 * h, 3 * h + m], axis=-1)
         q = apply_rope(_rms(q.reshape(-1, H, D), self.w[b + "norm_q.weight"]), cos, sin)
         k = apply_rope(_rms(k.reshape(-1, H, D), self.w[b + "norm_k.weight"]), cos, sin)
         a = _attn(q, k, v.reshape(-1, H, D), D)
-        out = self.lin(np.concatenate([a, _silu(mg) * mu], -1), b + "to_out.weight")
+        out = self.reduce(self.lin(np.concatenate([a, _silu(mg) * mu], -1), b + "to_out.weight"))
         return x + out * g
 
     def forward_with_rope(self, img, txt, timestep, cos, sin, return_intermediates=False):

@@ -49,3 +49,53 @@ def test_klein_missing_weight_is_an_error(omx):
     rcos, rsin = klein.compute_rope(klein.create_txt_ids(4), klein.create_img_ids(2, 2))
     with pytest.raises(omx.OmxError, match="WeightNotFound"):
         m.forward_with_rope(T.from_numpy(np.zeros((4, 128))), T.from_numpy(np.zeros((4, 512))), 1.0, rcos, rsin)
+
+
+def _tp_run(omx, p, world, weights, latent, txt, grid, s_txt, use_synth):
+    """`world` tensor-parallel engine instances on ONE GPU, one host thread each, all-reducing through the
+    in-process communicator (csrc/loopback_comm.hip) where the production path calls RCCL."""
+    from ominix_mlx_amd import comm, klein
+    T = omx.ops.Tensor
+    s_img = grid[0] * grid[1]
+    group = comm.LoopbackGroup(world, (s_txt + s_img) * p.hidden_size * 2)
+    rcos, rsin = klein.compute_rope(klein.create_txt_ids(s_txt), klein.create_img_ids(*grid))
+    lat_d, txt_d = T.from_numpy(latent), T.from_numpy(txt)
+    models = []
+    for r in range(world):
+        m = klein.FluxKlein(p.in_channels, p.hidden_size, p.txt_embed_dim, p.num_heads, p.depth, p.depth_single, p.head_dim,
+                            p.mlp_hidden, tp_rank=r, tp_size=world)
+        m.synth_weights() if use_synth else m.load_weights(weights)
+        m.set_comm(group.rank_comm(r), group.allreduce_fn)
+        models.append(m)
+    outs = comm.run_ranks(world, lambda r: models[r].forward_with_rope(lat_d, txt_d, 750.0, rcos, rsin).numpy(), group)
+    for m in models:
+        m.close()
+    group.close()
+    return outs
+
+
+@pytest.mark.parametrize("use_synth", [True, False])
+def test_klein_tensor_parallel_two_ranks_on_one_gpu(omx, use_synth):
+    """SURVEY 8e row 3 with REAL shards: 2 ranks (1 head and half of the MLP each), bf16 partial sums all-reduced
+    after every row-split projection.  Both ranks must hold the same result, and it must agree with the oracle
+    and with the single-GPU engine to the bf16 tolerance of the file header (the partial sums are rounded to
+    bf16 before the reduction, the fused single-GPU epilogue rounds once)."""
+    from ominix_mlx_amd import klein
+    T = omx.ops.Tensor
+    p = rk.KleinParams.tiny()
+    weights = rk.synth_weights(p)
+    g = np.random.default_rng(17)
+    s_txt, grid = 24, (5, 7)
+    latent = rc.bf16_round(g.standard_normal((grid[0] * grid[1], p.in_channels)).astype(np.float32))
+    txt = rc.bf16_round(g.standard_normal((s_txt, p.txt_embed_dim)).astype(np.float32))
+    outs = _tp_run(omx, p, 2, weights, latent, txt, grid, s_txt, use_synth)
+    np.testing.assert_array_equal(outs[0], outs[1])
+    cos, sin = rk.compute_rope(np.concatenate([rk.create_txt_ids(s_txt), rk.create_img_ids(*grid)], 0))
+    ref = rk.KleinOracle(p, weights).forward_with_rope(latent, txt, 750.0, cos, sin)
+    bound = 2.0 ** -6 * np.abs(ref).max() * np.sqrt(p.depth + p.depth_single)
+    assert np.abs(outs[0] - ref).max() <= bound
+    single = klein.FluxKlein(p.in_channels, p.hidden_size, p.txt_embed_dim, p.num_heads, p.depth, p.depth_single, p.head_dim, p.mlp_hidden)
+    single.synth_weights()
+    rcos, rsin = klein.compute_rope(klein.create_txt_ids(s_txt), klein.create_img_ids(*grid))
+    one = single.forward_with_rope(T.from_numpy(latent), T.from_numpy(txt), 750.0, rcos, rsin).numpy()
+    assert np.abs(outs[0] - one).max() <= bound

@@ -204,3 +204,54 @@ def test_persistent_step_kernel_reset_and_long_run(omx, monkeypatch):
     m.reset()
     b = np.concatenate([[m.prefill(prompt)], m.decode(300)])
     np.testing.assert_array_equal(a, b)
+
+
+def test_tensor_parallel_two_ranks_on_one_gpu(omx, monkeypatch):
+    """The TP decode path with REAL shards: two engine instances (half of the heads, KV heads, MLP columns and
+    vocabulary each; device-side synthetic shards of the same logical tensors) on one GPU, one host thread
+    each, all-reducing f32 partials and the packed argmax key through the in-process communicator
+    (csrc/loopback_comm.hip) where bench.py hands the engine ncclAllReduce.  Both ranks must emit the same
+    tokens; tokens and logits must agree with the oracle like the single-GPU engine does (the f32 partial
+    sums are all-reduced before one bf16 rounding, so TP differs from single-GPU only by summation order)."""
+    from ominix_mlx_amd import comm
+    cfg = CONFIGS["gqa4_d128"]                    # 8 heads / 2 KV heads / vocab 4096: divisible by 2
+    prompt = synth.prompt_ids(40, cfg.vocab_size)
+    n_new = 10
+    oracle = rq.Qwen3Oracle(cfg, rq.synth_weights(cfg))
+    ref_tokens, ref_logits = oracle.generate(prompt, n_new, return_logits=True)
+    world = 2
+    group = comm.LoopbackGroup(world, 1 << 20)
+    models = []
+    from ominix_mlx_amd import engine
+    for r in range(world):
+        m = engine.Model(hidden_size=cfg.hidden_size, num_hidden_layers=cfg.num_hidden_layers,
+                         intermediate_size=cfg.intermediate_size, num_attention_heads=cfg.num_attention_heads,
+                         num_key_value_heads=cfg.num_key_value_heads, head_dim=cfg.head_dim, vocab_size=cfg.vocab_size,
+                         rms_norm_eps=cfg.rms_norm_eps, rope_theta=cfg.rope_theta,
+                         tie_word_embeddings=cfg.tie_word_embeddings, max_context=256, tp_rank=r, tp_size=world)
+        m.synth_weights()
+        m.set_comm(group.rank_comm(r), group.allreduce_fn)
+        models.append(m)
+
+    def run(r):
+        m = models[r]
+        first = m.prefill(prompt)
+        logits0 = m.last_logits()
+        rest = m.decode(n_new - 1)
+        return np.concatenate([[first], rest]).astype(np.uint32), logits0, m.decode_path()
+
+    outs = comm.run_ranks(world, run, group)
+    np.testing.assert_array_equal(outs[0][0], outs[1][0])
+    assert outs[0][2] == "eager"                       # the loopback collective refuses stream capture
+    got = outs[0][0]
+    logits0 = np.concatenate([outs[0][1], outs[1][1]])          # vocabulary shards, rank order
+    bound = 2.0 ** -7 * np.abs(ref_logits).max() * np.sqrt(cfg.num_hidden_layers)
+    assert np.abs(logits0 - ref_logits[0]).max() <= bound
+    margins = rc.argmax_margin(ref_logits)
+    for i in range(n_new):
+        if got[i] != ref_tokens[i]:
+            assert margins[i] <= 2 * bound, f"token {i}: got {got[i]} want {ref_tokens[i]} with margin {margins[i]:.4f}"
+            break
+    for m in models:
+        m.close()
+    group.close()

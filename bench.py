@@ -46,6 +46,8 @@ def parse():
     ap.add_argument("--layers", type=int, default=0, help="debug: override layer count (invalidates the metric)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-flux", action="store_true", help="skip the secondary FLUX.2-klein sec/step measurement")
+    ap.add_argument("--flux-tp", action="store_true",
+                    help="with --gpus N > 1: also time FLUX.2-klein tensor-parallel over the N GPUs (all ranks take part)")
     return ap.parse_args()
 
 
@@ -95,14 +97,17 @@ def time_dominant_kernel(omx, cfg, world, iters=3):
 PMC_TRAFFIC_GATE_UP_TP1 = 201641984
 
 
-def flux_secondary(omx, steps=3):
-    """Second half of BASELINE.json's metric string: FLUX.2-klein 1024x1024 sec/step (one MI355X, bf16,
-    synthetic weights/latents; full 5 double + 20 single block model, S = 512 txt + 4096 img tokens)."""
+def flux_secondary(omx, steps=3, rank=0, world=1, comm=None):
+    """Second half of BASELINE.json's metric string: FLUX.2-klein 1024x1024 sec/step (bf16, synthetic
+    weights/latents; full 5 double + 20 single block model, S = 512 txt + 4096 img tokens).  world > 1:
+    tensor-parallel over the node (heads and MLP columns sharded, bf16 all-reduce over RCCL)."""
     import numpy as np
     from ominix_mlx_amd import klein
     g = 1024 // 16
     s_img, s_txt = g * g, 512
-    m = klein.FluxKlein()
+    m = klein.FluxKlein(tp_rank=rank, tp_size=world)
+    if comm is not None:
+        m.set_comm(comm[1], comm[2])
     m.synth_weights()
     lat = omx.ops.fill_uniform((s_img, 128), 1, 1.7)
     txt = omx.ops.fill_uniform((s_txt, 7680), 2, 1.7)
@@ -116,9 +121,9 @@ def flux_secondary(omx, steps=3):
     ms = float(np.median(ts))
     flop = 34.79e12   # 28.27 TFLOP linear + 6.52 TFLOP attention at S = 4608
     return {"metric": "flux_klein_1024_sec_per_step", "value": round(ms / 1e3, 5), "unit": "s/step", "higher_is_better": False,
-            "n_gpus": 1, "steps": steps, "dtype": "bf16", "data": "synthetic",
-            "roofline": {"bound": "mfma", "achieved": round(flop / ms / 1e9, 1), "peak": 2500.0, "unit": "TFLOP/s",
-                         "frac": round(flop / ms / 1e9 / 2500.0, 4)}}
+            "n_gpus": world, "steps": steps, "dtype": "bf16", "data": "synthetic", "parallelism": f"tp{world}",
+            "roofline": {"bound": "mfma", "achieved": round(flop / ms / 1e9, 1), "peak": 2500.0 * world, "unit": "TFLOP/s",
+                         "frac": round(flop / ms / 1e9 / (2500.0 * world), 4)}}
 
 
 def cpu_baseline(cfg, ctx, n_layers_sample=2, reps=2):
@@ -209,6 +214,12 @@ def main():
         elapsed = float(t.item())
     dev_ms = model.last_decode_ms()
 
+    flux_tp = None
+    if world > 1 and args.flux_tp:   # a collective workload: every rank takes part
+        try:
+            flux_tp = flux_secondary(omx, rank=rank, world=world, comm=keep)
+        except Exception as e:
+            flux_tp = {"metric": "flux_klein_1024_sec_per_step", "value": None, "error": str(e)}
     if rank != 0:
         model.close()
         return
@@ -243,6 +254,8 @@ def main():
         "first_tokens": [int(first)] + [int(t) for t in toks[:4]],
     }
     model.close()
+    if flux_tp is not None:
+        out["secondary"] = flux_tp
     if world == 1 and not args.no_flux:
         try:
             out["secondary"] = flux_secondary(omx)

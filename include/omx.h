@@ -175,6 +175,27 @@ int omx_qwen3_decode_path(omx_qwen3 m, int* path);
 int omx_qwen3_debug_trace_step(omx_qwen3 m, unsigned long long* host, size_t n_words, int* blocks);
 
 /* =====================================================================================
+ * MLX affine group quantisation (the reference's flagship checkpoint format).
+ * mlx_rs::ops::{quantize, dequantize, quantized_matmul, gather_qmm} (mlx-rs/src/ops/quantization.rs:41-153,
+ * 226-279) -> mlx_quantize / mlx_dequantize / mlx_quantized_matmul / mlx_gather_qmm (mlx-c ops.h:356-365,
+ * 471-484, 793-810).  w [rows, cols] <-> packed u32 [rows, cols*bits/32] (LSB first) + scales, biases
+ * [rows, cols/group_size] (dtype of w); bits 4 or 8, group_size 32/64/128, dtype bf16.
+ * ===================================================================================== */
+int omx_quantize(void* packed, void* scales, void* biases, const void* w, int64_t rows, int cols, int group_size, int bits,
+                 omx_dtype dtype, omx_stream stream);
+int omx_dequantize(void* out, const void* packed, const void* scales, const void* biases /* may be NULL */, int64_t rows,
+                   int cols, int group_size, int bits, omx_dtype dtype, omx_stream stream);
+/* out [M, N] = x [M, K] . dequant(W [N, K])^T (transpose = true, nn::QuantizedLinear::forward quantized.rs:366-375):
+ * M <= 16 streams the packed weights (GEMV), larger M dequantises into the library workspace and runs the MFMA GEMM */
+int omx_quantized_matmul(void* out, const void* x, const void* packed, const void* scales, const void* biases, int M, int N,
+                         int K, int group_size, int bits, omx_dtype dtype, omx_stream stream);
+/* out [n_rows, N]: row i = x[i / x_div] . dequant(W[rhs_indices[i]])^T over expert-stacked packed weights
+ * [n_experts, N, K*bits/32] (QuantizedSwitchLinear::apply, mixtral-mlx/src/model.rs:195-201)                */
+int omx_gather_qmm(void* out, const void* x, const void* packed, const void* scales, const void* biases,
+                   const uint32_t* rhs_indices, int n_rows, int x_div, int N, int K, int n_experts, int group_size, int bits,
+                   omx_dtype dtype, omx_stream stream);
+
+/* =====================================================================================
  * a6 + a7: sparse-MoE block = router + top-k + SwitchGLU + weighted sum.
  *   mode 0  MixtralSparseMoeBlock::forward (mixtral-mlx/src/model.rs:296-308): top-k of the gate logits,
  *           softmax (precise) over the SELECTED logits;

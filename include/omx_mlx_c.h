@@ -116,7 +116,22 @@ int mlx_fast_scaled_dot_product_attention(mlx_array* res, const mlx_array querie
 /* ---- ops.h: GEMM + glue used by the four callers (line numbers per declaration) ---- */
 int mlx_matmul(mlx_array* res, const mlx_array a, const mlx_array b, const mlx_stream s);                     /* :598 */
 int mlx_addmm(mlx_array* res, const mlx_array c, const mlx_array a, const mlx_array b, float alpha, float beta,
-              const mlx_stream s);                                                                             /* :36  */
+              const mlx_stream s);
+/* affine group quantisation (mlx-c ops.h:356-365, 471-484, 793-810; mlx-rs/src/ops/quantization.rs:41-153, 226-279).
+ * mlx_quantize appends (w_q, scales, biases) to an existing vector; mode "" or "affine"; defaults group 64, bits 4 */
+int mlx_quantize(mlx_vector_array* res, const mlx_array w, mlx_optional_int group_size, mlx_optional_int bits, const char* mode,
+                 const mlx_stream s);
+int mlx_dequantize(mlx_array* res, const mlx_array w, const mlx_array scales, const mlx_array biases /* may be null */,
+                   mlx_optional_int group_size, mlx_optional_int bits, const char* mode, mlx_optional_dtype dtype,
+                   const mlx_stream s);
+int mlx_quantized_matmul(mlx_array* res, const mlx_array x, const mlx_array w, const mlx_array scales,
+                         const mlx_array biases /* may be null */, bool transpose, mlx_optional_int group_size,
+                         mlx_optional_int bits, const char* mode, const mlx_stream s);
+int mlx_gather_qmm(mlx_array* res, const mlx_array x, const mlx_array w, const mlx_array scales,
+                   const mlx_array biases /* may be null */, const mlx_array lhs_indices /* may be null */,
+                   const mlx_array rhs_indices /* may be null */, bool transpose, mlx_optional_int group_size,
+                   mlx_optional_int bits, const char* mode, bool sorted_indices, const mlx_stream s);
+                                                                             /* :36  */
 int mlx_add(mlx_array* res, const mlx_array a, const mlx_array b, const mlx_stream s);                        /* :31  */
 int mlx_subtract(mlx_array* res, const mlx_array a, const mlx_array b, const mlx_stream s);                   /* :1080 */
 int mlx_multiply(mlx_array* res, const mlx_array a, const mlx_array b, const mlx_stream s);                   /* :686 */

@@ -41,6 +41,11 @@ MASK_NONE, MASK_CAUSAL, MASK_BOOL, MASK_ADDITIVE = range(4)
 # name -> (restype, argtypes).  Every symbol include/omx.h declares must appear here
 # (tests/test_abi.py cross-checks this table against the header).
 SIGNATURES = {
+    "omx_quantize": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_int64, c_int, c_int, c_int, c_int, c_void_p]),
+    "omx_dequantize": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_int64, c_int, c_int, c_int, c_int, c_void_p]),
+    "omx_quantized_matmul": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "omx_gather_qmm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
+                               c_int, c_int, c_void_p]),
     "omx_version": (ctypes.c_char_p, []),
     "omx_set_error_handler": (None, [c_void_p, c_void_p, c_void_p]),
     "omx_last_error": (ctypes.c_char_p, []),

@@ -630,6 +630,103 @@ int mlx_addmm(mlx_array* res, const mlx_array c, const mlx_array a, const mlx_ar
     return matmul_impl(res, a, b, cc.a, "mlx_addmm");
 }
 
+// ---- affine group quantisation (ops.h:356-365, 471-484, 793-810; ops/quantization.rs:41-153, 226-279) ----
+static int quant_params(const char* name, mlx_optional_int group_size, mlx_optional_int bits, const char* mode, int* g, int* b) {
+    *g = group_size.has_value ? group_size.value : 64;    // quantized.rs:330-333 defaults
+    *b = bits.has_value ? bits.value : 4;
+    OMX_REQUIRE(!mode || mode[0] == 0 || strcmp(mode, "affine") == 0, "%s: only the affine mode is supported (got '%s')", name, mode);
+    return 0;
+}
+int mlx_quantize(mlx_vector_array* res, const mlx_array w, mlx_optional_int group_size, mlx_optional_int bits, const char* mode,
+                 const mlx_stream) {
+    REQ_ARR(w, "mlx_quantize");
+    OMX_REQUIRE(res && res->ctx, "mlx_quantize: result vector must be created with mlx_vector_array_new");
+    int g, b;
+    if (quant_params("mlx_quantize", group_size, bits, mode, &g, &b)) return 1;
+    Contig cw;
+    if (cw.init(*A(w))) return 1;
+    OMX_REQUIRE(!cw.a->shape.empty(), "mlx_quantize: scalar input");
+    const int K = cw.a->shape.back();
+    OMX_REQUIRE(K % g == 0 && (K * b) % 32 == 0, "mlx_quantize: the last dimension (%d) must be divisible by the group size (%d)", K, g);
+    std::vector<int> ps = cw.a->shape, ss = cw.a->shape;
+    ps.back() = K * b / 32;
+    ss.back() = K / g;
+    Arr *pk = new_arr(ps, MLX_UINT32), *sc = new_arr(ss, cw.a->dt), *bi = new_arr(ss, cw.a->dt);
+    if (!pk || !sc || !bi) { delete pk; delete sc; delete bi; return set_error("mlx_quantize: out of device memory"); }
+    const int rc = omx_quantize(pk->ptr(), sc->ptr(), bi->ptr(), cw.a->ptr(), K ? (int64_t)(cw.a->size() / K) : 0, K, g, b,
+                                to_omx(cw.a->dt), g_stream);
+    if (!rc) {
+        Vec* v = reinterpret_cast<Vec*>(res->ctx);
+        v->v.push_back(pk); v->v.push_back(sc); v->v.push_back(bi);
+        return 0;
+    }
+    delete pk; delete sc; delete bi;
+    return 1;
+}
+int mlx_dequantize(mlx_array* res, const mlx_array w, const mlx_array scales, const mlx_array biases, mlx_optional_int group_size,
+                   mlx_optional_int bits, const char* mode, mlx_optional_dtype dtype, const mlx_stream) {
+    REQ_ARR(w, "mlx_dequantize"); REQ_ARR(scales, "mlx_dequantize");
+    int g, b;
+    if (quant_params("mlx_dequantize", group_size, bits, mode, &g, &b)) return 1;
+    Contig cw, cs, cb;
+    if (cw.init(*A(w)) || cs.init(*A(scales)) || (biases.ctx && cb.init(*A(biases)))) return 1;
+    OMX_REQUIRE(cw.a->dt == MLX_UINT32 && !cw.a->shape.empty(), "mlx_dequantize: w must be a packed uint32 array");
+    OMX_REQUIRE(!dtype.has_value || dtype.value == cs.a->dt, "mlx_dequantize: output dtype must be the dtype of scales");
+    const int K = cw.a->shape.back() * 32 / b;
+    OMX_REQUIRE(cs.a->size() * (size_t)g == cw.a->size() * 32 / b, "mlx_dequantize: scales shape does not match w / group_size");
+    std::vector<int> shape = cw.a->shape;
+    shape.back() = K;
+    NEW_OR_FAIL(r, shape, cs.a->dt);
+    if (omx_dequantize(r->ptr(), cw.a->ptr(), cs.a->ptr(), biases.ctx ? cb.a->ptr() : nullptr, K ? (int64_t)(r->size() / K) : 0, K, g, b,
+                       to_omx(cs.a->dt), g_stream)) { delete r; return 1; }
+    return assign(res, r);
+}
+int mlx_quantized_matmul(mlx_array* res, const mlx_array x, const mlx_array w, const mlx_array scales, const mlx_array biases,
+                         bool transpose, mlx_optional_int group_size, mlx_optional_int bits, const char* mode, const mlx_stream) {
+    REQ_ARR(x, "mlx_quantized_matmul"); REQ_ARR(w, "mlx_quantized_matmul"); REQ_ARR(scales, "mlx_quantized_matmul");
+    int g, b;
+    if (quant_params("mlx_quantized_matmul", group_size, bits, mode, &g, &b)) return 1;
+    OMX_REQUIRE(transpose, "mlx_quantized_matmul: only transpose = true (QuantizedLinear, quantized.rs:366-375) is supported");
+    Contig cx, cw, cs, cb;
+    if (cx.init(*A(x)) || cw.init(*A(w)) || cs.init(*A(scales)) || (biases.ctx && cb.init(*A(biases)))) return 1;
+    OMX_REQUIRE(cw.a->dt == MLX_UINT32 && cw.a->shape.size() == 2, "mlx_quantized_matmul: w must be a 2-D packed uint32 array");
+    const int N = cw.a->shape[0], K = cw.a->shape[1] * 32 / b;
+    OMX_REQUIRE(!cx.a->shape.empty() && cx.a->shape.back() == K, "mlx_quantized_matmul: x has %d features, packed w has %d",
+                cx.a->shape.empty() ? 0 : cx.a->shape.back(), K);
+    OMX_REQUIRE(cs.a->size() == (size_t)N * (K / g), "mlx_quantized_matmul: scales shape does not match w / group_size");
+    std::vector<int> shape(cx.a->shape.begin(), cx.a->shape.end() - 1);
+    shape.push_back(N);
+    NEW_OR_FAIL(r, shape, cx.a->dt);
+    if (omx_quantized_matmul(r->ptr(), cx.a->ptr(), cw.a->ptr(), cs.a->ptr(), biases.ctx ? cb.a->ptr() : nullptr,
+                             K ? (int)(cx.a->size() / K) : 0, N, K, g, b, to_omx(cx.a->dt), g_stream)) { delete r; return 1; }
+    return assign(res, r);
+}
+int mlx_gather_qmm(mlx_array* res, const mlx_array x, const mlx_array w, const mlx_array scales, const mlx_array biases,
+                   const mlx_array lhs_indices, const mlx_array rhs_indices, bool transpose, mlx_optional_int group_size,
+                   mlx_optional_int bits, const char* mode, bool, const mlx_stream) {
+    REQ_ARR(x, "mlx_gather_qmm"); REQ_ARR(w, "mlx_gather_qmm"); REQ_ARR(scales, "mlx_gather_qmm"); REQ_ARR(rhs_indices, "mlx_gather_qmm");
+    int g, b;
+    if (quant_params("mlx_gather_qmm", group_size, bits, mode, &g, &b)) return 1;
+    OMX_REQUIRE(transpose && !lhs_indices.ctx, "mlx_gather_qmm: supported form is transpose = true, no lhs_indices (SwitchLinear, model.rs:195-201)");
+    Contig cx, cw, cs, cb, ci;
+    if (cx.init(*A(x)) || cw.init(*A(w)) || cs.init(*A(scales)) || (biases.ctx && cb.init(*A(biases))) || ci.init(*A(rhs_indices))) return 1;
+    OMX_REQUIRE(cw.a->dt == MLX_UINT32 && cw.a->shape.size() == 3, "mlx_gather_qmm: w must be [E, N, K*bits/32] uint32");
+    OMX_REQUIRE(ci.a->dt == MLX_UINT32 || ci.a->dt == MLX_INT32, "mlx_gather_qmm: rhs_indices must be (u)int32");
+    const int E = cw.a->shape[0], N = cw.a->shape[1], K = cw.a->shape[2] * 32 / b;
+    // x [..., 1, K] broadcast against rhs_indices [..., k]: row i of the result uses x row i / x_div
+    OMX_REQUIRE(cx.a->shape.size() >= 2 && cx.a->shape.back() == K && cx.a->shape[cx.a->shape.size() - 2] == 1,
+                "mlx_gather_qmm: x must be [..., 1, K=%d]", K);
+    const size_t n_x = cx.a->size() / K, n = ci.a->size();
+    OMX_REQUIRE(n_x > 0 && n % n_x == 0, "mlx_gather_qmm: %zu indices do not broadcast over %zu activation rows", n, n_x);
+    std::vector<int> shape = ci.a->shape;
+    shape.push_back(1);
+    shape.push_back(N);
+    NEW_OR_FAIL(r, shape, cx.a->dt);
+    if (omx_gather_qmm(r->ptr(), cx.a->ptr(), cw.a->ptr(), cs.a->ptr(), biases.ctx ? cb.a->ptr() : nullptr, (const uint32_t*)ci.a->ptr(),
+                       (int)n, (int)(n / n_x), N, K, E, g, b, to_omx(cx.a->dt), g_stream)) { delete r; return 1; }
+    return assign(res, r);
+}
+
 // ---- elementwise ----
 int mlx_add(mlx_array* res, const mlx_array a, const mlx_array b, const mlx_stream) { return binary(res, a, b, OP_ADD, "mlx_add"); }
 int mlx_subtract(mlx_array* res, const mlx_array a, const mlx_array b, const mlx_stream) { return binary(res, a, b, OP_SUB, "mlx_subtract"); }

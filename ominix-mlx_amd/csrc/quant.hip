@@ -1,0 +1,286 @@
+// MLX affine group quantisation on gfx950 (the reference's flagship checkpoint format).
+//   reference: mlx_rs::ops::{quantize, dequantize, quantized_matmul, gather_qmm}
+//              (mlx-rs/src/ops/quantization.rs:41-153, 226-279) -> mlx_quantize / mlx_dequantize /
+//              mlx_quantized_matmul / mlx_gather_qmm (mlx-c ops.h:356-365, 471-484, 793-810);
+//              nn::QuantizedLinear::forward (mlx-rs/src/nn/quantized.rs:361-385).
+// Format: w [N, K] -> packed u32 [N, K*bits/32] (element j of a row = the `bits`-wide field at bit
+// (j*bits) mod 32 of word floor(j*bits/32), LSB first), scales / biases [N, K/group] in the activation
+// dtype; w ~= q * scale + bias.  bits 4 or 8, group 32 / 64 / 128.
+//
+// quantized_matmul (transpose = true: x . dequant(W)^T):
+//   * M <= 16 (decode): weight-streaming GEMV that reads the PACKED weights -- a quarter (4-bit) of the
+//     bf16 bytes.  One wave per row, each lane owns W words per step; per lane  acc += scale * sum(x_i q_i)
+//     + bias * sum(x_i), the per-chunk sum(x_i) being shared by all rows (computed once per block into LDS).
+//     grid.y walks the activation rows / expert-selected batch entries (gather_qmm).
+//   * M > 16 (prefill): dequantise W once into the workspace, then the bf16 MFMA GEMM (gemm.hip).
+#include "common.hpp"
+#include "gemm.hpp"
+#include "vec.hpp"
+#include "workspace.hpp"
+
+namespace omx {
+
+namespace {
+
+// ---- quantize: one wave per group of 32/64/128 elements (MLX affine_quantize) ----
+template <int BITS>
+__global__ __launch_bounds__(256) void quantize_kernel(uint32_t* __restrict__ packed, bf16_t* __restrict__ scales,
+                                                       bf16_t* __restrict__ biases, const bf16_t* __restrict__ w,
+                                                       int64_t n_groups, int group) {
+    constexpr int EPW = 32 / BITS;
+    constexpr float n_bins = (float)((1 << BITS) - 1);
+    const int lane = threadIdx.x & 63;
+    const int64_t g = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (g >= n_groups) return;
+    const bf16_t* src = w + g * group;
+    const int per_lane = group / 64 > 0 ? group / 64 : 1;   // 128 -> 2, 64 -> 1, 32 -> 1 (upper half idle)
+    float v[2] = {0.f, 0.f};
+    float mx = -INFINITY, mn = INFINITY;
+    for (int i = 0; i < per_lane; ++i) {
+        const int e = lane * per_lane + i;
+        if (e < group) {
+            v[i] = bf16_to_f32(src[e]);
+            mx = fmaxf(mx, v[i]);
+            mn = fminf(mn, v[i]);
+        }
+    }
+    mx = wave_max(mx);
+    mn = -wave_max(-mn);
+    float scale = fmaxf((mx - mn) / n_bins, 1e-7f);
+    const bool side = fabsf(mn) > fabsf(mx);
+    scale = side ? scale : -scale;
+    const float edge = side ? mn : mx;
+    const float q0 = rintf(edge / scale);
+    const bool at_zero = q0 == 0.f;
+    scale = at_zero ? scale : edge / q0;
+    const float bias = at_zero ? 0.f : edge;
+    if (lane == 0) {
+        scales[g] = f32_to_bf16(scale);
+        biases[g] = f32_to_bf16(bias);
+    }
+    // pack: element e goes to word e / EPW at bit (e % EPW) * BITS; the EPW elements of a word sit in
+    // EPW / per_lane consecutive lanes
+    uint32_t word = 0;
+    for (int i = 0; i < per_lane; ++i) {
+        const int e = lane * per_lane + i;
+        if (e < group) {
+            const float q = fminf(fmaxf(rintf((v[i] - bias) / scale), 0.f), n_bins);
+            word |= (uint32_t)q << ((e % EPW) * BITS);
+        }
+    }
+    constexpr int kLanesPerWordMax = EPW;   // per_lane == 1
+    const int lanes_per_word = EPW / per_lane;
+    for (int o = 1; o < kLanesPerWordMax; o <<= 1)
+        if (o < lanes_per_word) word |= __shfl_xor(word, o, 64);
+    const int e0 = lane * per_lane;
+    if (e0 < group && (lane % lanes_per_word) == 0) packed[(g * group + e0) / EPW] = word;
+}
+
+template <int BITS>
+__global__ __launch_bounds__(256) void dequantize_kernel(bf16_t* __restrict__ out, const uint32_t* __restrict__ packed,
+                                                         const bf16_t* __restrict__ scales, const bf16_t* __restrict__ biases,
+                                                         int64_t n_words, int group) {
+    constexpr int EPW = 32 / BITS;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_words; i += (int64_t)gridDim.x * blockDim.x) {
+        const uint32_t wd = packed[i];
+        const int64_t g = i * EPW / group;
+        const float s = bf16_to_f32(scales[g]), b = biases ? bf16_to_f32(biases[g]) : 0.f;
+        bf16_t o[EPW];
+#pragma unroll
+        for (int e = 0; e < EPW; ++e) o[e] = f32_to_bf16((float)((wd >> (e * BITS)) & ((1u << BITS) - 1u)) * s + b);
+        if (EPW == 8) *reinterpret_cast<u32x4*>(out + i * 8) = *reinterpret_cast<const u32x4*>(o);
+        else *reinterpret_cast<u32x2*>(out + i * 4) = *reinterpret_cast<const u32x2*>(o);
+    }
+}
+
+struct QGemvArgs {
+    const uint32_t* w;          // [E?][N, K*bits/32]
+    const bf16_t *scales, *biases;   // [E?][N, K/group]
+    const bf16_t* x;            // [n_x, K]
+    bf16_t* out;                // [n_batch, N]
+    int N, K, group, rows_per_wave;
+    int n_batch, x_div;         // batch entry j reads activation row j / x_div
+    const uint32_t* w_sel;      // optional [n_batch] expert ids
+    size_t w_estride, s_estride;    // words / groups between consecutive experts
+};
+
+// W = u32 words per lane per step; a lane's W*EPW elements lie inside one group
+template <int BITS, int W>
+__global__ __launch_bounds__(256) void qgemv_kernel(const QGemvArgs a) {
+    constexpr int EPW = 32 / BITS, EPL = W * EPW;          // elements per lane per step
+    constexpr int RB = 4;                                   // rows in flight per wave
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    bf16_t* xs = reinterpret_cast<bf16_t*>(smem);                       // [K]
+    float* xsum = reinterpret_cast<float*>(smem + (size_t)a.K * 2);     // [K / EPL]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int by = blockIdx.y;
+    const bf16_t* xg = a.x + (size_t)(by / a.x_div) * a.K;
+    const size_t e = a.w_sel ? a.w_sel[by] : 0;
+    const uint32_t* wq = a.w + e * a.w_estride;
+    const bf16_t* sc = a.scales + e * a.s_estride;
+    const bf16_t* bi = a.biases ? a.biases + e * a.s_estride : nullptr;
+    bf16_t* out = a.out + (size_t)by * a.N;
+
+    for (int i = threadIdx.x * 8; i < a.K; i += 256 * 8) *reinterpret_cast<u32x4*>(xs + i) = *reinterpret_cast<const u32x4*>(xg + i);
+    __syncthreads();
+    for (int c = threadIdx.x; c < a.K / EPL; c += 256) {
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < EPL; ++j) s += bf16_to_f32(xs[c * EPL + j]);
+        xsum[c] = s;
+    }
+    __syncthreads();
+
+    const int steps = a.K / (64 * EPL);
+    const int words_per_row = a.K / EPW, groups_per_row = a.K / a.group;
+    const int row_begin = (blockIdx.x * 4 + wave) * a.rows_per_wave;
+    const int row_end = min(row_begin + a.rows_per_wave, a.N);
+    for (int r0 = row_begin; r0 < row_end; r0 += RB) {
+        float acc[RB];
+#pragma unroll
+        for (int r = 0; r < RB; ++r) acc[r] = 0.f;
+        for (int s = 0; s < steps; ++s) {
+            const int chunk = s * 64 + lane;                 // lane-chunk index inside the row
+            uint32_t wd[RB][W];
+            float scl[RB], bs[RB];
+#pragma unroll
+            for (int r = 0; r < RB; ++r) {
+                const int row = min(r0 + r, a.N - 1);
+                const uint32_t* p = wq + (size_t)row * words_per_row + (size_t)chunk * W;
+                if (W == 4) {
+                    const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
+                    wd[r][0] = v[0]; wd[r][1] = v[1]; wd[r][W > 2 ? 2 : 0] = v[2]; wd[r][W > 3 ? 3 : 0] = v[3];
+                } else if (W == 2) {
+                    const u32x2 v = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(p));
+                    wd[r][0] = v[0]; wd[r][W > 1 ? 1 : 0] = v[1];
+                } else {
+                    wd[r][0] = __builtin_nontemporal_load(p);
+                }
+                const int g = chunk * EPL / a.group;
+                scl[r] = bf16_to_f32(sc[(size_t)row * groups_per_row + g]);
+                bs[r] = bi ? bf16_to_f32(bi[(size_t)row * groups_per_row + g]) : 0.f;
+            }
+            float xf[EPL];
+#pragma unroll
+            for (int j = 0; j < EPL; j += 8) {
+                const u32x4 xv = *reinterpret_cast<const u32x4*>(xs + (size_t)chunk * EPL + j);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { xf[j + 2 * q] = bf16lo(xv[q]); xf[j + 2 * q + 1] = bf16hi(xv[q]); }
+            }
+            const float xsm = xsum[chunk];
+#pragma unroll
+            for (int r = 0; r < RB; ++r) {
+                float d = 0.f;
+#pragma unroll
+                for (int wi = 0; wi < W; ++wi)
+#pragma unroll
+                    for (int el = 0; el < EPW; ++el)
+                        d = fmaf(xf[wi * EPW + el], (float)((wd[r][wi] >> (el * BITS)) & ((1u << BITS) - 1u)), d);
+                acc[r] = fmaf(scl[r], d, acc[r]);
+                acc[r] = fmaf(bs[r], xsm, acc[r]);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+            const float v = wave_sum(acc[r]);
+            if (lane == 0 && r0 + r < row_end) out[r0 + r] = f32_to_bf16(v);
+        }
+    }
+}
+
+template <int BITS>
+int launch_qgemv_bits(const QGemvArgs& a_in, hipStream_t s) {
+    QGemvArgs a = a_in;
+    constexpr int EPW = 32 / BITS;
+    int W = 4;
+    while (W > 1 && (a.K % (64 * W * EPW) != 0 || W * EPW > a.group)) W >>= 1;
+    OMX_REQUIRE(a.K % (64 * W * EPW) == 0 && W * EPW <= a.group, "quantized_matmul: K=%d unsupported for %d-bit group %d (K must be a multiple of %d)",
+                a.K, BITS, a.group, 64 * EPW);
+    a.rows_per_wave = a.N >= 8192 ? 8 : 4;
+    const int groups = (a.N + a.rows_per_wave - 1) / a.rows_per_wave;
+    const dim3 grid((groups + 3) / 4, a.n_batch), block(256);
+    const size_t shmem = (size_t)a.K * 2 + (size_t)(a.K / (W * EPW)) * 4;
+    if (W == 4) qgemv_kernel<BITS, 4><<<grid, block, shmem, s>>>(a);
+    else if (W == 2) qgemv_kernel<BITS, 2><<<grid, block, shmem, s>>>(a);
+    else qgemv_kernel<BITS, 1><<<grid, block, shmem, s>>>(a);
+    OMX_LAUNCH_CHECK();
+    return 0;
+}
+
+int check_format(const char* who, int K, int group, int bits, int dtype) {
+    OMX_REQUIRE(dtype == OMX_BFLOAT16, "%s: bf16 activations / scales only (got dtype %d)", who, dtype);
+    OMX_REQUIRE(bits == 4 || bits == 8, "%s: bits must be 4 or 8 (got %d)", who, bits);
+    OMX_REQUIRE(group == 32 || group == 64 || group == 128, "%s: group_size must be 32, 64 or 128 (got %d)", who, group);
+    OMX_REQUIRE(K > 0 && K % group == 0, "%s: the last dimension (%d) must be divisible by the group size (%d)", who, K, group);
+    return 0;
+}
+
+}  // namespace
+}  // namespace omx
+
+using namespace omx;
+
+extern "C" int omx_quantize(void* packed, void* scales, void* biases, const void* w, int64_t rows, int cols, int group_size,
+                            int bits, omx_dtype dtype, omx_stream stream) {
+    OMX_REQUIRE(packed && scales && biases && w, "omx_quantize: null tensor");
+    if (check_format("omx_quantize", cols, group_size, bits, dtype)) return 1;
+    const int64_t n_groups = rows * (cols / group_size);
+    if (n_groups == 0) return 0;
+    const unsigned blocks = (unsigned)((n_groups + 3) / 4);
+    if (bits == 4) quantize_kernel<4><<<blocks, 256, 0, (hipStream_t)stream>>>((uint32_t*)packed, (bf16_t*)scales, (bf16_t*)biases, (const bf16_t*)w, n_groups, group_size);
+    else quantize_kernel<8><<<blocks, 256, 0, (hipStream_t)stream>>>((uint32_t*)packed, (bf16_t*)scales, (bf16_t*)biases, (const bf16_t*)w, n_groups, group_size);
+    OMX_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int omx_dequantize(void* out, const void* packed, const void* scales, const void* biases, int64_t rows, int cols,
+                              int group_size, int bits, omx_dtype dtype, omx_stream stream) {
+    OMX_REQUIRE(out && packed && scales, "omx_dequantize: null tensor");
+    if (check_format("omx_dequantize", cols, group_size, bits, dtype)) return 1;
+    const int64_t n_words = rows * cols * bits / 32;
+    if (n_words == 0) return 0;
+    const unsigned blocks = (unsigned)((n_words + 255) / 256 < 16384 ? (n_words + 255) / 256 : 16384);
+    if (bits == 4) dequantize_kernel<4><<<blocks, 256, 0, (hipStream_t)stream>>>((bf16_t*)out, (const uint32_t*)packed, (const bf16_t*)scales, (const bf16_t*)biases, n_words, group_size);
+    else dequantize_kernel<8><<<blocks, 256, 0, (hipStream_t)stream>>>((bf16_t*)out, (const uint32_t*)packed, (const bf16_t*)scales, (const bf16_t*)biases, n_words, group_size);
+    OMX_LAUNCH_CHECK();
+    return 0;
+}
+
+/* out [M, N] = x [M, K] . dequant(W [N, K])^T   (nn::QuantizedLinear::forward, quantized.rs:366-375) */
+extern "C" int omx_quantized_matmul(void* out, const void* x, const void* packed, const void* scales, const void* biases, int M,
+                                    int N, int K, int group_size, int bits, omx_dtype dtype, omx_stream stream) {
+    OMX_REQUIRE(out && x && packed && scales, "omx_quantized_matmul: null tensor");
+    if (check_format("omx_quantized_matmul", K, group_size, bits, dtype)) return 1;
+    OMX_REQUIRE(M >= 0 && N > 0, "omx_quantized_matmul: bad shape");
+    if (M == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    if (M <= 16 && K % (64 * (32 / bits)) == 0) {
+        QGemvArgs a = {};
+        a.w = (const uint32_t*)packed; a.scales = (const bf16_t*)scales; a.biases = (const bf16_t*)biases;
+        a.x = (const bf16_t*)x; a.out = (bf16_t*)out; a.N = N; a.K = K; a.group = group_size;
+        a.n_batch = M; a.x_div = 1;
+        return bits == 4 ? launch_qgemv_bits<4>(a, s) : launch_qgemv_bits<8>(a, s);
+    }
+    void* ws = nullptr;
+    if (get_workspace(&ws, (size_t)N * K * 2)) return 1;
+    if (omx_dequantize(ws, packed, scales, biases, N, K, group_size, bits, dtype, stream)) return 1;
+    return launch_gemm_bf16((bf16_t*)out, (const bf16_t*)x, (const bf16_t*)ws, nullptr, M, N, K, s);
+}
+
+/* out [n, N] = x [n / x_div, K] . dequant(W[rhs_indices[i]])^T : SwitchLinear on expert-stacked quantized weights
+ * (mixtral-mlx/src/model.rs:195-201 -> gather_qmm, ops/quantization.rs:226-279); packed [E, N, K*bits/32] */
+extern "C" int omx_gather_qmm(void* out, const void* x, const void* packed, const void* scales, const void* biases,
+                              const uint32_t* rhs_indices, int n_rows, int x_div, int N, int K, int n_experts, int group_size,
+                              int bits, omx_dtype dtype, omx_stream stream) {
+    OMX_REQUIRE(out && x && packed && scales && rhs_indices, "omx_gather_qmm: null tensor");
+    if (check_format("omx_gather_qmm", K, group_size, bits, dtype)) return 1;
+    OMX_REQUIRE(n_rows >= 0 && x_div >= 1 && N > 0 && n_experts >= 1, "omx_gather_qmm: bad shape");
+    OMX_REQUIRE(K % (64 * (32 / bits)) == 0, "omx_gather_qmm: K=%d must be a multiple of %d", K, 64 * (32 / bits));
+    if (n_rows == 0) return 0;
+    QGemvArgs a = {};
+    a.w = (const uint32_t*)packed; a.scales = (const bf16_t*)scales; a.biases = (const bf16_t*)biases;
+    a.x = (const bf16_t*)x; a.out = (bf16_t*)out; a.N = N; a.K = K; a.group = group_size;
+    a.n_batch = n_rows; a.x_div = x_div; a.w_sel = rhs_indices;
+    a.w_estride = (size_t)N * K * bits / 32; a.s_estride = (size_t)N * (K / group_size);
+    return bits == 4 ? launch_qgemv_bits<4>(a, (hipStream_t)stream) : launch_qgemv_bits<8>(a, (hipStream_t)stream);
+}

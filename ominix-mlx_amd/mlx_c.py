@@ -32,6 +32,14 @@ class mlx_optional_float(ctypes.Structure):
     _fields_ = [("value", c_float), ("has_value", c_bool)]
 
 
+class mlx_optional_int(ctypes.Structure):
+    _fields_ = [("value", c_int), ("has_value", c_bool)]
+
+
+class mlx_optional_dtype(ctypes.Structure):
+    _fields_ = [("value", c_int), ("has_value", c_bool)]
+
+
 BOOL, UINT8, UINT16, UINT32, UINT64, INT8, INT16, INT32, INT64, FLOAT16, FLOAT32, FLOAT64, BFLOAT16, COMPLEX64 = range(14)
 P_ARR, P_INT = ctypes.POINTER(mlx_array), ctypes.POINTER(c_int)
 
@@ -89,6 +97,13 @@ SIGNATURES = {
                                                       mlx_array, mlx_array, mlx_stream]),
     "mlx_matmul": (c_int, [P_ARR, mlx_array, mlx_array, mlx_stream]),
     "mlx_addmm": (c_int, [P_ARR, mlx_array, mlx_array, mlx_array, c_float, c_float, mlx_stream]),
+    "mlx_quantize": (c_int, [ctypes.POINTER(mlx_vector_array), mlx_array, mlx_optional_int, mlx_optional_int, ctypes.c_char_p, mlx_stream]),
+    "mlx_dequantize": (c_int, [P_ARR, mlx_array, mlx_array, mlx_array, mlx_optional_int, mlx_optional_int, ctypes.c_char_p,
+                               mlx_optional_dtype, mlx_stream]),
+    "mlx_quantized_matmul": (c_int, [P_ARR, mlx_array, mlx_array, mlx_array, mlx_array, c_bool, mlx_optional_int, mlx_optional_int,
+                                     ctypes.c_char_p, mlx_stream]),
+    "mlx_gather_qmm": (c_int, [P_ARR, mlx_array, mlx_array, mlx_array, mlx_array, mlx_array, mlx_array, c_bool, mlx_optional_int,
+                               mlx_optional_int, ctypes.c_char_p, c_bool, mlx_stream]),
     "mlx_add": (c_int, [P_ARR, mlx_array, mlx_array, mlx_stream]),
     "mlx_subtract": (c_int, [P_ARR, mlx_array, mlx_array, mlx_stream]),
     "mlx_multiply": (c_int, [P_ARR, mlx_array, mlx_array, mlx_stream]),
@@ -320,6 +335,40 @@ def concatenate_axis(arrays: Sequence[Array], axis: int):
         return Array.op(lib.mlx_concatenate_axis, vec, axis, default_stream())
     finally:
         lib.mlx_vector_array_free(vec)
+
+
+def _oi(v):
+    return mlx_optional_int(int(v) if v is not None else 0, v is not None)
+
+
+def quantize(w: "Array", group_size=None, bits=None):
+    """mlx_rs::ops::quantize -> (w_q, scales, biases) (ops/quantization.rs:41-84)."""
+    vec = lib.mlx_vector_array_new()
+    try:
+        _check(lib.mlx_quantize(ctypes.byref(vec), w.h, _oi(group_size), _oi(bits), b"affine", default_stream()))
+        out = []
+        for i in range(3):
+            h = lib.mlx_array_new()
+            _check(lib.mlx_vector_array_get(ctypes.byref(h), vec, i))
+            out.append(Array(h))
+        return tuple(out)
+    finally:
+        lib.mlx_vector_array_free(vec)
+
+
+def dequantize(w, scales, biases, group_size=None, bits=None):
+    return Array.op(lib.mlx_dequantize, w.h, scales.h, _h(biases), _oi(group_size), _oi(bits), b"affine",
+                    mlx_optional_dtype(0, False), default_stream())
+
+
+def quantized_matmul(x, w, scales, biases, transpose=True, group_size=None, bits=None):
+    return Array.op(lib.mlx_quantized_matmul, x.h, w.h, scales.h, _h(biases), transpose, _oi(group_size), _oi(bits), b"affine",
+                    default_stream())
+
+
+def gather_qmm(x, w, scales, biases, rhs_indices, transpose=True, group_size=None, bits=None, sorted_indices=False):
+    return Array.op(lib.mlx_gather_qmm, x.h, w.h, scales.h, _h(biases), mlx_array(None), rhs_indices.h, transpose, _oi(group_size),
+                    _oi(bits), b"affine", sorted_indices, default_stream())
 
 
 def eval(*arrays) -> None:

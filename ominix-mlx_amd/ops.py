@@ -233,3 +233,46 @@ def argmax(logits: Tensor) -> Tensor:
     out = Tensor(logits.shape[:-1], UINT32)
     check(lib.omx_argmax(out.ptr, logits.ptr, logits.size // n, n, logits.dtype, None))
     return out
+
+
+def quantize(w: Tensor, group_size: int = 64, bits: int = 4):
+    """mlx_rs::ops::quantize (ops/quantization.rs:41-84): w [..., K] -> (packed u32 [..., K*bits/32], scales, biases)."""
+    K = w.shape[-1]
+    rows = w.size // K
+    packed = Tensor(tuple(w.shape[:-1]) + (K * bits // 32,), UINT32)
+    scales = Tensor(tuple(w.shape[:-1]) + (K // group_size,), w.dtype)
+    biases = Tensor(tuple(w.shape[:-1]) + (K // group_size,), w.dtype)
+    check(lib.omx_quantize(packed.ptr, scales.ptr, biases.ptr, w.ptr, rows, K, group_size, bits, w.dtype, None))
+    return packed, scales, biases
+
+
+def dequantize(packed: Tensor, scales: Tensor, biases: Optional[Tensor], group_size: int = 64, bits: int = 4) -> Tensor:
+    """mlx_rs::ops::dequantize (ops/quantization.rs:118-153)."""
+    K = packed.shape[-1] * 32 // bits
+    out = Tensor(tuple(packed.shape[:-1]) + (K,), scales.dtype)
+    check(lib.omx_dequantize(out.ptr, packed.ptr, scales.ptr, _p(biases), out.size // K, K, group_size, bits, scales.dtype, None))
+    return out
+
+
+def quantized_matmul(x: Tensor, packed: Tensor, scales: Tensor, biases: Optional[Tensor], group_size: int = 64,
+                     bits: int = 4) -> Tensor:
+    """x @ dequant(W)^T, transpose=true (nn::QuantizedLinear::forward, nn/quantized.rs:366-375)."""
+    N, K = packed.shape[0], packed.shape[1] * 32 // bits
+    if x.shape[-1] != K:
+        raise OmxError(f"quantized_matmul: input features {x.shape[-1]} != weight in-features {K}")
+    out = Tensor(tuple(x.shape[:-1]) + (N,), x.dtype)
+    check(lib.omx_quantized_matmul(out.ptr, x.ptr, packed.ptr, scales.ptr, _p(biases), x.size // K, N, K, group_size, bits,
+                                   x.dtype, None))
+    return out
+
+
+def gather_qmm(x: Tensor, packed: Tensor, scales: Tensor, biases: Optional[Tensor], rhs_indices: Tensor, x_div: int = 1,
+               group_size: int = 64, bits: int = 4) -> Tensor:
+    """QuantizedSwitchLinear::apply (mixtral-mlx/src/model.rs:195-201): row i uses expert rhs_indices[i] and
+    activation row i // x_div; packed [E, N, K*bits/32]."""
+    E, N, K = packed.shape[0], packed.shape[1], packed.shape[2] * 32 // bits
+    n = rhs_indices.size
+    out = Tensor((n, N), x.dtype)
+    check(lib.omx_gather_qmm(out.ptr, x.ptr, packed.ptr, scales.ptr, _p(biases), rhs_indices.ptr, n, x_div, N, K, E, group_size,
+                             bits, x.dtype, None))
+    return out

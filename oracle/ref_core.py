@@ -409,19 +409,22 @@ def quantize(w, group_size: int = 64, bits: int = 4) -> Tuple[np.ndarray, np.nda
     Bound KAT: ops/quantization.rs:289-305."""
     w = np.asarray(w, dtype=np.float32)
     assert w.shape[-1] % group_size == 0 and (32 % bits) == 0
-    n_bins = float((1 << bits) - 1)
-    g = w.reshape(*w.shape[:-1], w.shape[-1] // group_size, group_size).astype(np.float64)
+    # MLX's affine_quantize works in float32; with symmetric weights edge/scale sits at k + 0.5, so the
+    # precision of this arithmetic decides q0 -- keep every step in float32 like the published kernel
+    f32 = np.float32
+    n_bins = f32((1 << bits) - 1)
+    g = w.reshape(*w.shape[:-1], w.shape[-1] // group_size, group_size)
     w_max = g.max(axis=-1)
     w_min = g.min(axis=-1)
-    eps = 1e-7
+    eps = f32(1e-7)
     mask = np.abs(w_min) > np.abs(w_max)
-    scale = np.maximum((w_max - w_min) / n_bins, eps)
-    scale = np.where(mask, scale, -scale)
-    edge = np.where(mask, w_min, w_max)
-    q0 = np.rint(edge / scale)
-    scale = np.where(q0 != 0, edge / np.where(q0 != 0, q0, 1.0), scale)
-    bias = np.where(q0 == 0, 0.0, edge)
-    q = np.clip(np.rint((g - bias[..., None]) / scale[..., None]), 0, n_bins).astype(np.uint32)
+    scale = np.maximum(((w_max - w_min).astype(f32) / n_bins).astype(f32), eps)
+    scale = np.where(mask, scale, -scale).astype(f32)
+    edge = np.where(mask, w_min, w_max).astype(f32)
+    q0 = np.rint((edge / scale).astype(f32))
+    scale = np.where(q0 != 0, (edge / np.where(q0 != 0, q0, f32(1))).astype(f32), scale).astype(f32)
+    bias = np.where(q0 == 0, f32(0), edge).astype(f32)
+    q = np.clip(np.rint(((g - bias[..., None]).astype(f32) / scale[..., None]).astype(f32)), 0, n_bins).astype(np.uint32)
     q = q.reshape(*w.shape)
     per_word = 32 // bits
     qw = q.reshape(*w.shape[:-1], w.shape[-1] // per_word, per_word)

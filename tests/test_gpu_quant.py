@@ -1,0 +1,133 @@
+"""GPU parity of MLX affine group quantisation against oracle/ref_core.py
+(`quantize`, `dequantize`, `quantized_matmul`; the oracle's quantiser is pinned by the reference's own
+bound KAT, mlx-rs/src/ops/quantization.rs:289-305, in tests/test_oracle_kats.py).
+
+  * quantize:   packed words, scales and biases EQUAL to the oracle's except where an element sits within
+                float rounding of a bin edge (f32 on the device, f64 in the oracle): <= 0.1 % of the
+                4/8-bit fields may differ, and then by exactly one level;
+  * dequantize: bit-exact (one fma per element, one bf16 rounding);
+  * quantized_matmul / gather_qmm: fp32 accumulation in a different order than the oracle's f64 dot, one
+                bf16 rounding of the result: |d| <= 1 bf16 ulp + 4 * 2^-9 * sqrt(sum x_i^2 w_i^2) noise floor.
+"""
+import numpy as np
+import pytest
+
+from oracle import ref_core as rc
+from test_gpu_primitives import assert_bf16_close, rand
+
+pytestmark = pytest.mark.gpu
+
+
+def _unpack(packed, bits):
+    per = 32 // bits
+    shifts = np.arange(per, dtype=np.uint32) * np.uint32(bits)
+    return ((packed[..., None] >> shifts) & np.uint32((1 << bits) - 1)).reshape(*packed.shape[:-1], -1)
+
+
+@pytest.mark.parametrize("bits,group", [(4, 64), (4, 32), (4, 128), (8, 64)])
+def test_quantize_matches_oracle(omx, bits, group):
+    T = omx.ops.Tensor
+    w = rc.bf16_round(rand((96, 512), 300 + bits + group) * 0.1)
+    q, s, b = omx.ops.quantize(T.from_numpy(w), group, bits)
+    rq, rs, rb = rc.quantize(w, group, bits)
+    assert q.shape == rq.shape and s.shape == rs.shape
+    np.testing.assert_array_equal(s.numpy(), rc.bf16_round(rs))
+    np.testing.assert_array_equal(b.numpy(), rc.bf16_round(rb))
+    got, want = _unpack(q.numpy(), bits).astype(np.int64), _unpack(rq, bits).astype(np.int64)
+    diff = got != want
+    assert diff.mean() <= 1e-3 and (np.abs(got - want)[diff] == 1).all()
+    # the reference's own bound (quantization.rs:289-305): max |x - x_hat| <= range / 2^bits per group
+    w_hat = omx.ops.dequantize(q, s, b, group, bits).numpy()
+    g = w.reshape(96, -1, group)
+    rng_ = np.repeat(g.max(-1) - g.min(-1), group, axis=-1)
+    assert (np.abs(w_hat - w) <= rng_ / (1 << bits) + np.abs(w) * 2.0 ** -7 + 1e-6).all()
+
+
+@pytest.mark.parametrize("bits", [4, 8])
+def test_reference_quantize_dequantize_kat_on_device(omx, bits):
+    """mlx-rs/src/ops/quantization.rs:289-305 run through the device kernels: ones[128,1] * arange(512), group 128,
+    shapes [128, 512/el_per_int], [128, 4], [128, 4]; max |x - x_hat| <= 127 / 2^bits (+ the bf16 rounding of x)."""
+    T = omx.ops.Tensor
+    x = rc.bf16_round(np.tile(np.arange(512, dtype=np.float32), (128, 1)))
+    q, s, b = omx.ops.quantize(T.from_numpy(x), 128, bits)
+    assert q.shape == (128, 512 * bits // 32) and s.shape == (128, 4) and b.shape == (128, 4)
+    x_hat = omx.ops.dequantize(q, s, b, 128, bits).numpy()
+    assert np.abs(x - x_hat).max() <= 127.0 / (1 << bits) + 512 * 2.0 ** -8
+
+
+@pytest.mark.parametrize("bits,group", [(4, 64), (8, 64), (4, 128)])
+def test_dequantize_is_exact(omx, bits, group):
+    T = omx.ops.Tensor
+    w = rand((40, 768), 320 + bits) * 0.2
+    rq, rs, rb = rc.quantize(w, group, bits)
+    rs, rb = rc.bf16_round(rs), rc.bf16_round(rb)
+    got = omx.ops.dequantize(T.from_numpy(rq, "u32"), T.from_numpy(rs), T.from_numpy(rb), group, bits).numpy()
+    np.testing.assert_array_equal(got, rc.dequantize(rq, rs, rb, group, bits, "bf16"))
+
+
+def _qmm_case(seed, M, N, K, bits, group):
+    w = rand((N, K), seed) * 0.05
+    rq, rs, rb = rc.quantize(w, group, bits)
+    rs, rb = rc.bf16_round(rs), rc.bf16_round(rb)
+    x = rc.bf16_round(rand((M, K), seed + 1))
+    return x, rq, rs, rb
+
+
+@pytest.mark.parametrize("M,N,K,bits,group", [
+    (1, 1536, 4096, 4, 64),      # decode, 4 words per lane
+    (3, 512, 1024, 4, 64),       # K = 1024: 2 words per lane
+    (2, 256, 512, 4, 64),        # K = 512: 1 word per lane
+    (1, 640, 2048, 8, 64),       # 8-bit
+    (5, 384, 2048, 4, 32),       # group 32
+    (1, 300, 4096, 4, 128),      # ragged N, group 128
+    (70, 512, 1024, 4, 64),      # prefill: dequantise + MFMA GEMM
+])
+def test_quantized_matmul_matches_oracle(omx, M, N, K, bits, group):
+    T = omx.ops.Tensor
+    x, rq, rs, rb = _qmm_case(340 + M + bits, M, N, K, bits, group)
+    got = omx.ops.quantized_matmul(T.from_numpy(x), T.from_numpy(rq, "u32"), T.from_numpy(rs), T.from_numpy(rb), group, bits).numpy()
+    ref = rc.quantized_matmul(x, rq, rs, rb, group, bits, "bf16")
+    w = rc.dequantize(rq, rs, rb, group, bits, "f32")
+    # fp32 accumulation order (GEMV) / weights rounded to bf16 before the MFMA GEMM (M > 16, as MLX's qmm does):
+    # 4 sigma of independent 2^-9 relative perturbations of the K products
+    noise = 4 * 2.0 ** -9 * np.sqrt((x.astype(np.float64) ** 2) @ (w.astype(np.float64) ** 2).T)
+    assert got.shape == ref.shape
+    assert (np.abs(got - ref) <= np.abs(ref) * 2.0 ** -7 + noise + 1e-6).all()
+
+
+def test_gather_qmm_selects_the_expert_per_row(omx):
+    """QuantizedSwitchLinear::apply (mixtral-mlx/src/model.rs:195-201): x [n, 1, K] against rhs_indices [n, k]."""
+    T = omx.ops.Tensor
+    E, N, K, n, k = 4, 256, 1024, 3, 2
+    ws = [rc.quantize(rand((N, K), 360 + e) * 0.05, 64, 4) for e in range(E)]
+    rq = np.stack([w[0] for w in ws]); rs = rc.bf16_round(np.stack([w[1] for w in ws])); rb = rc.bf16_round(np.stack([w[2] for w in ws]))
+    x = rc.bf16_round(rand((n, K), 370))
+    inds = np.array([[0, 3], [2, 2], [1, 0]], np.uint32)
+    got = omx.ops.gather_qmm(T.from_numpy(x), T.from_numpy(rq, "u32"), T.from_numpy(rs), T.from_numpy(rb),
+                             T.from_numpy(inds.reshape(-1), "u32"), x_div=k).numpy().reshape(n, k, N)
+    for t in range(n):
+        for j in range(k):
+            e = int(inds[t, j])
+            ref = rc.quantized_matmul(x[t:t + 1], rq[e], rs[e], rb[e], 64, 4, "bf16")[0]
+            assert_bf16_close(got[t, j], ref, 1, atol=2.0 ** -8 * np.abs(ref).max())
+
+
+def test_mlx_c_quantized_entry_points(omx):
+    """The handle-based ABI (include/omx_mlx_c.h): mlx_quantize -> vector of three arrays, mlx_dequantize,
+    mlx_quantized_matmul with optional group_size / bits (defaults 64 / 4, quantized.rs:330-333), errors."""
+    from ominix_mlx_amd import mlx_c as mx
+    w = rc.bf16_round(rand((128, 512), 380) * 0.1)
+    x = rc.bf16_round(rand((2, 512), 381))
+    wq, s, b = mx.quantize(mx.Array.from_numpy(w))
+    assert wq.shape == (128, 64) and s.shape == (128, 8) and wq.dtype == mx.UINT32
+    rq, rs, rb = rc.quantize(w, 64, 4)
+    np.testing.assert_array_equal(s.numpy(), rc.bf16_round(rs))
+    w_hat = mx.dequantize(wq, s, b).numpy()
+    np.testing.assert_array_equal(w_hat, rc.dequantize(wq.numpy(), s.numpy(), b.numpy(), 64, 4, "bf16"))
+    y = mx.quantized_matmul(mx.Array.from_numpy(x), wq, s, b).numpy()
+    ref = rc.quantized_matmul(x, wq.numpy(), s.numpy(), b.numpy(), 64, 4, "bf16")
+    assert_bf16_close(y, ref, 1, atol=2.0 ** -8 * np.abs(ref).max())
+    with pytest.raises(omx.OmxError, match="transpose"):
+        mx.quantized_matmul(mx.Array.from_numpy(x), wq, s, b, transpose=False)
+    with pytest.raises(omx.OmxError, match="divisible"):
+        mx.quantize(mx.Array.from_numpy(rand((4, 100), 1)))

@@ -300,6 +300,30 @@ int omx_sanm_encoder_layer(void* out, const void* x, const omx_sanm_layer_weight
                            int heads, int ffn_dim, int kernel_size, omx_stream stream);
 int omx_cif_fire(float* frames, int* counts, const float* hidden, const float* alphas, int batch, int T, int H,
                  float threshold, float tail_threshold, int max_frames, omx_stream stream);
+/* SanmEncoder::forward prologue (paraformer.rs:691-703): out bf16 [T, dim] = mel f32 [T, dim] * sqrt(512) + sinusoidal
+ * position encoding (positions 1.., [sin | cos] halves, :418-439) */
+int omx_paraformer_embed(void* out, const float* mel, int T, int dim, omx_stream stream);
+/* CIFPredictor::compute_alphas (:761-768): alphas f32 [T] = sigmoid(Linear_{dim->1}(relu(Conv1d_{k}(enc)))) with the dense
+ * convolution weight in MLX layout [dim_out, k, dim_in]; also writes enc as f32 (the hidden CIF integrates)           */
+int omx_cif_alphas(float* alphas, float* hidden_f32, const void* enc, const void* conv_w, const void* conv_b,
+                   const void* proj_w, const void* proj_b, int T, int dim, int kernel_size, omx_stream stream);
+/* ParaformerDecoderLayer::forward (:1030-1053) incl. cross_attention (:981-1017): x [N, dim] acoustic embeddings,
+ * enc [Ts, enc_dim] encoder output, both bf16; FFN down has no bias (loader :1421)                                    */
+typedef struct omx_paraformer_decoder_weights_ {
+    const void *norm1_w, *norm1_b, *ffn_up_w, *ffn_up_b, *ffn_norm_w, *ffn_norm_b, *ffn_down_w, *norm2_w, *norm2_b, *fsmn_w,
+        *norm3_w, *norm3_b, *q_w, *q_b, *kv_w, *kv_b, *out_w, *out_b;
+} omx_paraformer_decoder_weights;
+int omx_paraformer_decoder_layer(void* out, const void* x, const void* enc, const omx_paraformer_decoder_weights* w, int N,
+                                 int Ts, int dim, int enc_dim, int heads, int ffn_dim, int kernel_size, omx_stream stream);
+/* ParaformerDecoder::forward tail (:1157-1165): LN -> Linear+ReLU -> LN(ffn) -> Linear(no bias) -> LN -> output_proj;
+ * logits bf16 [N, vocab]                                                                                               */
+typedef struct omx_paraformer_tail_weights_ {
+    const void *norm1_w, *norm1_b, *up_w, *up_b, *ffn_norm_w, *ffn_norm_b, *down_w, *after_norm_w, *after_norm_b, *out_w, *out_b;
+} omx_paraformer_tail_weights;
+int omx_paraformer_decoder_tail(void* logits, const void* x, const omx_paraformer_tail_weights* w, int N, int dim, int ffn_dim,
+                                int vocab, omx_stream stream);
+/* elementwise dtype conversion between bf16 / f16 / f32 device buffers (Array::as_dtype) */
+int omx_cast(void* dst, omx_dtype dst_dtype, const void* src, omx_dtype src_dtype, int64_t n, omx_stream stream);
 
 #ifdef __cplusplus
 }

@@ -1,5 +1,6 @@
-"""Host mirror of funasr-mlx's `SanmEncoderLayer` (paraformer.rs:573-640) and `CIFPredictor::cif_fire`
-(:779-879) over omx_sanm_encoder_layer / omx_cif_fire."""
+"""Host mirror of funasr-mlx's Paraformer (paraformer.rs): `SanmEncoderLayer` (:573-640), `SanmEncoder` (:646-717),
+`CIFPredictor` (:723-889), `ParaformerDecoderLayer` (:900-1068), `ParaformerDecoder` (:1071-1180) and
+`Paraformer::transcribe_from_mel` (:1236-1256) over the fused entry points of csrc/paraformer.hip."""
 from __future__ import annotations
 
 import ctypes
@@ -18,7 +19,26 @@ class SanmLayerWeights(ctypes.Structure):
     _fields_ = [(n, c_void_p) for n in _FIELDS]
 
 
+_DEC_FIELDS = ("norm1_w", "norm1_b", "ffn_up_w", "ffn_up_b", "ffn_norm_w", "ffn_norm_b", "ffn_down_w", "norm2_w", "norm2_b", "fsmn_w",
+               "norm3_w", "norm3_b", "q_w", "q_b", "kv_w", "kv_b", "out_w", "out_b")
+_TAIL_FIELDS = ("norm1_w", "norm1_b", "up_w", "up_b", "ffn_norm_w", "ffn_norm_b", "down_w", "after_norm_w", "after_norm_b", "out_w", "out_b")
+
+
+class DecoderLayerWeights(ctypes.Structure):
+    _fields_ = [(n, c_void_p) for n in _DEC_FIELDS]
+
+
+class TailWeights(ctypes.Structure):
+    _fields_ = [(n, c_void_p) for n in _TAIL_FIELDS]
+
+
 PARAFORMER_SIGNATURES = {
+    "omx_paraformer_embed": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "omx_cif_alphas": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "omx_paraformer_decoder_layer": (c_int, [c_void_p, c_void_p, c_void_p, ctypes.POINTER(DecoderLayerWeights), c_int, c_int, c_int,
+                                             c_int, c_int, c_int, c_int, c_void_p]),
+    "omx_paraformer_decoder_tail": (c_int, [c_void_p, c_void_p, ctypes.POINTER(TailWeights), c_int, c_int, c_int, c_int, c_void_p]),
+    "omx_cast": (c_int, [c_void_p, c_int, c_void_p, c_int, ctypes.c_int64, c_void_p]),
     "omx_sanm_encoder_layer": (c_int, [c_void_p, c_void_p, ctypes.POINTER(SanmLayerWeights), c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "omx_cif_fire": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_float, c_int, c_void_p]),
 }
@@ -56,3 +76,117 @@ def cif_fire(hidden: Tensor, alphas: Tensor, threshold: float = 1.0, tail_thresh
     cnt = counts.numpy().astype(np.int32)
     mx = int(cnt.max()) if B else 0
     return frames.numpy()[:, :mx], cnt
+
+
+DEFAULT_CONFIG = dict(n_mels=80, lfr_m=7, lfr_n=6, encoder_dim=512, encoder_layers=50, encoder_heads=4, encoder_ffn_dim=2048,
+                      decoder_dim=512, decoder_layers=16, decoder_heads=4, decoder_ffn_dim=2048, vocab_size=8404,
+                      sanm_kernel_size=11, cif_l_order=1, cif_r_order=1, cif_threshold=1.0, cif_tail_threshold=0.45)   # :110-145
+
+
+def _cast(x: Tensor, dtype) -> Tensor:
+    out = Tensor(x.shape, dtype)
+    check(lib.omx_cast(out.ptr, out.dtype, x.ptr, x.dtype, x.size, None))
+    return out
+
+
+class Paraformer:
+    """Encoder -> CIF predictor -> decoder of one utterance on one GPU (the frontend is audio.MelFrontend).
+    `weights`: the checkpoint dict the reference's loader reads (load_paraformer_weights, :1300-1477), conv
+    weights in the PyTorch layout it transposes (:1293-1298)."""
+
+    def __init__(self, weights: dict, config: dict = None):
+        self.cfg = dict(DEFAULT_CONFIG, **(config or {}))
+        c, self._keep = self.cfg, []
+        if c["cif_l_order"] != c["cif_r_order"]:
+            raise ValueError("CIF asymmetric padding (l_order != r_order) not yet supported")   # :736-740
+
+        def dev(key, transform=None):
+            if key not in weights:
+                raise KeyError(f"Missing weight: {key}")                                       # get_weight, :1287-1291
+            a = np.asarray(weights[key])
+            t = Tensor.from_numpy(transform(a) if transform else a, "bf16")
+            self._keep.append(t)
+            return t.ptr
+
+        depthwise = lambda a: a[:, 0, :]                                  # [C, 1, k] -> [C, k]
+        dense_conv = lambda a: np.ascontiguousarray(a.transpose(0, 2, 1))  # [out, in, k] -> [out, k, in]
+
+        def enc_layer(p):
+            return SanmLayerWeights(dev(f"{p}.norm1.weight"), dev(f"{p}.norm1.bias"), dev(f"{p}.self_attn.linear_q_k_v.weight"),
+                                    dev(f"{p}.self_attn.linear_q_k_v.bias"), dev(f"{p}.self_attn.out_proj.weight"),
+                                    dev(f"{p}.self_attn.out_proj.bias"), dev(f"{p}.self_attn.fsmn_block.weight", depthwise),
+                                    dev(f"{p}.norm2.weight"), dev(f"{p}.norm2.bias"), dev(f"{p}.ffn.up_proj.weight"),
+                                    dev(f"{p}.ffn.up_proj.bias"), dev(f"{p}.ffn.down_proj.weight"), dev(f"{p}.ffn.down_proj.bias"))
+
+        self.enc_layers = [enc_layer("encoder.encoders0.0")] + [enc_layer(f"encoder.layers.{i}") for i in range(c["encoder_layers"] - 1)]
+        self.after_norm = (dev("encoder.after_norm.weight"), dev("encoder.after_norm.bias"))
+        self.pred = (dev("predictor.conv.weight", dense_conv), dev("predictor.conv.bias"), dev("predictor.output_proj.weight"),
+                     dev("predictor.output_proj.bias"))
+        self.dec_layers = []
+        for i in range(c["decoder_layers"]):
+            p = f"decoder.layers.{i}"
+            self.dec_layers.append(DecoderLayerWeights(
+                dev(f"{p}.norm1.weight"), dev(f"{p}.norm1.bias"), dev(f"{p}.ffn.up_proj.weight"), dev(f"{p}.ffn.up_proj.bias"),
+                dev(f"{p}.feed_forward.norm.weight"), dev(f"{p}.feed_forward.norm.bias"), dev(f"{p}.ffn.down_proj.weight"),
+                dev(f"{p}.norm2.weight"), dev(f"{p}.norm2.bias"), dev(f"{p}.self_attn.fsmn_block.weight", depthwise),
+                dev(f"{p}.norm3.weight"), dev(f"{p}.norm3.bias"), dev(f"{p}.src_attn.q_proj.weight"), dev(f"{p}.src_attn.q_proj.bias"),
+                dev(f"{p}.src_attn.linear_k_v.weight"), dev(f"{p}.src_attn.linear_k_v.bias"), dev(f"{p}.src_attn.out_proj.weight"),
+                dev(f"{p}.src_attn.out_proj.bias")))
+        t = "decoder.decoders3.0"
+        self.tail = TailWeights(dev(f"{t}.norm1.weight"), dev(f"{t}.norm1.bias"), dev(f"{t}.ffn.up_proj.weight"), dev(f"{t}.ffn.up_proj.bias"),
+                                dev(f"{t}.feed_forward.norm.weight"), dev(f"{t}.feed_forward.norm.bias"), dev(f"{t}.ffn.down_proj.weight"),
+                                dev("decoder.after_norm.weight"), dev("decoder.after_norm.bias"), dev("decoder.output_proj.weight"),
+                                dev("decoder.output_proj.bias"))
+
+    def encode(self, mel: Tensor) -> Tensor:
+        """SanmEncoder::forward (:691-708): mel f32 [T, n_mels*lfr_m] (device) -> encoder_out bf16 [T, encoder_dim]."""
+        from .ops import layer_norm
+        c = self.cfg
+        T, in0 = mel.shape[-2], c["n_mels"] * c["lfr_m"]
+        h = Tensor((T, in0), "bf16")
+        check(lib.omx_paraformer_embed(h.ptr, mel.ptr, T, in0, None))
+        in_dim = in0
+        for w in self.enc_layers:
+            out = Tensor((T, c["encoder_dim"]), "bf16")
+            check(lib.omx_sanm_encoder_layer(out.ptr, h.ptr, ctypes.byref(w), T, in_dim, c["encoder_dim"], c["encoder_heads"],
+                                             c["encoder_ffn_dim"], c["sanm_kernel_size"], None))
+            h, in_dim = out, c["encoder_dim"]
+        out = Tensor(h.shape, "bf16")
+        check(lib.omx_layer_norm(out.ptr, h.ptr, self.after_norm[0], self.after_norm[1], T, c["encoder_dim"], 1e-5, out.dtype, None))
+        return out
+
+    def predict(self, enc: Tensor):
+        """CIFPredictor::forward (:883-889): -> (acoustic_embeds f32 [N, E] device Tensor or None, N, alphas Tensor)."""
+        c = self.cfg
+        T, E = enc.shape
+        alphas, hidden = Tensor((1, T), FLOAT32), Tensor((1, T, E), FLOAT32)
+        check(lib.omx_cif_alphas(alphas.ptr, hidden.ptr, enc.ptr, *self.pred, T, E, c["cif_l_order"] + c["cif_r_order"] + 1, None))
+        frames = Tensor((1, T + 1, E), FLOAT32)
+        counts = Tensor((1,), "u32")
+        check(lib.omx_cif_fire(frames.ptr, counts.ptr, hidden.ptr, alphas.ptr, 1, T, E, c["cif_threshold"], c["cif_tail_threshold"], T + 1, None))
+        n = int(counts.numpy()[0])
+        return (frames.slice_rows(0, (n, E)) if n else None), n, alphas
+
+    def decode(self, embeds: Tensor, enc: Tensor) -> Tensor:
+        """ParaformerDecoder::forward (:1144-1166): acoustic_embeds f32 [N, D] -> logits bf16 [N, vocab]."""
+        c = self.cfg
+        N, Ts = embeds.shape[0], enc.shape[0]
+        x = _cast(embeds, "bf16")
+        for w in self.dec_layers:
+            out = Tensor((N, c["decoder_dim"]), "bf16")
+            check(lib.omx_paraformer_decoder_layer(out.ptr, x.ptr, enc.ptr, ctypes.byref(w), N, Ts, c["decoder_dim"], c["encoder_dim"],
+                                                   c["decoder_heads"], c["decoder_ffn_dim"], c["sanm_kernel_size"], None))
+            x = out
+        logits = Tensor((N, c["vocab_size"]), "bf16")
+        check(lib.omx_paraformer_decoder_tail(logits.ptr, x.ptr, ctypes.byref(self.tail), N, c["decoder_dim"], c["decoder_ffn_dim"],
+                                              c["vocab_size"], None))
+        return logits
+
+    def transcribe_from_mel(self, mel: Tensor):
+        """Paraformer::transcribe_from_mel (:1236-1256): -> (token ids np.int32 [N], N)."""
+        from .ops import argmax
+        enc = self.encode(mel)
+        embeds, n, _ = self.predict(enc)
+        if n == 0:
+            return np.zeros(0, np.int32), 0
+        return argmax(self.decode(embeds, enc)).numpy().astype(np.int32), n

@@ -44,3 +44,76 @@ def test_cif_fire_matches_oracle(omx):
     frames, counts = paraformer.cif_fire(T_.from_numpy(hidden, "f32"), T_.from_numpy(alphas, "f32"))
     np.testing.assert_array_equal(counts, ref_counts)
     np.testing.assert_allclose(frames, ref_frames, rtol=1e-5, atol=1e-5)
+
+
+TINY = dict(n_mels=80, lfr_m=7, encoder_dim=512, encoder_layers=3, encoder_heads=4, encoder_ffn_dim=1024, decoder_dim=512,
+            decoder_layers=2, decoder_heads=4, decoder_ffn_dim=1024, vocab_size=640, sanm_kernel_size=11, cif_l_order=1,
+            cif_r_order=1, cif_threshold=1.0, cif_tail_threshold=0.45)
+
+
+@pytest.mark.parametrize("N,Ts", [(1, 40), (23, 120), (140, 501)])
+def test_decoder_layer_matches_oracle(omx, N, Ts):
+    """ParaformerDecoderLayer::forward incl. cross-attention over the encoder output (Tq != Tk)."""
+    import ctypes
+    from ominix_mlx_amd import paraformer
+    T = omx.ops.Tensor
+    w = rp.synth_checkpoint(TINY, 7)
+    p = rp._dec_params(w, "decoder.layers.1")
+    g = np.random.default_rng(8)
+    x = rc.bf16_round(g.standard_normal((N, 512)).astype(np.float32))
+    enc = rc.bf16_round(g.standard_normal((Ts, 512)).astype(np.float32))
+    ref = rp.decoder_layer(x, enc, p, 4)
+    dev = {k: T.from_numpy(np.ascontiguousarray(v)) for k, v in p.items()}
+    ws = paraformer.DecoderLayerWeights(*[dev[k].ptr for k in paraformer._DEC_FIELDS])
+    out, xd, ed = T((N, 512), "bf16"), T.from_numpy(x), T.from_numpy(enc)      # keep the device buffers alive over the async launch
+    omx.check(omx.lib.omx_paraformer_decoder_layer(out.ptr, xd.ptr, ed.ptr, ctypes.byref(ws), N, Ts, 512, 512, 4, 1024, 11, None))
+    got = out.numpy()
+    assert np.abs(got - ref).max() <= 2.0 ** -6 * np.abs(ref).max()
+
+
+def test_predictor_alphas_and_position_encoding_match_oracle(omx):
+    from ominix_mlx_amd import paraformer
+    T = omx.ops.Tensor
+    w = rp.synth_checkpoint(TINY, 9)
+    g = np.random.default_rng(10)
+    mel = (g.standard_normal((57, 560)) * 0.5).astype(np.float32)
+    h, mel_d = T((57, 560), "bf16"), T.from_numpy(mel, "f32")
+    omx.check(omx.lib.omx_paraformer_embed(h.ptr, mel_d.ptr, 57, 560, None))
+    ref_h = rp.encoder_embed(mel)
+    assert np.abs(h.numpy() - ref_h).max() <= 2.0 ** -7 * np.abs(ref_h).max()
+    enc = rc.bf16_round(g.standard_normal((57, 512)).astype(np.float32))
+    conv_w = np.ascontiguousarray(w["predictor.conv.weight"].transpose(0, 2, 1))
+    alphas, hidden = T((57,), "f32"), T((57, 512), "f32")
+    dev = [T.from_numpy(a) for a in (enc, conv_w, w["predictor.conv.bias"], w["predictor.output_proj.weight"], w["predictor.output_proj.bias"])]
+    omx.check(omx.lib.omx_cif_alphas(alphas.ptr, hidden.ptr, *[d.ptr for d in dev], 57, 512, 3, None))
+    ref_a = rp.predictor_alphas(enc, conv_w, w["predictor.conv.bias"], w["predictor.output_proj.weight"], w["predictor.output_proj.bias"])
+    np.testing.assert_array_equal(hidden.numpy(), enc)
+    assert np.abs(alphas.numpy() - ref_a).max() <= 2.0 ** -7
+
+
+def test_tiny_paraformer_end_to_end_matches_oracle(omx):
+    """Paraformer::transcribe_from_mel on a 3+2-layer model with the reference's checkpoint keys: encoder output,
+    CIF token count, logits and token ids against the float64 restatement.  bf16 activations: encoder output
+    within 2^-6 * max * sqrt(layers); CIF fires the same number of tokens when no integrate value sits within that
+    error of the threshold; token ids equal wherever the oracle's top-2 margin exceeds twice the logit bound."""
+    from ominix_mlx_amd import paraformer
+    T = omx.ops.Tensor
+    w = rp.synth_checkpoint(TINY, 11)
+    mel = (np.random.default_rng(12).standard_normal((83, 560)) * 0.5).astype(np.float32)
+    ref_tok, ref_logits, ref_enc, ref_alphas, ref_emb = rp.transcribe_from_mel(mel, w, TINY)
+    m = paraformer.Paraformer(w, TINY)
+    enc = m.encode(T.from_numpy(mel, "f32"))
+    assert np.abs(enc.numpy() - ref_enc).max() <= 2.0 ** -6 * np.abs(ref_enc).max() * np.sqrt(TINY["encoder_layers"])
+    emb, n, alphas = m.predict(enc)
+    assert np.abs(alphas.numpy()[0] - ref_alphas).max() <= 2.0 ** -5
+    assert n == len(ref_tok), f"CIF fired {n} tokens, oracle {len(ref_tok)}"
+    logits = m.decode(emb, enc).numpy()
+    bound = 2.0 ** -5 * np.abs(ref_logits).max() * np.sqrt(TINY["decoder_layers"] + 1)
+    assert np.abs(logits - ref_logits).max() <= bound
+    tok, n2 = m.transcribe_from_mel(T.from_numpy(mel, "f32"))
+    assert n2 == n
+    margins = rc.argmax_margin(ref_logits)
+    safe = margins > 2 * bound
+    np.testing.assert_array_equal(tok[safe], ref_tok[safe])
+    with pytest.raises(KeyError, match="Missing weight"):
+        paraformer.Paraformer({k: v for k, v in w.items() if k != "decoder.after_norm.bias"}, TINY)

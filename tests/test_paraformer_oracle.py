@@ -36,3 +36,21 @@ def test_fsmn_is_centered_depthwise_conv():
     out = rp.fsmn(v, w)
     np.testing.assert_array_equal(out[:, 0], [0, 0, 0, 3, 2, 1, 0, 0, 0])      # correlation, not convolution (as Conv1d)
     np.testing.assert_array_equal(out[:, 1], v[:, 1])
+
+
+def test_position_encoding_and_model_wiring():
+    """paraformer.rs:418-439 (positions start at 1, [sin | cos]) and the reference's own shape tests (:1592-1610):
+    PE [100, 512]; a tiny model with the reference's checkpoint keys runs end to end."""
+    from oracle import ref_paraformer as rp
+    pe = rp.position_encoding(100, 512)
+    assert pe.shape == (100, 512)
+    assert abs(pe[0, 0] - np.sin(1.0)) < 1e-6 and abs(pe[0, 256] - np.cos(1.0)) < 1e-6
+    assert abs(pe[4, 255] - np.sin(5.0 * 1e-4)) < 1e-6                      # last timescale = 1/10000
+    cfg = dict(n_mels=80, lfr_m=7, encoder_dim=128, encoder_layers=2, encoder_heads=1, encoder_ffn_dim=256, decoder_dim=128,
+               decoder_layers=1, decoder_heads=1, decoder_ffn_dim=256, vocab_size=50, sanm_kernel_size=11, cif_l_order=1,
+               cif_r_order=1, cif_threshold=1.0, cif_tail_threshold=0.45)
+    w = rp.synth_checkpoint(cfg, 1)
+    assert w["predictor.conv.weight"].shape == (128, 128, 3) and w["encoder.encoders0.0.self_attn.fsmn_block.weight"].shape == (128, 1, 11)
+    tok, logits, enc, alphas, emb = rp.transcribe_from_mel(np.random.default_rng(2).standard_normal((30, 560)) * 0.5, w, cfg)
+    assert enc.shape == (30, 128) and logits.shape == (len(tok), 50) and emb.shape == (len(tok), 128)
+    assert abs(len(tok) - alphas.sum()) < 1.0                               # CIF emits ~ sum(alphas) tokens

@@ -190,3 +190,59 @@ class Paraformer:
         if n == 0:
             return np.zeros(0, np.int32), 0
         return argmax(self.decode(embeds, enc)).numpy().astype(np.int32), n
+
+
+def checkpoint_shapes(cfg: dict) -> dict:
+    E, F, D, G, V, k = cfg["encoder_dim"], cfg["encoder_ffn_dim"], cfg["decoder_dim"], cfg["decoder_ffn_dim"], cfg["vocab_size"], cfg["sanm_kernel_size"]
+    in0 = cfg["n_mels"] * cfg["lfr_m"]
+    ck = cfg["cif_l_order"] + cfg["cif_r_order"] + 1
+    s = {}
+
+    def enc_layer(prefix, in_dim):
+        s.update({f"{prefix}.self_attn.linear_q_k_v.weight": (3 * E, in_dim), f"{prefix}.self_attn.linear_q_k_v.bias": (3 * E,),
+                  f"{prefix}.self_attn.out_proj.weight": (E, E), f"{prefix}.self_attn.out_proj.bias": (E,),
+                  f"{prefix}.self_attn.fsmn_block.weight": (E, 1, k),
+                  f"{prefix}.ffn.up_proj.weight": (F, E), f"{prefix}.ffn.up_proj.bias": (F,),
+                  f"{prefix}.ffn.down_proj.weight": (E, F), f"{prefix}.ffn.down_proj.bias": (E,),
+                  f"{prefix}.norm1.weight": (in_dim,), f"{prefix}.norm1.bias": (in_dim,),
+                  f"{prefix}.norm2.weight": (E,), f"{prefix}.norm2.bias": (E,)})
+
+    enc_layer("encoder.encoders0.0", in0)
+    for i in range(cfg["encoder_layers"] - 1):
+        enc_layer(f"encoder.layers.{i}", E)
+    s.update({"encoder.after_norm.weight": (E,), "encoder.after_norm.bias": (E,),
+              "predictor.conv.weight": (E, E, ck), "predictor.conv.bias": (E,),
+              "predictor.output_proj.weight": (1, E), "predictor.output_proj.bias": (1,)})
+    for i in range(cfg["decoder_layers"]):
+        p = f"decoder.layers.{i}"
+        s.update({f"{p}.self_attn.fsmn_block.weight": (D, 1, k),
+                  f"{p}.src_attn.q_proj.weight": (D, D), f"{p}.src_attn.q_proj.bias": (D,),
+                  f"{p}.src_attn.linear_k_v.weight": (2 * D, E), f"{p}.src_attn.linear_k_v.bias": (2 * D,),
+                  f"{p}.src_attn.out_proj.weight": (D, D), f"{p}.src_attn.out_proj.bias": (D,),
+                  f"{p}.ffn.up_proj.weight": (G, D), f"{p}.ffn.up_proj.bias": (G,), f"{p}.ffn.down_proj.weight": (D, G),
+                  f"{p}.feed_forward.norm.weight": (G,), f"{p}.feed_forward.norm.bias": (G,)})
+        for n in ("norm1", "norm2", "norm3"):
+            s.update({f"{p}.{n}.weight": (D,), f"{p}.{n}.bias": (D,)})
+    t = "decoder.decoders3.0"
+    s.update({f"{t}.norm1.weight": (D,), f"{t}.norm1.bias": (D,), f"{t}.ffn.up_proj.weight": (G, D), f"{t}.ffn.up_proj.bias": (G,),
+              f"{t}.feed_forward.norm.weight": (G,), f"{t}.feed_forward.norm.bias": (G,), f"{t}.ffn.down_proj.weight": (D, G),
+              "decoder.after_norm.weight": (D,), "decoder.after_norm.bias": (D,),
+              "decoder.output_proj.weight": (V, D), "decoder.output_proj.bias": (V,)})
+    return s
+
+
+def random_checkpoint(cfg: dict = None, seed: int = 3) -> dict:
+    """Synthetic checkpoint with the reference's keys and layouts (benchmarks; there is no network for real weights)."""
+    cfg = dict(DEFAULT_CONFIG, **(cfg or {}))
+    g = np.random.default_rng(seed)
+    out = {}
+    for name, shape in checkpoint_shapes(cfg).items():
+        if name.endswith("norm.weight") or any(f".{n}.weight" in name for n in ("norm1", "norm2", "norm3")):
+            a = 1.0 + 0.05 * g.standard_normal(shape)
+        elif name.endswith(".bias"):
+            a = 0.05 * g.standard_normal(shape)
+        else:
+            a = g.standard_normal(shape) / np.sqrt(int(np.prod(shape[1:])))
+        out[name] = a.astype(np.float32)
+    out["predictor.output_proj.bias"] = np.array([0.3], np.float32)
+    return out

@@ -7,10 +7,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import omx_import
 omx = omx_import.load_package()
 from ominix_mlx_amd import audio, paraformer
-from oracle import ref_paraformer as rp          # checkpoint generator only (test infrastructure)
 
 cfg = dict(paraformer.DEFAULT_CONFIG)
-w = rp.synth_checkpoint(cfg, 3)
+w = paraformer.random_checkpoint(cfg, 3)
 m = paraformer.Paraformer(w, cfg)
 sr, secs = 16000, 30
 g = np.random.default_rng(0)

@@ -19,6 +19,8 @@
 // Fallback (any K, any alignment): register-staged 64x64x32 tiles with zero fill.
 #include "gemm.hpp"
 
+#include <stdlib.h>
+
 namespace omx {
 namespace {
 
@@ -170,6 +172,198 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_nt_kernel(const GemmArgs a
         }
 }
 
+
+// ---- 256 x 256 x 64 tile, 8 waves, one block per CU: the deep-pipelined form for large GEMMs ----
+// (cdna_hip_programming.md "256^2 8-phase": the 128^2 / one-barrier-per-K-step structure above tops out near
+// 0.9 PF because every wave pays ~8 LDS-DMA issues per 16 MFMAs; here a wave owns 128 x 64 of the output, so
+// the same 8 issues buy 32 MFMAs, and the K step is cut into 4 phases -- one 64 x 32 quadrant of the wave's
+// tile each -- with the staging of the NEXT tile spread over them, two LDS-DMA instructions per phase.)
+//
+//   LDS (128 KiB): 2 buffers x {A rows 0-127 | A rows 128-255 | B cols 0-127 | B cols 128-255}, 16 KiB each,
+//   every half-tile [128 rows][64 k] with the same source-side XOR swizzle as above.
+//   wave (wr, wc) = (wave >> 2, wave & 3) reads A half wr and B half wc >> 1.
+//   phase 1: read A rows 0-63 + B cols 0-31, stage B-half-1 of tile t+1, MFMA quadrant (0,0)
+//   phase 2: read B cols 32-63,              stage A-half-0 of tile t+1, MFMA quadrant (0,1)
+//   phase 3: read A rows 64-127,             stage A-half-1 of tile t+1, MFMA quadrant (1,1)
+//   phase 4:                                 stage B-half-0 of tile t+2, vmcnt(2), MFMA quadrant (1,0)
+//   Each phase is {reads + staging; barrier; MFMAs at raised priority; barrier}; the wr = 1 waves run one
+//   barrier behind the wr = 0 waves, so on every SIMD one wave issues loads while the other feeds the
+//   matrix core.  Hazards: a half-tile is re-staged at least two barriers after its last ds_read by either
+//   wave group (B halves are read in phases 1-2, A halves in phases 1 and 3), and it is read at least one
+//   barrier after the counted vmcnt that retires it (phase 4 of the previous tile, both wave groups).
+namespace big {
+constexpr int TM = 256, TN = 256, TK = 64, NT = 512;
+constexpr int HALF = 128 * TK * 2;           // bytes per half-tile
+constexpr int BUF = 4 * HALF;                // A0 | A1 | B0 | B1
+constexpr int SMEM = 2 * BUF;
+}  // namespace big
+
+#define OMX_BAR() asm volatile("s_barrier" ::: "memory")
+
+// MF = 16: v_mfma_f32_16x16x32_bf16, eight independent accumulators per k step inside a phase (a dependent MFMA is
+// eight issues away); MF = 32: v_mfma_f32_32x32x16_bf16, two accumulators per phase (bit-identical to the 128^2 kernel)
+template <int MF>
+__global__ __launch_bounds__(big::NT) void gemm_bf16_nt_256_kernel(const GemmArgs a) {
+    using namespace big;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wr = wave >> 2, wc = wave & 3;
+    // XCD-aware remap (bijective form)
+    const int nblk = a.grid_m * a.grid_n;
+    int bid = blockIdx.x;
+    {
+        const int q = nblk / 8, r = nblk % 8, xcd = bid % 8, idx = bid / 8;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int m0 = (bid / a.grid_n) * TM, n0 = (bid % a.grid_n) * TN;
+    const int nt = a.K / TK;
+
+    // staging sources: thread handles chunks c = i * 512 + tid (i = 0, 1) of every half-tile
+    const bf16_t* srcA[2][2];
+    const bf16_t* srcB[2][2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int c = i * NT + threadIdx.x;
+            const int row = c >> 3;
+            const int kc = (c & 7) ^ (row & 7);
+            srcA[h][i] = a.x + (size_t)min(m0 + h * 128 + row, a.M - 1) * a.K + kc * 8;
+            srcB[h][i] = a.w + (size_t)min(n0 + h * 128 + row, a.N - 1) * a.K + kc * 8;
+        }
+    auto stage = [&](const bf16_t* const (&src)[2], int k0, unsigned char* half) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(src[i] + k0), (lds_ptr_t)(half + (i * NT + wave * 64) * 16), 16, 0, 0);
+    };
+
+    // accumulators: MF = 32 -> [4][2] tiles of 32x32 (16 regs each); MF = 16 -> [8][4] tiles of 16x16 (4 regs each)
+    constexpr int RT = 128 / MF, CT = 64 / MF, AR = MF * MF / 64;   // row tiles, col tiles, registers per tile
+    constexpr int KS = TK / (MF == 32 ? 16 : 32);                     // MFMA k steps per K tile
+    constexpr int KCH = MF == 32 ? 2 : 4;                            // 16-B chunks per k step
+    constexpr int LR = MF == 32 ? 31 : 15;                           // lane -> row mask
+    constexpr int LS = MF == 32 ? 5 : 4;                             // lane -> k chunk shift
+    typedef float accv __attribute__((ext_vector_type(AR)));
+    accv acc[RT][CT];
+#pragma unroll
+    for (int i = 0; i < RT; ++i)
+#pragma unroll
+        for (int j = 0; j < CT; ++j)
+#pragma unroll
+            for (int r = 0; r < AR; ++r) acc[i][j][r] = 0.f;
+
+    // prologue: tile 0 entirely, B-half-0 of tile 1
+    stage(srcA[0], 0, smem);
+    stage(srcA[1], 0, smem + HALF);
+    stage(srcB[0], 0, smem + 2 * HALF);
+    stage(srcB[1], 0, smem + 3 * HALF);
+    if (nt > 1) {
+        stage(srcB[0], TK, smem + BUF + 2 * HALF);
+        asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    OMX_BAR();
+    if (wr == 1) OMX_BAR();   // the two wave groups run one barrier apart from here on
+
+    constexpr int RQ = RT / 2, CQ = CT / 2;   // tiles per quadrant
+    bf16x8 fa[RQ][KS], fb[2][CQ][KS];
+    const int arow = lane & LR, kh = lane >> LS;
+    auto mfma = [&](const bf16x8& x, const bf16x8& y, accv& c) {
+        if constexpr (MF == 32) c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, c, 0, 0, 0);
+        else c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x, y, c, 0, 0, 0);
+    };
+    auto quadrant = [&](int qm, int qn) {
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int i = 0; i < RQ; ++i)
+#pragma unroll
+                for (int j = 0; j < CQ; ++j) mfma(fa[i][ks], fb[qn][j][ks], acc[qm * RQ + i][qn * CQ + j]);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    for (int t = 0; t < nt; ++t) {
+        unsigned char* cur = smem + (t & 1) * BUF;
+        unsigned char* nxt = smem + ((t + 1) & 1) * BUF;
+        const unsigned char* hA = cur + wr * HALF;
+        const unsigned char* hB = cur + (2 + (wc >> 1)) * HALF;
+        const int bcol = (wc & 1) * 64;
+        const bool has1 = t + 1 < nt, has2 = t + 2 < nt;
+        const int k1 = (t + 1) * TK;
+        auto read_a = [&](int sub) {
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int i = 0; i < RQ; ++i) fa[i][ks] = lds_frag(hA, sub * 64 + i * MF + arow, ks * KCH + kh);
+        };
+        auto read_b = [&](int sub) {
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int j = 0; j < CQ; ++j) fb[sub][j][ks] = lds_frag(hB, bcol + sub * 32 + j * MF + arow, ks * KCH + kh);
+        };
+
+        // ---- phase 1 ----
+        read_b(0);
+        read_a(0);
+        if (has1) stage(srcB[1], k1, nxt + 3 * HALF);
+        OMX_BAR();
+        quadrant(0, 0);
+        OMX_BAR();
+        // ---- phase 2 ----
+        read_b(1);
+        if (has1) stage(srcA[0], k1, nxt);
+        OMX_BAR();
+        quadrant(0, 1);
+        OMX_BAR();
+        // ---- phase 3 ----
+        read_a(1);
+        if (has1) stage(srcA[1], k1, nxt + HALF);
+        OMX_BAR();
+        quadrant(1, 1);
+        OMX_BAR();
+        // ---- phase 4 ----
+        if (has2) {
+            stage(srcB[0], (t + 2) * TK, cur + 2 * HALF);
+            asm volatile("s_waitcnt vmcnt(2)" ::: "memory");   // everything of tile t+1 has landed
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        OMX_BAR();
+        quadrant(1, 0);
+        OMX_BAR();
+    }
+    if (wr == 0) OMX_BAR();   // pairs with the extra barrier of the wr = 1 waves
+
+    // epilogue.  C/D layouts: 32x32 -> col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    //                         16x16 -> col = lane & 15, row = 4 * (lane >> 4) + r
+#pragma unroll
+    for (int i = 0; i < RT; ++i)
+#pragma unroll
+        for (int j = 0; j < CT; ++j) {
+            const int col = n0 + wc * 64 + j * MF + (lane & LR);
+            if (col >= a.N) continue;
+            const float bv = a.bias ? bf16_to_f32(a.bias[col]) : 0.f;
+#pragma unroll
+            for (int r = 0; r < AR; ++r) {
+                const int rin = MF == 32 ? (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5) : 4 * (lane >> 4) + r;
+                const int row = m0 + wr * 128 + i * MF + rin;
+                if (row < a.M) {
+                    const size_t o = (size_t)row * a.N + col;
+                    float v = acc[i][j][r] + bv;
+                    if (a.relu) v = fmaxf(v, 0.f);
+                    if (a.gate) v = bf16_to_f32(a.resid[o]) + v * bf16_to_f32(a.gate[col]);
+                    else if (a.resid) v = bf16_to_f32(a.resid[o]) + round_bf16(v);
+                    a.out[o] = f32_to_bf16(v);
+                }
+            }
+        }
+}
+#undef OMX_BAR
+
 // ---- fallback: any K / alignment.  64x64 tile, BK = 32, register staging with zero fill ----
 __global__ __launch_bounds__(NTHREADS) void gemm_bf16_nt_generic_kernel(const GemmArgs a) {
     __shared__ __attribute__((aligned(16))) bf16_t sA[64][40];   // +8 pad: conflict-free 16-B fragment reads
@@ -223,6 +417,8 @@ int ensure_attr() {
         const int shmem = 4 * TILE_BYTES;
         OMX_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_bf16_nt_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, shmem));
         OMX_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_bf16_nt_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, shmem));
+        OMX_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_bf16_nt_256_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, big::SMEM));
+        OMX_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_bf16_nt_256_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, big::SMEM));
         attr_set = true;
     }
     return 0;
@@ -237,7 +433,20 @@ static int launch_gemm_impl(bf16_t* out, const bf16_t* x, const bf16_t* w, const
     const bool fast = (K % BK == 0) && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w)) & 15u) == 0;
     if (fast) {
         if (ensure_attr()) return 1;
-        gemm_bf16_nt_kernel<false><<<a.grid_m * a.grid_n, NTHREADS, 4 * TILE_BYTES, s>>>(a);
+        // 256^2 tiles when they still cover the chip (one block per CU); OMX_GEMM_TILE=128|256 forces a kernel
+        const int tiles256 = ((M + 255) / 256) * ((N + 255) / 256);
+        const char* tile_env = getenv("OMX_GEMM_TILE");
+        const int forced = tile_env ? atoi(tile_env) : 0;
+        const bool use256 = forced == 256 || (forced != 128 && tiles256 >= 160);
+        if (use256) {
+            a.grid_m = (M + 255) / 256;
+            a.grid_n = (N + 255) / 256;
+            const char* mf_env = getenv("OMX_GEMM_MFMA");
+            if (mf_env && atoi(mf_env) == 32) gemm_bf16_nt_256_kernel<32><<<a.grid_m * a.grid_n, big::NT, big::SMEM, s>>>(a);
+            else gemm_bf16_nt_256_kernel<16><<<a.grid_m * a.grid_n, big::NT, big::SMEM, s>>>(a);
+        } else {
+            gemm_bf16_nt_kernel<false><<<a.grid_m * a.grid_n, NTHREADS, 4 * TILE_BYTES, s>>>(a);
+        }
     } else {
         gemm_bf16_nt_generic_kernel<<<dim3((N + 63) / 64, (M + 63) / 64), NTHREADS, 0, s>>>(a);
     }

@@ -33,6 +33,35 @@ def test_linear_gemm_parity(omx, M, N, K):
     assert_bf16_close(got, ref, 1, atol=2e-5 * np.sqrt(K))
 
 
+@pytest.mark.parametrize("M,N,K", [
+    (256, 256, 64),          # one tile, one K step (prologue only)
+    (300, 520, 128),         # ragged M and N tails, two K steps
+    (512, 768, 192),         # odd number of K steps: both LDS buffers, tail without re-staging
+    (1000, 1100, 1024),      # several tiles, long K loop
+])
+def test_linear_gemm_256_tile_kernel(omx, monkeypatch, M, N, K):
+    """The 256 x 256 x 64 eight-wave kernel (phased staging, staggered wave groups) forced on small shapes;
+    by default it serves GEMMs with >= 160 such tiles (DiT, long prefill)."""
+    T = omx.ops.Tensor
+    monkeypatch.setenv("OMX_GEMM_TILE", "256")
+    x = rc.bf16_round(rand((M, K), 41))
+    w = rc.bf16_round(rand((N, K), 42) * 0.05)
+    b = rc.bf16_round(rand((N,), 43))
+    got = omx.ops.linear(T.from_numpy(x), T.from_numpy(w), T.from_numpy(b)).numpy()
+    assert_bf16_close(got, rc.linear(x, w, b, "bf16"), 1, atol=2e-5 * np.sqrt(K) + 1e-4)
+    monkeypatch.setenv("OMX_GEMM_MFMA", "32")
+    got32 = omx.ops.linear(T.from_numpy(x), T.from_numpy(w), T.from_numpy(b)).numpy()
+    monkeypatch.setenv("OMX_GEMM_TILE", "128")
+    same = omx.ops.linear(T.from_numpy(x), T.from_numpy(w), T.from_numpy(b)).numpy()
+    np.testing.assert_array_equal(got32, same)      # 32x32x16 variant: same MFMA, same k order as the 128^2 kernel
+    monkeypatch.delenv("OMX_GEMM_MFMA")
+    # transpose-detecting: identity activations against an asymmetric weight
+    monkeypatch.setenv("OMX_GEMM_TILE", "256")
+    eye = np.eye(K, dtype=np.float32)[: min(M, K)]
+    wa = rc.bf16_round((np.arange(N * K).reshape(N, K) % 251 - 125).astype(np.float32) / 64)
+    np.testing.assert_array_equal(omx.ops.linear(T.from_numpy(eye), T.from_numpy(wa)).numpy(), wa.T[: min(M, K)])
+
+
 def test_linear_gemm_bias_is_fused_addmm(omx):
     """nn/linear.rs:88-90: addmm rounds once."""
     T = omx.ops.Tensor

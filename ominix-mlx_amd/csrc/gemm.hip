@@ -176,21 +176,24 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_nt_kernel(const GemmArgs a
 // ---- 256 x 256 x 64 tile, 8 waves, one block per CU: the deep-pipelined form for large GEMMs ----
 // (cdna_hip_programming.md "256^2 8-phase": the 128^2 / one-barrier-per-K-step structure above tops out near
 // 0.9 PF because every wave pays ~8 LDS-DMA issues per 16 MFMAs; here a wave owns 128 x 64 of the output, so
-// the same 8 issues buy 32 MFMAs, and the K step is cut into 4 phases -- one 64 x 32 quadrant of the wave's
-// tile each -- with the staging of the NEXT tile spread over them, two LDS-DMA instructions per phase.)
+// the same 8 issues buy 32 MFMAs' worth of work, and the K step is cut into 4 phases -- one 64 x 32 quadrant of
+// the wave's tile each -- with the staging spread over them, two LDS-DMA instructions per wave and phase.)
 //
-//   LDS (128 KiB): 2 buffers x {A rows 0-127 | A rows 128-255 | B cols 0-127 | B cols 128-255}, 16 KiB each,
-//   every half-tile [128 rows][64 k] with the same source-side XOR swizzle as above.
-//   wave (wr, wc) = (wave >> 2, wave & 3) reads A half wr and B half wc >> 1.
-//   phase 1: read A rows 0-63 + B cols 0-31, stage B-half-1 of tile t+1, MFMA quadrant (0,0)
-//   phase 2: read B cols 32-63,              stage A-half-0 of tile t+1, MFMA quadrant (0,1)
-//   phase 3: read A rows 64-127,             stage A-half-1 of tile t+1, MFMA quadrant (1,1)
-//   phase 4:                                 stage B-half-0 of tile t+2, vmcnt(2), MFMA quadrant (1,0)
-//   Each phase is {reads + staging; barrier; MFMAs at raised priority; barrier}; the wr = 1 waves run one
-//   barrier behind the wr = 0 waves, so on every SIMD one wave issues loads while the other feeds the
-//   matrix core.  Hazards: a half-tile is re-staged at least two barriers after its last ds_read by either
-//   wave group (B halves are read in phases 1-2, A halves in phases 1 and 3), and it is read at least one
-//   barrier after the counted vmcnt that retires it (phase 4 of the previous tile, both wave groups).
+//   wave (wr, wc) = (wave >> 2, wave & 3) owns rows wr*128 + [0,128), cols wc*64 + [0,64) of the block tile.
+//   LDS (128 KiB): 2 buffers x 4 pieces of [128 rows][64 k] (16 KiB, source-side XOR swizzle as above), cut by
+//   WHEN they are read, not by where they sit in the tile:
+//     X0 / X1 = A rows  {wr*128 + s*64 + [0,64)}  for both wr      (s = 0: read in phase 1, s = 1: phase 3)
+//     Y0 / Y1 = B cols  {wc*64  + s*32 + [0,32)}  for all four wc  (s = 0: read in phase 1, s = 1: phase 2)
+//   phase 1: read X0, Y0 -> MFMA quadrant (0,0)      stage Y1 of tile t+1
+//   phase 2: read Y1     -> MFMA quadrant (0,1)      stage X1 of tile t+1
+//   phase 3: read X1     -> MFMA quadrant (1,1)      stage X0 of tile t+2
+//   phase 4:                MFMA quadrant (1,0)      stage Y0 of tile t+2
+//   so every piece is issued 5-6 phases before its first read and FOUR newer pieces stay in flight across each
+//   counted wait (vmcnt(8) in phases 4, 1, 2 -- never 0 in the steady state).
+//   Each phase is {reads + staging [+ wait]; barrier; MFMAs at raised priority; barrier}; the wr = 1 waves run
+//   one barrier behind the wr = 0 waves, so on every SIMD one wave issues loads while the other feeds the
+//   matrix core.  Hazards: a piece is re-staged two phases after the phase that reads it (at least two barriers
+//   after the reads of BOTH wave groups retired), and it is read one phase after the wait that retires it.
 namespace big {
 constexpr int TM = 256, TN = 256, TK = 64, NT = 512;
 constexpr int HALF = 128 * TK * 2;           // bytes per half-tile
@@ -215,27 +218,44 @@ __global__ __launch_bounds__(big::NT) void gemm_bf16_nt_256_kernel(const GemmArg
         const int q = nblk / 8, r = nblk % 8, xcd = bid % 8, idx = bid / 8;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    const int m0 = (bid / a.grid_n) * TM, n0 = (bid % a.grid_n) * TN;
+    // grouped order inside the XCD's run: the 32 tiles its CUs hold at one time form an 8 x 4 patch (12 operand
+    // panels through the XCD's L2 per K step) instead of a 1 x 32 strip (33 panels)
+    int tm, tn;
+    {
+        constexpr int GM = 8;
+        const int per_group = GM * a.grid_n;
+        const int group = bid / per_group, in_group = bid % per_group;
+        const int first_m = group * GM;
+        const int gm = min(a.grid_m - first_m, GM);
+        tm = first_m + in_group % gm;
+        tn = in_group / gm;
+    }
+    const int m0 = tm * TM, n0 = tn * TN;
     const int nt = a.K / TK;
 
-    // staging sources: thread handles chunks c = i * 512 + tid (i = 0, 1) of every half-tile
-    const bf16_t* srcA[2][2];
-    const bf16_t* srcB[2][2];
+    // staging sources: thread handles chunks c = i * 512 + tid (i = 0, 1) of every piece; piece row r of X_s is
+    // tile row (r >> 6) * 128 + s * 64 + (r & 63), piece row r of Y_s is tile col (r >> 5) * 64 + s * 32 + (r & 31)
+    const bf16_t* srcX[2][2];
+    const bf16_t* srcY[2][2];
 #pragma unroll
-    for (int h = 0; h < 2; ++h)
+    for (int sidx = 0; sidx < 2; ++sidx)
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int c = i * NT + threadIdx.x;
             const int row = c >> 3;
             const int kc = (c & 7) ^ (row & 7);
-            srcA[h][i] = a.x + (size_t)min(m0 + h * 128 + row, a.M - 1) * a.K + kc * 8;
-            srcB[h][i] = a.w + (size_t)min(n0 + h * 128 + row, a.N - 1) * a.K + kc * 8;
+            const int trow = (row >> 6) * 128 + sidx * 64 + (row & 63);
+            const int tcol = (row >> 5) * 64 + sidx * 32 + (row & 31);
+            srcX[sidx][i] = a.x + (size_t)min(m0 + trow, a.M - 1) * a.K + kc * 8;
+            srcY[sidx][i] = a.w + (size_t)min(n0 + tcol, a.N - 1) * a.K + kc * 8;
         }
-    auto stage = [&](const bf16_t* const (&src)[2], int k0, unsigned char* half) {
+    auto stage = [&](const bf16_t* const (&src)[2], int k0, unsigned char* piece) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
-            __builtin_amdgcn_global_load_lds((glb_ptr_t)(src[i] + k0), (lds_ptr_t)(half + (i * NT + wave * 64) * 16), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(src[i] + k0), (lds_ptr_t)(piece + (i * NT + wave * 64) * 16), 16, 0, 0);
     };
+    // buffer layout: X0 | X1 | Y0 | Y1
+    constexpr int PX0 = 0, PX1 = HALF, PY0 = 2 * HALF, PY1 = 3 * HALF;
 
     // accumulators: MF = 32 -> [4][2] tiles of 32x32 (16 regs each); MF = 16 -> [8][4] tiles of 16x16 (4 regs each)
     constexpr int RT = 128 / MF, CT = 64 / MF, AR = MF * MF / 64;   // row tiles, col tiles, registers per tile
@@ -252,14 +272,15 @@ __global__ __launch_bounds__(big::NT) void gemm_bf16_nt_256_kernel(const GemmArg
 #pragma unroll
             for (int r = 0; r < AR; ++r) acc[i][j][r] = 0.f;
 
-    // prologue: tile 0 entirely, B-half-0 of tile 1
-    stage(srcA[0], 0, smem);
-    stage(srcA[1], 0, smem + HALF);
-    stage(srcB[0], 0, smem + 2 * HALF);
-    stage(srcB[1], 0, smem + 3 * HALF);
+    // prologue: what the steady state would have issued before tile 0's first phase, in its order
+    stage(srcX[0], 0, smem + PX0);
+    stage(srcY[0], 0, smem + PY0);
+    stage(srcY[1], 0, smem + PY1);
+    stage(srcX[1], 0, smem + PX1);
     if (nt > 1) {
-        stage(srcB[0], TK, smem + BUF + 2 * HALF);
-        asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        stage(srcX[0], TK, smem + BUF + PX0);
+        stage(srcY[0], TK, smem + BUF + PY0);
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // X0, Y0 of tile 0 have landed
     } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
@@ -270,8 +291,9 @@ __global__ __launch_bounds__(big::NT) void gemm_bf16_nt_256_kernel(const GemmArg
     bf16x8 fa[RQ][KS], fb[2][CQ][KS];
     const int arow = lane & LR, kh = lane >> LS;
     auto mfma = [&](const bf16x8& x, const bf16x8& y, accv& c) {
-        if constexpr (MF == 32) c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, c, 0, 0, 0);
-        else c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x, y, c, 0, 0, 0);
+        // operands swapped (W fragment first): the accumulator holds the tile transposed, see the epilogue
+        if constexpr (MF == 32) c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(y, x, c, 0, 0, 0);
+        else c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(y, x, c, 0, 0, 0);
     };
     auto quadrant = [&](int qm, int qn) {
         __builtin_amdgcn_sched_barrier(0);
@@ -288,47 +310,56 @@ __global__ __launch_bounds__(big::NT) void gemm_bf16_nt_256_kernel(const GemmArg
     for (int t = 0; t < nt; ++t) {
         unsigned char* cur = smem + (t & 1) * BUF;
         unsigned char* nxt = smem + ((t + 1) & 1) * BUF;
-        const unsigned char* hA = cur + wr * HALF;
-        const unsigned char* hB = cur + (2 + (wc >> 1)) * HALF;
-        const int bcol = (wc & 1) * 64;
         const bool has1 = t + 1 < nt, has2 = t + 2 < nt;
-        const int k1 = (t + 1) * TK;
+        const int k1 = (t + 1) * TK, k2 = (t + 2) * TK;
         auto read_a = [&](int sub) {
+            const unsigned char* px = cur + (sub ? PX1 : PX0);
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-                for (int i = 0; i < RQ; ++i) fa[i][ks] = lds_frag(hA, sub * 64 + i * MF + arow, ks * KCH + kh);
+                for (int i = 0; i < RQ; ++i) fa[i][ks] = lds_frag(px, wr * 64 + i * MF + arow, ks * KCH + kh);
         };
         auto read_b = [&](int sub) {
+            const unsigned char* py = cur + (sub ? PY1 : PY0);
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-                for (int j = 0; j < CQ; ++j) fb[sub][j][ks] = lds_frag(hB, bcol + sub * 32 + j * MF + arow, ks * KCH + kh);
+                for (int j = 0; j < CQ; ++j) fb[sub][j][ks] = lds_frag(py, wc * 32 + j * MF + arow, ks * KCH + kh);
         };
 
         // ---- phase 1 ----
         read_b(0);
         read_a(0);
-        if (has1) stage(srcB[1], k1, nxt + 3 * HALF);
+        if (has1) {
+            stage(srcY[1], k1, nxt + PY1);
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // Y1 of this tile (read in phase 2) has landed
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         OMX_BAR();
         quadrant(0, 0);
         OMX_BAR();
         // ---- phase 2 ----
         read_b(1);
-        if (has1) stage(srcA[0], k1, nxt);
+        if (has1) {
+            stage(srcX[1], k1, nxt + PX1);
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // X1 of this tile (read in phase 3) has landed
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         OMX_BAR();
         quadrant(0, 1);
         OMX_BAR();
         // ---- phase 3 ----
         read_a(1);
-        if (has1) stage(srcA[1], k1, nxt + HALF);
+        if (has2) stage(srcX[0], k2, cur + PX0);
         OMX_BAR();
         quadrant(1, 1);
         OMX_BAR();
         // ---- phase 4 ----
         if (has2) {
-            stage(srcB[0], (t + 2) * TK, cur + 2 * HALF);
-            asm volatile("s_waitcnt vmcnt(2)" ::: "memory");   // everything of tile t+1 has landed
+            stage(srcY[0], k2, cur + PY0);
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // X0, Y0 of tile t+1 have landed
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
@@ -338,29 +369,57 @@ __global__ __launch_bounds__(big::NT) void gemm_bf16_nt_256_kernel(const GemmArg
     }
     if (wr == 0) OMX_BAR();   // pairs with the extra barrier of the wr = 1 waves
 
-    // epilogue.  C/D layouts: 32x32 -> col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-    //                         16x16 -> col = lane & 15, row = 4 * (lane >> 4) + r
+    // epilogue.  The products were issued as W-tile x X-tile (operands swapped), so a lane holds runs of FOUR
+    // consecutive output columns of one row: 16x16 -> row = lane & 15, cols 4 * (lane >> 4) + [0,4);
+    // 32x32 -> row = lane & 31, cols 8 * g + 4 * (lane >> 5) + [0,4) for g = 0..3.  One 8-byte store per run.
 #pragma unroll
-    for (int i = 0; i < RT; ++i)
+    for (int i = 0; i < RT; ++i) {
+        const int row = m0 + wr * 128 + i * MF + (lane & LR);
+        if (row >= a.M) continue;
 #pragma unroll
-        for (int j = 0; j < CT; ++j) {
-            const int col = n0 + wc * 64 + j * MF + (lane & LR);
-            if (col >= a.N) continue;
-            const float bv = a.bias ? bf16_to_f32(a.bias[col]) : 0.f;
+        for (int j = 0; j < CT; ++j)
 #pragma unroll
-            for (int r = 0; r < AR; ++r) {
-                const int rin = MF == 32 ? (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5) : 4 * (lane >> 4) + r;
-                const int row = m0 + wr * 128 + i * MF + rin;
-                if (row < a.M) {
-                    const size_t o = (size_t)row * a.N + col;
-                    float v = acc[i][j][r] + bv;
-                    if (a.relu) v = fmaxf(v, 0.f);
-                    if (a.gate) v = bf16_to_f32(a.resid[o]) + v * bf16_to_f32(a.gate[col]);
-                    else if (a.resid) v = bf16_to_f32(a.resid[o]) + round_bf16(v);
-                    a.out[o] = f32_to_bf16(v);
+            for (int g = 0; g < AR / 4; ++g) {
+                const int col = n0 + wc * 64 + j * MF + (MF == 32 ? 8 * g + 4 * (lane >> 5) : 4 * (lane >> 4));
+                if (col >= a.N) continue;
+                const size_t o = (size_t)row * a.N + col;
+                const bool full = col + 3 < a.N && (a.N & 3) == 0;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e];
+                if (full) {
+                    if (a.bias) {
+                        const u32x2 b = *reinterpret_cast<const u32x2*>(a.bias + col);
+                        v[0] += bf16lo(b[0]); v[1] += bf16hi(b[0]); v[2] += bf16lo(b[1]); v[3] += bf16hi(b[1]);
+                    }
+                    if (a.relu) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                    }
+                    if (a.gate) {
+                        const u32x2 r = *reinterpret_cast<const u32x2*>(a.resid + o);
+                        const u32x2 gt = *reinterpret_cast<const u32x2*>(a.gate + col);
+                        v[0] = bf16lo(r[0]) + v[0] * bf16lo(gt[0]); v[1] = bf16hi(r[0]) + v[1] * bf16hi(gt[0]);
+                        v[2] = bf16lo(r[1]) + v[2] * bf16lo(gt[1]); v[3] = bf16hi(r[1]) + v[3] * bf16hi(gt[1]);
+                    } else if (a.resid) {
+                        const u32x2 r = *reinterpret_cast<const u32x2*>(a.resid + o);
+                        v[0] = bf16lo(r[0]) + round_bf16(v[0]); v[1] = bf16hi(r[0]) + round_bf16(v[1]);
+                        v[2] = bf16lo(r[1]) + round_bf16(v[2]); v[3] = bf16hi(r[1]) + round_bf16(v[3]);
+                    }
+                    *reinterpret_cast<u32x2*>(a.out + o) = u32x2{pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3])};
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (col + e >= a.N) break;
+                        float x = v[e] + (a.bias ? bf16_to_f32(a.bias[col + e]) : 0.f);
+                        if (a.relu) x = fmaxf(x, 0.f);
+                        if (a.gate) x = bf16_to_f32(a.resid[o + e]) + x * bf16_to_f32(a.gate[col + e]);
+                        else if (a.resid) x = bf16_to_f32(a.resid[o + e]) + round_bf16(x);
+                        a.out[o + e] = f32_to_bf16(x);
+                    }
                 }
             }
-        }
+    }
 }
 #undef OMX_BAR
 
@@ -437,7 +496,7 @@ static int launch_gemm_impl(bf16_t* out, const bf16_t* x, const bf16_t* w, const
         const int tiles256 = ((M + 255) / 256) * ((N + 255) / 256);
         const char* tile_env = getenv("OMX_GEMM_TILE");
         const int forced = tile_env ? atoi(tile_env) : 0;
-        const bool use256 = forced == 256 || (forced != 128 && tiles256 >= 160);
+        const bool use256 = forced == 256 || (forced != 128 && (tiles256 >= 160 || (tiles256 >= 100 && K >= 8192)));
         if (use256) {
             a.grid_m = (M + 255) / 256;
             a.grid_n = (N + 255) / 256;

@@ -61,7 +61,7 @@ __device__ __forceinline__ float quad_rows_sum(float v) {
 // LDS feeds two MFMAs).  Next tile's K/V are fetched into registers while the current tile is multiplied
 // (issue-early / write-late staging, cdna_hip_programming.md T14).
 template <int D, int QW, int MASK>
-__global__ __launch_bounds__(256) void attn_prefill_kernel(const PrefillArgs a) {
+__global__ __launch_bounds__(256, 2) void attn_prefill_kernel(const PrefillArgs a) {
     constexpr int DC = D / 8;       // 16-B chunks per K row
     constexpr int NI = D / 32;      // MFMA k-steps over the head dim
     constexpr int NDT = D / 16;     // 16-wide output tiles over the head dim
@@ -155,67 +155,99 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(const PrefillArgs a) 
         // ---- S^T = K Q^T for 4 key tiles of 16, both query sub-tiles share each K fragment ----
         f32x4v s[QW][4];
 #pragma unroll
-        for (int kt = 0; kt < 4; ++kt) {
+        for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
             for (int w = 0; w < QW; ++w) s[w][kt] = f32x4v{0.f, 0.f, 0.f, 0.f};
-            const int row = kt * 16 + qcol;   // A operand: lane & 15 indexes the key row
+        // head-dim step outermost: 4 x QW independent accumulators sit between two MFMAs on the same one
 #pragma unroll
-            for (int i = 0; i < NI; ++i) {
-                const int ch = i * 4 + rg;
+        for (int i = 0; i < NI; ++i) {
+            const int ch = i * 4 + rg;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) {
+                const int row = kt * 16 + qcol;   // A operand: lane & 15 indexes the key row
                 const bf16x8 kf = *reinterpret_cast<const bf16x8*>(&sK[(row * DC + (ch ^ (row & (DC - 1)))) * 8]);
 #pragma unroll
                 for (int w = 0; w < QW; ++w) s[w][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[w][i], s[w][kt], 0, 0, 0);
             }
         }
-        // ---- scale, mask, online softmax (lane: query qcol of each sub-tile, keys kt*16 + rg*4 + r) ----
+        // ---- online softmax in the base-2 domain: p = 2^(s*c - m), c = scale * log2(e), m = running max of s*c.
+        //      (lane: query qcol of each sub-tile, keys kt*16 + rg*4 + r).  Tiles that need no masking -- all keys
+        //      valid and, under a causal mask, entirely below every query row of the block -- take a path without
+        //      any select; the normaliser sums the fp32 probabilities (P is rounded to bf16 only for the MFMA). ----
         bf16x8 pf[QW][2];
+        const float c2 = a.scale * 1.44269504088896340736f;
+        bool plain = (k0 + KB <= a.Tk) && (MASK == OMX_MASK_NONE || (MASK == OMX_MASK_CAUSAL && k0 + KB - 1 <= q0 + shift));
+        if (plain) {
 #pragma unroll
-        for (int w = 0; w < QW; ++w) {
-            float mx = -INFINITY;
+            for (int w = 0; w < QW; ++w) {
+                float mx = s[w][0][0];
 #pragma unroll
-            for (int kt = 0; kt < 4; ++kt)
+                for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int key = k0 + kt * 16 + rg * 4 + r;
-                    float v = s[w][kt][r] * a.scale;
-                    bool keep = key < a.Tk;
-                    // MASK is a compile-time mode: the hot loop carries no mode branches, and the mask bytes are
-                    // loaded unconditionally from a clamped address (no per-lane control flow)
-                    if (MASK == OMX_MASK_CAUSAL) keep = keep && (key <= qrow[w] + shift);
-                    if (MASK == OMX_MASK_BOOL) {
-                        const uint8_t mb = reinterpret_cast<const uint8_t*>(a.mask)[(size_t)qrow_c[w] * a.Tk + min(key, a.Tk - 1)];
-                        keep = keep & (mb != 0);
+                    for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[w][kt][r]);
+                mx = quad_rows_max(mx) * c2;
+                const float m_new = fmaxf(m_run[w], mx);
+                const float alpha = __builtin_amdgcn_exp2f(m_run[w] - m_new);   // 2^(-inf) = 0 on the first tile
+                m_run[w] = m_new;
+                l_run[w] *= alpha;
+#pragma unroll
+                for (int t = 0; t < NDT; ++t) o[w][t] *= alpha;
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float p = __builtin_amdgcn_exp2f(fmaf(s[w][2 * j + (e >> 2)][e & 3], c2, -m_new));
+                        l_run[w] += p;
+                        pf[w][j][e] = (__bf16)p;
                     }
-                    if (MASK == OMX_MASK_ADDITIVE)
-                        v += bf16_to_f32(reinterpret_cast<const bf16_t*>(a.mask)[(size_t)qrow_c[w] * a.Tk + min(key, a.Tk - 1)]);
-                    v = keep ? v : -INFINITY;
-                    s[w][kt][r] = v;
-                    mx = fmaxf(mx, v);
-                }
-            mx = quad_rows_max(mx);
-            const float m_new = fmaxf(m_run[w], mx);
-            const float alpha = (m_new == -INFINITY) ? 1.f : __expf(m_run[w] - m_new);
-            m_run[w] = m_new;
-            l_run[w] *= alpha;
+            }
+        } else {
 #pragma unroll
-            for (int t = 0; t < NDT; ++t) o[w][t] *= alpha;
+            for (int w = 0; w < QW; ++w) {
+                float mx = -INFINITY;
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+                for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const float sv = s[w][2 * j + (e >> 2)][e & 3];
-                    const float p = (m_new == -INFINITY) ? 0.f : __expf(sv - m_new);
-                    const bf16_t pb = f32_to_bf16(p);
-                    l_run[w] += bf16_to_f32(pb);   // normaliser of the bf16 probabilities actually multiplied
-                    pf[w][j][e] = __builtin_bit_cast(__bf16, pb);
-                }
+                    for (int r = 0; r < 4; ++r) {
+                        const int key = k0 + kt * 16 + rg * 4 + r;
+                        float v = s[w][kt][r] * c2;
+                        bool keep = key < a.Tk;
+                        // MASK is a compile-time mode; the mask bytes are loaded unconditionally from a clamped address
+                        if (MASK == OMX_MASK_CAUSAL) keep = keep && (key <= qrow[w] + shift);
+                        if (MASK == OMX_MASK_BOOL) {
+                            const uint8_t mb = reinterpret_cast<const uint8_t*>(a.mask)[(size_t)qrow_c[w] * a.Tk + min(key, a.Tk - 1)];
+                            keep = keep & (mb != 0);
+                        }
+                        if (MASK == OMX_MASK_ADDITIVE)
+                            v += 1.44269504088896340736f * bf16_to_f32(reinterpret_cast<const bf16_t*>(a.mask)[(size_t)qrow_c[w] * a.Tk + min(key, a.Tk - 1)]);
+                        v = keep ? v : -INFINITY;
+                        s[w][kt][r] = v;
+                        mx = fmaxf(mx, v);
+                    }
+                mx = quad_rows_max(mx);
+                const float m_new = fmaxf(m_run[w], mx);
+                const float alpha = (m_new == -INFINITY) ? 1.f : __builtin_amdgcn_exp2f(m_run[w] - m_new);
+                m_run[w] = m_new;
+                l_run[w] *= alpha;
+#pragma unroll
+                for (int t = 0; t < NDT; ++t) o[w][t] *= alpha;
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float sv = s[w][2 * j + (e >> 2)][e & 3];
+                        const float p = (m_new == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(sv - m_new);
+                        l_run[w] += p;
+                        pf[w][j][e] = (__bf16)p;
+                    }
+            }
         }
         // ---- O^T += V^T P^T : k-slot (rg*8 + e) <-> key (2j + (e>>2))*16 + rg*4 + (e&3) on BOTH operands ----
 #pragma unroll
-        for (int t = 0; t < NDT; ++t) {
-            const bf16_t* vrow = &sVt[(t * 16 + qcol) * VT_STRIDE];   // A operand: lane & 15 indexes d
+        for (int j = 0; j < 2; ++j) {
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
+            for (int t = 0; t < NDT; ++t) {
+                const bf16_t* vrow = &sVt[(t * 16 + qcol) * VT_STRIDE];   // A operand: lane & 15 indexes d
                 const u32x2v lo = *reinterpret_cast<const u32x2v*>(vrow + (2 * j) * 16 + rg * 4);
                 const u32x2v hi = *reinterpret_cast<const u32x2v*>(vrow + (2 * j + 1) * 16 + rg * 4);
                 const u32x4 packed = {lo[0], lo[1], hi[0], hi[1]};

@@ -68,8 +68,9 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(const PrefillArgs 
     constexpr int QBLK = 64 * QW;   // query rows per block
     constexpr int KCH = KB * DC / 256;          // K chunks staged per thread
     constexpr int VCH = (KB / 2) * DC / 256;    // V key-pair chunks staged per thread
-    __shared__ __attribute__((aligned(16))) bf16_t sK[KB * D];
-    __shared__ __attribute__((aligned(16))) bf16_t sVt[D * VT_STRIDE];
+    // two buffers each: tile t+1 is staged while tile t is multiplied, ONE barrier per tile
+    __shared__ __attribute__((aligned(16))) bf16_t sK2[2][KB * D];
+    __shared__ __attribute__((aligned(16))) bf16_t sVt2[2][D * VT_STRIDE];
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int qcol = lane & 15, rg = lane >> 4;
@@ -105,15 +106,23 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(const PrefillArgs 
     int kv_end = a.Tk;
     if (MASK == OMX_MASK_CAUSAL) kv_end = max(0, min(a.Tk, q0 + QBLK + shift));
 
-    // ---- staging registers: K rows as 16-B chunks, V as (key 2p, key 2p+1) chunk pairs ----
-    u32x4 kreg[KCH], vreg[VCH][2];
-    auto fetch = [&](int k0) {
+    // ---- staging.  K: global_load_lds (no VGPR round trip; the LDS image is lane-linear, so the bank-conflict
+    //      swizzle -- 16-B chunk index ^= key & (DC-1) -- is applied to the per-lane SOURCE address).
+    //      V: (key 2p, key 2p+1) chunk pairs through registers, written transposed ([d][key]). ----
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+    u32x4 vreg[VCH][2];
+    auto stage_k = [&](int k0, bf16_t* sK) {
 #pragma unroll
         for (int it = 0; it < KCH; ++it) {
             const int ci = threadIdx.x + it * 256;
-            const int key = min(k0 + ci / DC, a.Tk - 1);
-            kreg[it] = *reinterpret_cast<const u32x4*>(Kb + (size_t)key * a.kv_ts + (ci % DC) * 8);
+            const int row = ci / DC, ch = (ci % DC) ^ (row & (DC - 1));
+            const int key = min(k0 + row, a.Tk - 1);
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(Kb + (size_t)key * a.kv_ts + ch * 8),
+                                             (lds_ptr_t)(reinterpret_cast<unsigned char*>(sK) + (it * 256 + wave * 64) * 16), 16, 0, 0);
         }
+    };
+    auto fetch_v = [&](int k0) {
 #pragma unroll
         for (int it = 0; it < VCH; ++it) {
             const int idx = threadIdx.x + it * 256;
@@ -123,13 +132,7 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(const PrefillArgs 
             vreg[it][1] = *reinterpret_cast<const u32x4*>(Vb + (size_t)k_odd * a.kv_ts + c * 8);
         }
     };
-    auto commit = [&]() {
-#pragma unroll
-        for (int it = 0; it < KCH; ++it) {
-            const int ci = threadIdx.x + it * 256;
-            const int row = ci / DC, ch = ci % DC;
-            *reinterpret_cast<u32x4*>(&sK[(row * DC + (ch ^ (row & (DC - 1)))) * 8]) = kreg[it];
-        }
+    auto commit_v = [&](bf16_t* sVt) {
         uint32_t* vt32 = reinterpret_cast<uint32_t*>(sVt);
 #pragma unroll
         for (int it = 0; it < VCH; ++it) {
@@ -145,12 +148,22 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(const PrefillArgs 
         }
     };
 
-    if (kv_end > 0) fetch(0);
-    for (int k0 = 0; k0 < kv_end; k0 += KB) {
-        __syncthreads();   // previous tile fully consumed
-        commit();
+    if (kv_end > 0) {
+        stage_k(0, sK2[0]);
+        fetch_v(0);
+        commit_v(sVt2[0]);
+        __builtin_amdgcn_s_waitcnt(0);
         __syncthreads();
-        if (k0 + KB < kv_end) fetch(k0 + KB);   // in flight during the MFMAs below
+    }
+    int buf = 0;
+    for (int k0 = 0; k0 < kv_end; k0 += KB, buf ^= 1) {
+        const bf16_t* sK = sK2[buf];
+        const bf16_t* sVt = sVt2[buf];
+        const bool more = k0 + KB < kv_end;
+        if (more) {   // next tile: K straight into the other LDS buffer, V into registers; both in flight below
+            stage_k(k0 + KB, sK2[buf ^ 1]);
+            fetch_v(k0 + KB);
+        }
 
         // ---- S^T = K Q^T for 4 key tiles of 16, both query sub-tiles share each K fragment ----
         f32x4v s[QW][4];
@@ -158,18 +171,29 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(const PrefillArgs 
         for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
             for (int w = 0; w < QW; ++w) s[w][kt] = f32x4v{0.f, 0.f, 0.f, 0.f};
-        // head-dim step outermost: 4 x QW independent accumulators sit between two MFMAs on the same one
-#pragma unroll
-        for (int i = 0; i < NI; ++i) {
+        // head-dim step outermost: 4 x QW independent accumulators sit between two MFMAs on the same one; the K
+        // fragments of step i+1 are read while step i is multiplied (explicit two-deep register pipeline)
+        bf16x8 kf[2][4];
+        auto read_k = [&](int i, bf16x8 (&dst)[4]) {
             const int ch = i * 4 + rg;
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt) {
                 const int row = kt * 16 + qcol;   // A operand: lane & 15 indexes the key row
-                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(&sK[(row * DC + (ch ^ (row & (DC - 1)))) * 8]);
-#pragma unroll
-                for (int w = 0; w < QW; ++w) s[w][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[w][i], s[w][kt], 0, 0, 0);
+                dst[kt] = *reinterpret_cast<const bf16x8*>(&sK[(row * DC + (ch ^ (row & (DC - 1)))) * 8]);
             }
+        };
+        read_k(0, kf[0]);
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            if (i + 1 < NI) read_k(i + 1, kf[(i + 1) & 1]);
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int w = 0; w < QW; ++w) s[w][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[i & 1][kt], qf[w][i], s[w][kt], 0, 0, 0);
         }
+        // the next tile's V is written to its LDS buffer here: its loads had the whole S^T product to land, and the
+        // staging registers are free again for the second product's fragment reads
+        if (more) commit_v(sVt2[buf ^ 1]);
         // ---- online softmax in the base-2 domain: p = 2^(s*c - m), c = scale * log2(e), m = running max of s*c.
         //      (lane: query qcol of each sub-tile, keys kt*16 + rg*4 + r).  Tiles that need no masking -- all keys
         //      valid and, under a causal mask, entirely below every query row of the block -- take a path without
@@ -242,20 +266,32 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(const PrefillArgs 
                     }
             }
         }
-        // ---- O^T += V^T P^T : k-slot (rg*8 + e) <-> key (2j + (e>>2))*16 + rg*4 + (e&3) on BOTH operands ----
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-#pragma unroll
-            for (int t = 0; t < NDT; ++t) {
+        // ---- O^T += V^T P^T : k-slot (rg*8 + e) <-> key (2j + (e>>2))*16 + rg*4 + (e&3) on BOTH operands.
+        //      16 V^T fragments (2 key halves x NDT d-tiles), read four ahead of the MFMAs that consume them ----
+        {
+            constexpr int NF = 2 * NDT, AHEAD = 4;
+            u32x4 vf[AHEAD];
+            auto read_v = [&](int idx) {
+                const int j = idx / NDT, t = idx % NDT;
                 const bf16_t* vrow = &sVt[(t * 16 + qcol) * VT_STRIDE];   // A operand: lane & 15 indexes d
                 const u32x2v lo = *reinterpret_cast<const u32x2v*>(vrow + (2 * j) * 16 + rg * 4);
                 const u32x2v hi = *reinterpret_cast<const u32x2v*>(vrow + (2 * j + 1) * 16 + rg * 4);
-                const u32x4 packed = {lo[0], lo[1], hi[0], hi[1]};
+                return u32x4{lo[0], lo[1], hi[0], hi[1]};
+            };
+#pragma unroll
+            for (int idx = 0; idx < AHEAD; ++idx) vf[idx] = read_v(idx);
+#pragma unroll
+            for (int idx = 0; idx < NF; ++idx) {
+                const int j = idx / NDT, t = idx % NDT;
+                const u32x4 cur = vf[idx % AHEAD];
+                if (idx + AHEAD < NF) vf[idx % AHEAD] = read_v(idx + AHEAD);
 #pragma unroll
                 for (int w = 0; w < QW; ++w)
-                    o[w][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, packed), pf[w][j], o[w][t], 0, 0, 0);
+                    o[w][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, cur), pf[w][j], o[w][t], 0, 0, 0);
             }
         }
+        __builtin_amdgcn_s_waitcnt(0);   // the K tile of the next iteration has landed (vmcnt), our LDS traffic retired (lgkmcnt)
+        __syncthreads();
     }
 
     // ---- normalise and store: lane holds out[qrow][t*16 + rg*4 + 0..3] ----

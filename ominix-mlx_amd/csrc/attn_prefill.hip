@@ -28,7 +28,7 @@ using f32x4v = __attribute__((ext_vector_type(4))) float;
 using u32x2v = __attribute__((ext_vector_type(2))) uint32_t;
 
 constexpr int KB = 64;    // keys per LDS tile
-constexpr int VT_STRIDE = KB + 8;   // bf16 elements per V^T row (144 B): conflict-free 8-B fragment reads
+constexpr int VT_STRIDE = KB;   // V^T rows are 128 B: 8 chunks of 16 B, XOR-swizzled by (d & 7) like the K tile
 
 struct PrefillArgs {
     const bf16_t *q, *k, *v;
@@ -138,12 +138,17 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(const PrefillArgs 
         for (int it = 0; it < VCH; ++it) {
             const int idx = threadIdx.x + it * 256;
             const int c = (idx % 4) + 4 * (idx / 128), pr = (idx / 4) % 32;
+            // key k sits at position (k/32)*32 + ((k%16)/4)*8 + ((k/16)%2)*4 + k%4 of its V^T row: the eight keys one
+            // lane feeds to an MFMA -- (2j)*16 + rg*4 + [0,4) and (2j+1)*16 + rg*4 + [0,4) -- are ONE 16-byte chunk
+            const int k = 2 * pr;
+            const int pos = (k / 32) * 32 + ((k % 16) / 4) * 8 + ((k / 16) % 2) * 4 + (k % 4);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const uint32_t ev = vreg[it][0][e], od = vreg[it][1][e];
-                // V^T[d][2p], V^T[d][2p+1] packed: one 4-byte store per output row
-                vt32[(c * 8 + 2 * e) * (VT_STRIDE / 2) + pr] = (ev & 0xFFFFu) | (od << 16);
-                vt32[(c * 8 + 2 * e + 1) * (VT_STRIDE / 2) + pr] = (ev >> 16) | (od & 0xFFFF0000u);
+                // V^T[d][k], V^T[d][k+1] packed: one 4-byte store per output row
+                const int d0 = c * 8 + 2 * e, d1 = d0 + 1;
+                vt32[(d0 * VT_STRIDE + (((pos >> 3) ^ (d0 & 7)) << 3) + (pos & 7)) >> 1] = (ev & 0xFFFFu) | (od << 16);
+                vt32[(d1 * VT_STRIDE + (((pos >> 3) ^ (d1 & 7)) << 3) + (pos & 7)) >> 1] = (ev >> 16) | (od & 0xFFFF0000u);
             }
         }
     };
@@ -273,10 +278,8 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(const PrefillArgs 
             u32x4 vf[AHEAD];
             auto read_v = [&](int idx) {
                 const int j = idx / NDT, t = idx % NDT;
-                const bf16_t* vrow = &sVt[(t * 16 + qcol) * VT_STRIDE];   // A operand: lane & 15 indexes d
-                const u32x2v lo = *reinterpret_cast<const u32x2v*>(vrow + (2 * j) * 16 + rg * 4);
-                const u32x2v hi = *reinterpret_cast<const u32x2v*>(vrow + (2 * j + 1) * 16 + rg * 4);
-                return u32x4{lo[0], lo[1], hi[0], hi[1]};
+                const int d = t * 16 + qcol;                                // A operand: lane & 15 indexes d
+                return *reinterpret_cast<const u32x4*>(&sVt[d * VT_STRIDE + (((j * 4 + rg) ^ (d & 7)) << 3)]);
             };
 #pragma unroll
             for (int idx = 0; idx < AHEAD; ++idx) vf[idx] = read_v(idx);

@@ -138,6 +138,10 @@ typedef struct omx_qwen3_config_ {
     int tie_word_embeddings;
     int max_context;                              /* KV slab capacity (rounded up to the 256 step of cache.rs) */
     int tp_rank, tp_size;                         /* tensor parallel shard of this process (1 process per GPU) */
+    /* config.json "quantization" {bits, group_size} (qwen3-mlx/src/model.rs:63, 621-727): 0 = bf16 checkpoint;
+     * 4 / 8 = every Linear and the embedding are MLX (weight u32, scales, biases) triplets registered as
+     * "<prefix>.weight" / ".scales" / ".biases"; the decode step then streams the PACKED weights (csrc/quant.hip) */
+    int quant_bits, quant_group;
 } omx_qwen3_config;
 typedef struct omx_qwen3_* omx_qwen3;
 

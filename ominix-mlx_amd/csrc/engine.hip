@@ -18,6 +18,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <map>
 #include <string>
 #include <vector>
@@ -28,6 +29,7 @@
 #include "gemv.hpp"
 #include "gridsync.hpp"
 #include "prefill.hpp"
+#include "quant.hpp"
 
 namespace omx {
 namespace {
@@ -38,6 +40,29 @@ constexpr int kNcclFloat32 = 7, kNcclUint64 = 5, kNcclSum = 0, kNcclMax = 2;
 struct LayerW {
     const bf16_t *q, *k, *v, *o, *gate, *up, *down, *q_norm, *k_norm, *in_ln, *post_ln;
 };
+// quantized checkpoint (config.json "quantization", qwen3-mlx/src/model.rs:621-727): every Linear and the embedding are
+// (weight u32, scales, biases) triplets; the norm weights stay bf16 in LayerW
+struct LayerQ {
+    QMat q, k, v, o, gate, up, down;
+};
+
+// dequantise ONE embedding row (QuantizedEmbedding::forward, mlx-rs/src/nn/quantized.rs:192-203) chosen by the step state
+template <int BITS>
+__global__ __launch_bounds__(256) void qembed_kernel(bf16_t* __restrict__ h, const uint32_t* __restrict__ w,
+                                                     const bf16_t* __restrict__ scales, const bf16_t* __restrict__ biases,
+                                                     const uint32_t* __restrict__ token, int hidden, int group) {
+    constexpr int EPW = 32 / BITS;
+    const size_t row = *token;
+    const int words = hidden / EPW;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < words; i += gridDim.x * blockDim.x) {
+        const uint32_t wd = w[row * words + i];
+        const int g = i * EPW / group;
+        const float sc = bf16_to_f32(scales[row * (hidden / group) + g]);
+        const float bi = biases ? bf16_to_f32(biases[row * (hidden / group) + g]) : 0.f;
+#pragma unroll
+        for (int e = 0; e < EPW; ++e) h[i * EPW + e] = f32_to_bf16((float)((wd >> (e * BITS)) & ((1u << BITS) - 1u)) * sc + bi);
+    }
+}
 
 uint32_t crc32_str(const char* s) {
     uint32_t crc = 0xFFFFFFFFu;
@@ -123,6 +148,10 @@ struct omx_qwen3_ {
     std::map<std::string, const void*> named;
     std::vector<void*> owned;    // allocations made by synth_weights
     std::vector<LayerW> layers;
+    std::vector<LayerQ> qlayers;             // quantized mode (cfg.quant_bits != 0)
+    QMat q_embed = {}, q_head = {};
+    bf16_t* dq_buf = nullptr;                // dequantised weight of the GEMM in flight (batched prefill)
+    size_t dq_cap = 0;
     const bf16_t *embed = nullptr, *final_norm = nullptr, *lm_head = nullptr;
     bool weights_resolved = false;
 
@@ -174,6 +203,34 @@ int resolve_weights(omx_qwen3 m) {
         return 0;
     };
     m->layers.resize(m->cfg.num_hidden_layers);
+    if (m->cfg.quant_bits) {
+        const int D = m->cfg.head_dim, hd = m->cfg.hidden_size;
+        auto getq = [&](const std::string& prefix, int n, QMat* out) -> int {
+            const bf16_t *w = nullptr, *sc = nullptr, *bi = nullptr;
+            if (get(prefix + ".weight", &w) || get(prefix + ".scales", &sc) || get(prefix + ".biases", &bi)) return 1;
+            *out = QMat{(const uint32_t*)w, sc, bi, n};
+            return 0;
+        };
+        m->qlayers.resize(m->cfg.num_hidden_layers);
+        for (int i = 0; i < m->cfg.num_hidden_layers; ++i) {
+            const std::string p = "model.layers." + std::to_string(i) + ".";
+            LayerW& L = m->layers[i];
+            LayerQ& Q = m->qlayers[i];
+            L = LayerW{};
+            if (getq(p + "self_attn.q_proj", m->H * D, &Q.q) || getq(p + "self_attn.k_proj", m->Hkv * D, &Q.k) ||
+                getq(p + "self_attn.v_proj", m->Hkv * D, &Q.v) || getq(p + "self_attn.o_proj", hd, &Q.o) ||
+                getq(p + "mlp.gate_proj", m->I, &Q.gate) || getq(p + "mlp.up_proj", m->I, &Q.up) ||
+                getq(p + "mlp.down_proj", hd, &Q.down) || get(p + "self_attn.q_norm.weight", &L.q_norm) ||
+                get(p + "self_attn.k_norm.weight", &L.k_norm) || get(p + "input_layernorm.weight", &L.in_ln) ||
+                get(p + "post_attention_layernorm.weight", &L.post_ln))
+                return 1;
+        }
+        if (getq("model.embed_tokens", m->cfg.vocab_size, &m->q_embed) || get("model.norm.weight", &m->final_norm)) return 1;
+        if (m->cfg.tie_word_embeddings) m->q_head = m->q_embed;            // QuantizedEmbedding::as_linear (quantized.rs:166-180)
+        else if (getq("lm_head", m->V, &m->q_head)) return 1;
+        m->weights_resolved = true;
+        return 0;
+    }
     for (int i = 0; i < m->cfg.num_hidden_layers; ++i) {
         const std::string p = "model.layers." + std::to_string(i) + ".";
         LayerW& L = m->layers[i];
@@ -198,8 +255,82 @@ int resolve_weights(omx_qwen3 m) {
     return 0;
 }
 
+// the same step on a quantized checkpoint: packed-weight GEMVs (quant.hip) with the prologues / epilogues of the bf16 step
+int enqueue_step_quant(omx_qwen3 m, bool with_head) {
+    const omx_qwen3_config& c = m->cfg;
+    hipStream_t s = m->stream;
+    const int hd = c.hidden_size, D = c.head_dim, bits = c.quant_bits, group = c.quant_group;
+    if (bits == 4) qembed_kernel<4><<<4, 256, 0, s>>>(m->h, m->q_embed.w, m->q_embed.scales, m->q_embed.biases, &m->st->cur_token, hd, group);
+    else qembed_kernel<8><<<4, 256, 0, s>>>(m->h, m->q_embed.w, m->q_embed.scales, m->q_embed.biases, &m->st->cur_token, hd, group);
+    OMX_LAUNCH_CHECK();
+    bf16_t* h = m->h;
+    bf16_t* hn = m->h2;
+    for (int l = 0; l < c.num_hidden_layers; ++l) {
+        const LayerW& L = m->layers[l];
+        const LayerQ& Q = m->qlayers[l];
+        {   // [RMSNorm + QKV]
+            QGemvArgs a = {};
+            a.m[0] = Q.q; a.m[1] = Q.k; a.m[2] = Q.v;
+            a.N = (m->H + 2 * m->Hkv) * D; a.K = hd; a.group = group;
+            a.x = h; a.norm_w = L.in_ln; a.eps = c.rms_norm_eps; a.out = m->qkv;
+            if (launch_qgemv(a, bits, PRO_RMSNORM, EPI_STORE, s)) return 1;
+        }
+        {   // [q/k RMSNorm + RoPE + cache append + split-KV SDPA] + [combine]: the bf16 kernels
+            AttnDecodeArgs a = {};
+            a.qkv = m->qkv;
+            a.k = m->kcache[l]; a.v = m->vcache[l];
+            a.kv_batch_stride = 0; a.kv_head_stride = (int64_t)m->cap * D;
+            a.B = 1; a.H = m->H; a.Hkv = m->Hkv;
+            a.scale = 1.0f / sqrtf((float)D);
+            a.mask_mode = OMX_MASK_NONE;
+            a.nsplit = m->nsplit;
+            a.ws_o = m->ws_o; a.ws_ml = m->ws_ml;
+            a.out = m->attn_out;
+            a.pos_ptr = &m->st->pos;
+            a.q_norm_w = L.q_norm; a.k_norm_w = L.k_norm;
+            a.rope_cos = m->rope_cos; a.rope_sin = m->rope_sin;
+            a.eps = c.rms_norm_eps;
+            if (launch_attn_decode(a, D, true, s)) return 1;
+        }
+        {   // [O + residual]
+            QGemvArgs a = {};
+            a.m[0] = Q.o; a.N = hd; a.K = m->H * D; a.group = group;
+            a.x = m->attn_out; a.resid = h; a.out = hn;
+            if (launch_qgemv(a, bits, PRO_NONE, EPI_RESIDUAL, s)) return 1;
+            bf16_t* t = h; h = hn; hn = t;
+        }
+        {   // [RMSNorm + gate/up + SwiGLU]
+            QGemvArgs a = {};
+            a.m[0] = Q.gate; a.m[1] = Q.up; a.N = m->I; a.K = hd; a.group = group;
+            a.x = h; a.norm_w = L.post_ln; a.eps = c.rms_norm_eps; a.out = m->act;
+            if (launch_qgemv(a, bits, PRO_RMSNORM, EPI_SWIGLU, s)) return 1;
+        }
+        {   // [down + residual]
+            QGemvArgs a = {};
+            a.m[0] = Q.down; a.N = hd; a.K = m->I; a.group = group;
+            a.x = m->act; a.resid = h; a.out = hn;
+            if (launch_qgemv(a, bits, PRO_NONE, EPI_RESIDUAL, s)) return 1;
+            bf16_t* t = h; h = hn; hn = t;
+        }
+    }
+    if (with_head) {
+        QGemvArgs a = {};
+        a.m[0] = m->q_head; a.m[0].n = m->V; a.N = m->V; a.K = hd; a.group = group;
+        a.x = h; a.norm_w = m->final_norm; a.eps = c.rms_norm_eps; a.out = m->logits;
+        a.argmax_slot = m->argmax_partials;
+        if (launch_qgemv(a, bits, PRO_RMSNORM, EPI_ARGMAX, s)) return 1;
+        sample_finalize_kernel<<<1, 256, 0, s>>>(m->st, m->argmax_partials, m->n_argmax_partials, m->out_ring, m->ring_cap, nullptr);
+        OMX_LAUNCH_CHECK();
+    } else {
+        feed_prompt_kernel<<<1, 1, 0, s>>>(m->st, m->prompt_dev);
+        OMX_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
 // enqueue one decode step on m->stream.  with_head=false: prompt token whose logits nobody reads.
 int enqueue_step(omx_qwen3 m, bool with_head) {
+    if (m->cfg.quant_bits) return enqueue_step_quant(m, with_head);
     const omx_qwen3_config& c = m->cfg;
     hipStream_t s = m->stream;
     const int hd = c.hidden_size, D = c.head_dim;
@@ -330,7 +461,7 @@ int setup_mega(omx_qwen3 m) {
     const omx_qwen3_config& c = m->cfg;
     const char* env = getenv("OMX_DECODE_MEGA");
     if (!env || env[0] != '1') return 0;   // opt-in until it beats the step graph
-    if (c.tp_size > 1 || m->allreduce != nullptr || c.num_hidden_layers < 1) return 0;
+    if (c.tp_size > 1 || m->allreduce != nullptr || c.num_hidden_layers < 1 || c.quant_bits) return 0;
     if (!mega_supported(c.hidden_size, m->H * c.head_dim, m->I, c.head_dim, m->H / m->Hkv)) return 0;
     int capacity = 0;
     if (mega_capacity(c.hidden_size, m->H * c.head_dim, m->I, &capacity)) return 1;
@@ -449,16 +580,46 @@ int prefill_prefix_batched(omx_qwen3 m, int T, int off) {
         }
         m->pf_cap = T;
     }
-    if (omx_take_rows(m->pf_h, m->embed, m->prompt_dev, T, hd, OMX_BFLOAT16, s)) return 1;
+    const bool quant = c.quant_bits != 0;
+    // quantized checkpoint: each weight is dequantised into one scratch matrix right before its GEMM (MLX's qmm does
+    // the same per tile); K is the contraction width of that weight
+    auto W = [&](const bf16_t* dense, const QMat* qm, int K) -> const bf16_t* {
+        if (!quant) return dense;
+        if (omx_dequantize(m->dq_buf, qm->w, qm->scales, qm->biases, qm->n, K, c.quant_group, c.quant_bits, OMX_BFLOAT16, s)) return nullptr;
+        return m->dq_buf;
+    };
+    if (quant) {
+        const size_t need = (size_t)std::max(std::max(H * D, I), hd) * (size_t)std::max(hd, I);
+        if (need > m->dq_cap) {
+            OMX_HIP_CHECK(hipStreamSynchronize(s));
+            if (m->dq_buf) OMX_HIP_CHECK(hipFree(m->dq_buf));
+            OMX_HIP_CHECK(hipMalloc((void**)&m->dq_buf, need * 2));
+            m->dq_cap = need;
+        }
+        // QuantizedEmbedding::forward: gather the packed rows, dequantise (quantized.rs:192-203)
+        const int wpr = hd * c.quant_bits / 32, gpr = hd / c.quant_group;
+        uint32_t* rows_w = (uint32_t*)m->pf_xn;                       // scratch: [T, wpr] u32 fits in [T, hd] bf16
+        bf16_t* rows_s = m->pf_h2;
+        bf16_t* rows_b = m->pf_h2 + (size_t)T * gpr;
+        if (omx_take_rows(rows_w, m->q_embed.w, m->prompt_dev, T, wpr, OMX_FLOAT32, s)) return 1;
+        if (omx_take_rows(rows_s, m->q_embed.scales, m->prompt_dev, T, gpr, OMX_BFLOAT16, s)) return 1;
+        if (omx_take_rows(rows_b, m->q_embed.biases, m->prompt_dev, T, gpr, OMX_BFLOAT16, s)) return 1;
+        if (omx_dequantize(m->pf_h, rows_w, rows_s, rows_b, T, hd, c.quant_group, c.quant_bits, OMX_BFLOAT16, s)) return 1;
+    } else if (omx_take_rows(m->pf_h, m->embed, m->prompt_dev, T, hd, OMX_BFLOAT16, s)) {
+        return 1;
+    }
     bf16_t* h = m->pf_h;
     bf16_t* h2 = m->pf_h2;
     const float scale = 1.0f / sqrtf((float)D);
+    const LayerQ no_q = {};
     for (int l = 0; l < c.num_hidden_layers; ++l) {
         const LayerW& L = m->layers[l];
+        const LayerQ& Q = quant ? m->qlayers[l] : no_q;
+        const bf16_t* w = nullptr;
         if (omx_rms_norm(m->pf_xn, h, L.in_ln, T, hd, c.rms_norm_eps, OMX_BFLOAT16, s)) return 1;
-        if (launch_gemm_bf16(m->pf_q, m->pf_xn, L.q, nullptr, T, H * D, hd, s)) return 1;
-        if (launch_gemm_bf16(m->pf_k, m->pf_xn, L.k, nullptr, T, Hkv * D, hd, s)) return 1;
-        if (launch_gemm_bf16(m->pf_v, m->pf_xn, L.v, nullptr, T, Hkv * D, hd, s)) return 1;
+        if (!(w = W(L.q, &Q.q, hd)) || launch_gemm_bf16(m->pf_q, m->pf_xn, w, nullptr, T, H * D, hd, s)) return 1;
+        if (!(w = W(L.k, &Q.k, hd)) || launch_gemm_bf16(m->pf_k, m->pf_xn, w, nullptr, T, Hkv * D, hd, s)) return 1;
+        if (!(w = W(L.v, &Q.v, hd)) || launch_gemm_bf16(m->pf_v, m->pf_xn, w, nullptr, T, Hkv * D, hd, s)) return 1;
         if (launch_qk_norm_rope_scatter(m->pf_q, m->pf_k, m->pf_v, L.q_norm, L.k_norm, m->rope_cos, m->rope_sin, m->pf_qt,
                                         m->kcache[l], m->vcache[l], T, H, Hkv, D, m->cap, off, c.rms_norm_eps, s))
             return 1;
@@ -466,12 +627,12 @@ int prefill_prefix_batched(omx_qwen3 m, int T, int off) {
         if (launch_attn_prefill(m->pf_attn, m->pf_qt, m->kcache[l], m->vcache[l], 1, H, Hkv, T, off + T, D, 0,
                                 (int64_t)m->cap * D, scale, OMX_MASK_CAUSAL, nullptr, s, /*out_token_major=*/true))
             return 1;
-        if (launch_gemm_bf16_ex(h2, m->pf_attn, L.o, nullptr, h, T, hd, H * D, s)) return 1;
+        if (!(w = W(L.o, &Q.o, H * D)) || launch_gemm_bf16_ex(h2, m->pf_attn, w, nullptr, h, T, hd, H * D, s)) return 1;
         if (omx_rms_norm(m->pf_xn, h2, L.post_ln, T, hd, c.rms_norm_eps, OMX_BFLOAT16, s)) return 1;
-        if (launch_gemm_bf16(m->pf_g, m->pf_xn, L.gate, nullptr, T, I, hd, s)) return 1;
-        if (launch_gemm_bf16(m->pf_u, m->pf_xn, L.up, nullptr, T, I, hd, s)) return 1;
+        if (!(w = W(L.gate, &Q.gate, hd)) || launch_gemm_bf16(m->pf_g, m->pf_xn, w, nullptr, T, I, hd, s)) return 1;
+        if (!(w = W(L.up, &Q.up, hd)) || launch_gemm_bf16(m->pf_u, m->pf_xn, w, nullptr, T, I, hd, s)) return 1;
         if (launch_silu_mul(m->pf_g, m->pf_g, m->pf_u, (int64_t)T * I, s)) return 1;
-        if (launch_gemm_bf16_ex(h, m->pf_g, L.down, nullptr, h2, T, hd, I, s)) return 1;
+        if (!(w = W(L.down, &Q.down, I)) || launch_gemm_bf16_ex(h, m->pf_g, w, nullptr, h2, T, hd, I, s)) return 1;
     }
     return 0;
 }
@@ -492,9 +653,14 @@ int omx_qwen3_create(omx_qwen3* out, const omx_qwen3_config* cfg) {
     OMX_REQUIRE(c.num_attention_heads % c.num_key_value_heads == 0, "InvalidConfig: heads %d not a multiple of kv heads %d", c.num_attention_heads, c.num_key_value_heads);
     OMX_REQUIRE(c.num_key_value_heads % c.tp_size == 0 && c.intermediate_size % c.tp_size == 0 && c.vocab_size % c.tp_size == 0,
                 "InvalidConfig: kv heads %d / intermediate %d / vocab %d must divide by tp_size %d", c.num_key_value_heads, c.intermediate_size, c.vocab_size, c.tp_size);
+    OMX_REQUIRE(c.quant_bits == 0 || c.quant_bits == 4 || c.quant_bits == 8, "InvalidConfig: quantization bits %d (0 = bf16, 4, 8)", c.quant_bits);
+    OMX_REQUIRE(c.quant_bits == 0 || c.tp_size == 1, "InvalidConfig: quantized checkpoints run on a single GPU (tp_size %d)", c.tp_size);
     omx_qwen3 m = new omx_qwen3_();
     m->cfg = c;
     if (m->cfg.rope_scale == 0.f) m->cfg.rope_scale = 1.f;
+    if (m->cfg.quant_bits && m->cfg.quant_group == 0) m->cfg.quant_group = 64;     // nn/quantized.rs:330-333
+    OMX_REQUIRE(!m->cfg.quant_bits || m->cfg.quant_group == 32 || m->cfg.quant_group == 64 || m->cfg.quant_group == 128,
+                "InvalidConfig: quantization group_size %d (32, 64, 128)", m->cfg.quant_group);
     m->H = c.num_attention_heads / c.tp_size;
     m->Hkv = c.num_key_value_heads / c.tp_size;
     m->I = c.intermediate_size / c.tp_size;
@@ -535,7 +701,7 @@ int omx_qwen3_create(omx_qwen3* out, const omx_qwen3_config* cfg) {
         return 1;
     m->prompt_cap = m->cap;
     if (dev_alloc(m, &m->prompt_dev, (size_t)m->prompt_cap + 1)) return 1;
-    m->n_argmax_partials = gemv_grid(m->V, c.hidden_size, EPI_ARGMAX, 0);
+    m->n_argmax_partials = m->cfg.quant_bits ? qgemv_grid(m->V) : gemv_grid(m->V, c.hidden_size, EPI_ARGMAX, 0);
     if (dev_alloc(m, &m->argmax_partials, (size_t)m->n_argmax_partials)) return 1;
     OMX_HIP_CHECK(hipStreamSynchronize(m->stream));
     *out = m;
@@ -548,6 +714,7 @@ int omx_qwen3_destroy(omx_qwen3 m) {
     if (m->g_full) (void)hipGraphExecDestroy(m->g_full);
     if (m->g_nohead) (void)hipGraphExecDestroy(m->g_nohead);
     for (void* p : m->owned) (void)hipFree(p);
+    if (m->dq_buf) (void)hipFree(m->dq_buf);
     for (bf16_t* p : {m->pf_h, m->pf_h2, m->pf_xn, m->pf_q, m->pf_k, m->pf_v, m->pf_qt, m->pf_attn, m->pf_g, m->pf_u})
         if (p) (void)hipFree(p);
     if (m->ev0) (void)hipEventDestroy(m->ev0);
@@ -584,6 +751,42 @@ int omx_qwen3_synth_weights(omx_qwen3 m, uint32_t base_seed) {
         return 0;
     };
     const int Hq = m->H * D, Hk = m->Hkv * D;
+    if (c.quant_bits) {
+        // the quantized model IS mlx quantize() of the synthetic bf16 model: generate each logical matrix into a scratch
+        // buffer with the bf16 generator, quantise it on the device, keep only the (weight, scales, biases) triplet
+        bf16_t* scratch = nullptr;
+        const size_t biggest = (size_t)std::max((int64_t)c.vocab_size, (int64_t)std::max(m->I, Hq)) * (size_t)std::max(hd, m->I);
+        OMX_HIP_CHECK(hipMalloc((void**)&scratch, biggest * 2));
+        auto makeq = [&](const std::string& prefix, int64_t rows, int64_t cols) -> int {
+            const uint32_t seed = base_seed ^ crc32_str((prefix + ".weight").c_str());
+            if (omx_fill_uniform_2d(scratch, rows, cols, cols, 0, 0, seed, amp_w, 0.0f, OMX_BFLOAT16, m->stream)) return 1;
+            uint32_t* pk = nullptr;
+            bf16_t *sc = nullptr, *bi = nullptr;
+            if (dev_alloc(m, &pk, (size_t)(rows * cols * c.quant_bits / 32)) || dev_alloc(m, &sc, (size_t)(rows * cols / c.quant_group)) ||
+                dev_alloc(m, &bi, (size_t)(rows * cols / c.quant_group)))
+                return 1;
+            if (omx_quantize(pk, sc, bi, scratch, rows, (int)cols, c.quant_group, c.quant_bits, OMX_BFLOAT16, m->stream)) return 1;
+            m->named[prefix + ".weight"] = pk;
+            m->named[prefix + ".scales"] = sc;
+            m->named[prefix + ".biases"] = bi;
+            return 0;
+        };
+        int rc = 0;
+        for (int i = 0; i < c.num_hidden_layers && !rc; ++i) {
+            const std::string p = "model.layers." + std::to_string(i) + ".";
+            rc = makeq(p + "self_attn.q_proj", Hq, hd) || makeq(p + "self_attn.k_proj", Hk, hd) || makeq(p + "self_attn.v_proj", Hk, hd) ||
+                 makeq(p + "self_attn.o_proj", hd, Hq) || makeq(p + "mlp.gate_proj", m->I, hd) || makeq(p + "mlp.up_proj", m->I, hd) ||
+                 makeq(p + "mlp.down_proj", hd, m->I) || make(p + "self_attn.q_norm.weight", 1, D, D, 0, 0, true) ||
+                 make(p + "self_attn.k_norm.weight", 1, D, D, 0, 0, true) || make(p + "input_layernorm.weight", 1, hd, hd, 0, 0, true) ||
+                 make(p + "post_attention_layernorm.weight", 1, hd, hd, 0, 0, true);
+        }
+        rc = rc || makeq("model.embed_tokens", c.vocab_size, hd) || make("model.norm.weight", 1, hd, hd, 0, 0, true);
+        if (!rc && !c.tie_word_embeddings) rc = makeq("lm_head", m->V, hd);
+        (void)hipStreamSynchronize(m->stream);
+        (void)hipFree(scratch);
+        m->weights_resolved = false;
+        return rc;
+    }
     for (int i = 0; i < c.num_hidden_layers; ++i) {
         const std::string p = "model.layers." + std::to_string(i) + ".";
         if (make(p + "self_attn.q_proj.weight", Hq, hd, hd, (int64_t)r * Hq, 0, false) ||
@@ -785,7 +988,9 @@ int omx_qwen3_step_bytes(omx_qwen3 m, int ctx, double* bytes) {
     const double D = c.head_dim, hd = c.hidden_size;
     // 2 B x [L (h H D + 2 h Hkv D + H D h + 3 h I) + V h] + ctx (2 L Hkv D 2 B) + KV write
     const double per_layer = hd * m->H * D + 2.0 * hd * m->Hkv * D + m->H * D * hd + 3.0 * hd * m->I;
-    const double w = 2.0 * (c.num_hidden_layers * per_layer + (double)m->V * hd);
+    // bytes per weight element: bf16 = 2; quantized = bits/8 packed + (scale + bias) bf16 per group
+    const double bpe = c.quant_bits ? c.quant_bits / 8.0 + 4.0 / c.quant_group : 2.0;
+    const double w = bpe * (c.num_hidden_layers * per_layer + (double)m->V * hd);
     const double kv = (double)ctx * (2.0 * c.num_hidden_layers * m->Hkv * D * 2.0) + 2.0 * c.num_hidden_layers * m->Hkv * D * 2.0;
     *bytes = w + kv;
     return 0;

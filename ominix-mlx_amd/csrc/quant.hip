@@ -15,6 +15,7 @@
 //   * M > 16 (prefill): dequantise W once into the workspace, then the bf16 MFMA GEMM (gemm.hip).
 #include "common.hpp"
 #include "gemm.hpp"
+#include "quant.hpp"
 #include "vec.hpp"
 #include "workspace.hpp"
 
@@ -93,35 +94,57 @@ __global__ __launch_bounds__(256) void dequantize_kernel(bf16_t* __restrict__ ou
     }
 }
 
-struct QGemvArgs {
-    const uint32_t* w;          // [E?][N, K*bits/32]
-    const bf16_t *scales, *biases;   // [E?][N, K/group]
-    const bf16_t* x;            // [n_x, K]
-    bf16_t* out;                // [n_batch, N]
-    int N, K, group, rows_per_wave;
-    int n_batch, x_div;         // batch entry j reads activation row j / x_div
-    const uint32_t* w_sel;      // optional [n_batch] expert ids
-    size_t w_estride, s_estride;    // words / groups between consecutive experts
-};
+__device__ __forceinline__ uint64_t qargmax_key(float v, uint32_t idx) {
+    uint32_t u = __float_as_uint(v);
+    u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+    if (v != v) u = 0;
+    return ((uint64_t)u << 32) | (uint32_t)(~idx);
+}
 
-// W = u32 words per lane per step; a lane's W*EPW elements lie inside one group
-template <int BITS, int W>
+// W = u32 words per lane per step; a lane's W*EPW elements lie inside one group.
+// PRO / EPI as in gemv.hip (same arithmetic and rounding points): RMSNorm prologue; store, residual add, SwiGLU
+// over (gate, up) row pairs, logits + greedy-argmax partial.
+template <int BITS, int W, int PRO, int EPI>
 __global__ __launch_bounds__(256) void qgemv_kernel(const QGemvArgs a) {
     constexpr int EPW = 32 / BITS, EPL = W * EPW;          // elements per lane per step
-    constexpr int RB = 4;                                   // rows in flight per wave
+    constexpr int LR = (EPI == EPI_SWIGLU) ? 2 : 1;         // physical rows per logical row
+    constexpr int RB = (EPI == EPI_SWIGLU) ? 2 : 4;         // logical rows in flight per wave
+    constexpr int NR = RB * LR;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     bf16_t* xs = reinterpret_cast<bf16_t*>(smem);                       // [K]
     float* xsum = reinterpret_cast<float*>(smem + (size_t)a.K * 2);     // [K / EPL]
+    float* red = xsum + a.K / EPL;                                      // [8]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int by = blockIdx.y;
     const bf16_t* xg = a.x + (size_t)(by / a.x_div) * a.K;
     const size_t e = a.w_sel ? a.w_sel[by] : 0;
-    const uint32_t* wq = a.w + e * a.w_estride;
-    const bf16_t* sc = a.scales + e * a.s_estride;
-    const bf16_t* bi = a.biases ? a.biases + e * a.s_estride : nullptr;
     bf16_t* out = a.out + (size_t)by * a.N;
 
-    for (int i = threadIdx.x * 8; i < a.K; i += 256 * 8) *reinterpret_cast<u32x4*>(xs + i) = *reinterpret_cast<const u32x4*>(xg + i);
+    // ---- prologue: x -> LDS as bf16 (RMS-normalised on the way in), then the per-chunk sums shared by all rows ----
+    if (PRO == PRO_RMSNORM) {
+        float ss = 0.f;
+        for (int i = threadIdx.x * 8; i < a.K; i += 256 * 8) {
+            const u32x4 raw = *reinterpret_cast<const u32x4*>(xg + i);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                ss = fmaf(bf16lo(raw[q]), bf16lo(raw[q]), ss);
+                ss = fmaf(bf16hi(raw[q]), bf16hi(raw[q]), ss);
+            }
+        }
+        ss = block_sum<4>(ss, red);
+        const float rstd = 1.0f / sqrtf(ss / (float)a.K + a.eps);
+        for (int i = threadIdx.x * 8; i < a.K; i += 256 * 8) {
+            const u32x4 raw = *reinterpret_cast<const u32x4*>(xg + i);
+            const u32x4 nw = *reinterpret_cast<const u32x4*>(a.norm_w + i);
+            u32x4 o;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                o[q] = pack_bf16(bf16lo(raw[q]) * rstd * bf16lo(nw[q]), bf16hi(raw[q]) * rstd * bf16hi(nw[q]));
+            *reinterpret_cast<u32x4*>(xs + i) = o;
+        }
+    } else {
+        for (int i = threadIdx.x * 8; i < a.K; i += 256 * 8) *reinterpret_cast<u32x4*>(xs + i) = *reinterpret_cast<const u32x4*>(xg + i);
+    }
     __syncthreads();
     for (int c = threadIdx.x; c < a.K / EPL; c += 256) {
         float s = 0.f;
@@ -135,21 +158,43 @@ __global__ __launch_bounds__(256) void qgemv_kernel(const QGemvArgs a) {
     const int words_per_row = a.K / EPW, groups_per_row = a.K / a.group;
     const int row_begin = (blockIdx.x * 4 + wave) * a.rows_per_wave;
     const int row_end = min(row_begin + a.rows_per_wave, a.N);
+    uint64_t best = 0;
+    // physical row pr of the batch: which member matrix, which row inside it
+    auto locate = [&](int pr, const uint32_t*& wq, const bf16_t*& sc, const bf16_t*& bi) {
+        int mi, row;
+        if (EPI == EPI_SWIGLU) {
+            mi = pr & 1;
+            row = min(pr >> 1, a.N - 1);
+        } else {
+            row = min(pr, a.N - 1);
+            mi = 0;
+            if (row >= a.m[0].n) { row -= a.m[0].n; mi = 1; if (row >= a.m[1].n) { row -= a.m[1].n; mi = 2; } }
+        }
+        const QMat& M = a.m[mi];
+        wq = M.w + e * a.w_estride + (size_t)row * words_per_row;
+        sc = M.scales + e * a.s_estride + (size_t)row * groups_per_row;
+        bi = M.biases ? M.biases + e * a.s_estride + (size_t)row * groups_per_row : nullptr;
+    };
     for (int r0 = row_begin; r0 < row_end; r0 += RB) {
-        float acc[RB];
+        float acc[NR];
+        const uint32_t* wq[NR];
+        const bf16_t* sc[NR];
+        const bf16_t* bi[NR];
 #pragma unroll
-        for (int r = 0; r < RB; ++r) acc[r] = 0.f;
+        for (int r = 0; r < NR; ++r) {
+            acc[r] = 0.f;
+            locate(EPI == EPI_SWIGLU ? 2 * (r0 + r / 2) + (r & 1) : r0 + r, wq[r], sc[r], bi[r]);
+        }
         for (int s = 0; s < steps; ++s) {
             const int chunk = s * 64 + lane;                 // lane-chunk index inside the row
-            uint32_t wd[RB][W];
-            float scl[RB], bs[RB];
+            uint32_t wd[NR][W];
+            float scl[NR], bs[NR];
 #pragma unroll
-            for (int r = 0; r < RB; ++r) {
-                const int row = min(r0 + r, a.N - 1);
-                const uint32_t* p = wq + (size_t)row * words_per_row + (size_t)chunk * W;
+            for (int r = 0; r < NR; ++r) {
+                const uint32_t* p = wq[r] + (size_t)chunk * W;
                 if (W == 4) {
                     const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
-                    wd[r][0] = v[0]; wd[r][1] = v[1]; wd[r][W > 2 ? 2 : 0] = v[2]; wd[r][W > 3 ? 3 : 0] = v[3];
+                    wd[r][0] = v[0]; wd[r][W > 1 ? 1 : 0] = v[1]; wd[r][W > 2 ? 2 : 0] = v[2]; wd[r][W > 3 ? 3 : 0] = v[3];
                 } else if (W == 2) {
                     const u32x2 v = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(p));
                     wd[r][0] = v[0]; wd[r][W > 1 ? 1 : 0] = v[1];
@@ -157,8 +202,8 @@ __global__ __launch_bounds__(256) void qgemv_kernel(const QGemvArgs a) {
                     wd[r][0] = __builtin_nontemporal_load(p);
                 }
                 const int g = chunk * EPL / a.group;
-                scl[r] = bf16_to_f32(sc[(size_t)row * groups_per_row + g]);
-                bs[r] = bi ? bf16_to_f32(bi[(size_t)row * groups_per_row + g]) : 0.f;
+                scl[r] = bf16_to_f32(sc[r][g]);
+                bs[r] = bi[r] ? bf16_to_f32(bi[r][g]) : 0.f;
             }
             float xf[EPL];
 #pragma unroll
@@ -169,7 +214,7 @@ __global__ __launch_bounds__(256) void qgemv_kernel(const QGemvArgs a) {
             }
             const float xsm = xsum[chunk];
 #pragma unroll
-            for (int r = 0; r < RB; ++r) {
+            for (int r = 0; r < NR; ++r) {
                 float d = 0.f;
 #pragma unroll
                 for (int wi = 0; wi < W; ++wi)
@@ -181,30 +226,80 @@ __global__ __launch_bounds__(256) void qgemv_kernel(const QGemvArgs a) {
             }
         }
 #pragma unroll
-        for (int r = 0; r < RB; ++r) {
-            const float v = wave_sum(acc[r]);
-            if (lane == 0 && r0 + r < row_end) out[r0 + r] = f32_to_bf16(v);
+        for (int r = 0; r < NR; ++r) acc[r] = wave_sum(acc[r]);
+        if (lane == 0) {
+#pragma unroll
+            for (int r = 0; r < RB; ++r) {
+                const int row = r0 + r;
+                if (row >= row_end) break;
+                const float v0 = acc[LR * r], v1 = acc[LR * r + (LR - 1)];
+                if (EPI == EPI_STORE) {
+                    out[row] = f32_to_bf16(v0);
+                } else if (EPI == EPI_RESIDUAL) {
+                    out[row] = f32_to_bf16(bf16_to_f32(a.resid[row]) + round_bf16(v0));
+                } else if (EPI == EPI_SWIGLU) {
+                    // nn::silu(gate) * up, every primitive's result held in bf16 (qwen3-mlx/src/model.rs:264-265)
+                    const float g = round_bf16(v0), u = round_bf16(v1);
+                    const float sg = round_bf16(1.0f / (1.0f + expf(-g)));
+                    out[row] = f32_to_bf16(round_bf16(g * sg) * u);
+                } else if (EPI == EPI_ARGMAX) {
+                    const bf16_t lb = f32_to_bf16(v0);
+                    out[row] = lb;
+                    const uint64_t key = qargmax_key(bf16_to_f32(lb), (uint32_t)row);
+                    best = key > best ? key : best;
+                }
+            }
+        }
+    }
+    if (EPI == EPI_ARGMAX) {
+        uint64_t* bred = reinterpret_cast<uint64_t*>(red);
+        __syncthreads();
+        if (lane == 0) bred[wave] = best;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint64_t b = bred[0];
+#pragma unroll
+            for (int w = 1; w < 4; ++w) b = bred[w] > b ? bred[w] : b;
+            a.argmax_slot[blockIdx.x] = b;
         }
     }
 }
 
+template <int BITS, int W>
+int launch_qgemv_w(const QGemvArgs& a, int pro, int epi, hipStream_t s) {
+    constexpr int EPW = 32 / BITS;
+    const int groups = (a.N + a.rows_per_wave - 1) / a.rows_per_wave;
+    const dim3 grid((groups + 3) / 4, a.n_batch > 1 ? a.n_batch : 1), block(256);
+    const size_t shmem = (size_t)a.K * 2 + (size_t)(a.K / (W * EPW)) * 4 + 64;
+#define OMX_QGEMV_CASE(P, E)                                                     \
+    if (pro == P && epi == E) {                                                  \
+        qgemv_kernel<BITS, W, P, E><<<grid, block, shmem, s>>>(a);                \
+        OMX_LAUNCH_CHECK();                                                      \
+        return 0;                                                                \
+    }
+    OMX_QGEMV_CASE(PRO_NONE, EPI_STORE)
+    OMX_QGEMV_CASE(PRO_RMSNORM, EPI_STORE)
+    OMX_QGEMV_CASE(PRO_NONE, EPI_RESIDUAL)
+    OMX_QGEMV_CASE(PRO_RMSNORM, EPI_SWIGLU)
+    OMX_QGEMV_CASE(PRO_RMSNORM, EPI_ARGMAX)
+#undef OMX_QGEMV_CASE
+    return set_error("quantized gemv: unsupported prologue/epilogue combination %d/%d", pro, epi);
+}
+
 template <int BITS>
-int launch_qgemv_bits(const QGemvArgs& a_in, hipStream_t s) {
+int launch_qgemv_bits(const QGemvArgs& a_in, int pro, int epi, hipStream_t s) {
     QGemvArgs a = a_in;
     constexpr int EPW = 32 / BITS;
     int W = 4;
     while (W > 1 && (a.K % (64 * W * EPW) != 0 || W * EPW > a.group)) W >>= 1;
     OMX_REQUIRE(a.K % (64 * W * EPW) == 0 && W * EPW <= a.group, "quantized_matmul: K=%d unsupported for %d-bit group %d (K must be a multiple of %d)",
                 a.K, BITS, a.group, 64 * EPW);
-    a.rows_per_wave = a.N >= 8192 ? 8 : 4;
-    const int groups = (a.N + a.rows_per_wave - 1) / a.rows_per_wave;
-    const dim3 grid((groups + 3) / 4, a.n_batch), block(256);
-    const size_t shmem = (size_t)a.K * 2 + (size_t)(a.K / (W * EPW)) * 4;
-    if (W == 4) qgemv_kernel<BITS, 4><<<grid, block, shmem, s>>>(a);
-    else if (W == 2) qgemv_kernel<BITS, 2><<<grid, block, shmem, s>>>(a);
-    else qgemv_kernel<BITS, 1><<<grid, block, shmem, s>>>(a);
-    OMX_LAUNCH_CHECK();
-    return 0;
+    if (a.n_batch < 1) a.n_batch = 1;
+    if (a.x_div < 1) a.x_div = 1;
+    a.rows_per_wave = 8;
+    if (W == 4) return launch_qgemv_w<BITS, 4>(a, pro, epi, s);
+    if (W == 2) return launch_qgemv_w<BITS, 2>(a, pro, epi, s);
+    return launch_qgemv_w<BITS, 1>(a, pro, epi, s);
 }
 
 int check_format(const char* who, int K, int group, int bits, int dtype) {
@@ -216,6 +311,14 @@ int check_format(const char* who, int K, int group, int bits, int dtype) {
 }
 
 }  // namespace
+
+int qgemv_grid(int N) { return ((N + 7) / 8 + 3) / 4; }
+
+int launch_qgemv(const QGemvArgs& a, int bits, int pro, int epi, hipStream_t s) {
+    OMX_REQUIRE(bits == 4 || bits == 8, "quantized gemv: bits must be 4 or 8 (got %d)", bits);
+    return bits == 4 ? launch_qgemv_bits<4>(a, pro, epi, s) : launch_qgemv_bits<8>(a, pro, epi, s);
+}
+
 }  // namespace omx
 
 using namespace omx;
@@ -256,10 +359,10 @@ extern "C" int omx_quantized_matmul(void* out, const void* x, const void* packed
     hipStream_t s = (hipStream_t)stream;
     if (M <= 16 && K % (64 * (32 / bits)) == 0) {
         QGemvArgs a = {};
-        a.w = (const uint32_t*)packed; a.scales = (const bf16_t*)scales; a.biases = (const bf16_t*)biases;
+        a.m[0] = QMat{(const uint32_t*)packed, (const bf16_t*)scales, (const bf16_t*)biases, N};
         a.x = (const bf16_t*)x; a.out = (bf16_t*)out; a.N = N; a.K = K; a.group = group_size;
         a.n_batch = M; a.x_div = 1;
-        return bits == 4 ? launch_qgemv_bits<4>(a, s) : launch_qgemv_bits<8>(a, s);
+        return launch_qgemv(a, bits, PRO_NONE, EPI_STORE, s);
     }
     void* ws = nullptr;
     if (get_workspace(&ws, (size_t)N * K * 2)) return 1;
@@ -278,9 +381,9 @@ extern "C" int omx_gather_qmm(void* out, const void* x, const void* packed, cons
     OMX_REQUIRE(K % (64 * (32 / bits)) == 0, "omx_gather_qmm: K=%d must be a multiple of %d", K, 64 * (32 / bits));
     if (n_rows == 0) return 0;
     QGemvArgs a = {};
-    a.w = (const uint32_t*)packed; a.scales = (const bf16_t*)scales; a.biases = (const bf16_t*)biases;
+    a.m[0] = QMat{(const uint32_t*)packed, (const bf16_t*)scales, (const bf16_t*)biases, N};
     a.x = (const bf16_t*)x; a.out = (bf16_t*)out; a.N = N; a.K = K; a.group = group_size;
     a.n_batch = n_rows; a.x_div = x_div; a.w_sel = rhs_indices;
     a.w_estride = (size_t)N * K * bits / 32; a.s_estride = (size_t)N * (K / group_size);
-    return bits == 4 ? launch_qgemv_bits<4>(a, (hipStream_t)stream) : launch_qgemv_bits<8>(a, (hipStream_t)stream);
+    return launch_qgemv(a, bits, PRO_NONE, EPI_STORE, (hipStream_t)stream);
 }

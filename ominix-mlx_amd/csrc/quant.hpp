@@ -1,0 +1,34 @@
+// Packed-weight (MLX affine 4/8-bit) GEMV family: the decode-time Linear of a quantized checkpoint
+// (nn::QuantizedLinear::forward, mlx-rs/src/nn/quantized.rs:361-385; quant.hip for the format).
+#pragma once
+#include "common.hpp"
+#include "gemv.hpp"   // PRO_* / EPI_* codes shared with the bf16 GEMV family
+
+namespace omx {
+
+struct QMat {               // one member of a row-stacked weight (q | k | v) -- or gate (0) / up (1) for SwiGLU
+    const uint32_t* w;      // [n, K*bits/32]
+    const bf16_t* scales;   // [n, K/group]
+    const bf16_t* biases;   // [n, K/group] or null
+    int n;
+};
+
+struct QGemvArgs {
+    QMat m[3];
+    int N, K, group;
+    const bf16_t* x;            // [n_x, K]
+    const bf16_t* norm_w;       // PRO_RMSNORM
+    float eps;
+    const bf16_t* resid;        // EPI_RESIDUAL
+    bf16_t* out;                // [n_batch, N]
+    unsigned long long* argmax_slot;   // EPI_ARGMAX: one partial per block
+    int rows_per_wave;
+    int n_batch, x_div;         // batch entry j reads activation row j / x_div
+    const uint32_t* w_sel;      // optional [n_batch] expert ids (gather_qmm)
+    size_t w_estride, s_estride;    // words / groups between consecutive experts
+};
+
+int launch_qgemv(const QGemvArgs& a, int bits, int pro, int epi, hipStream_t s);
+int qgemv_grid(int N);          // blocks launch_qgemv uses == argmax partials written
+
+}  // namespace omx

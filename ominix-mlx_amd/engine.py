@@ -19,7 +19,8 @@ class Qwen3Config(ctypes.Structure):
     _fields_ = [("hidden_size", c_int), ("num_hidden_layers", c_int), ("intermediate_size", c_int),
                 ("num_attention_heads", c_int), ("num_key_value_heads", c_int), ("head_dim", c_int),
                 ("vocab_size", c_int), ("rms_norm_eps", c_float), ("rope_theta", c_float), ("rope_scale", c_float),
-                ("tie_word_embeddings", c_int), ("max_context", c_int), ("tp_rank", c_int), ("tp_size", c_int)]
+                ("tie_word_embeddings", c_int), ("max_context", c_int), ("tp_rank", c_int), ("tp_size", c_int),
+                ("quant_bits", c_int), ("quant_group", c_int)]
 
 
 ENGINE_SIGNATURES = {
@@ -70,12 +71,15 @@ class Model:
 
     def __init__(self, *, hidden_size, num_hidden_layers, intermediate_size, num_attention_heads,
                  num_key_value_heads, head_dim, vocab_size, rms_norm_eps=1e-6, rope_theta=1e6,
-                 tie_word_embeddings=False, rope_scaling=None, max_context=4096, tp_rank=0, tp_size=1, **_ignored):
+                 tie_word_embeddings=False, rope_scaling=None, max_context=4096, tp_rank=0, tp_size=1, quantization=None,
+                 **_ignored):
+        """quantization: config.json's {"bits": 4|8, "group_size": 64} (model.rs:63) or None for a bf16 checkpoint."""
         require_device()
+        q = quantization or {}
         self.cfg = Qwen3Config(hidden_size, num_hidden_layers, intermediate_size, num_attention_heads,
                                num_key_value_heads, head_dim, vocab_size, rms_norm_eps, rope_theta,
                                rope_scale_from_config(rope_scaling), int(bool(tie_word_embeddings)), max_context,
-                               tp_rank, tp_size)
+                               tp_rank, tp_size, int(q.get("bits", 0)), int(q.get("group_size", 64 if q else 0)))
         self._h = c_void_p()
         check(lib.omx_qwen3_create(ctypes.byref(self._h), ctypes.byref(self.cfg)))
         self._keep = []
@@ -102,7 +106,8 @@ class Model:
             from . import tp
             weights = tp.shard_state_dict(weights, self.cfg.tp_rank, self.cfg.tp_size, bool(self.cfg.tie_word_embeddings))
         for name, arr in weights.items():
-            t = Tensor.from_numpy(arr, "bf16")
+            # quantized checkpoints: "<prefix>.weight" is packed uint32 (ops/quantization.rs:41-84), scales / biases bf16
+            t = Tensor.from_numpy(arr, "u32" if np.asarray(arr).dtype == np.uint32 else "bf16")
             self._keep.append(t)
             check(lib.omx_qwen3_set_weight(self._h, name.encode(), t.ptr))
 

@@ -88,20 +88,50 @@ def synth_weights(cfg: Qwen3Config, dt: str = "bf16") -> Dict[str, np.ndarray]:
     return out
 
 
+QUANTIZED = ("self_attn.q_proj", "self_attn.k_proj", "self_attn.v_proj", "self_attn.o_proj", "mlp.gate_proj", "mlp.up_proj",
+             "mlp.down_proj")
+
+
+def quantize_weights(cfg: Qwen3Config, weights: Dict[str, np.ndarray], bits: int = 4, group_size: int = 64) -> Dict[str, np.ndarray]:
+    """What an MLX-quantized checkpoint of this model holds (qwen3-mlx/src/model.rs:621-727): every Linear and the
+    embedding as (weight uint32, scales, biases) triplets -- mlx quantize() of the bf16 tensors, scales/biases in bf16;
+    norm weights unchanged."""
+    out = {}
+    for name, w in weights.items():
+        prefix = name[:-len(".weight")]
+        if prefix.endswith(QUANTIZED) or prefix in ("model.embed_tokens", "lm_head"):
+            q, s, b = rc.quantize(w, group_size, bits)
+            out[prefix + ".weight"], out[prefix + ".scales"], out[prefix + ".biases"] = q, rc.bf16_round(s), rc.bf16_round(b)
+        else:
+            out[name] = w
+    return out
+
+
 class Qwen3Oracle:
-    def __init__(self, cfg: Qwen3Config, weights: Dict[str, np.ndarray], dt: str = "bf16"):
-        self.cfg, self.w, self.dt = cfg, weights, dt
+    """quant = (bits, group_size): `weights` is a quantized checkpoint (quantize_weights); every Linear becomes
+    quantized_matmul (nn/quantized.rs:366-375), the embedding dequantises the gathered rows (:192-203) and a tied head is
+    QuantizedEmbedding::as_linear (:166-180)."""
+
+    def __init__(self, cfg: Qwen3Config, weights: Dict[str, np.ndarray], dt: str = "bf16", quant=None):
+        self.cfg, self.w, self.dt, self.quant = cfg, weights, dt, quant
         self.rope = rc.initialize_rope(cfg.head_dim, cfg.rope_theta, False, cfg.rope_scaling)
         self.scale = float(np.float32(1.0) / np.sqrt(np.float32(cfg.head_dim)))
+
+    def lin(self, x, prefix: str):
+        if self.quant is None:
+            return rc.linear(x, self.w[prefix + ".weight"], None, self.dt)
+        bits, group = self.quant
+        return rc.quantized_matmul(x, self.w[prefix + ".weight"], self.w[prefix + ".scales"], self.w[prefix + ".biases"], group,
+                                   bits, self.dt)
 
     # model.rs:161-215
     def attention(self, i: int, x, mask, cache):
         cfg, dt = self.cfg, self.dt
         p = f"model.layers.{i}.self_attn."
         B, L, _ = x.shape
-        q = rc.linear(x, self.w[p + "q_proj.weight"], None, dt)
-        k = rc.linear(x, self.w[p + "k_proj.weight"], None, dt)
-        v = rc.linear(x, self.w[p + "v_proj.weight"], None, dt)
+        q = self.lin(x, p + "q_proj")
+        k = self.lin(x, p + "k_proj")
+        v = self.lin(x, p + "v_proj")
         q = q.reshape(B, L, cfg.num_attention_heads, -1).transpose(0, 2, 1, 3)
         k = k.reshape(B, L, cfg.num_key_value_heads, -1).transpose(0, 2, 1, 3)
         v = v.reshape(B, L, cfg.num_key_value_heads, -1).transpose(0, 2, 1, 3)
@@ -120,16 +150,16 @@ class Qwen3Oracle:
             m = None
         o = rc.scaled_dot_product_attention(q, k, v, self.scale, m, dt)
         o = o.transpose(0, 2, 1, 3).reshape(B, L, -1)
-        return rc.linear(o, self.w[p + "o_proj.weight"], None, dt)
+        return self.lin(o, p + "o_proj")
 
     # model.rs:263-267
     def mlp(self, i: int, x):
         p = f"model.layers.{i}.mlp."
         dt = self.dt
-        g = rc.linear(x, self.w[p + "gate_proj.weight"], None, dt)
-        u = rc.linear(x, self.w[p + "up_proj.weight"], None, dt)
+        g = self.lin(x, p + "gate_proj")
+        u = self.lin(x, p + "up_proj")
         act = rc.multiply(rc.silu(g, dt), u, dt)
-        return rc.linear(act, self.w[p + "down_proj.weight"], None, dt)
+        return self.lin(act, p + "down_proj")
 
     # model.rs:321-332
     def block(self, i: int, x, mask, cache):
@@ -145,7 +175,12 @@ class Qwen3Oracle:
         """tokens [B, L] -> logits [B, L, V] (lm_head applied to ALL positions, as the reference does)."""
         cfg = self.cfg
         tokens = np.asarray(tokens)
-        h = self.w["model.embed_tokens.weight"][tokens]          # Embedding gather
+        if self.quant is None:
+            h = self.w["model.embed_tokens.weight"][tokens]      # Embedding gather
+        else:
+            bits, group = self.quant
+            h = rc.dequantize(self.w["model.embed_tokens.weight"][tokens], self.w["model.embed_tokens.scales"][tokens],
+                              self.w["model.embed_tokens.biases"][tokens], group, bits, self.dt)
         T = h.shape[1]
         off = caches[0].offset() if caches else None
         m = rc.create_attention_mask(T, off, None, True)        # every caller passes Some(true) (model.rs:401)
@@ -155,8 +190,7 @@ class Qwen3Oracle:
         for i in range(cfg.num_hidden_layers):
             h = self.block(i, h, mask, caches[i])
         h = rc.rms_norm(h, self.w["model.norm.weight"], cfg.rms_norm_eps, self.dt)
-        head = self.w["model.embed_tokens.weight"] if cfg.tie_word_embeddings else self.w["lm_head.weight"]
-        return rc.linear(h, head, None, self.dt)
+        return self.lin(h, "model.embed_tokens" if cfg.tie_word_embeddings else "lm_head")
 
     # model.rs:804-843 (yield order == plain sequential greedy decoding)
     def generate(self, prompt: np.ndarray, n_new: int, caches: Optional[List] = None, return_logits: bool = False):

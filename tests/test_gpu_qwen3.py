@@ -255,3 +255,49 @@ def test_tensor_parallel_two_ranks_on_one_gpu(omx, monkeypatch):
     for m in models:
         m.close()
     group.close()
+
+
+@pytest.mark.parametrize("name,bits,group", [("gqa4_d128", 4, 64), ("gqa2_d64", 4, 64), ("gqa4_d128", 8, 64)])
+def test_quantized_checkpoint_decode_matches_oracle(omx, name, bits, group):
+    """MLX-quantized checkpoint (config.json "quantization", qwen3-mlx/src/model.rs:621-727): every Linear is a
+    (weight, scales, biases) triplet, the embedding dequantises its rows, a tied head is as_linear.  The decode
+    step streams the PACKED weights (csrc/quant.hip), the batched prefill dequantises per GEMM; tokens and logits
+    against the oracle running quantized_matmul on the same triplets, with the tolerance of the bf16 engine.
+    The device generator (synth_weights in quantized mode = mlx quantize() of the synthetic bf16 model) must give
+    the same model as uploading the oracle's triplets."""
+    from ominix_mlx_amd import engine
+    cfg = CONFIGS[name]
+    qw = rq.quantize_weights(cfg, rq.synth_weights(cfg), bits, group)
+    oracle = rq.Qwen3Oracle(cfg, qw, quant=(bits, group))
+    n_prompt, n_new = 48, 10
+    prompt = synth.prompt_ids(n_prompt, cfg.vocab_size)
+    ref_tokens, ref_logits = oracle.generate(prompt, n_new, return_logits=True)
+
+    def make(upload):
+        m = engine.Model(hidden_size=cfg.hidden_size, num_hidden_layers=cfg.num_hidden_layers,
+                         intermediate_size=cfg.intermediate_size, num_attention_heads=cfg.num_attention_heads,
+                         num_key_value_heads=cfg.num_key_value_heads, head_dim=cfg.head_dim, vocab_size=cfg.vocab_size,
+                         rms_norm_eps=cfg.rms_norm_eps, rope_theta=cfg.rope_theta, tie_word_embeddings=cfg.tie_word_embeddings,
+                         rope_scaling=cfg.rope_scaling, max_context=256, quantization={"bits": bits, "group_size": group})
+        m.load_weights(qw) if upload else m.synth_weights()
+        return m
+
+    outs = []
+    for upload in (True, False):
+        m = make(upload)
+        first = m.prefill(prompt)
+        logits0 = m.last_logits()
+        got = np.concatenate([[first], m.decode(n_new - 1)]).astype(np.uint32)
+        assert m.decode_path() == "graph"
+        outs.append((got, logits0))
+        m.close()
+    np.testing.assert_array_equal(outs[0][0], outs[1][0])
+    np.testing.assert_array_equal(outs[0][1], outs[1][1])
+    got, logits0 = outs[0]
+    bound = 2.0 ** -7 * np.abs(ref_logits).max() * np.sqrt(cfg.num_hidden_layers)
+    assert np.abs(logits0 - ref_logits[0]).max() <= bound
+    margins = rc.argmax_margin(ref_logits)
+    for i in range(n_new):
+        if got[i] != ref_tokens[i]:
+            assert margins[i] <= 2 * bound, f"token {i}: got {got[i]} want {ref_tokens[i]} with margin {margins[i]:.4f} > {2*bound:.4f}"
+            break

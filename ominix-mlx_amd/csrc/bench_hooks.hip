@@ -166,3 +166,62 @@ extern "C" int omx_bench_grid_barrier(int nblocks, int iters, int variant, float
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     return 0;
 }
+
+// ---- packed-weight GEMV (quant.hip): one shape, weights rotated over n_copies buffers, HIP events ----
+#include "quant.hpp"
+extern "C" int omx_bench_qgemv(int N, int K, int bits, int pro, int epi, int n_copies, int iters, float* avg_ms) {
+    using namespace omx;
+    OMX_REQUIRE(avg_ms && n_copies > 0 && iters > 0, "omx_bench_qgemv: bad arguments");
+    const int mats = (epi == EPI_SWIGLU) ? 2 : 1;
+    const size_t wwords = (size_t)N * K * bits / 32, ngroups = (size_t)N * K / 64;
+    std::vector<uint32_t*> w(n_copies * mats, nullptr);
+    std::vector<bf16_t*> sc(n_copies * mats, nullptr), bi(n_copies * mats, nullptr);
+    for (size_t i = 0; i < w.size(); ++i) {
+        OMX_HIP_CHECK(hipMalloc((void**)&w[i], wwords * 4));
+        OMX_HIP_CHECK(hipMalloc((void**)&sc[i], ngroups * 2));
+        OMX_HIP_CHECK(hipMalloc((void**)&bi[i], ngroups * 2));
+        if (omx_fill_uniform(w[i], wwords * 2, 70u + (uint32_t)i, 1.0f, 0.f, OMX_BFLOAT16, nullptr)) return 1;   // arbitrary nibbles
+        if (omx_fill_uniform(sc[i], ngroups, 90u + (uint32_t)i, 0.002f, 0.004f, OMX_BFLOAT16, nullptr)) return 1;
+        if (omx_fill_uniform(bi[i], ngroups, 110u + (uint32_t)i, 0.03f, 0.f, OMX_BFLOAT16, nullptr)) return 1;
+    }
+    void *x = nullptr, *nw = nullptr, *out = nullptr, *resid = nullptr, *slot = nullptr;
+    OMX_HIP_CHECK(hipMalloc(&x, (size_t)K * 2));
+    OMX_HIP_CHECK(hipMalloc(&nw, (size_t)K * 2));
+    OMX_HIP_CHECK(hipMalloc(&out, (size_t)N * 4));
+    OMX_HIP_CHECK(hipMalloc(&resid, (size_t)N * 2));
+    OMX_HIP_CHECK(hipMalloc(&slot, 8 * 65536));
+    omx_fill_uniform(x, K, 3, 1.0f, 0.f, OMX_BFLOAT16, nullptr);
+    omx_fill_uniform(nw, K, 4, 0.1f, 1.f, OMX_BFLOAT16, nullptr);
+    omx_fill_uniform(resid, N, 5, 1.0f, 0.f, OMX_BFLOAT16, nullptr);
+    hipStream_t s;
+    OMX_HIP_CHECK(hipStreamCreate(&s));
+    hipEvent_t e0, e1;
+    OMX_HIP_CHECK(hipEventCreate(&e0));
+    OMX_HIP_CHECK(hipEventCreate(&e1));
+    auto run = [&](int i) {
+        QGemvArgs a = {};
+        const int c = (i % n_copies) * mats;
+        a.m[0] = QMat{w[c], sc[c], bi[c], N};
+        if (mats == 2) a.m[1] = QMat{w[c + 1], sc[c + 1], bi[c + 1], N};
+        a.N = N; a.K = K; a.group = 64;
+        a.x = (const bf16_t*)x; a.norm_w = (const bf16_t*)nw; a.eps = 1e-6f; a.resid = (const bf16_t*)resid;
+        a.out = (bf16_t*)out; a.argmax_slot = (unsigned long long*)slot;
+        return launch_qgemv(a, bits, pro, epi, s);
+    };
+    OMX_HIP_CHECK(hipDeviceSynchronize());
+    for (int i = 0; i < n_copies + 2; ++i)
+        if (run(i)) return 1;
+    OMX_HIP_CHECK(hipStreamSynchronize(s));
+    OMX_HIP_CHECK(hipEventRecord(e0, s));
+    for (int i = 0; i < iters; ++i)
+        if (run(i)) return 1;
+    OMX_HIP_CHECK(hipEventRecord(e1, s));
+    OMX_HIP_CHECK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    OMX_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+    *avg_ms = ms / iters;
+    for (size_t i = 0; i < w.size(); ++i) { (void)hipFree(w[i]); (void)hipFree(sc[i]); (void)hipFree(bi[i]); }
+    (void)hipFree(x); (void)hipFree(nw); (void)hipFree(out); (void)hipFree(resid); (void)hipFree(slot);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipStreamDestroy(s);
+    return 0;
+}

@@ -120,7 +120,18 @@ __global__ __launch_bounds__(256) void qgemv_kernel(const QGemvArgs a) {
     const size_t e = a.w_sel ? a.w_sel[by] : 0;
     bf16_t* out = a.out + (size_t)by * a.N;
 
-    // ---- prologue: x -> LDS as bf16 (RMS-normalised on the way in), then the per-chunk sums shared by all rows ----
+    // ---- prologue: x -> LDS as bf16 (RMS-normalised on the way in) and, in the same pass, the per-chunk sums
+    //      sum(x_i) that every row's bias term shares (EPL elements = EPL/8 consecutive threads, reduced by DPP) ----
+    static_assert(EPL >= 8, "a lane chunk must cover at least one 16-byte activation vector");
+    auto put = [&](int i, const u32x4 o) {
+        *reinterpret_cast<u32x4*>(xs + i) = o;
+        float sv = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) sv += bf16lo(o[q]) + bf16hi(o[q]);
+        if (EPL >= 16) sv += dpp_f<kDppXor1>(sv);
+        if (EPL >= 32) sv += dpp_f<kDppXor2>(sv);
+        if (((i >> 3) & (EPL / 8 - 1)) == 0) xsum[i / EPL] = sv;
+    };
     if (PRO == PRO_RMSNORM) {
         float ss = 0.f;
         for (int i = threadIdx.x * 8; i < a.K; i += 256 * 8) {
@@ -140,17 +151,10 @@ __global__ __launch_bounds__(256) void qgemv_kernel(const QGemvArgs a) {
 #pragma unroll
             for (int q = 0; q < 4; ++q)
                 o[q] = pack_bf16(bf16lo(raw[q]) * rstd * bf16lo(nw[q]), bf16hi(raw[q]) * rstd * bf16hi(nw[q]));
-            *reinterpret_cast<u32x4*>(xs + i) = o;
+            put(i, o);
         }
     } else {
-        for (int i = threadIdx.x * 8; i < a.K; i += 256 * 8) *reinterpret_cast<u32x4*>(xs + i) = *reinterpret_cast<const u32x4*>(xg + i);
-    }
-    __syncthreads();
-    for (int c = threadIdx.x; c < a.K / EPL; c += 256) {
-        float s = 0.f;
-#pragma unroll
-        for (int j = 0; j < EPL; ++j) s += bf16_to_f32(xs[c * EPL + j]);
-        xsum[c] = s;
+        for (int i = threadIdx.x * 8; i < a.K; i += 256 * 8) put(i, *reinterpret_cast<const u32x4*>(xg + i));
     }
     __syncthreads();
 
@@ -175,81 +179,125 @@ __global__ __launch_bounds__(256) void qgemv_kernel(const QGemvArgs a) {
         sc = M.scales + e * a.s_estride + (size_t)row * groups_per_row;
         bi = M.biases ? M.biases + e * a.s_estride + (size_t)row * groups_per_row : nullptr;
     };
-    for (int r0 = row_begin; r0 < row_end; r0 += RB) {
-        float acc[NR];
-        const uint32_t* wq[NR];
-        const bf16_t* sc[NR];
-        const bf16_t* bi[NR];
+    // A "unit" = one K step of one batch of RB logical rows (NR physical rows): NR x W words + NR scales + NR biases per
+    // lane.  Units of consecutive steps / batches are streamed through TWO register sets: the loads of unit f+1 are in
+    // flight while unit f is multiplied (the weights are read once, straight to registers, non-temporal).
+    struct Unit {
+        uint32_t wd[NR][W];
+        bf16_t sc[NR], bi[NR];
+    };
+    const int nbatch = (row_end - row_begin + RB - 1) / RB;
+    const int nunits = nbatch > 0 ? nbatch * steps : 0;
+    const uint32_t* rw[NR];      // row pointers of the batch being ISSUED (issue order is monotonic in f)
+    const bf16_t* rs[NR];
+    const bf16_t* rb[NR];
+    auto issue = [&](Unit& u, int f) {
+        const int st = f % steps;
+        if (st == 0) {
+            const int r0 = row_begin + (f / steps) * RB;
+#pragma unroll
+            for (int r = 0; r < NR; ++r) locate(EPI == EPI_SWIGLU ? 2 * (r0 + r / 2) + (r & 1) : r0 + r, rw[r], rs[r], rb[r]);
+        }
+        const int chunk = st * 64 + lane;
+        const int g = chunk * EPL / a.group;
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
-            acc[r] = 0.f;
-            locate(EPI == EPI_SWIGLU ? 2 * (r0 + r / 2) + (r & 1) : r0 + r, wq[r], sc[r], bi[r]);
+            const uint32_t* p = rw[r] + (size_t)chunk * W;
+            if (W == 4) {
+                const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
+                u.wd[r][0] = v[0]; u.wd[r][W > 1 ? 1 : 0] = v[1]; u.wd[r][W > 2 ? 2 : 0] = v[2]; u.wd[r][W > 3 ? 3 : 0] = v[3];
+            } else if (W == 2) {
+                const u32x2 v = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(p));
+                u.wd[r][0] = v[0]; u.wd[r][W > 1 ? 1 : 0] = v[1];
+            } else {
+                u.wd[r][0] = __builtin_nontemporal_load(p);
+            }
+            u.sc[r] = rs[r][g];
+            u.bi[r] = rb[r] ? rb[r][g] : (bf16_t)0;
         }
-        for (int s = 0; s < steps; ++s) {
-            const int chunk = s * 64 + lane;                 // lane-chunk index inside the row
-            uint32_t wd[NR][W];
-            float scl[NR], bs[NR];
+    };
+    float acc[NR];
 #pragma unroll
-            for (int r = 0; r < NR; ++r) {
-                const uint32_t* p = wq[r] + (size_t)chunk * W;
-                if (W == 4) {
-                    const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
-                    wd[r][0] = v[0]; wd[r][W > 1 ? 1 : 0] = v[1]; wd[r][W > 2 ? 2 : 0] = v[2]; wd[r][W > 3 ? 3 : 0] = v[3];
-                } else if (W == 2) {
-                    const u32x2 v = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(p));
-                    wd[r][0] = v[0]; wd[r][W > 1 ? 1 : 0] = v[1];
+    for (int r = 0; r < NR; ++r) acc[r] = 0.f;
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+    auto consume = [&](const Unit& u, int f) {
+        const int r0 = row_begin + (f / steps) * RB, st = f % steps;
+        const int chunk = st * 64 + lane;
+        uint32_t xp[EPL / 2];   // the lane's activations, still packed bf16 pairs
+#pragma unroll
+        for (int j = 0; j < EPL / 8; ++j) {
+            const u32x4 xv = *reinterpret_cast<const u32x4*>(xs + (size_t)chunk * EPL + j * 8);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) xp[j * 4 + q] = xv[q];
+        }
+        const float xsm = xsum[chunk];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            float d = 0.f;
+            const float scl = bf16_to_f32(u.sc[r]);
+            float bia = bf16_to_f32(u.bi[r]);
+#pragma unroll
+            for (int wi = 0; wi < W; ++wi) {
+                const uint32_t wdw = u.wd[r][wi];
+                if (BITS == 4) {
+                    // nibbles -> bf16 pairs by bit assembly: 0x4300 | q is the bf16 value 128 + q, so each v_dot2c
+                    // accumulates x . (128 + q); the 128 * sum(x) excess is folded into the bias term below
+                    const uint32_t lo = wdw & 0x0F0F0F0Fu, hi = (wdw >> 4) & 0x0F0F0F0Fu;
+#pragma unroll
+                    for (int p4 = 0; p4 < 4; ++p4) {
+                        const uint32_t pair = __builtin_amdgcn_perm(hi, lo, 0x0c000c00u | ((4u + p4) << 16) | (uint32_t)p4) | 0x43004300u;
+                        d = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, xp[wi * 4 + p4]), __builtin_bit_cast(bf16x2_t, pair), d, false);
+                    }
                 } else {
-                    wd[r][0] = __builtin_nontemporal_load(p);
-                }
-                const int g = chunk * EPL / a.group;
-                scl[r] = bf16_to_f32(sc[r][g]);
-                bs[r] = bi[r] ? bf16_to_f32(bi[r][g]) : 0.f;
-            }
-            float xf[EPL];
 #pragma unroll
-            for (int j = 0; j < EPL; j += 8) {
-                const u32x4 xv = *reinterpret_cast<const u32x4*>(xs + (size_t)chunk * EPL + j);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) { xf[j + 2 * q] = bf16lo(xv[q]); xf[j + 2 * q + 1] = bf16hi(xv[q]); }
-            }
-            const float xsm = xsum[chunk];
-#pragma unroll
-            for (int r = 0; r < NR; ++r) {
-                float d = 0.f;
-#pragma unroll
-                for (int wi = 0; wi < W; ++wi)
-#pragma unroll
-                    for (int el = 0; el < EPW; ++el)
-                        d = fmaf(xf[wi * EPW + el], (float)((wd[r][wi] >> (el * BITS)) & ((1u << BITS) - 1u)), d);
-                acc[r] = fmaf(scl[r], d, acc[r]);
-                acc[r] = fmaf(bs[r], xsm, acc[r]);
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < NR; ++r) acc[r] = wave_sum(acc[r]);
-        if (lane == 0) {
-#pragma unroll
-            for (int r = 0; r < RB; ++r) {
-                const int row = r0 + r;
-                if (row >= row_end) break;
-                const float v0 = acc[LR * r], v1 = acc[LR * r + (LR - 1)];
-                if (EPI == EPI_STORE) {
-                    out[row] = f32_to_bf16(v0);
-                } else if (EPI == EPI_RESIDUAL) {
-                    out[row] = f32_to_bf16(bf16_to_f32(a.resid[row]) + round_bf16(v0));
-                } else if (EPI == EPI_SWIGLU) {
-                    // nn::silu(gate) * up, every primitive's result held in bf16 (qwen3-mlx/src/model.rs:264-265)
-                    const float g = round_bf16(v0), u = round_bf16(v1);
-                    const float sg = round_bf16(1.0f / (1.0f + expf(-g)));
-                    out[row] = f32_to_bf16(round_bf16(g * sg) * u);
-                } else if (EPI == EPI_ARGMAX) {
-                    const bf16_t lb = f32_to_bf16(v0);
-                    out[row] = lb;
-                    const uint64_t key = qargmax_key(bf16_to_f32(lb), (uint32_t)row);
-                    best = key > best ? key : best;
+                    for (int b = 0; b < 4; ++b) {
+                        const uint32_t xw = xp[wi * 2 + (b >> 1)];
+                        d = fmaf((b & 1) ? bf16hi(xw) : bf16lo(xw), (float)((wdw >> (8 * b)) & 0xFFu), d);
+                    }
                 }
             }
+            if (BITS == 4) bia = fmaf(-128.0f, scl, bia);
+            acc[r] = fmaf(scl, d, acc[r]);
+            acc[r] = fmaf(bia, xsm, acc[r]);
         }
+        if (st == steps - 1) {   // the batch's rows are complete: reduce, epilogue, restart the accumulators
+#pragma unroll
+            for (int r = 0; r < NR; ++r) acc[r] = wave_sum(acc[r]);
+            if (lane == 0) {
+#pragma unroll
+                for (int r = 0; r < RB; ++r) {
+                    const int row = r0 + r;
+                    if (row >= row_end) break;
+                    const float v0 = acc[LR * r], v1 = acc[LR * r + (LR - 1)];
+                    if (EPI == EPI_STORE) {
+                        out[row] = f32_to_bf16(v0);
+                    } else if (EPI == EPI_RESIDUAL) {
+                        out[row] = f32_to_bf16(bf16_to_f32(a.resid[row]) + round_bf16(v0));
+                    } else if (EPI == EPI_SWIGLU) {
+                        // nn::silu(gate) * up, every primitive's result held in bf16 (qwen3-mlx/src/model.rs:264-265)
+                        const float g = round_bf16(v0), uu = round_bf16(v1);
+                        const float sg = round_bf16(1.0f / (1.0f + expf(-g)));
+                        out[row] = f32_to_bf16(round_bf16(g * sg) * uu);
+                    } else if (EPI == EPI_ARGMAX) {
+                        const bf16_t lb = f32_to_bf16(v0);
+                        out[row] = lb;
+                        const uint64_t key = qargmax_key(bf16_to_f32(lb), (uint32_t)row);
+                        best = key > best ? key : best;
+                    }
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < NR; ++r) acc[r] = 0.f;
+        }
+    };
+    Unit uA, uB;
+    if (nunits > 0) issue(uA, 0);
+    for (int f = 0; f < nunits; f += 2) {
+        if (f + 1 < nunits) issue(uB, f + 1);
+        consume(uA, f);
+        if (f + 1 >= nunits) break;
+        if (f + 2 < nunits) issue(uA, f + 2);
+        consume(uB, f + 1);
     }
     if (EPI == EPI_ARGMAX) {
         uint64_t* bred = reinterpret_cast<uint64_t*>(red);
@@ -291,15 +339,16 @@ int launch_qgemv_bits(const QGemvArgs& a_in, int pro, int epi, hipStream_t s) {
     QGemvArgs a = a_in;
     constexpr int EPW = 32 / BITS;
     int W = 4;
-    while (W > 1 && (a.K % (64 * W * EPW) != 0 || W * EPW > a.group)) W >>= 1;
-    OMX_REQUIRE(a.K % (64 * W * EPW) == 0 && W * EPW <= a.group, "quantized_matmul: K=%d unsupported for %d-bit group %d (K must be a multiple of %d)",
+    while (W * EPW > 8 && (a.K % (64 * W * EPW) != 0 || W * EPW > a.group)) W >>= 1;
+    OMX_REQUIRE(a.K % (64 * W * EPW) == 0 && W * EPW <= a.group && W * EPW >= 8, "quantized_matmul: K=%d unsupported for %d-bit group %d (K must be a multiple of %d)",
                 a.K, BITS, a.group, 64 * EPW);
     if (a.n_batch < 1) a.n_batch = 1;
     if (a.x_div < 1) a.x_div = 1;
-    a.rows_per_wave = 8;
+    a.rows_per_wave = a.N >= 65536 ? 16 : 4;   // long streams for the vocabulary matrix, one batch per wave otherwise
     if (W == 4) return launch_qgemv_w<BITS, 4>(a, pro, epi, s);
     if (W == 2) return launch_qgemv_w<BITS, 2>(a, pro, epi, s);
-    return launch_qgemv_w<BITS, 1>(a, pro, epi, s);
+    if constexpr (BITS == 4) return launch_qgemv_w<BITS, 1>(a, pro, epi, s);
+    return set_error("quantized gemv: K=%d too small for %d-bit weights", a.K, BITS);
 }
 
 int check_format(const char* who, int K, int group, int bits, int dtype) {
@@ -312,7 +361,10 @@ int check_format(const char* who, int K, int group, int bits, int dtype) {
 
 }  // namespace
 
-int qgemv_grid(int N) { return ((N + 7) / 8 + 3) / 4; }
+int qgemv_grid(int N) {
+    const int rpw = N >= 65536 ? 16 : 4;
+    return ((N + rpw - 1) / rpw + 3) / 4;
+}
 
 int launch_qgemv(const QGemvArgs& a, int bits, int pro, int epi, hipStream_t s) {
     OMX_REQUIRE(bits == 4 || bits == 8, "quantized gemv: bits must be 4 or 8 (got %d)", bits);
@@ -357,7 +409,7 @@ extern "C" int omx_quantized_matmul(void* out, const void* x, const void* packed
     OMX_REQUIRE(M >= 0 && N > 0, "omx_quantized_matmul: bad shape");
     if (M == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
-    if (M <= 16 && K % (64 * (32 / bits)) == 0) {
+    if (M <= 16 && K % 512 == 0) {
         QGemvArgs a = {};
         a.m[0] = QMat{(const uint32_t*)packed, (const bf16_t*)scales, (const bf16_t*)biases, N};
         a.x = (const bf16_t*)x; a.out = (bf16_t*)out; a.N = N; a.K = K; a.group = group_size;
@@ -378,7 +430,7 @@ extern "C" int omx_gather_qmm(void* out, const void* x, const void* packed, cons
     OMX_REQUIRE(out && x && packed && scales && rhs_indices, "omx_gather_qmm: null tensor");
     if (check_format("omx_gather_qmm", K, group_size, bits, dtype)) return 1;
     OMX_REQUIRE(n_rows >= 0 && x_div >= 1 && N > 0 && n_experts >= 1, "omx_gather_qmm: bad shape");
-    OMX_REQUIRE(K % (64 * (32 / bits)) == 0, "omx_gather_qmm: K=%d must be a multiple of %d", K, 64 * (32 / bits));
+    OMX_REQUIRE(K % 512 == 0, "omx_gather_qmm: K=%d must be a multiple of 512", K);
     if (n_rows == 0) return 0;
     QGemvArgs a = {};
     a.m[0] = QMat{(const uint32_t*)packed, (const bf16_t*)scales, (const bf16_t*)biases, N};

@@ -294,7 +294,9 @@ def test_quantized_checkpoint_decode_matches_oracle(omx, name, bits, group):
     np.testing.assert_array_equal(outs[0][0], outs[1][0])
     np.testing.assert_array_equal(outs[0][1], outs[1][1])
     got, logits0 = outs[0]
-    bound = 2.0 ** -7 * np.abs(ref_logits).max() * np.sqrt(cfg.num_hidden_layers)
+    # the bf16 engine's bound times sqrt(2): the batched prefill multiplies with weights dequantised to bf16 (as MLX's qmm
+    # does), one more 2^-9 relative perturbation per product than the oracle's float32 dequantisation
+    bound = 2.0 ** -7 * np.abs(ref_logits).max() * np.sqrt(2 * cfg.num_hidden_layers)
     assert np.abs(logits0 - ref_logits[0]).max() <= bound
     margins = rc.argmax_margin(ref_logits)
     for i in range(n_new):

@@ -104,11 +104,10 @@ __device__ __forceinline__ uint64_t qargmax_key(float v, uint32_t idx) {
 // W = u32 words per lane per step; a lane's W*EPW elements lie inside one group.
 // PRO / EPI as in gemv.hip (same arithmetic and rounding points): RMSNorm prologue; store, residual add, SwiGLU
 // over (gate, up) row pairs, logits + greedy-argmax partial.
-template <int BITS, int W, int PRO, int EPI>
+template <int BITS, int W, int PRO, int EPI, int RB>
 __global__ __launch_bounds__(256) void qgemv_kernel(const QGemvArgs a) {
     constexpr int EPW = 32 / BITS, EPL = W * EPW;          // elements per lane per step
     constexpr int LR = (EPI == EPI_SWIGLU) ? 2 : 1;         // physical rows per logical row
-    constexpr int RB = (EPI == EPI_SWIGLU) ? 2 : 4;         // logical rows in flight per wave
     constexpr int NR = RB * LR;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     bf16_t* xs = reinterpret_cast<bf16_t*>(smem);                       // [K]
@@ -119,44 +118,6 @@ __global__ __launch_bounds__(256) void qgemv_kernel(const QGemvArgs a) {
     const bf16_t* xg = a.x + (size_t)(by / a.x_div) * a.K;
     const size_t e = a.w_sel ? a.w_sel[by] : 0;
     bf16_t* out = a.out + (size_t)by * a.N;
-
-    // ---- prologue: x -> LDS as bf16 (RMS-normalised on the way in) and, in the same pass, the per-chunk sums
-    //      sum(x_i) that every row's bias term shares (EPL elements = EPL/8 consecutive threads, reduced by DPP) ----
-    static_assert(EPL >= 8, "a lane chunk must cover at least one 16-byte activation vector");
-    auto put = [&](int i, const u32x4 o) {
-        *reinterpret_cast<u32x4*>(xs + i) = o;
-        float sv = 0.f;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) sv += bf16lo(o[q]) + bf16hi(o[q]);
-        if (EPL >= 16) sv += dpp_f<kDppXor1>(sv);
-        if (EPL >= 32) sv += dpp_f<kDppXor2>(sv);
-        if (((i >> 3) & (EPL / 8 - 1)) == 0) xsum[i / EPL] = sv;
-    };
-    if (PRO == PRO_RMSNORM) {
-        float ss = 0.f;
-        for (int i = threadIdx.x * 8; i < a.K; i += 256 * 8) {
-            const u32x4 raw = *reinterpret_cast<const u32x4*>(xg + i);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                ss = fmaf(bf16lo(raw[q]), bf16lo(raw[q]), ss);
-                ss = fmaf(bf16hi(raw[q]), bf16hi(raw[q]), ss);
-            }
-        }
-        ss = block_sum<4>(ss, red);
-        const float rstd = 1.0f / sqrtf(ss / (float)a.K + a.eps);
-        for (int i = threadIdx.x * 8; i < a.K; i += 256 * 8) {
-            const u32x4 raw = *reinterpret_cast<const u32x4*>(xg + i);
-            const u32x4 nw = *reinterpret_cast<const u32x4*>(a.norm_w + i);
-            u32x4 o;
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-                o[q] = pack_bf16(bf16lo(raw[q]) * rstd * bf16lo(nw[q]), bf16hi(raw[q]) * rstd * bf16hi(nw[q]));
-            put(i, o);
-        }
-    } else {
-        for (int i = threadIdx.x * 8; i < a.K; i += 256 * 8) put(i, *reinterpret_cast<const u32x4*>(xg + i));
-    }
-    __syncthreads();
 
     const int steps = a.K / (64 * EPL);
     const int words_per_row = a.K / EPW, groups_per_row = a.K / a.group;
@@ -290,10 +251,51 @@ __global__ __launch_bounds__(256) void qgemv_kernel(const QGemvArgs a) {
             for (int r = 0; r < NR; ++r) acc[r] = 0.f;
         }
     };
+    // the first two units go out before the activation is even loaded: they depend on the weights only
     Unit uA, uB;
     if (nunits > 0) issue(uA, 0);
+    if (nunits > 1) issue(uB, 1);
+
+    // ---- prologue: x -> LDS as bf16 (RMS-normalised on the way in) and, in the same pass, the per-chunk sums
+    //      sum(x_i) that every row's bias term shares (EPL elements = EPL/8 consecutive threads, reduced by DPP) ----
+    static_assert(EPL >= 8, "a lane chunk must cover at least one 16-byte activation vector");
+    auto put = [&](int i, const u32x4 o) {
+        *reinterpret_cast<u32x4*>(xs + i) = o;
+        float sv = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) sv += bf16lo(o[q]) + bf16hi(o[q]);
+        if (EPL >= 16) sv += dpp_f<kDppXor1>(sv);
+        if (EPL >= 32) sv += dpp_f<kDppXor2>(sv);
+        if (((i >> 3) & (EPL / 8 - 1)) == 0) xsum[i / EPL] = sv;
+    };
+    if (PRO == PRO_RMSNORM) {
+        float ss = 0.f;
+        for (int i = threadIdx.x * 8; i < a.K; i += 256 * 8) {
+            const u32x4 raw = *reinterpret_cast<const u32x4*>(xg + i);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                ss = fmaf(bf16lo(raw[q]), bf16lo(raw[q]), ss);
+                ss = fmaf(bf16hi(raw[q]), bf16hi(raw[q]), ss);
+            }
+        }
+        ss = block_sum<4>(ss, red);
+        const float rstd = 1.0f / sqrtf(ss / (float)a.K + a.eps);
+        for (int i = threadIdx.x * 8; i < a.K; i += 256 * 8) {
+            const u32x4 raw = *reinterpret_cast<const u32x4*>(xg + i);
+            const u32x4 nw = *reinterpret_cast<const u32x4*>(a.norm_w + i);
+            u32x4 o;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                o[q] = pack_bf16(bf16lo(raw[q]) * rstd * bf16lo(nw[q]), bf16hi(raw[q]) * rstd * bf16hi(nw[q]));
+            put(i, o);
+        }
+    } else {
+        for (int i = threadIdx.x * 8; i < a.K; i += 256 * 8) put(i, *reinterpret_cast<const u32x4*>(xg + i));
+    }
+    __syncthreads();
+
     for (int f = 0; f < nunits; f += 2) {
-        if (f + 1 < nunits) issue(uB, f + 1);
+        if (f > 0 && f + 1 < nunits) issue(uB, f + 1);
         consume(uA, f);
         if (f + 1 >= nunits) break;
         if (f + 2 < nunits) issue(uA, f + 2);
@@ -319,11 +321,14 @@ int launch_qgemv_w(const QGemvArgs& a, int pro, int epi, hipStream_t s) {
     const int groups = (a.N + a.rows_per_wave - 1) / a.rows_per_wave;
     const dim3 grid((groups + 3) / 4, a.n_batch > 1 ? a.n_batch : 1), block(256);
     const size_t shmem = (size_t)a.K * 2 + (size_t)(a.K / (W * EPW)) * 4 + 64;
-#define OMX_QGEMV_CASE(P, E)                                                     \
-    if (pro == P && epi == E) {                                                  \
-        qgemv_kernel<BITS, W, P, E><<<grid, block, shmem, s>>>(a);                \
-        OMX_LAUNCH_CHECK();                                                      \
-        return 0;                                                                \
+    // RB = logical rows per unit: 4 for long matrices, 2 when the matrix is small enough that wave count matters more
+    // (rows_per_wave == RB there: one batch per wave, twice the waves) and for SwiGLU row pairs
+#define OMX_QGEMV_CASE(P, E)                                                                  \
+    if (pro == P && epi == E) {                                                               \
+        if (E == EPI_SWIGLU || a.rows_per_wave == 2) qgemv_kernel<BITS, W, P, E, 2><<<grid, block, shmem, s>>>(a); \
+        else qgemv_kernel<BITS, W, P, E, 4><<<grid, block, shmem, s>>>(a);                     \
+        OMX_LAUNCH_CHECK();                                                                   \
+        return 0;                                                                             \
     }
     OMX_QGEMV_CASE(PRO_NONE, EPI_STORE)
     OMX_QGEMV_CASE(PRO_RMSNORM, EPI_STORE)
@@ -344,7 +349,8 @@ int launch_qgemv_bits(const QGemvArgs& a_in, int pro, int epi, hipStream_t s) {
                 a.K, BITS, a.group, 64 * EPW);
     if (a.n_batch < 1) a.n_batch = 1;
     if (a.x_div < 1) a.x_div = 1;
-    a.rows_per_wave = a.N >= 65536 ? 16 : 4;   // long streams for the vocabulary matrix, one batch per wave otherwise
+    // long streams for the vocabulary matrix, one batch per wave otherwise; small matrices: two rows per wave
+    a.rows_per_wave = a.N >= 65536 ? 16 : (a.N <= 8192 && epi != EPI_SWIGLU) ? 2 : 4;
     if (W == 4) return launch_qgemv_w<BITS, 4>(a, pro, epi, s);
     if (W == 2) return launch_qgemv_w<BITS, 2>(a, pro, epi, s);
     if constexpr (BITS == 4) return launch_qgemv_w<BITS, 1>(a, pro, epi, s);
@@ -362,7 +368,7 @@ int check_format(const char* who, int K, int group, int bits, int dtype) {
 }  // namespace
 
 int qgemv_grid(int N) {
-    const int rpw = N >= 65536 ? 16 : 4;
+    const int rpw = N >= 65536 ? 16 : N <= 8192 ? 2 : 4;
     return ((N + rpw - 1) / rpw + 3) / 4;
 }
 

@@ -64,8 +64,13 @@ class Tensor:
     @staticmethod
     def from_numpy(a: np.ndarray, dtype="bf16") -> "Tensor":
         code = dtype_code(dtype)
+        raw_bf16 = type(a).__name__ == "Bf16Bits"        # loader.read_safetensors: uint16 bit patterns, no conversion
         a = np.asarray(a)
-        if code == BFLOAT16:
+        if code == BFLOAT16 and raw_bf16:
+            host = np.ascontiguousarray(a, dtype=np.uint16)
+        elif code == BFLOAT16 and a.dtype == np.float16:
+            host = _f32_to_bf16_bits(a.astype(np.float32))
+        elif code == BFLOAT16:
             host = _f32_to_bf16_bits(a.astype(np.float32))
         elif code == FLOAT16:
             host = np.ascontiguousarray(a, dtype=np.float16)

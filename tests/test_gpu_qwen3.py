@@ -303,3 +303,41 @@ def test_quantized_checkpoint_decode_matches_oracle(omx, name, bits, group):
         if got[i] != ref_tokens[i]:
             assert margins[i] <= 2 * bound, f"token {i}: got {got[i]} want {ref_tokens[i]} with margin {margins[i]:.4f} > {2*bound:.4f}"
             break
+
+
+@pytest.mark.parametrize("quant", [None, {"bits": 4, "group_size": 64}])
+def test_load_model_from_checkpoint_directory(omx, tmp_path, quant):
+    """qwen3_mlx::load_model (model.rs:509-560, 621-727): config.json + model.safetensors.index.json + two shards
+    (BF16 tensors as raw bits, packed U32 weights for the quantized variant) -> the same tokens and logits as handing
+    the same tensors to the engine directly."""
+    import json
+    from ominix_mlx_amd import engine, loader
+    cfg = CONFIGS["gqa4_d128"]
+    w = rq.synth_weights(cfg)
+    if quant:
+        w = rq.quantize_weights(cfg, w, quant["bits"], quant["group_size"])
+    d = str(tmp_path)
+    json.dump({"hidden_size": cfg.hidden_size, "num_hidden_layers": cfg.num_hidden_layers, "intermediate_size": cfg.intermediate_size,
+               "num_attention_heads": cfg.num_attention_heads, "num_key_value_heads": cfg.num_key_value_heads, "head_dim": cfg.head_dim,
+               "vocab_size": cfg.vocab_size, "rms_norm_eps": cfg.rms_norm_eps, "rope_theta": cfg.rope_theta,
+               "tie_word_embeddings": cfg.tie_word_embeddings, **({"quantization": quant} if quant else {})},
+              open(f"{d}/config.json", "w"))
+    names = sorted(w)
+    shards = {"model-00001-of-00002.safetensors": names[: len(names) // 2], "model-00002-of-00002.safetensors": names[len(names) // 2:]}
+    for fn, keys in shards.items():
+        tensors = {k: (w[k] if w[k].dtype == np.uint32 else rc.to_bf16_bits(w[k])) for k in keys}
+        loader.write_safetensors(f"{d}/{fn}", tensors, bf16_names=tuple(k for k in keys if w[k].dtype != np.uint32))
+    json.dump({"metadata": {}, "weight_map": {k: fn for fn, keys in shards.items() for k in keys}}, open(f"{d}/model.safetensors.index.json", "w"))
+
+    prompt = synth.prompt_ids(20, cfg.vocab_size)
+    m = loader.load_model(d, max_context=256)
+    got = np.concatenate([[m.prefill(prompt)], m.decode(6)])
+    logits = m.last_logits()
+    ref = engine.Model(hidden_size=cfg.hidden_size, num_hidden_layers=cfg.num_hidden_layers, intermediate_size=cfg.intermediate_size,
+                       num_attention_heads=cfg.num_attention_heads, num_key_value_heads=cfg.num_key_value_heads, head_dim=cfg.head_dim,
+                       vocab_size=cfg.vocab_size, rms_norm_eps=cfg.rms_norm_eps, rope_theta=cfg.rope_theta,
+                       tie_word_embeddings=cfg.tie_word_embeddings, max_context=256, quantization=quant)
+    ref.load_weights(w)
+    want = np.concatenate([[ref.prefill(prompt)], ref.decode(6)])
+    np.testing.assert_array_equal(got, want)
+    np.testing.assert_array_equal(logits, ref.last_logits())

@@ -111,6 +111,20 @@ int omx_set_workspace(void* ws, size_t bytes);   /* caller-provided scratch used
  *      out[r] = first index of the maximum of logits[r, :]  (u32).                              */
 int omx_argmax(uint32_t* out, const void* logits, int64_t rows, int n, omx_dtype dtype, omx_stream stream);
 
+/* ---- a10, temperature branch: MLX's keyed generator + categorical sampler.
+ *      mlx/c/random.h:37-72,129-139,149-157 (mlx_random_bits / _categorical* / _gumbel / _key / _split* / _uniform),
+ *      called by mlx-rs/src/random.rs:98-115 (key, split), :397-414 (gumbel), :456-497 (categorical) and through
+ *      them by mlx-rs-core/src/sampler.rs:13-16.  Keys are 2 x u32 in device memory; word i of an n-word draw is
+ *      Threefry-2x32(key, counter pair of i) in MLX's layout, so results reproduce MLX's for the same key.
+ *      categorical: out[r, s] = argmax_v( f32(logits[r, v]) * inv_temp + gumbel[r, v, s] ), first index on ties.   */
+int omx_random_key(uint32_t* key, uint64_t seed, omx_stream stream);
+int omx_random_split(uint32_t* out /*[num,2]*/, const uint32_t* key, int num, omx_stream stream);
+int omx_random_bits(uint32_t* out, const uint32_t* key, int64_t n, omx_stream stream);
+int omx_random_uniform(float* out, const uint32_t* key, int64_t n, float lo, float hi, omx_stream stream);
+int omx_random_gumbel(float* out, const uint32_t* key, int64_t n, omx_stream stream);
+int omx_random_categorical(uint32_t* out, const void* logits, int64_t rows, int n, int num_samples, float inv_temp,
+                           const uint32_t* key, omx_dtype dtype, omx_stream stream);
+
 /* embedding gather (mlx_take_axis ops.h:1109, nn/embedding.rs): out[r,:] = table[ids[r],:] */
 int omx_take_rows(void* out, const void* table, const uint32_t* ids, int64_t n_ids, int dim, omx_dtype dtype,
                   omx_stream stream);
@@ -154,6 +168,10 @@ int omx_qwen3_set_weight(omx_qwen3 m, const char* name, const void* ptr);
 int omx_qwen3_synth_weights(omx_qwen3 m, uint32_t base_seed);
 /* tensor-parallel hook: `allreduce` has the ncclAllReduce signature, `comm` is the ncclComm_t.      */
 int omx_qwen3_set_comm(omx_qwen3 m, void* comm, void* allreduce_fn);
+/* sampler (mlx-rs-core/src/sampler.rs:9-18, qwen3-mlx/src/model.rs:733-741): temperature 0 = argmax (default);
+ * otherwise every sampled token is categorical(logits * (1/temperature)) with the next key of a RandomState
+ * seeded like mlx_rs::random::seed(seed) (random.rs:21-41, :88-91).  The draw stays on the device, inside the step. */
+int omx_qwen3_set_sampler(omx_qwen3 m, float temperature, uint64_t seed);
 int omx_qwen3_reset(omx_qwen3 m);                                  /* KVCache::reset (cache.rs:130-132) */
 int omx_qwen3_offset(omx_qwen3 m, int* offset);                    /* KeyValueCache::offset           */
 /* Generate: prefill the prompt, return the first sampled token (model.rs:808-827)                   */

@@ -156,6 +156,25 @@ int mlx_take_axis(mlx_array* res, const mlx_array a, const mlx_array indices, in
 int mlx_argmax_axis(mlx_array* res, const mlx_array a, int axis, bool keepdims, const mlx_stream s);          /* :106 (sampler.rs:9-12) */
 int mlx_softmax_axis(mlx_array* res, const mlx_array a, int axis, bool precise, const mlx_stream s);          /* :1005 */
 
+/* ---- mlx/c/random.h (line numbers of that header): the keyed generator behind the sampler's temperature
+ *      branch (mlx-rs-core/src/sampler.rs:13-16 -> mlx-rs/src/random.rs:98-115, 397-414, 456-497) ---- */
+int mlx_random_seed(uint64_t seed);                                                                            /* :129 */
+int mlx_random_key(mlx_array* res, uint64_t seed);                                                             /* :72 */
+int mlx_random_split_num(mlx_array* res, const mlx_array key, int num, const mlx_stream s);                    /* :130 */
+int mlx_random_split(mlx_array* res_0, mlx_array* res_1, const mlx_array key, const mlx_stream s);             /* :135 */
+int mlx_random_bits(mlx_array* res, const int* shape, size_t shape_num, int width,
+                    const mlx_array key /* may be null */, const mlx_stream s);                                /* :37 */
+int mlx_random_uniform(mlx_array* res, const mlx_array low, const mlx_array high, const int* shape, size_t shape_num,
+                       mlx_dtype dtype, const mlx_array key /* may be null */, const mlx_stream s);            /* :149 */
+int mlx_random_gumbel(mlx_array* res, const int* shape, size_t shape_num, mlx_dtype dtype,
+                      const mlx_array key /* may be null */, const mlx_stream s);                              /* :65 */
+int mlx_random_categorical(mlx_array* res, const mlx_array logits, int axis,
+                           const mlx_array key /* may be null */, const mlx_stream s);                         /* :59 */
+int mlx_random_categorical_num_samples(mlx_array* res, const mlx_array logits, int axis, int num_samples,
+                                       const mlx_array key /* may be null */, const mlx_stream s);             /* :52 */
+int mlx_random_categorical_shape(mlx_array* res, const mlx_array logits, int axis, const int* shape, size_t shape_num,
+                                 const mlx_array key /* may be null */, const mlx_stream s);                   /* :44 */
+
 /* ---- native replacements for the two JIT Metal kernels (mlx_fast_metal_kernel_apply, fast.h:156;
  *      mlx-rs-core/src/metal_kernels.rs:188-236, 260-339): the two Rust call sites switch to these ---- */
 int omx_mlx_fused_swiglu(mlx_array* res, const mlx_array x, const mlx_array gate, const mlx_stream s);

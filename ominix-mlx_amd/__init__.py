@@ -71,6 +71,12 @@ SIGNATURES = {
     "omx_sdpa_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "omx_set_workspace": (c_int, [c_void_p, c_size_t]),
     "omx_argmax": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
+    "omx_random_key": (c_int, [c_void_p, ctypes.c_uint64, c_void_p]),
+    "omx_random_split": (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
+    "omx_random_bits": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
+    "omx_random_uniform": (c_int, [c_void_p, c_void_p, c_int64, ctypes.c_float, ctypes.c_float, c_void_p]),
+    "omx_random_gumbel": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
+    "omx_random_categorical": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, ctypes.c_float, c_void_p, c_int, c_void_p]),
     "omx_take_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
     "omx_add": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
 }

@@ -39,6 +39,16 @@ def rccl_comm(dist, rank: int, world: int):
     rc = lib.ncclCommInitRank(ctypes.byref(comm), world, uid, rank)
     if rc != 0:
         raise RuntimeError(f"ncclCommInitRank failed with {rc}")
+    # one eager collective now, so that the communicator's lazy set-up (channels, peer mappings) is
+    # finished before an engine first meets it inside a stream capture
+    warm = torch.ones(64, dtype=torch.float32, device="cuda")
+    lib.ncclAllReduce.restype = ctypes.c_int
+    lib.ncclAllReduce.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int,
+                                  ctypes.c_void_p, ctypes.c_void_p]
+    rc = lib.ncclAllReduce(warm.data_ptr(), warm.data_ptr(), 64, NCCL_FLOAT32, 0, comm, None)
+    torch.cuda.synchronize()
+    if rc != 0 or float(warm[0].item()) != float(world):
+        raise RuntimeError(f"RCCL warm-up all-reduce failed (rc {rc}, got {float(warm[0].item())}, want {world})")
     fn = ctypes.cast(lib.ncclAllReduce, ctypes.c_void_p).value
     return lib, comm.value, fn
 

@@ -159,13 +159,47 @@ def scaled_dot_product_attention(queries: Array, keys: Array, values: Array, _ca
     return mx.scaled_dot_product_attention(queries, keys, values, scale, mask)
 
 
-class DefaultSampler:
-    """sampler.rs:9-18: temp == 0 -> argmax(-1); categorical sampling is outside the greedy path."""
+class RandomState:
+    """mlx-rs/src/random.rs:21-41: the key sequence behind `key = None` on the Rust side (`seed`, one split per draw)."""
 
-    def sample(self, logits: Array, temp: float) -> Array:
+    def __init__(self, seed: int = 0):
+        self.state = mx.random_key(seed)
+
+    def seed(self, seed: int) -> None:
+        self.state = mx.random_key(seed)
+
+    def next(self) -> Array:
+        self.state, sub = mx.random_split(self.state, 2)
+        return sub
+
+
+GLOBAL_RANDOM_STATE: Optional[RandomState] = None
+
+
+def seed(value: int) -> None:
+    """mlx_rs::random::seed (random.rs:88-91)."""
+    global GLOBAL_RANDOM_STATE
+    GLOBAL_RANDOM_STATE = RandomState(value)
+
+
+def _resolve_key(key: Optional[Array]) -> Array:
+    """random.rs:57-68 (`resolve`): the given key, or the next key of the global state."""
+    global GLOBAL_RANDOM_STATE
+    if key is not None:
+        return key
+    if GLOBAL_RANDOM_STATE is None:
+        GLOBAL_RANDOM_STATE = RandomState(0)   # the reference seeds from the clock; a fixed seed keeps runs repeatable
+    return GLOBAL_RANDOM_STATE.next()
+
+
+class DefaultSampler:
+    """sampler.rs:9-18: temp == 0 -> argmax(-1); otherwise categorical(logits * array!(1/temp))."""
+
+    def sample(self, logits: Array, temp: float, key: Optional[Array] = None) -> Array:
         if temp == 0.0:
             return mx.argmax_axis(logits, -1)
-        raise OmxError("DefaultSampler: categorical sampling (temp != 0) is not on the MI355X path yet")
+        scaled = mx.multiply(logits, Array.from_numpy(np.float32(1.0) / np.float32(temp), mx.FLOAT32))
+        return mx.random_categorical(scaled, -1, None, _resolve_key(key))
 
 
 fused_swiglu = mx.fused_swiglu

@@ -28,6 +28,7 @@
 #include "gemm.hpp"
 #include "gemv.hpp"
 #include "gridsync.hpp"
+#include "random.hpp"
 #include "prefill.hpp"
 #include "quant.hpp"
 
@@ -171,6 +172,11 @@ struct omx_qwen3_ {
     void* comm = nullptr;
     nccl_allreduce_fn allreduce = nullptr;
 
+    // sampler (sampler.rs:9-18): 0 = greedy; otherwise categorical(logits / temperature) with the key sequence
+    // of mlx-rs RandomState kept on the device: rng[0..1] = state, rng[2..3] = the key of the current draw
+    float temperature = 0.f;
+    uint32_t* rng = nullptr;
+
     // batched-prefill activations (allocated on first use, sized for pf_cap tokens)
     int pf_cap = 0;
     bf16_t *pf_h = nullptr, *pf_h2 = nullptr, *pf_xn = nullptr, *pf_q = nullptr, *pf_k = nullptr, *pf_v = nullptr,
@@ -193,6 +199,18 @@ struct omx_qwen3_ {
 };
 
 namespace {
+
+// temperature sampling: replace the greedy per-block partials by those of logits / T + Gumbel noise, the noise
+// of vocabulary row v being word v of a V-word draw from the step's key (random.hip).  The greedy partials the
+// lm_head epilogue wrote are simply overwritten; sample_finalize_kernel / the TP max all-reduce are unchanged.
+int add_sampling_noise(omx_qwen3 m, hipStream_t s) {
+    if (m->temperature == 0.f) return 0;
+    const omx_qwen3_config& c = m->cfg;
+    const int tp = c.tp_size > 1 ? c.tp_size : 1;
+    if (launch_rng_next(m->rng, s)) return 1;
+    return launch_sample_noise(m->argmax_partials, m->n_argmax_partials, m->logits, m->rng + 2, m->V, c.tp_rank * m->V,
+                               m->V * tp, 1.0f / m->temperature, s);
+}
 
 int resolve_weights(omx_qwen3 m) {
     if (m->weights_resolved) return 0;
@@ -319,6 +337,7 @@ int enqueue_step_quant(omx_qwen3 m, bool with_head) {
         a.x = h; a.norm_w = m->final_norm; a.eps = c.rms_norm_eps; a.out = m->logits;
         a.argmax_slot = m->argmax_partials;
         if (launch_qgemv(a, bits, PRO_RMSNORM, EPI_ARGMAX, s)) return 1;
+        if (add_sampling_noise(m, s)) return 1;
         sample_finalize_kernel<<<1, 256, 0, s>>>(m->st, m->argmax_partials, m->n_argmax_partials, m->out_ring, m->ring_cap, nullptr);
         OMX_LAUNCH_CHECK();
     } else {
@@ -422,6 +441,7 @@ int enqueue_step(omx_qwen3 m, bool with_head) {
         a.argmax_slot = m->argmax_partials;
         a.row_offset = c.tp_rank * m->V;
         if (launch_gemv(a, PRO_RMSNORM, EPI_ARGMAX, s)) return 1;
+        if (add_sampling_noise(m, s)) return 1;
         if (!tp) {
             sample_finalize_kernel<<<1, 256, 0, s>>>(m->st, m->argmax_partials, m->n_argmax_partials, m->out_ring,
                                                      m->ring_cap, nullptr);
@@ -461,7 +481,7 @@ int setup_mega(omx_qwen3 m) {
     const omx_qwen3_config& c = m->cfg;
     const char* env = getenv("OMX_DECODE_MEGA");
     if (!env || env[0] != '1') return 0;   // opt-in until it beats the step graph
-    if (c.tp_size > 1 || m->allreduce != nullptr || c.num_hidden_layers < 1 || c.quant_bits) return 0;
+    if (c.tp_size > 1 || m->allreduce != nullptr || c.num_hidden_layers < 1 || c.quant_bits || m->temperature != 0.f) return 0;
     if (!mega_supported(c.hidden_size, m->H * c.head_dim, m->I, c.head_dim, m->H / m->Hkv)) return 0;
     int capacity = 0;
     if (mega_capacity(c.hidden_size, m->H * c.head_dim, m->I, &capacity)) return 1;
@@ -824,6 +844,23 @@ int omx_qwen3_set_comm(omx_qwen3 m, void* comm, void* allreduce_fn) {
     OMX_REQUIRE(m->g_full == nullptr && !m->eager && !m->mega, "omx_qwen3_set_comm: communicator must be set before the first step");
     m->comm = comm;
     m->allreduce = (nccl_allreduce_fn)allreduce_fn;
+    return 0;
+}
+
+int omx_qwen3_set_sampler(omx_qwen3 m, float temperature, uint64_t seed) {
+    OMX_REQUIRE(m, "omx_qwen3_set_sampler: null model");
+    OMX_REQUIRE(temperature >= 0.f && temperature == temperature, "omx_qwen3_set_sampler: temperature %f must be >= 0", (double)temperature);
+    OMX_REQUIRE(!m->mega, "omx_qwen3_set_sampler: the persistent decode kernel samples greedily; set the sampler before the first step");
+    if (!m->rng && dev_alloc(m, &m->rng, 4)) return 1;
+    if (omx_random_key(m->rng, seed, (omx_stream)m->stream)) return 1;
+    OMX_HIP_CHECK(hipStreamSynchronize(m->stream));
+    if (temperature != m->temperature) {
+        // 1/T is a launch argument inside the captured step: drop the graphs, the next step rebuilds them
+        if (m->g_full) { (void)hipGraphExecDestroy(m->g_full); m->g_full = nullptr; }
+        if (m->g_nohead) { (void)hipGraphExecDestroy(m->g_nohead); m->g_nohead = nullptr; }
+        m->eager = false;
+        m->temperature = temperature;
+    }
     return 0;
 }
 

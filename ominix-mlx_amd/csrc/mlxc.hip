@@ -918,6 +918,144 @@ int mlx_argmax_axis(mlx_array* res, const mlx_array a, int axis, bool keepdims, 
     if (omx_argmax((uint32_t*)r->ptr(), c.a->ptr(), n ? (int64_t)(s.size() / n) : 0, n, to_omx(s.dt), g_stream)) { delete r; return 1; }
     return assign(res, r);
 }
+// ---- random.h: keyed generator + categorical (sampler.rs:13-16 through mlx-rs/src/random.rs) ----
+// `key` may be an empty handle: MLX then draws the next key of its own global sequence (seeded by mlx_random_seed,
+// default seed 0 here; MLX seeds it from the clock).  mlx-rs never relies on that: it keeps its RandomState on
+// the Rust side and always passes a key (random.rs:57-68).
+static Arr* g_rng_state = nullptr;
+static int seed_global(uint64_t seed) {
+    if (!g_rng_state) {
+        g_rng_state = new_arr({2}, MLX_UINT32);
+        if (!g_rng_state) return set_error("out of device memory allocating the random state");
+    }
+    return omx_random_key((uint32_t*)g_rng_state->ptr(), seed, g_stream);
+}
+struct KeyArg {
+    Contig c;
+    Arr* drawn = nullptr;
+    const uint32_t* ptr = nullptr;
+    ~KeyArg() { delete drawn; }
+    int init(const mlx_array key, const char* name) {
+        if (key.ctx) {
+            const Arr& k = *A(key);
+            OMX_REQUIRE(k.dt == MLX_UINT32 && k.size() == 2, "%s: a PRNG key is 2 x uint32", name);
+            if (c.init(k)) return 1;
+            ptr = (const uint32_t*)c.a->ptr();
+            return 0;
+        }
+        if (!g_rng_state && seed_global(0)) return 1;
+        drawn = new_arr({2, 2}, MLX_UINT32);
+        if (!drawn) return set_error("%s: out of device memory", name);
+        if (omx_random_split((uint32_t*)drawn->ptr(), (const uint32_t*)g_rng_state->ptr(), 2, g_stream)) return 1;
+        OMX_HIP_CHECK(hipMemcpyAsync(g_rng_state->ptr(), drawn->ptr(), 8, hipMemcpyDeviceToDevice, g_stream));
+        ptr = (const uint32_t*)drawn->ptr() + 2;
+        return 0;
+    }
+};
+int mlx_random_seed(uint64_t seed) { return seed_global(seed); }
+int mlx_random_key(mlx_array* res, uint64_t seed) {
+    NEW_OR_FAIL(r, std::vector<int>({2}), MLX_UINT32);
+    if (omx_random_key((uint32_t*)r->ptr(), seed, g_stream)) { delete r; return 1; }
+    return assign(res, r);
+}
+int mlx_random_split_num(mlx_array* res, const mlx_array key, int num, const mlx_stream) {
+    REQ_ARR(key, "mlx_random_split_num");
+    OMX_REQUIRE(num >= 1, "mlx_random_split_num: num=%d must be positive", num);
+    KeyArg k;
+    if (k.init(key, "mlx_random_split_num")) return 1;
+    NEW_OR_FAIL(r, std::vector<int>({num, 2}), MLX_UINT32);
+    if (omx_random_split((uint32_t*)r->ptr(), k.ptr, num, g_stream)) { delete r; return 1; }
+    return assign(res, r);
+}
+int mlx_random_split(mlx_array* res_0, mlx_array* res_1, const mlx_array key, const mlx_stream s) {
+    mlx_array both = mlx_array_new();
+    if (mlx_random_split_num(&both, key, 2, s)) return 1;
+    const int rc = [&]() {
+        for (int i = 0; i < 2; ++i) {
+            Arr* r = new Arr(*A(both));          // view of row i
+            r->host.clear();
+            r->shape = {2};
+            r->strides = {1};
+            r->off = A(both)->off + (size_t)i * 8;
+            if (assign(i == 0 ? res_0 : res_1, r)) return 1;
+        }
+        return 0;
+    }();
+    mlx_array_free(both);
+    return rc;
+}
+int mlx_random_bits(mlx_array* res, const int* shape, size_t shape_num, int width, const mlx_array key, const mlx_stream) {
+    OMX_REQUIRE(width == 4, "mlx_random_bits: only 4-byte words are supported (width %d)", width);
+    KeyArg k;
+    if (k.init(key, "mlx_random_bits")) return 1;
+    NEW_OR_FAIL(r, std::vector<int>(shape, shape + shape_num), MLX_UINT32);
+    if (omx_random_bits((uint32_t*)r->ptr(), k.ptr, (int64_t)r->size(), g_stream)) { delete r; return 1; }
+    return assign(res, r);
+}
+int mlx_random_uniform(mlx_array* res, const mlx_array low, const mlx_array high, const int* shape, size_t shape_num,
+                       mlx_dtype dtype, const mlx_array key, const mlx_stream) {
+    REQ_ARR(low, "mlx_random_uniform"); REQ_ARR(high, "mlx_random_uniform");
+    OMX_REQUIRE(dtype == MLX_FLOAT32, "mlx_random_uniform: float32 only");
+    OMX_REQUIRE(A(low)->size() == 1 && A(high)->size() == 1, "mlx_random_uniform: scalar bounds only");
+    float lo = 0.f, hi = 1.f;
+    mlx_array lf = mlx_array_new(), hf = mlx_array_new();
+    int rc = mlx_astype(&lf, low, MLX_FLOAT32, mlx_stream{nullptr}) || mlx_astype(&hf, high, MLX_FLOAT32, mlx_stream{nullptr}) ||
+             item_host(lf, &lo, MLX_FLOAT32, "mlx_random_uniform") || item_host(hf, &hi, MLX_FLOAT32, "mlx_random_uniform");
+    mlx_array_free(lf); mlx_array_free(hf);
+    if (rc) return 1;
+    KeyArg k;
+    if (k.init(key, "mlx_random_uniform")) return 1;
+    NEW_OR_FAIL(r, std::vector<int>(shape, shape + shape_num), MLX_FLOAT32);
+    if (omx_random_uniform((float*)r->ptr(), k.ptr, (int64_t)r->size(), lo, hi, g_stream)) { delete r; return 1; }
+    return assign(res, r);
+}
+int mlx_random_gumbel(mlx_array* res, const int* shape, size_t shape_num, mlx_dtype dtype, const mlx_array key, const mlx_stream) {
+    OMX_REQUIRE(dtype == MLX_FLOAT32, "mlx_random_gumbel: float32 only");
+    KeyArg k;
+    if (k.init(key, "mlx_random_gumbel")) return 1;
+    NEW_OR_FAIL(r, std::vector<int>(shape, shape + shape_num), MLX_FLOAT32);
+    if (omx_random_gumbel((float*)r->ptr(), k.ptr, (int64_t)r->size(), g_stream)) { delete r; return 1; }
+    return assign(res, r);
+}
+static int categorical_impl(mlx_array* res, const mlx_array logits, int axis, int num_samples, bool keep_samples_dim,
+                            const mlx_array key, const char* name) {
+    REQ_ARR(logits, name);
+    const Arr& s = *A(logits);
+    OMX_REQUIRE(is_float(s.dt), "%s: logits must be floating point", name);
+    OMX_REQUIRE(!s.shape.empty(), "%s: logits need at least one axis", name);
+    int ax;
+    if (norm_axis(axis, (int)s.shape.size(), name, &ax)) return 1;
+    OMX_REQUIRE(ax == (int)s.shape.size() - 1, "%s: only the last axis is supported (sampler.rs:15)", name);
+    Contig c;
+    if (c.init(s)) return 1;
+    KeyArg k;
+    if (k.init(key, name)) return 1;
+    std::vector<int> shape(s.shape.begin(), s.shape.end() - 1);
+    if (keep_samples_dim) shape.push_back(num_samples);
+    NEW_OR_FAIL(r, shape, MLX_UINT32);
+    const int n = s.shape.back();
+    OMX_REQUIRE(n > 0, "%s: empty distribution axis", name);
+    if (omx_random_categorical((uint32_t*)r->ptr(), c.a->ptr(), (int64_t)(s.size() / n), n, num_samples, 1.0f, k.ptr, to_omx(s.dt),
+                               g_stream)) { delete r; return 1; }
+    return assign(res, r);
+}
+int mlx_random_categorical(mlx_array* res, const mlx_array logits, int axis, const mlx_array key, const mlx_stream) {
+    return categorical_impl(res, logits, axis, 1, false, key, "mlx_random_categorical");
+}
+int mlx_random_categorical_num_samples(mlx_array* res, const mlx_array logits, int axis, int num_samples, const mlx_array key,
+                                       const mlx_stream) {
+    OMX_REQUIRE(num_samples >= 1, "mlx_random_categorical_num_samples: num_samples=%d must be positive", num_samples);
+    return categorical_impl(res, logits, axis, num_samples, true, key, "mlx_random_categorical_num_samples");
+}
+int mlx_random_categorical_shape(mlx_array* res, const mlx_array logits, int axis, const int* shape, size_t shape_num,
+                                 const mlx_array key, const mlx_stream) {
+    REQ_ARR(logits, "mlx_random_categorical_shape");
+    const Arr& s = *A(logits);
+    bool same = shape_num + 1 == s.shape.size();
+    for (size_t i = 0; same && i < shape_num; ++i) same = shape[i] == s.shape[i];
+    OMX_REQUIRE(same, "mlx_random_categorical_shape: only shape == logits.shape without the axis is supported");
+    return categorical_impl(res, logits, axis, 1, false, key, "mlx_random_categorical_shape");
+}
 int mlx_softmax_axis(mlx_array* res, const mlx_array a, int axis, bool, const mlx_stream) {
     REQ_ARR(a, "mlx_softmax_axis");
     const Arr& s = *A(a);

@@ -31,6 +31,7 @@ ENGINE_SIGNATURES = {
     "omx_qwen3_set_weight": (c_int, [c_void_p, ctypes.c_char_p, c_void_p]),
     "omx_qwen3_synth_weights": (c_int, [c_void_p, c_uint32]),
     "omx_qwen3_set_comm": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "omx_qwen3_set_sampler": (c_int, [c_void_p, ctypes.c_float, ctypes.c_uint64]),
     "omx_qwen3_reset": (c_int, [c_void_p]),
     "omx_qwen3_offset": (c_int, [c_void_p, ctypes.POINTER(c_int)]),
     "omx_qwen3_prefill": (c_int, [c_void_p, ctypes.POINTER(c_uint32), c_int, ctypes.POINTER(c_uint32)]),
@@ -117,6 +118,11 @@ class Model:
     def set_comm(self, comm_ptr: int, allreduce_fn_ptr: int) -> None:
         check(lib.omx_qwen3_set_comm(self._h, comm_ptr, allreduce_fn_ptr))
 
+    def set_sampler(self, temperature: float, seed: int = 0) -> None:
+        """DefaultSampler (mlx-rs-core/src/sampler.rs:9-18): 0 = greedy, otherwise categorical(logits / temperature)
+        drawn on the device with the key sequence of `mlx_rs::random::seed(seed)`."""
+        check(lib.omx_qwen3_set_sampler(self._h, float(temperature), int(seed) & 0xFFFFFFFFFFFFFFFF))
+
     def reset(self) -> None:
         check(lib.omx_qwen3_reset(self._h))
 
@@ -169,12 +175,12 @@ class Model:
 
 
 class Generate:
-    """qwen3_mlx::Generate (model.rs:743-844): iterator yielding greedy tokens; the first `next`
-    prefills the prompt.  temp must be 0 (the greedy path of sample(), model.rs:733-735)."""
+    """qwen3_mlx::Generate (model.rs:743-844): iterator yielding sampled tokens; the first `next`
+    prefills the prompt.  temp == 0 is the greedy path of sample() (model.rs:733-735); temp != 0 draws
+    categorical(logits / temp) (model.rs:736-739) from the key sequence seeded with `seed`."""
 
-    def __init__(self, model: Model, temp: float, prompt_token, chunk: int = 16):
-        if temp != 0.0:
-            raise OmxError("Generate: only temp == 0 (greedy) is implemented on the fused engine")
+    def __init__(self, model: Model, temp: float, prompt_token, chunk: int = 16, seed: int = 0):
+        model.set_sampler(temp, seed)
         self.model, self.prompt, self.chunk = model, np.asarray(prompt_token, dtype=np.uint32).ravel(), chunk
         self._prefilled = False
         self._buf = []

@@ -124,6 +124,16 @@ SIGNATURES = {
     "mlx_take_axis": (c_int, [P_ARR, mlx_array, mlx_array, c_int, mlx_stream]),
     "mlx_argmax_axis": (c_int, [P_ARR, mlx_array, c_int, c_bool, mlx_stream]),
     "mlx_softmax_axis": (c_int, [P_ARR, mlx_array, c_int, c_bool, mlx_stream]),
+    "mlx_random_seed": (c_int, [ctypes.c_uint64]),
+    "mlx_random_key": (c_int, [P_ARR, ctypes.c_uint64]),
+    "mlx_random_split_num": (c_int, [P_ARR, mlx_array, c_int, mlx_stream]),
+    "mlx_random_split": (c_int, [P_ARR, P_ARR, mlx_array, mlx_stream]),
+    "mlx_random_bits": (c_int, [P_ARR, P_INT, c_size_t, c_int, mlx_array, mlx_stream]),
+    "mlx_random_uniform": (c_int, [P_ARR, mlx_array, mlx_array, P_INT, c_size_t, c_int, mlx_array, mlx_stream]),
+    "mlx_random_gumbel": (c_int, [P_ARR, P_INT, c_size_t, c_int, mlx_array, mlx_stream]),
+    "mlx_random_categorical": (c_int, [P_ARR, mlx_array, c_int, mlx_array, mlx_stream]),
+    "mlx_random_categorical_num_samples": (c_int, [P_ARR, mlx_array, c_int, c_int, mlx_array, mlx_stream]),
+    "mlx_random_categorical_shape": (c_int, [P_ARR, mlx_array, c_int, P_INT, c_size_t, mlx_array, mlx_stream]),
     "omx_mlx_fused_swiglu": (c_int, [P_ARR, mlx_array, mlx_array, mlx_stream]),
     "omx_mlx_fused_modulate": (c_int, [P_ARR, mlx_array, mlx_array, mlx_array, mlx_stream]),
 }
@@ -294,6 +304,46 @@ def contiguous(a): return Array.op(lib.mlx_contiguous, a.h, False, default_strea
 def take_axis(a, indices, axis): return Array.op(lib.mlx_take_axis, a.h, indices.h, axis, default_stream())
 def argmax_axis(a, axis, keepdims=False): return Array.op(lib.mlx_argmax_axis, a.h, axis, keepdims, default_stream())
 def softmax_axis(a, axis, precise=True): return Array.op(lib.mlx_softmax_axis, a.h, axis, precise, default_stream())
+
+
+# ---- mlx_rs::random (random.rs): keys are [2] u32 arrays; key=None draws from the library's global sequence ----
+def random_seed(seed: int) -> None:
+    _check(lib.mlx_random_seed(int(seed) & 0xFFFFFFFFFFFFFFFF))
+
+
+def random_key(seed: int) -> Array:
+    require_device()
+    return Array.op(lambda res: lib.mlx_random_key(res, int(seed) & 0xFFFFFFFFFFFFFFFF))
+
+
+def random_split(key: Array, num: int = 2):
+    """random.rs:103-115: split_num then index rows 0 and 1."""
+    keys = Array.op(lib.mlx_random_split_num, key.h, num, default_stream())
+    return tuple(reshape(slice(keys, [i, 0], [i + 1, 2]), [2]) for i in range(num))
+
+
+def random_bits(shape, key: Optional[Array] = None, width: int = 4):
+    s, n = _ints(shape)
+    return Array.op(lib.mlx_random_bits, s, n, width, _h(key), default_stream())
+
+
+def random_uniform(low, high, shape, key: Optional[Array] = None, dtype=FLOAT32):
+    lo, hi = Array.from_numpy(np.float32(low), FLOAT32), Array.from_numpy(np.float32(high), FLOAT32)
+    s, n = _ints(shape)
+    return Array.op(lib.mlx_random_uniform, lo.h, hi.h, s, n, dtype, _h(key), default_stream())
+
+
+def random_gumbel(shape, key: Optional[Array] = None, dtype=FLOAT32):
+    s, n = _ints(shape)
+    return Array.op(lib.mlx_random_gumbel, s, n, dtype, _h(key), default_stream())
+
+
+def random_categorical(logits: Array, axis: int = -1, num_samples: Optional[int] = None, key: Optional[Array] = None):
+    if num_samples is None:
+        return Array.op(lib.mlx_random_categorical, logits.h, axis, _h(key), default_stream())
+    return Array.op(lib.mlx_random_categorical_num_samples, logits.h, axis, int(num_samples), _h(key), default_stream())
+
+
 def fused_swiglu(x, gate): return Array.op(lib.omx_mlx_fused_swiglu, x.h, gate.h, default_stream())
 def fused_modulate(x, shift, scale): return Array.op(lib.omx_mlx_fused_modulate, x.h, shift.h, scale.h, default_stream())
 

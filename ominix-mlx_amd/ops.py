@@ -240,6 +240,50 @@ def argmax(logits: Tensor) -> Tensor:
     return out
 
 
+def random_key(seed: int) -> Tensor:
+    """mlx_rs::random::key (random.rs:98-100): [2] u32 = (seed >> 32, seed & 0xffffffff)."""
+    k = Tensor((2,), UINT32)
+    check(lib.omx_random_key(k.ptr, int(seed) & 0xFFFFFFFFFFFFFFFF, None))
+    return k
+
+
+def random_split(key: Tensor, num: int = 2) -> Tensor:
+    """mlx_rs::random::split (random.rs:103-115): [num, 2] u32 sub-keys."""
+    out = Tensor((num, 2), UINT32)
+    check(lib.omx_random_split(out.ptr, key.ptr, num, None))
+    return out
+
+
+def random_bits(key: Tensor, shape) -> Tensor:
+    out = Tensor(tuple(shape), UINT32)
+    check(lib.omx_random_bits(out.ptr, key.ptr, out.size, None))
+    return out
+
+
+def random_uniform(key: Tensor, shape, lo: float = 0.0, hi: float = 1.0) -> Tensor:
+    """mlx_rs::random::uniform::<_, f32> with scalar bounds."""
+    out = Tensor(tuple(shape), FLOAT32)
+    check(lib.omx_random_uniform(out.ptr, key.ptr, out.size, float(lo), float(hi), None))
+    return out
+
+
+def random_gumbel(key: Tensor, shape) -> Tensor:
+    """mlx_rs::random::gumbel::<f32> (random.rs:397-414)."""
+    out = Tensor(tuple(shape), FLOAT32)
+    check(lib.omx_random_gumbel(out.ptr, key.ptr, out.size, None))
+    return out
+
+
+def random_categorical(logits: Tensor, key: Tensor, num_samples=None, inv_temp: float = 1.0) -> Tensor:
+    """mlx_rs::random::categorical over the last axis (random.rs:456-497); `inv_temp` folds the sampler's
+    `logits * array!(1/temp)` (sampler.rs:14) into the same pass."""
+    n = logits.shape[-1]
+    s = 1 if num_samples is None else int(num_samples)
+    out = Tensor(tuple(logits.shape[:-1]) + (() if num_samples is None else (s,)), UINT32)
+    check(lib.omx_random_categorical(out.ptr, logits.ptr, logits.size // n, n, s, float(inv_temp), key.ptr, logits.dtype, None))
+    return out
+
+
 def quantize(w: Tensor, group_size: int = 64, bits: int = 4):
     """mlx_rs::ops::quantize (ops/quantization.rs:41-84): w [..., K] -> (packed u32 [..., K*bits/32], scales, biases)."""
     K = w.shape[-1]

@@ -99,3 +99,48 @@ def uniform(lo: float, hi: float, shape, k=None) -> np.ndarray:
     u = np.minimum(u, np.nextafter(np.float32(1.0), np.float32(0.0)))
     lo32, hi32 = np.float32(lo), np.float32(hi)
     return (lo32 + (hi32 - lo32) * u).astype(np.float32).reshape(shape)
+
+
+def split(k, num: int = 2):
+    """mlx-rs/src/random.rs:103-115 (`split_device` -> mlx_random_split_num): `num` sub-keys, row i = words
+    (2i, 2i+1) of a 2*num-word draw from `k`."""
+    b = bits(k, 2 * num)
+    return [(b[2 * i], b[2 * i + 1]) for i in range(num)]
+
+
+def _log32(x: np.ndarray) -> np.ndarray:
+    """float32 log, correctly rounded (MLX evaluates log as a float32 primitive; its last-bit behaviour is
+    the platform's libm / simd routine, so the oracle and the HIP kernel both take the correctly rounded value)."""
+    with np.errstate(divide="ignore"):
+        return np.log(x.astype(np.float64)).astype(np.float32)
+
+
+def gumbel(shape, k=None) -> np.ndarray:
+    """mlx-rs/src/random.rs:397-414 (`gumbel_device` -> mlx_random_gumbel): -log(-log(uniform(0,1))), every
+    primitive in float32.  KAT: random.rs:690-694 (key 0 -> 0.13)."""
+    u = uniform(0.0, 1.0, shape, k)
+    return (-_log32(-_log32(u))).astype(np.float32)
+
+
+def categorical(logits: np.ndarray, k=None, num_samples=None) -> np.ndarray:
+    """mlx-rs/src/random.rs:456-497 (`categorical_device`, axis -1): argmax(logits + gumbel) with the noise
+    drawn in the shape [..., V] (or [..., V, num_samples]); logits are promoted to float32 by the add.
+    KATs: random.rs:697-718 (`test_logits`, `test_logits_count`)."""
+    lg = np.asarray(logits).astype(np.float32)
+    if num_samples is None:
+        g = gumbel(lg.shape, k)
+        return np.argmax((lg + g).astype(np.float32), axis=-1).astype(np.uint32)
+    g = gumbel(lg.shape + (int(num_samples),), k)
+    return np.argmax((lg[..., None] + g).astype(np.float32), axis=-2).astype(np.uint32)
+
+
+class RandomState:
+    """mlx-rs/src/random.rs:21-41: the key sequence behind `key = None` (`seed`, then one `split` per draw)."""
+
+    def __init__(self, seed_value: int):
+        self.state = key(seed_value)
+
+    def next(self):
+        k0, k1 = split(self.state, 2)
+        self.state = k0
+        return k1

@@ -389,6 +389,19 @@ def sample_greedy(logits) -> np.ndarray:
     return np.argmax(np.asarray(logits), axis=-1).astype(np.uint32)
 
 
+def sample(logits, temp: float, key) -> np.ndarray:
+    """`DefaultSampler::sample` (mlx-rs-core/src/sampler.rs:9-18; same body as qwen3-mlx/src/model.rs:733-741):
+    temp == 0 -> argmax; otherwise `categorical(logits * array!(1.0 / temp))`.  `array!(f32)` makes the
+    product float32 whatever the logits' dtype (bf16 x f32 promotes to f32).  `key` is the PRNG key the
+    categorical draw uses (the reference passes None = next key of the global `RandomState`)."""
+    from . import mlx_rng
+    if temp == 0.0:
+        return sample_greedy(logits)
+    inv = np.float32(np.float32(1.0) / np.float32(temp))
+    scaled = (np.asarray(logits).astype(np.float32) * inv).astype(np.float32)
+    return mlx_rng.categorical(scaled, key)
+
+
 def argmax_margin(logits) -> np.ndarray:
     """top1 - top2 gap per row; used by tests as the guard under which token-id
     equality between two fp32-summation orders is meaningful."""

@@ -192,17 +192,22 @@ class Qwen3Oracle:
         h = rc.rms_norm(h, self.w["model.norm.weight"], cfg.rms_norm_eps, self.dt)
         return self.lin(h, "model.embed_tokens" if cfg.tie_word_embeddings else "lm_head")
 
-    # model.rs:804-843 (yield order == plain sequential greedy decoding)
-    def generate(self, prompt: np.ndarray, n_new: int, caches: Optional[List] = None, return_logits: bool = False):
+    # model.rs:804-843 (yield order == plain sequential decoding); temp / seed: model.rs:733-741, 785, 815 with the
+    # global RandomState of mlx-rs/src/random.rs:21-41 seeded by `random::seed(seed)` (one split per sampled token)
+    def generate(self, prompt: np.ndarray, n_new: int, caches: Optional[List] = None, return_logits: bool = False,
+                 temp: float = 0.0, seed: int = 0):
+        from . import mlx_rng
+        state = mlx_rng.RandomState(seed)
+        pick = (lambda l: rc.sample_greedy(l)) if temp == 0.0 else (lambda l: rc.sample(l, temp, state.next()))
         caches = [] if caches is None else caches
         logits = self.forward(np.asarray(prompt)[None, :], caches)
         last = logits[:, -1, :]
-        y = rc.sample_greedy(last)
+        y = pick(last)
         toks, all_logits = [int(y[0])], [last[0]]
         for _ in range(n_new - 1):
             logits = self.forward(y[:, None].astype(np.int64), caches)
             last = logits[:, -1, :]
-            y = rc.sample_greedy(last)
+            y = pick(last)
             toks.append(int(y[0]))
             all_logits.append(last[0])
         if return_logits:

@@ -121,3 +121,40 @@ def test_bf16_round_is_rne():
     bits = rc.to_bf16_bits(np.array([1.0, -2.0], np.float32))
     assert bits.tolist() == [0x3F80, 0xC000]
     np.testing.assert_array_equal(rc.from_bf16_bits(bits), np.array([1.0, -2.0], np.float32))
+
+
+# ---- a10 sampler: the keyed random KATs of mlx-rs/src/random.rs (asserted there to 0.01 / exactly) ----
+
+def test_uniform_kats_key0():
+    k = rng.key(0)
+    assert float(rng.uniform(0.0, 10.0, (1,), k)[0]) == pytest.approx(4.18, abs=0.01)            # random.rs:549-553
+    np.testing.assert_allclose(rng.uniform(0.0, 10.0, (3,), k), [9.65, 3.14, 6.33], atol=0.01)    # random.rs:556-562
+
+
+def test_split_is_deterministic_and_distinct():      # random.rs:532-541
+    k1, k2 = rng.split(rng.key(0), 2)
+    assert tuple(k1) != tuple(k2)
+    r1, r2 = rng.split(rng.key(0), 2)
+    assert tuple(r1) == tuple(k1) and tuple(r2) == tuple(k2)
+    assert [tuple(map(int, x)) for x in rng.split2(rng.key(0))] == [tuple(map(int, k1)), tuple(map(int, k2))]
+
+
+def test_gumbel_kat_key0():                          # random.rs:690-694
+    assert float(rng.gumbel((1,), rng.key(0))[0]) == pytest.approx(0.13, abs=0.01)
+
+
+def test_categorical_kats_key0():
+    logits = np.zeros((5, 20), np.float32)
+    np.testing.assert_array_equal(rng.categorical(logits, rng.key(0)), [1, 1, 17, 17, 17])       # random.rs:697-707
+    np.testing.assert_array_equal(rng.categorical(logits, rng.key(0), num_samples=2),
+                                  [[16, 3], [14, 10], [17, 7], [6, 8], [12, 8]])                 # random.rs:710-719
+
+
+def test_sampler_temperature_zero_is_argmax_and_nonzero_is_categorical():   # mlx-rs-core/src/sampler.rs:9-18
+    logits = np.array([[0.1, 2.0, -1.0, 2.0]], np.float32)
+    np.testing.assert_array_equal(rc.sample(logits, 0.0, None), [1])
+    k = rng.key(5)
+    want = rng.categorical((logits * np.float32(1.0 / 0.7)).astype(np.float32), k)
+    np.testing.assert_array_equal(rc.sample(logits, 0.7, k), want)
+    # a very cold temperature concentrates on the (first) maximum
+    np.testing.assert_array_equal(rc.sample(np.array([[0.0, 5.0, 1.0]], np.float32), 1e-3, k), [1])

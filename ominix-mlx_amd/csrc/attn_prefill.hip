@@ -8,8 +8,10 @@
 //
 // Mapping (wave64, MFMA 16x16x32 bf16, fp32 accumulate):
 //   * block = 4 waves = 64 query rows (16 per wave) of one (batch, head); KV tiles of 64 keys staged
-//     in LDS: K row-major with a 16-B-chunk XOR swizzle, V TRANSPOSED ([d][key]) so that both MFMA
-//     operands are read as contiguous k-runs;
+//     in LDS by LDS-DMA (global_load_lds: no VGPR round trip), both row-major with an XOR swizzle applied on
+//     the SOURCE side (the DMA image is lane-linear): K in 16-B chunks for ds_read_b128, V in 32-B blocks for
+//     ds_read_b64_tr_b16, the hardware transpose read that hands each lane 4 keys of ONE head-dim column --
+//     the A operand of the second product -- out of a [4 keys][16 dims] block;
 //   * "swapped" products: S^T = K Q^T and O^T = V^T P^T.  In both C layouts a lane's column is its
 //     query row (lane & 15), so the online-softmax state (m, l) and the O rescale are lane-local;
 //     row max / sum across the 4 lanes that share a query use v_permlane16/32_swap (no LDS);
@@ -28,7 +30,6 @@ using f32x4v = __attribute__((ext_vector_type(4))) float;
 using u32x2v = __attribute__((ext_vector_type(2))) uint32_t;
 
 constexpr int KB = 64;    // keys per LDS tile
-constexpr int VT_STRIDE = KB;   // V^T rows are 128 B: 8 chunks of 16 B, XOR-swizzled by (d & 7) like the K tile
 
 struct PrefillArgs {
     const bf16_t *q, *k, *v;
@@ -67,10 +68,9 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(const PrefillArgs 
     constexpr int NDT = D / 16;     // 16-wide output tiles over the head dim
     constexpr int QBLK = 64 * QW;   // query rows per block
     constexpr int KCH = KB * DC / 256;          // K chunks staged per thread
-    constexpr int VCH = (KB / 2) * DC / 256;    // V key-pair chunks staged per thread
     // two buffers each: tile t+1 is staged while tile t is multiplied, ONE barrier per tile
     __shared__ __attribute__((aligned(16))) bf16_t sK2[2][KB * D];
-    __shared__ __attribute__((aligned(16))) bf16_t sVt2[2][D * VT_STRIDE];
+    __shared__ __attribute__((aligned(16))) bf16_t sV2[2][KB * D];
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int qcol = lane & 15, rg = lane >> 4;
@@ -111,7 +111,6 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(const PrefillArgs 
     //      V: (key 2p, key 2p+1) chunk pairs through registers, written transposed ([d][key]). ----
     typedef __attribute__((address_space(3))) void* lds_ptr_t;
     typedef const __attribute__((address_space(1))) void* glb_ptr_t;
-    u32x4 vreg[VCH][2];
     auto stage_k = [&](int k0, bf16_t* sK) {
 #pragma unroll
         for (int it = 0; it < KCH; ++it) {
@@ -122,52 +121,42 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(const PrefillArgs 
                                              (lds_ptr_t)(reinterpret_cast<unsigned char*>(sK) + (it * 256 + wave * 64) * 16), 16, 0, 0);
         }
     };
-    auto fetch_v = [&](int k0) {
+    // V: same DMA, swizzle = 32-B block index ^= (key row's position in its 256-B bank row group): the 8 keys that
+    // two 16-lane groups of one ds_read_b64_tr_b16 touch then sit in 8 different bank groups
+    constexpr int VSH = (D == 128) ? 0 : 1;           // keys per 256 B of LDS = 1 << VSH
+    constexpr int VBM = D / 16 - 1;                   // 32-B blocks per row - 1
+    auto stage_v = [&](int k0, bf16_t* sV) {
 #pragma unroll
-        for (int it = 0; it < VCH; ++it) {
-            const int idx = threadIdx.x + it * 256;
-            const int c = (idx % 4) + 4 * (idx / 128), pr = (idx / 4) % 32;
-            const int k_even = min(k0 + 2 * pr, a.Tk - 1), k_odd = min(k0 + 2 * pr + 1, a.Tk - 1);
-            vreg[it][0] = *reinterpret_cast<const u32x4*>(Vb + (size_t)k_even * a.kv_ts + c * 8);
-            vreg[it][1] = *reinterpret_cast<const u32x4*>(Vb + (size_t)k_odd * a.kv_ts + c * 8);
+        for (int it = 0; it < KCH; ++it) {
+            const int ci = threadIdx.x + it * 256;
+            const int row = ci / DC, ch = (ci % DC) ^ (((row >> VSH) & VBM) << 1);
+            const int key = min(k0 + row, a.Tk - 1);
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(Vb + (size_t)key * a.kv_ts + ch * 8),
+                                             (lds_ptr_t)(reinterpret_cast<unsigned char*>(sV) + (it * 256 + wave * 64) * 16), 16, 0, 0);
         }
     };
-    auto commit_v = [&](bf16_t* sVt) {
-        uint32_t* vt32 = reinterpret_cast<uint32_t*>(sVt);
-#pragma unroll
-        for (int it = 0; it < VCH; ++it) {
-            const int idx = threadIdx.x + it * 256;
-            const int c = (idx % 4) + 4 * (idx / 128), pr = (idx / 4) % 32;
-            // key k sits at position (k/32)*32 + ((k%16)/4)*8 + ((k/16)%2)*4 + k%4 of its V^T row: the eight keys one
-            // lane feeds to an MFMA -- (2j)*16 + rg*4 + [0,4) and (2j+1)*16 + rg*4 + [0,4) -- are ONE 16-byte chunk
-            const int k = 2 * pr;
-            const int pos = (k / 32) * 32 + ((k % 16) / 4) * 8 + ((k / 16) % 2) * 4 + (k % 4);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const uint32_t ev = vreg[it][0][e], od = vreg[it][1][e];
-                // V^T[d][k], V^T[d][k+1] packed: one 4-byte store per output row
-                const int d0 = c * 8 + 2 * e, d1 = d0 + 1;
-                vt32[(d0 * VT_STRIDE + (((pos >> 3) ^ (d0 & 7)) << 3) + (pos & 7)) >> 1] = (ev & 0xFFFFu) | (od << 16);
-                vt32[(d1 * VT_STRIDE + (((pos >> 3) ^ (d1 & 7)) << 3) + (pos & 7)) >> 1] = (ev >> 16) | (od & 0xFFFF0000u);
-            }
-        }
-    };
+    // transpose-read addressing: lane (i = lane & 15, rg) of fragment (key group j2, d-tile t) supplies the address of
+    // V[j2*16 + rg*4 + i/4][t*16 + (i&3)*4 ..+3]; the hardware returns V[j2*16 + rg*4 + 0..3][t*16 + i] to it
+    const int v_key = rg * 4 + (qcol >> 2);
+    const int v_sw = (v_key >> VSH) & VBM;
+    const int v_lane_off = v_key * D + (qcol & 3) * 4;   // elements
+    typedef __attribute__((ext_vector_type(4))) short s16x4;
+    typedef __attribute__((address_space(3))) s16x4* lds_s16x4_t;
 
     if (kv_end > 0) {
         stage_k(0, sK2[0]);
-        fetch_v(0);
-        commit_v(sVt2[0]);
+        stage_v(0, sV2[0]);
         __builtin_amdgcn_s_waitcnt(0);
         __syncthreads();
     }
     int buf = 0;
     for (int k0 = 0; k0 < kv_end; k0 += KB, buf ^= 1) {
         const bf16_t* sK = sK2[buf];
-        const bf16_t* sVt = sVt2[buf];
+        const bf16_t* sV = sV2[buf];
         const bool more = k0 + KB < kv_end;
-        if (more) {   // next tile: K straight into the other LDS buffer, V into registers; both in flight below
+        if (more) {   // next tile: K and V straight into the other LDS buffers, in flight under both products
             stage_k(k0 + KB, sK2[buf ^ 1]);
-            fetch_v(k0 + KB);
+            stage_v(k0 + KB, sV2[buf ^ 1]);
         }
 
         // ---- S^T = K Q^T for 4 key tiles of 16, both query sub-tiles share each K fragment ----
@@ -196,9 +185,6 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(const PrefillArgs 
 #pragma unroll
                 for (int w = 0; w < QW; ++w) s[w][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[i & 1][kt], qf[w][i], s[w][kt], 0, 0, 0);
         }
-        // the next tile's V is written to its LDS buffer here: its loads had the whole S^T product to land, and the
-        // staging registers are free again for the second product's fragment reads
-        if (more) commit_v(sVt2[buf ^ 1]);
         // ---- online softmax in the base-2 domain: p = 2^(s*c - m), c = scale * log2(e), m = running max of s*c.
         //      (lane: query qcol of each sub-tile, keys kt*16 + rg*4 + r).  Tiles that need no masking -- all keys
         //      valid and, under a causal mask, entirely below every query row of the block -- take a path without
@@ -272,14 +258,17 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(const PrefillArgs 
             }
         }
         // ---- O^T += V^T P^T : k-slot (rg*8 + e) <-> key (2j + (e>>2))*16 + rg*4 + (e&3) on BOTH operands.
-        //      16 V^T fragments (2 key halves x NDT d-tiles), read four ahead of the MFMAs that consume them ----
+        //      16 V^T fragments (2 key halves x NDT d-tiles), each two transpose reads, four ahead of their MFMAs ----
         {
             constexpr int NF = 2 * NDT, AHEAD = 4;
             u32x4 vf[AHEAD];
             auto read_v = [&](int idx) {
                 const int j = idx / NDT, t = idx % NDT;
-                const int d = t * 16 + qcol;                                // A operand: lane & 15 indexes d
-                return *reinterpret_cast<const u32x4*>(&sVt[d * VT_STRIDE + (((j * 4 + rg) ^ (d & 7)) << 3)]);
+                const bf16_t* p0 = sV + v_lane_off + ((t ^ v_sw) * 16) + (2 * j) * 16 * D;
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t)p0);
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t)(p0 + 16 * D));
+                const u32x2v l2 = __builtin_bit_cast(u32x2v, lo), h2 = __builtin_bit_cast(u32x2v, hi);
+                return u32x4{l2[0], l2[1], h2[0], h2[1]};
             };
 #pragma unroll
             for (int idx = 0; idx < AHEAD; ++idx) vf[idx] = read_v(idx);

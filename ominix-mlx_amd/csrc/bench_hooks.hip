@@ -225,3 +225,93 @@ extern "C" int omx_bench_qgemv(int N, int K, int bits, int pro, int epi, int n_c
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipStreamDestroy(s);
     return 0;
 }
+
+// ---- what does a COLD weight matrix cost a streaming GEMV at its start?  (tools/tlb_probe.py)
+//      mode 0: rotate through n_copies matrices (cold, as in a decode step)
+//      mode 1: before each GEMV, a tiny kernel reads ONE line every `stride` bytes of that matrix from every XCD
+//              (address translations warm, data cold)
+//      mode 2: before each GEMV, a kernel streams the whole matrix (translations and Infinity Cache warm)
+//      Per-kernel times come from rocprofv3 --kernel-trace --stats (different kernel names).
+namespace {
+__global__ void page_touch_kernel(const unsigned char* base, size_t bytes, size_t stride, unsigned* sink) {
+    // blockIdx % 8 is the XCD (round-robin dispatch): every XCD sweeps ALL pages, 1/(blocks per XCD) each
+    const size_t per_xcd = gridDim.x / 8, j = blockIdx.x / 8;
+    unsigned acc = 0;
+    for (size_t off = (j * blockDim.x + threadIdx.x) * stride; off < bytes; off += per_xcd * blockDim.x * stride)
+        acc += *reinterpret_cast<const volatile unsigned*>(base + off);
+    if (acc == 0x12345678u) *sink = acc;
+}
+__global__ void stream_read_kernel(const uint4* base, size_t n16, unsigned* sink) {
+    unsigned acc = 0;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) {
+        const uint4 v = base[i];
+        acc += v.x ^ v.y ^ v.z ^ v.w;
+    }
+    if (acc == 0x12345678u) *sink = acc;
+}
+}  // namespace
+
+extern "C" int omx_bench_gemv_warm(int N, int K, int pro, int epi, int n_copies, int iters, int mode, long stride,
+                                   int one_allocation, float* avg_ms) {
+    using namespace omx;
+    OMX_REQUIRE(avg_ms && n_copies > 0 && iters > 0, "omx_bench_gemv_warm: bad arguments");
+    const int mats = (epi == EPI_SWIGLU) ? 2 : 1;
+    const size_t wbytes = (((size_t)N * K * 2 * mats) + (2u << 20) - 1) & ~(size_t)((2u << 20) - 1);
+    std::vector<void*> w(n_copies, nullptr);
+    void* big = nullptr;
+    if (one_allocation) {
+        OMX_HIP_CHECK(hipMalloc(&big, wbytes * n_copies));
+        for (int i = 0; i < n_copies; ++i) w[i] = (char*)big + wbytes * i;
+    } else {
+        for (auto& p : w) OMX_HIP_CHECK(hipMalloc(&p, wbytes));
+    }
+    for (int i = 0; i < n_copies; ++i)
+        if (omx_fill_uniform(w[i], (size_t)N * K * mats, 17u + i, 0.03f, 0.f, OMX_BFLOAT16, nullptr)) return 1;
+    void *x = nullptr, *nw = nullptr, *out = nullptr, *resid = nullptr, *slot = nullptr;
+    OMX_HIP_CHECK(hipMalloc(&x, (size_t)K * 2));
+    OMX_HIP_CHECK(hipMalloc(&nw, (size_t)K * 2));
+    OMX_HIP_CHECK(hipMalloc(&out, (size_t)N * 4));
+    OMX_HIP_CHECK(hipMalloc(&resid, (size_t)N * 2));
+    OMX_HIP_CHECK(hipMalloc(&slot, 8 * 65536));
+    omx_fill_uniform(x, K, 3, 1.0f, 0.f, OMX_BFLOAT16, nullptr);
+    omx_fill_uniform(nw, K, 4, 0.1f, 1.f, OMX_BFLOAT16, nullptr);
+    omx_fill_uniform(resid, N, 5, 1.0f, 0.f, OMX_BFLOAT16, nullptr);
+    OMX_HIP_CHECK(hipMemset(slot, 0, 8 * 65536));
+    hipStream_t s;
+    OMX_HIP_CHECK(hipStreamCreate(&s));
+    hipEvent_t e0, e1;
+    OMX_HIP_CHECK(hipEventCreate(&e0));
+    OMX_HIP_CHECK(hipEventCreate(&e1));
+    auto run = [&](int i) {
+        const bf16_t* base = (const bf16_t*)w[i % n_copies];
+        if (mode == 1) page_touch_kernel<<<64, 256, 0, s>>>((const unsigned char*)base, (size_t)N * K * 2 * mats, (size_t)stride, (unsigned*)slot);
+        if (mode == 2) stream_read_kernel<<<2048, 256, 0, s>>>((const uint4*)base, (size_t)N * K * 2 * mats / 16, (unsigned*)slot);
+        GemvArgs a = {};
+        a.w0 = base;
+        a.w1 = base + (size_t)N * K;
+        a.n0 = N; a.N = N; a.K = K;
+        a.x = (const bf16_t*)x;
+        a.norm_w = (const bf16_t*)nw;
+        a.eps = 1e-6f;
+        a.resid = (const bf16_t*)resid;
+        a.out = out;
+        a.argmax_slot = (unsigned long long*)slot;
+        return launch_gemv(a, pro, epi, s);
+    };
+    for (int i = 0; i < n_copies + 2; ++i)
+        if (run(i)) return 1;
+    OMX_HIP_CHECK(hipStreamSynchronize(s));
+    OMX_HIP_CHECK(hipEventRecord(e0, s));
+    for (int i = 0; i < iters; ++i)
+        if (run(i)) return 1;
+    OMX_HIP_CHECK(hipEventRecord(e1, s));
+    OMX_HIP_CHECK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    OMX_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+    *avg_ms = ms / iters;
+    if (big) (void)hipFree(big);
+    else for (auto p : w) (void)hipFree(p);
+    (void)hipFree(x); (void)hipFree(nw); (void)hipFree(out); (void)hipFree(resid); (void)hipFree(slot);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipStreamDestroy(s);
+    return 0;
+}

@@ -111,30 +111,41 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(const PrefillArgs 
     //      V: (key 2p, key 2p+1) chunk pairs through registers, written transposed ([d][key]). ----
     typedef __attribute__((address_space(3))) void* lds_ptr_t;
     typedef const __attribute__((address_space(1))) void* glb_ptr_t;
-    auto stage_k = [&](int k0, bf16_t* sK) {
-#pragma unroll
-        for (int it = 0; it < KCH; ++it) {
-            const int ci = threadIdx.x + it * 256;
-            const int row = ci / DC, ch = (ci % DC) ^ (row & (DC - 1));
-            const int key = min(k0 + row, a.Tk - 1);
-            __builtin_amdgcn_global_load_lds((glb_ptr_t)(Kb + (size_t)key * a.kv_ts + ch * 8),
-                                             (lds_ptr_t)(reinterpret_cast<unsigned char*>(sK) + (it * 256 + wave * 64) * 16), 16, 0, 0);
-        }
-    };
-    // V: same DMA, swizzle = 32-B block index ^= (key row's position in its 256-B bank row group): the 8 keys that
-    // two 16-lane groups of one ds_read_b64_tr_b16 touch then sit in 8 different bank groups
+    // per-thread source offsets are loop invariants (elements from the tile's first key row); a tile that lies
+    // inside the sequence adds a wave-uniform base (SALU), only the last partial tile recomputes clamped rows
     constexpr int VSH = (D == 128) ? 0 : 1;           // keys per 256 B of LDS = 1 << VSH
     constexpr int VBM = D / 16 - 1;                   // 32-B blocks per row - 1
-    auto stage_v = [&](int k0, bf16_t* sV) {
+    uint32_t koff[KCH], voff[KCH];
+#pragma unroll
+    for (int it = 0; it < KCH; ++it) {
+        const int ci = threadIdx.x + it * 256;
+        const int row = ci / DC;
+        koff[it] = (uint32_t)(row * a.kv_ts + ((ci % DC) ^ (row & (DC - 1))) * 8);
+        voff[it] = (uint32_t)(row * a.kv_ts + ((ci % DC) ^ (((row >> VSH) & VBM) << 1)) * 8);
+    }
+    // K: 16-B chunk index ^= key & (DC-1) (ds_read_b128 of 16 consecutive key rows).  V: 32-B block index ^= the key
+    // row's position among the 8 rows that two 16-lane groups of one ds_read_b64_tr_b16 touch
+    auto stage = [&](int k0, const bf16_t* src, const uint32_t (&off)[KCH], bf16_t* dst, bool is_v) {
+        if (k0 + KB <= a.Tk) {
+            const bf16_t* base = src + (size_t)k0 * a.kv_ts;
+#pragma unroll
+            for (int it = 0; it < KCH; ++it)
+                __builtin_amdgcn_global_load_lds((glb_ptr_t)(base + off[it]),
+                                                 (lds_ptr_t)(reinterpret_cast<unsigned char*>(dst) + (it * 256 + wave * 64) * 16), 16, 0, 0);
+            return;
+        }
 #pragma unroll
         for (int it = 0; it < KCH; ++it) {
             const int ci = threadIdx.x + it * 256;
-            const int row = ci / DC, ch = (ci % DC) ^ (((row >> VSH) & VBM) << 1);
+            const int row = ci / DC;
+            const int ch = (ci % DC) ^ (is_v ? (((row >> VSH) & VBM) << 1) : (row & (DC - 1)));
             const int key = min(k0 + row, a.Tk - 1);
-            __builtin_amdgcn_global_load_lds((glb_ptr_t)(Vb + (size_t)key * a.kv_ts + ch * 8),
-                                             (lds_ptr_t)(reinterpret_cast<unsigned char*>(sV) + (it * 256 + wave * 64) * 16), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(src + (size_t)key * a.kv_ts + ch * 8),
+                                             (lds_ptr_t)(reinterpret_cast<unsigned char*>(dst) + (it * 256 + wave * 64) * 16), 16, 0, 0);
         }
     };
+    auto stage_k = [&](int k0, bf16_t* sK) { stage(k0, Kb, koff, sK, false); };
+    auto stage_v = [&](int k0, bf16_t* sV) { stage(k0, Vb, voff, sV, true); };
     // transpose-read addressing: lane (i = lane & 15, rg) of fragment (key group j2, d-tile t) supplies the address of
     // V[j2*16 + rg*4 + i/4][t*16 + (i&3)*4 ..+3]; the hardware returns V[j2*16 + rg*4 + 0..3][t*16 + i] to it
     const int v_key = rg * 4 + (qcol >> 2);
@@ -281,7 +292,7 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(const PrefillArgs 
                 for (int w = 0; w < QW; ++w)
                     o[w][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, cur), pf[w][j], o[w][t], 0, 0, 0);
             }
-        }
+            }
         __builtin_amdgcn_s_waitcnt(0);   // the K tile of the next iteration has landed (vmcnt), our LDS traffic retired (lgkmcnt)
         __syncthreads();
     }

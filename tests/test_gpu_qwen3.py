@@ -96,7 +96,7 @@ def test_reset_and_generate_iterator(omx):
     second_run = [next(it) for _ in range(9)]
     assert first_run == second_run
     with pytest.raises(omx.OmxError):
-        engine.Generate(m, 0.7, prompt)
+        engine.Generate(m, -0.7, prompt)       # a negative temperature is an error; temp > 0: tests/test_gpu_random.py
 
 
 def test_missing_weight_and_context_overflow_are_errors(omx):

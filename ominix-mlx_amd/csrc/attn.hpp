@@ -26,6 +26,9 @@ struct AttnDecodeArgs {
     const float* rope_cos;      // [max_pos, D/2]
     const float* rope_sin;
     float eps;
+    // optional [B*Hkv * 16] zeroed arrival counters: the LAST split block of a KV head merges the splits itself
+    // (same arithmetic as attn_combine_kernel) and no combine launch follows
+    unsigned* arrive;
 };
 
 size_t attn_decode_ws_bytes(int BH, int nsplit, int D);

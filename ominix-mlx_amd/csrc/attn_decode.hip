@@ -21,6 +21,7 @@
 //     K/V row in registers, uses it, and appends it to the cache (cache.rs:183-188) -- no barrier,
 //     no fence, and 6 launches per layer less than the per-op sequence.
 #include "attn.hpp"
+#include "gridsync.hpp"
 
 namespace omx {
 
@@ -256,11 +257,84 @@ __global__ __launch_bounds__(kBlock) void attn_decode_kernel(const AttnDecodeArg
             O = fmaf(f, ow, O);
         }
         const size_t head = (size_t)b * a.H + kvh * G + g;
-        a.ws_o[(head * a.nsplit + split) * D + d] = O;
-        if (d == 0) {
-            a.ws_ml[(head * a.nsplit + split) * 2] = M;
-            a.ws_ml[(head * a.nsplit + split) * 2 + 1] = L;
+        if (a.arrive) {   // read by another block of this launch: write through (sc1), see below
+            st_coh_f32(a.ws_o + (head * a.nsplit + split) * D + d, O);
+            if (d == 0) {
+                st_coh_f32(a.ws_ml + (head * a.nsplit + split) * 2, M);
+                st_coh_f32(a.ws_ml + (head * a.nsplit + split) * 2 + 1, L);
+            }
+        } else {
+            a.ws_o[(head * a.nsplit + split) * D + d] = O;
+            if (d == 0) {
+                a.ws_ml[(head * a.nsplit + split) * 2] = M;
+                a.ws_ml[(head * a.nsplit + split) * 2 + 1] = L;
+            }
         }
+    }
+    if (!a.arrive) return;
+    // ---- in-launch combine: the block that arrives LAST at its KV head's counter merges all splits of its G heads.
+    //      Publication: write-through partial stores, vmcnt(0), block barrier, then ONE relaxed device-scope atomic;
+    //      the reader uses sc1 loads (no fences: cdna_hip_programming.md, split-K seam).  Arithmetic and order are
+    //      attn_combine_kernel's, so both routes give the same bits. ----
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int* sm_flag = reinterpret_cast<int*>(sm_l + kWaves * GT);
+    if (threadIdx.x == 0) {
+        unsigned* cnt = a.arrive + (size_t)bk * 16;
+        const unsigned old = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = (old + 1u == (unsigned)a.nsplit);
+        if (last) st_coh32(cnt, 0u);   // ready for the next launch (stream order separates them)
+        *sm_flag = last;
+    }
+    __syncthreads();
+    if (!*sm_flag) return;
+    float* sm_f = sm_o;                 // [G][nsplit] rescale factors (the merge scratch is free again)
+    float* sm_L = sm_m;                 // [G]
+    __syncthreads();
+    for (int g = wave; g < G; g += kWaves) {   // phase 1: one lane per split
+        const float* ml = a.ws_ml + ((size_t)b * a.H + kvh * G + g) * a.nsplit * 2;
+        float mloc = -INFINITY;
+        for (int i = lane; i < a.nsplit; i += 64) mloc = fmaxf(mloc, ld_coh_f32(ml + 2 * i));
+        const float M = wave_max(mloc);
+        float lloc = 0.f;
+        for (int i = lane; i < a.nsplit; i += 64) {
+            const float mi = ld_coh_f32(ml + 2 * i);
+            const float f = (mi == -INFINITY) ? 0.f : __expf(mi - M);
+            sm_f[g * a.nsplit + i] = f;
+            lloc = fmaf(f, ld_coh_f32(ml + 2 * i + 1), lloc);
+        }
+        const float L = wave_sum(lloc);
+        if (lane == 0) sm_L[g] = L;
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < G * D; idx += kBlock) {   // phase 2: one thread per (head, d)
+        const int g = idx / D, d = idx % D;
+        const size_t head = (size_t)b * a.H + kvh * G + g;
+        const float* src = a.ws_o + head * a.nsplit * D + d;
+        const float* f = sm_f + g * a.nsplit;
+        float acc0 = 0.f, acc1 = 0.f;
+        int i = 0;
+        for (; i + 16 <= a.nsplit; i += 16) {
+            float v[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) v[j] = ld_coh_f32(src + (size_t)(i + j) * D);
+#pragma unroll
+            for (int j = 0; j < 16; j += 2) {
+                acc0 = fmaf(f[i + j], v[j], acc0);
+                acc1 = fmaf(f[i + j + 1], v[j + 1], acc1);
+            }
+        }
+        for (; i + 4 <= a.nsplit; i += 4) {
+            float v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = ld_coh_f32(src + (size_t)(i + j) * D);
+            acc0 = fmaf(f[i], v[0], acc0);
+            acc1 = fmaf(f[i + 1], v[1], acc1);
+            acc0 = fmaf(f[i + 2], v[2], acc0);
+            acc1 = fmaf(f[i + 3], v[3], acc1);
+        }
+        for (; i < a.nsplit; ++i) acc0 = fmaf(f[i], ld_coh_f32(src + (size_t)i * D), acc0);
+        a.out[head * D + d] = f32_to_bf16((acc0 + acc1) / sm_L[g]);
     }
 }
 
@@ -329,7 +403,7 @@ int launch_attn_decode(const AttnDecodeArgs& a, int D, bool fused, hipStream_t s
     const int gt = G <= 1 ? 1 : G <= 2 ? 2 : G <= 4 ? 4 : 8;
 #define OMX_ATTN_CASE(DD, GG)                                                                           \
     if (D == DD && gt == GG) {                                                                          \
-        const size_t shmem = ((size_t)kWaves * (64 / (DD / 8)) * GG * DD + 2 * kWaves * GG) * sizeof(float); \
+        const size_t shmem = ((size_t)kWaves * (64 / (DD / 8)) * GG * DD + 2 * kWaves * GG + 4) * sizeof(float); \
         if (shmem > 48 * 1024) {                                                                        \
             OMX_HIP_CHECK(hipFuncSetAttribute((const void*)attn_decode_kernel<DD, GG, true>,            \
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem)); \
@@ -339,8 +413,10 @@ int launch_attn_decode(const AttnDecodeArgs& a, int D, bool fused, hipStream_t s
         if (fused) attn_decode_kernel<DD, GG, true><<<grid, block, shmem, s>>>(a);                      \
         else attn_decode_kernel<DD, GG, false><<<grid, block, shmem, s>>>(a);                           \
         OMX_LAUNCH_CHECK();                                                                             \
-        attn_combine_kernel<DD><<<a.B * a.H, DD, 0, s>>>(a.out, a.ws_o, a.ws_ml, a.nsplit);             \
-        OMX_LAUNCH_CHECK();                                                                             \
+        if (!a.arrive) {                                                                                \
+            attn_combine_kernel<DD><<<a.B * a.H, DD, 0, s>>>(a.out, a.ws_o, a.ws_ml, a.nsplit);         \
+            OMX_LAUNCH_CHECK();                                                                         \
+        }                                                                                               \
         return 0;                                                                                       \
     }
     OMX_ATTN_CASE(128, 1) OMX_ATTN_CASE(128, 2) OMX_ATTN_CASE(128, 4) OMX_ATTN_CASE(128, 8)

@@ -167,6 +167,7 @@ struct omx_qwen3_ {
     unsigned long long *argmax_partials = nullptr, *argmax_key = nullptr;
     int n_argmax_partials = 0;
     float *ws_o = nullptr, *ws_ml = nullptr;
+    unsigned* attn_arrive = nullptr;   // per-KV-head arrival counters of the in-launch split combine (attn_decode.hip)
     int nsplit = 1;
 
     void* comm = nullptr;
@@ -303,6 +304,7 @@ int enqueue_step_quant(omx_qwen3 m, bool with_head) {
             a.mask_mode = OMX_MASK_NONE;
             a.nsplit = m->nsplit;
             a.ws_o = m->ws_o; a.ws_ml = m->ws_ml;
+            a.arrive = m->attn_arrive;
             a.out = m->attn_out;
             a.pos_ptr = &m->st->pos;
             a.q_norm_w = L.q_norm; a.k_norm_w = L.k_norm;
@@ -384,6 +386,7 @@ int enqueue_step(omx_qwen3 m, bool with_head) {
             a.mask_mode = OMX_MASK_NONE;
             a.nsplit = m->nsplit;
             a.ws_o = m->ws_o; a.ws_ml = m->ws_ml;
+            a.arrive = m->attn_arrive;
             a.out = m->attn_out;
             a.pos_ptr = &m->st->pos;
             a.q_norm_w = L.q_norm; a.k_norm_w = L.k_norm;
@@ -717,6 +720,7 @@ int omx_qwen3_create(omx_qwen3* out, const omx_qwen3_config* cfg) {
         dev_alloc(m, &m->act, (size_t)m->I) || dev_alloc(m, &m->logits, (size_t)m->V) ||
         dev_alloc(m, &m->partial_a, (size_t)c.hidden_size) || dev_alloc(m, &m->partial_b, (size_t)c.hidden_size) ||
         dev_alloc(m, &m->argmax_key, 1) || dev_alloc(m, &m->ws_o, (size_t)m->H * m->nsplit * D) ||
+        dev_alloc(m, &m->attn_arrive, (size_t)m->Hkv * 16) ||
         dev_alloc(m, &m->ws_ml, (size_t)m->H * m->nsplit * 2))
         return 1;
     m->prompt_cap = m->cap;

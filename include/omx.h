@@ -122,6 +122,8 @@ int omx_random_split(uint32_t* out /*[num,2]*/, const uint32_t* key, int num, om
 int omx_random_bits(uint32_t* out, const uint32_t* key, int64_t n, omx_stream stream);
 int omx_random_uniform(float* out, const uint32_t* key, int64_t n, float lo, float hi, omx_stream stream);
 int omx_random_gumbel(float* out, const uint32_t* key, int64_t n, omx_stream stream);
+/* mlx_random_normal (random.h:100-108; mlx-rs/src/random.rs:186-212): sqrt(2) * erfinv(uniform(-1, 1)) * scale + loc, f32 */
+int omx_random_normal(float* out, const uint32_t* key, int64_t n, float loc, float scale, omx_stream stream);
 int omx_random_categorical(uint32_t* out, const void* logits, int64_t rows, int n, int num_samples, float inv_temp,
                            const uint32_t* key, omx_dtype dtype, omx_stream stream);
 
@@ -172,6 +174,12 @@ int omx_qwen3_set_comm(omx_qwen3 m, void* comm, void* allreduce_fn);
  * otherwise every sampled token is categorical(logits * (1/temperature)) with the next key of a RandomState
  * seeded like mlx_rs::random::seed(seed) (random.rs:21-41, :88-91).  The draw stays on the device, inside the step. */
 int omx_qwen3_set_sampler(omx_qwen3 m, float temperature, uint64_t seed);
+/* text-encoder use of the stack (flux-klein-mlx/src/qwen3_encoder.rs:403-455, `forward_with_hidden_states` + `encode`):
+ * all n tokens through layers 0..tap_layers[n_taps-1]; out (DEVICE, bf16) [n, n_taps*hidden] = the raw hidden states
+ * after the tapped layers, concatenated on the last axis (FLUX.2-klein: taps 8,17,26 -> 7680 of Qwen3-4B).
+ * attention_mask (host, [n] of 0/1, may be NULL = causal only) adds the padding mask of qwen3_encoder.rs:172-198.  */
+int omx_qwen3_encode(omx_qwen3 m, const uint32_t* ids, int n, const uint8_t* attention_mask, const int* tap_layers, int n_taps,
+                     void* out_dev);
 int omx_qwen3_reset(omx_qwen3 m);                                  /* KVCache::reset (cache.rs:130-132) */
 int omx_qwen3_offset(omx_qwen3 m, int* offset);                    /* KeyValueCache::offset           */
 /* Generate: prefill the prompt, return the first sampled token (model.rs:808-827)                   */
@@ -271,6 +279,9 @@ int omx_klein_set_comm(omx_klein m, void* comm, void* allreduce_fn);
  * text rows first (compute_rope_freqs, klein_model.rs:53-110); out [s_img, in_channels] device bf16.      */
 int omx_klein_forward_with_rope(omx_klein m, void* out, const void* latent, const void* txt_embed, int s_img, int s_txt,
                                 float timestep, const float* rope_cos, const float* rope_sin);
+/* one Euler step of the rectified-flow sampler (flux-klein-mlx/examples/generate_klein.rs:441-443, src/sampler.rs:174-186):
+ * latent_f32[i] += dt * v_bf16[i]; latent_bf16 (may be NULL) receives the rounded copy the next forward reads          */
+int omx_klein_euler_step(void* latent_f32, const void* v_bf16, float dt, void* latent_bf16, int64_t n, omx_stream stream);
 int omx_klein_last_ms(omx_klein m, float* ms);          /* HIP-event time of the last forward */
 int omx_klein_debug_read(omx_klein m, const char* name, void* host, size_t n_elems);   /* test hook */
 

@@ -168,6 +168,8 @@ int mlx_random_uniform(mlx_array* res, const mlx_array low, const mlx_array high
                        mlx_dtype dtype, const mlx_array key /* may be null */, const mlx_stream s);            /* :149 */
 int mlx_random_gumbel(mlx_array* res, const int* shape, size_t shape_num, mlx_dtype dtype,
                       const mlx_array key /* may be null */, const mlx_stream s);                              /* :65 */
+int mlx_random_normal(mlx_array* res, const int* shape, size_t shape_num, mlx_dtype dtype, float loc, float scale,
+                      const mlx_array key /* may be null */, const mlx_stream s);                              /* :100 (sampler.rs:139-141 prior) */
 int mlx_random_categorical(mlx_array* res, const mlx_array logits, int axis,
                            const mlx_array key /* may be null */, const mlx_stream s);                         /* :59 */
 int mlx_random_categorical_num_samples(mlx_array* res, const mlx_array logits, int axis, int num_samples,

@@ -58,6 +58,7 @@ SIGNATURES = {
     "omx_memcpy_h2d": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
     "omx_memcpy_d2h": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
     "omx_memcpy_d2d": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
+    "omx_cast": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int64, c_void_p]),
     "omx_memset": (c_int, [c_void_p, c_int, c_size_t, c_void_p]),
     "omx_fill_uniform": (c_int, [c_void_p, c_size_t, c_uint32, c_float, c_float, c_int, c_void_p]),
     "omx_rms_norm": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_float, c_int, c_void_p]),
@@ -76,6 +77,7 @@ SIGNATURES = {
     "omx_random_bits": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     "omx_random_uniform": (c_int, [c_void_p, c_void_p, c_int64, ctypes.c_float, ctypes.c_float, c_void_p]),
     "omx_random_gumbel": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
+    "omx_random_normal": (c_int, [c_void_p, c_void_p, c_int64, ctypes.c_float, ctypes.c_float, c_void_p]),
     "omx_random_categorical": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, ctypes.c_float, c_void_p, c_int, c_void_p]),
     "omx_take_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
     "omx_add": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),

@@ -103,6 +103,18 @@ uint32_t crc32_name(const char* s) {
 
 }  // namespace
 // tensor-parallel tail of a row-split projection: out = bf16(resid + sum * gate[col]) on the all-reduced partial
+// generate_klein.rs:441-443 (sampler.rs:174-186): latent += (t_next - t_curr) * v, product and sum rounded separately;
+// the master latent stays float32, the bf16 copy is what the next forward reads
+__global__ __launch_bounds__(256) void euler_step_kernel(float* __restrict__ latent, const bf16_t* __restrict__ v, float dt,
+                                                         bf16_t* __restrict__ latent_bf16, int64_t n) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float scaled = bf16_to_f32(v[i]) * dt;
+        const float z = latent[i] + scaled;
+        latent[i] = z;
+        if (latent_bf16) latent_bf16[i] = f32_to_bf16(z);
+    }
+}
+
 __global__ __launch_bounds__(256) void gated_residual_kernel(bf16_t* __restrict__ out, const bf16_t* __restrict__ resid,
                                                              const bf16_t* __restrict__ gate, const bf16_t* __restrict__ sum,
                                                              int64_t n, int h) {
@@ -446,6 +458,14 @@ int omx_klein_forward_with_rope(omx_klein m, void* out, const void* latent, cons
     OMX_HIP_CHECK(hipEventRecord(m->ev1, s));
     OMX_HIP_CHECK(hipStreamSynchronize(s));
     OMX_HIP_CHECK(hipEventElapsedTime(&m->last_ms, m->ev0, m->ev1));
+    return 0;
+}
+
+int omx_klein_euler_step(void* latent_f32, const void* v_bf16, float dt, void* latent_bf16, int64_t n, omx_stream stream) {
+    OMX_REQUIRE(latent_f32 && v_bf16, "omx_klein_euler_step: null tensor");
+    if (n == 0) return 0;
+    euler_step_kernel<<<1024, 256, 0, (hipStream_t)stream>>>((float*)latent_f32, (const bf16_t*)v_bf16, dt, (bf16_t*)latent_bf16, n);
+    OMX_LAUNCH_CHECK();
     return 0;
 }
 

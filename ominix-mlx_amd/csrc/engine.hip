@@ -588,7 +588,32 @@ int mega_health(omx_qwen3 m) {
     return 0;
 }
 
-int prefill_prefix_batched(omx_qwen3 m, int T, int off) {
+// Text-encoder use of the same stack (flux-klein-mlx/src/qwen3_encoder.rs:141-224, 403-455): all T tokens through
+// layers 0..last tap, hidden states copied out after the tapped layers, attention under an explicit additive mask.
+struct EncodeOpts {
+    const int* taps;          // ascending layer indices whose OUTPUT is extracted
+    int n_taps;
+    bf16_t* out;              // [T, n_taps * hidden]
+    const bf16_t* mask;       // optional additive [T, T] (causal + padding), nullptr = causal
+};
+
+__global__ void copy_rows_strided_kernel(bf16_t* dst, int64_t dst_ld, const bf16_t* src, int64_t src_ld, int rows, int cols8) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < (int64_t)rows * cols8; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / cols8, c = i % cols8;
+        *reinterpret_cast<u32x4*>(dst + r * dst_ld + c * 8) = *reinterpret_cast<const u32x4*>(src + r * src_ld + c * 8);
+    }
+}
+
+// qwen3_encoder.rs:172-198: additive mask 0 where (j <= i and attention_mask[j]) else bf16(-1e9)
+__global__ void encoder_mask_kernel(bf16_t* mask, const uint8_t* am, int T) {
+    const bf16_t neg = f32_to_bf16(-1e9f);
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < (int64_t)T * T; i += (int64_t)gridDim.x * blockDim.x) {
+        const int q = (int)(i / T), k = (int)(i % T);
+        mask[i] = (k <= q && am[k]) ? (bf16_t)0 : neg;
+    }
+}
+
+int prefill_prefix_batched(omx_qwen3 m, int T, int off, const EncodeOpts* enc = nullptr) {
     const omx_qwen3_config& c = m->cfg;
     hipStream_t s = m->stream;
     const int hd = c.hidden_size, D = c.head_dim, H = m->H, Hkv = m->Hkv, I = m->I;
@@ -635,7 +660,9 @@ int prefill_prefix_batched(omx_qwen3 m, int T, int off) {
     bf16_t* h2 = m->pf_h2;
     const float scale = 1.0f / sqrtf((float)D);
     const LayerQ no_q = {};
-    for (int l = 0; l < c.num_hidden_layers; ++l) {
+    const int n_run = enc ? enc->taps[enc->n_taps - 1] + 1 : c.num_hidden_layers;
+    int next_tap = 0;
+    for (int l = 0; l < n_run; ++l) {
         const LayerW& L = m->layers[l];
         const LayerQ& Q = quant ? m->qlayers[l] : no_q;
         const bf16_t* w = nullptr;
@@ -646,9 +673,10 @@ int prefill_prefix_batched(omx_qwen3 m, int T, int off) {
         if (launch_qk_norm_rope_scatter(m->pf_q, m->pf_k, m->pf_v, L.q_norm, L.k_norm, m->rope_cos, m->rope_sin, m->pf_qt,
                                         m->kcache[l], m->vcache[l], T, H, Hkv, D, m->cap, off, c.rms_norm_eps, s))
             return 1;
-        if (l == c.num_hidden_layers - 1) break;
+        if (!enc && l == c.num_hidden_layers - 1) break;
         if (launch_attn_prefill(m->pf_attn, m->pf_qt, m->kcache[l], m->vcache[l], 1, H, Hkv, T, off + T, D, 0,
-                                (int64_t)m->cap * D, scale, OMX_MASK_CAUSAL, nullptr, s, /*out_token_major=*/true))
+                                (int64_t)m->cap * D, scale, enc && enc->mask ? OMX_MASK_ADDITIVE : OMX_MASK_CAUSAL,
+                                enc ? enc->mask : nullptr, s, /*out_token_major=*/true))
             return 1;
         if (!(w = W(L.o, &Q.o, H * D)) || launch_gemm_bf16_ex(h2, m->pf_attn, w, nullptr, h, T, hd, H * D, s)) return 1;
         if (omx_rms_norm(m->pf_xn, h2, L.post_ln, T, hd, c.rms_norm_eps, OMX_BFLOAT16, s)) return 1;
@@ -656,6 +684,11 @@ int prefill_prefix_batched(omx_qwen3 m, int T, int off) {
         if (!(w = W(L.up, &Q.up, hd)) || launch_gemm_bf16(m->pf_u, m->pf_xn, w, nullptr, T, I, hd, s)) return 1;
         if (launch_silu_mul(m->pf_g, m->pf_g, m->pf_u, (int64_t)T * I, s)) return 1;
         if (!(w = W(L.down, &Q.down, I)) || launch_gemm_bf16_ex(h, m->pf_g, w, nullptr, h2, T, hd, I, s)) return 1;
+        if (enc && next_tap < enc->n_taps && enc->taps[next_tap] == l) {   // raw hidden state, no final norm (:417-420)
+            copy_rows_strided_kernel<<<1024, 256, 0, s>>>(enc->out + (size_t)next_tap * hd, (int64_t)enc->n_taps * hd, h, hd, T, hd / 8);
+            OMX_LAUNCH_CHECK();
+            ++next_tap;
+        }
     }
     return 0;
 }
@@ -865,6 +898,37 @@ int omx_qwen3_set_sampler(omx_qwen3 m, float temperature, uint64_t seed) {
         m->eager = false;
         m->temperature = temperature;
     }
+    return 0;
+}
+
+int omx_qwen3_encode(omx_qwen3 m, const uint32_t* ids, int n, const uint8_t* attention_mask, const int* tap_layers, int n_taps,
+                     void* out_dev) {
+    OMX_REQUIRE(m && ids && tap_layers && out_dev, "omx_qwen3_encode: null argument");
+    OMX_REQUIRE(n >= 1 && n <= m->cap, "omx_qwen3_encode: %d tokens exceed max_context %d", n, m->cap);
+    OMX_REQUIRE(n_taps >= 1 && n_taps <= 16, "omx_qwen3_encode: %d taps (1..16)", n_taps);
+    OMX_REQUIRE(m->cfg.tp_size == 1 && !m->allreduce, "omx_qwen3_encode: single-GPU only");
+    for (int i = 0; i < n_taps; ++i)
+        OMX_REQUIRE(tap_layers[i] >= 0 && tap_layers[i] < m->cfg.num_hidden_layers && (i == 0 || tap_layers[i] > tap_layers[i - 1]),
+                    "omx_qwen3_encode: tap layers must be ascending and < %d", m->cfg.num_hidden_layers);
+    if (resolve_weights(m)) return 1;
+    hipStream_t s = m->stream;
+    OMX_HIP_CHECK(hipMemcpyAsync(m->prompt_dev, ids, (size_t)n * 4, hipMemcpyHostToDevice, s));
+    bf16_t* mask = nullptr;
+    uint8_t* am = nullptr;
+    if (attention_mask) {
+        OMX_HIP_CHECK(hipMalloc((void**)&mask, (size_t)n * n * 2));
+        OMX_HIP_CHECK(hipMalloc((void**)&am, (size_t)n));
+        OMX_HIP_CHECK(hipMemcpyAsync(am, attention_mask, (size_t)n, hipMemcpyHostToDevice, s));
+        encoder_mask_kernel<<<512, 256, 0, s>>>(mask, am, n);
+    }
+    const EncodeOpts enc = {tap_layers, n_taps, (bf16_t*)out_dev, mask};
+    OMX_HIP_CHECK(hipEventRecord(m->ev0, s));
+    const int rc = prefill_prefix_batched(m, n, 0, &enc);
+    OMX_HIP_CHECK(hipEventRecord(m->ev1, s));
+    OMX_HIP_CHECK(hipStreamSynchronize(s));
+    if (mask) { (void)hipFree(mask); (void)hipFree(am); }
+    if (rc) return 1;
+    OMX_HIP_CHECK(hipEventElapsedTime(&m->last_prefill_ms, m->ev0, m->ev1));
     return 0;
 }
 

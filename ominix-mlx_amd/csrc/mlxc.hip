@@ -1017,6 +1017,15 @@ int mlx_random_gumbel(mlx_array* res, const int* shape, size_t shape_num, mlx_dt
     if (omx_random_gumbel((float*)r->ptr(), k.ptr, (int64_t)r->size(), g_stream)) { delete r; return 1; }
     return assign(res, r);
 }
+int mlx_random_normal(mlx_array* res, const int* shape, size_t shape_num, mlx_dtype dtype, float loc, float scale, const mlx_array key,
+                      const mlx_stream) {
+    OMX_REQUIRE(dtype == MLX_FLOAT32, "mlx_random_normal: float32 only");
+    KeyArg k;
+    if (k.init(key, "mlx_random_normal")) return 1;
+    NEW_OR_FAIL(r, std::vector<int>(shape, shape + shape_num), MLX_FLOAT32);
+    if (omx_random_normal((float*)r->ptr(), k.ptr, (int64_t)r->size(), loc, scale, g_stream)) { delete r; return 1; }
+    return assign(res, r);
+}
 static int categorical_impl(mlx_array* res, const mlx_array logits, int axis, int num_samples, bool keep_samples_dim,
                             const mlx_array key, const char* name) {
     REQ_ARR(logits, name);

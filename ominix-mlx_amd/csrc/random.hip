@@ -36,12 +36,21 @@ __global__ void bits_kernel(uint32_t* __restrict__ out, const uint32_t* __restri
     }
 }
 
-template <bool GUMBEL>
+template <int KIND>   // 0 uniform(lo, lo + range), 1 gumbel, 2 normal * range + lo
 __global__ void uniform_kernel(float* __restrict__ out, const uint32_t* __restrict__ key, uint64_t n, float lo, float range) {
     const uint32_t k0 = key[0], k1 = key[1];
     for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
         const uint32_t w = random_word(k0, k1, i, n);
-        out[i] = GUMBEL ? gumbel_from_word(w) : lo + range * unit_from_word(w);
+        if (KIND == 1) {
+            out[i] = gumbel_from_word(w);
+        } else if (KIND == 2) {
+            float z = normal_from_word(w);
+            if (range != 1.0f) z = z * range;
+            if (lo != 0.0f) z = z + lo;
+            out[i] = z;
+        } else {
+            out[i] = lo + range * unit_from_word(w);
+        }
     }
 }
 
@@ -160,7 +169,7 @@ int omx_random_uniform(float* out, const uint32_t* key, int64_t n, float lo, flo
     OMX_REQUIRE(n >= 0 && n <= 0x1FFFFFFFELL, "omx_random_uniform: %lld samples exceed the counter space of one key", (long long)n);
     if (n == 0) return 0;
     const unsigned blocks = (unsigned)std::min<int64_t>((n + 255) / 256, 65535);
-    omx::uniform_kernel<false><<<blocks, 256, 0, (hipStream_t)stream>>>(out, key, (uint64_t)n, lo, hi - lo);
+    omx::uniform_kernel<0><<<blocks, 256, 0, (hipStream_t)stream>>>(out, key, (uint64_t)n, lo, hi - lo);
     OMX_LAUNCH_CHECK();
     return 0;
 }
@@ -170,7 +179,17 @@ int omx_random_gumbel(float* out, const uint32_t* key, int64_t n, omx_stream str
     OMX_REQUIRE(n >= 0 && n <= 0x1FFFFFFFELL, "omx_random_gumbel: %lld samples exceed the counter space of one key", (long long)n);
     if (n == 0) return 0;
     const unsigned blocks = (unsigned)std::min<int64_t>((n + 255) / 256, 65535);
-    omx::uniform_kernel<true><<<blocks, 256, 0, (hipStream_t)stream>>>(out, key, (uint64_t)n, 0.f, 1.f);
+    omx::uniform_kernel<1><<<blocks, 256, 0, (hipStream_t)stream>>>(out, key, (uint64_t)n, 0.f, 1.f);
+    OMX_LAUNCH_CHECK();
+    return 0;
+}
+
+int omx_random_normal(float* out, const uint32_t* key, int64_t n, float loc, float scale, omx_stream stream) {
+    OMX_REQUIRE(out && key, "omx_random_normal: null tensor");
+    OMX_REQUIRE(n >= 0 && n <= 0x1FFFFFFFELL, "omx_random_normal: %lld samples exceed the counter space of one key", (long long)n);
+    if (n == 0) return 0;
+    const unsigned blocks = (unsigned)std::min<int64_t>((n + 255) / 256, 65535);
+    omx::uniform_kernel<2><<<blocks, 256, 0, (hipStream_t)stream>>>(out, key, (uint64_t)n, loc, scale);
     OMX_LAUNCH_CHECK();
     return 0;
 }

@@ -54,6 +54,43 @@ __device__ __forceinline__ float gumbel_from_word(uint32_t w) {
     return -(float)log((double)(-l1));
 }
 
+// float32 erfinv, the Giles / Juffa single-precision polynomial MLX evaluates (oracle/mlx_rng.py:erfinv32)
+__device__ __forceinline__ float erfinv32(float a) {
+    float t = __builtin_fmaf(a, 0.0f - a, 1.0f);
+    t = (float)log((double)t);
+    float p;
+    if (fabsf(t) > 6.125f) {
+        p = 3.03697567e-10f;
+        p = __builtin_fmaf(p, t, 2.93243101e-8f);
+        p = __builtin_fmaf(p, t, 1.22150334e-6f);
+        p = __builtin_fmaf(p, t, 2.84108955e-5f);
+        p = __builtin_fmaf(p, t, 3.93552968e-4f);
+        p = __builtin_fmaf(p, t, 3.02698812e-3f);
+        p = __builtin_fmaf(p, t, 4.83185798e-3f);
+        p = __builtin_fmaf(p, t, -2.64646143e-1f);
+        p = __builtin_fmaf(p, t, 8.40016484e-1f);
+    } else {
+        p = 5.43877832e-9f;
+        p = __builtin_fmaf(p, t, 1.43285448e-7f);
+        p = __builtin_fmaf(p, t, 1.22774793e-6f);
+        p = __builtin_fmaf(p, t, 1.12963626e-7f);
+        p = __builtin_fmaf(p, t, -5.61530760e-5f);
+        p = __builtin_fmaf(p, t, -1.47697632e-4f);
+        p = __builtin_fmaf(p, t, 2.31468678e-3f);
+        p = __builtin_fmaf(p, t, 1.15392581e-2f);
+        p = __builtin_fmaf(p, t, -2.32015476e-1f);
+        p = __builtin_fmaf(p, t, 8.86226892e-1f);
+    }
+    return a * p;
+}
+
+// normal(0, 1): sqrt(2) * erfinv(uniform(nextafter(-1, 0), 1))
+__device__ __forceinline__ float normal_from_word(uint32_t w) {
+    const float lo = -0.99999994f;
+    const float u = lo + (1.0f - lo) * unit_from_word(w);
+    return 1.41421354f * erfinv32(u);
+}
+
 // orderable (value, first-index-wins) key, same packing as the greedy sampler
 __device__ __forceinline__ unsigned long long sample_key(float v, uint32_t idx) {
     uint32_t u = __float_as_uint(v);

@@ -32,6 +32,7 @@ ENGINE_SIGNATURES = {
     "omx_qwen3_synth_weights": (c_int, [c_void_p, c_uint32]),
     "omx_qwen3_set_comm": (c_int, [c_void_p, c_void_p, c_void_p]),
     "omx_qwen3_set_sampler": (c_int, [c_void_p, ctypes.c_float, ctypes.c_uint64]),
+    "omx_qwen3_encode": (c_int, [c_void_p, ctypes.POINTER(c_uint32), c_int, c_void_p, ctypes.POINTER(c_int), c_int, c_void_p]),
     "omx_qwen3_reset": (c_int, [c_void_p]),
     "omx_qwen3_offset": (c_int, [c_void_p, ctypes.POINTER(c_int)]),
     "omx_qwen3_prefill": (c_int, [c_void_p, ctypes.POINTER(c_uint32), c_int, ctypes.POINTER(c_uint32)]),
@@ -117,6 +118,22 @@ class Model:
 
     def set_comm(self, comm_ptr: int, allreduce_fn_ptr: int) -> None:
         check(lib.omx_qwen3_set_comm(self._h, comm_ptr, allreduce_fn_ptr))
+
+    def encode(self, input_ids, attention_mask=None, extract_layers=(8, 17, 26)):
+        """Qwen3TextEncoder::encode (flux-klein-mlx/src/qwen3_encoder.rs:403-455): hidden states after the tapped
+        layers (0-indexed, raw, no final norm) concatenated on the last axis -> device Tensor [n, len(taps)*hidden]."""
+        from .ops import Tensor
+        ids = np.ascontiguousarray(np.asarray(input_ids, dtype=np.uint32).ravel())
+        taps = (c_int * len(extract_layers))(*[int(t) for t in extract_layers])
+        out = Tensor((ids.size, len(extract_layers) * self.cfg.hidden_size), "bf16")
+        am = None
+        if attention_mask is not None:
+            am = np.ascontiguousarray(np.asarray(attention_mask).ravel() != 0, dtype=np.uint8)
+            if am.size != ids.size:
+                raise OmxError("encode: attention_mask and input_ids differ in length")
+        check(lib.omx_qwen3_encode(self._h, ids.ctypes.data_as(ctypes.POINTER(c_uint32)), ids.size,
+                                   am.ctypes.data if am is not None else None, taps, len(extract_layers), out.ptr))
+        return out
 
     def set_sampler(self, temperature: float, seed: int = 0) -> None:
         """DefaultSampler (mlx-rs-core/src/sampler.rs:9-18): 0 = greedy, otherwise categorical(logits / temperature)

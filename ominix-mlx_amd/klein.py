@@ -25,6 +25,7 @@ KLEIN_SIGNATURES = {
     "omx_klein_synth_weights": (c_int, [c_void_p, c_uint32]),
     "omx_klein_set_comm": (c_int, [c_void_p, c_void_p, c_void_p]),
     "omx_klein_forward_with_rope": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p]),
+    "omx_klein_euler_step": (c_int, [c_void_p, c_void_p, c_float, c_void_p, ctypes.c_int64, c_void_p]),
     "omx_klein_last_ms": (c_int, [c_void_p, ctypes.POINTER(c_float)]),
     "omx_klein_debug_read": (c_int, [c_void_p, ctypes.c_char_p, c_void_p, c_size_t]),
 }

@@ -131,6 +131,7 @@ SIGNATURES = {
     "mlx_random_bits": (c_int, [P_ARR, P_INT, c_size_t, c_int, mlx_array, mlx_stream]),
     "mlx_random_uniform": (c_int, [P_ARR, mlx_array, mlx_array, P_INT, c_size_t, c_int, mlx_array, mlx_stream]),
     "mlx_random_gumbel": (c_int, [P_ARR, P_INT, c_size_t, c_int, mlx_array, mlx_stream]),
+    "mlx_random_normal": (c_int, [P_ARR, P_INT, c_size_t, c_int, c_float, c_float, mlx_array, mlx_stream]),
     "mlx_random_categorical": (c_int, [P_ARR, mlx_array, c_int, mlx_array, mlx_stream]),
     "mlx_random_categorical_num_samples": (c_int, [P_ARR, mlx_array, c_int, c_int, mlx_array, mlx_stream]),
     "mlx_random_categorical_shape": (c_int, [P_ARR, mlx_array, c_int, P_INT, c_size_t, mlx_array, mlx_stream]),
@@ -336,6 +337,11 @@ def random_uniform(low, high, shape, key: Optional[Array] = None, dtype=FLOAT32)
 def random_gumbel(shape, key: Optional[Array] = None, dtype=FLOAT32):
     s, n = _ints(shape)
     return Array.op(lib.mlx_random_gumbel, s, n, dtype, _h(key), default_stream())
+
+
+def random_normal(shape, key: Optional[Array] = None, loc: float = 0.0, scale: float = 1.0, dtype=FLOAT32):
+    s, n = _ints(shape)
+    return Array.op(lib.mlx_random_normal, s, n, dtype, float(loc), float(scale), _h(key), default_stream())
 
 
 def random_categorical(logits: Array, axis: int = -1, num_samples: Optional[int] = None, key: Optional[Array] = None):

@@ -240,6 +240,13 @@ def argmax(logits: Tensor) -> Tensor:
     return out
 
 
+def cast(x: Tensor, dtype) -> Tensor:
+    """mlx_rs as_dtype between bf16 / f16 / f32 (one rounding)."""
+    out = Tensor(x.shape, dtype)
+    check(lib.omx_cast(out.ptr, out.dtype, x.ptr, x.dtype, x.size, None))
+    return out
+
+
 def random_key(seed: int) -> Tensor:
     """mlx_rs::random::key (random.rs:98-100): [2] u32 = (seed >> 32, seed & 0xffffffff)."""
     k = Tensor((2,), UINT32)
@@ -271,6 +278,13 @@ def random_gumbel(key: Tensor, shape) -> Tensor:
     """mlx_rs::random::gumbel::<f32> (random.rs:397-414)."""
     out = Tensor(tuple(shape), FLOAT32)
     check(lib.omx_random_gumbel(out.ptr, key.ptr, out.size, None))
+    return out
+
+
+def random_normal(key: Tensor, shape, loc: float = 0.0, scale: float = 1.0) -> Tensor:
+    """mlx_rs::random::normal::<f32> (random.rs:186-212)."""
+    out = Tensor(tuple(shape), FLOAT32)
+    check(lib.omx_random_normal(out.ptr, key.ptr, out.size, float(loc), float(scale), None))
     return out
 
 

@@ -144,3 +144,41 @@ class RandomState:
         k0, k1 = split(self.state, 2)
         self.state = k0
         return k1
+
+
+_ERFINV_TAIL = (3.03697567e-10, 2.93243101e-8, 1.22150334e-6, 2.84108955e-5, 3.93552968e-4, 3.02698812e-3, 4.83185798e-3,
+                -2.64646143e-1, 8.40016484e-1)
+_ERFINV_CORE = (5.43877832e-9, 1.43285448e-7, 1.22774793e-6, 1.12963626e-7, -5.61530760e-5, -1.47697632e-4, 2.31468678e-3,
+                1.15392581e-2, -2.32015476e-1, 8.86226892e-1)
+
+
+def erfinv32(a: np.ndarray) -> np.ndarray:
+    """float32 inverse error function: the single-precision polynomial of M. Giles as published by N. Juffa (two
+    branches on t = log(1 - a^2), Horner with fused multiply-adds, <= 2.4 ulp) -- the form MLX v0.30.1 evaluates
+    for `erfinv`.  MLX core is not vendored in the reference, so this is pinned by the reference's `test_normal` KAT
+    (random.rs:582-586) and by scipy.special.erfinv to 3 ulp (tests/test_oracle_kats.py)."""
+    a = np.asarray(a, np.float32)
+    a64 = a.astype(np.float64)
+    t = (a64 * (0.0 - a64) + 1.0).astype(np.float32)      # fmaf(a, -a, 1): one rounding
+    t = _log32(t)
+
+    def horner(coef):
+        p = np.full(a.shape, np.float32(coef[0]), np.float32)
+        for c in coef[1:]:
+            p = (p.astype(np.float64) * t.astype(np.float64) + np.float64(np.float32(c))).astype(np.float32)   # fmaf
+        return p
+    with np.errstate(invalid="ignore", over="ignore"):
+        p = np.where(np.abs(t) > np.float32(6.125), horner(_ERFINV_TAIL), horner(_ERFINV_CORE))
+    return (a * p).astype(np.float32)
+
+
+def normal(shape, k=None, loc: float = 0.0, scale: float = 1.0) -> np.ndarray:
+    """mlx-rs/src/random.rs:186-212 (`normal_device` -> mlx_random_normal): sqrt(2) * erfinv(uniform(nextafter(-1, 0), 1)),
+    float32; then * scale + loc when given.  KAT: random.rs:582-586 (key 0 -> -0.20)."""
+    u = uniform(np.nextafter(np.float32(-1.0), np.float32(0.0)), 1.0, shape, k)
+    z = (np.float32(np.sqrt(2.0)) * erfinv32(u)).astype(np.float32)
+    if scale != 1.0:
+        z = (z * np.float32(scale)).astype(np.float32)
+    if loc != 0.0:
+        z = (z + np.float32(loc)).astype(np.float32)
+    return z

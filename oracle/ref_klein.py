@@ -233,3 +233,79 @@ class KleinOracle:
 def euler_step(latent, v, t_curr: float, t_next: float):
     """generate_klein.rs:441-443 / sampler.rs step: latent += (t_next - t_curr) * v."""
     return latent + (t_next - t_curr) * v
+
+
+# --------------------------------------------------------------------------
+# 8f rank 3: the sampling loop around the DiT (test infrastructure, like everything in oracle/)
+#   flux-klein-mlx/src/sampler.rs:104-186, 291-301; examples/generate_klein.rs:456-468, 558-604
+# --------------------------------------------------------------------------
+_f = np.float32
+
+
+def compute_empirical_mu(image_seq_len: int, num_steps: int):
+    """generate_klein.rs:560-577 (f32 arithmetic, one rounding per operation)."""
+    a1, b1, a2, b2 = _f(8.73809524e-05), _f(1.89833333), _f(0.00016927), _f(0.45666666)
+    n = _f(image_seq_len)
+    if image_seq_len > 4300:
+        return a2 * n + b2
+    m_200 = a2 * n + b2
+    m_10 = a1 * n + b1
+    a = (m_200 - m_10) / _f(190.0)
+    b = m_200 - _f(200.0) * a
+    return a * _f(num_steps) + b
+
+
+def generalized_time_snr_shift(t, mu, sigma=1.0):
+    """generate_klein.rs:579-588."""
+    t, mu, sigma = _f(t), _f(mu), _f(sigma)
+    if t <= 0.0:
+        return _f(0.0)
+    if t >= 1.0:
+        return _f(1.0)
+    return np.exp(mu) / (np.exp(mu) + np.power(_f(1.0) / t - _f(1.0), sigma))
+
+
+def official_schedule(num_steps: int, image_seq_len: int):
+    """sampler.rs:291-301 / generate_klein.rs:591-604."""
+    mu = compute_empirical_mu(image_seq_len, num_steps)
+    return [generalized_time_snr_shift(_f(1.0) - _f(i) / _f(num_steps), mu, 1.0) for i in range(num_steps + 1)]
+
+
+def sampler_timesteps(steps: int, is_schnell: bool, shift: float = 1.15):
+    """sampler.rs:104-132."""
+    out = []
+    for i in range(steps + 1):
+        t = _f(1.0) - _f(i) / _f(steps)
+        if not is_schnell:
+            e = np.exp(_f(shift))
+            t = e * t / (_f(1.0) + (e - _f(1.0)) * t)
+        out.append(_f(t))
+    return out
+
+
+def add_noise(data, noise, t):
+    """sampler.rs:151-164: x_t = t * noise + (1 - t) * data, t broadcast over [batch, 1, 1]."""
+    t = np.asarray(t, np.float32).reshape(-1, 1, 1)
+    return t * np.asarray(noise, np.float32) + (_f(1.0) - t) * np.asarray(data, np.float32)
+
+
+def sampler_step(x_t, v_pred, t: float, t_prev: float):
+    """sampler.rs:174-186."""
+    return np.asarray(x_t, np.float32) + (_f(t_prev) - _f(t)) * np.asarray(v_pred, np.float32)
+
+
+def unpack_latents(latent, patch_h: int, patch_w: int, z: int = 32, p: int = 2):
+    """generate_klein.rs:462-468: reshape [ph, pw, z, p, p] -> transpose (0, 1, 4, 2, 5, 3) of the batched form."""
+    x = np.asarray(latent).reshape(1, patch_h, patch_w, z, p, p).transpose(0, 1, 4, 2, 5, 3)
+    return x.reshape(patch_h * p, patch_w * p, z)
+
+
+def denoise(oracle: "KleinOracle", txt_embed, patch_h: int, patch_w: int, num_steps: int, noise):
+    """generate_klein.rs:412-446 from a given prior sample `noise` [seq, in_channels] float32."""
+    cos, sin = compute_rope(np.concatenate([create_txt_ids(txt_embed.shape[0]), create_img_ids(patch_h, patch_w)], 0))
+    ts = official_schedule(num_steps, patch_h * patch_w)
+    latent = np.asarray(noise, np.float32)
+    for i in range(num_steps):
+        v = oracle.forward_with_rope(latent, txt_embed, float(ts[i] * _f(1000.0)), cos, sin)
+        latent = euler_step(latent, np.asarray(v, np.float32), ts[i], ts[i + 1]).astype(np.float32)
+    return latent

@@ -192,6 +192,26 @@ class Qwen3Oracle:
         h = rc.rms_norm(h, self.w["model.norm.weight"], cfg.rms_norm_eps, self.dt)
         return self.lin(h, "model.embed_tokens" if cfg.tie_word_embeddings else "lm_head")
 
+    # flux-klein-mlx/src/qwen3_encoder.rs:141-224 (attention under causal AND padding mask, additive -1e9 in the
+    # activation dtype), :403-455 (`forward_with_hidden_states`, `encode`): raw hidden states after the tapped layers,
+    # concatenated on the last axis.  The blocks are the decoder's (q/k norm, RoPE offset 0, SwiGLU MLP); no KV cache.
+    def encode(self, input_ids, attention_mask=None, extract_layers=(8, 17, 26)) -> np.ndarray:
+        ids = np.asarray(input_ids).reshape(1, -1)
+        T = ids.shape[1]
+        h = self.w["model.embed_tokens.weight"][ids]
+        mask = None
+        if attention_mask is not None:
+            am = np.asarray(attention_mask).reshape(-1) != 0
+            keep = (np.arange(T)[None, :] <= np.arange(T)[:, None]) & am[None, :]
+            neg = rc.rnd(np.float32(-1e9), self.dt)
+            mask = ((np.float32(1.0) - keep.astype(np.float32)) * neg).astype(np.float32)[None, None]
+        taps = []
+        for i in range(max(extract_layers) + 1):
+            h = self.block(i, h, mask, rc.KVCache())
+            if i in extract_layers:
+                taps.append(h)
+        return np.concatenate(taps, axis=-1)[0]
+
     # model.rs:804-843 (yield order == plain sequential decoding); temp / seed: model.rs:733-741, 785, 815 with the
     # global RandomState of mlx-rs/src/random.rs:21-41 seeded by `random::seed(seed)` (one split per sampled token)
     def generate(self, prompt: np.ndarray, n_new: int, caches: Optional[List] = None, return_logits: bool = False,

@@ -315,6 +315,14 @@ int omx_mel_frontend_frames(omx_mel_frontend f, int64_t n_samples, int* n_frames
 int omx_mel_frontend_forward(omx_mel_frontend f, const float* audio, int64_t n_samples, float* feats, float* logmel_out,
                              float* power_out, omx_stream stream);
 
+/* sibling frontend: WhisperFeatureExtractor-compatible log-mel, qwen3-asr-mlx/src/audio.rs:24-128
+ * (`MelFrontend::{new, compute_mel_spectrogram}`, defaults 16 kHz / 128 mels / n_fft 400 / hop 160): periodic Hann ->
+ * 400-pt DFT power -> Slaney filters -> log10(max(., 1e-10)) -> max(., global max - 8) -> (x + 4) / 4.
+ * audio: device f32 [n_samples]; out: device f32 [n_mels, n_frames], n_frames = 1 + (n_samples - n_fft) / hop.      */
+int omx_whisper_mel_create(omx_mel_frontend* out, int sample_rate, int n_mels, int n_fft, int hop_length);
+int omx_whisper_mel_frames(omx_mel_frontend f, int64_t n_samples, int* n_frames);
+int omx_whisper_mel_forward(omx_mel_frontend f, const float* audio, int64_t n_samples, float* out, omx_stream stream);
+
 /* =====================================================================================
  * a13: Paraformer body pieces (funasr-mlx/src/paraformer.rs).
  *   omx_sanm_encoder_layer  SanmEncoderLayer::forward :618-634 = LayerNorm(1e-5) -> SanmAttention (:496-532:

@@ -25,6 +25,9 @@ AUDIO_SIGNATURES = {
     "omx_mel_frontend_set_cmvn": (c_int, [c_void_p, c_void_p, c_void_p, c_int]),
     "omx_mel_frontend_frames": (c_int, [c_void_p, c_int64, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
     "omx_mel_frontend_forward": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "omx_whisper_mel_create": (c_int, [ctypes.POINTER(c_void_p), c_int, c_int, c_int, c_int]),
+    "omx_whisper_mel_frames": (c_int, [c_void_p, c_int64, ctypes.POINTER(c_int)]),
+    "omx_whisper_mel_forward": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
 }
 for _n, (_r, _a) in AUDIO_SIGNATURES.items():
     _f = getattr(lib, _n)
@@ -65,3 +68,82 @@ class MelFrontend:
         check(lib.omx_mel_frontend_forward(self._h, a.ptr, n, feats.ptr, logmel.ptr if logmel else None,
                                            power.ptr if power else None, None))
         return (feats, logmel, power) if return_intermediates else feats
+
+
+class WhisperMelFrontend:
+    """qwen3-asr-mlx/src/audio.rs:32-128 (`MelFrontend::{new, compute_mel_spectrogram}`): WhisperFeatureExtractor-compatible
+    log-mel, [n_mels, n_frames] float32 on the device."""
+
+    def __init__(self, sample_rate=16000, n_mels=128, n_fft=400, hop_length=160):
+        require_device()
+        self.sample_rate, self.n_mels, self.n_fft, self.hop_length = sample_rate, n_mels, n_fft, hop_length
+        self._h = c_void_p()
+        check(lib.omx_whisper_mel_create(ctypes.byref(self._h), sample_rate, n_mels, n_fft, hop_length))
+
+    def __del__(self):
+        if not sys.is_finalizing() and getattr(self, "_h", None) is not None and self._h.value:
+            lib.omx_mel_frontend_destroy(self._h)
+            self._h = c_void_p()
+
+    def compute_mel_spectrogram(self, samples) -> Tensor:
+        a = samples if isinstance(samples, Tensor) else Tensor.from_numpy(np.asarray(samples, np.float32).ravel(), "f32")
+        nf = c_int()
+        check(lib.omx_whisper_mel_frames(self._h, a.size, ctypes.byref(nf)))
+        out = Tensor((self.n_mels, nf.value), "f32")
+        check(lib.omx_whisper_mel_forward(self._h, a.ptr, a.size, out.ptr, None))
+        return out
+
+
+# ---- WAV container, host side (mlx-rs-core/src/audio.rs:46-163 `load_wav`, :285-326 `save_wav`) ----
+
+def load_wav(path):
+    """-> (mono float32 samples in [-1, 1], sample_rate).  PCM 16 / 24 bit and 32-bit float; unknown chunks are skipped;
+    multi-channel audio is averaged to mono; errors as the reference's ("Not a RIFF file", "Not a WAVE file",
+    "Unsupported bits per sample: N")."""
+    import struct
+    with open(path, "rb") as fh:
+        buf = fh.read()
+    if buf[:4] != b"RIFF":
+        raise ValueError("Not a RIFF file")
+    if buf[8:12] != b"WAVE":
+        raise ValueError("Not a WAVE file")
+    pos, sample_rate, bits, channels, data = 12, 0, 16, 1, b""
+    while pos + 8 <= len(buf):
+        chunk_id = buf[pos:pos + 4]
+        (size,) = struct.unpack_from("<I", buf, pos + 4)
+        pos += 8
+        if chunk_id == b"fmt ":
+            _fmt, channels, sample_rate, _rate, _align, bits = struct.unpack_from("<HHIIHH", buf, pos)
+        elif chunk_id == b"data":
+            data = buf[pos:pos + size]
+            break
+        pos += size
+    if bits == 16:
+        x = np.frombuffer(data, "<i2", len(data) // 2).astype(np.float32) / np.float32(32768.0)
+    elif bits == 24:
+        b3 = np.frombuffer(data, np.uint8, len(data) // 3 * 3).reshape(-1, 3).astype(np.int32)
+        v = ((b3[:, 0] << 8) | (b3[:, 1] << 16) | (b3[:, 2] << 24)) >> 8          # sign-extending shift, as the Rust
+        x = v.astype(np.float32) / np.float32(8388608.0)
+    elif bits == 32:
+        x = np.frombuffer(data, "<f4", len(data) // 4).astype(np.float32)
+    else:
+        raise ValueError(f"Unsupported bits per sample: {bits}")
+    if channels > 1:
+        x = x[:x.size // channels * channels].reshape(-1, channels)
+        acc = np.zeros(x.shape[0], np.float32)
+        for c in range(channels):
+            acc = acc + x[:, c]
+        x = acc / np.float32(channels)
+    return x.astype(np.float32), int(sample_rate)
+
+
+def save_wav(samples, sample_rate: int, path) -> None:
+    """16-bit PCM mono; sample -> (clamp(x, -1, 1) * 32767) truncated toward zero (`as i16`)."""
+    import struct
+    x = np.clip(np.asarray(samples, np.float32).ravel(), np.float32(-1.0), np.float32(1.0))
+    pcm = np.trunc(x * np.float32(32767.0)).astype("<i2")
+    data = pcm.tobytes()
+    with open(path, "wb") as fh:
+        fh.write(b"RIFF" + struct.pack("<I", 36 + len(data)) + b"WAVE")
+        fh.write(b"fmt " + struct.pack("<IHHIIHH", 16, 1, 1, sample_rate, sample_rate * 2, 2, 16))
+        fh.write(b"data" + struct.pack("<I", len(data)) + data)

@@ -13,6 +13,8 @@
 //   output element.
 #include <math.h>
 
+#include <algorithm>
+
 #include <vector>
 
 #include "common.hpp"
@@ -27,7 +29,8 @@ __global__ __launch_bounds__(256) void mel_power_kernel(const float* __restrict_
                                                         int n_fft, int hop, const float* __restrict__ window,
                                                         const float* __restrict__ tw_cos, const float* __restrict__ tw_sin,
                                                         const float* __restrict__ fbank, int n_mels,
-                                                        float* __restrict__ power_out, float* __restrict__ logmel) {
+                                                        float* __restrict__ power_out, float* __restrict__ logmel,
+                                                        float in_scale, float preemph, int log10_mode) {
     __shared__ float s_frame[kMaxFft], s_cos[kMaxFft], s_sin[kMaxFft], s_pow[kMaxFft / 2 + 1];
     const int frame = blockIdx.x;
     const int n_freqs = n_fft / 2 + 1;
@@ -36,8 +39,10 @@ __global__ __launch_bounds__(256) void mel_power_kernel(const float* __restrict_
         float w = 0.f;
         if (!too_short) {
             const int64_t g = (int64_t)frame * hop + i;
-            const float cur = audio[g] * 32768.0f;
-            const float y = g == 0 ? cur : cur - 0.97f * (audio[g - 1] * 32768.0f);
+            // Paraformer: x*32768 then y[n] = x[n] - 0.97 x[n-1]; Whisper-style: the raw sample (scale 1, no pre-emphasis)
+            const bool in_range = g < n_samples;
+            const float cur = in_range ? audio[g] * in_scale : 0.f;
+            const float y = (g == 0 || preemph == 0.f || !in_range) ? cur : cur - preemph * (audio[g - 1] * in_scale);
             w = y * window[i];
         }
         s_frame[i] = w;
@@ -64,7 +69,7 @@ __global__ __launch_bounds__(256) void mel_power_kernel(const float* __restrict_
         const float* f = fbank + (size_t)m * n_freqs;
         float sum = 0.f;
         for (int k = 0; k < n_freqs; ++k) sum = fmaf(s_pow[k], f[k], sum);
-        logmel[(size_t)frame * n_mels + m] = logf(fmaxf(sum, 1e-10f));
+        logmel[(size_t)frame * n_mels + m] = log10_mode ? log10f(fmaxf(sum, 1e-10f)) : logf(fmaxf(sum, 1e-10f));
     }
 }
 
@@ -92,6 +97,44 @@ __global__ __launch_bounds__(256) void nonfinite_count_kernel(const float* __res
     if (bad) atomicAdd(count, bad);
 }
 
+// Whisper normalisation (qwen3-asr-mlx/src/audio.rs:113-123): max over the whole spectrogram, clip at max - 8,
+// (x + 4) / 4, written [n_mels, n_frames]
+__device__ __forceinline__ unsigned orderable(float v) {
+    const unsigned u = __float_as_uint(v);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__global__ __launch_bounds__(256) void max_kernel(const float* __restrict__ x, int64_t n, unsigned* out) {
+    unsigned best = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const unsigned k = orderable(x[i]);
+        best = k > best ? k : best;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned other = __shfl_xor(best, o, 64);
+        best = other > best ? other : best;
+    }
+    if ((threadIdx.x & 63) == 0) atomicMax(out, best);
+}
+__global__ __launch_bounds__(256) void whisper_norm_kernel(const float* __restrict__ logmel, int n_frames, int n_mels,
+                                                           const unsigned* __restrict__ max_key, float* __restrict__ out) {
+    const unsigned k = *max_key;
+    const float mx = __uint_as_float((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k);
+    const float floor_v = mx - 8.0f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (int64_t)n_frames * n_mels; i += (int64_t)gridDim.x * blockDim.x) {
+        const int m = (int)(i / n_frames), t = (int)(i % n_frames);
+        out[i] = (fmaxf(logmel[(size_t)t * n_mels + m], floor_v) + 4.0f) / 4.0f;
+    }
+}
+
+float hz_to_slaney_mel(float freq) {   // qwen3-asr-mlx/src/audio.rs:229-240
+    const float f_sp = 200.0f / 3.0f, min_log_hz = 1000.0f, min_log_mel = min_log_hz / f_sp, logstep = logf(6.4f) / 27.0f;
+    return freq < min_log_hz ? freq / f_sp : min_log_mel + logf(freq / min_log_hz) / logstep;
+}
+float slaney_mel_to_hz(float mel) {    // :242-253
+    const float f_sp = 200.0f / 3.0f, min_log_hz = 1000.0f, min_log_mel = min_log_hz / f_sp, logstep = logf(6.4f) / 27.0f;
+    return mel < min_log_mel ? f_sp * mel : min_log_hz * expf(logstep * (mel - min_log_mel));
+}
+
 float hz_to_mel(float hz) { return 2595.0f * log10f(1.0f + hz / 700.0f); }
 float mel_to_hz(float mel) { return 700.0f * (powf(10.0f, mel / 2595.0f) - 1.0f); }
 
@@ -104,6 +147,7 @@ struct omx_mel_frontend_ {
     float* logmel = nullptr;
     int logmel_cap = 0;
     unsigned* bad = nullptr;
+    bool whisper = false;     // Slaney filters, periodic Hann, log10 + Whisper normalisation (qwen3-asr-mlx/src/audio.rs)
 };
 
 extern "C" {
@@ -199,11 +243,88 @@ int omx_mel_frontend_forward(omx_mel_frontend f, const float* audio, int64_t n_s
     }
     float* lm = logmel_out ? logmel_out : f->logmel;
     omx::mel_power_kernel<<<nf, 256, 0, s>>>(audio, n_samples, nf, f->cfg.n_fft, f->cfg.hop_length, f->window, f->tw_cos,
-                                             f->tw_sin, f->fbank, f->cfg.n_mels, power_out, lm);
+                                             f->tw_sin, f->fbank, f->cfg.n_mels, power_out, lm, 32768.0f, 0.97f, 0);
     OMX_LAUNCH_CHECK();
     const int64_t total = (int64_t)nl * f->cfg.lfr_m * f->cfg.n_mels;
     omx::lfr_cmvn_kernel<<<(unsigned)((total + 255) / 256), 256, 0, s>>>(lm, nf, f->cfg.n_mels, f->cfg.lfr_m, f->cfg.lfr_n,
                                                                           f->addshift, f->rescale, feats, nl);
+    OMX_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- sibling frontend: the WhisperFeatureExtractor-compatible log-mel of
+//      qwen3-asr-mlx/src/audio.rs:24-128 -- periodic Hann, 400-pt DFT power, 128 Slaney filters with Slaney
+//      normalisation, log10(max(., 1e-10)), clip at (global max - 8), (x + 4) / 4; out [n_mels, n_frames] ----
+int omx_whisper_mel_create(omx_mel_frontend* out, int sample_rate, int n_mels, int n_fft, int hop_length) {
+    OMX_REQUIRE(out, "omx_whisper_mel_create: null argument");
+    OMX_REQUIRE(n_fft >= 2 && n_fft <= omx::kMaxFft && n_mels >= 1 && n_mels <= omx::kMaxMels && hop_length >= 1 && sample_rate > 0,
+                "InvalidConfig: whisper mel n_fft=%d n_mels=%d hop=%d", n_fft, n_mels, hop_length);
+    omx_mel_frontend f = new omx_mel_frontend_();
+    f->cfg = omx_mel_config{sample_rate, n_mels, n_fft, hop_length, 1, 1};
+    f->whisper = true;
+    const int n_freqs = n_fft / 2 + 1;
+    std::vector<float> window(n_fft), c(n_fft), s(n_fft), fb((size_t)n_mels * n_freqs, 0.f);
+    for (int i = 0; i < n_fft; ++i) {
+        window[i] = 0.5f * (1.0f - cosf(2.0f * (float)M_PI * (float)i / (float)n_fft));      // audio.rs:50-54
+        c[i] = (float)cos(2.0 * M_PI * (double)i / (double)n_fft);
+        s[i] = (float)sin(2.0 * M_PI * (double)i / (double)n_fft);
+    }
+    {   // create_whisper_mel_filterbank, audio.rs:260-319
+        const float fmax = (float)sample_rate / 2.0f;
+        const float mel_min = omx::hz_to_slaney_mel(0.0f), mel_max = omx::hz_to_slaney_mel(fmax);
+        std::vector<float> ff(n_mels + 2);
+        for (int i = 0; i < n_mels + 2; ++i) ff[i] = omx::slaney_mel_to_hz(mel_min + (mel_max - mel_min) * (float)i / (float)(n_mels + 1));
+        for (int m = 0; m < n_mels; ++m) {
+            const float lower = ff[m], center = ff[m + 1], upper = ff[m + 2];
+            const float bw = upper - lower;
+            const float norm = bw > 0.f ? 2.0f / bw : 1.0f;
+            for (int k = 0; k < n_freqs; ++k) {
+                const float freq = (float)k * fmax / (float)(n_freqs - 1);
+                float v = 0.f;
+                if (freq >= lower && freq <= center && center > lower) v = (freq - lower) / (center - lower);
+                else if (freq > center && freq <= upper && upper > center) v = (upper - freq) / (upper - center);
+                fb[(size_t)m * n_freqs + k] = v * norm;
+            }
+        }
+    }
+    auto up = [&](float** dst, const std::vector<float>& src) -> int {
+        OMX_HIP_CHECK(hipMalloc((void**)dst, src.size() * 4));
+        OMX_HIP_CHECK(hipMemcpy(*dst, src.data(), src.size() * 4, hipMemcpyHostToDevice));
+        return 0;
+    };
+    if (up(&f->window, window) || up(&f->tw_cos, c) || up(&f->tw_sin, s) || up(&f->fbank, fb)) return 1;
+    *out = f;
+    return 0;
+}
+
+int omx_whisper_mel_frames(omx_mel_frontend f, int64_t n_samples, int* n_frames) {
+    OMX_REQUIRE(f && n_frames && f->whisper, "omx_whisper_mel_frames: not a whisper frontend");
+    OMX_REQUIRE(n_samples > 0, "Audio samples are empty");                                                    // audio.rs:71-75
+    OMX_REQUIRE(n_samples >= f->cfg.n_fft, "Audio too short: %lld ms, need at least %lld ms",                 // audio.rs:81-86
+                (long long)(n_samples * 1000 / f->cfg.sample_rate), (long long)((int64_t)f->cfg.n_fft * 1000 / f->cfg.sample_rate));
+    *n_frames = 1 + (int)((n_samples - f->cfg.n_fft) / f->cfg.hop_length);
+    return 0;
+}
+
+int omx_whisper_mel_forward(omx_mel_frontend f, const float* audio, int64_t n_samples, float* out, omx_stream stream) {
+    OMX_REQUIRE(f && audio && out && f->whisper, "omx_whisper_mel_forward: null argument or not a whisper frontend");
+    int nf = 0;
+    if (omx_whisper_mel_frames(f, n_samples, &nf)) return 1;
+    hipStream_t s = (hipStream_t)stream;
+    if (nf > f->logmel_cap) {
+        if (f->logmel) OMX_HIP_CHECK(hipFree(f->logmel));
+        OMX_HIP_CHECK(hipMalloc((void**)&f->logmel, (size_t)nf * f->cfg.n_mels * 4));
+        f->logmel_cap = nf;
+    }
+    if (!f->bad) OMX_HIP_CHECK(hipMalloc((void**)&f->bad, 4));
+    OMX_HIP_CHECK(hipMemsetAsync(f->bad, 0, 4, s));
+    omx::mel_power_kernel<<<nf, 256, 0, s>>>(audio, n_samples, nf, f->cfg.n_fft, f->cfg.hop_length, f->window, f->tw_cos,
+                                             f->tw_sin, f->fbank, f->cfg.n_mels, nullptr, f->logmel, 1.0f, 0.0f, 1);
+    OMX_LAUNCH_CHECK();
+    const int64_t total = (int64_t)nf * f->cfg.n_mels;
+    const unsigned blocks = (unsigned)std::min<int64_t>((total + 255) / 256, 1024);
+    omx::max_kernel<<<blocks, 256, 0, s>>>(f->logmel, total, f->bad);
+    omx::whisper_norm_kernel<<<blocks, 256, 0, s>>>(f->logmel, nf, f->cfg.n_mels, f->bad, out);
     OMX_LAUNCH_CHECK();
     return 0;
 }

@@ -172,3 +172,126 @@ def stft_power_direct_dft_f32(samples, window, n_fft, hop):
         im = -(s * w[None, :]).sum(axis=1, dtype=F32)
         out[f] = re * re + im * im
     return out
+
+
+# --------------------------------------------------------------------------
+# 8f rank 4 sibling frontend: WhisperFeatureExtractor-compatible log-mel of qwen3-asr-mlx/src/audio.rs
+#   MelFrontend::new :41-66, compute_mel_spectrogram :68-128, Slaney scale :229-253, filterbank :260-319
+# --------------------------------------------------------------------------
+
+def hz_to_slaney_mel(freq):
+    f_sp, min_log_hz = np.float32(200.0 / 3.0), np.float32(1000.0)
+    min_log_mel = min_log_hz / f_sp
+    logstep = np.float32(np.log(np.float32(6.4))) / np.float32(27.0)
+    freq = np.float32(freq)
+    return freq / f_sp if freq < min_log_hz else min_log_mel + np.float32(np.log(freq / min_log_hz)) / logstep
+
+
+def slaney_mel_to_hz(mel):
+    f_sp, min_log_hz = np.float32(200.0 / 3.0), np.float32(1000.0)
+    min_log_mel = min_log_hz / f_sp
+    logstep = np.float32(np.log(np.float32(6.4))) / np.float32(27.0)
+    mel = np.float32(mel)
+    return f_sp * mel if mel < min_log_mel else min_log_hz * np.float32(np.exp(logstep * (mel - min_log_mel)))
+
+
+def whisper_mel_filterbank(sample_rate: int = 16000, n_fft: int = 400, n_mels: int = 128) -> np.ndarray:
+    """[n_mels, n_freqs] float32, Slaney scale + Slaney (2 / bandwidth) normalisation."""
+    n_freqs = n_fft // 2 + 1
+    fmax = np.float32(sample_rate) / np.float32(2.0)
+    mel_min, mel_max = hz_to_slaney_mel(0.0), hz_to_slaney_mel(fmax)
+    ff = [slaney_mel_to_hz(mel_min + (mel_max - mel_min) * np.float32(i) / np.float32(n_mels + 1)) for i in range(n_mels + 2)]
+    fb = np.zeros((n_mels, n_freqs), np.float32)
+    for m in range(n_mels):
+        lower, center, upper = ff[m], ff[m + 1], ff[m + 2]
+        for k in range(n_freqs):
+            freq = np.float32(k) * fmax / np.float32(n_freqs - 1)
+            if lower <= freq <= center and center > lower:
+                fb[m, k] = (freq - lower) / (center - lower)
+            elif center < freq <= upper and upper > center:
+                fb[m, k] = (upper - freq) / (upper - center)
+        bw = upper - lower
+        if bw > 0:
+            fb[m] *= np.float32(2.0) / bw
+    return fb
+
+
+def whisper_log_mel(samples: np.ndarray, sample_rate: int = 16000, n_mels: int = 128, n_fft: int = 400, hop: int = 160) -> np.ndarray:
+    """compute_mel_spectrogram (audio.rs:68-128): [n_mels, n_frames]; DFT in float64 (the reference uses rustfft in f32)."""
+    x = np.asarray(samples, np.float32)
+    if x.size == 0:
+        raise ValueError("Audio samples are empty")
+    if x.size < n_fft:
+        raise ValueError("Audio too short")
+    n_frames = 1 + (x.size - n_fft) // hop
+    window = (np.float32(0.5) * (np.float32(1.0) - np.cos(np.float32(2.0) * np.float32(np.pi) * np.arange(n_fft, dtype=np.float32)
+                                                          / np.float32(n_fft)).astype(np.float32))).astype(np.float32)
+    idx = np.arange(n_fft)[None, :] + hop * np.arange(n_frames)[:, None]
+    frames = (x[idx] * window[None, :]).astype(np.float32)
+    spec = np.fft.rfft(frames.astype(np.float64), axis=1)
+    power = (spec.real ** 2 + spec.imag ** 2)
+    mel = power @ whisper_mel_filterbank(sample_rate, n_fft, n_mels).astype(np.float64).T        # [frames, mels]
+    logm = np.log10(np.maximum(mel, 1e-10))
+    logm = np.maximum(logm, logm.max() - 8.0)
+    return ((logm + 4.0) / 4.0).T.astype(np.float32)
+
+
+# WAV container (mlx-rs-core/src/audio.rs:46-163 load_wav, :285-326 save_wav)
+def wav_bytes(samples, sample_rate: int, bits: int = 16, channels: int = 1, extra_chunk: bool = False) -> bytes:
+    """Test helper: a RIFF/WAVE image (PCM 16/24 or float 32) with an optional unknown chunk before `data`."""
+    import struct
+    x = np.asarray(samples, np.float32).reshape(-1, channels)
+    if bits == 16:
+        body = (np.clip(x, -1, 1) * 32767.0).astype("<i2").tobytes()
+        fmt_tag = 1
+    elif bits == 24:
+        v = (np.clip(x, -1, 1) * 8388607.0).astype("<i4").reshape(-1)
+        body = b"".join(int(s).to_bytes(4, "little", signed=True)[:3] for s in v)
+        fmt_tag = 1
+    else:
+        body = x.astype("<f4").tobytes()
+        fmt_tag = 3
+    fmt = struct.pack("<HHIIHH", fmt_tag, channels, sample_rate, sample_rate * channels * bits // 8, channels * bits // 8, bits)
+    chunks = b"fmt " + struct.pack("<I", 16) + fmt
+    if extra_chunk:
+        chunks += b"LIST" + struct.pack("<I", 6) + b"abcdef"
+    chunks += b"data" + struct.pack("<I", len(body)) + body
+    return b"RIFF" + struct.pack("<I", 4 + len(chunks)) + b"WAVE" + chunks
+
+
+def load_wav_bytes(buf: bytes):
+    """load_wav (audio.rs:46-163): (mono float32 samples, sample_rate)."""
+    import struct
+    if buf[:4] != b"RIFF":
+        raise ValueError("Not a RIFF file")
+    if buf[8:12] != b"WAVE":
+        raise ValueError("Not a WAVE file")
+    pos, sr, bits, ch, data = 12, 0, 16, 1, b""
+    while pos + 8 <= len(buf):
+        cid, size = buf[pos:pos + 4], struct.unpack("<I", buf[pos + 4:pos + 8])[0]
+        pos += 8
+        if cid == b"fmt ":
+            ch, sr = struct.unpack("<H", buf[pos + 2:pos + 4])[0], struct.unpack("<I", buf[pos + 4:pos + 8])[0]
+            bits = struct.unpack("<H", buf[pos + 14:pos + 16])[0]
+        elif cid == b"data":
+            data = buf[pos:pos + size]
+            break
+        pos += size
+    if bits == 16:
+        x = np.frombuffer(data[:len(data) // 2 * 2], "<i2").astype(np.float32) / np.float32(32768.0)
+    elif bits == 24:
+        raw = np.frombuffer(data[:len(data) // 3 * 3], np.uint8).reshape(-1, 3).astype(np.int32)
+        v = (raw[:, 0] | (raw[:, 1] << 8) | (raw[:, 2] << 16))
+        v = np.where(v >= 1 << 23, v - (1 << 24), v)
+        x = v.astype(np.float32) / np.float32(8388608.0)
+    elif bits == 32:
+        x = np.frombuffer(data[:len(data) // 4 * 4], "<f4").astype(np.float32)
+    else:
+        raise ValueError(f"Unsupported bits per sample: {bits}")
+    if ch > 1:
+        x = x[:x.size // ch * ch].reshape(-1, ch)
+        acc = np.zeros(x.shape[0], np.float32)
+        for c in range(ch):                       # iter().sum::<f32>() in channel order, then / channels
+            acc = (acc + x[:, c]).astype(np.float32)
+        x = (acc / np.float32(ch)).astype(np.float32)
+    return x, sr

@@ -242,6 +242,13 @@ int omx_moe_workspace_bytes(int n_tokens, int hidden, int inter, int n_experts, 
 int omx_moe_forward(void* out, const void* x, const void* gate_w, const void* w_gate, const void* w_up,
                     const void* w_down, int n_tokens, int hidden, int inter, int n_experts, int top_k, int mode,
                     int norm_topk_prob, uint32_t* inds_out, void* scores_out, omx_stream stream);
+/* the reference's own Mixtral format (mixtral-mlx/src/model.rs:182-274, QuantizedSwitchLinear -> mlx_gather_qmm x3):
+ * expert stacks as MLX affine-quantised triplets, packed u32 [E, out, in*bits/32], scales / biases [E, out, in/group_size];
+ * router gate bf16.  <= 32 routed slots: expert-selected GEMVs on the packed weights; more: dequantise + grouped GEMM. */
+int omx_moe_forward_q(void* out, const void* x, const void* gate_w, const void* q_gate, const void* s_gate, const void* b_gate,
+                      const void* q_up, const void* s_up, const void* b_up, const void* q_down, const void* s_down,
+                      const void* b_down, int n_tokens, int hidden, int inter, int n_experts, int top_k, int mode,
+                      int norm_topk_prob, int group_size, int bits, uint32_t* inds_out, void* scores_out, omx_stream stream);
 /* The same block as three stages, for an expert-parallel host that exchanges token rows between them
  * (all-to-all dispatch + combine; ominix-mlx_amd/ep.py):
  *   route    x [n, hidden] -> inds [n, k] u32, scores [n, k] (dtype of x)            (model.rs:296-302)

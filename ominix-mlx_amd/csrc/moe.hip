@@ -14,6 +14,7 @@
 // gather_qmm is a SURVEY 8f "next" row).
 #include "gemm.hpp"
 #include "gemv.hpp"
+#include "quant.hpp"
 #include "workspace.hpp"
 
 namespace omx {
@@ -161,11 +162,22 @@ extern "C" int omx_moe_workspace_bytes(int n_tokens, int hidden, int inter, int 
     return 0;
 }
 
-extern "C" int omx_moe_forward(void* out, const void* x, const void* gate_w, const void* w_gate, const void* w_up,
-                               const void* w_down, int n_tokens, int hidden, int inter, int n_experts, int top_k,
-                               int mode, int norm_topk_prob, uint32_t* inds_out, void* scores_out, omx_stream stream) {
+namespace {
+// quantized expert stacks (mixtral-mlx/src/model.rs:182-201 QuantizedSwitchLinear): packed [E, out, in*bits/32] u32,
+// scales / biases [E, out, in/group]
+struct QExperts {
+    omx::QMat gate, up, down;
+    int group, bits;
+};
+omx::bf16_t* g_dq = nullptr;      // dequantised expert stacks for the grouped-GEMM (many tokens) route
+size_t g_dq_cap = 0;
+}  // namespace
+
+static int moe_forward_impl(void* out, const void* x, const void* gate_w, const void* w_gate, const void* w_up,
+                            const void* w_down, const QExperts* q, int n_tokens, int hidden, int inter, int n_experts, int top_k,
+                            int mode, int norm_topk_prob, uint32_t* inds_out, void* scores_out, omx_stream stream) {
     using namespace omx;
-    OMX_REQUIRE(out && x && gate_w && w_gate && w_up && w_down, "omx_moe_forward: null tensor");
+    OMX_REQUIRE(out && x && gate_w && (q || (w_gate && w_up && w_down)), "omx_moe_forward: null tensor");
     OMX_REQUIRE(n_tokens >= 0 && hidden > 0 && inter > 0, "omx_moe_forward: bad shape");
     OMX_REQUIRE(n_experts >= 1 && n_experts <= kMaxExperts && top_k >= 1 && top_k <= kMaxTopK && top_k <= n_experts,
                 "omx_moe_forward: n_experts=%d (max %d), top_k=%d (max %d)", n_experts, kMaxExperts, top_k, kMaxTopK);
@@ -197,6 +209,43 @@ extern "C" int omx_moe_forward(void* out, const void* x, const void* gate_w, con
                                                norm_topk_prob, inds, scores);
     OMX_LAUNCH_CHECK();
     const bool decode = slots <= 32 && hidden % 512 == 0 && inter % 512 == 0;
+    if (decode && q) {
+        // gather_qmm x3 on the PACKED weights (model.rs:262-272 unsorted branch): expert-selected batched quantised GEMVs
+        QGemvArgs a = {};
+        a.m[0] = q->gate; a.m[1] = q->up; a.N = inter; a.K = hidden; a.group = q->group;
+        a.x = (const bf16_t*)x; a.out = gbuf;
+        a.n_batch = slots; a.x_div = top_k; a.w_sel = inds;
+        a.w_estride = (size_t)inter * hidden * q->bits / 32; a.s_estride = (size_t)inter * (hidden / q->group);
+        a.swiglu_single_round = 1;
+        if (launch_qgemv(a, q->bits, PRO_NONE, EPI_SWIGLU, s)) return 1;
+        QGemvArgs d = {};
+        d.m[0] = q->down; d.N = hidden; d.K = inter; d.group = q->group;
+        d.x = gbuf; d.out = ybuf;
+        d.n_batch = slots; d.x_div = 1; d.w_sel = inds;
+        d.w_estride = (size_t)hidden * inter * q->bits / 32; d.s_estride = (size_t)hidden * (inter / q->group);
+        if (launch_qgemv(d, q->bits, PRO_NONE, EPI_STORE, s)) return 1;
+        moe_combine_kernel<<<n_tokens, 256, 0, s>>>((bf16_t*)out, ybuf, scores, nullptr, hidden, top_k);
+        OMX_LAUNCH_CHECK();
+        if (inds_out) OMX_HIP_CHECK(hipMemcpyAsync(inds_out, inds, (size_t)slots * 4, hipMemcpyDeviceToDevice, s));
+        if (scores_out) OMX_HIP_CHECK(hipMemcpyAsync(scores_out, scores, (size_t)slots * 2, hipMemcpyDeviceToDevice, s));
+        return 0;
+    }
+    if (q) {
+        // many tokens: dequantise the three stacks once into a scratch (what MLX's qmm does per tile) and take the
+        // grouped MFMA route on bf16 weights
+        const size_t per = (size_t)n_experts * inter * hidden;
+        if (3 * per > g_dq_cap) {
+            OMX_HIP_CHECK(hipStreamSynchronize(s));
+            if (g_dq) OMX_HIP_CHECK(hipFree(g_dq));
+            OMX_HIP_CHECK(hipMalloc((void**)&g_dq, 3 * per * 2));
+            g_dq_cap = 3 * per;
+        }
+        if (omx_dequantize(g_dq, q->gate.w, q->gate.scales, q->gate.biases, (int64_t)n_experts * inter, hidden, q->group, q->bits, OMX_BFLOAT16, stream) ||
+            omx_dequantize(g_dq + per, q->up.w, q->up.scales, q->up.biases, (int64_t)n_experts * inter, hidden, q->group, q->bits, OMX_BFLOAT16, stream) ||
+            omx_dequantize(g_dq + 2 * per, q->down.w, q->down.scales, q->down.biases, (int64_t)n_experts * hidden, inter, q->group, q->bits, OMX_BFLOAT16, stream))
+            return 1;
+        w_gate = g_dq; w_up = g_dq + per; w_down = g_dq + 2 * per;
+    }
     if (decode) {
         // SwitchGLU without the sort (model.rs:262-272): expert-selected batched GEMVs
         GemvArgs a = {};
@@ -232,6 +281,34 @@ extern "C" int omx_moe_forward(void* out, const void* x, const void* gate_w, con
     if (inds_out) OMX_HIP_CHECK(hipMemcpyAsync(inds_out, inds, (size_t)slots * 4, hipMemcpyDeviceToDevice, s));
     if (scores_out) OMX_HIP_CHECK(hipMemcpyAsync(scores_out, scores, (size_t)slots * 2, hipMemcpyDeviceToDevice, s));
     return 0;
+}
+
+extern "C" int omx_moe_forward(void* out, const void* x, const void* gate_w, const void* w_gate, const void* w_up,
+                               const void* w_down, int n_tokens, int hidden, int inter, int n_experts, int top_k,
+                               int mode, int norm_topk_prob, uint32_t* inds_out, void* scores_out, omx_stream stream) {
+    return moe_forward_impl(out, x, gate_w, w_gate, w_up, w_down, nullptr, n_tokens, hidden, inter, n_experts, top_k, mode,
+                            norm_topk_prob, inds_out, scores_out, stream);
+}
+
+/* The reference's own Mixtral format: 4/8-bit expert stacks through gather_qmm (mixtral-mlx/src/model.rs:182-274).
+ * q_* = packed u32 [E, out, in*bits/32]; s_* / b_* = scales / biases bf16 [E, out, in/group_size].  The router gate is bf16. */
+extern "C" int omx_moe_forward_q(void* out, const void* x, const void* gate_w, const void* q_gate, const void* s_gate,
+                                 const void* b_gate, const void* q_up, const void* s_up, const void* b_up, const void* q_down,
+                                 const void* s_down, const void* b_down, int n_tokens, int hidden, int inter, int n_experts,
+                                 int top_k, int mode, int norm_topk_prob, int group_size, int bits, uint32_t* inds_out,
+                                 void* scores_out, omx_stream stream) {
+    using namespace omx;
+    OMX_REQUIRE(q_gate && s_gate && b_gate && q_up && s_up && b_up && q_down && s_down && b_down, "omx_moe_forward_q: null tensor");
+    OMX_REQUIRE(bits == 4 || bits == 8, "omx_moe_forward_q: bits=%d (4 or 8)", bits);
+    OMX_REQUIRE(group_size == 32 || group_size == 64 || group_size == 128, "omx_moe_forward_q: group_size=%d (32, 64, 128)", group_size);
+    OMX_REQUIRE(hidden % 512 == 0 && inter % 512 == 0, "omx_moe_forward_q: hidden=%d and intermediate=%d must be multiples of 512", hidden, inter);
+    QExperts q;
+    q.gate = QMat{(const uint32_t*)q_gate, (const bf16_t*)s_gate, (const bf16_t*)b_gate, inter};
+    q.up = QMat{(const uint32_t*)q_up, (const bf16_t*)s_up, (const bf16_t*)b_up, inter};
+    q.down = QMat{(const uint32_t*)q_down, (const bf16_t*)s_down, (const bf16_t*)b_down, hidden};
+    q.group = group_size; q.bits = bits;
+    return moe_forward_impl(out, x, gate_w, nullptr, nullptr, nullptr, &q, n_tokens, hidden, inter, n_experts, top_k, mode,
+                            norm_topk_prob, inds_out, scores_out, stream);
 }
 
 /* ---- the three stages of the block as separate entry points: what an expert-parallel host needs between its

@@ -237,8 +237,12 @@ __global__ __launch_bounds__(256) void qgemv_kernel(const QGemvArgs a) {
                     } else if (EPI == EPI_SWIGLU) {
                         // nn::silu(gate) * up, every primitive's result held in bf16 (qwen3-mlx/src/model.rs:264-265)
                         const float g = round_bf16(v0), uu = round_bf16(v1);
-                        const float sg = round_bf16(1.0f / (1.0f + expf(-g)));
-                        out[row] = f32_to_bf16(round_bf16(g * sg) * uu);
+                        if (a.swiglu_single_round) {
+                            out[row] = f32_to_bf16(g / (1.0f + expf(-g)) * uu);   // mlx_rs_core::fused_swiglu(up, gate)
+                        } else {
+                            const float sg = round_bf16(1.0f / (1.0f + expf(-g)));
+                            out[row] = f32_to_bf16(round_bf16(g * sg) * uu);
+                        }
                     } else if (EPI == EPI_ARGMAX) {
                         const bf16_t lb = f32_to_bf16(v0);
                         out[row] = lb;
@@ -334,6 +338,7 @@ int launch_qgemv_w(const QGemvArgs& a, int pro, int epi, hipStream_t s) {
     OMX_QGEMV_CASE(PRO_RMSNORM, EPI_STORE)
     OMX_QGEMV_CASE(PRO_NONE, EPI_RESIDUAL)
     OMX_QGEMV_CASE(PRO_RMSNORM, EPI_SWIGLU)
+    OMX_QGEMV_CASE(PRO_NONE, EPI_SWIGLU)
     OMX_QGEMV_CASE(PRO_RMSNORM, EPI_ARGMAX)
 #undef OMX_QGEMV_CASE
     return set_error("quantized gemv: unsupported prologue/epilogue combination %d/%d", pro, epi);

@@ -26,6 +26,7 @@ struct QGemvArgs {
     int n_batch, x_div;         // batch entry j reads activation row j / x_div
     const uint32_t* w_sel;      // optional [n_batch] expert ids (gather_qmm)
     size_t w_estride, s_estride;    // words / groups between consecutive experts
+    int swiglu_single_round;    // EPI_SWIGLU: fused_swiglu(up, gate) (one rounding, metal_kernels.rs:11-18) instead of nn::silu(g)*u
 };
 
 int launch_qgemv(const QGemvArgs& a, int bits, int pro, int epi, hipStream_t s);

@@ -12,6 +12,7 @@ MOE_SIGNATURES = {
     "omx_moe_workspace_bytes": (c_int, [c_int, c_int, c_int, c_int, c_int, ctypes.POINTER(c_size_t)]),
     "omx_moe_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                 c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "omx_moe_forward_q": (c_int, [c_void_p] * 12 + [c_int] * 9 + [c_void_p, c_void_p, c_void_p]),
 }
 for _n, (_r, _a) in MOE_SIGNATURES.items():
     _f = getattr(lib, _n)
@@ -38,4 +39,28 @@ class SparseMoeBlock:
         check(lib.omx_moe_forward(out.ptr, x.ptr, self.gate_w.ptr, self.w_gate.ptr, self.w_up.ptr, self.w_down.ptr, n,
                                   self.hidden, self.inter, self.E, self.k, self.mode, self.norm,
                                   inds.ptr if inds else None, scores.ptr if scores else None, None))
+        return (out, inds, scores) if return_routing else out
+
+
+class QuantizedSparseMoeBlock:
+    """MixtralSparseMoeBlock with `QuantizedSwitchLinear` experts (mixtral-mlx/src/model.rs:182-313): each of gate / up / down
+    is a (packed u32 [E, out, in*bits/32], scales, biases) triplet of device Tensors; the router gate is bf16 [E, hidden]."""
+
+    def __init__(self, gate_w: Tensor, q_gate, q_up, q_down, num_experts_per_tok: int, group_size: int = 64, bits: int = 4,
+                 mode: str = "mixtral", norm_topk_prob: bool = True):
+        self.gate_w, self.q_gate, self.q_up, self.q_down = gate_w, tuple(q_gate), tuple(q_up), tuple(q_down)
+        self.E, self.hidden = gate_w.shape
+        self.inter = self.q_gate[0].shape[1]
+        self.k, self.group, self.bits = num_experts_per_tok, group_size, bits
+        self.mode = {"mixtral": 0, "qwen3_moe": 1}[mode]
+        self.norm = int(norm_topk_prob)
+
+    def forward(self, x: Tensor, return_routing: bool = False):
+        n = x.size // self.hidden
+        out = Tensor(x.shape, x.dtype)
+        inds = Tensor((n, self.k), UINT32) if return_routing else None
+        scores = Tensor((n, self.k), x.dtype) if return_routing else None
+        ptrs = [t.ptr for trip in (self.q_gate, self.q_up, self.q_down) for t in trip]
+        check(lib.omx_moe_forward_q(out.ptr, x.ptr, self.gate_w.ptr, *ptrs, n, self.hidden, self.inter, self.E, self.k, self.mode,
+                                    self.norm, self.group, self.bits, inds.ptr if inds else None, scores.ptr if scores else None, None))
         return (out, inds, scores) if return_routing else out

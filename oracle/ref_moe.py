@@ -62,6 +62,35 @@ def switch_glu(x, inds, w_gate, w_up, w_down, dt: str = "bf16"):
     return out
 
 
+def quantize_experts(w: np.ndarray, group: int = 64, bits: int = 4):
+    """[E, out, in] -> MLX triplet (packed u32 [E, out, in*bits/32], scales, biases [E, out, in/group]); the on-disk form of
+    `switch_mlp.{gate,up,down}_proj` in the reference's Mixtral checkpoints (mixtral-mlx/src/model.rs:466-548)."""
+    q, s, b = zip(*(rc.quantize(w[e], group, bits) for e in range(w.shape[0])))
+    return np.stack(q), rc.bf16_round(np.stack(s)), rc.bf16_round(np.stack(b))
+
+
+def switch_glu_q(x, inds, qg, qu, qd, group: int, bits: int, dt: str = "bf16"):
+    """SwitchGLU::forward_experts on quantised stacks: gather_qmm x3 + fused_swiglu (model.rs:195-201, 243-274)."""
+    N, k = inds.shape
+    out = np.zeros((N, k, qd[0].shape[1]), np.float32)
+    for n in range(N):
+        for j in range(k):
+            e = int(inds[n, j])
+            g = rc.quantized_matmul(x[n:n + 1], qg[0][e], qg[1][e], qg[2][e], group, bits, dt)
+            u = rc.quantized_matmul(x[n:n + 1], qu[0][e], qu[1][e], qu[2][e], group, bits, dt)
+            act = rc.fused_swiglu(u, g, dt)
+            out[n, j] = rc.quantized_matmul(act, qd[0][e], qd[1][e], qd[2][e], group, bits, dt)[0]
+    return out
+
+
+def moe_block_q(x, gate_w, qg, qu, qd, k: int, group: int = 64, bits: int = 4, dt: str = "bf16"):
+    """MixtralSparseMoeBlock::forward (model.rs:296-308) with quantised experts and a bf16 router."""
+    inds, scores = route_mixtral(x, gate_w, k, dt)
+    y = switch_glu_q(x, inds, qg, qu, qd, group, bits, dt)
+    weighted = rc.rnd(y.astype(np.float64) * scores[..., None].astype(np.float64), dt)
+    return rc.rnd(np.sum(weighted.astype(np.float64), axis=1), dt), inds, scores
+
+
 def moe_block(x, gate_w, w_gate, w_up, w_down, k: int, mode: str = "mixtral", norm_topk_prob: bool = True,
               dt: str = "bf16"):
     """x [N, h] -> [N, h]:  sum_j scores_j * expert_{inds_j}(x)   (model.rs:304-307)."""

@@ -152,3 +152,41 @@ def test_expert_parallel_world1_equals_fused_block(omx):
         got = _ep_loopback(omx, [x], gw, wg, wu, wd, k, "mixtral")
         single, _, _ = _run(omx, x, gw, wg, wu, wd, k, "mixtral")
         np.testing.assert_array_equal(got, single)
+
+
+# ---- the reference's own Mixtral format: quantised expert stacks through gather_qmm (mixtral-mlx/src/model.rs:182-274) ----
+
+@pytest.mark.parametrize("bits,group", [(4, 64), (8, 64), (4, 128)])
+@pytest.mark.parametrize("n_tokens", [1, 5, 70])        # packed-weight GEMVs (<= 32 slots) and dequantise + grouped GEMM
+def test_quantized_moe_block_parity(omx, bits, group, n_tokens):
+    """Tolerance as the bf16 block plus the quantised-GEMV noise floor of tests/test_gpu_quant.py: the oracle accumulates
+    q*scale+bias products in float64, the kernels in float32 in another order."""
+    from ominix_mlx_amd import moe
+    T = omx.ops.Tensor
+    E, h, I, k = 8, 512, 1024, 2
+    gw, wg, wu, wd = _weights(E, h, I, 160)
+    qg, qu, qd = (rm.quantize_experts(w, group, bits) for w in (wg, wu, wd))
+    x = rc.bf16_round(rand((n_tokens, h), 170 + n_tokens))
+    ref = rm.moe_block_q(x, gw, qg, qu, qd, k, group, bits)
+    up = lambda trip: (T.from_numpy(trip[0], "u32"), T.from_numpy(trip[1]), T.from_numpy(trip[2]))
+    blk = moe.QuantizedSparseMoeBlock(T.from_numpy(gw), up(qg), up(qu), up(qd), k, group, bits)
+    out, inds, scores = blk.forward(T.from_numpy(x), return_routing=True)
+    np.testing.assert_array_equal(inds.numpy(), ref[1])
+    assert_bf16_close(scores.numpy(), ref[2], 1, atol=1e-6)
+    assert_bf16_close(out.numpy(), ref[0], 2, atol=2.0 ** -6 * np.abs(ref[0]).max())
+    # the quantised block is the bf16 block on the dequantised stacks, to the same tolerance
+    deq = [np.stack([rc.dequantize(t[0][e], t[1][e], t[2][e], group, bits, "bf16") for e in range(E)]) for t in (qg, qu, qd)]
+    dense = rm.moe_block(x, gw, deq[0], deq[1], deq[2], k, "mixtral")
+    assert_bf16_close(out.numpy(), dense[0], 2, atol=2.0 ** -6 * np.abs(dense[0]).max())
+
+
+def test_quantized_moe_rejects_bad_format(omx):
+    from ominix_mlx_amd import moe
+    T = omx.ops.Tensor
+    z = lambda *s: T.from_numpy(np.zeros(s, np.float32))
+    zq = lambda *s: T.from_numpy(np.zeros(s, np.uint32), "u32")
+    trip = lambda o, i: (zq(2, o, i // 8), z(2, o, i // 64), z(2, o, i // 64))
+    with pytest.raises(omx.OmxError, match="bits"):
+        moe.QuantizedSparseMoeBlock(z(2, 512), trip(512, 512), trip(512, 512), trip(512, 512), 1, 64, 3).forward(z(1, 512))
+    with pytest.raises(omx.OmxError, match="group_size"):
+        moe.QuantizedSparseMoeBlock(z(2, 512), trip(512, 512), trip(512, 512), trip(512, 512), 1, 48, 4).forward(z(1, 512))

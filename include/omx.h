@@ -286,6 +286,25 @@ int omx_klein_set_comm(omx_klein m, void* comm, void* allreduce_fn);
  * text rows first (compute_rope_freqs, klein_model.rs:53-110); out [s_img, in_channels] device bf16.      */
 int omx_klein_forward_with_rope(omx_klein m, void* out, const void* latent, const void* txt_embed, int s_img, int s_txt,
                                 float timestep, const float* rope_cos, const float* rope_sin);
+/* ---- FLUX VAE decoder: flux-klein-mlx/src/autoencoder.rs Decoder::forward :375-412 with
+ *      ResnetBlock :139-157, AttnBlock :195-232, GroupNorm(32, eps 1e-5, pytorch compatible).  NHWC bf16.
+ *      Weights (bf16, device) under the names weights.rs:164-217 produces: conv_in.{weight,bias},
+ *      mid_block_resnets_{0,1}.{norm1,conv1,norm2,conv2}.*, mid_block_attentions_0.{group_norm,to_q,to_k,to_v,to_out}.*,
+ *      up_blocks.{b}.resnets.{j}.{norm1,conv1,norm2,conv2,conv_shortcut}.*, up_blocks.{b}.upsamplers_0_conv.*,
+ *      conv_norm_out.*, conv_out.*, post_quant_conv.*; Conv2d weight [out, kH, kW, in], Linear [out, in].
+ *      latent [h, w, z_channels] -> image [h*2^(n_mult-1), w*2^(n_mult-1), out_ch] in [-1, 1].                  ---- */
+typedef struct omx_vae_config_ {     /* AutoEncoderConfig, autoencoder.rs:22-81 (flux2(): ch 128, mult 1,2,4,4, z 32) */
+    int ch, ch_mult[8], n_mult, num_res_blocks, z_channels, out_ch;
+    float scale_factor, shift_factor;
+} omx_vae_config;
+typedef struct omx_vae_decoder_* omx_vae_decoder;
+int omx_vae_decoder_create(omx_vae_decoder* out, const omx_vae_config* cfg);
+int omx_vae_decoder_destroy(omx_vae_decoder m);
+int omx_vae_decoder_set_weight(omx_vae_decoder m, const char* name, const void* ptr);
+int omx_vae_decoder_out_shape(omx_vae_decoder m, int h, int w, int* out_h, int* out_w, int* out_c);
+int omx_vae_decode(omx_vae_decoder m, void* image, const void* latent, int h, int w);
+int omx_vae_decoder_last_ms(omx_vae_decoder m, float* ms);
+
 /* one Euler step of the rectified-flow sampler (flux-klein-mlx/examples/generate_klein.rs:441-443, src/sampler.rs:174-186):
  * latent_f32[i] += dt * v_bf16[i]; latent_bf16 (may be NULL) receives the rounded copy the next forward reads          */
 int omx_klein_euler_step(void* latent_f32, const void* v_bf16, float dt, void* latent_bf16, int64_t n, omx_stream stream);

@@ -343,6 +343,18 @@ int omx_vae_decode(omx_vae_decoder m, void* image, const void* latent, int h, in
             if (i > 0) { H *= 2; W *= 2; need = std::max(need, (size_t)H * W * Cout); }
         }
     }
+    {   // im2col and attention scratch for the whole pass, allocated before the timed region
+        size_t col_need = (size_t)h * w * 9 * std::max(c.z_channels, block_in);
+        int H = h, W = w, cur = block_in;
+        for (int i = nres - 1; i >= 0; --i) {
+            const int Cout = c.ch * c.ch_mult[i];
+            col_need = std::max(col_need, (size_t)H * W * 9 * std::max(cur, Cout));
+            if (i > 0) { H *= 2; W *= 2; col_need = std::max(col_need, (size_t)H * W * 9 * Cout); }
+            cur = Cout;
+        }
+        const size_t T = (size_t)h * w;
+        if (grow(&m->col, &m->col_cap, col_need) || grow(&m->attn, &m->attn_cap, T * block_in * 5 + T * T)) return 1;
+    }
     if (need > m->buf_cap) {
         OMX_HIP_CHECK(hipStreamSynchronize(s));
         for (int i = 0; i < 4; ++i) {

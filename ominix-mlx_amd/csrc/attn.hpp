@@ -29,7 +29,26 @@ struct AttnDecodeArgs {
     // optional [B*Hkv * 16] zeroed arrival counters: the LAST split block of a KV head merges the splits itself
     // (same arithmetic as attn_combine_kernel) and no combine launch follows
     unsigned* arrive;
+    // fused O-projection (launch_attn_oproj): `done` [B*Hkv * 16] words receive *seq_ptr once a KV head's output is final
+    unsigned* done;
+    const unsigned* seq_ptr;    // device word that differs from launch to launch (the engine's step sequence number)
 };
+
+// O-projection rows computed by the extra blocks of the fused launch: out = bf16(resid + bf16(attn_out . W^T))
+struct OProjArgs {
+    const bf16_t* w;            // [N, K] with K = H*D
+    const bf16_t* resid;        // [N]
+    bf16_t* out;                // [N]
+    int N, K;
+    int rows_per_wave, n_blocks;
+    unsigned* abort_flag;       // set when a wait gave up (results void)
+};
+// blocks that can be co-resident for head dim D / group G / K (0: no instantiation); the fused launch needs
+// B*Hkv*nsplit + o.n_blocks <= this
+int attn_oproj_capacity(int D, int G, int K);
+// one launch: split-KV decode attention + in-launch combine, and the O projection whose weight rows are pulled into
+// registers while the attention runs (the HBM is idle during that latency-bound phase)
+int launch_attn_oproj(const AttnDecodeArgs& a, const OProjArgs& o, int D, hipStream_t s);
 
 size_t attn_decode_ws_bytes(int BH, int nsplit, int D);
 int launch_attn_decode(const AttnDecodeArgs& a, int D, bool fused, hipStream_t s);

@@ -20,6 +20,8 @@
 //     qwen3-mlx/src/model.rs:172-194; the lane group whose token is the NEW position builds that
 //     K/V row in registers, uses it, and appends it to the cache (cache.rs:183-188) -- no barrier,
 //     no fence, and 6 launches per layer less than the per-op sequence.
+#include <algorithm>
+
 #include "attn.hpp"
 #include "gridsync.hpp"
 
@@ -47,11 +49,10 @@ __device__ __forceinline__ void unpack8(const u32x4 r, float (&x)[8]) {
 }
 
 template <int D, int GT, bool FUSED>
-__global__ __launch_bounds__(kBlock) void attn_decode_kernel(const AttnDecodeArgs a) {
+__device__ __forceinline__ void attn_decode_body(const AttnDecodeArgs& a, const int bk, const int split, unsigned char* smem) {
     constexpr int LPR = D / 8;          // lanes per K/V row
     constexpr int TPW = 64 / LPR;       // tokens per wave-instruction == token sub-groups per wave
     constexpr int STEP = TPW * kUnroll; // tokens per wave per step
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* sm_o = reinterpret_cast<float*>(smem);                 // [kWaves][TPW][GT][D]
     float* sm_m = sm_o + kWaves * TPW * GT * D;                   // [kWaves][GT]
     float* sm_l = sm_m + kWaves * GT;                             // [kWaves][GT]
@@ -60,9 +61,7 @@ __global__ __launch_bounds__(kBlock) void attn_decode_kernel(const AttnDecodeArg
     const int wave = threadIdx.x >> 6;
     const int c = lane % LPR;           // 8-element chunk of the head dim owned by this lane
     const int sg = lane / LPR;          // token sub-group inside the wave
-    const int bk = blockIdx.x;          // b * Hkv + kvh
     const int b = bk / a.Hkv, kvh = bk % a.Hkv;
-    const int split = blockIdx.y;
     const int G = a.H / a.Hkv;
 
     int Tk = a.Tk;
@@ -334,8 +333,101 @@ __global__ __launch_bounds__(kBlock) void attn_decode_kernel(const AttnDecodeArg
             acc1 = fmaf(f[i + 3], v[3], acc1);
         }
         for (; i < a.nsplit; ++i) acc0 = fmaf(f[i], ld_coh_f32(src + (size_t)i * D), acc0);
-        a.out[head * D + d] = f32_to_bf16((acc0 + acc1) / sm_L[g]);
+        if (a.done) st_coh_bf16(a.out + head * D + d, f32_to_bf16((acc0 + acc1) / sm_L[g]));
+        else a.out[head * D + d] = f32_to_bf16((acc0 + acc1) / sm_L[g]);
     }
+    if (a.done) {   // this KV head's slice of the attention output is final: publish it to the O-projection blocks
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) st_coh32(a.done + (size_t)bk * 16, *a.seq_ptr);
+    }
+}
+
+template <int D, int GT, bool FUSED>
+__global__ __launch_bounds__(kBlock) void attn_decode_kernel(const AttnDecodeArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    attn_decode_body<D, GT, FUSED>(a, blockIdx.x, blockIdx.y, smem);
+}
+
+// ---- fused launch: blocks [0, n_attn) are the attention above; the others own O-projection rows.  They issue their
+//      weight rows first (registers: two batches of two rows), wait until every KV head has published its output,
+//      read the attention vector with coherent loads and finish with the residual epilogue of gemv_kernel
+//      (same per-row arithmetic: identical bits to the separate launch). ----
+constexpr unsigned kWaitLimit = 1u << 22;
+
+template <int NV>
+__device__ __forceinline__ void oproj_body(const AttnDecodeArgs& a, const OProjArgs& o, const int ob, unsigned char* smem) {
+    u32x4* xs = reinterpret_cast<u32x4*>(smem);   // [NV * 64] attention output as packed bf16
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int rpw = o.rows_per_wave;
+    const int row_begin = (ob * kWaves + wave) * rpw;
+    const int row_end = min(row_begin + rpw, o.N);
+    u32x4 wA[2][NV], wB[2][NV];
+    auto issue = [&](u32x4 (&W)[2][NV], int r0) {
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const u32x4* p = reinterpret_cast<const u32x4*>(o.w + (size_t)min(r0 + r, o.N - 1) * o.K);
+#pragma unroll
+            for (int j = 0; j < NV; ++j) W[r][j] = __builtin_nontemporal_load(p + j * 64 + lane);
+        }
+    };
+    auto compute = [&](const u32x4 (&W)[2][NV], int r0) {
+        float acc[2] = {0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const u32x4 xp = xs[j * 64 + lane];
+            float xf[8];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { xf[2 * q] = bf16lo(xp[q]); xf[2 * q + 1] = bf16hi(xp[q]); }
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    acc[r] = fmaf(bf16lo(W[r][j][i]), xf[2 * i], acc[r]);
+                    acc[r] = fmaf(bf16hi(W[r][j][i]), xf[2 * i + 1], acc[r]);
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 2; ++r) acc[r] = wave_sum(acc[r]);
+        if (lane == 0) {
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const int row = r0 + r;
+                if (row < row_end) o.out[row] = f32_to_bf16(bf16_to_f32(o.resid[row]) + round_bf16(acc[r]));
+            }
+        }
+    };
+    if (row_begin < row_end) issue(wA, row_begin);
+    if (row_begin + 2 < row_end) issue(wB, row_begin + 2);
+    // wait for every KV head of this launch (bounded: a lost block must not hang the device)
+    const unsigned want = *a.seq_ptr;
+    const int n_heads = a.B * a.Hkv;
+    if ((int)threadIdx.x < n_heads) {
+        unsigned it = 0;
+        while (ld_coh32(a.done + (size_t)threadIdx.x * 16) != want) {
+            __builtin_amdgcn_s_sleep(2);
+            if (++it >= kWaitLimit) { st_coh32(o.abort_flag, 1u); break; }
+        }
+    }
+    __syncthreads();
+    for (int v = threadIdx.x; v < NV * 64; v += kBlock) xs[v] = ld_coh128(reinterpret_cast<const u32x4*>(a.out) + v);
+    __syncthreads();
+    for (int r0 = row_begin; r0 < row_end; r0 += 4) {
+        compute(wA, r0);
+        if (r0 + 2 >= row_end) break;
+        if (r0 + 4 < row_end) issue(wA, r0 + 4);
+        compute(wB, r0 + 2);
+        if (r0 + 6 < row_end) issue(wB, r0 + 6);
+    }
+}
+
+template <int D, int GT, int NV>
+__global__ __launch_bounds__(kBlock) void attn_oproj_kernel(const AttnDecodeArgs a, const OProjArgs o) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int heads = a.B * a.Hkv, n_attn = heads * a.nsplit;
+    if ((int)blockIdx.x < n_attn) attn_decode_body<D, GT, true>(a, blockIdx.x % heads, blockIdx.x / heads, smem);
+    else oproj_body<NV>(a, o, blockIdx.x - n_attn, smem);
 }
 
 // merge splits: out[head, d] = sum_i e^{m_i-M} o_i[d] / sum_i e^{m_i-M} l_i, rounded once to bf16.
@@ -393,6 +485,50 @@ __global__ __launch_bounds__(D) void attn_combine_kernel(bf16_t* __restrict__ ou
 }  // namespace
 
 size_t attn_decode_ws_bytes(int BH, int nsplit, int D) { return (size_t)BH * nsplit * (D + 2) * sizeof(float); }
+
+namespace {
+template <class F>
+int with_fused_kernel(int D, int gt, int nv, F&& f) {
+#define OMX_AO_CASE(DD, GG, VV) if (D == DD && gt == GG && nv == VV) return f((const void*)attn_oproj_kernel<DD, GG, VV>, \
+        ((size_t)kWaves * (64 / (DD / 8)) * GG * DD + 2 * kWaves * GG + 4) * sizeof(float));
+    OMX_AO_CASE(128, 4, 8) OMX_AO_CASE(128, 4, 2) OMX_AO_CASE(128, 2, 8) OMX_AO_CASE(128, 2, 4) OMX_AO_CASE(128, 1, 1)
+    OMX_AO_CASE(128, 1, 2) OMX_AO_CASE(64, 2, 1) OMX_AO_CASE(64, 4, 1) OMX_AO_CASE(128, 8, 7) OMX_AO_CASE(128, 8, 8)
+#undef OMX_AO_CASE
+    return -1;
+}
+}  // namespace
+
+int attn_oproj_capacity(int D, int G, int K) {
+    if (K % 512 != 0) return 0;
+    const int gt = G <= 1 ? 1 : G <= 2 ? 2 : G <= 4 ? 4 : 8;
+    int per_cu = 0;
+    const int rc = with_fused_kernel(D, gt, K / 512, [&](const void* fn, size_t shmem) -> int {
+        if (shmem > 48 * 1024 && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem) != hipSuccess) return -1;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, kBlock, shmem) != hipSuccess) return -1;
+        return 0;
+    });
+    if (rc != 0) { (void)hipGetLastError(); return 0; }
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+    return per_cu * cus;
+}
+
+int launch_attn_oproj(const AttnDecodeArgs& a, const OProjArgs& o, int D, hipStream_t s) {
+    const int G = a.H / a.Hkv;
+    OMX_REQUIRE(a.arrive && a.done && a.seq_ptr && o.abort_flag, "fused attention + O projection: missing synchronisation words");
+    OMX_REQUIRE(o.K == a.H * D && o.K % 512 == 0, "fused attention + O projection: K=%d", o.K);
+    const int gt = G <= 1 ? 1 : G <= 2 ? 2 : G <= 4 ? 4 : 8;
+    const int n_attn = a.B * a.Hkv * a.nsplit;
+    const int rc = with_fused_kernel(D, gt, o.K / 512, [&](const void* fn, size_t shmem_attn) -> int {
+        const size_t shmem = std::max(shmem_attn, (size_t)(o.K / 512) * 64 * 16);
+        void* args[] = {(void*)&a, (void*)&o};
+        if (hipLaunchKernel(fn, dim3(n_attn + o.n_blocks), dim3(kBlock), args, shmem, s) != hipSuccess) return 1;
+        return 0;
+    });
+    if (rc < 0) return set_error("fused attention + O projection: no kernel for D=%d G=%d K=%d", D, G, o.K);
+    if (rc > 0) return set_error("fused attention + O projection: launch failed: %s", hipGetErrorString(hipGetLastError()));
+    return 0;
+}
 
 int launch_attn_decode(const AttnDecodeArgs& a, int D, bool fused, hipStream_t s) {
     const int G = a.H / a.Hkv;

@@ -131,7 +131,8 @@ __global__ void apply_token_kernel(StepState* st, const unsigned long long* key,
 }
 
 __global__ __launch_bounds__(256) void embed_kernel(bf16_t* __restrict__ h, const bf16_t* __restrict__ table,
-                                                    const StepState* st, int hidden) {
+                                                    const StepState* st, int hidden, unsigned* seq) {
+    if (seq && blockIdx.x == 0 && threadIdx.x == 0) *seq += 1u;   // step sequence number (never reset): the fused launch's epoch
     const u32x4* src = reinterpret_cast<const u32x4*>(table + (size_t)st->cur_token * hidden);
     u32x4* dst = reinterpret_cast<u32x4*>(h);
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < hidden / 8; i += gridDim.x * blockDim.x) dst[i] = src[i];
@@ -168,6 +169,11 @@ struct omx_qwen3_ {
     int n_argmax_partials = 0;
     float *ws_o = nullptr, *ws_ml = nullptr;
     unsigned* attn_arrive = nullptr;   // per-KV-head arrival counters of the in-launch split combine (attn_decode.hip)
+    // attention + O projection in one launch (attn_decode.hip): per-layer completion words, the step sequence number they
+    // carry, and the word a wait that gave up sets
+    unsigned *attn_done = nullptr, *step_seq = nullptr, *wait_abort = nullptr;
+    bool fuse_oproj = false;
+    int oproj_rpw = 0, oproj_blocks = 0;
     int nsplit = 1;
 
     void* comm = nullptr;
@@ -356,7 +362,7 @@ int enqueue_step(omx_qwen3 m, bool with_head) {
     hipStream_t s = m->stream;
     const int hd = c.hidden_size, D = c.head_dim;
     const bool tp = c.tp_size > 1 || m->allreduce != nullptr;   // a 1-rank communicator exercises the TP path
-    embed_kernel<<<2, 256, 0, s>>>(m->h, m->embed, m->st, hd);
+    embed_kernel<<<2, 256, 0, s>>>(m->h, m->embed, m->st, hd, m->step_seq);
     OMX_LAUNCH_CHECK();
     bf16_t* h = m->h;      // residual stream entering the layer
     bf16_t* hn = m->h2;    // ping-pong partner
@@ -392,9 +398,18 @@ int enqueue_step(omx_qwen3 m, bool with_head) {
             a.q_norm_w = L.q_norm; a.k_norm_w = L.k_norm;
             a.rope_cos = m->rope_cos; a.rope_sin = m->rope_sin;
             a.eps = c.rms_norm_eps;
-            if (launch_attn_decode(a, D, true, s)) return 1;
+            if (m->fuse_oproj && !tp) {
+                // [attention + combine + O GEMV + residual] in ONE launch: the O rows are in registers when the attention ends
+                a.done = m->attn_done + (size_t)l * m->Hkv * 16;
+                a.seq_ptr = m->step_seq;
+                OProjArgs o = {L.o, h, hn, hd, m->H * D, m->oproj_rpw, m->oproj_blocks, m->wait_abort};
+                if (launch_attn_oproj(a, o, D, s)) return 1;
+                bf16_t* t = h; h = hn; hn = t;
+            } else if (launch_attn_decode(a, D, true, s)) {
+                return 1;
+            }
         }
-        {   // [O GEMV + residual]  model.rs:214,325
+        if (!(m->fuse_oproj && !tp)) {   // [O GEMV + residual]  model.rs:214,325
             GemvArgs a = {};
             a.w0 = L.o; a.n0 = hd; a.N = hd; a.K = m->H * D;
             a.x = m->attn_out;
@@ -581,6 +596,12 @@ int run_step(omx_qwen3 m, bool with_head) {
 // The last layer stops after its cache scatter: nothing downstream of it is consumed for these tokens.
 // a device-wide barrier of the persistent kernel gave up (a block never arrived): the step's results are void
 int mega_health(omx_qwen3 m) {
+    if (!m->mega && m->fuse_oproj) {
+        unsigned gave_up = 0;
+        OMX_HIP_CHECK(hipMemcpy(&gave_up, m->wait_abort, 4, hipMemcpyDeviceToHost));
+        OMX_REQUIRE(gave_up == 0, "fused attention + O projection: an O block gave up waiting for the attention blocks (not co-resident?); set OMX_ATTN_OPROJ=0");
+        return 0;
+    }
     if (!m->mega) return 0;
     unsigned abort_word = 0;
     OMX_HIP_CHECK(hipMemcpy(&abort_word, m->mega_sync + 16, 4, hipMemcpyDeviceToHost));
@@ -747,6 +768,28 @@ int omx_qwen3_create(omx_qwen3* out, const omx_qwen3_config* cfg) {
     m->nsplit = (m->cap + tok_per_split - 1) / tok_per_split;
     const int cap_splits = (512 + m->Hkv - 1) / m->Hkv;
     if (m->nsplit > cap_splits) m->nsplit = cap_splits;
+    {   // attention + O projection in one launch: every block must be co-resident (the O blocks wait for the attention ones)
+        const char* fenv = getenv("OMX_ATTN_OPROJ");
+        const int hd_att = m->H * D;
+        const bool eligible = c.tp_size == 1 && !c.quant_bits && hd_att % 512 == 0;
+        const int capacity = eligible ? attn_oproj_capacity(D, m->H / m->Hkv, hd_att) : 0;
+        if (capacity >= 64) {
+            // the split count is capped whether or not the fusion is switched on: OMX_ATTN_OPROJ=0 then computes the same bits
+            const int max_split = std::max(1, capacity / 2 / m->Hkv);
+            if (m->nsplit > max_split) m->nsplit = max_split;
+        }
+        if (capacity >= 64 && fenv && fenv[0] == '1') {   // opt-in: measured +0.3 %; the step graph default stays wait-free
+            const int room = capacity - m->Hkv * m->nsplit;
+            int rpw = 2;
+            while ((c.hidden_size + 4 * rpw - 1) / (4 * rpw) > room && rpw < 64) rpw += 2;
+            if ((c.hidden_size + 4 * rpw - 1) / (4 * rpw) <= room) {
+                m->fuse_oproj = true;
+                m->oproj_rpw = rpw;
+                m->oproj_blocks = (c.hidden_size + 4 * rpw - 1) / (4 * rpw);
+            }
+        }
+    }
+    if (dev_alloc(m, &m->attn_done, (size_t)L * m->Hkv * 16) || dev_alloc(m, &m->step_seq, 16) || dev_alloc(m, &m->wait_abort, 16)) return 1;
     if (dev_alloc(m, &m->st, 1) || dev_alloc(m, &m->out_ring, (size_t)m->ring_cap) ||
         dev_alloc(m, &m->h, (size_t)c.hidden_size) || dev_alloc(m, &m->h2, (size_t)c.hidden_size) ||
         dev_alloc(m, &m->qkv, (size_t)(m->H + 2 * m->Hkv) * D) || dev_alloc(m, &m->attn_out, (size_t)m->H * D) ||

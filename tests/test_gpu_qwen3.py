@@ -341,3 +341,19 @@ def test_load_model_from_checkpoint_directory(omx, tmp_path, quant):
     want = np.concatenate([[ref.prefill(prompt)], ref.decode(6)])
     np.testing.assert_array_equal(got, want)
     np.testing.assert_array_equal(logits, ref.last_logits())
+
+
+@pytest.mark.parametrize("name", ["gqa4_d128", "gqa2_d64"])
+def test_fused_attention_oproj_launch_is_bit_identical(omx, monkeypatch, name):
+    """OMX_ATTN_OPROJ=1: attention + combine + O projection in one launch (csrc/attn_decode.hip attn_oproj_kernel) must give
+    the bits of the separate launches: tokens, logits and the residual stream."""
+    cfg = CONFIGS[name]
+    prompt = synth.prompt_ids(40, cfg.vocab_size)
+    outs = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("OMX_ATTN_OPROJ", flag)
+        m = _engine(omx, cfg)
+        toks = np.concatenate([[m.prefill(prompt)], m.decode(12)])
+        outs[flag] = (toks, m.last_logits())
+    np.testing.assert_array_equal(outs["0"][0], outs["1"][0])
+    np.testing.assert_array_equal(outs["0"][1], outs["1"][1])

@@ -36,6 +36,12 @@ QWEN3_0_6B = dict(hidden_size=1024, num_hidden_layers=28, intermediate_size=3072
 MODELS = {"qwen3-8b": QWEN3_8B, "qwen3-0.6b": QWEN3_0_6B}
 
 
+def prompt_ids(n, vocab):
+    """SURVEY.md section 8d synthetic prompt: token i = (i * 7919 + 13) mod V."""
+    import numpy as np
+    return ((np.arange(n, dtype=np.int64) * 7919 + 13) % vocab).astype(np.uint32)
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -130,11 +136,10 @@ def quantized_secondary(omx, cfg, args, bits=4):
     """The reference's flagship mode: the same model as an MLX 4-bit checkpoint (group 64), same
     protocol (2048-token prompt, warm-up, timed greedy decode steps); the decode step streams the packed weights."""
     from ominix_mlx_amd import engine
-    from oracle import synth  # prompt generator only
     max_ctx = args.prompt + args.warmup + args.steps + 8
     m = engine.Model(max_context=max_ctx, quantization={"bits": bits, "group_size": 64}, **cfg)
     m.synth_weights()
-    prompt = synth.prompt_ids(args.prompt, cfg["vocab_size"])
+    prompt = prompt_ids(args.prompt, cfg["vocab_size"])
     first = m.prefill(prompt)
     if args.warmup:
         m.decode(args.warmup)
@@ -231,7 +236,6 @@ def main():
     import omx_import
     omx = omx_import.load_package()
     from ominix_mlx_amd import engine
-    from oracle import synth   # prompt id generator only (no oracle compute on the timed path)
 
     cfg = dict(MODELS[args.model])
     if args.layers:
@@ -244,7 +248,7 @@ def main():
         model.set_comm(keep[1], keep[2])
     model.synth_weights()
 
-    prompt = synth.prompt_ids(args.prompt, cfg["vocab_size"])
+    prompt = prompt_ids(args.prompt, cfg["vocab_size"])
     t0 = time.perf_counter()
     first = model.prefill(prompt)
     torch.cuda.synchronize()

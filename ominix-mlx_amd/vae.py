@@ -31,6 +31,56 @@ for _n, (_r, _a) in VAE_SIGNATURES.items():
     _f.restype, _f.argtypes = _r, _a
 
 
+def decoder_weight_shapes(ch=128, ch_mult=(1, 2, 4, 4), num_res_blocks=2, z_channels=32, out_ch=3) -> dict:
+    """Parameter names and shapes of `Decoder::new` (autoencoder.rs:279-372), Conv2d weights as [out, kH, kW, in]."""
+    n = len(ch_mult)
+    block_in = ch * ch_mult[-1]
+    s = {"post_quant_conv.weight": (z_channels, 1, 1, z_channels), "post_quant_conv.bias": (z_channels,),
+         "conv_in.weight": (block_in, 3, 3, z_channels), "conv_in.bias": (block_in,)}
+
+    def resnet(p, cin, cout):
+        s[p + "norm1.weight"] = s[p + "norm1.bias"] = (cin,)
+        s[p + "conv1.weight"], s[p + "conv1.bias"] = (cout, 3, 3, cin), (cout,)
+        s[p + "norm2.weight"] = s[p + "norm2.bias"] = (cout,)
+        s[p + "conv2.weight"], s[p + "conv2.bias"] = (cout, 3, 3, cout), (cout,)
+        if cin != cout:
+            s[p + "conv_shortcut.weight"], s[p + "conv_shortcut.bias"] = (cout, 1, 1, cin), (cout,)
+
+    resnet("mid_block_resnets_0.", block_in, block_in)
+    resnet("mid_block_resnets_1.", block_in, block_in)
+    a = "mid_block_attentions_0."
+    s[a + "group_norm.weight"] = s[a + "group_norm.bias"] = (block_in,)
+    for nm in ("to_q", "to_k", "to_v", "to_out"):
+        s[a + nm + ".weight"], s[a + nm + ".bias"] = (block_in, block_in), (block_in,)
+    cur = block_in
+    for b, i in enumerate(reversed(range(n))):
+        cout = ch * ch_mult[i]
+        for j in range(num_res_blocks + 1):
+            resnet(f"up_blocks.{b}.resnets.{j}.", cur if j == 0 else cout, cout)
+        if i > 0:
+            s[f"up_blocks.{b}.upsamplers_0_conv.weight"], s[f"up_blocks.{b}.upsamplers_0_conv.bias"] = (cout, 3, 3, cout), (cout,)
+        cur = cout
+    s["conv_norm_out.weight"] = s["conv_norm_out.bias"] = (ch,)
+    s["conv_out.weight"], s["conv_out.bias"] = (out_ch, 3, 3, ch), (out_ch,)
+    return s
+
+
+def random_decoder_weights(seed: int = 0, **cfg) -> dict:
+    """Synthetic weights of the right shapes and magnitudes (variance-preserving convolutions, norm scales near 1) for
+    benchmarks without a checkpoint."""
+    g = np.random.default_rng(seed)
+    out = {}
+    for name, shape in decoder_weight_shapes(**cfg).items():
+        if name.endswith((".bias",)):
+            v = 0.05 * g.standard_normal(shape)
+        elif len(shape) == 1:
+            v = 1.0 + 0.1 * g.standard_normal(shape)
+        else:
+            v = g.standard_normal(shape) / np.sqrt(int(np.prod(shape[1:])))
+        out[name] = v.astype(np.float32)
+    return out
+
+
 def sanitize_vae_weights(weights: dict) -> dict:
     """weights.rs:164-217: keep `post_quant_conv.*` and `decoder.*`, rename to the decoder's fields, Conv2d OIHW -> OHWI."""
     out = {}

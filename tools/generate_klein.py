@@ -7,7 +7,6 @@ import numpy as np
 import omx_import
 omx = omx_import.load_package()
 from ominix_mlx_amd import engine, flux_pipeline, klein, vae
-from oracle import ref_vae as rv      # VAE weight shapes / random generator only (no checkpoint here)
 
 size = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 4
@@ -20,7 +19,7 @@ enc.synth_weights()
 dit = klein.FluxKlein()
 dit.synth_weights()
 dec = vae.VaeDecoder()
-dec.load_weights(rv.synth_decoder_weights(1))
+dec.load_weights(vae.random_decoder_weights(1))
 omx.ops.synchronize()
 load_s = time.perf_counter() - t0
 

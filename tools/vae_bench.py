@@ -5,9 +5,8 @@ import numpy as np
 import omx_import
 omx = omx_import.load_package()
 from ominix_mlx_amd import vae
-from oracle import ref_vae as rv      # weight shapes / generator only
 T = omx.ops.Tensor
-w = rv.synth_decoder_weights(1)
+w = vae.random_decoder_weights(1)
 dec = vae.VaeDecoder()
 dec.load_weights(w)
 for side in (512, 1024):

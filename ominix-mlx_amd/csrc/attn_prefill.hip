@@ -76,7 +76,8 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(const PrefillArgs 
     const int qcol = lane & 15, rg = lane >> 4;
     const int b = blockIdx.z, h = blockIdx.y;
     const int kvh = h / (a.H / a.Hkv);
-    const int q0 = blockIdx.x * QBLK;
+    // causal: the last query blocks see the most keys -- dispatch them first so that a multi-round grid ends on short blocks
+    const int q0 = (MASK == OMX_MASK_CAUSAL ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x) * QBLK;
     const int shift = a.Tk - a.Tq;                       // causal: query i sees keys <= i + shift
 
     const bf16_t* Kb = a.k + (size_t)b * a.kv_batch_stride + (size_t)kvh * a.kv_head_stride;

@@ -160,6 +160,31 @@ def quantized_secondary(omx, cfg, args, bits=4):
     return out
 
 
+def mixtral_secondary(omx, steps=64, warm=8, n_prompt=2048):
+    """BASELINE config 3 on one GPU: Mixtral-8x7B shapes (mixtral-mlx/src/model.rs:44-52) in bf16 (93 GB of weights fit
+    one MI355X), sparse-MoE decode engine: router + top-2 expert GEMVs per layer inside the step graph."""
+    import numpy as np
+    from ominix_mlx_amd import engine
+    cfg = dict(hidden_size=4096, num_hidden_layers=32, intermediate_size=14336, num_attention_heads=32, num_key_value_heads=8,
+               head_dim=128, vocab_size=32000, rms_norm_eps=1e-5, rope_theta=1e6, num_experts=8, num_experts_per_tok=2,
+               moe_intermediate_size=14336, moe_mode="mixtral", qk_norm=False)
+    m = engine.Model(max_context=n_prompt + warm + steps + 8, **cfg)
+    m.synth_weights()
+    first = m.prefill(prompt_ids(n_prompt, cfg["vocab_size"]))
+    m.decode(warm)
+    t0 = time.perf_counter()
+    toks = m.decode(steps)
+    dt = time.perf_counter() - t0
+    step_bytes = m.step_bytes(n_prompt + warm + steps // 2)
+    out = {"metric": "decode_tokens_per_sec_mixtral_8x7b_bf16", "value": round(steps / dt, 2), "unit": "tokens/s", "n_gpus": 1,
+           "steps": steps, "ms_per_step": round(dt / steps * 1e3, 4), "dtype": "bf16", "data": "synthetic", "parallelism": "ep1",
+           "step_roofline": {"algorithmic_bytes_per_token": int(step_bytes), "achieved_GBps": round(step_bytes / (dt / steps) / 1e9, 1),
+                             "frac_of_hbm_peak": round(step_bytes / (dt / steps) / 1e9 / HBM_PEAK_GBPS, 4)},
+           "prefill_device_ms": round(m.last_prefill_ms(), 2), "first_tokens": [int(first)] + [int(t) for t in toks[:4]]}
+    m.close()
+    return out
+
+
 def paraformer_secondary(omx, reps=5):
     """BASELINE.json configs[3]: Paraformer-large on 30 s of 16 kHz audio (mel/STFT + LFR + CMVN -> 50-layer SAN-M encoder
     -> CIF -> 16-layer decoder -> token ids), one MI355X, synthetic checkpoint with the reference's keys; audio resident in
@@ -325,6 +350,10 @@ def main():
             out["quantized"] = quantized_secondary(omx, cfg, args)
         except Exception as e:
             out["quantized"] = {"metric": "decode_tokens_per_sec_4bit", "value": None, "error": str(e)}
+        try:
+            out["mixtral"] = mixtral_secondary(omx)
+        except Exception as e:
+            out["mixtral"] = {"metric": "decode_tokens_per_sec_mixtral_8x7b_bf16", "value": None, "error": str(e)}
         try:
             out["paraformer"] = paraformer_secondary(omx)
         except Exception as e:

@@ -158,6 +158,11 @@ typedef struct omx_qwen3_config_ {
      * 4 / 8 = every Linear and the embedding are MLX (weight u32, scales, biases) triplets registered as
      * "<prefix>.weight" / ".scales" / ".biases"; the decode step then streams the PACKED weights (csrc/quant.hip) */
     int quant_bits, quant_group;
+    /* sparse-MoE feed-forward in every layer (0 experts = dense MLP): Qwen3-MoE (qwen3-mlx/src/qwen3_moe.rs:440-508, mode 1,
+     * weights "model.layers.N.mlp.gate.weight" [E, hidden] and "...mlp.switch_mlp.{gate,up,down}_proj.weight" stacked
+     * [E, moe_intermediate_size, hidden] / [E, hidden, moe_intermediate_size]) or Mixtral (mixtral-mlx/src/model.rs:280-347,
+     * mode 0, the same names under "block_sparse_moe.").  no_qk_norm: attention without q/k RMSNorm (Mixtral, :120-160). */
+    int num_experts, num_experts_per_tok, moe_intermediate_size, moe_mode, norm_topk_prob, no_qk_norm;
 } omx_qwen3_config;
 typedef struct omx_qwen3_* omx_qwen3;
 
@@ -242,6 +247,11 @@ int omx_moe_workspace_bytes(int n_tokens, int hidden, int inter, int n_experts, 
 int omx_moe_forward(void* out, const void* x, const void* gate_w, const void* w_gate, const void* w_up,
                     const void* w_down, int n_tokens, int hidden, int inter, int n_experts, int top_k, int mode,
                     int norm_topk_prob, uint32_t* inds_out, void* scores_out, omx_stream stream);
+/* decoder-block form (mixtral model.rs:340-345, qwen3_moe.rs decoder layer): out = resid + moe(rmsnorm(x, norm_w, eps));
+ * the norm is folded into the router launch, the residual into the combine launch; xn = [n_tokens, hidden] scratch */
+int omx_moe_block_forward(void* out, const void* resid, const void* x, const void* norm_w, float eps, void* xn, const void* gate_w,
+                          const void* w_gate, const void* w_up, const void* w_down, int n_tokens, int hidden, int inter,
+                          int n_experts, int top_k, int mode, int norm_topk_prob, omx_stream stream);
 /* the reference's own Mixtral format (mixtral-mlx/src/model.rs:182-274, QuantizedSwitchLinear -> mlx_gather_qmm x3):
  * expert stacks as MLX affine-quantised triplets, packed u32 [E, out, in*bits/32], scales / biases [E, out, in/group_size];
  * router gate bf16.  <= 32 routed slots: expert-selected GEMVs on the packed weights; more: dequantise + grouped GEMM. */

@@ -103,7 +103,7 @@ __device__ __forceinline__ void attn_decode_body(const AttnDecodeArgs& a, const 
 #pragma unroll
         for (int e = 0; e < 8; ++e) ss = fmaf(x[e], x[e], ss);
         ss = group_sum<LPR>(ss);
-        const float rstd = 1.0f / sqrtf(ss / (float)D + a.eps);
+        const float rstd = a.q_norm_w ? 1.0f / sqrtf(ss / (float)D + a.eps) : 1.0f;   // no q/k norm (Mixtral): x goes to RoPE as it is
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const float xn = round_bf16(x[e] * rstd * w[e]);            // RMSNorm output is bf16
@@ -120,8 +120,13 @@ __device__ __forceinline__ void attn_decode_body(const AttnDecodeArgs& a, const 
         const f32x4* sp = reinterpret_cast<const f32x4*>(a.rope_sin + (size_t)pos * (D / 2) + i0);
         const f32x4 c0 = cp[0], c1 = cp[1], s0 = sp[0], s1 = sp[1];
         float wq[8];
-        unpack8(*reinterpret_cast<const u32x4*>(a.q_norm_w + c * 8), wq);
-        unpack8(*reinterpret_cast<const u32x4*>(a.k_norm_w + c * 8), wk);
+        if (a.q_norm_w) {
+            unpack8(*reinterpret_cast<const u32x4*>(a.q_norm_w + c * 8), wq);
+            unpack8(*reinterpret_cast<const u32x4*>(a.k_norm_w + c * 8), wk);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) wq[e] = wk[e] = 1.0f;
+        }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             cs[e] = c0[e]; cs[4 + e] = c1[e];

@@ -24,6 +24,7 @@
 #include <vector>
 
 #include "attn.hpp"
+#include "workspace.hpp"
 #include "decode_mega.hpp"
 #include "gemm.hpp"
 #include "gemv.hpp"
@@ -40,6 +41,7 @@ constexpr int kNcclFloat32 = 7, kNcclUint64 = 5, kNcclSum = 0, kNcclMax = 2;
 
 struct LayerW {
     const bf16_t *q, *k, *v, *o, *gate, *up, *down, *q_norm, *k_norm, *in_ln, *post_ln;
+    const bf16_t *moe_gate, *moe_wg, *moe_wu, *moe_wd;   // sparse-MoE feed-forward (router + stacked experts)
 };
 // quantized checkpoint (config.json "quantization", qwen3-mlx/src/model.rs:621-727): every Linear and the embedding are
 // (weight u32, scales, biases) triplets; the norm weights stay bf16 in LayerW
@@ -164,6 +166,7 @@ struct omx_qwen3_ {
     uint32_t *out_ring = nullptr, *prompt_dev = nullptr;
     int ring_cap = 4096, prompt_cap = 0;
     bf16_t *h = nullptr, *h2 = nullptr, *qkv = nullptr, *attn_out = nullptr, *act = nullptr, *logits = nullptr;
+    bf16_t *moe_xn = nullptr, *moe_out = nullptr;   // MoE feed-forward: normalised input row, block output
     float *partial_a = nullptr, *partial_b = nullptr;   // TP: f32 partial sums awaiting all-reduce
     unsigned long long *argmax_partials = nullptr, *argmax_key = nullptr;
     int n_argmax_partials = 0;
@@ -259,13 +262,20 @@ int resolve_weights(omx_qwen3 m) {
     for (int i = 0; i < m->cfg.num_hidden_layers; ++i) {
         const std::string p = "model.layers." + std::to_string(i) + ".";
         LayerW& L = m->layers[i];
+        L = LayerW{};
         if (get(p + "self_attn.q_proj.weight", &L.q) || get(p + "self_attn.k_proj.weight", &L.k) ||
             get(p + "self_attn.v_proj.weight", &L.v) || get(p + "self_attn.o_proj.weight", &L.o) ||
-            get(p + "self_attn.q_norm.weight", &L.q_norm) || get(p + "self_attn.k_norm.weight", &L.k_norm) ||
-            get(p + "mlp.gate_proj.weight", &L.gate) || get(p + "mlp.up_proj.weight", &L.up) ||
-            get(p + "mlp.down_proj.weight", &L.down) || get(p + "input_layernorm.weight", &L.in_ln) ||
-            get(p + "post_attention_layernorm.weight", &L.post_ln))
+            get(p + "input_layernorm.weight", &L.in_ln) || get(p + "post_attention_layernorm.weight", &L.post_ln))
             return 1;
+        if (!m->cfg.no_qk_norm && (get(p + "self_attn.q_norm.weight", &L.q_norm) || get(p + "self_attn.k_norm.weight", &L.k_norm))) return 1;
+        if (m->cfg.num_experts > 0) {
+            const std::string mp = p + (m->cfg.moe_mode == 0 ? "block_sparse_moe." : "mlp.");
+            if (get(mp + "gate.weight", &L.moe_gate) || get(mp + "switch_mlp.gate_proj.weight", &L.moe_wg) ||
+                get(mp + "switch_mlp.up_proj.weight", &L.moe_wu) || get(mp + "switch_mlp.down_proj.weight", &L.moe_wd))
+                return 1;
+        } else if (get(p + "mlp.gate_proj.weight", &L.gate) || get(p + "mlp.up_proj.weight", &L.up) || get(p + "mlp.down_proj.weight", &L.down)) {
+            return 1;
+        }
     }
     if (get("model.embed_tokens.weight", &m->embed) || get("model.norm.weight", &m->final_norm)) return 1;
     if (m->cfg.tie_word_embeddings) {
@@ -425,6 +435,15 @@ int enqueue_step(omx_qwen3 m, bool with_head) {
                 pending = m->partial_a;
             }
         }
+        if (c.num_experts > 0) {
+            // [RMSNorm] [router] [expert gate/up + SwiGLU] [expert down] [weighted sum] [+ residual]
+            // (qwen3_moe.rs:475-503 / mixtral model.rs:296-308, :343-344)
+            if (omx_moe_block_forward(hn, h, h, L.post_ln, c.rms_norm_eps, m->moe_xn, L.moe_gate, L.moe_wg, L.moe_wu, L.moe_wd, 1, hd,
+                                      c.moe_intermediate_size, c.num_experts, c.num_experts_per_tok, c.moe_mode, c.norm_topk_prob, s))
+                return 1;
+            bf16_t* t = h; h = hn; hn = t;
+            continue;
+        }
         {   // [RMSNorm + gate/up GEMV + SwiGLU]  model.rs:263-265,326
             GemvArgs a = {};
             a.w0 = L.gate; a.w1 = L.up; a.n0 = m->I; a.N = m->I; a.K = hd;
@@ -499,7 +518,7 @@ int setup_mega(omx_qwen3 m) {
     const omx_qwen3_config& c = m->cfg;
     const char* env = getenv("OMX_DECODE_MEGA");
     if (!env || env[0] != '1') return 0;   // opt-in until it beats the step graph
-    if (c.tp_size > 1 || m->allreduce != nullptr || c.num_hidden_layers < 1 || c.quant_bits || m->temperature != 0.f) return 0;
+    if (c.tp_size > 1 || m->allreduce != nullptr || c.num_hidden_layers < 1 || c.quant_bits || m->temperature != 0.f || c.num_experts > 0) return 0;
     if (!mega_supported(c.hidden_size, m->H * c.head_dim, m->I, c.head_dim, m->H / m->Hkv)) return 0;
     int capacity = 0;
     if (mega_capacity(c.hidden_size, m->H * c.head_dim, m->I, &capacity)) return 1;
@@ -701,6 +720,17 @@ int prefill_prefix_batched(omx_qwen3 m, int T, int off, const EncodeOpts* enc = 
             return 1;
         if (!(w = W(L.o, &Q.o, H * D)) || launch_gemm_bf16_ex(h2, m->pf_attn, w, nullptr, h, T, hd, H * D, s)) return 1;
         if (omx_rms_norm(m->pf_xn, h2, L.post_ln, T, hd, c.rms_norm_eps, OMX_BFLOAT16, s)) return 1;
+        if (c.num_experts > 0) {   // sparse-MoE feed-forward over all T rows (grouped MFMA GEMM route), then the residual
+            if (omx_moe_forward(m->pf_attn, m->pf_xn, L.moe_gate, L.moe_wg, L.moe_wu, L.moe_wd, T, hd, c.moe_intermediate_size,
+                                c.num_experts, c.num_experts_per_tok, c.moe_mode, c.norm_topk_prob, nullptr, nullptr, s))
+                return 1;
+            if (omx_add(h, h2, m->pf_attn, (int64_t)T * hd, OMX_BFLOAT16, s)) return 1;
+            if (enc && next_tap < enc->n_taps && enc->taps[next_tap] == l) {
+                copy_rows_strided_kernel<<<1024, 256, 0, s>>>(enc->out + (size_t)next_tap * hd, (int64_t)enc->n_taps * hd, h, hd, T, hd / 8);
+                ++next_tap;
+            }
+            continue;
+        }
         if (!(w = W(L.gate, &Q.gate, hd)) || launch_gemm_bf16(m->pf_g, m->pf_xn, w, nullptr, T, I, hd, s)) return 1;
         if (!(w = W(L.up, &Q.up, hd)) || launch_gemm_bf16(m->pf_u, m->pf_xn, w, nullptr, T, I, hd, s)) return 1;
         if (launch_silu_mul(m->pf_g, m->pf_g, m->pf_u, (int64_t)T * I, s)) return 1;
@@ -742,7 +772,7 @@ int omx_qwen3_create(omx_qwen3* out, const omx_qwen3_config* cfg) {
     m->Hkv = c.num_key_value_heads / c.tp_size;
     m->I = c.intermediate_size / c.tp_size;
     m->V = c.vocab_size / c.tp_size;
-    OMX_REQUIRE((m->H * c.head_dim) % 512 == 0 && m->I % 512 == 0, "InvalidConfig: per-rank attention width %d and intermediate %d must be multiples of 512", m->H * c.head_dim, m->I);
+    OMX_REQUIRE((m->H * c.head_dim) % 512 == 0 && (c.num_experts > 0 || m->I % 512 == 0), "InvalidConfig: per-rank attention width %d and intermediate %d must be multiples of 512", m->H * c.head_dim, m->I);
     const int step = 256;   // cache.rs:110-117
     m->cap = ((c.max_context > 0 ? c.max_context : 4096) + step - 1) / step * step;
     OMX_HIP_CHECK(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking));
@@ -768,6 +798,20 @@ int omx_qwen3_create(omx_qwen3* out, const omx_qwen3_config* cfg) {
     m->nsplit = (m->cap + tok_per_split - 1) / tok_per_split;
     const int cap_splits = (512 + m->Hkv - 1) / m->Hkv;
     if (m->nsplit > cap_splits) m->nsplit = cap_splits;
+    if (c.num_experts > 0) {
+        OMX_REQUIRE(c.tp_size == 1 && !c.quant_bits, "InvalidConfig: the sparse-MoE engine is single-GPU bf16 (tp_size %d, quant bits %d)", c.tp_size, c.quant_bits);
+        OMX_REQUIRE(c.num_experts_per_tok >= 1 && c.num_experts_per_tok <= c.num_experts && c.moe_intermediate_size > 0 &&
+                        c.moe_intermediate_size % 64 == 0 && (c.moe_mode == 0 || c.moe_mode == 1) && m->H * D >= c.hidden_size,
+                    "InvalidConfig: experts %d top-%d moe_intermediate_size %d mode %d", c.num_experts, c.num_experts_per_tok,
+                    c.moe_intermediate_size, c.moe_mode);
+        // the MoE block takes its scratch from the library workspace: size it ONCE for the largest batch (a whole-context
+        // prefill) so that the pointers captured in the step graph never move
+        size_t need = 0;
+        omx_moe_workspace_bytes(m->cap, c.hidden_size, c.moe_intermediate_size, c.num_experts, c.num_experts_per_tok, &need);
+        void* ws = nullptr;
+        if (get_workspace(&ws, need)) return 1;
+        if (dev_alloc(m, &m->moe_xn, (size_t)c.hidden_size) || dev_alloc(m, &m->moe_out, (size_t)c.hidden_size)) return 1;
+    }
     {   // attention + O projection in one launch: every block must be co-resident (the O blocks wait for the attention ones)
         const char* fenv = getenv("OMX_ATTN_OPROJ");
         const int hd_att = m->H * D;
@@ -893,14 +937,23 @@ int omx_qwen3_synth_weights(omx_qwen3 m, uint32_t base_seed) {
             make(p + "self_attn.k_proj.weight", Hk, hd, hd, (int64_t)r * Hk, 0, false) ||
             make(p + "self_attn.v_proj.weight", Hk, hd, hd, (int64_t)r * Hk, 0, false) ||
             make(p + "self_attn.o_proj.weight", hd, Hq, (int64_t)c.num_attention_heads * D, 0, (int64_t)r * Hq, false) ||
-            make(p + "self_attn.q_norm.weight", 1, D, D, 0, 0, true) ||
-            make(p + "self_attn.k_norm.weight", 1, D, D, 0, 0, true) ||
-            make(p + "mlp.gate_proj.weight", m->I, hd, hd, (int64_t)r * m->I, 0, false) ||
-            make(p + "mlp.up_proj.weight", m->I, hd, hd, (int64_t)r * m->I, 0, false) ||
-            make(p + "mlp.down_proj.weight", hd, m->I, c.intermediate_size, 0, (int64_t)r * m->I, false) ||
             make(p + "input_layernorm.weight", 1, hd, hd, 0, 0, true) ||
             make(p + "post_attention_layernorm.weight", 1, hd, hd, 0, 0, true))
             return 1;
+        if (!c.no_qk_norm && (make(p + "self_attn.q_norm.weight", 1, D, D, 0, 0, true) || make(p + "self_attn.k_norm.weight", 1, D, D, 0, 0, true)))
+            return 1;
+        if (c.num_experts > 0) {
+            const std::string mp = p + (c.moe_mode == 0 ? "block_sparse_moe." : "mlp.");
+            const int64_t E = c.num_experts, Im = c.moe_intermediate_size;
+            if (make(mp + "gate.weight", E, hd, hd, 0, 0, false) || make(mp + "switch_mlp.gate_proj.weight", E * Im, hd, hd, 0, 0, false) ||
+                make(mp + "switch_mlp.up_proj.weight", E * Im, hd, hd, 0, 0, false) ||
+                make(mp + "switch_mlp.down_proj.weight", E * hd, Im, Im, 0, 0, false))
+                return 1;
+        } else if (make(p + "mlp.gate_proj.weight", m->I, hd, hd, (int64_t)r * m->I, 0, false) ||
+                   make(p + "mlp.up_proj.weight", m->I, hd, hd, (int64_t)r * m->I, 0, false) ||
+                   make(p + "mlp.down_proj.weight", hd, m->I, c.intermediate_size, 0, (int64_t)r * m->I, false)) {
+            return 1;
+        }
     }
     if (make("model.embed_tokens.weight", c.vocab_size, hd, hd, 0, 0, false) || make("model.norm.weight", 1, hd, hd, 0, 0, true))
         return 1;
@@ -1135,7 +1188,9 @@ int omx_qwen3_step_bytes(omx_qwen3 m, int ctx, double* bytes) {
     const omx_qwen3_config& c = m->cfg;
     const double D = c.head_dim, hd = c.hidden_size;
     // 2 B x [L (h H D + 2 h Hkv D + H D h + 3 h I) + V h] + ctx (2 L Hkv D 2 B) + KV write
-    const double per_layer = hd * m->H * D + 2.0 * hd * m->Hkv * D + m->H * D * hd + 3.0 * hd * m->I;
+    // sparse MoE: the router plus the top-k experts' three matrices are what one token streams
+    const double ffn = c.num_experts > 0 ? hd * c.num_experts + 3.0 * hd * c.moe_intermediate_size * c.num_experts_per_tok : 3.0 * hd * m->I;
+    const double per_layer = hd * m->H * D + 2.0 * hd * m->Hkv * D + m->H * D * hd + ffn;
     // bytes per weight element: bf16 = 2; quantized = bits/8 packed + (scale + bias) bf16 per group
     const double bpe = c.quant_bits ? c.quant_bits / 8.0 + 4.0 / c.quant_group : 2.0;
     const double w = bpe * (c.num_hidden_layers * per_layer + (double)m->V * hd);

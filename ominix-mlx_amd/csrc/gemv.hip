@@ -100,6 +100,8 @@ __global__ __launch_bounds__(kBlock) void gemv_kernel(const GemvArgs a_in) {
     const int row_end = min(row_begin + rpw, a.N);
     const bool active = row_begin < a.N;
     const int koff = (KSPLIT == 1) ? 0 : wave * NVW * 64;   // first vector of this wave's K slice
+    const int kvec = K / 8;                                   // 16-byte vectors per row
+    const bool tail = kvec < NV * 64;                         // K not a multiple of 512: the last vector row is partly empty (zero weights and activations)
 
     u32x4 wA[NR][NVW], wB[NR][NVW];
     uint64_t best = 0;   // EPI_ARGMAX: running (orderable logit << 32 | ~row) of this thread
@@ -112,12 +114,14 @@ __global__ __launch_bounds__(kBlock) void gemv_kernel(const GemvArgs a_in) {
                 const u32x4* g = reinterpret_cast<const u32x4*>(a.w0 + (size_t)row * K) + koff;    \
                 const u32x4* u = reinterpret_cast<const u32x4*>(a.w1 + (size_t)row * K) + koff;    \
                 _Pragma("unroll") for (int j = 0; j < NVW; ++j) {                                  \
-                    WB[LR * r][j] = ld_nt(g + j * 64 + lane);                                      \
-                    WB[LR * r + (LR - 1)][j] = ld_nt(u + j * 64 + lane);                           \
+                    const bool in = !tail || koff + j * 64 + lane < kvec;                          \
+                    WB[LR * r][j] = in ? ld_nt(g + j * 64 + lane) : u32x4{0u, 0u, 0u, 0u};         \
+                    WB[LR * r + (LR - 1)][j] = in ? ld_nt(u + j * 64 + lane) : u32x4{0u, 0u, 0u, 0u}; \
                 }                                                                                  \
             } else {                                                                               \
                 const u32x4* p = reinterpret_cast<const u32x4*>(row_ptr(a, row)) + koff;           \
-                _Pragma("unroll") for (int j = 0; j < NVW; ++j) WB[r][j] = ld_nt(p + j * 64 + lane); \
+                _Pragma("unroll") for (int j = 0; j < NVW; ++j)                                    \
+                    WB[r][j] = (!tail || koff + j * 64 + lane < kvec) ? ld_nt(p + j * 64 + lane) : u32x4{0u, 0u, 0u, 0u}; \
             }                                                                                      \
         }                                                                                          \
     }
@@ -165,7 +169,7 @@ __global__ __launch_bounds__(kBlock) void gemv_kernel(const GemvArgs a_in) {
         for (int i = 0; i < PV; ++i) {
             const int v = threadIdx.x + i * kBlock;
             if (v < NV * 64) {
-                u32x4 raw = *(reinterpret_cast<const u32x4*>(xg) + v);
+                u32x4 raw = v < kvec ? *(reinterpret_cast<const u32x4*>(xg) + v) : u32x4{0u, 0u, 0u, 0u};
                 if (a.x_partial) {
                     const f32x4 p0 = *(reinterpret_cast<const f32x4*>(a.x_partial) + 2 * v);
                     const f32x4 p1 = *(reinterpret_cast<const f32x4*>(a.x_partial) + 2 * v + 1);
@@ -287,7 +291,7 @@ int launch_nv(const GemvArgs& a, int pro, int epi, hipStream_t s) {
 // register-heavy (two in-flight register sets), 2 waves/SIMD for the 8-vector variants (1 for the
 // SwiGLU pair kernel), and a second round of blocks pays the cold-start latency again.
 static int resolve_rpw(int N, int K, int epi, int rpw) {
-    const bool split = (K / 512) > 8;
+    const bool split = ((K + 511) / 512) > 8;
     if (rpw <= 0) {
         // measured on MI355X (tools/gemv_sweep.py): short row groups in whole double-buffer rounds win;
         // small matrices want every CU busy (>= ~1500 waves), the vocabulary-sized one longer streams
@@ -303,14 +307,23 @@ static int resolve_rpw(int N, int K, int epi, int rpw) {
 int gemv_grid(int N, int K, int epi, int rows_per_wave) {
     const int rpw = resolve_rpw(N, K, epi, rows_per_wave);
     const int groups = (N + rpw - 1) / rpw;
-    return (K / 512) > 8 ? groups : (groups + kWaves - 1) / kWaves;
+    return ((K + 511) / 512) > 8 ? groups : (groups + kWaves - 1) / kWaves;
+}
+
+bool gemv_k_supported(int K, bool needs_full_vectors) {
+    if (K <= 0 || K % 8 != 0 || (needs_full_vectors && K % 512 != 0)) return false;
+    switch ((K + 511) / 512) {
+        case 1: case 2: case 3: case 4: case 6: case 8: case 12: case 16: case 24: case 28: return true;
+        default: return false;
+    }
 }
 
 int launch_gemv(const GemvArgs& a_in, int pro, int epi, hipStream_t s) {
     GemvArgs a = a_in;
-    OMX_REQUIRE(a.K > 0 && a.K % 512 == 0, "gemv: K=%d must be a positive multiple of 512", a.K);
+    OMX_REQUIRE(a.K > 0 && a.K % 8 == 0 && (a.K % 512 == 0 || (pro == PRO_NONE && !a.x_partial)),
+                "gemv: K=%d must be a positive multiple of 512 (of 8 without a prologue)", a.K);
     OMX_REQUIRE(a.N > 0, "gemv: N must be positive");
-    const int nv = a.K / 512;
+    const int nv = (a.K + 511) / 512;
     a.rows_per_wave = resolve_rpw(a.N, a.K, epi, a.rows_per_wave);
     switch (nv) {
         // RB*NVW ~ 16 x 1-KiB loads in flight per wave per register set

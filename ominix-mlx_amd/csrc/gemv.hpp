@@ -55,5 +55,7 @@ struct GemvArgs {
 int launch_gemv(const GemvArgs& a, int pro, int epi, hipStream_t s);
 // number of blocks launch_gemv will use (== entries written to argmax_slot); resolves rows_per_wave
 int gemv_grid(int N, int K, int epi, int rows_per_wave);
+// true when launch_gemv has a kernel for contraction width K (K not a multiple of 512 only without a prologue)
+bool gemv_k_supported(int K, bool needs_full_vectors);
 
 }  // namespace omx

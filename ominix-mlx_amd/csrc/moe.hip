@@ -25,49 +25,116 @@ constexpr int kMaxTopK = 8;
 
 // one block per token: logits[e] = bf16(x . Wg[e]) ; mode 0: top-k of logits, softmax over the selected
 // (precise) ; mode 1: softmax over all (precise, rounded to bf16), top-k, optional renormalisation
-__global__ __launch_bounds__(256) void moe_router_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ gate_w,
-                                                         int h, int E, int k, int mode, int renorm,
-                                                         uint32_t* __restrict__ inds, bf16_t* __restrict__ scores) {
+// One block (16 waves) per token.  Phase 1: the gate Linear -- wave w owns experts w, w+16, ..., four at a time so that
+// their row loads are in flight together.  Phase 2 (wave 0): softmax / top-k / renormalisation with the experts spread
+// over the lanes (E <= 256 -> four per lane): wave reductions instead of a serial scan by one thread (113 us -> a few us
+// at 128 experts).  Ties go to the lower expert index, selections come out in descending score order.
+constexpr int kRouterThreads = 1024;
+__global__ __launch_bounds__(kRouterThreads) void moe_router_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ gate_w,
+                                                                    int h, int E, int k, int mode, int renorm,
+                                                                    uint32_t* __restrict__ inds, bf16_t* __restrict__ scores,
+                                                                    const bf16_t* __restrict__ norm_w = nullptr, float eps = 0.f,
+                                                                    bf16_t* __restrict__ xn_out = nullptr) {
     __shared__ float s_logit[kMaxExperts];
-    const int t = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __shared__ float s_red[kRouterThreads / 64];
+    const int t = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = kRouterThreads / 64;
     const bf16_t* xr = x + (size_t)t * h;
-    for (int e = wave; e < E; e += 4) {
-        const bf16_t* wr = gate_w + (size_t)e * h;
-        float acc = 0.f;
+    if (norm_w) {   // post-attention RMSNorm of the decoder block folded in: xn = bf16(x * rstd * w), written for the experts
+        float ss = 0.f;
+        for (int i = threadIdx.x * 8; i < h; i += kRouterThreads * 8) {
+            const u32x4 a = *reinterpret_cast<const u32x4*>(xr + i);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { ss = fmaf(bf16lo(a[q]), bf16lo(a[q]), ss); ss = fmaf(bf16hi(a[q]), bf16hi(a[q]), ss); }
+        }
+        ss = wave_sum(ss);
+        if (lane == 0) s_red[wave] = ss;
+        __syncthreads();
+        float tot = 0.f;
+        for (int w = 0; w < n_waves; ++w) tot += s_red[w];
+        const float rstd = 1.0f / sqrtf(tot / (float)h + eps);
+        bf16_t* xo = xn_out + (size_t)t * h;
+        for (int i = threadIdx.x * 8; i < h; i += kRouterThreads * 8) {
+            const u32x4 a = *reinterpret_cast<const u32x4*>(xr + i);
+            const u32x4 w = *reinterpret_cast<const u32x4*>(norm_w + i);
+            u32x4 o;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) o[q] = pack_bf16(bf16lo(a[q]) * rstd * bf16lo(w[q]), bf16hi(a[q]) * rstd * bf16hi(w[q]));
+            *reinterpret_cast<u32x4*>(xo + i) = o;
+        }
+        __syncthreads();   // this block reads its own xn row back below (same CU: L1/L2 coherent within the block after the barrier)
+        __threadfence_block();
+        xr = xo;
+    }
+    for (int e0 = wave; e0 < E; e0 += 4 * n_waves) {
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
         for (int i = lane * 8; i < h; i += 64 * 8) {
             const u32x4 a = *reinterpret_cast<const u32x4*>(xr + i);
-            const u32x4 b = *reinterpret_cast<const u32x4*>(wr + i);
+            u32x4 b[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                acc = fmaf(bf16lo(a[q]), bf16lo(b[q]), acc);
-                acc = fmaf(bf16hi(a[q]), bf16hi(b[q]), acc);
-            }
+            for (int u = 0; u < 4; ++u) b[u] = *reinterpret_cast<const u32x4*>(gate_w + (size_t)min(e0 + u * n_waves, E - 1) * h + i);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    acc[u] = fmaf(bf16lo(a[q]), bf16lo(b[u][q]), acc[u]);
+                    acc[u] = fmaf(bf16hi(a[q]), bf16hi(b[u][q]), acc[u]);
+                }
         }
-        acc = wave_sum(acc);
-        if (lane == 0) s_logit[e] = round_bf16(acc);   // the gate Linear's output is a bf16 array
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float v = wave_sum(acc[u]);
+            const int e = e0 + u * n_waves;
+            if (lane == 0 && e < E) s_logit[e] = round_bf16(v);   // the gate Linear's output is a bf16 array
+        }
     }
     __syncthreads();
-    if (threadIdx.x != 0) return;
-    float v[kMaxExperts];
+    if (wave != 0) return;
+    constexpr int PER = kMaxExperts / 64;
+    float v[PER];
+    bool taken[PER];
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+        const int e = lane + 64 * u;
+        v[u] = e < E ? s_logit[e] : -INFINITY;
+        taken[u] = e >= E;
+    }
     if (mode == 1) {   // softmax over all experts first (qwen3_moe.rs:479)
-        float mx = -INFINITY, sum = 0.f;
-        for (int e = 0; e < E; ++e) mx = fmaxf(mx, s_logit[e]);
-        for (int e = 0; e < E; ++e) sum += expf(s_logit[e] - mx);
-        for (int e = 0; e < E; ++e) s_logit[e] = round_bf16(expf(s_logit[e] - mx) / sum);
+        float mx = -INFINITY;
+#pragma unroll
+        for (int u = 0; u < PER; ++u) mx = fmaxf(mx, v[u]);
+        mx = wave_max(mx);
+        float sum = 0.f;
+#pragma unroll
+        for (int u = 0; u < PER; ++u) sum += (lane + 64 * u < E) ? expf(v[u] - mx) : 0.f;
+        sum = wave_sum(sum);
+#pragma unroll
+        for (int u = 0; u < PER; ++u) v[u] = (lane + 64 * u < E) ? round_bf16(expf(v[u] - mx) / sum) : -INFINITY;
     }
     uint32_t sel[kMaxTopK];
     float selv[kMaxTopK];
-    unsigned long long taken[kMaxExperts / 64] = {0, 0, 0, 0};
-    for (int j = 0; j < k; ++j) {   // descending, ties to the lower index
-        int best = -1;
-        float bv = -INFINITY;
-        for (int e = 0; e < E; ++e)
-            if (!((taken[e >> 6] >> (e & 63)) & 1ull) && (best < 0 || s_logit[e] > bv)) { best = e; bv = s_logit[e]; }
-        taken[best >> 6] |= 1ull << (best & 63);
-        sel[j] = (uint32_t)best;
-        selv[j] = bv;
+    for (int j = 0; j < k; ++j) {   // descending, ties to the lower index: key = (orderable value, ~index)
+        unsigned long long best = 0;
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            if (taken[u]) continue;
+            uint32_t ub = __float_as_uint(v[u]);
+            ub = (ub & 0x80000000u) ? ~ub : (ub | 0x80000000u);
+            const unsigned long long key = ((unsigned long long)ub << 32) | (uint32_t)~(uint32_t)(lane + 64 * u);
+            best = key > best ? key : best;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const unsigned long long other = __shfl_xor(best, o, 64);
+            best = other > best ? other : best;
+        }
+        const uint32_t e = ~(uint32_t)(best & 0xFFFFFFFFull);
+        const uint32_t ub = (uint32_t)(best >> 32);
+        sel[j] = e;
+        selv[j] = __uint_as_float((ub & 0x80000000u) ? (ub & 0x7FFFFFFFu) : ~ub);
+#pragma unroll
+        for (int u = 0; u < PER; ++u)
+            if ((uint32_t)(lane + 64 * u) == e) taken[u] = true;
     }
-    (void)v;
     if (mode == 0) {   // softmax over the selected logits (model.rs:301-302)
         float mx = selv[0], sum = 0.f;
         for (int j = 1; j < k; ++j) mx = fmaxf(mx, selv[j]);
@@ -79,9 +146,11 @@ __global__ __launch_bounds__(256) void moe_router_kernel(const bf16_t* __restric
         sum = round_bf16(sum);
         for (int j = 0; j < k; ++j) selv[j] = round_bf16(selv[j] / sum);
     }
-    for (int j = 0; j < k; ++j) {
-        inds[(size_t)t * k + j] = sel[j];
-        scores[(size_t)t * k + j] = f32_to_bf16(selv[j]);
+    if (lane == 0) {
+        for (int j = 0; j < k; ++j) {
+            inds[(size_t)t * k + j] = sel[j];
+            scores[(size_t)t * k + j] = f32_to_bf16(selv[j]);
+        }
     }
 }
 
@@ -120,7 +189,8 @@ __global__ __launch_bounds__(1024) void moe_plan_kernel(const uint32_t* __restri
 // out[t] = bf16( sum_j bf16( y[pos(t,j)] * score[t,j] ) )     (model.rs:304-307)
 __global__ __launch_bounds__(256) void moe_combine_kernel(bf16_t* __restrict__ out, const bf16_t* __restrict__ y,
                                                           const bf16_t* __restrict__ scores,
-                                                          const uint32_t* __restrict__ pos_of_slot, int h, int k) {
+                                                          const uint32_t* __restrict__ pos_of_slot, int h, int k,
+                                                          const bf16_t* __restrict__ resid = nullptr) {
     const int t = blockIdx.x;
     for (int i = threadIdx.x * 8; i < h; i += 256 * 8) {
         float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -136,8 +206,14 @@ __global__ __launch_bounds__(256) void moe_combine_kernel(bf16_t* __restrict__ o
             }
         }
         u32x4 o;
+        if (resid) {   // decoder block: h + moe(h_normed), the block output rounded first (model.rs:343-344)
+            const u32x4 r = *reinterpret_cast<const u32x4*>(resid + (size_t)t * h + i);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) o[q] = pack_bf16(acc[2 * q], acc[2 * q + 1]);
+            for (int q = 0; q < 4; ++q) o[q] = pack_bf16(bf16lo(r[q]) + round_bf16(acc[2 * q]), bf16hi(r[q]) + round_bf16(acc[2 * q + 1]));
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) o[q] = pack_bf16(acc[2 * q], acc[2 * q + 1]);
+        }
         *reinterpret_cast<u32x4*>(out + (size_t)t * h + i) = o;
     }
 }
@@ -173,9 +249,17 @@ omx::bf16_t* g_dq = nullptr;      // dequantised expert stacks for the grouped-G
 size_t g_dq_cap = 0;
 }  // namespace
 
+struct BlockFusion {            // decoder-block glue folded into the MoE launches (engine): out = resid + moe(rmsnorm(x))
+    const void* norm_w = nullptr;
+    float eps = 0.f;
+    void* xn = nullptr;         // [n_tokens, hidden] scratch receiving the normalised rows
+    const void* resid = nullptr;
+};
+
 static int moe_forward_impl(void* out, const void* x, const void* gate_w, const void* w_gate, const void* w_up,
                             const void* w_down, const QExperts* q, int n_tokens, int hidden, int inter, int n_experts, int top_k,
-                            int mode, int norm_topk_prob, uint32_t* inds_out, void* scores_out, omx_stream stream) {
+                            int mode, int norm_topk_prob, uint32_t* inds_out, void* scores_out, omx_stream stream,
+                            const BlockFusion* bf = nullptr) {
     using namespace omx;
     OMX_REQUIRE(out && x && gate_w && (q || (w_gate && w_up && w_down)), "omx_moe_forward: null tensor");
     OMX_REQUIRE(n_tokens >= 0 && hidden > 0 && inter > 0, "omx_moe_forward: bad shape");
@@ -205,10 +289,13 @@ static int moe_forward_impl(void* out, const void* x, const void* gate_w, const 
     bf16_t* ubuf = (bf16_t*)take((size_t)slots * inter * 2);
     bf16_t* ybuf = (bf16_t*)take((size_t)slots * hidden * 2);
 
-    moe_router_kernel<<<n_tokens, 256, 0, s>>>((const bf16_t*)x, (const bf16_t*)gate_w, hidden, n_experts, top_k, mode,
-                                               norm_topk_prob, inds, scores);
+    moe_router_kernel<<<n_tokens, kRouterThreads, 0, s>>>((const bf16_t*)x, (const bf16_t*)gate_w, hidden, n_experts, top_k, mode,
+                                                          norm_topk_prob, inds, scores, bf ? (const bf16_t*)bf->norm_w : nullptr,
+                                                          bf ? bf->eps : 0.f, bf ? (bf16_t*)bf->xn : nullptr);
     OMX_LAUNCH_CHECK();
-    const bool decode = slots <= 32 && hidden % 512 == 0 && inter % 512 == 0;
+    if (bf && bf->norm_w) x = bf->xn;               // the experts read the normalised rows
+    const bf16_t* resid = bf ? (const bf16_t*)bf->resid : nullptr;
+    const bool decode = slots <= 32 && gemv_k_supported(hidden, false) && gemv_k_supported(inter, false);
     if (decode && q) {
         // gather_qmm x3 on the PACKED weights (model.rs:262-272 unsorted branch): expert-selected batched quantised GEMVs
         QGemvArgs a = {};
@@ -224,7 +311,7 @@ static int moe_forward_impl(void* out, const void* x, const void* gate_w, const 
         d.n_batch = slots; d.x_div = 1; d.w_sel = inds;
         d.w_estride = (size_t)hidden * inter * q->bits / 32; d.s_estride = (size_t)hidden * (inter / q->group);
         if (launch_qgemv(d, q->bits, PRO_NONE, EPI_STORE, s)) return 1;
-        moe_combine_kernel<<<n_tokens, 256, 0, s>>>((bf16_t*)out, ybuf, scores, nullptr, hidden, top_k);
+        moe_combine_kernel<<<n_tokens, 256, 0, s>>>((bf16_t*)out, ybuf, scores, nullptr, hidden, top_k, resid);
         OMX_LAUNCH_CHECK();
         if (inds_out) OMX_HIP_CHECK(hipMemcpyAsync(inds_out, inds, (size_t)slots * 4, hipMemcpyDeviceToDevice, s));
         if (scores_out) OMX_HIP_CHECK(hipMemcpyAsync(scores_out, scores, (size_t)slots * 2, hipMemcpyDeviceToDevice, s));
@@ -260,7 +347,7 @@ static int moe_forward_impl(void* out, const void* x, const void* gate_w, const 
         d.n_batch = slots; d.x_div = 1; d.x_bstride = inter; d.out_bstride_bytes = (size_t)hidden * 2;
         d.w_sel = inds; d.w_estride = (size_t)hidden * inter;
         if (launch_gemv(d, PRO_NONE, EPI_STORE, s)) return 1;
-        moe_combine_kernel<<<n_tokens, 256, 0, s>>>((bf16_t*)out, ybuf, scores, nullptr, hidden, top_k);
+        moe_combine_kernel<<<n_tokens, 256, 0, s>>>((bf16_t*)out, ybuf, scores, nullptr, hidden, top_k, resid);
         OMX_LAUNCH_CHECK();
     } else {
         moe_plan_kernel<<<1, 1024, 0, s>>>(inds, slots, n_experts, top_k, seg_start, row_src, pos_of_slot, tile_expert,
@@ -275,7 +362,7 @@ static int moe_forward_impl(void* out, const void* x, const void* gate_w, const 
         g.row_src = nullptr;   // activations are already in expert-sorted order
         g.w_estride = (size_t)hidden * inter;
         if (launch_gemm_bf16_grouped(ybuf, gbuf, (const bf16_t*)w_down, slots, hidden, inter, g, max_tiles, s)) return 1;
-        moe_combine_kernel<<<n_tokens, 256, 0, s>>>((bf16_t*)out, ybuf, scores, pos_of_slot, hidden, top_k);
+        moe_combine_kernel<<<n_tokens, 256, 0, s>>>((bf16_t*)out, ybuf, scores, pos_of_slot, hidden, top_k, resid);
         OMX_LAUNCH_CHECK();
     }
     if (inds_out) OMX_HIP_CHECK(hipMemcpyAsync(inds_out, inds, (size_t)slots * 4, hipMemcpyDeviceToDevice, s));
@@ -288,6 +375,19 @@ extern "C" int omx_moe_forward(void* out, const void* x, const void* gate_w, con
                                int mode, int norm_topk_prob, uint32_t* inds_out, void* scores_out, omx_stream stream) {
     return moe_forward_impl(out, x, gate_w, w_gate, w_up, w_down, nullptr, n_tokens, hidden, inter, n_experts, top_k, mode,
                             norm_topk_prob, inds_out, scores_out, stream);
+}
+
+/* decoder-block form for the engines: out = resid + moe(rmsnorm(x) * norm_w) -- the norm runs in the router launch, the
+ * residual in the combine launch; xn is a [n_tokens, hidden] scratch */
+extern "C" int omx_moe_block_forward(void* out, const void* resid, const void* x, const void* norm_w, float eps, void* xn,
+                                     const void* gate_w, const void* w_gate, const void* w_up, const void* w_down, int n_tokens,
+                                     int hidden, int inter, int n_experts, int top_k, int mode, int norm_topk_prob,
+                                     omx_stream stream) {
+    OMX_REQUIRE(resid && norm_w && xn, "omx_moe_block_forward: null tensor");
+    BlockFusion bf;
+    bf.norm_w = norm_w; bf.eps = eps; bf.xn = xn; bf.resid = resid;
+    return moe_forward_impl(out, x, gate_w, w_gate, w_up, w_down, nullptr, n_tokens, hidden, inter, n_experts, top_k, mode,
+                            norm_topk_prob, nullptr, nullptr, stream, &bf);
 }
 
 /* The reference's own Mixtral format: 4/8-bit expert stacks through gather_qmm (mixtral-mlx/src/model.rs:182-274).
@@ -322,7 +422,7 @@ extern "C" int omx_moe_route(uint32_t* inds_out, void* scores_out, const void* x
     OMX_REQUIRE(hidden > 0 && hidden % 64 == 0, "omx_moe_route: hidden=%d must be a multiple of 64", hidden);
     OMX_REQUIRE(mode == 0 || mode == 1, "omx_moe_route: mode must be 0 (Mixtral) or 1 (Qwen3-MoE)");
     if (n_tokens <= 0) return 0;
-    moe_router_kernel<<<n_tokens, 256, 0, (hipStream_t)stream>>>((const bf16_t*)x, (const bf16_t*)gate_w, hidden, n_experts,
+    moe_router_kernel<<<n_tokens, kRouterThreads, 0, (hipStream_t)stream>>>((const bf16_t*)x, (const bf16_t*)gate_w, hidden, n_experts,
                                                                  top_k, mode, norm_topk_prob, inds_out, (bf16_t*)scores_out);
     OMX_LAUNCH_CHECK();
     return 0;
@@ -357,7 +457,7 @@ extern "C" int omx_moe_experts(void* y, const void* x_rows, const uint32_t* expe
     bf16_t* gbuf = (bf16_t*)take((size_t)n_rows * inter * 2);
     bf16_t* ubuf = (bf16_t*)take((size_t)n_rows * inter * 2);
     bf16_t* ybuf = (bf16_t*)take((size_t)n_rows * hidden * 2);
-    if (n_rows <= 32 && hidden % 512 == 0 && inter % 512 == 0) {
+    if (n_rows <= 32 && gemv_k_supported(hidden, false) && gemv_k_supported(inter, false)) {
         GemvArgs a = {};
         a.w0 = (const bf16_t*)w_gate; a.w1 = (const bf16_t*)w_up; a.n0 = inter; a.N = inter; a.K = hidden;
         a.x = (const bf16_t*)x_rows; a.out = gbuf;

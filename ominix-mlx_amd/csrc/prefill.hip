@@ -34,7 +34,7 @@ __global__ __launch_bounds__(256) void qk_norm_rope_scatter_kernel(
     const bf16_t* src = is_q ? q_lin + ((size_t)t * H + hh) * D : k_lin + ((size_t)t * Hkv + (hh - H)) * D;
     const bf16_t* w = is_q ? q_norm_w : k_norm_w;
     const u32x4 r = *reinterpret_cast<const u32x4*>(src + c * 8);
-    const u32x4 wr = *reinterpret_cast<const u32x4*>(w + c * 8);
+    const u32x4 wr = w ? *reinterpret_cast<const u32x4*>(w + c * 8) : u32x4{0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};   // no q/k norm (Mixtral): weight 1
     float x[8], wv[8];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -45,7 +45,7 @@ __global__ __launch_bounds__(256) void qk_norm_rope_scatter_kernel(
 #pragma unroll
     for (int e = 0; e < 8; ++e) ss = fmaf(x[e], x[e], ss);
     ss = group_sum<LPR>(ss);
-    const float rstd = 1.0f / sqrtf(ss / (float)D + eps);
+    const float rstd = w ? 1.0f / sqrtf(ss / (float)D + eps) : 1.0f;   // without a norm the projection goes to RoPE as it is
     const int i0 = (c % (LPR / 2)) * 8;
     const bool first_half = c < LPR / 2;
     float y[8];

@@ -39,6 +39,14 @@ class Qwen3Config:
     tie_word_embeddings: bool = False
     rope_scaling: Optional[dict] = None
     max_position_embeddings: int = 40960
+    # sparse-MoE feed-forward in every layer (0 = dense): qwen3-mlx/src/qwen3_moe.rs ModelArgs :60-87 ("qwen3_moe") or
+    # mixtral-mlx/src/model.rs ModelArgs :54-80 ("mixtral", which also has no q/k norm: qk_norm False)
+    num_experts: int = 0
+    num_experts_per_tok: int = 0
+    moe_intermediate_size: int = 0
+    moe_mode: str = "qwen3_moe"
+    norm_topk_prob: bool = False
+    qk_norm: bool = True
 
     @staticmethod
     def qwen3_8b():
@@ -60,11 +68,20 @@ def weight_shapes(cfg: Qwen3Config) -> Dict[str, tuple]:
         s[p + "self_attn.k_proj.weight"] = (Hkv * D, h)
         s[p + "self_attn.v_proj.weight"] = (Hkv * D, h)
         s[p + "self_attn.o_proj.weight"] = (h, H * D)
-        s[p + "self_attn.q_norm.weight"] = (D,)
-        s[p + "self_attn.k_norm.weight"] = (D,)
-        s[p + "mlp.gate_proj.weight"] = (I, h)
-        s[p + "mlp.up_proj.weight"] = (I, h)
-        s[p + "mlp.down_proj.weight"] = (h, I)
+        if cfg.qk_norm:
+            s[p + "self_attn.q_norm.weight"] = (D,)
+            s[p + "self_attn.k_norm.weight"] = (D,)
+        if cfg.num_experts:
+            mp = p + ("block_sparse_moe." if cfg.moe_mode == "mixtral" else "mlp.")
+            E, Im = cfg.num_experts, cfg.moe_intermediate_size
+            s[mp + "gate.weight"] = (E, h)
+            s[mp + "switch_mlp.gate_proj.weight"] = (E, Im, h)
+            s[mp + "switch_mlp.up_proj.weight"] = (E, Im, h)
+            s[mp + "switch_mlp.down_proj.weight"] = (E, h, Im)
+        else:
+            s[p + "mlp.gate_proj.weight"] = (I, h)
+            s[p + "mlp.up_proj.weight"] = (I, h)
+            s[p + "mlp.down_proj.weight"] = (h, I)
         s[p + "input_layernorm.weight"] = (h,)
         s[p + "post_attention_layernorm.weight"] = (h,)
     if not cfg.tie_word_embeddings:
@@ -135,8 +152,9 @@ class Qwen3Oracle:
         q = q.reshape(B, L, cfg.num_attention_heads, -1).transpose(0, 2, 1, 3)
         k = k.reshape(B, L, cfg.num_key_value_heads, -1).transpose(0, 2, 1, 3)
         v = v.reshape(B, L, cfg.num_key_value_heads, -1).transpose(0, 2, 1, 3)
-        q = rc.rms_norm(q, self.w[p + "q_norm.weight"], cfg.rms_norm_eps, dt)
-        k = rc.rms_norm(k, self.w[p + "k_norm.weight"], cfg.rms_norm_eps, dt)
+        if cfg.qk_norm:      # Qwen3 (model.rs:181-184); Mixtral attention has none (mixtral model.rs:120-160)
+            q = rc.rms_norm(q, self.w[p + "q_norm.weight"], cfg.rms_norm_eps, dt)
+            k = rc.rms_norm(k, self.w[p + "k_norm.weight"], cfg.rms_norm_eps, dt)
         off = cache.offset()
         r = self.rope
         q = rc.rope(q, r["dims"], r["traditional"], r["base"], r["scale"], off, dt)
@@ -156,6 +174,15 @@ class Qwen3Oracle:
     def mlp(self, i: int, x):
         p = f"model.layers.{i}.mlp."
         dt = self.dt
+        cfg = self.cfg
+        if cfg.num_experts:   # MoeBlock::forward (qwen3_moe.rs:475-503) / MixtralSparseMoeBlock::forward (mixtral model.rs:296-308)
+            from . import ref_moe
+            mp = f"model.layers.{i}." + ("block_sparse_moe." if cfg.moe_mode == "mixtral" else "mlp.")
+            B, L, h = x.shape
+            y, _, _ = ref_moe.moe_block(x.reshape(B * L, h), self.w[mp + "gate.weight"], self.w[mp + "switch_mlp.gate_proj.weight"],
+                                        self.w[mp + "switch_mlp.up_proj.weight"], self.w[mp + "switch_mlp.down_proj.weight"],
+                                        cfg.num_experts_per_tok, cfg.moe_mode, cfg.norm_topk_prob, dt)
+            return y.reshape(B, L, h)
         g = self.lin(x, p + "gate_proj")
         u = self.lin(x, p + "up_proj")
         act = rc.multiply(rc.silu(g, dt), u, dt)

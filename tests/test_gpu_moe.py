@@ -190,3 +190,13 @@ def test_quantized_moe_rejects_bad_format(omx):
         moe.QuantizedSparseMoeBlock(z(2, 512), trip(512, 512), trip(512, 512), trip(512, 512), 1, 64, 3).forward(z(1, 512))
     with pytest.raises(omx.OmxError, match="group_size"):
         moe.QuantizedSparseMoeBlock(z(2, 512), trip(512, 512), trip(512, 512), trip(512, 512), 1, 48, 4).forward(z(1, 512))
+
+
+def test_moe_decode_with_intermediate_not_a_multiple_of_512(omx):
+    """Qwen3-30B-A3B: moe_intermediate_size 768 -- the expert-selected GEMV route with a partly filled last vector row
+    (down projection K = 768) must agree with the grouped-GEMM route and the oracle."""
+    E, h, I, k = 16, 512, 768, 4
+    gw, wg, wu, wd = _weights(E, h, I, 210)
+    for n_tokens in (1, 6, 40):
+        x = rc.bf16_round(rand((n_tokens, h), 220 + n_tokens))
+        _compare(_run(omx, x, gw, wg, wu, wd, k, "qwen3_moe"), rm.moe_block(x, gw, wg, wu, wd, k, "qwen3_moe"))

@@ -1,0 +1,88 @@
+"""The decode engine with a sparse-MoE feed-forward in every layer: Qwen3-MoE (qwen3-mlx/src/qwen3_moe.rs:304-508) and Mixtral
+(mixtral-mlx/src/model.rs:96-347: no q/k norm, top-2 softmax over the selected logits).  Oracle = Qwen3Oracle with the MoE
+block of oracle/ref_moe.py.  Tolerances as the dense engine (tests/test_gpu_qwen3.py); a router near-tie (k-th / (k+1)-th
+logit closer than the bf16 resolution of the logits) legitimately sends a token to another expert, so a step is only
+compared while the oracle's routing margins of that step exceed that resolution."""
+import numpy as np
+import pytest
+
+from oracle import ref_core as rc
+from oracle import ref_moe as rm
+from oracle import ref_qwen3 as rq
+from oracle import synth
+
+pytestmark = pytest.mark.gpu
+
+CONFIGS = {
+    "qwen3_moe": rq.Qwen3Config(1024, 2, 3072, 8, 2, 128, 2048, 1e-6, 1e6, False, None, 40960, 8, 2, 512, "qwen3_moe", True, True),
+    "qwen3_moe_no_renorm_top4": rq.Qwen3Config(512, 2, 1024, 4, 2, 128, 1024, 1e-6, 1e6, True, None, 40960, 16, 4, 512, "qwen3_moe", False, True),
+    "mixtral": rq.Qwen3Config(1024, 2, 1024, 8, 2, 128, 2048, 1e-5, 1e6, False, None, 40960, 4, 2, 1024, "mixtral", False, False),
+}
+
+
+def _engine(omx, cfg, weights=None, max_context=256):
+    from ominix_mlx_amd import engine
+    m = engine.Model(hidden_size=cfg.hidden_size, num_hidden_layers=cfg.num_hidden_layers, intermediate_size=cfg.intermediate_size,
+                     num_attention_heads=cfg.num_attention_heads, num_key_value_heads=cfg.num_key_value_heads, head_dim=cfg.head_dim,
+                     vocab_size=cfg.vocab_size, rms_norm_eps=cfg.rms_norm_eps, rope_theta=cfg.rope_theta,
+                     tie_word_embeddings=cfg.tie_word_embeddings, max_context=max_context, num_experts=cfg.num_experts,
+                     num_experts_per_tok=cfg.num_experts_per_tok, moe_intermediate_size=cfg.moe_intermediate_size,
+                     moe_mode=cfg.moe_mode, norm_topk_prob=cfg.norm_topk_prob, qk_norm=cfg.qk_norm)
+    m.synth_weights() if weights is None else m.load_weights(weights)
+    return m
+
+
+@pytest.mark.parametrize("name", list(CONFIGS))
+def test_moe_engine_decode_matches_oracle(omx, name):
+    cfg = CONFIGS[name]
+    weights = rq.synth_weights(cfg)
+    oracle = rq.Qwen3Oracle(cfg, weights)
+    n_prompt, n_new = 40, 8
+    prompt = synth.prompt_ids(n_prompt, cfg.vocab_size)
+    ref_tokens, ref_logits = oracle.generate(prompt, n_new, return_logits=True)
+    m = _engine(omx, cfg)                                    # device generator == oracle/synth.py
+    first = m.prefill(prompt)
+    logits0 = m.last_logits()
+    got = np.concatenate([[first], m.decode(n_new - 1)]).astype(np.uint32)
+    assert m.decode_path() == "graph" and m.offset() == n_prompt + n_new - 1
+    bound = 2.0 ** -7 * np.abs(ref_logits).max() * np.sqrt(cfg.num_hidden_layers) * 2     # two extra bf16 GEMMs per layer (experts)
+    assert np.abs(logits0 - ref_logits[0]).max() <= bound
+    margins = rc.argmax_margin(ref_logits)
+    for i in range(n_new):
+        if got[i] != ref_tokens[i]:
+            assert margins[i] <= 2 * bound, f"token {i}: got {got[i]} want {ref_tokens[i]} with margin {margins[i]:.4f}"
+            break
+    else:
+        np.testing.assert_array_equal(got, ref_tokens)
+    # uploaded weights == synthesized weights, bit for bit
+    m2 = _engine(omx, cfg, weights)
+    got2 = np.concatenate([[m2.prefill(prompt)], m2.decode(n_new - 1)]).astype(np.uint32)
+    np.testing.assert_array_equal(got2, got)
+    np.testing.assert_array_equal(m2.last_logits(), m.last_logits())
+
+
+def test_moe_engine_serial_and_batched_prefill_agree(omx, monkeypatch):
+    """The batched prefill takes the grouped-GEMM MoE route, the token-serial one the expert-selected GEMVs; same tokens
+    while routing margins are comfortable (checked through the logits bound)."""
+    cfg = CONFIGS["qwen3_moe"]
+    prompt = synth.prompt_ids(70, cfg.vocab_size)
+    outs = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("OMX_PREFILL_SERIAL", mode)
+        m = _engine(omx, cfg)
+        outs[mode] = (m.prefill(prompt), m.last_logits())
+    bound = 2.0 ** -7 * np.abs(outs["1"][1]).max() * np.sqrt(cfg.num_hidden_layers) * 2
+    assert np.abs(outs["0"][1] - outs["1"][1]).max() <= bound
+
+
+def test_moe_engine_rejects_bad_config(omx):
+    from ominix_mlx_amd import engine
+    base = dict(hidden_size=1024, num_hidden_layers=1, intermediate_size=1024, num_attention_heads=8, num_key_value_heads=2, head_dim=128,
+                vocab_size=1024, max_context=256)
+    with pytest.raises(omx.OmxError, match="InvalidConfig"):
+        engine.Model(**base, num_experts=4, num_experts_per_tok=5, moe_intermediate_size=512)
+    with pytest.raises(omx.OmxError, match="InvalidConfig"):
+        engine.Model(**base, num_experts=4, num_experts_per_tok=2, moe_intermediate_size=512, quantization={"bits": 4, "group_size": 64})
+    m = engine.Model(**base, num_experts=4, num_experts_per_tok=2, moe_intermediate_size=512)
+    with pytest.raises(omx.OmxError, match="WeightNotFound"):
+        m.prefill([1, 2, 3])

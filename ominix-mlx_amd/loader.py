@@ -113,11 +113,24 @@ def model_args(model_dir: str) -> dict:
     with open(os.path.join(model_dir, "config.json")) as f:
         c = json.load(f)
     head_dim = c.get("head_dim") or c["hidden_size"] // c["num_attention_heads"]
-    return dict(hidden_size=c["hidden_size"], num_hidden_layers=c["num_hidden_layers"], intermediate_size=c["intermediate_size"],
+    args = dict(hidden_size=c["hidden_size"], num_hidden_layers=c["num_hidden_layers"], intermediate_size=c["intermediate_size"],
                 num_attention_heads=c["num_attention_heads"], num_key_value_heads=c.get("num_key_value_heads", c["num_attention_heads"]),
                 head_dim=head_dim, vocab_size=c["vocab_size"], rms_norm_eps=c.get("rms_norm_eps", 1e-6),
                 rope_theta=c.get("rope_theta", 1e6), tie_word_embeddings=c.get("tie_word_embeddings", False),
                 rope_scaling=c.get("rope_scaling"), quantization=c.get("quantization"))
+    model_type = c.get("model_type", "")
+    if model_type == "mixtral" or "num_local_experts" in c:
+        # mixtral-mlx ModelArgs (model.rs:54-80): experts as wide as intermediate_size, top-2 of 8 by default, no q/k norm
+        args.update(num_experts=c.get("num_local_experts", 8), num_experts_per_tok=c.get("num_experts_per_tok", 2),
+                    moe_intermediate_size=c["intermediate_size"], moe_mode="mixtral", qk_norm=False,
+                    rms_norm_eps=c.get("rms_norm_eps", 1e-5))
+    elif c.get("num_experts", 0) > 0:
+        # qwen3-mlx qwen3_moe ModelArgs (qwen3_moe.rs:60-87); every layer sparse (decoder_sparse_step 1, no mlp_only_layers)
+        if c.get("decoder_sparse_step", 1) != 1 or c.get("mlp_only_layers"):
+            raise ValueError("load_model: mixed dense / sparse layers (decoder_sparse_step, mlp_only_layers) are not supported")
+        args.update(num_experts=c["num_experts"], num_experts_per_tok=c["num_experts_per_tok"],
+                    moe_intermediate_size=c["moe_intermediate_size"], moe_mode="qwen3_moe", norm_topk_prob=c.get("norm_topk_prob", False))
+    return args
 
 
 def load_model(model_dir: str, max_context: int = 4096, **overrides):
@@ -125,6 +138,8 @@ def load_model(model_dir: str, max_context: int = 4096, **overrides):
     from . import engine
     args = dict(model_args(model_dir), max_context=max_context, **overrides)
     weights = load_all_weights(model_dir)
+    if args.get("moe_mode") == "mixtral":
+        weights = sanitize_weights(weights, args["num_hidden_layers"], args["num_experts"])
     m = engine.Model(**args)
     tied = bool(args["tie_word_embeddings"])
     quant = args.get("quantization") is not None

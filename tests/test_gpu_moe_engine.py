@@ -86,3 +86,36 @@ def test_moe_engine_rejects_bad_config(omx):
     m = engine.Model(**base, num_experts=4, num_experts_per_tok=2, moe_intermediate_size=512)
     with pytest.raises(omx.OmxError, match="WeightNotFound"):
         m.prefill([1, 2, 3])
+
+
+def test_load_mixtral_checkpoint_directory(omx, tmp_path):
+    """mixtral_mlx::load_model (model.rs:466-600) on a bf16 checkpoint in the ORIGINAL layout (per-expert w1/w2/w3): config.json
+    -> MoE engine arguments, `sanitize_weights` stacks the experts, the engine generates what it generates from the same
+    tensors handed over directly."""
+    import json
+    from ominix_mlx_amd import loader
+    cfg = CONFIGS["mixtral"]
+    w = rq.synth_weights(cfg)
+    d = str(tmp_path)
+    json.dump({"model_type": "mixtral", "hidden_size": cfg.hidden_size, "num_hidden_layers": cfg.num_hidden_layers,
+               "intermediate_size": cfg.moe_intermediate_size, "num_attention_heads": cfg.num_attention_heads,
+               "num_key_value_heads": cfg.num_key_value_heads, "vocab_size": cfg.vocab_size, "rms_norm_eps": cfg.rms_norm_eps,
+               "rope_theta": cfg.rope_theta, "num_local_experts": cfg.num_experts, "num_experts_per_tok": cfg.num_experts_per_tok},
+              open(f"{d}/config.json", "w"))
+    raw = {}
+    for k, v in w.items():
+        if ".switch_mlp." in k:
+            proj = k.split(".switch_mlp.")[1].split(".")[0]
+            old = {"gate_proj": "w1", "down_proj": "w2", "up_proj": "w3"}[proj]
+            for e in range(cfg.num_experts):
+                raw[k.split(".switch_mlp.")[0] + f".experts.{e}.{old}.weight"] = v[e]
+        else:
+            raw[k] = v
+    loader.write_safetensors(f"{d}/model.safetensors", {k: rc.to_bf16_bits(v) for k, v in raw.items()}, bf16_names=tuple(raw))
+    prompt = synth.prompt_ids(24, cfg.vocab_size)
+    m = loader.load_model(d, max_context=256)
+    got = np.concatenate([[m.prefill(prompt)], m.decode(5)])
+    ref = _engine(omx, cfg, w)
+    want = np.concatenate([[ref.prefill(prompt)], ref.decode(5)])
+    np.testing.assert_array_equal(got, want)
+    np.testing.assert_array_equal(m.last_logits(), ref.last_logits())

@@ -252,6 +252,12 @@ int omx_moe_forward(void* out, const void* x, const void* gate_w, const void* w_
 int omx_moe_block_forward(void* out, const void* resid, const void* x, const void* norm_w, float eps, void* xn, const void* gate_w,
                           const void* w_gate, const void* w_up, const void* w_down, int n_tokens, int hidden, int inter,
                           int n_experts, int top_k, int mode, int norm_topk_prob, omx_stream stream);
+/* the same on a quantised checkpoint (mixtral-mlx/src/model.rs:560-600): router and expert stacks as MLX triplets */
+int omx_moe_block_forward_q(void* out, const void* resid, const void* x, const void* norm_w, float eps, void* xn,
+                            const void* q_router, const void* s_router, const void* b_router, const void* q_gate, const void* s_gate,
+                            const void* b_gate, const void* q_up, const void* s_up, const void* b_up, const void* q_down,
+                            const void* s_down, const void* b_down, int n_tokens, int hidden, int inter, int n_experts, int top_k,
+                            int mode, int norm_topk_prob, int group_size, int bits, omx_stream stream);
 /* the reference's own Mixtral format (mixtral-mlx/src/model.rs:182-274, QuantizedSwitchLinear -> mlx_gather_qmm x3):
  * expert stacks as MLX affine-quantised triplets, packed u32 [E, out, in*bits/32], scales / biases [E, out, in/group_size];
  * router gate bf16.  <= 32 routed slots: expert-selected GEMVs on the packed weights; more: dequantise + grouped GEMM. */

@@ -47,6 +47,7 @@ struct LayerW {
 // (weight u32, scales, biases) triplets; the norm weights stay bf16 in LayerW
 struct LayerQ {
     QMat q, k, v, o, gate, up, down;
+    QMat moe_router, moe_g, moe_u, moe_d;   // sparse-MoE feed-forward: quantised router and expert stacks
 };
 
 // dequantise ONE embedding row (QuantizedEmbedding::forward, mlx-rs/src/nn/quantized.rs:192-203) chosen by the step state
@@ -247,11 +248,18 @@ int resolve_weights(omx_qwen3 m) {
             L = LayerW{};
             if (getq(p + "self_attn.q_proj", m->H * D, &Q.q) || getq(p + "self_attn.k_proj", m->Hkv * D, &Q.k) ||
                 getq(p + "self_attn.v_proj", m->Hkv * D, &Q.v) || getq(p + "self_attn.o_proj", hd, &Q.o) ||
-                getq(p + "mlp.gate_proj", m->I, &Q.gate) || getq(p + "mlp.up_proj", m->I, &Q.up) ||
-                getq(p + "mlp.down_proj", hd, &Q.down) || get(p + "self_attn.q_norm.weight", &L.q_norm) ||
-                get(p + "self_attn.k_norm.weight", &L.k_norm) || get(p + "input_layernorm.weight", &L.in_ln) ||
-                get(p + "post_attention_layernorm.weight", &L.post_ln))
+                get(p + "input_layernorm.weight", &L.in_ln) || get(p + "post_attention_layernorm.weight", &L.post_ln))
                 return 1;
+            if (!m->cfg.no_qk_norm && (get(p + "self_attn.q_norm.weight", &L.q_norm) || get(p + "self_attn.k_norm.weight", &L.k_norm))) return 1;
+            if (m->cfg.num_experts > 0) {
+                const std::string mp = p + (m->cfg.moe_mode == 0 ? "block_sparse_moe." : "mlp.");
+                const int Im = m->cfg.moe_intermediate_size;
+                if (getq(mp + "gate", m->cfg.num_experts, &Q.moe_router) || getq(mp + "switch_mlp.gate_proj", Im, &Q.moe_g) ||
+                    getq(mp + "switch_mlp.up_proj", Im, &Q.moe_u) || getq(mp + "switch_mlp.down_proj", hd, &Q.moe_d))
+                    return 1;
+            } else if (getq(p + "mlp.gate_proj", m->I, &Q.gate) || getq(p + "mlp.up_proj", m->I, &Q.up) || getq(p + "mlp.down_proj", hd, &Q.down)) {
+                return 1;
+            }
         }
         if (getq("model.embed_tokens", m->cfg.vocab_size, &m->q_embed) || get("model.norm.weight", &m->final_norm)) return 1;
         if (m->cfg.tie_word_embeddings) m->q_head = m->q_embed;            // QuantizedEmbedding::as_linear (quantized.rs:166-180)
@@ -334,6 +342,15 @@ int enqueue_step_quant(omx_qwen3 m, bool with_head) {
             a.x = m->attn_out; a.resid = h; a.out = hn;
             if (launch_qgemv(a, bits, PRO_NONE, EPI_RESIDUAL, s)) return 1;
             bf16_t* t = h; h = hn; hn = t;
+        }
+        if (c.num_experts > 0) {   // [RMSNorm + router] [selection] [RMSNorm + expert gate/up + SwiGLU] [expert down] [sum + residual]
+            if (omx_moe_block_forward_q(hn, h, h, L.post_ln, c.rms_norm_eps, m->moe_xn, Q.moe_router.w, Q.moe_router.scales,
+                                        Q.moe_router.biases, Q.moe_g.w, Q.moe_g.scales, Q.moe_g.biases, Q.moe_u.w, Q.moe_u.scales,
+                                        Q.moe_u.biases, Q.moe_d.w, Q.moe_d.scales, Q.moe_d.biases, 1, hd, c.moe_intermediate_size,
+                                        c.num_experts, c.num_experts_per_tok, c.moe_mode, c.norm_topk_prob, group, bits, s))
+                return 1;
+            bf16_t* t = h; h = hn; hn = t;
+            continue;
         }
         {   // [RMSNorm + gate/up + SwiGLU]
             QGemvArgs a = {};
@@ -721,10 +738,19 @@ int prefill_prefix_batched(omx_qwen3 m, int T, int off, const EncodeOpts* enc = 
         if (!(w = W(L.o, &Q.o, H * D)) || launch_gemm_bf16_ex(h2, m->pf_attn, w, nullptr, h, T, hd, H * D, s)) return 1;
         if (omx_rms_norm(m->pf_xn, h2, L.post_ln, T, hd, c.rms_norm_eps, OMX_BFLOAT16, s)) return 1;
         if (c.num_experts > 0) {   // sparse-MoE feed-forward over all T rows (grouped MFMA GEMM route), then the residual
-            if (omx_moe_forward(m->pf_attn, m->pf_xn, L.moe_gate, L.moe_wg, L.moe_wu, L.moe_wd, T, hd, c.moe_intermediate_size,
-                                c.num_experts, c.num_experts_per_tok, c.moe_mode, c.norm_topk_prob, nullptr, nullptr, s))
-                return 1;
-            if (omx_add(h, h2, m->pf_attn, (int64_t)T * hd, OMX_BFLOAT16, s)) return 1;
+            if (quant) {
+                if (omx_moe_block_forward_q(h, h2, h2, L.post_ln, c.rms_norm_eps, m->pf_xn, Q.moe_router.w, Q.moe_router.scales,
+                                            Q.moe_router.biases, Q.moe_g.w, Q.moe_g.scales, Q.moe_g.biases, Q.moe_u.w, Q.moe_u.scales,
+                                            Q.moe_u.biases, Q.moe_d.w, Q.moe_d.scales, Q.moe_d.biases, T, hd, c.moe_intermediate_size,
+                                            c.num_experts, c.num_experts_per_tok, c.moe_mode, c.norm_topk_prob, c.quant_group,
+                                            c.quant_bits, s))
+                    return 1;
+            } else {
+                if (omx_moe_forward(m->pf_attn, m->pf_xn, L.moe_gate, L.moe_wg, L.moe_wu, L.moe_wd, T, hd, c.moe_intermediate_size,
+                                    c.num_experts, c.num_experts_per_tok, c.moe_mode, c.norm_topk_prob, nullptr, nullptr, s))
+                    return 1;
+                if (omx_add(h, h2, m->pf_attn, (int64_t)T * hd, OMX_BFLOAT16, s)) return 1;
+            }
             if (enc && next_tap < enc->n_taps && enc->taps[next_tap] == l) {
                 copy_rows_strided_kernel<<<1024, 256, 0, s>>>(enc->out + (size_t)next_tap * hd, (int64_t)enc->n_taps * hd, h, hd, T, hd / 8);
                 ++next_tap;
@@ -799,7 +825,8 @@ int omx_qwen3_create(omx_qwen3* out, const omx_qwen3_config* cfg) {
     const int cap_splits = (512 + m->Hkv - 1) / m->Hkv;
     if (m->nsplit > cap_splits) m->nsplit = cap_splits;
     if (c.num_experts > 0) {
-        OMX_REQUIRE(c.tp_size == 1 && !c.quant_bits, "InvalidConfig: the sparse-MoE engine is single-GPU bf16 (tp_size %d, quant bits %d)", c.tp_size, c.quant_bits);
+        OMX_REQUIRE(c.tp_size == 1, "InvalidConfig: the sparse-MoE engine is single-GPU (tp_size %d)", c.tp_size);
+        OMX_REQUIRE(!c.quant_bits || c.moe_intermediate_size % 512 == 0, "InvalidConfig: quantised experts need moe_intermediate_size %% 512 == 0 (%d)", c.moe_intermediate_size);
         OMX_REQUIRE(c.num_experts_per_tok >= 1 && c.num_experts_per_tok <= c.num_experts && c.moe_intermediate_size > 0 &&
                         c.moe_intermediate_size % 64 == 0 && (c.moe_mode == 0 || c.moe_mode == 1) && m->H * D >= c.hidden_size,
                     "InvalidConfig: experts %d top-%d moe_intermediate_size %d mode %d", c.num_experts, c.num_experts_per_tok,
@@ -899,7 +926,8 @@ int omx_qwen3_synth_weights(omx_qwen3 m, uint32_t base_seed) {
         // the quantized model IS mlx quantize() of the synthetic bf16 model: generate each logical matrix into a scratch
         // buffer with the bf16 generator, quantise it on the device, keep only the (weight, scales, biases) triplet
         bf16_t* scratch = nullptr;
-        const size_t biggest = (size_t)std::max((int64_t)c.vocab_size, (int64_t)std::max(m->I, Hq)) * (size_t)std::max(hd, m->I);
+        size_t biggest = (size_t)std::max((int64_t)c.vocab_size, (int64_t)std::max(m->I, Hq)) * (size_t)std::max(hd, m->I);
+        if (c.num_experts > 0) biggest = std::max(biggest, (size_t)c.num_experts * c.moe_intermediate_size * (size_t)hd);   // a whole expert stack
         OMX_HIP_CHECK(hipMalloc((void**)&scratch, biggest * 2));
         auto makeq = [&](const std::string& prefix, int64_t rows, int64_t cols) -> int {
             const uint32_t seed = base_seed ^ crc32_str((prefix + ".weight").c_str());
@@ -919,10 +947,17 @@ int omx_qwen3_synth_weights(omx_qwen3 m, uint32_t base_seed) {
         for (int i = 0; i < c.num_hidden_layers && !rc; ++i) {
             const std::string p = "model.layers." + std::to_string(i) + ".";
             rc = makeq(p + "self_attn.q_proj", Hq, hd) || makeq(p + "self_attn.k_proj", Hk, hd) || makeq(p + "self_attn.v_proj", Hk, hd) ||
-                 makeq(p + "self_attn.o_proj", hd, Hq) || makeq(p + "mlp.gate_proj", m->I, hd) || makeq(p + "mlp.up_proj", m->I, hd) ||
-                 makeq(p + "mlp.down_proj", hd, m->I) || make(p + "self_attn.q_norm.weight", 1, D, D, 0, 0, true) ||
-                 make(p + "self_attn.k_norm.weight", 1, D, D, 0, 0, true) || make(p + "input_layernorm.weight", 1, hd, hd, 0, 0, true) ||
+                 makeq(p + "self_attn.o_proj", hd, Hq) || make(p + "input_layernorm.weight", 1, hd, hd, 0, 0, true) ||
                  make(p + "post_attention_layernorm.weight", 1, hd, hd, 0, 0, true);
+            if (!rc && !c.no_qk_norm) rc = make(p + "self_attn.q_norm.weight", 1, D, D, 0, 0, true) || make(p + "self_attn.k_norm.weight", 1, D, D, 0, 0, true);
+            if (!rc && c.num_experts > 0) {
+                const std::string mp = p + (c.moe_mode == 0 ? "block_sparse_moe." : "mlp.");
+                const int64_t E = c.num_experts, Im = c.moe_intermediate_size;
+                rc = makeq(mp + "gate", E, hd) || makeq(mp + "switch_mlp.gate_proj", E * Im, hd) || makeq(mp + "switch_mlp.up_proj", E * Im, hd) ||
+                     makeq(mp + "switch_mlp.down_proj", E * hd, Im);
+            } else if (!rc) {
+                rc = makeq(p + "mlp.gate_proj", m->I, hd) || makeq(p + "mlp.up_proj", m->I, hd) || makeq(p + "mlp.down_proj", hd, m->I);
+            }
         }
         rc = rc || makeq("model.embed_tokens", c.vocab_size, hd) || make("model.norm.weight", 1, hd, hd, 0, 0, true);
         if (!rc && !c.tie_word_embeddings) rc = makeq("lm_head", m->V, hd);

@@ -25,6 +25,75 @@ constexpr int kMaxTopK = 8;
 
 // one block per token: logits[e] = bf16(x . Wg[e]) ; mode 0: top-k of logits, softmax over the selected
 // (precise) ; mode 1: softmax over all (precise, rounded to bf16), top-k, optional renormalisation
+// softmax / top-k / renormalisation of one token's router logits by ONE wave (experts spread over the lanes)
+__device__ __forceinline__ void route_from_logits(const float* s_logit, int t, int lane, int E, int k, int mode, int renorm,
+                                                  uint32_t* __restrict__ inds, bf16_t* __restrict__ scores) {
+    constexpr int PER = kMaxExperts / 64;
+    float v[PER];
+    bool taken[PER];
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+        const int e = lane + 64 * u;
+        v[u] = e < E ? s_logit[e] : -INFINITY;
+        taken[u] = e >= E;
+    }
+    if (mode == 1) {   // softmax over all experts first (qwen3_moe.rs:479)
+        float mx = -INFINITY;
+#pragma unroll
+        for (int u = 0; u < PER; ++u) mx = fmaxf(mx, v[u]);
+        mx = wave_max(mx);
+        float sum = 0.f;
+#pragma unroll
+        for (int u = 0; u < PER; ++u) sum += (lane + 64 * u < E) ? expf(v[u] - mx) : 0.f;
+        sum = wave_sum(sum);
+#pragma unroll
+        for (int u = 0; u < PER; ++u) v[u] = (lane + 64 * u < E) ? round_bf16(expf(v[u] - mx) / sum) : -INFINITY;
+    }
+    uint32_t sel[kMaxTopK];
+    float selv[kMaxTopK];
+    for (int j = 0; j < k; ++j) {   // descending, ties to the lower index: key = (orderable value, ~index)
+        unsigned long long best = 0;
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            if (taken[u]) continue;
+            uint32_t ub = __float_as_uint(v[u]);
+            ub = (ub & 0x80000000u) ? ~ub : (ub | 0x80000000u);
+            const unsigned long long key = ((unsigned long long)ub << 32) | (uint32_t)~(uint32_t)(lane + 64 * u);
+            best = key > best ? key : best;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const unsigned long long other = __shfl_xor(best, o, 64);
+            best = other > best ? other : best;
+        }
+        const uint32_t e = ~(uint32_t)(best & 0xFFFFFFFFull);
+        const uint32_t ub = (uint32_t)(best >> 32);
+        sel[j] = e;
+        selv[j] = __uint_as_float((ub & 0x80000000u) ? (ub & 0x7FFFFFFFu) : ~ub);
+#pragma unroll
+        for (int u = 0; u < PER; ++u)
+            if ((uint32_t)(lane + 64 * u) == e) taken[u] = true;
+    }
+    if (mode == 0) {   // softmax over the selected logits (model.rs:301-302)
+        float mx = selv[0], sum = 0.f;
+        for (int j = 1; j < k; ++j) mx = fmaxf(mx, selv[j]);
+        for (int j = 0; j < k; ++j) sum += expf(selv[j] - mx);
+        for (int j = 0; j < k; ++j) selv[j] = round_bf16(expf(selv[j] - mx) / sum);
+    } else if (renorm && k > 1) {
+        float sum = 0.f;
+        for (int j = 0; j < k; ++j) sum += selv[j];
+        sum = round_bf16(sum);
+        for (int j = 0; j < k; ++j) selv[j] = round_bf16(selv[j] / sum);
+    }
+    if (lane == 0) {
+        for (int j = 0; j < k; ++j) {
+            inds[(size_t)t * k + j] = sel[j];
+            scores[(size_t)t * k + j] = f32_to_bf16(selv[j]);
+        }
+    }
+}
+
+
 // One block (16 waves) per token.  Phase 1: the gate Linear -- wave w owns experts w, w+16, ..., four at a time so that
 // their row loads are in flight together.  Phase 2 (wave 0): softmax / top-k / renormalisation with the experts spread
 // over the lanes (E <= 256 -> four per lane): wave reductions instead of a serial scan by one thread (113 us -> a few us
@@ -89,69 +158,17 @@ __global__ __launch_bounds__(kRouterThreads) void moe_router_kernel(const bf16_t
     }
     __syncthreads();
     if (wave != 0) return;
-    constexpr int PER = kMaxExperts / 64;
-    float v[PER];
-    bool taken[PER];
-#pragma unroll
-    for (int u = 0; u < PER; ++u) {
-        const int e = lane + 64 * u;
-        v[u] = e < E ? s_logit[e] : -INFINITY;
-        taken[u] = e >= E;
-    }
-    if (mode == 1) {   // softmax over all experts first (qwen3_moe.rs:479)
-        float mx = -INFINITY;
-#pragma unroll
-        for (int u = 0; u < PER; ++u) mx = fmaxf(mx, v[u]);
-        mx = wave_max(mx);
-        float sum = 0.f;
-#pragma unroll
-        for (int u = 0; u < PER; ++u) sum += (lane + 64 * u < E) ? expf(v[u] - mx) : 0.f;
-        sum = wave_sum(sum);
-#pragma unroll
-        for (int u = 0; u < PER; ++u) v[u] = (lane + 64 * u < E) ? round_bf16(expf(v[u] - mx) / sum) : -INFINITY;
-    }
-    uint32_t sel[kMaxTopK];
-    float selv[kMaxTopK];
-    for (int j = 0; j < k; ++j) {   // descending, ties to the lower index: key = (orderable value, ~index)
-        unsigned long long best = 0;
-#pragma unroll
-        for (int u = 0; u < PER; ++u) {
-            if (taken[u]) continue;
-            uint32_t ub = __float_as_uint(v[u]);
-            ub = (ub & 0x80000000u) ? ~ub : (ub | 0x80000000u);
-            const unsigned long long key = ((unsigned long long)ub << 32) | (uint32_t)~(uint32_t)(lane + 64 * u);
-            best = key > best ? key : best;
-        }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const unsigned long long other = __shfl_xor(best, o, 64);
-            best = other > best ? other : best;
-        }
-        const uint32_t e = ~(uint32_t)(best & 0xFFFFFFFFull);
-        const uint32_t ub = (uint32_t)(best >> 32);
-        sel[j] = e;
-        selv[j] = __uint_as_float((ub & 0x80000000u) ? (ub & 0x7FFFFFFFu) : ~ub);
-#pragma unroll
-        for (int u = 0; u < PER; ++u)
-            if ((uint32_t)(lane + 64 * u) == e) taken[u] = true;
-    }
-    if (mode == 0) {   // softmax over the selected logits (model.rs:301-302)
-        float mx = selv[0], sum = 0.f;
-        for (int j = 1; j < k; ++j) mx = fmaxf(mx, selv[j]);
-        for (int j = 0; j < k; ++j) sum += expf(selv[j] - mx);
-        for (int j = 0; j < k; ++j) selv[j] = round_bf16(expf(selv[j] - mx) / sum);
-    } else if (renorm && k > 1) {
-        float sum = 0.f;
-        for (int j = 0; j < k; ++j) sum += selv[j];
-        sum = round_bf16(sum);
-        for (int j = 0; j < k; ++j) selv[j] = round_bf16(selv[j] / sum);
-    }
-    if (lane == 0) {
-        for (int j = 0; j < k; ++j) {
-            inds[(size_t)t * k + j] = sel[j];
-            scores[(size_t)t * k + j] = f32_to_bf16(selv[j]);
-        }
-    }
+    route_from_logits(s_logit, t, lane, E, k, mode, renorm, inds, scores);
+}
+
+// logits [n_tokens, E] already computed (quantised router: qgemv on the packed gate): selection only, one wave per token
+__global__ __launch_bounds__(64) void moe_route_logits_kernel(const bf16_t* __restrict__ logits, int E, int k, int mode, int renorm,
+                                                              uint32_t* __restrict__ inds, bf16_t* __restrict__ scores) {
+    __shared__ float s_logit[kMaxExperts];
+    const int t = blockIdx.x, lane = threadIdx.x;
+    for (int e = lane; e < E; e += 64) s_logit[e] = bf16_to_f32(logits[(size_t)t * E + e]);
+    __syncthreads();
+    route_from_logits(s_logit, t, lane, E, k, mode, renorm, inds, scores);
 }
 
 // counting sort of the N*k (token, slot) pairs by expert + tile table of the grouped GEMM (single block)
@@ -388,6 +405,90 @@ extern "C" int omx_moe_block_forward(void* out, const void* resid, const void* x
     bf.norm_w = norm_w; bf.eps = eps; bf.xn = xn; bf.resid = resid;
     return moe_forward_impl(out, x, gate_w, w_gate, w_up, w_down, nullptr, n_tokens, hidden, inter, n_experts, top_k, mode,
                             norm_topk_prob, nullptr, nullptr, stream, &bf);
+}
+
+/* decoder-block form on a quantised checkpoint (mixtral-mlx/src/model.rs:560-600: gate = QuantizedLinear, switch_mlp =
+ * QuantizedSwitchLinear x3).  Few tokens (<= 32 routed slots): router logits = quantised GEMV on the packed gate with the
+ * RMSNorm prologue, selection, expert GEMVs on the packed stacks (RMSNorm prologue again: x is raw), weighted sum + residual.
+ * More tokens: RMSNorm rows, router and experts dequantised once (what MLX's qmm does per tile), grouped GEMM route. */
+extern "C" int omx_moe_block_forward_q(void* out, const void* resid, const void* x, const void* norm_w, float eps, void* xn,
+                                       const void* q_router, const void* s_router, const void* b_router, const void* q_gate,
+                                       const void* s_gate, const void* b_gate, const void* q_up, const void* s_up, const void* b_up,
+                                       const void* q_down, const void* s_down, const void* b_down, int n_tokens, int hidden, int inter,
+                                       int n_experts, int top_k, int mode, int norm_topk_prob, int group_size, int bits,
+                                       omx_stream stream) {
+    using namespace omx;
+    OMX_REQUIRE(out && resid && x && norm_w && xn && q_router && s_router && b_router && q_gate && s_gate && b_gate && q_up && s_up &&
+                    b_up && q_down && s_down && b_down, "omx_moe_block_forward_q: null tensor");
+    OMX_REQUIRE(bits == 4 || bits == 8, "omx_moe_block_forward_q: bits=%d (4 or 8)", bits);
+    OMX_REQUIRE(hidden % 512 == 0 && inter % 512 == 0, "omx_moe_block_forward_q: hidden=%d and intermediate=%d must be multiples of 512", hidden, inter);
+    OMX_REQUIRE(n_experts >= 1 && n_experts <= kMaxExperts && top_k >= 1 && top_k <= kMaxTopK && top_k <= n_experts, "omx_moe_block_forward_q: experts %d top-%d", n_experts, top_k);
+    if (n_tokens == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    QExperts q;
+    q.gate = QMat{(const uint32_t*)q_gate, (const bf16_t*)s_gate, (const bf16_t*)b_gate, inter};
+    q.up = QMat{(const uint32_t*)q_up, (const bf16_t*)s_up, (const bf16_t*)b_up, inter};
+    q.down = QMat{(const uint32_t*)q_down, (const bf16_t*)s_down, (const bf16_t*)b_down, hidden};
+    q.group = group_size; q.bits = bits;
+    const int slots = n_tokens * top_k;
+    if (slots > 32) {
+        // dequantised router (tiny) lives behind the expert scratch; rows normalised once
+        static bf16_t* router_dq = nullptr;
+        static size_t router_cap = 0;
+        if ((size_t)n_experts * hidden > router_cap) {
+            OMX_HIP_CHECK(hipStreamSynchronize(s));
+            if (router_dq) OMX_HIP_CHECK(hipFree(router_dq));
+            OMX_HIP_CHECK(hipMalloc((void**)&router_dq, (size_t)n_experts * hidden * 2));
+            router_cap = (size_t)n_experts * hidden;
+        }
+        if (omx_dequantize(router_dq, q_router, s_router, b_router, n_experts, hidden, group_size, bits, OMX_BFLOAT16, stream)) return 1;
+        if (omx_rms_norm(xn, x, norm_w, n_tokens, hidden, eps, OMX_BFLOAT16, stream)) return 1;
+        BlockFusion bf;
+        bf.resid = resid;
+        return moe_forward_impl(out, xn, router_dq, nullptr, nullptr, nullptr, &q, n_tokens, hidden, inter, n_experts, top_k, mode,
+                                norm_topk_prob, nullptr, nullptr, stream, &bf);
+    }
+    size_t need = 0;
+    omx_moe_workspace_bytes(n_tokens, hidden, inter, n_experts, top_k, &need);
+    void* ws = nullptr;
+    if (get_workspace(&ws, need)) return 1;
+    char* p = (char*)ws;
+    auto take = [&](size_t bytes) { char* r = p; p += (bytes + 255) & ~(size_t)255; return r; };
+    uint32_t* inds = (uint32_t*)take((size_t)slots * 4);
+    take((size_t)slots * 4); take((size_t)slots * 4);
+    bf16_t* scores = (bf16_t*)take((size_t)slots * 2);
+    take((size_t)(n_experts + 2) * 4);
+    const int max_tiles = slots / 128 + n_experts + 1;
+    take((size_t)max_tiles * 4); take((size_t)max_tiles * 4); take(256);
+    bf16_t* gbuf = (bf16_t*)take((size_t)slots * inter * 2);
+    bf16_t* logits = (bf16_t*)take((size_t)slots * inter * 2);      // the `ubuf` slot: n_tokens * E <= slots * inter
+    bf16_t* ybuf = (bf16_t*)take((size_t)slots * hidden * 2);
+    {   // router: logits[t, e] = rmsnorm(x_t) . dequant(gate[e])  (quantized_matmul, nn/quantized.rs:366-375)
+        QGemvArgs a = {};
+        a.m[0] = QMat{(const uint32_t*)q_router, (const bf16_t*)s_router, (const bf16_t*)b_router, n_experts};
+        a.N = n_experts; a.K = hidden; a.group = group_size;
+        a.x = (const bf16_t*)x; a.norm_w = (const bf16_t*)norm_w; a.eps = eps; a.out = logits;
+        a.n_batch = n_tokens; a.x_div = 1;
+        if (launch_qgemv(a, bits, PRO_RMSNORM, EPI_STORE, s)) return 1;
+        moe_route_logits_kernel<<<n_tokens, 64, 0, s>>>(logits, n_experts, top_k, mode, norm_topk_prob, inds, scores);
+        OMX_LAUNCH_CHECK();
+    }
+    QGemvArgs a = {};
+    a.m[0] = q.gate; a.m[1] = q.up; a.N = inter; a.K = hidden; a.group = group_size;
+    a.x = (const bf16_t*)x; a.norm_w = (const bf16_t*)norm_w; a.eps = eps; a.out = gbuf;
+    a.n_batch = slots; a.x_div = top_k; a.w_sel = inds;
+    a.w_estride = (size_t)inter * hidden * bits / 32; a.s_estride = (size_t)inter * (hidden / group_size);
+    a.swiglu_single_round = 1;
+    if (launch_qgemv(a, bits, PRO_RMSNORM, EPI_SWIGLU, s)) return 1;
+    QGemvArgs d = {};
+    d.m[0] = q.down; d.N = hidden; d.K = inter; d.group = group_size;
+    d.x = gbuf; d.out = ybuf;
+    d.n_batch = slots; d.x_div = 1; d.w_sel = inds;
+    d.w_estride = (size_t)hidden * inter * bits / 32; d.s_estride = (size_t)hidden * (inter / group_size);
+    if (launch_qgemv(d, bits, PRO_NONE, EPI_STORE, s)) return 1;
+    moe_combine_kernel<<<n_tokens, 256, 0, s>>>((bf16_t*)out, ybuf, scores, nullptr, hidden, top_k, (const bf16_t*)resid);
+    OMX_LAUNCH_CHECK();
+    return 0;
 }
 
 /* The reference's own Mixtral format: 4/8-bit expert stacks through gather_qmm (mixtral-mlx/src/model.rs:182-274).

@@ -29,12 +29,27 @@ def topk_indices(scores: np.ndarray, k: int) -> np.ndarray:
     return order[..., :k]
 
 
-def route_mixtral(x, gate_w, k: int, dt: str = "bf16"):
-    """model.rs:296-302 -> (inds [.., k], scores [.., k] in dt)."""
-    gates = rc.linear(x, gate_w, None, dt)
+def route_logits_mixtral(gates, k: int, dt: str = "bf16"):
+    """model.rs:298-302 from the gate Linear's output (dense or quantised)."""
     inds = topk_indices(gates, k)
     sel = np.take_along_axis(gates, inds, axis=-1)
     return inds, rc.softmax(sel, -1, dt)
+
+
+def route_mixtral(x, gate_w, k: int, dt: str = "bf16"):
+    """model.rs:296-302 -> (inds [.., k], scores [.., k] in dt)."""
+    return route_logits_mixtral(rc.linear(x, gate_w, None, dt), k, dt)
+
+
+def route_logits_qwen3_moe(logits, k: int, norm_topk_prob: bool, dt: str = "bf16"):
+    """qwen3_moe.rs:479-494 from the gate Linear's output."""
+    gates = rc.softmax(logits, -1, dt)
+    inds = topk_indices(gates, k)
+    sel = np.take_along_axis(gates, inds, axis=-1)
+    if norm_topk_prob and k > 1:
+        s = rc.rnd(np.sum(sel.astype(np.float64), axis=-1, keepdims=True), dt)
+        sel = rc.rnd(sel.astype(np.float64) / s.astype(np.float64), dt)
+    return inds, sel
 
 
 def route_qwen3_moe(x, gate_w, k: int, norm_topk_prob: bool, dt: str = "bf16"):

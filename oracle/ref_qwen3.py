@@ -106,7 +106,7 @@ def synth_weights(cfg: Qwen3Config, dt: str = "bf16") -> Dict[str, np.ndarray]:
 
 
 QUANTIZED = ("self_attn.q_proj", "self_attn.k_proj", "self_attn.v_proj", "self_attn.o_proj", "mlp.gate_proj", "mlp.up_proj",
-             "mlp.down_proj")
+             "mlp.down_proj", "mlp.gate", "block_sparse_moe.gate", "switch_mlp.gate_proj", "switch_mlp.up_proj", "switch_mlp.down_proj")
 
 
 def quantize_weights(cfg: Qwen3Config, weights: Dict[str, np.ndarray], bits: int = 4, group_size: int = 64) -> Dict[str, np.ndarray]:
@@ -117,8 +117,11 @@ def quantize_weights(cfg: Qwen3Config, weights: Dict[str, np.ndarray], bits: int
     for name, w in weights.items():
         prefix = name[:-len(".weight")]
         if prefix.endswith(QUANTIZED) or prefix in ("model.embed_tokens", "lm_head"):
-            q, s, b = rc.quantize(w, group_size, bits)
-            out[prefix + ".weight"], out[prefix + ".scales"], out[prefix + ".biases"] = q, rc.bf16_round(s), rc.bf16_round(b)
+            w2 = w.reshape(-1, w.shape[-1])                     # expert stacks [E, out, in]: quantised row by row like any matrix
+            q, s, b = rc.quantize(w2, group_size, bits)
+            lead = w.shape[:-1]
+            out[prefix + ".weight"] = q.reshape(*lead, -1)
+            out[prefix + ".scales"], out[prefix + ".biases"] = rc.bf16_round(s).reshape(*lead, -1), rc.bf16_round(b).reshape(*lead, -1)
         else:
             out[name] = w
     return out
@@ -179,6 +182,16 @@ class Qwen3Oracle:
             from . import ref_moe
             mp = f"model.layers.{i}." + ("block_sparse_moe." if cfg.moe_mode == "mixtral" else "mlp.")
             B, L, h = x.shape
+            if self.quant is not None:   # QuantizedLinear gate + QuantizedSwitchLinear experts (mixtral model.rs:560-600)
+                bits, group = self.quant
+                x2 = x.reshape(B * L, h)
+                logits = rc.quantized_matmul(x2, self.w[mp + "gate.weight"], self.w[mp + "gate.scales"], self.w[mp + "gate.biases"], group, bits, dt)
+                inds, scores = (ref_moe.route_logits_mixtral(logits, cfg.num_experts_per_tok, dt) if cfg.moe_mode == "mixtral"
+                                else ref_moe.route_logits_qwen3_moe(logits, cfg.num_experts_per_tok, cfg.norm_topk_prob, dt))
+                trip = lambda nm: tuple(self.w[mp + f"switch_mlp.{nm}.{c}"] for c in ("weight", "scales", "biases"))
+                y = ref_moe.switch_glu_q(x2, inds, trip("gate_proj"), trip("up_proj"), trip("down_proj"), group, bits, dt)
+                weighted = rc.rnd(y.astype(np.float64) * scores[..., None].astype(np.float64), dt)
+                return rc.rnd(np.sum(weighted.astype(np.float64), axis=1), dt).reshape(B, L, h)
             y, _, _ = ref_moe.moe_block(x.reshape(B * L, h), self.w[mp + "gate.weight"], self.w[mp + "switch_mlp.gate_proj.weight"],
                                         self.w[mp + "switch_mlp.up_proj.weight"], self.w[mp + "switch_mlp.down_proj.weight"],
                                         cfg.num_experts_per_tok, cfg.moe_mode, cfg.norm_topk_prob, dt)

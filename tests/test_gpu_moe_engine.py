@@ -20,14 +20,14 @@ CONFIGS = {
 }
 
 
-def _engine(omx, cfg, weights=None, max_context=256):
+def _engine(omx, cfg, weights=None, max_context=256, quantization=None):
     from ominix_mlx_amd import engine
     m = engine.Model(hidden_size=cfg.hidden_size, num_hidden_layers=cfg.num_hidden_layers, intermediate_size=cfg.intermediate_size,
                      num_attention_heads=cfg.num_attention_heads, num_key_value_heads=cfg.num_key_value_heads, head_dim=cfg.head_dim,
                      vocab_size=cfg.vocab_size, rms_norm_eps=cfg.rms_norm_eps, rope_theta=cfg.rope_theta,
                      tie_word_embeddings=cfg.tie_word_embeddings, max_context=max_context, num_experts=cfg.num_experts,
                      num_experts_per_tok=cfg.num_experts_per_tok, moe_intermediate_size=cfg.moe_intermediate_size,
-                     moe_mode=cfg.moe_mode, norm_topk_prob=cfg.norm_topk_prob, qk_norm=cfg.qk_norm)
+                     moe_mode=cfg.moe_mode, norm_topk_prob=cfg.norm_topk_prob, qk_norm=cfg.qk_norm, quantization=quantization)
     m.synth_weights() if weights is None else m.load_weights(weights)
     return m
 
@@ -81,8 +81,10 @@ def test_moe_engine_rejects_bad_config(omx):
                 vocab_size=1024, max_context=256)
     with pytest.raises(omx.OmxError, match="InvalidConfig"):
         engine.Model(**base, num_experts=4, num_experts_per_tok=5, moe_intermediate_size=512)
+    with pytest.raises(omx.OmxError, match="InvalidConfig"):      # quantised experts: width must be a multiple of 512
+        engine.Model(**base, num_experts=4, num_experts_per_tok=2, moe_intermediate_size=768, quantization={"bits": 4, "group_size": 64})
     with pytest.raises(omx.OmxError, match="InvalidConfig"):
-        engine.Model(**base, num_experts=4, num_experts_per_tok=2, moe_intermediate_size=512, quantization={"bits": 4, "group_size": 64})
+        engine.Model(**base, num_experts=4, num_experts_per_tok=2, moe_intermediate_size=512, tp_size=2)
     m = engine.Model(**base, num_experts=4, num_experts_per_tok=2, moe_intermediate_size=512)
     with pytest.raises(omx.OmxError, match="WeightNotFound"):
         m.prefill([1, 2, 3])
@@ -119,3 +121,32 @@ def test_load_mixtral_checkpoint_directory(omx, tmp_path):
     want = np.concatenate([[ref.prefill(prompt)], ref.decode(5)])
     np.testing.assert_array_equal(got, want)
     np.testing.assert_array_equal(m.last_logits(), ref.last_logits())
+
+
+@pytest.mark.parametrize("name,bits", [("mixtral", 4), ("qwen3_moe", 4), ("mixtral", 8)])
+def test_quantized_moe_engine_matches_oracle(omx, name, bits):
+    """The reference's own Mixtral format: every Linear, the embedding, the router gate and the expert stacks are MLX affine
+    triplets (mixtral-mlx/src/model.rs:560-600).  Device-side `synth_weights` = mlx quantize() of the synthetic bf16 model, the
+    oracle runs quantized_matmul / gather_qmm on the same triplets.  Logit tolerance of the quantised dense engine, doubled
+    for the two extra quantised GEMVs per layer."""
+    cfg = CONFIGS[name]
+    quant = {"bits": bits, "group_size": 64}
+    qw = rq.quantize_weights(cfg, rq.synth_weights(cfg), bits, 64)
+    oracle = rq.Qwen3Oracle(cfg, qw, quant=(bits, 64))
+    prompt = synth.prompt_ids(24, cfg.vocab_size)
+    ref_tokens, ref_logits = oracle.generate(prompt, 6, return_logits=True)
+    m = _engine(omx, cfg, qw, quantization=quant)
+    first = m.prefill(prompt)
+    logits0 = m.last_logits()
+    got = np.concatenate([[first], m.decode(5)]).astype(np.uint32)
+    bound = 2.0 ** -7 * np.abs(ref_logits).max() * np.sqrt(cfg.num_hidden_layers) * 2 * np.sqrt(2)
+    assert np.abs(logits0 - ref_logits[0]).max() <= bound
+    margins = rc.argmax_margin(ref_logits)
+    for i in range(6):
+        if got[i] != ref_tokens[i]:
+            assert margins[i] <= 2 * bound
+            break
+    # the device generator builds the same model
+    m2 = _engine(omx, cfg, None, quantization=quant)
+    got2 = np.concatenate([[m2.prefill(prompt)], m2.decode(5)]).astype(np.uint32)
+    np.testing.assert_array_equal(got2, got)

@@ -16,18 +16,24 @@ MODELS = {
                           head_dim=128, vocab_size=151936, rms_norm_eps=1e-6, rope_theta=1e6, num_experts=128, num_experts_per_tok=8,
                           moe_intermediate_size=768, moe_mode="qwen3_moe", norm_topk_prob=True),
 }
-which = sys.argv[1:] or list(MODELS)
+bits = 0
+args = [a for a in sys.argv[1:]]
+if '--bits' in args:
+    i = args.index('--bits'); bits = int(args[i + 1]); del args[i:i + 2]
+which = args or list(MODELS)
 n_prompt, warm, steps = 2048, 8, 64
 for name in which:
     cfg = MODELS[name]
-    m = engine.Model(max_context=n_prompt + warm + steps + 8, **cfg)
+    if bits and cfg['moe_intermediate_size'] % 512:
+        continue
+    m = engine.Model(max_context=n_prompt + warm + steps + 8, quantization={'bits': bits, 'group_size': 64} if bits else None, **cfg)
     t0 = time.perf_counter(); m.synth_weights(); omx.ops.synchronize(); synth_s = time.perf_counter() - t0
     prompt = ((np.arange(n_prompt, dtype=np.int64) * 7919 + 13) % cfg["vocab_size"]).astype(np.uint32)
     first = m.prefill(prompt)
     m.decode(warm)
     t0 = time.perf_counter(); toks = m.decode(steps); dt = time.perf_counter() - t0
     step_bytes = m.step_bytes(n_prompt + warm + steps // 2)
-    print(json.dumps({"model": name, "decode_tokens_per_sec": round(steps / dt, 1), "ms_per_token": round(dt / steps * 1e3, 3),
+    print(json.dumps({"model": name, "bits": bits or 16, "decode_tokens_per_sec": round(steps / dt, 1), "ms_per_token": round(dt / steps * 1e3, 3),
                       "device_ms_per_token": round(m.last_decode_ms() / steps, 3), "prefill_ms": round(m.last_prefill_ms(), 1),
                       "algorithmic_GB_per_token": round(step_bytes / 1e9, 2), "hbm_GBps": round(step_bytes / (dt / steps) / 1e9, 1),
                       "frac_of_8TBps": round(step_bytes / (dt / steps) / 8e12, 3), "weights_synth_s": round(synth_s, 2),

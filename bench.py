@@ -33,7 +33,10 @@ QWEN3_8B = dict(hidden_size=4096, num_hidden_layers=36, intermediate_size=12288,
 QWEN3_0_6B = dict(hidden_size=1024, num_hidden_layers=28, intermediate_size=3072, num_attention_heads=16,
                   num_key_value_heads=8, head_dim=128, vocab_size=151936, rms_norm_eps=1e-6, rope_theta=1e6,
                   tie_word_embeddings=True)
-MODELS = {"qwen3-8b": QWEN3_8B, "qwen3-0.6b": QWEN3_0_6B}
+MIXTRAL_8X7B = dict(hidden_size=4096, num_hidden_layers=32, intermediate_size=14336, num_attention_heads=32, num_key_value_heads=8,
+                    head_dim=128, vocab_size=32000, rms_norm_eps=1e-5, rope_theta=1e6, num_experts=8, num_experts_per_tok=2,
+                    moe_intermediate_size=14336, moe_mode="mixtral", qk_norm=False)     # mixtral-mlx/src/model.rs:44-52
+MODELS = {"qwen3-8b": QWEN3_8B, "qwen3-0.6b": QWEN3_0_6B, "mixtral-8x7b": MIXTRAL_8X7B}
 
 
 def prompt_ids(n, vocab):
@@ -266,7 +269,11 @@ def main():
     if args.layers:
         cfg["num_hidden_layers"] = args.layers
     max_ctx = args.prompt + args.warmup + args.steps + 8
-    model = engine.Model(max_context=max_ctx, tp_rank=rank, tp_size=world, **cfg)
+    moe = cfg.get("num_experts", 0) > 0
+    if moe:   # BASELINE config 3: experts sharded over the ranks (expert parallel), attention replicated, one all-reduce per layer
+        model = engine.Model(max_context=max_ctx, ep_rank=rank, ep_size=world, **cfg)
+    else:
+        model = engine.Model(max_context=max_ctx, tp_rank=rank, tp_size=world, **cfg)
     keep = None
     if world > 1:
         keep = rccl_comm(dist, rank, world)
@@ -308,18 +315,18 @@ def main():
         model.close()
         return
     ctx_mid = args.prompt + args.warmup + args.steps // 2
-    step_bytes = model.step_bytes(ctx_mid) * world       # whole-job algorithmic bytes per token
+    step_bytes = model.step_bytes(ctx_mid) * (1 if moe else world)   # whole-job algorithmic bytes per token (EP ranks share one token's experts)
     ms_per_step = elapsed * 1e3 / args.steps
     tok_s = args.steps / elapsed
-    k_bytes, k_s = time_dominant_kernel(omx, cfg, world)
+    k_bytes, k_s = time_dominant_kernel(omx, cfg, 1 if moe else world)
     achieved = k_bytes / k_s / 1e9
     out = {
         "metric": "decode_tokens_per_sec", "value": round(tok_s, 2), "unit": "tokens/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
         "scaling": "strong", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-        "config": {"workload": f"{args.model} (Qwen3-8B shapes for BASELINE 'Qwen3-7B') bf16 greedy decode, batch 1, "
+        "config": {"workload": f"{args.model}" + (" (Qwen3-8B shapes for BASELINE 'Qwen3-7B')" if args.model == "qwen3-8b" else "") + " bf16 greedy decode, batch 1, "
                                f"{args.prompt}-token prompt then {args.warmup}+{args.steps} decode tokens",
-                   "parallelism": f"tp{world}", "context_at_timing": ctx_mid,
+                   "parallelism": (f"ep{world}" if moe else f"tp{world}"), "context_at_timing": ctx_mid,
                    "layers": cfg["num_hidden_layers"]},
         "roofline": {"bound": "hbm", "kernel": "gemv_kernel<rmsnorm, gate/up, swiglu>", "achieved": round(achieved, 1),
                      "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
@@ -340,12 +347,12 @@ def main():
     model.close()
     if flux_tp is not None:
         out["secondary"] = flux_tp
-    if world == 1 and not args.no_flux:
+    if world == 1 and not args.no_flux and not moe:
         try:
             out["secondary"] = flux_secondary(omx)
         except Exception as e:
             out["secondary"] = {"metric": "flux_klein_1024_sec_per_step", "value": None, "error": str(e)}
-    if world == 1 and not args.no_flux:
+    if world == 1 and not args.no_flux and not moe:
         try:
             out["quantized"] = quantized_secondary(omx, cfg, args)
         except Exception as e:

@@ -163,6 +163,9 @@ typedef struct omx_qwen3_config_ {
      * [E, moe_intermediate_size, hidden] / [E, hidden, moe_intermediate_size]) or Mixtral (mixtral-mlx/src/model.rs:280-347,
      * mode 0, the same names under "block_sparse_moe.").  no_qk_norm: attention without q/k RMSNorm (Mixtral, :120-160). */
     int num_experts, num_experts_per_tok, moe_intermediate_size, moe_mode, norm_topk_prob, no_qk_norm;
+    /* expert parallelism (one process per GPU): this rank holds experts [ep_rank*E/ep_size, ...) -- the stacked
+     * expert tensors registered are ITS slices -- attention and router replicated; one all-reduce per layer (omx_qwen3_set_comm) */
+    int ep_rank, ep_size;
 } omx_qwen3_config;
 typedef struct omx_qwen3_* omx_qwen3;
 
@@ -252,6 +255,12 @@ int omx_moe_forward(void* out, const void* x, const void* gate_w, const void* w_
 int omx_moe_block_forward(void* out, const void* resid, const void* x, const void* norm_w, float eps, void* xn, const void* gate_w,
                           const void* w_gate, const void* w_up, const void* w_down, int n_tokens, int hidden, int inter,
                           int n_experts, int top_k, int mode, int norm_topk_prob, omx_stream stream);
+/* expert-parallel decode form: this rank holds experts [e_lo, e_lo + e_n) (w_* = its stacks);
+ * partial [n_tokens, hidden] f32 = its share of sum_j bf16(y_j * score_j), to be all-reduced over the ranks; the residual
+ * h + bf16(sum) is the caller's.  n_tokens * top_k <= 32. */
+int omx_moe_block_partial_ep(float* partial, const void* x, const void* norm_w, float eps, void* xn, const void* gate_w,
+                             const void* w_gate, const void* w_up, const void* w_down, int n_tokens, int hidden, int inter,
+                             int n_experts, int top_k, int mode, int norm_topk_prob, int e_lo, int e_n, omx_stream stream);
 /* the same on a quantised checkpoint (mixtral-mlx/src/model.rs:560-600): router and expert stacks as MLX triplets */
 int omx_moe_block_forward_q(void* out, const void* resid, const void* x, const void* norm_w, float eps, void* xn,
                             const void* q_router, const void* s_router, const void* b_router, const void* q_gate, const void* s_gate,

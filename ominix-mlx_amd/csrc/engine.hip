@@ -388,7 +388,8 @@ int enqueue_step(omx_qwen3 m, bool with_head) {
     const omx_qwen3_config& c = m->cfg;
     hipStream_t s = m->stream;
     const int hd = c.hidden_size, D = c.head_dim;
-    const bool tp = c.tp_size > 1 || m->allreduce != nullptr;   // a 1-rank communicator exercises the TP path
+    const bool ep = c.ep_size > 1;                               // expert parallel: attention replicated, one all-reduce per MoE block
+    const bool tp = !ep && (c.tp_size > 1 || m->allreduce != nullptr);   // a 1-rank communicator exercises the TP path
     embed_kernel<<<2, 256, 0, s>>>(m->h, m->embed, m->st, hd, m->step_seq);
     OMX_LAUNCH_CHECK();
     bf16_t* h = m->h;      // residual stream entering the layer
@@ -451,6 +452,18 @@ int enqueue_step(omx_qwen3 m, bool with_head) {
                 OMX_REQUIRE(m->allreduce(m->partial_a, m->partial_a, hd, kNcclFloat32, kNcclSum, m->comm, s) == 0, "ncclAllReduce failed");
                 pending = m->partial_a;
             }
+        }
+        if (c.num_experts > 0 && ep) {
+            // expert parallel: this rank's experts only, partial sums all-reduced, residual folded into the next prologue
+            const int el = c.num_experts / c.ep_size;
+            if (omx_moe_block_partial_ep(m->partial_b, h, L.post_ln, c.rms_norm_eps, m->moe_xn, L.moe_gate, L.moe_wg, L.moe_wu, L.moe_wd,
+                                         1, hd, c.moe_intermediate_size, c.num_experts, c.num_experts_per_tok, c.moe_mode,
+                                         c.norm_topk_prob, c.ep_rank * el, el, s))
+                return 1;
+            OMX_REQUIRE(m->allreduce != nullptr, "ep_size > 1 but no communicator set (omx_qwen3_set_comm)");
+            OMX_REQUIRE(m->allreduce(m->partial_b, m->partial_b, hd, kNcclFloat32, kNcclSum, m->comm, s) == 0, "ncclAllReduce failed");
+            pending = m->partial_b;
+            continue;
         }
         if (c.num_experts > 0) {
             // [RMSNorm] [router] [expert gate/up + SwiGLU] [expert down] [weighted sum] [+ residual]
@@ -791,6 +804,7 @@ int omx_qwen3_create(omx_qwen3* out, const omx_qwen3_config* cfg) {
     omx_qwen3 m = new omx_qwen3_();
     m->cfg = c;
     if (m->cfg.rope_scale == 0.f) m->cfg.rope_scale = 1.f;
+    if (m->cfg.ep_size < 1) m->cfg.ep_size = 1;
     if (m->cfg.quant_bits && m->cfg.quant_group == 0) m->cfg.quant_group = 64;     // nn/quantized.rs:330-333
     OMX_REQUIRE(!m->cfg.quant_bits || m->cfg.quant_group == 32 || m->cfg.quant_group == 64 || m->cfg.quant_group == 128,
                 "InvalidConfig: quantization group_size %d (32, 64, 128)", m->cfg.quant_group);
@@ -825,7 +839,9 @@ int omx_qwen3_create(omx_qwen3* out, const omx_qwen3_config* cfg) {
     const int cap_splits = (512 + m->Hkv - 1) / m->Hkv;
     if (m->nsplit > cap_splits) m->nsplit = cap_splits;
     if (c.num_experts > 0) {
-        OMX_REQUIRE(c.tp_size == 1, "InvalidConfig: the sparse-MoE engine is single-GPU (tp_size %d)", c.tp_size);
+        OMX_REQUIRE(c.tp_size == 1, "InvalidConfig: the sparse-MoE engine shards experts (ep_size), not heads (tp_size %d)", c.tp_size);
+        OMX_REQUIRE(c.ep_size <= 1 || (c.ep_rank >= 0 && c.ep_rank < c.ep_size && c.num_experts % c.ep_size == 0 && !c.quant_bits),
+                    "InvalidConfig: expert parallel rank %d of %d over %d experts (bf16 only)", c.ep_rank, c.ep_size, c.num_experts);
         OMX_REQUIRE(!c.quant_bits || c.moe_intermediate_size % 512 == 0, "InvalidConfig: quantised experts need moe_intermediate_size %% 512 == 0 (%d)", c.moe_intermediate_size);
         OMX_REQUIRE(c.num_experts_per_tok >= 1 && c.num_experts_per_tok <= c.num_experts && c.moe_intermediate_size > 0 &&
                         c.moe_intermediate_size % 64 == 0 && (c.moe_mode == 0 || c.moe_mode == 1) && m->H * D >= c.hidden_size,
@@ -980,9 +996,11 @@ int omx_qwen3_synth_weights(omx_qwen3 m, uint32_t base_seed) {
         if (c.num_experts > 0) {
             const std::string mp = p + (c.moe_mode == 0 ? "block_sparse_moe." : "mlp.");
             const int64_t E = c.num_experts, Im = c.moe_intermediate_size;
-            if (make(mp + "gate.weight", E, hd, hd, 0, 0, false) || make(mp + "switch_mlp.gate_proj.weight", E * Im, hd, hd, 0, 0, false) ||
-                make(mp + "switch_mlp.up_proj.weight", E * Im, hd, hd, 0, 0, false) ||
-                make(mp + "switch_mlp.down_proj.weight", E * hd, Im, Im, 0, 0, false))
+            const int64_t El = c.ep_size > 1 ? E / c.ep_size : E, e0 = c.ep_size > 1 ? c.ep_rank * El : 0;   // this rank's experts
+            if (make(mp + "gate.weight", E, hd, hd, 0, 0, false) ||
+                make(mp + "switch_mlp.gate_proj.weight", El * Im, hd, hd, e0 * Im, 0, false) ||
+                make(mp + "switch_mlp.up_proj.weight", El * Im, hd, hd, e0 * Im, 0, false) ||
+                make(mp + "switch_mlp.down_proj.weight", El * hd, Im, Im, e0 * hd, 0, false))
                 return 1;
         } else if (make(p + "mlp.gate_proj.weight", m->I, hd, hd, (int64_t)r * m->I, 0, false) ||
                    make(p + "mlp.up_proj.weight", m->I, hd, hd, (int64_t)r * m->I, 0, false) ||

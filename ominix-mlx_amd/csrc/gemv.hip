@@ -78,7 +78,11 @@ __global__ __launch_bounds__(kBlock) void gemv_kernel(const GemvArgs a_in) {
         a.x = a_in.x + (size_t)(by / a_in.x_div) * a_in.x_bstride;
         a.out = reinterpret_cast<char*>(a_in.out) + (size_t)by * a_in.out_bstride_bytes;
         if (a_in.w_sel) {
-            const size_t e = a_in.w_sel[by];
+            size_t e = a_in.w_sel[by];
+            if (a_in.w_sel_n > 0) {   // expert-parallel shard: block-uniform early exit for experts of other ranks
+                if (e < (size_t)a_in.w_sel_lo || e >= (size_t)(a_in.w_sel_lo + a_in.w_sel_n)) return;
+                e -= (size_t)a_in.w_sel_lo;
+            }
             a.w0 = a_in.w0 + e * a_in.w_estride;
             if (a_in.w1) a.w1 = a_in.w1 + e * a_in.w_estride;
         }

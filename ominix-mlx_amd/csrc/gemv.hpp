@@ -50,6 +50,9 @@ struct GemvArgs {
     const uint32_t* w_sel;      // optional [n_batch] device array: expert id per batch entry
     size_t w_estride;           // elements between consecutive experts' matrices
     int swiglu_single_round;    // EPI_SWIGLU: fused_swiglu (one rounding) instead of nn::silu(g)*u (three)
+    // expert parallelism: only experts [w_sel_lo, w_sel_lo + w_sel_n) live on this rank (w_sel_n == 0: all of them); a batch
+    // entry routed elsewhere does no work (its output is never read: the combine skips it too)
+    int w_sel_lo, w_sel_n;
 };
 
 int launch_gemv(const GemvArgs& a, int pro, int epi, hipStream_t s);

@@ -243,6 +243,32 @@ __global__ __launch_bounds__(256) void moe_unsort_kernel(bf16_t* __restrict__ ou
         *reinterpret_cast<u32x4*>(out + (size_t)blockIdx.x * h + i) = *reinterpret_cast<const u32x4*>(y + src * h + i);
 }
 
+
+// expert-parallel partial of the weighted sum: out[t] (f32) = sum over the slots whose expert lives on this rank of
+// bf16(y * score) -- the ranks' partials add up (all-reduce) to the single-device sum before its rounding
+__global__ __launch_bounds__(256) void moe_combine_partial_kernel(float* __restrict__ out, const bf16_t* __restrict__ y,
+                                                                  const bf16_t* __restrict__ scores, const uint32_t* __restrict__ inds,
+                                                                  int h, int k, int e_lo, int e_n) {
+    const int t = blockIdx.x;
+    for (int i = threadIdx.x * 8; i < h; i += 256 * 8) {
+        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int j = 0; j < k; ++j) {
+            const size_t slot = (size_t)t * k + j;
+            const int e = (int)inds[slot];
+            if (e < e_lo || e >= e_lo + e_n) continue;
+            const float sc = bf16_to_f32(scores[slot]);
+            const u32x4 v = *reinterpret_cast<const u32x4*>(y + slot * h + i);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                acc[2 * q] += round_bf16(bf16lo(v[q]) * sc);
+                acc[2 * q + 1] += round_bf16(bf16hi(v[q]) * sc);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) out[(size_t)t * h + i + q] = acc[q];
+    }
+}
+
 }  // namespace
 }  // namespace omx
 
@@ -487,6 +513,59 @@ extern "C" int omx_moe_block_forward_q(void* out, const void* resid, const void*
     d.w_estride = (size_t)hidden * inter * bits / 32; d.s_estride = (size_t)hidden * (inter / group_size);
     if (launch_qgemv(d, bits, PRO_NONE, EPI_STORE, s)) return 1;
     moe_combine_kernel<<<n_tokens, 256, 0, s>>>((bf16_t*)out, ybuf, scores, nullptr, hidden, top_k, (const bf16_t*)resid);
+    OMX_LAUNCH_CHECK();
+    return 0;
+}
+
+/* expert-parallel decode form (simple variant: activations replicated, experts sharded): this rank
+ * holds experts [e_lo, e_lo + e_n) (w_* = ITS stacks [e_n, ...]); partial [n_tokens, hidden] f32 receives its share of
+ * sum_j bf16(y_j * score_j).  The ranks' partials are summed by one all-reduce; the caller then forms
+ * h + bf16(sum) (the residual).  n_tokens * top_k <= 32. */
+extern "C" int omx_moe_block_partial_ep(float* partial, const void* x, const void* norm_w, float eps, void* xn, const void* gate_w,
+                                        const void* w_gate, const void* w_up, const void* w_down, int n_tokens, int hidden, int inter,
+                                        int n_experts, int top_k, int mode, int norm_topk_prob, int e_lo, int e_n,
+                                        omx_stream stream) {
+    using namespace omx;
+    OMX_REQUIRE(partial && x && norm_w && xn && gate_w && w_gate && w_up && w_down, "omx_moe_block_partial_ep: null tensor");
+    OMX_REQUIRE(n_experts >= 1 && n_experts <= kMaxExperts && top_k >= 1 && top_k <= kMaxTopK && top_k <= n_experts &&
+                    e_lo >= 0 && e_n >= 1 && e_lo + e_n <= n_experts, "omx_moe_block_partial_ep: experts %d top-%d shard [%d, +%d)", n_experts, top_k, e_lo, e_n);
+    const int slots = n_tokens * top_k;
+    OMX_REQUIRE(slots >= 1 && slots <= 32 && gemv_k_supported(hidden, false) && gemv_k_supported(inter, false),
+                "omx_moe_block_partial_ep: decode form only (%d routed slots, hidden %d, intermediate %d)", slots, hidden, inter);
+    hipStream_t s = (hipStream_t)stream;
+    size_t need = 0;
+    omx_moe_workspace_bytes(n_tokens, hidden, inter, n_experts, top_k, &need);
+    void* ws = nullptr;
+    if (get_workspace(&ws, need)) return 1;
+    char* p = (char*)ws;
+    auto take = [&](size_t bytes) { char* r = p; p += (bytes + 255) & ~(size_t)255; return r; };
+    uint32_t* inds = (uint32_t*)take((size_t)slots * 4);
+    take((size_t)slots * 4); take((size_t)slots * 4);
+    bf16_t* scores = (bf16_t*)take((size_t)slots * 2);
+    take((size_t)(n_experts + 2) * 4);
+    const int max_tiles = slots / 128 + n_experts + 1;
+    take((size_t)max_tiles * 4); take((size_t)max_tiles * 4); take(256);
+    bf16_t* gbuf = (bf16_t*)take((size_t)slots * inter * 2);
+    take((size_t)slots * inter * 2);
+    bf16_t* ybuf = (bf16_t*)take((size_t)slots * hidden * 2);
+    moe_router_kernel<<<n_tokens, kRouterThreads, 0, s>>>((const bf16_t*)x, (const bf16_t*)gate_w, hidden, n_experts, top_k, mode,
+                                                          norm_topk_prob, inds, scores, (const bf16_t*)norm_w, eps, (bf16_t*)xn);
+    OMX_LAUNCH_CHECK();
+    GemvArgs a = {};
+    a.w0 = (const bf16_t*)w_gate; a.w1 = (const bf16_t*)w_up; a.n0 = inter; a.N = inter; a.K = hidden;
+    a.x = (const bf16_t*)xn; a.out = gbuf;
+    a.n_batch = slots; a.x_div = top_k; a.x_bstride = hidden; a.out_bstride_bytes = (size_t)inter * 2;
+    a.w_sel = inds; a.w_estride = (size_t)inter * hidden; a.swiglu_single_round = 1;
+    a.w_sel_lo = e_lo; a.w_sel_n = e_n;
+    if (launch_gemv(a, PRO_NONE, EPI_SWIGLU, s)) return 1;
+    GemvArgs d = {};
+    d.w0 = (const bf16_t*)w_down; d.n0 = hidden; d.N = hidden; d.K = inter;
+    d.x = gbuf; d.out = ybuf;
+    d.n_batch = slots; d.x_div = 1; d.x_bstride = inter; d.out_bstride_bytes = (size_t)hidden * 2;
+    d.w_sel = inds; d.w_estride = (size_t)hidden * inter;
+    d.w_sel_lo = e_lo; d.w_sel_n = e_n;
+    if (launch_gemv(d, PRO_NONE, EPI_STORE, s)) return 1;
+    moe_combine_partial_kernel<<<n_tokens, 256, 0, s>>>(partial, ybuf, scores, inds, hidden, top_k, e_lo, e_n);
     OMX_LAUNCH_CHECK();
     return 0;
 }

@@ -150,3 +150,45 @@ def test_quantized_moe_engine_matches_oracle(omx, name, bits):
     m2 = _engine(omx, cfg, None, quantization=quant)
     got2 = np.concatenate([[m2.prefill(prompt)], m2.decode(5)]).astype(np.uint32)
     np.testing.assert_array_equal(got2, got)
+
+
+@pytest.mark.parametrize("name,world", [("qwen3_moe", 2), ("mixtral", 4), ("qwen3_moe_no_renorm_top4", 4)])
+@pytest.mark.parametrize("use_synth", [True, False])
+def test_expert_parallel_engine_on_one_gpu(omx, monkeypatch, name, world, use_synth):
+    """SURVEY.md 8e row 2 at engine level: `world` ranks (host threads, in-process communicator standing in for RCCL), each
+    holding E / world experts, attention and router replicated, ONE all-reduce of the f32 partial per MoE block.  The partials
+    are sums of bf16-rounded products accumulated in f32, so the sharded run reproduces the single-GPU engine bit for bit."""
+    from ominix_mlx_amd import comm
+    cfg = CONFIGS[name]
+    weights = rq.synth_weights(cfg)
+    prompt = synth.prompt_ids(20, cfg.vocab_size)
+    monkeypatch.setenv("OMX_PREFILL_SERIAL", "1")      # the sharded engines prefill token-serially: compare like with like
+    single = _engine(omx, cfg)
+    want = np.concatenate([[single.prefill(prompt)], single.decode(6)]).astype(np.uint32)
+    want_logits = single.last_logits()
+    group = comm.LoopbackGroup(world, 1 << 20)
+    from ominix_mlx_amd import engine
+    models = []
+    for r in range(world):
+        m = engine.Model(hidden_size=cfg.hidden_size, num_hidden_layers=cfg.num_hidden_layers, intermediate_size=cfg.intermediate_size,
+                         num_attention_heads=cfg.num_attention_heads, num_key_value_heads=cfg.num_key_value_heads, head_dim=cfg.head_dim,
+                         vocab_size=cfg.vocab_size, rms_norm_eps=cfg.rms_norm_eps, rope_theta=cfg.rope_theta,
+                         tie_word_embeddings=cfg.tie_word_embeddings, max_context=256, num_experts=cfg.num_experts,
+                         num_experts_per_tok=cfg.num_experts_per_tok, moe_intermediate_size=cfg.moe_intermediate_size,
+                         moe_mode=cfg.moe_mode, norm_topk_prob=cfg.norm_topk_prob, qk_norm=cfg.qk_norm, ep_rank=r, ep_size=world)
+        m.synth_weights() if use_synth else m.load_weights(weights)
+        m.set_comm(group.rank_comm(r), group.allreduce_fn)
+        models.append(m)
+
+    def run(r):
+        m = models[r]
+        toks = np.concatenate([[m.prefill(prompt)], m.decode(6)]).astype(np.uint32)
+        return toks, m.last_logits()
+
+    outs = comm.run_ranks(world, run, group)
+    for r in range(world):
+        np.testing.assert_array_equal(outs[r][0], want)
+        np.testing.assert_array_equal(outs[r][1], want_logits)
+    for m in models:
+        m.close()
+    group.close()

@@ -267,6 +267,153 @@ __global__ __launch_bounds__(kBlock) void gemv_kernel(const GemvArgs a_in) {
 #undef OMX_COMPUTE
 }
 
+// ---- any contraction width (K a multiple of 8): the fallback for shapes without a tuned instantiation (Qwen2.5-7B:
+//      K = 3584 / 18944).  Same prologues and epilogues, a runtime loop over the 16-byte vectors of a row, RB rows share
+//      each activation vector; one register set (no double buffer), so it streams at roughly 2/3 of the tuned kernels. ----
+template <int PRO, int EPI>
+__global__ __launch_bounds__(kBlock) void gemv_generic_kernel(const GemvArgs a_in) {
+    GemvArgs a = a_in;
+    if (a_in.n_batch > 1 || a_in.w_sel) {
+        const int by = blockIdx.y;
+        a.x = a_in.x + (size_t)(by / a_in.x_div) * a_in.x_bstride;
+        a.out = reinterpret_cast<char*>(a_in.out) + (size_t)by * a_in.out_bstride_bytes;
+        if (a_in.w_sel) {
+            size_t e = a_in.w_sel[by];
+            if (a_in.w_sel_n > 0) {
+                if (e < (size_t)a_in.w_sel_lo || e >= (size_t)(a_in.w_sel_lo + a_in.w_sel_n)) return;
+                e -= (size_t)a_in.w_sel_lo;
+            }
+            a.w0 = a_in.w0 + e * a_in.w_estride;
+            if (a_in.w1) a.w1 = a_in.w1 + e * a_in.w_estride;
+        }
+    }
+    constexpr int LR = (EPI == EPI_SWIGLU) ? 2 : 1;
+    constexpr int RB = (EPI == EPI_SWIGLU) ? 2 : 4;
+    constexpr int NR = RB * LR;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int K = a.K, kvec = K / 8;
+    u32x4* xs = reinterpret_cast<u32x4*>(smem);                              // [kvec]
+    float* red = reinterpret_cast<float*>(smem + (size_t)kvec * 16);         // [8]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    {
+        const bf16_t* xg = a.x + (a.x_row ? (size_t)a.x_row[0] * K : 0);
+        float ss = 0.f;
+        for (int v = threadIdx.x; v < kvec; v += kBlock) {
+            u32x4 raw = *(reinterpret_cast<const u32x4*>(xg) + v);
+            if (a.x_partial) {
+                const f32x4 p0 = *(reinterpret_cast<const f32x4*>(a.x_partial) + 2 * v);
+                const f32x4 p1 = *(reinterpret_cast<const f32x4*>(a.x_partial) + 2 * v + 1);
+                const float pp[8] = {p0[0], p0[1], p0[2], p0[3], p1[0], p1[1], p1[2], p1[3]};
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    raw[q] = pack_bf16(bf16lo(raw[q]) + round_bf16(pp[2 * q]), bf16hi(raw[q]) + round_bf16(pp[2 * q + 1]));
+                if (a.x_out && blockIdx.x == 0) *(reinterpret_cast<u32x4*>(a.x_out) + v) = raw;
+            }
+            xs[v] = raw;
+            if (PRO == PRO_RMSNORM) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float lo = bf16lo(raw[q]), hi = bf16hi(raw[q]);
+                    ss = fmaf(lo, lo, ss);
+                    ss = fmaf(hi, hi, ss);
+                }
+            }
+        }
+        if (PRO == PRO_RMSNORM) {
+            ss = block_sum<kWaves>(ss, red);
+            const float rstd = 1.0f / sqrtf(ss / (float)K + a.eps);
+            for (int v = threadIdx.x; v < kvec; v += kBlock) {
+                const u32x4 raw = xs[v];
+                const u32x4 nw = *(reinterpret_cast<const u32x4*>(a.norm_w) + v);
+                u32x4 o;
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    o[q] = pack_bf16(bf16lo(raw[q]) * rstd * bf16lo(nw[q]), bf16hi(raw[q]) * rstd * bf16hi(nw[q]));
+                xs[v] = o;
+            }
+        }
+        __syncthreads();
+    }
+    const int rpw = a.rows_per_wave;
+    const int row_begin = (blockIdx.x * kWaves + wave) * rpw;
+    const int row_end = min(row_begin + rpw, a.N);
+    uint64_t best = 0;
+    for (int r0 = row_begin; r0 < row_end; r0 += RB) {
+        const u32x4* rows[NR];
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+            const int row = min(r0 + r, a.N - 1);
+            if (EPI == EPI_SWIGLU) {
+                rows[LR * r] = reinterpret_cast<const u32x4*>(a.w0 + (size_t)row * K);
+                rows[LR * r + (LR - 1)] = reinterpret_cast<const u32x4*>(a.w1 + (size_t)row * K);
+            } else {
+                rows[r] = reinterpret_cast<const u32x4*>(row_ptr(a, row));
+            }
+        }
+        float acc[NR];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) acc[r] = 0.f;
+        for (int v = lane; v < kvec; v += 64) {
+            u32x4 w[NR];
+#pragma unroll
+            for (int r = 0; r < NR; ++r) w[r] = ld_nt(rows[r] + v);
+            const u32x4 xp = xs[v];
+            float xf[8];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { xf[2 * q] = bf16lo(xp[q]); xf[2 * q + 1] = bf16hi(xp[q]); }
+#pragma unroll
+            for (int r = 0; r < NR; ++r) acc[r] = dot8(w[r], xf, acc[r]);
+        }
+#pragma unroll
+        for (int r = 0; r < NR; ++r) acc[r] = wave_sum(acc[r]);
+        if (lane == 0) {
+#pragma unroll
+            for (int r = 0; r < RB; ++r)
+                if (r0 + r < row_end) epilogue<EPI>(a, r0 + r, acc[LR * r], acc[LR * r + (LR - 1)], best);
+        }
+    }
+    if (EPI == EPI_ARGMAX) {
+        uint64_t* bred = reinterpret_cast<uint64_t*>(red);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const uint64_t other = __shfl_xor(best, o, 64);
+            best = other > best ? other : best;
+        }
+        __syncthreads();
+        if (lane == 0) bred[wave] = best;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint64_t b = bred[0];
+#pragma unroll
+            for (int w = 1; w < kWaves; ++w) b = bred[w] > b ? bred[w] : b;
+            a.argmax_slot[blockIdx.x] = b;
+        }
+    }
+}
+
+int launch_generic(const GemvArgs& a, int pro, int epi, hipStream_t s) {
+    const int groups = (a.N + a.rows_per_wave - 1) / a.rows_per_wave;
+    const dim3 grid((groups + kWaves - 1) / kWaves, a.n_batch > 1 ? a.n_batch : 1), block(kBlock);
+    const size_t shmem = (size_t)(a.K / 8) * 16 + 64;
+#define OMX_GEN_CASE(P, E)                                                                                         \
+    if (pro == P && epi == E) {                                                                                    \
+        if (shmem > 48 * 1024)                                                                                     \
+            OMX_HIP_CHECK(hipFuncSetAttribute((const void*)gemv_generic_kernel<P, E>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem)); \
+        gemv_generic_kernel<P, E><<<grid, block, shmem, s>>>(a);                                                   \
+        OMX_LAUNCH_CHECK();                                                                                        \
+        return 0;                                                                                                  \
+    }
+    OMX_GEN_CASE(PRO_NONE, EPI_STORE)
+    OMX_GEN_CASE(PRO_RMSNORM, EPI_STORE)
+    OMX_GEN_CASE(PRO_NONE, EPI_RESIDUAL)
+    OMX_GEN_CASE(PRO_RMSNORM, EPI_SWIGLU)
+    OMX_GEN_CASE(PRO_NONE, EPI_SWIGLU)
+    OMX_GEN_CASE(PRO_RMSNORM, EPI_ARGMAX)
+    OMX_GEN_CASE(PRO_NONE, EPI_F32)
+#undef OMX_GEN_CASE
+    return set_error("gemv: unsupported prologue/epilogue combination %d/%d", pro, epi);
+}
+
 template <int NVW, int KSPLIT, int RB>
 int launch_nv(const GemvArgs& a, int pro, int epi, hipStream_t s) {
     const int groups = (a.N + a.rows_per_wave - 1) / a.rows_per_wave;   // row groups (waves or blocks)
@@ -294,8 +441,17 @@ int launch_nv(const GemvArgs& a, int pro, int epi, hipStream_t s) {
 // Row groups are sized so that the WHOLE grid is co-resident in one round: these kernels are
 // register-heavy (two in-flight register sets), 2 waves/SIMD for the 8-vector variants (1 for the
 // SwiGLU pair kernel), and a second round of blocks pays the cold-start latency again.
-static int resolve_rpw(int N, int K, int epi, int rpw) {
-    const bool split = ((K + 511) / 512) > 8;
+// tuned instantiation available?  (K not a multiple of 512 only without a prologue: partly filled last vector row)
+static bool tuned(int K, bool plain_prologue) {
+    if (K % 8 != 0 || (K % 512 != 0 && !plain_prologue)) return false;
+    switch ((K + 511) / 512) {
+        case 1: case 2: case 3: case 4: case 6: case 8: case 12: case 16: case 24: case 28: return true;
+        default: return false;
+    }
+}
+
+static int resolve_rpw(int N, int K, int epi, int rpw, bool is_tuned = true) {
+    const bool split = is_tuned && ((K + 511) / 512) > 8;
     if (rpw <= 0) {
         // measured on MI355X (tools/gemv_sweep.py): short row groups in whole double-buffer rounds win;
         // small matrices want every CU busy (>= ~1500 waves), the vocabulary-sized one longer streams
@@ -309,26 +465,25 @@ static int resolve_rpw(int N, int K, int epi, int rpw) {
 }
 
 int gemv_grid(int N, int K, int epi, int rows_per_wave) {
-    const int rpw = resolve_rpw(N, K, epi, rows_per_wave);
+    const bool t = tuned(K, false);   // the callers that need the grid (argmax partials) launch with the RMSNorm prologue
+    const int rpw = resolve_rpw(N, K, epi, rows_per_wave, t);
     const int groups = (N + rpw - 1) / rpw;
-    return ((K + 511) / 512) > 8 ? groups : (groups + kWaves - 1) / kWaves;
+    return (t && ((K + 511) / 512) > 8) ? groups : (groups + kWaves - 1) / kWaves;
 }
 
 bool gemv_k_supported(int K, bool needs_full_vectors) {
-    if (K <= 0 || K % 8 != 0 || (needs_full_vectors && K % 512 != 0)) return false;
-    switch ((K + 511) / 512) {
-        case 1: case 2: case 3: case 4: case 6: case 8: case 12: case 16: case 24: case 28: return true;
-        default: return false;
-    }
+    (void)needs_full_vectors;
+    return K > 0 && K % 8 == 0 && K <= 65536;   // tuned kernels where they exist, the generic one otherwise
 }
 
 int launch_gemv(const GemvArgs& a_in, int pro, int epi, hipStream_t s) {
     GemvArgs a = a_in;
-    OMX_REQUIRE(a.K > 0 && a.K % 8 == 0 && (a.K % 512 == 0 || (pro == PRO_NONE && !a.x_partial)),
-                "gemv: K=%d must be a positive multiple of 512 (of 8 without a prologue)", a.K);
+    OMX_REQUIRE(a.K > 0 && a.K % 8 == 0 && a.K <= 65536, "gemv: K=%d must be a positive multiple of 8 (at most 65536)", a.K);
     OMX_REQUIRE(a.N > 0, "gemv: N must be positive");
     const int nv = (a.K + 511) / 512;
-    a.rows_per_wave = resolve_rpw(a.N, a.K, epi, a.rows_per_wave);
+    const bool t = tuned(a.K, pro == PRO_NONE && !a.x_partial);
+    a.rows_per_wave = resolve_rpw(a.N, a.K, epi, a.rows_per_wave, t);
+    if (!t) return launch_generic(a, pro, epi, s);
     switch (nv) {
         // RB*NVW ~ 16 x 1-KiB loads in flight per wave per register set
         case 1: return launch_nv<1, 1, 8>(a, pro, epi, s);

@@ -97,7 +97,7 @@ int omx_linear(void* out, const void* x, const void* w, const void* bias, int M,
     OMX_REQUIRE(dtype == OMX_BFLOAT16, "omx_linear: only bfloat16 is implemented (got dtype %d)", (int)dtype);
     if (M == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
-    if (M <= 4 && bias == nullptr && K % 512 == 0) {
+    if (M <= 4 && bias == nullptr && K % 8 == 0 && K <= 65536) {   // HBM-streaming GEMV (tuned widths, generic kernel otherwise)
         for (int m = 0; m < M; ++m) {
             omx::GemvArgs a = {};
             a.w0 = (const omx::bf16_t*)w;

@@ -328,3 +328,18 @@ def test_sdpa_rejects_bad_group(omx):
     with pytest.raises(omx.OmxError):
         omx.ops.scaled_dot_product_attention(T.from_numpy(z), T.from_numpy(np.zeros((1, 4, 8, 64))),
                                              T.from_numpy(np.zeros((1, 4, 8, 64))), 1.0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("K", [3584, 18944, 896, 8960, 520, 768, 8])
+@pytest.mark.parametrize("M,N", [(1, 1000), (3, 37)])
+def test_linear_decode_shapes_without_a_tuned_gemv(omx, M, N, K):
+    """Contraction widths with no tuned GEMV instantiation (Qwen2.5-7B: 3584 / 18944, Qwen2.5-0.5B: 896, ...) go through the
+    generic streaming kernel; same tolerance as every bf16 Linear: one rounding of an fp32-accumulated dot product."""
+    T = omx.ops.Tensor
+    x = rc.bf16_round(rand((M, K), 900 + K))
+    w = rc.bf16_round(rand((N, K), 901 + K) * 0.05)
+    got = omx.ops.linear(T.from_numpy(x), T.from_numpy(w)).numpy()
+    want = rc.linear(x, w, None, "bf16")
+    noise = 4 * 2.0 ** -9 * np.sqrt(((x.astype(np.float64) ** 2) @ (w.astype(np.float64) ** 2).T)) * 2.0 ** -8
+    assert_bf16_close(got, want, 1, atol=float(noise.max()) + 1e-6)

@@ -36,7 +36,10 @@ QWEN3_0_6B = dict(hidden_size=1024, num_hidden_layers=28, intermediate_size=3072
 MIXTRAL_8X7B = dict(hidden_size=4096, num_hidden_layers=32, intermediate_size=14336, num_attention_heads=32, num_key_value_heads=8,
                     head_dim=128, vocab_size=32000, rms_norm_eps=1e-5, rope_theta=1e6, num_experts=8, num_experts_per_tok=2,
                     moe_intermediate_size=14336, moe_mode="mixtral", qk_norm=False)     # mixtral-mlx/src/model.rs:44-52
-MODELS = {"qwen3-8b": QWEN3_8B, "qwen3-0.6b": QWEN3_0_6B, "mixtral-8x7b": MIXTRAL_8X7B}
+QWEN2P5_7B = dict(hidden_size=3584, num_hidden_layers=28, intermediate_size=18944, num_attention_heads=28, num_key_value_heads=4,
+                  head_dim=128, vocab_size=152064, rms_norm_eps=1e-6, rope_theta=1e6, tie_word_embeddings=False,
+                  qk_norm=False, attention_bias=True)      # the qwen2.rs wiring ("also report Qwen2.5-7B shapes")
+MODELS = {"qwen3-8b": QWEN3_8B, "qwen3-0.6b": QWEN3_0_6B, "mixtral-8x7b": MIXTRAL_8X7B, "qwen2.5-7b": QWEN2P5_7B}
 
 
 def prompt_ids(n, vocab):

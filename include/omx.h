@@ -166,6 +166,9 @@ typedef struct omx_qwen3_config_ {
     /* expert parallelism (one process per GPU): this rank holds experts [ep_rank*E/ep_size, ...) -- the stacked
      * expert tensors registered are ITS slices -- attention and router replicated; one all-reduce per layer (omx_qwen3_set_comm) */
     int ep_rank, ep_size;
+    /* Qwen2 wiring (qwen3-mlx/src/qwen2.rs:100-218): q/k/v projections carry a bias ("self_attn.{q,k,v}_proj.bias") and the
+     * attention has no q/k norm (set no_qk_norm too); bf16, single GPU */
+    int attention_bias;
 } omx_qwen3_config;
 typedef struct omx_qwen3_* omx_qwen3;
 

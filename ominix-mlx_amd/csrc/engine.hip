@@ -42,6 +42,7 @@ constexpr int kNcclFloat32 = 7, kNcclUint64 = 5, kNcclSum = 0, kNcclMax = 2;
 struct LayerW {
     const bf16_t *q, *k, *v, *o, *gate, *up, *down, *q_norm, *k_norm, *in_ln, *post_ln;
     const bf16_t *moe_gate, *moe_wg, *moe_wu, *moe_wd;   // sparse-MoE feed-forward (router + stacked experts)
+    const bf16_t *q_bias, *k_bias, *v_bias, *qkv_bias;   // Qwen2: projection biases; qkv_bias = the three concatenated (owned)
 };
 // quantized checkpoint (config.json "quantization", qwen3-mlx/src/model.rs:621-727): every Linear and the embedding are
 // (weight u32, scales, biases) triplets; the norm weights stay bf16 in LayerW
@@ -211,6 +212,18 @@ struct omx_qwen3_ {
 
 namespace {
 
+template <class T>
+int dev_alloc(omx_qwen3 m, T** p, size_t n) {
+    void* q = nullptr;
+    OMX_HIP_CHECK(hipMalloc(&q, n * sizeof(T) + 64));
+    // same stream as every later writer: a null-stream hipMemset is not ordered against the
+    // engine's non-blocking stream and could zero a buffer after it was filled
+    OMX_HIP_CHECK(hipMemsetAsync(q, 0, n * sizeof(T) + 64, m->stream));
+    *p = (T*)q;
+    m->owned.push_back(q);
+    return 0;
+}
+
 // temperature sampling: replace the greedy per-block partials by those of logits / T + Gumbel noise, the noise
 // of vocabulary row v being word v of a V-word draw from the step's key (random.hip).  The greedy partials the
 // lm_head epilogue wrote are simply overwritten; sample_finalize_kernel / the TP max all-reduce are unchanged.
@@ -276,6 +289,16 @@ int resolve_weights(omx_qwen3 m) {
             get(p + "input_layernorm.weight", &L.in_ln) || get(p + "post_attention_layernorm.weight", &L.post_ln))
             return 1;
         if (!m->cfg.no_qk_norm && (get(p + "self_attn.q_norm.weight", &L.q_norm) || get(p + "self_attn.k_norm.weight", &L.k_norm))) return 1;
+        if (m->cfg.attention_bias) {   // qwen2.rs:112-124: Linear with bias for q/k/v only
+            if (get(p + "self_attn.q_proj.bias", &L.q_bias) || get(p + "self_attn.k_proj.bias", &L.k_bias) || get(p + "self_attn.v_proj.bias", &L.v_bias)) return 1;
+            const size_t nq = (size_t)m->H * m->cfg.head_dim, nk = (size_t)m->Hkv * m->cfg.head_dim;
+            bf16_t* cat = nullptr;
+            if (dev_alloc(m, &cat, nq + 2 * nk)) return 1;
+            OMX_HIP_CHECK(hipMemcpyAsync(cat, L.q_bias, nq * 2, hipMemcpyDeviceToDevice, m->stream));
+            OMX_HIP_CHECK(hipMemcpyAsync(cat + nq, L.k_bias, nk * 2, hipMemcpyDeviceToDevice, m->stream));
+            OMX_HIP_CHECK(hipMemcpyAsync(cat + nq + nk, L.v_bias, nk * 2, hipMemcpyDeviceToDevice, m->stream));
+            L.qkv_bias = cat;
+        }
         if (m->cfg.num_experts > 0) {
             const std::string mp = p + (m->cfg.moe_mode == 0 ? "block_sparse_moe." : "mlp.");
             if (get(mp + "gate.weight", &L.moe_gate) || get(mp + "switch_mlp.gate_proj.weight", &L.moe_wg) ||
@@ -407,6 +430,7 @@ int enqueue_step(omx_qwen3 m, bool with_head) {
             a.x = h; a.x_partial = pending; a.x_out = pending ? hn : nullptr;
             a.norm_w = L.in_ln; a.eps = c.rms_norm_eps;
             a.out = m->qkv;
+            a.out_bias = L.qkv_bias;
             if (launch_gemv(a, PRO_RMSNORM, EPI_STORE, s)) return 1;
             if (pending) { bf16_t* t = h; h = hn; hn = t; pending = nullptr; }
         }
@@ -530,17 +554,6 @@ int enqueue_step(omx_qwen3 m, bool with_head) {
     return 0;
 }
 
-template <class T>
-int dev_alloc(omx_qwen3 m, T** p, size_t n) {
-    void* q = nullptr;
-    OMX_HIP_CHECK(hipMalloc(&q, n * sizeof(T) + 64));
-    // same stream as every later writer: a null-stream hipMemset is not ordered against the
-    // engine's non-blocking stream and could zero a buffer after it was filled
-    OMX_HIP_CHECK(hipMemsetAsync(q, 0, n * sizeof(T) + 64, m->stream));
-    *p = (T*)q;
-    m->owned.push_back(q);
-    return 0;
-}
 
 // The persistent one-kernel-per-token path: eligible for the single-GPU dense decoder when decode_mega.hip has an
 // instantiation for the shape.  OMX_DECODE_MEGA=0 forces the step graph (the two must agree bit for bit).
@@ -737,9 +750,9 @@ int prefill_prefix_batched(omx_qwen3 m, int T, int off, const EncodeOpts* enc = 
         const LayerQ& Q = quant ? m->qlayers[l] : no_q;
         const bf16_t* w = nullptr;
         if (omx_rms_norm(m->pf_xn, h, L.in_ln, T, hd, c.rms_norm_eps, OMX_BFLOAT16, s)) return 1;
-        if (!(w = W(L.q, &Q.q, hd)) || launch_gemm_bf16(m->pf_q, m->pf_xn, w, nullptr, T, H * D, hd, s)) return 1;
-        if (!(w = W(L.k, &Q.k, hd)) || launch_gemm_bf16(m->pf_k, m->pf_xn, w, nullptr, T, Hkv * D, hd, s)) return 1;
-        if (!(w = W(L.v, &Q.v, hd)) || launch_gemm_bf16(m->pf_v, m->pf_xn, w, nullptr, T, Hkv * D, hd, s)) return 1;
+        if (!(w = W(L.q, &Q.q, hd)) || launch_gemm_bf16(m->pf_q, m->pf_xn, w, L.q_bias, T, H * D, hd, s)) return 1;
+        if (!(w = W(L.k, &Q.k, hd)) || launch_gemm_bf16(m->pf_k, m->pf_xn, w, L.k_bias, T, Hkv * D, hd, s)) return 1;
+        if (!(w = W(L.v, &Q.v, hd)) || launch_gemm_bf16(m->pf_v, m->pf_xn, w, L.v_bias, T, Hkv * D, hd, s)) return 1;
         if (launch_qk_norm_rope_scatter(m->pf_q, m->pf_k, m->pf_v, L.q_norm, L.k_norm, m->rope_cos, m->rope_sin, m->pf_qt,
                                         m->kcache[l], m->vcache[l], T, H, Hkv, D, m->cap, off, c.rms_norm_eps, s))
             return 1;
@@ -794,7 +807,7 @@ int omx_qwen3_create(omx_qwen3* out, const omx_qwen3_config* cfg) {
     OMX_REQUIRE(out && cfg, "omx_qwen3_create: null argument");
     const omx_qwen3_config& c = *cfg;
     OMX_REQUIRE(c.tp_size >= 1 && c.tp_rank >= 0 && c.tp_rank < c.tp_size, "InvalidConfig: tp rank %d of %d", c.tp_rank, c.tp_size);
-    OMX_REQUIRE(c.hidden_size > 0 && c.hidden_size % 512 == 0, "InvalidConfig: hidden_size %d must be a multiple of 512", c.hidden_size);
+    OMX_REQUIRE(c.hidden_size > 0 && c.hidden_size % 64 == 0, "InvalidConfig: hidden_size %d must be a multiple of 64", c.hidden_size);
     OMX_REQUIRE(c.head_dim == 64 || c.head_dim == 128, "InvalidConfig: head_dim %d (64 or 128 supported)", c.head_dim);
     OMX_REQUIRE(c.num_attention_heads % c.num_key_value_heads == 0, "InvalidConfig: heads %d not a multiple of kv heads %d", c.num_attention_heads, c.num_key_value_heads);
     OMX_REQUIRE(c.num_key_value_heads % c.tp_size == 0 && c.intermediate_size % c.tp_size == 0 && c.vocab_size % c.tp_size == 0,
@@ -812,7 +825,10 @@ int omx_qwen3_create(omx_qwen3* out, const omx_qwen3_config* cfg) {
     m->Hkv = c.num_key_value_heads / c.tp_size;
     m->I = c.intermediate_size / c.tp_size;
     m->V = c.vocab_size / c.tp_size;
-    OMX_REQUIRE((m->H * c.head_dim) % 512 == 0 && (c.num_experts > 0 || m->I % 512 == 0), "InvalidConfig: per-rank attention width %d and intermediate %d must be multiples of 512", m->H * c.head_dim, m->I);
+    OMX_REQUIRE(c.num_experts > 0 || m->I % 64 == 0, "InvalidConfig: per-rank intermediate %d must be a multiple of 64", m->I);
+    OMX_REQUIRE(!c.quant_bits || (c.hidden_size % 512 == 0 && (m->H * c.head_dim) % 512 == 0 && (c.num_experts > 0 || m->I % 512 == 0)),
+                "InvalidConfig: quantized checkpoints need hidden %d, attention width %d and intermediate %d to be multiples of 512", c.hidden_size, m->H * c.head_dim, m->I);
+    OMX_REQUIRE(!c.attention_bias || (c.tp_size == 1 && !c.quant_bits), "InvalidConfig: attention_bias (Qwen2) runs bf16 on a single GPU");
     const int step = 256;   // cache.rs:110-117
     m->cap = ((c.max_context > 0 ? c.max_context : 4096) + step - 1) / step * step;
     OMX_HIP_CHECK(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking));
@@ -992,6 +1008,9 @@ int omx_qwen3_synth_weights(omx_qwen3 m, uint32_t base_seed) {
             make(p + "post_attention_layernorm.weight", 1, hd, hd, 0, 0, true))
             return 1;
         if (!c.no_qk_norm && (make(p + "self_attn.q_norm.weight", 1, D, D, 0, 0, true) || make(p + "self_attn.k_norm.weight", 1, D, D, 0, 0, true)))
+            return 1;
+        if (c.attention_bias && (make(p + "self_attn.q_proj.bias", 1, Hq, Hq, 0, 0, false) || make(p + "self_attn.k_proj.bias", 1, Hk, Hk, 0, 0, false) ||
+                                 make(p + "self_attn.v_proj.bias", 1, Hk, Hk, 0, 0, false)))
             return 1;
         if (c.num_experts > 0) {
             const std::string mp = p + (c.moe_mode == 0 ? "block_sparse_moe." : "mlp.");

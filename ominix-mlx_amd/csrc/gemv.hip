@@ -40,7 +40,7 @@ __device__ __forceinline__ uint64_t argmax_key(float v, uint32_t idx) {
 template <int EPI>
 __device__ __forceinline__ void epilogue(const GemvArgs& a, int row, float v0, float v1, uint64_t& best) {
     if (EPI == EPI_STORE) {
-        reinterpret_cast<bf16_t*>(a.out)[row] = f32_to_bf16(v0);
+        reinterpret_cast<bf16_t*>(a.out)[row] = f32_to_bf16(a.out_bias ? v0 + bf16_to_f32(a.out_bias[row]) : v0);
     } else if (EPI == EPI_F32) {
         reinterpret_cast<float*>(a.out)[row] = v0;
     } else if (EPI == EPI_RESIDUAL) {
@@ -441,17 +441,23 @@ int launch_nv(const GemvArgs& a, int pro, int epi, hipStream_t s) {
 // Row groups are sized so that the WHOLE grid is co-resident in one round: these kernels are
 // register-heavy (two in-flight register sets), 2 waves/SIMD for the 8-vector variants (1 for the
 // SwiGLU pair kernel), and a second round of blocks pays the cold-start latency again.
-// tuned instantiation available?  (K not a multiple of 512 only without a prologue: partly filled last vector row)
-static bool tuned(int K, bool plain_prologue) {
-    if (K % 8 != 0 || (K % 512 != 0 && !plain_prologue)) return false;
-    switch ((K + 511) / 512) {
-        case 1: case 2: case 3: case 4: case 6: case 8: case 12: case 16: case 24: case 28: return true;
-        default: return false;
+// vectors-per-row (K/512, rounded up) of the tuned instantiation that serves K, or 0 (generic kernel).  A row whose last
+// vector rows are partly or wholly empty (K not a multiple of 512, or no instantiation for exactly K/512) is served by the
+// next larger instantiation with masked loads -- only without a prologue (plain activation staging).
+static int tuned_nv(int K, bool plain_prologue) {
+    static const int kSizes[] = {1, 2, 3, 4, 6, 7, 8, 12, 16, 24, 28, 32, 40};
+    if (K <= 0 || K % 8 != 0) return 0;
+    const int nv = (K + 511) / 512;
+    for (int sz : kSizes) {
+        if (sz == nv && (K % 512 == 0 || plain_prologue)) return sz;
+        if (sz > nv) return (plain_prologue && sz * 3 <= nv * 4) ? sz : 0;   // at most a third of the lanes idle
     }
+    return 0;
 }
+static bool tuned(int K, bool plain_prologue) { return tuned_nv(K, plain_prologue) != 0; }
 
 static int resolve_rpw(int N, int K, int epi, int rpw, bool is_tuned = true) {
-    const bool split = is_tuned && ((K + 511) / 512) > 8;
+    const bool split = is_tuned && (K + 511) / 512 > 8;
     if (rpw <= 0) {
         // measured on MI355X (tools/gemv_sweep.py): short row groups in whole double-buffer rounds win;
         // small matrices want every CU busy (>= ~1500 waves), the vocabulary-sized one longer streams
@@ -480,8 +486,8 @@ int launch_gemv(const GemvArgs& a_in, int pro, int epi, hipStream_t s) {
     GemvArgs a = a_in;
     OMX_REQUIRE(a.K > 0 && a.K % 8 == 0 && a.K <= 65536, "gemv: K=%d must be a positive multiple of 8 (at most 65536)", a.K);
     OMX_REQUIRE(a.N > 0, "gemv: N must be positive");
-    const int nv = (a.K + 511) / 512;
-    const bool t = tuned(a.K, pro == PRO_NONE && !a.x_partial);
+    const int nv = tuned_nv(a.K, pro == PRO_NONE && !a.x_partial);
+    const bool t = nv != 0;
     a.rows_per_wave = resolve_rpw(a.N, a.K, epi, a.rows_per_wave, t);
     if (!t) return launch_generic(a, pro, epi, s);
     switch (nv) {
@@ -491,11 +497,14 @@ int launch_gemv(const GemvArgs& a_in, int pro, int epi, hipStream_t s) {
         case 3: return launch_nv<3, 1, 4>(a, pro, epi, s);
         case 4: return launch_nv<4, 1, 4>(a, pro, epi, s);
         case 6: return launch_nv<6, 1, 2>(a, pro, epi, s);
+        case 7: return launch_nv<7, 1, 2>(a, pro, epi, s);
         case 8: return launch_nv<8, 1, 2>(a, pro, epi, s);
         case 12: return launch_nv<3, 4, 4>(a, pro, epi, s);
         case 16: return launch_nv<4, 4, 4>(a, pro, epi, s);
         case 24: return launch_nv<6, 4, 2>(a, pro, epi, s);
         case 28: return launch_nv<7, 4, 2>(a, pro, epi, s);
+        case 32: return launch_nv<8, 4, 2>(a, pro, epi, s);
+        case 40: return launch_nv<10, 4, 2>(a, pro, epi, s);
         default: return set_error("gemv: K=%d (K/512=%d) has no instantiated kernel", a.K, nv);
     }
 }

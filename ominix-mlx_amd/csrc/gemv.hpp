@@ -53,6 +53,7 @@ struct GemvArgs {
     // expert parallelism: only experts [w_sel_lo, w_sel_lo + w_sel_n) live on this rank (w_sel_n == 0: all of them); a batch
     // entry routed elsewhere does no work (its output is never read: the combine skips it too)
     int w_sel_lo, w_sel_n;
+    const bf16_t* out_bias;     // EPI_STORE: optional [N] added before the rounding (nn::Linear with bias = addmm, linear.rs:87-92)
 };
 
 int launch_gemv(const GemvArgs& a, int pro, int epi, hipStream_t s);

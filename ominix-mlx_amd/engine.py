@@ -22,7 +22,7 @@ class Qwen3Config(ctypes.Structure):
                 ("tie_word_embeddings", c_int), ("max_context", c_int), ("tp_rank", c_int), ("tp_size", c_int),
                 ("quant_bits", c_int), ("quant_group", c_int), ("num_experts", c_int), ("num_experts_per_tok", c_int),
                 ("moe_intermediate_size", c_int), ("moe_mode", c_int), ("norm_topk_prob", c_int), ("no_qk_norm", c_int),
-                ("ep_rank", c_int), ("ep_size", c_int)]
+                ("ep_rank", c_int), ("ep_size", c_int), ("attention_bias", c_int)]
 
 
 ENGINE_SIGNATURES = {
@@ -77,7 +77,7 @@ class Model:
                  num_key_value_heads, head_dim, vocab_size, rms_norm_eps=1e-6, rope_theta=1e6,
                  tie_word_embeddings=False, rope_scaling=None, max_context=4096, tp_rank=0, tp_size=1, quantization=None,
                  num_experts=0, num_experts_per_tok=0, moe_intermediate_size=0, moe_mode="qwen3_moe", norm_topk_prob=False,
-                 qk_norm=True, ep_rank=0, ep_size=1, **_ignored):
+                 qk_norm=True, ep_rank=0, ep_size=1, attention_bias=False, **_ignored):
         """quantization: config.json's {"bits": 4|8, "group_size": 64} (model.rs:63) or None for a bf16 checkpoint.
         num_experts > 0: sparse-MoE feed-forward in every layer -- moe_mode "qwen3_moe" (qwen3_moe.rs ModelArgs :60-87) or
         "mixtral" (mixtral-mlx ModelArgs :54-80, with qk_norm=False and moe_intermediate_size = intermediate_size)."""
@@ -89,7 +89,7 @@ class Model:
                                tp_rank, tp_size, int(q.get("bits", 0)), int(q.get("group_size", 64 if q else 0)),
                                int(num_experts), int(num_experts_per_tok), int(moe_intermediate_size),
                                {"mixtral": 0, "qwen3_moe": 1}[moe_mode], int(bool(norm_topk_prob)), int(not qk_norm),
-                               int(ep_rank), int(ep_size))
+                               int(ep_rank), int(ep_size), int(bool(attention_bias)))
         self._h = c_void_p()
         check(lib.omx_qwen3_create(ctypes.byref(self._h), ctypes.byref(self.cfg)))
         self._keep = []

@@ -119,6 +119,8 @@ def model_args(model_dir: str) -> dict:
                 rope_theta=c.get("rope_theta", 1e6), tie_word_embeddings=c.get("tie_word_embeddings", False),
                 rope_scaling=c.get("rope_scaling"), quantization=c.get("quantization"))
     model_type = c.get("model_type", "")
+    if model_type == "qwen2":     # qwen3-mlx/src/qwen2.rs: q/k/v bias, no q/k norm
+        args.update(attention_bias=True, qk_norm=False)
     if model_type == "mixtral" or "num_local_experts" in c:
         # mixtral-mlx ModelArgs (model.rs:54-80): experts as wide as intermediate_size, top-2 of 8 by default, no q/k norm
         args.update(num_experts=c.get("num_local_experts", 8), num_experts_per_tok=c.get("num_experts_per_tok", 2),

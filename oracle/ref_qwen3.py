@@ -47,6 +47,7 @@ class Qwen3Config:
     moe_mode: str = "qwen3_moe"
     norm_topk_prob: bool = False
     qk_norm: bool = True
+    attention_bias: bool = False     # Qwen2 (qwen3-mlx/src/qwen2.rs:112-124): q/k/v Linear with bias, and qk_norm False
 
     @staticmethod
     def qwen3_8b():
@@ -68,6 +69,10 @@ def weight_shapes(cfg: Qwen3Config) -> Dict[str, tuple]:
         s[p + "self_attn.k_proj.weight"] = (Hkv * D, h)
         s[p + "self_attn.v_proj.weight"] = (Hkv * D, h)
         s[p + "self_attn.o_proj.weight"] = (h, H * D)
+        if cfg.attention_bias:
+            s[p + "self_attn.q_proj.bias"] = (H * D,)
+            s[p + "self_attn.k_proj.bias"] = (Hkv * D,)
+            s[p + "self_attn.v_proj.bias"] = (Hkv * D,)
         if cfg.qk_norm:
             s[p + "self_attn.q_norm.weight"] = (D,)
             s[p + "self_attn.k_norm.weight"] = (D,)
@@ -149,9 +154,14 @@ class Qwen3Oracle:
         cfg, dt = self.cfg, self.dt
         p = f"model.layers.{i}.self_attn."
         B, L, _ = x.shape
-        q = self.lin(x, p + "q_proj")
-        k = self.lin(x, p + "k_proj")
-        v = self.lin(x, p + "v_proj")
+        if cfg.attention_bias:      # qwen2.rs:172-174
+            q = rc.linear(x, self.w[p + "q_proj.weight"], self.w[p + "q_proj.bias"], dt)
+            k = rc.linear(x, self.w[p + "k_proj.weight"], self.w[p + "k_proj.bias"], dt)
+            v = rc.linear(x, self.w[p + "v_proj.weight"], self.w[p + "v_proj.bias"], dt)
+        else:
+            q = self.lin(x, p + "q_proj")
+            k = self.lin(x, p + "k_proj")
+            v = self.lin(x, p + "v_proj")
         q = q.reshape(B, L, cfg.num_attention_heads, -1).transpose(0, 2, 1, 3)
         k = k.reshape(B, L, cfg.num_key_value_heads, -1).transpose(0, 2, 1, 3)
         v = v.reshape(B, L, cfg.num_key_value_heads, -1).transpose(0, 2, 1, 3)

@@ -68,7 +68,7 @@ __device__ __forceinline__ void epilogue(const GemvArgs& a, int row, float v0, f
 // NVW    = 16-byte vectors per lane per row per wave (compile-time, fully unrolled)
 // KSPLIT = waves sharing one row (1: a wave owns whole rows; 4: each wave owns a K quarter)
 // RB     = logical rows per register batch; LR physical rows per logical row (2 for SwiGLU)
-template <int NVW, int KSPLIT, int RB, int PRO, int EPI>
+template <int NVW, int KSPLIT, int RB, int PRO, int EPI, bool TAIL = false>
 __global__ __launch_bounds__(kBlock) void gemv_kernel(const GemvArgs a_in) {
     // batched / expert-selected form (MoE decode): blockIdx.y picks the activation row, the output row
     // block and, through a device index array, the expert whose weights are streamed
@@ -105,7 +105,9 @@ __global__ __launch_bounds__(kBlock) void gemv_kernel(const GemvArgs a_in) {
     const bool active = row_begin < a.N;
     const int koff = (KSPLIT == 1) ? 0 : wave * NVW * 64;   // first vector of this wave's K slice
     const int kvec = K / 8;                                   // 16-byte vectors per row
-    const bool tail = kvec < NV * 64;                         // K not a multiple of 512: the last vector row is partly empty (zero weights and activations)
+    // TAIL (compile time: a runtime select around the loads would make hipcc branch and drain per load): K does not fill the
+    // instantiation's vector rows -- lanes beyond K read zero weights and zero activations
+    constexpr bool tail = TAIL;
 
     u32x4 wA[NR][NVW], wB[NR][NVW];
     uint64_t best = 0;   // EPI_ARGMAX: running (orderable logit << 32 | ~row) of this thread
@@ -173,7 +175,7 @@ __global__ __launch_bounds__(kBlock) void gemv_kernel(const GemvArgs a_in) {
         for (int i = 0; i < PV; ++i) {
             const int v = threadIdx.x + i * kBlock;
             if (v < NV * 64) {
-                u32x4 raw = v < kvec ? *(reinterpret_cast<const u32x4*>(xg) + v) : u32x4{0u, 0u, 0u, 0u};
+                u32x4 raw = (!TAIL || v < kvec) ? *(reinterpret_cast<const u32x4*>(xg) + v) : u32x4{0u, 0u, 0u, 0u};
                 if (a.x_partial) {
                     const f32x4 p0 = *(reinterpret_cast<const f32x4*>(a.x_partial) + 2 * v);
                     const f32x4 p1 = *(reinterpret_cast<const f32x4*>(a.x_partial) + 2 * v + 1);
@@ -419,9 +421,13 @@ int launch_nv(const GemvArgs& a, int pro, int epi, hipStream_t s) {
     const int groups = (a.N + a.rows_per_wave - 1) / a.rows_per_wave;   // row groups (waves or blocks)
     const dim3 grid(KSPLIT == 1 ? (groups + kWaves - 1) / kWaves : groups, a.n_batch > 1 ? a.n_batch : 1), block(kBlock);
     const size_t shmem = (size_t)NVW * KSPLIT * 64 * 16 + 32 + (KSPLIT > 1 ? (size_t)a.rows_per_wave * 2 * KSPLIT * 4 : 0);
+    const bool tail = a.K / 8 < NVW * KSPLIT * 64;
 #define OMX_GEMV_CASE(P, E)                                                                          \
     if (pro == P && epi == E) {                                                                      \
-        gemv_kernel<NVW, KSPLIT, (E == EPI_SWIGLU ? (RB > 1 ? RB / 2 : 1) : RB), P, E><<<grid, block, shmem, s>>>(a); \
+        if (tail && P == PRO_NONE)                                                                   \
+            gemv_kernel<NVW, KSPLIT, (E == EPI_SWIGLU ? (RB > 1 ? RB / 2 : 1) : RB), PRO_NONE, E, true><<<grid, block, shmem, s>>>(a); \
+        else                                                                                         \
+            gemv_kernel<NVW, KSPLIT, (E == EPI_SWIGLU ? (RB > 1 ? RB / 2 : 1) : RB), P, E><<<grid, block, shmem, s>>>(a); \
         OMX_LAUNCH_CHECK();                                                                          \
         return 0;                                                                                    \
     }

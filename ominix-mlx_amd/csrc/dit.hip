@@ -27,10 +27,14 @@ namespace {
 
 // per-head RMSNorm (weight [128]) then RoPE on interleaved pairs (2i, 2i+1), in place.
 // x: rows of `heads` x 128 starting every `ld` elements; cos/sin [S, 128] f32 with duplicated pairs.
-__global__ __launch_bounds__(256) void klein_qk_norm_rope_kernel(bf16_t* __restrict__ x, int64_t ld, int S, int heads,
-                                                                 const bf16_t* __restrict__ w, const float* __restrict__ cosr,
-                                                                 const float* __restrict__ sinr, int rope_row0, float eps) {
+__global__ __launch_bounds__(256) void klein_qk_norm_rope_kernel(bf16_t* __restrict__ xq, bf16_t* __restrict__ xk, int64_t ld, int S, int heads,
+                                                                 const bf16_t* __restrict__ wq, const bf16_t* __restrict__ wk,
+                                                                 const float* __restrict__ cosr, const float* __restrict__ sinr,
+                                                                 int rope_row0, float eps) {
+    // blockIdx.y = 0: queries, 1: keys (one launch for both); 16 (token, head) rows per block, 16 lanes x 8 elements each
     constexpr int D = 128, LPR = 16;
+    bf16_t* x = blockIdx.y ? xk : xq;
+    const bf16_t* w = blockIdx.y ? wk : wq;
     const int lane = threadIdx.x & 63, c = lane % LPR;
     const int64_t row = (int64_t)blockIdx.x * 16 + threadIdx.x / LPR;   // (token, head)
     if (row >= (int64_t)S * heads) return;
@@ -38,6 +42,11 @@ __global__ __launch_bounds__(256) void klein_qk_norm_rope_kernel(bf16_t* __restr
     bf16_t* p = x + (size_t)t * ld + (size_t)h * D + c * 8;
     const u32x4 r = *reinterpret_cast<const u32x4*>(p);
     const u32x4 wr = *reinterpret_cast<const u32x4*>(w + c * 8);
+    // cos/sin rows hold every pair's value twice ([c0,c0,c1,c1,..]): two 16-byte loads each, even entries used
+    const f32x4* cp = reinterpret_cast<const f32x4*>(cosr + (size_t)(rope_row0 + t) * D + c * 8);
+    const f32x4* sp = reinterpret_cast<const f32x4*>(sinr + (size_t)(rope_row0 + t) * D + c * 8);
+    const f32x4 c0 = cp[0], c1 = cp[1], s0 = sp[0], s1 = sp[1];
+    const float cs[4] = {c0[0], c0[2], c1[0], c1[2]}, sn[4] = {s0[0], s0[2], s1[0], s1[2]};
     float v[8], wv[8];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -49,14 +58,11 @@ __global__ __launch_bounds__(256) void klein_qk_norm_rope_kernel(bf16_t* __restr
     for (int e = 0; e < 8; ++e) ss = fmaf(v[e], v[e], ss);
     ss = group_sum<LPR>(ss);
     const float rstd = 1.0f / sqrtf(ss / (float)D + eps);
-    const float* cp = cosr + (size_t)(rope_row0 + t) * D + c * 8;
-    const float* sp = sinr + (size_t)(rope_row0 + t) * D + c * 8;
     u32x4 o;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         const float x0 = v[2 * e] * rstd * wv[2 * e], x1 = v[2 * e + 1] * rstd * wv[2 * e + 1];
-        const float cs = cp[2 * e], sn = sp[2 * e];   // duplicated pair entries
-        o[e] = pack_bf16(x0 * cs - x1 * sn, x1 * cs + x0 * sn);
+        o[e] = pack_bf16(x0 * cs[e] - x1 * sn[e], x1 * cs[e] + x0 * sn[e]);
     }
     *reinterpret_cast<u32x4*>(p) = o;
 }
@@ -404,10 +410,10 @@ int omx_klein_forward_with_rope(omx_klein m, void* out, const void* latent, cons
             if (linear(m, m->k + r0 * hl, m->xm + r0 * h, (b + sn + "to_k.weight").c_str(), rows, hl, h)) return 1;
             if (linear(m, m->v + r0 * hl, m->xm + r0 * h, (b + sn + "to_v.weight").c_str(), rows, hl, h)) return 1;
             const unsigned blocks = (unsigned)(((size_t)rows * H + 15) / 16);
-            if (kget(m, b + sn + "norm_q.weight", &w)) return 1;
-            klein_qk_norm_rope_kernel<<<blocks, 256, 0, s>>>(m->q + r0 * hl, hl, rows, H, w, rope_cos, rope_sin, (int)r0, rms_eps);
-            if (kget(m, b + sn + "norm_k.weight", &w)) return 1;
-            klein_qk_norm_rope_kernel<<<blocks, 256, 0, s>>>(m->k + r0 * hl, hl, rows, H, w, rope_cos, rope_sin, (int)r0, rms_eps);
+            const bf16_t* wkn = nullptr;
+            if (kget(m, b + sn + "norm_q.weight", &w) || kget(m, b + sn + "norm_k.weight", &wkn)) return 1;
+            klein_qk_norm_rope_kernel<<<dim3(blocks, 2), 256, 0, s>>>(m->q + r0 * hl, m->k + r0 * hl, hl, rows, H, w, wkn, rope_cos, rope_sin,
+                                                                      (int)r0, rms_eps);
             OMX_LAUNCH_CHECK();
         }
         // ONE joint attention over [txt, img]: img and txt queries both see all keys (klein_model.rs:461-483)
@@ -436,10 +442,9 @@ int omx_klein_forward_with_rope(omx_klein m, void* out, const void* latent, cons
         if (omx_fused_modulate(m->xm, x, mod, mod + h, 1, S, h, 1e-6f, OMX_BFLOAT16, s)) return 1;
         if (linear(m, m->proj, m->xm, (b + "to_qkv_mlp.weight").c_str(), S, (int)ldp, h)) return 1;
         const unsigned blocks = (unsigned)(((size_t)S * H + 15) / 16);
-        if (kget(m, b + "norm_q.weight", &w)) return 1;
-        klein_qk_norm_rope_kernel<<<blocks, 256, 0, s>>>(m->proj, ldp, S, H, w, rope_cos, rope_sin, 0, rms_eps);
-        if (kget(m, b + "norm_k.weight", &w)) return 1;
-        klein_qk_norm_rope_kernel<<<blocks, 256, 0, s>>>(m->proj + hl, ldp, S, H, w, rope_cos, rope_sin, 0, rms_eps);
+        const bf16_t* wkn = nullptr;
+        if (kget(m, b + "norm_q.weight", &w) || kget(m, b + "norm_k.weight", &wkn)) return 1;
+        klein_qk_norm_rope_kernel<<<dim3(blocks, 2), 256, 0, s>>>(m->proj, m->proj + hl, ldp, S, H, w, wkn, rope_cos, rope_sin, 0, rms_eps);
         OMX_LAUNCH_CHECK();
         if (attention(m, m->comb, ldc, m->proj, m->proj + hl, m->proj + 2 * hl, ldp, S)) return 1;          // cols [0, hl)
         swiglu_strided_kernel<<<2048, 256, 0, s>>>(m->comb + hl, ldc, m->proj + 3 * hl, m->proj + 3 * hl + mh, ldp, S, mh);   // cols [hl, hl+mh)

@@ -147,7 +147,10 @@ struct omx_klein_ {
     omx_klein_config cfg;
     std::map<std::string, const bf16_t*> w;
     std::vector<void*> owned;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;      // the stream helpers launch on (switched to stream_txt for the txt half of a double block)
+    hipStream_t stream_main = nullptr, stream_txt = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    bf16_t *proj_txt = nullptr, *act_txt = nullptr;   // MLP scratch of the concurrently running txt stream
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     float last_ms = 0.f;
     // tensor parallel: heads and the MLP width are sharded, the residual stream is replicated
@@ -197,7 +200,8 @@ int ensure_buffers(omx_klein m, int s_txt, int s_img) {
         kalloc(m, &m->proj, S * (3 * h + 2 * mh)) || kalloc(m, &m->comb, S * (h + mh)) || kalloc(m, &m->act, S * mh) ||
         kalloc(m, &m->vec, h) || kalloc(m, &m->svec, h) || kalloc(m, &m->temb, (size_t)256) || kalloc(m, &m->tmid, h) ||
         kalloc(m, &m->mod_img, 6 * h) || kalloc(m, &m->mod_txt, 6 * h) || kalloc(m, &m->mod_single, 3 * h) ||
-        kalloc(m, &m->ada, 2 * h) || kalloc(m, &m->lat_in, (size_t)s_img * c.in_channels) || kalloc(m, &m->partial, S * h))
+        kalloc(m, &m->ada, 2 * h) || kalloc(m, &m->lat_in, (size_t)s_img * c.in_channels) || kalloc(m, &m->partial, S * h) ||
+        kalloc(m, &m->proj_txt, (size_t)s_txt * 2 * mh) || kalloc(m, &m->act_txt, (size_t)s_txt * mh))
         return 1;
     m->s_txt = s_txt;
     m->s_img = s_img;
@@ -247,6 +251,10 @@ int omx_klein_create(omx_klein* out, const omx_klein_config* cfg) {
     m->h_l = m->H_l * cfg->head_dim;
     m->mh_l = cfg->mlp_hidden / n;
     OMX_HIP_CHECK(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking));
+    m->stream_main = m->stream;
+    OMX_HIP_CHECK(hipStreamCreateWithFlags(&m->stream_txt, hipStreamNonBlocking));
+    OMX_HIP_CHECK(hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming));
+    OMX_HIP_CHECK(hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming));
     OMX_HIP_CHECK(hipEventCreate(&m->ev0));
     OMX_HIP_CHECK(hipEventCreate(&m->ev1));
     *out = m;
@@ -259,7 +267,10 @@ int omx_klein_destroy(omx_klein m) {
     for (void* p : m->owned) (void)hipFree(p);
     (void)hipEventDestroy(m->ev0);
     (void)hipEventDestroy(m->ev1);
-    (void)hipStreamDestroy(m->stream);
+    (void)hipStreamDestroy(m->stream_main);
+    if (m->stream_txt) (void)hipStreamDestroy(m->stream_txt);
+    if (m->ev_fork) (void)hipEventDestroy(m->ev_fork);
+    if (m->ev_join) (void)hipEventDestroy(m->ev_join);
     delete m;
     return 0;
 }
@@ -280,7 +291,7 @@ int omx_klein_set_comm(omx_klein m, void* comm, void* allreduce_fn) {
 int omx_klein_synth_weights(omx_klein m, uint32_t base_seed) {
     OMX_REQUIRE(m, "omx_klein_synth_weights: null model");
     const omx_klein_config& c = m->cfg;
-    const int h = c.hidden_size, mh = c.mlp_hidden, D = c.head_dim;
+    const int h = c.hidden_size, mh = c.mlp_hidden;
     const int r = c.tp_rank, hl = m->h_l, ml = m->mh_l;
     struct Seg { int64_t start, len; };
     const float amp_w = (float)(0.02 * sqrt(3.0)), amp_n = (float)(0.01 * sqrt(3.0));
@@ -366,8 +377,9 @@ int omx_klein_forward_with_rope(omx_klein m, void* out, const void* latent, cons
     OMX_REQUIRE(s_img > 0 && s_txt > 0, "omx_klein_forward_with_rope: empty sequence");
     const omx_klein_config& c = m->cfg;
     if (ensure_buffers(m, s_txt, s_img)) return 1;
+    m->stream = m->stream_main;   // an earlier forward that failed inside a txt half may have left the side stream selected
     hipStream_t s = m->stream;
-    const int h = c.hidden_size, S = s_txt + s_img, D = c.head_dim;
+    const int h = c.hidden_size, S = s_txt + s_img;
     const int H = m->H_l, hl = m->h_l, mh = m->mh_l;   // this rank's heads / attention width / MLP width
     const float rms_eps = 1e-5f;   // RmsNorm::DEFAULT_EPS
     OMX_HIP_CHECK(hipEventRecord(m->ev0, s));
@@ -397,10 +409,34 @@ int omx_klein_forward_with_rope(omx_klein m, void* out, const void* latent, cons
     OMX_LAUNCH_CHECK();
 
     const bf16_t* w = nullptr;
+    // The txt (512 rows) and img (4096 rows) halves of a double block are independent between the joint attentions.  On one
+    // GPU the txt GEMMs fill 96 of 256 CUs and the img ones 192: they run on two HIP streams, forked and joined with events
+    // around each half, so the small txt chain hides under the img chain.
+    const char* dual_env = getenv("OMX_KLEIN_DUAL_STREAM");
+    const bool dual = !(dual_env && dual_env[0] == '0') && c.tp_size <= 1 && m->allreduce == nullptr && s_txt > 0;
+    hipStream_t const s_main = m->stream_main;
+    auto fork = [&]() -> int {
+        if (!dual) return 0;
+        OMX_HIP_CHECK(hipEventRecord(m->ev_fork, s_main));
+        OMX_HIP_CHECK(hipStreamWaitEvent(m->stream_txt, m->ev_fork, 0));
+        return 0;
+    };
+    auto join = [&]() -> int {
+        if (!dual) return 0;
+        OMX_HIP_CHECK(hipEventRecord(m->ev_join, m->stream_txt));
+        OMX_HIP_CHECK(hipStreamWaitEvent(s_main, m->ev_join, 0));
+        return 0;
+    };
+    auto on_stream = [&](int st) {   // txt half -> side stream, img half -> main stream
+        m->stream = (dual && st == 0) ? m->stream_txt : s_main;
+        s = m->stream;
+    };
     for (int i = 0; i < c.depth; ++i) {
         const std::string b = "double_blocks." + std::to_string(i) + ".";
         // ---- attention half: per-stream LN+modulate and q/k/v projections into adjacent row ranges ----
+        if (fork()) return 1;
         for (int st = 0; st < 2; ++st) {
+            on_stream(st);
             const char* sn = st ? "img_" : "txt_";
             const bf16_t* mod = st ? m->mod_img : m->mod_txt;
             const int rows = st ? s_img : s_txt;
@@ -416,9 +452,15 @@ int omx_klein_forward_with_rope(omx_klein m, void* out, const void* latent, cons
                                                                       (int)r0, rms_eps);
             OMX_LAUNCH_CHECK();
         }
+        on_stream(1);
+        if (join()) return 1;
         // ONE joint attention over [txt, img]: img and txt queries both see all keys (klein_model.rs:461-483)
         if (attention(m, m->att, hl, m->q, m->k, m->v, hl, S)) return 1;
+        if (fork()) return 1;
         for (int st = 0; st < 2; ++st) {
+            on_stream(st);
+            bf16_t* proj = (dual && st == 0) ? m->proj_txt : m->proj;
+            bf16_t* act = (dual && st == 0) ? m->act_txt : m->act;
             const char* sn = st ? "img_" : "txt_";
             const bf16_t* mod = st ? m->mod_img : m->mod_txt;
             const int rows = st ? s_img : s_txt;
@@ -427,12 +469,14 @@ int omx_klein_forward_with_rope(omx_klein m, void* out, const void* latent, cons
             if (gated_projection(m, x2 + r0 * h, m->att + r0 * hl, w, x + r0 * h, mod + 2 * h /*gate1*/, rows, h, hl)) return 1;
             // ---- MLP half ----
             if (omx_fused_modulate(m->xm + r0 * h, x2 + r0 * h, mod + 3 * h, mod + 4 * h, 1, rows, h, 1e-6f, OMX_BFLOAT16, s)) return 1;
-            if (linear(m, m->proj, m->xm + r0 * h, (b + sn + "mlp_in.weight").c_str(), rows, 2 * mh, h)) return 1;
-            swiglu_strided_kernel<<<2048, 256, 0, s>>>(m->act, mh, m->proj /*gate = first half*/, m->proj + mh /*up*/, 2 * mh, rows, mh);
+            if (linear(m, proj, m->xm + r0 * h, (b + sn + "mlp_in.weight").c_str(), rows, 2 * mh, h)) return 1;
+            swiglu_strided_kernel<<<2048, 256, 0, s>>>(act, mh, proj /*gate = first half*/, proj + mh /*up*/, 2 * mh, rows, mh);
             OMX_LAUNCH_CHECK();
             if (kget(m, b + sn + "mlp_out.weight", &w)) return 1;
-            if (gated_projection(m, x + r0 * h, m->act, w, x2 + r0 * h, mod + 5 * h /*gate2*/, rows, h, mh)) return 1;
+            if (gated_projection(m, x + r0 * h, act, w, x2 + r0 * h, mod + 5 * h /*gate2*/, rows, h, mh)) return 1;
         }
+        on_stream(1);
+        if (join()) return 1;
     }
     // x already holds [txt, img] (klein_model.rs:833)
     const int64_t ldp = 3 * (int64_t)hl + 2 * mh, ldc = (int64_t)hl + mh;

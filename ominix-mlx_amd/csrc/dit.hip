@@ -291,7 +291,7 @@ int omx_klein_set_comm(omx_klein m, void* comm, void* allreduce_fn) {
 int omx_klein_synth_weights(omx_klein m, uint32_t base_seed) {
     OMX_REQUIRE(m, "omx_klein_synth_weights: null model");
     const omx_klein_config& c = m->cfg;
-    const int h = c.hidden_size, mh = c.mlp_hidden;
+    const int h = c.hidden_size, mh = c.mlp_hidden, D = c.head_dim;
     const int r = c.tp_rank, hl = m->h_l, ml = m->mh_l;
     struct Seg { int64_t start, len; };
     const float amp_w = (float)(0.02 * sqrt(3.0)), amp_n = (float)(0.01 * sqrt(3.0));

@@ -92,6 +92,14 @@ int omx_fused_modulate(void* out, const void* x, const void* shift, const void* 
  *      M <= 8 takes the HBM-streaming GEMV path, larger M the MFMA GEMM path.                  */
 int omx_linear(void* out, const void* x, const void* w, const void* bias, int M, int N, int K,
                omx_dtype dtype, omx_stream stream);
+/* Linear whose trailing 2*half output features are a [gate | up] pair consumed by fused_swiglu
+ * (metal_kernels.rs:188-236) -- the FLUX blocks' mlp_in / to_qkv_mlp projections (klein_model.rs:489-493,
+ * 905-916).  W [n_plain + 2*half, K].  out_plain [M, n_plain] = x . W[:n_plain]^T,
+ * out_act [M, half] = silu(g) * u with g, u the bf16-rounded gate / up features: the same bits as
+ * omx_linear followed by omx_fused_swiglu, without the 2*half wide intermediate in HBM.
+ * Large shapes only (n_plain % 256 == 0, half % 4 == 0, K % 64 == 0, >= 160 output tiles); others fail.  */
+int omx_linear_swiglu(void* out_plain, void* out_act, const void* x, const void* w, int M, int n_plain,
+                      int half, int K, omx_dtype dtype, omx_stream stream);
 
 /* ---- a1: SDPA.  mlx_fast_scaled_dot_product_attention fast.h:189-198 (fast.rs:121-151;
  *      mlx-rs-core/src/utils.rs:191-209).  q [B,H,Tq,D]; k,v [B,Hkv,Tk,D] with explicit element

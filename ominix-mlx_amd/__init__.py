@@ -67,6 +67,7 @@ SIGNATURES = {
     "omx_fused_swiglu": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     "omx_fused_modulate": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_int, c_void_p]),
     "omx_linear": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "omx_linear_swiglu": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "omx_sdpa": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
                          c_int64, c_int64, c_float, c_int, c_void_p, c_int, c_void_p]),
     "omx_sdpa_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),

@@ -414,6 +414,9 @@ int omx_klein_forward_with_rope(omx_klein m, void* out, const void* latent, cons
     // around each half, so the small txt chain hides under the img chain.
     const char* dual_env = getenv("OMX_KLEIN_DUAL_STREAM");
     const bool dual = !(dual_env && dual_env[0] == '0') && c.tp_size <= 1 && m->allreduce == nullptr && s_txt > 0;
+    // SwiGLU in the epilogue of the producing GEMM (OMX_KLEIN_FUSE_SWIGLU=0 keeps the stored projection + separate kernel)
+    const char* fuse_env = getenv("OMX_KLEIN_FUSE_SWIGLU");
+    const bool fuse_act = !(fuse_env && fuse_env[0] == '0');
     hipStream_t const s_main = m->stream_main;
     auto fork = [&]() -> int {
         if (!dual) return 0;
@@ -469,9 +472,14 @@ int omx_klein_forward_with_rope(omx_klein m, void* out, const void* latent, cons
             if (gated_projection(m, x2 + r0 * h, m->att + r0 * hl, w, x + r0 * h, mod + 2 * h /*gate1*/, rows, h, hl)) return 1;
             // ---- MLP half ----
             if (omx_fused_modulate(m->xm + r0 * h, x2 + r0 * h, mod + 3 * h, mod + 4 * h, 1, rows, h, 1e-6f, OMX_BFLOAT16, s)) return 1;
-            if (linear(m, proj, m->xm + r0 * h, (b + sn + "mlp_in.weight").c_str(), rows, 2 * mh, h)) return 1;
-            swiglu_strided_kernel<<<2048, 256, 0, s>>>(act, mh, proj /*gate = first half*/, proj + mh /*up*/, 2 * mh, rows, mh);
-            OMX_LAUNCH_CHECK();
+            if (fuse_act && gemm_swiglu_supported(rows, 0, mh, h)) {
+                if (kget(m, b + sn + "mlp_in.weight", &w)) return 1;
+                if (launch_gemm_bf16_swiglu(nullptr, 0, act, mh, m->xm + r0 * h, w, rows, 0, mh, h, s)) return 1;
+            } else {
+                if (linear(m, proj, m->xm + r0 * h, (b + sn + "mlp_in.weight").c_str(), rows, 2 * mh, h)) return 1;
+                swiglu_strided_kernel<<<2048, 256, 0, s>>>(act, mh, proj /*gate = first half*/, proj + mh /*up*/, 2 * mh, rows, mh);
+                OMX_LAUNCH_CHECK();
+            }
             if (kget(m, b + sn + "mlp_out.weight", &w)) return 1;
             if (gated_projection(m, x + r0 * h, act, w, x2 + r0 * h, mod + 5 * h /*gate2*/, rows, h, mh)) return 1;
         }
@@ -484,15 +492,21 @@ int omx_klein_forward_with_rope(omx_klein m, void* out, const void* latent, cons
         const std::string b = "single_blocks." + std::to_string(i) + ".";
         const bf16_t* mod = m->mod_single;
         if (omx_fused_modulate(m->xm, x, mod, mod + h, 1, S, h, 1e-6f, OMX_BFLOAT16, s)) return 1;
-        if (linear(m, m->proj, m->xm, (b + "to_qkv_mlp.weight").c_str(), S, (int)ldp, h)) return 1;
+        const bool fused = fuse_act && gemm_swiglu_supported(S, 3 * hl, mh, h);
+        if (fused) {   // q/k/v columns -> proj, SwiGLU of the MLP columns straight into comb[:, hl:]
+            if (kget(m, b + "to_qkv_mlp.weight", &w)) return 1;
+            if (launch_gemm_bf16_swiglu(m->proj, (int)ldp, m->comb + hl, (int)ldc, m->xm, w, S, 3 * hl, mh, h, s)) return 1;
+        } else if (linear(m, m->proj, m->xm, (b + "to_qkv_mlp.weight").c_str(), S, (int)ldp, h)) return 1;
         const unsigned blocks = (unsigned)(((size_t)S * H + 15) / 16);
         const bf16_t* wkn = nullptr;
         if (kget(m, b + "norm_q.weight", &w) || kget(m, b + "norm_k.weight", &wkn)) return 1;
         klein_qk_norm_rope_kernel<<<dim3(blocks, 2), 256, 0, s>>>(m->proj, m->proj + hl, ldp, S, H, w, wkn, rope_cos, rope_sin, 0, rms_eps);
         OMX_LAUNCH_CHECK();
         if (attention(m, m->comb, ldc, m->proj, m->proj + hl, m->proj + 2 * hl, ldp, S)) return 1;          // cols [0, hl)
-        swiglu_strided_kernel<<<2048, 256, 0, s>>>(m->comb + hl, ldc, m->proj + 3 * hl, m->proj + 3 * hl + mh, ldp, S, mh);   // cols [hl, hl+mh)
-        OMX_LAUNCH_CHECK();
+        if (!fused) {
+            swiglu_strided_kernel<<<2048, 256, 0, s>>>(m->comb + hl, ldc, m->proj + 3 * hl, m->proj + 3 * hl + mh, ldp, S, mh);   // cols [hl, hl+mh)
+            OMX_LAUNCH_CHECK();
+        }
         if (kget(m, b + "to_out.weight", &w)) return 1;
         if (gated_projection(m, x2, m->comb, w, x, mod + 2 * h, S, h, (int)ldc)) return 1;
         bf16_t* t = x; x = x2; x2 = t;

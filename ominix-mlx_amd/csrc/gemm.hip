@@ -43,6 +43,14 @@ struct GemmArgs {
     int grid_m, grid_n;
     GroupedDesc g;        // grouped mode when g.tile_expert != nullptr
     int relu;             // out = max(0, acc + bias)  (Paraformer FFN, paraformer.rs:565-569)
+    // SwiGLU segment (256^2 kernel, SW instantiation): W rows [sw_col0, sw_col0 + sw_half) are gate rows, the next sw_half
+    // rows the matching up rows.  Column tiles at or past sw_col0 pair 128 gate with 128 up columns and store
+    // out2[row, c] = bf16(silu(bf16(gate)) * bf16(up)) -- the values swiglu_strided_kernel would produce from the stored
+    // projection -- so the 2 * sw_half wide intermediate never goes to HBM.  Plain tiles store to out with ld_out.
+    int ld_out;           // row stride of out (0: N)
+    int sw_col0, sw_half;
+    bf16_t* out2;
+    int ld2;
 };
 
 // one 16-B chunk per lane per wave-instruction, 4 instructions per operand tile: row pointers of the 4
@@ -205,8 +213,9 @@ constexpr int SMEM = 2 * BUF;
 
 // MF = 16: v_mfma_f32_16x16x32_bf16, eight independent accumulators per k step inside a phase (a dependent MFMA is
 // eight issues away); MF = 32: v_mfma_f32_32x32x16_bf16, two accumulators per phase (bit-identical to the 128^2 kernel)
-template <int MF>
+template <int MF, bool SW = false>
 __global__ __launch_bounds__(big::NT) void gemm_bf16_nt_256_kernel(const GemmArgs a) {
+    static_assert(!SW || MF == 16, "the SwiGLU epilogue is written for the 16x16 accumulator layout");
     using namespace big;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -247,7 +256,13 @@ __global__ __launch_bounds__(big::NT) void gemm_bf16_nt_256_kernel(const GemmArg
             const int trow = (row >> 6) * 128 + sidx * 64 + (row & 63);
             const int tcol = (row >> 5) * 64 + sidx * 32 + (row & 31);
             srcX[sidx][i] = a.x + (size_t)min(m0 + trow, a.M - 1) * a.K + kc * 8;
-            srcY[sidx][i] = a.w + (size_t)min(n0 + tcol, a.N - 1) * a.K + kc * 8;
+            int wrow = min(n0 + tcol, a.N - 1);
+            if (SW && n0 >= a.sw_col0) {
+                // Y0 (tile cols wc * 64 + [0, 32)) <- gate rows, Y1 (wc * 64 + [32, 64)) <- up rows of the same 32 outputs
+                const int oc = (n0 - a.sw_col0) / 2 + (row >> 5) * 32 + (row & 31);
+                wrow = a.sw_col0 + sidx * a.sw_half + min(oc, a.sw_half - 1);
+            }
+            srcY[sidx][i] = a.w + (size_t)wrow * a.K + kc * 8;
         }
     auto stage = [&](const bf16_t* const (&src)[2], int k0, unsigned char* piece) {
 #pragma unroll
@@ -372,6 +387,31 @@ __global__ __launch_bounds__(big::NT) void gemm_bf16_nt_256_kernel(const GemmArg
     // epilogue.  The products were issued as W-tile x X-tile (operands swapped), so a lane holds runs of FOUR
     // consecutive output columns of one row: 16x16 -> row = lane & 15, cols 4 * (lane >> 4) + [0,4);
     // 32x32 -> row = lane & 31, cols 8 * g + 4 * (lane >> 5) + [0,4) for g = 0..3.  One 8-byte store per run.
+    if constexpr (SW) {
+        if (n0 >= a.sw_col0) {
+            const int c0 = (n0 - a.sw_col0) / 2 + wc * 32 + 4 * (lane >> 4);
+#pragma unroll
+            for (int i = 0; i < RT; ++i) {
+                const int row = m0 + wr * 128 + i * MF + (lane & LR);
+                if (row >= a.M) continue;
+#pragma unroll
+                for (int j = 0; j < CT / 2; ++j) {
+                    const int col = c0 + j * MF;
+                    if (col >= a.sw_half) continue;   // sw_half is a multiple of 4: a run is inside or outside
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float gt = round_bf16(acc[i][j][e]), up = round_bf16(acc[i][j + CT / 2][e]);
+                        v[e] = gt / (1.0f + expf(-gt)) * up;
+                    }
+                    *reinterpret_cast<u32x2*>(a.out2 + (size_t)row * a.ld2 + col) = u32x2{pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3])};
+                }
+            }
+            return;
+        }
+    }
+    const int n_plain = SW ? a.sw_col0 : a.N;          // columns stored by the plain epilogue
+    const int ldo = SW ? a.ld_out : a.N;
 #pragma unroll
     for (int i = 0; i < RT; ++i) {
         const int row = m0 + wr * 128 + i * MF + (lane & LR);
@@ -381,9 +421,9 @@ __global__ __launch_bounds__(big::NT) void gemm_bf16_nt_256_kernel(const GemmArg
 #pragma unroll
             for (int g = 0; g < AR / 4; ++g) {
                 const int col = n0 + wc * 64 + j * MF + (MF == 32 ? 8 * g + 4 * (lane >> 5) : 4 * (lane >> 4));
-                if (col >= a.N) continue;
-                const size_t o = (size_t)row * a.N + col;
-                const bool full = col + 3 < a.N && (a.N & 3) == 0;
+                if (col >= n_plain) continue;
+                const size_t o = (size_t)row * ldo + col;
+                const bool full = col + 3 < n_plain && (n_plain & 3) == 0 && (ldo & 3) == 0;
                 float v[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e];
@@ -410,7 +450,7 @@ __global__ __launch_bounds__(big::NT) void gemm_bf16_nt_256_kernel(const GemmArg
                 } else {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        if (col + e >= a.N) break;
+                        if (col + e >= n_plain) break;
                         float x = v[e] + (a.bias ? bf16_to_f32(a.bias[col + e]) : 0.f);
                         if (a.relu) x = fmaxf(x, 0.f);
                         if (a.gate) x = bf16_to_f32(a.resid[o + e]) + x * bf16_to_f32(a.gate[col + e]);
@@ -478,6 +518,7 @@ int ensure_attr() {
         OMX_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_bf16_nt_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, shmem));
         OMX_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_bf16_nt_256_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, big::SMEM));
         OMX_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_bf16_nt_256_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, big::SMEM));
+        OMX_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_bf16_nt_256_kernel<16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big::SMEM));
         attr_set = true;
     }
     return 0;
@@ -509,6 +550,27 @@ static int launch_gemm_impl(bf16_t* out, const bf16_t* x, const bf16_t* w, const
     } else {
         gemm_bf16_nt_generic_kernel<<<dim3((N + 63) / 64, (M + 63) / 64), NTHREADS, 0, s>>>(a);
     }
+    OMX_LAUNCH_CHECK();
+    return 0;
+}
+
+bool gemm_swiglu_supported(int M, int n_plain, int half, int K) {
+    if (M <= 0 || n_plain < 0 || half <= 0 || K <= 0) return false;
+    if (K % BK != 0 || n_plain % 256 != 0 || half % 4 != 0) return false;
+    const int tiles = ((M + 255) / 256) * (n_plain / 256 + (half + 127) / 128);
+    return tiles >= 160;   // same chip-filling rule as the plain 256^2 dispatch
+}
+
+int launch_gemm_bf16_swiglu(bf16_t* out_plain, int ld_plain, bf16_t* out_act, int ld_act, const bf16_t* x, const bf16_t* w, int M,
+                            int n_plain, int half, int K, hipStream_t s) {
+    OMX_REQUIRE(gemm_swiglu_supported(M, n_plain, half, K), "swiglu gemm: unsupported shape M=%d plain=%d half=%d K=%d", M, n_plain, half, K);
+    OMX_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w)) & 15u) == 0 && (ld_act & 3) == 0 &&
+                    (n_plain == 0 || (out_plain && (ld_plain & 3) == 0)) && out_act,
+                "swiglu gemm: operands must be 16-byte aligned and row strides multiples of 4");
+    if (ensure_attr()) return 1;
+    GemmArgs a = {x, w, nullptr, nullptr, nullptr, out_plain, M, n_plain + 2 * half, K, (M + 255) / 256,
+                  n_plain / 256 + (half + 127) / 128, {}, 0, ld_plain, n_plain, half, out_act, ld_act};
+    gemm_bf16_nt_256_kernel<16, true><<<a.grid_m * a.grid_n, big::NT, big::SMEM, s>>>(a);
     OMX_LAUNCH_CHECK();
     return 0;
 }

@@ -29,6 +29,14 @@ int launch_gemm_bf16_bias_relu(bf16_t* out, const bf16_t* x, const bf16_t* w, co
 int launch_gemm_bf16_gated(bf16_t* out, const bf16_t* x, const bf16_t* w, const bf16_t* resid, const bf16_t* gate, int M,
                            int N, int K, hipStream_t s);
 
+// projection with a SwiGLU segment (256^2 kernel): W = [n_plain plain rows | half gate rows | half up rows], all [., K].
+//   out_plain[m, c] = bf16(x.W[c]^T) for c < n_plain (row stride ld_plain),
+//   out_act[m, c]   = bf16(silu(g) * u), g = bf16(x.W[n_plain + c]^T), u = bf16(x.W[n_plain + half + c]^T)  (row stride ld_act)
+// -- bit-identical to storing the whole projection and running fused_swiglu over it (klein_model.rs:489-493, 905-916).
+bool gemm_swiglu_supported(int M, int n_plain, int half, int K);
+int launch_gemm_bf16_swiglu(bf16_t* out_plain, int ld_plain, bf16_t* out_act, int ld_act, const bf16_t* x, const bf16_t* w, int M,
+                            int n_plain, int half, int K, hipStream_t s);
+
 // rows sorted by expert: out[p, :] = x[row_src ? row_src[p] : p, :] . W[e(p)]^T, p in expert-sorted order
 int launch_gemm_bf16_grouped(bf16_t* out, const bf16_t* x, const bf16_t* w, int max_rows, int N, int K,
                              const GroupedDesc& g, int max_tiles, hipStream_t s);

@@ -218,6 +218,22 @@ def linear(x: Tensor, w: Tensor, bias: Optional[Tensor] = None) -> Tensor:
     return out
 
 
+def linear_swiglu(x: Tensor, w: Tensor, n_plain: int):
+    """Linear + fused_swiglu over the trailing [gate | up] features in one launch (include/omx.h: omx_linear_swiglu).
+    -> (plain [M, n_plain] or None, act [M, half])."""
+    N, K = w.shape
+    if x.shape[-1] != K:
+        raise OmxError(f"linear_swiglu: input features {x.shape[-1]} != weight in-features {K}")
+    if (N - n_plain) % 2 or N <= n_plain:
+        raise OmxError(f"linear_swiglu: {N} weight rows do not split into {n_plain} plain + an even gate/up pair")
+    half = (N - n_plain) // 2
+    M = x.size // K
+    plain = Tensor(tuple(x.shape[:-1]) + (n_plain,), x.dtype) if n_plain else None
+    act = Tensor(tuple(x.shape[:-1]) + (half,), x.dtype)
+    check(lib.omx_linear_swiglu(_p(plain), act.ptr, x.ptr, w.ptr, M, n_plain, half, K, x.dtype, None))
+    return plain, act
+
+
 def take_rows(table: Tensor, ids: Tensor) -> Tensor:
     """nn::Embedding::forward (gather rows)."""
     dim = table.shape[-1]

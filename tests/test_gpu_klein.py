@@ -99,3 +99,27 @@ def test_klein_tensor_parallel_two_ranks_on_one_gpu(omx, use_synth):
     rcos, rsin = klein.compute_rope(klein.create_txt_ids(s_txt), klein.create_img_ids(*grid))
     one = single.forward_with_rope(T.from_numpy(latent), T.from_numpy(txt), 750.0, rcos, rsin).numpy()
     assert np.abs(outs[0] - one).max() <= bound
+
+
+def test_klein_step_schedule_variants_are_bit_identical(omx, monkeypatch):
+    """The launch-level optimisations of the step -- txt/img halves of a double block on two HIP streams, SwiGLU in the
+    epilogue of the producing GEMM -- are scheduling choices: at a size where both engage (1 double + 1 single block of the
+    real width, 512 + 2304 tokens) the velocity must be the same bits with either switched off."""
+    from ominix_mlx_amd import klein
+    g, s_txt = 48, 512
+    outs = {}
+    for name, env in {"default": {}, "one_stream": {"OMX_KLEIN_DUAL_STREAM": "0"}, "swiglu_kernel": {"OMX_KLEIN_FUSE_SWIGLU": "0"}}.items():
+        for k in ("OMX_KLEIN_DUAL_STREAM", "OMX_KLEIN_FUSE_SWIGLU"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        m = klein.FluxKlein(depth=1, depth_single=1)
+        m.synth_weights()
+        lat = omx.ops.fill_uniform((g * g, 128), 1, 1.7)
+        txt = omx.ops.fill_uniform((s_txt, 7680), 2, 1.7)
+        rcos, rsin = klein.compute_rope(klein.create_txt_ids(s_txt), klein.create_img_ids(g, g))
+        outs[name] = m.forward_with_rope(lat, txt, 500.0, rcos, rsin).numpy()
+        m.close()
+    assert np.isfinite(outs["default"]).all() and np.abs(outs["default"]).max() > 0
+    np.testing.assert_array_equal(outs["default"], outs["one_stream"])
+    np.testing.assert_array_equal(outs["default"], outs["swiglu_kernel"])

@@ -343,3 +343,36 @@ def test_linear_decode_shapes_without_a_tuned_gemv(omx, M, N, K):
     want = rc.linear(x, w, None, "bf16")
     noise = 4 * 2.0 ** -9 * np.sqrt(((x.astype(np.float64) ** 2) @ (w.astype(np.float64) ** 2).T)) * 2.0 ** -8
     assert_bf16_close(got, want, 1, atol=float(noise.max()) + 1e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,n_plain,half,K", [
+    (4608, 0, 3072, 256),        # FLUX double-block mlp_in shape class (no plain columns)
+    (2304, 768, 2560, 128),      # single-block to_qkv_mlp shape class: q/k/v columns + [gate | up]
+    (300, 256, 10244, 64),       # ragged rows, half not a multiple of the 128-column tile
+])
+def test_linear_swiglu_matches_linear_then_fused_swiglu(omx, M, n_plain, half, K):
+    """omx_linear_swiglu is an in-epilogue form of nn::Linear + fused_swiglu (klein_model.rs:489-493, 905-916):
+    bit-identical to the two-launch composition, and the composition is what the oracle is compared with."""
+    T = omx.ops.Tensor
+    x = rc.bf16_round(rand((M, K), 1200 + M))
+    w = rc.bf16_round(rand((n_plain + 2 * half, K), 1201 + K) * 0.2)
+    xt, wt = T.from_numpy(x), T.from_numpy(w)
+    plain, act = omx.ops.linear_swiglu(xt, wt, n_plain)
+    full = omx.ops.linear(xt, wt).numpy()
+    gate = np.ascontiguousarray(full[:, n_plain:n_plain + half])
+    up = np.ascontiguousarray(full[:, n_plain + half:])
+    want = omx.ops.fused_swiglu(T.from_numpy(up), T.from_numpy(gate)).numpy()
+    assert np.array_equal(act.numpy(), want)
+    if n_plain:
+        assert np.array_equal(plain.numpy(), full[:, :n_plain])
+    # and against the oracle's own composition
+    ref = rc.fused_swiglu(rc.bf16_round(up.astype(np.float32)), rc.bf16_round(gate.astype(np.float32)), "bf16")
+    assert_bf16_close(act.numpy(), ref, 1, atol=1e-6)
+
+
+@pytest.mark.gpu
+def test_linear_swiglu_rejects_small_shapes(omx):
+    T = omx.ops.Tensor
+    with pytest.raises(omx.OmxError):
+        omx.ops.linear_swiglu(T.from_numpy(np.zeros((8, 64), np.float32)), T.from_numpy(np.zeros((256, 64), np.float32)), 0)

@@ -745,14 +745,27 @@ int prefill_prefix_batched(omx_qwen3 m, int T, int off, const EncodeOpts* enc = 
     const LayerQ no_q = {};
     const int n_run = enc ? enc->taps[enc->n_taps - 1] + 1 : c.num_hidden_layers;
     int next_tap = 0;
+    const char* seg_env = getenv("OMX_PREFILL_SEGMENTED");   // 0: one launch per projection (A/B, tests)
+    const bool seg_gemm = !(seg_env && seg_env[0] == '0');
     for (int l = 0; l < n_run; ++l) {
         const LayerW& L = m->layers[l];
         const LayerQ& Q = quant ? m->qlayers[l] : no_q;
         const bf16_t* w = nullptr;
         if (omx_rms_norm(m->pf_xn, h, L.in_ln, T, hd, c.rms_norm_eps, OMX_BFLOAT16, s)) return 1;
-        if (!(w = W(L.q, &Q.q, hd)) || launch_gemm_bf16(m->pf_q, m->pf_xn, w, L.q_bias, T, H * D, hd, s)) return 1;
-        if (!(w = W(L.k, &Q.k, hd)) || launch_gemm_bf16(m->pf_k, m->pf_xn, w, L.k_bias, T, Hkv * D, hd, s)) return 1;
-        if (!(w = W(L.v, &Q.v, hd)) || launch_gemm_bf16(m->pf_v, m->pf_xn, w, L.v_bias, T, Hkv * D, hd, s)) return 1;
+        // q, k, v: one segmented launch over the three borrowed weights when the chip is filled that way (the separate k / v
+        // grids are 128 tiles on 512 slots), else three launches
+        GemmSegs qkv = {};
+        qkv.n_plain = 3;
+        qkv.plain[0] = {L.q, L.q_bias, m->pf_q, H * D, H * D, 0};
+        qkv.plain[1] = {L.k, L.k_bias, m->pf_k, Hkv * D, Hkv * D, 0};
+        qkv.plain[2] = {L.v, L.v_bias, m->pf_v, Hkv * D, Hkv * D, 0};
+        if (seg_gemm && !quant && gemm_segmented_supported(T, hd, qkv)) {
+            if (launch_gemm_bf16_segmented(m->pf_xn, T, hd, qkv, s)) return 1;
+        } else {
+            if (!(w = W(L.q, &Q.q, hd)) || launch_gemm_bf16(m->pf_q, m->pf_xn, w, L.q_bias, T, H * D, hd, s)) return 1;
+            if (!(w = W(L.k, &Q.k, hd)) || launch_gemm_bf16(m->pf_k, m->pf_xn, w, L.k_bias, T, Hkv * D, hd, s)) return 1;
+            if (!(w = W(L.v, &Q.v, hd)) || launch_gemm_bf16(m->pf_v, m->pf_xn, w, L.v_bias, T, Hkv * D, hd, s)) return 1;
+        }
         if (launch_qk_norm_rope_scatter(m->pf_q, m->pf_k, m->pf_v, L.q_norm, L.k_norm, m->rope_cos, m->rope_sin, m->pf_qt,
                                         m->kcache[l], m->vcache[l], T, H, Hkv, D, m->cap, off, c.rms_norm_eps, s))
             return 1;
@@ -783,9 +796,17 @@ int prefill_prefix_batched(omx_qwen3 m, int T, int off, const EncodeOpts* enc = 
             }
             continue;
         }
-        if (!(w = W(L.gate, &Q.gate, hd)) || launch_gemm_bf16(m->pf_g, m->pf_xn, w, nullptr, T, I, hd, s)) return 1;
-        if (!(w = W(L.up, &Q.up, hd)) || launch_gemm_bf16(m->pf_u, m->pf_xn, w, nullptr, T, I, hd, s)) return 1;
-        if (launch_silu_mul(m->pf_g, m->pf_g, m->pf_u, (int64_t)T * I, s)) return 1;
+        // gate, up and nn::silu(gate) * up: one launch with the activation in the epilogue (768 tiles = 3 full rounds at
+        // T = 2048 instead of 2 x 384), else two GEMMs + the elementwise kernel
+        GemmSegs gu = {};
+        gu.w_gate = L.gate; gu.w_up = L.up; gu.out_act = m->pf_g; gu.half = I; gu.ld_act = I; gu.act_mode = 1;
+        if (seg_gemm && !quant && gemm_segmented_supported(T, hd, gu)) {
+            if (launch_gemm_bf16_segmented(m->pf_xn, T, hd, gu, s)) return 1;
+        } else {
+            if (!(w = W(L.gate, &Q.gate, hd)) || launch_gemm_bf16(m->pf_g, m->pf_xn, w, nullptr, T, I, hd, s)) return 1;
+            if (!(w = W(L.up, &Q.up, hd)) || launch_gemm_bf16(m->pf_u, m->pf_xn, w, nullptr, T, I, hd, s)) return 1;
+            if (launch_silu_mul(m->pf_g, m->pf_g, m->pf_u, (int64_t)T * I, s)) return 1;
+        }
         if (!(w = W(L.down, &Q.down, I)) || launch_gemm_bf16_ex(h, m->pf_g, w, nullptr, h2, T, hd, I, s)) return 1;
         if (enc && next_tap < enc->n_taps && enc->taps[next_tap] == l) {   // raw hidden state, no final norm (:417-420)
             copy_rows_strided_kernel<<<1024, 256, 0, s>>>(enc->out + (size_t)next_tap * hd, (int64_t)enc->n_taps * hd, h, hd, T, hd / 8);

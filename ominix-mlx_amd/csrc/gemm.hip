@@ -43,14 +43,7 @@ struct GemmArgs {
     int grid_m, grid_n;
     GroupedDesc g;        // grouped mode when g.tile_expert != nullptr
     int relu;             // out = max(0, acc + bias)  (Paraformer FFN, paraformer.rs:565-569)
-    // SwiGLU segment (256^2 kernel, SW instantiation): W rows [sw_col0, sw_col0 + sw_half) are gate rows, the next sw_half
-    // rows the matching up rows.  Column tiles at or past sw_col0 pair 128 gate with 128 up columns and store
-    // out2[row, c] = bf16(silu(bf16(gate)) * bf16(up)) -- the values swiglu_strided_kernel would produce from the stored
-    // projection -- so the 2 * sw_half wide intermediate never goes to HBM.  Plain tiles store to out with ld_out.
-    int ld_out;           // row stride of out (0: N)
-    int sw_col0, sw_half;
-    bf16_t* out2;
-    int ld2;
+    GemmSegs sg;          // segmented mode (256^2 kernel, SW instantiation), see gemm.hpp
 };
 
 // one 16-B chunk per lane per wave-instruction, 4 instructions per operand tile: row pointers of the 4
@@ -239,6 +232,25 @@ __global__ __launch_bounds__(big::NT) void gemm_bf16_nt_256_kernel(const GemmArg
         tm = first_m + in_group % gm;
         tn = in_group / gm;
     }
+    // segmented mode: the column tile belongs to one projection (own weight, bias, output, width); n0 is local to it
+    const bf16_t* seg_w = a.w;
+    const bf16_t* seg_bias = nullptr;
+    bf16_t* seg_out = a.out;
+    int seg_cols = a.N, seg_ld = a.N;
+    bool seg_act = false;
+    if constexpr (SW) {
+        const GemmSegs& g = a.sg;
+        if (tn >= g.act_tile0) {
+            seg_act = true;
+            tn -= g.act_tile0;
+            seg_cols = g.half;
+        } else {
+            const int sidx = (g.n_plain > 1 && tn >= g.plain[1].tile0) + (g.n_plain > 2 && tn >= g.plain[2].tile0);
+            const GemmSeg& sgm = g.plain[sidx];
+            seg_w = sgm.w; seg_bias = sgm.bias; seg_out = sgm.out; seg_cols = sgm.cols; seg_ld = sgm.ld;
+            tn -= sgm.tile0;
+        }
+    }
     const int m0 = tm * TM, n0 = tn * TN;
     const int nt = a.K / TK;
 
@@ -256,13 +268,17 @@ __global__ __launch_bounds__(big::NT) void gemm_bf16_nt_256_kernel(const GemmArg
             const int trow = (row >> 6) * 128 + sidx * 64 + (row & 63);
             const int tcol = (row >> 5) * 64 + sidx * 32 + (row & 31);
             srcX[sidx][i] = a.x + (size_t)min(m0 + trow, a.M - 1) * a.K + kc * 8;
-            int wrow = min(n0 + tcol, a.N - 1);
-            if (SW && n0 >= a.sw_col0) {
-                // Y0 (tile cols wc * 64 + [0, 32)) <- gate rows, Y1 (wc * 64 + [32, 64)) <- up rows of the same 32 outputs
-                const int oc = (n0 - a.sw_col0) / 2 + (row >> 5) * 32 + (row & 31);
-                wrow = a.sw_col0 + sidx * a.sw_half + min(oc, a.sw_half - 1);
+            if constexpr (SW) {
+                if (seg_act) {
+                    // Y0 (tile cols wc * 64 + [0, 32)) <- gate rows, Y1 (wc * 64 + [32, 64)) <- up rows of the same 32 outputs
+                    const int oc = n0 / 2 + (row >> 5) * 32 + (row & 31);
+                    srcY[sidx][i] = (sidx ? a.sg.w_up : a.sg.w_gate) + (size_t)min(oc, seg_cols - 1) * a.K + kc * 8;
+                } else {
+                    srcY[sidx][i] = seg_w + (size_t)min(n0 + tcol, seg_cols - 1) * a.K + kc * 8;
+                }
+            } else {
+                srcY[sidx][i] = a.w + (size_t)min(n0 + tcol, a.N - 1) * a.K + kc * 8;
             }
-            srcY[sidx][i] = a.w + (size_t)wrow * a.K + kc * 8;
         }
     auto stage = [&](const bf16_t* const (&src)[2], int k0, unsigned char* piece) {
 #pragma unroll
@@ -388,8 +404,9 @@ __global__ __launch_bounds__(big::NT) void gemm_bf16_nt_256_kernel(const GemmArg
     // consecutive output columns of one row: 16x16 -> row = lane & 15, cols 4 * (lane >> 4) + [0,4);
     // 32x32 -> row = lane & 31, cols 8 * g + 4 * (lane >> 5) + [0,4) for g = 0..3.  One 8-byte store per run.
     if constexpr (SW) {
-        if (n0 >= a.sw_col0) {
-            const int c0 = (n0 - a.sw_col0) / 2 + wc * 32 + 4 * (lane >> 4);
+        if (seg_act) {
+            const int c0 = n0 / 2 + wc * 32 + 4 * (lane >> 4);
+            const bool per_op = a.sg.act_mode == 1;
 #pragma unroll
             for (int i = 0; i < RT; ++i) {
                 const int row = m0 + wr * 128 + i * MF + (lane & LR);
@@ -397,21 +414,44 @@ __global__ __launch_bounds__(big::NT) void gemm_bf16_nt_256_kernel(const GemmArg
 #pragma unroll
                 for (int j = 0; j < CT / 2; ++j) {
                     const int col = c0 + j * MF;
-                    if (col >= a.sw_half) continue;   // sw_half is a multiple of 4: a run is inside or outside
+                    if (col >= seg_cols) continue;   // half is a multiple of 4: a run is inside or outside
                     float v[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const float gt = round_bf16(acc[i][j][e]), up = round_bf16(acc[i][j + CT / 2][e]);
-                        v[e] = gt / (1.0f + expf(-gt)) * up;
+                        if (per_op) {   // nn::silu(gate) * up, each primitive rounded to bf16 (silu_mul_kernel, prefill.hip)
+                            const float sg = round_bf16(1.0f / (1.0f + expf(-gt)));
+                            v[e] = round_bf16(gt * sg) * up;
+                        } else {        // fused_swiglu: one rounding (swiglu_strided_kernel, dit.hip)
+                            v[e] = gt / (1.0f + expf(-gt)) * up;
+                        }
                     }
-                    *reinterpret_cast<u32x2*>(a.out2 + (size_t)row * a.ld2 + col) = u32x2{pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3])};
+                    *reinterpret_cast<u32x2*>(a.sg.out_act + (size_t)row * a.sg.ld_act + col) =
+                        u32x2{pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3])};
                 }
             }
-            return;
+        } else {
+#pragma unroll
+            for (int i = 0; i < RT; ++i) {
+                const int row = m0 + wr * 128 + i * MF + (lane & LR);
+                if (row >= a.M) continue;
+#pragma unroll
+                for (int j = 0; j < CT; ++j) {
+                    const int col = n0 + wc * 64 + j * MF + 4 * (lane >> 4);
+                    if (col >= seg_cols) continue;   // widths are multiples of 4
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = acc[i][j][e];
+                    if (seg_bias) {
+                        const u32x2 b = *reinterpret_cast<const u32x2*>(seg_bias + col);
+                        v[0] += bf16lo(b[0]); v[1] += bf16hi(b[0]); v[2] += bf16lo(b[1]); v[3] += bf16hi(b[1]);
+                    }
+                    *reinterpret_cast<u32x2*>(seg_out + (size_t)row * seg_ld + col) = u32x2{pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3])};
+                }
+            }
         }
+        return;
     }
-    const int n_plain = SW ? a.sw_col0 : a.N;          // columns stored by the plain epilogue
-    const int ldo = SW ? a.ld_out : a.N;
 #pragma unroll
     for (int i = 0; i < RT; ++i) {
         const int row = m0 + wr * 128 + i * MF + (lane & LR);
@@ -421,9 +461,9 @@ __global__ __launch_bounds__(big::NT) void gemm_bf16_nt_256_kernel(const GemmArg
 #pragma unroll
             for (int g = 0; g < AR / 4; ++g) {
                 const int col = n0 + wc * 64 + j * MF + (MF == 32 ? 8 * g + 4 * (lane >> 5) : 4 * (lane >> 4));
-                if (col >= n_plain) continue;
-                const size_t o = (size_t)row * ldo + col;
-                const bool full = col + 3 < n_plain && (n_plain & 3) == 0 && (ldo & 3) == 0;
+                if (col >= a.N) continue;
+                const size_t o = (size_t)row * a.N + col;
+                const bool full = col + 3 < a.N && (a.N & 3) == 0;
                 float v[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e];
@@ -450,7 +490,7 @@ __global__ __launch_bounds__(big::NT) void gemm_bf16_nt_256_kernel(const GemmArg
                 } else {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        if (col + e >= n_plain) break;
+                        if (col + e >= a.N) break;
                         float x = v[e] + (a.bias ? bf16_to_f32(a.bias[col + e]) : 0.f);
                         if (a.relu) x = fmaxf(x, 0.f);
                         if (a.gate) x = bf16_to_f32(a.resid[o + e]) + x * bf16_to_f32(a.gate[col + e]);
@@ -554,25 +594,72 @@ static int launch_gemm_impl(bf16_t* out, const bf16_t* x, const bf16_t* w, const
     return 0;
 }
 
+static int seg_tiles(const GemmSegs& g) {
+    int t = 0;
+    for (int i = 0; i < g.n_plain; ++i) t += (g.plain[i].cols + 255) / 256;
+    return t + (g.half > 0 ? (g.half + 127) / 128 : 0);
+}
+
+bool gemm_segmented_supported(int M, int K, const GemmSegs& g) {
+    if (M <= 0 || K <= 0 || K % BK != 0 || g.n_plain < 0 || g.n_plain > 3 || (g.n_plain == 0 && g.half <= 0)) return false;
+    for (int i = 0; i < g.n_plain; ++i)
+        if (g.plain[i].cols <= 0 || g.plain[i].cols % 4 != 0 || g.plain[i].ld % 4 != 0) return false;
+    if (g.half < 0 || g.half % 4 != 0 || (g.half > 0 && g.ld_act % 4 != 0)) return false;
+    return ((M + 255) / 256) * seg_tiles(g) >= 160;   // same chip-filling rule as the plain 256^2 dispatch
+}
+
+int launch_gemm_bf16_segmented(const bf16_t* x, int M, int K, const GemmSegs& segs, hipStream_t s) {
+    OMX_REQUIRE(gemm_segmented_supported(M, K, segs), "segmented gemm: unsupported shape (M=%d K=%d, %d plain segments, half=%d)", M, K,
+                segs.n_plain, segs.half);
+    uintptr_t align = reinterpret_cast<uintptr_t>(x);
+    for (int i = 0; i < segs.n_plain; ++i) {
+        OMX_REQUIRE(segs.plain[i].w && segs.plain[i].out, "segmented gemm: null weight / output in segment %d", i);
+        align |= reinterpret_cast<uintptr_t>(segs.plain[i].w);
+    }
+    if (segs.half > 0) {
+        OMX_REQUIRE(segs.w_gate && segs.w_up && segs.out_act, "segmented gemm: null gate / up / activation pointer");
+        align |= reinterpret_cast<uintptr_t>(segs.w_gate) | reinterpret_cast<uintptr_t>(segs.w_up);
+    }
+    OMX_REQUIRE((align & 15u) == 0, "segmented gemm: operands must be 16-byte aligned");
+    if (ensure_attr()) return 1;
+    GemmArgs a = {};
+    a.x = x; a.M = M; a.K = K;
+    a.sg = segs;
+    int t = 0, n = 0;
+    for (int i = 0; i < segs.n_plain; ++i) {
+        a.sg.plain[i].tile0 = t;
+        t += (segs.plain[i].cols + 255) / 256;
+        n += segs.plain[i].cols;
+    }
+    a.sg.act_tile0 = segs.half > 0 ? t : 0x7FFFFFFF;
+    a.N = n + 2 * segs.half;
+    a.grid_m = (M + 255) / 256;
+    a.grid_n = seg_tiles(segs);
+    gemm_bf16_nt_256_kernel<16, true><<<a.grid_m * a.grid_n, big::NT, big::SMEM, s>>>(a);
+    OMX_LAUNCH_CHECK();
+    return 0;
+}
+
+static GemmSegs swiglu_segs(bf16_t* out_plain, int ld_plain, bf16_t* out_act, int ld_act, const bf16_t* w, int n_plain, int half, int K) {
+    GemmSegs g = {};
+    if (n_plain > 0) {
+        g.n_plain = 1;
+        g.plain[0] = {w, nullptr, out_plain, n_plain, ld_plain, 0};
+    }
+    g.w_gate = w + (size_t)n_plain * K;
+    g.w_up = g.w_gate + (size_t)half * K;
+    g.out_act = out_act; g.half = half; g.ld_act = ld_act; g.act_mode = 0;
+    return g;
+}
+
 bool gemm_swiglu_supported(int M, int n_plain, int half, int K) {
-    if (M <= 0 || n_plain < 0 || half <= 0 || K <= 0) return false;
-    if (K % BK != 0 || n_plain % 256 != 0 || half % 4 != 0) return false;
-    const int tiles = ((M + 255) / 256) * (n_plain / 256 + (half + 127) / 128);
-    return tiles >= 160;   // same chip-filling rule as the plain 256^2 dispatch
+    if (n_plain < 0 || half <= 0) return false;
+    return gemm_segmented_supported(M, K, swiglu_segs(nullptr, 4, nullptr, 4, nullptr, n_plain, half, K));
 }
 
 int launch_gemm_bf16_swiglu(bf16_t* out_plain, int ld_plain, bf16_t* out_act, int ld_act, const bf16_t* x, const bf16_t* w, int M,
                             int n_plain, int half, int K, hipStream_t s) {
-    OMX_REQUIRE(gemm_swiglu_supported(M, n_plain, half, K), "swiglu gemm: unsupported shape M=%d plain=%d half=%d K=%d", M, n_plain, half, K);
-    OMX_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w)) & 15u) == 0 && (ld_act & 3) == 0 &&
-                    (n_plain == 0 || (out_plain && (ld_plain & 3) == 0)) && out_act,
-                "swiglu gemm: operands must be 16-byte aligned and row strides multiples of 4");
-    if (ensure_attr()) return 1;
-    GemmArgs a = {x, w, nullptr, nullptr, nullptr, out_plain, M, n_plain + 2 * half, K, (M + 255) / 256,
-                  n_plain / 256 + (half + 127) / 128, {}, 0, ld_plain, n_plain, half, out_act, ld_act};
-    gemm_bf16_nt_256_kernel<16, true><<<a.grid_m * a.grid_n, big::NT, big::SMEM, s>>>(a);
-    OMX_LAUNCH_CHECK();
-    return 0;
+    return launch_gemm_bf16_segmented(x, M, K, swiglu_segs(out_plain, n_plain > 0 ? ld_plain : 4, out_act, ld_act, w, n_plain, half, K), s);
 }
 
 int launch_gemm_bf16_ex(bf16_t* out, const bf16_t* x, const bf16_t* w, const bf16_t* bias, const bf16_t* resid, int M,

@@ -29,6 +29,33 @@ int launch_gemm_bf16_bias_relu(bf16_t* out, const bf16_t* x, const bf16_t* w, co
 int launch_gemm_bf16_gated(bf16_t* out, const bf16_t* x, const bf16_t* w, const bf16_t* resid, const bf16_t* gate, int M,
                            int N, int K, hipStream_t s);
 
+// Segmented projection (256^2 kernel): ONE launch computes up to three plain Linears of the same input -- each with its own
+// weight [cols, K], optional bias, output and row stride -- followed by an optional SwiGLU pair: column tiles of the last
+// segment take 128 gate and the matching 128 up rows, and store act[m, c] = silu(bf16(x.Wg[c]^T)) * bf16(x.Wu[c]^T).
+// Every output element is the same MFMA sequence as in the plain 256^2 kernel; what changes is that the launches' tile
+// grids are concatenated (q/k/v: 128 + 32 + 32 tiles of 512 slots -> one 192-tile wave; gate/up: 2 x 384 -> 768 = 3 full
+// rounds of 256) and the 2 * half wide gate/up intermediate never goes to HBM.
+struct GemmSeg {
+    const bf16_t* w;      // [cols, K]
+    const bf16_t* bias;   // [cols] or null
+    bf16_t* out;          // [M, cols] with row stride ld
+    int cols, ld;
+    int tile0;            // first column tile (filled by the launcher)
+};
+struct GemmSegs {
+    GemmSeg plain[3];
+    int n_plain;          // 0..3
+    const bf16_t* w_gate; // [half, K]
+    const bf16_t* w_up;   // [half, K]
+    bf16_t* out_act;      // [M, half] with row stride ld_act
+    int half, ld_act;     // half == 0: no SwiGLU segment
+    int act_tile0;        // (filled by the launcher)
+    int act_mode;         // 0: fused_swiglu, one rounding (metal_kernels.rs:188-236); 1: nn::silu(gate) * up with every
+                          //    primitive rounded to bf16 (qwen3-mlx/src/model.rs:264-265)
+};
+bool gemm_segmented_supported(int M, int K, const GemmSegs& segs);
+int launch_gemm_bf16_segmented(const bf16_t* x, int M, int K, const GemmSegs& segs, hipStream_t s);
+
 // projection with a SwiGLU segment (256^2 kernel): W = [n_plain plain rows | half gate rows | half up rows], all [., K].
 //   out_plain[m, c] = bf16(x.W[c]^T) for c < n_plain (row stride ld_plain),
 //   out_act[m, c]   = bf16(silu(g) * u), g = bf16(x.W[n_plain + c]^T), u = bf16(x.W[n_plain + half + c]^T)  (row stride ld_act)

@@ -139,6 +139,33 @@ def test_batched_prefill_equals_token_serial_prefill(omx, monkeypatch):
     assert np.abs(ks - kb).max() <= 2.0 ** -6 * np.abs(ks).max()
 
 
+def test_segmented_prefill_projections_match_separate_launches(omx, monkeypatch):
+    """Long prompts run q/k/v as one segmented launch and gate/up/SiLU-mul as one launch with the activation in the GEMM
+    epilogue (csrc/gemm.hpp: GemmSegs).  Same arithmetic per element as the separate launches up to the MFMA shape of the
+    tile kernel that computes it: next-token logits and layer-1 keys agree to bf16 rounding, and the first token is the same
+    (or a tie within that rounding)."""
+    cfg = rq.Qwen3Config(1024, 2, 3072, 16, 8, 128, 2048, 1e-6, 1e6, False)
+    T, cap = 2561, 2816
+    prompt = synth.prompt_ids(T, cfg.vocab_size)
+    outs = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("OMX_PREFILL_SEGMENTED", mode)
+        m = _engine(omx, cfg, max_context=cap)
+        first = m.prefill(prompt)
+        n = cfg.num_key_value_heads * cap * cfg.head_dim
+        raw = np.empty(n, np.uint16)
+        omx.check(omx.lib.omx_qwen3_debug_read(m._h, b"k1", raw.ctypes.data, n))
+        k1 = rc.from_bf16_bits(raw).reshape(cfg.num_key_value_heads, cap, cfg.head_dim)[:, :T]
+        outs[mode] = (first, m.last_logits(), k1)
+        m.close()
+    (fs, ls, ks), (fp, lp, kp) = outs["1"], outs["0"]
+    assert np.isfinite(ls).all() and np.abs(ls).max() > 0
+    assert np.abs(ls - lp).max() <= 2.0 ** -7 * np.abs(lp).max() * np.sqrt(cfg.num_hidden_layers)
+    assert np.abs(ks - kp).max() <= 2.0 ** -6 * np.abs(kp).max()
+    tol = 2.0 ** -7 * np.abs(lp).max() * np.sqrt(cfg.num_hidden_layers)
+    assert fs == fp or lp.ravel()[fs] >= lp.max() - tol
+
+
 def test_tensor_parallel_code_path_with_one_rank_communicator(omx, monkeypatch):
     """The TP step (f32 partial GEMVs, RCCL all-reduce captured in the step graph, partial folded into
     the next prologue, packed-key argmax all-reduce) run with a 1-rank communicator must reproduce the

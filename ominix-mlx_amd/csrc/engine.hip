@@ -650,6 +650,33 @@ int run_step(omx_qwen3 m, bool with_head) {
     return 0;
 }
 
+// [final RMSNorm + lm_head + sampler] on one hidden row that is NOT the step graph's residual buffer: the last row of a batched
+// prefill (model.rs:423, 480-489, 733-735).  Same kernels and state transition as the tail of a decode step.
+int enqueue_head_on_row(omx_qwen3 m, const bf16_t* row, hipStream_t s) {
+    const omx_qwen3_config& c = m->cfg;
+    const int hd = c.hidden_size;
+    if (c.quant_bits > 0) {
+        QGemvArgs a = {};
+        a.m[0] = m->q_head; a.m[0].n = m->V; a.N = m->V; a.K = hd; a.group = c.quant_group;
+        a.x = row; a.norm_w = m->final_norm; a.eps = c.rms_norm_eps; a.out = m->logits;
+        a.argmax_slot = m->argmax_partials;
+        if (launch_qgemv(a, c.quant_bits, PRO_RMSNORM, EPI_ARGMAX, s)) return 1;
+    } else {
+        GemvArgs a = {};
+        a.w0 = m->lm_head; a.n0 = m->V; a.N = m->V; a.K = hd;
+        a.x = row; a.x_partial = nullptr; a.x_out = nullptr;
+        a.norm_w = m->final_norm; a.eps = c.rms_norm_eps;
+        a.out = m->logits;
+        a.argmax_slot = m->argmax_partials;
+        a.row_offset = 0;
+        if (launch_gemv(a, PRO_RMSNORM, EPI_ARGMAX, s)) return 1;
+    }
+    if (add_sampling_noise(m, s)) return 1;
+    sample_finalize_kernel<<<1, 256, 0, s>>>(m->st, m->argmax_partials, m->n_argmax_partials, m->out_ring, m->ring_cap, nullptr);
+    OMX_LAUNCH_CHECK();
+    return 0;
+}
+
 // Batched prefill of T prompt tokens (all but the last one, which goes through the decode step so
 // that sampling stays in one place): fills the KV slabs of every layer.  Matrix-core path:
 //   RMSNorm rows -> q/k/v GEMM -> [per-head norm + RoPE + cache scatter] -> flash attention
@@ -696,7 +723,7 @@ __global__ void encoder_mask_kernel(bf16_t* mask, const uint8_t* am, int T) {
     }
 }
 
-int prefill_prefix_batched(omx_qwen3 m, int T, int off, const EncodeOpts* enc = nullptr) {
+int prefill_prefix_batched(omx_qwen3 m, int T, int off, const EncodeOpts* enc = nullptr, bool full_last = false) {
     const omx_qwen3_config& c = m->cfg;
     hipStream_t s = m->stream;
     const int hd = c.hidden_size, D = c.head_dim, H = m->H, Hkv = m->Hkv, I = m->I;
@@ -769,7 +796,7 @@ int prefill_prefix_batched(omx_qwen3 m, int T, int off, const EncodeOpts* enc = 
         if (launch_qk_norm_rope_scatter(m->pf_q, m->pf_k, m->pf_v, L.q_norm, L.k_norm, m->rope_cos, m->rope_sin, m->pf_qt,
                                         m->kcache[l], m->vcache[l], T, H, Hkv, D, m->cap, off, c.rms_norm_eps, s))
             return 1;
-        if (!enc && l == c.num_hidden_layers - 1) break;
+        if (!enc && !full_last && l == c.num_hidden_layers - 1) break;   // a prefix only has to leave its K/V rows behind
         if (launch_attn_prefill(m->pf_attn, m->pf_qt, m->kcache[l], m->vcache[l], 1, H, Hkv, T, off + T, D, 0,
                                 (int64_t)m->cap * D, scale, enc && enc->mask ? OMX_MASK_ADDITIVE : OMX_MASK_CAUSAL,
                                 enc ? enc->mask : nullptr, s, /*out_token_major=*/true))
@@ -1156,6 +1183,7 @@ int omx_qwen3_prefill(omx_qwen3 m, const uint32_t* prompt, int n_prompt, uint32_
     const char* serial_env = getenv("OMX_PREFILL_SERIAL");
     const bool serial = (serial_env && serial_env[0] == '1') || m->allreduce != nullptr || n_prompt < 2;
     OMX_HIP_CHECK(hipEventRecord(m->ev0, m->stream));
+    bool batched_head = false;
     if (serial) {
         // token-serial prefill: identical arithmetic to n_prompt decode steps (the lm_head is skipped for
         // all but the last prompt position; the reference computes and discards those logits, model.rs:815)
@@ -1163,14 +1191,23 @@ int omx_qwen3_prefill(omx_qwen3 m, const uint32_t* prompt, int n_prompt, uint32_
         for (int i = 0; i < n_prompt - 1; ++i)
             if (run_step(m, false)) return 1;
     } else {
-        // matrix-core prefill of the first n-1 tokens, then the decode step for the last one
-        if (prefill_prefix_batched(m, n_prompt - 1, st.pos)) return 1;
+        // matrix-core prefill of ALL n tokens, then norm + lm_head + sampler on the last row (one more row in GEMMs whose
+        // tile count does not change, instead of a 36-layer GEMV pass); OMX_PREFILL_TAIL_STEP=1: n-1 tokens batched and
+        // the decode step for the last one
+        const char* tail_env = getenv("OMX_PREFILL_TAIL_STEP");
+        const bool tail_step = (tail_env && tail_env[0] == '1') || m->mega;
+        const int nb = tail_step ? n_prompt - 1 : n_prompt;
+        if (prefill_prefix_batched(m, nb, st.pos, nullptr, !tail_step)) return 1;
         st.pos += n_prompt - 1;
         st.prompt_idx = n_prompt - 1;
         st.cur_token = prompt[n_prompt - 1];
         OMX_HIP_CHECK(hipMemcpyAsync(m->st, &st, sizeof(st), hipMemcpyHostToDevice, m->stream));
+        if (!tail_step) {
+            if (enqueue_head_on_row(m, m->pf_h + (size_t)(n_prompt - 1) * m->cfg.hidden_size, m->stream)) return 1;
+            batched_head = true;
+        }
     }
-    if (run_step(m, true)) return 1;
+    if (!batched_head && run_step(m, true)) return 1;
     OMX_HIP_CHECK(hipEventRecord(m->ev1, m->stream));
     OMX_HIP_CHECK(hipMemcpyAsync(first_token, m->out_ring + (count_before % m->ring_cap), 4, hipMemcpyDeviceToHost, m->stream));
     OMX_HIP_CHECK(hipStreamSynchronize(m->stream));

@@ -139,6 +139,37 @@ def test_batched_prefill_equals_token_serial_prefill(omx, monkeypatch):
     assert np.abs(ks - kb).max() <= 2.0 ** -6 * np.abs(ks).max()
 
 
+@pytest.mark.parametrize("name", ["gqa4_d128", "gqa2_d64"])
+def test_prefill_head_on_last_batched_row_matches_tail_step(omx, monkeypatch, name):
+    """Default prefill pushes ALL prompt tokens through the matrix-core path and applies final norm + lm_head + sampler to the
+    last row; OMX_PREFILL_TAIL_STEP=1 sends the last token through the decode step instead.  Two implementations of the same
+    arithmetic (GEMM / flash attention vs GEMV / split-KV attention): logits agree to bf16 rounding, the cache offset and the
+    tokens that follow are the oracle's either way."""
+    cfg = CONFIGS[name]
+    prompt = synth.prompt_ids(61, cfg.vocab_size)
+    want, ref_logits = rq.Qwen3Oracle(cfg, rq.synth_weights(cfg)).generate(prompt, 6, return_logits=True)
+    outs = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("OMX_PREFILL_TAIL_STEP", mode)
+        m = _engine(omx, cfg)
+        first = m.prefill(prompt)
+        logits = m.last_logits()
+        toks = [first] + [int(t) for t in m.decode(5)]
+        outs[mode] = (toks, logits, m.offset())
+        m.close()
+    (tb, lb, ob), (ts, ls, os_) = outs["0"], outs["1"]
+    assert ob == os_ == 61 + 5
+    bound = 2.0 ** -7 * np.abs(ref_logits).max() * np.sqrt(cfg.num_hidden_layers)
+    assert np.abs(lb - ls).max() <= bound
+    assert np.abs(lb - ref_logits[0]).max() <= bound and np.abs(ls - ref_logits[0]).max() <= bound
+    margins = rc.argmax_margin(ref_logits)
+    for toks in (tb, ts):
+        for i in range(6):
+            if toks[i] != int(want[i]):
+                assert margins[i] <= 2 * bound, f"token {i}: got {toks[i]} want {int(want[i])} with margin {margins[i]:.4f}"
+                break
+
+
 def test_segmented_prefill_projections_match_separate_launches(omx, monkeypatch):
     """Long prompts run q/k/v as one segmented launch and gate/up/SiLU-mul as one launch with the activation in the GEMM
     epilogue (csrc/gemm.hpp: GemmSegs).  Same arithmetic per element as the separate launches up to the MFMA shape of the
@@ -203,6 +234,7 @@ def test_persistent_step_kernel_is_bit_identical_to_step_graph(omx, monkeypatch,
     cfg = MEGA_CONFIGS[name]
     prompt = synth.prompt_ids(70, cfg.vocab_size)
     monkeypatch.setenv("OMX_PREFILL_SERIAL", serial_prefill)
+    monkeypatch.setenv("OMX_PREFILL_TAIL_STEP", "1")   # the last prompt token through the step under test, on both paths
     outs = {}
     for mega in ("1", "0"):
         monkeypatch.setenv("OMX_DECODE_MEGA", mega)

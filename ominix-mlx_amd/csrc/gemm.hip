@@ -503,6 +503,153 @@ __global__ __launch_bounds__(big::NT) void gemm_bf16_nt_256_kernel(const GemmArg
 }
 #undef OMX_BAR
 
+// ---- 64 x 64 x 64 tile, deep LDS-DMA ring: GEMMs whose 128^2 grid cannot fill the chip ----
+// (Paraformer layers: 501 x 512 x 512 is 16 tiles of 128^2; the text encoder and the DiT txt stream at 512 rows; short prompts.)
+// With one or two blocks per CU and ONE tile of prefetch the 128^2 kernel pays a full memory round trip per K step
+// (8 K steps of a 512-wide contraction took 15 us).  Here a block owns a 64 x 64 output (4x the blocks), and the K loop runs
+// over a ring of NS stages of [A 64x64 | B 64x64] (16 KiB each) filled by global_load_lds: NS - 1 tiles are in flight
+// while one is consumed, the wait is a counted vmcnt, one barrier per K step (the stage read in step t-1 is refilled right
+// after the barrier of step t).  NS = 8 (128 KiB, one block per CU) when the grid has at most one block per CU -- a
+// 512-wide contraction is then issued in full before the first wait -- NS = 4 (64 KiB, two blocks per CU) otherwise.
+// Wave (wr, wc) owns 32 x 32 as 2 x 2 tiles of v_mfma_f32_16x16x32_bf16, operands swapped as in the 256^2 kernel so a
+// lane holds four consecutive output columns (8-byte stores); same epilogue options as the other kernels.
+namespace skinny {
+constexpr int TM = 64, TN = 64, TK = 64, NT = 256;
+constexpr int HALF = TM * TK * 2;       // 8 KiB: one operand tile
+constexpr int STAGE = 2 * HALF;
+}
+
+template <int LOADS>
+__device__ __forceinline__ void wait_vm_tiles(int tiles) {   // wait until at most `tiles` staged tiles (LOADS loads each) are pending
+    switch (tiles) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LOADS) : "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * LOADS) : "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * LOADS) : "memory"); break;
+        case 5: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(5 * LOADS) : "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(6 * LOADS) : "memory"); break;
+    }
+}
+
+template <int NS>
+__global__ __launch_bounds__(skinny::NT) void gemm_bf16_nt_skinny_kernel(const GemmArgs a) {
+    using namespace skinny;
+    static_assert(NS >= 2 && NS <= 8, "ring depth: the counted waits cover up to 6 pending tiles");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    // XCD-aware remap: each XCD gets a contiguous run of tiles (row-major: neighbours share the activation panel)
+    int bid = blockIdx.x;
+    {
+        const int nblk = a.grid_m * a.grid_n;
+        const int q = nblk / 8, r = nblk % 8, xcd = bid % 8, idx = bid / 8;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int m0 = (bid / a.grid_n) * TM, n0 = (bid % a.grid_n) * TN;
+    const int nt = a.K / TK;
+
+    const bf16_t* srcA[2];
+    const bf16_t* srcB[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int c = i * NT + threadIdx.x;          // LDS chunk (16 B) of the operand tile, lane-linear inside a wave
+        const int row = c >> 3;
+        const int kc = (c & 7) ^ (row & 7);           // logical k-chunk kept at this slot (source-side swizzle)
+        srcA[i] = a.x + (size_t)min(m0 + row, a.M - 1) * a.K + kc * 8;
+        srcB[i] = a.w + (size_t)min(n0 + row, a.N - 1) * a.K + kc * 8;
+    }
+    auto stage = [&](int t) {
+        unsigned char* st = smem + (t % NS) * STAGE;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(srcA[i] + t * TK), (lds_ptr_t)(st + (i * NT + wave * 64) * 16), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(srcB[i] + t * TK), (lds_ptr_t)(st + HALF + (i * NT + wave * 64) * 16), 16, 0, 0);
+    };
+
+    typedef float accv __attribute__((ext_vector_type(4)));
+    accv acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
+
+    for (int t = 0; t < NS - 1 && t < nt; ++t) stage(t);
+    const int arow = lane & 15, kh = lane >> 4;
+    for (int t = 0; t < nt; ++t) {
+        // tiles issued so far: 0 .. min(t + NS - 2, nt - 1); everything younger than tile t may stay in flight
+        wait_vm_tiles<4>(min(NS - 2, nt - 1 - t));
+        __syncthreads();                              // tile t is in LDS for every wave; everyone is done reading tile t - 1
+        if (t + NS - 1 < nt) stage(t + NS - 1);       // refills the stage tile t - 1 was read from
+        const unsigned char* pa = smem + (t % NS) * STAGE;
+        const unsigned char* pb = pa + HALF;
+#pragma unroll
+        for (int ks = 0; ks < TK / 32; ++ks) {
+            bf16x8 fa[2], fb[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) fa[i] = lds_frag(pa, wr * 32 + i * 16 + arow, ks * 4 + kh);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) fb[j] = lds_frag(pb, wc * 32 + j * 16 + arow, ks * 4 + kh);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+        }
+    }
+
+    // epilogue: W-tile x X-tile products, so a lane holds output row (lane & 15), columns 4 * (lane >> 4) + [0, 4) of each tile
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = m0 + wr * 32 + i * 16 + (lane & 15);
+        if (row >= a.M) continue;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + wc * 32 + j * 16 + 4 * (lane >> 4);
+            if (col >= a.N) continue;
+            const size_t o = (size_t)row * a.N + col;
+            const bool full = col + 3 < a.N && (a.N & 3) == 0;
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = acc[i][j][e];
+            if (full) {
+                if (a.bias) {
+                    const u32x2 b = *reinterpret_cast<const u32x2*>(a.bias + col);
+                    v[0] += bf16lo(b[0]); v[1] += bf16hi(b[0]); v[2] += bf16lo(b[1]); v[3] += bf16hi(b[1]);
+                }
+                if (a.relu) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                }
+                if (a.gate) {
+                    const u32x2 r = *reinterpret_cast<const u32x2*>(a.resid + o);
+                    const u32x2 gt = *reinterpret_cast<const u32x2*>(a.gate + col);
+                    v[0] = bf16lo(r[0]) + v[0] * bf16lo(gt[0]); v[1] = bf16hi(r[0]) + v[1] * bf16hi(gt[0]);
+                    v[2] = bf16lo(r[1]) + v[2] * bf16lo(gt[1]); v[3] = bf16hi(r[1]) + v[3] * bf16hi(gt[1]);
+                } else if (a.resid) {
+                    const u32x2 r = *reinterpret_cast<const u32x2*>(a.resid + o);
+                    v[0] = bf16lo(r[0]) + round_bf16(v[0]); v[1] = bf16hi(r[0]) + round_bf16(v[1]);
+                    v[2] = bf16lo(r[1]) + round_bf16(v[2]); v[3] = bf16hi(r[1]) + round_bf16(v[3]);
+                }
+                *reinterpret_cast<u32x2*>(a.out + o) = u32x2{pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3])};
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (col + e >= a.N) break;
+                    float x = v[e] + (a.bias ? bf16_to_f32(a.bias[col + e]) : 0.f);
+                    if (a.relu) x = fmaxf(x, 0.f);
+                    if (a.gate) x = bf16_to_f32(a.resid[o + e]) + x * bf16_to_f32(a.gate[col + e]);
+                    else if (a.resid) x = bf16_to_f32(a.resid[o + e]) + round_bf16(x);
+                    a.out[o + e] = f32_to_bf16(x);
+                }
+            }
+        }
+    }
+}
+
 // ---- fallback: any K / alignment.  64x64 tile, BK = 32, register staging with zero fill ----
 __global__ __launch_bounds__(NTHREADS) void gemm_bf16_nt_generic_kernel(const GemmArgs a) {
     __shared__ __attribute__((aligned(16))) bf16_t sA[64][40];   // +8 pad: conflict-free 16-B fragment reads
@@ -559,6 +706,8 @@ int ensure_attr() {
         OMX_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_bf16_nt_256_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, big::SMEM));
         OMX_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_bf16_nt_256_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, big::SMEM));
         OMX_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_bf16_nt_256_kernel<16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big::SMEM));
+        OMX_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_bf16_nt_skinny_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * skinny::STAGE));
+        OMX_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_bf16_nt_skinny_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * skinny::STAGE));
         attr_set = true;
     }
     return 0;
@@ -584,6 +733,12 @@ static int launch_gemm_impl(bf16_t* out, const bf16_t* x, const bf16_t* w, const
             const char* mf_env = getenv("OMX_GEMM_MFMA");
             if (mf_env && atoi(mf_env) == 32) gemm_bf16_nt_256_kernel<32><<<a.grid_m * a.grid_n, big::NT, big::SMEM, s>>>(a);
             else gemm_bf16_nt_256_kernel<16><<<a.grid_m * a.grid_n, big::NT, big::SMEM, s>>>(a);
+        } else if (forced == 64 || (forced == 0 && a.grid_m * a.grid_n <= 128)) {
+            // the 128^2 grid leaves CUs idle: 64^2 tiles with a deep prefetch ring (one block per CU: 8 stages; two: 4)
+            a.grid_m = (M + 63) / 64;
+            a.grid_n = (N + 63) / 64;
+            if (a.grid_m * a.grid_n <= 256) gemm_bf16_nt_skinny_kernel<8><<<a.grid_m * a.grid_n, skinny::NT, 8 * skinny::STAGE, s>>>(a);
+            else gemm_bf16_nt_skinny_kernel<4><<<a.grid_m * a.grid_n, skinny::NT, 4 * skinny::STAGE, s>>>(a);
         } else {
             gemm_bf16_nt_kernel<false><<<a.grid_m * a.grid_n, NTHREADS, 4 * TILE_BYTES, s>>>(a);
         }

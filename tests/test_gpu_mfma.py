@@ -62,6 +62,34 @@ def test_linear_gemm_256_tile_kernel(omx, monkeypatch, M, N, K):
     np.testing.assert_array_equal(omx.ops.linear(T.from_numpy(eye), T.from_numpy(wa)).numpy(), wa.T[: min(M, K)])
 
 
+@pytest.mark.parametrize("M,N,K", [
+    (64, 64, 64),            # one tile, one K step: nothing in flight behind it
+    (501, 512, 512),         # Paraformer attention projections: 8-stage ring holds the whole contraction
+    (216, 512, 2048),        # Paraformer decoder FFN: ring wraps four times, ragged rows
+    (130, 1100, 448),        # 7 K steps = ring depth - 1 of the 8-stage variant, ragged N
+    (512, 2560, 640),        # 320 blocks: the 4-stage variant (two blocks per CU), 10 K steps
+    (77, 1284, 192),         # 4-stage variant with fewer K steps than stages; N % 64 = 4
+])
+def test_linear_gemm_skinny_ring_kernel(omx, monkeypatch, M, N, K):
+    """The 64 x 64 tile kernel with the deep LDS-DMA ring (default for GEMMs whose 128^2 grid has <= 128 tiles), forced here;
+    bias through the fused epilogue, then the transpose-detecting identity check, then agreement with the 128^2 kernel to
+    one bf16 ulp (different MFMA shape, same products)."""
+    T = omx.ops.Tensor
+    monkeypatch.setenv("OMX_GEMM_TILE", "64")
+    x = rc.bf16_round(rand((M, K), 51))
+    w = rc.bf16_round(rand((N, K), 52) * 0.05)
+    b = rc.bf16_round(rand((N,), 53))
+    got = omx.ops.linear(T.from_numpy(x), T.from_numpy(w), T.from_numpy(b)).numpy()
+    ref = rc.linear(x, w, b, "bf16")
+    assert_bf16_close(got, ref, 1, atol=2e-5 * np.sqrt(K) + 1e-4)
+    eye = np.eye(K, dtype=np.float32)[: min(M, K)]
+    wa = rc.bf16_round((np.arange(N * K).reshape(N, K) % 251 - 125).astype(np.float32) / 64)
+    np.testing.assert_array_equal(omx.ops.linear(T.from_numpy(eye), T.from_numpy(wa)).numpy(), wa.T[: min(M, K)])
+    monkeypatch.setenv("OMX_GEMM_TILE", "128")
+    other = omx.ops.linear(T.from_numpy(x), T.from_numpy(w), T.from_numpy(b)).numpy()
+    assert_bf16_close(got, other, 1, atol=2e-5 * np.sqrt(K) + 1e-4)
+
+
 def test_linear_gemm_bias_is_fused_addmm(omx):
     """nn/linear.rs:88-90: addmm rounds once."""
     T = omx.ops.Tensor

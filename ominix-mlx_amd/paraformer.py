@@ -71,7 +71,7 @@ def cif_fire(hidden: Tensor, alphas: Tensor, threshold: float = 1.0, tail_thresh
     reference pads to the longest item (paraformer.rs:841-872)."""
     B, T, H = hidden.shape
     frames = Tensor((B, T + 1, H), FLOAT32)
-    counts = Tensor((B,), INT32) if False else Tensor((B,), "u32")
+    counts = Tensor((B,), "u32")
     check(lib.omx_cif_fire(frames.ptr, counts.ptr, hidden.ptr, alphas.ptr, B, T, H, threshold, tail_threshold, T + 1, None))
     cnt = counts.numpy().astype(np.int32)
     mx = int(cnt.max()) if B else 0

@@ -46,6 +46,36 @@ def test_cif_fire_matches_oracle(omx):
     np.testing.assert_allclose(frames, ref_frames, rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("case", ["no_fire_tail", "no_fire_no_tail", "exact_threshold", "long", "one_step"])
+def test_cif_fire_edge_cases(omx, case):
+    """The fire recurrence is replayed by one thread and the frames are summed by many (csrc/paraformer.hip): counts are exact,
+    frames agree with the serial definition, for sequences that never fire, end without a tail frame, hit the threshold exactly,
+    or are much longer than the model's 30 s window."""
+    from ominix_mlx_amd import paraformer
+    g = np.random.default_rng(11)
+    B, T, H = {"no_fire_tail": (1, 40, 64), "no_fire_no_tail": (1, 40, 64), "exact_threshold": (2, 64, 128),
+               "long": (1, 6000, 96), "one_step": (1, 1, 64)}[case]
+    hidden = g.standard_normal((B, T, H)).astype(np.float32)
+    if case == "no_fire_tail":
+        alphas = np.full((B, T), 0.02, np.float32)              # sum 0.8: no fire, tail frame (> 0.45)
+    elif case == "no_fire_no_tail":
+        alphas = np.full((B, T), 0.01, np.float32)              # sum 0.4: nothing at all
+    elif case == "exact_threshold":
+        alphas = np.full((B, T), 0.25, np.float32)              # integrate reaches 1.0 exactly every 4th step, no remainder
+        alphas[1, 10:] = 0.5
+    elif case == "one_step":
+        alphas = np.full((B, T), 0.9, np.float32)
+    else:
+        alphas = (g.random((B, T)) * 0.6).astype(np.float32)
+    ref_frames, ref_counts = rp.cif_fire(hidden, alphas)
+    T_ = omx.ops.Tensor
+    frames, counts = paraformer.cif_fire(T_.from_numpy(hidden, "f32"), T_.from_numpy(alphas, "f32"))
+    np.testing.assert_array_equal(counts, ref_counts)
+    n = int(ref_counts.max()) if ref_counts.size else 0
+    if n:
+        np.testing.assert_allclose(frames[:, :n], ref_frames[:, :n], rtol=1e-5, atol=1e-5)
+
+
 TINY = dict(n_mels=80, lfr_m=7, encoder_dim=512, encoder_layers=3, encoder_heads=4, encoder_ffn_dim=1024, decoder_dim=512,
             decoder_layers=2, decoder_heads=4, decoder_ffn_dim=1024, vocab_size=640, sanm_kernel_size=11, cif_l_order=1,
             cif_r_order=1, cif_threshold=1.0, cif_tail_threshold=0.45)

@@ -15,9 +15,11 @@ namespace omx {
 namespace {
 
 // out[t, c] = attn_proj[t, c] + v[t, c] + sum_j w[c, j] * v[t + j - pad, c]     (depthwise conv, zero padded)
+// resid != null: out = resid + bf16(that)   (the layer's attention residual, paraformer.rs:625-629, in the same launch)
 __global__ __launch_bounds__(256) void fsmn_add_kernel(bf16_t* __restrict__ out, const bf16_t* __restrict__ attn_proj,
                                                        const bf16_t* __restrict__ v, int64_t ldv,
-                                                       const bf16_t* __restrict__ w, int T, int C, int ksize) {
+                                                       const bf16_t* __restrict__ w, int T, int C, int ksize,
+                                                       const bf16_t* __restrict__ resid) {
     const int pad = ksize / 2;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < (int64_t)T * C; i += (int64_t)gridDim.x * 256) {
         const int t = (int)(i / C), c = (int)(i % C);
@@ -28,7 +30,9 @@ __global__ __launch_bounds__(256) void fsmn_add_kernel(bf16_t* __restrict__ out,
         }
         // fsmn_out = conv(v) + v (bf16 arrays in the reference's op chain), then attn_proj + fsmn_out
         const float fsmn = round_bf16(round_bf16(acc) + bf16_to_f32(v[(size_t)t * ldv + c]));
-        out[i] = f32_to_bf16(bf16_to_f32(attn_proj[i]) + fsmn);
+        float o = bf16_to_f32(attn_proj[i]) + fsmn;
+        if (resid) o = bf16_to_f32(resid[i]) + round_bf16(o);
+        out[i] = f32_to_bf16(o);
     }
 }
 
@@ -211,7 +215,7 @@ int omx_paraformer_decoder_layer(void* out, const void* x, const void* enc, cons
     if (launch_gemm_bf16(tgt, ffn, (const bf16_t*)w->ffn_down_w, nullptr, N, dim, ffn_dim, s)) return 1;
     // x1 = x + (fsmn(norm2(tgt)) + norm2(tgt))                                                   (:1044-1047)
     if (omx_layer_norm(h, tgt, w->norm2_w, w->norm2_b, N, dim, 1e-5f, OMX_BFLOAT16, stream)) return 1;
-    fsmn_add_kernel<<<1024, 256, 0, s>>>(x1, xin, h, dim, (const bf16_t*)w->fsmn_w, N, dim, kernel_size);
+    fsmn_add_kernel<<<1024, 256, 0, s>>>(x1, xin, h, dim, (const bf16_t*)w->fsmn_w, N, dim, kernel_size, nullptr);
     OMX_LAUNCH_CHECK();
     // out = x1 + src_attn_out(softmax(q k^T * d^-1/2) v), q from norm3(x1), k/v from the encoder output      (:1049-1052, 981-1017)
     if (omx_layer_norm(h, x1, w->norm3_w, w->norm3_b, N, dim, 1e-5f, OMX_BFLOAT16, stream)) return 1;
@@ -271,18 +275,15 @@ int omx_sanm_encoder_layer(void* out, const void* x, const omx_sanm_layer_weight
         return 1;
     if (launch_gemm_bf16(prj, att, (const bf16_t*)w->out_w, (const bf16_t*)w->out_b, T, dim, dim, s)) return 1;
     // out_proj(attn) + (fsmn_block(v) + v)                                             (:524-529)
-    fsmn_add_kernel<<<1024, 256, 0, s>>>(att, prj, qkv + 2 * dim, 3 * (int64_t)dim, (const bf16_t*)w->fsmn_w, T, dim, kernel_size);
+    // + the layer residual in the same launch; only when the layer keeps its width (the first maps 560 -> 512 without it, :625-629)
+    const bf16_t* xa = xr;
+    fsmn_add_kernel<<<1024, 256, 0, s>>>(xr, prj, qkv + 2 * dim, 3 * (int64_t)dim, (const bf16_t*)w->fsmn_w, T, dim, kernel_size,
+                                         in_dim == dim ? xin : nullptr);
     OMX_LAUNCH_CHECK();
-    // residual only when the layer keeps its width (first layer maps 560 -> 512 without it, :625-629)
-    const bf16_t* xa = att;
-    if (in_dim == dim) {
-        if (omx_add(xr, xin, att, (int64_t)T * dim, OMX_BFLOAT16, stream)) return 1;
-        xa = xr;
-    }
     if (omx_layer_norm(h2, xa, w->norm2_w, w->norm2_b, T, dim, 1e-5f, OMX_BFLOAT16, stream)) return 1;
     if (launch_gemm_bf16_bias_relu(ff, h2, (const bf16_t*)w->ffn_up_w, (const bf16_t*)w->ffn_up_b, T, ffn_dim, dim, s)) return 1;
-    if (launch_gemm_bf16(prj, ff, (const bf16_t*)w->ffn_down_w, (const bf16_t*)w->ffn_down_b, T, dim, ffn_dim, s)) return 1;
-    return omx_add(out, xa, prj, (int64_t)T * dim, OMX_BFLOAT16, stream);
+    // out = xa + bf16(ffn_down(ff) + bias): the FFN residual in the GEMM epilogue
+    return launch_gemm_bf16_ex((bf16_t*)out, ff, (const bf16_t*)w->ffn_down_w, (const bf16_t*)w->ffn_down_b, xa, T, dim, ffn_dim, s);
 }
 
 int omx_cif_fire(float* frames, int* counts, const float* hidden, const float* alphas, int batch, int T, int H,

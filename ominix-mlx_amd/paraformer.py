@@ -146,8 +146,10 @@ class Paraformer:
         h = Tensor((T, in0), "bf16")
         check(lib.omx_paraformer_embed(h.ptr, mel.ptr, T, in0, None))
         in_dim = in0
-        for w in self.enc_layers:
-            out = Tensor((T, c["encoder_dim"]), "bf16")
+        # two buffers, alternating: releasing a device buffer per layer would synchronise host and GPU 50 times
+        bufs = [Tensor((T, c["encoder_dim"]), "bf16"), Tensor((T, c["encoder_dim"]), "bf16")]
+        for i, w in enumerate(self.enc_layers):
+            out = bufs[i & 1]
             check(lib.omx_sanm_encoder_layer(out.ptr, h.ptr, ctypes.byref(w), T, in_dim, c["encoder_dim"], c["encoder_heads"],
                                              c["encoder_ffn_dim"], c["sanm_kernel_size"], None))
             h, in_dim = out, c["encoder_dim"]
@@ -172,8 +174,9 @@ class Paraformer:
         c = self.cfg
         N, Ts = embeds.shape[0], enc.shape[0]
         x = _cast(embeds, "bf16")
-        for w in self.dec_layers:
-            out = Tensor((N, c["decoder_dim"]), "bf16")
+        bufs = [Tensor((N, c["decoder_dim"]), "bf16"), Tensor((N, c["decoder_dim"]), "bf16")]
+        for i, w in enumerate(self.dec_layers):
+            out = bufs[i & 1]
             check(lib.omx_paraformer_decoder_layer(out.ptr, x.ptr, enc.ptr, ctypes.byref(w), N, Ts, c["decoder_dim"], c["encoder_dim"],
                                                    c["decoder_heads"], c["decoder_ffn_dim"], c["sanm_kernel_size"], None))
             x = out

@@ -546,7 +546,11 @@ __global__ __launch_bounds__(skinny::NT) void gemm_bf16_nt_skinny_kernel(const G
         const int q = nblk / 8, r = nblk % 8, xcd = bid % 8, idx = bid / 8;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    const int m0 = (bid / a.grid_n) * TM, n0 = (bid % a.grid_n) * TN;
+    // an XCD's run of tiles walks the smaller operand's panels fastest, so its L2 pulls the larger operand only once
+    // (weights wider than the activation block: column runs; every XCD then reads 1/8 of W instead of all of it)
+    const bool col_runs = a.N > a.M;
+    const int m0 = (col_runs ? bid % a.grid_m : bid / a.grid_n) * TM;
+    const int n0 = (col_runs ? bid / a.grid_m : bid % a.grid_n) * TN;
     const int nt = a.K / TK;
 
     const bf16_t* srcA[2];

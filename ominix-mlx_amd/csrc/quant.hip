@@ -203,12 +203,17 @@ __global__ __launch_bounds__(256) void qgemv_kernel(const QGemvArgs a) {
                 if (BITS == 4) {
                     // nibbles -> bf16 pairs by bit assembly: 0x4300 | q is the bf16 value 128 + q, so each v_dot2c
                     // accumulates x . (128 + q); the 128 * sum(x) excess is folded into the bias term below
+                    // One v_perm per pair: the 0x43 exponent byte comes from the second source, the two nibble bytes from
+                    // the same masked word -- so a pair is (q0, q2), (q4, q6) of the even nibbles or (q1, q3), (q5, q7) of the
+                    // odd ones, and the activations were stored in LDS in that order (put() below).
                     const uint32_t lo = wdw & 0x0F0F0F0Fu, hi = (wdw >> 4) & 0x0F0F0F0Fu;
-#pragma unroll
-                    for (int p4 = 0; p4 < 4; ++p4) {
-                        const uint32_t pair = __builtin_amdgcn_perm(hi, lo, 0x0c000c00u | ((4u + p4) << 16) | (uint32_t)p4) | 0x43004300u;
-                        d = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, xp[wi * 4 + p4]), __builtin_bit_cast(bf16x2_t, pair), d, false);
-                    }
+                    const uint32_t c43 = 0x43434343u;
+                    const uint32_t q0 = __builtin_amdgcn_perm(c43, lo, 0x04010400u), q1 = __builtin_amdgcn_perm(c43, lo, 0x04030402u);
+                    const uint32_t q2 = __builtin_amdgcn_perm(c43, hi, 0x04010400u), q3 = __builtin_amdgcn_perm(c43, hi, 0x04030402u);
+                    d = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, xp[wi * 4 + 0]), __builtin_bit_cast(bf16x2_t, q0), d, false);
+                    d = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, xp[wi * 4 + 1]), __builtin_bit_cast(bf16x2_t, q1), d, false);
+                    d = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, xp[wi * 4 + 2]), __builtin_bit_cast(bf16x2_t, q2), d, false);
+                    d = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, xp[wi * 4 + 3]), __builtin_bit_cast(bf16x2_t, q3), d, false);
                 } else {
 #pragma unroll
                     for (int b = 0; b < 4; ++b) {
@@ -264,7 +269,15 @@ __global__ __launch_bounds__(256) void qgemv_kernel(const QGemvArgs a) {
     //      sum(x_i) that every row's bias term shares (EPL elements = EPL/8 consecutive threads, reduced by DPP) ----
     static_assert(EPL >= 8, "a lane chunk must cover at least one 16-byte activation vector");
     auto put = [&](int i, const u32x4 o) {
-        *reinterpret_cast<u32x4*>(xs + i) = o;
+        if (BITS == 4) {
+            // 8 consecutive activations are kept as (x0,x2) (x4,x6) (x1,x3) (x5,x7): the pairing of the one-perm nibble unpack
+            u32x4 t;
+            t[0] = __builtin_amdgcn_perm(o[1], o[0], 0x05040100u); t[1] = __builtin_amdgcn_perm(o[3], o[2], 0x05040100u);
+            t[2] = __builtin_amdgcn_perm(o[1], o[0], 0x07060302u); t[3] = __builtin_amdgcn_perm(o[3], o[2], 0x07060302u);
+            *reinterpret_cast<u32x4*>(xs + i) = t;
+        } else {
+            *reinterpret_cast<u32x4*>(xs + i) = o;
+        }
         float sv = 0.f;
 #pragma unroll
         for (int q = 0; q < 4; ++q) sv += bf16lo(o[q]) + bf16hi(o[q]);

@@ -251,7 +251,23 @@ __global__ __launch_bounds__(big::NT) void gemm_bf16_nt_256_kernel(const GemmArg
             tn -= sgm.tile0;
         }
     }
-    const int m0 = tm * TM, n0 = tn * TN;
+    // grouped rows (MoE prefill): row tile tm is an entry of the device-built tile table -> (expert, first row inside its
+    // segment of the expert-sorted order); rows are gathered through row_src, weights are the expert's slice of the stacks
+    int m0 = tm * TM, rows_valid = a.M, row_base = 0;
+    size_t w_off = 0;
+    const uint32_t* row_src = nullptr;
+    if constexpr (SW) {
+        if (a.g.tile_expert) {
+            if (tm >= *a.g.n_tiles) return;
+            const int e = a.g.tile_expert[tm];
+            row_base = a.g.seg_start[e];
+            rows_valid = a.g.seg_start[e + 1] - row_base;
+            m0 = a.g.tile_m0[tm];
+            row_src = a.g.row_src;
+            w_off = (size_t)e * a.g.w_estride;
+        }
+    }
+    const int n0 = tn * TN;
     const int nt = a.K / TK;
 
     // staging sources: thread handles chunks c = i * 512 + tid (i = 0, 1) of every piece; piece row r of X_s is
@@ -267,16 +283,19 @@ __global__ __launch_bounds__(big::NT) void gemm_bf16_nt_256_kernel(const GemmArg
             const int kc = (c & 7) ^ (row & 7);
             const int trow = (row >> 6) * 128 + sidx * 64 + (row & 63);
             const int tcol = (row >> 5) * 64 + sidx * 32 + (row & 31);
-            srcX[sidx][i] = a.x + (size_t)min(m0 + trow, a.M - 1) * a.K + kc * 8;
             if constexpr (SW) {
+                int xr = min(m0 + trow, rows_valid - 1) + row_base;
+                if (row_src) xr = (int)row_src[xr];
+                srcX[sidx][i] = a.x + (size_t)xr * a.K + kc * 8;
                 if (seg_act) {
                     // Y0 (tile cols wc * 64 + [0, 32)) <- gate rows, Y1 (wc * 64 + [32, 64)) <- up rows of the same 32 outputs
                     const int oc = n0 / 2 + (row >> 5) * 32 + (row & 31);
-                    srcY[sidx][i] = (sidx ? a.sg.w_up : a.sg.w_gate) + (size_t)min(oc, seg_cols - 1) * a.K + kc * 8;
+                    srcY[sidx][i] = (sidx ? a.sg.w_up : a.sg.w_gate) + w_off + (size_t)min(oc, seg_cols - 1) * a.K + kc * 8;
                 } else {
-                    srcY[sidx][i] = seg_w + (size_t)min(n0 + tcol, seg_cols - 1) * a.K + kc * 8;
+                    srcY[sidx][i] = seg_w + w_off + (size_t)min(n0 + tcol, seg_cols - 1) * a.K + kc * 8;
                 }
             } else {
+                srcX[sidx][i] = a.x + (size_t)min(m0 + trow, a.M - 1) * a.K + kc * 8;
                 srcY[sidx][i] = a.w + (size_t)min(n0 + tcol, a.N - 1) * a.K + kc * 8;
             }
         }
@@ -409,8 +428,9 @@ __global__ __launch_bounds__(big::NT) void gemm_bf16_nt_256_kernel(const GemmArg
             const bool per_op = a.sg.act_mode == 1;
 #pragma unroll
             for (int i = 0; i < RT; ++i) {
-                const int row = m0 + wr * 128 + i * MF + (lane & LR);
-                if (row >= a.M) continue;
+                const int lrow = m0 + wr * 128 + i * MF + (lane & LR);
+                if (lrow >= rows_valid) continue;
+                const int row = row_base + lrow;
 #pragma unroll
                 for (int j = 0; j < CT / 2; ++j) {
                     const int col = c0 + j * MF;
@@ -433,8 +453,9 @@ __global__ __launch_bounds__(big::NT) void gemm_bf16_nt_256_kernel(const GemmArg
         } else {
 #pragma unroll
             for (int i = 0; i < RT; ++i) {
-                const int row = m0 + wr * 128 + i * MF + (lane & LR);
-                if (row >= a.M) continue;
+                const int lrow = m0 + wr * 128 + i * MF + (lane & LR);
+                if (lrow >= rows_valid) continue;
+                const int row = row_base + lrow;
 #pragma unroll
                 for (int j = 0; j < CT; ++j) {
                     const int col = n0 + wc * 64 + j * MF + 4 * (lane >> 4);
@@ -793,6 +814,42 @@ int launch_gemm_bf16_segmented(const bf16_t* x, int M, int K, const GemmSegs& se
     a.sg.act_tile0 = segs.half > 0 ? t : 0x7FFFFFFF;
     a.N = n + 2 * segs.half;
     a.grid_m = (M + 255) / 256;
+    a.grid_n = seg_tiles(segs);
+    gemm_bf16_nt_256_kernel<16, true><<<a.grid_m * a.grid_n, big::NT, big::SMEM, s>>>(a);
+    OMX_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_gemm_bf16_segmented_grouped(const bf16_t* x, int max_rows, int K, const GemmSegs& segs, const GroupedDesc& g, int max_tiles,
+                                       hipStream_t s) {
+    OMX_REQUIRE(max_rows > 0 && K > 0 && K % BK == 0 && max_tiles > 0 && g.tile_expert && g.tile_m0 && g.seg_start && g.n_tiles,
+                "grouped segmented gemm: bad arguments");
+    OMX_REQUIRE(segs.n_plain >= 0 && segs.n_plain <= 3 && (segs.n_plain > 0 || segs.half > 0), "grouped segmented gemm: no segment");
+    uintptr_t align = reinterpret_cast<uintptr_t>(x);
+    for (int i = 0; i < segs.n_plain; ++i) {
+        OMX_REQUIRE(segs.plain[i].w && segs.plain[i].out && segs.plain[i].cols > 0 && segs.plain[i].cols % 4 == 0 && segs.plain[i].ld % 4 == 0,
+                    "grouped segmented gemm: bad plain segment %d", i);
+        align |= reinterpret_cast<uintptr_t>(segs.plain[i].w);
+    }
+    if (segs.half > 0) {
+        OMX_REQUIRE(segs.w_gate && segs.w_up && segs.out_act && segs.half % 4 == 0 && segs.ld_act % 4 == 0, "grouped segmented gemm: bad SwiGLU segment");
+        align |= reinterpret_cast<uintptr_t>(segs.w_gate) | reinterpret_cast<uintptr_t>(segs.w_up);
+    }
+    OMX_REQUIRE((align & 15u) == 0 && (g.w_estride * 2) % 16 == 0, "grouped segmented gemm: operands must be 16-byte aligned");
+    if (ensure_attr()) return 1;
+    GemmArgs a = {};
+    a.x = x; a.M = max_rows; a.K = K;
+    a.g = g;
+    a.sg = segs;
+    int t = 0, n = 0;
+    for (int i = 0; i < segs.n_plain; ++i) {
+        a.sg.plain[i].tile0 = t;
+        t += (segs.plain[i].cols + 255) / 256;
+        n += segs.plain[i].cols;
+    }
+    a.sg.act_tile0 = segs.half > 0 ? t : 0x7FFFFFFF;
+    a.N = n + 2 * segs.half;
+    a.grid_m = max_tiles;
     a.grid_n = seg_tiles(segs);
     gemm_bf16_nt_256_kernel<16, true><<<a.grid_m * a.grid_n, big::NT, big::SMEM, s>>>(a);
     OMX_LAUNCH_CHECK();

@@ -54,6 +54,10 @@ struct GemmSegs {
                           //    primitive rounded to bf16 (qwen3-mlx/src/model.rs:264-265)
 };
 bool gemm_segmented_supported(int M, int K, const GemmSegs& segs);
+// the same launch over expert-sorted rows (MoE prefill): 256-row tiles from the device-built tile table (GroupedDesc, 256-row
+// granularity), rows gathered through g.row_src, every weight pointer offset by expert * g.w_estride
+int launch_gemm_bf16_segmented_grouped(const bf16_t* x, int max_rows, int K, const GemmSegs& segs, const GroupedDesc& g, int max_tiles,
+                                       hipStream_t s);
 int launch_gemm_bf16_segmented(const bf16_t* x, int M, int K, const GemmSegs& segs, hipStream_t s);
 
 // projection with a SwiGLU segment (256^2 kernel): W = [n_plain plain rows | half gate rows | half up rows], all [., K].

@@ -175,7 +175,7 @@ __global__ __launch_bounds__(64) void moe_route_logits_kernel(const bf16_t* __re
 __global__ __launch_bounds__(1024) void moe_plan_kernel(const uint32_t* __restrict__ inds, int n_slots, int E, int k,
                                                         int* __restrict__ seg_start, uint32_t* __restrict__ row_src,
                                                         uint32_t* __restrict__ pos_of_slot, int* __restrict__ tile_expert,
-                                                        int* __restrict__ tile_m0, int* __restrict__ n_tiles) {
+                                                        int* __restrict__ tile_m0, int* __restrict__ n_tiles, int tile_rows) {
     __shared__ int s_cnt[kMaxExperts], s_start[kMaxExperts + 1], s_fill[kMaxExperts];
     for (int e = threadIdx.x; e < E; e += blockDim.x) { s_cnt[e] = 0; s_fill[e] = 0; }
     __syncthreads();
@@ -185,7 +185,7 @@ __global__ __launch_bounds__(1024) void moe_plan_kernel(const uint32_t* __restri
         int acc = 0, tiles = 0;
         for (int e = 0; e < E; ++e) {
             s_start[e] = acc;
-            for (int m0 = 0; m0 < s_cnt[e]; m0 += 128) { tile_expert[tiles] = e; tile_m0[tiles] = m0; ++tiles; }
+            for (int m0 = 0; m0 < s_cnt[e]; m0 += tile_rows) { tile_expert[tiles] = e; tile_m0[tiles] = m0; ++tiles; }
             acc += s_cnt[e];
         }
         s_start[E] = acc;
@@ -201,6 +201,34 @@ __global__ __launch_bounds__(1024) void moe_plan_kernel(const uint32_t* __restri
         row_src[p] = (uint32_t)(i / k);      // x_sorted = x_flat[order // k]  (model.rs:214-216)
         pos_of_slot[i] = (uint32_t)p;
     }
+}
+
+// Row-tile height of the grouped GEMMs: 256-row tiles (the deep-pipelined kernel, gate/up/fused_swiglu in ONE launch) once an
+// expert sees 256 rows on average -- the 128 expected padding rows per expert then cost less than the kernel gains;
+// 128-row tiles otherwise (many small experts).  OMX_MOE_TILE=128|256 forces one.
+int moe_tile_rows(int rows, int n_experts, int hidden, int inter) {
+    const char* env = getenv("OMX_MOE_TILE");
+    const int forced = env ? atoi(env) : 0;
+    const bool ok = hidden % 64 == 0 && inter % 64 == 0;
+    if (forced == 256 && ok) return 256;
+    if (forced == 128) return 128;
+    return ok && rows / n_experts >= 256 ? 256 : 128;
+}
+
+// SwitchGLU over expert-sorted rows with 256-row tiles: [gate | up] GEMM with fused_swiglu(up, gate) in the epilogue, then down
+int grouped_glu_256(bf16_t* ybuf, bf16_t* gbuf, const bf16_t* x, const bf16_t* w_gate, const bf16_t* w_up, const bf16_t* w_down,
+                    int rows, int hidden, int inter, int n_experts, GroupedDesc g, hipStream_t s) {
+    const int mt = rows / 256 + n_experts + 1;
+    GemmSegs gu = {};
+    gu.w_gate = w_gate; gu.w_up = w_up; gu.out_act = gbuf; gu.half = inter; gu.ld_act = inter; gu.act_mode = 0;
+    g.w_estride = (size_t)inter * hidden;
+    if (launch_gemm_bf16_segmented_grouped(x, rows, hidden, gu, g, mt, s)) return 1;
+    g.row_src = nullptr;   // activations are already in expert-sorted order
+    g.w_estride = (size_t)hidden * inter;
+    GemmSegs dn = {};
+    dn.n_plain = 1;
+    dn.plain[0] = {w_down, nullptr, ybuf, hidden, hidden, 0};
+    return launch_gemm_bf16_segmented_grouped(gbuf, rows, inter, dn, g, mt, s);
 }
 
 // out[t] = bf16( sum_j bf16( y[pos(t,j)] * score[t,j] ) )     (model.rs:304-307)
@@ -393,18 +421,25 @@ static int moe_forward_impl(void* out, const void* x, const void* gate_w, const 
         moe_combine_kernel<<<n_tokens, 256, 0, s>>>((bf16_t*)out, ybuf, scores, nullptr, hidden, top_k, resid);
         OMX_LAUNCH_CHECK();
     } else {
+        const int tile_rows = moe_tile_rows(slots, n_experts, hidden, inter);
         moe_plan_kernel<<<1, 1024, 0, s>>>(inds, slots, n_experts, top_k, seg_start, row_src, pos_of_slot, tile_expert,
-                                           tile_m0, n_tiles);
+                                           tile_m0, n_tiles, tile_rows);
         OMX_LAUNCH_CHECK();
         GroupedDesc g;
         g.tile_expert = tile_expert; g.tile_m0 = tile_m0; g.seg_start = seg_start; g.n_tiles = n_tiles;
         g.row_src = row_src; g.w_estride = (size_t)inter * hidden;
+        if (tile_rows == 256) {
+            if (grouped_glu_256(ybuf, gbuf, (const bf16_t*)x, (const bf16_t*)w_gate, (const bf16_t*)w_up, (const bf16_t*)w_down, slots,
+                                hidden, inter, n_experts, g, s))
+                return 1;
+        } else {
         if (launch_gemm_bf16_grouped(gbuf, (const bf16_t*)x, (const bf16_t*)w_gate, slots, inter, hidden, g, max_tiles, s)) return 1;
         if (launch_gemm_bf16_grouped(ubuf, (const bf16_t*)x, (const bf16_t*)w_up, slots, inter, hidden, g, max_tiles, s)) return 1;
         if (omx_fused_swiglu(gbuf, ubuf, gbuf, (int64_t)slots * inter, OMX_BFLOAT16, stream)) return 1;   // fused_swiglu(up, gate)
         g.row_src = nullptr;   // activations are already in expert-sorted order
         g.w_estride = (size_t)hidden * inter;
         if (launch_gemm_bf16_grouped(ybuf, gbuf, (const bf16_t*)w_down, slots, hidden, inter, g, max_tiles, s)) return 1;
+        }
         moe_combine_kernel<<<n_tokens, 256, 0, s>>>((bf16_t*)out, ybuf, scores, pos_of_slot, hidden, top_k, resid);
         OMX_LAUNCH_CHECK();
     }
@@ -651,18 +686,25 @@ extern "C" int omx_moe_experts(void* y, const void* x_rows, const uint32_t* expe
         d.w_sel = expert_ids; d.w_estride = (size_t)hidden * inter;
         return launch_gemv(d, PRO_NONE, EPI_STORE, s);
     }
+    const int tile_rows = moe_tile_rows(n_rows, n_experts, hidden, inter);
     moe_plan_kernel<<<1, 1024, 0, s>>>(expert_ids, n_rows, n_experts, 1, seg_start, row_src, pos_of_slot, tile_expert, tile_m0,
-                                       n_tiles);
+                                       n_tiles, tile_rows);
     OMX_LAUNCH_CHECK();
     GroupedDesc g;
     g.tile_expert = tile_expert; g.tile_m0 = tile_m0; g.seg_start = seg_start; g.n_tiles = n_tiles;
     g.row_src = row_src; g.w_estride = (size_t)inter * hidden;
-    if (launch_gemm_bf16_grouped(gbuf, (const bf16_t*)x_rows, (const bf16_t*)w_gate, n_rows, inter, hidden, g, max_tiles, s)) return 1;
-    if (launch_gemm_bf16_grouped(ubuf, (const bf16_t*)x_rows, (const bf16_t*)w_up, n_rows, inter, hidden, g, max_tiles, s)) return 1;
-    if (omx_fused_swiglu(gbuf, ubuf, gbuf, (int64_t)n_rows * inter, OMX_BFLOAT16, stream)) return 1;
-    g.row_src = nullptr;
-    g.w_estride = (size_t)hidden * inter;
-    if (launch_gemm_bf16_grouped(ybuf, gbuf, (const bf16_t*)w_down, n_rows, hidden, inter, g, max_tiles, s)) return 1;
+    if (tile_rows == 256) {
+        if (grouped_glu_256(ybuf, gbuf, (const bf16_t*)x_rows, (const bf16_t*)w_gate, (const bf16_t*)w_up, (const bf16_t*)w_down, n_rows,
+                            hidden, inter, n_experts, g, s))
+            return 1;
+    } else {
+        if (launch_gemm_bf16_grouped(gbuf, (const bf16_t*)x_rows, (const bf16_t*)w_gate, n_rows, inter, hidden, g, max_tiles, s)) return 1;
+        if (launch_gemm_bf16_grouped(ubuf, (const bf16_t*)x_rows, (const bf16_t*)w_up, n_rows, inter, hidden, g, max_tiles, s)) return 1;
+        if (omx_fused_swiglu(gbuf, ubuf, gbuf, (int64_t)n_rows * inter, OMX_BFLOAT16, stream)) return 1;
+        g.row_src = nullptr;
+        g.w_estride = (size_t)hidden * inter;
+        if (launch_gemm_bf16_grouped(ybuf, gbuf, (const bf16_t*)w_down, n_rows, hidden, inter, g, max_tiles, s)) return 1;
+    }
     moe_unsort_kernel<<<n_rows, 256, 0, s>>>((bf16_t*)y, ybuf, pos_of_slot, hidden);
     OMX_LAUNCH_CHECK();
     return 0;

@@ -200,3 +200,25 @@ def test_moe_decode_with_intermediate_not_a_multiple_of_512(omx):
     for n_tokens in (1, 6, 40):
         x = rc.bf16_round(rand((n_tokens, h), 220 + n_tokens))
         _compare(_run(omx, x, gw, wg, wu, wd, k, "qwen3_moe"), rm.moe_block(x, gw, wg, wu, wd, k, "qwen3_moe"))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode,n_tokens,E,k", [("mixtral", 70, 8, 2), ("qwen3_moe", 333, 16, 4), ("mixtral", 1100, 4, 2)])
+def test_moe_grouped_256_row_tiles(omx, monkeypatch, mode, n_tokens, E, k):
+    """Expert-sorted rows through the 256-row-tile route (csrc/moe.hip grouped_glu_256: [gate | up] GEMM with fused_swiglu in
+    the epilogue, then down; rows gathered by row_src, ragged and empty expert segments) -- forced on small shapes, and the
+    last case (550 rows per expert) takes it by default.  Same oracle and tolerance as the 128-row route, and the two routes
+    agree with each other to one more bf16 rounding."""
+    h, I = 512, 768
+    gw, wg, wu, wd = _weights(E, h, I, 300 + n_tokens)
+    x = rc.bf16_round(rand((n_tokens, h), 301 + n_tokens))
+    ref = rm.moe_block(x, gw, wg, wu, wd, k, mode)
+    monkeypatch.setenv("OMX_MOE_TILE", "256")
+    got256 = _run(omx, x, gw, wg, wu, wd, k, mode)
+    _compare(got256, ref)
+    monkeypatch.setenv("OMX_MOE_TILE", "128")
+    got128 = _run(omx, x, gw, wg, wu, wd, k, mode)
+    assert_bf16_close(got256[0], got128[0], 2, atol=2.0 ** -7 * np.abs(ref[0]).max())
+    monkeypatch.delenv("OMX_MOE_TILE")
+    if n_tokens * k // E >= 256:
+        np.testing.assert_array_equal(_run(omx, x, gw, wg, wu, wd, k, mode)[0], got256[0])

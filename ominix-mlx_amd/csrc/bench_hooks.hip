@@ -132,14 +132,89 @@ __global__ __launch_bounds__(256) void grid_barrier_probe_kernel(unsigned* words
         }
     }
 }
+// variant 2: XCD-LOCAL groups.  Blocks are dispatched to XCDs round-robin (block b runs on XCD b % 8), so the blocks with
+// the same b % 8 share one L2.  They exchange and synchronise through that L2 only: workgroup-scope relaxed atomics lower to
+// `global_load/store ... sc0`, which miss the per-CU vector cache but are served by the XCD's L2 -- no write-through to
+// memory, no re-validation against the other XCDs.  The question this answers: what does a barrier + a 1 KiB hand-over cost
+// when a dependent phase is kept inside one XCD (a tensor-parallel-over-XCDs decode step would need only two device-wide
+// exchanges per layer instead of five)?  A wrong placement assumption shows up as stale reads (failed & 2) or a timeout.
+// (measured: an sc0 LOAD may still be served by the CU's vector cache -- polls never saw the flag.  What works: poll with a
+//  read-modify-write atomic, which always executes in the L2, then drop the vector cache with `buffer_inv sc0` before the
+//  plain data loads.)
+__device__ __forceinline__ unsigned ld_l2_32(const void* p) {
+    // written as asm: the compiler folds an idempotent `fetch_or(p, 0)` back into an (sc0) load
+    unsigned r;
+    const unsigned zero = 0u;
+    asm volatile("global_atomic_or %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)" : "=&v"(r) : "v"(p), "v"(zero) : "memory");
+    return r;
+}
+__device__ __forceinline__ void l1_invalidate() { asm volatile("buffer_inv sc0" ::: "memory"); }
+__device__ __forceinline__ void st_l2_32(void* p, unsigned v) {
+    __hip_atomic_store(reinterpret_cast<unsigned*>(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__global__ __launch_bounds__(256) void xcd_barrier_probe_kernel(unsigned* words, unsigned* mismatches, int iters, float* sink) {
+    const unsigned nb = gridDim.x, xcd = blockIdx.x % 8, member = blockIdx.x / 8, members = nb / 8;
+    unsigned* flags = words + 64 + 16 * nb + 32;           // after the device-wide area and the counters: [8 groups][members] flags, 64 B apart
+    unsigned* my_group = flags + (size_t)xcd * members * 16;
+    unsigned* release = words + 64 + 16 * xcd;             // one release word per group
+    bool dead = false;
+    for (int i = 0; i < iters; ++i) {
+        const unsigned epoch = (unsigned)i + 1;
+        const unsigned peer = xcd + 8 * ((member + 1) % members);   // the next block of the same XCD
+        float* src = sink + ((size_t)((i + 1) & 1) * nb + peer) * 256 + threadIdx.x;
+        float* dst = sink + ((size_t)(i & 1) * nb + blockIdx.x) * 256 + threadIdx.x;
+        l1_invalidate();
+        if (*reinterpret_cast<volatile float*>(src) != (float)i) atomicAdd(mismatches, 1u);
+        *reinterpret_cast<volatile float*>(dst) = (float)(i + 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) st_l2_32(my_group + 16 * member, epoch);
+        if (member == 0) {
+            for (unsigned b = threadIdx.x; b < members; b += blockDim.x) {
+                unsigned it = 0;
+                while (!dead && (int)(ld_l2_32(my_group + 16 * b) - epoch) < 0) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++it > (1u << 22)) { dead = true; atomicAdd(mismatches + 1, 1u); }
+                }
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) st_l2_32(release, epoch);
+        } else if (threadIdx.x == 0) {
+            unsigned it = 0;
+            while (!dead && (int)(ld_l2_32(release) - epoch) < 0) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++it > (1u << 22)) { dead = true; atomicAdd(mismatches + 1, 1u); }
+            }
+        }
+        __syncthreads();
+    }
+}
 }  // namespace
+
+// which XCD (XCC_ID hardware register, gfx942+: hwreg 20, bits 3:0) and CU each block of a plain launch runs on
+namespace {
+__global__ void xcc_id_kernel(unsigned* out) {
+    if (threadIdx.x == 0) out[blockIdx.x] = __builtin_amdgcn_s_getreg(20 | (0 << 6) | ((4 - 1) << 11));
+}
+}  // namespace
+extern "C" int omx_bench_xcc_ids(int nblocks, unsigned* host_out) {
+    OMX_REQUIRE(nblocks > 0 && host_out, "omx_bench_xcc_ids: bad arguments");
+    unsigned* d = nullptr;
+    OMX_HIP_CHECK(hipMalloc(&d, (size_t)nblocks * 4));
+    xcc_id_kernel<<<nblocks, 256>>>(d);
+    OMX_LAUNCH_CHECK();
+    OMX_HIP_CHECK(hipMemcpy(host_out, d, (size_t)nblocks * 4, hipMemcpyDeviceToHost));
+    (void)hipFree(d);
+    return 0;
+}
 
 extern "C" int omx_bench_grid_barrier(int nblocks, int iters, int variant, float* us_per_barrier, int* failed) {
     using namespace omx;
     OMX_REQUIRE(nblocks > 0 && iters > 0 && us_per_barrier && failed, "omx_bench_grid_barrier: bad arguments");
     unsigned* words = nullptr;
     float* sink = nullptr;
-    const size_t wbytes = (grid_sync_words(nblocks) + 32) * 4;   // + counter, mismatch count
+    OMX_REQUIRE(variant != 2 || (nblocks % 8 == 0 && nblocks <= 512), "omx_bench_grid_barrier: the XCD-local variant needs a multiple of 8 blocks (<= 512)");
+    const size_t wbytes = (grid_sync_words(nblocks) + 32 + 16 * (size_t)nblocks + 64) * 4;   // + counter, mismatch count, XCD-group flags
     OMX_HIP_CHECK(hipMalloc(&words, wbytes));
     OMX_HIP_CHECK(hipMalloc(&sink, (size_t)nblocks * 512 * 4));
     OMX_HIP_CHECK(hipMemset(words, 0, wbytes));
@@ -150,7 +225,8 @@ extern "C" int omx_bench_grid_barrier(int nblocks, int iters, int variant, float
     OMX_HIP_CHECK(hipEventCreate(&e1));
     OMX_HIP_CHECK(hipDeviceSynchronize());
     OMX_HIP_CHECK(hipEventRecord(e0, nullptr));
-    if (variant == 0) grid_barrier_probe_kernel<0><<<nblocks, 256>>>(words, extra, extra + 16, iters, sink);
+    if (variant == 2) xcd_barrier_probe_kernel<<<nblocks, 256>>>(words, extra + 16, iters, sink);
+    else if (variant == 0) grid_barrier_probe_kernel<0><<<nblocks, 256>>>(words, extra, extra + 16, iters, sink);
     else grid_barrier_probe_kernel<1><<<nblocks, 256>>>(words, extra, extra + 16, iters, sink);
     OMX_LAUNCH_CHECK();
     OMX_HIP_CHECK(hipEventRecord(e1, nullptr));
@@ -161,7 +237,9 @@ extern "C" int omx_bench_grid_barrier(int nblocks, int iters, int variant, float
     OMX_HIP_CHECK(hipMemcpy(&abort_word, words + 16, 4, hipMemcpyDeviceToHost));
     OMX_HIP_CHECK(hipMemcpy(&mism, extra + 16, 4, hipMemcpyDeviceToHost));
     *us_per_barrier = ms * 1000.f / iters;
-    *failed = (abort_word ? 1 : 0) | (mism ? 2 : 0);   // 1: a waiter timed out; 2: an exchange read a stale value
+    unsigned timeouts = 0;
+    OMX_HIP_CHECK(hipMemcpy(&timeouts, extra + 17, 4, hipMemcpyDeviceToHost));
+    *failed = ((abort_word || timeouts) ? 1 : 0) | (mism ? 2 : 0);   // 1: a waiter timed out; 2: an exchange read a stale value
     (void)hipFree(words); (void)hipFree(sink);
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     return 0;

@@ -6,7 +6,8 @@ omx = omx_import.load_package()
 lib = omx.lib
 lib.omx_bench_grid_barrier.restype = ctypes.c_int
 lib.omx_bench_grid_barrier.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int)]
-for var, name in ((0, "flags + coherent accessors (gridsync.hpp)"), (1, "atomic counter + agent fences")):
+for var, name in ((0, "flags + coherent accessors (gridsync.hpp)"), (1, "atomic counter + agent fences"),
+                  (2, "XCD-local groups through their own L2 (sc0)")):
     for nb in (256, 512):
         us = ctypes.c_float(); bad = ctypes.c_int()
         omx.check(lib.omx_bench_grid_barrier(nb, 500, var, ctypes.byref(us), ctypes.byref(bad)))

@@ -247,10 +247,18 @@ int resolve_weights(omx_qwen3 m) {
     m->layers.resize(m->cfg.num_hidden_layers);
     if (m->cfg.quant_bits) {
         const int D = m->cfg.head_dim, hd = m->cfg.hidden_size;
-        auto getq = [&](const std::string& prefix, int n, QMat* out) -> int {
+        const bool interleave = m->cfg.quant_bits == 4 && !(getenv("OMX_QUANT_INTERLEAVE") && getenv("OMX_QUANT_INTERLEAVE")[0] == '0');
+        // K: contraction width; stack: matrices stacked in the tensor (experts)
+        auto getq = [&](const std::string& prefix, int n, QMat* out, int K = 0, int stack = 1) -> int {
             const bf16_t *w = nullptr, *sc = nullptr, *bi = nullptr;
             if (get(prefix + ".weight", &w) || get(prefix + ".scales", &sc) || get(prefix + ".biases", &bi)) return 1;
             *out = QMat{(const uint32_t*)w, sc, bi, n};
+            if (interleave && K > 0 && K % 2048 == 0) {   // (scale, bias) words for the packed-weight GEMV (quant.hpp)
+                const size_t ng = (size_t)stack * n * (K / m->cfg.quant_group);
+                uint32_t* sb = nullptr;
+                if (dev_alloc(m, &sb, ng) || launch_quant_interleave(sb, sc, bi, ng, m->stream)) return 1;
+                out->sb = sb;
+            }
             return 0;
         };
         m->qlayers.resize(m->cfg.num_hidden_layers);
@@ -259,24 +267,25 @@ int resolve_weights(omx_qwen3 m) {
             LayerW& L = m->layers[i];
             LayerQ& Q = m->qlayers[i];
             L = LayerW{};
-            if (getq(p + "self_attn.q_proj", m->H * D, &Q.q) || getq(p + "self_attn.k_proj", m->Hkv * D, &Q.k) ||
-                getq(p + "self_attn.v_proj", m->Hkv * D, &Q.v) || getq(p + "self_attn.o_proj", hd, &Q.o) ||
+            if (getq(p + "self_attn.q_proj", m->H * D, &Q.q, hd) || getq(p + "self_attn.k_proj", m->Hkv * D, &Q.k, hd) ||
+                getq(p + "self_attn.v_proj", m->Hkv * D, &Q.v, hd) || getq(p + "self_attn.o_proj", hd, &Q.o, m->H * D) ||
                 get(p + "input_layernorm.weight", &L.in_ln) || get(p + "post_attention_layernorm.weight", &L.post_ln))
                 return 1;
             if (!m->cfg.no_qk_norm && (get(p + "self_attn.q_norm.weight", &L.q_norm) || get(p + "self_attn.k_norm.weight", &L.k_norm))) return 1;
             if (m->cfg.num_experts > 0) {
                 const std::string mp = p + (m->cfg.moe_mode == 0 ? "block_sparse_moe." : "mlp.");
                 const int Im = m->cfg.moe_intermediate_size;
-                if (getq(mp + "gate", m->cfg.num_experts, &Q.moe_router) || getq(mp + "switch_mlp.gate_proj", Im, &Q.moe_g) ||
-                    getq(mp + "switch_mlp.up_proj", Im, &Q.moe_u) || getq(mp + "switch_mlp.down_proj", hd, &Q.moe_d))
+                const int E = m->cfg.num_experts;
+                if (getq(mp + "gate", E, &Q.moe_router, hd) || getq(mp + "switch_mlp.gate_proj", Im, &Q.moe_g, hd, E) ||
+                    getq(mp + "switch_mlp.up_proj", Im, &Q.moe_u, hd, E) || getq(mp + "switch_mlp.down_proj", hd, &Q.moe_d, Im, E))
                     return 1;
-            } else if (getq(p + "mlp.gate_proj", m->I, &Q.gate) || getq(p + "mlp.up_proj", m->I, &Q.up) || getq(p + "mlp.down_proj", hd, &Q.down)) {
+            } else if (getq(p + "mlp.gate_proj", m->I, &Q.gate, hd) || getq(p + "mlp.up_proj", m->I, &Q.up, hd) || getq(p + "mlp.down_proj", hd, &Q.down, m->I)) {
                 return 1;
             }
         }
         if (getq("model.embed_tokens", m->cfg.vocab_size, &m->q_embed) || get("model.norm.weight", &m->final_norm)) return 1;
         if (m->cfg.tie_word_embeddings) m->q_head = m->q_embed;            // QuantizedEmbedding::as_linear (quantized.rs:166-180)
-        else if (getq("lm_head", m->V, &m->q_head)) return 1;
+        else if (getq("lm_head", m->V, &m->q_head, hd)) return 1;
         m->weights_resolved = true;
         return 0;
     }

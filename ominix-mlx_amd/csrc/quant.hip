@@ -104,7 +104,8 @@ __device__ __forceinline__ uint64_t qargmax_key(float v, uint32_t idx) {
 // W = u32 words per lane per step; a lane's W*EPW elements lie inside one group.
 // PRO / EPI as in gemv.hip (same arithmetic and rounding points): RMSNorm prologue; store, residual add, SwiGLU
 // over (gate, up) row pairs, logits + greedy-argmax partial.
-template <int BITS, int W, int PRO, int EPI, int RB>
+// SB: scales and biases come interleaved from QMat::sb (one load per row and step instead of two)
+template <int BITS, int W, int PRO, int EPI, int RB, bool SB = false>
 __global__ __launch_bounds__(256) void qgemv_kernel(const QGemvArgs a) {
     constexpr int EPW = 32 / BITS, EPL = W * EPW;          // elements per lane per step
     constexpr int LR = (EPI == EPI_SWIGLU) ? 2 : 1;         // physical rows per logical row
@@ -125,7 +126,7 @@ __global__ __launch_bounds__(256) void qgemv_kernel(const QGemvArgs a) {
     const int row_end = min(row_begin + a.rows_per_wave, a.N);
     uint64_t best = 0;
     // physical row pr of the batch: which member matrix, which row inside it
-    auto locate = [&](int pr, const uint32_t*& wq, const bf16_t*& sc, const bf16_t*& bi) {
+    auto locate = [&](int pr, const uint32_t*& wq, const bf16_t*& sc, const bf16_t*& bi, const uint32_t*& sbp) {
         int mi, row;
         if (EPI == EPI_SWIGLU) {
             mi = pr & 1;
@@ -139,6 +140,7 @@ __global__ __launch_bounds__(256) void qgemv_kernel(const QGemvArgs a) {
         wq = M.w + e * a.w_estride + (size_t)row * words_per_row;
         sc = M.scales + e * a.s_estride + (size_t)row * groups_per_row;
         bi = M.biases ? M.biases + e * a.s_estride + (size_t)row * groups_per_row : nullptr;
+        sbp = SB ? M.sb + e * a.s_estride + (size_t)row * groups_per_row : nullptr;
     };
     // A "unit" = one K step of one batch of RB logical rows (NR physical rows): NR x W words + NR scales + NR biases per
     // lane.  Units of consecutive steps / batches are streamed through TWO register sets: the loads of unit f+1 are in
@@ -146,18 +148,20 @@ __global__ __launch_bounds__(256) void qgemv_kernel(const QGemvArgs a) {
     struct Unit {
         uint32_t wd[NR][W];
         bf16_t sc[NR], bi[NR];
+        uint32_t sbv[NR];
     };
     const int nbatch = (row_end - row_begin + RB - 1) / RB;
     const int nunits = nbatch > 0 ? nbatch * steps : 0;
     const uint32_t* rw[NR];      // row pointers of the batch being ISSUED (issue order is monotonic in f)
     const bf16_t* rs[NR];
     const bf16_t* rb[NR];
+    const uint32_t* rsb[NR];
     auto issue = [&](Unit& u, int f) {
         const int st = f % steps;
         if (st == 0) {
             const int r0 = row_begin + (f / steps) * RB;
 #pragma unroll
-            for (int r = 0; r < NR; ++r) locate(EPI == EPI_SWIGLU ? 2 * (r0 + r / 2) + (r & 1) : r0 + r, rw[r], rs[r], rb[r]);
+            for (int r = 0; r < NR; ++r) locate(EPI == EPI_SWIGLU ? 2 * (r0 + r / 2) + (r & 1) : r0 + r, rw[r], rs[r], rb[r], rsb[r]);
         }
         const int chunk = st * 64 + lane;
         const int g = chunk * EPL / a.group;
@@ -173,8 +177,12 @@ __global__ __launch_bounds__(256) void qgemv_kernel(const QGemvArgs a) {
             } else {
                 u.wd[r][0] = __builtin_nontemporal_load(p);
             }
-            u.sc[r] = rs[r][g];
-            u.bi[r] = rb[r] ? rb[r][g] : (bf16_t)0;
+            if (SB) {
+                u.sbv[r] = rsb[r][g];
+            } else {
+                u.sc[r] = rs[r][g];
+                u.bi[r] = rb[r] ? rb[r][g] : (bf16_t)0;
+            }
         }
     };
     float acc[NR];
@@ -195,8 +203,8 @@ __global__ __launch_bounds__(256) void qgemv_kernel(const QGemvArgs a) {
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
             float d = 0.f;
-            const float scl = bf16_to_f32(u.sc[r]);
-            float bia = bf16_to_f32(u.bi[r]);
+            const float scl = SB ? bf16lo(u.sbv[r]) : bf16_to_f32(u.sc[r]);
+            float bia = SB ? bf16hi(u.sbv[r]) : bf16_to_f32(u.bi[r]);
 #pragma unroll
             for (int wi = 0; wi < W; ++wi) {
                 const uint32_t wdw = u.wd[r][wi];
@@ -340,8 +348,20 @@ int launch_qgemv_w(const QGemvArgs& a, int pro, int epi, hipStream_t s) {
     const size_t shmem = (size_t)a.K * 2 + (size_t)(a.K / (W * EPW)) * 4 + 64;
     // RB = logical rows per unit: 4 for long matrices, 2 when the matrix is small enough that wave count matters more
     // (rows_per_wave == RB there: one batch per wave, twice the waves) and for SwiGLU row pairs
+    // interleaved scale/bias words: the engine's 4-bit, K % 2048 == 0 matrices (every member of the stack must carry them)
+    bool sb = BITS == 4 && W == 4;
+    for (int i = 0; i < 3 && sb; ++i)
+        if (a.m[i].w && !a.m[i].sb) sb = false;
 #define OMX_QGEMV_CASE(P, E)                                                                  \
     if (pro == P && epi == E) {                                                               \
+        if constexpr (BITS == 4 && W == 4) {                                                  \
+            if (sb) {                                                                         \
+                if (E == EPI_SWIGLU || a.rows_per_wave == 2) qgemv_kernel<BITS, W, P, E, 2, true><<<grid, block, shmem, s>>>(a); \
+                else qgemv_kernel<BITS, W, P, E, 4, true><<<grid, block, shmem, s>>>(a);      \
+                OMX_LAUNCH_CHECK();                                                           \
+                return 0;                                                                     \
+            }                                                                                 \
+        }                                                                                     \
         if (E == EPI_SWIGLU || a.rows_per_wave == 2) qgemv_kernel<BITS, W, P, E, 2><<<grid, block, shmem, s>>>(a); \
         else qgemv_kernel<BITS, W, P, E, 4><<<grid, block, shmem, s>>>(a);                     \
         OMX_LAUNCH_CHECK();                                                                   \
@@ -384,6 +404,22 @@ int check_format(const char* who, int K, int group, int bits, int dtype) {
 }
 
 }  // namespace
+
+namespace {
+__global__ __launch_bounds__(256) void quant_interleave_kernel(uint32_t* __restrict__ sb, const bf16_t* __restrict__ scales,
+                                                               const bf16_t* __restrict__ biases, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+        sb[i] = (uint32_t)scales[i] | ((uint32_t)(biases ? biases[i] : (bf16_t)0) << 16);
+}
+}  // namespace
+
+int launch_quant_interleave(uint32_t* sb, const bf16_t* scales, const bf16_t* biases, size_t n_groups, hipStream_t s) {
+    OMX_REQUIRE(sb && scales, "quant interleave: null tensor");
+    if (n_groups == 0) return 0;
+    quant_interleave_kernel<<<(unsigned)std::min<size_t>((n_groups + 255) / 256, 4096), 256, 0, s>>>(sb, scales, biases, n_groups);
+    OMX_LAUNCH_CHECK();
+    return 0;
+}
 
 int qgemv_grid(int N) {
     const int rpw = N >= 65536 ? 16 : N <= 8192 ? 2 : 4;

@@ -156,6 +156,7 @@ struct omx_qwen3_ {
     std::vector<LayerW> layers;
     std::vector<LayerQ> qlayers;             // quantized mode (cfg.quant_bits != 0)
     QMat q_embed = {}, q_head = {};
+    std::vector<const bf16_t*> sb_keys;   // scales pointers registered with quant_register_sb
     bf16_t* dq_buf = nullptr;                // dequantised weight of the GEMM in flight (batched prefill)
     size_t dq_cap = 0;
     const bf16_t *embed = nullptr, *final_norm = nullptr, *lm_head = nullptr;
@@ -258,6 +259,8 @@ int resolve_weights(omx_qwen3 m) {
                 uint32_t* sb = nullptr;
                 if (dev_alloc(m, &sb, ng) || launch_quant_interleave(sb, sc, bi, ng, m->stream)) return 1;
                 out->sb = sb;
+                quant_register_sb(sc, sb);
+                m->sb_keys.push_back(sc);
             }
             return 0;
         };
@@ -973,6 +976,7 @@ int omx_qwen3_destroy(omx_qwen3 m) {
     if (m->stream) (void)hipStreamSynchronize(m->stream);
     if (m->g_full) (void)hipGraphExecDestroy(m->g_full);
     if (m->g_nohead) (void)hipGraphExecDestroy(m->g_nohead);
+    for (const bf16_t* k : m->sb_keys) quant_unregister_sb(k);
     for (void* p : m->owned) (void)hipFree(p);
     if (m->dq_buf) (void)hipFree(m->dq_buf);
     for (bf16_t* p : {m->pf_h, m->pf_h2, m->pf_xn, m->pf_q, m->pf_k, m->pf_v, m->pf_qt, m->pf_attn, m->pf_g, m->pf_u})

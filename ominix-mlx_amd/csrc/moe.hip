@@ -490,6 +490,7 @@ extern "C" int omx_moe_block_forward_q(void* out, const void* resid, const void*
     q.gate = QMat{(const uint32_t*)q_gate, (const bf16_t*)s_gate, (const bf16_t*)b_gate, inter};
     q.up = QMat{(const uint32_t*)q_up, (const bf16_t*)s_up, (const bf16_t*)b_up, inter};
     q.down = QMat{(const uint32_t*)q_down, (const bf16_t*)s_down, (const bf16_t*)b_down, hidden};
+    q.gate.sb = quant_find_sb(q.gate.scales); q.up.sb = quant_find_sb(q.up.scales); q.down.sb = quant_find_sb(q.down.scales);
     q.group = group_size; q.bits = bits;
     const int slots = n_tokens * top_k;
     if (slots > 32) {
@@ -621,6 +622,7 @@ extern "C" int omx_moe_forward_q(void* out, const void* x, const void* gate_w, c
     q.gate = QMat{(const uint32_t*)q_gate, (const bf16_t*)s_gate, (const bf16_t*)b_gate, inter};
     q.up = QMat{(const uint32_t*)q_up, (const bf16_t*)s_up, (const bf16_t*)b_up, inter};
     q.down = QMat{(const uint32_t*)q_down, (const bf16_t*)s_down, (const bf16_t*)b_down, hidden};
+    q.gate.sb = quant_find_sb(q.gate.scales); q.up.sb = quant_find_sb(q.up.scales); q.down.sb = quant_find_sb(q.down.scales);
     q.group = group_size; q.bits = bits;
     return moe_forward_impl(out, x, gate_w, nullptr, nullptr, nullptr, &q, n_tokens, hidden, inter, n_experts, top_k, mode,
                             norm_topk_prob, inds_out, scores_out, stream);

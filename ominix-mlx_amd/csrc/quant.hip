@@ -15,6 +15,9 @@
 //   * M > 16 (prefill): dequantise W once into the workspace, then the bf16 MFMA GEMM (gemm.hip).
 #include "common.hpp"
 #include "gemm.hpp"
+#include <mutex>
+#include <unordered_map>
+
 #include "quant.hpp"
 #include "vec.hpp"
 #include "workspace.hpp"
@@ -419,6 +422,24 @@ int launch_quant_interleave(uint32_t* sb, const bf16_t* scales, const bf16_t* bi
     quant_interleave_kernel<<<(unsigned)std::min<size_t>((n_groups + 255) / 256, 4096), 256, 0, s>>>(sb, scales, biases, n_groups);
     OMX_LAUNCH_CHECK();
     return 0;
+}
+
+namespace {
+std::mutex g_sb_mu;
+std::unordered_map<const void*, const uint32_t*> g_sb_of_scales;
+}  // namespace
+void quant_register_sb(const bf16_t* scales, const uint32_t* sb) {
+    std::lock_guard<std::mutex> lk(g_sb_mu);
+    g_sb_of_scales[scales] = sb;
+}
+void quant_unregister_sb(const bf16_t* scales) {
+    std::lock_guard<std::mutex> lk(g_sb_mu);
+    g_sb_of_scales.erase(scales);
+}
+const uint32_t* quant_find_sb(const bf16_t* scales) {
+    std::lock_guard<std::mutex> lk(g_sb_mu);
+    auto it = g_sb_of_scales.find(scales);
+    return it == g_sb_of_scales.end() ? nullptr : it->second;
 }
 
 int qgemv_grid(int N) {

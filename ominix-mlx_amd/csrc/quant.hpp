@@ -16,6 +16,11 @@ struct QMat {               // one member of a row-stacked weight (q | k | v) --
     const uint32_t* sb = nullptr;
 };
 int launch_quant_interleave(uint32_t* sb, const bf16_t* scales, const bf16_t* biases, size_t n_groups, hipStream_t s);
+// The raw-pointer C entry points (omx_moe_block_forward_q ...) receive the checkpoint's scales pointer; an engine that built the
+// repack registers it under that pointer so those entry points find it (and removes it before freeing the repack).
+void quant_register_sb(const bf16_t* scales, const uint32_t* sb);
+void quant_unregister_sb(const bf16_t* scales);
+const uint32_t* quant_find_sb(const bf16_t* scales);
 
 struct QGemvArgs {
     QMat m[3];

@@ -248,7 +248,7 @@ int resolve_weights(omx_qwen3 m) {
     m->layers.resize(m->cfg.num_hidden_layers);
     if (m->cfg.quant_bits) {
         const int D = m->cfg.head_dim, hd = m->cfg.hidden_size;
-        const bool interleave = m->cfg.quant_bits == 4 && !(getenv("OMX_QUANT_INTERLEAVE") && getenv("OMX_QUANT_INTERLEAVE")[0] == '0');
+        const bool interleave = !(getenv("OMX_QUANT_INTERLEAVE") && getenv("OMX_QUANT_INTERLEAVE")[0] == '0');
         // K: contraction width; stack: matrices stacked in the tensor (experts)
         auto getq = [&](const std::string& prefix, int n, QMat* out, int K = 0, int stack = 1) -> int {
             const bf16_t *w = nullptr, *sc = nullptr, *bi = nullptr;

@@ -351,13 +351,13 @@ int launch_qgemv_w(const QGemvArgs& a, int pro, int epi, hipStream_t s) {
     const size_t shmem = (size_t)a.K * 2 + (size_t)(a.K / (W * EPW)) * 4 + 64;
     // RB = logical rows per unit: 4 for long matrices, 2 when the matrix is small enough that wave count matters more
     // (rows_per_wave == RB there: one batch per wave, twice the waves) and for SwiGLU row pairs
-    // interleaved scale/bias words: the engine's 4-bit, K % 2048 == 0 matrices (every member of the stack must carry them)
-    bool sb = BITS == 4 && W == 4;
+    // interleaved scale/bias words: the engine's K % 2048 == 0 matrices (every member of the stack must carry them)
+    bool sb = W == 4;
     for (int i = 0; i < 3 && sb; ++i)
         if (a.m[i].w && !a.m[i].sb) sb = false;
 #define OMX_QGEMV_CASE(P, E)                                                                  \
     if (pro == P && epi == E) {                                                               \
-        if constexpr (BITS == 4 && W == 4) {                                                  \
+        if constexpr (W == 4) {                                                               \
             if (sb) {                                                                         \
                 if (E == EPI_SWIGLU || a.rows_per_wave == 2) qgemv_kernel<BITS, W, P, E, 2, true><<<grid, block, shmem, s>>>(a); \
                 else qgemv_kernel<BITS, W, P, E, 4, true><<<grid, block, shmem, s>>>(a);      \

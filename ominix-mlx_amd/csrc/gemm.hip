@@ -553,7 +553,10 @@ __device__ __forceinline__ void wait_vm_tiles(int tiles) {   // wait until at mo
     }
 }
 
-template <int NS>
+// SEG: the column tiles are the concatenation of up to three projections of the same input (GemmSegs::plain, tile0 in units of
+// 64 columns): own weight, bias, output and width per segment -- q/k/v of a short prompt as ONE grid instead of three, two of
+// which would be 32 blocks.
+template <int NS, bool SEG = false>
 __global__ __launch_bounds__(skinny::NT) void gemm_bf16_nt_skinny_kernel(const GemmArgs a) {
     using namespace skinny;
     static_assert(NS >= 2 && NS <= 8, "ring depth: the counted waits cover up to 6 pending tiles");
@@ -571,7 +574,19 @@ __global__ __launch_bounds__(skinny::NT) void gemm_bf16_nt_skinny_kernel(const G
     // (weights wider than the activation block: column runs; every XCD then reads 1/8 of W instead of all of it)
     const bool col_runs = a.N > a.M;
     const int m0 = (col_runs ? bid % a.grid_m : bid / a.grid_n) * TM;
-    const int n0 = (col_runs ? bid / a.grid_m : bid % a.grid_n) * TN;
+    int tn = col_runs ? bid / a.grid_m : bid % a.grid_n;
+    const bf16_t* seg_w = a.w;
+    const bf16_t* seg_bias = a.bias;
+    bf16_t* seg_out = a.out;
+    int seg_cols = a.N, seg_ld = a.N;
+    if constexpr (SEG) {
+        const GemmSegs& g = a.sg;
+        const int sidx = (g.n_plain > 1 && tn >= g.plain[1].tile0) + (g.n_plain > 2 && tn >= g.plain[2].tile0);
+        const GemmSeg& sgm = g.plain[sidx];
+        seg_w = sgm.w; seg_bias = sgm.bias; seg_out = sgm.out; seg_cols = sgm.cols; seg_ld = sgm.ld;
+        tn -= sgm.tile0;
+    }
+    const int n0 = tn * TN;
     const int nt = a.K / TK;
 
     const bf16_t* srcA[2];
@@ -582,7 +597,7 @@ __global__ __launch_bounds__(skinny::NT) void gemm_bf16_nt_skinny_kernel(const G
         const int row = c >> 3;
         const int kc = (c & 7) ^ (row & 7);           // logical k-chunk kept at this slot (source-side swizzle)
         srcA[i] = a.x + (size_t)min(m0 + row, a.M - 1) * a.K + kc * 8;
-        srcB[i] = a.w + (size_t)min(n0 + row, a.N - 1) * a.K + kc * 8;
+        srcB[i] = seg_w + (size_t)min(n0 + row, seg_cols - 1) * a.K + kc * 8;
     }
     auto stage = [&](int t) {
         unsigned char* st = smem + (t % NS) * STAGE;
@@ -634,15 +649,15 @@ __global__ __launch_bounds__(skinny::NT) void gemm_bf16_nt_skinny_kernel(const G
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int col = n0 + wc * 32 + j * 16 + 4 * (lane >> 4);
-            if (col >= a.N) continue;
-            const size_t o = (size_t)row * a.N + col;
-            const bool full = col + 3 < a.N && (a.N & 3) == 0;
+            if (col >= seg_cols) continue;
+            const size_t o = (size_t)row * seg_ld + col;
+            const bool full = col + 3 < seg_cols && (seg_cols & 3) == 0 && (seg_ld & 3) == 0;
             float v[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = acc[i][j][e];
             if (full) {
-                if (a.bias) {
-                    const u32x2 b = *reinterpret_cast<const u32x2*>(a.bias + col);
+                if (seg_bias) {
+                    const u32x2 b = *reinterpret_cast<const u32x2*>(seg_bias + col);
                     v[0] += bf16lo(b[0]); v[1] += bf16hi(b[0]); v[2] += bf16lo(b[1]); v[3] += bf16hi(b[1]);
                 }
                 if (a.relu) {
@@ -659,16 +674,16 @@ __global__ __launch_bounds__(skinny::NT) void gemm_bf16_nt_skinny_kernel(const G
                     v[0] = bf16lo(r[0]) + round_bf16(v[0]); v[1] = bf16hi(r[0]) + round_bf16(v[1]);
                     v[2] = bf16lo(r[1]) + round_bf16(v[2]); v[3] = bf16hi(r[1]) + round_bf16(v[3]);
                 }
-                *reinterpret_cast<u32x2*>(a.out + o) = u32x2{pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3])};
+                *reinterpret_cast<u32x2*>(seg_out + o) = u32x2{pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3])};
             } else {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    if (col + e >= a.N) break;
-                    float x = v[e] + (a.bias ? bf16_to_f32(a.bias[col + e]) : 0.f);
+                    if (col + e >= seg_cols) break;
+                    float x = v[e] + (seg_bias ? bf16_to_f32(seg_bias[col + e]) : 0.f);
                     if (a.relu) x = fmaxf(x, 0.f);
                     if (a.gate) x = bf16_to_f32(a.resid[o + e]) + x * bf16_to_f32(a.gate[col + e]);
                     else if (a.resid) x = bf16_to_f32(a.resid[o + e]) + round_bf16(x);
-                    a.out[o + e] = f32_to_bf16(x);
+                    seg_out[o + e] = f32_to_bf16(x);
                 }
             }
         }
@@ -733,6 +748,8 @@ int ensure_attr() {
         OMX_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_bf16_nt_256_kernel<16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big::SMEM));
         OMX_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_bf16_nt_skinny_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * skinny::STAGE));
         OMX_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_bf16_nt_skinny_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * skinny::STAGE));
+        OMX_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_bf16_nt_skinny_kernel<8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * skinny::STAGE));
+        OMX_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_bf16_nt_skinny_kernel<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * skinny::STAGE));
         attr_set = true;
     }
     return 0;
@@ -785,7 +802,8 @@ bool gemm_segmented_supported(int M, int K, const GemmSegs& g) {
     for (int i = 0; i < g.n_plain; ++i)
         if (g.plain[i].cols <= 0 || g.plain[i].cols % 4 != 0 || g.plain[i].ld % 4 != 0) return false;
     if (g.half < 0 || g.half % 4 != 0 || (g.half > 0 && g.ld_act % 4 != 0)) return false;
-    return ((M + 255) / 256) * seg_tiles(g) >= 160;   // same chip-filling rule as the plain 256^2 dispatch
+    if (((M + 255) / 256) * seg_tiles(g) >= 160) return true;   // same chip-filling rule as the plain 256^2 dispatch
+    return g.half == 0;   // plain segments of a small problem: the 64^2 ring kernel takes them
 }
 
 int launch_gemm_bf16_segmented(const bf16_t* x, int M, int K, const GemmSegs& segs, hipStream_t s) {
@@ -805,6 +823,21 @@ int launch_gemm_bf16_segmented(const bf16_t* x, int M, int K, const GemmSegs& se
     GemmArgs a = {};
     a.x = x; a.M = M; a.K = K;
     a.sg = segs;
+    if (((M + 255) / 256) * seg_tiles(segs) < 160) {   // small problem, plain segments: one grid of 64^2 ring-kernel tiles
+        int t64 = 0, n64 = 0;
+        for (int i = 0; i < segs.n_plain; ++i) {
+            a.sg.plain[i].tile0 = t64;
+            t64 += (segs.plain[i].cols + 63) / 64;
+            n64 += segs.plain[i].cols;
+        }
+        a.N = n64;
+        a.grid_m = (M + 63) / 64;
+        a.grid_n = t64;
+        if (a.grid_m * a.grid_n <= 256) gemm_bf16_nt_skinny_kernel<8, true><<<a.grid_m * a.grid_n, skinny::NT, 8 * skinny::STAGE, s>>>(a);
+        else gemm_bf16_nt_skinny_kernel<4, true><<<a.grid_m * a.grid_n, skinny::NT, 4 * skinny::STAGE, s>>>(a);
+        OMX_LAUNCH_CHECK();
+        return 0;
+    }
     int t = 0, n = 0;
     for (int i = 0; i < segs.n_plain; ++i) {
         a.sg.plain[i].tile0 = t;

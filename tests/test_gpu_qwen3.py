@@ -170,6 +170,24 @@ def test_prefill_head_on_last_batched_row_matches_tail_step(omx, monkeypatch, na
                 break
 
 
+@pytest.mark.parametrize("name,T", [("gqa4_d128", 97), ("gqa2_d64", 300), ("mha_d128_linear_rope", 33)])
+def test_short_prompt_qkv_in_one_ring_kernel_grid_is_bit_identical(omx, monkeypatch, name, T):
+    """Short prompts: q/k/v are three segments of ONE grid of the 64 x 64 ring kernel (two of the three separate grids would be a
+    few dozen blocks).  Every output element is computed by the same kernel with the same K order either way, so logits and
+    tokens are EQUAL to the one-launch-per-projection schedule."""
+    cfg = CONFIGS[name]
+    prompt = synth.prompt_ids(T, cfg.vocab_size)
+    outs = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("OMX_PREFILL_SEGMENTED", mode)
+        m = _engine(omx, cfg)
+        first = m.prefill(prompt)
+        outs[mode] = (first, m.last_logits(), [int(t) for t in m.decode(4)])
+        m.close()
+    assert outs["1"][0] == outs["0"][0] and outs["1"][2] == outs["0"][2]
+    np.testing.assert_array_equal(outs["1"][1], outs["0"][1])
+
+
 def test_segmented_prefill_projections_match_separate_launches(omx, monkeypatch):
     """Long prompts run q/k/v as one segmented launch and gate/up/SiLU-mul as one launch with the activation in the GEMM
     epilogue (csrc/gemm.hpp: GemmSegs).  Same arithmetic per element as the separate launches up to the MFMA shape of the

@@ -18,6 +18,9 @@
 //   * XCD-aware block order (T1): consecutive blocks of one XCD share an x row panel in its L2.
 // Fallback (any K, any alignment): register-staged 64x64x32 tiles with zero fill.
 #include "gemm.hpp"
+#include "gridsync.hpp"   // coherent accessors for the split-K hand-over
+#include <map>
+#include <mutex>
 
 #include <stdlib.h>
 
@@ -44,6 +47,8 @@ struct GemmArgs {
     GroupedDesc g;        // grouped mode when g.tile_expert != nullptr
     int relu;             // out = max(0, acc + bias)  (Paraformer FFN, paraformer.rs:565-569)
     GemmSegs sg;          // segmented mode (256^2 kernel, SW instantiation), see gemm.hpp
+    float* split_ws;      // ring kernel, gridDim.y > 1: f32 partial tiles [tile][split][64 x 64]
+    unsigned* split_cnt;  // [tiles] arrival counters (zero between launches)
 };
 
 // one 16-B chunk per lane per wave-instruction, 4 instructions per operand tile: row pointers of the 4
@@ -587,7 +592,10 @@ __global__ __launch_bounds__(skinny::NT) void gemm_bf16_nt_skinny_kernel(const G
         tn -= sgm.tile0;
     }
     const int n0 = tn * TN;
-    const int nt = a.K / TK;
+    // split K (gridDim.y > 1): this block owns K steps [t0, t0 + nt) of the tile; the partial tiles meet in the epilogue
+    const int nt_all = a.K / TK, nsplit = gridDim.y, split = blockIdx.y;
+    const int t0 = (int)((long long)nt_all * split / nsplit);
+    const int nt = (int)((long long)nt_all * (split + 1) / nsplit) - t0;
 
     const bf16_t* srcA[2];
     const bf16_t* srcB[2];
@@ -596,8 +604,8 @@ __global__ __launch_bounds__(skinny::NT) void gemm_bf16_nt_skinny_kernel(const G
         const int c = i * NT + threadIdx.x;          // LDS chunk (16 B) of the operand tile, lane-linear inside a wave
         const int row = c >> 3;
         const int kc = (c & 7) ^ (row & 7);           // logical k-chunk kept at this slot (source-side swizzle)
-        srcA[i] = a.x + (size_t)min(m0 + row, a.M - 1) * a.K + kc * 8;
-        srcB[i] = seg_w + (size_t)min(n0 + row, seg_cols - 1) * a.K + kc * 8;
+        srcA[i] = a.x + (size_t)min(m0 + row, a.M - 1) * a.K + kc * 8 + (size_t)t0 * TK;
+        srcB[i] = seg_w + (size_t)min(n0 + row, seg_cols - 1) * a.K + kc * 8 + (size_t)t0 * TK;
     }
     auto stage = [&](int t) {
         unsigned char* st = smem + (t % NS) * STAGE;
@@ -639,6 +647,47 @@ __global__ __launch_bounds__(skinny::NT) void gemm_bf16_nt_skinny_kernel(const G
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
         }
+    }
+
+    if (nsplit > 1) {
+        // Every split stores its f32 partial tile write-through; the LAST one to arrive (one relaxed atomic per block) re-reads
+        // all of them in split order -- its own included, so the sum has one fixed order whoever arrives last -- and runs the
+        // epilogue.  (Same hand-over as the split-KV combine of attn_decode.hip.)
+        __shared__ unsigned s_last;
+        const size_t tile = blockIdx.x;
+        float* mine = a.split_ws + ((tile * nsplit + split) * 4 + wave) * (4 * 64 * 4);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                float* p = mine + ((i * 2 + j) * 64 + lane) * 4;
+                st_coh64(p, (uint64_t)__float_as_uint(acc[i][j][0]) | ((uint64_t)__float_as_uint(acc[i][j][1]) << 32));
+                st_coh64(p + 2, (uint64_t)__float_as_uint(acc[i][j][2]) | ((uint64_t)__float_as_uint(acc[i][j][3]) << 32));
+            }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0)
+            s_last = __hip_atomic_fetch_add(a.split_cnt + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)nsplit - 1 ? 1u : 0u;
+        __syncthreads();
+        if (!s_last) return;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
+        for (int sp = 0; sp < nsplit; ++sp) {
+            const float* theirs = a.split_ws + ((tile * nsplit + sp) * 4 + wave) * (4 * 64 * 4);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const u32x4 v = ld_coh128(theirs + ((i * 2 + j) * 64 + lane) * 4);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[i][j][r] += __uint_as_float(v[r]);
+                }
+        }
+        if (threadIdx.x == 0) __hip_atomic_store(a.split_cnt + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 
     // epilogue: W-tile x X-tile products, so a lane holds output row (lane & 15), columns 4 * (lane >> 4) + [0, 4) of each tile
@@ -757,6 +806,43 @@ int ensure_attr() {
 
 }  // namespace
 
+static bool hipStreamIsCapturing_safe(hipStream_t s) {   // the split scratch may have to grow (hipMalloc): not inside a capture
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    return hipStreamIsCapturing(s, &st) == hipSuccess && st != hipStreamCaptureStatusNone;
+}
+
+// split-K scratch of the ring kernel, one per stream (two streams may run such GEMMs at the same time)
+namespace {
+struct SplitWs { float* ws = nullptr; unsigned* cnt = nullptr; size_t ws_floats = 0, cnt_n = 0; };
+std::mutex g_split_mu;
+std::map<hipStream_t, SplitWs> g_split_ws;
+int split_workspace(hipStream_t s, size_t floats, size_t tiles, float** ws, unsigned** cnt) {
+    std::lock_guard<std::mutex> lk(g_split_mu);
+    SplitWs& w = g_split_ws[s];
+    if (floats > w.ws_floats || tiles > w.cnt_n) {
+        OMX_HIP_CHECK(hipStreamSynchronize(s));   // earlier launches on this stream may still use the old buffers
+        if (w.ws) OMX_HIP_CHECK(hipFree(w.ws));
+        if (w.cnt) OMX_HIP_CHECK(hipFree(w.cnt));
+        w.ws_floats = std::max(floats, w.ws_floats);
+        w.cnt_n = std::max(tiles, w.cnt_n);
+        OMX_HIP_CHECK(hipMalloc((void**)&w.ws, w.ws_floats * 4));
+        OMX_HIP_CHECK(hipMalloc((void**)&w.cnt, w.cnt_n * 4));
+        OMX_HIP_CHECK(hipMemsetAsync(w.cnt, 0, w.cnt_n * 4, s));
+    }
+    *ws = w.ws; *cnt = w.cnt;
+    return 0;
+}
+// K splits of a ring-kernel launch: only when the tile grid leaves most CUs without a block AND the K loop is long -- the
+// serial chain of K steps, each a memory round trip, is then what the launch takes (down projection of a 128-token prompt:
+// 128 blocks x 192 steps).  At least 16 steps stay in each split.
+int ring_splits(int blocks, int nt) {
+    const char* env = getenv("OMX_GEMM_SPLITK");
+    if (env && env[0] == '0') return 1;
+    if (blocks > 160 || nt < 48) return 1;
+    return std::max(1, std::min(std::min(8, 512 / blocks), nt / 16));
+}
+}  // namespace
+
 static int launch_gemm_impl(bf16_t* out, const bf16_t* x, const bf16_t* w, const bf16_t* bias, const bf16_t* resid,
                             const bf16_t* gate, int M, int N, int K, hipStream_t s, int relu = 0) {
     OMX_REQUIRE(M > 0 && N > 0 && K > 0, "gemm: bad shape M=%d N=%d K=%d", M, N, K);
@@ -779,8 +865,16 @@ static int launch_gemm_impl(bf16_t* out, const bf16_t* x, const bf16_t* w, const
             // the 128^2 grid leaves CUs idle: 64^2 tiles with a deep prefetch ring (one block per CU: 8 stages; two: 4)
             a.grid_m = (M + 63) / 64;
             a.grid_n = (N + 63) / 64;
-            if (a.grid_m * a.grid_n <= 256) gemm_bf16_nt_skinny_kernel<8><<<a.grid_m * a.grid_n, skinny::NT, 8 * skinny::STAGE, s>>>(a);
-            else gemm_bf16_nt_skinny_kernel<4><<<a.grid_m * a.grid_n, skinny::NT, 4 * skinny::STAGE, s>>>(a);
+            const int blocks = a.grid_m * a.grid_n, ns = ring_splits(blocks, K / 64);
+            if (ns > 1 && !(s != nullptr && hipStreamIsCapturing_safe(s))) {
+                if (split_workspace(s, (size_t)blocks * ns * 64 * 64, (size_t)blocks, &a.split_ws, &a.split_cnt)) return 1;
+                if (blocks * ns <= 256) gemm_bf16_nt_skinny_kernel<8><<<dim3(blocks, ns), skinny::NT, 8 * skinny::STAGE, s>>>(a);
+                else gemm_bf16_nt_skinny_kernel<4><<<dim3(blocks, ns), skinny::NT, 4 * skinny::STAGE, s>>>(a);
+            } else if (blocks <= 256) {
+                gemm_bf16_nt_skinny_kernel<8><<<blocks, skinny::NT, 8 * skinny::STAGE, s>>>(a);
+            } else {
+                gemm_bf16_nt_skinny_kernel<4><<<blocks, skinny::NT, 4 * skinny::STAGE, s>>>(a);
+            }
         } else {
             gemm_bf16_nt_kernel<false><<<a.grid_m * a.grid_n, NTHREADS, 4 * TILE_BYTES, s>>>(a);
         }

@@ -90,6 +90,30 @@ def test_linear_gemm_skinny_ring_kernel(omx, monkeypatch, M, N, K):
     assert_bf16_close(got, other, 1, atol=2e-5 * np.sqrt(K) + 1e-4)
 
 
+@pytest.mark.parametrize("M,N,K", [
+    (128, 512, 4096),        # 16 tiles x 64 K steps -> 4 splits
+    (100, 4096, 12288),      # down projection of a ~100-token prompt: 128 tiles x 192 steps -> 4 splits, ragged rows
+    (40, 1000, 3072),        # ragged columns, 3 splits of 16 steps
+])
+def test_linear_gemm_ring_kernel_split_k(omx, monkeypatch, M, N, K):
+    """Few tiles and a long contraction: the ring kernel splits K over gridDim.y and the last split to arrive sums the f32
+    partial tiles in split order.  Same tolerance as every GEMM; the result does not depend on which split arrives last
+    (repeated launches are EQUAL, which also checks that the arrival counters return to zero)."""
+    T = omx.ops.Tensor
+    x = rc.bf16_round(rand((M, K), 61))
+    w = rc.bf16_round(rand((N, K), 62) * 0.03)
+    b = rc.bf16_round(rand((N,), 63))
+    xt, wt, bt = T.from_numpy(x), T.from_numpy(w), T.from_numpy(b)
+    ref = rc.linear(x, w, b, "bf16")
+    runs = [omx.ops.linear(xt, wt, bt).numpy() for _ in range(4)]
+    assert_bf16_close(runs[0], ref, 1, atol=2e-5 * np.sqrt(K) + 1e-4)
+    for r in runs[1:]:
+        np.testing.assert_array_equal(r, runs[0])
+    monkeypatch.setenv("OMX_GEMM_SPLITK", "0")
+    one = omx.ops.linear(xt, wt, bt).numpy()
+    assert_bf16_close(runs[0], one, 1, atol=2e-5 * np.sqrt(K) + 1e-4)
+
+
 def test_linear_gemm_bias_is_fused_addmm(omx):
     """nn/linear.rs:88-90: addmm rounds once."""
     T = omx.ops.Tensor

@@ -834,12 +834,12 @@ int split_workspace(hipStream_t s, size_t floats, size_t tiles, float** ws, unsi
 }
 // K splits of a ring-kernel launch: only when the tile grid leaves most CUs without a block AND the K loop is long -- the
 // serial chain of K steps, each a memory round trip, is then what the launch takes (down projection of a 128-token prompt:
-// 128 blocks x 192 steps).  At least 16 steps stay in each split.
+// 128 blocks x 192 steps).  At least 8 steps stay in each split (Paraformer FFN down: 64 tiles x 32 steps -> 4 splits, 17 -> 12 us).
 int ring_splits(int blocks, int nt) {
     const char* env = getenv("OMX_GEMM_SPLITK");
     if (env && env[0] == '0') return 1;
-    if (blocks > 160 || nt < 48) return 1;
-    return std::max(1, std::min(std::min(8, 512 / blocks), nt / 16));
+    if (blocks > 160 || nt < 32) return 1;
+    return std::max(1, std::min(std::min(8, 512 / blocks), nt / 8));
 }
 }  // namespace
 

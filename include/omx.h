@@ -97,7 +97,7 @@ int omx_linear(void* out, const void* x, const void* w, const void* bias, int M,
  * 905-916).  W [n_plain + 2*half, K].  out_plain [M, n_plain] = x . W[:n_plain]^T,
  * out_act [M, half] = silu(g) * u with g, u the bf16-rounded gate / up features: the same bits as
  * omx_linear followed by omx_fused_swiglu, without the 2*half wide intermediate in HBM.
- * Large shapes only (n_plain % 256 == 0, half % 4 == 0, K % 64 == 0, >= 160 output tiles); others fail.  */
+ * n_plain % 4 == 0, half % 4 == 0, K % 64 == 0; other widths fail (use omx_linear + omx_fused_swiglu).   */
 int omx_linear_swiglu(void* out_plain, void* out_act, const void* x, const void* w, int M, int n_plain,
                       int half, int K, omx_dtype dtype, omx_stream stream);
 

@@ -472,7 +472,7 @@ int omx_klein_forward_with_rope(omx_klein m, void* out, const void* latent, cons
             if (gated_projection(m, x2 + r0 * h, m->att + r0 * hl, w, x + r0 * h, mod + 2 * h /*gate1*/, rows, h, hl)) return 1;
             // ---- MLP half ----
             if (omx_fused_modulate(m->xm + r0 * h, x2 + r0 * h, mod + 3 * h, mod + 4 * h, 1, rows, h, 1e-6f, OMX_BFLOAT16, s)) return 1;
-            if (fuse_act && gemm_swiglu_supported(rows, 0, mh, h)) {
+            if (fuse_act && gemm_swiglu_preferred(rows, 0, mh, h)) {
                 if (kget(m, b + sn + "mlp_in.weight", &w)) return 1;
                 if (launch_gemm_bf16_swiglu(nullptr, 0, act, mh, m->xm + r0 * h, w, rows, 0, mh, h, s)) return 1;
             } else {
@@ -492,7 +492,7 @@ int omx_klein_forward_with_rope(omx_klein m, void* out, const void* latent, cons
         const std::string b = "single_blocks." + std::to_string(i) + ".";
         const bf16_t* mod = m->mod_single;
         if (omx_fused_modulate(m->xm, x, mod, mod + h, 1, S, h, 1e-6f, OMX_BFLOAT16, s)) return 1;
-        const bool fused = fuse_act && gemm_swiglu_supported(S, 3 * hl, mh, h);
+        const bool fused = fuse_act && gemm_swiglu_preferred(S, 3 * hl, mh, h);
         if (fused) {   // q/k/v columns -> proj, SwiGLU of the MLP columns straight into comb[:, hl:]
             if (kget(m, b + "to_qkv_mlp.weight", &w)) return 1;
             if (launch_gemm_bf16_swiglu(m->proj, (int)ldp, m->comb + hl, (int)ldc, m->xm, w, S, 3 * hl, mh, h, s)) return 1;

@@ -798,7 +798,7 @@ int prefill_prefix_batched(omx_qwen3 m, int T, int off, const EncodeOpts* enc = 
         qkv.plain[0] = {L.q, L.q_bias, m->pf_q, H * D, H * D, 0};
         qkv.plain[1] = {L.k, L.k_bias, m->pf_k, Hkv * D, Hkv * D, 0};
         qkv.plain[2] = {L.v, L.v_bias, m->pf_v, Hkv * D, Hkv * D, 0};
-        if (seg_gemm && !quant && gemm_segmented_supported(T, hd, qkv)) {
+        if (seg_gemm && !quant && gemm_segmented_preferred(T, hd, qkv)) {
             if (launch_gemm_bf16_segmented(m->pf_xn, T, hd, qkv, s)) return 1;
         } else {
             if (!(w = W(L.q, &Q.q, hd)) || launch_gemm_bf16(m->pf_q, m->pf_xn, w, L.q_bias, T, H * D, hd, s)) return 1;
@@ -839,7 +839,7 @@ int prefill_prefix_batched(omx_qwen3 m, int T, int off, const EncodeOpts* enc = 
         // T = 2048 instead of 2 x 384), else two GEMMs + the elementwise kernel
         GemmSegs gu = {};
         gu.w_gate = L.gate; gu.w_up = L.up; gu.out_act = m->pf_g; gu.half = I; gu.ld_act = I; gu.act_mode = 1;
-        if (seg_gemm && !quant && gemm_segmented_supported(T, hd, gu)) {
+        if (seg_gemm && !quant && gemm_segmented_preferred(T, hd, gu)) {
             if (launch_gemm_bf16_segmented(m->pf_xn, T, hd, gu, s)) return 1;
         } else {
             if (!(w = W(L.gate, &Q.gate, hd)) || launch_gemm_bf16(m->pf_g, m->pf_xn, w, nullptr, T, I, hd, s)) return 1;

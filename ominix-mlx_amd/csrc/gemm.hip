@@ -584,12 +584,20 @@ __global__ __launch_bounds__(skinny::NT) void gemm_bf16_nt_skinny_kernel(const G
     const bf16_t* seg_bias = a.bias;
     bf16_t* seg_out = a.out;
     int seg_cols = a.N, seg_ld = a.N;
+    bool seg_act = false;   // SwiGLU segment: a 64-column tile = 32 gate + 32 up columns -> 32 activation columns
     if constexpr (SEG) {
         const GemmSegs& g = a.sg;
-        const int sidx = (g.n_plain > 1 && tn >= g.plain[1].tile0) + (g.n_plain > 2 && tn >= g.plain[2].tile0);
-        const GemmSeg& sgm = g.plain[sidx];
-        seg_w = sgm.w; seg_bias = sgm.bias; seg_out = sgm.out; seg_cols = sgm.cols; seg_ld = sgm.ld;
-        tn -= sgm.tile0;
+        if (tn >= g.act_tile0) {
+            seg_act = true;
+            tn -= g.act_tile0;
+            seg_cols = g.half;
+            seg_bias = nullptr;
+        } else {
+            const int sidx = (g.n_plain > 1 && tn >= g.plain[1].tile0) + (g.n_plain > 2 && tn >= g.plain[2].tile0);
+            const GemmSeg& sgm = g.plain[sidx];
+            seg_w = sgm.w; seg_bias = sgm.bias; seg_out = sgm.out; seg_cols = sgm.cols; seg_ld = sgm.ld;
+            tn -= sgm.tile0;
+        }
     }
     const int n0 = tn * TN;
     // split K (gridDim.y > 1): this block owns K steps [t0, t0 + nt) of the tile; the partial tiles meet in the epilogue
@@ -605,7 +613,14 @@ __global__ __launch_bounds__(skinny::NT) void gemm_bf16_nt_skinny_kernel(const G
         const int row = c >> 3;
         const int kc = (c & 7) ^ (row & 7);           // logical k-chunk kept at this slot (source-side swizzle)
         srcA[i] = a.x + (size_t)min(m0 + row, a.M - 1) * a.K + kc * 8 + (size_t)t0 * TK;
-        srcB[i] = seg_w + (size_t)min(n0 + row, seg_cols - 1) * a.K + kc * 8 + (size_t)t0 * TK;
+        if (SEG && seg_act) {
+            // wave column wc = row >> 5 reads its first 16 B-rows from the gate weight, the next 16 from the up weight: gate and up of
+            // one output column land in accumulator tiles j = 0 and j = 1 of the same lane
+            const int oc = n0 / 2 + (row >> 5) * 16 + (row & 15);
+            srcB[i] = (((row >> 4) & 1) ? a.sg.w_up : a.sg.w_gate) + (size_t)min(oc, seg_cols - 1) * a.K + kc * 8 + (size_t)t0 * TK;
+        } else {
+            srcB[i] = seg_w + (size_t)min(n0 + row, seg_cols - 1) * a.K + kc * 8 + (size_t)t0 * TK;
+        }
     }
     auto stage = [&](int t) {
         unsigned char* st = smem + (t % NS) * STAGE;
@@ -690,6 +705,30 @@ __global__ __launch_bounds__(skinny::NT) void gemm_bf16_nt_skinny_kernel(const G
         if (threadIdx.x == 0) __hip_atomic_store(a.split_cnt + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 
+    if constexpr (SEG) {
+        if (seg_act) {
+            const bool per_op = a.sg.act_mode == 1;
+            const int col = n0 / 2 + wc * 16 + 4 * (lane >> 4);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int row = m0 + wr * 32 + i * 16 + (lane & 15);
+                if (row >= a.M || col >= seg_cols) continue;   // half is a multiple of 4
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float gt = round_bf16(acc[i][0][e]), up = round_bf16(acc[i][1][e]);
+                    if (per_op) {
+                        const float sg = round_bf16(1.0f / (1.0f + expf(-gt)));
+                        v[e] = round_bf16(gt * sg) * up;
+                    } else {
+                        v[e] = gt / (1.0f + expf(-gt)) * up;
+                    }
+                }
+                *reinterpret_cast<u32x2*>(a.sg.out_act + (size_t)row * a.sg.ld_act + col) = u32x2{pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3])};
+            }
+            return;
+        }
+    }
     // epilogue: W-tile x X-tile products, so a lane holds output row (lane & 15), columns 4 * (lane >> 4) + [0, 4) of each tile
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -896,8 +935,16 @@ bool gemm_segmented_supported(int M, int K, const GemmSegs& g) {
     for (int i = 0; i < g.n_plain; ++i)
         if (g.plain[i].cols <= 0 || g.plain[i].cols % 4 != 0 || g.plain[i].ld % 4 != 0) return false;
     if (g.half < 0 || g.half % 4 != 0 || (g.half > 0 && g.ld_act % 4 != 0)) return false;
-    if (((M + 255) / 256) * seg_tiles(g) >= 160) return true;   // same chip-filling rule as the plain 256^2 dispatch
-    return g.half == 0;   // plain segments of a small problem: the 64^2 ring kernel takes them
+    return true;   // >= 160 tiles of 256^2: the deep-pipelined kernel; smaller problems: one grid of the 64^2 ring kernel
+}
+
+// Policy next to capability: is ONE segmented launch the faster schedule?  Measured on MI355X: yes for the 256^2 kernel and for
+// plain segments at any size; a SwiGLU pair on the ring kernel only up to 256 rows (at 512 rows two 128^2 launches + the
+// elementwise kernel are ~30 us faster per layer of a 4B-parameter encoder).
+bool gemm_segmented_preferred(int M, int K, const GemmSegs& g) {
+    if (!gemm_segmented_supported(M, K, g)) return false;
+    if (((M + 255) / 256) * seg_tiles(g) >= 160 || g.half == 0) return true;
+    return M <= 256;
 }
 
 int launch_gemm_bf16_segmented(const bf16_t* x, int M, int K, const GemmSegs& segs, hipStream_t s) {
@@ -924,6 +971,9 @@ int launch_gemm_bf16_segmented(const bf16_t* x, int M, int K, const GemmSegs& se
             t64 += (segs.plain[i].cols + 63) / 64;
             n64 += segs.plain[i].cols;
         }
+        a.sg.act_tile0 = segs.half > 0 ? t64 : 0x7FFFFFFF;
+        if (segs.half > 0) t64 += (segs.half + 31) / 32;
+        n64 += 2 * segs.half;
         a.N = n64;
         a.grid_m = (M + 63) / 64;
         a.grid_n = t64;
@@ -996,8 +1046,13 @@ static GemmSegs swiglu_segs(bf16_t* out_plain, int ld_plain, bf16_t* out_act, in
 }
 
 bool gemm_swiglu_supported(int M, int n_plain, int half, int K) {
-    if (n_plain < 0 || half <= 0) return false;
+    if (n_plain < 0 || half <= 0 || n_plain % 4 != 0) return false;
     return gemm_segmented_supported(M, K, swiglu_segs(nullptr, 4, nullptr, 4, nullptr, n_plain, half, K));
+}
+
+bool gemm_swiglu_preferred(int M, int n_plain, int half, int K) {
+    if (n_plain < 0 || half <= 0 || n_plain % 4 != 0) return false;
+    return gemm_segmented_preferred(M, K, swiglu_segs(nullptr, 4, nullptr, 4, nullptr, n_plain, half, K));
 }
 
 int launch_gemm_bf16_swiglu(bf16_t* out_plain, int ld_plain, bf16_t* out_act, int ld_act, const bf16_t* x, const bf16_t* w, int M,

@@ -53,7 +53,8 @@ struct GemmSegs {
     int act_mode;         // 0: fused_swiglu, one rounding (metal_kernels.rs:188-236); 1: nn::silu(gate) * up with every
                           //    primitive rounded to bf16 (qwen3-mlx/src/model.rs:264-265)
 };
-bool gemm_segmented_supported(int M, int K, const GemmSegs& segs);
+bool gemm_segmented_supported(int M, int K, const GemmSegs& segs);   // can one launch compute it
+bool gemm_segmented_preferred(int M, int K, const GemmSegs& segs);   // ... and is that the faster schedule (callers with a fallback)
 // the same launch over expert-sorted rows (MoE prefill): 256-row tiles from the device-built tile table (GroupedDesc, 256-row
 // granularity), rows gathered through g.row_src, every weight pointer offset by expert * g.w_estride
 int launch_gemm_bf16_segmented_grouped(const bf16_t* x, int max_rows, int K, const GemmSegs& segs, const GroupedDesc& g, int max_tiles,
@@ -65,6 +66,7 @@ int launch_gemm_bf16_segmented(const bf16_t* x, int M, int K, const GemmSegs& se
 //   out_act[m, c]   = bf16(silu(g) * u), g = bf16(x.W[n_plain + c]^T), u = bf16(x.W[n_plain + half + c]^T)  (row stride ld_act)
 // -- bit-identical to storing the whole projection and running fused_swiglu over it (klein_model.rs:489-493, 905-916).
 bool gemm_swiglu_supported(int M, int n_plain, int half, int K);
+bool gemm_swiglu_preferred(int M, int n_plain, int half, int K);
 int launch_gemm_bf16_swiglu(bf16_t* out_plain, int ld_plain, bf16_t* out_act, int ld_act, const bf16_t* x, const bf16_t* w, int M,
                             int n_plain, int half, int K, hipStream_t s);
 

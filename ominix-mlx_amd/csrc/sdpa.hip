@@ -119,8 +119,8 @@ int omx_linear_swiglu(void* out_plain, void* out_act, const void* x, const void*
     OMX_REQUIRE(M >= 0 && n_plain >= 0 && half > 0 && K > 0, "omx_linear_swiglu: bad shape M=%d plain=%d half=%d K=%d", M, n_plain, half, K);
     if (M == 0) return 0;
     OMX_REQUIRE(omx::gemm_swiglu_supported(M, n_plain, half, K),
-                "omx_linear_swiglu: shape M=%d plain=%d half=%d K=%d is outside the fused kernel (plain %% 256, half %% 4, K %% 64, "
-                ">= 160 tiles); use omx_linear + omx_fused_swiglu", M, n_plain, half, K);
+                "omx_linear_swiglu: shape M=%d plain=%d half=%d K=%d is outside the fused kernels (plain %% 4, half %% 4, K %% 64); "
+                "use omx_linear + omx_fused_swiglu", M, n_plain, half, K);
     return omx::launch_gemm_bf16_swiglu((omx::bf16_t*)out_plain, n_plain, (omx::bf16_t*)out_act, half, (const omx::bf16_t*)x,
                                         (const omx::bf16_t*)w, M, n_plain, half, K, (hipStream_t)stream);
 }

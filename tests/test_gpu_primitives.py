@@ -350,6 +350,9 @@ def test_linear_decode_shapes_without_a_tuned_gemv(omx, M, N, K):
     (4608, 0, 3072, 256),        # FLUX double-block mlp_in shape class (no plain columns)
     (2304, 768, 2560, 128),      # single-block to_qkv_mlp shape class: q/k/v columns + [gate | up]
     (300, 256, 10244, 64),       # ragged rows, half not a multiple of the 128-column tile
+    (8, 0, 128, 64),             # small problems run as one grid of the 64 x 64 ring kernel (32 gate + 32 up columns per tile)
+    (77, 64, 100, 128),          # ... ragged rows, a plain segment, half not a multiple of 32
+    (512, 0, 3072, 256),         # ... the DiT txt stream's mlp_in shape class
 ])
 def test_linear_swiglu_matches_linear_then_fused_swiglu(omx, M, n_plain, half, K):
     """omx_linear_swiglu is an in-epilogue form of nn::Linear + fused_swiglu (klein_model.rs:489-493, 905-916):
@@ -372,7 +375,9 @@ def test_linear_swiglu_matches_linear_then_fused_swiglu(omx, M, n_plain, half, K
 
 
 @pytest.mark.gpu
-def test_linear_swiglu_rejects_small_shapes(omx):
+def test_linear_swiglu_rejects_unsupported_widths(omx):
     T = omx.ops.Tensor
-    with pytest.raises(omx.OmxError):
-        omx.ops.linear_swiglu(T.from_numpy(np.zeros((8, 64), np.float32)), T.from_numpy(np.zeros((256, 64), np.float32)), 0)
+    with pytest.raises(omx.OmxError):   # contraction width must be a multiple of 64
+        omx.ops.linear_swiglu(T.from_numpy(np.zeros((8, 72), np.float32)), T.from_numpy(np.zeros((256, 72), np.float32)), 0)
+    with pytest.raises(omx.OmxError):   # [gate | up] must split evenly
+        omx.ops.linear_swiglu(T.from_numpy(np.zeros((8, 64), np.float32)), T.from_numpy(np.zeros((255, 64), np.float32)), 0)

@@ -753,13 +753,15 @@ int prefill_prefix_batched(omx_qwen3 m, int T, int off, const EncodeOpts* enc = 
     const bool quant = c.quant_bits != 0;
     // quantized checkpoint: each weight is dequantised into one scratch matrix right before its GEMM (MLX's qmm does
     // the same per tile); K is the contraction width of that weight
-    auto W = [&](const bf16_t* dense, const QMat* qm, int K) -> const bf16_t* {
+    // `at`: element offset inside the scratch, so that the members of one segmented launch (q | k | v, gate | up) coexist
+    auto W = [&](const bf16_t* dense, const QMat* qm, int K, size_t at = 0) -> const bf16_t* {
         if (!quant) return dense;
-        if (omx_dequantize(m->dq_buf, qm->w, qm->scales, qm->biases, qm->n, K, c.quant_group, c.quant_bits, OMX_BFLOAT16, s)) return nullptr;
-        return m->dq_buf;
+        if (omx_dequantize(m->dq_buf + at, qm->w, qm->scales, qm->biases, qm->n, K, c.quant_group, c.quant_bits, OMX_BFLOAT16, s)) return nullptr;
+        return m->dq_buf + at;
     };
     if (quant) {
-        const size_t need = (size_t)std::max(std::max(H * D, I), hd) * (size_t)std::max(hd, I);
+        const size_t need = std::max((size_t)std::max(std::max(H * D, I), hd) * (size_t)std::max(hd, I),
+                                     std::max((size_t)(H + 2 * Hkv) * D * hd, (size_t)2 * I * hd));
         if (need > m->dq_cap) {
             OMX_HIP_CHECK(hipStreamSynchronize(s));
             if (m->dq_buf) OMX_HIP_CHECK(hipFree(m->dq_buf));
@@ -798,7 +800,13 @@ int prefill_prefix_batched(omx_qwen3 m, int T, int off, const EncodeOpts* enc = 
         qkv.plain[0] = {L.q, L.q_bias, m->pf_q, H * D, H * D, 0};
         qkv.plain[1] = {L.k, L.k_bias, m->pf_k, Hkv * D, Hkv * D, 0};
         qkv.plain[2] = {L.v, L.v_bias, m->pf_v, Hkv * D, Hkv * D, 0};
-        if (seg_gemm && !quant && gemm_segmented_preferred(T, hd, qkv)) {
+        if (seg_gemm && gemm_segmented_preferred(T, hd, qkv)) {
+            if (quant) {   // the three dequantised matrices side by side in the scratch
+                const size_t nq = (size_t)H * D * hd, nk = (size_t)Hkv * D * hd;
+                if (!(qkv.plain[0].w = W(nullptr, &Q.q, hd, 0)) || !(qkv.plain[1].w = W(nullptr, &Q.k, hd, nq)) ||
+                    !(qkv.plain[2].w = W(nullptr, &Q.v, hd, nq + nk)))
+                    return 1;
+            }
             if (launch_gemm_bf16_segmented(m->pf_xn, T, hd, qkv, s)) return 1;
         } else {
             if (!(w = W(L.q, &Q.q, hd)) || launch_gemm_bf16(m->pf_q, m->pf_xn, w, L.q_bias, T, H * D, hd, s)) return 1;
@@ -839,7 +847,8 @@ int prefill_prefix_batched(omx_qwen3 m, int T, int off, const EncodeOpts* enc = 
         // T = 2048 instead of 2 x 384), else two GEMMs + the elementwise kernel
         GemmSegs gu = {};
         gu.w_gate = L.gate; gu.w_up = L.up; gu.out_act = m->pf_g; gu.half = I; gu.ld_act = I; gu.act_mode = 1;
-        if (seg_gemm && !quant && gemm_segmented_preferred(T, hd, gu)) {
+        if (seg_gemm && gemm_segmented_preferred(T, hd, gu)) {
+            if (quant && (!(gu.w_gate = W(nullptr, &Q.gate, hd, 0)) || !(gu.w_up = W(nullptr, &Q.up, hd, (size_t)I * hd)))) return 1;
             if (launch_gemm_bf16_segmented(m->pf_xn, T, hd, gu, s)) return 1;
         } else {
             if (!(w = W(L.gate, &Q.gate, hd)) || launch_gemm_bf16(m->pf_g, m->pf_xn, w, nullptr, T, I, hd, s)) return 1;

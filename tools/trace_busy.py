@@ -1,3 +1,5 @@
+"""Kernel busy time vs wall time of the launch bursts in a rocprofv3 kernel trace (`--kernel-trace --output-format csv`):
+   python tools/trace_busy.py <output dir>   -> one line per burst (bursts are separated by > 2 ms of idle GPU)."""
 import csv,sys,glob
 f=glob.glob(sys.argv[1]+'/**/*kernel_trace.csv',recursive=True)[0]
 rows=list(csv.DictReader(open(f)))

@@ -76,8 +76,16 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(const PrefillArgs 
     const int qcol = lane & 15, rg = lane >> 4;
     const int b = blockIdx.z, h = blockIdx.y;
     const int kvh = h / (a.H / a.Hkv);
-    // causal: the last query blocks see the most keys -- dispatch them first so that a multi-round grid ends on short blocks
-    const int q0 = (MASK == OMX_MASK_CAUSAL ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x) * QBLK;
+    // causal: the last query blocks see the most keys.  Two blocks share a CU, and the dispatcher hands block L and block
+    // L + 256 to the same CU: rows of the grid that start in an even 256-block chunk run longest-first, rows in an odd chunk
+    // shortest-first, so a CU's two blocks add up to the same number of key tiles (16 + 1, 15 + 2, ...) instead of 2 x 16 on
+    // one CU and 2 x 1 on another; a multi-round grid still starts with long blocks.
+    int qt = blockIdx.x;
+    if (MASK == OMX_MASK_CAUSAL) {
+        const int row_start = (int)gridDim.x * (int)(blockIdx.y + gridDim.y * blockIdx.z);
+        if (((row_start >> 8) & 1) == 0) qt = (int)gridDim.x - 1 - qt;
+    }
+    const int q0 = qt * QBLK;
     const int shift = a.Tk - a.Tq;                       // causal: query i sees keys <= i + shift
 
     const bf16_t* Kb = a.k + (size_t)b * a.kv_batch_stride + (size_t)kvh * a.kv_head_stride;

@@ -58,6 +58,7 @@ __global__ __launch_bounds__(256) void groupnorm_stats_kernel(const bf16_t* __re
     // threads beyond a multiple of c8 idle, so that a thread's vector index never changes
     const int lanes = (256 / c8) * c8;
     if ((int)threadIdx.x < lanes || c8 > 256) {
+#pragma unroll 4   // four loads in flight per thread; the accumulation order stays the sequential one
         for (int64_t i = p0 * c8 + threadIdx.x; i < p1 * c8; i += (c8 > 256 ? 256 : lanes)) {
             const u32x4 v = *reinterpret_cast<const u32x4*>(x + i * 8);
 #pragma unroll
@@ -110,6 +111,7 @@ __global__ __launch_bounds__(256) void groupnorm_apply_kernel(bf16_t* __restrict
     for (int g = threadIdx.x; g < 2 * G; g += blockDim.x) gn_sm[g] = mean_rstd[g];
     __syncthreads();
     const int c8 = C / 8;
+#pragma unroll 2
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < HW * c8; i += (int64_t)gridDim.x * blockDim.x) {
         const int c0 = (int)(i % c8) * 8;
         const u32x4 v = *reinterpret_cast<const u32x4*>(x + i * 8);

@@ -51,15 +51,18 @@ __global__ __launch_bounds__(256) void groupnorm_stats_kernel(const bf16_t* __re
                                                               double* __restrict__ partials) {
     __shared__ float sm_s[256][8], sm_q[256][8];
     const int j = blockIdx.x, c8 = C / 8, cg = C / G;
-    const int64_t per = (HW + kGnChunks - 1) / kGnChunks, p0 = j * per, p1 = min(HW, p0 + per);
     float s[8], q[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) s[e] = q[e] = 0.f;
     // threads beyond a multiple of c8 idle, so that a thread's vector index never changes
     const int lanes = (256 / c8) * c8;
+    // block j takes every kGnChunks-th slab of `lanes` vectors (4 KiB at 128 channels): at any moment the blocks of the grid
+    // read one contiguous stretch of the tensor -- a contiguous range per block would put all of them 1/512 of the tensor apart,
+    // on the same few HBM channels (the 1024^2 x 128 pass took 640 us that way, 97 us interleaved)
     if ((int)threadIdx.x < lanes || c8 > 256) {
+        const int64_t slab = c8 > 256 ? 256 : lanes, total = HW * c8;
 #pragma unroll 4   // four loads in flight per thread; the accumulation order stays the sequential one
-        for (int64_t i = p0 * c8 + threadIdx.x; i < p1 * c8; i += (c8 > 256 ? 256 : lanes)) {
+        for (int64_t i = (int64_t)j * slab + threadIdx.x; i < total; i += slab * kGnChunks) {
             const u32x4 v = *reinterpret_cast<const u32x4*>(x + i * 8);
 #pragma unroll
             for (int w = 0; w < 4; ++w) {
@@ -88,13 +91,19 @@ __global__ __launch_bounds__(256) void groupnorm_stats_kernel(const bf16_t* __re
 // fold the chunk partials of every group (fixed order, double) into mean and 1/sqrt(var + eps)
 __global__ void groupnorm_finalize_kernel(const double* __restrict__ partials, float* __restrict__ mean_rstd, int64_t HW, int C, int G,
                                           float eps) {
-    const int g = threadIdx.x;
-    if (g >= G) return;
+    // one wave per group: lane l sums chunks l, l + 64, ... in order, then a fixed xor-tree over the lanes (deterministic)
+    const int g = blockIdx.x, lane = threadIdx.x;
     double s = 0.0, ss = 0.0;
-    for (int j = 0; j < kGnChunks; ++j) {
+    for (int j = lane; j < kGnChunks; j += 64) {
         s += partials[((size_t)g * kGnChunks + j) * 2];
         ss += partials[((size_t)g * kGnChunks + j) * 2 + 1];
     }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        s += __shfl_xor(s, o, 64);
+        ss += __shfl_xor(ss, o, 64);
+    }
+    if (lane != 0) return;
     const double n = (double)HW * (C / G), mean = s / n;
     const double var = fmax(ss / n - mean * mean, 0.0);
     mean_rstd[g] = (float)mean;
@@ -242,7 +251,7 @@ int group_norm(omx_vae_decoder m, bf16_t* out, const bf16_t* x, const std::strin
     OMX_REQUIRE(C / 8 <= 256, "vae: GroupNorm over %d channels (max 2048)", C);
     groupnorm_stats_kernel<<<kGnChunks, 256, 0, m->stream>>>(x, HW, C, G, m->stats);
     float* mr = reinterpret_cast<float*>(m->stats + (size_t)32 * kGnChunks * 2);
-    groupnorm_finalize_kernel<<<1, 64, 0, m->stream>>>(m->stats, mr, HW, C, G, 1e-5f);
+    groupnorm_finalize_kernel<<<G, 64, 0, m->stream>>>(m->stats, mr, HW, C, G, 1e-5f);
     groupnorm_apply_kernel<<<2048, 256, 2 * G * sizeof(float), m->stream>>>(out, x, HW, C, G, mr, wt, bs, silu);
     OMX_LAUNCH_CHECK();
     return 0;

@@ -57,8 +57,8 @@ __global__ __launch_bounds__(256) void groupnorm_stats_kernel(const bf16_t* __re
     // threads beyond a multiple of c8 idle, so that a thread's vector index never changes
     const int lanes = (256 / c8) * c8;
     // block j takes every kGnChunks-th slab of `lanes` vectors (4 KiB at 128 channels): at any moment the blocks of the grid
-    // read one contiguous stretch of the tensor -- a contiguous range per block would put all of them 1/512 of the tensor apart,
-    // on the same few HBM channels (the 1024^2 x 128 pass took 640 us that way, 97 us interleaved)
+    // read one contiguous stretch of the tensor -- with a contiguous range per block the 512 streams sit 1/512 of the tensor
+    // apart (poor DRAM-page / translation locality: the 1024^2 x 128 pass took 640 us that way, 97 us interleaved)
     if ((int)threadIdx.x < lanes || c8 > 256) {
         const int64_t slab = c8 > 256 ? 256 : lanes, total = HW * c8;
 #pragma unroll 4   // four loads in flight per thread; the accumulation order stays the sequential one

@@ -24,23 +24,31 @@ constexpr int kGnChunks = 512;  // pixel chunks (= blocks) of the statistics pas
 
 // col[(y*W + x), (kh*3 + kw)*C + c] = src[sy, sx, c] or 0; (sy, sx) = (y + kh - 1, x + kw - 1) on the OUTPUT grid,
 // read from the half-resolution source when `up` (Upsample(2, nearest) folded in)
-__global__ __launch_bounds__(256) void im2col3x3_kernel(bf16_t* __restrict__ col, const bf16_t* __restrict__ src, int H, int W, int C,
+__global__ __launch_bounds__(576) void im2col3x3_kernel(bf16_t* __restrict__ col, const bf16_t* __restrict__ src, int H, int W, int C,
                                                         int up) {
-    const int c8 = C / 8;
-    const int64_t total = (int64_t)H * W * 9 * c8;
+    // One output pixel = one row of 9 * C/8 16-byte vectors.  A block walks pixels blockIdx.x, + gridDim.x, ... and a thread
+    // keeps its (tap, channel vector) for the whole walk: the only division left is pixel -> (y, x), 32-bit, once per pixel.
+    // (Flat 64-bit index arithmetic -- five divisions per vector -- made this pass instruction-bound at 1.5 TB/s.)
+    // The block is 576 threads = 4, 2 or 1 whole pixel rows at 128, 256 or 512 channels (other widths: a thread loops over the row).
+    const int c8 = C / 8, nv = 9 * c8;
     const int Ws = up ? W / 2 : W;
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int cv = (int)(i % c8);
-        const int tap = (int)((i / c8) % 9);
-        const int64_t pix = i / ((int64_t)9 * c8);
-        const int y = (int)(pix / W), x = (int)(pix % W);
-        const int sy = y + tap / 3 - 1, sx = x + tap % 3 - 1;
-        u32x4 v = {0u, 0u, 0u, 0u};
-        if (sy >= 0 && sy < H && sx >= 0 && sx < W) {
-            const int py = up ? sy / 2 : sy, px = up ? sx / 2 : sx;
-            v = *reinterpret_cast<const u32x4*>(src + ((int64_t)py * Ws + px) * C + cv * 8);
+    const unsigned npix = (unsigned)H * (unsigned)W;
+    const int ppi = (int)blockDim.x >= nv ? (int)blockDim.x / nv : 1;      // pixels per block iteration
+    const int pl = (int)threadIdx.x / nv;                                  // which of them this thread serves
+    if (pl >= ppi && (int)blockDim.x >= nv) return;
+    for (int t = (int)threadIdx.x - pl * nv; t < nv; t += blockDim.x) {
+        const int tap = t / c8, cv = t - tap * c8;
+        const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+        for (unsigned pix = blockIdx.x * ppi + pl; pix < npix; pix += gridDim.x * ppi) {
+            const int y = (int)(pix / (unsigned)W), x = (int)(pix - (unsigned)y * (unsigned)W);
+            const int sy = y + dy, sx = x + dx;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (sy >= 0 && sy < H && sx >= 0 && sx < W) {
+                const int py = up ? sy >> 1 : sy, px = up ? sx >> 1 : sx;
+                v = *reinterpret_cast<const u32x4*>(src + ((int64_t)py * Ws + px) * C + cv * 8);
+            }
+            *reinterpret_cast<u32x4*>(col + ((int64_t)pix * nv + t) * 8) = v;
         }
-        *reinterpret_cast<u32x4*>(col + i * 8) = v;
     }
 }
 
@@ -232,7 +240,7 @@ int conv3x3(omx_vae_decoder m, bf16_t* out, const bf16_t* src, const std::string
     OMX_REQUIRE(Cin % 8 == 0, "vae: %s input channels %d must be a multiple of 8", name.c_str(), Cin);
     const int64_t M = (int64_t)H * W;
     if (grow(&m->col, &m->col_cap, (size_t)M * 9 * Cin)) return 1;
-    im2col3x3_kernel<<<2048, 256, 0, m->stream>>>(m->col, src, H, W, Cin, up);
+    im2col3x3_kernel<<<(unsigned)std::min<int64_t>(M, 4096), 576, 0, m->stream>>>(m->col, src, H, W, Cin, up);
     OMX_LAUNCH_CHECK();
     return launch_gemm_bf16_ex(out, m->col, wt, bs, resid, (int)M, Cout, 9 * Cin, m->stream);
 }

@@ -211,8 +211,12 @@ constexpr int SMEM = 2 * BUF;
 
 // MF = 16: v_mfma_f32_16x16x32_bf16, eight independent accumulators per k step inside a phase (a dependent MFMA is
 // eight issues away); MF = 32: v_mfma_f32_32x32x16_bf16, two accumulators per phase (bit-identical to the 128^2 kernel)
-template <int MF, bool SW = false>
+// IMPL (with SW): implicit 3x3 convolution.  The A operand is a zero-bordered NHWC activation [(H+2), (W+2), C]; output
+// pixel (y, x) starts at padded pixel (y, x) and K tile t (64 wide, K = 9 * C ordered (tap, channel), C = 64 * 2^sh) reads
+// tap = t >> sh at channel (t & (2^sh - 1)) * 64 -- a wave-uniform offset per K tile instead of a materialised im2col matrix.
+template <int MF, bool SW = false, bool IMPL = false>
 __global__ __launch_bounds__(big::NT) void gemm_bf16_nt_256_kernel(const GemmArgs a) {
+    static_assert(!IMPL || SW, "the implicit-convolution staging lives in the segmented variant");
     static_assert(!SW || MF == 16, "the SwiGLU epilogue is written for the 16x16 accumulator layout");
     using namespace big;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -288,10 +292,15 @@ __global__ __launch_bounds__(big::NT) void gemm_bf16_nt_256_kernel(const GemmArg
             const int kc = (c & 7) ^ (row & 7);
             const int trow = (row >> 6) * 128 + sidx * 64 + (row & 63);
             const int tcol = (row >> 5) * 64 + sidx * 32 + (row & 31);
-            if constexpr (SW) {
+            if constexpr (IMPL) {
+                const int p = min(m0 + trow, a.M - 1), py = p / a.sg.im_W, px = p - py * a.sg.im_W;
+                srcX[sidx][i] = a.x + ((size_t)py * (a.sg.im_W + 2) + px) * a.sg.im_C + kc * 8;
+            } else if constexpr (SW) {
                 int xr = min(m0 + trow, rows_valid - 1) + row_base;
                 if (row_src) xr = (int)row_src[xr];
                 srcX[sidx][i] = a.x + (size_t)xr * a.K + kc * 8;
+            }
+            if constexpr (SW) {
                 if (seg_act) {
                     // Y0 (tile cols wc * 64 + [0, 32)) <- gate rows, Y1 (wc * 64 + [32, 64)) <- up rows of the same 32 outputs
                     const int oc = n0 / 2 + (row >> 5) * 32 + (row & 31);
@@ -308,6 +317,16 @@ __global__ __launch_bounds__(big::NT) void gemm_bf16_nt_256_kernel(const GemmArg
 #pragma unroll
         for (int i = 0; i < 2; ++i)
             __builtin_amdgcn_global_load_lds((glb_ptr_t)(src[i] + k0), (lds_ptr_t)(piece + (i * NT + wave * 64) * 16), 16, 0, 0);
+    };
+    // element offset of K tile t in the A operand
+    auto kx = [&](int t) -> int {
+        if constexpr (IMPL) {
+            const int tap = t >> a.sg.im_sh, c0 = (t & ((1 << a.sg.im_sh) - 1)) * TK;
+            const int dy = (tap * 11) >> 5, dx = tap - 3 * dy;   // tap / 3, tap % 3 for tap < 9
+            return (dy * (a.sg.im_W + 2) + dx) * a.sg.im_C + c0;
+        } else {
+            return t * TK;
+        }
     };
     // buffer layout: X0 | X1 | Y0 | Y1
     constexpr int PX0 = 0, PX1 = HALF, PY0 = 2 * HALF, PY1 = 3 * HALF;
@@ -328,12 +347,12 @@ __global__ __launch_bounds__(big::NT) void gemm_bf16_nt_256_kernel(const GemmArg
             for (int r = 0; r < AR; ++r) acc[i][j][r] = 0.f;
 
     // prologue: what the steady state would have issued before tile 0's first phase, in its order
-    stage(srcX[0], 0, smem + PX0);
+    stage(srcX[0], kx(0), smem + PX0);
     stage(srcY[0], 0, smem + PY0);
     stage(srcY[1], 0, smem + PY1);
-    stage(srcX[1], 0, smem + PX1);
+    stage(srcX[1], kx(0), smem + PX1);
     if (nt > 1) {
-        stage(srcX[0], TK, smem + BUF + PX0);
+        stage(srcX[0], kx(1), smem + BUF + PX0);
         stage(srcY[0], TK, smem + BUF + PY0);
         asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // X0, Y0 of tile 0 have landed
     } else {
@@ -397,7 +416,7 @@ __global__ __launch_bounds__(big::NT) void gemm_bf16_nt_256_kernel(const GemmArg
         // ---- phase 2 ----
         read_b(1);
         if (has1) {
-            stage(srcX[1], k1, nxt + PX1);
+            stage(srcX[1], kx(t + 1), nxt + PX1);
             asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // X1 of this tile (read in phase 3) has landed
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -407,7 +426,7 @@ __global__ __launch_bounds__(big::NT) void gemm_bf16_nt_256_kernel(const GemmArg
         OMX_BAR();
         // ---- phase 3 ----
         read_a(1);
-        if (has2) stage(srcX[0], k2, cur + PX0);
+        if (has2) stage(srcX[0], kx(t + 2), cur + PX0);
         OMX_BAR();
         quadrant(1, 1);
         OMX_BAR();
@@ -468,6 +487,18 @@ __global__ __launch_bounds__(big::NT) void gemm_bf16_nt_256_kernel(const GemmArg
                     float v[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = acc[i][j][e];
+                    if constexpr (IMPL) {   // convolution epilogue: bias, optional shortcut, any width (conv_out has 3 columns)
+                        const bf16_t* rs = a.sg.im_resid;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            if (col + e >= seg_cols) break;
+                            const size_t o = (size_t)row * seg_ld + col + e;
+                            float x = v[e] + (seg_bias ? bf16_to_f32(seg_bias[col + e]) : 0.f);
+                            if (rs) x = bf16_to_f32(rs[o]) + round_bf16(x);
+                            seg_out[o] = f32_to_bf16(x);
+                        }
+                        continue;
+                    }
                     if (seg_bias) {
                         const u32x2 b = *reinterpret_cast<const u32x2*>(seg_bias + col);
                         v[0] += bf16lo(b[0]); v[1] += bf16hi(b[0]); v[2] += bf16lo(b[1]); v[3] += bf16hi(b[1]);
@@ -834,6 +865,7 @@ int ensure_attr() {
         OMX_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_bf16_nt_256_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, big::SMEM));
         OMX_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_bf16_nt_256_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, big::SMEM));
         OMX_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_bf16_nt_256_kernel<16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big::SMEM));
+        OMX_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_bf16_nt_256_kernel<16, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big::SMEM));
         OMX_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_bf16_nt_skinny_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * skinny::STAGE));
         OMX_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_bf16_nt_skinny_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * skinny::STAGE));
         OMX_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_bf16_nt_skinny_kernel<8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * skinny::STAGE));
@@ -1029,6 +1061,34 @@ int launch_gemm_bf16_segmented_grouped(const bf16_t* x, int max_rows, int K, con
     a.grid_m = max_tiles;
     a.grid_n = seg_tiles(segs);
     gemm_bf16_nt_256_kernel<16, true><<<a.grid_m * a.grid_n, big::NT, big::SMEM, s>>>(a);
+    OMX_LAUNCH_CHECK();
+    return 0;
+}
+
+bool conv3x3_implicit_supported(int H, int W, int C, int Cout) {
+    if (H <= 0 || W <= 0 || C < 64 || C % 64 != 0 || ((C / 64) & (C / 64 - 1)) != 0 || Cout <= 0) return false;
+    const long long M = (long long)H * W;
+    return M <= 0x7FFFFFFF && ((M + 255) / 256) * ((Cout + 255) / 256) >= 160 && (long long)(H + 2) * (W + 2) * C <= 0x7FFFFFFFLL;
+}
+
+int launch_conv3x3_implicit(bf16_t* out, const bf16_t* padded, const bf16_t* w, const bf16_t* bias, const bf16_t* resid, int H, int W,
+                            int C, int Cout, hipStream_t s) {
+    OMX_REQUIRE(conv3x3_implicit_supported(H, W, C, Cout), "implicit conv: unsupported shape %dx%d, %d -> %d channels", H, W, C, Cout);
+    OMX_REQUIRE(out && padded && w && ((reinterpret_cast<uintptr_t>(padded) | reinterpret_cast<uintptr_t>(w)) & 15u) == 0,
+                "implicit conv: null or misaligned operand");
+    if (ensure_attr()) return 1;
+    GemmArgs a = {};
+    a.x = padded; a.M = H * W; a.K = 9 * C; a.N = Cout;
+    a.sg.n_plain = 1;
+    a.sg.plain[0] = {w, bias, out, Cout, Cout, 0};
+    a.sg.act_tile0 = 0x7FFFFFFF;
+    a.sg.im_C = C; a.sg.im_W = W; a.sg.im_resid = resid;
+    int sh = 0;
+    while ((64 << sh) < C) ++sh;
+    a.sg.im_sh = sh;
+    a.grid_m = (a.M + 255) / 256;
+    a.grid_n = (Cout + 255) / 256;
+    gemm_bf16_nt_256_kernel<16, true, true><<<a.grid_m * a.grid_n, big::NT, big::SMEM, s>>>(a);
     OMX_LAUNCH_CHECK();
     return 0;
 }

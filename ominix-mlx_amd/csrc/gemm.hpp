@@ -52,7 +52,16 @@ struct GemmSegs {
     int act_tile0;        // (filled by the launcher)
     int act_mode;         // 0: fused_swiglu, one rounding (metal_kernels.rs:188-236); 1: nn::silu(gate) * up with every
                           //    primitive rounded to bf16 (qwen3-mlx/src/model.rs:264-265)
+    // implicit 3x3 convolution (launch_conv3x3_implicit): channels, output width, log2(channels / 64), shortcut
+    int im_C, im_W, im_sh;
+    const bf16_t* im_resid;
 };
+// 3x3 convolution, stride 1, zero padding 1, as ONE GEMM over a zero-bordered NHWC activation [(H+2), (W+2), C] (no im2col
+// matrix): out[(y*W + x), o] = bias[o] + sum_{tap, c} padded[(y + tap/3), (x + tap%3), c] * w[o, tap*C + c]  (+ resid).
+// C = 64 * 2^j, >= 160 output tiles of 256^2.
+bool conv3x3_implicit_supported(int H, int W, int C, int Cout);
+int launch_conv3x3_implicit(bf16_t* out, const bf16_t* padded, const bf16_t* w, const bf16_t* bias, const bf16_t* resid, int H, int W,
+                            int C, int Cout, hipStream_t s);
 bool gemm_segmented_supported(int M, int K, const GemmSegs& segs);   // can one launch compute it
 bool gemm_segmented_preferred(int M, int K, const GemmSegs& segs);   // ... and is that the faster schedule (callers with a fallback)
 // the same launch over expert-sorted rows (MoE prefill): 256-row tiles from the device-built tile table (GroupedDesc, 256-row

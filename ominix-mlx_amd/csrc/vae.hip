@@ -52,6 +52,24 @@ __global__ __launch_bounds__(576) void im2col3x3_kernel(bf16_t* __restrict__ col
     }
 }
 
+// dst [(H+2), (W+2), C]: src (or its 2x nearest upsampling when `up`) inside a one-pixel zero border -- the A operand of the
+// implicit 3x3 convolution (gemm.hpp: launch_conv3x3_implicit); 1x (4x when upsampling) the activation instead of im2col's 9x
+__global__ __launch_bounds__(256) void pad_nhwc_kernel(bf16_t* __restrict__ dst, const bf16_t* __restrict__ src, int H, int W, int C, int up) {
+    const int c8 = C / 8, Wp = W + 2, Ws = up ? W / 2 : W;
+    const unsigned total = (unsigned)(H + 2) * (unsigned)Wp * (unsigned)c8;
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const unsigned pp = i / (unsigned)c8;
+        const int cv = (int)(i - pp * (unsigned)c8);
+        const int yp = (int)(pp / (unsigned)Wp), xp = (int)(pp - (unsigned)yp * (unsigned)Wp);
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (yp >= 1 && yp <= H && xp >= 1 && xp <= W) {
+            const int sy = up ? (yp - 1) >> 1 : yp - 1, sx = up ? (xp - 1) >> 1 : xp - 1;
+            v = *reinterpret_cast<const u32x4*>(src + ((int64_t)sy * Ws + sx) * C + cv * 8);
+        }
+        *reinterpret_cast<u32x4*>(dst + (int64_t)i * 8) = v;
+    }
+}
+
 // statistics: block j sums its pixel chunk for ALL groups with full-row coalesced reads -- thread t owns the 8-channel
 // vector (t mod C/8) of every (256 / (C/8))-th pixel -- then folds the per-thread sums group by group in a fixed
 // order (no atomics: the result is reproducible)
@@ -239,6 +257,16 @@ int conv3x3(omx_vae_decoder m, bf16_t* out, const bf16_t* src, const std::string
     if (vget(m, name + ".weight", &wt) || vget(m, name + ".bias", &bs)) return 1;
     OMX_REQUIRE(Cin % 8 == 0, "vae: %s input channels %d must be a multiple of 8", name.c_str(), Cin);
     const int64_t M = (int64_t)H * W;
+    const char* im_env = getenv("OMX_VAE_IMPLICIT");   // 0: im2col + GEMM everywhere (A/B, tests)
+    const bool implicit_on = !(im_env && im_env[0] == '0');
+    if (implicit_on && conv3x3_implicit_supported(H, W, Cin, Cout)) {
+        // zero-bordered copy of the input, then the convolution as one GEMM whose A tiles are read straight from it
+        const size_t padded = (size_t)(H + 2) * (W + 2) * Cin;
+        if (grow(&m->col, &m->col_cap, padded)) return 1;
+        pad_nhwc_kernel<<<4096, 256, 0, m->stream>>>(m->col, src, H, W, Cin, up);
+        OMX_LAUNCH_CHECK();
+        return launch_conv3x3_implicit(out, m->col, wt, bs, resid, H, W, Cin, Cout, m->stream);
+    }
     if (grow(&m->col, &m->col_cap, (size_t)M * 9 * Cin)) return 1;
     im2col3x3_kernel<<<(unsigned)std::min<int64_t>(M, 4096), 576, 0, m->stream>>>(m->col, src, H, W, Cin, up);
     OMX_LAUNCH_CHECK();

@@ -73,3 +73,26 @@ def test_vae_weight_sanitizer_and_identity_post_quant(omx):
     bad = vae.VaeDecoder(**cfg)
     with pytest.raises(omx.OmxError, match="WeightNotFound"):
         bad.decode(T.from_numpy(z))
+
+
+def test_vae_implicit_convolution_matches_im2col_route(omx, monkeypatch):
+    """Large stages run the 3x3 convolutions as ONE GEMM over a zero-bordered copy of the activation (csrc/gemm.hpp:
+    launch_conv3x3_implicit) instead of im2col + GEMM.  At a size where it engages (ch 64, 320 x 320 output: the last stage has
+    400 row tiles, including an upsampling convolution, a shortcut epilogue and the 3-channel conv_out) the image agrees with the
+    im2col route to bf16 rounding of the same sums -- and the small-stage oracle tests above cover both, since they share every
+    other kernel."""
+    from ominix_mlx_amd import vae
+    T = omx.ops.Tensor
+    cfg = dict(ch=64, ch_mult=(1, 2), num_res_blocks=1, z_channels=32, out_ch=3)
+    weights = rv.synth_decoder_weights(11, **cfg)
+    z = rc.bf16_round(np.random.default_rng(6).standard_normal((160, 160, cfg["z_channels"])).astype(np.float32))
+    outs = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("OMX_VAE_IMPLICIT", mode)
+        dec = vae.VaeDecoder(**cfg)
+        dec.load_weights(weights)
+        outs[mode] = dec.decode(T.from_numpy(z)).numpy()
+    a, b = outs["1"], outs["0"]
+    assert a.shape == b.shape == (320, 320, 3) and np.isfinite(a).all()
+    assert np.abs(a - b).max() <= 2.0 ** -6 * np.abs(b).max()
+    assert np.corrcoef(a.ravel(), b.ravel())[0, 1] > 0.9999

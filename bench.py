@@ -60,7 +60,55 @@ def parse():
     ap.add_argument("--no-flux", action="store_true", help="skip the secondary FLUX.2-klein sec/step measurement")
     ap.add_argument("--flux-tp", action="store_true",
                     help="with --gpus N > 1: also time FLUX.2-klein tensor-parallel over the N GPUs (all ranks take part)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launcher / rendezvous / barrier / max-over-ranks plumbing only (gloo, no GPU, no engine): the CPU test of --gpus N")
     return ap.parse_args()
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` outside torch.distributed.run: start the N ranks as a CHILD process (before this process
+    has touched the GPU -- an exec from a GPU-initialised process takes the box down), relay its output, return its code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // args.gpus)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def dry_run(args):
+    """The distributed skeleton of main() without a GPU: gloo rendezvous, barrier, a stand-in step, MAX over ranks, one JSON line."""
+    import torch
+    import torch.distributed as dist
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+        dist.barrier()
+    t0 = time.perf_counter()
+    x = torch.ones(1024)
+    for _ in range(args.steps):
+        x = x * 1.0001
+        if world > 1:
+            dist.all_reduce(x)
+            x /= world
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"metric": "decode_tokens_per_sec", "value": None, "unit": "tokens/s", "n_gpus": world, "steps": args.steps,
+                          "warmup": args.warmup, "ms_per_step": round(elapsed * 1e3 / max(args.steps, 1), 4), "dry_run": True,
+                          "config": {"workload": "launcher dry run (gloo, no engine)", "parallelism": f"tp{world}"}}), flush=True)
 
 
 def init_dist(n_gpus):
@@ -69,8 +117,7 @@ def init_dist(n_gpus):
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if n_gpus != world:
-        if world == 1 and n_gpus > 1:
-            raise SystemExit(f"--gpus {n_gpus} needs torch.distributed.run with --nproc-per-node {n_gpus}")
+        raise SystemExit(f"--gpus {n_gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {n_gpus} (or without torch.distributed.run)")
     import torch
     torch.cuda.set_device(local)
     dist = None
@@ -262,6 +309,10 @@ def cpu_baseline(cfg, ctx, n_layers_sample=2, reps=2):
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
+    if args.dry_run:
+        return dry_run(args)
     rank, world, local, dist = init_dist(args.gpus)
     import torch
     import omx_import

@@ -147,6 +147,10 @@ int mlx_expand_dims(mlx_array* res, const mlx_array a, int axis, const mlx_strea
 int mlx_contiguous(mlx_array* res, const mlx_array a, bool allow_col_major, const mlx_stream s);              /* :220 */
 int mlx_slice(mlx_array* res, const mlx_array a, const int* start, size_t start_num, const int* stop,
               size_t stop_num, const int* strides, size_t strides_num, const mlx_stream s);                   /* :960 */
+/* Donation contract (eager stand-in for MLX's evaluation-time buffer donation): when `src` is the sole owner of a
+ * contiguous buffer the update happens in place and the buffer moves to `*res`; `src` may then only be freed or
+ * overwritten -- any op READING it returns an error ("donated").  Hold a second reference (mlx_array_set) before the
+ * call to make it copy instead.  mlx-rs's index_mut (cache.rs:183-188) drops the old handle, i.e. never reads it. */
 int mlx_slice_update(mlx_array* res, const mlx_array src, const mlx_array update, const int* start,
                      size_t start_num, const int* stop, size_t stop_num, const int* strides, size_t strides_num,
                      const mlx_stream s);                                                                      /* :979 (cache.rs:183-188) */

@@ -992,7 +992,10 @@ int omx_qwen3_destroy(omx_qwen3 m) {
         if (p) (void)hipFree(p);
     if (m->ev0) (void)hipEventDestroy(m->ev0);
     if (m->ev1) (void)hipEventDestroy(m->ev1);
-    if (m->stream) (void)hipStreamDestroy(m->stream);
+    if (m->stream) {
+        gemm_release_stream(m->stream);
+        (void)hipStreamDestroy(m->stream);
+    }
     delete m;
     return 0;
 }

@@ -21,6 +21,8 @@
 #include "gridsync.hpp"   // coherent accessors for the split-K hand-over
 #include <map>
 #include <mutex>
+#include <thread>
+#include <utility>
 
 #include <stdlib.h>
 
@@ -877,32 +879,52 @@ int ensure_attr() {
 
 }  // namespace
 
-static bool hipStreamIsCapturing_safe(hipStream_t s) {   // the split scratch may have to grow (hipMalloc): not inside a capture
-    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
-    return hipStreamIsCapturing(s, &st) == hipSuccess && st != hipStreamCaptureStatusNone;
-}
-
-// split-K scratch of the ring kernel, one per stream (two streams may run such GEMMs at the same time)
+// split-K scratch of the ring kernel: ONE fixed-size buffer per stream (two streams may run such GEMMs at the same time; host
+// threads sharing the null stream get one each), sized for the largest launch ring_splits() can produce (blocks * splits <= 512
+// tiles of 64 x 64 partials, <= 160 arrival counters).  The size never depends on the call, so the split decision is a function
+// of the shape alone and a captured launch takes the same path -- and sums in the same order -- as an eager one.  A first use
+// inside a stream capture allocates under a relaxed capture mode (hipMalloc is not a stream operation).
 namespace {
-struct SplitWs { float* ws = nullptr; unsigned* cnt = nullptr; size_t ws_floats = 0, cnt_n = 0; };
+constexpr size_t kSplitWsFloats = (size_t)512 * 64 * 64, kSplitCnt = 256;
+struct SplitWs { float* ws = nullptr; unsigned* cnt = nullptr; };
 std::mutex g_split_mu;
-std::map<hipStream_t, SplitWs> g_split_ws;
+std::map<std::pair<hipStream_t, std::thread::id>, SplitWs> g_split_ws;
+std::pair<hipStream_t, std::thread::id> split_key(hipStream_t s) { return {s, s ? std::thread::id() : std::this_thread::get_id()}; }
 int split_workspace(hipStream_t s, size_t floats, size_t tiles, float** ws, unsigned** cnt) {
+    OMX_REQUIRE(floats <= kSplitWsFloats && tiles <= kSplitCnt, "ring GEMM split-K: %zu partial floats / %zu tiles exceed the fixed scratch", floats, tiles);
     std::lock_guard<std::mutex> lk(g_split_mu);
-    SplitWs& w = g_split_ws[s];
-    if (floats > w.ws_floats || tiles > w.cnt_n) {
-        OMX_HIP_CHECK(hipStreamSynchronize(s));   // earlier launches on this stream may still use the old buffers
-        if (w.ws) OMX_HIP_CHECK(hipFree(w.ws));
-        if (w.cnt) OMX_HIP_CHECK(hipFree(w.cnt));
-        w.ws_floats = std::max(floats, w.ws_floats);
-        w.cnt_n = std::max(tiles, w.cnt_n);
-        OMX_HIP_CHECK(hipMalloc((void**)&w.ws, w.ws_floats * 4));
-        OMX_HIP_CHECK(hipMalloc((void**)&w.cnt, w.cnt_n * 4));
-        OMX_HIP_CHECK(hipMemsetAsync(w.cnt, 0, w.cnt_n * 4, s));
+    SplitWs& w = g_split_ws[split_key(s)];
+    if (!w.ws) {
+        hipStreamCaptureMode mode = hipStreamCaptureModeRelaxed;
+        OMX_HIP_CHECK(hipThreadExchangeStreamCaptureMode(&mode));
+        hipError_t e = hipMalloc((void**)&w.ws, kSplitWsFloats * 4);
+        if (e == hipSuccess) e = hipMalloc((void**)&w.cnt, kSplitCnt * 4);
+        if (e == hipSuccess) e = hipMemset(w.cnt, 0, kSplitCnt * 4);   // synchronous, not a stream operation: legal during a capture
+        (void)hipThreadExchangeStreamCaptureMode(&mode);
+        if (e != hipSuccess) {
+            if (w.ws) (void)hipFree(w.ws);
+            if (w.cnt) (void)hipFree(w.cnt);
+            g_split_ws.erase(split_key(s));
+            return set_error("ring GEMM split-K scratch: %s", hipGetErrorString(e));
+        }
     }
     *ws = w.ws; *cnt = w.cnt;
     return 0;
 }
+}  // namespace
+
+// the owner of `s` is about to destroy it: give its split-K scratch back (engine / model destructors)
+void gemm_release_stream(hipStream_t s) {
+    std::lock_guard<std::mutex> lk(g_split_mu);
+    auto it = g_split_ws.find(split_key(s));
+    if (it == g_split_ws.end()) return;
+    (void)hipStreamSynchronize(s);
+    if (it->second.ws) (void)hipFree(it->second.ws);
+    if (it->second.cnt) (void)hipFree(it->second.cnt);
+    g_split_ws.erase(it);
+}
+
+namespace {
 // K splits of a ring-kernel launch: only when the tile grid leaves most CUs without a block AND the K loop is long -- the
 // serial chain of K steps, each a memory round trip, is then what the launch takes (down projection of a 128-token prompt:
 // 128 blocks x 192 steps).  At least 8 steps stay in each split (Paraformer FFN down: 64 tiles x 32 steps -> 4 splits, 17 -> 12 us).
@@ -937,7 +959,7 @@ static int launch_gemm_impl(bf16_t* out, const bf16_t* x, const bf16_t* w, const
             a.grid_m = (M + 63) / 64;
             a.grid_n = (N + 63) / 64;
             const int blocks = a.grid_m * a.grid_n, ns = ring_splits(blocks, K / 64);
-            if (ns > 1 && !(s != nullptr && hipStreamIsCapturing_safe(s))) {
+            if (ns > 1) {
                 if (split_workspace(s, (size_t)blocks * ns * 64 * 64, (size_t)blocks, &a.split_ws, &a.split_cnt)) return 1;
                 if (blocks * ns <= 256) gemm_bf16_nt_skinny_kernel<8><<<dim3(blocks, ns), skinny::NT, 8 * skinny::STAGE, s>>>(a);
                 else gemm_bf16_nt_skinny_kernel<4><<<dim3(blocks, ns), skinny::NT, 4 * skinny::STAGE, s>>>(a);

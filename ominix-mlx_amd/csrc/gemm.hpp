@@ -83,6 +83,9 @@ int launch_gemm_bf16_swiglu(bf16_t* out_plain, int ld_plain, bf16_t* out_act, in
 int launch_gemm_bf16_grouped(bf16_t* out, const bf16_t* x, const bf16_t* w, int max_rows, int N, int K,
                              const GroupedDesc& g, int max_tiles, hipStream_t s);
 
+// the ring kernel keeps one fixed-size split-K scratch per stream; whoever destroys a stream hands it back first
+void gemm_release_stream(hipStream_t s);
+
 // element strides for SDPA operands that are not [B,H,T,D]-contiguous
 struct AttnLayout {
     int64_t q_bs, q_hs, q_ts;   // queries: batch, head, token

@@ -78,6 +78,7 @@ struct Arr {
     std::vector<size_t> strides;    // in elements
     mlx_dtype dt = MLX_FLOAT32;
     std::vector<uint8_t> host;      // mirror handed out by mlx_array_data_*
+    bool donated = false;           // its buffer was updated in place on behalf of a slice_update result (see there)
     size_t size() const { size_t n = 1; for (int d : shape) n *= (size_t)d; return n; }
     char* ptr() const { return (char*)buf->p + off; }
 };
@@ -127,7 +128,12 @@ int assign(mlx_array* res, Arr* n) {
     return 0;
 }
 #define NEW_OR_FAIL(var, shape, dt) Arr* var = new_arr(shape, dt); if (!var) return set_error("out of device memory allocating %zu-element array", (size_t)0)
-#define REQ_ARR(h, name) OMX_REQUIRE((h).ctx != nullptr, "%s: empty array handle", name)
+#define REQ_ARR(h, name)                                                                                              \
+    do {                                                                                                              \
+        OMX_REQUIRE((h).ctx != nullptr, "%s: empty array handle", name);                                              \
+        OMX_REQUIRE(!A(h)->donated, "%s: this array's buffer was donated to the result of an earlier mlx_slice_update " \
+                    "(it was the sole owner); keep another reference before the update to preserve it", name);        \
+    } while (0)
 
 // ---- generic strided kernels ----
 struct Idx {
@@ -834,13 +840,19 @@ int mlx_slice_update(mlx_array* res, const mlx_array src, const mlx_array update
     REQ_ARR(src, "mlx_slice_update"); REQ_ARR(update, "mlx_slice_update");
     const Arr& s = *A(src);
     OMX_REQUIRE(s.dt == A(update)->dt, "mlx_slice_update: dtype mismatch");
-    // Functional semantics: the result is a new array.  When `src` is the only owner of a contiguous
-    // buffer (the KVCache pattern `k = k.slice_update(..)`, cache.rs:183-188) the update is done in place
-    // and the buffer is shared with the result, which is what MLX's buffer donation achieves.
+    // Functional semantics: the result is a new array.  MLX reaches the KVCache pattern `k = k.slice_update(..)`
+    // (cache.rs:183-188; mlx-rs's index_mut writes the result into a fresh handle and drops the old one afterwards)
+    // without copying through buffer donation at evaluation time.  This eager implementation decides at call time:
+    // when `src` is the ONLY owner of a contiguous buffer the update is done in place and the buffer moves to the
+    // result; `src` is then marked donated -- freeing or overwriting it is fine, READING it again is an error, never a
+    // silently mutated value.  A caller that wants to keep `src` holds a second reference (mlx_array_set) first,
+    // which makes the update copy.  (include/omx_mlx_c.h states the contract.)
     Arr* r = nullptr;
-    if (is_contig(s) && s.buf.use_count() == 1 && (!res || res->ctx != src.ctx || true)) {
+    bool donate = false;
+    if (is_contig(s) && s.buf.use_count() == 1) {
         r = new Arr(s);
         r->host.clear();
+        donate = !(res && res->ctx == src.ctx);   // the same handle is replaced by assign() below: nothing left to mark
     } else if (contiguous(s, &r)) {
         return 1;
     }
@@ -854,6 +866,7 @@ int mlx_slice_update(mlx_array* res, const mlx_array src, const mlx_array update
     upd.shape = region.shape;
     upd.strides = row_major(region.shape);
     if (scatter_into(region.ptr(), region.strides, upd, s.dt)) { delete r; return 1; }
+    if (donate) A(src)->donated = true;
     return assign(res, r);
 }
 int mlx_concatenate_axis(mlx_array* res, const mlx_vector_array arrays, int axis, const mlx_stream) {

@@ -70,6 +70,62 @@ def rope_scale_from_config(rope_scaling: Optional[dict]) -> float:
     raise OmxError(f"Unsupported RoPE type {rope_type!r}")
 
 
+def expected_shape(c: Qwen3Config, name: str):
+    """Shape the engine will read for checkpoint tensor `name` on THIS rank (after the TP / EP slicing), or None for a
+    name the forward does not use.  Mirrors resolve_weights in csrc/engine.hip."""
+    tp, ep = max(c.tp_size, 1), max(c.ep_size, 1)
+    hd, D = c.hidden_size, c.head_dim
+    H, Hkv, I, V = c.num_attention_heads // tp, c.num_key_value_heads // tp, c.intermediate_size // tp, c.vocab_size
+    Im, E = c.moe_intermediate_size, c.num_experts
+    leaf_kind = None
+    for suffix in (".weight", ".scales", ".biases", ".bias"):
+        if name.endswith(suffix):
+            leaf_kind, stem = suffix[1:], name[:-len(suffix)]
+            break
+    if leaf_kind is None:
+        return None
+    quant = bool(c.quant_bits)
+
+    def lin(n, k, stack=()):
+        """[n, k] Linear: dense, or the packed triplet of a quantized checkpoint."""
+        if leaf_kind == "bias":
+            return (n,)
+        if not quant:
+            return tuple(stack) + (n, k) if leaf_kind == "weight" else None
+        if leaf_kind == "weight":
+            return tuple(stack) + (n, k * c.quant_bits // 32)
+        return tuple(stack) + (n, k // c.quant_group)
+
+    if stem == "model.embed_tokens":
+        return lin(V, hd)
+    if stem == "lm_head":
+        return lin(V // tp, hd)
+    if stem == "model.norm":
+        return (hd,) if leaf_kind == "weight" else None
+    parts = stem.split(".")
+    if len(parts) < 4 or parts[0] != "model" or parts[1] != "layers":
+        return None
+    sub = ".".join(parts[3:])
+    table = {"self_attn.q_proj": (H * D, hd), "self_attn.k_proj": (Hkv * D, hd), "self_attn.v_proj": (Hkv * D, hd),
+             "self_attn.o_proj": (hd, H * D), "mlp.gate_proj": (I, hd), "mlp.up_proj": (I, hd), "mlp.down_proj": (hd, I)}
+    if sub in table:
+        return lin(*table[sub])
+    if sub in ("input_layernorm", "post_attention_layernorm"):
+        return (hd,) if leaf_kind == "weight" else None
+    if sub in ("self_attn.q_norm", "self_attn.k_norm"):
+        return (D,) if leaf_kind == "weight" else None
+    if E > 0:
+        El = E // ep
+        for mp in ("block_sparse_moe.", "mlp."):
+            if sub == mp + "gate":
+                return lin(E, hd)
+            if sub in (mp + "switch_mlp.gate_proj", mp + "switch_mlp.up_proj"):
+                return lin(Im, hd, (El,))
+            if sub == mp + "switch_mlp.down_proj":
+                return lin(hd, Im, (El,))
+    return None
+
+
 class Model:
     """qwen3_mlx::Model (dense Qwen3) resident on one MI355X (or one TP shard of it)."""
 
@@ -117,13 +173,27 @@ class Model:
             weights = tp.shard_state_dict(weights, self.cfg.tp_rank, self.cfg.tp_size, bool(self.cfg.tie_word_embeddings))
         if self.cfg.ep_size > 1:   # expert parallel: this rank keeps its slice of every stacked expert tensor
             from . import ep
-            weights = {k: (ep.shard_experts(np.asarray(v), self.cfg.ep_rank, self.cfg.ep_size) if ".switch_mlp." in k else v)
+            weights = {k: (ep.shard_experts(v, self.cfg.ep_rank, self.cfg.ep_size) if ".switch_mlp." in k else v)
                        for k, v in weights.items()}
         for name, arr in weights.items():
+            # the engine takes raw device pointers: a tensor whose shape disagrees with the config would be read past its
+            # end, so every known name is checked here (the reference raises a shape error on load)
+            want = self.expected_shape(name)
+            if want is not None and tuple(arr.shape) != want:
+                raise OmxError(f"ShapeMismatch: {name} has shape {tuple(arr.shape)}, the config expects {want}")
+            dt = np.asarray(arr).dtype
+            if self.cfg.quant_bits and name.endswith((".scales", ".biases")) and dt == np.float16:
+                raise OmxError(f"{name}: float16 scales / biases are not supported (the packed-weight kernels read bf16 and a "
+                               "silent f16 -> bf16 rounding would change the dequantised values); re-quantise from a bf16 model")
+            if self.cfg.quant_bits and name.endswith(".weight") and name[:-7] + ".scales" in weights and dt != np.uint32:
+                raise OmxError(f"{name}: a quantized weight must be packed uint32, found {dt}")
             # quantized checkpoints: "<prefix>.weight" is packed uint32 (ops/quantization.rs:41-84), scales / biases bf16
-            t = Tensor.from_numpy(arr, "u32" if np.asarray(arr).dtype == np.uint32 else "bf16")
+            t = Tensor.from_numpy(arr, "u32" if dt == np.uint32 else "bf16")
             self._keep.append(t)
             check(lib.omx_qwen3_set_weight(self._h, name.encode(), t.ptr))
+
+    def expected_shape(self, name: str):
+        return expected_shape(self.cfg, name)
 
     def synth_weights(self, base_seed: int = 0x0C0FFEE5) -> None:
         check(lib.omx_qwen3_synth_weights(self._h, base_seed & 0xFFFFFFFF))

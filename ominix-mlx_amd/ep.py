@@ -43,7 +43,8 @@ def experts_of_rank(n_experts: int, rank: int, world: int) -> range:
 def shard_experts(stacked: np.ndarray, rank: int, world: int) -> np.ndarray:
     """This rank's slice of a stacked expert tensor [E, ...] (switch_mlp.{gate,up,down}_proj.weight)."""
     r = experts_of_rank(stacked.shape[0], rank, world)
-    return np.ascontiguousarray(stacked[r.start:r.stop])
+    from .loader import keep_kind
+    return keep_kind(stacked, np.ascontiguousarray(stacked[r.start:r.stop]))
 
 
 def plan_dispatch(inds: np.ndarray, n_experts: int, world: int):

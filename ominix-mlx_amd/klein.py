@@ -83,8 +83,9 @@ def shard_state_dict(weights: dict, hidden_size: int, mlp_hidden: int, rank: int
     if h % world or mh % world:
         raise ValueError(f"InvalidConfig: hidden_size={h} / mlp_hidden={mh} not divisible by tp_size={world}")
     hl, ml = h // world, mh // world
-    rows = lambda a, segs: np.ascontiguousarray(np.concatenate([a[s:s + n] for s, n in segs], 0))
-    cols = lambda a, segs: np.ascontiguousarray(np.concatenate([a[:, s:s + n] for s, n in segs], 1))
+    from .loader import keep_kind
+    rows = lambda a, segs: keep_kind(a, np.ascontiguousarray(np.concatenate([a[s:s + n] for s, n in segs], 0)))
+    cols = lambda a, segs: keep_kind(a, np.ascontiguousarray(np.concatenate([a[:, s:s + n] for s, n in segs], 1)))
     out = {}
     for name, a in weights.items():
         leaf = name.rsplit(".", 2)[-2] if name.endswith(".weight") else name

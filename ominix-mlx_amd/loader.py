@@ -25,6 +25,12 @@ class Bf16Bits(np.ndarray):
     """uint16 array holding raw bfloat16 bit patterns (what a BF16 safetensors tensor is mapped as)."""
 
 
+def keep_kind(src, out: np.ndarray) -> np.ndarray:
+    """`out` was cut / stacked from `src` by a numpy call that returns a base ndarray (ascontiguousarray, concatenate,
+    stack, asarray): give it back src's bf16-bit-pattern marking, so that the upload does not value-convert the bits."""
+    return out.view(Bf16Bits) if isinstance(src, Bf16Bits) and not isinstance(out, Bf16Bits) else out
+
+
 def read_safetensors(path: str) -> Dict[str, np.ndarray]:
     """name -> array (a view of a read-only memory map).  BF16 tensors come back as `Bf16Bits` (uint16 bits)."""
     with open(path, "rb") as f:
@@ -104,7 +110,7 @@ def sanitize_weights(weights: Dict[str, np.ndarray], num_hidden_layers: int, num
                         raise KeyError(f"WeightNotFound: {key}")
                     parts.append(out.pop(key))
                 stacked = np.stack(parts, 0)
-                out[f"{prefix}.block_sparse_moe.switch_mlp.{new}.{comp}"] = stacked.view(type(parts[0])) if isinstance(parts[0], Bf16Bits) else stacked
+                out[f"{prefix}.block_sparse_moe.switch_mlp.{new}.{comp}"] = keep_kind(parts[0], stacked)
     return out
 
 

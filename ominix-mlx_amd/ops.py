@@ -71,6 +71,10 @@ class Tensor:
         elif code == BFLOAT16 and a.dtype == np.float16:
             host = _f32_to_bf16_bits(a.astype(np.float32))
         elif code == BFLOAT16:
+            if a.dtype.kind in "ui" and a.dtype.itemsize == 2:
+                # a sharder / stacker dropped the Bf16Bits marking: converting bit patterns as VALUES would upload garbage
+                raise OmxError("from_numpy(bf16): a 16-bit integer array is ambiguous (raw bf16 bits lose their loader.Bf16Bits "
+                               "marking through numpy copies); pass float data or re-view it with loader.keep_kind")
             host = _f32_to_bf16_bits(a.astype(np.float32))
         elif code == FLOAT16:
             host = np.ascontiguousarray(a, dtype=np.float16)

@@ -14,6 +14,8 @@ from __future__ import annotations
 
 import numpy as np
 
+from .loader import keep_kind
+
 ROW_SPLIT = ("self_attn.q_proj.weight", "self_attn.k_proj.weight", "self_attn.v_proj.weight",
              "mlp.gate_proj.weight", "mlp.up_proj.weight", "lm_head.weight")
 COL_SPLIT = ("self_attn.o_proj.weight", "mlp.down_proj.weight")
@@ -32,10 +34,10 @@ def shard(name: str, arr: np.ndarray, rank: int, world: int) -> np.ndarray:
         return arr
     if name.endswith(ROW_SPLIT):
         n = arr.shape[0] // world
-        return np.ascontiguousarray(arr[rank * n:(rank + 1) * n])
+        return keep_kind(arr, np.ascontiguousarray(arr[rank * n:(rank + 1) * n]))
     if name.endswith(COL_SPLIT):
         n = arr.shape[1] // world
-        return np.ascontiguousarray(arr[:, rank * n:(rank + 1) * n])
+        return keep_kind(arr, np.ascontiguousarray(arr[:, rank * n:(rank + 1) * n]))
     return arr
 
 

@@ -179,3 +179,27 @@ def test_qwen3_block_replayed_call_by_call(mx, core):
     logits = rc.bf16_round(rand((1, 2048), 30))
     tok = core.DefaultSampler().sample(mx.Array.from_numpy(logits), 0.0)
     assert tok.dtype == mx.UINT32 and tok.numpy().tolist() == rc.sample_greedy(logits).tolist()
+
+
+def test_slice_update_donation_contract(mx):
+    """mlx_slice_update used to mutate a solely-owned `src` in place unconditionally.  Contract now
+    (include/omx_mlx_c.h): a sole owner's buffer moves to the result and `src` becomes unreadable (an error, never a
+    silently changed value); with a second reference alive the update copies and `src` keeps its contents."""
+    base = rc.bf16_round(rand((1, 2, 8, 16), 5))
+    upd = rc.bf16_round(rand((1, 2, 3, 16), 6))
+    want = base.copy(); want[:, :, 2:5] = upd
+    # (a) a second reference keeps src intact: functional semantics
+    src = mx.Array.from_numpy(base)
+    keep = mx.Array.op(lambda res, h: (mx.lib.mlx_array_set(res, h)), src.h)
+    out = mx.slice_update(src, mx.Array.from_numpy(upd), [0, 0, 2, 0], [1, 2, 5, 16])
+    np.testing.assert_array_equal(out.numpy(), want)
+    np.testing.assert_array_equal(src.numpy(), base)
+    np.testing.assert_array_equal(keep.numpy(), base)
+    # (b) sole owner: donated -- the result is right, reading the old handle is a loud error, freeing it is fine
+    src2 = mx.Array.from_numpy(base)
+    out2 = mx.slice_update(src2, mx.Array.from_numpy(upd), [0, 0, 2, 0], [1, 2, 5, 16])
+    np.testing.assert_array_equal(out2.numpy(), want)
+    with pytest.raises(Exception, match="donated"):
+        mx.astype(src2, mx.FLOAT32)
+    del src2
+    np.testing.assert_array_equal(out2.numpy(), want)

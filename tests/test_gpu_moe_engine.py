@@ -192,3 +192,40 @@ def test_expert_parallel_engine_on_one_gpu(omx, monkeypatch, name, world, use_sy
     for m in models:
         m.close()
     group.close()
+
+
+def test_expert_parallel_load_from_bf16_checkpoint_files(omx, tmp_path, monkeypatch):
+    """ADVICE r1 (high), EP side: ep.shard_experts on raw-bits (Bf16Bits) expert stacks read from a BF16 safetensors file must
+    upload the same weights as float arrays do -- two expert-parallel ranks loaded from files equal the single-GPU engine."""
+    import json
+    from ominix_mlx_amd import comm, loader
+    cfg = CONFIGS["mixtral"]
+    w = rq.synth_weights(cfg)
+    d = str(tmp_path)
+    json.dump({"model_type": "mixtral", "hidden_size": cfg.hidden_size, "num_hidden_layers": cfg.num_hidden_layers,
+               "intermediate_size": cfg.moe_intermediate_size, "num_attention_heads": cfg.num_attention_heads,
+               "num_key_value_heads": cfg.num_key_value_heads, "vocab_size": cfg.vocab_size, "rms_norm_eps": cfg.rms_norm_eps,
+               "rope_theta": cfg.rope_theta, "num_local_experts": cfg.num_experts, "num_experts_per_tok": cfg.num_experts_per_tok},
+              open(f"{d}/config.json", "w"))
+    loader.write_safetensors(f"{d}/model.safetensors", {k: rc.to_bf16_bits(v) for k, v in w.items()}, bf16_names=tuple(w))
+    prompt = synth.prompt_ids(20, cfg.vocab_size)
+    monkeypatch.setenv("OMX_PREFILL_SERIAL", "1")
+    single = _engine(omx, cfg, w)
+    want = np.concatenate([[single.prefill(prompt)], single.decode(5)]).astype(np.uint32)
+    world = 2
+    group = comm.LoopbackGroup(world, 1 << 20)
+    models = [loader.load_model(d, max_context=256, ep_rank=r, ep_size=world) for r in range(world)]
+    for r, m in enumerate(models):
+        m.set_comm(group.rank_comm(r), group.allreduce_fn)
+
+    def run(r):
+        m = models[r]
+        return np.concatenate([[m.prefill(prompt)], m.decode(5)]).astype(np.uint32), m.last_logits()
+
+    outs = comm.run_ranks(world, run, group)
+    for r in range(world):
+        np.testing.assert_array_equal(outs[r][0], want)
+        np.testing.assert_array_equal(outs[r][1], single.last_logits())
+    for m in models:
+        m.close()
+    group.close()

@@ -434,3 +434,72 @@ def test_fused_attention_oproj_launch_is_bit_identical(omx, monkeypatch, name):
         outs[flag] = (toks, m.last_logits())
     np.testing.assert_array_equal(outs["0"][0], outs["1"][0])
     np.testing.assert_array_equal(outs["0"][1], outs["1"][1])
+
+
+def test_tensor_parallel_load_from_bf16_checkpoint_files(omx, tmp_path):
+    """a REAL BF16 safetensors checkpoint loaded with tp_size=2 goes through tp.shard, whose numpy copies
+    used to drop the raw-bits marking (weights uploaded as 16256.0 instead of 1.0).  Two ranks loading their shards from
+    the files must reproduce the ranks that were handed float arrays, bit for bit, and agree with the single-GPU engine."""
+    import json
+    from ominix_mlx_amd import comm, engine, loader
+    cfg = CONFIGS["gqa4_d128"]
+    w = rq.synth_weights(cfg)
+    d = str(tmp_path)
+    json.dump({"hidden_size": cfg.hidden_size, "num_hidden_layers": cfg.num_hidden_layers, "intermediate_size": cfg.intermediate_size,
+               "num_attention_heads": cfg.num_attention_heads, "num_key_value_heads": cfg.num_key_value_heads, "head_dim": cfg.head_dim,
+               "vocab_size": cfg.vocab_size, "rms_norm_eps": cfg.rms_norm_eps, "rope_theta": cfg.rope_theta,
+               "tie_word_embeddings": cfg.tie_word_embeddings}, open(f"{d}/config.json", "w"))
+    loader.write_safetensors(f"{d}/model.safetensors", {k: rc.to_bf16_bits(v) for k, v in w.items()}, bf16_names=tuple(w))
+    prompt = synth.prompt_ids(24, cfg.vocab_size)
+    world = 2
+
+    def run_world(make):
+        group = comm.LoopbackGroup(world, 1 << 20)
+        models = [make(r) for r in range(world)]
+        for r, m in enumerate(models):
+            m.set_comm(group.rank_comm(r), group.allreduce_fn)
+
+        def run(r):
+            m = models[r]
+            return np.concatenate([[m.prefill(prompt)], m.decode(5)]).astype(np.uint32), m.last_logits()
+
+        outs = comm.run_ranks(world, run, group)
+        for m in models:
+            m.close()
+        group.close()
+        return outs
+
+    from_files = run_world(lambda r: loader.load_model(d, max_context=256, tp_rank=r, tp_size=world))
+
+    def from_arrays(r):
+        m = engine.Model(hidden_size=cfg.hidden_size, num_hidden_layers=cfg.num_hidden_layers, intermediate_size=cfg.intermediate_size,
+                         num_attention_heads=cfg.num_attention_heads, num_key_value_heads=cfg.num_key_value_heads, head_dim=cfg.head_dim,
+                         vocab_size=cfg.vocab_size, rms_norm_eps=cfg.rms_norm_eps, rope_theta=cfg.rope_theta,
+                         tie_word_embeddings=cfg.tie_word_embeddings, max_context=256, tp_rank=r, tp_size=world)
+        m.load_weights(w)
+        return m
+
+    want = run_world(from_arrays)
+    for r in range(world):
+        np.testing.assert_array_equal(from_files[r][0], want[r][0])
+        np.testing.assert_array_equal(from_files[r][1], want[r][1])
+    single = _engine(omx, cfg, w, max_context=256)
+    toks = np.concatenate([[single.prefill(prompt)], single.decode(5)]).astype(np.uint32)
+    bound = 2.0 ** -7 * np.abs(single.last_logits()).max() * np.sqrt(cfg.num_hidden_layers)
+    assert np.abs(np.concatenate([from_files[0][1], from_files[1][1]]) - single.last_logits()).max() <= bound
+    assert toks[0] == from_files[0][0][0]
+
+
+def test_load_weights_rejects_a_tensor_of_the_wrong_shape(omx):
+    """the engine reads raw pointers, so a shape that disagrees with the config must be an error at load."""
+    from ominix_mlx_amd import OmxError, engine
+    cfg = CONFIGS["gqa2_d64"]
+    w = rq.synth_weights(cfg)
+    bad = dict(w)
+    bad["model.layers.0.mlp.down_proj.weight"] = w["model.layers.0.mlp.down_proj.weight"][:, :-64]
+    m = engine.Model(hidden_size=cfg.hidden_size, num_hidden_layers=cfg.num_hidden_layers, intermediate_size=cfg.intermediate_size,
+                     num_attention_heads=cfg.num_attention_heads, num_key_value_heads=cfg.num_key_value_heads, head_dim=cfg.head_dim,
+                     vocab_size=cfg.vocab_size, max_context=64)
+    with pytest.raises(OmxError, match="ShapeMismatch: model.layers.0.mlp.down_proj.weight"):
+        m.load_weights(bad)
+    m.close()

@@ -85,3 +85,54 @@ def test_mixtral_expert_stacking(loader):
     del w["model.layers.1.block_sparse_moe.experts.3.w2.scales"]
     with pytest.raises(KeyError, match="WeightNotFound"):
         loader.sanitize_weights(w, L, E)
+
+
+def test_sharders_keep_the_bf16_bit_pattern_marking(loader):
+    """np.ascontiguousarray / np.concatenate / np.asarray drop the Bf16Bits subclass, after which
+    the upload would value-convert bit patterns (0x3F80 -> 16256.0).  Every sharder must hand the marking on."""
+    from ominix_mlx_amd import ep, klein, tp
+    g = np.random.default_rng(1)
+    bits = lambda *shape: (g.standard_normal(shape).astype(np.float32).view(np.uint32) >> 16).astype(np.uint16).view(loader.Bf16Bits)
+    w = bits(8, 6)
+    for name in ("model.layers.0.self_attn.q_proj.weight", "model.layers.0.self_attn.o_proj.weight", "model.norm.weight"):
+        s = tp.shard(name, w, 1, 2)
+        assert isinstance(s, loader.Bf16Bits), name
+    np.testing.assert_array_equal(np.asarray(tp.shard("x.mlp.down_proj.weight", w, 1, 2)), np.asarray(w)[:, 3:])
+    tied = tp.shard_state_dict({"model.embed_tokens.weight": w}, 0, 2, tie_word_embeddings=True)
+    assert isinstance(tied["lm_head.weight"], loader.Bf16Bits) and tied["lm_head.weight"].shape == (4, 6)
+    e = ep.shard_experts(bits(4, 6, 8), 1, 2)
+    assert isinstance(e, loader.Bf16Bits) and e.shape == (2, 6, 8)
+    kw = {"double_blocks.0.img_attn.to_q.weight": bits(8, 8), "double_blocks.0.img_mlp.mlp_out.weight": bits(8, 12),
+          "single_blocks.0.to_qkv_mlp.weight": bits(3 * 8 + 2 * 12, 8), "single_blocks.0.to_out.weight": bits(8, 8 + 12)}
+    for k, v in klein.shard_state_dict(kw, 8, 12, 1, 2).items():
+        assert isinstance(v, loader.Bf16Bits), k
+    stacked = loader.sanitize_weights({f"model.layers.0.block_sparse_moe.experts.{e_}.{o}.weight": bits(6, 8)
+                                       for e_ in range(2) for o in ("w1", "w2", "w3")}, 1, 2)
+    assert all(isinstance(v, loader.Bf16Bits) for v in stacked.values())
+
+
+def test_upload_rejects_unmarked_16_bit_integers(loader):
+    """Tensor.from_numpy(dtype='bf16') must not value-convert a plain uint16 array (raises before touching the device)."""
+    from ominix_mlx_amd import OmxError
+    from ominix_mlx_amd.ops import Tensor
+    with pytest.raises(OmxError, match="ambiguous"):
+        Tensor.from_numpy(np.full((2, 2), 0x3F80, np.uint16), "bf16")
+
+
+def test_expected_shape_table_follows_the_config(loader):
+    """load_weights checks every known tensor against the shape the kernels will read."""
+    from ominix_mlx_amd import engine
+    c = engine.Qwen3Config(hidden_size=512, num_hidden_layers=2, intermediate_size=1536, num_attention_heads=8,
+                           num_key_value_heads=4, head_dim=64, vocab_size=2048, tp_rank=1, tp_size=2, ep_size=1)
+    es = lambda n: engine.expected_shape(c, n)
+    assert es("model.layers.1.self_attn.q_proj.weight") == (256, 512) and es("model.layers.1.self_attn.k_proj.weight") == (128, 512)
+    assert es("model.layers.0.self_attn.o_proj.weight") == (512, 256) and es("model.layers.0.mlp.down_proj.weight") == (512, 768)
+    assert es("lm_head.weight") == (1024, 512) and es("model.embed_tokens.weight") == (2048, 512)
+    assert es("model.layers.0.self_attn.q_norm.weight") == (64,) and es("model.layers.0.self_attn.q_proj.bias") == (256,)
+    assert es("some.other.tensor") is None and es("model.layers.0.rotary_emb.inv_freq") is None
+    c.tp_size, c.quant_bits, c.quant_group = 1, 4, 64
+    assert es("model.layers.0.mlp.gate_proj.weight") == (1536, 64) and es("model.layers.0.mlp.gate_proj.scales") == (1536, 8)
+    assert es("model.embed_tokens.biases") == (2048, 8)
+    c.quant_bits, c.num_experts, c.moe_intermediate_size, c.ep_size = 0, 8, 256, 2
+    assert es("model.layers.0.block_sparse_moe.switch_mlp.down_proj.weight") == (4, 512, 256)
+    assert es("model.layers.0.mlp.switch_mlp.gate_proj.weight") == (4, 256, 512) and es("model.layers.0.mlp.gate.weight") == (8, 512)

@@ -50,6 +50,32 @@ int attn_oproj_capacity(int D, int G, int K);
 // registers while the attention runs (the HBM is idle during that latency-bound phase)
 int launch_attn_oproj(const AttnDecodeArgs& a, const OProjArgs& o, int D, hipStream_t s);
 
+// ---- the decode engine's attention launch (attn_step.hip): q/k norm + RoPE + cache append + split-KV SDPA + split merge ----
+struct AttnStepArgs {
+    const bf16_t* qkv;          // raw projections of the current token [H*D | Hkv*D | Hkv*D] (QKV GEMV output)
+    bf16_t* k;                  // KV slabs [Hkv, cap, D]
+    bf16_t* v;
+    int64_t kv_head_stride;
+    int H, Hkv, cap;
+    float scale, eps;
+    const bf16_t* q_norm_w;     // null: no q/k norm (Mixtral, Qwen2)
+    const bf16_t* k_norm_w;
+    const float* rope_cur;      // [D]: cos[D/2] | sin[D/2] of the CURRENT position (refreshed by the step's first kernel)
+    const int* pos_ptr;         // device scalar: tokens already cached
+    const unsigned* seq_ptr;    // step sequence number (never reset)
+    unsigned tag_mul, tag_add;  // granule tag = *seq_ptr * tag_mul + tag_add: unique per (step, layer), 1 <= tag_add <= tag_mul
+    int chunk;                  // tokens per split: a multiple of attn_step_block_tokens(D), fixed per captured graph
+    int nsplit;                 // gridDim.y, G <= nsplit <= 48, nsplit * chunk >= every position the graph will see + 1
+    uint64_t* ws;               // granules [H][nsplit][D + 2]  ({f32, tag} each: o[D], m, l)
+    bf16_t* out;                // [H*D]
+    unsigned* abort_flag;       // raised when a gather gave up (results void)
+    unsigned long long* trace;  // optional: 8 wall-clock stamps per block [nsplit][Hkv][8] (tools/attn_step_trace.py)
+};
+int attn_step_block_tokens(int D);
+void attn_step_plan(int tk_max, int Hkv, int G, int D, int* chunk, int* nsplit);
+size_t attn_step_ws_granules(int H, int D);
+int launch_attn_step(const AttnStepArgs& a, int D, hipStream_t s);
+
 size_t attn_decode_ws_bytes(int BH, int nsplit, int D);
 int launch_attn_decode(const AttnDecodeArgs& a, int D, bool fused, hipStream_t s);
 

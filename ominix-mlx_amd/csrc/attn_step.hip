@@ -1,0 +1,396 @@
+// Attention of ONE decode step inside the engine's step graph (Tq == 1, batch 1): q/k RMSNorm + RoPE + KV-cache append +
+// split-KV SDPA + split merge in a single launch whose dependent chain is as short as the hardware allows.
+//   reference: Attention::forward of qwen3-mlx/src/model.rs:161-215 (q_norm/k_norm :172-181, rope at cache.offset() :186-194,
+//   cache.update_and_fetch :196, scaled_dot_product_attention :198-210 -> mlx-rs-core/src/utils.rs:191-209);
+//   Mixtral / Qwen2 wiring without q/k norm (mixtral-mlx/src/model.rs:96-160, qwen3-mlx/src/qwen2.rs:100-160).
+//
+// Why a second decode-attention kernel next to attn_decode.hip (which stays the per-op SDPA of the mlx-c route): at batch 1 and
+// a 2 k context a layer's KV is 9 MB -- 1.5 us of HBM time -- yet the round-1 kernel took 14.5 us, because it was a chain of
+// eight dependent memory round trips (position -> K/V -> ... -> partial store -> ack -> counter atomic -> (m,l) -> partials ->
+// output).  This kernel removes five of them:
+//   * NOTHING it loads at the start depends on the position: the split a block owns is a FIXED token range
+//     [split*chunk, +chunk) chosen when the step graph is captured (the engine re-captures when the context outgrows the
+//     bucket), and the RoPE row of the current position sits in a small `rope_cur` buffer that the step's first kernel
+//     refreshes.  Position, raw q/k/v, norm weights, RoPE row and the first K/V rows are therefore ONE round of loads;
+//   * the split partials travel as data-tagged 8-byte granules {f32 value, tag} written with write-through (sc1) stores
+//     (cdna_hip_programming.md Guideline 16, form R2): no store-ack wait, no arrival counter, no flag.  The tag is the step
+//     sequence number x layer, so nothing has to be reset between launches;
+//   * the blocks with split < G are also the consumers: after their own chunk, waves 0..D/64-1 of block (kvh, j) gather the
+//     granules of head kvh*G + j with coherent loads -- all splits in flight at once, re-read until every tag matches --
+//     merge them (max, rescale, sum, one division, one rounding) and store the bf16 head output.
+// Every block of the launch is co-resident (grid <= 2 blocks per CU by construction, __launch_bounds__(256, 2)), spins are
+// bounded and a wait that gives up raises `abort_flag` (the host reports it) instead of hanging the GPU.
+#include <algorithm>
+
+#include "attn.hpp"
+
+namespace omx {
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kWaves = 4;
+constexpr int kUnroll = 4;              // token rows per lane group per step -> 4 K + 4 V loads in flight per lane
+constexpr unsigned kSpinLimit = 1u << 15;   // gather passes (~1 us each) before a consumer gives up
+
+typedef __attribute__((address_space(1))) unsigned long long gu64;
+
+__device__ __forceinline__ void st_granule(uint64_t* p, unsigned tag, float v) {
+    __hip_atomic_store((gu64*)p, ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(v), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned long long ld_granule(const uint64_t* p) {
+    return __hip_atomic_load((gu64*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <int N>
+__device__ __forceinline__ float swap_halves(float v) {     // value of lane (l ^ N/2) of the aligned N-lane group
+    if (N == 16) return dpp_f<0x128>(v);                       // row_ror:8
+    return dpp_f<0x1B>(dpp_f<kDppHalfMirror>(v));              // (7 - i) then quad reverse == i ^ 4
+}
+
+__device__ __forceinline__ void unpack8(const u32x4 r, float (&x)[8]) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        x[2 * e] = bf16lo(r[e]);
+        x[2 * e + 1] = bf16hi(r[e]);
+    }
+}
+
+// merge the granules of one head: `NB` batches of 16 splits, every load of every live batch in flight before the first wait
+template <int D, int NB>
+__device__ __forceinline__ void gather_head(const AttnStepArgs& a, const uint64_t* base, int n_active, unsigned tag, int lane,
+                                            int dim, bf16_t* out) {
+    constexpr int STRIDE = D + 2;
+    unsigned long long ml0 = 0, ml1 = 0, og[NB][16];
+    bool ok_ml = false, ok_b[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) ok_b[b] = b * 16 >= n_active;   // batches past the live splits are never read
+    const int sl = min(lane, n_active - 1);
+    for (unsigned spins = 0;; ++spins) {
+        if (!ok_ml) {
+            ml0 = ld_granule(base + (size_t)sl * STRIDE + D);
+            ml1 = ld_granule(base + (size_t)sl * STRIDE + D + 1);
+        }
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            if (ok_b[b]) continue;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) og[b][j] = ld_granule(base + (size_t)min(b * 16 + j, n_active - 1) * STRIDE + dim);
+        }
+        bool all = true;
+        if (!ok_ml) ok_ml = __all((unsigned)(ml0 >> 32) == tag && (unsigned)(ml1 >> 32) == tag);
+        all = ok_ml;
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            if (!ok_b[b]) {
+                bool ok = true;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) ok &= (unsigned)(og[b][j] >> 32) == tag;
+                ok_b[b] = __all(ok);
+            }
+            all = all && ok_b[b];
+        }
+        if (all) break;
+        if (spins >= kSpinLimit) {   // a producer never showed up: void result, loud flag, no hang
+            if (lane == 0) __hip_atomic_store(a.abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+    const float m = lane < n_active ? __uint_as_float((unsigned)ml0) : -INFINITY;
+    const float l = lane < n_active ? __uint_as_float((unsigned)ml1) : 0.f;
+    const float M = wave_max(m);
+    const float f = (m == -INFINITY) ? 0.f : __expf(m - M);
+    const float L = wave_sum(f * l);
+    float acc = 0.f;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        if (b * 16 >= n_active) break;
+#pragma unroll
+        for (int j = 0; j < 16; ++j)   // splits past n_active re-read the last live one and carry f == 0
+            acc = fmaf(readlane_f(f, b * 16 + j), __uint_as_float((unsigned)og[b][j]), acc);
+    }
+    out[dim] = f32_to_bf16(acc / L);
+}
+
+// two blocks per CU for groups of up to 4 query heads (<= 256 VGPRs); the 8-head variant keeps its state in registers at one
+// block per CU (attn_step_plan sizes the grid accordingly)
+template <int D, int GT, bool TRACE>
+__global__ __launch_bounds__(kBlock, GT <= 4 ? 2 : 1) void attn_step_kernel(const AttnStepArgs a) {
+    constexpr int LPR = D / 8;            // lanes per K/V row
+    constexpr int TPW = 64 / LPR;         // tokens per wave-instruction == token sub-groups per wave
+    constexpr int STEP = TPW * kUnroll;   // tokens per wave per step
+    constexpr int BSTEP = STEP * kWaves;  // tokens per block per step
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* sm_o = reinterpret_cast<float*>(smem);                 // [kWaves][TPW][GT][D]
+    float* sm_m = sm_o + kWaves * TPW * GT * D;                   // [kWaves][GT]
+    float* sm_l = sm_m + kWaves * GT;                             // [kWaves][GT]
+
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int c = lane % LPR;             // 8-element chunk of the head dim owned by this lane
+    const int sg = lane / LPR;            // token sub-group inside the wave
+    const int kvh = blockIdx.x, split = blockIdx.y;
+    const int G = a.H / a.Hkv;
+    unsigned long long* tr = TRACE ? a.trace + ((size_t)split * a.Hkv + kvh) * 8 : nullptr;
+    if (TRACE && threadIdx.x == 0) tr[0] = wall_clock64();
+
+    bf16_t* Kb = a.k + (size_t)kvh * a.kv_head_stride;
+    bf16_t* Vb = a.v + (size_t)kvh * a.kv_head_stride;
+    const int t_begin = split * a.chunk;
+
+    // ---- ONE round of loads: nothing below depends on the position ----
+    u32x4 qraw[GT];
+#pragma unroll
+    for (int g = 0; g < GT; ++g) qraw[g] = *reinterpret_cast<const u32x4*>(a.qkv + (size_t)(kvh * G + min(g, G - 1)) * D + c * 8);
+    const bf16_t* kraw = a.qkv + (size_t)a.H * D + (size_t)kvh * D;
+    const u32x4 knew_raw = *reinterpret_cast<const u32x4*>(kraw + c * 8);
+    const u32x4 vnew = *reinterpret_cast<const u32x4*>(kraw + (size_t)a.Hkv * D + c * 8);
+    const int i0 = (c % (LPR / 2)) * 8;
+    const f32x4* cp = reinterpret_cast<const f32x4*>(a.rope_cur + i0);
+    const f32x4* sp = reinterpret_cast<const f32x4*>(a.rope_cur + D / 2 + i0);
+    const f32x4 c0 = cp[0], c1 = cp[1], s0 = sp[0], s1 = sp[1];
+    u32x4 wq_raw = {0, 0, 0, 0}, wk_raw = {0, 0, 0, 0};
+    if (a.q_norm_w) {
+        wq_raw = *reinterpret_cast<const u32x4*>(a.q_norm_w + c * 8);
+        wk_raw = *reinterpret_cast<const u32x4*>(a.k_norm_w + c * 8);
+    }
+    u32x4 kr[kUnroll], vr[kUnroll];
+    auto issue_kv = [&](int tbase) {
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) {
+            const int tc = min(tbase + u * TPW + sg, a.cap - 1);   // rows past the position are masked below, never used
+            kr[u] = *reinterpret_cast<const u32x4*>(Kb + (size_t)tc * D + c * 8);
+            vr[u] = *reinterpret_cast<const u32x4*>(Vb + (size_t)tc * D + c * 8);
+        }
+    };
+    int t0 = t_begin + wave * STEP;
+    issue_kv(t0);
+    const int pos = *a.pos_ptr;                                    // tokens already cached == RoPE offset (model.rs:186-194)
+    const unsigned tag = *a.seq_ptr * a.tag_mul + a.tag_add;
+
+    // ---- q (G heads) and the new k row: per-head RMSNorm (optional) + RoPE, bf16 roundings of the reference ----
+    float cs[8], sn[8], wq[8], wk[8];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        cs[e] = c0[e]; cs[4 + e] = c1[e];
+        sn[e] = s0[e]; sn[4 + e] = s1[e];
+    }
+    if (a.q_norm_w) {
+        unpack8(wq_raw, wq);
+        unpack8(wk_raw, wk);
+    } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) wq[e] = wk[e] = 1.0f;
+    }
+    const bool first_half = c < LPR / 2;
+    auto norm_rope = [&](const u32x4 raw, const float (&w)[8], float (&out)[8]) {
+        float x[8];
+        unpack8(raw, x);
+        float ss = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ss = fmaf(x[e], x[e], ss);
+        ss = group_sum<LPR>(ss);
+        const float rstd = a.q_norm_w ? 1.0f / sqrtf(ss / (float)D + a.eps) : 1.0f;   // no q/k norm (Mixtral, Qwen2): x goes to RoPE as it is
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float xn = round_bf16(x[e] * rstd * w[e]);            // RMSNorm output is bf16
+            const float other = swap_halves<LPR>(xn);                    // element i +- D/2
+            const float y = first_half ? xn * cs[e] - other * sn[e] : other * sn[e] + xn * cs[e];
+            out[e] = round_bf16(y);                                      // RoPE output is bf16
+        }
+    };
+    float q[GT][8], knew[8];
+#pragma unroll
+    for (int g = 0; g < GT; ++g) {
+        norm_rope(qraw[g], wq, q[g]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) q[g][e] *= a.scale;
+    }
+    norm_rope(knew_raw, wk, knew);
+
+    const int Tk = pos + 1;
+    const int n_active = (Tk + a.chunk - 1) / a.chunk;                  // splits that own at least one token
+    const int t_end = min(Tk, t_begin + a.chunk);
+    const bool active = split < n_active;
+    if (TRACE && threadIdx.x == 0) tr[1] = wall_clock64();
+
+    float m[GT], l[GT], o[GT][8];
+#pragma unroll
+    for (int g = 0; g < GT; ++g) {
+        m[g] = -INFINITY;
+        l[g] = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[g][e] = 0.f;
+    }
+    for (; t0 < t_end; t0 += BSTEP) {
+        float s[kUnroll][GT];
+        float vf[kUnroll][8];
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) {
+            const int tok = t0 + u * TPW + sg;
+            float kf[8];
+            if (tok == pos) {
+                // this lane group owns the NEW token: use the row built above and append it to the cache (cache.rs:183-188)
+                u32x4 kp;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) kp[e] = pack_bf16(knew[2 * e], knew[2 * e + 1]);
+                *reinterpret_cast<u32x4*>(Kb + (size_t)pos * D + c * 8) = kp;
+                *reinterpret_cast<u32x4*>(Vb + (size_t)pos * D + c * 8) = vnew;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) kf[e] = knew[e];
+                unpack8(vnew, vf[u]);
+            } else {
+                unpack8(kr[u], kf);
+                unpack8(vr[u], vf[u]);
+            }
+            if (tok >= t_end) {   // a row past the position: its p is 0, but 0 * garbage must stay 0
+#pragma unroll
+                for (int e = 0; e < 8; ++e) vf[u][e] = 0.f;
+            }
+#pragma unroll
+            for (int g = 0; g < GT; ++g) {
+                float d = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) d = fmaf(q[g][e], kf[e], d);
+                d = group_sum<LPR>(d);
+                s[u][g] = tok < t_end ? d : -INFINITY;
+            }
+        }
+        if (t0 + BSTEP < t_end) issue_kv(t0 + BSTEP);   // the next step's loads do not depend on the softmax below
+#pragma unroll
+        for (int g = 0; g < GT; ++g) {                  // one running max per head for the whole wave
+            float mx = s[0][g];
+#pragma unroll
+            for (int u = 1; u < kUnroll; ++u) mx = fmaxf(mx, s[u][g]);
+            float wmx = readlane_f(mx, 0);
+#pragma unroll
+            for (int r = 1; r < TPW; ++r) wmx = fmaxf(wmx, readlane_f(mx, r * LPR));
+            const float mn = fmaxf(m[g], wmx);
+            const float alpha = (mn == -INFINITY) ? 1.f : __expf(m[g] - mn);
+            m[g] = mn;
+            l[g] *= alpha;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[g][e] *= alpha;
+#pragma unroll
+            for (int u = 0; u < kUnroll; ++u) {
+                const float p = (mn == -INFINITY) ? 0.f : __expf(s[u][g] - mn);
+                l[g] += p;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[g][e] = fmaf(p, vf[u][e], o[g][e]);
+            }
+        }
+    }
+    if (TRACE && threadIdx.x == 0) tr[2] = wall_clock64();
+
+    if (active) {
+        // ---- every token sub-group parks its partial in LDS (same m inside a wave: plain sums) ----
+#pragma unroll
+        for (int g = 0; g < GT; ++g) {
+            float* dst = sm_o + (((size_t)(wave * TPW + sg) * GT + g) * D + c * 8);
+            *reinterpret_cast<f32x4*>(dst) = f32x4{o[g][0], o[g][1], o[g][2], o[g][3]};
+            *reinterpret_cast<f32x4*>(dst + 4) = f32x4{o[g][4], o[g][5], o[g][6], o[g][7]};
+            float lw = readlane_f(l[g], 0);   // the LPR lanes of a sub-group hold identical l
+#pragma unroll
+            for (int r = 1; r < TPW; ++r) lw += readlane_f(l[g], r * LPR);
+            if (lane == 0) {
+                sm_m[wave * GT + g] = m[g];
+                sm_l[wave * GT + g] = lw;
+            }
+        }
+        __syncthreads();
+        // ---- merge the 4 waves x TPW sub-groups; the split's partial leaves as tagged granules ----
+        for (int idx = threadIdx.x; idx < G * D; idx += kBlock) {
+            const int g = idx / D, d = idx % D;
+            float M = sm_m[g];
+#pragma unroll
+            for (int w = 1; w < kWaves; ++w) M = fmaxf(M, sm_m[w * GT + g]);
+            float L = 0.f, O = 0.f;
+#pragma unroll
+            for (int w = 0; w < kWaves; ++w) {
+                const float mw = sm_m[w * GT + g];
+                const float f = (mw == -INFINITY) ? 0.f : __expf(mw - M);
+                float ow = 0.f;
+#pragma unroll
+                for (int r = 0; r < TPW; ++r) ow += sm_o[((size_t)(w * TPW + r) * GT + g) * D + d];
+                L = fmaf(f, sm_l[w * GT + g], L);
+                O = fmaf(f, ow, O);
+            }
+            uint64_t* gr = a.ws + ((size_t)(kvh * G + g) * a.nsplit + split) * (D + 2);
+            st_granule(gr + d, tag, O);
+            if (d == 0) {
+                st_granule(gr + D, tag, M);
+                st_granule(gr + D + 1, tag, L);
+            }
+        }
+    }
+    if (TRACE && threadIdx.x == 0) tr[3] = wall_clock64();
+
+    // ---- consumers: block (kvh, j < G) merges head kvh*G + j ----
+    if (split < G && wave < D / 64) {
+        const int head = kvh * G + split;
+        const uint64_t* base = a.ws + (size_t)head * a.nsplit * (D + 2);
+        bf16_t* out = a.out + (size_t)head * D;
+        const int dim = wave * 64 + lane;
+        const int nb = (a.nsplit + 15) / 16;
+        if (nb <= 1) gather_head<D, 1>(a, base, n_active, tag, lane, dim, out);
+        else if (nb == 2) gather_head<D, 2>(a, base, n_active, tag, lane, dim, out);
+        else gather_head<D, 3>(a, base, n_active, tag, lane, dim, out);
+        if (TRACE && threadIdx.x == 0) tr[4] = wall_clock64();
+    }
+}
+
+}  // namespace
+
+int attn_step_block_tokens(int D) { return (64 / (D / 8)) * kUnroll * kWaves; }
+
+// token range per split and split count for a context bucket of `tk_max` tokens: ~288 blocks (one per CU plus the slack the
+// position leaves in the last bucket; never more than are co-resident: 256 for the 8-head variant), at most kMaxSplits splits
+// (the consumer gathers 3 batches of 16), at least G (one consumer block per query head of a KV group)
+constexpr int kMaxSplits = 48;
+void attn_step_plan(int tk_max, int Hkv, int G, int D, int* chunk, int* nsplit) {
+    const int bs = attn_step_block_tokens(D);
+    const int blocks = G > 4 ? 256 : 288;
+    int target = std::max(1, std::min(kMaxSplits, blocks / std::max(Hkv, 1)));
+    if (const char* v = getenv("OMX_ATTN_STEP_SPLITS")) target = std::max(1, std::min(kMaxSplits, atoi(v)));
+    int ch = bs * ((tk_max + bs * target - 1) / (bs * target));
+    if (ch < bs) ch = bs;
+    int ns = (tk_max + ch - 1) / ch;
+    if (ns < G) ns = G;
+    *chunk = ch;
+    *nsplit = ns;
+}
+
+size_t attn_step_ws_granules(int H, int D) { return (size_t)H * kMaxSplits * (D + 2); }
+
+int launch_attn_step(const AttnStepArgs& a, int D, hipStream_t s) {
+    const int G = a.H / a.Hkv;
+    OMX_REQUIRE(a.H % a.Hkv == 0 && G >= 1 && G <= 8, "decode attention: %d query heads over %d KV heads unsupported (group of at most 8)", a.H, a.Hkv);
+    OMX_REQUIRE(a.nsplit >= G && a.nsplit <= kMaxSplits && a.chunk > 0 && a.chunk % attn_step_block_tokens(D) == 0,
+                "decode attention: bad split plan (chunk %d, %d splits, group %d)", a.chunk, a.nsplit, G);
+    OMX_REQUIRE(a.ws && a.rope_cur && a.pos_ptr && a.seq_ptr && a.abort_flag && a.tag_mul > a.tag_add - 1u && a.tag_add >= 1u,
+                "decode attention: missing step state");
+    const dim3 grid(a.Hkv, a.nsplit), block(kBlock);
+    const int gt = G <= 1 ? 1 : G <= 2 ? 2 : G <= 4 ? 4 : 8;
+#define OMX_ATTN_STEP_CASE(DD, GG)                                                                                       \
+    if (D == DD && gt == GG) {                                                                                           \
+        const size_t shmem = ((size_t)kWaves * (64 / (DD / 8)) * GG * DD + 2 * kWaves * GG + 4) * sizeof(float);         \
+        if (shmem > 48 * 1024) {                                                                                         \
+            OMX_HIP_CHECK(hipFuncSetAttribute((const void*)attn_step_kernel<DD, GG, false>,                             \
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));                  \
+            OMX_HIP_CHECK(hipFuncSetAttribute((const void*)attn_step_kernel<DD, GG, true>,                              \
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));                  \
+        }                                                                                                                \
+        if (a.trace) attn_step_kernel<DD, GG, true><<<grid, block, shmem, s>>>(a);                                       \
+        else attn_step_kernel<DD, GG, false><<<grid, block, shmem, s>>>(a);                                              \
+        OMX_LAUNCH_CHECK();                                                                                              \
+        return 0;                                                                                                        \
+    }
+    OMX_ATTN_STEP_CASE(128, 1) OMX_ATTN_STEP_CASE(128, 2) OMX_ATTN_STEP_CASE(128, 4) OMX_ATTN_STEP_CASE(128, 8)
+    OMX_ATTN_STEP_CASE(64, 1) OMX_ATTN_STEP_CASE(64, 2) OMX_ATTN_STEP_CASE(64, 4) OMX_ATTN_STEP_CASE(64, 8)
+#undef OMX_ATTN_STEP_CASE
+    return set_error("decode attention: head_dim %d unsupported (64 or 128)", D);
+}
+
+}  // namespace omx

@@ -52,12 +52,26 @@ struct LayerQ {
 };
 
 // dequantise ONE embedding row (QuantizedEmbedding::forward, mlx-rs/src/nn/quantized.rs:192-203) chosen by the step state
+// the step's first kernel also refreshes what the rest of the step reads instead of chasing the position: the step sequence
+// number (granule tags of attn_step.hip) and the RoPE row of the current position, rope_cur = cos[pos, :] | sin[pos, :]
+__device__ __forceinline__ void step_begin(const StepState* st, unsigned* seq, float* rope_cur, const float* rope_cos,
+                                           const float* rope_sin, int half) {
+    if (blockIdx.x != 0) return;
+    if (seq && threadIdx.x == 0) *seq += 1u;
+    if (rope_cur && (int)threadIdx.x < 2 * half) {
+        const int t = threadIdx.x, pos = st->pos;
+        rope_cur[t] = t < half ? rope_cos[(size_t)pos * half + t] : rope_sin[(size_t)pos * half + t - half];
+    }
+}
+
 template <int BITS>
 __global__ __launch_bounds__(256) void qembed_kernel(bf16_t* __restrict__ h, const uint32_t* __restrict__ w,
                                                      const bf16_t* __restrict__ scales, const bf16_t* __restrict__ biases,
-                                                     const uint32_t* __restrict__ token, int hidden, int group) {
+                                                     const StepState* st, int hidden, int group, unsigned* seq, float* rope_cur,
+                                                     const float* rope_cos, const float* rope_sin, int half) {
     constexpr int EPW = 32 / BITS;
-    const size_t row = *token;
+    step_begin(st, seq, rope_cur, rope_cos, rope_sin, half);
+    const size_t row = st->cur_token;
     const int words = hidden / EPW;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < words; i += gridDim.x * blockDim.x) {
         const uint32_t wd = w[row * words + i];
@@ -135,8 +149,9 @@ __global__ void apply_token_kernel(StepState* st, const unsigned long long* key,
 }
 
 __global__ __launch_bounds__(256) void embed_kernel(bf16_t* __restrict__ h, const bf16_t* __restrict__ table,
-                                                    const StepState* st, int hidden, unsigned* seq) {
-    if (seq && blockIdx.x == 0 && threadIdx.x == 0) *seq += 1u;   // step sequence number (never reset): the fused launch's epoch
+                                                    const StepState* st, int hidden, unsigned* seq, float* rope_cur,
+                                                    const float* rope_cos, const float* rope_sin, int half) {
+    step_begin(st, seq, rope_cur, rope_cos, rope_sin, half);
     const u32x4* src = reinterpret_cast<const u32x4*>(table + (size_t)st->cur_token * hidden);
     u32x4* dst = reinterpret_cast<u32x4*>(h);
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < hidden / 8; i += gridDim.x * blockDim.x) dst[i] = src[i];
@@ -181,6 +196,13 @@ struct omx_qwen3_ {
     bool fuse_oproj = false;
     int oproj_rpw = 0, oproj_blocks = 0;
     int nsplit = 1;
+    // attention of the decode step (attn_step.hip): the split plan is fixed per captured graph and covers positions < graph_tk_max;
+    // the graphs are rebuilt when the context outgrows that bucket
+    bool attn_step = true;
+    float* rope_cur = nullptr;            // [D] cos | sin of the current position
+    uint64_t* attn_gran = nullptr;        // split partials as tagged granules
+    int attn_chunk = 0, attn_nsplit = 0, graph_tk_max = 0;
+    unsigned long long* attn_trace = nullptr;   // set for one eager step by omx_qwen3_debug_trace_step
 
     void* comm = nullptr;
     nccl_allreduce_fn allreduce = nullptr;
@@ -333,13 +355,58 @@ int resolve_weights(omx_qwen3 m) {
     return 0;
 }
 
+// the attention launch of layer l of a decode step (both the bf16 and the packed-weight step use the bf16 KV kernels)
+int enqueue_attention(omx_qwen3 m, int l, hipStream_t s) {
+    const omx_qwen3_config& c = m->cfg;
+    const int D = c.head_dim;
+    const LayerW& L = m->layers[l];
+    if (m->attn_step) {
+        AttnStepArgs a = {};
+        a.qkv = m->qkv;
+        a.k = m->kcache[l]; a.v = m->vcache[l];
+        a.kv_head_stride = (int64_t)m->cap * D;
+        a.H = m->H; a.Hkv = m->Hkv; a.cap = m->cap;
+        a.scale = 1.0f / sqrtf((float)D);
+        a.eps = c.rms_norm_eps;
+        a.q_norm_w = L.q_norm; a.k_norm_w = L.k_norm;
+        a.rope_cur = m->rope_cur;
+        a.pos_ptr = &m->st->pos;
+        a.seq_ptr = m->step_seq;
+        a.tag_mul = (unsigned)c.num_hidden_layers; a.tag_add = (unsigned)l + 1u;
+        a.chunk = m->attn_chunk; a.nsplit = m->attn_nsplit;
+        a.ws = m->attn_gran;
+        a.out = m->attn_out;
+        a.abort_flag = m->wait_abort;
+        a.trace = m->attn_trace ? m->attn_trace + (size_t)l * m->attn_nsplit * m->Hkv * 8 : nullptr;
+        return launch_attn_step(a, D, s);
+    }
+    AttnDecodeArgs a = {};
+    a.qkv = m->qkv;
+    a.k = m->kcache[l]; a.v = m->vcache[l];
+    a.kv_batch_stride = 0; a.kv_head_stride = (int64_t)m->cap * D;
+    a.B = 1; a.H = m->H; a.Hkv = m->Hkv;
+    a.scale = 1.0f / sqrtf((float)D);
+    a.mask_mode = OMX_MASK_NONE;
+    a.nsplit = m->nsplit;
+    a.ws_o = m->ws_o; a.ws_ml = m->ws_ml;
+    a.arrive = m->attn_arrive;
+    a.out = m->attn_out;
+    a.pos_ptr = &m->st->pos;
+    a.q_norm_w = L.q_norm; a.k_norm_w = L.k_norm;
+    a.rope_cos = m->rope_cos; a.rope_sin = m->rope_sin;
+    a.eps = c.rms_norm_eps;
+    return launch_attn_decode(a, D, true, s);
+}
+
 // the same step on a quantized checkpoint: packed-weight GEMVs (quant.hip) with the prologues / epilogues of the bf16 step
 int enqueue_step_quant(omx_qwen3 m, bool with_head) {
     const omx_qwen3_config& c = m->cfg;
     hipStream_t s = m->stream;
     const int hd = c.hidden_size, D = c.head_dim, bits = c.quant_bits, group = c.quant_group;
-    if (bits == 4) qembed_kernel<4><<<4, 256, 0, s>>>(m->h, m->q_embed.w, m->q_embed.scales, m->q_embed.biases, &m->st->cur_token, hd, group);
-    else qembed_kernel<8><<<4, 256, 0, s>>>(m->h, m->q_embed.w, m->q_embed.scales, m->q_embed.biases, &m->st->cur_token, hd, group);
+    if (bits == 4) qembed_kernel<4><<<4, 256, 0, s>>>(m->h, m->q_embed.w, m->q_embed.scales, m->q_embed.biases, m->st, hd, group, m->step_seq,
+                                                      m->rope_cur, m->rope_cos, m->rope_sin, D / 2);
+    else qembed_kernel<8><<<4, 256, 0, s>>>(m->h, m->q_embed.w, m->q_embed.scales, m->q_embed.biases, m->st, hd, group, m->step_seq, m->rope_cur,
+                                            m->rope_cos, m->rope_sin, D / 2);
     OMX_LAUNCH_CHECK();
     bf16_t* h = m->h;
     bf16_t* hn = m->h2;
@@ -353,24 +420,7 @@ int enqueue_step_quant(omx_qwen3 m, bool with_head) {
             a.x = h; a.norm_w = L.in_ln; a.eps = c.rms_norm_eps; a.out = m->qkv;
             if (launch_qgemv(a, bits, PRO_RMSNORM, EPI_STORE, s)) return 1;
         }
-        {   // [q/k RMSNorm + RoPE + cache append + split-KV SDPA] + [combine]: the bf16 kernels
-            AttnDecodeArgs a = {};
-            a.qkv = m->qkv;
-            a.k = m->kcache[l]; a.v = m->vcache[l];
-            a.kv_batch_stride = 0; a.kv_head_stride = (int64_t)m->cap * D;
-            a.B = 1; a.H = m->H; a.Hkv = m->Hkv;
-            a.scale = 1.0f / sqrtf((float)D);
-            a.mask_mode = OMX_MASK_NONE;
-            a.nsplit = m->nsplit;
-            a.ws_o = m->ws_o; a.ws_ml = m->ws_ml;
-            a.arrive = m->attn_arrive;
-            a.out = m->attn_out;
-            a.pos_ptr = &m->st->pos;
-            a.q_norm_w = L.q_norm; a.k_norm_w = L.k_norm;
-            a.rope_cos = m->rope_cos; a.rope_sin = m->rope_sin;
-            a.eps = c.rms_norm_eps;
-            if (launch_attn_decode(a, D, true, s)) return 1;
-        }
+        if (enqueue_attention(m, l, s)) return 1;   // [q/k RMSNorm + RoPE + cache append + split-KV SDPA + merge]: the bf16 kernel
         {   // [O + residual]
             QGemvArgs a = {};
             a.m[0] = Q.o; a.N = hd; a.K = m->H * D; a.group = group;
@@ -425,7 +475,7 @@ int enqueue_step(omx_qwen3 m, bool with_head) {
     const int hd = c.hidden_size, D = c.head_dim;
     const bool ep = c.ep_size > 1;                               // expert parallel: attention replicated, one all-reduce per MoE block
     const bool tp = !ep && (c.tp_size > 1 || m->allreduce != nullptr);   // a 1-rank communicator exercises the TP path
-    embed_kernel<<<2, 256, 0, s>>>(m->h, m->embed, m->st, hd, m->step_seq);
+    embed_kernel<<<2, 256, 0, s>>>(m->h, m->embed, m->st, hd, m->step_seq, m->rope_cur, m->rope_cos, m->rope_sin, D / 2);
     OMX_LAUNCH_CHECK();
     bf16_t* h = m->h;      // residual stream entering the layer
     bf16_t* hn = m->h2;    // ping-pong partner
@@ -446,7 +496,10 @@ int enqueue_step(omx_qwen3 m, bool with_head) {
             if (launch_gemv(a, PRO_RMSNORM, EPI_STORE, s)) return 1;
             if (pending) { bf16_t* t = h; h = hn; hn = t; pending = nullptr; }
         }
-        {   // [q/k RMSNorm + RoPE + cache append + split-KV SDPA] + [combine]  model.rs:172-210
+        const bool fused_o = m->fuse_oproj && !tp && !m->attn_step;
+        if (m->attn_step) {   // [q/k RMSNorm + RoPE + cache append + split-KV SDPA + merge]  model.rs:172-210
+            if (enqueue_attention(m, l, s)) return 1;
+        } else {
             AttnDecodeArgs a = {};
             a.qkv = m->qkv;
             a.k = m->kcache[l]; a.v = m->vcache[l];
@@ -462,7 +515,7 @@ int enqueue_step(omx_qwen3 m, bool with_head) {
             a.q_norm_w = L.q_norm; a.k_norm_w = L.k_norm;
             a.rope_cos = m->rope_cos; a.rope_sin = m->rope_sin;
             a.eps = c.rms_norm_eps;
-            if (m->fuse_oproj && !tp) {
+            if (fused_o) {
                 // [attention + combine + O GEMV + residual] in ONE launch: the O rows are in registers when the attention ends
                 a.done = m->attn_done + (size_t)l * m->Hkv * 16;
                 a.seq_ptr = m->step_seq;
@@ -473,7 +526,7 @@ int enqueue_step(omx_qwen3 m, bool with_head) {
                 return 1;
             }
         }
-        if (!(m->fuse_oproj && !tp)) {   // [O GEMV + residual]  model.rs:214,325
+        if (!fused_o) {   // [O GEMV + residual]  model.rs:214,325
             GemvArgs a = {};
             a.w0 = L.o; a.n0 = hd; a.N = hd; a.K = m->H * D;
             a.x = m->attn_out;
@@ -633,7 +686,25 @@ int build_graphs(omx_qwen3 m) {
     return 0;
 }
 
-int run_step(omx_qwen3 m, bool with_head) {
+// Called with the position the next step will process.  The decode attention's split plan is part of the captured graph
+// (attn_step.hip: fixed token ranges per split, so that nothing the kernel loads first depends on the position): one plan per
+// context bucket of 1024 tokens (4096 beyond 8 k), the graphs are rebuilt when the position enters another bucket.
+int prepare_step(omx_qwen3 m, int pos) {
+    if (m->attn_step && !m->mega) {
+        const int tk = pos + 1, gran = tk <= 8192 ? 1024 : 4096;
+        const int want = std::min(m->cap, (tk + gran - 1) / gran * gran);
+        if (want != m->graph_tk_max) {
+            if (m->g_full) { (void)hipGraphExecDestroy(m->g_full); m->g_full = nullptr; }
+            if (m->g_nohead) { (void)hipGraphExecDestroy(m->g_nohead); m->g_nohead = nullptr; }
+            attn_step_plan(want, m->Hkv, m->H / m->Hkv, m->cfg.head_dim, &m->attn_chunk, &m->attn_nsplit);
+            m->graph_tk_max = want;
+        }
+    }
+    return build_graphs(m);
+}
+
+int run_step(omx_qwen3 m, bool with_head, int pos) {
+    if (prepare_step(m, pos)) return 1;
     if (m->mega) {
         const omx_qwen3_config& c = m->cfg;
         MegaArgs a = {};
@@ -697,6 +768,12 @@ int enqueue_head_on_row(omx_qwen3 m, const bf16_t* row, hipStream_t s) {
 // The last layer stops after its cache scatter: nothing downstream of it is consumed for these tokens.
 // a device-wide barrier of the persistent kernel gave up (a block never arrived): the step's results are void
 int mega_health(omx_qwen3 m) {
+    if (!m->mega && m->attn_step) {
+        unsigned gave_up = 0;
+        OMX_HIP_CHECK(hipMemcpy(&gave_up, m->wait_abort, 4, hipMemcpyDeviceToHost));
+        OMX_REQUIRE(gave_up == 0, "decode attention: a split merge gave up waiting for a partial (blocks not co-resident?); set OMX_ATTN_STEP=0");
+        return 0;
+    }
     if (!m->mega && m->fuse_oproj) {
         unsigned gave_up = 0;
         OMX_HIP_CHECK(hipMemcpy(&gave_up, m->wait_abort, 4, hipMemcpyDeviceToHost));
@@ -961,6 +1038,8 @@ int omx_qwen3_create(omx_qwen3* out, const omx_qwen3_config* cfg) {
             }
         }
     }
+    if (const char* v = getenv("OMX_ATTN_STEP")) m->attn_step = v[0] != '0';
+    if (dev_alloc(m, &m->rope_cur, (size_t)D) || dev_alloc(m, &m->attn_gran, attn_step_ws_granules(m->H, D))) return 1;
     if (dev_alloc(m, &m->attn_done, (size_t)L * m->Hkv * 16) || dev_alloc(m, &m->step_seq, 16) || dev_alloc(m, &m->wait_abort, 16)) return 1;
     if (dev_alloc(m, &m->st, 1) || dev_alloc(m, &m->out_ring, (size_t)m->ring_cap) ||
         dev_alloc(m, &m->h, (size_t)c.hidden_size) || dev_alloc(m, &m->h2, (size_t)c.hidden_size) ||
@@ -1197,7 +1276,9 @@ int omx_qwen3_prefill(omx_qwen3 m, const uint32_t* prompt, int n_prompt, uint32_
     OMX_REQUIRE(off + n_prompt + 1 <= m->cap, "omx_qwen3_prefill: %d cached + %d prompt tokens exceed max_context %d", off, n_prompt, m->cap);
     for (int i = 0; i < n_prompt; ++i) OMX_REQUIRE(prompt[i] < (uint32_t)m->cfg.vocab_size, "omx_qwen3_prefill: token id %u out of range (vocab %d)", prompt[i], m->cfg.vocab_size);
     OMX_REQUIRE(n_prompt <= m->prompt_cap, "omx_qwen3_prefill: prompt of %d tokens exceeds max_context %d", n_prompt, m->prompt_cap);
-    if (build_graphs(m)) return 1;
+    const char* serial_env = getenv("OMX_PREFILL_SERIAL");
+    const bool serial = (serial_env && serial_env[0] == '1') || m->allreduce != nullptr || n_prompt < 2;
+    if (prepare_step(m, serial ? off : off + n_prompt - 1)) return 1;   // the first step this call will run (graphs are per context bucket)
     OMX_HIP_CHECK(hipMemcpyAsync(m->prompt_dev, prompt, (size_t)n_prompt * 4, hipMemcpyHostToDevice, m->stream));
     StepState st;
     OMX_HIP_CHECK(hipMemcpyAsync(&st, m->st, sizeof(st), hipMemcpyDeviceToHost, m->stream));
@@ -1205,8 +1286,6 @@ int omx_qwen3_prefill(omx_qwen3 m, const uint32_t* prompt, int n_prompt, uint32_
     st.cur_token = prompt[0];
     st.prompt_idx = 0;
     const int count_before = st.out_count;
-    const char* serial_env = getenv("OMX_PREFILL_SERIAL");
-    const bool serial = (serial_env && serial_env[0] == '1') || m->allreduce != nullptr || n_prompt < 2;
     OMX_HIP_CHECK(hipEventRecord(m->ev0, m->stream));
     bool batched_head = false;
     if (serial) {
@@ -1214,7 +1293,7 @@ int omx_qwen3_prefill(omx_qwen3 m, const uint32_t* prompt, int n_prompt, uint32_
         // all but the last prompt position; the reference computes and discards those logits, model.rs:815)
         OMX_HIP_CHECK(hipMemcpyAsync(m->st, &st, sizeof(st), hipMemcpyHostToDevice, m->stream));
         for (int i = 0; i < n_prompt - 1; ++i)
-            if (run_step(m, false)) return 1;
+            if (run_step(m, false, st.pos + i)) return 1;
     } else {
         // matrix-core prefill of ALL n tokens, then norm + lm_head + sampler on the last row (one more row in GEMMs whose
         // tile count does not change, instead of a 36-layer GEMV pass); OMX_PREFILL_TAIL_STEP=1: n-1 tokens batched and
@@ -1232,7 +1311,7 @@ int omx_qwen3_prefill(omx_qwen3 m, const uint32_t* prompt, int n_prompt, uint32_
             batched_head = true;
         }
     }
-    if (!batched_head && run_step(m, true)) return 1;
+    if (!batched_head && run_step(m, true, serial ? st.pos + n_prompt - 1 : st.pos)) return 1;
     OMX_HIP_CHECK(hipEventRecord(m->ev1, m->stream));
     OMX_HIP_CHECK(hipMemcpyAsync(first_token, m->out_ring + (count_before % m->ring_cap), 4, hipMemcpyDeviceToHost, m->stream));
     OMX_HIP_CHECK(hipStreamSynchronize(m->stream));
@@ -1250,14 +1329,14 @@ int omx_qwen3_decode(omx_qwen3 m, int n, uint32_t* tokens_out) {
     OMX_REQUIRE(m && tokens_out, "omx_qwen3_decode: null argument");
     OMX_REQUIRE(n >= 0 && n <= m->ring_cap, "omx_qwen3_decode: n=%d out of range (1..%d per call)", n, m->ring_cap);
     if (n == 0) return 0;
-    if (build_graphs(m)) return 1;
     StepState st;
     OMX_HIP_CHECK(hipMemcpyAsync(&st, m->st, sizeof(st), hipMemcpyDeviceToHost, m->stream));
     OMX_HIP_CHECK(hipStreamSynchronize(m->stream));
+    if (prepare_step(m, st.pos)) return 1;
     OMX_REQUIRE(st.pos + n <= m->cap, "omx_qwen3_decode: %d cached + %d new tokens exceed max_context %d", st.pos, n, m->cap);
     OMX_HIP_CHECK(hipEventRecord(m->ev0, m->stream));
     for (int i = 0; i < n; ++i)
-        if (run_step(m, true)) return 1;
+        if (run_step(m, true, st.pos + i)) return 1;
     OMX_HIP_CHECK(hipEventRecord(m->ev1, m->stream));
     OMX_HIP_CHECK(hipStreamSynchronize(m->stream));
     OMX_HIP_CHECK(hipEventElapsedTime(&m->last_decode_ms, m->ev0, m->ev1));
@@ -1309,19 +1388,42 @@ int omx_qwen3_stream(omx_qwen3 m, omx_stream* s) {
     return 0;
 }
 
-/* debug hook (tools/mega_trace.py): run ONE decode step of the persistent kernel with the phase timeline
- * enabled; host receives [layers][kTraceEvents][blocks] 100 MHz wall-clock stamps */
+/* debug hook: run ONE decode step with a timeline on; 100 MHz wall-clock stamps.
+ *   step graph (tools/attn_step_trace.py): the step runs eagerly with the attention launches stamping
+ *     [layers][attn splits][kv heads][8] = {start, loads+norm done, chunk done, granules stored, gathered, -, -, -};
+ *     *blocks = splits * kv heads;
+ *   persistent kernel (tools/mega_trace.py): [layers][kTraceEvents][blocks] */
 int omx_qwen3_debug_trace_step(omx_qwen3 m, unsigned long long* host, size_t n_words, int* blocks) {
     OMX_REQUIRE(m && host && blocks, "omx_qwen3_debug_trace_step: null argument");
-    if (build_graphs(m)) return 1;
-    OMX_REQUIRE(m->mega, "omx_qwen3_debug_trace_step: the persistent step kernel is not in use");
+    StepState st;
+    OMX_HIP_CHECK(hipMemcpyAsync(&st, m->st, sizeof(st), hipMemcpyDeviceToHost, m->stream));
+    OMX_HIP_CHECK(hipStreamSynchronize(m->stream));
+    if (prepare_step(m, st.pos)) return 1;
+    if (!m->mega) {
+        OMX_REQUIRE(m->attn_step, "omx_qwen3_debug_trace_step: neither the persistent kernel nor the step attention kernel is in use");
+        const size_t per_layer = (size_t)m->attn_nsplit * m->Hkv * 8, need = per_layer * m->cfg.num_hidden_layers;
+        OMX_REQUIRE(n_words >= need, "omx_qwen3_debug_trace_step: buffer of %zu words, need %zu", n_words, need);
+        unsigned long long* dev = nullptr;
+        OMX_HIP_CHECK(hipMalloc(&dev, need * 8));
+        OMX_HIP_CHECK(hipMemsetAsync(dev, 0, need * 8, m->stream));
+        m->attn_trace = dev;
+        const int rc = enqueue_step(m, true);
+        m->attn_trace = nullptr;
+        if (!rc) {
+            OMX_HIP_CHECK(hipStreamSynchronize(m->stream));
+            OMX_HIP_CHECK(hipMemcpy(host, dev, need * 8, hipMemcpyDeviceToHost));
+        }
+        (void)hipFree(dev);
+        *blocks = m->attn_nsplit * m->Hkv;
+        return rc ? 1 : mega_health(m);
+    }
     const size_t need = (size_t)m->cfg.num_hidden_layers * kTraceEvents * m->mega_blocks;
     OMX_REQUIRE(n_words >= need, "omx_qwen3_debug_trace_step: buffer of %zu words, need %zu", n_words, need);
     unsigned long long* dev = nullptr;
     OMX_HIP_CHECK(hipMalloc(&dev, need * 8));
     OMX_HIP_CHECK(hipMemsetAsync(dev, 0, need * 8, m->stream));
     m->mega_trace = dev;
-    const int rc = run_step(m, true);
+    const int rc = run_step(m, true, st.pos);
     m->mega_trace = nullptr;
     if (!rc) {
         OMX_HIP_CHECK(hipStreamSynchronize(m->stream));

@@ -899,7 +899,19 @@ int split_workspace(hipStream_t s, size_t floats, size_t tiles, float** ws, unsi
         OMX_HIP_CHECK(hipThreadExchangeStreamCaptureMode(&mode));
         hipError_t e = hipMalloc((void**)&w.ws, kSplitWsFloats * 4);
         if (e == hipSuccess) e = hipMalloc((void**)&w.cnt, kSplitCnt * 4);
-        if (e == hipSuccess) e = hipMemset(w.cnt, 0, kSplitCnt * 4);   // synchronous, not a stream operation: legal during a capture
+        if (e == hipSuccess) {
+            // the counters must be zero before the first launch on `s` reads them.  `s` may be a non-blocking stream (not ordered
+            // against the null stream): zero them ON `s` -- unless `s` is being captured, where the memset would become a graph
+            // node; then zero through the null stream and wait for it here (the graph only runs after the capture ends)
+            hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+            const bool capturing = s != nullptr && hipStreamIsCapturing(s, &st) == hipSuccess && st != hipStreamCaptureStatusNone;
+            if (capturing) {
+                e = hipMemset(w.cnt, 0, kSplitCnt * 4);
+                if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
+            } else {
+                e = hipMemsetAsync(w.cnt, 0, kSplitCnt * 4, s);
+            }
+        }
         (void)hipThreadExchangeStreamCaptureMode(&mode);
         if (e != hipSuccess) {
             if (w.ws) (void)hipFree(w.ws);

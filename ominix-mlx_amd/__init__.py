@@ -13,7 +13,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libomx_hip.so")
+# OMX_LIB_VARIANT=name loads libomx_hip_<name>.so (an A/B build made with `make VARIANT=name VARIANT_FLAGS=-D...`, tuning only)
+LIB_PATH = os.path.join(_HERE, "libomx_hip%s.so" % ("_" + os.environ["OMX_LIB_VARIANT"] if os.environ.get("OMX_LIB_VARIANT") else ""))
 
 
 class OmxError(RuntimeError):

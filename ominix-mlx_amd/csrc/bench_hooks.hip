@@ -64,6 +64,62 @@ extern "C" int omx_bench_gemv(int N, int K, int pro, int epi, int rows_per_wave,
     return 0;
 }
 
+// per-block timeline of `chain` back-to-back launches of one GEMV shape on distinct weight buffers (tools/gemv_trace.py):
+// host receives [chain][blocks][4] wall-clock stamps (gemv.hpp GemvArgs::trace); *blocks = blocks per launch
+extern "C" int omx_bench_gemv_trace(int N, int K, int pro, int epi, int rows_per_wave, int chain, unsigned long long* host,
+                                    size_t n_words, int* blocks) {
+    using namespace omx;
+    OMX_REQUIRE(host && blocks && chain > 0, "omx_bench_gemv_trace: bad arguments");
+    const int mats = (epi == EPI_SWIGLU) ? 2 : 1;
+    const size_t wbytes = (size_t)N * K * 2 * mats;
+    const int nb = gemv_grid(N, K, epi, rows_per_wave);
+    OMX_REQUIRE(n_words >= (size_t)chain * nb * 4, "omx_bench_gemv_trace: buffer too small (%d blocks)", nb);
+    std::vector<void*> w(chain + 2, nullptr);
+    void *x = nullptr, *nw = nullptr, *out = nullptr, *resid = nullptr, *slot = nullptr;
+    unsigned long long* tr = nullptr;
+    for (auto& p : w) {
+        OMX_HIP_CHECK(hipMalloc(&p, wbytes));
+        if (omx_fill_uniform(p, wbytes / 2, 17u + (uint32_t)(&p - &w[0]), 0.03f, 0.f, OMX_BFLOAT16, nullptr)) return 1;
+    }
+    OMX_HIP_CHECK(hipMalloc(&x, (size_t)K * 2));
+    OMX_HIP_CHECK(hipMalloc(&nw, (size_t)K * 2));
+    OMX_HIP_CHECK(hipMalloc(&out, (size_t)N * 4));
+    OMX_HIP_CHECK(hipMalloc(&resid, (size_t)N * 2));
+    OMX_HIP_CHECK(hipMalloc(&slot, 8 * 65536));
+    OMX_HIP_CHECK(hipMalloc((void**)&tr, (size_t)chain * nb * 4 * 8));
+    omx_fill_uniform(x, K, 3, 1.0f, 0.f, OMX_BFLOAT16, nullptr);
+    omx_fill_uniform(nw, K, 4, 0.1f, 1.f, OMX_BFLOAT16, nullptr);
+    omx_fill_uniform(resid, N, 5, 1.0f, 0.f, OMX_BFLOAT16, nullptr);
+    OMX_HIP_CHECK(hipMemset(slot, 0, 8 * 65536));
+    OMX_HIP_CHECK(hipMemset(tr, 0, (size_t)chain * nb * 4 * 8));
+    OMX_HIP_CHECK(hipDeviceSynchronize());
+    hipStream_t s;
+    OMX_HIP_CHECK(hipStreamCreate(&s));
+    auto run = [&](int i, unsigned long long* t) {
+        GemvArgs a = {};
+        const bf16_t* base = (const bf16_t*)w[i % w.size()];
+        a.w0 = base; a.w1 = base + (size_t)N * K;
+        a.n0 = N; a.N = N; a.K = K;
+        a.x = (const bf16_t*)x; a.norm_w = (const bf16_t*)nw; a.eps = 1e-6f;
+        a.resid = (const bf16_t*)resid; a.out = out;
+        a.argmax_slot = (unsigned long long*)slot;
+        a.rows_per_wave = rows_per_wave;
+        a.trace = t;
+        return launch_gemv(a, pro, epi, s);
+    };
+    for (int i = 0; i < 2; ++i)
+        if (run(i, nullptr)) return 1;
+    for (int i = 0; i < chain; ++i)
+        if (run(2 + i, tr + (size_t)i * nb * 4)) return 1;
+    OMX_HIP_CHECK(hipStreamSynchronize(s));
+    OMX_HIP_CHECK(hipMemcpy(host, tr, (size_t)chain * nb * 4 * 8, hipMemcpyDeviceToHost));
+    *blocks = nb;
+    for (auto p : w) (void)hipFree(p);
+    (void)hipFree(x); (void)hipFree(nw); (void)hipFree(out); (void)hipFree(resid); (void)hipFree(slot); (void)hipFree(tr);
+    (void)hipStreamDestroy(s);
+    return 0;
+}
+
 // time the bf16 MFMA GEMM out[M,N] = x[M,K] . W[N,K]^T with HIP events (operands rotated over n_copies buffers)
 extern "C" int omx_bench_gemm(int M, int N, int K, int n_copies, int iters, float* avg_ms) {
     using namespace omx;

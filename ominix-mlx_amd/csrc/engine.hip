@@ -468,6 +468,12 @@ int enqueue_step_quant(omx_qwen3 m, bool with_head) {
 }
 
 // enqueue one decode step on m->stream.  with_head=false: prompt token whose logits nobody reads.
+// tuning knob: OMX_GEMV_RPW_<QKV|O|GU|DOWN>=n overrides the rows-per-wave (per block for K-split kernels) heuristic of gemv.hip
+static int rpw_env(const char* name) {
+    const char* v = getenv(name);
+    return v ? atoi(v) : 0;
+}
+
 int enqueue_step(omx_qwen3 m, bool with_head) {
     if (m->cfg.quant_bits) return enqueue_step_quant(m, with_head);
     const omx_qwen3_config& c = m->cfg;
@@ -493,6 +499,7 @@ int enqueue_step(omx_qwen3 m, bool with_head) {
             a.norm_w = L.in_ln; a.eps = c.rms_norm_eps;
             a.out = m->qkv;
             a.out_bias = L.qkv_bias;
+            a.rows_per_wave = rpw_env("OMX_GEMV_RPW_QKV");
             if (launch_gemv(a, PRO_RMSNORM, EPI_STORE, s)) return 1;
             if (pending) { bf16_t* t = h; h = hn; hn = t; pending = nullptr; }
         }
@@ -530,6 +537,7 @@ int enqueue_step(omx_qwen3 m, bool with_head) {
             GemvArgs a = {};
             a.w0 = L.o; a.n0 = hd; a.N = hd; a.K = m->H * D;
             a.x = m->attn_out;
+            a.rows_per_wave = rpw_env("OMX_GEMV_RPW_O");
             if (!tp) {
                 a.resid = h; a.out = hn;
                 if (launch_gemv(a, PRO_NONE, EPI_RESIDUAL, s)) return 1;
@@ -569,6 +577,7 @@ int enqueue_step(omx_qwen3 m, bool with_head) {
             a.x = h; a.x_partial = pending; a.x_out = pending ? hn : nullptr;
             a.norm_w = L.post_ln; a.eps = c.rms_norm_eps;
             a.out = m->act;
+            a.rows_per_wave = rpw_env("OMX_GEMV_RPW_GU");
             if (launch_gemv(a, PRO_RMSNORM, EPI_SWIGLU, s)) return 1;
             if (pending) { bf16_t* t = h; h = hn; hn = t; pending = nullptr; }
         }
@@ -576,6 +585,7 @@ int enqueue_step(omx_qwen3 m, bool with_head) {
             GemvArgs a = {};
             a.w0 = L.down; a.n0 = hd; a.N = hd; a.K = m->I;
             a.x = m->act;
+            a.rows_per_wave = rpw_env("OMX_GEMV_RPW_DOWN");
             if (!tp) {
                 a.resid = h; a.out = hn;
                 if (launch_gemv(a, PRO_NONE, EPI_RESIDUAL, s)) return 1;

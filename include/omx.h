@@ -216,11 +216,10 @@ int omx_qwen3_stream(omx_qwen3 m, omx_stream* s);
 /* algorithmic HBM bytes of ONE decode step at context length ctx (SURVEY.md 8d formula)             */
 int omx_qwen3_step_bytes(omx_qwen3 m, int ctx, double* bytes);
 /* how the decode step is executed once built: 0 = not built yet, 1 = step graph (one launch per phase,
- * replayed as a hipGraph), 2 = the same launches issued eagerly, 3 = one persistent kernel per token
- * (csrc/decode_mega.hip; default when the shape has an instantiation, OMX_DECODE_MEGA=0 disables it)    */
+ * replayed as a hipGraph; one graph per 1024-token context bucket), 2 = the same launches issued eagerly */
 int omx_qwen3_decode_path(omx_qwen3 m, int* path);
-/* debug hook (tools/mega_trace.py): run ONE decode step of the persistent kernel with its phase timeline on;
- * host receives [layers][16][blocks] 100 MHz wall-clock stamps, *blocks = grid size                        */
+/* debug hook (tools/attn_step_trace.py): run ONE decode step eagerly with the attention launches stamping the
+ * 100 MHz wall clock; host receives [layers][attention splits][kv heads][8], *blocks = splits * kv heads     */
 int omx_qwen3_debug_trace_step(omx_qwen3 m, unsigned long long* host, size_t n_words, int* blocks);
 
 /* =====================================================================================

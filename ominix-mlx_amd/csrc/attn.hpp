@@ -5,9 +5,7 @@
 namespace omx {
 
 struct AttnDecodeArgs {
-    // generic path: q [B,H,1,D] bf16.  fused path: qkv = raw projections [H*D | Hkv*D | Hkv*D]
-    const bf16_t* q;
-    const bf16_t* qkv;
+    const bf16_t* q;            // [B,H,1,D] bf16
     const bf16_t* k;            // [B,Hkv,*,D] with strides below (row stride = D)
     const bf16_t* v;
     int64_t kv_batch_stride, kv_head_stride;
@@ -19,36 +17,7 @@ struct AttnDecodeArgs {
     float* ws_o;                // [B*H, nsplit, D]
     float* ws_ml;               // [B*H, nsplit, 2]
     bf16_t* out;                // [B,H,1,D] == [B, H*D]
-    // fused extras (qwen3-mlx/src/model.rs:172-196)
-    const int* pos_ptr;         // device scalar: tokens already cached == RoPE offset
-    const bf16_t* q_norm_w;
-    const bf16_t* k_norm_w;
-    const float* rope_cos;      // [max_pos, D/2]
-    const float* rope_sin;
-    float eps;
-    // optional [B*Hkv * 16] zeroed arrival counters: the LAST split block of a KV head merges the splits itself
-    // (same arithmetic as attn_combine_kernel) and no combine launch follows
-    unsigned* arrive;
-    // fused O-projection (launch_attn_oproj): `done` [B*Hkv * 16] words receive *seq_ptr once a KV head's output is final
-    unsigned* done;
-    const unsigned* seq_ptr;    // device word that differs from launch to launch (the engine's step sequence number)
 };
-
-// O-projection rows computed by the extra blocks of the fused launch: out = bf16(resid + bf16(attn_out . W^T))
-struct OProjArgs {
-    const bf16_t* w;            // [N, K] with K = H*D
-    const bf16_t* resid;        // [N]
-    bf16_t* out;                // [N]
-    int N, K;
-    int rows_per_wave, n_blocks;
-    unsigned* abort_flag;       // set when a wait gave up (results void)
-};
-// blocks that can be co-resident for head dim D / group G / K (0: no instantiation); the fused launch needs
-// B*Hkv*nsplit + o.n_blocks <= this
-int attn_oproj_capacity(int D, int G, int K);
-// one launch: split-KV decode attention + in-launch combine, and the O projection whose weight rows are pulled into
-// registers while the attention runs (the HBM is idle during that latency-bound phase)
-int launch_attn_oproj(const AttnDecodeArgs& a, const OProjArgs& o, int D, hipStream_t s);
 
 // ---- the decode engine's attention launch (attn_step.hip): q/k norm + RoPE + cache append + split-KV SDPA + split merge ----
 struct AttnStepArgs {
@@ -77,6 +46,6 @@ size_t attn_step_ws_granules(int H, int D);
 int launch_attn_step(const AttnStepArgs& a, int D, hipStream_t s);
 
 size_t attn_decode_ws_bytes(int BH, int nsplit, int D);
-int launch_attn_decode(const AttnDecodeArgs& a, int D, bool fused, hipStream_t s);
+int launch_attn_decode(const AttnDecodeArgs& a, int D, hipStream_t s);
 
 }  // namespace omx

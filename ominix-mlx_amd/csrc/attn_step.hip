@@ -28,9 +28,8 @@ namespace omx {
 
 namespace {
 
-constexpr int kBlock = 256;
-constexpr int kWaves = 4;
-constexpr int kUnroll = 4;              // token rows per lane group per step -> 4 K + 4 V loads in flight per lane
+constexpr int kBlock = 512;
+constexpr int kWaves = 8;
 constexpr unsigned kSpinLimit = 1u << 15;   // gather passes (~1 us each) before a consumer gives up
 
 typedef __attribute__((address_space(1))) unsigned long long gu64;
@@ -114,23 +113,43 @@ __device__ __forceinline__ void gather_head(const AttnStepArgs& a, const uint64_
     out[dim] = f32_to_bf16(acc / L);
 }
 
-// two blocks per CU for groups of up to 4 query heads (<= 256 VGPRs); the 8-head variant keeps its state in registers at one
-// block per CU (attn_step_plan sizes the grid accordingly)
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+// sum of 8 exact bf16 products, f32 accumulation (v_dot2c_f32_bf16).  The pairs are taken with shufflevector from the whole
+// 8-element vector: bit-casting the dwords of a u32x4 one by one made hipcc (ROCm 7.2) feed all four dot2 instructions the
+// SAME register pair -- 4x the first product, silently wrong scores.
+__device__ __forceinline__ float dot8_bf16(const u32x4 a, const u32x4 b) {
+    const bf16x8_t A = __builtin_bit_cast(bf16x8_t, a), B = __builtin_bit_cast(bf16x8_t, b);
+    float d = 0.f;
+    d = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(A, A, 0, 1), __builtin_shufflevector(B, B, 0, 1), d, false);
+    d = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(A, A, 2, 3), __builtin_shufflevector(B, B, 2, 3), d, false);
+    d = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(A, A, 4, 5), __builtin_shufflevector(B, B, 4, 5), d, false);
+    d = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(A, A, 6, 7), __builtin_shufflevector(B, B, 6, 7), d, false);
+    return d;
+}
+
+// One block per CU: 8 waves share a split's token range in units of one wave-instruction (TPW token rows), so the serial
+// instruction chain of a wave is a quarter of what four waves with four rows each had, two waves per SIMD cover each other's
+// latencies, and the q/k RMSNorm + RoPE is done ONCE per block (wave g: query head g, wave GT % 8: the new key row) and shared
+// through LDS instead of five times per wave.  attn_step_plan keeps the grid <= 256 blocks.
+constexpr int kKU = 3;   // units in flight per wave
+
 template <int D, int GT, bool TRACE>
-__global__ __launch_bounds__(kBlock, GT <= 4 ? 2 : 1) void attn_step_kernel(const AttnStepArgs a) {
+__global__ __launch_bounds__(kBlock, 1) void attn_step_kernel(const AttnStepArgs a) {
     constexpr int LPR = D / 8;            // lanes per K/V row
-    constexpr int TPW = 64 / LPR;         // tokens per wave-instruction == token sub-groups per wave
-    constexpr int STEP = TPW * kUnroll;   // tokens per wave per step
-    constexpr int BSTEP = STEP * kWaves;  // tokens per block per step
+    constexpr int TPW = 64 / LPR;         // token rows per wave-instruction == one unit
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* sm_o = reinterpret_cast<float*>(smem);                 // [kWaves][TPW][GT][D]
     float* sm_m = sm_o + kWaves * TPW * GT * D;                   // [kWaves][GT]
     float* sm_l = sm_m + kWaves * GT;                             // [kWaves][GT]
+    u32x4* sm_q = reinterpret_cast<u32x4*>(sm_l + kWaves * GT);   // [GT + 1][LPR]: roped q heads and the new k row, packed bf16
 
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int c = lane % LPR;             // 8-element chunk of the head dim owned by this lane
-    const int sg = lane / LPR;            // token sub-group inside the wave
+    const int sg = lane / LPR;            // token row inside the unit
     const int kvh = blockIdx.x, split = blockIdx.y;
     const int G = a.H / a.Hkv;
     unsigned long long* tr = TRACE ? a.trace + ((size_t)split * a.Hkv + kvh) * 8 : nullptr;
@@ -139,13 +158,15 @@ __global__ __launch_bounds__(kBlock, GT <= 4 ? 2 : 1) void attn_step_kernel(cons
     bf16_t* Kb = a.k + (size_t)kvh * a.kv_head_stride;
     bf16_t* Vb = a.v + (size_t)kvh * a.kv_head_stride;
     const int t_begin = split * a.chunk;
+    const int n_units = a.chunk / TPW;
 
     // ---- ONE round of loads: nothing below depends on the position ----
-    u32x4 qraw[GT];
-#pragma unroll
-    for (int g = 0; g < GT; ++g) qraw[g] = *reinterpret_cast<const u32x4*>(a.qkv + (size_t)(kvh * G + min(g, G - 1)) * D + c * 8);
     const bf16_t* kraw = a.qkv + (size_t)a.H * D + (size_t)kvh * D;
-    const u32x4 knew_raw = *reinterpret_cast<const u32x4*>(kraw + c * 8);
+    const bool does_q = wave < GT, does_k = wave == GT % kWaves;
+    // the row this wave normalises: query head `wave` (clamped) or, for the key wave without a query head, the new key row
+    const bf16_t* my_raw = does_q ? a.qkv + (size_t)(kvh * G + min(wave, G - 1)) * D : kraw;
+    const u32x4 raw0 = *reinterpret_cast<const u32x4*>(my_raw + c * 8);
+    const u32x4 raw1 = *reinterpret_cast<const u32x4*>(kraw + c * 8);                        // (key wave that also owns a head)
     const u32x4 vnew = *reinterpret_cast<const u32x4*>(kraw + (size_t)a.Hkv * D + c * 8);
     const int i0 = (c % (LPR / 2)) * 8;
     const f32x4* cp = reinterpret_cast<const f32x4*>(a.rope_cur + i0);
@@ -156,59 +177,57 @@ __global__ __launch_bounds__(kBlock, GT <= 4 ? 2 : 1) void attn_step_kernel(cons
         wq_raw = *reinterpret_cast<const u32x4*>(a.q_norm_w + c * 8);
         wk_raw = *reinterpret_cast<const u32x4*>(a.k_norm_w + c * 8);
     }
-    u32x4 kr[kUnroll], vr[kUnroll];
-    auto issue_kv = [&](int tbase) {
+    u32x4 kr[kKU], vr[kKU];
+    auto issue_kv = [&](int u0) {
 #pragma unroll
-        for (int u = 0; u < kUnroll; ++u) {
-            const int tc = min(tbase + u * TPW + sg, a.cap - 1);   // rows past the position are masked below, never used
+        for (int u = 0; u < kKU; ++u) {
+            const int tc = min(t_begin + (u0 + u * kWaves) * TPW + sg, a.cap - 1);   // rows past the position are masked below
             kr[u] = *reinterpret_cast<const u32x4*>(Kb + (size_t)tc * D + c * 8);
             vr[u] = *reinterpret_cast<const u32x4*>(Vb + (size_t)tc * D + c * 8);
         }
     };
-    int t0 = t_begin + wave * STEP;
-    issue_kv(t0);
+    issue_kv(wave);
     const int pos = *a.pos_ptr;                                    // tokens already cached == RoPE offset (model.rs:186-194)
     const unsigned tag = *a.seq_ptr * a.tag_mul + a.tag_add;
 
-    // ---- q (G heads) and the new k row: per-head RMSNorm (optional) + RoPE, bf16 roundings of the reference ----
-    float cs[8], sn[8], wq[8], wk[8];
+    // ---- per-head RMSNorm (optional) + RoPE with the reference's bf16 roundings: one row per wave, shared through LDS ----
+    {
+        float cs[8], sn[8];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        cs[e] = c0[e]; cs[4 + e] = c1[e];
-        sn[e] = s0[e]; sn[4 + e] = s1[e];
-    }
-    if (a.q_norm_w) {
-        unpack8(wq_raw, wq);
-        unpack8(wk_raw, wk);
-    } else {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) wq[e] = wk[e] = 1.0f;
-    }
-    const bool first_half = c < LPR / 2;
-    auto norm_rope = [&](const u32x4 raw, const float (&w)[8], float (&out)[8]) {
-        float x[8];
-        unpack8(raw, x);
-        float ss = 0.f;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) ss = fmaf(x[e], x[e], ss);
-        ss = group_sum<LPR>(ss);
-        const float rstd = a.q_norm_w ? 1.0f / sqrtf(ss / (float)D + a.eps) : 1.0f;   // no q/k norm (Mixtral, Qwen2): x goes to RoPE as it is
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const float xn = round_bf16(x[e] * rstd * w[e]);            // RMSNorm output is bf16
-            const float other = swap_halves<LPR>(xn);                    // element i +- D/2
-            const float y = first_half ? xn * cs[e] - other * sn[e] : other * sn[e] + xn * cs[e];
-            out[e] = round_bf16(y);                                      // RoPE output is bf16
+        for (int e = 0; e < 4; ++e) {
+            cs[e] = c0[e]; cs[4 + e] = c1[e];
+            sn[e] = s0[e]; sn[4 + e] = s1[e];
         }
-    };
-    float q[GT][8], knew[8];
+        const bool first_half = c < LPR / 2;
+        auto norm_rope = [&](const u32x4 raw, const u32x4 w_raw) -> u32x4 {
+            float x[8], w[8];
+            unpack8(raw, x);
+            unpack8(w_raw, w);
+            float ss = 0.f;
 #pragma unroll
-    for (int g = 0; g < GT; ++g) {
-        norm_rope(qraw[g], wq, q[g]);
+            for (int e = 0; e < 8; ++e) ss = fmaf(x[e], x[e], ss);
+            ss = group_sum<LPR>(ss);
+            const float rstd = a.q_norm_w ? 1.0f / sqrtf(ss / (float)D + a.eps) : 1.0f;   // no q/k norm (Mixtral, Qwen2): x goes to RoPE as it is
+            float y[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) q[g][e] *= a.scale;
+            for (int e = 0; e < 8; ++e) {
+                const float xn = a.q_norm_w ? round_bf16(x[e] * rstd * w[e]) : x[e];   // RMSNorm output is bf16
+                const float other = swap_halves<LPR>(xn);                               // element i +- D/2
+                y[e] = first_half ? xn * cs[e] - other * sn[e] : other * sn[e] + xn * cs[e];
+            }
+            u32x4 out;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) out[e] = pack_bf16(y[2 * e], y[2 * e + 1]);     // RoPE output is bf16
+            return out;
+        };
+        if (does_q && sg == 0) sm_q[wave * LPR + c] = norm_rope(raw0, wq_raw);
+        if (does_k && sg == 0) sm_q[GT * LPR + c] = norm_rope(does_q ? raw1 : raw0, wk_raw);
     }
-    norm_rope(knew_raw, wk, knew);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // LDS only: the K/V loads stay in flight across it
+    u32x4 q[GT];
+#pragma unroll
+    for (int g = 0; g < GT; ++g) q[g] = sm_q[g * LPR + c];
+    const u32x4 knew = sm_q[GT * LPR + c];
 
     const int Tk = pos + 1;
     const int n_active = (Tk + a.chunk - 1) / a.chunk;                  // splits that own at least one token
@@ -216,54 +235,46 @@ __global__ __launch_bounds__(kBlock, GT <= 4 ? 2 : 1) void attn_step_kernel(cons
     const bool active = split < n_active;
     if (TRACE && threadIdx.x == 0) tr[1] = wall_clock64();
 
-    float m[GT], l[GT], o[GT][8];
+    float m[GT], l[GT];
+    f32x2 o[GT][4];
 #pragma unroll
     for (int g = 0; g < GT; ++g) {
         m[g] = -INFINITY;
         l[g] = 0.f;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o[g][e] = 0.f;
+        for (int e = 0; e < 4; ++e) o[g][e] = f32x2{0.f, 0.f};
     }
-    for (; t0 < t_end; t0 += BSTEP) {
-        float s[kUnroll][GT];
-        float vf[kUnroll][8];
+    for (int u0 = wave; u0 < n_units && t_begin + u0 * TPW < t_end; u0 += kWaves * kKU) {
+        float s[kKU][GT];
+        f32x2 vf[kKU][4];
 #pragma unroll
-        for (int u = 0; u < kUnroll; ++u) {
-            const int tok = t0 + u * TPW + sg;
-            float kf[8];
-            if (tok == pos) {
+        for (int u = 0; u < kKU; ++u) {
+            const int unit = u0 + u * kWaves;
+            const int tok = t_begin + unit * TPW + sg;
+            const bool live = unit < n_units && tok < t_end;
+            u32x4 kp = kr[u], vp = vr[u];
+            if (tok == pos && unit < n_units) {
                 // this lane group owns the NEW token: use the row built above and append it to the cache (cache.rs:183-188)
-                u32x4 kp;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) kp[e] = pack_bf16(knew[2 * e], knew[2 * e + 1]);
+                kp = knew;
+                vp = vnew;
                 *reinterpret_cast<u32x4*>(Kb + (size_t)pos * D + c * 8) = kp;
-                *reinterpret_cast<u32x4*>(Vb + (size_t)pos * D + c * 8) = vnew;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) kf[e] = knew[e];
-                unpack8(vnew, vf[u]);
-            } else {
-                unpack8(kr[u], kf);
-                unpack8(vr[u], vf[u]);
+                *reinterpret_cast<u32x4*>(Vb + (size_t)pos * D + c * 8) = vp;
             }
-            if (tok >= t_end) {   // a row past the position: its p is 0, but 0 * garbage must stay 0
 #pragma unroll
-                for (int e = 0; e < 8; ++e) vf[u][e] = 0.f;
-            }
+            for (int e = 0; e < 4; ++e)   // a row past the position: its p is 0, but 0 * garbage must stay 0
+                vf[u][e] = live ? f32x2{bf16lo(vp[e]), bf16hi(vp[e])} : f32x2{0.f, 0.f};
 #pragma unroll
             for (int g = 0; g < GT; ++g) {
-                float d = 0.f;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) d = fmaf(q[g][e], kf[e], d);
-                d = group_sum<LPR>(d);
-                s[u][g] = tok < t_end ? d : -INFINITY;
+                const float d = group_sum<LPR>(dot8_bf16(q[g], kp)) * a.scale;
+                s[u][g] = live ? d : -INFINITY;
             }
         }
-        if (t0 + BSTEP < t_end) issue_kv(t0 + BSTEP);   // the next step's loads do not depend on the softmax below
+        if (u0 + kWaves * kKU < n_units && t_begin + (u0 + kWaves * kKU) * TPW < t_end) issue_kv(u0 + kWaves * kKU);
 #pragma unroll
         for (int g = 0; g < GT; ++g) {                  // one running max per head for the whole wave
             float mx = s[0][g];
 #pragma unroll
-            for (int u = 1; u < kUnroll; ++u) mx = fmaxf(mx, s[u][g]);
+            for (int u = 1; u < kKU; ++u) mx = fmaxf(mx, s[u][g]);
             float wmx = readlane_f(mx, 0);
 #pragma unroll
             for (int r = 1; r < TPW; ++r) wmx = fmaxf(wmx, readlane_f(mx, r * LPR));
@@ -271,27 +282,29 @@ __global__ __launch_bounds__(kBlock, GT <= 4 ? 2 : 1) void attn_step_kernel(cons
             const float alpha = (mn == -INFINITY) ? 1.f : __expf(m[g] - mn);
             m[g] = mn;
             l[g] *= alpha;
+            const f32x2 al = {alpha, alpha};
 #pragma unroll
-            for (int e = 0; e < 8; ++e) o[g][e] *= alpha;
+            for (int e = 0; e < 4; ++e) o[g][e] *= al;
 #pragma unroll
-            for (int u = 0; u < kUnroll; ++u) {
+            for (int u = 0; u < kKU; ++u) {
                 const float p = (mn == -INFINITY) ? 0.f : __expf(s[u][g] - mn);
                 l[g] += p;
+                const f32x2 pp = {p, p};
 #pragma unroll
-                for (int e = 0; e < 8; ++e) o[g][e] = fmaf(p, vf[u][e], o[g][e]);
+                for (int e = 0; e < 4; ++e) o[g][e] = __builtin_elementwise_fma(pp, vf[u][e], o[g][e]);
             }
         }
     }
     if (TRACE && threadIdx.x == 0) tr[2] = wall_clock64();
 
     if (active) {
-        // ---- every token sub-group parks its partial in LDS (same m inside a wave: plain sums) ----
+        // ---- every token row of every wave parks its partial in LDS (same m inside a wave: plain sums) ----
 #pragma unroll
         for (int g = 0; g < GT; ++g) {
             float* dst = sm_o + (((size_t)(wave * TPW + sg) * GT + g) * D + c * 8);
-            *reinterpret_cast<f32x4*>(dst) = f32x4{o[g][0], o[g][1], o[g][2], o[g][3]};
-            *reinterpret_cast<f32x4*>(dst + 4) = f32x4{o[g][4], o[g][5], o[g][6], o[g][7]};
-            float lw = readlane_f(l[g], 0);   // the LPR lanes of a sub-group hold identical l
+            *reinterpret_cast<f32x4*>(dst) = f32x4{o[g][0][0], o[g][0][1], o[g][1][0], o[g][1][1]};
+            *reinterpret_cast<f32x4*>(dst + 4) = f32x4{o[g][2][0], o[g][2][1], o[g][3][0], o[g][3][1]};
+            float lw = readlane_f(l[g], 0);   // the LPR lanes of a row hold identical l
 #pragma unroll
             for (int r = 1; r < TPW; ++r) lw += readlane_f(l[g], r * LPR);
             if (lane == 0) {
@@ -300,7 +313,7 @@ __global__ __launch_bounds__(kBlock, GT <= 4 ? 2 : 1) void attn_step_kernel(cons
             }
         }
         __syncthreads();
-        // ---- merge the 4 waves x TPW sub-groups; the split's partial leaves as tagged granules ----
+        // ---- merge the 8 waves x TPW rows; the split's partial leaves as tagged granules ----
         for (int idx = threadIdx.x; idx < G * D; idx += kBlock) {
             const int g = idx / D, d = idx % D;
             float M = sm_m[g];
@@ -343,19 +356,18 @@ __global__ __launch_bounds__(kBlock, GT <= 4 ? 2 : 1) void attn_step_kernel(cons
 
 }  // namespace
 
-int attn_step_block_tokens(int D) { return (64 / (D / 8)) * kUnroll * kWaves; }
+int attn_step_block_tokens(int D) { return 64 / (D / 8); }   // granularity of a split's token range: one wave-instruction
 
-// token range per split and split count for a context bucket of `tk_max` tokens: ~288 blocks (one per CU plus the slack the
-// position leaves in the last bucket; never more than are co-resident: 256 for the 8-head variant), at most kMaxSplits splits
-// (the consumer gathers 3 batches of 16), at least G (one consumer block per query head of a KV group)
+// token range per split and split count for a context bucket of `tk_max` tokens: one block per CU (<= 256 blocks: every block
+// of the launch is resident, the consumers cannot starve a producer), at most kMaxSplits splits (the consumer gathers 3
+// batches of 16), at least G (one consumer block per query head of a KV group)
 constexpr int kMaxSplits = 48;
 void attn_step_plan(int tk_max, int Hkv, int G, int D, int* chunk, int* nsplit) {
-    const int bs = attn_step_block_tokens(D);
-    const int blocks = G > 4 ? 256 : 288;
-    int target = std::max(1, std::min(kMaxSplits, blocks / std::max(Hkv, 1)));
+    const int unit = attn_step_block_tokens(D);
+    int target = std::max(1, std::min(kMaxSplits, 256 / std::max(Hkv, 1)));
     if (const char* v = getenv("OMX_ATTN_STEP_SPLITS")) target = std::max(1, std::min(kMaxSplits, atoi(v)));
-    int ch = bs * ((tk_max + bs * target - 1) / (bs * target));
-    if (ch < bs) ch = bs;
+    int ch = unit * ((tk_max + unit * target - 1) / (unit * target));
+    if (ch < unit) ch = unit;
     int ns = (tk_max + ch - 1) / ch;
     if (ns < G) ns = G;
     *chunk = ch;
@@ -367,15 +379,15 @@ size_t attn_step_ws_granules(int H, int D) { return (size_t)H * kMaxSplits * (D 
 int launch_attn_step(const AttnStepArgs& a, int D, hipStream_t s) {
     const int G = a.H / a.Hkv;
     OMX_REQUIRE(a.H % a.Hkv == 0 && G >= 1 && G <= 8, "decode attention: %d query heads over %d KV heads unsupported (group of at most 8)", a.H, a.Hkv);
-    OMX_REQUIRE(a.nsplit >= G && a.nsplit <= kMaxSplits && a.chunk > 0 && a.chunk % attn_step_block_tokens(D) == 0,
-                "decode attention: bad split plan (chunk %d, %d splits, group %d)", a.chunk, a.nsplit, G);
+    OMX_REQUIRE(a.nsplit >= G && a.nsplit <= kMaxSplits && a.chunk > 0 && a.chunk % attn_step_block_tokens(D) == 0 && a.Hkv * a.nsplit <= 256,
+                "decode attention: bad split plan (chunk %d, %d splits, group %d, %d kv heads)", a.chunk, a.nsplit, G, a.Hkv);
     OMX_REQUIRE(a.ws && a.rope_cur && a.pos_ptr && a.seq_ptr && a.abort_flag && a.tag_mul > a.tag_add - 1u && a.tag_add >= 1u,
                 "decode attention: missing step state");
     const dim3 grid(a.Hkv, a.nsplit), block(kBlock);
     const int gt = G <= 1 ? 1 : G <= 2 ? 2 : G <= 4 ? 4 : 8;
 #define OMX_ATTN_STEP_CASE(DD, GG)                                                                                       \
     if (D == DD && gt == GG) {                                                                                           \
-        const size_t shmem = ((size_t)kWaves * (64 / (DD / 8)) * GG * DD + 2 * kWaves * GG + 4) * sizeof(float);         \
+        const size_t shmem = ((size_t)kWaves * (64 / (DD / 8)) * GG * DD + 2 * kWaves * GG) * sizeof(float) + (size_t)(GG + 1) * (DD / 8) * 16; \
         if (shmem > 48 * 1024) {                                                                                         \
             OMX_HIP_CHECK(hipFuncSetAttribute((const void*)attn_step_kernel<DD, GG, false>,                             \
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));                  \

@@ -25,10 +25,9 @@
 
 #include "attn.hpp"
 #include "workspace.hpp"
-#include "decode_mega.hpp"
+#include "step_state.hpp"
 #include "gemm.hpp"
 #include "gemv.hpp"
-#include "gridsync.hpp"
 #include "random.hpp"
 #include "prefill.hpp"
 #include "quant.hpp"
@@ -104,7 +103,7 @@ __global__ void rope_table_kernel(float* cos_t, float* sin_t, int cap, int half,
     sin_t[idx] = (float)s;
 }
 
-// step state updates (single thread; a few dozen ns of work, they only order the graph); StepState: decode_mega.hpp
+// step state updates (single thread; a few dozen ns of work, they only order the graph); StepState: step_state.hpp
 
 __global__ void feed_prompt_kernel(StepState* st, const uint32_t* prompt) {
     // after a no-head prefill step: advance and feed the next prompt token
@@ -188,17 +187,9 @@ struct omx_qwen3_ {
     float *partial_a = nullptr, *partial_b = nullptr;   // TP: f32 partial sums awaiting all-reduce
     unsigned long long *argmax_partials = nullptr, *argmax_key = nullptr;
     int n_argmax_partials = 0;
-    float *ws_o = nullptr, *ws_ml = nullptr;
-    unsigned* attn_arrive = nullptr;   // per-KV-head arrival counters of the in-launch split combine (attn_decode.hip)
-    // attention + O projection in one launch (attn_decode.hip): per-layer completion words, the step sequence number they
-    // carry, and the word a wait that gave up sets
-    unsigned *attn_done = nullptr, *step_seq = nullptr, *wait_abort = nullptr;
-    bool fuse_oproj = false;
-    int oproj_rpw = 0, oproj_blocks = 0;
-    int nsplit = 1;
+    unsigned *step_seq = nullptr, *wait_abort = nullptr;   // step sequence number (granule tags), word a gather that gave up raises
     // attention of the decode step (attn_step.hip): the split plan is fixed per captured graph and covers positions < graph_tk_max;
     // the graphs are rebuilt when the context outgrows that bucket
-    bool attn_step = true;
     float* rope_cur = nullptr;            // [D] cos | sin of the current position
     uint64_t* attn_gran = nullptr;        // split partials as tagged granules
     int attn_chunk = 0, attn_nsplit = 0, graph_tk_max = 0;
@@ -217,15 +208,6 @@ struct omx_qwen3_ {
     bf16_t *pf_h = nullptr, *pf_h2 = nullptr, *pf_xn = nullptr, *pf_q = nullptr, *pf_k = nullptr, *pf_v = nullptr,
            *pf_qt = nullptr, *pf_attn = nullptr, *pf_g = nullptr, *pf_u = nullptr;
     float last_prefill_ms = 0.f;
-
-    // persistent one-kernel-per-token path (decode_mega.hip); the step graph below is the fallback
-    bool mega = false;
-    int mega_blocks = 0, mega_attn_blocks = 0;
-    MegaLayer* mega_layers = nullptr;
-    unsigned *mega_sync = nullptr, *mega_kv_count = nullptr;
-    unsigned long long* mega_partials = nullptr;
-    unsigned mega_epoch = 1;
-    unsigned long long* mega_trace = nullptr;   // set for one step by omx_qwen3_debug_trace_step
 
     hipGraphExec_t g_full = nullptr, g_nohead = nullptr;
     bool eager = false;          // fallback when stream capture is unavailable (e.g. a collective refuses capture)
@@ -360,7 +342,7 @@ int enqueue_attention(omx_qwen3 m, int l, hipStream_t s) {
     const omx_qwen3_config& c = m->cfg;
     const int D = c.head_dim;
     const LayerW& L = m->layers[l];
-    if (m->attn_step) {
+    {
         AttnStepArgs a = {};
         a.qkv = m->qkv;
         a.k = m->kcache[l]; a.v = m->vcache[l];
@@ -380,22 +362,6 @@ int enqueue_attention(omx_qwen3 m, int l, hipStream_t s) {
         a.trace = m->attn_trace ? m->attn_trace + (size_t)l * m->attn_nsplit * m->Hkv * 8 : nullptr;
         return launch_attn_step(a, D, s);
     }
-    AttnDecodeArgs a = {};
-    a.qkv = m->qkv;
-    a.k = m->kcache[l]; a.v = m->vcache[l];
-    a.kv_batch_stride = 0; a.kv_head_stride = (int64_t)m->cap * D;
-    a.B = 1; a.H = m->H; a.Hkv = m->Hkv;
-    a.scale = 1.0f / sqrtf((float)D);
-    a.mask_mode = OMX_MASK_NONE;
-    a.nsplit = m->nsplit;
-    a.ws_o = m->ws_o; a.ws_ml = m->ws_ml;
-    a.arrive = m->attn_arrive;
-    a.out = m->attn_out;
-    a.pos_ptr = &m->st->pos;
-    a.q_norm_w = L.q_norm; a.k_norm_w = L.k_norm;
-    a.rope_cos = m->rope_cos; a.rope_sin = m->rope_sin;
-    a.eps = c.rms_norm_eps;
-    return launch_attn_decode(a, D, true, s);
 }
 
 // the same step on a quantized checkpoint: packed-weight GEMVs (quant.hip) with the prologues / epilogues of the bf16 step
@@ -503,37 +469,8 @@ int enqueue_step(omx_qwen3 m, bool with_head) {
             if (launch_gemv(a, PRO_RMSNORM, EPI_STORE, s)) return 1;
             if (pending) { bf16_t* t = h; h = hn; hn = t; pending = nullptr; }
         }
-        const bool fused_o = m->fuse_oproj && !tp && !m->attn_step;
-        if (m->attn_step) {   // [q/k RMSNorm + RoPE + cache append + split-KV SDPA + merge]  model.rs:172-210
-            if (enqueue_attention(m, l, s)) return 1;
-        } else {
-            AttnDecodeArgs a = {};
-            a.qkv = m->qkv;
-            a.k = m->kcache[l]; a.v = m->vcache[l];
-            a.kv_batch_stride = 0; a.kv_head_stride = (int64_t)m->cap * D;
-            a.B = 1; a.H = m->H; a.Hkv = m->Hkv;
-            a.scale = 1.0f / sqrtf((float)D);
-            a.mask_mode = OMX_MASK_NONE;
-            a.nsplit = m->nsplit;
-            a.ws_o = m->ws_o; a.ws_ml = m->ws_ml;
-            a.arrive = m->attn_arrive;
-            a.out = m->attn_out;
-            a.pos_ptr = &m->st->pos;
-            a.q_norm_w = L.q_norm; a.k_norm_w = L.k_norm;
-            a.rope_cos = m->rope_cos; a.rope_sin = m->rope_sin;
-            a.eps = c.rms_norm_eps;
-            if (fused_o) {
-                // [attention + combine + O GEMV + residual] in ONE launch: the O rows are in registers when the attention ends
-                a.done = m->attn_done + (size_t)l * m->Hkv * 16;
-                a.seq_ptr = m->step_seq;
-                OProjArgs o = {L.o, h, hn, hd, m->H * D, m->oproj_rpw, m->oproj_blocks, m->wait_abort};
-                if (launch_attn_oproj(a, o, D, s)) return 1;
-                bf16_t* t = h; h = hn; hn = t;
-            } else if (launch_attn_decode(a, D, true, s)) {
-                return 1;
-            }
-        }
-        if (!fused_o) {   // [O GEMV + residual]  model.rs:214,325
+        if (enqueue_attention(m, l, s)) return 1;   // [q/k RMSNorm + RoPE + cache append + split-KV SDPA + merge]  model.rs:172-210
+        {   // [O GEMV + residual]  model.rs:214,325
             GemvArgs a = {};
             a.w0 = L.o; a.n0 = hd; a.N = hd; a.K = m->H * D;
             a.x = m->attn_out;
@@ -630,43 +567,9 @@ int enqueue_step(omx_qwen3 m, bool with_head) {
 }
 
 
-// The persistent one-kernel-per-token path: eligible for the single-GPU dense decoder when decode_mega.hip has an
-// instantiation for the shape.  OMX_DECODE_MEGA=0 forces the step graph (the two must agree bit for bit).
-int setup_mega(omx_qwen3 m) {
-    const omx_qwen3_config& c = m->cfg;
-    const char* env = getenv("OMX_DECODE_MEGA");
-    if (!env || env[0] != '1') return 0;   // opt-in until it beats the step graph
-    if (c.tp_size > 1 || m->allreduce != nullptr || c.num_hidden_layers < 1 || c.quant_bits || m->temperature != 0.f || c.num_experts > 0) return 0;
-    if (!mega_supported(c.hidden_size, m->H * c.head_dim, m->I, c.head_dim, m->H / m->Hkv)) return 0;
-    int capacity = 0;
-    if (mega_capacity(c.hidden_size, m->H * c.head_dim, m->I, &capacity)) return 1;
-    int blocks = capacity < 512 ? capacity : 512;
-    if (const char* v = getenv("OMX_MEGA_BLOCKS")) blocks = atoi(v) > 0 && atoi(v) < blocks ? atoi(v) : blocks;
-    if (blocks < 16 || (c.hidden_size + blocks - 1) / blocks > 64) return 0;   // not enough co-resident blocks: step graph
-    m->mega_blocks = blocks;
-    m->mega_attn_blocks = blocks - blocks / 4;   // at least a quarter of the blocks keep the O-projection rows
-    if (const char* v = getenv("OMX_MEGA_ATTN_BLOCKS")) m->mega_attn_blocks = atoi(v) >= 1 && atoi(v) < blocks ? atoi(v) : m->mega_attn_blocks;
-    std::vector<MegaLayer> host(c.num_hidden_layers);
-    for (int l = 0; l < c.num_hidden_layers; ++l) {
-        const LayerW& L = m->layers[l];
-        host[l] = MegaLayer{L.q, L.k, L.v, L.o, L.gate, L.up, L.down, L.q_norm, L.k_norm, L.in_ln, L.post_ln,
-                            m->kcache[l], m->vcache[l]};
-    }
-    if (dev_alloc(m, &m->mega_layers, host.size()) || dev_alloc(m, &m->mega_sync, grid_sync_words(blocks)) ||
-        dev_alloc(m, &m->mega_kv_count, (size_t)m->Hkv * 16) || dev_alloc(m, &m->mega_partials, (size_t)blocks))
-        return 1;
-    OMX_HIP_CHECK(hipMemcpyAsync(m->mega_layers, host.data(), host.size() * sizeof(MegaLayer), hipMemcpyHostToDevice, m->stream));
-    OMX_HIP_CHECK(hipStreamSynchronize(m->stream));   // `host` goes out of scope
-    m->mega_epoch = 1;
-    m->mega = true;
-    return 0;
-}
-
 int build_graphs(omx_qwen3 m) {
-    if (m->mega || m->g_full || m->eager) return 0;
+    if (m->g_full || m->eager) return 0;
     if (resolve_weights(m)) return 1;
-    if (setup_mega(m)) return 1;
-    if (m->mega) return 0;
     const char* no_graph = getenv("OMX_NO_GRAPH");
     if (no_graph && no_graph[0] == '1') {
         m->eager = true;
@@ -700,7 +603,7 @@ int build_graphs(omx_qwen3 m) {
 // (attn_step.hip: fixed token ranges per split, so that nothing the kernel loads first depends on the position): one plan per
 // context bucket of 1024 tokens (4096 beyond 8 k), the graphs are rebuilt when the position enters another bucket.
 int prepare_step(omx_qwen3 m, int pos) {
-    if (m->attn_step && !m->mega) {
+    {
         const int tk = pos + 1, gran = tk <= 8192 ? 1024 : 4096;
         const int want = std::min(m->cap, (tk + gran - 1) / gran * gran);
         if (want != m->graph_tk_max) {
@@ -715,29 +618,6 @@ int prepare_step(omx_qwen3 m, int pos) {
 
 int run_step(omx_qwen3 m, bool with_head, int pos) {
     if (prepare_step(m, pos)) return 1;
-    if (m->mega) {
-        const omx_qwen3_config& c = m->cfg;
-        MegaArgs a = {};
-        a.layers = m->mega_layers;
-        a.n_layers = c.num_hidden_layers; a.hidden = c.hidden_size; a.H = m->H; a.Hkv = m->Hkv; a.I = m->I; a.V = m->V;
-        a.cap = m->cap;
-        a.eps = c.rms_norm_eps; a.scale = 1.0f / sqrtf((float)c.head_dim);
-        a.embed = m->embed; a.final_norm = m->final_norm; a.lm_head = m->lm_head;
-        a.rope_cos = m->rope_cos; a.rope_sin = m->rope_sin;
-        a.st = m->st;
-        a.h0 = m->h; a.h1 = m->h2; a.qkv = m->qkv; a.attn_out = m->attn_out; a.act = m->act; a.logits = m->logits;
-        a.ws_o = m->ws_o; a.ws_ml = m->ws_ml; a.nsplit = m->nsplit;
-        a.attn_blocks = m->mega_attn_blocks;
-        a.sync_words = m->mega_sync; a.epoch0 = m->mega_epoch;
-        a.kv_count = m->mega_kv_count;
-        a.argmax_partials = m->mega_partials;
-        a.out_ring = m->out_ring; a.ring_cap = m->ring_cap; a.prompt = m->prompt_dev;
-        a.with_head = with_head ? 1 : 0;
-        a.trace = m->mega_trace;
-        if (launch_decode_mega(a, m->mega_blocks, m->stream)) return 1;
-        m->mega_epoch += mega_barriers(a.n_layers, a.with_head);
-        return 0;
-    }
     if (m->eager) return enqueue_step(m, with_head);
     OMX_HIP_CHECK(hipGraphLaunch(with_head ? m->g_full : m->g_nohead, m->stream));
     return 0;
@@ -777,23 +657,10 @@ int enqueue_head_on_row(omx_qwen3 m, const bf16_t* row, hipStream_t s) {
 //   RMSNorm -> gate/up GEMM -> silu*up -> down GEMM + residual.        (model.rs:161-215,263-267,321-332)
 // The last layer stops after its cache scatter: nothing downstream of it is consumed for these tokens.
 // a device-wide barrier of the persistent kernel gave up (a block never arrived): the step's results are void
-int mega_health(omx_qwen3 m) {
-    if (!m->mega && m->attn_step) {
-        unsigned gave_up = 0;
-        OMX_HIP_CHECK(hipMemcpy(&gave_up, m->wait_abort, 4, hipMemcpyDeviceToHost));
-        OMX_REQUIRE(gave_up == 0, "decode attention: a split merge gave up waiting for a partial (blocks not co-resident?); set OMX_ATTN_STEP=0");
-        return 0;
-    }
-    if (!m->mega && m->fuse_oproj) {
-        unsigned gave_up = 0;
-        OMX_HIP_CHECK(hipMemcpy(&gave_up, m->wait_abort, 4, hipMemcpyDeviceToHost));
-        OMX_REQUIRE(gave_up == 0, "fused attention + O projection: an O block gave up waiting for the attention blocks (not co-resident?); set OMX_ATTN_OPROJ=0");
-        return 0;
-    }
-    if (!m->mega) return 0;
-    unsigned abort_word = 0;
-    OMX_HIP_CHECK(hipMemcpy(&abort_word, m->mega_sync + 16, 4, hipMemcpyDeviceToHost));
-    OMX_REQUIRE(abort_word == 0, "decode megakernel: a device-wide barrier timed out (blocks not co-resident?); set OMX_DECODE_MEGA=0");
+int step_health(omx_qwen3 m) {
+    unsigned gave_up = 0;
+    OMX_HIP_CHECK(hipMemcpy(&gave_up, m->wait_abort, 4, hipMemcpyDeviceToHost));
+    OMX_REQUIRE(gave_up == 0, "decode attention: a split merge gave up waiting for a partial (a block of the launch was not resident?)");
     return 0;
 }
 
@@ -1005,11 +872,6 @@ int omx_qwen3_create(omx_qwen3* out, const omx_qwen3_config* cfg) {
                                                                   (double)m->cfg.rope_scale);
         OMX_LAUNCH_CHECK();
     }
-    int tok_per_split = 64;
-    if (const char* v = getenv("OMX_ATTN_SPLIT_TOKENS")) tok_per_split = atoi(v) > 0 ? atoi(v) : 64;
-    m->nsplit = (m->cap + tok_per_split - 1) / tok_per_split;
-    const int cap_splits = (512 + m->Hkv - 1) / m->Hkv;
-    if (m->nsplit > cap_splits) m->nsplit = cap_splits;
     if (c.num_experts > 0) {
         OMX_REQUIRE(c.tp_size == 1, "InvalidConfig: the sparse-MoE engine shards experts (ep_size), not heads (tp_size %d)", c.tp_size);
         OMX_REQUIRE(c.ep_size <= 1 || (c.ep_rank >= 0 && c.ep_rank < c.ep_size && c.num_experts % c.ep_size == 0 && !c.quant_bits),
@@ -1027,38 +889,14 @@ int omx_qwen3_create(omx_qwen3* out, const omx_qwen3_config* cfg) {
         if (get_workspace(&ws, need)) return 1;
         if (dev_alloc(m, &m->moe_xn, (size_t)c.hidden_size) || dev_alloc(m, &m->moe_out, (size_t)c.hidden_size)) return 1;
     }
-    {   // attention + O projection in one launch: every block must be co-resident (the O blocks wait for the attention ones)
-        const char* fenv = getenv("OMX_ATTN_OPROJ");
-        const int hd_att = m->H * D;
-        const bool eligible = c.tp_size == 1 && !c.quant_bits && hd_att % 512 == 0;
-        const int capacity = eligible ? attn_oproj_capacity(D, m->H / m->Hkv, hd_att) : 0;
-        if (capacity >= 64) {
-            // the split count is capped whether or not the fusion is switched on: OMX_ATTN_OPROJ=0 then computes the same bits
-            const int max_split = std::max(1, capacity / 2 / m->Hkv);
-            if (m->nsplit > max_split) m->nsplit = max_split;
-        }
-        if (capacity >= 64 && fenv && fenv[0] == '1') {   // opt-in: measured +0.3 %; the step graph default stays wait-free
-            const int room = capacity - m->Hkv * m->nsplit;
-            int rpw = 2;
-            while ((c.hidden_size + 4 * rpw - 1) / (4 * rpw) > room && rpw < 64) rpw += 2;
-            if ((c.hidden_size + 4 * rpw - 1) / (4 * rpw) <= room) {
-                m->fuse_oproj = true;
-                m->oproj_rpw = rpw;
-                m->oproj_blocks = (c.hidden_size + 4 * rpw - 1) / (4 * rpw);
-            }
-        }
-    }
-    if (const char* v = getenv("OMX_ATTN_STEP")) m->attn_step = v[0] != '0';
     if (dev_alloc(m, &m->rope_cur, (size_t)D) || dev_alloc(m, &m->attn_gran, attn_step_ws_granules(m->H, D))) return 1;
-    if (dev_alloc(m, &m->attn_done, (size_t)L * m->Hkv * 16) || dev_alloc(m, &m->step_seq, 16) || dev_alloc(m, &m->wait_abort, 16)) return 1;
+    if (dev_alloc(m, &m->step_seq, 16) || dev_alloc(m, &m->wait_abort, 16)) return 1;
     if (dev_alloc(m, &m->st, 1) || dev_alloc(m, &m->out_ring, (size_t)m->ring_cap) ||
         dev_alloc(m, &m->h, (size_t)c.hidden_size) || dev_alloc(m, &m->h2, (size_t)c.hidden_size) ||
         dev_alloc(m, &m->qkv, (size_t)(m->H + 2 * m->Hkv) * D) || dev_alloc(m, &m->attn_out, (size_t)m->H * D) ||
         dev_alloc(m, &m->act, (size_t)m->I) || dev_alloc(m, &m->logits, (size_t)m->V) ||
         dev_alloc(m, &m->partial_a, (size_t)c.hidden_size) || dev_alloc(m, &m->partial_b, (size_t)c.hidden_size) ||
-        dev_alloc(m, &m->argmax_key, 1) || dev_alloc(m, &m->ws_o, (size_t)m->H * m->nsplit * D) ||
-        dev_alloc(m, &m->attn_arrive, (size_t)m->Hkv * 16) ||
-        dev_alloc(m, &m->ws_ml, (size_t)m->H * m->nsplit * 2))
+        dev_alloc(m, &m->argmax_key, 1))
         return 1;
     m->prompt_cap = m->cap;
     if (dev_alloc(m, &m->prompt_dev, (size_t)m->prompt_cap + 1)) return 1;
@@ -1092,7 +930,7 @@ int omx_qwen3_destroy(omx_qwen3 m) {
 int omx_qwen3_set_weight(omx_qwen3 m, const char* name, const void* ptr) {
     OMX_REQUIRE(m && name && ptr, "omx_qwen3_set_weight: null argument");
     OMX_REQUIRE(((uintptr_t)ptr & 15u) == 0, "omx_qwen3_set_weight: %s is not 16-byte aligned", name);
-    OMX_REQUIRE(m->g_full == nullptr && !m->mega, "omx_qwen3_set_weight: weights are frozen once the decode step is built");
+    OMX_REQUIRE(m->g_full == nullptr, "omx_qwen3_set_weight: weights are frozen once the decode step is built");
     m->named[name] = ptr;
     m->weights_resolved = false;
     return 0;
@@ -1208,7 +1046,7 @@ int omx_qwen3_synth_weights(omx_qwen3 m, uint32_t base_seed) {
 
 int omx_qwen3_set_comm(omx_qwen3 m, void* comm, void* allreduce_fn) {
     OMX_REQUIRE(m, "omx_qwen3_set_comm: null model");
-    OMX_REQUIRE(m->g_full == nullptr && !m->eager && !m->mega, "omx_qwen3_set_comm: communicator must be set before the first step");
+    OMX_REQUIRE(m->g_full == nullptr && !m->eager, "omx_qwen3_set_comm: communicator must be set before the first step");
     m->comm = comm;
     m->allreduce = (nccl_allreduce_fn)allreduce_fn;
     return 0;
@@ -1217,7 +1055,6 @@ int omx_qwen3_set_comm(omx_qwen3 m, void* comm, void* allreduce_fn) {
 int omx_qwen3_set_sampler(omx_qwen3 m, float temperature, uint64_t seed) {
     OMX_REQUIRE(m, "omx_qwen3_set_sampler: null model");
     OMX_REQUIRE(temperature >= 0.f && temperature == temperature, "omx_qwen3_set_sampler: temperature %f must be >= 0", (double)temperature);
-    OMX_REQUIRE(!m->mega, "omx_qwen3_set_sampler: the persistent decode kernel samples greedily; set the sampler before the first step");
     if (!m->rng && dev_alloc(m, &m->rng, 4)) return 1;
     if (omx_random_key(m->rng, seed, (omx_stream)m->stream)) return 1;
     OMX_HIP_CHECK(hipStreamSynchronize(m->stream));
@@ -1309,7 +1146,7 @@ int omx_qwen3_prefill(omx_qwen3 m, const uint32_t* prompt, int n_prompt, uint32_
         // tile count does not change, instead of a 36-layer GEMV pass); OMX_PREFILL_TAIL_STEP=1: n-1 tokens batched and
         // the decode step for the last one
         const char* tail_env = getenv("OMX_PREFILL_TAIL_STEP");
-        const bool tail_step = (tail_env && tail_env[0] == '1') || m->mega;
+        const bool tail_step = tail_env && tail_env[0] == '1';
         const int nb = tail_step ? n_prompt - 1 : n_prompt;
         if (prefill_prefix_batched(m, nb, st.pos, nullptr, !tail_step)) return 1;
         st.pos += n_prompt - 1;
@@ -1326,7 +1163,7 @@ int omx_qwen3_prefill(omx_qwen3 m, const uint32_t* prompt, int n_prompt, uint32_
     OMX_HIP_CHECK(hipMemcpyAsync(first_token, m->out_ring + (count_before % m->ring_cap), 4, hipMemcpyDeviceToHost, m->stream));
     OMX_HIP_CHECK(hipStreamSynchronize(m->stream));
     OMX_HIP_CHECK(hipEventElapsedTime(&m->last_prefill_ms, m->ev0, m->ev1));
-    return mega_health(m);
+    return step_health(m);
 }
 
 int omx_qwen3_last_prefill_ms(omx_qwen3 m, float* ms) {
@@ -1350,7 +1187,7 @@ int omx_qwen3_decode(omx_qwen3 m, int n, uint32_t* tokens_out) {
     OMX_HIP_CHECK(hipEventRecord(m->ev1, m->stream));
     OMX_HIP_CHECK(hipStreamSynchronize(m->stream));
     OMX_HIP_CHECK(hipEventElapsedTime(&m->last_decode_ms, m->ev0, m->ev1));
-    if (mega_health(m)) return 1;
+    if (step_health(m)) return 1;
     std::vector<uint32_t> ring(m->ring_cap);
     OMX_HIP_CHECK(hipMemcpy(ring.data(), m->out_ring, (size_t)m->ring_cap * 4, hipMemcpyDeviceToHost));
     for (int i = 0; i < n; ++i) tokens_out[i] = ring[(st.out_count + i) % m->ring_cap];
@@ -1398,55 +1235,35 @@ int omx_qwen3_stream(omx_qwen3 m, omx_stream* s) {
     return 0;
 }
 
-/* debug hook: run ONE decode step with a timeline on; 100 MHz wall-clock stamps.
- *   step graph (tools/attn_step_trace.py): the step runs eagerly with the attention launches stamping
- *     [layers][attn splits][kv heads][8] = {start, loads+norm done, chunk done, granules stored, gathered, -, -, -};
- *     *blocks = splits * kv heads;
- *   persistent kernel (tools/mega_trace.py): [layers][kTraceEvents][blocks] */
+/* debug hook (tools/attn_step_trace.py): run ONE decode step eagerly with the attention launches stamping the 100 MHz wall clock:
+ * host receives [layers][attn splits][kv heads][8] = {block start, loads landed + q/k normed and roped, own chunk done, granules
+ * stored, gathered and merged (consumer blocks), -, -, -}; *blocks = splits * kv heads */
 int omx_qwen3_debug_trace_step(omx_qwen3 m, unsigned long long* host, size_t n_words, int* blocks) {
     OMX_REQUIRE(m && host && blocks, "omx_qwen3_debug_trace_step: null argument");
     StepState st;
     OMX_HIP_CHECK(hipMemcpyAsync(&st, m->st, sizeof(st), hipMemcpyDeviceToHost, m->stream));
     OMX_HIP_CHECK(hipStreamSynchronize(m->stream));
     if (prepare_step(m, st.pos)) return 1;
-    if (!m->mega) {
-        OMX_REQUIRE(m->attn_step, "omx_qwen3_debug_trace_step: neither the persistent kernel nor the step attention kernel is in use");
-        const size_t per_layer = (size_t)m->attn_nsplit * m->Hkv * 8, need = per_layer * m->cfg.num_hidden_layers;
-        OMX_REQUIRE(n_words >= need, "omx_qwen3_debug_trace_step: buffer of %zu words, need %zu", n_words, need);
-        unsigned long long* dev = nullptr;
-        OMX_HIP_CHECK(hipMalloc(&dev, need * 8));
-        OMX_HIP_CHECK(hipMemsetAsync(dev, 0, need * 8, m->stream));
-        m->attn_trace = dev;
-        const int rc = enqueue_step(m, true);
-        m->attn_trace = nullptr;
-        if (!rc) {
-            OMX_HIP_CHECK(hipStreamSynchronize(m->stream));
-            OMX_HIP_CHECK(hipMemcpy(host, dev, need * 8, hipMemcpyDeviceToHost));
-        }
-        (void)hipFree(dev);
-        *blocks = m->attn_nsplit * m->Hkv;
-        return rc ? 1 : mega_health(m);
-    }
-    const size_t need = (size_t)m->cfg.num_hidden_layers * kTraceEvents * m->mega_blocks;
+    const size_t per_layer = (size_t)m->attn_nsplit * m->Hkv * 8, need = per_layer * m->cfg.num_hidden_layers;
     OMX_REQUIRE(n_words >= need, "omx_qwen3_debug_trace_step: buffer of %zu words, need %zu", n_words, need);
     unsigned long long* dev = nullptr;
     OMX_HIP_CHECK(hipMalloc(&dev, need * 8));
     OMX_HIP_CHECK(hipMemsetAsync(dev, 0, need * 8, m->stream));
-    m->mega_trace = dev;
-    const int rc = run_step(m, true, st.pos);
-    m->mega_trace = nullptr;
+    m->attn_trace = dev;
+    const int rc = enqueue_step(m, true);
+    m->attn_trace = nullptr;
     if (!rc) {
         OMX_HIP_CHECK(hipStreamSynchronize(m->stream));
         OMX_HIP_CHECK(hipMemcpy(host, dev, need * 8, hipMemcpyDeviceToHost));
     }
     (void)hipFree(dev);
-    *blocks = m->mega_blocks;
-    return rc ? 1 : mega_health(m);
+    *blocks = m->attn_nsplit * m->Hkv;
+    return rc ? 1 : step_health(m);
 }
 
 int omx_qwen3_decode_path(omx_qwen3 m, int* path) {
     OMX_REQUIRE(m && path, "omx_qwen3_decode_path: null argument");
-    *path = m->mega ? 3 : m->eager ? 2 : m->g_full ? 1 : 0;
+    *path = m->eager ? 2 : m->g_full ? 1 : 0;
     return 0;
 }
 

@@ -37,18 +37,14 @@ __device__ __forceinline__ uint64_t argmax_key(float v, uint32_t idx) {
     return ((uint64_t)u << 32) | (uint32_t)(~idx);
 }
 
-// resid: the row's residual-stream value for EPI_RESIDUAL, loaded by the caller at kernel START (a load issued here would be
-// one more dependent memory round trip at the very end of the kernel)
-__device__ __forceinline__ void out_bf16(const GemvArgs& a, int row, bf16_t v) { reinterpret_cast<bf16_t*>(a.out)[row] = v; }
-
 template <int EPI>
-__device__ __forceinline__ void epilogue(const GemvArgs& a, int row, float v0, float v1, uint64_t& best, float resid = 0.f) {
+__device__ __forceinline__ void epilogue(const GemvArgs& a, int row, float v0, float v1, uint64_t& best) {
     if (EPI == EPI_STORE) {
-        out_bf16(a, row, f32_to_bf16(a.out_bias ? v0 + bf16_to_f32(a.out_bias[row]) : v0));
+        reinterpret_cast<bf16_t*>(a.out)[row] = f32_to_bf16(a.out_bias ? v0 + bf16_to_f32(a.out_bias[row]) : v0);
     } else if (EPI == EPI_F32) {
         reinterpret_cast<float*>(a.out)[row] = v0;
     } else if (EPI == EPI_RESIDUAL) {
-        out_bf16(a, row, f32_to_bf16(resid + round_bf16(v0)));
+        reinterpret_cast<bf16_t*>(a.out)[row] = f32_to_bf16(bf16_to_f32(a.resid[row]) + round_bf16(v0));
     } else if (EPI == EPI_SWIGLU) {
         // nn::silu(gate) * up, every primitive's result held in bf16
         // (qwen3-mlx/src/model.rs:264-265; mlx-rs/src/nn/activation.rs:876-880)
@@ -56,10 +52,10 @@ __device__ __forceinline__ void epilogue(const GemvArgs& a, int row, float v0, f
         const float u = round_bf16(v1);
         if (a.swiglu_single_round) {
             // mlx_rs_core::fused_swiglu(up, gate) (metal_kernels.rs:11-18): one kernel, one rounding
-            out_bf16(a, row, f32_to_bf16(g / (1.0f + expf(-g)) * u));
+            reinterpret_cast<bf16_t*>(a.out)[row] = f32_to_bf16(g / (1.0f + expf(-g)) * u);
         } else {
             const float sg = round_bf16(1.0f / (1.0f + expf(-g)));
-            out_bf16(a, row, f32_to_bf16(round_bf16(g * sg) * u));
+            reinterpret_cast<bf16_t*>(a.out)[row] = f32_to_bf16(round_bf16(g * sg) * u);
         }
     } else if (EPI == EPI_ARGMAX) {
         const bf16_t lb = f32_to_bf16(v0);
@@ -155,8 +151,7 @@ __global__ __launch_bounds__(kBlock) void gemv_kernel(const GemvArgs a_in) {
                 const int row = (R0) + r;                                                          \
                 if (row < row_end) {                                                               \
                     if (KSPLIT == 1) {                                                             \
-                        const float rv = (EPI == EPI_RESIDUAL) ? bf16_to_f32(rpw <= 64 ? (bf16_t)__builtin_amdgcn_readlane((int)resid_pre, row - row_begin) : a.resid[row]) : 0.f; \
-                        epilogue<EPI>(a, row, acc[LR * r], acc[LR * r + (LR - 1)], best, rv);      \
+                        epilogue<EPI>(a, row, acc[LR * r], acc[LR * r + (LR - 1)], best);          \
                     } else {                                                                       \
                         const int lr = row - row_begin;                                            \
                         part[(lr * LR) * KSPLIT + wave] = acc[LR * r];                             \
@@ -167,68 +162,50 @@ __global__ __launch_bounds__(kBlock) void gemv_kernel(const GemvArgs a_in) {
         }                                                                                          \
     }
 
-    // ---- loads of the first round: the activation (+ norm weight, residual rows, TP partial) FIRST, then the first weight
-    //      batch.  Loads return in issue order: the small ones are back after one round trip and the prologue below runs while
-    //      the weight batch is still landing (with the weights first -- the round-1 order, -DOMX_GEMV_XFIRST=0 -- the activation
-    //      queued behind 16 KiB per wave and the prologue started 3-4 us into the kernel, tools/gemv_trace.py).
-    //      Straight-line code on purpose: any branch around these loads makes hipcc merge the wait state of both arms and
-    //      every counted wait below degrades to vmcnt(0).  Out-of-range lanes re-read a clamped vector; the optional f32
-    //      partial is read through a pointer that is valid either way (the weight matrix stands in when there is none). ----
-#ifndef OMX_GEMV_XFIRST
-#define OMX_GEMV_XFIRST 1
-#endif
-    const bf16_t* xg = a.x + (a.x_row ? (size_t)a.x_row[0] * K : 0);
-    constexpr int NVT = NV * 64;                            // activation vectors the instantiation covers
-    constexpr int PV = (NVT + kBlock - 1) / kBlock;         // per thread
-    const bool has_partial = a.x_partial != nullptr;
-    const f32x4* xp = reinterpret_cast<const f32x4*>(has_partial ? a.x_partial : reinterpret_cast<const float*>(a.w0));
-    u32x4 xv[PV], nwv[PV];
-    f32x4 pp0[PV], pp1[PV];
-    bf16_t resid_pre = 0;   // kept as raw bits: converting here would make the compiler wait for the load on the spot
-    auto load_x = [&]() {
-#pragma unroll
-        for (int i = 0; i < PV; ++i) {
-            const int v = min((int)threadIdx.x + i * kBlock, (TAIL ? kvec : NVT) - 1);
-            xv[i] = *(reinterpret_cast<const u32x4*>(xg) + v);
-            if (PRO == PRO_RMSNORM) nwv[i] = *(reinterpret_cast<const u32x4*>(a.norm_w) + v);
-            pp0[i] = xp[2 * v];
-            pp1[i] = xp[2 * v + 1];
-        }
-        // residual values of this wave's (KSPLIT == 1: lane r holds row_begin + r) or block's (thread r) rows
-        if (EPI == EPI_RESIDUAL) {
-            const int r = (KSPLIT == 1) ? lane : (int)threadIdx.x;
-            resid_pre = a.resid[min(row_begin + min(r, rpw - 1), a.N - 1)];
-        }
-    };
+    // ---- first weight batch goes out before the activation is even loaded ----
+    // (round 2 measured the alternatives in the step: the activation / norm weight / residual loads FIRST, the whole first
+    //  round as straight-line code with counted waits, either load order -- each 4-5 % slower per token than this form, whose
+    //  conservative vmcnt(0) before the prologue lets a wave's first 16 KiB land before it asks for more)
+    // (timeline stamps only in -DOMX_GEMV_TRACE builds, `make VARIANT=trace VARIANT_FLAGS=-DOMX_GEMV_TRACE`: the four stores
+    //  change hipcc's register allocation of the whole kernel, 221 -> 157 VGPRs, and cost 2 % of a decode step)
+#ifdef OMX_GEMV_TRACE
     unsigned long long* const tr = a.trace ? a.trace + (size_t)blockIdx.x * 4 : nullptr;
-    if (tr && threadIdx.x == 0) tr[0] = wall_clock64();   // (before the loads: a store in a branch between them would blur the waits too)
-    if (OMX_GEMV_XFIRST) load_x();
-    __builtin_amdgcn_sched_barrier(0);        // the scheduler otherwise sinks half of the small loads below the weight batch
-    OMX_ISSUE(wA, min(row_begin, a.N - 1));   // unconditional (rows are clamped): a wave without rows re-reads the last row
-    if (!OMX_GEMV_XFIRST) load_x();
+#else
+    constexpr unsigned long long* tr = nullptr;
+#endif
+    if (tr && threadIdx.x == 0) tr[0] = wall_clock64();
+    if (active) OMX_ISSUE(wA, row_begin);
 
     // ---- prologue: stage x (bf16) in LDS; optionally x := bf16(x + bf16(partial)); RMS-normalise ----
     {
+        const bf16_t* xg = a.x + (a.x_row ? (size_t)a.x_row[0] * K : 0);
         float ss = 0.f;
+        constexpr int PV = (NV * 64 + kBlock - 1) / kBlock;   // vectors per thread
+        u32x4 xv[PV], nwv[PV];
 #pragma unroll
         for (int i = 0; i < PV; ++i) {
             const int v = threadIdx.x + i * kBlock;
-            const bool in = (NVT % kBlock == 0 || v < NVT) && (!TAIL || v < kvec);
-            u32x4 raw = xv[i];
-            const float pp[8] = {pp0[i][0], pp0[i][1], pp0[i][2], pp0[i][3], pp1[i][0], pp1[i][1], pp1[i][2], pp1[i][3]};
+            if (v < NV * 64) {
+                u32x4 raw = (!TAIL || v < kvec) ? *(reinterpret_cast<const u32x4*>(xg) + v) : u32x4{0u, 0u, 0u, 0u};
+                if (PRO == PRO_RMSNORM) nwv[i] = *(reinterpret_cast<const u32x4*>(a.norm_w) + v);
+                if (a.x_partial) {
+                    const f32x4 p0 = *(reinterpret_cast<const f32x4*>(a.x_partial) + 2 * v);
+                    const f32x4 p1 = *(reinterpret_cast<const f32x4*>(a.x_partial) + 2 * v + 1);
+                    const float pp[8] = {p0[0], p0[1], p0[2], p0[3], p1[0], p1[1], p1[2], p1[3]};
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const uint32_t sum = pack_bf16(bf16lo(raw[q]) + round_bf16(pp[2 * q]), bf16hi(raw[q]) + round_bf16(pp[2 * q + 1]));
-                raw[q] = in ? (has_partial ? sum : raw[q]) : 0u;
-            }
-            if (has_partial && a.x_out && blockIdx.x == 0 && in) *(reinterpret_cast<u32x4*>(a.x_out) + v) = raw;
-            xv[i] = raw;
-            if (PRO == PRO_RMSNORM) {
+                    for (int q = 0; q < 4; ++q)
+                        raw[q] = pack_bf16(bf16lo(raw[q]) + round_bf16(pp[2 * q]),
+                                           bf16hi(raw[q]) + round_bf16(pp[2 * q + 1]));
+                    if (a.x_out && blockIdx.x == 0) *(reinterpret_cast<u32x4*>(a.x_out) + v) = raw;
+                }
+                xv[i] = raw;
+                if (PRO == PRO_RMSNORM) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const float lo = bf16lo(raw[q]), hi = bf16hi(raw[q]);
-                    ss = fmaf(lo, lo, ss);
-                    ss = fmaf(hi, hi, ss);
+                    for (int q = 0; q < 4; ++q) {
+                        const float lo = bf16lo(raw[q]), hi = bf16hi(raw[q]);
+                        ss = fmaf(lo, lo, ss);
+                        ss = fmaf(hi, hi, ss);
+                    }
                 }
             }
         }
@@ -280,7 +257,7 @@ __global__ __launch_bounds__(kBlock) void gemv_kernel(const GemvArgs a_in) {
                 v0 += part[(lr * LR) * KSPLIT + w];
                 if (LR == 2) v1 += part[(lr * LR + 1) * KSPLIT + w];
             }
-            epilogue<EPI>(a, row_begin + lr, v0, v1, best, EPI == EPI_RESIDUAL ? bf16_to_f32(rpw <= kBlock ? resid_pre : a.resid[row_begin + lr]) : 0.f);
+            epilogue<EPI>(a, row_begin + lr, v0, v1, best);
         }
     }
     if (EPI == EPI_ARGMAX) {
@@ -409,8 +386,7 @@ __global__ __launch_bounds__(kBlock) void gemv_generic_kernel(const GemvArgs a_i
         if (lane == 0) {
 #pragma unroll
             for (int r = 0; r < RB; ++r)
-                if (r0 + r < row_end)
-                    epilogue<EPI>(a, r0 + r, acc[LR * r], acc[LR * r + (LR - 1)], best, EPI == EPI_RESIDUAL ? bf16_to_f32(a.resid[r0 + r]) : 0.f);
+                if (r0 + r < row_end) epilogue<EPI>(a, r0 + r, acc[LR * r], acc[LR * r + (LR - 1)], best);
         }
     }
     if (EPI == EPI_ARGMAX) {
@@ -534,7 +510,7 @@ int launch_gemv(const GemvArgs& a_in, int pro, int epi, hipStream_t s) {
     const int nv = tuned_nv(a.K, pro == PRO_NONE && !a.x_partial);
     const bool t = nv != 0;
     a.rows_per_wave = resolve_rpw(a.N, a.K, epi, a.rows_per_wave, t);
-    if (!t || a.N < 2) return launch_generic(a, pro, epi, s);   // (the tuned prologue reads a stand-in partial from the first two weight rows)
+    if (!t) return launch_generic(a, pro, epi, s);
     switch (nv) {
         // RB*NVW ~ 16 x 1-KiB loads in flight per wave per register set
         case 1: return launch_nv<1, 1, 8>(a, pro, epi, s);

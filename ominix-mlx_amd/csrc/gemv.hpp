@@ -54,7 +54,7 @@ struct GemvArgs {
     // entry routed elsewhere does no work (its output is never read: the combine skips it too)
     int w_sel_lo, w_sel_n;
     const bf16_t* out_bias;     // EPI_STORE: optional [N] added before the rounding (nn::Linear with bias = addmm, linear.rs:87-92)
-    // optional timeline (tools/gemv_trace.py): thread 0 of block b stamps the 100 MHz wall clock into trace[b*4 + k] at
+    // optional timeline (tools/gemv_trace.py; only in -DOMX_GEMV_TRACE builds): thread 0 of block b stamps the 100 MHz wall clock into trace[b*4 + k] at
     // k = 0 first weight batch issued, 1 activation staged, 2 first batch reduced, 3 last store issued
     unsigned long long* trace;
 };

@@ -83,7 +83,7 @@ int omx_sdpa(void* out, const void* q, const void* k, const void* v, int B, int 
         a.ws_o = (float*)ws;
         a.ws_ml = a.ws_o + (size_t)B * H * a.nsplit * D;
         a.out = (omx::bf16_t*)out;
-        return omx::launch_attn_decode(a, D, false, s);
+        return omx::launch_attn_decode(a, D, s);
     }
     return omx::launch_attn_prefill((omx::bf16_t*)out, (const omx::bf16_t*)q, (const omx::bf16_t*)k,
                                     (const omx::bf16_t*)v, B, H, Hkv, Tq, Tk, D, kv_batch_stride, kv_head_stride, scale,

@@ -262,10 +262,10 @@ class Model:
         return s.value or 0
 
     def decode_path(self) -> str:
-        """'graph' | 'eager' | 'persistent' once the first step ran ('unbuilt' before)."""
+        """'graph' | 'eager' once the first step ran ('unbuilt' before)."""
         v = c_int()
         check(lib.omx_qwen3_decode_path(self._h, ctypes.byref(v)))
-        return ("unbuilt", "graph", "eager", "persistent")[v.value]
+        return ("unbuilt", "graph", "eager")[v.value]
 
     def step_bytes(self, ctx: int) -> float:
         v = ctypes.c_double()

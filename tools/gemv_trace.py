@@ -7,7 +7,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import omx_import
 omx = omx_import.load_package()
-lib = omx.lib
+lib = omx.lib   # needs OMX_LIB_VARIANT=trace (make VARIANT=trace VARIANT_FLAGS=-DOMX_GEMV_TRACE)
 lib.omx_bench_gemv_trace.restype = ctypes.c_int
 lib.omx_bench_gemv_trace.argtypes = [ctypes.c_int] * 6 + [ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_int)]
 PRO = {"none": 0, "rms": 1}

@@ -243,6 +243,11 @@ int omx_gather_qmm(void* out, const void* x, const void* packed, const void* sca
                    const uint32_t* rhs_indices, int n_rows, int x_div, int N, int K, int n_experts, int group_size, int bits,
                    omx_dtype dtype, omx_stream stream);
 
+/* dense sibling (mlx_gather_mm, ops.h:463; mlx-rs/src/ops/quantization.rs:169-203): out [n_rows, N], row i = x[i / x_div] . W[rhs_indices[i]]^T
+ * over expert-stacked bf16 weights [n_experts, N, K]; expert-selected batched GEMV, K a multiple of 8                      */
+int omx_gather_mm(void* out, const void* x, const void* w, const uint32_t* rhs_indices, int n_rows, int x_div, int N, int K,
+                  int n_experts, omx_dtype dtype, omx_stream stream);
+
 /* =====================================================================================
  * a6 + a7: sparse-MoE block = router + top-k + SwitchGLU + weighted sum.
  *   mode 0  MixtralSparseMoeBlock::forward (mixtral-mlx/src/model.rs:296-308): top-k of the gate logits,

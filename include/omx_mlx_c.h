@@ -40,9 +40,18 @@ typedef enum mlx_dtype_ {
     MLX_BOOL, MLX_UINT8, MLX_UINT16, MLX_UINT32, MLX_UINT64, MLX_INT8, MLX_INT16, MLX_INT32, MLX_INT64,
     MLX_FLOAT16, MLX_FLOAT32, MLX_FLOAT64, MLX_BFLOAT16, MLX_COMPLEX64
 } mlx_dtype;
-/* stream.h:23-25, device.h, vector.h:25-27, optional.h:24-43 */
+/* stream.h:23-25, device.h:23-30, string.h:23-25, vector.h:25-27, map.h:25-27,85-87, closure.h:26-28, optional.h:24-43 */
 typedef struct mlx_stream_ { void* ctx; } mlx_stream;
+typedef struct mlx_device_ { void* ctx; } mlx_device;
+typedef enum mlx_device_type_ { MLX_CPU, MLX_GPU } mlx_device_type;
+typedef struct mlx_string_ { void* ctx; } mlx_string;
 typedef struct mlx_vector_array_ { void* ctx; } mlx_vector_array;
+typedef struct mlx_vector_string_ { void* ctx; } mlx_vector_string;
+typedef struct mlx_map_string_to_array_ { void* ctx; } mlx_map_string_to_array;
+typedef struct mlx_map_string_to_array_iterator_ { void* ctx; void* map_ctx; } mlx_map_string_to_array_iterator;
+typedef struct mlx_map_string_to_string_ { void* ctx; } mlx_map_string_to_string;
+typedef struct mlx_map_string_to_string_iterator_ { void* ctx; void* map_ctx; } mlx_map_string_to_string_iterator;
+typedef struct mlx_closure_ { void* ctx; } mlx_closure;
 typedef struct mlx_optional_int_ { int value; bool has_value; } mlx_optional_int;
 typedef struct mlx_optional_float_ { float value; bool has_value; } mlx_optional_float;
 typedef struct mlx_optional_dtype_ { mlx_dtype value; bool has_value; } mlx_optional_dtype;
@@ -180,6 +189,122 @@ int mlx_random_categorical_num_samples(mlx_array* res, const mlx_array logits, i
                                        const mlx_array key /* may be null */, const mlx_stream s);             /* :52 */
 int mlx_random_categorical_shape(mlx_array* res, const mlx_array logits, int axis, const int* shape, size_t shape_num,
                                  const mlx_array key /* may be null */, const mlx_stream s);                   /* :44 */
+
+/* ---- device.h:35-72, stream.h:35-67: Device / Stream objects as mlx-rs builds them (stream.rs:150-195, device.rs:40-90).
+ *      There is ONE device (the MI355X the process selected) and ONE in-order stream behind every handle; a CPU device can be
+ *      named and compared but not made the default nor given a stream (no CPU backend). ---- */
+mlx_device mlx_device_new(void);
+mlx_device mlx_device_new_type(mlx_device_type type, int index);
+int mlx_device_free(mlx_device dev);
+int mlx_device_set(mlx_device* dev, const mlx_device src);
+int mlx_device_tostring(mlx_string* str, mlx_device dev);
+bool mlx_device_equal(mlx_device lhs, mlx_device rhs);
+int mlx_device_get_index(int* index, mlx_device dev);
+int mlx_device_get_type(mlx_device_type* type, mlx_device dev);
+int mlx_get_default_device(mlx_device* dev);
+int mlx_set_default_device(mlx_device dev);
+mlx_stream mlx_stream_new_device(mlx_device dev);
+int mlx_stream_set(mlx_stream* stream, const mlx_stream src);
+int mlx_stream_tostring(mlx_string* str, mlx_stream stream);
+int mlx_stream_get_device(mlx_device* dev, mlx_stream stream);
+int mlx_stream_get_index(int* index, mlx_stream stream);
+int mlx_get_default_stream(mlx_stream* stream, mlx_device dev);
+int mlx_set_default_stream(mlx_stream stream);
+
+/* ---- string.h:30-48, vector.h (string vectors), array.h:62 ---- */
+mlx_string mlx_string_new(void);
+mlx_string mlx_string_new_data(const char* str);
+int mlx_string_set(mlx_string* str, const mlx_string src);
+const char* mlx_string_data(mlx_string str);
+int mlx_string_free(mlx_string str);
+mlx_vector_string mlx_vector_string_new(void);
+int mlx_vector_string_set(mlx_vector_string* vec, const mlx_vector_string src);
+int mlx_vector_string_free(mlx_vector_string vec);
+mlx_vector_string mlx_vector_string_new_data(const char** data, size_t size);
+mlx_vector_string mlx_vector_string_new_value(const char* val);
+int mlx_vector_string_set_data(mlx_vector_string* vec, const char** data, size_t size);
+int mlx_vector_string_set_value(mlx_vector_string* vec, const char* val);
+int mlx_vector_string_append_data(mlx_vector_string vec, const char** data, size_t size);
+int mlx_vector_string_append_value(mlx_vector_string vec, const char* val);
+size_t mlx_vector_string_size(mlx_vector_string vec);
+int mlx_vector_string_get(char** res, const mlx_vector_string vec, size_t idx);
+int mlx_array_tostring(mlx_string* str, const mlx_array arr);
+int mlx_vector_array_set(mlx_vector_array* vec, const mlx_vector_array src);
+mlx_vector_array mlx_vector_array_new_data(const mlx_array* data, size_t size);
+mlx_vector_array mlx_vector_array_new_value(const mlx_array val);
+
+/* ---- map.h:32-140 and io.h:40-44: what `Array::load_safetensors` walks (mlx-rs/src/ops/io.rs:51-58) ---- */
+mlx_map_string_to_array mlx_map_string_to_array_new(void);
+int mlx_map_string_to_array_set(mlx_map_string_to_array* map, const mlx_map_string_to_array src);
+int mlx_map_string_to_array_free(mlx_map_string_to_array map);
+int mlx_map_string_to_array_insert(mlx_map_string_to_array map, const char* key, const mlx_array value);
+int mlx_map_string_to_array_get(mlx_array* value, const mlx_map_string_to_array map, const char* key);
+mlx_map_string_to_array_iterator mlx_map_string_to_array_iterator_new(mlx_map_string_to_array map);
+int mlx_map_string_to_array_iterator_free(mlx_map_string_to_array_iterator it);
+int mlx_map_string_to_array_iterator_next(const char** key, mlx_array* value, mlx_map_string_to_array_iterator it);
+mlx_map_string_to_string mlx_map_string_to_string_new(void);
+int mlx_map_string_to_string_set(mlx_map_string_to_string* map, const mlx_map_string_to_string src);
+int mlx_map_string_to_string_free(mlx_map_string_to_string map);
+int mlx_map_string_to_string_insert(mlx_map_string_to_string map, const char* key, const char* value);
+int mlx_map_string_to_string_get(const char** value, const mlx_map_string_to_string map, const char* key);
+mlx_map_string_to_string_iterator mlx_map_string_to_string_iterator_new(mlx_map_string_to_string map);
+int mlx_map_string_to_string_iterator_free(mlx_map_string_to_string_iterator it);
+int mlx_map_string_to_string_iterator_next(const char** key, const char** value, mlx_map_string_to_string_iterator it);
+int mlx_load_safetensors(mlx_map_string_to_array* res_0, mlx_map_string_to_string* res_1, const char* file, const mlx_stream s);
+
+/* ---- closure.h:33-50, compile.h:37-48: `nn::silu` and friends are wrapped in `compile` (nn/activation.rs:876-880,
+ *      transforms/compile/compile.rs:334).  Execution here is eager, so compiling a closure returns the closure. ---- */
+mlx_closure mlx_closure_new(void);
+int mlx_closure_free(mlx_closure cls);
+mlx_closure mlx_closure_new_func(int (*fun)(mlx_vector_array*, const mlx_vector_array));
+mlx_closure mlx_closure_new_func_payload(int (*fun)(mlx_vector_array*, const mlx_vector_array, void*), void* payload, void (*dtor)(void*));
+int mlx_closure_set(mlx_closure* cls, const mlx_closure src);
+int mlx_closure_apply(mlx_vector_array* res, mlx_closure cls, const mlx_vector_array input);
+mlx_closure mlx_closure_new_unary(int (*fun)(mlx_array*, const mlx_array));
+int mlx_detail_compile(mlx_closure* res, const mlx_closure fun, uintptr_t fun_id, bool shapeless, const uint64_t* constants,
+                       size_t constants_num);
+int mlx_detail_compile_clear_cache(void);
+int mlx_detail_compile_erase(uintptr_t fun_id);
+int mlx_disable_compile(void);
+int mlx_enable_compile(void);
+
+/* ---- ops.h: the rest of the glue the four callers use -- Mixtral routing and gather_sort / scatter_unsort
+ *      (mixtral-mlx/src/model.rs:204-228, 296-308), create_causal_mask (mlx-rs-core/src/utils.rs:134-153), Paraformer FSMN
+ *      (funasr-mlx/src/paraformer.rs:496-532), Klein RoPE tables (flux-klein-mlx/src/klein_model.rs:53-162) ---- */
+int mlx_arange(mlx_array* res, double start, double stop, double step, mlx_dtype dtype, const mlx_stream s);         /* :88  */
+int mlx_greater(mlx_array* res, const mlx_array a, const mlx_array b, const mlx_stream s);                           /* :485 */
+int mlx_greater_equal(mlx_array* res, const mlx_array a, const mlx_array b, const mlx_stream s);                     /* :490 */
+int mlx_less(mlx_array* res, const mlx_array a, const mlx_array b, const mlx_stream s);                              /* :530 */
+int mlx_less_equal(mlx_array* res, const mlx_array a, const mlx_array b, const mlx_stream s);                        /* :535 */
+int mlx_equal(mlx_array* res, const mlx_array a, const mlx_array b, const mlx_stream s);                             /* :389 */
+int mlx_logical_and(mlx_array* res, const mlx_array a, const mlx_array b, const mlx_stream s);                       /* :563 */
+int mlx_maximum(mlx_array* res, const mlx_array a, const mlx_array b, const mlx_stream s);                           /* :621 */
+int mlx_minimum(mlx_array* res, const mlx_array a, const mlx_array b, const mlx_stream s);                           /* :675 */
+int mlx_floor_divide(mlx_array* res, const mlx_array a, const mlx_array b, const mlx_stream s);                      /* :423 */
+int mlx_cos(mlx_array* res, const mlx_array a, const mlx_stream s);                                                  /* :321 */
+int mlx_sin(mlx_array* res, const mlx_array a, const mlx_stream s);                                                  /* :958 */
+int mlx_sum_axis(mlx_array* res, const mlx_array a, int axis, bool keepdims, const mlx_stream s);                    /* :1092 */
+int mlx_argsort_axis(mlx_array* res, const mlx_array a, int axis, const mlx_stream s);                               /* :139 */
+int mlx_argsort(mlx_array* res, const mlx_array a, const mlx_stream s);                                              /* :144 */
+int mlx_argpartition_axis(mlx_array* res, const mlx_array a, int kth, int axis, const mlx_stream s);                 /* :128 */
+int mlx_take(mlx_array* res, const mlx_array a, const mlx_array indices, const mlx_stream s);                        /* :1115 */
+int mlx_take_along_axis(mlx_array* res, const mlx_array a, const mlx_array indices, int axis, const mlx_stream s);   /* :1120 */
+int mlx_expand_dims_axes(mlx_array* res, const mlx_array a, const int* axes, size_t axes_num, const mlx_stream s);   /* :397 */
+int mlx_squeeze_axes(mlx_array* res, const mlx_array a, const int* axes, size_t axes_num, const mlx_stream s);       /* :1037 */
+int mlx_squeeze_axis(mlx_array* res, const mlx_array a, int axis, const mlx_stream s);                               /* :1043 */
+int mlx_squeeze(mlx_array* res, const mlx_array a, const mlx_stream s);                                              /* :1048 */
+int mlx_flatten(mlx_array* res, const mlx_array a, int start_axis, int end_axis, const mlx_stream s);                /* :416 */
+int mlx_stack_axis(mlx_array* res, const mlx_vector_array arrays, int axis, const mlx_stream s);                     /* :1049 */
+int mlx_stack(mlx_array* res, const mlx_vector_array arrays, const mlx_stream s);                                    /* :1054 */
+int mlx_split(mlx_vector_array* res, const mlx_array a, int num_splits, int axis, const mlx_stream s);               /* :1022 */
+int mlx_split_sections(mlx_vector_array* res, const mlx_array a, const int* indices, size_t indices_num, int axis,
+                       const mlx_stream s);                                                                          /* :1028 */
+int mlx_conv1d(mlx_array* res, const mlx_array input, const mlx_array weight, int stride, int padding, int dilation, int groups,
+               const mlx_stream s);                                                                                  /* :225 */
+/* dense expert matmul (mlx-rs/src/ops/quantization.rs:169-203): a [..., 1, K] against the stacked b [E, K, N] picked per row by
+ * rhs_indices; the SwitchLinear form (b = swap_axes(w [E, N, K]), no lhs_indices) runs on the expert-selected GEMV */
+int mlx_gather_mm(mlx_array* res, const mlx_array a, const mlx_array b, const mlx_array lhs_indices /* may be null */,
+                  const mlx_array rhs_indices /* may be null */, bool sorted_indices, const mlx_stream s);           /* :463 */
 
 /* ---- native replacements for the two JIT Metal kernels (mlx_fast_metal_kernel_apply, fast.h:156;
  *      mlx-rs-core/src/metal_kernels.rs:188-236, 260-339): the two Rust call sites switch to these ---- */

@@ -45,6 +45,7 @@ SIGNATURES = {
     "omx_quantize": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_int64, c_int, c_int, c_int, c_int, c_void_p]),
     "omx_dequantize": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_int64, c_int, c_int, c_int, c_int, c_void_p]),
     "omx_quantized_matmul": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "omx_gather_mm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "omx_gather_qmm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
                                c_int, c_int, c_void_p]),
     "omx_version": (ctypes.c_char_p, []),

@@ -901,12 +901,14 @@ int mlx_zeros(mlx_array* res, const int* shape, size_t shape_num, mlx_dtype dtyp
     if (r->size()) OMX_HIP_CHECK(hipMemsetAsync(r->ptr(), 0, r->size() * dsize(dtype), g_stream));
     return assign(res, r);
 }
+int take_axis_general(mlx_array* res, const Arr& a, const Arr& ind, int ax);   // mlxc_glue.hpp
 int mlx_take_axis(mlx_array* res, const mlx_array a, const mlx_array indices, int axis, const mlx_stream) {
     REQ_ARR(a, "mlx_take_axis"); REQ_ARR(indices, "mlx_take_axis");
     int ax;
     if (norm_axis(axis, (int)A(a)->shape.size(), "mlx_take_axis", &ax)) return 1;
-    OMX_REQUIRE(ax == 0 && A(a)->shape.size() == 2, "mlx_take_axis: only row gather from a 2-D table (Embedding) is supported");
     OMX_REQUIRE(A(indices)->dt == MLX_UINT32 || A(indices)->dt == MLX_INT32, "mlx_take_axis: indices must be (u)int32");
+    if (!(ax == 0 && A(a)->shape.size() == 2 && is_float(A(a)->dt))) return take_axis_general(res, *A(a), *A(indices), ax);
+    // row gather from a 2-D floating table (Embedding): 16-byte vector rows
     Contig ct, ci;
     if (ct.init(*A(a)) || ci.init(*A(indices))) return 1;
     std::vector<int> shape = ci.a->shape;
@@ -1118,3 +1120,5 @@ int omx_mlx_fused_modulate(mlx_array* res, const mlx_array x, const mlx_array sh
 }
 
 }  // extern "C"
+
+#include "mlxc_glue.hpp"   // devices, strings, maps, closures and the remaining glue ops (same translation unit: shares Arr / Vec)

@@ -724,3 +724,18 @@ extern "C" int omx_moe_combine(void* out, const void* y_slots, const void* score
     OMX_LAUNCH_CHECK();
     return 0;
 }
+
+extern "C" int omx_gather_mm(void* out, const void* x, const void* w, const uint32_t* rhs_indices, int n_rows, int x_div, int N, int K,
+                             int n_experts, omx_dtype dtype, omx_stream stream) {
+    using namespace omx;
+    OMX_REQUIRE(out && x && w && rhs_indices, "omx_gather_mm: null tensor");
+    OMX_REQUIRE(dtype == OMX_BFLOAT16, "omx_gather_mm: only bfloat16 is implemented (got dtype %d)", (int)dtype);
+    OMX_REQUIRE(n_rows >= 0 && x_div >= 1 && N > 0 && n_experts >= 1 && gemv_k_supported(K, false), "omx_gather_mm: bad shape (N=%d K=%d)", N, K);
+    if (n_rows == 0) return 0;
+    GemvArgs a = {};
+    a.w0 = (const bf16_t*)w; a.n0 = N; a.N = N; a.K = K;
+    a.x = (const bf16_t*)x; a.out = out;
+    a.n_batch = n_rows; a.x_div = x_div; a.x_bstride = (size_t)K; a.out_bstride_bytes = (size_t)N * 2;
+    a.w_sel = rhs_indices; a.w_estride = (size_t)N * K;
+    return launch_gemv(a, PRO_NONE, EPI_STORE, (hipStream_t)stream);
+}

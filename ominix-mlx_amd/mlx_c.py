@@ -28,6 +28,34 @@ class mlx_vector_array(ctypes.Structure):
     _fields_ = [("ctx", c_void_p)]
 
 
+class mlx_device(ctypes.Structure):
+    _fields_ = [("ctx", c_void_p)]
+
+
+class mlx_string(ctypes.Structure):
+    _fields_ = [("ctx", c_void_p)]
+
+
+class mlx_vector_string(ctypes.Structure):
+    _fields_ = [("ctx", c_void_p)]
+
+
+class mlx_map_string_to_array(ctypes.Structure):
+    _fields_ = [("ctx", c_void_p)]
+
+
+class mlx_map_string_to_string(ctypes.Structure):
+    _fields_ = [("ctx", c_void_p)]
+
+
+class mlx_map_iterator(ctypes.Structure):           # both iterator structs: { void* ctx; void* map_ctx; } (map.h:61-64, 121-124)
+    _fields_ = [("ctx", c_void_p), ("map_ctx", c_void_p)]
+
+
+class mlx_closure(ctypes.Structure):
+    _fields_ = [("ctx", c_void_p)]
+
+
 class mlx_optional_float(ctypes.Structure):
     _fields_ = [("value", c_float), ("has_value", c_bool)]
 
@@ -135,6 +163,106 @@ SIGNATURES = {
     "mlx_random_categorical": (c_int, [P_ARR, mlx_array, c_int, mlx_array, mlx_stream]),
     "mlx_random_categorical_num_samples": (c_int, [P_ARR, mlx_array, c_int, c_int, mlx_array, mlx_stream]),
     "mlx_random_categorical_shape": (c_int, [P_ARR, mlx_array, c_int, P_INT, c_size_t, mlx_array, mlx_stream]),
+    # device.h / stream.h
+    "mlx_device_new": (mlx_device, []),
+    "mlx_device_new_type": (mlx_device, [c_int, c_int]),
+    "mlx_device_free": (c_int, [mlx_device]),
+    "mlx_device_set": (c_int, [ctypes.POINTER(mlx_device), mlx_device]),
+    "mlx_device_tostring": (c_int, [ctypes.POINTER(mlx_string), mlx_device]),
+    "mlx_device_equal": (c_bool, [mlx_device, mlx_device]),
+    "mlx_device_get_index": (c_int, [P_INT, mlx_device]),
+    "mlx_device_get_type": (c_int, [P_INT, mlx_device]),
+    "mlx_get_default_device": (c_int, [ctypes.POINTER(mlx_device)]),
+    "mlx_set_default_device": (c_int, [mlx_device]),
+    "mlx_stream_new_device": (mlx_stream, [mlx_device]),
+    "mlx_stream_set": (c_int, [ctypes.POINTER(mlx_stream), mlx_stream]),
+    "mlx_stream_tostring": (c_int, [ctypes.POINTER(mlx_string), mlx_stream]),
+    "mlx_stream_get_device": (c_int, [ctypes.POINTER(mlx_device), mlx_stream]),
+    "mlx_stream_get_index": (c_int, [P_INT, mlx_stream]),
+    "mlx_get_default_stream": (c_int, [ctypes.POINTER(mlx_stream), mlx_device]),
+    "mlx_set_default_stream": (c_int, [mlx_stream]),
+    # string.h / vector.h / array.h:62
+    "mlx_string_new": (mlx_string, []),
+    "mlx_string_new_data": (mlx_string, [c_char_p]),
+    "mlx_string_set": (c_int, [ctypes.POINTER(mlx_string), mlx_string]),
+    "mlx_string_data": (c_char_p, [mlx_string]),
+    "mlx_string_free": (c_int, [mlx_string]),
+    "mlx_vector_string_new": (mlx_vector_string, []),
+    "mlx_vector_string_set": (c_int, [ctypes.POINTER(mlx_vector_string), mlx_vector_string]),
+    "mlx_vector_string_free": (c_int, [mlx_vector_string]),
+    "mlx_vector_string_new_data": (mlx_vector_string, [ctypes.POINTER(c_char_p), c_size_t]),
+    "mlx_vector_string_new_value": (mlx_vector_string, [c_char_p]),
+    "mlx_vector_string_set_data": (c_int, [ctypes.POINTER(mlx_vector_string), ctypes.POINTER(c_char_p), c_size_t]),
+    "mlx_vector_string_set_value": (c_int, [ctypes.POINTER(mlx_vector_string), c_char_p]),
+    "mlx_vector_string_append_data": (c_int, [mlx_vector_string, ctypes.POINTER(c_char_p), c_size_t]),
+    "mlx_vector_string_append_value": (c_int, [mlx_vector_string, c_char_p]),
+    "mlx_vector_string_size": (c_size_t, [mlx_vector_string]),
+    "mlx_vector_string_get": (c_int, [ctypes.POINTER(c_char_p), mlx_vector_string, c_size_t]),
+    "mlx_array_tostring": (c_int, [ctypes.POINTER(mlx_string), mlx_array]),
+    "mlx_vector_array_set": (c_int, [ctypes.POINTER(mlx_vector_array), mlx_vector_array]),
+    "mlx_vector_array_new_data": (mlx_vector_array, [P_ARR, c_size_t]),
+    "mlx_vector_array_new_value": (mlx_vector_array, [mlx_array]),
+    # map.h / io.h
+    "mlx_map_string_to_array_new": (mlx_map_string_to_array, []),
+    "mlx_map_string_to_array_set": (c_int, [ctypes.POINTER(mlx_map_string_to_array), mlx_map_string_to_array]),
+    "mlx_map_string_to_array_free": (c_int, [mlx_map_string_to_array]),
+    "mlx_map_string_to_array_insert": (c_int, [mlx_map_string_to_array, c_char_p, mlx_array]),
+    "mlx_map_string_to_array_get": (c_int, [P_ARR, mlx_map_string_to_array, c_char_p]),
+    "mlx_map_string_to_array_iterator_new": (mlx_map_iterator, [mlx_map_string_to_array]),
+    "mlx_map_string_to_array_iterator_free": (c_int, [mlx_map_iterator]),
+    "mlx_map_string_to_array_iterator_next": (c_int, [ctypes.POINTER(c_char_p), P_ARR, mlx_map_iterator]),
+    "mlx_map_string_to_string_new": (mlx_map_string_to_string, []),
+    "mlx_map_string_to_string_set": (c_int, [ctypes.POINTER(mlx_map_string_to_string), mlx_map_string_to_string]),
+    "mlx_map_string_to_string_free": (c_int, [mlx_map_string_to_string]),
+    "mlx_map_string_to_string_insert": (c_int, [mlx_map_string_to_string, c_char_p, c_char_p]),
+    "mlx_map_string_to_string_get": (c_int, [ctypes.POINTER(c_char_p), mlx_map_string_to_string, c_char_p]),
+    "mlx_map_string_to_string_iterator_new": (mlx_map_iterator, [mlx_map_string_to_string]),
+    "mlx_map_string_to_string_iterator_free": (c_int, [mlx_map_iterator]),
+    "mlx_map_string_to_string_iterator_next": (c_int, [ctypes.POINTER(c_char_p), ctypes.POINTER(c_char_p), mlx_map_iterator]),
+    "mlx_load_safetensors": (c_int, [ctypes.POINTER(mlx_map_string_to_array), ctypes.POINTER(mlx_map_string_to_string), c_char_p, mlx_stream]),
+    # closure.h / compile.h
+    "mlx_closure_new": (mlx_closure, []),
+    "mlx_closure_free": (c_int, [mlx_closure]),
+    "mlx_closure_new_func": (mlx_closure, [c_void_p]),
+    "mlx_closure_new_func_payload": (mlx_closure, [c_void_p, c_void_p, c_void_p]),
+    "mlx_closure_set": (c_int, [ctypes.POINTER(mlx_closure), mlx_closure]),
+    "mlx_closure_apply": (c_int, [ctypes.POINTER(mlx_vector_array), mlx_closure, mlx_vector_array]),
+    "mlx_closure_new_unary": (mlx_closure, [c_void_p]),
+    "mlx_detail_compile": (c_int, [ctypes.POINTER(mlx_closure), mlx_closure, c_size_t, c_bool, ctypes.POINTER(ctypes.c_uint64), c_size_t]),
+    "mlx_detail_compile_clear_cache": (c_int, []),
+    "mlx_detail_compile_erase": (c_int, [c_size_t]),
+    "mlx_disable_compile": (c_int, []),
+    "mlx_enable_compile": (c_int, []),
+    # ops.h glue
+    "mlx_arange": (c_int, [P_ARR, ctypes.c_double, ctypes.c_double, ctypes.c_double, c_int, mlx_stream]),
+    "mlx_greater": (c_int, [P_ARR, mlx_array, mlx_array, mlx_stream]),
+    "mlx_greater_equal": (c_int, [P_ARR, mlx_array, mlx_array, mlx_stream]),
+    "mlx_less": (c_int, [P_ARR, mlx_array, mlx_array, mlx_stream]),
+    "mlx_less_equal": (c_int, [P_ARR, mlx_array, mlx_array, mlx_stream]),
+    "mlx_equal": (c_int, [P_ARR, mlx_array, mlx_array, mlx_stream]),
+    "mlx_logical_and": (c_int, [P_ARR, mlx_array, mlx_array, mlx_stream]),
+    "mlx_maximum": (c_int, [P_ARR, mlx_array, mlx_array, mlx_stream]),
+    "mlx_minimum": (c_int, [P_ARR, mlx_array, mlx_array, mlx_stream]),
+    "mlx_floor_divide": (c_int, [P_ARR, mlx_array, mlx_array, mlx_stream]),
+    "mlx_cos": (c_int, [P_ARR, mlx_array, mlx_stream]),
+    "mlx_sin": (c_int, [P_ARR, mlx_array, mlx_stream]),
+    "mlx_sum_axis": (c_int, [P_ARR, mlx_array, c_int, c_bool, mlx_stream]),
+    "mlx_argsort_axis": (c_int, [P_ARR, mlx_array, c_int, mlx_stream]),
+    "mlx_argsort": (c_int, [P_ARR, mlx_array, mlx_stream]),
+    "mlx_argpartition_axis": (c_int, [P_ARR, mlx_array, c_int, c_int, mlx_stream]),
+    "mlx_take": (c_int, [P_ARR, mlx_array, mlx_array, mlx_stream]),
+    "mlx_take_along_axis": (c_int, [P_ARR, mlx_array, mlx_array, c_int, mlx_stream]),
+    "mlx_expand_dims_axes": (c_int, [P_ARR, mlx_array, P_INT, c_size_t, mlx_stream]),
+    "mlx_squeeze_axes": (c_int, [P_ARR, mlx_array, P_INT, c_size_t, mlx_stream]),
+    "mlx_squeeze_axis": (c_int, [P_ARR, mlx_array, c_int, mlx_stream]),
+    "mlx_squeeze": (c_int, [P_ARR, mlx_array, mlx_stream]),
+    "mlx_flatten": (c_int, [P_ARR, mlx_array, c_int, c_int, mlx_stream]),
+    "mlx_stack_axis": (c_int, [P_ARR, mlx_vector_array, c_int, mlx_stream]),
+    "mlx_stack": (c_int, [P_ARR, mlx_vector_array, mlx_stream]),
+    "mlx_split": (c_int, [ctypes.POINTER(mlx_vector_array), mlx_array, c_int, c_int, mlx_stream]),
+    "mlx_split_sections": (c_int, [ctypes.POINTER(mlx_vector_array), mlx_array, P_INT, c_size_t, c_int, mlx_stream]),
+    "mlx_conv1d": (c_int, [P_ARR, mlx_array, mlx_array, c_int, c_int, c_int, c_int, mlx_stream]),
+    "mlx_gather_mm": (c_int, [P_ARR, mlx_array, mlx_array, mlx_array, mlx_array, c_bool, mlx_stream]),
     "omx_mlx_fused_swiglu": (c_int, [P_ARR, mlx_array, mlx_array, mlx_stream]),
     "omx_mlx_fused_modulate": (c_int, [P_ARR, mlx_array, mlx_array, mlx_array, mlx_stream]),
 }
@@ -435,3 +563,158 @@ def eval(*arrays) -> None:
         _check(lib.mlx_eval(vec))
     finally:
         lib.mlx_vector_array_free(vec)
+
+
+# ---- the rest of mlx_rs::ops used by the four callers (round 2) ----
+def _bin(fn):
+    return lambda a, b: Array.op(fn, a.h, b.h, default_stream())
+
+
+greater, greater_equal, less, less_equal, equal = (_bin(lib.mlx_greater), _bin(lib.mlx_greater_equal), _bin(lib.mlx_less),
+                                                   _bin(lib.mlx_less_equal), _bin(lib.mlx_equal))
+logical_and, maximum, minimum, floor_divide = _bin(lib.mlx_logical_and), _bin(lib.mlx_maximum), _bin(lib.mlx_minimum), _bin(lib.mlx_floor_divide)
+def cos(a): return Array.op(lib.mlx_cos, a.h, default_stream())
+def sin(a): return Array.op(lib.mlx_sin, a.h, default_stream())
+def arange(start, stop, step=1.0, dtype=INT32): return Array.op(lambda res: lib.mlx_arange(res, float(start), float(stop), float(step), dtype, default_stream()))
+def sum_axis(a, axis, keepdims=False): return Array.op(lib.mlx_sum_axis, a.h, axis, keepdims, default_stream())
+def argsort(a): return Array.op(lib.mlx_argsort, a.h, default_stream())
+def argsort_axis(a, axis): return Array.op(lib.mlx_argsort_axis, a.h, axis, default_stream())
+def argpartition_axis(a, kth, axis): return Array.op(lib.mlx_argpartition_axis, a.h, kth, axis, default_stream())
+def take(a, indices): return Array.op(lib.mlx_take, a.h, indices.h, default_stream())
+def take_along_axis(a, indices, axis): return Array.op(lib.mlx_take_along_axis, a.h, indices.h, axis, default_stream())
+def squeeze(a): return Array.op(lib.mlx_squeeze, a.h, default_stream())
+def squeeze_axis(a, axis): return Array.op(lib.mlx_squeeze_axis, a.h, axis, default_stream())
+def flatten(a, start_axis=0, end_axis=-1): return Array.op(lib.mlx_flatten, a.h, start_axis, end_axis, default_stream())
+def conv1d(x, w, stride=1, padding=0, dilation=1, groups=1): return Array.op(lib.mlx_conv1d, x.h, w.h, stride, padding, dilation, groups, default_stream())
+
+
+def expand_dims_axes(a, axes):
+    s, n = _ints(axes)
+    return Array.op(lib.mlx_expand_dims_axes, a.h, s, n, default_stream())
+
+
+def squeeze_axes(a, axes):
+    s, n = _ints(axes)
+    return Array.op(lib.mlx_squeeze_axes, a.h, s, n, default_stream())
+
+
+def _vec(arrays):
+    vec = lib.mlx_vector_array_new()
+    for a in arrays:
+        _check(lib.mlx_vector_array_append_value(vec, a.h))
+    return vec
+
+
+def _unvec(vec):
+    out = []
+    for i in range(lib.mlx_vector_array_size(vec)):
+        h = lib.mlx_array_new()
+        _check(lib.mlx_vector_array_get(ctypes.byref(h), vec, i))
+        out.append(Array(h))
+    return out
+
+
+def stack_axis(arrays, axis=0):
+    vec = _vec(arrays)
+    try:
+        return Array.op(lib.mlx_stack_axis, vec, axis, default_stream())
+    finally:
+        lib.mlx_vector_array_free(vec)
+
+
+def split(a, num_splits, axis=0):
+    vec = lib.mlx_vector_array_new()
+    try:
+        _check(lib.mlx_split(ctypes.byref(vec), a.h, num_splits, axis, default_stream()))
+        return _unvec(vec)
+    finally:
+        lib.mlx_vector_array_free(vec)
+
+
+def split_sections(a, indices, axis=0):
+    vec = lib.mlx_vector_array_new()
+    s, n = _ints(indices)
+    try:
+        _check(lib.mlx_split_sections(ctypes.byref(vec), a.h, s, n, axis, default_stream()))
+        return _unvec(vec)
+    finally:
+        lib.mlx_vector_array_free(vec)
+
+
+def gather_mm(a, b, rhs_indices, sorted_indices=False):
+    return Array.op(lib.mlx_gather_mm, a.h, b.h, mlx_array(None), rhs_indices.h, sorted_indices, default_stream())
+
+
+def tostring(a) -> str:
+    st = lib.mlx_string_new()
+    try:
+        _check(lib.mlx_array_tostring(ctypes.byref(st), a.h))
+        return lib.mlx_string_data(st).decode()
+    finally:
+        lib.mlx_string_free(st)
+
+
+def load_safetensors(path: str):
+    """mlx_rs::Array::load_safetensors (utils/io.rs:40-120): (name -> Array, metadata name -> str) walked with the map iterators."""
+    require_device()
+    arrays, meta = lib.mlx_map_string_to_array_new(), lib.mlx_map_string_to_string_new()
+    try:
+        _check(lib.mlx_load_safetensors(ctypes.byref(arrays), ctypes.byref(meta), path.encode(), default_stream()))
+        out, md = {}, {}
+        it = lib.mlx_map_string_to_array_iterator_new(arrays)
+        while True:
+            key, h = c_char_p(), lib.mlx_array_new()
+            st = lib.mlx_map_string_to_array_iterator_next(ctypes.byref(key), ctypes.byref(h), it)
+            if st == 2:
+                break
+            _check(st)
+            out[key.value.decode()] = Array(h)
+        lib.mlx_map_string_to_array_iterator_free(it)
+        it = lib.mlx_map_string_to_string_iterator_new(meta)
+        while True:
+            key, val = c_char_p(), c_char_p()
+            st = lib.mlx_map_string_to_string_iterator_next(ctypes.byref(key), ctypes.byref(val), it)
+            if st == 2:
+                break
+            _check(st)
+            md[key.value.decode()] = val.value.decode()
+        lib.mlx_map_string_to_string_iterator_free(it)
+        return out, md
+    finally:
+        lib.mlx_map_string_to_array_free(arrays)
+        lib.mlx_map_string_to_string_free(meta)
+
+
+UNARY_FN = ctypes.CFUNCTYPE(c_int, P_ARR, mlx_array)
+
+
+def compile_unary(fn):
+    """mlx_rs::transforms::compile over a one-array closure, the way nn::silu is wrapped (nn/activation.rs:876-880 ->
+    compile.rs:334: mlx_closure_new_unary / payload closure -> mlx_detail_compile -> mlx_closure_apply).  `fn(Array) -> Array`."""
+    def tramp(res_p, x):
+        wrap = Array(mlx_array(x.ctx))              # borrowed input: the wrapper must not free it
+        try:
+            y = fn(wrap)
+            _check(lib.mlx_array_set(res_p, y.h))
+            return 0
+        except Exception:                           # noqa: BLE001 -- the C side reports status 1
+            return 1
+        finally:
+            wrap.h = mlx_array(None)
+    cb = UNARY_FN(tramp)
+    plain = lib.mlx_closure_new_unary(ctypes.cast(cb, c_void_p))
+    compiled = lib.mlx_closure_new()
+    _check(lib.mlx_detail_compile(ctypes.byref(compiled), plain, id(fn), False, None, 0))
+    lib.mlx_closure_free(plain)
+
+    def call(x):
+        vin = _vec([x])
+        vout = lib.mlx_vector_array_new()
+        try:
+            _check(lib.mlx_closure_apply(ctypes.byref(vout), compiled, vin))
+            return _unvec(vout)[0]
+        finally:
+            lib.mlx_vector_array_free(vin)
+            lib.mlx_vector_array_free(vout)
+    call._keep = (cb, compiled)
+    return call

@@ -11,7 +11,7 @@ def declared(header):
     src = open(os.path.join(ROOT, "include", header)).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     names = re.findall(r"\b((?:omx|mlx)_[a-z0-9_]+)\s*\(", src)
-    return sorted({n for n in names if not n.endswith("_func")})
+    return sorted({n for n in names if not n.endswith("_handler_func")})
 
 
 def test_library_loads_without_gpu_and_reports_no_device(omx):
@@ -42,3 +42,44 @@ def test_product_has_no_cpu_fallback(omx):
     for mod in sorted(f for f in os.listdir(os.path.join(ROOT, "ominix-mlx_amd")) if f.endswith(".py")):
         text = open(os.path.join(ROOT, "ominix-mlx_amd", mod)).read()
         assert "import oracle" not in text and "from oracle" not in text
+
+
+# SURVEY.md section 8b, row "Hot-path subset a C-ABI replacement must export", spelled out (families expanded from the headers the
+# row cites: array.h, vector.h, string.h, stream.h, device.h, transforms.h, memory.h, io.h, fast.h, ops.h, closure.h, compile.h,
+# random.h).  VERDICT r1 "Next" #3: the list is checked against `nm -D` of the built library, not against our own header.
+SURVEY_8B = """
+mlx_array_new mlx_array_free mlx_array_set mlx_array_new_data mlx_array_new_int mlx_array_new_float32 mlx_array_new_bool mlx_array_shape
+mlx_array_ndim mlx_array_dim mlx_array_dtype mlx_array_size mlx_array_nbytes mlx_array_itemsize mlx_array_strides mlx_array_eval
+mlx_array_item_uint32 mlx_array_item_float32 mlx_array_data_uint8 mlx_array_data_uint16 mlx_array_data_uint32 mlx_array_data_int32
+mlx_array_data_float32 mlx_array_data_bfloat16 mlx_array_tostring
+mlx_vector_array_new mlx_vector_array_free mlx_vector_array_append_value mlx_vector_array_get mlx_vector_array_size
+mlx_vector_string_new mlx_vector_string_free mlx_vector_string_append_value mlx_vector_string_get mlx_vector_string_size
+mlx_string_new mlx_string_data mlx_string_free
+mlx_stream_new mlx_stream_new_device mlx_stream_free mlx_stream_equal mlx_stream_get_index mlx_get_default_stream
+mlx_default_cpu_stream_new mlx_default_gpu_stream_new
+mlx_device_new mlx_device_new_type mlx_device_free mlx_device_equal mlx_device_get_index mlx_device_get_type mlx_device_tostring
+mlx_get_default_device mlx_set_default_device mlx_set_error_handler mlx_eval mlx_async_eval mlx_synchronize mlx_clear_cache
+mlx_load_safetensors
+mlx_fast_scaled_dot_product_attention mlx_fast_rope mlx_fast_rms_norm mlx_fast_layer_norm
+mlx_matmul mlx_addmm mlx_quantized_matmul mlx_gather_mm mlx_gather_qmm mlx_dequantize
+mlx_reshape mlx_transpose_axes mlx_expand_dims mlx_expand_dims_axes mlx_squeeze_axes mlx_flatten mlx_concatenate_axis mlx_stack_axis
+mlx_split mlx_split_sections mlx_slice mlx_slice_update mlx_take mlx_take_axis mlx_take_along_axis mlx_astype mlx_add mlx_subtract
+mlx_multiply mlx_divide mlx_negative mlx_floor_divide mlx_maximum mlx_minimum mlx_sigmoid mlx_cos mlx_sin mlx_exp mlx_softmax_axis
+mlx_sum_axis mlx_argmax_axis mlx_argsort mlx_argpartition_axis mlx_arange mlx_zeros mlx_greater_equal mlx_less_equal mlx_logical_and
+mlx_conv1d mlx_random_categorical
+mlx_closure_new mlx_closure_free mlx_closure_new_func mlx_closure_new_func_payload mlx_closure_new_unary mlx_closure_set
+mlx_closure_apply mlx_detail_compile
+omx_mlx_fused_swiglu omx_mlx_fused_modulate
+""".split()
+
+
+def test_survey_8b_export_list_against_nm(omx):
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", omx.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = {ln.split()[-1] for ln in out.splitlines() if ln.strip()}
+    missing = [n for n in SURVEY_8B if n not in exported]
+    assert not missing, f"SURVEY 8b symbols missing from libomx_hip.so: {missing}"
+    # and each of them is declared in the header a maintainer would hand to bindgen, and bound for the tests
+    from ominix_mlx_amd import mlx_c
+    assert not [n for n in SURVEY_8B if n not in set(declared("omx_mlx_c.h"))]
+    assert not [n for n in SURVEY_8B if n not in mlx_c.SIGNATURES]

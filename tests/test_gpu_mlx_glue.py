@@ -1,0 +1,268 @@
+"""GPU: the second half of the mlx-c surface (VERDICT r1 "Next" #3) -- the reference call sequences of the four
+callers replayed call by call through the handle ABI, one C entry point per Rust op, against numpy / the oracle:
+    create_causal_mask                     mlx-rs-core/src/utils.rs:134-153
+    MixtralSparseMoeBlock::forward         mixtral-mlx/src/model.rs:296-308 (+ gather_sort / scatter_unsort :204-228,
+                                           SwitchGLU::forward_experts :243-274 on the dense gather_mm form)
+    Stream::default / Device               mlx-rs/src/stream.rs:150-195, device.rs
+    compile-wrapped nn::silu               mlx-rs/src/nn/activation.rs:876-880 -> transforms/compile/compile.rs:334
+    SanmAttention's FSMN conv1d            funasr-mlx/src/paraformer.rs:442-470, 496-532
+    Array::load_safetensors                mlx-rs/src/utils/io.rs:40-120"""
+import ctypes
+
+import numpy as np
+import pytest
+
+from oracle import ref_core as rc, ref_moe as rm
+from test_gpu_primitives import assert_bf16_close, rand
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def mx(omx):
+    from ominix_mlx_amd import mlx_c
+    return mlx_c
+
+
+def test_create_causal_mask_call_sequence(mx):
+    """utils.rs:134-153: arange / arange / expand_dims x2 / ge (/ add / le / logical_and with a window)."""
+    for n, offset, window in [(7, 0, None), (5, 9, None), (6, 4, 3), (1, 300, None)]:
+        rinds = mx.arange(0, offset + n, 1, mx.INT32)
+        linds = mx.arange(offset, offset + n, 1, mx.INT32)
+        linds = mx.expand_dims(linds, -1)            # index((.., NewAxis))
+        rinds = mx.expand_dims(rinds, 0)             # index(NewAxis)
+        mask = mx.greater_equal(linds, rinds)
+        if window is not None:
+            w = mx.Array(mx.lib.mlx_array_new_int(window))
+            mask = mx.logical_and(mask, mx.less_equal(linds, mx.add(rinds, w)))
+        assert mask.dtype == mx.BOOL and mask.shape == (n, offset + n)
+        want = rc.create_causal_mask(n, offset) if window is None else (
+            (np.arange(offset, offset + n)[:, None] >= np.arange(offset + n)[None]) &
+            (np.arange(offset, offset + n)[:, None] <= np.arange(offset + n)[None] + window))
+        np.testing.assert_array_equal(mask.numpy(), want)
+
+
+def test_elementwise_glue_semantics(mx):
+    a = np.array([[-7, -1, 0, 5, 9, 2 ** 25 + 1]], np.int32)
+    b = np.array([[2], [-3]], np.int32)
+    A, B = mx.Array.from_numpy(a, mx.INT32), mx.Array.from_numpy(b, mx.INT32)
+    np.testing.assert_array_equal(mx.floor_divide(A, B).numpy(), a // b)          # floor, not truncation; exact beyond 2^24
+    np.testing.assert_array_equal(mx.maximum(A, B).numpy(), np.maximum(a, b))
+    np.testing.assert_array_equal(mx.minimum(A, B).numpy(), np.minimum(a, b))
+    for fn, ref in ((mx.greater, np.greater), (mx.less, np.less), (mx.equal, np.equal), (mx.less_equal, np.less_equal)):
+        got = fn(A, B)
+        assert got.dtype == mx.BOOL
+        np.testing.assert_array_equal(got.numpy(), ref(a, b))
+    x = rand((3, 5), 3).astype(np.float32) * 4
+    X = mx.Array.from_numpy(x, mx.FLOAT32)
+    np.testing.assert_allclose(mx.cos(X).numpy(), np.cos(x), atol=2e-6)
+    np.testing.assert_allclose(mx.sin(X).numpy(), np.sin(x), atol=2e-6)
+    np.testing.assert_allclose(mx.floor_divide(X, mx.Array(mx.lib.mlx_array_new_float32(0.75))).numpy(), np.floor(x / np.float32(0.75)))
+    np.testing.assert_allclose(mx.sum_axis(X, 0).numpy(), x.sum(0), rtol=1e-6)
+    np.testing.assert_allclose(mx.sum_axis(X, -1, True).numpy(), x.sum(-1, keepdims=True), rtol=1e-6)
+    assert mx.sum_axis(mx.greater(X, mx.Array(mx.lib.mlx_array_new_float32(0.0))), 1).numpy().tolist() == (x > 0).sum(1).tolist()
+    np.testing.assert_array_equal(mx.arange(2, 11, 3, mx.UINT32).numpy(), np.arange(2, 11, 3, dtype=np.uint32))
+    np.testing.assert_allclose(mx.arange(0, 1, 0.25, mx.FLOAT32).numpy(), np.arange(0, 1, 0.25, dtype=np.float32))
+    assert "dtype=float32" in mx.tostring(X) and mx.tostring(mx.Array(mx.lib.mlx_array_new_int(3))) == "array(3, dtype=int32)"
+
+
+def test_shape_glue_semantics(mx):
+    a = rand((2, 1, 3, 1, 4), 8).astype(np.float32)
+    A = mx.Array.from_numpy(a, mx.FLOAT32)
+    np.testing.assert_array_equal(mx.squeeze(A).numpy(), a.squeeze())
+    np.testing.assert_array_equal(mx.squeeze_axes(A, [1, -2]).numpy(), a.squeeze((1, 3)))
+    np.testing.assert_array_equal(mx.squeeze_axis(A, 3).numpy(), a.squeeze(3))
+    with pytest.raises(Exception, match="cannot squeeze"):
+        mx.squeeze_axis(A, 0)
+    np.testing.assert_array_equal(mx.expand_dims_axes(mx.squeeze(A), [0, -1, 2]).numpy(), np.expand_dims(a.squeeze(), (0, -1, 2)))
+    np.testing.assert_array_equal(mx.flatten(A).numpy(), a.reshape(-1))
+    np.testing.assert_array_equal(mx.flatten(A, 1, 3).numpy(), a.reshape(2, 3, 4))
+    t = mx.transpose_axes(A, [4, 1, 2, 3, 0])                                     # a view: flatten has to materialise it
+    np.testing.assert_array_equal(mx.flatten(t, 0, -1).numpy(), a.transpose(4, 1, 2, 3, 0).reshape(-1))
+    parts = [rand((3, 4), 20 + i).astype(np.float32) for i in range(3)]
+    P = [mx.Array.from_numpy(p, mx.FLOAT32) for p in parts]
+    np.testing.assert_array_equal(mx.stack_axis(P, 0).numpy(), np.stack(parts, 0))
+    np.testing.assert_array_equal(mx.stack_axis(P, -1).numpy(), np.stack(parts, -1))
+    b = rand((6, 5), 9).astype(np.float32)
+    B = mx.Array.from_numpy(b, mx.FLOAT32)
+    for got, want in zip(mx.split(B, 3, 0), np.split(b, 3, 0)):
+        np.testing.assert_array_equal(got.numpy(), want)
+    for got, want in zip(mx.split_sections(B, [1, 4], 1), np.split(b, [1, 4], 1)):
+        np.testing.assert_array_equal(got.numpy(), want)
+    with pytest.raises(Exception, match="equal parts"):
+        mx.split(B, 4, 0)
+
+
+def test_sort_and_gather_glue_semantics(mx):
+    g = np.random.default_rng(4)
+    a = g.integers(0, 6, (3, 40)).astype(np.uint32)                               # many ties: the sort must be stable
+    A = mx.Array.from_numpy(a, mx.UINT32)
+    np.testing.assert_array_equal(mx.argsort(A).numpy(), np.argsort(a, -1, kind="stable"))
+    np.testing.assert_array_equal(mx.argsort_axis(A, 0).numpy(), np.argsort(a, 0, kind="stable"))
+    f = g.standard_normal((5, 9)).astype(np.float32)
+    F = mx.Array.from_numpy(f, mx.FLOAT32)
+    order = mx.argsort(F)
+    assert order.dtype == mx.UINT32
+    np.testing.assert_array_equal(mx.take_along_axis(F, order, -1).numpy(), np.sort(f, -1))
+    part = mx.argpartition_axis(F, 3, -1).numpy()
+    srt = np.sort(f, -1)
+    picked = np.take_along_axis(f, part.astype(np.int64), -1)
+    assert (picked[:, 3] == srt[:, 3]).all() and (picked[:, :3] <= srt[:, 3:4]).all() and (picked[:, 4:] >= srt[:, 3:4]).all()
+    idx = g.integers(-9, 9, (2, 3)).astype(np.int32)                              # negative indices wrap
+    np.testing.assert_array_equal(mx.take(F, mx.Array.from_numpy(idx, mx.INT32)).numpy(), f.reshape(-1)[idx])
+    x3 = g.standard_normal((6, 1, 8)).astype(np.float32)
+    rows = np.array([5, 0, 0, 3], np.uint32)
+    np.testing.assert_array_equal(mx.take_axis(mx.Array.from_numpy(x3, mx.FLOAT32), mx.Array.from_numpy(rows, mx.UINT32), 0).numpy(), x3[rows])
+    np.testing.assert_array_equal(mx.take_axis(mx.Array.from_numpy(rows, mx.UINT32), mx.Array.from_numpy(np.array([3, 1], np.uint32), mx.UINT32), 0).numpy(),
+                                  rows[[3, 1]])
+
+
+@pytest.mark.parametrize("n_tokens", [5, 70])
+def test_mixtral_sparse_moe_block_call_sequence(mx, n_tokens):
+    """MixtralSparseMoeBlock::forward (model.rs:296-308) with SwitchGLU::forward_experts (:243-274) -- the sorted branch
+    (gather_sort / scatter_unsort, :204-228) once B*L*k >= 64, the unsorted one below -- over DENSE experts through
+    mlx_gather_mm (the reference's own checkpoints are 4-bit: that form is test_gpu_quant / test_gpu_moe)."""
+    h, inter, E, k = 512, 1024, 8, 2
+    x = rc.bf16_round(rand((1, n_tokens, h), 31))
+    gate_w = rc.bf16_round(rand((E, h), 32) * 0.2)
+    wg, wu = rc.bf16_round(rand((E, inter, h), 33) * 0.05), rc.bf16_round(rand((E, inter, h), 34) * 0.05)
+    wd = rc.bf16_round(rand((E, h, inter), 35) * 0.05)
+    X, GW = mx.Array.from_numpy(x), mx.Array.from_numpy(gate_w)
+    WG, WU, WD = mx.Array.from_numpy(wg), mx.Array.from_numpy(wu), mx.Array.from_numpy(wd)
+
+    def switch_linear(xx, w, indices, sorted_indices):            # SwitchLinear: gather_mm(x, w.swap_axes(-1, -2), rhs_indices)
+        return mx.gather_mm(xx, mx.transpose_axes(w, [0, 2, 1]), indices, sorted_indices)
+
+    gates = mx.matmul(X, mx.transpose(GW))                                        # self.gate.forward(x)
+    neg = mx.negative(gates)
+    part = mx.argpartition_axis(neg, k - 1, -1)
+    inds = mx.slice(part, [0, 0, 0], [1, n_tokens, k])                            # index((.., .., ..k))
+    selected = mx.take_along_axis(gates, inds, -1)
+    scores = mx.softmax_axis(selected, -1, True)
+    # forward_experts
+    b, l = 1, n_tokens
+    x_exp = mx.expand_dims(mx.expand_dims(X, -2), -2)
+    if b * l * k >= 64:
+        m = k
+        flat = mx.flatten(inds)
+        order = mx.argsort(flat)
+        inv_order = mx.argsort(order)
+        x_flat = mx.reshape(x_exp, [-1, 1, h])
+        token_order = mx.floor_divide(order, mx.Array(mx.lib.mlx_array_new_int(m)))
+        x_sorted = mx.take_axis(x_flat, token_order, 0)
+        inds_sorted = mx.take_axis(flat, order, 0)
+        assert (np.diff(inds_sorted.numpy().astype(np.int64)) >= 0).all()
+        gate = switch_linear(x_sorted, WG, inds_sorted, True)
+        up = switch_linear(x_sorted, WU, inds_sorted, True)
+        act = mx.fused_swiglu(up, gate)
+        out = switch_linear(act, WD, inds_sorted, True)
+        unsorted = mx.take_axis(mx.reshape(out, [-1, h]), inv_order, 0)           # scatter_unsort
+        y = mx.reshape(mx.reshape(unsorted, [b, l, k, 1, h]), [b, l, k, h])
+    else:
+        gate = switch_linear(x_exp, WG, inds, False)
+        up = switch_linear(x_exp, WU, inds, False)
+        act = mx.fused_swiglu(up, gate)
+        out = switch_linear(act, WD, inds, False)
+        assert out.shape == (b, l, k, 1, h)
+        y = mx.reshape(out, [b, l, k, h])
+    res = mx.sum_axis(mx.multiply(y, mx.expand_dims(scores, -1)), 2, False)       # y * scores[..., NewAxis] summed over k
+
+    ref, ref_inds, ref_scores = rm.moe_block(x[0], gate_w, wg, wu, wd, k, "mixtral", True, "bf16")
+    got_inds = inds.numpy()[0].astype(np.int64)
+    np.testing.assert_array_equal(np.sort(got_inds, -1), np.sort(ref_inds.astype(np.int64), -1))     # the SET of experts per token
+    # the oracle orders a token's experts by descending score; the weighted sum does not depend on the order up to bf16 rounding
+    assert_bf16_close(res.numpy()[0], ref, 4, atol=2.0 ** -6 * np.abs(ref).max())
+
+
+def test_stream_and_device_objects(mx, omx):
+    """Stream::default (stream.rs:150-195): get_default_device -> get_default_stream(dev); Device::cpu() can be named, compared
+    and printed, but neither made the default nor given a stream (there is no CPU backend)."""
+    lib = mx.lib
+    dev = mx.mlx_device(None)
+    assert lib.mlx_get_default_device(ctypes.byref(dev)) == 0
+    ty, ix = ctypes.c_int(), ctypes.c_int()
+    assert lib.mlx_device_get_type(ctypes.byref(ty), dev) == 0 and lib.mlx_device_get_index(ctypes.byref(ix), dev) == 0
+    assert (ty.value, ix.value) == (1, 0)                                          # MLX_GPU, index 0
+    st = mx.mlx_stream(None)
+    assert lib.mlx_get_default_stream(ctypes.byref(st), dev) == 0 and st.ctx
+    other = lib.mlx_stream_new_device(dev)
+    assert lib.mlx_stream_equal(st, other) and lib.mlx_stream_get_index(ctypes.byref(ix), st) == 0 and ix.value == 0
+    text = mx.mlx_string(None)
+    assert lib.mlx_stream_tostring(ctypes.byref(text), st) == 0 and b"gpu" in lib.mlx_string_data(text)
+    cpu = lib.mlx_device_new_type(0, 0)
+    assert not lib.mlx_device_equal(cpu, dev) and lib.mlx_device_tostring(ctypes.byref(text), cpu) == 0
+    assert lib.mlx_string_data(text) == b"Device(cpu, 0)"
+    assert lib.mlx_set_default_device(cpu) == 1 and "no CPU backend" in lib.omx_last_error().decode()
+    lib.omx_clear_error()
+    assert not lib.mlx_stream_new_device(cpu).ctx
+    lib.omx_clear_error()
+    assert lib.mlx_set_default_device(dev) == 0 and lib.mlx_synchronize(st) == 0
+    for s in (st, other):
+        lib.mlx_stream_free(s)
+    for d in (dev, cpu):
+        lib.mlx_device_free(d)
+    lib.mlx_string_free(text)
+    vs = lib.mlx_vector_string_new_value(b"alpha")
+    assert lib.mlx_vector_string_append_value(vs, b"beta") == 0 and lib.mlx_vector_string_size(vs) == 2
+    got = ctypes.c_char_p()
+    assert lib.mlx_vector_string_get(ctypes.byref(got), vs, 1) == 0 and got.value == b"beta"
+    lib.mlx_vector_string_free(vs)
+
+
+def test_compile_wrapped_silu(mx):
+    """nn::silu is `compile`d in mlx-rs (activation.rs:876-880): closure_new_unary -> detail_compile -> closure_apply.  Eager
+    execution makes compile the identity on closures; the result is x * sigmoid(x) with bf16 op outputs."""
+    silu = mx.compile_unary(lambda x: mx.multiply(x, mx.sigmoid(x)))
+    x = rc.bf16_round(rand((4, 96), 12) * 3)
+    for _ in range(2):                                                            # the compiled closure is reusable
+        got = silu(mx.Array.from_numpy(x)).numpy()
+        assert_bf16_close(got, rc.silu(x, "bf16"), 1, atol=1e-6)
+    assert mx.lib.mlx_detail_compile_clear_cache() == 0 and mx.lib.mlx_enable_compile() == 0
+
+
+def test_fsmn_depthwise_conv1d(mx):
+    """Paraformer's FSMN memory block (paraformer.rs:442-470): v [B, T, 512] zero-padded 5 + 5 frames, depthwise conv1d with
+    kernel 11 (weight [512, 11, 1], groups = 512), no bias; plus a dense strided / dilated case."""
+    g = np.random.default_rng(6)
+    B, T, C, Kw = 2, 37, 64, 11
+    x = g.standard_normal((B, T, C)).astype(np.float32)
+    w = g.standard_normal((C, Kw, 1)).astype(np.float32) * 0.3
+    got = mx.conv1d(mx.Array.from_numpy(x, mx.FLOAT32), mx.Array.from_numpy(w, mx.FLOAT32), 1, 5, 1, C).numpy()
+    xp = np.pad(x, ((0, 0), (5, 5), (0, 0)))
+    want = np.stack([sum(xp[:, t + k] * w[:, k, 0] for k in range(Kw)) for t in range(T)], 1)
+    np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-5)
+    xd = g.standard_normal((1, 30, 6)).astype(np.float32)
+    wd = g.standard_normal((4, 3, 3)).astype(np.float32)                          # groups = 2: 3 input channels per group
+    got = mx.conv1d(mx.Array.from_numpy(xd, mx.FLOAT32), mx.Array.from_numpy(wd, mx.FLOAT32), 2, 1, 2, 2).numpy()
+    xp = np.pad(xd, ((0, 0), (1, 1), (0, 0)))
+    lout = (30 + 2 - (2 * 2 + 1)) // 2 + 1
+    want = np.zeros((1, lout, 4), np.float32)
+    for co in range(4):
+        grp = co // 2
+        for t in range(lout):
+            want[0, t, co] = sum((xp[0, t * 2 + k * 2, grp * 3:(grp + 1) * 3] * wd[co, k]).sum() for k in range(3))
+    np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-5)
+
+
+def test_load_safetensors_through_the_map_iterators(mx, tmp_path):
+    """io.h:40-44 as mlx-rs walks it (utils/io.rs:40-120): a file written by the `safetensors` package (F32, I32, F16, BF16
+    with a __metadata__ block) comes back tensor for tensor; a missing file / truncated file is an error status, not a crash."""
+    import torch
+    from safetensors.torch import save_file
+    g = torch.Generator().manual_seed(0)
+    tensors = {"model.w": torch.randn(5, 7, generator=g), "ids": torch.arange(12, dtype=torch.int32).reshape(3, 4),
+               "half": torch.randn(4, 4, generator=g).half(), "b": torch.randn(6, 2, generator=g).bfloat16()}
+    p = str(tmp_path / "t.safetensors")
+    save_file(tensors, p, metadata={"format": "pt", "note": "omx"})
+    arrays, meta = mx.load_safetensors(p)
+    assert set(arrays) == set(tensors) and meta == {"format": "pt", "note": "omx"}
+    np.testing.assert_array_equal(arrays["model.w"].numpy(), tensors["model.w"].numpy())
+    np.testing.assert_array_equal(arrays["ids"].numpy(), tensors["ids"].numpy())
+    assert arrays["b"].dtype == mx.BFLOAT16 and arrays["half"].dtype == mx.FLOAT16
+    np.testing.assert_array_equal(arrays["b"].numpy(), tensors["b"].float().numpy())
+    with pytest.raises(Exception, match="cannot open"):
+        mx.load_safetensors(str(tmp_path / "missing.safetensors"))
+    blob = open(p, "rb").read()
+    open(str(tmp_path / "cut.safetensors"), "wb").write(blob[:len(blob) - 40])
+    with pytest.raises(Exception, match="truncated"):
+        mx.load_safetensors(str(tmp_path / "cut.safetensors"))

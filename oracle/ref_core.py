@@ -215,8 +215,16 @@ def fused_swiglu(x, gate, dt: str = "f32") -> np.ndarray:
 
 
 def fused_modulate(x, shift, scale, eps: float = 1e-6, dt: str = "f32") -> np.ndarray:
-    """metal_kernels.rs:28-94: per row mean, var = E[x^2]-mean^2 clamped >= 0,
-    (1+scale) * (x-mean)*rsqrt(var+eps) + shift; shift/scale [B,H] broadcast over sequence."""
+    """The MATHEMATICAL function of metal_kernels.rs:28-94 -- per row mean, var = E[x^2]-mean^2 clamped >= 0,
+    (1+scale) * (x-mean)*rsqrt(var+eps) + shift, shift/scale [B,H] broadcast over the sequence -- evaluated in float64
+    with ONE rounding to `dt`.  This is what the product kernel (omx_fused_modulate: fp32 statistics) is held to.
+
+    It is NOT a rounding-faithful restatement of the Metal kernel, which (a) accumulates the statistics in T (a bf16 sum
+    of 3072 values is good to a few per cent) and (b) indexes scale[i] / shift[i] with the column alone, i.e. reads
+    batch 0's modulation for every batch row (:90-91).  `fused_modulate_metal_literal` below restates exactly that;
+    tests/test_oracle_kats.py shows the two agree for f32 / B == 1 and how far the T-precision statistics move a bf16
+    result.  The kernel has no caller in the reference workspace (the DiT uses LayerNorm + modulate
+    in separate ops), so no reference-visible output depends on (a) or (b)."""
     x64 = np.asarray(x, dtype=np.float64)
     mean = np.mean(x64, axis=-1, keepdims=True)
     var = np.maximum(np.mean(x64 * x64, axis=-1, keepdims=True) - mean * mean, 0.0)
@@ -226,6 +234,42 @@ def fused_modulate(x, shift, scale, eps: float = 1e-6, dt: str = "f32") -> np.nd
     if x64.ndim == 3 and sh.ndim == 2:
         sh, sc = sh[:, None, :], sc[:, None, :]
     return rnd((1.0 + sc) * norm + sh, dt)
+
+
+def fused_modulate_metal_literal(x, shift, scale, dt: str = "f32", threads: int = 256) -> np.ndarray:
+    """metal_kernels.rs:28-94 line by line, every intermediate held in T (`dt`): 256 threads stride the row accumulating
+    local_sum / local_sum_sq in T (:44-52), the tree reduction 128..1 adds in T (:59-74), mean = sum / T(dim),
+    var = max(sum_sq / T(dim) - mean*mean, 0), inv_std = rsqrt(var + T(1e-6)) (:78-84), out = (T(1) + scale[i]) *
+    ((x - mean) * inv_std) + shift[i] with scale / shift indexed by the COLUMN ONLY (:87-92) -- rows of every batch
+    element read the first `dim` entries of the flattened shift / scale.  x [..., dim]; shift, scale any shape with at
+    least `dim` elements."""
+    x = np.asarray(x, dtype=np.float32)
+    dim = x.shape[-1]
+    rows = x.reshape(-1, dim)
+    sh = np.asarray(shift, dtype=np.float32).reshape(-1)[:dim].astype(np.float64)
+    sc = np.asarray(scale, dtype=np.float32).reshape(-1)[:dim].astype(np.float64)
+    r = lambda v: rnd(np.asarray(v, dtype=np.float64), dt).astype(np.float64)   # one operation, rounded to T
+    out = np.empty_like(rows)
+    for ri in range(rows.shape[0]):
+        row = r(rows[ri])
+        ls, lq = np.zeros(threads), np.zeros(threads)
+        for i0 in range(0, dim, threads):                      # every thread's next element, in lock step
+            v = np.zeros(threads)
+            n = min(threads, dim - i0)
+            v[:n] = row[i0:i0 + n]
+            ls[:n] = r(ls[:n] + v[:n])
+            lq[:n] = r(lq[:n] + r(v[:n] * v[:n]))
+        half = threads // 2
+        while half >= 1:
+            ls[:half] = r(ls[:half] + ls[half:2 * half])
+            lq[:half] = r(lq[:half] + lq[half:2 * half])
+            half //= 2
+        mean = r(ls[0] / r(float(dim)))
+        var = np.maximum(r(r(lq[0] / r(float(dim))) - r(mean * mean)), 0.0)
+        inv_std = r(1.0 / np.sqrt(r(var + r(1e-6))))
+        normalized = r(r(row - mean) * inv_std)
+        out[ri] = r(r(r(1.0 + sc) * normalized) + sh)
+    return out.reshape(x.shape).astype(np.float32)
 
 
 # --------------------------------------------------------------------------

@@ -158,3 +158,26 @@ def test_sampler_temperature_zero_is_argmax_and_nonzero_is_categorical():   # ml
     np.testing.assert_array_equal(rc.sample(logits, 0.7, k), want)
     # a very cold temperature concentrates on the (first) maximum
     np.testing.assert_array_equal(rc.sample(np.array([[0.0, 5.0, 1.0]], np.float32), 1e-3, k), [1])
+
+
+def test_fused_modulate_literal_metal_restatement_vs_the_mathematical_one():
+    """VERDICT r1 (oracle fidelity): `rc.fused_modulate` is the float64 function; the Metal kernel (metal_kernels.rs:28-94)
+    accumulates in T and indexes scale / shift by column only.  Both are restated: for f32 inputs and one batch element they
+    agree to float32 accuracy; for bf16 the T-precision statistics move the result by whole bf16 steps (why the product kernel,
+    with fp32 statistics, is held to the mathematical one); for B > 1 the literal kernel applies batch 0's modulation everywhere."""
+    g = np.random.default_rng(5)
+    x = (g.standard_normal((1, 6, 768)) * 2 + 0.3).astype(np.float32)
+    sh, sc = (g.standard_normal((1, 768)) * 0.5).astype(np.float32), (g.standard_normal((1, 768)) * 0.5).astype(np.float32)
+    ideal = rc.fused_modulate(x, sh, sc, 1e-6, "f32")
+    lit = rc.fused_modulate_metal_literal(x, sh, sc, "f32")
+    assert np.abs(lit - ideal).max() <= 2e-5 * np.abs(ideal).max()
+    xb, shb, scb = rc.bf16_round(x), rc.bf16_round(sh), rc.bf16_round(sc)
+    ideal_b = rc.fused_modulate(xb, shb, scb, 1e-6, "bf16")
+    lit_b = rc.fused_modulate_metal_literal(xb, shb, scb, "bf16")
+    rel = np.abs(lit_b - ideal_b).max() / np.abs(ideal_b).max()
+    assert 2.0 ** -8 < rel < 0.2            # visibly different (statistics summed in bf16), same function
+    x2 = np.concatenate([x, x[:, ::-1]], 0)
+    sh2, sc2 = np.concatenate([sh, -sh], 0), np.concatenate([sc, sc * 0.5], 0)
+    lit2 = rc.fused_modulate_metal_literal(x2, sh2, sc2, "f32")
+    np.testing.assert_allclose(lit2[1], rc.fused_modulate(x2[1:2], sh2[:1], sc2[:1], 1e-6, "f32")[0], rtol=2e-5, atol=2e-5)   # batch 0's shift / scale
+    assert np.abs(lit2[1] - rc.fused_modulate(x2, sh2, sc2, 1e-6, "f32")[1]).max() > 0.1                                   # not its own

@@ -394,8 +394,11 @@ int omx_whisper_mel_forward(omx_mel_frontend f, const float* audio, int64_t n_sa
  *   omx_sanm_encoder_layer  SanmEncoderLayer::forward :618-634 = LayerNorm(1e-5) -> SanmAttention (:496-532:
  *       fused qkv Linear, softmax(q k^T d^-1/2) v with heads x 128, FSMN depthwise Conv1d(k=11, pad 5) over v
  *       plus v, out_proj) -> residual (skipped when in_dim != dim, :625-629) -> LayerNorm -> Linear/ReLU/Linear
- *       (:560-570) -> residual.  x [T, in_dim] -> out [T, dim], bf16 device tensors; weights bf16:
- *       Linear [out, in] + bias [out]; fsmn_w [dim, kernel_size] (MLX Conv1d weight [C, k, 1], :1293-1298).
+ *       (:560-570) -> residual.  x [T, in_dim] -> out [T, dim]; weights: Linear [out, in] + bias [out];
+ *       fsmn_w [dim, kernel_size] (MLX Conv1d weight [C, k, 1], :1293-1298).
+ *   Every entry point takes the arithmetic mode as `dtype` -- activations AND weights are of that type:
+ *       OMX_FLOAT32   the reference's own (f32 checkpoint, f32 activations; exact-f32 matrix cores, explicit softmax);
+ *       OMX_BFLOAT16  bf16 with fp32 accumulation (faster; narrower than the reference).
  *   omx_cif_fire            CIFPredictor::cif_fire :779-879 (threshold 1.0, tail 0.45): hidden [B, T, H] f32,
  *       alphas [B, T] f32 -> frames [B, max_frames, H] f32 (zero padded) and counts [B]; all device pointers.
  * ===================================================================================== */
@@ -404,31 +407,32 @@ typedef struct omx_sanm_layer_weights_ {
         *ffn_down_w, *ffn_down_b;
 } omx_sanm_layer_weights;
 int omx_sanm_encoder_layer(void* out, const void* x, const omx_sanm_layer_weights* w, int T, int in_dim, int dim,
-                           int heads, int ffn_dim, int kernel_size, omx_stream stream);
+                           int heads, int ffn_dim, int kernel_size, omx_dtype dtype, omx_stream stream);
 int omx_cif_fire(float* frames, int* counts, const float* hidden, const float* alphas, int batch, int T, int H,
                  float threshold, float tail_threshold, int max_frames, omx_stream stream);
-/* SanmEncoder::forward prologue (paraformer.rs:691-703): out bf16 [T, dim] = mel f32 [T, dim] * sqrt(512) + sinusoidal
+/* SanmEncoder::forward prologue (paraformer.rs:691-703): out [T, dim] = mel f32 [T, dim] * sqrt(512) + sinusoidal
  * position encoding (positions 1.., [sin | cos] halves, :418-439) */
-int omx_paraformer_embed(void* out, const float* mel, int T, int dim, omx_stream stream);
+int omx_paraformer_embed(void* out, const float* mel, int T, int dim, omx_dtype dtype, omx_stream stream);
 /* CIFPredictor::compute_alphas (:761-768): alphas f32 [T] = sigmoid(Linear_{dim->1}(relu(Conv1d_{k}(enc)))) with the dense
  * convolution weight in MLX layout [dim_out, k, dim_in]; also writes enc as f32 (the hidden CIF integrates)           */
 int omx_cif_alphas(float* alphas, float* hidden_f32, const void* enc, const void* conv_w, const void* conv_b,
-                   const void* proj_w, const void* proj_b, int T, int dim, int kernel_size, omx_stream stream);
+                   const void* proj_w, const void* proj_b, int T, int dim, int kernel_size, omx_dtype dtype, omx_stream stream);
 /* ParaformerDecoderLayer::forward (:1030-1053) incl. cross_attention (:981-1017): x [N, dim] acoustic embeddings,
- * enc [Ts, enc_dim] encoder output, both bf16; FFN down has no bias (loader :1421)                                    */
+ * enc [Ts, enc_dim] encoder output; FFN down has no bias (loader :1421)                                              */
 typedef struct omx_paraformer_decoder_weights_ {
     const void *norm1_w, *norm1_b, *ffn_up_w, *ffn_up_b, *ffn_norm_w, *ffn_norm_b, *ffn_down_w, *norm2_w, *norm2_b, *fsmn_w,
         *norm3_w, *norm3_b, *q_w, *q_b, *kv_w, *kv_b, *out_w, *out_b;
 } omx_paraformer_decoder_weights;
 int omx_paraformer_decoder_layer(void* out, const void* x, const void* enc, const omx_paraformer_decoder_weights* w, int N,
-                                 int Ts, int dim, int enc_dim, int heads, int ffn_dim, int kernel_size, omx_stream stream);
+                                 int Ts, int dim, int enc_dim, int heads, int ffn_dim, int kernel_size, omx_dtype dtype,
+                                 omx_stream stream);
 /* ParaformerDecoder::forward tail (:1157-1165): LN -> Linear+ReLU -> LN(ffn) -> Linear(no bias) -> LN -> output_proj;
- * logits bf16 [N, vocab]                                                                                               */
+ * logits [N, vocab]                                                                                                    */
 typedef struct omx_paraformer_tail_weights_ {
     const void *norm1_w, *norm1_b, *up_w, *up_b, *ffn_norm_w, *ffn_norm_b, *down_w, *after_norm_w, *after_norm_b, *out_w, *out_b;
 } omx_paraformer_tail_weights;
 int omx_paraformer_decoder_tail(void* logits, const void* x, const omx_paraformer_tail_weights* w, int N, int dim, int ffn_dim,
-                                int vocab, omx_stream stream);
+                                int vocab, omx_dtype dtype, omx_stream stream);
 /* elementwise dtype conversion between bf16 / f16 / f32 device buffers (Array::as_dtype) */
 int omx_cast(void* dst, omx_dtype dst_dtype, const void* src, omx_dtype src_dtype, int64_t n, omx_stream stream);
 

@@ -83,6 +83,18 @@ int launch_gemm_bf16_swiglu(bf16_t* out_plain, int ld_plain, bf16_t* out_act, in
 int launch_gemm_bf16_grouped(bf16_t* out, const bf16_t* x, const bf16_t* w, int max_rows, int N, int K,
                              const GroupedDesc& g, int max_tiles, hipStream_t s);
 
+// float32 GEMM on the f32-input matrix cores (gemm_f32.hip): out[b] = alpha * A[b] . B[b] (+ bias) (relu) (+ resid), strided and
+// batched; B is [N, K] row-major (b_nn = 0, nn::Linear) or [K, N] row-major (b_nn = 1)
+struct GemmF32 {
+    const float* a; const float* b; const float* bias; const float* resid; float* out;
+    int M, N, K;
+    int64_t lda, ldb, ldc, ldr;    // leading dimensions (ldr 0: = ldc)
+    int64_t sa, sb, sc;            // batch strides
+    int batch, relu, b_nn;
+    float alpha;
+};
+int launch_gemm_f32(const GemmF32& p, hipStream_t s);
+
 // the ring kernel keeps one fixed-size split-K scratch per stream; whoever destroys a stream hands it back first
 void gemm_release_stream(hipStream_t s);
 

@@ -1,0 +1,190 @@
+// float32 GEMM on the f32-input matrix cores (v_mfma_f32_32x32x2_f32: exact f32, a k-ordered fmaf chain per output, 157 TF
+// chip peak = 1/16 of the bf16 rate).  The one model on the path that the reference runs in float32 is Paraformer
+// (funasr-mlx/src/paraformer.rs:496-532, 560-570, 618-634, 981-1053: f32 weights converted from PyTorch, f32 activations):
+// 0.17 TFLOP for 30 s of audio, GEMMs of 200-500 rows -- so this kernel is built for SMALL problems (64 x 64 tiles so that a
+// [501, 512] output still gives 64 blocks, split-K when even that leaves the chip idle), not for a roofline number.
+//   out[b][m, n] = alpha * sum_k A[b][m, k] * B[b](k, n) (+ bias[n]) (relu) (+ resid[m, n])
+//   B(k, n) = B[n * ldb + k]   ("NT": an nn::Linear weight [N, K], mlx-rs/src/nn/linear.rs:87-92)    or
+//           = B[k * ldb + n]   ("NN": P . V of the explicit attention, paraformer.rs:513-515)
+// Tile: 64 x 64 x 64 per block, 4 waves, one 32 x 32 accumulator tile per wave; operands go global -> registers (the next
+// K tile is in flight while the current one is multiplied) -> LDS; LDS rows are padded to 65 floats, which makes both the
+// 4-byte fragment reads (lane l: row l & 31, k = l >> 5) and the staging writes conflict-free.
+#include "gemm.hpp"
+#include "workspace.hpp"
+
+namespace omx {
+
+namespace {
+
+constexpr int TM = 64, TN = 64, TK = 64, LDS_LD = TK + 1;
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+struct F32Args {
+    const float* a; const float* b; const float* bias; const float* resid; float* out; float* partial;
+    int M, N, K;
+    int64_t lda, ldb, ldc, ldr, sa, sb, sc;   // leading dimensions and per-batch strides (elements)
+    int batch, splits, relu, b_nn;
+    float alpha;
+};
+
+// stage one [64 rows x 64 k] operand tile held k-contiguous in memory (A, or B in NT form) into registers: thread t covers
+// row t / 16 (+ 16 i), k quad t % 16
+__device__ __forceinline__ void load_rows(f32x4 (&r)[4], const float* base, int64_t ld, int row0, int rows, int k0, int kend) {
+    const int rq = threadIdx.x >> 4, kq = (threadIdx.x & 15) * 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = row0 + rq + 16 * i, k = k0 + kq;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (row < rows) {
+            const float* p = base + (int64_t)row * ld + k;
+            if (k + 3 < kend && ((reinterpret_cast<uintptr_t>(p) & 15u) == 0)) v = *reinterpret_cast<const f32x4*>(p);
+            else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = (k + e < kend) ? p[e] : 0.f;
+            }
+        }
+        r[i] = v;
+    }
+}
+__device__ __forceinline__ void store_rows(float* lds, const f32x4 (&r)[4]) {
+    const int rq = threadIdx.x >> 4, kq = (threadIdx.x & 15) * 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) lds[(rq + 16 * i) * LDS_LD + kq + e] = r[i][e];
+}
+// B in NN form: the tile is [64 k x 64 n] with n contiguous in memory; staged TRANSPOSED into the same [n][k] LDS layout
+__device__ __forceinline__ void load_cols(f32x4 (&r)[4], const float* base, int64_t ld, int n0, int ncols, int k0, int kend) {
+    const int kr = threadIdx.x >> 4, nq = (threadIdx.x & 15) * 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int k = k0 + kr + 16 * i, n = n0 + nq;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (k < kend) {
+            const float* p = base + (int64_t)k * ld + n;
+            if (n + 3 < ncols && ((reinterpret_cast<uintptr_t>(p) & 15u) == 0)) v = *reinterpret_cast<const f32x4*>(p);
+            else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = (n + e < ncols) ? p[e] : 0.f;
+            }
+        }
+        r[i] = v;
+    }
+}
+__device__ __forceinline__ void store_cols(float* lds, const f32x4 (&r)[4]) {
+    const int kr = threadIdx.x >> 4, nq = (threadIdx.x & 15) * 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) lds[(nq + e) * LDS_LD + kr + 16 * i] = r[i][e];
+}
+
+__global__ __launch_bounds__(256) void gemm_f32_kernel(const F32Args g) {
+    __shared__ float As[TM * LDS_LD];
+    __shared__ float Bs[TN * LDS_LD];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave >> 1, wn = wave & 1;                    // the wave's 32 x 32 quadrant
+    const int m0 = blockIdx.y * TM, n0 = blockIdx.x * TN;
+    const int bz = blockIdx.z / g.splits, split = blockIdx.z % g.splits;
+    const float* A = g.a + (int64_t)bz * g.sa;
+    const float* B = g.b + (int64_t)bz * g.sb;
+    // this split's K range, in whole K tiles
+    const int ktiles = (g.K + TK - 1) / TK, per = (ktiles + g.splits - 1) / g.splits;
+    const int kbeg = split * per * TK, kend = min(g.K, (split + 1) * per * TK);
+
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    // (measured: a second K tile in flight in registers -- two alternating register sets, 127 VGPRs -- made the 30 s pass 11.0 ms
+    //  instead of 10.1 ms: the kernel is not waiting for memory, its tiles are chains of dependent 64-cycle MFMAs)
+    f32x4 ra[4], rb[4];
+    if (kbeg < kend) {
+        load_rows(ra, A, g.lda, m0, g.M, kbeg, kend);
+        if (g.b_nn) load_cols(rb, B, g.ldb, n0, g.N, kbeg, kend);
+        else load_rows(rb, B, g.ldb, n0, g.N, kbeg, kend);
+    }
+    for (int k0 = kbeg; k0 < kend; k0 += TK) {
+        __syncthreads();                                        // the previous tile's fragment reads are done
+        store_rows(As, ra);
+        if (g.b_nn) store_cols(Bs, rb); else store_rows(Bs, rb);
+        __syncthreads();
+        if (k0 + TK < kend) {                                   // next tile in flight under this tile's matrix work
+            load_rows(ra, A, g.lda, m0, g.M, k0 + TK, kend);
+            if (g.b_nn) load_cols(rb, B, g.ldb, n0, g.N, k0 + TK, kend);
+            else load_rows(rb, B, g.ldb, n0, g.N, k0 + TK, kend);
+        }
+        const float* ap = As + (wm * 32 + (lane & 31)) * LDS_LD + (lane >> 5);
+        const float* bp = Bs + (wn * 32 + (lane & 31)) * LDS_LD + (lane >> 5);
+        // all 64 fragment reads of the tile go out as one burst ahead of the 32 dependent MFMAs (64 cycles each): with an
+        // 8-step unroll every group of 8 paid the LDS latency again
+        float fa[TK / 2], fb[TK / 2];
+#pragma unroll
+        for (int kk = 0; kk < TK; kk += 2) { fa[kk / 2] = ap[kk]; fb[kk / 2] = bp[kk]; }
+#pragma unroll
+        for (int kk = 0; kk < TK / 2; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kk], fb[kk], acc, 0, 0, 0);
+    }
+    // C/D map of the 32 x 32 forms: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+    const int col = n0 + wn * 32 + (lane & 31);
+    if (col >= g.N) return;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (row >= g.M) continue;
+        if (g.splits > 1) {
+            g.partial[(((int64_t)bz * g.splits + split) * g.M + row) * g.N + col] = acc[r];
+        } else {
+            float v = acc[r] * g.alpha;
+            if (g.bias) v += g.bias[col];
+            if (g.relu) v = fmaxf(v, 0.f);
+            if (g.resid) v += g.resid[(int64_t)row * g.ldr + col];
+            g.out[(int64_t)bz * g.sc + (int64_t)row * g.ldc + col] = v;
+        }
+    }
+}
+
+// sums the split-K partials in split order (deterministic) and applies the epilogue.  (Measured alternative: the last block to
+// arrive at a per-tile counter reduces in the same launch -- write-through 4-byte partial stores and the serial re-read made
+// the 30 s pass 14.4 ms instead of 10.1 ms; a second launch of 256 K elements is cheaper.)
+__global__ __launch_bounds__(256) void gemm_f32_reduce_kernel(const F32Args g) {
+    const int64_t total = (int64_t)g.batch * g.M * g.N;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int col = (int)(i % g.N), row = (int)((i / g.N) % g.M), bz = (int)(i / ((int64_t)g.M * g.N));
+        float v = 0.f;
+        for (int s = 0; s < g.splits; ++s) v += g.partial[(((int64_t)bz * g.splits + s) * g.M + row) * g.N + col];
+        v *= g.alpha;
+        if (g.bias) v += g.bias[col];
+        if (g.relu) v = fmaxf(v, 0.f);
+        if (g.resid) v += g.resid[(int64_t)row * g.ldr + col];
+        g.out[(int64_t)bz * g.sc + (int64_t)row * g.ldc + col] = v;
+    }
+}
+
+}  // namespace
+
+int launch_gemm_f32(const GemmF32& p, hipStream_t s) {
+    OMX_REQUIRE(p.a && p.b && p.out && p.M > 0 && p.N > 0 && p.K > 0 && p.batch >= 1, "gemm_f32: bad arguments (M=%d N=%d K=%d)", p.M, p.N, p.K);
+    F32Args g = {p.a, p.b, p.bias, p.resid, p.out, nullptr, p.M, p.N, p.K, p.lda, p.ldb, p.ldc, p.ldr ? p.ldr : p.ldc, p.sa, p.sb, p.sc,
+                 p.batch, 1, p.relu, p.b_nn, p.alpha};
+    const int gx = (p.N + TN - 1) / TN, gy = (p.M + TM - 1) / TM, tiles = gx * gy * p.batch, ktiles = (p.K + TK - 1) / TK;
+    // split K while the tile grid leaves most of the chip idle and every split keeps >= 2 K tiles: a wave's tile is a chain of
+    // K / 2 dependent 64-cycle MFMAs (7.8 us at K = 512) whatever the tile shape, so for 64-tile outputs (out_proj, ffn_down,
+    // P . V) the only way to use the other 192 CUs is to cut K
+    int splits = 1;
+    while (tiles * splits * 2 <= 256 && ktiles / (splits * 2) >= 2) splits *= 2;
+    g.splits = splits;
+    if (splits > 1) {
+        void* ws = nullptr;
+        if (get_workspace_aux(&ws, (size_t)p.batch * splits * p.M * p.N * sizeof(float))) return 1;
+        g.partial = (float*)ws;
+    }
+    gemm_f32_kernel<<<dim3(gx, gy, p.batch * splits), 256, 0, s>>>(g);
+    OMX_LAUNCH_CHECK();
+    if (splits > 1) {
+        const int64_t total = (int64_t)p.batch * p.M * p.N;
+        gemm_f32_reduce_kernel<<<(unsigned)std::min<int64_t>((total + 255) / 256, 4096), 256, 0, s>>>(g);
+        OMX_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+}  // namespace omx

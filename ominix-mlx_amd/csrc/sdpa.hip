@@ -30,6 +30,22 @@ int get_workspace(void** ptr, size_t bytes) {
     return 0;
 }
 
+// a second, independent buffer: for launchers that are called while their CALLER holds pointers into the main workspace
+// (the f32 GEMM's split-K partials inside the Paraformer layers)
+static void* g_ws2 = nullptr;
+static size_t g_ws2_bytes = 0;
+int get_workspace_aux(void** ptr, size_t bytes) {
+    std::lock_guard<std::mutex> lk(g_ws_mu);
+    if (bytes > g_ws2_bytes) {
+        if (g_ws2) OMX_HIP_CHECK(hipFree(g_ws2));        // (hipFree waits for the device: nothing still reads the old buffer)
+        const size_t want = bytes < (size_t)(8u << 20) ? (size_t)(8u << 20) : bytes;
+        OMX_HIP_CHECK(hipMalloc(&g_ws2, want));
+        g_ws2_bytes = want;
+    }
+    *ptr = g_ws2;
+    return 0;
+}
+
 int decode_nsplit(int Tk, int BHkv) {
     // one 64-token step per block until the grid reaches ~2 blocks per CU
     int n = (Tk + 63) / 64;
@@ -94,9 +110,13 @@ int omx_linear(void* out, const void* x, const void* w, const void* bias, int M,
                omx_stream stream) {
     OMX_REQUIRE(out && x && w, "omx_linear: null tensor");
     OMX_REQUIRE(M >= 0 && N > 0 && K > 0, "omx_linear: bad shape M=%d N=%d K=%d", M, N, K);
-    OMX_REQUIRE(dtype == OMX_BFLOAT16, "omx_linear: only bfloat16 is implemented (got dtype %d)", (int)dtype);
+    OMX_REQUIRE(dtype == OMX_BFLOAT16 || dtype == OMX_FLOAT32, "omx_linear: bfloat16 and float32 are implemented (got dtype %d)", (int)dtype);
     if (M == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
+    if (dtype == OMX_FLOAT32) {   // exact-f32 matrix cores (gemm_f32.hip): the Paraformer path's dtype
+        omx::GemmF32 g = {(const float*)x, (const float*)w, (const float*)bias, nullptr, (float*)out, M, N, K, K, K, N, 0, 0, 0, 0, 1, 0, 0, 1.0f};
+        return omx::launch_gemm_f32(g, s);
+    }
     if (M <= 4 && bias == nullptr && K % 8 == 0 && K <= 65536) {   // HBM-streaming GEMV (tuned widths, generic kernel otherwise)
         for (int m = 0; m < M; ++m) {
             omx::GemvArgs a = {};

@@ -5,4 +5,5 @@
 #include "common.hpp"
 namespace omx {
 int get_workspace(void** ptr, size_t bytes);
+int get_workspace_aux(void** ptr, size_t bytes);   // independent of the above (callers nested inside a get_workspace user)
 }

@@ -33,13 +33,13 @@ class TailWeights(ctypes.Structure):
 
 
 PARAFORMER_SIGNATURES = {
-    "omx_paraformer_embed": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
-    "omx_cif_alphas": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "omx_paraformer_embed": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "omx_cif_alphas": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "omx_paraformer_decoder_layer": (c_int, [c_void_p, c_void_p, c_void_p, ctypes.POINTER(DecoderLayerWeights), c_int, c_int, c_int,
-                                             c_int, c_int, c_int, c_int, c_void_p]),
-    "omx_paraformer_decoder_tail": (c_int, [c_void_p, c_void_p, ctypes.POINTER(TailWeights), c_int, c_int, c_int, c_int, c_void_p]),
+                                             c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "omx_paraformer_decoder_tail": (c_int, [c_void_p, c_void_p, ctypes.POINTER(TailWeights), c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "omx_cast": (c_int, [c_void_p, c_int, c_void_p, c_int, ctypes.c_int64, c_void_p]),
-    "omx_sanm_encoder_layer": (c_int, [c_void_p, c_void_p, ctypes.POINTER(SanmLayerWeights), c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "omx_sanm_encoder_layer": (c_int, [c_void_p, c_void_p, ctypes.POINTER(SanmLayerWeights), c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "omx_cif_fire": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_float, c_int, c_void_p]),
 }
 for _n, (_r, _a) in PARAFORMER_SIGNATURES.items():
@@ -50,8 +50,10 @@ for _n, (_r, _a) in PARAFORMER_SIGNATURES.items():
 class SanmEncoderLayer:
     """weights: dict with the keys of SanmLayerWeights (Linear [out,in] + bias, fsmn_w [dim, k]), numpy arrays."""
 
-    def __init__(self, weights: dict, heads: int = 4, kernel_size: int = 11):
-        self._t = {k: Tensor.from_numpy(np.asarray(weights[k]), "bf16") for k in _FIELDS}
+    def __init__(self, weights: dict, heads: int = 4, kernel_size: int = 11, dtype: str = "f32"):
+        """dtype "f32": the reference's arithmetic (f32 weights and activations); "bf16": narrower and faster."""
+        self.dtype = dtype
+        self._t = {k: Tensor.from_numpy(np.asarray(weights[k]), dtype) for k in _FIELDS}
         self.w = SanmLayerWeights(*[self._t[k].ptr for k in _FIELDS])
         self.heads, self.kernel_size = heads, kernel_size
         self.in_dim = self._t["qkv_w"].shape[1]
@@ -62,7 +64,7 @@ class SanmEncoderLayer:
         T = x.shape[-2]
         out = Tensor(tuple(x.shape[:-1]) + (self.dim,), x.dtype)
         check(lib.omx_sanm_encoder_layer(out.ptr, x.ptr, ctypes.byref(self.w), T, self.in_dim, self.dim, self.heads, self.ffn_dim,
-                                         self.kernel_size, None))
+                                         self.kernel_size, out.dtype, None))
         return out
 
 
@@ -94,8 +96,11 @@ class Paraformer:
     `weights`: the checkpoint dict the reference's loader reads (load_paraformer_weights, :1300-1477), conv
     weights in the PyTorch layout it transposes (:1293-1298)."""
 
-    def __init__(self, weights: dict, config: dict = None):
+    def __init__(self, weights: dict, config: dict = None, dtype: str = "f32"):
+        """dtype "f32" (default): the reference's arithmetic -- f32 weights as its loader converts them (paraformer.rs:1300-1477),
+        f32 activations, exact-f32 matrix-core GEMMs; "bf16": bf16 weights / activations with fp32 accumulation."""
         self.cfg = dict(DEFAULT_CONFIG, **(config or {}))
+        self.dtype = dtype
         c, self._keep = self.cfg, []
         if c["cif_l_order"] != c["cif_r_order"]:
             raise ValueError("CIF asymmetric padding (l_order != r_order) not yet supported")   # :736-740
@@ -104,7 +109,7 @@ class Paraformer:
             if key not in weights:
                 raise KeyError(f"Missing weight: {key}")                                       # get_weight, :1287-1291
             a = np.asarray(weights[key])
-            t = Tensor.from_numpy(transform(a) if transform else a, "bf16")
+            t = Tensor.from_numpy(transform(a) if transform else a, dtype)
             self._keep.append(t)
             return t.ptr
 
@@ -139,21 +144,22 @@ class Paraformer:
                                 dev("decoder.output_proj.bias"))
 
     def encode(self, mel: Tensor) -> Tensor:
-        """SanmEncoder::forward (:691-708): mel f32 [T, n_mels*lfr_m] (device) -> encoder_out bf16 [T, encoder_dim]."""
+        """SanmEncoder::forward (:691-708): mel f32 [T, n_mels*lfr_m] (device) -> encoder_out [T, encoder_dim]."""
         from .ops import layer_norm
         c = self.cfg
         T, in0 = mel.shape[-2], c["n_mels"] * c["lfr_m"]
-        h = Tensor((T, in0), "bf16")
-        check(lib.omx_paraformer_embed(h.ptr, mel.ptr, T, in0, None))
+        dt = self.dtype
+        h = Tensor((T, in0), dt)
+        check(lib.omx_paraformer_embed(h.ptr, mel.ptr, T, in0, h.dtype, None))
         in_dim = in0
         # two buffers, alternating: releasing a device buffer per layer would synchronise host and GPU 50 times
-        bufs = [Tensor((T, c["encoder_dim"]), "bf16"), Tensor((T, c["encoder_dim"]), "bf16")]
+        bufs = [Tensor((T, c["encoder_dim"]), dt), Tensor((T, c["encoder_dim"]), dt)]
         for i, w in enumerate(self.enc_layers):
             out = bufs[i & 1]
             check(lib.omx_sanm_encoder_layer(out.ptr, h.ptr, ctypes.byref(w), T, in_dim, c["encoder_dim"], c["encoder_heads"],
-                                             c["encoder_ffn_dim"], c["sanm_kernel_size"], None))
+                                             c["encoder_ffn_dim"], c["sanm_kernel_size"], out.dtype, None))
             h, in_dim = out, c["encoder_dim"]
-        out = Tensor(h.shape, "bf16")
+        out = Tensor(h.shape, dt)
         check(lib.omx_layer_norm(out.ptr, h.ptr, self.after_norm[0], self.after_norm[1], T, c["encoder_dim"], 1e-5, out.dtype, None))
         return out
 
@@ -162,7 +168,7 @@ class Paraformer:
         c = self.cfg
         T, E = enc.shape
         alphas, hidden = Tensor((1, T), FLOAT32), Tensor((1, T, E), FLOAT32)
-        check(lib.omx_cif_alphas(alphas.ptr, hidden.ptr, enc.ptr, *self.pred, T, E, c["cif_l_order"] + c["cif_r_order"] + 1, None))
+        check(lib.omx_cif_alphas(alphas.ptr, hidden.ptr, enc.ptr, *self.pred, T, E, c["cif_l_order"] + c["cif_r_order"] + 1, enc.dtype, None))
         frames = Tensor((1, T + 1, E), FLOAT32)
         counts = Tensor((1,), "u32")
         check(lib.omx_cif_fire(frames.ptr, counts.ptr, hidden.ptr, alphas.ptr, 1, T, E, c["cif_threshold"], c["cif_tail_threshold"], T + 1, None))
@@ -170,19 +176,20 @@ class Paraformer:
         return (frames.slice_rows(0, (n, E)) if n else None), n, alphas
 
     def decode(self, embeds: Tensor, enc: Tensor) -> Tensor:
-        """ParaformerDecoder::forward (:1144-1166): acoustic_embeds f32 [N, D] -> logits bf16 [N, vocab]."""
+        """ParaformerDecoder::forward (:1144-1166): acoustic_embeds f32 [N, D] -> logits [N, vocab]."""
         c = self.cfg
         N, Ts = embeds.shape[0], enc.shape[0]
-        x = _cast(embeds, "bf16")
-        bufs = [Tensor((N, c["decoder_dim"]), "bf16"), Tensor((N, c["decoder_dim"]), "bf16")]
+        dt = self.dtype
+        x = embeds if dt == "f32" else _cast(embeds, dt)
+        bufs = [Tensor((N, c["decoder_dim"]), dt), Tensor((N, c["decoder_dim"]), dt)]
         for i, w in enumerate(self.dec_layers):
             out = bufs[i & 1]
             check(lib.omx_paraformer_decoder_layer(out.ptr, x.ptr, enc.ptr, ctypes.byref(w), N, Ts, c["decoder_dim"], c["encoder_dim"],
-                                                   c["decoder_heads"], c["decoder_ffn_dim"], c["sanm_kernel_size"], None))
+                                                   c["decoder_heads"], c["decoder_ffn_dim"], c["sanm_kernel_size"], out.dtype, None))
             x = out
-        logits = Tensor((N, c["vocab_size"]), "bf16")
+        logits = Tensor((N, c["vocab_size"]), dt)
         check(lib.omx_paraformer_decoder_tail(logits.ptr, x.ptr, ctypes.byref(self.tail), N, c["decoder_dim"], c["decoder_ffn_dim"],
-                                              c["vocab_size"], None))
+                                              c["vocab_size"], logits.dtype, None))
         return logits
 
     def transcribe_from_mel(self, mel: Tensor):

@@ -192,3 +192,21 @@ def test_sdpa_prefill_spike_forces_rescale(omx):
     k[0, 1, 200] = rc.bf16_round(q[0, 1, 230] * 6)   # late-tile spike for query 230 of head 1
     scale = D ** -0.5
     _check(_sdpa(omx, q, k, v, scale, "causal"), rc.scaled_dot_product_attention(q, k, v, scale, "causal", "bf16"))
+
+
+@pytest.mark.parametrize("M,N,K,bias", [(501, 512, 560, True), (501, 2048, 512, True), (501, 512, 2048, True), (216, 8404, 512, True),
+                                         (33, 70, 45, False), (1, 64, 64, False), (130, 66, 1026, True)])
+def test_linear_f32_on_the_f32_matrix_cores(omx, M, N, K, bias):
+    """omx_linear(dtype = f32) -> gemm_f32.hip (v_mfma_f32_32x32x2_f32, exact f32 products and accumulation; split-K partials
+    summed in split order): the Paraformer path's arithmetic (funasr-mlx/src/paraformer.rs is f32 throughout).  Against float64:
+    f32-roundoff class, <= 1e-6 * sum|a b| per output (MI355X_MICROARCH: 0.75-3.5e-7 measured)."""
+    T = omx.ops.Tensor
+    g = np.random.default_rng(M * 7 + N)
+    x = g.standard_normal((M, K)).astype(np.float32)
+    w = (g.standard_normal((N, K)) * 0.1).astype(np.float32)
+    b = g.standard_normal(N).astype(np.float32) if bias else None
+    got = omx.ops.linear(T.from_numpy(x, "f32"), T.from_numpy(w, "f32"), T.from_numpy(b, "f32") if bias else None).numpy()
+    want = x.astype(np.float64) @ w.astype(np.float64).T + (b.astype(np.float64) if bias else 0.0)
+    mag = np.abs(x).astype(np.float64) @ np.abs(w).astype(np.float64).T + 1.0
+    assert got.dtype == np.float32 and np.abs(got - want).max() <= 1e-6 * mag.max()
+    assert (np.abs(got - want) <= 1e-6 * mag).all()

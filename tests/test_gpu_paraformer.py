@@ -1,6 +1,7 @@
-"""GPU parity of the Paraformer body pieces (a13) against oracle/ref_paraformer.py.
-Tolerance: the reference path is float32; the MI355X build keeps activations in bf16, so the encoder
-layer is compared at 2^-6 * max|ref|; CIF is float32 on both sides (1e-5 relative)."""
+"""GPU parity of the Paraformer body pieces (a13) against oracle/ref_paraformer.py (a float64 restatement).
+Two arithmetic modes (include/omx.h): "f32" is the reference's own -- f32 weights and activations (funasr-mlx/src/paraformer.rs),
+exact-f32 matrix-core GEMMs -- and is held to 1e-4 of the largest reference value (VERDICT r1 "Next" #5); "bf16" (bf16 weights and
+activations, fp32 accumulation) is compared at 2^-6 * max|ref|.  CIF is float32 on both sides (1e-5 relative)."""
 import numpy as np
 import pytest
 
@@ -18,18 +19,26 @@ def _weights(in_dim, dim, ffn, k, seed):
             "ffn_down_b": r(dim, sc=0.1)}
 
 
+TOL = {"f32": 1e-4, "bf16": 2.0 ** -6}
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
 @pytest.mark.parametrize("T,in_dim", [(101, 512), (501, 512), (77, 560)])      # 560: the first layer (no attention residual)
-def test_sanm_encoder_layer_matches_oracle(omx, T, in_dim):
+def test_sanm_encoder_layer_matches_oracle(omx, T, in_dim, dtype):
     from ominix_mlx_amd import paraformer
     dim, ffn, heads, k = 512, 2048, 4, 11
     w = _weights(in_dim, dim, ffn, k, 3)
     for key in ("norm1_w", "norm2_w"):
         w[key] = rc.bf16_round(w[key])
-    x = rc.bf16_round(np.random.default_rng(4).standard_normal((T, in_dim)).astype(np.float32))
+    x = np.random.default_rng(4).standard_normal((T, in_dim)).astype(np.float32)
+    if dtype == "bf16":
+        x = rc.bf16_round(x)
+    else:                                                            # f32 mode: weights that are NOT bf16-representable
+        w = {k_: (v * np.float32(1.0009765625)).astype(np.float32) for k_, v in w.items()}
     ref = rp.sanm_encoder_layer(x, w, heads)
-    got = paraformer.SanmEncoderLayer(w, heads, k).forward(omx.ops.Tensor.from_numpy(x)).numpy()
+    got = paraformer.SanmEncoderLayer(w, heads, k, dtype).forward(omx.ops.Tensor.from_numpy(x, dtype)).numpy()
     assert got.shape == ref.shape
-    assert np.abs(got - ref).max() <= 2.0 ** -6 * np.abs(ref).max()
+    assert np.abs(got - ref).max() <= TOL[dtype] * np.abs(ref).max()
 
 
 def test_cif_fire_matches_oracle(omx):
@@ -81,8 +90,9 @@ TINY = dict(n_mels=80, lfr_m=7, encoder_dim=512, encoder_layers=3, encoder_heads
             cif_r_order=1, cif_threshold=1.0, cif_tail_threshold=0.45)
 
 
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
 @pytest.mark.parametrize("N,Ts", [(1, 40), (23, 120), (140, 501)])
-def test_decoder_layer_matches_oracle(omx, N, Ts):
+def test_decoder_layer_matches_oracle(omx, N, Ts, dtype):
     """ParaformerDecoderLayer::forward incl. cross-attention over the encoder output (Tq != Tk)."""
     import ctypes
     from ominix_mlx_amd import paraformer
@@ -90,35 +100,62 @@ def test_decoder_layer_matches_oracle(omx, N, Ts):
     w = rp.synth_checkpoint(TINY, 7)
     p = rp._dec_params(w, "decoder.layers.1")
     g = np.random.default_rng(8)
-    x = rc.bf16_round(g.standard_normal((N, 512)).astype(np.float32))
-    enc = rc.bf16_round(g.standard_normal((Ts, 512)).astype(np.float32))
+    x, enc = g.standard_normal((N, 512)).astype(np.float32), g.standard_normal((Ts, 512)).astype(np.float32)
+    if dtype == "bf16":
+        x, enc = rc.bf16_round(x), rc.bf16_round(enc)
     ref = rp.decoder_layer(x, enc, p, 4)
-    dev = {k: T.from_numpy(np.ascontiguousarray(v)) for k, v in p.items()}
+    dev = {k: T.from_numpy(np.ascontiguousarray(v), dtype) for k, v in p.items()}
     ws = paraformer.DecoderLayerWeights(*[dev[k].ptr for k in paraformer._DEC_FIELDS])
-    out, xd, ed = T((N, 512), "bf16"), T.from_numpy(x), T.from_numpy(enc)      # keep the device buffers alive over the async launch
-    omx.check(omx.lib.omx_paraformer_decoder_layer(out.ptr, xd.ptr, ed.ptr, ctypes.byref(ws), N, Ts, 512, 512, 4, 1024, 11, None))
+    out, xd, ed = T((N, 512), dtype), T.from_numpy(x, dtype), T.from_numpy(enc, dtype)      # keep the device buffers alive over the async launch
+    omx.check(omx.lib.omx_paraformer_decoder_layer(out.ptr, xd.ptr, ed.ptr, ctypes.byref(ws), N, Ts, 512, 512, 4, 1024, 11, out.dtype, None))
     got = out.numpy()
-    assert np.abs(got - ref).max() <= 2.0 ** -6 * np.abs(ref).max()
+    assert np.abs(got - ref).max() <= TOL[dtype] * np.abs(ref).max()
 
 
-def test_predictor_alphas_and_position_encoding_match_oracle(omx):
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_predictor_alphas_and_position_encoding_match_oracle(omx, dtype):
     from ominix_mlx_amd import paraformer
     T = omx.ops.Tensor
     w = rp.synth_checkpoint(TINY, 9)
     g = np.random.default_rng(10)
     mel = (g.standard_normal((57, 560)) * 0.5).astype(np.float32)
-    h, mel_d = T((57, 560), "bf16"), T.from_numpy(mel, "f32")
-    omx.check(omx.lib.omx_paraformer_embed(h.ptr, mel_d.ptr, 57, 560, None))
+    h, mel_d = T((57, 560), dtype), T.from_numpy(mel, "f32")
+    omx.check(omx.lib.omx_paraformer_embed(h.ptr, mel_d.ptr, 57, 560, h.dtype, None))
     ref_h = rp.encoder_embed(mel)
-    assert np.abs(h.numpy() - ref_h).max() <= 2.0 ** -7 * np.abs(ref_h).max()
-    enc = rc.bf16_round(g.standard_normal((57, 512)).astype(np.float32))
+    assert np.abs(h.numpy() - ref_h).max() <= (2.0 ** -7 if dtype == "bf16" else 2e-6) * np.abs(ref_h).max()
+    enc = g.standard_normal((57, 512)).astype(np.float32)
+    if dtype == "bf16":
+        enc = rc.bf16_round(enc)
     conv_w = np.ascontiguousarray(w["predictor.conv.weight"].transpose(0, 2, 1))
     alphas, hidden = T((57,), "f32"), T((57, 512), "f32")
-    dev = [T.from_numpy(a) for a in (enc, conv_w, w["predictor.conv.bias"], w["predictor.output_proj.weight"], w["predictor.output_proj.bias"])]
-    omx.check(omx.lib.omx_cif_alphas(alphas.ptr, hidden.ptr, *[d.ptr for d in dev], 57, 512, 3, None))
+    dev = [T.from_numpy(a, dtype) for a in (enc, conv_w, w["predictor.conv.bias"], w["predictor.output_proj.weight"], w["predictor.output_proj.bias"])]
+    omx.check(omx.lib.omx_cif_alphas(alphas.ptr, hidden.ptr, *[d.ptr for d in dev], 57, 512, 3, dev[0].dtype, None))
     ref_a = rp.predictor_alphas(enc, conv_w, w["predictor.conv.bias"], w["predictor.output_proj.weight"], w["predictor.output_proj.bias"])
     np.testing.assert_array_equal(hidden.numpy(), enc)
-    assert np.abs(alphas.numpy() - ref_a).max() <= 2.0 ** -7
+    assert np.abs(alphas.numpy() - ref_a).max() <= (2.0 ** -7 if dtype == "bf16" else 1e-5)
+
+
+def test_tiny_paraformer_end_to_end_f32_matches_oracle(omx):
+    """The reference's arithmetic end to end (f32 weights, f32 activations): encoder output, alphas, token count, logits
+    within 1e-4 of the float64 restatement's largest value, token ids equal wherever the top-2 margin exceeds twice that."""
+    from ominix_mlx_amd import paraformer
+    T = omx.ops.Tensor
+    w = rp.synth_checkpoint(TINY, 11)
+    mel = (np.random.default_rng(12).standard_normal((83, 560)) * 0.5).astype(np.float32)
+    ref_tok, ref_logits, ref_enc, ref_alphas, ref_emb = rp.transcribe_from_mel(mel, w, TINY)
+    m = paraformer.Paraformer(w, TINY)                               # dtype "f32" is the default
+    assert m.dtype == "f32"
+    enc = m.encode(T.from_numpy(mel, "f32"))
+    assert enc.dtype == omx.FLOAT32 and np.abs(enc.numpy() - ref_enc).max() <= 1e-4 * np.abs(ref_enc).max()
+    emb, n, alphas = m.predict(enc)
+    assert np.abs(alphas.numpy()[0] - ref_alphas).max() <= 1e-4 and n == len(ref_tok)
+    logits = m.decode(emb, enc).numpy()
+    bound = 1e-4 * np.abs(ref_logits).max()
+    assert np.abs(logits - ref_logits).max() <= bound
+    tok, n2 = m.transcribe_from_mel(T.from_numpy(mel, "f32"))
+    safe = rc.argmax_margin(ref_logits) > 2 * bound
+    assert n2 == n and safe.mean() > 0.9
+    np.testing.assert_array_equal(tok[safe], ref_tok[safe])
 
 
 def test_tiny_paraformer_end_to_end_matches_oracle(omx):
@@ -131,7 +168,7 @@ def test_tiny_paraformer_end_to_end_matches_oracle(omx):
     w = rp.synth_checkpoint(TINY, 11)
     mel = (np.random.default_rng(12).standard_normal((83, 560)) * 0.5).astype(np.float32)
     ref_tok, ref_logits, ref_enc, ref_alphas, ref_emb = rp.transcribe_from_mel(mel, w, TINY)
-    m = paraformer.Paraformer(w, TINY)
+    m = paraformer.Paraformer(w, TINY, dtype="bf16")
     enc = m.encode(T.from_numpy(mel, "f32"))
     assert np.abs(enc.numpy() - ref_enc).max() <= 2.0 ** -6 * np.abs(ref_enc).max() * np.sqrt(TINY["encoder_layers"])
     emb, n, alphas = m.predict(enc)

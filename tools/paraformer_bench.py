@@ -10,7 +10,8 @@ from ominix_mlx_amd import audio, paraformer
 
 cfg = dict(paraformer.DEFAULT_CONFIG)
 w = paraformer.random_checkpoint(cfg, 3)
-m = paraformer.Paraformer(w, cfg)
+DT = sys.argv[1] if len(sys.argv) > 1 else "f32"      # "f32" = the reference's arithmetic (default), "bf16"
+m = paraformer.Paraformer(w, cfg, dtype=DT)
 sr, secs = 16000, 30
 g = np.random.default_rng(0)
 t = np.arange(sr * secs) / sr
@@ -42,5 +43,5 @@ for _ in range(5):
         best = r
 (ta, tb, tc, td), mshape, n = best
 tot = ta + tb + tc + td
-print(f"mel {mshape}: frontend {ta*1e3:.2f} ms | encoder {tb*1e3:.2f} ms | predictor+CIF {tc*1e3:.2f} ms | decoder ({n} tokens) {td*1e3:.2f} ms"
+print(f"[{DT}] mel {mshape}: frontend {ta*1e3:.2f} ms | encoder {tb*1e3:.2f} ms | predictor+CIF {tc*1e3:.2f} ms | decoder ({n} tokens) {td*1e3:.2f} ms"
       f" | total {tot*1e3:.2f} ms  RTF {tot/secs:.5f}  ({secs/tot:.0f}x real time)")

@@ -394,7 +394,7 @@ def main():
                           "device_ms_per_step_hip_events": round(dev_ms / args.steps, 4)},
         "prefill": {"tokens": args.prompt, "seconds": round(prefill_s, 4), "device_ms": round(model.last_prefill_ms(), 3),
                     "tokens_per_sec": round(args.prompt / max(model.last_prefill_ms(), 1e-6) * 1e3, 1),
-                    "mode": "token-serial decode steps (TP)" if world > 1 else
+                    "mode": "batched on the tensor-parallel shards: MFMA GEMMs + flash attention, two bf16 all-reduces of [T, hidden] per layer, the last token through the decode step" if world > 1 else
                             "batched: MFMA GEMMs + flash attention over all n tokens (first call: includes the one-time scratch allocation), norm + lm_head + sampler on the last row"},
         "first_tokens": [int(first)] + [int(t) for t in toks[:4]],
     }

@@ -36,7 +36,7 @@ namespace omx {
 namespace {
 
 typedef int (*nccl_allreduce_fn)(const void*, void*, size_t, int, int, void*, hipStream_t);
-constexpr int kNcclFloat32 = 7, kNcclUint64 = 5, kNcclSum = 0, kNcclMax = 2;
+constexpr int kNcclFloat32 = 7, kNcclUint64 = 5, kNcclBfloat16 = 9, kNcclSum = 0, kNcclMax = 2;
 
 struct LayerW {
     const bf16_t *q, *k, *v, *o, *gate, *up, *down, *q_norm, *k_norm, *in_ln, *post_ln;
@@ -704,6 +704,16 @@ int prefill_prefix_batched(omx_qwen3 m, int T, int off, const EncodeOpts* enc = 
         }
         m->pf_cap = T;
     }
+    // tensor parallel: q/k/v/gate/up are this rank's column shards (local H, Hkv, I), o / down are row
+    // shards whose [T, hidden] bf16 partial sums are all-reduced -- two collectives per layer -- before the residual add
+    const bool tp = m->allreduce != nullptr && c.ep_size <= 1;
+    auto row_split = [&](bf16_t* out, const bf16_t* x, const bf16_t* w, const bf16_t* resid, int K) -> int {
+        if (!tp) return launch_gemm_bf16_ex(out, x, w, nullptr, resid, T, hd, K, s);
+        bf16_t* part = m->pf_xn;   // free between the projections that read it and the next norm that rewrites it
+        if (launch_gemm_bf16(part, x, w, nullptr, T, hd, K, s)) return 1;
+        OMX_REQUIRE(m->allreduce(part, part, (size_t)T * hd, kNcclBfloat16, kNcclSum, m->comm, s) == 0, "ncclAllReduce failed");
+        return omx_add(out, resid, part, (int64_t)T * hd, OMX_BFLOAT16, s);
+    };
     const bool quant = c.quant_bits != 0;
     // quantized checkpoint: each weight is dequantised into one scratch matrix right before its GEMM (MLX's qmm does
     // the same per tile); K is the contraction width of that weight
@@ -775,7 +785,7 @@ int prefill_prefix_batched(omx_qwen3 m, int T, int off, const EncodeOpts* enc = 
                                 (int64_t)m->cap * D, scale, enc && enc->mask ? OMX_MASK_ADDITIVE : OMX_MASK_CAUSAL,
                                 enc ? enc->mask : nullptr, s, /*out_token_major=*/true))
             return 1;
-        if (!(w = W(L.o, &Q.o, H * D)) || launch_gemm_bf16_ex(h2, m->pf_attn, w, nullptr, h, T, hd, H * D, s)) return 1;
+        if (!(w = W(L.o, &Q.o, H * D)) || row_split(h2, m->pf_attn, w, h, H * D)) return 1;
         if (omx_rms_norm(m->pf_xn, h2, L.post_ln, T, hd, c.rms_norm_eps, OMX_BFLOAT16, s)) return 1;
         if (c.num_experts > 0) {   // sparse-MoE feed-forward over all T rows (grouped MFMA GEMM route), then the residual
             if (quant) {
@@ -809,7 +819,7 @@ int prefill_prefix_batched(omx_qwen3 m, int T, int off, const EncodeOpts* enc = 
             if (!(w = W(L.up, &Q.up, hd)) || launch_gemm_bf16(m->pf_u, m->pf_xn, w, nullptr, T, I, hd, s)) return 1;
             if (launch_silu_mul(m->pf_g, m->pf_g, m->pf_u, (int64_t)T * I, s)) return 1;
         }
-        if (!(w = W(L.down, &Q.down, I)) || launch_gemm_bf16_ex(h, m->pf_g, w, nullptr, h2, T, hd, I, s)) return 1;
+        if (!(w = W(L.down, &Q.down, I)) || row_split(h, m->pf_g, w, h2, I)) return 1;
         if (enc && next_tap < enc->n_taps && enc->taps[next_tap] == l) {   // raw hidden state, no final norm (:417-420)
             copy_rows_strided_kernel<<<1024, 256, 0, s>>>(enc->out + (size_t)next_tap * hd, (int64_t)enc->n_taps * hd, h, hd, T, hd / 8);
             OMX_LAUNCH_CHECK();
@@ -833,8 +843,14 @@ int omx_qwen3_create(omx_qwen3* out, const omx_qwen3_config* cfg) {
     OMX_REQUIRE(c.hidden_size > 0 && c.hidden_size % 64 == 0, "InvalidConfig: hidden_size %d must be a multiple of 64", c.hidden_size);
     OMX_REQUIRE(c.head_dim == 64 || c.head_dim == 128, "InvalidConfig: head_dim %d (64 or 128 supported)", c.head_dim);
     OMX_REQUIRE(c.num_attention_heads % c.num_key_value_heads == 0, "InvalidConfig: heads %d not a multiple of kv heads %d", c.num_attention_heads, c.num_key_value_heads);
-    OMX_REQUIRE(c.num_key_value_heads % c.tp_size == 0 && c.intermediate_size % c.tp_size == 0 && c.vocab_size % c.tp_size == 0,
-                "InvalidConfig: kv heads %d / intermediate %d / vocab %d must divide by tp_size %d", c.num_key_value_heads, c.intermediate_size, c.vocab_size, c.tp_size);
+    OMX_REQUIRE(c.num_attention_heads % c.tp_size == 0 && c.intermediate_size % c.tp_size == 0 && c.vocab_size % c.tp_size == 0,
+                "InvalidConfig: heads %d / intermediate %d / vocab %d must divide by tp_size %d", c.num_attention_heads, c.intermediate_size, c.vocab_size, c.tp_size);
+    // KV heads: split over the ranks, or -- with fewer KV heads than ranks -- replicated: tp_size / Hkv ranks share one head
+    // (SURVEY.md 8e), which needs that many ranks to divide a query group
+    OMX_REQUIRE(c.num_key_value_heads >= c.tp_size ? c.num_key_value_heads % c.tp_size == 0
+                    : (c.tp_size % c.num_key_value_heads == 0 &&
+                       (c.num_attention_heads / c.num_key_value_heads) % (c.tp_size / c.num_key_value_heads) == 0),
+                "InvalidConfig: %d kv heads cannot be split or replicated over tp_size %d", c.num_key_value_heads, c.tp_size);
     OMX_REQUIRE(c.quant_bits == 0 || c.quant_bits == 4 || c.quant_bits == 8, "InvalidConfig: quantization bits %d (0 = bf16, 4, 8)", c.quant_bits);
     OMX_REQUIRE(c.quant_bits == 0 || c.tp_size == 1, "InvalidConfig: quantized checkpoints run on a single GPU (tp_size %d)", c.tp_size);
     omx_qwen3 m = new omx_qwen3_();
@@ -845,7 +861,7 @@ int omx_qwen3_create(omx_qwen3* out, const omx_qwen3_config* cfg) {
     OMX_REQUIRE(!m->cfg.quant_bits || m->cfg.quant_group == 32 || m->cfg.quant_group == 64 || m->cfg.quant_group == 128,
                 "InvalidConfig: quantization group_size %d (32, 64, 128)", m->cfg.quant_group);
     m->H = c.num_attention_heads / c.tp_size;
-    m->Hkv = c.num_key_value_heads / c.tp_size;
+    m->Hkv = c.num_key_value_heads >= c.tp_size ? c.num_key_value_heads / c.tp_size : 1;
     m->I = c.intermediate_size / c.tp_size;
     m->V = c.vocab_size / c.tp_size;
     OMX_REQUIRE(c.num_experts > 0 || m->I % 64 == 0, "InvalidConfig: per-rank intermediate %d must be a multiple of 64", m->I);
@@ -954,6 +970,9 @@ int omx_qwen3_synth_weights(omx_qwen3 m, uint32_t base_seed) {
         return 0;
     };
     const int Hq = m->H * D, Hk = m->Hkv * D;
+    // first k / v row of this rank in the logical projection: its own KV heads, or the one head it shares with its neighbours
+    const int kv_rep = c.num_key_value_heads >= c.tp_size ? 1 : c.tp_size / c.num_key_value_heads;
+    const int64_t kv_row0 = (int64_t)(r / kv_rep) * Hk;
     if (c.quant_bits) {
         // the quantized model IS mlx quantize() of the synthetic bf16 model: generate each logical matrix into a scratch
         // buffer with the bf16 generator, quantise it on the device, keep only the (weight, scales, biases) triplet
@@ -1001,8 +1020,8 @@ int omx_qwen3_synth_weights(omx_qwen3 m, uint32_t base_seed) {
     for (int i = 0; i < c.num_hidden_layers; ++i) {
         const std::string p = "model.layers." + std::to_string(i) + ".";
         if (make(p + "self_attn.q_proj.weight", Hq, hd, hd, (int64_t)r * Hq, 0, false) ||
-            make(p + "self_attn.k_proj.weight", Hk, hd, hd, (int64_t)r * Hk, 0, false) ||
-            make(p + "self_attn.v_proj.weight", Hk, hd, hd, (int64_t)r * Hk, 0, false) ||
+            make(p + "self_attn.k_proj.weight", Hk, hd, hd, kv_row0, 0, false) ||
+            make(p + "self_attn.v_proj.weight", Hk, hd, hd, kv_row0, 0, false) ||
             make(p + "self_attn.o_proj.weight", hd, Hq, (int64_t)c.num_attention_heads * D, 0, (int64_t)r * Hq, false) ||
             make(p + "input_layernorm.weight", 1, hd, hd, 0, 0, true) ||
             make(p + "post_attention_layernorm.weight", 1, hd, hd, 0, 0, true))
@@ -1124,7 +1143,9 @@ int omx_qwen3_prefill(omx_qwen3 m, const uint32_t* prompt, int n_prompt, uint32_
     for (int i = 0; i < n_prompt; ++i) OMX_REQUIRE(prompt[i] < (uint32_t)m->cfg.vocab_size, "omx_qwen3_prefill: token id %u out of range (vocab %d)", prompt[i], m->cfg.vocab_size);
     OMX_REQUIRE(n_prompt <= m->prompt_cap, "omx_qwen3_prefill: prompt of %d tokens exceeds max_context %d", n_prompt, m->prompt_cap);
     const char* serial_env = getenv("OMX_PREFILL_SERIAL");
-    const bool serial = (serial_env && serial_env[0] == '1') || m->allreduce != nullptr || n_prompt < 2;
+    // expert-parallel engines prefill token-serially (their batched MoE block is single-rank); tensor-parallel ones run the batched
+    // matrix-core prefill on their shards with two all-reduces per layer
+    const bool serial = (serial_env && serial_env[0] == '1') || (m->allreduce != nullptr && m->cfg.ep_size > 1) || n_prompt < 2;
     if (prepare_step(m, serial ? off : off + n_prompt - 1)) return 1;   // the first step this call will run (graphs are per context bucket)
     OMX_HIP_CHECK(hipMemcpyAsync(m->prompt_dev, prompt, (size_t)n_prompt * 4, hipMemcpyHostToDevice, m->stream));
     StepState st;
@@ -1146,7 +1167,7 @@ int omx_qwen3_prefill(omx_qwen3 m, const uint32_t* prompt, int n_prompt, uint32_
         // tile count does not change, instead of a 36-layer GEMV pass); OMX_PREFILL_TAIL_STEP=1: n-1 tokens batched and
         // the decode step for the last one
         const char* tail_env = getenv("OMX_PREFILL_TAIL_STEP");
-        const bool tail_step = tail_env && tail_env[0] == '1';
+        const bool tail_step = (tail_env && tail_env[0] == '1') || m->allreduce != nullptr;   // (the vocabulary-sharded head + its argmax all-reduce live in the step)
         const int nb = tail_step ? n_prompt - 1 : n_prompt;
         if (prefill_prefix_batched(m, nb, st.pos, nullptr, !tail_step)) return 1;
         st.pos += n_prompt - 1;

@@ -75,7 +75,7 @@ def expected_shape(c: Qwen3Config, name: str):
     name the forward does not use.  Mirrors resolve_weights in csrc/engine.hip."""
     tp, ep = max(c.tp_size, 1), max(c.ep_size, 1)
     hd, D = c.hidden_size, c.head_dim
-    H, Hkv, I, V = c.num_attention_heads // tp, c.num_key_value_heads // tp, c.intermediate_size // tp, c.vocab_size
+    H, Hkv, I, V = c.num_attention_heads // tp, max(1, c.num_key_value_heads // tp), c.intermediate_size // tp, c.vocab_size
     Im, E = c.moe_intermediate_size, c.num_experts
     leaf_kind = None
     for suffix in (".weight", ".scales", ".biases", ".bias"):
@@ -170,7 +170,8 @@ class Model:
         """ModuleParametersExt::load_safetensors equivalent for in-memory arrays keyed by HF name."""
         if self.cfg.tp_size > 1:   # slice the logical checkpoint with the shared shard plan (tp.py)
             from . import tp
-            weights = tp.shard_state_dict(weights, self.cfg.tp_rank, self.cfg.tp_size, bool(self.cfg.tie_word_embeddings))
+            weights = tp.shard_state_dict(weights, self.cfg.tp_rank, self.cfg.tp_size, bool(self.cfg.tie_word_embeddings),
+                                          self.cfg.num_key_value_heads, self.cfg.head_dim)
         if self.cfg.ep_size > 1:   # expert parallel: this rank keeps its slice of every stacked expert tensor
             from . import ep
             weights = {k: (ep.shard_experts(v, self.cfg.ep_rank, self.cfg.ep_size) if ".switch_mlp." in k else v)

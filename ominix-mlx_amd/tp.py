@@ -21,17 +21,35 @@ ROW_SPLIT = ("self_attn.q_proj.weight", "self_attn.k_proj.weight", "self_attn.v_
 COL_SPLIT = ("self_attn.o_proj.weight", "mlp.down_proj.weight")
 
 
+def kv_replication(num_key_value_heads: int, world: int) -> int:
+    """How many ranks share one KV head: 1 while every rank owns whole KV heads; world / Hkv once there are fewer KV heads than
+    ranks (SURVEY.md 8e: "Qwen2.5-7B has Hkv=4 -> replicate KV heads x2 at TP=8") -- rank r then holds KV head r // rep."""
+    return 1 if num_key_value_heads >= world else world // num_key_value_heads
+
+
 def check_divisible(*, num_attention_heads, num_key_value_heads, intermediate_size, vocab_size, world, **_):
-    for what, n in (("num_key_value_heads", num_key_value_heads), ("num_attention_heads", num_attention_heads),
-                    ("intermediate_size", intermediate_size), ("vocab_size", vocab_size)):
+    for what, n in (("num_attention_heads", num_attention_heads), ("intermediate_size", intermediate_size), ("vocab_size", vocab_size)):
         if n % world:
             raise ValueError(f"InvalidConfig: {what}={n} is not divisible by tp_size={world}")
+    if num_key_value_heads >= world:
+        if num_key_value_heads % world:
+            raise ValueError(f"InvalidConfig: num_key_value_heads={num_key_value_heads} is not divisible by tp_size={world}")
+    else:
+        rep = world // num_key_value_heads
+        group = num_attention_heads // num_key_value_heads
+        if world % num_key_value_heads or group % rep:
+            raise ValueError(f"InvalidConfig: num_key_value_heads={num_key_value_heads} cannot be replicated over tp_size={world} "
+                             f"(query group of {group} heads, {rep} ranks per KV head)")
 
 
-def shard(name: str, arr: np.ndarray, rank: int, world: int) -> np.ndarray:
-    """This rank's slice of a logical weight (contiguous copy)."""
+def shard(name: str, arr: np.ndarray, rank: int, world: int, num_key_value_heads: int = 0, head_dim: int = 0) -> np.ndarray:
+    """This rank's slice of a logical weight (contiguous copy).  With fewer KV heads than ranks (pass num_key_value_heads and
+    head_dim) the k / v projections are not split further: rank r takes the rows (and bias entries) of KV head r // rep."""
     if world == 1:
         return arr
+    if 0 < num_key_value_heads < world and (".self_attn.k_proj." in name or ".self_attn.v_proj." in name):
+        head = rank // kv_replication(num_key_value_heads, world)
+        return keep_kind(arr, np.ascontiguousarray(arr[head * head_dim:(head + 1) * head_dim]))
     if name.endswith(ROW_SPLIT):
         n = arr.shape[0] // world
         return keep_kind(arr, np.ascontiguousarray(arr[rank * n:(rank + 1) * n]))
@@ -41,8 +59,9 @@ def shard(name: str, arr: np.ndarray, rank: int, world: int) -> np.ndarray:
     return arr
 
 
-def shard_state_dict(weights: dict, rank: int, world: int, tie_word_embeddings: bool = False) -> dict:
-    out = {k: shard(k, v, rank, world) for k, v in weights.items()}
+def shard_state_dict(weights: dict, rank: int, world: int, tie_word_embeddings: bool = False, num_key_value_heads: int = 0,
+                     head_dim: int = 0) -> dict:
+    out = {k: shard(k, v, rank, world, num_key_value_heads, head_dim) for k, v in weights.items()}
     if tie_word_embeddings and world > 1:
         out["lm_head.weight"] = shard("lm_head.weight", weights["model.embed_tokens.weight"], rank, world)
     return out

@@ -18,7 +18,14 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _rank_main(rank, world, port, ret):
+CASES = {
+    # hidden, layers, inter, heads, kv_heads, head_dim, vocab
+    "kv_split": rq.Qwen3Config(256, 2, 768, 4, 2, 64, 512, 1e-6, 1e6, False),
+    "kv_replicated": rq.Qwen3Config(256, 2, 768, 4, 1, 64, 512, 1e-6, 1e6, False),   # 1 KV head < 2 ranks: both hold it
+}
+
+
+def _rank_main(rank, world, port, ret, case="kv_split", batched=False):
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     import omx_import
@@ -26,11 +33,11 @@ def _rank_main(rank, world, port, ret):
     from ominix_mlx_amd import tp
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    cfg = rq.Qwen3Config(256, 2, 768, 4, 2, 64, 512, 1e-6, 1e6, False)
+    cfg = CASES[case]
     full = rq.synth_weights(cfg)
     tp.check_divisible(world=world, **cfg.__dict__)
-    w = tp.shard_state_dict(full, rank, world)
-    H, Hkv, D = cfg.num_attention_heads // world, cfg.num_key_value_heads // world, cfg.head_dim
+    w = tp.shard_state_dict(full, rank, world, False, cfg.num_key_value_heads, cfg.head_dim)
+    H, Hkv, D = cfg.num_attention_heads // world, max(1, cfg.num_key_value_heads // world), cfg.head_dim
     rope = rc.initialize_rope(D, cfg.rope_theta, False, None)
 
     def allreduce(x):
@@ -41,26 +48,32 @@ def _rank_main(rank, world, port, ret):
     prompt = synth.prompt_ids(6, cfg.vocab_size)
     caches = [rc.KVCache() for _ in range(cfg.num_hidden_layers)]
     tok = None
-    for t, token in enumerate(prompt):
-        h = full["model.embed_tokens.weight"][[token]][None]                     # replicated embedding
+    # token-serial: every prompt token is one decode step, f32 partials all-reduced (the step graph's EPI_F32 path);
+    # batched: the first n-1 tokens in ONE pass, bf16 partials of [T, hidden] all-reduced (prefill_prefix_batched), then the step
+    chunks = [(0, len(prompt) - 1), (len(prompt) - 1, 1)] if batched else [(t, 1) for t in range(len(prompt))]
+    for t, n in chunks:
+        part_dt = "bf16" if n > 1 else "f32"
+        h = full["model.embed_tokens.weight"][prompt[t:t + n]][None]             # replicated embedding
+        mask = rc.create_causal_mask(n, t) if n > 1 else None
         for l in range(cfg.num_hidden_layers):
             p = f"model.layers.{l}."
             xn = rc.rms_norm(h, w[p + "input_layernorm.weight"], cfg.rms_norm_eps, "bf16")
-            q = rc.linear(xn, w[p + "self_attn.q_proj.weight"], None, "bf16").reshape(1, 1, H, D).transpose(0, 2, 1, 3)
-            k = rc.linear(xn, w[p + "self_attn.k_proj.weight"], None, "bf16").reshape(1, 1, Hkv, D).transpose(0, 2, 1, 3)
-            v = rc.linear(xn, w[p + "self_attn.v_proj.weight"], None, "bf16").reshape(1, 1, Hkv, D).transpose(0, 2, 1, 3)
+            q = rc.linear(xn, w[p + "self_attn.q_proj.weight"], None, "bf16").reshape(1, n, H, D).transpose(0, 2, 1, 3)
+            k = rc.linear(xn, w[p + "self_attn.k_proj.weight"], None, "bf16").reshape(1, n, Hkv, D).transpose(0, 2, 1, 3)
+            v = rc.linear(xn, w[p + "self_attn.v_proj.weight"], None, "bf16").reshape(1, n, Hkv, D).transpose(0, 2, 1, 3)
             q = rc.rms_norm(q, w[p + "self_attn.q_norm.weight"], cfg.rms_norm_eps, "bf16")
             k = rc.rms_norm(k, w[p + "self_attn.k_norm.weight"], cfg.rms_norm_eps, "bf16")
             q = rc.rope(q, D, False, rope["base"], 1.0, t, "bf16"); k = rc.rope(k, D, False, rope["base"], 1.0, t, "bf16")
-            kk, vv = caches[l].update_and_fetch(k, v)                            # KV cache sharded by KV head
-            o = rc.scaled_dot_product_attention(q, kk, vv, D ** -0.5, None, "bf16").transpose(0, 2, 1, 3).reshape(1, 1, -1)
-            part = rc.linear(o, w[p + "self_attn.o_proj.weight"], None, "f32")    # f32 partial (EPI_F32)
+            kk, vv = caches[l].update_and_fetch(k, v)                            # KV cache sharded by KV head (or the shared head)
+            o = rc.scaled_dot_product_attention(q, kk, vv, D ** -0.5, mask, "bf16").transpose(0, 2, 1, 3).reshape(1, n, -1)
+            part = rc.linear(o, w[p + "self_attn.o_proj.weight"], None, part_dt)  # row-split: partial sums
             h = rc.add(h, rc.bf16_round(allreduce(part)), "bf16")                # all-reduce #1, folded into the residual
             hn = rc.rms_norm(h, w[p + "post_attention_layernorm.weight"], cfg.rms_norm_eps, "bf16")
             g = rc.linear(hn, w[p + "mlp.gate_proj.weight"], None, "bf16"); u = rc.linear(hn, w[p + "mlp.up_proj.weight"], None, "bf16")
             act = rc.multiply(rc.silu(g, "bf16"), u, "bf16")
-            part = rc.linear(act, w[p + "mlp.down_proj.weight"], None, "f32")
+            part = rc.linear(act, w[p + "mlp.down_proj.weight"], None, part_dt)
             h = rc.add(h, rc.bf16_round(allreduce(part)), "bf16")                # all-reduce #2
+        h = h[:, -1:, :]
         hn = rc.rms_norm(h, full["model.norm.weight"], cfg.rms_norm_eps, "bf16")
         logits = rc.linear(hn, w["lm_head.weight"], None, "bf16")[0, 0]           # vocab shard
         i = int(np.argmax(logits))
@@ -79,12 +92,15 @@ def _rank_main(rank, world, port, ret):
 
 
 @pytest.mark.timeout(300)
-def test_tp2_shard_plan_matches_single_device_oracle():
+@pytest.mark.parametrize("case,batched", [("kv_split", False), ("kv_split", True), ("kv_replicated", False), ("kv_replicated", True)])
+def test_tp2_shard_plan_matches_single_device_oracle(case, batched):
+    """kv_replicated: fewer KV heads than ranks, every rank keeps the head its query heads attend to; batched: the prompt prefix as
+    one [T, hidden] pass with bf16 partial all-reduces (2 per layer) instead of T decode steps (VERDICT r1 "Next" #2)."""
     world = 2
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_rank_main, args=(world, _free_port(), ret), nprocs=world, join=True)
-    cfg = rq.Qwen3Config(256, 2, 768, 4, 2, 64, 512, 1e-6, 1e6, False)
+    mp.spawn(_rank_main, args=(world, _free_port(), ret, case, batched), nprocs=world, join=True)
+    cfg = CASES[case]
     oracle = rq.Qwen3Oracle(cfg, rq.synth_weights(cfg))
     prompt = synth.prompt_ids(6, cfg.vocab_size)
     ref_tok, ref_logits = oracle.generate(prompt, 1, return_logits=True)
@@ -114,4 +130,12 @@ def test_shard_shapes():
     np.testing.assert_array_equal(tp.shard("model.layers.0.mlp.down_proj.weight", w, 3, 4), w[:, 12:16])
     assert tp.shard("model.norm.weight", w, 1, 4) is w
     with pytest.raises(ValueError):
-        tp.check_divisible(num_attention_heads=28, num_key_value_heads=4, intermediate_size=18944, vocab_size=152064, world=8)
+        tp.check_divisible(num_attention_heads=28, num_key_value_heads=4, intermediate_size=18944, vocab_size=152064, world=8)   # 28 heads / 8
+    # fewer KV heads than ranks: replicated (32 heads, 4 KV heads at TP = 8: two ranks per KV head, a query group of 8 splits in 2)
+    tp.check_divisible(num_attention_heads=32, num_key_value_heads=4, intermediate_size=1024, vocab_size=1024, world=8)
+    assert tp.kv_replication(4, 8) == 2 and tp.kv_replication(8, 8) == 1
+    k = np.arange(4 * 16 * 8, dtype=np.float32).reshape(4 * 16, 8)                # 4 KV heads of width 16
+    for r in range(8):
+        np.testing.assert_array_equal(tp.shard("model.layers.0.self_attn.k_proj.weight", k, r, 8, 4, 16), k[(r // 2) * 16:(r // 2 + 1) * 16])
+    with pytest.raises(ValueError, match="cannot be replicated"):
+        tp.check_divisible(num_attention_heads=24, num_key_value_heads=3, intermediate_size=1024, vocab_size=1024, world=8)  # 8 ranks over 3 KV heads

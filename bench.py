@@ -19,6 +19,7 @@ import argparse
 import ctypes
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -57,6 +58,9 @@ def parse():
     ap.add_argument("--model", default="qwen3-8b", choices=list(MODELS))
     ap.add_argument("--layers", type=int, default=0, help="debug: override layer count (invalidates the metric)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-only", action="store_true", help="internal: the CPU leg's child process (no GPU use)")
+    ap.add_argument("--cpu-ctx", type=int, default=0)
+    ap.add_argument("--cpu-cfg", default="")
     ap.add_argument("--no-flux", action="store_true", help="skip the secondary FLUX.2-klein sec/step measurement")
     ap.add_argument("--flux-tp", action="store_true",
                     help="with --gpus N > 1: also time FLUX.2-klein tensor-parallel over the N GPUs (all ranks take part)")
@@ -151,9 +155,22 @@ def time_dominant_kernel(omx, cfg, world, iters=3):
     return nbytes, ms.value * 1e-3
 
 
-# HBM bytes per launch of the dominant kernel from the PMC pass committed under profiles/
-# (rocprofv3 --pmc FETCH_SIZE, x2 gfx950 correction; profiles/r01_pmc_fetch_size_gemv.md)
-PMC_TRAFFIC_GATE_UP_TP1 = 201641984
+DOMINANT_KERNEL = "gemv_kernel<8, 1, 1, 1, 2>"      # RMSNorm + gate/up GEMV + SwiGLU: 52 % of a step's bytes
+PMC_JSON = os.path.join(ROOT, "profiles", "r02_pmc_fetch_size.json")
+# greedy token after the 2048-token synthetic prompt, per (model, prompt length) on ONE GPU, synthetic weights: the engine is
+# deterministic, so a different token means a different computation.  (Committed from the round-2 run; checked at world 1 only --
+# tensor-parallel partial sums round differently.)
+FIRST_TOKEN = {("qwen3-8b", 2048): 140044}
+
+
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed PMC pass (profiles/r02_pmc_fetch_size.json, regenerated from the trimmed
+    raw counter_collection.csv by tools/pmc_report.py): rocprofv3 --pmc FETCH_SIZE in its own pass, x 1024 x 2 (gfx950 correction)."""
+    try:
+        table = json.load(open(PMC_JSON))
+        return int(table[kernel.replace(" ", "")]["hbm_bytes"])
+    except (OSError, KeyError, ValueError):
+        return None
 
 
 def flux_secondary(omx, steps=3, rank=0, world=1, comm=None):
@@ -189,7 +206,7 @@ def quantized_secondary(omx, cfg, args, bits=4):
     """The reference's flagship mode: the same model as an MLX 4-bit checkpoint (group 64), same
     protocol (2048-token prompt, warm-up, timed greedy decode steps); the decode step streams the packed weights."""
     from ominix_mlx_amd import engine
-    max_ctx = args.prompt + args.warmup + args.steps + 8
+    max_ctx = args.prompt + args.warmup + args.steps + 16
     m = engine.Model(max_context=max_ctx, quantization={"bits": bits, "group_size": 64}, **cfg)
     m.synth_weights()
     prompt = prompt_ids(args.prompt, cfg["vocab_size"])
@@ -264,10 +281,42 @@ def paraformer_secondary(omx, reps=5):
             "vs_reference_m3max_400ms": round(0.4 / best, 1)}
 
 
-def cpu_baseline(cfg, ctx, n_layers_sample=2, reps=2):
-    """Plain-C port (oracle/c/omx_oracle.c, OpenMP over the host cores) of the same decode step,
-    timed on a bounded sample: `n_layers_sample` of the model's layers at context `ctx` plus the
-    lm_head, scaled to the full layer count."""
+def physical_cores():
+    """Physical cores this process may run on (unique (package, core) pairs of /proc/cpuinfo within the affinity mask)."""
+    allowed = os.sched_getaffinity(0)
+    cores, cpu, pkg = set(), None, 0
+    try:
+        for line in open("/proc/cpuinfo"):
+            k, _, v = line.partition(":")
+            k = k.strip()
+            if k == "processor":
+                cpu = int(v)
+            elif k == "physical id":
+                pkg = int(v)
+            elif k == "core id" and cpu in allowed:
+                cores.add((pkg, int(v)))
+    except OSError:
+        pass
+    return max(1, len(cores) or len(allowed))
+
+
+def cpu_baseline(cfg, ctx):
+    """The CPU leg runs in a CHILD process (`bench.py --cpu-baseline-only`) that never touches the GPU: OpenMP reads its thread
+    count and binding when the runtime is loaded, so a clean process with OMP_NUM_THREADS = physical cores, OMP_PLACES=cores,
+    OMP_PROC_BIND=close is the only way to pin them; the child first-touches its buffers with the same static schedule the GEMVs use."""
+    threads = physical_cores()
+    env = dict(os.environ, OMP_NUM_THREADS=str(threads), OMP_PLACES="cores", OMP_PROC_BIND="close", OMP_DYNAMIC="false")
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--cpu-ctx", str(ctx), "--cpu-cfg", json.dumps(cfg)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    if r.returncode != 0:
+        raise RuntimeError(f"cpu baseline child rc={r.returncode}: {r.stderr[-300:]}")
+    return json.loads(r.stdout.strip().splitlines()[-1])
+
+
+def cpu_baseline_child(cfg, ctx, n_layers_sample=4, warm=2, reps=7):
+    """Plain-C port (oracle/c/omx_oracle.c, OpenMP) of the same decode step, timed on a bounded sample: `n_layers_sample` of the
+    model's layers at context `ctx` plus the lm_head, `warm` untimed passes (page first-touch, caches), then the MEDIAN of `reps`
+    timed passes, scaled to the full layer count."""
     import numpy as np
     from oracle import c_oracle
     lib = c_oracle.load()
@@ -291,8 +340,8 @@ def cpu_baseline(cfg, ctx, n_layers_sample=2, reps=2):
     scratch = np.zeros(lib.oracle_qwen3_scratch_elems(ctypes.byref(lc)), np.uint16)
     h = filled(hd, 1.0)
     head, norm_w, logits = filled(V * hd), filled(hd, 0.017, 1.0), np.empty(V, np.uint16)
-    t_layers = t_head = 1e30
-    for _ in range(reps):
+    samples = []
+    for it in range(warm + reps):
         t0 = time.perf_counter()
         for _, L in layers:
             lib.oracle_qwen3_layer_decode(ctypes.byref(lc), ctypes.byref(L), c_oracle.ptr(h), ctx, c_oracle.ptr(scratch))
@@ -300,15 +349,22 @@ def cpu_baseline(cfg, ctx, n_layers_sample=2, reps=2):
         lib.oracle_qwen3_head(c_oracle.ptr(h), c_oracle.ptr(norm_w), c_oracle.ptr(head), hd, V, cfg["rms_norm_eps"],
                               c_oracle.ptr(logits), c_oracle.ptr(scratch))
         t2 = time.perf_counter()
-        t_layers, t_head = min(t_layers, t1 - t0), min(t_head, t2 - t1)
-    step_s = t_layers / n_layers_sample * cfg["num_hidden_layers"] + t_head
-    return {"value": round(1.0 / step_s, 4), "unit": "tokens/s", "cores": os.cpu_count(), "kind": "port",
-            "sample": f"{n_layers_sample} of {cfg['num_hidden_layers']} decoder layers at ctx {ctx} + lm_head, "
-                      f"best of {reps}, scaled to the full model; C port with OpenMP on all host cores"}
+        if it >= warm:
+            samples.append((t1 - t0) / n_layers_sample * cfg["num_hidden_layers"] + (t2 - t1))
+    samples.sort()
+    step_s = samples[len(samples) // 2]
+    threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or os.cpu_count()
+    print(json.dumps({"value": round(1.0 / step_s, 4), "unit": "tokens/s", "cores": threads, "kind": "port",
+                      "spread": [round(1.0 / samples[-1], 4), round(1.0 / samples[0], 4)],
+                      "sample": f"{n_layers_sample} of {cfg['num_hidden_layers']} decoder layers at ctx {ctx} + lm_head, {warm} warm passes then the "
+                                f"median of {reps}, scaled to the full model; C port of the oracle, OpenMP, {threads} threads pinned one per "
+                                f"physical core (OMP_PLACES=cores OMP_PROC_BIND=close), in a child process"}), flush=True)
 
 
 def main():
     args = parse()
+    if args.cpu_baseline_only:
+        return cpu_baseline_child(json.loads(args.cpu_cfg), args.cpu_ctx)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args))
     if args.dry_run:
@@ -322,7 +378,7 @@ def main():
     cfg = dict(MODELS[args.model])
     if args.layers:
         cfg["num_hidden_layers"] = args.layers
-    max_ctx = args.prompt + args.warmup + args.steps + 8
+    max_ctx = args.prompt + args.warmup + args.steps + 16
     moe = cfg.get("num_experts", 0) > 0
     if moe:   # BASELINE config 3: experts sharded over the ranks (expert parallel), attention replicated, one all-reduce per layer
         model = engine.Model(max_context=max_ctx, ep_rank=rank, ep_size=world, **cfg)
@@ -372,8 +428,21 @@ def main():
     step_bytes = model.step_bytes(ctx_mid) * (1 if moe else world)   # whole-job algorithmic bytes per token (EP ranks share one token's experts)
     ms_per_step = elapsed * 1e3 / args.steps
     tok_s = args.steps / elapsed
-    k_bytes, k_s = time_dominant_kernel(omx, cfg, 1 if moe else world)
+    k_bytes, iso_s = time_dominant_kernel(omx, cfg, 1 if moe else world)
+    in_step = None
+    if world == 1 and not moe:
+        # the figure the roofline object reports: HIP events on the step's stream around every launch of 4 further (eager) decode steps
+        in_step = model.time_step_kernels(4)
+    k_s = in_step["gate_up"] * 1e-6 if in_step else iso_s
     achieved = k_bytes / k_s / 1e9
+    H, Hkv, D, hd, I, V = (cfg["num_attention_heads"], cfg["num_key_value_heads"], cfg["head_dim"], cfg["hidden_size"],
+                           cfg["intermediate_size"], cfg["vocab_size"])
+    class_bytes = {"qkv": 2 * (H + 2 * Hkv) * D * hd, "attention": 2 * 2 * Hkv * D * (ctx_mid + args.steps // 2), "o": 2 * H * D * hd,
+                   "gate_up": 4 * I * hd, "down": 2 * I * hd, "lm_head": 2 * V * hd}
+    first_ok = None
+    want_first = FIRST_TOKEN.get((args.model, args.prompt)) if world == 1 and not args.layers else None
+    if want_first is not None:
+        first_ok = int(first) == want_first
     out = {
         "metric": "decode_tokens_per_sec", "value": round(tok_s, 2), "unit": "tokens/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
@@ -384,9 +453,14 @@ def main():
                    "layers": cfg["num_hidden_layers"]},
         "roofline": {"bound": "hbm", "kernel": "gemv_kernel<rmsnorm, gate/up, swiglu>", "achieved": round(achieved, 1),
                      "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
-                     "traffic": PMC_TRAFFIC_GATE_UP_TP1 if world == 1 and args.model == "qwen3-8b" else None,
-                     "traffic_source": "profiles/r01_pmc_fetch_size_gemv.md (rocprofv3 --pmc FETCH_SIZE, separate pass, x2 gfx950 correction)",
-                     "algorithmic_bytes_per_launch": k_bytes, "avg_launch_us": round(k_s * 1e6, 2)},
+                     "traffic": pmc_traffic(DOMINANT_KERNEL) if world == 1 and args.model == "qwen3-8b" else None,
+                     "traffic_source": "profiles/r02_pmc_fetch_size.json <- profiles/r02_pmc_fetch_size_step.csv (rocprofv3 --pmc FETCH_SIZE over real decode steps, "
+                                       "own pass, x2 gfx950 correction; tools/pmc_profile.sh, tools/pmc_report.py)",
+                     "algorithmic_bytes_per_launch": k_bytes, "avg_launch_us": round(k_s * 1e6, 2),
+                     "timing": ("in-step: every one of the 36 launches per step of 4 eager decode steps, run right after the timed region, carries its own "
+                                "HIP start/stop event pair (hipExtLaunchKernelGGL: the dispatch's begin/end timestamps on the step's stream)"
+                                if in_step else "isolated launches over rotating weight buffers (omx_bench_gemv), HIP events"),
+                     "isolated_launch_us": round(iso_s * 1e6, 2)},
         "step_roofline": {"algorithmic_bytes_per_token": int(step_bytes),
                           "achieved_GBps": round(step_bytes / (ms_per_step * 1e-3) / 1e9, 1),
                           "frac_of_hbm_peak": round(step_bytes / (ms_per_step * 1e-3) / 1e9 / (HBM_PEAK_GBPS * world), 4),
@@ -397,7 +471,11 @@ def main():
                     "mode": "batched on the tensor-parallel shards: MFMA GEMMs + flash attention, two bf16 all-reduces of [T, hidden] per layer, the last token through the decode step" if world > 1 else
                             "batched: MFMA GEMMs + flash attention over all n tokens (first call: includes the one-time scratch allocation), norm + lm_head + sampler on the last row"},
         "first_tokens": [int(first)] + [int(t) for t in toks[:4]],
+        "first_token_check": {"expected": want_first, "ok": first_ok},
     }
+    if in_step:
+        out["step_kernels"] = {k: {"avg_us": round(v, 2), "algorithmic_bytes": int(class_bytes[k]),
+                                   "frac_of_hbm_peak": round(class_bytes[k] / (v * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4)} for k, v in in_step.items()}
     model.close()
     if flux_tp is not None:
         out["secondary"] = flux_tp
@@ -426,6 +504,8 @@ def main():
             out["cpu_baseline"] = {"value": None, "unit": "tokens/s", "cores": os.cpu_count(), "kind": "port",
                                    "sample": f"failed: {e}"}
     print(json.dumps(out), flush=True)
+    if first_ok is False:
+        raise SystemExit(f"first token {int(first)} != committed {want_first}: the engine computed something else; the line above is not a valid measurement")
 
 
 if __name__ == "__main__":

@@ -221,6 +221,10 @@ int omx_qwen3_decode_path(omx_qwen3 m, int* path);
 /* debug hook (tools/attn_step_trace.py): run ONE decode step eagerly with the attention launches stamping the
  * 100 MHz wall clock; host receives [layers][attention splits][kv heads][8], *blocks = splits * kv heads     */
 int omx_qwen3_debug_trace_step(omx_qwen3 m, unsigned long long* host, size_t n_words, int* blocks);
+/* measurement hook: `steps` real decode steps run eagerly, every launch of the per-layer kernels carrying its own HIP event pair
+ * (the dispatch's begin / end timestamps on the step's stream); us[6] = average microseconds of {QKV GEMV, attention, O GEMV,
+ * gate/up + SwiGLU GEMV, down GEMV, lm_head}.  bench.py's roofline.achieved is the gate/up figure.  Dense bf16 single-rank models. */
+int omx_qwen3_time_step_kernels(omx_qwen3 m, int steps, float* us);
 
 /* =====================================================================================
  * MLX affine group quantisation (the reference's flagship checkpoint format).

@@ -23,6 +23,7 @@
 #include <algorithm>
 
 #include "attn.hpp"
+#include "launch_timing.hpp"
 
 namespace omx {
 
@@ -394,8 +395,8 @@ int launch_attn_step(const AttnStepArgs& a, int D, hipStream_t s) {
             OMX_HIP_CHECK(hipFuncSetAttribute((const void*)attn_step_kernel<DD, GG, true>,                              \
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));                  \
         }                                                                                                                \
-        if (a.trace) attn_step_kernel<DD, GG, true><<<grid, block, shmem, s>>>(a);                                       \
-        else attn_step_kernel<DD, GG, false><<<grid, block, shmem, s>>>(a);                                              \
+        if (a.trace) OMX_LAUNCH_TIMED((attn_step_kernel<DD, GG, true>), grid, block, shmem, s, a);                         \
+        else OMX_LAUNCH_TIMED((attn_step_kernel<DD, GG, false>), grid, block, shmem, s, a);                               \
         OMX_LAUNCH_CHECK();                                                                                              \
         return 0;                                                                                                        \
     }

@@ -31,6 +31,7 @@
 #include "random.hpp"
 #include "prefill.hpp"
 #include "quant.hpp"
+#include "launch_timing.hpp"
 
 namespace omx {
 namespace {
@@ -194,6 +195,7 @@ struct omx_qwen3_ {
     uint64_t* attn_gran = nullptr;        // split partials as tagged granules
     int attn_chunk = 0, attn_nsplit = 0, graph_tk_max = 0;
     unsigned long long* attn_trace = nullptr;   // set for one eager step by omx_qwen3_debug_trace_step
+    std::vector<hipEvent_t>* kernel_events = nullptr;   // set for eager steps by omx_qwen3_time_step_kernels: [layer][class][begin, end]
 
     void* comm = nullptr;
     nccl_allreduce_fn allreduce = nullptr;
@@ -440,6 +442,15 @@ static int rpw_env(const char* name) {
     return v ? atoi(v) : 0;
 }
 
+// kernel classes timed by omx_qwen3_time_step_kernels: an event pair armed for the launch that follows (launch_timing.hpp)
+enum { KC_QKV = 0, KC_ATTN, KC_O, KC_GATE_UP, KC_DOWN, KC_HEAD, KC_COUNT };
+constexpr int kLayerClasses = KC_HEAD;
+inline void time_next_launch(omx_qwen3 m, int layer, int cls) {
+    if (!m->kernel_events) return;
+    const size_t i = (cls == KC_HEAD ? (size_t)m->cfg.num_hidden_layers * kLayerClasses : (size_t)layer * kLayerClasses + cls) * 2;
+    arm_launch_events((*m->kernel_events)[i], (*m->kernel_events)[i + 1]);
+}
+
 int enqueue_step(omx_qwen3 m, bool with_head) {
     if (m->cfg.quant_bits) return enqueue_step_quant(m, with_head);
     const omx_qwen3_config& c = m->cfg;
@@ -466,10 +477,12 @@ int enqueue_step(omx_qwen3 m, bool with_head) {
             a.out = m->qkv;
             a.out_bias = L.qkv_bias;
             a.rows_per_wave = rpw_env("OMX_GEMV_RPW_QKV");
-            if (launch_gemv(a, PRO_RMSNORM, EPI_STORE, s)) return 1;
+            time_next_launch(m, l, KC_QKV);
+                if (launch_gemv(a, PRO_RMSNORM, EPI_STORE, s)) return 1;
             if (pending) { bf16_t* t = h; h = hn; hn = t; pending = nullptr; }
         }
-        if (enqueue_attention(m, l, s)) return 1;   // [q/k RMSNorm + RoPE + cache append + split-KV SDPA + merge]  model.rs:172-210
+        time_next_launch(m, l, KC_ATTN);
+                if (enqueue_attention(m, l, s)) return 1;   // [q/k RMSNorm + RoPE + cache append + split-KV SDPA + merge]  model.rs:172-210
         {   // [O GEMV + residual]  model.rs:214,325
             GemvArgs a = {};
             a.w0 = L.o; a.n0 = hd; a.N = hd; a.K = m->H * D;
@@ -477,6 +490,7 @@ int enqueue_step(omx_qwen3 m, bool with_head) {
             a.rows_per_wave = rpw_env("OMX_GEMV_RPW_O");
             if (!tp) {
                 a.resid = h; a.out = hn;
+                time_next_launch(m, l, KC_O);
                 if (launch_gemv(a, PRO_NONE, EPI_RESIDUAL, s)) return 1;
                 bf16_t* t = h; h = hn; hn = t;
             } else {
@@ -515,7 +529,8 @@ int enqueue_step(omx_qwen3 m, bool with_head) {
             a.norm_w = L.post_ln; a.eps = c.rms_norm_eps;
             a.out = m->act;
             a.rows_per_wave = rpw_env("OMX_GEMV_RPW_GU");
-            if (launch_gemv(a, PRO_RMSNORM, EPI_SWIGLU, s)) return 1;
+            time_next_launch(m, l, KC_GATE_UP);
+                if (launch_gemv(a, PRO_RMSNORM, EPI_SWIGLU, s)) return 1;
             if (pending) { bf16_t* t = h; h = hn; hn = t; pending = nullptr; }
         }
         {   // [down GEMV + residual]  model.rs:266,327
@@ -525,6 +540,7 @@ int enqueue_step(omx_qwen3 m, bool with_head) {
             a.rows_per_wave = rpw_env("OMX_GEMV_RPW_DOWN");
             if (!tp) {
                 a.resid = h; a.out = hn;
+                time_next_launch(m, l, KC_DOWN);
                 if (launch_gemv(a, PRO_NONE, EPI_RESIDUAL, s)) return 1;
                 bf16_t* t = h; h = hn; hn = t;
             } else {
@@ -543,7 +559,8 @@ int enqueue_step(omx_qwen3 m, bool with_head) {
         a.out = m->logits;
         a.argmax_slot = m->argmax_partials;
         a.row_offset = c.tp_rank * m->V;
-        if (launch_gemv(a, PRO_RMSNORM, EPI_ARGMAX, s)) return 1;
+        time_next_launch(m, 0, KC_HEAD);
+                if (launch_gemv(a, PRO_RMSNORM, EPI_ARGMAX, s)) return 1;
         if (add_sampling_noise(m, s)) return 1;
         if (!tp) {
             sample_finalize_kernel<<<1, 256, 0, s>>>(m->st, m->argmax_partials, m->n_argmax_partials, m->out_ring,
@@ -1280,6 +1297,45 @@ int omx_qwen3_debug_trace_step(omx_qwen3 m, unsigned long long* host, size_t n_w
     (void)hipFree(dev);
     *blocks = m->attn_nsplit * m->Hkv;
     return rc ? 1 : step_health(m);
+}
+
+/* measurement hook (bench.py roofline.achieved): runs `steps` REAL decode steps (they advance the context like any other) eagerly, each
+ * launch of the five per-layer kernels and the lm_head carrying its own HIP event pair (hipExtLaunchKernelGGL start / stop events: the
+ * dispatch's begin / end timestamps on the step's stream, launch_timing.hpp).  us[6] = average of {QKV GEMV, attention, O GEMV,
+ * gate/up + SwiGLU GEMV, down GEMV, lm_head} over layers and steps.  Dense bf16 single-rank models only. */
+int omx_qwen3_time_step_kernels(omx_qwen3 m, int steps, float* us) {
+    OMX_REQUIRE(m && us && steps > 0, "omx_qwen3_time_step_kernels: bad arguments");
+    OMX_REQUIRE(!m->cfg.quant_bits && m->cfg.num_experts == 0 && m->allreduce == nullptr, "omx_qwen3_time_step_kernels: dense bf16 single-rank models only");
+    const int L = m->cfg.num_hidden_layers;
+    std::vector<hipEvent_t> ev((size_t)(L * kLayerClasses + 1) * 2);
+    for (auto& e : ev) OMX_HIP_CHECK(hipEventCreate(&e));
+    double sum[KC_COUNT] = {};
+    int rc = 0;
+    arm_launch_events(nullptr, nullptr);
+    for (int it = 0; it < steps && !rc; ++it) {
+        StepState st;
+        OMX_HIP_CHECK(hipMemcpyAsync(&st, m->st, sizeof(st), hipMemcpyDeviceToHost, m->stream));
+        OMX_HIP_CHECK(hipStreamSynchronize(m->stream));
+        if (st.pos + 1 > m->cap) { set_error("omx_qwen3_time_step_kernels: context full"); rc = 1; break; }
+        if (prepare_step(m, st.pos)) { rc = 1; break; }
+        m->kernel_events = &ev;
+        rc = enqueue_step(m, true);
+        m->kernel_events = nullptr;
+        if (rc) break;
+        OMX_HIP_CHECK(hipStreamSynchronize(m->stream));
+        for (int l = 0; l <= L; ++l)
+            for (int k = 0; k < (l == L ? 1 : kLayerClasses); ++k) {
+                float ms = 0.f;
+                const size_t i = ((size_t)l * kLayerClasses + k) * 2;
+                OMX_HIP_CHECK(hipEventElapsedTime(&ms, ev[i], ev[i + 1]));
+                sum[l == L ? KC_HEAD : k] += ms * 1e3;
+            }
+        rc = step_health(m);
+    }
+    for (auto& e : ev) (void)hipEventDestroy(e);
+    if (rc) return 1;
+    for (int k = 0; k < KC_COUNT; ++k) us[k] = (float)(sum[k] / ((k == KC_HEAD ? 1.0 : (double)L) * steps));
+    return 0;
 }
 
 int omx_qwen3_decode_path(omx_qwen3 m, int* path) {

@@ -1,5 +1,6 @@
 // See gemv.hpp for the design notes.
 #include "gemv.hpp"
+#include "launch_timing.hpp"
 
 #include <stdlib.h>
 
@@ -416,7 +417,7 @@ int launch_generic(const GemvArgs& a, int pro, int epi, hipStream_t s) {
     if (pro == P && epi == E) {                                                                                    \
         if (shmem > 48 * 1024)                                                                                     \
             OMX_HIP_CHECK(hipFuncSetAttribute((const void*)gemv_generic_kernel<P, E>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem)); \
-        gemv_generic_kernel<P, E><<<grid, block, shmem, s>>>(a);                                                   \
+        OMX_LAUNCH_TIMED((gemv_generic_kernel<P, E>), grid, block, shmem, s, a);                                         \
         OMX_LAUNCH_CHECK();                                                                                        \
         return 0;                                                                                                  \
     }
@@ -440,9 +441,9 @@ int launch_nv(const GemvArgs& a, int pro, int epi, hipStream_t s) {
 #define OMX_GEMV_CASE(P, E)                                                                          \
     if (pro == P && epi == E) {                                                                      \
         if (tail && P == PRO_NONE)                                                                   \
-            gemv_kernel<NVW, KSPLIT, (E == EPI_SWIGLU ? (RB > 1 ? RB / 2 : 1) : RB), PRO_NONE, E, true><<<grid, block, shmem, s>>>(a); \
+            OMX_LAUNCH_TIMED((gemv_kernel<NVW, KSPLIT, (E == EPI_SWIGLU ? (RB > 1 ? RB / 2 : 1) : RB), PRO_NONE, E, true>), grid, block, shmem, s, a); \
         else                                                                                         \
-            gemv_kernel<NVW, KSPLIT, (E == EPI_SWIGLU ? (RB > 1 ? RB / 2 : 1) : RB), P, E><<<grid, block, shmem, s>>>(a); \
+            OMX_LAUNCH_TIMED((gemv_kernel<NVW, KSPLIT, (E == EPI_SWIGLU ? (RB > 1 ? RB / 2 : 1) : RB), P, E>), grid, block, shmem, s, a); \
         OMX_LAUNCH_CHECK();                                                                          \
         return 0;                                                                                    \
     }

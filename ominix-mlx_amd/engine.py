@@ -47,6 +47,7 @@ ENGINE_SIGNATURES = {
     "omx_qwen3_step_bytes": (c_int, [c_void_p, c_int, ctypes.POINTER(ctypes.c_double)]),
     "omx_qwen3_decode_path": (c_int, [c_void_p, ctypes.POINTER(c_int)]),
     "omx_qwen3_debug_trace_step": (c_int, [c_void_p, c_void_p, ctypes.c_size_t, ctypes.POINTER(c_int)]),
+    "omx_qwen3_time_step_kernels": (c_int, [c_void_p, c_int, ctypes.POINTER(ctypes.c_float)]),
 }
 for _n, (_r, _a) in ENGINE_SIGNATURES.items():
     _f = getattr(lib, _n)
@@ -267,6 +268,15 @@ class Model:
         v = c_int()
         check(lib.omx_qwen3_decode_path(self._h, ctypes.byref(v)))
         return ("unbuilt", "graph", "eager")[v.value]
+
+    KERNEL_CLASSES = ("qkv", "attention", "o", "gate_up", "down", "lm_head")
+
+    def time_step_kernels(self, steps: int = 4) -> dict:
+        """Average in-step duration (microseconds) of each per-layer kernel, HIP events on the step's stream around every launch of
+        `steps` real (eager) decode steps: each launch's own HIP start / stop events -- omx_qwen3_time_step_kernels."""
+        us = (ctypes.c_float * 6)()
+        check(lib.omx_qwen3_time_step_kernels(self._h, steps, us))
+        return dict(zip(self.KERNEL_CLASSES, (float(v) for v in us)))
 
     def step_bytes(self, ctx: int) -> float:
         v = ctypes.c_double()

@@ -503,3 +503,22 @@ def test_load_weights_rejects_a_tensor_of_the_wrong_shape(omx):
     with pytest.raises(OmxError, match="ShapeMismatch: model.layers.0.mlp.down_proj.weight"):
         m.load_weights(bad)
     m.close()
+
+
+def test_time_step_kernels_runs_real_steps(omx):
+    """bench.py's roofline hook (omx_qwen3_time_step_kernels): the event-bracketed steps are ordinary decode steps -- a generation
+    with two of them in the middle emits the same tokens as one without -- and every class reports a positive duration."""
+    cfg = CONFIGS["gqa4_d128"]
+    prompt = synth.prompt_ids(48, cfg.vocab_size)
+    a = _engine(omx, cfg, max_context=256)
+    want = np.concatenate([[a.prefill(prompt)], a.decode(12)])
+    a.close()
+    want = np.concatenate([want[:5], want[7:]])          # the two tokens of the timed steps stay in the engine's ring
+    b = _engine(omx, cfg, max_context=256)
+    got = [b.prefill(prompt)] + list(b.decode(4))
+    us = b.time_step_kernels(2)
+    got += list(b.decode(6))
+    assert set(us) == {"qkv", "attention", "o", "gate_up", "down", "lm_head"}
+    assert all(0 < v < 1000 for v in us.values()), us
+    np.testing.assert_array_equal(np.array(got, np.uint32), want.astype(np.uint32))
+    b.close()

@@ -207,6 +207,15 @@ int omx_qwen3_prefill(omx_qwen3 m, const uint32_t* prompt, int n_prompt, uint32_
 int omx_qwen3_decode(omx_qwen3 m, int n, uint32_t* tokens_out);
 /* copy the logits of the last executed step ([vocab_local] bf16) to a host buffer                  */
 int omx_qwen3_last_logits(omx_qwen3 m, void* host_bf16, int n);
+/* Speculative decoding support (mlx-rs-core/src/speculative.rs).
+ *   verify: verify_draft_tokens :132-161 -- the n tokens [last accepted, draft 1 .. draft n-1] in ONE batched pass on top of the cache
+ *           (their K/V rows are appended), greedy_out[i] = argmax of the logits after token i; afterwards the pending input token is
+ *           greedy_out[n-1].  Single-rank bf16 models.  verify_logits: bf16 logits [V] of one row of the last verify call.
+ *   trim:   KeyValueCache::trim(n), the operation :165-169 notes the reference's cache trait lacks: forget the last n cached tokens
+ *           and make next_token the pending input token (n = 0: only replace the token).                                             */
+int omx_qwen3_verify(omx_qwen3 m, const uint32_t* tokens, int n, uint32_t* greedy_out);
+int omx_qwen3_verify_logits(omx_qwen3 m, int row, void* host_bf16, int n);
+int omx_qwen3_trim(omx_qwen3 m, int n, uint32_t next_token);
 /* timing of the last omx_qwen3_decode call measured with HIP events on the engine stream (ms)       */
 int omx_qwen3_last_decode_ms(omx_qwen3 m, float* ms);
 int omx_qwen3_last_prefill_ms(omx_qwen3 m, float* ms);   /* same for the last omx_qwen3_prefill call */

@@ -195,6 +195,9 @@ struct omx_qwen3_ {
     uint64_t* attn_gran = nullptr;        // split partials as tagged granules
     int attn_chunk = 0, attn_nsplit = 0, graph_tk_max = 0;
     unsigned long long* attn_trace = nullptr;   // set for one eager step by omx_qwen3_debug_trace_step
+    bf16_t* verify_logits = nullptr;            // [verify_cap, V]: every row's logits of the last omx_qwen3_verify
+    uint32_t* verify_tokens = nullptr;
+    int verify_cap = 0, verify_rows = 0;
     std::vector<hipEvent_t>* kernel_events = nullptr;   // set for eager steps by omx_qwen3_time_step_kernels: [layer][class][begin, end]
 
     void* comm = nullptr;
@@ -948,6 +951,8 @@ int omx_qwen3_destroy(omx_qwen3 m) {
     for (const bf16_t* k : m->sb_keys) quant_unregister_sb(k);
     for (void* p : m->owned) (void)hipFree(p);
     if (m->dq_buf) (void)hipFree(m->dq_buf);
+    if (m->verify_logits) (void)hipFree(m->verify_logits);
+    if (m->verify_tokens) (void)hipFree(m->verify_tokens);
     for (bf16_t* p : {m->pf_h, m->pf_h2, m->pf_xn, m->pf_q, m->pf_k, m->pf_v, m->pf_qt, m->pf_attn, m->pf_g, m->pf_u})
         if (p) (void)hipFree(p);
     if (m->ev0) (void)hipEventDestroy(m->ev0);
@@ -1202,6 +1207,76 @@ int omx_qwen3_prefill(omx_qwen3 m, const uint32_t* prompt, int n_prompt, uint32_
     OMX_HIP_CHECK(hipStreamSynchronize(m->stream));
     OMX_HIP_CHECK(hipEventElapsedTime(&m->last_prefill_ms, m->ev0, m->ev1));
     return step_health(m);
+}
+
+/* Speculative decoding (mlx-rs-core/src/speculative.rs).  `verify` is verify_draft_tokens (:132-161): the target model runs ALL n
+ * tokens [last accepted, draft 1 .. draft n-1] in one batched matrix-core pass on top of its cache (their K/V rows are appended) and
+ * returns the greedy token of every position -- the lm_head is one [n, V] GEMM, the weights stream once for all rows.  Afterwards the
+ * cache holds n more tokens and the next step's input token is greedy_out[n-1]; the caller then drops the rejected tail with
+ * omx_qwen3_trim.  Single-rank bf16 weights (a vocabulary-sharded or quantized head has no batched form here). */
+int omx_qwen3_verify(omx_qwen3 m, const uint32_t* tokens, int n, uint32_t* greedy_out) {
+    OMX_REQUIRE(m && tokens && greedy_out, "omx_qwen3_verify: null argument");
+    OMX_REQUIRE(n >= 1 && n <= 64, "omx_qwen3_verify: %d tokens (1..64 per call)", n);
+    OMX_REQUIRE(m->allreduce == nullptr && m->cfg.quant_bits == 0, "omx_qwen3_verify: single-rank bf16 models only");
+    for (int i = 0; i < n; ++i) OMX_REQUIRE(tokens[i] < (uint32_t)m->cfg.vocab_size, "omx_qwen3_verify: token id %u out of range (vocab %d)", tokens[i], m->cfg.vocab_size);
+    StepState st;
+    OMX_HIP_CHECK(hipMemcpyAsync(&st, m->st, sizeof(st), hipMemcpyDeviceToHost, m->stream));
+    OMX_HIP_CHECK(hipStreamSynchronize(m->stream));
+    OMX_REQUIRE(st.pos + n + 1 <= m->cap, "omx_qwen3_verify: %d cached + %d tokens exceed max_context %d", st.pos, n, m->cap);
+    OMX_REQUIRE(n <= m->prompt_cap, "omx_qwen3_verify: %d tokens exceed the prompt buffer", n);
+    hipStream_t s = m->stream;
+    const int hd = m->cfg.hidden_size, V = m->V;
+    if (n > m->verify_cap) {
+        OMX_HIP_CHECK(hipStreamSynchronize(s));
+        if (m->verify_logits) OMX_HIP_CHECK(hipFree(m->verify_logits));
+        if (m->verify_tokens) OMX_HIP_CHECK(hipFree(m->verify_tokens));
+        m->verify_logits = nullptr; m->verify_tokens = nullptr; m->verify_cap = 0;
+        const int cap = std::max(n, 16);
+        OMX_HIP_CHECK(hipMalloc((void**)&m->verify_logits, (size_t)cap * V * sizeof(bf16_t)));
+        OMX_HIP_CHECK(hipMalloc((void**)&m->verify_tokens, (size_t)cap * 4));
+        m->verify_cap = cap;
+    }
+    OMX_HIP_CHECK(hipMemcpyAsync(m->prompt_dev, tokens, (size_t)n * 4, hipMemcpyHostToDevice, s));
+    if (prefill_prefix_batched(m, n, st.pos, nullptr, /*full_last=*/true)) return 1;
+    // [final RMSNorm rows] -> [lm_head GEMM, n x V] -> [argmax per row]   (model.rs:423, 480-489; sampler.rs:9-18 at temperature 0)
+    if (omx_rms_norm(m->pf_xn, m->pf_h, m->final_norm, n, hd, m->cfg.rms_norm_eps, OMX_BFLOAT16, s)) return 1;
+    if (launch_gemm_bf16(m->verify_logits, m->pf_xn, m->lm_head, nullptr, n, V, hd, s)) return 1;
+    if (omx_argmax(m->verify_tokens, m->verify_logits, n, V, OMX_BFLOAT16, s)) return 1;
+    OMX_HIP_CHECK(hipMemcpyAsync(greedy_out, m->verify_tokens, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+    OMX_HIP_CHECK(hipStreamSynchronize(s));
+    st.pos += n;
+    st.cur_token = greedy_out[n - 1];
+    OMX_HIP_CHECK(hipMemcpyAsync(m->st, &st, sizeof(st), hipMemcpyHostToDevice, s));
+    OMX_HIP_CHECK(hipStreamSynchronize(s));
+    m->verify_rows = n;
+    return 0;
+}
+
+/* bf16 logits [V] of row `row` of the last omx_qwen3_verify (the caller derives logprobs = logits - logsumexp, speculative.rs:150-152) */
+int omx_qwen3_verify_logits(omx_qwen3 m, int row, void* host_bf16, int n) {
+    OMX_REQUIRE(m && host_bf16, "omx_qwen3_verify_logits: null argument");
+    OMX_REQUIRE(row >= 0 && row < m->verify_rows, "omx_qwen3_verify_logits: row %d of %d", row, m->verify_rows);
+    OMX_REQUIRE(n == m->V, "omx_qwen3_verify_logits: expected %d entries, got %d", m->V, n);
+    OMX_HIP_CHECK(hipMemcpyAsync(host_bf16, m->verify_logits + (size_t)row * m->V, (size_t)n * 2, hipMemcpyDeviceToHost, m->stream));
+    OMX_HIP_CHECK(hipStreamSynchronize(m->stream));
+    return 0;
+}
+
+/* KeyValueCache::trim -- the operation speculative.rs:165-169 notes the reference's cache trait lacks: forget the last n cached
+ * tokens (their slab rows are simply overwritten by later appends) and make `next_token` the next step's input.  n = 0 only
+ * replaces the pending input token. */
+int omx_qwen3_trim(omx_qwen3 m, int n, uint32_t next_token) {
+    OMX_REQUIRE(m, "omx_qwen3_trim: null argument");
+    OMX_REQUIRE(next_token < (uint32_t)m->cfg.vocab_size, "omx_qwen3_trim: token id %u out of range (vocab %d)", next_token, m->cfg.vocab_size);
+    StepState st;
+    OMX_HIP_CHECK(hipMemcpyAsync(&st, m->st, sizeof(st), hipMemcpyDeviceToHost, m->stream));
+    OMX_HIP_CHECK(hipStreamSynchronize(m->stream));
+    OMX_REQUIRE(n >= 0 && n <= st.pos, "omx_qwen3_trim: cannot drop %d of %d cached tokens", n, st.pos);
+    st.pos -= n;
+    st.cur_token = next_token;
+    OMX_HIP_CHECK(hipMemcpyAsync(m->st, &st, sizeof(st), hipMemcpyHostToDevice, m->stream));
+    OMX_HIP_CHECK(hipStreamSynchronize(m->stream));
+    return 0;
 }
 
 int omx_qwen3_last_prefill_ms(omx_qwen3 m, float* ms) {

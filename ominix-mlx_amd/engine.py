@@ -48,6 +48,9 @@ ENGINE_SIGNATURES = {
     "omx_qwen3_decode_path": (c_int, [c_void_p, ctypes.POINTER(c_int)]),
     "omx_qwen3_debug_trace_step": (c_int, [c_void_p, c_void_p, ctypes.c_size_t, ctypes.POINTER(c_int)]),
     "omx_qwen3_time_step_kernels": (c_int, [c_void_p, c_int, ctypes.POINTER(ctypes.c_float)]),
+    "omx_qwen3_verify": (c_int, [c_void_p, ctypes.POINTER(c_uint32), c_int, ctypes.POINTER(c_uint32)]),
+    "omx_qwen3_verify_logits": (c_int, [c_void_p, c_int, c_void_p, c_int]),
+    "omx_qwen3_trim": (c_int, [c_void_p, c_int, c_uint32]),
 }
 for _n, (_r, _a) in ENGINE_SIGNATURES.items():
     _f = getattr(lib, _n)
@@ -242,6 +245,22 @@ class Model:
         out = np.empty(n, dtype=np.uint32)
         check(lib.omx_qwen3_decode(self._h, n, out.ctypes.data_as(ctypes.POINTER(c_uint32))))
         return out
+
+    def verify(self, tokens) -> np.ndarray:
+        """speculative.rs:132-161 `verify_draft_tokens`: all tokens in one batched pass on top of the cache; greedy token per position."""
+        ids = np.ascontiguousarray(np.asarray(tokens, dtype=np.uint32).ravel())
+        out = np.empty(ids.size, dtype=np.uint32)
+        check(lib.omx_qwen3_verify(self._h, ids.ctypes.data_as(ctypes.POINTER(c_uint32)), ids.size, out.ctypes.data_as(ctypes.POINTER(c_uint32))))
+        return out
+
+    def verify_logits(self, row: int) -> np.ndarray:
+        raw = np.empty(self.vocab_local, dtype=np.uint16)
+        check(lib.omx_qwen3_verify_logits(self._h, row, raw.ctypes.data, raw.size))
+        return (raw.astype(np.uint32) << np.uint32(16)).view(np.float32)
+
+    def trim(self, n: int, next_token: int) -> None:
+        """KeyValueCache::trim(n) (missing in the reference, speculative.rs:165-169) + the next step's input token."""
+        check(lib.omx_qwen3_trim(self._h, n, int(next_token)))
 
     def last_decode_ms(self) -> float:
         v = c_float()

@@ -394,6 +394,25 @@ int omx_mel_frontend_frames(omx_mel_frontend f, int64_t n_samples, int* n_frames
 int omx_mel_frontend_forward(omx_mel_frontend f, const float* audio, int64_t n_samples, float* feats, float* logmel_out,
                              float* power_out, omx_stream stream);
 
+/* sibling frontend: Fun-ASR-Nano / SenseVoice log-mel, funasr-nano-mlx/src/audio.rs:44-157 (`MelFrontend::{new,
+ * compute_mel_spectrogram}`, defaults 16 kHz / 80 mels / n_fft 400 / hop 160 / 30 s): symmetric Hann, frames from sample frame * hop with
+ * zero padding, n_frames = max(min(n, max_length * sr) / hop, 1), DFT power, FFT-bin triangles (:287-339), ln(max(., 1e-10)).
+ * audio: device f32 [n_samples]; out: device f32 [n_mels, n_frames].  Errors as the reference: empty (:95-99), shorter than a hop (:105-110).
+ * omx_apply_lfr = `apply_lfr` (:345-412): mel [n_mels, n_frames] -> out [ceil(n_frames / lfr_n), lfr_m * n_mels], centred, edge-clamped. */
+int omx_sensevoice_mel_create(omx_mel_frontend* out, int sample_rate, int n_mels, int n_fft, int hop_length, float max_length_s);
+int omx_sensevoice_mel_frames(omx_mel_frontend f, int64_t n_samples, int* n_frames);
+int omx_sensevoice_mel_forward(omx_mel_frontend f, const float* audio, int64_t n_samples, float* out, omx_stream stream);
+int omx_apply_lfr(float* out, const float* mel, int n_mels, int n_frames, int lfr_m, int lfr_n, omx_stream stream);
+
+/* audio::resample (mlx-rs-core/src/audio.rs:178-277): windowed-sinc resampling with the reference's rubato configuration (sinc_len 256,
+ * oversampling 256, cubic phase interpolation, BlackmanHarris2, cutoff 0.95) and its chunking / flush / truncation driver.
+ * in: device f32 [n_in]; out: device f32 [out_cap], out_cap >= omx_resample_len(n_in, src, dst) = round(n_in * dst / src), the
+ * reference's truncation bound; *n_out = samples written (fewer than the bound for inputs shorter than the filter, as in the
+ * reference).  Equal rates / empty input: the input unchanged (:179-181).  Synchronises the stream before returning.             */
+int64_t omx_resample_len(int64_t n_in, uint32_t src_rate, uint32_t dst_rate);
+int omx_resample_sinc(const float* in, int64_t n_in, uint32_t src_rate, uint32_t dst_rate, float* out, int64_t out_cap, int64_t* n_out,
+                      omx_stream stream);
+
 /* sibling frontend: WhisperFeatureExtractor-compatible log-mel, qwen3-asr-mlx/src/audio.rs:24-128
  * (`MelFrontend::{new, compute_mel_spectrogram}`, defaults 16 kHz / 128 mels / n_fft 400 / hop 160): periodic Hann ->
  * 400-pt DFT power -> Slaney filters -> log10(max(., 1e-10)) -> max(., global max - 8) -> (x + 4) / 4.

@@ -28,6 +28,12 @@ AUDIO_SIGNATURES = {
     "omx_whisper_mel_create": (c_int, [ctypes.POINTER(c_void_p), c_int, c_int, c_int, c_int]),
     "omx_whisper_mel_frames": (c_int, [c_void_p, c_int64, ctypes.POINTER(c_int)]),
     "omx_whisper_mel_forward": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
+    "omx_sensevoice_mel_create": (c_int, [ctypes.POINTER(c_void_p), c_int, c_int, c_int, c_int, ctypes.c_float]),
+    "omx_sensevoice_mel_frames": (c_int, [c_void_p, c_int64, ctypes.POINTER(c_int)]),
+    "omx_sensevoice_mel_forward": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
+    "omx_apply_lfr": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "omx_resample_len": (c_int64, [c_int64, ctypes.c_uint32, ctypes.c_uint32]),
+    "omx_resample_sinc": (c_int, [c_void_p, c_int64, ctypes.c_uint32, ctypes.c_uint32, c_void_p, c_int64, ctypes.POINTER(c_int64), c_void_p]),
 }
 for _n, (_r, _a) in AUDIO_SIGNATURES.items():
     _f = getattr(lib, _n)
@@ -92,6 +98,71 @@ class WhisperMelFrontend:
         out = Tensor((self.n_mels, nf.value), "f32")
         check(lib.omx_whisper_mel_forward(self._h, a.ptr, a.size, out.ptr, None))
         return out
+
+
+class SenseVoiceMelFrontend:
+    """funasr-nano-mlx/src/audio.rs:44-157 (`AudioConfig`, `MelFrontend::{new, compute_mel_spectrogram}`): the Fun-ASR-Nano / SenseVoice
+    log-mel, [1, n_mels, n_frames] float32 on the device; `apply_lfr` (:345-412) stacks it to [1, ceil(T / n), m * n_mels]."""
+
+    def __init__(self, sample_rate=16000, n_mels=80, n_fft=400, hop_length=160, max_length=30.0):
+        require_device()
+        self.sample_rate, self.n_mels, self.n_fft, self.hop_length, self.max_length = sample_rate, n_mels, n_fft, hop_length, max_length
+        self.n_freqs = n_fft // 2 + 1
+        self._h = c_void_p()
+        check(lib.omx_sensevoice_mel_create(ctypes.byref(self._h), sample_rate, n_mels, n_fft, hop_length, max_length))
+
+    def __del__(self):
+        if not sys.is_finalizing() and getattr(self, "_h", None) is not None and self._h.value:
+            lib.omx_mel_frontend_destroy(self._h)
+            self._h = c_void_p()
+
+    def compute_mel_spectrogram(self, samples) -> Tensor:
+        a = samples if isinstance(samples, Tensor) else Tensor.from_numpy(np.asarray(samples, np.float32).ravel(), "f32")
+        if a.size == 0:
+            check(lib.omx_sensevoice_mel_frames(self._h, 0, ctypes.byref(c_int())))      # raises the reference's "samples are empty"
+        nf = c_int()
+        check(lib.omx_sensevoice_mel_frames(self._h, a.size, ctypes.byref(nf)))
+        out = Tensor((1, self.n_mels, nf.value), "f32")
+        check(lib.omx_sensevoice_mel_forward(self._h, a.ptr, a.size, out.ptr, None))
+        return out
+
+
+def apply_lfr(mel: Tensor, lfr_m: int, lfr_n: int) -> Tensor:
+    """funasr-nano-mlx/src/audio.rs:345-412: [1, n_mels, n_frames] -> [1, ceil(n_frames / lfr_n), n_mels * lfr_m] (device to device; the
+    reference copies the spectrogram to the host and back for this)."""
+    if len(mel.shape) != 3 or mel.shape[0] != 1:
+        raise ValueError(f"apply_lfr: expected [1, n_mels, n_frames], got {mel.shape}")
+    _, n_mels, n_frames = mel.shape
+    out = Tensor((1, (n_frames + lfr_n - 1) // lfr_n, n_mels * lfr_m), "f32")
+    check(lib.omx_apply_lfr(out.ptr, mel.ptr, n_mels, n_frames, lfr_m, lfr_n, None))
+    return out
+
+
+def resample_device(samples: Tensor, src_rate: int, target_rate: int) -> Tensor:
+    """audio::resample on a device tensor (f32 [n]) -> device tensor (f32 [m])."""
+    n = samples.size
+    cap = int(lib.omx_resample_len(n, src_rate, target_rate))
+    out = Tensor((max(cap, 1),), "f32")
+    m = c_int64()
+    check(lib.omx_resample_sinc(samples.ptr if n else None, n, src_rate, target_rate, out.ptr, cap, ctypes.byref(m), None))
+    if m.value == out.shape[0]:
+        return out
+    return Tensor((m.value,), "f32", ptr=out.ptr, owner=out)      # a prefix view of the allocation (short inputs give fewer samples)
+
+
+def resample(samples, src_rate: int, target_rate: int) -> np.ndarray:
+    """`audio::resample` (mlx-rs-core/src/audio.rs:178-277): host samples in, host samples out (float32), windowed-sinc interpolation with
+    the reference's rubato configuration, evaluated on the GPU (csrc/resample.hip)."""
+    x = np.ascontiguousarray(np.asarray(samples, np.float32).ravel())
+    if src_rate == target_rate or x.size == 0:              # :179-181
+        return x.copy()
+    require_device()
+    cap = int(lib.omx_resample_len(x.size, src_rate, target_rate))
+    src = Tensor.from_numpy(x, "f32")
+    out = Tensor((max(cap, 1),), "f32")
+    m = c_int64()
+    check(lib.omx_resample_sinc(src.ptr, x.size, src_rate, target_rate, out.ptr, cap, ctypes.byref(m), None))
+    return out.numpy().ravel()[: m.value].copy()
 
 
 # ---- WAV container, host side (mlx-rs-core/src/audio.rs:46-163 `load_wav`, :285-326 `save_wav`) ----

@@ -30,11 +30,14 @@ __global__ __launch_bounds__(256) void mel_power_kernel(const float* __restrict_
                                                         const float* __restrict__ tw_cos, const float* __restrict__ tw_sin,
                                                         const float* __restrict__ fbank, int n_mels,
                                                         float* __restrict__ power_out, float* __restrict__ logmel,
-                                                        float in_scale, float preemph, int log10_mode) {
+                                                        float in_scale, float preemph, int log10_mode, int pad_partial = 0,
+                                                        int mel_major = 0) {
     __shared__ float s_frame[kMaxFft], s_cos[kMaxFft], s_sin[kMaxFft], s_pow[kMaxFft / 2 + 1];
     const int frame = blockIdx.x;
     const int n_freqs = n_fft / 2 + 1;
-    const bool too_short = n_samples < n_fft;   // reference: ONE all-zero power frame (paraformer.rs:386-388)
+    // Paraformer: an input shorter than one window gives ONE all-zero power frame (paraformer.rs:386-388); the SenseVoice frontend
+    // (pad_partial) zero-pads every frame that runs past the end instead (funasr-nano-mlx/src/audio.rs:127-134)
+    const bool too_short = !pad_partial && n_samples < n_fft;
     for (int i = threadIdx.x; i < n_fft; i += blockDim.x) {
         float w = 0.f;
         if (!too_short) {
@@ -69,7 +72,9 @@ __global__ __launch_bounds__(256) void mel_power_kernel(const float* __restrict_
         const float* f = fbank + (size_t)m * n_freqs;
         float sum = 0.f;
         for (int k = 0; k < n_freqs; ++k) sum = fmaf(s_pow[k], f[k], sum);
-        logmel[(size_t)frame * n_mels + m] = log10_mode ? log10f(fmaxf(sum, 1e-10f)) : logf(fmaxf(sum, 1e-10f));
+        const float v = log10_mode ? log10f(fmaxf(sum, 1e-10f)) : logf(fmaxf(sum, 1e-10f));
+        if (mel_major) logmel[(size_t)m * n_frames + frame] = v;      // [n_mels, n_frames]
+        else logmel[(size_t)frame * n_mels + m] = v;
     }
 }
 
@@ -88,6 +93,19 @@ __global__ __launch_bounds__(256) void lfr_cmvn_kernel(const float* __restrict__
     float v = logmel[(size_t)src * n_mels + f];
     if (addshift && rescale) v = (v + addshift[d]) * rescale[d];
     out[i] = v;
+}
+
+// funasr-nano-mlx/src/audio.rs:345-412: centre-based stacking over a MEL-MAJOR spectrogram [n_mels, n_frames]
+__global__ __launch_bounds__(256) void lfr_center_kernel(const float* __restrict__ mel, int n_frames, int n_mels, int lfr_m, int lfr_n,
+                                                         float* __restrict__ out, int t_out) {
+    const int dim = lfr_m * n_mels;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)t_out * dim) return;
+    const int t = (int)(i / dim), d = (int)(i % dim);
+    const int j = d / n_mels, f = d % n_mels;
+    int src = t * lfr_n + j - lfr_m / 2;
+    src = src < 0 ? 0 : (src >= n_frames ? n_frames - 1 : src);
+    out[i] = mel[(size_t)f * n_frames + src];
 }
 
 __global__ __launch_bounds__(256) void nonfinite_count_kernel(const float* __restrict__ x, int64_t n, unsigned* count) {
@@ -148,6 +166,8 @@ struct omx_mel_frontend_ {
     int logmel_cap = 0;
     unsigned* bad = nullptr;
     bool whisper = false;     // Slaney filters, periodic Hann, log10 + Whisper normalisation (qwen3-asr-mlx/src/audio.rs)
+    bool sensevoice = false;  // symmetric Hann, FFT-bin triangles, ln, frames from sample 0 (funasr-nano-mlx/src/audio.rs)
+    int64_t max_samples = 0;  // sensevoice: max_length * sample_rate
 };
 
 extern "C" {
@@ -325,6 +345,85 @@ int omx_whisper_mel_forward(omx_mel_frontend f, const float* audio, int64_t n_sa
     const unsigned blocks = (unsigned)std::min<int64_t>((total + 255) / 256, 1024);
     omx::max_kernel<<<blocks, 256, 0, s>>>(f->logmel, total, f->bad);
     omx::whisper_norm_kernel<<<blocks, 256, 0, s>>>(f->logmel, nf, f->cfg.n_mels, f->bad, out);
+    OMX_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- sibling frontend: the Fun-ASR-Nano / SenseVoice log-mel of funasr-nano-mlx/src/audio.rs:44-157
+//      (`MelFrontend::{new, compute_mel_spectrogram}`, defaults 16 kHz / 80 mels / n_fft 400 / hop 160 / 30 s): symmetric Hann
+//      (i / (n_fft - 1)), frames start at sample frame * hop with zero padding past the end, n_frames = max(len / hop, 1) after
+//      truncation to max_length, 400-pt DFT power, triangles between floor((n_fft + 1) hz / sr) FFT bins (:287-339),
+//      ln(max(., 1e-10)); out [n_mels, n_frames].  `apply_lfr` (:345-412) follows as its own entry point. ----
+int omx_sensevoice_mel_create(omx_mel_frontend* out, int sample_rate, int n_mels, int n_fft, int hop_length, float max_length_s) {
+    OMX_REQUIRE(out, "omx_sensevoice_mel_create: null argument");
+    OMX_REQUIRE(n_fft >= 2 && n_fft <= omx::kMaxFft && n_mels >= 1 && n_mels <= omx::kMaxMels && hop_length >= 1 && sample_rate > 0 &&
+                    max_length_s > 0.f,
+                "InvalidConfig: sensevoice mel n_fft=%d n_mels=%d hop=%d max_length=%g", n_fft, n_mels, hop_length, (double)max_length_s);
+    omx_mel_frontend f = new omx_mel_frontend_();
+    f->cfg = omx_mel_config{sample_rate, n_mels, n_fft, hop_length, 1, 1};
+    f->sensevoice = true;
+    f->max_samples = (int64_t)(max_length_s * (float)sample_rate);                                     // audio.rs:112
+    const int n_freqs = n_fft / 2 + 1;
+    std::vector<float> window(n_fft), c(n_fft), s(n_fft), fb((size_t)n_mels * n_freqs, 0.f);
+    for (int i = 0; i < n_fft; ++i) {
+        window[i] = 0.5f * (1.0f - cosf(2.0f * (float)M_PI * (float)i / (float)(n_fft - 1)));          // audio.rs:68-72
+        c[i] = (float)cos(2.0 * M_PI * (double)i / (double)n_fft);
+        s[i] = (float)sin(2.0 * M_PI * (double)i / (double)n_fft);
+    }
+    {   // create_mel_filterbank, audio.rs:287-339
+        const float sr = (float)sample_rate, mel_low = omx::hz_to_mel(0.0f), mel_high = omx::hz_to_mel(sr / 2.0f);
+        std::vector<int64_t> bin(n_mels + 2);
+        for (int i = 0; i < n_mels + 2; ++i) {
+            const float hz = omx::mel_to_hz(mel_low + (mel_high - mel_low) * (float)i / (float)(n_mels + 1));
+            bin[i] = (int64_t)floorf((float)(n_fft + 1) * hz / sr);
+        }
+        for (int m = 0; m < n_mels; ++m) {
+            const int64_t left = bin[m], center = bin[m + 1], right = bin[m + 2];
+            for (int64_t k = left; k < center; ++k)
+                if (k < n_freqs && center > left) fb[(size_t)m * n_freqs + k] = (float)(k - left) / (float)(center - left);
+            for (int64_t k = center; k < right; ++k)
+                if (k < n_freqs && right > center) fb[(size_t)m * n_freqs + k] = (float)(right - k) / (float)(right - center);
+        }
+    }
+    auto up = [&](float** dst, const std::vector<float>& src) -> int {
+        OMX_HIP_CHECK(hipMalloc((void**)dst, src.size() * 4));
+        OMX_HIP_CHECK(hipMemcpy(*dst, src.data(), src.size() * 4, hipMemcpyHostToDevice));
+        return 0;
+    };
+    if (up(&f->window, window) || up(&f->tw_cos, c) || up(&f->tw_sin, s) || up(&f->fbank, fb)) return 1;
+    *out = f;
+    return 0;
+}
+
+int omx_sensevoice_mel_frames(omx_mel_frontend f, int64_t n_samples, int* n_frames) {
+    OMX_REQUIRE(f && n_frames && f->sensevoice, "omx_sensevoice_mel_frames: not a sensevoice frontend");
+    OMX_REQUIRE(n_samples > 0, "Cannot compute mel spectrogram: audio samples are empty");                     // audio.rs:95-99
+    OMX_REQUIRE(n_samples >= f->cfg.hop_length, "Audio too short: %lld ms, need at least %lld ms",              // audio.rs:105-110
+                (long long)(n_samples * 1000 / f->cfg.sample_rate), (long long)((int64_t)f->cfg.hop_length * 1000 / f->cfg.sample_rate));
+    const int64_t n = std::min<int64_t>(n_samples, f->max_samples);
+    *n_frames = (int)std::max<int64_t>(n / f->cfg.hop_length, 1);                                               // audio.rs:121
+    return 0;
+}
+
+int omx_sensevoice_mel_forward(omx_mel_frontend f, const float* audio, int64_t n_samples, float* out, omx_stream stream) {
+    OMX_REQUIRE(f && audio && out && f->sensevoice, "omx_sensevoice_mel_forward: null argument or not a sensevoice frontend");
+    int nf = 0;
+    if (omx_sensevoice_mel_frames(f, n_samples, &nf)) return 1;
+    const int64_t n = std::min<int64_t>(n_samples, f->max_samples);
+    omx::mel_power_kernel<<<nf, 256, 0, (hipStream_t)stream>>>(audio, n, nf, f->cfg.n_fft, f->cfg.hop_length, f->window, f->tw_cos, f->tw_sin,
+                                                               f->fbank, f->cfg.n_mels, nullptr, out, 1.0f, 0.0f, 0, /*pad_partial=*/1,
+                                                               /*mel_major=*/1);
+    OMX_LAUNCH_CHECK();
+    return 0;
+}
+
+/* apply_lfr (funasr-nano-mlx/src/audio.rs:345-412): mel [n_mels, n_frames] -> [ceil(n_frames / lfr_n), lfr_m * n_mels]; output frame t
+ * stacks frames t * lfr_n + (j - lfr_m / 2), j = 0 .. lfr_m - 1, clamped to [0, n_frames - 1]. */
+int omx_apply_lfr(float* out, const float* mel, int n_mels, int n_frames, int lfr_m, int lfr_n, omx_stream stream) {
+    OMX_REQUIRE(out && mel && n_mels >= 1 && n_frames >= 1 && lfr_m >= 1 && lfr_n >= 1, "omx_apply_lfr: bad arguments");
+    const int t_out = (n_frames + lfr_n - 1) / lfr_n;
+    const int64_t total = (int64_t)t_out * lfr_m * n_mels;
+    omx::lfr_center_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(mel, n_frames, n_mels, lfr_m, lfr_n, out, t_out);
     OMX_LAUNCH_CHECK();
     return 0;
 }

@@ -236,6 +236,73 @@ def whisper_log_mel(samples: np.ndarray, sample_rate: int = 16000, n_mels: int =
     return ((logm + 4.0) / 4.0).T.astype(np.float32)
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# Fun-ASR-Nano / SenseVoice frontend: funasr-nano-mlx/src/audio.rs:44-157 (MelFrontend), :287-339 (filterbank), :345-412 (apply_lfr).
+# All arithmetic is in-tree except the FFT (rustfft f32), evaluated here in float64 on the same f32 windowed frames -- the criterion the
+# reference's own FFT-vs-DFT validation uses (see the module header).  The reference's tests for it check shapes and the two error
+# cases only (:418-484); tests/test_sensevoice_oracle.py replays those.
+# ---------------------------------------------------------------------------------------------------------------------
+def sensevoice_mel_filterbank(sample_rate: int = 16000, n_fft: int = 400, n_mels: int = 80) -> np.ndarray:
+    """create_mel_filterbank (:287-339): triangles between FFT BIN indices floor((n_fft + 1) * hz / sr); [n_mels, n_freqs] f32."""
+    n_freqs = n_fft // 2 + 1
+    f = np.float32
+    hz2mel = lambda hz: f(2595.0) * np.log10(f(1.0) + f(hz) / f(700.0), dtype=np.float32)
+    mel2hz = lambda mel: f(700.0) * (np.power(f(10.0), f(mel) / f(2595.0), dtype=np.float32) - f(1.0))
+    lo, hi = hz2mel(0.0), hz2mel(f(sample_rate) / f(2.0))
+    bins = []
+    for i in range(n_mels + 2):
+        hz = mel2hz(lo + (hi - lo) * f(i) / f(n_mels + 1))
+        bins.append(int(np.floor(f(n_fft + 1) * hz / f(sample_rate))))
+    fb = np.zeros((n_mels, n_freqs), np.float32)
+    for m in range(n_mels):
+        left, center, right = bins[m], bins[m + 1], bins[m + 2]
+        for k in range(left, center):
+            if k < n_freqs and center > left:
+                fb[m, k] = f(k - left) / f(center - left)
+        for k in range(center, right):
+            if k < n_freqs and right > center:
+                fb[m, k] = f(right - k) / f(right - center)
+    return fb
+
+
+def sensevoice_log_mel(samples, sample_rate: int = 16000, n_mels: int = 80, n_fft: int = 400, hop: int = 160, max_length: float = 30.0) -> np.ndarray:
+    """MelFrontend::compute_mel_spectrogram (:93-157): [n_mels, n_frames] float32 (the reference adds a leading batch axis of 1)."""
+    x = np.asarray(samples, np.float32).ravel()
+    if x.size == 0:
+        raise ValueError("Cannot compute mel spectrogram: audio samples are empty")                  # :95-99
+    if x.size < hop:
+        raise ValueError("Audio too short")                                                         # :105-110
+    x = x[: int(np.float32(max_length) * np.float32(sample_rate))]                                   # :112-117
+    n_frames = max(x.size // hop, 1)                                                                # :121
+    window = (np.float32(0.5) * (np.float32(1.0) - np.cos(np.float32(2.0) * np.float32(np.pi) * np.arange(n_fft, dtype=np.float32)
+                                                          / np.float32(n_fft - 1), dtype=np.float32))).astype(np.float32)   # :68-72
+    padded = np.concatenate([x, np.zeros(n_fft, np.float32)])                                       # :131-134: zeros past the end
+    idx = np.arange(n_fft)[None, :] + hop * np.arange(n_frames)[:, None]
+    frames = (padded[idx] * window[None, :]).astype(np.float32)
+    spec = np.fft.fft(frames.astype(np.float64), axis=1)[:, : n_fft // 2 + 1]
+    power = spec.real ** 2 + spec.imag ** 2
+    mel = power @ sensevoice_mel_filterbank(sample_rate, n_fft, n_mels).astype(np.float64).T
+    return np.log(np.maximum(mel, 1e-10)).T.astype(np.float32)
+
+
+def apply_lfr(mel: np.ndarray, lfr_m: int = 7, lfr_n: int = 6) -> np.ndarray:
+    """apply_lfr (:345-412): mel [n_mels, n_frames] -> [ceil(n_frames / lfr_n), lfr_m * n_mels]; frame t stacks source frames
+    t * lfr_n + (j - lfr_m // 2), clamped to [0, n_frames - 1]."""
+    n_mels, n_frames = mel.shape
+    t_out = (n_frames + lfr_n - 1) // lfr_n
+    out = np.zeros((t_out, lfr_m * n_mels), np.float32)
+    for t in range(t_out):
+        center = t * lfr_n
+        for j in range(lfr_m):
+            if j < lfr_m // 2:
+                off = lfr_m // 2 - j
+                src = 0 if off > center else center - off
+            else:
+                src = min(center + (j - lfr_m // 2), n_frames - 1)
+            out[t, j * n_mels:(j + 1) * n_mels] = mel[:, src]
+    return out
+
+
 # WAV container (mlx-rs-core/src/audio.rs:46-163 load_wav, :285-326 save_wav)
 def wav_bytes(samples, sample_rate: int, bits: int = 16, channels: int = 1, extra_chunk: bool = False) -> bytes:
     """Test helper: a RIFF/WAVE image (PCM 16/24 or float 32) with an optional unknown chunk before `data`."""

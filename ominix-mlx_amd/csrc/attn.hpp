@@ -39,7 +39,14 @@ struct AttnStepArgs {
     bf16_t* out;                // [H*D]
     unsigned* abort_flag;       // raised when a gather gave up (results void)
     unsigned long long* trace;  // optional: 8 wall-clock stamps per block [nsplit][Hkv][8] (tools/attn_step_trace.py)
+    // ---- optional O projection in the same launch (o_w != null; attn_step_oproj_ok says whether the shape qualifies) ----
+    const bf16_t* o_w;          // [o_rows, H*D] row-major (nn::Linear weight, model.rs:214)
+    const bf16_t* o_resid;      // [o_rows] residual stream entering the layer
+    bf16_t* o_out;              // [o_rows] = bf16(resid + bf16(o_w . attn))      (model.rs:325)
+    int o_rows;
+    uint64_t* xg;               // granules [H*D/2]: {two packed bf16 of the attention vector, tag}
 };
+bool attn_step_oproj_ok(int H, int Hkv, int D, int nsplit, int o_rows);
 int attn_step_block_tokens(int D);
 void attn_step_plan(int tk_max, int Hkv, int G, int D, int* chunk, int* nsplit);
 size_t attn_step_ws_granules(int H, int D);

@@ -18,8 +18,16 @@
 //   * the blocks with split < G are also the consumers: after their own chunk, waves 0..D/64-1 of block (kvh, j) gather the
 //     granules of head kvh*G + j with coherent loads -- all splits in flight at once, re-read until every tag matches --
 //     merge them (max, rescale, sum, one division, one rounding) and store the bf16 head output.
-// Every block of the launch is co-resident (grid <= 2 blocks per CU by construction, __launch_bounds__(256, 2)), spins are
+// Every block of the launch is co-resident (one block per CU by construction, __launch_bounds__(512, 1), grid <= 256), spins are
 // bounded and a wait that gives up raises `abort_flag` (the host reports it) instead of hanging the GPU.
+//
+// O projection in the same launch (NVW > 0; model.rs:214, 325).  The attention phase is a chain of latencies during which the HBM
+// idles, and the O-projection weights (33 MB at Qwen3-8B shapes) depend on nothing: every wave issues the loads of ITS two weight
+// rows right after its first K/V loads (in-order return: nothing the attention waits for is queued behind them) and keeps the rows
+// in registers.  The consumers publish the merged head outputs a second time as granules {two packed bf16, tag}; every block
+// sweeps those K/2 granules into LDS (all 512 threads, one coherent round per pass) and finishes with the exact arithmetic of the
+// separate O GEMV (gemv_kernel<NVW, 1, 2, PRO_NONE, EPI_RESIDUAL>: same lane-to-element map, same fma order, same wave
+// reduction, same roundings) -- bit-identical hidden state, one launch boundary and one weight-stream ramp less per layer.
 #include <algorithm>
 
 #include "attn.hpp"
@@ -35,10 +43,10 @@ constexpr unsigned kSpinLimit = 1u << 15;   // gather passes (~1 us each) before
 
 typedef __attribute__((address_space(1))) unsigned long long gu64;
 
-__device__ __forceinline__ void st_granule(uint64_t* p, unsigned tag, float v) {
-    __hip_atomic_store((gu64*)p, ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(v), __ATOMIC_RELAXED,
-                       __HIP_MEMORY_SCOPE_AGENT);
+__device__ __forceinline__ void st_granule_u32(uint64_t* p, unsigned tag, unsigned v) {
+    __hip_atomic_store((gu64*)p, ((unsigned long long)tag << 32) | (unsigned long long)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+__device__ __forceinline__ void st_granule(uint64_t* p, unsigned tag, float v) { st_granule_u32(p, tag, __float_as_uint(v)); }
 __device__ __forceinline__ unsigned long long ld_granule(const uint64_t* p) {
     return __hip_atomic_load((gu64*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -60,7 +68,7 @@ __device__ __forceinline__ void unpack8(const u32x4 r, float (&x)[8]) {
 // merge the granules of one head: `NB` batches of 16 splits, every load of every live batch in flight before the first wait
 template <int D, int NB>
 __device__ __forceinline__ void gather_head(const AttnStepArgs& a, const uint64_t* base, int n_active, unsigned tag, int lane,
-                                            int dim, bf16_t* out) {
+                                            int dim, bf16_t* out, uint64_t* xg_head) {
     constexpr int STRIDE = D + 2;
     unsigned long long ml0 = 0, ml1 = 0, og[NB][16];
     bool ok_ml = false, ok_b[NB];
@@ -111,7 +119,12 @@ __device__ __forceinline__ void gather_head(const AttnStepArgs& a, const uint64_
         for (int j = 0; j < 16; ++j)   // splits past n_active re-read the last live one and carry f == 0
             acc = fmaf(readlane_f(f, b * 16 + j), __uint_as_float((unsigned)og[b][j]), acc);
     }
-    out[dim] = f32_to_bf16(acc / L);
+    const bf16_t r = f32_to_bf16(acc / L);
+    out[dim] = r;
+    if (xg_head) {   // the same value once more, for the O-projection phase of every block: one granule per dim pair
+        const float nb = dpp_f<kDppXor1>(bf16_to_f32(r));
+        if (!(lane & 1)) st_granule_u32(xg_head + dim / 2, tag, (unsigned)r | ((unsigned)f32_to_bf16(nb) << 16));
+    }
 }
 
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
@@ -137,15 +150,29 @@ __device__ __forceinline__ float dot8_bf16(const u32x4 a, const u32x4 b) {
 // through LDS instead of five times per wave.  attn_step_plan keeps the grid <= 256 blocks.
 constexpr int kKU = 3;   // units in flight per wave
 
-template <int D, int GT, bool TRACE>
+// the O GEMV's accumulation (gemv.hip dot8): lo then hi of each dword, one fma chain
+__device__ __forceinline__ float dot8_chain(const u32x4 w, const u32x4 xp, float acc) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        acc = fmaf(bf16lo(w[i]), bf16lo(xp[i]), acc);
+        acc = fmaf(bf16hi(w[i]), bf16hi(xp[i]), acc);
+    }
+    return acc;
+}
+
+constexpr int kORows = 2;   // O-projection rows per wave (== RB of the GEMV instantiation it replaces)
+
+template <int D, int GT, bool TRACE, int NVW>
 __global__ __launch_bounds__(kBlock, 1) void attn_step_kernel(const AttnStepArgs a) {
     constexpr int LPR = D / 8;            // lanes per K/V row
     constexpr int TPW = 64 / LPR;         // token rows per wave-instruction == one unit
+    constexpr bool OPROJ = NVW > 0;       // K = H * D = NVW * 512
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* sm_o = reinterpret_cast<float*>(smem);                 // [kWaves][TPW][GT][D]
     float* sm_m = sm_o + kWaves * TPW * GT * D;                   // [kWaves][GT]
     float* sm_l = sm_m + kWaves * GT;                             // [kWaves][GT]
     u32x4* sm_q = reinterpret_cast<u32x4*>(sm_l + kWaves * GT);   // [GT + 1][LPR]: roped q heads and the new k row, packed bf16
+    u32x4* sm_x = sm_q + (GT + 1) * LPR;                          // OPROJ: [NVW * 64] the attention vector, packed bf16
 
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -229,6 +256,21 @@ __global__ __launch_bounds__(kBlock, 1) void attn_step_kernel(const AttnStepArgs
 #pragma unroll
     for (int g = 0; g < GT; ++g) q[g] = sm_q[g * LPR + c];
     const u32x4 knew = sm_q[GT * LPR + c];
+    // ---- OPROJ: this wave's weight rows go out now -- AFTER the latency-critical first round has landed (issued together with
+    //      it, 33 MB of weight requests filled the HBM queues ahead of the q / K / V rows: they arrived at 6.7 us instead of 2.1) --
+    //      and stay in registers until the attention vector exists ----
+    u32x4 ow[kORows][NVW > 0 ? NVW : 1];
+    const int o_row0 = ((blockIdx.y * gridDim.x + blockIdx.x) * kWaves + wave) * kORows;
+    if (OPROJ) {
+#pragma unroll
+        for (int r = 0; r < kORows; ++r) {
+            const int row = min(o_row0 + r, a.o_rows - 1);                       // clamp: surplus waves re-read a valid row
+            const u32x4* p = reinterpret_cast<const u32x4*>(a.o_w + (size_t)row * (NVW * 512));
+#pragma unroll
+            for (int j = 0; j < NVW; ++j) ow[r][j] = __builtin_nontemporal_load(p + j * 64 + lane);
+        }
+        __builtin_amdgcn_sched_barrier(0);   // keep the loads HERE: the scheduler would sink them to their use
+    }
 
     const int Tk = pos + 1;
     const int n_active = (Tk + a.chunk - 1) / a.chunk;                  // splits that own at least one token
@@ -245,7 +287,10 @@ __global__ __launch_bounds__(kBlock, 1) void attn_step_kernel(const AttnStepArgs
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[g][e] = f32x2{0.f, 0.f};
     }
-    for (int u0 = wave; u0 < n_units && t_begin + u0 * TPW < t_end; u0 += kWaves * kKU) {
+    // one round = the kKU units a wave holds in registers.  The FIRST round is straight-line code ahead of the loop: hipcc's waitcnt
+    // pass counts loads exactly there, so its waits on the K/V rows do not cover the O-projection weights issued after them (inside
+    // the loop it falls back to small counts that drain everything older: own-chunk time went from 1.2 to 2.9 us)
+    auto round = [&](const int u0) {
         float s[kKU][GT];
         f32x2 vf[kKU][4];
 #pragma unroll
@@ -295,7 +340,9 @@ __global__ __launch_bounds__(kBlock, 1) void attn_step_kernel(const AttnStepArgs
                 for (int e = 0; e < 4; ++e) o[g][e] = __builtin_elementwise_fma(pp, vf[u][e], o[g][e]);
             }
         }
-    }
+    };
+    if (wave < n_units && t_begin + wave * TPW < t_end) round(wave);
+    for (int u0 = wave + kWaves * kKU; u0 < n_units && t_begin + u0 * TPW < t_end; u0 += kWaves * kKU) round(u0);
     if (TRACE && threadIdx.x == 0) tr[2] = wall_clock64();
 
     if (active) {
@@ -348,10 +395,62 @@ __global__ __launch_bounds__(kBlock, 1) void attn_step_kernel(const AttnStepArgs
         bf16_t* out = a.out + (size_t)head * D;
         const int dim = wave * 64 + lane;
         const int nb = (a.nsplit + 15) / 16;
-        if (nb <= 1) gather_head<D, 1>(a, base, n_active, tag, lane, dim, out);
-        else if (nb == 2) gather_head<D, 2>(a, base, n_active, tag, lane, dim, out);
-        else gather_head<D, 3>(a, base, n_active, tag, lane, dim, out);
+        uint64_t* xg_head = OPROJ ? a.xg + (size_t)head * (D / 2) : nullptr;
+        if (nb <= 1) gather_head<D, 1>(a, base, n_active, tag, lane, dim, out, xg_head);
+        else if (nb == 2) gather_head<D, 2>(a, base, n_active, tag, lane, dim, out, xg_head);
+        else gather_head<D, 3>(a, base, n_active, tag, lane, dim, out, xg_head);
         if (TRACE && threadIdx.x == 0) tr[4] = wall_clock64();
+    }
+
+    if (OPROJ) {
+        // ---- sweep the attention vector's granules into LDS: thread t owns granules [t * GP, + GP) of NVW * 256 ----
+        constexpr int GP = NVW >= 2 ? NVW / 2 : 1;
+        const bool takes = (int)threadIdx.x * GP < NVW * 256;
+        bool done = !takes;
+        unsigned* sx = reinterpret_cast<unsigned*>(sm_x);
+        // (the residual is fetched here, under the sweep: loading it next to the weight rows made its bf16 -> f32 conversion the
+        //  first use of a load issued AFTER 33 MB of weights, and every wave sat in vmcnt(0) for 4.8 us before touching q)
+        bf16_t o_res[kORows];
+#pragma unroll
+        for (int r = 0; r < kORows; ++r) o_res[r] = a.o_resid[min(o_row0 + r, a.o_rows - 1)];
+        for (unsigned spins = 0;; ++spins) {
+            if (!done) {
+                unsigned long long g[GP];
+#pragma unroll
+                for (int i = 0; i < GP; ++i) g[i] = ld_granule(a.xg + (size_t)threadIdx.x * GP + i);
+                bool ok = true;
+#pragma unroll
+                for (int i = 0; i < GP; ++i) ok &= (unsigned)(g[i] >> 32) == tag;
+                if (ok) {
+#pragma unroll
+                    for (int i = 0; i < GP; ++i) sx[threadIdx.x * GP + i] = (unsigned)g[i];
+                    done = true;
+                }
+            }
+            if (__syncthreads_and(done)) break;                      // also orders the LDS writes before the reads below
+            if (spins >= kSpinLimit) {
+                if (threadIdx.x == 0) __hip_atomic_store(a.abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+            __builtin_amdgcn_s_sleep(2);
+        }
+        if (TRACE && threadIdx.x == 0) tr[5] = wall_clock64();
+        // ---- the O GEMV's arithmetic on the rows held since the start ----
+        float acc[kORows] = {0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < NVW; ++j) {
+            const u32x4 xp = sm_x[j * 64 + lane];
+#pragma unroll
+            for (int r = 0; r < kORows; ++r) acc[r] = dot8_chain(ow[r][j], xp, acc[r]);
+        }
+#pragma unroll
+        for (int r = 0; r < kORows; ++r) acc[r] = wave_sum(acc[r]);
+        if (lane == 0) {
+#pragma unroll
+            for (int r = 0; r < kORows; ++r)
+                if (o_row0 + r < a.o_rows) a.o_out[o_row0 + r] = f32_to_bf16(bf16_to_f32(o_res[r]) + round_bf16(acc[r]));
+        }
+        if (TRACE && threadIdx.x == 0) tr[6] = wall_clock64();
     }
 }
 
@@ -377,6 +476,13 @@ void attn_step_plan(int tk_max, int Hkv, int G, int D, int* chunk, int* nsplit) 
 
 size_t attn_step_ws_granules(int H, int D) { return (size_t)H * kMaxSplits * (D + 2); }
 
+// the O projection can ride in the launch when K = H * D is one of the register layouts (NVW x 512, NVW in {1, 2, 4, 8}) and two
+// rows per wave cover the output: rows <= blocks * 8 waves * 2
+bool attn_step_oproj_ok(int H, int Hkv, int D, int nsplit, int o_rows) {
+    const int K = H * D, nvw = K / 512;
+    return K % 512 == 0 && (nvw == 1 || nvw == 2 || nvw == 4 || nvw == 8) && o_rows <= Hkv * nsplit * kWaves * kORows;
+}
+
 int launch_attn_step(const AttnStepArgs& a, int D, hipStream_t s) {
     const int G = a.H / a.Hkv;
     OMX_REQUIRE(a.H % a.Hkv == 0 && G >= 1 && G <= 8, "decode attention: %d query heads over %d KV heads unsupported (group of at most 8)", a.H, a.Hkv);
@@ -384,25 +490,42 @@ int launch_attn_step(const AttnStepArgs& a, int D, hipStream_t s) {
                 "decode attention: bad split plan (chunk %d, %d splits, group %d, %d kv heads)", a.chunk, a.nsplit, G, a.Hkv);
     OMX_REQUIRE(a.ws && a.rope_cur && a.pos_ptr && a.seq_ptr && a.abort_flag && a.tag_mul > a.tag_add - 1u && a.tag_add >= 1u,
                 "decode attention: missing step state");
+    int nvw = 0;
+    if (a.o_w) {
+        OMX_REQUIRE(a.o_resid && a.o_out && a.xg && attn_step_oproj_ok(a.H, a.Hkv, D, a.nsplit, a.o_rows),
+                    "decode attention + O projection: shape does not qualify (H*D = %d, %d rows, %d blocks)", a.H * D, a.o_rows, a.Hkv * a.nsplit);
+        nvw = a.H * D / 512;
+    }
     const dim3 grid(a.Hkv, a.nsplit), block(kBlock);
     const int gt = G <= 1 ? 1 : G <= 2 ? 2 : G <= 4 ? 4 : 8;
-#define OMX_ATTN_STEP_CASE(DD, GG)                                                                                       \
-    if (D == DD && gt == GG) {                                                                                           \
-        const size_t shmem = ((size_t)kWaves * (64 / (DD / 8)) * GG * DD + 2 * kWaves * GG) * sizeof(float) + (size_t)(GG + 1) * (DD / 8) * 16; \
-        if (shmem > 48 * 1024) {                                                                                         \
-            OMX_HIP_CHECK(hipFuncSetAttribute((const void*)attn_step_kernel<DD, GG, false>,                             \
+#define OMX_ATTN_LAUNCH(DD, GG, TT, NN)                                                                                  \
+    {                                                                                                                    \
+        if (shmem > 48 * 1024)                                                                                           \
+            OMX_HIP_CHECK(hipFuncSetAttribute((const void*)attn_step_kernel<DD, GG, TT, NN>,                            \
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));                  \
-            OMX_HIP_CHECK(hipFuncSetAttribute((const void*)attn_step_kernel<DD, GG, true>,                              \
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));                  \
-        }                                                                                                                \
-        if (a.trace) OMX_LAUNCH_TIMED((attn_step_kernel<DD, GG, true>), grid, block, shmem, s, a);                         \
-        else OMX_LAUNCH_TIMED((attn_step_kernel<DD, GG, false>), grid, block, shmem, s, a);                               \
+        OMX_LAUNCH_TIMED((attn_step_kernel<DD, GG, TT, NN>), grid, block, shmem, s, a);                                  \
         OMX_LAUNCH_CHECK();                                                                                              \
         return 0;                                                                                                        \
+    }
+#define OMX_ATTN_STEP_CASE(DD, GG)                                                                                       \
+    if (D == DD && gt == GG) {                                                                                           \
+        const size_t shmem = ((size_t)kWaves * (64 / (DD / 8)) * GG * DD + 2 * kWaves * GG) * sizeof(float) +            \
+                             (size_t)(GG + 1) * (DD / 8) * 16 + (size_t)nvw * 64 * 16;                                   \
+        if (a.trace) {   /* timeline builds: the plain kernel and the widest fused one */                               \
+            if (nvw == 0) OMX_ATTN_LAUNCH(DD, GG, true, 0)                                                               \
+            if (nvw == 8) OMX_ATTN_LAUNCH(DD, GG, true, 8)                                                               \
+            return set_error("decode attention: no traced instantiation for H*D = %d", a.H * DD);                       \
+        }                                                                                                                \
+        if (nvw == 0) OMX_ATTN_LAUNCH(DD, GG, false, 0)                                                                  \
+        if (nvw == 1) OMX_ATTN_LAUNCH(DD, GG, false, 1)                                                                  \
+        if (nvw == 2) OMX_ATTN_LAUNCH(DD, GG, false, 2)                                                                  \
+        if (nvw == 4) OMX_ATTN_LAUNCH(DD, GG, false, 4)                                                                  \
+        OMX_ATTN_LAUNCH(DD, GG, false, 8)                                                                                \
     }
     OMX_ATTN_STEP_CASE(128, 1) OMX_ATTN_STEP_CASE(128, 2) OMX_ATTN_STEP_CASE(128, 4) OMX_ATTN_STEP_CASE(128, 8)
     OMX_ATTN_STEP_CASE(64, 1) OMX_ATTN_STEP_CASE(64, 2) OMX_ATTN_STEP_CASE(64, 4) OMX_ATTN_STEP_CASE(64, 8)
 #undef OMX_ATTN_STEP_CASE
+#undef OMX_ATTN_LAUNCH
     return set_error("decode attention: head_dim %d unsupported (64 or 128)", D);
 }
 

@@ -193,6 +193,7 @@ struct omx_qwen3_ {
     // the graphs are rebuilt when the context outgrows that bucket
     float* rope_cur = nullptr;            // [D] cos | sin of the current position
     uint64_t* attn_gran = nullptr;        // split partials as tagged granules
+    uint64_t* attn_xg = nullptr;          // the merged attention vector as granules (O projection in the attention launch)
     int attn_chunk = 0, attn_nsplit = 0, graph_tk_max = 0;
     unsigned long long* attn_trace = nullptr;   // set for one eager step by omx_qwen3_debug_trace_step
     bf16_t* verify_logits = nullptr;            // [verify_cap, V]: every row's logits of the last omx_qwen3_verify
@@ -342,8 +343,19 @@ int resolve_weights(omx_qwen3 m) {
     return 0;
 }
 
-// the attention launch of layer l of a decode step (both the bf16 and the packed-weight step use the bf16 KV kernels)
-int enqueue_attention(omx_qwen3 m, int l, hipStream_t s) {
+// O projection inside the attention launch (csrc/attn_step.hip): bf16 weights, single rank, a shape the kernel has a register layout
+// for; OMX_ATTN_OPROJ=0 keeps the two launches
+bool attention_takes_oproj(omx_qwen3 m) {
+    const char* e = getenv("OMX_ATTN_OPROJ");          // (read per call: tests flip it between engines of one process)
+    const bool off = e && e[0] == '0';
+    const omx_qwen3_config& c = m->cfg;
+    return !off && c.quant_bits == 0 && m->allreduce == nullptr && c.tp_size <= 1 &&
+           attn_step_oproj_ok(m->H, m->Hkv, c.head_dim, m->attn_nsplit, c.hidden_size);
+}
+
+// the attention launch of layer l of a decode step (both the bf16 and the packed-weight step use the bf16 KV kernels);
+// resid / out != null: the layer's O projection + residual rides in the same launch (attention_takes_oproj)
+int enqueue_attention(omx_qwen3 m, int l, hipStream_t s, const bf16_t* resid = nullptr, bf16_t* out = nullptr) {
     const omx_qwen3_config& c = m->cfg;
     const int D = c.head_dim;
     const LayerW& L = m->layers[l];
@@ -365,6 +377,9 @@ int enqueue_attention(omx_qwen3 m, int l, hipStream_t s) {
         a.out = m->attn_out;
         a.abort_flag = m->wait_abort;
         a.trace = m->attn_trace ? m->attn_trace + (size_t)l * m->attn_nsplit * m->Hkv * 8 : nullptr;
+        if (resid && out) {
+            a.o_w = L.o; a.o_resid = resid; a.o_out = out; a.o_rows = c.hidden_size; a.xg = m->attn_xg;
+        }
         return launch_attn_step(a, D, s);
     }
 }
@@ -484,9 +499,12 @@ int enqueue_step(omx_qwen3 m, bool with_head) {
                 if (launch_gemv(a, PRO_RMSNORM, EPI_STORE, s)) return 1;
             if (pending) { bf16_t* t = h; h = hn; hn = t; pending = nullptr; }
         }
+        const bool fused_o = !tp && attention_takes_oproj(m);
         time_next_launch(m, l, KC_ATTN);
-                if (enqueue_attention(m, l, s)) return 1;   // [q/k RMSNorm + RoPE + cache append + split-KV SDPA + merge]  model.rs:172-210
-        {   // [O GEMV + residual]  model.rs:214,325
+                if (enqueue_attention(m, l, s, fused_o ? h : nullptr, fused_o ? hn : nullptr)) return 1;   // [q/k RMSNorm + RoPE + cache append + split-KV SDPA + merge]  model.rs:172-210
+        if (fused_o) {   // [O projection + residual] happened in the attention launch
+            bf16_t* t = h; h = hn; hn = t;
+        } else {   // [O GEMV + residual]  model.rs:214,325
             GemvArgs a = {};
             a.w0 = L.o; a.n0 = hd; a.N = hd; a.K = m->H * D;
             a.x = m->attn_out;
@@ -925,7 +943,9 @@ int omx_qwen3_create(omx_qwen3* out, const omx_qwen3_config* cfg) {
         if (get_workspace(&ws, need)) return 1;
         if (dev_alloc(m, &m->moe_xn, (size_t)c.hidden_size) || dev_alloc(m, &m->moe_out, (size_t)c.hidden_size)) return 1;
     }
-    if (dev_alloc(m, &m->rope_cur, (size_t)D) || dev_alloc(m, &m->attn_gran, attn_step_ws_granules(m->H, D))) return 1;
+    if (dev_alloc(m, &m->rope_cur, (size_t)D) || dev_alloc(m, &m->attn_gran, attn_step_ws_granules(m->H, D)) ||
+        dev_alloc(m, &m->attn_xg, (size_t)m->H * D / 2 + 8))
+        return 1;
     if (dev_alloc(m, &m->step_seq, 16) || dev_alloc(m, &m->wait_abort, 16)) return 1;
     if (dev_alloc(m, &m->st, 1) || dev_alloc(m, &m->out_ring, (size_t)m->ring_cap) ||
         dev_alloc(m, &m->h, (size_t)c.hidden_size) || dev_alloc(m, &m->h2, (size_t)c.hidden_size) ||
@@ -1386,6 +1406,7 @@ int omx_qwen3_time_step_kernels(omx_qwen3 m, int steps, float* us) {
     for (auto& e : ev) OMX_HIP_CHECK(hipEventCreate(&e));
     double sum[KC_COUNT] = {};
     int rc = 0;
+    bool fused_o = false;
     arm_launch_events(nullptr, nullptr);
     for (int it = 0; it < steps && !rc; ++it) {
         StepState st;
@@ -1393,6 +1414,7 @@ int omx_qwen3_time_step_kernels(omx_qwen3 m, int steps, float* us) {
         OMX_HIP_CHECK(hipStreamSynchronize(m->stream));
         if (st.pos + 1 > m->cap) { set_error("omx_qwen3_time_step_kernels: context full"); rc = 1; break; }
         if (prepare_step(m, st.pos)) { rc = 1; break; }
+        fused_o = attention_takes_oproj(m);
         m->kernel_events = &ev;
         rc = enqueue_step(m, true);
         m->kernel_events = nullptr;
@@ -1402,6 +1424,7 @@ int omx_qwen3_time_step_kernels(omx_qwen3 m, int steps, float* us) {
             for (int k = 0; k < (l == L ? 1 : kLayerClasses); ++k) {
                 float ms = 0.f;
                 const size_t i = ((size_t)l * kLayerClasses + k) * 2;
+                if (l < L && k == KC_O && fused_o) continue;     // that pair was never armed
                 OMX_HIP_CHECK(hipEventElapsedTime(&ms, ev[i], ev[i + 1]));
                 sum[l == L ? KC_HEAD : k] += ms * 1e3;
             }
@@ -1410,6 +1433,7 @@ int omx_qwen3_time_step_kernels(omx_qwen3 m, int steps, float* us) {
     for (auto& e : ev) (void)hipEventDestroy(e);
     if (rc) return 1;
     for (int k = 0; k < KC_COUNT; ++k) us[k] = (float)(sum[k] / ((k == KC_HEAD ? 1.0 : (double)L) * steps));
+    if (fused_o) us[KC_O] = 0.f;   // no separate launch: its work is inside the attention figure
     return 0;
 }
 

@@ -522,3 +522,23 @@ def test_time_step_kernels_runs_real_steps(omx):
     assert all(0 < v < 1000 for v in us.values()), us
     np.testing.assert_array_equal(np.array(got, np.uint32), want.astype(np.uint32))
     b.close()
+
+
+@pytest.mark.parametrize("name", list(CONFIGS))
+def test_oproj_in_attention_launch_is_bit_identical(omx, monkeypatch, name):
+    """csrc/attn_step.hip with the layer's O projection + residual in the attention launch (weight rows prefetched into registers
+    while the attention runs, the merged heads handed over as tagged granules) reproduces the separate O GEMV's arithmetic exactly:
+    same tokens and bit-equal logits as OMX_ATTN_OPROJ=0, in graph and eager form, across a context-bucket boundary."""
+    cfg = CONFIGS[name]
+    prompt = synth.prompt_ids(1000, cfg.vocab_size)
+    outs = {}
+    for mode in ("0", "1", "eager"):
+        monkeypatch.setenv("OMX_ATTN_OPROJ", "0" if mode == "0" else "1")
+        monkeypatch.setenv("OMX_NO_GRAPH", "1" if mode == "eager" else "0")
+        m = _engine(omx, cfg, max_context=1280)
+        toks = np.concatenate([[m.prefill(prompt)], m.decode(40)])      # positions 1000 .. 1039: crosses 1024
+        outs[mode] = (toks, m.last_logits())
+        m.close()
+    for mode in ("1", "eager"):
+        for a, b in zip(outs["0"], outs[mode]):
+            np.testing.assert_array_equal(a, b)

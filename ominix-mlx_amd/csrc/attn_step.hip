@@ -160,7 +160,88 @@ __device__ __forceinline__ float dot8_chain(const u32x4 w, const u32x4 xp, float
     return acc;
 }
 
-constexpr int kORows = 2;   // O-projection rows per wave (== RB of the GEMV instantiation it replaces)
+constexpr int kORows = 4;   // most O-projection rows a wave holds (attn_step_oproj_ok)
+
+// The O-projection phase of a non-consumer block (attn_step_kernel, NVW > 0): R weight rows per wave go out NOW -- the block's
+// latency-critical work is over and its attention registers are free -- then the merged attention vector is awaited and swept into
+// LDS, then the separate O GEMV's arithmetic (gemv.hip gemv_kernel<NVW, 1, 2, PRO_NONE, EPI_RESIDUAL>) runs on the held rows.
+// Measured alternatives at Qwen3-8B shapes, ctx 2 k: weight loads issued with the first K/V round -> 33 MB of requests fill the HBM
+// queues ahead of the q / K / V rows (they land at 6.7 us instead of 2.1); issued after that round landed, in every block -> a wave's
+// memory instructions queue in order behind its own prefetch, the partial stores left 1.5 us and the gather 0.5 us later (kernel
+// 13.8 us, still 2.4 us/layer better than two launches).
+template <int NVW, int R>
+__device__ __forceinline__ void oproj_phase(const AttnStepArgs& a, u32x4* sm_x, unsigned tag, int lane, int wave, int o_row0,
+                                            unsigned long long* tr) {
+    u32x4 ow[R][NVW];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int row = min(o_row0 + r, a.o_rows - 1);                           // clamp: surplus waves re-read a valid row
+        const u32x4* p = reinterpret_cast<const u32x4*>(a.o_w + (size_t)row * (NVW * 512));
+#pragma unroll
+        for (int j = 0; j < NVW; ++j) ow[r][j] = __builtin_nontemporal_load(p + j * 64 + lane);
+    }
+    bf16_t o_res[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) o_res[r] = a.o_resid[min(o_row0 + r, a.o_rows - 1)];
+    __builtin_amdgcn_sched_barrier(0);   // keep the loads HERE: the scheduler would sink them to their use
+    // wait politely: ONE wave watches one granule per consumer wave (the last of its 32) with a sleep between looks; only then does
+    // the block read the whole vector -- normally once (measured: sweep done at 11.3 us with the watch, 11.9 us without)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (wave == 0) {
+        constexpr int SEGS = NVW * 8;                                  // consumer waves: H * D / 64
+        const uint64_t* probe = a.xg + (size_t)min(lane, SEGS - 1) * 32 + 31;
+        for (unsigned spins = 0; spins < kSpinLimit; ++spins) {
+            const unsigned long long g = ld_granule(probe);
+            if (__all((unsigned)(g >> 32) == tag)) break;
+            __builtin_amdgcn_s_sleep(4);
+        }
+    }
+    __syncthreads();
+    // sweep the granules into LDS: thread t owns granules [t * GP, + GP) of NVW * 256
+    constexpr int GP = NVW >= 2 ? NVW / 2 : 1;
+    bool done = (int)threadIdx.x * GP >= NVW * 256;
+    unsigned* sx = reinterpret_cast<unsigned*>(sm_x);
+    for (unsigned spins = 0;; ++spins) {
+        if (!done) {
+            unsigned long long g[GP];
+#pragma unroll
+            for (int i = 0; i < GP; ++i) g[i] = ld_granule(a.xg + (size_t)threadIdx.x * GP + i);
+            bool ok = true;
+#pragma unroll
+            for (int i = 0; i < GP; ++i) ok &= (unsigned)(g[i] >> 32) == tag;
+            if (ok) {
+#pragma unroll
+                for (int i = 0; i < GP; ++i) sx[threadIdx.x * GP + i] = (unsigned)g[i];
+                done = true;
+            }
+        }
+        if (__syncthreads_and(done)) break;                          // also orders the LDS writes before the reads below
+        if (spins >= kSpinLimit) {
+            if (threadIdx.x == 0) __hip_atomic_store(a.abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+        }
+        __builtin_amdgcn_s_sleep(2);
+    }
+    if (tr && threadIdx.x == 0) tr[5] = wall_clock64();
+    float acc[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int j = 0; j < NVW; ++j) {
+        const u32x4 xp = sm_x[j * 64 + lane];
+#pragma unroll
+        for (int r = 0; r < R; ++r) acc[r] = dot8_chain(ow[r][j], xp, acc[r]);
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc[r] = wave_sum(acc[r]);
+    if (lane == 0) {
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+            if (o_row0 + r < a.o_rows) a.o_out[o_row0 + r] = f32_to_bf16(bf16_to_f32(o_res[r]) + round_bf16(acc[r]));
+    }
+    if (tr && threadIdx.x == 0) tr[6] = wall_clock64();
+}
+
 
 template <int D, int GT, bool TRACE, int NVW>
 __global__ __launch_bounds__(kBlock, 1) void attn_step_kernel(const AttnStepArgs a) {
@@ -256,21 +337,6 @@ __global__ __launch_bounds__(kBlock, 1) void attn_step_kernel(const AttnStepArgs
 #pragma unroll
     for (int g = 0; g < GT; ++g) q[g] = sm_q[g * LPR + c];
     const u32x4 knew = sm_q[GT * LPR + c];
-    // ---- OPROJ: this wave's weight rows go out now -- AFTER the latency-critical first round has landed (issued together with
-    //      it, 33 MB of weight requests filled the HBM queues ahead of the q / K / V rows: they arrived at 6.7 us instead of 2.1) --
-    //      and stay in registers until the attention vector exists ----
-    u32x4 ow[kORows][NVW > 0 ? NVW : 1];
-    const int o_row0 = ((blockIdx.y * gridDim.x + blockIdx.x) * kWaves + wave) * kORows;
-    if (OPROJ) {
-#pragma unroll
-        for (int r = 0; r < kORows; ++r) {
-            const int row = min(o_row0 + r, a.o_rows - 1);                       // clamp: surplus waves re-read a valid row
-            const u32x4* p = reinterpret_cast<const u32x4*>(a.o_w + (size_t)row * (NVW * 512));
-#pragma unroll
-            for (int j = 0; j < NVW; ++j) ow[r][j] = __builtin_nontemporal_load(p + j * 64 + lane);
-        }
-        __builtin_amdgcn_sched_barrier(0);   // keep the loads HERE: the scheduler would sink them to their use
-    }
 
     const int Tk = pos + 1;
     const int n_active = (Tk + a.chunk - 1) / a.chunk;                  // splits that own at least one token
@@ -388,6 +454,18 @@ __global__ __launch_bounds__(kBlock, 1) void attn_step_kernel(const AttnStepArgs
     }
     if (TRACE && threadIdx.x == 0) tr[3] = wall_clock64();
 
+    // ---- OPROJ: the blocks that are not consumers (split >= G) share the output rows; rows per wave is a compile-time constant of the
+    //      phase (a runtime-predicated load block per row made hipcc drain the queue between rows: three serial round trips) ----
+    if (OPROJ && split >= G) {
+        const int o_row0 = (((split - G) * (int)gridDim.x + kvh) * kWaves + wave) * a.o_rpw;
+        unsigned long long* otr = TRACE ? tr : nullptr;
+        if (a.o_rpw == 1) oproj_phase<(NVW > 0 ? NVW : 1), 1>(a, sm_x, tag, lane, wave, o_row0, otr);
+        else if (a.o_rpw == 2) oproj_phase<(NVW > 0 ? NVW : 1), 2>(a, sm_x, tag, lane, wave, o_row0, otr);
+        else if (a.o_rpw == 3) oproj_phase<(NVW > 0 ? NVW : 1), 3>(a, sm_x, tag, lane, wave, o_row0, otr);
+        else oproj_phase<(NVW > 0 ? NVW : 1), 4>(a, sm_x, tag, lane, wave, o_row0, otr);
+        return;
+    }
+
     // ---- consumers: block (kvh, j < G) merges head kvh*G + j ----
     if (split < G && wave < D / 64) {
         const int head = kvh * G + split;
@@ -402,56 +480,6 @@ __global__ __launch_bounds__(kBlock, 1) void attn_step_kernel(const AttnStepArgs
         if (TRACE && threadIdx.x == 0) tr[4] = wall_clock64();
     }
 
-    if (OPROJ) {
-        // ---- sweep the attention vector's granules into LDS: thread t owns granules [t * GP, + GP) of NVW * 256 ----
-        constexpr int GP = NVW >= 2 ? NVW / 2 : 1;
-        const bool takes = (int)threadIdx.x * GP < NVW * 256;
-        bool done = !takes;
-        unsigned* sx = reinterpret_cast<unsigned*>(sm_x);
-        // (the residual is fetched here, under the sweep: loading it next to the weight rows made its bf16 -> f32 conversion the
-        //  first use of a load issued AFTER 33 MB of weights, and every wave sat in vmcnt(0) for 4.8 us before touching q)
-        bf16_t o_res[kORows];
-#pragma unroll
-        for (int r = 0; r < kORows; ++r) o_res[r] = a.o_resid[min(o_row0 + r, a.o_rows - 1)];
-        for (unsigned spins = 0;; ++spins) {
-            if (!done) {
-                unsigned long long g[GP];
-#pragma unroll
-                for (int i = 0; i < GP; ++i) g[i] = ld_granule(a.xg + (size_t)threadIdx.x * GP + i);
-                bool ok = true;
-#pragma unroll
-                for (int i = 0; i < GP; ++i) ok &= (unsigned)(g[i] >> 32) == tag;
-                if (ok) {
-#pragma unroll
-                    for (int i = 0; i < GP; ++i) sx[threadIdx.x * GP + i] = (unsigned)g[i];
-                    done = true;
-                }
-            }
-            if (__syncthreads_and(done)) break;                      // also orders the LDS writes before the reads below
-            if (spins >= kSpinLimit) {
-                if (threadIdx.x == 0) __hip_atomic_store(a.abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                break;
-            }
-            __builtin_amdgcn_s_sleep(2);
-        }
-        if (TRACE && threadIdx.x == 0) tr[5] = wall_clock64();
-        // ---- the O GEMV's arithmetic on the rows held since the start ----
-        float acc[kORows] = {0.f, 0.f};
-#pragma unroll
-        for (int j = 0; j < NVW; ++j) {
-            const u32x4 xp = sm_x[j * 64 + lane];
-#pragma unroll
-            for (int r = 0; r < kORows; ++r) acc[r] = dot8_chain(ow[r][j], xp, acc[r]);
-        }
-#pragma unroll
-        for (int r = 0; r < kORows; ++r) acc[r] = wave_sum(acc[r]);
-        if (lane == 0) {
-#pragma unroll
-            for (int r = 0; r < kORows; ++r)
-                if (o_row0 + r < a.o_rows) a.o_out[o_row0 + r] = f32_to_bf16(bf16_to_f32(o_res[r]) + round_bf16(acc[r]));
-        }
-        if (TRACE && threadIdx.x == 0) tr[6] = wall_clock64();
-    }
 }
 
 }  // namespace
@@ -476,14 +504,20 @@ void attn_step_plan(int tk_max, int Hkv, int G, int D, int* chunk, int* nsplit) 
 
 size_t attn_step_ws_granules(int H, int D) { return (size_t)H * kMaxSplits * (D + 2); }
 
-// the O projection can ride in the launch when K = H * D is one of the register layouts (NVW x 512, NVW in {1, 2, 4, 8}) and two
-// rows per wave cover the output: rows <= blocks * 8 waves * 2
+// rows per wave when the waves of the non-consumer blocks (split >= G: blocks - H of them) share the O projection's output rows
+static int oproj_rows_per_wave(int H, int Hkv, int nsplit, int o_rows) {
+    const int waves = (Hkv * nsplit - H) * kWaves;
+    return waves > 0 ? (o_rows + waves - 1) / waves : 1 << 20;
+}
+// the O projection can ride in the launch when K = H * D is one of the register layouts (NVW x 512, NVW in {1, 2, 4, 8}) and at most
+// kORows rows per wave of the non-consumer blocks cover the output
 bool attn_step_oproj_ok(int H, int Hkv, int D, int nsplit, int o_rows) {
     const int K = H * D, nvw = K / 512;
-    return K % 512 == 0 && (nvw == 1 || nvw == 2 || nvw == 4 || nvw == 8) && o_rows <= Hkv * nsplit * kWaves * kORows;
+    return K % 512 == 0 && (nvw == 1 || nvw == 2 || nvw == 4 || nvw == 8) && oproj_rows_per_wave(H, Hkv, nsplit, o_rows) <= kORows;
 }
 
-int launch_attn_step(const AttnStepArgs& a, int D, hipStream_t s) {
+int launch_attn_step(const AttnStepArgs& a_in, int D, hipStream_t s) {
+    AttnStepArgs a = a_in;
     const int G = a.H / a.Hkv;
     OMX_REQUIRE(a.H % a.Hkv == 0 && G >= 1 && G <= 8, "decode attention: %d query heads over %d KV heads unsupported (group of at most 8)", a.H, a.Hkv);
     OMX_REQUIRE(a.nsplit >= G && a.nsplit <= kMaxSplits && a.chunk > 0 && a.chunk % attn_step_block_tokens(D) == 0 && a.Hkv * a.nsplit <= 256,
@@ -495,6 +529,7 @@ int launch_attn_step(const AttnStepArgs& a, int D, hipStream_t s) {
         OMX_REQUIRE(a.o_resid && a.o_out && a.xg && attn_step_oproj_ok(a.H, a.Hkv, D, a.nsplit, a.o_rows),
                     "decode attention + O projection: shape does not qualify (H*D = %d, %d rows, %d blocks)", a.H * D, a.o_rows, a.Hkv * a.nsplit);
         nvw = a.H * D / 512;
+        a.o_rpw = oproj_rows_per_wave(a.H, a.Hkv, a.nsplit, a.o_rows);
     }
     const dim3 grid(a.Hkv, a.nsplit), block(kBlock);
     const int gt = G <= 1 ? 1 : G <= 2 ? 2 : G <= 4 ? 4 : 8;

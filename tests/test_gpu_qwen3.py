@@ -519,7 +519,8 @@ def test_time_step_kernels_runs_real_steps(omx):
     us = b.time_step_kernels(2)
     got += list(b.decode(6))
     assert set(us) == {"qkv", "attention", "o", "gate_up", "down", "lm_head"}
-    assert all(0 < v < 1000 for v in us.values()), us
+    # ("o" is 0 when the O projection rides in the attention launch -- the default wherever the shape qualifies)
+    assert all(0 < v < 1000 for k, v in us.items() if k != "o") and 0 <= us["o"] < 1000, us
     np.testing.assert_array_equal(np.array(got, np.uint32), want.astype(np.uint32))
     b.close()
 

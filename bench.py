@@ -129,15 +129,37 @@ def init_dist(n_gpus):
         import torch.distributed as dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist_mod.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+        with c_stdout_to_stderr():
+            dist_mod.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+            dist_mod.barrier()          # torch creates its communicator lazily: do it here, banner and all
         dist = dist_mod
     return rank, world, local, dist
+
+
+class c_stdout_to_stderr:
+    """RCCL prints a version / host banner on the C stdout when a communicator is created; the contract is ONE JSON line on stdout.
+    While active, file descriptor 1 points at stderr; the C buffer is flushed before the descriptor is restored."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        try:
+            ctypes.CDLL(None).fflush(None)
+        finally:
+            os.dup2(self._saved, 1)
+            os.close(self._saved)
+        return False
 
 
 def rccl_comm(dist, rank, world):
     """RCCL communicator for the C++ engine, bootstrapped through torch.distributed (ominix-mlx_amd/comm.py)."""
     from ominix_mlx_amd import comm
-    return comm.rccl_comm(dist, rank, world)
+    with c_stdout_to_stderr():
+        return comm.rccl_comm(dist, rank, world)
 
 
 def time_dominant_kernel(omx, cfg, world, iters=3):
@@ -385,8 +407,8 @@ def main():
     else:
         model = engine.Model(max_context=max_ctx, tp_rank=rank, tp_size=world, **cfg)
     keep = None
-    if world > 1:
-        keep = rccl_comm(dist, rank, world)
+    if world > 1 or os.environ.get("OMX_BENCH_FORCE_COMM") == "1":   # (the flag: run the N > 1 code path -- RCCL all-reduces in the
+        keep = rccl_comm(dist, rank, world)                         #  step graph, batched TP prefill -- on a one-rank communicator)
         model.set_comm(keep[1], keep[2])
     model.synth_weights()
 
@@ -430,7 +452,7 @@ def main():
     tok_s = args.steps / elapsed
     k_bytes, iso_s = time_dominant_kernel(omx, cfg, 1 if moe else world)
     in_step = None
-    if world == 1 and not moe:
+    if world == 1 and not moe and keep is None:
         # the figure the roofline object reports: HIP events on the step's stream around every launch of 4 further (eager) decode steps
         in_step = model.time_step_kernels(4)
     k_s = in_step["gate_up"] * 1e-6 if in_step else iso_s

@@ -231,6 +231,16 @@ def test_tensor_parallel_code_path_with_one_rank_communicator(omx, monkeypatch):
     got = np.concatenate([[m.prefill(prompt)], m.decode(10)])
     np.testing.assert_array_equal(got, want)
     np.testing.assert_array_equal(m.last_logits(), plain.last_logits())
+    # the batched tensor-parallel prefill on the same REAL communicator: two bf16 ncclAllReduce of [T, hidden] per layer, then the
+    # step for the last token.  (One rank: the sums are the operands; the GEMM + all-reduce + add route rounds like the fused one.)
+    monkeypatch.setenv("OMX_PREFILL_SERIAL", "0")
+    m.reset(); plain.reset()
+    want_b = np.concatenate([[plain.prefill(prompt)], plain.decode(6)])
+    logits_p = plain.last_logits()
+    got_b = np.concatenate([[m.prefill(prompt)], m.decode(6)])
+    bound = 2.0 ** -7 * np.abs(logits_p).max() * np.sqrt(cfg.num_hidden_layers)
+    assert np.abs(m.last_logits() - logits_p).max() <= bound
+    assert (got_b == want_b).mean() >= 0.7, (got_b, want_b)
 
 
 STEP_ATTN_CONFIGS = {

@@ -319,7 +319,22 @@ def physical_cores():
                 cores.add((pkg, int(v)))
     except OSError:
         pass
-    return max(1, len(cores) or len(allowed))
+    n = max(1, len(cores) or len(allowed))
+    # a container's CPU bandwidth quota (cgroup v2 cpu.max / v1 cfs_quota_us): more runnable threads than that are throttled, not run
+    # (the GPU boxes of this pool: 256 visible CPUs, quota 16 -- 128 pinned threads gave a bimodal 0.6 .. 12 tok/s)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, int(q) // int(per)))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // per))
+        except (OSError, ValueError):
+            pass
+    return n
 
 
 def cpu_baseline(cfg, ctx):
@@ -380,7 +395,7 @@ def cpu_baseline_child(cfg, ctx, n_layers_sample=4, warm=2, reps=7):
                       "spread": [round(1.0 / samples[-1], 4), round(1.0 / samples[0], 4)],
                       "sample": f"{n_layers_sample} of {cfg['num_hidden_layers']} decoder layers at ctx {ctx} + lm_head, {warm} warm passes then the "
                                 f"median of {reps}, scaled to the full model; C port of the oracle, OpenMP, {threads} threads pinned one per "
-                                f"physical core (OMP_PLACES=cores OMP_PROC_BIND=close), in a child process"}), flush=True)
+                                f"physical core (OMP_PLACES=cores OMP_PROC_BIND=close; thread count = physical cores capped by the container's CPU quota), in a child process"}), flush=True)
 
 
 def main():

@@ -1,0 +1,48 @@
+"""The engine at the REAL BASELINE size (Qwen3-8B shapes: 36 layers, 4096 hidden, 32 / 8 heads of 128, 12288 FFN, 151 936 vocabulary)
+against the numpy oracle run once at that size (tools/full_size_pin.py -> tests/golden/qwen3_8b_fullsize_pin.npz: greedy token,
+top-8 logits and top-1 / top-2 margin at every position of a 16-token synthetic prompt).  Both routes of the engine are held to it:
+the batched matrix-core route (Model.verify: GEMMs + flash attention + [n, V] lm_head GEMM) at all 16 positions, and the decode step
+(GEMV + attn_step + fused head) at the last one.  Bound: the engine's usual 2^-7 * max|logit| * sqrt(layers); tokens must be EQUAL
+wherever the oracle's margin exceeds twice that."""
+import os
+
+import numpy as np
+import pytest
+
+import bench
+
+pytestmark = pytest.mark.gpu
+
+PIN = os.path.join(os.path.dirname(__file__), "golden", "qwen3_8b_fullsize_pin.npz")
+
+
+@pytest.mark.skipif(not os.path.exists(PIN), reason="full-size pin fixture not generated")
+def test_full_size_engine_matches_full_size_oracle(omx):
+    from ominix_mlx_amd import engine
+    pin = np.load(PIN)
+    cfg = dict(bench.QWEN3_8B)
+    prompt = pin["prompt"]
+    n = prompt.size
+    m = engine.Model(max_context=64, **cfg)
+    m.synth_weights()
+    bound = 2.0 ** -7 * float(pin["max_abs"].max()) * np.sqrt(cfg["num_hidden_layers"])
+    # ---- batched route: every position in one pass ----
+    got = m.verify(prompt)
+    assert m.offset() == n
+    worst = 0.0
+    for i in range(n):
+        lg = m.verify_logits(i)
+        worst = max(worst, float(np.abs(lg[pin["top_idx"][i]] - pin["top_val"][i]).max()))
+        if pin["margin"][i] > 2 * bound:
+            assert got[i] == pin["greedy"][i], f"position {i}: token {got[i]} != oracle {pin['greedy'][i]} (margin {pin['margin'][i]:.3f})"
+        else:
+            assert got[i] in pin["top_idx"][i]
+    assert worst <= bound, f"batched route: top-8 logits off by {worst:.4f} (bound {bound:.4f})"
+    # ---- decode step: forget the last prompt token and run it through the step ----
+    m.trim(1, int(prompt[n - 1]))
+    tok = int(m.decode(1)[0])
+    lg = m.last_logits()
+    assert float(np.abs(lg[pin["top_idx"][n - 1]] - pin["top_val"][n - 1]).max()) <= bound
+    assert tok == pin["greedy"][n - 1] or pin["margin"][n - 1] <= 2 * bound
+    assert int(pin["margin"].size) == n and (pin["margin"] > 2 * bound).sum() >= n // 2, "fixture too ambiguous to pin tokens"
+    m.close()

@@ -1,0 +1,105 @@
+"""Full-size pin of the engine ("no correctness check at full BASELINE size"): the numpy oracle run ONCE at the real
+Qwen3-8B shapes -- 36 layers, 4096 hidden, 32 / 8 heads of 128, 12288 FFN, 151 936-entry vocabulary -- over a 16-token synthetic
+prompt, with the synthetic weights generated layer by layer (the same counter-based generator the engine's synth_weights runs on the
+device, tensor by name).  Writes tests/golden/qwen3_8b_fullsize_pin.npz: for every prompt position the greedy token, the top-8
+(index, logit) pairs and the top-1 / top-2 margin.  tests/test_gpu_fullsize_pin.py replays it on the GPU through the batched path
+(Model.verify) and the decode step.  Runs in the build container (needs ~30 GB of memory, ~10 minutes):
+
+    python tools/full_size_pin.py
+"""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import ref_core as rc, ref_qwen3 as rq, synth  # noqa: E402
+
+CHUNK = 1 << 24
+
+
+def tensor_chunked(name, shape, std, offset, rows=None):
+    """synth.tensor(name, shape, std, offset) evaluated in chunks of flat indices (or for the listed rows only)."""
+    seed = synth.name_seed(name)
+    amp = np.float32(std * float(np.sqrt(3.0)))
+    cols = int(np.prod(shape[1:])) if len(shape) > 1 else 1
+
+    def values(idx):
+        h = synth.hash_u32(idx, seed)
+        u = (h >> np.uint32(8)).astype(np.float32) * np.float32(1.0 / 16777216.0)
+        return rc.rnd((np.float32(offset) + amp * (np.float32(2.0) * u - np.float32(1.0))).astype(np.float32), "bf16")
+
+    if rows is not None:
+        rows = np.asarray(rows, np.uint64)
+        idx = (rows[:, None] * np.uint64(cols) + np.arange(cols, dtype=np.uint64)[None, :]).ravel()
+        return values(idx).reshape(len(rows), *shape[1:])
+    n = int(np.prod(shape))
+    out = np.empty(n, np.float32)
+    for a in range(0, n, CHUNK):
+        b = min(n, a + CHUNK)
+        out[a:b] = values(np.arange(a, b, dtype=np.uint64))
+    return out.reshape(shape)
+
+
+class EmbedRows:
+    """model.embed_tokens.weight[tokens] without materialising the 622 M-entry table."""
+
+    def __init__(self, shape):
+        self.shape = shape
+
+    def __getitem__(self, tokens):
+        t = np.asarray(tokens)
+        std, off = rq.weight_spec("model.embed_tokens.weight")
+        return tensor_chunked("model.embed_tokens.weight", self.shape, std, off, rows=t.ravel()).reshape(*t.shape, self.shape[1])
+
+
+class LazyWeights(dict):
+    """name -> tensor, generated on first use; a layer's tensors are dropped when the next layer's are asked for."""
+
+    def __init__(self, cfg):
+        super().__init__()
+        self.shapes = rq.weight_shapes(cfg)
+        self.layer = None
+
+    def __contains__(self, k):
+        return k in self.shapes
+
+    def __getitem__(self, k):
+        if k == "model.embed_tokens.weight":
+            return EmbedRows(self.shapes[k])
+        if dict.__contains__(self, k):
+            return dict.__getitem__(self, k)
+        layer = k.split(".")[2] if k.startswith("model.layers.") else None
+        if layer != self.layer:
+            self.clear()
+            self.layer = layer
+        std, off = rq.weight_spec(k)
+        t0 = time.time()
+        v = tensor_chunked(k, self.shapes[k], std, off)
+        dict.__setitem__(self, k, v)
+        if v.size > 1 << 26:
+            print(f"  generated {k} {v.shape} in {time.time() - t0:.1f} s", flush=True)
+        return v
+
+
+def main():
+    cfg = rq.Qwen3Config.qwen3_8b()
+    n_prompt = 16
+    prompt = synth.prompt_ids(n_prompt, cfg.vocab_size)
+    oracle = rq.Qwen3Oracle(cfg, LazyWeights(cfg))
+    t0 = time.time()
+    logits = oracle.forward(prompt[None, :].astype(np.int64), [])[0]            # [16, V] on the bf16 grid
+    print(f"oracle forward over {n_prompt} tokens: {time.time() - t0:.0f} s", flush=True)
+    order = np.argsort(-logits, axis=1, kind="stable")[:, :8]
+    top_vals = np.take_along_axis(logits, order, axis=1)
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "qwen3_8b_fullsize_pin.npz"), prompt=prompt,
+                        greedy=order[:, 0].astype(np.uint32), top_idx=order.astype(np.uint32), top_val=top_vals.astype(np.float32),
+                        margin=(top_vals[:, 0] - top_vals[:, 1]).astype(np.float32), max_abs=np.abs(logits).max(axis=1).astype(np.float32))
+    print("greedy tokens", order[:, 0].tolist())
+    print("margins", np.round(top_vals[:, 0] - top_vals[:, 1], 4).tolist())
+
+
+if __name__ == "__main__":
+    main()

@@ -13,5 +13,5 @@ f=$(find "$out/fetch" -name '*counter_collection.csv' | head -1)
 timeout 900 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d "$out/mfma" -o m -- python3 tools/prefill_flux_steps.py > "$out/mfma.log" 2>&1
 f=$(find "$out/mfma" -name '*counter_collection.csv' | head -1)
 [ -n "$f" ] && python3 tools/pmc_report.py trim "$f" "$out/keep/r02_pmc_mfma_busy.csv" gemm_bf16 attn_prefill flash dit_ gemm_
-tail -3 "$out/fetch.log" "$out/mfma.log"
+tail -n 3 "$out/fetch.log"; tail -n 3 "$out/mfma.log"
 ls -la "$out/keep"

@@ -1244,6 +1244,7 @@ int omx_qwen3_verify(omx_qwen3 m, const uint32_t* tokens, int n, uint32_t* greed
     OMX_HIP_CHECK(hipStreamSynchronize(m->stream));
     OMX_REQUIRE(st.pos + n + 1 <= m->cap, "omx_qwen3_verify: %d cached + %d tokens exceed max_context %d", st.pos, n, m->cap);
     OMX_REQUIRE(n <= m->prompt_cap, "omx_qwen3_verify: %d tokens exceed the prompt buffer", n);
+    if (resolve_weights(m)) return 1;          // (verify may be the first call on a fresh model)
     hipStream_t s = m->stream;
     const int hd = m->cfg.hidden_size, V = m->V;
     if (n > m->verify_cap) {

@@ -35,8 +35,8 @@ def test_full_size_engine_matches_full_size_oracle(omx):
         worst = max(worst, float(np.abs(lg[pin["top_idx"][i]] - pin["top_val"][i]).max()))
         if pin["margin"][i] > 2 * bound:
             assert got[i] == pin["greedy"][i], f"position {i}: token {got[i]} != oracle {pin['greedy'][i]} (margin {pin['margin'][i]:.3f})"
-        else:
-            assert got[i] in pin["top_idx"][i]
+        else:   # (random weights give flat logits: most margins are below the bound; the oracle's choice must still be a near-maximum here)
+            assert lg[pin["greedy"][i]] >= lg.max() - 2 * bound
     assert worst <= bound, f"batched route: top-8 logits off by {worst:.4f} (bound {bound:.4f})"
     # ---- decode step: forget the last prompt token and run it through the step ----
     m.trim(1, int(prompt[n - 1]))
@@ -44,5 +44,6 @@ def test_full_size_engine_matches_full_size_oracle(omx):
     lg = m.last_logits()
     assert float(np.abs(lg[pin["top_idx"][n - 1]] - pin["top_val"][n - 1]).max()) <= bound
     assert tok == pin["greedy"][n - 1] or pin["margin"][n - 1] <= 2 * bound
-    assert int(pin["margin"].size) == n and (pin["margin"] > 2 * bound).sum() >= n // 2, "fixture too ambiguous to pin tokens"
+    agree = int((got == pin["greedy"]).sum())
+    assert agree >= n // 2, f"only {agree} of {n} greedy tokens agree with the full-size oracle"
     m.close()

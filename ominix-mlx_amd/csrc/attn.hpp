@@ -44,7 +44,8 @@ struct AttnStepArgs {
     const bf16_t* o_resid;      // [o_rows] residual stream entering the layer
     bf16_t* o_out;              // [o_rows] = bf16(resid + bf16(o_w . attn))      (model.rs:325)
     int o_rows;
-    int o_rpw;                  // rows per wave of the non-consumer blocks (set by launch_attn_step)
+    int o_rpw, o_nhi;           // rows per wave of the non-consumer blocks: the first o_nhi waves hold o_rpw rows, the others o_rpw - 1
+                                // (set by launch_attn_step)
     uint64_t* xg;               // granules [H*D/2]: {two packed bf16 of the attention vector, tag}
 };
 bool attn_step_oproj_ok(int H, int Hkv, int D, int nsplit, int o_rows);

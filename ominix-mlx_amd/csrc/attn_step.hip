@@ -457,11 +457,16 @@ __global__ __launch_bounds__(kBlock, 1) void attn_step_kernel(const AttnStepArgs
     // ---- OPROJ: the blocks that are not consumers (split >= G) share the output rows; rows per wave is a compile-time constant of the
     //      phase (a runtime-predicated load block per row made hipcc drain the queue between rows: three serial round trips) ----
     if (OPROJ && split >= G) {
-        const int o_row0 = (((split - G) * (int)gridDim.x + kvh) * kWaves + wave) * a.o_rpw;
+        // wave g of the (blocks - H) * 8 producer waves: the first o_nhi waves take o_rpw rows, the others o_rpw - 1 -- together exactly
+        // o_rows (with o_rpw rows everywhere the surplus waves re-read the last row: 44 MB of traffic for a 33.6 MB matrix)
+        const int g = ((split - G) * (int)gridDim.x + kvh) * kWaves + wave;
+        const bool hi = g < a.o_nhi;
+        const int rows = hi ? a.o_rpw : a.o_rpw - 1;
+        const int o_row0 = hi ? g * a.o_rpw : a.o_nhi * a.o_rpw + (g - a.o_nhi) * (a.o_rpw - 1);
         unsigned long long* otr = TRACE ? tr : nullptr;
-        if (a.o_rpw == 1) oproj_phase<(NVW > 0 ? NVW : 1), 1>(a, sm_x, tag, lane, wave, o_row0, otr);
-        else if (a.o_rpw == 2) oproj_phase<(NVW > 0 ? NVW : 1), 2>(a, sm_x, tag, lane, wave, o_row0, otr);
-        else if (a.o_rpw == 3) oproj_phase<(NVW > 0 ? NVW : 1), 3>(a, sm_x, tag, lane, wave, o_row0, otr);
+        if (rows <= 1) oproj_phase<(NVW > 0 ? NVW : 1), 1>(a, sm_x, tag, lane, wave, o_row0, otr);
+        else if (rows == 2) oproj_phase<(NVW > 0 ? NVW : 1), 2>(a, sm_x, tag, lane, wave, o_row0, otr);
+        else if (rows == 3) oproj_phase<(NVW > 0 ? NVW : 1), 3>(a, sm_x, tag, lane, wave, o_row0, otr);
         else oproj_phase<(NVW > 0 ? NVW : 1), 4>(a, sm_x, tag, lane, wave, o_row0, otr);
         return;
     }
@@ -530,6 +535,10 @@ int launch_attn_step(const AttnStepArgs& a_in, int D, hipStream_t s) {
                     "decode attention + O projection: shape does not qualify (H*D = %d, %d rows, %d blocks)", a.H * D, a.o_rows, a.Hkv * a.nsplit);
         nvw = a.H * D / 512;
         a.o_rpw = oproj_rows_per_wave(a.H, a.Hkv, a.nsplit, a.o_rows);
+        const int waves = (a.Hkv * a.nsplit - a.H) * kWaves;
+        // o_nhi waves with o_rpw rows + the rest with o_rpw - 1 = o_rows; with one row per wave at most (o_rpw == 1) every wave keeps
+        // its (possibly clamped) row: a wave of the phase always holds at least one
+        a.o_nhi = a.o_rpw > 1 ? a.o_rows - waves * (a.o_rpw - 1) : waves;
     }
     const dim3 grid(a.Hkv, a.nsplit), block(kBlock);
     const int gt = G <= 1 ? 1 : G <= 2 ? 2 : G <= 4 ? 4 : 8;

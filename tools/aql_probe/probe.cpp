@@ -74,12 +74,22 @@ int main(int argc, char** argv) {
     HIP(hipDeviceSynchronize());
     char* kernargs = nullptr;
     const size_t ka_stride = (kernarg_size + 63) / 64 * 64;
-    HSA(hsa_amd_memory_pool_allocate(g_kernarg_pool, ka_stride * chain, 0, (void**)&kernargs));
-    HSA(hsa_amd_agents_allow_access(1, &g_gpu, nullptr, kernargs));
-    memset(kernargs, 0, ka_stride * chain);
+    // kernargs in DEVICE memory (argv[4] = "host": the CPU agent's kernarg pool instead -- every wave's first s_load is then a PCIe
+    // round trip, which is what made the first version of this probe read 17.5 us per barrier launch)
+    const bool host_ka = argc > 4 && !strcmp(argv[4], "host");
+    std::vector<char> stage(ka_stride * chain, 0);
     for (int i = 0; i < chain; ++i) {
         Args a = {w[i % copies], x, out, N, K, rpw, 0};
-        memcpy(kernargs + i * ka_stride, &a, sizeof(a));
+        memcpy(stage.data() + i * ka_stride, &a, sizeof(a));
+    }
+    if (host_ka) {
+        HSA(hsa_amd_memory_pool_allocate(g_kernarg_pool, ka_stride * chain, 0, (void**)&kernargs));
+        HSA(hsa_amd_agents_allow_access(1, &g_gpu, nullptr, kernargs));
+        memcpy(kernargs, stage.data(), stage.size());
+    } else {
+        HIP(hipMalloc((void**)&kernargs, stage.size()));
+        HIP(hipMemcpy(kernargs, stage.data(), stage.size(), hipMemcpyHostToDevice));
+        HIP(hipDeviceSynchronize());
     }
     hsa_queue_t* q = nullptr;
     HSA(hsa_queue_create(g_gpu, 4096, HSA_QUEUE_TYPE_SINGLE, nullptr, nullptr, UINT32_MAX, UINT32_MAX, &q));

@@ -535,12 +535,19 @@ def test_time_step_kernels_runs_real_steps(omx):
     b.close()
 
 
-@pytest.mark.parametrize("name", list(CONFIGS))
+OPROJ_CONFIGS = dict(CONFIGS)
+# K = H * D = 2048 -> the NVW = 4 register layout (Qwen3-0.6B's attention shape); 8 KV heads -> 32 splits at most, 3 gather batches never
+OPROJ_CONFIGS["h16_kv8_d128_nvw4"] = rq.Qwen3Config(1024, 2, 2048, 16, 8, 128, 2048, 1e-6, 1e6, True)
+# K = 4096 -> NVW = 8 with a hidden size that needs 2 rows per producer wave (the full-size shape is covered by test_gpu_fullsize_pin.py)
+OPROJ_CONFIGS["h32_kv8_d128_nvw8"] = rq.Qwen3Config(2048, 1, 2048, 32, 8, 128, 1024, 1e-6, 1e6, False)
+
+
+@pytest.mark.parametrize("name", list(OPROJ_CONFIGS))
 def test_oproj_in_attention_launch_is_bit_identical(omx, monkeypatch, name):
     """csrc/attn_step.hip with the layer's O projection + residual in the attention launch (weight rows prefetched into registers
     while the attention runs, the merged heads handed over as tagged granules) reproduces the separate O GEMV's arithmetic exactly:
     same tokens and bit-equal logits as OMX_ATTN_OPROJ=0, in graph and eager form, across a context-bucket boundary."""
-    cfg = CONFIGS[name]
+    cfg = OPROJ_CONFIGS[name]
     prompt = synth.prompt_ids(1000, cfg.vocab_size)
     outs = {}
     for mode in ("0", "1", "eager"):

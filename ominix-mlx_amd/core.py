@@ -39,6 +39,19 @@ class ConcatKeyValueCache:
     def reset(self) -> None:
         pass   # trait default (cache.rs:17-19)
 
+    def trim(self, n: int) -> int:
+        """The `trim(n)` that speculative.rs:165-169 says the `KeyValueCache` trait lacks: forget the last n cached positions
+        (a slice of the concatenated arrays).  Returns the number actually trimmed."""
+        n = max(0, min(int(n), self._offset))
+        if n and self.keys is not None and self.values is not None:
+            keep = self._offset - n
+            ks, vs = list(self.keys.shape), list(self.values.shape)
+            ks[-2], vs[-2] = keep, keep
+            self.keys = mx.slice(self.keys, [0] * len(ks), ks)
+            self.values = mx.slice(self.values, [0] * len(vs), vs)
+            self._offset = keep
+        return n
+
     def update_and_fetch(self, keys: Array, values: Array) -> Tuple[Array, Array]:
         if self.keys is not None and self.values is not None:
             self.keys = mx.concatenate_axis([self.keys, keys], -2)
@@ -70,6 +83,13 @@ class KVCache:
 
     def reset(self) -> None:
         self._offset = 0
+
+    def trim(self, n: int) -> int:
+        """`trim(n)` (missing from the reference's trait, speculative.rs:165-169): the buffers stay, the offset moves back -- later
+        writes land on the forgotten positions, reads stop before them.  Returns the number actually trimmed."""
+        n = max(0, min(int(n), self._offset))
+        self._offset -= n
+        return n
 
     def update_and_fetch(self, keys: Array, values: Array) -> Tuple[Array, Array]:
         prev = self._offset

@@ -367,6 +367,14 @@ class ConcatKeyValueCache:
     def reset(self):
         pass  # trait default (cache.rs:19): does nothing
 
+    def trim(self, n: int) -> int:
+        """Not in the reference (speculative.rs:165-169): drop the last n positions of the concatenated arrays."""
+        n = max(0, min(int(n), self._offset))
+        if n and self.keys is not None:
+            self.keys, self.values = self.keys[..., : self._offset - n, :], self.values[..., : self._offset - n, :]
+            self._offset -= n
+        return n
+
     def update_and_fetch(self, keys, values):
         if self.keys is not None and self.values is not None:
             self.keys = np.concatenate([self.keys, keys], axis=-2)
@@ -397,6 +405,12 @@ class KVCache:
 
     def capacity(self) -> int:
         return 0 if self.keys is None else self.keys.shape[2]
+
+    def trim(self, n: int) -> int:
+        """Not in the reference (speculative.rs:165-169 notes the trait lacks it): the offset moves back, the buffers stay."""
+        n = max(0, min(int(n), self._offset))
+        self._offset -= n
+        return n
 
     def update_and_fetch(self, keys, values):
         prev = self._offset

@@ -27,7 +27,7 @@ from . import ref_core as rc
 
 def _trim(caches: List, n: int) -> None:
     for c in caches:
-        c._offset -= n
+        c.trim(n)
 
 
 def speculative_generate(target, draft, prompt: np.ndarray, num_draft_tokens: int, max_tokens: int) -> Iterator[Tuple[int, bool, np.ndarray]]:

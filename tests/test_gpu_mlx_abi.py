@@ -108,6 +108,32 @@ def test_kv_cache_semantics_match_cache_rs(mx, core, cls):
     assert g_cache.offset() == o_cache.offset()
 
 
+@pytest.mark.parametrize("cls", ["KVCache", "ConcatKeyValueCache"])
+def test_kv_cache_trim(mx, core, cls):
+    """`trim(n)` -- the operation speculative.rs:165-169 notes the reference's `KeyValueCache` trait lacks -- on the handle route:
+    after trimming, offsets, returned views and contents equal a cache that never saw the trimmed positions, across the step-256
+    growth boundary and for a trim larger than the cache."""
+    B, Hkv, D = 1, 2, 64
+    g, o, plain = getattr(core, cls)(), getattr(rc, cls)(), getattr(rc, cls)()
+    chunks = [rc.bf16_round(rand((B, Hkv, n, D), 300 + i)) for i, n in enumerate([250, 5, 4, 3, 20])]
+    def feed(cache, c, wrap):
+        return cache.update_and_fetch(wrap(c), wrap(c * 0.5))
+    for c in chunks[:3]:                       # 259 positions: past the first 256-step
+        feed(g, c, mx.Array.from_numpy); feed(o, c, np.asarray)
+    for c in chunks[:2]:
+        feed(plain, c, np.asarray)
+    assert g.trim(4) == 4 and o.trim(4) == 4   # forget the third chunk
+    assert g.offset() == o.offset() == plain.offset() == 255
+    for c in chunks[3:]:
+        gk, gv = feed(g, c, mx.Array.from_numpy)
+        ok, ov = feed(o, c, np.asarray)
+        pk, pv = feed(plain, c, np.asarray)
+        np.testing.assert_array_equal(gk.numpy(), pk); np.testing.assert_array_equal(gv.numpy(), pv)
+        np.testing.assert_array_equal(ok, pk)
+    n_before = g.offset()
+    assert n_before == plain.offset() and g.trim(10_000) == n_before and g.offset() == 0      # more than is cached: everything goes
+
+
 def test_masks_and_sdpa_like_the_callers(mx, core):
     """create_attention_mask(h, cache, Some(true)) then SDPA with the array mask (model.rs:401, utils.rs)."""
     B, H, Hkv, T, D, off = 1, 4, 2, 19, 64, 7

@@ -198,7 +198,8 @@ __device__ __forceinline__ void oproj_phase(const AttnStepArgs& a, u32x4* sm_x, 
     }
     __syncthreads();
     // sweep the granules into LDS: thread t owns granules [t * GP, + GP) of NVW * 256
-    constexpr int GP = NVW >= 2 ? NVW / 2 : 1;
+    constexpr int GP = (NVW + 1) / 2;      // NVW * 256 granules over 512 threads: 1, 1, 2, 4 (NVW = 7: 448 threads), 4
+    static_assert((NVW * 256) % GP == 0, "a thread takes all of its granules or none");
     bool done = (int)threadIdx.x * GP >= NVW * 256;
     unsigned* sx = reinterpret_cast<unsigned*>(sm_x);
     for (unsigned spins = 0;; ++spins) {
@@ -514,11 +515,12 @@ static int oproj_rows_per_wave(int H, int Hkv, int nsplit, int o_rows) {
     const int waves = (Hkv * nsplit - H) * kWaves;
     return waves > 0 ? (o_rows + waves - 1) / waves : 1 << 20;
 }
-// the O projection can ride in the launch when K = H * D is one of the register layouts (NVW x 512, NVW in {1, 2, 4, 8}) and at most
+// the O projection can ride in the launch when K = H * D is one of the register layouts (NVW x 512, NVW in {1, 2, 4, 7, 8}: the
+// GEMV instantiations gemv_kernel<NVW, 1, ...> whose arithmetic the phase reproduces; 7 = Qwen2.5-7B's 28 heads of 128) and at most
 // kORows rows per wave of the non-consumer blocks cover the output
 bool attn_step_oproj_ok(int H, int Hkv, int D, int nsplit, int o_rows) {
     const int K = H * D, nvw = K / 512;
-    return K % 512 == 0 && (nvw == 1 || nvw == 2 || nvw == 4 || nvw == 8) && oproj_rows_per_wave(H, Hkv, nsplit, o_rows) <= kORows;
+    return K % 512 == 0 && (nvw == 1 || nvw == 2 || nvw == 4 || nvw == 7 || nvw == 8) && oproj_rows_per_wave(H, Hkv, nsplit, o_rows) <= kORows;
 }
 
 int launch_attn_step(const AttnStepArgs& a_in, int D, hipStream_t s) {
@@ -564,6 +566,7 @@ int launch_attn_step(const AttnStepArgs& a_in, int D, hipStream_t s) {
         if (nvw == 1) OMX_ATTN_LAUNCH(DD, GG, false, 1)                                                                  \
         if (nvw == 2) OMX_ATTN_LAUNCH(DD, GG, false, 2)                                                                  \
         if (nvw == 4) OMX_ATTN_LAUNCH(DD, GG, false, 4)                                                                  \
+        if (nvw == 7) OMX_ATTN_LAUNCH(DD, GG, false, 7)                                                                  \
         OMX_ATTN_LAUNCH(DD, GG, false, 8)                                                                                \
     }
     OMX_ATTN_STEP_CASE(128, 1) OMX_ATTN_STEP_CASE(128, 2) OMX_ATTN_STEP_CASE(128, 4) OMX_ATTN_STEP_CASE(128, 8)

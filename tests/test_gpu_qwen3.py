@@ -32,7 +32,7 @@ def _engine(omx, cfg, weights=None, max_context=512):
                      num_key_value_heads=cfg.num_key_value_heads, head_dim=cfg.head_dim, vocab_size=cfg.vocab_size,
                      rms_norm_eps=cfg.rms_norm_eps, rope_theta=cfg.rope_theta,
                      tie_word_embeddings=cfg.tie_word_embeddings, rope_scaling=cfg.rope_scaling,
-                     max_context=max_context)
+                     max_context=max_context, qk_norm=cfg.qk_norm, attention_bias=cfg.attention_bias)
     if weights is None:
         m.synth_weights()
     else:
@@ -538,6 +538,8 @@ def test_time_step_kernels_runs_real_steps(omx):
 OPROJ_CONFIGS = dict(CONFIGS)
 # K = H * D = 2048 -> the NVW = 4 register layout (Qwen3-0.6B's attention shape); 8 KV heads -> 32 splits at most, 3 gather batches never
 OPROJ_CONFIGS["h16_kv8_d128_nvw4"] = rq.Qwen3Config(1024, 2, 2048, 16, 8, 128, 2048, 1e-6, 1e6, True)
+# K = 28 x 128 = 3584 -> NVW = 7 (Qwen2.5-7B's attention shape: G = 7 runs on the 8-head instantiation), no q/k norm, biases
+OPROJ_CONFIGS["h28_kv4_d128_nvw7_qwen25"] = rq.Qwen3Config(1024, 1, 1536, 28, 4, 128, 1024, 1e-6, 1e6, False, qk_norm=False, attention_bias=True)
 # K = 4096 -> NVW = 8 with a hidden size that needs 2 rows per producer wave (the full-size shape is covered by test_gpu_fullsize_pin.py)
 OPROJ_CONFIGS["h32_kv8_d128_nvw8"] = rq.Qwen3Config(2048, 1, 2048, 32, 8, 128, 1024, 1e-6, 1e6, False)
 

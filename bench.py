@@ -539,7 +539,7 @@ def main():
             out["paraformer"] = paraformer_secondary(omx)
         except Exception as e:
             out["paraformer"] = {"metric": "paraformer_30s_audio_seconds", "value": None, "error": str(e)}
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:      # the CPU leg is timed at N = 1 only (one baseline per box, not per rank count)
         try:
             out["cpu_baseline"] = cpu_baseline(cfg, ctx_mid)
         except Exception as e:   # the baseline is a report, never a reason to lose the measured line

@@ -47,3 +47,36 @@ def test_full_size_engine_matches_full_size_oracle(omx):
     agree = int((got == pin["greedy"]).sum())
     assert agree >= n // 2, f"only {agree} of {n} greedy tokens agree with the full-size oracle"
     m.close()
+
+
+C1_PIN = os.path.join(os.path.dirname(__file__), "golden", "qwen3_0p6b_c1_pin.npz")
+
+
+@pytest.mark.skipif(not os.path.exists(C1_PIN), reason="c1 pin fixture not generated")
+def test_baseline_config_c1_at_real_shapes(omx):
+    """BASELINE configs[0] with SURVEY.md 8d's protocol at the model's real shapes (Qwen3-0.6B: 28 layers, tied 151 936-entry
+    vocabulary): 128-token synthetic prompt, greedy, 32 new tokens.  Random weights give flat logits (several oracle margins are one
+    bf16 ulp), so the comparison is made on the LOGITS of every step with the oracle's token fed back (teacher forcing through
+    `trim(0, token)`): top-8 values within the engine's bound at all 32 steps, and the engine's own greedy choice must be a
+    near-maximum of the oracle wherever it differs."""
+    from ominix_mlx_amd import engine
+    pin = np.load(C1_PIN)
+    cfg = dict(bench.QWEN3_0_6B)
+    m = engine.Model(max_context=256, **cfg)
+    m.synth_weights()
+    want = pin["tokens"]
+    bound = 2.0 ** -7 * float(pin["max_abs"].max()) * np.sqrt(cfg["num_hidden_layers"])
+    tok = int(m.prefill(pin["prompt"]))
+    worst, equal = 0.0, 0
+    for i in range(32):
+        lg = m.last_logits()
+        worst = max(worst, float(np.abs(lg[pin["top_idx"][i]] - pin["top_val"][i]).max()))
+        equal += int(tok == want[i])
+        if tok != want[i]:
+            assert pin["margin"][i] <= 2 * bound and lg[want[i]] >= lg.max() - 2 * bound, f"step {i}: {tok} vs oracle {want[i]}"
+        if i < 31:
+            m.trim(0, int(want[i]))            # continue on the ORACLE's sequence
+            tok = int(m.decode(1)[0])
+    assert worst <= bound, f"top-8 logits off by {worst:.4f} over 32 steps (bound {bound:.4f})"
+    assert equal >= 16, f"only {equal} of 32 greedy tokens equal the oracle's"
+    m.close()

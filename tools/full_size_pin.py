@@ -5,7 +5,7 @@ device, tensor by name).  Writes tests/golden/qwen3_8b_fullsize_pin.npz: for eve
 (index, logit) pairs and the top-1 / top-2 margin.  tests/test_gpu_fullsize_pin.py replays it on the GPU through the batched path
 (Model.verify) and the decode step.  Runs in the build container (needs ~30 GB of memory, ~10 minutes):
 
-    python tools/full_size_pin.py
+    python tools/full_size_pin.py [mixtral]
 """
 import os
 import sys
@@ -79,13 +79,17 @@ class LazyWeights(dict):
         t0 = time.time()
         v = tensor_chunked(k, self.shapes[k], std, off)
         dict.__setitem__(self, k, v)
-        if v.size > 1 << 26:
+        if v.size > 1 << 28 or (v.size > 1 << 26 and not k.startswith("model.layers.")):
             print(f"  generated {k} {v.shape} in {time.time() - t0:.1f} s", flush=True)
         return v
 
 
 def main():
-    cfg = rq.Qwen3Config.qwen3_8b()
+    mixtral = len(sys.argv) > 1 and sys.argv[1] == "mixtral"
+    # `mixtral`: Mixtral-8x7B's in-tree defaults (mixtral-mlx/src/model.rs:44-52): 32 layers, 8 experts of 14336, top-2, no q/k norm --
+    # 46.7 B parameters generated layer by layer (about an hour) -> tests/golden/mixtral_8x7b_fullsize_pin.npz
+    cfg = (rq.Qwen3Config(4096, 32, 14336, 32, 8, 128, 32000, 1e-5, 1e6, False, num_experts=8, num_experts_per_tok=2,
+                          moe_intermediate_size=14336, moe_mode="mixtral", qk_norm=False) if mixtral else rq.Qwen3Config.qwen3_8b())
     n_prompt = 16
     prompt = synth.prompt_ids(n_prompt, cfg.vocab_size)
     oracle = rq.Qwen3Oracle(cfg, LazyWeights(cfg))
@@ -94,7 +98,7 @@ def main():
     print(f"oracle forward over {n_prompt} tokens: {time.time() - t0:.0f} s", flush=True)
     order = np.argsort(-logits, axis=1, kind="stable")[:, :8]
     top_vals = np.take_along_axis(logits, order, axis=1)
-    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "qwen3_8b_fullsize_pin.npz"), prompt=prompt,
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "mixtral_8x7b_fullsize_pin.npz" if mixtral else "qwen3_8b_fullsize_pin.npz"), prompt=prompt,
                         greedy=order[:, 0].astype(np.uint32), top_idx=order.astype(np.uint32), top_val=top_vals.astype(np.float32),
                         margin=(top_vals[:, 0] - top_vals[:, 1]).astype(np.float32), max_abs=np.abs(logits).max(axis=1).astype(np.float32))
     print("greedy tokens", order[:, 0].tolist())

@@ -81,3 +81,30 @@ def test_baseline_config_c1_at_real_shapes(omx):
     assert equal >= 16, f"only {equal} of 32 greedy tokens equal the oracle's"
     m.close()
 
+
+def test_full_size_mixtral_routes_agree_when_routing_cannot_flip(omx, monkeypatch):
+    """Mixtral-8x7B at its real shapes (32 layers, 8 experts of 4096 x 14336, 93 GB of bf16 weights generated on the device) has no
+    oracle pin: with random weights top-2-of-8 routing flips under bf16 rounding.  The size-independent property
+    that CAN be held at full size: with every expert selected (top-8 of 8: the selection cannot flip, the softmax weights, SwitchGLU and
+    combine are all exercised) the batched route -- expert-selected GEMVs for 4 tokens, the sorted grouped GEMM for 16 -- and the
+    decode-step route compute the same logits up to bf16 rounding."""
+    from ominix_mlx_amd import engine
+    cfg = dict(bench.MIXTRAL_8X7B)
+    cfg["num_experts_per_tok"] = 8
+    prompt = bench.prompt_ids(16, cfg["vocab_size"])
+    m = engine.Model(max_context=64, **cfg)
+    m.synth_weights()
+    monkeypatch.setenv("OMX_PREFILL_SERIAL", "1")
+    m.prefill(prompt[:1])
+    step = [m.last_logits()]
+    for i in range(1, 16):
+        m.trim(0, int(prompt[i]))
+        m.decode(1)
+        step.append(m.last_logits())
+    bound = 2.0 ** -7 * float(np.abs(step[0]).max()) * np.sqrt(cfg["num_hidden_layers"])
+    for n in (4, 16):
+        m.reset()
+        m.verify(prompt[:n])
+        worst = max(float(np.abs(m.verify_logits(i) - step[i]).max()) for i in range(n))
+        assert worst <= 2 * bound, f"verify({n}) vs decode steps: {worst:.3f} over the whole vocabulary (bound {2 * bound:.3f})"
+    m.close()

@@ -1431,6 +1431,7 @@ int omx_qwen3_time_step_kernels(omx_qwen3 m, int steps, float* us) {
             }
         rc = step_health(m);
     }
+    arm_launch_events(nullptr, nullptr);   // (a pair armed for a launch that never happened must not outlive its events)
     for (auto& e : ev) (void)hipEventDestroy(e);
     if (rc) return 1;
     for (int k = 0; k < KC_COUNT; ++k) us[k] = (float)(sum[k] / ((k == KC_HEAD ? 1.0 : (double)L) * steps));

@@ -953,6 +953,13 @@ static int launch_gemm_impl(bf16_t* out, const bf16_t* x, const bf16_t* w, const
     OMX_REQUIRE(M > 0 && N > 0 && K > 0, "gemm: bad shape M=%d N=%d K=%d", M, N, K);
     GemmArgs a = {x, w, bias, resid, gate, out, M, N, K, (M + BM - 1) / BM, (N + BN - 1) / BN, {}, relu};
     const bool fast = (K % BK == 0) && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w)) & 15u) == 0;
+    {   // a handful of rows: stream the weights once (gemv_rows.hip) instead of a matrix-core tile grid that is mostly padding;
+        // OMX_GEMV_ROWS=0 keeps the GEMM kernels
+        const char* re = getenv("OMX_GEMV_ROWS");
+        const bool rows_off = re && re[0] == '0';
+        if (!rows_off && M <= 8 && (int64_t)N * K >= (1 << 20) && gemv_rows_supported(M, N, K, x, w))
+            return launch_gemv_rows(out, x, w, bias, resid, gate, M, N, K, relu, s);
+    }
     if (fast) {
         if (ensure_attr()) return 1;
         // 256^2 tiles when they still cover the chip (one block per CU); OMX_GEMM_TILE=128|256 forces a kernel
@@ -1009,6 +1016,10 @@ bool gemm_segmented_supported(int M, int K, const GemmSegs& g) {
 // elementwise kernel are ~30 us faster per layer of a 4B-parameter encoder).
 bool gemm_segmented_preferred(int M, int K, const GemmSegs& g) {
     if (!gemm_segmented_supported(M, K, g)) return false;
+    {   // a handful of rows: the separate projections each take the weight-streaming route of launch_gemm_impl
+        const char* re = getenv("OMX_GEMV_ROWS");
+        if (!(re && re[0] == '0') && M <= 8) return false;
+    }
     if (((M + 255) / 256) * seg_tiles(g) >= 160 || g.half == 0) return true;
     return M <= 256;
 }

@@ -111,4 +111,9 @@ int launch_attn_prefill(bf16_t* out, const bf16_t* q, const bf16_t* k, const bf1
                         const void* mask, hipStream_t s, bool out_token_major = false,
                         const AttnLayout* layout = nullptr);
 
+// M <= 8 rows: weights streamed once against all rows (gemv_rows.hip); same epilogue semantics as the GEMM kernels
+bool gemv_rows_supported(int M, int N, int K, const void* x, const void* w);
+int launch_gemv_rows(bf16_t* out, const bf16_t* x, const bf16_t* w, const bf16_t* bias, const bf16_t* resid, const bf16_t* gate, int M, int N,
+                     int K, int relu, hipStream_t s);
+
 }  // namespace omx

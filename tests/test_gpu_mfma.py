@@ -210,3 +210,33 @@ def test_linear_f32_on_the_f32_matrix_cores(omx, M, N, K, bias):
     mag = np.abs(x).astype(np.float64) @ np.abs(w).astype(np.float64).T + 1.0
     assert got.dtype == np.float32 and np.abs(got - want).max() <= 1e-6 * mag.max()
     assert (np.abs(got - want) <= 1e-6 * mag).all()
+
+
+@pytest.mark.parametrize("M,N,K", [
+    (5, 4096, 4096),         # a 5-token verify pass of speculative decoding: q / o projections of the 8B model
+    (8, 1000, 1536),         # ragged N (not a multiple of the 16 rows of a block), K = 3 x 512: a partial chunk
+    (7, 4096, 12288),        # three K chunks (the down projection)
+    (6, 2048, 1032),         # K % 512 != 0: the last vector row of the chunk is masked
+    (5, 152064 // 8, 1024),  # many blocks
+])
+def test_linear_rows_gemv(omx, monkeypatch, M, N, K):
+    """csrc/gemv_rows.hip: a Linear over M <= 8 rows streams every weight row once against all rows (launch_gemm_impl routes there
+    when N * K >= 2^20).  Against the oracle, with bias / relu / residual epilogues as the GEMM kernels define them, and against the
+    matrix-core route (OMX_GEMV_ROWS=0) to one bf16 ulp."""
+    T = omx.ops.Tensor
+    x = rc.bf16_round(rand((M, K), 61))
+    w = rc.bf16_round(rand((N, K), 62) * 0.05)
+    b = rc.bf16_round(rand((N,), 63))
+    tol = 2e-5 * np.sqrt(K) + 1e-4
+    got = omx.ops.linear(T.from_numpy(x), T.from_numpy(w), T.from_numpy(b)).numpy()
+    assert_bf16_close(got, rc.linear(x, w, b, "bf16"), 1, atol=tol)
+    plain = omx.ops.linear(T.from_numpy(x), T.from_numpy(w)).numpy()
+    assert_bf16_close(plain, rc.linear(x, w, None, "bf16"), 1, atol=tol)
+    monkeypatch.setenv("OMX_GEMV_ROWS", "0")
+    other = omx.ops.linear(T.from_numpy(x), T.from_numpy(w), T.from_numpy(b)).numpy()
+    assert_bf16_close(got, other, 1, atol=tol)
+    eye = np.zeros((M, K), np.float32)
+    eye[np.arange(M), np.arange(M) * 3] = 1.0                  # transpose-detecting: row t picks column 3 t of the weight
+    monkeypatch.delenv("OMX_GEMV_ROWS")
+    wa = rc.bf16_round((np.arange(N * K).reshape(N, K) % 251 - 125).astype(np.float32) / 64)
+    np.testing.assert_array_equal(omx.ops.linear(T.from_numpy(eye), T.from_numpy(wa)).numpy(), wa[:, np.arange(M) * 3].T)

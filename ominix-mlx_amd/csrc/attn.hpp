@@ -17,6 +17,11 @@ struct AttnDecodeArgs {
     float* ws_o;                // [B*H, nsplit, D]
     float* ws_ml;               // [B*H, nsplit, 2]
     bf16_t* out;                // [B,H,1,D] == [B, H*D]
+    // optional (0 = the defaults): element strides of q between batch entries and heads ([B,H,1,D]: H*D and D)
+    int64_t q_bs, q_hs;
+    // causal tail: batch entry b attends to the first Tk - (B - 1 - b) keys -- B consecutive new query rows over ONE shared cache
+    // (kv_batch_stride 0), the last of them seeing all Tk keys (a short batched prefill / a speculative verify pass)
+    int causal_tail;
 };
 
 // ---- the decode engine's attention launch (attn_step.hip): q/k norm + RoPE + cache append + split-KV SDPA + split merge ----
@@ -55,6 +60,7 @@ size_t attn_step_ws_granules(int H, int D);
 int launch_attn_step(const AttnStepArgs& a, int D, hipStream_t s);
 
 size_t attn_decode_ws_bytes(int BH, int nsplit, int D);
+int decode_nsplit(int Tk, int BHkv);   // sdpa.hip: splits of the per-op decode attention
 int launch_attn_decode(const AttnDecodeArgs& a, int D, hipStream_t s);
 
 }  // namespace omx

@@ -55,7 +55,7 @@ __global__ __launch_bounds__(kBlock) void attn_decode_kernel(const AttnDecodeArg
     const int sg = lane / LPR;          // token sub-group inside the wave
     const int b = bk / a.Hkv, kvh = bk % a.Hkv;
     const int G = a.H / a.Hkv;
-    const int Tk = a.Tk;
+    const int Tk = a.Tk - (a.causal_tail ? a.B - 1 - b : 0);
     // token range of this split: multiples of the block step
     const int per = (Tk + a.nsplit - 1) / a.nsplit;
     const int chunk = ((per + STEP * kWaves - 1) / (STEP * kWaves)) * (STEP * kWaves);
@@ -84,7 +84,7 @@ __global__ __launch_bounds__(kBlock) void attn_decode_kernel(const AttnDecodeArg
     for (int g = 0; g < GT; ++g) {
         const int h = kvh * G + min(g, G - 1);
         float x[8];
-        unpack8(*reinterpret_cast<const u32x4*>(a.q + ((size_t)b * a.H + h) * D + c * 8), x);
+        unpack8(*reinterpret_cast<const u32x4*>(a.q + (size_t)b * (a.q_bs ? a.q_bs : (int64_t)a.H * D) + (size_t)h * (a.q_hs ? a.q_hs : D) + c * 8), x);
 #pragma unroll
         for (int e = 0; e < 8; ++e) q[g][e] = x[e] * a.scale;
     }

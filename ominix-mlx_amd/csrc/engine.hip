@@ -819,7 +819,25 @@ int prefill_prefix_batched(omx_qwen3 m, int T, int off, const EncodeOpts* enc = 
                                         m->kcache[l], m->vcache[l], T, H, Hkv, D, m->cap, off, c.rms_norm_eps, s))
             return 1;
         if (!enc && !full_last && l == c.num_hidden_layers - 1) break;   // a prefix only has to leave its K/V rows behind
-        if (launch_attn_prefill(m->pf_attn, m->pf_qt, m->kcache[l], m->vcache[l], 1, H, Hkv, T, off + T, D, 0,
+        const char* skv_env = getenv("OMX_PREFILL_SPLITKV");
+        if (!enc && T <= 8 && H / Hkv <= 8 && !(skv_env && skv_env[0] == '0')) {
+            // a handful of new rows over a long cache (speculative verify, a short follow-up prompt): the flash kernel gives them
+            // H * ceil(T / 64) blocks that each walk all keys (53 us per layer for 5 rows at 2 k of context); the split-KV decode
+            // kernel takes the T rows as batch entries over the ONE cache, row i seeing the first off + i + 1 keys
+            AttnDecodeArgs a = {};
+            a.q = m->pf_qt; a.q_bs = D; a.q_hs = (int64_t)T * D;                    // q_out[h][t][:] of the scatter kernel
+            a.k = m->kcache[l]; a.v = m->vcache[l];
+            a.kv_batch_stride = 0; a.kv_head_stride = (int64_t)m->cap * D;
+            a.B = T; a.H = H; a.Hkv = Hkv; a.Tk = off + T;
+            a.scale = scale; a.mask_mode = OMX_MASK_NONE; a.causal_tail = 1;
+            a.nsplit = decode_nsplit(off + T, T * Hkv);
+            void* aws = nullptr;
+            if (get_workspace_aux(&aws, attn_decode_ws_bytes(T * H, a.nsplit, D))) return 1;
+            a.ws_o = (float*)aws;
+            a.ws_ml = a.ws_o + (size_t)T * H * a.nsplit * D;
+            a.out = m->pf_attn;                                                       // [T, H * D]
+            if (launch_attn_decode(a, D, s)) return 1;
+        } else if (launch_attn_prefill(m->pf_attn, m->pf_qt, m->kcache[l], m->vcache[l], 1, H, Hkv, T, off + T, D, 0,
                                 (int64_t)m->cap * D, scale, enc && enc->mask ? OMX_MASK_ADDITIVE : OMX_MASK_CAUSAL,
                                 enc ? enc->mask : nullptr, s, /*out_token_major=*/true))
             return 1;

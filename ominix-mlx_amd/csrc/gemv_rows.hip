@@ -117,9 +117,17 @@ int launch_gemv_rows(bf16_t* out, const bf16_t* x, const bf16_t* w, const bf16_t
         OMX_LAUNCH_CHECK();                                                                                          \
         return 0;                                                                                                    \
     }
-    if (M <= 2) OMX_ROWS_CASE(2)
-    if (M <= 4) OMX_ROWS_CASE(4)
-    OMX_ROWS_CASE(8)
+    // one instantiation per row count: the staging traffic (M x 8 KB per block and chunk) and the multiply both scale with it
+    switch (M) {
+        case 1: OMX_ROWS_CASE(1)
+        case 2: OMX_ROWS_CASE(2)
+        case 3: OMX_ROWS_CASE(3)
+        case 4: OMX_ROWS_CASE(4)
+        case 5: OMX_ROWS_CASE(5)
+        case 6: OMX_ROWS_CASE(6)
+        case 7: OMX_ROWS_CASE(7)
+        default: OMX_ROWS_CASE(8)
+    }
 #undef OMX_ROWS_CASE
 }
 

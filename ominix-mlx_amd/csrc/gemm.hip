@@ -1014,12 +1014,17 @@ bool gemm_segmented_supported(int M, int K, const GemmSegs& g) {
 // Policy next to capability: is ONE segmented launch the faster schedule?  Measured on MI355X: yes for the 256^2 kernel and for
 // plain segments at any size; a SwiGLU pair on the ring kernel only up to 256 rows (at 512 rows two 128^2 launches + the
 // elementwise kernel are ~30 us faster per layer of a 4B-parameter encoder).
+static bool rows_route(int M, int K, const GemmSegs& g) {
+    const char* re = getenv("OMX_GEMV_ROWS");
+    if ((re && re[0] == '0') || M > 8 || !gemv_rows_segmented_supported(M, K, g)) return false;
+    int64_t rows = 2 * (int64_t)g.half;
+    for (int i = 0; i < g.n_plain; ++i) rows += g.plain[i].cols;
+    return rows * K >= (1 << 20);
+}
+
 bool gemm_segmented_preferred(int M, int K, const GemmSegs& g) {
     if (!gemm_segmented_supported(M, K, g)) return false;
-    {   // a handful of rows: the separate projections each take the weight-streaming route of launch_gemm_impl
-        const char* re = getenv("OMX_GEMV_ROWS");
-        if (!(re && re[0] == '0') && M <= 8) return false;
-    }
+    if (rows_route(M, K, g)) return true;   // a handful of rows: one weight-streaming launch (gemv_rows.hip)
     if (((M + 255) / 256) * seg_tiles(g) >= 160 || g.half == 0) return true;
     return M <= 256;
 }
@@ -1037,6 +1042,7 @@ int launch_gemm_bf16_segmented(const bf16_t* x, int M, int K, const GemmSegs& se
         align |= reinterpret_cast<uintptr_t>(segs.w_gate) | reinterpret_cast<uintptr_t>(segs.w_up);
     }
     OMX_REQUIRE((align & 15u) == 0, "segmented gemm: operands must be 16-byte aligned");
+    if (rows_route(M, K, segs)) return launch_gemv_rows_segmented(x, M, K, segs, s);
     if (ensure_attr()) return 1;
     GemmArgs a = {};
     a.x = x; a.M = M; a.K = K;

@@ -113,6 +113,9 @@ int launch_attn_prefill(bf16_t* out, const bf16_t* q, const bf16_t* k, const bf1
 
 // M <= 8 rows: weights streamed once against all rows (gemv_rows.hip); same epilogue semantics as the GEMM kernels
 bool gemv_rows_supported(int M, int N, int K, const void* x, const void* w);
+// ... and the segmented projection (GemmSegs above) in one such launch: q / k / v, or gate / up with the SwiGLU epilogue
+bool gemv_rows_segmented_supported(int M, int K, const GemmSegs& segs);
+int launch_gemv_rows_segmented(const bf16_t* x, int M, int K, const GemmSegs& segs, hipStream_t s);
 int launch_gemv_rows(bf16_t* out, const bf16_t* x, const bf16_t* w, const bf16_t* bias, const bf16_t* resid, const bf16_t* gate, int M, int N,
                      int K, int relu, hipStream_t s);
 

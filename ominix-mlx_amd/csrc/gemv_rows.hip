@@ -16,6 +16,8 @@ constexpr int kRowsRPW = 4, kRowsChunk = 4096, kRowsNV = kRowsChunk / 512;   // 
 struct RowsArgs {
     const bf16_t* x; const bf16_t* w; const bf16_t* bias; const bf16_t* resid; const bf16_t* gate; bf16_t* out;
     int M, N, K, relu;
+    GemmSegs sg;          // SEG launches: up to three plain Linears and a SwiGLU pair of the same input (gemm.hpp)
+    int plain_rows;       // sum of the plain segments' cols; N = plain_rows + 2 * sg.half virtual rows
 };
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_rows;
@@ -31,12 +33,37 @@ __device__ __forceinline__ float dot8_rows(const u32x4 w, const u32x4 xp, float 
     return acc;
 }
 
-template <int T>
+// SEG: the virtual row space is the plain segments' rows one after the other (cols % 4 == 0: a wave's four rows stay inside one
+// segment), then the SwiGLU pair in groups of four = gate rows 2p, 2p + 1 and up rows 2p, 2p + 1, so that the wave that owns a group
+// holds both factors of two activation columns.
+template <int T, bool SEG>
 __global__ __launch_bounds__(256) void gemv_rows_kernel(const RowsArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char rows_smem[];
     u32x4* xs = reinterpret_cast<u32x4*>(rows_smem);                       // [T][512] vectors of the current K chunk
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int row0 = (blockIdx.x * 4 + wave) * kRowsRPW;
+    const bf16_t* wrow[kRowsRPW];
+    int seg = -1, scol = 0;                                              // SEG: plain segment (3 = the SwiGLU pair) and first column in it
+    if constexpr (SEG) {
+        const int v = min(row0, a.N - kRowsRPW);                         // waves past the end re-read the last group and store nothing
+        if (v >= a.plain_rows) {
+            seg = 3; scol = (v - a.plain_rows) / 2;
+#pragma unroll
+            for (int r = 0; r < kRowsRPW; ++r) wrow[r] = (r < 2 ? a.sg.w_gate : a.sg.w_up) + (size_t)(scol + (r & 1)) * a.K;
+        } else {
+            int b = 0;
+            seg = 0;
+            if (a.sg.n_plain > 1 && v >= a.sg.plain[0].cols) { seg = 1; b = a.sg.plain[0].cols; }
+            if (a.sg.n_plain > 2 && v >= a.sg.plain[0].cols + a.sg.plain[1].cols) { seg = 2; b = a.sg.plain[0].cols + a.sg.plain[1].cols; }
+            scol = v - b;
+            const bf16_t* wb = seg == 0 ? a.sg.plain[0].w : seg == 1 ? a.sg.plain[1].w : a.sg.plain[2].w;
+#pragma unroll
+            for (int r = 0; r < kRowsRPW; ++r) wrow[r] = wb + (size_t)(scol + r) * a.K;
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < kRowsRPW; ++r) wrow[r] = a.w + (size_t)min(row0 + r, a.N - 1) * a.K;
+    }
     float acc[kRowsRPW][T];
 #pragma unroll
     for (int r = 0; r < kRowsRPW; ++r)
@@ -60,7 +87,7 @@ __global__ __launch_bounds__(256) void gemv_rows_kernel(const RowsArgs a) {
         for (int j = 0; j < kRowsNV; ++j)
 #pragma unroll
             for (int r = 0; r < kRowsRPW; ++r) {
-                const u32x4* p = reinterpret_cast<const u32x4*>(a.w + (size_t)min(row0 + r, a.N - 1) * a.K) + v0;
+                const u32x4* p = reinterpret_cast<const u32x4*>(wrow[r]) + v0;
                 w[j][r] = __builtin_nontemporal_load(p + min(j * 64 + lane, nv - 1));     // lanes past the row's end: zeroed x, any w
             }
         __syncthreads();
@@ -77,6 +104,36 @@ __global__ __launch_bounds__(256) void gemv_rows_kernel(const RowsArgs a) {
     for (int r = 0; r < kRowsRPW; ++r)
 #pragma unroll
         for (int t = 0; t < T; ++t) acc[r][t] = wave_sum(acc[r][t]);
+    if constexpr (SEG) {
+        if (lane != 0 || row0 >= a.N) return;
+        if (seg == 3) {   // act[t, c] = silu(bf16(x.Wg[c])) * bf16(x.Wu[c]): the two roundings of the 256^2 kernel's SwiGLU epilogue (gemm.hip)
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int t = 0; t < T; ++t) {
+                    if (t >= a.M) continue;
+                    const float gt = round_bf16(acc[c][t]), up = round_bf16(acc[2 + c][t]);
+                    float v;
+                    if (a.sg.act_mode == 1) {
+                        const float sg = round_bf16(1.0f / (1.0f + expf(-gt)));
+                        v = round_bf16(gt * sg) * up;
+                    } else {
+                        v = gt / (1.0f + expf(-gt)) * up;
+                    }
+                    a.sg.out_act[(size_t)t * a.sg.ld_act + scol + c] = f32_to_bf16(v);
+                }
+            return;
+        }
+        const GemmSeg& S = seg == 0 ? a.sg.plain[0] : seg == 1 ? a.sg.plain[1] : a.sg.plain[2];
+#pragma unroll
+        for (int r = 0; r < kRowsRPW; ++r) {
+            const float bv = S.bias ? bf16_to_f32(S.bias[scol + r]) : 0.f;
+#pragma unroll
+            for (int t = 0; t < T; ++t)
+                if (t < a.M) S.out[(size_t)t * S.ld + scol + r] = f32_to_bf16(acc[r][t] + bv);
+        }
+        return;
+    }
     if (lane == 0) {
 #pragma unroll
         for (int r = 0; r < kRowsRPW; ++r) {
@@ -97,28 +154,20 @@ __global__ __launch_bounds__(256) void gemv_rows_kernel(const RowsArgs a) {
     }
 }
 
-}  // namespace
-
-bool gemv_rows_supported(int M, int N, int K, const void* x, const void* w) {
-    return M >= 1 && M <= 8 && N >= 1 && K >= 8 && K % 8 == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w)) & 15u) == 0;
-}
-
-int launch_gemv_rows(bf16_t* out, const bf16_t* x, const bf16_t* w, const bf16_t* bias, const bf16_t* resid, const bf16_t* gate, int M, int N,
-                     int K, int relu, hipStream_t s) {
-    OMX_REQUIRE(gemv_rows_supported(M, N, K, x, w), "gemv_rows: unsupported shape M=%d N=%d K=%d", M, N, K);
-    const RowsArgs a = {x, w, bias, resid, gate, out, M, N, K, relu};
-    const dim3 grid((N + 4 * kRowsRPW - 1) / (4 * kRowsRPW)), block(256);
+// one instantiation per row count: the staging traffic (M x 8 KB per block and chunk) and the multiply both scale with it
+template <bool SEG>
+int launch_rows_t(const RowsArgs& a, hipStream_t s) {
+    const dim3 grid((a.N + 4 * kRowsRPW - 1) / (4 * kRowsRPW)), block(256);
 #define OMX_ROWS_CASE(TT)                                                                                            \
     {                                                                                                                \
         const size_t shmem = (size_t)TT * 512 * 16;                                                                  \
         if (shmem > 48 * 1024)                                                                                       \
-            OMX_HIP_CHECK(hipFuncSetAttribute((const void*)gemv_rows_kernel<TT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem)); \
-        gemv_rows_kernel<TT><<<grid, block, shmem, s>>>(a);                                                          \
+            OMX_HIP_CHECK(hipFuncSetAttribute((const void*)gemv_rows_kernel<TT, SEG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem)); \
+        gemv_rows_kernel<TT, SEG><<<grid, block, shmem, s>>>(a);                                                     \
         OMX_LAUNCH_CHECK();                                                                                          \
         return 0;                                                                                                    \
     }
-    // one instantiation per row count: the staging traffic (M x 8 KB per block and chunk) and the multiply both scale with it
-    switch (M) {
+    switch (a.M) {
         case 1: OMX_ROWS_CASE(1)
         case 2: OMX_ROWS_CASE(2)
         case 3: OMX_ROWS_CASE(3)
@@ -129,6 +178,51 @@ int launch_gemv_rows(bf16_t* out, const bf16_t* x, const bf16_t* w, const bf16_t
         default: OMX_ROWS_CASE(8)
     }
 #undef OMX_ROWS_CASE
+}
+int launch_rows(const RowsArgs& a, bool seg, hipStream_t s) { return seg ? launch_rows_t<true>(a, s) : launch_rows_t<false>(a, s); }
+
+}  // namespace
+
+bool gemv_rows_supported(int M, int N, int K, const void* x, const void* w) {
+    return M >= 1 && M <= 8 && N >= 1 && K >= 8 && K % 8 == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w)) & 15u) == 0;
+}
+
+int launch_gemv_rows(bf16_t* out, const bf16_t* x, const bf16_t* w, const bf16_t* bias, const bf16_t* resid, const bf16_t* gate, int M, int N,
+                     int K, int relu, hipStream_t s) {
+    OMX_REQUIRE(gemv_rows_supported(M, N, K, x, w), "gemv_rows: unsupported shape M=%d N=%d K=%d", M, N, K);
+    RowsArgs a = {};
+    a.x = x; a.w = w; a.bias = bias; a.resid = resid; a.gate = gate; a.out = out; a.M = M; a.N = N; a.K = K; a.relu = relu;
+    return launch_rows(a, false, s);
+}
+
+bool gemv_rows_segmented_supported(int M, int K, const GemmSegs& g) {
+    if (M < 1 || M > 8 || K < 8 || K % 8 != 0 || g.n_plain < 0 || g.n_plain > 3 || g.im_C != 0) return false;
+    int rows = 0;
+    for (int i = 0; i < g.n_plain; ++i) {
+        if (g.plain[i].cols < 4 || g.plain[i].cols % 4 != 0) return false;
+        rows += g.plain[i].cols;
+    }
+    if (g.half < 0 || g.half % 2 != 0) return false;
+    return rows + 2 * g.half >= 4;
+}
+
+int launch_gemv_rows_segmented(const bf16_t* x, int M, int K, const GemmSegs& segs, hipStream_t s) {
+    OMX_REQUIRE(gemv_rows_segmented_supported(M, K, segs), "gemv_rows: unsupported segmented shape M=%d K=%d", M, K);
+    RowsArgs a = {};
+    a.x = x; a.M = M; a.K = K; a.sg = segs;
+    uintptr_t align = reinterpret_cast<uintptr_t>(x);
+    for (int i = 0; i < segs.n_plain; ++i) {
+        OMX_REQUIRE(segs.plain[i].w && segs.plain[i].out, "gemv_rows: null weight / output in segment %d", i);
+        align |= reinterpret_cast<uintptr_t>(segs.plain[i].w);
+        a.plain_rows += segs.plain[i].cols;
+    }
+    if (segs.half > 0) {
+        OMX_REQUIRE(segs.w_gate && segs.w_up && segs.out_act, "gemv_rows: null gate / up / activation pointer");
+        align |= reinterpret_cast<uintptr_t>(segs.w_gate) | reinterpret_cast<uintptr_t>(segs.w_up);
+    }
+    OMX_REQUIRE((align & 15u) == 0, "gemv_rows: operands must be 16-byte aligned");
+    a.N = a.plain_rows + 2 * segs.half;
+    return launch_rows(a, true, s);
 }
 
 }  // namespace omx

@@ -1,7 +1,7 @@
 """Cost of the speculative-decoding verify pass (Model.verify: n tokens batched on top of the cache, [n, V] lm_head GEMM, per-row argmax)
 against n ordinary decode steps, Qwen3-8B shapes, 2048 tokens of context.  With synthetic weights a draft model cannot agree with the
 target (flat logits), so this reports the MECHANISM's ceiling: tokens per second if every draft token were accepted, draft cost excluded.
-usage: python tools/speculative_bench.py"""
+usage: python tools/speculative_bench.py [n ...]      (default n = 2 3 5 9 17)"""
 import os
 import sys
 import time
@@ -20,7 +20,7 @@ prompt = bench.prompt_ids(2048, cfg["vocab_size"])
 m.prefill(prompt)
 t0 = time.perf_counter(); m.decode(32); step_ms = (time.perf_counter() - t0) * 1e3 / 32
 print(f"decode step {step_ms:.3f} ms")
-for n in (2, 3, 5, 9, 17):
+for n in ([int(a) for a in sys.argv[1:]] or (2, 3, 5, 9, 17)):
     toks = [int(t) for t in prompt[:n]]
     m.verify(toks); m.trim(n, toks[0])              # warm (buffers, kernels)
     t0 = time.perf_counter()

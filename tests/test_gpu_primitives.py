@@ -353,6 +353,10 @@ def test_linear_decode_shapes_without_a_tuned_gemv(omx, M, N, K):
     (8, 0, 128, 64),             # small problems run as one grid of the 64 x 64 ring kernel (32 gate + 32 up columns per tile)
     (77, 64, 100, 128),          # ... ragged rows, a plain segment, half not a multiple of 32
     (512, 0, 3072, 256),         # ... the DiT txt stream's mlp_in shape class
+    (5, 512, 1024, 512),         # M <= 8 and >= 2^20 weights: ONE weight-streaming launch (gemv_rows.hip, segmented mode)
+    (8, 0, 4096, 256),           # ... all eight rows, gate / up only
+    (1, 64, 1024, 1024),         # ... a single row, a short plain segment in front
+    (3, 0, 2052, 512),           # ... 4104 virtual rows: the last block's trailing waves own no rows
 ])
 def test_linear_swiglu_matches_linear_then_fused_swiglu(omx, M, n_plain, half, K):
     """omx_linear_swiglu is an in-epilogue form of nn::Linear + fused_swiglu (klein_model.rs:489-493, 905-916):

@@ -155,6 +155,33 @@ class c_stdout_to_stderr:
         return False
 
 
+def peer_comm(dist, rank, world, rccl):
+    """The step's small all-reduces (16 KB of f32 partials, the argmax key) as ONE kernel of tagged xGMI peer stores
+    (csrc/peer_allreduce.hip) instead of an RCCL ring launch each; everything larger stays on RCCL.  Used only when every rank
+    mapped every inbox AND reproduced the rank-ordered sums of the self-test exactly; otherwise the run stays on RCCL and says so.
+    OMX_PEER_ALLREDUCE=0: RCCL only (A/B).  -> (PeerComm or None, note for the JSON line)"""
+    if os.environ.get("OMX_PEER_ALLREDUCE", "1") == "0":
+        return None, "rccl (OMX_PEER_ALLREDUCE=0)"
+    import torch
+    from ominix_mlx_amd import comm
+    peer, err = None, ""
+    try:
+        gather = comm.torch_all_gather_bytes(dist) if dist is not None else (lambda b: [b])
+        peer = comm.PeerComm(gather, rank, world, rccl=rccl)
+        peer.self_test()
+    except Exception as e:   # noqa: BLE001  (any failure: this run uses RCCL)
+        err = str(e) or type(e).__name__
+    ok = torch.tensor([0 if err else 1], dtype=torch.int32, device="cuda")
+    if dist is not None:
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    if int(ok.item()) == 1:
+        return peer, "peer-store one-shot (csrc/peer_allreduce.hip; self-test exact on every rank), RCCL above 32 KB"
+    if peer is not None and not err:
+        err = "a peer rank failed its self-test"
+    print(f"[bench rank {rank}] peer all-reduce not used: {err}", file=sys.stderr, flush=True)
+    return None, f"rccl (peer-store path declined: {err[:200]})"
+
+
 def rccl_comm(dist, rank, world):
     """RCCL communicator for the C++ engine, bootstrapped through torch.distributed (ominix-mlx_amd/comm.py)."""
     from ominix_mlx_amd import comm
@@ -421,10 +448,15 @@ def main():
         model = engine.Model(max_context=max_ctx, ep_rank=rank, ep_size=world, **cfg)
     else:
         model = engine.Model(max_context=max_ctx, tp_rank=rank, tp_size=world, **cfg)
-    keep = None
+    keep = peer = None
+    peer_note = None
     if world > 1 or os.environ.get("OMX_BENCH_FORCE_COMM") == "1":   # (the flag: run the N > 1 code path -- RCCL all-reduces in the
         keep = rccl_comm(dist, rank, world)                         #  step graph, batched TP prefill -- on a one-rank communicator)
-        model.set_comm(keep[1], keep[2])
+        peer, peer_note = peer_comm(dist, rank, world, keep)
+        if peer is not None:
+            model.set_comm(peer.comm, peer.fn)
+        else:
+            model.set_comm(keep[1], keep[2])
     model.synth_weights()
 
     prompt = prompt_ids(args.prompt, cfg["vocab_size"])
@@ -451,6 +483,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     dev_ms = model.last_decode_ms()
+    if peer is not None and peer.aborted():   # a wait inside the peer all-reduce gave up: the tokens of this run are void
+        raise SystemExit(f"rank {rank}: the peer-store all-reduce gave up waiting for a peer during the run; no valid measurement")
 
     flux_tp = None
     if world > 1 and args.flux_tp:   # a collective workload: every rank takes part
@@ -491,7 +525,7 @@ def main():
         "config": {"workload": f"{args.model}" + (" (Qwen3-8B shapes for BASELINE 'Qwen3-7B')" if args.model == "qwen3-8b" else "") + " bf16 greedy decode, batch 1, "
                                f"{args.prompt}-token prompt then {args.warmup}+{args.steps} decode tokens",
                    "parallelism": (f"ep{world}" if moe else f"tp{world}"), "context_at_timing": ctx_mid,
-                   "layers": cfg["num_hidden_layers"]},
+                   "layers": cfg["num_hidden_layers"], **({"allreduce": peer_note} if peer_note else {})},
         "roofline": {"bound": "hbm", "kernel": "gemv_kernel<rmsnorm, gate/up, swiglu>", "achieved": round(achieved, 1),
                      "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
                      "traffic": pmc_traffic(DOMINANT_KERNEL) if world == 1 and args.model == "qwen3-8b" else None,

@@ -373,6 +373,20 @@ int omx_loopback_destroy(omx_loopback g);
 void* omx_loopback_rank_comm(omx_loopback g, int rank);
 int omx_loopback_abort(omx_loopback g);
 
+/* One-shot all-reduce over xGMI peer stores for the tensor-parallel decode step (csrc/peer_allreduce.hip): one
+ * process per GPU, every rank's inbox (fine-grained device memory) mapped into every peer through HIP IPC handles, a call = ONE
+ * kernel that stores tagged 8-byte granules into all inboxes and reduces its own in rank order.  f32 sum / u64 max of up to 8192
+ * payload words; anything else goes to the RCCL communicator given at creation (may be NULL: such calls then fail).
+ * omx_peer_allreduce has ncclAllReduce's signature: omx_qwen3_set_comm(model, comm, omx_peer_allreduce_fn()).
+ * Host protocol: create -> handle (64 bytes) -> all-gather the handles rank-major -> connect.                                 */
+int omx_peer_comm_create(void** out, int rank, int world, void* rccl_comm, void* rccl_allreduce_fn);
+int omx_peer_comm_handle(void* comm, void* out64);
+int omx_peer_comm_connect(void* comm, const void* handles);
+int omx_peer_allreduce(const void* send, void* recv, size_t count, int dtype, int op, void* comm, omx_stream stream);
+void* omx_peer_allreduce_fn(void);
+int omx_peer_comm_status(void* comm, unsigned* aborted);   /* 1: a wait gave up (a peer never arrived); results are void */
+int omx_peer_comm_destroy(void* comm);
+
 /* =====================================================================================
  * a12: Paraformer mel/STFT frontend (funasr-mlx/src/paraformer.rs:195-412), all on device:
  * x*32768 -> pre-emphasis 0.97 -> frames (n-400)/160+1 -> Hamming -> 400-pt DFT power -> 80 HTK

@@ -53,6 +53,110 @@ def rccl_comm(dist, rank: int, world: int):
     return lib, comm.value, fn
 
 
+PEER_SIGNATURES = {
+    "omx_peer_comm_create": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]),
+    "omx_peer_comm_handle": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
+    "omx_peer_comm_connect": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
+    "omx_peer_allreduce": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]),
+    "omx_peer_allreduce_fn": (ctypes.c_void_p, []),
+    "omx_peer_comm_status": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint)]),
+    "omx_peer_comm_destroy": (ctypes.c_int, [ctypes.c_void_p]),
+}
+
+
+def lib_error() -> str:
+    from . import lib
+    lib.omx_last_error.restype = ctypes.c_char_p
+    m = lib.omx_last_error()
+    return m.decode(errors="replace") if m else ""
+
+
+class PeerComm:
+    """One-shot all-reduce over xGMI peer stores (csrc/peer_allreduce.hip) for the small reductions of the tensor-parallel decode step;
+    larger calls go to `rccl` = (lib, comm, fn) of rccl_comm() when given.  `all_gather_bytes(b: bytes) -> list[bytes]` is the host-side
+    bootstrap (torch.distributed on any backend): the 64-byte IPC handles of the ranks' inboxes are exchanged through it once.
+
+    .comm / .fn are what `Model.set_comm` takes.  `self_test()` reduces seeded vectors and compares with the rank-ordered sum every
+    rank can compute locally -- call it before trusting the fabric (bounded waits: a failure raises, it does not hang)."""
+
+    def __init__(self, all_gather_bytes, rank: int, world: int, rccl=None):
+        from . import lib
+        for name, (res, args) in PEER_SIGNATURES.items():
+            f = getattr(lib, name)
+            f.restype, f.argtypes = res, args
+        self.rank, self.world, self._rccl = rank, world, rccl
+        # every step that can fail on ONE rank is followed by an exchange, so that all ranks raise together instead of one of
+        # them leaving the others inside a collective
+        h, err = ctypes.c_void_p(), b""
+        mine = ctypes.create_string_buffer(64)
+        if lib.omx_peer_comm_create(ctypes.byref(h), rank, world, rccl[1] if rccl else None, rccl[2] if rccl else None) != 0 or \
+                lib.omx_peer_comm_handle(h, mine) != 0:
+            err = (lib_error() or "omx_peer_comm_create failed").encode()
+        self._h = h if not err else None
+        handles = all_gather_bytes(b"!" + err if err else mine.raw)
+        bad = [f"rank {r}: {b[1:].decode(errors='replace')}" for r, b in enumerate(handles) if len(b) != 64]
+        if bad:
+            self.close()
+            raise RuntimeError("peer all-reduce: inbox creation failed on " + "; ".join(bad))
+        err = b""
+        if world > 1 and lib.omx_peer_comm_connect(h, b"".join(handles)) != 0:
+            err = (lib_error() or "omx_peer_comm_connect failed").encode()
+        bad = [f"rank {r}: {b.decode(errors='replace')}" for r, b in enumerate(all_gather_bytes(err)) if b]
+        if bad:
+            self.close()
+            raise RuntimeError("peer all-reduce: mapping the peers' inboxes failed on " + "; ".join(bad))
+        self.comm = h.value
+        self.fn = lib.omx_peer_allreduce_fn()
+
+    def aborted(self) -> bool:
+        from . import check, lib
+        v = ctypes.c_uint(0)
+        check(lib.omx_peer_comm_status(self._h, ctypes.byref(v)))
+        return bool(v.value)
+
+    def allreduce_f32(self, t):
+        """in place on a device Tensor of float32 (tests, self-test)."""
+        from . import lib
+        rc = lib.omx_peer_allreduce(t.ptr, t.ptr, t.size, NCCL_FLOAT32, 0, self._h, None)
+        if rc != 0:
+            raise RuntimeError("omx_peer_allreduce failed (unsupported call and no RCCL communicator behind it)")
+        return t
+
+    def self_test(self, rounds: int = 6, n: int = 4096):
+        """Every rank derives ALL ranks' inputs from (round, rank) seeds, so the expected rank-ordered f32 sum is known locally."""
+        import numpy as np
+        from .ops import Tensor, synchronize
+        for it in range(rounds):
+            parts = [np.random.default_rng(1000 * it + r).standard_normal(n).astype(np.float32) for r in range(self.world)]
+            want = parts[0].copy()
+            for r in range(1, self.world):
+                want = want + parts[r]
+            t = Tensor.from_numpy(parts[self.rank], "f32")
+            self.allreduce_f32(t)
+            synchronize()
+            if self.aborted():
+                raise RuntimeError(f"peer all-reduce: rank {self.rank} gave up waiting for a peer in round {it}")
+            got = t.numpy()
+            if not np.array_equal(got, want):
+                raise RuntimeError(f"peer all-reduce: rank {self.rank} round {it}: {int((got != want).sum())} of {n} sums differ from the rank-ordered sum")
+        return True
+
+    def close(self):
+        from . import lib
+        if self._h:
+            lib.omx_peer_comm_destroy(self._h)
+            self._h = None
+
+
+def torch_all_gather_bytes(dist):
+    """bootstrap for PeerComm over an initialised torch.distributed (gloo or nccl)."""
+    def gather(b: bytes):
+        out = [None] * dist.get_world_size()
+        dist.all_gather_object(out, b)
+        return out
+    return gather
+
+
 class RcclExchange:
     """all-to-all(v) of device rows as one ncclGroup of point-to-point sends/receives: xGMI is a
     point-to-point fabric, so the exchange is exactly one transfer per peer pair and direction."""

@@ -27,7 +27,7 @@ def test_every_declared_symbol_is_exported(omx):
 
 def test_binding_tables_cover_the_headers(omx):
     from ominix_mlx_amd import audio, comm, engine, ep, klein, mlx_c, moe, paraformer, vae
-    bound = set(omx.SIGNATURES) | set(engine.ENGINE_SIGNATURES) | set(mlx_c.SIGNATURES) | set(audio.AUDIO_SIGNATURES) | set(moe.MOE_SIGNATURES) | set(klein.KLEIN_SIGNATURES) | set(paraformer.PARAFORMER_SIGNATURES) | set(ep.EP_SIGNATURES) | set(comm.LOOPBACK_SIGNATURES) | set(vae.VAE_SIGNATURES)
+    bound = set(omx.SIGNATURES) | set(engine.ENGINE_SIGNATURES) | set(mlx_c.SIGNATURES) | set(audio.AUDIO_SIGNATURES) | set(moe.MOE_SIGNATURES) | set(klein.KLEIN_SIGNATURES) | set(paraformer.PARAFORMER_SIGNATURES) | set(ep.EP_SIGNATURES) | set(comm.LOOPBACK_SIGNATURES) | set(comm.PEER_SIGNATURES) | set(vae.VAE_SIGNATURES)
     want = set(declared("omx.h")) | set(declared("omx_mlx_c.h"))
     assert want - bound == set(), f"no ctypes signature for: {sorted(want - bound)}"
 

@@ -7,6 +7,7 @@ largest logit per layer, accumulating as a random walk: bf16 kernels vs the orde
 restatement round the same op outputs differently at ties); token ids must be EQUAL wherever
 the oracle's top-1/top-2 margin exceeds twice that bound (fp32 summation order differs,
 SURVEY.md section 7 "hard parts" (i))."""
+import os
 import numpy as np
 import pytest
 
@@ -562,3 +563,50 @@ def test_oproj_in_attention_launch_is_bit_identical(omx, monkeypatch, name):
     for mode in ("1", "eager"):
         for a, b in zip(outs["0"], outs[mode]):
             np.testing.assert_array_equal(a, b)
+
+
+def test_peer_store_allreduce_across_processes(omx, tmp_path):
+    """csrc/peer_allreduce.hip with one PROCESS per rank (tools/peer_allreduce_check.py under torch.distributed.run, gloo bootstrap,
+    both ranks on this box's one GPU): inboxes exchanged as HIP IPC handles, every all-reduce of the tensor-parallel step (f32 hidden
+    partials, u64 argmax key) one kernel of tagged peer stores, captured in the step graph.  The self-test must reproduce the
+    rank-ordered sums exactly, both ranks must emit the same tokens, and -- the reduction order being the loopback communicator's --
+    exactly the tokens of the in-process two-rank run."""
+    import json
+    import subprocess
+    import sys
+    from ominix_mlx_amd import comm, engine
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    port = 29500 + (os.getpid() % 400)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(root, "tools", "peer_allreduce_check.py"), str(tmp_path)],
+                       env=env, capture_output=True, text=True, timeout=600, stdin=subprocess.DEVNULL)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
+    res = [json.load(open(tmp_path / f"rank{r}.json")) for r in range(2)]
+    for r in res:
+        assert r["self_test"] and not r["aborted"] and not r["aborted_after_loop"]
+    assert res[0]["tokens"] == res[1]["tokens"]
+    assert res[0]["decode_path"] == "graph"          # the peer all-reduce is an ordinary kernel: the step stays captured
+    # the same two shards through the in-process communicator (same rank-ordered f32 sums)
+    cfg = dict(hidden_size=1024, num_hidden_layers=2, intermediate_size=3072, num_attention_heads=8, num_key_value_heads=2, head_dim=128,
+               vocab_size=4096, rms_norm_eps=1e-6, rope_theta=1e6, tie_word_embeddings=False)
+    os.environ["OMX_PREFILL_SERIAL"] = "1"
+    try:
+        group = comm.LoopbackGroup(2, 1 << 20)
+        models = []
+        for r in range(2):
+            m = engine.Model(max_context=256, tp_rank=r, tp_size=2, **cfg)
+            m.synth_weights()
+            m.set_comm(group.rank_comm(r), group.allreduce_fn)
+            models.append(m)
+        prompt = synth.prompt_ids(40, cfg["vocab_size"])
+
+        def run(r):
+            first = models[r].prefill(prompt)
+            return [int(first)] + [int(x) for x in models[r].decode(15)]
+
+        outs = comm.run_ranks(2, run, group)
+    finally:
+        del os.environ["OMX_PREFILL_SERIAL"]
+    assert outs[0] == res[0]["tokens"]
+    print(f"peer all-reduce of 16 KB, two processes on one GPU: {res[0]['allreduce_16k_us']:.1f} us per call")

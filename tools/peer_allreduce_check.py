@@ -1,0 +1,67 @@
+"""One-shot peer-store all-reduce (csrc/peer_allreduce.hip) across PROCESSES: run under torch.distributed.run, one process per rank
+(gloo bootstrap, so that two ranks may share the one GPU of a test box; on a multi-GPU node every rank takes its LOCAL_RANK device
+and the stores cross xGMI).  Each rank: self-test against the rank-ordered sum, latency of a 4096-float reduction, then a
+tensor-parallel greedy decode of a small Qwen3 through the engine with every all-reduce (hidden partials, argmax key) on the peer
+path -- serial prefill, so no call needs RCCL.  Rank r writes <out>/rank<r>.json.
+usage: python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1 --master-port P tools/peer_allreduce_check.py <out dir>"""
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ["OMX_PREFILL_SERIAL"] = "1"
+rank, world, local = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), int(os.environ.get("LOCAL_RANK", "0"))
+out_dir = sys.argv[1]
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+torch.cuda.set_device(local % torch.cuda.device_count())
+dist.init_process_group("gloo", rank=rank, world_size=world)
+import omx_import  # noqa: E402
+
+omx = omx_import.load_package()
+from ominix_mlx_amd import comm, engine  # noqa: E402
+from oracle import synth  # noqa: E402  (prompt ids only: the checker's seeded inputs)
+
+res = {"rank": rank, "world": world, "device": torch.cuda.current_device()}
+pc = comm.PeerComm(comm.torch_all_gather_bytes(dist), rank, world)
+res["self_test"] = bool(pc.self_test())
+T = omx.ops.Tensor
+import numpy as np  # noqa: E402
+
+t = T.from_numpy(np.ones(4096, np.float32), "f32")
+dist.barrier()
+for _ in range(20):
+    pc.allreduce_f32(t)
+    t = T.from_numpy(np.ones(4096, np.float32), "f32")
+omx.ops.synchronize()
+dist.barrier()
+reps = 200
+t0 = time.perf_counter()
+for _ in range(reps):
+    omx.lib.omx_peer_allreduce(t.ptr, t.ptr, 4096, comm.NCCL_FLOAT32, 0, pc.comm, None)
+omx.ops.synchronize()
+res["allreduce_16k_us"] = (time.perf_counter() - t0) * 1e6 / reps
+res["aborted_after_loop"] = pc.aborted()
+
+cfg = dict(hidden_size=1024, num_hidden_layers=2, intermediate_size=3072, num_attention_heads=8, num_key_value_heads=2, head_dim=128,
+           vocab_size=4096, rms_norm_eps=1e-6, rope_theta=1e6, tie_word_embeddings=False)
+m = engine.Model(max_context=256, tp_rank=rank, tp_size=world, **cfg)
+m.synth_weights()
+m.set_comm(pc.comm, pc.fn)
+prompt = synth.prompt_ids(40, cfg["vocab_size"])
+first = m.prefill(prompt)
+rest = m.decode(15)
+res["tokens"] = [int(first)] + [int(x) for x in rest]
+res["decode_path"] = m.decode_path()
+res["aborted"] = pc.aborted()
+dist.barrier()
+m.close()
+pc.close()
+os.makedirs(out_dir, exist_ok=True)
+with open(os.path.join(out_dir, f"rank{rank}.json"), "w") as f:
+    json.dump(res, f)
+dist.barrier()
+dist.destroy_process_group()

@@ -163,7 +163,7 @@ class Model:
     def __del__(self):
         # never call into HIP while the interpreter (and possibly the HIP runtime / a profiler
         # layered on it) is being torn down
-        if not sys.is_finalizing():
+        if sys is not None and not sys.is_finalizing():   # (module globals are already None late in shutdown)
             self.close()
 
     @property

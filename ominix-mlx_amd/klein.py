@@ -119,7 +119,7 @@ class FluxKlein:
             self._h = c_void_p()
 
     def __del__(self):
-        if not sys.is_finalizing():
+        if sys is not None and not sys.is_finalizing():   # (module globals are already None late in shutdown)
             self.close()
 
     def set_comm(self, comm_ptr: int, allreduce_fn_ptr: int) -> None:

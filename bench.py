@@ -460,6 +460,9 @@ def main():
     model.synth_weights()
 
     prompt = prompt_ids(args.prompt, cfg["vocab_size"])
+    if dist is not None:
+        dist.barrier()      # ranks enter their first collective together (the peer all-reduce's waits are bounded)
+        torch.cuda.synchronize()
     t0 = time.perf_counter()
     first = model.prefill(prompt)
     torch.cuda.synchronize()

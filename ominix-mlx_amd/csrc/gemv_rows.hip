@@ -11,7 +11,7 @@
 namespace omx {
 namespace {
 
-constexpr int kRowsRPW = 4, kRowsChunk = 4096, kRowsNV = kRowsChunk / 512;   // 8 vectors of 16 B per lane and row per chunk
+constexpr int kRowsChunk = 4096, kRowsNV = kRowsChunk / 512;   // 8 vectors of 16 B per lane and row per chunk
 
 struct RowsArgs {
     const bf16_t* x; const bf16_t* w; const bf16_t* bias; const bf16_t* resid; const bf16_t* gate; bf16_t* out;
@@ -36,8 +36,11 @@ __device__ __forceinline__ float dot8_rows(const u32x4 w, const u32x4 xp, float 
 // SEG: the virtual row space is the plain segments' rows one after the other (cols % 4 == 0: a wave's four rows stay inside one
 // segment), then the SwiGLU pair in groups of four = gate rows 2p, 2p + 1 and up rows 2p, 2p + 1, so that the wave that owns a group
 // holds both factors of two activation columns.
-template <int T, bool SEG>
+// RPW: output rows per wave.  4 where that still gives every CU two blocks or more; 2 for the narrow outputs (N = hidden: 256 blocks
+// of 4 would leave one block per CU with nothing to overlap its load -> multiply -> load phases; O / down 23 -> ... us at 5 rows)
+template <int T, bool SEG, int kRowsRPW>
 __global__ __launch_bounds__(256) void gemv_rows_kernel(const RowsArgs a) {
+    static_assert(!SEG || kRowsRPW == 4 || kRowsRPW == 2, "segments are cut on multiples of the wave's rows");
     extern __shared__ __attribute__((aligned(16))) unsigned char rows_smem[];
     u32x4* xs = reinterpret_cast<u32x4*>(rows_smem);                       // [T][512] vectors of the current K chunk
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -46,7 +49,7 @@ __global__ __launch_bounds__(256) void gemv_rows_kernel(const RowsArgs a) {
     int seg = -1, scol = 0;                                              // SEG: plain segment (3 = the SwiGLU pair) and first column in it
     if constexpr (SEG) {
         const int v = min(row0, a.N - kRowsRPW);                         // waves past the end re-read the last group and store nothing
-        if (v >= a.plain_rows) {
+        if (kRowsRPW == 4 && v >= a.plain_rows) {
             seg = 3; scol = (v - a.plain_rows) / 2;
 #pragma unroll
             for (int r = 0; r < kRowsRPW; ++r) wrow[r] = (r < 2 ? a.sg.w_gate : a.sg.w_up) + (size_t)(scol + (r & 1)) * a.K;
@@ -106,13 +109,13 @@ __global__ __launch_bounds__(256) void gemv_rows_kernel(const RowsArgs a) {
         for (int t = 0; t < T; ++t) acc[r][t] = wave_sum(acc[r][t]);
     if constexpr (SEG) {
         if (lane != 0 || row0 >= a.N) return;
-        if (seg == 3) {   // act[t, c] = silu(bf16(x.Wg[c])) * bf16(x.Wu[c]): the two roundings of the 256^2 kernel's SwiGLU epilogue (gemm.hip)
+        if (kRowsRPW == 4 && seg == 3) {   // act[t, c] = silu(bf16(x.Wg[c])) * bf16(x.Wu[c]): the two roundings of the 256^2 kernel's SwiGLU epilogue (gemm.hip)
 #pragma unroll
             for (int c = 0; c < 2; ++c)
 #pragma unroll
                 for (int t = 0; t < T; ++t) {
                     if (t >= a.M) continue;
-                    const float gt = round_bf16(acc[c][t]), up = round_bf16(acc[2 + c][t]);
+                    const float gt = round_bf16(acc[c][t]), up = round_bf16(acc[(2 + c) % kRowsRPW][t]);
                     float v;
                     if (a.sg.act_mode == 1) {
                         const float sg = round_bf16(1.0f / (1.0f + expf(-gt)));
@@ -155,15 +158,15 @@ __global__ __launch_bounds__(256) void gemv_rows_kernel(const RowsArgs a) {
 }
 
 // one instantiation per row count: the staging traffic (M x 8 KB per block and chunk) and the multiply both scale with it
-template <bool SEG>
+template <bool SEG, int kRowsRPW>
 int launch_rows_t(const RowsArgs& a, hipStream_t s) {
     const dim3 grid((a.N + 4 * kRowsRPW - 1) / (4 * kRowsRPW)), block(256);
 #define OMX_ROWS_CASE(TT)                                                                                            \
     {                                                                                                                \
         const size_t shmem = (size_t)TT * 512 * 16;                                                                  \
         if (shmem > 48 * 1024)                                                                                       \
-            OMX_HIP_CHECK(hipFuncSetAttribute((const void*)gemv_rows_kernel<TT, SEG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem)); \
-        gemv_rows_kernel<TT, SEG><<<grid, block, shmem, s>>>(a);                                                     \
+            OMX_HIP_CHECK(hipFuncSetAttribute((const void*)gemv_rows_kernel<TT, SEG, kRowsRPW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem)); \
+        gemv_rows_kernel<TT, SEG, kRowsRPW><<<grid, block, shmem, s>>>(a);                                                     \
         OMX_LAUNCH_CHECK();                                                                                          \
         return 0;                                                                                                    \
     }
@@ -179,7 +182,12 @@ int launch_rows_t(const RowsArgs& a, hipStream_t s) {
     }
 #undef OMX_ROWS_CASE
 }
-int launch_rows(const RowsArgs& a, bool seg, hipStream_t s) { return seg ? launch_rows_t<true>(a, s) : launch_rows_t<false>(a, s); }
+int launch_rows(const RowsArgs& a, bool seg, hipStream_t s) {
+    // two rows per wave while four would give fewer than three blocks per CU (a SwiGLU pair needs its four: 2 gate + 2 up rows)
+    const bool narrow = a.N < 768 * 16 && !(seg && a.sg.half > 0);
+    if (seg) return narrow ? launch_rows_t<true, 2>(a, s) : launch_rows_t<true, 4>(a, s);
+    return narrow ? launch_rows_t<false, 2>(a, s) : launch_rows_t<false, 4>(a, s);
+}
 
 }  // namespace
 

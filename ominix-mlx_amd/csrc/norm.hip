@@ -33,8 +33,11 @@ __global__ __launch_bounds__(256) void rownorm_kernel(typename Elem<DT>::T* __re
         wr = w + bi * dim;
         br = b + bi * dim;
     }
+    // (unroll 8: with a handful of rows -- a decode-sized batch -- nothing hides a load's latency but the row's other loads; the rolled
+    // loop waited for each 16-byte load before issuing the next: 7.4 us for 5 rows of 4096)
     float s = 0.f;
     if (VEC) {
+#pragma unroll 8
         for (int i = lane * N; i < dim; i += 64 * N) {
             float v[N];
             Vec16<DT>::ld(xr + i, v);
@@ -55,7 +58,8 @@ __global__ __launch_bounds__(256) void rownorm_kernel(typename Elem<DT>::T* __re
         mean = s / (float)dim;
         float q = 0.f;
         if (VEC) {
-            for (int i = lane * N; i < dim; i += 64 * N) {
+    #pragma unroll 8
+        for (int i = lane * N; i < dim; i += 64 * N) {
                 float v[N];
                 Vec16<DT>::ld(xr + i, v);
 #pragma unroll
@@ -71,6 +75,7 @@ __global__ __launch_bounds__(256) void rownorm_kernel(typename Elem<DT>::T* __re
         rstd = 1.0f / sqrtf(q / (float)dim + eps);
     }
     if (VEC) {
+#pragma unroll 8
         for (int i = lane * N; i < dim; i += 64 * N) {
             float v[N], wv[N], bv[N];
             Vec16<DT>::ld(xr + i, v);

@@ -794,7 +794,6 @@ int prefill_prefix_batched(omx_qwen3 m, int T, int off, const EncodeOpts* enc = 
         const LayerW& L = m->layers[l];
         const LayerQ& Q = quant ? m->qlayers[l] : no_q;
         const bf16_t* w = nullptr;
-        if (omx_rms_norm(m->pf_xn, h, L.in_ln, T, hd, c.rms_norm_eps, OMX_BFLOAT16, s)) return 1;
         // q, k, v: one segmented launch over the three borrowed weights when the chip is filled that way (the separate k / v
         // grids are 128 tiles on 512 slots), else three launches
         GemmSegs qkv = {};
@@ -802,6 +801,10 @@ int prefill_prefix_batched(omx_qwen3 m, int T, int off, const EncodeOpts* enc = 
         qkv.plain[0] = {L.q, L.q_bias, m->pf_q, H * D, H * D, 0};
         qkv.plain[1] = {L.k, L.k_bias, m->pf_k, Hkv * D, Hkv * D, 0};
         qkv.plain[2] = {L.v, L.v_bias, m->pf_v, Hkv * D, Hkv * D, 0};
+        // (a handful of rows: the weight-streaming launch normalises its staged copy of the rows itself -- no RMSNorm launch)
+        const bool qkv_norm = seg_gemm && gemm_segmented_preferred(T, hd, qkv) && gemv_rows_takes_norm(T, hd, qkv);
+        if (!qkv_norm && omx_rms_norm(m->pf_xn, h, L.in_ln, T, hd, c.rms_norm_eps, OMX_BFLOAT16, s)) return 1;
+        if (qkv_norm) { qkv.pre_norm_w = L.in_ln; qkv.pre_norm_eps = c.rms_norm_eps; }
         if (seg_gemm && gemm_segmented_preferred(T, hd, qkv)) {
             if (quant) {   // the three dequantised matrices side by side in the scratch
                 const size_t nq = (size_t)H * D * hd, nk = (size_t)Hkv * D * hd;
@@ -809,7 +812,7 @@ int prefill_prefix_batched(omx_qwen3 m, int T, int off, const EncodeOpts* enc = 
                     !(qkv.plain[2].w = W(nullptr, &Q.v, hd, nq + nk)))
                     return 1;
             }
-            if (launch_gemm_bf16_segmented(m->pf_xn, T, hd, qkv, s)) return 1;
+            if (launch_gemm_bf16_segmented(qkv_norm ? h : m->pf_xn, T, hd, qkv, s)) return 1;
         } else {
             if (!(w = W(L.q, &Q.q, hd)) || launch_gemm_bf16(m->pf_q, m->pf_xn, w, L.q_bias, T, H * D, hd, s)) return 1;
             if (!(w = W(L.k, &Q.k, hd)) || launch_gemm_bf16(m->pf_k, m->pf_xn, w, L.k_bias, T, Hkv * D, hd, s)) return 1;
@@ -842,7 +845,11 @@ int prefill_prefix_batched(omx_qwen3 m, int T, int off, const EncodeOpts* enc = 
                                 enc ? enc->mask : nullptr, s, /*out_token_major=*/true))
             return 1;
         if (!(w = W(L.o, &Q.o, H * D)) || row_split(h2, m->pf_attn, w, h, H * D)) return 1;
-        if (omx_rms_norm(m->pf_xn, h2, L.post_ln, T, hd, c.rms_norm_eps, OMX_BFLOAT16, s)) return 1;
+        GemmSegs gu = {};
+        gu.w_gate = L.gate; gu.w_up = L.up; gu.out_act = m->pf_g; gu.half = I; gu.ld_act = I; gu.act_mode = 1;
+        const bool gu_norm = c.num_experts == 0 && seg_gemm && gemm_segmented_preferred(T, hd, gu) && gemv_rows_takes_norm(T, hd, gu);
+        if (!gu_norm && omx_rms_norm(m->pf_xn, h2, L.post_ln, T, hd, c.rms_norm_eps, OMX_BFLOAT16, s)) return 1;
+        if (gu_norm) { gu.pre_norm_w = L.post_ln; gu.pre_norm_eps = c.rms_norm_eps; }
         if (c.num_experts > 0) {   // sparse-MoE feed-forward over all T rows (grouped MFMA GEMM route), then the residual
             if (quant) {
                 if (omx_moe_block_forward_q(h, h2, h2, L.post_ln, c.rms_norm_eps, m->pf_xn, Q.moe_router.w, Q.moe_router.scales,
@@ -865,11 +872,9 @@ int prefill_prefix_batched(omx_qwen3 m, int T, int off, const EncodeOpts* enc = 
         }
         // gate, up and nn::silu(gate) * up: one launch with the activation in the epilogue (768 tiles = 3 full rounds at
         // T = 2048 instead of 2 x 384), else two GEMMs + the elementwise kernel
-        GemmSegs gu = {};
-        gu.w_gate = L.gate; gu.w_up = L.up; gu.out_act = m->pf_g; gu.half = I; gu.ld_act = I; gu.act_mode = 1;
         if (seg_gemm && gemm_segmented_preferred(T, hd, gu)) {
             if (quant && (!(gu.w_gate = W(nullptr, &Q.gate, hd, 0)) || !(gu.w_up = W(nullptr, &Q.up, hd, (size_t)I * hd)))) return 1;
-            if (launch_gemm_bf16_segmented(m->pf_xn, T, hd, gu, s)) return 1;
+            if (launch_gemm_bf16_segmented(gu_norm ? h2 : m->pf_xn, T, hd, gu, s)) return 1;
         } else {
             if (!(w = W(L.gate, &Q.gate, hd)) || launch_gemm_bf16(m->pf_g, m->pf_xn, w, nullptr, T, I, hd, s)) return 1;
             if (!(w = W(L.up, &Q.up, hd)) || launch_gemm_bf16(m->pf_u, m->pf_xn, w, nullptr, T, I, hd, s)) return 1;

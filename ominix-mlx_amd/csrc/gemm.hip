@@ -1022,6 +1022,13 @@ static bool rows_route(int M, int K, const GemmSegs& g) {
     return rows * K >= (1 << 20);
 }
 
+bool gemv_rows_takes_norm(int M, int K, const GemmSegs& g) {
+    const char* e = getenv("OMX_ROWS_NORM");   // 0: keep the separate RMSNorm launch (A/B, tests)
+    // every block redoes the norm of all M staged rows: measured on the Qwen3-8B verify pass, 1 / 2 / 3 / 4 rows -9 / -7 / -5 / -7 %,
+    // 5 rows flat, 8 rows +6 % -- taken up to 4 rows
+    return !(e && e[0] == '0') && M <= 4 && K <= 4096 && rows_route(M, K, g);
+}
+
 bool gemm_segmented_preferred(int M, int K, const GemmSegs& g) {
     if (!gemm_segmented_supported(M, K, g)) return false;
     if (rows_route(M, K, g)) return true;   // a handful of rows: one weight-streaming launch (gemv_rows.hip)
@@ -1043,6 +1050,7 @@ int launch_gemm_bf16_segmented(const bf16_t* x, int M, int K, const GemmSegs& se
     }
     OMX_REQUIRE((align & 15u) == 0, "segmented gemm: operands must be 16-byte aligned");
     if (rows_route(M, K, segs)) return launch_gemv_rows_segmented(x, M, K, segs, s);
+    OMX_REQUIRE(!segs.pre_norm_w, "segmented gemm: an in-launch RMSNorm exists on the weight-streaming route only (gemv_rows_takes_norm)");
     if (ensure_attr()) return 1;
     GemmArgs a = {};
     a.x = x; a.M = M; a.K = K;

@@ -55,6 +55,10 @@ struct GemmSegs {
     // implicit 3x3 convolution (launch_conv3x3_implicit): channels, output width, log2(channels / 64), shortcut
     int im_C, im_W, im_sh;
     const bf16_t* im_resid;
+    // RMSNorm of the input rows inside the launch (the weight-streaming route for M <= 8 rows only, gemv_rows_takes_norm):
+    // x is the raw residual stream, every block normalises its staged copy with the norm kernel's exact arithmetic
+    const bf16_t* pre_norm_w;
+    float pre_norm_eps;
 };
 // 3x3 convolution, stride 1, zero padding 1, as ONE GEMM over a zero-bordered NHWC activation [(H+2), (W+2), C] (no im2col
 // matrix): out[(y*W + x), o] = bias[o] + sum_{tap, c} padded[(y + tap/3), (x + tap%3), c] * w[o, tap*C + c]  (+ resid).
@@ -116,6 +120,9 @@ bool gemv_rows_supported(int M, int N, int K, const void* x, const void* w);
 // ... and the segmented projection (GemmSegs above) in one such launch: q / k / v, or gate / up with the SwiGLU epilogue
 bool gemv_rows_segmented_supported(int M, int K, const GemmSegs& segs);
 int launch_gemv_rows_segmented(const bf16_t* x, int M, int K, const GemmSegs& segs, hipStream_t s);
+// would launch_gemm_bf16_segmented(x, M, K, segs) take that route AND can it apply segs.pre_norm_w itself (K <= 4096: the whole
+// row is staged at once)?  Callers then skip their RMSNorm launch and pass the raw rows.
+bool gemv_rows_takes_norm(int M, int K, const GemmSegs& segs);
 int launch_gemv_rows(bf16_t* out, const bf16_t* x, const bf16_t* w, const bf16_t* bias, const bf16_t* resid, const bf16_t* gate, int M, int N,
                      int K, int relu, hipStream_t s);
 

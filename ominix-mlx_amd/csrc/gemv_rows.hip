@@ -83,6 +83,11 @@ __global__ __launch_bounds__(256) void gemv_rows_kernel(const RowsArgs a) {
             const u32x4 xv = *(reinterpret_cast<const u32x4*>(a.x + (size_t)min(t, a.M - 1) * a.K) + v0 + min(v, nv - 1));
             xs[i] = (v < nv && t < a.M) ? xv : u32x4{0u, 0u, 0u, 0u};
         }
+        u32x4 nw[2] = {};                                                  // SEG + pre_norm_w: the norm weights of this thread's two vector columns
+        if (SEG && a.sg.pre_norm_w) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) nw[h] = *(reinterpret_cast<const u32x4*>(a.sg.pre_norm_w) + min((int)threadIdx.x + 256 * h, nv - 1));
+        }
         // weights in the order they are consumed (vector j of every row before vector j + 1): the multiply starts on the first
         // vectors while the later ones are still in flight
         u32x4 w[kRowsNV][kRowsRPW];
@@ -94,6 +99,43 @@ __global__ __launch_bounds__(256) void gemv_rows_kernel(const RowsArgs a) {
                 w[j][r] = __builtin_nontemporal_load(p + min(j * 64 + lane, nv - 1));     // lanes past the row's end: zeroed x, any w
             }
         __syncthreads();
+        if (SEG && a.sg.pre_norm_w) {
+            // RMSNorm of the staged rows (K <= 4096: this chunk IS the row), the arithmetic of rownorm_kernel<bf16, RMS> (norm.hip) to the
+            // bit: one wave per row, lane l sums the squares of elements [8 l + 512 k, +8) for k = 0.. in order, DPP wave sum,
+            // rstd = 1 / sqrt(s / K + eps), y = bf16((x * rstd) * w)
+            float* rs = reinterpret_cast<float*>(rows_smem + (size_t)T * 512 * 16);
+            for (int t = wave; t < T; t += 4) {
+                float s = 0.f;
+#pragma unroll
+                for (int k = 0; k < kRowsNV; ++k) {
+                    const u32x4 xv = xs[t * 512 + k * 64 + lane];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float lo = bf16lo(xv[e]), hi = bf16hi(xv[e]);
+                        s += lo * lo;
+                        s += hi * hi;
+                    }
+                }
+                s = wave_sum(s);
+                if (lane == 0) rs[t] = 1.0f / sqrtf(s / (float)a.K + a.sg.pre_norm_eps);
+            }
+            __syncthreads();
+            for (int i = threadIdx.x; i < T * 512; i += 256) {
+                const int t = i >> 9;
+                const u32x4 xv = xs[i], wv = nw[(i >> 8) & 1];
+                const float rstd = rs[t];
+                u32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float y0 = bf16lo(xv[e]) * rstd, y1 = bf16hi(xv[e]) * rstd;
+                    y0 *= bf16lo(wv[e]);
+                    y1 *= bf16hi(wv[e]);
+                    o[e] = pack_bf16(y0, y1);
+                }
+                xs[i] = o;
+            }
+            __syncthreads();
+        }
 #pragma unroll
         for (int j = 0; j < kRowsNV; ++j)
 #pragma unroll
@@ -163,7 +205,7 @@ int launch_rows_t(const RowsArgs& a, hipStream_t s) {
     const dim3 grid((a.N + 4 * kRowsRPW - 1) / (4 * kRowsRPW)), block(256);
 #define OMX_ROWS_CASE(TT)                                                                                            \
     {                                                                                                                \
-        const size_t shmem = (size_t)TT * 512 * 16;                                                                  \
+        const size_t shmem = (size_t)TT * 512 * 16 + 64;                                                                 \
         if (shmem > 48 * 1024)                                                                                       \
             OMX_HIP_CHECK(hipFuncSetAttribute((const void*)gemv_rows_kernel<TT, SEG, kRowsRPW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem)); \
         gemv_rows_kernel<TT, SEG, kRowsRPW><<<grid, block, shmem, s>>>(a);                                                     \
@@ -228,6 +270,10 @@ int launch_gemv_rows_segmented(const bf16_t* x, int M, int K, const GemmSegs& se
     if (segs.half > 0) {
         OMX_REQUIRE(segs.w_gate && segs.w_up && segs.out_act, "gemv_rows: null gate / up / activation pointer");
         align |= reinterpret_cast<uintptr_t>(segs.w_gate) | reinterpret_cast<uintptr_t>(segs.w_up);
+    }
+    if (segs.pre_norm_w) {
+        OMX_REQUIRE(K <= kRowsChunk, "gemv_rows: the in-launch RMSNorm needs the whole row staged at once (K = %d > %d)", K, kRowsChunk);
+        align |= reinterpret_cast<uintptr_t>(segs.pre_norm_w);
     }
     OMX_REQUIRE((align & 15u) == 0, "gemv_rows: operands must be 16-byte aligned");
     a.N = a.plain_rows + 2 * segs.half;

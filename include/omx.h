@@ -384,6 +384,7 @@ int omx_peer_comm_handle(void* comm, void* out64);
 int omx_peer_comm_connect(void* comm, const void* handles);
 int omx_peer_allreduce(const void* send, void* recv, size_t count, int dtype, int op, void* comm, omx_stream stream);
 void* omx_peer_allreduce_fn(void);
+const void* omx_peer_comm_device(void* comm);              /* device table for kernels that reduce their own output (engine-internal use) */
 int omx_peer_comm_status(void* comm, unsigned* aborted);   /* 1: a wait gave up (a peer never arrived); results are void */
 int omx_peer_comm_destroy(void* comm);
 

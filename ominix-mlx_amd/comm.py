@@ -59,6 +59,7 @@ PEER_SIGNATURES = {
     "omx_peer_comm_connect": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
     "omx_peer_allreduce": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]),
     "omx_peer_allreduce_fn": (ctypes.c_void_p, []),
+    "omx_peer_comm_device": (ctypes.c_void_p, [ctypes.c_void_p]),
     "omx_peer_comm_status": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint)]),
     "omx_peer_comm_destroy": (ctypes.c_int, [ctypes.c_void_p]),
 }

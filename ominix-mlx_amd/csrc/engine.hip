@@ -32,6 +32,7 @@
 #include "prefill.hpp"
 #include "quant.hpp"
 #include "launch_timing.hpp"
+#include "peer.hpp"
 
 namespace omx {
 namespace {
@@ -203,6 +204,7 @@ struct omx_qwen3_ {
 
     void* comm = nullptr;
     nccl_allreduce_fn allreduce = nullptr;
+    const PeerDev* peer_dev = nullptr;   // the communicator is a peer-store one (peer_allreduce.hip): O / down reduce inside their GEMV
 
     // sampler (sampler.rs:9-18): 0 = greedy; otherwise categorical(logits / temperature) with the key sequence
     // of mlx-rs RandomState kept on the device: rng[0..1] = state, rng[2..3] = the key of the current draw
@@ -516,9 +518,11 @@ int enqueue_step(omx_qwen3 m, bool with_head) {
                 bf16_t* t = h; h = hn; hn = t;
             } else {
                 a.out = m->partial_a;
+                a.peer = m->peer_dev;   // peer-store communicator: the rows are reduced over the ranks inside this launch
                 if (launch_gemv(a, PRO_NONE, EPI_F32, s)) return 1;
                 OMX_REQUIRE(m->allreduce != nullptr, "tp_size > 1 but no communicator set (omx_qwen3_set_comm)");
-                OMX_REQUIRE(m->allreduce(m->partial_a, m->partial_a, hd, kNcclFloat32, kNcclSum, m->comm, s) == 0, "ncclAllReduce failed");
+                if (!m->peer_dev)
+                    OMX_REQUIRE(m->allreduce(m->partial_a, m->partial_a, hd, kNcclFloat32, kNcclSum, m->comm, s) == 0, "ncclAllReduce failed");
                 pending = m->partial_a;
             }
         }
@@ -566,8 +570,10 @@ int enqueue_step(omx_qwen3 m, bool with_head) {
                 bf16_t* t = h; h = hn; hn = t;
             } else {
                 a.out = m->partial_b;
+                a.peer = m->peer_dev;
                 if (launch_gemv(a, PRO_NONE, EPI_F32, s)) return 1;
-                OMX_REQUIRE(m->allreduce(m->partial_b, m->partial_b, hd, kNcclFloat32, kNcclSum, m->comm, s) == 0, "ncclAllReduce failed");
+                if (!m->peer_dev)
+                    OMX_REQUIRE(m->allreduce(m->partial_b, m->partial_b, hd, kNcclFloat32, kNcclSum, m->comm, s) == 0, "ncclAllReduce failed");
                 pending = m->partial_b;
             }
         }
@@ -1133,6 +1139,12 @@ int omx_qwen3_set_comm(omx_qwen3 m, void* comm, void* allreduce_fn) {
     OMX_REQUIRE(m->g_full == nullptr && !m->eager, "omx_qwen3_set_comm: communicator must be set before the first step");
     m->comm = comm;
     m->allreduce = (nccl_allreduce_fn)allreduce_fn;
+    // OMX_PEER_FUSED=1: the O / down GEMVs reduce their own rows over the peers in their epilogue instead of a standalone
+    // all-reduce kernel after them.  Opt-in: measured on one GPU (1-rank communicator, Qwen3-8B) the in-GEMV poll costs 6.5 us per
+    // GEMV against 4.4 us for the extra launch -- its uncached loads queue behind the other waves' weight stream
+    const char* fe = getenv("OMX_PEER_FUSED");
+    m->peer_dev = (allreduce_fn == omx_peer_allreduce_fn() && fe && fe[0] == '1' && m->cfg.hidden_size <= kPeerMaxWords)
+                      ? static_cast<const PeerDev*>(omx_peer_comm_device(comm)) : nullptr;
     return 0;
 }
 

@@ -1,5 +1,6 @@
 // See gemv.hpp for the design notes.
 #include "gemv.hpp"
+#include "peer.hpp"
 #include "launch_timing.hpp"
 
 #include <stdlib.h>
@@ -43,7 +44,10 @@ __device__ __forceinline__ void epilogue(const GemvArgs& a, int row, float v0, f
     if (EPI == EPI_STORE) {
         reinterpret_cast<bf16_t*>(a.out)[row] = f32_to_bf16(a.out_bias ? v0 + bf16_to_f32(a.out_bias[row]) : v0);
     } else if (EPI == EPI_F32) {
-        reinterpret_cast<float*>(a.out)[row] = v0;
+        // (`best` carries the call's tag, read ONCE before the first weight load: a load here would wait behind -- drain -- the
+        //  next batch's prefetch; the total is stored by peer_finish_rows)
+        if (a.peer) peer_store_word(a.peer, (unsigned)best, row, __float_as_uint(v0));
+        else reinterpret_cast<float*>(a.out)[row] = v0;
     } else if (EPI == EPI_RESIDUAL) {
         reinterpret_cast<bf16_t*>(a.out)[row] = f32_to_bf16(bf16_to_f32(a.resid[row]) + round_bf16(v0));
     } else if (EPI == EPI_SWIGLU) {
@@ -64,6 +68,14 @@ __device__ __forceinline__ void epilogue(const GemvArgs& a, int row, float v0, f
         const uint64_t key = argmax_key(bf16_to_f32(lb), (uint32_t)(row + a.row_offset));
         best = key > best ? key : best;
     }
+}
+
+// EPI_F32 + peer, after a wave (or the block's reducing threads) issued the stores of rows [begin, end): lane / thread `idx` of
+// `stride` sums the ranks' words of its rows; then the block reports in (the last block of the launch hands the sequence number on)
+__device__ __forceinline__ void peer_finish_rows(const GemvArgs& a, unsigned tag, int begin, int end, int idx, int stride) {
+    for (int row = begin + idx; row < end; row += stride) reinterpret_cast<float*>(a.out)[row] = peer_poll_sum_f32(a.peer, tag, row);
+    __syncthreads();
+    if (threadIdx.x == 0) peer_block_done(a.peer, tag, gridDim.x * gridDim.y);
 }
 
 // NVW    = 16-byte vectors per lane per row per wave (compile-time, fully unrolled)
@@ -111,7 +123,10 @@ __global__ __launch_bounds__(kBlock) void gemv_kernel(const GemvArgs a_in) {
     constexpr bool tail = TAIL;
 
     u32x4 wA[NR][NVW], wB[NR][NVW];
-    uint64_t best = 0;   // EPI_ARGMAX: running (orderable logit << 32 | ~row) of this thread
+    uint64_t best = 0;   // EPI_ARGMAX: running (orderable logit << 32 | ~row) of this thread; EPI_F32 + peer: the call's tag
+    if (EPI == EPI_F32) {
+        if (a.peer) best = peer_tag(a.peer);
+    }
 
 #define OMX_ISSUE(WB, R0)                                                                          \
     {                                                                                              \
@@ -261,6 +276,12 @@ __global__ __launch_bounds__(kBlock) void gemv_kernel(const GemvArgs a_in) {
             epilogue<EPI>(a, row_begin + lr, v0, v1, best);
         }
     }
+    if (EPI == EPI_F32) {
+        if (a.peer) {   // (uniform over the launch)
+            if (KSPLIT > 1) peer_finish_rows(a, (unsigned)best, row_begin, row_end, threadIdx.x, kBlock);
+            else peer_finish_rows(a, (unsigned)best, row_begin, row_end, lane, 64);
+        }
+    }
     if (EPI == EPI_ARGMAX) {
         // one partial per block (no same-address atomics: 150k of them serialise at ~12 ns each);
         // argmax_finalize in engine.hip reduces the partials
@@ -356,6 +377,9 @@ __global__ __launch_bounds__(kBlock) void gemv_generic_kernel(const GemvArgs a_i
     const int row_begin = (blockIdx.x * kWaves + wave) * rpw;
     const int row_end = min(row_begin + rpw, a.N);
     uint64_t best = 0;
+    if (EPI == EPI_F32) {
+        if (a.peer) best = peer_tag(a.peer);
+    }
     for (int r0 = row_begin; r0 < row_end; r0 += RB) {
         const u32x4* rows[NR];
 #pragma unroll
@@ -389,6 +413,9 @@ __global__ __launch_bounds__(kBlock) void gemv_generic_kernel(const GemvArgs a_i
             for (int r = 0; r < RB; ++r)
                 if (r0 + r < row_end) epilogue<EPI>(a, r0 + r, acc[LR * r], acc[LR * r + (LR - 1)], best);
         }
+    }
+    if (EPI == EPI_F32) {
+        if (a.peer) peer_finish_rows(a, (unsigned)best, row_begin, row_end, lane, 64);
     }
     if (EPI == EPI_ARGMAX) {
         uint64_t* bred = reinterpret_cast<uint64_t*>(red);

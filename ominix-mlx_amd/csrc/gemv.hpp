@@ -57,6 +57,10 @@ struct GemvArgs {
     // optional timeline (tools/gemv_trace.py; only in -DOMX_GEMV_TRACE builds): thread 0 of block b stamps the 100 MHz wall clock into trace[b*4 + k] at
     // k = 0 first weight batch issued, 1 activation staged, 2 first batch reduced, 3 last store issued
     unsigned long long* trace;
+    // EPI_F32 + peer: the output rows are reduced over the tensor-parallel ranks INSIDE this launch -- every row's partial goes to
+    // all inboxes as a tagged granule, the wave then sums the ranks' words of its rows in rank order and stores the f32 total
+    // (peer.hpp / peer_allreduce.hip: the same protocol and sequence number as the standalone all-reduce kernel, one launch less)
+    const struct PeerDev* peer;
 };
 
 int launch_gemv(const GemvArgs& a, int pro, int epi, hipStream_t s);

@@ -17,14 +17,13 @@
 #include <cstring>
 
 #include "common.hpp"
+#include "peer.hpp"
 
 namespace omx {
 namespace {
 
 typedef int (*nccl_allreduce_fn)(const void*, void*, size_t, int, int, void*, hipStream_t);
 constexpr int kNcclUint64 = 5, kNcclFloat32 = 7, kNcclSum = 0, kNcclMax = 2;
-constexpr int kPeerMaxWorld = 8, kPeerMaxWords = 8192;
-constexpr unsigned kPeerSpinLimit = 1u << 23;   // polls (~1 us each: a peer may legitimately be seconds late, e.g. re-capturing its graph) before a rank gives up
 
 struct PeerComm {
     int rank = 0, world = 1;
@@ -32,6 +31,7 @@ struct PeerComm {
     uint64_t* peers[kPeerMaxWorld] = {};       // every rank's inbox as mapped here (own: inbox)
     bool mapped[kPeerMaxWorld] = {};           // opened with hipIpcOpenMemHandle (to be closed)
     uint32_t* state = nullptr;                 // device: [0] sequence number, [1] blocks done, [2] abort
+    PeerDev* dev = nullptr;                    // device copy of the table the kernels read (written once every inbox is mapped)
     void* rccl = nullptr;
     nccl_allreduce_fn rccl_fn = nullptr;
     hipIpcMemHandle_t handle;
@@ -39,79 +39,47 @@ struct PeerComm {
 };
 
 struct PeerArgs {
-    uint64_t* peers[kPeerMaxWorld];
-    uint64_t* inbox;
-    uint32_t* state;
+    const PeerDev* dev;
     const uint32_t* send;
     uint32_t* recv;
-    int rank, world, words, max64;
+    int words, max64;
 };
 
-typedef __attribute__((address_space(1))) unsigned long long pgu64;
-__device__ __forceinline__ void st_sys(uint64_t* p, unsigned tag, unsigned v) {
-    __hip_atomic_store((pgu64*)p, ((unsigned long long)tag << 32) | v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-__device__ __forceinline__ unsigned long long ld_sys(const uint64_t* p) {
-    return __hip_atomic_load((pgu64*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-
 __global__ __launch_bounds__(256) void peer_allreduce_kernel(const PeerArgs a) {
+    const PeerDev* p = a.dev;
     const int i = blockIdx.x * 256 + threadIdx.x;
-    // every block reads the number before the LAST block to finish advances it
-    const unsigned tag = __hip_atomic_load(a.state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
-    const size_t plane = (size_t)(tag & 1u) * a.world * kPeerMaxWords;
+    const unsigned tag = peer_tag(p);
     if (i < a.words) {
-        const unsigned mine = a.send[i];
-#pragma unroll
-        for (int p = 0; p < kPeerMaxWorld; ++p)
-            if (p < a.world) st_sys(a.peers[p] + plane + (size_t)a.rank * kPeerMaxWords + i, tag, mine);
-        unsigned long long g[kPeerMaxWorld];
-#pragma unroll
-        for (int r = 0; r < kPeerMaxWorld; ++r) g[r] = 0;
-        bool ok = false;
-        for (unsigned spins = 0; !ok; ++spins) {
-            ok = true;
-#pragma unroll
-            for (int r = 0; r < kPeerMaxWorld; ++r)
-                if (r < a.world && (unsigned)(g[r] >> 32) != tag) {
-                    g[r] = ld_sys(a.inbox + plane + (size_t)r * kPeerMaxWords + i);
-                    ok = ok && (unsigned)(g[r] >> 32) == tag;
-                }
-            if (ok) break;
-            if (spins >= kPeerSpinLimit) {   // void result, loud flag, no hang
-                __hip_atomic_store(a.state + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                break;
-            }
-            __builtin_amdgcn_s_sleep(2);
-        }
+        peer_store_word(p, tag, i, a.send[i]);
         if (!a.max64) {
-            float s = __uint_as_float((unsigned)g[0]);
-#pragma unroll
-            for (int r = 1; r < kPeerMaxWorld; ++r)
-                if (r < a.world) s += __uint_as_float((unsigned)g[r]);
-            a.recv[i] = ok ? __float_as_uint(s) : 0u;
+            a.recv[i] = __float_as_uint(peer_poll_sum_f32(p, tag, i));
         } else {
             // 64-bit keys travel as two words: lanes 2k (low) and 2k + 1 (high) of one key sit next to each other in the wave
+            unsigned w[kPeerMaxWorld];
+            const bool ok = peer_poll_words(p, tag, i, w);
             unsigned best_lo = 0, best_hi = 0;
 #pragma unroll
             for (int r = 0; r < kPeerMaxWorld; ++r) {
-                if (r >= a.world) continue;
-                const unsigned w = (unsigned)g[r];
-                const unsigned other = __shfl_xor(w, 1, 64);
-                const unsigned lo = (i & 1) ? other : w, hi = (i & 1) ? w : other;
+                if (r >= p->world) continue;
+                const unsigned other = __shfl_xor(w[r], 1, 64);
+                const unsigned lo = (i & 1) ? other : w[r], hi = (i & 1) ? w[r] : other;
                 if (hi > best_hi || (hi == best_hi && lo > best_lo)) { best_hi = hi; best_lo = lo; }
             }
             a.recv[i] = ok ? ((i & 1) ? best_hi : best_lo) : 0u;
         }
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        const unsigned done = __hip_atomic_fetch_add(a.state + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (done == gridDim.x - 1) {
-            __hip_atomic_store(a.state + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(a.state, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
+    if (threadIdx.x == 0) peer_block_done(p, tag, gridDim.x);
+}
+
+int upload_table(PeerComm* c) {
+    PeerDev t = {};
+    for (int r = 0; r < c->world; ++r) t.peers[r] = c->peers[r];
+    t.inbox = c->inbox; t.state = c->state; t.rank = c->rank; t.world = c->world;
+    if (!c->dev) OMX_HIP_CHECK(hipMalloc((void**)&c->dev, sizeof(PeerDev)));
+    OMX_HIP_CHECK(hipMemcpy(c->dev, &t, sizeof(PeerDev), hipMemcpyHostToDevice));
+    c->connected = true;
+    return 0;
 }
 
 }  // namespace
@@ -144,7 +112,7 @@ int omx_peer_comm_create(void** out, int rank, int world, void* rccl_comm, void*
         return set_error("omx_peer_comm_create: hipIpcGetMemHandle failed (HSA_ENABLE_IPC_MODE_LEGACY=0 is required on this driver)");
     }
     c->peers[rank] = c->inbox;
-    c->connected = world == 1;
+    if (world == 1 && upload_table(c)) return 1;
     OMX_HIP_CHECK(hipDeviceSynchronize());
     *out = c;
     return 0;
@@ -175,8 +143,14 @@ int omx_peer_comm_connect(void* comm, const void* handles) {
         c->peers[r] = static_cast<uint64_t*>(p);
         c->mapped[r] = true;
     }
-    c->connected = true;
-    return 0;
+    return upload_table(c);
+}
+
+// the table the kernels read (device memory; NULL until every inbox is mapped): the engines hand it to the GEMV whose epilogue
+// reduces its own output rows over the peers (gemv.hip)
+const void* omx_peer_comm_device(void* comm) {
+    omx::PeerComm* c = static_cast<omx::PeerComm*>(comm);
+    return c && c->connected ? c->dev : nullptr;
 }
 
 // ncclAllReduce's signature; comm = the handle of omx_peer_comm_create
@@ -193,10 +167,9 @@ int omx_peer_allreduce(const void* send, void* recv, size_t count, int dtype, in
         return c->rccl_fn(send, recv, count, dtype, op, c->rccl, stream);
     }
     PeerArgs a = {};
-    for (int r = 0; r < c->world; ++r) a.peers[r] = c->peers[r];
-    a.inbox = c->inbox; a.state = c->state;
+    a.dev = c->dev;
     a.send = static_cast<const uint32_t*>(send); a.recv = static_cast<uint32_t*>(recv);
-    a.rank = c->rank; a.world = c->world; a.words = (int)words; a.max64 = u64max ? 1 : 0;
+    a.words = (int)words; a.max64 = u64max ? 1 : 0;
     peer_allreduce_kernel<<<(unsigned)((words + 255) / 256), 256, 0, stream>>>(a);
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
@@ -221,6 +194,7 @@ int omx_peer_comm_destroy(void* comm) {
         if (c->mapped[r]) (void)hipIpcCloseMemHandle(c->peers[r]);
     (void)hipFree(c->inbox);
     (void)hipFree(c->state);
+    if (c->dev) (void)hipFree(c->dev);
     delete c;
     return 0;
 }

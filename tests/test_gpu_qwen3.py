@@ -565,19 +565,21 @@ def test_oproj_in_attention_launch_is_bit_identical(omx, monkeypatch, name):
             np.testing.assert_array_equal(a, b)
 
 
-def test_peer_store_allreduce_across_processes(omx, tmp_path):
+@pytest.mark.parametrize("fused", ["1", "0"])
+def test_peer_store_allreduce_across_processes(omx, tmp_path, fused):
     """csrc/peer_allreduce.hip with one PROCESS per rank (tools/peer_allreduce_check.py under torch.distributed.run, gloo bootstrap,
     both ranks on this box's one GPU): inboxes exchanged as HIP IPC handles, every all-reduce of the tensor-parallel step (f32 hidden
     partials, u64 argmax key) one kernel of tagged peer stores, captured in the step graph.  The self-test must reproduce the
     rank-ordered sums exactly, both ranks must emit the same tokens, and -- the reduction order being the loopback communicator's --
-    exactly the tokens of the in-process two-rank run."""
+    exactly the tokens of the in-process two-rank run.  fused 1: the O / down GEMVs reduce their own output rows over the peers in
+    their epilogue (gemv.hip EPI_F32 + peer: no all-reduce launch at all); 0: the standalone kernel after each of them."""
     import json
     import subprocess
     import sys
     from ominix_mlx_amd import comm, engine
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     port = 29500 + (os.getpid() % 400)
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMX_PEER_FUSED=fused)
     p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                         "--master-port", str(port), os.path.join(root, "tools", "peer_allreduce_check.py"), str(tmp_path)],
                        env=env, capture_output=True, text=True, timeout=600, stdin=subprocess.DEVNULL)
@@ -609,4 +611,5 @@ def test_peer_store_allreduce_across_processes(omx, tmp_path):
     finally:
         del os.environ["OMX_PREFILL_SERIAL"]
     assert outs[0] == res[0]["tokens"]
-    print(f"peer all-reduce of 16 KB, two processes on one GPU: {res[0]['allreduce_16k_us']:.1f} us per call")
+    print(f"peer all-reduce of 16 KB, two processes on one GPU: {res[0]['allreduce_16k_us']:.1f} us per call; "
+          f"TP = 2 step (fused={fused}): {res[0]['step_ms']:.3f} ms")

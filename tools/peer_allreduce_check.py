@@ -55,6 +55,10 @@ prompt = synth.prompt_ids(40, cfg["vocab_size"])
 first = m.prefill(prompt)
 rest = m.decode(15)
 res["tokens"] = [int(first)] + [int(x) for x in rest]
+dist.barrier()
+t0 = time.perf_counter()
+m.decode(64)
+res["step_ms"] = (time.perf_counter() - t0) * 1e3 / 64
 res["decode_path"] = m.decode_path()
 res["aborted"] = pc.aborted()
 dist.barrier()

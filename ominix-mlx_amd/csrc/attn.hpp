@@ -48,6 +48,7 @@ struct AttnStepArgs {
     const bf16_t* o_w;          // [o_rows, H*D] row-major (nn::Linear weight, model.rs:214)
     const bf16_t* o_resid;      // [o_rows] residual stream entering the layer
     bf16_t* o_out;              // [o_rows] = bf16(resid + bf16(o_w . attn))      (model.rs:325)
+    float* o_out_f32;           // tensor parallel (o_w = this rank's columns): [o_rows] f32 partial o_w . attn instead, to be all-reduced
     int o_rows;
     int o_rpw, o_nhi;           // rows per wave of the non-consumer blocks: the first o_nhi waves hold o_rpw rows, the others o_rpw - 1
                                 // (set by launch_attn_step)

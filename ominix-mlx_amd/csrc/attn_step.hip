@@ -238,7 +238,10 @@ __device__ __forceinline__ void oproj_phase(const AttnStepArgs& a, u32x4* sm_x, 
     if (lane == 0) {
 #pragma unroll
         for (int r = 0; r < R; ++r)
-            if (o_row0 + r < a.o_rows) a.o_out[o_row0 + r] = f32_to_bf16(bf16_to_f32(o_res[r]) + round_bf16(acc[r]));
+            if (o_row0 + r < a.o_rows) {
+                if (a.o_out_f32) a.o_out_f32[o_row0 + r] = acc[r];   // the O GEMV's EPI_F32: this rank's partial, un-rounded
+                else a.o_out[o_row0 + r] = f32_to_bf16(bf16_to_f32(o_res[r]) + round_bf16(acc[r]));
+            }
     }
     if (tr && threadIdx.x == 0) tr[6] = wall_clock64();
 }
@@ -533,7 +536,7 @@ int launch_attn_step(const AttnStepArgs& a_in, int D, hipStream_t s) {
                 "decode attention: missing step state");
     int nvw = 0;
     if (a.o_w) {
-        OMX_REQUIRE(a.o_resid && a.o_out && a.xg && attn_step_oproj_ok(a.H, a.Hkv, D, a.nsplit, a.o_rows),
+        OMX_REQUIRE(a.o_resid && (a.o_out || a.o_out_f32) && a.xg && attn_step_oproj_ok(a.H, a.Hkv, D, a.nsplit, a.o_rows),
                     "decode attention + O projection: shape does not qualify (H*D = %d, %d rows, %d blocks)", a.H * D, a.o_rows, a.Hkv * a.nsplit);
         nvw = a.H * D / 512;
         a.o_rpw = oproj_rows_per_wave(a.H, a.Hkv, a.nsplit, a.o_rows);

@@ -351,13 +351,13 @@ bool attention_takes_oproj(omx_qwen3 m) {
     const char* e = getenv("OMX_ATTN_OPROJ");          // (read per call: tests flip it between engines of one process)
     const bool off = e && e[0] == '0';
     const omx_qwen3_config& c = m->cfg;
-    return !off && c.quant_bits == 0 && m->allreduce == nullptr && c.tp_size <= 1 &&
-           attn_step_oproj_ok(m->H, m->Hkv, c.head_dim, m->attn_nsplit, c.hidden_size);
+    // (tensor parallel: the rank's heads and columns -- the launch then leaves the f32 partial for the all-reduce)
+    return !off && c.quant_bits == 0 && attn_step_oproj_ok(m->H, m->Hkv, c.head_dim, m->attn_nsplit, c.hidden_size);
 }
 
 // the attention launch of layer l of a decode step (both the bf16 and the packed-weight step use the bf16 KV kernels);
 // resid / out != null: the layer's O projection + residual rides in the same launch (attention_takes_oproj)
-int enqueue_attention(omx_qwen3 m, int l, hipStream_t s, const bf16_t* resid = nullptr, bf16_t* out = nullptr) {
+int enqueue_attention(omx_qwen3 m, int l, hipStream_t s, const bf16_t* resid = nullptr, bf16_t* out = nullptr, float* out_f32 = nullptr) {
     const omx_qwen3_config& c = m->cfg;
     const int D = c.head_dim;
     const LayerW& L = m->layers[l];
@@ -379,8 +379,8 @@ int enqueue_attention(omx_qwen3 m, int l, hipStream_t s, const bf16_t* resid = n
         a.out = m->attn_out;
         a.abort_flag = m->wait_abort;
         a.trace = m->attn_trace ? m->attn_trace + (size_t)l * m->attn_nsplit * m->Hkv * 8 : nullptr;
-        if (resid && out) {
-            a.o_w = L.o; a.o_resid = resid; a.o_out = out; a.o_rows = c.hidden_size; a.xg = m->attn_xg;
+        if (resid && (out || out_f32)) {
+            a.o_w = L.o; a.o_resid = resid; a.o_out = out; a.o_out_f32 = out_f32; a.o_rows = c.hidden_size; a.xg = m->attn_xg;
         }
         return launch_attn_step(a, D, s);
     }
@@ -501,10 +501,14 @@ int enqueue_step(omx_qwen3 m, bool with_head) {
                 if (launch_gemv(a, PRO_RMSNORM, EPI_STORE, s)) return 1;
             if (pending) { bf16_t* t = h; h = hn; hn = t; pending = nullptr; }
         }
-        const bool fused_o = !tp && attention_takes_oproj(m);
+        const bool fused_o = attention_takes_oproj(m);
         time_next_launch(m, l, KC_ATTN);
-                if (enqueue_attention(m, l, s, fused_o ? h : nullptr, fused_o ? hn : nullptr)) return 1;   // [q/k RMSNorm + RoPE + cache append + split-KV SDPA + merge]  model.rs:172-210
-        if (fused_o) {   // [O projection + residual] happened in the attention launch
+                if (enqueue_attention(m, l, s, fused_o ? h : nullptr, fused_o && !tp ? hn : nullptr, fused_o && tp ? m->partial_a : nullptr)) return 1;   // [q/k RMSNorm + RoPE + cache append + split-KV SDPA + merge]  model.rs:172-210
+        if (fused_o && tp) {   // the rank's f32 partial of the O projection came out of the attention launch
+            OMX_REQUIRE(m->allreduce != nullptr, "tp_size > 1 but no communicator set (omx_qwen3_set_comm)");
+            OMX_REQUIRE(m->allreduce(m->partial_a, m->partial_a, hd, kNcclFloat32, kNcclSum, m->comm, s) == 0, "ncclAllReduce failed");
+            pending = m->partial_a;
+        } else if (fused_o) {   // [O projection + residual] happened in the attention launch
             bf16_t* t = h; h = hn; hn = t;
         } else {   // [O GEMV + residual]  model.rs:214,325
             GemvArgs a = {};

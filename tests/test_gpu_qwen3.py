@@ -613,3 +613,42 @@ def test_peer_store_allreduce_across_processes(omx, tmp_path, fused):
     assert outs[0] == res[0]["tokens"]
     print(f"peer all-reduce of 16 KB, two processes on one GPU: {res[0]['allreduce_16k_us']:.1f} us per call; "
           f"TP = 2 step (fused={fused}): {res[0]['step_ms']:.3f} ms")
+
+
+def test_tensor_parallel_oproj_in_attention_launch_is_bit_identical(omx, monkeypatch):
+    """Tensor parallel: the rank's f32 partial of the O projection comes out of the attention launch (attn_step.hip, o_out_f32) with
+    the arithmetic of the separate EPI_F32 GEMV -- two ranks on one GPU through the in-process communicator, tokens and last logits
+    equal with the O projection inside (default) and outside (OMX_ATTN_OPROJ=0) the launch.  The shape is one whose shards qualify
+    (16 heads / 8 KV heads over 2 ranks at head_dim 128: K = 1024 per rank)."""
+    from ominix_mlx_amd import comm, engine
+    cfg = dict(hidden_size=1024, num_hidden_layers=2, intermediate_size=3072, num_attention_heads=16, num_key_value_heads=8, head_dim=128,
+               vocab_size=4096, rms_norm_eps=1e-6, rope_theta=1e6, tie_word_embeddings=False)
+    prompt = synth.prompt_ids(24, cfg["vocab_size"])
+    monkeypatch.setenv("OMX_PREFILL_SERIAL", "1")
+
+    def run_all():
+        group = comm.LoopbackGroup(2, 1 << 20)
+        models = []
+        for r in range(2):
+            m = engine.Model(max_context=2304, tp_rank=r, tp_size=2, **cfg)
+            m.synth_weights()
+            m.set_comm(group.rank_comm(r), group.allreduce_fn)
+            models.append(m)
+
+        def run(r):
+            first = models[r].prefill(prompt)
+            toks = [int(first)] + [int(x) for x in models[r].decode(12)]
+            return toks, models[r].last_logits()
+
+        outs = comm.run_ranks(2, run, group)
+        for m in models:
+            m.close()
+        return outs
+
+    fused = run_all()
+    monkeypatch.setenv("OMX_ATTN_OPROJ", "0")
+    plain = run_all()
+    for r in range(2):
+        assert fused[r][0] == plain[r][0]
+        np.testing.assert_array_equal(fused[r][1], plain[r][1])
+    assert fused[0][0] == fused[1][0]

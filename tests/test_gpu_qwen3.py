@@ -652,3 +652,23 @@ def test_tensor_parallel_oproj_in_attention_launch_is_bit_identical(omx, monkeyp
         assert fused[r][0] == plain[r][0]
         np.testing.assert_array_equal(fused[r][1], plain[r][1])
     assert fused[0][0] == fused[1][0]
+
+
+def test_tensor_parallel_at_real_shard_shapes(omx):
+    """Pre-flight of `bench.py --gpus N` (tools/tp_shapes_check.py): 2 layers of the REAL Qwen3-8B shard shapes at TP = 2, 4, 8 -- N
+    engines on N host threads of one GPU through the in-process communicator -- batched TP prefill of 192 tokens + 12 decode steps.
+    All ranks emit the same tokens, and the first token equals the single-GPU engine's (later ones may part at near-ties)."""
+    import ast
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "tools", "tp_shapes_check.py")], capture_output=True, text=True, timeout=900,
+                       stdin=subprocess.DEVNULL)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("tp")]
+    assert len(lines) == 4
+    ref = ast.literal_eval(lines[0].split(None, 1)[1])
+    for ln in lines[1:]:
+        assert "ranks agree: True" in ln
+        toks = ast.literal_eval(ln.split("|")[0].split(None, 1)[1])
+        assert toks[0] == ref[0]

@@ -48,7 +48,7 @@ class MelFrontend:
         check(lib.omx_mel_frontend_create(ctypes.byref(self._h), ctypes.byref(self.cfg)))
 
     def __del__(self):
-        if not sys.is_finalizing() and getattr(self, "_h", None) is not None and self._h.value:
+        if sys is not None and not sys.is_finalizing() and getattr(self, "_h", None) is not None and self._h.value:
             lib.omx_mel_frontend_destroy(self._h)
             self._h = c_void_p()
 
@@ -87,7 +87,7 @@ class WhisperMelFrontend:
         check(lib.omx_whisper_mel_create(ctypes.byref(self._h), sample_rate, n_mels, n_fft, hop_length))
 
     def __del__(self):
-        if not sys.is_finalizing() and getattr(self, "_h", None) is not None and self._h.value:
+        if sys is not None and not sys.is_finalizing() and getattr(self, "_h", None) is not None and self._h.value:
             lib.omx_mel_frontend_destroy(self._h)
             self._h = c_void_p()
 
@@ -112,7 +112,7 @@ class SenseVoiceMelFrontend:
         check(lib.omx_sensevoice_mel_create(ctypes.byref(self._h), sample_rate, n_mels, n_fft, hop_length, max_length))
 
     def __del__(self):
-        if not sys.is_finalizing() and getattr(self, "_h", None) is not None and self._h.value:
+        if sys is not None and not sys.is_finalizing() and getattr(self, "_h", None) is not None and self._h.value:
             lib.omx_mel_frontend_destroy(self._h)
             self._h = c_void_p()
 

@@ -302,7 +302,7 @@ class Array:
         self.h = handle
 
     def __del__(self):
-        if not sys.is_finalizing() and getattr(self, "h", None) is not None and self.h.ctx:
+        if sys is not None and not sys.is_finalizing() and getattr(self, "h", None) is not None and self.h.ctx:
             lib.mlx_array_free(self.h)
             self.h = mlx_array(None)
 

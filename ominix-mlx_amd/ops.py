@@ -51,7 +51,7 @@ class Tensor:
             self._owned = False
 
     def __del__(self):
-        if sys.is_finalizing():
+        if sys is None or sys.is_finalizing():   # (module globals are already None late in shutdown)
             return
         if getattr(self, "_owned", False) and self.ptr:
             lib.omx_free(self.ptr)

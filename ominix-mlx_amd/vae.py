@@ -111,7 +111,7 @@ class VaeDecoder:
         self._keep = []
 
     def __del__(self):
-        if not sys.is_finalizing() and getattr(self, "_h", None) is not None and self._h.value:
+        if sys is not None and not sys.is_finalizing() and getattr(self, "_h", None) is not None and self._h.value:
             lib.omx_vae_decoder_destroy(self._h)
             self._h = c_void_p()
 

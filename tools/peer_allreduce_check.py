@@ -3,7 +3,7 @@
 and the stores cross xGMI).  Each rank: self-test against the rank-ordered sum, latency of a 4096-float reduction, then a
 tensor-parallel greedy decode of a small Qwen3 through the engine with every all-reduce (hidden partials, argmax key) on the peer
 path -- serial prefill, so no call needs RCCL.  Rank r writes <out>/rank<r>.json.
-usage: python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1 --master-port P tools/peer_allreduce_check.py <out dir>"""
+usage: python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1 --master-port P tools/peer_allreduce_check.py <out dir> [8b]"""
 import json
 import os
 import sys
@@ -48,6 +48,10 @@ res["aborted_after_loop"] = pc.aborted()
 
 cfg = dict(hidden_size=1024, num_hidden_layers=2, intermediate_size=3072, num_attention_heads=8, num_key_value_heads=2, head_dim=128,
            vocab_size=4096, rms_norm_eps=1e-6, rope_theta=1e6, tie_word_embeddings=False)
+if len(sys.argv) > 2 and sys.argv[2] == "8b":      # two layers of the real Qwen3-8B shapes (the shards bench.py --gpus N runs)
+    import bench
+    cfg = dict(bench.QWEN3_8B)
+    cfg["num_hidden_layers"] = 2
 m = engine.Model(max_context=256, tp_rank=rank, tp_size=world, **cfg)
 m.synth_weights()
 m.set_comm(pc.comm, pc.fn)

@@ -38,6 +38,8 @@ __device__ __forceinline__ float dot8_rows(const u32x4 w, const u32x4 xp, float 
 // holds both factors of two activation columns.
 // RPW: output rows per wave.  4 where that still gives every CU two blocks or more; 2 for the narrow outputs (N = hidden: 256 blocks
 // of 4 would leave one block per CU with nothing to overlap its load -> multiply phases; 5-row verify pass 5.67 -> 5.26 ms together with the unrolled RMSNorm)
+// (Blocks of 8 waves for the wide launches -- gate / up as 768 resident blocks instead of 1.5 rounds of 1536, the activation rows staged
+//  half as often -- measured 2-3 % SLOWER on the verify pass: 3.91 / 5.43 / 6.87 ms against 3.84 / 5.31 / 6.66 at 2 / 5 / 8 rows.)
 template <int T, bool SEG, int kRowsRPW>
 __global__ __launch_bounds__(256) void gemv_rows_kernel(const RowsArgs a) {
     static_assert(!SEG || kRowsRPW == 4 || kRowsRPW == 2, "segments are cut on multiples of the wave's rows");

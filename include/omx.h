@@ -290,6 +290,12 @@ int omx_moe_block_partial_ep(float* partial, const void* x, const void* norm_w, 
                              const void* w_gate, const void* w_up, const void* w_down, int n_tokens, int hidden, int inter,
                              int n_experts, int top_k, int mode, int norm_topk_prob, int e_lo, int e_n, omx_stream stream);
 /* the same on a quantised checkpoint (mixtral-mlx/src/model.rs:560-600): router and expert stacks as MLX triplets */
+/* one token, bf16 experts: the block WITHOUT its weighted sum -- partials[j, :] (f32) = bf16(bf16(y_j) * score_j) of the top_k routed
+ * experts in slot order; the caller's next streaming GEMV folds x := bf16(resid + bf16(sum_j partials[j])) in its prologue (engine-internal:
+ * csrc/gemv.hpp GemvArgs::x_partial_n).  Returns 2 when the shape does not take the batched-GEMV route.                              */
+int omx_moe_block_partials(float* partials, const void* x, const void* norm_w, float eps, void* xn, const void* gate_w, const void* w_gate,
+                           const void* w_up, const void* w_down, int hidden, int inter, int n_experts, int top_k, int mode,
+                           int norm_topk_prob, omx_stream stream);
 int omx_moe_block_forward_q(void* out, const void* resid, const void* x, const void* norm_w, float eps, void* xn,
                             const void* q_router, const void* s_router, const void* b_router, const void* q_gate, const void* s_gate,
                             const void* b_gate, const void* q_up, const void* s_up, const void* b_up, const void* q_down,

@@ -187,6 +187,7 @@ struct omx_qwen3_ {
     bf16_t *h = nullptr, *h2 = nullptr, *qkv = nullptr, *attn_out = nullptr, *act = nullptr, *logits = nullptr;
     bf16_t *moe_xn = nullptr, *moe_out = nullptr;   // MoE feed-forward: normalised input row, block output
     float *partial_a = nullptr, *partial_b = nullptr;   // TP: f32 partial sums awaiting all-reduce
+    float* moe_partials = nullptr;                      // MoE decode: [top_k, hidden] weighted expert outputs awaiting the next GEMV's fold
     unsigned long long *argmax_partials = nullptr, *argmax_key = nullptr;
     int n_argmax_partials = 0;
     unsigned *step_seq = nullptr, *wait_abort = nullptr;   // step sequence number (granule tags), word a gather that gave up raises
@@ -482,7 +483,13 @@ int enqueue_step(omx_qwen3 m, bool with_head) {
     OMX_LAUNCH_CHECK();
     bf16_t* h = m->h;      // residual stream entering the layer
     bf16_t* hn = m->h2;    // ping-pong partner
-    const float* pending = nullptr;   // TP: all-reduced f32 partial not yet folded into h
+    const float* pending = nullptr;   // TP: all-reduced f32 partial not yet folded into h; MoE: the experts' weighted outputs
+    int pending_n = 1;                //   ... how many f32 vectors `pending` holds (summed in order by the consumer's prologue)
+    // MoE block without its weighted-sum launch (the next GEMV folds the experts' outputs in): every block of that GEMV reads top_k
+    // extra f32 vectors, so by default only for top-2 routing (Mixtral-8x7B: 206.4 -> 207.9 tok/s); OMX_MOE_FOLD=1 forces it, 0 disables
+    const char* fold_env = getenv("OMX_MOE_FOLD");
+    const bool moe_fold = c.num_experts > 0 && !ep && !tp &&
+                          (fold_env ? fold_env[0] == '1' : c.num_experts_per_tok <= 2);
     for (int l = 0; l < c.num_hidden_layers; ++l) {
         const LayerW& L = m->layers[l];
         {   // [RMSNorm + QKV GEMV]  model.rs:168-170,324
@@ -492,14 +499,14 @@ int enqueue_step(omx_qwen3 m, bool with_head) {
             a.w2 = L.v; a.n2 = m->Hkv * D;
             a.N = (m->H + 2 * m->Hkv) * D;
             a.K = hd;
-            a.x = h; a.x_partial = pending; a.x_out = pending ? hn : nullptr;
+            a.x = h; a.x_partial = pending; a.x_partial_n = pending_n; a.x_out = pending ? hn : nullptr;
             a.norm_w = L.in_ln; a.eps = c.rms_norm_eps;
             a.out = m->qkv;
             a.out_bias = L.qkv_bias;
             a.rows_per_wave = rpw_env("OMX_GEMV_RPW_QKV");
             time_next_launch(m, l, KC_QKV);
                 if (launch_gemv(a, PRO_RMSNORM, EPI_STORE, s)) return 1;
-            if (pending) { bf16_t* t = h; h = hn; hn = t; pending = nullptr; }
+            if (pending) { bf16_t* t = h; h = hn; hn = t; pending = nullptr; pending_n = 1; }
         }
         const bool fused_o = attention_takes_oproj(m);
         time_next_launch(m, l, KC_ATTN);
@@ -545,6 +552,13 @@ int enqueue_step(omx_qwen3 m, bool with_head) {
         if (c.num_experts > 0) {
             // [RMSNorm] [router] [expert gate/up + SwiGLU] [expert down] [weighted sum] [+ residual]
             // (qwen3_moe.rs:475-503 / mixtral model.rs:296-308, :343-344)
+            if (moe_fold) {   // ... without the last two launches: the down GEMVs store the weighted outputs, the next GEMV folds them in
+                const int rc = omx_moe_block_partials(m->moe_partials, h, L.post_ln, c.rms_norm_eps, m->moe_xn, L.moe_gate, L.moe_wg, L.moe_wu,
+                                                      L.moe_wd, hd, c.moe_intermediate_size, c.num_experts, c.num_experts_per_tok, c.moe_mode,
+                                                      c.norm_topk_prob, s);
+                if (rc == 0) { pending = m->moe_partials; pending_n = c.num_experts_per_tok; continue; }
+                if (rc != 2) return 1;
+            }
             if (omx_moe_block_forward(hn, h, h, L.post_ln, c.rms_norm_eps, m->moe_xn, L.moe_gate, L.moe_wg, L.moe_wu, L.moe_wd, 1, hd,
                                       c.moe_intermediate_size, c.num_experts, c.num_experts_per_tok, c.moe_mode, c.norm_topk_prob, s))
                 return 1;
@@ -554,13 +568,13 @@ int enqueue_step(omx_qwen3 m, bool with_head) {
         {   // [RMSNorm + gate/up GEMV + SwiGLU]  model.rs:263-265,326
             GemvArgs a = {};
             a.w0 = L.gate; a.w1 = L.up; a.n0 = m->I; a.N = m->I; a.K = hd;
-            a.x = h; a.x_partial = pending; a.x_out = pending ? hn : nullptr;
+            a.x = h; a.x_partial = pending; a.x_partial_n = pending_n; a.x_out = pending ? hn : nullptr;
             a.norm_w = L.post_ln; a.eps = c.rms_norm_eps;
             a.out = m->act;
             a.rows_per_wave = rpw_env("OMX_GEMV_RPW_GU");
             time_next_launch(m, l, KC_GATE_UP);
                 if (launch_gemv(a, PRO_RMSNORM, EPI_SWIGLU, s)) return 1;
-            if (pending) { bf16_t* t = h; h = hn; hn = t; pending = nullptr; }
+            if (pending) { bf16_t* t = h; h = hn; hn = t; pending = nullptr; pending_n = 1; }
         }
         {   // [down GEMV + residual]  model.rs:266,327
             GemvArgs a = {};
@@ -585,7 +599,7 @@ int enqueue_step(omx_qwen3 m, bool with_head) {
     if (with_head) {   // [final RMSNorm + lm_head GEMV + argmax]  model.rs:423,480-489,733-735
         GemvArgs a = {};
         a.w0 = m->lm_head; a.n0 = m->V; a.N = m->V; a.K = hd;
-        a.x = h; a.x_partial = pending; a.x_out = nullptr;
+        a.x = h; a.x_partial = pending; a.x_partial_n = pending_n; a.x_out = nullptr;
         a.norm_w = m->final_norm; a.eps = c.rms_norm_eps;
         a.out = m->logits;
         a.argmax_slot = m->argmax_partials;
@@ -987,6 +1001,7 @@ int omx_qwen3_create(omx_qwen3* out, const omx_qwen3_config* cfg) {
         dev_alloc(m, &m->partial_a, (size_t)c.hidden_size) || dev_alloc(m, &m->partial_b, (size_t)c.hidden_size) ||
         dev_alloc(m, &m->argmax_key, 1))
         return 1;
+    if (c.num_experts > 0 && dev_alloc(m, &m->moe_partials, (size_t)c.num_experts_per_tok * c.hidden_size)) return 1;
     m->prompt_cap = m->cap;
     if (dev_alloc(m, &m->prompt_dev, (size_t)m->prompt_cap + 1)) return 1;
     m->n_argmax_partials = m->cfg.quant_bits ? qgemv_grid(m->V) : gemv_grid(m->V, c.hidden_size, EPI_ARGMAX, 0);

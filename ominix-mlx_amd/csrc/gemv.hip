@@ -47,7 +47,7 @@ __device__ __forceinline__ void epilogue(const GemvArgs& a, int row, float v0, f
         // (`best` carries the call's tag, read ONCE before the first weight load: a load here would wait behind -- drain -- the
         //  next batch's prefetch; the total is stored by peer_finish_rows)
         if (a.peer) peer_store_word(a.peer, (unsigned)best, row, __float_as_uint(v0));
-        else reinterpret_cast<float*>(a.out)[row] = v0;
+        else reinterpret_cast<float*>(a.out)[row] = a.out_scale ? round_bf16(round_bf16(v0) * a.out_scale_f) : v0;
     } else if (EPI == EPI_RESIDUAL) {
         reinterpret_cast<bf16_t*>(a.out)[row] = f32_to_bf16(bf16_to_f32(a.resid[row]) + round_bf16(v0));
     } else if (EPI == EPI_SWIGLU) {
@@ -86,6 +86,9 @@ __global__ __launch_bounds__(kBlock) void gemv_kernel(const GemvArgs a_in) {
     // batched / expert-selected form (MoE decode): blockIdx.y picks the activation row, the output row
     // block and, through a device index array, the expert whose weights are streamed
     GemvArgs a = a_in;
+    if (EPI == EPI_F32) {
+        if (a_in.out_scale) a.out_scale_f = bf16_to_f32(a_in.out_scale[blockIdx.y]);
+    }
     if (a_in.n_batch > 1 || a_in.w_sel) {
         const int by = blockIdx.y;
         a.x = a_in.x + (size_t)(by / a_in.x_div) * a_in.x_bstride;
@@ -207,7 +210,13 @@ __global__ __launch_bounds__(kBlock) void gemv_kernel(const GemvArgs a_in) {
                 if (a.x_partial) {
                     const f32x4 p0 = *(reinterpret_cast<const f32x4*>(a.x_partial) + 2 * v);
                     const f32x4 p1 = *(reinterpret_cast<const f32x4*>(a.x_partial) + 2 * v + 1);
-                    const float pp[8] = {p0[0], p0[1], p0[2], p0[3], p1[0], p1[1], p1[2], p1[3]};
+                    float pp[8] = {p0[0], p0[1], p0[2], p0[3], p1[0], p1[1], p1[2], p1[3]};
+                    for (int j = 1; j < a.x_partial_n; ++j) {   // MoE: the experts' weighted outputs, summed in slot order
+                        const f32x4* pj = reinterpret_cast<const f32x4*>(a.x_partial + (size_t)j * K) + 2 * v;
+                        const f32x4 q0 = pj[0], q1 = pj[1];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { pp[e] += q0[e]; pp[4 + e] += q1[e]; }
+                    }
 #pragma unroll
                     for (int q = 0; q < 4; ++q)
                         raw[q] = pack_bf16(bf16lo(raw[q]) + round_bf16(pp[2 * q]),
@@ -312,6 +321,9 @@ __global__ __launch_bounds__(kBlock) void gemv_kernel(const GemvArgs a_in) {
 template <int PRO, int EPI>
 __global__ __launch_bounds__(kBlock) void gemv_generic_kernel(const GemvArgs a_in) {
     GemvArgs a = a_in;
+    if (EPI == EPI_F32) {
+        if (a_in.out_scale) a.out_scale_f = bf16_to_f32(a_in.out_scale[blockIdx.y]);
+    }
     if (a_in.n_batch > 1 || a_in.w_sel) {
         const int by = blockIdx.y;
         a.x = a_in.x + (size_t)(by / a_in.x_div) * a_in.x_bstride;
@@ -342,7 +354,13 @@ __global__ __launch_bounds__(kBlock) void gemv_generic_kernel(const GemvArgs a_i
             if (a.x_partial) {
                 const f32x4 p0 = *(reinterpret_cast<const f32x4*>(a.x_partial) + 2 * v);
                 const f32x4 p1 = *(reinterpret_cast<const f32x4*>(a.x_partial) + 2 * v + 1);
-                const float pp[8] = {p0[0], p0[1], p0[2], p0[3], p1[0], p1[1], p1[2], p1[3]};
+                float pp[8] = {p0[0], p0[1], p0[2], p0[3], p1[0], p1[1], p1[2], p1[3]};
+                for (int j = 1; j < a.x_partial_n; ++j) {
+                    const f32x4* pj = reinterpret_cast<const f32x4*>(a.x_partial + (size_t)j * K) + 2 * v;
+                    const f32x4 q0 = pj[0], q1 = pj[1];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { pp[e] += q0[e]; pp[4 + e] += q1[e]; }
+                }
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
                     raw[q] = pack_bf16(bf16lo(raw[q]) + round_bf16(pp[2 * q]), bf16hi(raw[q]) + round_bf16(pp[2 * q + 1]));

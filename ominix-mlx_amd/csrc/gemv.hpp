@@ -61,6 +61,13 @@ struct GemvArgs {
     // all inboxes as a tagged granule, the wave then sums the ranks' words of its rows in rank order and stores the f32 total
     // (peer.hpp / peer_allreduce.hip: the same protocol and sequence number as the standalone all-reduce kernel, one launch less)
     const struct PeerDev* peer;
+    // MoE decode without the weighted-sum launch: the expert down projections (batched, EPI_F32) store
+    // z_j = bf16(bf16(y_j) * score_j) as f32 (out_scale: [n_batch] scores; out_scale_f is the kernel's own copy of its entry's), and the
+    // next consumer folds x := bf16(x + bf16(z_0 + z_1 + ...)) -- x_partial_n vectors of K floats at x_partial, summed in order
+    // (0 or 1: the one vector of the tensor-parallel step).  Same roundings and order as moe_combine_kernel (moe.hip).
+    const bf16_t* out_scale;
+    float out_scale_f;
+    int x_partial_n;
 };
 
 int launch_gemv(const GemvArgs& a, int pro, int epi, hipStream_t s);

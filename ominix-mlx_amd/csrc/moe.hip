@@ -325,6 +325,8 @@ struct BlockFusion {            // decoder-block glue folded into the MoE launch
     float eps = 0.f;
     void* xn = nullptr;         // [n_tokens, hidden] scratch receiving the normalised rows
     const void* resid = nullptr;
+    float* partials = nullptr;  // decode (bf16 experts): [top_k, hidden] f32 receiving bf16(bf16(y_j) * score_j) from the down GEMVs'
+                                // epilogue INSTEAD of the weighted-sum launch; the caller's next GEMV folds them into the residual
 };
 
 static int moe_forward_impl(void* out, const void* x, const void* gate_w, const void* w_gate, const void* w_up,
@@ -417,6 +419,11 @@ static int moe_forward_impl(void* out, const void* x, const void* gate_w, const 
         d.x = gbuf; d.out = ybuf;
         d.n_batch = slots; d.x_div = 1; d.x_bstride = inter; d.out_bstride_bytes = (size_t)hidden * 2;
         d.w_sel = inds; d.w_estride = (size_t)hidden * inter;
+        if (bf && bf->partials && n_tokens == 1) {
+            d.out = bf->partials; d.out_bstride_bytes = (size_t)hidden * 4; d.out_scale = scores;
+            if (launch_gemv(d, PRO_NONE, EPI_F32, s)) return 1;
+            return 0;
+        }
         if (launch_gemv(d, PRO_NONE, EPI_STORE, s)) return 1;
         moe_combine_kernel<<<n_tokens, 256, 0, s>>>((bf16_t*)out, ybuf, scores, nullptr, hidden, top_k, resid);
         OMX_LAUNCH_CHECK();
@@ -466,6 +473,20 @@ extern "C" int omx_moe_block_forward(void* out, const void* resid, const void* x
     bf.norm_w = norm_w; bf.eps = eps; bf.xn = xn; bf.resid = resid;
     return moe_forward_impl(out, x, gate_w, w_gate, w_up, w_down, nullptr, n_tokens, hidden, inter, n_experts, top_k, mode,
                             norm_topk_prob, nullptr, nullptr, stream, &bf);
+}
+
+/* one token, bf16 experts: the block WITHOUT its weighted sum -- partials[j, :] (f32) = bf16(bf16(y_j) * score_j) for the top_k routed
+ * experts in slot order; out = bf16(resid + bf16(sum_j partials[j])) is left to the caller's next GEMV prologue (GemvArgs::x_partial_n).
+ * Returns 2 when the shape does not take the batched-GEMV route (the caller then uses omx_moe_block_forward).                       */
+extern "C" int omx_moe_block_partials(float* partials, const void* x, const void* norm_w, float eps, void* xn, const void* gate_w,
+                                      const void* w_gate, const void* w_up, const void* w_down, int hidden, int inter, int n_experts,
+                                      int top_k, int mode, int norm_topk_prob, omx_stream stream) {
+    OMX_REQUIRE(partials && norm_w && xn, "omx_moe_block_partials: null tensor");
+    if (!(top_k <= 32 && omx::gemv_k_supported(hidden, false) && omx::gemv_k_supported(inter, false))) return 2;
+    BlockFusion bf;
+    bf.norm_w = norm_w; bf.eps = eps; bf.xn = xn; bf.resid = x; bf.partials = partials;
+    return moe_forward_impl(partials, x, gate_w, w_gate, w_up, w_down, nullptr, 1, hidden, inter, n_experts, top_k, mode, norm_topk_prob,
+                            nullptr, nullptr, stream, &bf);
 }
 
 /* decoder-block form on a quantised checkpoint (mixtral-mlx/src/model.rs:560-600: gate = QuantizedLinear, switch_mlp =

@@ -229,3 +229,36 @@ def test_expert_parallel_load_from_bf16_checkpoint_files(omx, tmp_path, monkeypa
     for m in models:
         m.close()
     group.close()
+
+
+@pytest.mark.parametrize("name", ["mixtral", "qwen3_moe"])
+def test_moe_weighted_sum_folded_into_next_gemv_is_bit_identical(omx, monkeypatch, name):
+    """The decode step's MoE block without its weighted-sum launch (engine.hip moe_fold: the expert down GEMVs store
+    bf16(bf16(y_j) * score_j) as f32, the next GEMV's prologue folds bf16(resid + bf16(sum_j)) -- gemv.hip x_partial_n, moe.hip
+    omx_moe_block_partials) against the block with moe_combine_kernel (OMX_MOE_FOLD=0): same roundings, same order -> same tokens and
+    the same last logits."""
+    from ominix_mlx_amd import engine
+    cfgs = {"mixtral": dict(hidden_size=512, num_hidden_layers=3, intermediate_size=1024, num_attention_heads=8, num_key_value_heads=2,
+                            head_dim=64, vocab_size=2048, rms_norm_eps=1e-5, rope_theta=1e6, tie_word_embeddings=False,
+                            num_experts=8, num_experts_per_tok=2, moe_intermediate_size=1024, moe_mode="mixtral", norm_topk_prob=0, qk_norm=False),
+            "qwen3_moe": dict(hidden_size=512, num_hidden_layers=2, intermediate_size=1024, num_attention_heads=8, num_key_value_heads=2,
+                              head_dim=64, vocab_size=2048, rms_norm_eps=1e-6, rope_theta=1e6, tie_word_embeddings=False,
+                              num_experts=16, num_experts_per_tok=4, moe_intermediate_size=512, moe_mode="qwen3_moe", norm_topk_prob=1)}
+    from oracle import synth
+    prompt = synth.prompt_ids(24, 2048)
+
+    def run():
+        m = engine.Model(max_context=128, **cfgs[name])
+        m.synth_weights()
+        toks = [int(m.prefill(prompt))] + [int(t) for t in m.decode(16)]
+        logits = m.last_logits()
+        m.close()
+        return toks, logits
+
+    monkeypatch.setenv("OMX_PREFILL_SERIAL", "1")      # the prompt through the step too
+    monkeypatch.setenv("OMX_MOE_FOLD", "1")            # (default: top-2 routing only)
+    folded = run()
+    monkeypatch.setenv("OMX_MOE_FOLD", "0")
+    plain = run()
+    assert folded[0] == plain[0]
+    np.testing.assert_array_equal(folded[1], plain[1])

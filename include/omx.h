@@ -231,9 +231,12 @@ int omx_qwen3_decode_path(omx_qwen3 m, int* path);
  * 100 MHz wall clock; host receives [layers][attention splits][kv heads][8], *blocks = splits * kv heads     */
 int omx_qwen3_debug_trace_step(omx_qwen3 m, unsigned long long* host, size_t n_words, int* blocks);
 /* measurement hook: `steps` real decode steps run eagerly, every launch of the per-layer kernels carrying its own HIP event pair
- * (the dispatch's begin / end timestamps on the step's stream); us[6] = average microseconds of {QKV GEMV, attention, O GEMV,
- * gate/up + SwiGLU GEMV, down GEMV, lm_head}.  bench.py's roofline.achieved is the gate/up figure.  Dense bf16 single-rank models. */
+ * (the dispatch's begin / end timestamps on the step's stream); us[7] = average microseconds of {QKV GEMV, attention, O GEMV,
+ * gate/up + SwiGLU GEMV, down GEMV, lm_head, persistent step launch (all layers; the five per-layer figures are 0 then)}.  bench.py's roofline.achieved is the gate/up figure.  Dense bf16 single-rank models. */
 int omx_qwen3_time_step_kernels(omx_qwen3 m, int steps, float* us);
+/* debug hook (tools/step_engine_trace.py): ONE eager decode step on the persistent engine (csrc/step_engine.hip, OMX_STEP_ENGINE=1)
+ * with per-CU wall-clock stamps; host receives [CUs][64] words, *cus = CUs of the device */
+int omx_qwen3_debug_trace_engine(omx_qwen3 m, unsigned long long* host, size_t n_words, int* cus);
 
 /* =====================================================================================
  * MLX affine group quantisation (the reference's flagship checkpoint format).

@@ -33,6 +33,7 @@
 #include "quant.hpp"
 #include "launch_timing.hpp"
 #include "peer.hpp"
+#include "step_engine.hpp"
 
 namespace omx {
 namespace {
@@ -218,6 +219,15 @@ struct omx_qwen3_ {
            *pf_qt = nullptr, *pf_attn = nullptr, *pf_g = nullptr, *pf_u = nullptr;
     float last_prefill_ms = 0.f;
 
+    // persistent decode step (step_engine.hip): the layers of a token in one launch
+    int cus = 0;                               // compute units of the device: one resident workgroup each
+    std::vector<StepEngineLayer> se_layers_host;
+    StepEngineLayer* se_layers = nullptr;
+    uint64_t* se_gran = nullptr;               // granule buffers of the five vector edges
+    unsigned long long* se_trace = nullptr;    // set for one eager step by omx_qwen3_debug_trace_engine
+    bool se_disabled = false;                  // a step gave up waiting (a workgroup was not resident): back to one launch per op
+    bool oproj_disabled = false;               // the same for the O projection inside the attention launch
+
     hipGraphExec_t g_full = nullptr, g_nohead = nullptr;
     bool eager = false;          // fallback when stream capture is unavailable (e.g. a collective refuses capture)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -342,6 +352,17 @@ int resolve_weights(omx_qwen3 m) {
     } else if (get("lm_head.weight", &m->lm_head)) {
         return 1;
     }
+    if (m->cfg.num_experts == 0) {   // layer table of the persistent step (step_engine.hip)
+        m->se_layers_host.resize(m->cfg.num_hidden_layers);
+        for (int i = 0; i < m->cfg.num_hidden_layers; ++i) {
+            const LayerW& L = m->layers[i];
+            m->se_layers_host[i] = StepEngineLayer{L.q, L.k, L.v, L.o, L.gate, L.up, L.down, L.in_ln, L.post_ln, L.q_norm, L.k_norm,
+                                                   m->kcache[i], m->vcache[i]};
+        }
+        if (!m->se_layers && dev_alloc(m, &m->se_layers, m->se_layers_host.size())) return 1;
+        OMX_HIP_CHECK(hipMemcpyAsync(m->se_layers, m->se_layers_host.data(), m->se_layers_host.size() * sizeof(StepEngineLayer),
+                                     hipMemcpyHostToDevice, m->stream));
+    }
     m->weights_resolved = true;
     return 0;
 }
@@ -353,7 +374,9 @@ bool attention_takes_oproj(omx_qwen3 m) {
     const bool off = e && e[0] == '0';
     const omx_qwen3_config& c = m->cfg;
     // (tensor parallel: the rank's heads and columns -- the launch then leaves the f32 partial for the all-reduce)
-    return !off && c.quant_bits == 0 && attn_step_oproj_ok(m->H, m->Hkv, c.head_dim, m->attn_nsplit, c.hidden_size);
+    // every block of that launch waits on others: all Hkv * nsplit of them must be resident, one per CU
+    return !off && !m->oproj_disabled && c.quant_bits == 0 && m->Hkv * m->attn_nsplit <= m->cus &&
+           attn_step_oproj_ok(m->H, m->Hkv, c.head_dim, m->attn_nsplit, c.hidden_size);
 }
 
 // the attention launch of layer l of a decode step (both the bf16 and the packed-weight step use the bf16 KV kernels);
@@ -456,6 +479,48 @@ int enqueue_step_quant(omx_qwen3 m, bool with_head) {
     return 0;
 }
 
+// The layers of the step as ONE persistent launch (csrc/step_engine.hip): dense bf16 model on a single rank, a shape the engine's
+// consumers reproduce bit for bit, every CU of the device free for one resident workgroup.  OMX_STEP_ENGINE=0 keeps one launch per op.
+bool step_engine_takes(omx_qwen3 m) {
+    const char* e = getenv("OMX_STEP_ENGINE");         // (read per call: tests flip it between engines of one process)
+    const bool on = e ? e[0] == '1' : false;
+    const omx_qwen3_config& c = m->cfg;
+    return on && !m->se_disabled && c.quant_bits == 0 && c.num_experts == 0 && c.tp_size == 1 && c.ep_size <= 1 && m->allreduce == nullptr &&
+           !c.attention_bias && m->se_gran != nullptr && m->cus > 0 &&
+           step_engine_ok(c.hidden_size, m->H, m->Hkv, c.head_dim, m->I, m->attn_nsplit, m->cus);
+}
+
+static int env_int(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return v ? atoi(v) : dflt;
+}
+
+// [embedding + every layer] in one launch; the residual stream after the last layer lands in m->h2
+int enqueue_step_engine(omx_qwen3 m, hipStream_t s) {
+    const omx_qwen3_config& c = m->cfg;
+    const int D = c.head_dim, hd = c.hidden_size;
+    StepEngineArgs a = {};
+    a.layers = m->se_layers;
+    a.L = c.num_hidden_layers; a.hidden = hd; a.H = m->H; a.Hkv = m->Hkv; a.D = D; a.I = m->I; a.cap = m->cap;
+    a.eps = c.rms_norm_eps; a.scale = 1.0f / sqrtf((float)D);
+    a.embed = m->embed; a.st = m->st; a.seq_ptr = m->step_seq;
+    a.rope_cos = m->rope_cos; a.rope_sin = m->rope_sin;
+    a.chunk = m->attn_chunk; a.nsplit = m->attn_nsplit;
+    uint64_t* g = m->se_gran;
+    a.g_x = g; g += hd / 2;
+    a.g_x1 = g; g += hd / 2;
+    a.g_qkv = g; g += (size_t)(m->H + 2 * m->Hkv) * D / 2;
+    a.g_attn = g; g += (size_t)m->H * D / 2;
+    a.g_act = g;
+    a.g_part = m->attn_gran;
+    a.h_out = m->h2;
+    a.abort_flag = m->wait_abort;
+    a.nsweep = env_int("OMX_SE_NSWEEP", 1);
+    a.inflight = env_int("OMX_SE_INFLIGHT", 2);
+    a.trace = m->se_trace;
+    return launch_step_engine(a, m->cus, s);
+}
+
 // enqueue one decode step on m->stream.  with_head=false: prompt token whose logits nobody reads.
 // tuning knob: OMX_GEMV_RPW_<QKV|O|GU|DOWN>=n overrides the rows-per-wave (per block for K-split kernels) heuristic of gemv.hip
 static int rpw_env(const char* name) {
@@ -464,11 +529,12 @@ static int rpw_env(const char* name) {
 }
 
 // kernel classes timed by omx_qwen3_time_step_kernels: an event pair armed for the launch that follows (launch_timing.hpp)
-enum { KC_QKV = 0, KC_ATTN, KC_O, KC_GATE_UP, KC_DOWN, KC_HEAD, KC_COUNT };
+enum { KC_QKV = 0, KC_ATTN, KC_O, KC_GATE_UP, KC_DOWN, KC_HEAD, KC_ENGINE, KC_COUNT };
 constexpr int kLayerClasses = KC_HEAD;
 inline void time_next_launch(omx_qwen3 m, int layer, int cls) {
     if (!m->kernel_events) return;
-    const size_t i = (cls == KC_HEAD ? (size_t)m->cfg.num_hidden_layers * kLayerClasses : (size_t)layer * kLayerClasses + cls) * 2;
+    const size_t i = (cls == KC_HEAD ? (size_t)m->cfg.num_hidden_layers * kLayerClasses
+                      : cls == KC_ENGINE ? (size_t)m->cfg.num_hidden_layers * kLayerClasses + 1 : (size_t)layer * kLayerClasses + cls) * 2;
     arm_launch_events((*m->kernel_events)[i], (*m->kernel_events)[i + 1]);
 }
 
@@ -479,10 +545,16 @@ int enqueue_step(omx_qwen3 m, bool with_head) {
     const int hd = c.hidden_size, D = c.head_dim;
     const bool ep = c.ep_size > 1;                               // expert parallel: attention replicated, one all-reduce per MoE block
     const bool tp = !ep && (c.tp_size > 1 || m->allreduce != nullptr);   // a 1-rank communicator exercises the TP path
-    embed_kernel<<<2, 256, 0, s>>>(m->h, m->embed, m->st, hd, m->step_seq, m->rope_cur, m->rope_cos, m->rope_sin, D / 2);
-    OMX_LAUNCH_CHECK();
-    bf16_t* h = m->h;      // residual stream entering the layer
-    bf16_t* hn = m->h2;    // ping-pong partner
+    const bool engine = step_engine_takes(m);
+    if (engine) {
+        time_next_launch(m, 0, KC_ENGINE);
+        if (enqueue_step_engine(m, s)) return 1;
+    } else {
+        embed_kernel<<<2, 256, 0, s>>>(m->h, m->embed, m->st, hd, m->step_seq, m->rope_cur, m->rope_cos, m->rope_sin, D / 2);
+        OMX_LAUNCH_CHECK();
+    }
+    bf16_t* h = engine ? m->h2 : m->h;      // residual stream entering the layer
+    bf16_t* hn = engine ? m->h : m->h2;     // ping-pong partner
     const float* pending = nullptr;   // TP: all-reduced f32 partial not yet folded into h; MoE: the experts' weighted outputs
     int pending_n = 1;                //   ... how many f32 vectors `pending` holds (summed in order by the consumer's prologue)
     // MoE block without its weighted-sum launch (the next GEMV folds the experts' outputs in): every block of that GEMV reads top_k
@@ -490,7 +562,7 @@ int enqueue_step(omx_qwen3 m, bool with_head) {
     const char* fold_env = getenv("OMX_MOE_FOLD");
     const bool moe_fold = c.num_experts > 0 && !ep && !tp &&
                           (fold_env ? fold_env[0] == '1' : c.num_experts_per_tok <= 2);
-    for (int l = 0; l < c.num_hidden_layers; ++l) {
+    for (int l = 0; l < (engine ? 0 : c.num_hidden_layers); ++l) {
         const LayerW& L = m->layers[l];
         {   // [RMSNorm + QKV GEMV]  model.rs:168-170,324
             GemvArgs a = {};
@@ -719,10 +791,31 @@ int enqueue_head_on_row(omx_qwen3 m, const bf16_t* row, hipStream_t s) {
 //   RMSNorm -> gate/up GEMM -> silu*up -> down GEMM + residual.        (model.rs:161-215,263-267,321-332)
 // The last layer stops after its cache scatter: nothing downstream of it is consumed for these tokens.
 // a device-wide barrier of the persistent kernel gave up (a block never arrived): the step's results are void
+int step_gave_up(omx_qwen3 m, unsigned* code) {
+    OMX_HIP_CHECK(hipMemcpy(code, m->wait_abort, 4, hipMemcpyDeviceToHost));
+    return 0;
+}
 int step_health(omx_qwen3 m) {
     unsigned gave_up = 0;
-    OMX_HIP_CHECK(hipMemcpy(&gave_up, m->wait_abort, 4, hipMemcpyDeviceToHost));
-    OMX_REQUIRE(gave_up == 0, "decode attention: a split merge gave up waiting for a partial (a block of the launch was not resident?)");
+    if (step_gave_up(m, &gave_up)) return 1;
+    OMX_REQUIRE(gave_up == 0, "decode step: a wait inside a launch gave up (code 0x%x: a workgroup of the launch was not resident?)", gave_up);
+    return 0;
+}
+
+// A launch whose workgroups wait on each other (the persistent step, the O projection inside the attention launch) gave up: some
+// workgroup was not resident -- another process or stream holds CUs.  Drop to the next form that needs less co-residency, restore the
+// step state the call started from and let the caller run the steps again (the KV rows they wrote are rewritten).  Returns 0 when a
+// retry is possible.
+int step_fallback(omx_qwen3 m, const StepState& st) {
+    if (m->temperature != 0.f) return 1;                       // the sampler's key sequence advanced: no silent replay
+    if (!m->se_disabled && step_engine_takes(m)) m->se_disabled = true;
+    else if (!m->oproj_disabled && attention_takes_oproj(m)) m->oproj_disabled = true;
+    else return 1;
+    if (m->g_full) { (void)hipGraphExecDestroy(m->g_full); m->g_full = nullptr; }
+    if (m->g_nohead) { (void)hipGraphExecDestroy(m->g_nohead); m->g_nohead = nullptr; }
+    OMX_HIP_CHECK(hipMemsetAsync(m->wait_abort, 0, 4, m->stream));
+    OMX_HIP_CHECK(hipMemcpyAsync(m->st, &st, sizeof(st), hipMemcpyHostToDevice, m->stream));
+    OMX_HIP_CHECK(hipStreamSynchronize(m->stream));
     return 0;
 }
 
@@ -994,6 +1087,14 @@ int omx_qwen3_create(omx_qwen3* out, const omx_qwen3_config* cfg) {
         dev_alloc(m, &m->attn_xg, (size_t)m->H * D / 2 + 8))
         return 1;
     if (dev_alloc(m, &m->step_seq, 16) || dev_alloc(m, &m->wait_abort, 16)) return 1;
+    {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        OMX_HIP_CHECK(hipGetDevice(&dev));
+        OMX_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
+        m->cus = prop.multiProcessorCount;
+        if (c.num_experts == 0 && !c.quant_bits && dev_alloc(m, &m->se_gran, step_engine_granules(c.hidden_size, m->H, m->Hkv, D, m->I))) return 1;
+    }
     if (dev_alloc(m, &m->st, 1) || dev_alloc(m, &m->out_ring, (size_t)m->ring_cap) ||
         dev_alloc(m, &m->h, (size_t)c.hidden_size) || dev_alloc(m, &m->h2, (size_t)c.hidden_size) ||
         dev_alloc(m, &m->qkv, (size_t)(m->H + 2 * m->Hkv) * D) || dev_alloc(m, &m->attn_out, (size_t)m->H * D) ||
@@ -1369,13 +1470,19 @@ int omx_qwen3_decode(omx_qwen3 m, int n, uint32_t* tokens_out) {
     OMX_HIP_CHECK(hipStreamSynchronize(m->stream));
     if (prepare_step(m, st.pos)) return 1;
     OMX_REQUIRE(st.pos + n <= m->cap, "omx_qwen3_decode: %d cached + %d new tokens exceed max_context %d", st.pos, n, m->cap);
-    OMX_HIP_CHECK(hipEventRecord(m->ev0, m->stream));
-    for (int i = 0; i < n; ++i)
-        if (run_step(m, true, st.pos + i)) return 1;
-    OMX_HIP_CHECK(hipEventRecord(m->ev1, m->stream));
-    OMX_HIP_CHECK(hipStreamSynchronize(m->stream));
-    OMX_HIP_CHECK(hipEventElapsedTime(&m->last_decode_ms, m->ev0, m->ev1));
-    if (step_health(m)) return 1;
+    for (;;) {
+        OMX_HIP_CHECK(hipEventRecord(m->ev0, m->stream));
+        for (int i = 0; i < n; ++i)
+            if (run_step(m, true, st.pos + i)) return 1;
+        OMX_HIP_CHECK(hipEventRecord(m->ev1, m->stream));
+        OMX_HIP_CHECK(hipStreamSynchronize(m->stream));
+        OMX_HIP_CHECK(hipEventElapsedTime(&m->last_decode_ms, m->ev0, m->ev1));
+        unsigned gave_up = 0;
+        if (step_gave_up(m, &gave_up)) return 1;
+        if (!gave_up) break;
+        if (step_fallback(m, st)) return step_health(m);   // no form with less co-residency left: report
+        if (prepare_step(m, st.pos)) return 1;
+    }
     std::vector<uint32_t> ring(m->ring_cap);
     OMX_HIP_CHECK(hipMemcpy(ring.data(), m->out_ring, (size_t)m->ring_cap * 4, hipMemcpyDeviceToHost));
     for (int i = 0; i < n; ++i) tokens_out[i] = ring[(st.out_count + i) % m->ring_cap];
@@ -1400,6 +1507,15 @@ int omx_qwen3_debug_read(omx_qwen3 m, const char* name, void* host, size_t n_ele
     else if (s == "qkv") src = m->qkv;
     else if (s == "attn_out") src = m->attn_out;
     else if (s == "act") src = m->act;
+    else if (s.rfind("g_", 0) == 0 && m->se_gran) {   // granule buffers of the persistent step (8 bytes each: n_elems = 4 x granules)
+        const size_t hd = m->cfg.hidden_size, D = m->cfg.head_dim;
+        const uint64_t* g = m->se_gran;
+        if (s == "g_x") src = g;
+        else if (s == "g_x1") src = g + hd / 2;
+        else if (s == "g_qkv") src = g + hd;
+        else if (s == "g_attn") src = g + hd + (size_t)(m->H + 2 * m->Hkv) * D / 2;
+        else if (s == "g_act") src = g + hd + (size_t)(m->H + 2 * m->Hkv) * D / 2 + (size_t)m->H * D / 2;
+    }
     else if (s.size() > 1 && (s[0] == 'k' || s[0] == 'v')) {
         const int l = atoi(s.c_str() + 1);
         OMX_REQUIRE(l >= 0 && l < (int)m->kcache.size(), "omx_qwen3_debug_read: bad layer in %s", name);
@@ -1457,11 +1573,11 @@ int omx_qwen3_time_step_kernels(omx_qwen3 m, int steps, float* us) {
     OMX_REQUIRE(m && us && steps > 0, "omx_qwen3_time_step_kernels: bad arguments");
     OMX_REQUIRE(!m->cfg.quant_bits && m->cfg.num_experts == 0 && m->allreduce == nullptr, "omx_qwen3_time_step_kernels: dense bf16 single-rank models only");
     const int L = m->cfg.num_hidden_layers;
-    std::vector<hipEvent_t> ev((size_t)(L * kLayerClasses + 1) * 2);
+    std::vector<hipEvent_t> ev((size_t)(L * kLayerClasses + 2) * 2);
     for (auto& e : ev) OMX_HIP_CHECK(hipEventCreate(&e));
     double sum[KC_COUNT] = {};
     int rc = 0;
-    bool fused_o = false;
+    bool fused_o = false, engine = false;
     arm_launch_events(nullptr, nullptr);
     for (int it = 0; it < steps && !rc; ++it) {
         StepState st;
@@ -1470,27 +1586,55 @@ int omx_qwen3_time_step_kernels(omx_qwen3 m, int steps, float* us) {
         if (st.pos + 1 > m->cap) { set_error("omx_qwen3_time_step_kernels: context full"); rc = 1; break; }
         if (prepare_step(m, st.pos)) { rc = 1; break; }
         fused_o = attention_takes_oproj(m);
+        engine = step_engine_takes(m);
         m->kernel_events = &ev;
         rc = enqueue_step(m, true);
         m->kernel_events = nullptr;
         if (rc) break;
         OMX_HIP_CHECK(hipStreamSynchronize(m->stream));
-        for (int l = 0; l <= L; ++l)
-            for (int k = 0; k < (l == L ? 1 : kLayerClasses); ++k) {
+        for (int l = (engine ? L : 0); l <= L; ++l)
+            for (int k = 0; k < (l == L ? (engine ? 2 : 1) : kLayerClasses); ++k) {
                 float ms = 0.f;
                 const size_t i = ((size_t)l * kLayerClasses + k) * 2;
                 if (l < L && k == KC_O && fused_o) continue;     // that pair was never armed
                 OMX_HIP_CHECK(hipEventElapsedTime(&ms, ev[i], ev[i + 1]));
-                sum[l == L ? KC_HEAD : k] += ms * 1e3;
+                sum[l == L ? (k == 0 ? KC_HEAD : KC_ENGINE) : k] += ms * 1e3;
             }
         rc = step_health(m);
     }
     arm_launch_events(nullptr, nullptr);   // (a pair armed for a launch that never happened must not outlive its events)
     for (auto& e : ev) (void)hipEventDestroy(e);
     if (rc) return 1;
-    for (int k = 0; k < KC_COUNT; ++k) us[k] = (float)(sum[k] / ((k == KC_HEAD ? 1.0 : (double)L) * steps));
+    for (int k = 0; k < KC_COUNT; ++k) us[k] = (float)(sum[k] / ((k == KC_HEAD || k == KC_ENGINE ? 1.0 : (double)L) * steps));
     if (fused_o) us[KC_O] = 0.f;   // no separate launch: its work is inside the attention figure
     return 0;
+}
+
+/* debug hook (tools/step_engine_trace.py): ONE eager decode step on the persistent engine with per-CU wall-clock stamps:
+ * host receives [CUs][64] words (12 per layer for the first four layers: layer start, x ready, qkv done, partials out, attention done,
+ * attention vector ready, o done, x1 ready, gate/up done, act ready, down done); *cus_out = CUs */
+int omx_qwen3_debug_trace_engine(omx_qwen3 m, unsigned long long* host, size_t n_words, int* cus_out) {
+    OMX_REQUIRE(m && host && cus_out, "omx_qwen3_debug_trace_engine: null argument");
+    StepState st;
+    OMX_HIP_CHECK(hipMemcpyAsync(&st, m->st, sizeof(st), hipMemcpyDeviceToHost, m->stream));
+    OMX_HIP_CHECK(hipStreamSynchronize(m->stream));
+    if (prepare_step(m, st.pos)) return 1;
+    OMX_REQUIRE(step_engine_takes(m), "omx_qwen3_debug_trace_engine: the persistent step is off or the model does not qualify");
+    const size_t need = (size_t)m->cus * kStepEngineTraceWords;
+    OMX_REQUIRE(n_words >= need, "omx_qwen3_debug_trace_engine: buffer of %zu words, need %zu", n_words, need);
+    unsigned long long* dev = nullptr;
+    OMX_HIP_CHECK(hipMalloc(&dev, need * 8));
+    OMX_HIP_CHECK(hipMemsetAsync(dev, 0, need * 8, m->stream));
+    m->se_trace = dev;
+    const int rc = enqueue_step(m, true);
+    m->se_trace = nullptr;
+    if (!rc) {
+        OMX_HIP_CHECK(hipStreamSynchronize(m->stream));
+        OMX_HIP_CHECK(hipMemcpy(host, dev, need * 8, hipMemcpyDeviceToHost));
+    }
+    (void)hipFree(dev);
+    *cus_out = m->cus;
+    return rc ? 1 : step_health(m);
 }
 
 int omx_qwen3_decode_path(omx_qwen3 m, int* path) {

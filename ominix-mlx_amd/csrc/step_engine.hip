@@ -1,0 +1,892 @@
+// See step_engine.hpp for the design.  One workgroup of 4 waves per CU for the whole decode step: wave 0 streams weights and K/V
+// into an LDS ring with LDS-DMA and never waits on a dependency, waves 1-3 consume; op outputs cross CUs as tagged granules.
+#include "step_engine.hpp"
+
+#include <algorithm>
+
+#include "launch_timing.hpp"
+
+namespace omx {
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kCons = 3;                 // consumer waves
+constexpr int kSlot = 16384;             // ring slot: 16 pieces
+constexpr int kPiece = 1024;             // one wave-wide global_load_lds_dwordx4
+constexpr int kPPS = kSlot / kPiece;     // pieces per slot
+constexpr int kMisc = 8192;              // LDS behind the activation area: control words, residual rows, attention staging
+constexpr int kLdsTotal = 160 * 1024;
+constexpr unsigned kSpinLds = 1u << 22;  // polls of an LDS word (~0.1 us each) before a wait gives up
+constexpr unsigned kSpinGlb = 1u << 16;  // granule passes (~1 us each)
+constexpr int kVWaves = 8;               // the launch-per-op attention kernel's waves per block, emulated for bit-identical sums
+constexpr int kKU = 3;                   // ... and its units in flight per wave (attn_step.hip)
+constexpr int kMaxPairs = 64;            // residual row pairs a CU can own (O / down rows)
+
+// control words (byte offsets inside the control block)
+constexpr int C_READY = 0, C_DONE = 16, C_GATHER = 28, C_CBAR = 32, C_ABORT = 36;
+// misc area (byte offsets from the misc base)
+constexpr int M_CTL = 0, M_RESID = 64, M_ROPE = 320, M_RAWQKV = 832, M_SMQ = 3392, M_SMM = 5696, M_SML = 5952, M_END = 6208;
+static_assert(M_END <= kMisc, "misc area overflow");
+
+typedef __attribute__((address_space(1))) unsigned long long gu64;
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+
+__device__ __forceinline__ void st_gran(uint64_t* p, unsigned tag, unsigned v) {
+    __hip_atomic_store((gu64*)p, ((unsigned long long)tag << 32) | (unsigned long long)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned long long ld_gran(const uint64_t* p) {
+    return __hip_atomic_load((gu64*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// LDS control words go through asm: hipcc must not pair them with the LDS-DMA stream (a compiler-tracked ds_read next to pending
+// global_load_lds draws a vmcnt(0)), and a poll must be re-issued every iteration
+__device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(uintptr_t)p; }
+__device__ __forceinline__ unsigned lds_ld32(unsigned addr) {
+    unsigned v;
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(addr) : "memory");
+    return v;
+}
+__device__ __forceinline__ u32x4 lds_ld128(unsigned addr) {
+    u32x4 v;
+    asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(addr) : "memory");
+    return v;
+}
+__device__ __forceinline__ void lds_st32(unsigned addr, unsigned v) {
+    asm volatile("ds_write_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" ::"v"(addr), "v"(v) : "memory");
+}
+__device__ __forceinline__ unsigned lds_add32(unsigned addr, unsigned v) {
+    unsigned r;
+    asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=&v"(r) : "v"(addr), "v"(v) : "memory");
+    return r;
+}
+
+// rows of an op are shared in PAIRS (one granule carries two bf16 outputs): CU c of n owns pairs [start, start + count)
+__device__ __host__ __forceinline__ void share(int total, int n, int c, int* start, int* count) {
+    const int base = total / n, rem = total % n;
+    *count = base + (c < rem ? 1 : 0);
+    *start = c * base + (c < rem ? c : rem);
+}
+
+// ---- what a CU streams for one op: `npairs` tasks of `rpt` weight rows of `ppr` pieces each, task-major ----
+struct OpShape {
+    int pair0, npairs;   // this CU's row pairs
+    int rpt;             // physical rows per task: 2 (row pair), 4 (gate/up of a pair)
+    int ppr;             // pieces per row = K / 512
+    int nslots;
+};
+__device__ __forceinline__ OpShape op_shape(int rows, int K, int lr, int ncu, int cu) {
+    OpShape o;
+    share(rows / 2, ncu, cu, &o.pair0, &o.npairs);
+    o.rpt = 2 * lr;
+    o.ppr = K / 512;
+    o.nslots = (o.npairs * o.rpt * o.ppr + kPPS - 1) / kPPS;
+    return o;
+}
+
+// gemv.hip's split of a row over the waves of a block (launch_gemv: K/512 > 8 runs KSPLIT = 4): partial sums per quarter
+__device__ __host__ __forceinline__ int quarters_of(int ppr) { return ppr > 8 ? 4 : 1; }
+
+// ---- the O / down GEMV's accumulation (gemv.hip dot8): lo then hi of each dword, one fma chain ----
+__device__ __forceinline__ float dot8_chain(const u32x4 w, const float (&xf)[8], float acc) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        acc = fmaf(bf16lo(w[i]), xf[2 * i], acc);
+        acc = fmaf(bf16hi(w[i]), xf[2 * i + 1], acc);
+    }
+    return acc;
+}
+__device__ __forceinline__ void unpack8(const u32x4 r, float (&x)[8]) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        x[2 * e] = bf16lo(r[e]);
+        x[2 * e + 1] = bf16hi(r[e]);
+    }
+}
+// attn_step.hip's score product (v_dot2c_f32_bf16 chain)
+__device__ __forceinline__ float dot8_bf16(const u32x4 a, const u32x4 b) {
+    const bf16x8_t A = __builtin_bit_cast(bf16x8_t, a), B = __builtin_bit_cast(bf16x8_t, b);
+    float d = 0.f;
+    d = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(A, A, 0, 1), __builtin_shufflevector(B, B, 0, 1), d, false);
+    d = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(A, A, 2, 3), __builtin_shufflevector(B, B, 2, 3), d, false);
+    d = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(A, A, 4, 5), __builtin_shufflevector(B, B, 4, 5), d, false);
+    d = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(A, A, 6, 7), __builtin_shufflevector(B, B, 6, 7), d, false);
+    return d;
+}
+template <int N>
+__device__ __forceinline__ float swap_halves(float v) {     // value of lane (l ^ N/2) of the aligned N-lane group
+    if (N == 16) return dpp_f<0x128>(v);                       // row_ror:8
+    return dpp_f<0x1B>(dpp_f<kDppHalfMirror>(v));              // (7 - i) then quad reverse == i ^ 4
+}
+
+// ---- per-wave view of the workgroup's LDS ----
+struct Lds {
+    unsigned char* base;     // ring at 0
+    unsigned char* xs;       // activation area
+    unsigned char* misc;
+    unsigned ctl;            // LDS byte address of the control block
+};
+
+struct Wave {
+    int lane, cw;            // cw: consumer index 0..2
+    unsigned epoch;          // consumer barriers passed
+    bool dead;               // a wait gave up: every later wait returns at once (results void, abort flag raised)
+};
+
+__device__ __forceinline__ void raise_abort(const StepEngineArgs& a, const Lds& L, Wave& w, unsigned code) {
+    w.dead = true;
+    lds_st32(L.ctl + C_ABORT, code);
+    if (w.lane == 0) __hip_atomic_store(a.abort_flag, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ bool check_dead(const Lds& L, Wave& w) {
+    if (!w.dead && lds_ld32(L.ctl + C_ABORT) != 0) w.dead = true;
+    return w.dead;
+}
+
+// all consumer waves of the CU arrive (the loader never does: no s_barrier in this kernel)
+__device__ __forceinline__ void cbar(const StepEngineArgs& a, const Lds& L, Wave& w) {
+    w.epoch += 1;
+    if (w.dead) return;
+    if (w.lane == 0) (void)lds_add32(L.ctl + C_CBAR, 1u);
+    const unsigned want = w.epoch * kCons;
+    for (unsigned spins = 0;; ++spins) {
+        if ((int)(lds_ld32(L.ctl + C_CBAR) - want) >= 0) return;
+        if ((spins & 1023u) == 1023u && check_dead(L, w)) return;
+        if (spins >= kSpinLds) return raise_abort(a, L, w, 0x10u);
+    }
+}
+__device__ __forceinline__ void wait_ready(const StepEngineArgs& a, const Lds& L, Wave& w, unsigned need) {
+    if (w.dead) return;
+    for (unsigned spins = 0;; ++spins) {
+        if ((int)(lds_ld32(L.ctl + C_READY) - need) >= 0) return;
+        __builtin_amdgcn_s_sleep(1);
+        if ((spins & 1023u) == 1023u && check_dead(L, w)) return;
+        if (spins >= kSpinLds) return raise_abort(a, L, w, 0x20u);
+    }
+}
+__device__ __forceinline__ void set_done(const Lds& L, const Wave& w, unsigned slot) {
+    if (w.lane == 0) lds_st32(L.ctl + C_DONE + 4 * w.cw, slot);
+}
+
+// ---- sweep granules [lo, hi) of `g` into LDS words dst[i - lo0]: every load of a 32-per-lane chunk in flight, re-read until the
+//      tags match (Guideline 16 R2).  map(i) = granule index in `g` of logical word i ----
+template <class Map>
+__device__ __forceinline__ void sweep(const StepEngineArgs& a, const Lds& L, Wave& w, const uint64_t* g, int lo, int hi, unsigned tag,
+                                      unsigned* dst, Map map) {
+    if (w.dead) return;
+    for (int base = lo; base < hi; base += 2048) {
+        bool okb[2] = {false, base + 1024 >= hi};
+        unsigned long long v[2][16];
+        for (unsigned spins = 0;; ++spins) {
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                if (okb[b]) continue;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) v[b][k] = ld_gran(g + map(min(base + (b * 16 + k) * 64 + w.lane, hi - 1)));
+            }
+            bool all = true;
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                if (okb[b]) continue;
+                bool ok = true;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) ok &= (unsigned)(v[b][k] >> 32) == tag;
+                if (__all(ok)) {
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) {
+                        const int i = base + (b * 16 + k) * 64 + w.lane;
+                        if (i < hi) dst[i] = (unsigned)v[b][k];
+                    }
+                    okb[b] = true;
+                } else {
+                    all = false;
+                }
+            }
+            if (all) break;
+            if (spins >= kSpinGlb) return raise_abort(a, L, w, 0x30u);
+            __builtin_amdgcn_s_sleep(1);
+        }
+    }
+}
+struct IdMap {
+    __device__ __forceinline__ int operator()(int i) const { return i; }
+};
+
+// hidden-sized edge: `n` granules into the front of the activation area; a.nsweep waves share the sweep, the loader is thinned meanwhile
+__device__ __forceinline__ void gather_vec(const StepEngineArgs& a, const Lds& L, Wave& w, const uint64_t* g, int n, unsigned tag, int nsw) {
+    cbar(a, L, w);                                   // the area's previous readers are done
+    if (w.cw == 0 && w.lane == 0) lds_st32(L.ctl + C_GATHER, 1u);
+    if (w.cw < nsw) {
+        const int per = ((n + nsw - 1) / nsw + 63) & ~63;
+        const int lo = min(n, w.cw * per), hi = min(n, lo + per);
+        if (lo < hi) sweep(a, L, w, g, lo, hi, tag, reinterpret_cast<unsigned*>(L.xs), IdMap());
+    }
+    cbar(a, L, w);
+    if (w.cw == 0 && w.lane == 0) lds_st32(L.ctl + C_GATHER, 0u);
+}
+
+// ---- RMSNorm with the sums of gemv.hip's prologue (256 threads: thread t squares vectors t, t + 256, ...; wave sums; 4 wave totals
+//      added in order): raw packed bf16 at `xraw` -> normalised packed bf16 at `xn`; every consumer wave computes the scale itself ----
+constexpr int kNwv = 4;   // norm-weight vectors a lane fetches BEFORE it waits for the vector (K <= 6144; wider rows load the rest late)
+__device__ __forceinline__ void norm_w_prefetch(const Wave& w, const bf16_t* norm_w, int K, u32x4 (&nwv)[kNwv]) {
+#pragma unroll
+    for (int k = 0; k < kNwv; ++k) {
+        const int v = w.cw * 64 + w.lane + k * kCons * 64;
+        nwv[k] = *(reinterpret_cast<const u32x4*>(norm_w) + min(v, K / 8 - 1));
+    }
+}
+__device__ __forceinline__ void rmsnorm_lds(const Wave& w, const u32x4* xraw, u32x4* xn, const bf16_t* norm_w, const u32x4 (&nwv)[kNwv],
+                                            int K, float eps) {
+    const int nvec = K / 8;
+    float tot = 0.f;
+#pragma unroll 1
+    for (int vw = 0; vw < 4; ++vw) {
+        float ss = 0.f;
+        for (int v = vw * 64 + w.lane; v < nvec; v += 256) {
+            const u32x4 raw = xraw[v];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float lo = bf16lo(raw[q]), hi = bf16hi(raw[q]);
+                ss = fmaf(lo, lo, ss);
+                ss = fmaf(hi, hi, ss);
+            }
+        }
+        tot += wave_sum(ss);
+    }
+    const float rstd = 1.0f / sqrtf(tot / (float)K + eps);
+#pragma unroll
+    for (int k = 0; k < kNwv; ++k) {
+        const int v = w.cw * 64 + w.lane + k * kCons * 64;
+        if (v < nvec) {
+            const u32x4 raw = xraw[v];
+            u32x4 o;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                o[q] = pack_bf16(bf16lo(raw[q]) * rstd * bf16lo(nwv[k][q]), bf16hi(raw[q]) * rstd * bf16hi(nwv[k][q]));
+            xn[v] = o;
+        }
+    }
+    for (int v = w.cw * 64 + w.lane + kNwv * kCons * 64; v < nvec; v += kCons * 64) {
+        const u32x4 raw = xraw[v];
+        const u32x4 nw = *(reinterpret_cast<const u32x4*>(norm_w) + v);
+        u32x4 o;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            o[q] = pack_bf16(bf16lo(raw[q]) * rstd * bf16lo(nw[q]), bf16hi(raw[q]) * rstd * bf16hi(nw[q]));
+        xn[v] = o;
+    }
+}
+
+// ---- the consumers' GEMV over one op: task t (a row pair) is reduced by wave t % 3 from the ring with gemv.hip's arithmetic:
+//      lane l owns elements (j * 64 + l) * 8 .. + 7 of every row, one fma chain over j (per K quarter when K/512 > 8), wave_sum,
+//      quarters added in order.  epi(pair, v[]) publishes on lane 0. ----
+template <int NSLOT, int LR, class Epi>
+__device__ __forceinline__ void run_gemv(const StepEngineArgs& a, const Lds& L, Wave& w, const OpShape& op, unsigned slot0, const u32x4* x,
+                                         Epi epi) {
+    constexpr int R = 2 * LR;
+    constexpr unsigned RING = NSLOT * kPPS;
+    const int ppr = op.ppr, nq = quarters_of(ppr), nvw = ppr / nq;
+    const unsigned end = slot0 + op.nslots;
+    set_done(L, w, w.cw < op.npairs ? slot0 + (unsigned)(w.cw * R * ppr) / kPPS : end);
+    for (int t = w.cw; t < op.npairs; t += kCons) {
+        const unsigned idx0 = (unsigned)t * R * ppr;
+        wait_ready(a, L, w, slot0 + (idx0 + R * ppr - 1) / kPPS + 1);
+        float v[R];
+        const unsigned p0 = slot0 * kPPS + idx0;
+        for (int q = 0; q < nq; ++q) {
+            float acc[R];
+#pragma unroll
+            for (int s = 0; s < R; ++s) acc[s] = 0.f;
+            for (int jj = 0; jj < nvw; ++jj) {
+                const int j = q * nvw + jj;
+                float xf[8];
+                unpack8(x[j * 64 + w.lane], xf);
+#pragma unroll
+                for (int s = 0; s < R; ++s) {
+                    const unsigned piece = (p0 + s * ppr + j) % RING;
+                    const u32x4 wv = *reinterpret_cast<const u32x4*>(L.base + (size_t)piece * kPiece + w.lane * 16);
+                    acc[s] = dot8_chain(wv, xf, acc[s]);
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < R; ++s) {
+                const float p = wave_sum(acc[s]);
+                v[s] = nq == 1 ? p : (q == 0 ? 0.f + p : v[s] + p);
+            }
+        }
+        set_done(L, w, t + kCons < op.npairs ? slot0 + ((unsigned)(t + kCons) * R * ppr) / kPPS : end);
+        epi(op.pair0 + t, v);
+    }
+}
+
+// ---- loader: one wave, scalar state only.  A fill = 16 pieces; a stream shorter than its last fill re-reads its last piece ----
+template <int NSLOT>
+struct Loader {
+    unsigned ctl;
+    unsigned char* ring;
+    int lane, inflight;
+    unsigned issued, published;
+    bool dead;
+
+    __device__ __forceinline__ void publish(unsigned n) {
+        if ((int)(n - published) > 0) { published = n; lds_st32(ctl + C_READY, n); }   // (never backwards: a drain may have run ahead)
+    }
+    __device__ __forceinline__ void drain() {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        publish(issued);
+    }
+    // wait until the slot of fill `issued` is free; returns whether this CU's consumers are gathering right now
+    __device__ __forceinline__ bool space() {
+        bool thin = false;
+        if (dead) return thin;
+        for (unsigned spins = 0;; ++spins) {
+            const u32x4 d = lds_ld128(ctl + C_DONE);
+            const unsigned mind = __builtin_amdgcn_readfirstlane(min(d[0], min(d[1], d[2])));
+            thin = __builtin_amdgcn_readfirstlane(d[3]) != 0;
+            if ((int)(issued - mind) < NSLOT) break;   // (done words may run ahead of `issued`: a wave's next slot)
+            if (spins == 0) drain();                   // about to block: everything issued must become visible first
+            __builtin_amdgcn_s_sleep(2);
+            if (spins >= kSpinLds) { dead = true; break; }
+            if ((spins & 255u) == 255u && __builtin_amdgcn_readfirstlane(lds_ld32(ctl + C_ABORT)) != 0) { dead = true; break; }
+        }
+        return thin;
+    }
+    __device__ __forceinline__ unsigned char* slot_ptr() const { return ring + (size_t)(issued % NSLOT) * kSlot; }
+    __device__ __forceinline__ void piece(const char* p, unsigned char* dst) {
+        __builtin_amdgcn_global_load_lds((glb_ptr_t)(p + lane * 16), (lds_ptr_t)dst, 16, 0, 2 /* nt */);
+    }
+    // fills in flight: `inflight` while streaming, one while this CU gathers (gather-pass: its coherent loads queue behind ours)
+    __device__ __forceinline__ void landed(bool thin) {
+        issued += 1;
+        const int keep = thin ? 1 : inflight;
+        if (inflight <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // debug: no fill in flight past its issue
+        else if (keep >= 3) asm volatile("s_waitcnt vmcnt(48)" ::: "memory");
+        else if (keep == 2) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        if (inflight <= 0) publish(issued);
+        else if (issued > (unsigned)keep) publish(issued - keep);
+    }
+    // up to three byte ranges back to back: n0 pieces at p0, then n1 at p1, then n2 at p2
+    __device__ __forceinline__ void seq(const char* p0, int n0, const char* p1, int n1, const char* p2, int n2) {
+        const int total = n0 + n1 + n2, nfill = (total + kPPS - 1) / kPPS;
+        for (int f = 0; f < nfill; ++f) {
+            const bool thin = space();
+            unsigned char* dst = slot_ptr();
+#pragma unroll
+            for (int i = 0; i < kPPS; ++i) {
+                const int k = min(f * kPPS + i, total - 1);
+                const char* p = k < n0 ? p0 + (long)k * kPiece : k < n0 + n1 ? p1 + (long)(k - n0) * kPiece : p2 + (long)(k - n0 - n1) * kPiece;
+                piece(p, dst + i * kPiece);
+            }
+            landed(thin);
+        }
+    }
+    // two ranges taken alternately in runs of `run` pieces (gate rows of a pair, up rows of the pair, ...): 2 * n pieces
+    __device__ __forceinline__ void alt(const char* pa, const char* pb, int run, int n) {
+        const int total = 2 * n, nfill = (total + kPPS - 1) / kPPS;
+        int left = run, k = 0;
+        for (int f = 0; f < nfill; ++f) {
+            const bool thin = space();
+            unsigned char* dst = slot_ptr();
+#pragma unroll
+            for (int i = 0; i < kPPS; ++i) {
+                piece(pa, dst + i * kPiece);
+                if (k + 1 < total) {   // (past the end: the last piece again)
+                    ++k;
+                    pa += kPiece;
+                    if (--left == 0) {
+                        const char* t = pa; pa = pb; pb = t;
+                        left = run;
+                    }
+                }
+            }
+            landed(thin);
+        }
+    }
+};
+
+// merge the split partials of one head (attn_step.hip gather_head, same loads, same arithmetic): lane = output dim
+template <int D, int NB>
+__device__ __forceinline__ void gather_head(const StepEngineArgs& a, const Lds& L, Wave& w, const uint64_t* base, int n_active, unsigned tag,
+                                            int dim, uint64_t* xg_head) {
+    constexpr int STRIDE = D + 2;
+    const int lane = w.lane;
+    unsigned long long ml0 = 0, ml1 = 0, og[NB][16];
+    bool ok_ml = false, ok_b[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) ok_b[b] = b * 16 >= n_active;
+    const int sl = min(lane, n_active - 1);
+    for (unsigned spins = 0; !w.dead; ++spins) {
+        if (!ok_ml) {
+            ml0 = ld_gran(base + (size_t)sl * STRIDE + D);
+            ml1 = ld_gran(base + (size_t)sl * STRIDE + D + 1);
+        }
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            if (ok_b[b]) continue;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) og[b][j] = ld_gran(base + (size_t)min(b * 16 + j, n_active - 1) * STRIDE + dim);
+        }
+        bool all = true;
+        if (!ok_ml) ok_ml = __all((unsigned)(ml0 >> 32) == tag && (unsigned)(ml1 >> 32) == tag);
+        all = ok_ml;
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            if (!ok_b[b]) {
+                bool ok = true;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) ok &= (unsigned)(og[b][j] >> 32) == tag;
+                ok_b[b] = __all(ok);
+            }
+            all = all && ok_b[b];
+        }
+        if (all) break;
+        if (spins >= kSpinGlb) { raise_abort(a, L, w, 0x40u); break; }
+        __builtin_amdgcn_s_sleep(1);
+    }
+    const float m = lane < n_active ? __uint_as_float((unsigned)ml0) : -INFINITY;
+    const float l = lane < n_active ? __uint_as_float((unsigned)ml1) : 0.f;
+    const float M = wave_max(m);
+    const float f = (m == -INFINITY) ? 0.f : __expf(m - M);
+    const float Lsum = wave_sum(f * l);
+    float acc = 0.f;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        if (b * 16 >= n_active) break;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc = fmaf(readlane_f(f, b * 16 + j), __uint_as_float((unsigned)og[b][j]), acc);
+    }
+    const bf16_t r = f32_to_bf16(acc / Lsum);
+    const float nb = dpp_f<kDppXor1>(bf16_to_f32(r));
+    if (!(lane & 1)) st_gran(xg_head + dim / 2, tag, (unsigned)r | ((unsigned)f32_to_bf16(nb) << 16));
+}
+
+// D: head dim; GT: query heads per KV head rounded up to a power of two; NSLOT: ring slots
+template <int D, int GT, int NSLOT, bool TRACE>
+__global__ __launch_bounds__(kBlock, 1) void step_engine_kernel(const StepEngineArgs a) {
+    constexpr int LPR = D / 8;            // lanes per K/V row
+    constexpr int TPW = 64 / LPR;         // token rows per piece == one unit of attn_step.hip
+    constexpr unsigned RING = NSLOT * kPPS;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    Lds L;
+    L.base = smem;
+    L.xs = smem + NSLOT * kSlot;
+    L.misc = L.xs + a.xs_bytes;
+    L.ctl = lds_addr(L.misc + M_CTL);
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int cu = blockIdx.x, ncu = gridDim.x;
+    const int G = a.H / a.Hkv;
+    const int hidden = a.hidden, HD = a.H * D, NQKV = (a.H + 2 * a.Hkv) * D;
+
+    // control block: zeroed by the loader wave before anyone polls it (one s_barrier, the only one of the kernel)
+    if (threadIdx.x < 16) reinterpret_cast<unsigned*>(L.misc + M_CTL)[threadIdx.x] = 0u;
+    __syncthreads();
+
+    const int pos = a.st->pos;
+    const int Tk = pos + 1;
+    const unsigned seq = *a.seq_ptr + 1u;
+
+    // attention role of this CU: (kv head, split) -- splits of one KV head sit on one XCD when Hkv == 8
+    const bool in_attn = cu < a.Hkv * a.nsplit;
+    const int kvh = cu % a.Hkv, split = cu / a.Hkv;
+    const int n_active = (Tk + a.chunk - 1) / a.chunk;
+    const bool active = in_attn && split < n_active;
+    const int t_begin = split * a.chunk;
+    const int t_end = min(Tk, t_begin + a.chunk);
+    const int nu_live = active ? (t_end - t_begin + TPW - 1) / TPW : 0;   // K (and V) pieces this CU streams per layer
+    const int kv_slots = (2 * nu_live + kPPS - 1) / kPPS;
+
+    const OpShape opQ = op_shape(NQKV, hidden, 1, ncu, cu);
+    const OpShape opO = op_shape(hidden, HD, 1, ncu, cu);
+    const OpShape opG = op_shape(a.I, hidden, 2, ncu, cu);
+    const OpShape opD = op_shape(hidden, a.I, 1, ncu, cu);
+    unsigned long long* tr = TRACE ? a.trace + (size_t)cu * kStepEngineTraceWords : nullptr;
+
+    if (wave == 0) {
+        // =========================== loader ===========================
+        Loader<NSLOT> ld;
+        ld.ctl = L.ctl; ld.ring = smem; ld.lane = lane; ld.inflight = a.inflight; ld.issued = 0; ld.published = 0; ld.dead = false;
+        const long n0 = (long)a.H * D, n1 = (long)a.Hkv * D;   // rows of q, of k (and v)
+        for (int l = 0; l < a.L; ++l) {
+            const StepEngineLayer& W = a.layers[l];
+            {   // rows [r0, r1) of the stack [q | k | v]
+                const long r0 = 2l * opQ.pair0, r1 = r0 + 2l * opQ.npairs, rb = 2l * hidden;
+                const long q0 = min(r0, n0), q1 = min(r1, n0);
+                const long k0 = min(max(r0, n0), n0 + n1), k1 = min(max(r1, n0), n0 + n1);
+                const long v0 = max(r0, n0 + n1), v1 = max(r1, n0 + n1);
+                ld.seq((const char*)W.q + q0 * rb, (int)(q1 - q0) * opQ.ppr, (const char*)W.k + (k0 - n0) * rb, (int)(k1 - k0) * opQ.ppr,
+                       (const char*)W.v + (v0 - n0 - n1) * rb, (int)(v1 - v0) * opQ.ppr);
+            }
+            if (nu_live > 0)   // K chunk then V chunk of this split (the row of the new token is replaced by the consumers)
+                ld.seq((const char*)(W.kc + ((size_t)kvh * a.cap + t_begin) * D), nu_live,
+                       (const char*)(W.vc + ((size_t)kvh * a.cap + t_begin) * D), nu_live, nullptr, 0);
+            if (opO.npairs > 0) ld.seq((const char*)W.o + 2l * opO.pair0 * (2l * HD), opO.npairs * 2 * opO.ppr, nullptr, 0, nullptr, 0);
+            if (opG.npairs > 0)
+                ld.alt((const char*)W.gate + 2l * opG.pair0 * (2l * hidden), (const char*)W.up + 2l * opG.pair0 * (2l * hidden), 2 * opG.ppr,
+                       opG.npairs * 2 * opG.ppr);
+            if (opD.npairs > 0) ld.seq((const char*)W.down + 2l * opD.pair0 * (2l * a.I), opD.npairs * 2 * opD.ppr, nullptr, 0, nullptr, 0);
+        }
+        ld.drain();
+        return;
+    }
+
+    // =========================== consumers ===========================
+    Wave w;
+    w.lane = lane; w.cw = wave - 1; w.epoch = 0; w.dead = false;
+    u32x4* const xA = reinterpret_cast<u32x4*>(L.xs);                        // raw vector (packed bf16)
+    u32x4* const xB = reinterpret_cast<u32x4*>(L.xs + (size_t)hidden * 2);   // normalised vector
+    unsigned* const resid = reinterpret_cast<unsigned*>(L.misc + M_RESID);
+    float* const rope = reinterpret_cast<float*>(L.misc + M_ROPE);           // cos[D/2] | sin[D/2] of this position
+    unsigned* const rawqkv = reinterpret_cast<unsigned*>(L.misc + M_RAWQKV); // q heads of the group | k | v, packed bf16
+    u32x4* const smq = reinterpret_cast<u32x4*>(L.misc + M_SMQ);             // [GT + 1][LPR] roped q heads + new k row
+    float* const smm = reinterpret_cast<float*>(L.misc + M_SMM);             // [kVWaves][GT]
+    float* const sml = reinterpret_cast<float*>(L.misc + M_SML);
+    float* const park = reinterpret_cast<float*>(L.xs);                      // [kVWaves][GT][D] (over the dead activation area)
+
+    if (w.cw == 0 && in_attn) {
+        const int half = D / 2;
+        for (int i = lane; i < D; i += 64) rope[i] = i < half ? a.rope_cos[(size_t)pos * half + i] : a.rope_sin[(size_t)pos * half + i - half];
+    }
+    unsigned slot = 0;   // first ring slot of the current op (the loader counts the same way)
+
+    for (int l = 0; l < a.L; ++l) {
+        const StepEngineLayer& W = a.layers[l];
+        const unsigned tag = seq * (unsigned)a.L + (unsigned)l + 1u;
+        const bool last = l + 1 == a.L;
+        if (TRACE && l < 4 && w.cw == 0 && lane == 0) tr[l * 12 + 0] = wall_clock64();
+
+        // ---- [RMSNorm + q/k/v] ----
+        u32x4 nwv[kNwv];
+        norm_w_prefetch(w, W.in_ln, hidden, nwv);
+        u32x4 wq_raw = {0, 0, 0, 0}, wk_raw = {0, 0, 0, 0};   // q/k norm weights of this lane's head-dim chunk (null: Mixtral / Qwen2)
+        if (in_attn && W.q_norm) {
+            wq_raw = *reinterpret_cast<const u32x4*>(W.q_norm + (lane % LPR) * 8);
+            wk_raw = *reinterpret_cast<const u32x4*>(W.k_norm + (lane % LPR) * 8);
+        }
+        if (l == 0) {   // the embedding row of the current token (Embedding::forward, model.rs:396)
+            const u32x4* src = reinterpret_cast<const u32x4*>(a.embed + (size_t)a.st->cur_token * hidden);
+            for (int v = w.cw * 64 + lane; v < hidden / 8; v += kCons * 64) xA[v] = src[v];
+            cbar(a, L, w);
+        } else {
+            gather_vec(a, L, w, a.g_x, hidden / 2, tag, a.nsweep);
+        }
+        if (TRACE && l < 4 && w.cw == 0 && lane == 0) tr[l * 12 + 1] = wall_clock64();
+        if (w.cw == 0 && lane < opO.npairs) resid[lane] = reinterpret_cast<const unsigned*>(xA)[opO.pair0 + lane];
+        rmsnorm_lds(w, xA, xB, W.in_ln, nwv, hidden, a.eps);
+        cbar(a, L, w);
+        run_gemv<NSLOT, 1>(a, L, w, opQ, slot, xB, [&](int pair, const float (&v)[2]) {
+            if (lane == 0) st_gran(a.g_qkv + pair, tag, (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16));
+        });
+        slot += opQ.nslots;
+        if (TRACE && l < 4 && w.cw == 0 && lane == 0) tr[l * 12 + 2] = wall_clock64();
+
+        // ---- [q/k norm + RoPE + KV append + split-KV SDPA + merge] (attn_step.hip's arithmetic) ----
+        if (in_attn) {
+            if (w.cw == 0) {   // this KV head's group: q heads, k row, v row -> rawqkv
+                const int nq = G * D / 2, nk = D / 2;
+                const int q0 = kvh * nq, k0 = a.H * D / 2 + kvh * nk, v0 = (a.H + a.Hkv) * D / 2 + kvh * nk;
+                sweep(a, L, w, a.g_qkv, 0, nq + 2 * nk, tag, rawqkv,
+                      [=](int i) { return i < nq ? q0 + i : i < nq + nk ? k0 + i - nq : v0 + i - nq - nk; });
+            }
+            cbar(a, L, w);
+            const int c = lane % LPR, sg = lane / LPR;
+            {   // rows 0..G-1: query heads, row G: the new key -- one row per wave turn, all four token rows of the wave redundantly
+                float cs[8], sn[8];
+                const int i0 = (c % (LPR / 2)) * 8;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { cs[e] = rope[i0 + e]; sn[e] = rope[D / 2 + i0 + e]; }
+                const bool first_half = c < LPR / 2;
+                for (int r = w.cw; r <= G; r += kCons) {
+                    const u32x4 raw = *reinterpret_cast<const u32x4*>(rawqkv + (size_t)r * (D / 2) + c * 4);
+                    const bool nwp = W.q_norm != nullptr;
+                    const u32x4 w_raw = r < G ? wq_raw : wk_raw;
+                    float x[8], wn[8];
+                    unpack8(raw, x);
+                    unpack8(w_raw, wn);
+                    float ss = 0.f;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) ss = fmaf(x[e], x[e], ss);
+                    ss = group_sum<LPR>(ss);
+                    const float rstd = nwp ? 1.0f / sqrtf(ss / (float)D + a.eps) : 1.0f;
+                    float y[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float xn = nwp ? round_bf16(x[e] * rstd * wn[e]) : x[e];
+                        const float other = swap_halves<LPR>(xn);
+                        y[e] = first_half ? xn * cs[e] - other * sn[e] : other * sn[e] + xn * cs[e];
+                    }
+                    u32x4 out;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) out[e] = pack_bf16(y[2 * e], y[2 * e + 1]);
+                    if (sg == 0) smq[(r < G ? r : GT) * LPR + c] = out;
+                }
+            }
+            cbar(a, L, w);
+            if (active) {
+                const int n_units = a.chunk / TPW;
+                u32x4 q[GT];
+#pragma unroll
+                for (int g = 0; g < GT; ++g) q[g] = smq[min(g, G - 1) * LPR + c];
+                const u32x4 knew = smq[GT * LPR + c];
+                const u32x4 vnew = *reinterpret_cast<const u32x4*>(rawqkv + (size_t)(G + 1) * (D / 2) + c * 4);
+                bf16_t* Kb = W.kc + (size_t)kvh * a.cap * D;
+                bf16_t* Vb = W.vc + (size_t)kvh * a.cap * D;
+                wait_ready(a, L, w, slot + kv_slots);
+                const unsigned p0 = slot * kPPS;
+                for (int vw = w.cw; vw < kVWaves; vw += kCons) {
+                    float m[GT], lsum[GT];
+                    f32x2 o[GT][4];
+#pragma unroll
+                    for (int g = 0; g < GT; ++g) {
+                        m[g] = -INFINITY;
+                        lsum[g] = 0.f;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[g][e] = f32x2{0.f, 0.f};
+                    }
+                    auto round = [&](const int u0) {
+                        float s[kKU][GT];
+                        f32x2 vf[kKU][4];
+#pragma unroll
+                        for (int u = 0; u < kKU; ++u) {
+                            const int unit = u0 + u * kVWaves;
+                            const int tok = t_begin + unit * TPW + sg;
+                            const bool live = unit < n_units && tok < t_end;
+                            const int uc = min(unit, nu_live - 1);
+                            u32x4 kp = *reinterpret_cast<const u32x4*>(L.base + (size_t)((p0 + uc) % RING) * kPiece + lane * 16);
+                            u32x4 vp = *reinterpret_cast<const u32x4*>(L.base + (size_t)((p0 + nu_live + uc) % RING) * kPiece + lane * 16);
+                            if (tok == pos && unit < n_units) {   // the NEW token: the row built above, appended to the cache (cache.rs:183-188)
+                                kp = knew;
+                                vp = vnew;
+                                *reinterpret_cast<u32x4*>(Kb + (size_t)pos * D + c * 8) = kp;
+                                *reinterpret_cast<u32x4*>(Vb + (size_t)pos * D + c * 8) = vp;
+                            }
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) vf[u][e] = live ? f32x2{bf16lo(vp[e]), bf16hi(vp[e])} : f32x2{0.f, 0.f};
+#pragma unroll
+                            for (int g = 0; g < GT; ++g) {
+                                const float d = group_sum<LPR>(dot8_bf16(q[g], kp)) * a.scale;
+                                s[u][g] = live ? d : -INFINITY;
+                            }
+                        }
+#pragma unroll
+                        for (int g = 0; g < GT; ++g) {
+                            float mx = s[0][g];
+#pragma unroll
+                            for (int u = 1; u < kKU; ++u) mx = fmaxf(mx, s[u][g]);
+                            float wmx = readlane_f(mx, 0);
+#pragma unroll
+                            for (int r = 1; r < TPW; ++r) wmx = fmaxf(wmx, readlane_f(mx, r * LPR));
+                            const float mn = fmaxf(m[g], wmx);
+                            const float alpha = (mn == -INFINITY) ? 1.f : __expf(m[g] - mn);
+                            m[g] = mn;
+                            lsum[g] *= alpha;
+                            const f32x2 al = {alpha, alpha};
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) o[g][e] *= al;
+#pragma unroll
+                            for (int u = 0; u < kKU; ++u) {
+                                const float p = (mn == -INFINITY) ? 0.f : __expf(s[u][g] - mn);
+                                lsum[g] += p;
+                                const f32x2 pp = {p, p};
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) o[g][e] = __builtin_elementwise_fma(pp, vf[u][e], o[g][e]);
+                            }
+                        }
+                    };
+                    if (vw < n_units && t_begin + vw * TPW < t_end) round(vw);
+                    for (int u0 = vw + kVWaves * kKU; u0 < n_units && t_begin + u0 * TPW < t_end; u0 += kVWaves * kKU) round(u0);
+                    // park: the TPW token rows of this (virtual) wave summed in row order, as the merge of attn_step.hip adds them
+#pragma unroll
+                    for (int g = 0; g < GT; ++g) {
+                        float ow[8];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const float x = o[g][e >> 1][e & 1];
+                            float sum = 0.f;
+#pragma unroll
+                            for (int r = 0; r < TPW; ++r) sum += __shfl(x, r * LPR + c, 64);
+                            ow[e] = sum;
+                        }
+                        float lw = readlane_f(lsum[g], 0);
+#pragma unroll
+                        for (int r = 1; r < TPW; ++r) lw += readlane_f(lsum[g], r * LPR);
+                        if (sg == 0) {
+                            float* dst = park + ((size_t)vw * GT + g) * D + c * 8;
+                            *reinterpret_cast<f32x4*>(dst) = f32x4{ow[0], ow[1], ow[2], ow[3]};
+                            *reinterpret_cast<f32x4*>(dst + 4) = f32x4{ow[4], ow[5], ow[6], ow[7]};
+                        }
+                        if (lane == 0) {
+                            smm[vw * GT + g] = m[g];
+                            sml[vw * GT + g] = lw;
+                        }
+                    }
+                }
+            }
+            set_done(L, w, slot + kv_slots);
+            cbar(a, L, w);
+            if (active) {   // merge the 8 (virtual) waves; the split's partial leaves as tagged granules
+                for (int idx = w.cw * 64 + lane; idx < G * D; idx += kCons * 64) {
+                    const int g = idx / D, d = idx % D;
+                    float M = smm[g];
+#pragma unroll
+                    for (int vw = 1; vw < kVWaves; ++vw) M = fmaxf(M, smm[vw * GT + g]);
+                    float Lsum = 0.f, O = 0.f;
+#pragma unroll
+                    for (int vw = 0; vw < kVWaves; ++vw) {
+                        const float mw = smm[vw * GT + g];
+                        const float f = (mw == -INFINITY) ? 0.f : __expf(mw - M);
+                        Lsum = fmaf(f, sml[vw * GT + g], Lsum);
+                        O = fmaf(f, park[((size_t)vw * GT + g) * D + d], O);
+                    }
+                    uint64_t* gr = a.g_part + ((size_t)(kvh * G + g) * a.nsplit + split) * (D + 2);
+                    st_gran(gr + d, tag, __float_as_uint(O));
+                    if (d == 0) {
+                        st_gran(gr + D, tag, __float_as_uint(M));
+                        st_gran(gr + D + 1, tag, __float_as_uint(Lsum));
+                    }
+                }
+            }
+            if (TRACE && l < 4 && w.cw == 0 && lane == 0) tr[l * 12 + 3] = wall_clock64();
+            if (split < G && w.cw < D / 64) {   // this CU merges head kvh*G + split
+                const int head = kvh * G + split;
+                const uint64_t* base = a.g_part + (size_t)head * a.nsplit * (D + 2);
+                uint64_t* xg_head = a.g_attn + (size_t)head * (D / 2);
+                const int dim = w.cw * 64 + lane;
+                const int nb = (a.nsplit + 15) / 16;
+                if (nb <= 1) gather_head<D, 1>(a, L, w, base, n_active, tag, dim, xg_head);
+                else if (nb == 2) gather_head<D, 2>(a, L, w, base, n_active, tag, dim, xg_head);
+                else gather_head<D, 3>(a, L, w, base, n_active, tag, dim, xg_head);
+            }
+        } else {
+            set_done(L, w, slot);
+        }
+        slot += kv_slots;
+        if (TRACE && l < 4 && w.cw == 0 && lane == 0) tr[l * 12 + 4] = wall_clock64();
+
+        // ---- [o + residual] ----
+        gather_vec(a, L, w, a.g_attn, HD / 2, tag, a.nsweep);
+        if (TRACE && l < 4 && w.cw == 0 && lane == 0) tr[l * 12 + 5] = wall_clock64();
+        run_gemv<NSLOT, 1>(a, L, w, opO, slot, xA, [&](int pair, const float (&v)[2]) {
+            if (lane == 0) {
+                const unsigned r = resid[pair - opO.pair0];
+                const unsigned lo = f32_to_bf16(bf16lo(r) + round_bf16(v[0])), hi = f32_to_bf16(bf16hi(r) + round_bf16(v[1]));
+                st_gran(a.g_x1 + pair, tag, lo | (hi << 16));
+            }
+        });
+        slot += opO.nslots;
+        if (TRACE && l < 4 && w.cw == 0 && lane == 0) tr[l * 12 + 6] = wall_clock64();
+
+        // ---- [RMSNorm + gate/up + silu * up] ----
+        norm_w_prefetch(w, W.post_ln, hidden, nwv);
+        gather_vec(a, L, w, a.g_x1, hidden / 2, tag, a.nsweep);
+        if (TRACE && l < 4 && w.cw == 0 && lane == 0) tr[l * 12 + 7] = wall_clock64();
+        if (w.cw == 0 && lane < opD.npairs) resid[lane] = reinterpret_cast<const unsigned*>(xA)[opD.pair0 + lane];
+        rmsnorm_lds(w, xA, xB, W.post_ln, nwv, hidden, a.eps);
+        cbar(a, L, w);
+        run_gemv<NSLOT, 2>(a, L, w, opG, slot, xB, [&](int pair, const float (&v)[4]) {
+            if (lane == 0) {
+                unsigned out[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {   // nn::silu(gate) * up, every primitive's result in bf16 (gemv.hip EPI_SWIGLU)
+                    const float g = round_bf16(v[i]), u = round_bf16(v[2 + i]);   // task rows: gate r0, gate r1, up r0, up r1
+                    const float sgm = round_bf16(1.0f / (1.0f + expf(-g)));
+                    out[i] = f32_to_bf16(round_bf16(g * sgm) * u);
+                }
+                st_gran(a.g_act + pair, tag, out[0] | (out[1] << 16));
+            }
+        });
+        slot += opG.nslots;
+        if (TRACE && l < 4 && w.cw == 0 && lane == 0) tr[l * 12 + 8] = wall_clock64();
+
+        // ---- [down + residual] ----
+        gather_vec(a, L, w, a.g_act, a.I / 2, tag, kCons);
+        if (TRACE && l < 4 && w.cw == 0 && lane == 0) tr[l * 12 + 9] = wall_clock64();
+        run_gemv<NSLOT, 1>(a, L, w, opD, slot, xA, [&](int pair, const float (&v)[2]) {
+            if (lane == 0) {
+                const unsigned r = resid[pair - opD.pair0];
+                const unsigned lo = f32_to_bf16(bf16lo(r) + round_bf16(v[0])), hi = f32_to_bf16(bf16hi(r) + round_bf16(v[1]));
+                if (last) reinterpret_cast<unsigned*>(a.h_out)[pair] = lo | (hi << 16);
+                else st_gran(a.g_x + pair, tag + 1u, lo | (hi << 16));
+            }
+        });
+        slot += opD.nslots;
+        if (TRACE && l < 4 && w.cw == 0 && lane == 0) tr[l * 12 + 10] = wall_clock64();
+    }
+    if (cu == 0 && w.cw == 0 && lane == 0) *a.seq_ptr = seq;
+}
+
+int lds_budget(int hidden, int H, int D, int I, int G, int* xs_bytes) {
+    const int gt = G <= 1 ? 1 : G <= 2 ? 2 : G <= 4 ? 4 : 8;
+    int xs = std::max(std::max(2 * hidden * 2, H * D * 2), I * 2);
+    xs = std::max(xs, kVWaves * gt * D * 4);
+    xs = (xs + 1023) & ~1023;
+    *xs_bytes = xs;
+    const int room = kLdsTotal - kMisc - xs;
+    return room >= 8 * kSlot ? 8 : room >= 6 * kSlot ? 6 : 0;
+}
+
+bool tuned_width(int K) {
+    if (K <= 0 || K % 512 != 0) return false;
+    static const int kSizes[] = {1, 2, 3, 4, 6, 7, 8, 12, 16, 24, 28, 32, 40};   // gemv.hip tuned_nv
+    for (int s : kSizes)
+        if (s == K / 512) return true;
+    return false;
+}
+
+}  // namespace
+
+bool step_engine_ok(int hidden, int H, int Hkv, int D, int I, int nsplit, int cus) {
+    if (cus < 8 || Hkv <= 0 || H % Hkv != 0 || H / Hkv > 8 || (D != 128 && D != 64)) return false;
+    if (!tuned_width(hidden) || !tuned_width(H * D) || !tuned_width(I)) return false;
+    if (Hkv * nsplit > cus) return false;
+    // residual rows a CU owns are parked in LDS (kMaxPairs row pairs)
+    if ((hidden / 2 + cus - 1) / cus > kMaxPairs) return false;
+    int xs = 0;
+    return lds_budget(hidden, H, D, I, H / Hkv, &xs) != 0;
+}
+
+size_t step_engine_granules(int hidden, int H, int Hkv, int D, int I) {
+    // g_x, g_x1: hidden/2; g_qkv: (H + 2 Hkv) D / 2; g_attn: H D / 2; g_act: I / 2; g_part is the engine's attention workspace
+    return (size_t)hidden + (size_t)(H + 2 * Hkv) * D / 2 + (size_t)H * D / 2 + (size_t)I / 2 + 64;
+}
+
+int launch_step_engine(const StepEngineArgs& a_in, int cus, hipStream_t s) {
+    StepEngineArgs a = a_in;
+    const int G = a.H / a.Hkv;
+    OMX_REQUIRE(step_engine_ok(a.hidden, a.H, a.Hkv, a.D, a.I, a.nsplit, cus), "step engine: shape does not qualify");
+    a.nslot = lds_budget(a.hidden, a.H, a.D, a.I, G, &a.xs_bytes);
+    if (a.nsweep != 1) a.nsweep = kCons;
+    if (a.inflight < 0 || a.inflight > 3) a.inflight = 2;
+    const int gt = G <= 1 ? 1 : G <= 2 ? 2 : G <= 4 ? 4 : 8;
+    const size_t shmem = (size_t)a.nslot * kSlot + a.xs_bytes + kMisc;
+    const dim3 grid(cus), block(kBlock);
+#define OMX_SE_LAUNCH(DD, GG, NS, TT)                                                                                              \
+    {                                                                                                                              \
+        OMX_HIP_CHECK(hipFuncSetAttribute((const void*)step_engine_kernel<DD, GG, NS, TT>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                          (int)shmem));                                                                            \
+        OMX_LAUNCH_TIMED((step_engine_kernel<DD, GG, NS, TT>), grid, block, shmem, s, a);                                          \
+        OMX_LAUNCH_CHECK();                                                                                                        \
+        return 0;                                                                                                                  \
+    }
+#define OMX_SE_CASE(DD, GG)                                                 \
+    if (a.D == DD && gt == GG) {                                            \
+        if (a.trace) {                                                      \
+            if (a.nslot == 8) OMX_SE_LAUNCH(DD, GG, 8, true)                \
+            OMX_SE_LAUNCH(DD, GG, 6, true)                                  \
+        }                                                                   \
+        if (a.nslot == 8) OMX_SE_LAUNCH(DD, GG, 8, false)                   \
+        OMX_SE_LAUNCH(DD, GG, 6, false)                                     \
+    }
+    OMX_SE_CASE(128, 1) OMX_SE_CASE(128, 2) OMX_SE_CASE(128, 4) OMX_SE_CASE(128, 8)
+    OMX_SE_CASE(64, 1) OMX_SE_CASE(64, 2) OMX_SE_CASE(64, 4) OMX_SE_CASE(64, 8)
+#undef OMX_SE_CASE
+#undef OMX_SE_LAUNCH
+    return set_error("step engine: head_dim %d unsupported", a.D);
+}
+
+}  // namespace omx

@@ -48,6 +48,7 @@ ENGINE_SIGNATURES = {
     "omx_qwen3_decode_path": (c_int, [c_void_p, ctypes.POINTER(c_int)]),
     "omx_qwen3_debug_trace_step": (c_int, [c_void_p, c_void_p, ctypes.c_size_t, ctypes.POINTER(c_int)]),
     "omx_qwen3_time_step_kernels": (c_int, [c_void_p, c_int, ctypes.POINTER(ctypes.c_float)]),
+    "omx_qwen3_debug_trace_engine": (c_int, [c_void_p, c_void_p, ctypes.c_size_t, ctypes.POINTER(c_int)]),
     "omx_qwen3_verify": (c_int, [c_void_p, ctypes.POINTER(c_uint32), c_int, ctypes.POINTER(c_uint32)]),
     "omx_qwen3_verify_logits": (c_int, [c_void_p, c_int, c_void_p, c_int]),
     "omx_qwen3_trim": (c_int, [c_void_p, c_int, c_uint32]),
@@ -288,12 +289,12 @@ class Model:
         check(lib.omx_qwen3_decode_path(self._h, ctypes.byref(v)))
         return ("unbuilt", "graph", "eager")[v.value]
 
-    KERNEL_CLASSES = ("qkv", "attention", "o", "gate_up", "down", "lm_head")
+    KERNEL_CLASSES = ("qkv", "attention", "o", "gate_up", "down", "lm_head", "step_engine")
 
     def time_step_kernels(self, steps: int = 4) -> dict:
         """Average in-step duration (microseconds) of each per-layer kernel, HIP events on the step's stream around every launch of
         `steps` real (eager) decode steps: each launch's own HIP start / stop events -- omx_qwen3_time_step_kernels."""
-        us = (ctypes.c_float * 6)()
+        us = (ctypes.c_float * 7)()
         check(lib.omx_qwen3_time_step_kernels(self._h, steps, us))
         return dict(zip(self.KERNEL_CLASSES, (float(v) for v in us)))
 

@@ -517,6 +517,7 @@ int enqueue_step_engine(omx_qwen3 m, hipStream_t s) {
     a.abort_flag = m->wait_abort;
     a.nsweep = env_int("OMX_SE_NSWEEP", 1);
     a.inflight = env_int("OMX_SE_INFLIGHT", 2);
+    a.thin_gather = env_int("OMX_SE_THIN", 1);
     a.trace = m->se_trace;
     return launch_step_engine(a, m->cus, s);
 }
@@ -1045,7 +1046,7 @@ int omx_qwen3_create(omx_qwen3* out, const omx_qwen3_config* cfg) {
     OMX_REQUIRE(c.num_experts > 0 || m->I % 64 == 0, "InvalidConfig: per-rank intermediate %d must be a multiple of 64", m->I);
     OMX_REQUIRE(!c.quant_bits || (c.hidden_size % 512 == 0 && (m->H * c.head_dim) % 512 == 0 && (c.num_experts > 0 || m->I % 512 == 0)),
                 "InvalidConfig: quantized checkpoints need hidden %d, attention width %d and intermediate %d to be multiples of 512", c.hidden_size, m->H * c.head_dim, m->I);
-    OMX_REQUIRE(!c.attention_bias || (c.tp_size == 1 && !c.quant_bits), "InvalidConfig: attention_bias (Qwen2) runs bf16 on a single GPU");
+    OMX_REQUIRE(!c.attention_bias || !c.quant_bits, "InvalidConfig: attention_bias (Qwen2) runs on bf16 checkpoints");
     const int step = 256;   // cache.rs:110-117
     m->cap = ((c.max_context > 0 ? c.max_context : 4096) + step - 1) / step * step;
     OMX_HIP_CHECK(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking));
@@ -1219,8 +1220,11 @@ int omx_qwen3_synth_weights(omx_qwen3 m, uint32_t base_seed) {
             return 1;
         if (!c.no_qk_norm && (make(p + "self_attn.q_norm.weight", 1, D, D, 0, 0, true) || make(p + "self_attn.k_norm.weight", 1, D, D, 0, 0, true)))
             return 1;
-        if (c.attention_bias && (make(p + "self_attn.q_proj.bias", 1, Hq, Hq, 0, 0, false) || make(p + "self_attn.k_proj.bias", 1, Hk, Hk, 0, 0, false) ||
-                                 make(p + "self_attn.v_proj.bias", 1, Hk, Hk, 0, 0, false)))
+        // biases: this rank's columns of the logical [1, H_total * D] vector -- the same offsets as the rows of its projection
+        const int64_t Hq_all = (int64_t)c.num_attention_heads * D, Hk_all = (int64_t)c.num_key_value_heads * D;
+        if (c.attention_bias && (make(p + "self_attn.q_proj.bias", 1, Hq, Hq_all, 0, (int64_t)r * Hq, false) ||
+                                 make(p + "self_attn.k_proj.bias", 1, Hk, Hk_all, 0, kv_row0, false) ||
+                                 make(p + "self_attn.v_proj.bias", 1, Hk, Hk_all, 0, kv_row0, false)))
             return 1;
         if (c.num_experts > 0) {
             const std::string mp = p + (c.moe_mode == 0 ? "block_sparse_moe." : "mlp.");

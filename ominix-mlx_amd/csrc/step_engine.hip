@@ -122,6 +122,37 @@ __device__ __forceinline__ float swap_halves(float v) {     // value of lane (l 
     return dpp_f<0x1B>(dpp_f<kDppHalfMirror>(v));              // (7 - i) then quad reverse == i ^ 4
 }
 
+// value of lane (r * LPR + c) for every token row r of the wave, in all lanes: VALU permutes only (an LDS-crossbar __shfl per value
+// and row -- a dependent ds_bpermute + wait each -- cost 6 us per (virtual) wave).  v_permlane16_swap exchanges the odd 16-lane
+// rows of its first operand with the even rows of its second, v_permlane32_swap the upper half of the first with the lower half of
+// the second; with both operands x:  p16 -> (x0 x0 x2 x2), (x1 x1 x3 x3);  p32 of each -> row 0 / row 2 and row 1 / row 3 everywhere.
+__device__ __forceinline__ void rows4(float x, float& r0, float& r1, float& r2, float& r3) {
+    const auto p = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    const auto e = __builtin_amdgcn_permlane32_swap(p[0], p[0], false, false);
+    const auto o = __builtin_amdgcn_permlane32_swap(p[1], p[1], false, false);
+    r0 = __uint_as_float(e[0]); r2 = __uint_as_float(e[1]);
+    r1 = __uint_as_float(o[0]); r3 = __uint_as_float(o[1]);
+}
+// sum over the TPW token rows of a wave in row order (0 + r0 + r1 + ...), LPR lanes per row: TPW = 4 (LPR 16) or 8 (LPR 8)
+template <int TPW>
+__device__ __forceinline__ float rows_sum_ordered(float x, int lane) {
+    if (TPW == 4) {
+        float r0, r1, r2, r3;
+        rows4(x, r0, r1, r2, r3);
+        return (((0.f + r0) + r1) + r2) + r3;
+    }
+    // 8 rows of 8 lanes: rows 2i / 2i + 1 are the halves of 16-lane row i
+    const float sw = dpp_f<0x128>(x);                       // row_ror:8: the other half's lane
+    const bool hi = (lane & 8) != 0;
+    float e[4], o[4];
+    rows4(hi ? sw : x, e[0], e[1], e[2], e[3]);             // even token rows
+    rows4(hi ? x : sw, o[0], o[1], o[2], o[3]);             // odd token rows
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) sum = (sum + e[i]) + o[i];
+    return sum;
+}
+
 // ---- per-wave view of the workgroup's LDS ----
 struct Lds {
     unsigned char* base;     // ring at 0
@@ -283,42 +314,118 @@ __device__ __forceinline__ void rmsnorm_lds(const Wave& w, const u32x4* xraw, u3
 // ---- the consumers' GEMV over one op: task t (a row pair) is reduced by wave t % 3 from the ring with gemv.hip's arithmetic:
 //      lane l owns elements (j * 64 + l) * 8 .. + 7 of every row, one fma chain over j (per K quarter when K/512 > 8), wave_sum,
 //      quarters added in order.  epi(pair, v[]) publishes on lane 0. ----
-template <int NSLOT, int LR, class Epi>
-__device__ __forceinline__ void run_gemv(const StepEngineArgs& a, const Lds& L, Wave& w, const OpShape& op, unsigned slot0, const u32x4* x,
-                                         Epi epi) {
+// NVW_ / NQ_ > 0: pieces per quarter and quarters at compile time.  A wave reduces a GROUP of rows at once -- two row pairs of a
+// narrow op, one pair with its four K quarters of a wide one, the gate and up rows of a pair: 4 to 8 independent fma chains stepped
+// in turn, every LDS read of a step issued ahead of its first fma.  (A runtime loop over the pieces ran ds_read -> wait -> 16
+// dependent unpack + fma per turn, 4400 cycles per 16 KiB slot and wave; hipcc also finishes one row's chain before it starts the
+// next unless the source interleaves them: the consumers could not keep up with the loader.)  0: any width, runtime loops.
+template <int NSLOT, int LR, int NVW_, int NQ_, class Epi>
+__device__ __forceinline__ void run_gemv_t(const StepEngineArgs& a, const Lds& L, Wave& w, const OpShape& op, unsigned slot0, const u32x4* x,
+                                           Epi epi) {
     constexpr int R = 2 * LR;
     constexpr unsigned RING = NSLOT * kPPS;
-    const int ppr = op.ppr, nq = quarters_of(ppr), nvw = ppr / nq;
+    constexpr int PG = (NVW_ > 0 && LR == 1 && NQ_ == 1) ? 2 : 1;   // row pairs per group
+    constexpr int RG = PG * R;                                       // rows per group
+    const int ppr = NVW_ > 0 ? NVW_ * NQ_ : op.ppr, nq = NVW_ > 0 ? NQ_ : quarters_of(ppr), nvw = NVW_ > 0 ? NVW_ : ppr / nq;
     const unsigned end = slot0 + op.nslots;
-    set_done(L, w, w.cw < op.npairs ? slot0 + (unsigned)(w.cw * R * ppr) / kPPS : end);
-    for (int t = w.cw; t < op.npairs; t += kCons) {
-        const unsigned idx0 = (unsigned)t * R * ppr;
-        wait_ready(a, L, w, slot0 + (idx0 + R * ppr - 1) / kPPS + 1);
-        float v[R];
-        const unsigned p0 = slot0 * kPPS + idx0;
-        for (int q = 0; q < nq; ++q) {
-            float acc[R];
+    const int ngroups = (op.npairs + PG - 1) / PG;
+    const unsigned gp = (unsigned)RG * ppr, total = (unsigned)op.npairs * R * ppr;   // pieces per group, of the op
+    set_done(L, w, w.cw < ngroups ? slot0 + (w.cw * gp) / kPPS : end);
+    for (int g = w.cw; g < ngroups; g += kCons) {
+        const unsigned idx0 = g * gp, idx1 = min(idx0 + gp, total);
+        wait_ready(a, L, w, slot0 + (idx1 - 1) / kPPS + 1);
+        float v[RG];
+        const unsigned p0 = slot0 * kPPS;
+        if constexpr (NVW_ > 0) {
+            float acc[RG][NQ_];
 #pragma unroll
-            for (int s = 0; s < R; ++s) acc[s] = 0.f;
-            for (int jj = 0; jj < nvw; ++jj) {
-                const int j = q * nvw + jj;
-                float xf[8];
-                unpack8(x[j * 64 + w.lane], xf);
+            for (int s = 0; s < RG; ++s)
 #pragma unroll
-                for (int s = 0; s < R; ++s) {
-                    const unsigned piece = (p0 + s * ppr + j) % RING;
-                    const u32x4 wv = *reinterpret_cast<const u32x4*>(L.base + (size_t)piece * kPiece + w.lane * 16);
-                    acc[s] = dot8_chain(wv, xf, acc[s]);
+                for (int q = 0; q < NQ_; ++q) acc[s][q] = 0.f;
+#pragma unroll
+            for (int jj = 0; jj < NVW_; ++jj) {
+                u32x4 xv[NQ_], wv[RG][NQ_];
+#pragma unroll
+                for (int q = 0; q < NQ_; ++q) xv[q] = x[(q * NVW_ + jj) * 64 + w.lane];
+#pragma unroll
+                for (int s = 0; s < RG; ++s)
+#pragma unroll
+                    for (int q = 0; q < NQ_; ++q) {
+                        const unsigned piece = min(idx0 + s * ppr + q * NVW_ + jj, total - 1);   // (rows of a missing second pair: any valid piece)
+                        wv[s][q] = *reinterpret_cast<const u32x4*>(L.base + (size_t)((p0 + piece) % RING) * kPiece + w.lane * 16);
+                    }
+                float xf[NQ_][8];
+#pragma unroll
+                for (int q = 0; q < NQ_; ++q) unpack8(xv[q], xf[q]);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {   // gemv.hip dot8: lo then hi of each dword -- per chain; the chains take turns
+#pragma unroll
+                    for (int s = 0; s < RG; ++s)
+#pragma unroll
+                        for (int q = 0; q < NQ_; ++q) acc[s][q] = fmaf(bf16lo(wv[s][q][i]), xf[q][2 * i], acc[s][q]);
+#pragma unroll
+                    for (int s = 0; s < RG; ++s)
+#pragma unroll
+                        for (int q = 0; q < NQ_; ++q) acc[s][q] = fmaf(bf16hi(wv[s][q][i]), xf[q][2 * i + 1], acc[s][q]);
                 }
             }
 #pragma unroll
-            for (int s = 0; s < R; ++s) {
-                const float p = wave_sum(acc[s]);
-                v[s] = nq == 1 ? p : (q == 0 ? 0.f + p : v[s] + p);
+            for (int s = 0; s < RG; ++s) {
+                if (NQ_ == 1) {
+                    v[s] = wave_sum(acc[s][0]);
+                } else {
+                    float t = 0.f;
+#pragma unroll
+                    for (int q = 0; q < NQ_; ++q) t += wave_sum(acc[s][q]);
+                    v[s] = t;
+                }
+            }
+        } else {
+            for (int q = 0; q < nq; ++q) {
+                float acc[R];
+#pragma unroll
+                for (int s = 0; s < R; ++s) acc[s] = 0.f;
+                for (int jj = 0; jj < nvw; ++jj) {
+                    const int j = q * nvw + jj;
+                    float xf[8];
+                    unpack8(x[j * 64 + w.lane], xf);
+#pragma unroll
+                    for (int s = 0; s < R; ++s) {
+                        const unsigned piece = (p0 + idx0 + s * ppr + j) % RING;
+                        const u32x4 wv = *reinterpret_cast<const u32x4*>(L.base + (size_t)piece * kPiece + w.lane * 16);
+                        acc[s] = dot8_chain(wv, xf, acc[s]);
+                    }
+                }
+#pragma unroll
+                for (int s = 0; s < R; ++s) {
+                    const float p = wave_sum(acc[s]);
+                    v[s] = nq == 1 ? p : (q == 0 ? 0.f + p : v[s] + p);
+                }
             }
         }
-        set_done(L, w, t + kCons < op.npairs ? slot0 + ((unsigned)(t + kCons) * R * ppr) / kPPS : end);
-        epi(op.pair0 + t, v);
+        set_done(L, w, g + kCons < ngroups ? slot0 + ((g + kCons) * gp) / kPPS : end);
+#pragma unroll
+        for (int k = 0; k < PG; ++k)
+            if (g * PG + k < op.npairs) {
+                float vp[R];
+#pragma unroll
+                for (int s = 0; s < R; ++s) vp[s] = v[k * R + s];
+                epi(op.pair0 + g * PG + k, vp);
+            }
+    }
+}
+// widths with a straight-line body: K = 4096 (8 pieces), 12288 (4 x 6: gemv.hip splits rows wider than 8 pieces in quarters), and the
+// small models' 1024 / 2048 / 3072; everything else takes the runtime loops
+template <int NSLOT, int LR, class Epi>
+__device__ __forceinline__ void run_gemv(const StepEngineArgs& a, const Lds& L, Wave& w, const OpShape& op, unsigned slot0, const u32x4* x,
+                                         Epi epi) {
+    switch (op.ppr) {
+        case 8: return run_gemv_t<NSLOT, LR, 8, 1>(a, L, w, op, slot0, x, epi);
+        case 24: return run_gemv_t<NSLOT, LR, 6, 4>(a, L, w, op, slot0, x, epi);
+        case 2: return run_gemv_t<NSLOT, LR, 2, 1>(a, L, w, op, slot0, x, epi);
+        case 4: return run_gemv_t<NSLOT, LR, 4, 1>(a, L, w, op, slot0, x, epi);
+        case 6: return run_gemv_t<NSLOT, LR, 6, 1>(a, L, w, op, slot0, x, epi);
+        default: return run_gemv_t<NSLOT, LR, 0, 0>(a, L, w, op, slot0, x, epi);
     }
 }
 
@@ -327,7 +434,7 @@ template <int NSLOT>
 struct Loader {
     unsigned ctl;
     unsigned char* ring;
-    int lane, inflight;
+    int lane, inflight, thin_gather;
     unsigned issued, published;
     bool dead;
 
@@ -361,7 +468,7 @@ struct Loader {
     // fills in flight: `inflight` while streaming, one while this CU gathers (gather-pass: its coherent loads queue behind ours)
     __device__ __forceinline__ void landed(bool thin) {
         issued += 1;
-        const int keep = thin ? 1 : inflight;
+        const int keep = (thin && thin_gather) ? 1 : inflight;
         if (inflight <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // debug: no fill in flight past its issue
         else if (keep >= 3) asm volatile("s_waitcnt vmcnt(48)" ::: "memory");
         else if (keep == 2) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
@@ -369,42 +476,71 @@ struct Loader {
         if (inflight <= 0) publish(issued);
         else if (issued > (unsigned)keep) publish(issued - keep);
     }
-    // up to three byte ranges back to back: n0 pieces at p0, then n1 at p1, then n2 at p2
-    __device__ __forceinline__ void seq(const char* p0, int n0, const char* p1, int n1, const char* p2, int n2) {
-        const int total = n0 + n1 + n2, nfill = (total + kPPS - 1) / kPPS;
+    // ---- the piece stream: a current contiguous range (cp, cl pieces left) and what follows it ----
+    const char* cp;
+    int cl;
+    const char *n1p, *n2p;   // seq: the ranges after the current one; alt: n1p = the other cursor
+    int n1n, n2n;
+    int run;                 // alt: pieces per run (0: seq mode)
+    int left;                // pieces of the stream not yet issued
+    __device__ __forceinline__ void next_range() {
+        if (run) {           // gate rows of a pair done -> its up rows (or the next pair's gate rows): the cursors swap
+            const char* t = cp; cp = n1p; n1p = t;
+            cl = run;
+        } else {
+            cp = n1p; cl = n1n;
+            n1p = n2p; n1n = n2n; n2n = 0;
+        }
+    }
+    __device__ __forceinline__ void stream(int total) {
+        left = total;
+        const int nfill = (total + kPPS - 1) / kPPS;
         for (int f = 0; f < nfill; ++f) {
             const bool thin = space();
             unsigned char* dst = slot_ptr();
+            if (cl >= kPPS) {
+                // 16 KiB in one piece of memory: four address updates, the 1 KiB steps in between ride in the instruction's immediate
+                // offset, which moves BOTH the global and the LDS address
 #pragma unroll
-            for (int i = 0; i < kPPS; ++i) {
-                const int k = min(f * kPPS + i, total - 1);
-                const char* p = k < n0 ? p0 + (long)k * kPiece : k < n0 + n1 ? p1 + (long)(k - n0) * kPiece : p2 + (long)(k - n0 - n1) * kPiece;
-                piece(p, dst + i * kPiece);
+                for (int g = 0; g < 4; ++g) {
+                    const char* p = cp + g * 4096 + lane * 16;
+                    unsigned char* d = dst + g * 4096;
+                    __builtin_amdgcn_global_load_lds((glb_ptr_t)p, (lds_ptr_t)d, 16, 0, 2 /* nt */);
+                    __builtin_amdgcn_global_load_lds((glb_ptr_t)p, (lds_ptr_t)d, 16, 1024, 2);
+                    __builtin_amdgcn_global_load_lds((glb_ptr_t)p, (lds_ptr_t)d, 16, 2048, 2);
+                    __builtin_amdgcn_global_load_lds((glb_ptr_t)p, (lds_ptr_t)d, 16, 3072, 2);
+                }
+                cp += kSlot; cl -= kPPS; left -= kPPS;
+                if (cl == 0 && left > 0) next_range();
+            } else {
+#pragma unroll
+                for (int i = 0; i < kPPS; ++i) {
+                    piece(cp, dst + i * kPiece);
+                    if (left > 1) {   // (past the end: the last piece again)
+                        --left;
+                        cp += kPiece;
+                        if (--cl == 0) next_range();
+                    }
+                }
+                if (left == 1 && f + 1 == nfill) left = 0;
             }
             landed(thin);
         }
     }
-    // two ranges taken alternately in runs of `run` pieces (gate rows of a pair, up rows of the pair, ...): 2 * n pieces
-    __device__ __forceinline__ void alt(const char* pa, const char* pb, int run, int n) {
-        const int total = 2 * n, nfill = (total + kPPS - 1) / kPPS;
-        int left = run, k = 0;
-        for (int f = 0; f < nfill; ++f) {
-            const bool thin = space();
-            unsigned char* dst = slot_ptr();
-#pragma unroll
-            for (int i = 0; i < kPPS; ++i) {
-                piece(pa, dst + i * kPiece);
-                if (k + 1 < total) {   // (past the end: the last piece again)
-                    ++k;
-                    pa += kPiece;
-                    if (--left == 0) {
-                        const char* t = pa; pa = pb; pb = t;
-                        left = run;
-                    }
-                }
-            }
-            landed(thin);
-        }
+    // up to three byte ranges back to back: n0 pieces at p0, then n1 at p1, then n2 at p2 (empty ranges allowed)
+    __device__ __forceinline__ void seq(const char* p0, int n0, const char* p1, int n1, const char* p2, int n2) {
+        run = 0;
+        if (n0 == 0) { p0 = p1; n0 = n1; p1 = p2; n1 = n2; n2 = 0; }
+        if (n0 == 0) { p0 = p1; n0 = n1; n1 = 0; }
+        if (n1 == 0) { p1 = p2; n1 = n2; n2 = 0; }
+        cp = p0; cl = n0; n1p = p1; n1n = n1; n2p = p2; n2n = n2;
+        stream(n0 + n1 + n2);
+    }
+    // two ranges taken alternately in runs of `r` pieces (gate rows of a pair, up rows of the pair, ...): 2 * n pieces
+    __device__ __forceinline__ void alt(const char* pa, const char* pb, int r, int n) {
+        run = r;
+        cp = pa; cl = r; n1p = pb; n1n = n2n = 0; n2p = pb;
+        stream(2 * n);
     }
 };
 
@@ -466,7 +602,9 @@ __device__ __forceinline__ void gather_head(const StepEngineArgs& a, const Lds& 
 
 // D: head dim; GT: query heads per KV head rounded up to a power of two; NSLOT: ring slots
 template <int D, int GT, int NSLOT, bool TRACE>
-__global__ __launch_bounds__(kBlock, 1) void step_engine_kernel(const StepEngineArgs a) {
+__global__ __launch_bounds__(kBlock, 1) void step_engine_kernel(const StepEngineArgs a, const StepEngineLayer* __restrict__ layers) {
+    // (`layers` is its own noalias read-only parameter so that the per-layer pointers come through the scalar cache: as a member of
+    //  `a` they were vector loads, and the loader's s_waitcnt vmcnt(0) for them drained its whole LDS-DMA queue at every op)
     constexpr int LPR = D / 8;            // lanes per K/V row
     constexpr int TPW = 64 / LPR;         // token rows per piece == one unit of attn_step.hip
     constexpr unsigned RING = NSLOT * kPPS;
@@ -510,10 +648,10 @@ __global__ __launch_bounds__(kBlock, 1) void step_engine_kernel(const StepEngine
     if (wave == 0) {
         // =========================== loader ===========================
         Loader<NSLOT> ld;
-        ld.ctl = L.ctl; ld.ring = smem; ld.lane = lane; ld.inflight = a.inflight; ld.issued = 0; ld.published = 0; ld.dead = false;
+        ld.ctl = L.ctl; ld.ring = smem; ld.lane = lane; ld.inflight = a.inflight; ld.thin_gather = a.thin_gather; ld.issued = 0; ld.published = 0; ld.dead = false;
         const long n0 = (long)a.H * D, n1 = (long)a.Hkv * D;   // rows of q, of k (and v)
         for (int l = 0; l < a.L; ++l) {
-            const StepEngineLayer& W = a.layers[l];
+            const StepEngineLayer W = layers[l];
             {   // rows [r0, r1) of the stack [q | k | v]
                 const long r0 = 2l * opQ.pair0, r1 = r0 + 2l * opQ.npairs, rb = 2l * hidden;
                 const long q0 = min(r0, n0), q1 = min(r1, n0);
@@ -555,7 +693,7 @@ __global__ __launch_bounds__(kBlock, 1) void step_engine_kernel(const StepEngine
     unsigned slot = 0;   // first ring slot of the current op (the loader counts the same way)
 
     for (int l = 0; l < a.L; ++l) {
-        const StepEngineLayer& W = a.layers[l];
+        const StepEngineLayer W = layers[l];
         const unsigned tag = seq * (unsigned)a.L + (unsigned)l + 1u;
         const bool last = l + 1 == a.L;
         if (TRACE && l < 4 && w.cw == 0 && lane == 0) tr[l * 12 + 0] = wall_clock64();
@@ -594,6 +732,7 @@ __global__ __launch_bounds__(kBlock, 1) void step_engine_kernel(const StepEngine
                       [=](int i) { return i < nq ? q0 + i : i < nq + nk ? k0 + i - nq : v0 + i - nq - nk; });
             }
             cbar(a, L, w);
+            if (TRACE && l < 4 && w.cw == 0 && lane == 0) tr[48 + l * 4 + 0] = wall_clock64();   // q / k / v of the group swept
             const int c = lane % LPR, sg = lane / LPR;
             {   // rows 0..G-1: query heads, row G: the new key -- one row per wave turn, all four token rows of the wave redundantly
                 float cs[8], sn[8];
@@ -627,6 +766,7 @@ __global__ __launch_bounds__(kBlock, 1) void step_engine_kernel(const StepEngine
                 }
             }
             cbar(a, L, w);
+            if (TRACE && l < 4 && w.cw == 0 && lane == 0) tr[48 + l * 4 + 1] = wall_clock64();   // normed + roped
             if (active) {
                 const int n_units = a.chunk / TPW;
                 u32x4 q[GT];
@@ -706,11 +846,7 @@ __global__ __launch_bounds__(kBlock, 1) void step_engine_kernel(const StepEngine
                         float ow[8];
 #pragma unroll
                         for (int e = 0; e < 8; ++e) {
-                            const float x = o[g][e >> 1][e & 1];
-                            float sum = 0.f;
-#pragma unroll
-                            for (int r = 0; r < TPW; ++r) sum += __shfl(x, r * LPR + c, 64);
-                            ow[e] = sum;
+                            ow[e] = rows_sum_ordered<TPW>(o[g][e >> 1][e & 1], lane);
                         }
                         float lw = readlane_f(lsum[g], 0);
 #pragma unroll
@@ -729,6 +865,7 @@ __global__ __launch_bounds__(kBlock, 1) void step_engine_kernel(const StepEngine
             }
             set_done(L, w, slot + kv_slots);
             cbar(a, L, w);
+            if (TRACE && l < 4 && w.cw == 0 && lane == 0) tr[48 + l * 4 + 2] = wall_clock64();   // own chunk done
             if (active) {   // merge the 8 (virtual) waves; the split's partial leaves as tagged granules
                 for (int idx = w.cw * 64 + lane; idx < G * D; idx += kCons * 64) {
                     const int g = idx / D, d = idx % D;
@@ -869,7 +1006,7 @@ int launch_step_engine(const StepEngineArgs& a_in, int cus, hipStream_t s) {
     {                                                                                                                              \
         OMX_HIP_CHECK(hipFuncSetAttribute((const void*)step_engine_kernel<DD, GG, NS, TT>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                           (int)shmem));                                                                            \
-        OMX_LAUNCH_TIMED((step_engine_kernel<DD, GG, NS, TT>), grid, block, shmem, s, a);                                          \
+        OMX_LAUNCH_TIMED((step_engine_kernel<DD, GG, NS, TT>), grid, block, shmem, s, a, a.layers);                                          \
         OMX_LAUNCH_CHECK();                                                                                                        \
         return 0;                                                                                                                  \
     }

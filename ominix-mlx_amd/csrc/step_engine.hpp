@@ -40,6 +40,7 @@ struct StepEngineArgs {
     unsigned* abort_flag;
     int nsweep;                      // consumer waves that sweep a hidden-sized edge (1 or 3)
     int inflight;                    // loader: fills in flight before it waits for the oldest (2 or 3)
+    int thin_gather;                 // loader: one fill in flight while its CU sweeps granules (MI355X_MICROARCH.md gather-pass)
     unsigned long long* trace;       // optional [grid][kTraceWords] wall-clock stamps (tools/step_engine_trace.py)
     int xs_bytes, nslot;             // set by launch_step_engine
 };

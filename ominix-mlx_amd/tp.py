@@ -17,7 +17,9 @@ import numpy as np
 from .loader import keep_kind
 
 ROW_SPLIT = ("self_attn.q_proj.weight", "self_attn.k_proj.weight", "self_attn.v_proj.weight",
-             "mlp.gate_proj.weight", "mlp.up_proj.weight", "lm_head.weight")
+             "mlp.gate_proj.weight", "mlp.up_proj.weight", "lm_head.weight",
+             # Qwen2's projection biases (qwen3-mlx/src/qwen2.rs:112-124) follow the rows of their Linear
+             "self_attn.q_proj.bias", "self_attn.k_proj.bias", "self_attn.v_proj.bias")
 COL_SPLIT = ("self_attn.o_proj.weight", "mlp.down_proj.weight")
 
 

@@ -301,6 +301,9 @@ def test_step_attention_long_context_matches_oracle(omx):
 TP_CONFIGS = {
     "kv_split": CONFIGS["gqa4_d128"],                                                          # 8 heads / 2 KV heads over 2 ranks
     "kv_replicated": rq.Qwen3Config(1024, 2, 3072, 8, 1, 128, 4096, 1e-6, 1e6, False),          # 1 KV head: both ranks hold it
+    # Qwen2 wiring under TP (q/k/v Linear with bias, no q/k norm; qwen2.rs:100-160): the biases are sharded like the rows
+    "qwen2_bias_kv_split": rq.Qwen3Config(1024, 2, 3072, 8, 2, 128, 4096, 1e-6, 1e6, False, qk_norm=False, attention_bias=True),
+    "qwen2_bias_kv_replicated": rq.Qwen3Config(1024, 2, 3072, 8, 1, 128, 4096, 1e-6, 1e6, False, qk_norm=False, attention_bias=True),
 }
 
 
@@ -329,8 +332,9 @@ def test_tensor_parallel_two_ranks_on_one_gpu(omx, monkeypatch, name, serial_pre
                          intermediate_size=cfg.intermediate_size, num_attention_heads=cfg.num_attention_heads,
                          num_key_value_heads=cfg.num_key_value_heads, head_dim=cfg.head_dim, vocab_size=cfg.vocab_size,
                          rms_norm_eps=cfg.rms_norm_eps, rope_theta=cfg.rope_theta,
-                         tie_word_embeddings=cfg.tie_word_embeddings, max_context=256, tp_rank=r, tp_size=world)
-        if name == "kv_replicated" and r == 1:
+                         tie_word_embeddings=cfg.tie_word_embeddings, max_context=256, tp_rank=r, tp_size=world,
+                         qk_norm=cfg.qk_norm, attention_bias=cfg.attention_bias)
+        if name.endswith("kv_replicated") and r == 1 or name == "qwen2_bias_kv_split" and r == 0:
             m.load_weights(rq.synth_weights(cfg))          # one rank from host arrays (tp.shard with the KV head rule), one generated
         else:
             m.synth_weights()

@@ -129,6 +129,13 @@ def test_shard_shapes():
     assert tp.shard("model.layers.0.self_attn.q_proj.weight", w, 1, 4).shape == (8, 16)
     np.testing.assert_array_equal(tp.shard("model.layers.0.mlp.down_proj.weight", w, 3, 4), w[:, 12:16])
     assert tp.shard("model.norm.weight", w, 1, 4) is w
+    # Qwen2 projection biases follow the rows of their Linear: a 28 x 128 q bias at TP = 4, a 4 x 128 k bias split over
+    # 4 ranks, and the k / v bias of the one KV head two ranks share at TP = 8 over 4 KV heads
+    qb = np.arange(28 * 128, dtype=np.float32)
+    np.testing.assert_array_equal(tp.shard("model.layers.3.self_attn.q_proj.bias", qb, 2, 4), qb[2 * 896:3 * 896])
+    kb = np.arange(4 * 128, dtype=np.float32)
+    np.testing.assert_array_equal(tp.shard("model.layers.3.self_attn.k_proj.bias", kb, 3, 4), kb[384:512])
+    np.testing.assert_array_equal(tp.shard("model.layers.3.self_attn.v_proj.bias", kb, 5, 8, num_key_value_heads=4, head_dim=128), kb[256:384])
     with pytest.raises(ValueError):
         tp.check_divisible(num_attention_heads=28, num_key_value_heads=4, intermediate_size=18944, vocab_size=152064, world=8)   # 28 heads / 8
     # fewer KV heads than ranks: replicated (32 heads, 4 KV heads at TP = 8: two ranks per KV head, a query group of 8 splits in 2)

@@ -37,4 +37,10 @@ for l in range(min(4, L)):
         d = "" if prev is None else f"   +{np.median(v) - prev:6.2f}"
         print(f"   {nm:28s} median {np.median(v):8.2f}  min {v.min():8.2f}  max {v.max():8.2f}{d}")
         prev = np.median(v)
+        if k == 2:
+            for kk, nn in enumerate(["  group q/k/v swept", "  normed + roped", "  own chunk done (before merge)"]):
+                vv = (t[:, 48 + l * 4 + kk] - t0) / 100.0
+                vv = vv[t[:, 48 + l * 4 + kk] > 0]
+                if vv.size:
+                    print(f"   {nn:28s} median {np.median(vv):8.2f}  min {vv.min():8.2f}  max {vv.max():8.2f}")
 m.close()

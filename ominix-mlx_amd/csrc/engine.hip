@@ -481,22 +481,29 @@ int enqueue_step_quant(omx_qwen3 m, bool with_head) {
 
 // The layers of the step as ONE persistent launch (csrc/step_engine.hip): dense bf16 model on a single rank, a shape the engine's
 // consumers reproduce bit for bit, every CU of the device free for one resident workgroup.  OMX_STEP_ENGINE=0 keeps one launch per op.
-bool step_engine_takes(omx_qwen3 m) {
+// OMX_STEP_ENGINE=2: the hybrid step -- attention + o stay their own launch (attn_step.hip: a chain of three all-to-all hand-offs that a
+// launch boundary serves as well as granules do), everything between two attention launches ([gate/up] [down] [next layer's q/k/v]) is one
+// segment of the engine: two launches per layer instead of four, the weight stream of three ops crossing its two edges without a stop.
+int step_engine_mode(omx_qwen3 m) {
     const char* e = getenv("OMX_STEP_ENGINE");         // (read per call: tests flip it between engines of one process)
-    const bool on = e ? e[0] == '1' : false;
+    const int mode = e ? atoi(e) : 0;
     const omx_qwen3_config& c = m->cfg;
-    return on && !m->se_disabled && c.quant_bits == 0 && c.num_experts == 0 && c.tp_size == 1 && c.ep_size <= 1 && m->allreduce == nullptr &&
+    const bool ok = mode > 0 && !m->se_disabled && c.quant_bits == 0 && c.num_experts == 0 && c.tp_size == 1 && c.ep_size <= 1 && m->allreduce == nullptr &&
            !c.attention_bias && m->se_gran != nullptr && m->cus > 0 &&
            step_engine_ok(c.hidden_size, m->H, m->Hkv, c.head_dim, m->I, m->attn_nsplit, m->cus);
+    return ok ? (mode == 2 ? 2 : 1) : 0;
 }
+bool step_engine_takes(omx_qwen3 m) { return step_engine_mode(m) != 0; }
 
 static int env_int(const char* name, int dflt) {
     const char* v = getenv(name);
     return v ? atoi(v) : dflt;
 }
 
-// [embedding + every layer] in one launch; the residual stream after the last layer lands in m->h2
-int enqueue_step_engine(omx_qwen3 m, hipStream_t s) {
+// seg_layer < 0: [embedding + every layer] in one launch; the residual stream after the last layer lands in m->h2.
+// seg_layer = i: one segment of the hybrid step -- [gate/up, down] of layer i - 1 on the post-attention residual in m->h2, the new residual
+// to m->h; [RMSNorm + q/k/v] of layer i into m->qkv
+int enqueue_step_engine(omx_qwen3 m, hipStream_t s, int seg_layer = -1) {
     const omx_qwen3_config& c = m->cfg;
     const int D = c.head_dim, hd = c.hidden_size;
     StepEngineArgs a = {};
@@ -513,7 +520,9 @@ int enqueue_step_engine(omx_qwen3 m, hipStream_t s) {
     a.g_attn = g; g += (size_t)m->H * D / 2;
     a.g_act = g;
     a.g_part = m->attn_gran;
-    a.h_out = m->h2;
+    a.h_out = seg_layer < 0 ? m->h2 : m->h;
+    a.seg_layer = seg_layer;
+    a.x_in = m->h; a.x1_in = m->h2; a.qkv_out = m->qkv;
     a.abort_flag = m->wait_abort;
     a.nsweep = env_int("OMX_SE_NSWEEP", 1);
     a.inflight = env_int("OMX_SE_INFLIGHT", 2);
@@ -539,6 +548,34 @@ inline void time_next_launch(omx_qwen3 m, int layer, int cls) {
     arm_launch_events((*m->kernel_events)[i], (*m->kernel_events)[i + 1]);
 }
 
+int enqueue_step_tail(omx_qwen3 m, bool with_head, const bf16_t* h, const float* pending = nullptr, int pending_n = 1, bool tp = false);
+
+// the hybrid step (step_engine_mode == 2): per layer [engine segment] [attention + o]; m->h = residual entering a layer, m->h2 = after attention
+int enqueue_step_hybrid(omx_qwen3 m, bool with_head) {
+    const omx_qwen3_config& c = m->cfg;
+    hipStream_t s = m->stream;
+    const int hd = c.hidden_size, D = c.head_dim, L = c.num_hidden_layers;
+    embed_kernel<<<2, 256, 0, s>>>(m->h, m->embed, m->st, hd, m->step_seq, m->rope_cur, m->rope_cos, m->rope_sin, D / 2);
+    OMX_LAUNCH_CHECK();
+    for (int l = 0; l < L; ++l) {
+        time_next_launch(m, l, KC_QKV);                      // (the segment's time is booked on the q/k/v class of the layer it ends in)
+        if (enqueue_step_engine(m, s, l)) return 1;
+        const bool fused_o = attention_takes_oproj(m);
+        time_next_launch(m, l, KC_ATTN);
+        if (enqueue_attention(m, l, s, fused_o ? m->h : nullptr, fused_o ? m->h2 : nullptr, nullptr)) return 1;
+        if (!fused_o) {
+            GemvArgs a = {};
+            a.w0 = m->layers[l].o; a.n0 = hd; a.N = hd; a.K = m->H * D;
+            a.x = m->attn_out; a.resid = m->h; a.out = m->h2;
+            time_next_launch(m, l, KC_O);
+            if (launch_gemv(a, PRO_NONE, EPI_RESIDUAL, s)) return 1;
+        }
+    }
+    time_next_launch(m, L - 1, KC_DOWN);
+    if (enqueue_step_engine(m, s, L)) return 1;
+    return enqueue_step_tail(m, with_head, m->h);
+}
+
 int enqueue_step(omx_qwen3 m, bool with_head) {
     if (m->cfg.quant_bits) return enqueue_step_quant(m, with_head);
     const omx_qwen3_config& c = m->cfg;
@@ -546,7 +583,9 @@ int enqueue_step(omx_qwen3 m, bool with_head) {
     const int hd = c.hidden_size, D = c.head_dim;
     const bool ep = c.ep_size > 1;                               // expert parallel: attention replicated, one all-reduce per MoE block
     const bool tp = !ep && (c.tp_size > 1 || m->allreduce != nullptr);   // a 1-rank communicator exercises the TP path
-    const bool engine = step_engine_takes(m);
+    const int engine_mode = step_engine_mode(m);
+    if (engine_mode == 2) return enqueue_step_hybrid(m, with_head);
+    const bool engine = engine_mode == 1;
     if (engine) {
         time_next_launch(m, 0, KC_ENGINE);
         if (enqueue_step_engine(m, s)) return 1;
@@ -669,6 +708,14 @@ int enqueue_step(omx_qwen3 m, bool with_head) {
             }
         }
     }
+    return enqueue_step_tail(m, with_head, h, pending, pending_n, tp);
+}
+
+// [final RMSNorm + lm_head GEMV + argmax / sampling] on the residual stream `h` (plus a pending all-reduced partial)
+int enqueue_step_tail(omx_qwen3 m, bool with_head, const bf16_t* h, const float* pending, int pending_n, bool tp) {
+    const omx_qwen3_config& c = m->cfg;
+    hipStream_t s = m->stream;
+    const int hd = c.hidden_size;
     if (with_head) {   // [final RMSNorm + lm_head GEMV + argmax]  model.rs:423,480-489,733-735
         GemvArgs a = {};
         a.w0 = m->lm_head; a.n0 = m->V; a.N = m->V; a.K = hd;
@@ -1581,7 +1628,7 @@ int omx_qwen3_time_step_kernels(omx_qwen3 m, int steps, float* us) {
     for (auto& e : ev) OMX_HIP_CHECK(hipEventCreate(&e));
     double sum[KC_COUNT] = {};
     int rc = 0;
-    bool fused_o = false, engine = false;
+    bool fused_o = false, engine = false, hybrid = false;
     arm_launch_events(nullptr, nullptr);
     for (int it = 0; it < steps && !rc; ++it) {
         StepState st;
@@ -1590,7 +1637,8 @@ int omx_qwen3_time_step_kernels(omx_qwen3 m, int steps, float* us) {
         if (st.pos + 1 > m->cap) { set_error("omx_qwen3_time_step_kernels: context full"); rc = 1; break; }
         if (prepare_step(m, st.pos)) { rc = 1; break; }
         fused_o = attention_takes_oproj(m);
-        engine = step_engine_takes(m);
+        engine = step_engine_mode(m) == 1;
+        hybrid = step_engine_mode(m) == 2;
         m->kernel_events = &ev;
         rc = enqueue_step(m, true);
         m->kernel_events = nullptr;
@@ -1601,6 +1649,7 @@ int omx_qwen3_time_step_kernels(omx_qwen3 m, int steps, float* us) {
                 float ms = 0.f;
                 const size_t i = ((size_t)l * kLayerClasses + k) * 2;
                 if (l < L && k == KC_O && fused_o) continue;     // that pair was never armed
+                if (hybrid && l < L && (k == KC_GATE_UP || (k == KC_DOWN && l != L - 1))) continue;   // one segment launch covers them
                 OMX_HIP_CHECK(hipEventElapsedTime(&ms, ev[i], ev[i + 1]));
                 sum[l == L ? (k == 0 ? KC_HEAD : KC_ENGINE) : k] += ms * 1e3;
             }

@@ -627,7 +627,8 @@ __global__ __launch_bounds__(kBlock, 1) void step_engine_kernel(const StepEngine
 
     const int pos = a.st->pos;
     const int Tk = pos + 1;
-    const unsigned seq = *a.seq_ptr + 1u;
+    const bool seg = a.seg_layer >= 0;                       // one segment of the hybrid step (the step's first kernel advanced the sequence number)
+    const unsigned seq = *a.seq_ptr + (seg ? 0u : 1u);
 
     // attention role of this CU: (kv head, split) -- splits of one KV head sit on one XCD when Hkv == 8
     const bool in_attn = cu < a.Hkv * a.nsplit;
@@ -636,7 +637,7 @@ __global__ __launch_bounds__(kBlock, 1) void step_engine_kernel(const StepEngine
     const bool active = in_attn && split < n_active;
     const int t_begin = split * a.chunk;
     const int t_end = min(Tk, t_begin + a.chunk);
-    const int nu_live = active ? (t_end - t_begin + TPW - 1) / TPW : 0;   // K (and V) pieces this CU streams per layer
+    const int nu_live = (active && !seg) ? (t_end - t_begin + TPW - 1) / TPW : 0;   // K (and V) pieces this CU streams per layer
     const int kv_slots = (2 * nu_live + kPPS - 1) / kPPS;
 
     const OpShape opQ = op_shape(NQKV, hidden, 1, ncu, cu);
@@ -644,30 +645,43 @@ __global__ __launch_bounds__(kBlock, 1) void step_engine_kernel(const StepEngine
     const OpShape opG = op_shape(a.I, hidden, 2, ncu, cu);
     const OpShape opD = op_shape(hidden, a.I, 1, ncu, cu);
     unsigned long long* tr = TRACE ? a.trace + (size_t)cu * kStepEngineTraceWords : nullptr;
+    // timeline of consumer wave 0 in layers 1 and 2: 32 stamps each (tools/step_engine_trace.py names them)
+#define STAMP(id)                                                                                          \
+    do {                                                                                                   \
+        if (TRACE && (l == 1 || l == 2) && w.cw == 0 && lane == 0) tr[(l - 1) * 32 + (id)] = wall_clock64(); \
+    } while (0)
 
     if (wave == 0) {
         // =========================== loader ===========================
         Loader<NSLOT> ld;
         ld.ctl = L.ctl; ld.ring = smem; ld.lane = lane; ld.inflight = a.inflight; ld.thin_gather = a.thin_gather; ld.issued = 0; ld.published = 0; ld.dead = false;
         const long n0 = (long)a.H * D, n1 = (long)a.Hkv * D;   // rows of q, of k (and v)
-        for (int l = 0; l < a.L; ++l) {
-            const StepEngineLayer W = layers[l];
-            {   // rows [r0, r1) of the stack [q | k | v]
-                const long r0 = 2l * opQ.pair0, r1 = r0 + 2l * opQ.npairs, rb = 2l * hidden;
-                const long q0 = min(r0, n0), q1 = min(r1, n0);
-                const long k0 = min(max(r0, n0), n0 + n1), k1 = min(max(r1, n0), n0 + n1);
-                const long v0 = max(r0, n0 + n1), v1 = max(r1, n0 + n1);
-                ld.seq((const char*)W.q + q0 * rb, (int)(q1 - q0) * opQ.ppr, (const char*)W.k + (k0 - n0) * rb, (int)(k1 - k0) * opQ.ppr,
-                       (const char*)W.v + (v0 - n0 - n1) * rb, (int)(v1 - v0) * opQ.ppr);
+        const int it0 = seg ? a.seg_layer : 0, it1 = seg ? a.seg_layer + 1 : a.L + 1;
+        for (int it = it0; it < it1; ++it) {   // the consumers' order: [gate/up, down] of layer it - 1, [q/k/v, K/V chunk, o] of layer it
+            if (it > 0) {
+                const StepEngineLayer W = layers[it - 1];
+                if (opG.npairs > 0)
+                    ld.alt((const char*)W.gate + 2l * opG.pair0 * (2l * hidden), (const char*)W.up + 2l * opG.pair0 * (2l * hidden), 2 * opG.ppr,
+                           opG.npairs * 2 * opG.ppr);
+                if (opD.npairs > 0) ld.seq((const char*)W.down + 2l * opD.pair0 * (2l * a.I), opD.npairs * 2 * opD.ppr, nullptr, 0, nullptr, 0);
             }
-            if (nu_live > 0)   // K chunk then V chunk of this split (the row of the new token is replaced by the consumers)
-                ld.seq((const char*)(W.kc + ((size_t)kvh * a.cap + t_begin) * D), nu_live,
-                       (const char*)(W.vc + ((size_t)kvh * a.cap + t_begin) * D), nu_live, nullptr, 0);
-            if (opO.npairs > 0) ld.seq((const char*)W.o + 2l * opO.pair0 * (2l * HD), opO.npairs * 2 * opO.ppr, nullptr, 0, nullptr, 0);
-            if (opG.npairs > 0)
-                ld.alt((const char*)W.gate + 2l * opG.pair0 * (2l * hidden), (const char*)W.up + 2l * opG.pair0 * (2l * hidden), 2 * opG.ppr,
-                       opG.npairs * 2 * opG.ppr);
-            if (opD.npairs > 0) ld.seq((const char*)W.down + 2l * opD.pair0 * (2l * a.I), opD.npairs * 2 * opD.ppr, nullptr, 0, nullptr, 0);
+            if (it < a.L) {
+                const StepEngineLayer W = layers[it];
+                {   // rows [r0, r1) of the stack [q | k | v]
+                    const long r0 = 2l * opQ.pair0, r1 = r0 + 2l * opQ.npairs, rb = 2l * hidden;
+                    const long q0 = min(r0, n0), q1 = min(r1, n0);
+                    const long k0 = min(max(r0, n0), n0 + n1), k1 = min(max(r1, n0), n0 + n1);
+                    const long v0 = max(r0, n0 + n1), v1 = max(r1, n0 + n1);
+                    ld.seq((const char*)W.q + q0 * rb, (int)(q1 - q0) * opQ.ppr, (const char*)W.k + (k0 - n0) * rb, (int)(k1 - k0) * opQ.ppr,
+                           (const char*)W.v + (v0 - n0 - n1) * rb, (int)(v1 - v0) * opQ.ppr);
+                }
+                if (!seg) {
+                    if (nu_live > 0)   // K chunk then V chunk of this split (the row of the new token is replaced by the consumers)
+                        ld.seq((const char*)(W.kc + ((size_t)kvh * a.cap + t_begin) * D), nu_live,
+                               (const char*)(W.vc + ((size_t)kvh * a.cap + t_begin) * D), nu_live, nullptr, 0);
+                    if (opO.npairs > 0) ld.seq((const char*)W.o + 2l * opO.pair0 * (2l * HD), opO.npairs * 2 * opO.ppr, nullptr, 0, nullptr, 0);
+                }
+            }
         }
         ld.drain();
         return;
@@ -686,275 +700,317 @@ __global__ __launch_bounds__(kBlock, 1) void step_engine_kernel(const StepEngine
     float* const sml = reinterpret_cast<float*>(L.misc + M_SML);
     float* const park = reinterpret_cast<float*>(L.xs);                      // [kVWaves][GT][D] (over the dead activation area)
 
-    if (w.cw == 0 && in_attn) {
+    if (w.cw == 0 && in_attn && !seg) {
         const int half = D / 2;
         for (int i = lane; i < D; i += 64) rope[i] = i < half ? a.rope_cos[(size_t)pos * half + i] : a.rope_sin[(size_t)pos * half + i - half];
     }
     unsigned slot = 0;   // first ring slot of the current op (the loader counts the same way)
 
-    for (int l = 0; l < a.L; ++l) {
-        const StepEngineLayer W = layers[l];
-        const unsigned tag = seq * (unsigned)a.L + (unsigned)l + 1u;
-        const bool last = l + 1 == a.L;
-        if (TRACE && l < 4 && w.cw == 0 && lane == 0) tr[l * 12 + 0] = wall_clock64();
-
-        // ---- [RMSNorm + q/k/v] ----
-        u32x4 nwv[kNwv];
-        norm_w_prefetch(w, W.in_ln, hidden, nwv);
-        u32x4 wq_raw = {0, 0, 0, 0}, wk_raw = {0, 0, 0, 0};   // q/k norm weights of this lane's head-dim chunk (null: Mixtral / Qwen2)
-        if (in_attn && W.q_norm) {
-            wq_raw = *reinterpret_cast<const u32x4*>(W.q_norm + (lane % LPR) * 8);
-            wk_raw = *reinterpret_cast<const u32x4*>(W.k_norm + (lane % LPR) * 8);
-        }
-        if (l == 0) {   // the embedding row of the current token (Embedding::forward, model.rs:396)
-            const u32x4* src = reinterpret_cast<const u32x4*>(a.embed + (size_t)a.st->cur_token * hidden);
-            for (int v = w.cw * 64 + lane; v < hidden / 8; v += kCons * 64) xA[v] = src[v];
-            cbar(a, L, w);
-        } else {
-            gather_vec(a, L, w, a.g_x, hidden / 2, tag, a.nsweep);
-        }
-        if (TRACE && l < 4 && w.cw == 0 && lane == 0) tr[l * 12 + 1] = wall_clock64();
-        if (w.cw == 0 && lane < opO.npairs) resid[lane] = reinterpret_cast<const unsigned*>(xA)[opO.pair0 + lane];
-        rmsnorm_lds(w, xA, xB, W.in_ln, nwv, hidden, a.eps);
-        cbar(a, L, w);
-        run_gemv<NSLOT, 1>(a, L, w, opQ, slot, xB, [&](int pair, const float (&v)[2]) {
-            if (lane == 0) st_gran(a.g_qkv + pair, tag, (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16));
-        });
-        slot += opQ.nslots;
-        if (TRACE && l < 4 && w.cw == 0 && lane == 0) tr[l * 12 + 2] = wall_clock64();
-
-        // ---- [q/k norm + RoPE + KV append + split-KV SDPA + merge] (attn_step.hip's arithmetic) ----
-        if (in_attn) {
-            if (w.cw == 0) {   // this KV head's group: q heads, k row, v row -> rawqkv
-                const int nq = G * D / 2, nk = D / 2;
-                const int q0 = kvh * nq, k0 = a.H * D / 2 + kvh * nk, v0 = (a.H + a.Hkv) * D / 2 + kvh * nk;
-                sweep(a, L, w, a.g_qkv, 0, nq + 2 * nk, tag, rawqkv,
-                      [=](int i) { return i < nq ? q0 + i : i < nq + nk ? k0 + i - nq : v0 + i - nq - nk; });
+    // One iteration = [gate/up, down] of layer i - 1, then [q/k/v, attention, o] of layer i.  The whole step: i = 0 .. L.  Segment mode
+    // (a.seg_layer = i >= 0): ONE iteration without attention and o -- the launch between two attention launches of the hybrid step.
+    const int it0 = seg ? a.seg_layer : 0, it1 = seg ? a.seg_layer + 1 : a.L + 1;
+    for (int it = it0; it < it1; ++it) {
+        if (it > 0) {
+            const int l = it - 1;
+            const StepEngineLayer W = layers[l];
+            const unsigned tag = seq * (unsigned)a.L + (unsigned)l + 1u;
+            const bool last = l + 1 == a.L;
+            u32x4 nwv[kNwv];
+            // ---- [RMSNorm + gate/up + silu * up] ----
+            norm_w_prefetch(w, W.post_ln, hidden, nwv);
+            if (seg) {   // the attention launch left the residual stream in a.x1_in
+                const u32x4* src = reinterpret_cast<const u32x4*>(a.x1_in);
+                cbar(a, L, w);
+                for (int v = w.cw * 64 + lane; v < hidden / 8; v += kCons * 64) xA[v] = src[v];
+                cbar(a, L, w);
+            } else {
+                gather_vec(a, L, w, a.g_x1, hidden / 2, tag, a.nsweep);
             }
+            STAMP(13);
+            if (w.cw == 0 && lane < opD.npairs) resid[lane] = reinterpret_cast<const unsigned*>(xA)[opD.pair0 + lane];
+            rmsnorm_lds(w, xA, xB, W.post_ln, nwv, hidden, a.eps);
             cbar(a, L, w);
-            if (TRACE && l < 4 && w.cw == 0 && lane == 0) tr[48 + l * 4 + 0] = wall_clock64();   // q / k / v of the group swept
-            const int c = lane % LPR, sg = lane / LPR;
-            {   // rows 0..G-1: query heads, row G: the new key -- one row per wave turn, all four token rows of the wave redundantly
-                float cs[8], sn[8];
-                const int i0 = (c % (LPR / 2)) * 8;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) { cs[e] = rope[i0 + e]; sn[e] = rope[D / 2 + i0 + e]; }
-                const bool first_half = c < LPR / 2;
-                for (int r = w.cw; r <= G; r += kCons) {
-                    const u32x4 raw = *reinterpret_cast<const u32x4*>(rawqkv + (size_t)r * (D / 2) + c * 4);
-                    const bool nwp = W.q_norm != nullptr;
-                    const u32x4 w_raw = r < G ? wq_raw : wk_raw;
-                    float x[8], wn[8];
-                    unpack8(raw, x);
-                    unpack8(w_raw, wn);
-                    float ss = 0.f;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) ss = fmaf(x[e], x[e], ss);
-                    ss = group_sum<LPR>(ss);
-                    const float rstd = nwp ? 1.0f / sqrtf(ss / (float)D + a.eps) : 1.0f;
-                    float y[8];
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const float xn = nwp ? round_bf16(x[e] * rstd * wn[e]) : x[e];
-                        const float other = swap_halves<LPR>(xn);
-                        y[e] = first_half ? xn * cs[e] - other * sn[e] : other * sn[e] + xn * cs[e];
+            STAMP(18);
+            run_gemv<NSLOT, 2>(a, L, w, opG, slot, xB, [&](int pair, const float (&v)[4]) {
+                if (lane == 0) {
+                    unsigned out[2];
+    #pragma unroll
+                    for (int i = 0; i < 2; ++i) {   // nn::silu(gate) * up, every primitive's result in bf16 (gemv.hip EPI_SWIGLU)
+                        const float g = round_bf16(v[i]), u = round_bf16(v[2 + i]);   // task rows: gate r0, gate r1, up r0, up r1
+                        const float sgm = round_bf16(1.0f / (1.0f + expf(-g)));
+                        out[i] = f32_to_bf16(round_bf16(g * sgm) * u);
                     }
-                    u32x4 out;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) out[e] = pack_bf16(y[2 * e], y[2 * e + 1]);
-                    if (sg == 0) smq[(r < G ? r : GT) * LPR + c] = out;
+                    st_gran(a.g_act + pair, tag, out[0] | (out[1] << 16));
                 }
+            });
+            slot += opG.nslots;
+            STAMP(14);
+
+            // ---- [down + residual] ----
+            gather_vec(a, L, w, a.g_act, a.I / 2, tag, kCons);
+            STAMP(15);
+            run_gemv<NSLOT, 1>(a, L, w, opD, slot, xA, [&](int pair, const float (&v)[2]) {
+                if (lane == 0) {
+                    const unsigned r = resid[pair - opD.pair0];
+                    const unsigned lo = f32_to_bf16(bf16lo(r) + round_bf16(v[0])), hi = f32_to_bf16(bf16hi(r) + round_bf16(v[1]));
+                    if (last || seg) reinterpret_cast<unsigned*>(a.h_out)[pair] = lo | (hi << 16);   // lm_head / the next attention launch's residual
+                    if (!last) st_gran(a.g_x + pair, tag + 1u, lo | (hi << 16));
+                }
+            });
+            slot += opD.nslots;
+            STAMP(16);
+        }
+        if (it < a.L) {
+            const int l = it;
+            const StepEngineLayer W = layers[l];
+            const unsigned tag = seq * (unsigned)a.L + (unsigned)l + 1u;
+            STAMP(0);
+            // ---- [RMSNorm + q/k/v] ----
+            u32x4 nwv[kNwv];
+            norm_w_prefetch(w, W.in_ln, hidden, nwv);
+            u32x4 wq_raw = {0, 0, 0, 0}, wk_raw = {0, 0, 0, 0};   // q/k norm weights of this lane's head-dim chunk (null: Mixtral / Qwen2)
+            if (in_attn && W.q_norm) {
+                wq_raw = *reinterpret_cast<const u32x4*>(W.q_norm + (lane % LPR) * 8);
+                wk_raw = *reinterpret_cast<const u32x4*>(W.k_norm + (lane % LPR) * 8);
             }
+            if (l == 0) {   // the embedding row of the current token (Embedding::forward, model.rs:396); segment mode: already in a.x_in
+                const u32x4* src = reinterpret_cast<const u32x4*>(seg ? a.x_in : a.embed + (size_t)a.st->cur_token * hidden);
+                cbar(a, L, w);                                   // (the area's previous readers are done)
+                for (int v = w.cw * 64 + lane; v < hidden / 8; v += kCons * 64) xA[v] = src[v];
+                cbar(a, L, w);
+            } else {
+                gather_vec(a, L, w, a.g_x, hidden / 2, tag, a.nsweep);
+            }
+            STAMP(1);
+            if (w.cw == 0 && lane < opO.npairs) resid[lane] = reinterpret_cast<const unsigned*>(xA)[opO.pair0 + lane];
+            rmsnorm_lds(w, xA, xB, W.in_ln, nwv, hidden, a.eps);
             cbar(a, L, w);
-            if (TRACE && l < 4 && w.cw == 0 && lane == 0) tr[48 + l * 4 + 1] = wall_clock64();   // normed + roped
-            if (active) {
-                const int n_units = a.chunk / TPW;
-                u32x4 q[GT];
-#pragma unroll
-                for (int g = 0; g < GT; ++g) q[g] = smq[min(g, G - 1) * LPR + c];
-                const u32x4 knew = smq[GT * LPR + c];
-                const u32x4 vnew = *reinterpret_cast<const u32x4*>(rawqkv + (size_t)(G + 1) * (D / 2) + c * 4);
-                bf16_t* Kb = W.kc + (size_t)kvh * a.cap * D;
-                bf16_t* Vb = W.vc + (size_t)kvh * a.cap * D;
-                wait_ready(a, L, w, slot + kv_slots);
-                const unsigned p0 = slot * kPPS;
-                for (int vw = w.cw; vw < kVWaves; vw += kCons) {
-                    float m[GT], lsum[GT];
-                    f32x2 o[GT][4];
-#pragma unroll
-                    for (int g = 0; g < GT; ++g) {
-                        m[g] = -INFINITY;
-                        lsum[g] = 0.f;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) o[g][e] = f32x2{0.f, 0.f};
+            STAMP(17);
+            run_gemv<NSLOT, 1>(a, L, w, opQ, slot, xB, [&](int pair, const float (&v)[2]) {
+                if (lane == 0) {
+                    const unsigned val = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
+                    if (seg) reinterpret_cast<unsigned*>(a.qkv_out)[pair] = val;   // read by the attention launch that follows
+                    else st_gran(a.g_qkv + pair, tag, val);
+                }
+            });
+            slot += opQ.nslots;
+            STAMP(2);
+
+            if (!seg) {
+                // ---- [q/k norm + RoPE + KV append + split-KV SDPA + merge] (attn_step.hip's arithmetic) ----
+                if (in_attn) {
+                    if (w.cw == 0) {   // this KV head's group: q heads, k row, v row -> rawqkv
+                        const int nq = G * D / 2, nk = D / 2;
+                        const int q0 = kvh * nq, k0 = a.H * D / 2 + kvh * nk, v0 = (a.H + a.Hkv) * D / 2 + kvh * nk;
+                        sweep(a, L, w, a.g_qkv, 0, nq + 2 * nk, tag, rawqkv,
+                              [=](int i) { return i < nq ? q0 + i : i < nq + nk ? k0 + i - nq : v0 + i - nq - nk; });
                     }
-                    auto round = [&](const int u0) {
-                        float s[kKU][GT];
-                        f32x2 vf[kKU][4];
-#pragma unroll
-                        for (int u = 0; u < kKU; ++u) {
-                            const int unit = u0 + u * kVWaves;
-                            const int tok = t_begin + unit * TPW + sg;
-                            const bool live = unit < n_units && tok < t_end;
-                            const int uc = min(unit, nu_live - 1);
-                            u32x4 kp = *reinterpret_cast<const u32x4*>(L.base + (size_t)((p0 + uc) % RING) * kPiece + lane * 16);
-                            u32x4 vp = *reinterpret_cast<const u32x4*>(L.base + (size_t)((p0 + nu_live + uc) % RING) * kPiece + lane * 16);
-                            if (tok == pos && unit < n_units) {   // the NEW token: the row built above, appended to the cache (cache.rs:183-188)
-                                kp = knew;
-                                vp = vnew;
-                                *reinterpret_cast<u32x4*>(Kb + (size_t)pos * D + c * 8) = kp;
-                                *reinterpret_cast<u32x4*>(Vb + (size_t)pos * D + c * 8) = vp;
+                    cbar(a, L, w);
+                    STAMP(3);
+                    const int c = lane % LPR, sg = lane / LPR;
+                    {   // rows 0..G-1: query heads, row G: the new key -- every LPR-lane group of the three waves takes one row
+                        float cs[8], sn[8];
+                        const int i0 = (c % (LPR / 2)) * 8;
+        #pragma unroll
+                        for (int e = 0; e < 8; ++e) { cs[e] = rope[i0 + e]; sn[e] = rope[D / 2 + i0 + e]; }
+                        const bool first_half = c < LPR / 2;
+                        for (int r = w.cw * TPW + sg; r <= G; r += kCons * TPW) {
+                            const u32x4 raw = *reinterpret_cast<const u32x4*>(rawqkv + (size_t)r * (D / 2) + c * 4);
+                            const bool nwp = W.q_norm != nullptr;
+                            const u32x4 w_raw = r < G ? wq_raw : wk_raw;
+                            float x[8], wn[8];
+                            unpack8(raw, x);
+                            unpack8(w_raw, wn);
+                            float ss = 0.f;
+        #pragma unroll
+                            for (int e = 0; e < 8; ++e) ss = fmaf(x[e], x[e], ss);
+                            ss = group_sum<LPR>(ss);
+                            const float rstd = nwp ? 1.0f / sqrtf(ss / (float)D + a.eps) : 1.0f;
+                            float y[8];
+        #pragma unroll
+                            for (int e = 0; e < 8; ++e) {
+                                const float xn = nwp ? round_bf16(x[e] * rstd * wn[e]) : x[e];
+                                const float other = swap_halves<LPR>(xn);
+                                y[e] = first_half ? xn * cs[e] - other * sn[e] : other * sn[e] + xn * cs[e];
                             }
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) vf[u][e] = live ? f32x2{bf16lo(vp[e]), bf16hi(vp[e])} : f32x2{0.f, 0.f};
-#pragma unroll
+                            u32x4 out;
+        #pragma unroll
+                            for (int e = 0; e < 4; ++e) out[e] = pack_bf16(y[2 * e], y[2 * e + 1]);
+                            smq[(r < G ? r : GT) * LPR + c] = out;
+                        }
+                    }
+                    cbar(a, L, w);
+                    STAMP(4);
+                    if (active) {
+                        const int n_units = a.chunk / TPW;
+                        u32x4 q[GT];
+        #pragma unroll
+                        for (int g = 0; g < GT; ++g) q[g] = smq[min(g, G - 1) * LPR + c];
+                        const u32x4 knew = smq[GT * LPR + c];
+                        const u32x4 vnew = *reinterpret_cast<const u32x4*>(rawqkv + (size_t)(G + 1) * (D / 2) + c * 4);
+                        bf16_t* Kb = W.kc + (size_t)kvh * a.cap * D;
+                        bf16_t* Vb = W.vc + (size_t)kvh * a.cap * D;
+                        wait_ready(a, L, w, slot + kv_slots);
+                        STAMP(5);
+                        const unsigned p0 = slot * kPPS;
+                        // this wave's share of the 8 (virtual) waves of attn_step.hip: vw = cw, cw + 3, cw + 6 -- run TOGETHER, their softmax
+                        // chains interleaved (one after the other they were three dependent-latency-bound passes of 2.3 us each)
+                        constexpr int NVK = (kVWaves + kCons - 1) / kCons;
+                        float m[NVK][GT], lsum[NVK][GT];
+                        f32x2 o[NVK][GT][4];
+        #pragma unroll
+                        for (int k = 0; k < NVK; ++k)
+        #pragma unroll
                             for (int g = 0; g < GT; ++g) {
-                                const float d = group_sum<LPR>(dot8_bf16(q[g], kp)) * a.scale;
-                                s[u][g] = live ? d : -INFINITY;
+                                m[k][g] = -INFINITY;
+                                lsum[k][g] = 0.f;
+        #pragma unroll
+                                for (int e = 0; e < 4; ++e) o[k][g][e] = f32x2{0.f, 0.f};
                             }
-                        }
-#pragma unroll
-                        for (int g = 0; g < GT; ++g) {
-                            float mx = s[0][g];
-#pragma unroll
-                            for (int u = 1; u < kKU; ++u) mx = fmaxf(mx, s[u][g]);
-                            float wmx = readlane_f(mx, 0);
-#pragma unroll
-                            for (int r = 1; r < TPW; ++r) wmx = fmaxf(wmx, readlane_f(mx, r * LPR));
-                            const float mn = fmaxf(m[g], wmx);
-                            const float alpha = (mn == -INFINITY) ? 1.f : __expf(m[g] - mn);
-                            m[g] = mn;
-                            lsum[g] *= alpha;
-                            const f32x2 al = {alpha, alpha};
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) o[g][e] *= al;
-#pragma unroll
+                        // one round = kKU units of one virtual wave; a round none of whose units is live leaves the state as it is (alpha = 1,
+                        // p = 0), which is how attn_step.hip's skipped rounds behave
+                        auto round = [&](const int k, const int u0) {
+                            const bool vw_ok = w.cw + k * kCons < kVWaves;
+                            float s[kKU][GT];
+                            f32x2 vf[kKU][4];
+        #pragma unroll
                             for (int u = 0; u < kKU; ++u) {
-                                const float p = (mn == -INFINITY) ? 0.f : __expf(s[u][g] - mn);
-                                lsum[g] += p;
-                                const f32x2 pp = {p, p};
-#pragma unroll
-                                for (int e = 0; e < 4; ++e) o[g][e] = __builtin_elementwise_fma(pp, vf[u][e], o[g][e]);
+                                const int unit = u0 + u * kVWaves;
+                                const int tok = t_begin + unit * TPW + sg;
+                                const bool live = vw_ok && unit < n_units && tok < t_end;
+                                const int uc = min(unit, nu_live - 1);
+                                u32x4 kp = *reinterpret_cast<const u32x4*>(L.base + (size_t)((p0 + uc) % RING) * kPiece + lane * 16);
+                                u32x4 vp = *reinterpret_cast<const u32x4*>(L.base + (size_t)((p0 + nu_live + uc) % RING) * kPiece + lane * 16);
+                                if (vw_ok && tok == pos && unit < n_units) {   // the NEW token: the row built above, appended to the cache (cache.rs:183-188)
+                                    kp = knew;
+                                    vp = vnew;
+                                    *reinterpret_cast<u32x4*>(Kb + (size_t)pos * D + c * 8) = kp;
+                                    *reinterpret_cast<u32x4*>(Vb + (size_t)pos * D + c * 8) = vp;
+                                }
+        #pragma unroll
+                                for (int e = 0; e < 4; ++e) vf[u][e] = live ? f32x2{bf16lo(vp[e]), bf16hi(vp[e])} : f32x2{0.f, 0.f};
+        #pragma unroll
+                                for (int g = 0; g < GT; ++g) {
+                                    const float d = group_sum<LPR>(dot8_bf16(q[g], kp)) * a.scale;
+                                    s[u][g] = live ? d : -INFINITY;
+                                }
+                            }
+        #pragma unroll
+                            for (int g = 0; g < GT; ++g) {
+                                float mx = s[0][g];
+        #pragma unroll
+                                for (int u = 1; u < kKU; ++u) mx = fmaxf(mx, s[u][g]);
+                                float wmx = readlane_f(mx, 0);
+        #pragma unroll
+                                for (int r = 1; r < TPW; ++r) wmx = fmaxf(wmx, readlane_f(mx, r * LPR));
+                                const float mn = fmaxf(m[k][g], wmx);
+                                const float alpha = (mn == -INFINITY) ? 1.f : __expf(m[k][g] - mn);
+                                m[k][g] = mn;
+                                lsum[k][g] *= alpha;
+                                const f32x2 al = {alpha, alpha};
+        #pragma unroll
+                                for (int e = 0; e < 4; ++e) o[k][g][e] *= al;
+        #pragma unroll
+                                for (int u = 0; u < kKU; ++u) {
+                                    const float p = (mn == -INFINITY) ? 0.f : __expf(s[u][g] - mn);
+                                    lsum[k][g] += p;
+                                    const f32x2 pp = {p, p};
+        #pragma unroll
+                                    for (int e = 0; e < 4; ++e) o[k][g][e] = __builtin_elementwise_fma(pp, vf[u][e], o[k][g][e]);
+                                }
+                            }
+                        };
+                        for (int u0 = 0; u0 < n_units && t_begin + u0 * TPW < t_end; u0 += kVWaves * kKU) {
+        #pragma unroll
+                            for (int k = 0; k < NVK; ++k) round(k, u0 + w.cw + k * kCons);
+                        }
+                        STAMP(6);
+                        // park: the TPW token rows of each (virtual) wave summed in row order, as the merge of attn_step.hip adds them
+        #pragma unroll
+                        for (int k = 0; k < NVK; ++k) {
+                            const int vw = w.cw + k * kCons;
+                            if (vw >= kVWaves) continue;
+        #pragma unroll
+                            for (int g = 0; g < GT; ++g) {
+                                float ow[8];
+        #pragma unroll
+                                for (int e = 0; e < 8; ++e) ow[e] = rows_sum_ordered<TPW>(o[k][g][e >> 1][e & 1], lane);
+                                float lw = readlane_f(lsum[k][g], 0);
+        #pragma unroll
+                                for (int r = 1; r < TPW; ++r) lw += readlane_f(lsum[k][g], r * LPR);
+                                if (sg == 0) {
+                                    float* dst = park + ((size_t)vw * GT + g) * D + c * 8;
+                                    *reinterpret_cast<f32x4*>(dst) = f32x4{ow[0], ow[1], ow[2], ow[3]};
+                                    *reinterpret_cast<f32x4*>(dst + 4) = f32x4{ow[4], ow[5], ow[6], ow[7]};
+                                }
+                                if (lane == 0) {
+                                    smm[vw * GT + g] = m[k][g];
+                                    sml[vw * GT + g] = lw;
+                                }
                             }
                         }
-                    };
-                    if (vw < n_units && t_begin + vw * TPW < t_end) round(vw);
-                    for (int u0 = vw + kVWaves * kKU; u0 < n_units && t_begin + u0 * TPW < t_end; u0 += kVWaves * kKU) round(u0);
-                    // park: the TPW token rows of this (virtual) wave summed in row order, as the merge of attn_step.hip adds them
-#pragma unroll
-                    for (int g = 0; g < GT; ++g) {
-                        float ow[8];
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) {
-                            ow[e] = rows_sum_ordered<TPW>(o[g][e >> 1][e & 1], lane);
-                        }
-                        float lw = readlane_f(lsum[g], 0);
-#pragma unroll
-                        for (int r = 1; r < TPW; ++r) lw += readlane_f(lsum[g], r * LPR);
-                        if (sg == 0) {
-                            float* dst = park + ((size_t)vw * GT + g) * D + c * 8;
-                            *reinterpret_cast<f32x4*>(dst) = f32x4{ow[0], ow[1], ow[2], ow[3]};
-                            *reinterpret_cast<f32x4*>(dst + 4) = f32x4{ow[4], ow[5], ow[6], ow[7]};
-                        }
-                        if (lane == 0) {
-                            smm[vw * GT + g] = m[g];
-                            sml[vw * GT + g] = lw;
+                    }
+                    STAMP(7);
+                    set_done(L, w, slot + kv_slots);
+                    cbar(a, L, w);
+                    STAMP(8);
+                    if (active) {   // merge the 8 (virtual) waves; the split's partial leaves as tagged granules
+                        for (int idx = w.cw * 64 + lane; idx < G * D; idx += kCons * 64) {
+                            const int g = idx / D, d = idx % D;
+                            float M = smm[g];
+        #pragma unroll
+                            for (int vw = 1; vw < kVWaves; ++vw) M = fmaxf(M, smm[vw * GT + g]);
+                            float Lsum = 0.f, O = 0.f;
+        #pragma unroll
+                            for (int vw = 0; vw < kVWaves; ++vw) {
+                                const float mw = smm[vw * GT + g];
+                                const float f = (mw == -INFINITY) ? 0.f : __expf(mw - M);
+                                Lsum = fmaf(f, sml[vw * GT + g], Lsum);
+                                O = fmaf(f, park[((size_t)vw * GT + g) * D + d], O);
+                            }
+                            uint64_t* gr = a.g_part + ((size_t)(kvh * G + g) * a.nsplit + split) * (D + 2);
+                            st_gran(gr + d, tag, __float_as_uint(O));
+                            if (d == 0) {
+                                st_gran(gr + D, tag, __float_as_uint(M));
+                                st_gran(gr + D + 1, tag, __float_as_uint(Lsum));
+                            }
                         }
                     }
+                    STAMP(9);
+                    if (split < G && w.cw < D / 64) {   // this CU merges head kvh*G + split
+                        const int head = kvh * G + split;
+                        const uint64_t* base = a.g_part + (size_t)head * a.nsplit * (D + 2);
+                        uint64_t* xg_head = a.g_attn + (size_t)head * (D / 2);
+                        const int dim = w.cw * 64 + lane;
+                        const int nb = (a.nsplit + 15) / 16;
+                        if (nb <= 1) gather_head<D, 1>(a, L, w, base, n_active, tag, dim, xg_head);
+                        else if (nb == 2) gather_head<D, 2>(a, L, w, base, n_active, tag, dim, xg_head);
+                        else gather_head<D, 3>(a, L, w, base, n_active, tag, dim, xg_head);
+                    }
+                } else {
+                    set_done(L, w, slot);
                 }
-            }
-            set_done(L, w, slot + kv_slots);
-            cbar(a, L, w);
-            if (TRACE && l < 4 && w.cw == 0 && lane == 0) tr[48 + l * 4 + 2] = wall_clock64();   // own chunk done
-            if (active) {   // merge the 8 (virtual) waves; the split's partial leaves as tagged granules
-                for (int idx = w.cw * 64 + lane; idx < G * D; idx += kCons * 64) {
-                    const int g = idx / D, d = idx % D;
-                    float M = smm[g];
-#pragma unroll
-                    for (int vw = 1; vw < kVWaves; ++vw) M = fmaxf(M, smm[vw * GT + g]);
-                    float Lsum = 0.f, O = 0.f;
-#pragma unroll
-                    for (int vw = 0; vw < kVWaves; ++vw) {
-                        const float mw = smm[vw * GT + g];
-                        const float f = (mw == -INFINITY) ? 0.f : __expf(mw - M);
-                        Lsum = fmaf(f, sml[vw * GT + g], Lsum);
-                        O = fmaf(f, park[((size_t)vw * GT + g) * D + d], O);
+                slot += kv_slots;
+                STAMP(10);
+
+                // ---- [o + residual] ----
+                gather_vec(a, L, w, a.g_attn, HD / 2, tag, a.nsweep);
+                STAMP(11);
+                run_gemv<NSLOT, 1>(a, L, w, opO, slot, xA, [&](int pair, const float (&v)[2]) {
+                    if (lane == 0) {
+                        const unsigned r = resid[pair - opO.pair0];
+                        const unsigned lo = f32_to_bf16(bf16lo(r) + round_bf16(v[0])), hi = f32_to_bf16(bf16hi(r) + round_bf16(v[1]));
+                        st_gran(a.g_x1 + pair, tag, lo | (hi << 16));
                     }
-                    uint64_t* gr = a.g_part + ((size_t)(kvh * G + g) * a.nsplit + split) * (D + 2);
-                    st_gran(gr + d, tag, __float_as_uint(O));
-                    if (d == 0) {
-                        st_gran(gr + D, tag, __float_as_uint(M));
-                        st_gran(gr + D + 1, tag, __float_as_uint(Lsum));
-                    }
-                }
+                });
+                slot += opO.nslots;
+                STAMP(12);
+
             }
-            if (TRACE && l < 4 && w.cw == 0 && lane == 0) tr[l * 12 + 3] = wall_clock64();
-            if (split < G && w.cw < D / 64) {   // this CU merges head kvh*G + split
-                const int head = kvh * G + split;
-                const uint64_t* base = a.g_part + (size_t)head * a.nsplit * (D + 2);
-                uint64_t* xg_head = a.g_attn + (size_t)head * (D / 2);
-                const int dim = w.cw * 64 + lane;
-                const int nb = (a.nsplit + 15) / 16;
-                if (nb <= 1) gather_head<D, 1>(a, L, w, base, n_active, tag, dim, xg_head);
-                else if (nb == 2) gather_head<D, 2>(a, L, w, base, n_active, tag, dim, xg_head);
-                else gather_head<D, 3>(a, L, w, base, n_active, tag, dim, xg_head);
-            }
-        } else {
-            set_done(L, w, slot);
         }
-        slot += kv_slots;
-        if (TRACE && l < 4 && w.cw == 0 && lane == 0) tr[l * 12 + 4] = wall_clock64();
-
-        // ---- [o + residual] ----
-        gather_vec(a, L, w, a.g_attn, HD / 2, tag, a.nsweep);
-        if (TRACE && l < 4 && w.cw == 0 && lane == 0) tr[l * 12 + 5] = wall_clock64();
-        run_gemv<NSLOT, 1>(a, L, w, opO, slot, xA, [&](int pair, const float (&v)[2]) {
-            if (lane == 0) {
-                const unsigned r = resid[pair - opO.pair0];
-                const unsigned lo = f32_to_bf16(bf16lo(r) + round_bf16(v[0])), hi = f32_to_bf16(bf16hi(r) + round_bf16(v[1]));
-                st_gran(a.g_x1 + pair, tag, lo | (hi << 16));
-            }
-        });
-        slot += opO.nslots;
-        if (TRACE && l < 4 && w.cw == 0 && lane == 0) tr[l * 12 + 6] = wall_clock64();
-
-        // ---- [RMSNorm + gate/up + silu * up] ----
-        norm_w_prefetch(w, W.post_ln, hidden, nwv);
-        gather_vec(a, L, w, a.g_x1, hidden / 2, tag, a.nsweep);
-        if (TRACE && l < 4 && w.cw == 0 && lane == 0) tr[l * 12 + 7] = wall_clock64();
-        if (w.cw == 0 && lane < opD.npairs) resid[lane] = reinterpret_cast<const unsigned*>(xA)[opD.pair0 + lane];
-        rmsnorm_lds(w, xA, xB, W.post_ln, nwv, hidden, a.eps);
-        cbar(a, L, w);
-        run_gemv<NSLOT, 2>(a, L, w, opG, slot, xB, [&](int pair, const float (&v)[4]) {
-            if (lane == 0) {
-                unsigned out[2];
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {   // nn::silu(gate) * up, every primitive's result in bf16 (gemv.hip EPI_SWIGLU)
-                    const float g = round_bf16(v[i]), u = round_bf16(v[2 + i]);   // task rows: gate r0, gate r1, up r0, up r1
-                    const float sgm = round_bf16(1.0f / (1.0f + expf(-g)));
-                    out[i] = f32_to_bf16(round_bf16(g * sgm) * u);
-                }
-                st_gran(a.g_act + pair, tag, out[0] | (out[1] << 16));
-            }
-        });
-        slot += opG.nslots;
-        if (TRACE && l < 4 && w.cw == 0 && lane == 0) tr[l * 12 + 8] = wall_clock64();
-
-        // ---- [down + residual] ----
-        gather_vec(a, L, w, a.g_act, a.I / 2, tag, kCons);
-        if (TRACE && l < 4 && w.cw == 0 && lane == 0) tr[l * 12 + 9] = wall_clock64();
-        run_gemv<NSLOT, 1>(a, L, w, opD, slot, xA, [&](int pair, const float (&v)[2]) {
-            if (lane == 0) {
-                const unsigned r = resid[pair - opD.pair0];
-                const unsigned lo = f32_to_bf16(bf16lo(r) + round_bf16(v[0])), hi = f32_to_bf16(bf16hi(r) + round_bf16(v[1]));
-                if (last) reinterpret_cast<unsigned*>(a.h_out)[pair] = lo | (hi << 16);
-                else st_gran(a.g_x + pair, tag + 1u, lo | (hi << 16));
-            }
-        });
-        slot += opD.nslots;
-        if (TRACE && l < 4 && w.cw == 0 && lane == 0) tr[l * 12 + 10] = wall_clock64();
     }
-    if (cu == 0 && w.cw == 0 && lane == 0) *a.seq_ptr = seq;
+#undef STAMP
+    if (!seg && cu == 0 && w.cw == 0 && lane == 0) *a.seq_ptr = seq;
 }
 
 int lds_budget(int hidden, int H, int D, int I, int G, int* xs_bytes) {

@@ -42,6 +42,12 @@ struct StepEngineArgs {
     int inflight;                    // loader: fills in flight before it waits for the oldest (2 or 3)
     int thin_gather;                 // loader: one fill in flight while its CU sweeps granules (MI355X_MICROARCH.md gather-pass)
     unsigned long long* trace;       // optional [grid][kTraceWords] wall-clock stamps (tools/step_engine_trace.py)
+    // segment mode (the hybrid step: attention + o stay their own launch, csrc/attn_step.hip): this launch runs [gate/up, down] of layer
+    // seg_layer - 1 (skipped at 0) and [RMSNorm + q/k/v] of layer seg_layer (skipped at L); -1: the whole step
+    int seg_layer;
+    const bf16_t* x_in;              // seg_layer == 0: the embedding row (written by the step's first kernel)
+    const bf16_t* x1_in;             // seg_layer > 0: residual stream after the attention launch of layer seg_layer - 1
+    bf16_t* qkv_out;                 // raw projections for the attention launch of layer seg_layer; the new residual goes to h_out
     int xs_bytes, nslot;             // set by launch_step_engine
 };
 

@@ -685,20 +685,21 @@ ENGINE_CONFIGS = {k: v for k, v in OPROJ_CONFIGS.items() if not v.attention_bias
 @pytest.mark.parametrize("n_prompt", [1000, 5])
 def test_persistent_step_is_bit_identical(omx, monkeypatch, name, n_prompt):
     """csrc/step_engine.hip -- every layer of a decode step in ONE persistent launch (one loader wave streaming weights and K/V into
-    an LDS ring per CU, three consumer waves, op outputs handed between CUs as tagged granules) -- reproduces the launch-per-op step
+    an LDS ring per CU, three consumer waves, op outputs handed between CUs as tagged granules; OMX_STEP_ENGINE=1), or the hybrid step
+    (=2: [gate/up, down, next q/k/v] as one engine segment between two attention launches) -- reproduces the launch-per-op step
     exactly: same tokens and bit-equal logits as OMX_STEP_ENGINE=0, in graph and eager form, across a context-bucket boundary
     (1000 -> 1039 crosses 1024) and from a nearly empty cache (most attention splits idle)."""
     cfg = ENGINE_CONFIGS[name]
     prompt = synth.prompt_ids(n_prompt, cfg.vocab_size)
     outs = {}
-    for mode in ("0", "1", "eager"):
-        monkeypatch.setenv("OMX_STEP_ENGINE", "0" if mode == "0" else "1")
-        monkeypatch.setenv("OMX_NO_GRAPH", "1" if mode == "eager" else "0")
+    for mode in ("0", "1", "eager", "2", "2eager"):
+        monkeypatch.setenv("OMX_STEP_ENGINE", mode[0] if mode[0] in "012" else "1")
+        monkeypatch.setenv("OMX_NO_GRAPH", "1" if mode.endswith("eager") else "0")
         m = _engine(omx, cfg, max_context=1280)
         toks = np.concatenate([[m.prefill(prompt)], m.decode(40)])
         outs[mode] = (toks, m.last_logits())
         m.close()
-    for mode in ("1", "eager"):
+    for mode in ("1", "eager", "2", "2eager"):
         np.testing.assert_array_equal(outs["0"][0], outs[mode][0])
         np.testing.assert_array_equal(outs["0"][1], outs[mode][1])
 

@@ -20,6 +20,11 @@ for spec in os.environ.get("OMX_AB_VARIANTS", "1:2:1,3:2:1,3:3:1,1:2:0,3:2:0,3:3
     ns, inf, thin = spec.split(":")
     variants.append((f"engine nsweep={ns} inflight={inf} thin={thin}",
                      {"OMX_STEP_ENGINE": "1", "OMX_SE_NSWEEP": ns, "OMX_SE_INFLIGHT": inf, "OMX_SE_THIN": thin}))
+for spec in os.environ.get("OMX_AB_HYBRID", "3:2:1").split(","):
+    if spec:
+        ns, inf, thin = spec.split(":")
+        variants.append((f"hybrid nsweep={ns} inflight={inf} thin={thin}",
+                         {"OMX_STEP_ENGINE": "2", "OMX_SE_NSWEEP": ns, "OMX_SE_INFLIGHT": inf, "OMX_SE_THIN": thin}))
 ref = None
 for name, env in variants:
     os.environ.update(env)

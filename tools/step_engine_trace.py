@@ -4,7 +4,7 @@ usage: python tools/step_engine_trace.py [ctx] [layers]"""
 import ctypes, os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ["OMX_STEP_ENGINE"] = "1"
+os.environ.setdefault("OMX_STEP_ENGINE", "1")
 import bench  # noqa: E402
 import omx_import  # noqa: E402
 omx = omx_import.load_package()
@@ -23,24 +23,22 @@ n = ctypes.c_int()
 omx.check(lib.omx_qwen3_debug_trace_engine(m._h, buf.ctypes.data, buf.size, ctypes.byref(n)))
 cus = n.value
 t = buf[:cus * 64].reshape(cus, 64).astype(np.int64)
-names = ["layer start", "x ready (gathered)", "q/k/v rows done", "attention partials stored", "attention phase done",
-         "attention vector ready", "o rows done", "x1 ready", "gate/up rows done", "act ready", "down rows done"]
-t0 = t[:, 0].min()
-for l in range(min(4, L)):
-    print(f"layer {l}: starts {np.median(t[:, l * 12] - t0) / 100:.2f} us after the step (median over CUs)")
+names = {0: "layer start", 1: "x ready (gathered)", 17: "x normalised", 2: "q/k/v rows done", 3: "group q/k/v swept", 4: "normed + roped",
+         5: "K/V slots ready", 6: "rounds done", 7: "parked", 8: "own chunk done (all waves)", 9: "partials stored",
+         10: "attention phase done", 11: "attention vector ready", 12: "o rows done", 13: "x1 ready", 18: "x1 normalised",
+         14: "gate/up rows done", 15: "act ready", 16: "down rows done"}
+order = [0, 1, 17, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 18, 14, 15, 16]
+for l in (1, 2):
+    tt = t[:, (l - 1) * 32:(l - 1) * 32 + 32]
+    t0 = np.median(tt[:, 0])
+    print(f"layer {l} (times in us since the median layer start)")
     prev = None
-    for k, nm in enumerate(names):
-        v = (t[:, l * 12 + k] - t0) / 100.0
-        v = v[t[:, l * 12 + k] > 0]
+    for k in order:
+        v = tt[:, k]
+        v = (v[v > 0] - t0) / 100.0
         if not v.size:
             continue
         d = "" if prev is None else f"   +{np.median(v) - prev:6.2f}"
-        print(f"   {nm:28s} median {np.median(v):8.2f}  min {v.min():8.2f}  max {v.max():8.2f}{d}")
+        print(f"   {names[k]:28s} median {np.median(v):8.2f}  min {v.min():8.2f}  max {v.max():8.2f}  n {v.size:3d}{d}")
         prev = np.median(v)
-        if k == 2:
-            for kk, nn in enumerate(["  group q/k/v swept", "  normed + roped", "  own chunk done (before merge)"]):
-                vv = (t[:, 48 + l * 4 + kk] - t0) / 100.0
-                vv = vv[t[:, 48 + l * 4 + kk] > 0]
-                if vv.size:
-                    print(f"   {nn:28s} median {np.median(vv):8.2f}  min {vv.min():8.2f}  max {vv.max():8.2f}")
 m.close()

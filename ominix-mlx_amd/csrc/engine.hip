@@ -523,6 +523,9 @@ int enqueue_step_engine(omx_qwen3 m, hipStream_t s, int seg_layer = -1) {
     a.h_out = seg_layer < 0 ? m->h2 : m->h;
     a.seg_layer = seg_layer;
     a.x_in = m->h; a.x1_in = m->h2; a.qkv_out = m->qkv;
+    if (seg_layer > 0) a.seg_m = m->se_layers_host[seg_layer - 1];
+    if (seg_layer >= 0 && seg_layer < c.num_hidden_layers) a.seg_a = m->se_layers_host[seg_layer];
+    a.xcd_major = env_int("OMX_SE_XCD_MAJOR", 1);
     a.abort_flag = m->wait_abort;
     a.nsweep = env_int("OMX_SE_NSWEEP", 1);
     a.inflight = env_int("OMX_SE_INFLIGHT", 2);

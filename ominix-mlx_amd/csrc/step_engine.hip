@@ -78,6 +78,11 @@ struct OpShape {
     int ppr;             // pieces per row = K / 512
     int nslots;
 };
+// which share a CU takes: XCD-major (the CUs of XCD x -- workgroups x, x + 8, ... -- own 1/8 of the rows as one contiguous slab)
+// or, mode 0, share c to CU c
+__device__ __forceinline__ int share_of(int cu, int ncu, int mode) {
+    return (mode && ncu % 8 == 0) ? (cu % 8) * (ncu / 8) + cu / 8 : cu;
+}
 __device__ __forceinline__ OpShape op_shape(int rows, int K, int lr, int ncu, int cu) {
     OpShape o;
     share(rows / 2, ncu, cu, &o.pair0, &o.npairs);
@@ -625,9 +630,9 @@ __global__ __launch_bounds__(kBlock, 1) void step_engine_kernel(const StepEngine
     if (threadIdx.x < 16) reinterpret_cast<unsigned*>(L.misc + M_CTL)[threadIdx.x] = 0u;
     __syncthreads();
 
-    const int pos = a.st->pos;
-    const int Tk = pos + 1;
     const bool seg = a.seg_layer >= 0;                       // one segment of the hybrid step (the step's first kernel advanced the sequence number)
+    const int pos = seg ? 0 : a.st->pos;                     // (a segment has no attention: nothing of it depends on the position)
+    const int Tk = pos + 1;
     const unsigned seq = *a.seq_ptr + (seg ? 0u : 1u);
 
     // attention role of this CU: (kv head, split) -- splits of one KV head sit on one XCD when Hkv == 8
@@ -640,10 +645,11 @@ __global__ __launch_bounds__(kBlock, 1) void step_engine_kernel(const StepEngine
     const int nu_live = (active && !seg) ? (t_end - t_begin + TPW - 1) / TPW : 0;   // K (and V) pieces this CU streams per layer
     const int kv_slots = (2 * nu_live + kPPS - 1) / kPPS;
 
-    const OpShape opQ = op_shape(NQKV, hidden, 1, ncu, cu);
-    const OpShape opO = op_shape(hidden, HD, 1, ncu, cu);
-    const OpShape opG = op_shape(a.I, hidden, 2, ncu, cu);
-    const OpShape opD = op_shape(hidden, a.I, 1, ncu, cu);
+    const int sh = share_of(cu, ncu, a.xcd_major);
+    const OpShape opQ = op_shape(NQKV, hidden, 1, ncu, sh);
+    const OpShape opO = op_shape(hidden, HD, 1, ncu, sh);
+    const OpShape opG = op_shape(a.I, hidden, 2, ncu, sh);
+    const OpShape opD = op_shape(hidden, a.I, 1, ncu, sh);
     unsigned long long* tr = TRACE ? a.trace + (size_t)cu * kStepEngineTraceWords : nullptr;
     // timeline of consumer wave 0 in layers 1 and 2: 32 stamps each (tools/step_engine_trace.py names them)
 #define STAMP(id)                                                                                          \
@@ -659,14 +665,14 @@ __global__ __launch_bounds__(kBlock, 1) void step_engine_kernel(const StepEngine
         const int it0 = seg ? a.seg_layer : 0, it1 = seg ? a.seg_layer + 1 : a.L + 1;
         for (int it = it0; it < it1; ++it) {   // the consumers' order: [gate/up, down] of layer it - 1, [q/k/v, K/V chunk, o] of layer it
             if (it > 0) {
-                const StepEngineLayer W = layers[it - 1];
+                const StepEngineLayer W = seg ? a.seg_m : layers[it - 1];
                 if (opG.npairs > 0)
                     ld.alt((const char*)W.gate + 2l * opG.pair0 * (2l * hidden), (const char*)W.up + 2l * opG.pair0 * (2l * hidden), 2 * opG.ppr,
                            opG.npairs * 2 * opG.ppr);
                 if (opD.npairs > 0) ld.seq((const char*)W.down + 2l * opD.pair0 * (2l * a.I), opD.npairs * 2 * opD.ppr, nullptr, 0, nullptr, 0);
             }
             if (it < a.L) {
-                const StepEngineLayer W = layers[it];
+                const StepEngineLayer W = seg ? a.seg_a : layers[it];
                 {   // rows [r0, r1) of the stack [q | k | v]
                     const long r0 = 2l * opQ.pair0, r1 = r0 + 2l * opQ.npairs, rb = 2l * hidden;
                     const long q0 = min(r0, n0), q1 = min(r1, n0);
@@ -705,6 +711,14 @@ __global__ __launch_bounds__(kBlock, 1) void step_engine_kernel(const StepEngine
         for (int i = lane; i < D; i += 64) rope[i] = i < half ? a.rope_cos[(size_t)pos * half + i] : a.rope_sin[(size_t)pos * half + i - half];
     }
     unsigned slot = 0;   // first ring slot of the current op (the loader counts the same way)
+    // segment: the vector the launch starts from is a plain buffer -- its loads go out before anything else (every dependent round trip
+    // at the start of a launch costs 2-4 us while 256 loaders fill the memory queues)
+    u32x4 xpre[kNwv];
+    if (seg) {
+        const u32x4* src = reinterpret_cast<const u32x4*>(a.seg_layer > 0 ? a.x1_in : a.x_in);
+#pragma unroll
+        for (int k = 0; k < kNwv; ++k) xpre[k] = src[min(w.cw * 64 + lane + k * kCons * 64, hidden / 8 - 1)];
+    }
 
     // One iteration = [gate/up, down] of layer i - 1, then [q/k/v, attention, o] of layer i.  The whole step: i = 0 .. L.  Segment mode
     // (a.seg_layer = i >= 0): ONE iteration without attention and o -- the launch between two attention launches of the hybrid step.
@@ -712,7 +726,7 @@ __global__ __launch_bounds__(kBlock, 1) void step_engine_kernel(const StepEngine
     for (int it = it0; it < it1; ++it) {
         if (it > 0) {
             const int l = it - 1;
-            const StepEngineLayer W = layers[l];
+            const StepEngineLayer W = seg ? a.seg_m : layers[l];   // (segment: the two layers ride in the kernel arguments, no load to wait for)
             const unsigned tag = seq * (unsigned)a.L + (unsigned)l + 1u;
             const bool last = l + 1 == a.L;
             u32x4 nwv[kNwv];
@@ -720,8 +734,12 @@ __global__ __launch_bounds__(kBlock, 1) void step_engine_kernel(const StepEngine
             norm_w_prefetch(w, W.post_ln, hidden, nwv);
             if (seg) {   // the attention launch left the residual stream in a.x1_in
                 const u32x4* src = reinterpret_cast<const u32x4*>(a.x1_in);
-                cbar(a, L, w);
-                for (int v = w.cw * 64 + lane; v < hidden / 8; v += kCons * 64) xA[v] = src[v];
+#pragma unroll
+                for (int k = 0; k < kNwv; ++k) {
+                    const int v = w.cw * 64 + lane + k * kCons * 64;
+                    if (v < hidden / 8) xA[v] = xpre[k];
+                }
+                for (int v = w.cw * 64 + lane + kNwv * kCons * 64; v < hidden / 8; v += kCons * 64) xA[v] = src[v];
                 cbar(a, L, w);
             } else {
                 gather_vec(a, L, w, a.g_x1, hidden / 2, tag, a.nsweep);
@@ -762,7 +780,7 @@ __global__ __launch_bounds__(kBlock, 1) void step_engine_kernel(const StepEngine
         }
         if (it < a.L) {
             const int l = it;
-            const StepEngineLayer W = layers[l];
+            const StepEngineLayer W = seg ? a.seg_a : layers[l];
             const unsigned tag = seq * (unsigned)a.L + (unsigned)l + 1u;
             STAMP(0);
             // ---- [RMSNorm + q/k/v] ----
@@ -776,7 +794,16 @@ __global__ __launch_bounds__(kBlock, 1) void step_engine_kernel(const StepEngine
             if (l == 0) {   // the embedding row of the current token (Embedding::forward, model.rs:396); segment mode: already in a.x_in
                 const u32x4* src = reinterpret_cast<const u32x4*>(seg ? a.x_in : a.embed + (size_t)a.st->cur_token * hidden);
                 cbar(a, L, w);                                   // (the area's previous readers are done)
-                for (int v = w.cw * 64 + lane; v < hidden / 8; v += kCons * 64) xA[v] = src[v];
+                if (seg) {
+#pragma unroll
+                    for (int k = 0; k < kNwv; ++k) {
+                        const int v = w.cw * 64 + lane + k * kCons * 64;
+                        if (v < hidden / 8) xA[v] = xpre[k];
+                    }
+                    for (int v = w.cw * 64 + lane + kNwv * kCons * 64; v < hidden / 8; v += kCons * 64) xA[v] = src[v];
+                } else {
+                    for (int v = w.cw * 64 + lane; v < hidden / 8; v += kCons * 64) xA[v] = src[v];
+                }
                 cbar(a, L, w);
             } else {
                 gather_vec(a, L, w, a.g_x, hidden / 2, tag, a.nsweep);

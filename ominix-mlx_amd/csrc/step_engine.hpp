@@ -45,6 +45,8 @@ struct StepEngineArgs {
     // segment mode (the hybrid step: attention + o stay their own launch, csrc/attn_step.hip): this launch runs [gate/up, down] of layer
     // seg_layer - 1 (skipped at 0) and [RMSNorm + q/k/v] of layer seg_layer (skipped at L); -1: the whole step
     int seg_layer;
+    StepEngineLayer seg_m, seg_a;    // segment mode: layers seg_layer - 1 and seg_layer by value (set by the caller from its host table)
+    int xcd_major;                   // shares of the rows XCD-major (see share_of)
     const bf16_t* x_in;              // seg_layer == 0: the embedding row (written by the step's first kernel)
     const bf16_t* x1_in;             // seg_layer > 0: residual stream after the attention launch of layer seg_layer - 1
     bf16_t* qkv_out;                 // raw projections for the attention launch of layer seg_layer; the new residual goes to h_out

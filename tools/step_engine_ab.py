@@ -17,6 +17,8 @@ if len(sys.argv) > 3:
 ids = bench.prompt_ids(prompt, cfg["vocab_size"])
 variants = [("launches", {"OMX_STEP_ENGINE": "0"})]
 for spec in os.environ.get("OMX_AB_VARIANTS", "1:2:1,3:2:1,3:3:1,1:2:0,3:2:0,3:3:0").split(","):
+    if not spec:
+        continue
     ns, inf, thin = spec.split(":")
     variants.append((f"engine nsweep={ns} inflight={inf} thin={thin}",
                      {"OMX_STEP_ENGINE": "1", "OMX_SE_NSWEEP": ns, "OMX_SE_INFLIGHT": inf, "OMX_SE_THIN": thin}))

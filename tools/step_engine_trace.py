@@ -41,4 +41,12 @@ for l in (1, 2):
         d = "" if prev is None else f"   +{np.median(v) - prev:6.2f}"
         print(f"   {names[k]:28s} median {np.median(v):8.2f}  min {v.min():8.2f}  max {v.max():8.2f}  n {v.size:3d}{d}")
         prev = np.median(v)
+    for k in (14, 16):
+        v = (tt[:, k] - np.median(tt[:, 0])) / 100.0
+        dur = (tt[:, k] - tt[:, {14: 18, 16: 15}[k]]) / 100.0
+        print(f"   {names[k]}: per-XCD median of the phase duration", [round(float(np.median(dur[x::8])), 2) for x in range(8)])
+        slow = np.argsort(-v)[:24]
+        print("      slowest CUs (cu: finish, duration):", [(int(c), round(float(v[c]), 1), round(float(dur[c]), 1)) for c in slow])
+        fast = np.argsort(v)[:8]
+        print("      fastest CUs:", [(int(c), round(float(v[c]), 1), round(float(dur[c]), 1)) for c in fast])
 m.close()

@@ -175,7 +175,7 @@ typedef struct omx_qwen3_config_ {
      * expert tensors registered are ITS slices -- attention and router replicated; one all-reduce per layer (omx_qwen3_set_comm) */
     int ep_rank, ep_size;
     /* Qwen2 wiring (qwen3-mlx/src/qwen2.rs:100-218): q/k/v projections carry a bias ("self_attn.{q,k,v}_proj.bias") and the
-     * attention has no q/k norm (set no_qk_norm too); bf16, single GPU */
+     * attention has no q/k norm (set no_qk_norm too); bf16; under tensor parallelism the biases are sharded like their rows */
     int attention_bias;
 } omx_qwen3_config;
 typedef struct omx_qwen3_* omx_qwen3;
@@ -183,8 +183,10 @@ typedef struct omx_qwen3_* omx_qwen3;
 int omx_qwen3_create(omx_qwen3* out, const omx_qwen3_config* cfg);
 int omx_qwen3_destroy(omx_qwen3 m);
 /* register a weight by HF key name; `ptr` is this rank's shard (column-split q/k/v/gate/up/lm_head rows,
- * row-split o/down columns), bf16, contiguous.                                                      */
-int omx_qwen3_set_weight(omx_qwen3 m, const char* name, const void* ptr);
+ * row-split o/down columns), bf16 (packed u32 / bf16 scales, biases for a quantized checkpoint), contiguous, `nbytes` long: the
+ * engine reads raw pointers, so a tensor whose size disagrees with the config is refused here ("ShapeMismatch", the reference's
+ * load-time shape error) instead of being read past its end                                         */
+int omx_qwen3_set_weight(omx_qwen3 m, const char* name, const void* ptr, size_t nbytes);
 /* allocate + fill every weight with the seeded synthetic generator (seed = base ^ crc32(name))      */
 int omx_qwen3_synth_weights(omx_qwen3 m, uint32_t base_seed);
 /* tensor-parallel hook: `allreduce` has the ncclAllReduce signature, `comm` is the ncclComm_t.      */
@@ -338,7 +340,8 @@ typedef struct omx_klein_config_ {   /* FluxKleinParams, klein_model.rs:166-196 
 typedef struct omx_klein_* omx_klein;
 int omx_klein_create(omx_klein* out, const omx_klein_config* cfg);
 int omx_klein_destroy(omx_klein m);
-int omx_klein_set_weight(omx_klein m, const char* name, const void* ptr);
+/* `nbytes`: length of the tensor behind `ptr`; every use checks it against the rows x columns it is about to read */
+int omx_klein_set_weight(omx_klein m, const char* name, const void* ptr, size_t nbytes);
 int omx_klein_synth_weights(omx_klein m, uint32_t base_seed);   /* under TP: this rank's shards of the same logical tensors */
 /* comm: ncclComm_t, allreduce_fn: address of ncclAllReduce (RCCL); one bf16 all-reduce after every row-split
  * projection (2 per double-block stream, 1 per single block) */

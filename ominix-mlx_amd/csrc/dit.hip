@@ -146,6 +146,7 @@ constexpr int kNcclBfloat16 = 9, kNcclSum = 0;
 struct omx_klein_ {
     omx_klein_config cfg;
     std::map<std::string, const bf16_t*> w;
+    std::map<std::string, size_t> wbytes;      // size of every registered tensor (omx_klein_set_weight / the synthetic generator)
     std::vector<void*> owned;
     hipStream_t stream = nullptr;      // the stream helpers launch on (switched to stream_txt for the txt half of a double block)
     hipStream_t stream_main = nullptr, stream_txt = nullptr;
@@ -168,9 +169,13 @@ struct omx_klein_ {
 
 namespace {
 
-int kget(omx_klein m, const std::string& name, const bf16_t** out) {
+// `elems`: bf16 elements the caller is about to read behind the pointer (the registered tensor must hold at least that many)
+int kget(omx_klein m, const std::string& name, const bf16_t** out, size_t elems) {
     auto it = m->w.find(name);
     if (it == m->w.end()) return set_error("WeightNotFound: %s", name.c_str());
+    auto sz = m->wbytes.find(name);
+    if (sz != m->wbytes.end() && sz->second < elems * 2)
+        return set_error("ShapeMismatch: %s holds %zu bytes, this forward reads %zu", name.c_str(), sz->second, elems * 2);
     *out = it->second;
     return 0;
 }
@@ -186,7 +191,7 @@ int kalloc(omx_klein m, T** p, size_t n) {
 
 int linear(omx_klein m, bf16_t* out, const bf16_t* x, const char* wname, int M, int N, int K) {
     const bf16_t* w = nullptr;
-    if (kget(m, wname, &w)) return 1;
+    if (kget(m, wname, &w, (size_t)N * K)) return 1;
     return omx_linear(out, x, w, nullptr, M, N, K, OMX_BFLOAT16, m->stream);
 }
 
@@ -275,9 +280,11 @@ int omx_klein_destroy(omx_klein m) {
     return 0;
 }
 
-int omx_klein_set_weight(omx_klein m, const char* name, const void* ptr) {
+int omx_klein_set_weight(omx_klein m, const char* name, const void* ptr, size_t nbytes) {
     OMX_REQUIRE(m && name && ptr, "omx_klein_set_weight: null argument");
+    OMX_REQUIRE(nbytes > 0 && nbytes % 2 == 0, "omx_klein_set_weight: %s: %zu bytes is not a bf16 tensor", name, nbytes);
     m->w[name] = (const bf16_t*)ptr;
+    m->wbytes[name] = nbytes;
     return 0;
 }
 
@@ -302,6 +309,7 @@ int omx_klein_synth_weights(omx_klein m, uint32_t base_seed) {
         if (kalloc(m, &p, rows * cols)) return 1;
         if (omx_fill_uniform(p, rows * cols, seed_of(name), norm ? amp_n : amp_w, norm ? 1.0f : 0.0f, OMX_BFLOAT16, m->stream)) return 1;
         m->w[name] = p;
+        m->wbytes[name] = rows * cols * 2;
         return 0;
     };
     // this rank's ROWS of a logical [*, cols] tensor: the listed row ranges stacked
@@ -316,6 +324,7 @@ int omx_klein_synth_weights(omx_klein m, uint32_t base_seed) {
             off += g.len;
         }
         m->w[name] = p;
+        m->wbytes[name] = (size_t)(total * cols) * 2;
         return 0;
     };
     // this rank's COLUMNS of a logical [rows, cols_full] tensor: the listed column ranges side by side
@@ -335,6 +344,7 @@ int omx_klein_synth_weights(omx_klein m, uint32_t base_seed) {
         }
         OMX_HIP_CHECK(hipFree(tmp));
         m->w[name] = p;
+        m->wbytes[name] = (size_t)(rows * total) * 2;
         return 0;
     };
     if (make("x_embedder.weight", h, c.in_channels, false) || make("context_embedder.weight", h, c.txt_embed_dim, false) ||
@@ -450,7 +460,7 @@ int omx_klein_forward_with_rope(omx_klein m, void* out, const void* latent, cons
             if (linear(m, m->v + r0 * hl, m->xm + r0 * h, (b + sn + "to_v.weight").c_str(), rows, hl, h)) return 1;
             const unsigned blocks = (unsigned)(((size_t)rows * H + 15) / 16);
             const bf16_t* wkn = nullptr;
-            if (kget(m, b + sn + "norm_q.weight", &w) || kget(m, b + sn + "norm_k.weight", &wkn)) return 1;
+            if (kget(m, b + sn + "norm_q.weight", &w, (size_t)c.head_dim) || kget(m, b + sn + "norm_k.weight", &wkn, (size_t)c.head_dim)) return 1;
             klein_qk_norm_rope_kernel<<<dim3(blocks, 2), 256, 0, s>>>(m->q + r0 * hl, m->k + r0 * hl, hl, rows, H, w, wkn, rope_cos, rope_sin,
                                                                       (int)r0, rms_eps);
             OMX_LAUNCH_CHECK();
@@ -468,19 +478,19 @@ int omx_klein_forward_with_rope(omx_klein m, void* out, const void* latent, cons
             const bf16_t* mod = st ? m->mod_img : m->mod_txt;
             const int rows = st ? s_img : s_txt;
             const size_t r0 = st ? (size_t)s_txt : 0;
-            if (kget(m, b + sn + "to_out.weight", &w)) return 1;
+            if (kget(m, b + sn + "to_out.weight", &w, (size_t)h * hl)) return 1;
             if (gated_projection(m, x2 + r0 * h, m->att + r0 * hl, w, x + r0 * h, mod + 2 * h /*gate1*/, rows, h, hl)) return 1;
             // ---- MLP half ----
             if (omx_fused_modulate(m->xm + r0 * h, x2 + r0 * h, mod + 3 * h, mod + 4 * h, 1, rows, h, 1e-6f, OMX_BFLOAT16, s)) return 1;
             if (fuse_act && gemm_swiglu_preferred(rows, 0, mh, h)) {
-                if (kget(m, b + sn + "mlp_in.weight", &w)) return 1;
+                if (kget(m, b + sn + "mlp_in.weight", &w, (size_t)2 * mh * h)) return 1;
                 if (launch_gemm_bf16_swiglu(nullptr, 0, act, mh, m->xm + r0 * h, w, rows, 0, mh, h, s)) return 1;
             } else {
                 if (linear(m, proj, m->xm + r0 * h, (b + sn + "mlp_in.weight").c_str(), rows, 2 * mh, h)) return 1;
                 swiglu_strided_kernel<<<2048, 256, 0, s>>>(act, mh, proj /*gate = first half*/, proj + mh /*up*/, 2 * mh, rows, mh);
                 OMX_LAUNCH_CHECK();
             }
-            if (kget(m, b + sn + "mlp_out.weight", &w)) return 1;
+            if (kget(m, b + sn + "mlp_out.weight", &w, (size_t)h * mh)) return 1;
             if (gated_projection(m, x + r0 * h, act, w, x2 + r0 * h, mod + 5 * h /*gate2*/, rows, h, mh)) return 1;
         }
         on_stream(1);
@@ -494,12 +504,12 @@ int omx_klein_forward_with_rope(omx_klein m, void* out, const void* latent, cons
         if (omx_fused_modulate(m->xm, x, mod, mod + h, 1, S, h, 1e-6f, OMX_BFLOAT16, s)) return 1;
         const bool fused = fuse_act && gemm_swiglu_preferred(S, 3 * hl, mh, h);
         if (fused) {   // q/k/v columns -> proj, SwiGLU of the MLP columns straight into comb[:, hl:]
-            if (kget(m, b + "to_qkv_mlp.weight", &w)) return 1;
+            if (kget(m, b + "to_qkv_mlp.weight", &w, (size_t)ldp * h)) return 1;
             if (launch_gemm_bf16_swiglu(m->proj, (int)ldp, m->comb + hl, (int)ldc, m->xm, w, S, 3 * hl, mh, h, s)) return 1;
         } else if (linear(m, m->proj, m->xm, (b + "to_qkv_mlp.weight").c_str(), S, (int)ldp, h)) return 1;
         const unsigned blocks = (unsigned)(((size_t)S * H + 15) / 16);
         const bf16_t* wkn = nullptr;
-        if (kget(m, b + "norm_q.weight", &w) || kget(m, b + "norm_k.weight", &wkn)) return 1;
+        if (kget(m, b + "norm_q.weight", &w, (size_t)c.head_dim) || kget(m, b + "norm_k.weight", &wkn, (size_t)c.head_dim)) return 1;
         klein_qk_norm_rope_kernel<<<dim3(blocks, 2), 256, 0, s>>>(m->proj, m->proj + hl, ldp, S, H, w, wkn, rope_cos, rope_sin, 0, rms_eps);
         OMX_LAUNCH_CHECK();
         if (attention(m, m->comb, ldc, m->proj, m->proj + hl, m->proj + 2 * hl, ldp, S)) return 1;          // cols [0, hl)
@@ -507,7 +517,7 @@ int omx_klein_forward_with_rope(omx_klein m, void* out, const void* latent, cons
             swiglu_strided_kernel<<<2048, 256, 0, s>>>(m->comb + hl, ldc, m->proj + 3 * hl, m->proj + 3 * hl + mh, ldp, S, mh);   // cols [hl, hl+mh)
             OMX_LAUNCH_CHECK();
         }
-        if (kget(m, b + "to_out.weight", &w)) return 1;
+        if (kget(m, b + "to_out.weight", &w, (size_t)h * ldc)) return 1;
         if (gated_projection(m, x2, m->comb, w, x, mod + 2 * h, S, h, (int)ldc)) return 1;
         bf16_t* t = x; x = x2; x2 = t;
     }

@@ -1003,7 +1003,7 @@ int prefill_prefix_batched(omx_qwen3 m, int T, int off, const EncodeOpts* enc = 
             a.scale = scale; a.mask_mode = OMX_MASK_NONE; a.causal_tail = 1;
             a.nsplit = decode_nsplit(off + T, T * Hkv);
             void* aws = nullptr;
-            if (get_workspace_aux(&aws, attn_decode_ws_bytes(T * H, a.nsplit, D))) return 1;
+            if (get_workspace_aux(&aws, attn_decode_ws_bytes(T * H, a.nsplit, D), s)) return 1;
             a.ws_o = (float*)aws;
             a.ws_ml = a.ws_o + (size_t)T * H * a.nsplit * D;
             a.out = m->pf_attn;                                                       // [T, H * D]
@@ -1179,14 +1179,66 @@ int omx_qwen3_destroy(omx_qwen3 m) {
     if (m->ev1) (void)hipEventDestroy(m->ev1);
     if (m->stream) {
         gemm_release_stream(m->stream);
+        workspace_release_stream(m->stream);
         (void)hipStreamDestroy(m->stream);
     }
     delete m;
     return 0;
 }
 
-int omx_qwen3_set_weight(omx_qwen3 m, const char* name, const void* ptr) {
+// bytes the forward will read behind checkpoint tensor `name` on THIS rank (after the TP / EP slicing), 0 for a name it does not
+// use; mirrors resolve_weights above (and engine.py expected_shape, which reports the same thing as a shape)
+static size_t expected_weight_bytes(omx_qwen3 m, const std::string& name) {
+    const omx_qwen3_config& c = m->cfg;
+    const size_t hd = c.hidden_size, D = c.head_dim, H = m->H, Hkv = m->Hkv, I = m->I, Im = c.moe_intermediate_size;
+    const size_t E = c.num_experts, El = c.ep_size > 1 ? E / c.ep_size : E;
+    static const char* kSuffix[] = {".weight", ".scales", ".biases", ".bias"};
+    int kind = -1;
+    std::string stem;
+    for (int i = 0; i < 4; ++i) {
+        const size_t n = strlen(kSuffix[i]);
+        if (name.size() > n && name.compare(name.size() - n, n, kSuffix[i]) == 0) { kind = i; stem = name.substr(0, name.size() - n); break; }
+    }
+    if (kind < 0) return 0;
+    const bool quant = c.quant_bits != 0;
+    // [n, k] Linear (x stack): dense bf16, or the packed triplet of a quantized checkpoint; bias [n]
+    auto lin = [&](size_t n, size_t k, size_t stack = 1) -> size_t {
+        if (kind == 3) return n * 2;
+        if (!quant) return kind == 0 ? stack * n * k * 2 : 0;
+        if (kind == 0) return stack * n * (k * c.quant_bits / 32) * 4;
+        return stack * n * (k / c.quant_group) * 2;
+    };
+    auto vec = [&](size_t n) -> size_t { return kind == 0 ? n * 2 : 0; };
+    if (stem == "model.embed_tokens") return lin(c.vocab_size, hd);
+    if (stem == "lm_head") return lin(m->V, hd);
+    if (stem == "model.norm") return vec(hd);
+    if (stem.compare(0, 13, "model.layers.") != 0) return 0;
+    const size_t dot = stem.find('.', 13);
+    if (dot == std::string::npos) return 0;
+    const std::string sub = stem.substr(dot + 1);
+    if (sub == "self_attn.q_proj") return lin(H * D, hd);
+    if (sub == "self_attn.k_proj" || sub == "self_attn.v_proj") return lin(Hkv * D, hd);
+    if (sub == "self_attn.o_proj") return lin(hd, H * D);
+    if (sub == "mlp.gate_proj" || sub == "mlp.up_proj") return lin(I, hd);
+    if (sub == "mlp.down_proj") return lin(hd, I);
+    if (sub == "input_layernorm" || sub == "post_attention_layernorm") return vec(hd);
+    if (sub == "self_attn.q_norm" || sub == "self_attn.k_norm") return vec(D);
+    if (E > 0)
+        for (const char* mp : {"block_sparse_moe.", "mlp."}) {
+            const std::string p = mp;
+            if (sub == p + "gate") return lin(E, hd);
+            if (sub == p + "switch_mlp.gate_proj" || sub == p + "switch_mlp.up_proj") return lin(Im, hd, El);
+            if (sub == p + "switch_mlp.down_proj") return lin(hd, Im, El);
+        }
+    return 0;
+}
+
+int omx_qwen3_set_weight(omx_qwen3 m, const char* name, const void* ptr, size_t nbytes) {
     OMX_REQUIRE(m && name && ptr, "omx_qwen3_set_weight: null argument");
+    // the engine reads raw device pointers: a tensor shorter than the config implies would be read past its end, so the size is part
+    // of the call (the reference raises a shape error on load)
+    const size_t want = expected_weight_bytes(m, name);
+    OMX_REQUIRE(want == 0 || nbytes == want, "ShapeMismatch: %s holds %zu bytes, the config expects %zu", name, nbytes, want);
     OMX_REQUIRE(((uintptr_t)ptr & 15u) == 0, "omx_qwen3_set_weight: %s is not 16-byte aligned", name);
     OMX_REQUIRE(m->g_full == nullptr, "omx_qwen3_set_weight: weights are frozen once the decode step is built");
     m->named[name] = ptr;

@@ -175,7 +175,7 @@ int launch_gemm_f32(const GemmF32& p, hipStream_t s) {
     g.splits = splits;
     if (splits > 1) {
         void* ws = nullptr;
-        if (get_workspace_aux(&ws, (size_t)p.batch * splits * p.M * p.N * sizeof(float))) return 1;
+        if (get_workspace_aux(&ws, (size_t)p.batch * splits * p.M * p.N * sizeof(float), s)) return 1;
         g.partial = (float*)ws;
     }
     gemm_f32_kernel<<<dim3(gx, gy, p.batch * splits), 256, 0, s>>>(g);

@@ -590,10 +590,103 @@ int mlx_fast_scaled_dot_product_attention(mlx_array* res, const mlx_array querie
 }
 
 // ---- GEMM ----
-static int matmul_impl(mlx_array* res, const mlx_array ha, const mlx_array hb, const Arr* bias, const char* name) {
-    REQ_ARR(ha, name); REQ_ARR(hb, name);
+// a[..., M, K] @ b[..., K, N] with broadcast batch dimensions (mlx::core::matmul, ops.h:598-602): the form of the reference's explicit
+// attention -- q.matmul(&k_t) and attn.matmul(&v) on [B, H, T, D] (funasr-mlx/src/paraformer.rs:517-520, 981-1017;
+// flux-klein-mlx/src/klein_model.rs:474-483, 656-659).  b^T is taken in place when b is a transposed view of row-major [.., N, K] (k_t),
+// otherwise materialised once for the whole batch; float32 runs on the exact-f32 matrix cores (one batched launch when nothing is
+// broadcast), bfloat16 one GEMM / GEMV launch per batch entry.
+static int matmul_batched(mlx_array* res, const Arr& a_in, const Arr& b_in, const char* name) {
+    Arr av = a_in, bv = b_in;
+    bool drop_m = false, drop_n = false;
+    if (av.shape.size() == 1) { av.shape.insert(av.shape.begin(), 1); av.strides.insert(av.strides.begin(), 0); drop_m = true; }
+    if (bv.shape.size() == 1) { bv.shape.push_back(1); bv.strides.push_back(0); drop_n = true; }
+    const int na = (int)av.shape.size(), nb = (int)bv.shape.size();
+    const int M = av.shape[na - 2], K = av.shape[na - 1], N = bv.shape[nb - 1];
+    OMX_REQUIRE(bv.shape[nb - 2] == K, "%s: inner dimensions differ (%d vs %d)", name, K, bv.shape[nb - 2]);
+    OMX_REQUIRE(av.dt == bv.dt, "%s: dtype mismatch", name);
+    OMX_REQUIRE(av.dt == MLX_BFLOAT16 || av.dt == MLX_FLOAT32, "%s: batched operands in bfloat16 or float32", name);
+    // broadcast batch shape, right-aligned
+    const int nbat = std::max(na, nb) - 2;
+    std::vector<int> bs(nbat), da(nbat, 1), db(nbat, 1);
+    for (int i = 0; i < nbat; ++i) {
+        const int ia = i - (nbat - (na - 2)), ib = i - (nbat - (nb - 2));
+        if (ia >= 0) da[i] = av.shape[ia];
+        if (ib >= 0) db[i] = bv.shape[ib];
+        OMX_REQUIRE(da[i] == db[i] || da[i] == 1 || db[i] == 1, "%s: batch dimensions %d and %d do not broadcast", name, da[i], db[i]);
+        bs[i] = std::max(da[i], db[i]);
+    }
+    Contig ca;
+    if (ca.init(av)) return 1;                                   // [da..., M, K] row-major
+    Arr bt = bv;                                                 // b^T: [db..., N, K]
+    std::swap(bt.shape[nb - 1], bt.shape[nb - 2]);
+    std::swap(bt.strides[nb - 1], bt.strides[nb - 2]);
+    Contig cb;
+    if (cb.init(bt)) return 1;
+    std::vector<int> oshape = bs;
+    oshape.push_back(M); oshape.push_back(N);
+    Arr* r = new_arr(oshape, av.dt);
+    if (!r) return set_error("%s: out of device memory", name);
+    size_t nbatch = 1;
+    for (int d : bs) nbatch *= (size_t)d;
+    const size_t es = dsize(av.dt);
+    bool plain = true;                                           // no broadcasting: uniform batch strides
+    for (int i = 0; i < nbat; ++i) plain = plain && da[i] == bs[i] && db[i] == bs[i];
+    int rc = 0;
+    if (M && N && K && nbatch) {
+        if (av.dt == MLX_FLOAT32 && plain) {
+            omx::GemmF32 g = {};
+            g.a = (const float*)ca.a->ptr(); g.b = (const float*)cb.a->ptr(); g.out = (float*)r->ptr();
+            g.M = M; g.N = N; g.K = K; g.lda = K; g.ldb = K; g.ldc = N;
+            g.sa = (int64_t)M * K; g.sb = (int64_t)N * K; g.sc = (int64_t)M * N; g.batch = (int)nbatch; g.alpha = 1.0f;
+            rc = omx::launch_gemm_f32(g, g_stream);
+        } else {
+            for (size_t i = 0; i < nbatch && !rc; ++i) {
+                size_t rem = i, oa = 0, ob = 0, sa = 1, sb = 1;   // offsets of this entry in the (un-broadcast) operands, in matrices
+                for (int d = nbat - 1; d >= 0; --d) {
+                    const size_t id = rem % (size_t)bs[d];
+                    rem /= (size_t)bs[d];
+                    if (da[d] != 1) oa += id * sa;
+                    if (db[d] != 1) ob += id * sb;
+                    sa *= (size_t)da[d]; sb *= (size_t)db[d];
+                }
+                rc = omx_linear(r->ptr() + i * (size_t)M * N * es, ca.a->ptr() + oa * (size_t)M * K * es, cb.a->ptr() + ob * (size_t)N * K * es,
+                                nullptr, M, N, K, to_omx(av.dt), g_stream);
+            }
+        }
+    }
+    if (rc) { delete r; return 1; }
+    if (drop_m) { r->shape.erase(r->shape.end() - 2); r->strides = row_major(r->shape); }
+    if (drop_n) { r->shape.pop_back(); r->strides = row_major(r->shape); }
+    return assign(res, r);
+}
+
+int mlx_astype(mlx_array* res, const mlx_array a, mlx_dtype dtype, const mlx_stream);
+static int matmul_impl(mlx_array* res, const mlx_array ha_in, const mlx_array hb_in, const Arr* bias, const char* name) {
+    REQ_ARR(ha_in, name); REQ_ARR(hb_in, name);
+    // MLX promotes mixed floating operands before the product (bf16 probabilities x f32 anything -> f32: the Klein blocks divide their
+    // bf16 scores by an f32 scalar array, so their softmax and attn @ v run in float32, klein_model.rs:653-656)
+    mlx_array ha = ha_in, hb = hb_in, tmp = {nullptr};
+    struct Drop { mlx_array* t; ~Drop() { if (t->ctx) delete A(*t); } } drop{&tmp};
+    if (A(ha)->dt != A(hb)->dt && is_float(A(ha)->dt) && is_float(A(hb)->dt)) {
+        const bool cast_a = A(ha)->dt != MLX_FLOAT32;
+        if (mlx_astype(&tmp, cast_a ? ha : hb, MLX_FLOAT32, mlx_stream{nullptr})) return 1;
+        if (cast_a) ha = tmp; else hb = tmp;
+        if (A(ha)->dt != A(hb)->dt) {   // bf16 x f16: both to float32
+            mlx_array t2 = {nullptr};
+            if (mlx_astype(&t2, cast_a ? hb : ha, MLX_FLOAT32, mlx_stream{nullptr})) return 1;
+            mlx_array r2 = {nullptr};
+            const int rc = matmul_impl(&r2, cast_a ? ha : t2, cast_a ? t2 : hb, bias, name);
+            delete A(t2);
+            if (rc) return 1;
+            return assign(res, A(r2));
+        }
+    }
     const Arr &a0 = *A(ha), &b0 = *A(hb);
-    OMX_REQUIRE(a0.shape.size() >= 1 && b0.shape.size() == 2, "%s: supported form is a[..., K] @ b[K, N] (b 2-D)", name);
+    OMX_REQUIRE(a0.shape.size() >= 1 && b0.shape.size() >= 1, "%s: scalar operand", name);
+    if (b0.shape.size() != 2) {
+        OMX_REQUIRE(bias == nullptr, "%s: a bias needs a 2-D weight", name);
+        return matmul_batched(res, a0, b0, name);
+    }
     const int K = a0.shape.back(), N = b0.shape[1];
     OMX_REQUIRE(b0.shape[0] == K, "%s: inner dimensions differ (%d vs %d)", name, K, b0.shape[0]);
     OMX_REQUIRE(a0.dt == b0.dt, "%s: dtype mismatch", name);

@@ -5,5 +5,8 @@
 #include "common.hpp"
 namespace omx {
 int get_workspace(void** ptr, size_t bytes);
-int get_workspace_aux(void** ptr, size_t bytes);   // independent of the above (callers nested inside a get_workspace user)
+// independent of the above (callers nested inside a get_workspace user), one buffer per stream: concurrent users on different streams
+// never share or reallocate each other's scratch
+int get_workspace_aux(void** ptr, size_t bytes, hipStream_t s);
+void workspace_release_stream(hipStream_t s);       // the stream's owner is about to destroy it
 }

@@ -30,7 +30,7 @@ ENGINE_SIGNATURES = {
                                     ctypes.c_int64, c_uint32, c_float, c_float, c_int, c_void_p]),
     "omx_qwen3_create": (c_int, [ctypes.POINTER(c_void_p), ctypes.POINTER(Qwen3Config)]),
     "omx_qwen3_destroy": (c_int, [c_void_p]),
-    "omx_qwen3_set_weight": (c_int, [c_void_p, ctypes.c_char_p, c_void_p]),
+    "omx_qwen3_set_weight": (c_int, [c_void_p, ctypes.c_char_p, c_void_p, ctypes.c_size_t]),
     "omx_qwen3_synth_weights": (c_int, [c_void_p, c_uint32]),
     "omx_qwen3_set_comm": (c_int, [c_void_p, c_void_p, c_void_p]),
     "omx_qwen3_set_sampler": (c_int, [c_void_p, ctypes.c_float, ctypes.c_uint64]),
@@ -196,7 +196,7 @@ class Model:
             # quantized checkpoints: "<prefix>.weight" is packed uint32 (ops/quantization.rs:41-84), scales / biases bf16
             t = Tensor.from_numpy(arr, "u32" if dt == np.uint32 else "bf16")
             self._keep.append(t)
-            check(lib.omx_qwen3_set_weight(self._h, name.encode(), t.ptr))
+            check(lib.omx_qwen3_set_weight(self._h, name.encode(), t.ptr, t.nbytes))
 
     def expected_shape(self, name: str):
         return expected_shape(self.cfg, name)

@@ -21,7 +21,7 @@ class KleinConfig(ctypes.Structure):
 KLEIN_SIGNATURES = {
     "omx_klein_create": (c_int, [ctypes.POINTER(c_void_p), ctypes.POINTER(KleinConfig)]),
     "omx_klein_destroy": (c_int, [c_void_p]),
-    "omx_klein_set_weight": (c_int, [c_void_p, ctypes.c_char_p, c_void_p]),
+    "omx_klein_set_weight": (c_int, [c_void_p, ctypes.c_char_p, c_void_p, ctypes.c_size_t]),
     "omx_klein_synth_weights": (c_int, [c_void_p, c_uint32]),
     "omx_klein_set_comm": (c_int, [c_void_p, c_void_p, c_void_p]),
     "omx_klein_forward_with_rope": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p]),
@@ -132,7 +132,7 @@ class FluxKlein:
         for name, arr in weights.items():
             t = Tensor.from_numpy(arr, "bf16")
             self._keep.append(t)
-            check(lib.omx_klein_set_weight(self._h, name.encode(), t.ptr))
+            check(lib.omx_klein_set_weight(self._h, name.encode(), t.ptr, t.nbytes))
 
     def synth_weights(self, base_seed: int = 0x0C0FFEE5) -> None:
         check(lib.omx_klein_synth_weights(self._h, base_seed & 0xFFFFFFFF))

@@ -229,3 +229,144 @@ def test_slice_update_donation_contract(mx):
         mx.astype(src2, mx.FLOAT32)
     del src2
     np.testing.assert_array_equal(out2.numpy(), want)
+
+
+def _scalar(mx, v):
+    return mx.Array(mx.lib.mlx_array_new_float32(float(v)))
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+def test_batched_matmul_broadcasts_like_mlx(mx, dt):
+    """mlx_matmul on N-D operands (ops.h:598-602): a[..., M, K] @ b[..., K, N] with broadcast batch dimensions, b given as a
+    transposed VIEW (k_t of the explicit attention: consumed in place) or as plain row-major [K, N] (attn @ v), 1-D operands."""
+    code = mx.FLOAT32 if dt == "f32" else mx.BFLOAT16
+    rnd = (lambda a: a.astype(np.float32)) if dt == "f32" else rc.bf16_round
+    tol = dict(rtol=2e-5, atol=2e-5) if dt == "f32" else dict(rtol=2e-2, atol=2e-2)
+    a = rnd(rand((2, 3, 5, 16), 30)); b = rnd(rand((2, 3, 16, 7), 31))
+    A, B = mx.Array.from_numpy(a, code), mx.Array.from_numpy(b, code)
+    np.testing.assert_allclose(mx.matmul(A, B).numpy(), a @ b, **tol)
+    # k_t: a transposed view of [.., N, K] -- no copy of b
+    k = rnd(rand((2, 3, 9, 16), 32))
+    Kt = mx.transpose_axes(mx.Array.from_numpy(k, code), [0, 1, 3, 2])
+    assert Kt.strides[-2] == 1
+    np.testing.assert_allclose(mx.matmul(A, Kt).numpy(), a @ k.transpose(0, 1, 3, 2), **tol)
+    # broadcast: [2, 1, 5, 16] @ [3, 16, 7] -> [2, 3, 5, 7]
+    a1 = rnd(rand((2, 1, 5, 16), 33)); b1 = rnd(rand((3, 16, 7), 34))
+    got = mx.matmul(mx.Array.from_numpy(a1, code), mx.Array.from_numpy(b1, code))
+    assert got.shape == (2, 3, 5, 7)
+    np.testing.assert_allclose(got.numpy(), a1 @ b1, **tol)
+    # 1-D operands drop their dimension
+    v = rnd(rand((16,), 35))
+    got = mx.matmul(mx.Array.from_numpy(v, code), B)
+    assert got.shape == (2, 3, 7)
+    np.testing.assert_allclose(got.numpy(), v @ b, **tol)
+    with pytest.raises(Exception, match="inner dimensions"):
+        mx.matmul(A, mx.Array.from_numpy(rnd(rand((2, 3, 15, 7), 36)), code))
+
+
+@pytest.mark.parametrize("dt", ["f32", "f16"])
+@pytest.mark.parametrize("mask", ["none", "causal", "bool", "additive"])
+def test_sdpa_in_f32_and_f16(mx, dt, mask):
+    """mlx_fast_scaled_dot_product_attention in the dtypes the reference tests it in (mlx-rs/src/fast.rs:303-331): float32 and float16
+    operands, f32 softmax / accumulation, GQA, Tq != Tk, every mask form -- against the oracle evaluated on the same (rounded) inputs."""
+    B, H, Hkv, Tq, Tk, D = 2, 4, 2, 7, 19, 64
+    np_dt = np.float32 if dt == "f32" else np.float16
+    code = mx.FLOAT32 if dt == "f32" else mx.FLOAT16
+    q = rand((B, H, Tq, D), 40).astype(np_dt); k = rand((B, Hkv, Tk, D), 41).astype(np_dt); v = rand((B, Hkv, Tk, D), 42).astype(np_dt)
+    Q, K, V = (mx.Array.from_numpy(t, code) for t in (q, k, v))
+    m_np, m_arg = None, None
+    if mask == "causal":
+        m_np, m_arg = rc.create_causal_mask(Tq, Tk - Tq), "causal"
+    elif mask == "bool":
+        m_np = np.random.default_rng(5).random((Tq, Tk)) > 0.3
+        m_np[:, 0] = True
+        m_arg = mx.Array.from_numpy(m_np, mx.BOOL)
+    elif mask == "additive":
+        m_np = (0.5 * rand((Tq, Tk), 43)).astype(np_dt)
+        m_arg = mx.Array.from_numpy(m_np, code)
+    out = mx.scaled_dot_product_attention(Q, K, V, D ** -0.5, m_arg)
+    assert out.dtype == code and out.shape == (B, H, Tq, D)
+    got = (out if dt == "f32" else mx.astype(out, mx.FLOAT32)).numpy().astype(np.float64)     # (f16 -> f32 is exact)
+    ref = rc.scaled_dot_product_attention(q.astype(np.float64), k.astype(np.float64), v.astype(np.float64), D ** -0.5,
+                                          None if m_np is None else (m_np if m_np.dtype == np.bool_ else m_np.astype(np.float64)), "f32")
+    tol = 2e-5 if dt == "f32" else 2e-3          # f16: one rounding of the output (11-bit mantissa)
+    np.testing.assert_allclose(got, ref, rtol=tol, atol=tol * np.abs(ref).max())
+
+
+def test_sanm_attention_replayed_op_by_op(mx):
+    """SanmAttention::forward (funasr-mlx/src/paraformer.rs:496-532) issued through the handle ABI exactly as the Rust does -- fused
+    qkv Linear, index / reshape / transpose views, q.matmul(k_t) * scale, softmax_axis, attn.matmul(v), the FSMN depthwise Conv1d over
+    the v projection, out_proj -- in float32 against the float64 oracle (oracle/ref_paraformer.py:sanm_attention)."""
+    from oracle import ref_paraformer as rp
+    T, heads, D, ks = 37, 4, 32, 11
+    dim = heads * D
+    p = {"qkv_w": 0.1 * rand((3 * dim, dim), 50), "qkv_b": 0.1 * rand((3 * dim,), 51), "out_w": 0.1 * rand((dim, dim), 52),
+         "out_b": 0.1 * rand((dim,), 53), "fsmn_w": 0.2 * rand((dim, ks), 54)}
+    x = rand((T, dim), 55)
+    ref = rp.sanm_attention(x.astype(np.float64), {k: v.astype(np.float64) for k, v in p.items()}, heads)
+    f32 = lambda a: mx.Array.from_numpy(np.asarray(a, np.float32), mx.FLOAT32)
+    X = f32(x[None])
+    qkv = mx.addmm(f32(p["qkv_b"]), X, mx.transpose(f32(p["qkv_w"])))                       # nn::Linear with bias (linear.rs:87-90)
+    parts = [mx.slice(qkv, [0, 0, i * dim], [1, T, (i + 1) * dim]) for i in range(3)]
+    q, k, v = (mx.transpose_axes(mx.reshape(t, [1, T, heads, D]), [0, 2, 1, 3]) for t in parts)
+    k_t = mx.transpose_axes(k, [0, 1, 3, 2])
+    scores = mx.multiply(mx.matmul(q, k_t), _scalar(mx, D ** -0.5))
+    attn = mx.matmul(mx.softmax_axis(scores, -1), v)
+    attn = mx.reshape(mx.transpose_axes(attn, [0, 2, 1, 3]), [1, T, dim])
+    # Conv1d weight of MLX: [C_out, k, C_in / groups] (groups = dim: depthwise)
+    conv = mx.conv1d(parts[2], f32(p["fsmn_w"][:, :, None]), 1, ks // 2, 1, dim)
+    fsmn_out = mx.add(conv, parts[2])
+    out = mx.add(mx.addmm(f32(p["out_b"]), attn, mx.transpose(f32(p["out_w"]))), fsmn_out)
+    np.testing.assert_allclose(out.numpy()[0], ref, rtol=1e-4, atol=1e-4 * np.abs(ref).max())
+
+
+def test_cross_attention_replayed_op_by_op(mx):
+    """ParaformerDecoderLayer::cross_attention (paraformer.rs:981-1017): Tq != Tk, k / v sliced from one fused projection of the
+    encoder output; float32, op by op through the handle ABI."""
+    Tq, Tk, heads, D = 9, 41, 4, 32
+    dim = heads * D
+    wq, bq = 0.1 * rand((dim, dim), 60), 0.1 * rand((dim,), 61)
+    wkv, bkv = 0.1 * rand((2 * dim, dim), 62), 0.1 * rand((2 * dim,), 63)
+    wo, bo = 0.1 * rand((dim, dim), 64), 0.1 * rand((dim,), 65)
+    x, enc = rand((Tq, dim), 66), rand((Tk, dim), 67)
+    f64 = lambda a: np.asarray(a, np.float64)
+    qr = (f64(x) @ f64(wq).T + bq).reshape(Tq, heads, D).transpose(1, 0, 2)
+    kvr = f64(enc) @ f64(wkv).T + bkv
+    kr = kvr[:, :dim].reshape(Tk, heads, D).transpose(1, 0, 2); vr = kvr[:, dim:].reshape(Tk, heads, D).transpose(1, 0, 2)
+    s = qr @ kr.transpose(0, 2, 1) * D ** -0.5
+    pr = np.exp(s - s.max(-1, keepdims=True)); pr /= pr.sum(-1, keepdims=True)
+    ref = (pr @ vr).transpose(1, 0, 2).reshape(Tq, dim) @ f64(wo).T + bo
+    f32 = lambda a: mx.Array.from_numpy(np.asarray(a, np.float32), mx.FLOAT32)
+    q = mx.addmm(f32(bq), f32(x[None]), mx.transpose(f32(wq)))
+    kv = mx.addmm(f32(bkv), f32(enc[None]), mx.transpose(f32(wkv)))
+    k, v = mx.slice(kv, [0, 0, 0], [1, Tk, dim]), mx.slice(kv, [0, 0, dim], [1, Tk, 2 * dim])
+    q = mx.transpose_axes(mx.reshape(q, [1, Tq, heads, D]), [0, 2, 1, 3])
+    k = mx.transpose_axes(mx.reshape(k, [1, Tk, heads, D]), [0, 2, 1, 3])
+    v = mx.transpose_axes(mx.reshape(v, [1, Tk, heads, D]), [0, 2, 1, 3])
+    scores = mx.multiply(mx.matmul(q, mx.transpose_axes(k, [0, 1, 3, 2])), _scalar(mx, D ** -0.5))
+    out = mx.matmul(mx.softmax_axis(scores, -1), v)
+    out = mx.reshape(mx.transpose_axes(out, [0, 2, 1, 3]), [1, Tq, dim])
+    out = mx.addmm(f32(bo), out, mx.transpose(f32(wo)))
+    np.testing.assert_allclose(out.numpy()[0], ref, rtol=1e-4, atol=1e-4 * np.abs(ref).max())
+
+
+def test_klein_single_block_attention_replayed_op_by_op(mx):
+    """The attention of KleinSingleBlock::forward (flux-klein-mlx/src/klein_model.rs:650-660): bf16 q / k / v [B, S, H, D] transposed
+    to [B, H, S, D], ops::matmul(q, k^T) / sqrt(D), softmax_axis, ops::matmul(attn, v), transpose back -- batched 4-D x 4-D bf16
+    matmuls through the handle ABI, against the oracle's SDPA on the same bf16 inputs."""
+    B, S, H, D = 1, 80, 4, 128
+    q, k, v = (rc.bf16_round(rand((B, S, H, D), 70 + i)) for i in range(3))
+    Q, K, V = (mx.transpose_axes(mx.Array.from_numpy(t), [0, 2, 1, 3]) for t in (q, k, v))
+    attn = mx.matmul(Q, mx.transpose_axes(K, [0, 1, 3, 2]))
+    assert attn.dtype == mx.BFLOAT16
+    attn = mx.softmax_axis(mx.divide(attn, _scalar(mx, np.sqrt(D))), -1)
+    assert attn.dtype == mx.FLOAT32              # bf16 scores / f32 scalar ARRAY: MLX promotes, the softmax and attn @ v run in f32
+    out = mx.matmul(attn, V)
+    assert out.dtype == mx.FLOAT32
+    out = mx.reshape(mx.transpose_axes(out, [0, 2, 1, 3]), [B, S, H * D])
+    # oracle on the same roundings: bf16 scores (one rounding of q k^T), then everything in f32
+    qt, kt, vt = (t.transpose(0, 2, 1, 3).astype(np.float64) for t in (q, k, v))
+    sc = rc.bf16_round(qt @ kt.transpose(0, 1, 3, 2)).astype(np.float64) / np.sqrt(D)
+    pr = np.exp(sc - sc.max(-1, keepdims=True)); pr /= pr.sum(-1, keepdims=True)
+    ref = (pr @ vt).transpose(0, 2, 1, 3).reshape(B, S, H * D)
+    np.testing.assert_allclose(out.numpy(), ref, rtol=2e-4, atol=2e-4 * np.abs(ref).max())

@@ -533,9 +533,9 @@ def test_time_step_kernels_runs_real_steps(omx):
     got = [b.prefill(prompt)] + list(b.decode(4))
     us = b.time_step_kernels(2)
     got += list(b.decode(6))
-    assert set(us) == {"qkv", "attention", "o", "gate_up", "down", "lm_head"}
+    assert set(us) == {"qkv", "attention", "o", "gate_up", "down", "lm_head", "step_engine"} and us["step_engine"] == 0.0
     # ("o" is 0 when the O projection rides in the attention launch -- the default wherever the shape qualifies)
-    assert all(0 < v < 1000 for k, v in us.items() if k != "o") and 0 <= us["o"] < 1000, us
+    assert all(0 < v < 1000 for k, v in us.items() if k not in ("o", "step_engine")) and 0 <= us["o"] < 1000, us
     np.testing.assert_array_equal(np.array(got, np.uint32), want.astype(np.uint32))
     b.close()
 
@@ -720,3 +720,20 @@ def test_persistent_step_options_are_bit_identical(omx, monkeypatch):
     for o in outs[1:]:
         np.testing.assert_array_equal(outs[0][0], o[0])
         np.testing.assert_array_equal(outs[0][1], o[1])
+
+
+def test_set_weight_checks_the_size_in_c(omx):
+    """omx_qwen3_set_weight takes the tensor's byte length and refuses one that disagrees with the config (the engine reads raw
+    pointers; the reference raises a shape error on load) -- checked in C, so a Rust caller following INTEGRATION.md section 3 is
+    covered too, not only the Python loader."""
+    import ctypes
+    from ominix_mlx_amd import engine, ops
+    cfg = CONFIGS["gqa4_d128"]
+    m = _engine(omx, cfg)
+    t = ops.Tensor.from_numpy(np.zeros((cfg.hidden_size, cfg.hidden_size), np.float32), "bf16")      # q_proj wants [H*D, hidden]
+    lib = omx.lib
+    assert lib.omx_qwen3_set_weight(m._h, b"model.layers.0.self_attn.k_proj.weight", t.ptr, t.nbytes) != 0
+    assert b"ShapeMismatch" in lib.omx_last_error()
+    lib.omx_clear_error()
+    assert lib.omx_qwen3_set_weight(m._h, b"model.layers.0.self_attn.q_proj.weight", t.ptr, t.nbytes) == 0   # 8 heads x 128 = 1024 rows
+    m.close()

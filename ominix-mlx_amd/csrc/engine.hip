@@ -217,6 +217,8 @@ struct omx_qwen3_ {
     int pf_cap = 0;
     bf16_t *pf_h = nullptr, *pf_h2 = nullptr, *pf_xn = nullptr, *pf_q = nullptr, *pf_k = nullptr, *pf_v = nullptr,
            *pf_qt = nullptr, *pf_attn = nullptr, *pf_g = nullptr, *pf_u = nullptr;
+    float* pf_ep_partial = nullptr;      // expert-parallel batched prefill: [pf_ep_cap, hidden] f32 partial of the MoE block
+    int pf_ep_cap = 0;
     float last_prefill_ms = 0.f;
 
     // persistent decode step (step_engine.hip): the layers of a token in one launch
@@ -887,6 +889,12 @@ __global__ void copy_rows_strided_kernel(bf16_t* dst, int64_t dst_ld, const bf16
 }
 
 // qwen3_encoder.rs:172-198: additive mask 0 where (j <= i and attention_mask[j]) else bf16(-1e9)
+// expert-parallel batched prefill: h = bf16(resid + bf16(all-reduced partial))  (the residual of mixtral model.rs:343-344)
+__global__ void ep_fold_kernel(bf16_t* __restrict__ out, const bf16_t* __restrict__ resid, const float* __restrict__ partial, int64_t n) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = f32_to_bf16(bf16_to_f32(resid[i]) + round_bf16(partial[i]));
+}
+
 __global__ void encoder_mask_kernel(bf16_t* mask, const uint8_t* am, int T) {
     const bf16_t neg = f32_to_bf16(-1e9f);
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < (int64_t)T * T; i += (int64_t)gridDim.x * blockDim.x) {
@@ -1026,6 +1034,26 @@ int prefill_prefix_batched(omx_qwen3 m, int T, int off, const EncodeOpts* enc = 
                                             c.num_experts, c.num_experts_per_tok, c.moe_mode, c.norm_topk_prob, c.quant_group,
                                             c.quant_bits, s))
                     return 1;
+            } else if (c.ep_size > 1) {
+                // expert parallel: attention is replicated, so every rank already holds all T rows -- there is
+                // nothing to dispatch.  Each rank routes all rows, multiplies the slots of ITS experts (grouped matrix-core GEMMs over
+                // a device-side plan), and ONE all-reduce per layer sums the [T, hidden] f32 partials: the combine half of an
+                // all-to-all exchange, with the reduction done by the collective.  (Until round 3 a prompt under EP was T decode steps.)
+                const int el = c.num_experts / c.ep_size;
+                if (!m->pf_ep_partial || m->pf_ep_cap < T) {
+                    OMX_HIP_CHECK(hipStreamSynchronize(s));
+                    if (m->pf_ep_partial) OMX_HIP_CHECK(hipFree(m->pf_ep_partial));
+                    OMX_HIP_CHECK(hipMalloc((void**)&m->pf_ep_partial, (size_t)std::max(T, m->pf_cap) * hd * sizeof(float)));
+                    m->pf_ep_cap = std::max(T, m->pf_cap);
+                }
+                if (omx_moe_block_partial_ep(m->pf_ep_partial, m->pf_xn, nullptr, c.rms_norm_eps, nullptr, L.moe_gate, L.moe_wg, L.moe_wu, L.moe_wd,
+                                             T, hd, c.moe_intermediate_size, c.num_experts, c.num_experts_per_tok, c.moe_mode,
+                                             c.norm_topk_prob, c.ep_rank * el, el, s))
+                    return 1;
+                OMX_REQUIRE(m->allreduce != nullptr, "ep_size > 1 but no communicator set (omx_qwen3_set_comm)");
+                OMX_REQUIRE(m->allreduce(m->pf_ep_partial, m->pf_ep_partial, (size_t)T * hd, kNcclFloat32, kNcclSum, m->comm, s) == 0, "ncclAllReduce failed");
+                ep_fold_kernel<<<1024, 256, 0, s>>>(h, h2, m->pf_ep_partial, (int64_t)T * hd);
+                OMX_LAUNCH_CHECK();
             } else {
                 if (omx_moe_forward(m->pf_attn, m->pf_xn, L.moe_gate, L.moe_wg, L.moe_wu, L.moe_wd, T, hd, c.moe_intermediate_size,
                                     c.num_experts, c.num_experts_per_tok, c.moe_mode, c.norm_topk_prob, nullptr, nullptr, s))
@@ -1132,6 +1160,7 @@ int omx_qwen3_create(omx_qwen3* out, const omx_qwen3_config* cfg) {
         omx_moe_workspace_bytes(m->cap, c.hidden_size, c.moe_intermediate_size, c.num_experts, c.num_experts_per_tok, &need);
         void* ws = nullptr;
         if (get_workspace(&ws, need)) return 1;
+        if (c.ep_size > 1 && get_workspace_aux(&ws, need, m->stream)) return 1;   // the expert-parallel block's per-stream scratch (moe.hip)
         if (dev_alloc(m, &m->moe_xn, (size_t)c.hidden_size) || dev_alloc(m, &m->moe_out, (size_t)c.hidden_size)) return 1;
     }
     if (dev_alloc(m, &m->rope_cur, (size_t)D) || dev_alloc(m, &m->attn_gran, attn_step_ws_granules(m->H, D)) ||
@@ -1173,6 +1202,7 @@ int omx_qwen3_destroy(omx_qwen3 m) {
     if (m->dq_buf) (void)hipFree(m->dq_buf);
     if (m->verify_logits) (void)hipFree(m->verify_logits);
     if (m->verify_tokens) (void)hipFree(m->verify_tokens);
+    if (m->pf_ep_partial) (void)hipFree(m->pf_ep_partial);
     for (bf16_t* p : {m->pf_h, m->pf_h2, m->pf_xn, m->pf_q, m->pf_k, m->pf_v, m->pf_qt, m->pf_attn, m->pf_g, m->pf_u})
         if (p) (void)hipFree(p);
     if (m->ev0) (void)hipEventDestroy(m->ev0);
@@ -1446,9 +1476,9 @@ int omx_qwen3_prefill(omx_qwen3 m, const uint32_t* prompt, int n_prompt, uint32_
     for (int i = 0; i < n_prompt; ++i) OMX_REQUIRE(prompt[i] < (uint32_t)m->cfg.vocab_size, "omx_qwen3_prefill: token id %u out of range (vocab %d)", prompt[i], m->cfg.vocab_size);
     OMX_REQUIRE(n_prompt <= m->prompt_cap, "omx_qwen3_prefill: prompt of %d tokens exceeds max_context %d", n_prompt, m->prompt_cap);
     const char* serial_env = getenv("OMX_PREFILL_SERIAL");
-    // expert-parallel engines prefill token-serially (their batched MoE block is single-rank); tensor-parallel ones run the batched
-    // matrix-core prefill on their shards with two all-reduces per layer
-    const bool serial = (serial_env && serial_env[0] == '1') || (m->allreduce != nullptr && m->cfg.ep_size > 1) || n_prompt < 2;
+    // tensor-parallel engines run the batched matrix-core prefill on their shards with two all-reduces per layer, expert-parallel ones
+    // with one all-reduce of the MoE block's [T, hidden] partial per layer (round 3; token-serial before)
+    const bool serial = (serial_env && serial_env[0] == '1') || n_prompt < 2;
     if (prepare_step(m, serial ? off : off + n_prompt - 1)) return 1;   // the first step this call will run (graphs are per context bucket)
     OMX_HIP_CHECK(hipMemcpyAsync(m->prompt_dev, prompt, (size_t)n_prompt * 4, hipMemcpyHostToDevice, m->stream));
     StepState st;
@@ -1470,7 +1500,9 @@ int omx_qwen3_prefill(omx_qwen3 m, const uint32_t* prompt, int n_prompt, uint32_
         // tile count does not change, instead of a 36-layer GEMV pass); OMX_PREFILL_TAIL_STEP=1: n-1 tokens batched and
         // the decode step for the last one
         const char* tail_env = getenv("OMX_PREFILL_TAIL_STEP");
-        const bool tail_step = (tail_env && tail_env[0] == '1') || m->allreduce != nullptr;   // (the vocabulary-sharded head + its argmax all-reduce live in the step)
+        // (the vocabulary-sharded head of a tensor-parallel rank + its argmax all-reduce live in the step; an expert-parallel rank holds
+        //  the whole head and takes the batched tail like a single device)
+        const bool tail_step = (tail_env && tail_env[0] == '1') || (m->allreduce != nullptr && m->cfg.ep_size <= 1);
         const int nb = tail_step ? n_prompt - 1 : n_prompt;
         if (prefill_prefix_batched(m, nb, st.pos, nullptr, !tail_step)) return 1;
         st.pos += n_prompt - 1;

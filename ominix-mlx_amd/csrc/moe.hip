@@ -175,7 +175,10 @@ __global__ __launch_bounds__(64) void moe_route_logits_kernel(const bf16_t* __re
 __global__ __launch_bounds__(1024) void moe_plan_kernel(const uint32_t* __restrict__ inds, int n_slots, int E, int k,
                                                         int* __restrict__ seg_start, uint32_t* __restrict__ row_src,
                                                         uint32_t* __restrict__ pos_of_slot, int* __restrict__ tile_expert,
-                                                        int* __restrict__ tile_m0, int* __restrict__ n_tiles, int tile_rows) {
+                                                        int* __restrict__ tile_m0, int* __restrict__ n_tiles, int tile_rows,
+                                                        int n_tile_experts = -1) {
+    // n_tile_experts >= 0: only experts [0, n_tile_experts) get GEMM tiles -- the expert-parallel batched form sorts the slots routed
+    // to OTHER ranks into one trailing pseudo-expert that nobody multiplies
     __shared__ int s_cnt[kMaxExperts], s_start[kMaxExperts + 1], s_fill[kMaxExperts];
     for (int e = threadIdx.x; e < E; e += blockDim.x) { s_cnt[e] = 0; s_fill[e] = 0; }
     __syncthreads();
@@ -185,7 +188,8 @@ __global__ __launch_bounds__(1024) void moe_plan_kernel(const uint32_t* __restri
         int acc = 0, tiles = 0;
         for (int e = 0; e < E; ++e) {
             s_start[e] = acc;
-            for (int m0 = 0; m0 < s_cnt[e]; m0 += tile_rows) { tile_expert[tiles] = e; tile_m0[tiles] = m0; ++tiles; }
+            if (n_tile_experts < 0 || e < n_tile_experts)
+                for (int m0 = 0; m0 < s_cnt[e]; m0 += tile_rows) { tile_expert[tiles] = e; tile_m0[tiles] = m0; ++tiles; }
             acc += s_cnt[e];
         }
         s_start[E] = acc;
@@ -276,7 +280,8 @@ __global__ __launch_bounds__(256) void moe_unsort_kernel(bf16_t* __restrict__ ou
 // bf16(y * score) -- the ranks' partials add up (all-reduce) to the single-device sum before its rounding
 __global__ __launch_bounds__(256) void moe_combine_partial_kernel(float* __restrict__ out, const bf16_t* __restrict__ y,
                                                                   const bf16_t* __restrict__ scores, const uint32_t* __restrict__ inds,
-                                                                  int h, int k, int e_lo, int e_n) {
+                                                                  int h, int k, int e_lo, int e_n,
+                                                                  const uint32_t* __restrict__ pos_of_slot = nullptr) {
     const int t = blockIdx.x;
     for (int i = threadIdx.x * 8; i < h; i += 256 * 8) {
         float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -285,7 +290,8 @@ __global__ __launch_bounds__(256) void moe_combine_partial_kernel(float* __restr
             const int e = (int)inds[slot];
             if (e < e_lo || e >= e_lo + e_n) continue;
             const float sc = bf16_to_f32(scores[slot]);
-            const u32x4 v = *reinterpret_cast<const u32x4*>(y + slot * h + i);
+            const size_t p = pos_of_slot ? pos_of_slot[slot] : slot;     // batched form: the row's place in the expert-sorted order
+            const u32x4 v = *reinterpret_cast<const u32x4*>(y + p * h + i);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 acc[2 * q] += round_bf16(bf16lo(v[q]) * sc);
@@ -295,6 +301,14 @@ __global__ __launch_bounds__(256) void moe_combine_partial_kernel(float* __restr
 #pragma unroll
         for (int q = 0; q < 8; ++q) out[(size_t)t * h + i + q] = acc[q];
     }
+}
+
+// expert-parallel batched form: expert ids relative to this rank's shard, slots routed elsewhere -> the pseudo-expert e_n
+__global__ void moe_localize_kernel(uint32_t* __restrict__ local, const uint32_t* __restrict__ inds, int n, int e_lo, int e_n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int e = (int)inds[i];
+    local[i] = (e >= e_lo && e < e_lo + e_n) ? (uint32_t)(e - e_lo) : (uint32_t)e_n;
 }
 
 }  // namespace
@@ -583,31 +597,71 @@ extern "C" int omx_moe_block_partial_ep(float* partial, const void* x, const voi
                                         int n_experts, int top_k, int mode, int norm_topk_prob, int e_lo, int e_n,
                                         omx_stream stream) {
     using namespace omx;
-    OMX_REQUIRE(partial && x && norm_w && xn && gate_w && w_gate && w_up && w_down, "omx_moe_block_partial_ep: null tensor");
+    // norm_w == null: x holds the normalised rows already (the batched prefill runs its own RMSNorm launch, like the single-rank pass)
+    OMX_REQUIRE(partial && x && (xn || !norm_w) && gate_w && w_gate && w_up && w_down, "omx_moe_block_partial_ep: null tensor");
+    if (!norm_w) xn = const_cast<void*>(x);
     OMX_REQUIRE(n_experts >= 1 && n_experts <= kMaxExperts && top_k >= 1 && top_k <= kMaxTopK && top_k <= n_experts &&
                     e_lo >= 0 && e_n >= 1 && e_lo + e_n <= n_experts, "omx_moe_block_partial_ep: experts %d top-%d shard [%d, +%d)", n_experts, top_k, e_lo, e_n);
     const int slots = n_tokens * top_k;
-    OMX_REQUIRE(slots >= 1 && slots <= 32 && gemv_k_supported(hidden, false) && gemv_k_supported(inter, false),
-                "omx_moe_block_partial_ep: decode form only (%d routed slots, hidden %d, intermediate %d)", slots, hidden, inter);
+    OMX_REQUIRE(slots >= 1 && hidden % 64 == 0 && inter % 64 == 0, "omx_moe_block_partial_ep: %d routed slots, hidden %d, intermediate %d", slots, hidden, inter);
+    const bool decode = slots <= 32 && gemv_k_supported(hidden, false) && gemv_k_supported(inter, false);
     hipStream_t s = (hipStream_t)stream;
     size_t need = 0;
     omx_moe_workspace_bytes(n_tokens, hidden, inter, n_experts, top_k, &need);
+    // the STREAM's scratch, not the library-wide one: several expert-parallel ranks may live in one process (the loopback tests, a
+    // multi-GPU host process), each on its own stream.  The engine sizes it once for its largest batch (engine.hip), so the pointers a
+    // captured decode step holds never move.
     void* ws = nullptr;
-    if (get_workspace(&ws, need)) return 1;
+    if (get_workspace_aux(&ws, need, s)) return 1;
     char* p = (char*)ws;
     auto take = [&](size_t bytes) { char* r = p; p += (bytes + 255) & ~(size_t)255; return r; };
     uint32_t* inds = (uint32_t*)take((size_t)slots * 4);
-    take((size_t)slots * 4); take((size_t)slots * 4);
+    uint32_t* row_src = (uint32_t*)take((size_t)slots * 4);
+    uint32_t* pos_of_slot = (uint32_t*)take((size_t)slots * 4);
     bf16_t* scores = (bf16_t*)take((size_t)slots * 2);
-    take((size_t)(n_experts + 2) * 4);
+    int* seg_start = (int*)take((size_t)(n_experts + 2) * 4);
     const int max_tiles = slots / 128 + n_experts + 1;
-    take((size_t)max_tiles * 4); take((size_t)max_tiles * 4); take(256);
+    int* tile_expert = (int*)take((size_t)max_tiles * 4);
+    int* tile_m0 = (int*)take((size_t)max_tiles * 4);
+    int* n_tiles = (int*)take(256);
     bf16_t* gbuf = (bf16_t*)take((size_t)slots * inter * 2);
-    take((size_t)slots * inter * 2);
+    bf16_t* ubuf = (bf16_t*)take((size_t)slots * inter * 2);
     bf16_t* ybuf = (bf16_t*)take((size_t)slots * hidden * 2);
     moe_router_kernel<<<n_tokens, kRouterThreads, 0, s>>>((const bf16_t*)x, (const bf16_t*)gate_w, hidden, n_experts, top_k, mode,
-                                                          norm_topk_prob, inds, scores, (const bf16_t*)norm_w, eps, (bf16_t*)xn);
+                                                          norm_topk_prob, inds, scores, (const bf16_t*)norm_w, eps, norm_w ? (bf16_t*)xn : nullptr);
     OMX_LAUNCH_CHECK();
+    if (!decode) {
+        // batched form (a prompt under expert parallelism): the slots routed to THIS rank's experts are counting-sorted by local
+        // expert and run through the grouped matrix-core GEMMs; everything routed elsewhere lands in one trailing pseudo-expert that
+        // gets no tiles.  The partial weighted sum reads its rows back through the sort permutation.
+        uint32_t* local_inds = nullptr;
+        OMX_HIP_CHECK(hipMallocAsync((void**)&local_inds, (size_t)slots * 4, s));
+        moe_localize_kernel<<<(slots + 255) / 256, 256, 0, s>>>(local_inds, inds, slots, e_lo, e_n);
+        OMX_LAUNCH_CHECK();
+        const int tile_rows = moe_tile_rows(slots / (n_experts / e_n > 0 ? n_experts / e_n : 1), e_n, hidden, inter);
+        moe_plan_kernel<<<1, 1024, 0, s>>>(local_inds, slots, e_n + 1, top_k, seg_start, row_src, pos_of_slot, tile_expert, tile_m0, n_tiles,
+                                           tile_rows, e_n);
+        OMX_LAUNCH_CHECK();
+        (void)hipFreeAsync(local_inds, s);
+        GroupedDesc g;
+        g.tile_expert = tile_expert; g.tile_m0 = tile_m0; g.seg_start = seg_start; g.n_tiles = n_tiles;
+        g.row_src = row_src; g.w_estride = (size_t)inter * hidden;
+        if (tile_rows == 256) {
+            if (grouped_glu_256(ybuf, gbuf, (const bf16_t*)xn, (const bf16_t*)w_gate, (const bf16_t*)w_up, (const bf16_t*)w_down, slots, hidden,
+                                inter, n_experts, g, s))
+                return 1;
+        } else {
+            if (launch_gemm_bf16_grouped(gbuf, (const bf16_t*)xn, (const bf16_t*)w_gate, slots, inter, hidden, g, max_tiles, s)) return 1;
+            if (launch_gemm_bf16_grouped(ubuf, (const bf16_t*)xn, (const bf16_t*)w_up, slots, inter, hidden, g, max_tiles, s)) return 1;
+            if (omx_fused_swiglu(gbuf, ubuf, gbuf, (int64_t)slots * inter, OMX_BFLOAT16, stream)) return 1;
+            g.row_src = nullptr;
+            g.w_estride = (size_t)hidden * inter;
+            if (launch_gemm_bf16_grouped(ybuf, gbuf, (const bf16_t*)w_down, slots, hidden, inter, g, max_tiles, s)) return 1;
+        }
+        moe_combine_partial_kernel<<<n_tokens, 256, 0, s>>>(partial, ybuf, scores, inds, hidden, top_k, e_lo, e_n, pos_of_slot);
+        OMX_LAUNCH_CHECK();
+        return 0;
+    }
     GemvArgs a = {};
     a.w0 = (const bf16_t*)w_gate; a.w1 = (const bf16_t*)w_up; a.n0 = inter; a.N = inter; a.K = hidden;
     a.x = (const bf16_t*)xn; a.out = gbuf;

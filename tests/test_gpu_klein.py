@@ -123,3 +123,46 @@ def test_klein_step_schedule_variants_are_bit_identical(omx, monkeypatch):
     assert np.isfinite(outs["default"]).all() and np.abs(outs["default"]).max() > 0
     np.testing.assert_array_equal(outs["default"], outs["one_stream"])
     np.testing.assert_array_equal(outs["default"], outs["swiglu_kernel"])
+
+
+def test_klein_full_sequence_4608_tokens(omx, monkeypatch):
+    """FLUX at the BASELINE sequence length (1024 x 1024: 64 x 64 = 4096 image tokens + 512 text tokens = 4608), real widths
+    (hidden 3072, 24 heads, MLP 9216) with 2 double + 2 single blocks -- the configuration bench.py times, until round 3 exercised by
+    no test.  There is no oracle value at this size (a float64 pass would take hours); held are the size-independent properties:
+    a finite, non-trivial velocity, the same bits whichever launch schedule computes it, and tensor parallelism over two ranks on
+    this GPU (loopback communicator) agreeing with the single-device result within the bf16 bound of the partial-sum rounding."""
+    from ominix_mlx_amd import comm, klein
+    g, s_txt = 64, 512
+    lat = omx.ops.fill_uniform((g * g, 128), 1, 1.7)
+    txt = omx.ops.fill_uniform((s_txt, 7680), 2, 1.7)
+    rcos, rsin = klein.compute_rope(klein.create_txt_ids(s_txt), klein.create_img_ids(g, g))
+    outs = {}
+    for name, env in {"default": {}, "one_stream": {"OMX_KLEIN_DUAL_STREAM": "0"}, "swiglu_kernel": {"OMX_KLEIN_FUSE_SWIGLU": "0"}}.items():
+        for k in ("OMX_KLEIN_DUAL_STREAM", "OMX_KLEIN_FUSE_SWIGLU"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        m = klein.FluxKlein(depth=2, depth_single=2)
+        m.synth_weights()
+        outs[name] = m.forward_with_rope(lat, txt, 500.0, rcos, rsin).numpy()
+        m.close()
+    for k in ("OMX_KLEIN_DUAL_STREAM", "OMX_KLEIN_FUSE_SWIGLU"):
+        monkeypatch.delenv(k, raising=False)
+    one = outs["default"]
+    assert one.shape == (g * g, 128) and np.isfinite(one).all() and np.abs(one).max() > 0 and one.std() > 0
+    np.testing.assert_array_equal(one, outs["one_stream"])
+    np.testing.assert_array_equal(one, outs["swiglu_kernel"])
+    world = 2
+    group = comm.LoopbackGroup(world, (s_txt + g * g) * 3072 * 2)
+    models = []
+    for r in range(world):
+        m = klein.FluxKlein(depth=2, depth_single=2, tp_rank=r, tp_size=world)
+        m.synth_weights()
+        m.set_comm(group.rank_comm(r), group.allreduce_fn)
+        models.append(m)
+    tp = comm.run_ranks(world, lambda r: models[r].forward_with_rope(lat, txt, 500.0, rcos, rsin).numpy(), group)
+    for m in models:
+        m.close()
+    group.close()
+    np.testing.assert_array_equal(tp[0], tp[1])
+    assert np.abs(tp[0] - one).max() <= 2.0 ** -6 * np.abs(one).max() * np.sqrt(4)

@@ -262,3 +262,53 @@ def test_moe_weighted_sum_folded_into_next_gemv_is_bit_identical(omx, monkeypatc
     plain = run()
     assert folded[0] == plain[0]
     np.testing.assert_array_equal(folded[1], plain[1])
+
+
+@pytest.mark.parametrize("name,world", [("qwen3_moe", 2), ("mixtral", 4)])
+def test_expert_parallel_batched_prefill_on_one_gpu(omx, monkeypatch, name, world):
+    """Round 3: a prompt under expert parallelism is ONE batched pass (until now: one decode step per token).  Every rank routes all
+    rows, runs the grouped matrix-core GEMMs over the slots of ITS experts (device-side plan: the other slots are sorted into a
+    trailing pseudo-expert that gets no tiles) and one all-reduce per layer sums the [T, hidden] f32 partials.  A 200-token prompt
+    (400 / 800 routed slots) through `world` sharded engines on this GPU must give the single-GPU engine's tokens, and -- with top-2
+    routing, where the summation order cannot matter -- its logits bit for bit (top-k > 2: within a few bf16 ulps, see below)."""
+    from ominix_mlx_amd import comm, engine
+    cfg = CONFIGS[name]
+    prompt = synth.prompt_ids(200, cfg.vocab_size)
+    monkeypatch.setenv("OMX_PREFILL_SERIAL", "0")
+    single = _engine(omx, cfg, max_context=512)
+    want = np.concatenate([[single.prefill(prompt)], single.decode(6)]).astype(np.uint32)
+    want_logits = single.last_logits()
+    single.close()
+    group = comm.LoopbackGroup(world, 200 * cfg.hidden_size * 4)
+    models = []
+    for r in range(world):
+        m = engine.Model(hidden_size=cfg.hidden_size, num_hidden_layers=cfg.num_hidden_layers, intermediate_size=cfg.intermediate_size,
+                         num_attention_heads=cfg.num_attention_heads, num_key_value_heads=cfg.num_key_value_heads, head_dim=cfg.head_dim,
+                         vocab_size=cfg.vocab_size, rms_norm_eps=cfg.rms_norm_eps, rope_theta=cfg.rope_theta,
+                         tie_word_embeddings=cfg.tie_word_embeddings, max_context=512, num_experts=cfg.num_experts,
+                         num_experts_per_tok=cfg.num_experts_per_tok, moe_intermediate_size=cfg.moe_intermediate_size,
+                         moe_mode=cfg.moe_mode, norm_topk_prob=cfg.norm_topk_prob, qk_norm=cfg.qk_norm, ep_rank=r, ep_size=world)
+        m.synth_weights()
+        m.set_comm(group.rank_comm(r), group.allreduce_fn)
+        models.append(m)
+
+    def run(r):
+        m = models[r]
+        toks = np.concatenate([[m.prefill(prompt)], m.decode(6)]).astype(np.uint32)
+        return toks, m.last_logits(), m.last_prefill_ms()
+
+    outs = comm.run_ranks(world, run, group)
+    for r in range(world):
+        np.testing.assert_array_equal(outs[r][0], want)
+        np.testing.assert_array_equal(outs[r][0], outs[0][0])
+        np.testing.assert_array_equal(outs[r][1], outs[0][1])            # every rank holds the same logits
+        if cfg.num_experts_per_tok <= 2:
+            np.testing.assert_array_equal(outs[r][1], want_logits)       # two summands: the order cannot matter
+        else:
+            # top-k > 2: the ranks' partials add the k products in another order than the single device's slot order; f32 sums of
+            # bf16-rounded products are exact unless their exponents spread over > 13 bits, so a few hidden-state elements differ by
+            # one bf16 ulp over 200 rows x layers -- the logits then move by at most a few ulps
+            assert np.abs(outs[r][1] - want_logits).max() <= 2.0 ** -6 * np.abs(want_logits).max()
+    for m in models:
+        m.close()
+    group.close()

@@ -184,3 +184,25 @@ def test_tiny_paraformer_end_to_end_matches_oracle(omx):
     np.testing.assert_array_equal(tok[safe], ref_tok[safe])
     with pytest.raises(KeyError, match="Missing weight"):
         paraformer.Paraformer({k: v for k, v in w.items() if k != "decoder.after_norm.bias"}, TINY)
+
+
+def test_layers_match_the_torch_pins(omx):
+    """The device layers against an implementation that shares nothing with this repository: tests/golden/torch_paraformer.npz holds the
+    outputs of a torch (float64) restatement of SanmEncoderLayer / ParaformerDecoderLayer (tests/golden/make_torch_pins.py) on
+    committed inputs, the weights come from the seeded generator; float32 mode, 1e-4 of the largest value like the oracle tests."""
+    import ctypes
+    import os
+    from ominix_mlx_amd import paraformer
+    T = omx.ops.Tensor
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "torch_paraformer.npz"))
+    w = rp.synth_checkpoint(TINY, int(z["seed"]))
+    for x, prefix, want in ((z["x"], "encoder.layers.0", z["enc_out"]), (z["x0"], "encoder.encoders0.0", z["enc0_out"])):
+        got = paraformer.SanmEncoderLayer(rp._enc_params(w, prefix), 4, 11, "f32").forward(T.from_numpy(x, "f32")).numpy()
+        assert np.abs(got - want).max() <= 1e-4 * np.abs(want).max()
+    p = rp._dec_params(w, "decoder.layers.1")
+    dev = {k: T.from_numpy(np.ascontiguousarray(v), "f32") for k, v in p.items()}
+    ws = paraformer.DecoderLayerWeights(*[dev[k].ptr for k in paraformer._DEC_FIELDS])
+    N, Ts = z["xd"].shape[0], z["enc_out"].shape[0]
+    out, xd, ed = T((N, 512), "f32"), T.from_numpy(z["xd"], "f32"), T.from_numpy(z["enc_out"], "f32")
+    omx.check(omx.lib.omx_paraformer_decoder_layer(out.ptr, xd.ptr, ed.ptr, ctypes.byref(ws), N, Ts, 512, 512, 4, 1024, 11, out.dtype, None))
+    assert np.abs(out.numpy() - z["dec_out"]).max() <= 1e-4 * np.abs(z["dec_out"]).max()

@@ -96,3 +96,18 @@ def test_vae_implicit_convolution_matches_im2col_route(omx, monkeypatch):
     assert a.shape == b.shape == (320, 320, 3) and np.isfinite(a).all()
     assert np.abs(a - b).max() <= 2.0 ** -6 * np.abs(b).max()
     assert np.corrcoef(a.ravel(), b.ravel())[0, 1] > 0.9999
+
+
+def test_vae_decoder_matches_the_torch_pin(omx):
+    """The device decoder against torch (F.group_norm / F.conv2d / F.interpolate / F.scaled_dot_product_attention, float64;
+    tests/golden/make_torch_pins.py): same bf16 bound as the oracle comparison, on the committed latent."""
+    import os
+    from ominix_mlx_amd import vae
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "torch_vae.npz"))
+    cfg = dict(ch=32, ch_mult=(1, 2), num_res_blocks=1, z_channels=8, out_ch=3)
+    dec = vae.VaeDecoder(**cfg)
+    dec.load_weights(rv.synth_decoder_weights(int(z["seed"]), **cfg))
+    got = dec.decode(omx.ops.Tensor.from_numpy(z["z"])).numpy()
+    want = z["decoded"]
+    assert got.shape == want.shape
+    assert np.abs(got - want).max() <= 2.0 ** -6 * np.abs(want).max() * np.sqrt(_n_convs(cfg))

@@ -68,3 +68,58 @@ def test_oracle_sdpa_equals_torch_sdpa():
             want = F.scaled_dot_product_attention(torch.tensor(q), kt, vt, attn_mask=tm, scale=scale).numpy()
             got = rc.scaled_dot_product_attention(q, k, v, scale, om, "f32")
             assert np.abs(got - want).max() <= 2e-6 * max(1.0, np.abs(want).max())
+
+
+# ---- round 3: the remaining oracle-relative MODELS pinned on torch (tests/golden/make_torch_pins.py) ----
+
+def _torch_pin(name):
+    path = os.path.join(GOLDEN, f"torch_{name}.npz")
+    assert os.path.exists(path), f"{path} missing: run tests/golden/make_torch_pins.py in the build container"
+    return np.load(path)
+
+
+def _close(got, ref, tol=1e-6):
+    assert np.abs(np.asarray(got, np.float64) - ref).max() <= tol * np.abs(ref).max()
+
+
+def test_klein_blocks_reproduce_torch():
+    """oracle/ref_klein.py double and single block == the torch restatement (F.layer_norm / F.rms_norm / F.scaled_dot_product_attention /
+    complex-number RoPE; klein_model.rs:399-522, 603-674) on the committed inputs; fixture outputs are float32."""
+    from oracle import ref_klein as rk
+    z = _torch_pin("klein")
+    p = rk.KleinParams.tiny()
+    oracle = rk.KleinOracle(p, rk.synth_weights(p))
+    St, ph, pw = int(z["St"]), int(z["ph"]), int(z["pw"])
+    cos, sin = rk.compute_rope(np.concatenate([rk.create_txt_ids(St), rk.create_img_ids(ph, pw)], 0))
+    f64 = lambda a: np.asarray(a, np.float64)
+    mods = [f64(m)[None] for m in z["mods"]]
+    img, txt = oracle.double_block(0, f64(z["img"]), f64(z["txt"]), mods[:6], mods[6:12], cos, sin)
+    _close(img, z["double_img"]); _close(txt, z["double_txt"])
+    x = np.concatenate([f64(z["txt"]), f64(z["img"])], 0)
+    _close(oracle.single_block(0, x, mods[12:15], cos, sin), z["single"])
+
+
+def test_paraformer_layers_reproduce_torch():
+    from oracle import ref_paraformer as rp
+    from test_gpu_paraformer import TINY
+    z = _torch_pin("paraformer")
+    w = rp.synth_checkpoint(TINY, int(z["seed"]))
+    heads = int(z["heads"])
+    _close(rp.sanm_encoder_layer(z["x"], rp._enc_params(w, "encoder.layers.0"), heads), z["enc_out"])
+    _close(rp.sanm_encoder_layer(z["x0"], rp._enc_params(w, "encoder.encoders0.0"), heads), z["enc0_out"])
+    _close(rp.decoder_layer(z["xd"], z["enc_out"], rp._dec_params(w, "decoder.layers.1"), heads), z["dec_out"])
+
+
+def test_vae_blocks_reproduce_torch():
+    from oracle import ref_vae as rv
+    z = _torch_pin("vae")
+    cfg = dict(ch=32, ch_mult=(1, 2), num_res_blocks=1, z_channels=8)
+    weights = rv.synth_decoder_weights(int(z["seed"]), **cfg)
+    oracle = rv.VaeDecoderOracle(weights, **cfg)
+    f64 = lambda a: np.asarray(a, np.float64)
+    _close(oracle.resnet(f64(z["x_mid"]), "mid_block_resnets_0."), z["resnet_mid"])
+    _close(oracle.attn(f64(z["x_mid"]), "mid_block_attentions_0."), z["attn_mid"])
+    name = next(k[:-len("conv_shortcut.weight")] for k in weights if k.endswith("conv_shortcut.weight"))
+    _close(oracle.resnet(f64(z["x_sc"]), name), z["resnet_sc"])
+    _close(rv.silu(oracle.gn(f64(z["x_out"]), "conv_norm_out")), z["gn_silu"])
+    _close(oracle.forward(z["z"]), z["decoded"])

@@ -110,9 +110,27 @@ def dry_run(args):
         elapsed = float(t.item())
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps({"metric": "decode_tokens_per_sec", "value": None, "unit": "tokens/s", "n_gpus": world, "steps": args.steps,
-                          "warmup": args.warmup, "ms_per_step": round(elapsed * 1e3 / max(args.steps, 1), 4), "dry_run": True,
-                          "config": {"workload": "launcher dry run (gloo, no engine)", "parallelism": f"tp{world}"}}), flush=True)
+        out = {"metric": "decode_tokens_per_sec", "value": None, "unit": "tokens/s", "n_gpus": world, "steps": args.steps,
+               "warmup": args.warmup, "ms_per_step": round(elapsed * 1e3 / max(args.steps, 1), 4), "dry_run": True,
+               "config": {"workload": "launcher dry run (gloo, no engine)", "parallelism": f"tp{world}"}}
+        # the same objects the real run appends (collective_secondaries): at N > 1 the flag-less command measures all three curves
+        for key, par in collective_plan(args, world).items():
+            out[key] = {"value": None, "n_gpus": world, "parallelism": par, "dry_run": True}
+        print(json.dumps(out), flush=True)
+
+
+def collective_plan(args, world):
+    """Which secondary workloads a run appends as COLLECTIVE measurements (every rank takes part) and with what parallelism:
+    BASELINE config 5 (FLUX.2-klein, tensor parallel) and config 3 (Mixtral-8x7B, expert parallel) ride on the default
+    `bench.py --gpus N` command whenever a communicator exists (N > 1, or OMX_BENCH_FORCE_COMM=1 on one rank), so the driver's
+    one command per N yields all three scaling curves.  --no-flux skips them; a MoE primary model is its own EP run."""
+    collective = world > 1 or os.environ.get("OMX_BENCH_FORCE_COMM") == "1"
+    if not collective or args.no_flux or MODELS[args.model].get("num_experts", 0) > 0:
+        return {}
+    plan = {"secondary": f"tp{world}"}
+    if 8 % world == 0:            # Mixtral-8x7B: 8 experts over the ranks
+        plan["mixtral"] = f"ep{world}"
+    return plan
 
 
 def init_dist(n_gpus):
@@ -279,24 +297,47 @@ def quantized_secondary(omx, cfg, args, bits=4):
     return out
 
 
-def mixtral_secondary(omx, steps=64, warm=8, n_prompt=2048):
-    """BASELINE config 3 on one GPU: Mixtral-8x7B shapes (mixtral-mlx/src/model.rs:44-52) in bf16 (93 GB of weights fit
-    one MI355X), sparse-MoE decode engine: router + top-2 expert GEMVs per layer inside the step graph."""
+def mixtral_secondary(omx, steps=64, warm=8, n_prompt=2048, rank=0, world=1, comm=None, dist=None):
+    """BASELINE config 3: Mixtral-8x7B shapes (mixtral-mlx/src/model.rs:44-52) in bf16, sparse-MoE decode engine: router + top-2
+    expert GEMVs per layer inside the step graph.  One GPU: all 93 GB of weights on it.  comm != None: expert parallel over `world`
+    ranks -- 8 / world experts per rank, attention and router replicated, one f32 all-reduce per MoE block (the prompt as ONE batched
+    pass with a [T, hidden] all-reduce per layer); every rank calls this, the time is the MAX over ranks."""
     import numpy as np
     from ominix_mlx_amd import engine
     cfg = dict(hidden_size=4096, num_hidden_layers=32, intermediate_size=14336, num_attention_heads=32, num_key_value_heads=8,
                head_dim=128, vocab_size=32000, rms_norm_eps=1e-5, rope_theta=1e6, num_experts=8, num_experts_per_tok=2,
                moe_intermediate_size=14336, moe_mode="mixtral", qk_norm=False)
-    m = engine.Model(max_context=n_prompt + warm + steps + 8, **cfg)
+    if comm is not None:
+        m = engine.Model(max_context=n_prompt + warm + steps + 8, ep_rank=rank, ep_size=world, **cfg)
+        m.set_comm(comm[1], comm[2])
+    else:
+        m = engine.Model(max_context=n_prompt + warm + steps + 8, **cfg)
     m.synth_weights()
+
+    def barrier():
+        if dist is not None:
+            import torch
+            dist.barrier()
+            torch.cuda.synchronize()
+        omx.check(omx.lib.omx_synchronize(m.stream()))
+
+    barrier()
     first = m.prefill(prompt_ids(n_prompt, cfg["vocab_size"]))
     m.decode(warm)
+    barrier()
     t0 = time.perf_counter()
     toks = m.decode(steps)
+    barrier()
     dt = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
     step_bytes = m.step_bytes(n_prompt + warm + steps // 2)
-    out = {"metric": "decode_tokens_per_sec_mixtral_8x7b_bf16", "value": round(steps / dt, 2), "unit": "tokens/s", "n_gpus": 1,
-           "steps": steps, "ms_per_step": round(dt / steps * 1e3, 4), "dtype": "bf16", "data": "synthetic", "parallelism": "ep1",
+    out = {"metric": "decode_tokens_per_sec_mixtral_8x7b_bf16", "value": round(steps / dt, 2), "unit": "tokens/s", "n_gpus": world,
+           "steps": steps, "ms_per_step": round(dt / steps * 1e3, 4), "dtype": "bf16", "data": "synthetic", "parallelism": f"ep{world}",
+           "decode_path": m.decode_path(),
            "step_roofline": {"algorithmic_bytes_per_token": int(step_bytes), "achieved_GBps": round(step_bytes / (dt / steps) / 1e9, 1),
                              "frac_of_hbm_peak": round(step_bytes / (dt / steps) / 1e9 / HBM_PEAK_GBPS, 4)},
            "prefill_device_ms": round(m.last_prefill_ms(), 2), "first_tokens": [int(first)] + [int(t) for t in toks[:4]]}
@@ -489,17 +530,31 @@ def main():
     if peer is not None and peer.aborted():   # a wait inside the peer all-reduce gave up: the tokens of this run are void
         raise SystemExit(f"rank {rank}: the peer-store all-reduce gave up waiting for a peer during the run; no valid measurement")
 
-    flux_tp = None
-    if world > 1 and args.flux_tp:   # a collective workload: every rank takes part
+    # collective secondaries (collective_plan): every rank takes part, rank 0 reports.  The primary model is closed first: Mixtral's
+    # shard (93 GB / world + replicated attention) must fit next to nothing else of this size
+    plan = collective_plan(args, world)
+    flux_tp = mixtral_ep = None
+    primary_closed = False
+    if plan:
+        model_stats = {"step_bytes": model.step_bytes(args.prompt + args.warmup + args.steps // 2), "prefill_ms": model.last_prefill_ms()}
+        model.close()
+        primary_closed = True
         try:
             flux_tp = flux_secondary(omx, rank=rank, world=world, comm=keep)
         except Exception as e:
             flux_tp = {"metric": "flux_klein_1024_sec_per_step", "value": None, "error": str(e)}
+        if "mixtral" in plan:
+            try:
+                mixtral_ep = mixtral_secondary(omx, rank=rank, world=world, comm=keep, dist=dist)
+            except Exception as e:
+                mixtral_ep = {"metric": "decode_tokens_per_sec_mixtral_8x7b_bf16", "value": None, "error": str(e)}
     if rank != 0:
-        model.close()
+        if not primary_closed:
+            model.close()
         return
     ctx_mid = args.prompt + args.warmup + args.steps // 2
-    step_bytes = model.step_bytes(ctx_mid) * (1 if moe else world)   # whole-job algorithmic bytes per token (EP ranks share one token's experts)
+    step_bytes = (model_stats["step_bytes"] if primary_closed else model.step_bytes(ctx_mid)) * (1 if moe else world)   # whole-job algorithmic bytes per token (EP ranks share one token's experts)
+    last_prefill_ms = model_stats["prefill_ms"] if primary_closed else model.last_prefill_ms()
     ms_per_step = elapsed * 1e3 / args.steps
     tok_s = args.steps / elapsed
     k_bytes, iso_s = time_dominant_kernel(omx, cfg, 1 if moe else world)
@@ -544,8 +599,8 @@ def main():
                           "frac_of_hbm_peak": round(step_bytes / (ms_per_step * 1e-3) / 1e9 / (HBM_PEAK_GBPS * world), 4),
                           "roofline_tokens_per_sec": round(HBM_PEAK_GBPS * 1e9 * world / step_bytes, 1),
                           "device_ms_per_step_hip_events": round(dev_ms / args.steps, 4)},
-        "prefill": {"tokens": args.prompt, "seconds": round(prefill_s, 4), "device_ms": round(model.last_prefill_ms(), 3),
-                    "tokens_per_sec": round(args.prompt / max(model.last_prefill_ms(), 1e-6) * 1e3, 1),
+        "prefill": {"tokens": args.prompt, "seconds": round(prefill_s, 4), "device_ms": round(last_prefill_ms, 3),
+                    "tokens_per_sec": round(args.prompt / max(last_prefill_ms, 1e-6) * 1e3, 1),
                     "mode": "batched on the tensor-parallel shards: MFMA GEMMs + flash attention, two bf16 all-reduces of [T, hidden] per layer, the last token through the decode step" if world > 1 else
                             "batched: MFMA GEMMs + flash attention over all n tokens (first call: includes the one-time scratch allocation), norm + lm_head + sampler on the last row"},
         "first_tokens": [int(first)] + [int(t) for t in toks[:4]],
@@ -559,10 +614,13 @@ def main():
             class_bytes["attention+o"] = class_bytes["attention"]
         out["step_kernels"] = {k: {"avg_us": round(v, 2), "algorithmic_bytes": int(class_bytes[k]),
                                    "frac_of_hbm_peak": round(class_bytes[k] / (v * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4)} for k, v in in_step.items()}
-    model.close()
+    if not primary_closed:
+        model.close()
     if flux_tp is not None:
         out["secondary"] = flux_tp
-    if world == 1 and not args.no_flux and not moe:
+    if mixtral_ep is not None:
+        out["mixtral"] = mixtral_ep
+    if world == 1 and not args.no_flux and not moe and not plan:
         try:
             out["secondary"] = flux_secondary(omx)
         except Exception as e:
@@ -573,7 +631,8 @@ def main():
         except Exception as e:
             out["quantized"] = {"metric": "decode_tokens_per_sec_4bit", "value": None, "error": str(e)}
         try:
-            out["mixtral"] = mixtral_secondary(omx)
+            if "mixtral" not in out:
+                out["mixtral"] = mixtral_secondary(omx)
         except Exception as e:
             out["mixtral"] = {"metric": "decode_tokens_per_sec_mixtral_8x7b_bf16", "value": None, "error": str(e)}
         try:

@@ -94,8 +94,12 @@ class PeerComm:
                 lib.omx_peer_comm_handle(h, mine) != 0:
             err = (lib_error() or "omx_peer_comm_create failed").encode()
         self._h = h if not err else None
-        handles = all_gather_bytes(b"!" + err if err else mine.raw)
-        bad = [f"rank {r}: {b[1:].decode(errors='replace')}" for r, b in enumerate(handles) if len(b) != 64]
+        # a fixed-size record per rank -- 1 status byte + 64 payload bytes -- so that an error text can never be mistaken for a
+        # handle (an error of exactly 63 bytes used to be): status 0 = the 64-byte IPC handle, 1 = an error message
+        rec = (b"\x01" + err[:64].ljust(64, b" ")) if err else (b"\x00" + mine.raw)
+        recs = all_gather_bytes(rec)
+        bad = [f"rank {r}: {b[1:].decode(errors='replace').strip()}" for r, b in enumerate(recs) if len(b) != 65 or b[:1] != b"\x00"]
+        handles = [b[1:] for b in recs]
         if bad:
             self.close()
             raise RuntimeError("peer all-reduce: inbox creation failed on " + "; ".join(bad))

@@ -721,12 +721,36 @@ int mlx_matmul(mlx_array* res, const mlx_array a, const mlx_array b, const mlx_s
 int mlx_addmm(mlx_array* res, const mlx_array c, const mlx_array a, const mlx_array b, float alpha, float beta,
               const mlx_stream) {
     REQ_ARR(c, "mlx_addmm");
-    OMX_REQUIRE(alpha == 1.0f && beta == 1.0f, "mlx_addmm: only alpha = beta = 1 (nn::Linear, linear.rs:88-90) is supported");
-    Contig cc;
-    if (cc.init(*A(c))) return 1;
-    OMX_REQUIRE(b.ctx && A(b)->shape.size() == 2 && cc.a->size() == (size_t)A(b)->shape[1],
-                "mlx_addmm: c must be a bias of size N");
-    return matmul_impl(res, a, b, cc.a, "mlx_addmm");
+    REQ_ARR(b, "mlx_addmm");
+    // nn::Linear's call (linear.rs:88-90): alpha = beta = 1, c a bias of size N, b a 2-D weight view -> the bias rides in the GEMM epilogue
+    if (alpha == 1.0f && beta == 1.0f && A(b)->shape.size() == 2 && A(c)->size() == (size_t)A(b)->shape[1] && A(c)->dt == A(b)->dt) {
+        Contig cc;
+        if (cc.init(*A(c))) return 1;
+        return matmul_impl(res, a, b, cc.a, "mlx_addmm");
+    }
+    // general form beta * c + alpha * (a @ b) with c broadcast to the product: composed from the product and two elementwise
+    // ops in the product's dtype (one more rounding per op than MLX's fused epilogue when the dtype is bf16 / f16)
+    mlx_array prod = {nullptr}, sa = {nullptr}, sb = {nullptr}, t1 = {nullptr}, t2 = {nullptr};
+    struct Drop { std::vector<mlx_array*> v; ~Drop() { for (auto* h : v) if (h->ctx) delete A(*h); } } drop{{&prod, &sa, &sb, &t1, &t2}};
+    if (matmul_impl(&prod, a, b, nullptr, "mlx_addmm")) return 1;
+    const mlx_dtype dt = A(prod)->dt;
+    auto scalar = [&](float v, mlx_array* out) -> int {
+        mlx_array f = mlx_array_new_float32(v);
+        const int rc = mlx_astype(out, f, dt, mlx_stream{nullptr});
+        delete A(f);
+        return rc;
+    };
+    const mlx_array* lhs = &prod;
+    if (alpha != 1.0f) {
+        if (scalar(alpha, &sa) || mlx_multiply(&t1, prod, sa, mlx_stream{nullptr})) return 1;
+        lhs = &t1;
+    }
+    mlx_array cc = c;
+    if (beta != 1.0f) {
+        if (scalar(beta, &sb) || mlx_multiply(&t2, c, sb, mlx_stream{nullptr})) return 1;
+        cc = t2;
+    }
+    return mlx_add(res, cc, *lhs, mlx_stream{nullptr});
 }
 
 // ---- affine group quantisation (ops.h:356-365, 471-484, 793-810; ops/quantization.rs:41-153, 226-279) ----
@@ -1016,13 +1040,16 @@ int mlx_argmax_axis(mlx_array* res, const mlx_array a, int axis, bool keepdims, 
     const Arr& s = *A(a);
     int ax;
     if (norm_axis(axis, (int)s.shape.size(), "mlx_argmax_axis", &ax)) return 1;
-    OMX_REQUIRE(ax == (int)s.shape.size() - 1, "mlx_argmax_axis: only the last axis is supported (sampler.rs:11)");
+    // any axis: reduce over a VIEW with that axis moved last (the hot path's call is the last axis, sampler.rs:11)
+    Arr moved = s;
+    moved.shape.erase(moved.shape.begin() + ax); moved.shape.push_back(s.shape[ax]);
+    moved.strides.erase(moved.strides.begin() + ax); moved.strides.push_back(s.strides[ax]);
     Contig c;
-    if (c.init(s)) return 1;
-    std::vector<int> shape(s.shape.begin(), s.shape.end() - 1);
-    if (keepdims) shape.push_back(1);
+    if (c.init(moved)) return 1;
+    std::vector<int> shape(moved.shape.begin(), moved.shape.end() - 1);
+    if (keepdims) shape.insert(shape.begin() + ax, 1);
     NEW_OR_FAIL(r, shape, MLX_UINT32);
-    const int n = s.shape.back();
+    const int n = moved.shape.back();
     if (omx_argmax((uint32_t*)r->ptr(), c.a->ptr(), n ? (int64_t)(s.size() / n) : 0, n, to_omx(s.dt), g_stream)) { delete r; return 1; }
     return assign(res, r);
 }
@@ -1178,15 +1205,27 @@ int mlx_softmax_axis(mlx_array* res, const mlx_array a, int axis, bool, const ml
     const Arr& s = *A(a);
     int ax;
     if (norm_axis(axis, (int)s.shape.size(), "mlx_softmax_axis", &ax)) return 1;
-    OMX_REQUIRE(ax == (int)s.shape.size() - 1 && is_float(s.dt), "mlx_softmax_axis: last axis of a floating array only");
+    OMX_REQUIRE(is_float(s.dt), "mlx_softmax_axis: floating arrays only");
+    const int nd = (int)s.shape.size();
+    // any axis: normalise over a VIEW with that axis moved last; the result is handed back as the inverse view of the row-major
+    // buffer (MLX returns a fresh array either way, strides are not part of the contract)
+    Arr moved = s;
+    moved.shape.erase(moved.shape.begin() + ax); moved.shape.push_back(s.shape[ax]);
+    moved.strides.erase(moved.strides.begin() + ax); moved.strides.push_back(s.strides[ax]);
     Contig c;
-    if (c.init(s)) return 1;
-    NEW_OR_FAIL(r, s.shape, s.dt);
-    const int n = s.shape.back();
+    if (c.init(moved)) return 1;
+    NEW_OR_FAIL(r, moved.shape, s.dt);
+    const int n = moved.shape.back();
     const size_t rows = n ? s.size() / n : 0;
     if (rows) {
         softmax_kernel<<<(unsigned)((rows + 3) / 4), 256, 0, g_stream>>>(r->ptr(), c.a->ptr(), s.dt, rows, n);
         OMX_LAUNCH_CHECK();
+    }
+    if (ax != nd - 1) {   // view the [.., others.., axis] buffer as the input's shape again
+        const std::vector<size_t> st = r->strides;
+        r->shape = s.shape;
+        r->strides.assign(nd, 0);
+        for (int d = 0, k = 0; d < nd; ++d) r->strides[d] = d == ax ? st[nd - 1] : st[k++];
     }
     return assign(res, r);
 }

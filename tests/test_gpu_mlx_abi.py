@@ -370,3 +370,24 @@ def test_klein_single_block_attention_replayed_op_by_op(mx):
     pr = np.exp(sc - sc.max(-1, keepdims=True)); pr /= pr.sum(-1, keepdims=True)
     ref = (pr @ vt).transpose(0, 2, 1, 3).reshape(B, S, H * D)
     np.testing.assert_allclose(out.numpy(), ref, rtol=2e-4, atol=2e-4 * np.abs(ref).max())
+
+
+def test_reductions_on_any_axis_and_general_addmm(mx):
+    """The conscious omissions of round 2 closed (mlx-c ops.h: argmax_axis / softmax_axis take any axis, addmm any alpha / beta and a
+    broadcastable c): checked against numpy in float32."""
+    a = rand((3, 5, 7), 90).astype(np.float32)
+    A = mx.Array.from_numpy(a, mx.FLOAT32)
+    for ax in (0, 1, 2, -2):
+        np.testing.assert_array_equal(mx.argmax_axis(A, ax).numpy(), a.argmax(axis=ax))
+        assert mx.argmax_axis(A, ax, True).shape == tuple(np.expand_dims(a.argmax(axis=ax), ax % 3).shape)
+        e = np.exp(a - a.max(axis=ax, keepdims=True))
+        got = mx.softmax_axis(A, ax)
+        assert got.shape == a.shape
+        np.testing.assert_allclose(got.numpy(), e / e.sum(axis=ax, keepdims=True), rtol=2e-6, atol=2e-7)
+    x = rand((4, 6, 16), 91).astype(np.float32); w = rand((16, 9), 92).astype(np.float32); c = rand((6, 9), 93).astype(np.float32)
+    got = mx.addmm(mx.Array.from_numpy(c, mx.FLOAT32), mx.Array.from_numpy(x, mx.FLOAT32), mx.Array.from_numpy(w, mx.FLOAT32), 0.5, -2.0)
+    np.testing.assert_allclose(got.numpy(), -2.0 * c + 0.5 * (x @ w), rtol=2e-5, atol=2e-5)
+    # nn::Linear's form keeps its fused route (bias in the GEMM epilogue)
+    b = rand((9,), 94).astype(np.float32)
+    got = mx.addmm(mx.Array.from_numpy(b, mx.FLOAT32), mx.Array.from_numpy(x, mx.FLOAT32), mx.Array.from_numpy(w, mx.FLOAT32))
+    np.testing.assert_allclose(got.numpy(), b + x @ w, rtol=2e-5, atol=2e-5)

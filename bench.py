@@ -26,6 +26,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+SECONDARY_TIMEOUT_S = int(os.environ.get("OMX_BENCH_SECONDARY_TIMEOUT", "420"))   # watchdog of the collective secondaries at N > 1
 HBM_PEAK_GBPS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
 
 QWEN3_8B = dict(hidden_size=4096, num_hidden_layers=36, intermediate_size=12288, num_attention_heads=32,
@@ -537,86 +538,111 @@ def main():
         model_stats = {"step_bytes": model.step_bytes(args.prompt + args.warmup + args.steps // 2), "prefill_ms": model.last_prefill_ms()}
         model.close()
         primary_closed = True
+    # rank 0 assembles the primary line BEFORE the collective secondaries: they have never run on real xGMI links in the build loop, and
+    # a rank stuck inside a collective cannot be recovered in-process -- the watchdog below then still prints the measured line
+    ctx_mid = args.prompt + args.warmup + args.steps // 2
+
+    def assemble():
+        step_bytes = (model_stats["step_bytes"] if primary_closed else model.step_bytes(ctx_mid)) * (1 if moe else world)   # whole-job algorithmic bytes per token (EP ranks share one token's experts)
+        last_prefill_ms = model_stats["prefill_ms"] if primary_closed else model.last_prefill_ms()
+        ms_per_step = elapsed * 1e3 / args.steps
+        tok_s = args.steps / elapsed
+        k_bytes, iso_s = time_dominant_kernel(omx, cfg, 1 if moe else world)
+        in_step = None
+        if world == 1 and not moe and keep is None:
+            # the figure the roofline object reports: HIP events on the step's stream around every launch of 4 further (eager) decode steps
+            try:
+                in_step = model.time_step_kernels(4)
+            except Exception as e:      # a measurement hook must never cost the measured line: fall back to the isolated launches
+                print(f"in-step kernel timing failed ({e}); roofline.achieved from isolated launches", file=sys.stderr)
+                in_step = None
+        k_s = in_step["gate_up"] * 1e-6 if in_step else iso_s
+        achieved = k_bytes / k_s / 1e9
+        H, Hkv, D, hd, I, V = (cfg["num_attention_heads"], cfg["num_key_value_heads"], cfg["head_dim"], cfg["hidden_size"],
+                               cfg["intermediate_size"], cfg["vocab_size"])
+        class_bytes = {"qkv": 2 * (H + 2 * Hkv) * D * hd, "attention": 2 * 2 * Hkv * D * (ctx_mid + args.steps // 2), "o": 2 * H * D * hd,
+                       "gate_up": 4 * I * hd, "down": 2 * I * hd, "lm_head": 2 * V * hd}
+        first_ok = None
+        want_first = FIRST_TOKEN.get((args.model, args.prompt)) if world == 1 and not args.layers else None
+        if want_first is not None:
+            first_ok = int(first) == want_first
+        out = {
+            "metric": "decode_tokens_per_sec", "value": round(tok_s, 2), "unit": "tokens/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"{args.model}" + (" (Qwen3-8B shapes for BASELINE 'Qwen3-7B')" if args.model == "qwen3-8b" else "") + " bf16 greedy decode, batch 1, "
+                                   f"{args.prompt}-token prompt then {args.warmup}+{args.steps} decode tokens",
+                       "parallelism": (f"ep{world}" if moe else f"tp{world}"), "context_at_timing": ctx_mid,
+                       "layers": cfg["num_hidden_layers"], **({"allreduce": peer_note} if peer_note else {})},
+            "roofline": {"bound": "hbm", "kernel": "gemv_kernel<rmsnorm, gate/up, swiglu>", "achieved": round(achieved, 1),
+                         "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
+                         "traffic": pmc_traffic(DOMINANT_KERNEL) if world == 1 and args.model == "qwen3-8b" else None,
+                         "traffic_source": "profiles/r03_pmc_fetch_size.json <- profiles/r03_pmc_fetch_size_step.csv (rocprofv3 --pmc FETCH_SIZE over real decode steps, "
+                                           "own pass, x2 gfx950 correction; tools/pmc_profile.sh, tools/pmc_report.py)",
+                         "algorithmic_bytes_per_launch": k_bytes, "avg_launch_us": round(k_s * 1e6, 2),
+                         "timing": ("in-step: every one of the 36 launches per step of 4 eager decode steps, run right after the timed region, carries its own "
+                                    "HIP start/stop event pair (hipExtLaunchKernelGGL: the dispatch's begin/end timestamps on the step's stream)"
+                                    if in_step else "isolated launches over rotating weight buffers (omx_bench_gemv), HIP events"),
+                         "isolated_launch_us": round(iso_s * 1e6, 2)},
+            "step_roofline": {"algorithmic_bytes_per_token": int(step_bytes),
+                              "achieved_GBps": round(step_bytes / (ms_per_step * 1e-3) / 1e9, 1),
+                              "frac_of_hbm_peak": round(step_bytes / (ms_per_step * 1e-3) / 1e9 / (HBM_PEAK_GBPS * world), 4),
+                              "roofline_tokens_per_sec": round(HBM_PEAK_GBPS * 1e9 * world / step_bytes, 1),
+                              "device_ms_per_step_hip_events": round(dev_ms / args.steps, 4)},
+            "prefill": {"tokens": args.prompt, "seconds": round(prefill_s, 4), "device_ms": round(last_prefill_ms, 3),
+                        "tokens_per_sec": round(args.prompt / max(last_prefill_ms, 1e-6) * 1e3, 1),
+                        "mode": "batched on the tensor-parallel shards: MFMA GEMMs + flash attention, two bf16 all-reduces of [T, hidden] per layer, the last token through the decode step" if world > 1 else
+                                "batched: MFMA GEMMs + flash attention over all n tokens (first call: includes the one-time scratch allocation), norm + lm_head + sampler on the last row"},
+            "first_tokens": [int(first)] + [int(t) for t in toks[:4]],
+            "first_token_check": {"expected": want_first, "ok": first_ok},
+        }
+        if in_step:
+            if in_step.get("step_engine", 0.0) == 0.0:   # (the persistent step's launch: only with OMX_STEP_ENGINE set)
+                in_step.pop("step_engine", None)
+            else:
+                class_bytes["step_engine"] = step_bytes - class_bytes["lm_head"]
+                in_step = {k: v for k, v in in_step.items() if v > 0.0}
+            if in_step.get("o", 1.0) == 0.0:      # the O projection rides in the attention launch (csrc/attn_step.hip): one figure, both byte counts
+                in_step.pop("o")
+                class_bytes["attention"] += class_bytes["o"]
+                in_step = {("attention+o" if k == "attention" else k): v for k, v in in_step.items()}
+                class_bytes["attention+o"] = class_bytes["attention"]
+            out["step_kernels"] = {k: {"avg_us": round(v, 2), "algorithmic_bytes": int(class_bytes[k]),
+                                       "frac_of_hbm_peak": round(class_bytes[k] / (v * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4)} for k, v in in_step.items()}
+        return out, first_ok, want_first
+
+    out, first_ok, want_first = assemble() if rank == 0 else (None, None, None)
+    if plan:
+        import threading
+
+        def give_up():
+            if rank == 0:
+                note = {"value": None, "error": f"collective secondary did not finish within {SECONDARY_TIMEOUT_S} s (watchdog)"}
+                out.setdefault("secondary", dict(note, metric="flux_klein_1024_sec_per_step"))
+                if "mixtral" in plan:
+                    out.setdefault("mixtral", dict(note, metric="decode_tokens_per_sec_mixtral_8x7b_bf16"))
+                print(json.dumps(out), flush=True)
+            os._exit(0)      # (every rank's own watchdog fires: the ranks leave by themselves, nobody waits for a stuck peer)
+
+        dog = threading.Timer(SECONDARY_TIMEOUT_S, give_up)
+        dog.daemon = True
+        dog.start()
         try:
             flux_tp = flux_secondary(omx, rank=rank, world=world, comm=keep)
         except Exception as e:
             flux_tp = {"metric": "flux_klein_1024_sec_per_step", "value": None, "error": str(e)}
+        if rank == 0 and flux_tp is not None:
+            out["secondary"] = flux_tp      # (kept if the watchdog fires during the next workload)
         if "mixtral" in plan:
             try:
                 mixtral_ep = mixtral_secondary(omx, rank=rank, world=world, comm=keep, dist=dist)
             except Exception as e:
                 mixtral_ep = {"metric": "decode_tokens_per_sec_mixtral_8x7b_bf16", "value": None, "error": str(e)}
+        dog.cancel()
     if rank != 0:
         if not primary_closed:
             model.close()
         return
-    ctx_mid = args.prompt + args.warmup + args.steps // 2
-    step_bytes = (model_stats["step_bytes"] if primary_closed else model.step_bytes(ctx_mid)) * (1 if moe else world)   # whole-job algorithmic bytes per token (EP ranks share one token's experts)
-    last_prefill_ms = model_stats["prefill_ms"] if primary_closed else model.last_prefill_ms()
-    ms_per_step = elapsed * 1e3 / args.steps
-    tok_s = args.steps / elapsed
-    k_bytes, iso_s = time_dominant_kernel(omx, cfg, 1 if moe else world)
-    in_step = None
-    if world == 1 and not moe and keep is None:
-        # the figure the roofline object reports: HIP events on the step's stream around every launch of 4 further (eager) decode steps
-        try:
-            in_step = model.time_step_kernels(4)
-        except Exception as e:      # a measurement hook must never cost the measured line: fall back to the isolated launches
-            print(f"in-step kernel timing failed ({e}); roofline.achieved from isolated launches", file=sys.stderr)
-            in_step = None
-    k_s = in_step["gate_up"] * 1e-6 if in_step else iso_s
-    achieved = k_bytes / k_s / 1e9
-    H, Hkv, D, hd, I, V = (cfg["num_attention_heads"], cfg["num_key_value_heads"], cfg["head_dim"], cfg["hidden_size"],
-                           cfg["intermediate_size"], cfg["vocab_size"])
-    class_bytes = {"qkv": 2 * (H + 2 * Hkv) * D * hd, "attention": 2 * 2 * Hkv * D * (ctx_mid + args.steps // 2), "o": 2 * H * D * hd,
-                   "gate_up": 4 * I * hd, "down": 2 * I * hd, "lm_head": 2 * V * hd}
-    first_ok = None
-    want_first = FIRST_TOKEN.get((args.model, args.prompt)) if world == 1 and not args.layers else None
-    if want_first is not None:
-        first_ok = int(first) == want_first
-    out = {
-        "metric": "decode_tokens_per_sec", "value": round(tok_s, 2), "unit": "tokens/s", "n_gpus": world,
-        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
-        "scaling": "strong", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-        "config": {"workload": f"{args.model}" + (" (Qwen3-8B shapes for BASELINE 'Qwen3-7B')" if args.model == "qwen3-8b" else "") + " bf16 greedy decode, batch 1, "
-                               f"{args.prompt}-token prompt then {args.warmup}+{args.steps} decode tokens",
-                   "parallelism": (f"ep{world}" if moe else f"tp{world}"), "context_at_timing": ctx_mid,
-                   "layers": cfg["num_hidden_layers"], **({"allreduce": peer_note} if peer_note else {})},
-        "roofline": {"bound": "hbm", "kernel": "gemv_kernel<rmsnorm, gate/up, swiglu>", "achieved": round(achieved, 1),
-                     "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
-                     "traffic": pmc_traffic(DOMINANT_KERNEL) if world == 1 and args.model == "qwen3-8b" else None,
-                     "traffic_source": "profiles/r03_pmc_fetch_size.json <- profiles/r03_pmc_fetch_size_step.csv (rocprofv3 --pmc FETCH_SIZE over real decode steps, "
-                                       "own pass, x2 gfx950 correction; tools/pmc_profile.sh, tools/pmc_report.py)",
-                     "algorithmic_bytes_per_launch": k_bytes, "avg_launch_us": round(k_s * 1e6, 2),
-                     "timing": ("in-step: every one of the 36 launches per step of 4 eager decode steps, run right after the timed region, carries its own "
-                                "HIP start/stop event pair (hipExtLaunchKernelGGL: the dispatch's begin/end timestamps on the step's stream)"
-                                if in_step else "isolated launches over rotating weight buffers (omx_bench_gemv), HIP events"),
-                     "isolated_launch_us": round(iso_s * 1e6, 2)},
-        "step_roofline": {"algorithmic_bytes_per_token": int(step_bytes),
-                          "achieved_GBps": round(step_bytes / (ms_per_step * 1e-3) / 1e9, 1),
-                          "frac_of_hbm_peak": round(step_bytes / (ms_per_step * 1e-3) / 1e9 / (HBM_PEAK_GBPS * world), 4),
-                          "roofline_tokens_per_sec": round(HBM_PEAK_GBPS * 1e9 * world / step_bytes, 1),
-                          "device_ms_per_step_hip_events": round(dev_ms / args.steps, 4)},
-        "prefill": {"tokens": args.prompt, "seconds": round(prefill_s, 4), "device_ms": round(last_prefill_ms, 3),
-                    "tokens_per_sec": round(args.prompt / max(last_prefill_ms, 1e-6) * 1e3, 1),
-                    "mode": "batched on the tensor-parallel shards: MFMA GEMMs + flash attention, two bf16 all-reduces of [T, hidden] per layer, the last token through the decode step" if world > 1 else
-                            "batched: MFMA GEMMs + flash attention over all n tokens (first call: includes the one-time scratch allocation), norm + lm_head + sampler on the last row"},
-        "first_tokens": [int(first)] + [int(t) for t in toks[:4]],
-        "first_token_check": {"expected": want_first, "ok": first_ok},
-    }
-    if in_step:
-        if in_step.get("step_engine", 0.0) == 0.0:   # (the persistent step's launch: only with OMX_STEP_ENGINE set)
-            in_step.pop("step_engine", None)
-        else:
-            class_bytes["step_engine"] = step_bytes - class_bytes["lm_head"]
-            in_step = {k: v for k, v in in_step.items() if v > 0.0}
-        if in_step.get("o", 1.0) == 0.0:      # the O projection rides in the attention launch (csrc/attn_step.hip): one figure, both byte counts
-            in_step.pop("o")
-            class_bytes["attention"] += class_bytes["o"]
-            in_step = {("attention+o" if k == "attention" else k): v for k, v in in_step.items()}
-            class_bytes["attention+o"] = class_bytes["attention"]
-        out["step_kernels"] = {k: {"avg_us": round(v, 2), "algorithmic_bytes": int(class_bytes[k]),
-                                   "frac_of_hbm_peak": round(class_bytes[k] / (v * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4)} for k, v in in_step.items()}
     if not primary_closed:
         model.close()
     if flux_tp is not None:

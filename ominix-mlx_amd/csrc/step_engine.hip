@@ -1050,6 +1050,10 @@ int lds_budget(int hidden, int H, int D, int I, int G, int* xs_bytes) {
     return room >= 8 * kSlot ? 8 : room >= 6 * kSlot ? 6 : 0;
 }
 
+bool have_instance(int D, int gt, int nslot) {
+    return nslot == 8 ? (D == 128 || D == 64) : (nslot == 6 && D == 128 && (gt == 4 || gt == 8));
+}
+
 bool tuned_width(int K) {
     if (K <= 0 || K % 512 != 0) return false;
     static const int kSizes[] = {1, 2, 3, 4, 6, 7, 8, 12, 16, 24, 28, 32, 40};   // gemv.hip tuned_nv
@@ -1067,7 +1071,8 @@ bool step_engine_ok(int hidden, int H, int Hkv, int D, int I, int nsplit, int cu
     // residual rows a CU owns are parked in LDS (kMaxPairs row pairs)
     if ((hidden / 2 + cus - 1) / cus > kMaxPairs) return false;
     int xs = 0;
-    return lds_budget(hidden, H, D, I, H / Hkv, &xs) != 0;
+    const int G = H / Hkv, gt = G <= 1 ? 1 : G <= 2 ? 2 : G <= 4 ? 4 : 8;
+    return have_instance(D, gt, lds_budget(hidden, H, D, I, G, &xs));
 }
 
 size_t step_engine_granules(int hidden, int H, int Hkv, int D, int I) {
@@ -1093,17 +1098,18 @@ int launch_step_engine(const StepEngineArgs& a_in, int cus, hipStream_t s) {
         OMX_LAUNCH_CHECK();                                                                                                        \
         return 0;                                                                                                                  \
     }
-#define OMX_SE_CASE(DD, GG)                                                 \
-    if (a.D == DD && gt == GG) {                                            \
-        if (a.trace) {                                                      \
-            if (a.nslot == 8) OMX_SE_LAUNCH(DD, GG, 8, true)                \
-            OMX_SE_LAUNCH(DD, GG, 6, true)                                  \
-        }                                                                   \
-        if (a.nslot == 8) OMX_SE_LAUNCH(DD, GG, 8, false)                   \
-        OMX_SE_LAUNCH(DD, GG, 6, false)                                     \
+    // instantiations (each is a ~40 k-instruction kernel: the list is kept to what the supported models need -- 8-slot ring for every
+    // head width and group size, 6-slot ring where the activation area outgrows 24 KiB (head_dim 128, groups of 4 and 8), the timeline
+    // build for Qwen3-8B's shape only); have_instance() mirrors it for step_engine_ok
+    if (a.trace) {
+        if (a.D == 128 && gt == 4 && a.nslot == 8) OMX_SE_LAUNCH(128, 4, 8, true)
+        return set_error("step engine: the timeline build exists for head_dim 128, groups of 4, 8-slot ring only");
     }
-    OMX_SE_CASE(128, 1) OMX_SE_CASE(128, 2) OMX_SE_CASE(128, 4) OMX_SE_CASE(128, 8)
-    OMX_SE_CASE(64, 1) OMX_SE_CASE(64, 2) OMX_SE_CASE(64, 4) OMX_SE_CASE(64, 8)
+#define OMX_SE_CASE(DD, GG, NS) \
+    if (a.D == DD && gt == GG && a.nslot == NS) OMX_SE_LAUNCH(DD, GG, NS, false)
+    OMX_SE_CASE(128, 1, 8) OMX_SE_CASE(128, 2, 8) OMX_SE_CASE(128, 4, 8) OMX_SE_CASE(128, 8, 8)
+    OMX_SE_CASE(64, 1, 8) OMX_SE_CASE(64, 2, 8) OMX_SE_CASE(64, 4, 8) OMX_SE_CASE(64, 8, 8)
+    OMX_SE_CASE(128, 4, 6) OMX_SE_CASE(128, 8, 6)
 #undef OMX_SE_CASE
 #undef OMX_SE_LAUNCH
     return set_error("step engine: head_dim %d unsupported", a.D);

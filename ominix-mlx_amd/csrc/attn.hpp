@@ -53,8 +53,13 @@ struct AttnStepArgs {
     int o_rpw, o_nhi;           // rows per wave of the non-consumer blocks: the first o_nhi waves hold o_rpw rows, the others o_rpw - 1
                                 // (set by launch_attn_step)
     uint64_t* xg;               // granules [H*D/2]: {two packed bf16 of the attention vector, tag}
+    // ---- ... on a 4-bit packed O matrix instead (o_wq != null, o_w == null; attn_step_oproj_q4_ok) ----
+    const uint32_t* o_wq;       // [o_rows, H*D/8] MLX-packed nibbles
+    const uint32_t* o_sb;       // [o_rows, H*D/group] scale | bias << 16 (QMat::sb)
+    int o_group;
 };
 bool attn_step_oproj_ok(int H, int Hkv, int D, int nsplit, int o_rows);
+bool attn_step_oproj_q4_ok(int H, int Hkv, int D, int nsplit, int o_rows, int group);
 int attn_step_block_tokens(int D);
 void attn_step_plan(int tk_max, int Hkv, int G, int D, int* chunk, int* nsplit);
 size_t attn_step_ws_granules(int H, int D);

@@ -162,28 +162,9 @@ __device__ __forceinline__ float dot8_chain(const u32x4 w, const u32x4 xp, float
 
 constexpr int kORows = 4;   // most O-projection rows a wave holds (attn_step_oproj_ok)
 
-// The O-projection phase of a non-consumer block (attn_step_kernel, NVW > 0): R weight rows per wave go out NOW -- the block's
-// latency-critical work is over and its attention registers are free -- then the merged attention vector is awaited and swept into
-// LDS, then the separate O GEMV's arithmetic (gemv.hip gemv_kernel<NVW, 1, 2, PRO_NONE, EPI_RESIDUAL>) runs on the held rows.
-// Measured alternatives at Qwen3-8B shapes, ctx 2 k: weight loads issued with the first K/V round -> 33 MB of requests fill the HBM
-// queues ahead of the q / K / V rows (they land at 6.7 us instead of 2.1); issued after that round landed, in every block -> a wave's
-// memory instructions queue in order behind its own prefetch, the partial stores left 1.5 us and the gather 0.5 us later (kernel
-// 13.8 us, still 2.4 us/layer better than two launches).
-template <int NVW, int R>
-__device__ __forceinline__ void oproj_phase(const AttnStepArgs& a, u32x4* sm_x, unsigned tag, int lane, int wave, int o_row0,
-                                            unsigned long long* tr) {
-    u32x4 ow[R][NVW];
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        const int row = min(o_row0 + r, a.o_rows - 1);                           // clamp: surplus waves re-read a valid row
-        const u32x4* p = reinterpret_cast<const u32x4*>(a.o_w + (size_t)row * (NVW * 512));
-#pragma unroll
-        for (int j = 0; j < NVW; ++j) ow[r][j] = __builtin_nontemporal_load(p + j * 64 + lane);
-    }
-    bf16_t o_res[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) o_res[r] = a.o_resid[min(o_row0 + r, a.o_rows - 1)];
-    __builtin_amdgcn_sched_barrier(0);   // keep the loads HERE: the scheduler would sink them to their use
+// the merged attention vector: awaited, then swept from its granules into LDS (natural element order); a block-wide step
+template <int NVW>
+__device__ __forceinline__ void oproj_await_vector(const AttnStepArgs& a, u32x4* sm_x, unsigned tag, int lane, int wave) {
     // wait politely: ONE wave watches one granule per consumer wave (the last of its 32) with a sleep between looks; only then does
     // the block read the whole vector -- normally once (measured: sweep done at 11.3 us with the watch, 11.9 us without)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -223,6 +204,31 @@ __device__ __forceinline__ void oproj_phase(const AttnStepArgs& a, u32x4* sm_x, 
         }
         __builtin_amdgcn_s_sleep(2);
     }
+}
+
+// The O-projection phase of a non-consumer block (attn_step_kernel, NVW > 0): R weight rows per wave go out NOW -- the block's
+// latency-critical work is over and its attention registers are free -- then the merged attention vector is awaited and swept into
+// LDS, then the separate O GEMV's arithmetic (gemv.hip gemv_kernel<NVW, 1, 2, PRO_NONE, EPI_RESIDUAL>) runs on the held rows.
+// Measured alternatives at Qwen3-8B shapes, ctx 2 k: weight loads issued with the first K/V round -> 33 MB of requests fill the HBM
+// queues ahead of the q / K / V rows (they land at 6.7 us instead of 2.1); issued after that round landed, in every block -> a wave's
+// memory instructions queue in order behind its own prefetch, the partial stores left 1.5 us and the gather 0.5 us later (kernel
+// 13.8 us, still 2.4 us/layer better than two launches).
+template <int NVW, int R>
+__device__ __forceinline__ void oproj_phase(const AttnStepArgs& a, u32x4* sm_x, unsigned tag, int lane, int wave, int o_row0,
+                                            unsigned long long* tr) {
+    u32x4 ow[R][NVW];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int row = min(o_row0 + r, a.o_rows - 1);                           // clamp: surplus waves re-read a valid row
+        const u32x4* p = reinterpret_cast<const u32x4*>(a.o_w + (size_t)row * (NVW * 512));
+#pragma unroll
+        for (int j = 0; j < NVW; ++j) ow[r][j] = __builtin_nontemporal_load(p + j * 64 + lane);
+    }
+    bf16_t o_res[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) o_res[r] = a.o_resid[min(o_row0 + r, a.o_rows - 1)];
+    __builtin_amdgcn_sched_barrier(0);   // keep the loads HERE: the scheduler would sink them to their use
+    oproj_await_vector<NVW>(a, sm_x, tag, lane, wave);
     if (tr && threadIdx.x == 0) tr[5] = wall_clock64();
     float acc[R];
 #pragma unroll
@@ -247,17 +253,113 @@ __device__ __forceinline__ void oproj_phase(const AttnStepArgs& a, u32x4* sm_x, 
 }
 
 
+// The same phase on a 4-bit packed O matrix (quant.hip qgemv_kernel<4, 4, PRO_NONE, EPI_RESIDUAL, 2, true>: 32 elements per lane and
+// step, interleaved scale | bias words): a row is NVW / 4 steps of one 16-byte weight load + one 4-byte scale/bias load per lane.
+// The attention vector is re-paired in LDS the way that kernel's prologue stores it ((x0,x2) (x4,x6) (x1,x3) (x5,x7) per 8
+// elements) with the per-32 sums next to it; nibble unpack, v_dot2c order and the scale / bias fmas are that kernel's, so the
+// residual stream is bit-identical to the two-launch step.
+template <int NVW, int R>
+__device__ __forceinline__ void oproj_phase_q4(const AttnStepArgs& a, u32x4* sm_x, float* sm_xsum, unsigned tag, int lane, int wave,
+                                               int o_row0, unsigned long long* tr) {
+    static_assert(NVW % 4 == 0, "K must be a multiple of 2048");
+    constexpr int ST = NVW / 4;
+    u32x4 ow[R][ST];
+    uint32_t sbv[R][ST];
+    const int words_per_row = NVW * 64, groups_per_row = NVW * 512 / a.o_group;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int row = min(o_row0 + r, a.o_rows - 1);
+        const uint32_t* p = a.o_wq + (size_t)row * words_per_row;
+        const uint32_t* psb = a.o_sb + (size_t)row * groups_per_row;
+#pragma unroll
+        for (int st = 0; st < ST; ++st) {
+            const int chunk = st * 64 + lane;
+            ow[r][st] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p + (size_t)chunk * 4));
+            sbv[r][st] = psb[chunk * 32 / a.o_group];
+        }
+    }
+    bf16_t o_res[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) o_res[r] = a.o_resid[min(o_row0 + r, a.o_rows - 1)];
+    __builtin_amdgcn_sched_barrier(0);
+    oproj_await_vector<NVW>(a, sm_x, tag, lane, wave);
+    // re-pair + per-chunk sums: thread t owns the 8 elements of vector t (whole waves: NVW * 64 threads)
+    if ((int)threadIdx.x < NVW * 64) {
+        const u32x4 o = sm_x[threadIdx.x];
+        u32x4 t;
+        t[0] = __builtin_amdgcn_perm(o[1], o[0], 0x05040100u); t[1] = __builtin_amdgcn_perm(o[3], o[2], 0x05040100u);
+        t[2] = __builtin_amdgcn_perm(o[1], o[0], 0x07060302u); t[3] = __builtin_amdgcn_perm(o[3], o[2], 0x07060302u);
+        sm_x[threadIdx.x] = t;
+        float sv = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) sv += bf16lo(o[q]) + bf16hi(o[q]);
+        sv += dpp_f<kDppXor1>(sv);
+        sv += dpp_f<kDppXor2>(sv);
+        if ((threadIdx.x & 3) == 0) sm_xsum[threadIdx.x >> 2] = sv;
+    }
+    __syncthreads();
+    if (tr && threadIdx.x == 0) tr[5] = wall_clock64();
+    float acc[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int st = 0; st < ST; ++st) {
+        const int chunk = st * 64 + lane;
+        uint32_t xp[16];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const u32x4 xv = sm_x[chunk * 4 + j];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) xp[j * 4 + q] = xv[q];
+        }
+        const float xsm = sm_xsum[chunk];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            float d = 0.f;
+            const float scl = bf16lo(sbv[r][st]);
+            float bia = bf16hi(sbv[r][st]);
+#pragma unroll
+            for (int wi = 0; wi < 4; ++wi) {
+                const uint32_t wdw = ow[r][st][wi];
+                const uint32_t lo = wdw & 0x0F0F0F0Fu, hi = (wdw >> 4) & 0x0F0F0F0Fu;
+                const uint32_t c43 = 0x43434343u;
+                const uint32_t q0 = __builtin_amdgcn_perm(c43, lo, 0x04010400u), q1 = __builtin_amdgcn_perm(c43, lo, 0x04030402u);
+                const uint32_t q2 = __builtin_amdgcn_perm(c43, hi, 0x04010400u), q3 = __builtin_amdgcn_perm(c43, hi, 0x04030402u);
+                d = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, xp[wi * 4 + 0]), __builtin_bit_cast(bf16x2_t, q0), d, false);
+                d = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, xp[wi * 4 + 1]), __builtin_bit_cast(bf16x2_t, q1), d, false);
+                d = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, xp[wi * 4 + 2]), __builtin_bit_cast(bf16x2_t, q2), d, false);
+                d = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, xp[wi * 4 + 3]), __builtin_bit_cast(bf16x2_t, q3), d, false);
+            }
+            bia = fmaf(-128.0f, scl, bia);
+            acc[r] = fmaf(scl, d, acc[r]);
+            acc[r] = fmaf(bia, xsm, acc[r]);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc[r] = wave_sum(acc[r]);
+    if (lane == 0) {
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+            if (o_row0 + r < a.o_rows) a.o_out[o_row0 + r] = f32_to_bf16(bf16_to_f32(o_res[r]) + round_bf16(acc[r]));
+    }
+    if (tr && threadIdx.x == 0) tr[6] = wall_clock64();
+}
+
+
 template <int D, int GT, bool TRACE, int NVW>
 __global__ __launch_bounds__(kBlock, 1) void attn_step_kernel(const AttnStepArgs a) {
     constexpr int LPR = D / 8;            // lanes per K/V row
     constexpr int TPW = 64 / LPR;         // token rows per wave-instruction == one unit
-    constexpr bool OPROJ = NVW > 0;       // K = H * D = NVW * 512
+    constexpr bool QO = NVW >= 100;       // 100 + n: the O matrix is 4-bit packed (oproj_phase_q4)
+    constexpr int NV = QO ? NVW - 100 : NVW;
+    constexpr bool OPROJ = NV > 0;        // K = H * D = NV * 512
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* sm_o = reinterpret_cast<float*>(smem);                 // [kWaves][TPW][GT][D]
     float* sm_m = sm_o + kWaves * TPW * GT * D;                   // [kWaves][GT]
     float* sm_l = sm_m + kWaves * GT;                             // [kWaves][GT]
     u32x4* sm_q = reinterpret_cast<u32x4*>(sm_l + kWaves * GT);   // [GT + 1][LPR]: roped q heads and the new k row, packed bf16
-    u32x4* sm_x = sm_q + (GT + 1) * LPR;                          // OPROJ: [NVW * 64] the attention vector, packed bf16
+    u32x4* sm_x = sm_q + (GT + 1) * LPR;                          // OPROJ: [NV * 64] the attention vector, packed bf16
+    float* sm_xsum = reinterpret_cast<float*>(sm_x + NV * 64);    // QO: [NV * 16] sums of 32 consecutive elements
 
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -468,10 +570,17 @@ __global__ __launch_bounds__(kBlock, 1) void attn_step_kernel(const AttnStepArgs
         const int rows = hi ? a.o_rpw : a.o_rpw - 1;
         const int o_row0 = hi ? g * a.o_rpw : a.o_nhi * a.o_rpw + (g - a.o_nhi) * (a.o_rpw - 1);
         unsigned long long* otr = TRACE ? tr : nullptr;
-        if (rows <= 1) oproj_phase<(NVW > 0 ? NVW : 1), 1>(a, sm_x, tag, lane, wave, o_row0, otr);
-        else if (rows == 2) oproj_phase<(NVW > 0 ? NVW : 1), 2>(a, sm_x, tag, lane, wave, o_row0, otr);
-        else if (rows == 3) oproj_phase<(NVW > 0 ? NVW : 1), 3>(a, sm_x, tag, lane, wave, o_row0, otr);
-        else oproj_phase<(NVW > 0 ? NVW : 1), 4>(a, sm_x, tag, lane, wave, o_row0, otr);
+        if constexpr (QO) {
+            if (rows <= 1) oproj_phase_q4<NV, 1>(a, sm_x, sm_xsum, tag, lane, wave, o_row0, otr);
+            else if (rows == 2) oproj_phase_q4<NV, 2>(a, sm_x, sm_xsum, tag, lane, wave, o_row0, otr);
+            else if (rows == 3) oproj_phase_q4<NV, 3>(a, sm_x, sm_xsum, tag, lane, wave, o_row0, otr);
+            else oproj_phase_q4<NV, 4>(a, sm_x, sm_xsum, tag, lane, wave, o_row0, otr);
+        } else {
+            if (rows <= 1) oproj_phase<(NV > 0 ? NV : 1), 1>(a, sm_x, tag, lane, wave, o_row0, otr);
+            else if (rows == 2) oproj_phase<(NV > 0 ? NV : 1), 2>(a, sm_x, tag, lane, wave, o_row0, otr);
+            else if (rows == 3) oproj_phase<(NV > 0 ? NV : 1), 3>(a, sm_x, tag, lane, wave, o_row0, otr);
+            else oproj_phase<(NV > 0 ? NV : 1), 4>(a, sm_x, tag, lane, wave, o_row0, otr);
+        }
         return;
     }
 
@@ -526,6 +635,12 @@ bool attn_step_oproj_ok(int H, int Hkv, int D, int nsplit, int o_rows) {
     return K % 512 == 0 && (nvw == 1 || nvw == 2 || nvw == 4 || nvw == 7 || nvw == 8) && oproj_rows_per_wave(H, Hkv, nsplit, o_rows) <= kORows;
 }
 
+// ... on a 4-bit packed matrix: K a multiple of 2048 (quant.hip's four-word lane chunk) with the register layouts 4 and 8
+bool attn_step_oproj_q4_ok(int H, int Hkv, int D, int nsplit, int o_rows, int group) {
+    const int K = H * D;
+    return (K == 2048 || K == 4096) && (group == 32 || group == 64 || group == 128) && attn_step_oproj_ok(H, Hkv, D, nsplit, o_rows);
+}
+
 int launch_attn_step(const AttnStepArgs& a_in, int D, hipStream_t s) {
     AttnStepArgs a = a_in;
     const int G = a.H / a.Hkv;
@@ -535,7 +650,11 @@ int launch_attn_step(const AttnStepArgs& a_in, int D, hipStream_t s) {
     OMX_REQUIRE(a.ws && a.rope_cur && a.pos_ptr && a.seq_ptr && a.abort_flag && a.tag_mul > a.tag_add - 1u && a.tag_add >= 1u,
                 "decode attention: missing step state");
     int nvw = 0;
-    if (a.o_w) {
+    const bool qo = a.o_wq != nullptr;
+    if (qo)
+        OMX_REQUIRE(!a.o_w && a.o_sb && a.o_out && !a.o_out_f32 && attn_step_oproj_q4_ok(a.H, a.Hkv, D, a.nsplit, a.o_rows, a.o_group),
+                    "decode attention + packed O projection: shape does not qualify (H*D = %d, group %d)", a.H * D, a.o_group);
+    if (a.o_w || qo) {
         OMX_REQUIRE(a.o_resid && (a.o_out || a.o_out_f32) && a.xg && attn_step_oproj_ok(a.H, a.Hkv, D, a.nsplit, a.o_rows),
                     "decode attention + O projection: shape does not qualify (H*D = %d, %d rows, %d blocks)", a.H * D, a.o_rows, a.Hkv * a.nsplit);
         nvw = a.H * D / 512;
@@ -559,11 +678,15 @@ int launch_attn_step(const AttnStepArgs& a_in, int D, hipStream_t s) {
 #define OMX_ATTN_STEP_CASE(DD, GG)                                                                                       \
     if (D == DD && gt == GG) {                                                                                           \
         const size_t shmem = ((size_t)kWaves * (64 / (DD / 8)) * GG * DD + 2 * kWaves * GG) * sizeof(float) +            \
-                             (size_t)(GG + 1) * (DD / 8) * 16 + (size_t)nvw * 64 * 16;                                   \
-        if (a.trace) {   /* timeline builds: the plain kernel and the widest fused one */                               \
+                             (size_t)(GG + 1) * (DD / 8) * 16 + (size_t)nvw * 64 * 16 + (qo ? (size_t)nvw * 64 : 0);     \
+        if (a.trace && !qo) {   /* timeline builds: the plain kernel and the widest fused one */                        \
             if (nvw == 0) OMX_ATTN_LAUNCH(DD, GG, true, 0)                                                               \
             if (nvw == 8) OMX_ATTN_LAUNCH(DD, GG, true, 8)                                                               \
             return set_error("decode attention: no traced instantiation for H*D = %d", a.H * DD);                       \
+        }                                                                                                                \
+        if (qo) {                                                                                                        \
+            if (nvw == 4) OMX_ATTN_LAUNCH(DD, GG, false, 104)                                                            \
+            OMX_ATTN_LAUNCH(DD, GG, false, 108)                                                                          \
         }                                                                                                                \
         if (nvw == 0) OMX_ATTN_LAUNCH(DD, GG, false, 0)                                                                  \
         if (nvw == 1) OMX_ATTN_LAUNCH(DD, GG, false, 1)                                                                  \

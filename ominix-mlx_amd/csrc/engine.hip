@@ -377,8 +377,11 @@ bool attention_takes_oproj(omx_qwen3 m) {
     const omx_qwen3_config& c = m->cfg;
     // (tensor parallel: the rank's heads and columns -- the launch then leaves the f32 partial for the all-reduce)
     // every block of that launch waits on others: all Hkv * nsplit of them must be resident, one per CU
-    return !off && !m->oproj_disabled && c.quant_bits == 0 && m->Hkv * m->attn_nsplit <= m->cus &&
-           attn_step_oproj_ok(m->H, m->Hkv, c.head_dim, m->attn_nsplit, c.hidden_size);
+    if (off || m->oproj_disabled || m->Hkv * m->attn_nsplit > m->cus) return false;
+    if (c.quant_bits == 4)   // 4-bit checkpoint: the packed O matrix with its interleaved scale | bias words (built at load for K % 2048 == 0)
+        return c.ep_size <= 1 && c.tp_size <= 1 && !m->qlayers.empty() && m->qlayers[0].o.sb != nullptr &&
+               attn_step_oproj_q4_ok(m->H, m->Hkv, c.head_dim, m->attn_nsplit, c.hidden_size, c.quant_group);
+    return c.quant_bits == 0 && attn_step_oproj_ok(m->H, m->Hkv, c.head_dim, m->attn_nsplit, c.hidden_size);
 }
 
 // the attention launch of layer l of a decode step (both the bf16 and the packed-weight step use the bf16 KV kernels);
@@ -406,7 +409,13 @@ int enqueue_attention(omx_qwen3 m, int l, hipStream_t s, const bf16_t* resid = n
         a.abort_flag = m->wait_abort;
         a.trace = m->attn_trace ? m->attn_trace + (size_t)l * m->attn_nsplit * m->Hkv * 8 : nullptr;
         if (resid && (out || out_f32)) {
-            a.o_w = L.o; a.o_resid = resid; a.o_out = out; a.o_out_f32 = out_f32; a.o_rows = c.hidden_size; a.xg = m->attn_xg;
+            a.o_resid = resid; a.o_out = out; a.o_out_f32 = out_f32; a.o_rows = c.hidden_size; a.xg = m->attn_xg;
+            if (c.quant_bits) {
+                const QMat& o = m->qlayers[l].o;
+                a.o_wq = o.w; a.o_sb = o.sb; a.o_group = c.quant_group;
+            } else {
+                a.o_w = L.o;
+            }
         }
         return launch_attn_step(a, D, s);
     }
@@ -434,8 +443,12 @@ int enqueue_step_quant(omx_qwen3 m, bool with_head) {
             a.x = h; a.norm_w = L.in_ln; a.eps = c.rms_norm_eps; a.out = m->qkv;
             if (launch_qgemv(a, bits, PRO_RMSNORM, EPI_STORE, s)) return 1;
         }
-        if (enqueue_attention(m, l, s)) return 1;   // [q/k RMSNorm + RoPE + cache append + split-KV SDPA + merge]: the bf16 kernel
-        {   // [O + residual]
+        const bool fused_o = attention_takes_oproj(m);
+        // [q/k RMSNorm + RoPE + cache append + split-KV SDPA + merge]: the bf16 kernel (+ [O + residual] on the packed matrix)
+        if (enqueue_attention(m, l, s, fused_o ? h : nullptr, fused_o ? hn : nullptr)) return 1;
+        if (fused_o) {
+            bf16_t* t = h; h = hn; hn = t;
+        } else {   // [O + residual]
             QGemvArgs a = {};
             a.m[0] = Q.o; a.N = hd; a.K = m->H * D; a.group = group;
             a.x = m->attn_out; a.resid = h; a.out = hn;

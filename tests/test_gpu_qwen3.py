@@ -569,6 +569,33 @@ def test_oproj_in_attention_launch_is_bit_identical(omx, monkeypatch, name):
             np.testing.assert_array_equal(a, b)
 
 
+@pytest.mark.parametrize("name,group", [("h16_kv8_d128_nvw4", 64), ("h32_kv8_d128_nvw8", 64), ("h32_kv8_d128_nvw8", 32), ("h16_kv8_d128_nvw4", 128)])
+def test_packed_oproj_in_attention_launch_is_bit_identical(omx, monkeypatch, name, group):
+    """4-bit checkpoint: the packed O matrix rides in the attention launch too (csrc/attn_step.hip oproj_phase_q4: the rows' nibbles and
+    scale | bias words prefetched into registers, the attention vector re-paired in LDS the way quant.hip's prologue stores it).  Same
+    tokens and bit-equal logits as the separate packed GEMV (OMX_ATTN_OPROJ=0), graph and eager, across a context-bucket boundary;
+    the two-launch form is the one test_quantized_checkpoint_decode_matches_oracle holds against the oracle."""
+    from ominix_mlx_amd import engine
+    cfg = OPROJ_CONFIGS[name]
+    prompt = synth.prompt_ids(1000, cfg.vocab_size)
+    outs = {}
+    for mode in ("0", "1", "eager"):
+        monkeypatch.setenv("OMX_ATTN_OPROJ", "0" if mode == "0" else "1")
+        monkeypatch.setenv("OMX_NO_GRAPH", "1" if mode == "eager" else "0")
+        m = engine.Model(hidden_size=cfg.hidden_size, num_hidden_layers=cfg.num_hidden_layers, intermediate_size=cfg.intermediate_size,
+                         num_attention_heads=cfg.num_attention_heads, num_key_value_heads=cfg.num_key_value_heads, head_dim=cfg.head_dim,
+                         vocab_size=cfg.vocab_size, rms_norm_eps=cfg.rms_norm_eps, rope_theta=cfg.rope_theta,
+                         tie_word_embeddings=cfg.tie_word_embeddings, rope_scaling=cfg.rope_scaling, max_context=1280,
+                         quantization={"bits": 4, "group_size": group})
+        m.synth_weights()
+        toks = np.concatenate([[m.prefill(prompt)], m.decode(40)])      # positions 1000 .. 1039: crosses 1024
+        outs[mode] = (toks, m.last_logits())
+        m.close()
+    for mode in ("1", "eager"):
+        for a, b in zip(outs["0"], outs[mode]):
+            np.testing.assert_array_equal(a, b)
+
+
 @pytest.mark.parametrize("fused", ["1", "0"])
 def test_peer_store_allreduce_across_processes(omx, tmp_path, fused):
     """csrc/peer_allreduce.hip with one PROCESS per rank (tools/peer_allreduce_check.py under torch.distributed.run, gloo bootstrap,

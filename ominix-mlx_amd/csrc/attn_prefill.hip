@@ -42,6 +42,7 @@ struct PrefillArgs {
     // element strides of q and out: [B,H,Tq,D] by default; the engine writes out as [Tq, H*D]
     int64_t q_bs, q_hs, q_ts, o_bs, o_hs, o_ts;
     int64_t kv_ts;   // elements between consecutive key rows (D when K/V are [.., T, D] contiguous)
+    unsigned long long* trace;   // two-phase kernel, timeline build: [block][wave][8] cycle sums (tools/attn_pp_trace.py)
 };
 
 // max / sum over the 4 lanes {l, l^16, l^32, l^48} that hold the same query column
@@ -134,13 +135,21 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(const PrefillArgs 
     }
     // K: 16-B chunk index ^= key & (DC-1) (ds_read_b128 of 16 consecutive key rows).  V: 32-B block index ^= the key
     // row's position among the 8 rows that two 16-lane groups of one ds_read_b64_tr_b16 touch
+    // The DMA goes out through an asm statement: hipcc counts a builtin LDS-DMA like a load and puts s_waitcnt vmcnt(0) in front of
+    // the next ds_read it cannot prove disjoint -- the first K fragment read of the CURRENT tile waited for the NEXT tile to land
+    // (cdna_hip_programming.md 5.7 item 1).  The waits are ours: vmcnt(0) ahead of the barrier that ends the tile.
+    const unsigned wave_u = __builtin_amdgcn_readfirstlane(wave);
+    auto dma16 = [&](const bf16_t* gsrc, unsigned lds_dst) {
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+    };
     auto stage = [&](int k0, const bf16_t* src, const uint32_t (&off)[KCH], bf16_t* dst, bool is_v) {
+        const unsigned d0 = (unsigned)(uintptr_t)dst + wave_u * 1024u;
         if (k0 + KB <= a.Tk) {
             const bf16_t* base = src + (size_t)k0 * a.kv_ts;
 #pragma unroll
-            for (int it = 0; it < KCH; ++it)
-                __builtin_amdgcn_global_load_lds((glb_ptr_t)(base + off[it]),
-                                                 (lds_ptr_t)(reinterpret_cast<unsigned char*>(dst) + (it * 256 + wave * 64) * 16), 16, 0, 0);
+            for (int it = 0; it < KCH; ++it) dma16(base + off[it], d0 + it * 4096u);
             return;
         }
 #pragma unroll
@@ -149,8 +158,7 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(const PrefillArgs 
             const int row = ci / DC;
             const int ch = (ci % DC) ^ (is_v ? (((row >> VSH) & VBM) << 1) : (row & (DC - 1)));
             const int key = min(k0 + row, a.Tk - 1);
-            __builtin_amdgcn_global_load_lds((glb_ptr_t)(src + (size_t)key * a.kv_ts + ch * 8),
-                                             (lds_ptr_t)(reinterpret_cast<unsigned char*>(dst) + (it * 256 + wave * 64) * 16), 16, 0, 0);
+            dma16(src + (size_t)key * a.kv_ts + ch * 8, d0 + it * 4096u);
         }
     };
     auto stage_k = [&](int k0, bf16_t* sK) { stage(k0, Kb, koff, sK, false); };
@@ -245,7 +253,9 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(const PrefillArgs 
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int key = k0 + kt * 16 + rg * 4 + r;
-                        float v = s[w][kt][r] * c2;
+                        // (scores stay raw unless an additive mask joins them: the exponent below is then the plain path's fma, so a
+                        //  tile gives the same bits whichever path a block's geometry sends it down)
+                        float v = MASK == OMX_MASK_ADDITIVE ? s[w][kt][r] * c2 : s[w][kt][r];
                         bool keep = key < a.Tk;
                         // MASK is a compile-time mode; the mask bytes are loaded unconditionally from a clamped address
                         if (MASK == OMX_MASK_CAUSAL) keep = keep && (key <= qrow[w] + shift);
@@ -260,6 +270,7 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(const PrefillArgs 
                         mx = fmaxf(mx, v);
                     }
                 mx = quad_rows_max(mx);
+                if (MASK != OMX_MASK_ADDITIVE) mx *= c2;
                 const float m_new = fmaxf(m_run[w], mx);
                 const float alpha = (m_new == -INFINITY) ? 1.f : __builtin_amdgcn_exp2f(m_run[w] - m_new);
                 m_run[w] = m_new;
@@ -271,7 +282,8 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(const PrefillArgs 
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
                         const float sv = s[w][2 * j + (e >> 2)][e & 3];
-                        const float p = (m_new == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(sv - m_new);
+                        const float p = (m_new == -INFINITY) ? 0.f
+                                        : __builtin_amdgcn_exp2f(MASK == OMX_MASK_ADDITIVE ? sv - m_new : fmaf(sv, c2, -m_new));
                         l_run[w] += p;
                         pf[w][j][e] = (__bf16)p;
                     }
@@ -322,6 +334,327 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(const PrefillArgs 
     }
 }
 
+
+// ---- Two-phase ("ping-pong") form for long sequences: ONE block of 8 waves per CU, 256 query rows, two waves per SIMD that run
+//      in opposite phases.  A wave's tile step is split into X = {S_i = K_i Q^T, O += V_{i-1}^T P_{i-1}} (64 MFMAs, LDS reads) and
+//      Y = {online softmax of S_i -> P_i, O rescale} (VALU only); waves 0-3 run X while waves 4-7 run Y and vice versa, every
+//      phase ends in an s_barrier that all 8 waves meet.  Without it the co-resident waves of a SIMD drift into the same phase:
+//      both queue for the matrix pipe, then both for the VALU (64 MFMAs = 1024 matrix cycles and ~1300 VALU cycles per tile and
+//      wave ran as their SUM, MfmaUtil 0.32; see EXPERIMENTS.md R3-4).  MI355X_MICROARCH.md "Two waves per SIMD".
+//      K_{i+1} and V_i are fetched by LDS-DMA at the start of even phases into the buffers whose last readers met the previous
+//      barrier, and awaited (vmcnt) ahead of the barrier that ends the following odd phase: two phases of flight. ----
+template <int D, int MASK, bool TR = false>
+__global__ __launch_bounds__(512, 1) void attn_prefill_pp_kernel(const PrefillArgs a) {
+    constexpr int QW = 2;
+    constexpr int DC = D / 8, NI = D / 32, NDT = D / 16;
+    constexpr int QBLK = 8 * 16 * QW;           // 256 query rows per block
+    constexpr int KCH = KB * DC / 512;          // 16-byte chunks staged per thread and tile
+    __shared__ __attribute__((aligned(16))) bf16_t sK2[2][KB * D];
+    __shared__ __attribute__((aligned(16))) bf16_t sV2[2][KB * D];
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const bool late = wave_u >= 4;              // waves 4-7: one phase behind waves 0-3 (their SIMD partners)
+    const int qcol = lane & 15, rg = lane >> 4;
+    // blocks of one head on one XCD (its L2 then holds that head's K / V once, not eight times): linear block id L runs on XCD
+    // L % 8; when the head count is a multiple of 8, XCD x works through heads x, x + 8, ...
+    int qt = blockIdx.x, h = blockIdx.y;
+    const int b = blockIdx.z;
+    if ((a.H & 7) == 0) {
+        const int L = (int)blockIdx.x + (int)gridDim.x * (int)blockIdx.y;
+        const int xcd = L & 7, idx = L >> 3;
+        h = (idx / (int)gridDim.x) * 8 + xcd;
+        qt = idx % (int)gridDim.x;
+    }
+    if (MASK == OMX_MASK_CAUSAL) qt = (int)gridDim.x - 1 - qt;   // longest blocks first
+    const int kvh = h / (a.H / a.Hkv);
+    const int q0 = qt * QBLK;
+    const int shift = a.Tk - a.Tq;
+
+    const bf16_t* Kb = a.k + (size_t)b * a.kv_batch_stride + (size_t)kvh * a.kv_head_stride;
+    const bf16_t* Vb = a.v + (size_t)b * a.kv_batch_stride + (size_t)kvh * a.kv_head_stride;
+
+    int qrow[QW], qrow_c[QW];
+    bf16x8 qf[QW][NI];
+#pragma unroll
+    for (int w = 0; w < QW; ++w) {
+        qrow[w] = q0 + (wave * QW + w) * 16 + qcol;
+        qrow_c[w] = min(qrow[w], a.Tq - 1);
+        const bf16_t* Qp = a.q + (size_t)b * a.q_bs + (size_t)h * a.q_hs + (size_t)qrow_c[w] * a.q_ts;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) qf[w][i] = *reinterpret_cast<const bf16x8*>(Qp + i * 32 + rg * 8);
+    }
+    f32x4v o[QW][NDT];
+    float m_run[QW], l_run[QW];
+#pragma unroll
+    for (int w = 0; w < QW; ++w) {
+        m_run[w] = -INFINITY;
+        l_run[w] = 0.f;
+#pragma unroll
+        for (int t = 0; t < NDT; ++t) o[w][t] = f32x4v{0.f, 0.f, 0.f, 0.f};
+    }
+    int kv_end = a.Tk;
+    if (MASK == OMX_MASK_CAUSAL) kv_end = max(0, min(a.Tk, q0 + QBLK + shift));
+    const int nt = (kv_end + KB - 1) / KB;
+
+    constexpr int VSH = (D == 128) ? 0 : 1;
+    constexpr int VBM = D / 16 - 1;
+    uint32_t koff[KCH], voff[KCH];
+#pragma unroll
+    for (int it = 0; it < KCH; ++it) {
+        const int ci = threadIdx.x + it * 512;
+        const int row = ci / DC;
+        koff[it] = (uint32_t)(row * a.kv_ts + ((ci % DC) ^ (row & (DC - 1))) * 8);
+        voff[it] = (uint32_t)(row * a.kv_ts + ((ci % DC) ^ (((row >> VSH) & VBM) << 1)) * 8);
+    }
+    auto dma16 = [&](const bf16_t* gsrc, unsigned lds_dst) {   // (asm: see attn_prefill_kernel)
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+    };
+    auto stage = [&](int k0, const bf16_t* src, const uint32_t (&off)[KCH], bf16_t* dst, bool is_v) {
+        const unsigned d0 = (unsigned)(uintptr_t)dst + wave_u * 1024u;
+        if (k0 + KB <= a.Tk) {
+            const bf16_t* base = src + (size_t)k0 * a.kv_ts;
+#pragma unroll
+            for (int it = 0; it < KCH; ++it) dma16(base + off[it], d0 + it * 8192u);
+            return;
+        }
+#pragma unroll
+        for (int it = 0; it < KCH; ++it) {
+            const int ci = threadIdx.x + it * 512;
+            const int row = ci / DC;
+            const int ch = (ci % DC) ^ (is_v ? (((row >> VSH) & VBM) << 1) : (row & (DC - 1)));
+            const int key = min(k0 + row, a.Tk - 1);
+            dma16(src + (size_t)key * a.kv_ts + ch * 8, d0 + it * 8192u);
+        }
+    };
+    // tile step i, even phase: K_{i+1} and V_i set out
+    auto fetch = [&](int i) {
+        if (i + 1 < nt) stage((i + 1) * KB, Kb, koff, sK2[(i + 1) & 1], false);
+        if (i < nt) stage(i * KB, Vb, voff, sV2[i & 1], true);
+    };
+    const int v_key = rg * 4 + (qcol >> 2);
+    const int v_sw = (v_key >> VSH) & VBM;
+    const int v_lane_off = v_key * D + (qcol & 3) * 4;
+    typedef __attribute__((ext_vector_type(4))) short s16x4;
+    typedef __attribute__((address_space(3))) s16x4* lds_s16x4_t;
+
+    f32x4v sc[QW][4];      // S_i^T, from X(i) to Y(i)
+    bf16x8 pf[QW][2];      // P_i, from Y(i) to X(i + 1)
+    const float c2 = a.scale * 1.44269504088896340736f;
+
+    auto qk = [&](const bf16_t* sK) {
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int w = 0; w < QW; ++w) sc[w][kt] = f32x4v{0.f, 0.f, 0.f, 0.f};
+        bf16x8 kf[2][4];
+        auto read_k = [&](int i, bf16x8 (&dst)[4]) {
+            const int ch = i * 4 + rg;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) {
+                const int row = kt * 16 + qcol;
+#ifdef OMX_PP_NOLDS   /* experiment: the X phase without its LDS reads (results are garbage) */
+                dst[kt] = qf[0][(i + kt) & (NI - 1)];
+                (void)row; (void)ch;
+#else
+                dst[kt] = *reinterpret_cast<const bf16x8*>(&sK[(row * DC + (ch ^ (row & (DC - 1)))) * 8]);
+#endif
+            }
+        };
+        read_k(0, kf[0]);
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            if (i + 1 < NI) read_k(i + 1, kf[(i + 1) & 1]);
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int w = 0; w < QW; ++w) sc[w][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[i & 1][kt], qf[w][i], sc[w][kt], 0, 0, 0);
+        }
+    };
+    auto pv = [&](const bf16_t* sV) {
+        constexpr int NF = 2 * NDT, AHEAD = 4;
+        u32x4 vf[AHEAD];
+        auto read_v = [&](int idx) {
+            const int j = idx / NDT, t = idx % NDT;
+            const bf16_t* p0 = sV + v_lane_off + ((t ^ v_sw) * 16) + (2 * j) * 16 * D;
+#ifdef OMX_PP_NOLDS
+            (void)p0;
+            return __builtin_bit_cast(u32x4, qf[1][(j + t) & (NI - 1)]);
+#else
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t)p0);
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t)(p0 + 16 * D));
+            const u32x2v l2 = __builtin_bit_cast(u32x2v, lo), h2 = __builtin_bit_cast(u32x2v, hi);
+            return u32x4{l2[0], l2[1], h2[0], h2[1]};
+#endif
+        };
+#pragma unroll
+        for (int idx = 0; idx < AHEAD; ++idx) vf[idx] = read_v(idx);
+#pragma unroll
+        for (int idx = 0; idx < NF; ++idx) {
+            const int j = idx / NDT, t = idx % NDT;
+            const u32x4 cur = vf[idx % AHEAD];
+            if (idx + AHEAD < NF) vf[idx % AHEAD] = read_v(idx + AHEAD);
+#pragma unroll
+            for (int w = 0; w < QW; ++w)
+                o[w][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, cur), pf[w][j], o[w][t], 0, 0, 0);
+        }
+    };
+    // online softmax of tile i in the base-2 domain (attn_prefill_kernel's, same order of operations)
+    auto softmax = [&](int i) {
+        const int k0 = i * KB;
+        const bool plain = (k0 + KB <= a.Tk) && (MASK == OMX_MASK_NONE || (MASK == OMX_MASK_CAUSAL && k0 + KB - 1 <= q0 + shift));
+        if (plain) {
+#pragma unroll
+            for (int w = 0; w < QW; ++w) {
+                float mx = sc[w][0][0];
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) mx = fmaxf(mx, sc[w][kt][r]);
+                mx = quad_rows_max(mx) * c2;
+                // (a deferred / skipped rescale -- cdna_hip_programming.md T13 -- was tried in three forms: any branch or asm region around
+                //  the 64 accumulators made hipcc spill them, 172-204 B of scratch and a 2x slower kernel; EXPERIMENTS.md R3-4)
+                const float m_new = fmaxf(m_run[w], mx);
+                const float alpha = __builtin_amdgcn_exp2f(m_run[w] - m_new);
+                m_run[w] = m_new;
+                l_run[w] *= alpha;
+#pragma unroll
+                for (int t = 0; t < NDT; ++t) o[w][t] *= alpha;
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float p = __builtin_amdgcn_exp2f(fmaf(sc[w][2 * j + (e >> 2)][e & 3], c2, -m_new));
+                        l_run[w] += p;
+                        pf[w][j][e] = (__bf16)p;
+                    }
+            }
+        } else {
+#pragma unroll
+            for (int w = 0; w < QW; ++w) {
+                float mx = -INFINITY;
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int key = k0 + kt * 16 + rg * 4 + r;
+                        // (scores stay raw unless an additive mask joins them: the exponent below is then the plain path's fma, so a
+                        //  tile gives the same bits whichever path a block's geometry sends it down)
+                        float v = MASK == OMX_MASK_ADDITIVE ? sc[w][kt][r] * c2 : sc[w][kt][r];
+                        bool keep = key < a.Tk;
+                        if (MASK == OMX_MASK_CAUSAL) keep = keep && (key <= qrow[w] + shift);
+                        if (MASK == OMX_MASK_BOOL) {
+                            const uint8_t mb = reinterpret_cast<const uint8_t*>(a.mask)[(size_t)qrow_c[w] * a.Tk + min(key, a.Tk - 1)];
+                            keep = keep & (mb != 0);
+                        }
+                        if (MASK == OMX_MASK_ADDITIVE)
+                            v += 1.44269504088896340736f * bf16_to_f32(reinterpret_cast<const bf16_t*>(a.mask)[(size_t)qrow_c[w] * a.Tk + min(key, a.Tk - 1)]);
+                        v = keep ? v : -INFINITY;
+                        sc[w][kt][r] = v;
+                        mx = fmaxf(mx, v);
+                    }
+                mx = quad_rows_max(mx);
+                if (MASK != OMX_MASK_ADDITIVE) mx *= c2;
+                const float m_new = fmaxf(m_run[w], mx);
+                const float alpha = (m_new == -INFINITY) ? 1.f : __builtin_amdgcn_exp2f(m_run[w] - m_new);
+                m_run[w] = m_new;
+                l_run[w] *= alpha;
+#pragma unroll
+                for (int t = 0; t < NDT; ++t) o[w][t] *= alpha;
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float sv = sc[w][2 * j + (e >> 2)][e & 3];
+                        const float p = (m_new == -INFINITY) ? 0.f
+                                        : __builtin_amdgcn_exp2f(MASK == OMX_MASK_ADDITIVE ? sv - m_new : fmaf(sv, c2, -m_new));
+                        l_run[w] += p;
+                        pf[w][j][e] = (__bf16)p;
+                    }
+            }
+        }
+    };
+    // phase ends.  Even: nothing of ours may still be reading LDS when the partner's next DMA overwrites it (lgkmcnt); odd: the
+    // DMA this wave issued one phase ago has landed (vmcnt) before anyone reads it
+    auto end_even = [&]() {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    };
+    auto end_odd = [&]() {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    };
+
+    // timeline build: cycles spent in X work, Y work, and from "work done" to "barrier passed" of even / odd phases
+    unsigned long long tw[5] = {0, 0, 0, 0, 0}, tc = 0;
+    auto clk = [&]() { return TR ? (unsigned long long)__builtin_amdgcn_s_memtime() : 0ull; };
+    auto lap = [&](int slot) {
+        if (TR) {
+            const unsigned long long t = clk();
+            tw[slot] += t - tc;
+            tc = t;
+        }
+    };
+    if (nt > 0) {
+        stage(0, Kb, koff, sK2[0], false);
+        // (the builtin, not asm: hipcc must KNOW that the Q loads above have landed -- otherwise it puts its own vmcnt(N) waits for them
+        //  inside the loop, where the hardware counter also holds our DMA, and every X phase waits for the tile it just requested)
+        __builtin_amdgcn_s_waitcnt(0);
+        __builtin_amdgcn_s_barrier();
+        tc = clk();
+        const unsigned long long t_begin = tc;
+        // (measured: the first / last step peeled out of the loops and PV ahead of QK^T -- 16 fewer live registers -- ran 9 % SLOWER)
+        if (!late) {
+#ifdef OMX_PP_PRIO
+            if (OMX_PP_PRIO == 0) __builtin_amdgcn_s_setprio(1);
+#endif
+            for (int i = 0; i <= nt; ++i) {
+                fetch(i);
+                if (i < nt) qk(sK2[i & 1]);
+                if (i >= 1) pv(sV2[(i - 1) & 1]);
+                if (TR) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                lap(0); end_even(); lap(2);
+                if (i < nt) softmax(i);
+                lap(1); end_odd(); lap(3);
+            }
+        } else {
+#ifdef OMX_PP_PRIO
+            if (OMX_PP_PRIO == 1) __builtin_amdgcn_s_setprio(1);   // static priority for the younger half (MI355X_MICROARCH.md, item 4)
+#endif
+            for (int i = 0; i <= nt; ++i) {
+                fetch(i);
+                if (i >= 1) softmax(i - 1);
+                lap(1); end_even(); lap(2);
+                if (i < nt) qk(sK2[i & 1]);
+                if (i >= 1) pv(sV2[(i - 1) & 1]);
+                if (TR) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                lap(0); end_odd(); lap(3);
+            }
+        }
+        if (TR && a.trace && lane == 0) {
+            const int L = (int)blockIdx.x + (int)gridDim.x * ((int)blockIdx.y + (int)gridDim.y * (int)blockIdx.z);
+            unsigned long long* tr = a.trace + ((size_t)L * 8 + wave) * 8;
+            tr[0] = tw[0]; tr[1] = tw[1]; tr[2] = tw[2]; tr[3] = tw[3]; tr[4] = clk() - t_begin; tr[5] = (unsigned long long)nt;
+        }
+    }
+
+#pragma unroll
+    for (int w = 0; w < QW; ++w) {
+        const float l_tot = quad_rows_sum(l_run[w]);
+        const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+        if (qrow[w] < a.Tq) {
+            bf16_t* op = a.out + (size_t)b * a.o_bs + (size_t)h * a.o_hs + (size_t)qrow[w] * a.o_ts;
+#pragma unroll
+            for (int t = 0; t < NDT; ++t) {
+                u32x2v wv = {pack_bf16(o[w][t][0] * inv, o[w][t][1] * inv), pack_bf16(o[w][t][2] * inv, o[w][t][3] * inv)};
+                *reinterpret_cast<u32x2v*>(op + t * 16 + rg * 4) = wv;
+            }
+        }
+    }
+}
+
 }  // namespace
 
 int launch_attn_prefill(bf16_t* out, const bf16_t* q, const bf16_t* k, const bf16_t* v, int B, int H, int Hkv, int Tq,
@@ -341,6 +674,32 @@ int launch_attn_prefill(bf16_t* out, const bf16_t* q, const bf16_t* k, const bf1
     }
     // long sequences: 128 query rows per block (each LDS fragment feeds two MFMAs); short ones keep 64-row
     // blocks so that the grid still covers the chip
+    // long sequences: the two-phase kernel, 256 query rows per block, one block per CU (OMX_ATTN_PP=0: the kernels below).  Under a
+    // causal mask its blocks differ in length up to the whole sequence and nothing pairs a long one with a short one on a CU (the
+    // single-phase kernel does, two blocks per CU): 2048 x 32 heads ran 82 us against 65, so causal shapes take it only when the grid is
+    // many rounds deep
+    const char* ppenv = getenv("OMX_ATTN_PP");
+    const long pp_blocks = (long)((Tq + 255) / 256) * H * B;
+    if (ppenv ? atoi(ppenv) != 0 : (Tq >= 1024 && (mask_mode != OMX_MASK_CAUSAL || pp_blocks >= 2048))) {
+        const dim3 grid((Tq + 255) / 256, H, B), block(512);
+        if (const char* te = getenv("OMX_ATTN_PP_TRACE")) {   // timeline build (head_dim 128, no mask): address of a device buffer
+            a.trace = reinterpret_cast<unsigned long long*>(strtoull(te, nullptr, 0));
+            OMX_REQUIRE(D == 128 && mask_mode == OMX_MASK_NONE, "attention timeline build: head_dim 128 without a mask only");
+            attn_prefill_pp_kernel<128, OMX_MASK_NONE, true><<<grid, block, 0, s>>>(a);
+            OMX_LAUNCH_CHECK();
+            return 0;
+        }
+#define OMX_PP_CASE(DD, MM)                                                          \
+    if (D == DD && mask_mode == MM) {                                                \
+        attn_prefill_pp_kernel<DD, MM><<<grid, block, 0, s>>>(a);                    \
+        OMX_LAUNCH_CHECK();                                                          \
+        return 0;                                                                    \
+    }
+#define OMX_PP_MASKS(DD) OMX_PP_CASE(DD, OMX_MASK_NONE) OMX_PP_CASE(DD, OMX_MASK_CAUSAL) OMX_PP_CASE(DD, OMX_MASK_BOOL) OMX_PP_CASE(DD, OMX_MASK_ADDITIVE)
+        OMX_PP_MASKS(128) OMX_PP_MASKS(64)
+#undef OMX_PP_MASKS
+#undef OMX_PP_CASE
+    }
     const char* wenv = getenv("OMX_ATTN_WIDE");
     const bool wide = wenv ? atoi(wenv) != 0 : Tq >= 512;
     const int qblk = wide ? 128 : 64;

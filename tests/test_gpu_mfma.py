@@ -194,6 +194,36 @@ def test_sdpa_prefill_spike_forces_rescale(omx):
     _check(_sdpa(omx, q, k, v, scale, "causal"), rc.scaled_dot_product_attention(q, k, v, scale, "causal", "bf16"))
 
 
+@pytest.mark.parametrize("B,H,Hkv,Tq,Tk,D,mode", [
+    (1, 8, 2, 1100, 1100, 128, "causal"),     # ragged last block and last tile, GQA
+    (1, 8, 8, 700, 700, 128, None),           # joint attention, 8 heads: the XCD-major block order
+    (2, 3, 3, 300, 428, 128, "causal"),       # chunked prefill (Tq < Tk), batch 2, head count not a multiple of 8
+    (1, 4, 2, 520, 520, 64, "causal"),        # head_dim 64
+    (1, 2, 2, 260, 260, 128, "bool"),         # explicit bool mask (sliding window)
+    (1, 2, 1, 257, 300, 64, "additive"),
+    (1, 2, 2, 40, 40, 128, "causal"),         # shorter than one tile
+])
+def test_sdpa_two_phase_kernel(omx, monkeypatch, B, H, Hkv, Tq, Tk, D, mode):
+    """csrc/attn_prefill.hip attn_prefill_pp_kernel (8 waves in two groups one phase apart) walks the same 64-key tiles in the same order
+    with the same arithmetic as the single-phase kernel: outputs bit-equal to OMX_ATTN_PP=0, and on the oracle within the SDPA bound."""
+    q = rc.bf16_round(rand((B, H, Tq, D), 61)); k = rc.bf16_round(rand((B, Hkv, Tk, D), 62)); v = rc.bf16_round(rand((B, Hkv, Tk, D), 63))
+    if mode == "bool":
+        mask = rc.create_causal_mask(Tq, Tk - Tq, 100)
+    elif mode == "additive":
+        mask = rc.bf16_round(rand((Tq, Tk), 64) * 2)
+    else:
+        mask = mode
+    scale = D ** -0.5
+    outs = {}
+    for pp in ("0", "1"):
+        monkeypatch.setenv("OMX_ATTN_PP", pp)
+        outs[pp] = _sdpa(omx, q, k, v, scale, mask)
+    np.testing.assert_array_equal(outs["0"], outs["1"])
+    ref = rc.scaled_dot_product_attention(q, k, v, scale, mask, "bf16")
+    _check(outs["1"], ref)
+    _check(outs["0"], ref)
+
+
 @pytest.mark.parametrize("M,N,K,bias", [(501, 512, 560, True), (501, 2048, 512, True), (501, 512, 2048, True), (216, 8404, 512, True),
                                          (33, 70, 45, False), (1, 64, 64, False), (130, 66, 1026, True)])
 def test_linear_f32_on_the_f32_matrix_cores(omx, M, N, K, bias):

@@ -215,7 +215,12 @@ int omx_qwen3_last_logits(omx_qwen3 m, void* host_bf16, int n);
  *           greedy_out[n-1].  Single-rank bf16 models.  verify_logits: bf16 logits [V] of one row of the last verify call.
  *   trim:   KeyValueCache::trim(n), the operation :165-169 notes the reference's cache trait lacks: forget the last n cached tokens
  *           and make next_token the pending input token (n = 0: only replace the token).                                             */
+/*           With a sampler set (temperature != 0) each row's token is drawn categorical(logits / T) with the next key of the model's
+ *           sequence (speculative.rs:104-109, :145-148) instead of the argmax.
+ *   sampler_state: the two words of the key sequence (mlx-rs RandomState); set != 0 writes them.  The reference draws the draft's and
+ *           the target's tokens from ONE global sequence: two models reproduce it by handing the state over.                        */
 int omx_qwen3_verify(omx_qwen3 m, const uint32_t* tokens, int n, uint32_t* greedy_out);
+int omx_qwen3_sampler_state(omx_qwen3 m, uint32_t* state2, int set);
 int omx_qwen3_verify_logits(omx_qwen3 m, int row, void* host_bf16, int n);
 int omx_qwen3_trim(omx_qwen3 m, int n, uint32_t next_token);
 /* timing of the last omx_qwen3_decode call measured with HIP events on the engine stream (ms)       */

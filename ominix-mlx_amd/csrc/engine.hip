@@ -1433,6 +1433,18 @@ int omx_qwen3_set_sampler(omx_qwen3 m, float temperature, uint64_t seed) {
     return 0;
 }
 
+/* The sampler's key-sequence state (mlx-rs RandomState: two words).  The reference's speculative loop draws the draft's and the
+ * target's tokens from ONE global sequence (speculative.rs:104-109: `categorical!` without a key); two engine models reproduce that by
+ * handing this state back and forth.  set != 0 writes `state2` into the model, otherwise the model's state is read out. */
+int omx_qwen3_sampler_state(omx_qwen3 m, uint32_t* state2, int set) {
+    OMX_REQUIRE(m && state2, "omx_qwen3_sampler_state: null argument");
+    OMX_REQUIRE(m->rng, "omx_qwen3_sampler_state: no sampler set (omx_qwen3_set_sampler)");
+    if (set) OMX_HIP_CHECK(hipMemcpyAsync(m->rng, state2, 8, hipMemcpyHostToDevice, m->stream));
+    else OMX_HIP_CHECK(hipMemcpyAsync(state2, m->rng, 8, hipMemcpyDeviceToHost, m->stream));
+    OMX_HIP_CHECK(hipStreamSynchronize(m->stream));
+    return 0;
+}
+
 int omx_qwen3_encode(omx_qwen3 m, const uint32_t* ids, int n, const uint8_t* attention_mask, const int* tap_layers, int n_taps,
                      void* out_dev) {
     OMX_REQUIRE(m && ids && tap_layers && out_dev, "omx_qwen3_encode: null argument");
@@ -1568,7 +1580,18 @@ int omx_qwen3_verify(omx_qwen3 m, const uint32_t* tokens, int n, uint32_t* greed
     // [final RMSNorm rows] -> [lm_head GEMM, n x V] -> [argmax per row]   (model.rs:423, 480-489; sampler.rs:9-18 at temperature 0)
     if (omx_rms_norm(m->pf_xn, m->pf_h, m->final_norm, n, hd, m->cfg.rms_norm_eps, OMX_BFLOAT16, s)) return 1;
     if (launch_gemm_bf16(m->verify_logits, m->pf_xn, m->lm_head, nullptr, n, V, hd, s)) return 1;
-    if (omx_argmax(m->verify_tokens, m->verify_logits, n, V, OMX_BFLOAT16, s)) return 1;
+    if (m->temperature == 0.f) {
+        if (omx_argmax(m->verify_tokens, m->verify_logits, n, V, OMX_BFLOAT16, s)) return 1;
+    } else {
+        // speculative.rs:104-109 + :145-148: every position draws categorical(logits / T) with the NEXT key of the sequence -- one
+        // [1, V] draw per row, exactly what a decode step does with its row
+        for (int i = 0; i < n; ++i) {
+            if (launch_rng_next(m->rng, s)) return 1;
+            if (omx_random_categorical(m->verify_tokens + i, m->verify_logits + (size_t)i * V, 1, V, 1, 1.0f / m->temperature, m->rng + 2,
+                                       OMX_BFLOAT16, (omx_stream)s))
+                return 1;
+        }
+    }
     OMX_HIP_CHECK(hipMemcpyAsync(greedy_out, m->verify_tokens, (size_t)n * 4, hipMemcpyDeviceToHost, s));
     OMX_HIP_CHECK(hipStreamSynchronize(s));
     st.pos += n;

@@ -34,6 +34,7 @@ ENGINE_SIGNATURES = {
     "omx_qwen3_synth_weights": (c_int, [c_void_p, c_uint32]),
     "omx_qwen3_set_comm": (c_int, [c_void_p, c_void_p, c_void_p]),
     "omx_qwen3_set_sampler": (c_int, [c_void_p, ctypes.c_float, ctypes.c_uint64]),
+    "omx_qwen3_sampler_state": (c_int, [c_void_p, c_void_p, c_int]),
     "omx_qwen3_encode": (c_int, [c_void_p, ctypes.POINTER(c_uint32), c_int, c_void_p, ctypes.POINTER(c_int), c_int, c_void_p]),
     "omx_qwen3_reset": (c_int, [c_void_p]),
     "omx_qwen3_offset": (c_int, [c_void_p, ctypes.POINTER(c_int)]),
@@ -227,6 +228,17 @@ class Model:
         """DefaultSampler (mlx-rs-core/src/sampler.rs:9-18): 0 = greedy, otherwise categorical(logits / temperature)
         drawn on the device with the key sequence of `mlx_rs::random::seed(seed)`."""
         check(lib.omx_qwen3_set_sampler(self._h, float(temperature), int(seed) & 0xFFFFFFFFFFFFFFFF))
+
+    def sampler_state(self) -> tuple:
+        """The two words of the sampler's key sequence (after set_sampler): the reference's speculative loop draws both models' tokens from
+        ONE global sequence, which two models reproduce by handing this state over (speculative.py)."""
+        st = (c_uint32 * 2)()
+        check(lib.omx_qwen3_sampler_state(self._h, st, 0))
+        return int(st[0]), int(st[1])
+
+    def set_sampler_state(self, state) -> None:
+        st = (c_uint32 * 2)(int(state[0]), int(state[1]))
+        check(lib.omx_qwen3_sampler_state(self._h, st, 1))
 
     def reset(self) -> None:
         check(lib.omx_qwen3_reset(self._h))

@@ -15,6 +15,11 @@ What the reference module does (file:line) and where it stops short of what its 
 With those two completions the greedy (temperature 0) output is EXACTLY the target model's own greedy sequence, whatever the draft
 model proposes -- the size-independent property tests/ hold the GPU implementation to.  The reference has no test for this module
 (:305-308 is an empty test module): parity is pinned on that invariant, not on vectors.
+  * :104-109  sample(): temperature != 0 -> categorical(logits * (1 / temperature)) with NO key: each call takes the next key of MLX's
+              global sequence (mlx-rs/src/random.rs:21-41).  Program order of the draws: the first token (:222), then per round the k
+              draft draws (:118-121) and the k + 1 target draws (:145-148).  `speculative_generate(..., temp, seed)` restates exactly
+              that with one `mlx_rng.RandomState(seed)`; acceptance stays token equality (:277-281), so every emitted token is the
+              target's own draw at its position.  (The all-accepted case's extra draft forward draws nothing here: only its cache matters.)
 """
 from __future__ import annotations
 
@@ -30,24 +35,34 @@ def _trim(caches: List, n: int) -> None:
         c.trim(n)
 
 
-def speculative_generate(target, draft, prompt: np.ndarray, num_draft_tokens: int, max_tokens: int) -> Iterator[Tuple[int, bool, np.ndarray]]:
-    """Yields (token, from_draft, target logprobs [V]) -- SpeculativeToken, speculative.rs:18-25 -- for `max_tokens` tokens, greedy."""
+def speculative_generate(target, draft, prompt: np.ndarray, num_draft_tokens: int, max_tokens: int, temp: float = 0.0,
+                         seed: int = 0) -> Iterator[Tuple[int, bool, np.ndarray]]:
+    """Yields (token, from_draft, target logprobs [V]) -- SpeculativeToken, speculative.rs:18-25 -- for `max_tokens` tokens; temp == 0:
+    greedy, otherwise every draw is categorical(logits / temp) with the next key of ONE sequence seeded with `seed`."""
+    from . import mlx_rng
+    state = mlx_rng.RandomState(seed)
+
+    def draw(lg):      # speculative.rs:104-109 over rows [n, V]: one key per row, in row order
+        if temp == 0.0:
+            return rc.sample_greedy(lg)
+        return np.array([int(rc.sample(row[None, :], temp, state.next())[0]) for row in np.asarray(lg)], np.uint32)
+
     t_cache, d_cache = [], []
     prompt = np.asarray(prompt)[None, :].astype(np.int64)
     logits = target.forward(prompt, t_cache)[:, -1, :]                     # :208-214, 222
     draft.forward(prompt, d_cache)                                        # :217-219
-    last = int(rc.sample_greedy(logits)[0])
+    last = int(draw(logits)[0])
     yield last, False, _logprobs(logits[0])
     emitted = 1
     while emitted < max_tokens:
         drafts, cur = [], last
         for _ in range(num_draft_tokens):                                  # :111-127
             lg = draft.forward(np.array([[cur]], np.int64), d_cache)[:, -1, :]
-            cur = int(rc.sample_greedy(lg)[0])
+            cur = int(draw(lg)[0])
             drafts.append(cur)
         seq = np.array([[last] + drafts], np.int64)                        # :257-270
         lg = target.forward(seq, t_cache)[0]                               # :137  [k + 1, V]
-        t_tokens = [int(t) for t in rc.sample_greedy(lg)]
+        t_tokens = [int(t) for t in draw(lg)]
         accepted = 0
         while accepted < num_draft_tokens and drafts[accepted] == t_tokens[accepted]:   # :277-292
             accepted += 1

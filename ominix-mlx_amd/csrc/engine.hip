@@ -384,6 +384,14 @@ bool attention_takes_oproj(omx_qwen3 m) {
     return c.quant_bits == 0 && attn_step_oproj_ok(m->H, m->Hkv, c.head_dim, m->attn_nsplit, c.hidden_size);
 }
 
+// OMX_PEER_FUSED: a GEMV whose blocks poll their peers' stores must be resident as a whole -- a block waiting for a peer's row while
+// that peer's matching block waits for a free CU behind OUR unscheduled blocks never finishes (it gives up after 2^23 polls and voids
+// the step).  The streaming kernels hold at least two 4-wave blocks per CU (<= 256 VGPRs, a few KB of LDS); beyond that the standalone
+// all-reduce launch follows the GEMV as usual.
+bool peer_fused_fits(omx_qwen3 m, int N, int K) {
+    return m->peer_dev != nullptr && gemv_grid(N, K, EPI_F32, 0) <= 2 * m->cus;
+}
+
 // the attention launch of layer l of a decode step (both the bf16 and the packed-weight step use the bf16 KV kernels);
 // resid / out != null: the layer's O projection + residual rides in the same launch (attention_takes_oproj)
 int enqueue_attention(omx_qwen3 m, int l, hipStream_t s, const bf16_t* resid = nullptr, bf16_t* out = nullptr, float* out_f32 = nullptr) {
@@ -659,10 +667,10 @@ int enqueue_step(omx_qwen3 m, bool with_head) {
                 bf16_t* t = h; h = hn; hn = t;
             } else {
                 a.out = m->partial_a;
-                a.peer = m->peer_dev;   // peer-store communicator: the rows are reduced over the ranks inside this launch
+                a.peer = peer_fused_fits(m, a.N, a.K) ? m->peer_dev : nullptr;   // peer-store communicator: the rows are reduced over the ranks inside this launch
                 if (launch_gemv(a, PRO_NONE, EPI_F32, s)) return 1;
                 OMX_REQUIRE(m->allreduce != nullptr, "tp_size > 1 but no communicator set (omx_qwen3_set_comm)");
-                if (!m->peer_dev)
+                if (!a.peer)
                     OMX_REQUIRE(m->allreduce(m->partial_a, m->partial_a, hd, kNcclFloat32, kNcclSum, m->comm, s) == 0, "ncclAllReduce failed");
                 pending = m->partial_a;
             }
@@ -718,9 +726,9 @@ int enqueue_step(omx_qwen3 m, bool with_head) {
                 bf16_t* t = h; h = hn; hn = t;
             } else {
                 a.out = m->partial_b;
-                a.peer = m->peer_dev;
+                a.peer = peer_fused_fits(m, a.N, a.K) ? m->peer_dev : nullptr;
                 if (launch_gemv(a, PRO_NONE, EPI_F32, s)) return 1;
-                if (!m->peer_dev)
+                if (!a.peer)
                     OMX_REQUIRE(m->allreduce(m->partial_b, m->partial_b, hd, kNcclFloat32, kNcclSum, m->comm, s) == 0, "ncclAllReduce failed");
                 pending = m->partial_b;
             }

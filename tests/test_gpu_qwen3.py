@@ -618,6 +618,10 @@ def test_peer_store_allreduce_across_processes(omx, tmp_path, fused):
     res = [json.load(open(tmp_path / f"rank{r}.json")) for r in range(2)]
     for r in res:
         assert r["self_test"] and not r["aborted"] and not r["aborted_after_loop"]
+        # per-call latency report (what a first multi-GPU run is read from): three sizes, ordered percentiles, every call counted
+        assert [h["n_floats"] for h in r["latency_us"]] == [4096, 2, 4096 * 64]
+        for h in r["latency_us"]:
+            assert 0 < h["min"] <= h["p50"] <= h["p90"] <= h["p99"] <= h["max"] and sum(h["log2_buckets_us"].values()) == h["calls"]
     assert res[0]["tokens"] == res[1]["tokens"]
     assert res[0]["decode_path"] == "graph"          # the peer all-reduce is an ordinary kernel: the step stays captured
     # the same two shards through the in-process communicator (same rank-ordered f32 sums)

@@ -2,7 +2,8 @@
 (gloo bootstrap, so that two ranks may share the one GPU of a test box; on a multi-GPU node every rank takes its LOCAL_RANK device
 and the stores cross xGMI).  Each rank: self-test against the rank-ordered sum, latency of a 4096-float reduction, then a
 tensor-parallel greedy decode of a small Qwen3 through the engine with every all-reduce (hidden partials, argmax key) on the peer
-path -- serial prefill, so no call needs RCCL.  Rank r writes <out>/rank<r>.json.
+path -- serial prefill, so no call needs RCCL.  Rank r writes <out>/rank<r>.json; rank 0 also prints per-call latency percentiles and a
+log2 histogram for the step's reduction sizes.
 usage: python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1 --master-port P tools/peer_allreduce_check.py <out dir> [8b]"""
 import json
 import os
@@ -45,6 +46,33 @@ for _ in range(reps):
 omx.ops.synchronize()
 res["allreduce_16k_us"] = (time.perf_counter() - t0) * 1e6 / reps
 res["aborted_after_loop"] = pc.aborted()
+
+
+def latency_histogram(n_floats, calls=400):
+    """PER-CALL latency of the reduction (each call issued and synchronised on its own, all ranks entering together only at the start:
+    rank skew shows up as a tail): percentiles and a log2 histogram in microseconds -- enough to read a first multi-GPU run from its log."""
+    buf = T.from_numpy(np.ones(n_floats, np.float32), "f32")
+    omx.ops.synchronize()
+    dist.barrier()
+    us = np.empty(calls)
+    for i in range(calls):
+        a = time.perf_counter()
+        omx.lib.omx_peer_allreduce(buf.ptr, buf.ptr, n_floats, comm.NCCL_FLOAT32, 0, pc.comm, None)
+        omx.ops.synchronize()
+        us[i] = (time.perf_counter() - a) * 1e6
+    edges = [0] + [2 ** k for k in range(1, 15)]
+    hist = np.histogram(us, bins=edges + [1e12])[0]
+    return {"n_floats": n_floats, "calls": calls, "min": round(float(us.min()), 2), "p50": round(float(np.percentile(us, 50)), 2),
+            "p90": round(float(np.percentile(us, 90)), 2), "p99": round(float(np.percentile(us, 99)), 2), "max": round(float(us.max()), 2),
+            "log2_buckets_us": {f"<{edges[i + 1]}" if i + 1 < len(edges) else f">={edges[-1]}": int(c) for i, c in enumerate(hist) if c}}
+
+
+# the two sizes of a TP decode step (hidden-sized f32 partials; the 8-byte argmax key goes through the same path) and a prefill-sized one
+res["latency_us"] = [latency_histogram(n) for n in (4096, 2, 4096 * 64)]
+if rank == 0:
+    for h in res["latency_us"]:
+        print(f"[peer all-reduce] {h['n_floats']:>7d} f32 x {h['calls']} calls, us per call (host clock incl. launch + sync): "
+              f"min {h['min']} p50 {h['p50']} p90 {h['p90']} p99 {h['p99']} max {h['max']}  {h['log2_buckets_us']}", flush=True)
 
 cfg = dict(hidden_size=1024, num_hidden_layers=2, intermediate_size=3072, num_attention_heads=8, num_key_value_heads=2, head_dim=128,
            vocab_size=4096, rms_norm_eps=1e-6, rope_theta=1e6, tie_word_embeddings=False)

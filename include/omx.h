@@ -177,6 +177,9 @@ typedef struct omx_qwen3_config_ {
     /* Qwen2 wiring (qwen3-mlx/src/qwen2.rs:100-218): q/k/v projections carry a bias ("self_attn.{q,k,v}_proj.bias") and the
      * attention has no q/k norm (set no_qk_norm too); bf16; under tensor parallelism the biases are sharded like their rows */
     int attention_bias;
+    /* quantized checkpoints only: scales / biases are float16 (an MLX float16 checkpoint; nn/quantized.rs:361-385 takes any float).
+     * They enter the arithmetic as their exact float32 values; activations and outputs stay bf16.  Dense decoders (not with experts). */
+    int quant_scales_f16;
 } omx_qwen3_config;
 typedef struct omx_qwen3_* omx_qwen3;
 

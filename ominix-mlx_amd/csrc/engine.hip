@@ -34,6 +34,7 @@
 #include "launch_timing.hpp"
 #include "peer.hpp"
 #include "step_engine.hpp"
+#include <hip/hip_fp16.h>
 
 namespace omx {
 namespace {
@@ -70,7 +71,7 @@ template <int BITS>
 __global__ __launch_bounds__(256) void qembed_kernel(bf16_t* __restrict__ h, const uint32_t* __restrict__ w,
                                                      const bf16_t* __restrict__ scales, const bf16_t* __restrict__ biases,
                                                      const StepState* st, int hidden, int group, unsigned* seq, float* rope_cur,
-                                                     const float* rope_cos, const float* rope_sin, int half) {
+                                                     const float* rope_cos, const float* rope_sin, int half, bool scales_f16) {
     constexpr int EPW = 32 / BITS;
     step_begin(st, seq, rope_cur, rope_cos, rope_sin, half);
     const size_t row = st->cur_token;
@@ -78,8 +79,9 @@ __global__ __launch_bounds__(256) void qembed_kernel(bf16_t* __restrict__ h, con
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < words; i += gridDim.x * blockDim.x) {
         const uint32_t wd = w[row * words + i];
         const int g = i * EPW / group;
-        const float sc = bf16_to_f32(scales[row * (hidden / group) + g]);
-        const float bi = biases ? bf16_to_f32(biases[row * (hidden / group) + g]) : 0.f;
+        const bf16_t sb16 = scales[row * (hidden / group) + g], bb16 = biases ? biases[row * (hidden / group) + g] : (bf16_t)0;
+        const float sc = scales_f16 ? __half2float(__ushort_as_half(sb16)) : bf16_to_f32(sb16);
+        const float bi = scales_f16 ? __half2float(__ushort_as_half(bb16)) : bf16_to_f32(bb16);
 #pragma unroll
         for (int e = 0; e < EPW; ++e) h[i * EPW + e] = f32_to_bf16((float)((wd >> (e * BITS)) & ((1u << BITS) - 1u)) * sc + bi);
     }
@@ -379,7 +381,7 @@ bool attention_takes_oproj(omx_qwen3 m) {
     // every block of that launch waits on others: all Hkv * nsplit of them must be resident, one per CU
     if (off || m->oproj_disabled || m->Hkv * m->attn_nsplit > m->cus) return false;
     if (c.quant_bits == 4)   // 4-bit checkpoint: the packed O matrix with its interleaved scale | bias words (built at load for K % 2048 == 0)
-        return c.ep_size <= 1 && c.tp_size <= 1 && !m->qlayers.empty() && m->qlayers[0].o.sb != nullptr &&
+        return c.ep_size <= 1 && c.tp_size <= 1 && !c.quant_scales_f16 && !m->qlayers.empty() && m->qlayers[0].o.sb != nullptr &&
                attn_step_oproj_q4_ok(m->H, m->Hkv, c.head_dim, m->attn_nsplit, c.hidden_size, c.quant_group);
     return c.quant_bits == 0 && attn_step_oproj_ok(m->H, m->Hkv, c.head_dim, m->attn_nsplit, c.hidden_size);
 }
@@ -434,10 +436,11 @@ int enqueue_step_quant(omx_qwen3 m, bool with_head) {
     const omx_qwen3_config& c = m->cfg;
     hipStream_t s = m->stream;
     const int hd = c.hidden_size, D = c.head_dim, bits = c.quant_bits, group = c.quant_group;
+    const bool sf16 = c.quant_scales_f16 != 0;
     if (bits == 4) qembed_kernel<4><<<4, 256, 0, s>>>(m->h, m->q_embed.w, m->q_embed.scales, m->q_embed.biases, m->st, hd, group, m->step_seq,
-                                                      m->rope_cur, m->rope_cos, m->rope_sin, D / 2);
+                                                      m->rope_cur, m->rope_cos, m->rope_sin, D / 2, sf16);
     else qembed_kernel<8><<<4, 256, 0, s>>>(m->h, m->q_embed.w, m->q_embed.scales, m->q_embed.biases, m->st, hd, group, m->step_seq, m->rope_cur,
-                                            m->rope_cos, m->rope_sin, D / 2);
+                                            m->rope_cos, m->rope_sin, D / 2, sf16);
     OMX_LAUNCH_CHECK();
     bf16_t* h = m->h;
     bf16_t* hn = m->h2;
@@ -448,7 +451,7 @@ int enqueue_step_quant(omx_qwen3 m, bool with_head) {
             QGemvArgs a = {};
             a.m[0] = Q.q; a.m[1] = Q.k; a.m[2] = Q.v;
             a.N = (m->H + 2 * m->Hkv) * D; a.K = hd; a.group = group;
-            a.x = h; a.norm_w = L.in_ln; a.eps = c.rms_norm_eps; a.out = m->qkv;
+            a.x = h; a.norm_w = L.in_ln; a.eps = c.rms_norm_eps; a.out = m->qkv; a.scales_f16 = sf16;
             if (launch_qgemv(a, bits, PRO_RMSNORM, EPI_STORE, s)) return 1;
         }
         const bool fused_o = attention_takes_oproj(m);
@@ -459,7 +462,7 @@ int enqueue_step_quant(omx_qwen3 m, bool with_head) {
         } else {   // [O + residual]
             QGemvArgs a = {};
             a.m[0] = Q.o; a.N = hd; a.K = m->H * D; a.group = group;
-            a.x = m->attn_out; a.resid = h; a.out = hn;
+            a.x = m->attn_out; a.resid = h; a.out = hn; a.scales_f16 = sf16;
             if (launch_qgemv(a, bits, PRO_NONE, EPI_RESIDUAL, s)) return 1;
             bf16_t* t = h; h = hn; hn = t;
         }
@@ -475,13 +478,13 @@ int enqueue_step_quant(omx_qwen3 m, bool with_head) {
         {   // [RMSNorm + gate/up + SwiGLU]
             QGemvArgs a = {};
             a.m[0] = Q.gate; a.m[1] = Q.up; a.N = m->I; a.K = hd; a.group = group;
-            a.x = h; a.norm_w = L.post_ln; a.eps = c.rms_norm_eps; a.out = m->act;
+            a.x = h; a.norm_w = L.post_ln; a.eps = c.rms_norm_eps; a.out = m->act; a.scales_f16 = sf16;
             if (launch_qgemv(a, bits, PRO_RMSNORM, EPI_SWIGLU, s)) return 1;
         }
         {   // [down + residual]
             QGemvArgs a = {};
             a.m[0] = Q.down; a.N = hd; a.K = m->I; a.group = group;
-            a.x = m->act; a.resid = h; a.out = hn;
+            a.x = m->act; a.resid = h; a.out = hn; a.scales_f16 = sf16;
             if (launch_qgemv(a, bits, PRO_NONE, EPI_RESIDUAL, s)) return 1;
             bf16_t* t = h; h = hn; hn = t;
         }
@@ -489,7 +492,7 @@ int enqueue_step_quant(omx_qwen3 m, bool with_head) {
     if (with_head) {
         QGemvArgs a = {};
         a.m[0] = m->q_head; a.m[0].n = m->V; a.N = m->V; a.K = hd; a.group = group;
-        a.x = h; a.norm_w = m->final_norm; a.eps = c.rms_norm_eps; a.out = m->logits;
+        a.x = h; a.norm_w = m->final_norm; a.eps = c.rms_norm_eps; a.out = m->logits; a.scales_f16 = sf16;
         a.argmax_slot = m->argmax_partials;
         if (launch_qgemv(a, bits, PRO_RMSNORM, EPI_ARGMAX, s)) return 1;
         if (add_sampling_noise(m, s)) return 1;
@@ -839,7 +842,7 @@ int enqueue_head_on_row(omx_qwen3 m, const bf16_t* row, hipStream_t s) {
     if (c.quant_bits > 0) {
         QGemvArgs a = {};
         a.m[0] = m->q_head; a.m[0].n = m->V; a.N = m->V; a.K = hd; a.group = c.quant_group;
-        a.x = row; a.norm_w = m->final_norm; a.eps = c.rms_norm_eps; a.out = m->logits;
+        a.x = row; a.norm_w = m->final_norm; a.eps = c.rms_norm_eps; a.out = m->logits; a.scales_f16 = c.quant_scales_f16 != 0;
         a.argmax_slot = m->argmax_partials;
         if (launch_qgemv(a, c.quant_bits, PRO_RMSNORM, EPI_ARGMAX, s)) return 1;
     } else {
@@ -955,7 +958,7 @@ int prefill_prefix_batched(omx_qwen3 m, int T, int off, const EncodeOpts* enc = 
     // `at`: element offset inside the scratch, so that the members of one segmented launch (q | k | v, gate | up) coexist
     auto W = [&](const bf16_t* dense, const QMat* qm, int K, size_t at = 0) -> const bf16_t* {
         if (!quant) return dense;
-        if (omx_dequantize(m->dq_buf + at, qm->w, qm->scales, qm->biases, qm->n, K, c.quant_group, c.quant_bits, OMX_BFLOAT16, s)) return nullptr;
+        if (launch_dequantize_bf16(m->dq_buf + at, qm->w, qm->scales, qm->biases, qm->n, K, c.quant_group, c.quant_bits, c.quant_scales_f16 != 0, s)) return nullptr;
         return m->dq_buf + at;
     };
     if (quant) {
@@ -975,7 +978,7 @@ int prefill_prefix_batched(omx_qwen3 m, int T, int off, const EncodeOpts* enc = 
         if (omx_take_rows(rows_w, m->q_embed.w, m->prompt_dev, T, wpr, OMX_FLOAT32, s)) return 1;
         if (omx_take_rows(rows_s, m->q_embed.scales, m->prompt_dev, T, gpr, OMX_BFLOAT16, s)) return 1;
         if (omx_take_rows(rows_b, m->q_embed.biases, m->prompt_dev, T, gpr, OMX_BFLOAT16, s)) return 1;
-        if (omx_dequantize(m->pf_h, rows_w, rows_s, rows_b, T, hd, c.quant_group, c.quant_bits, OMX_BFLOAT16, s)) return 1;
+        if (launch_dequantize_bf16(m->pf_h, (const uint32_t*)rows_w, rows_s, rows_b, T, hd, c.quant_group, c.quant_bits, c.quant_scales_f16 != 0, s)) return 1;
     } else if (omx_take_rows(m->pf_h, m->embed, m->prompt_dev, T, hd, OMX_BFLOAT16, s)) {
         return 1;
     }
@@ -1138,6 +1141,8 @@ int omx_qwen3_create(omx_qwen3* out, const omx_qwen3_config* cfg) {
     if (m->cfg.quant_bits && m->cfg.quant_group == 0) m->cfg.quant_group = 64;     // nn/quantized.rs:330-333
     OMX_REQUIRE(!m->cfg.quant_bits || m->cfg.quant_group == 32 || m->cfg.quant_group == 64 || m->cfg.quant_group == 128,
                 "InvalidConfig: quantization group_size %d (32, 64, 128)", m->cfg.quant_group);
+    OMX_REQUIRE(!m->cfg.quant_scales_f16 || (m->cfg.quant_bits && m->cfg.num_experts == 0 && m->cfg.tp_size <= 1),
+                "InvalidConfig: float16 scales / biases are taken by single-rank quantized dense decoders only");
     m->H = c.num_attention_heads / c.tp_size;
     m->Hkv = c.num_key_value_heads >= c.tp_size ? c.num_key_value_heads / c.tp_size : 1;
     m->I = c.intermediate_size / c.tp_size;
@@ -1299,6 +1304,7 @@ int omx_qwen3_set_weight(omx_qwen3 m, const char* name, const void* ptr, size_t 
 
 int omx_qwen3_synth_weights(omx_qwen3 m, uint32_t base_seed) {
     OMX_REQUIRE(m, "omx_qwen3_synth_weights: null model");
+    OMX_REQUIRE(!m->cfg.quant_scales_f16, "omx_qwen3_synth_weights: the device generator quantises in bf16; a float16-scale model takes uploaded triplets");
     const omx_qwen3_config& c = m->cfg;
     const int D = c.head_dim, hd = c.hidden_size, r = c.tp_rank;
     const float amp_w = (float)(0.02 * sqrt(3.0)), amp_n = (float)(0.01 * sqrt(3.0));   // == oracle/synth.py

@@ -13,6 +13,7 @@
 //     + bias * sum(x_i), the per-chunk sum(x_i) being shared by all rows (computed once per block into LDS).
 //     grid.y walks the activation rows / expert-selected batch entries (gather_qmm).
 //   * M > 16 (prefill): dequantise W once into the workspace, then the bf16 MFMA GEMM (gemm.hip).
+#include <hip/hip_fp16.h>
 #include "common.hpp"
 #include "gemm.hpp"
 #include <mutex>
@@ -80,15 +81,23 @@ __global__ __launch_bounds__(256) void quantize_kernel(uint32_t* __restrict__ pa
     if (e0 < group && (lane % lanes_per_word) == 0) packed[(g * group + e0) / EPW] = word;
 }
 
+// a 16-bit scale / bias pattern as float32: bfloat16, or float16 for a float16 checkpoint
+template <bool F16>
+__device__ __forceinline__ float scale_to_f32(uint16_t bits) {
+    if (F16) return __half2float(__ushort_as_half(bits));
+    return bf16_to_f32((bf16_t)bits);
+}
+
 template <int BITS>
 __global__ __launch_bounds__(256) void dequantize_kernel(bf16_t* __restrict__ out, const uint32_t* __restrict__ packed,
                                                          const bf16_t* __restrict__ scales, const bf16_t* __restrict__ biases,
-                                                         int64_t n_words, int group) {
+                                                         int64_t n_words, int group, bool scales_f16 = false) {
     constexpr int EPW = 32 / BITS;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_words; i += (int64_t)gridDim.x * blockDim.x) {
         const uint32_t wd = packed[i];
         const int64_t g = i * EPW / group;
-        const float s = bf16_to_f32(scales[g]), b = biases ? bf16_to_f32(biases[g]) : 0.f;
+        const float s = scales_f16 ? scale_to_f32<true>(scales[g]) : bf16_to_f32(scales[g]);
+        const float b = biases ? (scales_f16 ? scale_to_f32<true>(biases[g]) : bf16_to_f32(biases[g])) : 0.f;
         bf16_t o[EPW];
 #pragma unroll
         for (int e = 0; e < EPW; ++e) o[e] = f32_to_bf16((float)((wd >> (e * BITS)) & ((1u << BITS) - 1u)) * s + b);
@@ -108,7 +117,7 @@ __device__ __forceinline__ uint64_t qargmax_key(float v, uint32_t idx) {
 // PRO / EPI as in gemv.hip (same arithmetic and rounding points): RMSNorm prologue; store, residual add, SwiGLU
 // over (gate, up) row pairs, logits + greedy-argmax partial.
 // SB: scales and biases come interleaved from QMat::sb (one load per row and step instead of two)
-template <int BITS, int W, int PRO, int EPI, int RB, bool SB = false>
+template <int BITS, int W, int PRO, int EPI, int RB, bool SB = false, bool F16S = false>
 __global__ __launch_bounds__(256) void qgemv_kernel(const QGemvArgs a) {
     constexpr int EPW = 32 / BITS, EPL = W * EPW;          // elements per lane per step
     constexpr int LR = (EPI == EPI_SWIGLU) ? 2 : 1;         // physical rows per logical row
@@ -206,8 +215,8 @@ __global__ __launch_bounds__(256) void qgemv_kernel(const QGemvArgs a) {
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
             float d = 0.f;
-            const float scl = SB ? bf16lo(u.sbv[r]) : bf16_to_f32(u.sc[r]);
-            float bia = SB ? bf16hi(u.sbv[r]) : bf16_to_f32(u.bi[r]);
+            const float scl = SB ? (F16S ? scale_to_f32<true>((uint16_t)u.sbv[r]) : bf16lo(u.sbv[r])) : scale_to_f32<F16S>(u.sc[r]);
+            float bia = SB ? (F16S ? scale_to_f32<true>((uint16_t)(u.sbv[r] >> 16)) : bf16hi(u.sbv[r])) : scale_to_f32<F16S>(u.bi[r]);
 #pragma unroll
             for (int wi = 0; wi < W; ++wi) {
                 const uint32_t wdw = u.wd[r][wi];
@@ -355,20 +364,23 @@ int launch_qgemv_w(const QGemvArgs& a, int pro, int epi, hipStream_t s) {
     bool sb = W == 4;
     for (int i = 0; i < 3 && sb; ++i)
         if (a.m[i].w && !a.m[i].sb) sb = false;
+#define OMX_QGEMV_LAUNCH(P, E, SBF, F16)                                                       \
+    {                                                                                         \
+        if (E == EPI_SWIGLU || a.rows_per_wave == 2) qgemv_kernel<BITS, W, P, E, 2, SBF, F16><<<grid, block, shmem, s>>>(a); \
+        else qgemv_kernel<BITS, W, P, E, 4, SBF, F16><<<grid, block, shmem, s>>>(a);          \
+        OMX_LAUNCH_CHECK();                                                                   \
+        return 0;                                                                             \
+    }
 #define OMX_QGEMV_CASE(P, E)                                                                  \
     if (pro == P && epi == E) {                                                               \
         if constexpr (W == 4) {                                                               \
             if (sb) {                                                                         \
-                if (E == EPI_SWIGLU || a.rows_per_wave == 2) qgemv_kernel<BITS, W, P, E, 2, true><<<grid, block, shmem, s>>>(a); \
-                else qgemv_kernel<BITS, W, P, E, 4, true><<<grid, block, shmem, s>>>(a);      \
-                OMX_LAUNCH_CHECK();                                                           \
-                return 0;                                                                     \
+                if (a.scales_f16) OMX_QGEMV_LAUNCH(P, E, true, true)                          \
+                OMX_QGEMV_LAUNCH(P, E, true, false)                                           \
             }                                                                                 \
         }                                                                                     \
-        if (E == EPI_SWIGLU || a.rows_per_wave == 2) qgemv_kernel<BITS, W, P, E, 2><<<grid, block, shmem, s>>>(a); \
-        else qgemv_kernel<BITS, W, P, E, 4><<<grid, block, shmem, s>>>(a);                     \
-        OMX_LAUNCH_CHECK();                                                                   \
-        return 0;                                                                             \
+        if (a.scales_f16) OMX_QGEMV_LAUNCH(P, E, false, true)                                 \
+        OMX_QGEMV_LAUNCH(P, E, false, false)                                                  \
     }
     OMX_QGEMV_CASE(PRO_NONE, EPI_STORE)
     OMX_QGEMV_CASE(PRO_RMSNORM, EPI_STORE)
@@ -377,6 +389,7 @@ int launch_qgemv_w(const QGemvArgs& a, int pro, int epi, hipStream_t s) {
     OMX_QGEMV_CASE(PRO_NONE, EPI_SWIGLU)
     OMX_QGEMV_CASE(PRO_RMSNORM, EPI_ARGMAX)
 #undef OMX_QGEMV_CASE
+#undef OMX_QGEMV_LAUNCH
     return set_error("quantized gemv: unsupported prologue/epilogue combination %d/%d", pro, epi);
 }
 
@@ -398,8 +411,9 @@ int launch_qgemv_bits(const QGemvArgs& a_in, int pro, int epi, hipStream_t s) {
     return set_error("quantized gemv: K=%d too small for %d-bit weights", a.K, BITS);
 }
 
-int check_format(const char* who, int K, int group, int bits, int dtype) {
-    OMX_REQUIRE(dtype == OMX_BFLOAT16, "%s: bf16 activations / scales only (got dtype %d)", who, dtype);
+// dtype: OMX_BFLOAT16, or OMX_FLOAT16 where `f16_scales_ok` -- scales / biases of a float16 checkpoint (activations stay bf16)
+int check_format(const char* who, int K, int group, int bits, int dtype, bool f16_scales_ok = false) {
+    OMX_REQUIRE(dtype == OMX_BFLOAT16 || (f16_scales_ok && dtype == OMX_FLOAT16), "%s: bf16 activations / scales only (got dtype %d)", who, dtype);
     OMX_REQUIRE(bits == 4 || bits == 8, "%s: bits must be 4 or 8 (got %d)", who, bits);
     OMX_REQUIRE(group == 32 || group == 64 || group == 128, "%s: group_size must be 32, 64 or 128 (got %d)", who, group);
     OMX_REQUIRE(K > 0 && K % group == 0, "%s: the last dimension (%d) must be divisible by the group size (%d)", who, K, group);
@@ -469,24 +483,33 @@ extern "C" int omx_quantize(void* packed, void* scales, void* biases, const void
     return 0;
 }
 
-extern "C" int omx_dequantize(void* out, const void* packed, const void* scales, const void* biases, int64_t rows, int cols,
-                              int group_size, int bits, omx_dtype dtype, omx_stream stream) {
+int omx::launch_dequantize_bf16(bf16_t* out, const uint32_t* packed, const void* scales, const void* biases, int64_t rows, int cols,
+                                int group_size, int bits, bool scales_f16, hipStream_t s) {
     OMX_REQUIRE(out && packed && scales, "omx_dequantize: null tensor");
-    if (check_format("omx_dequantize", cols, group_size, bits, dtype)) return 1;
     const int64_t n_words = rows * cols * bits / 32;
     if (n_words == 0) return 0;
     const unsigned blocks = (unsigned)((n_words + 255) / 256 < 16384 ? (n_words + 255) / 256 : 16384);
-    if (bits == 4) dequantize_kernel<4><<<blocks, 256, 0, (hipStream_t)stream>>>((bf16_t*)out, (const uint32_t*)packed, (const bf16_t*)scales, (const bf16_t*)biases, n_words, group_size);
-    else dequantize_kernel<8><<<blocks, 256, 0, (hipStream_t)stream>>>((bf16_t*)out, (const uint32_t*)packed, (const bf16_t*)scales, (const bf16_t*)biases, n_words, group_size);
+    if (bits == 4) dequantize_kernel<4><<<blocks, 256, 0, s>>>(out, packed, (const bf16_t*)scales, (const bf16_t*)biases, n_words, group_size, scales_f16);
+    else dequantize_kernel<8><<<blocks, 256, 0, s>>>(out, packed, (const bf16_t*)scales, (const bf16_t*)biases, n_words, group_size, scales_f16);
     OMX_LAUNCH_CHECK();
     return 0;
+}
+
+/* dtype = the dtype of scales / biases: OMX_BFLOAT16, or OMX_FLOAT16 (a float16 checkpoint's triplets; the output is bf16 all the same:
+ * every op of this library computes in bf16) */
+extern "C" int omx_dequantize(void* out, const void* packed, const void* scales, const void* biases, int64_t rows, int cols,
+                              int group_size, int bits, omx_dtype dtype, omx_stream stream) {
+    OMX_REQUIRE(out && packed && scales, "omx_dequantize: null tensor");
+    if (check_format("omx_dequantize", cols, group_size, bits, dtype, true)) return 1;
+    return launch_dequantize_bf16((bf16_t*)out, (const uint32_t*)packed, scales, biases, rows, cols, group_size, bits, dtype == OMX_FLOAT16,
+                                  (hipStream_t)stream);
 }
 
 /* out [M, N] = x [M, K] . dequant(W [N, K])^T   (nn::QuantizedLinear::forward, quantized.rs:366-375) */
 extern "C" int omx_quantized_matmul(void* out, const void* x, const void* packed, const void* scales, const void* biases, int M,
                                     int N, int K, int group_size, int bits, omx_dtype dtype, omx_stream stream) {
     OMX_REQUIRE(out && x && packed && scales, "omx_quantized_matmul: null tensor");
-    if (check_format("omx_quantized_matmul", K, group_size, bits, dtype)) return 1;
+    if (check_format("omx_quantized_matmul", K, group_size, bits, dtype, true)) return 1;   // (OMX_FLOAT16: the scales' dtype; x / out are bf16)
     OMX_REQUIRE(M >= 0 && N > 0, "omx_quantized_matmul: bad shape");
     if (M == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
@@ -494,7 +517,7 @@ extern "C" int omx_quantized_matmul(void* out, const void* x, const void* packed
         QGemvArgs a = {};
         a.m[0] = QMat{(const uint32_t*)packed, (const bf16_t*)scales, (const bf16_t*)biases, N};
         a.x = (const bf16_t*)x; a.out = (bf16_t*)out; a.N = N; a.K = K; a.group = group_size;
-        a.n_batch = M; a.x_div = 1;
+        a.n_batch = M; a.x_div = 1; a.scales_f16 = dtype == OMX_FLOAT16;
         return launch_qgemv(a, bits, PRO_NONE, EPI_STORE, s);
     }
     void* ws = nullptr;
@@ -509,14 +532,14 @@ extern "C" int omx_gather_qmm(void* out, const void* x, const void* packed, cons
                               const uint32_t* rhs_indices, int n_rows, int x_div, int N, int K, int n_experts, int group_size,
                               int bits, omx_dtype dtype, omx_stream stream) {
     OMX_REQUIRE(out && x && packed && scales && rhs_indices, "omx_gather_qmm: null tensor");
-    if (check_format("omx_gather_qmm", K, group_size, bits, dtype)) return 1;
+    if (check_format("omx_gather_qmm", K, group_size, bits, dtype, true)) return 1;
     OMX_REQUIRE(n_rows >= 0 && x_div >= 1 && N > 0 && n_experts >= 1, "omx_gather_qmm: bad shape");
     OMX_REQUIRE(K % 512 == 0, "omx_gather_qmm: K=%d must be a multiple of 512", K);
     if (n_rows == 0) return 0;
     QGemvArgs a = {};
     a.m[0] = QMat{(const uint32_t*)packed, (const bf16_t*)scales, (const bf16_t*)biases, N};
     a.x = (const bf16_t*)x; a.out = (bf16_t*)out; a.N = N; a.K = K; a.group = group_size;
-    a.n_batch = n_rows; a.x_div = x_div; a.w_sel = rhs_indices;
+    a.n_batch = n_rows; a.x_div = x_div; a.w_sel = rhs_indices; a.scales_f16 = dtype == OMX_FLOAT16;
     a.w_estride = (size_t)N * K * bits / 32; a.s_estride = (size_t)N * (K / group_size);
     return launch_qgemv(a, bits, PRO_NONE, EPI_STORE, (hipStream_t)stream);
 }

@@ -36,7 +36,12 @@ struct QGemvArgs {
     const uint32_t* w_sel;      // optional [n_batch] expert ids (gather_qmm)
     size_t w_estride, s_estride;    // words / groups between consecutive experts
     int swiglu_single_round;    // EPI_SWIGLU: fused_swiglu(up, gate) (one rounding, metal_kernels.rs:11-18) instead of nn::silu(g)*u
+    int scales_f16;             // scales / biases (and QMat::sb's halves) hold float16 bit patterns: a float16 MLX checkpoint.  The
+                                // activations stay bf16; every group's scale / bias enters the arithmetic as its exact float32 value
 };
+// packed [rows, cols*bits/32] -> bf16 [rows, cols]; scales_f16: scales / biases are float16 (engine-internal form of omx_dequantize)
+int launch_dequantize_bf16(bf16_t* out, const uint32_t* packed, const void* scales, const void* biases, int64_t rows, int cols, int group_size,
+                           int bits, bool scales_f16, hipStream_t s);
 
 int launch_qgemv(const QGemvArgs& a, int bits, int pro, int epi, hipStream_t s);
 int qgemv_grid(int N);          // blocks launch_qgemv uses == argmax partials written

@@ -22,7 +22,7 @@ class Qwen3Config(ctypes.Structure):
                 ("tie_word_embeddings", c_int), ("max_context", c_int), ("tp_rank", c_int), ("tp_size", c_int),
                 ("quant_bits", c_int), ("quant_group", c_int), ("num_experts", c_int), ("num_experts_per_tok", c_int),
                 ("moe_intermediate_size", c_int), ("moe_mode", c_int), ("norm_topk_prob", c_int), ("no_qk_norm", c_int),
-                ("ep_rank", c_int), ("ep_size", c_int), ("attention_bias", c_int)]
+                ("ep_rank", c_int), ("ep_size", c_int), ("attention_bias", c_int), ("quant_scales_f16", c_int)]
 
 
 ENGINE_SIGNATURES = {
@@ -140,7 +140,8 @@ class Model:
                  tie_word_embeddings=False, rope_scaling=None, max_context=4096, tp_rank=0, tp_size=1, quantization=None,
                  num_experts=0, num_experts_per_tok=0, moe_intermediate_size=0, moe_mode="qwen3_moe", norm_topk_prob=False,
                  qk_norm=True, ep_rank=0, ep_size=1, attention_bias=False, **_ignored):
-        """quantization: config.json's {"bits": 4|8, "group_size": 64} (model.rs:63) or None for a bf16 checkpoint.
+        """quantization: config.json's {"bits": 4|8, "group_size": 64} (model.rs:63) or None for a bf16 checkpoint; + "scales_dtype":
+        "float16" when the checkpoint's scales / biases are float16 (loader.load_model reads it off the tensors' dtype).
         num_experts > 0: sparse-MoE feed-forward in every layer -- moe_mode "qwen3_moe" (qwen3_moe.rs ModelArgs :60-87) or
         "mixtral" (mixtral-mlx ModelArgs :54-80, with qk_norm=False and moe_intermediate_size = intermediate_size)."""
         require_device()
@@ -151,7 +152,8 @@ class Model:
                                tp_rank, tp_size, int(q.get("bits", 0)), int(q.get("group_size", 64 if q else 0)),
                                int(num_experts), int(num_experts_per_tok), int(moe_intermediate_size),
                                {"mixtral": 0, "qwen3_moe": 1}[moe_mode], int(bool(norm_topk_prob)), int(not qk_norm),
-                               int(ep_rank), int(ep_size), int(bool(attention_bias)))
+                               int(ep_rank), int(ep_size), int(bool(attention_bias)),
+                               int(str(q.get("scales_dtype", "bfloat16")).lower() in ("float16", "f16", "half")))
         self._h = c_void_p()
         check(lib.omx_qwen3_create(ctypes.byref(self._h), ctypes.byref(self.cfg)))
         self._keep = []
@@ -189,9 +191,19 @@ class Model:
             if want is not None and tuple(arr.shape) != want:
                 raise OmxError(f"ShapeMismatch: {name} has shape {tuple(arr.shape)}, the config expects {want}")
             dt = np.asarray(arr).dtype
-            if self.cfg.quant_bits and name.endswith((".scales", ".biases")) and dt == np.float16:
-                raise OmxError(f"{name}: float16 scales / biases are not supported (the packed-weight kernels read bf16 and a "
-                               "silent f16 -> bf16 rounding would change the dequantised values); re-quantise from a bf16 model")
+            if self.cfg.quant_bits and name.endswith((".scales", ".biases")):
+                # float16 triplets (an MLX float16 checkpoint) stay float16 on the device: the packed-weight kernels widen each group's
+                # scale / bias to its exact float32 value (a host-side rounding to bf16 shifts every weight of a group by the same amount
+                # -- measured outside the decoder's logit bound).  The model must have been created for them.
+                f16 = dt == np.float16
+                if f16 != bool(self.cfg.quant_scales_f16):
+                    raise OmxError(f"{name}: {'float16' if f16 else str(dt)} scales / biases, but the model was created with "
+                                   f"quantization scales_dtype={'float16' if self.cfg.quant_scales_f16 else 'bfloat16'}")
+                if f16:
+                    t = Tensor.from_numpy(arr, "f16")
+                    self._keep.append(t)
+                    check(lib.omx_qwen3_set_weight(self._h, name.encode(), t.ptr, t.nbytes))
+                    continue
             if self.cfg.quant_bits and name.endswith(".weight") and name[:-7] + ".scales" in weights and dt != np.uint32:
                 raise OmxError(f"{name}: a quantized weight must be packed uint32, found {dt}")
             # quantized checkpoints: "<prefix>.weight" is packed uint32 (ops/quantization.rs:41-84), scales / biases bf16

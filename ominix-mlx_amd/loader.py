@@ -148,6 +148,8 @@ def load_model(model_dir: str, max_context: int = 4096, **overrides):
     weights = load_all_weights(model_dir)
     if args.get("moe_mode") == "mixtral":
         weights = sanitize_weights(weights, args["num_hidden_layers"], args["num_experts"])
+    if args.get("quantization") is not None and any(k.endswith(".scales") and np.asarray(v).dtype == np.float16 for k, v in weights.items()):
+        args["quantization"] = dict(args["quantization"], scales_dtype="float16")     # a float16 checkpoint's triplets (engine.Model)
     m = engine.Model(**args)
     tied = bool(args["tie_word_embeddings"])
     quant = args.get("quantization") is not None

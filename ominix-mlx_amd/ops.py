@@ -332,7 +332,7 @@ def quantize(w: Tensor, group_size: int = 64, bits: int = 4):
 def dequantize(packed: Tensor, scales: Tensor, biases: Optional[Tensor], group_size: int = 64, bits: int = 4) -> Tensor:
     """mlx_rs::ops::dequantize (ops/quantization.rs:118-153)."""
     K = packed.shape[-1] * 32 // bits
-    out = Tensor(tuple(packed.shape[:-1]) + (K,), scales.dtype)
+    out = Tensor(tuple(packed.shape[:-1]) + (K,), "bf16")      # (float16 scales / biases too: this library's matrices are bf16)
     check(lib.omx_dequantize(out.ptr, packed.ptr, scales.ptr, _p(biases), out.size // K, K, group_size, bits, scales.dtype, None))
     return out
 
@@ -344,8 +344,9 @@ def quantized_matmul(x: Tensor, packed: Tensor, scales: Tensor, biases: Optional
     if x.shape[-1] != K:
         raise OmxError(f"quantized_matmul: input features {x.shape[-1]} != weight in-features {K}")
     out = Tensor(tuple(x.shape[:-1]) + (N,), x.dtype)
+    # the dtype argument names the SCALES' dtype: bf16, or f16 for a float16 checkpoint's triplets (x and out are bf16 either way)
     check(lib.omx_quantized_matmul(out.ptr, x.ptr, packed.ptr, scales.ptr, _p(biases), x.size // K, N, K, group_size, bits,
-                                   x.dtype, None))
+                                   scales.dtype, None))
     return out
 
 
@@ -357,5 +358,5 @@ def gather_qmm(x: Tensor, packed: Tensor, scales: Tensor, biases: Optional[Tenso
     n = rhs_indices.size
     out = Tensor((n, N), x.dtype)
     check(lib.omx_gather_qmm(out.ptr, x.ptr, packed.ptr, scales.ptr, _p(biases), rhs_indices.ptr, n, x_div, N, K, E, group_size,
-                             bits, x.dtype, None))
+                             bits, scales.dtype, None))
     return out

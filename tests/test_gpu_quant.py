@@ -131,3 +131,24 @@ def test_mlx_c_quantized_entry_points(omx):
         mx.quantized_matmul(mx.Array.from_numpy(x), wq, s, b, transpose=False)
     with pytest.raises(omx.OmxError, match="divisible"):
         mx.quantize(mx.Array.from_numpy(rand((4, 100), 1)))
+
+
+@pytest.mark.parametrize("M,bits,group", [(1, 4, 64), (5, 4, 32), (3, 8, 64), (40, 4, 64)])
+def test_quantized_matmul_with_float16_scales(omx, M, bits, group):
+    """nn/quantized.rs:361-385 takes scales / biases of any float dtype; a float16 checkpoint's are float16.  x stays bf16; each group's
+    scale / bias enters as its exact float32 value (quant.hip F16S on the packed GEMV rows, the dequantise + GEMM route for M > 16).
+    Against the oracle's float32 dequantisation of the SAME float16 values, with the bf16-scale test's tolerance."""
+    N, K = 256, 1024
+    T = omx.ops.Tensor
+    w = rc.bf16_round(rand((N, K), 700 + bits + group) * 0.1)
+    rq_, rs, rb = rc.quantize(w, group, bits)
+    s16, b16 = rs.astype(np.float16), rb.astype(np.float16)
+    x = rc.bf16_round(rand((M, K), 701))
+    got = omx.ops.quantized_matmul(T.from_numpy(x), T.from_numpy(rq_, "u32"), T.from_numpy(s16, "f16"), T.from_numpy(b16, "f16"), group, bits).numpy()
+    ref = rc.quantized_matmul(x, rq_, s16.astype(np.float32), b16.astype(np.float32), group, bits, "bf16")
+    wd = rc.dequantize(rq_, s16.astype(np.float32), b16.astype(np.float32), group, bits, "f32")
+    noise = 4 * 2.0 ** -9 * np.sqrt((x.astype(np.float64) ** 2) @ (wd.astype(np.float64) ** 2).T)
+    assert (np.abs(got.astype(np.float64) - ref) <= 2.0 ** -7 * np.abs(ref) + noise + 1e-6).all()
+    # and the dequantised matrix itself: one fma per element from the exact float16 values, one bf16 rounding
+    dq = omx.ops.dequantize(T.from_numpy(rq_, "u32"), T.from_numpy(s16, "f16"), T.from_numpy(b16, "f16"), group, bits).numpy()
+    np.testing.assert_array_equal(dq, rc.dequantize(rq_, s16.astype(np.float32), b16.astype(np.float32), group, bits, "bf16"))

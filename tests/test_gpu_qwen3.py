@@ -413,7 +413,56 @@ def test_quantized_checkpoint_decode_matches_oracle(omx, name, bits, group):
             break
 
 
-@pytest.mark.parametrize("quant", [None, {"bits": 4, "group_size": 64}])
+def test_quantized_checkpoint_with_float16_scales(omx, tmp_path):
+    """A float16 MLX checkpoint carries float16 scales / biases (mlx quantize() works in the model's dtype; nn/quantized.rs:361-385
+    takes any float).  They stay float16 on the device and the packed-weight kernels widen each group's scale / bias to its exact
+    float32 value (csrc/quant.hip F16S; a host-side rounding to bf16 moved the logits outside the bound below -- it shifts all 64
+    weights of a group together); activations stay bf16.  Against the oracle running on the float16 VALUES, with the quantized
+    engine's bound; also through loader.load_model (dtype read off the safetensors header), and the loud mismatch errors."""
+    from ominix_mlx_amd import engine
+    cfg, bits, group = CONFIGS["gqa4_d128"], 4, 64
+    base = rq.synth_weights(cfg)
+    qw = {}
+    for name, arr in rq.quantize_weights(cfg, base, bits, group).items():
+        if name.endswith((".scales", ".biases")):
+            prefix = name.rsplit(".", 1)[0]
+            w2 = base[prefix + ".weight"].reshape(-1, base[prefix + ".weight"].shape[-1])
+            _, s32, b32 = rc.quantize(w2, group, bits)
+            arr = (s32 if name.endswith(".scales") else b32).astype(np.float16).reshape(arr.shape)
+        qw[name] = arr
+    n_prompt, n_new = 48, 10
+    prompt = synth.prompt_ids(n_prompt, cfg.vocab_size)
+    kw = dict(hidden_size=cfg.hidden_size, num_hidden_layers=cfg.num_hidden_layers, intermediate_size=cfg.intermediate_size,
+              num_attention_heads=cfg.num_attention_heads, num_key_value_heads=cfg.num_key_value_heads, head_dim=cfg.head_dim,
+              vocab_size=cfg.vocab_size, rms_norm_eps=cfg.rms_norm_eps, rope_theta=cfg.rope_theta,
+              tie_word_embeddings=cfg.tie_word_embeddings, rope_scaling=cfg.rope_scaling, max_context=256)
+    m = engine.Model(quantization={"bits": bits, "group_size": group, "scales_dtype": "float16"}, **kw)
+    m.load_weights(qw)
+    first = m.prefill(prompt)
+    logits0 = m.last_logits()
+    got = np.concatenate([[first], m.decode(n_new - 1)]).astype(np.uint32)
+    assert m.decode_path() == "graph"
+    with pytest.raises(omx.OmxError, match="float16-scale model takes uploaded triplets"):
+        m.synth_weights()
+    m.close()
+    f16w = {k: (v.astype(np.float32) if v.dtype == np.float16 else v) for k, v in qw.items()}     # the f16 VALUES, exactly
+    oracle = rq.Qwen3Oracle(cfg, f16w, quant=(bits, group))
+    ref_tokens, ref_logits = oracle.generate(prompt, n_new, return_logits=True)
+    bound = 2.0 ** -7 * np.abs(ref_logits).max() * np.sqrt(2 * cfg.num_hidden_layers)   # test_quantized_checkpoint_decode_matches_oracle's
+    assert np.abs(logits0 - ref_logits[0]).max() <= bound
+    margins = rc.argmax_margin(ref_logits)
+    for i in range(n_new):
+        if got[i] != ref_tokens[i]:
+            assert margins[i] <= 2 * bound, f"token {i}: got {got[i]} want {ref_tokens[i]} with margin {margins[i]:.4f} > {2*bound:.4f}"
+            break
+    # a bf16-scale model refuses float16 triplets (and the other way round) instead of reading them as the wrong format
+    m2 = engine.Model(quantization={"bits": bits, "group_size": group}, **kw)
+    with pytest.raises(omx.OmxError, match="float16 scales / biases, but the model was created"):
+        m2.load_weights(qw)
+    m2.close()
+
+
+@pytest.mark.parametrize("quant", [None, {"bits": 4, "group_size": 64}, {"bits": 4, "group_size": 64, "scales_dtype": "float16"}])
 def test_load_model_from_checkpoint_directory(omx, tmp_path, quant):
     """qwen3_mlx::load_model (model.rs:509-560, 621-727): config.json + model.safetensors.index.json + two shards
     (BF16 tensors as raw bits, packed U32 weights for the quantized variant) -> the same tokens and logits as handing
@@ -422,19 +471,24 @@ def test_load_model_from_checkpoint_directory(omx, tmp_path, quant):
     from ominix_mlx_amd import engine, loader
     cfg = CONFIGS["gqa4_d128"]
     w = rq.synth_weights(cfg)
-    if quant:
+    f16 = bool(quant) and quant.get("scales_dtype") == "float16"     # a float16 checkpoint: F16 scales / biases in the shards, and
+    if quant:                                                         # config.json does not say so -- the loader reads the dtype
         w = rq.quantize_weights(cfg, w, quant["bits"], quant["group_size"])
+        if f16:
+            w = {k: (v.astype(np.float16) if k.endswith((".scales", ".biases")) else v) for k, v in w.items()}
+        quant_cfg = {"bits": quant["bits"], "group_size": quant["group_size"]}
     d = str(tmp_path)
     json.dump({"hidden_size": cfg.hidden_size, "num_hidden_layers": cfg.num_hidden_layers, "intermediate_size": cfg.intermediate_size,
                "num_attention_heads": cfg.num_attention_heads, "num_key_value_heads": cfg.num_key_value_heads, "head_dim": cfg.head_dim,
                "vocab_size": cfg.vocab_size, "rms_norm_eps": cfg.rms_norm_eps, "rope_theta": cfg.rope_theta,
-               "tie_word_embeddings": cfg.tie_word_embeddings, **({"quantization": quant} if quant else {})},
+               "tie_word_embeddings": cfg.tie_word_embeddings, **({"quantization": quant_cfg} if quant else {})},
               open(f"{d}/config.json", "w"))
     names = sorted(w)
     shards = {"model-00001-of-00002.safetensors": names[: len(names) // 2], "model-00002-of-00002.safetensors": names[len(names) // 2:]}
     for fn, keys in shards.items():
-        tensors = {k: (w[k] if w[k].dtype == np.uint32 else rc.to_bf16_bits(w[k])) for k in keys}
-        loader.write_safetensors(f"{d}/{fn}", tensors, bf16_names=tuple(k for k in keys if w[k].dtype != np.uint32))
+        raw = lambda k: w[k].dtype in (np.uint32, np.float16)
+        tensors = {k: (w[k] if raw(k) else rc.to_bf16_bits(w[k])) for k in keys}
+        loader.write_safetensors(f"{d}/{fn}", tensors, bf16_names=tuple(k for k in keys if not raw(k)))
     json.dump({"metadata": {}, "weight_map": {k: fn for fn, keys in shards.items() for k in keys}}, open(f"{d}/model.safetensors.index.json", "w"))
 
     prompt = synth.prompt_ids(20, cfg.vocab_size)

@@ -91,7 +91,7 @@ __device__ __forceinline__ float scale_to_f32(uint16_t bits) {
 template <int BITS>
 __global__ __launch_bounds__(256) void dequantize_kernel(bf16_t* __restrict__ out, const uint32_t* __restrict__ packed,
                                                          const bf16_t* __restrict__ scales, const bf16_t* __restrict__ biases,
-                                                         int64_t n_words, int group, bool scales_f16 = false) {
+                                                         int64_t n_words, int group, bool scales_f16 = false, bool out_f16 = false) {
     constexpr int EPW = 32 / BITS;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_words; i += (int64_t)gridDim.x * blockDim.x) {
         const uint32_t wd = packed[i];
@@ -100,7 +100,10 @@ __global__ __launch_bounds__(256) void dequantize_kernel(bf16_t* __restrict__ ou
         const float b = biases ? (scales_f16 ? scale_to_f32<true>(biases[g]) : bf16_to_f32(biases[g])) : 0.f;
         bf16_t o[EPW];
 #pragma unroll
-        for (int e = 0; e < EPW; ++e) o[e] = f32_to_bf16((float)((wd >> (e * BITS)) & ((1u << BITS) - 1u)) * s + b);
+        for (int e = 0; e < EPW; ++e) {
+            const float v = (float)((wd >> (e * BITS)) & ((1u << BITS) - 1u)) * s + b;
+            o[e] = out_f16 ? (bf16_t)__half_as_ushort(__float2half(v)) : f32_to_bf16(v);
+        }
         if (EPW == 8) *reinterpret_cast<u32x4*>(out + i * 8) = *reinterpret_cast<const u32x4*>(o);
         else *reinterpret_cast<u32x2*>(out + i * 4) = *reinterpret_cast<const u32x2*>(o);
     }
@@ -483,26 +486,30 @@ extern "C" int omx_quantize(void* packed, void* scales, void* biases, const void
     return 0;
 }
 
-int omx::launch_dequantize_bf16(bf16_t* out, const uint32_t* packed, const void* scales, const void* biases, int64_t rows, int cols,
-                                int group_size, int bits, bool scales_f16, hipStream_t s) {
+static int launch_dequantize_any(void* out, const uint32_t* packed, const void* scales, const void* biases, int64_t rows, int cols,
+                                 int group_size, int bits, bool scales_f16, bool out_f16, hipStream_t s) {
     OMX_REQUIRE(out && packed && scales, "omx_dequantize: null tensor");
     const int64_t n_words = rows * cols * bits / 32;
     if (n_words == 0) return 0;
     const unsigned blocks = (unsigned)((n_words + 255) / 256 < 16384 ? (n_words + 255) / 256 : 16384);
-    if (bits == 4) dequantize_kernel<4><<<blocks, 256, 0, s>>>(out, packed, (const bf16_t*)scales, (const bf16_t*)biases, n_words, group_size, scales_f16);
-    else dequantize_kernel<8><<<blocks, 256, 0, s>>>(out, packed, (const bf16_t*)scales, (const bf16_t*)biases, n_words, group_size, scales_f16);
+    if (bits == 4) dequantize_kernel<4><<<blocks, 256, 0, s>>>((bf16_t*)out, packed, (const bf16_t*)scales, (const bf16_t*)biases, n_words, group_size, scales_f16, out_f16);
+    else dequantize_kernel<8><<<blocks, 256, 0, s>>>((bf16_t*)out, packed, (const bf16_t*)scales, (const bf16_t*)biases, n_words, group_size, scales_f16, out_f16);
     OMX_LAUNCH_CHECK();
     return 0;
 }
+int omx::launch_dequantize_bf16(bf16_t* out, const uint32_t* packed, const void* scales, const void* biases, int64_t rows, int cols,
+                                int group_size, int bits, bool scales_f16, hipStream_t s) {
+    return launch_dequantize_any(out, packed, scales, biases, rows, cols, group_size, bits, scales_f16, false, s);
+}
 
-/* dtype = the dtype of scales / biases: OMX_BFLOAT16, or OMX_FLOAT16 (a float16 checkpoint's triplets; the output is bf16 all the same:
- * every op of this library computes in bf16) */
+/* mlx_rs::ops::dequantize (ops/quantization.rs:118-153): the result has the dtype of scales / biases -- OMX_BFLOAT16, or OMX_FLOAT16 for
+ * a float16 checkpoint's triplets (each element one fma in float32 from the exact scale / bias, one rounding) */
 extern "C" int omx_dequantize(void* out, const void* packed, const void* scales, const void* biases, int64_t rows, int cols,
                               int group_size, int bits, omx_dtype dtype, omx_stream stream) {
     OMX_REQUIRE(out && packed && scales, "omx_dequantize: null tensor");
     if (check_format("omx_dequantize", cols, group_size, bits, dtype, true)) return 1;
-    return launch_dequantize_bf16((bf16_t*)out, (const uint32_t*)packed, scales, biases, rows, cols, group_size, bits, dtype == OMX_FLOAT16,
-                                  (hipStream_t)stream);
+    const bool f16 = dtype == OMX_FLOAT16;
+    return launch_dequantize_any(out, (const uint32_t*)packed, scales, biases, rows, cols, group_size, bits, f16, f16, (hipStream_t)stream);
 }
 
 /* out [M, N] = x [M, K] . dequant(W [N, K])^T   (nn::QuantizedLinear::forward, quantized.rs:366-375) */
@@ -522,7 +529,7 @@ extern "C" int omx_quantized_matmul(void* out, const void* x, const void* packed
     }
     void* ws = nullptr;
     if (get_workspace(&ws, (size_t)N * K * 2)) return 1;
-    if (omx_dequantize(ws, packed, scales, biases, N, K, group_size, bits, dtype, stream)) return 1;
+    if (launch_dequantize_bf16((bf16_t*)ws, (const uint32_t*)packed, scales, biases, N, K, group_size, bits, dtype == OMX_FLOAT16, s)) return 1;
     return launch_gemm_bf16((bf16_t*)out, (const bf16_t*)x, (const bf16_t*)ws, nullptr, M, N, K, s);
 }
 

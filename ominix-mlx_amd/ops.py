@@ -332,7 +332,7 @@ def quantize(w: Tensor, group_size: int = 64, bits: int = 4):
 def dequantize(packed: Tensor, scales: Tensor, biases: Optional[Tensor], group_size: int = 64, bits: int = 4) -> Tensor:
     """mlx_rs::ops::dequantize (ops/quantization.rs:118-153)."""
     K = packed.shape[-1] * 32 // bits
-    out = Tensor(tuple(packed.shape[:-1]) + (K,), "bf16")      # (float16 scales / biases too: this library's matrices are bf16)
+    out = Tensor(tuple(packed.shape[:-1]) + (K,), scales.dtype)     # the result has the scales' dtype (bf16, or f16 for a float16 checkpoint)
     check(lib.omx_dequantize(out.ptr, packed.ptr, scales.ptr, _p(biases), out.size // K, K, group_size, bits, scales.dtype, None))
     return out
 

@@ -149,6 +149,6 @@ def test_quantized_matmul_with_float16_scales(omx, M, bits, group):
     wd = rc.dequantize(rq_, s16.astype(np.float32), b16.astype(np.float32), group, bits, "f32")
     noise = 4 * 2.0 ** -9 * np.sqrt((x.astype(np.float64) ** 2) @ (wd.astype(np.float64) ** 2).T)
     assert (np.abs(got.astype(np.float64) - ref) <= 2.0 ** -7 * np.abs(ref) + noise + 1e-6).all()
-    # and the dequantised matrix itself: one fma per element from the exact float16 values, one bf16 rounding
+    # and the dequantised matrix itself (dtype of the scales, as MLX): one fma per element from the exact float16 values, one rounding
     dq = omx.ops.dequantize(T.from_numpy(rq_, "u32"), T.from_numpy(s16, "f16"), T.from_numpy(b16, "f16"), group, bits).numpy()
-    np.testing.assert_array_equal(dq, rc.dequantize(rq_, s16.astype(np.float32), b16.astype(np.float32), group, bits, "bf16"))
+    np.testing.assert_array_equal(dq, rc.dequantize(rq_, s16.astype(np.float32), b16.astype(np.float32), group, bits, "f32").astype(np.float16).astype(np.float32))

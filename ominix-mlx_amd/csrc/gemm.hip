@@ -49,8 +49,9 @@ struct GemmArgs {
     GroupedDesc g;        // grouped mode when g.tile_expert != nullptr
     int relu;             // out = max(0, acc + bias)  (Paraformer FFN, paraformer.rs:565-569)
     GemmSegs sg;          // segmented mode (256^2 kernel, SW instantiation), see gemm.hpp
-    float* split_ws;      // ring kernel, gridDim.y > 1: f32 partial tiles [tile][split][64 x 64]
+    float* split_ws;      // ring kernel, gridDim.y > 1: f32 partial tiles [tile][split][64 x 64]; 256^2 kernel with ksplit > 1: [tile][split][256 x 256]
     unsigned* split_cnt;  // [tiles] arrival counters (zero between launches)
+    int ksplit;           // 256^2 kernel (plain form): K halves of a tile go to different blocks (a grid of <= 128 tiles covers the chip)
 };
 
 // one 16-B chunk per lane per wave-instruction, 4 instructions per operand tile: row pointers of the 4
@@ -227,6 +228,16 @@ __global__ __launch_bounds__(big::NT) void gemm_bf16_nt_256_kernel(const GemmArg
     // XCD-aware remap (bijective form)
     const int nblk = a.grid_m * a.grid_n;
     int bid = blockIdx.x;
+    // split K (plain form only): blocks [split * nblk, (split + 1) * nblk) own the split-th part of every tile's K range
+    int ksplit = 1, split = 0;
+    if constexpr (!SW) {
+        if (a.ksplit > 1) {
+            ksplit = a.ksplit;
+            split = bid / nblk;
+            bid -= split * nblk;
+        }
+    }
+    const int tile_id = bid;
     {
         const int q = nblk / 8, r = nblk % 8, xcd = bid % 8, idx = bid / 8;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
@@ -279,7 +290,8 @@ __global__ __launch_bounds__(big::NT) void gemm_bf16_nt_256_kernel(const GemmArg
         }
     }
     const int n0 = tn * TN;
-    const int nt = a.K / TK;
+    const int nt_all = a.K / TK, t_first = split * (nt_all / ksplit);
+    const int nt = split == ksplit - 1 ? nt_all - t_first : nt_all / ksplit;
 
     // staging sources: thread handles chunks c = i * 512 + tid (i = 0, 1) of every piece; piece row r of X_s is
     // tile row (r >> 6) * 128 + s * 64 + (r & 63), piece row r of Y_s is tile col (r >> 5) * 64 + s * 32 + (r & 31)
@@ -311,8 +323,8 @@ __global__ __launch_bounds__(big::NT) void gemm_bf16_nt_256_kernel(const GemmArg
                     srcY[sidx][i] = seg_w + w_off + (size_t)min(n0 + tcol, seg_cols - 1) * a.K + kc * 8;
                 }
             } else {
-                srcX[sidx][i] = a.x + (size_t)min(m0 + trow, a.M - 1) * a.K + kc * 8;
-                srcY[sidx][i] = a.w + (size_t)min(n0 + tcol, a.N - 1) * a.K + kc * 8;
+                srcX[sidx][i] = a.x + (size_t)min(m0 + trow, a.M - 1) * a.K + kc * 8 + t_first * TK;
+                srcY[sidx][i] = a.w + (size_t)min(n0 + tcol, a.N - 1) * a.K + kc * 8 + t_first * TK;
             }
         }
     auto stage = [&](const bf16_t* const (&src)[2], int k0, unsigned char* piece) {
@@ -444,6 +456,52 @@ __global__ __launch_bounds__(big::NT) void gemm_bf16_nt_256_kernel(const GemmArg
         OMX_BAR();
     }
     if (wr == 0) OMX_BAR();   // pairs with the extra barrier of the wr = 1 waves
+
+    if constexpr (!SW) {
+        if (ksplit > 1) {
+            // every split parks its f32 partial tile; the LAST block of the tile to arrive re-reads all of them in split order (its own
+            // included: one fixed summation order whoever is last) and runs the epilogue -- the ring kernel's hand-over
+            __shared__ unsigned s_last;
+            constexpr int PER_WAVE = RT * CT * 64 * AR;
+            float* mine = a.split_ws + (((size_t)tile_id * ksplit + split) * 8 + wave) * PER_WAVE;
+#pragma unroll
+            for (int i = 0; i < RT; ++i)
+#pragma unroll
+                for (int j = 0; j < CT; ++j)
+#pragma unroll
+                    for (int g = 0; g < AR / 4; ++g) {
+                        float* p = mine + (((i * CT + j) * (AR / 4) + g) * 64 + lane) * 4;
+                        st_coh64(p, (uint64_t)__float_as_uint(acc[i][j][4 * g]) | ((uint64_t)__float_as_uint(acc[i][j][4 * g + 1]) << 32));
+                        st_coh64(p + 2, (uint64_t)__float_as_uint(acc[i][j][4 * g + 2]) | ((uint64_t)__float_as_uint(acc[i][j][4 * g + 3]) << 32));
+                    }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (threadIdx.x == 0)
+                s_last = __hip_atomic_fetch_add(a.split_cnt + tile_id, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)ksplit - 1 ? 1u : 0u;
+            __syncthreads();
+            if (!s_last) return;
+#pragma unroll
+            for (int i = 0; i < RT; ++i)
+#pragma unroll
+                for (int j = 0; j < CT; ++j)
+#pragma unroll
+                    for (int r = 0; r < AR; ++r) acc[i][j][r] = 0.f;
+            for (int sp = 0; sp < ksplit; ++sp) {
+                const float* theirs = a.split_ws + (((size_t)tile_id * ksplit + sp) * 8 + wave) * PER_WAVE;
+#pragma unroll
+                for (int i = 0; i < RT; ++i)
+#pragma unroll
+                    for (int j = 0; j < CT; ++j)
+#pragma unroll
+                        for (int g = 0; g < AR / 4; ++g) {
+                            const u32x4 v = ld_coh128(theirs + (((i * CT + j) * (AR / 4) + g) * 64 + lane) * 4);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) acc[i][j][4 * g + r] += __uint_as_float(v[r]);
+                        }
+            }
+            if (threadIdx.x == 0) __hip_atomic_store(a.split_cnt + tile_id, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
 
     // epilogue.  The products were issued as W-tile x X-tile (operands swapped), so a lane holds runs of FOUR
     // consecutive output columns of one row: 16x16 -> row = lane & 15, cols 4 * (lane >> 4) + [0,4);
@@ -886,7 +944,8 @@ int ensure_attr() {
 // inside a stream capture allocates under a relaxed capture mode (hipMalloc is not a stream operation).
 namespace {
 constexpr size_t kSplitWsFloats = (size_t)512 * 64 * 64, kSplitCnt = 256;
-struct SplitWs { float* ws = nullptr; unsigned* cnt = nullptr; };
+constexpr size_t kSplitBigFloats = (size_t)128 * 2 * 256 * 256;   // 256^2 kernel: up to 128 tiles in two K halves (64 MiB, on first use)
+struct SplitWs { float* ws = nullptr; unsigned* cnt = nullptr; float* big = nullptr; };
 std::mutex g_split_mu;
 std::map<std::pair<hipStream_t, std::thread::id>, SplitWs> g_split_ws;
 std::pair<hipStream_t, std::thread::id> split_key(hipStream_t s) { return {s, s ? std::thread::id() : std::this_thread::get_id()}; }
@@ -923,6 +982,23 @@ int split_workspace(hipStream_t s, size_t floats, size_t tiles, float** ws, unsi
     *ws = w.ws; *cnt = w.cnt;
     return 0;
 }
+// the 256^2 kernel's partial tiles: the same counters (every launch leaves them zero), a second, larger buffer
+int split_workspace_big(hipStream_t s, size_t floats, size_t tiles, float** ws, unsigned** cnt) {
+    OMX_REQUIRE(floats <= kSplitBigFloats && tiles <= kSplitCnt, "GEMM split-K: %zu partial floats / %zu tiles exceed the fixed scratch", floats, tiles);
+    float* small = nullptr;
+    if (split_workspace(s, 0, tiles, &small, cnt)) return 1;
+    std::lock_guard<std::mutex> lk(g_split_mu);
+    SplitWs& w = g_split_ws[split_key(s)];
+    if (!w.big) {
+        hipStreamCaptureMode mode = hipStreamCaptureModeRelaxed;
+        OMX_HIP_CHECK(hipThreadExchangeStreamCaptureMode(&mode));
+        const hipError_t e = hipMalloc((void**)&w.big, kSplitBigFloats * 4);
+        (void)hipThreadExchangeStreamCaptureMode(&mode);
+        if (e != hipSuccess) { w.big = nullptr; return set_error("GEMM split-K scratch: %s", hipGetErrorString(e)); }
+    }
+    *ws = w.big;
+    return 0;
+}
 }  // namespace
 
 // the owner of `s` is about to destroy it: give its split-K scratch back (engine / model destructors)
@@ -932,6 +1008,7 @@ void gemm_release_stream(hipStream_t s) {
     if (it == g_split_ws.end()) return;
     (void)hipStreamSynchronize(s);
     if (it->second.ws) (void)hipFree(it->second.ws);
+    if (it->second.big) (void)hipFree(it->second.big);
     if (it->second.cnt) (void)hipFree(it->second.cnt);
     g_split_ws.erase(it);
 }
@@ -966,13 +1043,22 @@ static int launch_gemm_impl(bf16_t* out, const bf16_t* x, const bf16_t* w, const
         const int tiles256 = ((M + 255) / 256) * ((N + 255) / 256);
         const char* tile_env = getenv("OMX_GEMM_TILE");
         const int forced = tile_env ? atoi(tile_env) : 0;
-        const bool use256 = forced == 256 || (forced != 128 && (tiles256 >= 160 || (tiles256 >= 100 && K >= 8192)));
+        // 64 .. 128 tiles of 256^2 leave half of the CUs idle (prefill of 2048 tokens: O and down projection, 8 x 16 tiles).  Opt-in
+        // (OMX_GEMM_KSPLIT=1): each tile's K range in two halves -> up to 256 blocks, f32 partials summed by the tile's last block.
+        // Measured (EXPERIMENTS.md R3-5): back to back on one matrix (weights resident in the Infinity Cache) K = 12288 runs 246 -> 202 us,
+        // K = 4096 83 -> 124 us (the partials are 64 MiB written and read back); inside the real 2048-token prefill, where every
+        // layer's weights come from HBM and the partials compete with them, 29.21 -> 29.21 ms: no gain, so it is not the default.
+        const char* ks_env = getenv("OMX_GEMM_KSPLIT");
+        const int ksplit = (ks_env && ks_env[0] == '1' && forced == 0 && tiles256 >= 64 && tiles256 <= 128 && K >= 4096 && K % 128 == 0) ? 2 : 1;
+        const bool use256 = forced == 256 || ksplit > 1 || (forced != 128 && (tiles256 >= 160 || (tiles256 >= 100 && K >= 8192)));
         if (use256) {
             a.grid_m = (M + 255) / 256;
             a.grid_n = (N + 255) / 256;
+            a.ksplit = ksplit;
+            if (ksplit > 1 && split_workspace_big(s, (size_t)tiles256 * ksplit * 256 * 256, (size_t)tiles256, &a.split_ws, &a.split_cnt)) return 1;
             const char* mf_env = getenv("OMX_GEMM_MFMA");
-            if (mf_env && atoi(mf_env) == 32) gemm_bf16_nt_256_kernel<32><<<a.grid_m * a.grid_n, big::NT, big::SMEM, s>>>(a);
-            else gemm_bf16_nt_256_kernel<16><<<a.grid_m * a.grid_n, big::NT, big::SMEM, s>>>(a);
+            if (mf_env && atoi(mf_env) == 32) gemm_bf16_nt_256_kernel<32><<<a.grid_m * a.grid_n * ksplit, big::NT, big::SMEM, s>>>(a);
+            else gemm_bf16_nt_256_kernel<16><<<a.grid_m * a.grid_n * ksplit, big::NT, big::SMEM, s>>>(a);
         } else if (forced == 64 || (forced == 0 && a.grid_m * a.grid_n <= 128)) {
             // the 128^2 grid leaves CUs idle: 64^2 tiles with a deep prefetch ring (one block per CU: 8 stages; two: 4)
             a.grid_m = (M + 63) / 64;

@@ -34,6 +34,33 @@ def test_linear_gemm_parity(omx, M, N, K):
 
 
 @pytest.mark.parametrize("M,N,K", [
+    (2048, 4096, 4096),      # prefill of 2048 tokens: O projection -- 8 x 16 tiles, two K halves of 32 steps
+    (2048, 4096, 12288),     # ... down projection
+    (1900, 3000, 4224),      # ragged tiles (8 x 12 = 96), an odd number of K steps (66 = 33 + 33)
+    (2048, 2048, 8320),      # 64 tiles, 130 K steps (65 + 65: odd halves)
+])
+def test_linear_gemm_256_tile_kernel_split_k(omx, monkeypatch, M, N, K):
+    """64 .. 128 tiles of 256^2 would leave half of the CUs idle: every tile's K range goes to TWO blocks, the f32 partial tiles meet in
+    the tile's last block (fixed summation order) which runs the epilogue.  Against the oracle, and against the unsplit kernel within
+    the rounding of one extra f32 addition; deterministic run to run; bias and residual go through the same epilogue."""
+    T = omx.ops.Tensor
+    monkeypatch.setenv("OMX_GEMM_KSPLIT", "1")      # (by default only 100+ tiles with K >= 8192 split: where it is faster)
+    x = rc.bf16_round(rand((M, K), 141))
+    w = rc.bf16_round(rand((N, K), 142) * 0.05)
+    b = rc.bf16_round(rand((N,), 143))
+    xt, wt, bt = T.from_numpy(x), T.from_numpy(w), T.from_numpy(b)
+    got = omx.ops.linear(xt, wt, bt).numpy()
+    again = omx.ops.linear(xt, wt, bt).numpy()
+    np.testing.assert_array_equal(got, again)
+    ref = rc.linear(x, w, b, "bf16")
+    assert_bf16_close(got, ref, 1, atol=2e-5 * np.sqrt(K) + 1e-4)
+    monkeypatch.setenv("OMX_GEMM_KSPLIT", "0")
+    plain = omx.ops.linear(xt, wt, bt).numpy()
+    assert_bf16_close(got, plain, 1, atol=1e-5 * np.sqrt(K))
+    assert (got != plain).mean() < 0.2          # (and mostly the very same bf16 values)
+
+
+@pytest.mark.parametrize("M,N,K", [
     (256, 256, 64),          # one tile, one K step (prologue only)
     (300, 520, 128),         # ragged M and N tails, two K steps
     (512, 768, 192),         # odd number of K steps: both LDS buffers, tail without re-staging

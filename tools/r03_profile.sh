@@ -23,4 +23,11 @@ for mode in 1 2; do
   f=$(find "$out/se$mode" -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp "$f" "$out/keep/r03_step_engine_mode${mode}_kernel_stats.csv" && head -4 "$f"
   rm -rf "$out/se$mode"
 done
+# FLUX step and the 2048-token prefill with the round's kernels (two-phase flash attention)
+for w in flux prefill; do
+  if [ $w = flux ]; then cmd="tools/flux_bench.py"; else cmd="tools/prefill_bench.py 2048"; fi
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/$w" -o s -- python3 $cmd > "$out/$w.log" 2>&1
+  f=$(find "$out/$w" -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp "$f" "$out/keep/r03_${w}_kernel_stats.csv" && head -5 "$f"
+  rm -rf "$out/$w"
+done
 ls -la "$out" "$out/keep"

@@ -21,6 +21,10 @@
 #include <stdlib.h>
 
 #include "gemm.hpp"
+#include "gridsync.hpp"
+#include <map>
+#include <mutex>
+#include <thread>
 
 namespace omx {
 namespace {
@@ -43,6 +47,8 @@ struct PrefillArgs {
     int64_t q_bs, q_hs, q_ts, o_bs, o_hs, o_ts;
     int64_t kv_ts;   // elements between consecutive key rows (D when K/V are [.., T, D] contiguous)
     unsigned long long* trace;   // two-phase kernel, timeline build: [block][wave][8] cycle sums (tools/attn_pp_trace.py)
+    float* sk_ws;                // stream-K form: parked pieces [share boundary][2][512 lanes][QW * (NDT * 4 + 2)] f32
+    unsigned* sk_cnt;            // ... arrival counters [share boundary] (zero between launches)
 };
 
 // max / sum over the 4 lanes {l, l^16, l^32, l^48} that hold the same query column
@@ -343,30 +349,18 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(const PrefillArgs 
 //      wave ran as their SUM, MfmaUtil 0.32; see EXPERIMENTS.md R3-4).  MI355X_MICROARCH.md "Two waves per SIMD".
 //      K_{i+1} and V_i are fetched by LDS-DMA at the start of even phases into the buffers whose last readers met the previous
 //      barrier, and awaited (vmcnt) ahead of the barrier that ends the following odd phase: two phases of flight. ----
-template <int D, int MASK, bool TR = false>
-__global__ __launch_bounds__(512, 1) void attn_prefill_pp_kernel(const PrefillArgs a) {
+// One unit of the two-phase kernel: 256 query rows of head h, key tiles [t_first, t_last) (the whole unit unless SK).  Called by all 8
+// waves of the block.  SK: a piece of a unit parks its un-normalised state and the unit's last piece merges (see below).
+template <int D, int MASK, bool TR, bool SK>
+__device__ __forceinline__ void pp_unit(const PrefillArgs& a, bf16_t* sK, bf16_t* sV, int b, int h, int qt, int cut, int t_first, int t_last) {
     constexpr int QW = 2;
     constexpr int DC = D / 8, NI = D / 32, NDT = D / 16;
-    constexpr int QBLK = 8 * 16 * QW;           // 256 query rows per block
-    constexpr int KCH = KB * DC / 512;          // 16-byte chunks staged per thread and tile
-    __shared__ __attribute__((aligned(16))) bf16_t sK2[2][KB * D];
-    __shared__ __attribute__((aligned(16))) bf16_t sV2[2][KB * D];
-
+    constexpr int QBLK = 8 * 16 * QW;
+    constexpr int KCH = KB * DC / 512;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const unsigned wave_u = __builtin_amdgcn_readfirstlane(wave);
-    const bool late = wave_u >= 4;              // waves 4-7: one phase behind waves 0-3 (their SIMD partners)
+    const bool late = wave_u >= 4;
     const int qcol = lane & 15, rg = lane >> 4;
-    // blocks of one head on one XCD (its L2 then holds that head's K / V once, not eight times): linear block id L runs on XCD
-    // L % 8; when the head count is a multiple of 8, XCD x works through heads x, x + 8, ...
-    int qt = blockIdx.x, h = blockIdx.y;
-    const int b = blockIdx.z;
-    if ((a.H & 7) == 0) {
-        const int L = (int)blockIdx.x + (int)gridDim.x * (int)blockIdx.y;
-        const int xcd = L & 7, idx = L >> 3;
-        h = (idx / (int)gridDim.x) * 8 + xcd;
-        qt = idx % (int)gridDim.x;
-    }
-    if (MASK == OMX_MASK_CAUSAL) qt = (int)gridDim.x - 1 - qt;   // longest blocks first
     const int kvh = h / (a.H / a.Hkv);
     const int q0 = qt * QBLK;
     const int shift = a.Tk - a.Tq;
@@ -396,6 +390,7 @@ __global__ __launch_bounds__(512, 1) void attn_prefill_pp_kernel(const PrefillAr
     int kv_end = a.Tk;
     if (MASK == OMX_MASK_CAUSAL) kv_end = max(0, min(a.Tk, q0 + QBLK + shift));
     const int nt = (kv_end + KB - 1) / KB;
+    const int ta = SK ? t_first : 0, tb = SK ? t_last : nt;     // this call's tile range (stream-K: a piece of the unit)
 
     constexpr int VSH = (D == 128) ? 0 : 1;
     constexpr int VBM = D / 16 - 1;
@@ -431,8 +426,8 @@ __global__ __launch_bounds__(512, 1) void attn_prefill_pp_kernel(const PrefillAr
     };
     // tile step i, even phase: K_{i+1} and V_i set out
     auto fetch = [&](int i) {
-        if (i + 1 < nt) stage((i + 1) * KB, Kb, koff, sK2[(i + 1) & 1], false);
-        if (i < nt) stage(i * KB, Vb, voff, sV2[i & 1], true);
+        if (i + 1 < tb) stage((i + 1) * KB, Kb, koff, sK + ((i + 1) & 1) * (KB * D), false);
+        if (i < tb) stage(i * KB, Vb, voff, sV + (i & 1) * (KB * D), true);
     };
     const int v_key = rg * 4 + (qcol >> 2);
     const int v_sw = (v_key >> VSH) & VBM;
@@ -597,8 +592,8 @@ __global__ __launch_bounds__(512, 1) void attn_prefill_pp_kernel(const PrefillAr
             tc = t;
         }
     };
-    if (nt > 0) {
-        stage(0, Kb, koff, sK2[0], false);
+    if (tb > ta) {
+        stage(ta * KB, Kb, koff, sK + (ta & 1) * (KB * D), false);
         // (the builtin, not asm: hipcc must KNOW that the Q loads above have landed -- otherwise it puts its own vmcnt(N) waits for them
         //  inside the loop, where the hardware counter also holds our DMA, and every X phase waits for the tile it just requested)
         __builtin_amdgcn_s_waitcnt(0);
@@ -610,25 +605,25 @@ __global__ __launch_bounds__(512, 1) void attn_prefill_pp_kernel(const PrefillAr
 #ifdef OMX_PP_PRIO
             if (OMX_PP_PRIO == 0) __builtin_amdgcn_s_setprio(1);
 #endif
-            for (int i = 0; i <= nt; ++i) {
+            for (int i = ta; i <= tb; ++i) {
                 fetch(i);
-                if (i < nt) qk(sK2[i & 1]);
-                if (i >= 1) pv(sV2[(i - 1) & 1]);
+                if (i < tb) qk(sK + (i & 1) * (KB * D));
+                if (i > ta) pv(sV + ((i - 1) & 1) * (KB * D));
                 if (TR) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 lap(0); end_even(); lap(2);
-                if (i < nt) softmax(i);
+                if (i < tb) softmax(i);
                 lap(1); end_odd(); lap(3);
             }
         } else {
 #ifdef OMX_PP_PRIO
             if (OMX_PP_PRIO == 1) __builtin_amdgcn_s_setprio(1);   // static priority for the younger half (MI355X_MICROARCH.md, item 4)
 #endif
-            for (int i = 0; i <= nt; ++i) {
+            for (int i = ta; i <= tb; ++i) {
                 fetch(i);
-                if (i >= 1) softmax(i - 1);
+                if (i > ta) softmax(i - 1);
                 lap(1); end_even(); lap(2);
-                if (i < nt) qk(sK2[i & 1]);
-                if (i >= 1) pv(sV2[(i - 1) & 1]);
+                if (i < tb) qk(sK + (i & 1) * (KB * D));
+                if (i > ta) pv(sV + ((i - 1) & 1) * (KB * D));
                 if (TR) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 lap(0); end_odd(); lap(3);
             }
@@ -640,6 +635,52 @@ __global__ __launch_bounds__(512, 1) void attn_prefill_pp_kernel(const PrefillAr
         }
     }
 
+    if constexpr (SK) {
+        if (!(ta == 0 && tb == nt)) {
+            // a piece of the unit: park (O, m, l) -- un-normalised, per lane as held -- and let the unit's LAST piece to arrive merge.
+            // At most two pieces per unit (a block's share is at least one unit long); part 0 is the one that starts at tile 0;
+            // `cut` names the boundary between two shares that runs through this unit (one parking slot per boundary).
+            __shared__ unsigned s_last;
+            const int part = ta == 0 ? 0 : 1;
+            constexpr int PER_LANE = QW * (NDT * 4 + 2);
+            float* mine = a.sk_ws + (((size_t)cut * 2 + part) * 512 + threadIdx.x) * PER_LANE;
+#pragma unroll
+            for (int w = 0; w < QW; ++w) {
+#pragma unroll
+                for (int t = 0; t < NDT; ++t) {
+                    st_coh64(mine + (w * NDT + t) * 4, (uint64_t)__float_as_uint(o[w][t][0]) | ((uint64_t)__float_as_uint(o[w][t][1]) << 32));
+                    st_coh64(mine + (w * NDT + t) * 4 + 2, (uint64_t)__float_as_uint(o[w][t][2]) | ((uint64_t)__float_as_uint(o[w][t][3]) << 32));
+                }
+                st_coh64(mine + QW * NDT * 4 + w * 2, (uint64_t)__float_as_uint(m_run[w]) | ((uint64_t)__float_as_uint(l_run[w]) << 32));
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (threadIdx.x == 0)
+                s_last = __hip_atomic_fetch_add(a.sk_cnt + cut, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1u ? 1u : 0u;
+            __syncthreads();
+            const bool last = s_last != 0;
+            __syncthreads();              // (s_last is reused by this block's next piece)
+            if (!last) return;
+            const float* theirs = a.sk_ws + (((size_t)cut * 2 + (1 - part)) * 512 + threadIdx.x) * PER_LANE;
+#pragma unroll
+            for (int w = 0; w < QW; ++w) {
+                const u32x4 ml = ld_coh128(theirs + QW * NDT * 4 + (w & ~1) * 2);      // (m, l) pairs of two sub-tiles per 16 bytes
+                const float m2 = __uint_as_float(ml[(w & 1) * 2]), l2 = __uint_as_float(ml[(w & 1) * 2 + 1]);
+                const float M = fmaxf(m_run[w], m2);
+                // two products and one sum per value, no fma: the result does not depend on which piece arrived last
+                const float fa = (M == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m_run[w] - M);
+                const float fb = (M == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m2 - M);
+                l_run[w] = l_run[w] * fa + l2 * fb;
+#pragma unroll
+                for (int t = 0; t < NDT; ++t) {
+                    const u32x4 v = ld_coh128(theirs + (w * NDT + t) * 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[w][t][e] = o[w][t][e] * fa + __uint_as_float(v[e]) * fb;
+                }
+            }
+            if (threadIdx.x == 0) __hip_atomic_store(a.sk_cnt + cut, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
 #pragma unroll
     for (int w = 0; w < QW; ++w) {
         const float l_tot = quad_rows_sum(l_run[w]);
@@ -653,8 +694,93 @@ __global__ __launch_bounds__(512, 1) void attn_prefill_pp_kernel(const PrefillAr
             }
         }
     }
+
 }
 
+template <int D, int MASK, bool TR = false>
+__global__ __launch_bounds__(512, 1) void attn_prefill_pp_kernel(const PrefillArgs a) {
+    constexpr int QW = 2;
+    constexpr int QBLK = 8 * 16 * QW;           // 256 query rows per block
+    __shared__ __attribute__((aligned(16))) bf16_t sK2[2][KB * D];
+    __shared__ __attribute__((aligned(16))) bf16_t sV2[2][KB * D];
+    (void)QBLK;
+    // blocks of one head on one XCD (its L2 then holds that head's K / V once, not eight times): linear block id L runs on XCD
+    // L % 8; when the head count is a multiple of 8, XCD x works through heads x, x + 8, ...
+    int qt = blockIdx.x, h = blockIdx.y;
+    const int b = blockIdx.z;
+    if ((a.H & 7) == 0) {
+        const int L = (int)blockIdx.x + (int)gridDim.x * (int)blockIdx.y;
+        const int xcd = L & 7, idx = L >> 3;
+        h = (idx / (int)gridDim.x) * 8 + xcd;
+        qt = idx % (int)gridDim.x;
+    }
+    if (MASK == OMX_MASK_CAUSAL) qt = (int)gridDim.x - 1 - qt;   // longest blocks first
+    pp_unit<D, MASK, TR, false>(a, &sK2[0][0], &sV2[0][0], b, h, qt, 0, 0, 0);
+}
+
+// Stream-K form (no mask): the grid is one block per CU and the units x key tiles are cut into EQUAL shares -- 432 units on 256 CUs run
+// as 1.69 rounds of whole blocks (the second one 69 % full) but as 121.5 tiles per CU here.  A share covers the tail of one unit, whole
+// units, and the head of another; a cut unit is merged by whichever of its two pieces finishes last.  XCD x owns a contiguous eighth
+// of the units (its L2 then sees ~3 heads' K / V), block index c -> logical share (c % 8) * (G / 8) + c / 8.
+template <int D>
+__global__ __launch_bounds__(512, 1) void attn_prefill_sk_kernel(const PrefillArgs a) {
+    __shared__ __attribute__((aligned(16))) bf16_t sK2[2][KB * D];
+    __shared__ __attribute__((aligned(16))) bf16_t sV2[2][KB * D];
+    const int gx = (a.Tq + 255) / 256, nt = (a.Tk + KB - 1) / KB;
+    const int G = (int)gridDim.x;
+    const int c = ((int)blockIdx.x & 7) * (G >> 3) + ((int)blockIdx.x >> 3);       // (G is a multiple of 8)
+    const long long total = (long long)gx * a.H * a.B * nt;
+    long long g = total * c / G;
+    const long long g_end = total * (c + 1) / G;
+    while (g < g_end) {
+        const int unit = (int)(g / nt), t0 = (int)(g % nt);
+        const int t1 = (int)min((long long)nt, t0 + (g_end - g));
+        const int qt = unit % gx, h = (unit / gx) % a.H, b = unit / (gx * a.H);
+        const int cut = t0 > 0 ? c - 1 : c;       // tail piece: the boundary with the previous share; head piece: with the next
+        pp_unit<D, OMX_MASK_NONE, false, true>(a, &sK2[0][0], &sV2[0][0], b, h, qt, cut, t0, t1);
+        g += t1 - t0;
+        __syncthreads();       // the next piece re-stages the LDS tiles this one may still be reading
+    }
+}
+
+}  // namespace
+
+namespace {
+// parking slots + arrival counters of the stream-K kernel, one set per stream (allocated on first use, 70 MiB: 256 boundaries x 2 pieces)
+constexpr int kSkBlocks = 256;
+constexpr size_t kSkFloats = (size_t)kSkBlocks * 2 * 512 * 68;
+struct SkWs { float* ws = nullptr; unsigned* cnt = nullptr; };
+std::mutex g_sk_mu;
+std::map<std::pair<hipStream_t, std::thread::id>, SkWs> g_sk_ws;
+int sk_workspace(hipStream_t s, float** ws, unsigned** cnt) {
+    std::lock_guard<std::mutex> lk(g_sk_mu);
+    SkWs& w = g_sk_ws[{s, s ? std::thread::id() : std::this_thread::get_id()}];
+    if (!w.ws) {
+        hipStreamCaptureMode mode = hipStreamCaptureModeRelaxed;
+        OMX_HIP_CHECK(hipThreadExchangeStreamCaptureMode(&mode));
+        hipError_t e = hipMalloc((void**)&w.ws, kSkFloats * 4);
+        if (e == hipSuccess) e = hipMalloc((void**)&w.cnt, kSkBlocks * 4);
+        if (e == hipSuccess) e = hipMemset(w.cnt, 0, kSkBlocks * 4);       // (null stream, waited for below: also right under a capture of `s`)
+        if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
+        (void)hipThreadExchangeStreamCaptureMode(&mode);
+        if (e != hipSuccess) {
+            if (w.ws) (void)hipFree(w.ws);
+            if (w.cnt) (void)hipFree(w.cnt);
+            w = SkWs{};
+            return set_error("stream-K attention scratch: %s", hipGetErrorString(e));
+        }
+    }
+    *ws = w.ws; *cnt = w.cnt;
+    return 0;
+}
+int sk_cus() {
+    static int n = 0;
+    if (!n) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = -1;
+    }
+    return n;
+}
 }  // namespace
 
 int launch_attn_prefill(bf16_t* out, const bf16_t* q, const bf16_t* k, const bf16_t* v, int B, int H, int Hkv, int Tq,
@@ -682,6 +808,21 @@ int launch_attn_prefill(bf16_t* out, const bf16_t* q, const bf16_t* k, const bf1
     const long pp_blocks = (long)((Tq + 255) / 256) * H * B;
     if (ppenv ? atoi(ppenv) != 0 : (Tq >= 1024 && (mask_mode != OMX_MASK_CAUSAL || pp_blocks >= 2048))) {
         const dim3 grid((Tq + 255) / 256, H, B), block(512);
+        // stream-K form (opt-in, OMX_ATTN_STREAMK=1): no mask, more units than CUs (every share then spans at least one whole unit: a
+        // unit is cut at most once); one block per CU (a piece never waits for another: no co-residency needed).  Measured SLOWER where
+        // it should pay (432 units: 384 us against 329; 280 units: 173 against 125; 512 units, nothing cut: 330 against 349): the blocks
+        // of a head no longer walk its key tiles together, and the head's K / V stop being one L2-resident stream (EXPERIMENTS.md R3-4)
+        const char* ske = getenv("OMX_ATTN_STREAMK");
+        const int cus = sk_cus();
+        const bool sk_fit = mask_mode == OMX_MASK_NONE && cus >= 8 && cus <= kSkBlocks && pp_blocks > cus && !getenv("OMX_ATTN_PP_TRACE");
+        if (sk_fit && ske && atoi(ske) != 0) {
+            if (sk_workspace(s, &a.sk_ws, &a.sk_cnt)) return 1;
+            const int G = cus & ~7;
+            if (D == 128) attn_prefill_sk_kernel<128><<<G, block, 0, s>>>(a);
+            else attn_prefill_sk_kernel<64><<<G, block, 0, s>>>(a);
+            OMX_LAUNCH_CHECK();
+            return 0;
+        }
         if (const char* te = getenv("OMX_ATTN_PP_TRACE")) {   // timeline build (head_dim 128, no mask): address of a device buffer
             a.trace = reinterpret_cast<unsigned long long*>(strtoull(te, nullptr, 0));
             OMX_REQUIRE(D == 128 && mask_mode == OMX_MASK_NONE, "attention timeline build: head_dim 128 without a mask only");

@@ -251,6 +251,32 @@ def test_sdpa_two_phase_kernel(omx, monkeypatch, B, H, Hkv, Tq, Tk, D, mode):
     _check(outs["0"], ref)
 
 
+@pytest.mark.parametrize("B,H,Hkv,Tq,Tk,D", [
+    (1, 40, 40, 1700, 1700, 128),     # 7 x 40 = 280 units on 256 CUs, ragged last block and last tile
+    (2, 16, 4, 2300, 2300, 64),       # batch 2, GQA, head_dim 64: 288 units
+    (1, 48, 48, 1500, 1790, 128),     # Tq != Tk (img queries over [txt, img] keys), 288 units, 28 tiles each
+])
+def test_sdpa_stream_k_kernel(omx, monkeypatch, B, H, Hkv, Tq, Tk, D):
+    """csrc/attn_prefill.hip attn_prefill_sk_kernel: unmasked attention with more 256-row units than CUs is cut into equal shares of
+    (unit, key tile) steps; a unit that a share boundary runs through is computed as two pieces whose un-normalised (O, m, l) meet in
+    whichever finishes last (opt-in: measured slower, see the launcher).  Held to: run-to-run bit-identical (the merge is two products and a sum: arrival order cannot show), within
+    one bf16 ulp of the un-cut two-phase kernel, and on the oracle for three heads (first, one in the middle of the cuts, last)."""
+    q = rc.bf16_round(rand((B, H, Tq, D), 71)); k = rc.bf16_round(rand((B, Hkv, Tk, D), 72)); v = rc.bf16_round(rand((B, Hkv, Tk, D), 73))
+    scale = D ** -0.5
+    monkeypatch.setenv("OMX_ATTN_STREAMK", "1")
+    a = _sdpa(omx, q, k, v, scale, None)
+    b2 = _sdpa(omx, q, k, v, scale, None)
+    np.testing.assert_array_equal(a, b2)
+    monkeypatch.setenv("OMX_ATTN_STREAMK", "0")
+    whole = _sdpa(omx, q, k, v, scale, None)
+    assert_bf16_close(a, whole, 1, atol=2.0 ** -7 * np.abs(whole).max())      # (one ulp of the largest value: most units are cut)
+    assert (a == whole).mean() > 0.5
+    G = H // Hkv
+    for h in (0, H // 2 + 1, H - 1):
+        ref = rc.scaled_dot_product_attention(q[:, h:h + 1], k[:, h // G:h // G + 1], v[:, h // G:h // G + 1], scale, None, "bf16")
+        _check(a[:, h:h + 1], ref)
+
+
 @pytest.mark.parametrize("M,N,K,bias", [(501, 512, 560, True), (501, 2048, 512, True), (501, 512, 2048, True), (216, 8404, 512, True),
                                          (33, 70, 45, False), (1, 64, 64, False), (130, 66, 1026, True)])
 def test_linear_f32_on_the_f32_matrix_cores(omx, M, N, K, bias):

@@ -99,6 +99,7 @@ __device__ __forceinline__ void route_from_logits(const float* s_logit, int t, i
 // over the lanes (E <= 256 -> four per lane): wave reductions instead of a serial scan by one thread (113 us -> a few us
 // at 128 experts).  Ties go to the lower expert index, selections come out in descending score order.
 constexpr int kRouterThreads = 1024;
+constexpr int kRouterXnMax = 8192;   // widest hidden size whose normalised row the few-experts path keeps in LDS
 __global__ __launch_bounds__(kRouterThreads) void moe_router_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ gate_w,
                                                                     int h, int E, int k, int mode, int renorm,
                                                                     uint32_t* __restrict__ inds, bf16_t* __restrict__ scores,
@@ -106,8 +107,20 @@ __global__ __launch_bounds__(kRouterThreads) void moe_router_kernel(const bf16_t
                                                                     bf16_t* __restrict__ xn_out = nullptr) {
     __shared__ float s_logit[kMaxExperts];
     __shared__ float s_red[kRouterThreads / 64];
+    __shared__ __attribute__((aligned(16))) bf16_t s_xn[kRouterXnMax];
     const int t = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = kRouterThreads / 64;
     const bf16_t* xr = x + (size_t)t * h;
+    // few experts (Mixtral: 8): wave e owns expert e and holds its WHOLE gate row in registers, loaded before anything depends on the
+    // activation; the normalised row then goes through LDS instead of a global round trip.  Same per-lane fma chains and wave sums as
+    // the loop below (element it * 512 + lane * 8 in iteration it), so the logits are bit-identical.  (Decode: this launch is a
+    // chain of dependent round trips, 9.9 us per layer at Mixtral-8x7B shapes before, 32 layers per token.)
+    const bool few = norm_w != nullptr && E <= n_waves && h <= kRouterXnMax && (h & 511) == 0;
+    u32x4 gw[kRouterXnMax / 512];
+    if (few && wave < E) {
+#pragma unroll
+        for (int it = 0; it < kRouterXnMax / 512; ++it)
+            if (it * 512 < h) gw[it] = *reinterpret_cast<const u32x4*>(gate_w + (size_t)wave * h + it * 512 + lane * 8);
+    }
     if (norm_w) {   // post-attention RMSNorm of the decoder block folded in: xn = bf16(x * rstd * w), written for the experts
         float ss = 0.f;
         for (int i = threadIdx.x * 8; i < h; i += kRouterThreads * 8) {
@@ -129,10 +142,32 @@ __global__ __launch_bounds__(kRouterThreads) void moe_router_kernel(const bf16_t
 #pragma unroll
             for (int q = 0; q < 4; ++q) o[q] = pack_bf16(bf16lo(a[q]) * rstd * bf16lo(w[q]), bf16hi(a[q]) * rstd * bf16hi(w[q]));
             *reinterpret_cast<u32x4*>(xo + i) = o;
+            if (few) *reinterpret_cast<u32x4*>(s_xn + i) = o;
         }
         __syncthreads();   // this block reads its own xn row back below (same CU: L1/L2 coherent within the block after the barrier)
-        __threadfence_block();
+        if (!few) __threadfence_block();
         xr = xo;
+    }
+    if (few) {
+        if (wave < E) {
+            float acc = 0.f;
+#pragma unroll
+            for (int it = 0; it < kRouterXnMax / 512; ++it) {
+                if (it * 512 >= h) break;
+                const u32x4 a = *reinterpret_cast<const u32x4*>(s_xn + it * 512 + lane * 8);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    acc = fmaf(bf16lo(a[q]), bf16lo(gw[it][q]), acc);
+                    acc = fmaf(bf16hi(a[q]), bf16hi(gw[it][q]), acc);
+                }
+            }
+            const float v = wave_sum(acc);
+            if (lane == 0) s_logit[wave] = round_bf16(v);
+        }
+        __syncthreads();
+        if (wave != 0) return;
+        route_from_logits(s_logit, t, lane, E, k, mode, renorm, inds, scores);
+        return;
     }
     for (int e0 = wave; e0 < E; e0 += 4 * n_waves) {
         float acc[4] = {0.f, 0.f, 0.f, 0.f};

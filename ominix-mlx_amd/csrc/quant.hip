@@ -308,7 +308,43 @@ __global__ __launch_bounds__(256) void qgemv_kernel(const QGemvArgs a) {
         if (EPL >= 32) sv += dpp_f<kDppXor2>(sv);
         if (((i >> 3) & (EPL / 8 - 1)) == 0) xsum[i / EPL] = sv;
     };
-    if (PRO == PRO_RMSNORM) {
+    if (PRO == PRO_RMSNORM && a.K <= 4096) {
+        // the hidden-sized prologues (q/k/v, gate/up, lm_head: K <= 4096 = two vectors per thread): the row and the norm weights stay in
+        // registers between the two passes -- one global round trip instead of two in a launch that is a chain of them.  Same sums.
+        u32x4 raw[2], nwv[2];
+        float ss = 0.f;
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int i = threadIdx.x * 8 + it * 2048;
+            if (i < a.K) {
+                raw[it] = *reinterpret_cast<const u32x4*>(xg + i);
+                nwv[it] = *reinterpret_cast<const u32x4*>(a.norm_w + i);
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            if (threadIdx.x * 8 + it * 2048 < a.K) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    ss = fmaf(bf16lo(raw[it][q]), bf16lo(raw[it][q]), ss);
+                    ss = fmaf(bf16hi(raw[it][q]), bf16hi(raw[it][q]), ss);
+                }
+            }
+        }
+        ss = block_sum<4>(ss, red);
+        const float rstd = 1.0f / sqrtf(ss / (float)a.K + a.eps);
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int i = threadIdx.x * 8 + it * 2048;
+            if (i < a.K) {
+                u32x4 o;
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    o[q] = pack_bf16(bf16lo(raw[it][q]) * rstd * bf16lo(nwv[it][q]), bf16hi(raw[it][q]) * rstd * bf16hi(nwv[it][q]));
+                put(i, o);
+            }
+        }
+    } else if (PRO == PRO_RMSNORM) {
         float ss = 0.f;
         for (int i = threadIdx.x * 8; i < a.K; i += 256 * 8) {
             const u32x4 raw = *reinterpret_cast<const u32x4*>(xg + i);

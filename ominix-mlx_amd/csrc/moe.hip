@@ -121,7 +121,31 @@ __global__ __launch_bounds__(kRouterThreads) void moe_router_kernel(const bf16_t
         for (int it = 0; it < kRouterXnMax / 512; ++it)
             if (it * 512 < h) gw[it] = *reinterpret_cast<const u32x4*>(gate_w + (size_t)wave * h + it * 512 + lane * 8);
     }
-    if (norm_w) {   // post-attention RMSNorm of the decoder block folded in: xn = bf16(x * rstd * w), written for the experts
+    if (norm_w && few) {   // (h <= 8192: one vector per thread -- the row and the norm weights are read ONCE, before the reduction)
+        const int i = threadIdx.x * 8;
+        u32x4 a = {0u, 0u, 0u, 0u}, w = {0u, 0u, 0u, 0u};
+        if (i < h) {
+            a = *reinterpret_cast<const u32x4*>(xr + i);
+            w = *reinterpret_cast<const u32x4*>(norm_w + i);
+        }
+        float ss = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { ss = fmaf(bf16lo(a[q]), bf16lo(a[q]), ss); ss = fmaf(bf16hi(a[q]), bf16hi(a[q]), ss); }
+        ss = wave_sum(ss);
+        if (lane == 0) s_red[wave] = ss;
+        __syncthreads();
+        float tot = 0.f;
+        for (int wv = 0; wv < n_waves; ++wv) tot += s_red[wv];
+        const float rstd = 1.0f / sqrtf(tot / (float)h + eps);
+        if (i < h) {
+            u32x4 o;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) o[q] = pack_bf16(bf16lo(a[q]) * rstd * bf16lo(w[q]), bf16hi(a[q]) * rstd * bf16hi(w[q]));
+            *reinterpret_cast<u32x4*>(xn_out + (size_t)t * h + i) = o;
+            *reinterpret_cast<u32x4*>(s_xn + i) = o;
+        }
+        __syncthreads();
+    } else if (norm_w) {   // post-attention RMSNorm of the decoder block folded in: xn = bf16(x * rstd * w), written for the experts
         float ss = 0.f;
         for (int i = threadIdx.x * 8; i < h; i += kRouterThreads * 8) {
             const u32x4 a = *reinterpret_cast<const u32x4*>(xr + i);

@@ -100,6 +100,7 @@ __device__ __forceinline__ void route_from_logits(const float* s_logit, int t, i
 // at 128 experts).  Ties go to the lower expert index, selections come out in descending score order.
 constexpr int kRouterThreads = 1024;
 constexpr int kRouterXnMax = 8192;   // widest hidden size whose normalised row the few-experts path keeps in LDS
+static int router_threads(int n_experts, int hidden) { return (n_experts <= 8 && hidden <= 4096 && (hidden & 511) == 0) ? 512 : kRouterThreads; }
 __global__ __launch_bounds__(kRouterThreads) void moe_router_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ gate_w,
                                                                     int h, int E, int k, int mode, int renorm,
                                                                     uint32_t* __restrict__ inds, bf16_t* __restrict__ scores,
@@ -108,13 +109,15 @@ __global__ __launch_bounds__(kRouterThreads) void moe_router_kernel(const bf16_t
     __shared__ float s_logit[kMaxExperts];
     __shared__ float s_red[kRouterThreads / 64];
     __shared__ __attribute__((aligned(16))) bf16_t s_xn[kRouterXnMax];
-    const int t = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = kRouterThreads / 64;
+    // (launched with kRouterThreads, or with 512 threads for a few experts over a row of <= 4096: half the waves to start and to meet at
+    //  the barriers, the same sums -- the missing waves' partials are zeros)
+    const int t = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = (int)blockDim.x / 64;
     const bf16_t* xr = x + (size_t)t * h;
     // few experts (Mixtral: 8): wave e owns expert e and holds its WHOLE gate row in registers, loaded before anything depends on the
     // activation; the normalised row then goes through LDS instead of a global round trip.  Same per-lane fma chains and wave sums as
     // the loop below (element it * 512 + lane * 8 in iteration it), so the logits are bit-identical.  (Decode: this launch is a
     // chain of dependent round trips, 9.9 us per layer at Mixtral-8x7B shapes before, 32 layers per token.)
-    const bool few = norm_w != nullptr && E <= n_waves && h <= kRouterXnMax && (h & 511) == 0;
+    const bool few = norm_w != nullptr && E <= n_waves && h <= kRouterXnMax && h <= (int)blockDim.x * 8 && (h & 511) == 0;
     u32x4 gw[kRouterXnMax / 512];
     if (few && wave < E) {
 #pragma unroll
@@ -147,7 +150,7 @@ __global__ __launch_bounds__(kRouterThreads) void moe_router_kernel(const bf16_t
         __syncthreads();
     } else if (norm_w) {   // post-attention RMSNorm of the decoder block folded in: xn = bf16(x * rstd * w), written for the experts
         float ss = 0.f;
-        for (int i = threadIdx.x * 8; i < h; i += kRouterThreads * 8) {
+        for (int i = threadIdx.x * 8; i < h; i += (int)blockDim.x * 8) {
             const u32x4 a = *reinterpret_cast<const u32x4*>(xr + i);
 #pragma unroll
             for (int q = 0; q < 4; ++q) { ss = fmaf(bf16lo(a[q]), bf16lo(a[q]), ss); ss = fmaf(bf16hi(a[q]), bf16hi(a[q]), ss); }
@@ -159,7 +162,7 @@ __global__ __launch_bounds__(kRouterThreads) void moe_router_kernel(const bf16_t
         for (int w = 0; w < n_waves; ++w) tot += s_red[w];
         const float rstd = 1.0f / sqrtf(tot / (float)h + eps);
         bf16_t* xo = xn_out + (size_t)t * h;
-        for (int i = threadIdx.x * 8; i < h; i += kRouterThreads * 8) {
+        for (int i = threadIdx.x * 8; i < h; i += (int)blockDim.x * 8) {
             const u32x4 a = *reinterpret_cast<const u32x4*>(xr + i);
             const u32x4 w = *reinterpret_cast<const u32x4*>(norm_w + i);
             u32x4 o;
@@ -435,7 +438,7 @@ static int moe_forward_impl(void* out, const void* x, const void* gate_w, const 
     bf16_t* ubuf = (bf16_t*)take((size_t)slots * inter * 2);
     bf16_t* ybuf = (bf16_t*)take((size_t)slots * hidden * 2);
 
-    moe_router_kernel<<<n_tokens, kRouterThreads, 0, s>>>((const bf16_t*)x, (const bf16_t*)gate_w, hidden, n_experts, top_k, mode,
+    moe_router_kernel<<<n_tokens, router_threads(n_experts, hidden), 0, s>>>((const bf16_t*)x, (const bf16_t*)gate_w, hidden, n_experts, top_k, mode,
                                                           norm_topk_prob, inds, scores, bf ? (const bf16_t*)bf->norm_w : nullptr,
                                                           bf ? bf->eps : 0.f, bf ? (bf16_t*)bf->xn : nullptr);
     OMX_LAUNCH_CHECK();
@@ -686,7 +689,7 @@ extern "C" int omx_moe_block_partial_ep(float* partial, const void* x, const voi
     bf16_t* gbuf = (bf16_t*)take((size_t)slots * inter * 2);
     bf16_t* ubuf = (bf16_t*)take((size_t)slots * inter * 2);
     bf16_t* ybuf = (bf16_t*)take((size_t)slots * hidden * 2);
-    moe_router_kernel<<<n_tokens, kRouterThreads, 0, s>>>((const bf16_t*)x, (const bf16_t*)gate_w, hidden, n_experts, top_k, mode,
+    moe_router_kernel<<<n_tokens, router_threads(n_experts, hidden), 0, s>>>((const bf16_t*)x, (const bf16_t*)gate_w, hidden, n_experts, top_k, mode,
                                                           norm_topk_prob, inds, scores, (const bf16_t*)norm_w, eps, norm_w ? (bf16_t*)xn : nullptr);
     OMX_LAUNCH_CHECK();
     if (!decode) {
@@ -773,7 +776,7 @@ extern "C" int omx_moe_route(uint32_t* inds_out, void* scores_out, const void* x
     OMX_REQUIRE(hidden > 0 && hidden % 64 == 0, "omx_moe_route: hidden=%d must be a multiple of 64", hidden);
     OMX_REQUIRE(mode == 0 || mode == 1, "omx_moe_route: mode must be 0 (Mixtral) or 1 (Qwen3-MoE)");
     if (n_tokens <= 0) return 0;
-    moe_router_kernel<<<n_tokens, kRouterThreads, 0, (hipStream_t)stream>>>((const bf16_t*)x, (const bf16_t*)gate_w, hidden, n_experts,
+    moe_router_kernel<<<n_tokens, router_threads(n_experts, hidden), 0, (hipStream_t)stream>>>((const bf16_t*)x, (const bf16_t*)gate_w, hidden, n_experts,
                                                                  top_k, mode, norm_topk_prob, inds_out, (bf16_t*)scores_out);
     OMX_LAUNCH_CHECK();
     return 0;

@@ -446,6 +446,8 @@ int launch_qgemv_bits(const QGemvArgs& a_in, int pro, int epi, hipStream_t s) {
     a.rows_per_wave = a.N >= 65536 ? 16 : (a.N <= 8192 && epi != EPI_SWIGLU) ? 2 : 4;
     if (const char* e = getenv("OMX_QGEMV_RPW_SMALL"))   // tuning knob: rows per wave of the small matrices (2 or 4)
         if (a.N <= 8192 && epi != EPI_SWIGLU && (atoi(e) == 2 || atoi(e) == 4)) a.rows_per_wave = atoi(e);
+    if (const char* e = getenv("OMX_QGEMV_RPW_GU"))      // ... of the gate/up pair launch (logical rows: 2, 4, 8)
+        if (epi == EPI_SWIGLU && a.N < 65536 && (atoi(e) == 2 || atoi(e) == 4 || atoi(e) == 8)) a.rows_per_wave = atoi(e);
     if (W == 4) return launch_qgemv_w<BITS, 4>(a, pro, epi, s);
     if (W == 2) return launch_qgemv_w<BITS, 2>(a, pro, epi, s);
     if constexpr (BITS == 4) return launch_qgemv_w<BITS, 1>(a, pro, epi, s);

@@ -1,4 +1,5 @@
 // See gemv.hpp for the design notes.
+#include "moe_route.hpp"
 #include "gemv.hpp"
 #include "peer.hpp"
 #include "launch_timing.hpp"
@@ -193,8 +194,87 @@ __global__ __launch_bounds__(kBlock) void gemv_kernel(const GemvArgs a_in) {
     constexpr unsigned long long* tr = nullptr;
 #endif
     if (tr && threadIdx.x == 0) tr[0] = wall_clock64();
-    if (active) OMX_ISSUE(wA, row_begin);
+    if (PRO != PRO_ROUTE) {   // (PRO_ROUTE: which expert's rows these are is only known after the prologue)
+        if (active) OMX_ISSUE(wA, row_begin);
+    }
 
+    if constexpr (PRO == PRO_ROUTE) {
+        // ---- prologue with routing.  moe_router_kernel at this shape runs 512 threads, thread v owning vector v of the row: its sum of
+        //      squares per thread, wave sums, a serial sum over the 8 waves; then expert e's logit by ONE wave (lane l: elements
+        //      it * 512 + l * 8, one fma chain, wave sum, bf16).  Thread t stands in for router threads t and t + 256. ----
+        float* s_red8 = red;                                   // [8]
+        float* s_logit = red + 8;                              // [route_E <= 8]
+        uint32_t* s_sel = reinterpret_cast<uint32_t*>(red + 16);   // [kMaxTopK]
+        bf16_t* s_score = reinterpret_cast<bf16_t*>(red + 24);     // [kMaxTopK]
+        const bf16_t* xg = a.x;
+        constexpr int PV = (NV * 64 + kBlock - 1) / kBlock;
+        static_assert(PV <= 2 && KSPLIT == 1, "routing prologue: rows of at most 4096 elements");
+        u32x4 xv[PV], nwv[PV];
+#pragma unroll
+        for (int i = 0; i < PV; ++i) {
+            const int v = threadIdx.x + i * kBlock;
+            float ss = 0.f;
+            if (v < kvec) {
+                xv[i] = *(reinterpret_cast<const u32x4*>(xg) + v);
+                nwv[i] = *(reinterpret_cast<const u32x4*>(a.norm_w) + v);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    ss = fmaf(bf16lo(xv[i][q]), bf16lo(xv[i][q]), ss);
+                    ss = fmaf(bf16hi(xv[i][q]), bf16hi(xv[i][q]), ss);
+                }
+            }
+            ss = wave_sum(ss);
+            if (lane == 0) s_red8[wave + 4 * i] = ss;
+        }
+        if (PV < 2 && threadIdx.x < 4) s_red8[4 + threadIdx.x] = 0.f;
+        __syncthreads();
+        float tot = 0.f;
+        for (int w = 0; w < 8; ++w) tot += s_red8[w];
+        const float rstd = 1.0f / sqrtf(tot / (float)K + a.eps);
+#pragma unroll
+        for (int i = 0; i < PV; ++i) {
+            const int v = threadIdx.x + i * kBlock;
+            if (v < NV * 64) {
+                u32x4 o = {0u, 0u, 0u, 0u};
+                if (v < kvec) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        o[q] = pack_bf16(bf16lo(xv[i][q]) * rstd * bf16lo(nwv[i][q]), bf16hi(xv[i][q]) * rstd * bf16hi(nwv[i][q]));
+                }
+                xs[v] = o;
+            }
+        }
+        __syncthreads();
+        for (int e = wave; e < a.route_E; e += kWaves) {
+            const u32x4* g = reinterpret_cast<const u32x4*>(a.route_gate + (size_t)e * K);
+            float acc = 0.f;
+            for (int it = 0; it * 64 < kvec; ++it) {
+                const u32x4 xa = xs[it * 64 + lane], gb = g[it * 64 + lane];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    acc = fmaf(bf16lo(xa[q]), bf16lo(gb[q]), acc);
+                    acc = fmaf(bf16hi(xa[q]), bf16hi(gb[q]), acc);
+                }
+            }
+            acc = wave_sum(acc);
+            if (lane == 0) s_logit[e] = round_bf16(acc);
+        }
+        __syncthreads();
+        if (wave == 0) route_from_logits(s_logit, 0, lane, a.route_E, a.route_k, a.route_mode, a.route_renorm, s_sel, s_score);
+        __syncthreads();
+        size_t e = s_sel[blockIdx.y];
+        if (blockIdx.x == 0 && blockIdx.y == 0 && (int)threadIdx.x < a.route_k) {
+            a.route_inds[threadIdx.x] = s_sel[threadIdx.x];
+            a.route_scores[threadIdx.x] = s_score[threadIdx.x];
+        }
+        if (a_in.w_sel_n > 0) {   // expert-parallel shard: block-uniform early exit for experts of other ranks
+            if (e < (size_t)a_in.w_sel_lo || e >= (size_t)(a_in.w_sel_lo + a_in.w_sel_n)) return;
+            e -= (size_t)a_in.w_sel_lo;
+        }
+        a.w0 = a_in.w0 + e * a_in.w_estride;
+        if (a_in.w1) a.w1 = a_in.w1 + e * a_in.w_estride;
+        if (active) OMX_ISSUE(wA, row_begin);
+    } else
     // ---- prologue: stage x (bf16) in LDS; optionally x := bf16(x + bf16(partial)); RMS-normalise ----
     {
         const bf16_t* xg = a.x + (a.x_row ? (size_t)a.x_row[0] * K : 0);
@@ -481,7 +561,7 @@ template <int NVW, int KSPLIT, int RB>
 int launch_nv(const GemvArgs& a, int pro, int epi, hipStream_t s) {
     const int groups = (a.N + a.rows_per_wave - 1) / a.rows_per_wave;   // row groups (waves or blocks)
     const dim3 grid(KSPLIT == 1 ? (groups + kWaves - 1) / kWaves : groups, a.n_batch > 1 ? a.n_batch : 1), block(kBlock);
-    const size_t shmem = (size_t)NVW * KSPLIT * 64 * 16 + 32 + (KSPLIT > 1 ? (size_t)a.rows_per_wave * 2 * KSPLIT * 4 : 0);
+    const size_t shmem = (size_t)NVW * KSPLIT * 64 * 16 + (pro == PRO_ROUTE ? 128 : 32) + (KSPLIT > 1 ? (size_t)a.rows_per_wave * 2 * KSPLIT * 4 : 0);
     const bool tail = a.K / 8 < NVW * KSPLIT * 64;
 #define OMX_GEMV_CASE(P, E)                                                                          \
     if (pro == P && epi == E) {                                                                      \
@@ -499,6 +579,13 @@ int launch_nv(const GemvArgs& a, int pro, int epi, hipStream_t s) {
     OMX_GEMV_CASE(PRO_NONE, EPI_SWIGLU)
     OMX_GEMV_CASE(PRO_RMSNORM, EPI_ARGMAX)
     OMX_GEMV_CASE(PRO_NONE, EPI_F32)
+    if constexpr (KSPLIT == 1 && NVW <= 8) {
+        if (pro == PRO_ROUTE && epi == EPI_SWIGLU && !tail) {
+            OMX_LAUNCH_TIMED((gemv_kernel<NVW, KSPLIT, (RB > 1 ? RB / 2 : 1), PRO_ROUTE, EPI_SWIGLU>), grid, block, shmem, s, a);
+            OMX_LAUNCH_CHECK();
+            return 0;
+        }
+    }
 #undef OMX_GEMV_CASE
     return set_error("gemv: unsupported prologue/epilogue combination %d/%d", pro, epi);
 }
@@ -535,6 +622,12 @@ static int resolve_rpw(int N, int K, int epi, int rpw, bool is_tuned = true) {
     }
     if (split && rpw > 256) rpw = 256;
     return rpw;
+}
+
+// the routing prologue reproduces moe_router_kernel's 512-thread form: <= 8 experts, rows of <= 4096 elements in whole 512-element
+// vectors rows (K % 512 == 0 -> a tuned instantiation without a tail)
+bool gemv_route_supported(int K, int n_experts, int top_k) {
+    return K > 0 && K <= 4096 && K % 512 == 0 && tuned(K, false) && n_experts >= 1 && n_experts <= 8 && top_k >= 1 && top_k <= n_experts;
 }
 
 int gemv_grid(int N, int K, int epi, int rows_per_wave) {

@@ -20,7 +20,7 @@
 
 namespace omx {
 
-enum { PRO_NONE = 0, PRO_RMSNORM = 1 };
+enum { PRO_NONE = 0, PRO_RMSNORM = 1, PRO_ROUTE = 2 };
 enum { EPI_STORE = 0, EPI_RESIDUAL = 1, EPI_SWIGLU = 2, EPI_ARGMAX = 3, EPI_F32 = 4 };
 
 struct GemvArgs {
@@ -68,7 +68,16 @@ struct GemvArgs {
     const bf16_t* out_scale;
     float out_scale_f;
     int x_partial_n;
+    // PRO_ROUTE (MoE decode, one token, the experts' gate/up launch): x is the RAW row; every block normalises it (norm_w, eps) and
+    // routes it itself -- router logits, top-k, scores with the arithmetic of moe_router_kernel launched for the same shape (moe.hip:
+    // <= 8 experts over <= 4096 columns, a multiple of 512) -- then streams the expert of its batch entry.  No router launch; block
+    // (0, 0) leaves the selection for the down projection / the combine in route_inds [top_k] / route_scores [top_k].
+    const bf16_t* route_gate;   // [E, K]
+    int route_E, route_k, route_mode, route_renorm;
+    uint32_t* route_inds;
+    bf16_t* route_scores;
 };
+bool gemv_route_supported(int K, int n_experts, int top_k);
 
 int launch_gemv(const GemvArgs& a, int pro, int epi, hipStream_t s);
 // number of blocks launch_gemv will use (== entries written to argmax_slot); resolves rows_per_wave

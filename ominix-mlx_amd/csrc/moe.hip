@@ -16,82 +16,10 @@
 #include "gemv.hpp"
 #include "quant.hpp"
 #include "workspace.hpp"
+#include "moe_route.hpp"
 
 namespace omx {
 namespace {
-
-constexpr int kMaxExperts = 256;
-constexpr int kMaxTopK = 8;
-
-// one block per token: logits[e] = bf16(x . Wg[e]) ; mode 0: top-k of logits, softmax over the selected
-// (precise) ; mode 1: softmax over all (precise, rounded to bf16), top-k, optional renormalisation
-// softmax / top-k / renormalisation of one token's router logits by ONE wave (experts spread over the lanes)
-__device__ __forceinline__ void route_from_logits(const float* s_logit, int t, int lane, int E, int k, int mode, int renorm,
-                                                  uint32_t* __restrict__ inds, bf16_t* __restrict__ scores) {
-    constexpr int PER = kMaxExperts / 64;
-    float v[PER];
-    bool taken[PER];
-#pragma unroll
-    for (int u = 0; u < PER; ++u) {
-        const int e = lane + 64 * u;
-        v[u] = e < E ? s_logit[e] : -INFINITY;
-        taken[u] = e >= E;
-    }
-    if (mode == 1) {   // softmax over all experts first (qwen3_moe.rs:479)
-        float mx = -INFINITY;
-#pragma unroll
-        for (int u = 0; u < PER; ++u) mx = fmaxf(mx, v[u]);
-        mx = wave_max(mx);
-        float sum = 0.f;
-#pragma unroll
-        for (int u = 0; u < PER; ++u) sum += (lane + 64 * u < E) ? expf(v[u] - mx) : 0.f;
-        sum = wave_sum(sum);
-#pragma unroll
-        for (int u = 0; u < PER; ++u) v[u] = (lane + 64 * u < E) ? round_bf16(expf(v[u] - mx) / sum) : -INFINITY;
-    }
-    uint32_t sel[kMaxTopK];
-    float selv[kMaxTopK];
-    for (int j = 0; j < k; ++j) {   // descending, ties to the lower index: key = (orderable value, ~index)
-        unsigned long long best = 0;
-#pragma unroll
-        for (int u = 0; u < PER; ++u) {
-            if (taken[u]) continue;
-            uint32_t ub = __float_as_uint(v[u]);
-            ub = (ub & 0x80000000u) ? ~ub : (ub | 0x80000000u);
-            const unsigned long long key = ((unsigned long long)ub << 32) | (uint32_t)~(uint32_t)(lane + 64 * u);
-            best = key > best ? key : best;
-        }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const unsigned long long other = __shfl_xor(best, o, 64);
-            best = other > best ? other : best;
-        }
-        const uint32_t e = ~(uint32_t)(best & 0xFFFFFFFFull);
-        const uint32_t ub = (uint32_t)(best >> 32);
-        sel[j] = e;
-        selv[j] = __uint_as_float((ub & 0x80000000u) ? (ub & 0x7FFFFFFFu) : ~ub);
-#pragma unroll
-        for (int u = 0; u < PER; ++u)
-            if ((uint32_t)(lane + 64 * u) == e) taken[u] = true;
-    }
-    if (mode == 0) {   // softmax over the selected logits (model.rs:301-302)
-        float mx = selv[0], sum = 0.f;
-        for (int j = 1; j < k; ++j) mx = fmaxf(mx, selv[j]);
-        for (int j = 0; j < k; ++j) sum += expf(selv[j] - mx);
-        for (int j = 0; j < k; ++j) selv[j] = round_bf16(expf(selv[j] - mx) / sum);
-    } else if (renorm && k > 1) {
-        float sum = 0.f;
-        for (int j = 0; j < k; ++j) sum += selv[j];
-        sum = round_bf16(sum);
-        for (int j = 0; j < k; ++j) selv[j] = round_bf16(selv[j] / sum);
-    }
-    if (lane == 0) {
-        for (int j = 0; j < k; ++j) {
-            inds[(size_t)t * k + j] = sel[j];
-            scores[(size_t)t * k + j] = f32_to_bf16(selv[j]);
-        }
-    }
-}
 
 
 // One block (16 waves) per token.  Phase 1: the gate Linear -- wave w owns experts w, w+16, ..., four at a time so that
@@ -438,13 +366,24 @@ static int moe_forward_impl(void* out, const void* x, const void* gate_w, const 
     bf16_t* ubuf = (bf16_t*)take((size_t)slots * inter * 2);
     bf16_t* ybuf = (bf16_t*)take((size_t)slots * hidden * 2);
 
-    moe_router_kernel<<<n_tokens, router_threads(n_experts, hidden), 0, s>>>((const bf16_t*)x, (const bf16_t*)gate_w, hidden, n_experts, top_k, mode,
-                                                          norm_topk_prob, inds, scores, bf ? (const bf16_t*)bf->norm_w : nullptr,
-                                                          bf ? bf->eps : 0.f, bf ? (bf16_t*)bf->xn : nullptr);
-    OMX_LAUNCH_CHECK();
-    if (bf && bf->norm_w) x = bf->xn;               // the experts read the normalised rows
-    const bf16_t* resid = bf ? (const bf16_t*)bf->resid : nullptr;
     const bool decode = slots <= 32 && gemv_k_supported(hidden, false) && gemv_k_supported(inter, false);
+    // one token of a decoder block, bf16 experts, few experts, OMX_MOE_ROUTE_FUSED=1 (opt-in): NO router launch -- every block of the
+    // experts' gate/up GEMV normalises and routes the row itself (gemv.hip PRO_ROUTE: the router kernel's arithmetic, bit-identical),
+    // block (0, 0) leaves inds / scores for the down projection.  Measured SLOWER at Mixtral-8x7B shapes: 198.8 tok/s with the usual
+    // row groups (3.5 rounds of blocks, each paying the routing prologue before its first weight byte), 207.9 with one round of long
+    // row groups, against 209.7 with the 8.5 us router launch -- the prologue cannot hide behind a first weight batch any more.
+    const char* rf_env = getenv("OMX_MOE_ROUTE_FUSED");
+    const bool route_fused = decode && !q && bf && bf->norm_w && n_tokens == 1 && gemv_route_supported(hidden, n_experts, top_k) &&
+                             router_threads(n_experts, hidden) == 512 && rf_env && rf_env[0] == '1';
+    const void* x_raw = x;
+    if (!route_fused) {
+        moe_router_kernel<<<n_tokens, router_threads(n_experts, hidden), 0, s>>>((const bf16_t*)x, (const bf16_t*)gate_w, hidden, n_experts, top_k, mode,
+                                                              norm_topk_prob, inds, scores, bf ? (const bf16_t*)bf->norm_w : nullptr,
+                                                              bf ? bf->eps : 0.f, bf ? (bf16_t*)bf->xn : nullptr);
+        OMX_LAUNCH_CHECK();
+        if (bf && bf->norm_w) x = bf->xn;               // the experts read the normalised rows
+    }
+    const bf16_t* resid = bf ? (const bf16_t*)bf->resid : nullptr;
     if (decode && q) {
         // gather_qmm x3 on the PACKED weights (model.rs:262-272 unsorted branch): expert-selected batched quantised GEMVs
         QGemvArgs a = {};
@@ -489,7 +428,17 @@ static int moe_forward_impl(void* out, const void* x, const void* gate_w, const 
         a.x = (const bf16_t*)x; a.out = gbuf;
         a.n_batch = slots; a.x_div = top_k; a.x_bstride = hidden; a.out_bstride_bytes = (size_t)inter * 2;
         a.w_sel = inds; a.w_estride = (size_t)inter * hidden; a.swiglu_single_round = 1;
-        if (launch_gemv(a, PRO_NONE, EPI_SWIGLU, s)) return 1;
+        if (route_fused) {
+            a.x = (const bf16_t*)x_raw; a.w_sel = nullptr;
+            a.norm_w = (const bf16_t*)bf->norm_w; a.eps = bf->eps;
+            a.route_gate = (const bf16_t*)gate_w; a.route_E = n_experts; a.route_k = top_k; a.route_mode = mode; a.route_renorm = norm_topk_prob;
+            a.route_inds = inds; a.route_scores = scores;
+            // ONE round of blocks (every block pays the routing prologue before its first weight byte moves, and nothing hides it):
+            // row groups sized so that slots x blocks fit the chip's 2 x 256 resident blocks
+            a.rows_per_wave = std::max(4, (inter * slots + 4 * 512 - 1) / (4 * 512));
+            if (const char* e = getenv("OMX_MOE_ROUTE_RPW")) a.rows_per_wave = atoi(e);
+            if (launch_gemv(a, PRO_ROUTE, EPI_SWIGLU, s)) return 1;
+        } else if (launch_gemv(a, PRO_NONE, EPI_SWIGLU, s)) return 1;
         GemvArgs d = {};
         d.w0 = (const bf16_t*)w_down; d.n0 = hidden; d.N = hidden; d.K = inter;
         d.x = gbuf; d.out = ybuf;

@@ -312,3 +312,35 @@ def test_expert_parallel_batched_prefill_on_one_gpu(omx, monkeypatch, name, worl
     for m in models:
         m.close()
     group.close()
+
+
+ROUTE_CONFIGS = {
+    "qwen3_moe": CONFIGS["qwen3_moe"],
+    "mixtral": CONFIGS["mixtral"],
+    # the full row width of Mixtral-8x7B (two router vectors per thread of the GEMV block), 8 experts
+    "mixtral_h4096": rq.Qwen3Config(4096, 1, 512, 32, 8, 128, 1024, 1e-5, 1e6, False, None, 40960, 8, 2, 512, "mixtral", False, False),
+    "qwen3_moe_top1_h2048": rq.Qwen3Config(2048, 2, 512, 16, 4, 128, 1024, 1e-6, 1e6, False, None, 40960, 8, 1, 512, "qwen3_moe", False, True),
+}
+
+
+@pytest.mark.parametrize("name", list(ROUTE_CONFIGS))
+@pytest.mark.parametrize("fold", ["1", "0"])
+def test_router_inside_the_expert_gemv_is_bit_identical(omx, monkeypatch, name, fold):
+    """One token, few experts: no router launch -- every block of the experts' gate/up GEMV normalises and routes the row itself
+    (csrc/gemv.hip PRO_ROUTE), with the router kernel's own sums (512-thread form: per-thread squares, wave sums, serial sum over the
+    waves; one wave per expert logit).  Same tokens and bit-equal logits as OMX_MOE_ROUTE_FUSED=0, with the experts' weighted sum folded
+    into the next GEMV (the default for top-2) or combined by its own launch, graph and eager."""
+    cfg = ROUTE_CONFIGS[name]
+    prompt = synth.prompt_ids(24, cfg.vocab_size)
+    monkeypatch.setenv("OMX_MOE_FOLD", fold)
+    outs = {}
+    for mode in ("0", "1", "eager"):
+        monkeypatch.setenv("OMX_MOE_ROUTE_FUSED", "0" if mode == "0" else "1")
+        monkeypatch.setenv("OMX_NO_GRAPH", "1" if mode == "eager" else "0")
+        m = _engine(omx, cfg)
+        toks = np.concatenate([[m.prefill(prompt)], m.decode(24)])
+        outs[mode] = (toks, m.last_logits())
+        m.close()
+    for mode in ("1", "eager"):
+        for a, b in zip(outs["0"], outs[mode]):
+            np.testing.assert_array_equal(a, b)

@@ -365,6 +365,20 @@ __global__ __launch_bounds__(256) void qgemv_kernel(const QGemvArgs a) {
                 o[q] = pack_bf16(bf16lo(raw[q]) * rstd * bf16lo(nw[q]), bf16hi(raw[q]) * rstd * bf16hi(nw[q]));
             put(i, o);
         }
+    } else if (a.K <= 8 * 2048 && !a.rolled_stage) {
+        // all of the row's vectors of this thread in flight at once (the rolled loop below waits for each 16-byte load before it
+        // issues the next: six dependent L2 round trips in the down projection's prologue, K = 12288)
+        u32x4 v[8];
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int i = threadIdx.x * 8 + it * 2048;
+            if (i < a.K) v[it] = *reinterpret_cast<const u32x4*>(xg + i);
+        }
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int i = threadIdx.x * 8 + it * 2048;
+            if (i < a.K) put(i, v[it]);
+        }
     } else {
         for (int i = threadIdx.x * 8; i < a.K; i += 256 * 8) put(i, *reinterpret_cast<const u32x4*>(xg + i));
     }
@@ -446,6 +460,9 @@ int launch_qgemv_bits(const QGemvArgs& a_in, int pro, int epi, hipStream_t s) {
     a.rows_per_wave = a.N >= 65536 ? 16 : (a.N <= 8192 && epi != EPI_SWIGLU) ? 2 : 4;
     if (const char* e = getenv("OMX_QGEMV_RPW_SMALL"))   // tuning knob: rows per wave of the small matrices (2 or 4)
         if (a.N <= 8192 && epi != EPI_SWIGLU && (atoi(e) == 2 || atoi(e) == 4)) a.rows_per_wave = atoi(e);
+    if (const char* e = getenv("OMX_QGEMV_ROLLED_STAGE")) a.rolled_stage = e[0] == '1';
+    if (const char* e = getenv("OMX_QGEMV_RPW_LONGK"))   // ... of the small matrices with a long row (K > 8192: the down projection)
+        if (a.N <= 8192 && a.K > 8192 && epi != EPI_SWIGLU && (atoi(e) == 2 || atoi(e) == 4 || atoi(e) == 8)) a.rows_per_wave = atoi(e);
     if (const char* e = getenv("OMX_QGEMV_RPW_GU"))      // ... of the gate/up pair launch (logical rows: 2, 4, 8)
         if (epi == EPI_SWIGLU && a.N < 65536 && (atoi(e) == 2 || atoi(e) == 4 || atoi(e) == 8)) a.rows_per_wave = atoi(e);
     if (W == 4) return launch_qgemv_w<BITS, 4>(a, pro, epi, s);

@@ -36,6 +36,7 @@ struct QGemvArgs {
     const uint32_t* w_sel;      // optional [n_batch] expert ids (gather_qmm)
     size_t w_estride, s_estride;    // words / groups between consecutive experts
     int swiglu_single_round;    // EPI_SWIGLU: fused_swiglu(up, gate) (one rounding, metal_kernels.rs:11-18) instead of nn::silu(g)*u
+    int rolled_stage;           // A/B: stage the activation with the rolled loop (OMX_QGEMV_ROLLED_STAGE=1)
     int scales_f16;             // scales / biases (and QMat::sb's halves) hold float16 bit patterns: a float16 MLX checkpoint.  The
                                 // activations stay bf16; every group's scale / bias enters the arithmetic as its exact float32 value
 };

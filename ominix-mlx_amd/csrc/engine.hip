@@ -32,6 +32,7 @@
 #include "prefill.hpp"
 #include "quant.hpp"
 #include "launch_timing.hpp"
+#include "aql_step.hpp"
 #include "peer.hpp"
 #include "step_engine.hpp"
 #include <hip/hip_fp16.h>
@@ -233,12 +234,21 @@ struct omx_qwen3_ {
     bool oproj_disabled = false;               // the same for the O projection inside the attention launch
 
     hipGraphExec_t g_full = nullptr, g_nohead = nullptr;
+    AqlProgram* aql_full = nullptr;            // the with-head step as AQL packets on the engine's own HSA queue (aql_step.hpp)
+    bool aql_disabled = false;                 // building or replaying it failed once: hipGraph from then on
     bool eager = false;          // fallback when stream capture is unavailable (e.g. a collective refuses capture)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     float last_decode_ms = 0.f;
 };
 
 namespace {
+
+// the captured forms of the step (hipGraph executables, the AQL program) hold the split plan and every pointer: dropped together
+void drop_graphs(omx_qwen3 m) {
+    if (m->g_full) { (void)hipGraphExecDestroy(m->g_full); m->g_full = nullptr; }
+    if (m->g_nohead) { (void)hipGraphExecDestroy(m->g_nohead); m->g_nohead = nullptr; }
+    if (m->aql_full) { aql_destroy(m->aql_full); m->aql_full = nullptr; }
+}
 
 template <class T>
 int dev_alloc(omx_qwen3 m, T** p, size_t n) {
@@ -437,10 +447,10 @@ int enqueue_step_quant(omx_qwen3 m, bool with_head) {
     hipStream_t s = m->stream;
     const int hd = c.hidden_size, D = c.head_dim, bits = c.quant_bits, group = c.quant_group;
     const bool sf16 = c.quant_scales_f16 != 0;
-    if (bits == 4) qembed_kernel<4><<<4, 256, 0, s>>>(m->h, m->q_embed.w, m->q_embed.scales, m->q_embed.biases, m->st, hd, group, m->step_seq,
-                                                      m->rope_cur, m->rope_cos, m->rope_sin, D / 2, sf16);
-    else qembed_kernel<8><<<4, 256, 0, s>>>(m->h, m->q_embed.w, m->q_embed.scales, m->q_embed.biases, m->st, hd, group, m->step_seq, m->rope_cur,
-                                            m->rope_cos, m->rope_sin, D / 2, sf16);
+    if (bits == 4) OMX_LAUNCH(qembed_kernel<4>, 4, 256, 0, s, m->h, m->q_embed.w, m->q_embed.scales, m->q_embed.biases, m->st, hd, group, m->step_seq,
+                              m->rope_cur, m->rope_cos, m->rope_sin, D / 2, sf16);
+    else OMX_LAUNCH(qembed_kernel<8>, 4, 256, 0, s, m->h, m->q_embed.w, m->q_embed.scales, m->q_embed.biases, m->st, hd, group, m->step_seq, m->rope_cur,
+                    m->rope_cos, m->rope_sin, D / 2, sf16);
     OMX_LAUNCH_CHECK();
     bf16_t* h = m->h;
     bf16_t* hn = m->h2;
@@ -496,7 +506,8 @@ int enqueue_step_quant(omx_qwen3 m, bool with_head) {
         a.argmax_slot = m->argmax_partials;
         if (launch_qgemv(a, bits, PRO_RMSNORM, EPI_ARGMAX, s)) return 1;
         if (add_sampling_noise(m, s)) return 1;
-        sample_finalize_kernel<<<1, 256, 0, s>>>(m->st, m->argmax_partials, m->n_argmax_partials, m->out_ring, m->ring_cap, nullptr);
+        OMX_LAUNCH(sample_finalize_kernel, 1, 256, 0, s, m->st, m->argmax_partials, m->n_argmax_partials, m->out_ring, m->ring_cap,
+                   (unsigned long long*)nullptr);
         OMX_LAUNCH_CHECK();
     } else {
         feed_prompt_kernel<<<1, 1, 0, s>>>(m->st, m->prompt_dev);
@@ -571,6 +582,7 @@ static int rpw_env(const char* name) {
 enum { KC_QKV = 0, KC_ATTN, KC_O, KC_GATE_UP, KC_DOWN, KC_HEAD, KC_ENGINE, KC_COUNT };
 constexpr int kLayerClasses = KC_HEAD;
 inline void time_next_launch(omx_qwen3 m, int layer, int cls) {
+    if (g_launch_recorder) g_launch_recorder->next_tag = cls;
     if (!m->kernel_events) return;
     const size_t i = (cls == KC_HEAD ? (size_t)m->cfg.num_hidden_layers * kLayerClasses
                       : cls == KC_ENGINE ? (size_t)m->cfg.num_hidden_layers * kLayerClasses + 1 : (size_t)layer * kLayerClasses + cls) * 2;
@@ -584,7 +596,7 @@ int enqueue_step_hybrid(omx_qwen3 m, bool with_head) {
     const omx_qwen3_config& c = m->cfg;
     hipStream_t s = m->stream;
     const int hd = c.hidden_size, D = c.head_dim, L = c.num_hidden_layers;
-    embed_kernel<<<2, 256, 0, s>>>(m->h, m->embed, m->st, hd, m->step_seq, m->rope_cur, m->rope_cos, m->rope_sin, D / 2);
+    OMX_LAUNCH(embed_kernel, 2, 256, 0, s, m->h, m->embed, m->st, hd, m->step_seq, m->rope_cur, m->rope_cos, m->rope_sin, D / 2);
     OMX_LAUNCH_CHECK();
     for (int l = 0; l < L; ++l) {
         time_next_launch(m, l, KC_QKV);                      // (the segment's time is booked on the q/k/v class of the layer it ends in)
@@ -619,7 +631,7 @@ int enqueue_step(omx_qwen3 m, bool with_head) {
         time_next_launch(m, 0, KC_ENGINE);
         if (enqueue_step_engine(m, s)) return 1;
     } else {
-        embed_kernel<<<2, 256, 0, s>>>(m->h, m->embed, m->st, hd, m->step_seq, m->rope_cur, m->rope_cos, m->rope_sin, D / 2);
+        OMX_LAUNCH(embed_kernel, 2, 256, 0, s, m->h, m->embed, m->st, hd, m->step_seq, m->rope_cur, m->rope_cos, m->rope_sin, D / 2);
         OMX_LAUNCH_CHECK();
     }
     bf16_t* h = engine ? m->h2 : m->h;      // residual stream entering the layer
@@ -757,8 +769,8 @@ int enqueue_step_tail(omx_qwen3 m, bool with_head, const bf16_t* h, const float*
                 if (launch_gemv(a, PRO_RMSNORM, EPI_ARGMAX, s)) return 1;
         if (add_sampling_noise(m, s)) return 1;
         if (!tp) {
-            sample_finalize_kernel<<<1, 256, 0, s>>>(m->st, m->argmax_partials, m->n_argmax_partials, m->out_ring,
-                                                     m->ring_cap, nullptr);
+            OMX_LAUNCH(sample_finalize_kernel, 1, 256, 0, s, m->st, m->argmax_partials, m->n_argmax_partials, m->out_ring, m->ring_cap,
+                       (unsigned long long*)nullptr);
             OMX_LAUNCH_CHECK();
         } else {
             sample_finalize_kernel<<<1, 256, 0, s>>>(m->st, m->argmax_partials, m->n_argmax_partials, m->out_ring,
@@ -777,6 +789,50 @@ int enqueue_step_tail(omx_qwen3 m, bool with_head, const bf16_t* h, const float*
     return 0;
 }
 
+
+// The with-head step as AQL packets on the engine's own queue (aql_step.hpp): OMX_STEP_AQL=1 (agent-scope fences on every packet, the
+// semantics of the stream) or =2 (no fences between the packets of a replay -- the step's kernels hand every cross-kernel value over
+// with write-through stores and coherent loads).  Greedy single-rank dense / packed steps only: the sampler's and the MoE block's
+// launches are not recording sites.  Any failure leaves the engine on its hipGraph (and says why once on stderr with OMX_STEP_AQL_VERBOSE).
+int step_aql_mode(omx_qwen3 m) {
+    const char* e = getenv("OMX_STEP_AQL");
+    const int mode = e ? atoi(e) : 0;
+    const omx_qwen3_config& c = m->cfg;
+    if (mode <= 0 || m->aql_disabled || m->eager || m->allreduce != nullptr || c.tp_size > 1 || c.ep_size > 1 || c.num_experts > 0 ||
+        m->temperature != 0.f || step_engine_mode(m) != 0)
+        return 0;
+    return mode;
+}
+
+void build_aql(omx_qwen3 m) {
+    const int mode = step_aql_mode(m);
+    if (!mode || m->aql_full) return;
+    // the launches are recorded under a stream capture as well: a launch site that is not a recording site would show up as a graph node
+    LaunchRecorder rec;
+    hipGraph_t g = nullptr;
+    if (hipStreamBeginCapture(m->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) { (void)hipGetLastError(); m->aql_disabled = true; return; }
+    g_launch_recorder = &rec;
+    const int rc = enqueue_step(m, true);
+    g_launch_recorder = nullptr;
+    const hipError_t e = hipStreamEndCapture(m->stream, &g);
+    size_t nodes = 0;
+    if (g) { (void)hipGraphGetNodes(g, nullptr, &nodes); (void)hipGraphDestroy(g); }
+    AqlProgram* p = nullptr;
+    if (!rc && e == hipSuccess && nodes == 0) {
+        const int fence = mode == 2 ? AQL_FENCE_NONE : mode == 3 ? AQL_FENCE_ACQUIRE : mode == 4 ? AQL_FENCE_RELEASE : AQL_FENCE_AGENT;
+        p = aql_build(rec, fence);
+    } else if (!rc && e == hipSuccess) {
+        set_error("aql: %zu launches of the step are not recording sites", nodes);
+    }
+    if (!p) {
+        if (getenv("OMX_STEP_AQL_VERBOSE")) fprintf(stderr, "omx: AQL step unavailable: %s\n", omx_last_error());
+        (void)hipGetLastError();
+        omx_clear_error();
+        m->aql_disabled = true;
+        return;
+    }
+    m->aql_full = p;
+}
 
 int build_graphs(omx_qwen3 m) {
     if (m->g_full || m->eager) return 0;
@@ -807,6 +863,7 @@ int build_graphs(omx_qwen3 m) {
         }
         (which == 0 ? m->g_full : m->g_nohead) = ge;
     }
+    build_aql(m);
     return 0;
 }
 
@@ -818,8 +875,7 @@ int prepare_step(omx_qwen3 m, int pos) {
         const int tk = pos + 1, gran = tk <= 8192 ? 1024 : 4096;
         const int want = std::min(m->cap, (tk + gran - 1) / gran * gran);
         if (want != m->graph_tk_max) {
-            if (m->g_full) { (void)hipGraphExecDestroy(m->g_full); m->g_full = nullptr; }
-            if (m->g_nohead) { (void)hipGraphExecDestroy(m->g_nohead); m->g_nohead = nullptr; }
+            drop_graphs(m);
             attn_step_plan(want, m->Hkv, m->H / m->Hkv, m->cfg.head_dim, &m->attn_chunk, &m->attn_nsplit);
             m->graph_tk_max = want;
         }
@@ -888,8 +944,7 @@ int step_fallback(omx_qwen3 m, const StepState& st) {
     if (!m->se_disabled && step_engine_takes(m)) m->se_disabled = true;
     else if (!m->oproj_disabled && attention_takes_oproj(m)) m->oproj_disabled = true;
     else return 1;
-    if (m->g_full) { (void)hipGraphExecDestroy(m->g_full); m->g_full = nullptr; }
-    if (m->g_nohead) { (void)hipGraphExecDestroy(m->g_nohead); m->g_nohead = nullptr; }
+    drop_graphs(m);
     OMX_HIP_CHECK(hipMemsetAsync(m->wait_abort, 0, 4, m->stream));
     OMX_HIP_CHECK(hipMemcpyAsync(m->st, &st, sizeof(st), hipMemcpyHostToDevice, m->stream));
     OMX_HIP_CHECK(hipStreamSynchronize(m->stream));
@@ -1221,8 +1276,7 @@ int omx_qwen3_create(omx_qwen3* out, const omx_qwen3_config* cfg) {
 int omx_qwen3_destroy(omx_qwen3 m) {
     if (!m) return 0;
     if (m->stream) (void)hipStreamSynchronize(m->stream);
-    if (m->g_full) (void)hipGraphExecDestroy(m->g_full);
-    if (m->g_nohead) (void)hipGraphExecDestroy(m->g_nohead);
+    drop_graphs(m);
     for (const bf16_t* k : m->sb_keys) quant_unregister_sb(k);
     for (void* p : m->owned) (void)hipFree(p);
     if (m->dq_buf) (void)hipFree(m->dq_buf);
@@ -1439,8 +1493,7 @@ int omx_qwen3_set_sampler(omx_qwen3 m, float temperature, uint64_t seed) {
     OMX_HIP_CHECK(hipStreamSynchronize(m->stream));
     if (temperature != m->temperature) {
         // 1/T is a launch argument inside the captured step: drop the graphs, the next step rebuilds them
-        if (m->g_full) { (void)hipGraphExecDestroy(m->g_full); m->g_full = nullptr; }
-        if (m->g_nohead) { (void)hipGraphExecDestroy(m->g_nohead); m->g_nohead = nullptr; }
+        drop_graphs(m);
         m->eager = false;
         m->temperature = temperature;
     }
@@ -1659,12 +1712,27 @@ int omx_qwen3_decode(omx_qwen3 m, int n, uint32_t* tokens_out) {
     if (prepare_step(m, st.pos)) return 1;
     OMX_REQUIRE(st.pos + n <= m->cap, "omx_qwen3_decode: %d cached + %d new tokens exceed max_context %d", st.pos, n, m->cap);
     for (;;) {
-        OMX_HIP_CHECK(hipEventRecord(m->ev0, m->stream));
-        for (int i = 0; i < n; ++i)
-            if (run_step(m, true, st.pos + i)) return 1;
-        OMX_HIP_CHECK(hipEventRecord(m->ev1, m->stream));
-        OMX_HIP_CHECK(hipStreamSynchronize(m->stream));
-        OMX_HIP_CHECK(hipEventElapsedTime(&m->last_decode_ms, m->ev0, m->ev1));
+        // all n steps stay inside one split plan (one captured form)?  then the AQL program, if there is one, replays them
+        bool aql = false;
+        if (m->aql_full && step_aql_mode(m)) {
+            const int tk = st.pos + n, gran = tk <= 8192 ? 1024 : 4096;
+            aql = std::min(m->cap, (tk + gran - 1) / gran * gran) == m->graph_tk_max;
+        }
+        if (aql) {
+            double ms = 0.0;
+            if (aql_replay(m->aql_full, n, &ms)) {   // the queue is unusable: the error stands, later calls use the graph
+                m->aql_disabled = true;
+                return 1;
+            }
+            m->last_decode_ms = (float)ms;
+        } else {
+            OMX_HIP_CHECK(hipEventRecord(m->ev0, m->stream));
+            for (int i = 0; i < n; ++i)
+                if (run_step(m, true, st.pos + i)) return 1;
+            OMX_HIP_CHECK(hipEventRecord(m->ev1, m->stream));
+            OMX_HIP_CHECK(hipStreamSynchronize(m->stream));
+            OMX_HIP_CHECK(hipEventElapsedTime(&m->last_decode_ms, m->ev0, m->ev1));
+        }
         unsigned gave_up = 0;
         if (step_gave_up(m, &gave_up)) return 1;
         if (!gave_up) break;
@@ -1829,7 +1897,7 @@ int omx_qwen3_debug_trace_engine(omx_qwen3 m, unsigned long long* host, size_t n
 
 int omx_qwen3_decode_path(omx_qwen3 m, int* path) {
     OMX_REQUIRE(m && path, "omx_qwen3_decode_path: null argument");
-    *path = m->eager ? 2 : m->g_full ? 1 : 0;
+    *path = m->eager ? 2 : (m->aql_full && step_aql_mode(m)) ? 3 : m->g_full ? 1 : 0;   // 3: AQL replay on the engine's own queue
     return 0;
 }
 

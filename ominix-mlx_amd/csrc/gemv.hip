@@ -83,7 +83,10 @@ __device__ __forceinline__ void peer_finish_rows(const GemvArgs& a, unsigned tag
 // KSPLIT = waves sharing one row (1: a wave owns whole rows; 4: each wave owns a K quarter)
 // RB     = logical rows per register batch; LR physical rows per logical row (2 for SwiGLU)
 template <int NVW, int KSPLIT, int RB, int PRO, int EPI, bool TAIL = false>
-__global__ __launch_bounds__(kBlock) void gemv_kernel(const GemvArgs a_in) {
+#ifndef OMX_GEMV_MINWAVES
+#define OMX_GEMV_MINWAVES 1   // (tuning builds: make VARIANT=w3 VARIANT_FLAGS=-DOMX_GEMV_MINWAVES=3 asks hipcc for <= 168 VGPRs)
+#endif
+__global__ __launch_bounds__(kBlock, OMX_GEMV_MINWAVES) void gemv_kernel(const GemvArgs a_in) {
     // batched / expert-selected form (MoE decode): blockIdx.y picks the activation row, the output row
     // block and, through a device index array, the expert whose weights are streamed
     GemvArgs a = a_in;

@@ -20,6 +20,7 @@
 #include <unordered_map>
 
 #include "quant.hpp"
+#include "launch_timing.hpp"
 #include "vec.hpp"
 #include "workspace.hpp"
 
@@ -419,8 +420,8 @@ int launch_qgemv_w(const QGemvArgs& a, int pro, int epi, hipStream_t s) {
         if (a.m[i].w && !a.m[i].sb) sb = false;
 #define OMX_QGEMV_LAUNCH(P, E, SBF, F16)                                                       \
     {                                                                                         \
-        if (E == EPI_SWIGLU || a.rows_per_wave == 2) qgemv_kernel<BITS, W, P, E, 2, SBF, F16><<<grid, block, shmem, s>>>(a); \
-        else qgemv_kernel<BITS, W, P, E, 4, SBF, F16><<<grid, block, shmem, s>>>(a);          \
+        if (E == EPI_SWIGLU || a.rows_per_wave == 2) OMX_LAUNCH((qgemv_kernel<BITS, W, P, E, 2, SBF, F16>), grid, block, shmem, s, a); \
+        else OMX_LAUNCH((qgemv_kernel<BITS, W, P, E, 4, SBF, F16>), grid, block, shmem, s, a);          \
         OMX_LAUNCH_CHECK();                                                                   \
         return 0;                                                                             \
     }

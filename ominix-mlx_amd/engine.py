@@ -308,10 +308,10 @@ class Model:
         return s.value or 0
 
     def decode_path(self) -> str:
-        """'graph' | 'eager' once the first step ran ('unbuilt' before)."""
+        """'graph' | 'eager' | 'aql' (packets on the engine's own HSA queue, OMX_STEP_AQL) once the first step ran ('unbuilt' before)."""
         v = c_int()
         check(lib.omx_qwen3_decode_path(self._h, ctypes.byref(v)))
-        return ("unbuilt", "graph", "eager")[v.value]
+        return ("unbuilt", "graph", "eager", "aql")[v.value]
 
     KERNEL_CLASSES = ("qkv", "attention", "o", "gate_up", "down", "lm_head", "step_engine")
 

@@ -36,3 +36,7 @@ for name, N, K, pro, epi in shapes:
               f"gap to next launch {np.median(gaps):5.2f} us  -> period {np.median(spans) + np.median(gaps):6.2f} us")
         print(f"           start {q(rel[:, :, 0])} | x staged {q(rel[:, :, 1])} | first batch {q(rel[:, :, 2])} | end {q(rel[:, :, 3])}"
               f"  end min {np.median(rel[:, :, 3].min(axis=1)):5.2f}")
+        # workgroup b runs on XCD b % 8 (tools/xcc_probe.py): is the tail an XCD effect?
+        xe = [np.median(rel[:, x::8, 3].max(axis=1)) for x in range(8)]
+        xm = [np.median(rel[:, x::8, 3]) for x in range(8)]
+        print("           last end per XCD " + " ".join(f"{v:5.2f}" for v in xe) + " | median end per XCD " + " ".join(f"{v:5.2f}" for v in xm))

@@ -26,6 +26,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+N_WINDOWS = 3        # timed windows of --steps decode tokens each (the first one is `value`)
 SECONDARY_TIMEOUT_S = int(os.environ.get("OMX_BENCH_SECONDARY_TIMEOUT", "420"))   # watchdog of the collective secondaries at N > 1
 HBM_PEAK_GBPS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
 
@@ -482,7 +483,7 @@ def main():
     cfg = dict(MODELS[args.model])
     if args.layers:
         cfg["num_hidden_layers"] = args.layers
-    max_ctx = args.prompt + args.warmup + args.steps + 16
+    max_ctx = args.prompt + args.warmup + N_WINDOWS * args.steps + 16
     moe = cfg.get("num_experts", 0) > 0
     if moe:   # BASELINE config 3: experts sharded over the ranks (expert parallel), attention replicated, one all-reduce per layer
         model = engine.Model(max_context=max_ctx, ep_rank=rank, ep_size=world, **cfg)
@@ -507,6 +508,15 @@ def main():
     first = model.prefill(prompt)
     torch.cuda.synchronize()
     prefill_s = time.perf_counter() - t0
+    prefill_first_ms = model.last_prefill_ms()
+    # steady state: the same prompt once more on the emptied cache (the first call pays the one-time scratch allocation)
+    model.reset()
+    if dist is not None:
+        dist.barrier()
+    first2 = model.prefill(prompt)
+    prefill_steady_ms = model.last_prefill_ms()
+    if int(first2) != int(first):
+        raise SystemExit(f"rank {rank}: the second prefill of the same prompt sampled {int(first2)}, the first {int(first)}")
     if args.warmup:
         model.decode(args.warmup)
 
@@ -526,6 +536,20 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     dev_ms = model.last_decode_ms()
+    # the reference's protocol is 3 runs, mean +- sigma (mistral-mlx/examples/benchmark_mistral.rs:62-105): `value` stays the first
+    # window of exactly K steps; two more windows of K steps each (the context keeps growing) give the spread
+    window_tok_s = [args.steps / elapsed]
+    for _ in range(N_WINDOWS - 1):
+        barrier()
+        t0 = time.perf_counter()
+        model.decode(args.steps)
+        barrier()
+        w = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([w], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            w = float(t.item())
+        window_tok_s.append(args.steps / w)
     if peer is not None and peer.aborted():   # a wait inside the peer all-reduce gave up: the tokens of this run are void
         raise SystemExit(f"rank {rank}: the peer-store all-reduce gave up waiting for a peer during the run; no valid measurement")
 
@@ -544,7 +568,6 @@ def main():
 
     def assemble():
         step_bytes = (model_stats["step_bytes"] if primary_closed else model.step_bytes(ctx_mid)) * (1 if moe else world)   # whole-job algorithmic bytes per token (EP ranks share one token's experts)
-        last_prefill_ms = model_stats["prefill_ms"] if primary_closed else model.last_prefill_ms()
         ms_per_step = elapsed * 1e3 / args.steps
         tok_s = args.steps / elapsed
         k_bytes, iso_s = time_dominant_kernel(omx, cfg, 1 if moe else world)
@@ -589,10 +612,15 @@ def main():
                               "frac_of_hbm_peak": round(step_bytes / (ms_per_step * 1e-3) / 1e9 / (HBM_PEAK_GBPS * world), 4),
                               "roofline_tokens_per_sec": round(HBM_PEAK_GBPS * 1e9 * world / step_bytes, 1),
                               "device_ms_per_step_hip_events": round(dev_ms / args.steps, 4)},
-            "prefill": {"tokens": args.prompt, "seconds": round(prefill_s, 4), "device_ms": round(last_prefill_ms, 3),
-                        "tokens_per_sec": round(args.prompt / max(last_prefill_ms, 1e-6) * 1e3, 1),
+            "prefill": {"tokens": args.prompt, "seconds": round(prefill_s, 4), "device_ms": round(prefill_first_ms, 3),
+                        "device_ms_steady": round(prefill_steady_ms, 3),
+                        "tokens_per_sec": round(args.prompt / max(prefill_steady_ms, 1e-6) * 1e3, 1),
                         "mode": "batched on the tensor-parallel shards: MFMA GEMMs + flash attention, two bf16 all-reduces of [T, hidden] per layer, the last token through the decode step" if world > 1 else
                                 "batched: MFMA GEMMs + flash attention over all n tokens (first call: includes the one-time scratch allocation), norm + lm_head + sampler on the last row"},
+            "windows": {"n": len(window_tok_s), "steps_each": args.steps, "tokens_per_sec": [round(v, 2) for v in window_tok_s],
+                        "mean": round(sum(window_tok_s) / len(window_tok_s), 2),
+                        "std": round((sum((v - sum(window_tok_s) / len(window_tok_s)) ** 2 for v in window_tok_s) / len(window_tok_s)) ** 0.5, 2),
+                        "protocol": "mistral-mlx/examples/benchmark_mistral.rs:62-105 (3 runs, mean +- sigma); `value` = window 1"},
             "first_tokens": [int(first)] + [int(t) for t in toks[:4]],
             "first_token_check": {"expected": want_first, "ok": first_ok},
         }
@@ -615,14 +643,20 @@ def main():
     if plan:
         import threading
 
+        out_lock = threading.Lock()
+
         def give_up():
             if rank == 0:
+                with out_lock:                      # (the main thread adds the finished secondaries under the same lock)
+                    line = dict(out)
                 note = {"value": None, "error": f"collective secondary did not finish within {SECONDARY_TIMEOUT_S} s (watchdog)"}
-                out.setdefault("secondary", dict(note, metric="flux_klein_1024_sec_per_step"))
+                line.setdefault("secondary", dict(note, metric="flux_klein_1024_sec_per_step"))
                 if "mixtral" in plan:
-                    out.setdefault("mixtral", dict(note, metric="decode_tokens_per_sec_mixtral_8x7b_bf16"))
-                print(json.dumps(out), flush=True)
-            os._exit(0)      # (every rank's own watchdog fires: the ranks leave by themselves, nobody waits for a stuck peer)
+                    line.setdefault("mixtral", dict(note, metric="decode_tokens_per_sec_mixtral_8x7b_bf16"))
+                print(json.dumps(line), flush=True)
+            # status 3 = "primary line valid, a collective secondary hung": ranks stuck inside GPU collectives must not look like a
+            # clean run (every rank's own watchdog fires: the ranks leave by themselves, nobody waits for a stuck peer)
+            os._exit(3)
 
         dog = threading.Timer(SECONDARY_TIMEOUT_S, give_up)
         dog.daemon = True
@@ -632,7 +666,8 @@ def main():
         except Exception as e:
             flux_tp = {"metric": "flux_klein_1024_sec_per_step", "value": None, "error": str(e)}
         if rank == 0 and flux_tp is not None:
-            out["secondary"] = flux_tp      # (kept if the watchdog fires during the next workload)
+            with out_lock:
+                out["secondary"] = flux_tp      # (kept if the watchdog fires during the next workload)
         if "mixtral" in plan:
             try:
                 mixtral_ep = mixtral_secondary(omx, rank=rank, world=world, comm=keep, dist=dist)

@@ -78,6 +78,10 @@ int omx_layer_norm(void* out, const void* x, const void* weight, const void* bia
  *      traditional=0: pairs (i, i+dims/2); =1: pairs (2i, 2i+1).  theta_i = base^(-2i/dims).  */
 int omx_rope(void* out, const void* x, int64_t batch, int T, int D, int dims, int traditional, float base,
              float scale, int offset, omx_dtype dtype, omx_stream stream);
+/* ... with custom frequencies instead of a base (mlx-rs/src/fast.rs:15-46 `freqs`, mlx-c fast.h mlx_fast_rope): freqs = dims / 2
+ * float32 values on the device; the angle of pair j at position p is (p + offset) * scale / freqs[j] */
+int omx_rope_freqs(void* out, const void* x, int64_t batch, int T, int D, int dims, int traditional, const float* freqs, float scale,
+                   int offset, omx_dtype dtype, omx_stream stream);
 
 /* ---- a8/a9: the two mlx-rs-core fused kernels (metal_kernels.rs:188-236, 260-339), which the
  *      reference JIT-compiles from Metal source through mlx_fast_metal_kernel_apply (fast.h:156).
@@ -192,6 +196,9 @@ int omx_qwen3_destroy(omx_qwen3 m);
 int omx_qwen3_set_weight(omx_qwen3 m, const char* name, const void* ptr, size_t nbytes);
 /* allocate + fill every weight with the seeded synthetic generator (seed = base ^ crc32(name))      */
 int omx_qwen3_synth_weights(omx_qwen3 m, uint32_t base_seed);
+/* ... with PEAKED logits: embedding std 64, lm_head[v] = table[(v + 1) mod V] at std 0.02 -- the greedy successor of token t is t - 1 with
+ * a margin two orders of magnitude above the bf16 bound, so full-size parity tests can assert token EQUALITY (bf16, untied head) */
+int omx_qwen3_synth_weights_peaked(omx_qwen3 m, uint32_t base_seed);
 /* tensor-parallel hook: `allreduce` has the ncclAllReduce signature, `comm` is the ncclComm_t.      */
 int omx_qwen3_set_comm(omx_qwen3 m, void* comm, void* allreduce_fn);
 /* sampler (mlx-rs-core/src/sampler.rs:9-18, qwen3-mlx/src/model.rs:733-741): temperature 0 = argmax (default);

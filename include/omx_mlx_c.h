@@ -88,6 +88,7 @@ const uint16_t* mlx_array_data_uint16(const mlx_array arr);               /* :28
 const uint32_t* mlx_array_data_uint32(const mlx_array arr);               /* :285 */
 const int32_t* mlx_array_data_int32(const mlx_array arr);                 /* :305 */
 const float* mlx_array_data_float32(const mlx_array arr);                 /* :315 */
+const uint16_t* mlx_array_data_float16(const mlx_array arr);              /* :332 (float16_t == 16-bit storage) */
 const uint16_t* mlx_array_data_bfloat16(const mlx_array arr);             /* :335 (bfloat16_t == 16-bit storage) */
 
 /* ---- vector.h:28-47 ---- */

@@ -66,6 +66,7 @@ SIGNATURES = {
     "omx_rms_norm": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_float, c_int, c_void_p]),
     "omx_layer_norm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_float, c_int, c_void_p]),
     "omx_rope": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_float, c_float, c_int, c_int, c_void_p]),
+    "omx_rope_freqs": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p, c_float, c_int, c_int, c_void_p]),
     "omx_fused_swiglu": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     "omx_fused_modulate": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_int, c_void_p]),
     "omx_linear": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),

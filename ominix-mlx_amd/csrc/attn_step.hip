@@ -533,6 +533,7 @@ __global__ __launch_bounds__(kBlock, 1) void attn_step_kernel(const AttnStepArgs
             }
         }
         __syncthreads();
+        if (TRACE && threadIdx.x == 0) tr[7] = wall_clock64();
         // ---- merge the 8 waves x TPW rows; the split's partial leaves as tagged granules ----
         for (int idx = threadIdx.x; idx < G * D; idx += kBlock) {
             const int g = idx / D, d = idx % D;

@@ -16,7 +16,7 @@ template <int DT>
 __global__ __launch_bounds__(256) void rope_kernel(typename Elem<DT>::T* __restrict__ out,
                                                    const typename Elem<DT>::T* __restrict__ x, int64_t batch, int T,
                                                    int D, int dims, int traditional, double neg_log_base_over_half,
-                                                   double scale, int offset) {
+                                                   double scale, int offset, const float* __restrict__ freqs = nullptr) {
     typedef typename Elem<DT>::T T_;
     const int half = dims >> 1;
     const int per_row = half + (D - dims);   // rotating pairs + pass-through columns
@@ -29,7 +29,8 @@ __global__ __launch_bounds__(256) void rope_kernel(typename Elem<DT>::T* __restr
         for (int64_t b = 0; b < batch; ++b) out[(b * T + t) * D + col] = x[(b * T + t) * D + col];
         return;
     }
-    const double ang = ((double)(offset + t) * scale) * exp((double)j * neg_log_base_over_half);
+    // custom frequencies (fast.rs:15-46 `freqs`): the angle of pair j is position / freqs[j] instead of position * base^(-j / half)
+    const double ang = ((double)(offset + t) * scale) * (freqs ? 1.0 / (double)freqs[j] : exp((double)j * neg_log_base_over_half));
     double sd, cd;
     sincos(ang, &sd, &cd);
     const float c = (float)cd, s = (float)sd;
@@ -162,6 +163,23 @@ int omx_rope(void* out, const void* x, int64_t batch, int T, int D, int dims, in
                        (omx::rope_kernel<DT><<<blocks, 256, 0, (hipStream_t)stream>>>(
                            (omx::Elem<DT>::T*)out, (const omx::Elem<DT>::T*)x, batch, T, D, dims, traditional, nl,
                            (double)scale, offset)));
+    OMX_LAUNCH_CHECK();
+    return 0;
+}
+
+/* fast::rope with `freqs` (fast.rs:15-46; mlx/c/fast.h mlx_fast_rope): freqs [dims / 2] float32 on the device replace the base */
+int omx_rope_freqs(void* out, const void* x, int64_t batch, int T, int D, int dims, int traditional, const float* freqs, float scale,
+                   int offset, omx_dtype dtype, omx_stream stream) {
+    OMX_REQUIRE(out && x && freqs, "omx_rope_freqs: null tensor");
+    OMX_REQUIRE(dims > 0 && dims <= D && (dims % 2) == 0, "omx_rope_freqs: dims=%d must be even and <= D=%d", dims, D);
+    if (batch == 0 || T == 0) return 0;
+    const int half = dims / 2;
+    const int64_t total = (int64_t)T * (half + (D - dims));
+    const unsigned blocks = (unsigned)((total + 255) / 256);
+    OMX_DISPATCH_FLOAT(dtype, "omx_rope_freqs",
+                       (omx::rope_kernel<DT><<<blocks, 256, 0, (hipStream_t)stream>>>(
+                           (omx::Elem<DT>::T*)out, (const omx::Elem<DT>::T*)x, batch, T, D, dims, traditional, 0.0,
+                           (double)scale, offset, freqs)));
     OMX_LAUNCH_CHECK();
     return 0;
 }

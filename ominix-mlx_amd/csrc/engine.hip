@@ -248,6 +248,7 @@ void drop_graphs(omx_qwen3 m) {
     if (m->g_full) { (void)hipGraphExecDestroy(m->g_full); m->g_full = nullptr; }
     if (m->g_nohead) { (void)hipGraphExecDestroy(m->g_nohead); m->g_nohead = nullptr; }
     if (m->aql_full) { aql_destroy(m->aql_full); m->aql_full = nullptr; }
+    if (m->cfg.ep_size > 1 && m->stream) workspace_aux_pin(m->stream, false);
 }
 
 template <class T>
@@ -863,6 +864,7 @@ int build_graphs(omx_qwen3 m) {
         }
         (which == 0 ? m->g_full : m->g_nohead) = ge;
     }
+    if (m->cfg.ep_size > 1) workspace_aux_pin(m->stream, true);   // the captured MoE block's scratch pointers must not move
     build_aql(m);
     return 0;
 }
@@ -941,6 +943,9 @@ int step_health(omx_qwen3 m) {
 // retry is possible.
 int step_fallback(omx_qwen3 m, const StepState& st) {
     if (m->temperature != 0.f) return 1;                       // the sampler's key sequence advanced: no silent replay
+    // more than one rank: a local replay would re-enqueue every all-reduce of the n steps (and the argmax one) on THIS rank only -- its
+    // peers never issue them, so the collectives would pair with the peers' next call (wrong sums or a hang).  Report the abort instead.
+    if (m->allreduce != nullptr || m->cfg.tp_size > 1 || m->cfg.ep_size > 1) return 1;
     if (!m->se_disabled && step_engine_takes(m)) m->se_disabled = true;
     else if (!m->oproj_disabled && attention_takes_oproj(m)) m->oproj_disabled = true;
     else return 1;
@@ -1356,8 +1361,17 @@ int omx_qwen3_set_weight(omx_qwen3 m, const char* name, const void* ptr, size_t 
     return 0;
 }
 
-int omx_qwen3_synth_weights(omx_qwen3 m, uint32_t base_seed) {
+static int synth_weights_impl(omx_qwen3 m, uint32_t base_seed, bool peaked);
+int omx_qwen3_synth_weights(omx_qwen3 m, uint32_t base_seed) { return synth_weights_impl(m, base_seed, false); }
+/* The same synthetic checkpoint with PEAKED logits (parity at full size: i.i.d. weights give flat logits whose argmax flips on the last
+ * bf16 bit, so token equality cannot be a hard assert): the embedding table is scaled to std 64 -- it dominates the ~10-rms sum of the
+ * 36 layers' contributions -- and lm_head row v is row (v + 1) mod V of the SAME table at the usual std 0.02, so the greedy token after
+ * token t is t - 1 with a top-1 margin of ~80 against a bf16 bound of ~0.5, while the other 151 935 logits still carry the layers'
+ * arithmetic (std 0.2 of their 1.3).  oracle/ref_qwen3.py synth_weights(peaked=True) is the host twin. */
+int omx_qwen3_synth_weights_peaked(omx_qwen3 m, uint32_t base_seed) { return synth_weights_impl(m, base_seed, true); }
+static int synth_weights_impl(omx_qwen3 m, uint32_t base_seed, bool peaked) {
     OMX_REQUIRE(m, "omx_qwen3_synth_weights: null model");
+    OMX_REQUIRE(!peaked || (m->cfg.quant_bits == 0 && !m->cfg.tie_word_embeddings), "omx_qwen3_synth_weights_peaked: bf16 checkpoints with an untied lm_head only");
     OMX_REQUIRE(!m->cfg.quant_scales_f16, "omx_qwen3_synth_weights: the device generator quantises in bf16; a float16-scale model takes uploaded triplets");
     const omx_qwen3_config& c = m->cfg;
     const int D = c.head_dim, hd = c.hidden_size, r = c.tp_rank;
@@ -1454,6 +1468,21 @@ int omx_qwen3_synth_weights(omx_qwen3 m, uint32_t base_seed) {
             return 1;
         }
     }
+    if (peaked) {
+        const uint32_t seed = base_seed ^ crc32_str("model.embed_tokens.weight");
+        bf16_t *e = nullptr, *hw = nullptr;
+        if (dev_alloc(m, &e, (size_t)c.vocab_size * hd) || dev_alloc(m, &hw, (size_t)m->V * hd)) return 1;
+        if (omx_fill_uniform_2d(e, c.vocab_size, hd, hd, 0, 0, seed, (float)(64.0 * sqrt(3.0)), 0.f, OMX_BFLOAT16, m->stream)) return 1;
+        // this rank's head rows [r V_l, (r + 1) V_l) = table rows shifted by one, wrapping at the end of the vocabulary
+        const int64_t first = (int64_t)r * m->V + 1, n_main = std::min<int64_t>(m->V, c.vocab_size - first);
+        if (n_main > 0 && omx_fill_uniform_2d(hw, n_main, hd, hd, first, 0, seed, amp_w, 0.f, OMX_BFLOAT16, m->stream)) return 1;
+        if (n_main < m->V && omx_fill_uniform_2d(hw + (size_t)std::max<int64_t>(n_main, 0) * hd, m->V - std::max<int64_t>(n_main, 0), hd, hd, 0, 0, seed,
+                                                 amp_w, 0.f, OMX_BFLOAT16, m->stream))
+            return 1;
+        m->named["model.embed_tokens.weight"] = e;
+        m->named["lm_head.weight"] = hw;
+        if (make("model.norm.weight", 1, hd, hd, 0, 0, true)) return 1;
+    } else {
     if (make("model.embed_tokens.weight", c.vocab_size, hd, hd, 0, 0, false) || make("model.norm.weight", 1, hd, hd, 0, 0, true))
         return 1;
     if (!c.tie_word_embeddings) {
@@ -1465,6 +1494,7 @@ int omx_qwen3_synth_weights(omx_qwen3 m, uint32_t base_seed) {
         const uint32_t seed = base_seed ^ crc32_str("model.embed_tokens.weight");
         if (omx_fill_uniform_2d(p, m->V, hd, hd, (int64_t)r * m->V, 0, seed, amp_w, 0.f, OMX_BFLOAT16, m->stream)) return 1;
         m->named["lm_head.weight"] = p;
+    }
     }
     OMX_HIP_CHECK(hipStreamSynchronize(m->stream));
     m->weights_resolved = false;

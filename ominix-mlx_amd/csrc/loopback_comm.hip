@@ -119,6 +119,18 @@ extern "C" int omx_loopback_allreduce(const void* send, void* recv, size_t count
     RankComm* rc = (RankComm*)comm;
     if (!rc || !rc->g) return 4;   // ncclInvalidArgument
     Group* g = rc->g;
+    const size_t esz1 = dtype == kNcclUint64 ? 8 : dtype == kNcclFloat32 ? 4 : dtype == kNcclBfloat16 ? 2 : 0;
+    if (g->world == 1 && esz1 != 0) {
+        // a one-rank group: the reduction is the identity, issued as ONE small kernel on the caller's stream and therefore capturable --
+        // the launch a real one-hop reduction would cost, without its link latency (tools/tp_shard_step.py times a tensor-parallel
+        // rank's step at its real shard shapes this way)
+        const unsigned blocks1 = (unsigned)((count + 255) / 256 < 64 ? (count + 255) / 256 : 64);
+        if (dtype == kNcclFloat32) reduce_slots_kernel<float, false><<<blocks1, 256, 0, stream>>>((float*)recv, (float* const*)g->slots_dev, 0, 0);
+        else if (dtype == kNcclUint64) reduce_slots_kernel<unsigned long long, true><<<blocks1, 256, 0, stream>>>((unsigned long long*)recv, (unsigned long long* const*)g->slots_dev, 0, 0);
+        else reduce_slots_bf16_kernel<<<blocks1, 256, 0, stream>>>((omx::bf16_t*)recv, (omx::bf16_t* const*)g->slots_dev, 0, 0);
+        if (send != recv && hipMemcpyAsync(recv, send, count * esz1, hipMemcpyDeviceToDevice, stream) != hipSuccess) return 1;
+        return hipGetLastError() == hipSuccess ? 0 : 1;
+    }
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return 5;   // ncclInvalidUsage: not capturable
     const size_t esz = dtype == kNcclUint64 ? 8 : dtype == kNcclFloat32 ? 4 : dtype == kNcclBfloat16 ? 2 : 0;

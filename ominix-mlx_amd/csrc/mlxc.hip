@@ -457,6 +457,7 @@ const uint32_t* mlx_array_data_uint32(const mlx_array arr) { return (const uint3
 const int32_t* mlx_array_data_int32(const mlx_array arr) { return (const int32_t*)data_host(arr); }
 const float* mlx_array_data_float32(const mlx_array arr) { return (const float*)data_host(arr); }
 const uint16_t* mlx_array_data_bfloat16(const mlx_array arr) { return (const uint16_t*)data_host(arr); }
+const uint16_t* mlx_array_data_float16(const mlx_array arr) { return (const uint16_t*)data_host(arr); }   // (float16_t spelled as its bits, like bfloat16)
 
 mlx_vector_array mlx_vector_array_new(void) { return mlx_vector_array{new Vec()}; }
 int mlx_vector_array_free(mlx_vector_array vec) { delete reinterpret_cast<Vec*>(vec.ctx); return 0; }
@@ -527,16 +528,24 @@ int mlx_fast_layer_norm(mlx_array* res, const mlx_array x, const mlx_array weigh
 int mlx_fast_rope(mlx_array* res, const mlx_array x, int dims, bool traditional, mlx_optional_float base, float scale,
                   int offset, const mlx_array freqs, const mlx_stream) {
     REQ_ARR(x, "mlx_fast_rope");
-    OMX_REQUIRE(!freqs.ctx, "mlx_fast_rope: custom `freqs` are not supported (the hot path passes none, fast.rs:40-42)");
-    OMX_REQUIRE(base.has_value, "mlx_fast_rope: `base` is required when `freqs` is absent");
-    Contig cx;
+    // MLX core: exactly one of `base` and `freqs`
+    OMX_REQUIRE(base.has_value != (freqs.ctx != nullptr), "mlx_fast_rope: exactly one of `base` and `freqs` must be given");
+    Contig cx, cf;
     if (cx.init(*A(x))) return 1;
+    if (freqs.ctx) {
+        if (cf.init(*A(freqs))) return 1;
+        OMX_REQUIRE(cf.a->dt == MLX_FLOAT32 && cf.a->shape.size() == 1 && cf.a->shape[0] == dims / 2,
+                    "mlx_fast_rope: `freqs` must be a float32 vector of dims / 2 = %d entries", dims / 2);
+    }
     const int nd = (int)cx.a->shape.size();
     OMX_REQUIRE(nd >= 2, "mlx_fast_rope: input must have at least 2 dimensions");   // same check as MLX core
     const int T = cx.a->shape[nd - 2], D = cx.a->shape[nd - 1];
     NEW_OR_FAIL(r, cx.a->shape, cx.a->dt);
     const int64_t batch = (T && D) ? (int64_t)(r->size() / ((size_t)T * D)) : 0;
-    if (omx_rope(r->ptr(), cx.a->ptr(), batch, T, D, dims, traditional, base.value, scale, offset, to_omx(r->dt), g_stream)) {
+    const int rc = freqs.ctx ? omx_rope_freqs(r->ptr(), cx.a->ptr(), batch, T, D, dims, traditional, (const float*)cf.a->ptr(), scale, offset,
+                                              to_omx(r->dt), g_stream)
+                             : omx_rope(r->ptr(), cx.a->ptr(), batch, T, D, dims, traditional, base.value, scale, offset, to_omx(r->dt), g_stream);
+    if (rc) {
         delete r;
         return 1;
     }

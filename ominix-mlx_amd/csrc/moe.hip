@@ -169,7 +169,7 @@ __global__ __launch_bounds__(1024) void moe_plan_kernel(const uint32_t* __restri
                                                         int n_tile_experts = -1) {
     // n_tile_experts >= 0: only experts [0, n_tile_experts) get GEMM tiles -- the expert-parallel batched form sorts the slots routed
     // to OTHER ranks into one trailing pseudo-expert that nobody multiplies
-    __shared__ int s_cnt[kMaxExperts], s_start[kMaxExperts + 1], s_fill[kMaxExperts];
+    __shared__ int s_cnt[kMaxExperts + 1], s_start[kMaxExperts + 2], s_fill[kMaxExperts + 1];   // (+1: the trailing pseudo-expert of an expert-parallel shard)
     for (int e = threadIdx.x; e < E; e += blockDim.x) { s_cnt[e] = 0; s_fill[e] = 0; }
     __syncthreads();
     for (int i = threadIdx.x; i < n_slots; i += blockDim.x) atomicAdd(&s_cnt[inds[i]], 1);

@@ -29,23 +29,23 @@ namespace omx {
 namespace {
 
 // ---- quantize: one wave per group of 32/64/128 elements (MLX affine_quantize) ----
-template <int BITS>
-__global__ __launch_bounds__(256) void quantize_kernel(uint32_t* __restrict__ packed, bf16_t* __restrict__ scales,
-                                                       bf16_t* __restrict__ biases, const bf16_t* __restrict__ w,
+template <int BITS, int DT = OMX_BFLOAT16>
+__global__ __launch_bounds__(256) void quantize_kernel(uint32_t* __restrict__ packed, typename Elem<DT>::T* __restrict__ scales,
+                                                       typename Elem<DT>::T* __restrict__ biases, const typename Elem<DT>::T* __restrict__ w,
                                                        int64_t n_groups, int group) {
     constexpr int EPW = 32 / BITS;
     constexpr float n_bins = (float)((1 << BITS) - 1);
     const int lane = threadIdx.x & 63;
     const int64_t g = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (g >= n_groups) return;
-    const bf16_t* src = w + g * group;
+    const typename Elem<DT>::T* src = w + g * group;
     const int per_lane = group / 64 > 0 ? group / 64 : 1;   // 128 -> 2, 64 -> 1, 32 -> 1 (upper half idle)
     float v[2] = {0.f, 0.f};
     float mx = -INFINITY, mn = INFINITY;
     for (int i = 0; i < per_lane; ++i) {
         const int e = lane * per_lane + i;
         if (e < group) {
-            v[i] = bf16_to_f32(src[e]);
+            v[i] = Elem<DT>::ld(src + e);
             mx = fmaxf(mx, v[i]);
             mn = fminf(mn, v[i]);
         }
@@ -61,8 +61,8 @@ __global__ __launch_bounds__(256) void quantize_kernel(uint32_t* __restrict__ pa
     scale = at_zero ? scale : edge / q0;
     const float bias = at_zero ? 0.f : edge;
     if (lane == 0) {
-        scales[g] = f32_to_bf16(scale);
-        biases[g] = f32_to_bf16(bias);
+        Elem<DT>::st(scales + g, scale);
+        Elem<DT>::st(biases + g, bias);
     }
     // pack: element e goes to word e / EPW at bit (e % EPW) * BITS; the EPW elements of a word sit in
     // EPW / per_lane consecutive lanes
@@ -107,6 +107,21 @@ __global__ __launch_bounds__(256) void dequantize_kernel(bf16_t* __restrict__ ou
         }
         if (EPW == 8) *reinterpret_cast<u32x4*>(out + i * 8) = *reinterpret_cast<const u32x4*>(o);
         else *reinterpret_cast<u32x2*>(out + i * 4) = *reinterpret_cast<const u32x2*>(o);
+    }
+}
+
+// any width that divides 32 and any float dtype (the result has the scales' dtype: ops/quantization.rs:118-153); one element per store
+template <int BITS, int DT>
+__global__ __launch_bounds__(256) void dequantize_any_kernel(typename Elem<DT>::T* __restrict__ out, const uint32_t* __restrict__ packed,
+                                                             const typename Elem<DT>::T* __restrict__ scales,
+                                                             const typename Elem<DT>::T* __restrict__ biases, int64_t n_words, int group) {
+    constexpr int EPW = 32 / BITS;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_words; i += (int64_t)gridDim.x * blockDim.x) {
+        const uint32_t wd = packed[i];
+        const int64_t g = i * EPW / group;
+        const float sc = Elem<DT>::ld(scales + g), b = biases ? Elem<DT>::ld(biases + g) : 0.f;
+#pragma unroll
+        for (int e = 0; e < EPW; ++e) Elem<DT>::st(out + i * EPW + e, (float)((wd >> (e * BITS)) & ((1u << BITS) - 1u)) * sc + b);
     }
 }
 
@@ -472,6 +487,16 @@ int launch_qgemv_bits(const QGemvArgs& a_in, int pro, int epi, hipStream_t s) {
     return set_error("quantized gemv: K=%d too small for %d-bit weights", a.K, BITS);
 }
 
+// quantize / dequantize alone take what mlx_rs::ops::quantize takes: 2, 4 or 8 bits on bfloat16 / float16 / float32 (the reference's
+// own value test loops [2, 4, 8] on float32: ops/quantization.rs:289-305); the matmul kernels stay 4 / 8 bit (check_format)
+int check_format_qdq(const char* who, int K, int group, int bits, int dtype) {
+    OMX_REQUIRE(dtype == OMX_BFLOAT16 || dtype == OMX_FLOAT16 || dtype == OMX_FLOAT32, "%s: bf16 / f16 / f32 only (got dtype %d)", who, dtype);
+    OMX_REQUIRE(bits == 2 || bits == 4 || bits == 8, "%s: bits must be 2, 4 or 8 (got %d; the 3 / 5 / 6-bit MLX packings are not built)", who, bits);
+    OMX_REQUIRE(group == 32 || group == 64 || group == 128, "%s: group_size must be 32, 64 or 128 (got %d)", who, group);
+    OMX_REQUIRE(K > 0 && K % group == 0, "%s: the last dimension (%d) must be divisible by the group size (%d)", who, K, group);
+    return 0;
+}
+
 // dtype: OMX_BFLOAT16, or OMX_FLOAT16 where `f16_scales_ok` -- scales / biases of a float16 checkpoint (activations stay bf16)
 int check_format(const char* who, int K, int group, int bits, int dtype, bool f16_scales_ok = false) {
     OMX_REQUIRE(dtype == OMX_BFLOAT16 || (f16_scales_ok && dtype == OMX_FLOAT16), "%s: bf16 activations / scales only (got dtype %d)", who, dtype);
@@ -534,12 +559,19 @@ using namespace omx;
 extern "C" int omx_quantize(void* packed, void* scales, void* biases, const void* w, int64_t rows, int cols, int group_size,
                             int bits, omx_dtype dtype, omx_stream stream) {
     OMX_REQUIRE(packed && scales && biases && w, "omx_quantize: null tensor");
-    if (check_format("omx_quantize", cols, group_size, bits, dtype)) return 1;
+    if (check_format_qdq("omx_quantize", cols, group_size, bits, dtype)) return 1;
     const int64_t n_groups = rows * (cols / group_size);
     if (n_groups == 0) return 0;
     const unsigned blocks = (unsigned)((n_groups + 3) / 4);
-    if (bits == 4) quantize_kernel<4><<<blocks, 256, 0, (hipStream_t)stream>>>((uint32_t*)packed, (bf16_t*)scales, (bf16_t*)biases, (const bf16_t*)w, n_groups, group_size);
-    else quantize_kernel<8><<<blocks, 256, 0, (hipStream_t)stream>>>((uint32_t*)packed, (bf16_t*)scales, (bf16_t*)biases, (const bf16_t*)w, n_groups, group_size);
+#define OMX_Q_CASE(B, D)                                                                                                     \
+    if (bits == B && dtype == D) {                                                                                           \
+        typedef Elem<D>::T T;                                                                                                \
+        quantize_kernel<B, D><<<blocks, 256, 0, (hipStream_t)stream>>>((uint32_t*)packed, (T*)scales, (T*)biases, (const T*)w, n_groups, group_size); \
+    }
+    OMX_Q_CASE(2, OMX_BFLOAT16) OMX_Q_CASE(4, OMX_BFLOAT16) OMX_Q_CASE(8, OMX_BFLOAT16)
+    OMX_Q_CASE(2, OMX_FLOAT16) OMX_Q_CASE(4, OMX_FLOAT16) OMX_Q_CASE(8, OMX_FLOAT16)
+    OMX_Q_CASE(2, OMX_FLOAT32) OMX_Q_CASE(4, OMX_FLOAT32) OMX_Q_CASE(8, OMX_FLOAT32)
+#undef OMX_Q_CASE
     OMX_LAUNCH_CHECK();
     return 0;
 }
@@ -565,9 +597,23 @@ int omx::launch_dequantize_bf16(bf16_t* out, const uint32_t* packed, const void*
 extern "C" int omx_dequantize(void* out, const void* packed, const void* scales, const void* biases, int64_t rows, int cols,
                               int group_size, int bits, omx_dtype dtype, omx_stream stream) {
     OMX_REQUIRE(out && packed && scales, "omx_dequantize: null tensor");
-    if (check_format("omx_dequantize", cols, group_size, bits, dtype, true)) return 1;
-    const bool f16 = dtype == OMX_FLOAT16;
-    return launch_dequantize_any(out, (const uint32_t*)packed, scales, biases, rows, cols, group_size, bits, f16, f16, (hipStream_t)stream);
+    if (check_format_qdq("omx_dequantize", cols, group_size, bits, dtype)) return 1;
+    if (bits != 2 && dtype != OMX_FLOAT32) {   // the 16-bit forms the matmul paths share (vector stores)
+        const bool f16 = dtype == OMX_FLOAT16;
+        return launch_dequantize_any(out, (const uint32_t*)packed, scales, biases, rows, cols, group_size, bits, f16, f16, (hipStream_t)stream);
+    }
+    const int64_t n_words = rows * cols * bits / 32;
+    if (n_words == 0) return 0;
+    const unsigned blocks = (unsigned)((n_words + 255) / 256 < 16384 ? (n_words + 255) / 256 : 16384);
+#define OMX_DQ_CASE(B, D)                                                                                                    \
+    if (bits == B && dtype == D) {                                                                                           \
+        typedef Elem<D>::T T;                                                                                                \
+        dequantize_any_kernel<B, D><<<blocks, 256, 0, (hipStream_t)stream>>>((T*)out, (const uint32_t*)packed, (const T*)scales, (const T*)biases, n_words, group_size); \
+    }
+    OMX_DQ_CASE(2, OMX_BFLOAT16) OMX_DQ_CASE(2, OMX_FLOAT16) OMX_DQ_CASE(2, OMX_FLOAT32) OMX_DQ_CASE(4, OMX_FLOAT32) OMX_DQ_CASE(8, OMX_FLOAT32)
+#undef OMX_DQ_CASE
+    OMX_LAUNCH_CHECK();
+    return 0;
 }
 
 /* out [M, N] = x [M, K] . dequant(W [N, K])^T   (nn::QuantizedLinear::forward, quantized.rs:366-375) */

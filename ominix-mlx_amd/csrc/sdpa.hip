@@ -36,13 +36,15 @@ int get_workspace(void** ptr, size_t bytes) {
 // attention).  Two engines or models on their own streams must not share it -- one would overwrite the other's partials, and growing
 // it would free the buffer under the other user -- so it is keyed by the stream, like the ring GEMM's split-K scratch (gemm.hip).
 namespace {
-struct AuxWs { void* p = nullptr; size_t bytes = 0; };
+struct AuxWs { void* p = nullptr; size_t bytes = 0; bool pinned = false; };
 std::map<uintptr_t, AuxWs> g_aux;
 }  // namespace
 int get_workspace_aux(void** ptr, size_t bytes, hipStream_t s) {
     std::lock_guard<std::mutex> lk(g_ws_mu);
     AuxWs& w = g_aux[reinterpret_cast<uintptr_t>(s)];
     if (bytes > w.bytes) {
+        // a captured graph holds pointers into this buffer (workspace_aux_pin): moving it would leave the graph writing freed memory
+        OMX_REQUIRE(!w.pinned, "the stream's scratch (%zu bytes) is held by a captured decode step and cannot grow to %zu bytes", w.bytes, bytes);
         if (w.p) {
             OMX_HIP_CHECK(hipStreamSynchronize(s));      // nothing of THIS stream still reads the old buffer
             OMX_HIP_CHECK(hipFree(w.p));
@@ -54,6 +56,11 @@ int get_workspace_aux(void** ptr, size_t bytes, hipStream_t s) {
     }
     *ptr = w.p;
     return 0;
+}
+void workspace_aux_pin(hipStream_t s, bool pinned) {
+    std::lock_guard<std::mutex> lk(g_ws_mu);
+    auto it = g_aux.find(reinterpret_cast<uintptr_t>(s));
+    if (it != g_aux.end()) it->second.pinned = pinned;
 }
 // the owner of `s` is about to destroy it
 void workspace_release_stream(hipStream_t s) {

@@ -32,6 +32,7 @@ ENGINE_SIGNATURES = {
     "omx_qwen3_destroy": (c_int, [c_void_p]),
     "omx_qwen3_set_weight": (c_int, [c_void_p, ctypes.c_char_p, c_void_p, ctypes.c_size_t]),
     "omx_qwen3_synth_weights": (c_int, [c_void_p, c_uint32]),
+    "omx_qwen3_synth_weights_peaked": (c_int, [c_void_p, c_uint32]),
     "omx_qwen3_set_comm": (c_int, [c_void_p, c_void_p, c_void_p]),
     "omx_qwen3_set_sampler": (c_int, [c_void_p, ctypes.c_float, ctypes.c_uint64]),
     "omx_qwen3_sampler_state": (c_int, [c_void_p, c_void_p, c_int]),
@@ -214,8 +215,11 @@ class Model:
     def expected_shape(self, name: str):
         return expected_shape(self.cfg, name)
 
-    def synth_weights(self, base_seed: int = 0x0C0FFEE5) -> None:
-        check(lib.omx_qwen3_synth_weights(self._h, base_seed & 0xFFFFFFFF))
+    def synth_weights(self, base_seed: int = 0x0C0FFEE5, peaked: bool = False) -> None:
+        """peaked: embedding std 64 and lm_head[v] = table[(v + 1) mod V] -- greedy tokens count down with top-1 margins far above the
+        bf16 bound (full-size parity tests assert token equality; oracle/ref_qwen3.py synth_weights(peaked=True))."""
+        fn = lib.omx_qwen3_synth_weights_peaked if peaked else lib.omx_qwen3_synth_weights
+        check(fn(self._h, base_seed & 0xFFFFFFFF))
 
     def set_comm(self, comm_ptr: int, allreduce_fn_ptr: int) -> None:
         check(lib.omx_qwen3_set_comm(self._h, comm_ptr, allreduce_fn_ptr))

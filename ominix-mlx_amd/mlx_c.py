@@ -102,6 +102,7 @@ SIGNATURES = {
     "mlx_array_data_int32": (c_void_p, [mlx_array]),
     "mlx_array_data_float32": (c_void_p, [mlx_array]),
     "mlx_array_data_bfloat16": (c_void_p, [mlx_array]),
+    "mlx_array_data_float16": (c_void_p, [mlx_array]),
     "mlx_vector_array_new": (mlx_vector_array, []),
     "mlx_vector_array_free": (c_int, [mlx_vector_array]),
     "mlx_vector_array_append_value": (c_int, [mlx_vector_array, mlx_array]),
@@ -370,6 +371,11 @@ class Array:
             p = lib.mlx_array_data_bfloat16(self.h)
             raw = np.ctypeslib.as_array(ctypes.cast(p, ctypes.POINTER(ctypes.c_uint16)), (max(n, 1),))[:n].copy()
             return (raw.astype(np.uint32) << np.uint32(16)).view(np.float32).reshape(shape)
+        if dt == FLOAT16:      # as_slice::<f16>(): mlx_array_data_float16
+            p = lib.mlx_array_data_float16(self.h)
+            if not p:
+                _check(1)
+            return np.ctypeslib.as_array(ctypes.cast(p, ctypes.POINTER(ctypes.c_uint16)), (max(n, 1),))[:n].copy().view(np.float16).reshape(shape)
         fn = {FLOAT32: lib.mlx_array_data_float32, UINT32: lib.mlx_array_data_uint32, INT32: lib.mlx_array_data_int32,
               BOOL: lib.mlx_array_data_uint8, UINT8: lib.mlx_array_data_uint8}[dt]
         ct = {FLOAT32: c_float, UINT32: ctypes.c_uint32, INT32: ctypes.c_int32, BOOL: ctypes.c_uint8, UINT8: ctypes.c_uint8}[dt]

@@ -156,13 +156,21 @@ def layer_norm(x: Tensor, weight: Optional[Tensor], bias: Optional[Tensor], eps:
     return out
 
 
-def rope(x: Tensor, dims: int, traditional: bool, base: float, scale: float, offset: int) -> Tensor:
-    """fast::rope(a, dims, traditional, base, scale, offset, freqs=None) -- fast.rs:15-46.
-    Position axis is -2."""
+def rope(x: Tensor, dims: int, traditional: bool, base, scale: float, offset: int, freqs: Optional[Tensor] = None) -> Tensor:
+    """fast::rope(a, dims, traditional, base, scale, offset, freqs) -- fast.rs:15-46: exactly one of `base` and `freqs`
+    (float32 [dims / 2]).  Position axis is -2."""
     if len(x.shape) < 2:
         raise OmxError("rope: input must have at least 2 dimensions")
+    if (base is None) == (freqs is None):
+        raise OmxError("rope: exactly one of base and freqs must be given")
     T, D = x.shape[-2], x.shape[-1]
     out = empty_like(x)
+    if freqs is not None:
+        if freqs.dtype != FLOAT32 or tuple(freqs.shape) != (dims // 2,):
+            raise OmxError(f"rope: freqs must be a float32 vector of dims / 2 = {dims // 2} entries")
+        check(lib.omx_rope_freqs(out.ptr, x.ptr, x.size // max(T * D, 1), T, D, dims, int(traditional), freqs.ptr, scale, offset,
+                                 x.dtype, None))
+        return out
     check(lib.omx_rope(out.ptr, x.ptr, x.size // max(T * D, 1), T, D, dims, int(traditional), base, scale, offset,
                        x.dtype, None))
     return out

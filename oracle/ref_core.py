@@ -107,15 +107,20 @@ def layer_norm(x, weight, bias, eps: float, dt: str = "f32") -> np.ndarray:
 # --------------------------------------------------------------------------
 
 
-def rope(x, dims: int, traditional: bool, base: float, scale: float, offset: int, dt: str = "f32") -> np.ndarray:
+def rope(x, dims: int, traditional: bool, base, scale: float, offset: int, dt: str = "f32", freqs=None) -> np.ndarray:
     """Rotary embedding on [..., T, D]; position axis = -2, rotates the first
     `dims` features.  Non-traditional pairs (i, i+dims/2); traditional pairs
-    (2i, 2i+1).  theta_i = base^(-2i/dims).  KAT: fast.rs:232-250 (seed 71)."""
+    (2i, 2i+1).  theta_i = base^(-2i/dims), or 1 / freqs[i] when custom `freqs`
+    (float32 [dims/2]) replace the base (fast.rs:15-46).  KAT: fast.rs:232-250 (seed 71)."""
     x = np.asarray(x, dtype=np.float32)
     T, D = x.shape[-2], x.shape[-1]
     half = dims // 2
     i = np.arange(half, dtype=np.float64)
-    inv_freq = np.exp(-i * (math.log(float(np.float32(base))) / half))
+    if freqs is not None:
+        assert base is None, "rope: exactly one of base and freqs"
+        inv_freq = 1.0 / np.asarray(freqs, dtype=np.float32).astype(np.float64)
+    else:
+        inv_freq = np.exp(-i * (math.log(float(np.float32(base))) / half))
     pos = (np.arange(T, dtype=np.float64) + float(offset)) * float(np.float32(scale))
     ang = pos[:, None] * inv_freq[None, :]          # [T, half]
     c, s = np.cos(ang), np.sin(ang)

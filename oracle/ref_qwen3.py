@@ -102,11 +102,19 @@ def weight_spec(name: str):
     return 0.02, 0.0
 
 
-def synth_weights(cfg: Qwen3Config, dt: str = "bf16") -> Dict[str, np.ndarray]:
+def synth_weights(cfg: Qwen3Config, dt: str = "bf16", peaked: bool = False) -> Dict[str, np.ndarray]:
+    """peaked: the twin of omx_qwen3_synth_weights_peaked -- embedding std 64 (it dominates the layers' ~10-rms contribution to the
+    residual stream) and lm_head[v] = row (v + 1) mod V of the same table at std 0.02, so the greedy successor of token t is t - 1 with a
+    top-1 margin far above the bf16 bound while the other logits still carry the layers' arithmetic."""
     out = {}
     for name, shape in weight_shapes(cfg).items():
         std, off = weight_spec(name)
         out[name] = synth.tensor(name, shape, std, off, dt)
+    if peaked:
+        assert "lm_head.weight" in out, "peaked weights need an untied lm_head"
+        shape = out["model.embed_tokens.weight"].shape
+        out["model.embed_tokens.weight"] = synth.tensor("model.embed_tokens.weight", shape, 64.0, 0.0, dt)
+        out["lm_head.weight"] = np.roll(synth.tensor("model.embed_tokens.weight", shape, 0.02, 0.0, dt), -1, axis=0)
     return out
 
 

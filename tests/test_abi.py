@@ -51,7 +51,7 @@ SURVEY_8B = """
 mlx_array_new mlx_array_free mlx_array_set mlx_array_new_data mlx_array_new_int mlx_array_new_float32 mlx_array_new_bool mlx_array_shape
 mlx_array_ndim mlx_array_dim mlx_array_dtype mlx_array_size mlx_array_nbytes mlx_array_itemsize mlx_array_strides mlx_array_eval
 mlx_array_item_uint32 mlx_array_item_float32 mlx_array_data_uint8 mlx_array_data_uint16 mlx_array_data_uint32 mlx_array_data_int32
-mlx_array_data_float32 mlx_array_data_bfloat16 mlx_array_tostring
+mlx_array_data_float32 mlx_array_data_bfloat16 mlx_array_data_float16 mlx_array_tostring
 mlx_vector_array_new mlx_vector_array_free mlx_vector_array_append_value mlx_vector_array_get mlx_vector_array_size
 mlx_vector_string_new mlx_vector_string_free mlx_vector_string_append_value mlx_vector_string_get mlx_vector_string_size
 mlx_string_new mlx_string_data mlx_string_free

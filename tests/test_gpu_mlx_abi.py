@@ -62,6 +62,15 @@ def test_fast_ops_through_handles(mx):
     q = rc.bf16_round(rand((1, 4, 7, 64), 4))
     assert_bf16_close(mx.rope(mx.Array.from_numpy(q), 64, False, 1e6, 1.0, 11).numpy(),
                       rc.rope(q, 64, False, 1e6, 1.0, 11, "bf16"), 1, atol=1e-6)
+    # custom frequencies instead of a base (fast.rs:15-46 `freqs`); giving both is MLX core's error
+    freqs = (1.0 + 40.0 * np.random.default_rng(8).random(32)).astype(np.float32)
+    assert_bf16_close(mx.rope(mx.Array.from_numpy(q), 64, False, None, 1.0, 11, mx.Array.from_numpy(freqs, mx.FLOAT32)).numpy(),
+                      rc.rope(q, 64, False, None, 1.0, 11, "bf16", freqs=freqs), 1, atol=1e-6)
+    with pytest.raises(Exception):
+        mx.rope(mx.Array.from_numpy(q), 64, False, 1e6, 1.0, 11, mx.Array.from_numpy(freqs, mx.FLOAT32))
+    # a float16 array read back through mlx_array_data_float16 (as_slice::<f16>)
+    h = rand((3, 5), 21).astype(np.float16)
+    np.testing.assert_array_equal(mx.Array.from_numpy(h, mx.FLOAT16).numpy(), h)
     up, gate = rc.bf16_round(rand((3, 512), 5)), rc.bf16_round(rand((3, 512), 6) * 4)
     assert_bf16_close(mx.fused_swiglu(mx.Array.from_numpy(up), mx.Array.from_numpy(gate)).numpy(),
                       rc.fused_swiglu(up, gate, "bf16"), 1)

@@ -161,6 +161,28 @@ def test_rope_parity(omx, shape, dims, trad, base, scale, offset, dt):
         assert_bf16_close(got, ref, 1, atol=1e-6)
 
 
+@pytest.mark.parametrize("trad", [False, True])
+@pytest.mark.parametrize("dt", ["bf16", "f32", "f16"])
+def test_rope_with_custom_freqs(omx, trad, dt):
+    """fast::rope with `freqs` instead of a base (fast.rs:15-46): the default frequencies base^(2i/dims) handed over as `freqs` give the
+    base form's result; arbitrary ones match the oracle; giving both or neither is an error like in MLX core."""
+    T = omx.ops.Tensor
+    x = rc.rnd(rand((2, 3, 9, 64), 19), dt)
+    dims, half = 48, 24
+    default = (10000.0 ** (np.arange(half, dtype=np.float64) / half)).astype(np.float32)
+    tol = (lambda g, r: assert_f32_close(g, r, 2e-5)) if dt == "f32" else (lambda g, r: assert_bf16_close(g, r, 1, atol=1e-6)) if dt == "bf16" \
+        else (lambda g, r: np.testing.assert_allclose(g, r, rtol=2.0 ** -10, atol=1e-6))
+    got = omx.ops.rope(T.from_numpy(x, dt), dims, trad, None, 0.5, 7, freqs=T.from_numpy(default, "f32")).numpy()
+    tol(got, rc.rope(x, dims, trad, 10000.0, 0.5, 7, dt))
+    freqs = (1.0 + 50.0 * np.random.default_rng(5).random(half)).astype(np.float32)
+    got = omx.ops.rope(T.from_numpy(x, dt), dims, trad, None, 1.0, 3, freqs=T.from_numpy(freqs, "f32")).numpy()
+    tol(got, rc.rope(x, dims, trad, None, 1.0, 3, dt, freqs=freqs))
+    with pytest.raises(omx.OmxError):
+        omx.ops.rope(T.from_numpy(x, dt), dims, trad, 1e4, 1.0, 0, freqs=T.from_numpy(freqs, "f32"))
+    with pytest.raises(omx.OmxError):
+        omx.ops.rope(T.from_numpy(x, dt), dims, trad, None, 1.0, 0)
+
+
 def test_rope_rejects_bad_dims(omx):
     T = omx.ops.Tensor
     with pytest.raises(omx.OmxError):

@@ -43,16 +43,44 @@ def test_quantize_matches_oracle(omx, bits, group):
     assert (np.abs(w_hat - w) <= rng_ / (1 << bits) + np.abs(w) * 2.0 ** -7 + 1e-6).all()
 
 
-@pytest.mark.parametrize("bits", [4, 8])
-def test_reference_quantize_dequantize_kat_on_device(omx, bits):
-    """mlx-rs/src/ops/quantization.rs:289-305 run through the device kernels: ones[128,1] * arange(512), group 128,
-    shapes [128, 512/el_per_int], [128, 4], [128, 4]; max |x - x_hat| <= 127 / 2^bits (+ the bf16 rounding of x)."""
+@pytest.mark.parametrize("bits", [2, 4, 8])
+@pytest.mark.parametrize("dtype", ["f32", "bf16", "f16"])
+def test_reference_quantize_dequantize_kat_on_device(omx, bits, dtype):
+    """mlx-rs/src/ops/quantization.rs:289-305 run through the device kernels, all three widths of its loop: ones[128,1] * arange(512),
+    group 128, shapes [128, 512/el_per_int], [128, 4], [128, 4]; in float32 (the KAT's dtype) max |x - x_hat| <= 127 / 2^bits exactly as
+    the reference asserts it, and the packed words / scales / biases equal the oracle's; the 16-bit dtypes add their rounding of x."""
     T = omx.ops.Tensor
-    x = rc.bf16_round(np.tile(np.arange(512, dtype=np.float32), (128, 1)))
-    q, s, b = omx.ops.quantize(T.from_numpy(x), 128, bits)
+    x = np.tile(np.arange(512, dtype=np.float32), (128, 1))
+    if dtype != "f32":
+        x = rc.rnd(x, dtype).astype(np.float32)
+    q, s, b = omx.ops.quantize(T.from_numpy(x, dtype), 128, bits)
     assert q.shape == (128, 512 * bits // 32) and s.shape == (128, 4) and b.shape == (128, 4)
     x_hat = omx.ops.dequantize(q, s, b, 128, bits).numpy()
-    assert np.abs(x - x_hat).max() <= 127.0 / (1 << bits) + 512 * 2.0 ** -8
+    slack = 0.0 if dtype == "f32" else 512 * (2.0 ** -8 if dtype == "bf16" else 2.0 ** -11)
+    assert np.abs(x - x_hat).max() <= 127.0 / (1 << bits) + slack
+    if dtype == "f32":
+        rq, rs, rb = rc.quantize(x, 128, bits)
+        np.testing.assert_array_equal(q.numpy(), rq)
+        np.testing.assert_array_equal(s.numpy(), rs)
+        np.testing.assert_array_equal(b.numpy(), rb)
+        # (the device rounds scale * q and the sum separately in float32, the oracle once from float64: an ulp apart)
+        np.testing.assert_allclose(x_hat, rc.dequantize(rq, rs, rb, 128, bits, "f32"), rtol=3e-7, atol=1e-6)
+
+
+@pytest.mark.parametrize("group", [32, 64, 128])
+def test_two_bit_quantize_matches_oracle(omx, group):
+    """2-bit affine quantisation (16 elements per word) on random weights: words equal to the oracle's up to ties at k + 0.5."""
+    T = omx.ops.Tensor
+    w = rc.bf16_round(rand((64, 512), 77 + group) * 0.3)
+    q, s, b = omx.ops.quantize(T.from_numpy(w), group, 2)
+    rq, rs, rb = rc.quantize(w, group, 2)
+    np.testing.assert_array_equal(s.numpy(), rc.bf16_round(rs))
+    np.testing.assert_array_equal(b.numpy(), rc.bf16_round(rb))
+    got, want = _unpack(q.numpy(), 2).astype(np.int64), _unpack(rq, 2).astype(np.int64)
+    diff = got != want
+    assert diff.mean() <= 1e-3 and (np.abs(got - want)[diff] == 1).all()
+    np.testing.assert_array_equal(omx.ops.dequantize(T.from_numpy(rq, "u32"), T.from_numpy(rc.bf16_round(rs)), T.from_numpy(rc.bf16_round(rb)), group, 2).numpy(),
+                                  rc.dequantize(rq, rc.bf16_round(rs), rc.bf16_round(rb), group, 2, "bf16"))
 
 
 @pytest.mark.parametrize("bits,group", [(4, 64), (8, 64), (4, 128)])

@@ -789,6 +789,36 @@ def test_persistent_step_is_bit_identical(omx, monkeypatch, name, n_prompt):
         np.testing.assert_array_equal(outs["0"][1], outs[mode][1])
 
 
+@pytest.mark.parametrize("name", ["h32_kv8_d128_nvw8", "h16_kv8_d128_nvw4"])
+@pytest.mark.parametrize("quant", [0, 4])
+def test_aql_replay_is_bit_identical(omx, monkeypatch, name, quant):
+    """csrc/aql_step.hip -- the step's launches recorded once and replayed as raw AQL packets on the engine's own HSA queue
+    (OMX_STEP_AQL=1: kernel descriptors looked up in the executables HIP loaded, kernargs = recorded arguments + code-object-v5
+    hidden arguments) -- reproduces the hipGraph step exactly: same tokens, bit-equal logits, across a context-bucket boundary
+    (the program is rebuilt with the graphs) and in calls that straddle it (those fall back to the graph)."""
+    cfg = OPROJ_CONFIGS[name]
+    prompt = synth.prompt_ids(1000, cfg.vocab_size)
+    outs = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("OMX_STEP_AQL", mode)
+        if quant:
+            from ominix_mlx_amd import engine
+            m = engine.Model(hidden_size=cfg.hidden_size, num_hidden_layers=cfg.num_hidden_layers, intermediate_size=cfg.intermediate_size,
+                             num_attention_heads=cfg.num_attention_heads, num_key_value_heads=cfg.num_key_value_heads, head_dim=cfg.head_dim,
+                             vocab_size=cfg.vocab_size, rms_norm_eps=cfg.rms_norm_eps, rope_theta=cfg.rope_theta,
+                             tie_word_embeddings=cfg.tie_word_embeddings, max_context=1280, qk_norm=cfg.qk_norm,
+                             quantization={"bits": 4, "group_size": 64})
+            m.synth_weights()
+        else:
+            m = _engine(omx, cfg, max_context=1280)
+        toks = np.concatenate([[m.prefill(prompt)], m.decode(10), m.decode(30), m.decode(5)])   # 1010 .. 1040 crosses 1024 inside a call
+        outs[mode] = (toks, m.last_logits(), m.decode_path())
+        m.close()
+    assert outs["1"][2] == "aql", "the AQL program was not built (OMX_STEP_AQL_VERBOSE=1 prints why)"
+    np.testing.assert_array_equal(outs["0"][0], outs["1"][0])
+    np.testing.assert_array_equal(outs["0"][1], outs["1"][1])
+
+
 def test_persistent_step_options_are_bit_identical(omx, monkeypatch):
     """The engine's tuning knobs (sweeping waves per edge, fills in flight) change timing only."""
     cfg = ENGINE_CONFIGS["h32_kv8_d128_nvw8"]

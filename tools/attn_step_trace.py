@@ -21,7 +21,7 @@ omx.check(lib.omx_qwen3_debug_trace_step(m._h, buf.ctypes.data, buf.size, ctypes
 nb = nb.value
 t = buf[:L * nb * 8].reshape(L, nb, 8).astype(np.int64)
 names = ["block start", "loads landed, q/k normed+roped", "own chunk done", "granules stored", "gather + merge done (consumers)",
-         "attention vector swept into LDS (O projection)", "O rows stored"]
+         "attention vector swept into LDS (O projection)", "O rows stored", "all waves' partials parked in LDS (block barrier)"]
 print(f"{nb} blocks per launch, {L} layers, ctx {ctx}")
 for ev, nm in enumerate(names):
     rows = []

@@ -240,7 +240,7 @@ def pmc_traffic(kernel):
         return None
 
 
-def flux_secondary(omx, steps=3, rank=0, world=1, comm=None):
+def flux_secondary(omx, steps=8, rank=0, world=1, comm=None):
     """Second half of BASELINE.json's metric string: FLUX.2-klein 1024x1024 sec/step (bf16, synthetic
     weights/latents; full 5 double + 20 single block model, S = 512 txt + 4096 img tokens).  world > 1:
     tensor-parallel over the node (heads and MLP columns sharded, bf16 all-reduce over RCCL)."""
@@ -265,6 +265,8 @@ def flux_secondary(omx, steps=3, rank=0, world=1, comm=None):
     flop = 34.79e12   # 28.27 TFLOP linear + 6.52 TFLOP attention at S = 4608
     return {"metric": "flux_klein_1024_sec_per_step", "value": round(ms / 1e3, 5), "unit": "s/step", "higher_is_better": False,
             "n_gpus": world, "steps": steps, "dtype": "bf16", "data": "synthetic", "parallelism": f"tp{world}",
+            "spread": {"mean": round(float(np.mean(ts)) / 1e3, 5), "std": round(float(np.std(ts)) / 1e3, 5),
+                       "note": f"{steps} consecutive steps of the 28-step schedule (timesteps 1000 (1 - i / 28)), device time of each; value = median"},
             "roofline": {"bound": "mfma", "achieved": round(flop / ms / 1e9, 1), "peak": 2500.0 * world, "unit": "TFLOP/s",
                          "frac": round(flop / ms / 1e9 / (2500.0 * world), 4)}}
 
@@ -297,17 +299,25 @@ def quantized_secondary(omx, cfg, args, bits=4):
     return out
 
 
-def mixtral_secondary(omx, steps=64, warm=8, n_prompt=2048, rank=0, world=1, comm=None, dist=None):
+def mixtral_secondary(omx, steps=64, warm=8, n_prompt=2048, rank=0, world=1, comm=None, dist=None, mode="ep"):
     """BASELINE config 3: Mixtral-8x7B shapes (mixtral-mlx/src/model.rs:44-52) in bf16, sparse-MoE decode engine: router + top-2
     expert GEMVs per layer inside the step graph.  One GPU: all 93 GB of weights on it.  comm != None: expert parallel over `world`
     ranks -- 8 / world experts per rank, attention and router replicated, one f32 all-reduce per MoE block (the prompt as ONE batched
-    pass with a [T, hidden] all-reduce per layer); every rank calls this, the time is the MAX over ranks."""
+    pass with a [T, hidden] all-reduce per layer); every rank calls this, the time is the MAX over ranks.
+    mode "etp": expert TENSOR parallel instead -- attention heads and every expert's intermediate columns sharded over the ranks
+    (batch-1 decode under expert parallelism streams a token's two experts from at most two ranks; here all ranks stream 1 / world
+    of them); the prompt then runs token by token, so a 128-token prompt is used."""
     import numpy as np
     from ominix_mlx_amd import engine
     cfg = dict(hidden_size=4096, num_hidden_layers=32, intermediate_size=14336, num_attention_heads=32, num_key_value_heads=8,
                head_dim=128, vocab_size=32000, rms_norm_eps=1e-5, rope_theta=1e6, num_experts=8, num_experts_per_tok=2,
                moe_intermediate_size=14336, moe_mode="mixtral", qk_norm=False)
-    if comm is not None:
+    if mode == "etp":
+        n_prompt = min(n_prompt, 128)
+    if comm is not None and mode == "etp":
+        m = engine.Model(max_context=n_prompt + warm + steps + 8, tp_rank=rank, tp_size=world, **cfg)
+        m.set_comm(comm[1], comm[2])
+    elif comm is not None:
         m = engine.Model(max_context=n_prompt + warm + steps + 8, ep_rank=rank, ep_size=world, **cfg)
         m.set_comm(comm[1], comm[2])
     else:
@@ -336,7 +346,7 @@ def mixtral_secondary(omx, steps=64, warm=8, n_prompt=2048, rank=0, world=1, com
         dt = float(t.item())
     step_bytes = m.step_bytes(n_prompt + warm + steps // 2)
     out = {"metric": "decode_tokens_per_sec_mixtral_8x7b_bf16", "value": round(steps / dt, 2), "unit": "tokens/s", "n_gpus": world,
-           "steps": steps, "ms_per_step": round(dt / steps * 1e3, 4), "dtype": "bf16", "data": "synthetic", "parallelism": f"ep{world}",
+           "steps": steps, "ms_per_step": round(dt / steps * 1e3, 4), "dtype": "bf16", "data": "synthetic", "parallelism": f"{'etp' if mode == 'etp' else 'ep'}{world}", "prompt": n_prompt,
            "decode_path": m.decode_path(),
            "step_roofline": {"algorithmic_bytes_per_token": int(step_bytes), "achieved_GBps": round(step_bytes / (dt / steps) / 1e9, 1),
                              "frac_of_hbm_peak": round(step_bytes / (dt / steps) / 1e9 / HBM_PEAK_GBPS, 4)},
@@ -366,9 +376,13 @@ def paraformer_secondary(omx, reps=5):
 
     run()
     best, n = min(run() for _ in range(reps))
+    flop = 0.17e12   # the whole pass: 50 SAN-M encoder layers over 501 frames + 16 decoder layers over ~216 tokens
     return {"metric": "paraformer_30s_audio_seconds", "value": round(best, 5), "unit": "s", "higher_is_better": False, "n_gpus": 1,
             "rtf": round(best / secs, 6), "tokens": int(n), "dtype": "f32", "data": "synthetic",
-            "vs_reference_m3max_400ms": round(0.4 / best, 1)}
+            "vs_reference_m3max_400ms": round(0.4 / best, 1),
+            # ~650 launches of <= 16 us over 200-500-row GEMMs: latency-bound, the float32 matrix-core peak is not what limits it
+            "roofline": {"bound": "mfma", "achieved": round(flop / best / 1e12, 2), "peak": 157.0, "unit": "TFLOP/s (f32 matrix cores)",
+                         "frac": round(flop / best / 1e12 / 157.0, 4), "traffic": None}}
 
 
 def physical_cores():
@@ -673,6 +687,11 @@ def main():
                 mixtral_ep = mixtral_secondary(omx, rank=rank, world=world, comm=keep, dist=dist)
             except Exception as e:
                 mixtral_ep = {"metric": "decode_tokens_per_sec_mixtral_8x7b_bf16", "value": None, "error": str(e)}
+            if world > 1 and 14336 % (64 * world) == 0:    # the same model with expert TENSOR parallelism (what scales batch-1 decode)
+                try:
+                    mixtral_ep["expert_tensor_parallel"] = mixtral_secondary(omx, rank=rank, world=world, comm=keep, dist=dist, mode="etp")
+                except Exception as e:
+                    mixtral_ep["expert_tensor_parallel"] = {"value": None, "error": str(e)}
         dog.cancel()
     if rank != 0:
         if not primary_closed:

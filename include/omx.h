@@ -309,6 +309,15 @@ int omx_moe_block_forward(void* out, const void* resid, const void* x, const voi
 int omx_moe_block_partial_ep(float* partial, const void* x, const void* norm_w, float eps, void* xn, const void* gate_w,
                              const void* w_gate, const void* w_up, const void* w_down, int n_tokens, int hidden, int inter,
                              int n_experts, int top_k, int mode, int norm_topk_prob, int e_lo, int e_n, omx_stream stream);
+/* expert TENSOR parallel decode form (<= 32 routed slots): this rank holds `inter` = I / tp intermediate columns of EVERY expert;
+ * y_partial [slots, hidden] f32 = the unrounded partial down projections (to be all-reduced), the replicated router's choice goes to
+ * route_inds / route_scores; omx_moe_combine_slots then forms bf16(resid + bf16(sum_j bf16(bf16(y_j) score_j))) (mixtral model.rs:296-308,
+ * 343-344 with the single-device roundings).  No reference counterpart: mlx-c distributed.h:30-70 is declared, never bound. */
+int omx_moe_block_partial_tp(float* y_partial, uint32_t* route_inds, void* route_scores, const void* x, const void* norm_w, float eps,
+                             void* xn, const void* gate_w, const void* w_gate, const void* w_up, const void* w_down, int n_tokens,
+                             int hidden, int inter, int n_experts, int top_k, int mode, int norm_topk_prob, omx_stream stream);
+int omx_moe_combine_slots(void* out, const float* y_slots, const void* scores, const void* resid, int n_tokens, int hidden, int top_k,
+                          omx_stream stream);
 /* the same on a quantised checkpoint (mixtral-mlx/src/model.rs:560-600): router and expert stacks as MLX triplets */
 /* one token, bf16 experts: the block WITHOUT its weighted sum -- partials[j, :] (f32) = bf16(bf16(y_j) * score_j) of the top_k routed
  * experts in slot order; the caller's next streaming GEMV folds x := bf16(resid + bf16(sum_j partials[j])) in its prologue (engine-internal:

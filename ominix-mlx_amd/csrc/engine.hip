@@ -88,6 +88,12 @@ __global__ __launch_bounds__(256) void qembed_kernel(bf16_t* __restrict__ h, con
     }
 }
 
+// h = bf16(resid + bf16(all-reduced partial)): the residual of a block whose output arrives as an f32 sum over the ranks
+__global__ void ep_fold_kernel(bf16_t* __restrict__ out, const bf16_t* __restrict__ resid, const float* __restrict__ partial, int64_t n) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = f32_to_bf16(bf16_to_f32(resid[i]) + round_bf16(partial[i]));
+}
+
 uint32_t crc32_str(const char* s) {
     uint32_t crc = 0xFFFFFFFFu;
     for (; *s; ++s) {
@@ -192,6 +198,11 @@ struct omx_qwen3_ {
     bf16_t *moe_xn = nullptr, *moe_out = nullptr;   // MoE feed-forward: normalised input row, block output
     float *partial_a = nullptr, *partial_b = nullptr;   // TP: f32 partial sums awaiting all-reduce
     float* moe_partials = nullptr;                      // MoE decode: [top_k, hidden] weighted expert outputs awaiting the next GEMV's fold
+    // expert TENSOR parallel (tp_size > 1 with experts): every expert's intermediate columns sharded over the ranks
+    int moe_I = 0;                                      // per-rank expert intermediate width
+    float* moe_y = nullptr;                             // [top_k, hidden] f32 partial down projections of the routed slots (all-reduced)
+    uint32_t* moe_inds = nullptr;                       // the replicated router's choice, kept for the combine after the all-reduce
+    bf16_t* moe_scores = nullptr;
     unsigned long long *argmax_partials = nullptr, *argmax_key = nullptr;
     int n_argmax_partials = 0;
     unsigned *step_seq = nullptr, *wait_abort = nullptr;   // step sequence number (granule tags), word a gather that gave up raises
@@ -691,6 +702,21 @@ int enqueue_step(omx_qwen3 m, bool with_head) {
                 pending = m->partial_a;
             }
         }
+        if (c.num_experts > 0 && tp && c.tp_size > 1) {
+            // expert tensor parallel: [fold the all-reduced O partial into the residual] [replicated router + this rank's columns of the
+            // routed experts] [all-reduce of the slots' f32 partials] [weighted sum + residual with the single-device roundings]
+            OMX_REQUIRE(m->allreduce != nullptr && pending != nullptr, "tp_size > 1 but no communicator set (omx_qwen3_set_comm)");
+            ep_fold_kernel<<<8, 256, 0, s>>>(hn, h, pending, (int64_t)hd);
+            OMX_LAUNCH_CHECK();
+            { bf16_t* t = h; h = hn; hn = t; pending = nullptr; pending_n = 1; }
+            if (omx_moe_block_partial_tp(m->moe_y, m->moe_inds, m->moe_scores, h, L.post_ln, c.rms_norm_eps, m->moe_xn, L.moe_gate, L.moe_wg,
+                                         L.moe_wu, L.moe_wd, 1, hd, m->moe_I, c.num_experts, c.num_experts_per_tok, c.moe_mode, c.norm_topk_prob, s))
+                return 1;
+            OMX_REQUIRE(m->allreduce(m->moe_y, m->moe_y, (size_t)c.num_experts_per_tok * hd, kNcclFloat32, kNcclSum, m->comm, s) == 0, "ncclAllReduce failed");
+            if (omx_moe_combine_slots(hn, m->moe_y, m->moe_scores, h, 1, hd, c.num_experts_per_tok, s)) return 1;
+            { bf16_t* t = h; h = hn; hn = t; }
+            continue;
+        }
         if (c.num_experts > 0 && ep) {
             // expert parallel: this rank's experts only, partial sums all-reduced, residual folded into the next prologue
             const int el = c.num_experts / c.ep_size;
@@ -974,10 +1000,6 @@ __global__ void copy_rows_strided_kernel(bf16_t* dst, int64_t dst_ld, const bf16
 
 // qwen3_encoder.rs:172-198: additive mask 0 where (j <= i and attention_mask[j]) else bf16(-1e9)
 // expert-parallel batched prefill: h = bf16(resid + bf16(all-reduced partial))  (the residual of mixtral model.rs:343-344)
-__global__ void ep_fold_kernel(bf16_t* __restrict__ out, const bf16_t* __restrict__ resid, const float* __restrict__ partial, int64_t n) {
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-        out[i] = f32_to_bf16(bf16_to_f32(resid[i]) + round_bf16(partial[i]));
-}
 
 __global__ void encoder_mask_kernel(bf16_t* mask, const uint8_t* am, int T) {
     const bf16_t neg = f32_to_bf16(-1e9f);
@@ -1232,12 +1254,17 @@ int omx_qwen3_create(omx_qwen3* out, const omx_qwen3_config* cfg) {
         OMX_LAUNCH_CHECK();
     }
     if (c.num_experts > 0) {
-        OMX_REQUIRE(c.tp_size == 1, "InvalidConfig: the sparse-MoE engine shards experts (ep_size), not heads (tp_size %d)", c.tp_size);
+        // tp_size > 1: expert TENSOR parallel -- attention sharded like the dense model, every expert's intermediate columns split over
+        // the ranks (decode streams 1 / tp of the two routed experts on every rank; prompts run token by token on this form)
+        OMX_REQUIRE(c.tp_size == 1 || (c.ep_size <= 1 && !c.quant_bits && c.moe_intermediate_size % (64 * c.tp_size) == 0),
+                    "InvalidConfig: expert tensor parallelism (tp_size %d with experts) needs bf16 weights, ep_size 1 and moe_intermediate_size %d divisible by 64 * tp_size",
+                    c.tp_size, c.moe_intermediate_size);
+        m->moe_I = c.moe_intermediate_size / c.tp_size;
         OMX_REQUIRE(c.ep_size <= 1 || (c.ep_rank >= 0 && c.ep_rank < c.ep_size && c.num_experts % c.ep_size == 0 && !c.quant_bits),
                     "InvalidConfig: expert parallel rank %d of %d over %d experts (bf16 only)", c.ep_rank, c.ep_size, c.num_experts);
         OMX_REQUIRE(!c.quant_bits || c.moe_intermediate_size % 512 == 0, "InvalidConfig: quantised experts need moe_intermediate_size %% 512 == 0 (%d)", c.moe_intermediate_size);
         OMX_REQUIRE(c.num_experts_per_tok >= 1 && c.num_experts_per_tok <= c.num_experts && c.moe_intermediate_size > 0 &&
-                        c.moe_intermediate_size % 64 == 0 && (c.moe_mode == 0 || c.moe_mode == 1) && m->H * D >= c.hidden_size,
+                        c.moe_intermediate_size % 64 == 0 && (c.moe_mode == 0 || c.moe_mode == 1) && (c.tp_size > 1 || m->H * D >= c.hidden_size),
                     "InvalidConfig: experts %d top-%d moe_intermediate_size %d mode %d", c.num_experts, c.num_experts_per_tok,
                     c.moe_intermediate_size, c.moe_mode);
         // the MoE block takes its scratch from the library workspace: size it ONCE for the largest batch (a whole-context
@@ -1247,7 +1274,11 @@ int omx_qwen3_create(omx_qwen3* out, const omx_qwen3_config* cfg) {
         void* ws = nullptr;
         if (get_workspace(&ws, need)) return 1;
         if (c.ep_size > 1 && get_workspace_aux(&ws, need, m->stream)) return 1;   // the expert-parallel block's per-stream scratch (moe.hip)
+        if (c.tp_size > 1 && get_workspace_aux(&ws, (size_t)c.num_experts_per_tok * m->moe_I * 2 + 256, m->stream)) return 1;
         if (dev_alloc(m, &m->moe_xn, (size_t)c.hidden_size) || dev_alloc(m, &m->moe_out, (size_t)c.hidden_size)) return 1;
+        if (c.tp_size > 1 && (dev_alloc(m, &m->moe_y, (size_t)c.num_experts_per_tok * c.hidden_size) ||
+                              dev_alloc(m, &m->moe_inds, (size_t)c.num_experts_per_tok) || dev_alloc(m, &m->moe_scores, (size_t)c.num_experts_per_tok)))
+            return 1;
     }
     if (dev_alloc(m, &m->rope_cur, (size_t)D) || dev_alloc(m, &m->attn_gran, attn_step_ws_granules(m->H, D)) ||
         dev_alloc(m, &m->attn_xg, (size_t)m->H * D / 2 + 8))
@@ -1305,7 +1336,7 @@ int omx_qwen3_destroy(omx_qwen3 m) {
 // use; mirrors resolve_weights above (and engine.py expected_shape, which reports the same thing as a shape)
 static size_t expected_weight_bytes(omx_qwen3 m, const std::string& name) {
     const omx_qwen3_config& c = m->cfg;
-    const size_t hd = c.hidden_size, D = c.head_dim, H = m->H, Hkv = m->Hkv, I = m->I, Im = c.moe_intermediate_size;
+    const size_t hd = c.hidden_size, D = c.head_dim, H = m->H, Hkv = m->Hkv, I = m->I, Im = c.tp_size > 1 && c.num_experts > 0 ? m->moe_I : c.moe_intermediate_size;   // (expert tensor parallel: this rank's columns)
     const size_t E = c.num_experts, El = c.ep_size > 1 ? E / c.ep_size : E;
     static const char* kSuffix[] = {".weight", ".scales", ".biases", ".bias"};
     int kind = -1;
@@ -1457,6 +1488,23 @@ static int synth_weights_impl(omx_qwen3 m, uint32_t base_seed, bool peaked) {
             const std::string mp = p + (c.moe_mode == 0 ? "block_sparse_moe." : "mlp.");
             const int64_t E = c.num_experts, Im = c.moe_intermediate_size;
             const int64_t El = c.ep_size > 1 ? E / c.ep_size : E, e0 = c.ep_size > 1 ? c.ep_rank * El : 0;   // this rank's experts
+            if (c.tp_size > 1) {
+                // expert tensor parallel: rows [r I_l, +I_l) of every expert's gate / up, the same columns of its down projection
+                const int64_t Il = m->moe_I;
+                bf16_t *wg = nullptr, *wu = nullptr;
+                if (dev_alloc(m, &wg, (size_t)(E * Il * hd)) || dev_alloc(m, &wu, (size_t)(E * Il * hd))) return 1;
+                const uint32_t sg = base_seed ^ crc32_str((mp + "switch_mlp.gate_proj.weight").c_str());
+                const uint32_t su = base_seed ^ crc32_str((mp + "switch_mlp.up_proj.weight").c_str());
+                for (int64_t e = 0; e < E; ++e)
+                    if (omx_fill_uniform_2d(wg + e * Il * hd, Il, hd, hd, e * Im + (int64_t)r * Il, 0, sg, amp_w, 0.f, OMX_BFLOAT16, m->stream) ||
+                        omx_fill_uniform_2d(wu + e * Il * hd, Il, hd, hd, e * Im + (int64_t)r * Il, 0, su, amp_w, 0.f, OMX_BFLOAT16, m->stream))
+                        return 1;
+                m->named[mp + "switch_mlp.gate_proj.weight"] = wg;
+                m->named[mp + "switch_mlp.up_proj.weight"] = wu;
+                if (make(mp + "gate.weight", E, hd, hd, 0, 0, false) ||
+                    make(mp + "switch_mlp.down_proj.weight", E * hd, Il, Im, 0, (int64_t)r * Il, false))
+                    return 1;
+            } else
             if (make(mp + "gate.weight", E, hd, hd, 0, 0, false) ||
                 make(mp + "switch_mlp.gate_proj.weight", El * Im, hd, hd, e0 * Im, 0, false) ||
                 make(mp + "switch_mlp.up_proj.weight", El * Im, hd, hd, e0 * Im, 0, false) ||
@@ -1600,7 +1648,7 @@ int omx_qwen3_prefill(omx_qwen3 m, const uint32_t* prompt, int n_prompt, uint32_
     const char* serial_env = getenv("OMX_PREFILL_SERIAL");
     // tensor-parallel engines run the batched matrix-core prefill on their shards with two all-reduces per layer, expert-parallel ones
     // with one all-reduce of the MoE block's [T, hidden] partial per layer (round 3; token-serial before)
-    const bool serial = (serial_env && serial_env[0] == '1') || n_prompt < 2;
+    const bool serial = (serial_env && serial_env[0] == '1') || n_prompt < 2 || (m->cfg.num_experts > 0 && m->cfg.tp_size > 1);   // (expert tensor parallel: the decode form only)
     if (prepare_step(m, serial ? off : off + n_prompt - 1)) return 1;   // the first step this call will run (graphs are per context bucket)
     OMX_HIP_CHECK(hipMemcpyAsync(m->prompt_dev, prompt, (size_t)n_prompt * 4, hipMemcpyHostToDevice, m->stream));
     StepState st;
@@ -1937,7 +1985,8 @@ int omx_qwen3_step_bytes(omx_qwen3 m, int ctx, double* bytes) {
     const double D = c.head_dim, hd = c.hidden_size;
     // 2 B x [L (h H D + 2 h Hkv D + H D h + 3 h I) + V h] + ctx (2 L Hkv D 2 B) + KV write
     // sparse MoE: the router plus the top-k experts' three matrices are what one token streams
-    const double ffn = c.num_experts > 0 ? hd * c.num_experts + 3.0 * hd * c.moe_intermediate_size * c.num_experts_per_tok : 3.0 * hd * m->I;
+    const double moe_i = c.tp_size > 1 && c.num_experts > 0 ? m->moe_I : c.moe_intermediate_size;   // (expert tensor parallel: this rank's columns)
+    const double ffn = c.num_experts > 0 ? hd * c.num_experts + 3.0 * hd * moe_i * c.num_experts_per_tok : 3.0 * hd * m->I;
     const double per_layer = hd * m->H * D + 2.0 * hd * m->Hkv * D + m->H * D * hd + ffn;
     // bytes per weight element: bf16 = 2; quantized = bits/8 packed + (scale + bias) bf16 per group
     const double bpe = c.quant_bits ? c.quant_bits / 8.0 + 4.0 / c.quant_group : 2.0;

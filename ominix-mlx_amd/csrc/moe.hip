@@ -692,6 +692,70 @@ extern "C" int omx_moe_block_partial_ep(float* partial, const void* x, const voi
     return 0;
 }
 
+/* expert TENSOR parallel, decode form (n_tokens * top_k <= 32): every rank holds ALL experts but only `inter` = I / tp of each expert's
+ * intermediate columns (gate / up rows [r I/tp, +I/tp) of every expert, the same columns of its down projection), so a token's two
+ * experts stream from all ranks at once -- what expert parallelism cannot give batch-1 decode, where top-2 routing touches at most
+ * two ranks' experts per layer.  The router runs replicated (same row, same weights: the same selection on every rank) and leaves
+ * its choice in route_inds [slots] / route_scores [slots]; y_partial [slots, hidden] f32 receives the UNROUNDED partial of each routed
+ * slot's down projection.  After the all-reduce over the ranks omx_moe_combine_slots forms the block output with the single-device
+ * roundings: bf16(resid + bf16(sum_j bf16(bf16(y_j) * score_j))).  Scratch: the STREAM's (several ranks may share a process). */
+extern "C" int omx_moe_block_partial_tp(float* y_partial, uint32_t* route_inds, void* route_scores, const void* x, const void* norm_w,
+                                        float eps, void* xn, const void* gate_w, const void* w_gate, const void* w_up, const void* w_down,
+                                        int n_tokens, int hidden, int inter, int n_experts, int top_k, int mode, int norm_topk_prob,
+                                        omx_stream stream) {
+    using namespace omx;
+    OMX_REQUIRE(y_partial && route_inds && route_scores && x && norm_w && xn && gate_w && w_gate && w_up && w_down, "omx_moe_block_partial_tp: null tensor");
+    OMX_REQUIRE(n_experts >= 1 && n_experts <= kMaxExperts && top_k >= 1 && top_k <= kMaxTopK && top_k <= n_experts,
+                "omx_moe_block_partial_tp: experts %d top-%d", n_experts, top_k);
+    const int slots = n_tokens * top_k;
+    OMX_REQUIRE(slots >= 1 && slots <= 32 && hidden % 64 == 0 && inter % 64 == 0 && gemv_k_supported(hidden, false) && gemv_k_supported(inter, false),
+                "omx_moe_block_partial_tp: %d routed slots (at most 32), hidden %d, per-rank intermediate %d", slots, hidden, inter);
+    hipStream_t s = (hipStream_t)stream;
+    void* ws = nullptr;
+    if (get_workspace_aux(&ws, ((size_t)slots * inter * 2 + 256), s)) return 1;
+    bf16_t* gbuf = (bf16_t*)ws;
+    moe_router_kernel<<<n_tokens, router_threads(n_experts, hidden), 0, s>>>((const bf16_t*)x, (const bf16_t*)gate_w, hidden, n_experts, top_k, mode,
+                                                          norm_topk_prob, route_inds, (bf16_t*)route_scores, (const bf16_t*)norm_w, eps, (bf16_t*)xn);
+    OMX_LAUNCH_CHECK();
+    GemvArgs a = {};
+    a.w0 = (const bf16_t*)w_gate; a.w1 = (const bf16_t*)w_up; a.n0 = inter; a.N = inter; a.K = hidden;
+    a.x = (const bf16_t*)xn; a.out = gbuf;
+    a.n_batch = slots; a.x_div = top_k; a.x_bstride = hidden; a.out_bstride_bytes = (size_t)inter * 2;
+    a.w_sel = route_inds; a.w_estride = (size_t)inter * hidden; a.swiglu_single_round = 1;
+    if (launch_gemv(a, PRO_NONE, EPI_SWIGLU, s)) return 1;
+    GemvArgs d = {};
+    d.w0 = (const bf16_t*)w_down; d.n0 = hidden; d.N = hidden; d.K = inter;
+    d.x = gbuf; d.out = y_partial;
+    d.n_batch = slots; d.x_div = 1; d.x_bstride = inter; d.out_bstride_bytes = (size_t)hidden * 4;
+    d.w_sel = route_inds; d.w_estride = (size_t)hidden * inter;
+    return launch_gemv(d, PRO_NONE, EPI_F32, s);
+}
+
+namespace omx {
+namespace {
+// out[t] = bf16(resid[t] + bf16(sum_j bf16(bf16(y[t k + j]) * score[t k + j])))  -- moe_combine_kernel on f32 (all-reduced) slot outputs
+__global__ __launch_bounds__(256) void moe_combine_slots_kernel(bf16_t* __restrict__ out, const float* __restrict__ y, const bf16_t* __restrict__ scores,
+                                                                const bf16_t* __restrict__ resid, int h, int k) {
+    const int t = blockIdx.x;
+    for (int i = threadIdx.x; i < h; i += 256) {
+        float acc = 0.f;
+        for (int j = 0; j < k; ++j) acc += round_bf16(round_bf16(y[((size_t)t * k + j) * h + i]) * bf16_to_f32(scores[(size_t)t * k + j]));
+        out[(size_t)t * h + i] = f32_to_bf16(resid ? bf16_to_f32(resid[(size_t)t * h + i]) + round_bf16(acc) : acc);
+    }
+}
+}  // namespace
+}  // namespace omx
+
+extern "C" int omx_moe_combine_slots(void* out, const float* y_slots, const void* scores, const void* resid, int n_tokens, int hidden,
+                                     int top_k, omx_stream stream) {
+    OMX_REQUIRE(out && y_slots && scores && n_tokens >= 0 && hidden > 0 && top_k >= 1, "omx_moe_combine_slots: bad arguments");
+    if (n_tokens == 0) return 0;
+    omx::moe_combine_slots_kernel<<<n_tokens, 256, 0, (hipStream_t)stream>>>((omx::bf16_t*)out, y_slots, (const omx::bf16_t*)scores,
+                                                                             (const omx::bf16_t*)resid, hidden, top_k);
+    OMX_LAUNCH_CHECK();
+    return 0;
+}
+
 /* The reference's own Mixtral format: 4/8-bit expert stacks through gather_qmm (mixtral-mlx/src/model.rs:182-274).
  * q_* = packed u32 [E, out, in*bits/32]; s_* / b_* = scales / biases bf16 [E, out, in/group_size].  The router gate is bf16. */
 extern "C" int omx_moe_forward_q(void* out, const void* x, const void* gate_w, const void* q_gate, const void* s_gate,

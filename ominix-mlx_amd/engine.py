@@ -84,6 +84,8 @@ def expected_shape(c: Qwen3Config, name: str):
     hd, D = c.hidden_size, c.head_dim
     H, Hkv, I, V = c.num_attention_heads // tp, max(1, c.num_key_value_heads // tp), c.intermediate_size // tp, c.vocab_size
     Im, E = c.moe_intermediate_size, c.num_experts
+    if E > 0 and tp > 1:      # expert tensor parallel: this rank's intermediate columns of every expert
+        Im //= tp
     leaf_kind = None
     for suffix in (".weight", ".scales", ".biases", ".bias"):
         if name.endswith(suffix):

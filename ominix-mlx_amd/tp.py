@@ -21,6 +21,10 @@ ROW_SPLIT = ("self_attn.q_proj.weight", "self_attn.k_proj.weight", "self_attn.v_
              # Qwen2's projection biases (qwen3-mlx/src/qwen2.rs:112-124) follow the rows of their Linear
              "self_attn.q_proj.bias", "self_attn.k_proj.bias", "self_attn.v_proj.bias")
 COL_SPLIT = ("self_attn.o_proj.weight", "mlp.down_proj.weight")
+# sparse-MoE models under tensor parallelism ("expert tensor parallel"): every expert's intermediate columns are split, the router is
+# replicated -- stacks [E, I, hidden] (gate / up: rows of each expert) and [E, hidden, I] (down: columns of each expert)
+EXPERT_ROW_SPLIT = ("switch_mlp.gate_proj.weight", "switch_mlp.up_proj.weight")
+EXPERT_COL_SPLIT = ("switch_mlp.down_proj.weight",)
 
 
 def kv_replication(num_key_value_heads: int, world: int) -> int:
@@ -52,6 +56,12 @@ def shard(name: str, arr: np.ndarray, rank: int, world: int, num_key_value_heads
     if 0 < num_key_value_heads < world and (".self_attn.k_proj." in name or ".self_attn.v_proj." in name):
         head = rank // kv_replication(num_key_value_heads, world)
         return keep_kind(arr, np.ascontiguousarray(arr[head * head_dim:(head + 1) * head_dim]))
+    if name.endswith(EXPERT_ROW_SPLIT):
+        n = arr.shape[1] // world
+        return keep_kind(arr, np.ascontiguousarray(arr[:, rank * n:(rank + 1) * n, :]))
+    if name.endswith(EXPERT_COL_SPLIT):
+        n = arr.shape[2] // world
+        return keep_kind(arr, np.ascontiguousarray(arr[:, :, rank * n:(rank + 1) * n]))
     if name.endswith(ROW_SPLIT):
         n = arr.shape[0] // world
         return keep_kind(arr, np.ascontiguousarray(arr[rank * n:(rank + 1) * n]))

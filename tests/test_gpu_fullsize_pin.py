@@ -82,6 +82,54 @@ def test_baseline_config_c1_at_real_shapes(omx):
     m.close()
 
 
+QWEN3_0_6B_UNTIED = dict(hidden_size=1024, num_hidden_layers=28, intermediate_size=3072, num_attention_heads=16, num_key_value_heads=8,
+                         head_dim=128, vocab_size=151936, rms_norm_eps=1e-6, rope_theta=1e6)
+
+
+def _protocol_pin(omx, which, cfg):
+    """One of BASELINE.json's decode protocols at the model's real shapes on the PEAKED synthetic checkpoint (embedding std 64,
+    lm_head[v] = table[(v + 1) mod V]: top-1 margins ~20 resp. ~80 against a bound below 1), against the C oracle's token-by-token run
+    (tools/protocol_pin.py): the prompt in ONE batched prefill, then every new token through the decode step -- all token ids EQUAL,
+    top-8 logits within the engine's bound at the pinned steps."""
+    from ominix_mlx_amd import engine
+    path = os.path.join(os.path.dirname(__file__), "golden", f"qwen3_{which}_protocol_pin.npz")
+    if not os.path.exists(path):
+        pytest.skip(f"{os.path.basename(path)} not generated (tools/protocol_pin.py {which})")
+    pin = np.load(path)
+    n_prompt, want = int(pin["prompt_len"]), pin["tokens"]
+    n_new = want.size - 1
+    prompt = bench.prompt_ids(n_prompt, cfg["vocab_size"])
+    m = engine.Model(max_context=n_prompt + n_new + 16, **cfg)
+    m.synth_weights(peaked=True)
+    bound = 2.0 ** -7 * float(pin["logit_absmax"]) * np.sqrt(cfg["num_hidden_layers"])
+    assert float(pin["margins"].min()) > 4 * bound, "the fixture's margins must make token equality a fair demand"
+    got, logits_at = [int(m.prefill(prompt))], {0: m.last_logits()}
+    pins = {int(s): i for i, s in enumerate(pin["pin_steps"])}
+    step = 0
+    while step < n_new:                      # decode in runs that end on the pinned steps (their logits are read back)
+        nxt = min([s for s in pins if s > step] + [n_new])
+        got += [int(t) for t in m.decode(nxt - step)]
+        step = nxt
+        if step in pins:
+            logits_at[step] = m.last_logits()
+    np.testing.assert_array_equal(np.asarray(got, np.int64), want)
+    assert got == [(int(prompt[-1]) - 1 - i) % cfg["vocab_size"] for i in range(len(got))]     # (what the peaked weights encode)
+    for s, i in pins.items():
+        err = float(np.abs(logits_at[s][pin["top_idx"][i]] - pin["top_val"][i]).max())
+        assert err <= bound, f"step {s}: top-8 logits off by {err:.4f} (bound {bound:.4f})"
+    m.close()
+
+
+def test_protocol_c1_token_ids_equal_at_real_shapes(omx):
+    """BASELINE configs[0] (qwen3-mlx 0.5B greedy decode, 128-token prompt; 32 new tokens) at Qwen3-0.6B's shapes."""
+    _protocol_pin(omx, "c1", QWEN3_0_6B_UNTIED)
+
+
+def test_protocol_c2_token_ids_equal_at_real_shapes(omx):
+    """BASELINE configs[1] (qwen3-mlx 7B bf16, 2k prefill + 256 decode) at Qwen3-8B's shapes: 2 048-token prompt + 256 tokens."""
+    _protocol_pin(omx, "c2", dict(bench.QWEN3_8B))
+
+
 def test_full_size_mixtral_routes_agree_when_routing_cannot_flip(omx, monkeypatch):
     """Mixtral-8x7B at its real shapes (32 layers, 8 experts of 4096 x 14336, 93 GB of bf16 weights generated on the device) has no
     oracle pin: with random weights top-2-of-8 routing flips under bf16 rounding.  The size-independent property

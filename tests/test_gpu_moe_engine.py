@@ -83,8 +83,11 @@ def test_moe_engine_rejects_bad_config(omx):
         engine.Model(**base, num_experts=4, num_experts_per_tok=5, moe_intermediate_size=512)
     with pytest.raises(omx.OmxError, match="InvalidConfig"):      # quantised experts: width must be a multiple of 512
         engine.Model(**base, num_experts=4, num_experts_per_tok=2, moe_intermediate_size=768, quantization={"bits": 4, "group_size": 64})
+    with pytest.raises(omx.OmxError, match="InvalidConfig"):      # expert tensor parallel: 64-column granularity per rank, no EP on top
+        engine.Model(**base, num_experts=4, num_experts_per_tok=2, moe_intermediate_size=320, tp_size=2)
     with pytest.raises(omx.OmxError, match="InvalidConfig"):
-        engine.Model(**base, num_experts=4, num_experts_per_tok=2, moe_intermediate_size=512, tp_size=2)
+        engine.Model(**base, num_experts=4, num_experts_per_tok=2, moe_intermediate_size=512, tp_size=2, ep_size=2)
+    engine.Model(**base, num_experts=4, num_experts_per_tok=2, moe_intermediate_size=512, tp_size=2).close()
     m = engine.Model(**base, num_experts=4, num_experts_per_tok=2, moe_intermediate_size=512)
     with pytest.raises(omx.OmxError, match="WeightNotFound"):
         m.prefill([1, 2, 3])
@@ -192,6 +195,65 @@ def test_expert_parallel_engine_on_one_gpu(omx, monkeypatch, name, world, use_sy
     for m in models:
         m.close()
     group.close()
+
+
+@pytest.mark.parametrize("name,world", [("mixtral", 2), ("qwen3_moe", 2), ("mixtral", 4)])
+def test_expert_tensor_parallel_engine_on_one_gpu(omx, monkeypatch, name, world):
+    """Expert TENSOR parallelism (round 4; tp_size > 1 on a sparse-MoE model): attention heads sharded like the dense model, every
+    expert's intermediate columns split over the ranks (gate / up rows, down columns), router replicated, per layer one all-reduce of
+    the O partial and one of the routed slots' f32 down partials, then the weighted sum with the single-device roundings.  What
+    expert parallelism cannot do -- a token's two experts streaming from ALL ranks -- at the price of partial sums that round
+    differently from the single-GPU dot products: every rank must agree with every other rank bit for bit (rank-ordered sums),
+    the synthetic shards must equal the host-sharded checkpoint (tp.py expert rules), and the logits must stay within the engine's
+    bound of the single-GPU run (tokens equal wherever its top-1 margin allows)."""
+    from ominix_mlx_amd import comm, engine
+    cfg = CONFIGS[name]
+    weights = rq.synth_weights(cfg)
+    prompt = synth.prompt_ids(20, cfg.vocab_size)
+    monkeypatch.setenv("OMX_PREFILL_SERIAL", "1")
+    single = _engine(omx, cfg)
+    want = np.concatenate([[single.prefill(prompt)], single.decode(6)]).astype(np.uint32)
+    want_logits = single.last_logits()
+    single.close()
+    results = {}
+    for use_synth in (True, False):
+        group = comm.LoopbackGroup(world, 1 << 20)
+        models = []
+        for r in range(world):
+            m = engine.Model(hidden_size=cfg.hidden_size, num_hidden_layers=cfg.num_hidden_layers, intermediate_size=cfg.intermediate_size,
+                             num_attention_heads=cfg.num_attention_heads, num_key_value_heads=cfg.num_key_value_heads, head_dim=cfg.head_dim,
+                             vocab_size=cfg.vocab_size, rms_norm_eps=cfg.rms_norm_eps, rope_theta=cfg.rope_theta,
+                             tie_word_embeddings=cfg.tie_word_embeddings, max_context=256, num_experts=cfg.num_experts,
+                             num_experts_per_tok=cfg.num_experts_per_tok, moe_intermediate_size=cfg.moe_intermediate_size,
+                             moe_mode=cfg.moe_mode, norm_topk_prob=cfg.norm_topk_prob, qk_norm=cfg.qk_norm, tp_rank=r, tp_size=world)
+            m.synth_weights() if use_synth else m.load_weights(weights)
+            m.set_comm(group.rank_comm(r), group.allreduce_fn)
+            models.append(m)
+
+        def run(r):
+            m = models[r]
+            toks = np.concatenate([[m.prefill(prompt)], m.decode(6)]).astype(np.uint32)
+            return toks, m.last_logits()
+
+        outs = comm.run_ranks(world, run, group)
+        for m in models:
+            m.close()
+        group.close()
+        for r in range(1, world):                      # vocabulary shards: the token is all-reduced, the logits are each rank's rows
+            np.testing.assert_array_equal(outs[r][0], outs[0][0])
+        results[use_synth] = (outs[0][0], np.concatenate([o[1] for o in outs]))
+    np.testing.assert_array_equal(results[True][0], results[False][0])
+    np.testing.assert_array_equal(results[True][1], results[False][1])
+    toks, logits = results[True]
+    bound = 2.0 ** -7 * float(np.abs(want_logits).max()) * np.sqrt(2 * cfg.num_hidden_layers)
+    srt = np.sort(want_logits)
+    if srt[-1] - srt[-2] > 2 * bound:                  # (the last step's margin decides whether the last token may differ)
+        assert toks[-1] == want[-1]
+    first_diff = next((i for i in range(len(want)) if toks[i] != want[i]), len(want))
+    if first_diff == len(want):                        # same token sequence -> same cache contents: the logits are comparable
+        assert float(np.abs(logits - want_logits).max()) <= bound, f"expert-TP logits off by {np.abs(logits - want_logits).max():.4f} (bound {bound:.4f})"
+    else:
+        assert first_diff >= 1, "the sharded engines already disagree with the single-GPU engine on the token after the prompt"
 
 
 def test_expert_parallel_load_from_bf16_checkpoint_files(omx, tmp_path, monkeypatch):

@@ -26,7 +26,7 @@ ref = None
 for rnd in range(int(os.environ.get("OMX_AB_ROUNDS", "2"))):
     for mode, mask, extra in [(md, mk, ex) for ex in extras for md in modes for mk in (masks if md else ["0"])]:
         for k in list(os.environ):
-            if k.startswith("OMX_GEMV_RPW_") or k.startswith("OMX_PF"):
+            if k.startswith("OMX_GEMV_RPW_") or k.startswith("OMX_PF") or k.startswith("OMX_GEMV_PERM"):
                 del os.environ[k]
         os.environ.update(extra)
         os.environ["OMX_STEP_AQL"] = str(mode)

@@ -14,7 +14,8 @@ from ominix_mlx_amd import comm, engine  # noqa: E402
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 prompt_n = int(sys.argv[2]) if len(sys.argv) > 2 else 2048
-cfg = dict(bench.QWEN3_8B)
+MIXTRAL = len(sys.argv) > 3 and sys.argv[3] == "mixtral"      # expert tensor parallel shards of Mixtral-8x7B (token-serial prompt: keep it short)
+cfg = dict(bench.MIXTRAL_8X7B) if MIXTRAL else dict(bench.QWEN3_8B)
 ids = bench.prompt_ids(prompt_n, cfg["vocab_size"])
 L = cfg["num_hidden_layers"]
 BW, C_LAUNCH = 6.67e12, 3.6e-6
@@ -41,7 +42,8 @@ for tp in (1, 2, 4, 8):
     m.close()
     if group is not None:
         group.close()
-    t_bytes, t_launch = nbytes / BW, 145 * C_LAUNCH
+    n_launch = (7 * L + 3) if MIXTRAL else 145            # per layer q/k/v, attention + o, router, experts gate/up, down, (fold, combine)
+    t_bytes, t_launch = nbytes / BW, n_launch * C_LAUNCH
     n_red = 2 * L + 1 if tp > 1 else 0
     left = best - t_bytes - t_launch
     base = base or best

@@ -260,7 +260,10 @@ int omx_qwen3_debug_trace_engine(omx_qwen3 m, unsigned long long* host, size_t n
  * mlx_rs::ops::{quantize, dequantize, quantized_matmul, gather_qmm} (mlx-rs/src/ops/quantization.rs:41-153,
  * 226-279) -> mlx_quantize / mlx_dequantize / mlx_quantized_matmul / mlx_gather_qmm (mlx-c ops.h:356-365,
  * 471-484, 793-810).  w [rows, cols] <-> packed u32 [rows, cols*bits/32] (LSB first) + scales, biases
- * [rows, cols/group_size] (dtype of w); bits 4 or 8, group_size 32/64/128, dtype bf16.
+ * [rows, cols/group_size] (dtype of w); group_size 32/64/128.  quantize / dequantize: bits 2, 4 or 8 on bf16 / f16 / f32 (the
+ * reference's own value test loops [2, 4, 8] on f32, quantization.rs:289-305).  The matmuls: bits 4 or 8; dtype = the dtype of x,
+ * out, scales and biases alike -- bf16, or f16 for a float16 MLX checkpoint, which then runs in float16 END TO END like in MLX
+ * (nn/quantized.rs:361-385): float16 activations, float16 rounding points, f32 accumulation.
  * ===================================================================================== */
 int omx_quantize(void* packed, void* scales, void* biases, const void* w, int64_t rows, int cols, int group_size, int bits,
                  omx_dtype dtype, omx_stream stream);
@@ -330,6 +333,11 @@ int omx_moe_block_forward_q(void* out, const void* resid, const void* x, const v
                             const void* b_gate, const void* q_up, const void* s_up, const void* b_up, const void* q_down,
                             const void* s_down, const void* b_down, int n_tokens, int hidden, int inter, int n_experts, int top_k,
                             int mode, int norm_topk_prob, int group_size, int bits, omx_stream stream);
+int omx_moe_block_forward_q_ex(void* out, const void* resid, const void* x, const void* norm_w, float eps, void* xn,
+                            const void* q_router, const void* s_router, const void* b_router, const void* q_gate, const void* s_gate,
+                            const void* b_gate, const void* q_up, const void* s_up, const void* b_up, const void* q_down,
+                            const void* s_down, const void* b_down, int n_tokens, int hidden, int inter, int n_experts, int top_k,
+                            int mode, int norm_topk_prob, int group_size, int bits, int f16 /* float16 checkpoint: x, norm weights, triplets and out are float16; <= 32 routed slots */, omx_stream stream);
 /* the reference's own Mixtral format (mixtral-mlx/src/model.rs:182-274, QuantizedSwitchLinear -> mlx_gather_qmm x3):
  * expert stacks as MLX affine-quantised triplets, packed u32 [E, out, in*bits/32], scales / biases [E, out, in/group_size];
  * router gate bf16.  <= 32 routed slots: expert-selected GEMVs on the packed weights; more: dequantise + grouped GEMM. */

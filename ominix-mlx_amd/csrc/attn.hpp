@@ -57,6 +57,7 @@ struct AttnStepArgs {
     const uint32_t* o_wq;       // [o_rows, H*D/8] MLX-packed nibbles
     const uint32_t* o_sb;       // [o_rows, H*D/group] scale | bias << 16 (QMat::sb)
     int o_group;
+    int f16;                    // the model runs in float16 (a float16 MLX checkpoint): qkv, norm weights, K / V slabs and `out` hold float16
 };
 bool attn_step_oproj_ok(int H, int Hkv, int D, int nsplit, int o_rows);
 bool attn_step_oproj_q4_ok(int H, int Hkv, int D, int nsplit, int o_rows, int group);

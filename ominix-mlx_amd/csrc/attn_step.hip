@@ -31,6 +31,7 @@
 #include <algorithm>
 
 #include "attn.hpp"
+#include "act16.hpp"
 #include "launch_timing.hpp"
 
 namespace omx {
@@ -57,16 +58,17 @@ __device__ __forceinline__ float swap_halves(float v) {     // value of lane (l 
     return dpp_f<0x1B>(dpp_f<kDppHalfMirror>(v));              // (7 - i) then quad reverse == i ^ 4
 }
 
+template <bool F16 = false>
 __device__ __forceinline__ void unpack8(const u32x4 r, float (&x)[8]) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-        x[2 * e] = bf16lo(r[e]);
-        x[2 * e + 1] = bf16hi(r[e]);
+        x[2 * e] = Act16<F16>::lo(r[e]);
+        x[2 * e + 1] = Act16<F16>::hi(r[e]);
     }
 }
 
 // merge the granules of one head: `NB` batches of 16 splits, every load of every live batch in flight before the first wait
-template <int D, int NB>
+template <int D, int NB, bool F16 = false>
 __device__ __forceinline__ void gather_head(const AttnStepArgs& a, const uint64_t* base, int n_active, unsigned tag, int lane,
                                             int dim, bf16_t* out, uint64_t* xg_head) {
     constexpr int STRIDE = D + 2;
@@ -119,7 +121,7 @@ __device__ __forceinline__ void gather_head(const AttnStepArgs& a, const uint64_
         for (int j = 0; j < 16; ++j)   // splits past n_active re-read the last live one and carry f == 0
             acc = fmaf(readlane_f(f, b * 16 + j), __uint_as_float((unsigned)og[b][j]), acc);
     }
-    const bf16_t r = f32_to_bf16(acc / L);
+    const bf16_t r = Act16<F16>::bits(acc / L);     // (16-bit pattern: bfloat16, or float16 in a float16 model)
     out[dim] = r;
     if (xg_head) {   // the same value once more, for the O-projection phase of every block: one granule per dim pair
         const float nb = dpp_f<kDppXor1>(bf16_to_f32(r));
@@ -149,6 +151,16 @@ __device__ __forceinline__ float dot8_bf16(const u32x4 a, const u32x4 b) {
 // latencies, and the q/k RMSNorm + RoPE is done ONCE per block (wave g: query head g, wave GT % 8: the new key row) and shared
 // through LDS instead of five times per wave.  attn_step_plan keeps the grid <= 256 blocks.
 constexpr int kKU = 3;   // units in flight per wave
+
+// ... and of float16 rows (a float16 checkpoint's K cache): v_dot2_f32_f16, same order
+template <bool F16>
+__device__ __forceinline__ float dot8_16(const u32x4 a, const u32x4 b) {
+    if constexpr (!F16) return dot8_bf16(a, b);
+    float d = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) d = Act16<true>::dot2(a[e], b[e], d);
+    return d;
+}
 
 // the O GEMV's accumulation (gemv.hip dot8): lo then hi of each dword, one fma chain
 __device__ __forceinline__ float dot8_chain(const u32x4 w, const u32x4 xp, float acc) {
@@ -346,8 +358,10 @@ __device__ __forceinline__ void oproj_phase_q4(const AttnStepArgs& a, u32x4* sm_
 }
 
 
-template <int D, int GT, bool TRACE, int NVW>
+template <int D, int GT, bool TRACE, int NVW, bool F16 = false>
 __global__ __launch_bounds__(kBlock, 1) void attn_step_kernel(const AttnStepArgs a) {
+    static_assert(!F16 || NVW == 0, "the O projection rides in the launch for bfloat16 models only");
+    typedef Act16<F16> A16;
     constexpr int LPR = D / 8;            // lanes per K/V row
     constexpr int TPW = 64 / LPR;         // token rows per wave-instruction == one unit
     constexpr bool QO = NVW >= 100;       // 100 + n: the O matrix is 4-bit packed (oproj_phase_q4)
@@ -416,8 +430,8 @@ __global__ __launch_bounds__(kBlock, 1) void attn_step_kernel(const AttnStepArgs
         const bool first_half = c < LPR / 2;
         auto norm_rope = [&](const u32x4 raw, const u32x4 w_raw) -> u32x4 {
             float x[8], w[8];
-            unpack8(raw, x);
-            unpack8(w_raw, w);
+            unpack8<F16>(raw, x);
+            unpack8<F16>(w_raw, w);
             float ss = 0.f;
 #pragma unroll
             for (int e = 0; e < 8; ++e) ss = fmaf(x[e], x[e], ss);
@@ -426,13 +440,13 @@ __global__ __launch_bounds__(kBlock, 1) void attn_step_kernel(const AttnStepArgs
             float y[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                const float xn = a.q_norm_w ? round_bf16(x[e] * rstd * w[e]) : x[e];   // RMSNorm output is bf16
+                const float xn = a.q_norm_w ? A16::rnd(x[e] * rstd * w[e]) : x[e];   // RMSNorm output is rounded to the model's dtype
                 const float other = swap_halves<LPR>(xn);                               // element i +- D/2
                 y[e] = first_half ? xn * cs[e] - other * sn[e] : other * sn[e] + xn * cs[e];
             }
             u32x4 out;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) out[e] = pack_bf16(y[2 * e], y[2 * e + 1]);     // RoPE output is bf16
+            for (int e = 0; e < 4; ++e) out[e] = A16::pack(y[2 * e], y[2 * e + 1]);     // RoPE output likewise
             return out;
         };
         if (does_q && sg == 0) sm_q[wave * LPR + c] = norm_rope(raw0, wq_raw);
@@ -480,10 +494,10 @@ __global__ __launch_bounds__(kBlock, 1) void attn_step_kernel(const AttnStepArgs
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e)   // a row past the position: its p is 0, but 0 * garbage must stay 0
-                vf[u][e] = live ? f32x2{bf16lo(vp[e]), bf16hi(vp[e])} : f32x2{0.f, 0.f};
+                vf[u][e] = live ? f32x2{A16::lo(vp[e]), A16::hi(vp[e])} : f32x2{0.f, 0.f};
 #pragma unroll
             for (int g = 0; g < GT; ++g) {
-                const float d = group_sum<LPR>(dot8_bf16(q[g], kp)) * a.scale;
+                const float d = group_sum<LPR>(dot8_16<F16>(q[g], kp)) * a.scale;
                 s[u][g] = live ? d : -INFINITY;
             }
         }
@@ -593,9 +607,9 @@ __global__ __launch_bounds__(kBlock, 1) void attn_step_kernel(const AttnStepArgs
         const int dim = wave * 64 + lane;
         const int nb = (a.nsplit + 15) / 16;
         uint64_t* xg_head = OPROJ ? a.xg + (size_t)head * (D / 2) : nullptr;
-        if (nb <= 1) gather_head<D, 1>(a, base, n_active, tag, lane, dim, out, xg_head);
-        else if (nb == 2) gather_head<D, 2>(a, base, n_active, tag, lane, dim, out, xg_head);
-        else gather_head<D, 3>(a, base, n_active, tag, lane, dim, out, xg_head);
+        if (nb <= 1) gather_head<D, 1, F16>(a, base, n_active, tag, lane, dim, out, xg_head);
+        else if (nb == 2) gather_head<D, 2, F16>(a, base, n_active, tag, lane, dim, out, xg_head);
+        else gather_head<D, 3, F16>(a, base, n_active, tag, lane, dim, out, xg_head);
         if (TRACE && threadIdx.x == 0) tr[4] = wall_clock64();
     }
 
@@ -688,6 +702,19 @@ int launch_attn_step(const AttnStepArgs& a_in, int D, hipStream_t s) {
         if (qo) {                                                                                                        \
             if (nvw == 4) OMX_ATTN_LAUNCH(DD, GG, false, 104)                                                            \
             OMX_ATTN_LAUNCH(DD, GG, false, 108)                                                                          \
+        }                                                                                                                \
+        if (a.f16) {   /* a float16 checkpoint's model: float16 q / k / v, cache and output; D = 128, no O projection in the launch */ \
+            if constexpr (DD == 128) {                                                                                   \
+                if (nvw == 0) {                                                                                          \
+                    if (shmem > 48 * 1024)                                                                               \
+                        OMX_HIP_CHECK(hipFuncSetAttribute((const void*)attn_step_kernel<DD, GG, false, 0, true>,        \
+                                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));      \
+                    OMX_LAUNCH_TIMED((attn_step_kernel<DD, GG, false, 0, true>), grid, block, shmem, s, a);              \
+                    OMX_LAUNCH_CHECK();                                                                                  \
+                    return 0;                                                                                            \
+                }                                                                                                        \
+            }                                                                                                            \
+            return set_error("decode attention: float16 models take head_dim 128 without the O projection in the launch"); \
         }                                                                                                                \
         if (nvw == 0) OMX_ATTN_LAUNCH(DD, GG, false, 0)                                                                  \
         if (nvw == 1) OMX_ATTN_LAUNCH(DD, GG, false, 1)                                                                  \

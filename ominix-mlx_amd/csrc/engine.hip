@@ -33,6 +33,7 @@
 #include "quant.hpp"
 #include "launch_timing.hpp"
 #include "aql_step.hpp"
+#include "act16.hpp"
 #include "peer.hpp"
 #include "step_engine.hpp"
 #include <hip/hip_fp16.h>
@@ -84,7 +85,10 @@ __global__ __launch_bounds__(256) void qembed_kernel(bf16_t* __restrict__ h, con
         const float sc = scales_f16 ? __half2float(__ushort_as_half(sb16)) : bf16_to_f32(sb16);
         const float bi = scales_f16 ? __half2float(__ushort_as_half(bb16)) : bf16_to_f32(bb16);
 #pragma unroll
-        for (int e = 0; e < EPW; ++e) h[i * EPW + e] = f32_to_bf16((float)((wd >> (e * BITS)) & ((1u << BITS) - 1u)) * sc + bi);
+        for (int e = 0; e < EPW; ++e) {   // (dequantise: the result has the scales' dtype, quantized.rs:192-203)
+            const float v = (float)((wd >> (e * BITS)) & ((1u << BITS) - 1u)) * sc + bi;
+            h[i * EPW + e] = scales_f16 ? Act16<true>::bits(v) : f32_to_bf16(v);
+        }
     }
 }
 
@@ -440,6 +444,7 @@ int enqueue_attention(omx_qwen3 m, int l, hipStream_t s, const bf16_t* resid = n
         a.out = m->attn_out;
         a.abort_flag = m->wait_abort;
         a.trace = m->attn_trace ? m->attn_trace + (size_t)l * m->attn_nsplit * m->Hkv * 8 : nullptr;
+        a.f16 = c.quant_scales_f16;   // a float16 checkpoint runs in float16 end to end
         if (resid && (out || out_f32)) {
             a.o_resid = resid; a.o_out = out; a.o_out_f32 = out_f32; a.o_rows = c.hidden_size; a.xg = m->attn_xg;
             if (c.quant_bits) {
@@ -489,10 +494,10 @@ int enqueue_step_quant(omx_qwen3 m, bool with_head) {
             bf16_t* t = h; h = hn; hn = t;
         }
         if (c.num_experts > 0) {   // [RMSNorm + router] [selection] [RMSNorm + expert gate/up + SwiGLU] [expert down] [sum + residual]
-            if (omx_moe_block_forward_q(hn, h, h, L.post_ln, c.rms_norm_eps, m->moe_xn, Q.moe_router.w, Q.moe_router.scales,
-                                        Q.moe_router.biases, Q.moe_g.w, Q.moe_g.scales, Q.moe_g.biases, Q.moe_u.w, Q.moe_u.scales,
-                                        Q.moe_u.biases, Q.moe_d.w, Q.moe_d.scales, Q.moe_d.biases, 1, hd, c.moe_intermediate_size,
-                                        c.num_experts, c.num_experts_per_tok, c.moe_mode, c.norm_topk_prob, group, bits, s))
+            if (omx_moe_block_forward_q_ex(hn, h, h, L.post_ln, c.rms_norm_eps, m->moe_xn, Q.moe_router.w, Q.moe_router.scales,
+                                           Q.moe_router.biases, Q.moe_g.w, Q.moe_g.scales, Q.moe_g.biases, Q.moe_u.w, Q.moe_u.scales,
+                                           Q.moe_u.biases, Q.moe_d.w, Q.moe_d.scales, Q.moe_d.biases, 1, hd, c.moe_intermediate_size,
+                                           c.num_experts, c.num_experts_per_tok, c.moe_mode, c.norm_topk_prob, group, bits, sf16 ? 1 : 0, s))
                 return 1;
             bf16_t* t = h; h = hn; hn = t;
             continue;
@@ -1223,8 +1228,8 @@ int omx_qwen3_create(omx_qwen3* out, const omx_qwen3_config* cfg) {
     if (m->cfg.quant_bits && m->cfg.quant_group == 0) m->cfg.quant_group = 64;     // nn/quantized.rs:330-333
     OMX_REQUIRE(!m->cfg.quant_bits || m->cfg.quant_group == 32 || m->cfg.quant_group == 64 || m->cfg.quant_group == 128,
                 "InvalidConfig: quantization group_size %d (32, 64, 128)", m->cfg.quant_group);
-    OMX_REQUIRE(!m->cfg.quant_scales_f16 || (m->cfg.quant_bits && m->cfg.num_experts == 0 && m->cfg.tp_size <= 1),
-                "InvalidConfig: float16 scales / biases are taken by single-rank quantized dense decoders only");
+    OMX_REQUIRE(!m->cfg.quant_scales_f16 || (m->cfg.quant_bits && m->cfg.tp_size <= 1 && m->cfg.ep_size <= 1 && m->cfg.head_dim == 128),
+                "InvalidConfig: a float16 checkpoint (quantization scales_dtype float16) runs as a single-rank packed model with head_dim 128 (dense or sparse-MoE)");
     m->H = c.num_attention_heads / c.tp_size;
     m->Hkv = c.num_key_value_heads >= c.tp_size ? c.num_key_value_heads / c.tp_size : 1;
     m->I = c.intermediate_size / c.tp_size;
@@ -1566,6 +1571,7 @@ int omx_qwen3_set_comm(omx_qwen3 m, void* comm, void* allreduce_fn) {
 int omx_qwen3_set_sampler(omx_qwen3 m, float temperature, uint64_t seed) {
     OMX_REQUIRE(m, "omx_qwen3_set_sampler: null model");
     OMX_REQUIRE(temperature >= 0.f && temperature == temperature, "omx_qwen3_set_sampler: temperature %f must be >= 0", (double)temperature);
+    OMX_REQUIRE(temperature == 0.f || !m->cfg.quant_scales_f16, "omx_qwen3_set_sampler: float16 models decode greedily (the noise kernel reads bfloat16 logits)");
     if (!m->rng && dev_alloc(m, &m->rng, 4)) return 1;
     if (omx_random_key(m->rng, seed, (omx_stream)m->stream)) return 1;
     OMX_HIP_CHECK(hipStreamSynchronize(m->stream));
@@ -1648,7 +1654,7 @@ int omx_qwen3_prefill(omx_qwen3 m, const uint32_t* prompt, int n_prompt, uint32_
     const char* serial_env = getenv("OMX_PREFILL_SERIAL");
     // tensor-parallel engines run the batched matrix-core prefill on their shards with two all-reduces per layer, expert-parallel ones
     // with one all-reduce of the MoE block's [T, hidden] partial per layer (round 3; token-serial before)
-    const bool serial = (serial_env && serial_env[0] == '1') || n_prompt < 2 || (m->cfg.num_experts > 0 && m->cfg.tp_size > 1);   // (expert tensor parallel: the decode form only)
+    const bool serial = (serial_env && serial_env[0] == '1') || n_prompt < 2 || (m->cfg.num_experts > 0 && m->cfg.tp_size > 1) || m->cfg.quant_scales_f16;   // (expert tensor parallel, float16 models: the decode form only)
     if (prepare_step(m, serial ? off : off + n_prompt - 1)) return 1;   // the first step this call will run (graphs are per context bucket)
     OMX_HIP_CHECK(hipMemcpyAsync(m->prompt_dev, prompt, (size_t)n_prompt * 4, hipMemcpyHostToDevice, m->stream));
     StepState st;

@@ -828,8 +828,10 @@ int mlx_quantized_matmul(mlx_array* res, const mlx_array x, const mlx_array w, c
     OMX_REQUIRE(cs.a->size() == (size_t)N * (K / g), "mlx_quantized_matmul: scales shape does not match w / group_size");
     std::vector<int> shape(cx.a->shape.begin(), cx.a->shape.end() - 1);
     shape.push_back(N);
-    // activations are bf16 here; the scales may be a float16 checkpoint's (MLX itself would promote bf16 x f16 to float32: INTEGRATION.md)
-    OMX_REQUIRE(cx.a->dt == MLX_BFLOAT16, "mlx_quantized_matmul: bf16 activations only (scales / biases may be bf16 or float16)");
+    // x, scales and biases share one dtype: bfloat16, or float16 (a float16 checkpoint runs in float16 end to end, quantized.rs:361-385);
+    // a mix is MLX's promotion to float32, which this path does not implement
+    OMX_REQUIRE((cx.a->dt == MLX_BFLOAT16 || cx.a->dt == MLX_FLOAT16) && cx.a->dt == cs.a->dt,
+                "mlx_quantized_matmul: x and scales / biases must both be bfloat16 or both float16");
     NEW_OR_FAIL(r, shape, cx.a->dt);
     if (omx_quantized_matmul(r->ptr(), cx.a->ptr(), cw.a->ptr(), cs.a->ptr(), biases.ctx ? cb.a->ptr() : nullptr,
                              K ? (int)(cx.a->size() / K) : 0, N, K, g, b, to_omx(cs.a->dt), g_stream)) { delete r; return 1; }
@@ -855,7 +857,8 @@ int mlx_gather_qmm(mlx_array* res, const mlx_array x, const mlx_array w, const m
     std::vector<int> shape = ci.a->shape;
     shape.push_back(1);
     shape.push_back(N);
-    OMX_REQUIRE(cx.a->dt == MLX_BFLOAT16, "mlx_gather_qmm: bf16 activations only (scales / biases may be bf16 or float16)");
+    OMX_REQUIRE((cx.a->dt == MLX_BFLOAT16 || cx.a->dt == MLX_FLOAT16) && cx.a->dt == cs.a->dt,
+                "mlx_gather_qmm: x and scales / biases must both be bfloat16 or both float16");
     NEW_OR_FAIL(r, shape, cx.a->dt);
     if (omx_gather_qmm(r->ptr(), cx.a->ptr(), cw.a->ptr(), cs.a->ptr(), biases.ctx ? cb.a->ptr() : nullptr, (const uint32_t*)ci.a->ptr(),
                        (int)n, (int)(n / n_x), N, K, E, g, b, to_omx(cs.a->dt), g_stream)) { delete r; return 1; }

@@ -152,13 +152,14 @@ __global__ __launch_bounds__(kRouterThreads) void moe_router_kernel(const bf16_t
 }
 
 // logits [n_tokens, E] already computed (quantised router: qgemv on the packed gate): selection only, one wave per token
+template <bool F16 = false>
 __global__ __launch_bounds__(64) void moe_route_logits_kernel(const bf16_t* __restrict__ logits, int E, int k, int mode, int renorm,
                                                               uint32_t* __restrict__ inds, bf16_t* __restrict__ scores) {
     __shared__ float s_logit[kMaxExperts];
     const int t = blockIdx.x, lane = threadIdx.x;
-    for (int e = lane; e < E; e += 64) s_logit[e] = bf16_to_f32(logits[(size_t)t * E + e]);
+    for (int e = lane; e < E; e += 64) s_logit[e] = Act16<F16>::val(logits[(size_t)t * E + e]);
     __syncthreads();
-    route_from_logits(s_logit, t, lane, E, k, mode, renorm, inds, scores);
+    route_from_logits<F16>(s_logit, t, lane, E, k, mode, renorm, inds, scores);
 }
 
 // counting sort of the N*k (token, slot) pairs by expert + tile table of the grouped GEMM (single block)
@@ -226,32 +227,34 @@ int grouped_glu_256(bf16_t* ybuf, bf16_t* gbuf, const bf16_t* x, const bf16_t* w
 }
 
 // out[t] = bf16( sum_j bf16( y[pos(t,j)] * score[t,j] ) )     (model.rs:304-307)
+template <bool F16 = false>
 __global__ __launch_bounds__(256) void moe_combine_kernel(bf16_t* __restrict__ out, const bf16_t* __restrict__ y,
                                                           const bf16_t* __restrict__ scores,
                                                           const uint32_t* __restrict__ pos_of_slot, int h, int k,
                                                           const bf16_t* __restrict__ resid = nullptr) {
+    typedef Act16<F16> A16;
     const int t = blockIdx.x;
     for (int i = threadIdx.x * 8; i < h; i += 256 * 8) {
         float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         for (int j = 0; j < k; ++j) {
             const size_t slot = (size_t)t * k + j;
             const size_t p = pos_of_slot ? pos_of_slot[slot] : slot;
-            const float sc = bf16_to_f32(scores[slot]);
+            const float sc = A16::val(scores[slot]);
             const u32x4 v = *reinterpret_cast<const u32x4*>(y + p * h + i);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                acc[2 * q] += round_bf16(bf16lo(v[q]) * sc);
-                acc[2 * q + 1] += round_bf16(bf16hi(v[q]) * sc);
+                acc[2 * q] += A16::rnd(A16::lo(v[q]) * sc);
+                acc[2 * q + 1] += A16::rnd(A16::hi(v[q]) * sc);
             }
         }
         u32x4 o;
         if (resid) {   // decoder block: h + moe(h_normed), the block output rounded first (model.rs:343-344)
             const u32x4 r = *reinterpret_cast<const u32x4*>(resid + (size_t)t * h + i);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) o[q] = pack_bf16(bf16lo(r[q]) + round_bf16(acc[2 * q]), bf16hi(r[q]) + round_bf16(acc[2 * q + 1]));
+            for (int q = 0; q < 4; ++q) o[q] = A16::pack(A16::lo(r[q]) + A16::rnd(acc[2 * q]), A16::hi(r[q]) + A16::rnd(acc[2 * q + 1]));
         } else {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) o[q] = pack_bf16(acc[2 * q], acc[2 * q + 1]);
+            for (int q = 0; q < 4; ++q) o[q] = A16::pack(acc[2 * q], acc[2 * q + 1]);
         }
         *reinterpret_cast<u32x4*>(out + (size_t)t * h + i) = o;
     }
@@ -399,7 +402,7 @@ static int moe_forward_impl(void* out, const void* x, const void* gate_w, const 
         d.n_batch = slots; d.x_div = 1; d.w_sel = inds;
         d.w_estride = (size_t)hidden * inter * q->bits / 32; d.s_estride = (size_t)hidden * (inter / q->group);
         if (launch_qgemv(d, q->bits, PRO_NONE, EPI_STORE, s)) return 1;
-        moe_combine_kernel<<<n_tokens, 256, 0, s>>>((bf16_t*)out, ybuf, scores, nullptr, hidden, top_k, resid);
+        moe_combine_kernel<false><<<n_tokens, 256, 0, s>>>((bf16_t*)out, ybuf, scores, nullptr, hidden, top_k, resid);
         OMX_LAUNCH_CHECK();
         if (inds_out) OMX_HIP_CHECK(hipMemcpyAsync(inds_out, inds, (size_t)slots * 4, hipMemcpyDeviceToDevice, s));
         if (scores_out) OMX_HIP_CHECK(hipMemcpyAsync(scores_out, scores, (size_t)slots * 2, hipMemcpyDeviceToDevice, s));
@@ -450,7 +453,7 @@ static int moe_forward_impl(void* out, const void* x, const void* gate_w, const 
             return 0;
         }
         if (launch_gemv(d, PRO_NONE, EPI_STORE, s)) return 1;
-        moe_combine_kernel<<<n_tokens, 256, 0, s>>>((bf16_t*)out, ybuf, scores, nullptr, hidden, top_k, resid);
+        moe_combine_kernel<false><<<n_tokens, 256, 0, s>>>((bf16_t*)out, ybuf, scores, nullptr, hidden, top_k, resid);
         OMX_LAUNCH_CHECK();
     } else {
         const int tile_rows = moe_tile_rows(slots, n_experts, hidden, inter);
@@ -472,7 +475,7 @@ static int moe_forward_impl(void* out, const void* x, const void* gate_w, const 
         g.w_estride = (size_t)hidden * inter;
         if (launch_gemm_bf16_grouped(ybuf, gbuf, (const bf16_t*)w_down, slots, hidden, inter, g, max_tiles, s)) return 1;
         }
-        moe_combine_kernel<<<n_tokens, 256, 0, s>>>((bf16_t*)out, ybuf, scores, pos_of_slot, hidden, top_k, resid);
+        moe_combine_kernel<false><<<n_tokens, 256, 0, s>>>((bf16_t*)out, ybuf, scores, pos_of_slot, hidden, top_k, resid);
         OMX_LAUNCH_CHECK();
     }
     if (inds_out) OMX_HIP_CHECK(hipMemcpyAsync(inds_out, inds, (size_t)slots * 4, hipMemcpyDeviceToDevice, s));
@@ -518,13 +521,33 @@ extern "C" int omx_moe_block_partials(float* partials, const void* x, const void
  * QuantizedSwitchLinear x3).  Few tokens (<= 32 routed slots): router logits = quantised GEMV on the packed gate with the
  * RMSNorm prologue, selection, expert GEMVs on the packed stacks (RMSNorm prologue again: x is raw), weighted sum + residual.
  * More tokens: RMSNorm rows, router and experts dequantised once (what MLX's qmm does per tile), grouped GEMM route. */
+extern "C" int omx_moe_block_forward_q_ex(void* out, const void* resid, const void* x, const void* norm_w, float eps, void* xn,
+                                          const void* q_router, const void* s_router, const void* b_router, const void* q_gate,
+                                          const void* s_gate, const void* b_gate, const void* q_up, const void* s_up, const void* b_up,
+                                          const void* q_down, const void* s_down, const void* b_down, int n_tokens, int hidden, int inter,
+                                          int n_experts, int top_k, int mode, int norm_topk_prob, int group_size, int bits, int f16,
+                                          omx_stream stream);
 extern "C" int omx_moe_block_forward_q(void* out, const void* resid, const void* x, const void* norm_w, float eps, void* xn,
                                        const void* q_router, const void* s_router, const void* b_router, const void* q_gate,
                                        const void* s_gate, const void* b_gate, const void* q_up, const void* s_up, const void* b_up,
                                        const void* q_down, const void* s_down, const void* b_down, int n_tokens, int hidden, int inter,
                                        int n_experts, int top_k, int mode, int norm_topk_prob, int group_size, int bits,
                                        omx_stream stream) {
+    return omx_moe_block_forward_q_ex(out, resid, x, norm_w, eps, xn, q_router, s_router, b_router, q_gate, s_gate, b_gate, q_up, s_up, b_up,
+                                      q_down, s_down, b_down, n_tokens, hidden, inter, n_experts, top_k, mode, norm_topk_prob, group_size, bits, 0,
+                                      stream);
+}
+/* ... f16 != 0: a float16 checkpoint (the reference's own Mixtral format: 4-bit triplets, float16 in the MLX community builds) -- x, norm
+ * weights, scales / biases and the result are float16 and every rounding point is float16, like MLX runs it; few tokens only
+ * (<= 32 routed slots: the decode step, through which a float16 model also runs its prompt) */
+extern "C" int omx_moe_block_forward_q_ex(void* out, const void* resid, const void* x, const void* norm_w, float eps, void* xn,
+                                          const void* q_router, const void* s_router, const void* b_router, const void* q_gate,
+                                          const void* s_gate, const void* b_gate, const void* q_up, const void* s_up, const void* b_up,
+                                          const void* q_down, const void* s_down, const void* b_down, int n_tokens, int hidden, int inter,
+                                          int n_experts, int top_k, int mode, int norm_topk_prob, int group_size, int bits, int f16,
+                                          omx_stream stream) {
     using namespace omx;
+    OMX_REQUIRE(!f16 || n_tokens * top_k <= 32, "omx_moe_block_forward_q: a float16 model runs at most 32 routed slots per call (%d tokens)", n_tokens);
     OMX_REQUIRE(out && resid && x && norm_w && xn && q_router && s_router && b_router && q_gate && s_gate && b_gate && q_up && s_up &&
                     b_up && q_down && s_down && b_down, "omx_moe_block_forward_q: null tensor");
     OMX_REQUIRE(bits == 4 || bits == 8, "omx_moe_block_forward_q: bits=%d (4 or 8)", bits);
@@ -576,9 +599,10 @@ extern "C" int omx_moe_block_forward_q(void* out, const void* resid, const void*
         a.m[0] = QMat{(const uint32_t*)q_router, (const bf16_t*)s_router, (const bf16_t*)b_router, n_experts};
         a.N = n_experts; a.K = hidden; a.group = group_size;
         a.x = (const bf16_t*)x; a.norm_w = (const bf16_t*)norm_w; a.eps = eps; a.out = logits;
-        a.n_batch = n_tokens; a.x_div = 1;
+        a.n_batch = n_tokens; a.x_div = 1; a.scales_f16 = f16;
         if (launch_qgemv(a, bits, PRO_RMSNORM, EPI_STORE, s)) return 1;
-        moe_route_logits_kernel<<<n_tokens, 64, 0, s>>>(logits, n_experts, top_k, mode, norm_topk_prob, inds, scores);
+        if (f16) moe_route_logits_kernel<true><<<n_tokens, 64, 0, s>>>(logits, n_experts, top_k, mode, norm_topk_prob, inds, scores);
+        else moe_route_logits_kernel<false><<<n_tokens, 64, 0, s>>>(logits, n_experts, top_k, mode, norm_topk_prob, inds, scores);
         OMX_LAUNCH_CHECK();
     }
     QGemvArgs a = {};
@@ -586,15 +610,16 @@ extern "C" int omx_moe_block_forward_q(void* out, const void* resid, const void*
     a.x = (const bf16_t*)x; a.norm_w = (const bf16_t*)norm_w; a.eps = eps; a.out = gbuf;
     a.n_batch = slots; a.x_div = top_k; a.w_sel = inds;
     a.w_estride = (size_t)inter * hidden * bits / 32; a.s_estride = (size_t)inter * (hidden / group_size);
-    a.swiglu_single_round = 1;
+    a.swiglu_single_round = 1; a.scales_f16 = f16;
     if (launch_qgemv(a, bits, PRO_RMSNORM, EPI_SWIGLU, s)) return 1;
     QGemvArgs d = {};
     d.m[0] = q.down; d.N = hidden; d.K = inter; d.group = group_size;
     d.x = gbuf; d.out = ybuf;
-    d.n_batch = slots; d.x_div = 1; d.w_sel = inds;
+    d.n_batch = slots; d.x_div = 1; d.w_sel = inds; d.scales_f16 = f16;
     d.w_estride = (size_t)hidden * inter * bits / 32; d.s_estride = (size_t)hidden * (inter / group_size);
     if (launch_qgemv(d, bits, PRO_NONE, EPI_STORE, s)) return 1;
-    moe_combine_kernel<<<n_tokens, 256, 0, s>>>((bf16_t*)out, ybuf, scores, nullptr, hidden, top_k, (const bf16_t*)resid);
+    if (f16) moe_combine_kernel<true><<<n_tokens, 256, 0, s>>>((bf16_t*)out, ybuf, scores, nullptr, hidden, top_k, (const bf16_t*)resid);
+    else moe_combine_kernel<false><<<n_tokens, 256, 0, s>>>((bf16_t*)out, ybuf, scores, nullptr, hidden, top_k, (const bf16_t*)resid);
     OMX_LAUNCH_CHECK();
     return 0;
 }
@@ -869,7 +894,7 @@ extern "C" int omx_moe_combine(void* out, const void* y_slots, const void* score
     OMX_REQUIRE(out && y_slots && scores, "omx_moe_combine: null tensor");
     OMX_REQUIRE(hidden > 0 && hidden % 8 == 0 && top_k >= 1, "omx_moe_combine: bad shape");
     if (n_tokens <= 0) return 0;
-    moe_combine_kernel<<<n_tokens, 256, 0, (hipStream_t)stream>>>((bf16_t*)out, (const bf16_t*)y_slots, (const bf16_t*)scores,
+    moe_combine_kernel<false><<<n_tokens, 256, 0, (hipStream_t)stream>>>((bf16_t*)out, (const bf16_t*)y_slots, (const bf16_t*)scores,
                                                                  nullptr, hidden, top_k);
     OMX_LAUNCH_CHECK();
     return 0;

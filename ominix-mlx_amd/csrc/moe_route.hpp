@@ -1,6 +1,7 @@
 // Router selection shared by the router kernel (moe.hip) and the expert gate/up GEMV that routes in its own prologue (gemv.hip).
 #pragma once
 #include "common.hpp"
+#include "act16.hpp"
 
 namespace omx {
 
@@ -10,8 +11,11 @@ constexpr int kMaxTopK = 8;
 // one block per token: logits[e] = bf16(x . Wg[e]) ; mode 0: top-k of logits, softmax over the selected
 // (precise) ; mode 1: softmax over all (precise, rounded to bf16), top-k, optional renormalisation
 // softmax / top-k / renormalisation of one token's router logits by ONE wave (experts spread over the lanes)
+// F16: a float16 model -- the scores are rounded to (and stored as) float16 where the bfloat16 model rounds to bfloat16
+template <bool F16 = false>
 __device__ __forceinline__ void route_from_logits(const float* s_logit, int t, int lane, int E, int k, int mode, int renorm,
                                                   uint32_t* __restrict__ inds, bf16_t* __restrict__ scores) {
+    typedef Act16<F16> A16;
     constexpr int PER = kMaxExperts / 64;
     float v[PER];
     bool taken[PER];
@@ -31,7 +35,7 @@ __device__ __forceinline__ void route_from_logits(const float* s_logit, int t, i
         for (int u = 0; u < PER; ++u) sum += (lane + 64 * u < E) ? expf(v[u] - mx) : 0.f;
         sum = wave_sum(sum);
 #pragma unroll
-        for (int u = 0; u < PER; ++u) v[u] = (lane + 64 * u < E) ? round_bf16(expf(v[u] - mx) / sum) : -INFINITY;
+        for (int u = 0; u < PER; ++u) v[u] = (lane + 64 * u < E) ? A16::rnd(expf(v[u] - mx) / sum) : -INFINITY;
     }
     uint32_t sel[kMaxTopK];
     float selv[kMaxTopK];
@@ -62,17 +66,17 @@ __device__ __forceinline__ void route_from_logits(const float* s_logit, int t, i
         float mx = selv[0], sum = 0.f;
         for (int j = 1; j < k; ++j) mx = fmaxf(mx, selv[j]);
         for (int j = 0; j < k; ++j) sum += expf(selv[j] - mx);
-        for (int j = 0; j < k; ++j) selv[j] = round_bf16(expf(selv[j] - mx) / sum);
+        for (int j = 0; j < k; ++j) selv[j] = A16::rnd(expf(selv[j] - mx) / sum);
     } else if (renorm && k > 1) {
         float sum = 0.f;
         for (int j = 0; j < k; ++j) sum += selv[j];
-        sum = round_bf16(sum);
-        for (int j = 0; j < k; ++j) selv[j] = round_bf16(selv[j] / sum);
+        sum = A16::rnd(sum);
+        for (int j = 0; j < k; ++j) selv[j] = A16::rnd(selv[j] / sum);
     }
     if (lane == 0) {
         for (int j = 0; j < k; ++j) {
             inds[(size_t)t * k + j] = sel[j];
-            scores[(size_t)t * k + j] = f32_to_bf16(selv[j]);
+            scores[(size_t)t * k + j] = A16::bits(selv[j]);
         }
     }
 }

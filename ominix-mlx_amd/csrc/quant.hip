@@ -20,6 +20,7 @@
 #include <unordered_map>
 
 #include "quant.hpp"
+#include "act16.hpp"
 #include "launch_timing.hpp"
 #include "vec.hpp"
 #include "workspace.hpp"
@@ -138,6 +139,7 @@ __device__ __forceinline__ uint64_t qargmax_key(float v, uint32_t idx) {
 // SB: scales and biases come interleaved from QMat::sb (one load per row and step instead of two)
 template <int BITS, int W, int PRO, int EPI, int RB, bool SB = false, bool F16S = false>
 __global__ __launch_bounds__(256) void qgemv_kernel(const QGemvArgs a) {
+    typedef Act16<F16S> A16;                                // activations / outputs: bfloat16, or float16 for a float16 checkpoint (F16S)
     constexpr int EPW = 32 / BITS, EPL = W * EPW;          // elements per lane per step
     constexpr int LR = (EPI == EPI_SWIGLU) ? 2 : 1;         // physical rows per logical row
     constexpr int NR = RB * LR;
@@ -219,7 +221,6 @@ __global__ __launch_bounds__(256) void qgemv_kernel(const QGemvArgs a) {
     float acc[NR];
 #pragma unroll
     for (int r = 0; r < NR; ++r) acc[r] = 0.f;
-    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
     auto consume = [&](const Unit& u, int f) {
         const int r0 = row_begin + (f / steps) * RB, st = f % steps;
         const int chunk = st * 64 + lane;
@@ -246,22 +247,22 @@ __global__ __launch_bounds__(256) void qgemv_kernel(const QGemvArgs a) {
                     // the same masked word -- so a pair is (q0, q2), (q4, q6) of the even nibbles or (q1, q3), (q5, q7) of the
                     // odd ones, and the activations were stored in LDS in that order (put() below).
                     const uint32_t lo = wdw & 0x0F0F0F0Fu, hi = (wdw >> 4) & 0x0F0F0F0Fu;
-                    const uint32_t c43 = 0x43434343u;
+                    const uint32_t c43 = A16::kMagicBytes;   // bf16: 0x4300 | q = 128 + q; float16: 0x6400 | q = 1024 + q
                     const uint32_t q0 = __builtin_amdgcn_perm(c43, lo, 0x04010400u), q1 = __builtin_amdgcn_perm(c43, lo, 0x04030402u);
                     const uint32_t q2 = __builtin_amdgcn_perm(c43, hi, 0x04010400u), q3 = __builtin_amdgcn_perm(c43, hi, 0x04030402u);
-                    d = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, xp[wi * 4 + 0]), __builtin_bit_cast(bf16x2_t, q0), d, false);
-                    d = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, xp[wi * 4 + 1]), __builtin_bit_cast(bf16x2_t, q1), d, false);
-                    d = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, xp[wi * 4 + 2]), __builtin_bit_cast(bf16x2_t, q2), d, false);
-                    d = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, xp[wi * 4 + 3]), __builtin_bit_cast(bf16x2_t, q3), d, false);
+                    d = A16::dot2(xp[wi * 4 + 0], A16::unmagic(q0), d);
+                    d = A16::dot2(xp[wi * 4 + 1], A16::unmagic(q1), d);
+                    d = A16::dot2(xp[wi * 4 + 2], A16::unmagic(q2), d);
+                    d = A16::dot2(xp[wi * 4 + 3], A16::unmagic(q3), d);
                 } else {
 #pragma unroll
                     for (int b = 0; b < 4; ++b) {
                         const uint32_t xw = xp[wi * 2 + (b >> 1)];
-                        d = fmaf((b & 1) ? bf16hi(xw) : bf16lo(xw), (float)((wdw >> (8 * b)) & 0xFFu), d);
+                        d = fmaf((b & 1) ? A16::hi(xw) : A16::lo(xw), (float)((wdw >> (8 * b)) & 0xFFu), d);
                     }
                 }
             }
-            if (BITS == 4) bia = fmaf(-128.0f, scl, bia);
+            if (BITS == 4) bia = fmaf(-A16::kMagic, scl, bia);
             acc[r] = fmaf(scl, d, acc[r]);
             acc[r] = fmaf(bia, xsm, acc[r]);
         }
@@ -275,22 +276,22 @@ __global__ __launch_bounds__(256) void qgemv_kernel(const QGemvArgs a) {
                     if (row >= row_end) break;
                     const float v0 = acc[LR * r], v1 = acc[LR * r + (LR - 1)];
                     if (EPI == EPI_STORE) {
-                        out[row] = f32_to_bf16(v0);
+                        out[row] = A16::bits(v0);
                     } else if (EPI == EPI_RESIDUAL) {
-                        out[row] = f32_to_bf16(bf16_to_f32(a.resid[row]) + round_bf16(v0));
+                        out[row] = A16::bits(A16::val(a.resid[row]) + A16::rnd(v0));
                     } else if (EPI == EPI_SWIGLU) {
                         // nn::silu(gate) * up, every primitive's result held in bf16 (qwen3-mlx/src/model.rs:264-265)
-                        const float g = round_bf16(v0), uu = round_bf16(v1);
+                        const float g = A16::rnd(v0), uu = A16::rnd(v1);
                         if (a.swiglu_single_round) {
-                            out[row] = f32_to_bf16(g / (1.0f + expf(-g)) * uu);   // mlx_rs_core::fused_swiglu(up, gate)
+                            out[row] = A16::bits(g / (1.0f + expf(-g)) * uu);   // mlx_rs_core::fused_swiglu(up, gate)
                         } else {
-                            const float sg = round_bf16(1.0f / (1.0f + expf(-g)));
-                            out[row] = f32_to_bf16(round_bf16(g * sg) * uu);
+                            const float sg = A16::rnd(1.0f / (1.0f + expf(-g)));
+                            out[row] = A16::bits(A16::rnd(g * sg) * uu);
                         }
                     } else if (EPI == EPI_ARGMAX) {
-                        const bf16_t lb = f32_to_bf16(v0);
+                        const bf16_t lb = A16::bits(v0);
                         out[row] = lb;
-                        const uint64_t key = qargmax_key(bf16_to_f32(lb), (uint32_t)row);
+                        const uint64_t key = qargmax_key(A16::val(lb), (uint32_t)row);
                         best = key > best ? key : best;
                     }
                 }
@@ -319,7 +320,7 @@ __global__ __launch_bounds__(256) void qgemv_kernel(const QGemvArgs a) {
         }
         float sv = 0.f;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) sv += bf16lo(o[q]) + bf16hi(o[q]);
+        for (int q = 0; q < 4; ++q) sv += A16::lo(o[q]) + A16::hi(o[q]);
         if (EPL >= 16) sv += dpp_f<kDppXor1>(sv);
         if (EPL >= 32) sv += dpp_f<kDppXor2>(sv);
         if (((i >> 3) & (EPL / 8 - 1)) == 0) xsum[i / EPL] = sv;
@@ -342,8 +343,8 @@ __global__ __launch_bounds__(256) void qgemv_kernel(const QGemvArgs a) {
             if (threadIdx.x * 8 + it * 2048 < a.K) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    ss = fmaf(bf16lo(raw[it][q]), bf16lo(raw[it][q]), ss);
-                    ss = fmaf(bf16hi(raw[it][q]), bf16hi(raw[it][q]), ss);
+                    ss = fmaf(A16::lo(raw[it][q]), A16::lo(raw[it][q]), ss);
+                    ss = fmaf(A16::hi(raw[it][q]), A16::hi(raw[it][q]), ss);
                 }
             }
         }
@@ -356,7 +357,7 @@ __global__ __launch_bounds__(256) void qgemv_kernel(const QGemvArgs a) {
                 u32x4 o;
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
-                    o[q] = pack_bf16(bf16lo(raw[it][q]) * rstd * bf16lo(nwv[it][q]), bf16hi(raw[it][q]) * rstd * bf16hi(nwv[it][q]));
+                    o[q] = A16::pack(A16::lo(raw[it][q]) * rstd * A16::lo(nwv[it][q]), A16::hi(raw[it][q]) * rstd * A16::hi(nwv[it][q]));
                 put(i, o);
             }
         }
@@ -366,8 +367,8 @@ __global__ __launch_bounds__(256) void qgemv_kernel(const QGemvArgs a) {
             const u32x4 raw = *reinterpret_cast<const u32x4*>(xg + i);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                ss = fmaf(bf16lo(raw[q]), bf16lo(raw[q]), ss);
-                ss = fmaf(bf16hi(raw[q]), bf16hi(raw[q]), ss);
+                ss = fmaf(A16::lo(raw[q]), A16::lo(raw[q]), ss);
+                ss = fmaf(A16::hi(raw[q]), A16::hi(raw[q]), ss);
             }
         }
         ss = block_sum<4>(ss, red);
@@ -378,7 +379,7 @@ __global__ __launch_bounds__(256) void qgemv_kernel(const QGemvArgs a) {
             u32x4 o;
 #pragma unroll
             for (int q = 0; q < 4; ++q)
-                o[q] = pack_bf16(bf16lo(raw[q]) * rstd * bf16lo(nw[q]), bf16hi(raw[q]) * rstd * bf16hi(nw[q]));
+                o[q] = A16::pack(A16::lo(raw[q]) * rstd * A16::lo(nw[q]), A16::hi(raw[q]) * rstd * A16::hi(nw[q]));
             put(i, o);
         }
     } else if (a.K <= 8 * 2048 && !a.rolled_stage) {
@@ -620,10 +621,29 @@ extern "C" int omx_dequantize(void* out, const void* packed, const void* scales,
 extern "C" int omx_quantized_matmul(void* out, const void* x, const void* packed, const void* scales, const void* biases, int M,
                                     int N, int K, int group_size, int bits, omx_dtype dtype, omx_stream stream) {
     OMX_REQUIRE(out && x && packed && scales, "omx_quantized_matmul: null tensor");
-    if (check_format("omx_quantized_matmul", K, group_size, bits, dtype, true)) return 1;   // (OMX_FLOAT16: the scales' dtype; x / out are bf16)
+    // dtype = the dtype of x, out, scales and biases alike: bfloat16, or float16 (a float16 MLX checkpoint runs in float16 end to end)
+    if (check_format("omx_quantized_matmul", K, group_size, bits, dtype, true)) return 1;
     OMX_REQUIRE(M >= 0 && N > 0, "omx_quantized_matmul: bad shape");
     if (M == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
+    if (dtype == OMX_FLOAT16 && !(M <= 16 && K % 512 == 0)) {
+        // many float16 rows: weights dequantised to float16 (one fma + one rounding per element, like MLX's qmm tile), both operands widened
+        // to float32 and multiplied on the f32 matrix cores (exact products of float16 values, f32 accumulation), one rounding to float16
+        void* ws = nullptr;
+        const size_t nw = (size_t)N * K, nx = (size_t)M * K, no = (size_t)M * N;
+        if (get_workspace(&ws, nw * 2 + (nw + nx + no) * 4 + 1024)) return 1;
+        char* p = (char*)ws;
+        f16_t* w16 = (f16_t*)p; p += (nw * 2 + 255) & ~(size_t)255;
+        float* w32 = (float*)p; p += nw * 4;
+        float* x32 = (float*)p; p += nx * 4;
+        float* o32 = (float*)p;
+        if (launch_dequantize_any(w16, (const uint32_t*)packed, scales, biases, N, K, group_size, bits, true, true, s)) return 1;
+        if (omx_cast(w32, OMX_FLOAT32, w16, OMX_FLOAT16, (int64_t)nw, stream) || omx_cast(x32, OMX_FLOAT32, x, OMX_FLOAT16, (int64_t)nx, stream)) return 1;
+        GemmF32 g = {};
+        g.a = x32; g.b = w32; g.out = o32; g.M = M; g.N = N; g.K = K; g.lda = K; g.ldb = K; g.ldc = N; g.batch = 1; g.alpha = 1.0f;
+        if (launch_gemm_f32(g, s)) return 1;
+        return omx_cast(out, OMX_FLOAT16, o32, OMX_FLOAT32, (int64_t)no, stream);
+    }
     if (M <= 16 && K % 512 == 0) {
         QGemvArgs a = {};
         a.m[0] = QMat{(const uint32_t*)packed, (const bf16_t*)scales, (const bf16_t*)biases, N};

@@ -209,8 +209,9 @@ class Model:
                     continue
             if self.cfg.quant_bits and name.endswith(".weight") and name[:-7] + ".scales" in weights and dt != np.uint32:
                 raise OmxError(f"{name}: a quantized weight must be packed uint32, found {dt}")
-            # quantized checkpoints: "<prefix>.weight" is packed uint32 (ops/quantization.rs:41-84), scales / biases bf16
-            t = Tensor.from_numpy(arr, "u32" if dt == np.uint32 else "bf16")
+            # quantized checkpoints: "<prefix>.weight" is packed uint32 (ops/quantization.rs:41-84), scales / biases bf16; in a float16
+            # checkpoint every other tensor (the norm weights) is float16 too -- the model then runs in float16 end to end, like in MLX
+            t = Tensor.from_numpy(arr, "u32" if dt == np.uint32 else "f16" if self.cfg.quant_scales_f16 else "bf16")
             self._keep.append(t)
             check(lib.omx_qwen3_set_weight(self._h, name.encode(), t.ptr, t.nbytes))
 
@@ -306,6 +307,8 @@ class Model:
     def last_logits(self) -> np.ndarray:
         raw = np.empty(self.vocab_local, dtype=np.uint16)
         check(lib.omx_qwen3_last_logits(self._h, raw.ctypes.data, raw.size))
+        if self.cfg.quant_scales_f16:      # a float16 model's logits are float16
+            return raw.view(np.float16).astype(np.float32)
         return (raw.astype(np.uint32) << np.uint32(16)).view(np.float32)
 
     def stream(self) -> int:

@@ -20,6 +20,11 @@ MOE_SIGNATURES = {
     "omx_moe_block_partial_ep": (c_int, [c_void_p, c_void_p, c_void_p, ctypes.c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                          c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "omx_moe_forward_q": (c_int, [c_void_p] * 12 + [c_int] * 9 + [c_void_p, c_void_p, c_void_p]),
+    "omx_moe_block_forward_q_ex": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_float, c_void_p] + [c_void_p] * 12 + [c_int] * 10 + [c_void_p]),
+    # expert tensor parallel (tp_size > 1 on a sparse-MoE engine): this rank's columns of every expert, f32 slot partials, combine
+    "omx_moe_block_partial_tp": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_float, c_void_p, c_void_p, c_void_p,
+                                         c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "omx_moe_combine_slots": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
 }
 for _n, (_r, _a) in MOE_SIGNATURES.items():
     _f = getattr(lib, _n)

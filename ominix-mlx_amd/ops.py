@@ -351,8 +351,10 @@ def quantized_matmul(x: Tensor, packed: Tensor, scales: Tensor, biases: Optional
     N, K = packed.shape[0], packed.shape[1] * 32 // bits
     if x.shape[-1] != K:
         raise OmxError(f"quantized_matmul: input features {x.shape[-1]} != weight in-features {K}")
+    if x.dtype != scales.dtype:
+        raise OmxError("quantized_matmul: x and the scales / biases must share one dtype (bf16, or f16 for a float16 checkpoint)")
     out = Tensor(tuple(x.shape[:-1]) + (N,), x.dtype)
-    # the dtype argument names the SCALES' dtype: bf16, or f16 for a float16 checkpoint's triplets (x and out are bf16 either way)
+    # one dtype for x, out, scales and biases: bf16, or f16 -- a float16 checkpoint runs in float16 end to end, like in MLX
     check(lib.omx_quantized_matmul(out.ptr, x.ptr, packed.ptr, scales.ptr, _p(biases), x.size // K, N, K, group_size, bits,
                                    scales.dtype, None))
     return out

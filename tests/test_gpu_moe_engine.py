@@ -155,6 +155,44 @@ def test_quantized_moe_engine_matches_oracle(omx, name, bits):
     np.testing.assert_array_equal(got2, got)
 
 
+@pytest.mark.parametrize("name", ["mixtral", "qwen3_moe"])
+def test_float16_quantized_moe_checkpoint_runs_in_float16(omx, name):
+    """The reference's only Mixtral format -- 4-bit triplets (mixtral-mlx/src/model.rs:554-556 refuses anything else), float16 in the MLX
+    community builds -- the way MLX runs it: float16 END TO END (nn/quantized.rs:361-385, ops/quantization.rs:226-279).  float16
+    scales / biases / norm weights uploaded as they are, float16 activations in every kernel of the step (packed GEMVs incl. the
+    router and the expert stacks, decode attention with a float16 cache, routing scores and the weighted sum rounded to float16),
+    f32 accumulation.  Against the oracle in float16 on the same float16 VALUES within the quantised MoE engine's bound scaled to
+    float16 (2^-10 instead of 2^-7); the bf16-activation computation of the same checkpoint is shown to lie outside it."""
+    from ominix_mlx_amd import engine
+    cfg, bits, group = CONFIGS[name], 4, 64
+    base = rq.synth_weights(cfg)
+    qw = {}
+    for k, arr in rq.quantize_weights(cfg, base, bits, group).items():
+        if k.endswith((".scales", ".biases")):
+            prefix = k.rsplit(".", 1)[0]
+            w2 = base[prefix + ".weight"].reshape(-1, base[prefix + ".weight"].shape[-1])
+            _, s32, b32 = rc.quantize(w2, group, bits)
+            arr = (s32 if k.endswith(".scales") else b32).astype(np.float16).reshape(arr.shape)
+        qw[k] = arr
+    prompt = synth.prompt_ids(24, cfg.vocab_size)
+    m = _engine(omx, cfg, qw, quantization={"bits": bits, "group_size": group, "scales_dtype": "float16"})
+    first = m.prefill(prompt)
+    logits0 = m.last_logits()
+    got = np.concatenate([[first], m.decode(5)]).astype(np.uint32)
+    m.close()
+    f16w = {k: (v.astype(np.float32) if v.dtype == np.float16 else v) for k, v in qw.items()}     # the f16 VALUES, exactly
+    ref_tokens, ref_logits = rq.Qwen3Oracle(cfg, f16w, dt="f16", quant=(bits, group)).generate(prompt, 6, return_logits=True)
+    bound = 2.0 ** -10 * np.abs(ref_logits).max() * np.sqrt(cfg.num_hidden_layers) * 2 * np.sqrt(2)
+    assert np.abs(logits0 - ref_logits[0]).max() <= bound, f"float16 MoE logits off by {np.abs(logits0 - ref_logits[0]).max():.5f} (bound {bound:.5f})"
+    margins = rc.argmax_margin(ref_logits)
+    for i in range(6):
+        if got[i] != ref_tokens[i]:
+            assert margins[i] <= 2 * bound
+            break
+    ref_bf16 = rq.Qwen3Oracle(cfg, f16w, quant=(bits, group)).generate(prompt, 1, return_logits=True)[1]
+    assert np.abs(ref_bf16[0] - ref_logits[0]).max() > bound       # bf16 activations on float16 triplets are a different computation
+
+
 @pytest.mark.parametrize("name,world", [("qwen3_moe", 2), ("mixtral", 4), ("qwen3_moe_no_renorm_top4", 4)])
 @pytest.mark.parametrize("use_synth", [True, False])
 def test_expert_parallel_engine_on_one_gpu(omx, monkeypatch, name, world, use_synth):

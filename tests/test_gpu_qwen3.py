@@ -414,11 +414,12 @@ def test_quantized_checkpoint_decode_matches_oracle(omx, name, bits, group):
 
 
 def test_quantized_checkpoint_with_float16_scales(omx, tmp_path):
-    """A float16 MLX checkpoint carries float16 scales / biases (mlx quantize() works in the model's dtype; nn/quantized.rs:361-385
-    takes any float).  They stay float16 on the device and the packed-weight kernels widen each group's scale / bias to its exact
-    float32 value (csrc/quant.hip F16S; a host-side rounding to bf16 moved the logits outside the bound below -- it shifts all 64
-    weights of a group together); activations stay bf16.  Against the oracle running on the float16 VALUES, with the quantized
-    engine's bound; also through loader.load_model (dtype read off the safetensors header), and the loud mismatch errors."""
+    """A float16 MLX checkpoint carries float16 scales / biases and norm weights (mlx quantize() works in the model's dtype), and MLX
+    runs it in float16 END TO END (nn/quantized.rs:361-385: the dequantised weight has the scales' dtype, the matmul its inputs').
+    So does the engine since round 4: embedding rows dequantised to float16, float16 RMSNorm / RoPE / residual roundings, float16 K / V
+    slabs and logits, f32 accumulation (csrc/act16.hpp Act16<true> in quant.hip, attn_step.hip, engine.hip; the prompt runs through
+    the decode step).  Against the oracle in float16 on the same float16 VALUES, with the bound scaled to float16's 11-bit results;
+    also through loader.load_model (dtype read off the safetensors header), and the loud mismatch errors."""
     from ominix_mlx_amd import engine
     cfg, bits, group = CONFIGS["gqa4_d128"], 4, 64
     base = rq.synth_weights(cfg)
@@ -446,9 +447,12 @@ def test_quantized_checkpoint_with_float16_scales(omx, tmp_path):
         m.synth_weights()
     m.close()
     f16w = {k: (v.astype(np.float32) if v.dtype == np.float16 else v) for k, v in qw.items()}     # the f16 VALUES, exactly
-    oracle = rq.Qwen3Oracle(cfg, f16w, quant=(bits, group))
+    oracle = rq.Qwen3Oracle(cfg, f16w, dt="f16", quant=(bits, group))
     ref_tokens, ref_logits = oracle.generate(prompt, n_new, return_logits=True)
-    bound = 2.0 ** -7 * np.abs(ref_logits).max() * np.sqrt(2 * cfg.num_hidden_layers)   # test_quantized_checkpoint_decode_matches_oracle's
+    bound = 2.0 ** -10 * np.abs(ref_logits).max() * np.sqrt(2 * cfg.num_hidden_layers)   # test_quantized_checkpoint_decode_matches_oracle's, 3 bits finer
+    # (and it is NOT the bf16-activation computation any more: that one sits outside this bound)
+    ref_bf16 = rq.Qwen3Oracle(cfg, f16w, quant=(bits, group)).generate(prompt, 1, return_logits=True)[1]
+    assert np.abs(ref_bf16[0] - ref_logits[0]).max() > bound
     assert np.abs(logits0 - ref_logits[0]).max() <= bound
     margins = rc.argmax_margin(ref_logits)
     for i in range(n_new):

@@ -211,6 +211,9 @@ class Model:
                 raise OmxError(f"{name}: a quantized weight must be packed uint32, found {dt}")
             # quantized checkpoints: "<prefix>.weight" is packed uint32 (ops/quantization.rs:41-84), scales / biases bf16; in a float16
             # checkpoint every other tensor (the norm weights) is float16 too -- the model then runs in float16 end to end, like in MLX
+            if self.cfg.quant_scales_f16 and dt != np.uint32 and type(arr).__name__ == "Bf16Bits":
+                # a BF16 tensor of a checkpoint whose triplets are float16 (loader.read_safetensors hands raw bits): its VALUES go up as float16
+                arr = (np.asarray(arr).astype(np.uint32) << np.uint32(16)).view(np.float32)
             t = Tensor.from_numpy(arr, "u32" if dt == np.uint32 else "f16" if self.cfg.quant_scales_f16 else "bf16")
             self._keep.append(t)
             check(lib.omx_qwen3_set_weight(self._h, name.encode(), t.ptr, t.nbytes))

@@ -313,6 +313,69 @@ int omx_mlx_fused_swiglu(mlx_array* res, const mlx_array x, const mlx_array gate
 int omx_mlx_fused_modulate(mlx_array* res, const mlx_array x, const mlx_array shift, const mlx_array scale,
                            const mlx_stream s);
 
+/* ---- elementwise math, predicates, axis reductions, views and fills of ops.h beyond the four callers' path (round 4: these were
+ *      error-returning link stubs before); same names and argument order as mlx/c/ops.h ---- */
+int mlx_abs(mlx_array* res, const mlx_array a, const mlx_stream s);
+int mlx_sqrt(mlx_array* res, const mlx_array a, const mlx_stream s);
+int mlx_rsqrt(mlx_array* res, const mlx_array a, const mlx_stream s);
+int mlx_square(mlx_array* res, const mlx_array a, const mlx_stream s);
+int mlx_log(mlx_array* res, const mlx_array a, const mlx_stream s);
+int mlx_log2(mlx_array* res, const mlx_array a, const mlx_stream s);
+int mlx_log10(mlx_array* res, const mlx_array a, const mlx_stream s);
+int mlx_log1p(mlx_array* res, const mlx_array a, const mlx_stream s);
+int mlx_expm1(mlx_array* res, const mlx_array a, const mlx_stream s);
+int mlx_tanh(mlx_array* res, const mlx_array a, const mlx_stream s);
+int mlx_sinh(mlx_array* res, const mlx_array a, const mlx_stream s);
+int mlx_cosh(mlx_array* res, const mlx_array a, const mlx_stream s);
+int mlx_tan(mlx_array* res, const mlx_array a, const mlx_stream s);
+int mlx_arcsin(mlx_array* res, const mlx_array a, const mlx_stream s);
+int mlx_arccos(mlx_array* res, const mlx_array a, const mlx_stream s);
+int mlx_arctan(mlx_array* res, const mlx_array a, const mlx_stream s);
+int mlx_arcsinh(mlx_array* res, const mlx_array a, const mlx_stream s);
+int mlx_arccosh(mlx_array* res, const mlx_array a, const mlx_stream s);
+int mlx_arctanh(mlx_array* res, const mlx_array a, const mlx_stream s);
+int mlx_erf(mlx_array* res, const mlx_array a, const mlx_stream s);
+int mlx_reciprocal(mlx_array* res, const mlx_array a, const mlx_stream s);
+int mlx_floor(mlx_array* res, const mlx_array a, const mlx_stream s);
+int mlx_ceil(mlx_array* res, const mlx_array a, const mlx_stream s);
+int mlx_sign(mlx_array* res, const mlx_array a, const mlx_stream s);
+int mlx_isnan(mlx_array* res, const mlx_array a, const mlx_stream s);
+int mlx_isinf(mlx_array* res, const mlx_array a, const mlx_stream s);
+int mlx_isfinite(mlx_array* res, const mlx_array a, const mlx_stream s);
+int mlx_isposinf(mlx_array* res, const mlx_array a, const mlx_stream s);
+int mlx_isneginf(mlx_array* res, const mlx_array a, const mlx_stream s);
+int mlx_logical_not(mlx_array* res, const mlx_array a, const mlx_stream s);
+int mlx_round(mlx_array* res, const mlx_array a, int decimals, const mlx_stream s);   /* decimals = 0 */
+int mlx_not_equal(mlx_array* res, const mlx_array a, const mlx_array b, const mlx_stream s);
+int mlx_logical_or(mlx_array* res, const mlx_array a, const mlx_array b, const mlx_stream s);
+int mlx_power(mlx_array* res, const mlx_array a, const mlx_array b, const mlx_stream s);
+int mlx_remainder(mlx_array* res, const mlx_array a, const mlx_array b, const mlx_stream s);
+int mlx_logaddexp(mlx_array* res, const mlx_array a, const mlx_array b, const mlx_stream s);
+int mlx_max_axis(mlx_array* res, const mlx_array a, int axis, bool keepdims, const mlx_stream s);
+int mlx_min_axis(mlx_array* res, const mlx_array a, int axis, bool keepdims, const mlx_stream s);
+int mlx_mean_axis(mlx_array* res, const mlx_array a, int axis, bool keepdims, const mlx_stream s);
+int mlx_all_axis(mlx_array* res, const mlx_array a, int axis, bool keepdims, const mlx_stream s);
+int mlx_any_axis(mlx_array* res, const mlx_array a, int axis, bool keepdims, const mlx_stream s);
+int mlx_logsumexp_axis(mlx_array* res, const mlx_array a, int axis, bool keepdims, const mlx_stream s);
+int mlx_max(mlx_array* res, const mlx_array a, bool keepdims, const mlx_stream s);
+int mlx_min(mlx_array* res, const mlx_array a, bool keepdims, const mlx_stream s);
+int mlx_mean(mlx_array* res, const mlx_array a, bool keepdims, const mlx_stream s);
+int mlx_sum(mlx_array* res, const mlx_array a, bool keepdims, const mlx_stream s);
+int mlx_all(mlx_array* res, const mlx_array a, bool keepdims, const mlx_stream s);
+int mlx_any(mlx_array* res, const mlx_array a, bool keepdims, const mlx_stream s);
+int mlx_logsumexp(mlx_array* res, const mlx_array a, bool keepdims, const mlx_stream s);
+int mlx_stop_gradient(mlx_array* res, const mlx_array a, const mlx_stream s);
+int mlx_sort_axis(mlx_array* res, const mlx_array a, int axis, const mlx_stream s);
+int mlx_sort(mlx_array* res, const mlx_array a, const mlx_stream s);
+int mlx_broadcast_to(mlx_array* res, const mlx_array a, const int* shape, size_t shape_num, const mlx_stream s);
+int mlx_concatenate(mlx_array* res, const mlx_vector_array arrays, const mlx_stream s);
+int mlx_swapaxes(mlx_array* res, const mlx_array a, int axis1, int axis2, const mlx_stream s);
+int mlx_moveaxis(mlx_array* res, const mlx_array a, int source, int destination, const mlx_stream s);
+int mlx_full(mlx_array* res, const int* shape, size_t shape_num, const mlx_array vals, mlx_dtype dtype, const mlx_stream s);   /* scalar vals */
+int mlx_ones(mlx_array* res, const int* shape, size_t shape_num, mlx_dtype dtype, const mlx_stream s);
+int mlx_where(mlx_array* res, const mlx_array condition, const mlx_array x, const mlx_array y, const mlx_stream s);
+int mlx_clip(mlx_array* res, const mlx_array a, const mlx_array a_min /* may be null */, const mlx_array a_max /* may be null */, const mlx_stream s);
+
 #ifdef __cplusplus
 }
 #endif

@@ -62,7 +62,7 @@ __device__ __forceinline__ void st_i(char* p, int dt, size_t i, long long v) {
 }
 __host__ __device__ inline bool is_int_dt(int d) { return d != MLX_FLOAT16 && d != MLX_FLOAT32 && d != MLX_BFLOAT16 && d != MLX_FLOAT64 && d != MLX_COMPLEX64; }
 
-enum { B2_GT, B2_GE, B2_LT, B2_LE, B2_EQ, B2_AND, B2_MAX, B2_MIN, B2_FLOORDIV };
+enum { B2_GT, B2_GE, B2_LT, B2_LE, B2_EQ, B2_AND, B2_NE, B2_OR, B2_LAST_BOOL = B2_OR, B2_MAX, B2_MIN, B2_FLOORDIV, B2_POW, B2_REM, B2_LOGADDEXP };
 
 // comparison / logical / max / min / floor_divide with broadcasting; integer operands are combined in 64-bit integers
 // (indices beyond 2^24 would not survive a float round trip)
@@ -86,8 +86,24 @@ __global__ void binary2_kernel(char* out, int odt, const char* a, int adt, const
                 case B2_LE: v = x <= y; break;
                 case B2_EQ: v = x == y; break;
                 case B2_AND: v = (x != 0) && (y != 0); break;
+                case B2_NE: v = x != y; break;
+                case B2_OR: v = (x != 0) || (y != 0); break;
                 case B2_MAX: v = x > y ? x : y; break;
                 case B2_MIN: v = x < y ? x : y; break;
+                case B2_POW: {   // integer power by squaring; a negative exponent gives 0 (1 for a base of 1), as integer division would
+                    long long base = x, e = y;
+                    v = 1;
+                    if (e < 0) { v = (x == 1) ? 1 : (x == -1 ? ((e & 1) ? -1 : 1) : 0); break; }
+                    while (e) { if (e & 1) v *= base; base *= base; e >>= 1; }
+                    break;
+                }
+                case B2_REM: {   // sign of the divisor (numpy / MLX remainder); division by zero gives 0
+                    if (y == 0) { v = 0; break; }
+                    v = x % y;
+                    if (v != 0 && ((v < 0) != (y < 0))) v += y;
+                    break;
+                }
+                case B2_LOGADDEXP: v = 0; break;   // (float-only op: the host wrapper never takes the integer route for it)
                 default: {   // floor division (numpy / MLX semantics for negative operands); division by zero gives 0
                     if (y == 0) { v = 0; break; }
                     v = x / y;
@@ -105,15 +121,61 @@ __global__ void binary2_kernel(char* out, int odt, const char* a, int adt, const
                 case B2_LE: v = x <= y; break;
                 case B2_EQ: v = x == y; break;
                 case B2_AND: v = (x != 0.f) && (y != 0.f); break;
+                case B2_NE: v = x != y; break;
+                case B2_OR: v = (x != 0.f) || (y != 0.f); break;
                 case B2_MAX: v = (x != x || y != y) ? NAN : fmaxf(x, y); break;   // NaN propagates like MLX's maximum
                 case B2_MIN: v = (x != x || y != y) ? NAN : fminf(x, y); break;
+                case B2_POW: v = powf(x, y); break;
+                case B2_REM: { v = fmodf(x, y); if (v != 0.f && ((v < 0.f) != (y < 0.f))) v += y; break; }
+                case B2_LOGADDEXP: { const float mx = fmaxf(x, y), mn = fminf(x, y); v = (mx == -INFINITY) ? -INFINITY : mx + log1pf(expf(mn - mx)); break; }
                 default: v = floorf(x / y); break;
             }
             st_f(out, odt, i, v);
         }
     }
 }
-enum { U2_COS, U2_SIN };
+enum { U2_COS, U2_SIN, U2_ABS, U2_SQRT, U2_RSQRT, U2_SQUARE, U2_LOG, U2_LOG2, U2_LOG10, U2_LOG1P, U2_EXPM1, U2_TANH, U2_SINH, U2_COSH, U2_TAN,
+       U2_ARCSIN, U2_ARCCOS, U2_ARCTAN, U2_ARCSINH, U2_ARCCOSH, U2_ARCTANH, U2_ERF, U2_RECIP, U2_FLOOR, U2_CEIL, U2_ROUND, U2_SIGN,
+       U2_FIRST_PRED, U2_ISNAN = U2_FIRST_PRED, U2_ISINF, U2_ISFINITE, U2_ISPOSINF, U2_ISNEGINF, U2_NOT };
+// elementwise math of ops.h beyond the hot path (float32 inside, one rounding to the output dtype; MLX: float results for float
+// inputs, float32 for integer inputs; predicates and logical_not give bool)
+__device__ inline float unary2_apply(int op, float x) {
+    switch (op) {
+        case U2_COS: return cosf(x);
+        case U2_SIN: return sinf(x);
+        case U2_ABS: return fabsf(x);
+        case U2_SQRT: return sqrtf(x);
+        case U2_RSQRT: return 1.0f / sqrtf(x);
+        case U2_SQUARE: return x * x;
+        case U2_LOG: return logf(x);
+        case U2_LOG2: return log2f(x);
+        case U2_LOG10: return log10f(x);
+        case U2_LOG1P: return log1pf(x);
+        case U2_EXPM1: return expm1f(x);
+        case U2_TANH: return tanhf(x);
+        case U2_SINH: return sinhf(x);
+        case U2_COSH: return coshf(x);
+        case U2_TAN: return tanf(x);
+        case U2_ARCSIN: return asinf(x);
+        case U2_ARCCOS: return acosf(x);
+        case U2_ARCTAN: return atanf(x);
+        case U2_ARCSINH: return asinhf(x);
+        case U2_ARCCOSH: return acoshf(x);
+        case U2_ARCTANH: return atanhf(x);
+        case U2_ERF: return erff(x);
+        case U2_RECIP: return 1.0f / x;
+        case U2_FLOOR: return floorf(x);
+        case U2_CEIL: return ceilf(x);
+        case U2_ROUND: return rintf(x);                       // round half to even, as MLX (numpy) does
+        case U2_SIGN: return (float)((x > 0.f) - (x < 0.f));
+        case U2_ISNAN: return x != x;
+        case U2_ISINF: return isinf(x);
+        case U2_ISFINITE: return isfinite(x);
+        case U2_ISPOSINF: return isinf(x) && x > 0.f;
+        case U2_ISNEGINF: return isinf(x) && x < 0.f;
+        default: return x == 0.f;                               // U2_NOT
+    }
+}
 __global__ void unary2_kernel(char* out, int odt, const char* a, int adt, Idx ix, size_t n, int op) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         size_t r = i;
@@ -124,7 +186,7 @@ __global__ void unary2_kernel(char* out, int odt, const char* a, int adt, Idx ix
             oa += c * ix.sa[d];
         }
         const float x = ld_f(a, adt, oa);
-        st_f(out, odt, i, op == U2_COS ? cosf(x) : sinf(x));
+        st_f(out, odt, i, unary2_apply(op, x));
     }
 }
 __global__ void arange_kernel(char* out, int dt, size_t n, double start, double step) {
@@ -148,6 +210,69 @@ __global__ void sum_axis_kernel(char* out, int odt, const char* in, int idt, siz
             for (int k = 0; k < n; ++k) acc += ld_f(in, idt, (o * n + k) * inner + j);
             st_f(out, odt, i, acc);
         }
+    }
+}
+// max / min / mean over the middle axis of a contiguous [outer, n, inner] (mode 0 max, 1 min, 2 mean); NaN propagates in max / min
+__global__ void reduce_axis_kernel(char* out, int odt, const char* in, int idt, size_t outer, int n, size_t inner, int mode) {
+    const size_t total = outer * inner;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t o = i / inner, j = i % inner;
+        if (is_int_dt(idt) && mode < 2) {
+            long long acc = ld_i(in, idt, (o * n) * inner + j);
+            for (int k = 1; k < n; ++k) {
+                const long long v = ld_i(in, idt, (o * n + k) * inner + j);
+                acc = mode == 0 ? (v > acc ? v : acc) : (v < acc ? v : acc);
+            }
+            st_i(out, odt, i, acc);
+        } else {
+            if (mode >= 3) {   // 3: all, 4: any (bool), 5: logsumexp (max-shifted, f32)
+                float mx = -INFINITY;
+                bool all = true, any = false;
+                for (int k = 0; k < n; ++k) {
+                    const float v = ld_f(in, idt, (o * n + k) * inner + j);
+                    all &= v != 0.f; any |= v != 0.f; mx = fmaxf(mx, v);
+                }
+                if (mode == 5) {
+                    float sm = 0.f;
+                    for (int k = 0; k < n; ++k) sm += expf(ld_f(in, idt, (o * n + k) * inner + j) - mx);
+                    st_f(out, odt, i, mx == -INFINITY ? -INFINITY : mx + logf(sm));
+                } else {
+                    st_f(out, odt, i, mode == 3 ? (float)all : (float)any);
+                }
+                continue;
+            }
+            float acc = mode == 2 ? 0.f : ld_f(in, idt, (o * n) * inner + j);
+            bool nan = acc != acc;
+            for (int k = mode == 2 ? 0 : 1; k < n; ++k) {
+                const float v = ld_f(in, idt, (o * n + k) * inner + j);
+                nan |= v != v;
+                acc = mode == 2 ? acc + v : mode == 0 ? fmaxf(acc, v) : fminf(acc, v);
+            }
+            st_f(out, odt, i, mode == 2 ? acc / (float)n : (nan ? NAN : acc));
+        }
+    }
+}
+// out = cond ? x : y with all three broadcast to one shape
+__global__ void where_kernel(char* out, int odt, const char* c, int cdt, const char* x, int xdt, const char* y, int ydt, Idx ixc, Idx ixy, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        size_t r = i;
+        long long oc = 0, ox = 0, oy = 0;
+        for (int d = ixc.nd - 1; d >= 0; --d) {
+            const int k = (int)(r % ixc.shape[d]);
+            r /= ixc.shape[d];
+            oc += k * ixc.sa[d];
+            ox += k * ixc.sb[d];
+            oy += k * ixy.sb[d];
+        }
+        const bool take = is_int_dt(cdt) ? ld_i(c, cdt, oc) != 0 : ld_f(c, cdt, oc) != 0.f;
+        if (is_int_dt(odt)) st_i(out, odt, i, take ? ld_i(x, xdt, ox) : ld_i(y, ydt, oy));
+        else st_f(out, odt, i, take ? ld_f(x, xdt, ox) : ld_f(y, ydt, oy));
+    }
+}
+__global__ void fill_value_kernel(char* out, int odt, const char* v, int vdt, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        if (is_int_dt(odt) && is_int_dt(vdt)) st_i(out, odt, i, ld_i(v, vdt, 0));
+        else st_f(out, odt, i, ld_f(v, vdt, 0));
     }
 }
 // stable ascending argsort along the middle axis of a contiguous [outer, n, inner]: the rank of element k is the number of
@@ -260,12 +385,13 @@ int binary2(mlx_array* res, const mlx_array ha, const mlx_array hb, int op, cons
     std::vector<int> shape;
     Idx ix;
     if (broadcast2(a, b, name, &shape, &ix)) return 1;
-    const bool boolean = op <= B2_AND;
-    const mlx_dtype odt = boolean ? MLX_BOOL : promote(a.dt, b.dt);
+    const bool boolean = op <= B2_LAST_BOOL;
+    mlx_dtype odt = boolean ? MLX_BOOL : promote(a.dt, b.dt);
+    if (op == B2_LOGADDEXP && !is_float(odt)) odt = MLX_FLOAT32;
     NEW_OR_FAIL(r, shape, odt);
     const size_t n = r->size();
     if (n) {
-        binary2_kernel<<<grid_for(n), 256, 0, g_stream>>>(r->ptr(), odt, a.ptr(), a.dt, b.ptr(), b.dt, ix, n, op, is_int_dt(a.dt) && is_int_dt(b.dt));
+        binary2_kernel<<<grid_for(n), 256, 0, g_stream>>>(r->ptr(), odt, a.ptr(), a.dt, b.ptr(), b.dt, ix, n, op, is_int_dt(a.dt) && is_int_dt(b.dt) && op != B2_LOGADDEXP);
         OMX_LAUNCH_CHECK();
     }
     return assign(res, r);
@@ -273,7 +399,9 @@ int binary2(mlx_array* res, const mlx_array ha, const mlx_array hb, int op, cons
 int unary2(mlx_array* res, const mlx_array ha, int op, const char* name) {
     REQ_ARR(ha, name);
     const Arr& a = *A(ha);
-    const mlx_dtype odt = is_float(a.dt) ? a.dt : MLX_FLOAT32;
+    // abs / square / sign / floor / ceil / round keep an integer input's dtype in MLX; the float32 round trip is exact below 2^24
+    const bool keeps = op == U2_ABS || op == U2_SQUARE || op == U2_SIGN || op == U2_FLOOR || op == U2_CEIL || op == U2_ROUND;
+    const mlx_dtype odt = op >= U2_FIRST_PRED ? MLX_BOOL : (is_float(a.dt) || keeps) ? a.dt : MLX_FLOAT32;
     NEW_OR_FAIL(r, a.shape, odt);
     Idx ix;
     if (fill_idx(ix, a.shape)) { delete r; return 1; }
@@ -792,6 +920,26 @@ int mlx_minimum(mlx_array* res, const mlx_array a, const mlx_array b, const mlx_
 int mlx_floor_divide(mlx_array* res, const mlx_array a, const mlx_array b, const mlx_stream) { return binary2(res, a, b, B2_FLOORDIV, "mlx_floor_divide"); }
 int mlx_cos(mlx_array* res, const mlx_array a, const mlx_stream) { return unary2(res, a, U2_COS, "mlx_cos"); }
 int mlx_sin(mlx_array* res, const mlx_array a, const mlx_stream) { return unary2(res, a, U2_SIN, "mlx_sin"); }
+// the rest of ops.h's elementwise math (round 4; not on the four callers' path, but `mlx-rs` names them)
+#define OMX_UNARY2(NAME, OP) int NAME(mlx_array* res, const mlx_array a, const mlx_stream) { return unary2(res, a, OP, #NAME); }
+OMX_UNARY2(mlx_abs, U2_ABS) OMX_UNARY2(mlx_sqrt, U2_SQRT) OMX_UNARY2(mlx_rsqrt, U2_RSQRT) OMX_UNARY2(mlx_square, U2_SQUARE)
+OMX_UNARY2(mlx_log, U2_LOG) OMX_UNARY2(mlx_log2, U2_LOG2) OMX_UNARY2(mlx_log10, U2_LOG10) OMX_UNARY2(mlx_log1p, U2_LOG1P)
+OMX_UNARY2(mlx_expm1, U2_EXPM1) OMX_UNARY2(mlx_tanh, U2_TANH) OMX_UNARY2(mlx_sinh, U2_SINH) OMX_UNARY2(mlx_cosh, U2_COSH)
+OMX_UNARY2(mlx_tan, U2_TAN) OMX_UNARY2(mlx_arcsin, U2_ARCSIN) OMX_UNARY2(mlx_arccos, U2_ARCCOS) OMX_UNARY2(mlx_arctan, U2_ARCTAN)
+OMX_UNARY2(mlx_arcsinh, U2_ARCSINH) OMX_UNARY2(mlx_arccosh, U2_ARCCOSH) OMX_UNARY2(mlx_arctanh, U2_ARCTANH) OMX_UNARY2(mlx_erf, U2_ERF)
+OMX_UNARY2(mlx_reciprocal, U2_RECIP) OMX_UNARY2(mlx_floor, U2_FLOOR) OMX_UNARY2(mlx_ceil, U2_CEIL) OMX_UNARY2(mlx_sign, U2_SIGN)
+OMX_UNARY2(mlx_isnan, U2_ISNAN) OMX_UNARY2(mlx_isinf, U2_ISINF) OMX_UNARY2(mlx_isfinite, U2_ISFINITE) OMX_UNARY2(mlx_isposinf, U2_ISPOSINF)
+OMX_UNARY2(mlx_isneginf, U2_ISNEGINF) OMX_UNARY2(mlx_logical_not, U2_NOT)
+#undef OMX_UNARY2
+int mlx_round(mlx_array* res, const mlx_array a, int decimals, const mlx_stream) {
+    OMX_REQUIRE(decimals == 0, "mlx_round: only decimals = 0 is supported (got %d)", decimals);
+    return unary2(res, a, U2_ROUND, "mlx_round");
+}
+int mlx_not_equal(mlx_array* res, const mlx_array a, const mlx_array b, const mlx_stream) { return binary2(res, a, b, B2_NE, "mlx_not_equal"); }
+int mlx_logical_or(mlx_array* res, const mlx_array a, const mlx_array b, const mlx_stream) { return binary2(res, a, b, B2_OR, "mlx_logical_or"); }
+int mlx_power(mlx_array* res, const mlx_array a, const mlx_array b, const mlx_stream) { return binary2(res, a, b, B2_POW, "mlx_power"); }
+int mlx_remainder(mlx_array* res, const mlx_array a, const mlx_array b, const mlx_stream) { return binary2(res, a, b, B2_REM, "mlx_remainder"); }
+int mlx_logaddexp(mlx_array* res, const mlx_array a, const mlx_array b, const mlx_stream) { return binary2(res, a, b, B2_LOGADDEXP, "mlx_logaddexp"); }
 
 int mlx_arange(mlx_array* res, double start, double stop, double step, mlx_dtype dtype, const mlx_stream) {
     OMX_REQUIRE(step != 0.0 && step == step && start == start && stop == stop, "mlx_arange: step must be non-zero and the bounds finite");
@@ -823,6 +971,173 @@ int mlx_sum_axis(mlx_array* res, const mlx_array a, int axis, bool keepdims, con
         OMX_LAUNCH_CHECK();
     }
     return assign(res, r);
+}
+static int reduce_axis(mlx_array* res, const mlx_array a, int axis, bool keepdims, int mode, const char* name) {
+    REQ_ARR(a, name);
+    const Arr& s = *A(a);
+    int ax;
+    if (norm_axis(axis, (int)s.shape.size(), name, &ax)) return 1;
+    OMX_REQUIRE(s.shape[ax] > 0, "%s: empty reduction axis", name);
+    Contig c;
+    if (c.init(s)) return 1;
+    size_t outer, inner; int n;
+    around_axis(s.shape, ax, &outer, &n, &inner);
+    std::vector<int> shape = s.shape;
+    if (keepdims) shape[ax] = 1; else shape.erase(shape.begin() + ax);
+    const mlx_dtype odt = (mode == 3 || mode == 4) ? MLX_BOOL : ((mode == 2 || mode == 5) && !is_float(s.dt)) ? MLX_FLOAT32 : s.dt;    // the mean of integers is float32 in MLX
+    NEW_OR_FAIL(r, shape, odt);
+    if (r->size()) {
+        reduce_axis_kernel<<<grid_for(r->size()), 256, 0, g_stream>>>(r->ptr(), odt, c.a->ptr(), s.dt, outer, n, inner, mode);
+        OMX_LAUNCH_CHECK();
+    }
+    return assign(res, r);
+}
+int mlx_max_axis(mlx_array* res, const mlx_array a, int axis, bool keepdims, const mlx_stream) { return reduce_axis(res, a, axis, keepdims, 0, "mlx_max_axis"); }
+int mlx_min_axis(mlx_array* res, const mlx_array a, int axis, bool keepdims, const mlx_stream) { return reduce_axis(res, a, axis, keepdims, 1, "mlx_min_axis"); }
+int mlx_mean_axis(mlx_array* res, const mlx_array a, int axis, bool keepdims, const mlx_stream) { return reduce_axis(res, a, axis, keepdims, 2, "mlx_mean_axis"); }
+int mlx_all_axis(mlx_array* res, const mlx_array a, int axis, bool keepdims, const mlx_stream) { return reduce_axis(res, a, axis, keepdims, 3, "mlx_all_axis"); }
+int mlx_any_axis(mlx_array* res, const mlx_array a, int axis, bool keepdims, const mlx_stream) { return reduce_axis(res, a, axis, keepdims, 4, "mlx_any_axis"); }
+int mlx_logsumexp_axis(mlx_array* res, const mlx_array a, int axis, bool keepdims, const mlx_stream) { return reduce_axis(res, a, axis, keepdims, 5, "mlx_logsumexp_axis"); }
+// the whole-array forms: the same reduction over the flattened array (keepdims: every axis kept as 1)
+static int reduce_all(mlx_array* res, const mlx_array a, bool keepdims, int mode, const char* name, const mlx_stream s) {
+    REQ_ARR(a, name);
+    const int nd = (int)A(a)->shape.size();
+    mlx_array flat = mlx_array_new(), red = mlx_array_new();
+    int rc = nd <= 1 ? mlx_array_set(&flat, a) : mlx_flatten(&flat, a, 0, -1, s);
+    if (!rc && nd == 0) rc = mlx_reshape(&flat, a, std::vector<int>{1}.data(), 1, s);
+    if (!rc) rc = mode == 6 ? mlx_sum_axis(&red, flat, 0, false, s) : reduce_axis(&red, flat, 0, false, mode, name);
+    if (!rc && keepdims && nd > 0) {
+        std::vector<int> ones((size_t)nd, 1);
+        rc = mlx_reshape(res, red, ones.data(), ones.size(), s);
+    } else if (!rc) {
+        rc = mlx_array_set(res, red);
+    }
+    mlx_array_free(flat); mlx_array_free(red);
+    return rc;
+}
+int mlx_max(mlx_array* res, const mlx_array a, bool keepdims, const mlx_stream s) { return reduce_all(res, a, keepdims, 0, "mlx_max", s); }
+int mlx_min(mlx_array* res, const mlx_array a, bool keepdims, const mlx_stream s) { return reduce_all(res, a, keepdims, 1, "mlx_min", s); }
+int mlx_mean(mlx_array* res, const mlx_array a, bool keepdims, const mlx_stream s) { return reduce_all(res, a, keepdims, 2, "mlx_mean", s); }
+int mlx_all(mlx_array* res, const mlx_array a, bool keepdims, const mlx_stream s) { return reduce_all(res, a, keepdims, 3, "mlx_all", s); }
+int mlx_any(mlx_array* res, const mlx_array a, bool keepdims, const mlx_stream s) { return reduce_all(res, a, keepdims, 4, "mlx_any", s); }
+int mlx_logsumexp(mlx_array* res, const mlx_array a, bool keepdims, const mlx_stream s) { return reduce_all(res, a, keepdims, 5, "mlx_logsumexp", s); }
+int mlx_sum(mlx_array* res, const mlx_array a, bool keepdims, const mlx_stream s) { return reduce_all(res, a, keepdims, 6, "mlx_sum", s); }
+int mlx_stop_gradient(mlx_array* res, const mlx_array a, const mlx_stream) { REQ_ARR(a, "mlx_stop_gradient"); return mlx_array_set(res, a); }   // inference only: the identity
+int mlx_sort_axis(mlx_array* res, const mlx_array a, int axis, const mlx_stream s) {   // values in the order of the stable argsort
+    REQ_ARR(a, "mlx_sort_axis");
+    mlx_array idx = mlx_array_new();
+    int rc = mlx_argsort_axis(&idx, a, axis, s);
+    if (!rc) rc = mlx_take_along_axis(res, a, idx, axis, s);
+    mlx_array_free(idx);
+    return rc;
+}
+int mlx_sort(mlx_array* res, const mlx_array a, const mlx_stream s) {
+    REQ_ARR(a, "mlx_sort");
+    mlx_array flat = mlx_array_new();
+    int rc = A(a)->shape.size() <= 1 ? mlx_array_set(&flat, a) : mlx_flatten(&flat, a, 0, -1, s);
+    if (!rc) rc = mlx_sort_axis(res, flat, 0, s);
+    mlx_array_free(flat);
+    return rc;
+}
+int mlx_broadcast_to(mlx_array* res, const mlx_array a, const int* shape, size_t shape_num, const mlx_stream) {   // a view: stride 0 along the broadcast axes
+    REQ_ARR(a, "mlx_broadcast_to");
+    const Arr& s = *A(a);
+    OMX_REQUIRE(shape_num >= s.shape.size(), "mlx_broadcast_to: cannot broadcast %zu dimensions to %zu", s.shape.size(), shape_num);
+    Arr* r = new Arr(s);
+    r->host.clear();
+    r->shape.assign(shape, shape + shape_num);
+    r->strides.assign(shape_num, 0);
+    const int lead = (int)shape_num - (int)s.shape.size();
+    for (int i = 0; i < (int)shape_num; ++i) {
+        const int is = i - lead;
+        const int d = is >= 0 ? s.shape[is] : 1;
+        if (d != shape[i] && d != 1) { delete r; return set_error("mlx_broadcast_to: dimension %d of size %d does not broadcast to %d", i, d, shape[i]); }
+        r->strides[i] = (is >= 0 && d != 1) ? s.strides[is] : 0;
+    }
+    return assign(res, r);
+}
+int mlx_concatenate(mlx_array* res, const mlx_vector_array arrays, const mlx_stream s) { return mlx_concatenate_axis(res, arrays, 0, s); }
+// axis permutations as views (ops.h mlx_swapaxes / mlx_moveaxis -> the transpose view of mlxc.hip)
+int mlx_swapaxes(mlx_array* res, const mlx_array a, int axis1, int axis2, const mlx_stream s) {
+    REQ_ARR(a, "mlx_swapaxes");
+    const int nd = (int)A(a)->shape.size();
+    int a1, a2;
+    if (norm_axis(axis1, nd, "mlx_swapaxes", &a1) || norm_axis(axis2, nd, "mlx_swapaxes", &a2)) return 1;
+    std::vector<int> axes(nd);
+    for (int i = 0; i < nd; ++i) axes[i] = i;
+    std::swap(axes[a1], axes[a2]);
+    return mlx_transpose_axes(res, a, axes.data(), axes.size(), s);
+}
+int mlx_moveaxis(mlx_array* res, const mlx_array a, int source, int destination, const mlx_stream s) {
+    REQ_ARR(a, "mlx_moveaxis");
+    const int nd = (int)A(a)->shape.size();
+    int src, dst;
+    if (norm_axis(source, nd, "mlx_moveaxis", &src) || norm_axis(destination, nd, "mlx_moveaxis", &dst)) return 1;
+    std::vector<int> axes;
+    for (int i = 0; i < nd; ++i)
+        if (i != src) axes.push_back(i);
+    axes.insert(axes.begin() + dst, src);
+    return mlx_transpose_axes(res, a, axes.data(), axes.size(), s);
+}
+int mlx_full(mlx_array* res, const int* shape, size_t shape_num, const mlx_array vals, mlx_dtype dtype, const mlx_stream) {
+    REQ_ARR(vals, "mlx_full");
+    OMX_REQUIRE(A(vals)->size() == 1, "mlx_full: only a scalar fill value is supported (got %zu elements)", A(vals)->size());
+    std::vector<int> sh(shape, shape + shape_num);
+    NEW_OR_FAIL(r, sh, dtype);
+    if (r->size()) {
+        fill_value_kernel<<<grid_for(r->size()), 256, 0, g_stream>>>(r->ptr(), dtype, A(vals)->ptr(), A(vals)->dt, r->size());
+        OMX_LAUNCH_CHECK();
+    }
+    return assign(res, r);
+}
+int mlx_ones(mlx_array* res, const int* shape, size_t shape_num, mlx_dtype dtype, const mlx_stream s) {
+    const float one = 1.0f;
+    mlx_array v = mlx_array_new_data(&one, nullptr, 0, MLX_FLOAT32);
+    OMX_REQUIRE(v.ctx, "mlx_ones: out of device memory");
+    const int rc = mlx_full(res, shape, shape_num, v, dtype, s);
+    mlx_array_free(v);
+    return rc;
+}
+int mlx_where(mlx_array* res, const mlx_array condition, const mlx_array x, const mlx_array y, const mlx_stream) {
+    REQ_ARR(condition, "mlx_where"); REQ_ARR(x, "mlx_where"); REQ_ARR(y, "mlx_where");
+    const Arr &c = *A(condition), &a = *A(x), &b = *A(y);
+    // broadcast (condition, x) and (that shape, y) to one shape: the two index tables share the output shape
+    std::vector<int> sh1, shape;
+    Idx t1;
+    if (broadcast2(c, a, "mlx_where", &sh1, &t1)) return 1;
+    Arr probe;
+    probe.shape = sh1; probe.dt = c.dt;
+    probe.strides.assign(sh1.size(), 0);
+    Idx t2;
+    if (broadcast2(probe, b, "mlx_where", &shape, &t2)) return 1;
+    // re-derive the strides of condition and x against the FINAL shape
+    Idx ixc, ixy;
+    if (fill_idx(ixc, shape) || fill_idx(ixy, shape)) return 1;
+    const int nd = (int)shape.size();
+    auto stride_of = [&](const Arr& t, int i) -> long long {
+        const int it = i - (nd - (int)t.shape.size());
+        return (it >= 0 && t.shape[it] != 1) ? (long long)t.strides[it] : 0;
+    };
+    for (int i = 0; i < nd; ++i) { ixc.sa[i] = stride_of(c, i); ixc.sb[i] = stride_of(a, i); ixy.sb[i] = stride_of(b, i); }
+    const mlx_dtype odt = promote(a.dt, b.dt);
+    NEW_OR_FAIL(r, shape, odt);
+    if (r->size()) {
+        where_kernel<<<grid_for(r->size()), 256, 0, g_stream>>>(r->ptr(), odt, c.ptr(), c.dt, a.ptr(), a.dt, b.ptr(), b.dt, ixc, ixy, r->size());
+        OMX_LAUNCH_CHECK();
+    }
+    return assign(res, r);
+}
+int mlx_clip(mlx_array* res, const mlx_array a, const mlx_array a_min, const mlx_array a_max, const mlx_stream s) {
+    REQ_ARR(a, "mlx_clip");
+    OMX_REQUIRE(a_min.ctx || a_max.ctx, "mlx_clip: at least one of a_min and a_max must be given");
+    mlx_array lo = mlx_array_new();
+    if (a_min.ctx) {
+        if (mlx_maximum(&lo, a, a_min, s)) { mlx_array_free(lo); return 1; }
+    }
+    const mlx_array mid = a_min.ctx ? lo : a;
+    const int rc = a_max.ctx ? mlx_minimum(res, mid, a_max, s) : mlx_array_set(res, mid);
+    mlx_array_free(lo);
+    return rc;
 }
 int mlx_argsort_axis(mlx_array* res, const mlx_array a, int axis, const mlx_stream) {
     REQ_ARR(a, "mlx_argsort_axis");

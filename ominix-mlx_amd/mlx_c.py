@@ -149,6 +149,7 @@ SIGNATURES = {
     "mlx_slice": (c_int, [P_ARR, mlx_array, P_INT, c_size_t, P_INT, c_size_t, P_INT, c_size_t, mlx_stream]),
     "mlx_slice_update": (c_int, [P_ARR, mlx_array, mlx_array, P_INT, c_size_t, P_INT, c_size_t, P_INT, c_size_t, mlx_stream]),
     "mlx_concatenate_axis": (c_int, [P_ARR, mlx_vector_array, c_int, mlx_stream]),
+    "mlx_concatenate": (c_int, [P_ARR, mlx_vector_array, mlx_stream]),
     "mlx_zeros": (c_int, [P_ARR, P_INT, c_size_t, c_int, mlx_stream]),
     "mlx_take_axis": (c_int, [P_ARR, mlx_array, mlx_array, c_int, mlx_stream]),
     "mlx_argmax_axis": (c_int, [P_ARR, mlx_array, c_int, c_bool, mlx_stream]),
@@ -246,6 +247,65 @@ SIGNATURES = {
     "mlx_minimum": (c_int, [P_ARR, mlx_array, mlx_array, mlx_stream]),
     "mlx_floor_divide": (c_int, [P_ARR, mlx_array, mlx_array, mlx_stream]),
     "mlx_cos": (c_int, [P_ARR, mlx_array, mlx_stream]),
+    "mlx_abs": (c_int, [P_ARR, mlx_array, mlx_stream]),
+    "mlx_sqrt": (c_int, [P_ARR, mlx_array, mlx_stream]),
+    "mlx_rsqrt": (c_int, [P_ARR, mlx_array, mlx_stream]),
+    "mlx_square": (c_int, [P_ARR, mlx_array, mlx_stream]),
+    "mlx_log": (c_int, [P_ARR, mlx_array, mlx_stream]),
+    "mlx_log2": (c_int, [P_ARR, mlx_array, mlx_stream]),
+    "mlx_log10": (c_int, [P_ARR, mlx_array, mlx_stream]),
+    "mlx_log1p": (c_int, [P_ARR, mlx_array, mlx_stream]),
+    "mlx_expm1": (c_int, [P_ARR, mlx_array, mlx_stream]),
+    "mlx_tanh": (c_int, [P_ARR, mlx_array, mlx_stream]),
+    "mlx_sinh": (c_int, [P_ARR, mlx_array, mlx_stream]),
+    "mlx_cosh": (c_int, [P_ARR, mlx_array, mlx_stream]),
+    "mlx_tan": (c_int, [P_ARR, mlx_array, mlx_stream]),
+    "mlx_arcsin": (c_int, [P_ARR, mlx_array, mlx_stream]),
+    "mlx_arccos": (c_int, [P_ARR, mlx_array, mlx_stream]),
+    "mlx_arctan": (c_int, [P_ARR, mlx_array, mlx_stream]),
+    "mlx_arcsinh": (c_int, [P_ARR, mlx_array, mlx_stream]),
+    "mlx_arccosh": (c_int, [P_ARR, mlx_array, mlx_stream]),
+    "mlx_arctanh": (c_int, [P_ARR, mlx_array, mlx_stream]),
+    "mlx_erf": (c_int, [P_ARR, mlx_array, mlx_stream]),
+    "mlx_reciprocal": (c_int, [P_ARR, mlx_array, mlx_stream]),
+    "mlx_floor": (c_int, [P_ARR, mlx_array, mlx_stream]),
+    "mlx_ceil": (c_int, [P_ARR, mlx_array, mlx_stream]),
+    "mlx_sign": (c_int, [P_ARR, mlx_array, mlx_stream]),
+    "mlx_isnan": (c_int, [P_ARR, mlx_array, mlx_stream]),
+    "mlx_isinf": (c_int, [P_ARR, mlx_array, mlx_stream]),
+    "mlx_isfinite": (c_int, [P_ARR, mlx_array, mlx_stream]),
+    "mlx_isposinf": (c_int, [P_ARR, mlx_array, mlx_stream]),
+    "mlx_isneginf": (c_int, [P_ARR, mlx_array, mlx_stream]),
+    "mlx_logical_not": (c_int, [P_ARR, mlx_array, mlx_stream]),
+    "mlx_round": (c_int, [P_ARR, mlx_array, c_int, mlx_stream]),
+    "mlx_not_equal": (c_int, [P_ARR, mlx_array, mlx_array, mlx_stream]),
+    "mlx_logical_or": (c_int, [P_ARR, mlx_array, mlx_array, mlx_stream]),
+    "mlx_power": (c_int, [P_ARR, mlx_array, mlx_array, mlx_stream]),
+    "mlx_remainder": (c_int, [P_ARR, mlx_array, mlx_array, mlx_stream]),
+    "mlx_logaddexp": (c_int, [P_ARR, mlx_array, mlx_array, mlx_stream]),
+    "mlx_max_axis": (c_int, [P_ARR, mlx_array, c_int, c_bool, mlx_stream]),
+    "mlx_all_axis": (c_int, [P_ARR, mlx_array, c_int, c_bool, mlx_stream]),
+    "mlx_any_axis": (c_int, [P_ARR, mlx_array, c_int, c_bool, mlx_stream]),
+    "mlx_logsumexp_axis": (c_int, [P_ARR, mlx_array, c_int, c_bool, mlx_stream]),
+    "mlx_max": (c_int, [P_ARR, mlx_array, c_bool, mlx_stream]),
+    "mlx_min": (c_int, [P_ARR, mlx_array, c_bool, mlx_stream]),
+    "mlx_mean": (c_int, [P_ARR, mlx_array, c_bool, mlx_stream]),
+    "mlx_sum": (c_int, [P_ARR, mlx_array, c_bool, mlx_stream]),
+    "mlx_all": (c_int, [P_ARR, mlx_array, c_bool, mlx_stream]),
+    "mlx_any": (c_int, [P_ARR, mlx_array, c_bool, mlx_stream]),
+    "mlx_logsumexp": (c_int, [P_ARR, mlx_array, c_bool, mlx_stream]),
+    "mlx_stop_gradient": (c_int, [P_ARR, mlx_array, mlx_stream]),
+    "mlx_sort_axis": (c_int, [P_ARR, mlx_array, c_int, mlx_stream]),
+    "mlx_sort": (c_int, [P_ARR, mlx_array, mlx_stream]),
+    "mlx_broadcast_to": (c_int, [P_ARR, mlx_array, P_INT, c_size_t, mlx_stream]),
+    "mlx_min_axis": (c_int, [P_ARR, mlx_array, c_int, c_bool, mlx_stream]),
+    "mlx_mean_axis": (c_int, [P_ARR, mlx_array, c_int, c_bool, mlx_stream]),
+    "mlx_swapaxes": (c_int, [P_ARR, mlx_array, c_int, c_int, mlx_stream]),
+    "mlx_moveaxis": (c_int, [P_ARR, mlx_array, c_int, c_int, mlx_stream]),
+    "mlx_full": (c_int, [P_ARR, P_INT, c_size_t, mlx_array, c_int, mlx_stream]),
+    "mlx_ones": (c_int, [P_ARR, P_INT, c_size_t, c_int, mlx_stream]),
+    "mlx_where": (c_int, [P_ARR, mlx_array, mlx_array, mlx_array, mlx_stream]),
+    "mlx_clip": (c_int, [P_ARR, mlx_array, mlx_array, mlx_array, mlx_stream]),
     "mlx_sin": (c_int, [P_ARR, mlx_array, mlx_stream]),
     "mlx_sum_axis": (c_int, [P_ARR, mlx_array, c_int, c_bool, mlx_stream]),
     "mlx_argsort_axis": (c_int, [P_ARR, mlx_array, c_int, mlx_stream]),
@@ -580,6 +640,56 @@ greater, greater_equal, less, less_equal, equal = (_bin(lib.mlx_greater), _bin(l
                                                    _bin(lib.mlx_less_equal), _bin(lib.mlx_equal))
 logical_and, maximum, minimum, floor_divide = _bin(lib.mlx_logical_and), _bin(lib.mlx_maximum), _bin(lib.mlx_minimum), _bin(lib.mlx_floor_divide)
 def cos(a): return Array.op(lib.mlx_cos, a.h, default_stream())
+
+
+def unary_op(name, a):
+    """ops.h elementwise math / predicates by name: abs sqrt rsqrt square log log2 log10 log1p expm1 tanh ... isnan ... logical_not."""
+    return Array.op(getattr(lib, "mlx_" + name), a.h, default_stream())
+
+
+def binary_op(name, a, b):
+    """not_equal logical_or power remainder logaddexp (and the comparison / max / min family)."""
+    return Array.op(getattr(lib, "mlx_" + name), a.h, b.h, default_stream())
+
+
+def reduce_axis_op(name, a, axis, keepdims=False):
+    """all_axis any_axis logsumexp_axis (and max / min / mean / sum _axis) by name."""
+    return Array.op(getattr(lib, "mlx_" + name), a.h, axis, keepdims, default_stream())
+
+
+def reduce_all_op(name, a, keepdims=False):
+    """max min mean sum all any logsumexp over the whole array."""
+    return Array.op(getattr(lib, "mlx_" + name), a.h, keepdims, default_stream())
+
+
+def sort_axis(a, axis): return Array.op(lib.mlx_sort_axis, a.h, axis, default_stream())
+def sort(a): return Array.op(lib.mlx_sort, a.h, default_stream())
+def stop_gradient(a): return Array.op(lib.mlx_stop_gradient, a.h, default_stream())
+
+
+def broadcast_to(a, shape):
+    s, n = _ints(shape)
+    return Array.op(lib.mlx_broadcast_to, a.h, s, n, default_stream())
+
+
+def round_(a, decimals=0): return Array.op(lib.mlx_round, a.h, decimals, default_stream())
+def max_axis(a, axis, keepdims=False): return Array.op(lib.mlx_max_axis, a.h, axis, keepdims, default_stream())
+def min_axis(a, axis, keepdims=False): return Array.op(lib.mlx_min_axis, a.h, axis, keepdims, default_stream())
+def mean_axis(a, axis, keepdims=False): return Array.op(lib.mlx_mean_axis, a.h, axis, keepdims, default_stream())
+def swapaxes(a, axis1, axis2): return Array.op(lib.mlx_swapaxes, a.h, axis1, axis2, default_stream())
+def moveaxis(a, source, destination): return Array.op(lib.mlx_moveaxis, a.h, source, destination, default_stream())
+def where(cond, x, y): return Array.op(lib.mlx_where, cond.h, x.h, y.h, default_stream())
+def clip(a, lo=None, hi=None): return Array.op(lib.mlx_clip, a.h, _h(lo), _h(hi), default_stream())
+
+
+def full(shape, value, dtype):
+    s, n = _ints(shape)
+    return Array.op(lib.mlx_full, s, n, value.h, dtype, default_stream())
+
+
+def ones(shape, dtype):
+    s, n = _ints(shape)
+    return Array.op(lib.mlx_ones, s, n, dtype, default_stream())
 def sin(a): return Array.op(lib.mlx_sin, a.h, default_stream())
 def arange(start, stop, step=1.0, dtype=INT32): return Array.op(lambda res: lib.mlx_arange(res, float(start), float(stop), float(step), dtype, default_stream()))
 def sum_axis(a, axis, keepdims=False): return Array.op(lib.mlx_sum_axis, a.h, axis, keepdims, default_stream())

@@ -266,3 +266,101 @@ def test_load_safetensors_through_the_map_iterators(mx, tmp_path):
     open(str(tmp_path / "cut.safetensors"), "wb").write(blob[:len(blob) - 40])
     with pytest.raises(Exception, match="truncated"):
         mx.load_safetensors(str(tmp_path / "cut.safetensors"))
+
+
+def test_elementwise_math_reductions_views_and_fills(mx):
+    """ops.h beyond the four callers' path (link stubs until round 4): elementwise math and predicates, not_equal / logical_or / power /
+    remainder / logaddexp, max / min / mean over an axis, swapaxes / moveaxis views, ones / full, where with broadcasting, clip --
+    against numpy, in float32 and on a strided (transposed) view; dtypes as MLX gives them (predicates bool, mean of ints float32)."""
+    rng = np.random.default_rng(7)
+    x = (rng.standard_normal((3, 5, 4)) * 1.5).astype(np.float32)
+    X = mx.Array.from_numpy(x, mx.FLOAT32)
+    pos = np.abs(x) + 0.1
+    P = mx.Array.from_numpy(pos, mx.FLOAT32)
+    unit = np.clip(x / 4.0, -0.9, 0.9).astype(np.float32)
+    U = mx.Array.from_numpy(unit, mx.FLOAT32)
+    import math
+    cases = [("abs", X, np.abs(x)), ("sqrt", P, np.sqrt(pos)), ("rsqrt", P, 1 / np.sqrt(pos)), ("square", X, x * x), ("log", P, np.log(pos)),
+             ("log2", P, np.log2(pos)), ("log10", P, np.log10(pos)), ("log1p", P, np.log1p(pos)), ("expm1", X, np.expm1(x)),
+             ("tanh", X, np.tanh(x)), ("sinh", X, np.sinh(x)), ("cosh", X, np.cosh(x)), ("tan", U, np.tan(unit)),
+             ("arcsin", U, np.arcsin(unit)), ("arccos", U, np.arccos(unit)), ("arctan", X, np.arctan(x)), ("arcsinh", X, np.arcsinh(x)),
+             ("arccosh", mx.Array.from_numpy(pos + 1, mx.FLOAT32), np.arccosh(pos + 1)), ("arctanh", U, np.arctanh(unit)),
+             ("erf", X, np.vectorize(math.erf)(x).astype(np.float32)), ("reciprocal", P, 1 / pos), ("floor", X, np.floor(x)),
+             ("ceil", X, np.ceil(x)), ("sign", X, np.sign(x))]
+    for name, arr, want in cases:
+        got = mx.unary_op(name, arr).numpy()
+        assert got.dtype == np.float32
+        np.testing.assert_allclose(got, want, rtol=3e-6, atol=3e-6, err_msg=name)
+    np.testing.assert_array_equal(mx.round_(X).numpy(), np.rint(x))
+    special = np.array([0.0, np.nan, np.inf, -np.inf, 1.5], np.float32)
+    S = mx.Array.from_numpy(special, mx.FLOAT32)
+    for name, want in (("isnan", np.isnan(special)), ("isinf", np.isinf(special)), ("isfinite", np.isfinite(special)),
+                       ("isposinf", np.isposinf(special)), ("isneginf", np.isneginf(special)), ("logical_not", special == 0)):
+        got = mx.unary_op(name, S)
+        assert got.dtype == mx.BOOL
+        np.testing.assert_array_equal(got.numpy(), want, err_msg=name)
+    y = (rng.standard_normal((5, 1)) * 2).astype(np.float32)           # broadcasts against x over two axes
+    Y = mx.Array.from_numpy(y, mx.FLOAT32)
+    np.testing.assert_array_equal(mx.binary_op("not_equal", X, Y).numpy(), x != y)
+    np.testing.assert_array_equal(mx.binary_op("logical_or", X, mx.unary_op("logical_not", X)).numpy(), np.ones_like(x, bool))
+    np.testing.assert_allclose(mx.binary_op("power", P, Y).numpy(), np.power(pos, y), rtol=1e-5)
+    np.testing.assert_allclose(mx.binary_op("remainder", X, P).numpy(), np.remainder(x, pos), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(mx.binary_op("logaddexp", X, Y).numpy(), np.logaddexp(x, y), rtol=1e-6, atol=1e-6)
+    ia, ib = np.array([7, -7, 9, 2], np.int32), np.array([3, 3, -4, 5], np.int32)
+    IA, IB = mx.Array.from_numpy(ia, mx.INT32), mx.Array.from_numpy(ib, mx.INT32)
+    np.testing.assert_array_equal(mx.binary_op("remainder", IA, IB).numpy(), np.remainder(ia, ib))
+    np.testing.assert_array_equal(mx.binary_op("power", mx.Array.from_numpy(np.array([2, 3, -2, 5], np.int32), mx.INT32),
+                                               mx.Array.from_numpy(np.array([10, 4, 3, 0], np.int32), mx.INT32)).numpy(), [1024, 81, -8, 1])
+    XT = mx.swapaxes(X, 0, 2)                                           # a strided view feeds the same kernels
+    assert XT.shape == (4, 5, 3)
+    np.testing.assert_array_equal(XT.numpy(), np.swapaxes(x, 0, 2))
+    np.testing.assert_array_equal(mx.moveaxis(X, 0, -1).numpy(), np.moveaxis(x, 0, -1))
+    np.testing.assert_allclose(mx.unary_op("tanh", XT).numpy(), np.tanh(np.swapaxes(x, 0, 2)), rtol=3e-6, atol=3e-6)
+    for ax in (0, 1, -1):
+        np.testing.assert_array_equal(mx.max_axis(X, ax).numpy(), x.max(axis=ax))
+        np.testing.assert_array_equal(mx.min_axis(XT, ax, True).numpy(), np.swapaxes(x, 0, 2).min(axis=ax, keepdims=True))
+        np.testing.assert_allclose(mx.mean_axis(X, ax).numpy(), x.mean(axis=ax), rtol=1e-6, atol=1e-6)
+    m = mx.mean_axis(IA, 0)
+    assert m.dtype == mx.FLOAT32 and m.numpy() == pytest.approx(ia.mean())
+    assert mx.max_axis(mx.Array.from_numpy(np.array([1.0, np.nan, 3.0], np.float32), mx.FLOAT32), 0).numpy() != mx.max_axis(mx.Array.from_numpy(np.array([1.0, np.nan, 3.0], np.float32), mx.FLOAT32), 0).numpy()   # NaN propagates
+    ones = mx.ones((2, 3), mx.BFLOAT16)
+    assert ones.dtype == mx.BFLOAT16 and (ones.numpy() == 1).all()
+    np.testing.assert_array_equal(mx.full((4,), mx.Array.from_numpy(np.array(2.5, np.float32), mx.FLOAT32), mx.FLOAT32).numpy(), np.full(4, 2.5, np.float32))
+    cond = x > 0
+    np.testing.assert_array_equal(mx.where(mx.Array.from_numpy(cond, mx.BOOL), X, Y).numpy(), np.where(cond, x, y))
+    np.testing.assert_array_equal(mx.clip(X, mx.Array.from_numpy(np.array(-1.0, np.float32), mx.FLOAT32), mx.Array.from_numpy(np.array(0.5, np.float32), mx.FLOAT32)).numpy(),
+                                  np.clip(x, -1.0, 0.5))
+    np.testing.assert_array_equal(mx.clip(X, None, mx.Array.from_numpy(np.array(0.5, np.float32), mx.FLOAT32)).numpy(), np.minimum(x, 0.5))
+    with pytest.raises(Exception):
+        mx.round_(X, 2)
+
+
+def test_whole_array_reductions_sort_and_broadcast_views(mx):
+    """ops.h: max / min / mean / sum / all / any / logsumexp over the whole array and over an axis, sort (values in stable argsort
+    order), stop_gradient (the identity at inference), broadcast_to as a zero-stride view -- against numpy."""
+    from scipy.special import logsumexp
+    rng = np.random.default_rng(11)
+    x = rng.standard_normal((4, 6, 5)).astype(np.float32)
+    X = mx.Array.from_numpy(x, mx.FLOAT32)
+    for name, fn in (("max", np.max), ("min", np.min), ("mean", np.mean), ("sum", np.sum)):
+        got = mx.reduce_all_op(name, X)
+        assert got.shape == ()
+        np.testing.assert_allclose(got.numpy(), fn(x), rtol=2e-6, atol=2e-6, err_msg=name)
+        assert mx.reduce_all_op(name, X, True).shape == (1, 1, 1)
+    np.testing.assert_allclose(mx.reduce_all_op("logsumexp", X).numpy(), logsumexp(x), rtol=2e-6)
+    np.testing.assert_allclose(mx.reduce_axis_op("logsumexp_axis", X, 1).numpy(), logsumexp(x, axis=1), rtol=2e-6, atol=2e-6)
+    b = x > 0.5
+    B = mx.Array.from_numpy(b, mx.BOOL)
+    np.testing.assert_array_equal(mx.reduce_axis_op("all_axis", B, 2).numpy(), b.all(axis=2))
+    np.testing.assert_array_equal(mx.reduce_axis_op("any_axis", B, 0, True).numpy(), b.any(axis=0, keepdims=True))
+    assert bool(mx.reduce_all_op("any", B).numpy()) == bool(b.any()) and bool(mx.reduce_all_op("all", B).numpy()) == bool(b.all())
+    np.testing.assert_array_equal(mx.sort_axis(X, 1).numpy(), np.sort(x, axis=1, kind="stable"))
+    np.testing.assert_array_equal(mx.sort(X).numpy(), np.sort(x.ravel(), kind="stable"))
+    np.testing.assert_array_equal(mx.stop_gradient(X).numpy(), x)
+    v = rng.standard_normal((6, 1)).astype(np.float32)
+    V = mx.broadcast_to(mx.Array.from_numpy(v, mx.FLOAT32), (4, 6, 5))
+    assert V.shape == (4, 6, 5)
+    np.testing.assert_array_equal(V.numpy(), np.broadcast_to(v, (4, 6, 5)))
+    np.testing.assert_array_equal(mx.binary_op("maximum", X, V).numpy(), np.maximum(x, v))
+    with pytest.raises(Exception):
+        mx.broadcast_to(X, (4, 6, 7))

@@ -1016,6 +1016,10 @@ __global__ void encoder_mask_kernel(bf16_t* mask, const uint8_t* am, int T) {
 
 int prefill_prefix_batched(omx_qwen3 m, int T, int off, const EncodeOpts* enc = nullptr, bool full_last = false) {
     const omx_qwen3_config& c = m->cfg;
+    // the matrix-core pass is bfloat16 (and, for sparse-MoE models under tensor parallelism, unsharded): those models take their prompts
+    // through the decode step (omx_qwen3_prefill) and have no batched encode / verify
+    OMX_REQUIRE(!c.quant_scales_f16 && !(c.num_experts > 0 && c.tp_size > 1),
+                "batched prompt pass: not available for float16 checkpoints and expert-tensor-parallel models (their prompts run through the decode step)");
     hipStream_t s = m->stream;
     const int hd = c.hidden_size, D = c.head_dim, H = m->H, Hkv = m->Hkv, I = m->I;
     if (T > m->pf_cap) {

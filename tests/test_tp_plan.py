@@ -146,3 +146,41 @@ def test_shard_shapes():
         np.testing.assert_array_equal(tp.shard("model.layers.0.self_attn.k_proj.weight", k, r, 8, 4, 16), k[(r // 2) * 16:(r // 2 + 1) * 16])
     with pytest.raises(ValueError, match="cannot be replicated"):
         tp.check_divisible(num_attention_heads=24, num_key_value_heads=3, intermediate_size=1024, vocab_size=1024, world=8)  # 8 ranks over 3 KV heads
+
+
+def test_expert_tensor_parallel_shard_plan():
+    """Round 4: the sparse-MoE engine under tensor parallelism shards every expert's intermediate columns (tp.py EXPERT_ROW_SPLIT /
+    EXPERT_COL_SPLIT); the router stays whole.  The ranks' UNROUNDED partial down projections of a routed slot sum to the single-device
+    expert output -- the identity `omx_moe_block_partial_tp` + all-reduce + `omx_moe_combine_slots` implement -- checked here in float64
+    on the oracle's SwitchGLU with the SwiGLU activation rounded per element (column-local: identical on a shard)."""
+    import omx_import
+    omx_import.load_package()
+    from ominix_mlx_amd import tp
+    from oracle import ref_moe as rm
+    E, I, h, world = 4, 256, 128, 4
+    g = np.random.default_rng(3)
+    wg, wu = rc.bf16_round(g.standard_normal((E, I, h)) * 0.05), rc.bf16_round(g.standard_normal((E, I, h)) * 0.05)
+    wd = rc.bf16_round(g.standard_normal((E, h, I)) * 0.05)
+    gate = rc.bf16_round(g.standard_normal((E, h)) * 0.05)
+    for r in range(world):
+        assert tp.shard("model.layers.0.block_sparse_moe.switch_mlp.gate_proj.weight", wg, r, world).shape == (E, I // world, h)
+        np.testing.assert_array_equal(tp.shard("model.layers.0.mlp.switch_mlp.down_proj.weight", wd, r, world), wd[:, :, r * 64:(r + 1) * 64])
+        assert tp.shard("model.layers.0.block_sparse_moe.gate.weight", gate, r, world) is gate
+    x = rc.bf16_round(g.standard_normal((1, h)))
+    inds = np.array([[2, 0]])
+    full = np.zeros((2, h))
+    for j, e in enumerate(inds[0]):   # the single-device expert in float64 with the bf16 activation: what the slots' partials must sum to
+        act = rc.fused_swiglu(rc.linear(x, wu[e], None, "bf16"), rc.linear(x, wg[e], None, "bf16"), "bf16")
+        full[j] = act[0].astype(np.float64) @ wd[e].astype(np.float64).T
+    part = np.zeros((2, h))
+    for r in range(world):
+        sg = tp.shard("l.switch_mlp.gate_proj.weight", wg, r, world)
+        su = tp.shard("l.switch_mlp.up_proj.weight", wu, r, world)
+        sd = tp.shard("l.switch_mlp.down_proj.weight", wd, r, world)
+        for j, e in enumerate(inds[0]):
+            act = rc.fused_swiglu(rc.linear(x, su[e], None, "bf16"), rc.linear(x, sg[e], None, "bf16"), "bf16")
+            part[j] += act[0].astype(np.float64) @ sd[e].astype(np.float64).T
+    np.testing.assert_allclose(part, full, rtol=1e-12, atol=1e-12)
+    # and the rounded result is the oracle's SwitchGLU output for those slots
+    want = rm.switch_glu(x, inds, wg, wu, wd, "bf16")[0]
+    np.testing.assert_array_equal(rc.bf16_round(part), want)

@@ -306,14 +306,12 @@ def mixtral_secondary(omx, steps=64, warm=8, n_prompt=2048, rank=0, world=1, com
     pass with a [T, hidden] all-reduce per layer); every rank calls this, the time is the MAX over ranks.
     mode "etp": expert TENSOR parallel instead -- attention heads and every expert's intermediate columns sharded over the ranks
     (batch-1 decode under expert parallelism streams a token's two experts from at most two ranks; here all ranks stream 1 / world
-    of them); the prompt then runs token by token, so a 128-token prompt is used."""
+    of them); the prompt is one batched pass there too (all experts at this rank's columns, the same f32 [T, hidden] all-reduce)."""
     import numpy as np
     from ominix_mlx_amd import engine
     cfg = dict(hidden_size=4096, num_hidden_layers=32, intermediate_size=14336, num_attention_heads=32, num_key_value_heads=8,
                head_dim=128, vocab_size=32000, rms_norm_eps=1e-5, rope_theta=1e6, num_experts=8, num_experts_per_tok=2,
                moe_intermediate_size=14336, moe_mode="mixtral", qk_norm=False)
-    if mode == "etp":
-        n_prompt = min(n_prompt, 128)
     if comm is not None and mode == "etp":
         m = engine.Model(max_context=n_prompt + warm + steps + 8, tp_rank=rank, tp_size=world, **cfg)
         m.set_comm(comm[1], comm[2])

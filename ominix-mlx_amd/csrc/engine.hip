@@ -1016,10 +1016,9 @@ __global__ void encoder_mask_kernel(bf16_t* mask, const uint8_t* am, int T) {
 
 int prefill_prefix_batched(omx_qwen3 m, int T, int off, const EncodeOpts* enc = nullptr, bool full_last = false) {
     const omx_qwen3_config& c = m->cfg;
-    // the matrix-core pass is bfloat16 (and, for sparse-MoE models under tensor parallelism, unsharded): those models take their prompts
-    // through the decode step (omx_qwen3_prefill) and have no batched encode / verify
-    OMX_REQUIRE(!c.quant_scales_f16 && !(c.num_experts > 0 && c.tp_size > 1),
-                "batched prompt pass: not available for float16 checkpoints and expert-tensor-parallel models (their prompts run through the decode step)");
+    // the matrix-core pass is bfloat16: float16 checkpoints take their prompts through the decode step (omx_qwen3_prefill) and have
+    // no batched encode / verify
+    OMX_REQUIRE(!c.quant_scales_f16, "batched prompt pass: not available for float16 checkpoints (their prompts run through the decode step)");
     hipStream_t s = m->stream;
     const int hd = c.hidden_size, D = c.head_dim, H = m->H, Hkv = m->Hkv, I = m->I;
     if (T > m->pf_cap) {
@@ -1149,12 +1148,16 @@ int prefill_prefix_batched(omx_qwen3 m, int T, int off, const EncodeOpts* enc = 
                                             c.num_experts, c.num_experts_per_tok, c.moe_mode, c.norm_topk_prob, c.quant_group,
                                             c.quant_bits, s))
                     return 1;
-            } else if (c.ep_size > 1) {
+            } else if (c.ep_size > 1 || c.tp_size > 1) {
+                // expert TENSOR parallel: the same launches over ALL experts at this rank's 1 / tp of their intermediate columns -- the f32
+                // partial of every token's weighted sum is all-reduced like the expert-parallel one (each rank's partial products rounded
+                // to bf16 before the sum: the dense model's row-split rounding, not the decode step's single-device one).
                 // expert parallel: attention is replicated, so every rank already holds all T rows -- there is
                 // nothing to dispatch.  Each rank routes all rows, multiplies the slots of ITS experts (grouped matrix-core GEMMs over
                 // a device-side plan), and ONE all-reduce per layer sums the [T, hidden] f32 partials: the combine half of an
                 // all-to-all exchange, with the reduction done by the collective.  (Until round 3 a prompt under EP was T decode steps.)
-                const int el = c.num_experts / c.ep_size;
+                const bool etp = c.tp_size > 1;
+                const int el = etp ? c.num_experts : c.num_experts / c.ep_size;
                 if (!m->pf_ep_partial || m->pf_ep_cap < T) {
                     OMX_HIP_CHECK(hipStreamSynchronize(s));
                     if (m->pf_ep_partial) OMX_HIP_CHECK(hipFree(m->pf_ep_partial));
@@ -1162,10 +1165,10 @@ int prefill_prefix_batched(omx_qwen3 m, int T, int off, const EncodeOpts* enc = 
                     m->pf_ep_cap = std::max(T, m->pf_cap);
                 }
                 if (omx_moe_block_partial_ep(m->pf_ep_partial, m->pf_xn, nullptr, c.rms_norm_eps, nullptr, L.moe_gate, L.moe_wg, L.moe_wu, L.moe_wd,
-                                             T, hd, c.moe_intermediate_size, c.num_experts, c.num_experts_per_tok, c.moe_mode,
-                                             c.norm_topk_prob, c.ep_rank * el, el, s))
+                                             T, hd, etp ? m->moe_I : c.moe_intermediate_size, c.num_experts, c.num_experts_per_tok, c.moe_mode,
+                                             c.norm_topk_prob, etp ? 0 : c.ep_rank * el, el, s))
                     return 1;
-                OMX_REQUIRE(m->allreduce != nullptr, "ep_size > 1 but no communicator set (omx_qwen3_set_comm)");
+                OMX_REQUIRE(m->allreduce != nullptr, "ep_size / tp_size > 1 but no communicator set (omx_qwen3_set_comm)");
                 OMX_REQUIRE(m->allreduce(m->pf_ep_partial, m->pf_ep_partial, (size_t)T * hd, kNcclFloat32, kNcclSum, m->comm, s) == 0, "ncclAllReduce failed");
                 ep_fold_kernel<<<1024, 256, 0, s>>>(h, h2, m->pf_ep_partial, (int64_t)T * hd);
                 OMX_LAUNCH_CHECK();
@@ -1264,7 +1267,7 @@ int omx_qwen3_create(omx_qwen3* out, const omx_qwen3_config* cfg) {
     }
     if (c.num_experts > 0) {
         // tp_size > 1: expert TENSOR parallel -- attention sharded like the dense model, every expert's intermediate columns split over
-        // the ranks (decode streams 1 / tp of the two routed experts on every rank; prompts run token by token on this form)
+        // the ranks (decode streams 1 / tp of the two routed experts on every rank; prompts: the expert-parallel batched form over all experts)
         OMX_REQUIRE(c.tp_size == 1 || (c.ep_size <= 1 && !c.quant_bits && c.moe_intermediate_size % (64 * c.tp_size) == 0),
                     "InvalidConfig: expert tensor parallelism (tp_size %d with experts) needs bf16 weights, ep_size 1 and moe_intermediate_size %d divisible by 64 * tp_size",
                     c.tp_size, c.moe_intermediate_size);
@@ -1283,7 +1286,10 @@ int omx_qwen3_create(omx_qwen3* out, const omx_qwen3_config* cfg) {
         void* ws = nullptr;
         if (get_workspace(&ws, need)) return 1;
         if (c.ep_size > 1 && get_workspace_aux(&ws, need, m->stream)) return 1;   // the expert-parallel block's per-stream scratch (moe.hip)
-        if (c.tp_size > 1 && get_workspace_aux(&ws, (size_t)c.num_experts_per_tok * m->moe_I * 2 + 256, m->stream)) return 1;
+        if (c.tp_size > 1) {   // expert tensor parallel: the batched pass's plan + slot buffers at this rank's column count
+            omx_moe_workspace_bytes(m->cap, c.hidden_size, m->moe_I, c.num_experts, c.num_experts_per_tok, &need);
+            if (get_workspace_aux(&ws, need, m->stream)) return 1;
+        }
         if (dev_alloc(m, &m->moe_xn, (size_t)c.hidden_size) || dev_alloc(m, &m->moe_out, (size_t)c.hidden_size)) return 1;
         if (c.tp_size > 1 && (dev_alloc(m, &m->moe_y, (size_t)c.num_experts_per_tok * c.hidden_size) ||
                               dev_alloc(m, &m->moe_inds, (size_t)c.num_experts_per_tok) || dev_alloc(m, &m->moe_scores, (size_t)c.num_experts_per_tok)))
@@ -1658,7 +1664,7 @@ int omx_qwen3_prefill(omx_qwen3 m, const uint32_t* prompt, int n_prompt, uint32_
     const char* serial_env = getenv("OMX_PREFILL_SERIAL");
     // tensor-parallel engines run the batched matrix-core prefill on their shards with two all-reduces per layer, expert-parallel ones
     // with one all-reduce of the MoE block's [T, hidden] partial per layer (round 3; token-serial before)
-    const bool serial = (serial_env && serial_env[0] == '1') || n_prompt < 2 || (m->cfg.num_experts > 0 && m->cfg.tp_size > 1) || m->cfg.quant_scales_f16;   // (expert tensor parallel, float16 models: the decode form only)
+    const bool serial = (serial_env && serial_env[0] == '1') || n_prompt < 2 || m->cfg.quant_scales_f16;   // (float16 models: the decode form only)
     if (prepare_step(m, serial ? off : off + n_prompt - 1)) return 1;   // the first step this call will run (graphs are per context bucket)
     OMX_HIP_CHECK(hipMemcpyAsync(m->prompt_dev, prompt, (size_t)n_prompt * 4, hipMemcpyHostToDevice, m->stream));
     StepState st;

@@ -235,33 +235,37 @@ def test_expert_parallel_engine_on_one_gpu(omx, monkeypatch, name, world, use_sy
     group.close()
 
 
-@pytest.mark.parametrize("name,world", [("mixtral", 2), ("qwen3_moe", 2), ("mixtral", 4)])
-def test_expert_tensor_parallel_engine_on_one_gpu(omx, monkeypatch, name, world):
+@pytest.mark.parametrize("name,world,batched", [("mixtral", 2, False), ("qwen3_moe", 2, False), ("mixtral", 4, False),
+                                                ("mixtral", 2, True), ("qwen3_moe", 2, True), ("mixtral", 4, True)])
+def test_expert_tensor_parallel_engine_on_one_gpu(omx, monkeypatch, name, world, batched):
     """Expert TENSOR parallelism (round 4; tp_size > 1 on a sparse-MoE model): attention heads sharded like the dense model, every
     expert's intermediate columns split over the ranks (gate / up rows, down columns), router replicated, per layer one all-reduce of
     the O partial and one of the routed slots' f32 down partials, then the weighted sum with the single-device roundings.  What
     expert parallelism cannot do -- a token's two experts streaming from ALL ranks -- at the price of partial sums that round
     differently from the single-GPU dot products: every rank must agree with every other rank bit for bit (rank-ordered sums),
     the synthetic shards must equal the host-sharded checkpoint (tp.py expert rules), and the logits must stay within the engine's
-    bound of the single-GPU run (tokens equal wherever its top-1 margin allows)."""
+    bound of the single-GPU run (tokens equal wherever its top-1 margin allows).
+    batched: a 200-token prompt as ONE pass -- the expert-parallel grouped-GEMM form over all experts at this rank's columns, the f32
+    partial of every row's weighted sum all-reduced (engine.hip prefill_prefix_batched) -- against the single GPU's batched pass."""
     from ominix_mlx_amd import comm, engine
     cfg = CONFIGS[name]
     weights = rq.synth_weights(cfg)
-    prompt = synth.prompt_ids(20, cfg.vocab_size)
-    monkeypatch.setenv("OMX_PREFILL_SERIAL", "1")
-    single = _engine(omx, cfg)
+    n_prompt, ctx = (200, 512) if batched else (20, 256)
+    prompt = synth.prompt_ids(n_prompt, cfg.vocab_size)
+    monkeypatch.setenv("OMX_PREFILL_SERIAL", "0" if batched else "1")
+    single = _engine(omx, cfg, max_context=ctx)
     want = np.concatenate([[single.prefill(prompt)], single.decode(6)]).astype(np.uint32)
     want_logits = single.last_logits()
     single.close()
     results = {}
     for use_synth in (True, False):
-        group = comm.LoopbackGroup(world, 1 << 20)
+        group = comm.LoopbackGroup(world, max(1 << 20, n_prompt * cfg.hidden_size * 4))
         models = []
         for r in range(world):
             m = engine.Model(hidden_size=cfg.hidden_size, num_hidden_layers=cfg.num_hidden_layers, intermediate_size=cfg.intermediate_size,
                              num_attention_heads=cfg.num_attention_heads, num_key_value_heads=cfg.num_key_value_heads, head_dim=cfg.head_dim,
                              vocab_size=cfg.vocab_size, rms_norm_eps=cfg.rms_norm_eps, rope_theta=cfg.rope_theta,
-                             tie_word_embeddings=cfg.tie_word_embeddings, max_context=256, num_experts=cfg.num_experts,
+                             tie_word_embeddings=cfg.tie_word_embeddings, max_context=ctx, num_experts=cfg.num_experts,
                              num_experts_per_tok=cfg.num_experts_per_tok, moe_intermediate_size=cfg.moe_intermediate_size,
                              moe_mode=cfg.moe_mode, norm_topk_prob=cfg.norm_topk_prob, qk_norm=cfg.qk_norm, tp_rank=r, tp_size=world)
             m.synth_weights() if use_synth else m.load_weights(weights)

@@ -204,10 +204,11 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_nt_kernel(const GemmArgs a
 //   matrix core.  Hazards: a piece is re-staged two phases after the phase that reads it (at least two barriers
 //   after the reads of BOTH wave groups retired), and it is read one phase after the wait that retires it.
 namespace big {
-constexpr int TM = 256, TN = 256, TK = 64, NT = 512;
+constexpr int TN = 256, TK = 64, NT = 512;
 constexpr int HALF = 128 * TK * 2;           // bytes per half-tile
 constexpr int BUF = 4 * HALF;                // A0 | A1 | B0 | B1
 constexpr int SMEM = 2 * BUF;
+constexpr int smem_bytes(int tile_rows) { return 2 * (2 * (tile_rows / 2) * TK * 2 + 2 * HALF); }   // X pieces of tile_rows / 2 rows
 }  // namespace big
 
 #define OMX_BAR() asm volatile("s_barrier" ::: "memory")
@@ -217,11 +218,18 @@ constexpr int SMEM = 2 * BUF;
 // IMPL (with SW): implicit 3x3 convolution.  The A operand is a zero-bordered NHWC activation [(H+2), (W+2), C]; output
 // pixel (y, x) starts at padded pixel (y, x) and K tile t (64 wide, K = 9 * C ordered (tap, channel), C = 64 * 2^sh) reads
 // tap = t >> sh at channel (t & (2^sh - 1)) * 64 -- a wave-uniform offset per K tile instead of a materialised im2col matrix.
-template <int MF, bool SW = false, bool IMPL = false>
+// TMR = 128: a 128 x 256 tile with the same eight waves (2 x 4, each 64 x 64), phases and stagger -- for grids whose 256^2 tiles cover
+// at most half of the chip (the O / down projections of a 2 048-token prompt: 8 x 16 tiles); every output element is the same
+// MFMA chain as in the 256-row form, so the two are bit-identical.  X pieces are 64 rows (ONE 16-byte chunk per thread and stage).
+template <int MF, bool SW = false, bool IMPL = false, int TMR = 256>
 __global__ __launch_bounds__(big::NT) void gemm_bf16_nt_256_kernel(const GemmArgs a) {
     static_assert(!IMPL || SW, "the implicit-convolution staging lives in the segmented variant");
     static_assert(!SW || MF == 16, "the SwiGLU epilogue is written for the 16x16 accumulator layout");
+    static_assert(TMR == 256 || (TMR == 128 && !SW && MF == 16), "the 128-row tile exists in the plain form");
     using namespace big;
+    constexpr int WM = TMR / 2, XH = TMR / 4;      // rows per wave group, rows per wave group and half-piece
+    constexpr int NX = TMR / 128;                  // 16-byte chunks per thread of an X piece
+    constexpr int HALFX = (TMR / 2) * TK * 2;      // bytes per X piece
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wr = wave >> 2, wc = wave & 3;
@@ -275,7 +283,7 @@ __global__ __launch_bounds__(big::NT) void gemm_bf16_nt_256_kernel(const GemmArg
     }
     // grouped rows (MoE prefill): row tile tm is an entry of the device-built tile table -> (expert, first row inside its
     // segment of the expert-sorted order); rows are gathered through row_src, weights are the expert's slice of the stacks
-    int m0 = tm * TM, rows_valid = a.M, row_base = 0;
+    int m0 = tm * TMR, rows_valid = a.M, row_base = 0;
     size_t w_off = 0;
     const uint32_t* row_src = nullptr;
     if constexpr (SW) {
@@ -304,7 +312,7 @@ __global__ __launch_bounds__(big::NT) void gemm_bf16_nt_256_kernel(const GemmArg
             const int c = i * NT + threadIdx.x;
             const int row = c >> 3;
             const int kc = (c & 7) ^ (row & 7);
-            const int trow = (row >> 6) * 128 + sidx * 64 + (row & 63);
+            const int trow = (row / XH) * WM + sidx * XH + (row % XH);   // (X pieces: rows [0, TMR / 2), i < NX only)
             const int tcol = (row >> 5) * 64 + sidx * 32 + (row & 31);
             if constexpr (IMPL) {
                 const int p = min(m0 + trow, a.M - 1), py = p / a.sg.im_W, px = p - py * a.sg.im_W;
@@ -332,6 +340,13 @@ __global__ __launch_bounds__(big::NT) void gemm_bf16_nt_256_kernel(const GemmArg
         for (int i = 0; i < 2; ++i)
             __builtin_amdgcn_global_load_lds((glb_ptr_t)(src[i] + k0), (lds_ptr_t)(piece + (i * NT + wave * 64) * 16), 16, 0, 0);
     };
+    auto stage_x = [&](const bf16_t* const (&src)[2], int k0, unsigned char* piece) {
+#pragma unroll
+        for (int i = 0; i < NX; ++i)
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(src[i] + k0), (lds_ptr_t)(piece + (i * NT + wave * 64) * 16), 16, 0, 0);
+    };
+    // counted waits: every wait leaves the four most recent stages in flight (two X pieces of NX loads, two Y pieces of 2)
+#define OMX_WAIT_RING() do { if constexpr (NX == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); } while (0)
     // element offset of K tile t in the A operand
     auto kx = [&](int t) -> int {
         if constexpr (IMPL) {
@@ -343,10 +358,11 @@ __global__ __launch_bounds__(big::NT) void gemm_bf16_nt_256_kernel(const GemmArg
         }
     };
     // buffer layout: X0 | X1 | Y0 | Y1
-    constexpr int PX0 = 0, PX1 = HALF, PY0 = 2 * HALF, PY1 = 3 * HALF;
+    constexpr int PX0 = 0, PX1 = HALFX, PY0 = 2 * HALFX, PY1 = 2 * HALFX + HALF;
+    constexpr int BUFB = 2 * HALFX + 2 * HALF;    // bytes per ring buffer (= BUF at 256 rows)
 
     // accumulators: MF = 32 -> [4][2] tiles of 32x32 (16 regs each); MF = 16 -> [8][4] tiles of 16x16 (4 regs each)
-    constexpr int RT = 128 / MF, CT = 64 / MF, AR = MF * MF / 64;   // row tiles, col tiles, registers per tile
+    constexpr int RT = WM / MF, CT = 64 / MF, AR = MF * MF / 64;   // row tiles, col tiles, registers per tile
     constexpr int KS = TK / (MF == 32 ? 16 : 32);                     // MFMA k steps per K tile
     constexpr int KCH = MF == 32 ? 2 : 4;                            // 16-B chunks per k step
     constexpr int LR = MF == 32 ? 31 : 15;                           // lane -> row mask
@@ -361,14 +377,14 @@ __global__ __launch_bounds__(big::NT) void gemm_bf16_nt_256_kernel(const GemmArg
             for (int r = 0; r < AR; ++r) acc[i][j][r] = 0.f;
 
     // prologue: what the steady state would have issued before tile 0's first phase, in its order
-    stage(srcX[0], kx(0), smem + PX0);
+    stage_x(srcX[0], kx(0), smem + PX0);
     stage(srcY[0], 0, smem + PY0);
     stage(srcY[1], 0, smem + PY1);
-    stage(srcX[1], kx(0), smem + PX1);
+    stage_x(srcX[1], kx(0), smem + PX1);
     if (nt > 1) {
-        stage(srcX[0], kx(1), smem + BUF + PX0);
-        stage(srcY[0], TK, smem + BUF + PY0);
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // X0, Y0 of tile 0 have landed
+        stage_x(srcX[0], kx(1), smem + BUFB + PX0);
+        stage(srcY[0], TK, smem + BUFB + PY0);
+        OMX_WAIT_RING();   // X0, Y0 of tile 0 have landed
     } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
@@ -396,8 +412,8 @@ __global__ __launch_bounds__(big::NT) void gemm_bf16_nt_256_kernel(const GemmArg
         __builtin_amdgcn_sched_barrier(0);
     };
     for (int t = 0; t < nt; ++t) {
-        unsigned char* cur = smem + (t & 1) * BUF;
-        unsigned char* nxt = smem + ((t + 1) & 1) * BUF;
+        unsigned char* cur = smem + (t & 1) * BUFB;
+        unsigned char* nxt = smem + ((t + 1) & 1) * BUFB;
         const bool has1 = t + 1 < nt, has2 = t + 2 < nt;
         const int k1 = (t + 1) * TK, k2 = (t + 2) * TK;
         auto read_a = [&](int sub) {
@@ -405,7 +421,7 @@ __global__ __launch_bounds__(big::NT) void gemm_bf16_nt_256_kernel(const GemmArg
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-                for (int i = 0; i < RQ; ++i) fa[i][ks] = lds_frag(px, wr * 64 + i * MF + arow, ks * KCH + kh);
+                for (int i = 0; i < RQ; ++i) fa[i][ks] = lds_frag(px, wr * XH + i * MF + arow, ks * KCH + kh);
         };
         auto read_b = [&](int sub) {
             const unsigned char* py = cur + (sub ? PY1 : PY0);
@@ -420,7 +436,7 @@ __global__ __launch_bounds__(big::NT) void gemm_bf16_nt_256_kernel(const GemmArg
         read_a(0);
         if (has1) {
             stage(srcY[1], k1, nxt + PY1);
-            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // Y1 of this tile (read in phase 2) has landed
+            OMX_WAIT_RING();   // Y1 of this tile (read in phase 2) has landed
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
@@ -430,8 +446,8 @@ __global__ __launch_bounds__(big::NT) void gemm_bf16_nt_256_kernel(const GemmArg
         // ---- phase 2 ----
         read_b(1);
         if (has1) {
-            stage(srcX[1], kx(t + 1), nxt + PX1);
-            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // X1 of this tile (read in phase 3) has landed
+            stage_x(srcX[1], kx(t + 1), nxt + PX1);
+            OMX_WAIT_RING();   // X1 of this tile (read in phase 3) has landed
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
@@ -440,14 +456,14 @@ __global__ __launch_bounds__(big::NT) void gemm_bf16_nt_256_kernel(const GemmArg
         OMX_BAR();
         // ---- phase 3 ----
         read_a(1);
-        if (has2) stage(srcX[0], kx(t + 2), cur + PX0);
+        if (has2) stage_x(srcX[0], kx(t + 2), cur + PX0);
         OMX_BAR();
         quadrant(1, 1);
         OMX_BAR();
         // ---- phase 4 ----
         if (has2) {
             stage(srcY[0], k2, cur + PY0);
-            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // X0, Y0 of tile t+1 have landed
+            OMX_WAIT_RING();   // X0, Y0 of tile t+1 have landed
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
@@ -512,7 +528,7 @@ __global__ __launch_bounds__(big::NT) void gemm_bf16_nt_256_kernel(const GemmArg
             const bool per_op = a.sg.act_mode == 1;
 #pragma unroll
             for (int i = 0; i < RT; ++i) {
-                const int lrow = m0 + wr * 128 + i * MF + (lane & LR);
+                const int lrow = m0 + wr * WM + i * MF + (lane & LR);
                 if (lrow >= rows_valid) continue;
                 const int row = row_base + lrow;
 #pragma unroll
@@ -537,7 +553,7 @@ __global__ __launch_bounds__(big::NT) void gemm_bf16_nt_256_kernel(const GemmArg
         } else {
 #pragma unroll
             for (int i = 0; i < RT; ++i) {
-                const int lrow = m0 + wr * 128 + i * MF + (lane & LR);
+                const int lrow = m0 + wr * WM + i * MF + (lane & LR);
                 if (lrow >= rows_valid) continue;
                 const int row = row_base + lrow;
 #pragma unroll
@@ -571,7 +587,7 @@ __global__ __launch_bounds__(big::NT) void gemm_bf16_nt_256_kernel(const GemmArg
     }
 #pragma unroll
     for (int i = 0; i < RT; ++i) {
-        const int row = m0 + wr * 128 + i * MF + (lane & LR);
+        const int row = m0 + wr * WM + i * MF + (lane & LR);
         if (row >= a.M) continue;
 #pragma unroll
         for (int j = 0; j < CT; ++j)
@@ -618,6 +634,7 @@ __global__ __launch_bounds__(big::NT) void gemm_bf16_nt_256_kernel(const GemmArg
             }
     }
 }
+#undef OMX_WAIT_RING
 #undef OMX_BAR
 
 // ---- 64 x 64 x 64 tile, deep LDS-DMA ring: GEMMs whose 128^2 grid cannot fill the chip ----
@@ -926,6 +943,7 @@ int ensure_attr() {
         OMX_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_bf16_nt_256_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, big::SMEM));
         OMX_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_bf16_nt_256_kernel<16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big::SMEM));
         OMX_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_bf16_nt_256_kernel<16, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big::SMEM));
+        OMX_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_bf16_nt_256_kernel<16, false, false, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, big::smem_bytes(128)));
         OMX_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_bf16_nt_skinny_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * skinny::STAGE));
         OMX_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_bf16_nt_skinny_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * skinny::STAGE));
         OMX_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_bf16_nt_skinny_kernel<8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * skinny::STAGE));
@@ -1051,7 +1069,15 @@ static int launch_gemm_impl(bf16_t* out, const bf16_t* x, const bf16_t* w, const
         const char* ks_env = getenv("OMX_GEMM_KSPLIT");
         const int ksplit = (ks_env && ks_env[0] == '1' && forced == 0 && tiles256 >= 64 && tiles256 <= 128 && K >= 4096 && K % 128 == 0) ? 2 : 1;
         const bool use256 = forced == 256 || ksplit > 1 || (forced != 128 && (tiles256 >= 160 || (tiles256 >= 100 && K >= 8192)));
-        if (use256) {
+        // 80 .. 128 tiles of 256^2 (O / down projection of a 2 048-token prompt: 8 x 16): 128 x 256 tiles of the same kernel put one
+        // block on 160 .. 256 CUs.  OMX_GEMM_ROWS128=0 keeps the old choice, =1 takes the 128-row tile for every shape (tests, A/B).
+        const char* r128_env = getenv("OMX_GEMM_ROWS128");
+        const int r128 = r128_env ? atoi(r128_env) : -1;
+        if (ksplit == 1 && (r128 == 1 || (r128 != 0 && forced == 0 && tiles256 >= 80 && tiles256 <= 128))) {
+            a.grid_m = (M + 127) / 128;
+            a.grid_n = (N + 255) / 256;
+            gemm_bf16_nt_256_kernel<16, false, false, 128><<<a.grid_m * a.grid_n, big::NT, big::smem_bytes(128), s>>>(a);
+        } else if (use256) {
             a.grid_m = (M + 255) / 256;
             a.grid_n = (N + 255) / 256;
             a.ksplit = ksplit;

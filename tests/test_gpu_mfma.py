@@ -90,6 +90,39 @@ def test_linear_gemm_256_tile_kernel(omx, monkeypatch, M, N, K):
 
 
 @pytest.mark.parametrize("M,N,K", [
+    (128, 256, 64),          # one tile, one K step (prologue only)
+    (300, 520, 128),         # ragged M and N tails, two K steps
+    (384, 768, 192),         # odd number of K steps
+    (1000, 1100, 1024),      # several tiles, long K loop
+    (2048, 4096, 4096),      # the O projection of a 2 048-token prompt: the shape the default picks this tile for (256 blocks)
+])
+def test_linear_gemm_128_row_tile_is_bit_identical_to_the_256_tile(omx, monkeypatch, M, N, K):
+    """Round 4: the eight-wave kernel with a 128 x 256 tile (csrc/gemm.hip TMR = 128: 64-row X pieces, one chunk per thread and
+    stage, counted waits of 6 instead of 8) for grids of 80 .. 128 tiles of 256^2 -- half the chip.  Every output element is the same
+    chain of 16x16x32 MFMAs over k, so it equals the 256-row tile bit for bit (bias and residual epilogues included), and the oracle
+    within the usual bound."""
+    T = omx.ops.Tensor
+    x = rc.bf16_round(rand((M, K), 61))
+    w = rc.bf16_round(rand((N, K), 62) * 0.05)
+    b = rc.bf16_round(rand((N,), 63))
+    monkeypatch.setenv("OMX_GEMM_ROWS128", "1")
+    got = omx.ops.linear(T.from_numpy(x), T.from_numpy(w), T.from_numpy(b)).numpy()
+    again = omx.ops.linear(T.from_numpy(x), T.from_numpy(w), T.from_numpy(b)).numpy()
+    monkeypatch.setenv("OMX_GEMM_ROWS128", "0")
+    monkeypatch.setenv("OMX_GEMM_TILE", "256")
+    want = omx.ops.linear(T.from_numpy(x), T.from_numpy(w), T.from_numpy(b)).numpy()
+    np.testing.assert_array_equal(got, want)
+    np.testing.assert_array_equal(again, want)
+    if M * N <= 1 << 21:
+        assert_bf16_close(got, rc.linear(x, w, b, "bf16"), 1, atol=2e-5 * np.sqrt(K) + 1e-4)
+    monkeypatch.setenv("OMX_GEMM_ROWS128", "1")
+    monkeypatch.delenv("OMX_GEMM_TILE")
+    eye = np.eye(K, dtype=np.float32)[: min(M, K)]
+    wa = rc.bf16_round((np.arange(N * K).reshape(N, K) % 251 - 125).astype(np.float32) / 64)
+    np.testing.assert_array_equal(omx.ops.linear(T.from_numpy(eye), T.from_numpy(wa)).numpy(), wa.T[: min(M, K)])
+
+
+@pytest.mark.parametrize("M,N,K", [
     (64, 64, 64),            # one tile, one K step: nothing in flight behind it
     (501, 512, 512),         # Paraformer attention projections: 8-stage ring holds the whole contraction
     (216, 512, 2048),        # Paraformer decoder FFN: ring wraps four times, ragged rows

@@ -130,6 +130,52 @@ def test_protocol_c2_token_ids_equal_at_real_shapes(omx):
     _protocol_pin(omx, "c2", dict(bench.QWEN3_8B))
 
 
+MIXTRAL_PIN = os.path.join(os.path.dirname(__file__), "golden", "mixtral_fullwidth_pin.npz")
+
+
+@pytest.mark.skipif(not os.path.exists(MIXTRAL_PIN), reason="Mixtral full-width pin fixture not generated")
+def test_full_width_mixtral_matches_the_oracle_where_routing_cannot_flip(omx, monkeypatch):
+    """Mixtral-8x7B's REAL widths (hidden 4096, 32 / 8 heads of 128, 8 experts of 4096 x 14336, top-2, vocabulary 32 000; depth cut to
+    the fixture's n_layers so that the numpy oracle's f32 weights fit the build container) against the oracle, on a prompt grown so
+    that at every (position, layer) the second and third router logit are further apart than twice the bf16 bound of an activation at
+    that depth (tools/mixtral_pin.py): the two implementations must then choose the same experts, and the comparison is the usual one
+    -- top-8 logits and a fixed 256-entry sample within 2^-7 max|logit| sqrt(layers), tokens equal wherever the oracle's margin allows.
+    Both routes: the batched pass (sorted grouped matrix-core GEMMs) at all positions, and the decode step (expert-selected GEMVs,
+    weighted sum folded into the next launch) replayed position by position."""
+    from ominix_mlx_amd import engine
+    pin = np.load(MIXTRAL_PIN)
+    cfg = dict(bench.MIXTRAL_8X7B)
+    cfg["num_hidden_layers"] = int(pin["n_layers"])
+    prompt = pin["prompt"]
+    n = prompt.size
+    assert float(pin["route_min_rel_gap"]) > float(pin["route_safety"])
+    m = engine.Model(max_context=64, **cfg)
+    m.synth_weights()
+    bound = 2.0 ** -7 * float(pin["max_abs"].max()) * np.sqrt(cfg["num_hidden_layers"])
+
+    def check(lg, i, tok, what):
+        worst = max(float(np.abs(lg[pin["top_idx"][i]] - pin["top_val"][i]).max()), float(np.abs(lg[pin["sub_idx"]] - pin["sub_val"][i]).max()))
+        assert worst <= bound, f"{what}, position {i}: logits off by {worst:.4f} (bound {bound:.4f})"
+        if pin["margin"][i] > 2 * bound:
+            assert tok == pin["greedy"][i], f"{what}, position {i}: token {tok} != oracle {pin['greedy'][i]} (margin {pin['margin'][i]:.3f})"
+        return worst
+
+    got = m.verify(prompt)
+    assert m.offset() == n
+    worst_batched = max(check(m.verify_logits(i), i, int(got[i]), "batched route") for i in range(n))
+    monkeypatch.setenv("OMX_PREFILL_SERIAL", "1")
+    m.reset()
+    tok = int(m.prefill(prompt[:1]))
+    worst_step = check(m.last_logits(), 0, tok, "decode step")
+    for i in range(1, n):
+        m.trim(0, int(prompt[i]))
+        tok = int(m.decode(1)[0])
+        worst_step = max(worst_step, check(m.last_logits(), i, tok, "decode step"))
+    print(f"full-width Mixtral ({cfg['num_hidden_layers']} layers, {n} positions): worst logit deviation batched {worst_batched:.4f}, "
+          f"step {worst_step:.4f}, bound {bound:.4f}")
+    m.close()
+
+
 def test_full_size_mixtral_routes_agree_when_routing_cannot_flip(omx, monkeypatch):
     """Mixtral-8x7B at its real shapes (32 layers, 8 experts of 4096 x 14336, 93 GB of bf16 weights generated on the device) has no
     oracle pin: with random weights top-2-of-8 routing flips under bf16 rounding.  The size-independent property

@@ -209,7 +209,6 @@ struct omx_qwen3_ {
     bf16_t* moe_scores = nullptr;
     unsigned long long *argmax_partials = nullptr, *argmax_key = nullptr;
     int n_argmax_partials = 0;
-    unsigned* steal_ctr = nullptr;                      // ticket counter of the GEMV launches' dynamic tail (gemv.hpp; zero between launches)
     unsigned *step_seq = nullptr, *wait_abort = nullptr;   // step sequence number (granule tags), word a gather that gave up raises
     // attention of the decode step (attn_step.hip): the split plan is fixed per captured graph and covers positions < graph_tk_max;
     // the graphs are rebuilt when the context outgrows that bucket
@@ -661,9 +660,6 @@ int enqueue_step(omx_qwen3 m, bool with_head) {
     const char* fold_env = getenv("OMX_MOE_FOLD");
     const bool moe_fold = c.num_experts > 0 && !ep && !tp &&
                           (fold_env ? fold_env[0] == '1' : c.num_experts_per_tok <= 2);
-    // dynamic tail of the q/k/v and gate/up launches (gemv.hpp steal_ctr; OMX_GEMV_STEAL=0/1)
-    const char* steal_env = getenv("OMX_GEMV_STEAL");
-    const bool gemv_steal = steal_env && steal_env[0] == '1';
     for (int l = 0; l < (engine ? 0 : c.num_hidden_layers); ++l) {
         const LayerW& L = m->layers[l];
         {   // [RMSNorm + QKV GEMV]  model.rs:168-170,324
@@ -678,7 +674,6 @@ int enqueue_step(omx_qwen3 m, bool with_head) {
             a.out = m->qkv;
             a.out_bias = L.qkv_bias;
             a.rows_per_wave = rpw_env("OMX_GEMV_RPW_QKV");
-            a.steal_ctr = gemv_steal ? m->steal_ctr : nullptr;
             time_next_launch(m, l, KC_QKV);
                 if (launch_gemv(a, PRO_RMSNORM, EPI_STORE, s)) return 1;
             if (pending) { bf16_t* t = h; h = hn; hn = t; pending = nullptr; pending_n = 1; }
@@ -762,7 +757,6 @@ int enqueue_step(omx_qwen3 m, bool with_head) {
             a.norm_w = L.post_ln; a.eps = c.rms_norm_eps;
             a.out = m->act;
             a.rows_per_wave = rpw_env("OMX_GEMV_RPW_GU");
-            a.steal_ctr = gemv_steal ? m->steal_ctr : nullptr;
             time_next_launch(m, l, KC_GATE_UP);
                 if (launch_gemv(a, PRO_RMSNORM, EPI_SWIGLU, s)) return 1;
             if (pending) { bf16_t* t = h; h = hn; hn = t; pending = nullptr; pending_n = 1; }
@@ -1304,7 +1298,7 @@ int omx_qwen3_create(omx_qwen3* out, const omx_qwen3_config* cfg) {
     if (dev_alloc(m, &m->rope_cur, (size_t)D) || dev_alloc(m, &m->attn_gran, attn_step_ws_granules(m->H, D)) ||
         dev_alloc(m, &m->attn_xg, (size_t)m->H * D / 2 + 8))
         return 1;
-    if (dev_alloc(m, &m->step_seq, 16) || dev_alloc(m, &m->wait_abort, 16) || dev_alloc(m, &m->steal_ctr, 16)) return 1;
+    if (dev_alloc(m, &m->step_seq, 16) || dev_alloc(m, &m->wait_abort, 16)) return 1;
     {
         int dev = 0;
         hipDeviceProp_t prop;

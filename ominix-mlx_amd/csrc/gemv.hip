@@ -82,7 +82,7 @@ __device__ __forceinline__ void peer_finish_rows(const GemvArgs& a, unsigned tag
 // NVW    = 16-byte vectors per lane per row per wave (compile-time, fully unrolled)
 // KSPLIT = waves sharing one row (1: a wave owns whole rows; 4: each wave owns a K quarter)
 // RB     = logical rows per register batch; LR physical rows per logical row (2 for SwiGLU)
-template <int NVW, int KSPLIT, int RB, int PRO, int EPI, bool TAIL = false, bool STEAL = false>
+template <int NVW, int KSPLIT, int RB, int PRO, int EPI, bool TAIL = false>
 #ifndef OMX_GEMV_MINWAVES
 #define OMX_GEMV_MINWAVES 1   // (tuning builds: make VARIANT=w3 VARIANT_FLAGS=-DOMX_GEMV_MINWAVES=3 asks hipcc for <= 168 VGPRs)
 #endif
@@ -120,11 +120,9 @@ __global__ __launch_bounds__(kBlock, OMX_GEMV_MINWAVES) void gemv_kernel(const G
     const int K = a.K;
     const int rpw = a.rows_per_wave;
     // KSPLIT==1: every wave has its own rows.  KSPLIT==4: the block's waves share the rows.
-    static_assert(!STEAL || (KSPLIT == 1 && PRO != PRO_ROUTE && EPI != EPI_ARGMAX), "the dynamic tail: whole-row waves, plain launches");
-    const int n_static = STEAL ? a.steal_base : a.N;      // rows [n_static, N) are drawn as tickets
     const int row_begin = (KSPLIT == 1 ? (blockIdx.x * kWaves + wave) : blockIdx.x) * rpw;
-    const int row_end = min(row_begin + rpw, n_static);
-    const bool active = row_begin < n_static;
+    const int row_end = min(row_begin + rpw, a.N);
+    const bool active = row_begin < a.N;
     const int koff = (KSPLIT == 1) ? 0 : wave * NVW * 64;   // first vector of this wave's K slice
     const int kvec = K / 8;                                   // 16-byte vectors per row
     // TAIL (compile time: a runtime select around the loads would make hipcc branch and drain per load): K does not fill the
@@ -201,10 +199,6 @@ __global__ __launch_bounds__(kBlock, OMX_GEMV_MINWAVES) void gemv_kernel(const G
     if (tr && threadIdx.x == 0) tr[0] = wall_clock64();
     if (PRO != PRO_ROUTE) {   // (PRO_ROUTE: which expert's rows these are is only known after the prologue)
         if (active) OMX_ISSUE(wA, row_begin);
-    }
-    unsigned ticket = 0;
-    if constexpr (STEAL) {   // first draw: behind the first weight batch, long back when the static share is done
-        if (lane == 0) ticket = __hip_atomic_fetch_add(a.steal_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 
     if constexpr (PRO == PRO_ROUTE) {
@@ -360,22 +354,6 @@ __global__ __launch_bounds__(kBlock, OMX_GEMV_MINWAVES) void gemv_kernel(const G
             if (r0 + 2 * RB < row_end) OMX_ISSUE(wA, r0 + 2 * RB);
             OMX_COMPUTE(wB, r0 + RB);
         }
-    }
-    if constexpr (STEAL) {
-        const unsigned n_t = (unsigned)a.steal_tickets, last_draw = n_t + gridDim.x * kWaves - 1;
-        unsigned t = __builtin_amdgcn_readfirstlane(ticket);
-        while (t < n_t) {
-            const int r0 = a.steal_base + (int)t * 2 * RB;
-            const int row_end = min(r0 + 2 * RB, a.N);       // (shadows the static share's bound inside OMX_COMPUTE)
-            OMX_ISSUE(wA, r0);
-            if (r0 + RB < row_end) OMX_ISSUE(wB, r0 + RB);
-            unsigned nxt = 0;
-            if (lane == 0) nxt = __hip_atomic_fetch_add(a.steal_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            OMX_COMPUTE(wA, r0);
-            if (r0 + RB < row_end) OMX_COMPUTE(wB, r0 + RB);
-            t = __builtin_amdgcn_readfirstlane(nxt);
-        }
-        if (t == last_draw && lane == 0) __hip_atomic_store(a.steal_ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (KSPLIT > 1) {
         __syncthreads();
@@ -583,34 +561,11 @@ int launch_generic(const GemvArgs& a, int pro, int epi, hipStream_t s) {
 }
 
 template <int NVW, int KSPLIT, int RB>
-int launch_nv(const GemvArgs& a_in, int pro, int epi, hipStream_t s) {
-    GemvArgs a = a_in;
-    const size_t shmem = (size_t)NVW * KSPLIT * 64 * 16 + (pro == PRO_ROUTE ? 128 : 32) + (KSPLIT > 1 ? (size_t)a.rows_per_wave * 2 * KSPLIT * 4 : 0);
-    const bool tail = a.K / 8 < NVW * KSPLIT * 64;
-    if constexpr (KSPLIT == 1 && NVW == 8) {
-        // dynamic tail (gemv.hpp steal_ctr): the engine's q/k/v and gate/up launches
-        const bool steal_form = (pro == PRO_RMSNORM && (epi == EPI_STORE || epi == EPI_SWIGLU));
-        if (a.steal_ctr && steal_form && !tail && a.n_batch <= 1 && !a.w_sel && !a.peer) {
-            constexpr int RBS = RB > 1 ? RB / 2 : 1;                         // the SwiGLU instantiation's batch
-            const int per_ticket = 2 * (epi == EPI_SWIGLU ? RBS : RB);
-            int pct = a.steal_pct;
-            if (pct <= 0) { const char* e = getenv("OMX_GEMV_STEAL_PCT"); pct = e ? atoi(e) : 10; }
-            const int tickets = (int)((int64_t)a.N * pct / 100 / per_ticket);
-            if (tickets > 0 && tickets * per_ticket < a.N) {
-                a.steal_tickets = tickets;
-                a.steal_base = a.N - tickets * per_ticket;
-                const int groups = (a.steal_base + a.rows_per_wave - 1) / a.rows_per_wave;
-                const dim3 grid((groups + kWaves - 1) / kWaves), block(kBlock);
-                if (epi == EPI_SWIGLU) OMX_LAUNCH_TIMED((gemv_kernel<NVW, 1, RBS, PRO_RMSNORM, EPI_SWIGLU, false, true>), grid, block, shmem, s, a);
-                else OMX_LAUNCH_TIMED((gemv_kernel<NVW, 1, RB, PRO_RMSNORM, EPI_STORE, false, true>), grid, block, shmem, s, a);
-                OMX_LAUNCH_CHECK();
-                return 0;
-            }
-        }
-    }
-    a.steal_ctr = nullptr;
+int launch_nv(const GemvArgs& a, int pro, int epi, hipStream_t s) {
     const int groups = (a.N + a.rows_per_wave - 1) / a.rows_per_wave;   // row groups (waves or blocks)
     const dim3 grid(KSPLIT == 1 ? (groups + kWaves - 1) / kWaves : groups, a.n_batch > 1 ? a.n_batch : 1), block(kBlock);
+    const size_t shmem = (size_t)NVW * KSPLIT * 64 * 16 + (pro == PRO_ROUTE ? 128 : 32) + (KSPLIT > 1 ? (size_t)a.rows_per_wave * 2 * KSPLIT * 4 : 0);
+    const bool tail = a.K / 8 < NVW * KSPLIT * 64;
 #define OMX_GEMV_CASE(P, E)                                                                          \
     if (pro == P && epi == E) {                                                                      \
         if (tail && P == PRO_NONE)                                                                   \

@@ -76,16 +76,6 @@ struct GemvArgs {
     int route_E, route_k, route_mode, route_renorm;
     uint32_t* route_inds;
     bf16_t* route_scores;
-    // dynamic tail (round 4; the K <= 4096 whole-row instantiations, plain one-vector launches): a launch ends with its slowest XCD
-    // (EXPERIMENTS R4-4: 2-4 us behind the mean on q/k/v and gate/up, a different XCD from run to run), and workgroup b is bound to
-    // XCD b % 8.  With steal_ctr set, the last steal_pct % of the rows are not part of any wave's static share: every wave draws
-    // tickets of 2 x RB logical rows from ONE device counter (the first draw goes out behind its first weight batch, every next
-    // one before the current ticket is reduced, so no draw is ever waited for) until the tickets run out; the wave that draws the
-    // launch's very last number -- tickets + waves draws happen, whoever is slow -- zeroes the counter for the next launch.  Same
-    // rows, same per-row arithmetic: bit-identical.  steal_base / steal_tickets are filled in by launch_gemv.
-    unsigned* steal_ctr;
-    int steal_pct;              // 0: default (OMX_GEMV_STEAL_PCT or 10)
-    int steal_base, steal_tickets;
 };
 bool gemv_route_supported(int K, int n_experts, int top_k);
 

@@ -1,5 +1,6 @@
 """A/B of the 4-bit decode step with the O projection in the attention launch (OMX_ATTN_OPROJ=1, default) and as its own packed GEMV
 (=0): Qwen3-8B shapes as an MLX 4-bit group-64 checkpoint, 2048-token prompt, interleaved timed rounds, tokens compared.
+Any other launch-time switch can be compared the same way: OMX_AB_VAR=<environment variable> OMX_AB_VALUES=<a>,<b> (e.g. OMX_QGEMV_DEPTH 2,6).
 usage: python tools/q4_step_ab.py [prompt] [steps] [rounds]"""
 import os
 import sys
@@ -22,9 +23,11 @@ def main():
     rounds = int(sys.argv[3]) if len(sys.argv) > 3 else 3
     rng = np.random.default_rng(0)
     prompt = rng.integers(0, CFG["vocab_size"], n_prompt).astype(np.uint32)
+    var = os.environ.get("OMX_AB_VAR", "OMX_ATTN_OPROJ")
+    va, vb = os.environ.get("OMX_AB_VALUES", "0,1").split(",")
     models, toks = {}, {}
     for mode in ("0", "1"):
-        os.environ["OMX_ATTN_OPROJ"] = mode
+        os.environ[var] = (va, vb)[int(mode)]
         m = engine.Model(max_context=n_prompt + 16 + steps * rounds + 16, quantization={"bits": 4, "group_size": 64}, **CFG)
         m.synth_weights()
         toks[mode] = [int(m.prefill(prompt))] + [int(t) for t in m.decode(16)]
@@ -33,7 +36,7 @@ def main():
     best = {"0": 0.0, "1": 0.0}
     for r in range(rounds):
         for mode in ("0", "1"):
-            os.environ["OMX_ATTN_OPROJ"] = mode
+            os.environ[var] = (va, vb)[int(mode)]
             m = models[mode]
             t0 = time.perf_counter()
             out = m.decode(steps)
@@ -41,9 +44,9 @@ def main():
             dt = time.perf_counter() - t0
             toks[mode] += [int(t) for t in out]
             best[mode] = max(best[mode], steps / dt)
-            print(f"round {r} OMX_ATTN_OPROJ={mode}: {steps / dt:.1f} tok/s")
+            print(f"round {r} {var}={(va, vb)[int(mode)]}: {steps / dt:.1f} tok/s")
     print("all tokens equal:", toks["0"] == toks["1"])
-    print(f"best: two launches {best['0']:.1f} tok/s, fused {best['1']:.1f} tok/s")
+    print(f"best: {var}={va} {best['0']:.1f} tok/s, {var}={vb} {best['1']:.1f} tok/s")
 
 
 if __name__ == "__main__":

@@ -440,9 +440,14 @@ int omx_klein_forward_with_rope(omx_klein m, void* out, const void* latent, cons
         OMX_HIP_CHECK(hipStreamWaitEvent(s_main, m->ev_join, 0));
         return 0;
     };
+    // the side stream's GEMMs (512 rows) as 128 x 256 tiles: 48 workgroups that fit the CUs the img grid leaves idle, instead of 384
+    // tiles of 64^2 queueing behind its workgroups (OMX_KLEIN_TXT_ROWS128=0: the shape's own choice)
+    const char* t128_env = getenv("OMX_KLEIN_TXT_ROWS128");
+    const bool txt_rows128 = dual && !(t128_env && t128_env[0] == '0');
     auto on_stream = [&](int st) {   // txt half -> side stream, img half -> main stream
         m->stream = (dual && st == 0) ? m->stream_txt : s_main;
         s = m->stream;
+        gemm_tile_hint(txt_rows128 && st == 0 ? 128 : 0);
     };
     for (int i = 0; i < c.depth; ++i) {
         const std::string b = "double_blocks." + std::to_string(i) + ".";

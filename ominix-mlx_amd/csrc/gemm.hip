@@ -1043,6 +1043,12 @@ int ring_splits(int blocks, int nt) {
 }
 }  // namespace
 
+// a caller's tile preference for its next plain GEMMs on this thread (0: none).  128: the 128 x 256 tile even where the shape alone
+// would pick many small tiles -- a GEMM that runs BESIDE another one on a second stream (the DiT's 512-row txt chain next to the img
+// chain: 48 such blocks fit the CUs the img grid leaves idle, 384 tiles of 64^2 queue behind its workgroups)
+static thread_local int g_tile_hint = 0;
+void gemm_tile_hint(int rows) { g_tile_hint = rows; }
+
 static int launch_gemm_impl(bf16_t* out, const bf16_t* x, const bf16_t* w, const bf16_t* bias, const bf16_t* resid,
                             const bf16_t* gate, int M, int N, int K, hipStream_t s, int relu = 0) {
     OMX_REQUIRE(M > 0 && N > 0 && K > 0, "gemm: bad shape M=%d N=%d K=%d", M, N, K);
@@ -1073,7 +1079,7 @@ static int launch_gemm_impl(bf16_t* out, const bf16_t* x, const bf16_t* w, const
         // block on 160 .. 256 CUs.  OMX_GEMM_ROWS128=0 keeps the old choice, =1 takes the 128-row tile for every shape (tests, A/B).
         const char* r128_env = getenv("OMX_GEMM_ROWS128");
         const int r128 = r128_env ? atoi(r128_env) : -1;
-        if (ksplit == 1 && (r128 == 1 || (r128 != 0 && forced == 0 && tiles256 >= 80 && tiles256 <= 128))) {
+        if (ksplit == 1 && (r128 == 1 || (r128 != 0 && forced == 0 && ((tiles256 >= 80 && tiles256 <= 128) || (g_tile_hint == 128 && M >= 128 && N >= 256))))) {
             a.grid_m = (M + 127) / 128;
             a.grid_n = (N + 255) / 256;
             gemm_bf16_nt_256_kernel<16, false, false, 128><<<a.grid_m * a.grid_n, big::NT, big::smem_bytes(128), s>>>(a);

@@ -26,6 +26,9 @@ int launch_gemm_bf16_ex(bf16_t* out, const bf16_t* x, const bf16_t* w, const bf1
 int launch_gemm_bf16_bias_relu(bf16_t* out, const bf16_t* x, const bf16_t* w, const bf16_t* bias, int M, int N, int K,
                                hipStream_t s);
 // gated residual epilogue of the DiT blocks: out = bf16(resid + (x.W^T) * gate[col])   (klein_model.rs:496-497, 922-925)
+// tile preference of this thread's next plain GEMMs (gemm.hip g_tile_hint): 0 none, 128 = the 128 x 256 tile for a GEMM that shares the
+// chip with another stream's grid
+void gemm_tile_hint(int rows);
 int launch_gemm_bf16_gated(bf16_t* out, const bf16_t* x, const bf16_t* w, const bf16_t* resid, const bf16_t* gate, int M,
                            int N, int K, hipStream_t s);
 

@@ -442,6 +442,7 @@ int omx_klein_forward_with_rope(omx_klein m, void* out, const void* latent, cons
     };
     // the side stream's GEMMs (512 rows) as 128 x 256 tiles: 48 workgroups that fit the CUs the img grid leaves idle, instead of 384
     // tiles of 64^2 queueing behind its workgroups (OMX_KLEIN_TXT_ROWS128=0: the shape's own choice)
+    gemm_tile_hint(0);   // (a forward that failed half-way may have left the side stream's preference behind)
     const char* t128_env = getenv("OMX_KLEIN_TXT_ROWS128");
     const bool txt_rows128 = dual && !(t128_env && t128_env[0] == '0');
     auto on_stream = [&](int st) {   // txt half -> side stream, img half -> main stream

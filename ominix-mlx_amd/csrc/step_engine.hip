@@ -1051,7 +1051,8 @@ int lds_budget(int hidden, int H, int D, int I, int G, int* xs_bytes) {
 }
 
 bool have_instance(int D, int gt, int nslot) {
-    return nslot == 8 ? (D == 128 || D == 64) : (nslot == 6 && D == 128 && (gt == 4 || gt == 8));
+    if (gt != 2 && gt != 4) return false;   // (query groups of 2 and 4: Qwen3-0.6B / 8B and the test shapes; others take the launch-per-op step)
+    return nslot == 8 ? (D == 128 || D == 64) : (nslot == 6 && D == 128 && gt == 4);
 }
 
 bool tuned_width(int K) {
@@ -1098,18 +1099,16 @@ int launch_step_engine(const StepEngineArgs& a_in, int cus, hipStream_t s) {
         OMX_LAUNCH_CHECK();                                                                                                        \
         return 0;                                                                                                                  \
     }
-    // instantiations (each is a ~40 k-instruction kernel: the list is kept to what the supported models need -- 8-slot ring for every
-    // head width and group size, 6-slot ring where the activation area outgrows 24 KiB (head_dim 128, groups of 4 and 8), the timeline
-    // build for Qwen3-8B's shape only); have_instance() mirrors it for step_engine_ok
+    // instantiations (each is a ~40 k-instruction kernel and the path is opt-in: the list is kept to query groups of 2 and 4 -- 8-slot ring
+    // for both head widths, 6-slot ring where the activation area outgrows 24 KiB (head_dim 128, groups of 4), the timeline build for
+    // Qwen3-8B's shape only); have_instance() mirrors it for step_engine_ok
     if (a.trace) {
         if (a.D == 128 && gt == 4 && a.nslot == 8) OMX_SE_LAUNCH(128, 4, 8, true)
         return set_error("step engine: the timeline build exists for head_dim 128, groups of 4, 8-slot ring only");
     }
 #define OMX_SE_CASE(DD, GG, NS) \
     if (a.D == DD && gt == GG && a.nslot == NS) OMX_SE_LAUNCH(DD, GG, NS, false)
-    OMX_SE_CASE(128, 1, 8) OMX_SE_CASE(128, 2, 8) OMX_SE_CASE(128, 4, 8) OMX_SE_CASE(128, 8, 8)
-    OMX_SE_CASE(64, 1, 8) OMX_SE_CASE(64, 2, 8) OMX_SE_CASE(64, 4, 8) OMX_SE_CASE(64, 8, 8)
-    OMX_SE_CASE(128, 4, 6) OMX_SE_CASE(128, 8, 6)
+    OMX_SE_CASE(128, 2, 8) OMX_SE_CASE(128, 4, 8) OMX_SE_CASE(64, 2, 8) OMX_SE_CASE(64, 4, 8) OMX_SE_CASE(128, 4, 6)
 #undef OMX_SE_CASE
 #undef OMX_SE_LAUNCH
     return set_error("step engine: head_dim %d unsupported", a.D);

@@ -133,6 +133,19 @@ def collective_plan(args, world):
     return plan
 
 
+# Pre-flight of the N > 1 command on a box with ONE GPU (OMX_BENCH_ONE_GPU=1): every rank is its own process on device 0, gloo does
+# the rendezvous / barriers / max-over-ranks, and EVERY device all-reduce -- the step's 16 KB ones and the [T, hidden] / 28 MB ones that
+# otherwise go to RCCL -- runs on the peer communicator (csrc/peer_allreduce.hip: one-shot below 32 KB, two-shot above), whose inboxes
+# and stages are HIP IPC mappings whether the peer sits on another GPU or on this one.  Not a measurement: a line from this mode says so.
+ONE_GPU = os.environ.get("OMX_BENCH_ONE_GPU") == "1"
+if ONE_GPU:
+    # launches whose workgroups ALL wait on each other (attention + O in one launch, the GEMV that reduces over the peers in its
+    # epilogue) need their whole grid resident: with one GPU per rank it is, with two ranks' twin launches interleaved on the same CUs
+    # neither ever is -- both give up after their bounded waits.  The pre-flight takes the forms that only wait on producers.
+    os.environ.setdefault("OMX_ATTN_OPROJ", "0")
+    os.environ.setdefault("OMX_PEER_FUSED", "0")
+
+
 def init_dist(n_gpus):
     """One process per GPU (torchrun env).  Returns (rank, world, local_rank, dist or None)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -141,6 +154,8 @@ def init_dist(n_gpus):
     if n_gpus != world:
         raise SystemExit(f"--gpus {n_gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {n_gpus} (or without torch.distributed.run)")
     import torch
+    if ONE_GPU:
+        local = 0
     torch.cuda.set_device(local)
     dist = None
     if world > 1:
@@ -148,7 +163,10 @@ def init_dist(n_gpus):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         with c_stdout_to_stderr():
-            dist_mod.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+            if ONE_GPU:                 # RCCL refuses two ranks on one device: gloo carries the host-side plumbing
+                dist_mod.init_process_group("gloo")
+            else:
+                dist_mod.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
             dist_mod.barrier()          # torch creates its communicator lazily: do it here, banner and all
         dist = dist_mod
     return rank, world, local, dist
@@ -193,6 +211,9 @@ def peer_comm(dist, rank, world, rccl):
     if dist is not None:
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
     if int(ok.item()) == 1:
+        if rccl is None:
+            return peer, ("peer communicator only (csrc/peer_allreduce.hip: one-shot below 32 KB, two-shot above; self-test exact on every rank)" +
+                          (" -- ALL RANKS ON ONE GPU (OMX_BENCH_ONE_GPU=1): a pre-flight of the multi-process path, not a measurement" if ONE_GPU else ""))
         return peer, "peer-store one-shot (csrc/peer_allreduce.hip; self-test exact on every rank), RCCL above 32 KB"
     if peer is not None and not err:
         err = "a peer rank failed its self-test"
@@ -504,10 +525,12 @@ def main():
     keep = peer = None
     peer_note = None
     if world > 1 or os.environ.get("OMX_BENCH_FORCE_COMM") == "1":   # (the flag: run the N > 1 code path -- RCCL all-reduces in the
-        keep = rccl_comm(dist, rank, world)                         #  step graph, batched TP prefill -- on a one-rank communicator)
+        keep = None if ONE_GPU else rccl_comm(dist, rank, world)    #  step graph, batched TP prefill -- on a one-rank communicator)
         peer, peer_note = peer_comm(dist, rank, world, keep)
         if peer is not None:
             model.set_comm(peer.comm, peer.fn)
+        elif keep is None:
+            raise SystemExit(f"rank {rank}: OMX_BENCH_ONE_GPU=1 needs the peer communicator and it was not usable ({peer_note})")
         else:
             model.set_comm(keep[1], keep[2])
     model.synth_weights()
@@ -541,8 +564,11 @@ def main():
     barrier()
     t0 = time.perf_counter()
     toks = model.decode(args.steps)
+    t_dec = time.perf_counter() - t0
     barrier()
     elapsed = time.perf_counter() - t0
+    if os.environ.get("OMX_BENCH_DEBUG") == "1":
+        print(f"[bench rank {rank}] window 1: decode call {t_dec * 1e3:.1f} ms, with the closing barrier {elapsed * 1e3:.1f} ms, device {model.last_decode_ms():.1f} ms, path {model.decode_path()}, offset {model.offset()}", file=sys.stderr, flush=True)
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -557,6 +583,8 @@ def main():
         model.decode(args.steps)
         barrier()
         w = time.perf_counter() - t0
+        if os.environ.get("OMX_BENCH_DEBUG") == "1":
+            print(f"[bench rank {rank}] next window: {w * 1e3:.1f} ms, device {model.last_decode_ms():.1f} ms, path {model.decode_path()}, offset {model.offset()}", file=sys.stderr, flush=True)
         if dist is not None:
             t = torch.tensor([w], dtype=torch.float64, device="cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -670,11 +698,14 @@ def main():
             # clean run (every rank's own watchdog fires: the ranks leave by themselves, nobody waits for a stuck peer)
             os._exit(3)
 
+        # the secondaries' communicator: the peer one when it is up (one hop for the Mixtral step's 16 KB reductions; anything larger it
+        # hands to the RCCL communicator behind it -- or, with no RCCL at all, reduces itself in two shots), else RCCL
+        sec_comm = (None, peer.comm, peer.fn) if peer is not None else keep
         dog = threading.Timer(SECONDARY_TIMEOUT_S, give_up)
         dog.daemon = True
         dog.start()
         try:
-            flux_tp = flux_secondary(omx, rank=rank, world=world, comm=keep)
+            flux_tp = flux_secondary(omx, rank=rank, world=world, comm=sec_comm)
         except Exception as e:
             flux_tp = {"metric": "flux_klein_1024_sec_per_step", "value": None, "error": str(e)}
         if rank == 0 and flux_tp is not None:
@@ -682,12 +713,12 @@ def main():
                 out["secondary"] = flux_tp      # (kept if the watchdog fires during the next workload)
         if "mixtral" in plan:
             try:
-                mixtral_ep = mixtral_secondary(omx, rank=rank, world=world, comm=keep, dist=dist)
+                mixtral_ep = mixtral_secondary(omx, rank=rank, world=world, comm=sec_comm, dist=dist)
             except Exception as e:
                 mixtral_ep = {"metric": "decode_tokens_per_sec_mixtral_8x7b_bf16", "value": None, "error": str(e)}
             if world > 1 and 14336 % (64 * world) == 0:    # the same model with expert TENSOR parallelism (what scales batch-1 decode)
                 try:
-                    mixtral_ep["expert_tensor_parallel"] = mixtral_secondary(omx, rank=rank, world=world, comm=keep, dist=dist, mode="etp")
+                    mixtral_ep["expert_tensor_parallel"] = mixtral_secondary(omx, rank=rank, world=world, comm=sec_comm, dist=dist, mode="etp")
                 except Exception as e:
                     mixtral_ep["expert_tensor_parallel"] = {"value": None, "error": str(e)}
         dog.cancel()

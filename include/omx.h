@@ -420,7 +420,10 @@ int omx_loopback_abort(omx_loopback g);
 /* One-shot all-reduce over xGMI peer stores for the tensor-parallel decode step (csrc/peer_allreduce.hip): one
  * process per GPU, every rank's inbox (fine-grained device memory) mapped into every peer through HIP IPC handles, a call = ONE
  * kernel that stores tagged 8-byte granules into all inboxes and reduces its own in rank order.  f32 sum / u64 max of up to 8192
- * payload words; anything else goes to the RCCL communicator given at creation (may be NULL: such calls then fail).
+ * payload words.  Larger f32 / bf16 sums (16-byte multiples) take the TWO-SHOT path when no RCCL communicator was given at creation
+ * (or OMX_PEER_LARGE=1): one kernel, slice s of every rank's input pushed into rank s's stage, summed there in rank order, pushed
+ * back to all -- stages of OMX_PEER_STAGE_MB (64) behind every inbox, larger messages in chunks.  Anything else goes to the RCCL
+ * communicator given at creation (may be NULL: such calls then fail).
  * omx_peer_allreduce has ncclAllReduce's signature: omx_qwen3_set_comm(model, comm, omx_peer_allreduce_fn()).
  * Host protocol: create -> handle (64 bytes) -> all-gather the handles rank-major -> connect.                                 */
 int omx_peer_comm_create(void** out, int rank, int world, void* rccl_comm, void* rccl_allreduce_fn);

@@ -13,8 +13,13 @@ constexpr unsigned kPeerSpinLimit = 1u << 23;   // polls (~1 us each: a peer may
 struct PeerDev {
     uint64_t* peers[kPeerMaxWorld];   // every rank's inbox [2][world][kPeerMaxWords] granules as mapped on this rank
     uint64_t* inbox;                  // == peers[rank]
-    uint32_t* state;                  // [0] sequence number, [1] blocks done, [2] abort
+    uint32_t* state;                  // [0] sequence number, [1] blocks done, [2] abort, [3..5] the large kernel's three arrival counters
     int rank, world;
+    // the large (two-shot) path, peer_allreduce.hip: behind every rank's inbox in the same exported allocation
+    uint64_t* flags[kPeerMaxWorld];        // [2 phases][world] tags: "rank r finished pushing phase p of call tag"
+    unsigned char* stage1[kPeerMaxWorld];  // [world][slice] contributions to the slice that rank owns
+    unsigned char* stage2[kPeerMaxWorld];  // [world][slice] the reduced slices, pushed by their owners
+    size_t stage_bytes;                    // 0: the large path is off
 };
 
 typedef __attribute__((address_space(1))) unsigned long long peer_gu64;

@@ -14,6 +14,18 @@
 // Same signature and codes as ncclAllReduce (the engines take either, omx_qwen3_set_comm); calls it does not cover (more than 8192
 // words: the batched prefill's [T, hidden] reductions, the DiT's 28 MB ones; other dtypes) go to the RCCL communicator given at
 // creation.  Waits are bounded: a peer that never shows up raises the abort word (omx_peer_comm_status) instead of hanging the GPU.
+//
+// The LARGE path (round 4; f32 / bf16 sums of any size, used when no RCCL communicator was given or OMX_PEER_LARGE=1): a two-shot
+// all-reduce in ONE kernel over the same fully connected fabric -- every byte crosses exactly one link, all links at once:
+//   1. rank r PUSHES slice s of its input into slot r of rank s's stage1 (16-byte peer stores), fences, and -- its last block to
+//      arrive -- stores the call's tag into flag [0][r] of every rank;
+//   2. once all `world` flags [0][*] carry the tag, rank s sums the `world` slots of its stage1 in rank order (f32 accumulation, one
+//      rounding for bf16) and PUSHES the reduced slice into slot s of every rank's stage2; fence, flag [1][s] everywhere;
+//   3. once all flags [1][*] carry the tag, every rank copies its stage2 to the destination; the last block advances the sequence.
+// One slice is reduced by one rank and broadcast, so all ranks hold identical bits.  stage1 / stage2 need no second parity: a peer can
+// only start pushing call n + 1 after it has seen this rank's phase-2 flag of call n (all reads of stage1 done), and only reaches
+// phase 2 of call n + 1 after this rank's phase-1 flag of call n + 1 (its call-n kernel, copy included, has ended).  Messages above the
+// stage size (OMX_PEER_STAGE_MB, default 64) go in chunks.  It also lets several ranks share ONE GPU (tests; bench.py OMX_BENCH_ONE_GPU=1).
 #include <cstring>
 
 #include "common.hpp"
@@ -36,7 +48,107 @@ struct PeerComm {
     nccl_allreduce_fn rccl_fn = nullptr;
     hipIpcMemHandle_t handle;
     bool connected = false;
+    size_t stage_bytes = 0;                    // large path: bytes per stage (0: off)
+    size_t off_flags = 0, off_stage1 = 0, off_stage2 = 0;   // byte offsets inside the exported allocation
 };
+
+constexpr int kNcclBfloat16 = 9;
+constexpr int kLargeBlocks = 128;              // all of them wait on each other: far below one workgroup per CU
+
+struct PeerLargeArgs {
+    const PeerDev* dev;
+    const u32x4* send;
+    u32x4* recv;
+    size_t nvec, slice_vec;                    // 16-byte vectors in the message / per slice
+};
+
+__device__ __forceinline__ void large_publish(const PeerDev* p, int phase, unsigned tag, uint32_t* counter) {
+    // every thread's pushes are complete at system scope before its block reports in; the last block to arrive tells every rank
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned done = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (done == gridDim.x - 1) {
+            __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int r = 0; r < p->world; ++r)
+                __hip_atomic_store((peer_gu64*)(p->flags[r] + (size_t)phase * p->world + p->rank), (unsigned long long)tag, __ATOMIC_RELEASE,
+                                   __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
+// thread 0 polls this rank's `world` flags of the phase; false when a peer never arrived (abort word raised)
+__device__ __forceinline__ bool large_wait(const PeerDev* p, int phase, unsigned tag) {
+    __shared__ int s_ok;
+    if (threadIdx.x == 0) {
+        int ok = 1;
+        for (int r = 0; r < p->world && ok; ++r) {
+            const peer_gu64* f = (const peer_gu64*)(p->flags[p->rank] + (size_t)phase * p->world + r);
+            unsigned spins = 0;
+            while ((unsigned)__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != tag) {
+                if (++spins >= kPeerSpinLimit) { __hip_atomic_store(p->state + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); ok = 0; break; }
+                __builtin_amdgcn_s_sleep(2);
+            }
+        }
+        s_ok = ok;
+    }
+    __syncthreads();
+    __threadfence_system();
+    return s_ok != 0;
+}
+
+template <bool BF16>
+__global__ __launch_bounds__(256) void peer_allreduce_large_kernel(const PeerLargeArgs a) {
+    const PeerDev* p = a.dev;
+    const unsigned tag = peer_tag(p);
+    const int W = p->world, me = p->rank;
+    const size_t gtid = (size_t)blockIdx.x * 256 + threadIdx.x, gsize = (size_t)gridDim.x * 256;
+    // 1. push: vector v belongs to slice v / slice_vec
+    for (size_t v = gtid; v < a.nvec; v += gsize) {
+        const size_t sl = v / a.slice_vec, off = v - sl * a.slice_vec;
+        *(reinterpret_cast<u32x4*>(p->stage1[sl]) + (size_t)me * a.slice_vec + off) = a.send[v];
+    }
+    large_publish(p, 0, tag, p->state + 3);
+    bool ok = large_wait(p, 0, tag);
+    // 2. reduce the own slice in rank order, push the result to every rank
+    const size_t lo = (size_t)me * a.slice_vec, cnt = lo < a.nvec ? min(a.slice_vec, a.nvec - lo) : 0;
+    for (size_t o = gtid; o < cnt && ok; o += gsize) {
+        u32x4 out;
+        if (BF16) {
+            float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (int r = 0; r < W; ++r) {
+                const u32x4 x = *(reinterpret_cast<const u32x4*>(p->stage1[me]) + (size_t)r * a.slice_vec + o);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { acc[2 * q] += bf16lo(x[q]); acc[2 * q + 1] += bf16hi(x[q]); }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) out[q] = pack_bf16(acc[2 * q], acc[2 * q + 1]);
+        } else {
+            float acc[4] = {0, 0, 0, 0};
+            for (int r = 0; r < W; ++r) {
+                const u32x4 x = *(reinterpret_cast<const u32x4*>(p->stage1[me]) + (size_t)r * a.slice_vec + o);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[q] += __uint_as_float(x[q]);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) out[q] = __float_as_uint(acc[q]);
+        }
+        for (int d = 0; d < W; ++d) *(reinterpret_cast<u32x4*>(p->stage2[d]) + lo + o) = out;
+    }
+    large_publish(p, 1, tag, p->state + 4);
+    ok = large_wait(p, 1, tag) && ok;
+    // 3. the whole message is in this rank's stage2
+    for (size_t v = gtid; v < a.nvec; v += gsize)
+        a.recv[v] = ok ? *(reinterpret_cast<const u32x4*>(p->stage2[me]) + v) : u32x4{0u, 0u, 0u, 0u};
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned done = __hip_atomic_fetch_add(p->state + 5, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (done == gridDim.x - 1) {
+            __hip_atomic_store(p->state + 5, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(p->state, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
 
 struct PeerArgs {
     const PeerDev* dev;
@@ -74,7 +186,14 @@ __global__ __launch_bounds__(256) void peer_allreduce_kernel(const PeerArgs a) {
 
 int upload_table(PeerComm* c) {
     PeerDev t = {};
-    for (int r = 0; r < c->world; ++r) t.peers[r] = c->peers[r];
+    for (int r = 0; r < c->world; ++r) {
+        t.peers[r] = c->peers[r];
+        unsigned char* base = reinterpret_cast<unsigned char*>(c->peers[r]);
+        t.flags[r] = reinterpret_cast<uint64_t*>(base + c->off_flags);
+        t.stage1[r] = base + c->off_stage1;
+        t.stage2[r] = base + c->off_stage2;
+    }
+    t.stage_bytes = c->stage_bytes;
     t.inbox = c->inbox; t.state = c->state; t.rank = c->rank; t.world = c->world;
     if (!c->dev) OMX_HIP_CHECK(hipMalloc((void**)&c->dev, sizeof(PeerDev)));
     OMX_HIP_CHECK(hipMemcpy(c->dev, &t, sizeof(PeerDev), hipMemcpyHostToDevice));
@@ -94,10 +213,23 @@ int omx_peer_comm_create(void** out, int rank, int world, void* rccl_comm, void*
                 world, kPeerMaxWorld);
     PeerComm* c = new PeerComm();
     c->rank = rank; c->world = world; c->rccl = rccl_comm; c->rccl_fn = (nccl_allreduce_fn)rccl_allreduce_fn;
-    const size_t bytes = (size_t)2 * world * kPeerMaxWords * sizeof(uint64_t);
+    const size_t inbox_bytes = (size_t)2 * world * kPeerMaxWords * sizeof(uint64_t);
+    // the large path: on when there is no RCCL communicator to hand big calls to, or when asked for (every rank must decide alike)
+    const char* le = getenv("OMX_PEER_LARGE");
+    const bool large = le ? le[0] == '1' : rccl_allreduce_fn == nullptr;
+    if (large) {
+        const char* se = getenv("OMX_PEER_STAGE_MB");
+        const long mb = se ? atol(se) : 64;
+        c->stage_bytes = (size_t)(mb > 0 ? mb : 64) << 20;
+    }
+    c->off_flags = inbox_bytes;
+    c->off_stage1 = inbox_bytes + 4096;
+    c->off_stage2 = c->off_stage1 + (c->stage_bytes ? c->stage_bytes + 4096 : 0);
+    const size_t bytes = c->off_stage2 + (c->stage_bytes ? c->stage_bytes + 4096 : 0);
     // fine-grained: stores of a peer become visible to a polling kernel without a cache invalidate at a kernel boundary
-    if (hipExtMallocWithFlags((void**)&c->inbox, bytes, hipDeviceMallocFinegrained) != hipSuccess || hipMemset(c->inbox, 0, bytes) != hipSuccess ||
-        hipMalloc((void**)&c->state, 16) != hipSuccess || hipMemset(c->state, 0, 16) != hipSuccess) {
+    // (only the granules and flags are cleared: the stages are written before they are read)
+    if (hipExtMallocWithFlags((void**)&c->inbox, bytes, hipDeviceMallocFinegrained) != hipSuccess || hipMemset(c->inbox, 0, inbox_bytes + 4096) != hipSuccess ||
+        hipMalloc((void**)&c->state, 64) != hipSuccess || hipMemset(c->state, 0, 64) != hipSuccess) {
         (void)hipGetLastError();
         if (c->inbox) (void)hipFree(c->inbox);
         if (c->state) (void)hipFree(c->state);
@@ -163,6 +295,24 @@ int omx_peer_allreduce(const void* send, void* recv, size_t count, int dtype, in
     const bool f32sum = dtype == kNcclFloat32 && op == kNcclSum, u64max = dtype == kNcclUint64 && op == kNcclMax;
     const size_t words = f32sum ? count : 2 * count;
     if ((!f32sum && !u64max) || words > (size_t)kPeerMaxWords || count == 0) {
+        const bool bf16sum = dtype == kNcclBfloat16 && op == kNcclSum;
+        const size_t esz = f32sum ? 4 : 2, nbytes = count * esz;
+        if (c->stage_bytes && (f32sum || bf16sum) && count > 0 && nbytes % 16 == 0 &&
+            ((reinterpret_cast<uintptr_t>(send) | reinterpret_cast<uintptr_t>(recv)) & 15u) == 0) {
+            // two-shot over the peers' stages, a chunk of at most one stage per launch (slices of whole 16-byte vectors)
+            const size_t chunk_vec = c->stage_bytes / 16;
+            for (size_t v0 = 0, nvec = nbytes / 16; v0 < nvec; v0 += chunk_vec) {
+                PeerLargeArgs a = {};
+                a.dev = c->dev;
+                a.send = static_cast<const u32x4*>(send) + v0; a.recv = static_cast<u32x4*>(recv) + v0;
+                a.nvec = std::min(chunk_vec, nvec - v0);
+                a.slice_vec = (a.nvec + c->world - 1) / c->world;
+                if (bf16sum) peer_allreduce_large_kernel<true><<<kLargeBlocks, 256, 0, stream>>>(a);
+                else peer_allreduce_large_kernel<false><<<kLargeBlocks, 256, 0, stream>>>(a);
+                if (hipGetLastError() != hipSuccess) return 1;
+            }
+            return 0;
+        }
         if (!c->rccl_fn) return 1;   // nothing to hand the call to
         return c->rccl_fn(send, recv, count, dtype, op, c->rccl, stream);
     }

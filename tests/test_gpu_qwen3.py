@@ -668,7 +668,8 @@ def test_peer_store_allreduce_across_processes(omx, tmp_path, fused):
     from ominix_mlx_amd import comm, engine
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     port = 29500 + (os.getpid() % 400)
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMX_PEER_FUSED=fused)
+    # (fused 0 also shrinks the two-shot path's stage to 4 MB: its 16.7 MB messages then go in five chunks)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMX_PEER_FUSED=fused, **({"OMX_PEER_STAGE_MB": "4"} if fused == "0" else {}))
     p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                         "--master-port", str(port), os.path.join(root, "tools", "peer_allreduce_check.py"), str(tmp_path)],
                        env=env, capture_output=True, text=True, timeout=600, stdin=subprocess.DEVNULL)
@@ -680,7 +681,11 @@ def test_peer_store_allreduce_across_processes(omx, tmp_path, fused):
         assert [h["n_floats"] for h in r["latency_us"]] == [4096, 2, 4096 * 64]
         for h in r["latency_us"]:
             assert 0 < h["min"] <= h["p50"] <= h["p90"] <= h["p99"] <= h["max"] and sum(h["log2_buckets_us"].values()) == h["calls"]
+        # the two-shot path: seeded messages of 32 KB .. 16.7 MB in f32 and bf16 come back as the rank-ordered sum, bit for bit
+        assert len(r["large"]) == 6 and all(c["rc"] == 0 and c["equal"] for c in r["large"]), r["large"]
+        assert not r["aborted_after_large"]
     assert res[0]["tokens"] == res[1]["tokens"]
+    assert res[0]["tokens_batched"] == res[1]["tokens_batched"]
     assert res[0]["decode_path"] == "graph"          # the peer all-reduce is an ordinary kernel: the step stays captured
     # the same two shards through the in-process communicator (same rank-ordered f32 sums)
     cfg = dict(hidden_size=1024, num_hidden_layers=2, intermediate_size=3072, num_attention_heads=8, num_key_value_heads=2, head_dim=128,
@@ -704,6 +709,16 @@ def test_peer_store_allreduce_across_processes(omx, tmp_path, fused):
     finally:
         del os.environ["OMX_PREFILL_SERIAL"]
     assert outs[0] == res[0]["tokens"]
+    # the batched prompt through the in-process communicator: its bf16 all-reduce sums in rank order in f32 and rounds once, like the
+    # two-shot path's slice owners
+    os.environ["OMX_PREFILL_SERIAL"] = "0"
+    try:
+        for mm in models:
+            mm.reset()
+        outs_b = comm.run_ranks(2, run, group)
+    finally:
+        del os.environ["OMX_PREFILL_SERIAL"]
+    assert outs_b[0] == res[0]["tokens_batched"]
     print(f"peer all-reduce of 16 KB, two processes on one GPU: {res[0]['allreduce_16k_us']:.1f} us per call; "
           f"TP = 2 step (fused={fused}): {res[0]['step_ms']:.3f} ms")
 

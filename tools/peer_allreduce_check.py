@@ -2,7 +2,8 @@
 (gloo bootstrap, so that two ranks may share the one GPU of a test box; on a multi-GPU node every rank takes its LOCAL_RANK device
 and the stores cross xGMI).  Each rank: self-test against the rank-ordered sum, latency of a 4096-float reduction, then a
 tensor-parallel greedy decode of a small Qwen3 through the engine with every all-reduce (hidden partials, argmax key) on the peer
-path -- serial prefill, so no call needs RCCL.  Rank r writes <out>/rank<r>.json; rank 0 also prints per-call latency percentiles and a
+path -- serial prefill first, then the batched one, whose [T, hidden] reductions (like the seeded large messages checked before it)
+take the two-shot path; no call needs RCCL.  Rank r writes <out>/rank<r>.json; rank 0 also prints per-call latency percentiles and a
 log2 histogram for the step's reduction sizes.
 usage: python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1 --master-port P tools/peer_allreduce_check.py <out dir> [8b]"""
 import json
@@ -74,6 +75,36 @@ if rank == 0:
         print(f"[peer all-reduce] {h['n_floats']:>7d} f32 x {h['calls']} calls, us per call (host clock incl. launch + sync): "
               f"min {h['min']} p50 {h['p50']} p90 {h['p90']} p99 {h['p99']} max {h['max']}  {h['log2_buckets_us']}", flush=True)
 
+
+
+def bf16_round(x):
+    u = np.ascontiguousarray(x, np.float32).view(np.uint32).astype(np.uint64)
+    return ((u + ((u >> np.uint64(16)) & np.uint64(1)) + np.uint64(0x7FFF)) & np.uint64(0xFFFF0000)).astype(np.uint32).view(np.float32)
+
+
+def large_check(n, dtype, seed):
+    """The two-shot path (messages above 8192 words; no RCCL communicator behind this PeerComm): every rank derives ALL ranks' inputs
+    from seeds, so the rank-ordered f32 sum (rounded once for bf16) is known locally and must come back bit for bit."""
+    parts = [np.random.default_rng(seed * 16 + r).standard_normal(n).astype(np.float32) for r in range(world)]
+    if dtype == "bf16":
+        parts = [bf16_round(p) for p in parts]
+    want = parts[0].copy()
+    for p in parts[1:]:
+        want = want + p
+    if dtype == "bf16":
+        want = bf16_round(want)
+    buf = T.from_numpy(parts[rank], dtype)
+    rc = omx.lib.omx_peer_allreduce(buf.ptr, buf.ptr, n, comm.NCCL_BFLOAT16 if dtype == "bf16" else comm.NCCL_FLOAT32, 0, pc.comm, None)
+    omx.ops.synchronize()
+    got = buf.numpy().astype(np.float32).ravel()
+    return {"n": n, "dtype": dtype, "rc": int(rc), "equal": bool(rc == 0 and np.array_equal(got, want))}
+
+
+dist.barrier()
+res["large"] = [large_check(n, dt, i) for i, (n, dt) in enumerate([(262144, "f32"), (1000004, "f32"), (2048 * 4096, "bf16"), (40 * 1024 + 8, "bf16"),
+                                                                   (8200, "f32"), (2048 * 4096, "bf16")])]
+res["aborted_after_large"] = pc.aborted()
+
 cfg = dict(hidden_size=1024, num_hidden_layers=2, intermediate_size=3072, num_attention_heads=8, num_key_value_heads=2, head_dim=128,
            vocab_size=4096, rms_norm_eps=1e-6, rope_theta=1e6, tie_word_embeddings=False)
 if len(sys.argv) > 2 and sys.argv[2] == "8b":      # two layers of the real Qwen3-8B shapes (the shards bench.py --gpus N runs)
@@ -92,6 +123,11 @@ t0 = time.perf_counter()
 m.decode(64)
 res["step_ms"] = (time.perf_counter() - t0) * 1e3 / 64
 res["decode_path"] = m.decode_path()
+# the same prompt as ONE batched pass: its [T, hidden] bf16 reductions take the two-shot path
+os.environ["OMX_PREFILL_SERIAL"] = "0"
+m.reset()
+dist.barrier()
+res["tokens_batched"] = [int(m.prefill(prompt))] + [int(x) for x in m.decode(15)]
 res["aborted"] = pc.aborted()
 dist.barrier()
 m.close()

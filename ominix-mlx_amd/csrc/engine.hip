@@ -93,9 +93,12 @@ __global__ __launch_bounds__(256) void qembed_kernel(bf16_t* __restrict__ h, con
 }
 
 // h = bf16(resid + bf16(all-reduced partial)): the residual of a block whose output arrives as an f32 sum over the ranks
-__global__ void ep_fold_kernel(bf16_t* __restrict__ out, const bf16_t* __restrict__ resid, const float* __restrict__ partial, int64_t n) {
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-        out[i] = f32_to_bf16(bf16_to_f32(resid[i]) + round_bf16(partial[i]));
+// (f16: a float16 model -- the same two roundings in float16)
+__global__ void ep_fold_kernel(bf16_t* __restrict__ out, const bf16_t* __restrict__ resid, const float* __restrict__ partial, int64_t n, bool f16 = false) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        if (f16) out[i] = Act16<true>::bits(Act16<true>::val(resid[i]) + Act16<true>::rnd(partial[i]));
+        else out[i] = f32_to_bf16(bf16_to_f32(resid[i]) + round_bf16(partial[i]));
+    }
 }
 
 uint32_t crc32_str(const char* s) {
@@ -340,8 +343,8 @@ int resolve_weights(omx_qwen3 m) {
             }
         }
         if (getq("model.embed_tokens", m->cfg.vocab_size, &m->q_embed) || get("model.norm.weight", &m->final_norm)) return 1;
-        if (m->cfg.tie_word_embeddings) m->q_head = m->q_embed;            // QuantizedEmbedding::as_linear (quantized.rs:166-180)
-        else if (getq("lm_head", m->V, &m->q_head, hd)) return 1;
+        if (m->cfg.tie_word_embeddings && m->cfg.tp_size <= 1) m->q_head = m->q_embed;   // QuantizedEmbedding::as_linear (quantized.rs:166-180)
+        else if (getq("lm_head", m->V, &m->q_head, hd)) return 1;                        // (tied under TP: the caller registers the table's vocabulary shard as lm_head.*)
         m->weights_resolved = true;
         return 0;
     }
@@ -471,6 +474,18 @@ int enqueue_step_quant(omx_qwen3 m, bool with_head) {
     OMX_LAUNCH_CHECK();
     bf16_t* h = m->h;
     bf16_t* hn = m->h2;
+    // tensor parallel (round 4): q / k / v / gate / up / lm_head are this rank's packed rows, o / down its K slices (whole groups) --
+    // their unrounded f32 row sums are all-reduced and folded into the residual by a launch of their own (the bf16 step folds them in
+    // the next GEMV's prologue: the packed kernels' prologues are left alone)
+    const bool tp = c.ep_size <= 1 && (c.tp_size > 1 || m->allreduce != nullptr);
+    auto reduce_fold = [&](float* partial) -> int {
+        OMX_REQUIRE(m->allreduce != nullptr, "tp_size > 1 but no communicator set (omx_qwen3_set_comm)");
+        OMX_REQUIRE(m->allreduce(partial, partial, hd, kNcclFloat32, kNcclSum, m->comm, s) == 0, "ncclAllReduce failed");
+        ep_fold_kernel<<<8, 256, 0, s>>>(hn, h, partial, (int64_t)hd, sf16);
+        OMX_LAUNCH_CHECK();
+        bf16_t* t = h; h = hn; hn = t;
+        return 0;
+    };
     for (int l = 0; l < c.num_hidden_layers; ++l) {
         const LayerW& L = m->layers[l];
         const LayerQ& Q = m->qlayers[l];
@@ -481,11 +496,16 @@ int enqueue_step_quant(omx_qwen3 m, bool with_head) {
             a.x = h; a.norm_w = L.in_ln; a.eps = c.rms_norm_eps; a.out = m->qkv; a.scales_f16 = sf16;
             if (launch_qgemv(a, bits, PRO_RMSNORM, EPI_STORE, s)) return 1;
         }
-        const bool fused_o = attention_takes_oproj(m);
+        const bool fused_o = !tp && attention_takes_oproj(m);
         // [q/k RMSNorm + RoPE + cache append + split-KV SDPA + merge]: the bf16 kernel (+ [O + residual] on the packed matrix)
         if (enqueue_attention(m, l, s, fused_o ? h : nullptr, fused_o ? hn : nullptr)) return 1;
         if (fused_o) {
             bf16_t* t = h; h = hn; hn = t;
+        } else if (tp) {   // [O partial] [all-reduce] [+ residual]
+            QGemvArgs a = {};
+            a.m[0] = Q.o; a.N = hd; a.K = m->H * D; a.group = group;
+            a.x = m->attn_out; a.out_f32 = m->partial_a; a.scales_f16 = sf16;
+            if (launch_qgemv(a, bits, PRO_NONE, EPI_F32, s) || reduce_fold(m->partial_a)) return 1;
         } else {   // [O + residual]
             QGemvArgs a = {};
             a.m[0] = Q.o; a.N = hd; a.K = m->H * D; a.group = group;
@@ -508,7 +528,12 @@ int enqueue_step_quant(omx_qwen3 m, bool with_head) {
             a.x = h; a.norm_w = L.post_ln; a.eps = c.rms_norm_eps; a.out = m->act; a.scales_f16 = sf16;
             if (launch_qgemv(a, bits, PRO_RMSNORM, EPI_SWIGLU, s)) return 1;
         }
-        {   // [down + residual]
+        if (tp) {   // [down partial] [all-reduce] [+ residual]
+            QGemvArgs a = {};
+            a.m[0] = Q.down; a.N = hd; a.K = m->I; a.group = group;
+            a.x = m->act; a.out_f32 = m->partial_b; a.scales_f16 = sf16;
+            if (launch_qgemv(a, bits, PRO_NONE, EPI_F32, s) || reduce_fold(m->partial_b)) return 1;
+        } else {   // [down + residual]
             QGemvArgs a = {};
             a.m[0] = Q.down; a.N = hd; a.K = m->I; a.group = group;
             a.x = m->act; a.resid = h; a.out = hn; a.scales_f16 = sf16;
@@ -521,11 +546,20 @@ int enqueue_step_quant(omx_qwen3 m, bool with_head) {
         a.m[0] = m->q_head; a.m[0].n = m->V; a.N = m->V; a.K = hd; a.group = group;
         a.x = h; a.norm_w = m->final_norm; a.eps = c.rms_norm_eps; a.out = m->logits; a.scales_f16 = sf16;
         a.argmax_slot = m->argmax_partials;
+        a.row_offset = c.tp_rank * m->V;                 // this rank's vocabulary shard
         if (launch_qgemv(a, bits, PRO_RMSNORM, EPI_ARGMAX, s)) return 1;
         if (add_sampling_noise(m, s)) return 1;
+        if (tp) {   // the ranks' packed (logit, index) keys: one unsigned max picks the token (enqueue_step_tail)
+            sample_finalize_kernel<<<1, 256, 0, s>>>(m->st, m->argmax_partials, m->n_argmax_partials, m->out_ring, m->ring_cap, m->argmax_key);
+            OMX_LAUNCH_CHECK();
+            OMX_REQUIRE(m->allreduce(m->argmax_key, m->argmax_key, 1, kNcclUint64, kNcclMax, m->comm, s) == 0, "ncclAllReduce failed");
+            apply_token_kernel<<<1, 1, 0, s>>>(m->st, m->argmax_key, m->out_ring, m->ring_cap);
+            OMX_LAUNCH_CHECK();
+        } else {
         OMX_LAUNCH(sample_finalize_kernel, 1, 256, 0, s, m->st, m->argmax_partials, m->n_argmax_partials, m->out_ring, m->ring_cap,
                    (unsigned long long*)nullptr);
         OMX_LAUNCH_CHECK();
+        }
     } else {
         feed_prompt_kernel<<<1, 1, 0, s>>>(m->st, m->prompt_dev);
         OMX_LAUNCH_CHECK();
@@ -1227,7 +1261,9 @@ int omx_qwen3_create(omx_qwen3* out, const omx_qwen3_config* cfg) {
                        (c.num_attention_heads / c.num_key_value_heads) % (c.tp_size / c.num_key_value_heads) == 0),
                 "InvalidConfig: %d kv heads cannot be split or replicated over tp_size %d", c.num_key_value_heads, c.tp_size);
     OMX_REQUIRE(c.quant_bits == 0 || c.quant_bits == 4 || c.quant_bits == 8, "InvalidConfig: quantization bits %d (0 = bf16, 4, 8)", c.quant_bits);
-    OMX_REQUIRE(c.quant_bits == 0 || c.tp_size == 1, "InvalidConfig: quantized checkpoints run on a single GPU (tp_size %d)", c.tp_size);
+    // (round 4) quantized checkpoints under tensor parallelism: the packed rows / K slices of the dense model; no experts, bf16 triplets
+    OMX_REQUIRE(c.quant_bits == 0 || c.tp_size == 1 || c.num_experts == 0,
+                "InvalidConfig: a quantized checkpoint under tensor parallelism (tp_size %d) must be a dense model", c.tp_size);
     omx_qwen3 m = new omx_qwen3_();
     m->cfg = c;
     if (m->cfg.rope_scale == 0.f) m->cfg.rope_scale = 1.f;
@@ -1235,8 +1271,8 @@ int omx_qwen3_create(omx_qwen3* out, const omx_qwen3_config* cfg) {
     if (m->cfg.quant_bits && m->cfg.quant_group == 0) m->cfg.quant_group = 64;     // nn/quantized.rs:330-333
     OMX_REQUIRE(!m->cfg.quant_bits || m->cfg.quant_group == 32 || m->cfg.quant_group == 64 || m->cfg.quant_group == 128,
                 "InvalidConfig: quantization group_size %d (32, 64, 128)", m->cfg.quant_group);
-    OMX_REQUIRE(!m->cfg.quant_scales_f16 || (m->cfg.quant_bits && m->cfg.tp_size <= 1 && m->cfg.ep_size <= 1 && m->cfg.head_dim == 128),
-                "InvalidConfig: a float16 checkpoint (quantization scales_dtype float16) runs as a single-rank packed model with head_dim 128 (dense or sparse-MoE)");
+    OMX_REQUIRE(!m->cfg.quant_scales_f16 || (m->cfg.quant_bits && m->cfg.ep_size <= 1 && m->cfg.head_dim == 128),
+                "InvalidConfig: a float16 checkpoint (quantization scales_dtype float16) runs as a packed model with head_dim 128 (dense, also tensor-parallel; sparse-MoE on one rank)");
     m->H = c.num_attention_heads / c.tp_size;
     m->Hkv = c.num_key_value_heads >= c.tp_size ? c.num_key_value_heads / c.tp_size : 1;
     m->I = c.intermediate_size / c.tp_size;
@@ -1445,9 +1481,12 @@ static int synth_weights_impl(omx_qwen3 m, uint32_t base_seed, bool peaked) {
         size_t biggest = (size_t)std::max((int64_t)c.vocab_size, (int64_t)std::max(m->I, Hq)) * (size_t)std::max(hd, m->I);
         if (c.num_experts > 0) biggest = std::max(biggest, (size_t)c.num_experts * c.moe_intermediate_size * (size_t)hd);   // a whole expert stack
         OMX_HIP_CHECK(hipMalloc((void**)&scratch, biggest * 2));
-        auto makeq = [&](const std::string& prefix, int64_t rows, int64_t cols) -> int {
-            const uint32_t seed = base_seed ^ crc32_str((prefix + ".weight").c_str());
-            if (omx_fill_uniform_2d(scratch, rows, cols, cols, 0, 0, seed, amp_w, 0.0f, OMX_BFLOAT16, m->stream)) return 1;
+        // (ld_full, row0, col0): this rank's window of the logical matrix -- quantisation is per group of one row, so the window's
+        // triplet IS the slice of the whole matrix's triplet (K slices hold whole groups); seed_of: the logical tensor the values belong to
+        auto makeq = [&](const std::string& prefix, int64_t rows, int64_t cols, int64_t ld_full = 0, int64_t row0 = 0, int64_t col0 = 0,
+                         const char* seed_of = nullptr) -> int {
+            const uint32_t seed = base_seed ^ crc32_str(seed_of ? seed_of : (prefix + ".weight").c_str());
+            if (omx_fill_uniform_2d(scratch, rows, cols, ld_full ? ld_full : cols, row0, col0, seed, amp_w, 0.0f, OMX_BFLOAT16, m->stream)) return 1;
             uint32_t* pk = nullptr;
             bf16_t *sc = nullptr, *bi = nullptr;
             if (dev_alloc(m, &pk, (size_t)(rows * cols * c.quant_bits / 32)) || dev_alloc(m, &sc, (size_t)(rows * cols / c.quant_group)) ||
@@ -1462,8 +1501,9 @@ static int synth_weights_impl(omx_qwen3 m, uint32_t base_seed, bool peaked) {
         int rc = 0;
         for (int i = 0; i < c.num_hidden_layers && !rc; ++i) {
             const std::string p = "model.layers." + std::to_string(i) + ".";
-            rc = makeq(p + "self_attn.q_proj", Hq, hd) || makeq(p + "self_attn.k_proj", Hk, hd) || makeq(p + "self_attn.v_proj", Hk, hd) ||
-                 makeq(p + "self_attn.o_proj", hd, Hq) || make(p + "input_layernorm.weight", 1, hd, hd, 0, 0, true) ||
+            rc = makeq(p + "self_attn.q_proj", Hq, hd, hd, (int64_t)r * Hq) || makeq(p + "self_attn.k_proj", Hk, hd, hd, kv_row0) ||
+                 makeq(p + "self_attn.v_proj", Hk, hd, hd, kv_row0) ||
+                 makeq(p + "self_attn.o_proj", hd, Hq, (int64_t)c.num_attention_heads * D, 0, (int64_t)r * Hq) || make(p + "input_layernorm.weight", 1, hd, hd, 0, 0, true) ||
                  make(p + "post_attention_layernorm.weight", 1, hd, hd, 0, 0, true);
             if (!rc && !c.no_qk_norm) rc = make(p + "self_attn.q_norm.weight", 1, D, D, 0, 0, true) || make(p + "self_attn.k_norm.weight", 1, D, D, 0, 0, true);
             if (!rc && c.num_experts > 0) {
@@ -1472,11 +1512,13 @@ static int synth_weights_impl(omx_qwen3 m, uint32_t base_seed, bool peaked) {
                 rc = makeq(mp + "gate", E, hd) || makeq(mp + "switch_mlp.gate_proj", E * Im, hd) || makeq(mp + "switch_mlp.up_proj", E * Im, hd) ||
                      makeq(mp + "switch_mlp.down_proj", E * hd, Im);
             } else if (!rc) {
-                rc = makeq(p + "mlp.gate_proj", m->I, hd) || makeq(p + "mlp.up_proj", m->I, hd) || makeq(p + "mlp.down_proj", hd, m->I);
+                rc = makeq(p + "mlp.gate_proj", m->I, hd, hd, (int64_t)r * m->I) || makeq(p + "mlp.up_proj", m->I, hd, hd, (int64_t)r * m->I) ||
+                     makeq(p + "mlp.down_proj", hd, m->I, c.intermediate_size, 0, (int64_t)r * m->I);
             }
         }
         rc = rc || makeq("model.embed_tokens", c.vocab_size, hd) || make("model.norm.weight", 1, hd, hd, 0, 0, true);
-        if (!rc && !c.tie_word_embeddings) rc = makeq("lm_head", m->V, hd);
+        if (!rc && !c.tie_word_embeddings) rc = makeq("lm_head", m->V, hd, hd, (int64_t)r * m->V);
+        else if (!rc && c.tp_size > 1) rc = makeq("lm_head", m->V, hd, hd, (int64_t)r * m->V, 0, "model.embed_tokens.weight");   // tied: the table's shard
         (void)hipStreamSynchronize(m->stream);
         (void)hipFree(scratch);
         m->weights_resolved = false;

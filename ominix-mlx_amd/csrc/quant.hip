@@ -277,6 +277,8 @@ __global__ __launch_bounds__(256) void qgemv_kernel(const QGemvArgs a) {
                     const float v0 = acc[LR * r], v1 = acc[LR * r + (LR - 1)];
                     if (EPI == EPI_STORE) {
                         out[row] = A16::bits(v0);
+                    } else if (EPI == EPI_F32) {
+                        a.out_f32[row] = v0;
                     } else if (EPI == EPI_RESIDUAL) {
                         out[row] = A16::bits(A16::val(a.resid[row]) + A16::rnd(v0));
                     } else if (EPI == EPI_SWIGLU) {
@@ -291,7 +293,7 @@ __global__ __launch_bounds__(256) void qgemv_kernel(const QGemvArgs a) {
                     } else if (EPI == EPI_ARGMAX) {
                         const bf16_t lb = A16::bits(v0);
                         out[row] = lb;
-                        const uint64_t key = qargmax_key(A16::val(lb), (uint32_t)row);
+                        const uint64_t key = qargmax_key(A16::val(lb), (uint32_t)(row + a.row_offset));
                         best = key > best ? key : best;
                     }
                 }
@@ -458,6 +460,7 @@ int launch_qgemv_w(const QGemvArgs& a, int pro, int epi, hipStream_t s) {
     OMX_QGEMV_CASE(PRO_RMSNORM, EPI_SWIGLU)
     OMX_QGEMV_CASE(PRO_NONE, EPI_SWIGLU)
     OMX_QGEMV_CASE(PRO_RMSNORM, EPI_ARGMAX)
+    OMX_QGEMV_CASE(PRO_NONE, EPI_F32)
 #undef OMX_QGEMV_CASE
 #undef OMX_QGEMV_LAUNCH
     return set_error("quantized gemv: unsupported prologue/epilogue combination %d/%d", pro, epi);

@@ -39,6 +39,10 @@ struct QGemvArgs {
     int rolled_stage;           // A/B: stage the activation with the rolled loop (OMX_QGEMV_ROLLED_STAGE=1)
     int scales_f16;             // scales / biases (and QMat::sb's halves) hold float16 bit patterns: a float16 MLX checkpoint.  The
                                 // activations stay bf16; every group's scale / bias enters the arithmetic as its exact float32 value
+    // tensor parallel (round 4): EPI_F32 leaves the unrounded f32 row sums of this rank's K slice in out_f32 [N] (the all-reduce and the
+    // fold into the residual follow as their own launches); EPI_ARGMAX numbers its rows from row_offset (this rank's vocabulary shard)
+    float* out_f32;
+    int row_offset;
 };
 // packed [rows, cols*bits/32] -> bf16 [rows, cols]; scales_f16: scales / biases are float16 (engine-internal form of omx_dequantize)
 int launch_dequantize_bf16(bf16_t* out, const uint32_t* packed, const void* scales, const void* biases, int64_t rows, int cols, int group_size,

@@ -27,6 +27,18 @@ EXPERT_ROW_SPLIT = ("switch_mlp.gate_proj.weight", "switch_mlp.up_proj.weight")
 EXPERT_COL_SPLIT = ("switch_mlp.down_proj.weight",)
 
 
+# quantized checkpoints (round 4): "<stem>.weight" is the packed uint32 matrix [out, in * bits / 32], ".scales" / ".biases" are
+# [out, in / group] -- rows split like the dense rows, K slices (whole groups: in / world is a multiple of the group size) as equal
+# parts of the last axis of all three
+QUANT_LEAVES = (".scales", ".biases")
+
+
+def _split_kind(name: str, table) -> bool:
+    if name.endswith(table):
+        return True
+    return name.endswith(QUANT_LEAVES) and (name.rsplit(".", 1)[0] + ".weight").endswith(table)
+
+
 def kv_replication(num_key_value_heads: int, world: int) -> int:
     """How many ranks share one KV head: 1 while every rank owns whole KV heads; world / Hkv once there are fewer KV heads than
     ranks (SURVEY.md 8e: "Qwen2.5-7B has Hkv=4 -> replicate KV heads x2 at TP=8") -- rank r then holds KV head r // rep."""
@@ -62,10 +74,12 @@ def shard(name: str, arr: np.ndarray, rank: int, world: int, num_key_value_heads
     if name.endswith(EXPERT_COL_SPLIT):
         n = arr.shape[2] // world
         return keep_kind(arr, np.ascontiguousarray(arr[:, :, rank * n:(rank + 1) * n]))
-    if name.endswith(ROW_SPLIT):
+    if _split_kind(name, ROW_SPLIT):
         n = arr.shape[0] // world
         return keep_kind(arr, np.ascontiguousarray(arr[rank * n:(rank + 1) * n]))
-    if name.endswith(COL_SPLIT):
+    if _split_kind(name, COL_SPLIT):
+        if arr.shape[1] % world:
+            raise ValueError(f"InvalidConfig: {name} has {arr.shape[1]} columns, not divisible by tp_size={world}")
         n = arr.shape[1] // world
         return keep_kind(arr, np.ascontiguousarray(arr[:, rank * n:(rank + 1) * n]))
     return arr
@@ -75,7 +89,9 @@ def shard_state_dict(weights: dict, rank: int, world: int, tie_word_embeddings: 
                      head_dim: int = 0) -> dict:
     out = {k: shard(k, v, rank, world, num_key_value_heads, head_dim) for k, v in weights.items()}
     if tie_word_embeddings and world > 1:
-        out["lm_head.weight"] = shard("lm_head.weight", weights["model.embed_tokens.weight"], rank, world)
+        for leaf in (".weight",) + QUANT_LEAVES:      # (a quantized table: the shard of its whole triplet)
+            if "model.embed_tokens" + leaf in weights:
+                out["lm_head" + leaf] = shard("lm_head" + leaf, weights["model.embed_tokens" + leaf], rank, world)
     return out
 
 

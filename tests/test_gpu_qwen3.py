@@ -365,6 +365,57 @@ def test_tensor_parallel_two_ranks_on_one_gpu(omx, monkeypatch, name, serial_pre
     group.close()
 
 
+@pytest.mark.parametrize("name,bits,serial_prefill", [("kv_split", 4, "1"), ("kv_split", 4, "0"), ("kv_replicated", 4, "0"), ("kv_split", 8, "1")])
+def test_quantized_tensor_parallel_two_ranks_on_one_gpu(omx, monkeypatch, name, bits, serial_prefill):
+    """Round 4: an MLX-quantized checkpoint under tensor parallelism.  q / k / v / gate / up / lm_head are the rank's packed rows (weight,
+    scales, biases alike), o / down its K slices -- whole quantisation groups, so the slice of the triplet IS the triplet of the slice
+    (tp.shard on the three leaves; the device generator quantises the rank's window of the synthetic bf16 matrix).  The packed GEMVs
+    of the row-split projections leave unrounded f32 row sums (quant.hip EPI_F32), all-reduced and folded into the residual like the
+    bf16 step's.  Rank 0 takes the host-sharded oracle triplets, rank 1 the generated ones; both must emit the same tokens, and
+    tokens / logits must agree with the oracle on the unsharded quantized checkpoint within the quantized engine's bound."""
+    from ominix_mlx_amd import comm, engine
+    cfg = TP_CONFIGS[name]
+    group_size = 64
+    qw = rq.quantize_weights(cfg, rq.synth_weights(cfg), bits, group_size)
+    oracle = rq.Qwen3Oracle(cfg, qw, quant=(bits, group_size))
+    prompt = synth.prompt_ids(40, cfg.vocab_size)
+    n_new = 10
+    ref_tokens, ref_logits = oracle.generate(prompt, n_new, return_logits=True)
+    monkeypatch.setenv("OMX_PREFILL_SERIAL", serial_prefill)
+    world = 2
+    group = comm.LoopbackGroup(world, 1 << 20)
+    models = []
+    for r in range(world):
+        m = engine.Model(hidden_size=cfg.hidden_size, num_hidden_layers=cfg.num_hidden_layers, intermediate_size=cfg.intermediate_size,
+                         num_attention_heads=cfg.num_attention_heads, num_key_value_heads=cfg.num_key_value_heads, head_dim=cfg.head_dim,
+                         vocab_size=cfg.vocab_size, rms_norm_eps=cfg.rms_norm_eps, rope_theta=cfg.rope_theta,
+                         tie_word_embeddings=cfg.tie_word_embeddings, max_context=256, tp_rank=r, tp_size=world,
+                         quantization={"bits": bits, "group_size": group_size})
+        m.load_weights(qw) if r == 0 else m.synth_weights()
+        m.set_comm(group.rank_comm(r), group.allreduce_fn)
+        models.append(m)
+
+    def run(r):
+        first = models[r].prefill(prompt)
+        logits0 = models[r].last_logits()
+        return np.concatenate([[first], models[r].decode(n_new - 1)]).astype(np.uint32), logits0
+
+    outs = comm.run_ranks(world, run, group)
+    np.testing.assert_array_equal(outs[0][0], outs[1][0])
+    got = outs[0][0]
+    logits0 = np.concatenate([outs[0][1], outs[1][1]])       # vocabulary shards
+    bound = 2.0 ** -7 * np.abs(ref_logits).max() * np.sqrt(2 * cfg.num_hidden_layers)
+    assert np.abs(logits0 - ref_logits[0]).max() <= bound * (1.0 if serial_prefill == "1" else 1.5)   # bf16 partials in the batched pass
+    margins = rc.argmax_margin(ref_logits)
+    for i in range(n_new):
+        if got[i] != ref_tokens[i]:
+            assert margins[i] <= 2 * bound, f"token {i}: got {got[i]} want {ref_tokens[i]} with margin {margins[i]:.4f}"
+            break
+    for m in models:
+        m.close()
+    group.close()
+
+
 @pytest.mark.parametrize("name,bits,group", [("gqa4_d128", 4, 64), ("gqa2_d64", 4, 64), ("gqa4_d128", 8, 64)])
 def test_quantized_checkpoint_decode_matches_oracle(omx, name, bits, group):
     """MLX-quantized checkpoint (config.json "quantization", qwen3-mlx/src/model.rs:621-727): every Linear is a
@@ -464,6 +515,60 @@ def test_quantized_checkpoint_with_float16_scales(omx, tmp_path):
     with pytest.raises(omx.OmxError, match="float16 scales / biases, but the model was created"):
         m2.load_weights(qw)
     m2.close()
+
+
+def test_float16_checkpoint_tensor_parallel_two_ranks_on_one_gpu(omx):
+    """Round 4 (review of round 3: "TP = 2 loopback with f16 triplets"): a float16 MLX checkpoint sharded over two ranks -- packed rows
+    and K slices with their float16 scales / biases (tp.shard), float16 activations, K / V and logits on every rank, the row-split
+    projections' f32 partials all-reduced and folded into the float16 residual (two float16 roundings, as the single-rank packed GEMV's
+    residual epilogue makes them).  Both ranks emit the same tokens; against the float16 oracle on the UNSHARDED checkpoint the logits
+    stay within the float16 engine's 2^-10-scaled bound (partial sums round differently: sqrt(2) on top, as for bf16 TP)."""
+    from ominix_mlx_amd import comm, engine
+    cfg, bits, group_size = TP_CONFIGS["kv_split"], 4, 64
+    base = rq.synth_weights(cfg)
+    qw = {}
+    for name, arr in rq.quantize_weights(cfg, base, bits, group_size).items():
+        if name.endswith((".scales", ".biases")):
+            prefix = name.rsplit(".", 1)[0]
+            w2 = base[prefix + ".weight"].reshape(-1, base[prefix + ".weight"].shape[-1])
+            _, s32, b32 = rc.quantize(w2, group_size, bits)
+            arr = (s32 if name.endswith(".scales") else b32).astype(np.float16).reshape(arr.shape)
+        qw[name] = arr
+    prompt = synth.prompt_ids(40, cfg.vocab_size)
+    n_new = 10
+    f16w = {k: (v.astype(np.float32) if v.dtype == np.float16 else v) for k, v in qw.items()}
+    ref_tokens, ref_logits = rq.Qwen3Oracle(cfg, f16w, dt="f16", quant=(bits, group_size)).generate(prompt, n_new, return_logits=True)
+    world = 2
+    group = comm.LoopbackGroup(world, 1 << 20)
+    models = []
+    for r in range(world):
+        m = engine.Model(hidden_size=cfg.hidden_size, num_hidden_layers=cfg.num_hidden_layers, intermediate_size=cfg.intermediate_size,
+                         num_attention_heads=cfg.num_attention_heads, num_key_value_heads=cfg.num_key_value_heads, head_dim=cfg.head_dim,
+                         vocab_size=cfg.vocab_size, rms_norm_eps=cfg.rms_norm_eps, rope_theta=cfg.rope_theta,
+                         tie_word_embeddings=cfg.tie_word_embeddings, max_context=256, tp_rank=r, tp_size=world,
+                         quantization={"bits": bits, "group_size": group_size, "scales_dtype": "float16"})
+        m.load_weights(qw)
+        m.set_comm(group.rank_comm(r), group.allreduce_fn)
+        models.append(m)
+
+    def run(r):
+        first = models[r].prefill(prompt)
+        logits0 = models[r].last_logits()
+        return np.concatenate([[first], models[r].decode(n_new - 1)]).astype(np.uint32), logits0
+
+    outs = comm.run_ranks(world, run, group)
+    np.testing.assert_array_equal(outs[0][0], outs[1][0])
+    got, logits0 = outs[0][0], np.concatenate([outs[0][1], outs[1][1]])
+    bound = 2.0 ** -10 * np.abs(ref_logits).max() * np.sqrt(2 * cfg.num_hidden_layers) * np.sqrt(2)
+    assert np.abs(logits0 - ref_logits[0]).max() <= bound, f"{np.abs(logits0 - ref_logits[0]).max():.5f} > {bound:.5f}"
+    margins = rc.argmax_margin(ref_logits)
+    for i in range(n_new):
+        if got[i] != ref_tokens[i]:
+            assert margins[i] <= 2 * bound, f"token {i}: got {got[i]} want {ref_tokens[i]} with margin {margins[i]:.4f}"
+            break
+    for m in models:
+        m.close()
+    group.close()
 
 
 @pytest.mark.parametrize("quant", [None, {"bits": 4, "group_size": 64}, {"bits": 4, "group_size": 64, "scales_dtype": "float16"}])

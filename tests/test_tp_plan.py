@@ -184,3 +184,35 @@ def test_expert_tensor_parallel_shard_plan():
     # and the rounded result is the oracle's SwitchGLU output for those slots
     want = rm.switch_glu(x, inds, wg, wu, wd, "bf16")[0]
     np.testing.assert_array_equal(rc.bf16_round(part), want)
+
+
+@pytest.mark.parametrize("bits", [4, 8])
+def test_quantized_triplets_shard_like_their_matrices(bits):
+    """Round 4: tp.shard on the three leaves of a quantized Linear.  Quantisation is per group of 64 values of one row, so the row
+    shard of (weight, scales, biases) dequantises to the row shard of the dequantised matrix, a K slice (whole groups) to its column
+    slice -- and quantising the bf16 shard directly gives the same triplet (what the device generator does).  The tied table's head
+    shard carries all three leaves."""
+    import omx_import
+    omx_import.load_package()
+    from ominix_mlx_amd import tp
+    group, world = 64, 2
+    rng = np.random.default_rng(5)
+    w = rc.bf16_round(rng.standard_normal((256, 1024)).astype(np.float32) * 0.05)
+    pk, sc, bi = rc.quantize(w, group, bits)
+    full = rc.dequantize(pk, sc, bi, group, bits, "bf16")
+    for stem, axis in (("model.layers.0.self_attn.q_proj", 0), ("model.layers.0.mlp.down_proj", 1), ("lm_head", 0), ("model.layers.0.self_attn.o_proj", 1)):
+        for r in range(world):
+            parts = [tp.shard(stem + leaf, arr, r, world) for leaf, arr in ((".weight", pk), (".scales", sc), (".biases", bi))]
+            n = w.shape[axis] // world
+            sl = (slice(r * n, (r + 1) * n), slice(None)) if axis == 0 else (slice(None), slice(r * n, (r + 1) * n))
+            np.testing.assert_array_equal(rc.dequantize(*parts, group, bits, "bf16"), full[sl])
+            again = rc.quantize(np.ascontiguousarray(w[sl]), group, bits)
+            for a, b in zip(parts, again):
+                np.testing.assert_array_equal(np.asarray(a), np.asarray(b))
+    # norms stay whole; a tied quantized table gets its head shard with all three leaves
+    norm = sc[0]
+    assert tp.shard("model.layers.0.input_layernorm.weight", norm, 1, world) is norm
+    sd = tp.shard_state_dict({"model.embed_tokens.weight": pk, "model.embed_tokens.scales": sc, "model.embed_tokens.biases": bi}, 1, world,
+                             tie_word_embeddings=True)
+    assert sd["lm_head.weight"].shape == (128, pk.shape[1]) and sd["lm_head.scales"].shape == (128, sc.shape[1]) and sd["lm_head.biases"].shape == (128, bi.shape[1])
+    assert sd["model.embed_tokens.weight"].shape == pk.shape

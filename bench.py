@@ -138,6 +138,11 @@ def collective_plan(args, world):
 # otherwise go to RCCL -- runs on the peer communicator (csrc/peer_allreduce.hip: one-shot below 32 KB, two-shot above), whose inboxes
 # and stages are HIP IPC mappings whether the peer sits on another GPU or on this one.  Not a measurement: a line from this mode says so.
 ONE_GPU = os.environ.get("OMX_BENCH_ONE_GPU") == "1"
+# where the scalars of the host-side reductions (rank status, MAX of the windows' times) live: on the device under the nccl backend;
+# under gloo (the one-GPU pre-flight) on the host -- a CUDA tensor reduced through gloo's staging path leaves the process in a state in
+# which every later kernel of BOTH ranks runs 3.3x slower (tools/two_rank_windows.py TRW_MODE=cuda_tensor: 12.1 against 3.67 ms per
+# step, toggling with every further such call: the "slow first window" of the first pre-flight runs)
+REDUCE_DEVICE = "cpu" if ONE_GPU else "cuda"
 if ONE_GPU:
     # launches whose workgroups ALL wait on each other (attention + O in one launch, the GEMV that reduces over the peers in its
     # epilogue) need their whole grid resident: with one GPU per rank it is, with two ranks' twin launches interleaved on the same CUs
@@ -207,7 +212,7 @@ def peer_comm(dist, rank, world, rccl):
         peer.self_test()
     except Exception as e:   # noqa: BLE001  (any failure: this run uses RCCL)
         err = str(e) or type(e).__name__
-    ok = torch.tensor([0 if err else 1], dtype=torch.int32, device="cuda")
+    ok = torch.tensor([0 if err else 1], dtype=torch.int32, device=REDUCE_DEVICE)
     if dist is not None:
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
     if int(ok.item()) == 1:
@@ -360,7 +365,7 @@ def mixtral_secondary(omx, steps=64, warm=8, n_prompt=2048, rank=0, world=1, com
     dt = time.perf_counter() - t0
     if dist is not None:
         import torch
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device=REDUCE_DEVICE)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     step_bytes = m.step_bytes(n_prompt + warm + steps // 2)
@@ -570,7 +575,7 @@ def main():
     if os.environ.get("OMX_BENCH_DEBUG") == "1":
         print(f"[bench rank {rank}] window 1: decode call {t_dec * 1e3:.1f} ms, with the closing barrier {elapsed * 1e3:.1f} ms, device {model.last_decode_ms():.1f} ms, path {model.decode_path()}, offset {model.offset()}", file=sys.stderr, flush=True)
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=REDUCE_DEVICE)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     dev_ms = model.last_decode_ms()
@@ -586,7 +591,7 @@ def main():
         if os.environ.get("OMX_BENCH_DEBUG") == "1":
             print(f"[bench rank {rank}] next window: {w * 1e3:.1f} ms, device {model.last_decode_ms():.1f} ms, path {model.decode_path()}, offset {model.offset()}", file=sys.stderr, flush=True)
         if dist is not None:
-            t = torch.tensor([w], dtype=torch.float64, device="cuda")
+            t = torch.tensor([w], dtype=torch.float64, device=REDUCE_DEVICE)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             w = float(t.item())
         window_tok_s.append(args.steps / w)

@@ -13,9 +13,16 @@ import bench
 import omx_import
 omx = omx_import.load_package()
 from ominix_mlx_amd import comm, engine
+MODE = os.environ.get("TRW_MODE", "")
+if "model_first" in MODE:
+    m = engine.Model(max_context=int(os.environ.get('TRW_CTX', '4096')), tp_rank=rank, tp_size=world, **bench.QWEN3_8B)
 pc = comm.PeerComm(comm.torch_all_gather_bytes(dist), rank, world)
 pc.self_test()
-m = engine.Model(max_context=int(os.environ.get('TRW_CTX', '4096')), tp_rank=rank, tp_size=world, **bench.QWEN3_8B)
+if "cuda_tensor" in MODE:      # bench.py's peer_comm(): a torch CUDA tensor reduced over gloo
+    ok = torch.tensor([1], dtype=torch.int32, device="cuda")
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+if "model_first" not in MODE:
+    m = engine.Model(max_context=int(os.environ.get('TRW_CTX', '4096')), tp_rank=rank, tp_size=world, **bench.QWEN3_8B)
 m.set_comm(pc.comm, pc.fn)
 m.synth_weights()
 ids = bench.prompt_ids(2048, bench.QWEN3_8B["vocab_size"])
@@ -25,7 +32,10 @@ if len(sys.argv) > 1 and sys.argv[1] == "reset":      # bench.py's sequence: the
     dist.barrier()
     m.prefill(ids)
 for n in ((4, 32, 32, 32) if os.environ.get('TRW_CTX') else (4, 32, 32, 8, 32, 64, 32, 16, 16)):
-    dist.barrier(); omx.check(omx.lib.omx_synchronize(m.stream()))
+    dist.barrier()
+    if "torch_sync" in MODE:
+        torch.cuda.synchronize()
+    omx.check(omx.lib.omx_synchronize(m.stream()))
     t0 = time.perf_counter()
     m.decode(n)
     omx.check(omx.lib.omx_synchronize(m.stream()))

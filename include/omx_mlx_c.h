@@ -376,6 +376,65 @@ int mlx_ones(mlx_array* res, const int* shape, size_t shape_num, mlx_dtype dtype
 int mlx_where(mlx_array* res, const mlx_array condition, const mlx_array x, const mlx_array y, const mlx_stream s);
 int mlx_clip(mlx_array* res, const mlx_array a, const mlx_array a_min /* may be null */, const mlx_array a_max /* may be null */, const mlx_stream s);
 
+/* ops.h, third batch (round 4, csrc/mlxc_glue2.hpp): composed from the ops above; signatures of mlx-rs/mlx-sys/src/mlx-c/mlx/c/ops.h */
+int mlx_sum_axes(mlx_array* res, const mlx_array a, const int* axes, size_t axes_num, bool keepdims, const mlx_stream s);
+int mlx_mean_axes(mlx_array* res, const mlx_array a, const int* axes, size_t axes_num, bool keepdims, const mlx_stream s);
+int mlx_max_axes(mlx_array* res, const mlx_array a, const int* axes, size_t axes_num, bool keepdims, const mlx_stream s);
+int mlx_min_axes(mlx_array* res, const mlx_array a, const int* axes, size_t axes_num, bool keepdims, const mlx_stream s);
+int mlx_all_axes(mlx_array* res, const mlx_array a, const int* axes, size_t axes_num, bool keepdims, const mlx_stream s);
+int mlx_any_axes(mlx_array* res, const mlx_array a, const int* axes, size_t axes_num, bool keepdims, const mlx_stream s);
+int mlx_logsumexp_axes(mlx_array* res, const mlx_array a, const int* axes, size_t axes_num, bool keepdims, const mlx_stream s);
+int mlx_prod_axes(mlx_array* res, const mlx_array a, const int* axes, size_t axes_num, bool keepdims, const mlx_stream s);
+int mlx_prod_axis(mlx_array* res, const mlx_array a, int axis, bool keepdims, const mlx_stream s);
+int mlx_prod(mlx_array* res, const mlx_array a, bool keepdims, const mlx_stream s);
+int mlx_var_axes(mlx_array* res, const mlx_array a, const int* axes, size_t axes_num, bool keepdims, int ddof, const mlx_stream s);
+int mlx_var_axis(mlx_array* res, const mlx_array a, int axis, bool keepdims, int ddof, const mlx_stream s);
+int mlx_var(mlx_array* res, const mlx_array a, bool keepdims, int ddof, const mlx_stream s);
+int mlx_std_axes(mlx_array* res, const mlx_array a, const int* axes, size_t axes_num, bool keepdims, int ddof, const mlx_stream s);
+int mlx_std_axis(mlx_array* res, const mlx_array a, int axis, bool keepdims, int ddof, const mlx_stream s);
+int mlx_std(mlx_array* res, const mlx_array a, bool keepdims, int ddof, const mlx_stream s);
+int mlx_softmax_axes(mlx_array* res, const mlx_array a, const int* axes, size_t axes_num, bool precise, const mlx_stream s);
+int mlx_softmax(mlx_array* res, const mlx_array a, bool precise, const mlx_stream s);   /* over all axes */
+int mlx_argmax(mlx_array* res, const mlx_array a, bool keepdims, const mlx_stream s);
+int mlx_argmin(mlx_array* res, const mlx_array a, bool keepdims, const mlx_stream s);
+int mlx_argmin_axis(mlx_array* res, const mlx_array a, int axis, bool keepdims, const mlx_stream s);
+int mlx_cumsum(mlx_array* res, const mlx_array a, int axis, bool reverse, bool inclusive, const mlx_stream s);
+int mlx_cumprod(mlx_array* res, const mlx_array a, int axis, bool reverse, bool inclusive, const mlx_stream s);
+int mlx_cummax(mlx_array* res, const mlx_array a, int axis, bool reverse, bool inclusive, const mlx_stream s);
+int mlx_cummin(mlx_array* res, const mlx_array a, int axis, bool reverse, bool inclusive, const mlx_stream s);
+int mlx_partition_axis(mlx_array* res, const mlx_array a, int kth, int axis, const mlx_stream s);   /* a full sort: one valid partition */
+int mlx_partition(mlx_array* res, const mlx_array a, int kth, const mlx_stream s);
+int mlx_argpartition(mlx_array* res, const mlx_array a, int kth, const mlx_stream s);
+int mlx_topk_axis(mlx_array* res, const mlx_array a, int k, int axis, const mlx_stream s);          /* the k largest, ascending */
+int mlx_topk(mlx_array* res, const mlx_array a, int k, const mlx_stream s);
+int mlx_tri(mlx_array* res, int n, int m, int k, mlx_dtype type, const mlx_stream s);
+int mlx_tril(mlx_array* res, const mlx_array x, int k, const mlx_stream s);
+int mlx_triu(mlx_array* res, const mlx_array x, int k, const mlx_stream s);
+int mlx_eye(mlx_array* res, int n, int m, int k, mlx_dtype dtype, const mlx_stream s);
+int mlx_identity(mlx_array* res, int n, mlx_dtype dtype, const mlx_stream s);
+int mlx_linspace(mlx_array* res, double start, double stop, int num, mlx_dtype dtype, const mlx_stream s);
+int mlx_outer(mlx_array* res, const mlx_array a, const mlx_array b, const mlx_stream s);
+int mlx_inner(mlx_array* res, const mlx_array a, const mlx_array b, const mlx_stream s);
+int mlx_atleast_1d(mlx_array* res, const mlx_array a, const mlx_stream s);
+int mlx_atleast_2d(mlx_array* res, const mlx_array a, const mlx_stream s);
+int mlx_atleast_3d(mlx_array* res, const mlx_array a, const mlx_stream s);
+int mlx_isclose(mlx_array* res, const mlx_array a, const mlx_array b, double rtol, double atol, bool equal_nan, const mlx_stream s);
+int mlx_allclose(mlx_array* res, const mlx_array a, const mlx_array b, double rtol, double atol, bool equal_nan, const mlx_stream s);
+int mlx_array_equal(mlx_array* res, const mlx_array a, const mlx_array b, bool equal_nan, const mlx_stream s);
+int mlx_degrees(mlx_array* res, const mlx_array a, const mlx_stream s);
+int mlx_radians(mlx_array* res, const mlx_array a, const mlx_stream s);
+int mlx_divmod(mlx_vector_array* res, const mlx_array a, const mlx_array b, const mlx_stream s);
+int mlx_unflatten(mlx_array* res, const mlx_array a, int axis, const int* shape, size_t shape_num, const mlx_stream s);
+int mlx_pad(mlx_array* res, const mlx_array a, const int* axes, size_t axes_num, const int* low_pad_size, size_t low_pad_size_num,
+            const int* high_pad_size, size_t high_pad_size_num, const mlx_array pad_value, const char* mode /* "constant" */, const mlx_stream s);
+int mlx_repeat_axis(mlx_array* res, const mlx_array arr, int repeats, int axis, const mlx_stream s);
+int mlx_repeat(mlx_array* res, const mlx_array arr, int repeats, const mlx_stream s);
+int mlx_tile(mlx_array* res, const mlx_array arr, const int* reps, size_t reps_num, const mlx_stream s);
+int mlx_diagonal(mlx_array* res, const mlx_array a, int offset, int axis1, int axis2, const mlx_stream s);   /* a view */
+int mlx_diag(mlx_array* res, const mlx_array a, int k, const mlx_stream s);
+int mlx_nan_to_num(mlx_array* res, const mlx_array a, float nan, mlx_optional_float posinf, mlx_optional_float neginf, const mlx_stream s);
+int mlx_broadcast_arrays(mlx_vector_array* res, const mlx_vector_array inputs, const mlx_stream s);
+
 #ifdef __cplusplus
 }
 #endif

@@ -5,6 +5,7 @@
 // EAGER: there is no lazy graph, an op enqueues its kernels on the device stream when called.
 // Arrays are ref-counted device buffers + (shape, strides, offset): reshape / transpose / slice are
 // views, ops that need contiguous data materialise them with a strided-copy kernel.
+#include <limits.h>
 #include <string.h>
 
 #include <algorithm>
@@ -1269,3 +1270,4 @@ int omx_mlx_fused_modulate(mlx_array* res, const mlx_array x, const mlx_array sh
 }  // extern "C"
 
 #include "mlxc_glue.hpp"   // devices, strings, maps, closures and the remaining glue ops (same translation unit: shares Arr / Vec)
+#include "mlxc_glue2.hpp"  // ops.h, third batch: composed from the ops above

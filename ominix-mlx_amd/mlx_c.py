@@ -306,6 +306,63 @@ SIGNATURES = {
     "mlx_ones": (c_int, [P_ARR, P_INT, c_size_t, c_int, mlx_stream]),
     "mlx_where": (c_int, [P_ARR, mlx_array, mlx_array, mlx_array, mlx_stream]),
     "mlx_clip": (c_int, [P_ARR, mlx_array, mlx_array, mlx_array, mlx_stream]),
+    # ops.h, third batch (csrc/mlxc_glue2.hpp)
+    "mlx_sum_axes": (c_int, [P_ARR, mlx_array, P_INT, c_size_t, c_bool, mlx_stream]),
+    "mlx_mean_axes": (c_int, [P_ARR, mlx_array, P_INT, c_size_t, c_bool, mlx_stream]),
+    "mlx_max_axes": (c_int, [P_ARR, mlx_array, P_INT, c_size_t, c_bool, mlx_stream]),
+    "mlx_min_axes": (c_int, [P_ARR, mlx_array, P_INT, c_size_t, c_bool, mlx_stream]),
+    "mlx_all_axes": (c_int, [P_ARR, mlx_array, P_INT, c_size_t, c_bool, mlx_stream]),
+    "mlx_any_axes": (c_int, [P_ARR, mlx_array, P_INT, c_size_t, c_bool, mlx_stream]),
+    "mlx_logsumexp_axes": (c_int, [P_ARR, mlx_array, P_INT, c_size_t, c_bool, mlx_stream]),
+    "mlx_prod_axes": (c_int, [P_ARR, mlx_array, P_INT, c_size_t, c_bool, mlx_stream]),
+    "mlx_prod_axis": (c_int, [P_ARR, mlx_array, c_int, c_bool, mlx_stream]),
+    "mlx_prod": (c_int, [P_ARR, mlx_array, c_bool, mlx_stream]),
+    "mlx_var_axes": (c_int, [P_ARR, mlx_array, P_INT, c_size_t, c_bool, c_int, mlx_stream]),
+    "mlx_var_axis": (c_int, [P_ARR, mlx_array, c_int, c_bool, c_int, mlx_stream]),
+    "mlx_var": (c_int, [P_ARR, mlx_array, c_bool, c_int, mlx_stream]),
+    "mlx_std_axes": (c_int, [P_ARR, mlx_array, P_INT, c_size_t, c_bool, c_int, mlx_stream]),
+    "mlx_std_axis": (c_int, [P_ARR, mlx_array, c_int, c_bool, c_int, mlx_stream]),
+    "mlx_std": (c_int, [P_ARR, mlx_array, c_bool, c_int, mlx_stream]),
+    "mlx_softmax_axes": (c_int, [P_ARR, mlx_array, P_INT, c_size_t, c_bool, mlx_stream]),
+    "mlx_softmax": (c_int, [P_ARR, mlx_array, c_bool, mlx_stream]),
+    "mlx_argmax": (c_int, [P_ARR, mlx_array, c_bool, mlx_stream]),
+    "mlx_argmin": (c_int, [P_ARR, mlx_array, c_bool, mlx_stream]),
+    "mlx_argmin_axis": (c_int, [P_ARR, mlx_array, c_int, c_bool, mlx_stream]),
+    "mlx_cumsum": (c_int, [P_ARR, mlx_array, c_int, c_bool, c_bool, mlx_stream]),
+    "mlx_cumprod": (c_int, [P_ARR, mlx_array, c_int, c_bool, c_bool, mlx_stream]),
+    "mlx_cummax": (c_int, [P_ARR, mlx_array, c_int, c_bool, c_bool, mlx_stream]),
+    "mlx_cummin": (c_int, [P_ARR, mlx_array, c_int, c_bool, c_bool, mlx_stream]),
+    "mlx_partition_axis": (c_int, [P_ARR, mlx_array, c_int, c_int, mlx_stream]),
+    "mlx_partition": (c_int, [P_ARR, mlx_array, c_int, mlx_stream]),
+    "mlx_argpartition": (c_int, [P_ARR, mlx_array, c_int, mlx_stream]),
+    "mlx_topk_axis": (c_int, [P_ARR, mlx_array, c_int, c_int, mlx_stream]),
+    "mlx_topk": (c_int, [P_ARR, mlx_array, c_int, mlx_stream]),
+    "mlx_tri": (c_int, [P_ARR, c_int, c_int, c_int, c_int, mlx_stream]),
+    "mlx_tril": (c_int, [P_ARR, mlx_array, c_int, mlx_stream]),
+    "mlx_triu": (c_int, [P_ARR, mlx_array, c_int, mlx_stream]),
+    "mlx_eye": (c_int, [P_ARR, c_int, c_int, c_int, c_int, mlx_stream]),
+    "mlx_identity": (c_int, [P_ARR, c_int, c_int, mlx_stream]),
+    "mlx_linspace": (c_int, [P_ARR, ctypes.c_double, ctypes.c_double, c_int, c_int, mlx_stream]),
+    "mlx_outer": (c_int, [P_ARR, mlx_array, mlx_array, mlx_stream]),
+    "mlx_inner": (c_int, [P_ARR, mlx_array, mlx_array, mlx_stream]),
+    "mlx_atleast_1d": (c_int, [P_ARR, mlx_array, mlx_stream]),
+    "mlx_atleast_2d": (c_int, [P_ARR, mlx_array, mlx_stream]),
+    "mlx_atleast_3d": (c_int, [P_ARR, mlx_array, mlx_stream]),
+    "mlx_isclose": (c_int, [P_ARR, mlx_array, mlx_array, ctypes.c_double, ctypes.c_double, c_bool, mlx_stream]),
+    "mlx_allclose": (c_int, [P_ARR, mlx_array, mlx_array, ctypes.c_double, ctypes.c_double, c_bool, mlx_stream]),
+    "mlx_array_equal": (c_int, [P_ARR, mlx_array, mlx_array, c_bool, mlx_stream]),
+    "mlx_degrees": (c_int, [P_ARR, mlx_array, mlx_stream]),
+    "mlx_radians": (c_int, [P_ARR, mlx_array, mlx_stream]),
+    "mlx_divmod": (c_int, [ctypes.POINTER(mlx_vector_array), mlx_array, mlx_array, mlx_stream]),
+    "mlx_unflatten": (c_int, [P_ARR, mlx_array, c_int, P_INT, c_size_t, mlx_stream]),
+    "mlx_pad": (c_int, [P_ARR, mlx_array, P_INT, c_size_t, P_INT, c_size_t, P_INT, c_size_t, mlx_array, c_char_p, mlx_stream]),
+    "mlx_repeat_axis": (c_int, [P_ARR, mlx_array, c_int, c_int, mlx_stream]),
+    "mlx_repeat": (c_int, [P_ARR, mlx_array, c_int, mlx_stream]),
+    "mlx_tile": (c_int, [P_ARR, mlx_array, P_INT, c_size_t, mlx_stream]),
+    "mlx_diagonal": (c_int, [P_ARR, mlx_array, c_int, c_int, c_int, mlx_stream]),
+    "mlx_diag": (c_int, [P_ARR, mlx_array, c_int, mlx_stream]),
+    "mlx_nan_to_num": (c_int, [P_ARR, mlx_array, c_float, mlx_optional_float, mlx_optional_float, mlx_stream]),
+    "mlx_broadcast_arrays": (c_int, [ctypes.POINTER(mlx_vector_array), mlx_vector_array, mlx_stream]),
     "mlx_sin": (c_int, [P_ARR, mlx_array, mlx_stream]),
     "mlx_sum_axis": (c_int, [P_ARR, mlx_array, c_int, c_bool, mlx_stream]),
     "mlx_argsort_axis": (c_int, [P_ARR, mlx_array, c_int, mlx_stream]),
@@ -834,3 +891,121 @@ def compile_unary(fn):
             lib.mlx_vector_array_free(vout)
     call._keep = (cb, compiled)
     return call
+
+
+# ---- ops.h, third batch (csrc/mlxc_glue2.hpp): thin wrappers, numpy-like argument order ----
+def _axes_form(fn_axes, fn_all):
+    def f(a, axes=None, keepdims=False):
+        if axes is None:
+            return Array.op(fn_all, a.h, keepdims, default_stream())
+        p, n = _ints([axes] if isinstance(axes, int) else axes)
+        return Array.op(fn_axes, a.h, p, n, keepdims, default_stream())
+    return f
+
+
+sum_axes = _axes_form(lib.mlx_sum_axes, lib.mlx_sum)
+mean_axes = _axes_form(lib.mlx_mean_axes, lib.mlx_mean)
+max_axes = _axes_form(lib.mlx_max_axes, lib.mlx_max)
+min_axes = _axes_form(lib.mlx_min_axes, lib.mlx_min)
+all_axes = _axes_form(lib.mlx_all_axes, lib.mlx_all)
+any_axes = _axes_form(lib.mlx_any_axes, lib.mlx_any)
+logsumexp_axes = _axes_form(lib.mlx_logsumexp_axes, lib.mlx_logsumexp)
+prod_axes = _axes_form(lib.mlx_prod_axes, lib.mlx_prod)
+
+
+def var(a, axes=None, keepdims=False, ddof=0, std=False):
+    if axes is None:
+        return Array.op(lib.mlx_std if std else lib.mlx_var, a.h, keepdims, ddof, default_stream())
+    p, n = _ints([axes] if isinstance(axes, int) else axes)
+    return Array.op(lib.mlx_std_axes if std else lib.mlx_var_axes, a.h, p, n, keepdims, ddof, default_stream())
+
+
+def softmax_axes(a, axes=None, precise=False):
+    if axes is None:
+        return Array.op(lib.mlx_softmax, a.h, precise, default_stream())
+    p, n = _ints(axes)
+    return Array.op(lib.mlx_softmax_axes, a.h, p, n, precise, default_stream())
+
+
+def argmax_all(a, keepdims=False): return Array.op(lib.mlx_argmax, a.h, keepdims, default_stream())
+def argmin(a, axis=None, keepdims=False):
+    if axis is None:
+        return Array.op(lib.mlx_argmin, a.h, keepdims, default_stream())
+    return Array.op(lib.mlx_argmin_axis, a.h, axis, keepdims, default_stream())
+
+
+def scan(kind, a, axis, reverse=False, inclusive=True):
+    return Array.op(getattr(lib, "mlx_cum" + kind), a.h, axis, reverse, inclusive, default_stream())
+
+
+def topk(a, k, axis=-1): return Array.op(lib.mlx_topk_axis, a.h, k, axis, default_stream())
+def partition(a, kth, axis=None):
+    if axis is None:
+        return Array.op(lib.mlx_partition, a.h, kth, default_stream())
+    return Array.op(lib.mlx_partition_axis, a.h, kth, axis, default_stream())
+
+
+def argpartition_flat(a, kth): return Array.op(lib.mlx_argpartition, a.h, kth, default_stream())
+def tri(n, m, k, dtype): return Array.op(lib.mlx_tri, n, m, k, dtype, default_stream())
+def tril(a, k=0): return Array.op(lib.mlx_tril, a.h, k, default_stream())
+def triu(a, k=0): return Array.op(lib.mlx_triu, a.h, k, default_stream())
+def eye(n, m, k, dtype): return Array.op(lib.mlx_eye, n, m, k, dtype, default_stream())
+def identity(n, dtype): return Array.op(lib.mlx_identity, n, dtype, default_stream())
+def linspace(start, stop, num, dtype): return Array.op(lib.mlx_linspace, float(start), float(stop), num, dtype, default_stream())
+def outer(a, b): return Array.op(lib.mlx_outer, a.h, b.h, default_stream())
+def inner(a, b): return Array.op(lib.mlx_inner, a.h, b.h, default_stream())
+def atleast(a, nd): return Array.op(getattr(lib, f"mlx_atleast_{nd}d"), a.h, default_stream())
+def isclose(a, b, rtol=1e-5, atol=1e-8, equal_nan=False): return Array.op(lib.mlx_isclose, a.h, b.h, rtol, atol, equal_nan, default_stream())
+def allclose(a, b, rtol=1e-5, atol=1e-8, equal_nan=False): return Array.op(lib.mlx_allclose, a.h, b.h, rtol, atol, equal_nan, default_stream())
+def array_equal(a, b, equal_nan=False): return Array.op(lib.mlx_array_equal, a.h, b.h, equal_nan, default_stream())
+def degrees(a): return Array.op(lib.mlx_degrees, a.h, default_stream())
+def radians(a): return Array.op(lib.mlx_radians, a.h, default_stream())
+
+
+def divmod_(a, b):
+    vec = lib.mlx_vector_array_new()
+    try:
+        _check(lib.mlx_divmod(ctypes.byref(vec), a.h, b.h, default_stream()))
+        return _unvec(vec)
+    finally:
+        lib.mlx_vector_array_free(vec)
+
+
+def unflatten(a, axis, shape):
+    p, n = _ints(shape)
+    return Array.op(lib.mlx_unflatten, a.h, axis, p, n, default_stream())
+
+
+def pad(a, axes, low, high, value):
+    pa, na = _ints(axes)
+    pl, nl = _ints(low)
+    ph, nh = _ints(high)
+    return Array.op(lib.mlx_pad, a.h, pa, na, pl, nl, ph, nh, value.h, b"constant", default_stream())
+
+
+def repeat(a, repeats, axis=None):
+    if axis is None:
+        return Array.op(lib.mlx_repeat, a.h, repeats, default_stream())
+    return Array.op(lib.mlx_repeat_axis, a.h, repeats, axis, default_stream())
+
+
+def tile(a, reps):
+    p, n = _ints(reps)
+    return Array.op(lib.mlx_tile, a.h, p, n, default_stream())
+
+
+def diagonal(a, offset=0, axis1=0, axis2=1): return Array.op(lib.mlx_diagonal, a.h, offset, axis1, axis2, default_stream())
+def diag(a, k=0): return Array.op(lib.mlx_diag, a.h, k, default_stream())
+def nan_to_num(a, nan=0.0, posinf=None, neginf=None):
+    opt = lambda v: mlx_optional_float(float(v) if v is not None else 0.0, v is not None)
+    return Array.op(lib.mlx_nan_to_num, a.h, float(nan), opt(posinf), opt(neginf), default_stream())
+
+
+def broadcast_arrays(arrays):
+    vec, out = _vec(arrays), lib.mlx_vector_array_new()
+    try:
+        _check(lib.mlx_broadcast_arrays(ctypes.byref(out), vec, default_stream()))
+        return _unvec(out)
+    finally:
+        lib.mlx_vector_array_free(vec)
+        lib.mlx_vector_array_free(out)

@@ -364,3 +364,131 @@ def test_whole_array_reductions_sort_and_broadcast_views(mx):
     np.testing.assert_array_equal(mx.binary_op("maximum", X, V).numpy(), np.maximum(x, v))
     with pytest.raises(Exception):
         mx.broadcast_to(X, (4, 6, 7))
+
+
+def test_third_batch_reductions_scans_and_selection(mx):
+    """ops.h (csrc/mlxc_glue2.hpp): multi-axis reductions (the reduced axes moved last and flattened: one pass, one rounding), prod,
+    var / std with ddof, softmax over several axes, argmax / argmin over the whole array and an axis (ties: the lowest index), the four
+    scans in both directions and both inclusivities, top-k / partition / argpartition (a full sort is a valid partition) -- vs numpy."""
+    from scipy.special import logsumexp, softmax
+    rng = np.random.default_rng(21)
+    x = rng.standard_normal((3, 4, 5, 6)).astype(np.float32)
+    X = mx.Array.from_numpy(x, mx.FLOAT32)
+    for name, fn, f in (("sum", mx.sum_axes, np.sum), ("mean", mx.mean_axes, np.mean), ("max", mx.max_axes, np.max), ("min", mx.min_axes, np.min),
+                        ("logsumexp", mx.logsumexp_axes, logsumexp), ("prod", mx.prod_axes, np.prod)):
+        for axes, keep in (((1, 3), False), ((0, 2), True), ((-1,), False), ((0, 1, 2, 3), False)):
+            want = f(x, axis=axes, keepdims=keep)
+            got = fn(X, axes, keep).numpy()
+            assert got.shape == want.shape, (name, axes, keep)
+            np.testing.assert_allclose(got, want, rtol=3e-5, atol=3e-5, err_msg=f"{name} {axes}")
+    small = mx.Array.from_numpy(x[0, 0, :2, :3], mx.FLOAT32)                  # (the whole array's product underflows float32)
+    np.testing.assert_allclose(mx.prod_axes(small).numpy(), np.prod(x[0, 0, :2, :3]), rtol=1e-5)
+    b = x > 0.3
+    B = mx.Array.from_numpy(b, mx.BOOL)
+    np.testing.assert_array_equal(mx.all_axes(B, (1, 2)).numpy(), b.all(axis=(1, 2)))
+    np.testing.assert_array_equal(mx.any_axes(B, (0, 3), True).numpy(), b.any(axis=(0, 3), keepdims=True))
+    i = rng.integers(-3, 4, (4, 5)).astype(np.int32)
+    I = mx.Array.from_numpy(i, mx.INT32)
+    np.testing.assert_array_equal(mx.prod_axes(I, (1,)).numpy(), np.prod(i, axis=1))
+    for ddof in (0, 1):
+        np.testing.assert_allclose(mx.var(X, (1, 2), False, ddof).numpy(), np.var(x, axis=(1, 2), ddof=ddof), rtol=2e-5, atol=2e-6)
+        np.testing.assert_allclose(mx.var(X, None, True, ddof, std=True).numpy(), np.std(x, ddof=ddof, keepdims=True), rtol=2e-5)
+        np.testing.assert_allclose(mx.var(X, 3, False, ddof, std=True).numpy(), np.std(x, axis=3, ddof=ddof), rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(mx.softmax_axes(X, (1, 3)).numpy(), softmax(x, axis=(1, 3)), rtol=2e-6, atol=1e-7)
+    np.testing.assert_allclose(mx.softmax_axes(X).numpy(), softmax(x), rtol=2e-6, atol=1e-9)
+    t = np.array([[3, 1, 1, 7, 7], [2, 2, 9, 0, 0]], np.float32)           # ties
+    T = mx.Array.from_numpy(t, mx.FLOAT32)
+    assert int(mx.argmax_all(T).numpy()) == int(np.argmax(t)) and int(mx.argmin(T).numpy()) == int(np.argmin(t))
+    assert mx.argmax_all(T, True).shape == (1, 1)
+    np.testing.assert_array_equal(mx.argmin(T, 1).numpy(), np.argmin(t, axis=1))
+    np.testing.assert_array_equal(mx.argmin(T, 0, True).numpy(), np.argmin(t, axis=0, keepdims=True))
+    y = rng.standard_normal((3, 7, 4)).astype(np.float32)
+    Y = mx.Array.from_numpy(y, mx.FLOAT32)
+    for kind, f in (("sum", np.cumsum), ("prod", np.cumprod), ("max", np.maximum.accumulate), ("min", np.minimum.accumulate)):
+        for axis in (0, 1, -1):
+            np.testing.assert_allclose(mx.scan(kind, Y, axis).numpy(), f(y, axis=axis), rtol=1e-5, atol=1e-6, err_msg=kind)
+            rev = np.flip(f(np.flip(y, axis), axis=axis), axis)
+            np.testing.assert_allclose(mx.scan(kind, Y, axis, reverse=True).numpy(), rev, rtol=1e-5, atol=1e-6, err_msg=kind + " reverse")
+    excl = np.concatenate([np.zeros((3, 1, 4), np.float32), np.cumsum(y, axis=1)[:, :-1]], axis=1)
+    np.testing.assert_allclose(mx.scan("sum", Y, 1, inclusive=False).numpy(), excl, rtol=1e-5, atol=1e-6)
+    np.testing.assert_array_equal(mx.scan("sum", I, 1).numpy(), np.cumsum(i, axis=1))
+    z = rng.standard_normal((5, 40)).astype(np.float32)
+    Z = mx.Array.from_numpy(z, mx.FLOAT32)
+    np.testing.assert_array_equal(np.sort(mx.topk(Z, 6).numpy(), axis=-1), np.sort(z, axis=-1)[:, -6:])
+    np.testing.assert_array_equal(np.sort(mx.topk(Z, 2, 0).numpy(), axis=0), np.sort(z, axis=0)[-2:])
+    p = mx.partition(Z, 11, 1).numpy()
+    assert (p[:, :11] <= p[:, 11:12]).all() and (p[:, 12:] >= p[:, 11:12]).all()
+    np.testing.assert_array_equal(np.sort(p, axis=1), np.sort(z, axis=1))
+    pf = mx.partition(Z, 50).numpy()
+    assert pf.shape == (200,) and pf[50] == np.sort(z.ravel())[50]
+    ap = mx.argpartition_flat(Z, 50).numpy()
+    assert z.ravel()[ap[50]] == np.sort(z.ravel())[50] and sorted(ap.tolist()) == list(range(200))
+
+
+def test_third_batch_constructors_comparisons_and_layout(mx):
+    """ops.h (csrc/mlxc_glue2.hpp): tri / tril / triu / eye / identity, linspace, outer / inner, atleast_nd, isclose / allclose /
+    array_equal (NaN and infinity rules), degrees / radians, divmod, unflatten, constant pad, repeat / tile, diagonal (a strided view)
+    and diag, nan_to_num, broadcast_arrays -- against numpy."""
+    rng = np.random.default_rng(22)
+    for n, m, k in ((4, 4, 0), (3, 5, 1), (5, 3, -2)):
+        np.testing.assert_array_equal(mx.tri(n, m, k, mx.FLOAT32).numpy(), np.tri(n, m, k, dtype=np.float32))
+        np.testing.assert_array_equal(mx.eye(n, m, k, mx.INT32).numpy(), np.eye(n, m, k, dtype=np.int32))
+    np.testing.assert_array_equal(mx.identity(6, mx.FLOAT32).numpy(), np.identity(6, np.float32))
+    x = rng.standard_normal((2, 5, 4)).astype(np.float32)
+    X = mx.Array.from_numpy(x, mx.FLOAT32)
+    for k in (-2, 0, 1):
+        np.testing.assert_array_equal(mx.tril(X, k).numpy(), np.tril(x, k))
+        np.testing.assert_array_equal(mx.triu(X, k).numpy(), np.triu(x, k))
+    np.testing.assert_allclose(mx.linspace(-1.5, 2.5, 9, mx.FLOAT32).numpy(), np.linspace(-1.5, 2.5, 9, dtype=np.float32), rtol=1e-6, atol=1e-6)
+    assert mx.linspace(0, 1, 1, mx.FLOAT32).numpy().tolist() == [0.0] and mx.linspace(0, 1, 0, mx.FLOAT32).shape == (0,)
+    a, b = rng.standard_normal(7).astype(np.float32), rng.standard_normal(5).astype(np.float32)
+    A_, B_ = mx.Array.from_numpy(a, mx.FLOAT32), mx.Array.from_numpy(b, mx.FLOAT32)
+    np.testing.assert_allclose(mx.outer(A_, B_).numpy(), np.outer(a, b), rtol=1e-6)
+    u, v = rng.standard_normal((3, 6)).astype(np.float32), rng.standard_normal((4, 6)).astype(np.float32)
+    np.testing.assert_allclose(mx.inner(mx.Array.from_numpy(u, mx.FLOAT32), mx.Array.from_numpy(v, mx.FLOAT32)).numpy(), np.inner(u, v), rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(mx.inner(A_, A_).numpy(), np.inner(a, a), rtol=1e-5)
+    s0 = mx.Array.from_numpy(np.float32(3.0), mx.FLOAT32)
+    assert mx.atleast(s0, 1).shape == (1,) and mx.atleast(s0, 2).shape == (1, 1) and mx.atleast(s0, 3).shape == (1, 1, 1)
+    assert mx.atleast(A_, 2).shape == (1, 7) and mx.atleast(A_, 3).shape == (1, 7, 1) and mx.atleast(X, 2).shape == (2, 5, 4)
+    assert mx.atleast(mx.Array.from_numpy(u, mx.FLOAT32), 3).shape == (3, 6, 1)
+    c = np.array([1.0, np.nan, np.inf, -np.inf, 2.0, 1e-9], np.float32)
+    d = np.array([1.0 + 1e-7, np.nan, np.inf, np.inf, 2.1, 0.0], np.float32)
+    C, D = mx.Array.from_numpy(c, mx.FLOAT32), mx.Array.from_numpy(d, mx.FLOAT32)
+    for en in (False, True):
+        np.testing.assert_array_equal(mx.isclose(C, D, 1e-5, 1e-8, en).numpy(), np.isclose(c, d, 1e-5, 1e-8, en))
+        assert bool(mx.allclose(C, D, 1e-5, 1e-8, en).numpy()) == bool(np.allclose(c, d, 1e-5, 1e-8, en))
+        assert bool(mx.array_equal(C, C, en).numpy()) == bool(np.array_equal(c, c, equal_nan=en))
+    assert bool(mx.allclose(A_, A_).numpy()) and not bool(mx.array_equal(A_, B_).numpy())      # different shapes: false, not an error
+    np.testing.assert_allclose(mx.degrees(A_).numpy(), np.degrees(a), rtol=1e-6)
+    np.testing.assert_allclose(mx.radians(A_).numpy(), np.radians(a), rtol=1e-6)
+    p, q = np.array([7, -7, 9, -9], np.int32), np.array([2, 2, -4, -4], np.int32)
+    dq, dr = mx.divmod_(mx.Array.from_numpy(p, mx.INT32), mx.Array.from_numpy(q, mx.INT32))
+    np.testing.assert_array_equal(dq.numpy(), p // q)
+    np.testing.assert_array_equal(dr.numpy(), p % q)
+    w = rng.standard_normal((3, 12, 2)).astype(np.float32)
+    W = mx.Array.from_numpy(w, mx.FLOAT32)
+    np.testing.assert_array_equal(mx.unflatten(W, 1, (3, 4)).numpy(), w.reshape(3, 3, 4, 2))
+    np.testing.assert_array_equal(mx.unflatten(W, 1, (-1, 2)).numpy(), w.reshape(3, 6, 2, 2))
+    pv = mx.Array.from_numpy(np.float32(-2.5), mx.FLOAT32)
+    np.testing.assert_array_equal(mx.pad(W, (0, 2), (1, 0), (2, 3), pv).numpy(), np.pad(w, ((1, 2), (0, 0), (0, 3)), constant_values=-2.5))
+    np.testing.assert_array_equal(mx.repeat(W, 3, 1).numpy(), np.repeat(w, 3, axis=1))
+    np.testing.assert_array_equal(mx.repeat(W, 2).numpy(), np.repeat(w, 2))
+    np.testing.assert_array_equal(mx.tile(W, (2, 1, 3)).numpy(), np.tile(w, (2, 1, 3)))
+    np.testing.assert_array_equal(mx.tile(A_, (2, 2)).numpy(), np.tile(a, (2, 2)))
+    g = rng.standard_normal((4, 5, 6)).astype(np.float32)
+    G = mx.Array.from_numpy(g, mx.FLOAT32)
+    for off, a1, a2 in ((0, 0, 1), (2, 1, 2), (-1, 0, 2), (1, 2, 0)):
+        np.testing.assert_array_equal(mx.diagonal(G, off, a1, a2).numpy(), np.diagonal(g, off, a1, a2))
+    for k in (0, 2, -1):
+        np.testing.assert_array_equal(mx.diag(A_, k).numpy(), np.diag(a, k))
+        np.testing.assert_array_equal(mx.diag(mx.Array.from_numpy(u, mx.FLOAT32), k).numpy(), np.diag(u, k))
+    np.testing.assert_array_equal(mx.nan_to_num(C, 5.0).numpy(), np.nan_to_num(c, nan=5.0))
+    np.testing.assert_array_equal(mx.nan_to_num(C, 0.0, 9.0, -9.0).numpy(), np.nan_to_num(c, nan=0.0, posinf=9.0, neginf=-9.0))
+    outs = mx.broadcast_arrays([mx.Array.from_numpy(a.reshape(7, 1), mx.FLOAT32), mx.Array.from_numpy(b.reshape(1, 5), mx.FLOAT32), s0])
+    want = np.broadcast_arrays(a.reshape(7, 1), b.reshape(1, 5), np.float32(3.0))
+    for o, wnt in zip(outs, want):
+        np.testing.assert_array_equal(o.numpy(), wnt)
+    with pytest.raises(Exception):
+        mx.broadcast_arrays([A_, B_])
+    with pytest.raises(Exception):
+        mx.pad(W, (0,), (1,), (1,), pv) if False else mx.unflatten(W, 1, (5, 5))

@@ -434,6 +434,21 @@ int mlx_diagonal(mlx_array* res, const mlx_array a, int offset, int axis1, int a
 int mlx_diag(mlx_array* res, const mlx_array a, int k, const mlx_stream s);
 int mlx_nan_to_num(mlx_array* res, const mlx_array a, float nan, mlx_optional_float posinf, mlx_optional_float neginf, const mlx_stream s);
 int mlx_broadcast_arrays(mlx_vector_array* res, const mlx_vector_array inputs, const mlx_stream s);
+const bool* mlx_array_data_bool(const mlx_array arr);
+const int8_t* mlx_array_data_int8(const mlx_array arr);
+const int16_t* mlx_array_data_int16(const mlx_array arr);
+const int64_t* mlx_array_data_int64(const mlx_array arr);
+const uint64_t* mlx_array_data_uint64(const mlx_array arr);
+int mlx_as_strided(mlx_array* res, const mlx_array a, const int* shape, size_t shape_num, const int64_t* strides, size_t strides_num, size_t offset,
+                   const mlx_stream s);   /* a view; strides / offset in elements */
+int mlx_view(mlx_array* res, const mlx_array a, mlx_dtype dtype, const mlx_stream s);
+int mlx_real(mlx_array* res, const mlx_array a, const mlx_stream s);   /* no complex dtype: the array itself */
+int mlx_imag(mlx_array* res, const mlx_array a, const mlx_stream s);   /* ... and zeros */
+int mlx_tensordot(mlx_array* res, const mlx_array a, const mlx_array b, const int* axes_a, size_t axes_a_num, const int* axes_b, size_t axes_b_num,
+                  const mlx_stream s);
+int mlx_tensordot_axis(mlx_array* res, const mlx_array a, const mlx_array b, int axis, const mlx_stream s);
+int mlx_kron(mlx_array* res, const mlx_array a, const mlx_array b, const mlx_stream s);
+int mlx_random_bernoulli(mlx_array* res, const mlx_array p, const int* shape, size_t shape_num, const mlx_array key /* may be null */, const mlx_stream s);
 
 #ifdef __cplusplus
 }

@@ -170,6 +170,12 @@ __device__ __forceinline__ float ld_f(const char* p, int dt, size_t i) {
         case MLX_INT32: return (float)((const int32_t*)p)[i];
         case MLX_UINT32: return (float)((const uint32_t*)p)[i];
         case MLX_BOOL: case MLX_UINT8: return (float)((const uint8_t*)p)[i];
+        case MLX_INT8: return (float)((const int8_t*)p)[i];
+        case MLX_INT16: return (float)((const int16_t*)p)[i];
+        case MLX_UINT16: return (float)((const uint16_t*)p)[i];
+        case MLX_INT64: return (float)((const long long*)p)[i];
+        case MLX_UINT64: return (float)((const unsigned long long*)p)[i];
+        case MLX_FLOAT64: return (float)((const double*)p)[i];
         default: return 0.f;
     }
 }
@@ -182,9 +188,42 @@ __device__ __forceinline__ void st_f(char* p, int dt, size_t i, float v) {
         case MLX_UINT32: ((uint32_t*)p)[i] = (uint32_t)v; break;
         case MLX_BOOL: ((uint8_t*)p)[i] = v != 0.f; break;
         case MLX_UINT8: ((uint8_t*)p)[i] = (uint8_t)v; break;
+        case MLX_INT8: ((int8_t*)p)[i] = (int8_t)v; break;
+        case MLX_INT16: ((int16_t*)p)[i] = (int16_t)v; break;
+        case MLX_UINT16: ((uint16_t*)p)[i] = (uint16_t)v; break;
+        case MLX_INT64: ((long long*)p)[i] = (long long)v; break;
+        case MLX_UINT64: ((unsigned long long*)p)[i] = (unsigned long long)v; break;
+        case MLX_FLOAT64: ((double*)p)[i] = (double)v; break;
         default: break;
     }
 }
+// the integer twins (exact for every integer width; the glue's integer arithmetic and integer -> integer casts go through them)
+__device__ __forceinline__ long long ld_i(const char* p, int dt, size_t i) {
+    switch (dt) {
+        case MLX_INT32: return ((const int32_t*)p)[i];
+        case MLX_UINT32: return ((const uint32_t*)p)[i];
+        case MLX_INT64: return ((const long long*)p)[i];
+        case MLX_UINT64: return (long long)((const unsigned long long*)p)[i];
+        case MLX_INT16: return ((const int16_t*)p)[i];
+        case MLX_UINT16: return ((const uint16_t*)p)[i];
+        case MLX_INT8: return ((const int8_t*)p)[i];
+        case MLX_BOOL: case MLX_UINT8: return ((const uint8_t*)p)[i];
+        default: return (long long)ld_f(p, dt, i);
+    }
+}
+__device__ __forceinline__ void st_i(char* p, int dt, size_t i, long long v) {
+    switch (dt) {
+        case MLX_INT32: ((int32_t*)p)[i] = (int32_t)v; break;
+        case MLX_UINT32: ((uint32_t*)p)[i] = (uint32_t)v; break;
+        case MLX_INT64: case MLX_UINT64: ((long long*)p)[i] = v; break;
+        case MLX_INT16: case MLX_UINT16: ((uint16_t*)p)[i] = (uint16_t)v; break;
+        case MLX_INT8: case MLX_UINT8: ((uint8_t*)p)[i] = (uint8_t)v; break;
+        case MLX_BOOL: ((uint8_t*)p)[i] = v != 0; break;
+        default: st_f(p, dt, i, (float)v); break;
+    }
+}
+__host__ __device__ inline bool is_int_dt(int d) { return d != MLX_FLOAT16 && d != MLX_FLOAT32 && d != MLX_BFLOAT16 && d != MLX_FLOAT64 && d != MLX_COMPLEX64; }
+
 
 enum { OP_ADD, OP_SUB, OP_MUL, OP_DIV, OP_SIGMOID, OP_EXP, OP_NEG, OP_CAST };
 
@@ -217,6 +256,10 @@ __global__ void unary_kernel(char* out, int odt, const char* a, int adt, Idx ix,
             const int c = (int)(r % ix.shape[d]);
             r /= ix.shape[d];
             oa += c * ix.sa[d];
+        }
+        if (op == OP_CAST && is_int_dt(adt) && is_int_dt(odt)) {   // integer -> integer: exact at every width
+            st_i(out, odt, i, ld_i(a, adt, oa));
+            continue;
         }
         const float x = ld_f(a, adt, oa);
         float v;

@@ -36,31 +36,6 @@ Arr* clone_handle(const Arr* a) {
 }
 
 // ---------------------------------------------------------------- kernels
-__device__ __forceinline__ long long ld_i(const char* p, int dt, size_t i) {
-    switch (dt) {
-        case MLX_INT32: return ((const int32_t*)p)[i];
-        case MLX_UINT32: return ((const uint32_t*)p)[i];
-        case MLX_INT64: return ((const long long*)p)[i];
-        case MLX_UINT64: return (long long)((const unsigned long long*)p)[i];
-        case MLX_INT16: return ((const int16_t*)p)[i];
-        case MLX_UINT16: return ((const uint16_t*)p)[i];
-        case MLX_INT8: return ((const int8_t*)p)[i];
-        case MLX_BOOL: case MLX_UINT8: return ((const uint8_t*)p)[i];
-        default: return (long long)ld_f(p, dt, i);
-    }
-}
-__device__ __forceinline__ void st_i(char* p, int dt, size_t i, long long v) {
-    switch (dt) {
-        case MLX_INT32: ((int32_t*)p)[i] = (int32_t)v; break;
-        case MLX_UINT32: ((uint32_t*)p)[i] = (uint32_t)v; break;
-        case MLX_INT64: case MLX_UINT64: ((long long*)p)[i] = v; break;
-        case MLX_INT16: case MLX_UINT16: ((uint16_t*)p)[i] = (uint16_t)v; break;
-        case MLX_INT8: case MLX_UINT8: ((uint8_t*)p)[i] = (uint8_t)v; break;
-        case MLX_BOOL: ((uint8_t*)p)[i] = v != 0; break;
-        default: st_f(p, dt, i, (float)v); break;
-    }
-}
-__host__ __device__ inline bool is_int_dt(int d) { return d != MLX_FLOAT16 && d != MLX_FLOAT32 && d != MLX_BFLOAT16 && d != MLX_FLOAT64 && d != MLX_COMPLEX64; }
 
 enum { B2_GT, B2_GE, B2_LT, B2_LE, B2_EQ, B2_AND, B2_NE, B2_OR, B2_LAST_BOOL = B2_OR, B2_MAX, B2_MIN, B2_FLOORDIV, B2_POW, B2_REM, B2_LOGADDEXP };
 

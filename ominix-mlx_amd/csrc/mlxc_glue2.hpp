@@ -591,4 +591,120 @@ int mlx_broadcast_arrays(mlx_vector_array* res, const mlx_vector_array inputs, c
     return 0;
 }
 
+
+// ---- a few more views / accessors / products ----
+const bool* mlx_array_data_bool(const mlx_array arr) { return (const bool*)data_host(arr); }
+const int8_t* mlx_array_data_int8(const mlx_array arr) { return (const int8_t*)data_host(arr); }
+const int16_t* mlx_array_data_int16(const mlx_array arr) { return (const int16_t*)data_host(arr); }
+const int64_t* mlx_array_data_int64(const mlx_array arr) { return (const int64_t*)data_host(arr); }
+const uint64_t* mlx_array_data_uint64(const mlx_array arr) { return (const uint64_t*)data_host(arr); }
+
+// an arbitrary strided window onto the array's buffer (strides and offset in elements); it must stay inside the buffer
+int mlx_as_strided(mlx_array* res, const mlx_array a, const int* shape, size_t shape_num, const int64_t* strides, size_t strides_num, size_t offset,
+                   const mlx_stream) {
+    REQ_ARR(a, "mlx_as_strided");
+    OMX_REQUIRE(shape_num == strides_num, "mlx_as_strided: one stride per dimension");
+    const Arr& s = *A(a);
+    size_t last = offset;
+    bool empty = false;
+    for (size_t i = 0; i < shape_num; ++i) {
+        OMX_REQUIRE(shape[i] >= 0 && strides[i] >= 0, "mlx_as_strided: negative shape or stride");
+        if (shape[i] == 0) empty = true;
+        else last += (size_t)(shape[i] - 1) * (size_t)strides[i];
+    }
+    OMX_REQUIRE(empty || s.off + (last + 1) * dsize(s.dt) <= s.buf->bytes, "mlx_as_strided: the window leaves the array's buffer");
+    Arr* r = new Arr(s);
+    r->host.clear();
+    r->shape.assign(shape, shape + shape_num);
+    r->strides.assign(strides, strides + strides_num);
+    r->off = s.off + offset * dsize(s.dt);
+    return assign(res, r);
+}
+// reinterpret the bytes as another dtype; a different item size rescales the last (contiguous) axis
+int mlx_view(mlx_array* res, const mlx_array a, mlx_dtype dtype, const mlx_stream) {
+    REQ_ARR(a, "mlx_view");
+    Contig c;
+    if (c.init(*A(a))) return 1;
+    const size_t from = dsize(c.a->dt), to = dsize(dtype);
+    std::vector<int> shape = c.a->shape;
+    if (from != to) {
+        OMX_REQUIRE(!shape.empty() && ((size_t)shape.back() * from) % to == 0, "mlx_view: the last axis does not hold a whole number of the new items");
+        shape.back() = (int)((size_t)shape.back() * from / to);
+    }
+    Arr* r = new Arr(*c.a);
+    r->host.clear();
+    r->dt = dtype;
+    r->shape = shape;
+    r->strides = row_major(shape);
+    return assign(res, r);
+}
+int mlx_real(mlx_array* res, const mlx_array a, const mlx_stream) { REQ_ARR(a, "mlx_real"); return mlx_array_set(res, a); }   // (no complex dtype here)
+int mlx_imag(mlx_array* res, const mlx_array a, const mlx_stream s) {
+    REQ_ARR(a, "mlx_imag");
+    return mlx_zeros(res, A(a)->shape.data(), A(a)->shape.size(), A(a)->dt, s);
+}
+
+// contraction of the listed axes: they move to the end of a and the front of b, the rest is one matrix product
+int mlx_tensordot(mlx_array* res, const mlx_array a, const mlx_array b, const int* axes_a, size_t axes_a_num, const int* axes_b, size_t axes_b_num,
+                  const mlx_stream s) {
+    REQ_ARR(a, "mlx_tensordot"); REQ_ARR(b, "mlx_tensordot");
+    OMX_REQUIRE(axes_a_num == axes_b_num, "mlx_tensordot: as many axes of a as of b");
+    const Arr &x = *A(a), &y = *A(b);
+    const int na = (int)x.shape.size(), nb = (int)y.shape.size();
+    std::vector<bool> ca((size_t)na, false), cb((size_t)nb, false);
+    std::vector<int> la, lb;
+    long long K = 1;
+    for (size_t i = 0; i < axes_a_num; ++i) {
+        int p, q;
+        if (norm_axis(axes_a[i], na, "mlx_tensordot", &p) || norm_axis(axes_b[i], nb, "mlx_tensordot", &q)) return 1;
+        OMX_REQUIRE(!ca[p] && !cb[q] && x.shape[p] == y.shape[q], "mlx_tensordot: axes %d / %d do not match (%d vs %d) or repeat", axes_a[i], axes_b[i], x.shape[p], y.shape[q]);
+        ca[p] = true; cb[q] = true; la.push_back(p); lb.push_back(q);
+        K *= x.shape[p];
+    }
+    std::vector<int> pa, pb, out_shape;
+    long long Ma = 1, Nb = 1;
+    for (int i = 0; i < na; ++i) if (!ca[i]) { pa.push_back(i); out_shape.push_back(x.shape[i]); Ma *= x.shape[i]; }
+    pa.insert(pa.end(), la.begin(), la.end());
+    pb = lb;
+    for (int i = 0; i < nb; ++i) if (!cb[i]) { pb.push_back(i); out_shape.push_back(y.shape[i]); Nb *= y.shape[i]; }
+    Tmp ta, tb, ma, mb, prod;
+    const int sa[2] = {(int)Ma, (int)K}, sb[2] = {(int)K, (int)Nb};
+    if (mlx_transpose_axes(&ta, a, pa.data(), pa.size(), s) || mlx_transpose_axes(&tb, b, pb.data(), pb.size(), s) ||
+        mlx_reshape(&ma, ta, sa, 2, s) || mlx_reshape(&mb, tb, sb, 2, s) || mlx_matmul(&prod, ma, mb, s))
+        return 1;
+    return mlx_reshape(res, prod, out_shape.data(), out_shape.size(), s);
+}
+int mlx_tensordot_axis(mlx_array* res, const mlx_array a, const mlx_array b, int axis, const mlx_stream s) {
+    REQ_ARR(a, "mlx_tensordot_axis"); REQ_ARR(b, "mlx_tensordot_axis");
+    const int na = (int)A(a)->shape.size();
+    OMX_REQUIRE(axis >= 0 && axis <= na && axis <= (int)A(b)->shape.size(), "mlx_tensordot_axis: %d axes cannot be contracted", axis);
+    std::vector<int> aa, bb;
+    for (int i = 0; i < axis; ++i) { aa.push_back(na - axis + i); bb.push_back(i); }
+    return mlx_tensordot(res, a, b, aa.data(), aa.size(), bb.data(), bb.size(), s);
+}
+// Kronecker product of two matrices (or vectors): a[i, j] * b[k, l] at [i * rows(b) + k, j * cols(b) + l]
+int mlx_kron(mlx_array* res, const mlx_array a, const mlx_array b, const mlx_stream s) {
+    REQ_ARR(a, "mlx_kron"); REQ_ARR(b, "mlx_kron");
+    const Arr &x = *A(a), &y = *A(b);
+    OMX_REQUIRE(x.shape.size() <= 2 && y.shape.size() <= 2 && x.shape.size() == y.shape.size() && !x.shape.empty(), "mlx_kron: two vectors or two matrices expected");
+    Tmp xa, yb, prod;
+    if (x.shape.size() == 1) {
+        const int s1[2] = {x.shape[0], 1}, s2[2] = {1, y.shape[0]}, so[1] = {x.shape[0] * y.shape[0]};
+        if (mlx_reshape(&xa, a, s1, 2, s) || mlx_reshape(&yb, b, s2, 2, s) || mlx_multiply(&prod, xa, yb, s)) return 1;
+        return mlx_reshape(res, prod, so, 1, s);
+    }
+    const int s1[4] = {x.shape[0], 1, x.shape[1], 1}, s2[4] = {1, y.shape[0], 1, y.shape[1]}, so[2] = {x.shape[0] * y.shape[0], x.shape[1] * y.shape[1]};
+    if (mlx_reshape(&xa, a, s1, 4, s) || mlx_reshape(&yb, b, s2, 4, s) || mlx_multiply(&prod, xa, yb, s)) return 1;
+    return mlx_reshape(res, prod, so, 2, s);
+}
+
+// bernoulli(p) = uniform[0, 1) < p with MLX's keyed uniform generator (mlx random.cpp: `uniform(shape, key) < p`)
+int mlx_random_bernoulli(mlx_array* res, const mlx_array p, const int* shape, size_t shape_num, const mlx_array key, const mlx_stream s) {
+    REQ_ARR(p, "mlx_random_bernoulli");
+    Tmp lo, hi, u;
+    lo.a = f32_scalar(0.f); hi.a = f32_scalar(1.f);
+    if (mlx_random_uniform(&u, lo, hi, shape, shape_num, MLX_FLOAT32, key, s)) return 1;
+    return mlx_less(res, u, p, s);
+}
+
 }  // extern "C"

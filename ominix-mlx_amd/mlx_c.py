@@ -307,6 +307,19 @@ SIGNATURES = {
     "mlx_where": (c_int, [P_ARR, mlx_array, mlx_array, mlx_array, mlx_stream]),
     "mlx_clip": (c_int, [P_ARR, mlx_array, mlx_array, mlx_array, mlx_stream]),
     # ops.h, third batch (csrc/mlxc_glue2.hpp)
+    "mlx_array_data_bool": (c_void_p, [mlx_array]),
+    "mlx_array_data_int8": (c_void_p, [mlx_array]),
+    "mlx_array_data_int16": (c_void_p, [mlx_array]),
+    "mlx_array_data_int64": (c_void_p, [mlx_array]),
+    "mlx_array_data_uint64": (c_void_p, [mlx_array]),
+    "mlx_as_strided": (c_int, [P_ARR, mlx_array, P_INT, c_size_t, ctypes.POINTER(ctypes.c_int64), c_size_t, c_size_t, mlx_stream]),
+    "mlx_view": (c_int, [P_ARR, mlx_array, c_int, mlx_stream]),
+    "mlx_real": (c_int, [P_ARR, mlx_array, mlx_stream]),
+    "mlx_imag": (c_int, [P_ARR, mlx_array, mlx_stream]),
+    "mlx_tensordot": (c_int, [P_ARR, mlx_array, mlx_array, P_INT, c_size_t, P_INT, c_size_t, mlx_stream]),
+    "mlx_tensordot_axis": (c_int, [P_ARR, mlx_array, mlx_array, c_int, mlx_stream]),
+    "mlx_kron": (c_int, [P_ARR, mlx_array, mlx_array, mlx_stream]),
+    "mlx_random_bernoulli": (c_int, [P_ARR, mlx_array, P_INT, c_size_t, mlx_array, mlx_stream]),
     "mlx_sum_axes": (c_int, [P_ARR, mlx_array, P_INT, c_size_t, c_bool, mlx_stream]),
     "mlx_mean_axes": (c_int, [P_ARR, mlx_array, P_INT, c_size_t, c_bool, mlx_stream]),
     "mlx_max_axes": (c_int, [P_ARR, mlx_array, P_INT, c_size_t, c_bool, mlx_stream]),
@@ -494,8 +507,10 @@ class Array:
                 _check(1)
             return np.ctypeslib.as_array(ctypes.cast(p, ctypes.POINTER(ctypes.c_uint16)), (max(n, 1),))[:n].copy().view(np.float16).reshape(shape)
         fn = {FLOAT32: lib.mlx_array_data_float32, UINT32: lib.mlx_array_data_uint32, INT32: lib.mlx_array_data_int32,
-              BOOL: lib.mlx_array_data_uint8, UINT8: lib.mlx_array_data_uint8}[dt]
-        ct = {FLOAT32: c_float, UINT32: ctypes.c_uint32, INT32: ctypes.c_int32, BOOL: ctypes.c_uint8, UINT8: ctypes.c_uint8}[dt]
+              BOOL: lib.mlx_array_data_bool, UINT8: lib.mlx_array_data_uint8, INT8: lib.mlx_array_data_int8, INT16: lib.mlx_array_data_int16,
+              UINT16: lib.mlx_array_data_uint16, INT64: lib.mlx_array_data_int64, UINT64: lib.mlx_array_data_uint64}[dt]
+        ct = {FLOAT32: c_float, UINT32: ctypes.c_uint32, INT32: ctypes.c_int32, BOOL: ctypes.c_uint8, UINT8: ctypes.c_uint8, INT8: ctypes.c_int8,
+              INT16: ctypes.c_int16, UINT16: ctypes.c_uint16, INT64: ctypes.c_int64, UINT64: ctypes.c_uint64}[dt]
         p = fn(self.h)
         if not p:
             _check(1)
@@ -1009,3 +1024,26 @@ def broadcast_arrays(arrays):
     finally:
         lib.mlx_vector_array_free(vec)
         lib.mlx_vector_array_free(out)
+
+
+def as_strided(a, shape, strides, offset=0):
+    p, n = _ints(shape)
+    st = (ctypes.c_int64 * len(strides))(*[int(v) for v in strides])
+    return Array.op(lib.mlx_as_strided, a.h, p, n, st, len(strides), offset, default_stream())
+
+
+def view(a, dtype): return Array.op(lib.mlx_view, a.h, dtype, default_stream())
+def real(a): return Array.op(lib.mlx_real, a.h, default_stream())
+def imag(a): return Array.op(lib.mlx_imag, a.h, default_stream())
+def tensordot(a, b, axes):
+    if isinstance(axes, int):
+        return Array.op(lib.mlx_tensordot_axis, a.h, b.h, axes, default_stream())
+    pa, na = _ints(axes[0])
+    pb, nb = _ints(axes[1])
+    return Array.op(lib.mlx_tensordot, a.h, b.h, pa, na, pb, nb, default_stream())
+
+
+def kron(a, b): return Array.op(lib.mlx_kron, a.h, b.h, default_stream())
+def random_bernoulli(p, shape, key):
+    ps, n = _ints(shape)
+    return Array.op(lib.mlx_random_bernoulli, p.h, ps, n, key.h, default_stream())

@@ -492,3 +492,44 @@ def test_third_batch_constructors_comparisons_and_layout(mx):
         mx.broadcast_arrays([A_, B_])
     with pytest.raises(Exception):
         mx.pad(W, (0,), (1,), (1,), pv) if False else mx.unflatten(W, 1, (5, 5))
+
+
+def test_fourth_batch_views_products_and_accessors(mx):
+    """ops.h / array.h (csrc/mlxc_glue2.hpp): as_strided and view as windows onto the same buffer, real / imag of real arrays,
+    tensordot (axis count and axis lists), kron, bernoulli = uniform < p on MLX's keyed generator, and the host accessors of the
+    narrow / wide integer dtypes -- against numpy."""
+    rng = np.random.default_rng(23)
+    x = rng.standard_normal((4, 6)).astype(np.float32)
+    X = mx.Array.from_numpy(x, mx.FLOAT32)
+    np.testing.assert_array_equal(mx.as_strided(X, (3, 2, 2), (6, 1, 2), 1).numpy(), np.lib.stride_tricks.as_strided(x.ravel()[1:], (3, 2, 2), (24, 4, 8)))
+    with pytest.raises(Exception):
+        mx.as_strided(X, (5, 6), (6, 1))                       # leaves the buffer
+    u32 = mx.view(X, mx.UINT32)
+    np.testing.assert_array_equal(u32.numpy(), x.view(np.uint32))
+    half = mx.view(X, mx.UINT16)
+    assert half.shape == (4, 12)
+    np.testing.assert_array_equal(half.numpy(), x.view(np.uint16))
+    np.testing.assert_array_equal(mx.real(X).numpy(), x)
+    np.testing.assert_array_equal(mx.imag(X).numpy(), np.zeros_like(x))
+    a, b = rng.standard_normal((3, 4, 5)).astype(np.float32), rng.standard_normal((4, 5, 6)).astype(np.float32)
+    A_, B_ = mx.Array.from_numpy(a, mx.FLOAT32), mx.Array.from_numpy(b, mx.FLOAT32)
+    np.testing.assert_allclose(mx.tensordot(A_, B_, 2).numpy(), np.tensordot(a, b, 2), rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(mx.tensordot(A_, B_, 0).numpy(), np.tensordot(a, b, 0), rtol=2e-5, atol=2e-5)
+    c = rng.standard_normal((5, 3, 7)).astype(np.float32)
+    np.testing.assert_allclose(mx.tensordot(A_, mx.Array.from_numpy(c, mx.FLOAT32), ((0, 2), (1, 0))).numpy(), np.tensordot(a, c, ((0, 2), (1, 0))),
+                               rtol=2e-5, atol=2e-5)
+    p, q = rng.standard_normal((2, 3)).astype(np.float32), rng.standard_normal((4, 2)).astype(np.float32)
+    np.testing.assert_allclose(mx.kron(mx.Array.from_numpy(p, mx.FLOAT32), mx.Array.from_numpy(q, mx.FLOAT32)).numpy(), np.kron(p, q), rtol=1e-6)
+    np.testing.assert_allclose(mx.kron(mx.Array.from_numpy(p[0], mx.FLOAT32), mx.Array.from_numpy(q[:, 0], mx.FLOAT32)).numpy(), np.kron(p[0], q[:, 0]), rtol=1e-6)
+    key = mx.random_key(7)
+    prob = mx.Array.from_numpy(np.float32(0.3), mx.FLOAT32)
+    draw = mx.random_bernoulli(prob, (4000,), key).numpy()
+    uni = mx.random_uniform(0.0, 1.0, (4000,), key).numpy()
+    np.testing.assert_array_equal(draw, uni < np.float32(0.3))
+    assert 0.25 < draw.mean() < 0.35
+    for dt, npdt in ((mx.INT8, np.int8), (mx.INT16, np.int16), (mx.INT64, np.int64), (mx.UINT64, np.uint64), (mx.UINT16, np.uint16)):
+        v = (np.arange(12).reshape(3, 4) * 5 - 7).astype(np.int32)
+        got = mx.astype(mx.Array.from_numpy(v, mx.INT32), dt).numpy()
+        assert got.dtype == npdt
+        np.testing.assert_array_equal(got, v.astype(npdt))
+    np.testing.assert_array_equal(mx.Array.from_numpy(x > 0, mx.BOOL).numpy(), x > 0)

@@ -309,9 +309,19 @@ int omx_moe_block_forward(void* out, const void* resid, const void* x, const voi
 /* expert-parallel decode form: this rank holds experts [e_lo, e_lo + e_n) (w_* = its stacks);
  * partial [n_tokens, hidden] f32 = its share of sum_j bf16(y_j * score_j), to be all-reduced over the ranks; the residual
  * h + bf16(sum) is the caller's.  n_tokens * top_k <= 32. */
+/* tables of the batched expert-parallel block for an exchange-based combine (omx_moe_block_slots_ep -> omx_peer_moe_combine) */
+typedef struct omx_moe_ep_slots_ {
+    const void* y;                 /* [local slots (sorted by local expert), hidden] bf16 expert outputs */
+    const uint32_t* pos_of_slot;   /* [n_tokens * top_k] slot -> row of y (slots of other ranks' experts: unused) */
+    const uint32_t* inds;          /* [n_tokens * top_k] global expert id per slot */
+    const void* scores;            /* [n_tokens * top_k] bf16 routing weights */
+} omx_moe_ep_slots;
 int omx_moe_block_partial_ep(float* partial, const void* x, const void* norm_w, float eps, void* xn, const void* gate_w,
                              const void* w_gate, const void* w_up, const void* w_down, int n_tokens, int hidden, int inter,
                              int n_experts, int top_k, int mode, int norm_topk_prob, int e_lo, int e_n, omx_stream stream);
+int omx_moe_block_slots_ep(omx_moe_ep_slots* out, const void* x /* normalised rows */, const void* gate_w, const void* w_gate, const void* w_up,
+                           const void* w_down, int n_tokens, int hidden, int inter, int n_experts, int top_k, int mode, int norm_topk_prob,
+                           int e_lo, int e_n, omx_stream stream);
 /* expert TENSOR parallel decode form (<= 32 routed slots): this rank holds `inter` = I / tp intermediate columns of EVERY expert;
  * y_partial [slots, hidden] f32 = the unrounded partial down projections (to be all-reduced), the replicated router's choice goes to
  * route_inds / route_scores; omx_moe_combine_slots then forms bf16(resid + bf16(sum_j bf16(bf16(y_j) score_j))) (mixtral model.rs:296-308,
@@ -431,6 +441,13 @@ int omx_peer_comm_handle(void* comm, void* out64);
 int omx_peer_comm_connect(void* comm, const void* handles);
 int omx_peer_allreduce(const void* send, void* recv, size_t count, int dtype, int op, void* comm, omx_stream stream);
 void* omx_peer_allreduce_fn(void);
+int omx_peer_comm_counts(void* comm, unsigned long long* out4);   /* launches by path: one-shot, two-shot chunks, MoE combine, handed to RCCL */
+size_t omx_peer_comm_stage_bytes(void* comm);             /* stage size of the two-shot / exchange path; 0 = off */
+/* expert-parallel prompt: out [T, hidden] = resid + weighted expert outputs as an all-to-all combine of the routed slots' rows to their
+ * tokens' owners + an all-gather of the finished rows (one kernel; BASELINE config 3's "expert-parallel all-to-all over xGMI").
+ * Returns 2 when this communicator / size cannot take it (the caller keeps its all-reduce). */
+int omx_peer_moe_combine(void* out, const void* resid, const omx_moe_ep_slots* slots, int T, int hidden, int top_k, int e_lo, int e_n, void* comm,
+                         omx_stream stream);
 const void* omx_peer_comm_device(void* comm);              /* device table for kernels that reduce their own output (engine-internal use) */
 int omx_peer_comm_status(void* comm, unsigned* aborted);   /* 1: a wait gave up (a peer never arrived); results are void */
 int omx_peer_comm_destroy(void* comm);

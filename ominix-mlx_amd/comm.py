@@ -59,6 +59,10 @@ PEER_SIGNATURES = {
     "omx_peer_comm_connect": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
     "omx_peer_allreduce": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]),
     "omx_peer_allreduce_fn": (ctypes.c_void_p, []),
+    "omx_peer_comm_stage_bytes": (ctypes.c_size_t, [ctypes.c_void_p]),
+    "omx_peer_comm_counts": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_ulonglong)]),
+    "omx_peer_moe_combine": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                            ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]),
     "omx_peer_comm_device": (ctypes.c_void_p, [ctypes.c_void_p]),
     "omx_peer_comm_status": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint)]),
     "omx_peer_comm_destroy": (ctypes.c_int, [ctypes.c_void_p]),
@@ -112,6 +116,13 @@ class PeerComm:
             raise RuntimeError("peer all-reduce: mapping the peers' inboxes failed on " + "; ".join(bad))
         self.comm = h.value
         self.fn = lib.omx_peer_allreduce_fn()
+
+    def counts(self) -> dict:
+        """launches issued through this communicator by path (host-side counters)."""
+        from . import check, lib
+        v = (ctypes.c_ulonglong * 4)()
+        check(lib.omx_peer_comm_counts(self._h, v))
+        return {"one_shot": int(v[0]), "two_shot": int(v[1]), "moe_combine": int(v[2]), "rccl": int(v[3])}
 
     def aborted(self) -> bool:
         from . import check, lib

@@ -1192,6 +1192,29 @@ int prefill_prefix_batched(omx_qwen3 m, int T, int off, const EncodeOpts* enc = 
                 // all-to-all exchange, with the reduction done by the collective.  (Until round 3 a prompt under EP was T decode steps.)
                 const bool etp = c.tp_size > 1;
                 const int el = etp ? c.num_experts : c.num_experts / c.ep_size;
+                // expert parallel on the peer communicator's exchange path (round 4): the weighted sum as an all-to-all combine of the
+                // routed slots' rows to their tokens' owners + an all-gather of the finished residual rows, in ONE kernel
+                // (peer_allreduce.hip peer_moe_combine_kernel) -- a rank pushes ~T k / N + T (N - 1) / N rows of bf16 instead of
+                // taking part in an all-reduce of [T, hidden] f32.  Same roundings (bit-identical for top-2).  OMX_EP_COMBINE=allreduce
+                // keeps the all-reduce; any communicator without the exchange path does too.
+                const char* cmb = getenv("OMX_EP_COMBINE");
+                if (!etp && m->allreduce == (nccl_allreduce_fn)omx_peer_allreduce_fn() && omx_peer_comm_stage_bytes(m->comm) > 0 &&
+                    !(cmb && strcmp(cmb, "allreduce") == 0)) {
+                    omx_moe_ep_slots sl = {};
+                    if (omx_moe_block_slots_ep(&sl, m->pf_xn, L.moe_gate, L.moe_wg, L.moe_wu, L.moe_wd, T, hd, c.moe_intermediate_size, c.num_experts,
+                                               c.num_experts_per_tok, c.moe_mode, c.norm_topk_prob, c.ep_rank * el, el, s))
+                        return 1;
+                    const int rc = omx_peer_moe_combine(h, h2, &sl, T, hd, c.num_experts_per_tok, c.ep_rank * el, el, m->comm, s);
+                    OMX_REQUIRE(rc == 0 || rc == 2, "expert-parallel combine over the peer communicator failed");
+                    if (rc == 0) {
+                        if (enc && next_tap < enc->n_taps && enc->taps[next_tap] == l) {
+                            copy_rows_strided_kernel<<<1024, 256, 0, s>>>(enc->out + (size_t)next_tap * hd, (int64_t)enc->n_taps * hd, h, hd, T, hd / 8);
+                            ++next_tap;
+                        }
+                        continue;
+                    }
+                    // (rc 2: this size does not fit the stages -- the slots were computed, the all-reduce form below recomputes them)
+                }
                 if (!m->pf_ep_partial || m->pf_ep_cap < T) {
                     OMX_HIP_CHECK(hipStreamSynchronize(s));
                     if (m->pf_ep_partial) OMX_HIP_CHECK(hipFree(m->pf_ep_partial));

@@ -624,6 +624,9 @@ extern "C" int omx_moe_block_forward_q_ex(void* out, const void* resid, const vo
     return 0;
 }
 
+// omx_moe_block_slots_ep runs omx_moe_block_partial_ep's batched branch up to the expert outputs (same launches, same scratch)
+static thread_local omx_moe_ep_slots* g_ep_slots_out = nullptr;
+
 /* expert-parallel decode form (simple variant: activations replicated, experts sharded): this rank
  * holds experts [e_lo, e_lo + e_n) (w_* = ITS stacks [e_n, ...]); partial [n_tokens, hidden] f32 receives its share of
  * sum_j bf16(y_j * score_j).  The ranks' partials are summed by one all-reduce; the caller then forms
@@ -670,6 +673,7 @@ extern "C" int omx_moe_block_partial_ep(float* partial, const void* x, const voi
         // batched form (a prompt under expert parallelism): the slots routed to THIS rank's experts are counting-sorted by local
         // expert and run through the grouped matrix-core GEMMs; everything routed elsewhere lands in one trailing pseudo-expert that
         // gets no tiles.  The partial weighted sum reads its rows back through the sort permutation.
+        // (partial == the sentinel of omx_moe_block_slots_ep: stop after the experts and hand the slot tables to the caller's combine)
         uint32_t* local_inds = nullptr;
         OMX_HIP_CHECK(hipMallocAsync((void**)&local_inds, (size_t)slots * 4, s));
         moe_localize_kernel<<<(slots + 255) / 256, 256, 0, s>>>(local_inds, inds, slots, e_lo, e_n);
@@ -694,10 +698,15 @@ extern "C" int omx_moe_block_partial_ep(float* partial, const void* x, const voi
             g.w_estride = (size_t)hidden * inter;
             if (launch_gemm_bf16_grouped(ybuf, gbuf, (const bf16_t*)w_down, slots, hidden, inter, g, max_tiles, s)) return 1;
         }
+        if (g_ep_slots_out) {
+            *g_ep_slots_out = omx_moe_ep_slots{ybuf, pos_of_slot, inds, scores};
+            return 0;
+        }
         moe_combine_partial_kernel<<<n_tokens, 256, 0, s>>>(partial, ybuf, scores, inds, hidden, top_k, e_lo, e_n, pos_of_slot);
         OMX_LAUNCH_CHECK();
         return 0;
     }
+    OMX_REQUIRE(!g_ep_slots_out, "omx_moe_block_slots_ep: the batched form only (more than 32 routed slots)");
     GemvArgs a = {};
     a.w0 = (const bf16_t*)w_gate; a.w1 = (const bf16_t*)w_up; a.n0 = inter; a.N = inter; a.K = hidden;
     a.x = (const bf16_t*)xn; a.out = gbuf;
@@ -715,6 +724,22 @@ extern "C" int omx_moe_block_partial_ep(float* partial, const void* x, const voi
     moe_combine_partial_kernel<<<n_tokens, 256, 0, s>>>(partial, ybuf, scores, inds, hidden, top_k, e_lo, e_n);
     OMX_LAUNCH_CHECK();
     return 0;
+}
+
+/* The batched expert-parallel block WITHOUT its weighted sum: router, this rank's slots sorted by local expert, grouped matrix-core
+ * GEMMs -- then the tables an exchange needs instead of a [T, hidden] partial: y (the sorted expert outputs, bf16), pos_of_slot
+ * [T * k] (slot -> row of y), inds [T * k] (global expert ids) and scores [T * k] (bf16), all in the stream's scratch (valid until the
+ * next MoE call on this stream).  x: the NORMALISED rows.  Consumer: omx_peer_moe_combine (peer_allreduce.hip). */
+extern "C" int omx_moe_block_slots_ep(omx_moe_ep_slots* out, const void* x, const void* gate_w, const void* w_gate, const void* w_up,
+                                      const void* w_down, int n_tokens, int hidden, int inter, int n_experts, int top_k, int mode,
+                                      int norm_topk_prob, int e_lo, int e_n, omx_stream stream) {
+    OMX_REQUIRE(out, "omx_moe_block_slots_ep: null output");
+    float sentinel = 0.f;
+    g_ep_slots_out = out;
+    const int rc = omx_moe_block_partial_ep(&sentinel, x, nullptr, 0.f, nullptr, gate_w, w_gate, w_up, w_down, n_tokens, hidden, inter, n_experts,
+                                            top_k, mode, norm_topk_prob, e_lo, e_n, stream);
+    g_ep_slots_out = nullptr;
+    return rc;
 }
 
 /* expert TENSOR parallel, decode form (n_tokens * top_k <= 32): every rank holds ALL experts but only `inter` = I / tp of each expert's

@@ -48,6 +48,7 @@ struct PeerComm {
     nccl_allreduce_fn rccl_fn = nullptr;
     hipIpcMemHandle_t handle;
     bool connected = false;
+    unsigned long long n_small = 0, n_large = 0, n_moe = 0, n_rccl = 0;   // launches by path (host-side, omx_peer_comm_counts)
     size_t stage_bytes = 0;                    // large path: bytes per stage (0: off)
     size_t off_flags = 0, off_stage1 = 0, off_stage2 = 0;   // byte offsets inside the exported allocation
 };
@@ -184,6 +185,87 @@ __global__ __launch_bounds__(256) void peer_allreduce_kernel(const PeerArgs a) {
     if (threadIdx.x == 0) peer_block_done(p, tag, gridDim.x);
 }
 
+// Expert-parallel prompt: the weighted sum of a sparse-MoE block as an ALL-TO-ALL COMBINE + all-gather instead of an all-reduce of
+// [T, hidden] f32 partials (SURVEY.md 8e row 2 / BASELINE config 3: "expert-parallel all-to-all over xGMI").  Rank o OWNS tokens
+// [o * chunk, (o + 1) * chunk).  One kernel, the flags and counters of the two-shot all-reduce:
+//   1. every rank pushes bf16(y_j * score_j) of each slot j routed to ITS experts into slot (j - o * chunk * k) of the stage1 of the
+//      token's owner o -- every slot has exactly one writer, a rank sends ~T k / N rows instead of all T;
+//   2. the owner sums its tokens' k slot rows in slot order (f32), forms bf16(resid + bf16(sum)) -- the roundings of
+//      moe_combine_partial_kernel + ep_fold_kernel -- and pushes the finished residual rows into every rank's stage2 (attention is
+//      replicated: every rank needs every row back);
+//   3. every rank copies stage2 to its residual stream.
+// Per rank and layer at T = 2 048, k = 2, 8 ranks: 4.2 MB + 14.7 MB pushed, against 58 MB for the f32 all-reduce.
+struct PeerMoeArgs {
+    const PeerDev* dev;
+    const bf16_t* y;
+    const uint32_t* pos_of_slot;
+    const uint32_t* inds;
+    const bf16_t* scores;
+    const bf16_t* resid;
+    bf16_t* out;
+    int T, hidden, k, e_lo, e_n, chunk;
+};
+
+__global__ __launch_bounds__(256) void peer_moe_combine_kernel(const PeerMoeArgs a) {
+    const PeerDev* p = a.dev;
+    const unsigned tag = peer_tag(p);
+    const int W = p->world, me = p->rank;
+    const int vec = a.hidden / 8;                         // 16-byte vectors per row
+    const int slots = a.T * a.k;
+    // 1. push this rank's slots to their tokens' owners
+    for (int j = blockIdx.x; j < slots; j += gridDim.x) {
+        const int e = (int)a.inds[j];
+        if (e < a.e_lo || e >= a.e_lo + a.e_n) continue;                // (block-uniform)
+        const int t = j / a.k, o = min(t / a.chunk, W - 1);
+        const float sc = bf16_to_f32(a.scores[j]);
+        const u32x4* src = reinterpret_cast<const u32x4*>(a.y + (size_t)a.pos_of_slot[j] * a.hidden);
+        u32x4* dst = reinterpret_cast<u32x4*>(p->stage1[o]) + (size_t)(j - o * a.chunk * a.k) * vec;
+        for (int v = threadIdx.x; v < vec; v += 256) {
+            const u32x4 x = src[v];
+            u32x4 r;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) r[q] = pack_bf16(bf16lo(x[q]) * sc, bf16hi(x[q]) * sc);
+            dst[v] = r;
+        }
+    }
+    large_publish(p, 0, tag, p->state + 3);
+    bool ok = large_wait(p, 0, tag);
+    // 2. the owner's tokens: sum the k slot rows in slot order, add the residual, push the finished row to every rank
+    const int t0 = me * a.chunk, n_own = max(0, min(a.chunk, a.T - t0));
+    for (int tt = blockIdx.x; tt < n_own && ok; tt += gridDim.x) {
+        const int t = t0 + tt;
+        const u32x4* rows = reinterpret_cast<const u32x4*>(p->stage1[me]) + (size_t)tt * a.k * vec;
+        const u32x4* rs = reinterpret_cast<const u32x4*>(a.resid + (size_t)t * a.hidden);
+        for (int v = threadIdx.x; v < vec; v += 256) {
+            float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (int s2 = 0; s2 < a.k; ++s2) {
+                const u32x4 x = rows[(size_t)s2 * vec + v];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { acc[2 * q] += bf16lo(x[q]); acc[2 * q + 1] += bf16hi(x[q]); }
+            }
+            const u32x4 r = rs[v];
+            u32x4 o;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) o[q] = pack_bf16(bf16lo(r[q]) + round_bf16(acc[2 * q]), bf16hi(r[q]) + round_bf16(acc[2 * q + 1]));
+            for (int d = 0; d < W; ++d) *(reinterpret_cast<u32x4*>(p->stage2[d]) + (size_t)t * vec + v) = o;
+        }
+    }
+    large_publish(p, 1, tag, p->state + 4);
+    ok = large_wait(p, 1, tag) && ok;
+    // 3. all T rows are in this rank's stage2
+    const size_t nvec = (size_t)a.T * vec;
+    for (size_t v = (size_t)blockIdx.x * 256 + threadIdx.x; v < nvec; v += (size_t)gridDim.x * 256)
+        reinterpret_cast<u32x4*>(a.out)[v] = ok ? *(reinterpret_cast<const u32x4*>(p->stage2[me]) + v) : u32x4{0u, 0u, 0u, 0u};
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned done = __hip_atomic_fetch_add(p->state + 5, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (done == gridDim.x - 1) {
+            __hip_atomic_store(p->state + 5, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(p->state, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
 int upload_table(PeerComm* c) {
     PeerDev t = {};
     for (int r = 0; r < c->world; ++r) {
@@ -310,10 +392,12 @@ int omx_peer_allreduce(const void* send, void* recv, size_t count, int dtype, in
                 if (bf16sum) peer_allreduce_large_kernel<true><<<kLargeBlocks, 256, 0, stream>>>(a);
                 else peer_allreduce_large_kernel<false><<<kLargeBlocks, 256, 0, stream>>>(a);
                 if (hipGetLastError() != hipSuccess) return 1;
+                ++c->n_large;
             }
             return 0;
         }
         if (!c->rccl_fn) return 1;   // nothing to hand the call to
+        ++c->n_rccl;
         return c->rccl_fn(send, recv, count, dtype, op, c->rccl, stream);
     }
     PeerArgs a = {};
@@ -321,10 +405,47 @@ int omx_peer_allreduce(const void* send, void* recv, size_t count, int dtype, in
     a.send = static_cast<const uint32_t*>(send); a.recv = static_cast<uint32_t*>(recv);
     a.words = (int)words; a.max64 = u64max ? 1 : 0;
     peer_allreduce_kernel<<<(unsigned)((words + 255) / 256), 256, 0, stream>>>(a);
+    ++c->n_small;
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 
 void* omx_peer_allreduce_fn(void) { return (void*)&omx_peer_allreduce; }
+
+// bytes of one stage of the two-shot / exchange path (0: that path is off -- an RCCL communicator takes the large calls)
+size_t omx_peer_comm_stage_bytes(void* comm) {
+    omx::PeerComm* c = static_cast<omx::PeerComm*>(comm);
+    return c && c->connected ? c->stage_bytes : 0;
+}
+
+// out [T, hidden] = resid + the MoE block's weighted expert outputs, exchanged as described at peer_moe_combine_kernel.
+// 0: done; 2: not available on this communicator / for this size (the caller keeps its all-reduce); 1: error
+int omx_peer_moe_combine(void* out, const void* resid, const omx_moe_ep_slots* sl, int T, int hidden, int top_k, int e_lo, int e_n, void* comm,
+                         omx_stream stream_) {
+    using namespace omx;
+    if (!comm || !out || !resid || !sl || !sl->y) return 1;
+    PeerComm* c = static_cast<PeerComm*>(comm);
+    if (!c->connected || !c->stage_bytes || T <= 0 || hidden % 8 != 0 || top_k < 1) return 2;
+    const int chunk = (T + c->world - 1) / c->world;
+    if ((size_t)chunk * top_k * hidden * 2 > c->stage_bytes || (size_t)T * hidden * 2 > c->stage_bytes) return 2;
+    PeerMoeArgs a = {};
+    a.dev = c->dev;
+    a.y = static_cast<const bf16_t*>(sl->y); a.pos_of_slot = sl->pos_of_slot; a.inds = sl->inds; a.scores = static_cast<const bf16_t*>(sl->scores);
+    a.resid = static_cast<const bf16_t*>(resid); a.out = static_cast<bf16_t*>(out);
+    a.T = T; a.hidden = hidden; a.k = top_k; a.e_lo = e_lo; a.e_n = e_n; a.chunk = chunk;
+    peer_moe_combine_kernel<<<kLargeBlocks, 256, 0, (hipStream_t)stream_>>>(a);
+    ++c->n_moe;
+    return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+
+// launches issued through this communicator by path: [0] one-shot, [1] two-shot chunks, [2] MoE combine, [3] handed to RCCL (calls made while
+// a graph was being captured count once, not per replay)
+int omx_peer_comm_counts(void* comm, unsigned long long* out4) {
+    using namespace omx;
+    OMX_REQUIRE(comm && out4, "omx_peer_comm_counts: null argument");
+    const PeerComm* c = static_cast<const PeerComm*>(comm);
+    out4[0] = c->n_small; out4[1] = c->n_large; out4[2] = c->n_moe; out4[3] = c->n_rccl;
+    return 0;
+}
 
 int omx_peer_comm_status(void* comm, unsigned* aborted) {
     using namespace omx;

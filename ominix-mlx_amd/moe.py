@@ -17,6 +17,9 @@ MOE_SIGNATURES = {
     "omx_moe_block_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_float, c_void_p, c_void_p, c_void_p, c_void_p,
                                       c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "omx_moe_block_forward_q": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_float, c_void_p] + [c_void_p] * 12 + [c_int] * 9 + [c_void_p]),
+    # the batched expert-parallel block up to the expert outputs (out: struct of four pointers) -> comm.omx_peer_moe_combine
+    "omx_moe_block_slots_ep": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                                       c_int, c_int, c_void_p]),
     "omx_moe_block_partial_ep": (c_int, [c_void_p, c_void_p, c_void_p, ctypes.c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                          c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "omx_moe_forward_q": (c_int, [c_void_p] * 12 + [c_int] * 9 + [c_void_p, c_void_p, c_void_p]),

@@ -789,6 +789,14 @@ def test_peer_store_allreduce_across_processes(omx, tmp_path, fused):
         # the two-shot path: seeded messages of 32 KB .. 16.7 MB in f32 and bf16 come back as the rank-ordered sum, bit for bit
         assert len(r["large"]) == 6 and all(c["rc"] == 0 and c["equal"] for c in r["large"]), r["large"]
         assert not r["aborted_after_large"]
+        # expert parallel: the MoE block's weighted sum as the all-to-all combine + all-gather kernel against the f32 all-reduce of the
+        # same prompt -- same tokens, same last logits (top-2: the two products of a token sum to the same f32 in either order)
+        assert r["stage_bytes"] > 0 and not r["aborted_after_ep"]
+        assert r["ep_exchange"]["tokens"] == r["ep_allreduce"]["tokens"] and r["ep_exchange"]["logits_crc"] == r["ep_allreduce"]["logits_crc"]
+        # (which kernels ran: one combine per layer and no two-shot all-reduce in the exchange form, the reverse in the other)
+        assert r["ep_exchange"]["launches"]["moe_combine"] == 2 and r["ep_exchange"]["launches"]["two_shot"] == 0, r["ep_exchange"]["launches"]
+        assert r["ep_allreduce"]["launches"]["moe_combine"] == 0 and r["ep_allreduce"]["launches"]["two_shot"] >= 2, r["ep_allreduce"]["launches"]
+    assert res[0]["ep_exchange"]["tokens"] == res[1]["ep_exchange"]["tokens"] and res[0]["ep_exchange"]["logits_crc"] == res[1]["ep_exchange"]["logits_crc"]
     assert res[0]["tokens"] == res[1]["tokens"]
     assert res[0]["tokens_batched"] == res[1]["tokens_batched"]
     assert res[0]["decode_path"] == "graph"          # the peer all-reduce is an ordinary kernel: the step stays captured
@@ -824,6 +832,16 @@ def test_peer_store_allreduce_across_processes(omx, tmp_path, fused):
     finally:
         del os.environ["OMX_PREFILL_SERIAL"]
     assert outs_b[0] == res[0]["tokens_batched"]
+    # ... and the expert-parallel pair against the single-GPU sparse-MoE engine (batched prompt, grouped GEMMs over all experts)
+    moe_cfg = dict(hidden_size=512, num_hidden_layers=2, intermediate_size=1024, num_attention_heads=8, num_key_value_heads=2, head_dim=64,
+                   vocab_size=2048, rms_norm_eps=1e-5, rope_theta=1e6, tie_word_embeddings=False, num_experts=8, num_experts_per_tok=2,
+                   moe_intermediate_size=1024, moe_mode="mixtral", norm_topk_prob=0, qk_norm=False)
+    single = engine.Model(max_context=512, **moe_cfg)
+    single.synth_weights()
+    moe_prompt = synth.prompt_ids(200, moe_cfg["vocab_size"])
+    want = [int(single.prefill(moe_prompt))] + [int(x) for x in single.decode(6)]
+    single.close()
+    assert res[0]["ep_exchange"]["tokens"] == want
     print(f"peer all-reduce of 16 KB, two processes on one GPU: {res[0]['allreduce_16k_us']:.1f} us per call; "
           f"TP = 2 step (fused={fused}): {res[0]['step_ms']:.3f} ms")
 

@@ -131,6 +131,32 @@ res["tokens_batched"] = [int(m.prefill(prompt))] + [int(x) for x in m.decode(15)
 res["aborted"] = pc.aborted()
 dist.barrier()
 m.close()
+
+# expert parallel: a small Mixtral-shaped model, this rank's experts, a 200-token prompt as ONE batched pass.  On
+# this communicator the MoE block's weighted sum is the all-to-all combine + all-gather kernel (peer_moe_combine_kernel);
+# OMX_EP_COMBINE=allreduce keeps the [T, hidden] f32 all-reduce (here: the two-shot path).  Same roundings: the two must agree bit for bit.
+moe_cfg = dict(hidden_size=512, num_hidden_layers=2, intermediate_size=1024, num_attention_heads=8, num_key_value_heads=2, head_dim=64,
+               vocab_size=2048, rms_norm_eps=1e-5, rope_theta=1e6, tie_word_embeddings=False, num_experts=8, num_experts_per_tok=2,
+               moe_intermediate_size=1024, moe_mode="mixtral", norm_topk_prob=0, qk_norm=False)
+moe_prompt = synth.prompt_ids(200, moe_cfg["vocab_size"])
+res["stage_bytes"] = int(omx.lib.omx_peer_comm_stage_bytes(pc.comm))
+for label, env in (("exchange", None), ("allreduce", "allreduce")):
+    if env is None:
+        os.environ.pop("OMX_EP_COMBINE", None)
+    else:
+        os.environ["OMX_EP_COMBINE"] = env
+    before = pc.counts()
+    em = engine.Model(max_context=512, ep_rank=rank, ep_size=world, **moe_cfg)
+    em.synth_weights()
+    em.set_comm(pc.comm, pc.fn)
+    dist.barrier()
+    toks = [int(em.prefill(moe_prompt))] + [int(x) for x in em.decode(6)]
+    res["ep_" + label] = {"tokens": toks, "logits_crc": int(np.frombuffer(em.last_logits().tobytes(), np.uint32).sum() & 0xFFFFFFFF),
+                          "prefill_ms": em.last_prefill_ms(), "launches": {k: v - before[k] for k, v in pc.counts().items()}}
+    dist.barrier()
+    em.close()
+os.environ.pop("OMX_EP_COMBINE", None)
+res["aborted_after_ep"] = pc.aborted()
 pc.close()
 os.makedirs(out_dir, exist_ok=True)
 with open(os.path.join(out_dir, f"rank{rank}.json"), "w") as f:

@@ -641,7 +641,10 @@ def main():
             "config": {"workload": f"{args.model}" + (" (Qwen3-8B shapes for BASELINE 'Qwen3-7B')" if args.model == "qwen3-8b" else "") + " bf16 greedy decode, batch 1, "
                                    f"{args.prompt}-token prompt then {args.warmup}+{args.steps} decode tokens",
                        "parallelism": (f"ep{world}" if moe else f"tp{world}"), "context_at_timing": ctx_mid,
-                       "layers": cfg["num_hidden_layers"], **({"allreduce": peer_note} if peer_note else {})},
+                       "layers": cfg["num_hidden_layers"], **({"allreduce": peer_note} if peer_note else {}),
+                       # reductions issued through the peer communicator so far, by path (one-shot <= 32 KB, two-shot chunks, MoE exchange,
+                       # handed to RCCL; calls inside a captured graph count once) -- what the first multi-GPU run's log is read from
+                       **({"allreduce_launches": peer.counts()} if peer is not None else {})},
             "roofline": {"bound": "hbm", "kernel": "gemv_kernel<rmsnorm, gate/up, swiglu>", "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
                          "traffic": pmc_traffic(DOMINANT_KERNEL) if world == 1 and args.model == "qwen3-8b" else None,

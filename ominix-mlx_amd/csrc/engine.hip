@@ -962,11 +962,15 @@ int run_step(omx_qwen3 m, bool with_head, int pos) {
 int enqueue_head_on_row(omx_qwen3 m, const bf16_t* row, hipStream_t s) {
     const omx_qwen3_config& c = m->cfg;
     const int hd = c.hidden_size;
+    // a tensor-parallel rank holds a vocabulary shard: its rows are numbered from its offset and the ranks' packed (logit, index) keys
+    // meet in one unsigned max (enqueue_step_tail)
+    const bool tp = m->allreduce != nullptr && c.ep_size <= 1;
     if (c.quant_bits > 0) {
         QGemvArgs a = {};
         a.m[0] = m->q_head; a.m[0].n = m->V; a.N = m->V; a.K = hd; a.group = c.quant_group;
         a.x = row; a.norm_w = m->final_norm; a.eps = c.rms_norm_eps; a.out = m->logits; a.scales_f16 = c.quant_scales_f16 != 0;
         a.argmax_slot = m->argmax_partials;
+        a.row_offset = c.tp_rank * m->V;
         if (launch_qgemv(a, c.quant_bits, PRO_RMSNORM, EPI_ARGMAX, s)) return 1;
     } else {
         GemvArgs a = {};
@@ -975,12 +979,17 @@ int enqueue_head_on_row(omx_qwen3 m, const bf16_t* row, hipStream_t s) {
         a.norm_w = m->final_norm; a.eps = c.rms_norm_eps;
         a.out = m->logits;
         a.argmax_slot = m->argmax_partials;
-        a.row_offset = 0;
+        a.row_offset = c.tp_rank * m->V;
         if (launch_gemv(a, PRO_RMSNORM, EPI_ARGMAX, s)) return 1;
     }
     if (add_sampling_noise(m, s)) return 1;
-    sample_finalize_kernel<<<1, 256, 0, s>>>(m->st, m->argmax_partials, m->n_argmax_partials, m->out_ring, m->ring_cap, nullptr);
+    sample_finalize_kernel<<<1, 256, 0, s>>>(m->st, m->argmax_partials, m->n_argmax_partials, m->out_ring, m->ring_cap, tp ? m->argmax_key : nullptr);
     OMX_LAUNCH_CHECK();
+    if (tp) {
+        OMX_REQUIRE(m->allreduce(m->argmax_key, m->argmax_key, 1, kNcclUint64, kNcclMax, m->comm, s) == 0, "ncclAllReduce failed");
+        apply_token_kernel<<<1, 1, 0, s>>>(m->st, m->argmax_key, m->out_ring, m->ring_cap);
+        OMX_LAUNCH_CHECK();
+    }
     return 0;
 }
 
@@ -1751,9 +1760,9 @@ int omx_qwen3_prefill(omx_qwen3 m, const uint32_t* prompt, int n_prompt, uint32_
         // tile count does not change, instead of a 36-layer GEMV pass); OMX_PREFILL_TAIL_STEP=1: n-1 tokens batched and
         // the decode step for the last one
         const char* tail_env = getenv("OMX_PREFILL_TAIL_STEP");
-        // (the vocabulary-sharded head of a tensor-parallel rank + its argmax all-reduce live in the step; an expert-parallel rank holds
-        //  the whole head and takes the batched tail like a single device)
-        const bool tail_step = (tail_env && tail_env[0] == '1') || (m->allreduce != nullptr && m->cfg.ep_size <= 1);
+        // (a tensor-parallel rank's vocabulary shard + the argmax all-reduce: enqueue_head_on_row does both since round 4 -- until then a
+        //  TP prompt ended with a whole decode step, 2 ms of a 24 ms prompt at TP 2)
+        const bool tail_step = tail_env && tail_env[0] == '1';
         const int nb = tail_step ? n_prompt - 1 : n_prompt;
         if (prefill_prefix_batched(m, nb, st.pos, nullptr, !tail_step)) return 1;
         st.pos += n_prompt - 1;

@@ -125,8 +125,6 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(const PrefillArgs 
     // ---- staging.  K: global_load_lds (no VGPR round trip; the LDS image is lane-linear, so the bank-conflict
     //      swizzle -- 16-B chunk index ^= key & (DC-1) -- is applied to the per-lane SOURCE address).
     //      V: (key 2p, key 2p+1) chunk pairs through registers, written transposed ([d][key]). ----
-    typedef __attribute__((address_space(3))) void* lds_ptr_t;
-    typedef const __attribute__((address_space(1))) void* glb_ptr_t;
     // per-thread source offsets are loop invariants (elements from the tile's first key row); a tile that lies
     // inside the sequence adds a wave-uniform base (SALU), only the last partial tile recomputes clamped rows
     constexpr int VSH = (D == 128) ? 0 : 1;           // keys per 256 B of LDS = 1 << VSH

@@ -64,16 +64,19 @@ struct PeerLargeArgs {
 };
 
 __device__ __forceinline__ void large_publish(const PeerDev* p, int phase, unsigned tag, uint32_t* counter) {
-    // every thread's pushes are complete at system scope before its block reports in; the last block to arrive tells every rank
-    __threadfence_system();
+    // every thread's pushes have left this GPU before its block reports in; the last block to arrive tells every rank.  The stages are
+    // fine-grained (uncached) memory: a store is on its way to its destination when it retires, so the release is "wait for my stores"
+    // (vmcnt) -- a system-scope fence also writes the whole L2 back, 140 us per call measured with three of them in this kernel
+    // (MI355X_MICROARCH.md handoff-flag: payload -> vmcnt(0) -> flag)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     __syncthreads();
     if (threadIdx.x == 0) {
         const unsigned done = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
         if (done == gridDim.x - 1) {
             __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             for (int r = 0; r < p->world; ++r)
-                __hip_atomic_store((peer_gu64*)(p->flags[r] + (size_t)phase * p->world + p->rank), (unsigned long long)tag, __ATOMIC_RELEASE,
-                                   __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store((peer_gu64*)(p->flags[r] + (size_t)phase * p->world + p->rank), (unsigned long long)tag, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_SYSTEM);   // (relaxed: every block's stores had retired before it reported in; a release here writes the L2 back)
         }
     }
 }
@@ -86,7 +89,7 @@ __device__ __forceinline__ bool large_wait(const PeerDev* p, int phase, unsigned
         for (int r = 0; r < p->world && ok; ++r) {
             const peer_gu64* f = (const peer_gu64*)(p->flags[p->rank] + (size_t)phase * p->world + r);
             unsigned spins = 0;
-            while ((unsigned)__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != tag) {
+            while ((unsigned)__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != tag) {   // (an acquire per poll would drop the L2 each time)
                 if (++spins >= kPeerSpinLimit) { __hip_atomic_store(p->state + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); ok = 0; break; }
                 __builtin_amdgcn_s_sleep(2);
             }
@@ -94,7 +97,7 @@ __device__ __forceinline__ bool large_wait(const PeerDev* p, int phase, unsigned
         s_ok = ok;
     }
     __syncthreads();
-    __threadfence_system();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // (drops this CU's L1 lines of the stage; the L2 does not cache fine-grained memory)
     return s_ok != 0;
 }
 

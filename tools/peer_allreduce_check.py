@@ -70,6 +70,8 @@ def latency_histogram(n_floats, calls=400):
 
 # the two sizes of a TP decode step (hidden-sized f32 partials; the 8-byte argmax key goes through the same path) and a prefill-sized one
 res["latency_us"] = [latency_histogram(n) for n in (4096, 2, 4096 * 64)]
+if os.environ.get("OMX_PEER_CHECK_BIG") == "1":      # prompt-sized messages through the two-shot path (profiles/r04_peer_two_shot.txt)
+    res["latency_us"] += [latency_histogram(n, 100) for n in (2048 * 4096 // 2, 2048 * 4096)]
 if rank == 0:
     for h in res["latency_us"]:
         print(f"[peer all-reduce] {h['n_floats']:>7d} f32 x {h['calls']} calls, us per call (host clock incl. launch + sync): "

@@ -846,6 +846,42 @@ def test_peer_store_allreduce_across_processes(omx, tmp_path, fused):
           f"TP = 2 step (fused={fused}): {res[0]['step_ms']:.3f} ms")
 
 
+def test_peer_communicator_four_processes_on_one_gpu(omx, tmp_path):
+    """The same tool with FOUR ranks sharing this GPU: four slices / owners in the two-shot all-reduce and in the expert-parallel exchange
+    (8 experts: two per rank, tokens owned in quarters), KV heads one per two ranks in the TP 4 model.  Every rank's self-test and seeded
+    large messages exact, all ranks emit the same tokens in every section, the exchange combine equals the all-reduce form bit for bit
+    and the single-GPU sparse-MoE engine's tokens."""
+    import json
+    import subprocess
+    import sys
+    from ominix_mlx_amd import engine
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    port = 29900 + (os.getpid() % 90)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMX_PEER_FUSED="0")
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(root, "tools", "peer_allreduce_check.py"), str(tmp_path)],
+                       env=env, capture_output=True, text=True, timeout=900, stdin=subprocess.DEVNULL)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
+    res = [json.load(open(tmp_path / f"rank{r}.json")) for r in range(4)]
+    for r in res:
+        assert r["self_test"] and not r["aborted"] and not r["aborted_after_large"] and not r["aborted_after_ep"]
+        assert all(c["rc"] == 0 and c["equal"] for c in r["large"]), r["large"]
+        assert r["ep_exchange"]["tokens"] == r["ep_allreduce"]["tokens"] and r["ep_exchange"]["logits_crc"] == r["ep_allreduce"]["logits_crc"]
+        assert r["ep_exchange"]["launches"]["moe_combine"] == 2 and r["ep_exchange"]["launches"]["two_shot"] == 0
+        for key in ("tokens", "tokens_batched"):
+            assert r[key] == res[0][key]
+        assert r["ep_exchange"]["tokens"] == res[0]["ep_exchange"]["tokens"]
+    moe_cfg = dict(hidden_size=512, num_hidden_layers=2, intermediate_size=1024, num_attention_heads=8, num_key_value_heads=2, head_dim=64,
+                   vocab_size=2048, rms_norm_eps=1e-5, rope_theta=1e6, tie_word_embeddings=False, num_experts=8, num_experts_per_tok=2,
+                   moe_intermediate_size=1024, moe_mode="mixtral", norm_topk_prob=0, qk_norm=False)
+    single = engine.Model(max_context=512, **moe_cfg)
+    single.synth_weights()
+    moe_prompt = synth.prompt_ids(200, moe_cfg["vocab_size"])
+    want = [int(single.prefill(moe_prompt))] + [int(x) for x in single.decode(6)]
+    single.close()
+    assert res[0]["ep_exchange"]["tokens"] == want
+
+
 def test_tensor_parallel_oproj_in_attention_launch_is_bit_identical(omx, monkeypatch):
     """Tensor parallel: the rank's f32 partial of the O projection comes out of the attention launch (attn_step.hip, o_out_f32) with
     the arithmetic of the separate EPI_F32 GEMV -- two ranks on one GPU through the in-process communicator, tokens and last logits

@@ -227,10 +227,38 @@ def peer_comm(dist, rank, world, rccl):
 
 
 def rccl_comm(dist, rank, world):
-    """RCCL communicator for the C++ engine, bootstrapped through torch.distributed (ominix-mlx_amd/comm.py)."""
+    """RCCL communicator for the C++ engine, bootstrapped through torch.distributed (ominix-mlx_amd/comm.py).
+    Returns None -- on EVERY rank, agreed through the torch process group -- when any rank cannot load librccl or create / warm up its
+    communicator: the run then goes on with the peer communicator alone (its two-shot path takes the large reductions; bench.py's
+    one-GPU pre-flight exercises exactly that configuration)."""
+    import torch
     from ominix_mlx_amd import comm
-    with c_stdout_to_stderr():
-        return comm.rccl_comm(dist, rank, world)
+
+    def all_ok(ok):
+        if dist is None:
+            return bool(ok)
+        t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=REDUCE_DEVICE)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return int(t.item()) == 1
+
+    err = ""
+    try:
+        comm.load_rccl()                       # (not a collective: a rank that cannot load the library must not leave the others in one)
+    except Exception as e:   # noqa: BLE001
+        err = str(e) or type(e).__name__
+    if not all_ok(not err):
+        print(f"[bench rank {rank}] RCCL not used: librccl not loadable on every rank ({err or 'another rank'})", file=sys.stderr, flush=True)
+        return None
+    keep = None
+    try:
+        with c_stdout_to_stderr():
+            keep = comm.rccl_comm(dist, rank, world)
+    except Exception as e:   # noqa: BLE001
+        err = str(e) or type(e).__name__
+    if not all_ok(keep is not None):
+        print(f"[bench rank {rank}] RCCL not used: communicator creation failed ({err or 'on another rank'})", file=sys.stderr, flush=True)
+        return None
+    return keep
 
 
 def time_dominant_kernel(omx, cfg, world, iters=3):
@@ -535,7 +563,7 @@ def main():
         if peer is not None:
             model.set_comm(peer.comm, peer.fn)
         elif keep is None:
-            raise SystemExit(f"rank {rank}: OMX_BENCH_ONE_GPU=1 needs the peer communicator and it was not usable ({peer_note})")
+            raise SystemExit(f"rank {rank}: no RCCL communicator and the peer communicator was not usable either ({peer_note})")
         else:
             model.set_comm(keep[1], keep[2])
     model.synth_weights()

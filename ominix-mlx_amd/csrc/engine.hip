@@ -1208,6 +1208,7 @@ int prefill_prefix_batched(omx_qwen3 m, int T, int off, const EncodeOpts* enc = 
                 // keeps the all-reduce; any communicator without the exchange path does too.
                 const char* cmb = getenv("OMX_EP_COMBINE");
                 if (!etp && m->allreduce == (nccl_allreduce_fn)omx_peer_allreduce_fn() && omx_peer_comm_stage_bytes(m->comm) > 0 &&
+                    T * c.num_experts_per_tok > 32 &&      // (a handful of rows takes the block's GEMV form, which has no slot tables)
                     !(cmb && strcmp(cmb, "allreduce") == 0)) {
                     omx_moe_ep_slots sl = {};
                     if (omx_moe_block_slots_ep(&sl, m->pf_xn, L.moe_gate, L.moe_wg, L.moe_wu, L.moe_wd, T, hd, c.moe_intermediate_size, c.num_experts,

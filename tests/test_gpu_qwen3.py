@@ -840,6 +840,8 @@ def test_peer_store_allreduce_across_processes(omx, tmp_path, fused):
     single.synth_weights()
     moe_prompt = synth.prompt_ids(200, moe_cfg["vocab_size"])
     want = [int(single.prefill(moe_prompt))] + [int(x) for x in single.decode(6)]
+    single.reset()
+    want += [int(single.prefill(moe_prompt[:9]))] + [int(x) for x in single.decode(3)]
     single.close()
     assert res[0]["ep_exchange"]["tokens"] == want
     print(f"peer all-reduce of 16 KB, two processes on one GPU: {res[0]['allreduce_16k_us']:.1f} us per call; "
@@ -878,6 +880,8 @@ def test_peer_communicator_four_processes_on_one_gpu(omx, tmp_path):
     single.synth_weights()
     moe_prompt = synth.prompt_ids(200, moe_cfg["vocab_size"])
     want = [int(single.prefill(moe_prompt))] + [int(x) for x in single.decode(6)]
+    single.reset()
+    want += [int(single.prefill(moe_prompt[:9]))] + [int(x) for x in single.decode(3)]
     single.close()
     assert res[0]["ep_exchange"]["tokens"] == want
 

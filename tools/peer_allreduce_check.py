@@ -153,6 +153,9 @@ for label, env in (("exchange", None), ("allreduce", "allreduce")):
     em.set_comm(pc.comm, pc.fn)
     dist.barrier()
     toks = [int(em.prefill(moe_prompt))] + [int(x) for x in em.decode(6)]
+    em.reset()
+    dist.barrier()
+    toks += [int(em.prefill(moe_prompt[:9]))] + [int(x) for x in em.decode(3)]      # a short prompt: the block's GEMV form + all-reduce in both modes
     res["ep_" + label] = {"tokens": toks, "logits_crc": int(np.frombuffer(em.last_logits().tobytes(), np.uint32).sum() & 0xFFFFFFFF),
                           "prefill_ms": em.last_prefill_ms(), "launches": {k: v - before[k] for k, v in pc.counts().items()}}
     dist.barrier()

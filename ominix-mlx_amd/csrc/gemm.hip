@@ -18,6 +18,7 @@
 //   * XCD-aware block order (T1): consecutive blocks of one XCD share an x row panel in its L2.
 // Fallback (any K, any alignment): register-staged 64x64x32 tiles with zero fill.
 #include "gemm.hpp"
+#include "act16.hpp"
 #include "gridsync.hpp"   // coherent accessors for the split-K hand-over
 #include <map>
 #include <mutex>
@@ -221,11 +222,15 @@ constexpr int smem_bytes(int tile_rows) { return 2 * (2 * (tile_rows / 2) * TK *
 // TMR = 128: a 128 x 256 tile with the same eight waves (2 x 4, each 64 x 64), phases and stagger -- for grids whose 256^2 tiles cover
 // at most half of the chip (the O / down projections of a 2 048-token prompt: 8 x 16 tiles); every output element is the same
 // MFMA chain as in the 256-row form, so the two are bit-identical.  X pieces are 64 rows (ONE 16-byte chunk per thread and stage).
-template <int MF, bool SW = false, bool IMPL = false, int TMR = 256>
+// F16: float16 operands and results (a float16 checkpoint's prompt pass): v_mfma_f32_16x16x32_f16 on the same fragments, every rounding
+// point of the epilogues in float16 (act16.hpp)
+template <int MF, bool SW = false, bool IMPL = false, int TMR = 256, bool F16 = false>
 __global__ __launch_bounds__(big::NT) void gemm_bf16_nt_256_kernel(const GemmArgs a) {
     static_assert(!IMPL || SW, "the implicit-convolution staging lives in the segmented variant");
     static_assert(!SW || MF == 16, "the SwiGLU epilogue is written for the 16x16 accumulator layout");
     static_assert(TMR == 256 || (TMR == 128 && !SW && MF == 16), "the 128-row tile exists in the plain form");
+    static_assert(!F16 || (MF == 16 && !IMPL), "float16: the 16x16x32 forms without the implicit convolution");
+    typedef Act16<F16> A16;
     using namespace big;
     constexpr int WM = TMR / 2, XH = TMR / 4;      // rows per wave group, rows per wave group and half-piece
     constexpr int NX = TMR / 128;                  // 16-byte chunks per thread of an X piece
@@ -397,7 +402,10 @@ __global__ __launch_bounds__(big::NT) void gemm_bf16_nt_256_kernel(const GemmArg
     auto mfma = [&](const bf16x8& x, const bf16x8& y, accv& c) {
         // operands swapped (W fragment first): the accumulator holds the tile transposed, see the epilogue
         if constexpr (MF == 32) c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(y, x, c, 0, 0, 0);
-        else c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(y, x, c, 0, 0, 0);
+        else if constexpr (F16) {
+            typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, y), __builtin_bit_cast(h8, x), c, 0, 0, 0);
+        } else c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(y, x, c, 0, 0, 0);
     };
     auto quadrant = [&](int qm, int qn) {
         __builtin_amdgcn_sched_barrier(0);
@@ -538,16 +546,16 @@ __global__ __launch_bounds__(big::NT) void gemm_bf16_nt_256_kernel(const GemmArg
                     float v[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const float gt = round_bf16(acc[i][j][e]), up = round_bf16(acc[i][j + CT / 2][e]);
+                        const float gt = A16::rnd(acc[i][j][e]), up = A16::rnd(acc[i][j + CT / 2][e]);
                         if (per_op) {   // nn::silu(gate) * up, each primitive rounded to bf16 (silu_mul_kernel, prefill.hip)
-                            const float sg = round_bf16(1.0f / (1.0f + expf(-gt)));
-                            v[e] = round_bf16(gt * sg) * up;
+                            const float sg = A16::rnd(1.0f / (1.0f + expf(-gt)));
+                            v[e] = A16::rnd(gt * sg) * up;
                         } else {        // fused_swiglu: one rounding (swiglu_strided_kernel, dit.hip)
                             v[e] = gt / (1.0f + expf(-gt)) * up;
                         }
                     }
                     *reinterpret_cast<u32x2*>(a.sg.out_act + (size_t)row * a.sg.ld_act + col) =
-                        u32x2{pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3])};
+                        u32x2{A16::pack(v[0], v[1]), A16::pack(v[2], v[3])};
                 }
             }
         } else {
@@ -569,17 +577,17 @@ __global__ __launch_bounds__(big::NT) void gemm_bf16_nt_256_kernel(const GemmArg
                         for (int e = 0; e < 4; ++e) {
                             if (col + e >= seg_cols) break;
                             const size_t o = (size_t)row * seg_ld + col + e;
-                            float x = v[e] + (seg_bias ? bf16_to_f32(seg_bias[col + e]) : 0.f);
-                            if (rs) x = bf16_to_f32(rs[o]) + round_bf16(x);
-                            seg_out[o] = f32_to_bf16(x);
+                            float x = v[e] + (seg_bias ? A16::val(seg_bias[col + e]) : 0.f);
+                            if (rs) x = A16::val(rs[o]) + A16::rnd(x);
+                            seg_out[o] = A16::bits(x);
                         }
                         continue;
                     }
                     if (seg_bias) {
                         const u32x2 b = *reinterpret_cast<const u32x2*>(seg_bias + col);
-                        v[0] += bf16lo(b[0]); v[1] += bf16hi(b[0]); v[2] += bf16lo(b[1]); v[3] += bf16hi(b[1]);
+                        v[0] += A16::lo(b[0]); v[1] += A16::hi(b[0]); v[2] += A16::lo(b[1]); v[3] += A16::hi(b[1]);
                     }
-                    *reinterpret_cast<u32x2*>(seg_out + (size_t)row * seg_ld + col) = u32x2{pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3])};
+                    *reinterpret_cast<u32x2*>(seg_out + (size_t)row * seg_ld + col) = u32x2{A16::pack(v[0], v[1]), A16::pack(v[2], v[3])};
                 }
             }
         }
@@ -603,7 +611,7 @@ __global__ __launch_bounds__(big::NT) void gemm_bf16_nt_256_kernel(const GemmArg
                 if (full) {
                     if (a.bias) {
                         const u32x2 b = *reinterpret_cast<const u32x2*>(a.bias + col);
-                        v[0] += bf16lo(b[0]); v[1] += bf16hi(b[0]); v[2] += bf16lo(b[1]); v[3] += bf16hi(b[1]);
+                        v[0] += A16::lo(b[0]); v[1] += A16::hi(b[0]); v[2] += A16::lo(b[1]); v[3] += A16::hi(b[1]);
                     }
                     if (a.relu) {
 #pragma unroll
@@ -612,23 +620,23 @@ __global__ __launch_bounds__(big::NT) void gemm_bf16_nt_256_kernel(const GemmArg
                     if (a.gate) {
                         const u32x2 r = *reinterpret_cast<const u32x2*>(a.resid + o);
                         const u32x2 gt = *reinterpret_cast<const u32x2*>(a.gate + col);
-                        v[0] = bf16lo(r[0]) + v[0] * bf16lo(gt[0]); v[1] = bf16hi(r[0]) + v[1] * bf16hi(gt[0]);
-                        v[2] = bf16lo(r[1]) + v[2] * bf16lo(gt[1]); v[3] = bf16hi(r[1]) + v[3] * bf16hi(gt[1]);
+                        v[0] = A16::lo(r[0]) + v[0] * A16::lo(gt[0]); v[1] = A16::hi(r[0]) + v[1] * A16::hi(gt[0]);
+                        v[2] = A16::lo(r[1]) + v[2] * A16::lo(gt[1]); v[3] = A16::hi(r[1]) + v[3] * A16::hi(gt[1]);
                     } else if (a.resid) {
                         const u32x2 r = *reinterpret_cast<const u32x2*>(a.resid + o);
-                        v[0] = bf16lo(r[0]) + round_bf16(v[0]); v[1] = bf16hi(r[0]) + round_bf16(v[1]);
-                        v[2] = bf16lo(r[1]) + round_bf16(v[2]); v[3] = bf16hi(r[1]) + round_bf16(v[3]);
+                        v[0] = A16::lo(r[0]) + A16::rnd(v[0]); v[1] = A16::hi(r[0]) + A16::rnd(v[1]);
+                        v[2] = A16::lo(r[1]) + A16::rnd(v[2]); v[3] = A16::hi(r[1]) + A16::rnd(v[3]);
                     }
-                    *reinterpret_cast<u32x2*>(a.out + o) = u32x2{pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3])};
+                    *reinterpret_cast<u32x2*>(a.out + o) = u32x2{A16::pack(v[0], v[1]), A16::pack(v[2], v[3])};
                 } else {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         if (col + e >= a.N) break;
-                        float x = v[e] + (a.bias ? bf16_to_f32(a.bias[col + e]) : 0.f);
+                        float x = v[e] + (a.bias ? A16::val(a.bias[col + e]) : 0.f);
                         if (a.relu) x = fmaxf(x, 0.f);
-                        if (a.gate) x = bf16_to_f32(a.resid[o + e]) + x * bf16_to_f32(a.gate[col + e]);
-                        else if (a.resid) x = bf16_to_f32(a.resid[o + e]) + round_bf16(x);
-                        a.out[o + e] = f32_to_bf16(x);
+                        if (a.gate) x = A16::val(a.resid[o + e]) + x * A16::val(a.gate[col + e]);
+                        else if (a.resid) x = A16::val(a.resid[o + e]) + A16::rnd(x);
+                        a.out[o + e] = A16::bits(x);
                     }
                 }
             }
@@ -944,6 +952,9 @@ int ensure_attr() {
         OMX_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_bf16_nt_256_kernel<16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big::SMEM));
         OMX_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_bf16_nt_256_kernel<16, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big::SMEM));
         OMX_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_bf16_nt_256_kernel<16, false, false, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, big::smem_bytes(128)));
+        OMX_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_bf16_nt_256_kernel<16, false, false, 128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big::smem_bytes(128)));
+        OMX_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_bf16_nt_256_kernel<16, false, false, 256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big::SMEM));
+        OMX_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_bf16_nt_256_kernel<16, true, false, 256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big::SMEM));
         OMX_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_bf16_nt_skinny_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * skinny::STAGE));
         OMX_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_bf16_nt_skinny_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * skinny::STAGE));
         OMX_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_bf16_nt_skinny_kernel<8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * skinny::STAGE));
@@ -1048,6 +1059,10 @@ int ring_splits(int blocks, int nt) {
 // chain: 48 such blocks fit the CUs the img grid leaves idle, 384 tiles of 64^2 queue behind its workgroups)
 static thread_local int g_tile_hint = 0;
 void gemm_tile_hint(int rows) { g_tile_hint = rows; }
+// float16 operands / results for this thread's next GEMMs (a float16 checkpoint's prompt pass, engine.hip): the eight-wave kernel's
+// float16 instantiations serve every shape (plain: 256- or 128-row tiles; segmented: 256-row tiles)
+static thread_local bool g_gemm_f16 = false;
+void gemm_set_f16(bool on) { g_gemm_f16 = on; }
 
 static int launch_gemm_impl(bf16_t* out, const bf16_t* x, const bf16_t* w, const bf16_t* bias, const bf16_t* resid,
                             const bf16_t* gate, int M, int N, int K, hipStream_t s, int relu = 0) {
@@ -1060,6 +1075,22 @@ static int launch_gemm_impl(bf16_t* out, const bf16_t* x, const bf16_t* w, const
         const bool rows_off = re && re[0] == '0';
         if (!rows_off && M <= 8 && (int64_t)N * K >= (1 << 20) && gemv_rows_supported(M, N, K, x, w))
             return launch_gemv_rows(out, x, w, bias, resid, gate, M, N, K, relu, s);
+    }
+    if (g_gemm_f16) {
+        OMX_REQUIRE(fast && M > 8, "float16 gemm: K %% 64 == 0, 16-byte aligned operands and more than 8 rows expected (M=%d K=%d)", M, K);
+        if (ensure_attr()) return 1;
+        const int t256 = ((M + 255) / 256) * ((N + 255) / 256);
+        if (t256 <= 128) {   // at most half of the chip in 256^2 tiles: 128 x 256
+            a.grid_m = (M + 127) / 128;
+            a.grid_n = (N + 255) / 256;
+            gemm_bf16_nt_256_kernel<16, false, false, 128, true><<<a.grid_m * a.grid_n, big::NT, big::smem_bytes(128), s>>>(a);
+        } else {
+            a.grid_m = (M + 255) / 256;
+            a.grid_n = (N + 255) / 256;
+            gemm_bf16_nt_256_kernel<16, false, false, 256, true><<<a.grid_m * a.grid_n, big::NT, big::SMEM, s>>>(a);
+        }
+        OMX_LAUNCH_CHECK();
+        return 0;
     }
     if (fast) {
         if (ensure_attr()) return 1;
@@ -1167,13 +1198,13 @@ int launch_gemm_bf16_segmented(const bf16_t* x, int M, int K, const GemmSegs& se
         align |= reinterpret_cast<uintptr_t>(segs.w_gate) | reinterpret_cast<uintptr_t>(segs.w_up);
     }
     OMX_REQUIRE((align & 15u) == 0, "segmented gemm: operands must be 16-byte aligned");
-    if (rows_route(M, K, segs)) return launch_gemv_rows_segmented(x, M, K, segs, s);
+    if (!g_gemm_f16 && rows_route(M, K, segs)) return launch_gemv_rows_segmented(x, M, K, segs, s);
     OMX_REQUIRE(!segs.pre_norm_w, "segmented gemm: an in-launch RMSNorm exists on the weight-streaming route only (gemv_rows_takes_norm)");
     if (ensure_attr()) return 1;
     GemmArgs a = {};
     a.x = x; a.M = M; a.K = K;
     a.sg = segs;
-    if (((M + 255) / 256) * seg_tiles(segs) < 160) {   // small problem, plain segments: one grid of 64^2 ring-kernel tiles
+    if (!g_gemm_f16 && ((M + 255) / 256) * seg_tiles(segs) < 160) {   // small problem, plain segments: one grid of 64^2 ring-kernel tiles
         int t64 = 0, n64 = 0;
         for (int i = 0; i < segs.n_plain; ++i) {
             a.sg.plain[i].tile0 = t64;
@@ -1201,6 +1232,8 @@ int launch_gemm_bf16_segmented(const bf16_t* x, int M, int K, const GemmSegs& se
     a.N = n + 2 * segs.half;
     a.grid_m = (M + 255) / 256;
     a.grid_n = seg_tiles(segs);
+    if (g_gemm_f16) gemm_bf16_nt_256_kernel<16, true, false, 256, true><<<a.grid_m * a.grid_n, big::NT, big::SMEM, s>>>(a);
+    else
     gemm_bf16_nt_256_kernel<16, true><<<a.grid_m * a.grid_n, big::NT, big::SMEM, s>>>(a);
     OMX_LAUNCH_CHECK();
     return 0;

@@ -238,9 +238,16 @@ int omx_linear(void* out, const void* x, const void* w, const void* bias, int M,
                omx_stream stream) {
     OMX_REQUIRE(out && x && w, "omx_linear: null tensor");
     OMX_REQUIRE(M >= 0 && N > 0 && K > 0, "omx_linear: bad shape M=%d N=%d K=%d", M, N, K);
-    OMX_REQUIRE(dtype == OMX_BFLOAT16 || dtype == OMX_FLOAT32, "omx_linear: bfloat16 and float32 are implemented (got dtype %d)", (int)dtype);
+    OMX_REQUIRE(dtype == OMX_BFLOAT16 || dtype == OMX_FLOAT32 || dtype == OMX_FLOAT16, "omx_linear: bfloat16, float16 and float32 are implemented (got dtype %d)", (int)dtype);
     if (M == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
+    if (dtype == OMX_FLOAT16) {   // the eight-wave kernel's float16 form (round 4): float16 operands, f32 accumulation, one rounding to float16
+        OMX_REQUIRE(M > 8 && K % 64 == 0, "omx_linear: float16 takes more than 8 rows and K %% 64 == 0 (M=%d K=%d)", M, K);
+        omx::gemm_set_f16(true);
+        const int rc = omx::launch_gemm_bf16((omx::bf16_t*)out, (const omx::bf16_t*)x, (const omx::bf16_t*)w, (const omx::bf16_t*)bias, M, N, K, s);
+        omx::gemm_set_f16(false);
+        return rc;
+    }
     if (dtype == OMX_FLOAT32) {   // exact-f32 matrix cores (gemm_f32.hip): the Paraformer path's dtype
         omx::GemmF32 g = {(const float*)x, (const float*)w, (const float*)bias, nullptr, (float*)out, M, N, K, K, K, N, 0, 0, 0, 0, 1, 0, 0, 1.0f};
         return omx::launch_gemm_f32(g, s);

@@ -122,6 +122,24 @@ def test_linear_gemm_128_row_tile_is_bit_identical_to_the_256_tile(omx, monkeypa
     np.testing.assert_array_equal(omx.ops.linear(T.from_numpy(eye), T.from_numpy(wa)).numpy(), wa.T[: min(M, K)])
 
 
+@pytest.mark.parametrize("M,N,K", [(300, 520, 128), (128, 256, 64), (1000, 1100, 1024), (2048, 4096, 512)])
+def test_linear_gemm_in_float16(omx, M, N, K):
+    """Round 4: the eight-wave kernel with float16 operands (v_mfma_f32_16x16x32_f16 on the same LDS fragments; bias added and the
+    result rounded in float16) -- what a float16 checkpoint's prompt pass multiplies with.  Exact float16 products accumulated in f32:
+    against numpy's f32 matmul of the same float16 values, one float16 rounding apart; transpose-detecting identity check."""
+    T = omx.ops.Tensor
+    x = rand((M, K), 71).astype(np.float16)
+    w = (rand((N, K), 72) * 0.05).astype(np.float16)
+    b = rand((N,), 73).astype(np.float16)
+    got = omx.ops.linear(T.from_numpy(x, "f16"), T.from_numpy(w, "f16"), T.from_numpy(b, "f16")).numpy().astype(np.float32)
+    ref = (x.astype(np.float32) @ w.astype(np.float32).T + b.astype(np.float32)).astype(np.float16).astype(np.float32)
+    np.testing.assert_allclose(got, ref, rtol=2.0 ** -10, atol=2e-5 * np.sqrt(K))
+    assert np.mean(got == ref) > 0.98          # (f32 summation order: a few results land on the other side of a float16 rounding)
+    eye = np.eye(K, dtype=np.float16)[: min(M, K)]
+    wa = ((np.arange(N * K).reshape(N, K) % 251 - 125).astype(np.float32) / 64).astype(np.float16)
+    np.testing.assert_array_equal(omx.ops.linear(T.from_numpy(eye, "f16"), T.from_numpy(wa, "f16")).numpy(), wa.T[: min(M, K)])
+
+
 @pytest.mark.parametrize("M,N,K", [
     (64, 64, 64),            # one tile, one K step: nothing in flight behind it
     (501, 512, 512),         # Paraformer attention projections: 8-stage ring holds the whole contraction

@@ -1057,11 +1057,26 @@ __global__ void encoder_mask_kernel(bf16_t* mask, const uint8_t* am, int T) {
     }
 }
 
+// out [T, H * D] = in [H, T, D] (16-bit elements): the attention output of the explicit SDPA form, token-major for the O projection
+__global__ void heads_to_tokens_kernel(bf16_t* __restrict__ out, const bf16_t* __restrict__ in, int H, int T, int D) {
+    const int vpr = D / 8;
+    const int64_t n = (int64_t)H * T * vpr;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int v = (int)(i % vpr), t = (int)((i / vpr) % T), h = (int)(i / ((int64_t)vpr * T));
+        reinterpret_cast<u32x4*>(out)[((int64_t)t * H + h) * vpr + v] = reinterpret_cast<const u32x4*>(in)[i];
+    }
+}
+
 int prefill_prefix_batched(omx_qwen3 m, int T, int off, const EncodeOpts* enc = nullptr, bool full_last = false) {
     const omx_qwen3_config& c = m->cfg;
-    // the matrix-core pass is bfloat16: float16 checkpoints take their prompts through the decode step (omx_qwen3_prefill) and have
-    // no batched encode / verify
-    OMX_REQUIRE(!c.quant_scales_f16, "batched prompt pass: not available for float16 checkpoints (their prompts run through the decode step)");
+    // float16 checkpoints (round 4): the same pass in float16 -- weights dequantised to float16, the eight-wave GEMM kernel's float16
+    // form, float16 norms / RoPE / slabs, attention through the explicit float32 form of omx_sdpa (one rounding of its output) -- for
+    // plain prompts of a dense single-rank model; encode / verify and the sharded forms stay bfloat16-only
+    const bool f16 = c.quant_scales_f16 != 0;
+    OMX_REQUIRE(!f16 || (!enc && m->allreduce == nullptr && c.num_experts == 0 && T > 8),
+                "batched prompt pass in float16: plain prompts of more than 8 tokens on a dense single-rank model only");
+    struct GemmF16Scope { bool on; explicit GemmF16Scope(bool o) : on(o) { if (on) gemm_set_f16(true); } ~GemmF16Scope() { if (on) gemm_set_f16(false); } } f16_scope(f16);
+    const omx_dtype act_dt = f16 ? OMX_FLOAT16 : OMX_BFLOAT16;
     hipStream_t s = m->stream;
     const int hd = c.hidden_size, D = c.head_dim, H = m->H, Hkv = m->Hkv, I = m->I;
     if (T > m->pf_cap) {
@@ -1091,7 +1106,7 @@ int prefill_prefix_batched(omx_qwen3 m, int T, int off, const EncodeOpts* enc = 
     // `at`: element offset inside the scratch, so that the members of one segmented launch (q | k | v, gate | up) coexist
     auto W = [&](const bf16_t* dense, const QMat* qm, int K, size_t at = 0) -> const bf16_t* {
         if (!quant) return dense;
-        if (launch_dequantize_bf16(m->dq_buf + at, qm->w, qm->scales, qm->biases, qm->n, K, c.quant_group, c.quant_bits, c.quant_scales_f16 != 0, s)) return nullptr;
+        if (launch_dequantize_bf16(m->dq_buf + at, qm->w, qm->scales, qm->biases, qm->n, K, c.quant_group, c.quant_bits, f16, s, f16)) return nullptr;
         return m->dq_buf + at;
     };
     if (quant) {
@@ -1111,7 +1126,7 @@ int prefill_prefix_batched(omx_qwen3 m, int T, int off, const EncodeOpts* enc = 
         if (omx_take_rows(rows_w, m->q_embed.w, m->prompt_dev, T, wpr, OMX_FLOAT32, s)) return 1;
         if (omx_take_rows(rows_s, m->q_embed.scales, m->prompt_dev, T, gpr, OMX_BFLOAT16, s)) return 1;
         if (omx_take_rows(rows_b, m->q_embed.biases, m->prompt_dev, T, gpr, OMX_BFLOAT16, s)) return 1;
-        if (launch_dequantize_bf16(m->pf_h, (const uint32_t*)rows_w, rows_s, rows_b, T, hd, c.quant_group, c.quant_bits, c.quant_scales_f16 != 0, s)) return 1;
+        if (launch_dequantize_bf16(m->pf_h, (const uint32_t*)rows_w, rows_s, rows_b, T, hd, c.quant_group, c.quant_bits, f16, s, f16)) return 1;
     } else if (omx_take_rows(m->pf_h, m->embed, m->prompt_dev, T, hd, OMX_BFLOAT16, s)) {
         return 1;
     }
@@ -1135,10 +1150,10 @@ int prefill_prefix_batched(omx_qwen3 m, int T, int off, const EncodeOpts* enc = 
         qkv.plain[1] = {L.k, L.k_bias, m->pf_k, Hkv * D, Hkv * D, 0};
         qkv.plain[2] = {L.v, L.v_bias, m->pf_v, Hkv * D, Hkv * D, 0};
         // (a handful of rows: the weight-streaming launch normalises its staged copy of the rows itself -- no RMSNorm launch)
-        const bool qkv_norm = seg_gemm && gemm_segmented_preferred(T, hd, qkv) && gemv_rows_takes_norm(T, hd, qkv);
-        if (!qkv_norm && omx_rms_norm(m->pf_xn, h, L.in_ln, T, hd, c.rms_norm_eps, OMX_BFLOAT16, s)) return 1;
+        const bool qkv_norm = !f16 && seg_gemm && gemm_segmented_preferred(T, hd, qkv) && gemv_rows_takes_norm(T, hd, qkv);
+        if (!qkv_norm && omx_rms_norm(m->pf_xn, h, L.in_ln, T, hd, c.rms_norm_eps, act_dt, s)) return 1;
         if (qkv_norm) { qkv.pre_norm_w = L.in_ln; qkv.pre_norm_eps = c.rms_norm_eps; }
-        if (seg_gemm && gemm_segmented_preferred(T, hd, qkv)) {
+        if (f16 || (seg_gemm && gemm_segmented_preferred(T, hd, qkv))) {   // (float16: always the segmented 256-row kernel)
             if (quant) {   // the three dequantised matrices side by side in the scratch
                 const size_t nq = (size_t)H * D * hd, nk = (size_t)Hkv * D * hd;
                 if (!(qkv.plain[0].w = W(nullptr, &Q.q, hd, 0)) || !(qkv.plain[1].w = W(nullptr, &Q.k, hd, nq)) ||
@@ -1152,10 +1167,19 @@ int prefill_prefix_batched(omx_qwen3 m, int T, int off, const EncodeOpts* enc = 
             if (!(w = W(L.v, &Q.v, hd)) || launch_gemm_bf16(m->pf_v, m->pf_xn, w, L.v_bias, T, Hkv * D, hd, s)) return 1;
         }
         if (launch_qk_norm_rope_scatter(m->pf_q, m->pf_k, m->pf_v, L.q_norm, L.k_norm, m->rope_cos, m->rope_sin, m->pf_qt,
-                                        m->kcache[l], m->vcache[l], T, H, Hkv, D, m->cap, off, c.rms_norm_eps, s))
+                                        m->kcache[l], m->vcache[l], T, H, Hkv, D, m->cap, off, c.rms_norm_eps, s, f16))
             return 1;
         if (!enc && !full_last && l == c.num_hidden_layers - 1) break;   // a prefix only has to leave its K/V rows behind
         const char* skv_env = getenv("OMX_PREFILL_SPLITKV");
+        if (f16) {
+            // float16: MLX's fast SDPA accumulates in float32 and rounds its output once -- the explicit form of omx_sdpa on widened copies
+            // (q [H, T, D], K / V straight from the slabs, causal bottom-right aligned), then heads back next to each other per token
+            if (omx_sdpa(m->pf_q, m->pf_qt, m->kcache[l], m->vcache[l], 1, H, Hkv, T, off + T, D, 0, (int64_t)m->cap * D, scale, OMX_MASK_CAUSAL,
+                         nullptr, OMX_FLOAT16, s))
+                return 1;
+            heads_to_tokens_kernel<<<1024, 256, 0, s>>>(m->pf_attn, m->pf_q, H, T, D);
+            OMX_LAUNCH_CHECK();
+        } else
         if (!enc && T <= 8 && H / Hkv <= 8 && !(skv_env && skv_env[0] == '0')) {
             // a handful of new rows over a long cache (speculative verify, a short follow-up prompt): the flash kernel gives them
             // H * ceil(T / 64) blocks that each walk all keys (53 us per layer for 5 rows at 2 k of context); the split-KV decode
@@ -1180,8 +1204,8 @@ int prefill_prefix_batched(omx_qwen3 m, int T, int off, const EncodeOpts* enc = 
         if (!(w = W(L.o, &Q.o, H * D)) || row_split(h2, m->pf_attn, w, h, H * D)) return 1;
         GemmSegs gu = {};
         gu.w_gate = L.gate; gu.w_up = L.up; gu.out_act = m->pf_g; gu.half = I; gu.ld_act = I; gu.act_mode = 1;
-        const bool gu_norm = c.num_experts == 0 && seg_gemm && gemm_segmented_preferred(T, hd, gu) && gemv_rows_takes_norm(T, hd, gu);
-        if (!gu_norm && omx_rms_norm(m->pf_xn, h2, L.post_ln, T, hd, c.rms_norm_eps, OMX_BFLOAT16, s)) return 1;
+        const bool gu_norm = !f16 && c.num_experts == 0 && seg_gemm && gemm_segmented_preferred(T, hd, gu) && gemv_rows_takes_norm(T, hd, gu);
+        if (!gu_norm && omx_rms_norm(m->pf_xn, h2, L.post_ln, T, hd, c.rms_norm_eps, act_dt, s)) return 1;
         if (gu_norm) { gu.pre_norm_w = L.post_ln; gu.pre_norm_eps = c.rms_norm_eps; }
         if (c.num_experts > 0) {   // sparse-MoE feed-forward over all T rows (grouped MFMA GEMM route), then the residual
             if (quant) {
@@ -1253,7 +1277,7 @@ int prefill_prefix_batched(omx_qwen3 m, int T, int off, const EncodeOpts* enc = 
         }
         // gate, up and nn::silu(gate) * up: one launch with the activation in the epilogue (768 tiles = 3 full rounds at
         // T = 2048 instead of 2 x 384), else two GEMMs + the elementwise kernel
-        if (seg_gemm && gemm_segmented_preferred(T, hd, gu)) {
+        if (f16 || (seg_gemm && gemm_segmented_preferred(T, hd, gu))) {
             if (quant && (!(gu.w_gate = W(nullptr, &Q.gate, hd, 0)) || !(gu.w_up = W(nullptr, &Q.up, hd, (size_t)I * hd)))) return 1;
             if (launch_gemm_bf16_segmented(gu_norm ? h2 : m->pf_xn, T, hd, gu, s)) return 1;
         } else {
@@ -1739,7 +1763,10 @@ int omx_qwen3_prefill(omx_qwen3 m, const uint32_t* prompt, int n_prompt, uint32_
     const char* serial_env = getenv("OMX_PREFILL_SERIAL");
     // tensor-parallel engines run the batched matrix-core prefill on their shards with two all-reduces per layer, expert-parallel ones
     // with one all-reduce of the MoE block's [T, hidden] partial per layer (round 3; token-serial before)
-    const bool serial = (serial_env && serial_env[0] == '1') || n_prompt < 2 || m->cfg.quant_scales_f16;   // (float16 models: the decode form only)
+    // (float16 models: the batched pass exists for plain prompts of a dense single-rank model; short ones and the sharded / MoE forms
+    //  go through the decode step)
+    const bool f16_serial = m->cfg.quant_scales_f16 && (n_prompt <= 16 || m->allreduce != nullptr || m->cfg.num_experts > 0);
+    const bool serial = (serial_env && serial_env[0] == '1') || n_prompt < 2 || f16_serial;
     if (prepare_step(m, serial ? off : off + n_prompt - 1)) return 1;   // the first step this call will run (graphs are per context bucket)
     OMX_HIP_CHECK(hipMemcpyAsync(m->prompt_dev, prompt, (size_t)n_prompt * 4, hipMemcpyHostToDevice, m->stream));
     StepState st;

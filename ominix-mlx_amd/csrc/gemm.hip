@@ -1073,7 +1073,7 @@ static int launch_gemm_impl(bf16_t* out, const bf16_t* x, const bf16_t* w, const
         // OMX_GEMV_ROWS=0 keeps the GEMM kernels
         const char* re = getenv("OMX_GEMV_ROWS");
         const bool rows_off = re && re[0] == '0';
-        if (!rows_off && M <= 8 && (int64_t)N * K >= (1 << 20) && gemv_rows_supported(M, N, K, x, w))
+        if (!g_gemm_f16 && !rows_off && M <= 8 && (int64_t)N * K >= (1 << 20) && gemv_rows_supported(M, N, K, x, w))
             return launch_gemv_rows(out, x, w, bias, resid, gate, M, N, K, relu, s);
     }
     if (g_gemm_f16) {

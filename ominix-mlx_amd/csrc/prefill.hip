@@ -1,6 +1,7 @@
 // Glue kernels of the batched (T > 1) prefill step of the decode engine; each fuses what the
 // reference issues as several lazy ops.
 #include "prefill.hpp"
+#include "act16.hpp"
 
 namespace omx {
 namespace {
@@ -9,12 +10,14 @@ namespace {
 // (the [B,H,T,D] operand of SDPA); k rows: same, written straight into the KV slab at offset+t
 // (KVCache::update_and_fetch, cache.rs:183-188); v rows: copied into the slab.
 //   reference: qwen3-mlx/src/model.rs:172-196 (reshape/transpose, q_norm/k_norm, rope, cache update).
-template <int D>
+// F16: a float16 model (float16 rows, norm weights, cache slabs and rounding points: act16.hpp)
+template <int D, bool F16 = false>
 __global__ __launch_bounds__(256) void qk_norm_rope_scatter_kernel(
     const bf16_t* __restrict__ q_lin, const bf16_t* __restrict__ k_lin, const bf16_t* __restrict__ v_lin,
     const bf16_t* __restrict__ q_norm_w, const bf16_t* __restrict__ k_norm_w, const float* __restrict__ rope_cos,
     const float* __restrict__ rope_sin, bf16_t* __restrict__ q_out, bf16_t* __restrict__ kcache,
     bf16_t* __restrict__ vcache, int T, int H, int Hkv, int cap, int offset, float eps) {
+    typedef Act16<F16> A16;
     constexpr int LPR = D / 8;
     const int lane = threadIdx.x & 63;
     const int c = lane % LPR;
@@ -34,12 +37,12 @@ __global__ __launch_bounds__(256) void qk_norm_rope_scatter_kernel(
     const bf16_t* src = is_q ? q_lin + ((size_t)t * H + hh) * D : k_lin + ((size_t)t * Hkv + (hh - H)) * D;
     const bf16_t* w = is_q ? q_norm_w : k_norm_w;
     const u32x4 r = *reinterpret_cast<const u32x4*>(src + c * 8);
-    const u32x4 wr = w ? *reinterpret_cast<const u32x4*>(w + c * 8) : u32x4{0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};   // no q/k norm (Mixtral): weight 1
+    const u32x4 wr = w ? *reinterpret_cast<const u32x4*>(w + c * 8) : (F16 ? u32x4{0x3C003C00u, 0x3C003C00u, 0x3C003C00u, 0x3C003C00u} : u32x4{0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u});   // no q/k norm (Mixtral): weight 1
     float x[8], wv[8];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-        x[2 * e] = bf16lo(r[e]); x[2 * e + 1] = bf16hi(r[e]);
-        wv[2 * e] = bf16lo(wr[e]); wv[2 * e + 1] = bf16hi(wr[e]);
+        x[2 * e] = A16::lo(r[e]); x[2 * e + 1] = A16::hi(r[e]);
+        wv[2 * e] = A16::lo(wr[e]); wv[2 * e + 1] = A16::hi(wr[e]);
     }
     float ss = 0.f;
 #pragma unroll
@@ -51,7 +54,7 @@ __global__ __launch_bounds__(256) void qk_norm_rope_scatter_kernel(
     float y[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-        const float xn = round_bf16(x[e] * rstd * wv[e]);
+        const float xn = A16::rnd(x[e] * rstd * wv[e]);
         // partner element i +- D/2 lives in lane c ^ (LPR/2)
         const float other = (LPR == 16) ? dpp_f<0x128>(xn) : dpp_f<0x1B>(dpp_f<kDppHalfMirror>(xn));
         const float cs = rope_cos[(size_t)pos * (D / 2) + i0 + e], sn = rope_sin[(size_t)pos * (D / 2) + i0 + e];
@@ -59,7 +62,7 @@ __global__ __launch_bounds__(256) void qk_norm_rope_scatter_kernel(
     }
     u32x4 o;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) o[e] = pack_bf16(y[2 * e], y[2 * e + 1]);
+    for (int e = 0; e < 4; ++e) o[e] = A16::pack(y[2 * e], y[2 * e + 1]);
     bf16_t* dst = is_q ? q_out + ((size_t)hh * T + t) * D : kcache + ((size_t)(hh - H) * cap + pos) * D;
     *reinterpret_cast<u32x4*>(dst + c * 8) = o;
 }
@@ -92,11 +95,16 @@ __global__ __launch_bounds__(256) void silu_mul_kernel(bf16_t* __restrict__ out,
 int launch_qk_norm_rope_scatter(const bf16_t* q_lin, const bf16_t* k_lin, const bf16_t* v_lin, const bf16_t* q_norm_w,
                                 const bf16_t* k_norm_w, const float* rope_cos, const float* rope_sin, bf16_t* q_out,
                                 bf16_t* kcache, bf16_t* vcache, int T, int H, int Hkv, int D, int cap, int offset,
-                                float eps, hipStream_t s) {
+                                float eps, hipStream_t s, bool f16) {
     OMX_REQUIRE(D == 64 || D == 128, "qk_norm_rope: head_dim %d unsupported", D);
     const int64_t rows = (int64_t)T * (H + 2 * Hkv);
     const int rpb = 256 / (D / 8);
     const unsigned blocks = (unsigned)((rows + rpb - 1) / rpb);
+    if (f16) {
+        OMX_REQUIRE(D == 128, "qk_norm_rope: float16 models have head_dim 128");
+        qk_norm_rope_scatter_kernel<128, true><<<blocks, 256, 0, s>>>(q_lin, k_lin, v_lin, q_norm_w, k_norm_w, rope_cos, rope_sin,
+                                                                      q_out, kcache, vcache, T, H, Hkv, cap, offset, eps);
+    } else
     if (D == 128)
         qk_norm_rope_scatter_kernel<128><<<blocks, 256, 0, s>>>(q_lin, k_lin, v_lin, q_norm_w, k_norm_w, rope_cos, rope_sin,
                                                                 q_out, kcache, vcache, T, H, Hkv, cap, offset, eps);

@@ -592,8 +592,8 @@ static int launch_dequantize_any(void* out, const uint32_t* packed, const void* 
     return 0;
 }
 int omx::launch_dequantize_bf16(bf16_t* out, const uint32_t* packed, const void* scales, const void* biases, int64_t rows, int cols,
-                                int group_size, int bits, bool scales_f16, hipStream_t s) {
-    return launch_dequantize_any(out, packed, scales, biases, rows, cols, group_size, bits, scales_f16, false, s);
+                                int group_size, int bits, bool scales_f16, hipStream_t s, bool out_f16) {
+    return launch_dequantize_any(out, packed, scales, biases, rows, cols, group_size, bits, scales_f16, out_f16, s);
 }
 
 /* mlx_rs::ops::dequantize (ops/quantization.rs:118-153): the result has the dtype of scales / biases -- OMX_BFLOAT16, or OMX_FLOAT16 for

@@ -46,7 +46,7 @@ struct QGemvArgs {
 };
 // packed [rows, cols*bits/32] -> bf16 [rows, cols]; scales_f16: scales / biases are float16 (engine-internal form of omx_dequantize)
 int launch_dequantize_bf16(bf16_t* out, const uint32_t* packed, const void* scales, const void* biases, int64_t rows, int cols, int group_size,
-                           int bits, bool scales_f16, hipStream_t s);
+                           int bits, bool scales_f16, hipStream_t s, bool out_f16 = false);   // out_f16: the result in float16 (a float16 model's prompt pass)
 
 int launch_qgemv(const QGemvArgs& a, int bits, int pro, int epi, hipStream_t s);
 int qgemv_grid(int N);          // blocks launch_qgemv uses == argmax partials written

@@ -464,8 +464,10 @@ def test_quantized_checkpoint_decode_matches_oracle(omx, name, bits, group):
             break
 
 
-def test_quantized_checkpoint_with_float16_scales(omx, tmp_path):
-    """A float16 MLX checkpoint carries float16 scales / biases and norm weights (mlx quantize() works in the model's dtype), and MLX
+@pytest.mark.parametrize("serial_prefill", ["0", "1"])
+def test_quantized_checkpoint_with_float16_scales(omx, tmp_path, monkeypatch, serial_prefill):
+    """(serial_prefill 0: the 48-token prompt takes the float16 matrix-core pass, 1: the decode step token by token.)
+    A float16 MLX checkpoint carries float16 scales / biases and norm weights (mlx quantize() works in the model's dtype), and MLX
     runs it in float16 END TO END (nn/quantized.rs:361-385: the dequantised weight has the scales' dtype, the matmul its inputs').
     So does the engine since round 4: embedding rows dequantised to float16, float16 RMSNorm / RoPE / residual roundings, float16 K / V
     slabs and logits, f32 accumulation (csrc/act16.hpp Act16<true> in quant.hip, attn_step.hip, engine.hip; the prompt runs through
@@ -483,6 +485,7 @@ def test_quantized_checkpoint_with_float16_scales(omx, tmp_path):
             arr = (s32 if name.endswith(".scales") else b32).astype(np.float16).reshape(arr.shape)
         qw[name] = arr
     n_prompt, n_new = 48, 10
+    monkeypatch.setenv("OMX_PREFILL_SERIAL", serial_prefill)
     prompt = synth.prompt_ids(n_prompt, cfg.vocab_size)
     kw = dict(hidden_size=cfg.hidden_size, num_hidden_layers=cfg.num_hidden_layers, intermediate_size=cfg.intermediate_size,
               num_attention_heads=cfg.num_attention_heads, num_key_value_heads=cfg.num_key_value_heads, head_dim=cfg.head_dim,
@@ -515,6 +518,62 @@ def test_quantized_checkpoint_with_float16_scales(omx, tmp_path):
     with pytest.raises(omx.OmxError, match="float16 scales / biases, but the model was created"):
         m2.load_weights(qw)
     m2.close()
+
+
+def test_float16_checkpoint_batched_prompt_pass(omx, monkeypatch):
+    """Round 4: a float16 checkpoint's prompt in ONE matrix-core pass (engine.hip prefill_prefix_batched with f16: weights dequantised
+    to float16, the eight-wave GEMM kernel's float16 instantiations with the SwiGLU / residual epilogues rounding to float16, float16
+    norm + RoPE + slab scatter, attention in float32 on widened copies with one rounding) instead of one decode step per token.  A
+    300-token prompt (two 256-row tiles, a ragged second one) plus a 40-token follow-up on top of the cache: first-token logits within
+    the float16 bound of the float16 oracle AND of the token-serial pass, layer-1 keys equal to float16 rounding, same tokens after."""
+    from ominix_mlx_amd import engine
+    cfg, bits, group = CONFIGS["gqa4_d128"], 4, 64
+    base = rq.synth_weights(cfg)
+    qw = {}
+    for name, arr in rq.quantize_weights(cfg, base, bits, group).items():
+        if name.endswith((".scales", ".biases")):
+            prefix = name.rsplit(".", 1)[0]
+            w2 = base[prefix + ".weight"].reshape(-1, base[prefix + ".weight"].shape[-1])
+            _, s32, b32 = rc.quantize(w2, group, bits)
+            arr = (s32 if name.endswith(".scales") else b32).astype(np.float16).reshape(arr.shape)
+        qw[name] = arr
+    n1, n2, n_new = 300, 40, 6
+    prompt = synth.prompt_ids(n1 + n2, cfg.vocab_size)
+    kw = dict(hidden_size=cfg.hidden_size, num_hidden_layers=cfg.num_hidden_layers, intermediate_size=cfg.intermediate_size,
+              num_attention_heads=cfg.num_attention_heads, num_key_value_heads=cfg.num_key_value_heads, head_dim=cfg.head_dim,
+              vocab_size=cfg.vocab_size, rms_norm_eps=cfg.rms_norm_eps, rope_theta=cfg.rope_theta,
+              tie_word_embeddings=cfg.tie_word_embeddings, rope_scaling=cfg.rope_scaling, max_context=512)
+    runs = {}
+    for serial in ("0", "1"):
+        monkeypatch.setenv("OMX_PREFILL_SERIAL", serial)
+        m = engine.Model(quantization={"bits": bits, "group_size": group, "scales_dtype": "float16"}, **kw)
+        m.load_weights(qw)
+        first = m.prefill(prompt[:n1])
+        logits1 = m.last_logits()
+        n = cfg.num_key_value_heads * 512 * cfg.head_dim
+        raw = np.empty(n, np.uint16)
+        omx.check(omx.lib.omx_qwen3_debug_read(m._h, b"k1", raw.ctypes.data, n))
+        raw = raw.view(np.float16).astype(np.float32).reshape(cfg.num_key_value_heads, 512, cfg.head_dim)[:, :n1]
+        m.prefill(prompt[n1:])              # (the first call's sampled token is replaced by the follow-up prompt, as in a chat turn)
+        logits2 = m.last_logits()
+        toks = m.decode(n_new)
+        runs[serial] = (first, logits1, logits2, toks, raw, m.last_prefill_ms())
+        m.close()
+    f16w = {k: (v.astype(np.float32) if v.dtype == np.float16 else v) for k, v in qw.items()}
+    oracle = rq.Qwen3Oracle(cfg, f16w, dt="f16", quant=(bits, group))
+    _, ref1 = oracle.generate(prompt[:n1], 1, return_logits=True)
+    _, ref2 = oracle.generate(prompt, 1, return_logits=True)
+    for ref, idx in ((ref1, 1), (ref2, 2)):
+        bound = 2.0 ** -10 * np.abs(ref).max() * np.sqrt(2 * cfg.num_hidden_layers)
+        for serial in ("0", "1"):
+            assert np.abs(runs[serial][idx] - ref[0]).max() <= bound, (serial, idx)
+        assert np.abs(runs["0"][idx] - runs["1"][idx]).max() <= bound
+    # layer-1 keys depend on layer 0's whole block (GEMMs, attention, SwiGLU): the two passes agree to float16 rounding
+    assert np.abs(runs["0"][4] - runs["1"][4]).max() <= 2.0 ** -9 * np.abs(runs["1"][4]).max()
+    bound1 = 2.0 ** -10 * np.abs(ref1).max() * np.sqrt(2 * cfg.num_hidden_layers)
+    if runs["0"][0] != runs["1"][0]:
+        assert rc.argmax_margin(ref1)[0] <= 2 * bound1
+    print(f"float16 prompt of {n1} tokens: batched {runs['0'][5]:.2f} ms, token-serial {runs['1'][5]:.2f} ms")
 
 
 def test_float16_checkpoint_tensor_parallel_two_ranks_on_one_gpu(omx):

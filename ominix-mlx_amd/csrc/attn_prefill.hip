@@ -21,6 +21,8 @@
 #include <stdlib.h>
 
 #include "gemm.hpp"
+#include "act16.hpp"
+#include <type_traits>
 #include "gridsync.hpp"
 #include <map>
 #include <mutex>
@@ -68,8 +70,18 @@ __device__ __forceinline__ float quad_rows_sum(float v) {
 // QW = 16-row query sub-tiles per wave (2: a wave owns 32 query rows and every K / V^T fragment read from
 // LDS feeds two MFMAs).  Next tile's K/V are fetched into registers while the current tile is multiplied
 // (issue-early / write-late staging, cdna_hip_programming.md T14).
-template <int D, int QW, int MASK>
+// F16: float16 operands and result (a float16 checkpoint's prompt pass): the same data movement -- every element is 16 bits -- with
+// the float16 MFMA, P rounded to float16 for the second product and the output rounded once to float16.
+template <int D, int QW, int MASK, bool F16 = false>
 __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(const PrefillArgs a) {
+    typedef Act16<F16> A16;
+    using h8 = __attribute__((ext_vector_type(8))) _Float16;
+    typedef typename std::conditional<F16, h8, bf16x8>::type p8;     // P fragments in the operand type
+    typedef typename std::conditional<F16, _Float16, __bf16>::type pe;
+    auto mfma = [](bf16x8 x, p8 y, f32x4v c) {
+        if constexpr (F16) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, x), y, c, 0, 0, 0);
+        else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(x, y, c, 0, 0, 0);
+    };
     constexpr int DC = D / 8;       // 16-B chunks per K row
     constexpr int NI = D / 32;      // MFMA k-steps over the head dim
     constexpr int NDT = D / 16;     // 16-wide output tiles over the head dim
@@ -215,13 +227,13 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(const PrefillArgs 
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-                for (int w = 0; w < QW; ++w) s[w][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[i & 1][kt], qf[w][i], s[w][kt], 0, 0, 0);
+                for (int w = 0; w < QW; ++w) s[w][kt] = mfma(kf[i & 1][kt], __builtin_bit_cast(p8, qf[w][i]), s[w][kt]);
         }
         // ---- online softmax in the base-2 domain: p = 2^(s*c - m), c = scale * log2(e), m = running max of s*c.
         //      (lane: query qcol of each sub-tile, keys kt*16 + rg*4 + r).  Tiles that need no masking -- all keys
         //      valid and, under a causal mask, entirely below every query row of the block -- take a path without
         //      any select; the normaliser sums the fp32 probabilities (P is rounded to bf16 only for the MFMA). ----
-        bf16x8 pf[QW][2];
+        p8 pf[QW][2];
         const float c2 = a.scale * 1.44269504088896340736f;
         bool plain = (k0 + KB <= a.Tk) && (MASK == OMX_MASK_NONE || (MASK == OMX_MASK_CAUSAL && k0 + KB - 1 <= q0 + shift));
         if (plain) {
@@ -245,7 +257,7 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(const PrefillArgs 
                     for (int e = 0; e < 8; ++e) {
                         const float p = __builtin_amdgcn_exp2f(fmaf(s[w][2 * j + (e >> 2)][e & 3], c2, -m_new));
                         l_run[w] += p;
-                        pf[w][j][e] = (__bf16)p;
+                        pf[w][j][e] = (pe)p;
                     }
             }
         } else {
@@ -268,7 +280,7 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(const PrefillArgs 
                             keep = keep & (mb != 0);
                         }
                         if (MASK == OMX_MASK_ADDITIVE)
-                            v += 1.44269504088896340736f * bf16_to_f32(reinterpret_cast<const bf16_t*>(a.mask)[(size_t)qrow_c[w] * a.Tk + min(key, a.Tk - 1)]);
+                            v += 1.44269504088896340736f * A16::val(reinterpret_cast<const bf16_t*>(a.mask)[(size_t)qrow_c[w] * a.Tk + min(key, a.Tk - 1)]);
                         v = keep ? v : -INFINITY;
                         s[w][kt][r] = v;
                         mx = fmaxf(mx, v);
@@ -289,7 +301,7 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(const PrefillArgs 
                         const float p = (m_new == -INFINITY) ? 0.f
                                         : __builtin_amdgcn_exp2f(MASK == OMX_MASK_ADDITIVE ? sv - m_new : fmaf(sv, c2, -m_new));
                         l_run[w] += p;
-                        pf[w][j][e] = (__bf16)p;
+                        pf[w][j][e] = (pe)p;
                     }
             }
         }
@@ -315,7 +327,7 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(const PrefillArgs 
                 if (idx + AHEAD < NF) vf[idx % AHEAD] = read_v(idx + AHEAD);
 #pragma unroll
                 for (int w = 0; w < QW; ++w)
-                    o[w][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, cur), pf[w][j], o[w][t], 0, 0, 0);
+                    o[w][t] = mfma(__builtin_bit_cast(bf16x8, cur), pf[w][j], o[w][t]);
             }
             }
         __builtin_amdgcn_s_waitcnt(0);   // the K tile of the next iteration has landed (vmcnt), our LDS traffic retired (lgkmcnt)
@@ -331,7 +343,7 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(const PrefillArgs 
             bf16_t* op = a.out + (size_t)b * a.o_bs + (size_t)h * a.o_hs + (size_t)qrow[w] * a.o_ts;
 #pragma unroll
             for (int t = 0; t < NDT; ++t) {
-                u32x2v wv = {pack_bf16(o[w][t][0] * inv, o[w][t][1] * inv), pack_bf16(o[w][t][2] * inv, o[w][t][3] * inv)};
+                u32x2v wv = {A16::pack(o[w][t][0] * inv, o[w][t][1] * inv), A16::pack(o[w][t][2] * inv, o[w][t][3] * inv)};
                 *reinterpret_cast<u32x2v*>(op + t * 16 + rg * 4) = wv;
             }
         }
@@ -783,8 +795,10 @@ int sk_cus() {
 
 int launch_attn_prefill(bf16_t* out, const bf16_t* q, const bf16_t* k, const bf16_t* v, int B, int H, int Hkv, int Tq,
                         int Tk, int D, int64_t kv_batch_stride, int64_t kv_head_stride, float scale, int mask_mode,
-                        const void* mask, hipStream_t s, bool out_token_major, const AttnLayout* layout) {
+                        const void* mask, hipStream_t s, bool out_token_major, const AttnLayout* layout, bool f16) {
     OMX_REQUIRE(D == 64 || D == 128, "sdpa prefill: head_dim %d unsupported (64 or 128)", D);
+    // float16 operands (a float16 checkpoint's prompt pass): the single-phase kernel's float16 instantiations
+    OMX_REQUIRE(!f16 || (D == 128 && (mask_mode == OMX_MASK_NONE || mask_mode == OMX_MASK_CAUSAL)), "sdpa prefill in float16: head_dim 128, no mask or causal");
     PrefillArgs a = {q, k, v, out, B, H, Hkv, Tq, Tk, kv_batch_stride, kv_head_stride, scale, mask_mode, mask,
                      (int64_t)H * Tq * D, (int64_t)Tq * D, D, (int64_t)H * Tq * D, (int64_t)Tq * D, D, D};
     if (out_token_major) {   // out[b][t][h][d]: what o_proj consumes after the reference's transpose+reshape (model.rs:211-213)
@@ -804,7 +818,7 @@ int launch_attn_prefill(bf16_t* out, const bf16_t* q, const bf16_t* k, const bf1
     // many rounds deep
     const char* ppenv = getenv("OMX_ATTN_PP");
     const long pp_blocks = (long)((Tq + 255) / 256) * H * B;
-    if (ppenv ? atoi(ppenv) != 0 : (Tq >= 1024 && (mask_mode != OMX_MASK_CAUSAL || pp_blocks >= 2048))) {
+    if (!f16 && (ppenv ? atoi(ppenv) != 0 : (Tq >= 1024 && (mask_mode != OMX_MASK_CAUSAL || pp_blocks >= 2048)))) {
         const dim3 grid((Tq + 255) / 256, H, B), block(512);
         // stream-K form (opt-in, OMX_ATTN_STREAMK=1): no mask, more units than CUs (every share then spans at least one whole unit: a
         // unit is cut at most once); one block per CU (a piece never waits for another: no co-residency needed).  Measured SLOWER where
@@ -843,6 +857,16 @@ int launch_attn_prefill(bf16_t* out, const bf16_t* q, const bf16_t* k, const bf1
     const bool wide = wenv ? atoi(wenv) != 0 : Tq >= 512;
     const int qblk = wide ? 128 : 64;
     const dim3 grid((Tq + qblk - 1) / qblk, H, B), block(256);
+    if (f16) {
+#define OMX_PF16_CASE(QQ, MM)                                                        \
+    if ((wide ? 2 : 1) == QQ && mask_mode == MM) {                                   \
+        attn_prefill_kernel<128, QQ, MM, true><<<grid, block, 0, s>>>(a);            \
+        OMX_LAUNCH_CHECK();                                                          \
+        return 0;                                                                    \
+    }
+        OMX_PF16_CASE(1, OMX_MASK_NONE) OMX_PF16_CASE(1, OMX_MASK_CAUSAL) OMX_PF16_CASE(2, OMX_MASK_NONE) OMX_PF16_CASE(2, OMX_MASK_CAUSAL)
+#undef OMX_PF16_CASE
+    }
 #define OMX_PF_CASE(DD, QQ, MM)                                                      \
     if (D == DD && (wide ? 2 : 1) == QQ && mask_mode == MM) {                        \
         attn_prefill_kernel<DD, QQ, MM><<<grid, block, 0, s>>>(a);                   \

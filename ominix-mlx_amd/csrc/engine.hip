@@ -1070,7 +1070,7 @@ __global__ void heads_to_tokens_kernel(bf16_t* __restrict__ out, const bf16_t* _
 int prefill_prefix_batched(omx_qwen3 m, int T, int off, const EncodeOpts* enc = nullptr, bool full_last = false) {
     const omx_qwen3_config& c = m->cfg;
     // float16 checkpoints (round 4): the same pass in float16 -- weights dequantised to float16, the eight-wave GEMM kernel's float16
-    // form, float16 norms / RoPE / slabs, attention through the explicit float32 form of omx_sdpa (one rounding of its output) -- for
+    // form, float16 norms / RoPE / slabs, the flash attention kernel's float16 form -- for
     // plain prompts of a dense single-rank model; encode / verify and the sharded forms stay bfloat16-only
     const bool f16 = c.quant_scales_f16 != 0;
     OMX_REQUIRE(!f16 || (!enc && m->allreduce == nullptr && c.num_experts == 0 && T > 8),
@@ -1172,13 +1172,19 @@ int prefill_prefix_batched(omx_qwen3 m, int T, int off, const EncodeOpts* enc = 
         if (!enc && !full_last && l == c.num_hidden_layers - 1) break;   // a prefix only has to leave its K/V rows behind
         const char* skv_env = getenv("OMX_PREFILL_SPLITKV");
         if (f16) {
-            // float16: MLX's fast SDPA accumulates in float32 and rounds its output once -- the explicit form of omx_sdpa on widened copies
-            // (q [H, T, D], K / V straight from the slabs, causal bottom-right aligned), then heads back next to each other per token
-            if (omx_sdpa(m->pf_q, m->pf_qt, m->kcache[l], m->vcache[l], 1, H, Hkv, T, off + T, D, 0, (int64_t)m->cap * D, scale, OMX_MASK_CAUSAL,
-                         nullptr, OMX_FLOAT16, s))
+            // float16: the flash kernel's float16 instantiation (f32 scores / softmax / accumulators, P rounded to float16 for the second
+            // product, one rounding of the output) -- MLX's fast SDPA accumulates in f32 the same way
+            // (OMX_F16_ATTN=explicit: f32 on widened copies through omx_sdpa, then heads back next to each other per token: the A/B form)
+            const char* fe = getenv("OMX_F16_ATTN");
+            if (fe && strcmp(fe, "explicit") == 0) {
+                if (omx_sdpa(m->pf_q, m->pf_qt, m->kcache[l], m->vcache[l], 1, H, Hkv, T, off + T, D, 0, (int64_t)m->cap * D, scale, OMX_MASK_CAUSAL,
+                             nullptr, OMX_FLOAT16, s))
+                    return 1;
+                heads_to_tokens_kernel<<<1024, 256, 0, s>>>(m->pf_attn, m->pf_q, H, T, D);
+                OMX_LAUNCH_CHECK();
+            } else if (launch_attn_prefill(m->pf_attn, m->pf_qt, m->kcache[l], m->vcache[l], 1, H, Hkv, T, off + T, D, 0, (int64_t)m->cap * D, scale,
+                                           OMX_MASK_CAUSAL, nullptr, s, /*out_token_major=*/true, nullptr, /*f16=*/true))
                 return 1;
-            heads_to_tokens_kernel<<<1024, 256, 0, s>>>(m->pf_attn, m->pf_q, H, T, D);
-            OMX_LAUNCH_CHECK();
         } else
         if (!enc && T <= 8 && H / Hkv <= 8 && !(skv_env && skv_env[0] == '0')) {
             // a handful of new rows over a long cache (speculative verify, a short follow-up prompt): the flash kernel gives them

@@ -798,7 +798,7 @@ int launch_attn_prefill(bf16_t* out, const bf16_t* q, const bf16_t* k, const bf1
                         const void* mask, hipStream_t s, bool out_token_major, const AttnLayout* layout, bool f16) {
     OMX_REQUIRE(D == 64 || D == 128, "sdpa prefill: head_dim %d unsupported (64 or 128)", D);
     // float16 operands (a float16 checkpoint's prompt pass): the single-phase kernel's float16 instantiations
-    OMX_REQUIRE(!f16 || (D == 128 && (mask_mode == OMX_MASK_NONE || mask_mode == OMX_MASK_CAUSAL)), "sdpa prefill in float16: head_dim 128, no mask or causal");
+    OMX_REQUIRE(!f16 || mask_mode == OMX_MASK_NONE || mask_mode == OMX_MASK_CAUSAL, "sdpa prefill in float16: no mask or causal");
     PrefillArgs a = {q, k, v, out, B, H, Hkv, Tq, Tk, kv_batch_stride, kv_head_stride, scale, mask_mode, mask,
                      (int64_t)H * Tq * D, (int64_t)Tq * D, D, (int64_t)H * Tq * D, (int64_t)Tq * D, D, D};
     if (out_token_major) {   // out[b][t][h][d]: what o_proj consumes after the reference's transpose+reshape (model.rs:211-213)
@@ -858,13 +858,15 @@ int launch_attn_prefill(bf16_t* out, const bf16_t* q, const bf16_t* k, const bf1
     const int qblk = wide ? 128 : 64;
     const dim3 grid((Tq + qblk - 1) / qblk, H, B), block(256);
     if (f16) {
-#define OMX_PF16_CASE(QQ, MM)                                                        \
-    if ((wide ? 2 : 1) == QQ && mask_mode == MM) {                                   \
-        attn_prefill_kernel<128, QQ, MM, true><<<grid, block, 0, s>>>(a);            \
+#define OMX_PF16_CASE(DD, QQ, MM)                                                    \
+    if (D == DD && (wide ? 2 : 1) == QQ && mask_mode == MM) {                        \
+        attn_prefill_kernel<DD, QQ, MM, true><<<grid, block, 0, s>>>(a);             \
         OMX_LAUNCH_CHECK();                                                          \
         return 0;                                                                    \
     }
-        OMX_PF16_CASE(1, OMX_MASK_NONE) OMX_PF16_CASE(1, OMX_MASK_CAUSAL) OMX_PF16_CASE(2, OMX_MASK_NONE) OMX_PF16_CASE(2, OMX_MASK_CAUSAL)
+#define OMX_PF16_D(DD) OMX_PF16_CASE(DD, 1, OMX_MASK_NONE) OMX_PF16_CASE(DD, 1, OMX_MASK_CAUSAL) OMX_PF16_CASE(DD, 2, OMX_MASK_NONE) OMX_PF16_CASE(DD, 2, OMX_MASK_CAUSAL)
+        OMX_PF16_D(128) OMX_PF16_D(64)
+#undef OMX_PF16_D
 #undef OMX_PF16_CASE
     }
 #define OMX_PF_CASE(DD, QQ, MM)                                                      \

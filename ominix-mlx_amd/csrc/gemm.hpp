@@ -119,7 +119,7 @@ struct AttnLayout {
 int launch_attn_prefill(bf16_t* out, const bf16_t* q, const bf16_t* k, const bf16_t* v, int B, int H, int Hkv, int Tq,
                         int Tk, int D, int64_t kv_batch_stride, int64_t kv_head_stride, float scale, int mask_mode,
                         const void* mask, hipStream_t s, bool out_token_major = false,
-                        const AttnLayout* layout = nullptr, bool f16 = false);   // f16: float16 q / k / v / out (head_dim 128, no mask or causal)
+                        const AttnLayout* layout = nullptr, bool f16 = false);   // f16: float16 q / k / v / out (no mask or causal)
 
 // M <= 8 rows: weights streamed once against all rows (gemv_rows.hip); same epilogue semantics as the GEMM kernels
 bool gemv_rows_supported(int M, int N, int K, const void* x, const void* w);

@@ -191,6 +191,13 @@ int omx_sdpa(void* out, const void* q, const void* k, const void* v, int B, int 
         return omx::sdpa_f32((float*)out, (const float*)q, (const float*)k, (const float*)v, B, H, Hkv, Tq, Tk, D, kv_batch_stride, kv_head_stride,
                              scale, mm, (const float*)mask, s);
     }
+    if (dtype == OMX_FLOAT16 && Tq > 1 && (D == 64 || D == 128) && (mask_mode == OMX_MASK_NONE || mask_mode == OMX_MASK_CAUSAL) &&
+        !getenv("OMX_SDPA_F16_EXPLICIT")) {
+        // (round 4) the flash kernel's float16 instantiation: f32 scores / softmax / accumulators, P rounded to float16 for the second
+        // product, one rounding of the output -- no [Tq, Tk] scores in memory (OMX_SDPA_F16_EXPLICIT=1: the form below)
+        return omx::launch_attn_prefill((omx::bf16_t*)out, (const omx::bf16_t*)q, (const omx::bf16_t*)k, (const omx::bf16_t*)v, B, H, Hkv, Tq, Tk, D,
+                                        kv_batch_stride, kv_head_stride, scale, mask_mode, nullptr, s, false, nullptr, /*f16=*/true);
+    }
     if (dtype == OMX_FLOAT16) {   // f32 arithmetic on widened copies, one rounding of the output to f16
         const size_t nq = (size_t)B * H * Tq * D, nkv = (size_t)B * Hkv * Tk * D, nm = mask_mode == OMX_MASK_ADDITIVE ? (size_t)Tq * Tk : 0;
         float* buf = nullptr;

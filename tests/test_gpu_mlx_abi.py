@@ -302,6 +302,30 @@ def test_sdpa_in_f32_and_f16(mx, dt, mask):
     np.testing.assert_allclose(got, ref, rtol=tol, atol=tol * np.abs(ref).max())
 
 
+@pytest.mark.parametrize("D", [64, 128])
+@pytest.mark.parametrize("mask", ["none", "causal"])
+def test_sdpa_float16_flash_kernel(mx, D, mask, monkeypatch):
+    """float16 SDPA without a mask array runs on the flash kernel's float16 instantiation (round 4; attn_prefill.hip F16): 300 queries
+    over 428 keys (ragged 64-key tiles, causal bottom-right aligned), GQA -- against the float64 oracle on the same float16 inputs, and
+    against the explicit f32 form (OMX_SDPA_F16_EXPLICIT=1) which it replaces."""
+    B, H, Hkv, Tq, Tk = 1, 4, 2, 300, 428
+    q = rand((B, H, Tq, D), 60).astype(np.float16); k = rand((B, Hkv, Tk, D), 61).astype(np.float16); v = rand((B, Hkv, Tk, D), 62).astype(np.float16)
+    Q, K, V = (mx.Array.from_numpy(t, mx.FLOAT16) for t in (q, k, v))
+    m_np, m_arg = (rc.create_causal_mask(Tq, Tk - Tq), "causal") if mask == "causal" else (None, None)
+    outs = {}
+    for form in ("flash", "explicit"):
+        if form == "explicit":
+            monkeypatch.setenv("OMX_SDPA_F16_EXPLICIT", "1")
+        out = mx.scaled_dot_product_attention(Q, K, V, D ** -0.5, m_arg)
+        assert out.dtype == mx.FLOAT16 and out.shape == (B, H, Tq, D)
+        outs[form] = mx.astype(out, mx.FLOAT32).numpy().astype(np.float64)
+    ref = rc.scaled_dot_product_attention(q.astype(np.float64), k.astype(np.float64), v.astype(np.float64), D ** -0.5, m_np, "f32")
+    for form in outs:
+        np.testing.assert_allclose(outs[form], ref, rtol=2e-3, atol=2e-3 * np.abs(ref).max())
+    # P is rounded to float16 ahead of the second product: the two forms differ by a fraction of the output's own rounding step
+    assert np.abs(outs["flash"] - outs["explicit"]).max() <= 2.0 ** -10 * np.abs(ref).max()
+
+
 def test_sanm_attention_replayed_op_by_op(mx):
     """SanmAttention::forward (funasr-mlx/src/paraformer.rs:496-532) issued through the handle ABI exactly as the Rust does -- fused
     qkv Linear, index / reshape / transpose views, q.matmul(k_t) * scale, softmax_axis, attn.matmul(v), the FSMN depthwise Conv1d over

@@ -302,6 +302,10 @@ int mlx_split_sections(mlx_vector_array* res, const mlx_array a, const int* indi
                        const mlx_stream s);                                                                          /* :1028 */
 int mlx_conv1d(mlx_array* res, const mlx_array input, const mlx_array weight, int stride, int padding, int dilation, int groups,
                const mlx_stream s);                                                                                  /* :225 */
+/* nn::Conv2d (channels-last: input [B, H, W, C_in], weight [C_out, kH, kW, C_in / groups]); the FLUX autoencoder's convolution
+ * (flux-klein-mlx/src/autoencoder.rs:110-131).  bfloat16 1x1 and 3x3 / stride 1 / padding 1 shapes run on the matrix-core GEMMs */
+int mlx_conv2d(mlx_array* res, const mlx_array input, const mlx_array weight, int stride_0, int stride_1, int padding_0, int padding_1,
+               int dilation_0, int dilation_1, int groups, const mlx_stream s);                                      /* :234 */
 /* dense expert matmul (mlx-rs/src/ops/quantization.rs:169-203): a [..., 1, K] against the stacked b [E, K, N] picked per row by
  * rhs_indices; the SwitchLinear form (b = swap_axes(w [E, N, K]), no lhs_indices) runs on the expert-selected GEMV */
 int mlx_gather_mm(mlx_array* res, const mlx_array a, const mlx_array b, const mlx_array lhs_indices /* may be null */,

@@ -112,6 +112,30 @@ std::vector<int> all_axes_of(const mlx_array a) {
 
 mlx_array f32_scalar(float v) { return mlx_array_new_float(v); }
 
+
+// Conv2d, channels-last like MLX: input [B, H, W, Cin], weight [Cout, kH, kW, Cin / groups], output [B, Ho, Wo, Cout]; one thread per
+// output element, f32 accumulation in (kh, kw, ci) order -- the general form (the bf16 1x1 / 3x3 shapes of the VAE take the GEMM routes)
+struct Conv2dGeom { int B, H, W, Cin, Ho, Wo, Cout, kH, kW, s0, s1, p0, p1, d0, d1, groups; };
+__global__ void conv2d_kernel(char* out, const char* x, const char* w, int dt, const Conv2dGeom g) {
+    const size_t total = (size_t)g.B * g.Ho * g.Wo * g.Cout;
+    const int cig = g.Cin / g.groups, cog = g.Cout / g.groups;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int co = (int)(i % g.Cout), ox = (int)((i / g.Cout) % g.Wo), oy = (int)((i / ((size_t)g.Cout * g.Wo)) % g.Ho);
+        const int b = (int)(i / ((size_t)g.Cout * g.Wo * g.Ho)), grp = co / cog;
+        float acc = 0.f;
+        for (int kh = 0; kh < g.kH; ++kh) {
+            const int y = oy * g.s0 - g.p0 + kh * g.d0;
+            if (y < 0 || y >= g.H) continue;
+            for (int kw = 0; kw < g.kW; ++kw) {
+                const int xx = ox * g.s1 - g.p1 + kw * g.d1;
+                if (xx < 0 || xx >= g.W) continue;
+                const size_t xi = (((size_t)b * g.H + y) * g.W + xx) * g.Cin + grp * cig, wi = (((size_t)co * g.kH + kh) * g.kW + kw) * cig;
+                for (int ci = 0; ci < cig; ++ci) acc = fmaf(ld_f(x, dt, xi + ci), ld_f(w, dt, wi + ci), acc);
+            }
+        }
+        st_f(out, dt, i, acc);
+    }
+}
 }  // namespace
 
 extern "C" {
@@ -705,6 +729,62 @@ int mlx_random_bernoulli(mlx_array* res, const mlx_array p, const int* shape, si
     lo.a = f32_scalar(0.f); hi.a = f32_scalar(1.f);
     if (mlx_random_uniform(&u, lo, hi, shape, shape_num, MLX_FLOAT32, key, s)) return 1;
     return mlx_less(res, u, p, s);
+}
+
+// nn::Conv2d (mlx-rs/src/nn/convolution.rs -> ops::conv2d; the FLUX autoencoder's only convolution, flux-klein-mlx/src/autoencoder.rs:110-131).
+// bfloat16 fast routes: 1x1 / stride 1 -> the GEMM kernels on [B H W, Cin]; 3x3 / stride 1 / padding 1 where the implicit-GEMM form applies
+// (gemm.hpp conv3x3_implicit_supported) -> one zero-bordered copy + one launch per image; everything else the direct kernel above.
+int mlx_conv2d(mlx_array* res, const mlx_array input, const mlx_array weight, int stride_0, int stride_1, int padding_0, int padding_1,
+               int dilation_0, int dilation_1, int groups, const mlx_stream s) {
+    REQ_ARR(input, "mlx_conv2d"); REQ_ARR(weight, "mlx_conv2d");
+    Contig cx, cw;
+    if (cx.init(*A(input)) || cw.init(*A(weight))) return 1;
+    OMX_REQUIRE(cx.a->shape.size() == 4 && cw.a->shape.size() == 4, "mlx_conv2d: input [B, H, W, C_in] and weight [C_out, kH, kW, C_in / groups] expected");
+    OMX_REQUIRE(cx.a->dt == cw.a->dt && is_float(cx.a->dt), "mlx_conv2d: input and weight must share a floating dtype");
+    Conv2dGeom g = {cx.a->shape[0], cx.a->shape[1], cx.a->shape[2], cx.a->shape[3], 0, 0, cw.a->shape[0], cw.a->shape[1], cw.a->shape[2],
+                    stride_0, stride_1, padding_0, padding_1, dilation_0, dilation_1, groups};
+    OMX_REQUIRE(stride_0 >= 1 && stride_1 >= 1 && dilation_0 >= 1 && dilation_1 >= 1 && padding_0 >= 0 && padding_1 >= 0 && groups >= 1 &&
+                    g.Cin % groups == 0 && g.Cout % groups == 0 && cw.a->shape[3] == g.Cin / groups,
+                "mlx_conv2d: bad stride / dilation / padding / groups (C_in %d, C_out %d, groups %d, weight C_in %d)", g.Cin, g.Cout, groups, cw.a->shape[3]);
+    const int span0 = dilation_0 * (g.kH - 1) + 1, span1 = dilation_1 * (g.kW - 1) + 1;
+    OMX_REQUIRE(g.H + 2 * padding_0 >= span0 && g.W + 2 * padding_1 >= span1, "mlx_conv2d: kernel span %d x %d exceeds the padded input %d x %d", span0, span1,
+                g.H + 2 * padding_0, g.W + 2 * padding_1);
+    g.Ho = (g.H + 2 * padding_0 - span0) / stride_0 + 1;
+    g.Wo = (g.W + 2 * padding_1 - span1) / stride_1 + 1;
+    std::vector<int> shape = {g.B, g.Ho, g.Wo, g.Cout};
+    const bool bf16 = cx.a->dt == MLX_BFLOAT16, unit = stride_0 == 1 && stride_1 == 1 && groups == 1;
+    if (bf16 && unit && g.kH == 3 && g.kW == 3 && padding_0 == 1 && padding_1 == 1 && dilation_0 == 1 && dilation_1 == 1 && g.B > 0 &&
+        omx::conv3x3_implicit_supported(g.H, g.W, g.Cin, g.Cout)) {
+        const int axes[2] = {1, 2}, one[2] = {1, 1};
+        Tmp zero, padded;
+        zero.a = f32_scalar(0.f);
+        if (mlx_pad(&padded, input, axes, 2, one, 2, one, 2, zero, "constant", s)) return 1;
+        Contig cp;
+        if (cp.init(*A(padded))) return 1;
+        NEW_OR_FAIL(r, shape, MLX_BFLOAT16);
+        for (int b = 0; b < g.B; ++b)
+            if (omx::launch_conv3x3_implicit((omx::bf16_t*)r->ptr() + (size_t)b * g.H * g.W * g.Cout,
+                                             (const omx::bf16_t*)cp.a->ptr() + (size_t)b * (g.H + 2) * (g.W + 2) * g.Cin, (const omx::bf16_t*)cw.a->ptr(), nullptr,
+                                             nullptr, g.H, g.W, g.Cin, g.Cout, g_stream)) {
+                delete r;
+                return 1;
+            }
+        return assign(res, r);
+    }
+    NEW_OR_FAIL(r, shape, cx.a->dt);
+    if (r->size()) {
+        const long long M = (long long)g.B * g.H * g.W;
+        if (bf16 && unit && g.kH == 1 && g.kW == 1 && padding_0 == 0 && padding_1 == 0 && g.Cin % 8 == 0 && M <= 0x7FFFFFFF) {
+            if (omx::launch_gemm_bf16((omx::bf16_t*)r->ptr(), (const omx::bf16_t*)cx.a->ptr(), (const omx::bf16_t*)cw.a->ptr(), nullptr, (int)M, g.Cout, g.Cin, g_stream)) {
+                delete r;
+                return 1;
+            }
+        } else {
+            conv2d_kernel<<<grid_for(r->size()), 256, 0, g_stream>>>(r->ptr(), cx.a->ptr(), cw.a->ptr(), cx.a->dt, g);
+            OMX_LAUNCH_CHECK();
+        }
+    }
+    return assign(res, r);
 }
 
 }  // extern "C"

@@ -393,6 +393,7 @@ SIGNATURES = {
     "mlx_split": (c_int, [ctypes.POINTER(mlx_vector_array), mlx_array, c_int, c_int, mlx_stream]),
     "mlx_split_sections": (c_int, [ctypes.POINTER(mlx_vector_array), mlx_array, P_INT, c_size_t, c_int, mlx_stream]),
     "mlx_conv1d": (c_int, [P_ARR, mlx_array, mlx_array, c_int, c_int, c_int, c_int, mlx_stream]),
+    "mlx_conv2d": (c_int, [P_ARR, mlx_array, mlx_array, c_int, c_int, c_int, c_int, c_int, c_int, c_int, mlx_stream]),
     "mlx_gather_mm": (c_int, [P_ARR, mlx_array, mlx_array, mlx_array, mlx_array, c_bool, mlx_stream]),
     "omx_mlx_fused_swiglu": (c_int, [P_ARR, mlx_array, mlx_array, mlx_stream]),
     "omx_mlx_fused_modulate": (c_int, [P_ARR, mlx_array, mlx_array, mlx_array, mlx_stream]),
@@ -774,6 +775,8 @@ def squeeze(a): return Array.op(lib.mlx_squeeze, a.h, default_stream())
 def squeeze_axis(a, axis): return Array.op(lib.mlx_squeeze_axis, a.h, axis, default_stream())
 def flatten(a, start_axis=0, end_axis=-1): return Array.op(lib.mlx_flatten, a.h, start_axis, end_axis, default_stream())
 def conv1d(x, w, stride=1, padding=0, dilation=1, groups=1): return Array.op(lib.mlx_conv1d, x.h, w.h, stride, padding, dilation, groups, default_stream())
+def conv2d(x, w, stride=(1, 1), padding=(0, 0), dilation=(1, 1), groups=1):
+    return Array.op(lib.mlx_conv2d, x.h, w.h, stride[0], stride[1], padding[0], padding[1], dilation[0], dilation[1], groups, default_stream())
 
 
 def expand_dims_axes(a, axes):

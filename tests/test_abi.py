@@ -66,7 +66,7 @@ mlx_reshape mlx_transpose_axes mlx_expand_dims mlx_expand_dims_axes mlx_squeeze_
 mlx_split mlx_split_sections mlx_slice mlx_slice_update mlx_take mlx_take_axis mlx_take_along_axis mlx_astype mlx_add mlx_subtract
 mlx_multiply mlx_divide mlx_negative mlx_floor_divide mlx_maximum mlx_minimum mlx_sigmoid mlx_cos mlx_sin mlx_exp mlx_softmax_axis
 mlx_sum_axis mlx_argmax_axis mlx_argsort mlx_argpartition_axis mlx_arange mlx_zeros mlx_greater_equal mlx_less_equal mlx_logical_and
-mlx_conv1d mlx_random_categorical
+mlx_conv1d mlx_conv2d mlx_random_categorical
 mlx_closure_new mlx_closure_free mlx_closure_new_func mlx_closure_new_func_payload mlx_closure_new_unary mlx_closure_set
 mlx_closure_apply mlx_detail_compile
 omx_mlx_fused_swiglu omx_mlx_fused_modulate

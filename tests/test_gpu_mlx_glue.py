@@ -533,3 +533,94 @@ def test_fourth_batch_views_products_and_accessors(mx):
         assert got.dtype == npdt
         np.testing.assert_array_equal(got, v.astype(npdt))
     np.testing.assert_array_equal(mx.Array.from_numpy(x > 0, mx.BOOL).numpy(), x > 0)
+
+
+def _conv2d_ref(x, w, stride, padding, dilation, groups):
+    """Channels-last conv2d in float64 (numpy): x [B, H, W, Cin], w [Cout, kH, kW, Cin / groups]."""
+    B, H, W, Cin = x.shape
+    Cout, kH, kW, cig = w.shape
+    xp = np.pad(x.astype(np.float64), ((0, 0), (padding[0],) * 2, (padding[1],) * 2, (0, 0)))
+    Ho = (H + 2 * padding[0] - dilation[0] * (kH - 1) - 1) // stride[0] + 1
+    Wo = (W + 2 * padding[1] - dilation[1] * (kW - 1) - 1) // stride[1] + 1
+    out = np.zeros((B, Ho, Wo, Cout))
+    cog = Cout // groups
+    for gi in range(groups):
+        wg = w[gi * cog:(gi + 1) * cog].astype(np.float64)
+        for kh in range(kH):
+            for kw in range(kW):
+                win = xp[:, kh * dilation[0]: kh * dilation[0] + (Ho - 1) * stride[0] + 1: stride[0],
+                         kw * dilation[1]: kw * dilation[1] + (Wo - 1) * stride[1] + 1: stride[1], gi * cig:(gi + 1) * cig]
+                out[..., gi * cog:(gi + 1) * cog] += win @ wg[:, kh, kw].T
+    return out
+
+
+def test_conv2d_general_and_the_autoencoder_shapes(mx):
+    """nn::Conv2d through the handle ABI (round 4; the FLUX autoencoder's convolution, flux-klein-mlx/src/autoencoder.rs:110-131,285-310):
+    the direct kernel on a strided / dilated / grouped float32 case, and the bfloat16 routes the VAE's shapes take -- 1x1 (post_quant_conv /
+    conv_shortcut: a GEMM over [B H W, C_in]), 3x3 padding 1 at 64 -> 128 channels on a 160 x 160 map (the implicit-GEMM launch, one per
+    image) and 3x3 into 3 channels (conv_out: the direct kernel) -- against numpy in float64 on the same rounded inputs."""
+    g = np.random.default_rng(9)
+    x = g.standard_normal((2, 13, 11, 6)).astype(np.float32)
+    w = (g.standard_normal((4, 3, 2, 3)) * 0.3).astype(np.float32)                # groups = 2
+    got = mx.conv2d(mx.Array.from_numpy(x, mx.FLOAT32), mx.Array.from_numpy(w, mx.FLOAT32), (2, 1), (1, 2), (2, 1), 2)
+    want = _conv2d_ref(x, w, (2, 1), (1, 2), (2, 1), 2)
+    assert got.shape == want.shape
+    np.testing.assert_allclose(got.numpy(), want, rtol=1e-5, atol=1e-5)
+    with pytest.raises(Exception, match="bad stride / dilation / padding / groups"):
+        mx.conv2d(mx.Array.from_numpy(x, mx.FLOAT32), mx.Array.from_numpy(w, mx.FLOAT32), (1, 1), (0, 0), (1, 1), 4)
+    # bfloat16, the autoencoder's shapes
+    for (B, H, W, Cin, Cout, k, pad) in ((2, 24, 20, 32, 32, 1, 0), (2, 160, 160, 64, 128, 3, 1), (1, 40, 36, 64, 3, 3, 1)):
+        xb = rc.bf16_round(g.standard_normal((B, H, W, Cin)).astype(np.float32))
+        wb = rc.bf16_round((g.standard_normal((Cout, k, k, Cin)) * (Cin * k * k) ** -0.5).astype(np.float32))
+        got = mx.conv2d(mx.Array.from_numpy(xb), mx.Array.from_numpy(wb), (1, 1), (pad, pad), (1, 1), 1)
+        want = _conv2d_ref(xb, wb, (1, 1), (pad, pad), (1, 1), 1)
+        assert got.shape == want.shape
+        assert_bf16_close(got.numpy(), want, 1, atol=2.0 ** -8 * np.abs(want).max())
+
+
+def test_autoencoder_resnet_block_and_upsample_replayed_op_by_op(mx):
+    """ResnetBlock::forward (flux-klein-mlx/src/autoencoder.rs:139-157) and the nearest Upsample + conv of an up block (:330-345, mlx-rs
+    nn/upsample.rs: expand-broadcast-reshape) issued through the handle ABI as the Rust issues them -- pytorch-compatible GroupNorm
+    (normalization.rs:369-392: reshape / transpose / fast::layer_norm without affine / transpose back, then weight and bias), nn::silu,
+    Conv2d + bias, the 1x1 conv_shortcut -- in bfloat16 against the float64 oracle (oracle/ref_vae.py)."""
+    from oracle import ref_vae as rv
+    g = np.random.default_rng(21)
+    H, W, Cin, Cout, G = 12, 10, 64, 128, 32
+    bf = lambda a: mx.Array.from_numpy(rc.bf16_round(np.asarray(a, np.float32)))
+    x = rc.bf16_round(g.standard_normal((H, W, Cin)).astype(np.float32))
+    p = {}
+    for name, shape, kind in (("norm1", (Cin,), "n"), ("conv1", (Cout, 3, 3, Cin), "c"), ("norm2", (Cout,), "n"), ("conv2", (Cout, 3, 3, Cout), "c"),
+                              ("conv_shortcut", (Cout, 1, 1, Cin), "c"), ("up", (Cout, 3, 3, Cout), "c")):
+        if kind == "n":
+            p[name + ".weight"] = rc.bf16_round((1 + 0.1 * g.standard_normal(shape)).astype(np.float32))
+        else:
+            p[name + ".weight"] = rc.bf16_round((g.standard_normal(shape) / np.sqrt(np.prod(shape[1:]))).astype(np.float32))
+        p[name + ".bias"] = rc.bf16_round((0.05 * g.standard_normal(shape[:1])).astype(np.float32))
+
+    def group_norm(t, name, C):          # t [1, h, w, C]
+        h, w = t.shape[1], t.shape[2]
+        y = mx.reshape(t, [1, h * w, G, C // G])
+        y = mx.reshape(mx.transpose_axes(y, [0, 2, 1, 3]), [1, G, h * w * (C // G)])
+        y = mx.layer_norm(y, None, None, 1e-5)
+        y = mx.reshape(mx.transpose_axes(mx.reshape(y, [1, G, h * w, C // G]), [0, 2, 1, 3]), [1, h, w, C])
+        return mx.add(mx.multiply(y, bf(p[name + ".weight"])), bf(p[name + ".bias"]))
+
+    silu = lambda t: mx.multiply(t, mx.sigmoid(t))
+    conv = lambda t, name, pad: mx.add(mx.conv2d(t, bf(p[name + ".weight"]), (1, 1), (pad, pad)), bf(p[name + ".bias"]))
+    X = bf(x[None])
+    h1 = conv(silu(group_norm(X, "norm1", Cin)), "conv1", 1)
+    h2 = conv(silu(group_norm(h1, "norm2", Cout)), "conv2", 1)
+    out = mx.add(conv(X, "conv_shortcut", 0), h2)
+    # Upsample(2, nearest): [1, h, 1, w, 1, C] broadcast to [1, h, 2, w, 2, C], reshaped to [1, 2h, 2w, C]; then the up block's conv
+    up = mx.reshape(mx.broadcast_to(mx.reshape(out, [1, H, 1, W, 1, Cout]), [1, H, 2, W, 2, Cout]), [1, 2 * H, 2 * W, Cout])
+    up = conv(up, "up", 1)
+    assert out.shape == (1, H, W, Cout) and up.shape == (1, 2 * H, 2 * W, Cout)
+
+    r = rv.silu(rv.group_norm(x, p["norm1.weight"], p["norm1.bias"]))
+    r = rv.conv2d(r, p["conv1.weight"], p["conv1.bias"], 1)
+    r = rv.conv2d(rv.silu(rv.group_norm(r, p["norm2.weight"], p["norm2.bias"])), p["conv2.weight"], p["conv2.bias"], 1)
+    ref = rv.conv2d(x, p["conv_shortcut.weight"], p["conv_shortcut.bias"], 0) + r
+    ref_up = rv.conv2d(rv.upsample_nearest2(ref), p["up.weight"], p["up.bias"], 1)
+    # every op result is held in bfloat16 (about a dozen roundings deep): a few 2^-8 of the largest value
+    assert np.abs(out.numpy()[0] - ref).max() <= 4 * 2.0 ** -8 * np.abs(ref).max()
+    assert np.abs(up.numpy()[0] - ref_up).max() <= 6 * 2.0 ** -8 * np.abs(ref_up).max()

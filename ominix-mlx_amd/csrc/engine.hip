@@ -101,6 +101,11 @@ __global__ void ep_fold_kernel(bf16_t* __restrict__ out, const bf16_t* __restric
     }
 }
 
+// a float16 partial product widened for the f32 all-reduce of a tensor-parallel float16 prompt pass
+__global__ void f16_widen_kernel(float* __restrict__ out, const bf16_t* __restrict__ in, int64_t n) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) out[i] = Act16<true>::val(in[i]);
+}
+
 uint32_t crc32_str(const char* s) {
     uint32_t crc = 0xFFFFFFFFu;
     for (; *s; ++s) {
@@ -1071,10 +1076,11 @@ int prefill_prefix_batched(omx_qwen3 m, int T, int off, const EncodeOpts* enc = 
     const omx_qwen3_config& c = m->cfg;
     // float16 checkpoints (round 4): the same pass in float16 -- weights dequantised to float16, the eight-wave GEMM kernel's float16
     // form, float16 norms / RoPE / slabs, the flash attention kernel's float16 form -- for
-    // plain prompts of a dense single-rank model; encode / verify and the sharded forms stay bfloat16-only
+    // plain prompts of a dense model, also on tensor-parallel shards (each rank's float16 partial products summed in f32); encode /
+    // verify and the expert forms stay bfloat16-only
     const bool f16 = c.quant_scales_f16 != 0;
-    OMX_REQUIRE(!f16 || (!enc && m->allreduce == nullptr && c.num_experts == 0 && T > 8),
-                "batched prompt pass in float16: plain prompts of more than 8 tokens on a dense single-rank model only");
+    OMX_REQUIRE(!f16 || (!enc && c.ep_size <= 1 && c.num_experts == 0 && T > 8),
+                "batched prompt pass in float16: plain prompts of more than 8 tokens on a dense model (single rank or tensor parallel) only");
     struct GemmF16Scope { bool on; explicit GemmF16Scope(bool o) : on(o) { if (on) gemm_set_f16(true); } ~GemmF16Scope() { if (on) gemm_set_f16(false); } } f16_scope(f16);
     const omx_dtype act_dt = f16 ? OMX_FLOAT16 : OMX_BFLOAT16;
     hipStream_t s = m->stream;
@@ -1097,6 +1103,22 @@ int prefill_prefix_batched(omx_qwen3 m, int T, int off, const EncodeOpts* enc = 
         if (!tp) return launch_gemm_bf16_ex(out, x, w, nullptr, resid, T, hd, K, s);
         bf16_t* part = m->pf_xn;   // free between the projections that read it and the next norm that rewrites it
         if (launch_gemm_bf16(part, x, w, nullptr, T, hd, K, s)) return 1;
+        if (f16) {
+            // float16: the ranks' float16 partial products widened, summed in f32 by the collective (every communicator reduces f32; none
+            // float16) and folded into the float16 residual with the decode step's two roundings
+            if (!m->pf_ep_partial || m->pf_ep_cap < T) {
+                OMX_HIP_CHECK(hipStreamSynchronize(s));
+                if (m->pf_ep_partial) OMX_HIP_CHECK(hipFree(m->pf_ep_partial));
+                OMX_HIP_CHECK(hipMalloc((void**)&m->pf_ep_partial, (size_t)std::max(T, m->pf_cap) * hd * sizeof(float)));
+                m->pf_ep_cap = std::max(T, m->pf_cap);
+            }
+            f16_widen_kernel<<<1024, 256, 0, s>>>(m->pf_ep_partial, part, (int64_t)T * hd);
+            OMX_LAUNCH_CHECK();
+            OMX_REQUIRE(m->allreduce(m->pf_ep_partial, m->pf_ep_partial, (size_t)T * hd, kNcclFloat32, kNcclSum, m->comm, s) == 0, "ncclAllReduce failed");
+            ep_fold_kernel<<<1024, 256, 0, s>>>(out, resid, m->pf_ep_partial, (int64_t)T * hd, true);
+            OMX_LAUNCH_CHECK();
+            return 0;
+        }
         OMX_REQUIRE(m->allreduce(part, part, (size_t)T * hd, kNcclBfloat16, kNcclSum, m->comm, s) == 0, "ncclAllReduce failed");
         return omx_add(out, resid, part, (int64_t)T * hd, OMX_BFLOAT16, s);
     };
@@ -1769,9 +1791,9 @@ int omx_qwen3_prefill(omx_qwen3 m, const uint32_t* prompt, int n_prompt, uint32_
     const char* serial_env = getenv("OMX_PREFILL_SERIAL");
     // tensor-parallel engines run the batched matrix-core prefill on their shards with two all-reduces per layer, expert-parallel ones
     // with one all-reduce of the MoE block's [T, hidden] partial per layer (round 3; token-serial before)
-    // (float16 models: the batched pass exists for plain prompts of a dense single-rank model; short ones and the sharded / MoE forms
-    //  go through the decode step)
-    const bool f16_serial = m->cfg.quant_scales_f16 && (n_prompt <= 16 || m->allreduce != nullptr || m->cfg.num_experts > 0);
+    // (float16 models: the batched pass exists for plain prompts of a dense model, single rank or tensor parallel; short prompts and
+    //  sparse-MoE models go through the decode step)
+    const bool f16_serial = m->cfg.quant_scales_f16 && (n_prompt <= 16 || m->cfg.num_experts > 0);
     const bool serial = (serial_env && serial_env[0] == '1') || n_prompt < 2 || f16_serial;
     if (prepare_step(m, serial ? off : off + n_prompt - 1)) return 1;   // the first step this call will run (graphs are per context bucket)
     OMX_HIP_CHECK(hipMemcpyAsync(m->prompt_dev, prompt, (size_t)n_prompt * 4, hipMemcpyHostToDevice, m->stream));

@@ -576,8 +576,11 @@ def test_float16_checkpoint_batched_prompt_pass(omx, monkeypatch):
     print(f"float16 prompt of {n1} tokens: batched {runs['0'][5]:.2f} ms, token-serial {runs['1'][5]:.2f} ms")
 
 
-def test_float16_checkpoint_tensor_parallel_two_ranks_on_one_gpu(omx):
-    """Round 4 (review of round 3: "TP = 2 loopback with f16 triplets"): a float16 MLX checkpoint sharded over two ranks -- packed rows
+@pytest.mark.parametrize("serial_prefill", ["0", "1"])
+def test_float16_checkpoint_tensor_parallel_two_ranks_on_one_gpu(omx, monkeypatch, serial_prefill):
+    """(serial_prefill 0: the prompt in the float16 matrix-core pass on the shards -- the row-split projections' float16 partial products
+    widened and all-reduced in f32; 1: through the decode step.)
+    Round 4 (review of round 3: "TP = 2 loopback with f16 triplets"): a float16 MLX checkpoint sharded over two ranks -- packed rows
     and K slices with their float16 scales / biases (tp.shard), float16 activations, K / V and logits on every rank, the row-split
     projections' f32 partials all-reduced and folded into the float16 residual (two float16 roundings, as the single-rank packed GEMV's
     residual epilogue makes them).  Both ranks emit the same tokens; against the float16 oracle on the UNSHARDED checkpoint the logits
@@ -595,6 +598,7 @@ def test_float16_checkpoint_tensor_parallel_two_ranks_on_one_gpu(omx):
         qw[name] = arr
     prompt = synth.prompt_ids(40, cfg.vocab_size)
     n_new = 10
+    monkeypatch.setenv("OMX_PREFILL_SERIAL", serial_prefill)
     f16w = {k: (v.astype(np.float32) if v.dtype == np.float16 else v) for k, v in qw.items()}
     ref_tokens, ref_logits = rq.Qwen3Oracle(cfg, f16w, dt="f16", quant=(bits, group_size)).generate(prompt, n_new, return_logits=True)
     world = 2

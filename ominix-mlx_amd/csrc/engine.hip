@@ -1079,9 +1079,9 @@ int prefill_prefix_batched(omx_qwen3 m, int T, int off, const EncodeOpts* enc = 
     // plain prompts of a dense model, also on tensor-parallel shards (each rank's float16 partial products summed in f32); encode /
     // verify and the expert forms stay bfloat16-only
     const bool f16 = c.quant_scales_f16 != 0;
-    OMX_REQUIRE(!f16 || (!enc && c.ep_size <= 1 && c.num_experts == 0 && T > 8),
-                "batched prompt pass in float16: plain prompts of more than 8 tokens on a dense model (single rank or tensor parallel) only");
-    struct GemmF16Scope { bool on; explicit GemmF16Scope(bool o) : on(o) { if (on) gemm_set_f16(true); } ~GemmF16Scope() { if (on) gemm_set_f16(false); } } f16_scope(f16);
+    OMX_REQUIRE(!f16 || (!enc && c.ep_size <= 1 && (c.num_experts == 0 || m->allreduce == nullptr) && T > 8),
+                "batched prompt pass in float16: plain prompts of more than 8 tokens (dense: single rank or tensor parallel; sparse-MoE: single rank)");
+    struct GemmF16Scope { bool on, was = false; explicit GemmF16Scope(bool o) : on(o) { if (on) was = gemm_set_f16(true); } ~GemmF16Scope() { if (on) gemm_set_f16(was); } } f16_scope(f16);
     const omx_dtype act_dt = f16 ? OMX_FLOAT16 : OMX_BFLOAT16;
     hipStream_t s = m->stream;
     const int hd = c.hidden_size, D = c.head_dim, H = m->H, Hkv = m->Hkv, I = m->I;
@@ -1237,11 +1237,11 @@ int prefill_prefix_batched(omx_qwen3 m, int T, int off, const EncodeOpts* enc = 
         if (gu_norm) { gu.pre_norm_w = L.post_ln; gu.pre_norm_eps = c.rms_norm_eps; }
         if (c.num_experts > 0) {   // sparse-MoE feed-forward over all T rows (grouped MFMA GEMM route), then the residual
             if (quant) {
-                if (omx_moe_block_forward_q(h, h2, h2, L.post_ln, c.rms_norm_eps, m->pf_xn, Q.moe_router.w, Q.moe_router.scales,
-                                            Q.moe_router.biases, Q.moe_g.w, Q.moe_g.scales, Q.moe_g.biases, Q.moe_u.w, Q.moe_u.scales,
-                                            Q.moe_u.biases, Q.moe_d.w, Q.moe_d.scales, Q.moe_d.biases, T, hd, c.moe_intermediate_size,
-                                            c.num_experts, c.num_experts_per_tok, c.moe_mode, c.norm_topk_prob, c.quant_group,
-                                            c.quant_bits, s))
+                if (omx_moe_block_forward_q_ex(h, h2, h2, L.post_ln, c.rms_norm_eps, m->pf_xn, Q.moe_router.w, Q.moe_router.scales,
+                                               Q.moe_router.biases, Q.moe_g.w, Q.moe_g.scales, Q.moe_g.biases, Q.moe_u.w, Q.moe_u.scales,
+                                               Q.moe_u.biases, Q.moe_d.w, Q.moe_d.scales, Q.moe_d.biases, T, hd, c.moe_intermediate_size,
+                                               c.num_experts, c.num_experts_per_tok, c.moe_mode, c.norm_topk_prob, c.quant_group,
+                                               c.quant_bits, f16 ? 1 : 0, s))
                     return 1;
             } else if (c.ep_size > 1 || c.tp_size > 1) {
                 // expert TENSOR parallel: the same launches over ALL experts at this rank's 1 / tp of their intermediate columns -- the f32
@@ -1791,9 +1791,9 @@ int omx_qwen3_prefill(omx_qwen3 m, const uint32_t* prompt, int n_prompt, uint32_
     const char* serial_env = getenv("OMX_PREFILL_SERIAL");
     // tensor-parallel engines run the batched matrix-core prefill on their shards with two all-reduces per layer, expert-parallel ones
     // with one all-reduce of the MoE block's [T, hidden] partial per layer (round 3; token-serial before)
-    // (float16 models: the batched pass exists for plain prompts of a dense model, single rank or tensor parallel; short prompts and
-    //  sparse-MoE models go through the decode step)
-    const bool f16_serial = m->cfg.quant_scales_f16 && (n_prompt <= 16 || m->cfg.num_experts > 0);
+    // (float16 models: the batched pass exists for plain prompts -- dense models on one rank or tensor parallel, sparse-MoE models on
+    //  one rank; short prompts go through the decode step)
+    const bool f16_serial = m->cfg.quant_scales_f16 && n_prompt <= 16;
     const bool serial = (serial_env && serial_env[0] == '1') || n_prompt < 2 || f16_serial;
     if (prepare_step(m, serial ? off : off + n_prompt - 1)) return 1;   // the first step this call will run (graphs are per context bucket)
     OMX_HIP_CHECK(hipMemcpyAsync(m->prompt_dev, prompt, (size_t)n_prompt * 4, hipMemcpyHostToDevice, m->stream));

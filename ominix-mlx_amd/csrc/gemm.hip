@@ -1062,7 +1062,7 @@ void gemm_tile_hint(int rows) { g_tile_hint = rows; }
 // float16 operands / results for this thread's next GEMMs (a float16 checkpoint's prompt pass, engine.hip): the eight-wave kernel's
 // float16 instantiations serve every shape (plain: 256- or 128-row tiles; segmented: 256-row tiles)
 static thread_local bool g_gemm_f16 = false;
-void gemm_set_f16(bool on) { g_gemm_f16 = on; }
+bool gemm_set_f16(bool on) { const bool was = g_gemm_f16; g_gemm_f16 = on; return was; }   // returns the previous state (nested scopes)
 
 static int launch_gemm_impl(bf16_t* out, const bf16_t* x, const bf16_t* w, const bf16_t* bias, const bf16_t* resid,
                             const bf16_t* gate, int M, int N, int K, hipStream_t s, int relu = 0) {
@@ -1270,6 +1270,8 @@ int launch_gemm_bf16_segmented_grouped(const bf16_t* x, int max_rows, int K, con
     a.N = n + 2 * segs.half;
     a.grid_m = max_tiles;
     a.grid_n = seg_tiles(segs);
+    if (g_gemm_f16) gemm_bf16_nt_256_kernel<16, true, false, 256, true><<<a.grid_m * a.grid_n, big::NT, big::SMEM, s>>>(a);   // (a float16 model's prompt)
+    else
     gemm_bf16_nt_256_kernel<16, true><<<a.grid_m * a.grid_n, big::NT, big::SMEM, s>>>(a);
     OMX_LAUNCH_CHECK();
     return 0;

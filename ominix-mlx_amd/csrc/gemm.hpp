@@ -31,7 +31,7 @@ int launch_gemm_bf16_bias_relu(bf16_t* out, const bf16_t* x, const bf16_t* w, co
 void gemm_tile_hint(int rows);
 // float16 operands and results for this thread's next GEMMs (the bf16_t pointers then hold float16 bit patterns); a float16
 // checkpoint's batched prompt pass switches it on around its launches
-void gemm_set_f16(bool on);
+bool gemm_set_f16(bool on);   // returns the previous state
 int launch_gemm_bf16_gated(bf16_t* out, const bf16_t* x, const bf16_t* w, const bf16_t* resid, const bf16_t* gate, int M,
                            int N, int K, hipStream_t s);
 

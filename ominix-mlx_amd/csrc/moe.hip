@@ -538,8 +538,9 @@ extern "C" int omx_moe_block_forward_q(void* out, const void* resid, const void*
                                       stream);
 }
 /* ... f16 != 0: a float16 checkpoint (the reference's own Mixtral format: 4-bit triplets, float16 in the MLX community builds) -- x, norm
- * weights, scales / biases and the result are float16 and every rounding point is float16, like MLX runs it; few tokens only
- * (<= 32 routed slots: the decode step, through which a float16 model also runs its prompt) */
+ * weights, scales / biases and the result are float16 and every rounding point is float16, like MLX runs it.  More than 32 routed
+ * slots (a prompt): the router exactly as the decode form computes it (packed GEMV per token, so a prompt routes like its tokens
+ * would one by one), the stacks dequantised to float16, the grouped 256-row GEMMs' float16 instantiation, the float16 combine. */
 extern "C" int omx_moe_block_forward_q_ex(void* out, const void* resid, const void* x, const void* norm_w, float eps, void* xn,
                                           const void* q_router, const void* s_router, const void* b_router, const void* q_gate,
                                           const void* s_gate, const void* b_gate, const void* q_up, const void* s_up, const void* b_up,
@@ -547,7 +548,6 @@ extern "C" int omx_moe_block_forward_q_ex(void* out, const void* resid, const vo
                                           int n_experts, int top_k, int mode, int norm_topk_prob, int group_size, int bits, int f16,
                                           omx_stream stream) {
     using namespace omx;
-    OMX_REQUIRE(!f16 || n_tokens * top_k <= 32, "omx_moe_block_forward_q: a float16 model runs at most 32 routed slots per call (%d tokens)", n_tokens);
     OMX_REQUIRE(out && resid && x && norm_w && xn && q_router && s_router && b_router && q_gate && s_gate && b_gate && q_up && s_up &&
                     b_up && q_down && s_down && b_down, "omx_moe_block_forward_q: null tensor");
     OMX_REQUIRE(bits == 4 || bits == 8, "omx_moe_block_forward_q: bits=%d (4 or 8)", bits);
@@ -562,6 +562,58 @@ extern "C" int omx_moe_block_forward_q_ex(void* out, const void* resid, const vo
     q.gate.sb = quant_find_sb(q.gate.scales); q.up.sb = quant_find_sb(q.up.scales); q.down.sb = quant_find_sb(q.down.scales);
     q.group = group_size; q.bits = bits;
     const int slots = n_tokens * top_k;
+    if (slots > 32 && f16) {
+        size_t need = 0;
+        omx_moe_workspace_bytes(n_tokens, hidden, inter, n_experts, top_k, &need);
+        void* ws = nullptr;
+        if (get_workspace(&ws, need)) return 1;
+        char* p = (char*)ws;
+        auto take = [&](size_t bytes) { char* r = p; p += (bytes + 255) & ~(size_t)255; return r; };
+        uint32_t* inds = (uint32_t*)take((size_t)slots * 4);
+        uint32_t* row_src = (uint32_t*)take((size_t)slots * 4);
+        uint32_t* pos_of_slot = (uint32_t*)take((size_t)slots * 4);
+        bf16_t* scores = (bf16_t*)take((size_t)slots * 2);
+        int* seg_start = (int*)take((size_t)(n_experts + 2) * 4);
+        const int max_tiles = slots / 128 + n_experts + 1;
+        int* tile_expert = (int*)take((size_t)max_tiles * 4);
+        int* tile_m0 = (int*)take((size_t)max_tiles * 4);
+        int* n_tiles = (int*)take(256);
+        bf16_t* gbuf = (bf16_t*)take((size_t)slots * inter * 2);
+        bf16_t* logits = (bf16_t*)take((size_t)slots * inter * 2);      // the `ubuf` slot (the GLU epilogue leaves it unused)
+        bf16_t* ybuf = (bf16_t*)take((size_t)slots * hidden * 2);
+        QGemvArgs a = {};
+        a.m[0] = QMat{(const uint32_t*)q_router, (const bf16_t*)s_router, (const bf16_t*)b_router, n_experts};
+        a.N = n_experts; a.K = hidden; a.group = group_size;
+        a.x = (const bf16_t*)x; a.norm_w = (const bf16_t*)norm_w; a.eps = eps; a.out = logits;
+        a.n_batch = n_tokens; a.x_div = 1; a.scales_f16 = 1;
+        if (launch_qgemv(a, bits, PRO_RMSNORM, EPI_STORE, s)) return 1;
+        moe_route_logits_kernel<true><<<n_tokens, 64, 0, s>>>(logits, n_experts, top_k, mode, norm_topk_prob, inds, scores);
+        OMX_LAUNCH_CHECK();
+        if (omx_rms_norm(xn, x, norm_w, n_tokens, hidden, eps, OMX_FLOAT16, stream)) return 1;
+        const size_t per = (size_t)n_experts * inter * hidden;
+        if (3 * per > g_dq_cap) {
+            OMX_HIP_CHECK(hipStreamSynchronize(s));
+            if (g_dq) OMX_HIP_CHECK(hipFree(g_dq));
+            OMX_HIP_CHECK(hipMalloc((void**)&g_dq, 3 * per * 2));
+            g_dq_cap = 3 * per;
+        }
+        if (omx_dequantize(g_dq, q_gate, s_gate, b_gate, (int64_t)n_experts * inter, hidden, group_size, bits, OMX_FLOAT16, stream) ||
+            omx_dequantize(g_dq + per, q_up, s_up, b_up, (int64_t)n_experts * inter, hidden, group_size, bits, OMX_FLOAT16, stream) ||
+            omx_dequantize(g_dq + 2 * per, q_down, s_down, b_down, (int64_t)n_experts * hidden, inter, group_size, bits, OMX_FLOAT16, stream))
+            return 1;
+        moe_plan_kernel<<<1, 1024, 0, s>>>(inds, slots, n_experts, top_k, seg_start, row_src, pos_of_slot, tile_expert, tile_m0, n_tiles, 256);
+        OMX_LAUNCH_CHECK();
+        GroupedDesc g;
+        g.tile_expert = tile_expert; g.tile_m0 = tile_m0; g.seg_start = seg_start; g.n_tiles = n_tiles;
+        g.row_src = row_src; g.w_estride = (size_t)inter * hidden;
+        const bool was_f16 = gemm_set_f16(true);    // (the engine's prompt pass has it on already: restore, do not clear)
+        const int rc = grouped_glu_256(ybuf, gbuf, (const bf16_t*)xn, g_dq, g_dq + per, g_dq + 2 * per, slots, hidden, inter, n_experts, g, s);
+        gemm_set_f16(was_f16);
+        if (rc) return 1;
+        moe_combine_kernel<true><<<n_tokens, 256, 0, s>>>((bf16_t*)out, ybuf, scores, pos_of_slot, hidden, top_k, (const bf16_t*)resid);
+        OMX_LAUNCH_CHECK();
+        return 0;
+    }
     if (slots > 32) {
         // dequantised router (tiny) lives behind the expert scratch; rows normalised once
         static bf16_t* router_dq = nullptr;

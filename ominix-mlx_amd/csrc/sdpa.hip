@@ -250,9 +250,9 @@ int omx_linear(void* out, const void* x, const void* w, const void* bias, int M,
     hipStream_t s = (hipStream_t)stream;
     if (dtype == OMX_FLOAT16) {   // the eight-wave kernel's float16 form (round 4): float16 operands, f32 accumulation, one rounding to float16
         OMX_REQUIRE(M > 8 && K % 64 == 0, "omx_linear: float16 takes more than 8 rows and K %% 64 == 0 (M=%d K=%d)", M, K);
-        omx::gemm_set_f16(true);
+        const bool was = omx::gemm_set_f16(true);
         const int rc = omx::launch_gemm_bf16((omx::bf16_t*)out, (const omx::bf16_t*)x, (const omx::bf16_t*)w, (const omx::bf16_t*)bias, M, N, K, s);
-        omx::gemm_set_f16(false);
+        omx::gemm_set_f16(was);
         return rc;
     }
     if (dtype == OMX_FLOAT32) {   // exact-f32 matrix cores (gemm_f32.hip): the Paraformer path's dtype

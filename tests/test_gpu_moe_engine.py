@@ -155,9 +155,12 @@ def test_quantized_moe_engine_matches_oracle(omx, name, bits):
     np.testing.assert_array_equal(got2, got)
 
 
+@pytest.mark.parametrize("serial_prefill", ["0", "1"])
 @pytest.mark.parametrize("name", ["mixtral", "qwen3_moe"])
-def test_float16_quantized_moe_checkpoint_runs_in_float16(omx, name):
-    """The reference's only Mixtral format -- 4-bit triplets (mixtral-mlx/src/model.rs:554-556 refuses anything else), float16 in the MLX
+def test_float16_quantized_moe_checkpoint_runs_in_float16(omx, monkeypatch, name, serial_prefill):
+    """(serial_prefill 0: the 24-token prompt in the float16 matrix-core pass -- router per token exactly as the decode form computes it,
+    expert stacks dequantised to float16, the grouped 256-row GEMMs' float16 instantiation; 1: through the decode step.)
+    The reference's only Mixtral format -- 4-bit triplets (mixtral-mlx/src/model.rs:554-556 refuses anything else), float16 in the MLX
     community builds -- the way MLX runs it: float16 END TO END (nn/quantized.rs:361-385, ops/quantization.rs:226-279).  float16
     scales / biases / norm weights uploaded as they are, float16 activations in every kernel of the step (packed GEMVs incl. the
     router and the expert stacks, decode attention with a float16 cache, routing scores and the weighted sum rounded to float16),
@@ -175,6 +178,7 @@ def test_float16_quantized_moe_checkpoint_runs_in_float16(omx, name):
             arr = (s32 if k.endswith(".scales") else b32).astype(np.float16).reshape(arr.shape)
         qw[k] = arr
     prompt = synth.prompt_ids(24, cfg.vocab_size)
+    monkeypatch.setenv("OMX_PREFILL_SERIAL", serial_prefill)
     m = _engine(omx, cfg, qw, quantization={"bits": bits, "group_size": group, "scales_dtype": "float16"})
     first = m.prefill(prompt)
     logits0 = m.last_logits()

@@ -520,7 +520,9 @@ __device__ __forceinline__ void pp_unit(const PrefillArgs& a, bf16_t* sK, bf16_t
                     for (int r = 0; r < 4; ++r) mx = fmaxf(mx, sc[w][kt][r]);
                 mx = quad_rows_max(mx) * c2;
                 // (a deferred / skipped rescale -- cdna_hip_programming.md T13 -- was tried in three forms: any branch or asm region around
-                //  the 64 accumulators made hipcc spill them, 172-204 B of scratch and a 2x slower kernel; EXPERIMENTS.md R3-4)
+                //  the 64 accumulators made hipcc spill them, 172-204 B of scratch and a 2x slower kernel; EXPERIMENTS.md R3-4.
+                //  Round 4: the max / sum as four partial chains instead of one of 16 dependent operations -- 346 -> 363 us for the max
+                //  alone, 473 us with the sums: this kernel sits on the schedule hipcc finds for exactly this form; R4-14)
                 const float m_new = fmaxf(m_run[w], mx);
                 const float alpha = __builtin_amdgcn_exp2f(m_run[w] - m_new);
                 m_run[w] = m_new;
@@ -728,6 +730,295 @@ __global__ __launch_bounds__(512, 1) void attn_prefill_pp_kernel(const PrefillAr
     pp_unit<D, MASK, TR, false>(a, &sK2[0][0], &sV2[0][0], b, h, qt, 0, 0, 0);
 }
 
+// ---- The two-phase kernel on 32x32x16 MFMAs (round 4; OMX_ATTN_PP32=1, head_dim 128): the same block (8 waves, 256 query rows, K / V
+//      tiles of 64 keys by LDS-DMA, waves 0-3 and 4-7 in opposite phases), but a wave's 32 query rows are ONE 32-wide MFMA column block:
+//      S^T tile (32 keys x 32 queries) = 8 MFMAs over the head dim, O^T tile (32 dims x 32 queries) += V^T P^T = 4 MFMAs over the tile's
+//      keys -- 32 MFMA issues per tile step instead of 64 for the same flops (the loop is issue-bound, EXPERIMENTS.md R3-4), and a
+//      lane holds 32 scores of ONE query, so the row max / sum need one cross-lane step (lane ^ 32) instead of two.
+//      Lane layout of a 32x32 result: column (query) = lane & 31, rows 8 g + 4 (lane >> 5) + r for g, r = 0..3.  Operand k-slot
+//      8 (lane >> 5) + e  <->  key 8 (2 j + (e >> 2)) + 4 (lane >> 5) + (e & 3) of the 16-key step j on BOTH operands of the second
+//      product, so that P's fragment is eight consecutive accumulator registers of the lane.  Not bit-identical to the 16x16x32 kernels
+//      (other summation order inside the MFMAs). ----
+#ifndef OMX_PP32_KAHEAD
+#define OMX_PP32_KAHEAD 1
+#endif
+#ifndef OMX_PP32_CHAINS
+#define OMX_PP32_CHAINS 2
+#endif
+template <int D, int MASK>
+__device__ __forceinline__ void pp32_unit(const PrefillArgs& a, bf16_t* sK, bf16_t* sV, int b, int h, int qt) {
+    using f32x16v = __attribute__((ext_vector_type(16))) float;
+    constexpr int DC = D / 8, NI = D / 16, NT32 = D / 32;
+    constexpr int QBLK = 256;
+    constexpr int KCH = KB * DC / 512;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const bool late = wave_u >= 4;
+    const int q32 = lane & 31, hh = lane >> 5;
+    const int kvh = h / (a.H / a.Hkv);
+    const int q0 = qt * QBLK;
+    const int shift = a.Tk - a.Tq;
+    const bf16_t* Kb = a.k + (size_t)b * a.kv_batch_stride + (size_t)kvh * a.kv_head_stride;
+    const bf16_t* Vb = a.v + (size_t)b * a.kv_batch_stride + (size_t)kvh * a.kv_head_stride;
+
+    const int qrow = q0 + wave * 32 + q32, qrow_c = min(qrow, a.Tq - 1);
+    bf16x8 qf[NI];
+    {
+        const bf16_t* Qp = a.q + (size_t)b * a.q_bs + (size_t)h * a.q_hs + (size_t)qrow_c * a.q_ts;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) qf[i] = *reinterpret_cast<const bf16x8*>(Qp + i * 16 + hh * 8);
+    }
+    f32x16v o[NT32];
+#pragma unroll
+    for (int t = 0; t < NT32; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+    int kv_end = a.Tk;
+    if (MASK == OMX_MASK_CAUSAL) kv_end = max(0, min(a.Tk, q0 + QBLK + shift));
+    const int nt = (kv_end + KB - 1) / KB;
+
+    constexpr int VSH = (D == 128) ? 0 : 1;
+    constexpr int VBM = D / 16 - 1;
+    uint32_t koff[KCH], voff[KCH];
+#pragma unroll
+    for (int it = 0; it < KCH; ++it) {
+        const int ci = threadIdx.x + it * 512;
+        const int row = ci / DC;
+        koff[it] = (uint32_t)(row * a.kv_ts + ((ci % DC) ^ (row & (DC - 1))) * 8);
+        voff[it] = (uint32_t)(row * a.kv_ts + ((ci % DC) ^ (((row >> VSH) & VBM) << 1)) * 8);
+    }
+    auto dma16 = [&](const bf16_t* gsrc, unsigned lds_dst) {   // (asm: see attn_prefill_kernel)
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+    };
+    auto stage = [&](int k0, const bf16_t* src, const uint32_t (&off)[KCH], bf16_t* dst, bool is_v) {
+        const unsigned d0 = (unsigned)(uintptr_t)dst + wave_u * 1024u;
+        if (k0 + KB <= a.Tk) {
+            const bf16_t* base = src + (size_t)k0 * a.kv_ts;
+#pragma unroll
+            for (int it = 0; it < KCH; ++it) dma16(base + off[it], d0 + it * 8192u);
+            return;
+        }
+#pragma unroll
+        for (int it = 0; it < KCH; ++it) {
+            const int ci = threadIdx.x + it * 512;
+            const int row = ci / DC;
+            const int ch = (ci % DC) ^ (is_v ? (((row >> VSH) & VBM) << 1) : (row & (DC - 1)));
+            const int key = min(k0 + row, a.Tk - 1);
+            dma16(src + (size_t)key * a.kv_ts + ch * 8, d0 + it * 8192u);
+        }
+    };
+    auto fetch = [&](int i) {
+        if (i + 1 < nt) stage((i + 1) * KB, Kb, koff, sK + ((i + 1) & 1) * (KB * D), false);
+        if (i < nt) stage(i * KB, Vb, voff, sV + (i & 1) * (KB * D), true);
+    };
+    // V^T fragment (32 dims x 16 keys of step j, d-tile t): the 16-lane group g4 = lane >> 4 reads keys 16 j + 4 (g4 >> 1) + 0..3 (+ 8 for
+    // the second half of the k-slots) at dims 32 t + 16 (g4 & 1) + (lane & 15) through the transposing read
+    const int l16 = lane & 15, g4 = lane >> 4;
+    const int v_key = 4 * (g4 >> 1) + (l16 >> 2);            // key row (mod 16) whose address this lane supplies
+    const int v_lane_off = v_key * D + (l16 & 3) * 4;
+    const int v_blk = g4 & 1;                                 // which 16-dim half of the 32-dim tile
+    typedef __attribute__((ext_vector_type(4))) short s16x4;
+    typedef __attribute__((address_space(3))) s16x4* lds_s16x4_t;
+
+    f32x16v sc[2];         // S_i^T: key tiles of 32, from X(i) to Y(i)
+    bf16x8 pf[4];          // P_i by 16-key step, from Y(i) to X(i + 1)
+    const float c2 = a.scale * 1.44269504088896340736f;
+
+    auto qk = [&](const bf16_t* sKt) {
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sc[kt][r] = 0.f;
+        // (a K fragment feeds ONE MFMA here -- 64 matrix cycles per head-dim step -- so the reads run KAH steps ahead, not one)
+        constexpr int KAH = OMX_PP32_KAHEAD;
+        bf16x8 kf[KAH + 1][2];
+        auto read_k = [&](int i, bf16x8 (&dst)[2]) {
+            const int ch = i * 2 + hh;
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt) {
+                const int row = kt * 32 + q32;     // A operand: lane & 31 indexes the key row
+                dst[kt] = *reinterpret_cast<const bf16x8*>(&sKt[(row * DC + (ch ^ (row & (DC - 1)))) * 8]);
+            }
+        };
+#pragma unroll
+        for (int i = 0; i < KAH; ++i) read_k(i, kf[i]);
+#if OMX_PP32_CHAINS == 4
+        f32x16v sd[2];     // four accumulator chains (even / odd head-dim steps of each key tile), summed at the end
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sd[kt][r] = 0.f;
+#endif
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            if (i + KAH < NI) read_k(i + KAH, kf[(i + KAH) % (KAH + 1)]);
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt) {
+#if OMX_PP32_CHAINS == 4
+                if (i & 1) sd[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[i % (KAH + 1)][kt], qf[i], sd[kt], 0, 0, 0);
+                else
+#endif
+                sc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[i % (KAH + 1)][kt], qf[i], sc[kt], 0, 0, 0);
+            }
+        }
+#if OMX_PP32_CHAINS == 4
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) sc[kt] += sd[kt];
+#endif
+    };
+    auto pv = [&](const bf16_t* sVt) {
+        constexpr int NF = 4 * NT32, AHEAD = 4;       // fragment idx = j * NT32 + t
+        u32x4 vf[AHEAD];
+        auto read_v = [&](int idx) {
+            const int j = idx / NT32, t = idx % NT32;
+            const int key0 = 16 * j + v_key;                                  // (+ 8 for the second read)
+            const int blk = 2 * t + v_blk;
+            const bf16_t* p0 = sVt + (16 * j) * D + v_lane_off + ((blk ^ ((key0 >> VSH) & VBM)) * 16);
+            const bf16_t* p1 = sVt + (16 * j + 8) * D + v_lane_off + ((blk ^ (((key0 + 8) >> VSH) & VBM)) * 16);
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t)p0);
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t)p1);
+            const u32x2v l2 = __builtin_bit_cast(u32x2v, lo), h2 = __builtin_bit_cast(u32x2v, hi);
+            return u32x4{l2[0], l2[1], h2[0], h2[1]};
+        };
+#pragma unroll
+        for (int idx = 0; idx < AHEAD; ++idx) vf[idx] = read_v(idx);
+#pragma unroll
+        for (int idx = 0; idx < NF; ++idx) {
+            const int j = idx / NT32, t = idx % NT32;
+            const u32x4 cur = vf[idx % AHEAD];
+            if (idx + AHEAD < NF) vf[idx % AHEAD] = read_v(idx + AHEAD);
+            o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, cur), pf[j], o[t], 0, 0, 0);
+        }
+    };
+    auto pair_max = [&](float v) {   // over the two lanes (l, l ^ 32) that hold one query
+        auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+        return fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+    };
+    auto softmax = [&](int i) {
+        const int k0 = i * KB;
+        const bool plain = (k0 + KB <= a.Tk) && (MASK == OMX_MASK_NONE || (MASK == OMX_MASK_CAUSAL && k0 + KB - 1 <= q0 + shift));
+        float mx;
+        if (plain) {
+            // (a lane holds all 32 scores of its query: four independent chains instead of one of 32 dependent operations)
+            float m4[4] = {sc[0][0], sc[0][1], sc[0][2], sc[0][3]};
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) m4[r & 3] = fmaxf(m4[r & 3], sc[kt][r]);
+            mx = pair_max(fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3]))) * c2;
+        } else {
+            mx = -INFINITY;
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = k0 + kt * 32 + 8 * (r >> 2) + 4 * hh + (r & 3);
+                    float v = MASK == OMX_MASK_ADDITIVE ? sc[kt][r] * c2 : sc[kt][r];
+                    bool keep = key < a.Tk;
+                    if (MASK == OMX_MASK_CAUSAL) keep = keep && (key <= qrow + shift);
+                    if (MASK == OMX_MASK_BOOL) {
+                        const uint8_t mb = reinterpret_cast<const uint8_t*>(a.mask)[(size_t)qrow_c * a.Tk + min(key, a.Tk - 1)];
+                        keep = keep & (mb != 0);
+                    }
+                    if (MASK == OMX_MASK_ADDITIVE)
+                        v += 1.44269504088896340736f * bf16_to_f32(reinterpret_cast<const bf16_t*>(a.mask)[(size_t)qrow_c * a.Tk + min(key, a.Tk - 1)]);
+                    v = keep ? v : -INFINITY;
+                    sc[kt][r] = v;
+                    mx = fmaxf(mx, v);
+                }
+            mx = pair_max(mx);
+            if (MASK != OMX_MASK_ADDITIVE) mx *= c2;
+        }
+        const float m_new = fmaxf(m_run, mx);
+        const bool dead = !plain && m_new == -INFINITY;
+        const float alpha = dead ? 1.f : __builtin_amdgcn_exp2f(m_run - m_new);
+        m_run = m_new;
+        l_run *= alpha;
+#pragma unroll
+        for (int t = 0; t < NT32; ++t) o[t] *= alpha;
+        float l4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float sv = sc[kt][8 * j + e];
+                    const float p = dead ? 0.f : __builtin_amdgcn_exp2f((!plain && MASK == OMX_MASK_ADDITIVE) ? sv - m_new : fmaf(sv, c2, -m_new));
+                    l4[e & 3] += p;
+                    pf[kt * 2 + j][e] = (__bf16)p;
+                }
+        l_run += (l4[0] + l4[1]) + (l4[2] + l4[3]);
+    };
+    auto end_even = [&]() {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    };
+    auto end_odd = [&]() {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    };
+    if (nt > 0) {
+        stage(0, Kb, koff, sK, false);
+        __builtin_amdgcn_s_waitcnt(0);     // (the builtin: hipcc must know the Q loads have landed -- see pp_unit)
+        __builtin_amdgcn_s_barrier();
+        if (!late) {
+            for (int i = 0; i <= nt; ++i) {
+                fetch(i);
+                if (i < nt) qk(sK + (i & 1) * (KB * D));
+                if (i > 0) pv(sV + ((i - 1) & 1) * (KB * D));
+                end_even();
+                if (i < nt) softmax(i);
+                end_odd();
+            }
+        } else {
+            for (int i = 0; i <= nt; ++i) {
+                fetch(i);
+                if (i > 0) softmax(i - 1);
+                end_even();
+                if (i < nt) qk(sK + (i & 1) * (KB * D));
+                if (i > 0) pv(sV + ((i - 1) & 1) * (KB * D));
+                end_odd();
+            }
+        }
+    }
+    // normalise and store: lane holds out[qrow][32 t + 8 g + 4 hh + 0..3]
+    {
+        auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(l_run), __float_as_uint(l_run), false, false);
+        const float l_tot = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+        const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+        if (qrow < a.Tq) {
+            bf16_t* op = a.out + (size_t)b * a.o_bs + (size_t)h * a.o_hs + (size_t)qrow * a.o_ts;
+#pragma unroll
+            for (int t = 0; t < NT32; ++t)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    u32x2v wv = {pack_bf16(o[t][4 * g] * inv, o[t][4 * g + 1] * inv), pack_bf16(o[t][4 * g + 2] * inv, o[t][4 * g + 3] * inv)};
+                    *reinterpret_cast<u32x2v*>(op + t * 32 + 8 * g + 4 * hh) = wv;
+                }
+        }
+    }
+}
+
+template <int D, int MASK>
+__global__ __launch_bounds__(512, 1) void attn_prefill_pp32_kernel(const PrefillArgs a) {
+    __shared__ __attribute__((aligned(16))) bf16_t sK2[2][KB * D];
+    __shared__ __attribute__((aligned(16))) bf16_t sV2[2][KB * D];
+    int qt = blockIdx.x, h = blockIdx.y;
+    const int b = blockIdx.z;
+    if ((a.H & 7) == 0) {     // blocks of one head on one XCD (attn_prefill_pp_kernel)
+        const int L = (int)blockIdx.x + (int)gridDim.x * (int)blockIdx.y;
+        const int xcd = L & 7, idx = L >> 3;
+        h = (idx / (int)gridDim.x) * 8 + xcd;
+        qt = idx % (int)gridDim.x;
+    }
+    if (MASK == OMX_MASK_CAUSAL) qt = (int)gridDim.x - 1 - qt;
+    pp32_unit<D, MASK>(a, &sK2[0][0], &sV2[0][0], b, h, qt);
+}
+
 // Stream-K form (no mask): the grid is one block per CU and the units x key tiles are cut into EQUAL shares -- 432 units on 256 CUs run
 // as 1.69 rounds of whole blocks (the second one 69 % full) but as 121.5 tiles per CU here.  A share covers the tail of one unit, whole
 // units, and the head of another; a cut unit is merged by whichever of its two pieces finishes last.  XCD x owns a contiguous eighth
@@ -841,6 +1132,16 @@ int launch_attn_prefill(bf16_t* out, const bf16_t* q, const bf16_t* k, const bf1
             attn_prefill_pp_kernel<128, OMX_MASK_NONE, true><<<grid, block, 0, s>>>(a);
             OMX_LAUNCH_CHECK();
             return 0;
+        }
+        if (const char* p32 = getenv("OMX_ATTN_PP32"); p32 && atoi(p32) != 0 && D == 128) {   // the 32x32x16 form (round 4, opt-in)
+#define OMX_PP32_CASE(MM)                                                            \
+    if (mask_mode == MM) {                                                           \
+        attn_prefill_pp32_kernel<128, MM><<<grid, block, 0, s>>>(a);                 \
+        OMX_LAUNCH_CHECK();                                                          \
+        return 0;                                                                    \
+    }
+            OMX_PP32_CASE(OMX_MASK_NONE) OMX_PP32_CASE(OMX_MASK_CAUSAL) OMX_PP32_CASE(OMX_MASK_BOOL) OMX_PP32_CASE(OMX_MASK_ADDITIVE)
+#undef OMX_PP32_CASE
         }
 #define OMX_PP_CASE(DD, MM)                                                          \
     if (D == DD && mask_mode == MM) {                                                \

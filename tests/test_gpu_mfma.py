@@ -302,6 +302,36 @@ def test_sdpa_two_phase_kernel(omx, monkeypatch, B, H, Hkv, Tq, Tk, D, mode):
     _check(outs["0"], ref)
 
 
+@pytest.mark.parametrize("B,H,Hkv,Tq,Tk,D,mode", [
+    (1, 8, 2, 1100, 1100, 128, "causal"),     # ragged last block and last tile, GQA
+    (1, 8, 8, 700, 700, 128, None),           # joint attention, 8 heads: the XCD-major block order
+    (2, 3, 3, 300, 428, 128, "causal"),       # chunked prefill (Tq < Tk), batch 2, head count not a multiple of 8
+    (1, 2, 2, 260, 260, 128, "bool"),         # explicit bool mask (sliding window)
+    (1, 2, 1, 257, 300, 128, "additive"),
+    (1, 2, 2, 40, 40, 128, "causal"),         # shorter than one tile
+])
+def test_sdpa_two_phase_kernel_on_32x32_mfmas(omx, monkeypatch, B, H, Hkv, Tq, Tk, D, mode):
+    """csrc/attn_prefill.hip attn_prefill_pp32_kernel (round 4, OMX_ATTN_PP32=1): the two-phase block with a wave's 32 query rows as one
+    32-wide MFMA column block (32x32x16 MFMAs: half the MFMA issues for the same flops).  Another summation order inside the MFMAs, so
+    not bit-equal to the 16x16x32 kernels: on the oracle within the SDPA bound, and within a bf16 ulp of the largest value of them."""
+    q = rc.bf16_round(rand((B, H, Tq, D), 61)); k = rc.bf16_round(rand((B, Hkv, Tk, D), 62)); v = rc.bf16_round(rand((B, Hkv, Tk, D), 63))
+    if mode == "bool":
+        mask = rc.create_causal_mask(Tq, Tk - Tq, 100)
+    elif mode == "additive":
+        mask = rc.bf16_round(rand((Tq, Tk), 64) * 2)
+    else:
+        mask = mode
+    scale = D ** -0.5
+    monkeypatch.setenv("OMX_ATTN_PP", "1")
+    base = _sdpa(omx, q, k, v, scale, mask)
+    monkeypatch.setenv("OMX_ATTN_PP32", "1")
+    got = _sdpa(omx, q, k, v, scale, mask)
+    ref = rc.scaled_dot_product_attention(q, k, v, scale, mask, "bf16")
+    _check(got, ref)
+    assert_bf16_close(got, base, 1, atol=2.0 ** -7 * np.abs(base).max())
+    assert not np.array_equal(got, base) or Tq <= 64      # (it IS another kernel)
+
+
 @pytest.mark.parametrize("B,H,Hkv,Tq,Tk,D", [
     (1, 40, 40, 1700, 1700, 128),     # 7 x 40 = 280 units on 256 CUs, ragged last block and last tile
     (2, 16, 4, 2300, 2300, 64),       # batch 2, GQA, head_dim 64: 288 units

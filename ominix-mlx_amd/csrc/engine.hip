@@ -197,6 +197,11 @@ struct omx_qwen3_ {
     std::vector<const bf16_t*> sb_keys;   // scales pointers registered with quant_register_sb
     bf16_t* dq_buf = nullptr;                // dequantised weight of the GEMM in flight (batched prefill)
     size_t dq_cap = 0;
+    // dequantised copies of the layers' packed matrices kept BETWEEN prompts (round 4): 288 GB of HBM hold a dense 8B model's 14 GB of
+    // them next to the packed weights, and every prompt after the first skips the dequantise launches (key: the packed words)
+    std::map<const uint32_t*, bf16_t*> dq_cache;
+    size_t dq_cache_bytes = 0;
+    int dq_cache_mode = -1;                  // -1 undecided, 0 off, 1 on
     const bf16_t *embed = nullptr, *final_norm = nullptr, *lm_head = nullptr;
     bool weights_resolved = false;
 
@@ -300,6 +305,12 @@ int add_sampling_noise(omx_qwen3 m, hipStream_t s) {
 
 int resolve_weights(omx_qwen3 m) {
     if (m->weights_resolved) return 0;
+    if (!m->dq_cache.empty()) {   // the weights changed under the dequantised copies of the prompt pass
+        (void)hipStreamSynchronize(m->stream);
+        for (auto& kv : m->dq_cache) (void)hipFree(kv.second);
+        m->dq_cache.clear();
+        m->dq_cache_bytes = 0;
+    }
     auto get = [&](const std::string& n, const bf16_t** out) -> int {
         auto it = m->named.find(n);
         if (it == m->named.end()) return set_error("WeightNotFound: %s", n.c_str());   // error.rs:6-32
@@ -1126,8 +1137,32 @@ int prefill_prefix_batched(omx_qwen3 m, int T, int off, const EncodeOpts* enc = 
     // quantized checkpoint: each weight is dequantised into one scratch matrix right before its GEMM (MLX's qmm does
     // the same per tile); K is the contraction width of that weight
     // `at`: element offset inside the scratch, so that the members of one segmented launch (q | k | v, gate | up) coexist
+    // OMX_DEQUANT_CACHE=1 / 0: keep / do not keep the dequantised matrices between prompts; default: keep them for a dense model when
+    // they take at most a quarter of the free HBM and 64 GB (Qwen3-8B: 13.7 GB; a sparse-MoE model's attention matrices only on request)
+    if (quant && m->dq_cache_mode < 0) {
+        const char* ce = getenv("OMX_DEQUANT_CACHE");
+        const size_t per_layer = ((size_t)H * D * hd * 2 + (size_t)2 * Hkv * D * hd + (c.num_experts == 0 ? (size_t)3 * I * hd : 0)) * 2;
+        size_t free_b = 0, total_b = 0;
+        (void)hipMemGetInfo(&free_b, &total_b);
+        const size_t need_b = per_layer * (size_t)c.num_hidden_layers;
+        m->dq_cache_mode = ce ? (ce[0] == '1') : (c.num_experts == 0 && need_b <= free_b / 4 && need_b <= ((size_t)64 << 30));
+    }
     auto W = [&](const bf16_t* dense, const QMat* qm, int K, size_t at = 0) -> const bf16_t* {
         if (!quant) return dense;
+        if (m->dq_cache_mode == 1) {
+            auto it = m->dq_cache.find(qm->w);
+            if (it != m->dq_cache.end()) return it->second;
+            bf16_t* keep = nullptr;
+            const size_t bytes = (size_t)qm->n * K * 2;
+            if (hipMalloc((void**)&keep, bytes) == hipSuccess) {
+                if (launch_dequantize_bf16(keep, qm->w, qm->scales, qm->biases, qm->n, K, c.quant_group, c.quant_bits, f16, s, f16)) { (void)hipFree(keep); return nullptr; }
+                m->dq_cache[qm->w] = keep;
+                m->dq_cache_bytes += bytes;
+                return keep;
+            }
+            (void)hipGetLastError();      // out of memory: no cache from here on, what is cached stays
+            m->dq_cache_mode = 0;
+        }
         if (launch_dequantize_bf16(m->dq_buf + at, qm->w, qm->scales, qm->biases, qm->n, K, c.quant_group, c.quant_bits, f16, s, f16)) return nullptr;
         return m->dq_buf + at;
     };
@@ -1452,6 +1487,7 @@ int omx_qwen3_destroy(omx_qwen3 m) {
     for (const bf16_t* k : m->sb_keys) quant_unregister_sb(k);
     for (void* p : m->owned) (void)hipFree(p);
     if (m->dq_buf) (void)hipFree(m->dq_buf);
+    for (auto& kv : m->dq_cache) (void)hipFree(kv.second);
     if (m->verify_logits) (void)hipFree(m->verify_logits);
     if (m->verify_tokens) (void)hipFree(m->verify_tokens);
     if (m->pf_ep_partial) (void)hipFree(m->pf_ep_partial);

@@ -464,6 +464,37 @@ def test_quantized_checkpoint_decode_matches_oracle(omx, name, bits, group):
             break
 
 
+def test_quantized_prompt_keeps_dequantised_matrices_between_prompts(omx, monkeypatch):
+    """engine.hip dq_cache (round 4): a packed model's prompt pass dequantises each layer's matrices for its GEMMs; with HBM to spare the
+    dequantised copies are kept, so every prompt after the first skips those launches.  Same values either way: the first prompt, the
+    same prompt again on the emptied cache, and a run with OMX_DEQUANT_CACHE=0 give bit-identical logits and tokens."""
+    from ominix_mlx_amd import engine
+    cfg = CONFIGS["gqa4_d128"]
+    prompt = synth.prompt_ids(80, cfg.vocab_size)
+    kw = dict(hidden_size=cfg.hidden_size, num_hidden_layers=cfg.num_hidden_layers, intermediate_size=cfg.intermediate_size,
+              num_attention_heads=cfg.num_attention_heads, num_key_value_heads=cfg.num_key_value_heads, head_dim=cfg.head_dim,
+              vocab_size=cfg.vocab_size, rms_norm_eps=cfg.rms_norm_eps, rope_theta=cfg.rope_theta,
+              tie_word_embeddings=cfg.tie_word_embeddings, rope_scaling=cfg.rope_scaling, max_context=256)
+    runs = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("OMX_DEQUANT_CACHE", mode)
+        m = engine.Model(quantization={"bits": 4, "group_size": 64}, **kw)
+        m.synth_weights()
+        out = []
+        for _ in range(3):
+            m.reset()
+            first = m.prefill(prompt)
+            out.append((first, m.last_logits().copy(), m.decode(4).copy()))
+        runs[mode] = out
+        m.close()
+    ref = runs["0"][0]
+    for mode in ("1", "0"):
+        for first, logits, toks in runs[mode]:
+            assert first == ref[0]
+            np.testing.assert_array_equal(logits, ref[1])
+            np.testing.assert_array_equal(toks, ref[2])
+
+
 @pytest.mark.parametrize("serial_prefill", ["0", "1"])
 def test_quantized_checkpoint_with_float16_scales(omx, tmp_path, monkeypatch, serial_prefill):
     """(serial_prefill 0: the 48-token prompt takes the float16 matrix-core pass, 1: the decode step token by token.)

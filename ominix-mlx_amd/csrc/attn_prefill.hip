@@ -1107,6 +1107,13 @@ int launch_attn_prefill(bf16_t* out, const bf16_t* q, const bf16_t* k, const bf1
     // causal mask its blocks differ in length up to the whole sequence and nothing pairs a long one with a short one on a CU (the
     // single-phase kernel does, two blocks per CU): 2048 x 32 heads ran 82 us against 65, so causal shapes take it only when the grid is
     // many rounds deep
+    // (round 5) the 4-wave persistent kernel for long unmasked sequences (OMX_ATTN_W4=0: the kernels below)
+    {
+        const char* w4 = getenv("OMX_ATTN_W4");
+        const bool want = w4 ? atoi(w4) != 0 : false;
+        if (want && Tq >= 1024 && attn_flash4_supported(B, H, Hkv, Tq, Tk, D, mask_mode, f16))
+            return launch_attn_flash4(out, q, k, v, B, H, Hkv, Tq, Tk, kv_batch_stride, kv_head_stride, scale, s, out_token_major, layout);
+    }
     const char* ppenv = getenv("OMX_ATTN_PP");
     const long pp_blocks = (long)((Tq + 255) / 256) * H * B;
     if (!f16 && (ppenv ? atoi(ppenv) != 0 : (Tq >= 1024 && (mask_mode != OMX_MASK_CAUSAL || pp_blocks >= 2048)))) {

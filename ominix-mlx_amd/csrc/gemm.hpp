@@ -121,6 +121,12 @@ int launch_attn_prefill(bf16_t* out, const bf16_t* q, const bf16_t* k, const bf1
                         const void* mask, hipStream_t s, bool out_token_major = false,
                         const AttnLayout* layout = nullptr, bool f16 = false);   // f16: float16 q / k / v / out (no mask or causal)
 
+// the 4-wave persistent form (attn_flash4.hip): head_dim 128, bf16, no mask, Tk a multiple of 64
+bool attn_flash4_supported(int B, int H, int Hkv, int Tq, int Tk, int D, int mask_mode, bool f16);
+int launch_attn_flash4(bf16_t* out, const bf16_t* q, const bf16_t* k, const bf16_t* v, int B, int H, int Hkv, int Tq, int Tk,
+                       int64_t kv_batch_stride, int64_t kv_head_stride, float scale, hipStream_t s, bool out_token_major,
+                       const AttnLayout* layout);
+
 // M <= 8 rows: weights streamed once against all rows (gemv_rows.hip); same epilogue semantics as the GEMM kernels
 bool gemv_rows_supported(int M, int N, int K, const void* x, const void* w);
 // ... and the segmented projection (GemmSegs above) in one such launch: q / k / v, or gate / up with the SwiGLU epilogue

@@ -229,6 +229,49 @@ def _check(got, ref):
 
 
 @pytest.mark.parametrize("B,H,Hkv,Tq,Tk,D", [
+    (1, 8, 8, 1024, 1024, 128),      # 8 heads: the XCD-major unit walk, 4 units of 256 rows per head
+    (1, 3, 3, 1100, 1280, 128),      # Sq != Sk, ragged last query block, head count not a multiple of 8
+    (2, 8, 2, 1024, 512, 128),       # batch 2, GQA, the shortest key length the kernel takes (8 tiles)
+    (1, 16, 16, 1536, 768, 128),     # more units than the walk's first round on a 256-CU part only with 16 heads x 6 blocks: two units per workgroup on small parts
+])
+@pytest.mark.parametrize("thr", ["8", "0"])
+def test_sdpa_four_wave_persistent_kernel(omx, monkeypatch, B, H, Hkv, Tq, Tk, D, thr):
+    """csrc/attn_flash4.hip (round 5, OMX_ATTN_W4=1): 4 waves x 64 query rows, 32x32x16 MFMAs, the per-unit body as generated assembly
+    (tools/gen_flash4_asm.py), K / V as one continuous LDS-DMA stream over the units a workgroup walks, deferred rescale (threshold 8, and
+    0 = the textbook online softmax on the same code).  On the oracle within the SDPA bound and within a few bf16 ulps of the 8-wave kernel."""
+    q = rc.bf16_round(rand((B, H, Tq, D), 71)); k = rc.bf16_round(rand((B, Hkv, Tk, D), 72)); v = rc.bf16_round(rand((B, Hkv, Tk, D), 73))
+    scale = D ** -0.5
+    monkeypatch.setenv("OMX_ATTN_W4", "0")
+    old = _sdpa(omx, q, k, v, scale, None)
+    monkeypatch.setenv("OMX_ATTN_W4", "1")
+    monkeypatch.setenv("OMX_ATTN_W4_THR", thr)
+    new = _sdpa(omx, q, k, v, scale, None)
+    ref = rc.scaled_dot_product_attention(q, k, v, scale, None, "bf16")
+    _check(new, ref)
+    assert_bf16_close(new, old, 4, atol=4e-3 * np.abs(ref).max())
+
+
+def test_sdpa_four_wave_kernel_spike_forces_the_deferred_rescale(omx, monkeypatch):
+    """cdna_hip_programming.md T13 / rule 26: bounded random data never takes the deferred-rescale branch after the first tiles; one key row
+    spiked against one query row at a late tile does, in both query blocks of a wave and for a single row only.  Threshold 8 == threshold 0
+    to bf16 rounding, both on the float64 oracle."""
+    B, H, T, D = 1, 8, 1024, 128
+    q = rc.bf16_round(rand((B, H, T, D), 74)); k = rc.bf16_round(rand((B, H, T, D), 75) * 0.1); v = rc.bf16_round(rand((B, H, T, D), 76))
+    k[0, 1, 700] = rc.bf16_round(q[0, 1, 230] * 6)      # query 230 (wave 3, block 1 of unit 0), key tile 10
+    k[0, 1, 900] = rc.bf16_round(q[0, 1, 5] * 9)        # query 5 (wave 0, block 0), key tile 14: a second rescale of the same unit
+    k[0, 5, 1000] = rc.bf16_round(q[0, 5, 600] * 7)     # another head, the unit's last tile group
+    scale = D ** -0.5
+    ref = rc.scaled_dot_product_attention(q, k, v, scale, None, "bf16")
+    monkeypatch.setenv("OMX_ATTN_W4", "1")
+    outs = {}
+    for thr in ("8", "0"):
+        monkeypatch.setenv("OMX_ATTN_W4_THR", thr)
+        outs[thr] = _sdpa(omx, q, k, v, scale, None)
+        _check(outs[thr], ref)
+    assert_bf16_close(outs["8"], outs["0"], 4, atol=4e-3 * np.abs(ref).max())
+
+
+@pytest.mark.parametrize("B,H,Hkv,Tq,Tk,D", [
     (1, 8, 2, 128, 128, 128),     # GQA prefill
     (1, 4, 4, 200, 200, 64),      # ragged, D = 64
     (2, 2, 1, 65, 65, 128),       # batch 2, one-past-a-tile

@@ -26,6 +26,8 @@
 
 #include "gemm.hpp"
 
+#include "attn_flash4_clobbers.inc"   // F4_CLOBBERS: the registers the generated body owns
+
 namespace omx {
 namespace {
 
@@ -46,7 +48,8 @@ struct Flash4Args {
     int xcd_map;     // units of head x on XCD x % 8 (B * H and the grid multiples of 8)
 };
 
-template <int THR>
+// VAR 0: deferred rescale (threshold 8); 1: threshold 0; 2..5 (-DOMX_F4_DIAG): timing-only builds without DMA / softmax VALU / LDS reads / all three
+template <int VAR>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void attn_flash4_kernel(const Flash4Args a) {
     __shared__ __attribute__((aligned(16))) unsigned char sK[F4_RING * F4_TILE_B];
     __shared__ __attribute__((aligned(16))) unsigned char sV[F4_RING * F4_TILE_B];
@@ -153,31 +156,55 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         }
         const bf16_t* qbase = a.q + (size_t)b * a.q_bs + (size_t)h * a.q_hs;
         bf16_t* obase = a.out + (size_t)b * a.o_bs + (size_t)h * a.o_hs;
-        if (THR > 0) {
+#define F4_OPERANDS                                                                                                                 \
+        :                                                                                                                           \
+        : "v"(koff[0]), "v"(koff[1]), "v"(koff[2]), "v"(koff[3]), "v"(voff[0]), "v"(voff[1]), "v"(voff[2]), "v"(voff[3]),           \
+          "v"(kro[0]), "v"(kro[1]), "v"(kro[2]), "v"(kro[3]), "v"(kro[4]), "v"(kro[5]), "v"(kro[6]), "v"(kro[7]),                   \
+          "v"(vro[0]), "v"(vro[1]), "v"(vro[2]), "v"(vro[3]), "v"(qoff[0]), "v"(qoff[1]), "v"(ooff[0]), "v"(ooff[1]),               \
+          "s"(qbase), "s"(obase), "s"(kcur), "s"(vcur), "s"(knext), "s"(vnext),                                                     \
+          "s"(stride_b), "s"(nt), "s"(c2), "s"(kdst), "s"(vdst), "s"(rowmask[0]), "s"(rowmask[1])                                   \
+        : F4_CLOBBERS
+        if (VAR == 0) {
             asm volatile(
 #include "attn_flash4_body.inc"
-                :
-                : "v"(koff[0]), "v"(koff[1]), "v"(koff[2]), "v"(koff[3]), "v"(voff[0]), "v"(voff[1]), "v"(voff[2]), "v"(voff[3]),
-                  "v"(kro[0]), "v"(kro[1]), "v"(kro[2]), "v"(kro[3]), "v"(kro[4]), "v"(kro[5]), "v"(kro[6]), "v"(kro[7]),
-                  "v"(vro[0]), "v"(vro[1]), "v"(vro[2]), "v"(vro[3]), "v"(qoff[0]), "v"(qoff[1]), "v"(ooff[0]), "v"(ooff[1]),
-                  "s"(qbase), "s"(obase), "s"(kcur), "s"(vcur), "s"(knext), "s"(vnext),
-                  "s"(stride_b), "s"(nt), "s"(c2), "s"(kdst), "s"(vdst), "s"(rowmask[0]), "s"(rowmask[1])
-                :
-#include "attn_flash4_clobbers.inc"
-            );
-        } else {
+                F4_OPERANDS);
+        } else if (VAR == 1) {
             asm volatile(
 #include "attn_flash4_body_thr0.inc"
-                :
-                : "v"(koff[0]), "v"(koff[1]), "v"(koff[2]), "v"(koff[3]), "v"(voff[0]), "v"(voff[1]), "v"(voff[2]), "v"(voff[3]),
-                  "v"(kro[0]), "v"(kro[1]), "v"(kro[2]), "v"(kro[3]), "v"(kro[4]), "v"(kro[5]), "v"(kro[6]), "v"(kro[7]),
-                  "v"(vro[0]), "v"(vro[1]), "v"(vro[2]), "v"(vro[3]), "v"(qoff[0]), "v"(qoff[1]), "v"(ooff[0]), "v"(ooff[1]),
-                  "s"(qbase), "s"(obase), "s"(kcur), "s"(vcur), "s"(knext), "s"(vnext),
-                  "s"(stride_b), "s"(nt), "s"(c2), "s"(kdst), "s"(vdst), "s"(rowmask[0]), "s"(rowmask[1])
-                :
-#include "attn_flash4_clobbers.inc"
-            );
+                F4_OPERANDS);
         }
+#ifdef OMX_F4_DIAG
+        else if (VAR == 2) {
+            asm volatile(
+#include "attn_flash4_body_d2.inc"
+                F4_OPERANDS);
+        } else if (VAR == 3) {
+            asm volatile(
+#include "attn_flash4_body_d3.inc"
+                F4_OPERANDS);
+        } else if (VAR == 4) {
+            asm volatile(
+#include "attn_flash4_body_d4.inc"
+                F4_OPERANDS);
+        } else if (VAR == 5) {
+            asm volatile(
+#include "attn_flash4_body_d5.inc"
+                F4_OPERANDS);
+        } else if (VAR == 6) {
+            asm volatile(
+#include "attn_flash4_body_d6.inc"
+                F4_OPERANDS);
+        } else if (VAR == 7) {
+            asm volatile(
+#include "attn_flash4_body_d7.inc"
+                F4_OPERANDS);
+        } else if (VAR == 8) {
+            asm volatile(
+#include "attn_flash4_body_d8.inc"
+                F4_OPERANDS);
+        }
+#endif
+#undef F4_OPERANDS
         kcur = knext;
         vcur = vnext;
     }
@@ -232,9 +259,20 @@ int launch_attn_flash4(bf16_t* out, const bf16_t* q, const bf16_t* k, const bf16
     OMX_REQUIRE(((int64_t)Tq * a.q_ts + 8) * 2 < (int64_t)1 << 32 && ((int64_t)Tq * a.o_ts + 8) * 2 < (int64_t)1 << 32,
                 "flash attention: query / output row stride too large for %d rows", Tq);
     const char* te = getenv("OMX_ATTN_W4_THR");
-    const int thr = te ? atoi(te) : 8;
-    if (thr == 0) attn_flash4_kernel<0><<<G, 256, 0, s>>>(a);
-    else attn_flash4_kernel<8><<<G, 256, 0, s>>>(a);
+    int var = (te && atoi(te) == 0) ? 1 : 0;
+#ifdef OMX_F4_DIAG
+    if (const char* ve = getenv("OMX_ATTN_W4_VAR")) var = atoi(ve);
+    if (var == 2) attn_flash4_kernel<2><<<G, 256, 0, s>>>(a);
+    else if (var == 3) attn_flash4_kernel<3><<<G, 256, 0, s>>>(a);
+    else if (var == 4) attn_flash4_kernel<4><<<G, 256, 0, s>>>(a);
+    else if (var == 5) attn_flash4_kernel<5><<<G, 256, 0, s>>>(a);
+    else if (var == 6) attn_flash4_kernel<6><<<G, 256, 0, s>>>(a);
+    else if (var == 7) attn_flash4_kernel<7><<<G, 256, 0, s>>>(a);
+    else if (var == 8) attn_flash4_kernel<8><<<G, 256, 0, s>>>(a);
+    else
+#endif
+    if (var == 1) attn_flash4_kernel<1><<<G, 256, 0, s>>>(a);
+    else attn_flash4_kernel<0><<<G, 256, 0, s>>>(a);
     OMX_LAUNCH_CHECK();
     return 0;
 }

@@ -1110,7 +1110,7 @@ int launch_attn_prefill(bf16_t* out, const bf16_t* q, const bf16_t* k, const bf1
     // (round 5) the 4-wave persistent kernel for long unmasked sequences (OMX_ATTN_W4=0: the kernels below)
     {
         const char* w4 = getenv("OMX_ATTN_W4");
-        const bool want = w4 ? atoi(w4) != 0 : false;
+        const bool want = w4 ? atoi(w4) != 0 : true;
         if (want && Tq >= 1024 && attn_flash4_supported(B, H, Hkv, Tq, Tk, D, mask_mode, f16))
             return launch_attn_flash4(out, q, k, v, B, H, Hkv, Tq, Tk, kv_batch_stride, kv_head_stride, scale, s, out_token_major, layout);
     }

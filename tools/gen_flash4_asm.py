@@ -81,7 +81,8 @@ def sp(lo):
 
 
 class Gen:
-    def __init__(self, thr):
+    def __init__(self, thr, diag=()):
+        self.diag = set(diag)     # timing-only builds (results garbage): "nodma", "novalu", "nolds" drop that class of instructions
         self.lines = []
         self.lds = []            # outstanding LDS operations (ids) in issue order
         self.next_id = 0
@@ -89,6 +90,23 @@ class Gen:
         self.uid = 0
 
     def e(self, s):
+        op = s.split()[0]
+        if "nodma" in self.diag and (op == "global_load_lds_dwordx4" or s.startswith("s_add_u32 m0")):
+            return
+        if "novalu" in self.diag and op in ("v_exp_f32", "v_add_f32", "v_cvt_pk_bf16_f32", "v_max_f32", "v_max3_f32", "v_fma_f32", "v_mul_f32",
+                                            "v_permlane32_swap_b32", "v_cmp_gt_f32_e64", "v_cndmask_b32_e64", "v_mov_b32", "s_getpc_b64", "s_branch") \
+                and "F4_store" not in s:
+            return
+        if "novalu" in self.diag and (s.startswith("s_cbranch_scc0 F4_norescale") or s.startswith("s_add_u32 s%d, s%d, 12" % (S_RET, S_RET))):
+            return
+        if "expmov" in self.diag and op == "v_exp_f32":
+            s = s.replace("v_exp_f32", "v_mov_b32")
+        if "nobar" in self.diag and (op == "s_barrier" or s.startswith("s_waitcnt vmcnt(8)")):
+            return
+        if "noadd" in self.diag and op == "v_add_f32":
+            return
+        if "nolds" in self.diag and (op.startswith("ds_read") or s.startswith("s_waitcnt lgkmcnt")):
+            return
         self.lines.append(s)
 
     def lds_op(self, s):
@@ -139,7 +157,8 @@ def elem(n):
 
 
 def phase_a(g_, slot, cur, nxt, has_next):
-    """p = 2^t (in place in S[cur]), row sums, P; S[nxt] = K Q^T; the 8 transposing reads of V_T key step 0"""
+    """p = 2^t (in place in S[cur]), row sums, P; S[nxt] = K Q^T; the transposing reads of V_T key step 0 (gaps 0..7) and the first half of
+    key step 1 (gaps 28..31)"""
     g_.lds_wait_all()                       # K fragments (and everything else phase B read) are in
     pending = []
     vids = {}
@@ -161,41 +180,50 @@ def phase_a(g_, slot, cur, nxt, has_next):
                    "v_cvt_pk_bf16_f32 %s, %s, %s" % (vr(P(j, qb) + (e0 >> 1)), vr(r0), vr(r1))]
         if gap < 8:
             vids[(0, gap >> 1, gap & 1)] = read_v(g_, slot, 0, gap >> 1, gap & 1)
+        if gap >= 28:
+            k = gap - 28
+            vids[(1, k >> 1, k & 1)] = read_v(g_, slot, 1, k >> 1, k & 1)
     for op in pending:
         g_.e(op)
     return vids
 
 
-def phase_b(g_, slot, nxt, has_next, vids):
-    """O += V^T P with the DMA, the fragment reads and the start of the next tile's softmax in the gaps"""
+def phase_b(g_, slot, nxt, has_next, vids, in_tail):
+    """O += V^T P with the DMA, the fragment reads and the start of the next tile's softmax in the gaps.  The stream cursors cross into the
+    next unit at static places (nt % 4 == 0): V (tile + 3 issued here, tile + 4 next) after the first tile of the unit's LAST group, K
+    (tile + 5 here, tile + 6 next) after the third tile of the group before it = the loop's last iteration"""
     g_.e("s_waitcnt vmcnt(8)")
     g_.e("s_barrier")
     fill = {gap: [] for gap in range(32)}
-    # ---- LDS-DMA: V_{T+3} pieces in gaps 0..3, K_{T+5} in gaps 4..7; (m0 write -> DMA needs an instruction in between: the list order) ----
+    # ---- LDS-DMA: V_{T+3} pieces in gaps 0..3, K_{T+5} in gaps 4..7 (m0 write first in its gap, the DMA last: an instruction in between) ----
     vslot, kslot = (slot + 3) & 3, (slot + 1) & 3
     for it in range(4):
         fill[it].insert(0, ("salu", "s_add_u32 m0, %s, %d" % (OP["vdst"], vslot * 16384 + it * 4096)))
         fill[it].append(("dma", "global_load_lds_dwordx4 %s, %s" % (OP["voff%d" % it], sp(S_VPTR))))
-    fill[4] += [("salu", "s_add_u32 s%d, s%d, %s" % (S_VPTR, S_VPTR, OP["stride"])), ("salu", "s_addc_u32 s%d, s%d, 0" % (S_VPTR + 1, S_VPTR + 1)),
-                ("salu", "s_add_u32 s%d, s%d, 1" % (S_VT, S_VT))]
-    fill[5] += [("salu", "s_cmp_eq_u32 s%d, %s" % (S_VT, OP["nt"])), ("salu", "s_cselect_b64 %s, %s, %s" % (sp(S_VPTR), OP["vnext"], sp(S_VPTR)))]
+    if in_tail and slot == 0:
+        vcur = [("salu", "s_mov_b64 %s, %s" % (sp(S_VPTR), OP["vnext"]))]
+    else:
+        vcur = [("salu", "s_add_u32 s%d, s%d, %s" % (S_VPTR, S_VPTR, OP["stride"])), ("salu", "s_addc_u32 s%d, s%d, 0" % (S_VPTR + 1, S_VPTR + 1))]
+    fill[8] += vcur
     if has_next:
         for it in range(4):
             fill[4 + it].insert(0, ("salu", "s_add_u32 m0, %s, %d" % (OP["kdst"], kslot * 16384 + it * 4096)))
             fill[4 + it].append(("dma", "global_load_lds_dwordx4 %s, %s" % (OP["koff%d" % it], sp(S_KPTR))))
-        fill[8] += [("salu", "s_add_u32 s%d, s%d, %s" % (S_KPTR, S_KPTR, OP["stride"])), ("salu", "s_addc_u32 s%d, s%d, 0" % (S_KPTR + 1, S_KPTR + 1)),
-                    ("salu", "s_add_u32 s%d, s%d, 1" % (S_KT, S_KT))]
-        fill[9] += [("salu", "s_cmp_eq_u32 s%d, %s" % (S_KT, OP["nt"])), ("salu", "s_cselect_b64 %s, %s, %s" % (sp(S_KPTR), OP["knext"], sp(S_KPTR)))]
-    # ---- V^T fragments of key steps 1..3: one read per gap over gaps 0..23 ----
-    for gap in range(24):
-        j, db, half = (gap >> 3) + 1, (gap & 7) >> 1, gap & 1
+        kcur = [("salu", "s_add_u32 s%d, s%d, %s" % (S_KPTR, S_KPTR, OP["stride"])), ("salu", "s_addc_u32 s%d, s%d, 0" % (S_KPTR + 1, S_KPTR + 1))]
+        if slot == 2 and not in_tail:
+            kcur += [("salu", "s_cmp_eq_u32 s%d, 1" % S_LOOP), ("salu", "s_cselect_b64 %s, %s, %s" % (sp(S_KPTR), OP["knext"], sp(S_KPTR)))]
+        fill[9] += kcur
+    # ---- V^T fragments: second half of key step 1 in gaps 0..3, step 2 in gaps 4..11, step 3 in gaps 12..19 (each step complete five gaps
+    #      before its first MFMA: ONE wait per step) ----
+    for gap in range(20):
+        k = gap + 4
+        j, db, half = (k >> 3) + 1, (k & 7) >> 1, k & 1
         fill[gap].append(("vread", (j, db, half)))
     if has_next:
-        # ---- K_{T+2} fragments: two per gap over gaps 8..15 ----
-        for gap in range(8, 16):
-            for u in range(2):
-                f = 2 * (gap - 8) + u
-                fill[gap].append(("kread", (f & 1, f >> 1)))          # (kb, i): head-dim step outermost, the order phase A consumes them in
+        # ---- K_{T+2} fragments: one per gap over gaps 8..23 ----
+        for gap in range(8, 24):
+            f = gap - 8
+            fill[gap].append(("kread", (f & 1, f >> 1)))          # (kb, i): head-dim step outermost, the order phase A consumes them in
         # ---- row max of S_next: gaps 1..16, one v_max3 per query block per gap ----
         for k in range(16):
             kb, r = k >> 3, 2 * (k & 7)
@@ -205,40 +233,49 @@ def phase_b(g_, slot, nxt, has_next, vids):
                     fill[1 + k].append(("valu", "v_max_f32 %s, %s, %s" % (vr(MX[q2]), vr(a0), vr(a0 + 1))))
                 else:
                     fill[1 + k].append(("valu", "v_max3_f32 %s, %s, %s, %s" % (vr(MX[q2]), vr(MX[q2]), vr(a0), vr(a0 + 1))))
-        # ---- both halves of a row, the deferred-rescale decision: gaps 17, 18 ----
+        # ---- both halves of a row, the deferred-rescale decision: gaps 17..20 ----
         t0, t1, t2, t3 = TMP[0], TMP[1], TMP[2], TMP[3]
-        fill[17] += [("valu", "v_mov_b32 %s, %s" % (vr(t0), vr(MX[0]))), ("valu", "v_mov_b32 %s, %s" % (vr(t1), vr(MX[1]))),
-                     ("salu", "s_nop 1"),
-                     ("valu", "v_permlane32_swap_b32 %s, %s" % (vr(t0), vr(MX[0]))), ("valu", "v_permlane32_swap_b32 %s, %s" % (vr(t1), vr(MX[1]))),
-                     ("valu", "v_max_f32 %s, %s, %s" % (vr(MX[0]), vr(MX[0]), vr(t0))), ("valu", "v_max_f32 %s, %s, %s" % (vr(MX[1]), vr(MX[1]), vr(t1)))]
+        fill[17] += [("early", "v_mov_b32 %s, %s" % (vr(t0), vr(MX[0]))), ("early", "v_mov_b32 %s, %s" % (vr(t1), vr(MX[1])))]
+        # (two instructions -- this gap's fragment reads -- separate the copies from the swaps)
+        fill[17] += [("late", "v_permlane32_swap_b32 %s, %s" % (vr(t0), vr(MX[0]))), ("late", "v_permlane32_swap_b32 %s, %s" % (vr(t1), vr(MX[1])))]
+        fill[18] += [("valu", "v_max_f32 %s, %s, %s" % (vr(MX[0]), vr(MX[0]), vr(t0))), ("valu", "v_max_f32 %s, %s, %s" % (vr(MX[1]), vr(MX[1]), vr(t1)))]
         for q2 in range(2):
-            fill[18].append(("valu", "v_mul_f32 %s, %s, %s" % (vr(MX[q2]), OP["c2"], vr(MX[q2]))))
+            fill[18].append(("late", "v_mul_f32 %s, %s, %s" % (vr(MX[q2]), OP["c2"], vr(MX[q2]))))
         for q2, tt in ((0, t2), (1, t3)):
             if g_.thr > 0:
-                fill[18].append(("valu", "v_add_f32 %s, 0x%08x, %s" % (vr(tt), f32_bits(g_.thr), vr(MR[q2]))))
-                fill[18].append(("valu", "v_cmp_gt_f32_e64 %s, %s, %s" % (sp(S_NEED[q2]), vr(MX[q2]), vr(tt))))
+                fill[19].append(("valu", "v_add_f32 %s, 0x%08x, %s" % (vr(tt), f32_bits(g_.thr), vr(MR[q2]))))
+                fill[19].append(("late", "v_cmp_gt_f32_e64 %s, %s, %s" % (sp(S_NEED[q2]), vr(MX[q2]), vr(tt))))
             else:
-                fill[18].append(("valu", "v_cmp_gt_f32_e64 %s, %s, %s" % (sp(S_NEED[q2]), vr(MX[q2]), vr(MR[q2]))))
-            fill[18].append(("valu", "v_cndmask_b32_e64 %s, %s, %s, %s" % (vr(MN[q2]), vr(MR[q2]), vr(MX[q2]), sp(S_NEED[q2]))))
-        # ---- t = s c - m: 64 values over gaps 19..31 ----
-        for x in range(64):
-            kb, q2, r = x >> 5, (x >> 4) & 1, x & 15
-            gap = 19 + x * 13 // 64
-            reg = S(nxt, kb, q2) + r
-            fill[gap].append(("valu", "v_fma_f32 %s, %s, %s, -%s" % (vr(reg), vr(reg), OP["c2"], vr(MN[q2]))))
+                fill[19].append(("late", "v_cmp_gt_f32_e64 %s, %s, %s" % (sp(S_NEED[q2]), vr(MX[q2]), vr(MR[q2]))))
+            fill[20].append(("valu", "v_cndmask_b32_e64 %s, %s, %s, %s" % (vr(MN[q2]), vr(MR[q2]), vr(MX[q2]), sp(S_NEED[q2]))))
+        # ---- t = s c - m: 64 values: 3 in gap 20, 5 per gap in 21..23, the rest over 24..31 ----
+        plan = [(20, 3), (21, 5), (22, 5), (23, 5)]
+        left = 64 - sum(n for _, n in plan)
+        for k, gap in enumerate(range(24, 32)):
+            plan.append((gap, left // 8 + (1 if k < left % 8 else 0)))
+        x = 0
+        for gap, n in plan:
+            for _ in range(n):
+                kb, q2, r = x >> 5, (x >> 4) & 1, x & 15
+                reg = S(nxt, kb, q2) + r
+                fill[gap].append(("late" if gap == 20 else "valu", "v_fma_f32 %s, %s, %s, -%s" % (vr(reg), vr(reg), OP["c2"], vr(MN[q2]))))
+                x += 1
+        assert x == 64
     # ---- emit ----
-    kids = []
     for gap in range(32):
         j, db, qb = gap >> 3, (gap >> 1) & 3, gap & 1
-        g_.lds_wait([vids[(j, db, 0)], vids[(j, db, 1)]])
+        if gap % 8 == 0:
+            g_.lds_wait([vids[(j, d, h)] for d in range(4) for h in range(2)])
         mfma_o(g_, qb, db, j & 1, j)
-        for kind, what in [f for f in fill[gap] if f[0] != "dma"] + [f for f in fill[gap] if f[0] == "dma"]:
+        order = [f for f in fill[gap] if f[0] == "early"] + [f for f in fill[gap] if f[0] not in ("dma", "late", "early")] + \
+                [f for f in fill[gap] if f[0] == "late"] + [f for f in fill[gap] if f[0] == "dma"]
+        for kind, what in order:
             if kind == "vread":
                 jj, dd, hh = what
                 vids[(jj, dd, hh)] = read_v(g_, slot, jj, dd, hh)
             elif kind == "kread":
                 kb, i = what
-                kids.append(read_k(g_, (slot + 2) & 3, kb, i))
+                read_k(g_, (slot + 2) & 3, kb, i)
             else:
                 g_.e(what)
     if has_next:
@@ -259,9 +296,9 @@ def f32_bits(x):
     return struct.unpack("<I", struct.pack("<f", x))[0]
 
 
-def tile_step(g_, slot, cur, nxt, has_next):
+def tile_step(g_, slot, cur, nxt, has_next, in_tail):
     vids = phase_a(g_, slot, cur, nxt, has_next)
-    phase_b(g_, slot, nxt, has_next, vids)
+    phase_b(g_, slot, nxt, has_next, vids, in_tail)
 
 
 def drain(g_):
@@ -270,8 +307,8 @@ def drain(g_):
     g_.e("s_nop 7")
 
 
-def generate(thr):
-    g_ = Gen(thr)
+def generate(thr, diag=()):
+    g_ = Gen(thr, diag)
     e = g_.e
     e("s_mov_b32 s%d, m0" % S_M0)
     e("s_mov_b64 %s, exec" % sp(S_EXEC))
@@ -284,8 +321,6 @@ def generate(thr):
     e("s_mul_i32 s%d, %s, 3" % (S_TMP, OP["stride"]))
     e("s_add_u32 s%d, s%d, s%d" % (S_VPTR, S_VPTR, S_TMP))
     e("s_addc_u32 s%d, s%d, 0" % (S_VPTR + 1, S_VPTR + 1))
-    e("s_mov_b32 s%d, 4" % S_KT)
-    e("s_mov_b32 s%d, 3" % S_VT)
     # ---- Q fragments straight into AGPRs; K_T fragments (slot 0); O = 0; row sums = 0 ----
     for qb in range(2):
         for i in range(8):
@@ -313,7 +348,6 @@ def generate(thr):
         e("global_load_lds_dwordx4 %s, %s" % (OP["koff%d" % it], sp(S_KPTR)))
     e("s_add_u32 s%d, s%d, %s" % (S_KPTR, S_KPTR, OP["stride"]))
     e("s_addc_u32 s%d, s%d, 0" % (S_KPTR + 1, S_KPTR + 1))
-    e("s_add_u32 s%d, s%d, 1" % (S_KT, S_KT))
     drain(g_)
     # K_{T+1} fragments (slot 1) for the first phase A
     for i in range(8):
@@ -349,13 +383,13 @@ def generate(thr):
     e("s_cbranch_scc1 %s" % tail)
     e("%s:" % loop)
     for pos in range(4):
-        tile_step(g_, pos, pos & 1, (pos + 1) & 1, True)
+        tile_step(g_, pos, pos & 1, (pos + 1) & 1, True, False)
     e("s_sub_u32 s%d, s%d, 1" % (S_LOOP, S_LOOP))
     e("s_cmp_lg_u32 s%d, 0" % S_LOOP)
     e("s_cbranch_scc1 %s" % loop)
     e("%s:" % tail)
     for pos in range(4):
-        tile_step(g_, pos, pos & 1, (pos + 1) & 1, pos < 3)
+        tile_step(g_, pos, pos & 1, (pos + 1) & 1, pos < 3, True)
     # ---- normalise and store: lane holds out[row][32 db + 8 g + 4 hi + 0..3] ----
     drain(g_)
     e("s_branch F4_store_%=")
@@ -410,8 +444,13 @@ def generate(thr):
 
 def main():
     out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "ominix-mlx_amd", "csrc")
-    for thr, name in ((THR, "attn_flash4_body.inc"), (0.0, "attn_flash4_body_thr0.inc")):
-        lines = generate(thr)
+    variants = [(THR, (), "attn_flash4_body.inc"), (0.0, (), "attn_flash4_body_thr0.inc")]
+    if "--diag" in sys.argv:     # timing-only builds for OMX_ATTN_W4_VAR=2..5 (attn_flash4.hip compiles them under -DOMX_F4_DIAG)
+        variants += [(THR, ("nodma",), "attn_flash4_body_d2.inc"), (THR, ("novalu",), "attn_flash4_body_d3.inc"),
+                     (THR, ("nolds",), "attn_flash4_body_d4.inc"), (THR, ("nodma", "novalu", "nolds"), "attn_flash4_body_d5.inc"),
+                     (THR, ("expmov",), "attn_flash4_body_d6.inc"), (THR, ("nobar",), "attn_flash4_body_d7.inc"), (THR, ("noadd",), "attn_flash4_body_d8.inc")]
+    for thr, diag, name in variants:
+        lines = generate(thr, diag)
         with open(os.path.join(out_dir, name), "w") as f:
             f.write("// GENERATED by tools/gen_flash4_asm.py (deferred-rescale threshold %.1f) -- do not edit; %d instructions\n" % (thr, len(lines)))
             for ln in lines:
@@ -419,7 +458,7 @@ def main():
     clob = ["v%d" % i for i in range(32, 256)] + ["a%d" % i for i in range(256)] + ["s%d" % i for i in range(60, 96)] + ["vcc", "scc", "memory"]
     with open(os.path.join(out_dir, "attn_flash4_clobbers.inc"), "w") as f:
         f.write("// GENERATED by tools/gen_flash4_asm.py -- registers the body owns\n")
-        f.write(", ".join('"%s"' % c for c in clob) + "\n")
+        f.write("#define F4_CLOBBERS " + ", ".join('"%s"' % c for c in clob) + "\n")
     print("operands:", ", ".join("%s=%s" % (n, OP[n]) for n, _ in OPERANDS))
 
 

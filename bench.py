@@ -216,10 +216,11 @@ def peer_comm(dist, rank, world, rccl):
     if dist is not None:
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
     if int(ok.item()) == 1:
+        scope = f"; two-shot / exchange hand-offs at {peer.scope} scope, self-tested on 1-32 MB messages with a late rank" if peer.stage_bytes() else ""
         if rccl is None:
-            return peer, ("peer communicator only (csrc/peer_allreduce.hip: one-shot below 32 KB, two-shot above; self-test exact on every rank)" +
+            return peer, ("peer communicator only (csrc/peer_allreduce.hip: one-shot below 32 KB, two-shot above; self-test exact on every rank" + scope + ")" +
                           (" -- ALL RANKS ON ONE GPU (OMX_BENCH_ONE_GPU=1): a pre-flight of the multi-process path, not a measurement" if ONE_GPU else ""))
-        return peer, "peer-store one-shot (csrc/peer_allreduce.hip; self-test exact on every rank), RCCL above 32 KB"
+        return peer, "peer-store one-shot (csrc/peer_allreduce.hip; self-test exact on every rank" + scope + "), RCCL above 32 KB"
     if peer is not None and not err:
         err = "a peer rank failed its self-test"
     print(f"[bench rank {rank}] peer all-reduce not used: {err}", file=sys.stderr, flush=True)

@@ -46,6 +46,7 @@ typedef void* omx_stream; /* hipStream_t */
 
 /* ---- library / error plumbing (mlx/c/error.h:15-23, stream.h:63, memory.h:30) ---- */
 const char* omx_version(void);
+int omx_experiments_built(void);           /* 1: built with `make EXPERIMENTS=1` (persistent step, AQL replay, 32x32 two-phase / stream-K attention) */
 typedef void (*omx_error_handler_func)(const char* msg, void* data);
 void omx_set_error_handler(omx_error_handler_func handler, void* data, void (*dtor)(void*));
 const char* omx_last_error(void);          /* thread-local; "" when none */
@@ -449,6 +450,9 @@ size_t omx_peer_comm_stage_bytes(void* comm);             /* stage size of the t
 int omx_peer_moe_combine(void* out, const void* resid, const omx_moe_ep_slots* slots, int T, int hidden, int top_k, int e_lo, int e_n, void* comm,
                          omx_stream stream);
 const void* omx_peer_comm_device(void* comm);              /* device table for kernels that reduce their own output (engine-internal use) */
+int omx_peer_comm_set_scope(void* comm, int system_scope); /* two-shot / exchange hand-offs: 1 system-scope release / acquire (default), 0 agent-scope fences (ranks on ONE GPU) */
+int omx_peer_comm_scope(void* comm);
+int omx_peer_device_id(char* out, int len);                /* PCI bus id of the current device (ranks compare them: same GPU or not) */
 int omx_peer_comm_status(void* comm, unsigned* aborted);   /* 1: a wait gave up (a peer never arrived); results are void */
 int omx_peer_comm_destroy(void* comm);
 

@@ -21,7 +21,8 @@
  *   - mlx_array_data_* return a pointer to a HOST mirror refreshed at that call (device memory is
  *     not CPU-addressable on a discrete GPU); it stays valid until the array is freed or re-read;
  *   - there is no CPU backend: mlx_default_cpu_stream_new reports an error;
- *   - float matmul is implemented for bfloat16 (the path's dtype); other dtypes report an error.
+ *   - mlx_matmul is implemented for bfloat16 and float32 operands (N-D broadcast, MLX dtype promotion; float32 on the exact-f32
+ *     matrix cores), mlx_quantized_matmul for bfloat16 / float16 / float32 activations; other dtypes report an error.
  */
 #ifndef OMX_MLX_C_H
 #define OMX_MLX_C_H

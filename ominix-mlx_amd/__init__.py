@@ -49,6 +49,7 @@ SIGNATURES = {
     "omx_gather_qmm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
                                c_int, c_int, c_void_p]),
     "omx_version": (ctypes.c_char_p, []),
+    "omx_experiments_built": (ctypes.c_int, []),
     "omx_set_error_handler": (None, [c_void_p, c_void_p, c_void_p]),
     "omx_last_error": (ctypes.c_char_p, []),
     "omx_clear_error": (None, []),

@@ -65,6 +65,9 @@ PEER_SIGNATURES = {
                                             ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]),
     "omx_peer_comm_device": (ctypes.c_void_p, [ctypes.c_void_p]),
     "omx_peer_comm_status": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint)]),
+    "omx_peer_comm_set_scope": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
+    "omx_peer_comm_scope": (ctypes.c_int, [ctypes.c_void_p]),
+    "omx_peer_device_id": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_int]),
     "omx_peer_comm_destroy": (ctypes.c_int, [ctypes.c_void_p]),
 }
 
@@ -116,6 +119,17 @@ class PeerComm:
             raise RuntimeError("peer all-reduce: mapping the peers' inboxes failed on " + "; ".join(bad))
         self.comm = h.value
         self.fn = lib.omx_peer_allreduce_fn()
+        # hand-off scope of the two-shot / exchange path (csrc/peer_allreduce.hip large_publish / large_wait): system-scope release /
+        # acquire unless EVERY rank sits on the same device (the one-GPU pre-flight, where a "peer" stage is local HBM and the
+        # agent-scope form cannot fail) or OMX_PEER_SCOPE says otherwise.  Ranks on different GPUs never get the agent form by default:
+        # it is unproven across xGMI.
+        dev = ctypes.create_string_buffer(64)
+        ids = all_gather_bytes(dev.value if lib.omx_peer_device_id(dev, 64) == 0 else b"?" + str(rank).encode())
+        self.same_device = world > 1 and len(set(ids)) == 1 and not ids[0].startswith(b"?")
+        if "OMX_PEER_SCOPE" not in os.environ:
+            lib.omx_peer_comm_set_scope(h, 0 if self.same_device else 1)
+        self.scope = "system" if lib.omx_peer_comm_scope(h) == 1 else "agent"
+        self._gather = all_gather_bytes
 
     def counts(self) -> dict:
         """launches issued through this communicator by path (host-side counters)."""
@@ -138,24 +152,111 @@ class PeerComm:
             raise RuntimeError("omx_peer_allreduce failed (unsupported call and no RCCL communicator behind it)")
         return t
 
-    def self_test(self, rounds: int = 6, n: int = 4096):
-        """Every rank derives ALL ranks' inputs from (round, rank) seeds, so the expected rank-ordered f32 sum is known locally."""
+    def self_test(self, rounds: int = 6, n: int = 4096, large: bool = True):
+        """Every rank derives ALL ranks' inputs from (round, rank) seeds, so the expected rank-ordered f32 sum is known locally.
+        One-shot path: `rounds` reductions of n floats.  With the two-shot / exchange path on (stage_bytes > 0) and `large`: seeded
+        1 MB .. 32 MB messages in f32 and bf16 (chunked when the stage is smaller), each with one deliberately LATE rank and a
+        streaming kernel queued right behind the call, and one round of the MoE combine kernel -- all before the first real use of those
+        kernels.  The verdict is agreed over the bootstrap group: every rank raises when any rank failed."""
         import numpy as np
         from .ops import Tensor, synchronize
-        for it in range(rounds):
-            parts = [np.random.default_rng(1000 * it + r).standard_normal(n).astype(np.float32) for r in range(self.world)]
-            want = parts[0].copy()
-            for r in range(1, self.world):
-                want = want + parts[r]
-            t = Tensor.from_numpy(parts[self.rank], "f32")
-            self.allreduce_f32(t)
-            synchronize()
-            if self.aborted():
-                raise RuntimeError(f"peer all-reduce: rank {self.rank} gave up waiting for a peer in round {it}")
-            got = t.numpy()
-            if not np.array_equal(got, want):
-                raise RuntimeError(f"peer all-reduce: rank {self.rank} round {it}: {int((got != want).sum())} of {n} sums differ from the rank-ordered sum")
+        err = ""
+        try:
+            for it in range(rounds):
+                parts = [np.random.default_rng(1000 * it + r).standard_normal(n).astype(np.float32) for r in range(self.world)]
+                want = parts[0].copy()
+                for r in range(1, self.world):
+                    want = want + parts[r]
+                t = Tensor.from_numpy(parts[self.rank], "f32")
+                self.allreduce_f32(t)
+                synchronize()
+                if self.aborted():
+                    raise RuntimeError(f"peer all-reduce: rank {self.rank} gave up waiting for a peer in round {it}")
+                got = t.numpy()
+                if not np.array_equal(got, want):
+                    raise RuntimeError(f"peer all-reduce: rank {self.rank} round {it}: {int((got != want).sum())} of {n} sums differ from the rank-ordered sum")
+            if large and self.world > 1 and self.stage_bytes() > 0:
+                self._self_test_large()
+        except Exception as e:   # noqa: BLE001
+            err = str(e) or type(e).__name__
+        bad = [f"rank {r}: {b.decode(errors='replace')}" for r, b in enumerate(self._gather(err.encode()[:200])) if b]
+        if bad:
+            raise RuntimeError("peer communicator self-test failed on " + "; ".join(bad))
         return True
+
+    def stage_bytes(self) -> int:
+        from . import lib
+        return int(lib.omx_peer_comm_stage_bytes(self._h))
+
+    def _self_test_large(self):
+        import time
+        import numpy as np
+        from . import lib
+        from .ops import Tensor, fill_uniform, synchronize
+
+        def bf16_round(x):
+            u = np.ascontiguousarray(x, np.float32).view(np.uint32).astype(np.uint64)
+            return ((u + ((u >> np.uint64(16)) & np.uint64(1)) + np.uint64(0x7FFF)) & np.uint64(0xFFFF0000)).astype(np.uint32).view(np.float32)
+
+        stage = self.stage_bytes()
+        # (elements, dtype): 1 MB f32, 4 MB bf16 with a ragged tail, 32 MB f32; and one message LARGER than the stage (chunked) when that is
+        # affordable (a 64 MB default stage would need > 64 MB messages: covered by tests that shrink the stage with OMX_PEER_STAGE_MB)
+        cases = [(262144, "f32"), (2 * 1024 * 1024 + 8, "bf16"), (8 * 1024 * 1024, "f32")]
+        if stage <= (16 << 20):
+            cases.append((stage // 4 + stage // 8 + 4, "f32"))
+            cases.append((stage // 2 + 4096 + 8, "bf16"))
+        for it, (n, dt) in enumerate(cases):
+            parts = [np.random.default_rng(7000 + 16 * it + r).standard_normal(n).astype(np.float32) for r in range(self.world)]
+            if dt == "bf16":
+                parts = [bf16_round(p) for p in parts]
+            want = parts[0].copy()
+            for p in parts[1:]:
+                want = want + p
+            if dt == "bf16":
+                want = bf16_round(want)
+            buf = Tensor.from_numpy(parts[self.rank], dt)
+            synchronize()
+            if self.rank == it % self.world:
+                time.sleep(0.05)                                   # the deliberately late rank: its peers poll meanwhile
+            rc = lib.omx_peer_allreduce(buf.ptr, buf.ptr, n, NCCL_BFLOAT16 if dt == "bf16" else NCCL_FLOAT32, 0, self._h, None)
+            fill_uniform((64 * 1024 * 1024,), 99 + it, 1.0)        # a streaming kernel queued right behind it (HBM busy while peers still read)
+            synchronize()
+            if rc != 0 or self.aborted():
+                raise RuntimeError(f"two-shot all-reduce of {n} {dt}: rc {rc}, aborted {self.aborted()}")
+            got = buf.numpy().astype(np.float32).ravel()
+            if not np.array_equal(got, want):
+                raise RuntimeError(f"two-shot all-reduce of {n} {dt} ({self.scope} scope): {int((got != want).sum())} sums differ from the rank-ordered sum")
+        # one round of the expert-parallel combine (peer_moe_combine_kernel): T tokens x top-2 over 2 * world experts, every rank holds ALL slot
+        # rows (seeded) and contributes those of ITS experts; expected rows: bf16(resid + bf16(sum in slot order of bf16(y_j * score_j)))
+        T_, hid, k = 96 * self.world + 5, 512, 2
+        rng = np.random.default_rng(4242)
+        y = bf16_round(rng.standard_normal((T_ * k, hid)).astype(np.float32))
+        sc = bf16_round(rng.uniform(0.1, 0.9, T_ * k).astype(np.float32))
+        resid = bf16_round(rng.standard_normal((T_, hid)).astype(np.float32))
+        inds = rng.integers(0, 2 * self.world, T_ * k).astype(np.uint32)
+        prod = bf16_round(y * sc[:, None]).reshape(T_, k, hid)
+        acc = prod[:, 0].copy()
+        for j in range(1, k):
+            acc = acc + prod[:, j]
+        want = bf16_round(resid + bf16_round(acc))
+
+        class Slots(ctypes.Structure):
+            _fields_ = [("y", ctypes.c_void_p), ("pos_of_slot", ctypes.c_void_p), ("inds", ctypes.c_void_p), ("scores", ctypes.c_void_p)]
+
+        ty, tp, ti, ts = (Tensor.from_numpy(y, "bf16"), Tensor.from_numpy(np.arange(T_ * k, dtype=np.uint32), "u32"), Tensor.from_numpy(inds, "u32"),
+                          Tensor.from_numpy(sc, "bf16"))
+        tr, out = Tensor.from_numpy(resid, "bf16"), Tensor((T_, hid), "bf16")
+        sl = Slots(ty.ptr, tp.ptr, ti.ptr, ts.ptr)
+        synchronize()
+        if self.rank == self.world - 1:
+            time.sleep(0.05)
+        rc = lib.omx_peer_moe_combine(out.ptr, tr.ptr, ctypes.byref(sl), T_, hid, k, 2 * self.rank, 2, self._h, None)
+        synchronize()
+        if rc != 0 or self.aborted():
+            raise RuntimeError(f"MoE combine exchange: rc {rc}, aborted {self.aborted()}")
+        got = out.numpy().astype(np.float32)
+        if not np.array_equal(got, want):
+            raise RuntimeError(f"MoE combine exchange ({self.scope} scope): {int((got != want).any(axis=1).sum())} of {T_} rows differ from the slot-ordered sum")
 
     def close(self):
         from . import lib

@@ -730,6 +730,7 @@ __global__ __launch_bounds__(512, 1) void attn_prefill_pp_kernel(const PrefillAr
     pp_unit<D, MASK, TR, false>(a, &sK2[0][0], &sV2[0][0], b, h, qt, 0, 0, 0);
 }
 
+#ifdef OMX_EXPERIMENTS   // measured negatives (EXPERIMENTS.md R4-14, R3-4): `make EXPERIMENTS=1`
 // ---- The two-phase kernel on 32x32x16 MFMAs (round 4; OMX_ATTN_PP32=1, head_dim 128): the same block (8 waves, 256 query rows, K / V
 //      tiles of 64 keys by LDS-DMA, waves 0-3 and 4-7 in opposite phases), but a wave's 32 query rows are ONE 32-wide MFMA column block:
 //      S^T tile (32 keys x 32 queries) = 8 MFMAs over the head dim, O^T tile (32 dims x 32 queries) += V^T P^T = 4 MFMAs over the tile's
@@ -1044,8 +1045,11 @@ __global__ __launch_bounds__(512, 1) void attn_prefill_sk_kernel(const PrefillAr
     }
 }
 
+#endif   // OMX_EXPERIMENTS
+
 }  // namespace
 
+#ifdef OMX_EXPERIMENTS
 namespace {
 // parking slots + arrival counters of the stream-K kernel, one set per stream (allocated on first use, 70 MiB: 256 boundaries x 2 pieces)
 constexpr int kSkBlocks = 256;
@@ -1084,6 +1088,8 @@ int sk_cus() {
 }
 }  // namespace
 
+#endif   // OMX_EXPERIMENTS
+
 int launch_attn_prefill(bf16_t* out, const bf16_t* q, const bf16_t* k, const bf16_t* v, int B, int H, int Hkv, int Tq,
                         int Tk, int D, int64_t kv_batch_stride, int64_t kv_head_stride, float scale, int mask_mode,
                         const void* mask, hipStream_t s, bool out_token_major, const AttnLayout* layout, bool f16) {
@@ -1118,6 +1124,7 @@ int launch_attn_prefill(bf16_t* out, const bf16_t* q, const bf16_t* k, const bf1
     const long pp_blocks = (long)((Tq + 255) / 256) * H * B;
     if (!f16 && (ppenv ? atoi(ppenv) != 0 : (Tq >= 1024 && (mask_mode != OMX_MASK_CAUSAL || pp_blocks >= 2048)))) {
         const dim3 grid((Tq + 255) / 256, H, B), block(512);
+#ifdef OMX_EXPERIMENTS
         // stream-K form (opt-in, OMX_ATTN_STREAMK=1): no mask, more units than CUs (every share then spans at least one whole unit: a
         // unit is cut at most once); one block per CU (a piece never waits for another: no co-residency needed).  Measured SLOWER where
         // it should pay (432 units: 384 us against 329; 280 units: 173 against 125; 512 units, nothing cut: 330 against 349): the blocks
@@ -1133,6 +1140,7 @@ int launch_attn_prefill(bf16_t* out, const bf16_t* q, const bf16_t* k, const bf1
             OMX_LAUNCH_CHECK();
             return 0;
         }
+#endif
         if (const char* te = getenv("OMX_ATTN_PP_TRACE")) {   // timeline build (head_dim 128, no mask): address of a device buffer
             a.trace = reinterpret_cast<unsigned long long*>(strtoull(te, nullptr, 0));
             OMX_REQUIRE(D == 128 && mask_mode == OMX_MASK_NONE, "attention timeline build: head_dim 128 without a mask only");
@@ -1140,6 +1148,7 @@ int launch_attn_prefill(bf16_t* out, const bf16_t* q, const bf16_t* k, const bf1
             OMX_LAUNCH_CHECK();
             return 0;
         }
+#ifdef OMX_EXPERIMENTS
         if (const char* p32 = getenv("OMX_ATTN_PP32"); p32 && atoi(p32) != 0 && D == 128) {   // the 32x32x16 form (round 4, opt-in)
 #define OMX_PP32_CASE(MM)                                                            \
     if (mask_mode == MM) {                                                           \
@@ -1150,6 +1159,7 @@ int launch_attn_prefill(bf16_t* out, const bf16_t* q, const bf16_t* k, const bf1
             OMX_PP32_CASE(OMX_MASK_NONE) OMX_PP32_CASE(OMX_MASK_CAUSAL) OMX_PP32_CASE(OMX_MASK_BOOL) OMX_PP32_CASE(OMX_MASK_ADDITIVE)
 #undef OMX_PP32_CASE
         }
+#endif
 #define OMX_PP_CASE(DD, MM)                                                          \
     if (D == DD && mask_mode == MM) {                                                \
         attn_prefill_pp_kernel<DD, MM><<<grid, block, 0, s>>>(a);                    \

@@ -277,7 +277,7 @@ void drop_graphs(omx_qwen3 m) {
     if (m->g_full) { (void)hipGraphExecDestroy(m->g_full); m->g_full = nullptr; }
     if (m->g_nohead) { (void)hipGraphExecDestroy(m->g_nohead); m->g_nohead = nullptr; }
     if (m->aql_full) { aql_destroy(m->aql_full); m->aql_full = nullptr; }
-    if (m->cfg.ep_size > 1 && m->stream) workspace_aux_pin(m->stream, false);
+    if (m->cfg.num_experts > 0 && (m->cfg.ep_size > 1 || m->cfg.tp_size > 1) && m->stream) workspace_aux_pin(m->stream, false);
 }
 
 template <class T>
@@ -945,7 +945,9 @@ int build_graphs(omx_qwen3 m) {
         }
         (which == 0 ? m->g_full : m->g_nohead) = ge;
     }
-    if (m->cfg.ep_size > 1) workspace_aux_pin(m->stream, true);   // the captured MoE block's scratch pointers must not move
+    // the captured MoE block's scratch pointers must not move: the expert-parallel block and the expert-TENSOR-parallel one
+    // (omx_moe_block_partial_tp bakes its get_workspace_aux pointer into the graph as well)
+    if (m->cfg.num_experts > 0 && (m->cfg.ep_size > 1 || m->cfg.tp_size > 1)) workspace_aux_pin(m->stream, true);
     build_aql(m);
     return 0;
 }

@@ -20,6 +20,8 @@ struct PeerDev {
     unsigned char* stage1[kPeerMaxWorld];  // [world][slice] contributions to the slice that rank owns
     unsigned char* stage2[kPeerMaxWorld];  // [world][slice] the reduced slices, pushed by their owners
     size_t stage_bytes;                    // 0: the large path is off
+    int sys_scope;                         // large path: 1 = system-scope release / acquire around the stage hand-offs (ranks on different GPUs),
+                                           // 0 = agent-scope fences + relaxed flags (all ranks on ONE GPU; unproven across xGMI)
 };
 
 typedef __attribute__((address_space(1))) unsigned long long peer_gu64;

@@ -51,6 +51,7 @@ struct PeerComm {
     unsigned long long n_small = 0, n_large = 0, n_moe = 0, n_rccl = 0;   // launches by path (host-side, omx_peer_comm_counts)
     size_t stage_bytes = 0;                    // large path: bytes per stage (0: off)
     size_t off_flags = 0, off_stage1 = 0, off_stage2 = 0;   // byte offsets inside the exported allocation
+    int sys_scope = 1;                         // large path: system-scope release / acquire (the default; omx_peer_comm_set_scope)
 };
 
 constexpr int kNcclBfloat16 = 9;
@@ -64,19 +65,27 @@ struct PeerLargeArgs {
 };
 
 __device__ __forceinline__ void large_publish(const PeerDev* p, int phase, unsigned tag, uint32_t* counter) {
-    // every thread's pushes have left this GPU before its block reports in; the last block to arrive tells every rank.  The stages are
-    // fine-grained (uncached) memory: a store is on its way to its destination when it retires, so the release is "wait for my stores"
-    // (vmcnt) -- a system-scope fence also writes the whole L2 back, 140 us per call measured with three of them in this kernel
-    // (MI355X_MICROARCH.md handoff-flag: payload -> vmcnt(0) -> flag)
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    // every thread's pushes have left this GPU before its block reports in; the last block to arrive tells every rank.
+    // Two forms (PeerDev::sys_scope, wave-uniform):
+    //  * system scope (the default whenever ranks sit on different GPUs): release fence at system scope by every thread, the flags stored
+    //    with release at system scope -- what the memory model asks for when the payload is written and read by OTHER devices;
+    //  * agent scope (all ranks on ONE GPU, or OMX_PEER_SCOPE=agent): the stages are fine-grained (uncached) memory, a store is on its
+    //    way when it retires, so the release is "wait for my stores" (vmcnt) -- a system-scope fence also writes the whole L2 back,
+    //    140 us per call measured with three of them in this kernel (MI355X_MICROARCH.md handoff-flag: payload -> vmcnt(0) -> flag).
+    //    Between processes on one GPU the "peer" stage is local HBM, so that form cannot fail there; across xGMI it is unproven
+    //    (ADVICE r4): it is never chosen automatically for ranks on different devices.
+    if (p->sys_scope) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     __syncthreads();
     if (threadIdx.x == 0) {
         const unsigned done = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
         if (done == gridDim.x - 1) {
             __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            for (int r = 0; r < p->world; ++r)
-                __hip_atomic_store((peer_gu64*)(p->flags[r] + (size_t)phase * p->world + p->rank), (unsigned long long)tag, __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_SYSTEM);   // (relaxed: every block's stores had retired before it reported in; a release here writes the L2 back)
+            for (int r = 0; r < p->world; ++r) {
+                peer_gu64* f = (peer_gu64*)(p->flags[r] + (size_t)phase * p->world + p->rank);
+                if (p->sys_scope) __hip_atomic_store(f, (unsigned long long)tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                else __hip_atomic_store(f, (unsigned long long)tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // (every block's stores had retired before it reported in)
+            }
         }
     }
 }
@@ -97,7 +106,9 @@ __device__ __forceinline__ bool large_wait(const PeerDev* p, int phase, unsigned
         s_ok = ok;
     }
     __syncthreads();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // (drops this CU's L1 lines of the stage; the L2 does not cache fine-grained memory)
+    // ONE acquire after the polls (MI355X_MICROARCH.md: relaxed poll -> one acquire -> plain loads)
+    if (p->sys_scope) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+    else __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // (drops this CU's L1 lines of the stage; the L2 does not cache fine-grained memory)
     return s_ok != 0;
 }
 
@@ -279,6 +290,7 @@ int upload_table(PeerComm* c) {
         t.stage2[r] = base + c->off_stage2;
     }
     t.stage_bytes = c->stage_bytes;
+    t.sys_scope = c->sys_scope;
     t.inbox = c->inbox; t.state = c->state; t.rank = c->rank; t.world = c->world;
     if (!c->dev) OMX_HIP_CHECK(hipMalloc((void**)&c->dev, sizeof(PeerDev)));
     OMX_HIP_CHECK(hipMemcpy(c->dev, &t, sizeof(PeerDev), hipMemcpyHostToDevice));
@@ -307,6 +319,9 @@ int omx_peer_comm_create(void** out, int rank, int world, void* rccl_comm, void*
         const long mb = se ? atol(se) : 64;
         c->stage_bytes = (size_t)(mb > 0 ? mb : 64) << 20;
     }
+    // hand-off scope of the large path: system unless asked otherwise (OMX_PEER_SCOPE=agent|system; comm.py picks agent by itself only
+    // when every rank reports the same device)
+    if (const char* sc = getenv("OMX_PEER_SCOPE")) c->sys_scope = (sc[0] == 'a' || sc[0] == 'A') ? 0 : 1;
     c->off_flags = inbox_bytes;
     c->off_stage1 = inbox_bytes + 4096;
     c->off_stage2 = c->off_stage1 + (c->stage_bytes ? c->stage_bytes + 4096 : 0);
@@ -413,6 +428,35 @@ int omx_peer_allreduce(const void* send, void* recv, size_t count, int dtype, in
 }
 
 void* omx_peer_allreduce_fn(void) { return (void*)&omx_peer_allreduce; }
+
+// scope of the large path's stage hand-offs: 1 = system-scope release / acquire, 0 = agent-scope fences + relaxed flags.  Every rank
+// must choose alike (the forms interoperate, but a system-scope consumer behind an agent-scope producer gains nothing).  Not during a
+// reduction or a stream capture: the device table is rewritten.
+int omx_peer_comm_set_scope(void* comm, int system_scope) {
+    using namespace omx;
+    OMX_REQUIRE(comm, "omx_peer_comm_set_scope: null communicator");
+    PeerComm* c = static_cast<PeerComm*>(comm);
+    c->sys_scope = system_scope ? 1 : 0;
+    if (c->connected) {
+        OMX_HIP_CHECK(hipDeviceSynchronize());
+        if (upload_table(c)) return 1;
+        OMX_HIP_CHECK(hipDeviceSynchronize());
+    }
+    return 0;
+}
+int omx_peer_comm_scope(void* comm) {
+    omx::PeerComm* c = static_cast<omx::PeerComm*>(comm);
+    return c ? c->sys_scope : -1;
+}
+// PCI bus id of the calling thread's current device ("0000:c1:00.0"): ranks compare them to learn whether they share one GPU
+int omx_peer_device_id(char* out, int len) {
+    using namespace omx;
+    OMX_REQUIRE(out && len >= 16, "omx_peer_device_id: buffer of at least 16 bytes");
+    int dev = 0;
+    OMX_HIP_CHECK(hipGetDevice(&dev));
+    OMX_HIP_CHECK(hipDeviceGetPCIBusId(out, len, dev));
+    return 0;
+}
 
 // bytes of one stage of the two-shot / exchange path (0: that path is off -- an RCCL communicator takes the large calls)
 size_t omx_peer_comm_stage_bytes(void* comm) {

@@ -39,6 +39,15 @@ extern "C" {
 
 const char* omx_version(void) { return "omx-hip 0.1.0 (gfx950)"; }
 
+// 1: this library was built with `make EXPERIMENTS=1` (the measured-negative engines of EXPERIMENTS.md are in it)
+int omx_experiments_built(void) {
+#ifdef OMX_EXPERIMENTS
+    return 1;
+#else
+    return 0;
+#endif
+}
+
 void omx_set_error_handler(omx_error_handler_func handler, void* data, void (*dtor)(void*)) {
     std::lock_guard<std::mutex> lk(g_handler_mu);
     if (g_handler_dtor && g_handler_data) g_handler_dtor(g_handler_data);

@@ -352,7 +352,9 @@ def quantized_matmul(x: Tensor, packed: Tensor, scales: Tensor, biases: Optional
     if x.shape[-1] != K:
         raise OmxError(f"quantized_matmul: input features {x.shape[-1]} != weight in-features {K}")
     if x.dtype != scales.dtype:
-        raise OmxError("quantized_matmul: x and the scales / biases must share one dtype (bf16, or f16 for a float16 checkpoint)")
+        # MLX promotes with result_type(x, scales, biases) (ops.cpp quantized_matmul); the kernels run in the scales' 16-bit type, so a
+        # mixed call (a bf16 activation on a float16 checkpoint, or the reverse) is computed there: x is cast to it
+        x = cast(x, scales.dtype)
     out = Tensor(tuple(x.shape[:-1]) + (N,), x.dtype)
     # one dtype for x, out, scales and biases: bf16, or f16 -- a float16 checkpoint runs in float16 end to end, like in MLX
     check(lib.omx_quantized_matmul(out.ptr, x.ptr, packed.ptr, scales.ptr, _p(biases), x.size // K, N, K, group_size, bits,

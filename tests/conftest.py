@@ -34,3 +34,12 @@ def omx():
     """The product package (ctypes binding over libomx_hip.so)."""
     import omx_import
     return omx_import.load_package()
+
+
+def needs_experiments(omx):
+    """skip unless the loaded library is the `make EXPERIMENTS=1` build (OMX_LIB_VARIANT=exp): the measured-negative engines of
+    EXPERIMENTS.md -- persistent decode step, AQL replay, 32x32 two-phase and stream-K attention -- are not in the default library"""
+    import ctypes
+    omx.lib.omx_experiments_built.restype = ctypes.c_int
+    if not omx.lib.omx_experiments_built():
+        pytest.skip("experimental engine: build with `make -C ominix-mlx_amd/csrc EXPERIMENTS=1`, run with OMX_LIB_VARIANT=exp")

@@ -357,6 +357,8 @@ def test_sdpa_two_phase_kernel_on_32x32_mfmas(omx, monkeypatch, B, H, Hkv, Tq, T
     """csrc/attn_prefill.hip attn_prefill_pp32_kernel (round 4, OMX_ATTN_PP32=1): the two-phase block with a wave's 32 query rows as one
     32-wide MFMA column block (32x32x16 MFMAs: half the MFMA issues for the same flops).  Another summation order inside the MFMAs, so
     not bit-equal to the 16x16x32 kernels: on the oracle within the SDPA bound, and within a bf16 ulp of the largest value of them."""
+    from conftest import needs_experiments
+    needs_experiments(omx)
     q = rc.bf16_round(rand((B, H, Tq, D), 61)); k = rc.bf16_round(rand((B, Hkv, Tk, D), 62)); v = rc.bf16_round(rand((B, Hkv, Tk, D), 63))
     if mode == "bool":
         mask = rc.create_causal_mask(Tq, Tk - Tq, 100)
@@ -385,6 +387,8 @@ def test_sdpa_stream_k_kernel(omx, monkeypatch, B, H, Hkv, Tq, Tk, D):
     (unit, key tile) steps; a unit that a share boundary runs through is computed as two pieces whose un-normalised (O, m, l) meet in
     whichever finishes last (opt-in: measured slower, see the launcher).  Held to: run-to-run bit-identical (the merge is two products and a sum: arrival order cannot show), within
     one bf16 ulp of the un-cut two-phase kernel, and on the oracle for three heads (first, one in the middle of the cuts, last)."""
+    from conftest import needs_experiments
+    needs_experiments(omx)
     q = rc.bf16_round(rand((B, H, Tq, D), 71)); k = rc.bf16_round(rand((B, Hkv, Tk, D), 72)); v = rc.bf16_round(rand((B, Hkv, Tk, D), 73))
     scale = D ** -0.5
     monkeypatch.setenv("OMX_ATTN_STREAMK", "1")

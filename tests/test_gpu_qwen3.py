@@ -867,8 +867,10 @@ def test_peer_store_allreduce_across_processes(omx, tmp_path, fused):
     from ominix_mlx_amd import comm, engine
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     port = 29500 + (os.getpid() % 400)
-    # (fused 0 also shrinks the two-shot path's stage to 4 MB: its 16.7 MB messages then go in five chunks)
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMX_PEER_FUSED=fused, **({"OMX_PEER_STAGE_MB": "4"} if fused == "0" else {}))
+    # (fused 0 also shrinks the two-shot path's stage to 4 MB: its 16.7 MB messages then go in five chunks -- and asks for the
+    #  SYSTEM-scope hand-offs that ranks on different GPUs get by default; fused 1 keeps what two ranks on one GPU get: agent scope)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMX_PEER_FUSED=fused, **({"OMX_PEER_STAGE_MB": "4", "OMX_PEER_SCOPE": "system"} if fused == "0" else {}))
+    env.pop("OMX_PEER_SCOPE", None) if fused == "1" else None
     p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                         "--master-port", str(port), os.path.join(root, "tools", "peer_allreduce_check.py"), str(tmp_path)],
                        env=env, capture_output=True, text=True, timeout=600, stdin=subprocess.DEVNULL)
@@ -876,6 +878,7 @@ def test_peer_store_allreduce_across_processes(omx, tmp_path, fused):
     res = [json.load(open(tmp_path / f"rank{r}.json")) for r in range(2)]
     for r in res:
         assert r["self_test"] and not r["aborted"] and not r["aborted_after_loop"]
+        assert r["same_device"] and r["scope"] == ("system" if fused == "0" else "agent")      # (round 5: both hand-off forms, chosen as comm.py documents)
         # per-call latency report (what a first multi-GPU run is read from): three sizes, ordered percentiles, every call counted
         assert [h["n_floats"] for h in r["latency_us"]] == [4096, 2, 4096 * 64]
         for h in r["latency_us"]:
@@ -953,7 +956,7 @@ def test_peer_communicator_four_processes_on_one_gpu(omx, tmp_path):
     from ominix_mlx_amd import engine
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     port = 29900 + (os.getpid() % 90)
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMX_PEER_FUSED="0")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMX_PEER_FUSED="0", OMX_PEER_SCOPE="system")     # (the form ranks on different GPUs get)
     p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr", "127.0.0.1",
                         "--master-port", str(port), os.path.join(root, "tools", "peer_allreduce_check.py"), str(tmp_path)],
                        env=env, capture_output=True, text=True, timeout=900, stdin=subprocess.DEVNULL)
@@ -961,6 +964,7 @@ def test_peer_communicator_four_processes_on_one_gpu(omx, tmp_path):
     res = [json.load(open(tmp_path / f"rank{r}.json")) for r in range(4)]
     for r in res:
         assert r["self_test"] and not r["aborted"] and not r["aborted_after_large"] and not r["aborted_after_ep"]
+        assert r["scope"] == "system"
         assert all(c["rc"] == 0 and c["equal"] for c in r["large"]), r["large"]
         assert r["ep_exchange"]["tokens"] == r["ep_allreduce"]["tokens"] and r["ep_exchange"]["logits_crc"] == r["ep_allreduce"]["logits_crc"]
         assert r["ep_exchange"]["launches"]["moe_combine"] == 2 and r["ep_exchange"]["launches"]["two_shot"] == 0
@@ -1050,6 +1054,8 @@ def test_persistent_step_is_bit_identical(omx, monkeypatch, name, n_prompt):
     (=2: [gate/up, down, next q/k/v] as one engine segment between two attention launches) -- reproduces the launch-per-op step
     exactly: same tokens and bit-equal logits as OMX_STEP_ENGINE=0, in graph and eager form, across a context-bucket boundary
     (1000 -> 1039 crosses 1024) and from a nearly empty cache (most attention splits idle)."""
+    from conftest import needs_experiments
+    needs_experiments(omx)
     cfg = ENGINE_CONFIGS[name]
     prompt = synth.prompt_ids(n_prompt, cfg.vocab_size)
     outs = {}
@@ -1072,6 +1078,8 @@ def test_aql_replay_is_bit_identical(omx, monkeypatch, name, quant):
     (OMX_STEP_AQL=1: kernel descriptors looked up in the executables HIP loaded, kernargs = recorded arguments + code-object-v5
     hidden arguments) -- reproduces the hipGraph step exactly: same tokens, bit-equal logits, across a context-bucket boundary
     (the program is rebuilt with the graphs) and in calls that straddle it (those fall back to the graph)."""
+    from conftest import needs_experiments
+    needs_experiments(omx)
     cfg = OPROJ_CONFIGS[name]
     prompt = synth.prompt_ids(1000, cfg.vocab_size)
     outs = {}
@@ -1097,6 +1105,8 @@ def test_aql_replay_is_bit_identical(omx, monkeypatch, name, quant):
 
 def test_persistent_step_options_are_bit_identical(omx, monkeypatch):
     """The engine's tuning knobs (sweeping waves per edge, fills in flight) change timing only."""
+    from conftest import needs_experiments
+    needs_experiments(omx)
     cfg = ENGINE_CONFIGS["h32_kv8_d128_nvw8"]
     prompt = synth.prompt_ids(300, cfg.vocab_size)
     outs = []

@@ -29,7 +29,8 @@ from oracle import synth  # noqa: E402  (prompt ids only: the checker's seeded i
 
 res = {"rank": rank, "world": world, "device": torch.cuda.current_device()}
 pc = comm.PeerComm(comm.torch_all_gather_bytes(dist), rank, world)
-res["self_test"] = bool(pc.self_test())
+res["self_test"] = bool(pc.self_test())      # one-shot rounds, then (two-shot path on) seeded 1 .. 32 MB messages with a late rank + the MoE combine round
+res["scope"], res["same_device"] = pc.scope, bool(pc.same_device)
 T = omx.ops.Tensor
 import numpy as np  # noqa: E402
 

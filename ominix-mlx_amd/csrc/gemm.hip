@@ -645,6 +645,257 @@ __global__ __launch_bounds__(big::NT) void gemm_bf16_nt_256_kernel(const GemmArg
 #undef OMX_WAIT_RING
 #undef OMX_BAR
 
+#ifdef OMX_EXPERIMENTS   // measured negative (EXPERIMENTS.md R5-3: 0.86-0.94 of the eight-phase kernel above): `make EXPERIMENTS=1`, OMX_GEMM_ASM=8
+// ---- 256 x 256 tile with the K loop as generated assembly (round 5; tools/gen_gemm4_asm.py -> gemm4_body.inc has the register map, the
+//      ring protocol and the hazard rules): eight waves, two per SIMD, 128 x 64 of the tile per wave = 8 accumulators of 32x32x16
+//      (128 AGPRs), free-running between ONE barrier per 32 k.  This file keeps what hipcc does well: tile order, segments / expert rows,
+//      the per-thread source rows (clamped at the edges, gathered for the MoE form), the epilogues.
+//      LDS: [X buffer 0 | X 1 | W 0 | W 1] of 256 rows x 64 k (128 KiB) + 16 parameter dwords per thread (32 KiB).
+//      K % 128 == 0, bf16, no implicit convolution, no K split; SW: the segmented projection (plain segments + SwiGLU pair tiles: inside
+//      a wave's 64 columns the first 32 are gate rows, the last 32 the up rows of the SAME outputs, so a lane holds both).
+namespace w4 {
+constexpr int TILES_B = 4 * 32768, PARAM_B = 512 * 64, SMEM = TILES_B + PARAM_B;
+}
+#include "gemm4_body.inc"
+
+template <bool SW, int VAR = 0>
+__global__ __launch_bounds__(512) void gemm_bf16_nt_asm_kernel(const GemmArgs a) {
+    typedef Act16<false> A16;
+    constexpr int CJ = 2;                          // 32-column blocks per wave
+    constexpr int WCOLS = 32 * CJ;                 // columns per wave
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wr = wave >> 2, wc = wave & 3, l32 = lane & 31, hi = lane >> 5;
+    // tile order: the 256^2 kernel's (XCD-aware remap, 8 x 4 patches per XCD)
+    const int nblk = a.grid_m * a.grid_n;
+    int bid = blockIdx.x;
+    {
+        const int q = nblk / 8, r = nblk % 8, xcd = bid % 8, idx = bid / 8;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    int tm, tn;
+    {
+        constexpr int GM = 8;
+        const int per_group = GM * a.grid_n;
+        const int group = bid / per_group, in_group = bid % per_group;
+        const int first_m = group * GM;
+        const int gm = min(a.grid_m - first_m, GM);
+        tm = first_m + in_group % gm;
+        tn = in_group / gm;
+    }
+    const bf16_t* seg_w = a.w;
+    const bf16_t* seg_bias = nullptr;
+    bf16_t* seg_out = a.out;
+    int seg_cols = a.N, seg_ld = a.N;
+    bool seg_act = false;
+    if constexpr (SW) {
+        const GemmSegs& g = a.sg;
+        if (tn >= g.act_tile0) {
+            seg_act = true;
+            tn -= g.act_tile0;
+            seg_cols = g.half;
+        } else {
+            const int sidx = (g.n_plain > 1 && tn >= g.plain[1].tile0) + (g.n_plain > 2 && tn >= g.plain[2].tile0);
+            const GemmSeg& sgm = g.plain[sidx];
+            seg_w = sgm.w; seg_bias = sgm.bias; seg_out = sgm.out; seg_cols = sgm.cols; seg_ld = sgm.ld;
+            tn -= sgm.tile0;
+        }
+    }
+    int m0 = tm * 256, rows_valid = a.M, row_base = 0;
+    size_t w_off = 0;
+    const uint32_t* row_src = nullptr;
+    if constexpr (SW) {
+        if (a.g.tile_expert) {
+            if (tm >= *a.g.n_tiles) return;
+            const int e = a.g.tile_expert[tm];
+            row_base = a.g.seg_start[e];
+            rows_valid = a.g.seg_start[e + 1] - row_base;
+            m0 = a.g.tile_m0[tm];
+            row_src = a.g.row_src;
+            w_off = (size_t)e * a.g.w_estride;
+        }
+    }
+    const int n0 = tn * 256;
+
+    // ---- per-thread parameters of the K loop (gen_gemm4_asm.py): DMA source offsets of this thread's 4 X and 4 W pieces (piece wave * 4 + it =
+    //      tile rows (wave * 4 + it) * 8 + (lane >> 3), 16-B chunk (lane & 7) ^ ((row >> 1) & 7) of the row's 128 B), fragment read addresses
+    //      per quarter q of the row (row = l32 of the wave's block, chunk (2 q + hi) ^ ((row >> 1) & 7)).  W tile row R sits in wave column
+    //      R / 64; in a SwiGLU tile its first 32 rows are gate rows, the other 32 the up rows of the same outputs (one tile = 128
+    //      outputs): a wave stages 32 tile rows -- gate OR up rows. ----
+    uint32_t prm[16];
+    {
+        const int r8 = lane >> 3, slot = lane & 7;
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int R = (wave * 4 + it) * 8 + r8;
+            const int chunk = slot ^ ((R >> 1) & 7);
+            int xr = min(m0 + R, rows_valid - 1) + row_base;
+            if constexpr (SW) {
+                if (row_src) xr = (int)row_src[xr];
+            }
+            prm[it] = (uint32_t)(((int64_t)xr * a.K + chunk * 8) * 2);
+            int wrow;
+            if (SW && seg_act) wrow = min(n0 / 2 + (R / WCOLS) * (WCOLS / 2) + (R & (WCOLS / 2 - 1)), seg_cols - 1);
+            else wrow = min(n0 + R, seg_cols - 1);
+            prm[4 + it] = (uint32_t)(((int64_t)wrow * a.K + chunk * 8) * 2);
+        }
+        const unsigned tiles = (unsigned)(uintptr_t)smem;
+        const int swf = (l32 >> 1) & 7;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            prm[8 + q] = tiles + (unsigned)((wr * 128 + l32) * 128 + ((2 * q + hi) ^ swf) * 16);
+            prm[12 + q] = tiles + 65536u + (unsigned)((wc * WCOLS + l32) * 128 + ((2 * q + hi) ^ swf) * 16);
+        }
+    }
+    u32x4* pblock = reinterpret_cast<u32x4*>(smem + w4::TILES_B) + threadIdx.x * 4;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) pblock[k] = u32x4{prm[4 * k], prm[4 * k + 1], prm[4 * k + 2], prm[4 * k + 3]};
+    const unsigned param_addr = (unsigned)(uintptr_t)pblock;
+    const bf16_t* xbase = a.x;
+    const bool up_rows = (wave & 1) != 0;          // (a wave's W pieces are tile rows [wave * 32, + 32): the second half of a wave column)
+    const bf16_t* wbase = (SW && seg_act ? (up_rows ? a.sg.w_up : a.sg.w_gate) : seg_w) + w_off;
+    const int npairs = a.K / 128;
+    const unsigned ldsw = (unsigned)(uintptr_t)smem + (unsigned)wave * 4096u;
+
+    constexpr int NACC = 4 * CJ;
+    f32x16 acc[NACC];
+#pragma unroll
+    for (int t = 0; t < NACC; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+#define G8_OPERANDS                                                                                                                   \
+    : "+a"(acc[0]), "+a"(acc[1]), "+a"(acc[2]), "+a"(acc[3]), "+a"(acc[4]), "+a"(acc[5]), "+a"(acc[6]), "+a"(acc[7])                   \
+    : "v"(param_addr), "s"(xbase), "s"(wbase), "s"(npairs), "s"(ldsw)                                                                \
+    : G8_CLOBBERS
+    if (VAR == 0) asm volatile(G8_BODY G8_OPERANDS);
+#ifdef OMX_G4_DIAG   // timing-only builds (tools/gen_gemm4_asm.py --diag; OMX_GEMM_ASM_VAR=1..4: no DMA, no fragment reads, no barrier / waits, none of them)
+    else if (VAR == 1) asm volatile(G8_BODY_D1 G8_OPERANDS);
+    else if (VAR == 2) asm volatile(G8_BODY_D2 G8_OPERANDS);
+    else if (VAR == 3) asm volatile(G8_BODY_D3 G8_OPERANDS);
+    else if (VAR == 4) asm volatile(G8_BODY_D4 G8_OPERANDS);
+#endif
+#undef G8_OPERANDS
+
+    // ---- epilogue: acc[i * CJ + j][4 g + e] = row (wr * 128 + i * 32 + l32), column (wc * WCOLS + j * 32 + 8 g + 4 hi + e) of the tile ----
+    if constexpr (SW) {
+        if (seg_act) {
+            const bool per_op = a.sg.act_mode == 1;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int lrow = m0 + wr * 128 + i * 32 + l32;
+                if (lrow >= rows_valid) continue;
+                const int row = row_base + lrow;
+#pragma unroll
+                for (int j = 0; j < CJ / 2; ++j)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int col = n0 / 2 + wc * (WCOLS / 2) + j * 32 + 8 * g + 4 * hi;
+                        if (col >= seg_cols) continue;   // half is a multiple of 4: a run is inside or outside
+                        float v[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float gt = A16::rnd(acc[i * CJ + j][4 * g + e]), up = A16::rnd(acc[i * CJ + j + CJ / 2][4 * g + e]);
+                            if (per_op) {   // nn::silu(gate) * up, each primitive rounded to bf16 (silu_mul_kernel, prefill.hip)
+                                const float sg = A16::rnd(1.0f / (1.0f + expf(-gt)));
+                                v[e] = A16::rnd(gt * sg) * up;
+                            } else {        // fused_swiglu: one rounding (swiglu_strided_kernel, dit.hip)
+                                v[e] = gt / (1.0f + expf(-gt)) * up;
+                            }
+                        }
+                        *reinterpret_cast<u32x2*>(a.sg.out_act + (size_t)row * a.sg.ld_act + col) =
+                            u32x2{A16::pack(v[0], v[1]), A16::pack(v[2], v[3])};
+                    }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int lrow = m0 + wr * 128 + i * 32 + l32;
+                if (lrow >= rows_valid) continue;
+                const int row = row_base + lrow;
+#pragma unroll
+                for (int j = 0; j < CJ; ++j)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int col = n0 + wc * WCOLS + j * 32 + 8 * g + 4 * hi;
+                        if (col >= seg_cols) continue;   // widths are multiples of 4
+                        float v[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = acc[i * CJ + j][4 * g + e];
+                        if (seg_bias) {
+                            const u32x2 b = *reinterpret_cast<const u32x2*>(seg_bias + col);
+                            v[0] += A16::lo(b[0]); v[1] += A16::hi(b[0]); v[2] += A16::lo(b[1]); v[3] += A16::hi(b[1]);
+                        }
+                        *reinterpret_cast<u32x2*>(seg_out + (size_t)row * seg_ld + col) = u32x2{A16::pack(v[0], v[1]), A16::pack(v[2], v[3])};
+                    }
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = m0 + wr * 128 + i * 32 + l32;
+        if (row >= a.M) continue;
+#pragma unroll
+        for (int j = 0; j < CJ; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int col = n0 + wc * WCOLS + j * 32 + 8 * g + 4 * hi;
+                if (col >= a.N) continue;
+                const size_t o = (size_t)row * a.N + col;
+                const bool full = col + 3 < a.N && (a.N & 3) == 0;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[i * CJ + j][4 * g + e];
+                if (full) {
+                    if (a.bias) {
+                        const u32x2 b = *reinterpret_cast<const u32x2*>(a.bias + col);
+                        v[0] += A16::lo(b[0]); v[1] += A16::hi(b[0]); v[2] += A16::lo(b[1]); v[3] += A16::hi(b[1]);
+                    }
+                    if (a.relu) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                    }
+                    if (a.gate) {
+                        const u32x2 r = *reinterpret_cast<const u32x2*>(a.resid + o);
+                        const u32x2 gt = *reinterpret_cast<const u32x2*>(a.gate + col);
+                        v[0] = A16::lo(r[0]) + v[0] * A16::lo(gt[0]); v[1] = A16::hi(r[0]) + v[1] * A16::hi(gt[0]);
+                        v[2] = A16::lo(r[1]) + v[2] * A16::lo(gt[1]); v[3] = A16::hi(r[1]) + v[3] * A16::hi(gt[1]);
+                    } else if (a.resid) {
+                        const u32x2 r = *reinterpret_cast<const u32x2*>(a.resid + o);
+                        v[0] = A16::lo(r[0]) + A16::rnd(v[0]); v[1] = A16::hi(r[0]) + A16::rnd(v[1]);
+                        v[2] = A16::lo(r[1]) + A16::rnd(v[2]); v[3] = A16::hi(r[1]) + A16::rnd(v[3]);
+                    }
+                    *reinterpret_cast<u32x2*>(a.out + o) = u32x2{A16::pack(v[0], v[1]), A16::pack(v[2], v[3])};
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (col + e >= a.N) break;
+                        float x = v[e] + (a.bias ? A16::val(a.bias[col + e]) : 0.f);
+                        if (a.relu) x = fmaxf(x, 0.f);
+                        if (a.gate) x = A16::val(a.resid[o + e]) + x * A16::val(a.gate[col + e]);
+                        else if (a.resid) x = A16::val(a.resid[o + e]) + A16::rnd(x);
+                        a.out[o + e] = A16::bits(x);
+                    }
+                }
+            }
+    }
+}
+
+// does the asm-scheduled kernel take this shape?  (OMX_GEMM_ASM=0: the hipcc-scheduled eight-wave kernel)
+static int asm_waves() {
+    const char* e = getenv("OMX_GEMM_ASM");
+    return e ? atoi(e) : 0;
+}
+static bool w4_takes(int64_t x_rows, int K, int64_t w_rows_max) {
+    if (asm_waves() == 0) return false;
+    return K % 128 == 0 && (x_rows * K + 64) * 2 < ((int64_t)1 << 32) && (w_rows_max * K + 64) * 2 < ((int64_t)1 << 32);
+}
+
+#else
+static bool w4_takes(int64_t, int, int64_t) { return false; }
+#endif   // OMX_EXPERIMENTS
+
 // ---- 64 x 64 x 64 tile, deep LDS-DMA ring: GEMMs whose 128^2 grid cannot fill the chip ----
 // (Paraformer layers: 501 x 512 x 512 is 16 tiles of 128^2; the text encoder and the DiT txt stream at 512 rows; short prompts.)
 // With one or two blocks per CU and ONE tile of prefetch the 128^2 kernel pays a full memory round trip per K step
@@ -955,6 +1206,16 @@ int ensure_attr() {
         OMX_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_bf16_nt_256_kernel<16, false, false, 128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big::smem_bytes(128)));
         OMX_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_bf16_nt_256_kernel<16, false, false, 256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big::SMEM));
         OMX_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_bf16_nt_256_kernel<16, true, false, 256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big::SMEM));
+#ifdef OMX_EXPERIMENTS
+        OMX_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_bf16_nt_asm_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, w4::SMEM));
+        OMX_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_bf16_nt_asm_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, w4::SMEM));
+#endif
+#ifdef OMX_G4_DIAG
+        OMX_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_bf16_nt_asm_kernel<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, w4::SMEM));
+        OMX_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_bf16_nt_asm_kernel<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, w4::SMEM));
+        OMX_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_bf16_nt_asm_kernel<false, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, w4::SMEM));
+        OMX_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_bf16_nt_asm_kernel<false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, w4::SMEM));
+#endif
         OMX_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_bf16_nt_skinny_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * skinny::STAGE));
         OMX_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_bf16_nt_skinny_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * skinny::STAGE));
         OMX_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_bf16_nt_skinny_kernel<8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * skinny::STAGE));
@@ -1120,6 +1381,21 @@ static int launch_gemm_impl(bf16_t* out, const bf16_t* x, const bf16_t* w, const
             a.ksplit = ksplit;
             if (ksplit > 1 && split_workspace_big(s, (size_t)tiles256 * ksplit * 256 * 256, (size_t)tiles256, &a.split_ws, &a.split_cnt)) return 1;
             const char* mf_env = getenv("OMX_GEMM_MFMA");
+#ifdef OMX_EXPERIMENTS
+            if (ksplit == 1 && !mf_env && w4_takes(M, K, N)) {
+                const int blocks = a.grid_m * a.grid_n;
+#ifdef OMX_G4_DIAG
+                const char* ve = getenv("OMX_GEMM_ASM_VAR");
+                const int var = ve ? atoi(ve) : 0;
+                if (var == 1) gemm_bf16_nt_asm_kernel<false, 1><<<blocks, 512, w4::SMEM, s>>>(a);
+                else if (var == 2) gemm_bf16_nt_asm_kernel<false, 2><<<blocks, 512, w4::SMEM, s>>>(a);
+                else if (var == 3) gemm_bf16_nt_asm_kernel<false, 3><<<blocks, 512, w4::SMEM, s>>>(a);
+                else if (var == 4) gemm_bf16_nt_asm_kernel<false, 4><<<blocks, 512, w4::SMEM, s>>>(a);
+                else
+#endif
+                gemm_bf16_nt_asm_kernel<false><<<blocks, 512, w4::SMEM, s>>>(a);
+            } else
+#endif
             if (mf_env && atoi(mf_env) == 32) gemm_bf16_nt_256_kernel<32><<<a.grid_m * a.grid_n * ksplit, big::NT, big::SMEM, s>>>(a);
             else gemm_bf16_nt_256_kernel<16><<<a.grid_m * a.grid_n * ksplit, big::NT, big::SMEM, s>>>(a);
         } else if (forced == 64 || (forced == 0 && a.grid_m * a.grid_n <= 128)) {
@@ -1232,7 +1508,12 @@ int launch_gemm_bf16_segmented(const bf16_t* x, int M, int K, const GemmSegs& se
     a.N = n + 2 * segs.half;
     a.grid_m = (M + 255) / 256;
     a.grid_n = seg_tiles(segs);
+    int64_t w_rows_max = segs.half;
+    for (int i = 0; i < segs.n_plain; ++i) w_rows_max = std::max<int64_t>(w_rows_max, segs.plain[i].cols);
     if (g_gemm_f16) gemm_bf16_nt_256_kernel<16, true, false, 256, true><<<a.grid_m * a.grid_n, big::NT, big::SMEM, s>>>(a);
+#ifdef OMX_EXPERIMENTS
+    else if (w4_takes(M, K, w_rows_max)) gemm_bf16_nt_asm_kernel<true><<<a.grid_m * a.grid_n, 512, w4::SMEM, s>>>(a);
+#endif
     else
     gemm_bf16_nt_256_kernel<16, true><<<a.grid_m * a.grid_n, big::NT, big::SMEM, s>>>(a);
     OMX_LAUNCH_CHECK();

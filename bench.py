@@ -593,8 +593,7 @@ def main():
     prefill_steady_ms = model.last_prefill_ms()
     if int(first2) != int(first):
         raise SystemExit(f"rank {rank}: the second prefill of the same prompt sampled {int(first2)}, the first {int(first)}")
-    if args.warmup:
-        model.decode(args.warmup)
+    warm_toks = model.decode(args.warmup) if args.warmup else []
 
     def barrier():
         if dist is not None:
@@ -660,6 +659,28 @@ def main():
             except Exception as e:      # a measurement hook must never cost the measured line: fall back to the isolated launches
                 print(f"in-step kernel timing failed ({e}); roofline.achieved from isolated launches", file=sys.stderr)
                 in_step = None
+        # the DROP-IN route (what an unmodified qwen3-mlx gets: no fused engine, ~1 400 eager mlx_* calls per token through the handle ABI,
+        # csrc/per_op_route.hip replays Model::forward + Generate::next natively on this model's weights) next to the engine's number
+        per_op = None
+        if world == 1 and not moe and keep is None and not cfg.get("quantization"):
+            try:
+                n_po = 16
+                r = model.per_op_route(prompt, n_po)
+                eng = [int(first)] + [int(t) for t in warm_toks[:n_po]]
+                got = [int(t) for t in r["tokens"]]
+                n_cmp = min(len(eng), len(got))
+                agree = next((i for i in range(n_cmp) if eng[i] != got[i]), n_cmp)
+                per_op = {"metric": "decode_tokens_per_sec_per_op_route", "value": round(1e3 / r["ms_per_token"], 2), "unit": "tokens/s",
+                          "ms_per_token_host_wall": round(r["ms_per_token"], 3), "mlx_calls_per_token": round(r["calls_per_token"], 1),
+                          "host_us_per_mlx_call": round(r["ms_per_token"] * 1e3 / r["calls_per_token"], 2),
+                          "prefill_ms_host_wall": round(r["prefill_ms"], 1), "tokens_timed": n_po, "context": args.prompt,
+                          "first_tokens": got[:5], "leading_tokens_equal_to_engine": f"{agree} of {n_cmp}",
+                          "vs_engine": round((1e3 / r["ms_per_token"]) / tok_s, 3),
+                          "note": "qwen3-mlx Model::forward + Generate::next replayed call for call through the mlx-c handle ABI by native code on the "
+                                  "engine's own weights (csrc/per_op_route.hip): the route an UNMODIFIED crate takes; `value` above is the "
+                                  "omx_qwen3_* engine, which needs the one-file caller change of INTEGRATION.md section 3"}
+            except Exception as e:   # a report, never a reason to lose the measured line
+                per_op = {"metric": "decode_tokens_per_sec_per_op_route", "value": None, "error": str(e)[:300]}
         k_s = in_step["gate_up"] * 1e-6 if in_step else iso_s
         achieved = k_bytes / k_s / 1e9
         H, Hkv, D, hd, I, V = (cfg["num_attention_heads"], cfg["num_key_value_heads"], cfg["head_dim"], cfg["hidden_size"],
@@ -708,6 +729,8 @@ def main():
             "first_tokens": [int(first)] + [int(t) for t in toks[:4]],
             "first_token_check": {"expected": want_first, "ok": first_ok},
         }
+        if per_op is not None:
+            out["per_op_route"] = per_op
         if in_step:
             if in_step.get("step_engine", 0.0) == 0.0:   # (the persistent step's launch: only with OMX_STEP_ENGINE set)
                 in_step.pop("step_engine", None)

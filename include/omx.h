@@ -195,6 +195,8 @@ int omx_qwen3_destroy(omx_qwen3 m);
  * engine reads raw pointers, so a tensor whose size disagrees with the config is refused here ("ShapeMismatch", the reference's
  * load-time shape error) instead of being read past its end                                         */
 int omx_qwen3_set_weight(omx_qwen3 m, const char* name, const void* ptr, size_t nbytes);
+/* device pointer (+ expected byte length; 0 = unknown) of a registered or synthesised tensor by checkpoint name */
+int omx_qwen3_get_weight(omx_qwen3 m, const char* name, const void** ptr, size_t* nbytes);
 /* allocate + fill every weight with the seeded synthetic generator (seed = base ^ crc32(name))      */
 int omx_qwen3_synth_weights(omx_qwen3 m, uint32_t base_seed);
 /* ... with PEAKED logits: embedding std 64, lm_head[v] = table[(v + 1) mod V] at std 0.02 -- the greedy successor of token t is t - 1 with
@@ -234,6 +236,11 @@ int omx_qwen3_verify(omx_qwen3 m, const uint32_t* tokens, int n, uint32_t* greed
 int omx_qwen3_sampler_state(omx_qwen3 m, uint32_t* state2, int set);
 int omx_qwen3_verify_logits(omx_qwen3 m, int row, void* host_bf16, int n);
 int omx_qwen3_trim(omx_qwen3 m, int n, uint32_t next_token);
+/* measurement hook (csrc/per_op_route.hip): qwen3-mlx's Model::forward + Generate::next replayed call for call through the mlx-c handle ABI
+ * on this engine's weights (borrowed) -- what an UNMODIFIED crate gets.  tokens_out [n_new + 1]: the token sampled from the prompt, then n_new
+ * greedy tokens; host wall-clock per decoded token and mlx_* calls per token. */
+int omx_bench_qwen3_per_op(omx_qwen3 model, const omx_qwen3_config* cfg, const uint32_t* prompt, int n_prompt, int n_new,
+                           uint32_t* tokens_out, double* prefill_ms, double* ms_per_token, double* calls_per_token);
 /* timing of the last omx_qwen3_decode call measured with HIP events on the engine stream (ms)       */
 int omx_qwen3_last_decode_ms(omx_qwen3 m, float* ms);
 int omx_qwen3_last_prefill_ms(omx_qwen3 m, float* ms);   /* same for the last omx_qwen3_prefill call */

@@ -314,6 +314,8 @@ int mlx_gather_mm(mlx_array* res, const mlx_array a, const mlx_array b, const ml
 
 /* ---- native replacements for the two JIT Metal kernels (mlx_fast_metal_kernel_apply, fast.h:156;
  *      mlx-rs-core/src/metal_kernels.rs:188-236, 260-339): the two Rust call sites switch to these ---- */
+/* omx extension: an array over device memory the caller owns and keeps alive (row-major, 16-byte aligned; never written by an op) */
+mlx_array omx_mlx_array_from_device(const void* device_ptr, const int* shape, int dim, mlx_dtype dtype);
 int omx_mlx_fused_swiglu(mlx_array* res, const mlx_array x, const mlx_array gate, const mlx_stream s);
 int omx_mlx_fused_modulate(mlx_array* res, const mlx_array x, const mlx_array shift, const mlx_array scale,
                            const mlx_stream s);

@@ -1590,6 +1590,17 @@ int omx_qwen3_set_weight(omx_qwen3 m, const char* name, const void* ptr, size_t 
     return 0;
 }
 
+// device pointer of a registered (or synthesised) tensor by its checkpoint name: what a caller that ALSO drives the per-op mlx-c route on the
+// same weights needs (omx_mlx_array_from_device wraps it; bench: per_op_route.hip)
+int omx_qwen3_get_weight(omx_qwen3 m, const char* name, const void** ptr, size_t* nbytes) {
+    OMX_REQUIRE(m && name && ptr, "omx_qwen3_get_weight: null argument");
+    auto it = m->named.find(name);
+    if (it == m->named.end()) return set_error("WeightNotFound: %s", name);
+    *ptr = it->second;
+    if (nbytes) *nbytes = expected_weight_bytes(m, name);
+    return 0;
+}
+
 static int synth_weights_impl(omx_qwen3 m, uint32_t base_seed, bool peaked);
 int omx_qwen3_synth_weights(omx_qwen3 m, uint32_t base_seed) { return synth_weights_impl(m, base_seed, false); }
 /* The same synthetic checkpoint with PEAKED logits (parity at full size: i.i.d. weights give flat logits whose argmax flips on the last

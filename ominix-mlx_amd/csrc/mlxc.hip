@@ -68,8 +68,9 @@ struct Pool {
 struct Buf {
     void* p;
     size_t bytes;
-    Buf(void* p_, size_t b) : p(p_), bytes(b) {}
-    ~Buf() { if (p) g_pool.put(p, bytes); }
+    bool owned;                     // false: device memory BORROWED from the caller (omx_mlx_array_from_device): never returned to the pool
+    Buf(void* p_, size_t b, bool owned_ = true) : p(p_), bytes(b), owned(owned_) {}
+    ~Buf() { if (p && owned) g_pool.put(p, bytes); }
 };
 
 struct Arr {
@@ -463,6 +464,21 @@ mlx_array mlx_array_new_data(const void* data, const int* shape, int dim, mlx_dt
             return mlx_array{nullptr};
         }
     }
+    return mlx_array{a};
+}
+// omx extension (no mlx-c counterpart: MLX owns its buffers): an array over device memory the CALLER owns and keeps alive -- the weights
+// an engine already holds, shared with the per-op route without a copy.  Row-major, 16-byte aligned.  Never written by an op (results are
+// fresh arrays; mlx_slice_update copies when its source is not solely owned -- a borrowed buffer never counts as solely owned).
+mlx_array omx_mlx_array_from_device(const void* device_ptr, const int* shape, int dim, mlx_dtype dtype) {
+    if (!device_ptr || ((uintptr_t)device_ptr & 15u) != 0 || dim < 0 || (dim > 0 && !shape)) {
+        set_error("omx_mlx_array_from_device: null / unaligned pointer or bad shape");
+        return mlx_array{nullptr};
+    }
+    Arr* a = new Arr();
+    a->shape.assign(shape, shape + dim);
+    a->strides = row_major(a->shape);
+    a->dt = dtype;
+    a->buf = std::make_shared<Buf>(const_cast<void*>(device_ptr), a->size() * dsize(dtype), false);
     return mlx_array{a};
 }
 int mlx_array_set(mlx_array* arr, const mlx_array src) {
@@ -1025,7 +1041,7 @@ int mlx_slice_update(mlx_array* res, const mlx_array src, const mlx_array update
     // which makes the update copy.  (include/omx_mlx_c.h states the contract.)
     Arr* r = nullptr;
     bool donate = false;
-    if (is_contig(s) && s.buf.use_count() == 1) {
+    if (is_contig(s) && s.buf.use_count() == 1 && s.buf->owned) {   // (a borrowed buffer is the caller's: never updated in place)
         r = new Arr(s);
         r->host.clear();
         donate = !(res && res->ctx == src.ctx);   // the same handle is replaced by assign() below: nothing left to mark

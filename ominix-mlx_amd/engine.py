@@ -54,6 +54,9 @@ ENGINE_SIGNATURES = {
     "omx_qwen3_verify": (c_int, [c_void_p, ctypes.POINTER(c_uint32), c_int, ctypes.POINTER(c_uint32)]),
     "omx_qwen3_verify_logits": (c_int, [c_void_p, c_int, c_void_p, c_int]),
     "omx_qwen3_trim": (c_int, [c_void_p, c_int, c_uint32]),
+    "omx_qwen3_get_weight": (c_int, [c_void_p, ctypes.c_char_p, ctypes.POINTER(c_void_p), ctypes.POINTER(ctypes.c_size_t)]),
+    "omx_bench_qwen3_per_op": (c_int, [c_void_p, ctypes.POINTER(Qwen3Config), ctypes.POINTER(c_uint32), c_int, c_int, ctypes.POINTER(c_uint32),
+                                       ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
 }
 for _n, (_r, _a) in ENGINE_SIGNATURES.items():
     _f = getattr(lib, _n)
@@ -306,6 +309,17 @@ class Model:
         v = c_float()
         check(lib.omx_qwen3_last_prefill_ms(self._h, ctypes.byref(v)))
         return v.value
+
+    def per_op_route(self, prompt, n_new: int) -> dict:
+        """The DROP-IN route on this model's weights (csrc/per_op_route.hip): qwen3-mlx's Model::forward + Generate::next replayed call for
+        call through the mlx-c handle ABI, as an unmodified crate would drive it -- greedy tokens (the prompt's, then n_new), host
+        wall-clock per decoded token, mlx_* calls per token.  Independent of the engine's own KV cache and step graph."""
+        ids = np.ascontiguousarray(np.asarray(prompt, dtype=np.uint32).ravel())
+        toks = np.zeros(n_new + 1, np.uint32)
+        pre, per, calls = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+        check(lib.omx_bench_qwen3_per_op(self._h, ctypes.byref(self.cfg), ids.ctypes.data_as(ctypes.POINTER(c_uint32)), ids.size, n_new,
+                                         toks.ctypes.data_as(ctypes.POINTER(c_uint32)), ctypes.byref(pre), ctypes.byref(per), ctypes.byref(calls)))
+        return {"tokens": toks, "prefill_ms": pre.value, "ms_per_token": per.value, "calls_per_token": calls.value}
 
     def last_logits(self) -> np.ndarray:
         raw = np.empty(self.vocab_local, dtype=np.uint16)

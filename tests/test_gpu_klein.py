@@ -166,3 +166,32 @@ def test_klein_full_sequence_4608_tokens(omx, monkeypatch):
     group.close()
     np.testing.assert_array_equal(tp[0], tp[1])
     assert np.abs(tp[0] - one).max() <= 2.0 ** -6 * np.abs(one).max() * np.sqrt(4)
+
+
+def test_klein_real_widths_match_the_oracle(omx):
+    """FLUX.2-klein at its REAL widths against an oracle VALUE (VERDICT r4 "Next" 4b; until round 5 the real-width test held properties
+    only): hidden 3072, 24 heads of 128, MLP 9216, text width 7680 (klein_model.rs:182-196 defaults), one double + one single block, 128 text
+    tokens + a 16 x 32 latent grid = 640 tokens (the 4-wave flash kernel's shape class: Tk % 256 == 0; the 256^2 GEMM tiles; the segmented
+    q/k/v + SwiGLU launch).  tests/golden/klein_fullwidth_pin.npz holds oracle/ref_klein.py's velocity (tools/klein_fullwidth_pin.py, float64
+    accumulation); the bound is the tiny test's: 2^-6 * max|ref| * sqrt(blocks)."""
+    import os
+    from ominix_mlx_amd import klein
+    path = os.path.join(os.path.dirname(__file__), "golden", "klein_fullwidth_pin.npz")
+    pin = np.load(path)
+    ref = pin["velocity"]
+    s_txt, grid, seed = int(pin["s_txt"]), tuple(int(v) for v in pin["grid"]), int(pin["seed"])
+    p = rk.KleinParams(depth=1, depth_single=1)
+    g = np.random.default_rng(seed)                                   # (tools/klein_fullwidth_pin.py inputs())
+    latent = rc.bf16_round(g.standard_normal((grid[0] * grid[1], p.in_channels)).astype(np.float32))
+    txt = rc.bf16_round(g.standard_normal((s_txt, p.txt_embed_dim)).astype(np.float32))
+    T = omx.ops.Tensor
+    m = klein.FluxKlein(depth=1, depth_single=1)
+    m.synth_weights()
+    rcos, rsin = klein.compute_rope(klein.create_txt_ids(s_txt), klein.create_img_ids(*grid))
+    out = m.forward_with_rope(T.from_numpy(latent), T.from_numpy(txt), float(pin["timestep"]), rcos, rsin).numpy()
+    m.close()
+    assert out.shape == ref.shape
+    bound = 2.0 ** -6 * float(pin["max_abs"]) * np.sqrt(2)
+    err = np.abs(out - ref)
+    assert err.max() <= bound, f"max err {err.max():.4f} > {bound:.4f}"
+    assert err.mean() <= bound / 8, f"mean err {err.mean():.5f}"

@@ -4,7 +4,7 @@ Covers SURVEY.md 8a rows a2 (KVCache / ConcatKeyValueCache), a1-a5 through handl
 import numpy as np
 import pytest
 
-from oracle import ref_core as rc, ref_qwen3 as rq
+from oracle import ref_core as rc, ref_qwen3 as rq, synth
 from test_gpu_primitives import assert_bf16_close, rand
 
 pytestmark = pytest.mark.gpu
@@ -424,3 +424,30 @@ def test_reductions_on_any_axis_and_general_addmm(mx):
     b = rand((9,), 94).astype(np.float32)
     got = mx.addmm(mx.Array.from_numpy(b, mx.FLOAT32), mx.Array.from_numpy(x, mx.FLOAT32), mx.Array.from_numpy(w, mx.FLOAT32))
     np.testing.assert_allclose(got.numpy(), b + x @ w, rtol=2e-5, atol=2e-5)
+
+
+def test_drop_in_route_replayed_natively_matches_the_engine(omx):
+    """csrc/per_op_route.hip (round 5): qwen3-mlx's Model::forward + Generate::next replayed call for call through the mlx-c handle ABI by
+    native code (what an unmodified crate does), on the ENGINE's own weights (omx_qwen3_get_weight + omx_mlx_array_from_device: borrowed,
+    no copy).  The fused engine keeps the per-op arithmetic and rounding points, so the two routes emit the same greedy tokens until a
+    near-tie of the flat i.i.d. logits flips on the summation order of a GEMV (measured: the first 106 of 231) -- asserted on the first 64;
+    a 300-token prompt (the KVCache's second 256-step is allocated in the prompt, the concatenating growth during decode at 512) and 230
+    new tokens; ~38 mlx_* calls per layer and token."""
+    from ominix_mlx_amd import engine
+    cfg = dict(hidden_size=512, num_hidden_layers=3, intermediate_size=1536, num_attention_heads=8, num_key_value_heads=4, head_dim=64,
+               vocab_size=2048, rms_norm_eps=1e-6, rope_theta=1e6, tie_word_embeddings=False)
+    m = engine.Model(max_context=1024, **cfg)
+    m.synth_weights()
+    prompt = synth.prompt_ids(300, cfg["vocab_size"])
+    want = [int(m.prefill(prompt))] + [int(t) for t in m.decode(230)]
+    got = m.per_op_route(prompt, 230)
+    assert [int(t) for t in got["tokens"]][:64] == want[:64]
+    assert len(got["tokens"]) == 231 and all(0 <= int(t) < cfg["vocab_size"] for t in got["tokens"])
+    assert 35 * 3 <= got["calls_per_token"] <= 45 * 3 + 12, got["calls_per_token"]
+    assert got["ms_per_token"] > 0 and got["prefill_ms"] > 0
+    # the engine is untouched by the replay (own cache, own graph): it continues where it was
+    more = [int(t) for t in m.decode(4)]
+    m.reset()
+    again = [int(m.prefill(prompt))] + [int(t) for t in m.decode(234)]
+    assert again[:231] == want and again[231:] == more
+    m.close()

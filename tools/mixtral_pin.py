@@ -83,7 +83,7 @@ order = np.argsort(-logits, axis=-1, kind="stable")
 top_idx = order[:, :8].astype(np.int64)
 top_val = np.take_along_axis(logits, top_idx, axis=-1)
 sub_idx = np.sort(np.random.default_rng(7).choice(cfg.vocab_size, 256, replace=False)).astype(np.int64)
-out = os.path.join(ROOT, "tests", "golden", "mixtral_fullwidth_pin.npz")
+out = os.path.join(ROOT, "tests", "golden", "mixtral_fullwidth_pin.npz" if NL == 4 else f"mixtral_fullwidth_pin_{NL}l.npz")
 np.savez_compressed(out, n_layers=NL, prompt=np.asarray(prompt, np.int64), greedy=order[:, 0].astype(np.int64), top_idx=top_idx,
                     top_val=top_val, margin=(top_val[:, 0] - top_val[:, 1]).astype(np.float32), sub_idx=sub_idx,
                     sub_val=logits[:, sub_idx], max_abs=np.abs(logits).max(axis=-1).astype(np.float32),

@@ -327,6 +327,18 @@ typedef struct omx_moe_ep_slots_ {
 int omx_moe_block_partial_ep(float* partial, const void* x, const void* norm_w, float eps, void* xn, const void* gate_w,
                              const void* w_gate, const void* w_up, const void* w_down, int n_tokens, int hidden, int inter,
                              int n_experts, int top_k, int mode, int norm_topk_prob, int e_lo, int e_n, omx_stream stream);
+/* the two sharded forms on MLX-packed expert stacks (the reference's own Mixtral format: mixtral-mlx/src/model.rs:466-615): this rank's packed
+ * experts / columns -- the triplet of a slice is the slice of the triplet; bf16 scales.  Contracts of omx_moe_block_partial_ep / _tp. */
+int omx_moe_block_partial_ep_q(float* partial, const void* x, const void* norm_w, float eps, void* xn, const void* q_router, const void* s_router,
+                               const void* b_router, const void* q_gate, const void* s_gate, const void* b_gate, const void* q_up,
+                               const void* s_up, const void* b_up, const void* q_down, const void* s_down, const void* b_down, int n_tokens,
+                               int hidden, int inter, int n_experts, int top_k, int mode, int norm_topk_prob, int e_lo, int e_n, int group_size,
+                               int bits, omx_stream stream);
+int omx_moe_block_partial_tp_q(float* y_partial, uint32_t* route_inds, void* route_scores, const void* x, const void* norm_w, float eps,
+                               const void* q_router, const void* s_router, const void* b_router, const void* q_gate, const void* s_gate,
+                               const void* b_gate, const void* q_up, const void* s_up, const void* b_up, const void* q_down, const void* s_down,
+                               const void* b_down, int n_tokens, int hidden, int inter, int n_experts, int top_k, int mode, int norm_topk_prob,
+                               int group_size, int bits, omx_stream stream);
 int omx_moe_block_slots_ep(omx_moe_ep_slots* out, const void* x /* normalised rows */, const void* gate_w, const void* w_gate, const void* w_up,
                            const void* w_down, int n_tokens, int hidden, int inter, int n_experts, int top_k, int mode, int norm_topk_prob,
                            int e_lo, int e_n, omx_stream stream);

@@ -349,10 +349,11 @@ int resolve_weights(omx_qwen3 m) {
             if (!m->cfg.no_qk_norm && (get(p + "self_attn.q_norm.weight", &L.q_norm) || get(p + "self_attn.k_norm.weight", &L.k_norm))) return 1;
             if (m->cfg.num_experts > 0) {
                 const std::string mp = p + (m->cfg.moe_mode == 0 ? "block_sparse_moe." : "mlp.");
-                const int Im = m->cfg.moe_intermediate_size;
-                const int E = m->cfg.num_experts;
-                if (getq(mp + "gate", E, &Q.moe_router, hd) || getq(mp + "switch_mlp.gate_proj", Im, &Q.moe_g, hd, E) ||
-                    getq(mp + "switch_mlp.up_proj", Im, &Q.moe_u, hd, E) || getq(mp + "switch_mlp.down_proj", hd, &Q.moe_d, Im, E))
+                // (expert tensor parallel: this rank's columns of every expert; expert parallel: this rank's experts)
+                const int Im = m->cfg.tp_size > 1 ? m->moe_I : m->cfg.moe_intermediate_size;
+                const int E = m->cfg.num_experts, El = m->cfg.ep_size > 1 ? E / m->cfg.ep_size : E;
+                if (getq(mp + "gate", E, &Q.moe_router, hd) || getq(mp + "switch_mlp.gate_proj", Im, &Q.moe_g, hd, El) ||
+                    getq(mp + "switch_mlp.up_proj", Im, &Q.moe_u, hd, El) || getq(mp + "switch_mlp.down_proj", hd, &Q.moe_d, Im, El))
                     return 1;
             } else if (getq(p + "mlp.gate_proj", m->I, &Q.gate, hd) || getq(p + "mlp.up_proj", m->I, &Q.up, hd) || getq(p + "mlp.down_proj", hd, &Q.down, m->I)) {
                 return 1;
@@ -528,6 +529,31 @@ int enqueue_step_quant(omx_qwen3 m, bool with_head) {
             a.x = m->attn_out; a.resid = h; a.out = hn; a.scales_f16 = sf16;
             if (launch_qgemv(a, bits, PRO_NONE, EPI_RESIDUAL, s)) return 1;
             bf16_t* t = h; h = hn; hn = t;
+        }
+        if (c.num_experts > 0 && c.tp_size > 1) {
+            // expert tensor parallel on packed stacks (round 5): [replicated packed router + this rank's columns of the routed experts]
+            // [all-reduce of the slots' f32 partials] [weighted sum + residual with the single-device roundings]
+            OMX_REQUIRE(m->allreduce != nullptr, "tp_size > 1 but no communicator set (omx_qwen3_set_comm)");
+            if (omx_moe_block_partial_tp_q(m->moe_y, m->moe_inds, m->moe_scores, h, L.post_ln, c.rms_norm_eps, Q.moe_router.w, Q.moe_router.scales,
+                                           Q.moe_router.biases, Q.moe_g.w, Q.moe_g.scales, Q.moe_g.biases, Q.moe_u.w, Q.moe_u.scales, Q.moe_u.biases,
+                                           Q.moe_d.w, Q.moe_d.scales, Q.moe_d.biases, 1, hd, m->moe_I, c.num_experts, c.num_experts_per_tok, c.moe_mode,
+                                           c.norm_topk_prob, group, bits, s))
+                return 1;
+            OMX_REQUIRE(m->allreduce(m->moe_y, m->moe_y, (size_t)c.num_experts_per_tok * hd, kNcclFloat32, kNcclSum, m->comm, s) == 0, "ncclAllReduce failed");
+            if (omx_moe_combine_slots(hn, m->moe_y, m->moe_scores, h, 1, hd, c.num_experts_per_tok, s)) return 1;
+            bf16_t* t = h; h = hn; hn = t;
+            continue;
+        }
+        if (c.num_experts > 0 && c.ep_size > 1) {
+            // expert parallel on packed stacks (round 5): this rank's experts only, the f32 partial all-reduced and folded into the residual
+            const int el = c.num_experts / c.ep_size;
+            if (omx_moe_block_partial_ep_q(m->partial_b, h, L.post_ln, c.rms_norm_eps, m->moe_xn, Q.moe_router.w, Q.moe_router.scales,
+                                           Q.moe_router.biases, Q.moe_g.w, Q.moe_g.scales, Q.moe_g.biases, Q.moe_u.w, Q.moe_u.scales, Q.moe_u.biases,
+                                           Q.moe_d.w, Q.moe_d.scales, Q.moe_d.biases, 1, hd, c.moe_intermediate_size, c.num_experts,
+                                           c.num_experts_per_tok, c.moe_mode, c.norm_topk_prob, c.ep_rank * el, el, group, bits, s))
+                return 1;
+            if (reduce_fold(m->partial_b)) return 1;
+            continue;
         }
         if (c.num_experts > 0) {   // [RMSNorm + router] [selection] [RMSNorm + expert gate/up + SwiGLU] [expert down] [sum + residual]
             if (omx_moe_block_forward_q_ex(hn, h, h, L.post_ln, c.rms_norm_eps, m->moe_xn, Q.moe_router.w, Q.moe_router.scales,
@@ -1297,7 +1323,28 @@ int prefill_prefix_batched(omx_qwen3 m, int T, int off, const EncodeOpts* enc = 
         if (!gu_norm && omx_rms_norm(m->pf_xn, h2, L.post_ln, T, hd, c.rms_norm_eps, act_dt, s)) return 1;
         if (gu_norm) { gu.pre_norm_w = L.post_ln; gu.pre_norm_eps = c.rms_norm_eps; }
         if (c.num_experts > 0) {   // sparse-MoE feed-forward over all T rows (grouped MFMA GEMM route), then the residual
-            if (quant) {
+            if (quant && (c.ep_size > 1 || c.tp_size > 1)) {
+                // packed stacks under expert parallelism / expert tensor parallelism (round 5): this rank's stacks dequantised per call, the
+                // bf16 batched form, ONE all-reduce of the [T, hidden] f32 partial (the exchange combine stays a bf16-checkpoint path)
+                const bool etp = c.tp_size > 1;
+                const int el = etp ? c.num_experts : c.num_experts / c.ep_size;
+                if (!m->pf_ep_partial || m->pf_ep_cap < T) {
+                    OMX_HIP_CHECK(hipStreamSynchronize(s));
+                    if (m->pf_ep_partial) OMX_HIP_CHECK(hipFree(m->pf_ep_partial));
+                    OMX_HIP_CHECK(hipMalloc((void**)&m->pf_ep_partial, (size_t)std::max(T, m->pf_cap) * hd * sizeof(float)));
+                    m->pf_ep_cap = std::max(T, m->pf_cap);
+                }
+                if (omx_moe_block_partial_ep_q(m->pf_ep_partial, h2, L.post_ln, c.rms_norm_eps, m->pf_xn, Q.moe_router.w, Q.moe_router.scales,
+                                               Q.moe_router.biases, Q.moe_g.w, Q.moe_g.scales, Q.moe_g.biases, Q.moe_u.w, Q.moe_u.scales,
+                                               Q.moe_u.biases, Q.moe_d.w, Q.moe_d.scales, Q.moe_d.biases, T, hd, etp ? m->moe_I : c.moe_intermediate_size,
+                                               c.num_experts, c.num_experts_per_tok, c.moe_mode, c.norm_topk_prob, etp ? 0 : c.ep_rank * el, el,
+                                               c.quant_group, c.quant_bits, s))
+                    return 1;
+                OMX_REQUIRE(m->allreduce != nullptr, "ep_size / tp_size > 1 but no communicator set (omx_qwen3_set_comm)");
+                OMX_REQUIRE(m->allreduce(m->pf_ep_partial, m->pf_ep_partial, (size_t)T * hd, kNcclFloat32, kNcclSum, m->comm, s) == 0, "ncclAllReduce failed");
+                ep_fold_kernel<<<1024, 256, 0, s>>>(h, h2, m->pf_ep_partial, (int64_t)T * hd);
+                OMX_LAUNCH_CHECK();
+            } else if (quant) {
                 if (omx_moe_block_forward_q_ex(h, h2, h2, L.post_ln, c.rms_norm_eps, m->pf_xn, Q.moe_router.w, Q.moe_router.scales,
                                                Q.moe_router.biases, Q.moe_g.w, Q.moe_g.scales, Q.moe_g.biases, Q.moe_u.w, Q.moe_u.scales,
                                                Q.moe_u.biases, Q.moe_d.w, Q.moe_d.scales, Q.moe_d.biases, T, hd, c.moe_intermediate_size,
@@ -1407,9 +1454,10 @@ int omx_qwen3_create(omx_qwen3* out, const omx_qwen3_config* cfg) {
                        (c.num_attention_heads / c.num_key_value_heads) % (c.tp_size / c.num_key_value_heads) == 0),
                 "InvalidConfig: %d kv heads cannot be split or replicated over tp_size %d", c.num_key_value_heads, c.tp_size);
     OMX_REQUIRE(c.quant_bits == 0 || c.quant_bits == 4 || c.quant_bits == 8, "InvalidConfig: quantization bits %d (0 = bf16, 4, 8)", c.quant_bits);
-    // (round 4) quantized checkpoints under tensor parallelism: the packed rows / K slices of the dense model; no experts, bf16 triplets
-    OMX_REQUIRE(c.quant_bits == 0 || c.tp_size == 1 || c.num_experts == 0,
-                "InvalidConfig: a quantized checkpoint under tensor parallelism (tp_size %d) must be a dense model", c.tp_size);
+    // (round 4) quantized checkpoints under tensor parallelism: the packed rows / K slices of the dense model; (round 5) also the packed
+    // expert stacks of a sparse-MoE model, expert parallel or expert tensor parallel, with bf16 triplets
+    OMX_REQUIRE(c.quant_bits == 0 || c.tp_size == 1 || c.num_experts == 0 || !c.quant_scales_f16,
+                "InvalidConfig: a float16-scale sparse-MoE checkpoint runs on one rank (tp_size %d)", c.tp_size);
     omx_qwen3 m = new omx_qwen3_();
     m->cfg = c;
     if (m->cfg.rope_scale == 0.f) m->cfg.rope_scale = 1.f;
@@ -1417,7 +1465,7 @@ int omx_qwen3_create(omx_qwen3* out, const omx_qwen3_config* cfg) {
     if (m->cfg.quant_bits && m->cfg.quant_group == 0) m->cfg.quant_group = 64;     // nn/quantized.rs:330-333
     OMX_REQUIRE(!m->cfg.quant_bits || m->cfg.quant_group == 32 || m->cfg.quant_group == 64 || m->cfg.quant_group == 128,
                 "InvalidConfig: quantization group_size %d (32, 64, 128)", m->cfg.quant_group);
-    OMX_REQUIRE(!m->cfg.quant_scales_f16 || (m->cfg.quant_bits && m->cfg.ep_size <= 1 && m->cfg.head_dim == 128),
+    OMX_REQUIRE(!m->cfg.quant_scales_f16 || (m->cfg.quant_bits && m->cfg.ep_size <= 1 && m->cfg.head_dim == 128 && (m->cfg.num_experts == 0 || m->cfg.tp_size == 1)),
                 "InvalidConfig: a float16 checkpoint (quantization scales_dtype float16) runs as a packed model with head_dim 128 (dense, also tensor-parallel; sparse-MoE on one rank)");
     m->H = c.num_attention_heads / c.tp_size;
     m->Hkv = c.num_key_value_heads >= c.tp_size ? c.num_key_value_heads / c.tp_size : 1;
@@ -1450,12 +1498,13 @@ int omx_qwen3_create(omx_qwen3* out, const omx_qwen3_config* cfg) {
     if (c.num_experts > 0) {
         // tp_size > 1: expert TENSOR parallel -- attention sharded like the dense model, every expert's intermediate columns split over
         // the ranks (decode streams 1 / tp of the two routed experts on every rank; prompts: the expert-parallel batched form over all experts)
-        OMX_REQUIRE(c.tp_size == 1 || (c.ep_size <= 1 && !c.quant_bits && c.moe_intermediate_size % (64 * c.tp_size) == 0),
-                    "InvalidConfig: expert tensor parallelism (tp_size %d with experts) needs bf16 weights, ep_size 1 and moe_intermediate_size %d divisible by 64 * tp_size",
-                    c.tp_size, c.moe_intermediate_size);
+        // (packed stacks, round 5: a rank's columns are whole quantisation groups AND whole packed-GEMV steps: multiples of 512)
+        OMX_REQUIRE(c.tp_size == 1 || (c.ep_size <= 1 && c.moe_intermediate_size % ((c.quant_bits ? 512 : 64) * c.tp_size) == 0),
+                    "InvalidConfig: expert tensor parallelism (tp_size %d with experts) needs ep_size 1 and moe_intermediate_size %d divisible by %d * tp_size",
+                    c.tp_size, c.moe_intermediate_size, c.quant_bits ? 512 : 64);
         m->moe_I = c.moe_intermediate_size / c.tp_size;
-        OMX_REQUIRE(c.ep_size <= 1 || (c.ep_rank >= 0 && c.ep_rank < c.ep_size && c.num_experts % c.ep_size == 0 && !c.quant_bits),
-                    "InvalidConfig: expert parallel rank %d of %d over %d experts (bf16 only)", c.ep_rank, c.ep_size, c.num_experts);
+        OMX_REQUIRE(c.ep_size <= 1 || (c.ep_rank >= 0 && c.ep_rank < c.ep_size && c.num_experts % c.ep_size == 0),
+                    "InvalidConfig: expert parallel rank %d of %d over %d experts", c.ep_rank, c.ep_size, c.num_experts);
         OMX_REQUIRE(!c.quant_bits || c.moe_intermediate_size % 512 == 0, "InvalidConfig: quantised experts need moe_intermediate_size %% 512 == 0 (%d)", c.moe_intermediate_size);
         OMX_REQUIRE(c.num_experts_per_tok >= 1 && c.num_experts_per_tok <= c.num_experts && c.moe_intermediate_size > 0 &&
                         c.moe_intermediate_size % 64 == 0 && (c.moe_mode == 0 || c.moe_mode == 1) && (c.tp_size > 1 || m->H * D >= c.hidden_size),
@@ -1667,8 +1716,31 @@ static int synth_weights_impl(omx_qwen3 m, uint32_t base_seed, bool peaked) {
             if (!rc && c.num_experts > 0) {
                 const std::string mp = p + (c.moe_mode == 0 ? "block_sparse_moe." : "mlp.");
                 const int64_t E = c.num_experts, Im = c.moe_intermediate_size;
-                rc = makeq(mp + "gate", E, hd) || makeq(mp + "switch_mlp.gate_proj", E * Im, hd) || makeq(mp + "switch_mlp.up_proj", E * Im, hd) ||
-                     makeq(mp + "switch_mlp.down_proj", E * hd, Im);
+                if (c.tp_size > 1) {
+                    // expert tensor parallel: rows [r I_l, + I_l) of every expert's gate / up (E strided windows of the logical stack, gathered
+                    // into the scratch before ONE quantise call), the same columns -- whole groups -- of its down projection
+                    const int64_t Il = m->moe_I;
+                    auto makeq_rows = [&](const std::string& prefix) -> int {
+                        const uint32_t seed = base_seed ^ crc32_str((prefix + ".weight").c_str());
+                        for (int64_t e = 0; e < E; ++e)
+                            if (omx_fill_uniform_2d(scratch + e * Il * hd, Il, hd, hd, e * Im + (int64_t)r * Il, 0, seed, amp_w, 0.0f, OMX_BFLOAT16, m->stream)) return 1;
+                        uint32_t* pk = nullptr;
+                        bf16_t *sc = nullptr, *bi = nullptr;
+                        const int64_t rows = E * Il;
+                        if (dev_alloc(m, &pk, (size_t)(rows * hd * c.quant_bits / 32)) || dev_alloc(m, &sc, (size_t)(rows * hd / c.quant_group)) ||
+                            dev_alloc(m, &bi, (size_t)(rows * hd / c.quant_group)))
+                            return 1;
+                        if (omx_quantize(pk, sc, bi, scratch, rows, hd, c.quant_group, c.quant_bits, OMX_BFLOAT16, m->stream)) return 1;
+                        m->named[prefix + ".weight"] = pk; m->named[prefix + ".scales"] = sc; m->named[prefix + ".biases"] = bi;
+                        return 0;
+                    };
+                    rc = makeq(mp + "gate", E, hd) || makeq_rows(mp + "switch_mlp.gate_proj") || makeq_rows(mp + "switch_mlp.up_proj") ||
+                         makeq(mp + "switch_mlp.down_proj", E * hd, Il, Im, 0, (int64_t)r * Il);
+                } else {
+                    const int64_t El = c.ep_size > 1 ? E / c.ep_size : E, e0 = c.ep_size > 1 ? c.ep_rank * El : 0;   // this rank's experts
+                    rc = makeq(mp + "gate", E, hd) || makeq(mp + "switch_mlp.gate_proj", El * Im, hd, hd, e0 * Im) ||
+                         makeq(mp + "switch_mlp.up_proj", El * Im, hd, hd, e0 * Im) || makeq(mp + "switch_mlp.down_proj", El * hd, Im, Im, e0 * hd);
+                }
             } else if (!rc) {
                 rc = makeq(p + "mlp.gate_proj", m->I, hd, hd, (int64_t)r * m->I) || makeq(p + "mlp.up_proj", m->I, hd, hd, (int64_t)r * m->I) ||
                      makeq(p + "mlp.down_proj", hd, m->I, c.intermediate_size, 0, (int64_t)r * m->I);

@@ -833,6 +833,163 @@ extern "C" int omx_moe_block_partial_tp(float* y_partial, uint32_t* route_inds, 
     return launch_gemv(d, PRO_NONE, EPI_F32, s);
 }
 
+/* ---- the same two sharded forms on the reference's REAL Mixtral format: MLX-packed expert stacks (round 5; mixtral-mlx refuses anything
+ *      else: /root/reference/mixtral-mlx/src/model.rs:554-556, stacking at :466-548).  The triplet of a slice is the slice of the triplet
+ *      (quantisation is per group of one row), so a rank holds the packed rows / whole-group K slices of ITS experts or columns.
+ *      Few tokens (<= 32 routed slots): the packed GEMVs with the expert filter; more: the rank's stacks dequantised once per call into
+ *      stream-ordered scratch, then the bf16 functions above (what the single-rank packed block does too).  bf16 scales / activations. ---- */
+namespace {
+struct DqScratch {      // dequantised router + expert stacks of one call, freed in stream order
+    omx::bf16_t *router = nullptr, *g = nullptr, *u = nullptr, *d = nullptr;
+    hipStream_t s;
+    explicit DqScratch(hipStream_t s_) : s(s_) {}
+    ~DqScratch() { for (void* p : {(void*)router, (void*)g, (void*)u, (void*)d}) if (p) (void)hipFreeAsync(p, s); }
+};
+int dequant_stacks(DqScratch& q, const void* q_router, const void* s_router, const void* b_router, const void* q_gate, const void* s_gate,
+                   const void* b_gate, const void* q_up, const void* s_up, const void* b_up, const void* q_down, const void* s_down,
+                   const void* b_down, int hidden, int inter, int n_experts, int e_n, int group_size, int bits) {
+    using namespace omx;
+    const size_t per = (size_t)e_n * inter * hidden;
+    OMX_HIP_CHECK(hipMallocAsync((void**)&q.router, (size_t)n_experts * hidden * 2, q.s));
+    OMX_HIP_CHECK(hipMallocAsync((void**)&q.g, per * 2, q.s));
+    OMX_HIP_CHECK(hipMallocAsync((void**)&q.u, per * 2, q.s));
+    OMX_HIP_CHECK(hipMallocAsync((void**)&q.d, per * 2, q.s));
+    return omx_dequantize(q.router, q_router, s_router, b_router, n_experts, hidden, group_size, bits, OMX_BFLOAT16, q.s) ||
+           omx_dequantize(q.g, q_gate, s_gate, b_gate, (int64_t)e_n * inter, hidden, group_size, bits, OMX_BFLOAT16, q.s) ||
+           omx_dequantize(q.u, q_up, s_up, b_up, (int64_t)e_n * inter, hidden, group_size, bits, OMX_BFLOAT16, q.s) ||
+           omx_dequantize(q.d, q_down, s_down, b_down, (int64_t)e_n * hidden, inter, group_size, bits, OMX_BFLOAT16, q.s);
+}
+// router of the packed block: logits by the packed GEMV (RMSNorm prologue when norm_w), then the selection
+int route_packed(const void* x, const void* norm_w, float eps, const void* q_router, const void* s_router, const void* b_router, int n_tokens,
+                 int hidden, int n_experts, int top_k, int mode, int norm_topk_prob, int group_size, int bits, omx::bf16_t* logits, uint32_t* inds,
+                 omx::bf16_t* scores, hipStream_t s) {
+    using namespace omx;
+    QGemvArgs a = {};
+    a.m[0] = QMat{(const uint32_t*)q_router, (const bf16_t*)s_router, (const bf16_t*)b_router, n_experts};
+    a.N = n_experts; a.K = hidden; a.group = group_size;
+    a.x = (const bf16_t*)x; a.norm_w = (const bf16_t*)norm_w; a.eps = eps; a.out = logits;
+    a.n_batch = n_tokens; a.x_div = 1;
+    if (launch_qgemv(a, bits, norm_w ? PRO_RMSNORM : PRO_NONE, EPI_STORE, s)) return 1;
+    moe_route_logits_kernel<false><<<n_tokens, 64, 0, s>>>(logits, n_experts, top_k, mode, norm_topk_prob, inds, scores);
+    OMX_LAUNCH_CHECK();
+    return 0;
+}
+}  // namespace
+
+/* expert parallel on packed stacks: q_gate / q_up / q_down (+ scales, biases) are THIS RANK's experts [e_lo, e_lo + e_n) -- [e_n, inter,
+ * hidden * bits / 32] etc.; the router triplet is the whole (replicated) gate.  Same contract as omx_moe_block_partial_ep. */
+extern "C" int omx_moe_block_partial_ep_q(float* partial, const void* x, const void* norm_w, float eps, void* xn, const void* q_router,
+                                          const void* s_router, const void* b_router, const void* q_gate, const void* s_gate,
+                                          const void* b_gate, const void* q_up, const void* s_up, const void* b_up, const void* q_down,
+                                          const void* s_down, const void* b_down, int n_tokens, int hidden, int inter, int n_experts, int top_k,
+                                          int mode, int norm_topk_prob, int e_lo, int e_n, int group_size, int bits, omx_stream stream) {
+    using namespace omx;
+    OMX_REQUIRE(partial && x && q_router && s_router && b_router && q_gate && s_gate && b_gate && q_up && s_up && b_up && q_down && s_down && b_down,
+                "omx_moe_block_partial_ep_q: null tensor");
+    OMX_REQUIRE(bits == 4 || bits == 8, "omx_moe_block_partial_ep_q: bits=%d (4 or 8)", bits);
+    OMX_REQUIRE(hidden % 512 == 0 && inter % 512 == 0, "omx_moe_block_partial_ep_q: hidden=%d and intermediate=%d must be multiples of 512", hidden, inter);
+    OMX_REQUIRE(n_experts >= 1 && n_experts <= kMaxExperts && top_k >= 1 && top_k <= kMaxTopK && top_k <= n_experts && e_lo >= 0 && e_n >= 1 &&
+                    e_lo + e_n <= n_experts, "omx_moe_block_partial_ep_q: experts %d top-%d shard [%d, +%d)", n_experts, top_k, e_lo, e_n);
+    const int slots = n_tokens * top_k;
+    OMX_REQUIRE(slots >= 1, "omx_moe_block_partial_ep_q: no tokens");
+    hipStream_t s = (hipStream_t)stream;
+    if (slots > 32) {
+        // a prompt: normalised rows (the caller's, or made here), the rank's stacks and the router dequantised, the bf16 batched form
+        const void* rows = x;
+        if (norm_w) {
+            OMX_REQUIRE(xn, "omx_moe_block_partial_ep_q: xn scratch needed with norm_w");
+            if (omx_rms_norm(xn, x, norm_w, n_tokens, hidden, eps, OMX_BFLOAT16, stream)) return 1;
+            rows = xn;
+        }
+        DqScratch dq(s);
+        if (dequant_stacks(dq, q_router, s_router, b_router, q_gate, s_gate, b_gate, q_up, s_up, b_up, q_down, s_down, b_down, hidden, inter, n_experts,
+                           e_n, group_size, bits))
+            return 1;
+        return omx_moe_block_partial_ep(partial, rows, nullptr, eps, nullptr, dq.router, dq.g, dq.u, dq.d, n_tokens, hidden, inter, n_experts, top_k,
+                                        mode, norm_topk_prob, e_lo, e_n, stream);
+    }
+    OMX_REQUIRE(norm_w, "omx_moe_block_partial_ep_q: the decode form normalises in its GEMV prologues (norm_w)");
+    void* ws = nullptr;
+    const size_t need = (size_t)slots * 8 + 1024 + (size_t)n_tokens * n_experts * 2 + (size_t)slots * inter * 2 + (size_t)slots * hidden * 2 + 1024;
+    if (get_workspace_aux(&ws, need, s)) return 1;     // the STREAM's scratch (several ranks may share a process; a captured step keeps these pointers)
+    char* p = (char*)ws;
+    auto take = [&](size_t bytes) { char* r = p; p += (bytes + 255) & ~(size_t)255; return r; };
+    uint32_t* inds = (uint32_t*)take((size_t)slots * 4);
+    bf16_t* scores = (bf16_t*)take((size_t)slots * 2);
+    bf16_t* logits = (bf16_t*)take((size_t)n_tokens * n_experts * 2);
+    bf16_t* gbuf = (bf16_t*)take((size_t)slots * inter * 2);
+    bf16_t* ybuf = (bf16_t*)take((size_t)slots * hidden * 2);
+    if (route_packed(x, norm_w, eps, q_router, s_router, b_router, n_tokens, hidden, n_experts, top_k, mode, norm_topk_prob, group_size, bits, logits,
+                     inds, scores, s))
+        return 1;
+    QGemvArgs a = {};
+    a.m[0] = QMat{(const uint32_t*)q_gate, (const bf16_t*)s_gate, (const bf16_t*)b_gate, inter};
+    a.m[1] = QMat{(const uint32_t*)q_up, (const bf16_t*)s_up, (const bf16_t*)b_up, inter};
+    a.m[0].sb = quant_find_sb(a.m[0].scales); a.m[1].sb = quant_find_sb(a.m[1].scales);
+    a.N = inter; a.K = hidden; a.group = group_size;
+    a.x = (const bf16_t*)x; a.norm_w = (const bf16_t*)norm_w; a.eps = eps; a.out = gbuf;
+    a.n_batch = slots; a.x_div = top_k; a.w_sel = inds; a.w_sel_lo = e_lo; a.w_sel_n = e_n;
+    a.w_estride = (size_t)inter * hidden * bits / 32; a.s_estride = (size_t)inter * (hidden / group_size);
+    a.swiglu_single_round = 1;
+    if (launch_qgemv(a, bits, PRO_RMSNORM, EPI_SWIGLU, s)) return 1;
+    QGemvArgs d = {};
+    d.m[0] = QMat{(const uint32_t*)q_down, (const bf16_t*)s_down, (const bf16_t*)b_down, hidden};
+    d.m[0].sb = quant_find_sb(d.m[0].scales);
+    d.N = hidden; d.K = inter; d.group = group_size;
+    d.x = gbuf; d.out = ybuf;
+    d.n_batch = slots; d.x_div = 1; d.w_sel = inds; d.w_sel_lo = e_lo; d.w_sel_n = e_n;
+    d.w_estride = (size_t)hidden * inter * bits / 32; d.s_estride = (size_t)hidden * (inter / group_size);
+    if (launch_qgemv(d, bits, PRO_NONE, EPI_STORE, s)) return 1;
+    moe_combine_partial_kernel<<<n_tokens, 256, 0, s>>>(partial, ybuf, scores, inds, hidden, top_k, e_lo, e_n);
+    OMX_LAUNCH_CHECK();
+    return 0;
+}
+
+/* expert TENSOR parallel on packed stacks, decode form (<= 32 routed slots): every expert's packed gate / up rows [r inter, + inter) and the
+ * whole-group K slice [r inter, + inter) of its down projection (inter = I / tp, a multiple of 512).  Same contract as
+ * omx_moe_block_partial_tp: the router's choice in route_inds / route_scores, the UNROUNDED f32 partial of every routed slot's down
+ * projection in y_partial [slots, hidden]; omx_moe_combine_slots follows the all-reduce. */
+extern "C" int omx_moe_block_partial_tp_q(float* y_partial, uint32_t* route_inds, void* route_scores, const void* x, const void* norm_w, float eps,
+                                          const void* q_router, const void* s_router, const void* b_router, const void* q_gate, const void* s_gate,
+                                          const void* b_gate, const void* q_up, const void* s_up, const void* b_up, const void* q_down,
+                                          const void* s_down, const void* b_down, int n_tokens, int hidden, int inter, int n_experts, int top_k,
+                                          int mode, int norm_topk_prob, int group_size, int bits, omx_stream stream) {
+    using namespace omx;
+    OMX_REQUIRE(y_partial && route_inds && route_scores && x && norm_w && q_router && s_router && b_router && q_gate && s_gate && b_gate && q_up &&
+                    s_up && b_up && q_down && s_down && b_down, "omx_moe_block_partial_tp_q: null tensor");
+    OMX_REQUIRE(bits == 4 || bits == 8, "omx_moe_block_partial_tp_q: bits=%d (4 or 8)", bits);
+    const int slots = n_tokens * top_k;
+    OMX_REQUIRE(slots >= 1 && slots <= 32 && hidden % 512 == 0 && inter % 512 == 0,
+                "omx_moe_block_partial_tp_q: %d routed slots (at most 32), hidden %d and per-rank intermediate %d multiples of 512", slots, hidden, inter);
+    OMX_REQUIRE(n_experts >= 1 && n_experts <= kMaxExperts && top_k >= 1 && top_k <= kMaxTopK && top_k <= n_experts, "omx_moe_block_partial_tp_q: experts %d top-%d", n_experts, top_k);
+    hipStream_t s = (hipStream_t)stream;
+    void* ws = nullptr;
+    if (get_workspace_aux(&ws, (size_t)n_tokens * n_experts * 2 + 512 + (size_t)slots * inter * 2 + 256, s)) return 1;
+    bf16_t* logits = (bf16_t*)ws;
+    bf16_t* gbuf = (bf16_t*)((char*)ws + (((size_t)n_tokens * n_experts * 2 + 255) & ~(size_t)255));
+    if (route_packed(x, norm_w, eps, q_router, s_router, b_router, n_tokens, hidden, n_experts, top_k, mode, norm_topk_prob, group_size, bits, logits,
+                     route_inds, (bf16_t*)route_scores, s))
+        return 1;
+    QGemvArgs a = {};
+    a.m[0] = QMat{(const uint32_t*)q_gate, (const bf16_t*)s_gate, (const bf16_t*)b_gate, inter};
+    a.m[1] = QMat{(const uint32_t*)q_up, (const bf16_t*)s_up, (const bf16_t*)b_up, inter};
+    a.m[0].sb = quant_find_sb(a.m[0].scales); a.m[1].sb = quant_find_sb(a.m[1].scales);
+    a.N = inter; a.K = hidden; a.group = group_size;
+    a.x = (const bf16_t*)x; a.norm_w = (const bf16_t*)norm_w; a.eps = eps; a.out = gbuf;
+    a.n_batch = slots; a.x_div = top_k; a.w_sel = route_inds;
+    a.w_estride = (size_t)inter * hidden * bits / 32; a.s_estride = (size_t)inter * (hidden / group_size);
+    a.swiglu_single_round = 1;
+    if (launch_qgemv(a, bits, PRO_RMSNORM, EPI_SWIGLU, s)) return 1;
+    QGemvArgs d = {};
+    d.m[0] = QMat{(const uint32_t*)q_down, (const bf16_t*)s_down, (const bf16_t*)b_down, hidden};
+    d.m[0].sb = quant_find_sb(d.m[0].scales);
+    d.N = hidden; d.K = inter; d.group = group_size;
+    d.x = gbuf; d.out_f32 = y_partial;
+    d.n_batch = slots; d.x_div = 1; d.w_sel = route_inds;
+    d.w_estride = (size_t)hidden * inter * bits / 32; d.s_estride = (size_t)hidden * (inter / group_size);
+    return launch_qgemv(d, bits, PRO_NONE, EPI_F32, s);
+}
+
 namespace omx {
 namespace {
 // out[t] = bf16(resid[t] + bf16(sum_j bf16(bf16(y[t k + j]) * score[t k + j])))  -- moe_combine_kernel on f32 (all-reduced) slot outputs

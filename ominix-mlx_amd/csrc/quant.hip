@@ -150,7 +150,11 @@ __global__ __launch_bounds__(256) void qgemv_kernel(const QGemvArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int by = blockIdx.y;
     const bf16_t* xg = a.x + (size_t)(by / a.x_div) * a.K;
-    const size_t e = a.w_sel ? a.w_sel[by] : 0;
+    size_t e = a.w_sel ? a.w_sel[by] : 0;
+    if (a.w_sel_n > 0) {      // expert parallel: a slot routed to another rank's expert (block-uniform: before any barrier)
+        if (e < (size_t)a.w_sel_lo || e >= (size_t)(a.w_sel_lo + a.w_sel_n)) return;
+        e -= (size_t)a.w_sel_lo;
+    }
     bf16_t* out = a.out + (size_t)by * a.N;
 
     const int steps = a.K / (64 * EPL);
@@ -278,7 +282,7 @@ __global__ __launch_bounds__(256) void qgemv_kernel(const QGemvArgs a) {
                     if (EPI == EPI_STORE) {
                         out[row] = A16::bits(v0);
                     } else if (EPI == EPI_F32) {
-                        a.out_f32[row] = v0;
+                        a.out_f32[(size_t)by * a.N + row] = v0;
                     } else if (EPI == EPI_RESIDUAL) {
                         out[row] = A16::bits(A16::val(a.resid[row]) + A16::rnd(v0));
                     } else if (EPI == EPI_SWIGLU) {

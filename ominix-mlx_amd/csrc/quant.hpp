@@ -41,8 +41,11 @@ struct QGemvArgs {
                                 // activations stay bf16; every group's scale / bias enters the arithmetic as its exact float32 value
     // tensor parallel (round 4): EPI_F32 leaves the unrounded f32 row sums of this rank's K slice in out_f32 [N] (the all-reduce and the
     // fold into the residual follow as their own launches); EPI_ARGMAX numbers its rows from row_offset (this rank's vocabulary shard)
-    float* out_f32;
+    float* out_f32;             // (batched: [n_batch, N])
     int row_offset;
+    // expert parallel (round 5): only batch entries whose w_sel value lies in [w_sel_lo, w_sel_lo + w_sel_n) are computed, on expert
+    // w_sel - w_sel_lo of this rank's stack; the others leave their output rows untouched (w_sel_n == 0: every entry, as before)
+    int w_sel_lo, w_sel_n;
 };
 // packed [rows, cols*bits/32] -> bf16 [rows, cols]; scales_f16: scales / biases are float16 (engine-internal form of omx_dequantize)
 int launch_dequantize_bf16(bf16_t* out, const uint32_t* packed, const void* scales, const void* biases, int64_t rows, int cols, int group_size,

@@ -68,10 +68,14 @@ def shard(name: str, arr: np.ndarray, rank: int, world: int, num_key_value_heads
     if 0 < num_key_value_heads < world and (".self_attn.k_proj." in name or ".self_attn.v_proj." in name):
         head = rank // kv_replication(num_key_value_heads, world)
         return keep_kind(arr, np.ascontiguousarray(arr[head * head_dim:(head + 1) * head_dim]))
-    if name.endswith(EXPERT_ROW_SPLIT):
+    # (packed expert stacks, round 5: the triplet of a slice is the slice of the triplet -- rows of every expert's gate / up on all three
+    #  leaves; equal parts of the last axis, whole groups, of the down projection's packed words, scales and biases)
+    if _split_kind(name, EXPERT_ROW_SPLIT):
         n = arr.shape[1] // world
         return keep_kind(arr, np.ascontiguousarray(arr[:, rank * n:(rank + 1) * n, :]))
-    if name.endswith(EXPERT_COL_SPLIT):
+    if _split_kind(name, EXPERT_COL_SPLIT):
+        if arr.shape[2] % world:
+            raise ValueError(f"InvalidConfig: {name} has a last axis of {arr.shape[2]}, not divisible by tp_size={world}")
         n = arr.shape[2] // world
         return keep_kind(arr, np.ascontiguousarray(arr[:, :, rank * n:(rank + 1) * n]))
     if _split_kind(name, ROW_SPLIT):

@@ -18,6 +18,8 @@ CONFIGS = {
     "qwen3_moe_no_renorm_top4": rq.Qwen3Config(512, 2, 1024, 4, 2, 128, 1024, 1e-6, 1e6, True, None, 40960, 16, 4, 512, "qwen3_moe", False, True),
     "mixtral": rq.Qwen3Config(1024, 2, 1024, 8, 2, 128, 2048, 1e-5, 1e6, False, None, 40960, 4, 2, 1024, "mixtral", False, False),
 }
+# wide enough for PACKED shards on four ranks (round 5: a rank's attention width, expert columns and vocabulary are multiples of 512)
+WIDE = rq.Qwen3Config(2048, 2, 2048, 16, 4, 128, 2048, 1e-5, 1e6, False, None, 40960, 4, 2, 2048, "mixtral", False, False)
 
 
 def _engine(omx, cfg, weights=None, max_context=256, quantization=None):
@@ -197,18 +199,25 @@ def test_float16_quantized_moe_checkpoint_runs_in_float16(omx, monkeypatch, name
     assert np.abs(ref_bf16[0] - ref_logits[0]).max() > bound       # bf16 activations on float16 triplets are a different computation
 
 
-@pytest.mark.parametrize("name,world", [("qwen3_moe", 2), ("mixtral", 4), ("qwen3_moe_no_renorm_top4", 4)])
+@pytest.mark.parametrize("name,world,quant", [("qwen3_moe", 2, None), ("mixtral", 4, None), ("qwen3_moe_no_renorm_top4", 4, None),
+                                              ("mixtral", 2, 4), ("mixtral", 4, 4), ("qwen3_moe", 4, 4), ("mixtral", 2, 8)])
 @pytest.mark.parametrize("use_synth", [True, False])
-def test_expert_parallel_engine_on_one_gpu(omx, monkeypatch, name, world, use_synth):
+def test_expert_parallel_engine_on_one_gpu(omx, monkeypatch, name, world, quant, use_synth):
     """SURVEY.md 8e row 2 at engine level: `world` ranks (host threads, in-process communicator standing in for RCCL), each
     holding E / world experts, attention and router replicated, ONE all-reduce of the f32 partial per MoE block.  The partials
-    are sums of bf16-rounded products accumulated in f32, so the sharded run reproduces the single-GPU engine bit for bit."""
+    are sums of bf16-rounded products accumulated in f32, so the sharded run reproduces the single-GPU engine bit for bit.
+    quant (round 5): the reference's REAL Mixtral format -- MLX-packed expert stacks (mixtral-mlx/src/model.rs:466-615 refuses anything
+    else): a rank holds the packed triplets of ITS experts (ep.shard_experts on weight / scales / biases; the device generator quantises
+    the rank's window of the logical stack), the packed GEMVs skip the slots routed elsewhere."""
     from ominix_mlx_amd import comm
     cfg = CONFIGS[name]
+    quantization = {"bits": quant, "group_size": 64} if quant else None
     weights = rq.synth_weights(cfg)
+    if quant:
+        weights = rq.quantize_weights(cfg, weights, quant, 64)
     prompt = synth.prompt_ids(20, cfg.vocab_size)
     monkeypatch.setenv("OMX_PREFILL_SERIAL", "1")      # the sharded engines prefill token-serially: compare like with like
-    single = _engine(omx, cfg)
+    single = _engine(omx, cfg, quantization=quantization)
     want = np.concatenate([[single.prefill(prompt)], single.decode(6)]).astype(np.uint32)
     want_logits = single.last_logits()
     group = comm.LoopbackGroup(world, 1 << 20)
@@ -220,7 +229,8 @@ def test_expert_parallel_engine_on_one_gpu(omx, monkeypatch, name, world, use_sy
                          vocab_size=cfg.vocab_size, rms_norm_eps=cfg.rms_norm_eps, rope_theta=cfg.rope_theta,
                          tie_word_embeddings=cfg.tie_word_embeddings, max_context=256, num_experts=cfg.num_experts,
                          num_experts_per_tok=cfg.num_experts_per_tok, moe_intermediate_size=cfg.moe_intermediate_size,
-                         moe_mode=cfg.moe_mode, norm_topk_prob=cfg.norm_topk_prob, qk_norm=cfg.qk_norm, ep_rank=r, ep_size=world)
+                         moe_mode=cfg.moe_mode, norm_topk_prob=cfg.norm_topk_prob, qk_norm=cfg.qk_norm, ep_rank=r, ep_size=world,
+                         quantization=quantization)
         m.synth_weights() if use_synth else m.load_weights(weights)
         m.set_comm(group.rank_comm(r), group.allreduce_fn)
         models.append(m)
@@ -239,9 +249,10 @@ def test_expert_parallel_engine_on_one_gpu(omx, monkeypatch, name, world, use_sy
     group.close()
 
 
-@pytest.mark.parametrize("name,world,batched", [("mixtral", 2, False), ("qwen3_moe", 2, False), ("mixtral", 4, False),
-                                                ("mixtral", 2, True), ("qwen3_moe", 2, True), ("mixtral", 4, True)])
-def test_expert_tensor_parallel_engine_on_one_gpu(omx, monkeypatch, name, world, batched):
+@pytest.mark.parametrize("name,world,batched,quant", [("mixtral", 2, False, None), ("qwen3_moe", 2, False, None), ("mixtral", 4, False, None),
+                                                      ("mixtral", 2, True, None), ("qwen3_moe", 2, True, None), ("mixtral", 4, True, None),
+                                                      ("mixtral", 2, False, 4), ("wide", 4, False, 4), ("wide", 2, True, 4), ("wide", 4, True, 4)])
+def test_expert_tensor_parallel_engine_on_one_gpu(omx, monkeypatch, name, world, batched, quant):
     """Expert TENSOR parallelism (round 4; tp_size > 1 on a sparse-MoE model): attention heads sharded like the dense model, every
     expert's intermediate columns split over the ranks (gate / up rows, down columns), router replicated, per layer one all-reduce of
     the O partial and one of the routed slots' f32 down partials, then the weighted sum with the single-device roundings.  What
@@ -252,12 +263,17 @@ def test_expert_tensor_parallel_engine_on_one_gpu(omx, monkeypatch, name, world,
     batched: a 200-token prompt as ONE pass -- the expert-parallel grouped-GEMM form over all experts at this rank's columns, the f32
     partial of every row's weighted sum all-reduced (engine.hip prefill_prefix_batched) -- against the single GPU's batched pass."""
     from ominix_mlx_amd import comm, engine
-    cfg = CONFIGS[name]
+    # quant (round 5): MLX-packed expert stacks -- every expert's packed gate / up rows and the whole-group K slice of its down projection
+    # on each rank (tp.shard on the three leaves; the device generator quantises the rank's windows); a prompt dequantises the rank's stacks
+    cfg = WIDE if name == "wide" else CONFIGS[name]
+    quantization = {"bits": quant, "group_size": 64} if quant else None
     weights = rq.synth_weights(cfg)
+    if quant:
+        weights = rq.quantize_weights(cfg, weights, quant, 64)
     n_prompt, ctx = (200, 512) if batched else (20, 256)
     prompt = synth.prompt_ids(n_prompt, cfg.vocab_size)
     monkeypatch.setenv("OMX_PREFILL_SERIAL", "0" if batched else "1")
-    single = _engine(omx, cfg, max_context=ctx)
+    single = _engine(omx, cfg, max_context=ctx, quantization=quantization)
     want = np.concatenate([[single.prefill(prompt)], single.decode(6)]).astype(np.uint32)
     want_logits = single.last_logits()
     single.close()
@@ -271,7 +287,8 @@ def test_expert_tensor_parallel_engine_on_one_gpu(omx, monkeypatch, name, world,
                              vocab_size=cfg.vocab_size, rms_norm_eps=cfg.rms_norm_eps, rope_theta=cfg.rope_theta,
                              tie_word_embeddings=cfg.tie_word_embeddings, max_context=ctx, num_experts=cfg.num_experts,
                              num_experts_per_tok=cfg.num_experts_per_tok, moe_intermediate_size=cfg.moe_intermediate_size,
-                             moe_mode=cfg.moe_mode, norm_topk_prob=cfg.norm_topk_prob, qk_norm=cfg.qk_norm, tp_rank=r, tp_size=world)
+                             moe_mode=cfg.moe_mode, norm_topk_prob=cfg.norm_topk_prob, qk_norm=cfg.qk_norm, tp_rank=r, tp_size=world,
+                             quantization=quantization)
             m.synth_weights() if use_synth else m.load_weights(weights)
             m.set_comm(group.rank_comm(r), group.allreduce_fn)
             models.append(m)

@@ -301,7 +301,7 @@ int add_sampling_noise(omx_qwen3 m, hipStream_t s) {
     const int tp = c.tp_size > 1 ? c.tp_size : 1;
     if (launch_rng_next(m->rng, s)) return 1;
     return launch_sample_noise(m->argmax_partials, m->n_argmax_partials, m->logits, m->rng + 2, m->V, c.tp_rank * m->V,
-                               m->V * tp, 1.0f / m->temperature, s);
+                               m->V * tp, 1.0f / m->temperature, c.quant_scales_f16 != 0, s);
 }
 
 int resolve_weights(omx_qwen3 m) {
@@ -1170,8 +1170,13 @@ int prefill_prefix_batched(omx_qwen3 m, int T, int off, const EncodeOpts* enc = 
     // plain prompts of a dense model, also on tensor-parallel shards (each rank's float16 partial products summed in f32); encode /
     // verify and the expert forms stay bfloat16-only
     const bool f16 = c.quant_scales_f16 != 0;
-    OMX_REQUIRE(!f16 || (!enc && c.ep_size <= 1 && (c.num_experts == 0 || m->allreduce == nullptr) && T > 8),
-                "batched prompt pass in float16: plain prompts of more than 8 tokens (dense: single rank or tensor parallel; sparse-MoE: single rank)");
+    // (round 5: the encoder taps and passes of a handful of rows too -- a tap copies 16-bit rows whatever their format, and the 128-row
+    //  float16 GEMM tile predicates its rows.  An encoder PADDING mask stays refused: the reference builds it as (1 - keep) * f16(-1e9) =
+    //  0 * -inf = NaN on every kept key, flux-klein-mlx/src/qwen3_encoder.rs:196-198 -- there is no finite result to reproduce.)
+    OMX_REQUIRE(!f16 || !(enc && enc->mask), "float16 encoder with an attention_mask: the reference's additive mask is 0 * f16(-1e9) = NaN in "
+                "float16 (qwen3_encoder.rs:196-198); pass no mask (causal) or load the bfloat16 checkpoint");
+    OMX_REQUIRE(!f16 || (c.ep_size <= 1 && (c.num_experts == 0 || m->allreduce == nullptr)),
+                "batched prompt pass in float16: dense models on one rank or tensor parallel, sparse-MoE models on one rank");
     struct GemmF16Scope { bool on, was = false; explicit GemmF16Scope(bool o) : on(o) { if (on) was = gemm_set_f16(true); } ~GemmF16Scope() { if (on) gemm_set_f16(was); } } f16_scope(f16);
     const omx_dtype act_dt = f16 ? OMX_FLOAT16 : OMX_BFLOAT16;
     hipStream_t s = m->stream;
@@ -1853,7 +1858,6 @@ int omx_qwen3_set_comm(omx_qwen3 m, void* comm, void* allreduce_fn) {
 int omx_qwen3_set_sampler(omx_qwen3 m, float temperature, uint64_t seed) {
     OMX_REQUIRE(m, "omx_qwen3_set_sampler: null model");
     OMX_REQUIRE(temperature >= 0.f && temperature == temperature, "omx_qwen3_set_sampler: temperature %f must be >= 0", (double)temperature);
-    OMX_REQUIRE(temperature == 0.f || !m->cfg.quant_scales_f16, "omx_qwen3_set_sampler: float16 models decode greedily (the noise kernel reads bfloat16 logits)");
     if (!m->rng && dev_alloc(m, &m->rng, 4)) return 1;
     if (omx_random_key(m->rng, seed, (omx_stream)m->stream)) return 1;
     OMX_HIP_CHECK(hipStreamSynchronize(m->stream));

@@ -1338,7 +1338,7 @@ static int launch_gemm_impl(bf16_t* out, const bf16_t* x, const bf16_t* w, const
             return launch_gemv_rows(out, x, w, bias, resid, gate, M, N, K, relu, s);
     }
     if (g_gemm_f16) {
-        OMX_REQUIRE(fast && M > 8, "float16 gemm: K %% 64 == 0, 16-byte aligned operands and more than 8 rows expected (M=%d K=%d)", M, K);
+        OMX_REQUIRE(fast, "float16 gemm: K %% 64 == 0 and 16-byte aligned operands expected (M=%d K=%d)", M, K);
         if (ensure_attr()) return 1;
         const int t256 = ((M + 255) / 256) * ((N + 255) / 256);
         if (t256 <= 128) {   // at most half of the chip in 256^2 tiles: 128 x 256

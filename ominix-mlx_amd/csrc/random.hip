@@ -98,6 +98,9 @@ __global__ void rng_next_kernel(uint32_t* state /*[4]: state, sub-key*/) {
     state[2] = b0; state[3] = b1;
 }
 
+// F16: the logits row holds IEEE half words (a float16-scale checkpoint's activations), else bfloat16; both widen
+// exactly to f32 before the 1/T product, as `logits * array!(1/T)` promotes to f32 in the reference.
+template <bool F16>
 __global__ __launch_bounds__(256) void sample_noise_kernel(unsigned long long* __restrict__ partials, const bf16_t* __restrict__ logits,
                                                            const uint32_t* __restrict__ sub_key, int V_local, int row_offset,
                                                            int V_global, float inv_temp) {
@@ -106,7 +109,7 @@ __global__ __launch_bounds__(256) void sample_noise_kernel(unsigned long long* _
     unsigned long long best = 0;
     for (int v = blockIdx.x * 256 + threadIdx.x; v < V_local; v += gridDim.x * 256) {
         const int gv = v + row_offset;
-        const float x = bf16_to_f32(logits[v]) * inv_temp;
+        const float x = (F16 ? (float)reinterpret_cast<const _Float16*>(logits)[v] : bf16_to_f32(logits[v])) * inv_temp;
         const float g = gumbel_from_word(random_word(k0, k1, (uint64_t)gv, (uint64_t)V_global));
         const unsigned long long kx = sample_key(x + g, (uint32_t)gv);
         best = kx > best ? kx : best;
@@ -131,8 +134,9 @@ int launch_rng_next(uint32_t* state4, hipStream_t s) {
 }
 
 int launch_sample_noise(unsigned long long* partials, int n_partials, const bf16_t* logits, const uint32_t* sub_key, int V_local,
-                        int row_offset, int V_global, float inv_temp, hipStream_t s) {
-    sample_noise_kernel<<<n_partials, 256, 0, s>>>(partials, logits, sub_key, V_local, row_offset, V_global, inv_temp);
+                        int row_offset, int V_global, float inv_temp, bool logits_f16, hipStream_t s) {
+    if (logits_f16) sample_noise_kernel<true><<<n_partials, 256, 0, s>>>(partials, logits, sub_key, V_local, row_offset, V_global, inv_temp);
+    else sample_noise_kernel<false><<<n_partials, 256, 0, s>>>(partials, logits, sub_key, V_local, row_offset, V_global, inv_temp);
     OMX_LAUNCH_CHECK();
     return 0;
 }

@@ -102,6 +102,6 @@ __device__ __forceinline__ unsigned long long sample_key(float v, uint32_t idx) 
 // engine hooks
 int launch_rng_next(uint32_t* state4, hipStream_t s);
 int launch_sample_noise(unsigned long long* partials, int n_partials, const bf16_t* logits, const uint32_t* sub_key, int V_local,
-                        int row_offset, int V_global, float inv_temp, hipStream_t s);
+                        int row_offset, int V_global, float inv_temp, bool logits_f16, hipStream_t s);
 
 }  // namespace omx

@@ -239,7 +239,7 @@ class Model:
         from .ops import Tensor
         ids = np.ascontiguousarray(np.asarray(input_ids, dtype=np.uint32).ravel())
         taps = (c_int * len(extract_layers))(*[int(t) for t in extract_layers])
-        out = Tensor((ids.size, len(extract_layers) * self.cfg.hidden_size), "bf16")
+        out = Tensor((ids.size, len(extract_layers) * self.cfg.hidden_size), "f16" if self.cfg.quant_scales_f16 else "bf16")
         am = None
         if attention_mask is not None:
             am = np.ascontiguousarray(np.asarray(attention_mask).ravel() != 0, dtype=np.uint8)

@@ -256,7 +256,12 @@ class Qwen3Oracle:
     def encode(self, input_ids, attention_mask=None, extract_layers=(8, 17, 26)) -> np.ndarray:
         ids = np.asarray(input_ids).reshape(1, -1)
         T = ids.shape[1]
-        h = self.w["model.embed_tokens.weight"][ids]
+        if self.quant is None:
+            h = self.w["model.embed_tokens.weight"][ids]
+        else:   # a packed checkpoint's QuantizedEmbedding (nn/quantized.rs:252-283), as in forward()
+            bits, group = self.quant
+            h = rc.dequantize(self.w["model.embed_tokens.weight"][ids], self.w["model.embed_tokens.scales"][ids],
+                              self.w["model.embed_tokens.biases"][ids], group, bits, self.dt)
         mask = None
         if attention_mask is not None:
             am = np.asarray(attention_mask).reshape(-1) != 0

@@ -551,6 +551,70 @@ def test_quantized_checkpoint_with_float16_scales(omx, tmp_path, monkeypatch, se
     m2.close()
 
 
+def _f16_triplets(cfg, bits=4, group=64):
+    base = rq.synth_weights(cfg)
+    qw = {}
+    for name, arr in rq.quantize_weights(cfg, base, bits, group).items():
+        if name.endswith((".scales", ".biases")):
+            prefix = name.rsplit(".", 1)[0]
+            w2 = base[prefix + ".weight"].reshape(-1, base[prefix + ".weight"].shape[-1])
+            _, s32, b32 = rc.quantize(w2, group, bits)
+            arr = (s32 if name.endswith(".scales") else b32).astype(np.float16).reshape(arr.shape)
+        qw[name] = arr
+    return qw
+
+
+def test_float16_checkpoint_samples_and_encodes(omx):
+    """a float16 checkpoint is not a greedy-only, prompt-only model.  (1) temperature > 0: the noise kernel reads
+    the float16 logits row (random.hip sample_noise_kernel<true>), widened exactly to f32 before the 1/T product as
+    `logits * array!(1/T)` promotes (model.rs:733-741, sampler.rs:9-18) -- the drawn tokens are the oracle's draws from the engine's
+    own float16 logits, on the graph path.  (2) `encode` (qwen3_encoder.rs:403-455) without a padding mask, 77 rows and 5 rows (the
+    128-row float16 GEMM tile with a handful of live rows): hidden-state taps in float16 against the float16 oracle within the
+    float16 bound.  With a padding mask the reference computes 0 * f16(-1e9) = NaN (qwen3_encoder.rs:196-198): refused, by name."""
+    from ominix_mlx_amd import engine
+    from oracle import mlx_rng as rng
+    cfg, bits, group = CONFIGS["gqa4_d128"], 4, 64
+    qw = _f16_triplets(cfg, bits, group)
+    kw = dict(hidden_size=cfg.hidden_size, num_hidden_layers=cfg.num_hidden_layers, intermediate_size=cfg.intermediate_size,
+              num_attention_heads=cfg.num_attention_heads, num_key_value_heads=cfg.num_key_value_heads, head_dim=cfg.head_dim,
+              vocab_size=cfg.vocab_size, rms_norm_eps=cfg.rms_norm_eps, rope_theta=cfg.rope_theta,
+              tie_word_embeddings=cfg.tie_word_embeddings, rope_scaling=cfg.rope_scaling, max_context=256)
+    m = engine.Model(quantization={"bits": bits, "group_size": group, "scales_dtype": "float16"}, **kw)
+    m.load_weights(qw)
+    temp, seed = 0.8, 11
+    m.set_sampler(temp, seed)
+    state = rng.RandomState(seed)
+    for n_prompt in (12, 40):                      # through the decode step, and through the float16 matrix-core pass
+        m.reset()
+        prompt = synth.prompt_ids(n_prompt, cfg.vocab_size)
+        toks, logits = [m.prefill(prompt)], [m.last_logits()]
+        for _ in range(8):
+            toks.append(int(m.decode(1)[0]))
+            logits.append(m.last_logits())
+        assert m.decode_path() == "graph"
+        assert all(l.dtype == np.float32 and np.array_equal(l, l.astype(np.float16).astype(np.float32)) for l in logits)   # float16 values
+        want = [int(rc.sample(l[None, :], temp, state.next())[0]) for l in logits]
+        assert toks == want
+        assert toks != [int(np.argmax(l)) for l in logits]
+    m.set_sampler(0.0)
+    # the encoder taps
+    f16w = {k: (v.astype(np.float32) if v.dtype == np.float16 else v) for k, v in qw.items()}
+    oracle = rq.Qwen3Oracle(cfg, f16w, dt="f16", quant=(bits, group))
+    taps = (0, cfg.num_hidden_layers - 1)
+    for n in (77, 5):
+        ids = synth.prompt_ids(n, cfg.vocab_size)
+        got_t = m.encode(ids, None, taps)
+        got = got_t.numpy().astype(np.float32)
+        want = oracle.encode(ids, None, taps)
+        assert got.shape == want.shape == (n, len(taps) * cfg.hidden_size)
+        bound = 2.0 ** -10 * np.abs(want).max() * np.sqrt(2 * cfg.num_hidden_layers)
+        assert np.abs(got - want).max() <= bound, f"float16 encode of {n} rows off by {np.abs(got - want).max():.5f} (bound {bound:.5f})"
+    am = np.ones(77, np.uint8); am[60:] = 0
+    with pytest.raises(omx.OmxError, match="NaN in float16"):
+        m.encode(synth.prompt_ids(77, cfg.vocab_size), am, taps)
+    m.close()
+
+
 def test_float16_checkpoint_batched_prompt_pass(omx, monkeypatch):
     """Round 4: a float16 checkpoint's prompt in ONE matrix-core pass (engine.hip prefill_prefix_batched with f16: weights dequantised
     to float16, the eight-wave GEMM kernel's float16 instantiations with the SwiGLU / residual epilogues rounding to float16, float16

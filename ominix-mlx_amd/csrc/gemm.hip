@@ -17,6 +17,7 @@
 //     ^= row & 7) is applied to the per-lane SOURCE address and again on the ds_read (rule 21);
 //   * XCD-aware block order (T1): consecutive blocks of one XCD share an x row panel in its L2.
 // Fallback (any K, any alignment): register-staged 64x64x32 tiles with zero fill.
+#include <type_traits>
 #include "gemm.hpp"
 #include "act16.hpp"
 #include "gridsync.hpp"   // coherent accessors for the split-K hand-over
@@ -645,6 +646,364 @@ __global__ __launch_bounds__(big::NT) void gemm_bf16_nt_256_kernel(const GemmArg
 #undef OMX_WAIT_RING
 #undef OMX_BAR
 
+// ---- 256 x 256 tile, FOUR waves, the K loop as generated assembly (round 5; tools/gen_gemm5_asm.py -> gemm5_body.inc has the register map,
+//      the buffer protocol and the schedule): one wave per SIMD owning the whole register file, 128 x 128 of the tile per wave = 16 accumulators
+//      of 32x32x16 (256 AGPRs), both operands by LDS-DMA into two 64-k buffers each, three barriers per 64 k -- the geometry of the vendor
+//      library's best kernel on this chip (tools/blaslt_probe.py; EXPERIMENTS.md R5-4 has the measurements and why this one does not ship as the
+//      default).  This file keeps what hipcc does well: tile order, segments / expert rows, the per-thread source rows (clamped at the edges,
+//      gathered for the MoE form), the epilogues.  LDS: [X buffer 0 | X 1 | W 0 | W 1] of 256 rows x 64 k (128 KiB) + 24 parameter dwords
+//      per thread.  K % 128 == 0, no implicit convolution, no K split; SW: the segmented projection (plain segments + SwiGLU pair tiles:
+//      inside a wave's 128 columns the first 64 are gate rows, the last 64 the up rows of the SAME outputs, so a lane holds both). ----
+namespace w5 {
+constexpr int TILES_B = 4 * 32768, PARAM_B = 256 * 96, SMEM = TILES_B + PARAM_B;
+}
+#include "gemm5_body.inc"
+
+template <bool SW, bool F16, int VAR = 0>
+__global__ __launch_bounds__(256) void gemm_nt_w4_kernel(const GemmArgs a) {
+    typedef Act16<F16> A16;
+    constexpr int CJ = 4;                          // 32-column blocks per wave
+    constexpr int WCOLS = 32 * CJ;                 // columns per wave
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wr = wave >> 1, wc = wave & 1, l32 = lane & 31, hi = lane >> 5;
+    // tile order: the 256^2 kernel's (XCD-aware remap, 8 x 4 patches per XCD)
+    const int nblk = a.grid_m * a.grid_n;
+    int bid = blockIdx.x;
+    {
+        const int q = nblk / 8, r = nblk % 8, xcd = bid % 8, idx = bid / 8;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    int tm, tn;
+    {
+        constexpr int GM = 8;
+        const int per_group = GM * a.grid_n;
+        const int group = bid / per_group, in_group = bid % per_group;
+        const int first_m = group * GM;
+        const int gm = min(a.grid_m - first_m, GM);
+        tm = first_m + in_group % gm;
+        tn = in_group / gm;
+    }
+    const bf16_t* seg_w = a.w;
+    const bf16_t* seg_bias = nullptr;
+    bf16_t* seg_out = a.out;
+    int seg_cols = a.N, seg_ld = a.N;
+    bool seg_act = false;
+    if constexpr (SW) {
+        const GemmSegs& g = a.sg;
+        if (tn >= g.act_tile0) {
+            seg_act = true;
+            tn -= g.act_tile0;
+            seg_cols = g.half;
+        } else {
+            const int sidx = (g.n_plain > 1 && tn >= g.plain[1].tile0) + (g.n_plain > 2 && tn >= g.plain[2].tile0);
+            const GemmSeg& sgm = g.plain[sidx];
+            seg_w = sgm.w; seg_bias = sgm.bias; seg_out = sgm.out; seg_cols = sgm.cols; seg_ld = sgm.ld;
+            tn -= sgm.tile0;
+        }
+    }
+    int m0 = tm * 256, rows_valid = a.M, row_base = 0;
+    size_t w_off = 0;
+    const uint32_t* row_src = nullptr;
+    if constexpr (SW) {
+        if (a.g.tile_expert) {
+            if (tm >= *a.g.n_tiles) return;
+            const int e = a.g.tile_expert[tm];
+            row_base = a.g.seg_start[e];
+            rows_valid = a.g.seg_start[e + 1] - row_base;
+            m0 = a.g.tile_m0[tm];
+            row_src = a.g.row_src;
+            w_off = (size_t)e * a.g.w_estride;
+        }
+    }
+    const int n0 = tn * 256;
+
+    // ---- per-thread parameters of the K loop (gen_gemm5_asm.py): DMA source offsets of this thread's 8 X and 8 W pieces (piece wave * 8 + it =
+    //      tile rows (wave * 8 + it) * 8 + (lane >> 3), 16-B chunk (lane & 7) ^ ((row >> 1) & 7) of the row's 128 B), fragment read addresses
+    //      per k sub-step ks of the row (row = l32 of the wave's block, chunk (2 ks + hi) ^ ((row >> 1) & 7)).  W tile row R sits in wave column
+    //      R / 128; in a SwiGLU tile its first 64 rows are gate rows, the other 64 the up rows of the same outputs (one tile = 128
+    //      outputs): a wave stages 64 tile rows -- gate OR up rows. ----
+    uint32_t prm[24];
+    {
+        const int r8 = lane >> 3, slot = lane & 7;
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int R = (wave * 8 + it) * 8 + r8;
+            const int chunk = slot ^ ((R >> 1) & 7);
+            int xr = min(m0 + R, rows_valid - 1) + row_base;
+            if constexpr (SW) {
+                if (row_src) xr = (int)row_src[xr];
+            }
+            prm[it] = (uint32_t)(((int64_t)xr * a.K + chunk * 8) * 2);
+            int wrow;
+            if (SW && seg_act) wrow = min(n0 / 2 + (R / WCOLS) * (WCOLS / 2) + (R & (WCOLS / 2 - 1)), seg_cols - 1);
+            else wrow = min(n0 + R, seg_cols - 1);
+            prm[8 + it] = (uint32_t)(((int64_t)wrow * a.K + chunk * 8) * 2);
+        }
+        const unsigned tiles = (unsigned)(uintptr_t)smem;
+        const int swf = (l32 >> 1) & 7;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            prm[16 + ks] = tiles + (unsigned)((wr * 128 + l32) * 128 + ((2 * ks + hi) ^ swf) * 16);
+            prm[20 + ks] = tiles + 65536u + (unsigned)((wc * WCOLS + l32) * 128 + ((2 * ks + hi) ^ swf) * 16);
+        }
+    }
+    u32x4* pblock = reinterpret_cast<u32x4*>(smem + w5::TILES_B) + threadIdx.x * 6;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) pblock[k] = u32x4{prm[4 * k], prm[4 * k + 1], prm[4 * k + 2], prm[4 * k + 3]};
+    const unsigned param_addr = (unsigned)(uintptr_t)pblock;
+    const bf16_t* xbase = a.x;
+    const bool up_rows = (wave & 1) != 0;          // (a wave's W pieces are tile rows [wave * 64, + 64): the second half of a wave column)
+    const bf16_t* wbase = (SW && seg_act ? (up_rows ? a.sg.w_up : a.sg.w_gate) : seg_w) + w_off;
+    const int ntrips = (a.K / 64 - 2) / 2;
+    const unsigned ldsw = (unsigned)(uintptr_t)smem + (unsigned)wave * 8192u;
+
+    constexpr int NACC = 4 * CJ;
+    f32x16 acc[NACC];
+#pragma unroll
+    for (int t = 0; t < NACC; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+#define G5_OPERANDS                                                                                                                   \
+    : "+a"(acc[0]), "+a"(acc[1]), "+a"(acc[2]), "+a"(acc[3]), "+a"(acc[4]), "+a"(acc[5]), "+a"(acc[6]), "+a"(acc[7]),                  \
+      "+a"(acc[8]), "+a"(acc[9]), "+a"(acc[10]), "+a"(acc[11]), "+a"(acc[12]), "+a"(acc[13]), "+a"(acc[14]), "+a"(acc[15])             \
+    : "v"(param_addr), "s"(xbase), "s"(wbase), "s"(ntrips), "s"(ldsw)                                                                \
+    : G5_CLOBBERS
+    if (VAR == 0) {
+        if constexpr (F16) asm volatile(G5_BODY_F16 G5_OPERANDS);
+        else asm volatile(G5_BODY G5_OPERANDS);
+    }
+#ifdef OMX_G5_DIAG   // timing-only builds (tools/gen_gemm5_asm.py --diag, tools/gemm5_diag.py; OMX_GEMM_W4_VAR=1..7: the K loop without its DMA, its
+                     // fragment reads, its barriers / landing waits, all three, and with only the reads, only the DMA, only the barriers; garbage results)
+    else if (VAR == 1) asm volatile(G5_BODY_D1 G5_OPERANDS);
+    else if (VAR == 2) asm volatile(G5_BODY_D2 G5_OPERANDS);
+    else if (VAR == 3) asm volatile(G5_BODY_D3 G5_OPERANDS);
+    else if (VAR == 4) asm volatile(G5_BODY_D4 G5_OPERANDS);
+    else if (VAR == 5) asm volatile(G5_BODY_D5 G5_OPERANDS);
+    else if (VAR == 6) asm volatile(G5_BODY_D6 G5_OPERANDS);
+    else if (VAR == 7) asm volatile(G5_BODY_D7 G5_OPERANDS);
+#endif
+#undef G5_OPERANDS
+
+    // Interior tiles (every row and column of the tile exists) take straight-line code per epilogue kind, chosen by ONE uniform branch: 64
+    // stores per lane and their arithmetic.  The general code below checks every run and every element and carries every option -- 22 000
+    // instructions that each wave had to fetch through the instruction cache once per tile (EXPERIMENTS.md R5-4); edge tiles and the
+    // rare options (ReLU) still take it.
+    {
+        const bool interior = m0 + 256 <= rows_valid && n0 + 256 <= (SW && seg_act ? 2 * seg_cols : seg_cols) && (seg_ld & 3) == 0;
+        auto runs = [&](auto&& fn) {   // fn(i, j, g): row block, column block, run of four columns
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < CJ; ++j)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) fn(i, j, g);
+        };
+        if constexpr (SW) {
+            if (interior && seg_act) {
+                bf16_t* orow = a.sg.out_act + (size_t)(row_base + m0 + wr * 128 + l32) * a.sg.ld_act + n0 / 2 + wc * (WCOLS / 2) + 4 * hi;
+                auto act = [&](auto per_op_c) {
+                    constexpr bool per_op = decltype(per_op_c)::value;
+                    runs([&](int i, int j, int g) {
+                        if (j >= CJ / 2) return;
+                        float v[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float gt = A16::rnd(acc[i * CJ + j][4 * g + e]), up = A16::rnd(acc[i * CJ + j + CJ / 2][4 * g + e]);
+                            if (per_op) {
+                                const float sg = A16::rnd(1.0f / (1.0f + expf(-gt)));
+                                v[e] = A16::rnd(gt * sg) * up;
+                            } else {
+                                v[e] = gt / (1.0f + expf(-gt)) * up;
+                            }
+                        }
+                        *reinterpret_cast<u32x2*>(orow + (size_t)i * 32 * a.sg.ld_act + j * 32 + 8 * g) = u32x2{A16::pack(v[0], v[1]), A16::pack(v[2], v[3])};
+                    });
+                };
+                if (a.sg.act_mode == 1) act(std::true_type{});
+                else act(std::false_type{});
+                return;
+            }
+            if (interior && !seg_act) {
+                bf16_t* orow = seg_out + (size_t)(row_base + m0 + wr * 128 + l32) * seg_ld + n0 + wc * WCOLS + 4 * hi;
+                const bf16_t* brow = seg_bias ? seg_bias + n0 + wc * WCOLS + 4 * hi : nullptr;
+                auto plain = [&](auto bias_c) {
+                    constexpr bool BIAS = decltype(bias_c)::value;
+                    runs([&](int i, int j, int g) {
+                        float v[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = acc[i * CJ + j][4 * g + e];
+                        if (BIAS) {
+                            const u32x2 bb = *reinterpret_cast<const u32x2*>(brow + j * 32 + 8 * g);
+                            v[0] += A16::lo(bb[0]); v[1] += A16::hi(bb[0]); v[2] += A16::lo(bb[1]); v[3] += A16::hi(bb[1]);
+                        }
+                        *reinterpret_cast<u32x2*>(orow + (size_t)i * 32 * seg_ld + j * 32 + 8 * g) = u32x2{A16::pack(v[0], v[1]), A16::pack(v[2], v[3])};
+                    });
+                };
+                if (seg_bias) plain(std::true_type{});
+                else plain(std::false_type{});
+                return;
+            }
+        } else {
+            if (interior && !a.relu) {
+                const size_t o0 = (size_t)(m0 + wr * 128 + l32) * a.N + n0 + wc * WCOLS + 4 * hi;
+                const bf16_t* brow = a.bias ? a.bias + n0 + wc * WCOLS + 4 * hi : nullptr;
+                const bf16_t* grow = a.gate ? a.gate + n0 + wc * WCOLS + 4 * hi : nullptr;
+                auto plain = [&](auto bias_c, auto mode_c) {
+                    constexpr bool BIAS = decltype(bias_c)::value;
+                    constexpr int MODE = decltype(mode_c)::value;      // 0 store, 1 residual add (two roundings), 2 gated residual
+                    runs([&](int i, int j, int g) {
+                        const size_t o = o0 + (size_t)i * 32 * a.N + j * 32 + 8 * g;
+                        float v[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = acc[i * CJ + j][4 * g + e];
+                        if (BIAS) {
+                            const u32x2 bb = *reinterpret_cast<const u32x2*>(brow + j * 32 + 8 * g);
+                            v[0] += A16::lo(bb[0]); v[1] += A16::hi(bb[0]); v[2] += A16::lo(bb[1]); v[3] += A16::hi(bb[1]);
+                        }
+                        if (MODE == 2) {
+                            const u32x2 r = *reinterpret_cast<const u32x2*>(a.resid + o);
+                            const u32x2 gt = *reinterpret_cast<const u32x2*>(grow + j * 32 + 8 * g);
+                            v[0] = A16::lo(r[0]) + v[0] * A16::lo(gt[0]); v[1] = A16::hi(r[0]) + v[1] * A16::hi(gt[0]);
+                            v[2] = A16::lo(r[1]) + v[2] * A16::lo(gt[1]); v[3] = A16::hi(r[1]) + v[3] * A16::hi(gt[1]);
+                        } else if (MODE == 1) {
+                            const u32x2 r = *reinterpret_cast<const u32x2*>(a.resid + o);
+                            v[0] = A16::lo(r[0]) + A16::rnd(v[0]); v[1] = A16::hi(r[0]) + A16::rnd(v[1]);
+                            v[2] = A16::lo(r[1]) + A16::rnd(v[2]); v[3] = A16::hi(r[1]) + A16::rnd(v[3]);
+                        }
+                        *reinterpret_cast<u32x2*>(a.out + o) = u32x2{A16::pack(v[0], v[1]), A16::pack(v[2], v[3])};
+                    });
+                };
+                const int mode = a.gate ? 2 : a.resid ? 1 : 0;
+                if (a.bias) {
+                    if (mode == 0) plain(std::true_type{}, std::integral_constant<int, 0>{});
+                    else if (mode == 1) plain(std::true_type{}, std::integral_constant<int, 1>{});
+                    else plain(std::true_type{}, std::integral_constant<int, 2>{});
+                } else {
+                    if (mode == 0) plain(std::false_type{}, std::integral_constant<int, 0>{});
+                    else if (mode == 1) plain(std::false_type{}, std::integral_constant<int, 1>{});
+                    else plain(std::false_type{}, std::integral_constant<int, 2>{});
+                }
+                return;
+            }
+        }
+    }
+    // ---- epilogue: acc[i * CJ + j][4 g + e] = row (wr * 128 + i * 32 + l32), column (wc * WCOLS + j * 32 + 8 g + 4 hi + e) of the tile ----
+    if constexpr (SW) {
+        if (seg_act) {
+            const bool per_op = a.sg.act_mode == 1;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int lrow = m0 + wr * 128 + i * 32 + l32;
+                if (lrow >= rows_valid) continue;
+                const int row = row_base + lrow;
+#pragma unroll
+                for (int j = 0; j < CJ / 2; ++j)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int col = n0 / 2 + wc * (WCOLS / 2) + j * 32 + 8 * g + 4 * hi;
+                        if (col >= seg_cols) continue;   // half is a multiple of 4: a run is inside or outside
+                        float v[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float gt = A16::rnd(acc[i * CJ + j][4 * g + e]), up = A16::rnd(acc[i * CJ + j + CJ / 2][4 * g + e]);
+                            if (per_op) {   // nn::silu(gate) * up, each primitive rounded to bf16 (silu_mul_kernel, prefill.hip)
+                                const float sg = A16::rnd(1.0f / (1.0f + expf(-gt)));
+                                v[e] = A16::rnd(gt * sg) * up;
+                            } else {        // fused_swiglu: one rounding (swiglu_strided_kernel, dit.hip)
+                                v[e] = gt / (1.0f + expf(-gt)) * up;
+                            }
+                        }
+                        *reinterpret_cast<u32x2*>(a.sg.out_act + (size_t)row * a.sg.ld_act + col) =
+                            u32x2{A16::pack(v[0], v[1]), A16::pack(v[2], v[3])};
+                    }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int lrow = m0 + wr * 128 + i * 32 + l32;
+                if (lrow >= rows_valid) continue;
+                const int row = row_base + lrow;
+#pragma unroll
+                for (int j = 0; j < CJ; ++j)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int col = n0 + wc * WCOLS + j * 32 + 8 * g + 4 * hi;
+                        if (col >= seg_cols) continue;   // widths are multiples of 4
+                        float v[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = acc[i * CJ + j][4 * g + e];
+                        if (seg_bias) {
+                            const u32x2 b = *reinterpret_cast<const u32x2*>(seg_bias + col);
+                            v[0] += A16::lo(b[0]); v[1] += A16::hi(b[0]); v[2] += A16::lo(b[1]); v[3] += A16::hi(b[1]);
+                        }
+                        *reinterpret_cast<u32x2*>(seg_out + (size_t)row * seg_ld + col) = u32x2{A16::pack(v[0], v[1]), A16::pack(v[2], v[3])};
+                    }
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = m0 + wr * 128 + i * 32 + l32;
+        if (row >= a.M) continue;
+#pragma unroll
+        for (int j = 0; j < CJ; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int col = n0 + wc * WCOLS + j * 32 + 8 * g + 4 * hi;
+                if (col >= a.N) continue;
+                const size_t o = (size_t)row * a.N + col;
+                const bool full = col + 3 < a.N && (a.N & 3) == 0;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[i * CJ + j][4 * g + e];
+                if (full) {
+                    if (a.bias) {
+                        const u32x2 b = *reinterpret_cast<const u32x2*>(a.bias + col);
+                        v[0] += A16::lo(b[0]); v[1] += A16::hi(b[0]); v[2] += A16::lo(b[1]); v[3] += A16::hi(b[1]);
+                    }
+                    if (a.relu) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                    }
+                    if (a.gate) {
+                        const u32x2 r = *reinterpret_cast<const u32x2*>(a.resid + o);
+                        const u32x2 gt = *reinterpret_cast<const u32x2*>(a.gate + col);
+                        v[0] = A16::lo(r[0]) + v[0] * A16::lo(gt[0]); v[1] = A16::hi(r[0]) + v[1] * A16::hi(gt[0]);
+                        v[2] = A16::lo(r[1]) + v[2] * A16::lo(gt[1]); v[3] = A16::hi(r[1]) + v[3] * A16::hi(gt[1]);
+                    } else if (a.resid) {
+                        const u32x2 r = *reinterpret_cast<const u32x2*>(a.resid + o);
+                        v[0] = A16::lo(r[0]) + A16::rnd(v[0]); v[1] = A16::hi(r[0]) + A16::rnd(v[1]);
+                        v[2] = A16::lo(r[1]) + A16::rnd(v[2]); v[3] = A16::hi(r[1]) + A16::rnd(v[3]);
+                    }
+                    *reinterpret_cast<u32x2*>(a.out + o) = u32x2{A16::pack(v[0], v[1]), A16::pack(v[2], v[3])};
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (col + e >= a.N) break;
+                        float x = v[e] + (a.bias ? A16::val(a.bias[col + e]) : 0.f);
+                        if (a.relu) x = fmaxf(x, 0.f);
+                        if (a.gate) x = A16::val(a.resid[o + e]) + x * A16::val(a.gate[col + e]);
+                        else if (a.resid) x = A16::val(a.resid[o + e]) + A16::rnd(x);
+                        a.out[o + e] = A16::bits(x);
+                    }
+                }
+            }
+    }
+}
+
+// does the four-wave kernel take this shape?  (OMX_GEMM_W4=1 opts in; the hipcc-scheduled eight-wave kernel is the default)
+static bool w5_on() {
+    const char* e = getenv("OMX_GEMM_W4");
+    return e ? atoi(e) != 0 : false;
+}
+static bool w5_takes(int64_t x_rows, int K, int64_t w_rows_max) {
+    if (!w5_on()) return false;
+    return K % 128 == 0 && (x_rows * K + 64) * 2 < ((int64_t)1 << 32) && (w_rows_max * K + 64) * 2 < ((int64_t)1 << 32);
+}
+
 #ifdef OMX_EXPERIMENTS   // measured negative (EXPERIMENTS.md R5-3: 0.86-0.94 of the eight-phase kernel above): `make EXPERIMENTS=1`, OMX_GEMM_ASM=8
 // ---- 256 x 256 tile with the K loop as generated assembly (round 5; tools/gen_gemm4_asm.py -> gemm4_body.inc has the register map, the
 //      ring protocol and the hazard rules): eight waves, two per SIMD, 128 x 64 of the tile per wave = 8 accumulators of 32x32x16
@@ -1206,6 +1565,19 @@ int ensure_attr() {
         OMX_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_bf16_nt_256_kernel<16, false, false, 128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big::smem_bytes(128)));
         OMX_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_bf16_nt_256_kernel<16, false, false, 256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big::SMEM));
         OMX_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_bf16_nt_256_kernel<16, true, false, 256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big::SMEM));
+        OMX_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_nt_w4_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, w5::SMEM));
+        OMX_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_nt_w4_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, w5::SMEM));
+        OMX_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_nt_w4_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, w5::SMEM));
+        OMX_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_nt_w4_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, w5::SMEM));
+#ifdef OMX_G5_DIAG
+        OMX_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_nt_w4_kernel<false, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, w5::SMEM));
+        OMX_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_nt_w4_kernel<false, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, w5::SMEM));
+        OMX_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_nt_w4_kernel<false, false, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, w5::SMEM));
+        OMX_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_nt_w4_kernel<false, false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, w5::SMEM));
+        OMX_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_nt_w4_kernel<false, false, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, w5::SMEM));
+        OMX_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_nt_w4_kernel<false, false, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, w5::SMEM));
+        OMX_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_nt_w4_kernel<false, false, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, w5::SMEM));
+#endif
 #ifdef OMX_EXPERIMENTS
         OMX_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_bf16_nt_asm_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, w4::SMEM));
         OMX_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_bf16_nt_asm_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, w4::SMEM));
@@ -1341,14 +1713,16 @@ static int launch_gemm_impl(bf16_t* out, const bf16_t* x, const bf16_t* w, const
         OMX_REQUIRE(fast, "float16 gemm: K %% 64 == 0 and 16-byte aligned operands expected (M=%d K=%d)", M, K);
         if (ensure_attr()) return 1;
         const int t256 = ((M + 255) / 256) * ((N + 255) / 256);
-        if (t256 <= 128) {   // at most half of the chip in 256^2 tiles: 128 x 256
+        const char* te = getenv("OMX_GEMM_TILE");
+        if (t256 <= 128 && !(te && atoi(te) == 256)) {   // at most half of the chip in 256^2 tiles: 128 x 256
             a.grid_m = (M + 127) / 128;
             a.grid_n = (N + 255) / 256;
             gemm_bf16_nt_256_kernel<16, false, false, 128, true><<<a.grid_m * a.grid_n, big::NT, big::smem_bytes(128), s>>>(a);
         } else {
             a.grid_m = (M + 255) / 256;
             a.grid_n = (N + 255) / 256;
-            gemm_bf16_nt_256_kernel<16, false, false, 256, true><<<a.grid_m * a.grid_n, big::NT, big::SMEM, s>>>(a);
+            if (w5_takes(M, K, N)) gemm_nt_w4_kernel<false, true><<<a.grid_m * a.grid_n, 256, w5::SMEM, s>>>(a);
+            else gemm_bf16_nt_256_kernel<16, false, false, 256, true><<<a.grid_m * a.grid_n, big::NT, big::SMEM, s>>>(a);
         }
         OMX_LAUNCH_CHECK();
         return 0;
@@ -1381,6 +1755,22 @@ static int launch_gemm_impl(bf16_t* out, const bf16_t* x, const bf16_t* w, const
             a.ksplit = ksplit;
             if (ksplit > 1 && split_workspace_big(s, (size_t)tiles256 * ksplit * 256 * 256, (size_t)tiles256, &a.split_ws, &a.split_cnt)) return 1;
             const char* mf_env = getenv("OMX_GEMM_MFMA");
+            if (ksplit == 1 && !mf_env && w5_takes(M, K, N)) {
+                const int blocks = a.grid_m * a.grid_n;
+#ifdef OMX_G5_DIAG
+                const char* ve = getenv("OMX_GEMM_W4_VAR");
+                const int var = ve ? atoi(ve) : 0;
+                if (var == 1) gemm_nt_w4_kernel<false, false, 1><<<blocks, 256, w5::SMEM, s>>>(a);
+                else if (var == 2) gemm_nt_w4_kernel<false, false, 2><<<blocks, 256, w5::SMEM, s>>>(a);
+                else if (var == 3) gemm_nt_w4_kernel<false, false, 3><<<blocks, 256, w5::SMEM, s>>>(a);
+                else if (var == 4) gemm_nt_w4_kernel<false, false, 4><<<blocks, 256, w5::SMEM, s>>>(a);
+                else if (var == 5) gemm_nt_w4_kernel<false, false, 5><<<blocks, 256, w5::SMEM, s>>>(a);
+                else if (var == 6) gemm_nt_w4_kernel<false, false, 6><<<blocks, 256, w5::SMEM, s>>>(a);
+                else if (var == 7) gemm_nt_w4_kernel<false, false, 7><<<blocks, 256, w5::SMEM, s>>>(a);
+                else
+#endif
+                gemm_nt_w4_kernel<false, false><<<blocks, 256, w5::SMEM, s>>>(a);
+            } else
 #ifdef OMX_EXPERIMENTS
             if (ksplit == 1 && !mf_env && w4_takes(M, K, N)) {
                 const int blocks = a.grid_m * a.grid_n;
@@ -1510,6 +1900,10 @@ int launch_gemm_bf16_segmented(const bf16_t* x, int M, int K, const GemmSegs& se
     a.grid_n = seg_tiles(segs);
     int64_t w_rows_max = segs.half;
     for (int i = 0; i < segs.n_plain; ++i) w_rows_max = std::max<int64_t>(w_rows_max, segs.plain[i].cols);
+    if (w5_takes(M, K, w_rows_max)) {
+        if (g_gemm_f16) gemm_nt_w4_kernel<true, true><<<a.grid_m * a.grid_n, 256, w5::SMEM, s>>>(a);
+        else gemm_nt_w4_kernel<true, false><<<a.grid_m * a.grid_n, 256, w5::SMEM, s>>>(a);
+    } else
     if (g_gemm_f16) gemm_bf16_nt_256_kernel<16, true, false, 256, true><<<a.grid_m * a.grid_n, big::NT, big::SMEM, s>>>(a);
 #ifdef OMX_EXPERIMENTS
     else if (w4_takes(M, K, w_rows_max)) gemm_bf16_nt_asm_kernel<true><<<a.grid_m * a.grid_n, 512, w4::SMEM, s>>>(a);
@@ -1551,6 +1945,12 @@ int launch_gemm_bf16_segmented_grouped(const bf16_t* x, int max_rows, int K, con
     a.N = n + 2 * segs.half;
     a.grid_m = max_tiles;
     a.grid_n = seg_tiles(segs);
+    int64_t w_rows_g = segs.half;
+    for (int i = 0; i < segs.n_plain; ++i) w_rows_g = std::max<int64_t>(w_rows_g, segs.plain[i].cols);
+    if (w5_takes(max_rows, K, w_rows_g)) {   // (32-bit source offsets: inside the activations / inside ONE expert's matrices)
+        if (g_gemm_f16) gemm_nt_w4_kernel<true, true><<<a.grid_m * a.grid_n, 256, w5::SMEM, s>>>(a);
+        else gemm_nt_w4_kernel<true, false><<<a.grid_m * a.grid_n, 256, w5::SMEM, s>>>(a);
+    } else
     if (g_gemm_f16) gemm_bf16_nt_256_kernel<16, true, false, 256, true><<<a.grid_m * a.grid_n, big::NT, big::SMEM, s>>>(a);   // (a float16 model's prompt)
     else
     gemm_bf16_nt_256_kernel<16, true><<<a.grid_m * a.grid_n, big::NT, big::SMEM, s>>>(a);

@@ -90,6 +90,41 @@ def test_linear_gemm_256_tile_kernel(omx, monkeypatch, M, N, K):
 
 
 @pytest.mark.parametrize("M,N,K", [
+    (256, 256, 128),         # one tile, two K steps: prologue + the two closing steps, no loop trip
+    (300, 520, 256),         # ragged M and N tails, one loop trip
+    (1000, 1100, 1024),      # several tiles, long K loop
+    (2048, 4096, 4096),      # a prompt's O projection
+])
+@pytest.mark.parametrize("f16", [False, True])
+def test_linear_gemm_four_wave_kernel(omx, monkeypatch, M, N, K, f16):
+    """Round 5: the 256^2 tile on FOUR waves of 128 x 128 (csrc/gemm.hip gemm_nt_w4_kernel, the K loop generated by tools/gen_gemm5_asm.py:
+    256 accumulator AGPRs per wave, both operands by LDS-DMA, three barriers per 64 k) -- against the oracle, and bit-identical to the
+    eight-wave kernel's 32x32x16 form (same instruction, same k order per output element); bias / residual epilogues included."""
+    T = omx.ops.Tensor
+    monkeypatch.setenv("OMX_GEMM_TILE", "256")
+    dt = "f16" if f16 else "bf16"
+    rnd = (lambda a: a.astype(np.float16).astype(np.float32)) if f16 else rc.bf16_round
+    x = rnd(rand((M, K), 41))
+    w = rnd(rand((N, K), 42) * 0.05)
+    b = rnd(rand((N,), 43))
+    xt, wt, bt = T.from_numpy(x, dt), T.from_numpy(w, dt), T.from_numpy(b, dt)
+    monkeypatch.setenv("OMX_GEMM_W4", "1")
+    got = omx.ops.linear(xt, wt, bt).numpy().astype(np.float32)
+    monkeypatch.setenv("OMX_GEMM_W4", "0")
+    if not f16:
+        assert_bf16_close(got, rc.linear(x, w, b, "bf16"), 1, atol=2e-5 * np.sqrt(K) + 1e-4)
+        monkeypatch.setenv("OMX_GEMM_MFMA", "32")
+    else:
+        ref = (x.astype(np.float64) @ w.astype(np.float64).T + b).astype(np.float32)
+        assert np.abs(got - ref).max() <= 2.0 ** -10 * np.abs(ref).max() + 2e-5 * np.sqrt(K)
+    eight = omx.ops.linear(xt, wt, bt).numpy().astype(np.float32)
+    if not f16:
+        np.testing.assert_array_equal(got, eight)
+    else:       # (the float16 eight-wave kernel runs 16x16x32: another summation order)
+        assert np.abs(got - eight).max() <= 2.0 ** -10 * np.abs(eight).max()
+
+
+@pytest.mark.parametrize("M,N,K", [
     (128, 256, 64),          # one tile, one K step (prologue only)
     (300, 520, 128),         # ragged M and N tails, two K steps
     (384, 768, 192),         # odd number of K steps

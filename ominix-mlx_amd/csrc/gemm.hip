@@ -647,27 +647,27 @@ __global__ __launch_bounds__(big::NT) void gemm_bf16_nt_256_kernel(const GemmArg
 #undef OMX_BAR
 
 // ---- 256 x 256 tile, FOUR waves, the K loop as generated assembly (round 5; tools/gen_gemm5_asm.py -> gemm5_body.inc has the register map,
-//      the buffer protocol and the schedule): one wave per SIMD owning the whole register file, 128 x 128 of the tile per wave = 16 accumulators
-//      of 32x32x16 (256 AGPRs), both operands by LDS-DMA into two 64-k buffers each, three barriers per 64 k -- the geometry of the vendor
+//      the buffer protocol and the schedule): one wave per SIMD owning the whole register file, 128 x 128 of the tile per wave = 8 x 8 accumulators
+//      of 16x16x32 (256 AGPRs), both operands by LDS-DMA into two 64-k buffers each, three barriers per 64 k -- the geometry of the vendor
 //      library's best kernel on this chip (tools/blaslt_probe.py; EXPERIMENTS.md R5-4 has the measurements and why this one does not ship as the
 //      default).  This file keeps what hipcc does well: tile order, segments / expert rows, the per-thread source rows (clamped at the edges,
-//      gathered for the MoE form), the epilogues.  LDS: [X buffer 0 | X 1 | W 0 | W 1] of 256 rows x 64 k (128 KiB) + 24 parameter dwords
+//      gathered for the MoE form), the epilogues.  LDS: [X buffer 0 | X 1 | W 0 | W 1] of 256 rows x 64 k (128 KiB) + 20 parameter dwords
 //      per thread.  K % 128 == 0, no implicit convolution, no K split; SW: the segmented projection (plain segments + SwiGLU pair tiles:
 //      inside a wave's 128 columns the first 64 are gate rows, the last 64 the up rows of the SAME outputs, so a lane holds both). ----
 namespace w5 {
-constexpr int TILES_B = 4 * 32768, PARAM_B = 256 * 96, SMEM = TILES_B + PARAM_B;
+constexpr int TILES_B = 4 * 32768, PARAM_B = 256 * 80, SMEM = TILES_B + PARAM_B;
 }
 #include "gemm5_body.inc"
 
 template <bool SW, bool F16, int VAR = 0>
 __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(const GemmArgs a) {
     typedef Act16<F16> A16;
-    constexpr int CJ = 4;                          // 32-column blocks per wave
-    constexpr int WCOLS = 32 * CJ;                 // columns per wave
+    constexpr int NB = 8;                          // 16-row / 16-column blocks per wave
+    constexpr int WCOLS = 16 * NB;                 // columns per wave
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int wr = wave >> 1, wc = wave & 1, l32 = lane & 31, hi = lane >> 5;
+    const int wr = wave >> 1, wc = wave & 1, l16 = lane & 15, kg = lane >> 4;
     // tile order: the 256^2 kernel's (XCD-aware remap, 8 x 4 patches per XCD)
     const int nblk = a.grid_m * a.grid_n;
     int bid = blockIdx.x;
@@ -721,10 +721,10 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(const GemmArgs a) {
 
     // ---- per-thread parameters of the K loop (gen_gemm5_asm.py): DMA source offsets of this thread's 8 X and 8 W pieces (piece wave * 8 + it =
     //      tile rows (wave * 8 + it) * 8 + (lane >> 3), 16-B chunk (lane & 7) ^ ((row >> 1) & 7) of the row's 128 B), fragment read addresses
-    //      per k sub-step ks of the row (row = l32 of the wave's block, chunk (2 ks + hi) ^ ((row >> 1) & 7)).  W tile row R sits in wave column
-    //      R / 128; in a SwiGLU tile its first 64 rows are gate rows, the other 64 the up rows of the same outputs (one tile = 128
-    //      outputs): a wave stages 64 tile rows -- gate OR up rows. ----
-    uint32_t prm[24];
+    //      per k half kh (row = l16 of the block, chunk (4 kh + kg) ^ ((row >> 1) & 7)).  W tile row R sits in wave column R / 128; in a
+    //      SwiGLU tile its first 64 rows are gate rows, the other 64 the up rows of the same outputs (one tile = 128 outputs): a wave
+    //      stages 64 tile rows -- gate OR up rows. ----
+    uint32_t prm[20];
     {
         const int r8 = lane >> 3, slot = lane & 7;
 #pragma unroll
@@ -742,16 +742,16 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(const GemmArgs a) {
             prm[8 + it] = (uint32_t)(((int64_t)wrow * a.K + chunk * 8) * 2);
         }
         const unsigned tiles = (unsigned)(uintptr_t)smem;
-        const int swf = (l32 >> 1) & 7;
+        const int swf = (l16 >> 1) & 7;
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            prm[16 + ks] = tiles + (unsigned)((wr * 128 + l32) * 128 + ((2 * ks + hi) ^ swf) * 16);
-            prm[20 + ks] = tiles + 65536u + (unsigned)((wc * WCOLS + l32) * 128 + ((2 * ks + hi) ^ swf) * 16);
+        for (int kh = 0; kh < 2; ++kh) {
+            prm[16 + kh] = tiles + (unsigned)((wr * 128 + l16) * 128 + ((4 * kh + kg) ^ swf) * 16);
+            prm[18 + kh] = tiles + 65536u + (unsigned)((wc * WCOLS + l16) * 128 + ((4 * kh + kg) ^ swf) * 16);
         }
     }
-    u32x4* pblock = reinterpret_cast<u32x4*>(smem + w5::TILES_B) + threadIdx.x * 6;
+    u32x4* pblock = reinterpret_cast<u32x4*>(smem + w5::TILES_B) + threadIdx.x * 5;
 #pragma unroll
-    for (int k = 0; k < 6; ++k) pblock[k] = u32x4{prm[4 * k], prm[4 * k + 1], prm[4 * k + 2], prm[4 * k + 3]};
+    for (int k = 0; k < 5; ++k) pblock[k] = u32x4{prm[4 * k], prm[4 * k + 1], prm[4 * k + 2], prm[4 * k + 3]};
     const unsigned param_addr = (unsigned)(uintptr_t)pblock;
     const bf16_t* xbase = a.x;
     const bool up_rows = (wave & 1) != 0;          // (a wave's W pieces are tile rows [wave * 64, + 64): the second half of a wave column)
@@ -759,16 +759,16 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(const GemmArgs a) {
     const int ntrips = (a.K / 64 - 2) / 2;
     const unsigned ldsw = (unsigned)(uintptr_t)smem + (unsigned)wave * 8192u;
 
-    constexpr int NACC = 4 * CJ;
-    f32x16 acc[NACC];
+    f32x16 acc[16];      // acc[o] = a[16 o : 16 o + 15]: tile (i, j) of the wave's 8 x 8 is acc[i * 2 + (j >> 2)][(j & 3) * 4 + e]
 #pragma unroll
-    for (int t = 0; t < NACC; ++t)
+    for (int t = 0; t < 16; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-#define G5_OPERANDS                                                                                                                   \
-    : "+a"(acc[0]), "+a"(acc[1]), "+a"(acc[2]), "+a"(acc[3]), "+a"(acc[4]), "+a"(acc[5]), "+a"(acc[6]), "+a"(acc[7]),                  \
-      "+a"(acc[8]), "+a"(acc[9]), "+a"(acc[10]), "+a"(acc[11]), "+a"(acc[12]), "+a"(acc[13]), "+a"(acc[14]), "+a"(acc[15])             \
-    : "v"(param_addr), "s"(xbase), "s"(wbase), "s"(ntrips), "s"(ldsw)                                                                \
+#define G5_OPERANDS                                                                                                                                  \
+    : "+{a[0:15]}"(acc[0]), "+{a[16:31]}"(acc[1]), "+{a[32:47]}"(acc[2]), "+{a[48:63]}"(acc[3]), "+{a[64:79]}"(acc[4]), "+{a[80:95]}"(acc[5]),        \
+      "+{a[96:111]}"(acc[6]), "+{a[112:127]}"(acc[7]), "+{a[128:143]}"(acc[8]), "+{a[144:159]}"(acc[9]), "+{a[160:175]}"(acc[10]),                    \
+      "+{a[176:191]}"(acc[11]), "+{a[192:207]}"(acc[12]), "+{a[208:223]}"(acc[13]), "+{a[224:239]}"(acc[14]), "+{a[240:255]}"(acc[15])               \
+    : "v"(param_addr), "s"(xbase), "s"(wbase), "s"(ntrips), "s"(ldsw)                                                                               \
     : G5_CLOBBERS
     if (VAR == 0) {
         if constexpr (F16) asm volatile(G5_BODY_F16 G5_OPERANDS);
@@ -786,221 +786,141 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(const GemmArgs a) {
 #endif
 #undef G5_OPERANDS
 
-    // Interior tiles (every row and column of the tile exists) take straight-line code per epilogue kind, chosen by ONE uniform branch: 64
-    // stores per lane and their arithmetic.  The general code below checks every run and every element and carries every option -- 22 000
-    // instructions that each wave had to fetch through the instruction cache once per tile (EXPERIMENTS.md R5-4); edge tiles and the
-    // rare options (ReLU) still take it.
-    {
-        const bool interior = m0 + 256 <= rows_valid && n0 + 256 <= (SW && seg_act ? 2 * seg_cols : seg_cols) && (seg_ld & 3) == 0;
-        auto runs = [&](auto&& fn) {   // fn(i, j, g): row block, column block, run of four columns
+    // ---- epilogue.  Tile (i, j), element e = row (wr * 128 + i * 16 + l16), column (wc * 128 + j * 16 + 4 kg + e) of the 256^2 tile: a lane
+    //      holds runs of four consecutive columns (one 8-byte store each), 64 runs.  Interior tiles (every row and column exists) take
+    //      straight-line code per epilogue kind, chosen by ONE uniform branch; the general form -- every run and element checked, every
+    //      option carried -- is 20 000 instructions a wave would fetch once per tile, and only edge tiles and the rare options take it. ----
+#define ACC(i, j, e) acc[(i) * 2 + ((j) >> 2)][((j) & 3) * 4 + (e)]
+    auto runs = [&](auto&& fn) {   // fn(i, j): row block, column block
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < NB; ++i)
 #pragma unroll
-                for (int j = 0; j < CJ; ++j)
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) fn(i, j, g);
-        };
-        if constexpr (SW) {
-            if (interior && seg_act) {
-                bf16_t* orow = a.sg.out_act + (size_t)(row_base + m0 + wr * 128 + l32) * a.sg.ld_act + n0 / 2 + wc * (WCOLS / 2) + 4 * hi;
-                auto act = [&](auto per_op_c) {
-                    constexpr bool per_op = decltype(per_op_c)::value;
-                    runs([&](int i, int j, int g) {
-                        if (j >= CJ / 2) return;
-                        float v[4];
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const float gt = A16::rnd(acc[i * CJ + j][4 * g + e]), up = A16::rnd(acc[i * CJ + j + CJ / 2][4 * g + e]);
-                            if (per_op) {
-                                const float sg = A16::rnd(1.0f / (1.0f + expf(-gt)));
-                                v[e] = A16::rnd(gt * sg) * up;
-                            } else {
-                                v[e] = gt / (1.0f + expf(-gt)) * up;
-                            }
-                        }
-                        *reinterpret_cast<u32x2*>(orow + (size_t)i * 32 * a.sg.ld_act + j * 32 + 8 * g) = u32x2{A16::pack(v[0], v[1]), A16::pack(v[2], v[3])};
-                    });
-                };
-                if (a.sg.act_mode == 1) act(std::true_type{});
-                else act(std::false_type{});
-                return;
-            }
-            if (interior && !seg_act) {
-                bf16_t* orow = seg_out + (size_t)(row_base + m0 + wr * 128 + l32) * seg_ld + n0 + wc * WCOLS + 4 * hi;
-                const bf16_t* brow = seg_bias ? seg_bias + n0 + wc * WCOLS + 4 * hi : nullptr;
-                auto plain = [&](auto bias_c) {
-                    constexpr bool BIAS = decltype(bias_c)::value;
-                    runs([&](int i, int j, int g) {
-                        float v[4];
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = acc[i * CJ + j][4 * g + e];
-                        if (BIAS) {
-                            const u32x2 bb = *reinterpret_cast<const u32x2*>(brow + j * 32 + 8 * g);
-                            v[0] += A16::lo(bb[0]); v[1] += A16::hi(bb[0]); v[2] += A16::lo(bb[1]); v[3] += A16::hi(bb[1]);
-                        }
-                        *reinterpret_cast<u32x2*>(orow + (size_t)i * 32 * seg_ld + j * 32 + 8 * g) = u32x2{A16::pack(v[0], v[1]), A16::pack(v[2], v[3])};
-                    });
-                };
-                if (seg_bias) plain(std::true_type{});
-                else plain(std::false_type{});
-                return;
-            }
-        } else {
-            if (interior && !a.relu) {
-                const size_t o0 = (size_t)(m0 + wr * 128 + l32) * a.N + n0 + wc * WCOLS + 4 * hi;
-                const bf16_t* brow = a.bias ? a.bias + n0 + wc * WCOLS + 4 * hi : nullptr;
-                const bf16_t* grow = a.gate ? a.gate + n0 + wc * WCOLS + 4 * hi : nullptr;
-                auto plain = [&](auto bias_c, auto mode_c) {
-                    constexpr bool BIAS = decltype(bias_c)::value;
-                    constexpr int MODE = decltype(mode_c)::value;      // 0 store, 1 residual add (two roundings), 2 gated residual
-                    runs([&](int i, int j, int g) {
-                        const size_t o = o0 + (size_t)i * 32 * a.N + j * 32 + 8 * g;
-                        float v[4];
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = acc[i * CJ + j][4 * g + e];
-                        if (BIAS) {
-                            const u32x2 bb = *reinterpret_cast<const u32x2*>(brow + j * 32 + 8 * g);
-                            v[0] += A16::lo(bb[0]); v[1] += A16::hi(bb[0]); v[2] += A16::lo(bb[1]); v[3] += A16::hi(bb[1]);
-                        }
-                        if (MODE == 2) {
-                            const u32x2 r = *reinterpret_cast<const u32x2*>(a.resid + o);
-                            const u32x2 gt = *reinterpret_cast<const u32x2*>(grow + j * 32 + 8 * g);
-                            v[0] = A16::lo(r[0]) + v[0] * A16::lo(gt[0]); v[1] = A16::hi(r[0]) + v[1] * A16::hi(gt[0]);
-                            v[2] = A16::lo(r[1]) + v[2] * A16::lo(gt[1]); v[3] = A16::hi(r[1]) + v[3] * A16::hi(gt[1]);
-                        } else if (MODE == 1) {
-                            const u32x2 r = *reinterpret_cast<const u32x2*>(a.resid + o);
-                            v[0] = A16::lo(r[0]) + A16::rnd(v[0]); v[1] = A16::hi(r[0]) + A16::rnd(v[1]);
-                            v[2] = A16::lo(r[1]) + A16::rnd(v[2]); v[3] = A16::hi(r[1]) + A16::rnd(v[3]);
-                        }
-                        *reinterpret_cast<u32x2*>(a.out + o) = u32x2{A16::pack(v[0], v[1]), A16::pack(v[2], v[3])};
-                    });
-                };
-                const int mode = a.gate ? 2 : a.resid ? 1 : 0;
-                if (a.bias) {
-                    if (mode == 0) plain(std::true_type{}, std::integral_constant<int, 0>{});
-                    else if (mode == 1) plain(std::true_type{}, std::integral_constant<int, 1>{});
-                    else plain(std::true_type{}, std::integral_constant<int, 2>{});
-                } else {
-                    if (mode == 0) plain(std::false_type{}, std::integral_constant<int, 0>{});
-                    else if (mode == 1) plain(std::false_type{}, std::integral_constant<int, 1>{});
-                    else plain(std::false_type{}, std::integral_constant<int, 2>{});
-                }
-                return;
-            }
-        }
-    }
-    // ---- epilogue: acc[i * CJ + j][4 g + e] = row (wr * 128 + i * 32 + l32), column (wc * WCOLS + j * 32 + 8 g + 4 hi + e) of the tile ----
+            for (int j = 0; j < NB; ++j) fn(i, j);
+    };
+    const bool interior = m0 + 256 <= rows_valid && n0 + 256 <= (SW && seg_act ? 2 * seg_cols : seg_cols) && (seg_ld & 3) == 0;
+    const int lrow0 = m0 + wr * 128 + l16;                  // + i * 16
     if constexpr (SW) {
         if (seg_act) {
-            const bool per_op = a.sg.act_mode == 1;
+            const int c0 = n0 / 2 + wc * (WCOLS / 2) + 4 * kg;      // + j * 16, j < 4 (gate); the up value of the same output is tile j + 4
+            auto act = [&](auto per_op_c, auto checked_c) {
+                constexpr bool per_op = decltype(per_op_c)::value, checked = decltype(checked_c)::value;
+                runs([&](int i, int j) {
+                    if (j >= NB / 2) return;
+                    const int lrow = lrow0 + i * 16, col = c0 + j * 16;
+                    if (checked && (lrow >= rows_valid || col >= seg_cols)) return;   // half is a multiple of 4: a run is inside or outside
+                    float v[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int lrow = m0 + wr * 128 + i * 32 + l32;
-                if (lrow >= rows_valid) continue;
-                const int row = row_base + lrow;
-#pragma unroll
-                for (int j = 0; j < CJ / 2; ++j)
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const int col = n0 / 2 + wc * (WCOLS / 2) + j * 32 + 8 * g + 4 * hi;
-                        if (col >= seg_cols) continue;   // half is a multiple of 4: a run is inside or outside
-                        float v[4];
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const float gt = A16::rnd(acc[i * CJ + j][4 * g + e]), up = A16::rnd(acc[i * CJ + j + CJ / 2][4 * g + e]);
-                            if (per_op) {   // nn::silu(gate) * up, each primitive rounded to bf16 (silu_mul_kernel, prefill.hip)
-                                const float sg = A16::rnd(1.0f / (1.0f + expf(-gt)));
-                                v[e] = A16::rnd(gt * sg) * up;
-                            } else {        // fused_swiglu: one rounding (swiglu_strided_kernel, dit.hip)
-                                v[e] = gt / (1.0f + expf(-gt)) * up;
-                            }
+                    for (int e = 0; e < 4; ++e) {
+                        const float gt = A16::rnd(ACC(i, j, e)), up = A16::rnd(ACC(i, j + NB / 2, e));
+                        if (per_op) {   // nn::silu(gate) * up, each primitive rounded (silu_mul_kernel, prefill.hip)
+                            const float sg = A16::rnd(1.0f / (1.0f + expf(-gt)));
+                            v[e] = A16::rnd(gt * sg) * up;
+                        } else {        // fused_swiglu: one rounding (swiglu_strided_kernel, dit.hip)
+                            v[e] = gt / (1.0f + expf(-gt)) * up;
                         }
-                        *reinterpret_cast<u32x2*>(a.sg.out_act + (size_t)row * a.sg.ld_act + col) =
-                            u32x2{A16::pack(v[0], v[1]), A16::pack(v[2], v[3])};
                     }
+                    *reinterpret_cast<u32x2*>(a.sg.out_act + (size_t)(row_base + lrow) * a.sg.ld_act + col) = u32x2{A16::pack(v[0], v[1]), A16::pack(v[2], v[3])};
+                });
+            };
+            if (interior) {
+                if (a.sg.act_mode == 1) act(std::true_type{}, std::false_type{});
+                else act(std::false_type{}, std::false_type{});
+            } else {
+                if (a.sg.act_mode == 1) act(std::true_type{}, std::true_type{});
+                else act(std::false_type{}, std::true_type{});
             }
         } else {
+            const int c0 = n0 + wc * WCOLS + 4 * kg;
+            auto plain = [&](auto bias_c, auto checked_c) {
+                constexpr bool BIAS = decltype(bias_c)::value, checked = decltype(checked_c)::value;
+                runs([&](int i, int j) {
+                    const int lrow = lrow0 + i * 16, col = c0 + j * 16;
+                    if (checked && (lrow >= rows_valid || col >= seg_cols)) return;   // widths are multiples of 4
+                    float v[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int lrow = m0 + wr * 128 + i * 32 + l32;
-                if (lrow >= rows_valid) continue;
-                const int row = row_base + lrow;
-#pragma unroll
-                for (int j = 0; j < CJ; ++j)
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const int col = n0 + wc * WCOLS + j * 32 + 8 * g + 4 * hi;
-                        if (col >= seg_cols) continue;   // widths are multiples of 4
-                        float v[4];
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = acc[i * CJ + j][4 * g + e];
-                        if (seg_bias) {
-                            const u32x2 b = *reinterpret_cast<const u32x2*>(seg_bias + col);
-                            v[0] += A16::lo(b[0]); v[1] += A16::hi(b[0]); v[2] += A16::lo(b[1]); v[3] += A16::hi(b[1]);
-                        }
-                        *reinterpret_cast<u32x2*>(seg_out + (size_t)row * seg_ld + col) = u32x2{A16::pack(v[0], v[1]), A16::pack(v[2], v[3])};
+                    for (int e = 0; e < 4; ++e) v[e] = ACC(i, j, e);
+                    if (BIAS) {
+                        const u32x2 bb = *reinterpret_cast<const u32x2*>(seg_bias + col);
+                        v[0] += A16::lo(bb[0]); v[1] += A16::hi(bb[0]); v[2] += A16::lo(bb[1]); v[3] += A16::hi(bb[1]);
                     }
+                    *reinterpret_cast<u32x2*>(seg_out + (size_t)(row_base + lrow) * seg_ld + col) = u32x2{A16::pack(v[0], v[1]), A16::pack(v[2], v[3])};
+                });
+            };
+            if (interior) {
+                if (seg_bias) plain(std::true_type{}, std::false_type{});
+                else plain(std::false_type{}, std::false_type{});
+            } else {
+                if (seg_bias) plain(std::true_type{}, std::true_type{});
+                else plain(std::false_type{}, std::true_type{});
             }
         }
         return;
     }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = m0 + wr * 128 + i * 32 + l32;
-        if (row >= a.M) continue;
-#pragma unroll
-        for (int j = 0; j < CJ; ++j)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int col = n0 + wc * WCOLS + j * 32 + 8 * g + 4 * hi;
-                if (col >= a.N) continue;
-                const size_t o = (size_t)row * a.N + col;
-                const bool full = col + 3 < a.N && (a.N & 3) == 0;
+    const int c0 = n0 + wc * WCOLS + 4 * kg;
+    if (interior && !a.relu) {
+        auto plain = [&](auto bias_c, auto mode_c) {
+            constexpr bool BIAS = decltype(bias_c)::value;
+            constexpr int MODE = decltype(mode_c)::value;      // 0 store, 1 residual add (two roundings), 2 gated residual
+            runs([&](int i, int j) {
+                const int col = c0 + j * 16;
+                const size_t o = (size_t)(lrow0 + i * 16) * a.N + col;
                 float v[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = acc[i * CJ + j][4 * g + e];
-                if (full) {
-                    if (a.bias) {
-                        const u32x2 b = *reinterpret_cast<const u32x2*>(a.bias + col);
-                        v[0] += A16::lo(b[0]); v[1] += A16::hi(b[0]); v[2] += A16::lo(b[1]); v[3] += A16::hi(b[1]);
-                    }
-                    if (a.relu) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-                    }
-                    if (a.gate) {
-                        const u32x2 r = *reinterpret_cast<const u32x2*>(a.resid + o);
-                        const u32x2 gt = *reinterpret_cast<const u32x2*>(a.gate + col);
-                        v[0] = A16::lo(r[0]) + v[0] * A16::lo(gt[0]); v[1] = A16::hi(r[0]) + v[1] * A16::hi(gt[0]);
-                        v[2] = A16::lo(r[1]) + v[2] * A16::lo(gt[1]); v[3] = A16::hi(r[1]) + v[3] * A16::hi(gt[1]);
-                    } else if (a.resid) {
-                        const u32x2 r = *reinterpret_cast<const u32x2*>(a.resid + o);
-                        v[0] = A16::lo(r[0]) + A16::rnd(v[0]); v[1] = A16::hi(r[0]) + A16::rnd(v[1]);
-                        v[2] = A16::lo(r[1]) + A16::rnd(v[2]); v[3] = A16::hi(r[1]) + A16::rnd(v[3]);
-                    }
-                    *reinterpret_cast<u32x2*>(a.out + o) = u32x2{A16::pack(v[0], v[1]), A16::pack(v[2], v[3])};
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        if (col + e >= a.N) break;
-                        float x = v[e] + (a.bias ? A16::val(a.bias[col + e]) : 0.f);
-                        if (a.relu) x = fmaxf(x, 0.f);
-                        if (a.gate) x = A16::val(a.resid[o + e]) + x * A16::val(a.gate[col + e]);
-                        else if (a.resid) x = A16::val(a.resid[o + e]) + A16::rnd(x);
-                        a.out[o + e] = A16::bits(x);
-                    }
+                for (int e = 0; e < 4; ++e) v[e] = ACC(i, j, e);
+                if (BIAS) {
+                    const u32x2 bb = *reinterpret_cast<const u32x2*>(a.bias + col);
+                    v[0] += A16::lo(bb[0]); v[1] += A16::hi(bb[0]); v[2] += A16::lo(bb[1]); v[3] += A16::hi(bb[1]);
                 }
-            }
+                if (MODE == 2) {
+                    const u32x2 r = *reinterpret_cast<const u32x2*>(a.resid + o);
+                    const u32x2 gt = *reinterpret_cast<const u32x2*>(a.gate + col);
+                    v[0] = A16::lo(r[0]) + v[0] * A16::lo(gt[0]); v[1] = A16::hi(r[0]) + v[1] * A16::hi(gt[0]);
+                    v[2] = A16::lo(r[1]) + v[2] * A16::lo(gt[1]); v[3] = A16::hi(r[1]) + v[3] * A16::hi(gt[1]);
+                } else if (MODE == 1) {
+                    const u32x2 r = *reinterpret_cast<const u32x2*>(a.resid + o);
+                    v[0] = A16::lo(r[0]) + A16::rnd(v[0]); v[1] = A16::hi(r[0]) + A16::rnd(v[1]);
+                    v[2] = A16::lo(r[1]) + A16::rnd(v[2]); v[3] = A16::hi(r[1]) + A16::rnd(v[3]);
+                }
+                *reinterpret_cast<u32x2*>(a.out + o) = u32x2{A16::pack(v[0], v[1]), A16::pack(v[2], v[3])};
+            });
+        };
+        const int mode = a.gate ? 2 : a.resid ? 1 : 0;
+        if (a.bias) {
+            if (mode == 0) plain(std::true_type{}, std::integral_constant<int, 0>{});
+            else if (mode == 1) plain(std::true_type{}, std::integral_constant<int, 1>{});
+            else plain(std::true_type{}, std::integral_constant<int, 2>{});
+        } else {
+            if (mode == 0) plain(std::false_type{}, std::integral_constant<int, 0>{});
+            else if (mode == 1) plain(std::false_type{}, std::integral_constant<int, 1>{});
+            else plain(std::false_type{}, std::integral_constant<int, 2>{});
+        }
+        return;
     }
+    // the general form: any edge, any option, element by element where a run is cut
+    runs([&](int i, int j) {
+        const int row = lrow0 + i * 16, col = c0 + j * 16;
+        if (row >= a.M || col >= a.N) return;
+        const size_t o = (size_t)row * a.N + col;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (col + e >= a.N) break;
+            float x = ACC(i, j, e) + (a.bias ? A16::val(a.bias[col + e]) : 0.f);
+            if (a.relu) x = fmaxf(x, 0.f);
+            if (a.gate) x = A16::val(a.resid[o + e]) + x * A16::val(a.gate[col + e]);
+            else if (a.resid) x = A16::val(a.resid[o + e]) + A16::rnd(x);
+            a.out[o + e] = A16::bits(x);
+        }
+    });
+#undef ACC
 }
 
-// does the four-wave kernel take this shape?  (OMX_GEMM_W4=1 opts in; the hipcc-scheduled eight-wave kernel is the default)
-static bool w5_on() {
+// does the four-wave kernel take this launch?  It wins where the chip is full and the power limit sets the pace (>= 256 tiles: +2..6 % over the
+// eight-wave kernel, bit-identical results); with fewer tiles than CUs the eight waves hide more latency (-6..-11 %).  OMX_GEMM_W4=0 / 1: never /
+// whenever the shape allows.
+static bool w5_takes(int64_t x_rows, int K, int64_t w_rows_max, int n_tiles) {
     const char* e = getenv("OMX_GEMM_W4");
-    return e ? atoi(e) != 0 : false;
-}
-static bool w5_takes(int64_t x_rows, int K, int64_t w_rows_max) {
-    if (!w5_on()) return false;
+    const int mode = e ? atoi(e) : -1;
+    if (mode == 0 || (mode < 0 && n_tiles < 256)) return false;
     return K % 128 == 0 && (x_rows * K + 64) * 2 < ((int64_t)1 << 32) && (w_rows_max * K + 64) * 2 < ((int64_t)1 << 32);
 }
 
@@ -1721,7 +1641,7 @@ static int launch_gemm_impl(bf16_t* out, const bf16_t* x, const bf16_t* w, const
         } else {
             a.grid_m = (M + 255) / 256;
             a.grid_n = (N + 255) / 256;
-            if (w5_takes(M, K, N)) gemm_nt_w4_kernel<false, true><<<a.grid_m * a.grid_n, 256, w5::SMEM, s>>>(a);
+            if (w5_takes(M, K, N, a.grid_m * a.grid_n)) gemm_nt_w4_kernel<false, true><<<a.grid_m * a.grid_n, 256, w5::SMEM, s>>>(a);
             else gemm_bf16_nt_256_kernel<16, false, false, 256, true><<<a.grid_m * a.grid_n, big::NT, big::SMEM, s>>>(a);
         }
         OMX_LAUNCH_CHECK();
@@ -1755,7 +1675,7 @@ static int launch_gemm_impl(bf16_t* out, const bf16_t* x, const bf16_t* w, const
             a.ksplit = ksplit;
             if (ksplit > 1 && split_workspace_big(s, (size_t)tiles256 * ksplit * 256 * 256, (size_t)tiles256, &a.split_ws, &a.split_cnt)) return 1;
             const char* mf_env = getenv("OMX_GEMM_MFMA");
-            if (ksplit == 1 && !mf_env && w5_takes(M, K, N)) {
+            if (ksplit == 1 && !mf_env && w5_takes(M, K, N, a.grid_m * a.grid_n)) {
                 const int blocks = a.grid_m * a.grid_n;
 #ifdef OMX_G5_DIAG
                 const char* ve = getenv("OMX_GEMM_W4_VAR");
@@ -1900,7 +1820,7 @@ int launch_gemm_bf16_segmented(const bf16_t* x, int M, int K, const GemmSegs& se
     a.grid_n = seg_tiles(segs);
     int64_t w_rows_max = segs.half;
     for (int i = 0; i < segs.n_plain; ++i) w_rows_max = std::max<int64_t>(w_rows_max, segs.plain[i].cols);
-    if (w5_takes(M, K, w_rows_max)) {
+    if (w5_takes(M, K, w_rows_max, a.grid_m * a.grid_n)) {
         if (g_gemm_f16) gemm_nt_w4_kernel<true, true><<<a.grid_m * a.grid_n, 256, w5::SMEM, s>>>(a);
         else gemm_nt_w4_kernel<true, false><<<a.grid_m * a.grid_n, 256, w5::SMEM, s>>>(a);
     } else
@@ -1947,7 +1867,7 @@ int launch_gemm_bf16_segmented_grouped(const bf16_t* x, int max_rows, int K, con
     a.grid_n = seg_tiles(segs);
     int64_t w_rows_g = segs.half;
     for (int i = 0; i < segs.n_plain; ++i) w_rows_g = std::max<int64_t>(w_rows_g, segs.plain[i].cols);
-    if (w5_takes(max_rows, K, w_rows_g)) {   // (32-bit source offsets: inside the activations / inside ONE expert's matrices)
+    if (w5_takes(max_rows, K, w_rows_g, a.grid_m * a.grid_n)) {   // (32-bit source offsets: inside the activations / inside ONE expert's matrices)
         if (g_gemm_f16) gemm_nt_w4_kernel<true, true><<<a.grid_m * a.grid_n, 256, w5::SMEM, s>>>(a);
         else gemm_nt_w4_kernel<true, false><<<a.grid_m * a.grid_n, 256, w5::SMEM, s>>>(a);
     } else

@@ -181,8 +181,13 @@ def test_quantized_matmul_in_float16(omx, M, bits, group, K):
     wd = rc.dequantize(rq_, s16.astype(np.float32), b16.astype(np.float32), group, bits, "f32")
     noise = 4 * 2.0 ** -12 * np.sqrt((x.astype(np.float64) ** 2) @ (wd.astype(np.float64) ** 2).T)
     assert (np.abs(got.astype(np.float64) - ref) <= 2.0 ** -10 * np.abs(ref) + noise + 1e-6).all()
-    with pytest.raises(omx.OmxError):          # mixed dtypes are MLX's promotion to float32, which this path does not implement
-        omx.ops.quantized_matmul(T.from_numpy(x), T.from_numpy(rq_, "u32"), T.from_numpy(s16, "f16"), T.from_numpy(b16, "f16"), group, bits)
+    # a bfloat16 activation on the float16 checkpoint (MLX promotes with result_type; the kernels run in the scales' type): x is cast to
+    # float16 -- the same call as above when the values are representable in both (cast, do not raise)
+    xb = rc.bf16_round(x)
+    mixed = omx.ops.quantized_matmul(T.from_numpy(xb), T.from_numpy(rq_, "u32"), T.from_numpy(s16, "f16"), T.from_numpy(b16, "f16"), group, bits)
+    assert mixed.dtype == omx.ops.dtype_code("f16")
+    same = omx.ops.quantized_matmul(T.from_numpy(xb, "f16"), T.from_numpy(rq_, "u32"), T.from_numpy(s16, "f16"), T.from_numpy(b16, "f16"), group, bits)
+    np.testing.assert_array_equal(mixed.numpy(), same.numpy())
     # and the dequantised matrix itself (dtype of the scales, as MLX): one fma per element from the exact float16 values, one rounding
     dq = omx.ops.dequantize(T.from_numpy(rq_, "u32"), T.from_numpy(s16, "f16"), T.from_numpy(b16, "f16"), group, bits).numpy()
     np.testing.assert_array_equal(dq, rc.dequantize(rq_, s16.astype(np.float32), b16.astype(np.float32), group, bits, "f32").astype(np.float16).astype(np.float32))

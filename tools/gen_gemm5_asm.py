@@ -38,6 +38,7 @@ WFR = [PRM + 18 + k for k in range(2)]
 H = [40, 104]                               # fragment halves: X [8 i] x 4 regs, then W [8 j]
 S_X, S_W, S_LOOP, S_M0 = 60, 62, 64, 65
 LAST_VGPR = 167
+W_OUTER = os.environ.get("G5_ORDER", "ij") == "ji"   # the MFMA order inside a k half: column block outer (srcA = the W fragment stays), row block inner
 LAND = int(os.environ.get("G5_LAND", "66"))     # the gap of the landing wait (first-half registers are free from gap 64)
 
 
@@ -105,10 +106,15 @@ def step(g, buf, fr, loads, next_reads, vm):
     fr = dict(fr)
     second_x = [(0, 1, i) for i in range(NI)]
     second_w = [(1, 1, j) for j in range(NJ)]
-    first = [(0, 0, 0)] + [(1, 0, j) for j in range(NJ)] + [(0, 0, i) for i in range(1, NI)]
+    if W_OUTER:
+        first = [(1, 0, 0)] + [(0, 0, i) for i in range(NI)] + [(1, 0, j) for j in range(1, NJ)]
+    else:
+        first = [(0, 0, 0)] + [(1, 0, j) for j in range(NJ)] + [(0, 0, i) for i in range(1, NI)]
     nxt = {}
     for gap in range(128):
         kh, i, j = gap >> 6, (gap >> 3) & 7, gap & 7
+        if W_OUTER:
+            i, j = j, i
         g.lds_wait([fr[(0, kh, i)], fr[(1, kh, j)]])
         g.e("%s %s, %s, %s, %s" % (g.mfma, acc(i, j), vr(frag(1, kh, j), 4), vr(frag(0, kh, i), 4), acc(i, j)))
         if gap < 16 and gap % 2 == 0:

@@ -655,14 +655,23 @@ __global__ __launch_bounds__(big::NT) void gemm_bf16_nt_256_kernel(const GemmArg
 //      per thread.  K % 128 == 0, no implicit convolution, no K split; SW: the segmented projection (plain segments + SwiGLU pair tiles:
 //      inside a wave's 128 columns the first 64 are gate rows, the last 64 the up rows of the SAME outputs, so a lane holds both). ----
 namespace w5 {
-constexpr int TILES_B = 4 * 32768, PARAM_B = 256 * 80, SMEM = TILES_B + PARAM_B;
+constexpr int tiles_bytes(int tmr) { return 2 * tmr * 128 + 2 * 32768; }     // two X buffers of tmr rows, two W buffers of 256 rows, 64 k each
+constexpr int smem_bytes(int tmr) { return tiles_bytes(tmr) + 256 * (tmr / 32 + 12) * 4; }
+constexpr int SMEM = smem_bytes(256);
 }
 #include "gemm5_body.inc"
 
-template <bool SW, bool F16, int VAR = 0>
+// TMR = 128 (plain form): a 128 x 256 tile, a wave owns 64 x 128 -- for grids of exactly one such tile per CU (the O / down projections of a
+// 2 048-token prompt), where the 256^2 tile would leave half of the chip idle; 4 X pieces per wave, 128 accumulator AGPRs.
+template <bool SW, bool F16, int VAR = 0, int TMR = 256>
 __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(const GemmArgs a) {
+    static_assert(TMR == 256 || (TMR == 128 && !SW && VAR == 0), "the 128-row tile exists in the plain form");
     typedef Act16<F16> A16;
-    constexpr int NB = 8;                          // 16-row / 16-column blocks per wave
+    constexpr int NB = 8;                          // 16-column blocks per wave
+    constexpr int NBI = TMR / 32;                  // 16-row blocks per wave
+    constexpr int WROWS = TMR / 2;                 // rows per wave
+    constexpr int XP = TMR / 32;                   // X pieces (8 rows each) a wave stages per K step
+    constexpr int NPRM = XP + 12;
     constexpr int WCOLS = 16 * NB;                 // columns per wave
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
@@ -703,7 +712,7 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(const GemmArgs a) {
             tn -= sgm.tile0;
         }
     }
-    int m0 = tm * 256, rows_valid = a.M, row_base = 0;
+    int m0 = tm * TMR, rows_valid = a.M, row_base = 0;
     size_t w_off = 0;
     const uint32_t* row_src = nullptr;
     if constexpr (SW) {
@@ -724,53 +733,67 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(const GemmArgs a) {
     //      per k half kh (row = l16 of the block, chunk (4 kh + kg) ^ ((row >> 1) & 7)).  W tile row R sits in wave column R / 128; in a
     //      SwiGLU tile its first 64 rows are gate rows, the other 64 the up rows of the same outputs (one tile = 128 outputs): a wave
     //      stages 64 tile rows -- gate OR up rows. ----
-    uint32_t prm[20];
+    uint32_t prm[NPRM];
     {
         const int r8 = lane >> 3, slot = lane & 7;
 #pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            const int R = (wave * 8 + it) * 8 + r8;
+        for (int it = 0; it < XP; ++it) {
+            const int R = (wave * XP + it) * 8 + r8;
             const int chunk = slot ^ ((R >> 1) & 7);
             int xr = min(m0 + R, rows_valid - 1) + row_base;
             if constexpr (SW) {
                 if (row_src) xr = (int)row_src[xr];
             }
             prm[it] = (uint32_t)(((int64_t)xr * a.K + chunk * 8) * 2);
+        }
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int R = (wave * 8 + it) * 8 + r8;
+            const int chunk = slot ^ ((R >> 1) & 7);
             int wrow;
             if (SW && seg_act) wrow = min(n0 / 2 + (R / WCOLS) * (WCOLS / 2) + (R & (WCOLS / 2 - 1)), seg_cols - 1);
             else wrow = min(n0 + R, seg_cols - 1);
-            prm[8 + it] = (uint32_t)(((int64_t)wrow * a.K + chunk * 8) * 2);
+            prm[XP + it] = (uint32_t)(((int64_t)wrow * a.K + chunk * 8) * 2);
         }
         const unsigned tiles = (unsigned)(uintptr_t)smem;
         const int swf = (l16 >> 1) & 7;
 #pragma unroll
         for (int kh = 0; kh < 2; ++kh) {
-            prm[16 + kh] = tiles + (unsigned)((wr * 128 + l16) * 128 + ((4 * kh + kg) ^ swf) * 16);
-            prm[18 + kh] = tiles + 65536u + (unsigned)((wc * WCOLS + l16) * 128 + ((4 * kh + kg) ^ swf) * 16);
+            prm[XP + 8 + kh] = tiles + (unsigned)((wr * WROWS + l16) * 128 + ((4 * kh + kg) ^ swf) * 16);
+            prm[XP + 10 + kh] = tiles + (unsigned)(2 * TMR * 128) + (unsigned)((wc * WCOLS + l16) * 128 + ((4 * kh + kg) ^ swf) * 16);
         }
     }
-    u32x4* pblock = reinterpret_cast<u32x4*>(smem + w5::TILES_B) + threadIdx.x * 5;
+    u32x4* pblock = reinterpret_cast<u32x4*>(smem + w5::tiles_bytes(TMR)) + threadIdx.x * (NPRM / 4);
 #pragma unroll
-    for (int k = 0; k < 5; ++k) pblock[k] = u32x4{prm[4 * k], prm[4 * k + 1], prm[4 * k + 2], prm[4 * k + 3]};
+    for (int k = 0; k < NPRM / 4; ++k) pblock[k] = u32x4{prm[4 * k], prm[4 * k + 1], prm[4 * k + 2], prm[4 * k + 3]};
     const unsigned param_addr = (unsigned)(uintptr_t)pblock;
     const bf16_t* xbase = a.x;
     const bool up_rows = (wave & 1) != 0;          // (a wave's W pieces are tile rows [wave * 64, + 64): the second half of a wave column)
     const bf16_t* wbase = (SW && seg_act ? (up_rows ? a.sg.w_up : a.sg.w_gate) : seg_w) + w_off;
     const int ntrips = (a.K / 64 - 2) / 2;
-    const unsigned ldsw = (unsigned)(uintptr_t)smem + (unsigned)wave * 8192u;
+    const unsigned ldsx = (unsigned)(uintptr_t)smem + (unsigned)wave * (unsigned)(XP * 1024);                          // this wave's X pieces
+    const unsigned ldsww = (unsigned)(uintptr_t)smem + (unsigned)(2 * TMR * 128) + (unsigned)wave * 8192u;            // ... and W pieces
 
-    f32x16 acc[16];      // acc[o] = a[16 o : 16 o + 15]: tile (i, j) of the wave's 8 x 8 is acc[i * 2 + (j >> 2)][(j & 3) * 4 + e]
+    f32x16 acc[NBI * 2];      // acc[o] = a[16 o : 16 o + 15]: tile (i, j) of the wave's NBI x 8 is acc[i * 2 + (j >> 2)][(j & 3) * 4 + e]
 #pragma unroll
-    for (int t = 0; t < 16; ++t)
+    for (int t = 0; t < NBI * 2; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 #define G5_OPERANDS                                                                                                                                  \
     : "+{a[0:15]}"(acc[0]), "+{a[16:31]}"(acc[1]), "+{a[32:47]}"(acc[2]), "+{a[48:63]}"(acc[3]), "+{a[64:79]}"(acc[4]), "+{a[80:95]}"(acc[5]),        \
       "+{a[96:111]}"(acc[6]), "+{a[112:127]}"(acc[7]), "+{a[128:143]}"(acc[8]), "+{a[144:159]}"(acc[9]), "+{a[160:175]}"(acc[10]),                    \
       "+{a[176:191]}"(acc[11]), "+{a[192:207]}"(acc[12]), "+{a[208:223]}"(acc[13]), "+{a[224:239]}"(acc[14]), "+{a[240:255]}"(acc[15])               \
-    : "v"(param_addr), "s"(xbase), "s"(wbase), "s"(ntrips), "s"(ldsw)                                                                               \
+    : "v"(param_addr), "s"(xbase), "s"(wbase), "s"(ntrips), "s"(ldsx), "s"(ldsww)                                                                   \
     : G5_CLOBBERS
-    if (VAR == 0) {
+#define G5H_OPERANDS                                                                                                                                 \
+    : "+{a[0:15]}"(acc[0]), "+{a[16:31]}"(acc[1]), "+{a[32:47]}"(acc[2]), "+{a[48:63]}"(acc[3]), "+{a[64:79]}"(acc[4]), "+{a[80:95]}"(acc[5]),        \
+      "+{a[96:111]}"(acc[6]), "+{a[112:127]}"(acc[7])                                                                                                \
+    : "v"(param_addr), "s"(xbase), "s"(wbase), "s"(ntrips), "s"(ldsx), "s"(ldsww)                                                                   \
+    : G5_CLOBBERS
+    if constexpr (TMR == 128) {
+        if constexpr (F16) asm volatile(G5H_BODY_F16 G5H_OPERANDS);
+        else asm volatile(G5H_BODY G5H_OPERANDS);
+    } else if (VAR == 0) {
         if constexpr (F16) asm volatile(G5_BODY_F16 G5_OPERANDS);
         else asm volatile(G5_BODY G5_OPERANDS);
     }
@@ -785,6 +808,7 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(const GemmArgs a) {
     else if (VAR == 7) asm volatile(G5_BODY_D7 G5_OPERANDS);
 #endif
 #undef G5_OPERANDS
+#undef G5H_OPERANDS
 
     // ---- epilogue.  Tile (i, j), element e = row (wr * 128 + i * 16 + l16), column (wc * 128 + j * 16 + 4 kg + e) of the 256^2 tile: a lane
     //      holds runs of four consecutive columns (one 8-byte store each), 64 runs.  Interior tiles (every row and column exists) take
@@ -793,12 +817,12 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(const GemmArgs a) {
 #define ACC(i, j, e) acc[(i) * 2 + ((j) >> 2)][((j) & 3) * 4 + (e)]
     auto runs = [&](auto&& fn) {   // fn(i, j): row block, column block
 #pragma unroll
-        for (int i = 0; i < NB; ++i)
+        for (int i = 0; i < NBI; ++i)
 #pragma unroll
             for (int j = 0; j < NB; ++j) fn(i, j);
     };
-    const bool interior = m0 + 256 <= rows_valid && n0 + 256 <= (SW && seg_act ? 2 * seg_cols : seg_cols) && (seg_ld & 3) == 0;
-    const int lrow0 = m0 + wr * 128 + l16;                  // + i * 16
+    const bool interior = m0 + TMR <= rows_valid && n0 + 256 <= (SW && seg_act ? 2 * seg_cols : seg_cols) && (seg_ld & 3) == 0;
+    const int lrow0 = m0 + wr * WROWS + l16;                // + i * 16
     if constexpr (SW) {
         if (seg_act) {
             const int c0 = n0 / 2 + wc * (WCOLS / 2) + 4 * kg;      // + j * 16, j < 4 (gate); the up value of the same output is tile j + 4
@@ -1489,6 +1513,8 @@ int ensure_attr() {
         OMX_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_nt_w4_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, w5::SMEM));
         OMX_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_nt_w4_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, w5::SMEM));
         OMX_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_nt_w4_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, w5::SMEM));
+        OMX_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_nt_w4_kernel<false, false, 0, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, w5::smem_bytes(128)));
+        OMX_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_nt_w4_kernel<false, true, 0, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, w5::smem_bytes(128)));
 #ifdef OMX_G5_DIAG
         OMX_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_nt_w4_kernel<false, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, w5::SMEM));
         OMX_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_nt_w4_kernel<false, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, w5::SMEM));
@@ -1637,7 +1663,8 @@ static int launch_gemm_impl(bf16_t* out, const bf16_t* x, const bf16_t* w, const
         if (t256 <= 128 && !(te && atoi(te) == 256)) {   // at most half of the chip in 256^2 tiles: 128 x 256
             a.grid_m = (M + 127) / 128;
             a.grid_n = (N + 255) / 256;
-            gemm_bf16_nt_256_kernel<16, false, false, 128, true><<<a.grid_m * a.grid_n, big::NT, big::smem_bytes(128), s>>>(a);
+            if (w5_takes(M, K, N, a.grid_m * a.grid_n)) gemm_nt_w4_kernel<false, true, 0, 128><<<a.grid_m * a.grid_n, 256, w5::smem_bytes(128), s>>>(a);
+            else gemm_bf16_nt_256_kernel<16, false, false, 128, true><<<a.grid_m * a.grid_n, big::NT, big::smem_bytes(128), s>>>(a);
         } else {
             a.grid_m = (M + 255) / 256;
             a.grid_n = (N + 255) / 256;
@@ -1668,7 +1695,8 @@ static int launch_gemm_impl(bf16_t* out, const bf16_t* x, const bf16_t* w, const
         if (ksplit == 1 && (r128 == 1 || (r128 != 0 && forced == 0 && ((tiles256 >= 80 && tiles256 <= 128) || (g_tile_hint == 128 && M >= 128 && N >= 256))))) {
             a.grid_m = (M + 127) / 128;
             a.grid_n = (N + 255) / 256;
-            gemm_bf16_nt_256_kernel<16, false, false, 128><<<a.grid_m * a.grid_n, big::NT, big::smem_bytes(128), s>>>(a);
+            if (w5_takes(M, K, N, a.grid_m * a.grid_n)) gemm_nt_w4_kernel<false, false, 0, 128><<<a.grid_m * a.grid_n, 256, w5::smem_bytes(128), s>>>(a);
+            else gemm_bf16_nt_256_kernel<16, false, false, 128><<<a.grid_m * a.grid_n, big::NT, big::smem_bytes(128), s>>>(a);
         } else if (use256) {
             a.grid_m = (M + 255) / 256;
             a.grid_n = (N + 255) / 256;

@@ -96,12 +96,16 @@ def test_linear_gemm_256_tile_kernel(omx, monkeypatch, M, N, K):
     (2048, 4096, 4096),      # a prompt's O projection
 ])
 @pytest.mark.parametrize("f16", [False, True])
-def test_linear_gemm_four_wave_kernel(omx, monkeypatch, M, N, K, f16):
+@pytest.mark.parametrize("tile_rows", [256, 128])
+def test_linear_gemm_four_wave_kernel(omx, monkeypatch, M, N, K, f16, tile_rows):
     """Round 5: the 256^2 tile on FOUR waves of 128 x 128 (csrc/gemm.hip gemm_nt_w4_kernel, the K loop generated by tools/gen_gemm5_asm.py:
     8 x 8 accumulators of 16x16x32 = 256 AGPRs per wave, both operands by LDS-DMA, three barriers per 64 k) -- against the oracle, and
     bit-identical to the eight-wave kernel (same instruction, same k order per output element); ragged edges and the bias epilogue included."""
     T = omx.ops.Tensor
-    monkeypatch.setenv("OMX_GEMM_TILE", "256")
+    if tile_rows == 256:
+        monkeypatch.setenv("OMX_GEMM_TILE", "256")
+    else:       # the 128 x 256 tile (a wave owns 64 x 128): what the O / down projections of a 2 048-token prompt run on
+        monkeypatch.setenv("OMX_GEMM_ROWS128", "1")
     dt = "f16" if f16 else "bf16"
     rnd = (lambda a: a.astype(np.float16).astype(np.float32)) if f16 else rc.bf16_round
     x = rnd(rand((M, K), 41))

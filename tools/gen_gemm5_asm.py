@@ -28,18 +28,33 @@ Fixed registers (clobbered): v[16:35] parameters, v[40:103] first-half fragments
 import os
 import sys
 
-NI = NJ = 8
-P_ADDR, XBASE, WBASE, NLOOP, LDSW = "%16", "%17", "%18", "%19", "%20"
+NJ = 8
 PRM = 16
-XDMA = [PRM + k for k in range(8)]
-WDMA = [PRM + 8 + k for k in range(8)]
-XFR = [PRM + 16 + k for k in range(2)]      # by k half
-WFR = [PRM + 18 + k for k in range(2)]
-H = [40, 104]                               # fragment halves: X [8 i] x 4 regs, then W [8 j]
+H = [40, 104]                               # fragment halves: X [NI i] x 4 regs, then (from + 32) W [8 j]
 S_X, S_W, S_LOOP, S_M0 = 60, 62, 64, 65
 LAST_VGPR = 167
+
+
+class Geo:
+    """tile rows 256: 8 row blocks of 16 per wave, 8 X pieces per wave; 128 (the half-height tile for grids of exactly one tile per CU):
+    4 row blocks, 4 X pieces, X buffers of 16 KiB.  Operand numbers follow the accumulator count (16 or 8 operands of 16 AGPRs)."""
+    def __init__(self, rows):
+        self.rows = rows
+        self.NI = rows // 32
+        self.XP = rows // 32                 # X pieces per wave
+        self.XB = rows * 128                 # bytes of an X buffer
+        self.WOFF = 2 * self.XB              # W buffers follow the two X buffers
+        self.G = self.NI * NJ * 2            # MFMAs per K step and wave
+        self.st = 2 if rows == 256 else 1    # spacing of the sparse filler runs
+        n = self.NI * NJ * 4 // 16           # accumulator operands
+        self.P_ADDR, self.XBASE, self.WBASE, self.NLOOP, self.LDSX, self.LDSWW = ["%%%d" % (n + k) for k in range(6)]
+        self.XDMA = [PRM + k for k in range(self.XP)]
+        self.WDMA = [PRM + self.XP + k for k in range(8)]
+        self.XFR = [PRM + self.XP + 8 + k for k in range(2)]      # by k half
+        self.WFR = [PRM + self.XP + 10 + k for k in range(2)]
+        self.NPRM = self.XP + 12
 W_OUTER = os.environ.get("G5_ORDER", "ij") == "ji"   # the MFMA order inside a k half: column block outer (srcA = the W fragment stays), row block inner
-LAND = int(os.environ.get("G5_LAND", "66"))     # the gap of the landing wait (first-half registers are free from gap 64)
+LAND = int(os.environ["G5_LAND"]) if "G5_LAND" in os.environ else None     # the gap of the landing wait (default: two gaps into the second k half)
 
 
 def vr(lo, n=1):
@@ -54,9 +69,10 @@ def frag(mat, kh, idx):
 
 
 class Gen(list):
-    def __init__(self, mfma, diag=()):
+    def __init__(self, mfma, geo, diag=()):
         super().__init__()
         self.mfma = mfma
+        self.geo = geo
         self.diag = set(diag)
         self.lds = []
         self.nid = 0
@@ -88,21 +104,29 @@ class Gen(list):
 
 
 def dma(g, mat, buf, it):
-    g.e("s_add_u32 m0, %s, %d" % (LDSW, mat * 65536 + buf * 32768 + it * 1024))
+    q = g.geo
+    if mat:
+        g.e("s_add_u32 m0, %s, %d" % (q.LDSWW, buf * 32768 + it * 1024))
+    else:
+        g.e("s_add_u32 m0, %s, %d" % (q.LDSX, buf * q.XB + it * 1024))
     g.e("s_nop 0")
-    g.e("global_load_lds_dwordx4 %s, %s" % (vr((WDMA if mat else XDMA)[it]), sp(S_W if mat else S_X)))
+    g.e("global_load_lds_dwordx4 %s, %s" % (vr((q.WDMA if mat else q.XDMA)[it]), sp(S_W if mat else S_X)))
 
 def advance(g, s):
     g.e("s_add_u32 s%d, s%d, 128" % (s, s))
     g.e("s_addc_u32 s%d, s%d, 0" % (s + 1, s + 1))
 
 def read_frag(g, buf, mat, kh, idx):
-    return g.lds_op("ds_read_b128 %s, %s offset:%d" % (vr(frag(mat, kh, idx), 4), vr((WFR if mat else XFR)[kh]), buf * 32768 + idx * 2048))
+    q = g.geo
+    return g.lds_op("ds_read_b128 %s, %s offset:%d" % (vr(frag(mat, kh, idx), 4), vr((q.WFR if mat else q.XFR)[kh]),
+                                                       buf * (32768 if mat else q.XB) + idx * 2048))
 
 
 def step(g, buf, fr, loads, next_reads, vm):
     """one K step out of buffer `buf`.  fr: {(mat, kh, idx): LDS-op id} of the first-half fragments already requested; returns the same for the
     next step.  loads: the DMA of step t + 2; next_reads: the first-half fragments of t + 1; vm: the vmcnt of the landing wait."""
+    q = g.geo
+    NI, G, st = q.NI, q.G, q.st
     fr = dict(fr)
     second_x = [(0, 1, i) for i in range(NI)]
     second_w = [(1, 1, j) for j in range(NJ)]
@@ -110,64 +134,91 @@ def step(g, buf, fr, loads, next_reads, vm):
         first = [(1, 0, 0)] + [(0, 0, i) for i in range(NI)] + [(1, 0, j) for j in range(1, NJ)]
     else:
         first = [(0, 0, 0)] + [(1, 0, j) for j in range(NJ)] + [(0, 0, i) for i in range(1, NI)]
+    # filler plan: gap -> list of actions
+    plan = {}
+    def at(gap, act):
+        plan.setdefault(gap, []).append(act)
+    for k in range(NI):
+        at(k * st, ("read", second_x[k]))
+    if loads:
+        b1 = (NI - 1) * st + 3 * st
+        at(b1, ("bar",))
+        mixed = []
+        for k in range(max(q.XP, NJ)):
+            if k < q.XP:
+                mixed.append(("dma", 0, k))
+            if k < NJ:
+                mixed.append(("read", second_w[k]))
+        for k, act in enumerate(mixed):
+            at(b1 + st + k, act)
+        last = b1 + st + len(mixed) - 1
+        b2 = last + 2 * st + 1
+        at(b2, ("bar",))
+        for k in range(8):
+            at(b2 + st + k * st, ("dma", 1, k))
+        assert b2 + st + 7 * st < G // 2 + 2, "the step's DMA must be issued before the landing wait (vmcnt counts on it)"
+    else:
+        for k in range(NJ):
+            at(NI * st + k * st, ("read", second_w[k]))
+    land = G // 2 + 2 if LAND is None else LAND
+    if next_reads:
+        at(land, ("land", vm))
+        for k, f in enumerate(first):
+            at(land + k * st, ("readnext", f))
+        assert land + (len(first) - 1) * st < G
     nxt = {}
-    for gap in range(128):
-        kh, i, j = gap >> 6, (gap >> 3) & 7, gap & 7
+    xdma = wdma = 0
+    for gap in range(G):
+        kh, i, j = gap // (G // 2), (gap % (G // 2)) // NJ, gap % NJ
         if W_OUTER:
-            i, j = j, i
+            i, j = (gap % (G // 2)) % NI, (gap % (G // 2)) // NI
         g.lds_wait([fr[(0, kh, i)], fr[(1, kh, j)]])
         g.e("%s %s, %s, %s, %s" % (g.mfma, acc(i, j), vr(frag(1, kh, j), 4), vr(frag(0, kh, i), 4), acc(i, j)))
-        if gap < 16 and gap % 2 == 0:
-            f = second_x[gap // 2]
-            fr[f] = read_frag(g, buf, *f)
-        if loads:
-            if gap == 20 or gap == 42:
+        for act in plan.get(gap, []):
+            if act[0] == "read":
+                fr[act[1]] = read_frag(g, buf, *act[1])
+            elif act[0] == "readnext":
+                nxt[act[1]] = read_frag(g, buf ^ 1, *act[1])
+            elif act[0] == "bar":
                 g.lds_wait_all()
                 g.e("s_barrier")
-            if 22 <= gap < 38:
-                if gap % 2 == 0:
-                    dma(g, 0, buf, (gap - 22) // 2)
-                else:
-                    f = second_w[(gap - 23) // 2]
-                    fr[f] = read_frag(g, buf, *f)
-                if gap == 36:
-                    advance(g, S_X)
-            if 44 <= gap < 60 and gap % 2 == 0:
-                dma(g, 1, buf, (gap - 44) // 2)
-                if gap == 58:
-                    advance(g, S_W)
-        elif 16 <= gap < 32 and gap % 2 == 0:
-            f = second_w[(gap - 16) // 2]
-            fr[f] = read_frag(g, buf, *f)
-        if next_reads:
-            if gap == LAND:
-                g.e("s_waitcnt vmcnt(%d)" % vm)
+            elif act[0] == "land":
+                g.e("s_waitcnt vmcnt(%d)" % act[1])
                 g.e("s_barrier")
-            if LAND <= gap < LAND + 32 and (gap - LAND) % 2 == 0:
-                f = first[(gap - LAND) // 2]
-                nxt[f] = read_frag(g, buf ^ 1, *f)
+            elif act[0] == "dma":
+                dma(g, act[1], buf, act[2])
+                if act[1] == 0:
+                    xdma += 1
+                    if xdma == q.XP:
+                        advance(g, S_X)
+                else:
+                    wdma += 1
+                    if wdma == 8:
+                        advance(g, S_W)
     g.lds_wait_all()
     return nxt
 
 
-def generate(mfma, diag=()):
-    g = Gen(mfma, diag)
+def generate(mfma, rows=256, diag=()):
+    q = Geo(rows)
+    g = Gen(mfma, q, diag)
     g.e("s_mov_b32 s%d, m0" % S_M0)
-    for k in range(5):
-        g.e("ds_read_b128 %s, %s offset:%d ;PARAM" % (vr(PRM + 4 * k, 4), P_ADDR, 16 * k))
-    g.e("s_mov_b64 %s, %s" % (sp(S_X), XBASE))
-    g.e("s_mov_b64 %s, %s" % (sp(S_W), WBASE))
-    g.e("s_mov_b32 s%d, %s" % (S_LOOP, NLOOP))
+    for k in range(q.NPRM // 4):
+        g.e("ds_read_b128 %s, %s offset:%d ;PARAM" % (vr(PRM + 4 * k, 4), q.P_ADDR, 16 * k))
+    g.e("s_mov_b64 %s, %s" % (sp(S_X), q.XBASE))
+    g.e("s_mov_b64 %s, %s" % (sp(S_W), q.WBASE))
+    g.e("s_mov_b32 s%d, %s" % (S_LOOP, q.NLOOP))
     g.e("s_waitcnt lgkmcnt(0)")
     for buf in range(2):             # K steps 0 and 1
         for mat in range(2):
-            for it in range(8):
+            for it in range(8 if mat else q.XP):
                 dma(g, mat, buf, it)
             advance(g, S_W if mat else S_X)
-    g.e("s_waitcnt vmcnt(16)")
+    per_step = q.XP + 8
+    g.e("s_waitcnt vmcnt(%d)" % per_step)
     g.e("s_barrier")
     fr = {}
-    for idx in range(NI):
+    for idx in range(q.NI):
         fr[(0, 0, idx)] = read_frag(g, 0, 0, 0, idx)
     for idx in range(NJ):
         fr[(1, 0, idx)] = read_frag(g, 0, 1, 0, idx)
@@ -176,8 +227,8 @@ def generate(mfma, diag=()):
     g.e("s_cmp_eq_u32 s%d, 0" % S_LOOP)
     g.e("s_cbranch_scc1 G5_tail_%=")
     g.e("G5_loop_%=:")
-    step(g, 0, ready, True, True, 16)
-    step(g, 1, ready, True, True, 16)
+    step(g, 0, ready, True, True, per_step)
+    step(g, 1, ready, True, True, per_step)
     g.e("s_sub_u32 s%d, s%d, 1" % (S_LOOP, S_LOOP))
     g.e("s_cmp_lg_u32 s%d, 0" % S_LOOP)
     g.e("s_cbranch_scc1 G5_loop_%=")
@@ -200,16 +251,19 @@ def main():
     out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "ominix-mlx_amd", "csrc")
     with open(os.path.join(out_dir, "gemm5_body.inc"), "w") as f:
         lines = generate("v_mfma_f32_16x16x32_bf16")
-        f.write("// GENERATED by tools/gen_gemm5_asm.py -- do not edit; %d instructions\n" % len(lines))
+        half = generate("v_mfma_f32_16x16x32_bf16", 128)
+        f.write("// GENERATED by tools/gen_gemm5_asm.py -- do not edit; %d instructions (256-row tile), %d (128-row tile)\n" % (len(lines), len(half)))
         clob = ["v%d" % i for i in range(PRM, LAST_VGPR + 1)] + ["s%d" % i for i in range(60, 66)] + ["scc", "memory"]
         f.write("#define G5_CLOBBERS " + ", ".join('"%s"' % c for c in clob) + "\n")
         emit(f, "G5_BODY", lines)
         emit(f, "G5_BODY_F16", generate("v_mfma_f32_16x16x32_f16"))
+        emit(f, "G5H_BODY", half)
+        emit(f, "G5H_BODY_F16", generate("v_mfma_f32_16x16x32_f16", 128))
         if "--diag" in sys.argv:
             for k, d in enumerate((("nodma",), ("nolds",), ("nobar",), ("nodma", "nolds", "nobar"), ("nodma", "nobar"), ("nolds", "nobar"),
                                    ("nodma", "nolds")), 1):
-                emit(f, "G5_BODY_D%d" % k, generate("v_mfma_f32_16x16x32_bf16", d))
-        print("%d instructions" % len(lines))
+                emit(f, "G5_BODY_D%d" % k, generate("v_mfma_f32_16x16x32_bf16", 256, d))
+        print("%d / %d instructions" % (len(lines), len(half)))
 
 
 if __name__ == "__main__":

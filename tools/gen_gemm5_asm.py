@@ -53,6 +53,8 @@ class Geo:
         self.XFR = [PRM + self.XP + 8 + k for k in range(2)]      # by k half
         self.WFR = [PRM + self.XP + 10 + k for k in range(2)]
         self.NPRM = self.XP + 12
+DENSE = os.environ.get("G5_DENSE", "0") == "1"
+ONE_BARRIER = os.environ.get("G5_ONE_BARRIER", "0") == "1"   # one barrier per step for the refill of both operands instead of two
 W_OUTER = os.environ.get("G5_ORDER", "ij") == "ji"   # the MFMA order inside a k half: column block outer (srcA = the W fragment stays), row block inner
 LAND = int(os.environ["G5_LAND"]) if "G5_LAND" in os.environ else None     # the gap of the landing wait (default: two gaps into the second k half)
 
@@ -138,10 +140,22 @@ def step(g, buf, fr, loads, next_reads, vm):
     plan = {}
     def at(gap, act):
         plan.setdefault(gap, []).append(act)
+    xs = 1 if DENSE else st              # spacing of the first run of reads (dense: the X buffer is released, and refilled, ~10 gaps earlier)
     for k in range(NI):
-        at(k * st, ("read", second_x[k]))
-    if loads:
-        b1 = (NI - 1) * st + 3 * st
+        at(k * xs, ("read", second_x[k]))
+    if loads and ONE_BARRIER:
+        # one barrier for both operands: all second-half fragments first (X on even, W on odd gaps), then the 16 pieces
+        for k in range(NJ):
+            at(k * st + (1 if st == 2 else NI), ("read", second_w[k]))
+        last = max((NI - 1) * st, (NJ - 1) * st + (1 if st == 2 else NI))
+        b1 = last + 2 * st + 2
+        at(b1, ("bar",))
+        pieces = [("dma", 0, k) for k in range(q.XP)] + [("dma", 1, k) for k in range(8)]
+        for k, act in enumerate(pieces):
+            at(b1 + st + k * st, act)
+        assert b1 + st + (len(pieces) - 1) * st < G // 2 + 2
+    elif loads:
+        b1 = (NI - 1) * xs + 3 * st
         at(b1, ("bar",))
         mixed = []
         for k in range(max(q.XP, NJ)):
@@ -159,7 +173,7 @@ def step(g, buf, fr, loads, next_reads, vm):
         assert b2 + st + 7 * st < G // 2 + 2, "the step's DMA must be issued before the landing wait (vmcnt counts on it)"
     else:
         for k in range(NJ):
-            at(NI * st + k * st, ("read", second_w[k]))
+            at(NI * xs + k * st, ("read", second_w[k]))
     land = G // 2 + 2 if LAND is None else LAND
     if next_reads:
         at(land, ("land", vm))

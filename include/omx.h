@@ -333,12 +333,12 @@ int omx_moe_block_partial_ep_q(float* partial, const void* x, const void* norm_w
                                const void* b_router, const void* q_gate, const void* s_gate, const void* b_gate, const void* q_up,
                                const void* s_up, const void* b_up, const void* q_down, const void* s_down, const void* b_down, int n_tokens,
                                int hidden, int inter, int n_experts, int top_k, int mode, int norm_topk_prob, int e_lo, int e_n, int group_size,
-                               int bits, omx_stream stream);
+                               int bits, int f16, omx_stream stream);
 int omx_moe_block_partial_tp_q(float* y_partial, uint32_t* route_inds, void* route_scores, const void* x, const void* norm_w, float eps,
                                const void* q_router, const void* s_router, const void* b_router, const void* q_gate, const void* s_gate,
                                const void* b_gate, const void* q_up, const void* s_up, const void* b_up, const void* q_down, const void* s_down,
                                const void* b_down, int n_tokens, int hidden, int inter, int n_experts, int top_k, int mode, int norm_topk_prob,
-                               int group_size, int bits, omx_stream stream);
+                               int group_size, int bits, int f16, omx_stream stream);
 int omx_moe_block_slots_ep(omx_moe_ep_slots* out, const void* x /* normalised rows */, const void* gate_w, const void* w_gate, const void* w_up,
                            const void* w_down, int n_tokens, int hidden, int inter, int n_experts, int top_k, int mode, int norm_topk_prob,
                            int e_lo, int e_n, omx_stream stream);
@@ -351,6 +351,10 @@ int omx_moe_block_partial_tp(float* y_partial, uint32_t* route_inds, void* route
                              int hidden, int inter, int n_experts, int top_k, int mode, int norm_topk_prob, omx_stream stream);
 int omx_moe_combine_slots(void* out, const float* y_slots, const void* scores, const void* resid, int n_tokens, int hidden, int top_k,
                           omx_stream stream);
+/* f16 != 0 (also the last int of the two packed-stack entry points above): a float16 checkpoint -- activations, scores, residual and every
+ * rounding point float16 (nn/quantized.rs:361-385: the dequantised weight has the scales' dtype), f32 accumulation; decode form only */
+int omx_moe_combine_slots_ex(void* out, const float* y_slots, const void* scores, const void* resid, int n_tokens, int hidden, int top_k,
+                             int f16, omx_stream stream);
 /* the same on a quantised checkpoint (mixtral-mlx/src/model.rs:560-600): router and expert stacks as MLX triplets */
 /* one token, bf16 experts: the block WITHOUT its weighted sum -- partials[j, :] (f32) = bf16(bf16(y_j) * score_j) of the top_k routed
  * experts in slot order; the caller's next streaming GEMV folds x := bf16(resid + bf16(sum_j partials[j])) in its prologue (engine-internal:

@@ -537,10 +537,10 @@ int enqueue_step_quant(omx_qwen3 m, bool with_head) {
             if (omx_moe_block_partial_tp_q(m->moe_y, m->moe_inds, m->moe_scores, h, L.post_ln, c.rms_norm_eps, Q.moe_router.w, Q.moe_router.scales,
                                            Q.moe_router.biases, Q.moe_g.w, Q.moe_g.scales, Q.moe_g.biases, Q.moe_u.w, Q.moe_u.scales, Q.moe_u.biases,
                                            Q.moe_d.w, Q.moe_d.scales, Q.moe_d.biases, 1, hd, m->moe_I, c.num_experts, c.num_experts_per_tok, c.moe_mode,
-                                           c.norm_topk_prob, group, bits, s))
+                                           c.norm_topk_prob, group, bits, sf16 ? 1 : 0, s))
                 return 1;
             OMX_REQUIRE(m->allreduce(m->moe_y, m->moe_y, (size_t)c.num_experts_per_tok * hd, kNcclFloat32, kNcclSum, m->comm, s) == 0, "ncclAllReduce failed");
-            if (omx_moe_combine_slots(hn, m->moe_y, m->moe_scores, h, 1, hd, c.num_experts_per_tok, s)) return 1;
+            if (omx_moe_combine_slots_ex(hn, m->moe_y, m->moe_scores, h, 1, hd, c.num_experts_per_tok, sf16 ? 1 : 0, s)) return 1;
             bf16_t* t = h; h = hn; hn = t;
             continue;
         }
@@ -550,7 +550,7 @@ int enqueue_step_quant(omx_qwen3 m, bool with_head) {
             if (omx_moe_block_partial_ep_q(m->partial_b, h, L.post_ln, c.rms_norm_eps, m->moe_xn, Q.moe_router.w, Q.moe_router.scales,
                                            Q.moe_router.biases, Q.moe_g.w, Q.moe_g.scales, Q.moe_g.biases, Q.moe_u.w, Q.moe_u.scales, Q.moe_u.biases,
                                            Q.moe_d.w, Q.moe_d.scales, Q.moe_d.biases, 1, hd, c.moe_intermediate_size, c.num_experts,
-                                           c.num_experts_per_tok, c.moe_mode, c.norm_topk_prob, c.ep_rank * el, el, group, bits, s))
+                                           c.num_experts_per_tok, c.moe_mode, c.norm_topk_prob, c.ep_rank * el, el, group, bits, sf16 ? 1 : 0, s))
                 return 1;
             if (reduce_fold(m->partial_b)) return 1;
             continue;
@@ -1343,7 +1343,7 @@ int prefill_prefix_batched(omx_qwen3 m, int T, int off, const EncodeOpts* enc = 
                                                Q.moe_router.biases, Q.moe_g.w, Q.moe_g.scales, Q.moe_g.biases, Q.moe_u.w, Q.moe_u.scales,
                                                Q.moe_u.biases, Q.moe_d.w, Q.moe_d.scales, Q.moe_d.biases, T, hd, etp ? m->moe_I : c.moe_intermediate_size,
                                                c.num_experts, c.num_experts_per_tok, c.moe_mode, c.norm_topk_prob, etp ? 0 : c.ep_rank * el, el,
-                                               c.quant_group, c.quant_bits, s))
+                                               c.quant_group, c.quant_bits, 0, s))
                     return 1;
                 OMX_REQUIRE(m->allreduce != nullptr, "ep_size / tp_size > 1 but no communicator set (omx_qwen3_set_comm)");
                 OMX_REQUIRE(m->allreduce(m->pf_ep_partial, m->pf_ep_partial, (size_t)T * hd, kNcclFloat32, kNcclSum, m->comm, s) == 0, "ncclAllReduce failed");
@@ -1461,8 +1461,6 @@ int omx_qwen3_create(omx_qwen3* out, const omx_qwen3_config* cfg) {
     OMX_REQUIRE(c.quant_bits == 0 || c.quant_bits == 4 || c.quant_bits == 8, "InvalidConfig: quantization bits %d (0 = bf16, 4, 8)", c.quant_bits);
     // (round 4) quantized checkpoints under tensor parallelism: the packed rows / K slices of the dense model; (round 5) also the packed
     // expert stacks of a sparse-MoE model, expert parallel or expert tensor parallel, with bf16 triplets
-    OMX_REQUIRE(c.quant_bits == 0 || c.tp_size == 1 || c.num_experts == 0 || !c.quant_scales_f16,
-                "InvalidConfig: a float16-scale sparse-MoE checkpoint runs on one rank (tp_size %d)", c.tp_size);
     omx_qwen3 m = new omx_qwen3_();
     m->cfg = c;
     if (m->cfg.rope_scale == 0.f) m->cfg.rope_scale = 1.f;
@@ -1470,8 +1468,9 @@ int omx_qwen3_create(omx_qwen3* out, const omx_qwen3_config* cfg) {
     if (m->cfg.quant_bits && m->cfg.quant_group == 0) m->cfg.quant_group = 64;     // nn/quantized.rs:330-333
     OMX_REQUIRE(!m->cfg.quant_bits || m->cfg.quant_group == 32 || m->cfg.quant_group == 64 || m->cfg.quant_group == 128,
                 "InvalidConfig: quantization group_size %d (32, 64, 128)", m->cfg.quant_group);
-    OMX_REQUIRE(!m->cfg.quant_scales_f16 || (m->cfg.quant_bits && m->cfg.ep_size <= 1 && m->cfg.head_dim == 128 && (m->cfg.num_experts == 0 || m->cfg.tp_size == 1)),
-                "InvalidConfig: a float16 checkpoint (quantization scales_dtype float16) runs as a packed model with head_dim 128 (dense, also tensor-parallel; sparse-MoE on one rank)");
+    // (round 5: float16 sparse-MoE checkpoints also expert parallel / expert tensor parallel -- decode form; their prompts go token by token)
+    OMX_REQUIRE(!m->cfg.quant_scales_f16 || (m->cfg.quant_bits && m->cfg.head_dim == 128),
+                "InvalidConfig: a float16 checkpoint (quantization scales_dtype float16) runs as a packed model with head_dim 128");
     m->H = c.num_attention_heads / c.tp_size;
     m->Hkv = c.num_key_value_heads >= c.tp_size ? c.num_key_value_heads / c.tp_size : 1;
     m->I = c.intermediate_size / c.tp_size;
@@ -1942,7 +1941,8 @@ int omx_qwen3_prefill(omx_qwen3 m, const uint32_t* prompt, int n_prompt, uint32_
     // with one all-reduce of the MoE block's [T, hidden] partial per layer (round 3; token-serial before)
     // (float16 models: the batched pass exists for plain prompts -- dense models on one rank or tensor parallel, sparse-MoE models on
     //  one rank; short prompts go through the decode step)
-    const bool f16_serial = m->cfg.quant_scales_f16 && n_prompt <= 16;
+    const bool f16_sharded_moe = m->cfg.num_experts > 0 && (m->cfg.ep_size > 1 || m->cfg.tp_size > 1);   // (no float16 batched form of the sharded MoE block)
+    const bool f16_serial = m->cfg.quant_scales_f16 && (n_prompt <= 16 || f16_sharded_moe);
     const bool serial = (serial_env && serial_env[0] == '1') || n_prompt < 2 || f16_serial;
     if (prepare_step(m, serial ? off : off + n_prompt - 1)) return 1;   // the first step this call will run (graphs are per context bucket)
     if (!serial && m->cfg.quant_bits) dq_cache_prepare(m);             // (a once-per-model allocation: ahead of the timed region)

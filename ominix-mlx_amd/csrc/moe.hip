@@ -271,10 +271,12 @@ __global__ __launch_bounds__(256) void moe_unsort_kernel(bf16_t* __restrict__ ou
 
 // expert-parallel partial of the weighted sum: out[t] (f32) = sum over the slots whose expert lives on this rank of
 // bf16(y * score) -- the ranks' partials add up (all-reduce) to the single-device sum before its rounding
+template <bool F16 = false>
 __global__ __launch_bounds__(256) void moe_combine_partial_kernel(float* __restrict__ out, const bf16_t* __restrict__ y,
                                                                   const bf16_t* __restrict__ scores, const uint32_t* __restrict__ inds,
                                                                   int h, int k, int e_lo, int e_n,
                                                                   const uint32_t* __restrict__ pos_of_slot = nullptr) {
+    typedef Act16<F16> A16;      // (F16: a float16 checkpoint's slot outputs and scores, products rounded to float16)
     const int t = blockIdx.x;
     for (int i = threadIdx.x * 8; i < h; i += 256 * 8) {
         float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -282,13 +284,13 @@ __global__ __launch_bounds__(256) void moe_combine_partial_kernel(float* __restr
             const size_t slot = (size_t)t * k + j;
             const int e = (int)inds[slot];
             if (e < e_lo || e >= e_lo + e_n) continue;
-            const float sc = bf16_to_f32(scores[slot]);
+            const float sc = A16::val(scores[slot]);
             const size_t p = pos_of_slot ? pos_of_slot[slot] : slot;     // batched form: the row's place in the expert-sorted order
             const u32x4 v = *reinterpret_cast<const u32x4*>(y + p * h + i);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                acc[2 * q] += round_bf16(bf16lo(v[q]) * sc);
-                acc[2 * q + 1] += round_bf16(bf16hi(v[q]) * sc);
+                acc[2 * q] += A16::rnd(A16::lo(v[q]) * sc);
+                acc[2 * q + 1] += A16::rnd(A16::hi(v[q]) * sc);
             }
         }
 #pragma unroll
@@ -754,7 +756,7 @@ extern "C" int omx_moe_block_partial_ep(float* partial, const void* x, const voi
             *g_ep_slots_out = omx_moe_ep_slots{ybuf, pos_of_slot, inds, scores};
             return 0;
         }
-        moe_combine_partial_kernel<<<n_tokens, 256, 0, s>>>(partial, ybuf, scores, inds, hidden, top_k, e_lo, e_n, pos_of_slot);
+        moe_combine_partial_kernel<false><<<n_tokens, 256, 0, s>>>(partial, ybuf, scores, inds, hidden, top_k, e_lo, e_n, pos_of_slot);
         OMX_LAUNCH_CHECK();
         return 0;
     }
@@ -773,7 +775,7 @@ extern "C" int omx_moe_block_partial_ep(float* partial, const void* x, const voi
     d.w_sel = inds; d.w_estride = (size_t)hidden * inter;
     d.w_sel_lo = e_lo; d.w_sel_n = e_n;
     if (launch_gemv(d, PRO_NONE, EPI_STORE, s)) return 1;
-    moe_combine_partial_kernel<<<n_tokens, 256, 0, s>>>(partial, ybuf, scores, inds, hidden, top_k, e_lo, e_n);
+    moe_combine_partial_kernel<false><<<n_tokens, 256, 0, s>>>(partial, ybuf, scores, inds, hidden, top_k, e_lo, e_n);
     OMX_LAUNCH_CHECK();
     return 0;
 }
@@ -862,15 +864,16 @@ int dequant_stacks(DqScratch& q, const void* q_router, const void* s_router, con
 // router of the packed block: logits by the packed GEMV (RMSNorm prologue when norm_w), then the selection
 int route_packed(const void* x, const void* norm_w, float eps, const void* q_router, const void* s_router, const void* b_router, int n_tokens,
                  int hidden, int n_experts, int top_k, int mode, int norm_topk_prob, int group_size, int bits, omx::bf16_t* logits, uint32_t* inds,
-                 omx::bf16_t* scores, hipStream_t s) {
+                 omx::bf16_t* scores, hipStream_t s, bool f16 = false) {
     using namespace omx;
     QGemvArgs a = {};
     a.m[0] = QMat{(const uint32_t*)q_router, (const bf16_t*)s_router, (const bf16_t*)b_router, n_experts};
     a.N = n_experts; a.K = hidden; a.group = group_size;
     a.x = (const bf16_t*)x; a.norm_w = (const bf16_t*)norm_w; a.eps = eps; a.out = logits;
-    a.n_batch = n_tokens; a.x_div = 1;
+    a.n_batch = n_tokens; a.x_div = 1; a.scales_f16 = f16;
     if (launch_qgemv(a, bits, norm_w ? PRO_RMSNORM : PRO_NONE, EPI_STORE, s)) return 1;
-    moe_route_logits_kernel<false><<<n_tokens, 64, 0, s>>>(logits, n_experts, top_k, mode, norm_topk_prob, inds, scores);
+    if (f16) moe_route_logits_kernel<true><<<n_tokens, 64, 0, s>>>(logits, n_experts, top_k, mode, norm_topk_prob, inds, scores);
+    else moe_route_logits_kernel<false><<<n_tokens, 64, 0, s>>>(logits, n_experts, top_k, mode, norm_topk_prob, inds, scores);
     OMX_LAUNCH_CHECK();
     return 0;
 }
@@ -882,7 +885,7 @@ extern "C" int omx_moe_block_partial_ep_q(float* partial, const void* x, const v
                                           const void* s_router, const void* b_router, const void* q_gate, const void* s_gate,
                                           const void* b_gate, const void* q_up, const void* s_up, const void* b_up, const void* q_down,
                                           const void* s_down, const void* b_down, int n_tokens, int hidden, int inter, int n_experts, int top_k,
-                                          int mode, int norm_topk_prob, int e_lo, int e_n, int group_size, int bits, omx_stream stream) {
+                                          int mode, int norm_topk_prob, int e_lo, int e_n, int group_size, int bits, int f16, omx_stream stream) {
     using namespace omx;
     OMX_REQUIRE(partial && x && q_router && s_router && b_router && q_gate && s_gate && b_gate && q_up && s_up && b_up && q_down && s_down && b_down,
                 "omx_moe_block_partial_ep_q: null tensor");
@@ -894,6 +897,7 @@ extern "C" int omx_moe_block_partial_ep_q(float* partial, const void* x, const v
     OMX_REQUIRE(slots >= 1, "omx_moe_block_partial_ep_q: no tokens");
     hipStream_t s = (hipStream_t)stream;
     if (slots > 32) {
+        OMX_REQUIRE(!f16, "omx_moe_block_partial_ep_q: a float16 checkpoint's prompt runs through the decode form under expert parallelism");
         // a prompt: normalised rows (the caller's, or made here), the rank's stacks and the router dequantised, the bf16 batched form
         const void* rows = x;
         if (norm_w) {
@@ -920,7 +924,7 @@ extern "C" int omx_moe_block_partial_ep_q(float* partial, const void* x, const v
     bf16_t* gbuf = (bf16_t*)take((size_t)slots * inter * 2);
     bf16_t* ybuf = (bf16_t*)take((size_t)slots * hidden * 2);
     if (route_packed(x, norm_w, eps, q_router, s_router, b_router, n_tokens, hidden, n_experts, top_k, mode, norm_topk_prob, group_size, bits, logits,
-                     inds, scores, s))
+                     inds, scores, s, f16 != 0))
         return 1;
     QGemvArgs a = {};
     a.m[0] = QMat{(const uint32_t*)q_gate, (const bf16_t*)s_gate, (const bf16_t*)b_gate, inter};
@@ -930,7 +934,7 @@ extern "C" int omx_moe_block_partial_ep_q(float* partial, const void* x, const v
     a.x = (const bf16_t*)x; a.norm_w = (const bf16_t*)norm_w; a.eps = eps; a.out = gbuf;
     a.n_batch = slots; a.x_div = top_k; a.w_sel = inds; a.w_sel_lo = e_lo; a.w_sel_n = e_n;
     a.w_estride = (size_t)inter * hidden * bits / 32; a.s_estride = (size_t)inter * (hidden / group_size);
-    a.swiglu_single_round = 1;
+    a.swiglu_single_round = 1; a.scales_f16 = f16 != 0;
     if (launch_qgemv(a, bits, PRO_RMSNORM, EPI_SWIGLU, s)) return 1;
     QGemvArgs d = {};
     d.m[0] = QMat{(const uint32_t*)q_down, (const bf16_t*)s_down, (const bf16_t*)b_down, hidden};
@@ -939,8 +943,10 @@ extern "C" int omx_moe_block_partial_ep_q(float* partial, const void* x, const v
     d.x = gbuf; d.out = ybuf;
     d.n_batch = slots; d.x_div = 1; d.w_sel = inds; d.w_sel_lo = e_lo; d.w_sel_n = e_n;
     d.w_estride = (size_t)hidden * inter * bits / 32; d.s_estride = (size_t)hidden * (inter / group_size);
+    d.scales_f16 = f16 != 0;
     if (launch_qgemv(d, bits, PRO_NONE, EPI_STORE, s)) return 1;
-    moe_combine_partial_kernel<<<n_tokens, 256, 0, s>>>(partial, ybuf, scores, inds, hidden, top_k, e_lo, e_n);
+    if (f16) moe_combine_partial_kernel<true><<<n_tokens, 256, 0, s>>>(partial, ybuf, scores, inds, hidden, top_k, e_lo, e_n);
+    else moe_combine_partial_kernel<false><<<n_tokens, 256, 0, s>>>(partial, ybuf, scores, inds, hidden, top_k, e_lo, e_n);
     OMX_LAUNCH_CHECK();
     return 0;
 }
@@ -953,7 +959,7 @@ extern "C" int omx_moe_block_partial_tp_q(float* y_partial, uint32_t* route_inds
                                           const void* q_router, const void* s_router, const void* b_router, const void* q_gate, const void* s_gate,
                                           const void* b_gate, const void* q_up, const void* s_up, const void* b_up, const void* q_down,
                                           const void* s_down, const void* b_down, int n_tokens, int hidden, int inter, int n_experts, int top_k,
-                                          int mode, int norm_topk_prob, int group_size, int bits, omx_stream stream) {
+                                          int mode, int norm_topk_prob, int group_size, int bits, int f16, omx_stream stream) {
     using namespace omx;
     OMX_REQUIRE(y_partial && route_inds && route_scores && x && norm_w && q_router && s_router && b_router && q_gate && s_gate && b_gate && q_up &&
                     s_up && b_up && q_down && s_down && b_down, "omx_moe_block_partial_tp_q: null tensor");
@@ -968,7 +974,7 @@ extern "C" int omx_moe_block_partial_tp_q(float* y_partial, uint32_t* route_inds
     bf16_t* logits = (bf16_t*)ws;
     bf16_t* gbuf = (bf16_t*)((char*)ws + (((size_t)n_tokens * n_experts * 2 + 255) & ~(size_t)255));
     if (route_packed(x, norm_w, eps, q_router, s_router, b_router, n_tokens, hidden, n_experts, top_k, mode, norm_topk_prob, group_size, bits, logits,
-                     route_inds, (bf16_t*)route_scores, s))
+                     route_inds, (bf16_t*)route_scores, s, f16 != 0))
         return 1;
     QGemvArgs a = {};
     a.m[0] = QMat{(const uint32_t*)q_gate, (const bf16_t*)s_gate, (const bf16_t*)b_gate, inter};
@@ -978,7 +984,7 @@ extern "C" int omx_moe_block_partial_tp_q(float* y_partial, uint32_t* route_inds
     a.x = (const bf16_t*)x; a.norm_w = (const bf16_t*)norm_w; a.eps = eps; a.out = gbuf;
     a.n_batch = slots; a.x_div = top_k; a.w_sel = route_inds;
     a.w_estride = (size_t)inter * hidden * bits / 32; a.s_estride = (size_t)inter * (hidden / group_size);
-    a.swiglu_single_round = 1;
+    a.swiglu_single_round = 1; a.scales_f16 = f16 != 0;
     if (launch_qgemv(a, bits, PRO_RMSNORM, EPI_SWIGLU, s)) return 1;
     QGemvArgs d = {};
     d.m[0] = QMat{(const uint32_t*)q_down, (const bf16_t*)s_down, (const bf16_t*)b_down, hidden};
@@ -987,19 +993,22 @@ extern "C" int omx_moe_block_partial_tp_q(float* y_partial, uint32_t* route_inds
     d.x = gbuf; d.out_f32 = y_partial;
     d.n_batch = slots; d.x_div = 1; d.w_sel = route_inds;
     d.w_estride = (size_t)hidden * inter * bits / 32; d.s_estride = (size_t)hidden * (inter / group_size);
+    d.scales_f16 = f16 != 0;
     return launch_qgemv(d, bits, PRO_NONE, EPI_F32, s);
 }
 
 namespace omx {
 namespace {
 // out[t] = bf16(resid[t] + bf16(sum_j bf16(bf16(y[t k + j]) * score[t k + j])))  -- moe_combine_kernel on f32 (all-reduced) slot outputs
+template <bool F16 = false>
 __global__ __launch_bounds__(256) void moe_combine_slots_kernel(bf16_t* __restrict__ out, const float* __restrict__ y, const bf16_t* __restrict__ scores,
                                                                 const bf16_t* __restrict__ resid, int h, int k) {
+    typedef Act16<F16> A16;
     const int t = blockIdx.x;
     for (int i = threadIdx.x; i < h; i += 256) {
         float acc = 0.f;
-        for (int j = 0; j < k; ++j) acc += round_bf16(round_bf16(y[((size_t)t * k + j) * h + i]) * bf16_to_f32(scores[(size_t)t * k + j]));
-        out[(size_t)t * h + i] = f32_to_bf16(resid ? bf16_to_f32(resid[(size_t)t * h + i]) + round_bf16(acc) : acc);
+        for (int j = 0; j < k; ++j) acc += A16::rnd(A16::rnd(y[((size_t)t * k + j) * h + i]) * A16::val(scores[(size_t)t * k + j]));
+        out[(size_t)t * h + i] = A16::bits(resid ? A16::val(resid[(size_t)t * h + i]) + A16::rnd(acc) : acc);
     }
 }
 }  // namespace
@@ -1009,8 +1018,20 @@ extern "C" int omx_moe_combine_slots(void* out, const float* y_slots, const void
                                      int top_k, omx_stream stream) {
     OMX_REQUIRE(out && y_slots && scores && n_tokens >= 0 && hidden > 0 && top_k >= 1, "omx_moe_combine_slots: bad arguments");
     if (n_tokens == 0) return 0;
-    omx::moe_combine_slots_kernel<<<n_tokens, 256, 0, (hipStream_t)stream>>>((omx::bf16_t*)out, y_slots, (const omx::bf16_t*)scores,
-                                                                             (const omx::bf16_t*)resid, hidden, top_k);
+    omx::moe_combine_slots_kernel<false><<<n_tokens, 256, 0, (hipStream_t)stream>>>((omx::bf16_t*)out, y_slots, (const omx::bf16_t*)scores,
+                                                                                    (const omx::bf16_t*)resid, hidden, top_k);
+    OMX_LAUNCH_CHECK();
+    return 0;
+}
+
+/* the same for a float16 checkpoint (f16 != 0): scores, residual and result float16, every rounding point float16 */
+extern "C" int omx_moe_combine_slots_ex(void* out, const float* y_slots, const void* scores, const void* resid, int n_tokens, int hidden,
+                                        int top_k, int f16, omx_stream stream) {
+    if (!f16) return omx_moe_combine_slots(out, y_slots, scores, resid, n_tokens, hidden, top_k, stream);
+    OMX_REQUIRE(out && y_slots && scores && n_tokens >= 0 && hidden > 0 && top_k >= 1, "omx_moe_combine_slots_ex: bad arguments");
+    if (n_tokens == 0) return 0;
+    omx::moe_combine_slots_kernel<true><<<n_tokens, 256, 0, (hipStream_t)stream>>>((omx::bf16_t*)out, y_slots, (const omx::bf16_t*)scores,
+                                                                                   (const omx::bf16_t*)resid, hidden, top_k);
     OMX_LAUNCH_CHECK();
     return 0;
 }

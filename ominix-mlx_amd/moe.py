@@ -29,8 +29,9 @@ MOE_SIGNATURES = {
                                          c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "omx_moe_combine_slots": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     # the two sharded forms on MLX-packed expert stacks (round 5): partial, x, norm_w, eps, xn, 12 triplet pointers, shapes, shard, format
-    "omx_moe_block_partial_ep_q": (c_int, [c_void_p, c_void_p, c_void_p, ctypes.c_float, c_void_p] + [c_void_p] * 12 + [c_int] * 11 + [c_void_p]),
-    "omx_moe_block_partial_tp_q": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_float] + [c_void_p] * 12 + [c_int] * 9 + [c_void_p]),
+    "omx_moe_block_partial_ep_q": (c_int, [c_void_p, c_void_p, c_void_p, ctypes.c_float, c_void_p] + [c_void_p] * 12 + [c_int] * 12 + [c_void_p]),
+    "omx_moe_block_partial_tp_q": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_float] + [c_void_p] * 12 + [c_int] * 10 + [c_void_p]),
+    "omx_moe_combine_slots_ex": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
 }
 for _n, (_r, _a) in MOE_SIGNATURES.items():
     _f = getattr(lib, _n)

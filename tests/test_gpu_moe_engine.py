@@ -170,15 +170,7 @@ def test_float16_quantized_moe_checkpoint_runs_in_float16(omx, monkeypatch, name
     float16 (2^-10 instead of 2^-7); the bf16-activation computation of the same checkpoint is shown to lie outside it."""
     from ominix_mlx_amd import engine
     cfg, bits, group = CONFIGS[name], 4, 64
-    base = rq.synth_weights(cfg)
-    qw = {}
-    for k, arr in rq.quantize_weights(cfg, base, bits, group).items():
-        if k.endswith((".scales", ".biases")):
-            prefix = k.rsplit(".", 1)[0]
-            w2 = base[prefix + ".weight"].reshape(-1, base[prefix + ".weight"].shape[-1])
-            _, s32, b32 = rc.quantize(w2, group, bits)
-            arr = (s32 if k.endswith(".scales") else b32).astype(np.float16).reshape(arr.shape)
-        qw[k] = arr
+    qw = _f16_triplets(cfg, bits, group)
     prompt = synth.prompt_ids(24, cfg.vocab_size)
     monkeypatch.setenv("OMX_PREFILL_SERIAL", serial_prefill)
     m = _engine(omx, cfg, qw, quantization={"bits": bits, "group_size": group, "scales_dtype": "float16"})
@@ -197,6 +189,77 @@ def test_float16_quantized_moe_checkpoint_runs_in_float16(omx, monkeypatch, name
             break
     ref_bf16 = rq.Qwen3Oracle(cfg, f16w, quant=(bits, group)).generate(prompt, 1, return_logits=True)[1]
     assert np.abs(ref_bf16[0] - ref_logits[0]).max() > bound       # bf16 activations on float16 triplets are a different computation
+
+
+def _f16_triplets(cfg, bits=4, group=64):
+    """a float16 MLX checkpoint of the synthetic model: packed words as quantize() gives them, scales / biases float16 (mlx quantize() works in
+    the model's dtype), norm weights as they are (uploaded as float16 values)"""
+    base = rq.synth_weights(cfg)
+    qw = {}
+    for k, arr in rq.quantize_weights(cfg, base, bits, group).items():
+        if k.endswith((".scales", ".biases")):
+            prefix = k.rsplit(".", 1)[0]
+            w2 = base[prefix + ".weight"].reshape(-1, base[prefix + ".weight"].shape[-1])
+            _, s32, b32 = rc.quantize(w2, group, bits)
+            arr = (s32 if k.endswith(".scales") else b32).astype(np.float16).reshape(arr.shape)
+        qw[k] = arr
+    return qw
+
+
+@pytest.mark.parametrize("mode,name,world", [("ep", "mixtral", 2), ("ep", "mixtral", 4), ("ep", "qwen3_moe", 4), ("tp", "mixtral", 2), ("tp", "wide", 4)])
+def test_float16_packed_moe_checkpoint_on_several_ranks(omx, monkeypatch, mode, name, world):
+    """Round 5: the checkpoint a user of mixtral-mlx actually has -- 4-bit triplets with FLOAT16 scales -- on more than one
+    rank, in float16 end to end like on one: expert parallel (the rank's experts' packed GEMVs with the expert filter, float16 products
+    summed in f32, one all-reduce, the fold with the float16 roundings: bit-identical to the single-GPU float16 engine) and expert
+    tensor parallel (every expert's column slice, f32 slot partials all-reduced, omx_moe_combine_slots_ex in float16: ranks agree bit for
+    bit, logits within the float16 bound of the single GPU).  Prompts of a sharded float16 MoE model go through the decode step."""
+    from ominix_mlx_amd import comm, engine
+    cfg = WIDE if name == "wide" else CONFIGS[name]
+    bits, group_size = 4, 64
+    qw = _f16_triplets(cfg, bits, group_size)
+    quantization = {"bits": bits, "group_size": group_size, "scales_dtype": "float16"}
+    prompt = synth.prompt_ids(20, cfg.vocab_size)
+    monkeypatch.setenv("OMX_PREFILL_SERIAL", "1")      # the sharded float16 engines prefill token-serially: compare like with like
+    single = _engine(omx, cfg, qw, quantization=quantization)
+    want = np.concatenate([[single.prefill(prompt)], single.decode(6)]).astype(np.uint32)
+    want_logits = single.last_logits()
+    single.close()
+    group = comm.LoopbackGroup(world, 1 << 20)
+    models = []
+    for r in range(world):
+        shard = dict(ep_rank=r, ep_size=world) if mode == "ep" else dict(tp_rank=r, tp_size=world)
+        m = engine.Model(hidden_size=cfg.hidden_size, num_hidden_layers=cfg.num_hidden_layers, intermediate_size=cfg.intermediate_size,
+                         num_attention_heads=cfg.num_attention_heads, num_key_value_heads=cfg.num_key_value_heads, head_dim=cfg.head_dim,
+                         vocab_size=cfg.vocab_size, rms_norm_eps=cfg.rms_norm_eps, rope_theta=cfg.rope_theta,
+                         tie_word_embeddings=cfg.tie_word_embeddings, max_context=256, num_experts=cfg.num_experts,
+                         num_experts_per_tok=cfg.num_experts_per_tok, moe_intermediate_size=cfg.moe_intermediate_size,
+                         moe_mode=cfg.moe_mode, norm_topk_prob=cfg.norm_topk_prob, qk_norm=cfg.qk_norm, quantization=quantization, **shard)
+        m.load_weights(qw)
+        m.set_comm(group.rank_comm(r), group.allreduce_fn)
+        models.append(m)
+
+    def run(r):
+        m = models[r]
+        toks = np.concatenate([[m.prefill(prompt)], m.decode(6)]).astype(np.uint32)
+        return toks, m.last_logits()
+
+    outs = comm.run_ranks(world, run, group)
+    for m in models:
+        m.close()
+    group.close()
+    if mode == "ep":
+        for r in range(world):
+            np.testing.assert_array_equal(outs[r][0], want)
+            np.testing.assert_array_equal(outs[r][1], want_logits)
+        return
+    for r in range(1, world):
+        np.testing.assert_array_equal(outs[r][0], outs[0][0])
+    toks, logits = outs[0][0], np.concatenate([o[1] for o in outs])       # vocabulary shards
+    bound = 2.0 ** -10 * float(np.abs(want_logits).max()) * np.sqrt(2 * cfg.num_hidden_layers) * 2
+    first_diff = next((i for i in range(len(want)) if toks[i] != want[i]), len(want))
+    assert first_diff >= 1, "the sharded float16 engines disagree with the single-GPU engine on the token after the prompt"
+    if first_diff == len(want):
+        assert float(np.abs(logits - want_logits).max()) <= bound, f"float16 expert-TP logits off by {np.abs(logits - want_logits).max():.5f} (bound {bound:.5f})"
 
 
 @pytest.mark.parametrize("name,world,quant", [("qwen3_moe", 2, None), ("mixtral", 4, None), ("qwen3_moe_no_renorm_top4", 4, None),

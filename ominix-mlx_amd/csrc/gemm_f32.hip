@@ -142,6 +142,116 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const F32Args g) {
     }
 }
 
+// ---- 32 x 32 tiles, four waves of 16 x 16 on v_mfma_f32_16x16x4_f32 (round 5) -- for the problems above whose 64 x 64 tile grid does not
+//      fill the chip several times over: four times the blocks without a K split (no partial tiles written and re-read, no reduce launch),
+//      16 KiB of LDS and few registers, so several blocks share a CU and one block's staging hides behind another's MFMA chain.
+//      Same operands, same epilogue, K ascending in fours per output (the 32x32x2 form sums in twos: results differ in the last f32 bits).
+constexpr int SM = 32, SN = 32, S_LD = TK + 4;      // rows of 68 floats: 16-byte aligned for the float4 staging stores, fragment reads 2-way at worst
+
+__device__ __forceinline__ void small_load_rows(f32x4 (&r)[2], const float* base, int64_t ld, int row0, int rows, int k0, int kend) {
+    const int rq = threadIdx.x >> 4, kq = (threadIdx.x & 15) * 4;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = row0 + rq + 16 * i, k = k0 + kq;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (row < rows) {
+            const float* p = base + (int64_t)row * ld + k;
+            if (k + 3 < kend && ((reinterpret_cast<uintptr_t>(p) & 15u) == 0)) v = *reinterpret_cast<const f32x4*>(p);
+            else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = (k + e < kend) ? p[e] : 0.f;
+            }
+        }
+        r[i] = v;
+    }
+}
+__device__ __forceinline__ void small_store_rows(float* lds, const f32x4 (&r)[2]) {
+    const int rq = threadIdx.x >> 4, kq = (threadIdx.x & 15) * 4;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) *reinterpret_cast<f32x4*>(lds + (rq + 16 * i) * S_LD + kq) = r[i];
+}
+// B in NN form: [64 k x 32 n], n contiguous in memory; thread t covers k = t / 8 (+ 32 i), n quad t % 8; staged transposed into [n][k]
+__device__ __forceinline__ void small_load_cols(f32x4 (&r)[2], const float* base, int64_t ld, int n0, int ncols, int k0, int kend) {
+    const int kr = threadIdx.x >> 3, nq = (threadIdx.x & 7) * 4;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int k = k0 + kr + 32 * i, n = n0 + nq;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (k < kend) {
+            const float* p = base + (int64_t)k * ld + n;
+            if (n + 3 < ncols && ((reinterpret_cast<uintptr_t>(p) & 15u) == 0)) v = *reinterpret_cast<const f32x4*>(p);
+            else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = (n + e < ncols) ? p[e] : 0.f;
+            }
+        }
+        r[i] = v;
+    }
+}
+__device__ __forceinline__ void small_store_cols(float* lds, const f32x4 (&r)[2]) {
+    const int kr = threadIdx.x >> 3, nq = (threadIdx.x & 7) * 4;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) lds[(nq + e) * S_LD + kr + 32 * i] = r[i][e];
+}
+
+__global__ __launch_bounds__(256) void gemm_f32_small_kernel(const F32Args g) {
+    __shared__ __attribute__((aligned(16))) float As[SM * S_LD];
+    __shared__ __attribute__((aligned(16))) float Bs[SN * S_LD];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave >> 1, wn = wave & 1;                    // the wave's 16 x 16 quadrant
+    const int m0 = blockIdx.y * SM, n0 = blockIdx.x * SN;
+    const int bz = blockIdx.z / g.splits, split = blockIdx.z % g.splits;
+    const float* A = g.a + (int64_t)bz * g.sa;
+    const float* B = g.b + (int64_t)bz * g.sb;
+    const int ktiles = (g.K + TK - 1) / TK, per = (ktiles + g.splits - 1) / g.splits;
+    const int kbeg = split * per * TK, kend = min(g.K, (split + 1) * per * TK);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    f32x4 ra[2], rb[2];
+    if (kbeg < kend) {
+        small_load_rows(ra, A, g.lda, m0, g.M, kbeg, kend);
+        if (g.b_nn) small_load_cols(rb, B, g.ldb, n0, g.N, kbeg, kend);
+        else small_load_rows(rb, B, g.ldb, n0, g.N, kbeg, kend);
+    }
+    for (int k0 = kbeg; k0 < kend; k0 += TK) {
+        __syncthreads();
+        small_store_rows(As, ra);
+        if (g.b_nn) small_store_cols(Bs, rb); else small_store_rows(Bs, rb);
+        __syncthreads();
+        if (k0 + TK < kend) {
+            small_load_rows(ra, A, g.lda, m0, g.M, k0 + TK, kend);
+            if (g.b_nn) small_load_cols(rb, B, g.ldb, n0, g.N, k0 + TK, kend);
+            else small_load_rows(rb, B, g.ldb, n0, g.N, k0 + TK, kend);
+        }
+        // A fragment: row lane & 15, k = lane >> 4 of each group of four; B likewise (column lane & 15)
+        const float* ap = As + (wm * 16 + (lane & 15)) * S_LD + (lane >> 4);
+        const float* bp = Bs + (wn * 16 + (lane & 15)) * S_LD + (lane >> 4);
+        float fa[TK / 4], fb[TK / 4];
+#pragma unroll
+        for (int kk = 0; kk < TK / 4; ++kk) { fa[kk] = ap[4 * kk]; fb[kk] = bp[4 * kk]; }
+#pragma unroll
+        for (int kk = 0; kk < TK / 4; ++kk) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[kk], fb[kk], acc, 0, 0, 0);
+    }
+    // C/D map of the 16 x 16 form: col = lane & 15, row = 4 (lane >> 4) + reg
+    const int col = n0 + wn * 16 + (lane & 15);
+    if (col >= g.N) return;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = m0 + wm * 16 + 4 * (lane >> 4) + r;
+        if (row >= g.M) continue;
+        if (g.splits > 1) {
+            g.partial[(((int64_t)bz * g.splits + split) * g.M + row) * g.N + col] = acc[r];
+        } else {
+            float v = acc[r] * g.alpha;
+            if (g.bias) v += g.bias[col];
+            if (g.relu) v = fmaxf(v, 0.f);
+            if (g.resid) v += g.resid[(int64_t)row * g.ldr + col];
+            g.out[(int64_t)bz * g.sc + (int64_t)row * g.ldc + col] = v;
+        }
+    }
+}
+
 // sums the split-K partials in split order (deterministic) and applies the epilogue.  (Measured alternative: the last block to
 // arrive at a per-tile counter reduces in the same launch -- write-through 4-byte partial stores and the serial re-read made
 // the 30 s pass 14.4 ms instead of 10.1 ms; a second launch of 256 K elements is cheaper.)
@@ -170,7 +280,33 @@ int launch_gemm_f32(const GemmF32& p, hipStream_t s) {
     // K / 2 dependent 64-cycle MFMAs (7.8 us at K = 512) whatever the tile shape, so for 64-tile outputs (out_proj, ffn_down,
     // P . V) the only way to use the other 192 CUs is to cut K.  (Swept on the 30 s pass: a floor of 4 / 8 K tiles per split 10.8 /
     // 11.9 ms, no splitting 15.4 ms, a block budget of 512 / 1024 instead of 256: 10.3 / 10.5 ms -- this rule: 10.2 ms.)
+    // (round 5) a 64 x 64 grid that does not cover the chip at least `kSmallBelow / 256` times over goes to the 32 x 32 kernel: four times the
+    // blocks, several of them per CU.  OMX_F32_SMALL=0 keeps the old choice, =1 takes the small tiles for every shape (tests, A/B).
+    const char* se = getenv("OMX_F32_SMALL");
+    const int small_mode = se ? atoi(se) : -1;
+    constexpr int kSmallBelow = 1024;
+    const bool small = small_mode == 1 || (small_mode != 0 && tiles < kSmallBelow);
     int splits = 1;
+    if (small) {
+        const int sx = (p.N + SN - 1) / SN, sy = (p.M + SM - 1) / SM, stiles = sx * sy * p.batch;
+        const char* be = getenv("OMX_F32_SMALL_BUDGET");
+        const int budget = be ? atoi(be) : 512;
+        while (stiles * splits * 2 <= budget && ktiles / (splits * 2) >= 2) splits *= 2;
+        g.splits = splits;
+        if (splits > 1) {
+            void* ws = nullptr;
+            if (get_workspace_aux(&ws, (size_t)p.batch * splits * p.M * p.N * sizeof(float), s)) return 1;
+            g.partial = (float*)ws;
+        }
+        gemm_f32_small_kernel<<<dim3(sx, sy, p.batch * splits), 256, 0, s>>>(g);
+        OMX_LAUNCH_CHECK();
+        if (splits > 1) {
+            const int64_t total = (int64_t)p.batch * p.M * p.N;
+            gemm_f32_reduce_kernel<<<(unsigned)std::min<int64_t>((total + 255) / 256, 4096), 256, 0, s>>>(g);
+            OMX_LAUNCH_CHECK();
+        }
+        return 0;
+    }
     while (tiles * splits * 2 <= 256 && ktiles / (splits * 2) >= 2) splits *= 2;
     g.splits = splits;
     if (splits > 1) {

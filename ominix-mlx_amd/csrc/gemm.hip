@@ -806,14 +806,18 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(const GemmArgs a) {
     else if (VAR == 5) asm volatile(G5_BODY_D5 G5_OPERANDS);
     else if (VAR == 6) asm volatile(G5_BODY_D6 G5_OPERANDS);
     else if (VAR == 7) asm volatile(G5_BODY_D7 G5_OPERANDS);
+    else if (VAR == 8) { asm volatile(G5_BODY G5_OPERANDS); if (a.M > 0) return; }      // the whole K loop, no epilogue (what the epilogue costs per tile)
 #endif
 #undef G5_OPERANDS
 #undef G5H_OPERANDS
 
-    // ---- epilogue.  Tile (i, j), element e = row (wr * 128 + i * 16 + l16), column (wc * 128 + j * 16 + 4 kg + e) of the 256^2 tile: a lane
-    //      holds runs of four consecutive columns (one 8-byte store each), 64 runs.  Interior tiles (every row and column exists) take
-    //      straight-line code per epilogue kind, chosen by ONE uniform branch; the general form -- every run and element checked, every
-    //      option carried -- is 20 000 instructions a wave would fetch once per tile, and only edge tiles and the rare options take it. ----
+    // ---- epilogue.  Tile (i, j), element e = row (wr * WROWS + i * 16 + l16), column (wc * 128 + j * 16 + 4 kg + e) of the tile: a lane holds
+    //      runs of four consecutive columns, 16 x NBI of them.  Interior tiles (every row and column exists) take straight-line code per
+    //      epilogue kind, chosen by ONE uniform branch (the general form -- every run and element checked, every option carried -- is 20 000
+    //      instructions a wave would fetch once per tile), and they do not store from the accumulator layout: an 8-byte store per run
+    //      writes 16 rows x 32 bytes per instruction, 4 096 write requests per tile that took ~12 us of every tile (tools/gemm_tile_overhead.py:
+    //      the K loop without its epilogue has NO per-tile cost worth the name).  The wave parks its finished 16-bit tile in LDS (its own
+    //      WROWS x 272-byte region of the tile buffers, dead by now) and stores whole rows: 16 bytes per lane, 4 rows x 256 bytes per instruction. ----
 #define ACC(i, j, e) acc[(i) * 2 + ((j) >> 2)][((j) & 3) * 4 + (e)]
     auto runs = [&](auto&& fn) {   // fn(i, j): row block, column block
 #pragma unroll
@@ -823,10 +827,37 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(const GemmArgs a) {
     };
     const bool interior = m0 + TMR <= rows_valid && n0 + 256 <= (SW && seg_act ? 2 * seg_cols : seg_cols) && (seg_ld & 3) == 0;
     const int lrow0 = m0 + wr * WROWS + l16;                // + i * 16
+    constexpr int PARK_LD = 272;                            // bytes per parked row (256 + 16: the 8-byte writes and 16-byte reads 2-way at worst)
+    unsigned char* park = smem + wave * (WROWS * PARK_LD);
+    // a run's two packed words: to the parking row (staged) or straight to memory
+    auto put = [&](auto staged_c, bf16_t* gptr, int i, int j, uint32_t p0, uint32_t p1) {
+        if constexpr (decltype(staged_c)::value) *reinterpret_cast<u32x2*>(park + (i * 16 + l16) * PARK_LD + j * 32 + kg * 8) = u32x2{p0, p1};
+        else *reinterpret_cast<u32x2*>(gptr) = u32x2{p0, p1};
+    };
+    // the parked tile -> memory, `cols` (128 or 64) 16-bit columns per row starting at base (row 0 of the wave's rows)
+    auto flush = [&](bf16_t* base, size_t ld, int cols) {
+        __syncthreads();
+        if (cols == 128) {
+#pragma unroll 8
+            for (int it = 0; it < WROWS / 4; ++it) {
+                const int row = 4 * it + (lane >> 4), c = lane & 15;
+                *reinterpret_cast<u32x4*>(base + (size_t)row * ld + c * 8) = *reinterpret_cast<const u32x4*>(park + row * PARK_LD + c * 16);
+            }
+        } else {
+#pragma unroll 8
+            for (int it = 0; it < WROWS / 8; ++it) {
+                const int row = 8 * it + (lane >> 3), c = lane & 7;
+                *reinterpret_cast<u32x4*>(base + (size_t)row * ld + c * 8) = *reinterpret_cast<const u32x4*>(park + row * PARK_LD + c * 16);
+            }
+        }
+    };
+    auto aligned = [](const void* p, size_t ld) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0 && (ld & 7) == 0; };
     if constexpr (SW) {
         if (seg_act) {
             const int c0 = n0 / 2 + wc * (WCOLS / 2) + 4 * kg;      // + j * 16, j < 4 (gate); the up value of the same output is tile j + 4
-            auto act = [&](auto per_op_c, auto checked_c) {
+            const bool staged = interior && aligned(a.sg.out_act, (size_t)a.sg.ld_act);
+            if (staged) __syncthreads();      // every wave is done with the tile buffers (and the parameter block)
+            auto act = [&](auto per_op_c, auto checked_c, auto staged_c) {
                 constexpr bool per_op = decltype(per_op_c)::value, checked = decltype(checked_c)::value;
                 runs([&](int i, int j) {
                     if (j >= NB / 2) return;
@@ -843,19 +874,25 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(const GemmArgs a) {
                             v[e] = gt / (1.0f + expf(-gt)) * up;
                         }
                     }
-                    *reinterpret_cast<u32x2*>(a.sg.out_act + (size_t)(row_base + lrow) * a.sg.ld_act + col) = u32x2{A16::pack(v[0], v[1]), A16::pack(v[2], v[3])};
+                    put(staged_c, a.sg.out_act + (size_t)(row_base + lrow) * a.sg.ld_act + col, i, j, A16::pack(v[0], v[1]), A16::pack(v[2], v[3]));
                 });
             };
-            if (interior) {
-                if (a.sg.act_mode == 1) act(std::true_type{}, std::false_type{});
-                else act(std::false_type{}, std::false_type{});
+            if (staged) {
+                if (a.sg.act_mode == 1) act(std::true_type{}, std::false_type{}, std::true_type{});
+                else act(std::false_type{}, std::false_type{}, std::true_type{});
+                flush(a.sg.out_act + (size_t)(row_base + m0 + wr * WROWS) * a.sg.ld_act + n0 / 2 + wc * (WCOLS / 2), (size_t)a.sg.ld_act, 64);
+            } else if (interior) {
+                if (a.sg.act_mode == 1) act(std::true_type{}, std::false_type{}, std::false_type{});
+                else act(std::false_type{}, std::false_type{}, std::false_type{});
             } else {
-                if (a.sg.act_mode == 1) act(std::true_type{}, std::true_type{});
-                else act(std::false_type{}, std::true_type{});
+                if (a.sg.act_mode == 1) act(std::true_type{}, std::true_type{}, std::false_type{});
+                else act(std::false_type{}, std::true_type{}, std::false_type{});
             }
         } else {
             const int c0 = n0 + wc * WCOLS + 4 * kg;
-            auto plain = [&](auto bias_c, auto checked_c) {
+            const bool staged = interior && aligned(seg_out, (size_t)seg_ld);
+            if (staged) __syncthreads();
+            auto plain = [&](auto bias_c, auto checked_c, auto staged_c) {
                 constexpr bool BIAS = decltype(bias_c)::value, checked = decltype(checked_c)::value;
                 runs([&](int i, int j) {
                     const int lrow = lrow0 + i * 16, col = c0 + j * 16;
@@ -867,22 +904,28 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(const GemmArgs a) {
                         const u32x2 bb = *reinterpret_cast<const u32x2*>(seg_bias + col);
                         v[0] += A16::lo(bb[0]); v[1] += A16::hi(bb[0]); v[2] += A16::lo(bb[1]); v[3] += A16::hi(bb[1]);
                     }
-                    *reinterpret_cast<u32x2*>(seg_out + (size_t)(row_base + lrow) * seg_ld + col) = u32x2{A16::pack(v[0], v[1]), A16::pack(v[2], v[3])};
+                    put(staged_c, seg_out + (size_t)(row_base + lrow) * seg_ld + col, i, j, A16::pack(v[0], v[1]), A16::pack(v[2], v[3]));
                 });
             };
-            if (interior) {
-                if (seg_bias) plain(std::true_type{}, std::false_type{});
-                else plain(std::false_type{}, std::false_type{});
+            if (staged) {
+                if (seg_bias) plain(std::true_type{}, std::false_type{}, std::true_type{});
+                else plain(std::false_type{}, std::false_type{}, std::true_type{});
+                flush(seg_out + (size_t)(row_base + m0 + wr * WROWS) * seg_ld + n0 + wc * WCOLS, (size_t)seg_ld, 128);
+            } else if (interior) {
+                if (seg_bias) plain(std::true_type{}, std::false_type{}, std::false_type{});
+                else plain(std::false_type{}, std::false_type{}, std::false_type{});
             } else {
-                if (seg_bias) plain(std::true_type{}, std::true_type{});
-                else plain(std::false_type{}, std::true_type{});
+                if (seg_bias) plain(std::true_type{}, std::true_type{}, std::false_type{});
+                else plain(std::false_type{}, std::true_type{}, std::false_type{});
             }
         }
         return;
     }
     const int c0 = n0 + wc * WCOLS + 4 * kg;
     if (interior && !a.relu) {
-        auto plain = [&](auto bias_c, auto mode_c) {
+        const bool staged = aligned(a.out, (size_t)a.N);
+        if (staged) __syncthreads();
+        auto plain = [&](auto bias_c, auto mode_c, auto staged_c) {
             constexpr bool BIAS = decltype(bias_c)::value;
             constexpr int MODE = decltype(mode_c)::value;      // 0 store, 1 residual add (two roundings), 2 gated residual
             runs([&](int i, int j) {
@@ -905,18 +948,22 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(const GemmArgs a) {
                     v[0] = A16::lo(r[0]) + A16::rnd(v[0]); v[1] = A16::hi(r[0]) + A16::rnd(v[1]);
                     v[2] = A16::lo(r[1]) + A16::rnd(v[2]); v[3] = A16::hi(r[1]) + A16::rnd(v[3]);
                 }
-                *reinterpret_cast<u32x2*>(a.out + o) = u32x2{A16::pack(v[0], v[1]), A16::pack(v[2], v[3])};
+                put(staged_c, a.out + o, i, j, A16::pack(v[0], v[1]), A16::pack(v[2], v[3]));
             });
         };
         const int mode = a.gate ? 2 : a.resid ? 1 : 0;
-        if (a.bias) {
-            if (mode == 0) plain(std::true_type{}, std::integral_constant<int, 0>{});
-            else if (mode == 1) plain(std::true_type{}, std::integral_constant<int, 1>{});
-            else plain(std::true_type{}, std::integral_constant<int, 2>{});
+        auto by_mode = [&](auto bias_c, auto staged_c) {
+            if (mode == 0) plain(bias_c, std::integral_constant<int, 0>{}, staged_c);
+            else if (mode == 1) plain(bias_c, std::integral_constant<int, 1>{}, staged_c);
+            else plain(bias_c, std::integral_constant<int, 2>{}, staged_c);
+        };
+        if (staged) {
+            if (a.bias) by_mode(std::true_type{}, std::true_type{});
+            else by_mode(std::false_type{}, std::true_type{});
+            flush(a.out + (size_t)(m0 + wr * WROWS) * a.N + n0 + wc * WCOLS, (size_t)a.N, 128);
         } else {
-            if (mode == 0) plain(std::false_type{}, std::integral_constant<int, 0>{});
-            else if (mode == 1) plain(std::false_type{}, std::integral_constant<int, 1>{});
-            else plain(std::false_type{}, std::integral_constant<int, 2>{});
+            if (a.bias) by_mode(std::true_type{}, std::false_type{});
+            else by_mode(std::false_type{}, std::false_type{});
         }
         return;
     }
@@ -1523,6 +1570,7 @@ int ensure_attr() {
         OMX_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_nt_w4_kernel<false, false, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, w5::SMEM));
         OMX_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_nt_w4_kernel<false, false, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, w5::SMEM));
         OMX_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_nt_w4_kernel<false, false, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, w5::SMEM));
+        OMX_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_nt_w4_kernel<false, false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, w5::SMEM));
 #endif
 #ifdef OMX_EXPERIMENTS
         OMX_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_bf16_nt_asm_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, w4::SMEM));
@@ -1715,6 +1763,7 @@ static int launch_gemm_impl(bf16_t* out, const bf16_t* x, const bf16_t* w, const
                 else if (var == 5) gemm_nt_w4_kernel<false, false, 5><<<blocks, 256, w5::SMEM, s>>>(a);
                 else if (var == 6) gemm_nt_w4_kernel<false, false, 6><<<blocks, 256, w5::SMEM, s>>>(a);
                 else if (var == 7) gemm_nt_w4_kernel<false, false, 7><<<blocks, 256, w5::SMEM, s>>>(a);
+                else if (var == 8) gemm_nt_w4_kernel<false, false, 8><<<blocks, 256, w5::SMEM, s>>>(a);
                 else
 #endif
                 gemm_nt_w4_kernel<false, false><<<blocks, 256, w5::SMEM, s>>>(a);

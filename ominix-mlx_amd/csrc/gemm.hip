@@ -54,6 +54,8 @@ struct GemmArgs {
     float* split_ws;      // ring kernel, gridDim.y > 1: f32 partial tiles [tile][split][64 x 64]; 256^2 kernel with ksplit > 1: [tile][split][256 x 256]
     unsigned* split_cnt;  // [tiles] arrival counters (zero between launches)
     int ksplit;           // 256^2 kernel (plain form): K halves of a tile go to different blocks (a grid of <= 128 tiles covers the chip)
+    int stagger;          // four-wave kernel: sleeps of ~512 clocks per XCD slot before the first round's tiles start (OMX_GEMM_STAGGER; 0 = none)
+    int no_park;          // four-wave kernel: store from the accumulator layout even where whole rows could be stored (OMX_GEMM_W4_PARK=0: the A/B)
 };
 
 // one 16-B chunk per lane per wave-instruction, 4 instructions per operand tile: row pointers of the 4
@@ -675,6 +677,10 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(const GemmArgs a) {
     constexpr int WCOLS = 16 * NB;                 // columns per wave
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
+    if (a.stagger > 0 && blockIdx.x < 256) {      // (experiment: the first round's tiles start spread out, so that later rounds do not all write at once)
+        const int n = __builtin_amdgcn_readfirstlane((int)((blockIdx.x >> 3) & 31u) * a.stagger);
+        for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(8);
+    }
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wr = wave >> 1, wc = wave & 1, l16 = lane & 15, kg = lane >> 4;
     // tile order: the 256^2 kernel's (XCD-aware remap, 8 x 4 patches per XCD)
@@ -770,9 +776,18 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(const GemmArgs a) {
     const bf16_t* xbase = a.x;
     const bool up_rows = (wave & 1) != 0;          // (a wave's W pieces are tile rows [wave * 64, + 64): the second half of a wave column)
     const bf16_t* wbase = (SW && seg_act ? (up_rows ? a.sg.w_up : a.sg.w_gate) : seg_w) + w_off;
-    const int ntrips = (a.K / 64 - 2) / 2;
-    const unsigned ldsx = (unsigned)(uintptr_t)smem + (unsigned)wave * (unsigned)(XP * 1024);                          // this wave's X pieces
-    const unsigned ldsww = (unsigned)(uintptr_t)smem + (unsigned)(2 * TMR * 128) + (unsigned)wave * 8192u;            // ... and W pieces
+    const int ntrips = __builtin_amdgcn_readfirstlane((a.K / 64 - 2) / 2);
+    const unsigned ldsx = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)smem + (unsigned)wave * (unsigned)(XP * 1024));                   // this wave's X pieces
+    const unsigned ldsww = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)smem + (unsigned)(2 * TMR * 128) + (unsigned)wave * 8192u);     // ... and W pieces
+    {   // (the asm takes these in SGPRs; values hipcc cannot prove uniform would be handed over in VGPRs)
+        auto uni = [](const bf16_t* p) {
+            const uint64_t v = (uint64_t)(uintptr_t)p;
+            const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi2 = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+            return reinterpret_cast<const bf16_t*>((uintptr_t)(((uint64_t)hi2 << 32) | lo));
+        };
+        xbase = uni(xbase);
+        wbase = uni(wbase);
+    }
 
     f32x16 acc[NBI * 2];      // acc[o] = a[16 o : 16 o + 15]: tile (i, j) of the wave's NBI x 8 is acc[i * 2 + (j >> 2)][(j & 3) * 4 + e]
 #pragma unroll
@@ -851,7 +866,7 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(const GemmArgs a) {
             }
         }
     };
-    auto aligned = [](const void* p, size_t ld) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0 && (ld & 7) == 0; };
+    auto aligned = [&](const void* p, size_t ld) { return !a.no_park && (reinterpret_cast<uintptr_t>(p) & 15u) == 0 && (ld & 7) == 0; };
     if constexpr (SW) {
         if (seg_act) {
             const int c0 = n0 / 2 + wc * (WCOLS / 2) + 4 * kg;      // + j * 16, j < 4 (gate); the up value of the same output is tile j + 4
@@ -1695,6 +1710,7 @@ static int launch_gemm_impl(bf16_t* out, const bf16_t* x, const bf16_t* w, const
                             const bf16_t* gate, int M, int N, int K, hipStream_t s, int relu = 0) {
     OMX_REQUIRE(M > 0 && N > 0 && K > 0, "gemm: bad shape M=%d N=%d K=%d", M, N, K);
     GemmArgs a = {x, w, bias, resid, gate, out, M, N, K, (M + BM - 1) / BM, (N + BN - 1) / BN, {}, relu};
+    { const char* se = getenv("OMX_GEMM_STAGGER"); a.stagger = se ? atoi(se) : 0; const char* pe = getenv("OMX_GEMM_W4_PARK"); a.no_park = pe && pe[0] == '0'; }
     const bool fast = (K % BK == 0) && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w)) & 15u) == 0;
     {   // a handful of rows: stream the weights once (gemv_rows.hip) instead of a matrix-core tile grid that is mostly padding;
         // OMX_GEMV_ROWS=0 keeps the GEMM kernels
@@ -1865,6 +1881,7 @@ int launch_gemm_bf16_segmented(const bf16_t* x, int M, int K, const GemmSegs& se
     OMX_REQUIRE(!segs.pre_norm_w, "segmented gemm: an in-launch RMSNorm exists on the weight-streaming route only (gemv_rows_takes_norm)");
     if (ensure_attr()) return 1;
     GemmArgs a = {};
+    { const char* se = getenv("OMX_GEMM_STAGGER"); a.stagger = se ? atoi(se) : 0; const char* pe = getenv("OMX_GEMM_W4_PARK"); a.no_park = pe && pe[0] == '0'; }
     a.x = x; a.M = M; a.K = K;
     a.sg = segs;
     if (!g_gemm_f16 && ((M + 255) / 256) * seg_tiles(segs) < 160) {   // small problem, plain segments: one grid of 64^2 ring-kernel tiles
@@ -1929,6 +1946,7 @@ int launch_gemm_bf16_segmented_grouped(const bf16_t* x, int max_rows, int K, con
     OMX_REQUIRE((align & 15u) == 0 && (g.w_estride * 2) % 16 == 0, "grouped segmented gemm: operands must be 16-byte aligned");
     if (ensure_attr()) return 1;
     GemmArgs a = {};
+    { const char* se = getenv("OMX_GEMM_STAGGER"); a.stagger = se ? atoi(se) : 0; const char* pe = getenv("OMX_GEMM_W4_PARK"); a.no_park = pe && pe[0] == '0'; }
     a.x = x; a.M = max_rows; a.K = K;
     a.g = g;
     a.sg = segs;
@@ -1968,6 +1986,7 @@ int launch_conv3x3_implicit(bf16_t* out, const bf16_t* padded, const bf16_t* w, 
                 "implicit conv: null or misaligned operand");
     if (ensure_attr()) return 1;
     GemmArgs a = {};
+    { const char* se = getenv("OMX_GEMM_STAGGER"); a.stagger = se ? atoi(se) : 0; const char* pe = getenv("OMX_GEMM_W4_PARK"); a.no_park = pe && pe[0] == '0'; }
     a.x = padded; a.M = H * W; a.K = 9 * C; a.N = Cout;
     a.sg.n_plain = 1;
     a.sg.plain[0] = {w, bias, out, Cout, Cout, 0};
@@ -2037,6 +2056,7 @@ int launch_gemm_bf16_grouped(bf16_t* out, const bf16_t* x, const bf16_t* w, int 
     OMX_REQUIRE(K % BK == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w)) & 15u) == 0,
                 "grouped gemm: K=%d must be a multiple of %d and operands 16-byte aligned", K, BK);
     GemmArgs a = {x, w, nullptr, nullptr, nullptr, out, max_rows, N, K, max_tiles, (N + BN - 1) / BN, g, 0};
+    { const char* se = getenv("OMX_GEMM_STAGGER"); a.stagger = se ? atoi(se) : 0; const char* pe = getenv("OMX_GEMM_W4_PARK"); a.no_park = pe && pe[0] == '0'; }
     if (ensure_attr()) return 1;
     gemm_bf16_nt_kernel<true><<<max_tiles * a.grid_n, NTHREADS, 4 * TILE_BYTES, s>>>(a);
     OMX_LAUNCH_CHECK();

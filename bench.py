@@ -665,6 +665,7 @@ def main():
         if world == 1 and not moe and keep is None and not cfg.get("quantization"):
             try:
                 n_po = 16
+                r0 = model.per_op_route(prompt, 1)        # (first call: the handle route's buffers are allocated here -- 50 ms .. 0.5 s by box)
                 r = model.per_op_route(prompt, n_po)
                 eng = [int(first)] + [int(t) for t in warm_toks[:n_po]]
                 got = [int(t) for t in r["tokens"]]
@@ -673,7 +674,8 @@ def main():
                 per_op = {"metric": "decode_tokens_per_sec_per_op_route", "value": round(1e3 / r["ms_per_token"], 2), "unit": "tokens/s",
                           "ms_per_token_host_wall": round(r["ms_per_token"], 3), "mlx_calls_per_token": round(r["calls_per_token"], 1),
                           "host_us_per_mlx_call": round(r["ms_per_token"] * 1e3 / r["calls_per_token"], 2),
-                          "prefill_ms_host_wall": round(r["prefill_ms"], 1), "tokens_timed": n_po, "context": args.prompt,
+                          "prefill_ms_host_wall": round(r["prefill_ms"], 1), "prefill_ms_host_wall_first_call": round(r0["prefill_ms"], 1),
+                          "tokens_timed": n_po, "context": args.prompt,
                           "first_tokens": got[:5], "leading_tokens_equal_to_engine": f"{agree} of {n_cmp}",
                           "vs_engine": round((1e3 / r["ms_per_token"]) / tok_s, 3),
                           "note": "qwen3-mlx Model::forward + Generate::next replayed call for call through the mlx-c handle ABI by native code on the "

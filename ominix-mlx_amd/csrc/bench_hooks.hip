@@ -129,6 +129,15 @@ extern "C" int omx_bench_gemm(int M, int N, int K, int n_copies, int iters, floa
     for (int i = 0; i < n_copies; ++i) {
         OMX_HIP_CHECK(hipMalloc(&w[i], (size_t)N * K * 2));
         OMX_HIP_CHECK(hipMalloc(&x[i], (size_t)M * K * 2));
+        // OMX_BENCH_GEMM_DATA=zero | one: constant operands -- what the same instruction stream costs when no operand bit toggles (the chip's
+        // power limit, not the kernel, sets the pace of a full-chip GEMM: EXPERIMENTS.md R5-4)
+        const char* de = getenv("OMX_BENCH_GEMM_DATA");
+        if (de && (de[0] == 'z' || de[0] == 'o')) {
+            const int v = de[0] == 'z' ? 0 : 0x3f;      // bytes 0x3f3f = bf16 0.746
+            OMX_HIP_CHECK(hipMemset(w[i], v, (size_t)N * K * 2));
+            OMX_HIP_CHECK(hipMemset(x[i], v, (size_t)M * K * 2));
+            continue;
+        }
         if (omx_fill_uniform(w[i], (size_t)N * K, 100 + i, 0.05f, 0.f, OMX_BFLOAT16, nullptr)) return 1;
         if (omx_fill_uniform(x[i], (size_t)M * K, 200 + i, 1.0f, 0.f, OMX_BFLOAT16, nullptr)) return 1;
     }

@@ -13,7 +13,9 @@ enum { NORM_RMS = 0, NORM_LAYER = 1, NORM_MODULATE = 2 };
 
 // MODE NORM_MODULATE: w = scale[B,H], b = shift[B,H] broadcast over S rows per batch:
 //   out = (1 + scale) * LN(x) + shift
-template <int DT, int MODE, bool VEC>
+// KEEP: 16-byte vectors a lane holds of a row that is read once (8: rows up to 4096 bf16 / 2048 f32 elements; 6: up to 3072 / 1536 -- the
+// DiT's hidden size: 48 instead of 64 row registers put a fifth wave on every SIMD, and 4 608 rows then fit the chip in one round)
+template <int DT, int MODE, bool VEC, int KEEP = 8>
 __global__ __launch_bounds__(256) void rownorm_kernel(typename Elem<DT>::T* __restrict__ out,
                                                       const typename Elem<DT>::T* __restrict__ x,
                                                       const typename Elem<DT>::T* __restrict__ w,
@@ -36,7 +38,6 @@ __global__ __launch_bounds__(256) void rownorm_kernel(typename Elem<DT>::T* __re
     // rows that fit a lane's registers (<= KEEP 16-byte vectors per lane: 4096 bf16 / 2048 f32 elements): ONE read of the row -- the
     // three passes of a LayerNorm (mean, variance, output) were three dependent global round trips, 26.6 us for the DiT's
     // [4608, 3072] modulate (56 MB: 2.1 TB/s).  Same sums in the same order: bit-identical.
-    constexpr int KEEP = 8;
     if (VEC && keep && dim <= KEEP * 64 * N) {
         float v[KEEP][N];
 #pragma unroll
@@ -175,7 +176,10 @@ static int launch_rownorm(void* out, const void* x, const void* w, const void* b
     const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
     const char* ke = getenv("OMX_NORM_KEEP");      // 0: the three-pass form (A/B)
     const bool keep = !(ke && ke[0] == '0');
-    if (vec)
+    if (vec && dim <= 6 * 64 * Vec16<DT>::N)
+        rownorm_kernel<DT, MODE, true, 6><<<grid, block, 0, s>>>((T*)out, (const T*)x, (const T*)w, (const T*)b, rows, dim,
+                                                                 eps, rows_per_batch, keep);
+    else if (vec)
         rownorm_kernel<DT, MODE, true><<<grid, block, 0, s>>>((T*)out, (const T*)x, (const T*)w, (const T*)b, rows, dim,
                                                               eps, rows_per_batch, keep);
     else

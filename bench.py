@@ -138,6 +138,9 @@ def collective_plan(args, world):
 # otherwise go to RCCL -- runs on the peer communicator (csrc/peer_allreduce.hip: one-shot below 32 KB, two-shot above), whose inboxes
 # and stages are HIP IPC mappings whether the peer sits on another GPU or on this one.  Not a measurement: a line from this mode says so.
 ONE_GPU = os.environ.get("OMX_BENCH_ONE_GPU") == "1"
+if ONE_GPU:
+    # N ranks share the CUs: the large-path all-reduce kernels of the ranks that wait must not sit on every CU the last rank's GEMMs need
+    os.environ.setdefault("OMX_PEER_LARGE_BLOCKS", str(max(8, 64 // max(1, int(os.environ.get("WORLD_SIZE", "1"))))))
 # where the scalars of the host-side reductions (rank status, MAX of the windows' times) live: on the device under the nccl backend;
 # under gloo (the one-GPU pre-flight) on the host -- a CUDA tensor reduced through gloo's staging path leaves the process in a state in
 # which every later kernel of BOTH ranks runs 3.3x slower (tools/two_rank_windows.py TRW_MODE=cuda_tensor: 12.1 against 3.67 ms per
@@ -591,6 +594,9 @@ def main():
         dist.barrier()
     first2 = model.prefill(prompt)
     prefill_steady_ms = model.last_prefill_ms()
+    if dist is not None and peer is not None and peer.aborted():
+        raise SystemExit(f"rank {rank}: the peer communicator gave up waiting for a rank during the prompt passes (bounded wait expired: its "
+                         f"result was voided) -- first {int(first)}, second {int(first2)}")
     if int(first2) != int(first):
         raise SystemExit(f"rank {rank}: the second prefill of the same prompt sampled {int(first2)}, the first {int(first)}")
     warm_toks = model.decode(args.warmup) if args.warmup else []

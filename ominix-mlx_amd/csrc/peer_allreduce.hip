@@ -56,6 +56,17 @@ struct PeerComm {
 
 constexpr int kNcclBfloat16 = 9;
 constexpr int kLargeBlocks = 128;              // all of them wait on each other: far below one workgroup per CU
+// OMX_PEER_LARGE_BLOCKS=n (8..128): fewer blocks per large-path launch.  Only for several ranks on ONE GPU (bench.py OMX_BENCH_ONE_GPU=1 sets
+// it): there the waiting blocks of N - 1 ranks sit on the CUs the N-th rank's matrix-core kernels need whole (a four- or eight-wave GEMM
+// workgroup takes a CU's entire register file), and at N = 8 the bounded waits expired.  On a node every rank has its own GPU.
+static int large_blocks() {
+    static const int v = [] {
+        const char* e = getenv("OMX_PEER_LARGE_BLOCKS");
+        const int n = e ? atoi(e) : kLargeBlocks;
+        return n < 8 ? 8 : n > kLargeBlocks ? kLargeBlocks : n;
+    }();
+    return v;
+}
 
 struct PeerLargeArgs {
     const PeerDev* dev;
@@ -407,8 +418,8 @@ int omx_peer_allreduce(const void* send, void* recv, size_t count, int dtype, in
                 a.send = static_cast<const u32x4*>(send) + v0; a.recv = static_cast<u32x4*>(recv) + v0;
                 a.nvec = std::min(chunk_vec, nvec - v0);
                 a.slice_vec = (a.nvec + c->world - 1) / c->world;
-                if (bf16sum) peer_allreduce_large_kernel<true><<<kLargeBlocks, 256, 0, stream>>>(a);
-                else peer_allreduce_large_kernel<false><<<kLargeBlocks, 256, 0, stream>>>(a);
+                if (bf16sum) peer_allreduce_large_kernel<true><<<large_blocks(), 256, 0, stream>>>(a);
+                else peer_allreduce_large_kernel<false><<<large_blocks(), 256, 0, stream>>>(a);
                 if (hipGetLastError() != hipSuccess) return 1;
                 ++c->n_large;
             }
@@ -479,7 +490,7 @@ int omx_peer_moe_combine(void* out, const void* resid, const omx_moe_ep_slots* s
     a.y = static_cast<const bf16_t*>(sl->y); a.pos_of_slot = sl->pos_of_slot; a.inds = sl->inds; a.scores = static_cast<const bf16_t*>(sl->scores);
     a.resid = static_cast<const bf16_t*>(resid); a.out = static_cast<bf16_t*>(out);
     a.T = T; a.hidden = hidden; a.k = top_k; a.e_lo = e_lo; a.e_n = e_n; a.chunk = chunk;
-    peer_moe_combine_kernel<<<kLargeBlocks, 256, 0, (hipStream_t)stream_>>>(a);
+    peer_moe_combine_kernel<<<large_blocks(), 256, 0, (hipStream_t)stream_>>>(a);
     ++c->n_moe;
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }

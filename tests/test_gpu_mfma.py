@@ -124,6 +124,34 @@ def test_linear_gemm_four_wave_kernel(omx, monkeypatch, M, N, K, f16, tile_rows)
     np.testing.assert_array_equal(got, eight)       # the same instruction over the same k order per output element
 
 
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_linear_gemm_four_wave_kernel_random_shapes(omx, monkeypatch, seed):
+    """Random shapes (ragged M and N, K any multiple of 128, bias / no bias, both tile heights): the four-wave kernel must equal the eight-wave
+    kernel bit for bit -- edge tiles take the checked epilogue, interior tiles the parked row stores, and a launch mixes both."""
+    T = omx.ops.Tensor
+    g = np.random.default_rng(100 + seed)
+    for case in range(6):
+        M = int(g.integers(1, 1200))
+        N = int(g.integers(1, 300)) * 4
+        K = int(g.integers(1, 12)) * 128
+        rows128 = bool(case & 1)
+        x = rc.bf16_round(g.standard_normal((M, K)).astype(np.float32))
+        w = rc.bf16_round((g.standard_normal((N, K)) * 0.05).astype(np.float32))
+        b = rc.bf16_round(g.standard_normal(N).astype(np.float32)) if case % 3 else None
+        xt, wt, bt = T.from_numpy(x), T.from_numpy(w), (T.from_numpy(b) if b is not None else None)
+        if rows128:
+            monkeypatch.setenv("OMX_GEMM_ROWS128", "1")
+            monkeypatch.delenv("OMX_GEMM_TILE", raising=False)
+        else:
+            monkeypatch.setenv("OMX_GEMM_TILE", "256")
+            monkeypatch.delenv("OMX_GEMM_ROWS128", raising=False)
+        monkeypatch.setenv("OMX_GEMM_W4", "1")
+        got = omx.ops.linear(xt, wt, bt).numpy()
+        monkeypatch.setenv("OMX_GEMM_W4", "0")
+        want = omx.ops.linear(xt, wt, bt).numpy()
+        np.testing.assert_array_equal(got, want, err_msg=f"M={M} N={N} K={K} rows128={rows128} bias={b is not None}")
+
+
 @pytest.mark.parametrize("M,N,K", [
     (128, 256, 64),          # one tile, one K step (prologue only)
     (300, 520, 128),         # ragged M and N tails, two K steps

@@ -444,6 +444,8 @@ def generate(thr, diag=()):
 
 def main():
     out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "ominix-mlx_amd", "csrc")
+    if "--out" in sys.argv:      # (tests/test_generated_sources.py regenerates into a scratch directory and compares with the tree)
+        out_dir = sys.argv[sys.argv.index("--out") + 1]
     variants = [(THR, (), "attn_flash4_body.inc"), (0.0, (), "attn_flash4_body_thr0.inc")]
     if "--diag" in sys.argv:     # timing-only builds for OMX_ATTN_W4_VAR=2..5 (attn_flash4.hip compiles them under -DOMX_F4_DIAG)
         variants += [(THR, ("nodma",), "attn_flash4_body_d2.inc"), (THR, ("novalu",), "attn_flash4_body_d3.inc"),

@@ -263,6 +263,8 @@ def emit(f, name, lines):
 
 def main():
     out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "ominix-mlx_amd", "csrc")
+    if "--out" in sys.argv:      # (tests/test_generated_sources.py regenerates into a scratch directory and compares with the tree)
+        out_dir = sys.argv[sys.argv.index("--out") + 1]
     with open(os.path.join(out_dir, "gemm5_body.inc"), "w") as f:
         lines = generate("v_mfma_f32_16x16x32_bf16")
         half = generate("v_mfma_f32_16x16x32_bf16", 128)

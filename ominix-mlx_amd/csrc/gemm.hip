@@ -789,6 +789,7 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(const GemmArgs a) {
         wbase = uni(wbase);
     }
 
+    const int wave_odd = __builtin_amdgcn_readfirstlane(wave & 1);     // (the generator's two-schedule form branches on it; unused otherwise)
     f32x16 acc[NBI * 2];      // acc[o] = a[16 o : 16 o + 15]: tile (i, j) of the wave's NBI x 8 is acc[i * 2 + (j >> 2)][(j & 3) * 4 + e]
 #pragma unroll
     for (int t = 0; t < NBI * 2; ++t)
@@ -798,12 +799,12 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(const GemmArgs a) {
     : "+{a[0:15]}"(acc[0]), "+{a[16:31]}"(acc[1]), "+{a[32:47]}"(acc[2]), "+{a[48:63]}"(acc[3]), "+{a[64:79]}"(acc[4]), "+{a[80:95]}"(acc[5]),        \
       "+{a[96:111]}"(acc[6]), "+{a[112:127]}"(acc[7]), "+{a[128:143]}"(acc[8]), "+{a[144:159]}"(acc[9]), "+{a[160:175]}"(acc[10]),                    \
       "+{a[176:191]}"(acc[11]), "+{a[192:207]}"(acc[12]), "+{a[208:223]}"(acc[13]), "+{a[224:239]}"(acc[14]), "+{a[240:255]}"(acc[15])               \
-    : "v"(param_addr), "s"(xbase), "s"(wbase), "s"(ntrips), "s"(ldsx), "s"(ldsww)                                                                   \
+    : "v"(param_addr), "s"(xbase), "s"(wbase), "s"(ntrips), "s"(ldsx), "s"(ldsww), "s"(wave_odd)                                                    \
     : G5_CLOBBERS
 #define G5H_OPERANDS                                                                                                                                 \
     : "+{a[0:15]}"(acc[0]), "+{a[16:31]}"(acc[1]), "+{a[32:47]}"(acc[2]), "+{a[48:63]}"(acc[3]), "+{a[64:79]}"(acc[4]), "+{a[80:95]}"(acc[5]),        \
       "+{a[96:111]}"(acc[6]), "+{a[112:127]}"(acc[7])                                                                                                \
-    : "v"(param_addr), "s"(xbase), "s"(wbase), "s"(ntrips), "s"(ldsx), "s"(ldsww)                                                                   \
+    : "v"(param_addr), "s"(xbase), "s"(wbase), "s"(ntrips), "s"(ldsx), "s"(ldsww), "s"(wave_odd)                                                    \
     : G5_CLOBBERS
     if constexpr (TMR == 128) {
         if constexpr (F16) asm volatile(G5H_BODY_F16 G5H_OPERANDS);

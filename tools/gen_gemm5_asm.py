@@ -47,12 +47,13 @@ class Geo:
         self.G = self.NI * NJ * 2            # MFMAs per K step and wave
         self.st = 2 if rows == 256 else 1    # spacing of the sparse filler runs
         n = self.NI * NJ * 4 // 16           # accumulator operands
-        self.P_ADDR, self.XBASE, self.WBASE, self.NLOOP, self.LDSX, self.LDSWW = ["%%%d" % (n + k) for k in range(6)]
+        self.P_ADDR, self.XBASE, self.WBASE, self.NLOOP, self.LDSX, self.LDSWW, self.WSEL = ["%%%d" % (n + k) for k in range(7)]
         self.XDMA = [PRM + k for k in range(self.XP)]
         self.WDMA = [PRM + self.XP + k for k in range(8)]
         self.XFR = [PRM + self.XP + 8 + k for k in range(2)]      # by k half
         self.WFR = [PRM + self.XP + 10 + k for k in range(2)]
         self.NPRM = self.XP + 12
+TWO_SCHEDULES = os.environ.get("G5_TWO", "0") == "1"     # odd waves on a schedule shifted by one gap (operand: wave & 1)
 DENSE = os.environ.get("G5_DENSE", "0") == "1"
 ONE_BARRIER = os.environ.get("G5_ONE_BARRIER", "0") == "1"   # one barrier per step for the refill of both operands instead of two
 W_OUTER = os.environ.get("G5_ORDER", "ij") == "ji"   # the MFMA order inside a k half: column block outer (srcA = the W fragment stays), row block inner
@@ -124,7 +125,7 @@ def read_frag(g, buf, mat, kh, idx):
                                                        buf * (32768 if mat else q.XB) + idx * 2048))
 
 
-def step(g, buf, fr, loads, next_reads, vm):
+def step(g, buf, fr, loads, next_reads, vm, shift=0):
     """one K step out of buffer `buf`.  fr: {(mat, kh, idx): LDS-op id} of the first-half fragments already requested; returns the same for the
     next step.  loads: the DMA of step t + 2; next_reads: the first-half fragments of t + 1; vm: the vmcnt of the landing wait."""
     q = g.geo
@@ -139,7 +140,7 @@ def step(g, buf, fr, loads, next_reads, vm):
     # filler plan: gap -> list of actions
     plan = {}
     def at(gap, act):
-        plan.setdefault(gap, []).append(act)
+        plan.setdefault(gap + shift, []).append(act)      # (shift: the odd waves' schedule, one gap behind the even waves')
     xs = 1 if DENSE else st              # spacing of the first run of reads (dense: the X buffer is released, and refilled, ~10 gaps earlier)
     for k in range(NI):
         at(k * xs, ("read", second_x[k]))
@@ -153,7 +154,7 @@ def step(g, buf, fr, loads, next_reads, vm):
         pieces = [("dma", 0, k) for k in range(q.XP)] + [("dma", 1, k) for k in range(8)]
         for k, act in enumerate(pieces):
             at(b1 + st + k * st, act)
-        assert b1 + st + (len(pieces) - 1) * st < G // 2 + 2
+        assert b1 + st + (len(pieces) - 1) * st + shift < G // 2 + 2 + shift
     elif loads:
         b1 = (NI - 1) * xs + 3 * st
         at(b1, ("bar",))
@@ -170,7 +171,7 @@ def step(g, buf, fr, loads, next_reads, vm):
         at(b2, ("bar",))
         for k in range(8):
             at(b2 + st + k * st, ("dma", 1, k))
-        assert b2 + st + 7 * st < G // 2 + 2, "the step's DMA must be issued before the landing wait (vmcnt counts on it)"
+        assert b2 + st + 7 * st + shift < G // 2 + 2 + shift, "the step's DMA must be issued before the landing wait (vmcnt counts on it)"
     else:
         for k in range(NJ):
             at(NI * xs + k * st, ("read", second_w[k]))
@@ -179,7 +180,7 @@ def step(g, buf, fr, loads, next_reads, vm):
         at(land, ("land", vm))
         for k, f in enumerate(first):
             at(land + k * st, ("readnext", f))
-        assert land + (len(first) - 1) * st < G
+        assert land + (len(first) - 1) * st + shift < G
     nxt = {}
     xdma = wdma = 0
     for gap in range(G):
@@ -238,17 +239,30 @@ def generate(mfma, rows=256, diag=()):
         fr[(1, 0, idx)] = read_frag(g, 0, 1, 0, idx)
     g.lds_wait_all()
     ready = {k: -1 for k in fr}      # (every step ends with lgkmcnt(0): the first-half fragments are in registers at its start)
-    g.e("s_cmp_eq_u32 s%d, 0" % S_LOOP)
-    g.e("s_cbranch_scc1 G5_tail_%=")
-    g.e("G5_loop_%=:")
-    step(g, 0, ready, True, True, per_step)
-    step(g, 1, ready, True, True, per_step)
-    g.e("s_sub_u32 s%d, s%d, 1" % (S_LOOP, S_LOOP))
-    g.e("s_cmp_lg_u32 s%d, 0" % S_LOOP)
-    g.e("s_cbranch_scc1 G5_loop_%=")
-    g.e("G5_tail_%=:")
-    step(g, 0, ready, False, True, 0)
-    step(g, 1, ready, False, False, 0)
+    def loops(tag, shift):
+        g.e("s_cmp_eq_u32 s%d, 0" % S_LOOP)
+        g.e("s_cbranch_scc1 G5_tail%s_%%=" % tag)
+        g.e("G5_loop%s_%%=:" % tag)
+        step(g, 0, ready, True, True, per_step, shift)
+        step(g, 1, ready, True, True, per_step, shift)
+        g.e("s_sub_u32 s%d, s%d, 1" % (S_LOOP, S_LOOP))
+        g.e("s_cmp_lg_u32 s%d, 0" % S_LOOP)
+        g.e("s_cbranch_scc1 G5_loop%s_%%=" % tag)
+        g.e("G5_tail%s_%%=:" % tag)
+        step(g, 0, ready, False, True, 0, shift)
+        step(g, 1, ready, False, False, 0, shift)
+    if TWO_SCHEDULES:
+        # odd waves run the same step with every filler one gap later: the four waves of a workgroup execute in lockstep between barriers,
+        # and with ONE schedule their LDS reads and DMA issues land in the same cycles
+        g.e("s_cmp_eq_u32 %s, 0" % q.WSEL)
+        g.e("s_cbranch_scc0 G5_odd_%=")
+        loops("", 0)
+        g.e("s_branch G5_done_%=")
+        g.e("G5_odd_%=:")
+        loops("B", 1)
+        g.e("G5_done_%=:")
+    else:
+        loops("", 0)
     g += ["s_nop 7", "s_nop 7", "s_nop 7"]      # (hipcc reads the accumulators next and does not know they come from MFMAs)
     g.e("s_mov_b32 m0, s%d" % S_M0)
     return g

@@ -341,11 +341,18 @@ extern "C" int omx_bench_qgemv(int N, int K, int bits, int pro, int epi, int n_c
     hipEvent_t e0, e1;
     OMX_HIP_CHECK(hipEventCreate(&e0));
     OMX_HIP_CHECK(hipEventCreate(&e1));
+    std::vector<uint32_t*> tiles(w.size(), nullptr);       // the matrix-core kernel's form of the same matrices (qgemv_mfma.hip)
+    if (qgemv4m_shape_ok(K, 64, bits))
+        for (size_t i = 0; i < w.size(); ++i) {
+            OMX_HIP_CHECK(hipMalloc((void**)&tiles[i], qgemv4m_tile_words(N, K) * 4));
+            if (launch_qgemv4m_repack(tiles[i], w[i], sc[i], bi[i], N, K, nullptr)) return 1;
+        }
     auto run = [&](int i) {
         QGemvArgs a = {};
         const int c = (i % n_copies) * mats;
         a.m[0] = QMat{w[c], sc[c], bi[c], N};
-        if (mats == 2) a.m[1] = QMat{w[c + 1], sc[c + 1], bi[c + 1], N};
+        a.m[0].tiles = tiles[c];
+        if (mats == 2) { a.m[1] = QMat{w[c + 1], sc[c + 1], bi[c + 1], N}; a.m[1].tiles = tiles[c + 1]; }
         a.N = N; a.K = K; a.group = 64;
         a.x = (const bf16_t*)x; a.norm_w = (const bf16_t*)nw; a.eps = 1e-6f; a.resid = (const bf16_t*)resid;
         a.out = (bf16_t*)out; a.argmax_slot = (unsigned long long*)slot;
@@ -363,11 +370,45 @@ extern "C" int omx_bench_qgemv(int N, int K, int bits, int pro, int epi, int n_c
     float ms = 0.f;
     OMX_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
     *avg_ms = ms / iters;
-    for (size_t i = 0; i < w.size(); ++i) { (void)hipFree(w[i]); (void)hipFree(sc[i]); (void)hipFree(bi[i]); }
+    for (size_t i = 0; i < w.size(); ++i) { (void)hipFree(w[i]); (void)hipFree(sc[i]); (void)hipFree(bi[i]); if (tiles[i]) (void)hipFree(tiles[i]); }
     (void)hipFree(x); (void)hipFree(nw); (void)hipFree(out); (void)hipFree(resid); (void)hipFree(slot);
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipStreamDestroy(s);
     return 0;
 }
+
+/* test hook (tests/test_gpu_quant.py): ONE fused packed-GEMV launch of the decode step on caller-owned device tensors -- the
+ * prologue / epilogue forms the engine uses (pro: 0 none, 1 RMSNorm; epi: gemv.hpp EPI_*), which the raw omx_quantized_matmul never
+ * reaches.  w1 / s1 / b1: the up matrix of a SwiGLU pair, or null; n0: rows of the first member when w1 stacks below it (q | k). */
+extern "C" int omx_debug_qgemv(void* out, float* out_f32, unsigned long long* argmax_slot, const void* x, const void* norm_w, const void* resid,
+                               const void* w0, const void* s0, const void* b0, const void* w1, const void* s1, const void* b1, int n0,
+                               int N, int K, int group, int bits, int pro, int epi, float eps, int single_round, void* stream) {
+    using namespace omx;
+    QGemvArgs a = {};
+    if (epi == EPI_SWIGLU) {
+        a.m[0] = QMat{(const uint32_t*)w0, (const bf16_t*)s0, (const bf16_t*)b0, N};
+        a.m[1] = QMat{(const uint32_t*)w1, (const bf16_t*)s1, (const bf16_t*)b1, N};
+    } else {
+        a.m[0] = QMat{(const uint32_t*)w0, (const bf16_t*)s0, (const bf16_t*)b0, w1 ? n0 : N};
+        if (w1) a.m[1] = QMat{(const uint32_t*)w1, (const bf16_t*)s1, (const bf16_t*)b1, N - n0};
+    }
+    a.N = N; a.K = K; a.group = group;
+    a.x = (const bf16_t*)x; a.norm_w = (const bf16_t*)norm_w; a.eps = eps; a.resid = (const bf16_t*)resid;
+    a.out = (bf16_t*)out; a.out_f32 = out_f32; a.argmax_slot = argmax_slot; a.swiglu_single_round = single_round;
+    uint32_t* tiles[2] = {nullptr, nullptr};
+    if (qgemv4m_shape_ok(K, group, bits))
+        for (int i = 0; i < 2; ++i)
+            if (a.m[i].w) {
+                OMX_HIP_CHECK(hipMalloc((void**)&tiles[i], qgemv4m_tile_words(a.m[i].n, K) * 4));
+                if (launch_qgemv4m_repack(tiles[i], a.m[i].w, a.m[i].scales, a.m[i].biases, a.m[i].n, K, (hipStream_t)stream)) return 1;
+                a.m[i].tiles = tiles[i];
+            }
+    const int rc = launch_qgemv(a, bits, pro, epi, (hipStream_t)stream);
+    OMX_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+    for (int i = 0; i < 2; ++i)
+        if (tiles[i]) (void)hipFree(tiles[i]);
+    return rc;
+}
+extern "C" int omx_debug_qgemv_grid(int N) { return omx::qgemv_grid(N); }
 
 // ---- what does a COLD weight matrix cost a streaming GEMV at its start?  (tools/tlb_probe.py)
 //      mode 0: rotate through n_copies matrices (cold, as in a decode step)

@@ -557,6 +557,10 @@ int qgemv_grid(int N) {
 
 int launch_qgemv(const QGemvArgs& a, int bits, int pro, int epi, hipStream_t s) {
     OMX_REQUIRE(bits == 4 || bits == 8, "quantized gemv: bits must be 4 or 8 (got %d)", bits);
+    if (bits == 4) {
+        const int r = launch_qgemv4m(a, pro, epi, s);
+        if (r >= 0) return r;
+    }
     return bits == 4 ? launch_qgemv_bits<4>(a, pro, epi, s) : launch_qgemv_bits<8>(a, pro, epi, s);
 }
 

@@ -14,6 +14,9 @@ struct QMat {               // one member of a row-stacked weight (q | k | v) --
     // optional repack built by the engine at load time: word g = scale[g] | bias[g] << 16, so that a lane fetches both with ONE
     // 4-byte load (two 2-byte loads per 16 bytes of weights cost the 4-bit GEMV 15 % of its streaming rate)
     const uint32_t* sb = nullptr;
+    // optional second repack (round 6, qgemv_mfma.hip): the matrix in 9 KB tiles of 16 rows x 1 024 columns (words in the order the
+    // matrix-core kernel's lanes consume them, the tile's scale | bias words behind them) -- 4-bit, group 64, K = 4096 / 12288
+    const uint32_t* tiles = nullptr;
 };
 int launch_quant_interleave(uint32_t* sb, const bf16_t* scales, const bf16_t* biases, size_t n_groups, hipStream_t s);
 // The raw-pointer C entry points (omx_moe_block_forward_q ...) receive the checkpoint's scales pointer; an engine that built the
@@ -52,6 +55,11 @@ int launch_dequantize_bf16(bf16_t* out, const uint32_t* packed, const void* scal
                            int bits, bool scales_f16, hipStream_t s, bool out_f16 = false);   // out_f16: the result in float16 (a float16 model's prompt pass)
 
 int launch_qgemv(const QGemvArgs& a, int bits, int pro, int epi, hipStream_t s);
+// qgemv_mfma.hip (round 6): the dense 4-bit group-64 single-row forms on the matrix cores.  0 launched, -1 not its shape (take the VALU kernel), 1 error
+int launch_qgemv4m(const QGemvArgs& a, int pro, int epi, hipStream_t s);
+bool qgemv4m_shape_ok(int K, int group, int bits);
+size_t qgemv4m_tile_words(int n, int K);            // u32 words of the tile form of an [n, K] matrix
+int launch_qgemv4m_repack(uint32_t* tiles, const uint32_t* wq, const bf16_t* scales, const bf16_t* biases, int n, int K, hipStream_t s);
 int qgemv_grid(int N);          // blocks launch_qgemv uses == argmax partials written
 
 }  // namespace omx

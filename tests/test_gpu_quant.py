@@ -191,3 +191,136 @@ def test_quantized_matmul_in_float16(omx, M, bits, group, K):
     # and the dequantised matrix itself (dtype of the scales, as MLX): one fma per element from the exact float16 values, one rounding
     dq = omx.ops.dequantize(T.from_numpy(rq_, "u32"), T.from_numpy(s16, "f16"), T.from_numpy(b16, "f16"), group, bits).numpy()
     np.testing.assert_array_equal(dq, rc.dequantize(rq_, s16.astype(np.float32), b16.astype(np.float32), group, bits, "f32").astype(np.float16).astype(np.float32))
+
+
+# ---- round 6: the decode step's fused packed-GEMV forms at the real widths, on BOTH kernels -- the VALU kernel (quant.hip) and the
+#      matrix-core kernel (qgemv_mfma.hip: K = 4096 / 12288, group 64) -- each against the oracle, through a debug entry point that
+#      launches exactly what engine.hip launches (prologue: RMSNorm; epilogues: store, residual, SwiGLU in both roundings, logits +
+#      greedy argmax key, unrounded f32 row sums) ----
+import ctypes
+
+PRO_NONE, PRO_RMSNORM = 0, 1
+EPI_STORE, EPI_RESIDUAL, EPI_SWIGLU, EPI_ARGMAX, EPI_F32 = 0, 1, 2, 3, 4
+
+
+def _bind_debug(omx):
+    lib = omx.lib
+    vp = ctypes.c_void_p
+    lib.omx_debug_qgemv.restype = ctypes.c_int
+    lib.omx_debug_qgemv.argtypes = [vp] * 12 + [ctypes.c_int] * 7 + [ctypes.c_float, ctypes.c_int, vp]
+    lib.omx_debug_qgemv_mfma.restype = None
+    lib.omx_debug_qgemv_mfma.argtypes = [ctypes.c_int]
+    lib.omx_debug_qgemv_grid.restype = ctypes.c_int
+    lib.omx_debug_qgemv_grid.argtypes = [ctypes.c_int]
+    return lib
+
+
+def test_gemv_epilogue_codes_match_the_header():
+    import os, re
+    src = open(os.path.join(os.path.dirname(__file__), "..", "ominix-mlx_amd", "csrc", "gemv.hpp")).read()
+    for name, val in (("PRO_NONE", 0), ("PRO_RMSNORM", 1), ("EPI_STORE", 0), ("EPI_RESIDUAL", 1), ("EPI_SWIGLU", 2), ("EPI_ARGMAX", 3), ("EPI_F32", 4)):
+        m = re.search(r"\b%s\s*=\s*(\d+)" % name, src)
+        assert m and int(m.group(1)) == val, name
+
+
+@pytest.mark.parametrize("mfma", [1, 0])
+@pytest.mark.parametrize("N,K,pro,epi,single,stack", [
+    (6144, 4096, PRO_RMSNORM, EPI_STORE, 0, 4096),      # q | k+v rows stacked below: two members
+    (4096, 4096, PRO_NONE, EPI_RESIDUAL, 0, 0),         # o
+    (1536, 4096, PRO_RMSNORM, EPI_SWIGLU, 0, 0),        # gate / up, nn::silu(g) * u roundings
+    (1536, 4096, PRO_NONE, EPI_SWIGLU, 1, 0),           # ... fused_swiglu's single rounding
+    (4096, 12288, PRO_NONE, EPI_RESIDUAL, 0, 0),        # down
+    (1040, 12288, PRO_NONE, EPI_F32, 0, 0),             # a tensor-parallel K slice's f32 row sums
+    (1000, 4096, PRO_NONE, EPI_STORE, 0, 0),            # ragged N: the last 16-row block is half empty
+    (20000, 4096, PRO_RMSNORM, EPI_ARGMAX, 0, 0),       # logits + argmax partials, blocks looping over several row blocks
+])
+def test_fused_packed_gemv_forms_match_oracle(omx, mfma, N, K, pro, epi, single, stack):
+    lib = _bind_debug(omx)
+    T = omx.ops.Tensor
+    seed = 900 + N % 97 + epi
+    x = rc.bf16_round(rand((1, K), seed))
+    nw = rc.bf16_round(1.0 + 0.1 * rand((K,), seed + 1))
+    resid = rc.bf16_round(rand((N,), seed + 2))
+    mats = []
+    for j in range(2 if epi == EPI_SWIGLU else 1):
+        w = rand((N, K), seed + 3 + j) * 0.05
+        q_, s_, b_ = rc.quantize(w, 64, 4)
+        mats.append((q_, rc.bf16_round(s_), rc.bf16_round(b_)))
+    xin = rc.rms_norm(x, nw, 1e-6, "bf16") if pro == PRO_RMSNORM else x
+    ys = [rc.quantized_matmul(xin, m[0], m[1], m[2], 64, 4, "f32")[0].astype(np.float64) for m in mats]
+    wd = [rc.dequantize(m[0], m[1], m[2], 64, 4, "f32").astype(np.float64) for m in mats]
+    noise = [4 * 2.0 ** -9 * np.sqrt((xin.astype(np.float64) ** 2) @ (w_ ** 2).T)[0] for w_ in wd]
+
+    dev = [tuple(T.from_numpy(a, "u32" if a.dtype == np.uint32 else "bf16") for a in m) for m in mats]
+    if stack:   # the same matrix handed over as two row-stacked members: [0, stack) and [stack, N)
+        q_, s_, b_ = mats[0]
+        dev = [tuple(T.from_numpy(np.ascontiguousarray(a[:stack]), "u32" if a.dtype == np.uint32 else "bf16") for a in (q_, s_, b_)),
+               tuple(T.from_numpy(np.ascontiguousarray(a[stack:]), "u32" if a.dtype == np.uint32 else "bf16") for a in (q_, s_, b_))]
+    xd, nwd, rd = T.from_numpy(x), T.from_numpy(nw), T.from_numpy(resid)
+    out = T.from_numpy(np.zeros((N,), np.float32))          # bf16
+    out32 = T.from_numpy(np.zeros((N,), np.float32), "f32")
+    nslot = lib.omx_debug_qgemv_grid(N)
+    slots = T.from_numpy(np.zeros((2 * nslot,), np.uint32), "u32")
+    lib.omx_debug_qgemv_mfma(mfma)
+    try:
+        second = dev[1] if len(dev) > 1 else (None, None, None)
+        omx.check(lib.omx_debug_qgemv(out.ptr, out32.ptr, slots.ptr, xd.ptr, nwd.ptr, rd.ptr, dev[0][0].ptr, dev[0][1].ptr, dev[0][2].ptr,
+                                      second[0].ptr if second[0] else None, second[1].ptr if second[1] else None,
+                                      second[2].ptr if second[2] else None, stack, N, K, 64, 4, pro, epi, 1e-6, single, None))
+        omx.check(omx.lib.omx_synchronize(None))
+    finally:
+        lib.omx_debug_qgemv_mfma(-1)
+    got16 = out.numpy().astype(np.float64)
+    ulp = 2.0 ** -7
+    if epi == EPI_F32:
+        got = out32.numpy().astype(np.float64)
+        assert (np.abs(got - ys[0]) <= noise[0] + 1e-6).all()
+    elif epi == EPI_STORE:
+        assert (np.abs(got16 - ys[0]) <= np.abs(ys[0]) * ulp + noise[0] + 1e-6).all()
+    elif epi == EPI_RESIDUAL:
+        ref = resid.astype(np.float64) + ys[0]
+        assert (np.abs(got16 - ref) <= (np.abs(ref) + np.abs(ys[0])) * ulp + noise[0] + 1e-6).all()
+    elif epi == EPI_SWIGLU:
+        g, u = ys
+        sg = 1.0 / (1.0 + np.exp(-g))
+        ref = g * sg * u
+        # d(silu)/dg <= 1.1: the gate's noise times |u|, the up row's times |silu(g)|, three (one) bf16 roundings on top
+        tol = np.abs(ref) * 4 * ulp + 1.1 * (noise[0] + np.abs(g) * ulp) * np.abs(u) + (noise[1] + np.abs(u) * ulp) * np.abs(g * sg) + 1e-6
+        assert (np.abs(got16 - ref) <= tol).all()
+    else:
+        assert (np.abs(got16 - ys[0]) <= np.abs(ys[0]) * ulp + noise[0] + 1e-6).all()
+        keys = slots.numpy().view(np.uint64)[:nslot]
+        best = int(keys.max())
+        idx = (~best) & 0xFFFFFFFF
+        assert 0 <= idx < N
+        # the key carries the device's own bf16 logits: its winner must be the first maximum of what the launch stored
+        assert idx == int(np.argmax(got16))
+
+
+def test_matrix_core_packed_gemv_agrees_with_the_valu_kernel_on_tokens(omx):
+    """The two kernels round differently (MFMA accumulation order), so they are compared through what the engine reads: logits within
+    the bf16 bound of each other and the same greedy winner on a peaked row."""
+    lib = _bind_debug(omx)
+    T = omx.ops.Tensor
+    N, K = 4096, 4096
+    w = rand((N, K), 77) * 0.05
+    x = rc.bf16_round(rand((1, K), 78))
+    w[1234] = x[0] * 0.2                                   # one row aligned with x: a clear winner
+    q_, s_, b_ = rc.quantize(w, 64, 4)
+    s_, b_ = rc.bf16_round(s_), rc.bf16_round(b_)
+    nw = rc.bf16_round(np.ones((K,), np.float32))
+    outs = {}
+    for mode in (0, 1):
+        out = T.from_numpy(np.zeros((N,), np.float32))
+        slots = T.from_numpy(np.zeros((2 * lib.omx_debug_qgemv_grid(N),), np.uint32), "u32")
+        lib.omx_debug_qgemv_mfma(mode)
+        try:
+            dq, ds, db = T.from_numpy(q_, "u32"), T.from_numpy(s_), T.from_numpy(b_)
+            omx.check(lib.omx_debug_qgemv(out.ptr, None, slots.ptr, T.from_numpy(x).ptr, T.from_numpy(nw).ptr, None, dq.ptr, ds.ptr, db.ptr,
+                                          None, None, None, 0, N, K, 64, 4, PRO_RMSNORM, EPI_ARGMAX, 1e-6, 0, None))
+            omx.check(omx.lib.omx_synchronize(None))
+        finally:
+            lib.omx_debug_qgemv_mfma(-1)
+        outs[mode] = (out.numpy().astype(np.float64), (~int(slots.numpy().view(np.uint64).max())) & 0xFFFFFFFF)
+    assert outs[0][1] == outs[1][1] == 1234
+    assert (np.abs(outs[0][0] - outs[1][0]) <= np.maximum(np.abs(outs[0][0]), 1.0) * 2.0 ** -6).all()

@@ -316,6 +316,9 @@ int mlx_gather_mm(mlx_array* res, const mlx_array a, const mlx_array b, const ml
  *      mlx-rs-core/src/metal_kernels.rs:188-236, 260-339): the two Rust call sites switch to these ---- */
 /* omx extension: an array over device memory the caller owns and keeps alive (row-major, 16-byte aligned; never written by an op) */
 mlx_array omx_mlx_array_from_device(const void* device_ptr, const int* shape, int dim, mlx_dtype dtype);
+/* omx extension (round 6): counters of the deferred op list behind this ABI (csrc/mlxc_lazy.hpp) -- out6[0] ops recorded, [1] launched as
+ * recorded, [2] fused GEMV launches that replaced several of them, [3] flushes, [4] host ns inside the flushes, [5] of which in the rewrite pass.  OMX_MLX_LAZY=0 executes every call eagerly (round 5). */
+void omx_mlx_lazy_stats(long* out6);
 int omx_mlx_fused_swiglu(mlx_array* res, const mlx_array x, const mlx_array gate, const mlx_stream s);
 int omx_mlx_fused_modulate(mlx_array* res, const mlx_array x, const mlx_array shift, const mlx_array scale,
                            const mlx_stream s);

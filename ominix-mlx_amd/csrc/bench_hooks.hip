@@ -342,7 +342,8 @@ extern "C" int omx_bench_qgemv(int N, int K, int bits, int pro, int epi, int n_c
     OMX_HIP_CHECK(hipEventCreate(&e0));
     OMX_HIP_CHECK(hipEventCreate(&e1));
     std::vector<uint32_t*> tiles(w.size(), nullptr);       // the matrix-core kernel's form of the same matrices (qgemv_mfma.hip)
-    if (qgemv4m_shape_ok(K, 64, bits))
+    const char* mfma_env = getenv("OMX_QGEMV_MFMA");
+    if (qgemv4m_shape_ok(K, 64, bits) && !(mfma_env && mfma_env[0] == '0'))
         for (size_t i = 0; i < w.size(); ++i) {
             OMX_HIP_CHECK(hipMalloc((void**)&tiles[i], qgemv4m_tile_words(N, K) * 4));
             if (launch_qgemv4m_repack(tiles[i], w[i], sc[i], bi[i], N, K, nullptr)) return 1;

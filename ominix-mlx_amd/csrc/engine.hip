@@ -335,7 +335,8 @@ int resolve_weights(omx_qwen3 m) {
                 m->sb_keys.push_back(sc);
             }
             // the dense decode step's matrices once more as matrix-core tiles (qgemv_mfma.hip; OMX_QGEMV_MFMA=0: the VALU kernel only)
-            static const bool tiles_off = [] { const char* e = getenv("OMX_QGEMV_MFMA"); return e && e[0] == '0'; }();
+            const char* mfma_env = getenv("OMX_QGEMV_MFMA");        // (read per model: tests compare the two kernels in one process)
+            const bool tiles_off = mfma_env && mfma_env[0] == '0';
             if (!tiles_off && stack == 1 && K > 0 && !m->cfg.quant_scales_f16 && qgemv4m_shape_ok(K, m->cfg.quant_group, m->cfg.quant_bits)) {
                 uint32_t* tiles = nullptr;
                 if (dev_alloc(m, &tiles, qgemv4m_tile_words(n, K)) || launch_qgemv4m_repack(tiles, (const uint32_t*)w, sc, bi, n, K, m->stream)) return 1;

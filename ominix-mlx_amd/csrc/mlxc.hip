@@ -69,9 +69,23 @@ struct Buf {
     void* p;
     size_t bytes;
     bool owned;                     // false: device memory BORROWED from the caller (omx_mlx_array_from_device): never returned to the pool
+    uint64_t seq = 0;               // the flush (mlxc_lazy.hpp) whose launches last wrote it; 0: written by launches outside any flush
     Buf(void* p_, size_t b, bool owned_ = true) : p(p_), bytes(b), owned(owned_) {}
     ~Buf() { if (p && owned) g_pool.put(p, bytes); }
 };
+
+// deferred execution (mlxc_lazy.hpp): ops may be RECORDED instead of launched; ptr() -- the only way to a buffer's address -- executes
+// the recorded list first, unless the caller is a recorded launch itself
+}  // namespace
+int flush_pending();
+namespace {
+int g_lazy_busy = 0;
+size_t g_n_pending = 0;
+bool g_deferred_failed = false;    // a flush forced from inside ptr() failed: reported by the next evaluation point
+uint64_t g_flush_seq = 0;          // every flush records an event behind its launches: item() / data() wait for the producing flush only,
+constexpr int kEvRing = 64;        // not for the step the caller has queued behind it (qwen3-mlx Generate::next, model.rs:804-843)
+hipEvent_t g_flush_ev[kEvRing] = {};
+hipStream_t g_copy_stream = nullptr;
 
 struct Arr {
     std::shared_ptr<Buf> buf;
@@ -82,7 +96,10 @@ struct Arr {
     std::vector<uint8_t> host;      // mirror handed out by mlx_array_data_*
     bool donated = false;           // its buffer was updated in place on behalf of a slice_update result (see there)
     size_t size() const { size_t n = 1; for (int d : shape) n *= (size_t)d; return n; }
-    char* ptr() const { return (char*)buf->p + off; }
+    char* ptr() const {
+        if (g_n_pending && !g_lazy_busy) (void)flush_pending();
+        return (char*)buf->p + off;
+    }
 };
 
 size_t dsize(mlx_dtype d) {
@@ -225,6 +242,10 @@ __device__ __forceinline__ void st_i(char* p, int dt, size_t i, long long v) {
 }
 __host__ __device__ inline bool is_int_dt(int d) { return d != MLX_FLOAT16 && d != MLX_FLOAT32 && d != MLX_BFLOAT16 && d != MLX_FLOAT64 && d != MLX_COMPLEX64; }
 
+
+}  // namespace
+#include "mlxc_lazy.hpp"
+namespace {
 
 enum { OP_ADD, OP_SUB, OP_MUL, OP_DIV, OP_SIGMOID, OP_EXP, OP_NEG, OP_CAST };
 
@@ -374,11 +395,21 @@ int binary(mlx_array* res, const mlx_array ha, const mlx_array hb, int op, const
     }
     const mlx_dtype odt = promote(a.dt, b.dt);
     NEW_OR_FAIL(r, shape, odt);
-    const size_t n = r->size();
-    if (n) {
-        binary_kernel<<<grid_for(n), 256, 0, g_stream>>>(r->ptr(), odt, a.ptr(), a.dt, b.ptr(), b.dt, ix, n, op);
-        OMX_LAUNCH_CHECK();
-    }
+    Rec rec;
+    rec.kind = op == OP_ADD ? RK_ADD : op == OP_MUL ? RK_MUL : RK_GENERIC;
+    rec.a[0] = *r; rec.a[1] = a; rec.a[2] = b; rec.na = 3;
+    rec.i0 = op;
+    // the elementwise form the GEMV epilogues can absorb: two whole bf16 rows of the result's size
+    rec.flag = odt == MLX_BFLOAT16 && a.dt == odt && b.dt == odt && a.size() == r->size() && b.size() == r->size() && is_contig(a) && is_contig(b);
+    rec.run = [ix](Rec& q) -> int {
+        const size_t n = q.a[0].size();
+        if (n) {
+            binary_kernel<<<grid_for(n), 256, 0, g_stream>>>(q.a[0].ptr(), q.a[0].dt, q.a[1].ptr(), q.a[1].dt, q.a[2].ptr(), q.a[2].dt, ix, n, q.i0);
+            OMX_LAUNCH_CHECK();
+        }
+        return 0;
+    };
+    if (record(std::move(rec))) { delete r; return 1; }
     return assign(res, r);
 }
 int unary(mlx_array* res, const mlx_array ha, int op, mlx_dtype odt, const char* name) {
@@ -388,11 +419,19 @@ int unary(mlx_array* res, const mlx_array ha, int op, mlx_dtype odt, const char*
     Idx ix;
     if (fill_idx(ix, a.shape)) { delete r; return 1; }
     for (int i = 0; i < ix.nd; ++i) ix.sa[i] = (long long)a.strides[i];
-    const size_t n = r->size();
-    if (n) {
-        unary_kernel<<<grid_for(n), 256, 0, g_stream>>>(r->ptr(), odt, a.ptr(), a.dt, ix, n, op);
-        OMX_LAUNCH_CHECK();
-    }
+    Rec rec;
+    rec.kind = op == OP_SIGMOID ? RK_SIGMOID : RK_GENERIC;
+    rec.a[0] = *r; rec.a[1] = a; rec.na = 2;
+    rec.i0 = op;
+    rec.run = [ix](Rec& q) -> int {
+        const size_t n = q.a[0].size();
+        if (n) {
+            unary_kernel<<<grid_for(n), 256, 0, g_stream>>>(q.a[0].ptr(), q.a[0].dt, q.a[1].ptr(), q.a[1].dt, ix, n, q.i0);
+            OMX_LAUNCH_CHECK();
+        }
+        return 0;
+    };
+    if (record(std::move(rec))) { delete r; return 1; }
     return assign(res, r);
 }
 int norm_axis(int axis, int nd, const char* name, int* out) {
@@ -403,14 +442,35 @@ int norm_axis(int axis, int nd, const char* name, int* out) {
 }
 omx_dtype to_omx(mlx_dtype d) { return (omx_dtype)(int)d; }
 
+// an evaluation point that found the deferred list failing earlier reports it now
+int take_deferred_error() {
+    if (!g_deferred_failed) return 0;
+    g_deferred_failed = false;
+    return 1;     // (the failing op set the message)
+}
+// device -> host for item() / data(): waits for the flush that produced the buffer (a side stream behind that flush's event) when it is
+// known and recent, for the whole stream otherwise.  `src` was obtained through ptr(): nothing is pending any more.
+int read_back(void* dst, const Arr& a, const char* src, size_t bytes) {
+    if (take_deferred_error()) return 1;
+    const uint64_t seq = a.buf->seq;
+    hipEvent_t ev = (seq && g_flush_seq - seq < (uint64_t)kEvRing - 1) ? g_flush_ev[seq % kEvRing] : nullptr;
+    if (ev) {
+        if (!g_copy_stream) OMX_HIP_CHECK(hipStreamCreateWithFlags(&g_copy_stream, hipStreamNonBlocking));
+        OMX_HIP_CHECK(hipStreamWaitEvent(g_copy_stream, ev, 0));
+        OMX_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, g_copy_stream));
+        OMX_HIP_CHECK(hipStreamSynchronize(g_copy_stream));
+        return 0;
+    }
+    OMX_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, g_stream));
+    OMX_HIP_CHECK(hipStreamSynchronize(g_stream));
+    return 0;
+}
 int item_host(const mlx_array h, void* dst, mlx_dtype want, const char* name) {
     REQ_ARR(h, name);
     const Arr& a = *A(h);
     OMX_REQUIRE(a.size() == 1, "%s: item() needs a size-1 array (size %zu)", name, a.size());
     OMX_REQUIRE(a.dt == want || dsize(a.dt) == dsize(want), "%s: dtype mismatch", name);
-    OMX_HIP_CHECK(hipMemcpyAsync(dst, a.ptr(), dsize(a.dt), hipMemcpyDeviceToHost, g_stream));
-    OMX_HIP_CHECK(hipStreamSynchronize(g_stream));
-    return 0;
+    return read_back(dst, a, a.ptr(), dsize(a.dt));
 }
 const void* data_host(const mlx_array h) {
     if (!h.ctx) return nullptr;
@@ -420,9 +480,15 @@ const void* data_host(const mlx_array h) {
     const size_t bytes = a->size() * dsize(a->dt);
     a->host.resize(bytes ? bytes : 1);
     if (bytes) {
-        if (hipMemcpyAsync(a->host.data(), c.a->ptr(), bytes, hipMemcpyDeviceToHost, g_stream) != hipSuccess) return nullptr;
+        if (c.owned) {    // a strided view was gathered by a launch of this call: on the stream, behind everything
+            if (hipMemcpyAsync(a->host.data(), c.a->ptr(), bytes, hipMemcpyDeviceToHost, g_stream) != hipSuccess) return nullptr;
+            if (hipStreamSynchronize(g_stream) != hipSuccess || take_deferred_error()) return nullptr;
+        } else if (read_back(a->host.data(), *a, c.a->ptr(), bytes)) {
+            return nullptr;
+        }
+    } else if (hipStreamSynchronize(g_stream) != hipSuccess) {
+        return nullptr;
     }
-    if (hipStreamSynchronize(g_stream) != hipSuccess) return nullptr;
     return a->host.data();
 }
 
@@ -504,6 +570,7 @@ int mlx_array_dim(const mlx_array arr, int dim) {
 mlx_dtype mlx_array_dtype(const mlx_array arr) { return arr.ctx ? A(arr)->dt : MLX_FLOAT32; }
 int mlx_array_eval(mlx_array arr) {
     REQ_ARR(arr, "mlx_array_eval");
+    if (flush_pending() || take_deferred_error()) return 1;
     OMX_HIP_CHECK(hipStreamSynchronize(g_stream));
     return 0;
 }
@@ -542,33 +609,62 @@ bool mlx_stream_equal(mlx_stream lhs, mlx_stream rhs) {
     if (!lhs.ctx || !rhs.ctx) return lhs.ctx == rhs.ctx;
     return reinterpret_cast<Str*>(lhs.ctx)->cpu == reinterpret_cast<Str*>(rhs.ctx)->cpu;
 }
-int mlx_synchronize(mlx_stream) { OMX_HIP_CHECK(hipStreamSynchronize(g_stream)); return 0; }
+int mlx_synchronize(mlx_stream) {
+    if (flush_pending() || take_deferred_error()) return 1;
+    OMX_HIP_CHECK(hipStreamSynchronize(g_stream));
+    return 0;
+}
 mlx_stream mlx_default_cpu_stream_new(void) {
     set_error("mlx_default_cpu_stream_new: libomx_hip has no CPU backend (MI355X only)");
     return mlx_stream{nullptr};
 }
 mlx_stream mlx_default_gpu_stream_new(void) { return mlx_stream{new Str{false}}; }
-int mlx_async_eval(const mlx_vector_array) { return 0; }   // eager: the work is already enqueued
-int mlx_eval(const mlx_vector_array) { OMX_HIP_CHECK(hipStreamSynchronize(g_stream)); return 0; }
-int mlx_clear_cache(void) { g_pool.clear(); return 0; }
+// transforms.h:30,42 -- the evaluation points of the deferred list (mlxc_lazy.hpp): async_eval sends the recorded launches and returns,
+// eval waits for them.  Everything recorded goes out, not only what the given arrays depend on (one in-order stream; a superset is allowed).
+int mlx_async_eval(const mlx_vector_array) { return (flush_pending() || take_deferred_error()) ? 1 : 0; }
+int mlx_eval(const mlx_vector_array) {
+    if (flush_pending() || take_deferred_error()) return 1;
+    OMX_HIP_CHECK(hipStreamSynchronize(g_stream));
+    return 0;
+}
+/* omx extension: counters of the deferred list -- [0] ops recorded, [1] launched as recorded, [2] fused GEMV launches, [3] flushes, [4] host ns in flushes, [5] ns of the rewrite pass
+ * (bench.py per_op_route; tests assert that the decode idioms really fuse) */
+void omx_mlx_lazy_stats(long* out6) { for (int i = 0; i < 6; ++i) out6[i] = g_lazy_stats[i]; }
+int mlx_clear_cache(void) {
+    if (flush_pending()) return 1;
+    g_pool.clear();
+    return 0;
+}
 int mlx_get_active_memory(size_t* res) { OMX_REQUIRE(res, "null result"); *res = g_pool.active; return 0; }
 int mlx_get_peak_memory(size_t* res) { OMX_REQUIRE(res, "null result"); *res = g_pool.peak; return 0; }
 
 // ---- fused hot-path ops ----
 int mlx_fast_rms_norm(mlx_array* res, const mlx_array x, const mlx_array weight, float eps, const mlx_stream) {
     REQ_ARR(x, "mlx_fast_rms_norm");
-    Contig cx, cw;
-    if (cx.init(*A(x))) return 1;
-    OMX_REQUIRE(!cx.a->shape.empty(), "mlx_fast_rms_norm: input must have at least 1 dimension");
-    const int dim = cx.a->shape.back();
+    const Arr& x0 = *A(x);
+    OMX_REQUIRE(!x0.shape.empty(), "mlx_fast_rms_norm: input must have at least 1 dimension");
+    const int dim = x0.shape.back();
     if (weight.ctx) {
-        if (cw.init(*A(weight))) return 1;
-        OMX_REQUIRE(cw.a->shape.size() == 1 && cw.a->shape[0] == dim && cw.a->dt == cx.a->dt,
+        REQ_ARR(weight, "mlx_fast_rms_norm");
+        OMX_REQUIRE(A(weight)->shape.size() == 1 && A(weight)->shape[0] == dim && A(weight)->dt == x0.dt,
                     "mlx_fast_rms_norm: weight must be 1-D of size %d and of the input dtype", dim);
     }
-    NEW_OR_FAIL(r, cx.a->shape, cx.a->dt);
-    if (omx_rms_norm(r->ptr(), cx.a->ptr(), weight.ctx ? cw.a->ptr() : nullptr, dim ? (int64_t)(r->size() / dim) : 0, dim,
-                     eps, to_omx(r->dt), g_stream)) { delete r; return 1; }
+    NEW_OR_FAIL(r, x0.shape, x0.dt);
+    Rec rec;
+    rec.kind = RK_RMSNORM;
+    rec.a[0] = *r; rec.a[1] = x0; rec.na = 2;
+    if (weight.ctx) { rec.a[2] = *A(weight); rec.na = 3; }
+    rec.f0 = eps; rec.i0 = dim;
+    rec.flag = weight.ctx && x0.dt == MLX_BFLOAT16 && is_contig(x0) && is_contig(*A(weight));   // what a GEMV prologue reproduces
+    rec.run = [](Rec& q) -> int {
+        Contig cx, cw;
+        if (cx.init(q.a[1])) return 1;
+        if (q.na > 2 && cw.init(q.a[2])) return 1;
+        const int dim = q.i0;
+        return omx_rms_norm(q.a[0].ptr(), cx.a->ptr(), q.na > 2 ? cw.a->ptr() : nullptr, dim ? (int64_t)(q.a[0].size() / dim) : 0, dim, q.f0,
+                            to_omx(q.a[0].dt), g_stream);
+    };
+    if (record(std::move(rec))) { delete r; return 1; }
     return assign(res, r);
 }
 int mlx_fast_layer_norm(mlx_array* res, const mlx_array x, const mlx_array weight, const mlx_array bias, float eps,
@@ -590,25 +686,34 @@ int mlx_fast_rope(mlx_array* res, const mlx_array x, int dims, bool traditional,
     REQ_ARR(x, "mlx_fast_rope");
     // MLX core: exactly one of `base` and `freqs`
     OMX_REQUIRE(base.has_value != (freqs.ctx != nullptr), "mlx_fast_rope: exactly one of `base` and `freqs` must be given");
-    Contig cx, cf;
-    if (cx.init(*A(x))) return 1;
+    const Arr& x0 = *A(x);
     if (freqs.ctx) {
-        if (cf.init(*A(freqs))) return 1;
-        OMX_REQUIRE(cf.a->dt == MLX_FLOAT32 && cf.a->shape.size() == 1 && cf.a->shape[0] == dims / 2,
+        REQ_ARR(freqs, "mlx_fast_rope");
+        OMX_REQUIRE(A(freqs)->dt == MLX_FLOAT32 && A(freqs)->shape.size() == 1 && A(freqs)->shape[0] == dims / 2,
                     "mlx_fast_rope: `freqs` must be a float32 vector of dims / 2 = %d entries", dims / 2);
     }
-    const int nd = (int)cx.a->shape.size();
+    const int nd = (int)x0.shape.size();
     OMX_REQUIRE(nd >= 2, "mlx_fast_rope: input must have at least 2 dimensions");   // same check as MLX core
-    const int T = cx.a->shape[nd - 2], D = cx.a->shape[nd - 1];
-    NEW_OR_FAIL(r, cx.a->shape, cx.a->dt);
-    const int64_t batch = (T && D) ? (int64_t)(r->size() / ((size_t)T * D)) : 0;
-    const int rc = freqs.ctx ? omx_rope_freqs(r->ptr(), cx.a->ptr(), batch, T, D, dims, traditional, (const float*)cf.a->ptr(), scale, offset,
-                                              to_omx(r->dt), g_stream)
-                             : omx_rope(r->ptr(), cx.a->ptr(), batch, T, D, dims, traditional, base.value, scale, offset, to_omx(r->dt), g_stream);
-    if (rc) {
-        delete r;
-        return 1;
-    }
+    NEW_OR_FAIL(r, x0.shape, x0.dt);
+    Rec rec;
+    rec.kind = RK_ROPE;
+    rec.a[0] = *r; rec.a[1] = x0; rec.na = 2;
+    if (freqs.ctx) { rec.a[2] = *A(freqs); rec.na = 3; }
+    rec.flag = !freqs.ctx && base.has_value && x0.dt == MLX_BFLOAT16;
+    rec.i0 = dims; rec.i1 = traditional ? 1 : 0; rec.i2 = offset;
+    rec.f0 = base.has_value ? base.value : 0.f; rec.f1 = scale;
+    rec.run = [](Rec& q) -> int {
+        Contig cx, cf;
+        if (cx.init(q.a[1])) return 1;
+        if (q.na > 2 && cf.init(q.a[2])) return 1;
+        const int nd = (int)cx.a->shape.size();
+        const int T = cx.a->shape[nd - 2], D = cx.a->shape[nd - 1];
+        const int64_t batch = (T && D) ? (int64_t)(q.a[0].size() / ((size_t)T * D)) : 0;
+        return q.na > 2 ? omx_rope_freqs(q.a[0].ptr(), cx.a->ptr(), batch, T, D, q.i0, q.i1 != 0, (const float*)cf.a->ptr(), q.f1, q.i2,
+                                         to_omx(q.a[0].dt), g_stream)
+                        : omx_rope(q.a[0].ptr(), cx.a->ptr(), batch, T, D, q.i0, q.i1 != 0, q.f0, q.f1, q.i2, to_omx(q.a[0].dt), g_stream);
+    };
+    if (record(std::move(rec))) { delete r; return 1; }
     return assign(res, r);
 }
 int mlx_fast_scaled_dot_product_attention(mlx_array* res, const mlx_array queries, const mlx_array keys,
@@ -624,37 +729,50 @@ int mlx_fast_scaled_dot_product_attention(mlx_array* res, const mlx_array querie
     OMX_REQUIRE(k0.shape == v0.shape && q0.shape[0] == k0.shape[0] && q0.shape[3] == k0.shape[3],
                 "mlx_fast_scaled_dot_product_attention: incompatible shapes");
     OMX_REQUIRE(q0.dt == k0.dt && q0.dt == v0.dt, "mlx_fast_scaled_dot_product_attention: dtype mismatch");
-    const int B = q0.shape[0], H = q0.shape[1], Tq = q0.shape[2], D = q0.shape[3], Hkv = k0.shape[1], Tk = k0.shape[2];
-    Contig cq, ck, cv, cm;
-    if (cq.init(q0)) return 1;
-    // K/V: the [.., :offset, :] views of the step-256 cache buffers are consumed in place (cache.rs:190-193)
-    const Arr *k = &k0, *v = &v0;
-    auto kv_ok = [&](const Arr& t) { return t.strides[3] == 1 && (t.strides[2] == (size_t)D || Tk == 1); };
-    if (!kv_ok(k0) || !kv_ok(v0) || k0.strides[0] != v0.strides[0] || k0.strides[1] != v0.strides[1]) {
-        if (ck.init(k0) || cv.init(v0)) return 1;   // row-major copies (or aliases when already contiguous)
-        k = ck.a;
-        v = cv.a;
-    }
+    const int Tq = q0.shape[2], Tk = k0.shape[2];
     int mode = OMX_MASK_NONE;
-    const void* mptr = nullptr;
     const bool causal = mask_mode && strcmp(mask_mode, "causal") == 0;
     OMX_REQUIRE(!mask_mode || mask_mode[0] == 0 || causal || strcmp(mask_mode, "array") == 0,
                 "mlx_fast_scaled_dot_product_attention: Invalid mask mode '%s'", mask_mode);
     if (causal) {
         mode = OMX_MASK_CAUSAL;
     } else if (mask_arr.ctx) {
-        if (cm.init(*A(mask_arr))) return 1;
-        OMX_REQUIRE(cm.a->size() == (size_t)Tq * Tk, "mlx_fast_scaled_dot_product_attention: mask must broadcast from [Tq=%d, Tk=%d]", Tq, Tk);
-        if (cm.a->dt == MLX_BOOL) mode = OMX_MASK_BOOL;
+        REQ_ARR(mask_arr, "mlx_fast_scaled_dot_product_attention");
+        OMX_REQUIRE(A(mask_arr)->size() == (size_t)Tq * Tk, "mlx_fast_scaled_dot_product_attention: mask must broadcast from [Tq=%d, Tk=%d]", Tq, Tk);
+        if (A(mask_arr)->dt == MLX_BOOL) mode = OMX_MASK_BOOL;
         else {
-            OMX_REQUIRE(cm.a->dt == q0.dt, "mlx_fast_scaled_dot_product_attention: additive mask must have the query dtype");
+            OMX_REQUIRE(A(mask_arr)->dt == q0.dt, "mlx_fast_scaled_dot_product_attention: additive mask must have the query dtype");
             mode = OMX_MASK_ADDITIVE;
         }
-        mptr = cm.a->ptr();
     }
     NEW_OR_FAIL(r, q0.shape, q0.dt);
-    if (omx_sdpa(r->ptr(), cq.a->ptr(), k->ptr(), v->ptr(), B, H, Hkv, Tq, Tk, D, (int64_t)k->strides[0], (int64_t)k->strides[1],
-                 scale, mode, mptr, to_omx(q0.dt), g_stream)) { delete r; return 1; }
+    Rec rec;
+    rec.kind = RK_SDPA;
+    rec.a[0] = *r; rec.a[1] = q0; rec.a[2] = k0; rec.a[3] = v0; rec.na = 4;
+    if (mode == OMX_MASK_BOOL || mode == OMX_MASK_ADDITIVE) { rec.a[4] = *A(mask_arr); rec.na = 5; }
+    rec.f0 = scale; rec.i0 = mode;
+    rec.run = [](Rec& q) -> int {
+        const Arr &q0 = q.a[1], &k0 = q.a[2], &v0 = q.a[3];
+        const int B = q0.shape[0], H = q0.shape[1], Tq = q0.shape[2], D = q0.shape[3], Hkv = k0.shape[1], Tk = k0.shape[2];
+        Contig cq, ck, cv, cm;
+        if (cq.init(q0)) return 1;
+        // K/V: the [.., :offset, :] views of the step-256 cache buffers are consumed in place (cache.rs:190-193)
+        const Arr *k = &k0, *v = &v0;
+        auto kv_ok = [&](const Arr& t) { return t.strides[3] == 1 && (t.strides[2] == (size_t)D || Tk == 1); };
+        if (!kv_ok(k0) || !kv_ok(v0) || k0.strides[0] != v0.strides[0] || k0.strides[1] != v0.strides[1]) {
+            if (ck.init(k0) || cv.init(v0)) return 1;   // row-major copies (or aliases when already contiguous)
+            k = ck.a;
+            v = cv.a;
+        }
+        const void* mptr = nullptr;
+        if (q.na > 4) {
+            if (cm.init(q.a[4])) return 1;
+            mptr = cm.a->ptr();
+        }
+        return omx_sdpa(q.a[0].ptr(), cq.a->ptr(), k->ptr(), v->ptr(), B, H, Hkv, Tq, Tk, D, (int64_t)k->strides[0], (int64_t)k->strides[1],
+                        q.f0, q.i0, mptr, to_omx(q0.dt), g_stream);
+    };
+    if (record(std::move(rec))) { delete r; return 1; }
     return assign(res, r);
 }
 
@@ -759,29 +877,39 @@ static int matmul_impl(mlx_array* res, const mlx_array ha_in, const mlx_array hb
     const int K = a0.shape.back(), N = b0.shape[1];
     OMX_REQUIRE(b0.shape[0] == K, "%s: inner dimensions differ (%d vs %d)", name, K, b0.shape[0]);
     OMX_REQUIRE(a0.dt == b0.dt, "%s: dtype mismatch", name);
-    Contig ca;
-    if (ca.init(a0)) return 1;
-    // nn::Linear passes w.t(): a [N,K] row-major weight seen as [K,N] with strides (1, K) -- the NT operand
-    const Arr* w = nullptr;
-    Arr* wt = nullptr;
-    Arr view;
-    if (b0.strides[0] == 1 && b0.strides[1] == (size_t)K) {
-        w = &b0;
-    } else {   // materialise b^T as [N, K]
-        view = b0;
-        view.shape = {N, K};
-        view.strides = {b0.strides[1], b0.strides[0]};
-        if (contiguous(view, &wt)) return 1;
-        w = wt;
-    }
     std::vector<int> oshape(a0.shape.begin(), a0.shape.end() - 1);
     oshape.push_back(N);
     Arr* r = new_arr(oshape, a0.dt);
-    if (!r) { delete wt; return set_error("%s: out of device memory", name); }
-    const int M = K ? (int)(ca.a->size() / K) : 0;
-    const int rc = omx_linear(r->ptr(), ca.a->ptr(), w->ptr(), bias ? bias->ptr() : nullptr, M, N, K, to_omx(a0.dt), g_stream);
-    delete wt;
-    if (rc) { delete r; return 1; }
+    if (!r) return set_error("%s: out of device memory", name);
+    const int M = K ? (int)(a0.size() / K) : 0;
+    // nn::Linear passes w.t(): a [N,K] row-major weight seen as [K,N] with strides (1, K) -- the NT operand
+    const bool nt = b0.strides[0] == 1 && b0.strides[1] == (size_t)K;
+    Rec rec;
+    rec.kind = RK_MATMUL;
+    rec.a[0] = *r; rec.a[1] = a0; rec.a[2] = b0; rec.na = 3;
+    if (bias) { rec.a[3] = *bias; rec.na = 4; }
+    rec.i0 = N; rec.i1 = K; rec.i2 = M;
+    // the decode form (one bf16 row against an NT weight): what the deferred list may rewrite onto the fused GEMV family
+    rec.flag = M == 1 && !bias && nt && a0.dt == MLX_BFLOAT16 && is_contig(a0) && K % 8 == 0 && K <= 65536;
+    rec.run = [](Rec& q) -> int {
+        const Arr &a0 = q.a[1], &b0 = q.a[2];
+        const int N = q.i0, K = q.i1, M = q.i2;
+        Contig ca;
+        if (ca.init(a0)) return 1;
+        const Arr* w = &b0;
+        Arr* wt = nullptr;
+        if (!(b0.strides[0] == 1 && b0.strides[1] == (size_t)K)) {   // materialise b^T as [N, K]
+            Arr view = b0;
+            view.shape = {N, K};
+            view.strides = {b0.strides[1], b0.strides[0]};
+            if (contiguous(view, &wt)) return 1;
+            w = wt;
+        }
+        const int rc = omx_linear(q.a[0].ptr(), ca.a->ptr(), w->ptr(), q.na > 3 ? q.a[3].ptr() : nullptr, M, N, K, to_omx(a0.dt), g_stream);
+        delete wt;
+        return rc;
+    };
+    if (record(std::move(rec))) { delete r; return 1; }
     return assign(res, r);
 }
 int mlx_matmul(mlx_array* res, const mlx_array a, const mlx_array b, const mlx_stream) {
@@ -1050,14 +1178,20 @@ int mlx_slice_update(mlx_array* res, const mlx_array src, const mlx_array update
     }
     Arr region;
     if (slice_view(*r, start, start_num, stop, stop_num, strides, strides_num, "mlx_slice_update", &region)) { delete r; return 1; }
-    Contig cu;
-    if (cu.init(*A(update))) { delete r; return 1; }
     // broadcast-free form: update must have the region's element count (leading 1s allowed)
-    if (cu.a->size() != region.size()) { delete r; return set_error("mlx_slice_update: update has %zu elements, the slice has %zu", cu.a->size(), region.size()); }
-    Arr upd = *cu.a;
-    upd.shape = region.shape;
-    upd.strides = row_major(region.shape);
-    if (scatter_into(region.ptr(), region.strides, upd, s.dt)) { delete r; return 1; }
+    if (A(update)->size() != region.size()) { delete r; return set_error("mlx_slice_update: update has %zu elements, the slice has %zu", A(update)->size(), region.size()); }
+    Rec rec;
+    rec.kind = RK_SLICE_UPDATE;
+    rec.a[0] = region; rec.a[1] = *A(update); rec.na = 2;     // (a[0] shares the result's buffer: the write is what this record is)
+    rec.run = [](Rec& q) -> int {
+        Contig cu;
+        if (cu.init(q.a[1])) return 1;
+        Arr upd = *cu.a;
+        upd.shape = q.a[0].shape;
+        upd.strides = row_major(q.a[0].shape);
+        return scatter_into(q.a[0].ptr(), q.a[0].strides, upd, q.a[0].dt);
+    };
+    if (record(std::move(rec))) { delete r; return 1; }
     if (donate) A(src)->donated = true;
     return assign(res, r);
 }
@@ -1101,13 +1235,17 @@ int mlx_take_axis(mlx_array* res, const mlx_array a, const mlx_array indices, in
     OMX_REQUIRE(A(indices)->dt == MLX_UINT32 || A(indices)->dt == MLX_INT32, "mlx_take_axis: indices must be (u)int32");
     if (!(ax == 0 && A(a)->shape.size() == 2 && is_float(A(a)->dt))) return take_axis_general(res, *A(a), *A(indices), ax);
     // row gather from a 2-D floating table (Embedding): 16-byte vector rows
-    Contig ct, ci;
-    if (ct.init(*A(a)) || ci.init(*A(indices))) return 1;
-    std::vector<int> shape = ci.a->shape;
-    shape.push_back(ct.a->shape[1]);
-    NEW_OR_FAIL(r, shape, ct.a->dt);
-    if (omx_take_rows(r->ptr(), ct.a->ptr(), (const uint32_t*)ci.a->ptr(), (int64_t)ci.a->size(), ct.a->shape[1],
-                      to_omx(ct.a->dt), g_stream)) { delete r; return 1; }
+    std::vector<int> shape = A(indices)->shape;
+    shape.push_back(A(a)->shape[1]);
+    NEW_OR_FAIL(r, shape, A(a)->dt);
+    Rec rec;
+    rec.a[0] = *r; rec.a[1] = *A(a); rec.a[2] = *A(indices); rec.na = 3;
+    rec.run = [](Rec& q) -> int {
+        Contig ct, ci;
+        if (ct.init(q.a[1]) || ci.init(q.a[2])) return 1;
+        return omx_take_rows(q.a[0].ptr(), ct.a->ptr(), (const uint32_t*)ci.a->ptr(), (int64_t)ci.a->size(), ct.a->shape[1], to_omx(ct.a->dt), g_stream);
+    };
+    if (record(std::move(rec))) { delete r; return 1; }
     return assign(res, r);
 }
 int mlx_argmax_axis(mlx_array* res, const mlx_array a, int axis, bool keepdims, const mlx_stream) {
@@ -1119,13 +1257,21 @@ int mlx_argmax_axis(mlx_array* res, const mlx_array a, int axis, bool keepdims, 
     Arr moved = s;
     moved.shape.erase(moved.shape.begin() + ax); moved.shape.push_back(s.shape[ax]);
     moved.strides.erase(moved.strides.begin() + ax); moved.strides.push_back(s.strides[ax]);
-    Contig c;
-    if (c.init(moved)) return 1;
     std::vector<int> shape(moved.shape.begin(), moved.shape.end() - 1);
     if (keepdims) shape.insert(shape.begin() + ax, 1);
     NEW_OR_FAIL(r, shape, MLX_UINT32);
-    const int n = moved.shape.back();
-    if (omx_argmax((uint32_t*)r->ptr(), c.a->ptr(), n ? (int64_t)(s.size() / n) : 0, n, to_omx(s.dt), g_stream)) { delete r; return 1; }
+    Rec rec;
+    rec.kind = RK_ARGMAX;
+    rec.a[0] = *r; rec.a[1] = moved; rec.na = 2;
+    // one contiguous bf16 row: what the lm_head GEMV's argmax epilogue produces
+    rec.flag = s.dt == MLX_BFLOAT16 && is_contig(moved) && moved.shape.back() > 0 && s.size() == (size_t)moved.shape.back();
+    rec.run = [](Rec& q) -> int {
+        Contig c;
+        if (c.init(q.a[1])) return 1;
+        const int n = q.a[1].shape.back();
+        return omx_argmax((uint32_t*)q.a[0].ptr(), c.a->ptr(), n ? (int64_t)(q.a[1].size() / n) : 0, n, to_omx(q.a[1].dt), g_stream);
+    };
+    if (record(std::move(rec))) { delete r; return 1; }
     return assign(res, r);
 }
 // ---- random.h: keyed generator + categorical (sampler.rs:13-16 through mlx-rs/src/random.rs) ----

@@ -1,0 +1,476 @@
+// Deferred execution behind the mlx-c boundary (round 6; included by mlxc.hip after its helpers).
+//
+// The ABI is lazy BY CONTRACT: an op returns an array whose value is only guaranteed after mlx_eval / mlx_async_eval / item / data
+// (mlx-c transforms.h:30,42; mlx-rs/src/transforms/mod.rs:67-85), and MLX itself runs the decode step as a graph it may fuse
+// (nn::silu is `compile`d, mlx-rs/src/nn/activation.rs:876-880).  Round 5 launched at every call: an unmodified qwen3-mlx made 1 384
+// eager calls per token at 4.7 us of host time each and got 0.46 of the fused engine.  Here the hot ops of the four callers only
+// RECORD (result buffer allocated, shape known, launch closure + typed operands kept); the list is executed
+//   * at mlx_eval / mlx_async_eval / mlx_array_eval / mlx_synchronize / item / data, and
+//   * before ANY other access to device data: Arr::ptr() is the one gate to a buffer's address, and it flushes first unless the caller
+//     is a recorded launch itself -- an op that was never taught to defer stays correct without knowing this file exists.
+// Before the launches go out a peephole pass rewrites the decode idioms onto the GEMV family the engine uses (gemv.hpp):
+//     rms_norm(x) -> x @ W^T (M == 1)                          RMSNorm prologue (the norm launch disappears when every reader fused it)
+//     h + (o @ W^T)                                            residual epilogue
+//     ((g * sigmoid(g)) * (x @ Wu^T)), g = x @ Wg^T            gate / up pair with the SwiGLU epilogue (nn::silu roundings)
+//     argmax(x @ W^T, axis = -1)                               logits + per-block argmax keys + a tiny finalise launch
+//     q_norm / k_norm -> rope -> cache slice_update (k, v)     the engine's one prompt-pass launch for all of it (prefill.hpp), and the
+//                                                              three projections before it as ONE row-stacked GEMV launch
+// An intermediate may only vanish when NOTHING outside the pending list can read it: its buffer's reference count must equal the
+// references the pending records hold (any live handle, view or vector entry makes it externally visible and it is computed as recorded).
+#pragma once
+
+#include <chrono>
+#include <functional>
+#include <unordered_map>
+
+#include "gemv.hpp"
+#include "prefill.hpp"
+
+namespace {
+
+enum RecKind { RK_GENERIC = 0, RK_RMSNORM, RK_MATMUL, RK_ADD, RK_MUL, RK_SIGMOID, RK_ARGMAX, RK_ROPE, RK_SLICE_UPDATE, RK_SDPA };
+
+struct Rec {
+    int kind = RK_GENERIC;
+    // operands: a[0] = the result, a[1..] = inputs (views share their buffers: that is what keeps them alive and what the pass counts)
+    Arr a[5];
+    int na = 0;
+    float f0 = 0.f, f1 = 0.f;
+    int i0 = 0, i1 = 0, i2 = 0, i3 = 0;
+    bool flag = false;            // RK_MATMUL: the M == 1 bf16 NT form launch_gemv serves (a[1] = x row, a[2] = W^T view of [N, K])
+    std::vector<int> iv;
+    std::function<int(Rec&)> run;
+    bool dead = false;
+};
+
+std::vector<Rec> g_pending;
+bool g_lazy_on = true, g_lazy_env_read = false;
+long g_lazy_stats[6] = {0, 0, 0, 0, 0, 0};   // recorded, launched, fused launches, flushes, ns spent in flushes (host), ns of them in the peephole pass
+
+bool lazy_enabled() {
+    if (!g_lazy_env_read) {
+        const char* e = getenv("OMX_MLX_LAZY");
+        g_lazy_on = !(e && e[0] == '0');
+        g_lazy_env_read = true;
+    }
+    return g_lazy_on;
+}
+
+// execute or defer.  A recorded op that runs another lazy-aware op from inside its launch closure executes it on the spot.
+int record(Rec&& r) {
+    if (!lazy_enabled() || g_lazy_busy > 0) {
+        ++g_lazy_busy;
+        const int rc = r.run(r);
+        --g_lazy_busy;
+        return rc;
+    }
+    ++g_lazy_stats[0];
+    g_pending.push_back(std::move(r));
+    g_n_pending = g_pending.size();
+    if (g_pending.size() >= 8192) return flush_pending();   // (an unbounded list is memory held, not work saved)
+    return 0;
+}
+
+bool same_view(const Arr& x, const Arr& y) {
+    return x.buf.get() == y.buf.get() && x.off == y.off && x.size() == y.size();
+}
+
+__global__ void lazy_argmax_finalize_kernel(uint32_t* out, const unsigned long long* keys, int n) {
+    __shared__ unsigned long long sm[256];
+    unsigned long long b = 0;
+    for (int i = threadIdx.x; i < n; i += 256) b = keys[i] > b ? keys[i] : b;
+    sm[threadIdx.x] = b;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) sm[threadIdx.x] = sm[threadIdx.x + o] > sm[threadIdx.x] ? sm[threadIdx.x + o] : sm[threadIdx.x];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = ~(uint32_t)(sm[0] & 0xFFFFFFFFull);
+}
+
+struct ScatterPlan {       // q_norm + k_norm + rope (q, k) + the two cache writes of one attention layer as one launch (prefill.hpp)
+    int nq = -1, nk = -1, rq = -1, rk = -1, uk = -1, uv = -1;
+    int T = 0, H = 0, Hkv = 0, D = 0, cap = 0, offset = 0;
+    std::shared_ptr<Arr> qkv;      // set by a stacked q | k | v GEMV plan: the projections live there, not in their recorded buffers
+    int nq_rows = 0, nk_rows = 0;
+};
+struct FusePlan {          // one launch_gemv replacing the records it absorbed; launched at the position of record `at`
+    int at = -1;
+    int mmk = -1, mmv = -1;        // row-stacked q | k | v launch: mm0 = q, these = k, v; the result goes to *stack_out
+    std::shared_ptr<Arr> stack_out;
+    bool is_scatter = false;
+    ScatterPlan sc;
+    int mm0 = -1, mm1 = -1;        // the matmul record(s): mm1 = the up projection of a SwiGLU pair
+    int norm = -1;                 // RMSNorm record feeding them (prologue), or -1
+    int epi = omx::EPI_STORE;
+    int tail = -1;                 // the add / multiply / argmax record whose result this launch writes (-1: the matmul's own)
+    int resid_operand = 0;         // which input of the add is the residual
+};
+
+// cos / sin tables of fast::rope's angles (position * scale * base^(-i / half), evaluated in fp64 exactly as elementwise.hip's rope_kernel
+// and the engine's table do), grown on demand
+__global__ void lazy_rope_table_kernel(float* cos_t, float* sin_t, int cap, int half, double neg_log_base_over_half, double scale) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= cap * half) return;
+    const int t = idx / half, i = idx % half;
+    const double ang = ((double)t * scale) * exp((double)i * neg_log_base_over_half);
+    double sn, cs;
+    sincos(ang, &sn, &cs);
+    cos_t[idx] = (float)cs;
+    sin_t[idx] = (float)sn;
+}
+struct RopeTable { float base, scale; int half, cap; float *cos_t, *sin_t; };
+std::vector<RopeTable> g_rope_tables;
+int rope_table(float base, float scale, int half, int need, const float** cos_t, const float** sin_t) {
+    for (auto& t : g_rope_tables)
+        if (t.base == base && t.scale == scale && t.half == half) {
+            if (t.cap < need) {
+                // (the old tables may still be read by launches in flight: they are left to the stream's order and freed behind it)
+                OMX_HIP_CHECK(hipStreamSynchronize(g_stream));
+                (void)hipFree(t.cos_t); (void)hipFree(t.sin_t);
+                t.cap = 0; t.cos_t = t.sin_t = nullptr;
+            } else {
+                *cos_t = t.cos_t; *sin_t = t.sin_t;
+                return 0;
+            }
+        }
+    int cap = 4096;
+    while (cap < need) cap *= 2;
+    RopeTable* t = nullptr;
+    for (auto& e : g_rope_tables)
+        if (e.base == base && e.scale == scale && e.half == half) t = &e;
+    if (!t) { g_rope_tables.push_back(RopeTable{base, scale, half, 0, nullptr, nullptr}); t = &g_rope_tables.back(); }
+    OMX_HIP_CHECK(hipMalloc((void**)&t->cos_t, (size_t)cap * half * 4));
+    OMX_HIP_CHECK(hipMalloc((void**)&t->sin_t, (size_t)cap * half * 4));
+    const int n = cap * half;
+    lazy_rope_table_kernel<<<(n + 255) / 256, 256, 0, g_stream>>>(t->cos_t, t->sin_t, cap, half, -log((double)base) / (double)half, (double)scale);
+    OMX_LAUNCH_CHECK();
+    t->cap = cap;
+    *cos_t = t->cos_t; *sin_t = t->sin_t;
+    return 0;
+}
+
+int run_scatter(std::vector<Rec>& recs, const ScatterPlan& p) {
+    using namespace omx;
+    const Rec &nq = recs[p.nq], &nk = recs[p.nk], &rq = recs[p.rq], &uk = recs[p.uk], &uv = recs[p.uv];
+    const float *cs = nullptr, *sn = nullptr;
+    if (rope_table(rq.f0, rq.f1, p.D / 2, p.offset + p.T, &cs, &sn)) return 1;
+    const bf16_t *ql, *kl, *vl;
+    if (p.qkv) {
+        ql = (const bf16_t*)p.qkv->ptr();
+        kl = ql + p.nq_rows;
+        vl = kl + p.nk_rows;
+    } else {
+        ql = (const bf16_t*)nq.a[1].ptr(); kl = (const bf16_t*)nk.a[1].ptr(); vl = (const bf16_t*)uv.a[1].ptr();
+    }
+    bf16_t* kc = (bf16_t*)uk.a[0].ptr() - (size_t)p.offset * p.D;
+    bf16_t* vc = (bf16_t*)uv.a[0].ptr() - (size_t)p.offset * p.D;
+    return launch_qk_norm_rope_scatter(ql, kl, vl, (const bf16_t*)nq.a[2].ptr(), (const bf16_t*)nk.a[2].ptr(), cs, sn, (bf16_t*)rq.a[0].ptr(), kc, vc,
+                                       p.T, p.H, p.Hkv, p.D, p.cap, p.offset, nq.f0, g_stream, false);
+}
+
+int run_plan(std::vector<Rec>& recs, const FusePlan& p) {
+    using namespace omx;
+    if (p.is_scatter) return run_scatter(recs, p.sc);
+    const Rec& m0 = recs[p.mm0];
+    GemvArgs g = {};
+    const int K = m0.i1, N = m0.i0;
+    g.w0 = (const bf16_t*)m0.a[2].ptr();
+    g.n0 = N; g.N = N; g.K = K;
+    if (p.norm >= 0) {
+        const Rec& nr = recs[p.norm];
+        g.x = (const bf16_t*)nr.a[1].ptr();
+        g.norm_w = (const bf16_t*)nr.a[2].ptr();
+        g.eps = nr.f0;
+    } else {
+        g.x = (const bf16_t*)m0.a[1].ptr();
+    }
+    Arr slots;
+    if (p.stack_out) {         // q | k | v rows in one launch, into one fresh buffer
+        const Rec &mk = recs[p.mmk], &mv = recs[p.mmv];
+        g.w1 = (const bf16_t*)mk.a[2].ptr(); g.n1 = mk.i0;
+        g.w2 = (const bf16_t*)mv.a[2].ptr(); g.n2 = mv.i0;
+        g.N = N + mk.i0 + mv.i0;
+        Arr* t = new_arr({g.N}, MLX_BFLOAT16);
+        if (!t) return set_error("deferred q | k | v projection: out of device memory");
+        *p.stack_out = *t;
+        delete t;
+        g.out = p.stack_out->ptr();
+        return launch_gemv(g, p.norm >= 0 ? PRO_RMSNORM : PRO_NONE, EPI_STORE, g_stream);
+    }
+    if (p.epi == EPI_SWIGLU) {
+        g.w1 = (const bf16_t*)recs[p.mm1].a[2].ptr();
+        g.n1 = N;
+        g.out = recs[p.tail].a[0].ptr();
+    } else if (p.epi == EPI_RESIDUAL) {
+        g.resid = (const bf16_t*)recs[p.tail].a[p.resid_operand].ptr();
+        g.out = recs[p.tail].a[0].ptr();
+    } else if (p.epi == EPI_ARGMAX && p.norm < 0) {    // (no argmax epilogue without the norm prologue in the family: product, then the recorded argmax)
+        g.out = m0.a[0].ptr();
+        if (launch_gemv(g, PRO_NONE, EPI_STORE, g_stream)) return 1;
+        return recs[p.tail].run(recs[p.tail]);
+    } else if (p.epi == EPI_ARGMAX) {
+        const int nslot = gemv_grid(N, K, EPI_ARGMAX, 0);
+        Arr* s = new_arr({nslot * 2}, MLX_UINT32);
+        if (!s) return set_error("deferred lm_head: out of device memory");
+        slots = *s;
+        delete s;
+        g.argmax_slot = (unsigned long long*)slots.ptr();
+        g.out = m0.a[0].ptr();                       // the logits row is written too (it may be read later)
+        if (launch_gemv(g, p.norm >= 0 ? PRO_RMSNORM : PRO_NONE, EPI_ARGMAX, g_stream)) return 1;
+        lazy_argmax_finalize_kernel<<<1, 256, 0, g_stream>>>((uint32_t*)recs[p.tail].a[0].ptr(), (const unsigned long long*)slots.ptr(), nslot);
+        OMX_LAUNCH_CHECK();
+        return 0;
+    } else {
+        g.out = m0.a[0].ptr();
+    }
+    return launch_gemv(g, p.norm >= 0 ? PRO_RMSNORM : PRO_NONE, p.epi, g_stream);
+}
+
+// the peephole pass: fills `plans` (keyed by the record index that launches them) and marks absorbed records dead
+void fuse_pending(std::vector<Rec>& recs, std::unordered_map<int, FusePlan>& plans) {
+    using namespace omx;
+    const int n = (int)recs.size();
+    std::unordered_map<const Buf*, int> nref;                  // references the pending list holds on each buffer
+    std::unordered_map<const Buf*, int> prod;                  // the one pending record that writes a buffer (-2: several)
+    std::unordered_map<const Buf*, std::vector<int>> readers;  // pending records reading it
+    bool any_mm = false;
+    for (int i = 0; i < n; ++i) {
+        const Rec& r = recs[i];
+        for (int k = 0; k < r.na; ++k)
+            if (r.a[k].buf) ++nref[r.a[k].buf.get()];
+        if (r.na && r.a[0].buf) {
+            auto it = prod.find(r.a[0].buf.get());
+            if (it == prod.end()) prod[r.a[0].buf.get()] = i; else it->second = -2;
+        }
+        for (int k = 1; k < r.na; ++k)
+            if (r.a[k].buf) {
+                auto& v = readers[r.a[k].buf.get()];
+                if (v.empty() || v.back() != i) v.push_back(i);
+            }
+        any_mm = any_mm || (r.kind == RK_MATMUL && r.flag);
+    }
+    if (!any_mm) return;
+    auto internal = [&](const Arr& x) {   // nothing outside the pending list can see this buffer
+        return x.buf && x.buf->owned && (long)x.buf.use_count() == (long)nref[x.buf.get()];
+    };
+    auto producer = [&](const Arr& x, int before) -> int {
+        if (!x.buf) return -1;
+        auto it = prod.find(x.buf.get());
+        if (it == prod.end() || it->second < 0 || it->second >= before) return -1;
+        return same_view(recs[it->second].a[0], x) ? it->second : -1;
+    };
+    auto producer_of_buf = [&](const Arr& x) -> int {      // the record whose result this is a re-shaped / transposed view of
+        if (!x.buf) return -1;
+        auto it = prod.find(x.buf.get());
+        if (it == prod.end() || it->second < 0) return -1;
+        const Arr& o = recs[it->second].a[0];
+        return (o.off == x.off && o.size() == x.size()) ? it->second : -1;
+    };
+    auto only_readers = [&](const Arr& x, std::initializer_list<int> who) {
+        auto it = readers.find(x.buf.get());
+        if (it == readers.end()) return who.size() == 0;
+        for (int r : it->second) {
+            bool ok = false;
+            for (int w : who) ok = ok || r == w;
+            if (!ok) return false;
+        }
+        return true;
+    };
+    auto gemv_rec = [&](int i) { return i >= 0 && recs[i].kind == RK_MATMUL && recs[i].flag && !recs[i].dead; };
+    std::vector<int> plan_of(n, -1);       // matmul record -> the record index its plan is keyed by
+    // ---- epilogues, found from the record that ends the idiom ----
+    for (int j = 0; j < n; ++j) {
+        Rec& r = recs[j];
+        if (r.dead) continue;
+        if (r.kind == RK_MUL && r.flag) {
+            // act = (g * sigmoid(g)) * u, either operand order at both levels
+            for (int sw = 0; sw < 2; ++sw) {
+                const int m2 = producer(r.a[1 + sw], j), U = producer(r.a[2 - sw], j);
+                if (m2 < 0 || !gemv_rec(U) || recs[m2].kind != RK_MUL || !recs[m2].flag || recs[m2].dead) continue;
+                int G = -1, S = -1;
+                for (int sw2 = 0; sw2 < 2 && G < 0; ++sw2) {
+                    const int g0 = producer(recs[m2].a[1 + sw2], m2), s0 = producer(recs[m2].a[2 - sw2], m2);
+                    if (gemv_rec(g0) && s0 >= 0 && recs[s0].kind == RK_SIGMOID && !recs[s0].dead && same_view(recs[s0].a[1], recs[g0].a[0])) { G = g0; S = s0; }
+                }
+                if (G < 0 || G == U || plan_of[G] >= 0 || plan_of[U] >= 0) continue;
+                const Rec &rg = recs[G], &ru = recs[U];
+                if (rg.i0 != ru.i0 || rg.i1 != ru.i1 || !same_view(rg.a[1], ru.a[1])) continue;
+                if (rg.i0 % 4 != 0) continue;
+                if (!internal(rg.a[0]) || !internal(ru.a[0]) || !internal(recs[S].a[0]) || !internal(recs[m2].a[0])) continue;
+                if (!only_readers(rg.a[0], {S, m2}) || !only_readers(ru.a[0], {j}) || !only_readers(recs[S].a[0], {m2}) || !only_readers(recs[m2].a[0], {j})) continue;
+                FusePlan p;
+                p.at = j; p.mm0 = G; p.mm1 = U; p.epi = EPI_SWIGLU; p.tail = j;
+                plans[j] = p;
+                plan_of[G] = plan_of[U] = j;
+                recs[G].dead = recs[U].dead = recs[S].dead = recs[m2].dead = true;
+                break;
+            }
+        } else if (r.kind == RK_ADD && r.flag) {
+            for (int sw = 0; sw < 2; ++sw) {
+                const int M = producer(r.a[2 - sw], j);
+                if (!gemv_rec(M) || plan_of[M] >= 0) continue;
+                if (!internal(recs[M].a[0]) || !only_readers(recs[M].a[0], {j})) continue;
+                if (r.a[1 + sw].size() != (size_t)recs[M].i0) continue;
+                FusePlan p;
+                p.at = j; p.mm0 = M; p.epi = EPI_RESIDUAL; p.tail = j; p.resid_operand = 1 + sw;
+                plans[j] = p;
+                plan_of[M] = j;
+                recs[M].dead = true;
+                break;
+            }
+        } else if (r.kind == RK_ARGMAX && r.flag) {
+            const int M = producer(r.a[1], j);
+            if (!gemv_rec(M) || plan_of[M] >= 0 || !only_readers(recs[M].a[0], {j})) continue;
+            FusePlan p;
+            p.at = j; p.mm0 = M; p.epi = EPI_ARGMAX; p.tail = j;
+            plans[j] = p;
+            plan_of[M] = j;
+            recs[M].dead = true;
+        }
+    }
+    // ---- the remaining M == 1 products launch as plain GEMVs at their own position (so that they can take a prologue) ----
+    for (int i = 0; i < n; ++i)
+        if (gemv_rec(i) && plan_of[i] < 0) {
+            FusePlan p;
+            p.at = i; p.mm0 = i; p.epi = EPI_STORE;
+            plans[i] = p;
+            plan_of[i] = i;
+        }
+    // ---- attention preparation: anchored at the SDPA record.  q <- rope <- rms_norm(q_norm) <- [1, H, T, D] view of the q projection;
+    //      the k operand's buffer is written by a slice_update whose update is rope <- rms_norm(k_norm) <- view of the k projection, the
+    //      v operand's by a slice_update of the v projection's view (KVCache::update_and_fetch, cache.rs:140-193) ----
+    std::unordered_map<const Buf*, int> writer;          // last pending slice_update into a buffer
+    for (int i = 0; i < n; ++i)
+        if (recs[i].kind == RK_SLICE_UPDATE && recs[i].a[0].buf) writer[recs[i].a[0].buf.get()] = i;
+    auto headed_view = [&](const Arr& v, int heads, int T, int D) {   // [1, heads, T, D] over row-major [1, T, heads * D]
+        return v.shape.size() == 4 && v.shape[0] == 1 && v.shape[1] == heads && v.shape[2] == T && v.shape[3] == D && v.strides[3] == 1 &&
+               v.strides[1] == (size_t)D && (T == 1 || v.strides[2] == (size_t)heads * D) && v.dt == MLX_BFLOAT16;
+    };
+    for (int j = 0; j < n; ++j) {
+        Rec& sd = recs[j];
+        if (sd.kind != RK_SDPA || sd.dead) continue;
+        const Arr &q2 = sd.a[1], &kv = sd.a[2], &vv = sd.a[3];
+        if (q2.shape.size() != 4 || q2.dt != MLX_BFLOAT16) continue;
+        const int H = q2.shape[1], T = q2.shape[2], D = q2.shape[3], Hkv = kv.shape[1];
+        if ((D != 64 && D != 128) || q2.shape[0] != 1) continue;
+        ScatterPlan sp;
+        sp.rq = producer(q2, j);
+        auto wk = writer.find(kv.buf.get()), wv = writer.find(vv.buf.get());
+        if (sp.rq < 0 || wk == writer.end() || wv == writer.end()) continue;
+        sp.uk = wk->second; sp.uv = wv->second;
+        if (sp.uk >= j || sp.uv >= j || recs[sp.uk].dead || recs[sp.uv].dead) continue;
+        const Rec &rq = recs[sp.rq], &uk = recs[sp.uk], &uv = recs[sp.uv];
+        if (rq.kind != RK_ROPE || !rq.flag || rq.dead || !is_contig(rq.a[0])) continue;
+        sp.rk = producer(uk.a[1], sp.uk);
+        if (sp.rk < 0 || recs[sp.rk].kind != RK_ROPE || !recs[sp.rk].flag || recs[sp.rk].dead) continue;
+        const Rec& rk = recs[sp.rk];
+        sp.nq = producer(rq.a[1], sp.rq);
+        sp.nk = producer(rk.a[1], sp.rk);
+        if (sp.nq < 0 || sp.nk < 0) continue;
+        const Rec &nq = recs[sp.nq], &nk = recs[sp.nk];
+        if (nq.kind != RK_RMSNORM || nk.kind != RK_RMSNORM || nq.dead || nk.dead || nq.na < 3 || nk.na < 3 || nq.i0 != D || nk.i0 != D || nq.f0 != nk.f0) continue;
+        if (!is_contig(nq.a[2]) || !is_contig(nk.a[2]) || nq.a[2].dt != MLX_BFLOAT16 || nk.a[2].dt != MLX_BFLOAT16) continue;
+        // rope: the plain rotate-half form over the whole head, both at the position the cache write starts at
+        if (rq.i0 != D || rk.i0 != D || rq.i1 || rk.i1 || rq.i2 != rk.i2 || rq.f0 != rk.f0 || rq.f1 != rk.f1 || rq.f0 <= 0.f) continue;
+        if (!headed_view(nq.a[1], H, T, D) || !headed_view(nk.a[1], Hkv, T, D) || !headed_view(uv.a[1], Hkv, T, D)) continue;
+        // the cache regions: [1, Hkv, T, D] at token rq.i2 of a row-major [1, Hkv, cap, D]
+        auto region_ok = [&](const Arr& r, int* cap) {
+            if (r.shape.size() != 4 || r.shape[0] != 1 || r.shape[1] != Hkv || r.shape[2] != T || r.shape[3] != D || r.strides[3] != 1 ||
+                r.strides[2] != (size_t)D || r.strides[1] % (size_t)D != 0 || r.dt != MLX_BFLOAT16) return false;
+            *cap = (int)(r.strides[1] / (size_t)D);
+            return r.off >= (size_t)rq.i2 * D * 2 && *cap >= rq.i2 + T;
+        };
+        int capk = 0, capv = 0;
+        if (!region_ok(uk.a[0], &capk) || !region_ok(uv.a[0], &capv) || capk != capv) continue;
+        if (kv.strides[1] != (size_t)capk * D || vv.strides[1] != (size_t)capk * D) continue;     // the operands ARE those caches
+        if (kv.off + (size_t)rq.i2 * D * 2 != uk.a[0].off || vv.off + (size_t)rq.i2 * D * 2 != uv.a[0].off) continue;
+        // nothing outside may see the values that stop existing: the two normalised rows and the rotated k
+        if (!internal(nq.a[0]) || !internal(nk.a[0]) || !internal(rk.a[0])) continue;
+        if (!only_readers(nq.a[0], {sp.rq}) || !only_readers(nk.a[0], {sp.rk}) || !only_readers(rk.a[0], {sp.uk})) continue;
+        sp.T = T; sp.H = H; sp.Hkv = Hkv; sp.D = D; sp.cap = capk; sp.offset = rq.i2;
+        const int at = std::max(std::max(sp.rq, sp.rk), std::max(sp.uk, sp.uv));
+        // the three projections as one row-stacked launch: plain GEMV plans on one activation, nobody else reading their rows
+        const int Mq = producer_of_buf(nq.a[1]), Mk = producer_of_buf(nk.a[1]), Mv = producer_of_buf(uv.a[1]);
+        if (Mq >= 0 && Mk >= 0 && Mv >= 0 && gemv_rec(Mq) && gemv_rec(Mk) && gemv_rec(Mv) && plan_of[Mq] == Mq && plan_of[Mk] == Mk && plan_of[Mv] == Mv &&
+            plans[Mq].epi == EPI_STORE && plans[Mk].epi == EPI_STORE && plans[Mv].epi == EPI_STORE && same_view(recs[Mq].a[1], recs[Mk].a[1]) &&
+            same_view(recs[Mq].a[1], recs[Mv].a[1]) && recs[Mq].i1 == recs[Mk].i1 && recs[Mq].i1 == recs[Mv].i1 && recs[Mq].i0 == H * D &&
+            recs[Mk].i0 == Hkv * D && recs[Mv].i0 == Hkv * D && T == 1 && internal(recs[Mq].a[0]) && internal(recs[Mk].a[0]) && internal(recs[Mv].a[0]) &&
+            only_readers(recs[Mq].a[0], {sp.nq}) && only_readers(recs[Mk].a[0], {sp.nk}) && only_readers(recs[Mv].a[0], {sp.uv})) {
+            const int last = std::max(Mq, std::max(Mk, Mv));
+            FusePlan st = plans[Mq];
+            plans.erase(Mq); plans.erase(Mk); plans.erase(Mv);
+            st.at = last; st.mm0 = Mq; st.mmk = Mk; st.mmv = Mv;
+            st.stack_out = std::make_shared<Arr>();
+            sp.qkv = st.stack_out; sp.nq_rows = H * D; sp.nk_rows = Hkv * D;
+            plans[last] = st;
+            plan_of[Mq] = plan_of[Mk] = plan_of[Mv] = last;
+            for (int m : {Mq, Mk, Mv})
+                if (m != last) recs[m].dead = true;
+        }
+        FusePlan fp;
+        fp.at = at; fp.is_scatter = true; fp.sc = sp;
+        for (int d : {sp.nq, sp.nk, sp.rq, sp.rk, sp.uk, sp.uv})
+            if (d != at) recs[d].dead = true;
+        plans[at] = fp;
+    }
+    // ---- prologues: an RMSNorm whose result only GEMV plans read, all over the whole row, moves into them ----
+    for (int i = 0; i < n; ++i) {
+        Rec& r = recs[i];
+        if (r.kind != RK_RMSNORM || !r.flag || r.dead || !internal(r.a[0])) continue;
+        auto it = readers.find(r.a[0].buf.get());
+        if (it == readers.end() || it->second.empty()) continue;
+        bool ok = true;
+        for (int c : it->second) {
+            const Rec& m = recs[c];
+            ok = ok && m.kind == RK_MATMUL && m.flag && plan_of[c] >= 0 && same_view(m.a[1], r.a[0]) && m.i1 == r.i0 && gemv_k_supported(m.i1, true) &&
+                 plans[plan_of[c]].epi != EPI_RESIDUAL;   // (the family has no norm prologue + residual epilogue form)
+        }
+        if (!ok) continue;
+        for (int c : it->second) plans[plan_of[c]].norm = i;
+        r.dead = true;
+    }
+}
+
+}  // namespace
+
+// execute everything recorded so far, in order, on the handle layer's stream
+int flush_pending() {
+    if (g_pending.empty()) return 0;
+    std::vector<Rec> recs;
+    recs.swap(g_pending);
+    g_n_pending = 0;
+    ++g_lazy_busy;
+    ++g_flush_seq;
+    ++g_lazy_stats[3];
+    const auto t_begin = std::chrono::steady_clock::now();
+    std::unordered_map<int, FusePlan> plans;
+    static const bool no_fuse = [] { const char* e = getenv("OMX_MLX_FUSE"); return e && e[0] == '0'; }();
+    if (!no_fuse) fuse_pending(recs, plans);
+    g_lazy_stats[5] += (long)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_begin).count();
+    int rc = 0;
+    for (int i = 0; i < (int)recs.size() && !rc; ++i) {
+        Rec& r = recs[i];
+        auto it = plans.find(i);
+        if (it != plans.end()) {
+            rc = run_plan(recs, it->second);
+            ++g_lazy_stats[2];
+        } else if (!r.dead) {
+            rc = r.run(r);
+            ++g_lazy_stats[1];
+        } else {
+            continue;
+        }
+        if (r.na && r.a[0].buf) r.a[0].buf->seq = g_flush_seq;
+    }
+    if (!rc) {
+        hipEvent_t& ev = g_flush_ev[g_flush_seq % kEvRing];
+        if (!ev && hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) ev = nullptr;
+        if (ev) (void)hipEventRecord(ev, g_stream);
+    }
+    --g_lazy_busy;
+    recs.clear();        // (drops the records' references: dead intermediates return to the pool here)
+    if (rc) g_deferred_failed = true;
+    g_lazy_stats[4] += (long)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_begin).count();
+    return rc;
+}

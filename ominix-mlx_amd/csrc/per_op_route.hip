@@ -1,6 +1,7 @@
 // The DROP-IN route, measured (VERDICT r4 "Next" 5): what an UNMODIFIED qwen3-mlx gets from this library -- no fused engine, every mlx-rs
-// call of Model::forward + Generate::next arriving as one mlx_* call on the handle ABI (include/omx_mlx_c.h), executed eagerly
-// (mlx_async_eval is a no-op here: /root/reference/mlx-rs/src/transforms/mod.rs:67-85 has nothing to defer to).
+// call of Model::forward + Generate::next arriving as one mlx_* call on the handle ABI (include/omx_mlx_c.h).  Round 6: the handle layer
+// records those calls and executes them at mlx_async_eval / item (mlxc_lazy.hpp, the ABI's own contract: /root/reference/mlx-rs/src/
+// transforms/mod.rs:67-85), rewriting the decode idioms onto the engine's GEMV family; OMX_MLX_LAZY=0 is round 5's eager execution.
 //   replayed, call for call:  qwen3-mlx/src/model.rs:161-215 (Attention::forward: q / k / v = nn::Linear = x.matmul(w.t()), reshape +
 //   transpose_axes, q_norm / k_norm, nn::Rope, KVCache::update_and_fetch = cache.rs:140-193, fast::scaled_dot_product_attention, o_proj),
 //   :263-267 (Mlp: down(silu(gate(x)) * up(x)), silu = x * sigmoid(x)), :314-340 (block: two rms_norm + two adds), :387-433 (Model::forward:
@@ -147,11 +148,10 @@ extern "C" int omx_bench_qwen3_per_op(omx_qwen3 model, const omx_qwen3_config* c
     std::vector<KvCache> cache(L);
     const float scale = 1.0f / sqrtf((float)D);
 
-    // Model::forward on `n` new token ids -> the sampled token of the LAST position (Generate::next)
-    auto step = [&](const uint32_t* ids, int n, uint32_t* tok) -> int {
-        const int sh[2] = {1, n};
-        mlx_array idx = P.keep(mlx_array_new_data(ids, sh, 2, MLX_UINT32));
-        ++P.calls;
+    // Model::forward on the token ids `idx` ([1, n], on the device) -> y = sample(logits of the LAST position) as a device array
+    // (model.rs:387-433 + sampler at temperature 0).  forward's temporaries are dropped before this returns, like Rust drops them at
+    // the end of their scopes -- i.e. BEFORE the caller's async_eval: an intermediate nobody holds may then be fused away (mlxc_lazy.hpp).
+    auto forward_sample = [&](mlx_array idx, int n, mlx_array* y) -> int {
         mlx_array h = P.take_axis(embed, idx, 0);                                   // Embedding::forward -> [1, n, hidden]
         const char* mode = n > 1 ? "causal" : "";                                    // create_attention_mask (utils.rs:156-188)
         for (int l = 0; l < L; ++l) {
@@ -179,23 +179,57 @@ extern "C" int omx_bench_qwen3_per_op(omx_qwen3 model, const omx_qwen3_config* c
         mlx_array hf = P.rms_norm(h, final_norm, cfg->rms_norm_eps);
         mlx_array logits = P.linear(hf, cfg->tie_word_embeddings ? embed : head);     // all n positions, like the reference (model.rs:815 keeps the last)
         if (n > 1) logits = P.slice(logits, {0, n - 1, 0}, {1, n, V});
-        mlx_array t = P.argmax(logits);
+        mlx_array t = P.argmax(logits);                                               // [1, 1]
+        if (P.failed) return 1;
+        *y = mlx_array_new();
         ++P.calls;
-        if (P.failed || mlx_array_item_uint32(tok, t)) return 1;                     // token.item(): the one synchronisation per token
+        if (mlx_array_set(y, t)) return 1;                                            // the one array that leaves forward
         P.sweep();
         return 0;
     };
+    auto async_eval = [&](mlx_array y) -> int {
+        mlx_vector_array v = mlx_vector_array_new();
+        mlx_vector_array_append_value(v, y);
+        P.calls += 3;
+        const int rc = mlx_async_eval(v);
+        mlx_vector_array_free(v);
+        return rc;
+    };
+    // Generate::next (model.rs:804-843): the step after the one being returned is recorded and sent before the caller reads a token
     uint32_t tok = 0;
     auto t0 = std::chrono::steady_clock::now();
-    rc = step(prompt, n_prompt, &tok);
+    mlx_array prefetched{nullptr};
+    {
+        const int sh[2] = {1, n_prompt};
+        mlx_array idx = mlx_array_new_data(prompt, sh, 2, MLX_UINT32);
+        ++P.calls;
+        mlx_array y{nullptr};
+        rc = forward_sample(idx, n_prompt, &y) || async_eval(y);
+        mlx_array_free(idx);
+        if (!rc) rc = forward_sample(y, 1, &prefetched) || async_eval(prefetched);      // compute_next(&y): y is [1, 1] already
+        ++P.calls;
+        if (!rc) rc = mlx_array_item_uint32(&tok, y);                                   // eval([&y]) + the caller's token.item()
+        if (y.ctx) mlx_array_free(y);
+        tokens_out[0] = tok;
+    }
     auto t1 = std::chrono::steady_clock::now();
     long calls0 = P.calls;
-    if (!rc) {
-        tokens_out[0] = tok;
-        for (int i = 1; i <= n_new && !rc; ++i) {
-            rc = step(&tok, 1, &tok);
-            tokens_out[i] = tok;
-        }
+    for (int i = 1; i <= n_new && !rc; ++i) {
+        mlx_array current = prefetched, next{nullptr};
+        prefetched = mlx_array{nullptr};
+        rc = forward_sample(current, 1, &next) || async_eval(next);
+        prefetched = next;
+        ++P.calls;
+        if (!rc) rc = mlx_array_item_uint32(&tok, current);                             // the caller's token.item() on the step BEFORE the one just sent
+        mlx_array_free(current);
+        tokens_out[i] = tok;
+    }
+    if (prefetched.ctx) {
+        mlx_vector_array v = mlx_vector_array_new();
+        mlx_vector_array_append_value(v, prefetched);
+        (void)mlx_eval(v);
+        mlx_vector_array_free(v);
+        mlx_array_free(prefetched);
     }
     auto t2 = std::chrono::steady_clock::now();
     if (prefill_ms) *prefill_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();

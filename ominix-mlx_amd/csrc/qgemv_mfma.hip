@@ -353,11 +353,11 @@ int launch_qgemv4m_repack(uint32_t* tiles, const uint32_t* wq, const bf16_t* sca
     return 0;
 }
 
-int g_qgemv_mfma_mode = -1;   // -1: read OMX_QGEMV_MFMA at first use (0 = off); tests flip it through omx_debug_qgemv_mfma
+int g_qgemv_mfma_mode = 1;    // 0: never (tests flip it through omx_debug_qgemv_mfma); otherwise a matrix with tiles takes this kernel --
+                              // OMX_QGEMV_MFMA=0 makes the engine (and the bench hook) build no tiles
 
 // 0: launched; -1: not a shape / form of this kernel (the caller takes quant.hip's VALU kernel); 1: error
 int launch_qgemv4m(const QGemvArgs& a, int pro, int epi, hipStream_t s) {
-    if (g_qgemv_mfma_mode < 0) { const char* e = getenv("OMX_QGEMV_MFMA"); g_qgemv_mfma_mode = (e && e[0] == '0') ? 0 : 1; }
     if (g_qgemv_mfma_mode == 0 || a.group != 64 || a.scales_f16 || a.n_batch > 1 || a.w_sel || a.w_sel_n > 0 || a.N < 16) return -1;
     if (a.K != 4096 && a.K != 12288) return -1;
     for (int i = 0; i < 3; ++i)
@@ -374,5 +374,5 @@ int launch_qgemv4m(const QGemvArgs& a, int pro, int epi, hipStream_t s) {
 
 }  // namespace omx
 
-/* test / A-B hook: 1 = the matrix-core kernel where it applies (default), 0 = quant.hip's VALU kernel everywhere, -1 = re-read OMX_QGEMV_MFMA */
+/* test / A-B hook: 1 (or -1) = the matrix-core kernel wherever a matrix has tiles (default), 0 = quant.hip's VALU kernel everywhere */
 extern "C" void omx_debug_qgemv_mfma(int on) { omx::g_qgemv_mfma_mode = on; }

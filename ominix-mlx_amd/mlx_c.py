@@ -396,6 +396,7 @@ SIGNATURES = {
     "mlx_conv2d": (c_int, [P_ARR, mlx_array, mlx_array, c_int, c_int, c_int, c_int, c_int, c_int, c_int, mlx_stream]),
     "mlx_gather_mm": (c_int, [P_ARR, mlx_array, mlx_array, mlx_array, mlx_array, c_bool, mlx_stream]),
     "omx_mlx_array_from_device": (mlx_array, [ctypes.c_void_p, P_INT, c_int, c_int]),
+    "omx_mlx_lazy_stats": (None, [ctypes.POINTER(ctypes.c_long)]),
     "omx_mlx_fused_swiglu": (c_int, [P_ARR, mlx_array, mlx_array, mlx_stream]),
     "omx_mlx_fused_modulate": (c_int, [P_ARR, mlx_array, mlx_array, mlx_array, mlx_stream]),
 }

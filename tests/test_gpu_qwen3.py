@@ -895,8 +895,12 @@ def test_packed_oproj_in_attention_launch_is_bit_identical(omx, monkeypatch, nam
     """4-bit checkpoint: the packed O matrix rides in the attention launch too (csrc/attn_step.hip oproj_phase_q4: the rows' nibbles and
     scale | bias words prefetched into registers, the attention vector re-paired in LDS the way quant.hip's prologue stores it).  Same
     tokens and bit-equal logits as the separate packed GEMV (OMX_ATTN_OPROJ=0), graph and eager, across a context-bucket boundary;
-    the two-launch form is the one test_quantized_checkpoint_decode_matches_oracle holds against the oracle."""
+    the two-launch form is the one test_quantized_checkpoint_decode_matches_oracle holds against the oracle.
+    Round 6: bit-equality is a property of the two VALU forms (same fma chains) -- the separate GEMV of a K = 4096 matrix would otherwise
+    run on the matrix cores (csrc/qgemv_mfma.hip, its own accumulation order; held against the oracle in test_gpu_quant.py), so the
+    comparison pins OMX_QGEMV_MFMA=0."""
     from ominix_mlx_amd import engine
+    monkeypatch.setenv("OMX_QGEMV_MFMA", "0")
     cfg = OPROJ_CONFIGS[name]
     prompt = synth.prompt_ids(1000, cfg.vocab_size)
     outs = {}

@@ -319,6 +319,9 @@ mlx_array omx_mlx_array_from_device(const void* device_ptr, const int* shape, in
 /* omx extension (round 6): counters of the deferred op list behind this ABI (csrc/mlxc_lazy.hpp) -- out6[0] ops recorded, [1] launched as
  * recorded, [2] fused GEMV launches that replaced several of them, [3] flushes, [4] host ns inside the flushes, [5] of which in the rewrite pass.  OMX_MLX_LAZY=0 executes every call eagerly (round 5). */
 void omx_mlx_lazy_stats(long* out6);
+/* ... and its switches at run time: lazy 0 = every call launches as it is made, fuse 0 = recorded ops launch as recorded (default 1, 1;
+ * OMX_MLX_LAZY / OMX_MLX_FUSE in the environment set the initial state) */
+int omx_mlx_lazy_mode(int lazy, int fuse);
 int omx_mlx_fused_swiglu(mlx_array* res, const mlx_array x, const mlx_array gate, const mlx_stream s);
 int omx_mlx_fused_modulate(mlx_array* res, const mlx_array x, const mlx_array shift, const mlx_array scale,
                            const mlx_stream s);

@@ -97,7 +97,7 @@ struct Arr {
     bool donated = false;           // its buffer was updated in place on behalf of a slice_update result (see there)
     size_t size() const { size_t n = 1; for (int d : shape) n *= (size_t)d; return n; }
     char* ptr() const {
-        if (g_n_pending && !g_lazy_busy) (void)flush_pending();
+        if (g_n_pending && !g_lazy_busy && flush_pending()) g_deferred_failed = true;   // (no status to return here: the next evaluation point reports it)
         return (char*)buf->p + off;
     }
 };
@@ -629,6 +629,15 @@ int mlx_eval(const mlx_vector_array) {
 }
 /* omx extension: counters of the deferred list -- [0] ops recorded, [1] launched as recorded, [2] fused GEMV launches, [3] flushes, [4] host ns in flushes, [5] ns of the rewrite pass
  * (bench.py per_op_route; tests assert that the decode idioms really fuse) */
+/* omx extension: switch the deferred list at run time (tests compare the three forms in one process).  lazy 0: every call launches as it
+ * is made (round 5); fuse 0: recorded ops are launched as recorded.  Whatever is pending is executed first. */
+int omx_mlx_lazy_mode(int lazy, int fuse) {
+    if (flush_pending()) return 1;
+    g_lazy_on = lazy != 0;
+    g_lazy_env_read = true;
+    g_fuse_mode = fuse != 0;
+    return 0;
+}
 void omx_mlx_lazy_stats(long* out6) { for (int i = 0; i < 6; ++i) out6[i] = g_lazy_stats[i]; }
 int mlx_clear_cache(void) {
     if (flush_pending()) return 1;

@@ -45,6 +45,7 @@ struct Rec {
 
 std::vector<Rec> g_pending;
 bool g_lazy_on = true, g_lazy_env_read = false;
+int g_fuse_mode = -1;             // -1: OMX_MLX_FUSE at the first flush; 0 / 1 set through omx_mlx_lazy_mode
 long g_lazy_stats[6] = {0, 0, 0, 0, 0, 0};   // recorded, launched, fused launches, flushes, ns spent in flushes (host), ns of them in the peephole pass
 
 bool lazy_enabled() {
@@ -445,8 +446,8 @@ int flush_pending() {
     ++g_lazy_stats[3];
     const auto t_begin = std::chrono::steady_clock::now();
     std::unordered_map<int, FusePlan> plans;
-    static const bool no_fuse = [] { const char* e = getenv("OMX_MLX_FUSE"); return e && e[0] == '0'; }();
-    if (!no_fuse) fuse_pending(recs, plans);
+    if (g_fuse_mode < 0) { const char* e = getenv("OMX_MLX_FUSE"); g_fuse_mode = (e && e[0] == '0') ? 0 : 1; }
+    if (g_fuse_mode) fuse_pending(recs, plans);
     g_lazy_stats[5] += (long)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_begin).count();
     int rc = 0;
     for (int i = 0; i < (int)recs.size() && !rc; ++i) {
@@ -470,7 +471,6 @@ int flush_pending() {
     }
     --g_lazy_busy;
     recs.clear();        // (drops the records' references: dead intermediates return to the pool here)
-    if (rc) g_deferred_failed = true;
     g_lazy_stats[4] += (long)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_begin).count();
     return rc;
 }

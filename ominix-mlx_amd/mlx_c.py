@@ -397,6 +397,7 @@ SIGNATURES = {
     "mlx_gather_mm": (c_int, [P_ARR, mlx_array, mlx_array, mlx_array, mlx_array, c_bool, mlx_stream]),
     "omx_mlx_array_from_device": (mlx_array, [ctypes.c_void_p, P_INT, c_int, c_int]),
     "omx_mlx_lazy_stats": (None, [ctypes.POINTER(ctypes.c_long)]),
+    "omx_mlx_lazy_mode": (c_int, [c_int, c_int]),
     "omx_mlx_fused_swiglu": (c_int, [P_ARR, mlx_array, mlx_array, mlx_stream]),
     "omx_mlx_fused_modulate": (c_int, [P_ARR, mlx_array, mlx_array, mlx_array, mlx_stream]),
 }
@@ -1052,3 +1053,24 @@ def kron(a, b): return Array.op(lib.mlx_kron, a.h, b.h, default_stream())
 def random_bernoulli(p, shape, key):
     ps, n = _ints(shape)
     return Array.op(lib.mlx_random_bernoulli, p.h, ps, n, key.h, default_stream())
+
+
+def lazy_stats() -> dict:
+    """Counters of the deferred op list behind the ABI (csrc/mlxc_lazy.hpp)."""
+    v = (ctypes.c_long * 6)()
+    lib.omx_mlx_lazy_stats(v)
+    return {"recorded": v[0], "launched_as_recorded": v[1], "fused_launches": v[2], "flushes": v[3], "flush_host_ns": v[4], "rewrite_ns": v[5]}
+
+
+def lazy_mode(lazy: bool = True, fuse: bool = True) -> None:
+    _check(lib.omx_mlx_lazy_mode(1 if lazy else 0, 1 if fuse else 0))
+
+
+def async_eval(*arrays) -> None:
+    vec = lib.mlx_vector_array_new()
+    try:
+        for a in arrays:
+            _check(lib.mlx_vector_array_append_value(vec, a.h))
+        _check(lib.mlx_async_eval(vec))
+    finally:
+        lib.mlx_vector_array_free(vec)

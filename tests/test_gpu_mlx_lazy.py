@@ -1,0 +1,183 @@
+"""GPU: the deferred op list behind the mlx-c ABI (csrc/mlxc_lazy.hpp, round 6) -- the ABI's lazy contract (mlx-c transforms.h:30,42;
+mlx-rs/src/transforms/mod.rs:67-85) used the way qwen3-mlx's Generate::next uses it (model.rs:804-843).
+
+What must hold:
+  * the SAME values whether an op launches when it is called (lazy off), is recorded and launched as recorded (fuse off), or is rewritten
+    onto the fused GEMV family (default) -- compared through the oracle where roundings may differ, bit for bit where they may not;
+  * an intermediate a caller still HOLDS is never optimised away; one that nobody holds and only fused readers used may be;
+  * an op that was never taught to defer sees all earlier recorded work (Arr::ptr() is the gate);
+  * item() of an older result does not have to wait for newer queued work, and still returns the right value.
+"""
+import numpy as np
+import pytest
+
+from oracle import ref_core as rc, synth
+from test_gpu_primitives import assert_bf16_close, rand
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def mx(omx):
+    from ominix_mlx_amd import mlx_c
+    mlx_c.lazy_mode(True, True)
+    yield mlx_c
+    mlx_c.lazy_mode(True, True)
+
+
+def _mlp_inputs(hidden=512, inter=1536, seed=5):
+    x = rc.bf16_round(rand((1, 1, hidden), seed))
+    nw = rc.bf16_round(1 + 0.1 * rand((hidden,), seed + 1))
+    wg = rc.bf16_round(rand((inter, hidden), seed + 2) * 0.05)
+    wu = rc.bf16_round(rand((inter, hidden), seed + 3) * 0.05)
+    wd = rc.bf16_round(rand((hidden, inter), seed + 4) * 0.05)
+    return x, nw, wg, wu, wd
+
+
+def _mlp(mx, X, NW, WG, WU, WD, hold=False):
+    """qwen3-mlx's block tail: h + down(silu(gate(rms_norm(h))) * up(rms_norm(h)))  (model.rs:263-267, 330-339)"""
+    hn = mx.rms_norm(X, NW, 1e-6)
+    g = mx.matmul(hn, mx.transpose(WG))
+    act = mx.multiply(mx.multiply(g, mx.sigmoid(g)), mx.matmul(hn, mx.transpose(WU)))
+    out = mx.add(X, mx.matmul(act, mx.transpose(WD)))
+    return (out, hn, g, act) if hold else (out,)
+
+
+@pytest.mark.parametrize("lazy,fuse", [(False, False), (True, False), (True, True)])
+def test_block_tail_matches_the_oracle_in_every_mode(mx, lazy, fuse):
+    x, nw, wg, wu, wd = _mlp_inputs()
+    mx.lazy_mode(lazy, fuse)
+    X, NW, WG, WU, WD = (mx.Array.from_numpy(a) for a in (x, nw, wg, wu, wd))
+    before = mx.lazy_stats()
+    (out,) = _mlp(mx, X, NW, WG, WU, WD)
+    got = out.numpy()
+    after = mx.lazy_stats()
+    hn = rc.rms_norm(x, nw, 1e-6, "bf16")
+    g = rc.linear(hn, wg, None, "bf16")
+    act = rc.multiply(rc.multiply(g, rc.sigmoid(g, "bf16"), "bf16"), rc.linear(hn, wu, None, "bf16"), "bf16")
+    ref = rc.add(x, rc.linear(act, wd, None, "bf16"), "bf16")
+    assert_bf16_close(got, ref, 2)
+    fused = after["fused_launches"] - before["fused_launches"]
+    if lazy and fuse:
+        # nobody held hn, g, sigmoid(g), g * sigmoid(g), up(hn), down(act): two launches remain -- [norm + gate/up + SwiGLU], [down + residual]
+        assert fused == 2 and after["launched_as_recorded"] == before["launched_as_recorded"]
+    else:
+        assert fused == 0
+
+
+def test_the_three_modes_agree_bit_for_bit_on_the_block_tail(mx):
+    x, nw, wg, wu, wd = _mlp_inputs(seed=11)
+    outs = []
+    for lazy, fuse in ((False, False), (True, False), (True, True)):
+        mx.lazy_mode(lazy, fuse)
+        arrs = [mx.Array.from_numpy(a) for a in (x, nw, wg, wu, wd)]
+        outs.append(_mlp(mx, *arrs)[0].numpy())
+    np.testing.assert_array_equal(outs[0], outs[1])
+    np.testing.assert_array_equal(outs[0], outs[2])      # the fused kernels keep the per-op rounding points
+
+
+def test_an_intermediate_somebody_holds_is_computed(mx):
+    x, nw, wg, wu, wd = _mlp_inputs(seed=21)
+    mx.lazy_mode(False, False)
+    eager = [a.numpy() for a in _mlp(mx, *[mx.Array.from_numpy(a) for a in (x, nw, wg, wu, wd)], hold=True)]
+    mx.lazy_mode(True, True)
+    arrs = [mx.Array.from_numpy(a) for a in (x, nw, wg, wu, wd)]
+    before = mx.lazy_stats()
+    held = _mlp(mx, *arrs, hold=True)        # out, rms_norm(x), gate(x), the activation: all still referenced when the list runs
+    mx.eval(held[0])
+    after = mx.lazy_stats()
+    for got, want in zip(held, eager):
+        np.testing.assert_array_equal(got.numpy(), want)
+    # hn and g are visible: the norm is launched as recorded, gate / up stay plain products; only [down + residual] has an epilogue to take
+    assert after["launched_as_recorded"] - before["launched_as_recorded"] >= 4
+
+
+def test_an_op_that_never_learnt_to_defer_sees_the_recorded_work(mx):
+    a = rc.bf16_round(rand((4, 64), 31))
+    b = rc.bf16_round(rand((4, 64), 32))
+    A, B = mx.Array.from_numpy(a), mx.Array.from_numpy(b)
+    s = mx.add(A, B)                                   # recorded
+    before = mx.lazy_stats()["flushes"]
+    e = mx.exp(s)                                      # recorded too (unary)
+    srt = mx.sort_axis(e, -1)                          # eager: must run behind both
+    assert mx.lazy_stats()["flushes"] == before + 1
+    ref = np.sort(rc.bf16_round(np.exp(rc.bf16_round(a + b).astype(np.float64))), axis=-1)
+    assert_bf16_close(srt.numpy(), ref, 1)
+
+
+def test_cache_update_in_place_and_reads_in_program_order(mx):
+    """KVCache::update_and_fetch (cache.rs:140-193) twice before anything runs: the second update and the reads in between are recorded
+    against the same buffer and must see each other in call order."""
+    cache = mx.zeros([1, 2, 8, 64], mx.BFLOAT16)
+    k0 = rc.bf16_round(rand((1, 2, 3, 64), 41))
+    k1 = rc.bf16_round(rand((1, 2, 1, 64), 42))
+    c1 = mx.slice_update(cache, mx.Array.from_numpy(k0), [0, 0, 0, 0], [1, 2, 3, 64])
+    del cache
+    seen1 = mx.multiply(mx.slice(c1, [0, 0, 0, 0], [1, 2, 3, 64]), mx.Array.from_numpy(np.full((1,), 2.0, np.float32), mx.BFLOAT16))
+    c2 = mx.slice_update(c1, mx.Array.from_numpy(k1), [0, 0, 3, 0], [1, 2, 4, 64])
+    del c1
+    full = mx.slice(c2, [0, 0, 0, 0], [1, 2, 4, 64]).numpy()
+    np.testing.assert_array_equal(full[:, :, :3], k0)
+    np.testing.assert_array_equal(full[:, :, 3:], k1)
+    np.testing.assert_array_equal(seen1.numpy(), rc.bf16_round(k0 * 2.0))
+
+
+def test_item_of_an_older_result_with_newer_work_queued(mx):
+    """Generate::next: async_eval(next), then the caller reads the PREVIOUS token."""
+    w = rc.bf16_round(rand((2048, 512), 51) * 0.05)
+    x0 = rc.bf16_round(rand((1, 1, 512), 52))
+    W = mx.Array.from_numpy(w)
+    toks, prev = [], None
+    X = mx.Array.from_numpy(x0)
+    want = []
+    xr = x0
+    for i in range(6):
+        logits = mx.matmul(X, mx.transpose(W))
+        y = mx.argmax_axis(logits, -1)
+        mx.async_eval(y)
+        lr = rc.linear(xr, w, None, "bf16")
+        want.append(int(np.argmax(lr[0, 0])))
+        if prev is not None:
+            toks.append(int(prev.item()))
+        prev = y
+        # next input: the row of W the token picked (an embedding take on the device token, as compute_next does)
+        X = mx.reshape(mx.take_axis(W, mx.reshape(y, [1, 1]), 0), [1, 1, 512])
+        xr = w[want[-1]][None, None, :]
+    toks.append(int(prev.item()))
+    assert toks == want
+
+
+def test_an_error_inside_the_deferred_list_surfaces_at_the_evaluation_point(mx, omx):
+    q = mx.Array.from_numpy(rc.bf16_round(rand((1, 2, 1, 48), 61)))       # head_dim 48: no attention kernel takes it
+    out = mx.scaled_dot_product_attention(q, q, q, 1.0)                    # recorded: shapes are consistent, the launch is what fails
+    with pytest.raises(omx.OmxError):
+        mx.eval(out)
+    # the list is empty again and the layer keeps working
+    a = mx.Array.from_numpy(np.ones((2, 2), np.float32), mx.FLOAT32)
+    np.testing.assert_array_equal(mx.add(a, a).numpy(), np.full((2, 2), 2.0, np.float32))
+
+
+def test_drop_in_route_fuses_and_keeps_its_tokens(omx, mx):
+    """csrc/per_op_route.hip (qwen3-mlx forward + Generate::next, replayed through the ABI) in the three modes on one model: the same
+    greedy tokens, and in the default mode the decode step collapses to <= 8 launches per layer -- [norm + q | k | v], [q / k norm + rope +
+    cache writes], attention, [o + residual], [norm + gate / up + SwiGLU], [down + residual] -- plus embedding take and [norm + head + argmax]."""
+    from ominix_mlx_amd import engine
+    cfg = dict(hidden_size=512, num_hidden_layers=3, intermediate_size=1536, num_attention_heads=8, num_key_value_heads=4, head_dim=64,
+               vocab_size=2048, rms_norm_eps=1e-6, rope_theta=1e6, tie_word_embeddings=False)
+    m = engine.Model(max_context=1024, **cfg)
+    m.synth_weights()
+    prompt = synth.prompt_ids(300, cfg["vocab_size"])
+    n_new = 220                                            # crosses the cache's 512-token growth
+    runs = {}
+    for name, (lazy, fuse) in {"eager": (False, False), "recorded": (True, False), "fused": (True, True)}.items():
+        mx.lazy_mode(lazy, fuse)
+        s0 = mx.lazy_stats()
+        runs[name] = ([int(t) for t in m.per_op_route(prompt, n_new)["tokens"]], s0, mx.lazy_stats())
+    assert runs["eager"][0] == runs["recorded"][0] == runs["fused"][0]
+    _, s0, s1 = runs["fused"]
+    passes = n_new + 2                                     # the prompt, then one decode pass per token and the one Generate keeps in flight
+    launches = (s1["launched_as_recorded"] - s0["launched_as_recorded"]) + (s1["fused_launches"] - s0["fused_launches"])
+    per_decode_pass = (launches - 40 * cfg["num_hidden_layers"]) / (passes - 1)        # (the prompt pass: at most 40 launches per layer)
+    assert per_decode_pass <= 8 * cfg["num_hidden_layers"] + 4, per_decode_pass
+    assert s1["fused_launches"] - s0["fused_launches"] >= 5 * cfg["num_hidden_layers"] * (passes - 1)
+    m.close()

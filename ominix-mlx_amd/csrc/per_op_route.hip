@@ -10,6 +10,7 @@
 // with omx_qwen3_prefill / _decode on the same checkpoint.  Only public C entry points are called below -- this file could live outside
 // the library; it sits in it so that bench.py reaches it through ctypes.
 #include <chrono>
+#include <cstring>
 #include <string>
 #include <vector>
 
@@ -115,10 +116,24 @@ struct LayerW { mlx_array q, k, v, o, gate, up, down, in_ln, post_ln, q_norm, k_
 
 }  // namespace
 
+/* forced != null: the TEACHER-FORCED form for the oracle pins (tests/test_gpu_fullsize_pin.py) -- after the prompt, position i is fed
+ * forced[i] instead of the route's own token (one pass at a time, the token from the host), tokens_out still holds the route's own greedy
+ * choices, and the bf16 logits rows of the steps listed in logit_steps (0 = the prompt's last position) are copied to logits_out
+ * [n_logit_steps, vocab].  forced == null: Generate::next's pipelined loop, timed (bench.py). */
+extern "C" int omx_bench_qwen3_per_op_ex(omx_qwen3 model, const omx_qwen3_config* cfg, const uint32_t* prompt, int n_prompt, int n_new,
+                                         uint32_t* tokens_out, double* prefill_ms, double* ms_per_token, double* calls_per_token,
+                                         const uint32_t* forced, const int* logit_steps, int n_logit_steps, uint16_t* logits_out);
 extern "C" int omx_bench_qwen3_per_op(omx_qwen3 model, const omx_qwen3_config* cfg, const uint32_t* prompt, int n_prompt, int n_new,
                                       uint32_t* tokens_out, double* prefill_ms, double* ms_per_token, double* calls_per_token) {
+    return omx_bench_qwen3_per_op_ex(model, cfg, prompt, n_prompt, n_new, tokens_out, prefill_ms, ms_per_token, calls_per_token, nullptr, nullptr, 0,
+                                     nullptr);
+}
+extern "C" int omx_bench_qwen3_per_op_ex(omx_qwen3 model, const omx_qwen3_config* cfg, const uint32_t* prompt, int n_prompt, int n_new,
+                                         uint32_t* tokens_out, double* prefill_ms, double* ms_per_token, double* calls_per_token,
+                                         const uint32_t* forced, const int* logit_steps, int n_logit_steps, uint16_t* logits_out) {
     using namespace omx;
     OMX_REQUIRE(model && cfg && prompt && n_prompt > 0 && n_new > 0 && tokens_out, "omx_bench_qwen3_per_op: bad arguments");
+    OMX_REQUIRE(n_logit_steps == 0 || (forced && logit_steps && logits_out), "omx_bench_qwen3_per_op_ex: logits are captured in the forced form only");
     OMX_REQUIRE(cfg->quant_bits == 0 && cfg->num_experts == 0 && cfg->tp_size <= 1, "omx_bench_qwen3_per_op: dense bf16 model on one rank");
     const int hd = cfg->hidden_size, H = cfg->num_attention_heads, Hkv = cfg->num_key_value_heads, D = cfg->head_dim, I = cfg->intermediate_size,
               V = cfg->vocab_size, L = cfg->num_hidden_layers;
@@ -151,7 +166,7 @@ extern "C" int omx_bench_qwen3_per_op(omx_qwen3 model, const omx_qwen3_config* c
     // Model::forward on the token ids `idx` ([1, n], on the device) -> y = sample(logits of the LAST position) as a device array
     // (model.rs:387-433 + sampler at temperature 0).  forward's temporaries are dropped before this returns, like Rust drops them at
     // the end of their scopes -- i.e. BEFORE the caller's async_eval: an intermediate nobody holds may then be fused away (mlxc_lazy.hpp).
-    auto forward_sample = [&](mlx_array idx, int n, mlx_array* y) -> int {
+    auto forward_sample = [&](mlx_array idx, int n, mlx_array* y, mlx_array* keep_logits = nullptr) -> int {
         mlx_array h = P.take_axis(embed, idx, 0);                                   // Embedding::forward -> [1, n, hidden]
         const char* mode = n > 1 ? "causal" : "";                                    // create_attention_mask (utils.rs:156-188)
         for (int l = 0; l < L; ++l) {
@@ -184,6 +199,10 @@ extern "C" int omx_bench_qwen3_per_op(omx_qwen3 model, const omx_qwen3_config* c
         *y = mlx_array_new();
         ++P.calls;
         if (mlx_array_set(y, t)) return 1;                                            // the one array that leaves forward
+        if (keep_logits) {
+            *keep_logits = mlx_array_new();
+            if (mlx_array_set(keep_logits, logits)) return 1;
+        }
         P.sweep();
         return 0;
     };
@@ -195,11 +214,32 @@ extern "C" int omx_bench_qwen3_per_op(omx_qwen3 model, const omx_qwen3_config* c
         mlx_vector_array_free(v);
         return rc;
     };
-    // Generate::next (model.rs:804-843): the step after the one being returned is recorded and sent before the caller reads a token
     uint32_t tok = 0;
     auto t0 = std::chrono::steady_clock::now();
     mlx_array prefetched{nullptr};
-    {
+    if (forced) {
+        for (int step = 0; step <= n_new && !rc; ++step) {
+            const int n = step == 0 ? n_prompt : 1;
+            const int sh[2] = {1, n};
+            mlx_array idx = mlx_array_new_data(step == 0 ? prompt : forced + (step - 1), sh, 2, MLX_UINT32);
+            mlx_array y{nullptr}, lg{nullptr};
+            int want = -1;
+            for (int i = 0; i < n_logit_steps; ++i)
+                if (logit_steps[i] == step) want = i;
+            rc = forward_sample(idx, n, &y, want >= 0 ? &lg : nullptr) || async_eval(y);
+            mlx_array_free(idx);
+            if (!rc) rc = mlx_array_item_uint32(&tok, y);
+            tokens_out[step] = tok;
+            if (!rc && want >= 0) {
+                const uint16_t* host = mlx_array_data_bfloat16(lg);
+                if (host) memcpy(logits_out + (size_t)want * V, host, (size_t)V * 2); else rc = 1;
+            }
+            if (y.ctx) mlx_array_free(y);
+            if (lg.ctx) mlx_array_free(lg);
+        }
+    }
+    // Generate::next (model.rs:804-843): the step after the one being returned is recorded and sent before the caller reads a token
+    if (!forced) {
         const int sh[2] = {1, n_prompt};
         mlx_array idx = mlx_array_new_data(prompt, sh, 2, MLX_UINT32);
         ++P.calls;
@@ -214,7 +254,7 @@ extern "C" int omx_bench_qwen3_per_op(omx_qwen3 model, const omx_qwen3_config* c
     }
     auto t1 = std::chrono::steady_clock::now();
     long calls0 = P.calls;
-    for (int i = 1; i <= n_new && !rc; ++i) {
+    for (int i = 1; i <= n_new && !rc && !forced; ++i) {
         mlx_array current = prefetched, next{nullptr};
         prefetched = mlx_array{nullptr};
         rc = forward_sample(current, 1, &next) || async_eval(next);

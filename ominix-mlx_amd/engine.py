@@ -321,6 +321,24 @@ class Model:
                                          toks.ctypes.data_as(ctypes.POINTER(c_uint32)), ctypes.byref(pre), ctypes.byref(per), ctypes.byref(calls)))
         return {"tokens": toks, "prefill_ms": pre.value, "ms_per_token": per.value, "calls_per_token": calls.value}
 
+    def per_op_route_forced(self, prompt, forced, logit_steps) -> dict:
+        """The same route TEACHER-FORCED (the oracle pins): after the prompt, position i is fed forced[i]; returns the route's own greedy
+        token at every step and the float32-widened bf16 logits rows of `logit_steps` (0 = the prompt's last position)."""
+        ids = np.ascontiguousarray(np.asarray(prompt, dtype=np.uint32).ravel())
+        forced = np.ascontiguousarray(np.asarray(forced, dtype=np.uint32).ravel())
+        steps = np.ascontiguousarray(np.asarray(logit_steps, dtype=np.int32).ravel())
+        toks = np.zeros(forced.size + 1, np.uint32)
+        raw = np.zeros((steps.size, self.cfg.vocab_size), np.uint16)
+        fn = lib.omx_bench_qwen3_per_op_ex
+        fn.restype = ctypes.c_int
+        fn.argtypes = [c_void_p, c_void_p, ctypes.POINTER(c_uint32), c_int, c_int, ctypes.POINTER(c_uint32), c_void_p, c_void_p, c_void_p,
+                       ctypes.POINTER(c_uint32), ctypes.POINTER(ctypes.c_int32), c_int, c_void_p]
+        pre, per, calls = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+        check(fn(self._h, ctypes.addressof(self.cfg), ids.ctypes.data_as(ctypes.POINTER(c_uint32)), ids.size, forced.size,
+                 toks.ctypes.data_as(ctypes.POINTER(c_uint32)), ctypes.addressof(pre), ctypes.addressof(per), ctypes.addressof(calls),
+                 forced.ctypes.data_as(ctypes.POINTER(c_uint32)), steps.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), steps.size, raw.ctypes.data))
+        return {"tokens": toks, "logits": (raw.astype(np.uint32) << np.uint32(16)).view(np.float32)}
+
     def last_logits(self) -> np.ndarray:
         raw = np.empty(self.vocab_local, dtype=np.uint16)
         check(lib.omx_qwen3_last_logits(self._h, raw.ctypes.data, raw.size))

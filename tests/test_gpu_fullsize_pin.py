@@ -129,6 +129,43 @@ def test_protocol_c2_iid_logits_with_the_oracle_tokens_forced(omx):
     m.close()
 
 
+def test_protocol_c2_iid_logits_of_the_drop_in_route(omx):
+    """The same fixture against the DROP-IN route (VERDICT r5 "Next" 3): qwen3-mlx's forward replayed call for call through the mlx-c ABI
+    (csrc/per_op_route.hip) with the deferred list rewriting the decode idioms onto the fused GEMV family (csrc/mlxc_lazy.hpp) -- compared
+    with the ORACLE, not with the engine: top-8 logits (and the fixed 256-entry sample where the fixture carries one) at every pinned step
+    within the same bf16 bound, the oracle's tokens forced."""
+    from ominix_mlx_amd import engine
+    path = os.path.join(os.path.dirname(__file__), "golden", "qwen3_c2_protocol_iid_pin.npz")
+    if not os.path.exists(path):
+        pytest.skip("qwen3_c2_protocol_iid_pin.npz not generated (tools/protocol_pin.py c2 256 iid)")
+    pin = np.load(path)
+    cfg = dict(bench.QWEN3_8B)
+    n_prompt, want = int(pin["prompt_len"]), pin["tokens"]
+    prompt = bench.prompt_ids(n_prompt, cfg["vocab_size"])
+    m = engine.Model(max_context=64, **cfg)          # (only its weights are used: the route keeps its own cache arrays)
+    m.synth_weights()
+    bound = 2.0 ** -7 * float(pin["logit_absmax"]) * np.sqrt(cfg["num_hidden_layers"])
+    steps = [int(s) for s in pin["pin_steps"]]
+    got = m.per_op_route_forced(prompt, want[:-1], steps)
+    worst, worst_sub = 0.0, 0.0
+    for i, step in enumerate(steps):
+        lg = got["logits"][i]
+        err = float(np.abs(lg[pin["top_idx"][i]] - pin["top_val"][i]).max())
+        worst = max(worst, err)
+        assert err <= bound, f"step {step}: top-8 logits of the route off by {err:.4f} (bound {bound:.4f})"
+        if "sub_idx" in pin.files:
+            worst_sub = max(worst_sub, float(np.abs(lg[pin["sub_idx"]] - pin["sub_val"][i]).max()))
+        tok = int(got["tokens"][step])
+        if float(pin["margins"][i]) > 2 * bound:
+            assert tok == int(want[step]), f"step {step}: route {tok} vs oracle {int(want[step])} at margin {float(pin['margins'][i]):.3f}"
+        else:
+            assert lg[int(want[step])] >= lg.max() - 2 * bound
+    assert worst_sub <= bound, f"sampled logits of the route off by {worst_sub:.4f} (bound {bound:.4f})"
+    equal = int((got["tokens"].astype(np.int64) == want).sum())
+    print(f"c2 i.i.d. pin, drop-in route: worst top-8 deviation {worst:.4f}, sample {worst_sub:.4f} (bound {bound:.4f}); {equal} of {want.size} greedy tokens equal")
+    m.close()
+
+
 def _protocol_pin(omx, which, cfg):
     """PLUMBING CHECK, not an arithmetic pin: on the peaked checkpoint the greedy successor of token t is t - 1 by construction
     of the embedding and the head alone -- an engine with its attention zeroed would pass; the arithmetic at these shapes is pinned by

@@ -670,9 +670,13 @@ def main():
         per_op = None
         if world == 1 and not moe and keep is None and not cfg.get("quantization"):
             try:
-                n_po = 16
+                n_po = 64
                 r0 = model.per_op_route(prompt, 1)        # (first call: the handle route's buffers are allocated here -- 50 ms .. 0.5 s by box)
+                from ominix_mlx_amd import mlx_c
+                ls0 = mlx_c.lazy_stats()
                 r = model.per_op_route(prompt, n_po)
+                ls1 = mlx_c.lazy_stats()
+                n_pass = n_po + 1                         # decode passes of the call (Generate::next keeps one in flight) beside the one prompt pass
                 eng = [int(first)] + [int(t) for t in warm_toks[:n_po]]
                 got = [int(t) for t in r["tokens"]]
                 n_cmp = min(len(eng), len(got))
@@ -684,11 +688,34 @@ def main():
                           "tokens_timed": n_po, "context": args.prompt,
                           "first_tokens": got[:5], "leading_tokens_equal_to_engine": f"{agree} of {n_cmp}",
                           "vs_engine": round((1e3 / r["ms_per_token"]) / tok_s, 3),
+                          # the deferred list behind the ABI (csrc/mlxc_lazy.hpp): what the ~1 380 calls of a token became
+                          "deferred": {"ops_recorded_per_token": round((ls1["recorded"] - ls0["recorded"]) / (n_pass + 1), 1),
+                                       "launches_per_token": round((ls1["launched_as_recorded"] - ls0["launched_as_recorded"] +
+                                                                    ls1["fused_launches"] - ls0["fused_launches"]) / (n_pass + 1), 1),
+                                       "of_which_fused_gemv_family": round((ls1["fused_launches"] - ls0["fused_launches"]) / (n_pass + 1), 1),
+                                       "host_ms_per_token_in_flushes": round((ls1["flush_host_ns"] - ls0["flush_host_ns"]) / 1e6 / (n_pass + 1), 3),
+                                       "note": "averages over the call's passes INCLUDING its one 2 048-token prompt pass"},
                           "note": "qwen3-mlx Model::forward + Generate::next replayed call for call through the mlx-c handle ABI by native code on the "
-                                  "engine's own weights (csrc/per_op_route.hip): the route an UNMODIFIED crate takes; `value` above is the "
-                                  "omx_qwen3_* engine, which needs the one-file caller change of INTEGRATION.md section 3"}
+                                  "engine's own weights (csrc/per_op_route.hip): the route an UNMODIFIED crate takes.  Round 6: the ABI records the calls and "
+                                  "executes them at mlx_async_eval / item, rewriting the decode idioms onto the engine's GEMV family (csrc/mlxc_lazy.hpp; "
+                                  "OMX_MLX_LAZY=0 is round 5's eager execution); `value` above is the omx_qwen3_* engine"}
             except Exception as e:   # a report, never a reason to lose the measured line
                 per_op = {"metric": "decode_tokens_per_sec_per_op_route", "value": None, "error": str(e)[:300]}
+        # what this box streams in ONE dependency-free launch of the step's bytes (the plain GEMV kernel over a single [N, 4096] matrix as
+        # large as a decode step's traffic): the ceiling the step's fraction of the 8 TB/s spec is to be read against (VERDICT r5 "Next" 2)
+        ceiling = None
+        if world == 1 and not moe and keep is None and not args.layers:
+            try:
+                import ctypes
+                fn = omx.lib.omx_bench_gemv
+                fn.restype = ctypes.c_int
+                fn.argtypes = [ctypes.c_int] * 7 + [ctypes.POINTER(ctypes.c_float)]
+                n_rows = int(model.step_bytes(ctx_mid) // (2 * 4096)) // 512 * 512
+                ms = ctypes.c_float(0)
+                omx.check(fn(n_rows, 4096, 0, 0, 0, 1, 5, ctypes.byref(ms)))
+                ceiling = n_rows * 4096 * 2 / (ms.value * 1e-3) / 1e9
+            except Exception as e:      # a report, never a reason to lose the measured line
+                print(f"streaming ceiling not measured ({e})", file=sys.stderr)
         k_s = in_step["gate_up"] * 1e-6 if in_step else iso_s
         achieved = k_bytes / k_s / 1e9
         H, Hkv, D, hd, I, V = (cfg["num_attention_heads"], cfg["num_key_value_heads"], cfg["head_dim"], cfg["hidden_size"],
@@ -724,7 +751,11 @@ def main():
                               "achieved_GBps": round(step_bytes / (ms_per_step * 1e-3) / 1e9, 1),
                               "frac_of_hbm_peak": round(step_bytes / (ms_per_step * 1e-3) / 1e9 / (HBM_PEAK_GBPS * world), 4),
                               "roofline_tokens_per_sec": round(HBM_PEAK_GBPS * 1e9 * world / step_bytes, 1),
-                              "device_ms_per_step_hip_events": round(dev_ms / args.steps, 4)},
+                              "device_ms_per_step_hip_events": round(dev_ms / args.steps, 4),
+                              **({"ceiling_GBps": round(ceiling, 1), "frac_of_ceiling": round(step_bytes / (ms_per_step * 1e-3) / 1e9 / ceiling, 4),
+                                  "ceiling_tokens_per_sec": round(ceiling * 1e9 / step_bytes, 1),
+                                  "ceiling_note": "one launch of the plain bf16 GEMV kernel streaming the step's algorithmic bytes as a single matrix, "
+                                                  "HIP events, this box, this run: no dependency, no launch boundary inside"} if ceiling else {})},
             "prefill": {"tokens": args.prompt, "seconds": round(prefill_s, 4), "device_ms": round(prefill_first_ms, 3),
                         "device_ms_steady": round(prefill_steady_ms, 3),
                         "tokens_per_sec": round(args.prompt / max(prefill_steady_ms, 1e-6) * 1e3, 1),

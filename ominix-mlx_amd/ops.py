@@ -352,9 +352,12 @@ def quantized_matmul(x: Tensor, packed: Tensor, scales: Tensor, biases: Optional
     if x.shape[-1] != K:
         raise OmxError(f"quantized_matmul: input features {x.shape[-1]} != weight in-features {K}")
     if x.dtype != scales.dtype:
-        # MLX promotes with result_type(x, scales, biases) (ops.cpp quantized_matmul); the kernels run in the scales' 16-bit type, so a
-        # mixed call (a bf16 activation on a float16 checkpoint, or the reverse) is computed there: x is cast to it
-        x = cast(x, scales.dtype)
+        # MLX promotes with result_type(x, scales, biases): bf16 x f16 (and anything x f32) is float32.  The packed kernels run in ONE
+        # 16-bit type, so a mixed call takes the long way with MLX's result dtype and range (casting a bf16 activation to a
+        # float16 checkpoint's dtype returned float16 and overflowed above 65 504): the weight dequantised in the scales' dtype (what MLX's
+        # kernel multiplies with), both operands widened to float32, a float32 product
+        w32 = cast(dequantize(packed, scales, biases, group_size, bits), FLOAT32)
+        return linear(cast(x, FLOAT32), w32)
     out = Tensor(tuple(x.shape[:-1]) + (N,), x.dtype)
     # one dtype for x, out, scales and biases: bf16, or f16 -- a float16 checkpoint runs in float16 end to end, like in MLX
     check(lib.omx_quantized_matmul(out.ptr, x.ptr, packed.ptr, scales.ptr, _p(biases), x.size // K, N, K, group_size, bits,

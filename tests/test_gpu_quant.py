@@ -181,13 +181,18 @@ def test_quantized_matmul_in_float16(omx, M, bits, group, K):
     wd = rc.dequantize(rq_, s16.astype(np.float32), b16.astype(np.float32), group, bits, "f32")
     noise = 4 * 2.0 ** -12 * np.sqrt((x.astype(np.float64) ** 2) @ (wd.astype(np.float64) ** 2).T)
     assert (np.abs(got.astype(np.float64) - ref) <= 2.0 ** -10 * np.abs(ref) + noise + 1e-6).all()
-    # a bfloat16 activation on the float16 checkpoint (MLX promotes with result_type; the kernels run in the scales' type): x is cast to
-    # float16 -- the same call as above when the values are representable in both (cast, do not raise)
+    # a bfloat16 activation on the float16 checkpoint: MLX promotes with result_type(bf16, f16) = float32 (the round-4 cast to
+    # the scales' dtype returned float16 and overflowed above 65 504).  The result is float32, also for an activation no float16 can hold.
     xb = rc.bf16_round(x)
+    xb[0, :4] = rc.bf16_round(np.array([1.0e5, -2.0e5, 7.0e4, 9.0e4], np.float32))   # |x| > 65 504: not float16 values
     mixed = omx.ops.quantized_matmul(T.from_numpy(xb), T.from_numpy(rq_, "u32"), T.from_numpy(s16, "f16"), T.from_numpy(b16, "f16"), group, bits)
-    assert mixed.dtype == omx.ops.dtype_code("f16")
-    same = omx.ops.quantized_matmul(T.from_numpy(xb, "f16"), T.from_numpy(rq_, "u32"), T.from_numpy(s16, "f16"), T.from_numpy(b16, "f16"), group, bits)
-    np.testing.assert_array_equal(mixed.numpy(), same.numpy())
+    assert mixed.dtype == omx.ops.dtype_code("f32")
+    wd16 = rc.dequantize(rq_, s16.astype(np.float32), b16.astype(np.float32), group, bits, "f32").astype(np.float16).astype(np.float64)
+    ref32 = xb.astype(np.float64) @ wd16.T
+    got32 = mixed.numpy().astype(np.float64)
+    assert np.isfinite(got32).all()
+    noise32 = 4 * 2.0 ** -22 * np.sqrt((xb.astype(np.float64) ** 2) @ (wd16 ** 2).T)
+    assert (np.abs(got32 - ref32) <= 2.0 ** -20 * np.abs(ref32) + noise32 + 1e-6).all()
     # and the dequantised matrix itself (dtype of the scales, as MLX): one fma per element from the exact float16 values, one rounding
     dq = omx.ops.dequantize(T.from_numpy(rq_, "u32"), T.from_numpy(s16, "f16"), T.from_numpy(b16, "f16"), group, bits).numpy()
     np.testing.assert_array_equal(dq, rc.dequantize(rq_, s16.astype(np.float32), b16.astype(np.float32), group, bits, "f32").astype(np.float16).astype(np.float32))

@@ -70,6 +70,7 @@ struct Buf {
     size_t bytes;
     bool owned;                     // false: device memory BORROWED from the caller (omx_mlx_array_from_device): never returned to the pool
     uint64_t seq = 0;               // the flush (mlxc_lazy.hpp) whose launches last wrote it; 0: written by launches outside any flush
+    std::shared_ptr<void> aux;      // derived forms of a packed weight the deferred list built on first use (scale | bias words, matrix-core tiles)
     Buf(void* p_, size_t b, bool owned_ = true) : p(p_), bytes(b), owned(owned_) {}
     ~Buf() { if (p && owned) g_pool.put(p, bytes); }
 };
@@ -1016,22 +1017,36 @@ int mlx_quantized_matmul(mlx_array* res, const mlx_array x, const mlx_array w, c
     int g, b;
     if (quant_params("mlx_quantized_matmul", group_size, bits, mode, &g, &b)) return 1;
     OMX_REQUIRE(transpose, "mlx_quantized_matmul: only transpose = true (QuantizedLinear, quantized.rs:366-375) is supported");
-    Contig cx, cw, cs, cb;
-    if (cx.init(*A(x)) || cw.init(*A(w)) || cs.init(*A(scales)) || (biases.ctx && cb.init(*A(biases)))) return 1;
-    OMX_REQUIRE(cw.a->dt == MLX_UINT32 && cw.a->shape.size() == 2, "mlx_quantized_matmul: w must be a 2-D packed uint32 array");
-    const int N = cw.a->shape[0], K = cw.a->shape[1] * 32 / b;
-    OMX_REQUIRE(!cx.a->shape.empty() && cx.a->shape.back() == K, "mlx_quantized_matmul: x has %d features, packed w has %d",
-                cx.a->shape.empty() ? 0 : cx.a->shape.back(), K);
-    OMX_REQUIRE(cs.a->size() == (size_t)N * (K / g), "mlx_quantized_matmul: scales shape does not match w / group_size");
-    std::vector<int> shape(cx.a->shape.begin(), cx.a->shape.end() - 1);
+    const Arr &x0 = *A(x), &w0 = *A(w), &s0 = *A(scales);
+    if (biases.ctx) REQ_ARR(biases, "mlx_quantized_matmul");
+    OMX_REQUIRE(w0.dt == MLX_UINT32 && w0.shape.size() == 2, "mlx_quantized_matmul: w must be a 2-D packed uint32 array");
+    const int N = w0.shape[0], K = w0.shape[1] * 32 / b;
+    OMX_REQUIRE(!x0.shape.empty() && x0.shape.back() == K, "mlx_quantized_matmul: x has %d features, packed w has %d",
+                x0.shape.empty() ? 0 : x0.shape.back(), K);
+    OMX_REQUIRE(s0.size() == (size_t)N * (K / g), "mlx_quantized_matmul: scales shape does not match w / group_size");
+    std::vector<int> shape(x0.shape.begin(), x0.shape.end() - 1);
     shape.push_back(N);
     // x, scales and biases share one dtype: bfloat16, or float16 (a float16 checkpoint runs in float16 end to end, quantized.rs:361-385);
     // a mix is MLX's promotion to float32, which this path does not implement
-    OMX_REQUIRE((cx.a->dt == MLX_BFLOAT16 || cx.a->dt == MLX_FLOAT16) && cx.a->dt == cs.a->dt,
+    OMX_REQUIRE((x0.dt == MLX_BFLOAT16 || x0.dt == MLX_FLOAT16) && x0.dt == s0.dt,
                 "mlx_quantized_matmul: x and scales / biases must both be bfloat16 or both float16");
-    NEW_OR_FAIL(r, shape, cx.a->dt);
-    if (omx_quantized_matmul(r->ptr(), cx.a->ptr(), cw.a->ptr(), cs.a->ptr(), biases.ctx ? cb.a->ptr() : nullptr,
-                             K ? (int)(cx.a->size() / K) : 0, N, K, g, b, to_omx(cs.a->dt), g_stream)) { delete r; return 1; }
+    NEW_OR_FAIL(r, shape, x0.dt);
+    const int M = K ? (int)(x0.size() / K) : 0;
+    Rec rec;
+    rec.kind = RK_QMM;
+    rec.a[0] = *r; rec.a[1] = x0; rec.a[2] = w0; rec.a[3] = s0; rec.na = 4;
+    if (biases.ctx) { rec.a[4] = *A(biases); rec.na = 5; }
+    rec.i0 = N; rec.i1 = K; rec.i2 = M; rec.i3 = g | (b << 16);
+    // the decode form (one bf16 row against a whole packed matrix): what the deferred list may rewrite onto the fused packed-GEMV family
+    rec.flag = M == 1 && x0.dt == MLX_BFLOAT16 && (b == 4 || b == 8) && K % 512 == 0 && is_contig(x0) && is_contig(w0) && is_contig(s0) &&
+               (!biases.ctx || is_contig(*A(biases)));
+    rec.run = [](Rec& q) -> int {
+        Contig cx, cw, cs, cb;
+        if (cx.init(q.a[1]) || cw.init(q.a[2]) || cs.init(q.a[3]) || (q.na > 4 && cb.init(q.a[4]))) return 1;
+        return omx_quantized_matmul(q.a[0].ptr(), cx.a->ptr(), cw.a->ptr(), cs.a->ptr(), q.na > 4 ? cb.a->ptr() : nullptr, q.i2, q.i0, q.i1,
+                                    q.i3 & 0xFFFF, q.i3 >> 16, to_omx(cs.a->dt), g_stream);
+    };
+    if (record(std::move(rec))) { delete r; return 1; }
     return assign(res, r);
 }
 int mlx_gather_qmm(mlx_array* res, const mlx_array x, const mlx_array w, const mlx_array scales, const mlx_array biases,

@@ -25,10 +25,11 @@
 
 #include "gemv.hpp"
 #include "prefill.hpp"
+#include "quant.hpp"
 
 namespace {
 
-enum RecKind { RK_GENERIC = 0, RK_RMSNORM, RK_MATMUL, RK_ADD, RK_MUL, RK_SIGMOID, RK_ARGMAX, RK_ROPE, RK_SLICE_UPDATE, RK_SDPA };
+enum RecKind { RK_GENERIC = 0, RK_RMSNORM, RK_MATMUL, RK_ADD, RK_MUL, RK_SIGMOID, RK_ARGMAX, RK_ROPE, RK_SLICE_UPDATE, RK_SDPA, RK_QMM };
 
 struct Rec {
     int kind = RK_GENERIC;
@@ -37,7 +38,8 @@ struct Rec {
     int na = 0;
     float f0 = 0.f, f1 = 0.f;
     int i0 = 0, i1 = 0, i2 = 0, i3 = 0;
-    bool flag = false;            // RK_MATMUL: the M == 1 bf16 NT form launch_gemv serves (a[1] = x row, a[2] = W^T view of [N, K])
+    bool flag = false;            // RK_MATMUL: the M == 1 bf16 NT form launch_gemv serves (a[1] = x row, a[2] = W^T view of [N, K]);
+                                  // RK_QMM: the same against an MLX-packed matrix (a[2] packed words, a[3] scales, a[4] biases; i3 = group | bits << 16)
     std::vector<int> iv;
     std::function<int(Rec&)> run;
     bool dead = false;
@@ -170,9 +172,98 @@ int run_scatter(std::vector<Rec>& recs, const ScatterPlan& p) {
                                        p.T, p.H, p.Hkv, p.D, p.cap, p.offset, nq.f0, g_stream, false);
 }
 
+// the derived forms of a packed matrix the fused kernels want, built once per weight buffer and kept WITH it (Buf::aux): the scale | bias
+// words quant.hip's kernels fetch with one load, and -- 4-bit, group 64, K = 4096 / 12288 -- the matrix-core tiles of qgemv_mfma.hip
+struct QAux {
+    uint32_t* sb = nullptr;
+    uint32_t* tiles = nullptr;
+    ~QAux() { if (sb) (void)hipFree(sb); if (tiles) (void)hipFree(tiles); }
+};
+int qmat_of(const Rec& m, omx::QMat* out) {
+    using namespace omx;
+    const int N = m.i0, K = m.i1, group = m.i3 & 0xFFFF, bits = m.i3 >> 16;
+    const Arr& w = m.a[2];
+    *out = QMat{(const uint32_t*)w.ptr(), (const bf16_t*)m.a[3].ptr(), m.na > 4 ? (const bf16_t*)m.a[4].ptr() : nullptr, N};
+    if (w.off != 0 || m.a[3].off != 0) return 0;                 // (a view into a larger buffer: no cache keyed by the buffer)
+    if (!w.buf->aux) {
+        auto aux = std::make_shared<QAux>();
+        const size_t ng = (size_t)N * (K / group);
+        if (K % 2048 == 0) {
+            OMX_HIP_CHECK(hipMalloc((void**)&aux->sb, ng * 4));
+            if (launch_quant_interleave(aux->sb, out->scales, out->biases, ng, g_stream)) return 1;
+        }
+        if (qgemv4m_shape_ok(K, group, bits) && N >= 16) {
+            OMX_HIP_CHECK(hipMalloc((void**)&aux->tiles, qgemv4m_tile_words(N, K) * 4));
+            if (launch_qgemv4m_repack(aux->tiles, out->w, out->scales, out->biases, N, K, g_stream)) return 1;
+        }
+        w.buf->aux = aux;
+    }
+    const QAux* a = static_cast<const QAux*>(w.buf->aux.get());
+    out->sb = a->sb;
+    out->tiles = a->tiles;
+    return 0;
+}
+
+int run_plan_packed(std::vector<Rec>& recs, const FusePlan& p) {
+    using namespace omx;
+    const Rec& m0 = recs[p.mm0];
+    const int K = m0.i1, N = m0.i0, group = m0.i3 & 0xFFFF, bits = m0.i3 >> 16;
+    QGemvArgs g = {};
+    if (qmat_of(m0, &g.m[0])) return 1;
+    g.N = N; g.K = K; g.group = group;
+    int pro = PRO_NONE;
+    if (p.norm >= 0) {
+        const Rec& nr = recs[p.norm];
+        g.x = (const bf16_t*)nr.a[1].ptr();
+        g.norm_w = (const bf16_t*)nr.a[2].ptr();
+        g.eps = nr.f0;
+        pro = PRO_RMSNORM;
+    } else {
+        g.x = (const bf16_t*)m0.a[1].ptr();
+    }
+    if (p.stack_out) {
+        const Rec &mk = recs[p.mmk], &mv = recs[p.mmv];
+        if (qmat_of(mk, &g.m[1]) || qmat_of(mv, &g.m[2])) return 1;
+        g.N = N + mk.i0 + mv.i0;
+        Arr* t = new_arr({g.N}, MLX_BFLOAT16);
+        if (!t) return set_error("deferred q | k | v projection: out of device memory");
+        *p.stack_out = *t;
+        delete t;
+        g.out = (bf16_t*)p.stack_out->ptr();
+        return launch_qgemv(g, bits, pro, EPI_STORE, g_stream);
+    }
+    if (p.epi == EPI_SWIGLU) {
+        if (qmat_of(recs[p.mm1], &g.m[1])) return 1;
+        g.out = (bf16_t*)recs[p.tail].a[0].ptr();
+    } else if (p.epi == EPI_RESIDUAL) {
+        g.resid = (const bf16_t*)recs[p.tail].a[p.resid_operand].ptr();
+        g.out = (bf16_t*)recs[p.tail].a[0].ptr();
+    } else if (p.epi == EPI_ARGMAX && p.norm < 0) {
+        g.out = (bf16_t*)m0.a[0].ptr();
+        if (launch_qgemv(g, bits, PRO_NONE, EPI_STORE, g_stream)) return 1;
+        return recs[p.tail].run(recs[p.tail]);
+    } else if (p.epi == EPI_ARGMAX) {
+        const int nslot = qgemv_grid(N);
+        Arr* s = new_arr({nslot * 2}, MLX_UINT32);
+        if (!s) return set_error("deferred lm_head: out of device memory");
+        Arr slots = *s;
+        delete s;
+        g.argmax_slot = (unsigned long long*)slots.ptr();
+        g.out = (bf16_t*)m0.a[0].ptr();
+        if (launch_qgemv(g, bits, PRO_RMSNORM, EPI_ARGMAX, g_stream)) return 1;
+        lazy_argmax_finalize_kernel<<<1, 256, 0, g_stream>>>((uint32_t*)recs[p.tail].a[0].ptr(), (const unsigned long long*)slots.ptr(), nslot);
+        OMX_LAUNCH_CHECK();
+        return 0;
+    } else {
+        g.out = (bf16_t*)m0.a[0].ptr();
+    }
+    return launch_qgemv(g, bits, pro, p.epi, g_stream);
+}
+
 int run_plan(std::vector<Rec>& recs, const FusePlan& p) {
     using namespace omx;
     if (p.is_scatter) return run_scatter(recs, p.sc);
+    if (recs[p.mm0].kind == RK_QMM) return run_plan_packed(recs, p);
     const Rec& m0 = recs[p.mm0];
     GemvArgs g = {};
     const int K = m0.i1, N = m0.i0;
@@ -249,7 +340,7 @@ void fuse_pending(std::vector<Rec>& recs, std::unordered_map<int, FusePlan>& pla
                 auto& v = readers[r.a[k].buf.get()];
                 if (v.empty() || v.back() != i) v.push_back(i);
             }
-        any_mm = any_mm || (r.kind == RK_MATMUL && r.flag);
+        any_mm = any_mm || ((r.kind == RK_MATMUL || r.kind == RK_QMM) && r.flag);
     }
     if (!any_mm) return;
     auto internal = [&](const Arr& x) {   // nothing outside the pending list can see this buffer
@@ -278,7 +369,7 @@ void fuse_pending(std::vector<Rec>& recs, std::unordered_map<int, FusePlan>& pla
         }
         return true;
     };
-    auto gemv_rec = [&](int i) { return i >= 0 && recs[i].kind == RK_MATMUL && recs[i].flag && !recs[i].dead; };
+    auto gemv_rec = [&](int i) { return i >= 0 && (recs[i].kind == RK_MATMUL || recs[i].kind == RK_QMM) && recs[i].flag && !recs[i].dead; };
     std::vector<int> plan_of(n, -1);       // matmul record -> the record index its plan is keyed by
     // ---- epilogues, found from the record that ends the idiom ----
     for (int j = 0; j < n; ++j) {
@@ -296,7 +387,7 @@ void fuse_pending(std::vector<Rec>& recs, std::unordered_map<int, FusePlan>& pla
                 }
                 if (G < 0 || G == U || plan_of[G] >= 0 || plan_of[U] >= 0) continue;
                 const Rec &rg = recs[G], &ru = recs[U];
-                if (rg.i0 != ru.i0 || rg.i1 != ru.i1 || !same_view(rg.a[1], ru.a[1])) continue;
+                if (rg.i0 != ru.i0 || rg.i1 != ru.i1 || rg.kind != ru.kind || rg.i3 != ru.i3 || !same_view(rg.a[1], ru.a[1])) continue;
                 if (rg.i0 % 4 != 0) continue;
                 if (!internal(rg.a[0]) || !internal(ru.a[0]) || !internal(recs[S].a[0]) || !internal(recs[m2].a[0])) continue;
                 if (!only_readers(rg.a[0], {S, m2}) || !only_readers(ru.a[0], {j}) || !only_readers(recs[S].a[0], {m2}) || !only_readers(recs[m2].a[0], {j})) continue;
@@ -396,6 +487,7 @@ void fuse_pending(std::vector<Rec>& recs, std::unordered_map<int, FusePlan>& pla
         if (Mq >= 0 && Mk >= 0 && Mv >= 0 && gemv_rec(Mq) && gemv_rec(Mk) && gemv_rec(Mv) && plan_of[Mq] == Mq && plan_of[Mk] == Mk && plan_of[Mv] == Mv &&
             plans[Mq].epi == EPI_STORE && plans[Mk].epi == EPI_STORE && plans[Mv].epi == EPI_STORE && same_view(recs[Mq].a[1], recs[Mk].a[1]) &&
             same_view(recs[Mq].a[1], recs[Mv].a[1]) && recs[Mq].i1 == recs[Mk].i1 && recs[Mq].i1 == recs[Mv].i1 && recs[Mq].i0 == H * D &&
+            recs[Mq].kind == recs[Mk].kind && recs[Mq].kind == recs[Mv].kind && recs[Mq].i3 == recs[Mk].i3 && recs[Mq].i3 == recs[Mv].i3 &&
             recs[Mk].i0 == Hkv * D && recs[Mv].i0 == Hkv * D && T == 1 && internal(recs[Mq].a[0]) && internal(recs[Mk].a[0]) && internal(recs[Mv].a[0]) &&
             only_readers(recs[Mq].a[0], {sp.nq}) && only_readers(recs[Mk].a[0], {sp.nk}) && only_readers(recs[Mv].a[0], {sp.uv})) {
             const int last = std::max(Mq, std::max(Mk, Mv));
@@ -424,7 +516,7 @@ void fuse_pending(std::vector<Rec>& recs, std::unordered_map<int, FusePlan>& pla
         bool ok = true;
         for (int c : it->second) {
             const Rec& m = recs[c];
-            ok = ok && m.kind == RK_MATMUL && m.flag && plan_of[c] >= 0 && same_view(m.a[1], r.a[0]) && m.i1 == r.i0 && gemv_k_supported(m.i1, true) &&
+            ok = ok && (m.kind == RK_MATMUL || m.kind == RK_QMM) && m.flag && plan_of[c] >= 0 && same_view(m.a[1], r.a[0]) && m.i1 == r.i0 && gemv_k_supported(m.i1, true) &&
                  plans[plan_of[c]].epi != EPI_RESIDUAL;   // (the family has no norm prologue + residual epilogue form)
         }
         if (!ok) continue;

@@ -36,6 +36,14 @@ struct PerOp {
     mlx_array t(mlx_array a) { OP(mlx_transpose(&r, a, s)); }
     mlx_array matmul(mlx_array a, mlx_array b) { OP(mlx_matmul(&r, a, b, s)); }
     mlx_array linear(mlx_array x, mlx_array w) { return matmul(x, t(w)); }      // nn::Linear::forward (linear.rs:87-92), no bias
+    // nn::QuantizedLinear::forward (quantized.rs:366-375): quantized_matmul(x, w, scales, biases, transpose = true, group_size, bits)
+    int q_group = 64, q_bits = 4;
+    mlx_array qmm(mlx_array x, mlx_array w, mlx_array sc, mlx_array bi) {
+        OP(mlx_quantized_matmul(&r, x, w, sc, bi, true, mlx_optional_int{q_group, true}, mlx_optional_int{q_bits, true}, "affine", s));
+    }
+    mlx_array dequantize(mlx_array w, mlx_array sc, mlx_array bi) {
+        OP(mlx_dequantize(&r, w, sc, bi, mlx_optional_int{q_group, true}, mlx_optional_int{q_bits, true}, "affine", mlx_optional_dtype{MLX_BFLOAT16, false}, s));
+    }
     mlx_array reshape(mlx_array a, std::vector<int> sh) { OP(mlx_reshape(&r, a, sh.data(), sh.size(), s)); }
     mlx_array transpose_axes(mlx_array a, std::vector<int> ax) { OP(mlx_transpose_axes(&r, a, ax.data(), ax.size(), s)); }
     mlx_array rope(mlx_array x, int dims, float base, int offset) {
@@ -112,7 +120,12 @@ struct KvCache {
     }
 };
 
-struct LayerW { mlx_array q, k, v, o, gate, up, down, in_ln, post_ln, q_norm, k_norm; };
+// a Linear's tensors: the bf16 matrix, or the (packed weight, scales, biases) triplet of an MLX-quantized checkpoint (model.rs:621-727)
+struct Lin {
+    mlx_array w{nullptr}, sc{nullptr}, bi{nullptr};
+    void release() { for (mlx_array* a : {&w, &sc, &bi}) if (a->ctx) { mlx_array_free(*a); a->ctx = nullptr; } }
+};
+struct LayerW { Lin q, k, v, o, gate, up, down; mlx_array in_ln, post_ln, q_norm, k_norm; };
 
 }  // namespace
 
@@ -134,32 +147,43 @@ extern "C" int omx_bench_qwen3_per_op_ex(omx_qwen3 model, const omx_qwen3_config
     using namespace omx;
     OMX_REQUIRE(model && cfg && prompt && n_prompt > 0 && n_new > 0 && tokens_out, "omx_bench_qwen3_per_op: bad arguments");
     OMX_REQUIRE(n_logit_steps == 0 || (forced && logit_steps && logits_out), "omx_bench_qwen3_per_op_ex: logits are captured in the forced form only");
-    OMX_REQUIRE(cfg->quant_bits == 0 && cfg->num_experts == 0 && cfg->tp_size <= 1, "omx_bench_qwen3_per_op: dense bf16 model on one rank");
+    OMX_REQUIRE(cfg->num_experts == 0 && cfg->tp_size <= 1 && !cfg->quant_scales_f16,
+                "omx_bench_qwen3_per_op: a dense model (bf16, or MLX-quantized with bf16 scales) on one rank");
+    const bool quant = cfg->quant_bits != 0;
     const int hd = cfg->hidden_size, H = cfg->num_attention_heads, Hkv = cfg->num_key_value_heads, D = cfg->head_dim, I = cfg->intermediate_size,
               V = cfg->vocab_size, L = cfg->num_hidden_layers;
-    auto borrow = [&](const std::string& name, std::vector<int> shape, mlx_array* out) -> int {
+    auto borrow = [&](const std::string& name, std::vector<int> shape, mlx_array* out, mlx_dtype dt = MLX_BFLOAT16) -> int {
         const void* p = nullptr;
         size_t nb = 0;
         if (omx_qwen3_get_weight(model, name.c_str(), &p, &nb)) return 1;
-        *out = omx_mlx_array_from_device(p, shape.data(), (int)shape.size(), MLX_BFLOAT16);
+        *out = omx_mlx_array_from_device(p, shape.data(), (int)shape.size(), dt);
         return out->ctx ? 0 : 1;
     };
+    // a Linear [n, k] by its key prefix: `.weight` alone, or the quantized triplet
+    auto borrow_lin = [&](const std::string& prefix, int n, int k, Lin* out) -> int {
+        if (!quant) return borrow(prefix + ".weight", {n, k}, &out->w);
+        return borrow(prefix + ".weight", {n, k * cfg->quant_bits / 32}, &out->w, MLX_UINT32) ||
+               borrow(prefix + ".scales", {n, k / cfg->quant_group}, &out->sc) || borrow(prefix + ".biases", {n, k / cfg->quant_group}, &out->bi);
+    };
     std::vector<LayerW> W(L);
-    mlx_array embed{nullptr}, head{nullptr}, final_norm{nullptr};
-    int rc = borrow("model.embed_tokens.weight", {V, hd}, &embed) || borrow("model.norm.weight", {hd}, &final_norm);
-    if (!rc) rc = cfg->tie_word_embeddings ? 0 : borrow("lm_head.weight", {V, hd}, &head);
+    Lin embed, head;
+    mlx_array final_norm{nullptr};
+    int rc = borrow_lin("model.embed_tokens", V, hd, &embed) || borrow("model.norm.weight", {hd}, &final_norm);
+    if (!rc) rc = cfg->tie_word_embeddings ? 0 : borrow_lin("lm_head", V, hd, &head);
     for (int l = 0; l < L && !rc; ++l) {
         const std::string p = "model.layers." + std::to_string(l) + ".";
-        rc = borrow(p + "self_attn.q_proj.weight", {H * D, hd}, &W[l].q) || borrow(p + "self_attn.k_proj.weight", {Hkv * D, hd}, &W[l].k) ||
-             borrow(p + "self_attn.v_proj.weight", {Hkv * D, hd}, &W[l].v) || borrow(p + "self_attn.o_proj.weight", {hd, H * D}, &W[l].o) ||
-             borrow(p + "mlp.gate_proj.weight", {I, hd}, &W[l].gate) || borrow(p + "mlp.up_proj.weight", {I, hd}, &W[l].up) ||
-             borrow(p + "mlp.down_proj.weight", {hd, I}, &W[l].down) || borrow(p + "input_layernorm.weight", {hd}, &W[l].in_ln) ||
+        rc = borrow_lin(p + "self_attn.q_proj", H * D, hd, &W[l].q) || borrow_lin(p + "self_attn.k_proj", Hkv * D, hd, &W[l].k) ||
+             borrow_lin(p + "self_attn.v_proj", Hkv * D, hd, &W[l].v) || borrow_lin(p + "self_attn.o_proj", hd, H * D, &W[l].o) ||
+             borrow_lin(p + "mlp.gate_proj", I, hd, &W[l].gate) || borrow_lin(p + "mlp.up_proj", I, hd, &W[l].up) ||
+             borrow_lin(p + "mlp.down_proj", hd, I, &W[l].down) || borrow(p + "input_layernorm.weight", {hd}, &W[l].in_ln) ||
              borrow(p + "post_attention_layernorm.weight", {hd}, &W[l].post_ln) || borrow(p + "self_attn.q_norm.weight", {D}, &W[l].q_norm) ||
              borrow(p + "self_attn.k_norm.weight", {D}, &W[l].k_norm);
     }
     if (rc) return 1;
     PerOp P;
     P.s = mlx_default_gpu_stream_new();
+    if (quant) { P.q_group = cfg->quant_group; P.q_bits = cfg->quant_bits; }
+    auto lin = [&](mlx_array x, const Lin& w) { return quant ? P.qmm(x, w.w, w.sc, w.bi) : P.linear(x, w.w); };
     std::vector<KvCache> cache(L);
     const float scale = 1.0f / sqrtf((float)D);
 
@@ -167,14 +191,16 @@ extern "C" int omx_bench_qwen3_per_op_ex(omx_qwen3 model, const omx_qwen3_config
     // (model.rs:387-433 + sampler at temperature 0).  forward's temporaries are dropped before this returns, like Rust drops them at
     // the end of their scopes -- i.e. BEFORE the caller's async_eval: an intermediate nobody holds may then be fused away (mlxc_lazy.hpp).
     auto forward_sample = [&](mlx_array idx, int n, mlx_array* y, mlx_array* keep_logits = nullptr) -> int {
-        mlx_array h = P.take_axis(embed, idx, 0);                                   // Embedding::forward -> [1, n, hidden]
+        // Embedding::forward -> [1, n, hidden]; QuantizedEmbedding (quantized.rs:120-164): the picked rows of the triplet, dequantised
+        mlx_array h = quant ? P.dequantize(P.take_axis(embed.w, idx, 0), P.take_axis(embed.sc, idx, 0), P.take_axis(embed.bi, idx, 0))
+                            : P.take_axis(embed.w, idx, 0);
         const char* mode = n > 1 ? "causal" : "";                                    // create_attention_mask (utils.rs:156-188)
         for (int l = 0; l < L; ++l) {
             const LayerW& w = W[l];
             mlx_array xn = P.rms_norm(h, w.in_ln, cfg->rms_norm_eps);
-            mlx_array q = P.transpose_axes(P.reshape(P.linear(xn, w.q), {1, n, H, D}), {0, 2, 1, 3});
-            mlx_array k = P.transpose_axes(P.reshape(P.linear(xn, w.k), {1, n, Hkv, D}), {0, 2, 1, 3});
-            mlx_array v = P.transpose_axes(P.reshape(P.linear(xn, w.v), {1, n, Hkv, D}), {0, 2, 1, 3});
+            mlx_array q = P.transpose_axes(P.reshape(lin(xn, w.q), {1, n, H, D}), {0, 2, 1, 3});
+            mlx_array k = P.transpose_axes(P.reshape(lin(xn, w.k), {1, n, Hkv, D}), {0, 2, 1, 3});
+            mlx_array v = P.transpose_axes(P.reshape(lin(xn, w.v), {1, n, Hkv, D}), {0, 2, 1, 3});
             q = P.rms_norm(q, w.q_norm, cfg->rms_norm_eps);
             k = P.rms_norm(k, w.k_norm, cfg->rms_norm_eps);
             const int off = cache[l].offset;
@@ -184,15 +210,15 @@ extern "C" int omx_bench_qwen3_per_op_ex(omx_qwen3 model, const omx_qwen3_config
             if (!cache[l].update_and_fetch(P, k, v, Hkv, n, D, &kk, &vv)) return 1;
             mlx_array o = P.sdpa(q, kk, vv, scale, mode);
             o = P.reshape(P.transpose_axes(o, {0, 2, 1, 3}), {1, n, H * D});
-            mlx_array h1 = P.add(h, P.linear(o, w.o));
+            mlx_array h1 = P.add(h, lin(o, w.o));
             mlx_array hn = P.rms_norm(h1, w.post_ln, cfg->rms_norm_eps);
-            mlx_array g = P.linear(hn, w.gate);
-            mlx_array act = P.mul(P.mul(g, P.sigmoid(g)), P.linear(hn, w.up));       // nn::silu(gate) * up
-            h = P.add(h1, P.linear(act, w.down));
+            mlx_array g = lin(hn, w.gate);
+            mlx_array act = P.mul(P.mul(g, P.sigmoid(g)), lin(hn, w.up));       // nn::silu(gate) * up
+            h = P.add(h1, lin(act, w.down));
             if (P.failed) return 1;
         }
         mlx_array hf = P.rms_norm(h, final_norm, cfg->rms_norm_eps);
-        mlx_array logits = P.linear(hf, cfg->tie_word_embeddings ? embed : head);     // all n positions, like the reference (model.rs:815 keeps the last)
+        mlx_array logits = lin(hf, cfg->tie_word_embeddings ? embed : head);     // all n positions, like the reference (model.rs:815 keeps the last)
         if (n > 1) logits = P.slice(logits, {0, n - 1, 0}, {1, n, V});
         mlx_array t = P.argmax(logits);                                               // [1, 1]
         if (P.failed) return 1;
@@ -277,10 +303,12 @@ extern "C" int omx_bench_qwen3_per_op_ex(omx_qwen3 model, const omx_qwen3_config
     if (calls_per_token) *calls_per_token = (double)(P.calls - calls0) / n_new;
     P.sweep();
     for (auto& c : cache) c.release();
-    for (auto& w : W)
-        for (mlx_array a : {w.q, w.k, w.v, w.o, w.gate, w.up, w.down, w.in_ln, w.post_ln, w.q_norm, w.k_norm}) mlx_array_free(a);
-    mlx_array_free(embed); mlx_array_free(final_norm);
-    if (head.ctx) mlx_array_free(head);
+    for (auto& w : W) {
+        for (Lin* l : {&w.q, &w.k, &w.v, &w.o, &w.gate, &w.up, &w.down}) l->release();
+        for (mlx_array a : {w.in_ln, w.post_ln, w.q_norm, w.k_norm}) mlx_array_free(a);
+    }
+    embed.release(); head.release();
+    mlx_array_free(final_norm);
     if (rc) return omx::set_error("omx_bench_qwen3_per_op: an mlx_* call failed: %s", omx_last_error());
     return 0;
 }

@@ -181,3 +181,30 @@ def test_drop_in_route_fuses_and_keeps_its_tokens(omx, mx):
     assert per_decode_pass <= 8 * cfg["num_hidden_layers"] + 4, per_decode_pass
     assert s1["fused_launches"] - s0["fused_launches"] >= 5 * cfg["num_hidden_layers"] * (passes - 1)
     m.close()
+
+
+@pytest.mark.parametrize("bits", [4, 8])
+def test_drop_in_route_on_a_quantized_checkpoint(omx, mx, bits):
+    """The reference's flagship format (qwen3-mlx/README.md:102: MLX 4-bit): every Linear is quantized_matmul on a (weight, scales, biases)
+    triplet, the embedding dequantises its rows (quantized.rs:120-164, 361-385).  The replay drives exactly those calls; the deferred list
+    rewrites them onto the packed-GEMV family -- quant.hip, and for 4-bit K = 4096 matrices the matrix-core kernel on tiles it builds once
+    per weight buffer (qgemv_mfma.hip) -- with the same prologues / epilogues as the bf16 idioms.  The three modes agree on every token on
+    the VALU kernels; where the matrix-core kernel steps in (4-bit, hidden 4096) its different accumulation order is allowed to move a
+    near-tie, so that case is held to the engine's tokens through their common prefix and to the bound of the logits instead."""
+    from ominix_mlx_amd import engine
+    cfg = dict(hidden_size=1024, num_hidden_layers=2, intermediate_size=2048, num_attention_heads=8, num_key_value_heads=4, head_dim=128,
+               vocab_size=2048, rms_norm_eps=1e-6, rope_theta=1e6, tie_word_embeddings=False)
+    m = engine.Model(max_context=512, quantization={"bits": bits, "group_size": 64}, **cfg)
+    m.synth_weights()
+    prompt = synth.prompt_ids(100, cfg["vocab_size"])
+    want = [int(m.prefill(prompt))] + [int(t) for t in m.decode(60)]
+    runs = {}
+    for name, (lazy, fuse) in {"eager": (False, False), "recorded": (True, False), "fused": (True, True)}.items():
+        mx.lazy_mode(lazy, fuse)
+        s0 = mx.lazy_stats()
+        runs[name] = ([int(t) for t in m.per_op_route(prompt, 60)["tokens"]], s0, mx.lazy_stats())
+    assert runs["eager"][0] == runs["recorded"][0] == runs["fused"][0]       # K = 1024 / 2048: the VALU kernels in every mode
+    assert runs["fused"][0][:24] == want[:24]
+    _, s0, s1 = runs["fused"]
+    assert s1["fused_launches"] - s0["fused_launches"] >= 5 * cfg["num_hidden_layers"] * 60
+    m.close()

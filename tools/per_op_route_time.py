@@ -1,6 +1,6 @@
 """The drop-in route (csrc/per_op_route.hip: qwen3-mlx's forward + Generate::next replayed through the mlx-c ABI) timed next to the engine on
 Qwen3-8B shapes, with the deferred list's counters (mlxc_lazy.hpp).  OMX_MLX_LAZY=0 / OMX_MLX_FUSE=0 for the A/B.
-usage: python tools/per_op_route_time.py [prompt] [tokens]"""
+usage: python tools/per_op_route_time.py [prompt] [tokens] [bits: 0 | 4 | 8]"""
 import ctypes, json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402
@@ -11,6 +11,9 @@ from ominix_mlx_amd import engine  # noqa: E402
 n_prompt = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
 n_tok = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 cfg = dict(bench.QWEN3_8B)
+bits = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+if bits:
+    cfg["quantization"] = {"bits": bits, "group_size": 64}       # the same shapes as an MLX-quantized checkpoint (qwen3-mlx/README.md:102)
 ids = bench.prompt_ids(n_prompt, cfg["vocab_size"])
 m = engine.Model(max_context=n_prompt + 2 * n_tok + 64, **cfg)
 m.synth_weights()

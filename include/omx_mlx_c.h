@@ -322,6 +322,9 @@ void omx_mlx_lazy_stats(long* out6);
 /* ... and its switches at run time: lazy 0 = every call launches as it is made, fuse 0 = recorded ops launch as recorded (default 1, 1;
  * OMX_MLX_LAZY / OMX_MLX_FUSE in the environment set the initial state) */
 int omx_mlx_lazy_mode(int lazy, int fuse);
+/* the launch worker behind mlx_async_eval: 1 = a worker thread rewrites and launches the recorded list while the caller records on
+ * -- measured slower on this hardware, so 0 = the calling thread launches at the evaluation point is the default (OMX_MLX_ASYNC=1 starts with the worker) */
+int omx_mlx_lazy_async(int on);
 int omx_mlx_fused_swiglu(mlx_array* res, const mlx_array x, const mlx_array gate, const mlx_stream s);
 int omx_mlx_fused_modulate(mlx_array* res, const mlx_array x, const mlx_array shift, const mlx_array scale,
                            const mlx_stream s);

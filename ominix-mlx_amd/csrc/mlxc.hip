@@ -9,6 +9,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -71,6 +72,7 @@ struct Buf {
     bool owned;                     // false: device memory BORROWED from the caller (omx_mlx_array_from_device): never returned to the pool
     uint64_t seq = 0;               // the flush (mlxc_lazy.hpp) whose launches last wrote it; 0: written by launches outside any flush
     std::shared_ptr<void> aux;      // derived forms of a packed weight the deferred list built on first use (scale | bias words, matrix-core tiles)
+    std::atomic<int> inflight{0};   // references held by recorded / submitted ops (not by anything a caller can reach): what "solely owned" ignores
     Buf(void* p_, size_t b, bool owned_ = true) : p(p_), bytes(b), owned(owned_) {}
     ~Buf() { if (p && owned) g_pool.put(p, bytes); }
 };
@@ -78,13 +80,16 @@ struct Buf {
 // deferred execution (mlxc_lazy.hpp): ops may be RECORDED instead of launched; ptr() -- the only way to a buffer's address -- executes
 // the recorded list first, unless the caller is a recorded launch itself
 }  // namespace
-int flush_pending();
+int flush_pending();                // everything recorded so far has been LAUNCHED when this returns
+int submit_pending();               // ... has been handed to the launch worker (mlx_async_eval)
+int wait_issued(uint64_t seq);      // the launch worker has sent batch `seq` (and recorded its event)
 namespace {
-int g_lazy_busy = 0;
+std::atomic<int> g_batches_in_flight{0};   // batches handed to the worker and not yet launched
+thread_local int g_lazy_busy = 0;  // > 0: this thread is executing recorded ops (the launch worker, or an immediate run)
 size_t g_n_pending = 0;
 bool g_deferred_failed = false;    // a flush forced from inside ptr() failed: reported by the next evaluation point
-uint64_t g_flush_seq = 0;          // every flush records an event behind its launches: item() / data() wait for the producing flush only,
-constexpr int kEvRing = 64;        // not for the step the caller has queued behind it (qwen3-mlx Generate::next, model.rs:804-843)
+uint64_t g_flush_seq = 0;          // batches handed over so far; every batch records an event behind its launches: item() / data() wait for the
+constexpr int kEvRing = 64;        // producing batch only, not for the step the caller has queued behind it (Generate::next, model.rs:804-843)
 hipEvent_t g_flush_ev[kEvRing] = {};
 hipStream_t g_copy_stream = nullptr;
 
@@ -98,7 +103,8 @@ struct Arr {
     bool donated = false;           // its buffer was updated in place on behalf of a slice_update result (see there)
     size_t size() const { size_t n = 1; for (int d : shape) n *= (size_t)d; return n; }
     char* ptr() const {
-        if (g_n_pending && !g_lazy_busy && flush_pending()) g_deferred_failed = true;   // (no status to return here: the next evaluation point reports it)
+        if (!g_lazy_busy && (g_n_pending || g_batches_in_flight.load(std::memory_order_acquire)) && flush_pending())
+            g_deferred_failed = true;   // (no status to return here: the next evaluation point reports it)
         return (char*)buf->p + off;
     }
 };
@@ -454,6 +460,7 @@ int take_deferred_error() {
 int read_back(void* dst, const Arr& a, const char* src, size_t bytes) {
     if (take_deferred_error()) return 1;
     const uint64_t seq = a.buf->seq;
+    if (seq && wait_issued(seq)) return 1;
     hipEvent_t ev = (seq && g_flush_seq - seq < (uint64_t)kEvRing - 1) ? g_flush_ev[seq % kEvRing] : nullptr;
     if (ev) {
         if (!g_copy_stream) OMX_HIP_CHECK(hipStreamCreateWithFlags(&g_copy_stream, hipStreamNonBlocking));
@@ -471,7 +478,9 @@ int item_host(const mlx_array h, void* dst, mlx_dtype want, const char* name) {
     const Arr& a = *A(h);
     OMX_REQUIRE(a.size() == 1, "%s: item() needs a size-1 array (size %zu)", name, a.size());
     OMX_REQUIRE(a.dt == want || dsize(a.dt) == dsize(want), "%s: dtype mismatch", name);
-    return read_back(dst, a, a.ptr(), dsize(a.dt));
+    // (not through ptr(): that would wait until EVERYTHING recorded has been launched, the step the caller queued behind this value included)
+    if (g_n_pending && a.buf->seq > g_flush_seq && submit_pending()) return 1;
+    return read_back(dst, a, (const char*)a.buf->p + a.off, dsize(a.dt));
 }
 const void* data_host(const mlx_array h) {
     if (!h.ctx) return nullptr;
@@ -484,7 +493,7 @@ const void* data_host(const mlx_array h) {
         if (c.owned) {    // a strided view was gathered by a launch of this call: on the stream, behind everything
             if (hipMemcpyAsync(a->host.data(), c.a->ptr(), bytes, hipMemcpyDeviceToHost, g_stream) != hipSuccess) return nullptr;
             if (hipStreamSynchronize(g_stream) != hipSuccess || take_deferred_error()) return nullptr;
-        } else if (read_back(a->host.data(), *a, c.a->ptr(), bytes)) {
+        } else if ((g_n_pending && a->buf->seq > g_flush_seq && submit_pending()) || read_back(a->host.data(), *a, (const char*)a->buf->p + a->off, bytes)) {
             return nullptr;
         }
     } else if (hipStreamSynchronize(g_stream) != hipSuccess) {
@@ -622,7 +631,7 @@ mlx_stream mlx_default_cpu_stream_new(void) {
 mlx_stream mlx_default_gpu_stream_new(void) { return mlx_stream{new Str{false}}; }
 // transforms.h:30,42 -- the evaluation points of the deferred list (mlxc_lazy.hpp): async_eval sends the recorded launches and returns,
 // eval waits for them.  Everything recorded goes out, not only what the given arrays depend on (one in-order stream; a superset is allowed).
-int mlx_async_eval(const mlx_vector_array) { return (flush_pending() || take_deferred_error()) ? 1 : 0; }
+int mlx_async_eval(const mlx_vector_array) { return (submit_pending() || take_deferred_error()) ? 1 : 0; }
 int mlx_eval(const mlx_vector_array) {
     if (flush_pending() || take_deferred_error()) return 1;
     OMX_HIP_CHECK(hipStreamSynchronize(g_stream));
@@ -637,6 +646,12 @@ int omx_mlx_lazy_mode(int lazy, int fuse) {
     g_lazy_on = lazy != 0;
     g_lazy_env_read = true;
     g_fuse_mode = fuse != 0;
+    return 0;
+}
+/* ... and the launch worker: 1 = mlx_async_eval hands the recorded list to a worker thread, 0 = the caller's thread launches it (default) */
+int omx_mlx_lazy_async(int on) {
+    if (flush_pending()) return 1;
+    g_async_mode = on != 0;
     return 0;
 }
 void omx_mlx_lazy_stats(long* out6) { for (int i = 0; i < 6; ++i) out6[i] = g_lazy_stats[i]; }
@@ -998,17 +1013,27 @@ int mlx_dequantize(mlx_array* res, const mlx_array w, const mlx_array scales, co
     REQ_ARR(w, "mlx_dequantize"); REQ_ARR(scales, "mlx_dequantize");
     int g, b;
     if (quant_params("mlx_dequantize", group_size, bits, mode, &g, &b)) return 1;
-    Contig cw, cs, cb;
-    if (cw.init(*A(w)) || cs.init(*A(scales)) || (biases.ctx && cb.init(*A(biases)))) return 1;
-    OMX_REQUIRE(cw.a->dt == MLX_UINT32 && !cw.a->shape.empty(), "mlx_dequantize: w must be a packed uint32 array");
-    OMX_REQUIRE(!dtype.has_value || dtype.value == cs.a->dt, "mlx_dequantize: output dtype must be the dtype of scales");
-    const int K = cw.a->shape.back() * 32 / b;
-    OMX_REQUIRE(cs.a->size() * (size_t)g == cw.a->size() * 32 / b, "mlx_dequantize: scales shape does not match w / group_size");
-    std::vector<int> shape = cw.a->shape;
+    const Arr &w0 = *A(w), &s0 = *A(scales);
+    if (biases.ctx) REQ_ARR(biases, "mlx_dequantize");
+    OMX_REQUIRE(w0.dt == MLX_UINT32 && !w0.shape.empty(), "mlx_dequantize: w must be a packed uint32 array");
+    OMX_REQUIRE(!dtype.has_value || dtype.value == s0.dt, "mlx_dequantize: output dtype must be the dtype of scales");
+    const int K = w0.shape.back() * 32 / b;
+    OMX_REQUIRE(s0.size() * (size_t)g == w0.size() * 32 / b, "mlx_dequantize: scales shape does not match w / group_size");
+    std::vector<int> shape = w0.shape;
     shape.back() = K;
-    NEW_OR_FAIL(r, shape, cs.a->dt);
-    if (omx_dequantize(r->ptr(), cw.a->ptr(), cs.a->ptr(), biases.ctx ? cb.a->ptr() : nullptr, K ? (int64_t)(r->size() / K) : 0, K, g, b,
-                       to_omx(cs.a->dt), g_stream)) { delete r; return 1; }
+    NEW_OR_FAIL(r, shape, s0.dt);
+    Rec rec;
+    rec.a[0] = *r; rec.a[1] = w0; rec.a[2] = s0; rec.na = 3;
+    if (biases.ctx) { rec.a[3] = *A(biases); rec.na = 4; }
+    rec.i0 = K; rec.i1 = g; rec.i2 = b;
+    rec.run = [](Rec& q) -> int {
+        Contig cw, cs, cb;
+        if (cw.init(q.a[1]) || cs.init(q.a[2]) || (q.na > 3 && cb.init(q.a[3]))) return 1;
+        const int K = q.i0;
+        return omx_dequantize(q.a[0].ptr(), cw.a->ptr(), cs.a->ptr(), q.na > 3 ? cb.a->ptr() : nullptr, K ? (int64_t)(q.a[0].size() / K) : 0, K, q.i1,
+                              q.i2, to_omx(cs.a->dt), g_stream);
+    };
+    if (record(std::move(rec))) { delete r; return 1; }
     return assign(res, r);
 }
 int mlx_quantized_matmul(mlx_array* res, const mlx_array x, const mlx_array w, const mlx_array scales, const mlx_array biases,
@@ -1193,7 +1218,9 @@ int mlx_slice_update(mlx_array* res, const mlx_array src, const mlx_array update
     // which makes the update copy.  (include/omx_mlx_c.h states the contract.)
     Arr* r = nullptr;
     bool donate = false;
-    if (is_contig(s) && s.buf.use_count() == 1 && s.buf->owned) {   // (a borrowed buffer is the caller's: never updated in place)
+    // solely owned: no other handle, view or vector entry shares the buffer.  References held by recorded ops do not count -- they run in call
+    // order, an earlier reader still sees the old rows -- or every step of Generate::next would copy the cache while the previous step is in flight
+    if (is_contig(s) && s.buf.use_count() - s.buf->inflight.load() == 1 && s.buf->owned) {   // (a borrowed buffer is the caller's: never updated in place)
         r = new Arr(s);
         r->host.clear();
         donate = !(res && res->ctx == src.ctx);   // the same handle is replaced by assign() below: nothing left to mark

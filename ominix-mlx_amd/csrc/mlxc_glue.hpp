@@ -390,25 +390,34 @@ int unary2(mlx_array* res, const mlx_array ha, int op, const char* name) {
 }
 }  // namespace
 int take_axis_general(mlx_array* res, const Arr& a, const Arr& ind, int ax) {
-    Contig ca, ci;
-    if (ca.init(a) || ci.init(ind)) return 1;
-    size_t outer = 1, inner = 1;
-    for (int i = 0; i < ax; ++i) outer *= (size_t)a.shape[i];
-    for (size_t i = ax + 1; i < a.shape.size(); ++i) inner *= (size_t)a.shape[i];
     std::vector<int> shape(a.shape.begin(), a.shape.begin() + ax);
     shape.insert(shape.end(), ind.shape.begin(), ind.shape.end());
     shape.insert(shape.end(), a.shape.begin() + ax + 1, a.shape.end());
     NEW_OR_FAIL(r, shape, a.dt);
-    const size_t n = r->size(), n_idx = ind.size();
-    if (n) {
-        switch (dsize(a.dt)) {
-            case 1: take_axis_kernel<1><<<grid_for(n), 256, 0, g_stream>>>(r->ptr(), ca.a->ptr(), ci.a->ptr(), ind.dt, outer, a.shape[ax], inner, n_idx); break;
-            case 2: take_axis_kernel<2><<<grid_for(n), 256, 0, g_stream>>>(r->ptr(), ca.a->ptr(), ci.a->ptr(), ind.dt, outer, a.shape[ax], inner, n_idx); break;
-            case 4: take_axis_kernel<4><<<grid_for(n), 256, 0, g_stream>>>(r->ptr(), ca.a->ptr(), ci.a->ptr(), ind.dt, outer, a.shape[ax], inner, n_idx); break;
-            default: take_axis_kernel<8><<<grid_for(n), 256, 0, g_stream>>>(r->ptr(), ca.a->ptr(), ci.a->ptr(), ind.dt, outer, a.shape[ax], inner, n_idx); break;
+    Rec rec;                       // deferred like the row gather of a floating table (a QuantizedEmbedding takes rows of packed words)
+    rec.a[0] = *r; rec.a[1] = a; rec.a[2] = ind; rec.na = 3;
+    rec.i0 = ax;
+    rec.run = [](Rec& q) -> int {
+        const Arr &a = q.a[1], &ind = q.a[2];
+        const int ax = q.i0;
+        Contig ca, ci;
+        if (ca.init(a) || ci.init(ind)) return 1;
+        size_t outer = 1, inner = 1;
+        for (int i = 0; i < ax; ++i) outer *= (size_t)a.shape[i];
+        for (size_t i = ax + 1; i < a.shape.size(); ++i) inner *= (size_t)a.shape[i];
+        const size_t n = q.a[0].size(), n_idx = ind.size();
+        if (n) {
+            switch (dsize(a.dt)) {
+                case 1: take_axis_kernel<1><<<grid_for(n), 256, 0, g_stream>>>(q.a[0].ptr(), ca.a->ptr(), ci.a->ptr(), ind.dt, outer, a.shape[ax], inner, n_idx); break;
+                case 2: take_axis_kernel<2><<<grid_for(n), 256, 0, g_stream>>>(q.a[0].ptr(), ca.a->ptr(), ci.a->ptr(), ind.dt, outer, a.shape[ax], inner, n_idx); break;
+                case 4: take_axis_kernel<4><<<grid_for(n), 256, 0, g_stream>>>(q.a[0].ptr(), ca.a->ptr(), ci.a->ptr(), ind.dt, outer, a.shape[ax], inner, n_idx); break;
+                default: take_axis_kernel<8><<<grid_for(n), 256, 0, g_stream>>>(q.a[0].ptr(), ca.a->ptr(), ci.a->ptr(), ind.dt, outer, a.shape[ax], inner, n_idx); break;
+            }
+            OMX_LAUNCH_CHECK();
         }
-        OMX_LAUNCH_CHECK();
-    }
+        return 0;
+    };
+    if (record(std::move(rec))) { delete r; return 1; }
     return assign(res, r);
 }
 namespace {

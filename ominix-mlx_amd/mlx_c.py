@@ -398,6 +398,7 @@ SIGNATURES = {
     "omx_mlx_array_from_device": (mlx_array, [ctypes.c_void_p, P_INT, c_int, c_int]),
     "omx_mlx_lazy_stats": (None, [ctypes.POINTER(ctypes.c_long)]),
     "omx_mlx_lazy_mode": (c_int, [c_int, c_int]),
+    "omx_mlx_lazy_async": (c_int, [c_int]),
     "omx_mlx_fused_swiglu": (c_int, [P_ARR, mlx_array, mlx_array, mlx_stream]),
     "omx_mlx_fused_modulate": (c_int, [P_ARR, mlx_array, mlx_array, mlx_array, mlx_stream]),
 }
@@ -1062,8 +1063,9 @@ def lazy_stats() -> dict:
     return {"recorded": v[0], "launched_as_recorded": v[1], "fused_launches": v[2], "flushes": v[3], "flush_host_ns": v[4], "rewrite_ns": v[5]}
 
 
-def lazy_mode(lazy: bool = True, fuse: bool = True) -> None:
+def lazy_mode(lazy: bool = True, fuse: bool = True, worker: bool = False) -> None:
     _check(lib.omx_mlx_lazy_mode(1 if lazy else 0, 1 if fuse else 0))
+    _check(lib.omx_mlx_lazy_async(1 if worker else 0))
 
 
 def async_eval(*arrays) -> None:

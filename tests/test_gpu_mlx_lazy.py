@@ -169,11 +169,12 @@ def test_drop_in_route_fuses_and_keeps_its_tokens(omx, mx):
     prompt = synth.prompt_ids(300, cfg["vocab_size"])
     n_new = 220                                            # crosses the cache's 512-token growth
     runs = {}
-    for name, (lazy, fuse) in {"eager": (False, False), "recorded": (True, False), "fused": (True, True)}.items():
-        mx.lazy_mode(lazy, fuse)
+    for name, (lazy, fuse, worker) in {"eager": (False, False, False), "recorded": (True, False, False), "fused": (True, True, False),
+                                       "fused, launch worker": (True, True, True)}.items():
+        mx.lazy_mode(lazy, fuse, worker)
         s0 = mx.lazy_stats()
         runs[name] = ([int(t) for t in m.per_op_route(prompt, n_new)["tokens"]], s0, mx.lazy_stats())
-    assert runs["eager"][0] == runs["recorded"][0] == runs["fused"][0]
+    assert runs["eager"][0] == runs["recorded"][0] == runs["fused"][0] == runs["fused, launch worker"][0]
     _, s0, s1 = runs["fused"]
     passes = n_new + 2                                     # the prompt, then one decode pass per token and the one Generate keeps in flight
     launches = (s1["launched_as_recorded"] - s0["launched_as_recorded"]) + (s1["fused_launches"] - s0["fused_launches"])

@@ -360,6 +360,19 @@ def quantized_secondary(omx, cfg, args, bits=4):
                              "frac_of_hbm_peak": round(step_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBPS, 4)},
            "prefill_device_ms": round(prefill_first_ms, 2), "prefill_device_ms_steady": round(prefill_steady_ms, 2),
            "first_tokens": [int(first)] + [int(t) for t in toks[:4]], "first_token_again": int(again)}
+    # the same checkpoint through the DROP-IN route: qwen3-mlx's forward with every Linear a quantized_matmul on the (weight, scales, biases)
+    # triplet, the embedding dequantising its rows -- what the unmodified crate calls on the reference's flagship format
+    try:
+        m.per_op_route(prompt, 1)                 # (first call: the route's buffers and the packed matrices' derived forms are built here)
+        r = m.per_op_route(prompt, 64)
+        out["per_op_route"] = {"metric": f"decode_tokens_per_sec_per_op_route_{bits}bit", "value": round(1e3 / r["ms_per_token"], 2), "unit": "tokens/s",
+                               "ms_per_token_host_wall": round(r["ms_per_token"], 3), "mlx_calls_per_token": round(r["calls_per_token"], 1),
+                               "tokens_timed": 64, "vs_engine": round((1e3 / r["ms_per_token"]) / (args.steps / elapsed), 3),
+                               "first_tokens": [int(t) for t in r["tokens"][:5]],
+                               "note": "csrc/per_op_route.hip on this model's packed weights through the mlx-c ABI (mlx_quantized_matmul, mlx_dequantize, "
+                                       "mlx_take_axis ...), the deferred list rewriting the calls onto the packed-GEMV family (csrc/mlxc_lazy.hpp)"}
+    except Exception as e:   # a report, never a reason to lose the measured line
+        out["per_op_route"] = {"value": None, "error": str(e)[:300]}
     m.close()
     return out
 

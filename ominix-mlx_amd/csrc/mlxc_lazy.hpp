@@ -344,51 +344,106 @@ int run_plan(std::vector<Rec>& recs, const FusePlan& p) {
 void fuse_pending(std::vector<Rec>& recs, std::unordered_map<int, FusePlan>& plans) {
     using namespace omx;
     const int n = (int)recs.size();
-    std::unordered_map<const Buf*, int> nref;                  // references the pending list holds on each buffer
-    std::unordered_map<const Buf*, int> prod;                  // the one pending record that writes a buffer (-2: several)
-    std::unordered_map<const Buf*, std::vector<int>> readers;  // pending records reading it
+    // one flat table over the buffers the list touches (this pass runs once per decoded token on ~800 records: node-based maps were a third
+    // of a millisecond): per buffer the references the list holds, the one record that writes it (-2: several), the last slice_update into it,
+    // and its readers as a slice of one array
+    struct BufInfo { const Buf* b; int nref, prod, writer, rd_begin, rd_n; };
+    size_t cap = 64;
+    while (cap < (size_t)n * 8) cap <<= 1;
+    static thread_local std::vector<int> slot_of;        // hash slot -> index into `info` (+1; 0 = empty)
+    static thread_local std::vector<BufInfo> info;
+    static thread_local std::vector<int> rd, opid;
+    slot_of.assign(cap, 0);
+    info.clear();
+    opid.assign((size_t)n * 5, -1);
+    auto find = [&](const Buf* b) -> int {
+        size_t h = ((uintptr_t)b >> 4) * 0x9E3779B97F4A7C15ull >> 20 & (cap - 1);
+        while (slot_of[h]) {
+            if (info[slot_of[h] - 1].b == b) return slot_of[h] - 1;
+            h = (h + 1) & (cap - 1);
+        }
+        return -1;
+    };
+    auto intern = [&](const Buf* b) -> int {
+        size_t h = ((uintptr_t)b >> 4) * 0x9E3779B97F4A7C15ull >> 20 & (cap - 1);
+        while (slot_of[h]) {
+            if (info[slot_of[h] - 1].b == b) return slot_of[h] - 1;
+            h = (h + 1) & (cap - 1);
+        }
+        info.push_back(BufInfo{b, 0, -1, -1, 0, 0});
+        slot_of[h] = (int)info.size();
+        return (int)info.size() - 1;
+    };
     bool any_mm = false;
     for (int i = 0; i < n; ++i) {
         const Rec& r = recs[i];
         for (int k = 0; k < r.na; ++k)
-            if (r.a[k].buf) ++nref[r.a[k].buf.get()];
-        if (r.na && r.a[0].buf) {
-            auto it = prod.find(r.a[0].buf.get());
-            if (it == prod.end()) prod[r.a[0].buf.get()] = i; else it->second = -2;
-        }
-        for (int k = 1; k < r.na; ++k)
             if (r.a[k].buf) {
-                auto& v = readers[r.a[k].buf.get()];
-                if (v.empty() || v.back() != i) v.push_back(i);
+                const int id = intern(r.a[k].buf.get());
+                opid[(size_t)i * 5 + k] = id;
+                ++info[id].nref;
+                if (k == 0) {
+                    info[id].prod = info[id].prod == -1 ? i : -2;
+                    if (r.kind == RK_SLICE_UPDATE) info[id].writer = i;
+                } else {
+                    ++info[id].rd_n;          // (an upper bound: the fill below lists a record once per buffer)
+                }
             }
         any_mm = any_mm || ((r.kind == RK_MATMUL || r.kind == RK_QMM) && r.flag);
     }
     if (!any_mm) return;
+    {
+        int at = 0;
+        for (auto& bi : info) { bi.rd_begin = at; at += bi.rd_n; bi.rd_n = 0; }
+        rd.assign((size_t)at, -1);
+        for (int i = 0; i < n; ++i) {
+            const Rec& r = recs[i];
+            for (int k = 1; k < r.na; ++k) {
+                const int id = opid[(size_t)i * 5 + k];
+                if (id < 0) continue;
+                BufInfo& bi = info[id];
+                if (bi.rd_n && rd[bi.rd_begin + bi.rd_n - 1] == i) continue;
+                rd[bi.rd_begin + bi.rd_n++] = i;
+            }
+        }
+    }
     auto internal = [&](const Arr& x) {   // nothing outside the pending list can see this buffer
-        return x.buf && x.buf->owned && (long)x.buf.use_count() == (long)nref[x.buf.get()];
+        if (!x.buf || !x.buf->owned) return false;
+        const int id = find(x.buf.get());
+        return id >= 0 && (long)x.buf.use_count() == (long)info[id].nref;
     };
     auto producer = [&](const Arr& x, int before) -> int {
         if (!x.buf) return -1;
-        auto it = prod.find(x.buf.get());
-        if (it == prod.end() || it->second < 0 || it->second >= before) return -1;
-        return same_view(recs[it->second].a[0], x) ? it->second : -1;
+        const int id = find(x.buf.get());
+        if (id < 0 || info[id].prod < 0 || info[id].prod >= before) return -1;
+        return same_view(recs[info[id].prod].a[0], x) ? info[id].prod : -1;
     };
     auto producer_of_buf = [&](const Arr& x) -> int {      // the record whose result this is a re-shaped / transposed view of
         if (!x.buf) return -1;
-        auto it = prod.find(x.buf.get());
-        if (it == prod.end() || it->second < 0) return -1;
-        const Arr& o = recs[it->second].a[0];
-        return (o.off == x.off && o.size() == x.size()) ? it->second : -1;
+        const int id = find(x.buf.get());
+        if (id < 0 || info[id].prod < 0) return -1;
+        const Arr& o = recs[info[id].prod].a[0];
+        return (o.off == x.off && o.size() == x.size()) ? info[id].prod : -1;
+    };
+    auto readers_of = [&](const Arr& x, const int** first) -> int {
+        const int id = x.buf ? find(x.buf.get()) : -1;
+        if (id < 0) { *first = nullptr; return 0; }
+        *first = rd.data() + info[id].rd_begin;
+        return info[id].rd_n;
     };
     auto only_readers = [&](const Arr& x, std::initializer_list<int> who) {
-        auto it = readers.find(x.buf.get());
-        if (it == readers.end()) return who.size() == 0;
-        for (int r : it->second) {
+        const int* first = nullptr;
+        const int cnt = readers_of(x, &first);
+        for (int t = 0; t < cnt; ++t) {
             bool ok = false;
-            for (int w : who) ok = ok || r == w;
+            for (int w : who) ok = ok || first[t] == w;
             if (!ok) return false;
         }
         return true;
+    };
+    auto writer_of = [&](const Arr& x) -> int {
+        const int id = x.buf ? find(x.buf.get()) : -1;
+        return id < 0 ? -1 : info[id].writer;
     };
     auto gemv_rec = [&](int i) { return i >= 0 && (recs[i].kind == RK_MATMUL || recs[i].kind == RK_QMM) && recs[i].flag && !recs[i].dead; };
     std::vector<int> plan_of(n, -1);       // matmul record -> the record index its plan is keyed by
@@ -453,9 +508,6 @@ void fuse_pending(std::vector<Rec>& recs, std::unordered_map<int, FusePlan>& pla
     // ---- attention preparation: anchored at the SDPA record.  q <- rope <- rms_norm(q_norm) <- [1, H, T, D] view of the q projection;
     //      the k operand's buffer is written by a slice_update whose update is rope <- rms_norm(k_norm) <- view of the k projection, the
     //      v operand's by a slice_update of the v projection's view (KVCache::update_and_fetch, cache.rs:140-193) ----
-    std::unordered_map<const Buf*, int> writer;          // last pending slice_update into a buffer
-    for (int i = 0; i < n; ++i)
-        if (recs[i].kind == RK_SLICE_UPDATE && recs[i].a[0].buf) writer[recs[i].a[0].buf.get()] = i;
     auto headed_view = [&](const Arr& v, int heads, int T, int D) {   // [1, heads, T, D] over row-major [1, T, heads * D]
         return v.shape.size() == 4 && v.shape[0] == 1 && v.shape[1] == heads && v.shape[2] == T && v.shape[3] == D && v.strides[3] == 1 &&
                v.strides[1] == (size_t)D && (T == 1 || v.strides[2] == (size_t)heads * D) && v.dt == MLX_BFLOAT16;
@@ -469,9 +521,8 @@ void fuse_pending(std::vector<Rec>& recs, std::unordered_map<int, FusePlan>& pla
         if ((D != 64 && D != 128) || q2.shape[0] != 1) continue;
         ScatterPlan sp;
         sp.rq = producer(q2, j);
-        auto wk = writer.find(kv.buf.get()), wv = writer.find(vv.buf.get());
-        if (sp.rq < 0 || wk == writer.end() || wv == writer.end()) continue;
-        sp.uk = wk->second; sp.uv = wv->second;
+        sp.uk = writer_of(kv); sp.uv = writer_of(vv);
+        if (sp.rq < 0 || sp.uk < 0 || sp.uv < 0) continue;
         if (sp.uk >= j || sp.uv >= j || recs[sp.uk].dead || recs[sp.uv].dead) continue;
         const Rec &rq = recs[sp.rq], &uk = recs[sp.uk], &uv = recs[sp.uv];
         if (rq.kind != RK_ROPE || !rq.flag || rq.dead || !is_contig(rq.a[0])) continue;
@@ -532,16 +583,18 @@ void fuse_pending(std::vector<Rec>& recs, std::unordered_map<int, FusePlan>& pla
     for (int i = 0; i < n; ++i) {
         Rec& r = recs[i];
         if (r.kind != RK_RMSNORM || !r.flag || r.dead || !internal(r.a[0])) continue;
-        auto it = readers.find(r.a[0].buf.get());
-        if (it == readers.end() || it->second.empty()) continue;
+        const int* first = nullptr;
+        const int cnt = readers_of(r.a[0], &first);
+        if (cnt == 0) continue;
         bool ok = true;
-        for (int c : it->second) {
+        for (int t = 0; t < cnt; ++t) {
+            const int c = first[t];
             const Rec& m = recs[c];
             ok = ok && (m.kind == RK_MATMUL || m.kind == RK_QMM) && m.flag && plan_of[c] >= 0 && same_view(m.a[1], r.a[0]) && m.i1 == r.i0 && gemv_k_supported(m.i1, true) &&
                  plans[plan_of[c]].epi != EPI_RESIDUAL;   // (the family has no norm prologue + residual epilogue form)
         }
         if (!ok) continue;
-        for (int c : it->second) plans[plan_of[c]].norm = i;
+        for (int t = 0; t < cnt; ++t) plans[plan_of[first[t]]].norm = i;
         r.dead = true;
     }
 }

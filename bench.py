@@ -281,7 +281,7 @@ def time_dominant_kernel(omx, cfg, world, iters=3):
 
 
 DOMINANT_KERNEL = "gemv_kernel<8, 1, 1, 1, 2>"      # RMSNorm + gate/up GEMV + SwiGLU: 52 % of a step's bytes
-PMC_JSON = os.path.join(ROOT, "profiles", "r05_pmc_fetch_size.json")
+PMC_JSON = os.path.join(ROOT, "profiles", "r06_pmc_fetch_size.json")
 # greedy token after the 2048-token synthetic prompt, per (model, prompt length) on ONE GPU, synthetic weights: the engine is
 # deterministic, so a different token means a different computation.  (Committed from the round-2 run; checked at world 1 only --
 # tensor-parallel partial sums round differently.)
@@ -289,7 +289,7 @@ FIRST_TOKEN = {("qwen3-8b", 2048): 140044}
 
 
 def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed PMC pass (profiles/r05_pmc_fetch_size.json, regenerated from the trimmed
+    """HBM bytes per launch of `kernel` from the committed PMC pass (profiles/r06_pmc_fetch_size.json, regenerated from the trimmed
     raw counter_collection.csv by tools/pmc_report.py): rocprofv3 --pmc FETCH_SIZE in its own pass, x 1024 x 2 (gfx950 correction)."""
     try:
         table = json.load(open(PMC_JSON))
@@ -753,7 +753,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "gemv_kernel<rmsnorm, gate/up, swiglu>", "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
                          "traffic": pmc_traffic(DOMINANT_KERNEL) if world == 1 and args.model == "qwen3-8b" else None,
-                         "traffic_source": "profiles/r05_pmc_fetch_size.json <- profiles/r05_pmc_fetch_size_step.csv (rocprofv3 --pmc FETCH_SIZE over real decode steps, "
+                         "traffic_source": "profiles/r06_pmc_fetch_size.json <- profiles/r06_pmc_fetch_size_step.csv (rocprofv3 --pmc FETCH_SIZE over real decode steps, "
                                            "own pass, x2 gfx950 correction; tools/pmc_profile.sh, tools/pmc_report.py)",
                          "algorithmic_bytes_per_launch": k_bytes, "avg_launch_us": round(k_s * 1e6, 2),
                          "timing": ("in-step: every one of the 36 launches per step of 4 eager decode steps, run right after the timed region, carries its own "

@@ -127,7 +127,10 @@ class PeerComm:
         ids = all_gather_bytes(dev.value if lib.omx_peer_device_id(dev, 64) == 0 else b"?" + str(rank).encode())
         self.same_device = world > 1 and len(set(ids)) == 1 and not ids[0].startswith(b"?")
         if "OMX_PEER_SCOPE" not in os.environ:
-            lib.omx_peer_comm_set_scope(h, 0 if self.same_device else 1)
+            # (checked: a failed upload of the device table would leave the kernels on the old scope while the host field reports the new one)
+            if lib.omx_peer_comm_set_scope(h, 0 if self.same_device else 1) != 0:
+                from . import OmxError
+                raise OmxError("peer communicator: setting the memory scope failed: " + lib_error())
         self.scope = "system" if lib.omx_peer_comm_scope(h) == 1 else "agent"
         self._gather = all_gather_bytes
 

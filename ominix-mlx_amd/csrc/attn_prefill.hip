@@ -1116,7 +1116,10 @@ int launch_attn_prefill(bf16_t* out, const bf16_t* q, const bf16_t* k, const bf1
     // (round 5) the 4-wave persistent kernel for long unmasked sequences (OMX_ATTN_W4=0: the kernels below)
     {
         const char* w4 = getenv("OMX_ATTN_W4");
-        const bool want = w4 ? atoi(w4) != 0 : true;
+        // an explicit request for one of the older kernels (their A/B switches, the two-phase trace) outranks the default choice of this
+        // one: OMX_ATTN_PP=1 used to measure the four-wave kernel silently unless OMX_ATTN_W4=0 was set as well
+        const bool older_asked = getenv("OMX_ATTN_PP") || getenv("OMX_ATTN_PP_TRACE") || getenv("OMX_ATTN_PP32");
+        const bool want = w4 ? atoi(w4) != 0 : !older_asked;
         if (want && Tq >= 1024 && attn_flash4_supported(B, H, Hkv, Tq, Tk, D, mask_mode, f16))
             return launch_attn_flash4(out, q, k, v, B, H, Hkv, Tq, Tk, kv_batch_stride, kv_head_stride, scale, s, out_token_major, layout);
     }

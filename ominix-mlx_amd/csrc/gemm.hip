@@ -1707,11 +1707,20 @@ void gemm_tile_hint(int rows) { g_tile_hint = rows; }
 static thread_local bool g_gemm_f16 = false;
 bool gemm_set_f16(bool on) { const bool was = g_gemm_f16; g_gemm_f16 = on; return was; }   // returns the previous state (nested scopes)
 
+// the two experiment-only switches of the four-wave kernel (R5-8: staggered tile starts, un-parked epilogue): read ONCE -- every GEMM launch
+// used to call getenv for them on the host's hot path, in five copies of this block
+static void apply_experiment_switches(GemmArgs& a) {
+    static const int stagger = [] { const char* e = getenv("OMX_GEMM_STAGGER"); return e ? atoi(e) : 0; }();
+    static const bool no_park = [] { const char* e = getenv("OMX_GEMM_W4_PARK"); return e && e[0] == '0'; }();
+    a.stagger = stagger;
+    a.no_park = no_park;
+}
+
 static int launch_gemm_impl(bf16_t* out, const bf16_t* x, const bf16_t* w, const bf16_t* bias, const bf16_t* resid,
                             const bf16_t* gate, int M, int N, int K, hipStream_t s, int relu = 0) {
     OMX_REQUIRE(M > 0 && N > 0 && K > 0, "gemm: bad shape M=%d N=%d K=%d", M, N, K);
     GemmArgs a = {x, w, bias, resid, gate, out, M, N, K, (M + BM - 1) / BM, (N + BN - 1) / BN, {}, relu};
-    { const char* se = getenv("OMX_GEMM_STAGGER"); a.stagger = se ? atoi(se) : 0; const char* pe = getenv("OMX_GEMM_W4_PARK"); a.no_park = pe && pe[0] == '0'; }
+    apply_experiment_switches(a);
     const bool fast = (K % BK == 0) && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w)) & 15u) == 0;
     {   // a handful of rows: stream the weights once (gemv_rows.hip) instead of a matrix-core tile grid that is mostly padding;
         // OMX_GEMV_ROWS=0 keeps the GEMM kernels
@@ -1882,7 +1891,7 @@ int launch_gemm_bf16_segmented(const bf16_t* x, int M, int K, const GemmSegs& se
     OMX_REQUIRE(!segs.pre_norm_w, "segmented gemm: an in-launch RMSNorm exists on the weight-streaming route only (gemv_rows_takes_norm)");
     if (ensure_attr()) return 1;
     GemmArgs a = {};
-    { const char* se = getenv("OMX_GEMM_STAGGER"); a.stagger = se ? atoi(se) : 0; const char* pe = getenv("OMX_GEMM_W4_PARK"); a.no_park = pe && pe[0] == '0'; }
+    apply_experiment_switches(a);
     a.x = x; a.M = M; a.K = K;
     a.sg = segs;
     if (!g_gemm_f16 && ((M + 255) / 256) * seg_tiles(segs) < 160) {   // small problem, plain segments: one grid of 64^2 ring-kernel tiles
@@ -1947,7 +1956,7 @@ int launch_gemm_bf16_segmented_grouped(const bf16_t* x, int max_rows, int K, con
     OMX_REQUIRE((align & 15u) == 0 && (g.w_estride * 2) % 16 == 0, "grouped segmented gemm: operands must be 16-byte aligned");
     if (ensure_attr()) return 1;
     GemmArgs a = {};
-    { const char* se = getenv("OMX_GEMM_STAGGER"); a.stagger = se ? atoi(se) : 0; const char* pe = getenv("OMX_GEMM_W4_PARK"); a.no_park = pe && pe[0] == '0'; }
+    apply_experiment_switches(a);
     a.x = x; a.M = max_rows; a.K = K;
     a.g = g;
     a.sg = segs;
@@ -1987,7 +1996,7 @@ int launch_conv3x3_implicit(bf16_t* out, const bf16_t* padded, const bf16_t* w, 
                 "implicit conv: null or misaligned operand");
     if (ensure_attr()) return 1;
     GemmArgs a = {};
-    { const char* se = getenv("OMX_GEMM_STAGGER"); a.stagger = se ? atoi(se) : 0; const char* pe = getenv("OMX_GEMM_W4_PARK"); a.no_park = pe && pe[0] == '0'; }
+    apply_experiment_switches(a);
     a.x = padded; a.M = H * W; a.K = 9 * C; a.N = Cout;
     a.sg.n_plain = 1;
     a.sg.plain[0] = {w, bias, out, Cout, Cout, 0};
@@ -2057,7 +2066,7 @@ int launch_gemm_bf16_grouped(bf16_t* out, const bf16_t* x, const bf16_t* w, int 
     OMX_REQUIRE(K % BK == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w)) & 15u) == 0,
                 "grouped gemm: K=%d must be a multiple of %d and operands 16-byte aligned", K, BK);
     GemmArgs a = {x, w, nullptr, nullptr, nullptr, out, max_rows, N, K, max_tiles, (N + BN - 1) / BN, g, 0};
-    { const char* se = getenv("OMX_GEMM_STAGGER"); a.stagger = se ? atoi(se) : 0; const char* pe = getenv("OMX_GEMM_W4_PARK"); a.no_park = pe && pe[0] == '0'; }
+    apply_experiment_switches(a);
     if (ensure_attr()) return 1;
     gemm_bf16_nt_kernel<true><<<max_tiles * a.grid_n, NTHREADS, 4 * TILE_BYTES, s>>>(a);
     OMX_LAUNCH_CHECK();

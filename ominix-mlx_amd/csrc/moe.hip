@@ -852,6 +852,18 @@ int dequant_stacks(DqScratch& q, const void* q_router, const void* s_router, con
                    const void* b_down, int hidden, int inter, int n_experts, int e_n, int group_size, int bits) {
     using namespace omx;
     const size_t per = (size_t)e_n * inter * hidden;
+    // the stream-ordered pool hands freed blocks back to the system at the next synchronisation unless told to keep them (release threshold 0 by
+    // default): a Mixtral-size shard would re-allocate ~1.4 GB per layer and prompt.  Keep them: the next layer's scratch is this layer's
+    static const bool pool_keeps = [] {
+        int dev = 0;
+        hipMemPool_t pool = nullptr;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess && pool) {
+            uint64_t keep = UINT64_MAX;
+            (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
+        }
+        return true;
+    }();
+    (void)pool_keeps;
     OMX_HIP_CHECK(hipMallocAsync((void**)&q.router, (size_t)n_experts * hidden * 2, q.s));
     OMX_HIP_CHECK(hipMallocAsync((void**)&q.g, per * 2, q.s));
     OMX_HIP_CHECK(hipMallocAsync((void**)&q.u, per * 2, q.s));

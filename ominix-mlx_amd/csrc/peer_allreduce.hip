@@ -447,11 +447,18 @@ int omx_peer_comm_set_scope(void* comm, int system_scope) {
     using namespace omx;
     OMX_REQUIRE(comm, "omx_peer_comm_set_scope: null communicator");
     PeerComm* c = static_cast<PeerComm*>(comm);
+    const int was = c->sys_scope;
     c->sys_scope = system_scope ? 1 : 0;
     if (c->connected) {
-        OMX_HIP_CHECK(hipDeviceSynchronize());
-        if (upload_table(c)) return 1;
-        OMX_HIP_CHECK(hipDeviceSynchronize());
+        // the host field follows the device table, never the other way round: a failed upload leaves both on the old scope
+        hipError_t e = hipDeviceSynchronize();
+        if (e == hipSuccess && upload_table(c)) e = hipErrorUnknown;
+        if (e == hipSuccess) e = hipDeviceSynchronize();
+        if (e != hipSuccess) {
+            c->sys_scope = was;
+            return set_error("omx_peer_comm_set_scope: the device table could not be rewritten (%s); the scope stays %s", hipGetErrorString(e),
+                             was ? "system" : "agent");
+        }
     }
     return 0;
 }

@@ -13,6 +13,23 @@ import bench
 
 pytestmark = pytest.mark.gpu
 
+
+def _report(fixture, route, worst, max_logit, layers, rule, tokens=None):
+    """One line per (fixture, route) for DESIGN.md section 2's table: the measured deviation as a multiple of SURVEY 8c's
+    2^-7 * max|logit| next to the rule the test holds it to (written to gpurun_out/parity_r06.jsonl when that directory exists)."""
+    import json
+    unit = 2.0 ** -7 * max_logit
+    row = {"fixture": fixture, "route": route, "layers": layers, "max_abs_logit": round(float(max_logit), 4), "worst_deviation": round(float(worst), 4),
+           "multiple_of_survey_unit": round(float(worst) / unit, 2), "rule": rule, "rule_multiple": round({"sqrt(L)": np.sqrt(layers), "sqrt(2L)": np.sqrt(2 * layers)}[rule], 2)}
+    if tokens is not None:
+        row["greedy_tokens_equal"] = tokens
+    print("parity:", json.dumps(row))
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(out):
+        with open(os.path.join(out, "parity_r06.jsonl"), "a") as f:
+            f.write(json.dumps(row) + "\n")
+
+
 PIN = os.path.join(os.path.dirname(__file__), "golden", "qwen3_8b_fullsize_pin.npz")
 
 
@@ -38,6 +55,8 @@ def test_full_size_engine_matches_full_size_oracle(omx):
         else:   # (random weights give flat logits: most margins are below the bound; the oracle's choice must still be a near-maximum here)
             assert lg[pin["greedy"][i]] >= lg.max() - 2 * bound
     assert worst <= bound, f"batched route: top-8 logits off by {worst:.4f} (bound {bound:.4f})"
+    _report("qwen3_8b_fullsize_pin (16 positions)", "engine, batched pass", worst, float(pin["max_abs"].max()), cfg["num_hidden_layers"], "sqrt(L)",
+            f"{int((got == pin['greedy']).sum())} of {n}")
     # ---- decode step: forget the last prompt token and run it through the step ----
     m.trim(1, int(prompt[n - 1]))
     tok = int(m.decode(1)[0])
@@ -78,6 +97,7 @@ def test_baseline_config_c1_at_real_shapes(omx):
             m.trim(0, int(want[i]))            # continue on the ORACLE's sequence
             tok = int(m.decode(1)[0])
     assert worst <= bound, f"top-8 logits off by {worst:.4f} over 32 steps (bound {bound:.4f})"
+    _report("qwen3_0p6b_c1_pin (128 + 32, oracle tokens forced)", "engine", worst, float(pin["max_abs"].max()), cfg["num_hidden_layers"], "sqrt(L)", f"{equal} of 32")
     assert equal >= 16, f"only {equal} of 32 greedy tokens equal the oracle's"
     m.close()
 
@@ -107,16 +127,25 @@ def test_protocol_c2_iid_logits_with_the_oracle_tokens_forced(omx):
     m.synth_weights()
     bound = 2.0 ** -7 * float(pin["logit_absmax"]) * np.sqrt(cfg["num_hidden_layers"])
     pins = {int(s): i for i, s in enumerate(pin["pin_steps"])}
+    # round 6 (VERDICT r5 "Next" 6a): the fixture pins every 16th step, a fixed 256-entry sample of the row beside its top-8, and keeps the
+    # oracle's top-1 / top-2 margin of EVERY step -- so the token is asserted wherever the margin decides it, not at five steps only
+    all_margins = pin["all_margins"] if "all_margins" in pin.files else None
     tok = int(m.prefill(prompt))
-    equal, worst = 0, 0.0
+    equal, worst, worst_sub = 0, 0.0, 0.0
     for step in range(n_new + 1):
         equal += int(tok == int(want[step]))
+        if all_margins is not None and float(all_margins[step]) > 2 * bound:
+            assert tok == int(want[step]), f"step {step}: {tok} vs oracle {int(want[step])} at margin {float(all_margins[step]):.3f}"
         if step in pins:
             i = pins[step]
             lg = m.last_logits()
             err = float(np.abs(lg[pin["top_idx"][i]] - pin["top_val"][i]).max())
             worst = max(worst, err)
             assert err <= bound, f"step {step}: top-8 logits off by {err:.4f} (bound {bound:.4f})"
+            if "sub_idx" in pin.files:
+                sub = float(np.abs(lg[pin["sub_idx"]] - pin["sub_val"][i]).max())
+                worst_sub = max(worst_sub, sub)
+                assert sub <= bound, f"step {step}: sampled logits off by {sub:.4f} (bound {bound:.4f})"
             if float(pin["margins"][i]) > 2 * bound:
                 assert tok == int(want[step]), f"step {step}: {tok} vs oracle {int(want[step])} at margin {float(pin['margins'][i]):.3f}"
             else:
@@ -125,7 +154,11 @@ def test_protocol_c2_iid_logits_with_the_oracle_tokens_forced(omx):
             m.trim(0, int(want[step]))           # continue on the ORACLE's sequence
             tok = int(m.decode(1)[0])
     print(f"c2 i.i.d. pin: worst top-8 logit deviation {worst:.4f} (bound {bound:.4f}); {equal} of {n_new + 1} greedy tokens equal the oracle's")
-    assert equal >= (n_new + 1) // 4, f"only {equal} of {n_new + 1} greedy tokens equal the oracle's"
+    _report(f"qwen3_c2_protocol_iid_pin (2 048 + 256, {len(pins)} pinned steps)", "engine", max(worst, worst_sub), float(pin["logit_absmax"]),
+            cfg["num_hidden_layers"], "sqrt(L)", f"{equal} of {n_new + 1}")
+    # flat synthetic logits: most margins are below the bound, where two bf16 pipelines may legitimately differ -- yet they agree on nine
+    # tokens in ten (measured 235 of 257); an engine that agreed on a quarter (the old assert) would be broken
+    assert equal >= int(0.8 * (n_new + 1)), f"only {equal} of {n_new + 1} greedy tokens equal the oracle's"
     m.close()
 
 
@@ -163,6 +196,8 @@ def test_protocol_c2_iid_logits_of_the_drop_in_route(omx):
     assert worst_sub <= bound, f"sampled logits of the route off by {worst_sub:.4f} (bound {bound:.4f})"
     equal = int((got["tokens"].astype(np.int64) == want).sum())
     print(f"c2 i.i.d. pin, drop-in route: worst top-8 deviation {worst:.4f}, sample {worst_sub:.4f} (bound {bound:.4f}); {equal} of {want.size} greedy tokens equal")
+    _report(f"qwen3_c2_protocol_iid_pin (2 048 + 256, {len(steps)} pinned steps)", "drop-in route (mlx-c ABI, deferred + fused)", max(worst, worst_sub),
+            float(pin["logit_absmax"]), cfg["num_hidden_layers"], "sqrt(L)", f"{equal} of {want.size}")
     m.close()
 
 
@@ -267,6 +302,8 @@ def test_full_width_mixtral_matches_the_oracle_where_routing_cannot_flip(omx, mo
         worst_step = max(worst_step, check(m.last_logits(), i, tok, "decode step"))
     print(f"full-width Mixtral ({cfg['num_hidden_layers']} layers, {n} positions): worst logit deviation batched {worst_batched:.4f}, "
           f"step {worst_step:.4f}, bound {bound:.4f}")
+    _report(f"{fixture} ({n} positions)", "engine, batched pass", worst_batched, float(pin["max_abs"].max()), cfg["num_hidden_layers"], "sqrt(2L)")
+    _report(f"{fixture} ({n} positions)", "engine, decode step", worst_step, float(pin["max_abs"].max()), cfg["num_hidden_layers"], "sqrt(2L)")
     m.close()
 
 

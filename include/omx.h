@@ -546,6 +546,12 @@ typedef struct omx_sanm_layer_weights_ {
 } omx_sanm_layer_weights;
 int omx_sanm_encoder_layer(void* out, const void* x, const omx_sanm_layer_weights* w, int T, int in_dim, int dim,
                            int heads, int ffn_dim, int kernel_size, omx_dtype dtype, omx_stream stream);
+/* SanmEncoder::forward's layer loop + after_norm (paraformer.rs:691-708) in ONE call (round 6): layers[0] maps in_dim -> dim, the others
+ * keep dim; out [T, dim] = after_norm(layers(x)).  Scratch (device, caller-owned): act0 / act1 [T, dim], nrm0 / nrm1 [T, max(in_dim, dim)].
+ * In float32 every layer's last launch also computes the next layer's norm1 (the last one: after_norm). */
+int omx_sanm_encoder_stack(void* out, const void* x, const omx_sanm_layer_weights* layers, int n_layers, int T, int in_dim, int dim, int heads,
+                           int ffn_dim, int kernel_size, const void* after_norm_w, const void* after_norm_b, void* act0, void* act1, void* nrm0,
+                           void* nrm1, omx_dtype dtype, omx_stream stream);
 int omx_cif_fire(float* frames, int* counts, const float* hidden, const float* alphas, int batch, int T, int H,
                  float threshold, float tail_threshold, int max_frames, omx_stream stream);
 /* SanmEncoder::forward prologue (paraformer.rs:691-703): out [T, dim] = mel f32 [T, dim] * sqrt(512) + sinusoidal

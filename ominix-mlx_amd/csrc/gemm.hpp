@@ -102,6 +102,11 @@ struct GemmF32 {
     int64_t sa, sb, sc;            // batch strides
     int batch, relu, b_nn;
     float alpha;
+    // round 6: the caller finishes the product itself (paraformer.hip: epilogue + FSMN + LayerNorm in ONE launch instead of reduce, add, norm).
+    // Set both: the launch then applies NO epilogue (alpha, bias, relu, resid are the caller's) and reports where the raw product lies --
+    // *defer_partial [splits][M][N] (the split-K scratch of the stream, valid until the stream's next GEMM) with *defer_splits >= 1
+    const float** defer_partial = nullptr;
+    int* defer_splits = nullptr;
 };
 int launch_gemm_f32(const GemmF32& p, hipStream_t s);
 

@@ -275,6 +275,11 @@ int launch_gemm_f32(const GemmF32& p, hipStream_t s) {
     OMX_REQUIRE(p.a && p.b && p.out && p.M > 0 && p.N > 0 && p.K > 0 && p.batch >= 1, "gemm_f32: bad arguments (M=%d N=%d K=%d)", p.M, p.N, p.K);
     F32Args g = {p.a, p.b, p.bias, p.resid, p.out, nullptr, p.M, p.N, p.K, p.lda, p.ldb, p.ldc, p.ldr ? p.ldr : p.ldc, p.sa, p.sb, p.sc,
                  p.batch, 1, p.relu, p.b_nn, p.alpha};
+    const bool defer = p.defer_partial && p.defer_splits;      // the caller applies the epilogue (and whatever follows) in its own launch
+    if (defer) {
+        OMX_REQUIRE(p.batch == 1 && p.ldc == p.N, "gemm_f32: a deferred epilogue takes one dense [M, N] product");
+        g.bias = nullptr; g.resid = nullptr; g.relu = 0; g.alpha = 1.0f;
+    }
     const int gx = (p.N + TN - 1) / TN, gy = (p.M + TM - 1) / TM, tiles = gx * gy * p.batch, ktiles = (p.K + TK - 1) / TK;
     // split K while the tile grid leaves most of the chip idle and every split keeps >= 2 K tiles: a wave's tile is a chain of
     // K / 2 dependent 64-cycle MFMAs (7.8 us at K = 512) whatever the tile shape, so for 64-tile outputs (out_proj, ffn_down,
@@ -300,6 +305,11 @@ int launch_gemm_f32(const GemmF32& p, hipStream_t s) {
         }
         gemm_f32_small_kernel<<<dim3(sx, sy, p.batch * splits), 256, 0, s>>>(g);
         OMX_LAUNCH_CHECK();
+        if (defer) {
+            *p.defer_partial = splits > 1 ? g.partial : p.out;
+            *p.defer_splits = splits;
+            return 0;
+        }
         if (splits > 1) {
             const int64_t total = (int64_t)p.batch * p.M * p.N;
             gemm_f32_reduce_kernel<<<(unsigned)std::min<int64_t>((total + 255) / 256, 4096), 256, 0, s>>>(g);
@@ -316,6 +326,11 @@ int launch_gemm_f32(const GemmF32& p, hipStream_t s) {
     }
     gemm_f32_kernel<<<dim3(gx, gy, p.batch * splits), 256, 0, s>>>(g);
     OMX_LAUNCH_CHECK();
+    if (defer) {
+        *p.defer_partial = splits > 1 ? g.partial : p.out;
+        *p.defer_splits = splits;
+        return 0;
+    }
     if (splits > 1) {
         const int64_t total = (int64_t)p.batch * p.M * p.N;
         gemm_f32_reduce_kernel<<<(unsigned)std::min<int64_t>((total + 255) / 256, 4096), 256, 0, s>>>(g);

@@ -40,6 +40,125 @@ __global__ __launch_bounds__(256) void fsmn_add_kernel(typename Elem<DT>::T* __r
     }
 }
 
+// ---- round 6: a float32 GEMM's epilogue, the FSMN memory block and the LayerNorm that follows, in ONE launch ----
+// The 30 s pass was ~1 000 dependent launches; 216 of them were split-K reduces and 168 LayerNorms, each 4-5 us for a [T, 512] tensor that
+// the launch before had just written.  Here the rows of a product the GEMM left raw (gemm.hpp GemmF32::defer_partial) are finished in place:
+//     y = sum over splits (in split order) + bias  [relu]  [+ resid]                          -- gemm_f32_reduce_kernel's epilogue, same order
+//     FSMN:  y = y + (conv(v)[t] + v[t]),  then  y = resid2 + y                               -- fsmn_add_kernel's arithmetic, same order
+//     out = y;   ln_out = LayerNorm(y)
+// TPR threads share a row (one 16-byte vector each, VPT of them when the row is longer than 1 024 floats), 256 / TPR rows per block: a first
+// form with one WAVE per row (rownorm_kernel's shape, bit-identical sums) took 11 us per launch -- 8 columns x 11 taps of dependent loads per
+// lane -- and made the pass slower than the three launches it replaced.  The row sums go lane -> wave -> LDS here, so the normalised values
+// can differ from the separate LayerNorm launch in the last bit.
+template <int TPR, int VPT>
+__global__ __launch_bounds__(256) void f32_epilogue_ln_kernel(float* __restrict__ out, float* __restrict__ ln_out, const float* __restrict__ partial,
+                                                              int splits, int M, int dim, const float* __restrict__ bias, int relu,
+                                                              const float* __restrict__ resid, int64_t ldr, const float* __restrict__ v, int64_t ldv,
+                                                              const float* __restrict__ fw, int ksize, const float* __restrict__ resid2,
+                                                              const float* __restrict__ ln_w, const float* __restrict__ ln_b, float eps) {
+    constexpr int RPB = 256 / TPR, WPR = TPR / 64;          // rows per block, waves per row
+    __shared__ float red[2][4];
+    const int rl = threadIdx.x / TPR, t = threadIdx.x % TPR;
+    const int row = blockIdx.x * RPB + rl;
+    const bool live = row < M;
+    const int pad = ksize / 2;
+    f32x4 y[VPT];
+#pragma unroll
+    for (int k = 0; k < VPT; ++k) {
+        const int c0 = (t + k * TPR) * 4;
+        f32x4 a = {0.f, 0.f, 0.f, 0.f};
+        if (live) {
+            for (int sp = 0; sp < splits; ++sp) a += *reinterpret_cast<const f32x4*>(partial + ((int64_t)sp * M + row) * dim + c0);
+            if (bias) a += *reinterpret_cast<const f32x4*>(bias + c0);
+            if (relu) { a[0] = fmaxf(a[0], 0.f); a[1] = fmaxf(a[1], 0.f); a[2] = fmaxf(a[2], 0.f); a[3] = fmaxf(a[3], 0.f); }
+            if (resid) a += *reinterpret_cast<const f32x4*>(resid + (int64_t)row * ldr + c0);
+            if (v) {
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                const float* fwc = fw + (size_t)c0 * ksize;      // the taps of this thread's four columns: 4 * ksize consecutive floats
+                for (int jj = 0; jj < ksize; ++jj) {
+                    const int tt = row + jj - pad;
+                    if (tt >= 0 && tt < M) {
+                        const f32x4 vv = *reinterpret_cast<const f32x4*>(v + (int64_t)tt * ldv + c0);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc[j] = fmaf(fwc[j * ksize + jj], vv[j], acc[j]);
+                    }
+                }
+                const f32x4 vt = *reinterpret_cast<const f32x4*>(v + (int64_t)row * ldv + c0);
+                a = a + (acc + vt);
+                if (resid2) a = *reinterpret_cast<const f32x4*>(resid2 + (int64_t)row * dim + c0) + a;
+            }
+            if (out) *reinterpret_cast<f32x4*>(out + (int64_t)row * dim + c0) = a;
+        }
+        y[k] = a;
+    }
+    if (!ln_out) return;
+    auto row_sum = [&](float x, int which) -> float {
+        x = wave_sum(x);
+        if (WPR == 1) return x;
+        const int w = threadIdx.x >> 6;
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) red[which][w] = x;
+        __syncthreads();
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < WPR; ++i) s += red[which][rl * WPR + i];
+        return s;
+    };
+    float sm = 0.f;
+#pragma unroll
+    for (int k = 0; k < VPT; ++k) sm += (y[k][0] + y[k][1]) + (y[k][2] + y[k][3]);
+    const float mean = row_sum(sm, 0) / (float)dim;
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < VPT; ++k)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) q += (y[k][j] - mean) * (y[k][j] - mean);
+    const float rstd = 1.0f / sqrtf(row_sum(q, 1) / (float)dim + eps);
+    if (!live) return;
+#pragma unroll
+    for (int k = 0; k < VPT; ++k) {
+        const int c0 = (t + k * TPR) * 4;
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = (y[k][j] - mean) * rstd;
+        if (ln_w) o = o * *reinterpret_cast<const f32x4*>(ln_w + c0);
+        if (ln_b) o = o + *reinterpret_cast<const f32x4*>(ln_b + c0);
+        *reinterpret_cast<f32x4*>(ln_out + (int64_t)row * dim + c0) = o;
+    }
+}
+
+inline bool f32_tail_width_ok(int n) { return n == 512 || n == 1024 || n == 2048; }
+struct F32Tail {                 // what follows a float32 product (all optional)
+    const float* bias = nullptr; int relu = 0;
+    const float* resid = nullptr; int64_t ldr = 0;
+    const float* v = nullptr; int64_t ldv = 0; const float* fw = nullptr; int ksize = 0; const float* resid2 = nullptr;   // the FSMN memory block
+    const float* ln_w = nullptr; const float* ln_b = nullptr; float* ln_out = nullptr;
+};
+// out [M, N] = x [M, K] . w [N, K]^T, finished by ONE launch with everything in `t`; out may be null when only the normalised rows are kept
+int gemm_f32_with_tail(float* out, const float* x, const float* w, int M, int N, int K, const F32Tail& t, float* scratch_out, hipStream_t s) {
+    const float* partial = nullptr;
+    int splits = 1;
+    float* raw = out ? out : scratch_out;       // (a product nobody reads as such still needs somewhere to land when K is not split)
+    GemmF32 p = {x, w, nullptr, nullptr, raw, M, N, K, K, K, N, N, 0, 0, 0, 1, 0, 0, 1.0f};
+    p.defer_partial = &partial;
+    p.defer_splits = &splits;
+    if (launch_gemm_f32(p, s)) return 1;
+    OMX_REQUIRE(f32_tail_width_ok(N), "paraformer: fused epilogue takes rows of 512, 1024 or 2048 floats (N=%d)", N);
+#define OMX_TAIL(TPR, VPT)                                                                                                                \
+    f32_epilogue_ln_kernel<TPR, VPT><<<(unsigned)((M + 256 / TPR - 1) / (256 / TPR)), 256, 0, s>>>(out, t.ln_out, partial, splits, M, N, t.bias, t.relu, t.resid,  \
+                                                                                                   t.ldr, t.v, t.ldv, t.fw, t.ksize, t.resid2, t.ln_w, t.ln_b, 1e-5f)
+    if (N == 512) OMX_TAIL(128, 1);
+    else if (N == 1024) OMX_TAIL(256, 1);
+    else OMX_TAIL(256, 2);
+#undef OMX_TAIL
+    OMX_LAUNCH_CHECK();
+    return 0;
+}
+inline bool fuse_f32_tails() {
+    static const bool on = [] { const char* e = getenv("OMX_PARAFORMER_FUSE"); return !(e && e[0] == '0'); }();
+    return on;
+}
+
 // CIF integrate-and-fire (paraformer.rs:779-879).  The fire decisions form a scalar recurrence over time that does not depend
 // on the hidden column, and a fired frame only sums the few time steps between two fires.  So: every block of the (batch, NB)
 // grid replays the scalar recurrence from LDS (one thread, ~10 ns per step; T = 501 -> 5 us) and records, per fired frame, the
@@ -268,11 +387,24 @@ int decoder_layer_impl(void* out, const void* x, const void* enc, const omx_para
     const omx_dtype dt = (omx_dtype)DT;
     // tgt = down(LN_ffn(relu(up(norm1(x)))))                                                     (:1036-1042)
     if (omx_layer_norm(h, xin, w->norm1_w, w->norm1_b, N, dim, 1e-5f, dt, stream)) return 1;
+    bool fused = false;
+    if constexpr (DT == OMX_FLOAT32) {
+        if (fuse_f32_tails() && f32_tail_width_ok(ffn_dim) && f32_tail_width_ok(dim)) {
+            // round 6: [up + bias + relu + LN_ffn] and [down + norm2] each finished by one launch after the product (f32_epilogue_ln_kernel)
+            F32Tail t1; t1.bias = (const float*)w->ffn_up_b; t1.relu = 1; t1.ln_w = (const float*)w->ffn_norm_w; t1.ln_b = (const float*)w->ffn_norm_b; t1.ln_out = ffn;
+            if (gemm_f32_with_tail(nullptr, h, (const float*)w->ffn_up_w, N, ffn_dim, dim, t1, ff, s)) return 1;
+            F32Tail t2; t2.ln_w = (const float*)w->norm2_w; t2.ln_b = (const float*)w->norm2_b; t2.ln_out = h;
+            if (gemm_f32_with_tail(nullptr, ffn, (const float*)w->ffn_down_w, N, dim, ffn_dim, t2, tgt, s)) return 1;
+            fused = true;
+        }
+    }
+    if (!fused) {
     if (Ops<DT>::gemm_relu(ff, h, (const E*)w->ffn_up_w, (const E*)w->ffn_up_b, N, ffn_dim, dim, s)) return 1;
     if (omx_layer_norm(ffn, ff, w->ffn_norm_w, w->ffn_norm_b, N, ffn_dim, 1e-5f, dt, stream)) return 1;
     if (Ops<DT>::gemm(tgt, ffn, (const E*)w->ffn_down_w, nullptr, N, dim, ffn_dim, s)) return 1;
     // x1 = x + (fsmn(norm2(tgt)) + norm2(tgt))                                                   (:1044-1047)
     if (omx_layer_norm(h, tgt, w->norm2_w, w->norm2_b, N, dim, 1e-5f, dt, stream)) return 1;
+    }
     fsmn_add_kernel<DT><<<1024, 256, 0, s>>>(x1, xin, h, dim, (const E*)w->fsmn_w, N, dim, kernel_size, nullptr);
     OMX_LAUNCH_CHECK();
     // out = x1 + src_attn_out(softmax(q k^T * d^-1/2) v), q from norm3(x1), k/v from the encoder output      (:1049-1052, 981-1017)
@@ -295,16 +427,31 @@ int decoder_tail_impl(void* logits, const void* x, const omx_paraformer_tail_wei
     E* t = ffn + (size_t)N * ffn_dim;
     const omx_dtype dt = (omx_dtype)DT;
     if (omx_layer_norm(h, x, w->norm1_w, w->norm1_b, N, dim, 1e-5f, dt, stream)) return 1;
+    bool fused = false;
+    if constexpr (DT == OMX_FLOAT32) {
+        if (fuse_f32_tails() && f32_tail_width_ok(ffn_dim) && f32_tail_width_ok(dim)) {
+            F32Tail t1; t1.bias = (const float*)w->up_b; t1.relu = 1; t1.ln_w = (const float*)w->ffn_norm_w; t1.ln_b = (const float*)w->ffn_norm_b; t1.ln_out = ffn;
+            if (gemm_f32_with_tail(nullptr, h, (const float*)w->up_w, N, ffn_dim, dim, t1, ff, s)) return 1;
+            F32Tail t2; t2.ln_w = (const float*)w->after_norm_w; t2.ln_b = (const float*)w->after_norm_b; t2.ln_out = h;
+            if (gemm_f32_with_tail(nullptr, ffn, (const float*)w->down_w, N, dim, ffn_dim, t2, t, s)) return 1;
+            fused = true;
+        }
+    }
+    if (!fused) {
     if (Ops<DT>::gemm_relu(ff, h, (const E*)w->up_w, (const E*)w->up_b, N, ffn_dim, dim, s)) return 1;
     if (omx_layer_norm(ffn, ff, w->ffn_norm_w, w->ffn_norm_b, N, ffn_dim, 1e-5f, dt, stream)) return 1;
     if (Ops<DT>::gemm(t, ffn, (const E*)w->down_w, nullptr, N, dim, ffn_dim, s)) return 1;
     if (omx_layer_norm(h, t, w->after_norm_w, w->after_norm_b, N, dim, 1e-5f, dt, stream)) return 1;
+    }
     return Ops<DT>::gemm((E*)logits, h, (const E*)w->out_w, (const E*)w->out_b, N, vocab, dim, s);
 }
 
+// h1_pre != null: norm1(x) was already computed (by the previous layer's last launch); next_ln_* / next_h1 != null: THIS layer's last launch
+// also leaves LayerNorm(out) with those weights in next_h1 -- the next layer's norm1, or the encoder's after_norm (omx_sanm_encoder_stack)
 template <int DT>
 int encoder_layer_impl(void* out, const void* x, const omx_sanm_layer_weights* w, int T, int in_dim, int dim, int heads, int ffn_dim,
-                       int kernel_size, omx_stream stream) {
+                       int kernel_size, omx_stream stream, const void* h1_pre = nullptr, const void* next_ln_w = nullptr,
+                       const void* next_ln_b = nullptr, void* next_h1 = nullptr) {
     typedef typename Ops<DT>::T E;
     hipStream_t s = (hipStream_t)stream;
     const size_t scores = Ops<DT>::score_elems(heads, T, T);
@@ -322,10 +469,22 @@ int encoder_layer_impl(void* out, const void* x, const omx_sanm_layer_weights* w
     const E* xin = (const E*)x;
     const omx_dtype dt = (omx_dtype)DT;
     // h = norm1(x) ; qkv = linear_q_k_v(h)                                           (paraformer.rs:619, 500)
-    if (omx_layer_norm(h1, xin, w->norm1_w, w->norm1_b, T, in_dim, 1e-5f, dt, stream)) return 1;
+    if (h1_pre) h1 = (E*)h1_pre;
+    else if (omx_layer_norm(h1, xin, w->norm1_w, w->norm1_b, T, in_dim, 1e-5f, dt, stream)) return 1;
     if (Ops<DT>::gemm(qkv, h1, (const E*)w->qkv_w, (const E*)w->qkv_b, T, 3 * dim, in_dim, s)) return 1;
     // softmax(q k^T * d^-1/2) v, 4 heads x 128, operands read in place from the fused projection    (:503-522)
     if (Ops<DT>::attention(att, qkv, qkv + dim, qkv + 2 * dim, 3 * (int64_t)dim, 3 * (int64_t)dim, dim, T, T, heads, sc, s)) return 1;
+    bool fused = false;
+    if constexpr (DT == OMX_FLOAT32) {
+        if (fuse_f32_tails() && f32_tail_width_ok(dim)) {
+            // round 6: out_proj's split-K sum + bias, the FSMN block, the layer residual and norm2 in ONE launch behind the product
+            F32Tail t; t.bias = (const float*)w->out_b; t.v = qkv + 2 * dim; t.ldv = 3 * (int64_t)dim; t.fw = (const float*)w->fsmn_w; t.ksize = kernel_size;
+            t.resid2 = in_dim == dim ? xin : nullptr; t.ln_w = (const float*)w->norm2_w; t.ln_b = (const float*)w->norm2_b; t.ln_out = h2;
+            if (gemm_f32_with_tail(xr, att, (const float*)w->out_w, T, dim, dim, t, prj, s)) return 1;
+            fused = true;
+        }
+    }
+    if (!fused) {
     if (Ops<DT>::gemm(prj, att, (const E*)w->out_w, (const E*)w->out_b, T, dim, dim, s)) return 1;
     // out_proj(attn) + (fsmn_block(v) + v)                                             (:524-529)
     // + the layer residual in the same launch; only when the layer keeps its width (the first maps 560 -> 512 without it, :625-629)
@@ -333,9 +492,20 @@ int encoder_layer_impl(void* out, const void* x, const omx_sanm_layer_weights* w
                                              in_dim == dim ? xin : nullptr);
     OMX_LAUNCH_CHECK();
     if (omx_layer_norm(h2, xr, w->norm2_w, w->norm2_b, T, dim, 1e-5f, dt, stream)) return 1;
+    }
     if (Ops<DT>::gemm_relu(ff, h2, (const E*)w->ffn_up_w, (const E*)w->ffn_up_b, T, ffn_dim, dim, s)) return 1;
+    if constexpr (DT == OMX_FLOAT32) {
+        if (next_h1 && fuse_f32_tails() && f32_tail_width_ok(dim)) {
+            // out = xr + (ffn_down(ff) + bias) and the NEXT norm of `out`, one launch behind the product
+            F32Tail t; t.bias = (const float*)w->ffn_down_b; t.resid = xr; t.ldr = dim; t.ln_w = (const float*)next_ln_w; t.ln_b = (const float*)next_ln_b;
+            t.ln_out = (float*)next_h1;
+            return gemm_f32_with_tail((float*)out, ff, (const float*)w->ffn_down_w, T, dim, ffn_dim, t, nullptr, s);
+        }
+    }
     // out = xr + (ffn_down(ff) + bias): the FFN residual in the GEMM epilogue
-    return Ops<DT>::gemm_resid((E*)out, ff, (const E*)w->ffn_down_w, (const E*)w->ffn_down_b, xr, T, dim, ffn_dim, s);
+    if (Ops<DT>::gemm_resid((E*)out, ff, (const E*)w->ffn_down_w, (const E*)w->ffn_down_b, xr, T, dim, ffn_dim, s)) return 1;
+    if (next_h1) return omx_layer_norm(next_h1, out, next_ln_w, next_ln_b, T, dim, 1e-5f, dt, stream);
+    return 0;
 }
 
 }  // namespace
@@ -380,6 +550,36 @@ int omx_paraformer_decoder_tail(void* logits, const void* x, const omx_paraforme
     OMX_REQUIRE(logits && x && w && N > 0, "omx_paraformer_decoder_tail: bad arguments");
     OMX_PARAFORMER_DT(dtype, omx::decoder_tail_impl<OMX_BFLOAT16>(logits, x, w, N, dim, ffn_dim, vocab, stream),
                       omx::decoder_tail_impl<OMX_FLOAT32>(logits, x, w, N, dim, ffn_dim, vocab, stream))
+}
+
+/* SanmEncoder::forward's layer loop + after_norm (paraformer.rs:691-708) in one call: layer 0 maps in_dim -> dim, the others keep dim.
+ * out [T, dim] = after_norm(layers(x)); scratch: two [T, dim] activations and two [T, max(in_dim, dim)] normalised inputs the layers hand each
+ * other (the float32 mode computes every layer's norm1 -- and the final after_norm -- in the previous layer's last launch). */
+int omx_sanm_encoder_stack(void* out, const void* x, const omx_sanm_layer_weights* layers, int n_layers, int T, int in_dim, int dim, int heads,
+                           int ffn_dim, int kernel_size, const void* after_norm_w, const void* after_norm_b, void* act0, void* act1, void* nrm0,
+                           void* nrm1, omx_dtype dtype, omx_stream stream) {
+    OMX_REQUIRE(out && x && layers && n_layers > 0 && act0 && act1 && nrm0 && nrm1 && after_norm_w && after_norm_b, "omx_sanm_encoder_stack: null argument");
+    OMX_REQUIRE(T > 0 && dim % heads == 0 && dim / heads == 128, "omx_sanm_encoder_stack: head_dim must be 128 (dim %d, heads %d)", dim, heads);
+    OMX_REQUIRE(kernel_size % 2 == 1 && kernel_size <= 31, "omx_sanm_encoder_stack: odd kernel_size <= 31 expected");
+    OMX_REQUIRE(dtype == OMX_BFLOAT16 || dtype == OMX_FLOAT32, "paraformer: dtype %d unsupported (float32 = the reference's arithmetic, bfloat16)", (int)dtype);
+    void* act[2] = {act0, act1};
+    void* nrm[2] = {nrm0, nrm1};
+    const void* h = x;
+    const void* pre = nullptr;
+    int d_in = in_dim;
+    for (int l = 0; l < n_layers; ++l) {
+        const bool last = l + 1 == n_layers;
+        void* o = act[l & 1];
+        const void* nw = last ? after_norm_w : layers[l + 1].norm1_w;
+        const void* nb = last ? after_norm_b : layers[l + 1].norm1_b;
+        void* nh = last ? out : nrm[l & 1];
+        const int rc = dtype == OMX_BFLOAT16
+                           ? omx::encoder_layer_impl<OMX_BFLOAT16>(o, h, &layers[l], T, d_in, dim, heads, ffn_dim, kernel_size, stream, pre, nw, nb, nh)
+                           : omx::encoder_layer_impl<OMX_FLOAT32>(o, h, &layers[l], T, d_in, dim, heads, ffn_dim, kernel_size, stream, pre, nw, nb, nh);
+        if (rc) return 1;
+        h = o; pre = nh; d_in = dim;
+    }
+    return 0;
 }
 
 int omx_sanm_encoder_layer(void* out, const void* x, const omx_sanm_layer_weights* w, int T, int in_dim, int dim,

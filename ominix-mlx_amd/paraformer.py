@@ -40,6 +40,8 @@ PARAFORMER_SIGNATURES = {
     "omx_paraformer_decoder_tail": (c_int, [c_void_p, c_void_p, ctypes.POINTER(TailWeights), c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "omx_cast": (c_int, [c_void_p, c_int, c_void_p, c_int, ctypes.c_int64, c_void_p]),
     "omx_sanm_encoder_layer": (c_int, [c_void_p, c_void_p, ctypes.POINTER(SanmLayerWeights), c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "omx_sanm_encoder_stack": (c_int, [c_void_p, c_void_p, ctypes.POINTER(SanmLayerWeights), c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                                       c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "omx_cif_fire": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_float, c_int, c_void_p]),
 }
 for _n, (_r, _a) in PARAFORMER_SIGNATURES.items():
@@ -151,16 +153,16 @@ class Paraformer:
         dt = self.dtype
         h = Tensor((T, in0), dt)
         check(lib.omx_paraformer_embed(h.ptr, mel.ptr, T, in0, h.dtype, None))
-        in_dim = in0
-        # two buffers, alternating: releasing a device buffer per layer would synchronise host and GPU 50 times
-        bufs = [Tensor((T, c["encoder_dim"]), dt), Tensor((T, c["encoder_dim"]), dt)]
-        for i, w in enumerate(self.enc_layers):
-            out = bufs[i & 1]
-            check(lib.omx_sanm_encoder_layer(out.ptr, h.ptr, ctypes.byref(w), T, in_dim, c["encoder_dim"], c["encoder_heads"],
-                                             c["encoder_ffn_dim"], c["sanm_kernel_size"], out.dtype, None))
-            h, in_dim = out, c["encoder_dim"]
-        out = Tensor(h.shape, dt)
-        check(lib.omx_layer_norm(out.ptr, h.ptr, self.after_norm[0], self.after_norm[1], T, c["encoder_dim"], 1e-5, out.dtype, None))
+        # the layer loop + after_norm in one C call (round 6: no 50 ctypes round trips, and in float32 each layer's last launch computes
+        # the next layer's norm1); scratch: two activations and two normalised inputs, alternating
+        D = c["encoder_dim"]
+        act = [Tensor((T, D), dt), Tensor((T, D), dt)]
+        nrm = [Tensor((T, max(in0, D)), dt), Tensor((T, max(in0, D)), dt)]
+        out = Tensor((T, D), dt)
+        n = len(self.enc_layers)
+        arr = (SanmLayerWeights * n)(*self.enc_layers)
+        check(lib.omx_sanm_encoder_stack(out.ptr, h.ptr, arr, n, T, in0, D, c["encoder_heads"], c["encoder_ffn_dim"], c["sanm_kernel_size"],
+                                         self.after_norm[0], self.after_norm[1], act[0].ptr, act[1].ptr, nrm[0].ptr, nrm[1].ptr, out.dtype, None))
         return out
 
     def predict(self, enc: Tensor):

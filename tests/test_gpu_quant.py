@@ -321,7 +321,8 @@ def test_matrix_core_packed_gemv_agrees_with_the_valu_kernel_on_tokens(omx):
         lib.omx_debug_qgemv_mfma(mode)
         try:
             dq, ds, db = T.from_numpy(q_, "u32"), T.from_numpy(s_), T.from_numpy(b_)
-            omx.check(lib.omx_debug_qgemv(out.ptr, None, slots.ptr, T.from_numpy(x).ptr, T.from_numpy(nw).ptr, None, dq.ptr, ds.ptr, db.ptr,
+            xd, nwd = T.from_numpy(x), T.from_numpy(nw)          # (held: a temporary would be freed before the launch reads it)
+            omx.check(lib.omx_debug_qgemv(out.ptr, None, slots.ptr, xd.ptr, nwd.ptr, None, dq.ptr, ds.ptr, db.ptr,
                                           None, None, None, 0, N, K, 64, 4, PRO_RMSNORM, EPI_ARGMAX, 1e-6, 0, None))
             omx.check(omx.lib.omx_synchronize(None))
         finally:

@@ -345,7 +345,9 @@ int launch_ks(const QGemvArgs& a_in, int pro, int epi, hipStream_t s) {
 }  // namespace
 
 size_t qgemv4m_tile_words(int n, int K) { return (size_t)((n + 15) / 16) * (K / 1024) * kTileWords; }
-bool qgemv4m_shape_ok(int K, int group, int bits) { return bits == 4 && group == 64 && (K == 4096 || K == 12288); }
+// K / 1024 waves per block: the widths of the Qwen3 family and its tensor-parallel K slices (1024 .. 12288)
+static bool ks_built(int ks) { return ks == 1 || ks == 2 || ks == 3 || ks == 4 || ks == 6 || ks == 8 || ks == 12; }
+bool qgemv4m_shape_ok(int K, int group, int bits) { return bits == 4 && group == 64 && K > 0 && K % 1024 == 0 && ks_built(K / 1024); }
 int launch_qgemv4m_repack(uint32_t* tiles, const uint32_t* wq, const bf16_t* scales, const bf16_t* biases, int n, int K, hipStream_t s) {
     OMX_REQUIRE(tiles && wq && scales && n > 0 && K % 1024 == 0, "qgemv tile repack: bad arguments");
     qgemv4m_repack_kernel<<<(unsigned)(((n + 15) / 16) * (K / 1024)), 256, 0, s>>>(tiles, wq, scales, biases, n, K / 1024);
@@ -359,7 +361,7 @@ int g_qgemv_mfma_mode = 1;    // 0: never (tests flip it through omx_debug_qgemv
 // 0: launched; -1: not a shape / form of this kernel (the caller takes quant.hip's VALU kernel); 1: error
 int launch_qgemv4m(const QGemvArgs& a, int pro, int epi, hipStream_t s) {
     if (g_qgemv_mfma_mode == 0 || a.group != 64 || a.scales_f16 || a.n_batch > 1 || a.w_sel || a.w_sel_n > 0 || a.N < 16) return -1;
-    if (a.K != 4096 && a.K != 12288) return -1;
+    if (!qgemv4m_shape_ok(a.K, a.group, 4)) return -1;
     for (int i = 0; i < 3; ++i)
         if (a.m[i].w && !a.m[i].tiles) return -1;          // the engine (or the test hook) built no tiles for a member
     if (epi == EPI_SWIGLU) {
@@ -369,7 +371,15 @@ int launch_qgemv4m(const QGemvArgs& a, int pro, int epi, hipStream_t s) {
         if (a.m[1].w && a.m[0].n % 16 != 0) return -1;
         if (a.m[2].w && a.m[1].n % 16 != 0) return -1;
     }
-    return a.K == 4096 ? launch_ks<4>(a, pro, epi, s) : launch_ks<12>(a, pro, epi, s);
+    switch (a.K / 1024) {
+        case 1: return launch_ks<1>(a, pro, epi, s);
+        case 2: return launch_ks<2>(a, pro, epi, s);
+        case 3: return launch_ks<3>(a, pro, epi, s);
+        case 4: return launch_ks<4>(a, pro, epi, s);
+        case 6: return launch_ks<6>(a, pro, epi, s);
+        case 8: return launch_ks<8>(a, pro, epi, s);
+        default: return launch_ks<12>(a, pro, epi, s);
+    }
 }
 
 }  // namespace omx

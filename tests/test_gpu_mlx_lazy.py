@@ -190,8 +190,9 @@ def test_drop_in_route_on_a_quantized_checkpoint(omx, mx, bits):
     triplet, the embedding dequantises its rows (quantized.rs:120-164, 361-385).  The replay drives exactly those calls; the deferred list
     rewrites them onto the packed-GEMV family -- quant.hip, and for 4-bit K = 4096 matrices the matrix-core kernel on tiles it builds once
     per weight buffer (qgemv_mfma.hip) -- with the same prologues / epilogues as the bf16 idioms.  The three modes agree on every token on
-    the VALU kernels; where the matrix-core kernel steps in (4-bit, hidden 4096) its different accumulation order is allowed to move a
-    near-tie, so that case is held to the engine's tokens through their common prefix and to the bound of the logits instead."""
+    the VALU kernels (8-bit); where the matrix-core kernel steps in (4-bit, K a multiple of 1 024) its different accumulation order is
+    allowed to move a near-tie, so that case is held through the streams' common prefix (the logits are held to the oracle at full size:
+    test_gpu_fullsize_pin.py, test_gpu_quant.py)."""
     from ominix_mlx_amd import engine
     cfg = dict(hidden_size=1024, num_hidden_layers=2, intermediate_size=2048, num_attention_heads=8, num_key_value_heads=4, head_dim=128,
                vocab_size=2048, rms_norm_eps=1e-6, rope_theta=1e6, tie_word_embeddings=False)
@@ -204,8 +205,20 @@ def test_drop_in_route_on_a_quantized_checkpoint(omx, mx, bits):
         mx.lazy_mode(lazy, fuse)
         s0 = mx.lazy_stats()
         runs[name] = ([int(t) for t in m.per_op_route(prompt, 60)["tokens"]], s0, mx.lazy_stats())
-    assert runs["eager"][0] == runs["recorded"][0] == runs["fused"][0]       # K = 1024 / 2048: the VALU kernels in every mode
-    assert runs["fused"][0][:24] == want[:24]
+    assert runs["eager"][0] == runs["recorded"][0]                            # the same launches, now or later
+    if bits == 8:
+        assert runs["fused"][0] == runs["eager"][0]                          # 8-bit: the VALU kernel in every mode, the same rounding points
+        assert runs["fused"][0][:24] == want[:24]
+    else:
+        # 4-bit, K a multiple of 1 024: the fused plans (and the engine) multiply on the matrix cores -- another accumulation order than the
+        # VALU kernel the unfused calls take, so a near-tie of the flat synthetic logits may move; the streams must share their start
+        def common(a, b):
+            n = 0
+            while n < min(len(a), len(b)) and a[n] == b[n]:
+                n += 1
+            return n
+        assert common(runs["fused"][0], runs["eager"][0]) >= 8, (runs["fused"][0][:12], runs["eager"][0][:12])
+        assert common(runs["fused"][0], want) >= 8, (runs["fused"][0][:12], want[:12])
     _, s0, s1 = runs["fused"]
     assert s1["fused_launches"] - s0["fused_launches"] >= 5 * cfg["num_hidden_layers"] * 60
     m.close()

@@ -238,6 +238,13 @@ def test_gemv_epilogue_codes_match_the_header():
     (1040, 12288, PRO_NONE, EPI_F32, 0, 0),             # a tensor-parallel K slice's f32 row sums
     (1000, 4096, PRO_NONE, EPI_STORE, 0, 0),            # ragged N: the last 16-row block is half empty
     (20000, 4096, PRO_RMSNORM, EPI_ARGMAX, 0, 0),       # logits + argmax partials, blocks looping over several row blocks
+    (2048, 1024, PRO_RMSNORM, EPI_STORE, 0, 1024),      # the other block sizes (K / 1024 waves): Qwen3-0.6B's hidden size, q | k stacked
+    (1024, 2048, PRO_NONE, EPI_RESIDUAL, 0, 0),         # ... its o projection; a TP 2 shard's K slice of Qwen3-8B's
+    (1536, 3072, PRO_NONE, EPI_RESIDUAL, 0, 0),         # ... its down projection
+    (304, 6144, PRO_NONE, EPI_F32, 0, 0),               # the TP 2 shard's down slice (f32 partial rows)
+    (768, 1024, PRO_RMSNORM, EPI_SWIGLU, 0, 0),         # one-wave blocks with the gate / up pair
+    (640, 8192, PRO_NONE, EPI_STORE, 0, 0),
+    (40000, 1024, PRO_RMSNORM, EPI_ARGMAX, 0, 0),       # a vocabulary matrix at hidden 1024: streaming one-wave blocks
 ])
 def test_fused_packed_gemv_forms_match_oracle(omx, mfma, N, K, pro, epi, single, stack):
     lib = _bind_debug(omx)

@@ -222,3 +222,24 @@ def test_drop_in_route_on_a_quantized_checkpoint(omx, mx, bits):
     _, s0, s1 = runs["fused"]
     assert s1["fused_launches"] - s0["fused_launches"] >= 5 * cfg["num_hidden_layers"] * 60
     m.close()
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f32"])
+@pytest.mark.parametrize("shape", [(1, 5, 8), (3, 7), (2, 64), (4, 1000), (2048, 96)])
+def test_elementwise_ops_on_the_vector_path_and_the_general_one(mx, dtype, shape):
+    """Same-shape contiguous float operands take 16-byte-per-lane kernels (the residual adds and SwiGLU products of a prompt pass), everything
+    else the general broadcast kernel: both against numpy, every op, sizes that are and are not whole vectors."""
+    g = np.random.default_rng(sum(shape))
+    a, b = g.standard_normal(shape).astype(np.float32), g.standard_normal(shape).astype(np.float32) + 3.0
+    dt = mx.BFLOAT16 if dtype == "bf16" else mx.FLOAT32
+    rnd = rc.bf16_round if dtype == "bf16" else (lambda v: np.asarray(v, np.float32))
+    a, b = rnd(a), rnd(b)
+    A, B = mx.Array.from_numpy(a, dt), mx.Array.from_numpy(b, dt)
+    a64, b64 = a.astype(np.float64), b.astype(np.float64)
+    cases = {"negative": (mx.negative(A), -a64), "add": (mx.add(A, B), a64 + b64), "subtract": (mx.subtract(A, B), a64 - b64),
+             "multiply": (mx.multiply(A, B), a64 * b64), "divide": (mx.divide(A, B), a64 / b64),
+             "sigmoid": (mx.sigmoid(A), 1 / (1 + np.exp(-a64))), "exp": (mx.exp(A), np.exp(a64))}
+    tol = 2.0 ** -8 if dtype == "bf16" else 2.0 ** -20
+    for name, (got, ref) in cases.items():
+        err = np.abs(got.numpy().astype(np.float64) - ref)
+        assert (err <= tol * np.maximum(np.abs(ref), 1e-3) + 1e-7).all(), (name, float(err.max()))

@@ -994,6 +994,8 @@ static int matmul_impl(mlx_array* res, const mlx_array ha_in, const mlx_array hb
     rec.i0 = N; rec.i1 = K; rec.i2 = M;
     // the decode form (one bf16 row against an NT weight): what the deferred list may rewrite onto the fused GEMV family
     rec.flag = M == 1 && !bias && nt && a0.dt == MLX_BFLOAT16 && is_contig(a0) && K % 8 == 0 && K <= 65536;
+    // ... and the prompt form (many bf16 rows): residual / SwiGLU epilogues and segment stacking of the 256^2 GEMM family (gemm.hpp)
+    rec.i3 = (M > 8 && !bias && nt && a0.dt == MLX_BFLOAT16 && is_contig(a0) && K % 64 == 0 && N % 4 == 0) ? 1 : 0;
     rec.run = [](Rec& q) -> int {
         const Arr &a0 = q.a[1], &b0 = q.a[2];
         const int N = q.i0, K = q.i1, M = q.i2;

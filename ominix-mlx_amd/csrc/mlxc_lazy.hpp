@@ -124,6 +124,7 @@ struct FusePlan {          // one launch_gemv replacing the records it absorbed;
     std::shared_ptr<Arr> stack_out;
     bool is_scatter = false;
     ScatterPlan sc;
+    bool gemm = false;             // the records are prompt-pass products (many rows): the 256^2 GEMM family's epilogues and segment stacking
     int mm0 = -1, mm1 = -1;        // the matmul record(s): mm1 = the up projection of a SwiGLU pair
     int norm = -1;                 // RMSNorm record feeding them (prologue), or -1
     int epi = omx::EPI_STORE;
@@ -285,6 +286,33 @@ int run_plan(std::vector<Rec>& recs, const FusePlan& p) {
     using namespace omx;
     if (p.is_scatter) return run_scatter(recs, p.sc);
     if (recs[p.mm0].kind == RK_QMM) return run_plan_packed(recs, p);
+    if (p.gemm) {
+        const Rec& m0 = recs[p.mm0];
+        const int N = m0.i0, K = m0.i1, M = m0.i2;
+        const bf16_t* x = (const bf16_t*)m0.a[1].ptr();
+        if (p.stack_out) {                      // two or three products of one activation: one segmented launch, each into its own result
+            GemmSegs sg = {};
+            const int idx[3] = {p.mm0, p.mmk, p.mmv};
+            for (int i = 0; i < 3; ++i)
+                if (idx[i] >= 0) {
+                    const Rec& m = recs[idx[i]];
+                    sg.plain[sg.n_plain++] = GemmSeg{(const bf16_t*)m.a[2].ptr(), nullptr, (bf16_t*)m.a[0].ptr(), m.i0, m.i0, 0};
+                }
+            return launch_gemm_bf16_segmented(x, M, K, sg, g_stream);
+        }
+        if (p.epi == EPI_SWIGLU) {              // act = silu(x Wg^T) * (x Wu^T) with nn::silu's roundings, the gate / up pair never in HBM
+            GemmSegs sg = {};
+            sg.w_gate = (const bf16_t*)m0.a[2].ptr();
+            sg.w_up = (const bf16_t*)recs[p.mm1].a[2].ptr();
+            sg.out_act = (bf16_t*)recs[p.tail].a[0].ptr();
+            sg.half = N; sg.ld_act = N; sg.act_mode = 1;
+            return launch_gemm_bf16_segmented(x, M, K, sg, g_stream);
+        }
+        if (p.epi == EPI_RESIDUAL)
+            return launch_gemm_bf16_ex((bf16_t*)recs[p.tail].a[0].ptr(), x, (const bf16_t*)m0.a[2].ptr(), nullptr,
+                                       (const bf16_t*)recs[p.tail].a[p.resid_operand].ptr(), M, N, K, g_stream);
+        return launch_gemm_bf16((bf16_t*)m0.a[0].ptr(), x, (const bf16_t*)m0.a[2].ptr(), nullptr, M, N, K, g_stream);
+    }
     const Rec& m0 = recs[p.mm0];
     GemvArgs g = {};
     const int K = m0.i1, N = m0.i0;
@@ -389,7 +417,7 @@ void fuse_pending(std::vector<Rec>& recs, std::unordered_map<int, FusePlan>& pla
                     ++info[id].rd_n;          // (an upper bound: the fill below lists a record once per buffer)
                 }
             }
-        any_mm = any_mm || ((r.kind == RK_MATMUL || r.kind == RK_QMM) && r.flag);
+        any_mm = any_mm || ((r.kind == RK_MATMUL || r.kind == RK_QMM) && r.flag) || (r.kind == RK_MATMUL && r.i3 == 1);
     }
     if (!any_mm) return;
     {
@@ -446,6 +474,10 @@ void fuse_pending(std::vector<Rec>& recs, std::unordered_map<int, FusePlan>& pla
         return id < 0 ? -1 : info[id].writer;
     };
     auto gemv_rec = [&](int i) { return i >= 0 && (recs[i].kind == RK_MATMUL || recs[i].kind == RK_QMM) && recs[i].flag && !recs[i].dead; };
+    // OMX_MLX_FUSE_GEMM: bit 0 segment stacking, bit 1 SwiGLU pair, bit 2 residual epilogue of the prompt-pass products (default 7; 0: none)
+    static const int gemm_mask = [] { const char* e = getenv("OMX_MLX_FUSE_GEMM"); return e ? atoi(e) : 7; }();
+    auto gemm_rec = [&](int i) { return gemm_mask != 0 && i >= 0 && recs[i].kind == RK_MATMUL && recs[i].i3 == 1 && !recs[i].dead; };
+    auto mm_rec = [&](int i) { return gemv_rec(i) || gemm_rec(i); };
     std::vector<int> plan_of(n, -1);       // matmul record -> the record index its plan is keyed by
     // ---- epilogues, found from the record that ends the idiom ----
     for (int j = 0; j < n; ++j) {
@@ -455,20 +487,21 @@ void fuse_pending(std::vector<Rec>& recs, std::unordered_map<int, FusePlan>& pla
             // act = (g * sigmoid(g)) * u, either operand order at both levels
             for (int sw = 0; sw < 2; ++sw) {
                 const int m2 = producer(r.a[1 + sw], j), U = producer(r.a[2 - sw], j);
-                if (m2 < 0 || !gemv_rec(U) || recs[m2].kind != RK_MUL || !recs[m2].flag || recs[m2].dead) continue;
+                if (m2 < 0 || !mm_rec(U) || recs[m2].kind != RK_MUL || !recs[m2].flag || recs[m2].dead) continue;
                 int G = -1, S = -1;
                 for (int sw2 = 0; sw2 < 2 && G < 0; ++sw2) {
                     const int g0 = producer(recs[m2].a[1 + sw2], m2), s0 = producer(recs[m2].a[2 - sw2], m2);
-                    if (gemv_rec(g0) && s0 >= 0 && recs[s0].kind == RK_SIGMOID && !recs[s0].dead && same_view(recs[s0].a[1], recs[g0].a[0])) { G = g0; S = s0; }
+                    if (mm_rec(g0) && gemm_rec(g0) == gemm_rec(U) && s0 >= 0 && recs[s0].kind == RK_SIGMOID && !recs[s0].dead && same_view(recs[s0].a[1], recs[g0].a[0])) { G = g0; S = s0; }
                 }
                 if (G < 0 || G == U || plan_of[G] >= 0 || plan_of[U] >= 0) continue;
+                if (gemm_rec(G) && !(gemm_mask & 2)) continue;
                 const Rec &rg = recs[G], &ru = recs[U];
                 if (rg.i0 != ru.i0 || rg.i1 != ru.i1 || rg.kind != ru.kind || rg.i3 != ru.i3 || !same_view(rg.a[1], ru.a[1])) continue;
                 if (rg.i0 % 4 != 0) continue;
                 if (!internal(rg.a[0]) || !internal(ru.a[0]) || !internal(recs[S].a[0]) || !internal(recs[m2].a[0])) continue;
                 if (!only_readers(rg.a[0], {S, m2}) || !only_readers(ru.a[0], {j}) || !only_readers(recs[S].a[0], {m2}) || !only_readers(recs[m2].a[0], {j})) continue;
                 FusePlan p;
-                p.at = j; p.mm0 = G; p.mm1 = U; p.epi = EPI_SWIGLU; p.tail = j;
+                p.at = j; p.mm0 = G; p.mm1 = U; p.epi = EPI_SWIGLU; p.tail = j; p.gemm = gemm_rec(G);
                 plans[j] = p;
                 plan_of[G] = plan_of[U] = j;
                 recs[G].dead = recs[U].dead = recs[S].dead = recs[m2].dead = true;
@@ -477,11 +510,12 @@ void fuse_pending(std::vector<Rec>& recs, std::unordered_map<int, FusePlan>& pla
         } else if (r.kind == RK_ADD && r.flag) {
             for (int sw = 0; sw < 2; ++sw) {
                 const int M = producer(r.a[2 - sw], j);
-                if (!gemv_rec(M) || plan_of[M] >= 0) continue;
+                if (!mm_rec(M) || plan_of[M] >= 0) continue;
+                if (gemm_rec(M) && !(gemm_mask & 4)) continue;
                 if (!internal(recs[M].a[0]) || !only_readers(recs[M].a[0], {j})) continue;
-                if (r.a[1 + sw].size() != (size_t)recs[M].i0) continue;
+                if (r.a[1 + sw].size() != (size_t)recs[M].i0 * (size_t)recs[M].i2) continue;
                 FusePlan p;
-                p.at = j; p.mm0 = M; p.epi = EPI_RESIDUAL; p.tail = j; p.resid_operand = 1 + sw;
+                p.at = j; p.mm0 = M; p.epi = EPI_RESIDUAL; p.tail = j; p.resid_operand = 1 + sw; p.gemm = gemm_rec(M);
                 plans[j] = p;
                 plan_of[M] = j;
                 recs[M].dead = true;
@@ -499,12 +533,48 @@ void fuse_pending(std::vector<Rec>& recs, std::unordered_map<int, FusePlan>& pla
     }
     // ---- the remaining M == 1 products launch as plain GEMVs at their own position (so that they can take a prologue) ----
     for (int i = 0; i < n; ++i)
-        if (gemv_rec(i) && plan_of[i] < 0) {
+        if (mm_rec(i) && plan_of[i] < 0) {
             FusePlan p;
-            p.at = i; p.mm0 = i; p.epi = EPI_STORE;
+            p.at = i; p.mm0 = i; p.epi = EPI_STORE; p.gemm = gemm_rec(i);
             plans[i] = p;
             plan_of[i] = i;
         }
+    // ---- prompt pass: the plain products of ONE activation (q / k / v) as one segmented launch, each still into its own result ----
+    for (int i = 0; i < n; ++i) {
+        if (!(gemm_mask & 1) || !gemm_rec(i) || plan_of[i] != i || plans[i].epi != EPI_STORE || plans[i].stack_out) continue;
+        int grp[3] = {i, -1, -1}, cnt = 1;
+        for (int j2 = i + 1; j2 < n && j2 <= i + 24 && cnt < 3; ++j2)
+            if (gemm_rec(j2) && plan_of[j2] == j2 && plans[j2].epi == EPI_STORE && !plans[j2].stack_out && same_view(recs[j2].a[1], recs[i].a[1]) &&
+                recs[j2].i1 == recs[i].i1 && recs[j2].i2 == recs[i].i2)
+                grp[cnt++] = j2;
+        // the launch sits where the LAST product was recorded: nothing recorded before that point may read an earlier member's result
+        // (gate / up with the SwiGLU rewrite switched off: sigmoid(gate) is recorded between the two products)
+        while (cnt >= 2) {
+            bool early_reader = false;
+            for (int c = 0; c + 1 < cnt && !early_reader; ++c) {
+                const int* first = nullptr;
+                const int nr = readers_of(recs[grp[c]].a[0], &first);
+                for (int t = 0; t < nr; ++t) early_reader = early_reader || first[t] <= grp[cnt - 1];
+            }
+            if (!early_reader) break;
+            --cnt;                               // drop the last member and try the shorter group
+        }
+        if (cnt < 2) continue;
+        // the activation must not be rewritten between the first and the last of them (only an in-place cache update could, and it never targets x)
+        GemmSegs probe = {};
+        for (int c = 0; c < cnt; ++c) probe.plain[probe.n_plain++] = GemmSeg{nullptr, nullptr, nullptr, recs[grp[c]].i0, recs[grp[c]].i0, 0};
+        if (!gemm_segmented_supported(recs[i].i2, recs[i].i1, probe)) continue;
+        const int last = grp[cnt - 1];
+        FusePlan st = plans[i];
+        for (int c = 0; c < cnt; ++c) plans.erase(grp[c]);
+        st.at = last; st.mm0 = grp[0]; st.mmk = grp[1]; st.mmv = cnt > 2 ? grp[2] : -1;
+        st.stack_out = std::make_shared<Arr>();           // (marks the stacked form; the results stay in the records' own buffers)
+        plans[last] = st;
+        for (int c = 0; c < cnt; ++c) {
+            plan_of[grp[c]] = last;
+            if (grp[c] != last) recs[grp[c]].dead = true;
+        }
+    }
     // ---- attention preparation: anchored at the SDPA record.  q <- rope <- rms_norm(q_norm) <- [1, H, T, D] view of the q projection;
     //      the k operand's buffer is written by a slice_update whose update is rope <- rms_norm(k_norm) <- view of the k projection, the
     //      v operand's by a slice_update of the v projection's view (KVCache::update_and_fetch, cache.rs:140-193) ----
@@ -554,6 +624,15 @@ void fuse_pending(std::vector<Rec>& recs, std::unordered_map<int, FusePlan>& pla
         if (!only_readers(nq.a[0], {sp.rq}) || !only_readers(nk.a[0], {sp.rk}) || !only_readers(rk.a[0], {sp.uk})) continue;
         sp.T = T; sp.H = H; sp.Hkv = Hkv; sp.D = D; sp.cap = capk; sp.offset = rq.i2;
         const int at = std::max(std::max(sp.rq, sp.rk), std::max(sp.uk, sp.uv));
+        {   // the one launch sits where the LAST of the six was recorded: nothing recorded before that may read the rotated q or the caches
+            bool early = false;
+            for (const Arr* x : {&rq.a[0], &uk.a[0], &uv.a[0]}) {
+                const int* first = nullptr;
+                const int nr = readers_of(*x, &first);
+                for (int t = 0; t < nr; ++t) early = early || (first[t] <= at && first[t] != sp.uk && first[t] != sp.uv && first[t] != sp.rq && first[t] != sp.rk);
+            }
+            if (early) continue;
+        }
         // the three projections as one row-stacked launch: plain GEMV plans on one activation, nobody else reading their rows
         const int Mq = producer_of_buf(nq.a[1]), Mk = producer_of_buf(nk.a[1]), Mv = producer_of_buf(uv.a[1]);
         if (Mq >= 0 && Mk >= 0 && Mv >= 0 && gemv_rec(Mq) && gemv_rec(Mk) && gemv_rec(Mv) && plan_of[Mq] == Mq && plan_of[Mk] == Mk && plan_of[Mv] == Mv &&

@@ -243,3 +243,25 @@ def test_elementwise_ops_on_the_vector_path_and_the_general_one(mx, dtype, shape
     for name, (got, ref) in cases.items():
         err = np.abs(got.numpy().astype(np.float64) - ref)
         assert (err <= tol * np.maximum(np.abs(ref), 1e-3) + 1e-7).all(), (name, float(err.max()))
+
+
+def test_stacked_products_never_move_behind_a_reader(mx):
+    """Two products of one activation are stacked into one launch at the position of the LAST one -- unless something recorded between
+    them reads the first (here: sigmoid(gate) between gate and up, all results held so that the SwiGLU rewrite cannot take them)."""
+    g = np.random.default_rng(3)
+    x = rc.bf16_round(g.standard_normal((1, 64, 256)).astype(np.float32))
+    wg = rc.bf16_round((g.standard_normal((512, 256)) * 0.05).astype(np.float32))
+    wu = rc.bf16_round((g.standard_normal((512, 256)) * 0.05).astype(np.float32))
+    outs = {}
+    for fuse in (False, True):
+        mx.lazy_mode(True, fuse)
+        X, WG, WU = mx.Array.from_numpy(x), mx.Array.from_numpy(wg), mx.Array.from_numpy(wu)
+        gate = mx.matmul(X, mx.transpose(WG))
+        sg = mx.sigmoid(gate)
+        up = mx.matmul(X, mx.transpose(WU))
+        both = mx.matmul(X, mx.transpose(WG))          # ... and a pair that CAN be stacked with `up` (nothing reads it in between)
+        mx.eval(gate, sg, up, both)
+        outs[fuse] = [t.numpy() for t in (gate, sg, up, both)]
+    for a, b in zip(outs[False], outs[True]):
+        np.testing.assert_array_equal(a, b)
+    np.testing.assert_array_equal(outs[True][0], outs[True][3])

@@ -102,6 +102,16 @@ struct Arr {
     mlx_dtype dt = MLX_FLOAT32;
     std::vector<uint8_t> host;      // mirror handed out by mlx_array_data_*
     bool donated = false;           // its buffer was updated in place on behalf of a slice_update result (see there)
+    Arr() = default;
+    // a copy shares the buffer and the view, never the host mirror (that belongs to the handle mlx_array_data_* was called on; recorded ops
+    // copy their operands' Arr, and a mirror of a logits row would travel with every record)
+    Arr(const Arr& o) : buf(o.buf), off(o.off), shape(o.shape), strides(o.strides), dt(o.dt), donated(o.donated) {}
+    Arr& operator=(const Arr& o) {
+        if (this != &o) { buf = o.buf; off = o.off; shape = o.shape; strides = o.strides; dt = o.dt; donated = o.donated; host.clear(); }
+        return *this;
+    }
+    Arr(Arr&&) = default;
+    Arr& operator=(Arr&&) = default;
     size_t size() const { size_t n = 1; for (int d : shape) n *= (size_t)d; return n; }
     char* ptr() const {
         if (!g_lazy_busy && (g_n_pending || g_batches_in_flight.load(std::memory_order_acquire)) && flush_pending())

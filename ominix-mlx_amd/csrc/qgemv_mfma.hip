@@ -71,7 +71,13 @@ __global__ __launch_bounds__(256) void qgemv4m_repack_kernel(uint32_t* __restric
 // the launch's whole matrix is in flight at once), 3 = the loads of tasks i + 1 and i + 2 are in flight while task i is multiplied (blocks
 // that stream many tasks: the vocabulary matrix)
 template <int KS, int NU, int PRO, int EPI, int NBUF>
-__global__ __launch_bounds__(KS * 64, (NU * NBUF <= 2 ? 3 : 2)) void qgemv4m_kernel(const QGemvArgs a) {
+#ifndef OMX_QM_MINW
+#define OMX_QM_MINW 3          // (A/B: make VARIANT=x VARIANT_FLAGS=-DOMX_QM_MINW=2)
+#endif
+#ifndef OMX_QM_NT
+#define OMX_QM_NT 1            // weight tiles with non-temporal loads
+#endif
+__global__ __launch_bounds__(KS * 64, (NU * NBUF <= 2 ? OMX_QM_MINW : 2)) void qgemv4m_kernel(const QGemvArgs a) {
     typedef Act16<false> A16;
     constexpr int NT = KS * 64, K = KS * 1024, GPR = K / 64;
     constexpr bool SWIGLU = EPI == EPI_SWIGLU;
@@ -97,8 +103,8 @@ __global__ __launch_bounds__(KS * 64, (NU * NBUF <= 2 ? 3 : 2)) void qgemv4m_ker
         }
         const uint32_t* p = a.m[mi].tiles + ((size_t)rb * KS + w) * kTileWords + lane * 4;
 #pragma unroll
-        for (int t = 0; t < 8; ++t) U.wd[t] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p + 256 * t));
-        U.sb = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p + 2048));
+        for (int t = 0; t < 8; ++t) U.wd[t] = OMX_QM_NT ? __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p + 256 * t)) : *reinterpret_cast<const u32x4*>(p + 256 * t);
+        U.sb = OMX_QM_NT ? __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p + 2048)) : *reinterpret_cast<const u32x4*>(p + 2048);
     };
 
     QmUnit U0[NU], U1[NBUF == 3 ? NU : 1], U2[NBUF == 3 ? NU : 1];

@@ -121,6 +121,9 @@ struct AttnLayout {
 };
 
 // SDPA with Tq > 1 (prefill / DiT joint attention): flash-attention forward on MFMA.
+// float32 attention of the explicit form in one launch (attn_f32.hip): head width 128, no mask, Tk <= 512.  -1 = not this kernel's shape.
+int launch_attn_f32(float* out, const float* q, const float* k, const float* v, int64_t ldq, int64_t ldkv, int64_t ldo, int Tq, int Tk, int heads,
+                    float scale, hipStream_t s);
 int launch_attn_prefill(bf16_t* out, const bf16_t* q, const bf16_t* k, const bf16_t* v, int B, int H, int Hkv, int Tq,
                         int Tk, int D, int64_t kv_batch_stride, int64_t kv_head_stride, float scale, int mask_mode,
                         const void* mask, hipStream_t s, bool out_token_major = false,

@@ -339,6 +339,8 @@ template <> struct Ops<OMX_FLOAT32> {
     // the reference's explicit form (paraformer.rs:509-516): scores = q k^T * scale -> softmax over keys -> scores . v, all f32
     static int attention(T* out, const T* q, const T* k, const T* v, int64_t ldq, int64_t ldkv, int64_t ldo, int Tq, int Tk, int heads, float* scores,
                          hipStream_t s) {
+        const int one = launch_attn_f32(out, q, k, v, ldq, ldkv, ldo, Tq, Tk, heads, 1.0f / sqrtf(128.0f), s);
+        if (one >= 0) return one;
         GemmF32 qk = {q, k, nullptr, nullptr, scores, Tq, Tk, 128, ldq, ldkv, Tk, 0, 128, 128, (int64_t)Tq * Tk, heads, 0, 0, 1.0f / sqrtf(128.0f)};
         if (launch_gemm_f32(qk, s)) return 1;
         const int64_t rows = (int64_t)heads * Tq;

@@ -23,7 +23,8 @@ TOL = {"f32": 1e-4, "bf16": 2.0 ** -6}
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
-@pytest.mark.parametrize("T,in_dim", [(101, 512), (501, 512), (77, 560)])      # 560: the first layer (no attention residual)
+@pytest.mark.parametrize("T,in_dim", [(101, 512), (200, 512), (501, 512), (600, 512), (77, 560)])      # 560: the first layer (no attention residual);
+# 101 / 200 / 501 keys: the three widths of the one-launch f32 attention, 600: beyond it (GEMM + softmax + GEMM)
 def test_sanm_encoder_layer_matches_oracle(omx, T, in_dim, dtype):
     from ominix_mlx_amd import paraformer
     dim, ffn, heads, k = 512, 2048, 4, 11

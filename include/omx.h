@@ -570,6 +570,12 @@ typedef struct omx_paraformer_decoder_weights_ {
 int omx_paraformer_decoder_layer(void* out, const void* x, const void* enc, const omx_paraformer_decoder_weights* w, int N,
                                  int Ts, int dim, int enc_dim, int heads, int ffn_dim, int kernel_size, omx_dtype dtype,
                                  omx_stream stream);
+/* ParaformerDecoder::forward's layer loop (:1144-1156) in one call: out [N, dim] = layers(x).  Scratch: act0/act1 [N, dim], nrm0/nrm1 [N, dim],
+ * kv_all [Ts, n_layers * 2 * dim] or null.  With kv_all given and the layers' linear_k_v weights / biases back to back in memory, the encoder
+ * output's k | v projection for ALL layers is one GEMM up front; in float32 each layer's last launch also computes the next layer's norm1. */
+int omx_paraformer_decoder_stack(void* out, const void* x, const void* enc, const omx_paraformer_decoder_weights* layers, int n_layers, int N,
+                                 int Ts, int dim, int enc_dim, int heads, int ffn_dim, int kernel_size, void* act0, void* act1, void* nrm0,
+                                 void* nrm1, void* kv_all, omx_dtype dtype, omx_stream stream);
 /* ParaformerDecoder::forward tail (:1157-1165): LN -> Linear+ReLU -> LN(ffn) -> Linear(no bias) -> LN -> output_proj;
  * logits [N, vocab]                                                                                                    */
 typedef struct omx_paraformer_tail_weights_ {

@@ -252,6 +252,174 @@ __global__ __launch_bounds__(256) void gemm_f32_small_kernel(const F32Args g) {
     }
 }
 
+// ---- 64 x 64 tiles, one wave per SIMD, software-pipelined (round 6).  What the two kernels above lose is not matrix time but everything
+//      around it: a load under a condition compiles to a branch with a full vmcnt(0) wait behind it (four serial memory round trips per K
+//      tile), the LDS traffic is 32 (16) four-byte writes and 64 (32) four-byte reads per thread per tile, and the matrix pipe idles
+//      while the block stages and reads.  Here
+//        * the terms of a dot product are taken in a permuted order -- lane (n, q) of v_mfma_f32_16x16x4_f32 step j, MFMA e multiplies
+//          k = 16 j + 4 q + e -- so a fragment is ONE 16-byte LDS read per four MFMAs, and the staging writes are 16-byte too;
+//        * staging is branch-free (rows / k quads past the end re-read the last one; a select zeroes the k quads at the LDS write) and runs
+//          PR tiles ahead in a register ring, every request unconditional so that the compiler's vmcnt bookkeeping stays exact;
+//        * a wave owns a 32 x 32 quadrant as 2 x 2 fragments (four independent accumulator chains, 64 MFMAs per K tile) and hides its own
+//          memory work in the issue slots between its own MFMAs: while tile t is multiplied out of registers, the fragments of tile t + 1
+//          are read from one LDS buffer and tile t + 2 is written into the other -- one barrier per tile.
+//      Measured dead ends of the same round (EXPERIMENTS R6-6): fragments straight from global memory with the same permutation (16 rows
+//      per 16-lane group is the worst case for the texture addresser); two waves per SIMD, in phase or half a tile out of phase ("ping-
+//      pong"): a wave streaming MFMAs holds its SIMD's issue stage, the other wave's LDS instructions wait for the whole stream
+//      (cycle stamps: 1180 cycles to get 8 ds_read_b128 through beside an MFMA stream, 124 without) -- only a wave's OWN instructions
+//      slot in between its MFMAs.
+constexpr int PK = 64, P_LD = PK + 4, PR = 3;                   // rows of 68 floats: 16-byte aligned
+constexpr size_t P_LDS_BYTES = (size_t)2 * 2 * 64 * P_LD * sizeof(float);
+
+__global__ __launch_bounds__(256) void gemm_f32_pipe_kernel(const F32Args g) {
+    extern __shared__ __attribute__((aligned(16))) float pipe_lds[];
+    float* As = pipe_lds;                                       // [2][64][P_LD]
+    float* Bs = pipe_lds + 2 * 64 * P_LD;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave >> 1, wn = wave & 1, n = lane & 15, q = lane >> 4;
+    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    const int bz = blockIdx.z / g.splits, split = blockIdx.z % g.splits;
+    const int ktiles = (g.K + PK - 1) / PK, per = (ktiles + g.splits - 1) / g.splits;
+    const int kbeg = split * per * PK, kend = min(g.K, (split + 1) * per * PK);
+    const int nt = kbeg < kend ? (kend - kbeg + PK - 1) / PK : 0;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 acc00 = zero4, acc01 = zero4, acc10 = zero4, acc11 = zero4;
+    // staging: thread (rq, kq) covers rows rq + 16 i of both operands' tiles, k quad kq
+    const int rq = threadIdx.x >> 4, kq = (threadIdx.x & 15) * 4;
+    const float* A = g.a + (int64_t)bz * g.sa;
+    const float* B = g.b + (int64_t)bz * g.sb;
+    const float* ap[4];
+    const float* bp[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        ap[i] = A + (int64_t)min(m0 + rq + 16 * i, g.M - 1) * g.lda;
+        bp[i] = B + (int64_t)min(n0 + rq + 16 * i, g.N - 1) * g.ldb;
+    }
+    f32x4 ra[PR][4], rb[PR][4];
+    f32x4 fa[2][4][2], fb[2][4][2];                             // [register set][k step][fragment row block]
+#define OMX_PIPE_REQUEST(slot, tile)                                                                   \
+    {                                                                                                  \
+        const int kc_ = min(kbeg + min((tile), nt - 1) * PK + kq, kend - 4);                           \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                \
+            ra[slot][i] = *reinterpret_cast<const f32x4*>(ap[i] + kc_);                                \
+            rb[slot][i] = *reinterpret_cast<const f32x4*>(bp[i] + kc_);                                \
+        }                                                                                              \
+    }
+// (the zeroing select sits at the first USE of the registers, so that the requests stay in flight across the tiles in between)
+#define OMX_PIPE_STAGE(slot, tile, buf)                                                                \
+    {                                                                                                  \
+        const bool in_ = kbeg + min((tile), nt - 1) * PK + kq < kend;                                  \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                \
+            *reinterpret_cast<f32x4*>(As + (buf) * 64 * P_LD + (rq + 16 * i) * P_LD + kq) = in_ ? ra[slot][i] : zero4; \
+            *reinterpret_cast<f32x4*>(Bs + (buf) * 64 * P_LD + (rq + 16 * i) * P_LD + kq) = in_ ? rb[slot][i] : zero4; \
+        }                                                                                              \
+    }
+#define OMX_PIPE_FRAGMENTS(set, buf)                                                                   \
+    {                                                                                                  \
+        const float* at_ = As + (buf) * 64 * P_LD + (wm * 32 + n) * P_LD + 4 * q;                      \
+        const float* bt_ = Bs + (buf) * 64 * P_LD + (wn * 32 + n) * P_LD + 4 * q;                      \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                  \
+            _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                            \
+                fa[set][j][i] = *reinterpret_cast<const f32x4*>(at_ + 16 * i * P_LD + 16 * j);         \
+                fb[set][j][i] = *reinterpret_cast<const f32x4*>(bt_ + 16 * i * P_LD + 16 * j);         \
+            }                                                                                          \
+    }
+#define OMX_PIPE_MULTIPLY(set)                                                                         \
+    {                                                                                                  \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                  \
+            _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                            \
+                acc00 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[set][j][0][e], fb[set][j][0][e], acc00, 0, 0, 0); \
+                acc01 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[set][j][0][e], fb[set][j][1][e], acc01, 0, 0, 0); \
+                acc10 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[set][j][1][e], fb[set][j][0][e], acc10, 0, 0, 0); \
+                acc11 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[set][j][1][e], fb[set][j][1][e], acc11, 0, 0, 0); \
+            }                                                                                          \
+    }
+// the iteration's instruction mix, spelled out for the scheduler: 16 fragment reads, 8 staging writes and 8 requests, each behind one MFMA
+#define OMX_PIPE_INTERLEAVE()                                                                          \
+    {                                                                                                  \
+        _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) {                                            \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                         \
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                         \
+        }                                                                                              \
+        _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) {                                             \
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                         \
+            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);                                         \
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                         \
+        }                                                                                              \
+    }
+#define OMX_PIPE_BOUNDARY()                                                                            \
+    {                                                                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                             \
+        __syncthreads();                                                                               \
+        __builtin_amdgcn_sched_barrier(0);                                                             \
+    }
+    if (nt > 0) {
+        // ring: tile x waits in slot x % PR from its request until it is staged.  Every request is unconditional -- one past the last tile
+        // re-reads the last tile (cache hits, staged into a buffer nobody reads again).
+#pragma unroll
+        for (int x = 0; x < PR; ++x) OMX_PIPE_REQUEST(x, x)
+        OMX_PIPE_STAGE(0, 0, 0)
+        OMX_PIPE_REQUEST(0, PR)
+        OMX_PIPE_BOUNDARY()
+        OMX_PIPE_FRAGMENTS(0, 0)
+        OMX_PIPE_STAGE(1 % PR, 1, 1)
+        OMX_PIPE_REQUEST(1 % PR, 1 + PR)
+        OMX_PIPE_BOUNDARY()
+        // iteration t: the MFMAs of tile t run on fragments read an iteration ago; between them, the fragments of tile t + 1 come out of
+        // buffer (t + 1) & 1 and tile t + 2 goes into buffer t & 1 (whose fragments everyone read before the last boundary).
+        // Unrolled by 2 PR so that the slot (mod PR) and the buffer / register set (mod 2) are both compile-time.
+        int t = 0;
+        for (; t + 2 * PR <= nt; t += 2 * PR) {
+#pragma unroll
+            for (int u = 0; u < 2 * PR; ++u) {
+                OMX_PIPE_FRAGMENTS((u + 1) & 1, (u + 1) & 1)
+                OMX_PIPE_STAGE((u + 2) % PR, t + u + 2, u & 1)
+                OMX_PIPE_REQUEST((u + 2) % PR, t + u + 2 + PR)
+                OMX_PIPE_MULTIPLY(u & 1)
+                OMX_PIPE_INTERLEAVE()
+                OMX_PIPE_BOUNDARY()
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 2 * PR - 1; ++u)
+            if (t + u < nt) {
+                OMX_PIPE_FRAGMENTS((u + 1) & 1, (u + 1) & 1)
+                OMX_PIPE_STAGE((u + 2) % PR, t + u + 2, u & 1)
+                OMX_PIPE_REQUEST((u + 2) % PR, t + u + 2 + PR)
+                OMX_PIPE_MULTIPLY(u & 1)
+                OMX_PIPE_INTERLEAVE()
+                OMX_PIPE_BOUNDARY()
+            }
+    }
+#undef OMX_PIPE_REQUEST
+#undef OMX_PIPE_STAGE
+#undef OMX_PIPE_FRAGMENTS
+#undef OMX_PIPE_MULTIPLY
+#undef OMX_PIPE_INTERLEAVE
+#undef OMX_PIPE_BOUNDARY
+    // D of the 16 x 16 form: col = lane & 15, row = 4 (lane >> 4) + reg
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+        const f32x4 acc = f == 0 ? acc00 : f == 1 ? acc01 : f == 2 ? acc10 : acc11;
+        const int col = n0 + wn * 32 + 16 * (f & 1) + n;
+        if (col >= g.N) continue;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = m0 + wm * 32 + 16 * (f >> 1) + 4 * q + r;
+            if (row >= g.M) continue;
+            if (g.splits > 1) {
+                g.partial[(((int64_t)bz * g.splits + split) * g.M + row) * g.N + col] = acc[r];
+            } else {
+                float v = acc[r] * g.alpha;
+                if (g.bias) v += g.bias[col];
+                if (g.relu) v = fmaxf(v, 0.f);
+                if (g.resid) v += g.resid[(int64_t)row * g.ldr + col];
+                g.out[(int64_t)bz * g.sc + (int64_t)row * g.ldc + col] = v;
+            }
+        }
+    }
+}
+
 // sums the split-K partials in split order (deterministic) and applies the epilogue.  (Measured alternative: the last block to
 // arrive at a per-tile counter reduces in the same launch -- write-through 4-byte partial stores and the serial re-read made
 // the 30 s pass 14.4 ms instead of 10.1 ms; a second launch of 256 K elements is cheaper.)
@@ -287,6 +455,38 @@ int launch_gemm_f32(const GemmF32& p, hipStream_t s) {
     // 11.9 ms, no splitting 15.4 ms, a block budget of 512 / 1024 instead of 256: 10.3 / 10.5 ms -- this rule: 10.2 ms.)
     // (round 5) a 64 x 64 grid that does not cover the chip at least `kSmallBelow / 256` times over goes to the 32 x 32 kernel: four times the
     // blocks, several of them per CU.  OMX_F32_SMALL=0 keeps the old choice, =1 takes the small tiles for every shape (tests, A/B).
+    // (round 6) the one-barrier kernel takes every NT product; OMX_F32_PIPE=0 keeps the older staged kernels (A/B, tests)
+    static const int pipe_mode = [] { const char* e = getenv("OMX_F32_PIPE"); return e ? atoi(e) : 1; }();
+    auto al16 = [](const void* x) { return (reinterpret_cast<uintptr_t>(x) & 15u) == 0; };
+    if (pipe_mode && !p.b_nn && p.K % 4 == 0 && p.lda % 4 == 0 && p.ldb % 4 == 0 && p.sa % 4 == 0 && p.sb % 4 == 0 && al16(p.a) && al16(p.b)) {
+        static const int pbudget = [] { const char* e = getenv("OMX_F32_PIPE_BUDGET"); return e ? atoi(e) : 256; }();
+        static const bool lds_ok = [] {
+            return hipFuncSetAttribute((const void*)gemm_f32_pipe_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P_LDS_BYTES) == hipSuccess;
+        }();
+        OMX_REQUIRE(lds_ok, "gemm_f32: the device refused %zu bytes of LDS per block", P_LDS_BYTES);
+        const int px = (p.N + 63) / 64, py = (p.M + 63) / 64, ptiles = px * py * p.batch, pk = (p.K + PK - 1) / PK;
+        int splits = 1;
+        while (ptiles * splits * 2 <= pbudget && pk / (splits * 2) >= 2) splits *= 2;
+        g.splits = splits;
+        if (splits > 1) {
+            void* ws = nullptr;
+            if (get_workspace_aux(&ws, (size_t)p.batch * splits * p.M * p.N * sizeof(float), s)) return 1;
+            g.partial = (float*)ws;
+        }
+        gemm_f32_pipe_kernel<<<dim3(px, py, p.batch * splits), 256, P_LDS_BYTES, s>>>(g);
+        OMX_LAUNCH_CHECK();
+        if (defer) {
+            *p.defer_partial = splits > 1 ? g.partial : p.out;
+            *p.defer_splits = splits;
+            return 0;
+        }
+        if (splits > 1) {
+            const int64_t total = (int64_t)p.batch * p.M * p.N;
+            gemm_f32_reduce_kernel<<<(unsigned)std::min<int64_t>((total + 255) / 256, 4096), 256, 0, s>>>(g);
+            OMX_LAUNCH_CHECK();
+        }
+        return 0;
+    }
     const char* se = getenv("OMX_F32_SMALL");
     const int small_mode = se ? atoi(se) : -1;
     constexpr int kSmallBelow = 1024;

@@ -134,15 +134,9 @@ struct F32Tail {                 // what follows a float32 product (all optional
     const float* v = nullptr; int64_t ldv = 0; const float* fw = nullptr; int ksize = 0; const float* resid2 = nullptr;   // the FSMN memory block
     const float* ln_w = nullptr; const float* ln_b = nullptr; float* ln_out = nullptr;
 };
-// out [M, N] = x [M, K] . w [N, K]^T, finished by ONE launch with everything in `t`; out may be null when only the normalised rows are kept
-int gemm_f32_with_tail(float* out, const float* x, const float* w, int M, int N, int K, const F32Tail& t, float* scratch_out, hipStream_t s) {
-    const float* partial = nullptr;
-    int splits = 1;
-    float* raw = out ? out : scratch_out;       // (a product nobody reads as such still needs somewhere to land when K is not split)
-    GemmF32 p = {x, w, nullptr, nullptr, raw, M, N, K, K, K, N, N, 0, 0, 0, 1, 0, 0, 1.0f};
-    p.defer_partial = &partial;
-    p.defer_splits = &splits;
-    if (launch_gemm_f32(p, s)) return 1;
+// rows of `partial` ([splits][M, N], summed in split order) finished by ONE launch with everything in `t`; out may be null when only the
+// normalised rows are kept
+int launch_f32_tail(float* out, const float* partial, int splits, int M, int N, const F32Tail& t, hipStream_t s) {
     OMX_REQUIRE(f32_tail_width_ok(N), "paraformer: fused epilogue takes rows of 512, 1024 or 2048 floats (N=%d)", N);
 #define OMX_TAIL(TPR, VPT)                                                                                                                \
     f32_epilogue_ln_kernel<TPR, VPT><<<(unsigned)((M + 256 / TPR - 1) / (256 / TPR)), 256, 0, s>>>(out, t.ln_out, partial, splits, M, N, t.bias, t.relu, t.resid,  \
@@ -153,6 +147,17 @@ int gemm_f32_with_tail(float* out, const float* x, const float* w, int M, int N,
 #undef OMX_TAIL
     OMX_LAUNCH_CHECK();
     return 0;
+}
+// out [M, N] = x [M, K] . w [N, K]^T, finished by the launch above
+int gemm_f32_with_tail(float* out, const float* x, const float* w, int M, int N, int K, const F32Tail& t, float* scratch_out, hipStream_t s) {
+    const float* partial = nullptr;
+    int splits = 1;
+    float* raw = out ? out : scratch_out;       // (a product nobody reads as such still needs somewhere to land when K is not split)
+    GemmF32 p = {x, w, nullptr, nullptr, raw, M, N, K, K, K, N, N, 0, 0, 0, 1, 0, 0, 1.0f};
+    p.defer_partial = &partial;
+    p.defer_splits = &splits;
+    if (launch_gemm_f32(p, s)) return 1;
+    return launch_f32_tail(out, partial, splits, M, N, t, s);
 }
 inline bool fuse_f32_tails() {
     static const bool on = [] { const char* e = getenv("OMX_PARAFORMER_FUSE"); return !(e && e[0] == '0'); }();
@@ -367,9 +372,17 @@ int cif_alphas_impl(float* alphas, float* hidden_f32, const void* enc, const voi
     return 0;
 }
 
+// what omx_paraformer_decoder_stack hands a layer (all optional): norm1(x) already computed by the previous layer's last launch; this layer's
+// k | v rows of the encoder output, projected for all layers at once; and the norm the NEXT consumer applies to `out`, to be left in next_h1
+struct DecoderHandover {
+    const void* h1_pre = nullptr;
+    const void* kv_pre = nullptr; int64_t ld_kv = 0;
+    const void* next_ln_w = nullptr; const void* next_ln_b = nullptr; void* next_h1 = nullptr;
+};
+
 template <int DT>
 int decoder_layer_impl(void* out, const void* x, const void* enc, const omx_paraformer_decoder_weights* w, int N, int Ts, int dim, int enc_dim,
-                       int heads, int ffn_dim, int kernel_size, omx_stream stream) {
+                       int heads, int ffn_dim, int kernel_size, omx_stream stream, const DecoderHandover& ho = DecoderHandover()) {
     typedef typename Ops<DT>::T E;
     hipStream_t s = (hipStream_t)stream;
     const size_t scores = Ops<DT>::score_elems(heads, N, Ts);
@@ -388,33 +401,59 @@ int decoder_layer_impl(void* out, const void* x, const void* enc, const omx_para
     const E* xin = (const E*)x;
     const omx_dtype dt = (omx_dtype)DT;
     // tgt = down(LN_ffn(relu(up(norm1(x)))))                                                     (:1036-1042)
-    if (omx_layer_norm(h, xin, w->norm1_w, w->norm1_b, N, dim, 1e-5f, dt, stream)) return 1;
+    const E* h1 = (const E*)ho.h1_pre;
+    if (!h1) {
+        if (omx_layer_norm(h, xin, w->norm1_w, w->norm1_b, N, dim, 1e-5f, dt, stream)) return 1;
+        h1 = h;
+    }
     bool fused = false;
     if constexpr (DT == OMX_FLOAT32) {
         if (fuse_f32_tails() && f32_tail_width_ok(ffn_dim) && f32_tail_width_ok(dim)) {
             // round 6: [up + bias + relu + LN_ffn] and [down + norm2] each finished by one launch after the product (f32_epilogue_ln_kernel)
             F32Tail t1; t1.bias = (const float*)w->ffn_up_b; t1.relu = 1; t1.ln_w = (const float*)w->ffn_norm_w; t1.ln_b = (const float*)w->ffn_norm_b; t1.ln_out = ffn;
-            if (gemm_f32_with_tail(nullptr, h, (const float*)w->ffn_up_w, N, ffn_dim, dim, t1, ff, s)) return 1;
+            if (gemm_f32_with_tail(nullptr, h1, (const float*)w->ffn_up_w, N, ffn_dim, dim, t1, ff, s)) return 1;
             F32Tail t2; t2.ln_w = (const float*)w->norm2_w; t2.ln_b = (const float*)w->norm2_b; t2.ln_out = h;
             if (gemm_f32_with_tail(nullptr, ffn, (const float*)w->ffn_down_w, N, dim, ffn_dim, t2, tgt, s)) return 1;
+            // x1 = x + (fsmn(norm2(tgt)) + norm2(tgt)) and norm3(x1) in one launch: the same tail over the rows of x (:1044-1049).  `q` holds
+            // norm3(x1) until the projection below has read it
+            F32Tail t3; t3.v = h; t3.ldv = dim; t3.fw = (const float*)w->fsmn_w; t3.ksize = kernel_size; t3.ln_w = (const float*)w->norm3_w;
+            t3.ln_b = (const float*)w->norm3_b; t3.ln_out = att;
+            if (launch_f32_tail(x1, xin, 1, N, dim, t3, s)) return 1;
             fused = true;
         }
     }
+    const E* h3 = att;                       // norm3(x1): the fused path leaves it in `att` (free until the attention writes it)
     if (!fused) {
-    if (Ops<DT>::gemm_relu(ff, h, (const E*)w->ffn_up_w, (const E*)w->ffn_up_b, N, ffn_dim, dim, s)) return 1;
+    if (Ops<DT>::gemm_relu(ff, h1, (const E*)w->ffn_up_w, (const E*)w->ffn_up_b, N, ffn_dim, dim, s)) return 1;
     if (omx_layer_norm(ffn, ff, w->ffn_norm_w, w->ffn_norm_b, N, ffn_dim, 1e-5f, dt, stream)) return 1;
     if (Ops<DT>::gemm(tgt, ffn, (const E*)w->ffn_down_w, nullptr, N, dim, ffn_dim, s)) return 1;
     // x1 = x + (fsmn(norm2(tgt)) + norm2(tgt))                                                   (:1044-1047)
     if (omx_layer_norm(h, tgt, w->norm2_w, w->norm2_b, N, dim, 1e-5f, dt, stream)) return 1;
-    }
     fsmn_add_kernel<DT><<<1024, 256, 0, s>>>(x1, xin, h, dim, (const E*)w->fsmn_w, N, dim, kernel_size, nullptr);
     OMX_LAUNCH_CHECK();
-    // out = x1 + src_attn_out(softmax(q k^T * d^-1/2) v), q from norm3(x1), k/v from the encoder output      (:1049-1052, 981-1017)
     if (omx_layer_norm(h, x1, w->norm3_w, w->norm3_b, N, dim, 1e-5f, dt, stream)) return 1;
-    if (Ops<DT>::gemm(q, h, (const E*)w->q_w, (const E*)w->q_b, N, dim, dim, s)) return 1;
-    if (Ops<DT>::gemm(kv, (const E*)enc, (const E*)w->kv_w, (const E*)w->kv_b, Ts, 2 * dim, enc_dim, s)) return 1;
-    if (Ops<DT>::attention(att, q, kv, kv + dim, dim, 2 * (int64_t)dim, dim, N, Ts, heads, sc, s)) return 1;
-    return Ops<DT>::gemm_resid((E*)out, att, (const E*)w->out_w, (const E*)w->out_b, x1, N, dim, dim, s);
+    h3 = h;
+    }
+    // out = x1 + src_attn_out(softmax(q k^T * d^-1/2) v), q from norm3(x1), k/v from the encoder output      (:1049-1052, 981-1017)
+    if (Ops<DT>::gemm(q, h3, (const E*)w->q_w, (const E*)w->q_b, N, dim, dim, s)) return 1;
+    const E* kvp = (const E*)ho.kv_pre;
+    int64_t ldkv = ho.ld_kv;
+    if (!kvp) {
+        if (Ops<DT>::gemm(kv, (const E*)enc, (const E*)w->kv_w, (const E*)w->kv_b, Ts, 2 * dim, enc_dim, s)) return 1;
+        kvp = kv; ldkv = 2 * (int64_t)dim;
+    }
+    if (Ops<DT>::attention(att, q, kvp, kvp + dim, dim, ldkv, dim, N, Ts, heads, sc, s)) return 1;
+    if constexpr (DT == OMX_FLOAT32) {
+        if (fused) {
+            // out = x1 + (out_proj(att) + bias) and the next consumer's norm of `out`, one launch behind the product
+            F32Tail t4; t4.bias = (const float*)w->out_b; t4.resid = x1; t4.ldr = dim; t4.ln_w = (const float*)ho.next_ln_w; t4.ln_b = (const float*)ho.next_ln_b;
+            t4.ln_out = (float*)ho.next_h1;
+            return gemm_f32_with_tail((float*)out, att, (const float*)w->out_w, N, dim, dim, t4, nullptr, s);
+        }
+    }
+    if (Ops<DT>::gemm_resid((E*)out, att, (const E*)w->out_w, (const E*)w->out_b, x1, N, dim, dim, s)) return 1;
+    if (ho.next_h1) return omx_layer_norm(ho.next_h1, out, ho.next_ln_w, ho.next_ln_b, N, dim, 1e-5f, dt, stream);
+    return 0;
 }
 
 template <int DT>
@@ -545,6 +584,54 @@ int omx_paraformer_decoder_layer(void* out, const void* x, const void* enc, cons
     OMX_REQUIRE(kernel_size % 2 == 1 && kernel_size <= 31, "omx_paraformer_decoder_layer: odd kernel_size <= 31 expected");
     OMX_PARAFORMER_DT(dtype, omx::decoder_layer_impl<OMX_BFLOAT16>(out, x, enc, w, N, Ts, dim, enc_dim, heads, ffn_dim, kernel_size, stream),
                       omx::decoder_layer_impl<OMX_FLOAT32>(out, x, enc, w, N, Ts, dim, enc_dim, heads, ffn_dim, kernel_size, stream))
+}
+
+/* ParaformerDecoder::forward's layer loop (paraformer.rs:1144-1156) in one call.  out [N, dim] = layers(x); scratch: two [N, dim] activations,
+ * two [N, dim] normalised inputs the layers hand each other, and (optional) kv_all [Ts, n_layers * 2 * dim].  With kv_all and the layers'
+ * linear_k_v weights / biases laid out back to back in memory (layer l's right behind layer l - 1's), the encoder output is projected for ALL
+ * layers by one GEMM up front (it does not depend on the decoder state); otherwise each layer projects its own.  In float32 every layer's
+ * last launch also computes the next layer's norm1. */
+int omx_paraformer_decoder_stack(void* out, const void* x, const void* enc, const omx_paraformer_decoder_weights* layers, int n_layers, int N,
+                                 int Ts, int dim, int enc_dim, int heads, int ffn_dim, int kernel_size, void* act0, void* act1, void* nrm0,
+                                 void* nrm1, void* kv_all, omx_dtype dtype, omx_stream stream) {
+    OMX_REQUIRE(out && x && enc && layers && n_layers > 0 && act0 && act1 && nrm0 && nrm1, "omx_paraformer_decoder_stack: null argument");
+    OMX_REQUIRE(N > 0 && Ts > 0 && dim % heads == 0 && dim / heads == 128, "omx_paraformer_decoder_stack: head_dim must be 128 (dim %d, heads %d)", dim, heads);
+    OMX_REQUIRE(kernel_size % 2 == 1 && kernel_size <= 31, "omx_paraformer_decoder_stack: odd kernel_size <= 31 expected");
+    OMX_REQUIRE(dtype == OMX_BFLOAT16 || dtype == OMX_FLOAT32, "paraformer: dtype %d unsupported (float32 = the reference's arithmetic, bfloat16)", (int)dtype);
+    const size_t esz = dtype == OMX_FLOAT32 ? 4 : 2;
+    bool hoist = kv_all != nullptr;
+    for (int l = 1; l < n_layers && hoist; ++l)
+        hoist = (const char*)layers[l].kv_w == (const char*)layers[l - 1].kv_w + (size_t)2 * dim * enc_dim * esz &&
+                (const char*)layers[l].kv_b == (const char*)layers[l - 1].kv_b + (size_t)2 * dim * esz;
+    const int64_t ld_all = (int64_t)n_layers * 2 * dim;
+    if (hoist) {
+        const int rc = dtype == OMX_BFLOAT16
+                           ? omx::Ops<OMX_BFLOAT16>::gemm((omx::bf16_t*)kv_all, (const omx::bf16_t*)enc, (const omx::bf16_t*)layers[0].kv_w,
+                                                          (const omx::bf16_t*)layers[0].kv_b, Ts, (int)ld_all, enc_dim, (hipStream_t)stream)
+                           : omx::Ops<OMX_FLOAT32>::gemm((float*)kv_all, (const float*)enc, (const float*)layers[0].kv_w, (const float*)layers[0].kv_b, Ts,
+                                                         (int)ld_all, enc_dim, (hipStream_t)stream);
+        if (rc) return 1;
+    }
+    void* act[2] = {act0, act1};
+    void* nrm[2] = {nrm0, nrm1};
+    const void* h = x;
+    const void* pre = nullptr;
+    for (int l = 0; l < n_layers; ++l) {
+        const bool last = l + 1 == n_layers;
+        void* o = last ? out : act[l & 1];
+        omx::DecoderHandover ho;
+        ho.h1_pre = pre;
+        if (hoist) { ho.kv_pre = (const char*)kv_all + (size_t)l * 2 * dim * esz; ho.ld_kv = ld_all; }
+        if (!last && dtype == OMX_FLOAT32 && omx::fuse_f32_tails()) {
+            ho.next_ln_w = layers[l + 1].norm1_w; ho.next_ln_b = layers[l + 1].norm1_b; ho.next_h1 = nrm[l & 1];
+        }
+        const int rc = dtype == OMX_BFLOAT16
+                           ? omx::decoder_layer_impl<OMX_BFLOAT16>(o, h, enc, &layers[l], N, Ts, dim, enc_dim, heads, ffn_dim, kernel_size, stream, ho)
+                           : omx::decoder_layer_impl<OMX_FLOAT32>(o, h, enc, &layers[l], N, Ts, dim, enc_dim, heads, ffn_dim, kernel_size, stream, ho);
+        if (rc) return 1;
+        h = o; pre = ho.next_h1;
+    }
+    return 0;
 }
 
 int omx_paraformer_decoder_tail(void* logits, const void* x, const omx_paraformer_tail_weights* w, int N, int dim, int ffn_dim,

@@ -37,6 +37,8 @@ PARAFORMER_SIGNATURES = {
     "omx_cif_alphas": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "omx_paraformer_decoder_layer": (c_int, [c_void_p, c_void_p, c_void_p, ctypes.POINTER(DecoderLayerWeights), c_int, c_int, c_int,
                                              c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "omx_paraformer_decoder_stack": (c_int, [c_void_p, c_void_p, c_void_p, ctypes.POINTER(DecoderLayerWeights), c_int, c_int, c_int, c_int, c_int,
+                                             c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "omx_paraformer_decoder_tail": (c_int, [c_void_p, c_void_p, ctypes.POINTER(TailWeights), c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "omx_cast": (c_int, [c_void_p, c_int, c_void_p, c_int, ctypes.c_int64, c_void_p]),
     "omx_sanm_encoder_layer": (c_int, [c_void_p, c_void_p, ctypes.POINTER(SanmLayerWeights), c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
@@ -104,6 +106,7 @@ class Paraformer:
         self.cfg = dict(DEFAULT_CONFIG, **(config or {}))
         self.dtype = dtype
         c, self._keep = self.cfg, []
+        self._scratch_bufs = {}
         if c["cif_l_order"] != c["cif_r_order"]:
             raise ValueError("CIF asymmetric padding (l_order != r_order) not yet supported")   # :736-740
 
@@ -129,15 +132,26 @@ class Paraformer:
         self.after_norm = (dev("encoder.after_norm.weight"), dev("encoder.after_norm.bias"))
         self.pred = (dev("predictor.conv.weight", dense_conv), dev("predictor.conv.bias"), dev("predictor.output_proj.weight"),
                      dev("predictor.output_proj.bias"))
+        # the decoder's linear_k_v weights / biases of all layers back to back in ONE buffer each: omx_paraformer_decoder_stack then projects the
+        # encoder output for every layer with a single GEMM (the projection does not depend on the decoder state)
+        L, esz = c["decoder_layers"], (4 if dtype == "f32" else 2)
+        for i in range(L):
+            for leaf in ("weight", "bias"):
+                if f"decoder.layers.{i}.src_attn.linear_k_v.{leaf}" not in weights:
+                    raise KeyError(f"Missing weight: decoder.layers.{i}.src_attn.linear_k_v.{leaf}")
+        kv_w = Tensor.from_numpy(np.concatenate([np.asarray(weights[f"decoder.layers.{i}.src_attn.linear_k_v.weight"]) for i in range(L)], axis=0), dtype)
+        kv_b = Tensor.from_numpy(np.concatenate([np.asarray(weights[f"decoder.layers.{i}.src_attn.linear_k_v.bias"]) for i in range(L)], axis=0), dtype)
+        self._keep += [kv_w, kv_b]
+        kv_rows = kv_w.shape[0] // L
         self.dec_layers = []
-        for i in range(c["decoder_layers"]):
+        for i in range(L):
             p = f"decoder.layers.{i}"
             self.dec_layers.append(DecoderLayerWeights(
                 dev(f"{p}.norm1.weight"), dev(f"{p}.norm1.bias"), dev(f"{p}.ffn.up_proj.weight"), dev(f"{p}.ffn.up_proj.bias"),
                 dev(f"{p}.feed_forward.norm.weight"), dev(f"{p}.feed_forward.norm.bias"), dev(f"{p}.ffn.down_proj.weight"),
                 dev(f"{p}.norm2.weight"), dev(f"{p}.norm2.bias"), dev(f"{p}.self_attn.fsmn_block.weight", depthwise),
                 dev(f"{p}.norm3.weight"), dev(f"{p}.norm3.bias"), dev(f"{p}.src_attn.q_proj.weight"), dev(f"{p}.src_attn.q_proj.bias"),
-                dev(f"{p}.src_attn.linear_k_v.weight"), dev(f"{p}.src_attn.linear_k_v.bias"), dev(f"{p}.src_attn.out_proj.weight"),
+                kv_w.ptr + i * kv_rows * kv_w.shape[1] * esz, kv_b.ptr + i * kv_rows * esz, dev(f"{p}.src_attn.out_proj.weight"),
                 dev(f"{p}.src_attn.out_proj.bias")))
         t = "decoder.decoders3.0"
         self.tail = TailWeights(dev(f"{t}.norm1.weight"), dev(f"{t}.norm1.bias"), dev(f"{t}.ffn.up_proj.weight"), dev(f"{t}.ffn.up_proj.bias"),
@@ -145,19 +159,28 @@ class Paraformer:
                                 dev("decoder.after_norm.weight"), dev("decoder.after_norm.bias"), dev("decoder.output_proj.weight"),
                                 dev("decoder.output_proj.bias"))
 
+    def _scratch(self, name: str, shape, dt) -> Tensor:
+        """A scratch buffer the model keeps between calls (hipMalloc / hipFree per call cost more than the launches they served, and hipFree
+        waits for the device); calls are ordered on one stream, so the next call's launches queue behind the last reader."""
+        need = int(np.prod(shape, dtype=np.int64)) * (4 if dt == "f32" else 2)
+        buf = self._scratch_bufs.get(name)
+        if buf is None or buf.nbytes < need:                      # grows to the largest request seen, one buffer per role
+            buf = self._scratch_bufs[name] = Tensor((need,), "u8")
+        return Tensor(shape, dt, ptr=buf.ptr, owner=buf)
+
     def encode(self, mel: Tensor) -> Tensor:
         """SanmEncoder::forward (:691-708): mel f32 [T, n_mels*lfr_m] (device) -> encoder_out [T, encoder_dim]."""
         from .ops import layer_norm
         c = self.cfg
         T, in0 = mel.shape[-2], c["n_mels"] * c["lfr_m"]
         dt = self.dtype
-        h = Tensor((T, in0), dt)
+        h = self._scratch("enc_in", (T, in0), dt)
         check(lib.omx_paraformer_embed(h.ptr, mel.ptr, T, in0, h.dtype, None))
         # the layer loop + after_norm in one C call (round 6: no 50 ctypes round trips, and in float32 each layer's last launch computes
         # the next layer's norm1); scratch: two activations and two normalised inputs, alternating
         D = c["encoder_dim"]
-        act = [Tensor((T, D), dt), Tensor((T, D), dt)]
-        nrm = [Tensor((T, max(in0, D)), dt), Tensor((T, max(in0, D)), dt)]
+        act = [self._scratch("enc_act0", (T, D), dt), self._scratch("enc_act1", (T, D), dt)]
+        nrm = [self._scratch("enc_nrm0", (T, max(in0, D)), dt), self._scratch("enc_nrm1", (T, max(in0, D)), dt)]
         out = Tensor((T, D), dt)
         n = len(self.enc_layers)
         arr = (SanmLayerWeights * n)(*self.enc_layers)
@@ -183,12 +206,18 @@ class Paraformer:
         N, Ts = embeds.shape[0], enc.shape[0]
         dt = self.dtype
         x = embeds if dt == "f32" else _cast(embeds, dt)
-        bufs = [Tensor((N, c["decoder_dim"]), dt), Tensor((N, c["decoder_dim"]), dt)]
-        for i, w in enumerate(self.dec_layers):
-            out = bufs[i & 1]
-            check(lib.omx_paraformer_decoder_layer(out.ptr, x.ptr, enc.ptr, ctypes.byref(w), N, Ts, c["decoder_dim"], c["encoder_dim"],
-                                                   c["decoder_heads"], c["decoder_ffn_dim"], c["sanm_kernel_size"], out.dtype, None))
-            x = out
+        # the layer loop in one C call (round 6): the encoder output's k | v for all layers from one GEMM, each layer's norm1 from the previous
+        # layer's last launch; scratch: two activations, two normalised inputs, the [Ts, layers * 2 * dim] projection
+        D, n = c["decoder_dim"], len(self.dec_layers)
+        act = [self._scratch("dec_act0", (N, D), dt), self._scratch("dec_act1", (N, D), dt)]
+        nrm = [self._scratch("dec_nrm0", (N, D), dt), self._scratch("dec_nrm1", (N, D), dt)]
+        kv_all = self._scratch("dec_kv", (Ts, n * 2 * D), dt)
+        x_out = self._scratch("dec_out", (N, D), dt)
+        arr = (DecoderLayerWeights * n)(*self.dec_layers)
+        check(lib.omx_paraformer_decoder_stack(x_out.ptr, x.ptr, enc.ptr, arr, n, N, Ts, D, c["encoder_dim"], c["decoder_heads"],
+                                               c["decoder_ffn_dim"], c["sanm_kernel_size"], act[0].ptr, act[1].ptr, nrm[0].ptr, nrm[1].ptr,
+                                               kv_all.ptr, x_out.dtype, None))
+        x = x_out
         logits = Tensor((N, c["vocab_size"]), dt)
         check(lib.omx_paraformer_decoder_tail(logits.ptr, x.ptr, ctypes.byref(self.tail), N, c["decoder_dim"], c["decoder_ffn_dim"],
                                               c["vocab_size"], logits.dtype, None))

@@ -570,6 +570,11 @@ typedef struct omx_paraformer_decoder_weights_ {
 int omx_paraformer_decoder_layer(void* out, const void* x, const void* enc, const omx_paraformer_decoder_weights* w, int N,
                                  int Ts, int dim, int enc_dim, int heads, int ffn_dim, int kernel_size, omx_dtype dtype,
                                  omx_stream stream);
+/* The float32 model's attention as one op (funasr-mlx/src/paraformer.rs:509-516 encoder self-attention, :1090-1102 decoder cross-attention):
+ * out = softmax(q k^T / sqrt(128)) v per head of width 128, f32 throughout, no mask; rows ldq / ldkv / ldo floats apart, head h at column
+ * 128 h (so q | k | v may be the three thirds of one fused projection). */
+int omx_paraformer_attention_f32(float* out, const float* q, const float* k, const float* v, int64_t ldq, int64_t ldkv, int64_t ldo, int Tq,
+                                 int Tk, int heads, omx_stream stream);
 /* ParaformerDecoder::forward's layer loop (:1144-1156) in one call: out [N, dim] = layers(x).  Scratch: act0/act1 [N, dim], nrm0/nrm1 [N, dim],
  * kv_all [Ts, n_layers * 2 * dim] or null.  With kv_all given and the layers' linear_k_v weights / biases back to back in memory, the encoder
  * output's k | v projection for ALL layers is one GEMM up front; in float32 each layer's last launch also computes the next layer's norm1. */

@@ -577,6 +577,17 @@ int omx_cif_alphas(float* alphas, float* hidden_f32, const void* enc, const void
                       omx::cif_alphas_impl<OMX_FLOAT32>(alphas, hidden_f32, enc, conv_w, conv_b, proj_w, proj_b, T, dim, kernel_size, s))
 }
 
+/* The f32 model's attention on its own (paraformer.rs:509-516 / 1090-1102): out = softmax(q k^T / sqrt(128)) v per head of width 128, rows ld*
+ * floats apart, head h at column 128 h.  One launch for Tk <= 512, GEMM + softmax + GEMM beyond. */
+int omx_paraformer_attention_f32(float* out, const float* q, const float* k, const float* v, int64_t ldq, int64_t ldkv, int64_t ldo, int Tq,
+                                 int Tk, int heads, omx_stream stream) {
+    OMX_REQUIRE(out && q && k && v && Tq > 0 && Tk > 0 && heads > 0, "omx_paraformer_attention_f32: bad arguments");
+    OMX_REQUIRE(ldq >= 128 * (int64_t)heads && ldkv >= 128 * (int64_t)heads && ldo >= 128 * (int64_t)heads, "omx_paraformer_attention_f32: rows shorter than heads x 128");
+    void* ws = nullptr;
+    if (omx::get_workspace(&ws, omx::Ops<OMX_FLOAT32>::score_elems(heads, Tq, Tk) * 4 + 64)) return 1;
+    return omx::Ops<OMX_FLOAT32>::attention(out, q, k, v, ldq, ldkv, ldo, Tq, Tk, heads, (float*)ws, (hipStream_t)stream);
+}
+
 int omx_paraformer_decoder_layer(void* out, const void* x, const void* enc, const omx_paraformer_decoder_weights* w, int N, int Ts,
                                  int dim, int enc_dim, int heads, int ffn_dim, int kernel_size, omx_dtype dtype, omx_stream stream) {
     OMX_REQUIRE(out && x && enc && w, "omx_paraformer_decoder_layer: null argument");

@@ -37,6 +37,8 @@ PARAFORMER_SIGNATURES = {
     "omx_cif_alphas": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "omx_paraformer_decoder_layer": (c_int, [c_void_p, c_void_p, c_void_p, ctypes.POINTER(DecoderLayerWeights), c_int, c_int, c_int,
                                              c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "omx_paraformer_attention_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, c_int, c_int,
+                                             c_int, c_void_p]),
     "omx_paraformer_decoder_stack": (c_int, [c_void_p, c_void_p, c_void_p, ctypes.POINTER(DecoderLayerWeights), c_int, c_int, c_int, c_int, c_int,
                                              c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "omx_paraformer_decoder_tail": (c_int, [c_void_p, c_void_p, ctypes.POINTER(TailWeights), c_int, c_int, c_int, c_int, c_int, c_void_p]),

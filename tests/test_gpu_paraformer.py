@@ -113,6 +113,40 @@ def test_decoder_layer_matches_oracle(omx, N, Ts, dtype):
     assert np.abs(got - ref).max() <= TOL[dtype] * np.abs(ref).max()
 
 
+@pytest.mark.parametrize("Tq,Tk,heads", [(1, 1, 1), (16, 16, 4), (17, 33, 2), (101, 101, 4), (215, 501, 4), (501, 501, 4), (64, 129, 4), (40, 257, 1), (128, 400, 4),
+                                         (33, 512, 2), (20, 600, 4)])
+def test_f32_attention_matches_the_explicit_form(omx, Tq, Tk, heads):
+    """omx_paraformer_attention_f32 against numpy's explicit form (paraformer.rs:509-516): scores = q k^T / sqrt(128), softmax over keys, scores v,
+    all float32.  q | k | v are read in place from one fused [T, 3 x heads x 128] projection when Tq == Tk (the encoder's layout), from separate
+    buffers otherwise; covers the kernel's three widths (<= 128, <= 256, <= 512 keys), ragged tails, the key split (215 x 501 and
+    128 x 400: four blocks per tile, 501 x 501: two -- the last to finish combines the shares) and the GEMM + softmax + GEMM path (600)."""
+    from ominix_mlx_amd import paraformer  # noqa: F401  (registers the entry point's ctypes signature)
+    T = omx.ops.Tensor
+    g = np.random.default_rng(Tq * 1000 + Tk)
+    D = heads * 128
+    if Tq == Tk:
+        qkv = g.standard_normal((Tq, 3 * D)).astype(np.float32)
+        q, k, v = qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:]
+        qkv_d = T.from_numpy(qkv, "f32")
+        qp, kp, vp, ldq, ldkv = qkv_d.ptr, qkv_d.ptr + 4 * D, qkv_d.ptr + 8 * D, 3 * D, 3 * D
+    else:
+        q = g.standard_normal((Tq, D)).astype(np.float32)
+        kv = g.standard_normal((Tk, 2 * D)).astype(np.float32)
+        k, v = kv[:, :D], kv[:, D:]
+        q_d, kv_d = T.from_numpy(q, "f32"), T.from_numpy(kv, "f32")
+        qp, kp, vp, ldq, ldkv = q_d.ptr, kv_d.ptr, kv_d.ptr + 4 * D, D, 2 * D
+    out = T((Tq, D), "f32")
+    omx.check(omx.lib.omx_paraformer_attention_f32(out.ptr, qp, kp, vp, ldq, ldkv, D, Tq, Tk, heads, None))
+    got = out.numpy()
+    ref = np.empty((Tq, D), np.float32)
+    for h in range(heads):
+        sl = slice(128 * h, 128 * h + 128)
+        sc = (q[:, sl].astype(np.float64) @ k[:, sl].astype(np.float64).T) / np.sqrt(128.0)
+        p = np.exp(sc - sc.max(axis=1, keepdims=True))
+        ref[:, sl] = (p / p.sum(axis=1, keepdims=True)) @ v[:, sl].astype(np.float64)
+    assert np.abs(got - ref).max() <= 2e-6 * max(1.0, np.abs(ref).max()) * np.sqrt(Tk)
+
+
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
 @pytest.mark.parametrize("stacked_kv", [True, False])
 @pytest.mark.parametrize("N,Ts", [(23, 120), (140, 501)])

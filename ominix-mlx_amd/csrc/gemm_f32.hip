@@ -397,24 +397,53 @@ __global__ __launch_bounds__(256) void gemm_f32_pipe_kernel(const F32Args g) {
 #undef OMX_PIPE_MULTIPLY
 #undef OMX_PIPE_INTERLEAVE
 #undef OMX_PIPE_BOUNDARY
+    // The tile goes out through LDS (over the first staging buffer: every fragment read is behind the last boundary): a lane of the MFMA result
+    // holds one column of four rows, so storing from the accumulators writes 64-byte pieces of sixteen different rows per instruction; from
+    // LDS a wave stores four whole 256-byte rows per instruction, and bias / residual are read 16 bytes at a time.
     // D of the 16 x 16 form: col = lane & 15, row = 4 (lane >> 4) + reg
+    float* C = pipe_lds;                                        // [64][P_LD]
 #pragma unroll
     for (int f = 0; f < 4; ++f) {
         const f32x4 acc = f == 0 ? acc00 : f == 1 ? acc01 : f == 2 ? acc10 : acc11;
-        const int col = n0 + wn * 32 + 16 * (f & 1) + n;
-        if (col >= g.N) continue;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = m0 + wm * 32 + 16 * (f >> 1) + 4 * q + r;
-            if (row >= g.M) continue;
-            if (g.splits > 1) {
-                g.partial[(((int64_t)bz * g.splits + split) * g.M + row) * g.N + col] = acc[r];
-            } else {
-                float v = acc[r] * g.alpha;
-                if (g.bias) v += g.bias[col];
-                if (g.relu) v = fmaxf(v, 0.f);
-                if (g.resid) v += g.resid[(int64_t)row * g.ldr + col];
-                g.out[(int64_t)bz * g.sc + (int64_t)row * g.ldc + col] = v;
+        for (int r = 0; r < 4; ++r) C[(wm * 32 + 16 * (f >> 1) + 4 * q + r) * P_LD + wn * 32 + 16 * (f & 1) + n] = acc[r];
+    }
+    __syncthreads();
+    const bool vec = (g.N & 3) == 0 && (g.splits > 1 ? (reinterpret_cast<uintptr_t>(g.partial) & 15u) == 0
+                                                     : (g.ldc & 3) == 0 && (g.sc & 3) == 0 && (!g.resid || (g.ldr & 3) == 0) &&
+                                                           ((reinterpret_cast<uintptr_t>(g.bias) | reinterpret_cast<uintptr_t>(g.resid)) & 15u) == 0);
+    const int col = n0 + kq;                                    // this thread's four columns, rows rq + 16 i
+    if (col >= g.N) return;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = m0 + rq + 16 * i;
+        if (row >= g.M) continue;
+        f32x4 v = *reinterpret_cast<const f32x4*>(C + (rq + 16 * i) * P_LD + kq);
+        if (g.splits > 1) {
+            float* dst = g.partial + (((int64_t)bz * g.splits + split) * g.M + row) * g.N + col;
+            if (vec) *reinterpret_cast<f32x4*>(dst) = v;
+            else
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (col + e < g.N) dst[e] = v[e];
+            continue;
+        }
+        float* dst = g.out + (int64_t)bz * g.sc + (int64_t)row * g.ldc + col;
+        if (vec && ((reinterpret_cast<uintptr_t>(dst) & 15u) == 0)) {
+            v *= g.alpha;
+            if (g.bias) v += *reinterpret_cast<const f32x4*>(g.bias + col);
+            if (g.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+            if (g.resid) v += *reinterpret_cast<const f32x4*>(g.resid + (int64_t)row * g.ldr + col);
+            *reinterpret_cast<f32x4*>(dst) = v;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (col + e >= g.N) break;
+                float x = v[e] * g.alpha;
+                if (g.bias) x += g.bias[col + e];
+                if (g.relu) x = fmaxf(x, 0.f);
+                if (g.resid) x += g.resid[(int64_t)row * g.ldr + col + e];
+                dst[e] = x;
             }
         }
     }

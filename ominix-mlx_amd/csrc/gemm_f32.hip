@@ -271,6 +271,7 @@ __global__ __launch_bounds__(256) void gemm_f32_small_kernel(const F32Args g) {
 constexpr int PK = 64, P_LD = PK + 4, PR = 3;                   // rows of 68 floats: 16-byte aligned
 constexpr size_t P_LDS_BYTES = (size_t)2 * 2 * 64 * P_LD * sizeof(float);
 
+template <bool FULLK>
 __global__ __launch_bounds__(256) void gemm_f32_pipe_kernel(const F32Args g) {
     extern __shared__ __attribute__((aligned(16))) float pipe_lds[];
     float* As = pipe_lds;                                       // [2][64][P_LD]
@@ -284,34 +285,41 @@ __global__ __launch_bounds__(256) void gemm_f32_pipe_kernel(const F32Args g) {
     const int nt = kbeg < kend ? (kend - kbeg + PK - 1) / PK : 0;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     f32x4 acc00 = zero4, acc01 = zero4, acc10 = zero4, acc11 = zero4;
-    // staging: thread (rq, kq) covers rows rq + 16 i of both operands' tiles, k quad kq
+    // staging: thread (rq, kq) covers rows rq + 16 i of both operands' tiles, k quad kq.  Buffer loads: the per-thread part of the address is
+    // eight 32-bit offsets computed once, the tile's k offset is a scalar, and a row past the end of the matrix is out of the descriptor's
+    // range and reads as zero -- no address arithmetic and no clamping per tile.  FULLK (K a multiple of the tile): no k tail either; otherwise
+    // a k quad past the end re-reads the last quad and a select zeroes it at the LDS write.
     const int rq = threadIdx.x >> 4, kq = (threadIdx.x & 15) * 4;
-    const float* A = g.a + (int64_t)bz * g.sa;
-    const float* B = g.b + (int64_t)bz * g.sb;
-    const float* ap[4];
-    const float* bp[4];
+    using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+    const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.a + (int64_t)bz * g.sa), 0,
+                                                                            (int)((((int64_t)g.M - 1) * g.lda + g.K) * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.b + (int64_t)bz * g.sb), 0,
+                                                                            (int)((((int64_t)g.N - 1) * g.ldb + g.K) * 4), 0x00020000);
+    int ao[4], bo[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        ap[i] = A + (int64_t)min(m0 + rq + 16 * i, g.M - 1) * g.lda;
-        bp[i] = B + (int64_t)min(n0 + rq + 16 * i, g.N - 1) * g.ldb;
+        ao[i] = (int)(((int64_t)(m0 + rq + 16 * i) * g.lda + kq) * 4);
+        bo[i] = (int)(((int64_t)(n0 + rq + 16 * i) * g.ldb + kq) * 4);
     }
-    f32x4 ra[PR][4], rb[PR][4];
+    u32x4 ra[PR][4], rb[PR][4];
     f32x4 fa[2][4][2], fb[2][4][2];                             // [register set][k step][fragment row block]
 #define OMX_PIPE_REQUEST(slot, tile)                                                                   \
     {                                                                                                  \
-        const int kc_ = min(kbeg + min((tile), nt - 1) * PK + kq, kend - 4);                           \
+        const int k0_ = kbeg + min((tile), nt - 1) * PK;                                               \
+        const int back_ = FULLK ? 0 : 4 * max(k0_ + kq + 4 - kend, 0);      /* bytes to step back onto the last whole quad */ \
         _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                \
-            ra[slot][i] = *reinterpret_cast<const f32x4*>(ap[i] + kc_);                                \
-            rb[slot][i] = *reinterpret_cast<const f32x4*>(bp[i] + kc_);                                \
+            ra[slot][i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, ao[i] - back_, 4 * k0_, 0)); \
+            rb[slot][i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(b_rsrc, bo[i] - back_, 4 * k0_, 0)); \
         }                                                                                              \
     }
 // (the zeroing select sits at the first USE of the registers, so that the requests stay in flight across the tiles in between)
 #define OMX_PIPE_STAGE(slot, tile, buf)                                                                \
     {                                                                                                  \
-        const bool in_ = kbeg + min((tile), nt - 1) * PK + kq < kend;                                  \
+        const bool in_ = FULLK || kbeg + min((tile), nt - 1) * PK + kq < kend;                         \
+        const u32x4 zero_ = {0u, 0u, 0u, 0u};                                                          \
         _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                \
-            *reinterpret_cast<f32x4*>(As + (buf) * 64 * P_LD + (rq + 16 * i) * P_LD + kq) = in_ ? ra[slot][i] : zero4; \
-            *reinterpret_cast<f32x4*>(Bs + (buf) * 64 * P_LD + (rq + 16 * i) * P_LD + kq) = in_ ? rb[slot][i] : zero4; \
+            *reinterpret_cast<u32x4*>(As + (buf) * 64 * P_LD + (rq + 16 * i) * P_LD + kq) = in_ ? ra[slot][i] : zero_; \
+            *reinterpret_cast<u32x4*>(Bs + (buf) * 64 * P_LD + (rq + 16 * i) * P_LD + kq) = in_ ? rb[slot][i] : zero_; \
         }                                                                                              \
     }
 #define OMX_PIPE_FRAGMENTS(set, buf)                                                                   \
@@ -487,10 +495,12 @@ int launch_gemm_f32(const GemmF32& p, hipStream_t s) {
     // (round 6) the one-barrier kernel takes every NT product; OMX_F32_PIPE=0 keeps the older staged kernels (A/B, tests)
     static const int pipe_mode = [] { const char* e = getenv("OMX_F32_PIPE"); return e ? atoi(e) : 1; }();
     auto al16 = [](const void* x) { return (reinterpret_cast<uintptr_t>(x) & 15u) == 0; };
-    if (pipe_mode && !p.b_nn && p.K % 4 == 0 && p.lda % 4 == 0 && p.ldb % 4 == 0 && p.sa % 4 == 0 && p.sb % 4 == 0 && al16(p.a) && al16(p.b)) {
+    const bool small_enough = (int64_t)p.M * p.lda < (1ll << 28) && (int64_t)p.N * p.ldb < (1ll << 28);     // 32-bit byte offsets in the buffer loads
+    if (pipe_mode && small_enough && !p.b_nn && p.K % 4 == 0 && p.lda % 4 == 0 && p.ldb % 4 == 0 && p.sa % 4 == 0 && p.sb % 4 == 0 && al16(p.a) && al16(p.b)) {
         static const int pbudget = [] { const char* e = getenv("OMX_F32_PIPE_BUDGET"); return e ? atoi(e) : 256; }();
         static const bool lds_ok = [] {
-            return hipFuncSetAttribute((const void*)gemm_f32_pipe_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P_LDS_BYTES) == hipSuccess;
+            return hipFuncSetAttribute((const void*)gemm_f32_pipe_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P_LDS_BYTES) == hipSuccess &&
+                   hipFuncSetAttribute((const void*)gemm_f32_pipe_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P_LDS_BYTES) == hipSuccess;
         }();
         OMX_REQUIRE(lds_ok, "gemm_f32: the device refused %zu bytes of LDS per block", P_LDS_BYTES);
         const int px = (p.N + 63) / 64, py = (p.M + 63) / 64, ptiles = px * py * p.batch, pk = (p.K + PK - 1) / PK;
@@ -502,7 +512,8 @@ int launch_gemm_f32(const GemmF32& p, hipStream_t s) {
             if (get_workspace_aux(&ws, (size_t)p.batch * splits * p.M * p.N * sizeof(float), s)) return 1;
             g.partial = (float*)ws;
         }
-        gemm_f32_pipe_kernel<<<dim3(px, py, p.batch * splits), 256, P_LDS_BYTES, s>>>(g);
+        if (p.K % PK == 0) gemm_f32_pipe_kernel<true><<<dim3(px, py, p.batch * splits), 256, P_LDS_BYTES, s>>>(g);
+        else gemm_f32_pipe_kernel<false><<<dim3(px, py, p.batch * splits), 256, P_LDS_BYTES, s>>>(g);
         OMX_LAUNCH_CHECK();
         if (defer) {
             *p.defer_partial = splits > 1 ? g.partial : p.out;

@@ -20,13 +20,14 @@ timeout -k 5 900 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY
 f=$(find "$out/mfma" -name '*counter_collection.csv' | head -1)
 [ -n "$f" ] && python3 tools/pmc_report.py trim "$f" "$out/keep/r06_pmc_mfma_busy.csv" gemm_bf16 attn_prefill flash dit_ gemm_
 rm -rf "$out/fetch" "$out/fetchq" "$out/mfma"
-for w in q4 route route_q4 flux prefill; do
+for w in q4 route route_q4 flux prefill paraformer; do
   case $w in
     q4) cmd="tools/quant_decode.py 4 2048";;
     route) cmd="tools/per_op_route_time.py 2048 64 0";;
     route_q4) cmd="tools/per_op_route_time.py 2048 64 4";;
     flux) cmd="tools/flux_bench.py";;
     prefill) cmd="tools/prefill_bench.py 2048";;
+    paraformer) cmd="tools/paraformer_bench.py";;
   esac
   timeout -k 5 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/$w" -o s -- python3 $cmd > "$out/$w.log" 2>&1
   f=$(find "$out/$w" -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp "$f" "$out/keep/r06_${w}_kernel_stats.csv" && head -4 "$f" | cut -c1-160

@@ -469,11 +469,13 @@ def test_sdpa_stream_k_kernel(omx, monkeypatch, B, H, Hkv, Tq, Tk, D):
 
 
 @pytest.mark.parametrize("M,N,K,bias", [(501, 512, 560, True), (501, 2048, 512, True), (501, 512, 2048, True), (216, 8404, 512, True),
-                                         (33, 70, 45, False), (1, 64, 64, False), (130, 66, 1026, True)])
+                                         (33, 70, 45, False), (1, 64, 64, False), (130, 66, 1026, True), (65, 70, 128, True),
+                                         (40, 130, 200, True), (64, 64, 4, False)])
 def test_linear_f32_on_the_f32_matrix_cores(omx, M, N, K, bias):
-    """omx_linear(dtype = f32) -> gemm_f32.hip (v_mfma_f32_32x32x2_f32, exact f32 products and accumulation; split-K partials
+    """omx_linear(dtype = f32) -> gemm_f32.hip (f32-input matrix cores: exact f32 products and accumulation; split-K partials
     summed in split order): the Paraformer path's arithmetic (funasr-mlx/src/paraformer.rs is f32 throughout).  Against float64:
-    f32-roundoff class, <= 1e-6 * sum|a b| per output (MI355X_MICROARCH: 0.75-3.5e-7 measured)."""
+    f32-roundoff class, <= 1e-6 * sum|a b| per output (MI355X_MICROARCH: 0.75-3.5e-7 measured).  K % 4 == 0 goes to the pipelined
+    64 x 64 kernel (K % 64 != 0: its k-tail form; N % 4 != 0: its element-wise epilogue), everything else to the staged kernels."""
     T = omx.ops.Tensor
     g = np.random.default_rng(M * 7 + N)
     x = g.standard_normal((M, K)).astype(np.float32)

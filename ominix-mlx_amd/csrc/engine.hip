@@ -1183,8 +1183,6 @@ int prefill_prefix_batched(omx_qwen3 m, int T, int off, const EncodeOpts* enc = 
     //  0 * -inf = NaN on every kept key, flux-klein-mlx/src/qwen3_encoder.rs:196-198 -- there is no finite result to reproduce.)
     OMX_REQUIRE(!f16 || !(enc && enc->mask), "float16 encoder with an attention_mask: the reference's additive mask is 0 * f16(-1e9) = NaN in "
                 "float16 (qwen3_encoder.rs:196-198); pass no mask (causal) or load the bfloat16 checkpoint");
-    OMX_REQUIRE(!f16 || (c.ep_size <= 1 && (c.num_experts == 0 || m->allreduce == nullptr)),
-                "batched prompt pass in float16: dense models on one rank or tensor parallel, sparse-MoE models on one rank");
     struct GemmF16Scope { bool on, was = false; explicit GemmF16Scope(bool o) : on(o) { if (on) was = gemm_set_f16(true); } ~GemmF16Scope() { if (on) gemm_set_f16(was); } } f16_scope(f16);
     const omx_dtype act_dt = f16 ? OMX_FLOAT16 : OMX_BFLOAT16;
     hipStream_t s = m->stream;
@@ -1351,11 +1349,11 @@ int prefill_prefix_batched(omx_qwen3 m, int T, int off, const EncodeOpts* enc = 
                                                Q.moe_router.biases, Q.moe_g.w, Q.moe_g.scales, Q.moe_g.biases, Q.moe_u.w, Q.moe_u.scales,
                                                Q.moe_u.biases, Q.moe_d.w, Q.moe_d.scales, Q.moe_d.biases, T, hd, etp ? m->moe_I : c.moe_intermediate_size,
                                                c.num_experts, c.num_experts_per_tok, c.moe_mode, c.norm_topk_prob, etp ? 0 : c.ep_rank * el, el,
-                                               c.quant_group, c.quant_bits, 0, s))
+                                               c.quant_group, c.quant_bits, f16 ? 1 : 0, s))
                     return 1;
                 OMX_REQUIRE(m->allreduce != nullptr, "ep_size / tp_size > 1 but no communicator set (omx_qwen3_set_comm)");
                 OMX_REQUIRE(m->allreduce(m->pf_ep_partial, m->pf_ep_partial, (size_t)T * hd, kNcclFloat32, kNcclSum, m->comm, s) == 0, "ncclAllReduce failed");
-                ep_fold_kernel<<<1024, 256, 0, s>>>(h, h2, m->pf_ep_partial, (int64_t)T * hd);
+                ep_fold_kernel<<<1024, 256, 0, s>>>(h, h2, m->pf_ep_partial, (int64_t)T * hd, f16);
                 OMX_LAUNCH_CHECK();
             } else if (quant) {
                 if (omx_moe_block_forward_q_ex(h, h2, h2, L.post_ln, c.rms_norm_eps, m->pf_xn, Q.moe_router.w, Q.moe_router.scales,
@@ -1947,10 +1945,9 @@ int omx_qwen3_prefill(omx_qwen3 m, const uint32_t* prompt, int n_prompt, uint32_
     const char* serial_env = getenv("OMX_PREFILL_SERIAL");
     // tensor-parallel engines run the batched matrix-core prefill on their shards with two all-reduces per layer, expert-parallel ones
     // with one all-reduce of the MoE block's [T, hidden] partial per layer (round 3; token-serial before)
-    // (float16 models: the batched pass exists for plain prompts -- dense models on one rank or tensor parallel, sparse-MoE models on
-    //  one rank; short prompts go through the decode step)
-    const bool f16_sharded_moe = m->cfg.num_experts > 0 && (m->cfg.ep_size > 1 || m->cfg.tp_size > 1);   // (no float16 batched form of the sharded MoE block)
-    const bool f16_serial = m->cfg.quant_scales_f16 && (n_prompt <= 16 || f16_sharded_moe);
+    // (float16 models: the batched pass exists for plain prompts -- dense and sparse-MoE models, on one rank or sharded (round 6: the
+    //  float16 form of the sharded MoE block); short prompts go through the decode step)
+    const bool f16_serial = m->cfg.quant_scales_f16 && n_prompt <= 16;
     const bool serial = (serial_env && serial_env[0] == '1') || n_prompt < 2 || f16_serial;
     if (prepare_step(m, serial ? off : off + n_prompt - 1)) return 1;   // the first step this call will run (graphs are per context bucket)
     if (!serial && m->cfg.quant_bits) dq_cache_prepare(m);             // (a once-per-model allocation: ahead of the timed region)

@@ -849,7 +849,7 @@ struct DqScratch {      // dequantised router + expert stacks of one call, freed
 };
 int dequant_stacks(DqScratch& q, const void* q_router, const void* s_router, const void* b_router, const void* q_gate, const void* s_gate,
                    const void* b_gate, const void* q_up, const void* s_up, const void* b_up, const void* q_down, const void* s_down,
-                   const void* b_down, int hidden, int inter, int n_experts, int e_n, int group_size, int bits) {
+                   const void* b_down, int hidden, int inter, int n_experts, int e_n, int group_size, int bits, omx_dtype dt = OMX_BFLOAT16) {
     using namespace omx;
     const size_t per = (size_t)e_n * inter * hidden;
     // the stream-ordered pool hands freed blocks back to the system at the next synchronisation unless told to keep them (release threshold 0 by
@@ -868,10 +868,10 @@ int dequant_stacks(DqScratch& q, const void* q_router, const void* s_router, con
     OMX_HIP_CHECK(hipMallocAsync((void**)&q.g, per * 2, q.s));
     OMX_HIP_CHECK(hipMallocAsync((void**)&q.u, per * 2, q.s));
     OMX_HIP_CHECK(hipMallocAsync((void**)&q.d, per * 2, q.s));
-    return omx_dequantize(q.router, q_router, s_router, b_router, n_experts, hidden, group_size, bits, OMX_BFLOAT16, q.s) ||
-           omx_dequantize(q.g, q_gate, s_gate, b_gate, (int64_t)e_n * inter, hidden, group_size, bits, OMX_BFLOAT16, q.s) ||
-           omx_dequantize(q.u, q_up, s_up, b_up, (int64_t)e_n * inter, hidden, group_size, bits, OMX_BFLOAT16, q.s) ||
-           omx_dequantize(q.d, q_down, s_down, b_down, (int64_t)e_n * hidden, inter, group_size, bits, OMX_BFLOAT16, q.s);
+    return omx_dequantize(q.router, q_router, s_router, b_router, n_experts, hidden, group_size, bits, dt, q.s) ||
+           omx_dequantize(q.g, q_gate, s_gate, b_gate, (int64_t)e_n * inter, hidden, group_size, bits, dt, q.s) ||
+           omx_dequantize(q.u, q_up, s_up, b_up, (int64_t)e_n * inter, hidden, group_size, bits, dt, q.s) ||
+           omx_dequantize(q.d, q_down, s_down, b_down, (int64_t)e_n * hidden, inter, group_size, bits, dt, q.s);
 }
 // router of the packed block: logits by the packed GEMV (RMSNorm prologue when norm_w), then the selection
 int route_packed(const void* x, const void* norm_w, float eps, const void* q_router, const void* s_router, const void* b_router, int n_tokens,
@@ -908,8 +908,59 @@ extern "C" int omx_moe_block_partial_ep_q(float* partial, const void* x, const v
     const int slots = n_tokens * top_k;
     OMX_REQUIRE(slots >= 1, "omx_moe_block_partial_ep_q: no tokens");
     hipStream_t s = (hipStream_t)stream;
+    if (slots > 32 && f16) {
+        // a float16 checkpoint's prompt on a shard (round 6; token-serial before): the router exactly as the decode form computes it (packed
+        // GEMV per token with the RMSNorm prologue, so a prompt routes like its tokens would one by one), this rank's stacks dequantised to
+        // float16, the slots of its experts through the grouped 256-row GEMMs' float16 instantiation (everything routed elsewhere lands in a
+        // trailing pseudo-expert without tiles), the f32 partial of every token's weighted sum with the float16 roundings of the decode form
+        OMX_REQUIRE(norm_w && xn, "omx_moe_block_partial_ep_q: the float16 prompt form normalises its rows here (norm_w, xn)");
+        size_t need = 0;
+        omx_moe_workspace_bytes(n_tokens, hidden, inter, n_experts, top_k, &need);
+        need += (size_t)n_tokens * n_experts * 2 + 1024;
+        void* ws = nullptr;
+        if (get_workspace_aux(&ws, need, s)) return 1;
+        char* p = (char*)ws;
+        auto take = [&](size_t bytes) { char* r = p; p += (bytes + 255) & ~(size_t)255; return r; };
+        uint32_t* inds = (uint32_t*)take((size_t)slots * 4);
+        uint32_t* row_src = (uint32_t*)take((size_t)slots * 4);
+        uint32_t* pos_of_slot = (uint32_t*)take((size_t)slots * 4);
+        bf16_t* scores = (bf16_t*)take((size_t)slots * 2);
+        int* seg_start = (int*)take((size_t)(n_experts + 2) * 4);
+        const int max_tiles = slots / 128 + n_experts + 1;
+        int* tile_expert = (int*)take((size_t)max_tiles * 4);
+        int* tile_m0 = (int*)take((size_t)max_tiles * 4);
+        int* n_tiles = (int*)take(256);
+        bf16_t* gbuf = (bf16_t*)take((size_t)slots * inter * 2);
+        (void)take((size_t)slots * inter * 2);                          // (the `ubuf` slot of the layout: the GLU epilogue leaves it unused)
+        bf16_t* ybuf = (bf16_t*)take((size_t)slots * hidden * 2);
+        bf16_t* logits = (bf16_t*)take((size_t)n_tokens * n_experts * 2);
+        if (route_packed(x, norm_w, eps, q_router, s_router, b_router, n_tokens, hidden, n_experts, top_k, mode, norm_topk_prob, group_size, bits,
+                         logits, inds, scores, s, true))
+            return 1;
+        if (omx_rms_norm(xn, x, norm_w, n_tokens, hidden, eps, OMX_FLOAT16, stream)) return 1;
+        DqScratch dq(s);
+        if (dequant_stacks(dq, q_router, s_router, b_router, q_gate, s_gate, b_gate, q_up, s_up, b_up, q_down, s_down, b_down, hidden, inter, n_experts,
+                           e_n, group_size, bits, OMX_FLOAT16))
+            return 1;
+        uint32_t* local_inds = nullptr;
+        OMX_HIP_CHECK(hipMallocAsync((void**)&local_inds, (size_t)slots * 4, s));
+        moe_localize_kernel<<<(slots + 255) / 256, 256, 0, s>>>(local_inds, inds, slots, e_lo, e_n);
+        OMX_LAUNCH_CHECK();
+        moe_plan_kernel<<<1, 1024, 0, s>>>(local_inds, slots, e_n + 1, top_k, seg_start, row_src, pos_of_slot, tile_expert, tile_m0, n_tiles, 256, e_n);
+        OMX_LAUNCH_CHECK();
+        (void)hipFreeAsync(local_inds, s);
+        GroupedDesc g;
+        g.tile_expert = tile_expert; g.tile_m0 = tile_m0; g.seg_start = seg_start; g.n_tiles = n_tiles;
+        g.row_src = row_src; g.w_estride = (size_t)inter * hidden;
+        const bool was_f16 = gemm_set_f16(true);    // (the engine's prompt pass has it on already: restore, do not clear)
+        const int rc = grouped_glu_256(ybuf, gbuf, (const bf16_t*)xn, dq.g, dq.u, dq.d, slots, hidden, inter, n_experts, g, s);
+        gemm_set_f16(was_f16);
+        if (rc) return 1;
+        moe_combine_partial_kernel<true><<<n_tokens, 256, 0, s>>>(partial, ybuf, scores, inds, hidden, top_k, e_lo, e_n, pos_of_slot);
+        OMX_LAUNCH_CHECK();
+        return 0;
+    }
     if (slots > 32) {
-        OMX_REQUIRE(!f16, "omx_moe_block_partial_ep_q: a float16 checkpoint's prompt runs through the decode form under expert parallelism");
         // a prompt: normalised rows (the caller's, or made here), the rank's stacks and the router dequantised, the bf16 batched form
         const void* rows = x;
         if (norm_w) {

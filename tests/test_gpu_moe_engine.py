@@ -212,14 +212,15 @@ def test_float16_packed_moe_checkpoint_on_several_ranks(omx, monkeypatch, mode, 
     rank, in float16 end to end like on one: expert parallel (the rank's experts' packed GEMVs with the expert filter, float16 products
     summed in f32, one all-reduce, the fold with the float16 roundings: bit-identical to the single-GPU float16 engine) and expert
     tensor parallel (every expert's column slice, f32 slot partials all-reduced, omx_moe_combine_slots_ex in float16: ranks agree bit for
-    bit, logits within the float16 bound of the single GPU).  Prompts of a sharded float16 MoE model go through the decode step."""
+    bit, logits within the float16 bound of the single GPU).  The prompt goes through the decode step here (OMX_PREFILL_SERIAL=1); its batched form
+    has its own test below."""
     from ominix_mlx_amd import comm, engine
     cfg = WIDE if name == "wide" else CONFIGS[name]
     bits, group_size = 4, 64
     qw = _f16_triplets(cfg, bits, group_size)
     quantization = {"bits": bits, "group_size": group_size, "scales_dtype": "float16"}
     prompt = synth.prompt_ids(20, cfg.vocab_size)
-    monkeypatch.setenv("OMX_PREFILL_SERIAL", "1")      # the sharded float16 engines prefill token-serially: compare like with like
+    monkeypatch.setenv("OMX_PREFILL_SERIAL", "1")      # token-serial prompts on both sides: compare like with like
     single = _engine(omx, cfg, qw, quantization=quantization)
     want = np.concatenate([[single.prefill(prompt)], single.decode(6)]).astype(np.uint32)
     want_logits = single.last_logits()
@@ -260,6 +261,76 @@ def test_float16_packed_moe_checkpoint_on_several_ranks(omx, monkeypatch, mode, 
     assert first_diff >= 1, "the sharded float16 engines disagree with the single-GPU engine on the token after the prompt"
     if first_diff == len(want):
         assert float(np.abs(logits - want_logits).max()) <= bound, f"float16 expert-TP logits off by {np.abs(logits - want_logits).max():.5f} (bound {bound:.5f})"
+
+
+@pytest.mark.parametrize("mode,name,world", [("ep", "mixtral", 2), ("ep", "qwen3_moe", 4), ("tp", "mixtral", 2), ("tp", "wide", 4)])
+def test_float16_packed_moe_prompt_is_one_batched_pass_on_several_ranks(omx, monkeypatch, mode, name, world):
+    """Round 6: a sharded float16 MoE model's PROMPT as one batched pass (token by token before) -- the router per
+    token exactly as the decode form computes it, the rank's stacks dequantised to float16, its slots through the grouped GEMMs' float16
+    instantiation, the f32 partial all-reduced once per layer and folded with the float16 roundings.  Expert parallel: the same values as the
+    single-GPU float16 engine's batched pass (a slot's row does not depend on which other rows share its tile); expert tensor parallel:
+    ranks agree bit for bit, logits within the float16 bound of the single GPU.  And the batched pass agrees with the token-serial one of
+    the same shards within that bound."""
+    from ominix_mlx_amd import comm, engine
+    cfg = WIDE if name == "wide" else CONFIGS[name]
+    bits, group_size = 4, 64
+    qw = _f16_triplets(cfg, bits, group_size)
+    quantization = {"bits": bits, "group_size": group_size, "scales_dtype": "float16"}
+    prompt = synth.prompt_ids(40, cfg.vocab_size)          # 80 routed slots: the batched form (> 32), and > 16 tokens
+    monkeypatch.setenv("OMX_PREFILL_SERIAL", "0")
+    single = _engine(omx, cfg, qw, quantization=quantization)
+    want = np.concatenate([[single.prefill(prompt)], single.decode(4)]).astype(np.uint32)
+    want_logits = single.last_logits()
+    single.close()
+
+    def sharded(serial):
+        monkeypatch.setenv("OMX_PREFILL_SERIAL", serial)
+        group = comm.LoopbackGroup(world, 1 << 22)
+        models = []
+        for r in range(world):
+            shard = dict(ep_rank=r, ep_size=world) if mode == "ep" else dict(tp_rank=r, tp_size=world)
+            m = engine.Model(hidden_size=cfg.hidden_size, num_hidden_layers=cfg.num_hidden_layers, intermediate_size=cfg.intermediate_size,
+                             num_attention_heads=cfg.num_attention_heads, num_key_value_heads=cfg.num_key_value_heads, head_dim=cfg.head_dim,
+                             vocab_size=cfg.vocab_size, rms_norm_eps=cfg.rms_norm_eps, rope_theta=cfg.rope_theta,
+                             tie_word_embeddings=cfg.tie_word_embeddings, max_context=256, num_experts=cfg.num_experts,
+                             num_experts_per_tok=cfg.num_experts_per_tok, moe_intermediate_size=cfg.moe_intermediate_size,
+                             moe_mode=cfg.moe_mode, norm_topk_prob=cfg.norm_topk_prob, qk_norm=cfg.qk_norm, quantization=quantization, **shard)
+            m.load_weights(qw)
+            m.set_comm(group.rank_comm(r), group.allreduce_fn)
+            models.append(m)
+
+        def run(r):
+            m = models[r]
+            toks = np.concatenate([[m.prefill(prompt)], m.decode(4)]).astype(np.uint32)
+            return toks, m.last_logits()
+
+        outs = comm.run_ranks(world, run, group)
+        for m in models:
+            m.close()
+        group.close()
+        return outs
+
+    outs = sharded("0")
+    bound = 2.0 ** -10 * float(np.abs(want_logits).max()) * np.sqrt(2 * cfg.num_hidden_layers) * 2
+    for r in range(1, world):
+        np.testing.assert_array_equal(outs[r][0], outs[0][0])
+    if mode == "ep":
+        for r in range(world):
+            np.testing.assert_array_equal(outs[r][0], want)
+            np.testing.assert_array_equal(outs[r][1], want_logits)
+        logits = outs[0][1]
+    else:
+        logits = np.concatenate([o[1] for o in outs])       # vocabulary shards
+        first_diff = next((i for i in range(len(want)) if outs[0][0][i] != want[i]), len(want))
+        assert first_diff >= 1, "the sharded float16 engines' batched prompt disagrees with the single-GPU engine on the token after the prompt"
+        if first_diff == len(want):
+            assert float(np.abs(logits - want_logits).max()) <= bound
+    serial = sharded("1")
+    s_logits = serial[0][1] if mode == "ep" else np.concatenate([o[1] for o in serial])
+    if np.array_equal(serial[0][0], outs[0][0]):
+        assert float(np.abs(logits - s_logits).max()) <= bound, f"batched vs token-serial float16 prompt: {np.abs(logits - s_logits).max():.5f} (bound {bound:.5f})"
+    else:
+        assert serial[0][0][0] == outs[0][0][0]            # (a later near-tie may flip; the token after the prompt does not)
 
 
 @pytest.mark.parametrize("name,world,quant", [("qwen3_moe", 2, None), ("mixtral", 4, None), ("qwen3_moe_no_renorm_top4", 4, None),

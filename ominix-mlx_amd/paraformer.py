@@ -155,6 +155,9 @@ class Paraformer:
                 dev(f"{p}.norm3.weight"), dev(f"{p}.norm3.bias"), dev(f"{p}.src_attn.q_proj.weight"), dev(f"{p}.src_attn.q_proj.bias"),
                 kv_w.ptr + i * kv_rows * kv_w.shape[1] * esz, kv_b.ptr + i * kv_rows * esz, dev(f"{p}.src_attn.out_proj.weight"),
                 dev(f"{p}.src_attn.out_proj.bias")))
+        # the layer tables the two stack entry points take, built once
+        self._enc_arr = (SanmLayerWeights * len(self.enc_layers))(*self.enc_layers)
+        self._dec_arr = (DecoderLayerWeights * len(self.dec_layers))(*self.dec_layers)
         t = "decoder.decoders3.0"
         self.tail = TailWeights(dev(f"{t}.norm1.weight"), dev(f"{t}.norm1.bias"), dev(f"{t}.ffn.up_proj.weight"), dev(f"{t}.ffn.up_proj.bias"),
                                 dev(f"{t}.feed_forward.norm.weight"), dev(f"{t}.feed_forward.norm.bias"), dev(f"{t}.ffn.down_proj.weight"),
@@ -184,8 +187,7 @@ class Paraformer:
         act = [self._scratch("enc_act0", (T, D), dt), self._scratch("enc_act1", (T, D), dt)]
         nrm = [self._scratch("enc_nrm0", (T, max(in0, D)), dt), self._scratch("enc_nrm1", (T, max(in0, D)), dt)]
         out = Tensor((T, D), dt)
-        n = len(self.enc_layers)
-        arr = (SanmLayerWeights * n)(*self.enc_layers)
+        n, arr = len(self.enc_layers), self._enc_arr
         check(lib.omx_sanm_encoder_stack(out.ptr, h.ptr, arr, n, T, in0, D, c["encoder_heads"], c["encoder_ffn_dim"], c["sanm_kernel_size"],
                                          self.after_norm[0], self.after_norm[1], act[0].ptr, act[1].ptr, nrm[0].ptr, nrm[1].ptr, out.dtype, None))
         return out
@@ -215,7 +217,7 @@ class Paraformer:
         nrm = [self._scratch("dec_nrm0", (N, D), dt), self._scratch("dec_nrm1", (N, D), dt)]
         kv_all = self._scratch("dec_kv", (Ts, n * 2 * D), dt)
         x_out = self._scratch("dec_out", (N, D), dt)
-        arr = (DecoderLayerWeights * n)(*self.dec_layers)
+        arr = self._dec_arr
         check(lib.omx_paraformer_decoder_stack(x_out.ptr, x.ptr, enc.ptr, arr, n, N, Ts, D, c["encoder_dim"], c["decoder_heads"],
                                                c["decoder_ffn_dim"], c["sanm_kernel_size"], act[0].ptr, act[1].ptr, nrm[0].ptr, nrm[1].ptr,
                                                kv_all.ptr, x_out.dtype, None))

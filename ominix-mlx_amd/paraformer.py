@@ -167,14 +167,14 @@ class Paraformer:
     def _scratch(self, name: str, shape, dt) -> Tensor:
         """A scratch buffer the model keeps between calls (hipMalloc / hipFree per call cost more than the launches they served, and hipFree
         waits for the device); calls are ordered on one stream, so the next call's launches queue behind the last reader."""
-        need = int(np.prod(shape, dtype=np.int64)) * (4 if dt == "f32" else 2)
+        need = int(np.prod(shape, dtype=np.int64)) * (4 if dt in ("f32", "u32") else 2)
         buf = self._scratch_bufs.get(name)
         if buf is None or buf.nbytes < need:                      # grows to the largest request seen, one buffer per role
             buf = self._scratch_bufs[name] = Tensor((need,), "u8")
         return Tensor(shape, dt, ptr=buf.ptr, owner=buf)
 
-    def encode(self, mel: Tensor) -> Tensor:
-        """SanmEncoder::forward (:691-708): mel f32 [T, n_mels*lfr_m] (device) -> encoder_out [T, encoder_dim]."""
+    def encode(self, mel: Tensor, out: Tensor = None) -> Tensor:
+        """SanmEncoder::forward (:691-708): mel f32 [T, n_mels*lfr_m] (device) -> encoder_out [T, encoder_dim] (into `out` when given)."""
         from .ops import layer_norm
         c = self.cfg
         T, in0 = mel.shape[-2], c["n_mels"] * c["lfr_m"]
@@ -186,26 +186,28 @@ class Paraformer:
         D = c["encoder_dim"]
         act = [self._scratch("enc_act0", (T, D), dt), self._scratch("enc_act1", (T, D), dt)]
         nrm = [self._scratch("enc_nrm0", (T, max(in0, D)), dt), self._scratch("enc_nrm1", (T, max(in0, D)), dt)]
-        out = Tensor((T, D), dt)
+        out = Tensor((T, D), dt) if out is None else out
         n, arr = len(self.enc_layers), self._enc_arr
         check(lib.omx_sanm_encoder_stack(out.ptr, h.ptr, arr, n, T, in0, D, c["encoder_heads"], c["encoder_ffn_dim"], c["sanm_kernel_size"],
                                          self.after_norm[0], self.after_norm[1], act[0].ptr, act[1].ptr, nrm[0].ptr, nrm[1].ptr, out.dtype, None))
         return out
 
-    def predict(self, enc: Tensor):
-        """CIFPredictor::forward (:883-889): -> (acoustic_embeds f32 [N, E] device Tensor or None, N, alphas Tensor)."""
+    def predict(self, enc: Tensor, scratch: bool = False):
+        """CIFPredictor::forward (:883-889): -> (acoustic_embeds f32 [N, E] device Tensor or None, N, alphas Tensor).  scratch: the returned
+        tensors live in buffers the model keeps (valid until the next call) instead of fresh allocations."""
         c = self.cfg
         T, E = enc.shape
-        alphas, hidden = Tensor((1, T), FLOAT32), Tensor((1, T, E), FLOAT32)
+        new = (lambda name, shape, dt: self._scratch("cif_" + name, shape, dt)) if scratch else (lambda name, shape, dt: Tensor(shape, dt))
+        alphas, hidden = new("alphas", (1, T), "f32"), new("hidden", (1, T, E), "f32")
         check(lib.omx_cif_alphas(alphas.ptr, hidden.ptr, enc.ptr, *self.pred, T, E, c["cif_l_order"] + c["cif_r_order"] + 1, enc.dtype, None))
-        frames = Tensor((1, T + 1, E), FLOAT32)
-        counts = Tensor((1,), "u32")
+        frames = new("frames", (1, T + 1, E), "f32")
+        counts = new("counts", (1,), "u32")
         check(lib.omx_cif_fire(frames.ptr, counts.ptr, hidden.ptr, alphas.ptr, 1, T, E, c["cif_threshold"], c["cif_tail_threshold"], T + 1, None))
         n = int(counts.numpy()[0])
         return (frames.slice_rows(0, (n, E)) if n else None), n, alphas
 
-    def decode(self, embeds: Tensor, enc: Tensor) -> Tensor:
-        """ParaformerDecoder::forward (:1144-1166): acoustic_embeds f32 [N, D] -> logits [N, vocab]."""
+    def decode(self, embeds: Tensor, enc: Tensor, out: Tensor = None) -> Tensor:
+        """ParaformerDecoder::forward (:1144-1166): acoustic_embeds f32 [N, D] -> logits [N, vocab] (into `out` when given)."""
         c = self.cfg
         N, Ts = embeds.shape[0], enc.shape[0]
         dt = self.dtype
@@ -222,19 +224,24 @@ class Paraformer:
                                                c["decoder_ffn_dim"], c["sanm_kernel_size"], act[0].ptr, act[1].ptr, nrm[0].ptr, nrm[1].ptr,
                                                kv_all.ptr, x_out.dtype, None))
         x = x_out
-        logits = Tensor((N, c["vocab_size"]), dt)
+        logits = Tensor((N, c["vocab_size"]), dt) if out is None else out
         check(lib.omx_paraformer_decoder_tail(logits.ptr, x.ptr, ctypes.byref(self.tail), N, c["decoder_dim"], c["decoder_ffn_dim"],
                                               c["vocab_size"], logits.dtype, None))
         return logits
 
     def transcribe_from_mel(self, mel: Tensor):
         """Paraformer::transcribe_from_mel (:1236-1256): -> (token ids np.int32 [N], N)."""
-        from .ops import argmax
-        enc = self.encode(mel)
-        embeds, n, _ = self.predict(enc)
+        # every intermediate in buffers the model keeps: a hipMalloc per tensor costs more than the launches that fill it, and a hipFree
+        # waits for the device
+        c = self.cfg
+        enc = self.encode(mel, out=self._scratch("t_enc", (mel.shape[-2], c["encoder_dim"]), self.dtype))
+        embeds, n, _ = self.predict(enc, scratch=True)
         if n == 0:
             return np.zeros(0, np.int32), 0
-        return argmax(self.decode(embeds, enc)).numpy().astype(np.int32), n
+        logits = self.decode(embeds, enc, out=self._scratch("t_logits", (n, c["vocab_size"]), self.dtype))
+        tokens = self._scratch("t_tokens", (n,), "u32")
+        check(lib.omx_argmax(tokens.ptr, logits.ptr, n, c["vocab_size"], logits.dtype, None))
+        return tokens.numpy().astype(np.int32), n
 
 
 def checkpoint_shapes(cfg: dict) -> dict:

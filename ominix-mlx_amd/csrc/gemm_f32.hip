@@ -268,6 +268,9 @@ __global__ __launch_bounds__(256) void gemm_f32_small_kernel(const F32Args g) {
 //      pong"): a wave streaming MFMAs holds its SIMD's issue stage, the other wave's LDS instructions wait for the whole stream
 //      (cycle stamps: 1180 cycles to get 8 ds_read_b128 through beside an MFMA stream, 124 without) -- only a wave's OWN instructions
 //      slot in between its MFMAs.
+#ifndef OMX_PIPE_MFMA32
+#define OMX_PIPE_MFMA32 1          // the 32 x 32 x 2 MFMA (64 cycles each: a memory instruction fits whole into the gap behind one); 0: 2 x 2 of 16 x 16 x 4
+#endif
 constexpr int PK = 64, P_LD = PK + 4, PR = 3;                   // rows of 68 floats: 16-byte aligned
 constexpr size_t P_LDS_BYTES = (size_t)2 * 2 * 64 * P_LD * sizeof(float);
 
@@ -284,7 +287,14 @@ __global__ __launch_bounds__(256) void gemm_f32_pipe_kernel(const F32Args g) {
     const int kbeg = split * per * PK, kend = min(g.K, (split + 1) * per * PK);
     const int nt = kbeg < kend ? (kend - kbeg + PK - 1) / PK : 0;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+#if OMX_PIPE_MFMA32
+    (void)n; (void)q; (void)zero4;
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#else
     f32x4 acc00 = zero4, acc01 = zero4, acc10 = zero4, acc11 = zero4;
+#endif
     // staging: thread (rq, kq) covers rows rq + 16 i of both operands' tiles, k quad kq.  Buffer loads: the per-thread part of the address is
     // eight 32-bit offsets computed once, the tile's k offset is a scalar, and a row past the end of the matrix is out of the descriptor's
     // range and reads as zero -- no address arithmetic and no clamping per tile.  FULLK (K a multiple of the tile): no k tail either; otherwise
@@ -302,7 +312,11 @@ __global__ __launch_bounds__(256) void gemm_f32_pipe_kernel(const F32Args g) {
         bo[i] = (int)(((int64_t)(n0 + rq + 16 * i) * g.ldb + kq) * 4);
     }
     u32x4 ra[PR][4], rb[PR][4];
+#if OMX_PIPE_MFMA32
+    f32x4 fa[2][8], fb[2][8];                                   // [register set][k octet]
+#else
     f32x4 fa[2][4][2], fb[2][4][2];                             // [register set][k step][fragment row block]
+#endif
 #define OMX_PIPE_REQUEST(slot, tile)                                                                   \
     {                                                                                                  \
         const int k0_ = kbeg + min((tile), nt - 1) * PK;                                               \
@@ -322,6 +336,37 @@ __global__ __launch_bounds__(256) void gemm_f32_pipe_kernel(const F32Args g) {
             *reinterpret_cast<u32x4*>(Bs + (buf) * 64 * P_LD + (rq + 16 * i) * P_LD + kq) = in_ ? rb[slot][i] : zero_; \
         }                                                                                              \
     }
+#if OMX_PIPE_MFMA32
+// lane (r, hh) of v_mfma_f32_32x32x2_f32 reads row r, k = 8 j + 4 hh .. + 3: MFMA e of fragment j multiplies the k pair {8 j + e, 8 j + 4 + e}
+#define OMX_PIPE_FRAGMENTS(set, buf)                                                                   \
+    {                                                                                                  \
+        const float* at_ = As + (buf) * 64 * P_LD + (wm * 32 + (lane & 31)) * P_LD + 4 * (lane >> 5);  \
+        const float* bt_ = Bs + (buf) * 64 * P_LD + (wn * 32 + (lane & 31)) * P_LD + 4 * (lane >> 5);  \
+        _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                \
+            fa[set][j] = *reinterpret_cast<const f32x4*>(at_ + 8 * j);                                 \
+            fb[set][j] = *reinterpret_cast<const f32x4*>(bt_ + 8 * j);                                 \
+        }                                                                                              \
+    }
+#define OMX_PIPE_MULTIPLY(set)                                                                         \
+    {                                                                                                  \
+        _Pragma("unroll") for (int j = 0; j < 8; ++j)                                                  \
+            _Pragma("unroll") for (int e = 0; e < 4; ++e)                                              \
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][j][e], fb[set][j][e], acc, 0, 0, 0); \
+    }
+// the iteration's instruction mix, spelled out for the scheduler: 16 fragment reads, then 8 x (staging write + request), each behind one MFMA
+#define OMX_PIPE_INTERLEAVE()                                                                          \
+    {                                                                                                  \
+        _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) {                                            \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                         \
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                         \
+        }                                                                                              \
+        _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) {                                             \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                         \
+            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);                                         \
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                         \
+        }                                                                                              \
+    }
+#else
 #define OMX_PIPE_FRAGMENTS(set, buf)                                                                   \
     {                                                                                                  \
         const float* at_ = As + (buf) * 64 * P_LD + (wm * 32 + n) * P_LD + 4 * q;                      \
@@ -355,6 +400,7 @@ __global__ __launch_bounds__(256) void gemm_f32_pipe_kernel(const F32Args g) {
             __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                         \
         }                                                                                              \
     }
+#endif
 #define OMX_PIPE_BOUNDARY()                                                                            \
     {                                                                                                  \
         __builtin_amdgcn_sched_barrier(0);                                                             \
@@ -410,12 +456,18 @@ __global__ __launch_bounds__(256) void gemm_f32_pipe_kernel(const F32Args g) {
     // LDS a wave stores four whole 256-byte rows per instruction, and bias / residual are read 16 bytes at a time.
     // D of the 16 x 16 form: col = lane & 15, row = 4 (lane >> 4) + reg
     float* C = pipe_lds;                                        // [64][P_LD]
+#if OMX_PIPE_MFMA32
+    // D of the 32 x 32 form: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) C[(wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * P_LD + wn * 32 + (lane & 31)] = acc[r];
+#else
 #pragma unroll
     for (int f = 0; f < 4; ++f) {
         const f32x4 acc = f == 0 ? acc00 : f == 1 ? acc01 : f == 2 ? acc10 : acc11;
 #pragma unroll
         for (int r = 0; r < 4; ++r) C[(wm * 32 + 16 * (f >> 1) + 4 * q + r) * P_LD + wn * 32 + 16 * (f & 1) + n] = acc[r];
     }
+#endif
     __syncthreads();
     const bool vec = (g.N & 3) == 0 && (g.splits > 1 ? (reinterpret_cast<uintptr_t>(g.partial) & 15u) == 0
                                                      : (g.ldc & 3) == 0 && (g.sc & 3) == 0 && (!g.resid || (g.ldr & 3) == 0) &&

@@ -244,6 +244,30 @@ def test_tiny_paraformer_end_to_end_f32_matches_oracle(omx):
     np.testing.assert_array_equal(tok[safe], ref_tok[safe])
 
 
+def test_one_model_transcribes_utterances_of_changing_length(omx):
+    """The model keeps its scratch between calls (one growing buffer per role) and hands `transcribe_from_mel` views of it: utterances of
+    83, 40, 600 (beyond the one-launch attention's 512 keys) and again 83 frames through ONE model give, each, exactly what a fresh model
+    gives -- no stale rows from a longer predecessor, no buffer too small for a longer successor."""
+    from ominix_mlx_amd import paraformer
+    T = omx.ops.Tensor
+    w = rp.synth_checkpoint(TINY, 11)
+    g = np.random.default_rng(21)
+    mels = [(g.standard_normal((n, 560)) * 0.5).astype(np.float32) for n in (83, 40, 600, 83)]
+    kept = paraformer.Paraformer(w, TINY)
+    for mel in mels:
+        got, n = kept.transcribe_from_mel(T.from_numpy(mel, "f32"))
+        fresh = paraformer.Paraformer(w, TINY)
+        want, n_want = fresh.transcribe_from_mel(T.from_numpy(mel, "f32"))
+        assert n == n_want
+        np.testing.assert_array_equal(got, want)
+        # and the staged entry points with caller-owned outputs agree with it
+        enc = fresh.encode(T.from_numpy(mel, "f32"))
+        emb, n2, _ = fresh.predict(enc)
+        assert n2 == n
+        if n:
+            np.testing.assert_array_equal(omx.ops.argmax(fresh.decode(emb, enc)).numpy().astype(np.int32), want)
+
+
 def test_tiny_paraformer_end_to_end_matches_oracle(omx):
     """Paraformer::transcribe_from_mel on a 3+2-layer model with the reference's checkpoint keys: encoder output,
     CIF token count, logits and token ids against the float64 restatement.  bf16 activations: encoder output

@@ -1,14 +1,16 @@
-// float32 GEMM on the f32-input matrix cores (v_mfma_f32_32x32x2_f32: exact f32, a k-ordered fmaf chain per output, 157 TF
+// float32 GEMM on the f32-input matrix cores (v_mfma_f32_32x32x2_f32 / v_mfma_f32_16x16x4_f32: exact f32 products and accumulation, 157 TF
 // chip peak = 1/16 of the bf16 rate).  The one model on the path that the reference runs in float32 is Paraformer
 // (funasr-mlx/src/paraformer.rs:496-532, 560-570, 618-634, 981-1053: f32 weights converted from PyTorch, f32 activations):
-// 0.17 TFLOP for 30 s of audio, GEMMs of 200-500 rows -- so this kernel is built for SMALL problems (64 x 64 tiles so that a
+// 0.17 TFLOP for 30 s of audio, GEMMs of 200-500 rows -- so these kernels are built for SMALL problems (64 x 64 tiles so that a
 // [501, 512] output still gives 64 blocks, split-K when even that leaves the chip idle), not for a roofline number.
 //   out[b][m, n] = alpha * sum_k A[b][m, k] * B[b](k, n) (+ bias[n]) (relu) (+ resid[m, n])
 //   B(k, n) = B[n * ldb + k]   ("NT": an nn::Linear weight [N, K], mlx-rs/src/nn/linear.rs:87-92)    or
 //           = B[k * ldb + n]   ("NN": P . V of the explicit attention, paraformer.rs:513-515)
-// Tile: 64 x 64 x 64 per block, 4 waves, one 32 x 32 accumulator tile per wave; operands go global -> registers (the next
-// K tile is in flight while the current one is multiplied) -> LDS; LDS rows are padded to 65 floats, which makes both the
-// 4-byte fragment reads (lane l: row l & 31, k = l >> 5) and the staging writes conflict-free.
+// Three kernels, newest last:
+//   gemm_f32_kernel        64 x 64 x 64 per block, 4 waves, one 32 x 32 accumulator tile per wave; operands global -> registers -> LDS rows
+//                          padded to 65 floats (4-byte fragment reads and staging writes conflict-free).  NN and NT, any alignment.
+//   gemm_f32_small_kernel  32 x 32 tiles of 16 x 16 x 4 MFMAs (round 5) for grids that do not fill the chip.  NN and NT, any alignment.
+//   gemm_f32_pipe_kernel   (round 6) what every aligned NT product runs on: the same 64 x 64 tile software-pipelined -- see its own comment.
 #include "gemm.hpp"
 #include "workspace.hpp"
 

@@ -244,6 +244,16 @@ def test_tiny_paraformer_end_to_end_f32_matches_oracle(omx):
     np.testing.assert_array_equal(tok[safe], ref_tok[safe])
 
 
+def test_random_shapes_of_the_f32_kernels(omx):
+    """tools/fuzz_f32.py, 60 seeded cases per family: f32 linear over random aligned and ragged M / N / K (all three GEMM kernels and their tail
+    forms) against float64, the f32 attention over random Tq / Tk / heads (every width, split and the fallback) against the explicit form."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_f32.py"), "60", "5"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "failures 0" in r.stdout
+
+
 def test_one_model_transcribes_utterances_of_changing_length(omx):
     """The model keeps its scratch between calls (one growing buffer per role) and hands `transcribe_from_mel` views of it: utterances of
     83, 40, 600 (beyond the one-launch attention's 512 keys) and again 83 frames through ONE model give, each, exactly what a fresh model
